@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X batched DSP backend.
+
+Contract (see DESIGN.md "Measurement"):
+  python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line on rank 0.
+
+Workload at every N: BASELINE.json configs[1] per GPU -- 4096 concurrent mono
+streams, polyphase resample 16 kHz -> 48 kHz (MSResample, quality 3).  A
+"step" is one 10 ms tick of the whole batch = one kernel launch: 4096 x 160
+int16 in, 4096 x 480 int16 out, inputs already resident in HBM.  Streams are
+independent, so N GPUs run N independent shards (weak scaling, no collective
+in the data path); value = real-time stream capacity of the whole job
+= streams processed per second / 100 ticks per second.
+
+To keep the measurement honest for a 5 MB/tick working set, the K steps walk
+a ring of distinct input/output tick buffers larger than the 256 MiB
+Infinity Cache, and the K launches are replayed from one hipGraph so the
+host's per-launch cost (Python + hipLaunch) is not what is timed.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+TICKS_PER_S = 100.0    # MSTicker interval 10 ms (src/base/msticker.c:46)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU (configs[1]: 4096)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel roofline table")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def synth_pcm_batch(nstreams, n, rate, seed0=0x5EED, sigma=3000.0):
+    """N(0, 3000) + -20 dBFS 1 kHz tone, one RNG per 64-stream group (cheap, still distinct)."""
+    out = np.empty((nstreams, n), np.int16)
+    t = np.arange(n) / rate
+    tone = 3276.7 * np.sin(2 * np.pi * 1000.0 * t)
+    for g in range(0, nstreams, 64):
+        rng = np.random.default_rng(seed0 + g)
+        k = min(64, nstreams - g)
+        out[g:g + k] = np.clip(np.round(rng.normal(0.0, sigma, (k, n)) + tone), -32767, 32767).astype(np.int16)
+    return out
+
+
+class Leg:
+    """One kernel measured as K graph-replayed launches over a ring of tick buffers."""
+
+    def __init__(self, ctx, name, launch, ring, alg_bytes, units, unit_name):
+        self.ctx, self.name, self.launch, self.ring = ctx, name, launch, ring
+        self.alg_bytes, self.units, self.unit_name = alg_bytes, units, unit_name
+
+    def run(self, steps, warmup, use_graph=True):
+        for i in range(warmup):
+            self.launch(i % self.ring)
+        self.ctx.sync()
+        graph = None
+        if use_graph:
+            self.ctx.capture_begin()
+            for i in range(steps):
+                self.launch(i % self.ring)
+            graph = self.ctx.capture_end()
+            graph.launch()  # untimed: uploads the graph, K more warm steps
+            self.ctx.sync()
+        return graph
+
+    def timed(self, steps, graph):
+        self.ctx.timer_start()
+        if graph is not None:
+            graph.launch()
+        else:
+            for i in range(steps):
+                self.launch(i % self.ring)
+        return self.ctx.timer_stop()  # ms over the K launches, HIP events on the launch stream
+
+
+def roofline(ev_ms, steps, alg_bytes, traffic=None):
+    dur_s = ev_ms * 1e-3 / steps
+    gbs = alg_bytes / dur_s / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "avg_launch_us": round(dur_s * 1e6, 3), "algorithmic_bytes_per_launch": int(alg_bytes)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if there is one."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def make_resample_leg(ms, torch, ctx, nstreams):
+    in_len, out_len = 160, 480
+    per_tick = nstreams * (in_len + out_len) * 2
+    ring = max(2, min(128, -(-(320 << 20) // per_tick)))
+    rs = ms.ResamplerBatch(ctx, nstreams, 16000, 48000)
+    host = synth_pcm_batch(nstreams, in_len * 4, 16000)
+    ins = []
+    for r in range(ring):
+        o = (r % 4) * in_len
+        ins.append(torch.from_numpy(np.ascontiguousarray(host[:, o:o + in_len])).cuda())
+    outs = [torch.zeros((nstreams, out_len), dtype=torch.int16, device="cuda") for _ in range(ring)]
+    torch.cuda.synchronize()
+
+    def launch(i):
+        rs.process(ins[i], out=outs[i])
+
+    leg = Leg(ctx, "resample_up_kernel<3,48,8>", launch, ring, per_tick, nstreams, "stream-ticks")
+    leg.keep = (rs, ins, outs, host)
+    return leg
+
+
+def make_mixer_leg(ms, torch, ctx, nconf=128, mm=32, ns=480):
+    per_tick = 2 * nconf * mm * ns * 2
+    ring = max(2, min(64, -(-(320 << 20) // per_tick)))
+    mx = ms.MixerBatch(ctx, nconf, mm, ns)
+    base = synth_pcm_batch(nconf * mm, ns, 48000, sigma=1500.0).reshape(nconf, mm, ns)
+    ins = [torch.from_numpy(np.roll(base, r, axis=2).copy()).cuda() for r in range(ring)]
+    outs = [torch.zeros((nconf, mm, ns), dtype=torch.int16, device="cuda") for _ in range(ring)]
+
+    def launch(i):
+        mx.process(ins[i], None, 1, out=outs[i])
+
+    leg = Leg(ctx, "mixer_kernel<32,0>", launch, ring, per_tick, nconf, "conference-ticks")
+    leg.keep = (mx, ins, outs)
+    return leg
+
+
+def make_volume_leg(ms, torch, ctx, nstreams=4096, ns=480):
+    per_tick = nstreams * ns * 2 * 2
+    ring = max(2, min(64, -(-(320 << 20) // per_tick)))
+    vb = ms.VolumeBatch(ctx, nstreams, 48000)
+    p = vb.default_params()
+    p.agc_enabled = 1
+    vb.set_params([p] * nstreams)
+    base = synth_pcm_batch(nstreams, ns, 48000)
+    bufs = [torch.from_numpy(np.roll(base, r, axis=1).copy()).cuda() for r in range(ring)]
+
+    def launch(i):
+        vb.process(bufs[i])
+
+    leg = Leg(ctx, "volume_kernel", launch, ring, per_tick, nstreams, "stream-ticks")
+    leg.keep = (vb, bufs)
+    return leg
+
+
+def make_equalizer_leg(ms, torch, ctx, nstreams=4096, ns=480):
+    per_tick = nstreams * ns * 2 * 2
+    ring = max(2, min(64, -(-(320 << 20) // per_tick)))
+    eq = ms.EqualizerBatch(ctx, nstreams, 48000)
+    eq.set_gain(0, 1000.0, 2.0, 500.0)
+    taps = eq.taps(0)
+    for s in range(1, nstreams):
+        eq.set_taps(s, taps)
+    base = synth_pcm_batch(nstreams, ns, 48000)
+    bufs = [torch.from_numpy(np.roll(base, r, axis=1).copy()).cuda() for r in range(ring)]
+
+    def launch(i):
+        eq.process(bufs[i])
+
+    leg = Leg(ctx, "equalizer_kernel<512>", launch, ring, per_tick, nstreams, "stream-ticks")
+    leg.keep = (eq, bufs)
+    return leg
+
+
+def make_scaler_leg(ms, torch, ctx, nframes=64):
+    sw, sh, dw, dh = 1920, 1080, 1280, 720
+    sc = ms.ScalerBatch(ctx, sw, sh, dw, dh, ms.MI_PIX_RGB24)
+    per_step = nframes * (sc.src_bytes + sc.dst_bytes)
+    ring = 2  # 2 x 376 MB already exceeds the Infinity Cache
+    rng = np.random.default_rng(0x5EED)
+    yy, xx = np.mgrid[0:sh, 0:sw]
+    y = (16 + 200 * (xx + yy) / (sw + sh)).astype(np.float32)
+    frames = []
+    for f in range(4):
+        yf = (y + rng.normal(0, 12, y.shape)).clip(0, 255).astype(np.uint8)
+        u = (128 + 100 * np.sin(2 * np.pi * np.arange(sw // 2) / (sw // 2) + f))[None, :].repeat(sh // 2, 0)
+        v = (128 + 100 * np.cos(2 * np.pi * np.arange(sh // 2) / (sh // 2) + f))[:, None].repeat(sw // 2, 1)
+        frames.append(np.concatenate([yf.ravel(), u.clip(0, 255).astype(np.uint8).ravel(),
+                                      v.clip(0, 255).astype(np.uint8).ravel()]))
+    host = np.stack([frames[i % 4] for i in range(nframes)])
+    ins = [torch.from_numpy(host).cuda() for _ in range(ring)]
+    outs = [torch.zeros((nframes, sc.dst_bytes), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+
+    def launch(i):
+        sc.process(ins[i], out=outs[i])
+
+    leg = Leg(ctx, "scaler_kernel<true>", launch, ring, per_step, nframes, "frames")
+    leg.keep = (sc, ins, outs)
+    leg.mpix_in = nframes * sw * sh / 1e6
+    return leg
+
+
+def cpu_baseline_resample(nstreams, seconds):
+    """The oracle (CPU restatement of the reference path: one resampler object per stream,
+    called tick by tick) on this host's cores -- 1 thread, bounded sample."""
+    import oracle
+    oracle.build()
+    L = oracle.lib()
+    L.orc_bench_resample.restype = C.c_double
+    L.orc_bench_resample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                     C.POINTER(C.c_int16), C.POINTER(C.c_longlong)]
+    x = synth_pcm_batch(nstreams, 160, 16000)
+    xp = x.ctypes.data_as(C.POINTER(C.c_int16))
+    t = L.orc_bench_resample(nstreams, 160, 2, 16000, 48000, xp, None)
+    nticks = max(2, int(seconds / (t / 2)))
+    t = L.orc_bench_resample(nstreams, 160, nticks, 16000, 48000, xp, None)
+    stream_ticks_per_s = nstreams * nticks / t
+    return {"value": round(stream_ticks_per_s / TICKS_PER_S, 1), "unit": "concurrent 48 kHz streams (10 ms ticks in real time)",
+            "cores": 1, "kind": "port",
+            "sample": f"{nstreams} streams x {nticks} ticks of 160 samples 16k->48k, oracle/resample.c, "
+                      f"{t:.1f} s on 1 of {os.cpu_count()} host cores",
+            "us_per_stream_tick": round(t / (nstreams * nticks) * 1e6, 3)}
+
+
+def main():
+    a = parse()
+    import torch
+    import mediastreamer2_amd as ms
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # the driver launches N ranks for --gpus N; a bare `--gpus N` without torchrun is a usage error
+        if world == 1 and a.gpus > 1:
+            print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    ctx = ms.Context(local)
+    props = ctx.props()
+    leg = make_resample_leg(ms, torch, ctx, a.streams)
+    graph = leg.run(a.steps, a.warmup, use_graph=not a.no_graph)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    ev_ms = leg.timed(a.steps, graph)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, ev_ms_max = float(tt[0]), float(tt[1])
+    else:
+        ev_ms_max = ev_ms
+
+    total_streams = a.streams * world
+    stream_ticks_per_s = total_streams * a.steps / dt
+    line = {
+        "metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale",
+        "value": round(stream_ticks_per_s / TICKS_PER_S, 1),
+        "unit": "concurrent 48 kHz streams (10 ms ticks sustained in real time)",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 6),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 4096 concurrent mono streams/GPU, MSResample polyphase 16k->48k, "
+                               "one 10 ms tick per step",
+                   "streams_per_gpu": a.streams, "in_samples": 160, "out_samples": 480,
+                   "tick_ms": 10, "tick_budget_used": round(dt / a.steps / 0.010, 6),
+                   "launch": "eager" if a.no_graph else "hipGraph replay of K ticks",
+                   "ring_ticks": leg.ring, "parallelism": f"{world} independent stream shards",
+                   "device": props["name"], "cu_count": props["cu_count"]},
+        "roofline": roofline(ev_ms_max, a.steps, leg.alg_bytes, pmc_traffic("resample_up_kernel")),
+    }
+    line["roofline"]["kernel"] = leg.name
+
+    if rank == 0 and world == 1:
+        if not a.no_extras:
+            extras = []
+            ksteps = max(20, min(a.steps, 100))
+            for mk in (make_mixer_leg, make_volume_leg, make_equalizer_leg, make_scaler_leg):
+                try:
+                    lg = mk(ms, torch, ctx)
+                    g = lg.run(ksteps, 3, use_graph=not a.no_graph)
+                    ctx.sync()
+                    ms_ = lg.timed(ksteps, g)
+                    ctx.sync()
+                    r = roofline(ms_, ksteps, lg.alg_bytes, pmc_traffic(lg.name.split("<")[0]))
+                    r["kernel"] = lg.name
+                    r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
+                    if hasattr(lg, "mpix_in"):
+                        r["mpix_per_s_in"] = round(lg.mpix_in / (ms_ * 1e-3 / ksteps), 1)
+                    extras.append(r)
+                    del lg, g
+                    torch.cuda.empty_cache()
+                except Exception as e:  # an optional leg must never take the headline down
+                    extras.append({"kernel": mk.__name__, "error": str(e)[:200]})
+            line["other_kernels"] = extras
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,244 @@
+/*
+ * msmi355x.h -- C ABI of libmsmi355x: the MI355X (gfx950) batched DSP backend
+ * behind mediastreamer2's audio/video filter hot path.
+ *
+ * One object = one filter TYPE for a whole batch of streams; one call = one
+ * 10 ms tick (or one frame) of every stream in the batch = one kernel launch.
+ * The per-stream MSFilter facades (mediastreamer2_amd/host/) stage their frame
+ * into a batch slot and call these entry points where the reference calls its
+ * per-stream inner loops:
+ *
+ *   mi_resampler_*  replaces speex_resampler_init / _process_int as called from
+ *                   src/audiofilters/msresample.c:102-115 and :150-177
+ *   mi_mixer_*      replaces the loops of mixer_process,
+ *                   src/audiofilters/audiomixer.c:301-344 (accumulate :33-38,
+ *                   apply_gain :46-51, channel_process_out :113-130)
+ *   mi_volume_*     replaces update_energy / apply_gain and the control chain of
+ *                   volume_process, src/audiofilters/msvolume.c:388-445,:480-513
+ *   mi_equalizer_*  replaces equalizer_state_run -> ms_fir_mem16,
+ *                   src/audiofilters/equalizer.c:263-269, src/utils/dsptools.c:253-268,
+ *                   and the design path equalizer.c:147-172,:215-237
+ *   mi_aec_*        replaces speex_echo_cancellation + speex_preprocess_run as
+ *                   called from src/audiofilters/speexec.c:200-203,:297-298
+ *   mi_scaler_*     replaces MSScalerDesc.context_process,
+ *                   include/mediastreamer2/msvideo.h:473-478, src/voip/msvideo.c:542-581
+ *
+ * (all paths relative to the mediastreamer2 5.5.0 tree).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types.
+ *   - every function returns MI_OK (0) or a negative MI_E* code;
+ *     mi_last_error() gives the message for the calling thread.
+ *   - pointers named d_* are DEVICE pointers (HBM), h_* are host pointers.
+ *   - PCM is little-endian int16, one contiguous row per stream ("packed
+ *     10 ms frames"); `stride` arguments are in samples.
+ *   - launches are asynchronous on the context's HIP stream; *_host variants
+ *     copy in, launch, copy out and synchronise.
+ *   - there is NO CPU fallback: without a usable HIP device every create
+ *     call fails with MI_ENODEV.
+ */
+#ifndef MSMI355X_H
+#define MSMI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)  /* bad argument */
+#define MI_ENODEV (-2)  /* no HIP device / HIP runtime error */
+#define MI_ENOMEM (-3)
+#define MI_ENOTSUP (-4) /* configuration outside what the reference path uses */
+
+#define MSMI355X_ABI_VERSION 1
+
+int mi_abi_version(void);
+const char *mi_last_error(void);
+
+/* ------------------------------------------------------------- context */
+typedef struct mi_ctx mi_ctx;
+/* hip_stream: an existing hipStream_t to launch on (e.g. the caller's
+ * framework stream), or NULL to create a private non-blocking stream. */
+int mi_ctx_create(int device, void *hip_stream, mi_ctx **out);
+void mi_ctx_destroy(mi_ctx *ctx);
+int mi_ctx_sync(mi_ctx *ctx);
+void *mi_ctx_stream(mi_ctx *ctx);
+int mi_ctx_device(mi_ctx *ctx);
+/* device properties the bench reports: CU count, HBM bytes, name */
+int mi_ctx_props(mi_ctx *ctx, int *cu_count, size_t *hbm_bytes, char *name, int name_cap);
+
+void *mi_dev_alloc(mi_ctx *ctx, size_t bytes);   /* NULL on failure */
+void mi_dev_free(mi_ctx *ctx, void *d_ptr);
+void *mi_host_alloc(mi_ctx *ctx, size_t bytes);  /* pinned host memory */
+void mi_host_free(mi_ctx *ctx, void *h_ptr);
+int mi_copy_h2d(mi_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on ctx stream */
+int mi_copy_d2h(mi_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* async on ctx stream */
+int mi_memset(mi_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* hipGraph capture of everything the mi_* calls enqueue on the context stream
+ * between begin and end (a tick's worth of launches, or K ticks): replaying the
+ * graph removes the per-launch host cost from launch-bound inner loops.  The
+ * captured calls must not synchronise or allocate (steady-state process calls
+ * do not). */
+typedef struct mi_graph mi_graph;
+int mi_ctx_capture_begin(mi_ctx *ctx);
+int mi_ctx_capture_end(mi_ctx *ctx, mi_graph **out);
+int mi_graph_launch(mi_graph *g);
+void mi_graph_destroy(mi_graph *g);
+
+/* HIP-event stopwatch on the context stream (what bench.py's roofline uses) */
+int mi_timer_start(mi_ctx *ctx);
+int mi_timer_stop(mi_ctx *ctx, float *elapsed_ms); /* synchronises the stop event */
+
+/* ----------------------------------------------------------- resampler */
+/* A batch of `nstreams` mono resamplers with one (in_rate, out_rate, quality).
+ * quality: 3 (SPEEX_RESAMPLER_QUALITY_VOIP, the only one msresample.c:104 uses
+ * on x86) or 4.  State per stream: filt_len-1 input samples of history and
+ * the fractional read position, zero-initialised like speex_resampler_init. */
+typedef struct mi_resampler mi_resampler;
+int mi_resampler_create(mi_ctx *ctx, int nstreams, uint32_t in_rate, uint32_t out_rate, int quality,
+                        mi_resampler **out);
+void mi_resampler_destroy(mi_resampler *r);
+int mi_resampler_reset(mi_resampler *r, int first, int count);
+/* msresample.c:151-152: in_len*out_rate/in_rate + 1 */
+int mi_resampler_out_capacity(const mi_resampler *r, int in_len);
+/* filter facts for tests/DESIGN: taps per phase, phases (den_rate), num_rate,
+ * 1 if the direct polyphase table is in use, 0 for the interpolated table */
+int mi_resampler_info(const mi_resampler *r, int *filt_len, int *den_rate, int *num_rate, int *direct);
+int mi_resampler_get_table(const mi_resampler *r, float *h_dst, int cap); /* returns length */
+/* One input block of in_len samples per stream (msresample.c:150-177 body).
+ * d_in  [nstreams][in_stride]  int16
+ * d_out [nstreams][out_stride] int16, out_stride >= mi_resampler_out_capacity
+ * d_out_len [nstreams] int32 produced counts, may be NULL */
+int mi_resampler_process(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out,
+                         int out_stride, int32_t *d_out_len);
+int mi_resampler_process_host(mi_resampler *r, const int16_t *h_in, int in_len, int in_stride,
+                              int16_t *h_out, int out_stride, int32_t *h_out_len);
+
+/* --------------------------------------------------------------- mixer */
+/* `nconf` MSAudioMixer instances with up to `max_members` (<= 50,
+ * audiomixer.c:29) linked pins each and `nsamples` samples per tick
+ * (audiomixer.c:190 bytespertick/2). */
+typedef struct mi_mixer mi_mixer;
+#define MI_MIXER_MAX_CHANNELS 50
+#define MI_MIX_LINKED 1u   /* pin is connected (f->inputs[i] != NULL) */
+#define MI_MIX_ACTIVE 2u   /* MS_AUDIO_MIXER_SET_ACTIVE, audiomixer.c:384-393 */
+#define MI_MIX_OUTPUT 4u   /* MS_AUDIO_MIXER_ENABLE_OUTPUT, audiomixer.c:395-408 */
+int mi_mixer_create(mi_ctx *ctx, int nconf, int max_members, int nsamples, mi_mixer **out);
+void mi_mixer_destroy(mi_mixer *m);
+/* h_flags / h_gain [nconf][max_members]; NULL keeps the current values.
+ * Defaults: LINKED|ACTIVE|OUTPUT, gain 1.0 (channel_init audiomixer.c:65-71). */
+int mi_mixer_set_controls(mi_mixer *m, const uint8_t *h_flags, const float *h_gain);
+/* One tick.  d_in [nconf][max_members][nsamples]; d_has_data [nconf][max_members]
+ * (0 = the bufferizer read came up short -> zeros, audiomixer.c:88), NULL = all 1.
+ * conf_mode 1 (MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE): d_out [nconf][max_members][nsamples],
+ * rows of unlinked / output-disabled pins are not written.
+ * conf_mode 0: d_out [nconf][nsamples] (the one block dupb'd to every output). */
+int mi_mixer_process(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data, int conf_mode,
+                     int16_t *d_out);
+int mi_mixer_process_host(mi_mixer *m, const int16_t *h_in, const uint8_t *h_has_data, int conf_mode,
+                          int16_t *h_out);
+/* Split form for a conference whose members live on several GPUs:
+ * partial int32 sums of the LOCAL members, an int32 all-reduce by the caller
+ * (RCCL), then the local outputs from the global sum. */
+int mi_mixer_partial_sum(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data, int32_t *d_sum);
+int mi_mixer_finalize(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data, const int32_t *d_sum,
+                      int conf_mode, int16_t *d_out);
+
+/* -------------------------------------------------------------- volume */
+typedef struct mi_volume mi_volume;
+/* user-settable fields of struct Volume (msvolume.c:48-86), set by the
+ * MS_VOLUME_* methods (msvolume.c:516-536) */
+typedef struct mi_volume_params {
+	float static_gain;                                /* MS_VOLUME_SET_GAIN / _DB_GAIN */
+	float vol_upramp, vol_fast_upramp, vol_downramp;  /* MS_VOLUME_SET_EA_SPEED */
+	float ea_thres, ea_transmit_thres, force;         /* MS_VOLUME_SET_EA_* */
+	int32_t sustain_time;                             /* MS_VOLUME_SET_EA_SUSTAIN */
+	int32_t ng_cut_time;
+	float ng_threshold, ng_floorgain;                 /* MS_VOLUME_SET_NOISE_GATE_* */
+	int32_t agc_enabled, noise_gate_enabled, remove_dc;
+	int32_t peer; /* index (same batch) of the MS_VOLUME_SET_PEER filter, -1 = none */
+} mi_volume_params;
+/* running state (msvolume.c:49-53,:58-62,:79) -- read back every tick for
+ * MS_VOLUME_GET / GET_LINEAR / GET_MIN / GET_MAX */
+typedef struct mi_volume_state {
+	float energy, level_pk, instant_energy, lt_speaker_en;
+	float gain, target_gain, ng_gain;
+	int32_t dc_offset, sustain_dur, ng_noise_dur, fast_upramp;
+} mi_volume_state;
+int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out);
+void mi_volume_destroy(mi_volume *v);
+void mi_volume_default_params(mi_volume_params *p);          /* volume_init msvolume.c:88-118 */
+int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_params *h_params);
+int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h_state); /* syncs */
+int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_state *h_state);
+/* One chunk per stream, in place: d_samples [nstreams][stride].
+ * d_nsamples [nstreams] int32 per-stream chunk length (0 = stream idle this
+ * tick), or NULL -> every stream processes `nsamples`. */
+int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples);
+int mi_volume_process_host(mi_volume *v, int16_t *h_samples, int nsamples, int stride,
+                           const int32_t *h_nsamples);
+
+/* ----------------------------------------------------------- equalizer */
+typedef struct mi_equalizer mi_equalizer;
+int mi_equalizer_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_equalizer **out);
+void mi_equalizer_destroy(mi_equalizer *e);
+int mi_equalizer_fir_len(const mi_equalizer *e); /* 128 / 256 / 512, equalizer.c:60-66 */
+/* MS_EQUALIZER_SET_GAIN on one stream (equalizer.c:147-172); marks taps stale */
+int mi_equalizer_set_gain(mi_equalizer *e, int stream, float freq_hz, float gain, float width_hz);
+/* MS_FILTER_SET_SAMPLE_RATE semantics for one stream's gains: flatten (A14) */
+int mi_equalizer_flatten(mi_equalizer *e, int stream);
+int mi_equalizer_set_active(mi_equalizer *e, int stream, int active); /* MS_EQUALIZER_SET_ACTIVE */
+/* MS_EQUALIZER_DUMP_STATE (equalizer.c:317-328): nfft/2 floats */
+int mi_equalizer_dump(mi_equalizer *e, int stream, float *h_dst, int cap);
+int mi_equalizer_get_taps(mi_equalizer *e, int stream, float *h_dst, int cap); /* designs if stale */
+int mi_equalizer_set_taps(mi_equalizer *e, int stream, const float *h_taps, int n);
+/* in place; designs + uploads stale taps first (equalizer.c:265) */
+int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride);
+int mi_equalizer_process_host(mi_equalizer *e, int16_t *h_samples, int nsamples, int stride);
+
+/* ----------------------------------------------------------------- AEC */
+typedef struct mi_aec mi_aec;
+/* speex_ec_preprocess sizing, speexec.c:171-180,:194-203 */
+int mi_aec_framesize(int framesize_at_8000, int sample_rate);
+int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, int filter_length,
+                  mi_aec **out);
+void mi_aec_destroy(mi_aec *a);
+int mi_aec_reset(mi_aec *a, int first, int count);
+/* One frame (frame_size samples) per stream: d_mic = near-end + echo
+ * (speexec.c `echo`), d_ref = delayed far-end (`ref`), d_out = cleaned.
+ * d_run [nstreams] u8: 0 = this stream has no full frame this tick (A23), NULL = all run.
+ * flags bit0: also run the residual-echo/denoise post-filter (speex_preprocess_run). */
+#define MI_AEC_POSTFILTER 1u
+int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
+                   const uint8_t *d_run, unsigned flags);
+int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
+                        const uint8_t *h_run, unsigned flags);
+/* state bytes per stream (for DESIGN/roofline accounting) */
+size_t mi_aec_state_bytes(const mi_aec *a);
+/* debug/parity read-back of one stream's float arrays: "W","foreground","X","power" ... */
+int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap);
+
+/* -------------------------------------------------------------- scaler */
+typedef struct mi_scaler mi_scaler;
+#define MI_PIX_I420 0  /* MS_YUV420P, layout of ms_yuv_buf_init msvideo.c:85-99 */
+#define MI_PIX_RGB24 1 /* MS_RGB24: R,G,B bytes, stride 3*w */
+/* MSScalerDesc.create_context (msvideo.h:474-475); src is always I420 */
+int mi_scaler_create(mi_ctx *ctx, int src_w, int src_h, int dst_w, int dst_h, int dst_fmt, mi_scaler **out);
+void mi_scaler_destroy(mi_scaler *s);
+size_t mi_scaler_src_bytes(const mi_scaler *s);
+size_t mi_scaler_dst_bytes(const mi_scaler *s);
+/* MSScalerDesc.context_process for `nframes` frames of a batch:
+ * frame i at d_src + i*src_pitch, result at d_dst + i*dst_pitch. */
+int mi_scaler_process(mi_scaler *s, int nframes, const uint8_t *d_src, size_t src_pitch, uint8_t *d_dst,
+                      size_t dst_pitch);
+int mi_scaler_process_host(mi_scaler *s, int nframes, const uint8_t *h_src, size_t src_pitch, uint8_t *h_dst,
+                           size_t dst_pitch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSMI355X_H */

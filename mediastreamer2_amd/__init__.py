@@ -1,0 +1,372 @@
+"""mediastreamer2_amd -- MI355X (gfx950) batched DSP backend for mediastreamer2's
+audio/video filter hot path.
+
+This package is a thin Python view of the C ABI in include/msmi355x.h
+(libmsmi355x.so, hand-written HIP kernels in csrc/).  Python/PyTorch is used
+by tests and bench.py only for device buffers, streams and torch.distributed;
+the product is the shared library and the MSFilter facades in host/.
+
+Numpy arrays go through the *_host entry points (H2D + kernel + D2H);
+torch CUDA(HIP) tensors and raw device pointers go through the device-resident
+entry points and stay asynchronous on the context stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MiError, VolumeParams, VolumeState, check, load  # noqa: F401
+
+MI_MIX_LINKED, MI_MIX_ACTIVE, MI_MIX_OUTPUT = 1, 2, 4
+MI_PIX_I420, MI_PIX_RGB24 = 0, 1
+MI_AEC_POSTFILTER = 1
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr()
+    raise TypeError(type(x))
+
+
+def _on_device(x):
+    return isinstance(x, int) or (_is_torch(x) and x.is_cuda)
+
+
+class Context:
+    """mi_ctx: one per GPU; launches go to `stream` (a hipStream_t handle, e.g.
+    torch.cuda.current_stream().cuda_stream) or to a private stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load()
+        h = C.c_void_p()
+        check(self.L.mi_ctx_create(int(device), stream, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        check(self.L.mi_ctx_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.L.mi_ctx_stream(self.h)
+
+    def props(self):
+        cu, hbm, name = C.c_int(), C.c_size_t(), C.create_string_buffer(128)
+        check(self.L.mi_ctx_props(self.h, C.byref(cu), C.byref(hbm), name, 128))
+        return {"cu_count": cu.value, "hbm_bytes": hbm.value, "name": name.value.decode()}
+
+    def capture_begin(self):
+        check(self.L.mi_ctx_capture_begin(self.h))
+
+    def capture_end(self):
+        g = C.c_void_p()
+        check(self.L.mi_ctx_capture_end(self.h, C.byref(g)))
+        return Graph(self, g)
+
+    def timer_start(self):
+        check(self.L.mi_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.L.mi_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+
+class Graph:
+    """A captured sequence of mi_* launches (hipGraph)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def launch(self):
+        check(self.ctx.L.mi_graph_launch(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.L.mi_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Batch:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "h", None) and self._destroy:
+            getattr(self.ctx.L, self._destroy)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ResamplerBatch(_Batch):
+    """nstreams MSResample cores (msresample.c:102-177)."""
+    _destroy = "mi_resampler_destroy"
+
+    def __init__(self, ctx, nstreams, in_rate, out_rate, quality=3):
+        self.ctx, self.nstreams, self.in_rate, self.out_rate = ctx, nstreams, in_rate, out_rate
+        h = C.c_void_p()
+        check(ctx.L.mi_resampler_create(ctx.h, nstreams, in_rate, out_rate, quality, C.byref(h)))
+        self.h = h
+
+    def info(self):
+        v = [C.c_int() for _ in range(4)]
+        check(self.ctx.L.mi_resampler_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("filt_len", "den_rate", "num_rate", "direct"), (x.value for x in v)))
+
+    def table(self):
+        n = self.ctx.L.mi_resampler_get_table(self.h, None, 0)
+        t = np.zeros(n, np.float32)
+        self.ctx.L.mi_resampler_get_table(self.h, t.ctypes.data, n)
+        return t
+
+    def out_capacity(self, in_len):
+        return self.ctx.L.mi_resampler_out_capacity(self.h, in_len)
+
+    def reset(self, first=0, count=None):
+        check(self.ctx.L.mi_resampler_reset(self.h, first, self.nstreams - first if count is None else count))
+
+    def process(self, x, out=None, out_len=None):
+        """x [nstreams, in_len] int16 (numpy -> host path, torch cuda -> device path).
+        Returns (out [nstreams, out_stride], out_len [nstreams] or None)."""
+        n, in_len = x.shape
+        assert n == self.nstreams
+        cap = self.out_capacity(in_len)
+        ostride = (cap + 7) & ~7
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, np.int16)
+            out = np.zeros((n, ostride), np.int16)
+            ol = np.zeros(n, np.int32)
+            check(self.ctx.L.mi_resampler_process_host(self.h, _ptr(x), in_len, x.shape[1], _ptr(out), ostride, _ptr(ol)))
+            return out, ol
+        import torch
+        if out is None:
+            out = torch.zeros((n, ostride), dtype=torch.int16, device=x.device)
+        check(self.ctx.L.mi_resampler_process(self.h, _ptr(x), in_len, x.stride(0), _ptr(out), out.stride(0), _ptr(out_len)))
+        return out, out_len
+
+
+class MixerBatch(_Batch):
+    """nconf MSAudioMixer ticks (audiomixer.c:288-346)."""
+    _destroy = "mi_mixer_destroy"
+
+    def __init__(self, ctx, nconf, max_members, nsamples):
+        self.ctx, self.nconf, self.mm, self.ns = ctx, nconf, max_members, nsamples
+        h = C.c_void_p()
+        check(ctx.L.mi_mixer_create(ctx.h, nconf, max_members, nsamples, C.byref(h)))
+        self.h = h
+
+    def set_controls(self, flags=None, gain=None):
+        f = None if flags is None else np.ascontiguousarray(flags, np.uint8).reshape(self.nconf, self.mm)
+        g = None if gain is None else np.ascontiguousarray(gain, np.float32).reshape(self.nconf, self.mm)
+        check(self.ctx.L.mi_mixer_set_controls(self.h, _ptr(f), _ptr(g)))
+
+    def process(self, x, has_data=None, conf_mode=1, out=None):
+        """x [nconf, mm, ns] int16."""
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, np.int16)
+            hd = None if has_data is None else np.ascontiguousarray(has_data, np.uint8)
+            if out is None:
+                out = np.zeros(x.shape if conf_mode else (self.nconf, self.ns), np.int16)
+            check(self.ctx.L.mi_mixer_process_host(self.h, _ptr(x), _ptr(hd), int(conf_mode), _ptr(out)))
+            return out
+        import torch
+        if out is None:
+            out = torch.zeros(tuple(x.shape) if conf_mode else (self.nconf, self.ns), dtype=torch.int16, device=x.device)
+        check(self.ctx.L.mi_mixer_process(self.h, _ptr(x), _ptr(has_data), int(conf_mode), _ptr(out)))
+        return out
+
+    def partial_sum(self, x, d_sum, has_data=None):
+        check(self.ctx.L.mi_mixer_partial_sum(self.h, _ptr(x), _ptr(has_data), _ptr(d_sum)))
+        return d_sum
+
+    def finalize(self, x, d_sum, out, has_data=None, conf_mode=1):
+        check(self.ctx.L.mi_mixer_finalize(self.h, _ptr(x), _ptr(has_data), _ptr(d_sum), int(conf_mode), _ptr(out)))
+        return out
+
+
+class VolumeBatch(_Batch):
+    """nstreams MSVolume chunks (msvolume.c:471-514)."""
+    _destroy = "mi_volume_destroy"
+
+    def __init__(self, ctx, nstreams, sample_rate):
+        self.ctx, self.nstreams, self.rate = ctx, nstreams, sample_rate
+        h = C.c_void_p()
+        check(ctx.L.mi_volume_create(ctx.h, nstreams, sample_rate, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def default_params():
+        p = VolumeParams()
+        load().mi_volume_default_params(C.byref(p))
+        return p
+
+    def set_params(self, params, first=0):
+        arr = (VolumeParams * len(params))(*params)
+        check(self.ctx.L.mi_volume_set_params(self.h, first, len(params), arr))
+
+    def get_state(self, first=0, count=None):
+        count = self.nstreams - first if count is None else count
+        arr = (VolumeState * count)()
+        check(self.ctx.L.mi_volume_get_state(self.h, first, count, arr))
+        return list(arr)
+
+    def set_state(self, states, first=0):
+        arr = (VolumeState * len(states))(*states)
+        check(self.ctx.L.mi_volume_set_state(self.h, first, len(states), arr))
+
+    def process(self, x, nsamples=None, per_stream=None):
+        """x [nstreams, stride] int16, modified in place (numpy: returns the array)."""
+        n, stride = x.shape
+        nsamples = stride if nsamples is None else nsamples
+        if isinstance(x, np.ndarray):
+            assert x.dtype == np.int16 and x.flags["C_CONTIGUOUS"]
+            ps = None if per_stream is None else np.ascontiguousarray(per_stream, np.int32)
+            check(self.ctx.L.mi_volume_process_host(self.h, _ptr(x), nsamples, stride, _ptr(ps)))
+            return x
+        check(self.ctx.L.mi_volume_process(self.h, _ptr(x), nsamples, x.stride(0), _ptr(per_stream)))
+        return x
+
+
+class EqualizerBatch(_Batch):
+    """nstreams MSEqualizer FIRs (equalizer.c:263-288, dsptools.c:253-268)."""
+    _destroy = "mi_equalizer_destroy"
+
+    def __init__(self, ctx, nstreams, sample_rate):
+        self.ctx, self.nstreams, self.rate = ctx, nstreams, sample_rate
+        h = C.c_void_p()
+        check(ctx.L.mi_equalizer_create(ctx.h, nstreams, sample_rate, C.byref(h)))
+        self.h = h
+        self.fir_len = ctx.L.mi_equalizer_fir_len(h)
+
+    def set_gain(self, stream, freq, gain, width):
+        check(self.ctx.L.mi_equalizer_set_gain(self.h, stream, freq, gain, width))
+
+    def flatten(self, stream):
+        check(self.ctx.L.mi_equalizer_flatten(self.h, stream))
+
+    def set_active(self, stream, active):
+        check(self.ctx.L.mi_equalizer_set_active(self.h, stream, int(active)))
+
+    def dump(self, stream):
+        a = np.zeros(self.fir_len // 2, np.float32)
+        check(self.ctx.L.mi_equalizer_dump(self.h, stream, _ptr(a), len(a)))
+        return a
+
+    def taps(self, stream):
+        a = np.zeros(self.fir_len, np.float32)
+        check(self.ctx.L.mi_equalizer_get_taps(self.h, stream, _ptr(a), len(a)))
+        return a
+
+    def set_taps(self, stream, taps):
+        t = np.ascontiguousarray(taps, np.float32)
+        check(self.ctx.L.mi_equalizer_set_taps(self.h, stream, _ptr(t), len(t)))
+
+    def process(self, x, nsamples=None):
+        n, stride = x.shape
+        nsamples = stride if nsamples is None else nsamples
+        if isinstance(x, np.ndarray):
+            assert x.dtype == np.int16 and x.flags["C_CONTIGUOUS"]
+            check(self.ctx.L.mi_equalizer_process_host(self.h, _ptr(x), nsamples, stride))
+            return x
+        check(self.ctx.L.mi_equalizer_process(self.h, _ptr(x), nsamples, x.stride(0)))
+        return x
+
+
+class AecBatch(_Batch):
+    """nstreams MSSpeexEC cores (speexec.c:188-305): MDF canceller + post-filter."""
+    _destroy = "mi_aec_destroy"
+
+    def __init__(self, ctx, nstreams, sample_rate, frame_size=None, filter_length=None, tail_ms=128):
+        self.ctx, self.nstreams, self.rate = ctx, nstreams, sample_rate
+        if frame_size is None:
+            frame_size = ctx.L.mi_aec_framesize(64, sample_rate)  # speexec.c:41,171-180
+        if filter_length is None:
+            filter_length = tail_ms * sample_rate // 1000  # speexec.c:194
+        self.frame, self.filter_length = frame_size, filter_length
+        h = C.c_void_p()
+        check(ctx.L.mi_aec_create(ctx.h, nstreams, sample_rate, frame_size, filter_length, C.byref(h)))
+        self.h = h
+
+    def state_bytes(self):
+        return self.ctx.L.mi_aec_state_bytes(self.h)
+
+    def reset(self, first=0, count=None):
+        check(self.ctx.L.mi_aec_reset(self.h, first, self.nstreams - first if count is None else count))
+
+    def get(self, stream, what, n):
+        a = np.zeros(n, np.float32)
+        got = self.ctx.L.mi_aec_get(self.h, stream, what.encode(), _ptr(a), n)
+        if got < 0:
+            check(got)
+        return a[:got]
+
+    def process(self, mic, ref, out=None, run=None, flags=MI_AEC_POSTFILTER):
+        n, stride = mic.shape
+        if isinstance(mic, np.ndarray):
+            mic = np.ascontiguousarray(mic, np.int16)
+            ref = np.ascontiguousarray(ref, np.int16)
+            out = np.zeros_like(mic) if out is None else out
+            r = None if run is None else np.ascontiguousarray(run, np.uint8)
+            check(self.ctx.L.mi_aec_process_host(self.h, _ptr(mic), _ptr(ref), _ptr(out), stride, _ptr(r), flags))
+            return out
+        import torch
+        if out is None:
+            out = torch.zeros_like(mic)
+        check(self.ctx.L.mi_aec_process(self.h, _ptr(mic), _ptr(ref), _ptr(out), mic.stride(0), _ptr(run), flags))
+        return out
+
+
+class ScalerBatch(_Batch):
+    """MSScalerDesc context (msvideo.h:473-478) for a batch of I420 frames."""
+    _destroy = "mi_scaler_destroy"
+
+    def __init__(self, ctx, sw, sh, dw, dh, dst_fmt=MI_PIX_RGB24):
+        self.ctx = ctx
+        self.sw, self.sh, self.dw, self.dh, self.fmt = sw, sh, dw, dh, dst_fmt
+        h = C.c_void_p()
+        check(ctx.L.mi_scaler_create(ctx.h, sw, sh, dw, dh, dst_fmt, C.byref(h)))
+        self.h = h
+        self.src_bytes = ctx.L.mi_scaler_src_bytes(h)
+        self.dst_bytes = ctx.L.mi_scaler_dst_bytes(h)
+
+    def process(self, src, out=None):
+        """src [nframes, src_bytes] uint8."""
+        nf = src.shape[0]
+        if isinstance(src, np.ndarray):
+            src = np.ascontiguousarray(src, np.uint8)
+            out = np.zeros((nf, self.dst_bytes), np.uint8) if out is None else out
+            check(self.ctx.L.mi_scaler_process_host(self.h, nf, _ptr(src), src.shape[1], _ptr(out), out.shape[1]))
+            return out
+        import torch
+        if out is None:
+            out = torch.zeros((nf, self.dst_bytes), dtype=torch.uint8, device=src.device)
+        check(self.ctx.L.mi_scaler_process(self.h, nf, _ptr(src), src.stride(0), _ptr(out), out.stride(0)))
+        return out

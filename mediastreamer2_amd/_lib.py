@@ -1,0 +1,182 @@
+"""ctypes loader for libmsmi355x.so (the C ABI of include/msmi355x.h).
+
+There is no CPU fallback: if the shared library is missing it must be built
+(`python -c "import __graft_entry__ as g; g.build()"`), and on a machine
+without a HIP device every `mi_*_create` returns MI_ENODEV, which surfaces
+here as MiError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsmi355x.so")
+
+MI_OK, MI_EINVAL, MI_ENODEV, MI_ENOMEM, MI_ENOTSUP = 0, -1, -2, -3, -4
+
+
+class MiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmsmi355x error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/msmi355x.h declares (tests check the export table against this)
+EXPORTS = [
+    "mi_abi_version", "mi_last_error",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
+    "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_memset",
+    "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
+    "mi_timer_start", "mi_timer_stop",
+    "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_out_capacity",
+    "mi_resampler_info", "mi_resampler_get_table", "mi_resampler_process", "mi_resampler_process_host",
+    "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
+    "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
+    "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
+    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_process", "mi_volume_process_host",
+    "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
+    "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
+    "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
+    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process",
+    "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_get",
+    "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
+    "mi_scaler_process", "mi_scaler_process_host",
+]
+
+
+class VolumeParams(C.Structure):
+    _fields_ = [
+        ("static_gain", C.c_float),
+        ("vol_upramp", C.c_float), ("vol_fast_upramp", C.c_float), ("vol_downramp", C.c_float),
+        ("ea_thres", C.c_float), ("ea_transmit_thres", C.c_float), ("force", C.c_float),
+        ("sustain_time", C.c_int32), ("ng_cut_time", C.c_int32),
+        ("ng_threshold", C.c_float), ("ng_floorgain", C.c_float),
+        ("agc_enabled", C.c_int32), ("noise_gate_enabled", C.c_int32), ("remove_dc", C.c_int32),
+        ("peer", C.c_int32),
+    ]
+
+
+class VolumeState(C.Structure):
+    _fields_ = [
+        ("energy", C.c_float), ("level_pk", C.c_float), ("instant_energy", C.c_float),
+        ("lt_speaker_en", C.c_float), ("gain", C.c_float), ("target_gain", C.c_float),
+        ("ng_gain", C.c_float), ("dc_offset", C.c_int32), ("sustain_dur", C.c_int32),
+        ("ng_noise_dur", C.c_int32), ("fast_upramp", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, u32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_float
+    pp = C.POINTER(vp)
+    L.mi_abi_version.restype = i32
+    L.mi_last_error.restype = C.c_char_p
+    L.mi_ctx_create.argtypes = [i32, vp, pp]
+    L.mi_ctx_destroy.argtypes = [vp]
+    L.mi_ctx_destroy.restype = None
+    L.mi_ctx_sync.argtypes = [vp]
+    L.mi_ctx_stream.argtypes = [vp]
+    L.mi_ctx_stream.restype = vp
+    L.mi_ctx_device.argtypes = [vp]
+    L.mi_ctx_props.argtypes = [vp, C.POINTER(i32), C.POINTER(sz), C.c_char_p, i32]
+    L.mi_dev_alloc.argtypes = [vp, sz]
+    L.mi_dev_alloc.restype = vp
+    L.mi_dev_free.argtypes = [vp, vp]
+    L.mi_dev_free.restype = None
+    L.mi_host_alloc.argtypes = [vp, sz]
+    L.mi_host_alloc.restype = vp
+    L.mi_host_free.argtypes = [vp, vp]
+    L.mi_host_free.restype = None
+    L.mi_copy_h2d.argtypes = [vp, vp, vp, sz]
+    L.mi_copy_d2h.argtypes = [vp, vp, vp, sz]
+    L.mi_memset.argtypes = [vp, vp, i32, sz]
+    L.mi_ctx_capture_begin.argtypes = [vp]
+    L.mi_ctx_capture_end.argtypes = [vp, pp]
+    L.mi_graph_launch.argtypes = [vp]
+    L.mi_graph_destroy.argtypes = [vp]
+    L.mi_graph_destroy.restype = None
+    L.mi_timer_start.argtypes = [vp]
+    L.mi_timer_stop.argtypes = [vp, C.POINTER(f32)]
+
+    L.mi_resampler_create.argtypes = [vp, i32, u32, u32, i32, pp]
+    L.mi_resampler_destroy.argtypes = [vp]
+    L.mi_resampler_destroy.restype = None
+    L.mi_resampler_reset.argtypes = [vp, i32, i32]
+    L.mi_resampler_out_capacity.argtypes = [vp, i32]
+    L.mi_resampler_info.argtypes = [vp] + [C.POINTER(i32)] * 4
+    L.mi_resampler_get_table.argtypes = [vp, vp, i32]
+    L.mi_resampler_process.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    L.mi_resampler_process_host.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+
+    L.mi_mixer_create.argtypes = [vp, i32, i32, i32, pp]
+    L.mi_mixer_destroy.argtypes = [vp]
+    L.mi_mixer_destroy.restype = None
+    L.mi_mixer_set_controls.argtypes = [vp, vp, vp]
+    L.mi_mixer_process.argtypes = [vp, vp, vp, i32, vp]
+    L.mi_mixer_process_host.argtypes = [vp, vp, vp, i32, vp]
+    L.mi_mixer_partial_sum.argtypes = [vp, vp, vp, vp]
+    L.mi_mixer_finalize.argtypes = [vp, vp, vp, vp, i32, vp]
+
+    L.mi_volume_create.argtypes = [vp, i32, i32, pp]
+    L.mi_volume_destroy.argtypes = [vp]
+    L.mi_volume_destroy.restype = None
+    L.mi_volume_default_params.argtypes = [C.POINTER(VolumeParams)]
+    L.mi_volume_default_params.restype = None
+    L.mi_volume_set_params.argtypes = [vp, i32, i32, C.POINTER(VolumeParams)]
+    L.mi_volume_get_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
+    L.mi_volume_set_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
+    L.mi_volume_process.argtypes = [vp, vp, i32, i32, vp]
+    L.mi_volume_process_host.argtypes = [vp, vp, i32, i32, vp]
+
+    if hasattr(L, "mi_equalizer_create"):
+        L.mi_equalizer_create.argtypes = [vp, i32, i32, pp]
+        L.mi_equalizer_destroy.argtypes = [vp]
+        L.mi_equalizer_destroy.restype = None
+        L.mi_equalizer_fir_len.argtypes = [vp]
+        L.mi_equalizer_set_gain.argtypes = [vp, i32, f32, f32, f32]
+        L.mi_equalizer_flatten.argtypes = [vp, i32]
+        L.mi_equalizer_set_active.argtypes = [vp, i32, i32]
+        L.mi_equalizer_dump.argtypes = [vp, i32, vp, i32]
+        L.mi_equalizer_get_taps.argtypes = [vp, i32, vp, i32]
+        L.mi_equalizer_set_taps.argtypes = [vp, i32, vp, i32]
+        L.mi_equalizer_process.argtypes = [vp, vp, i32, i32]
+        L.mi_equalizer_process_host.argtypes = [vp, vp, i32, i32]
+    if hasattr(L, "mi_aec_create"):
+        L.mi_aec_framesize.argtypes = [i32, i32]
+        L.mi_aec_create.argtypes = [vp, i32, i32, i32, i32, pp]
+        L.mi_aec_destroy.argtypes = [vp]
+        L.mi_aec_destroy.restype = None
+        L.mi_aec_reset.argtypes = [vp, i32, i32]
+        L.mi_aec_process.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
+        L.mi_aec_process_host.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
+        L.mi_aec_state_bytes.argtypes = [vp]
+        L.mi_aec_state_bytes.restype = sz
+        L.mi_aec_get.argtypes = [vp, i32, C.c_char_p, vp, i32]
+    if hasattr(L, "mi_scaler_create"):
+        L.mi_scaler_create.argtypes = [vp, i32, i32, i32, i32, i32, pp]
+        L.mi_scaler_destroy.argtypes = [vp]
+        L.mi_scaler_destroy.restype = None
+        L.mi_scaler_src_bytes.argtypes = [vp]
+        L.mi_scaler_src_bytes.restype = sz
+        L.mi_scaler_dst_bytes.argtypes = [vp]
+        L.mi_scaler_dst_bytes.restype = sz
+        L.mi_scaler_process.argtypes = [vp, i32, vp, sz, vp, sz]
+        L.mi_scaler_process_host.argtypes = [vp, i32, vp, sz, vp, sz]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != MI_OK:
+        raise MiError(rc, load().mi_last_error().decode(errors="replace"))
+    return rc

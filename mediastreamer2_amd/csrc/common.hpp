@@ -1,0 +1,70 @@
+// common.hpp -- shared host-side plumbing of libmsmi355x (error reporting,
+// context object, small RAII helpers).  gfx950 only; no CUDA/other-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/msmi355x.h"
+
+namespace mi {
+
+void set_error(const char *fmt, ...);
+
+#define MI_HIP(expr)                                                                        \
+	do {                                                                                    \
+		hipError_t e__ = (expr);                                                            \
+		if (e__ != hipSuccess) {                                                            \
+			mi::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+			return MI_ENODEV;                                                               \
+		}                                                                                   \
+	} while (0)
+
+#define MI_CHECK_ARG(cond)                                                           \
+	do {                                                                             \
+		if (!(cond)) {                                                               \
+			mi::set_error("%s:%d invalid argument: %s", __FILE__, __LINE__, #cond);  \
+			return MI_EINVAL;                                                        \
+		}                                                                            \
+	} while (0)
+
+#define MI_LAUNCH_CHECK()                                                                  \
+	do {                                                                                   \
+		hipError_t e__ = hipGetLastError();                                                \
+		if (e__ != hipSuccess) {                                                           \
+			mi::set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+			return MI_ENODEV;                                                              \
+		}                                                                                  \
+	} while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+} // namespace mi
+
+struct mi_graph {
+	struct mi_ctx *ctx = nullptr;
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+};
+
+struct mi_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	int cu_count = 0;
+	size_t hbm_bytes = 0;
+	char name[128] = {0};
+	// scratch for *_host entry points (grown on demand)
+	void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+	size_t scratch_bytes[4] = {0, 0, 0, 0};
+	int ensure_scratch(int slot, size_t bytes, void **out);
+	int activate() const;
+};

@@ -1,0 +1,207 @@
+// ctx.hip -- context, memory and timing entry points of the C ABI.
+#include "common.hpp"
+
+namespace mi {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+} // namespace mi
+
+int mi_ctx::activate() const {
+	MI_HIP(hipSetDevice(device));
+	return MI_OK;
+}
+
+int mi_ctx::ensure_scratch(int slot, size_t bytes, void **out) {
+	if (bytes > scratch_bytes[slot]) {
+		if (scratch[slot]) (void)hipFree(scratch[slot]);
+		scratch[slot] = nullptr;
+		scratch_bytes[slot] = 0;
+		MI_HIP(hipMalloc(&scratch[slot], bytes));
+		scratch_bytes[slot] = bytes;
+	}
+	*out = scratch[slot];
+	return MI_OK;
+}
+
+extern "C" {
+
+int mi_abi_version(void) { return MSMI355X_ABI_VERSION; }
+const char *mi_last_error(void) { return mi::g_err; }
+
+int mi_ctx_create(int device, void *hip_stream, mi_ctx **out) {
+	MI_CHECK_ARG(out != nullptr);
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0) {
+		mi::set_error("no HIP device available (%s); libmsmi355x has no CPU fallback",
+		              e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+		return MI_ENODEV;
+	}
+	MI_CHECK_ARG(device >= 0 && device < ndev);
+	MI_HIP(hipSetDevice(device));
+	mi_ctx *c = new mi_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+		c->cu_count = prop.multiProcessorCount;
+		c->hbm_bytes = prop.totalGlobalMem;
+		snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+	}
+	if (hip_stream) {
+		c->stream = (hipStream_t)hip_stream;
+		c->own_stream = false;
+	} else {
+		if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+			mi::set_error("hipStreamCreate failed");
+			delete c;
+			return MI_ENODEV;
+		}
+		c->own_stream = true;
+	}
+	if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+		mi::set_error("hipEventCreate failed");
+		delete c;
+		return MI_ENODEV;
+	}
+	*out = c;
+	return MI_OK;
+}
+
+void mi_ctx_destroy(mi_ctx *c) {
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (int i = 0; i < 4; ++i)
+		if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int mi_ctx_sync(mi_ctx *c) {
+	MI_CHECK_ARG(c != nullptr);
+	MI_HIP(hipStreamSynchronize(c->stream));
+	return MI_OK;
+}
+
+void *mi_ctx_stream(mi_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int mi_ctx_device(mi_ctx *c) { return c ? c->device : -1; }
+
+int mi_ctx_props(mi_ctx *c, int *cu_count, size_t *hbm_bytes, char *name, int name_cap) {
+	MI_CHECK_ARG(c != nullptr);
+	if (cu_count) *cu_count = c->cu_count;
+	if (hbm_bytes) *hbm_bytes = c->hbm_bytes;
+	if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", c->name);
+	return MI_OK;
+}
+
+void *mi_dev_alloc(mi_ctx *c, size_t bytes) {
+	if (!c || c->activate() != MI_OK) return nullptr;
+	void *p = nullptr;
+	if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+		mi::set_error("hipMalloc(%zu) failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+void mi_dev_free(mi_ctx *c, void *p) {
+	if (!c || !p) return;
+	(void)hipSetDevice(c->device);
+	(void)hipFree(p);
+}
+
+void *mi_host_alloc(mi_ctx *c, size_t bytes) {
+	if (!c || c->activate() != MI_OK) return nullptr;
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+		mi::set_error("hipHostMalloc(%zu) failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+void mi_host_free(mi_ctx *c, void *p) {
+	if (!c || !p) return;
+	(void)hipHostFree(p);
+}
+
+int mi_copy_h2d(mi_ctx *c, void *d, const void *h, size_t n) {
+	MI_CHECK_ARG(c && d && h);
+	MI_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
+	return MI_OK;
+}
+
+int mi_copy_d2h(mi_ctx *c, void *h, const void *d, size_t n) {
+	MI_CHECK_ARG(c && d && h);
+	MI_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+	return MI_OK;
+}
+
+int mi_memset(mi_ctx *c, void *d, int value, size_t n) {
+	MI_CHECK_ARG(c && d);
+	MI_HIP(hipMemsetAsync(d, value, n, c->stream));
+	return MI_OK;
+}
+
+int mi_ctx_capture_begin(mi_ctx *c) {
+	MI_CHECK_ARG(c != nullptr);
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+	return MI_OK;
+}
+
+int mi_ctx_capture_end(mi_ctx *c, mi_graph **out) {
+	MI_CHECK_ARG(c && out);
+	*out = nullptr;
+	hipGraph_t graph = nullptr;
+	MI_HIP(hipStreamEndCapture(c->stream, &graph));
+	mi_graph *g = new mi_graph();
+	g->ctx = c;
+	g->graph = graph;
+	hipError_t e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+	if (e != hipSuccess) {
+		mi::set_error("hipGraphInstantiate -> %s", hipGetErrorString(e));
+		(void)hipGraphDestroy(graph);
+		delete g;
+		return MI_ENODEV;
+	}
+	*out = g;
+	return MI_OK;
+}
+
+int mi_graph_launch(mi_graph *g) {
+	MI_CHECK_ARG(g != nullptr);
+	MI_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+	return MI_OK;
+}
+
+void mi_graph_destroy(mi_graph *g) {
+	if (!g) return;
+	if (g->exec) (void)hipGraphExecDestroy(g->exec);
+	if (g->graph) (void)hipGraphDestroy(g->graph);
+	delete g;
+}
+
+int mi_timer_start(mi_ctx *c) {
+	MI_CHECK_ARG(c != nullptr);
+	MI_HIP(hipEventRecord(c->ev0, c->stream));
+	return MI_OK;
+}
+
+int mi_timer_stop(mi_ctx *c, float *ms) {
+	MI_CHECK_ARG(c && ms);
+	MI_HIP(hipEventRecord(c->ev1, c->stream));
+	MI_HIP(hipEventSynchronize(c->ev1));
+	MI_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+	return MI_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,353 @@
+// equalizer.hip -- batched MSEqualizer for gfx950.  Built with -ffp-contract=off.
+//
+// Run path (per tick, on the GPU): equalizer_state_run -> ms_fir_mem16
+// (src/audiofilters/equalizer.c:263-269, src/utils/dsptools.c:253-268): an
+// nfft-tap (128/256/512) direct-form FIR per stream,
+//     y[n] = ((x[n-ord+1]*h[ord-1] + h[ord-2]*x[n-ord+2]) + ...) + h[0]*x[n]
+// evaluated in exactly that order with separate float32 multiply and add, so
+// the int16 output is bit-identical to the reference build.  The delay line
+// is not shifted: the last ord-1 inputs live in HBM as int16 (exact), are
+// staged with the new block into LDS as float, and every lane slides a
+// register window over it (1 LDS read feeds R outputs); the stream's taps are
+// wave-uniform and come through the scalar cache.
+//
+// Design path (on gain changes only, on the host): MS_EQUALIZER_SET_GAIN
+// (equalizer.c:128-172), then impulse response = packed inverse FFT, half
+// swap, Hamming window (equalizer.c:184-237), uploaded as the stream's taps.
+#include "common.hpp"
+#include "host_fft.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int EQ_R = 4;        // outputs per lane
+constexpr int EQ_THREADS = 128;
+
+struct EqArgs {
+	int16_t *samples;
+	int16_t *hist;      // [nstreams][ord] int16 (ord-1 used)
+	const float *taps;  // [nstreams][ord]
+	const uint8_t *active;
+	int nstreams, nsamples, stride, ord;
+};
+
+template <int ORD>
+__global__ __launch_bounds__(EQ_THREADS) void equalizer_kernel(EqArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float *buf = reinterpret_cast<float *>(smem); // [ORD-1 + nsamples + EQ_R]
+	const int s = blockIdx.x;
+	if (!a.active[s]) return;
+	const int tid = threadIdx.x;
+	int16_t *xs = a.samples + (size_t)s * a.stride;
+	int16_t *hs = a.hist + (size_t)s * ORD;
+	const float *__restrict__ h = a.taps + (size_t)s * ORD;
+
+	for (int i = tid; i < ORD - 1; i += EQ_THREADS) buf[i] = (float)hs[i];
+	for (int i = tid; i < a.nsamples; i += EQ_THREADS) buf[ORD - 1 + i] = (float)xs[i];
+	for (int i = tid; i < EQ_R; i += EQ_THREADS) buf[ORD - 1 + a.nsamples + i] = 0.f;
+	__syncthreads();
+
+	for (int n0 = tid * EQ_R; n0 < a.nsamples; n0 += EQ_THREADS * EQ_R) {
+		float w[EQ_R], acc[EQ_R];
+#pragma unroll
+		for (int r = 0; r < EQ_R; ++r) acc[r] = 0.f;
+#pragma unroll
+		for (int r = 0; r < EQ_R - 1; ++r) w[r] = buf[n0 + r];
+		// jj = ORD-1-j: tap h[ORD-1-jj] meets buf[n + jj]  (oldest sample first)
+#pragma unroll 8
+		for (int jj = 0; jj < ORD; jj += EQ_R) {
+#pragma unroll
+			for (int u = 0; u < EQ_R; ++u) {
+				const float c = h[ORD - 1 - (jj + u)];
+				w[(u + EQ_R - 1) % EQ_R] = buf[n0 + EQ_R - 1 + jj + u];
+#pragma unroll
+				for (int r = 0; r < EQ_R; ++r) {
+					const float p = c * w[(u + r) % EQ_R];
+					acc[r] = acc[r] + p;
+				}
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < EQ_R; ++r) {
+			if (n0 + r < a.nsamples) {
+				const float v = acc[r];
+				// (int16_t)float of the reference is UB out of range (equalizer.c:251-255); saturate
+				const int q = v >= 32767.f ? 32767 : (v <= -32768.f ? -32768 : (int)v);
+				xs[n0 + r] = (int16_t)q;
+			}
+		}
+	}
+	// new delay line: the last ORD-1 inputs
+	for (int i = tid; i < ORD - 1; i += EQ_THREADS) hs[i] = (int16_t)buf[a.nsamples + i];
+}
+
+struct HostEq { // EqualizerState equalizer.c:37-46 (design-side fields)
+	std::vector<float> spectrum; // fft_cpx, packed real
+	bool stale = true;
+	bool active = true;
+};
+
+} // namespace
+
+struct mi_equalizer {
+	mi_ctx *ctx = nullptr;
+	int nstreams = 0, rate = 0, nfft = 0;
+	std::vector<HostEq> st;
+	bool any_stale = true, active_dirty = true;
+	float *d_taps = nullptr;
+	int16_t *d_hist = nullptr;
+	uint8_t *d_active = nullptr;
+	std::mutex mu;
+};
+
+namespace {
+
+void flatten(mi_equalizer *e, HostEq &s) { // equalizer.c:49-55
+	s.spectrum.assign((size_t)e->nfft, 0.f);
+	const float val = (float)(1.0f / e->nfft);
+	s.spectrum[0] = val;
+	for (int i = 1; i < e->nfft; i += 2) s.spectrum[(size_t)i] = val;
+	s.stale = true;
+}
+
+int hz_to_index(const mi_equalizer *e, int hz) { // equalizer.c:95-108
+	if (hz < 0) return -1;
+	if (hz > (e->rate / 2)) hz = (e->rate / 2);
+	int ret = ((hz * e->nfft) + (e->rate / 2)) / e->rate;
+	if (ret == e->nfft / 2) ret = (e->nfft / 2) - 1;
+	return ret;
+}
+
+int index2hz(const mi_equalizer *e, int index) { return (index * e->rate + e->nfft / 2) / e->nfft; }
+
+float gainpoint(int f, int freq_0, float sqrt_gain, int freq_bw) { // equalizer.c:128-135
+	float k1 = ((float)(f * f) - (float)(freq_0 * freq_0));
+	k1 *= k1;
+	float k2 = (float)(f * freq_bw);
+	k2 *= k2;
+	return (k1 + k2 * sqrt_gain) / (k1 + k2 / sqrt_gain);
+}
+
+void point_set(mi_equalizer *e, HostEq &s, int i, float gain) { // equalizer.c:137-145
+	const int index = 1 + ((i - 1) * 2);
+	if (index >= 0 && index < e->nfft)
+		s.spectrum[(size_t)index] = (s.spectrum[(size_t)index] * (int)(gain * 32768)) / 32768;
+}
+
+void design(const mi_equalizer *e, const HostEq &s, float *fir) { // equalizer.c:215-237
+	const int n = e->nfft, half = n / 2;
+	mi::packed_real_ifft(n, s.spectrum.data(), fir);
+	for (int i = 0; i < half; ++i) std::swap(fir[i], fir[i + half]); // time_shift :184-193
+	for (int i = 0; i < n; ++i) {                                    // norm_and_apodize :203-213
+		const float x = (float)((float)i * 2 * M_PI / (float)n);
+		const float w = (float)(0.54 - (0.46 * cos(x)));
+		fir[i] = w * (float)fir[i];
+	}
+}
+
+int upload_stale(mi_equalizer *e) {
+	if (e->any_stale) {
+		std::vector<float> fir((size_t)e->nfft);
+		for (int s = 0; s < e->nstreams; ++s) {
+			HostEq &h = e->st[(size_t)s];
+			if (!h.stale) continue;
+			design(e, h, fir.data());
+			MI_HIP(hipMemcpyAsync(e->d_taps + (size_t)s * e->nfft, fir.data(), sizeof(float) * (size_t)e->nfft,
+			                      hipMemcpyHostToDevice, e->ctx->stream));
+			MI_HIP(hipStreamSynchronize(e->ctx->stream)); // fir is reused
+			h.stale = false;
+		}
+		e->any_stale = false;
+	}
+	if (e->active_dirty) {
+		std::vector<uint8_t> act((size_t)e->nstreams);
+		for (int s = 0; s < e->nstreams; ++s) act[(size_t)s] = e->st[(size_t)s].active ? 1 : 0;
+		MI_HIP(hipMemcpyAsync(e->d_active, act.data(), act.size(), hipMemcpyHostToDevice, e->ctx->stream));
+		MI_HIP(hipStreamSynchronize(e->ctx->stream));
+		e->active_dirty = false;
+	}
+	return MI_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mi_equalizer_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_equalizer **out) {
+	MI_CHECK_ARG(ctx && out && nstreams > 0 && sample_rate > 0);
+	*out = nullptr;
+	if (ctx->activate() != MI_OK) return MI_ENODEV;
+	mi_equalizer *e = new mi_equalizer();
+	e->ctx = ctx;
+	e->nstreams = nstreams;
+	e->rate = sample_rate;
+	e->nfft = sample_rate < 16000 ? 128 : (sample_rate < 32000 ? 256 : 512); // equalizer.c:60-66
+	e->st.resize((size_t)nstreams);
+	// one flat design shared by every stream at start
+	flatten(e, e->st[0]);
+	std::vector<float> fir((size_t)e->nfft);
+	design(e, e->st[0], fir.data());
+	std::vector<float> all((size_t)nstreams * e->nfft);
+	for (int s = 0; s < nstreams; ++s) {
+		if (s) e->st[(size_t)s].spectrum = e->st[0].spectrum;
+		e->st[(size_t)s].stale = false;
+		memcpy(all.data() + (size_t)s * e->nfft, fir.data(), sizeof(float) * (size_t)e->nfft);
+	}
+	e->any_stale = false;
+	const size_t hb = (size_t)nstreams * e->nfft * sizeof(int16_t);
+	if (hipMalloc((void **)&e->d_taps, all.size() * sizeof(float)) != hipSuccess ||
+	    hipMalloc((void **)&e->d_hist, hb) != hipSuccess ||
+	    hipMalloc((void **)&e->d_active, (size_t)nstreams) != hipSuccess) {
+		mi::set_error("hipMalloc failed for equalizer state");
+		mi_equalizer_destroy(e);
+		return MI_ENOMEM;
+	}
+	if (hipMemcpy(e->d_taps, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemset(e->d_hist, 0, hb) != hipSuccess) {
+		mi::set_error("equalizer state upload failed");
+		mi_equalizer_destroy(e);
+		return MI_ENODEV;
+	}
+	*out = e;
+	return MI_OK;
+}
+
+void mi_equalizer_destroy(mi_equalizer *e) {
+	if (!e) return;
+	(void)hipSetDevice(e->ctx->device);
+	if (e->d_taps) (void)hipFree(e->d_taps);
+	if (e->d_hist) (void)hipFree(e->d_hist);
+	if (e->d_active) (void)hipFree(e->d_active);
+	delete e;
+}
+
+int mi_equalizer_fir_len(const mi_equalizer *e) { return e ? e->nfft : MI_EINVAL; }
+
+int mi_equalizer_set_gain(mi_equalizer *e, int stream, float freq_hz, float gain, float width_hz) {
+	MI_CHECK_ARG(e && stream >= 0 && stream < e->nstreams);
+	std::lock_guard<std::mutex> lk(e->mu);
+	HostEq &s = e->st[(size_t)stream];
+	// equalizer_state_set equalizer.c:147-172
+	const int freq_0 = (int)freq_hz;
+	int freq_bw = (int)width_hz;
+	const int delta_f = index2hz(e, 1);
+	const float sqrt_gain = (float)sqrt(gain);
+	const int mid = hz_to_index(e, freq_0);
+	freq_bw -= delta_f / 2;
+	if (freq_bw < delta_f / 2) freq_bw = delta_f / 2;
+	int i = mid, f;
+	point_set(e, s, i, gain);
+	do {
+		i++;
+		f = index2hz(e, i);
+		gain = gainpoint(f - delta_f, freq_0, sqrt_gain, freq_bw);
+		point_set(e, s, i, gain);
+	} while (i < e->nfft / 2 && (gain > 1.1 || gain < 0.9));
+	i = mid;
+	do {
+		i--;
+		f = index2hz(e, i);
+		gain = gainpoint(f + delta_f, freq_0, sqrt_gain, freq_bw);
+		point_set(e, s, i, gain);
+	} while (i >= 0 && (gain > 1.1 || gain < 0.9));
+	s.stale = true;
+	e->any_stale = true;
+	return MI_OK;
+}
+
+int mi_equalizer_flatten(mi_equalizer *e, int stream) {
+	MI_CHECK_ARG(e && stream >= 0 && stream < e->nstreams);
+	std::lock_guard<std::mutex> lk(e->mu);
+	flatten(e, e->st[(size_t)stream]);
+	e->any_stale = true;
+	return MI_OK;
+}
+
+int mi_equalizer_set_active(mi_equalizer *e, int stream, int active) {
+	MI_CHECK_ARG(e && stream >= 0 && stream < e->nstreams);
+	std::lock_guard<std::mutex> lk(e->mu);
+	e->st[(size_t)stream].active = active != 0;
+	e->active_dirty = true;
+	return MI_OK;
+}
+
+int mi_equalizer_dump(mi_equalizer *e, int stream, float *h_dst, int cap) { // equalizer.c:317-328
+	MI_CHECK_ARG(e && h_dst && stream >= 0 && stream < e->nstreams && cap >= e->nfft / 2);
+	std::lock_guard<std::mutex> lk(e->mu);
+	const HostEq &s = e->st[(size_t)stream];
+	float *t = h_dst;
+	*t++ = s.spectrum[0];
+	for (int i = 1; i < e->nfft && (t - h_dst) < cap; i += 2) *t++ = ((float)s.spectrum[(size_t)i] * (float)e->nfft) / 1.0f;
+	return MI_OK;
+}
+
+int mi_equalizer_get_taps(mi_equalizer *e, int stream, float *h_dst, int cap) {
+	MI_CHECK_ARG(e && h_dst && stream >= 0 && stream < e->nstreams && cap >= e->nfft);
+	std::lock_guard<std::mutex> lk(e->mu);
+	if (e->ctx->activate() != MI_OK) return MI_ENODEV;
+	int rc = upload_stale(e);
+	if (rc != MI_OK) return rc;
+	MI_HIP(hipStreamSynchronize(e->ctx->stream));
+	MI_HIP(hipMemcpy(h_dst, e->d_taps + (size_t)stream * e->nfft, sizeof(float) * (size_t)e->nfft,
+	                 hipMemcpyDeviceToHost));
+	return MI_OK;
+}
+
+int mi_equalizer_set_taps(mi_equalizer *e, int stream, const float *h_taps, int n) {
+	MI_CHECK_ARG(e && h_taps && stream >= 0 && stream < e->nstreams && n == e->nfft);
+	std::lock_guard<std::mutex> lk(e->mu);
+	if (e->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(e->ctx->stream));
+	MI_HIP(hipMemcpy(e->d_taps + (size_t)stream * e->nfft, h_taps, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+	e->st[(size_t)stream].stale = false;
+	return MI_OK;
+}
+
+int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride) {
+	MI_CHECK_ARG(e && d_samples && nsamples > 0 && stride >= nsamples);
+	if (nsamples > 8192) {
+		mi::set_error("block of %d samples exceeds the equalizer kernel's LDS staging (max 8192)", nsamples);
+		return MI_ENOTSUP;
+	}
+	std::lock_guard<std::mutex> lk(e->mu);
+	if (e->ctx->activate() != MI_OK) return MI_ENODEV;
+	int rc = upload_stale(e);
+	if (rc != MI_OK) return rc;
+	EqArgs a;
+	a.samples = d_samples;
+	a.hist = e->d_hist;
+	a.taps = e->d_taps;
+	a.active = e->d_active;
+	a.nstreams = e->nstreams;
+	a.nsamples = nsamples;
+	a.stride = stride;
+	a.ord = e->nfft;
+	const size_t lds = (size_t)(e->nfft - 1 + nsamples + EQ_R) * sizeof(float);
+	hipStream_t st = e->ctx->stream;
+	switch (e->nfft) {
+		case 128: hipLaunchKernelGGL(equalizer_kernel<128>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
+		case 256: hipLaunchKernelGGL(equalizer_kernel<256>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
+		default: hipLaunchKernelGGL(equalizer_kernel<512>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
+	}
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_equalizer_process_host(mi_equalizer *e, int16_t *h_samples, int nsamples, int stride) {
+	MI_CHECK_ARG(e && h_samples);
+	mi_ctx *c = e->ctx;
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	const size_t b = (size_t)e->nstreams * stride * sizeof(int16_t);
+	void *d;
+	int rc;
+	if ((rc = c->ensure_scratch(0, b, &d)) != MI_OK) return rc;
+	MI_HIP(hipMemcpyAsync(d, h_samples, b, hipMemcpyHostToDevice, c->stream));
+	rc = mi_equalizer_process(e, (int16_t *)d, nsamples, stride);
+	if (rc != MI_OK) return rc;
+	MI_HIP(hipMemcpyAsync(h_samples, d, b, hipMemcpyDeviceToHost, c->stream));
+	MI_HIP(hipStreamSynchronize(c->stream));
+	return MI_OK;
+}
+
+} // extern "C"

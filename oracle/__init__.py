@@ -1,0 +1,299 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY -- parity unpinned, see oracle/ms2_oracle.h.  Import
+this from tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() and
+from nowhere else; the product package never touches it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
+        for f in os.listdir(_HERE)
+        if f.endswith((".c", ".h"))
+    ):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _declare(_LIB)
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class OrcVolume(C.Structure):
+    _fields_ = [
+        ("energy", C.c_float), ("level_pk", C.c_float), ("instant_energy", C.c_float),
+        ("lt_speaker_en", C.c_float), ("gain", C.c_float), ("static_gain", C.c_float),
+        ("dc_offset", C.c_int), ("vol_upramp", C.c_float), ("vol_fast_upramp", C.c_float),
+        ("vol_downramp", C.c_float), ("ea_thres", C.c_float), ("ea_transmit_thres", C.c_float),
+        ("force", C.c_float), ("target_gain", C.c_float), ("sustain_time", C.c_int),
+        ("sustain_dur", C.c_int), ("sample_rate", C.c_int), ("nsamples", C.c_int),
+        ("ng_cut_time", C.c_int), ("ng_noise_dur", C.c_int), ("ng_threshold", C.c_float),
+        ("ng_floorgain", C.c_float), ("ng_gain", C.c_float), ("agc_enabled", C.c_int),
+        ("noise_gate_enabled", C.c_int), ("remove_dc", C.c_int), ("fast_upramp", C.c_int),
+        ("has_peer", C.c_int),
+    ]
+
+
+def _declare(L):
+    i16p, u8p, f32p, i32p = (C.POINTER(t) for t in (C.c_int16, C.c_uint8, C.c_float, C.c_int32))
+    L.orc_mixer_tick.argtypes = [i16p, u8p, f32p, u8p, u8p, C.c_int, C.c_int, C.c_int, i16p, i32p]
+    L.orc_mixer_tick.restype = None
+    for n in ("orc_volume_init",):
+        getattr(L, n).argtypes = [C.POINTER(OrcVolume)]
+    L.orc_volume_set_rate.argtypes = [C.POINTER(OrcVolume), C.c_int]
+    L.orc_volume_set_gain.argtypes = [C.POINTER(OrcVolume), C.c_float]
+    L.orc_volume_set_db_gain.argtypes = [C.POINTER(OrcVolume), C.c_float]
+    L.orc_volume_enable_noise_gate.argtypes = [C.POINTER(OrcVolume), C.c_int]
+    L.orc_volume_chunk.argtypes = [C.POINTER(OrcVolume), i16p, C.c_int, C.c_float]
+    L.orc_resampler_new.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+    L.orc_resampler_new.restype = C.c_void_p
+    L.orc_resampler_free.argtypes = [C.c_void_p]
+    L.orc_resampler_process.argtypes = [C.c_void_p, i16p, C.POINTER(C.c_uint32), i16p, C.POINTER(C.c_uint32)]
+    for n in ("orc_resampler_filt_len", "orc_resampler_den_rate", "orc_resampler_num_rate",
+              "orc_resampler_is_direct"):
+        getattr(L, n).argtypes = [C.c_void_p]
+        getattr(L, n).restype = C.c_int
+    L.orc_resampler_table.argtypes = [C.c_void_p, f32p, C.c_int]
+    L.orc_resampler_table.restype = C.c_int
+    L.orc_msresample_outcap.argtypes = [C.c_uint32] * 3
+    L.orc_msresample_outcap.restype = C.c_uint32
+    L.orc_ms_fft.argtypes = [C.c_int, f32p, f32p]
+    L.orc_ms_ifft.argtypes = [C.c_int, f32p, f32p]
+    L.orc_equalizer_new.argtypes = [C.c_int]
+    L.orc_equalizer_new.restype = C.c_void_p
+    L.orc_equalizer_free.argtypes = [C.c_void_p]
+    L.orc_equalizer_set_rate.argtypes = [C.c_void_p, C.c_int]
+    L.orc_equalizer_set_gain.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
+    L.orc_equalizer_design.argtypes = [C.c_void_p]
+    L.orc_equalizer_run.argtypes = [C.c_void_p, i16p, C.c_int]
+    L.orc_fir_mem16.argtypes = [f32p, f32p, f32p, C.c_int, C.c_int, f32p]
+    L.orc_scale_plane_bilinear.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+    L.orc_i420_scale.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+    L.orc_i420_to_rgb24.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int]
+    L.orc_i420_scale_to_rgb24.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+    if hasattr(L, "orc_echo_new"):
+        L.orc_echo_new.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_echo_new.restype = C.c_void_p
+        L.orc_echo_free.argtypes = [C.c_void_p]
+        L.orc_echo_cancel.argtypes = [C.c_void_p, i16p, i16p, i16p]
+        L.orc_echo_get.argtypes = [C.c_void_p, C.c_char_p, f32p, C.c_int]
+        L.orc_echo_get.restype = C.c_int
+        L.adjust_framesize_8000.argtypes = [C.c_int, C.c_int]
+        L.adjust_framesize_8000.restype = C.c_int
+    if hasattr(L, "orc_preproc_new"):
+        L.orc_preproc_new.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.orc_preproc_new.restype = C.c_void_p
+        L.orc_preproc_free.argtypes = [C.c_void_p]
+        L.orc_preproc_run.argtypes = [C.c_void_p, i16p]
+
+
+# ------------------------------------------------------------------ helpers
+def mixer_tick(inp, has_data=None, gain=None, active=None, out_enabled=None, conf_mode=1):
+    """inp [members][nsamples] int16 -> (out, sum). conf_mode 0 -> out is [nsamples]."""
+    inp = np.ascontiguousarray(inp, dtype=np.int16)
+    m, n = inp.shape
+    has_data = np.ones(m, np.uint8) if has_data is None else np.ascontiguousarray(has_data, np.uint8)
+    gain = np.ones(m, np.float32) if gain is None else np.ascontiguousarray(gain, np.float32)
+    active = np.ones(m, np.uint8) if active is None else np.ascontiguousarray(active, np.uint8)
+    out_enabled = np.ones(m, np.uint8) if out_enabled is None else np.ascontiguousarray(out_enabled, np.uint8)
+    out = np.zeros((m, n) if conf_mode else (n,), np.int16)
+    s = np.zeros(n, np.int32)
+    lib().orc_mixer_tick(_p(inp, C.c_int16), _p(has_data, C.c_uint8), _p(gain, C.c_float),
+                         _p(active, C.c_uint8), _p(out_enabled, C.c_uint8), m, n, int(conf_mode),
+                         _p(out, C.c_int16), _p(s, C.c_int32))
+    return out, s
+
+
+class Volume:
+    def __init__(self, rate=48000):
+        self.v = OrcVolume()
+        lib().orc_volume_init(C.byref(self.v))
+        lib().orc_volume_set_rate(C.byref(self.v), rate)
+
+    def chunk(self, samples, peer_energy=0.0):
+        s = np.array(samples, dtype=np.int16, copy=True)
+        lib().orc_volume_chunk(C.byref(self.v), _p(s, C.c_int16), len(s), float(peer_energy))
+        return s
+
+
+class Resampler:
+    def __init__(self, in_rate, out_rate, quality=3):
+        self.h = lib().orc_resampler_new(in_rate, out_rate, quality)
+        if not self.h:
+            raise ValueError("unsupported resampler config")
+        self.in_rate, self.out_rate = in_rate, out_rate
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_resampler_free(self.h)
+            self.h = None
+
+    @property
+    def filt_len(self):
+        return lib().orc_resampler_filt_len(self.h)
+
+    @property
+    def den_rate(self):
+        return lib().orc_resampler_den_rate(self.h)
+
+    @property
+    def num_rate(self):
+        return lib().orc_resampler_num_rate(self.h)
+
+    @property
+    def direct(self):
+        return bool(lib().orc_resampler_is_direct(self.h))
+
+    def table(self):
+        n = lib().orc_resampler_table(self.h, None, 0)
+        t = np.zeros(n, np.float32)
+        lib().orc_resampler_table(self.h, _p(t, C.c_float), n)
+        return t
+
+    def process(self, x):
+        """One input block as msresample.c:150-177 would hand it over."""
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        cap = lib().orc_msresample_outcap(len(x), self.in_rate, self.out_rate)
+        out = np.zeros(cap, np.int16)
+        il, ol = C.c_uint32(len(x)), C.c_uint32(cap)
+        lib().orc_resampler_process(self.h, _p(x, C.c_int16), C.byref(il), _p(out, C.c_int16), C.byref(ol))
+        assert il.value == len(x), "resampler did not consume its input (msresample.c:163)"
+        return out[: ol.value]
+
+
+def ms_fft(x):
+    x = np.ascontiguousarray(x, np.float32)
+    o = np.zeros_like(x)
+    lib().orc_ms_fft(len(x), _p(x, C.c_float), _p(o, C.c_float))
+    return o
+
+
+def ms_ifft(x):
+    x = np.ascontiguousarray(x, np.float32)
+    o = np.zeros_like(x)
+    lib().orc_ms_ifft(len(x), _p(x, C.c_float), _p(o, C.c_float))
+    return o
+
+
+class _EqState(C.Structure):
+    _fields_ = [("rate", C.c_int), ("nfft", C.c_int), ("fir_len", C.c_int),
+                ("fft_cpx", C.POINTER(C.c_float)), ("fir", C.POINTER(C.c_float)),
+                ("mem", C.POINTER(C.c_float)), ("needs_update", C.c_int), ("active", C.c_int)]
+
+
+class Equalizer:
+    def __init__(self, rate):
+        self.h = lib().orc_equalizer_new(rate)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_equalizer_free(self.h)
+            self.h = None
+
+    def _st(self):
+        return C.cast(self.h, C.POINTER(_EqState)).contents
+
+    def set_gain(self, freq, gain, width):
+        lib().orc_equalizer_set_gain(self.h, int(freq), float(gain), int(width))
+
+    def taps(self):
+        lib().orc_equalizer_design(self.h)
+        st = self._st()
+        return np.ctypeslib.as_array(st.fir, (st.fir_len,)).copy()
+
+    def spectrum(self):
+        st = self._st()
+        return np.ctypeslib.as_array(st.fft_cpx, (st.nfft,)).copy()
+
+    def run(self, samples):
+        s = np.array(samples, dtype=np.int16, copy=True)
+        lib().orc_equalizer_run(self.h, _p(s, C.c_int16), len(s))
+        return s
+
+
+def i420_size(w, h):
+    h2 = h + (h & 1)
+    return w * h2 + 2 * (w // 2) * (h2 // 2)
+
+
+def i420_scale(src, sw, sh, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros(i420_size(dw, dh), np.uint8)
+    lib().orc_i420_scale(_p(src, C.c_uint8), sw, sh, _p(dst, C.c_uint8), dw, dh)
+    return dst
+
+
+def i420_to_rgb24(src, w, h):
+    src = np.ascontiguousarray(src, np.uint8)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    lib().orc_i420_to_rgb24(_p(src, C.c_uint8), w, h, _p(rgb, C.c_uint8), w * 3)
+    return rgb
+
+
+def i420_scale_to_rgb24(src, sw, sh, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    rgb = np.zeros((dh, dw, 3), np.uint8)
+    lib().orc_i420_scale_to_rgb24(_p(src, C.c_uint8), sw, sh, _p(rgb, C.c_uint8), dw, dh)
+    return rgb
+
+
+class Echo:
+    def __init__(self, frame_size, filter_length, rate):
+        self.h = lib().orc_echo_new(frame_size, filter_length, rate)
+        self.frame = frame_size
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_echo_free(self.h)
+            self.h = None
+
+    def cancel(self, rec, play):
+        rec = np.ascontiguousarray(rec, np.int16)
+        play = np.ascontiguousarray(play, np.int16)
+        out = np.zeros(self.frame, np.int16)
+        lib().orc_echo_cancel(self.h, _p(rec, C.c_int16), _p(play, C.c_int16), _p(out, C.c_int16))
+        return out
+
+    def get(self, what, n):
+        a = np.zeros(n, np.float32)
+        got = lib().orc_echo_get(self.h, what.encode(), _p(a, C.c_float), n)
+        return a[:got]
+
+
+class Preproc:
+    def __init__(self, frame_size, rate, echo=None):
+        self.echo = echo
+        self.h = lib().orc_preproc_new(frame_size, rate, echo.h if echo is not None else None)
+        self.frame = frame_size
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_preproc_free(self.h)
+            self.h = None
+
+    def run(self, x):
+        x = np.array(x, dtype=np.int16, copy=True)
+        lib().orc_preproc_run(self.h, _p(x, C.c_int16))
+        return x

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+    orc.build()
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One mi_ctx on device 0 -- fails loudly if the HIP library or GPU is missing."""
+    import mediastreamer2_amd as ms
+    c = ms.Context(0)
+    yield c
+    c.close()
+
+
+def synth_pcm(stream_id, n, sigma=3000.0, tone_hz=1000.0, rate=48000, t0=0):
+    """SURVEY 8(d) synthetic audio: N(0,sigma) + -20 dBFS tone, clipped to +-32767."""
+    rng = np.random.default_rng(0x5EED + stream_id)
+    t = (np.arange(n) + t0) / rate
+    x = rng.normal(0.0, sigma, n) + 3276.7 * np.sin(2 * np.pi * tone_hz * t)
+    return np.clip(np.round(x), -32767, 32767).astype(np.int16)
+
+
+@pytest.fixture
+def pcm():
+    return synth_pcm

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/msmi355x.h declares; without a GPU, create calls fail
+loudly (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import mediastreamer2_amd as ms
+from mediastreamer2_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "msmi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_export_list_agree():
+    assert _header_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    missing = [s for s in _header_symbols() if not hasattr(L, s)]
+    assert not missing, f"libmsmi355x.so lacks {missing}"
+    assert L.mi_abi_version() == 1
+
+
+def test_library_is_in_tree_and_has_gfx950_code():
+    assert os.path.dirname(_lib.LIB_PATH) == os.path.join(ROOT, "mediastreamer2_amd")
+    out = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ms.MiError) as e:
+        ms.Context(0)
+    assert e.value.code == _lib.MI_ENODEV
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under mediastreamer2_amd/ or include/ may name it."""
+    bad = []
+    for base in ("mediastreamer2_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".hpp", ".h", ".c", ".cpp", ".cc")):
+                    txt = open(os.path.join(dp, fn), errors="replace").read()
+                    if re.search(r"\bimport oracle\b|from oracle\b|ms2_oracle\.h|liboracle", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,123 @@
+"""GPU parity: mi_resampler_* (HIP) vs the CPU oracle's restatement of the
+speex resampler as msresample.c:150-177 drives it.  Float path: the kernels use
+fused multiply-add, the oracle separate mul/add, so the int16 outputs may differ
+by 1 LSB where a value sits on a rounding boundary.  Tolerances (north_star):
+RMS error <= 1e-4 of full scale; we also require max |diff| <= 1 LSB."""
+import numpy as np
+import pytest
+
+import mediastreamer2_amd as ms
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+FULL_SCALE = 32768.0
+RMS_TOL = 1e-4  # relative to full scale, BASELINE.json north_star
+
+
+def _run_both(ctx, oracle, in_rate, out_rate, nstreams, in_len, nticks, sigma=3000.0):
+    rs = ms.ResamplerBatch(ctx, nstreams, in_rate, out_rate)
+    orcs = [oracle.Resampler(in_rate, out_rate) for _ in range(nstreams)]
+    x_all = np.stack([synth_pcm(s, in_len * nticks, sigma=sigma, rate=in_rate) for s in range(nstreams)])
+    worst, sq, cnt = 0, 0.0, 0
+    for t in range(nticks):
+        x = x_all[:, t * in_len:(t + 1) * in_len]
+        out, olen = rs.process(np.ascontiguousarray(x))
+        for s in range(nstreams):
+            ref = orcs[s].process(x[s])
+            assert olen[s] == len(ref), (s, t, olen[s], len(ref))
+            d = out[s, :olen[s]].astype(np.int32) - ref.astype(np.int32)
+            worst = max(worst, int(np.abs(d).max()))
+            sq += float((d.astype(np.float64) ** 2).sum())
+            cnt += len(d)
+    rs.close()
+    return worst, np.sqrt(sq / cnt) / FULL_SCALE
+
+
+@pytest.mark.parametrize("in_rate,out_rate,in_len", [
+    (16000, 48000, 160),   # BASELINE config 2 (fast up-sampling kernel, den=3)
+    (8000, 48000, 80),     # BASELINE config 1 (den=6)
+    (8000, 16000, 80),     # den=2
+    (48000, 16000, 480),   # down-sampling, 144 taps, generic kernel
+    (44100, 48000, 441),   # interpolated (non-direct) table
+    (16000, 8000, 160),
+    (48000, 44100, 480),
+])
+def test_resampler_matches_oracle(ctx, oracle, in_rate, out_rate, in_len):
+    worst, rms = _run_both(ctx, oracle, in_rate, out_rate, nstreams=9, in_len=in_len, nticks=12)
+    assert worst <= 1, f"max |gpu-oracle| = {worst} LSB"
+    assert rms <= RMS_TOL, f"rms = {rms}"
+
+
+def test_resampler_table_equals_oracle_table(ctx, oracle):
+    for a, b in ((16000, 48000), (48000, 16000), (44100, 48000), (8000, 48000)):
+        rs = ms.ResamplerBatch(ctx, 1, a, b)
+        o = oracle.Resampler(a, b)
+        assert rs.info() == {"filt_len": o.filt_len, "den_rate": o.den_rate, "num_rate": o.num_rate,
+                             "direct": int(o.direct)}
+        np.testing.assert_array_equal(rs.table(), o.table())
+        rs.close()
+
+
+def test_resampler_edge_inputs(ctx, oracle):
+    """silence, full-scale square (saturation in WORD2INT), -32768, ragged block sizes."""
+    n = 6
+    rs = ms.ResamplerBatch(ctx, n, 16000, 48000)
+    orcs = [oracle.Resampler(16000, 48000) for _ in range(n)]
+    for blk in (160, 8, 3, 1, 157, 160, 320):
+        x = np.zeros((n, blk), np.int16)
+        x[1] = 32767
+        x[2] = -32768
+        x[3] = np.where(np.arange(blk) % 2 == 0, 32767, -32768)
+        x[4] = synth_pcm(4, blk, sigma=20000.0, rate=16000)
+        x[5] = np.where((np.arange(blk) // 5) % 2 == 0, 32767, -32767)
+        out, olen = rs.process(x)
+        for s in range(n):
+            ref = orcs[s].process(x[s])
+            assert olen[s] == len(ref)
+            d = np.abs(out[s, :olen[s]].astype(np.int32) - ref.astype(np.int32))
+            assert d.max(initial=0) <= 1, (blk, s, d.max())
+    rs.close()
+
+
+def test_resampler_reset_and_independence(ctx, oracle):
+    """resetting one stream zeroes its history only; streams do not leak into each other."""
+    rs = ms.ResamplerBatch(ctx, 4, 16000, 48000)
+    x = np.stack([synth_pcm(s, 160, rate=16000) for s in range(4)])
+    first, _ = rs.process(x)
+    second, _ = rs.process(x)
+    assert not np.array_equal(first, second)  # history matters
+    rs.reset(2, 1)
+    third, _ = rs.process(x)
+    np.testing.assert_array_equal(third[2], first[2])
+    o = oracle.Resampler(16000, 48000)
+    for _ in range(3):
+        ref = o.process(x[0])
+    assert np.abs(third[0, :480].astype(int) - ref.astype(int)).max() <= 1
+    rs.close()
+
+
+def test_resampler_full_size_config2_properties(ctx, oracle):
+    """BASELINE config 2 at full size (4096 streams), device-resident path:
+    identical streams give identical outputs, and sampled streams match the oracle."""
+    torch = pytest.importorskip("torch")
+    n, in_len = 4096, 160
+    rs = ms.ResamplerBatch(ctx, n, 16000, 48000)
+    base = np.stack([synth_pcm(s % 64, in_len * 3, rate=16000) for s in range(n)])
+    x = torch.from_numpy(base).cuda()
+    outs = []
+    for t in range(3):
+        xt = x[:, t * in_len:(t + 1) * in_len].contiguous()
+        out, _ = rs.process(xt)
+        ctx.sync()
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy()[:, :480])
+    for t in range(3):
+        o = outs[t].reshape(64, 64, 480)  # stream s and s+64k carry the same signal
+        assert (o == o[:1]).all()
+    for s in (0, 1, 63, 4095):
+        orc = oracle.Resampler(16000, 48000)
+        for t in range(3):
+            ref = orc.process(base[s, t * in_len:(t + 1) * in_len])
+            assert np.abs(outs[t][s].astype(int) - ref.astype(int)).max() <= 1
+    rs.close()

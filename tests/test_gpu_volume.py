@@ -1,0 +1,163 @@
+"""GPU parity: mi_volume_* vs the oracle's restatement of msvolume.c.
+Integer output samples and the float control state must both be BIT-EXACT
+(the Q12 gain depends on the float state)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mediastreamer2_amd as ms
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(f):
+    return np.float32(f).view(np.uint32)
+
+
+def _cmp_state(st, ov, tag):
+    for name in ("energy", "level_pk", "instant_energy", "lt_speaker_en", "gain", "target_gain", "ng_gain"):
+        assert _bits(getattr(st, name)) == _bits(getattr(ov, name)), (tag, name, getattr(st, name), getattr(ov, name))
+    for name in ("dc_offset", "sustain_dur", "ng_noise_dur", "fast_upramp"):
+        assert getattr(st, name) == getattr(ov, name), (tag, name)
+
+
+def _mk(oracle, rate, **kw):
+    v = oracle.Volume(rate)
+    for k, val in kw.items():
+        setattr(v.v, k, val)
+    return v
+
+
+@pytest.mark.parametrize("rate,n", [(48000, 480), (16000, 160), (8000, 80)])
+def test_volume_modes_bit_exact(ctx, oracle, rate, n):
+    # stream configs: plain meter, static gain, AGC, noise gate, DC removal, AGC+NG, echo limiter pair
+    cfgs = [
+        dict(),
+        dict(static_gain=0.5, gain=0.5, target_gain=0.5),
+        dict(agc_enabled=1),
+        dict(noise_gate_enabled=1, gain=0.005, target_gain=0.005),
+        dict(remove_dc=1),
+        dict(agc_enabled=1, noise_gate_enabled=1, gain=0.005, target_gain=0.005, static_gain=2.0),
+        dict(static_gain=1.7, gain=1.7, target_gain=1.7),
+        dict(has_peer=1),           # stream 7: mic path, peer = stream 8
+        dict(),                     # stream 8: speaker path (the peer)
+    ]
+    ns = len(cfgs)
+    vb = ms.VolumeBatch(ctx, ns, rate)
+    params, states, orcs = [], vb.get_state(), []
+    for i, cfg in enumerate(cfgs):
+        p = vb.default_params()
+        o = _mk(oracle, rate, **cfg)
+        p.static_gain = o.v.static_gain
+        p.agc_enabled = o.v.agc_enabled
+        p.noise_gate_enabled = o.v.noise_gate_enabled
+        p.remove_dc = o.v.remove_dc
+        p.peer = 8 if cfg.get("has_peer") else -1
+        states[i].gain = o.v.gain
+        states[i].target_gain = o.v.target_gain
+        params.append(p)
+        orcs.append(o)
+    vb.set_params(params)
+    vb.set_state(states)
+    nticks = 60
+    sig = [synth_pcm(i, n * nticks, sigma=(300.0 if i in (3, 5) else 4000.0), rate=rate) for i in range(ns)]
+    # make the noise-gated streams alternate loud/quiet, add a DC offset to stream 4
+    for i in (3, 5):
+        env = (np.arange(n * nticks) // (n * 10)) % 2
+        sig[i] = (sig[i].astype(np.int32) * (1 + 15 * env)).clip(-32767, 32767).astype(np.int16)
+    sig[4] = (sig[4].astype(np.int32) + 900).clip(-32767, 32767).astype(np.int16)
+    sig[8] = (sig[8].astype(np.int32) * ((np.arange(n * nticks) // (n * 15)) % 2)).astype(np.int16)
+    peer_prev = 0.0  # energy of stream 8 at the end of the previous launch
+    for t in range(nticks):
+        x = np.stack([s[t * n:(t + 1) * n] for s in sig])
+        got = vb.process(np.ascontiguousarray(x.copy()))
+        st = vb.get_state()
+        for i in range(ns):
+            ref = orcs[i].chunk(x[i], peer_energy=peer_prev if i == 7 else 0.0)
+            np.testing.assert_array_equal(got[i], ref, err_msg=f"tick {t} stream {i}")
+            _cmp_state(st[i], orcs[i].v, (t, i))
+        peer_prev = orcs[8].v.energy
+    vb.close()
+
+
+def test_volume_unity_gain_leaves_minus_32768_untouched(ctx, oracle):
+    """A1: gain == 1 skips the sample loop, so -32768 survives (msvolume.c:440)."""
+    vb = ms.VolumeBatch(ctx, 2, 48000)
+    x = np.full((2, 480), -32768, np.int16)
+    p = vb.default_params()
+    q = vb.default_params()
+    q.static_gain = 0.999
+    vb.set_params([p, q])
+    s = vb.get_state()
+    s[1].gain = s[1].target_gain = 0.999
+    vb.set_state(s)
+    got = vb.process(x.copy())
+    assert (got[0] == -32768).all()
+    o = oracle.Volume(48000)
+    o.v.static_gain = o.v.gain = o.v.target_gain = np.float32(0.999)
+    np.testing.assert_array_equal(got[1], o.chunk(x[1]))
+    vb.close()
+
+
+def test_volume_ragged_chunks(ctx, oracle):
+    """light path: every stream hands over a different block length, some none (msvolume.c:505-512)."""
+    n, cap = 21, 488
+    vb = ms.VolumeBatch(ctx, n, 48000)
+    params = []
+    for i in range(n):
+        p = vb.default_params()
+        p.static_gain = 0.25 + 0.1 * i
+        params.append(p)
+    vb.set_params(params)
+    st = vb.get_state()
+    orcs = []
+    for i in range(n):
+        st[i].gain = st[i].target_gain = params[i].static_gain
+        o = oracle.Volume(48000)
+        o.v.static_gain = o.v.gain = o.v.target_gain = params[i].static_gain
+        orcs.append(o)
+    vb.set_state(st)
+    rng = np.random.default_rng(5)
+    for t in range(6):
+        lens = rng.integers(0, cap + 1, n).astype(np.int32)
+        lens[0] = 0
+        lens[1] = cap
+        x = np.stack([synth_pcm(100 + i, cap, sigma=5000.0, t0=t * cap) for i in range(n)])
+        got = vb.process(np.ascontiguousarray(x.copy()), nsamples=cap, per_stream=lens)
+        for i in range(n):
+            ref = x[i].copy()
+            if lens[i] > 0:
+                ref[:lens[i]] = orcs[i].chunk(x[i, :lens[i]])
+            np.testing.assert_array_equal(got[i], ref, err_msg=f"tick {t} stream {i} len {lens[i]}")
+    vb.close()
+
+
+def test_volume_full_size_4096_streams_agc(ctx, oracle):
+    """BASELINE config 3's AGC leg at full size, device-resident: streams that carry the same
+    signal must produce identical bytes and state; sampled streams match the oracle bit for bit."""
+    torch = pytest.importorskip("torch")
+    n, ns, ticks = 4096, 480, 5
+    vb = ms.VolumeBatch(ctx, n, 48000)
+    p = vb.default_params()
+    p.agc_enabled = 1
+    vb.set_params([p] * n)
+    base = np.stack([synth_pcm(s % 32, ns * ticks, sigma=5000.0) for s in range(n)])
+    orcs = {s: oracle.Volume(48000) for s in (0, 31, 4095)}
+    for o in orcs.values():
+        o.v.agc_enabled = 1
+    for t in range(ticks):
+        d = torch.from_numpy(np.ascontiguousarray(base[:, t * ns:(t + 1) * ns])).cuda()
+        vb.process(d)
+        ctx.sync()
+        torch.cuda.synchronize()
+        out = d.cpu().numpy()
+        grp = out.reshape(128, 32, ns)
+        assert (grp == grp[:1]).all()
+        for s, o in orcs.items():
+            np.testing.assert_array_equal(out[s], o.chunk(base[s, t * ns:(t + 1) * ns]))
+    st = vb.get_state()
+    for s, o in orcs.items():
+        _cmp_state(st[s], o.v, s)
+    vb.close()
