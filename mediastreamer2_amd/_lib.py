@@ -76,6 +76,13 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 and must be the
+    # first to load it, otherwise torch.cuda later reports "No HIP GPUs are available".
+    # (Only a load-order fix -- nothing in this package computes with torch.)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i32, u32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_float
     pp = C.POINTER(vp)

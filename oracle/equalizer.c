@@ -224,6 +224,36 @@ static void rfft_inverse(RFft *st, const float *f, float *t) {
 	cfft(&st->sub, st->tmp, (cpx *)t);
 }
 
+/* persistent handle = ms_fft_init (dsptools.c:333-341): forward + backward tables */
+struct OrcFft {
+	RFft fwd, bwd;
+	int n;
+};
+
+OrcFft *orc_fft_new(int nfft) {
+	OrcFft *t = (OrcFft *)malloc(sizeof(*t));
+	rfft_init(&t->fwd, nfft, 0);
+	rfft_init(&t->bwd, nfft, 1);
+	t->n = nfft;
+	return t;
+}
+
+void orc_fft_free(OrcFft *t) {
+	if (!t) return;
+	rfft_free(&t->fwd);
+	rfft_free(&t->bwd);
+	free(t);
+}
+
+void orc_fft_forward(OrcFft *t, const float *in, float *out) { /* == ms_fft == speex spx_fft (kiss backend) */
+	int i;
+	float scale = 1.f / t->n;
+	rfft_forward(&t->fwd, in, out);
+	for (i = 0; i < t->n; i++) out[i] *= scale;
+}
+
+void orc_fft_inverse(OrcFft *t, const float *in, float *out) { rfft_inverse(&t->bwd, in, out); }
+
 void orc_ms_fft(int nfft, const float *in, float *out) { /* dsptools.c:358-369 */
 	RFft st;
 	int i;

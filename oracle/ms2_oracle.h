@@ -98,6 +98,11 @@ uint32_t orc_msresample_outcap(uint32_t inlen, uint32_t in_rate, uint32_t out_ra
  * :320-408 (kf_work), :412-475 (factor/alloc), src/utils/kiss_fftr.c:40-81,
  * :175-259 (kiss_fftr2), :261-296 (kiss_fftri2); wrappers ms_fft/ms_ifft
  * src/utils/dsptools.c:333-376. nfft must be even, factors of 4 and 2 only. */
+typedef struct OrcFft OrcFft; /* ms_fft_init handle */
+OrcFft *orc_fft_new(int nfft);
+void orc_fft_free(OrcFft *t);
+void orc_fft_forward(OrcFft *t, const float *in, float *out); /* scaled 1/N */
+void orc_fft_inverse(OrcFft *t, const float *in, float *out); /* unscaled */
 void orc_ms_fft(int nfft, const float *in, float *out);  /* forward, scaled 1/N */
 void orc_ms_ifft(int nfft, const float *in, float *out); /* inverse, unscaled */
 
