@@ -1,0 +1,181 @@
+"""GPU parity: mi_aec_* (MDF echo canceller + post-filter) vs the oracle's
+restatement of the libspeexdsp algorithm speexec.c:297-298 calls.
+
+The HIP kernel mirrors the oracle's float32 operation order (FFT butterflies,
+block accumulation, serial decision sums), so the canceller is expected to be
+bit-identical until the proportional-step norms (tree-reduced on the GPU) come
+into play (state `adapted`), and within the north_star tolerance afterwards:
+RMS error <= 1e-4 of full scale over the first 2 s from identical zero state."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mediastreamer2_amd as ms
+from mediastreamer2_amd import _lib
+
+pytestmark = pytest.mark.gpu
+FULL_SCALE = 32768.0
+
+
+def make_echo_scene(seed, rate, nsamp, near_sigma=300.0, far_sigma=3000.0):
+    """mic = 0.5*ref through a fixed 64-tap decaying IR, 20 ms delay, + near-end noise."""
+    rng = np.random.default_rng(0x5EED + seed)
+    far = rng.normal(0, far_sigma, nsamp)
+    far = np.convolve(far, [0.5, 0.3, 0.2])[:nsamp] + 3276.7 * np.sin(2 * np.pi * 1000 * np.arange(nsamp) / rate)
+    ir = np.random.default_rng(1234).normal(0, 1, 64) * np.exp(-np.arange(64) / 12.0)
+    ir /= np.sqrt((ir ** 2).sum())
+    d = int(0.020 * rate)
+    echo = 0.5 * np.convolve(np.concatenate([np.zeros(d), far]), ir)[:nsamp]
+    mic = echo + rng.normal(0, near_sigma, nsamp)
+    to16 = lambda v: np.clip(np.round(v), -32767, 32767).astype(np.int16)
+    return to16(mic), to16(far)
+
+
+@pytest.mark.parametrize("F", [256, 128])
+def test_fft_bit_exact(ctx, oracle, F):
+    """The in-LDS real FFT == the kiss_fft float build restated in the oracle (ms_fft / ms_ifft)."""
+    torch = pytest.importorskip("torch")
+    L = _lib.load()
+    L.mi_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    rate = 48000 if F == 256 else 16000
+    aec = ms.AecBatch(ctx, 1, rate, frame_size=F, filter_length=4 * F)
+    N, nfr = 2 * F, 6
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 3000, (nfr, N)).astype(np.float32)
+    x[1] = 0
+    x[2, :] = 0
+    x[2, 5] = 1.0
+    d = torch.from_numpy(x).cuda()
+    o = torch.zeros_like(d)
+    assert L.mi_debug_fft(aec.h, d.data_ptr(), o.data_ptr(), nfr, 0) == 0
+    ctx.sync()
+    spec = o.cpu().numpy()
+    for i in range(nfr):
+        ref = oracle.ms_fft(x[i])                      # [DC, re1, im1, ..., Nyq]
+        got = np.empty(N, np.float32)
+        got[0], got[N - 1] = spec[i, 0], spec[i, 1]    # kernel layout [DC, Nyq, re1, im1, ...]
+        got[1:N - 1] = spec[i, 2:]
+        np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg=f"fwd frame {i}")
+    t = torch.zeros_like(d)
+    assert L.mi_debug_fft(aec.h, o.data_ptr(), t.data_ptr(), nfr, 1) == 0
+    ctx.sync()
+    back = t.cpu().numpy()
+    for i in range(nfr):
+        ref = oracle.ms_ifft(oracle.ms_fft(x[i]))
+        np.testing.assert_array_equal(back[i].view(np.uint32), ref.view(np.uint32), err_msg=f"inv frame {i}")
+    aec.close()
+
+
+def _run_pair(ctx, oracle, rate, F, tail_ms, nstreams, nframes, postfilter, scene_kw=None):
+    flen = tail_ms * rate // 1000
+    aec = ms.AecBatch(ctx, nstreams, rate, frame_size=F, filter_length=flen)
+    ecs = [oracle.Echo(F, flen, rate) for _ in range(nstreams)]
+    pps = [oracle.Preproc(F, rate, ecs[s]) for s in range(nstreams)] if postfilter else None
+    scenes = [make_echo_scene(s, rate, F * nframes, **(scene_kw or {})) for s in range(nstreams)]
+    mic = np.stack([m for m, _ in scenes])
+    far = np.stack([f for _, f in scenes])
+    got = np.zeros_like(mic)
+    ref = np.zeros_like(mic)
+    flags = ms.MI_AEC_POSTFILTER if postfilter else 0
+    for f in range(nframes):
+        sl = slice(f * F, (f + 1) * F)
+        got[:, sl] = aec.process(np.ascontiguousarray(mic[:, sl]), np.ascontiguousarray(far[:, sl]), flags=flags)
+        for s in range(nstreams):
+            o = ecs[s].cancel(mic[s, sl], far[s, sl])
+            ref[s, sl] = pps[s].run(o) if postfilter else o
+    return aec, ecs, mic, far, got, ref
+
+
+@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128)])
+def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
+    """First frames from zero state: outputs, W, foreground, X history and every control scalar
+    equal the oracle's bit for bit (no tree-reduced quantity is in use yet)."""
+    nframes = 12
+    aec, ecs, mic, far, got, ref = _run_pair(ctx, oracle, rate, F, tail_ms, 3, nframes, postfilter=False)
+    M = (tail_ms * rate // 1000 + F - 1) // F
+    N = 2 * F
+    for s in range(3):
+        sc_g, sc_o = aec.get(s, "scalars", 16), ecs[s].get("scalars", 16)
+        assert sc_o[8] == 0, "scene adapted too early for this test"
+        np.testing.assert_array_equal(got[s], ref[s], err_msg=f"stream {s} output")
+        np.testing.assert_array_equal(sc_g.view(np.uint32), sc_o.view(np.uint32), err_msg=f"scalars {s}")
+        for what, n in (("W", M * N), ("foreground", M * N), ("X", (M + 1) * N), ("E", N), ("power", F + 1),
+                        ("power_1", F + 1), ("Eh", F + 1), ("Yh", F + 1), ("last_y", N)):
+            np.testing.assert_array_equal(aec.get(s, what, n).view(np.uint32), ecs[s].get(what, n).view(np.uint32),
+                                          err_msg=f"stream {s} {what}")
+    aec.close()
+
+
+@pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(48000, 256, 128, False), (48000, 256, 128, True),
+                                                      (16000, 128, 128, True), (16000, 128, 250, False)])
+def test_aec_two_seconds_within_tolerance(ctx, oracle, rate, F, tail_ms, postfilter):
+    """2 s from zero state (BASELINE config 3 geometry at 48 kHz): RMS error <= 1e-4 of full scale,
+    same adaptation decisions, and the canceller actually cancels (ERLE)."""
+    nframes = int(2.0 * rate / F)
+    ns = 4
+    aec, ecs, mic, far, got, ref = _run_pair(ctx, oracle, rate, F, tail_ms, ns, nframes, postfilter)
+    for s in range(ns):
+        d = got[s].astype(np.float64) - ref[s].astype(np.float64)
+        rms = np.sqrt(np.mean(d ** 2)) / FULL_SCALE
+        assert rms <= 1e-4, f"stream {s}: rms {rms:.3e}, max {np.abs(d).max()}"
+        sg, so = aec.get(s, "scalars", 16), ecs[s].get("scalars", 16)
+        assert sg[8] == so[8] == 1.0, "both must have reached the adapted state"
+        assert sg[11] == so[11] == nframes
+        tail = slice(-rate // 2, None)
+        pw = lambda v: np.mean(v[tail].astype(np.float64) ** 2) + 1e-9
+        erle, erle_ref = 10 * np.log10(pw(mic[s]) / pw(got[s])), 10 * np.log10(pw(mic[s]) / pw(ref[s]))
+        # the scene's near-end noise (sigma 300 vs ~1500 rms echo) caps the linear canceller at ~14 dB
+        assert erle > (6.0 if not postfilter else 12.0), f"stream {s}: ERLE {erle:.1f} dB"
+        assert abs(erle - erle_ref) < 0.1, f"stream {s}: ERLE {erle:.2f} dB vs oracle {erle_ref:.2f} dB"
+    aec.close()
+
+
+def test_aec_run_mask_and_reset(ctx, oracle):
+    """A23: streams without a full frame this tick are skipped (state untouched); reset returns
+    a stream to the zero state."""
+    rate, F, flen = 16000, 128, 2048
+    aec = ms.AecBatch(ctx, 3, rate, frame_size=F, filter_length=flen)
+    mic, far = make_echo_scene(0, rate, F * 20)
+    mic3, far3 = np.stack([mic] * 3), np.stack([far] * 3)
+    outs = []
+    for f in range(10):
+        sl = slice(f * F, (f + 1) * F)
+        run = np.array([1, f % 2 == 0, 1], np.uint8)
+        sentinel = np.full((3, F), 777, np.int16)
+        o = aec.process(np.ascontiguousarray(mic3[:, sl]), np.ascontiguousarray(far3[:, sl]), out=sentinel, run=run)
+        outs.append(o.copy())
+        if not run[1]:
+            assert (o[1] == 777).all()
+        np.testing.assert_array_equal(o[0], o[2])
+    first = outs[0][0].copy()
+    aec.reset(0, 1)
+    o = aec.process(np.ascontiguousarray(mic3[:, :F]), np.ascontiguousarray(far3[:, :F]))
+    np.testing.assert_array_equal(o[0], first)
+    aec.close()
+
+
+def test_aec_full_size_4096_streams(ctx, oracle):
+    """BASELINE config 3 geometry at full batch size, device-resident: identical scenes give identical
+    bytes across the batch; sampled streams equal the oracle over the first frames."""
+    torch = pytest.importorskip("torch")
+    rate, F, n, nframes = 48000, 256, 4096, 6
+    flen = 128 * rate // 1000
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    assert aec.state_bytes() >= (25 * 512 + 2 * 24 * 512) * 4
+    scenes = [make_echo_scene(s, rate, F * nframes) for s in range(8)]
+    mic = np.stack([scenes[s % 8][0] for s in range(n)])
+    far = np.stack([scenes[s % 8][1] for s in range(n)])
+    ecs = {s: oracle.Echo(F, flen, rate) for s in (0, 7, 4095)}
+    for f in range(nframes):
+        sl = slice(f * F, (f + 1) * F)
+        dm = torch.from_numpy(np.ascontiguousarray(mic[:, sl])).cuda()
+        dr = torch.from_numpy(np.ascontiguousarray(far[:, sl])).cuda()
+        o = aec.process(dm, dr, flags=0)
+        ctx.sync()
+        out = o.cpu().numpy()
+        grp = out.reshape(512, 8, F)
+        assert (grp == grp[:1]).all()
+        for s, e in ecs.items():
+            np.testing.assert_array_equal(out[s], e.cancel(mic[s, sl], far[s, sl]), err_msg=f"frame {f} stream {s}")
+    aec.close()
