@@ -67,6 +67,8 @@ class Leg:
         self.alg_bytes, self.units, self.unit_name = alg_bytes, units, unit_name
 
     def run(self, steps, warmup, use_graph=True):
+        import torch
+        torch.cuda.synchronize()  # buffers were filled on torch's stream; launches go to the context's stream
         for i in range(warmup):
             self.launch(i % self.ring)
         self.ctx.sync()
@@ -209,6 +211,36 @@ def make_scaler_leg(ms, torch, ctx, nframes=64):
     return leg
 
 
+def make_aec_leg(ms, torch, ctx, nstreams=4096):
+    """BASELINE configs[2] geometry: 48 kHz, 256-sample frames, 128 ms tail (M=24, N=512), post-filter on."""
+    rate, F = 48000, 256
+    aec = ms.AecBatch(ctx, nstreams, rate, frame_size=F, filter_length=128 * rate // 1000)
+    # SURVEY 8(d): per 256-sample frame mic+ref+out 1536 B, W read+write 2x49152, foreground 49152,
+    # X history read 51200, newest X block 2048
+    per_frame = nstreams * 202240
+    rng = np.random.default_rng(0x5EED)
+    far = synth_pcm_batch(nstreams, F * 4, rate)
+    ir = rng.normal(0, 1, 64) * np.exp(-np.arange(64) / 12.0)
+    ir /= np.sqrt((ir ** 2).sum())
+    ring = 4
+    mics, refs, outs = [], [], []
+    for r in range(ring):
+        f = far[:, r * F:(r + 1) * F].astype(np.float32)
+        echo = 0.5 * np.apply_along_axis(lambda v: np.convolve(v, ir)[:F], 1, f[:256])
+        mic = np.tile(echo, (nstreams // 256 + 1, 1))[:nstreams] + rng.normal(0, 300, (nstreams, F))
+        mics.append(torch.from_numpy(np.clip(np.round(mic), -32767, 32767).astype(np.int16)).cuda())
+        refs.append(torch.from_numpy(np.ascontiguousarray(far[:, r * F:(r + 1) * F])).cuda())
+        outs.append(torch.zeros((nstreams, F), dtype=torch.int16, device="cuda"))
+
+    def launch(i):
+        aec.process(mics[i], refs[i], out=outs[i])
+
+    leg = Leg(ctx, "aec_kernel<256>", launch, ring, per_frame, nstreams, "stream-frames (256 samples)")
+    leg.keep = (aec, mics, refs, outs)
+    leg.state_bytes = aec.state_bytes() * nstreams
+    return leg
+
+
 def cpu_baseline_resample(nstreams, seconds):
     """The oracle (CPU restatement of the reference path: one resampler object per stream,
     called tick by tick) on this host's cores -- 1 thread, bounded sample."""
@@ -302,7 +334,7 @@ def main():
         if not a.no_extras:
             extras = []
             ksteps = max(20, min(a.steps, 100))
-            for mk in (make_mixer_leg, make_volume_leg, make_equalizer_leg, make_scaler_leg):
+            for mk in (make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg, make_scaler_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
@@ -312,6 +344,9 @@ def main():
                     r = roofline(ms_, ksteps, lg.alg_bytes, pmc_traffic(lg.name.split("<")[0]))
                     r["kernel"] = lg.name
                     r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
+                    if hasattr(lg, "state_bytes"):
+                        r["resident_state_bytes"] = int(lg.state_bytes)
+                        r["streams_per_10ms_tick_at_this_rate"] = int(lg.units * 0.010 / (ms_ * 1e-3 / ksteps) / 1.875)
                     if hasattr(lg, "mpix_in"):
                         r["mpix_per_s_in"] = round(lg.mpix_in / (ms_ * 1e-3 / ksteps), 1)
                     extras.append(r)

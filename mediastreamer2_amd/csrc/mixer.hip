@@ -103,19 +103,26 @@ __global__ __launch_bounds__(256) void mixer_kernel(MixArgs a) {
 		store_sat(a.out + (size_t)c * a.ns + 4 * q, sum);
 		return;
 	}
+	if (MODE == 2) {
+		// outputs from the all-reduced sum: every local member's own (gained) contribution is re-derived
+		for (int m = 0; m < a.mm; ++m) {
+			const unsigned f = fl[m];
+			if (f & MI_MIX_OUTPUT) {
+				bool summed;
+				int4 own = load_contrib(a, c, m, q, f, summed);
+				if (!summed) own = make_int4(0, 0, 0, 0);
+				store_sat(a.out + ((size_t)(c * a.mm + m) * a.ns) + 4 * q,
+				          make_int4(sum.x - own.x, sum.y - own.y, sum.z - own.z, sum.w - own.w));
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int m = 0; m < NMAX; ++m) {
 		if (m < a.mm) {
 			const unsigned f = fl[m];
 			if (f & MI_MIX_OUTPUT) {
-				int4 own;
-				if (MODE == 2) {
-					bool summed;
-					own = load_contrib(a, c, m, q, f, summed);
-					if (!summed) own = make_int4(0, 0, 0, 0);
-				} else {
-					own = v[m]; // zero unless the channel was summed (active)
-				}
+				const int4 own = v[m]; // zero unless the channel was summed (active)
 				store_sat(a.out + ((size_t)(c * a.mm + m) * a.ns) + 4 * q,
 				          make_int4(sum.x - own.x, sum.y - own.y, sum.z - own.z, sum.w - own.w));
 			}

@@ -1,0 +1,49 @@
+"""Multi-GPU placement for the hot path: one process per GPU.
+
+Streams (resampler, AEC, volume, equalizer, scaler) are independent, so they
+shard statically with no data-path collective.  The conference mixer is the one
+exchange step: sum[i] = sum over members (audiomixer.c:304-314).  Conferences are
+placed whole on one GPU whenever possible (zero communication); a conference
+whose members are split contributes an int32 partial sum per GPU, and ONE
+all-reduce (RCCL over xGMI, `torch.distributed` backend "nccl"; "gloo" in the CPU
+tests) of the [n_split_conf, nsamples] tensor makes every GPU hold the total.
+Integer addition is associative, so the result is bit-identical to the
+single-GPU mix regardless of reduction order.
+"""
+from dataclasses import dataclass
+from typing import List, Sequence
+
+
+def shard_range(n_units: int, world: int, rank: int):
+    """Contiguous balanced shard [lo, hi) of n_units independent units for `rank`."""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+@dataclass
+class ConferencePlacement:
+    local_whole: List[int]     # conferences fully owned by this rank
+    split: List[int]           # conferences whose members are spread over all ranks
+    member_lo: int = 0         # this rank's member range inside every split conference
+    member_hi: int = 0
+
+
+def place_conferences(n_conf: int, members: int, world: int, rank: int,
+                      split_conf: Sequence[int] = ()) -> ConferencePlacement:
+    """Whole conferences round-robin over ranks; the ones listed in `split_conf` (too large for
+    one GPU's stream budget, or co-located with their members' AEC state) are member-sharded."""
+    split = sorted(set(split_conf))
+    whole = [c for c in range(n_conf) if c not in split]
+    lo, hi = shard_range(members, world, rank)
+    return ConferencePlacement([c for i, c in enumerate(whole) if i % world == rank], split, lo, hi)
+
+
+def allreduce_partial_sums(partial, group=None):
+    """In-place int32 SUM all-reduce of the partial mixes of the split conferences."""
+    import torch
+    import torch.distributed as dist
+    assert partial.dtype == torch.int32
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+    return partial
