@@ -66,9 +66,8 @@ struct AecScalars {
 	float memX, memD, memE, notch0, notch1;
 	int adapted, saturated, screwed_up, cancel_count, xhead;
 	int nb_adapt, min_count;
-	int pad[12];
 };
-static_assert(sizeof(AecScalars) == 128, "scalar record");
+static_assert(sizeof(AecScalars) == 80, "scalar record");
 
 struct AecArgs {
 	const int16_t *mic, *ref;
@@ -82,7 +81,6 @@ struct AecArgs {
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
 	int sampling_rate;
 	AecTables t;
-	FftPlan plan;
 };
 
 // offsets (in floats) inside the per-stream small-state block, as multiples of F
@@ -132,16 +130,26 @@ struct Lds {
 	int flag[4];
 };
 
+// kiss_fft factorisation (4s first, then 2), stages listed deepest first:
+// F=256: radix 4,4,4,4 with m = 1,4,16,64;  F=128: radix 2 (m=1) then 4,4,4 with m = 2,8,32.
+__host__ __device__ constexpr int plan_p(int F, int s) { return (F == 128 && s == 0) ? 2 : 4; }
+__host__ __device__ constexpr int plan_m(int F, int s) {
+	return F == 128 ? (s == 0 ? 1 : (s == 1 ? 2 : (s == 2 ? 8 : 32))) : (s == 0 ? 1 : (s == 1 ? 4 : (s == 2 ? 16 : 64)));
+}
+__host__ __device__ constexpr int plan_fs(int F, int s) { return s == 0 ? 64 : (s == 1 ? 16 : (s == 2 ? 4 : 1)); }
+
 // ---- complex FFT of F points, in place on z (kiss order). All F lanes call it.
 template <int F>
-__device__ void cfft(Lds<F> &L, const float2 *src, bool inverse, const FftPlan &plan) {
+__device__ void cfft(Lds<F> &L, const float2 *src, bool inverse) {
 	const int tid = threadIdx.x;
 	float2 val = src[L.perm[tid]];
 	__syncthreads();
 	L.zbuf[tid] = val;
 	__syncthreads();
-	for (int s = 0; s < plan.nstages; ++s) {
-		const int p = plan.p[s], m = plan.m[s], fs = plan.fs[s];
+#pragma unroll
+	for (int s = 0; s < 4; ++s) {
+		constexpr int FF = F;
+		const int p = plan_p(FF, s), m = plan_m(FF, s), fs = plan_fs(FF, s);
 		if (tid < F / p) {
 			const int i = tid / m, j = tid - i * m;
 			float2 *Fo = L.zbuf + i * (p * m) + j;
@@ -188,9 +196,9 @@ __device__ void cfft(Lds<F> &L, const float2 *src, bool inverse, const FftPlan &
 // time L.tbuf[2F] -> this lane's bin (scaled by 1/N like spx_fft / ms_fft).
 // bin 0 returns (DC, Nyquist).  Also leaves the interleaved spectrum in L.spec.
 template <int F>
-__device__ float2 rfft_forward(Lds<F> &L, const FftPlan &plan) {
+__device__ float2 rfft_forward(Lds<F> &L) {
 	const int tid = threadIdx.x;
-	cfft<F>(L, reinterpret_cast<const float2 *>(L.tbuf), false, plan);
+	cfft<F>(L, reinterpret_cast<const float2 *>(L.tbuf), false);
 	const float scale = 1.f / (2 * F);
 	if (tid == 0) {
 		const float2 t0 = L.zbuf[0];
@@ -218,7 +226,7 @@ __device__ float2 rfft_forward(Lds<F> &L, const FftPlan &plan) {
 
 // L.spec (interleaved spectrum, every lane has written its bin) -> time in L.tbuf, unscaled.
 template <int F>
-__device__ void rfft_inverse(Lds<F> &L, const FftPlan &plan) {
+__device__ void rfft_inverse(Lds<F> &L) {
 	const int tid = threadIdx.x;
 	float2 *tmp = reinterpret_cast<float2 *>(L.tbuf); // staging for the pre-processed bins
 	__syncthreads();
@@ -239,7 +247,7 @@ __device__ void rfft_inverse(Lds<F> &L, const FftPlan &plan) {
 		tmp[F - k] = c;
 	}
 	__syncthreads();
-	cfft<F>(L, tmp, true, plan);
+	cfft<F>(L, tmp, true);
 	// zbuf[n] = (t[2n], t[2n+1])
 	const float2 r = L.zbuf[tid];
 	L.tbuf[2 * tid] = r.x;
@@ -247,17 +255,49 @@ __device__ void rfft_inverse(Lds<F> &L, const FftPlan &plan) {
 	__syncthreads();
 }
 
-// mdf_inner_prod order: pairs, then a running sum.  One lane.
-__device__ __forceinline__ float inner_prod_serial(const float *x, const float *y, int len) {
-	float sum = 0;
-	for (int i = 0; i < len; i += 2) {
-		float part = 0;
-		part = part + x[i] * y[i];
-		part = part + x[i + 1] * y[i + 1];
-		sum = sum + part;
-	}
-	return sum;
+__device__ __forceinline__ float rdlane(float v, int l) {
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
+
+// Serial-order reductions executed by ONE wave: every lane owns K = F/64 consecutive
+// elements in registers, the products are formed lane-parallel (same values the
+// library's loop forms), and only the running sum walks the lanes in order via
+// v_readlane, so the dependent chain never waits on LDS.
+template <int F>
+struct WaveSeq {
+	static constexpr int K = F / 64;
+	// mdf_inner_prod: sum += (x0*y0 + x1*y1) over consecutive pairs
+	__device__ static float inner_prod(const float *x, const float *y, int lane) {
+		float part[K / 2];
+#pragma unroll
+		for (int k = 0; k < K; k += 2) {
+			float p = 0;
+			p = p + x[lane * K + k] * y[lane * K + k];
+			p = p + x[lane * K + k + 1] * y[lane * K + k + 1];
+			part[k / 2] = p;
+		}
+		float sum = 0;
+#pragma unroll
+		for (int l = 0; l < 64; ++l) {
+#pragma unroll
+			for (int k = 0; k < K / 2; ++k) sum = sum + rdlane(part[k], l);
+		}
+		return sum;
+	}
+	// acc = init; for j = F-1 .. 0: acc = acc + a[j]*b[j]   (descending)
+	__device__ static float dot_desc(float init, const float *a, const float *b, int lane) {
+		float p[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) p[k] = a[lane * K + k] * b[lane * K + k];
+		float acc = init;
+#pragma unroll
+		for (int l = 63; l >= 0; --l) {
+#pragma unroll
+			for (int k = K - 1; k >= 0; --k) acc = acc + rdlane(p[k], l);
+		}
+		return acc;
+	}
+};
 
 __device__ __forceinline__ int16_t word2int(float x) {
 	if (x < -32767.5f) return (int16_t)-32768;
@@ -267,10 +307,12 @@ __device__ __forceinline__ int16_t word2int(float x) {
 
 __device__ __forceinline__ float qcurve(float x) { return 1.f / (1.f + .15f / x); }
 
+__constant__ float kHypergeom[21] = {0.82157f, 1.02017f, 1.20461f, 1.37534f, 1.53363f, 1.68092f, 1.81865f,
+                                     1.94811f, 2.07038f, 2.18638f, 2.29688f, 2.40255f, 2.50391f, 2.60144f,
+                                     2.69551f, 2.78647f, 2.87458f, 2.96015f, 3.04333f, 3.12431f, 3.20326f};
+
 __device__ float hypergeom_gain(float xx) {
-	const float table[21] = {0.82157f, 1.02017f, 1.20461f, 1.37534f, 1.53363f, 1.68092f, 1.81865f,
-	                         1.94811f, 2.07038f, 2.18638f, 2.29688f, 2.40255f, 2.50391f, 2.60144f,
-	                         2.69551f, 2.78647f, 2.87458f, 2.96015f, 3.04333f, 3.12431f, 3.20326f};
+	const float *table = kHypergeom;
 	const float x = xx;
 	const float integer = (float)floor(2 * x);
 	const int ind = (int)integer;
@@ -281,13 +323,30 @@ __device__ float hypergeom_gain(float xx) {
 }
 
 // filterbank_compute_bank32 in the library's accumulation order: one lane per band.
+// pl/pr hold the per-bin products filter_left*ps / filter_right*ps (formed lane-parallel).
 template <int F>
-__device__ __forceinline__ float band_sum(const AecTables &t, int b, const float *ps) {
+__device__ __forceinline__ float band_sum(const AecTables &t, int b, const float *pl, const float *pr) {
 	float mel = 0;
 	const int r0 = t.brange[4 * b + 0], r1 = t.brange[4 * b + 1];
 	const int l0 = t.brange[4 * b + 2], l1 = t.brange[4 * b + 3];
-	for (int i = r0; i < r1; ++i) mel += t.bfr[i] * ps[i];
-	for (int i = l0; i < l1; ++i) mel += t.bfl[i] * ps[i];
+	int i = r0;
+	for (; i + 4 <= r1; i += 4) {
+		const float a0 = pr[i], a1 = pr[i + 1], a2 = pr[i + 2], a3 = pr[i + 3];
+		mel += a0;
+		mel += a1;
+		mel += a2;
+		mel += a3;
+	}
+	for (; i < r1; ++i) mel += pr[i];
+	i = l0;
+	for (; i + 4 <= l1; i += 4) {
+		const float a0 = pl[i], a1 = pl[i + 1], a2 = pl[i + 2], a3 = pl[i + 3];
+		mel += a0;
+		mel += a1;
+		mel += a2;
+		mel += a3;
+	}
+	for (; i < l1; ++i) mel += pl[i];
 	return mel;
 }
 
@@ -325,21 +384,36 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 
 	// ---------------------------------------------------------------- serial: DC notch (wave 0), Sxx (wave 1 or lane 1)
 	float Sxx = 0;
-	if (tid == 0) {
+	constexpr int K = F / 64;
+	if (wave == 0) {
+		// filter_dc_notch16: a 2-state IIR, inherently serial; samples come out of registers
 		const float radius = a.notch_radius;
 		const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
 		float m0 = sc.notch0, m1 = sc.notch1;
-		for (int i = 0; i < F; ++i) {
-			const float vin = L.fin[i];
-			const float vout = m0 + vin;
-			m0 = m1 + 2 * (-vin + radius * vout);
-			m1 = vin - den2 * vout;
-			L.v[i] = radius * vout;
+		float xin[K], yo[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) xin[k] = L.fin[lane * K + k];
+#pragma unroll
+		for (int l = 0; l < 64; ++l) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				const float vin = rdlane(xin[k], l);
+				const float vout = m0 + vin;
+				m0 = m1 + 2 * (-vin + radius * vout);
+				m1 = vin - den2 * vout;
+				const float y = radius * vout;
+				if (lane == l) yo[k] = y;
+			}
 		}
-		L.red[0] = m0;
-		L.red[1] = m1;
-	} else if (tid == F - 64) {
-		L.red[2] = inner_prod_serial(L.tbuf + F, L.tbuf + F, F);
+#pragma unroll
+		for (int k = 0; k < K; ++k) L.v[lane * K + k] = yo[k];
+		if (lane == 0) {
+			L.red[0] = m0;
+			L.red[1] = m1;
+		}
+	} else if (wave == 1) {
+		const float r = WaveSeq<F>::inner_prod(L.tbuf + F, L.tbuf + F, lane);
+		if (lane == 0) L.red[2] = r;
 	}
 	__syncthreads();
 	sc.notch0 = L.red[0];
@@ -353,7 +427,7 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 	sc.memX = (float)a.ref[(size_t)s * a.stride + F - 1];
 
 	// ---------------------------------------------------------------- X0 = FFT(x), into the ring
-	const float2 X0 = rfft_forward<F>(L, a.plan);
+	const float2 X0 = rfft_forward<F>(L);
 	const int head = (sc.xhead + M) % (M + 1); // the slot of the oldest block becomes the newest
 	sc.xhead = head;
 	Xs[(size_t)head * F + tid] = X0;
@@ -409,10 +483,10 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		if (do_grad) w = grad(w, Xs[xslot(jb + 1)], L.prop[jb]);
 		L.spec[2 * tid] = w.x;
 		L.spec[2 * tid + 1] = w.y;
-		rfft_inverse<F>(L, a.plan);
+		rfft_inverse<F>(L);
 		L.tbuf[F + tid] = 0.f;
 		__syncthreads();
-		w = rfft_forward<F>(L, a.plan);
+		w = rfft_forward<F>(L);
 		Ws[(size_t)jb * F + tid] = w;
 		if (pass == 0) wsp0 = w;
 		else wspc = w;
@@ -421,15 +495,24 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 	// ---------------------------------------------------------------- the one streaming pass over X, FG, W
 	float2 yfg = make_float2(0, 0), ybgs = make_float2(0, 0);
 	{
+		// software-pipelined: block j+1's three loads are in flight while block j is consumed
 		float2 xj = X0;
+		float2 xn = Xs[xslot(1)];
+		float2 fg = FGs[tid];
+		float2 wl = Ws[tid];
+		float nn_acc[64 / 4]; // weight norms, 4 blocks per register group (reduced after the loop)
 		for (int j = 0; j < M; ++j) {
-			const float2 xn = Xs[xslot(j + 1)];
-			const float2 fg = FGs[(size_t)j * F + tid];
+			float2 xn2 = xn, fg2 = fg, wl2 = wl;
+			if (j + 1 < M) {
+				xn2 = Xs[xslot(j + 2)];
+				fg2 = FGs[(size_t)(j + 1) * F + tid];
+				wl2 = Ws[(size_t)(j + 1) * F + tid];
+			}
 			float2 w;
 			if (j == 0) w = wsp0;
 			else if (j == jc) w = wspc;
 			else {
-				w = Ws[(size_t)j * F + tid];
+				w = wl;
 				if (do_grad) {
 					w = grad(w, xn, L.prop[j]);
 					Ws[(size_t)j * F + tid] = w;
@@ -447,30 +530,41 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 				ybgs.y += (xj.y * w.x + xj.x * w.y);
 			}
 			// per-block weight norm (tree reduction; only feeds the proportional step)
-			float nn = w.x * w.x + w.y * w.y;
-			for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
-			if (lane == 0) L.wn[j * 4 + wave] = nn;
+			if (!(a.flags & 0x100)) {
+				float nn = w.x * w.x + w.y * w.y;
+				for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
+				if (lane == 0) L.wn[j * 4 + wave] = nn;
+			}
 			xj = xn;
+			xn = xn2;
+			fg = fg2;
+			wl = wl2;
 		}
+		(void)nn_acc;
 	}
 
 	// ---------------------------------------------------------------- time-domain responses
 	L.spec[2 * tid] = yfg.x;
 	L.spec[2 * tid + 1] = yfg.y;
-	rfft_inverse<F>(L, a.plan);
+	rfft_inverse<F>(L);
 	L.efg[tid] = L.tbuf[F + tid];
 	L.e1[tid] = L.input[tid] - L.tbuf[F + tid]; // foreground error
 	__syncthreads();
 	L.spec[2 * tid] = ybgs.x;
 	L.spec[2 * tid + 1] = ybgs.y;
-	rfft_inverse<F>(L, a.plan);
+	rfft_inverse<F>(L);
 	L.ybg[tid] = L.tbuf[F + tid];
 	L.e2[tid] = L.input[tid] - L.tbuf[F + tid]; // background error
 	L.v[tid] = L.efg[tid] - L.tbuf[F + tid];    // difference of the two responses
 	__syncthreads();
-	if (tid < 3) {
-		const float *p = tid == 0 ? L.e1 : (tid == 1 ? L.v : L.e2);
-		L.red[tid] = inner_prod_serial(p, p, F);
+	if (wave < 3 && wave < F / 64) {
+		const float *p = wave == 0 ? L.e1 : (wave == 1 ? L.v : L.e2);
+		const float r = WaveSeq<F>::inner_prod(p, p, lane);
+		if (lane == 0) L.red[wave] = r;
+	}
+	if (F / 64 < 3 && wave == 0) { // 2-wave workgroups: wave 0 takes the third sum
+		const float r = WaveSeq<F>::inner_prod(L.e2, L.e2, lane);
+		if (lane == 0) L.red[2] = r;
 	}
 	__syncthreads();
 	const float Sff = L.red[0];
@@ -525,20 +619,41 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 	// ---------------------------------------------------------------- output (serial de-emphasis) + correlations
 	L.v[tid] = L.input[tid] - L.efg[tid];
 	__syncthreads();
-	if (tid == 0) {
+	if (wave == 0) {
 		float memE = sc.memE;
-		for (int i = 0; i < F; ++i) {
-			float t = L.v[i];
-			t = t + .9f * memE;
-			L.tbuf[i] = t; // tmp_out
-			memE = t;
+		float xin[K], yo[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) xin[k] = L.v[lane * K + k];
+#pragma unroll
+		for (int l = 0; l < 64; ++l) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				float t = rdlane(xin[k], l);
+				t = t + .9f * memE;
+				memE = t;
+				if (lane == l) yo[k] = t;
+			}
 		}
-		L.red[3] = memE;
-	} else if (tid >= F - 64 && tid < F - 64 + 3) {
-		const int q = tid - (F - 64);
-		const float *x = q == 0 ? L.e2 : (q == 1 ? L.ybg : L.input);
-		const float *y = q == 0 ? L.ybg : (q == 1 ? L.ybg : L.input);
-		L.red[q] = inner_prod_serial(x, y, F);
+#pragma unroll
+		for (int k = 0; k < K; ++k) L.tbuf[lane * K + k] = yo[k]; // tmp_out
+		if (lane == 0) L.red[3] = memE;
+		if (F / 64 < 3) { // 2-wave workgroups: Sdd here
+			const float r = WaveSeq<F>::inner_prod(L.input, L.input, lane);
+			if (lane == 0) L.red[2] = r;
+		}
+	} else if (wave == 1) {
+		const float r = WaveSeq<F>::inner_prod(L.e2, L.ybg, lane);
+		if (lane == 0) L.red[0] = r;
+		if (F / 64 < 3) {
+			const float r2 = WaveSeq<F>::inner_prod(L.ybg, L.ybg, lane);
+			if (lane == 0) L.red[1] = r2;
+		}
+	} else if (wave == 2) {
+		const float r = WaveSeq<F>::inner_prod(L.ybg, L.ybg, lane);
+		if (lane == 0) L.red[1] = r;
+	} else if (wave == 3) {
+		const float r = WaveSeq<F>::inner_prod(L.input, L.input, lane);
+		if (lane == 0) L.red[2] = r;
 	}
 	__syncthreads();
 	sc.memE = L.red[3];
@@ -551,12 +666,12 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 	L.tbuf[tid] = 0.f;
 	L.tbuf[F + tid] = L.e2[tid];
 	__syncthreads();
-	const float2 Ecur = rfft_forward<F>(L, a.plan);
+	const float2 Ecur = rfft_forward<F>(L);
 	__syncthreads();
 	L.tbuf[tid] = 0.f;
 	L.tbuf[F + tid] = L.ybg[tid];
 	__syncthreads();
-	const float2 Ycur = rfft_forward<F>(L, a.plan);
+	const float2 Ycur = rfft_forward<F>(L);
 	reinterpret_cast<float2 *>(sm + SL::E)[tid] = Ecur;
 	float Rf_k, Yf_k, Xf_k, Rf_F = 0, Yf_F = 0, Xf_F = 0;
 	if (tid == 0) {
@@ -648,16 +763,13 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		}
 	}
 	__syncthreads();
-	if (tid < 2) {
+	if (wave < 2) {
 		// j = F down to 0, starting from FLOAT_ONE
-		float acc = 1.0f;
 		const float eF = L.red[8], yF = L.red[9];
-		acc = acc + (tid == 0 ? eF * yF : yF * yF);
-		for (int j = F - 1; j >= 0; --j) {
-			const float Eh = L.e1[j], Yh = L.e2[j];
-			acc = acc + (tid == 0 ? Eh * Yh : Yh * Yh);
-		}
-		L.red[tid] = acc;
+		float acc = 1.0f;
+		acc = acc + (wave == 0 ? eF * yF : yF * yF);
+		acc = WaveSeq<F>::dot_desc(acc, wave == 0 ? L.e1 : L.e2, L.e2, lane);
+		if (lane == 0) L.red[wave] = acc;
 	}
 	__syncthreads();
 	float Pey = L.red[0], Pyy = L.red[1];
@@ -721,7 +833,7 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		L.tbuf[tid] = a.t.hann[tid] * ly_old;
 		L.tbuf[F + tid] = a.t.hann[F + tid] * ly_new;
 		__syncthreads();
-		const float2 Yr = rfft_forward<F>(L, a.plan);
+		const float2 Yr = rfft_forward<F>(L);
 		float res = (tid == 0) ? Yr.x * Yr.x : Yr.x * Yr.x + Yr.y * Yr.y;
 		const float leak2 = (sc.leak_estimate > .5) ? 1.f : 2 * sc.leak_estimate;
 		res = (float)(int32_t)(leak2 * res);
@@ -734,7 +846,10 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		}
 		sm[SL::ECHON + tid] = en;
 		float *vec = L.e1; // per-bin exchange vector
-		vec[tid] = en;
+		float *pl = L.spec, *pr = L.spec + F; // per-bin filterbank products
+		const float wl = a.t.bfl[tid], wr = a.t.bfr[tid];
+		pl[tid] = wl * en;
+		pr[tid] = wr * en;
 		// analysis frame: [inbuf, x] * window
 		const float inb = sm[SL::INBUF + tid];
 		const float xcur = (float)out_i;
@@ -743,14 +858,16 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		L.tbuf[F + tid] = xcur * a.t.pwin[F + tid];
 		__syncthreads();
 		float *bandv = L.band; // [0..24) echo_noise bands, [24..48) ps bands, [48..72) noise bands, [72..96) misc
-		if (tid < NB_BANDS) bandv[tid] = band_sum<F>(a.t, tid, vec);
+		if (tid < NB_BANDS) bandv[tid] = band_sum<F>(a.t, tid, pl, pr);
 		__syncthreads();
-		float2 ft = rfft_forward<F>(L, a.plan);
+		float2 ft = rfft_forward<F>(L);
 		const float ps = (tid == 0) ? ft.x * ft.x : ft.x * ft.x + ft.y * ft.y;
 		__syncthreads();
 		vec[tid] = ps;
+		pl[tid] = wl * ps;
+		pr[tid] = wr * ps;
 		__syncthreads();
-		if (tid < NB_BANDS) bandv[NB_BANDS + tid] = band_sum<F>(a.t, tid, vec);
+		if (tid < NB_BANDS) bandv[NB_BANDS + tid] = band_sum<F>(a.t, tid, pl, pr);
 		// update_noise_prob
 		float S = sm[SL::S_ + tid], Smin = sm[SL::SMIN + tid], Stmp = sm[SL::STMP + tid];
 		if (tid == 0 || tid == F - 1) S = .8f * S + .2f * ps;
@@ -779,9 +896,10 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		}
 		sm[SL::NOISE + tid] = noise;
 		__syncthreads();
-		vec[tid] = noise;
+		pl[tid] = wl * noise;
+		pr[tid] = wr * noise;
 		__syncthreads();
-		if (tid < NB_BANDS) bandv[2 * NB_BANDS + tid] = band_sum<F>(a.t, tid, vec);
+		if (tid < NB_BANDS) bandv[2 * NB_BANDS + tid] = band_sum<F>(a.t, tid, pl, pr);
 		__syncthreads();
 		if (sc.min_count > min_range) sc.min_count = 0;
 
@@ -852,7 +970,6 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		__syncthreads();
 		// filterbank_compute_psd16: back to linear frequency
 		const int bl = a.t.bleft[tid], br = bl + 1;
-		const float wl = a.t.bfl[tid], wr = a.t.bfr[tid];
 		auto psd = [&](const float *mel) -> float {
 			float t = mel[bl] * wl;
 			t += mel[br] * wr;
@@ -889,7 +1006,7 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 		}
 		L.spec[2 * tid] = ft.x;
 		L.spec[2 * tid + 1] = ft.y;
-		rfft_inverse<F>(L, a.plan);
+		rfft_inverse<F>(L);
 		const float f_lo = L.tbuf[tid] * a.t.pwin[tid];
 		const float f_hi = L.tbuf[F + tid] * a.t.pwin[F + tid];
 		const float ob = sm[SL::OUTBUF + tid];
@@ -903,7 +1020,7 @@ __global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
 
 // ---- debug: forward/inverse transform of one 2F-point frame per block (parity of the FFT itself)
 template <int F>
-__global__ __launch_bounds__(F) void fft_debug_kernel(const float *in, float *out, int inverse, AecTables t, FftPlan plan) {
+__global__ __launch_bounds__(F) void fft_debug_kernel(const float *in, float *out, int inverse, AecTables t) {
 	__shared__ Lds<F> L;
 	const int tid = threadIdx.x;
 	L.tw[tid] = t.tw[tid];
@@ -915,13 +1032,13 @@ __global__ __launch_bounds__(F) void fft_debug_kernel(const float *in, float *ou
 		L.tbuf[tid] = src[tid];
 		L.tbuf[F + tid] = src[F + tid];
 		__syncthreads();
-		const float2 r = rfft_forward<F>(L, plan);
+		const float2 r = rfft_forward<F>(L);
 		dst[2 * tid] = r.x;
 		dst[2 * tid + 1] = r.y;
 	} else {
 		L.spec[2 * tid] = src[2 * tid];
 		L.spec[2 * tid + 1] = src[2 * tid + 1];
-		rfft_inverse<F>(L, plan);
+		rfft_inverse<F>(L);
 		dst[tid] = L.tbuf[tid];
 		dst[F + tid] = L.tbuf[F + tid];
 	}
@@ -1001,6 +1118,13 @@ int build_tables(mi_aec *a) {
 		a->plan.m[s] = rest[(size_t)L];
 		a->plan.fs[s] = stride[(size_t)L];
 	}
+	// the kernels carry this plan as compile-time constants; make sure both agree
+	if (a->plan.nstages != 4) return MI_ENOTSUP;
+	for (int s = 0; s < 4; ++s)
+		if (a->plan.p[s] != plan_p(F, s) || a->plan.m[s] != plan_m(F, s) || a->plan.fs[s] != plan_fs(F, s)) {
+			mi::set_error("FFT plan mismatch for F=%d stage %d", F, s);
+			return MI_ENOTSUP;
+		}
 	std::vector<uint16_t> perm((size_t)F);
 	for (int o = 0; o < F; ++o) {
 		int rem = o, src = 0;
@@ -1244,7 +1368,6 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	g.ss_1 = a->ss_1;
 	g.sampling_rate = a->rate;
 	g.t = a->t;
-	g.plan = a->plan;
 	if (a->F == 256) hipLaunchKernelGGL(aec_kernel<256>, dim3(a->nstreams), dim3(256), 0, a->ctx->stream, g);
 	else hipLaunchKernelGGL(aec_kernel<128>, dim3(a->nstreams), dim3(128), 0, a->ctx->stream, g);
 	MI_LAUNCH_CHECK();
@@ -1338,11 +1461,9 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int inverse) {
 	MI_CHECK_ARG(a && d_in && d_out && nframes > 0);
 	if (a->F == 256)
-		hipLaunchKernelGGL(fft_debug_kernel<256>, dim3(nframes), dim3(256), 0, a->ctx->stream, d_in, d_out, inverse, a->t,
-		                   a->plan);
+		hipLaunchKernelGGL(fft_debug_kernel<256>, dim3(nframes), dim3(256), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	else
-		hipLaunchKernelGGL(fft_debug_kernel<128>, dim3(nframes), dim3(128), 0, a->ctx->stream, d_in, d_out, inverse, a->t,
-		                   a->plan);
+		hipLaunchKernelGGL(fft_debug_kernel<128>, dim3(nframes), dim3(128), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
