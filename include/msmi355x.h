@@ -117,6 +117,10 @@ int mi_resampler_process(mi_resampler *r, const int16_t *d_in, int in_len, int i
                          int out_stride, int32_t *d_out_len);
 int mi_resampler_process_host(mi_resampler *r, const int16_t *h_in, int in_len, int in_stride,
                               int16_t *h_out, int out_stride, int32_t *h_out_len);
+/* same, but only streams with d_run[s] != 0 consume a block this tick (idle streams keep
+ * their state and their output row is left untouched); d_run == NULL runs every stream */
+int mi_resampler_process_masked(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out,
+                                int out_stride, int32_t *d_out_len, const uint8_t *d_run);
 
 /* --------------------------------------------------------------- mixer */
 /* `nconf` MSAudioMixer instances with up to `max_members` (<= 50,
@@ -141,6 +145,11 @@ int mi_mixer_process(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data
                      int16_t *d_out);
 int mi_mixer_process_host(mi_mixer *m, const int16_t *h_in, const uint8_t *h_has_data, int conf_mode,
                           int16_t *h_out);
+/* d_run [nconf]: conferences with 0 are skipped this tick (bypass mode / nothing to mix,
+ * audiomixer.c:244-286); d_conf_mode [nconf] per-conference mode, NULL -> `conf_mode` for all.
+ * d_out is always [nconf][max_members][nsamples]; a non-conference mixer writes row 0. */
+int mi_mixer_process_masked(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data, int conf_mode,
+                            const uint8_t *d_conf_mode, int16_t *d_out, const uint8_t *d_run);
 /* Split form for a conference whose members live on several GPUs:
  * partial int32 sums of the LOCAL members, an int32 all-reduce by the caller
  * (RCCL), then the local outputs from the global sum. */
@@ -199,6 +208,9 @@ int mi_equalizer_set_taps(mi_equalizer *e, int stream, const float *h_taps, int 
 /* in place; designs + uploads stale taps first (equalizer.c:265) */
 int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride);
 int mi_equalizer_process_host(mi_equalizer *e, int16_t *h_samples, int nsamples, int stride);
+/* d_nsamples [nstreams]: per-stream block length this tick (0 = idle), NULL -> nsamples for all */
+int mi_equalizer_process_masked(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride,
+                                const int32_t *d_nsamples);
 
 /* ----------------------------------------------------------------- AEC */
 typedef struct mi_aec mi_aec;

@@ -29,6 +29,7 @@ EXPORTS = [
     "mi_timer_start", "mi_timer_stop",
     "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_out_capacity",
     "mi_resampler_info", "mi_resampler_get_table", "mi_resampler_process", "mi_resampler_process_host",
+    "mi_resampler_process_masked", "mi_mixer_process_masked", "mi_equalizer_process_masked",
     "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
@@ -124,6 +125,9 @@ def load():
     L.mi_resampler_get_table.argtypes = [vp, vp, i32]
     L.mi_resampler_process.argtypes = [vp, vp, i32, i32, vp, i32, vp]
     L.mi_resampler_process_host.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    L.mi_resampler_process_masked.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+    L.mi_mixer_process_masked.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.mi_equalizer_process_masked.argtypes = [vp, vp, i32, i32, vp]
 
     L.mi_mixer_create.argtypes = [vp, i32, i32, i32, pp]
     L.mi_mixer_destroy.argtypes = [vp]

@@ -29,6 +29,7 @@ struct EqArgs {
 	int16_t *hist;      // [nstreams][ord] int16 (ord-1 used)
 	const float *taps;  // [nstreams][ord]
 	const uint8_t *active;
+	const int32_t *nper; // per-stream block length or null
 	int nstreams, nsamples, stride, ord;
 };
 
@@ -38,17 +39,19 @@ __global__ __launch_bounds__(EQ_THREADS) void equalizer_kernel(EqArgs a) {
 	float *buf = reinterpret_cast<float *>(smem); // [ORD-1 + nsamples + EQ_R]
 	const int s = blockIdx.x;
 	if (!a.active[s]) return;
+	const int nsamples = a.nper ? min(max(a.nper[s], 0), a.nsamples) : a.nsamples;
+	if (nsamples == 0) return;
 	const int tid = threadIdx.x;
 	int16_t *xs = a.samples + (size_t)s * a.stride;
 	int16_t *hs = a.hist + (size_t)s * ORD;
 	const float *__restrict__ h = a.taps + (size_t)s * ORD;
 
 	for (int i = tid; i < ORD - 1; i += EQ_THREADS) buf[i] = (float)hs[i];
-	for (int i = tid; i < a.nsamples; i += EQ_THREADS) buf[ORD - 1 + i] = (float)xs[i];
-	for (int i = tid; i < EQ_R; i += EQ_THREADS) buf[ORD - 1 + a.nsamples + i] = 0.f;
+	for (int i = tid; i < nsamples; i += EQ_THREADS) buf[ORD - 1 + i] = (float)xs[i];
+	for (int i = tid; i < EQ_R; i += EQ_THREADS) buf[ORD - 1 + nsamples + i] = 0.f;
 	__syncthreads();
 
-	for (int n0 = tid * EQ_R; n0 < a.nsamples; n0 += EQ_THREADS * EQ_R) {
+	for (int n0 = tid * EQ_R; n0 < nsamples; n0 += EQ_THREADS * EQ_R) {
 		float w[EQ_R], acc[EQ_R];
 #pragma unroll
 		for (int r = 0; r < EQ_R; ++r) acc[r] = 0.f;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(EQ_THREADS) void equalizer_kernel(EqArgs a) {
 		}
 #pragma unroll
 		for (int r = 0; r < EQ_R; ++r) {
-			if (n0 + r < a.nsamples) {
+			if (n0 + r < nsamples) {
 				const float v = acc[r];
 				// (int16_t)float of the reference is UB out of range (equalizer.c:251-255); saturate
 				const int q = v >= 32767.f ? 32767 : (v <= -32768.f ? -32768 : (int)v);
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(EQ_THREADS) void equalizer_kernel(EqArgs a) {
 		}
 	}
 	// new delay line: the last ORD-1 inputs
-	for (int i = tid; i < ORD - 1; i += EQ_THREADS) hs[i] = (int16_t)buf[a.nsamples + i];
+	for (int i = tid; i < ORD - 1; i += EQ_THREADS) hs[i] = (int16_t)buf[nsamples + i];
 }
 
 struct HostEq { // EqualizerState equalizer.c:37-46 (design-side fields)
@@ -305,6 +308,11 @@ int mi_equalizer_set_taps(mi_equalizer *e, int stream, const float *h_taps, int 
 }
 
 int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride) {
+	return mi_equalizer_process_masked(e, d_samples, nsamples, stride, nullptr);
+}
+
+int mi_equalizer_process_masked(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride,
+                                const int32_t *d_nsamples) {
 	MI_CHECK_ARG(e && d_samples && nsamples > 0 && stride >= nsamples);
 	if (nsamples > 8192) {
 		mi::set_error("block of %d samples exceeds the equalizer kernel's LDS staging (max 8192)", nsamples);
@@ -319,6 +327,7 @@ int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int 
 	a.hist = e->d_hist;
 	a.taps = e->d_taps;
 	a.active = e->d_active;
+	a.nper = d_nsamples;
 	a.nstreams = e->nstreams;
 	a.nsamples = nsamples;
 	a.stride = stride;

@@ -31,7 +31,9 @@ struct MixArgs {
 	int16_t *out;
 	int32_t *sum_out;      // partial mode
 	const int32_t *sum_in; // finalize mode
-	int nconf, mm, ns, quads, conf_mode;
+	const uint8_t *run;       // [nconf] or null
+	const uint8_t *conf_modes; // [nconf] or null
+	int nconf, mm, ns, quads, conf_mode, out_conf_stride;
 };
 
 __device__ __forceinline__ int4 widen(const short4 v) { return make_int4(v.x, v.y, v.z, v.w); }
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(256) void mixer_kernel(MixArgs a) {
 	if (g >= (long long)a.nconf * a.quads) return;
 	const int c = (int)(g / a.quads);
 	const int q = (int)(g - (long long)c * a.quads);
+	if (a.run && !a.run[c]) return;
+	const int conf_mode = a.conf_modes ? a.conf_modes[c] : a.conf_mode;
 	const uint8_t *fl = a.flags + (size_t)c * a.mm;
 
 	int4 sum = make_int4(0, 0, 0, 0);
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(256) void mixer_kernel(MixArgs a) {
 		*reinterpret_cast<int4 *>(a.sum_out + (size_t)c * a.ns + 4 * q) = sum;
 		return;
 	}
-	if (a.conf_mode == 0) {
-		store_sat(a.out + (size_t)c * a.ns + 4 * q, sum);
+	if (conf_mode == 0) {
+		store_sat(a.out + (size_t)c * a.out_conf_stride + 4 * q, sum);
 		return;
 	}
 	if (MODE == 2) {
@@ -160,6 +164,9 @@ static void fill_args(mi_mixer *m, MixArgs &a, const int16_t *d_in, const uint8_
 	a.out = nullptr;
 	a.sum_out = nullptr;
 	a.sum_in = nullptr;
+	a.run = nullptr;
+	a.conf_modes = nullptr;
+	a.out_conf_stride = m->ns;
 	a.nconf = m->nconf;
 	a.mm = m->mm;
 	a.ns = m->ns;
@@ -227,6 +234,19 @@ int mi_mixer_process(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data
 	MixArgs a;
 	fill_args(m, a, d_in, d_has_data, conf_mode);
 	a.out = d_out;
+	return launch_mixer<0>(m, a);
+}
+
+int mi_mixer_process_masked(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data, int conf_mode,
+                            const uint8_t *d_conf_mode, int16_t *d_out, const uint8_t *d_run) {
+	MI_CHECK_ARG(m && d_in && d_out);
+	if (m->ctx->activate() != MI_OK) return MI_ENODEV;
+	MixArgs a;
+	fill_args(m, a, d_in, d_has_data, conf_mode);
+	a.out = d_out;
+	a.run = d_run;
+	a.conf_modes = d_conf_mode;
+	a.out_conf_stride = m->mm * m->ns; // one full [members][nsamples] slab per conference
 	return launch_mixer<0>(m, a);
 }
 

@@ -131,6 +131,7 @@ struct UpArgs {
 	int32_t *out_len;
 	int16_t *hist;
 	const float *table;
+	const uint8_t *run;
 	int in_len, in_stride, out_stride, hist_stride, nstreams;
 	int tiles; // ceil(in_len / R)
 	int spb;   // streams per block
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void resample_up_kernel(UpArgs a) {
 	const int s0 = blockIdx.x * a.spb;
 	const int nloc = min(a.spb, a.nstreams - s0);
 	constexpr int HIST = FILT - 1;
+	auto live = [&](int sl) -> bool { return a.run == nullptr || a.run[s0 + sl] != 0; };
 
 	// ---- stage history + input as float (coalesced 8-byte loads)
 	{
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void resample_up_kernel(UpArgs a) {
 	// ---- compute: lane = (stream, tile, phase)
 	const int lps = DEN * a.tiles;
 	const int sl = tid / lps;
-	if (sl < nloc) {
+	if (sl < nloc && live(sl)) {
 		const int rem = tid - sl * lps;
 		const int tile = rem / DEN, p = rem - tile * DEN;
 		const int m0 = tile * R;
@@ -231,22 +233,25 @@ __global__ __launch_bounds__(256) void resample_up_kernel(UpArgs a) {
 		const int oq = out_per_stream >> 3;
 		for (int i = tid; i < nloc * oq; i += 256) {
 			const int s = i / oq, q = i - s * oq;
+			if (!live(s)) continue;
 			const uint4 v = *reinterpret_cast<const uint4 *>(obuf + s * ostage_stride + 8 * q);
 			*reinterpret_cast<uint4 *>(a.out + (size_t)(s0 + s) * a.out_stride + 8 * q) = v;
 		}
 	} else {
 		for (int i = tid; i < nloc * out_per_stream; i += 256) {
 			const int s = i / out_per_stream, q = i - s * out_per_stream;
+			if (!live(s)) continue;
 			a.out[(size_t)(s0 + s) * a.out_stride + q] = obuf[s * ostage_stride + q];
 		}
 	}
 	// ---- new history = last FILT-1 samples of (history ++ input)
 	for (int i = tid; i < nloc * HIST; i += 256) {
 		const int s = i / HIST, h = i - s * HIST;
+		if (!live(s)) continue;
 		a.hist[(size_t)(s0 + s) * a.hist_stride + h] = (int16_t)xbuf[s * a.xs + skew(a.in_len + h)];
 	}
 	if (a.out_len)
-		for (int i = tid; i < nloc; i += 256) a.out_len[s0 + i] = out_per_stream;
+		for (int i = tid; i < nloc; i += 256) a.out_len[s0 + i] = live(i) ? out_per_stream : 0;
 }
 
 struct GenArgs {
@@ -256,6 +261,7 @@ struct GenArgs {
 	int16_t *hist;
 	int2 *pos;
 	const float *table;
+	const uint8_t *run;
 	int table_len, table_in_lds;
 	int in_len, in_stride, out_stride, out_cap, hist_stride, nstreams;
 	int filt_len, num, den, oversample, direct;
@@ -269,6 +275,10 @@ __global__ __launch_bounds__(256) void resample_generic_kernel(GenArgs a) {
 	float *tl = x + ((xlen + 3) & ~3);
 	const int s = blockIdx.x;
 	const int tid = threadIdx.x;
+	if (a.run && !a.run[s]) {
+		if (tid == 0 && a.out_len) a.out_len[s] = 0;
+		return;
+	}
 	const int16_t *hin = a.hist + (size_t)s * a.hist_stride;
 	for (int i = tid; i < N - 1; i += 256) x[i] = (float)hin[i];
 	const int16_t *sin_ = a.in + (size_t)s * a.in_stride;
@@ -353,7 +363,7 @@ struct mi_resampler {
 
 template <int DEN, int FILT, int R>
 static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out,
-                     int out_stride, int32_t *d_out_len, bool *done) {
+                     int out_stride, int32_t *d_out_len, const uint8_t *d_run, bool *done) {
 	*done = false;
 	const int tiles = mi::ceil_div(in_len, R);
 	const int lps = DEN * tiles;
@@ -371,6 +381,7 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
 	a.out_len = d_out_len;
 	a.hist = r->d_hist;
 	a.table = r->d_table;
+	a.run = d_run;
 	a.in_len = in_len;
 	a.in_stride = in_stride;
 	a.out_stride = out_stride;
@@ -477,6 +488,11 @@ int mi_resampler_get_table(const mi_resampler *r, float *h_dst, int cap) {
 
 int mi_resampler_process(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out,
                          int out_stride, int32_t *d_out_len) {
+	return mi_resampler_process_masked(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, nullptr);
+}
+
+int mi_resampler_process_masked(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out,
+                                int out_stride, int32_t *d_out_len, const uint8_t *d_run) {
 	MI_CHECK_ARG(r && d_in && d_out && in_len > 0 && in_stride >= in_len);
 	const int cap = mi_resampler_out_capacity(r, in_len);
 	// the reference allocates cap samples (msresample.c:154); integer up-sampling
@@ -489,10 +505,10 @@ int mi_resampler_process(mi_resampler *r, const int16_t *d_in, int in_len, int i
 		bool done = false;
 		int rc = MI_OK;
 		switch (r->d.den) {
-			case 2: rc = launch_up<2, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, &done); break;
-			case 3: rc = launch_up<3, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, &done); break;
-			case 4: rc = launch_up<4, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, &done); break;
-			case 6: rc = launch_up<6, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, &done); break;
+			case 2: rc = launch_up<2, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			case 3: rc = launch_up<3, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			case 4: rc = launch_up<4, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			case 6: rc = launch_up<6, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
 			default: break;
 		}
 		if (rc != MI_OK) return rc;
@@ -506,6 +522,7 @@ int mi_resampler_process(mi_resampler *r, const int16_t *d_in, int in_len, int i
 	a.hist = r->d_hist;
 	a.pos = r->d_pos;
 	a.table = r->d_table;
+	a.run = d_run;
 	a.table_len = (int)r->d.table.size();
 	a.in_len = in_len;
 	a.in_stride = in_stride;

@@ -1,0 +1,1614 @@
+// filters.cpp -- the MI355X filter plugin: MSFilterDesc facades registered under the
+// reference's MS_*_ID so that ms_factory_create_filter(f, MS_RESAMPLE_ID) etc. hand out
+// these instead of the CPU filters (registration prepends, lookup is first-match:
+// src/base/msfactory.c:281,:440-450; plugins load after the built-ins: src/voip/msvoip.c:369-374).
+//
+// What stays on the host, exactly as in the reference: queues, bufferizers and the
+// per-stream framing state machines (mixer bypass/flow control, EC zero injection,
+// volume re-framing), method tables, locking.  What moves to the GPU: the sample
+// loops, through the C ABI of include/msmi355x.h.
+//
+// Batching: the reference runs one process() per filter per tick (src/base/msticker.c:244-259).
+// Here process() STAGES its 10 ms block into a slot of a per-type pool and emits the result
+// of the PREVIOUS tick; one postponed ticker task (src/base/msfilter.c:289-300, run before the
+// graphs of the next tick, msticker.c:301-312) launches every staged pool: one kernel per
+// filter type for all streams.  Cost: one tick (10 ms) of added latency per GPU filter; this
+// is the only scheduling-compatible option without touching the ticker.
+#include "../../include/ms2_plugin_abi.h"
+#include "../../include/msmi355x.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxRounds = 4; // blocks one stream may hand over within a single tick
+
+[[noreturn]] void die(const char *what) {
+	ms_error("msmi355x plugin: %s: %s", what, mi_last_error());
+	fprintf(stderr, "msmi355x plugin: %s: %s (there is no CPU fallback)\n", what, mi_last_error());
+	abort();
+}
+#define MI_MUST(expr)                     \
+	do {                                  \
+		if ((expr) != MI_OK) die(#expr);  \
+	} while (0)
+
+struct Pool {
+	virtual ~Pool() {}
+	virtual void flush() = 0;               // launch the staged blocks, fetch the results
+	virtual void emit(MSFilter *f, int slot) = 0; // hand a slot's results to its filter's output queues
+	std::vector<uint8_t> used;
+	std::vector<MSFilter *> owner;
+	MSTicker *ticker = nullptr; // a pool serves the filters of ONE ticker thread
+	int capacity = 0;
+	void init_slots(int cap) {
+		capacity = cap;
+		used.assign((size_t)cap, 0);
+		owner.assign((size_t)cap, nullptr);
+	}
+	int acquire(MSFilter *f) {
+		for (int i = 0; i < capacity; ++i)
+			if (!used[(size_t)i]) {
+				used[(size_t)i] = 1;
+				owner[(size_t)i] = f;
+				return i;
+			}
+		ms_error("msmi355x plugin: pool exhausted (%d slots; raise MSMI355X_SLOTS)", capacity);
+		return -1;
+	}
+	void release(int slot) {
+		used[(size_t)slot] = 0;
+		owner[(size_t)slot] = nullptr;
+	}
+	void emit_all() {
+		for (int i = 0; i < capacity; ++i)
+			if (used[(size_t)i] && owner[(size_t)i]) emit(owner[(size_t)i], i);
+	}
+};
+
+struct Hub {
+	std::recursive_mutex mu;
+	mi_ctx *ctx = nullptr;
+	int capacity = 256;
+	std::map<MSTicker *, bool> flush_pending;
+	std::vector<Pool *> pools;
+	mi_ctx *context() {
+		if (!ctx) {
+			const char *cap = getenv("MSMI355X_SLOTS");
+			if (cap && atoi(cap) > 0) capacity = atoi(cap);
+			const char *dev = getenv("MSMI355X_DEVICE");
+			if (mi_ctx_create(dev ? atoi(dev) : 0, nullptr, &ctx) != MI_OK) die("mi_ctx_create");
+		}
+		return ctx;
+	}
+};
+Hub g_hub;
+
+template <typename T>
+T *pinned(size_t n) {
+	void *p = mi_host_alloc(g_hub.context(), n * sizeof(T));
+	if (!p) die("mi_host_alloc");
+	memset(p, 0, n * sizeof(T));
+	return (T *)p;
+}
+template <typename T>
+T *devmem(size_t n) {
+	void *p = mi_dev_alloc(g_hub.context(), n * sizeof(T));
+	if (!p) die("mi_dev_alloc");
+	return (T *)p;
+}
+
+void flush_ticker(MSTicker *t) {
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (t == nullptr) g_hub.flush_pending.clear(); // the requesting filter was detached meanwhile: flush everything
+	else g_hub.flush_pending[t] = false;
+	for (Pool *p : g_hub.pools)
+		if (t == nullptr || p->ticker == t) {
+			p->flush();
+			p->emit_all();
+		}
+}
+
+// Runs on the ticker thread at the start of the next tick, before any process() (msticker.c:301-312):
+// one launch per staged pool, then the results go straight into the owners' output queues, so the
+// downstream filters see them in this tick's graph run even if the owner itself gets no new input.
+void flush_task(MSFilter *f) { flush_ticker(f->ticker); }
+
+// called by a filter that staged work this tick
+void request_flush(MSFilter *f) {
+	if (!g_hub.flush_pending[f->ticker]) {
+		g_hub.flush_pending[f->ticker] = true;
+		ms_filter_postpone_task(f, flush_task);
+	}
+}
+
+// =================================================================== resampler
+struct ResamplePool : Pool {
+	uint32_t in_rate, out_rate;
+	int in_len, ostride;
+	mi_resampler *r = nullptr;
+	int16_t *h_in, *h_out, *d_in, *d_out;
+	int32_t *h_olen, *d_olen;
+	uint8_t *h_run, *d_run;
+	std::vector<int> staged, ready;
+	ResamplePool(uint32_t ir, uint32_t orate) : in_rate(ir), out_rate(orate) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_resampler_create(g_hub.context(), capacity, ir, orate, 3 /* SPEEX_RESAMPLER_QUALITY_VOIP */, &r));
+		in_len = (int)(ir / 100);
+		ostride = (mi_resampler_out_capacity(r, in_len) + 7) & ~7;
+		const size_t c = (size_t)capacity;
+		h_in = pinned<int16_t>(kMaxRounds * c * in_len);
+		h_out = pinned<int16_t>(kMaxRounds * c * ostride);
+		h_olen = pinned<int32_t>(kMaxRounds * c);
+		h_run = pinned<uint8_t>(kMaxRounds * c);
+		d_in = devmem<int16_t>(c * in_len);
+		d_out = devmem<int16_t>(c * ostride);
+		d_olen = devmem<int32_t>(c);
+		d_run = devmem<uint8_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r_ = 0; r_ < maxr; ++r_) {
+			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = staged[(size_t)s] > r_;
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in + r_ * c * in_len, c * in_len * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r_ * c, c));
+			MI_MUST(mi_resampler_process_masked(r, d_in, in_len, in_len, d_out, ostride, d_olen, d_run));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r_ * c * ostride, d_out, c * ostride * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_olen + r_ * c, d_olen, c * 4));
+		}
+		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override;
+};
+std::map<std::tuple<MSTicker *, uint32_t, uint32_t>, ResamplePool *> g_resample_pools;
+
+struct ResampleData { // ResampleData msresample.c:33-42
+	MSBufferizer *bz;
+	uint32_t ts;
+	uint32_t input_rate, output_rate;
+	int in_nchannels, out_nchannels;
+	ResamplePool *pool;
+	int slot;
+};
+
+void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
+	ResampleData *d = (ResampleData *)ms_malloc0(sizeof(*d));
+	d->bz = ms_bufferizer_new();
+	d->input_rate = 8000;
+	d->output_rate = 16000;
+	d->in_nchannels = d->out_nchannels = 1;
+	d->slot = -1;
+	f->data = d;
+}
+
+void resample_release(ResampleData *d) {
+	if (d->pool && d->slot >= 0) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		d->pool->release(d->slot);
+		d->pool->staged[(size_t)d->slot] = d->pool->ready[(size_t)d->slot] = 0;
+		MI_MUST(mi_resampler_reset(d->pool->r, d->slot, 1));
+	}
+	d->pool = nullptr;
+	d->slot = -1;
+}
+
+void resample_uninit(MSFilter *f) {
+	ResampleData *d = (ResampleData *)f->data;
+	resample_release(d);
+	ms_bufferizer_destroy(d->bz);
+	ms_free(d);
+}
+
+// msresample.c:87-100: first input channel copied to every output channel
+mblk_t *channel_adapt(int in_nch, int out_nch, mblk_t *im) {
+	if (out_nch == in_nch) return im;
+	const size_t n = msgdsize(im) / (2 * (size_t)in_nch);
+	mblk_t *om = allocb(n * 2 * (size_t)out_nch, 0);
+	const int16_t *s = (const int16_t *)im->b_rptr;
+	int16_t *o = (int16_t *)om->b_wptr;
+	for (size_t i = 0; i < n; ++i)
+		for (int c = 0; c < out_nch; ++c) o[i * out_nch + c] = s[i * in_nch];
+	om->b_wptr += n * 2 * (size_t)out_nch;
+	mblk_meta_copy(im, om);
+	freemsg(im);
+	return om;
+}
+
+void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-179
+	ResampleData *d = (ResampleData *)f->data;
+	mblk_t *im;
+	if (d->output_rate == d->input_rate) { // :126-135 pass-through
+		while ((im = ms_queue_get(f->inputs[0])) != NULL)
+			ms_queue_put(f->outputs[0], channel_adapt(d->in_nchannels, d->out_nchannels, im));
+		return;
+	}
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (d->in_nchannels != 1) {
+		ms_error("MSResample[mi355x]: %d input channels: only mono is batched", d->in_nchannels);
+		ms_queue_flush(f->inputs[0]);
+		ms_filter_unlock(f);
+		return;
+	}
+	if (d->pool && (d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate))
+		resample_release(d); // rates changed: the handle is re-created, history lost (:138-148)
+	if (!d->pool) {
+		auto key = std::make_tuple(f->ticker, d->input_rate, d->output_rate);
+		auto it = g_resample_pools.find(key);
+		if (it == g_resample_pools.end()) {
+			ResamplePool *p = new ResamplePool(d->input_rate, d->output_rate);
+			p->ticker = f->ticker;
+			g_hub.pools.push_back(p);
+			it = g_resample_pools.emplace(key, p).first;
+		}
+		d->pool = it->second;
+		d->slot = d->pool->acquire(f);
+		if (d->slot < 0) {
+			d->pool = nullptr;
+			ms_queue_flush(f->inputs[0]);
+			ms_filter_unlock(f);
+			return;
+		}
+	}
+	ResamplePool *p = d->pool;
+	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
+	// this tick's input, re-framed to 10 ms blocks (a streaming filter: the sample sequence is
+	// independent of the blocking); the results are emitted by the flush task (ResamplePool::emit)
+	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
+	const size_t nbytes = (size_t)p->in_len * 2;
+	while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->bz) >= nbytes) {
+		ms_bufferizer_read(d->bz, (uint8_t *)(p->h_in + (p->staged[s] * c + s) * p->in_len), nbytes);
+		p->staged[s]++;
+	}
+	if (p->staged[s]) request_flush(f);
+	ms_filter_unlock(f);
+}
+
+void ResamplePool::emit(MSFilter *f, int slot) {
+	ResampleData *d = (ResampleData *)f->data;
+	const size_t c = (size_t)capacity, s = (size_t)slot;
+	for (int r = 0; r < ready[s]; ++r) {
+		const int outlen = h_olen[r * c + s];
+		mblk_t *om = allocb((size_t)outlen * 2, 0);
+		memcpy(om->b_wptr, h_out + (r * c + s) * ostride, (size_t)outlen * 2);
+		om->b_wptr += outlen * 2;
+		mblk_set_timestamp_info(om, d->ts); // msresample.c:168-169
+		d->ts += (uint32_t)outlen;
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], channel_adapt(1, d->out_nchannels, om));
+		else freemsg(om);
+	}
+	ready[s] = 0;
+}
+
+int resample_set_sr(MSFilter *f, void *arg) { // :181-192
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->input_rate = *(unsigned int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+int resample_set_output_sr(MSFilter *f, void *arg) { // :194-205
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->output_rate = *(unsigned int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+int resample_set_in_nch(MSFilter *f, void *arg) {
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->in_nchannels = *(int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+int resample_set_out_nch(MSFilter *f, void *arg) {
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->out_nchannels = *(int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+MSFilterMethod resample_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, resample_set_sr},
+                                     {MS_FILTER_SET_OUTPUT_SAMPLE_RATE, resample_set_output_sr},
+                                     {MS_FILTER_SET_NCHANNELS, resample_set_in_nch},
+                                     {MS_FILTER_SET_OUTPUT_NCHANNELS, resample_set_out_nch},
+                                     {0, NULL}};
+
+// ====================================================================== volume
+struct Extremum { // OrtpExtremum (oRTP utils): windowed min/max, period in ms
+	float current = 0, last_stable = 0;
+	uint64_t t0 = (uint64_t)-1;
+	int period;
+	void reset() {
+		current = last_stable = 0;
+		t0 = (uint64_t)-1;
+	}
+	bool check_init(uint64_t now, float v) {
+		if (t0 != (uint64_t)-1 && (int)(now - t0) > period) {
+			last_stable = current;
+			t0 = (uint64_t)-1;
+		}
+		if (t0 == (uint64_t)-1) {
+			current = v;
+			t0 = now;
+			return true;
+		}
+		return false;
+	}
+	void record_min(uint64_t now, float v) {
+		check_init(now, v);
+		if (v < current) current = v;
+	}
+	void record_max(uint64_t now, float v) {
+		check_init(now, v);
+		if (v > current) current = v;
+	}
+};
+
+struct VolumePool : Pool {
+	int rate, cap_samples;
+	mi_volume *v = nullptr;
+	int16_t *h_buf, *d_buf;
+	int32_t *h_n, *d_n;
+	std::vector<int> staged, ready;
+	std::vector<mi_volume_params> params;
+	std::vector<mi_volume_state> state;
+	std::vector<uint8_t> params_dirty, state_dirty;
+	VolumePool(int r) : rate(r) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_volume_create(g_hub.context(), capacity, rate, &v));
+		cap_samples = std::max(960, rate / 100 * 2);
+		cap_samples = (cap_samples + 7) & ~7;
+		const size_t c = (size_t)capacity;
+		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
+		h_n = pinned<int32_t>(kMaxRounds * c);
+		d_buf = devmem<int16_t>(c * cap_samples);
+		d_n = devmem<int32_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+		mi_volume_params p;
+		mi_volume_default_params(&p);
+		params.assign(c, p);
+		state.resize(c);
+		MI_MUST(mi_volume_get_state(v, 0, capacity, state.data()));
+		params_dirty.assign(c, 0);
+		state_dirty.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		for (int s = 0; s < capacity; ++s) {
+			if (params_dirty[(size_t)s]) MI_MUST(mi_volume_set_params(v, s, 1, &params[(size_t)s]));
+			if (state_dirty[(size_t)s]) MI_MUST(mi_volume_set_state(v, s, 1, &state[(size_t)s]));
+			params_dirty[(size_t)s] = state_dirty[(size_t)s] = 0;
+		}
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r = 0; r < maxr; ++r) {
+			for (int s = 0; s < capacity; ++s)
+				if (staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, c * cap_samples * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
+			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, c * cap_samples * 2));
+		}
+		if (maxr) {
+			MI_MUST(mi_ctx_sync(ctx));
+			MI_MUST(mi_volume_get_state(v, 0, capacity, state.data())); // meters for the app thread
+		}
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override;
+};
+std::map<std::pair<MSTicker *, int>, VolumePool *> g_volume_pools;
+
+struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
+	mi_volume_params p;
+	float gain, target_gain; // pending values for a slot not yet acquired
+	int sample_rate, nsamples;
+	MSFilter *peer;
+	MSBufferizer *buffer;
+	Extremum min, max;
+	VolumePool *pool;
+	int slot;
+	bool ng_soft_start;
+};
+
+void volume_init(MSFilter *f) { // msvolume.c:88-118
+	VolumeData *d = new VolumeData();
+	mi_volume_default_params(&d->p);
+	d->gain = d->target_gain = 1;
+	d->sample_rate = 8000;
+	d->nsamples = 80;
+	d->peer = NULL;
+	d->buffer = ms_bufferizer_new();
+	d->max.period = 1000;
+	d->min.period = 30000;
+	d->pool = nullptr;
+	d->slot = -1;
+	f->data = d;
+}
+
+void volume_uninit(MSFilter *f) {
+	VolumeData *d = (VolumeData *)f->data;
+	if (d->pool && d->slot >= 0) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		d->pool->release(d->slot);
+	}
+	ms_bufferizer_destroy(d->buffer);
+	delete d;
+}
+
+mi_volume_state *vstate(VolumeData *d) { return (d->pool && d->slot >= 0) ? &d->pool->state[(size_t)d->slot] : nullptr; }
+
+void volume_push_params(VolumeData *d) {
+	if (!d->pool || d->slot < 0) return;
+	d->pool->params[(size_t)d->slot] = d->p;
+	d->pool->params_dirty[(size_t)d->slot] = 1;
+}
+
+void volume_attach_slot(MSFilter *f) {
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (d->pool && (d->pool->rate != d->sample_rate || d->pool->ticker != f->ticker)) {
+		d->pool->release(d->slot);
+		d->pool = nullptr;
+		d->slot = -1;
+	}
+	if (!d->pool) {
+		auto key = std::make_pair(f->ticker, d->sample_rate);
+		auto it = g_volume_pools.find(key);
+		if (it == g_volume_pools.end()) {
+			VolumePool *p = new VolumePool(d->sample_rate);
+			p->ticker = f->ticker;
+			g_hub.pools.push_back(p);
+			it = g_volume_pools.emplace(key, p).first;
+		}
+		d->pool = it->second;
+		d->slot = d->pool->acquire(f);
+		if (d->slot < 0) {
+			d->pool = nullptr;
+			return;
+		}
+		// fresh slot: volume_init state, then whatever the methods set before attach
+		mi_volume_state st;
+		memset(&st, 0, sizeof(st));
+		st.gain = d->gain;
+		st.target_gain = d->target_gain;
+		st.ng_gain = 1;
+		d->pool->state[(size_t)d->slot] = st;
+		d->pool->state_dirty[(size_t)d->slot] = 1;
+	}
+	// the peer is addressed by its slot in the same pool
+	d->p.peer = -1;
+	if (d->peer) {
+		VolumeData *pd = (VolumeData *)d->peer->data;
+		if (pd->pool == d->pool && pd->slot >= 0) d->p.peer = pd->slot;
+		else ms_warning("MSVolume[mi355x]: peer not in the same batch yet (different rate or not attached)");
+	}
+	volume_push_params(d);
+}
+
+void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
+	VolumeData *d = (VolumeData *)f->data;
+	d->nsamples = (int)(0.01 * (float)d->sample_rate);
+	d->min.reset();
+	d->max.reset();
+	volume_attach_slot(f);
+}
+
+void volume_process(MSFilter *f) { // msvolume.c:471-514
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!d->pool) volume_attach_slot(f);
+	if (!d->pool) {
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	if (d->peer && d->p.peer < 0) volume_attach_slot(f);
+	VolumePool *p = d->pool;
+	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
+	mblk_t *m;
+	if (d->p.agc_enabled || d->peer != NULL) { // :480-503 re-framed to 10 ms chunks
+		const size_t nbytes = (size_t)d->nsamples * 2;
+		ms_bufferizer_put_from_queue(d->buffer, f->inputs[0]);
+		while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->buffer) >= nbytes) {
+			ms_bufferizer_read(d->buffer, (uint8_t *)(p->h_buf + (p->staged[s] * c + s) * p->cap_samples), nbytes);
+			p->h_n[p->staged[s] * c + s] = d->nsamples;
+			p->staged[s]++;
+		}
+	} else { // :505-512 light path: one chunk per mblk, whatever its size
+		while (p->staged[s] < kMaxRounds && (m = ms_queue_get(f->inputs[0])) != NULL) {
+			int n = (int)(msgdsize(m) / 2);
+			if (n > p->cap_samples) {
+				ms_warning("MSVolume[mi355x]: block of %d samples truncated to %d", n, p->cap_samples);
+				n = p->cap_samples;
+			}
+			memcpy(p->h_buf + (p->staged[s] * c + s) * p->cap_samples, m->b_rptr, (size_t)n * 2);
+			p->h_n[p->staged[s] * c + s] = n;
+			p->staged[s]++;
+			freemsg(m);
+		}
+	}
+	if (p->staged[s]) request_flush(f);
+}
+
+void VolumePool::emit(MSFilter *f, int slot) {
+	VolumeData *d = (VolumeData *)f->data;
+	const size_t c = (size_t)capacity, s = (size_t)slot;
+	for (int r = 0; r < ready[s]; ++r) {
+		const int n = h_n[r * c + s];
+		mblk_t *om = allocb((size_t)n * 2, 0);
+		memcpy(om->b_wptr, h_buf + (r * c + s) * cap_samples, (size_t)n * 2);
+		om->b_wptr += n * 2;
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
+		else freemsg(om);
+	}
+	if (ready[s] && f->ticker) { // meters (update_energy msvolume.c:405-406)
+		d->max.record_max(f->ticker->time, state[s].energy);
+		d->min.record_min(f->ticker->time, state[s].energy);
+	}
+	ready[s] = 0;
+}
+
+float linear_to_dbm0(float linear) { // ms_volume_linear_to_dbm0 msvolume.c:565-568
+	if (linear == 0) return MS_VOLUME_DB_LOWEST;
+	return 10 * log10f(linear);
+}
+
+int volume_get(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mi_volume_state *st = vstate(d);
+	*(float *)arg = linear_to_dbm0(st ? st->energy : 0.f);
+	return 0;
+}
+int volume_get_linear(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mi_volume_state *st = vstate(d);
+	*(float *)arg = st ? st->energy : 0.f;
+	return 0;
+}
+int volume_get_min(MSFilter *f, void *arg) {
+	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->min.current);
+	return 0;
+}
+int volume_get_max(MSFilter *f, void *arg) {
+	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->max.current);
+	return 0;
+}
+void volume_set_gains(VolumeData *d, bool also_target) {
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mi_volume_state *st = vstate(d);
+	if (st) {
+		st->gain = d->gain;
+		if (also_target) st->target_gain = d->target_gain;
+		d->pool->state_dirty[(size_t)d->slot] = 1;
+	}
+	volume_push_params(d);
+}
+int volume_set_gain(MSFilter *f, void *arg) { // :270-276
+	VolumeData *d = (VolumeData *)f->data;
+	d->gain = d->target_gain = d->p.static_gain = *(float *)arg;
+	volume_set_gains(d, true);
+	return 0;
+}
+int volume_set_db_gain(MSFilter *f, void *arg) { // :262-268 (power ratio)
+	VolumeData *d = (VolumeData *)f->data;
+	d->gain = d->p.static_gain = (float)pow(10, (*(float *)arg) / 10);
+	volume_set_gains(d, false);
+	return 0;
+}
+int volume_get_gain(MSFilter *f, void *arg) {
+	*(float *)arg = ((VolumeData *)f->data)->p.static_gain;
+	return 0;
+}
+int volume_get_gain_db(MSFilter *f, void *arg) {
+	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->p.static_gain);
+	return 0;
+}
+int volume_set_peer(MSFilter *f, void *arg) { // :292-297 stores the MSFilter*
+	VolumeData *d = (VolumeData *)f->data;
+	d->peer = (MSFilter *)arg;
+	if (d->pool) volume_attach_slot(f);
+	return 0;
+}
+int volume_set_rate(MSFilter *f, void *arg) {
+	((VolumeData *)f->data)->sample_rate = *(int *)arg;
+	return 0;
+}
+#define VOL_FLOAT_SETTER(name, field, check)                       \
+	int name(MSFilter *f, void *arg) {                             \
+		VolumeData *d = (VolumeData *)f->data;                     \
+		const float val = *(float *)arg;                           \
+		if (!(check)) {                                            \
+			ms_error("MSVolume: parameter out of range");          \
+			return -1;                                             \
+		}                                                          \
+		d->p.field = val;                                          \
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);        \
+		volume_push_params(d);                                     \
+		return 0;                                                  \
+	}
+VOL_FLOAT_SETTER(volume_set_ea_threshold, ea_thres, val >= 0 && val <= 1) // :305-314
+VOL_FLOAT_SETTER(volume_set_ea_speed, vol_upramp, val >= 0 && val <= .5)  // :324-333
+VOL_FLOAT_SETTER(volume_set_ea_force, force, true)
+VOL_FLOAT_SETTER(volume_set_ea_transmit, ea_transmit_thres, true)
+VOL_FLOAT_SETTER(volume_set_ng_threshold, ng_threshold, true)
+int volume_set_ea_sustain(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.sustain_time = *(int *)arg;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	volume_push_params(d);
+	return 0;
+}
+int volume_set_agc(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.agc_enabled = *(int *)arg;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	volume_push_params(d);
+	return 0;
+}
+int volume_enable_noise_gate(MSFilter *f, void *arg) { // :352-359
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.noise_gate_enabled = *(bool_t *)arg;
+	if (d->p.noise_gate_enabled) d->gain = d->target_gain = d->p.ng_floorgain;
+	volume_set_gains(d, d->p.noise_gate_enabled != 0);
+	return 0;
+}
+int volume_set_ng_floorgain(MSFilter *f, void *arg) { // :367-378
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.ng_floorgain = *(float *)arg;
+	if (d->p.ng_floorgain < 0.005f) d->p.ng_floorgain = 0.005f;
+	if (d->p.noise_gate_enabled) d->gain = d->target_gain = d->p.ng_floorgain;
+	volume_set_gains(d, d->p.noise_gate_enabled != 0);
+	return 0;
+}
+int volume_remove_dc(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.remove_dc = *(int *)arg;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	volume_push_params(d);
+	return 0;
+}
+MSFilterMethod volume_methods[] = {{MS_VOLUME_GET, volume_get},
+                                   {MS_VOLUME_GET_LINEAR, volume_get_linear},
+                                   {MS_VOLUME_SET_GAIN, volume_set_gain},
+                                   {MS_VOLUME_SET_PEER, volume_set_peer},
+                                   {MS_VOLUME_SET_EA_THRESHOLD, volume_set_ea_threshold},
+                                   {MS_VOLUME_SET_EA_SPEED, volume_set_ea_speed},
+                                   {MS_VOLUME_SET_EA_FORCE, volume_set_ea_force},
+                                   {MS_VOLUME_SET_EA_SUSTAIN, volume_set_ea_sustain},
+                                   {MS_VOLUME_SET_EA_TRANSMIT_THRESHOLD, volume_set_ea_transmit},
+                                   {MS_FILTER_SET_SAMPLE_RATE, volume_set_rate},
+                                   {MS_VOLUME_ENABLE_AGC, volume_set_agc},
+                                   {MS_VOLUME_ENABLE_NOISE_GATE, volume_enable_noise_gate},
+                                   {MS_VOLUME_SET_NOISE_GATE_THRESHOLD, volume_set_ng_threshold},
+                                   {MS_VOLUME_SET_NOISE_GATE_FLOORGAIN, volume_set_ng_floorgain},
+                                   {MS_VOLUME_SET_DB_GAIN, volume_set_db_gain},
+                                   {MS_VOLUME_GET_GAIN, volume_get_gain},
+                                   {MS_VOLUME_GET_GAIN_DB, volume_get_gain_db},
+                                   {MS_VOLUME_REMOVE_DC, volume_remove_dc},
+                                   {MS_VOLUME_GET_MIN, volume_get_min},
+                                   {MS_VOLUME_GET_MAX, volume_get_max},
+                                   {0, NULL}};
+
+// =================================================================== equalizer
+struct EqualizerPool : Pool {
+	int rate, cap_samples;
+	mi_equalizer *e = nullptr;
+	int16_t *h_buf, *d_buf;
+	int32_t *h_n, *d_n;
+	std::vector<int> staged, ready;
+	EqualizerPool(int r) : rate(r) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_equalizer_create(g_hub.context(), capacity, rate, &e));
+		cap_samples = (std::max(960, rate / 100 * 2) + 7) & ~7;
+		const size_t c = (size_t)capacity;
+		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
+		h_n = pinned<int32_t>(kMaxRounds * c);
+		d_buf = devmem<int16_t>(c * cap_samples);
+		d_n = devmem<int32_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r = 0; r < maxr; ++r) {
+			for (int s = 0; s < capacity; ++s)
+				if (staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, c * cap_samples * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
+			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, c * cap_samples * 2));
+		}
+		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override {
+		const size_t c = (size_t)capacity, s = (size_t)slot;
+		for (int r = 0; r < ready[s]; ++r) {
+			const int n = h_n[r * c + s];
+			mblk_t *om = allocb((size_t)n * 2, 0);
+			memcpy(om->b_wptr, h_buf + (r * c + s) * cap_samples, (size_t)n * 2);
+			om->b_wptr += n * 2;
+			if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
+			else freemsg(om);
+		}
+		ready[s] = 0;
+	}
+};
+std::map<std::pair<MSTicker *, int>, EqualizerPool *> g_equalizer_pools;
+
+struct EqualizerData {
+	int rate;
+	bool active;
+	EqualizerPool *pool;
+	int slot;
+	std::vector<MSEqualizerGain> *pending; // gains since the last rate change, in call order
+};
+
+// Gains set before the filter is attached to a ticker are kept in `pending` and replayed, in
+// order, when the slot is acquired (the reference keeps them in its own fft_cpx array).
+void equalizer_attach(MSFilter *f) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (d->pool && d->pool->rate == d->rate && d->pool->ticker == f->ticker) return;
+	if (d->pool) d->pool->release(d->slot);
+	d->pool = nullptr;
+	d->slot = -1;
+	if (!f->ticker) return;
+	auto key = std::make_pair(f->ticker, d->rate);
+	auto it = g_equalizer_pools.find(key);
+	if (it == g_equalizer_pools.end()) {
+		EqualizerPool *p = new EqualizerPool(d->rate);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_equalizer_pools.emplace(key, p).first;
+	}
+	d->pool = it->second;
+	d->slot = d->pool->acquire(f);
+	if (d->slot < 0) {
+		d->pool = nullptr;
+		return;
+	}
+	MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot)); // equalizer_rate_update flattens
+	MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
+	for (const MSEqualizerGain &g : *d->pending)
+		MI_MUST(mi_equalizer_set_gain(d->pool->e, d->slot, g.frequency, g.gain, g.width));
+}
+
+void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
+	EqualizerData *d = (EqualizerData *)ms_malloc0(sizeof(*d));
+	d->rate = 8000;
+	d->active = true;
+	d->slot = -1;
+	d->pending = new std::vector<MSEqualizerGain>();
+	f->data = d;
+}
+void equalizer_preprocess(MSFilter *f) { equalizer_attach(f); }
+void equalizer_uninit(MSFilter *f) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	if (d->pool) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		d->pool->release(d->slot);
+	}
+	delete d->pending;
+	ms_free(d);
+}
+void equalizer_process(MSFilter *f) { // equalizer.c:279-288
+	EqualizerData *d = (EqualizerData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mblk_t *m;
+	if (!d->pool) equalizer_attach(f);
+	if (!d->pool) {
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	EqualizerPool *p = d->pool;
+	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
+	while (p->staged[s] < kMaxRounds && (m = ms_queue_get(f->inputs[0])) != NULL) {
+		int n = (int)(msgdsize(m) / 2);
+		if (n > p->cap_samples) n = p->cap_samples;
+		memcpy(p->h_buf + (p->staged[s] * c + s) * p->cap_samples, m->b_rptr, (size_t)n * 2);
+		p->h_n[p->staged[s] * c + s] = n;
+		p->staged[s]++;
+		freemsg(m);
+	}
+	if (p->staged[s]) request_flush(f);
+}
+int equalizer_set_gain(MSFilter *f, void *arg) { // equalizer.c:290-295
+	EqualizerData *d = (EqualizerData *)f->data;
+	MSEqualizerGain *g = (MSEqualizerGain *)arg;
+	d->pending->push_back(*g);
+	if (!d->pool) return 0;
+	return mi_equalizer_set_gain(d->pool->e, d->slot, g->frequency, g->gain, g->width) == MI_OK ? 0 : -1;
+}
+int equalizer_get_gain(MSFilter *f, void *arg) { // equalizer.c:297-303 incl. its slot-indexing quirk
+	EqualizerData *d = (EqualizerData *)f->data;
+	MSEqualizerGain *g = (MSEqualizerGain *)arg;
+	g->width = 0;
+	g->gain = 0;
+	if (!d->pool) return -1;
+	const int nfft = mi_equalizer_fir_len(d->pool->e);
+	std::vector<float> dump((size_t)nfft / 2);
+	if (mi_equalizer_dump(d->pool->e, d->slot, dump.data(), nfft / 2) != MI_OK) return -1;
+	int hz = (int)g->frequency;
+	if (hz >= 0) {
+		if (hz > d->rate / 2) hz = d->rate / 2;
+		int idx = ((hz * nfft) + (d->rate / 2)) / d->rate;
+		if (idx == nfft / 2) idx = nfft / 2 - 1;
+		// the reference reads fft_cpx[idx*2]: an imaginary slot, 0 for idx >= 1; DC slot for idx == 0
+		g->gain = idx == 0 ? dump[0] * nfft : 0.f;
+	}
+	return 0;
+}
+int equalizer_set_rate(MSFilter *f, void *arg) { // equalizer.c:305-309
+	EqualizerData *d = (EqualizerData *)f->data;
+	d->rate = *(int *)arg;
+	d->pending->clear(); // equalizer_rate_update re-allocates a flat spectrum
+	if (d->pool && d->pool->rate == d->rate) MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot));
+	else equalizer_attach(f);
+	return 0;
+}
+int equalizer_set_active(MSFilter *f, void *arg) { // equalizer.c:311-315: arg read as bool_t
+	EqualizerData *d = (EqualizerData *)f->data;
+	d->active = *(bool_t *)arg != 0;
+	if (d->pool) MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
+	return 0;
+}
+int equalizer_dump(MSFilter *f, void *arg) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	if (!d->pool) return -1;
+	return mi_equalizer_dump(d->pool->e, d->slot, (float *)arg, mi_equalizer_fir_len(d->pool->e) / 2) == MI_OK ? 0 : -1;
+}
+int equalizer_get_nfreqs(MSFilter *f, void *arg) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	*(int *)arg = (d->rate < 16000 ? 128 : (d->rate < 32000 ? 256 : 512)) / 2;
+	return 0;
+}
+MSFilterMethod equalizer_methods[] = {{MS_EQUALIZER_SET_GAIN, equalizer_set_gain},
+                                      {MS_EQUALIZER_GET_GAIN, equalizer_get_gain},
+                                      {MS_EQUALIZER_SET_ACTIVE, equalizer_set_active},
+                                      {MS_FILTER_SET_SAMPLE_RATE, equalizer_set_rate},
+                                      {MS_EQUALIZER_DUMP_STATE, equalizer_dump},
+                                      {MS_EQUALIZER_GET_NUM_FREQUENCIES, equalizer_get_nfreqs},
+                                      {0, NULL}};
+
+// ======================================================================= mixer
+constexpr int MIXER_MAX_CHANNELS = MI_MIXER_MAX_CHANNELS; // audiomixer.c:29
+constexpr uint64_t BYPASS_MODE_TIMEOUT = 1000;            // audiomixer.c:31
+
+struct MixerPool : Pool {
+	int ns; // samples per tick (all channels interleaved)
+	mi_mixer *m = nullptr;
+	int16_t *h_in, *h_out, *d_in, *d_out;
+	uint8_t *h_has, *d_has, *h_run, *d_run, *h_mode, *d_mode;
+	std::vector<uint8_t> flags;
+	std::vector<float> gain;
+	bool ctl_dirty = true;
+	std::vector<uint8_t> staged, ready;
+	MixerPool(int nsamples) : ns(nsamples) {
+		init_slots(std::max(1, g_hub.capacity / 8));
+		MI_MUST(mi_mixer_create(g_hub.context(), capacity, MIXER_MAX_CHANNELS, ns, &m));
+		const size_t c = (size_t)capacity, n = c * MIXER_MAX_CHANNELS;
+		h_in = pinned<int16_t>(n * ns);
+		h_out = pinned<int16_t>(n * ns);
+		d_in = devmem<int16_t>(n * ns);
+		d_out = devmem<int16_t>(n * ns);
+		h_has = pinned<uint8_t>(n);
+		d_has = devmem<uint8_t>(n);
+		h_run = pinned<uint8_t>(c);
+		d_run = devmem<uint8_t>(c);
+		h_mode = pinned<uint8_t>(c);
+		d_mode = devmem<uint8_t>(c);
+		flags.assign(n, 0);
+		gain.assign(n, 1.0f);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity, n = c * MIXER_MAX_CHANNELS;
+		bool any = false;
+		for (size_t s = 0; s < c; ++s) {
+			h_run[s] = staged[s];
+			any |= staged[s] != 0;
+		}
+		if (ctl_dirty) {
+			MI_MUST(mi_mixer_set_controls(m, flags.data(), gain.data()));
+			ctl_dirty = false;
+		}
+		if (any) {
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, n * ns * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_has, h_has, n));
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, c));
+			MI_MUST(mi_copy_h2d(ctx, d_mode, h_mode, c));
+			MI_MUST(mi_mixer_process_masked(m, d_in, d_has, 1, d_mode, d_out, d_run));
+			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, n * ns * 2));
+			MI_MUST(mi_ctx_sync(ctx));
+		}
+		for (size_t s = 0; s < c; ++s) {
+			ready[s] = staged[s];
+			staged[s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override;
+};
+std::map<std::pair<MSTicker *, int>, MixerPool *> g_mixer_pools;
+
+struct Channel { // audiomixer.c:53-63
+	MSBufferizer bufferizer;
+	float gain;
+	int min_fullness;
+	uint64_t last_flow_control, last_activity;
+	bool_t active, output_enabled;
+};
+struct MixerState { // audiomixer.c:132-143
+	int nchannels, rate, bytespertick;
+	Channel channels[MIXER_MAX_CHANNELS];
+	int conf_mode, skip_threshold, master_channel;
+	bool_t bypass_mode, single_output;
+	MixerPool *pool;
+	int slot;
+};
+
+void mixer_init(MSFilter *f) { // audiomixer.c:145-156
+	MixerState *s = (MixerState *)ms_malloc0(sizeof(*s));
+	s->conf_mode = FALSE;
+	s->nchannels = 1;
+	s->rate = 44100;
+	s->master_channel = -1;
+	s->slot = -1;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+		ms_bufferizer_init(&s->channels[i].bufferizer);
+		s->channels[i].gain = 1.0;
+		s->channels[i].active = TRUE;
+		s->channels[i].output_enabled = TRUE;
+	}
+	f->data = s;
+}
+void mixer_uninit(MSFilter *f) {
+	MixerState *s = (MixerState *)f->data;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) ms_bufferizer_uninit(&s->channels[i].bufferizer);
+	ms_free(s);
+}
+bool_t has_single_output(MSFilter *f, MixerState *s) { // audiomixer.c:167-176
+	int count = 0;
+	for (int i = 0; i < f->desc->noutputs; ++i)
+		if (f->outputs[i] && s->channels[i].output_enabled) count++;
+	return count == 1;
+}
+void mixer_push_controls(MSFilter *f, MixerState *s) {
+	if (!s->pool) return;
+	MixerPool *p = s->pool;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+		uint8_t fl = 0;
+		if (f->inputs[i]) fl |= MI_MIX_LINKED;
+		if (s->channels[i].active) fl |= MI_MIX_ACTIVE;
+		if (f->outputs[i] && s->channels[i].output_enabled) fl |= MI_MIX_OUTPUT;
+		p->flags[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = fl;
+		p->gain[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = s->channels[i].gain;
+	}
+	p->ctl_dirty = true;
+}
+void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
+	MixerState *s = (MixerState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->bytespertick = (2 * s->nchannels * s->rate * f->ticker->interval) / 1000;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+		s->channels[i].last_flow_control = (uint64_t)-1;
+		s->channels[i].last_activity = (uint64_t)-1;
+	}
+	s->skip_threshold = s->bytespertick * 2;
+	s->bypass_mode = FALSE;
+	s->single_output = has_single_output(f, s);
+	const int ns = s->bytespertick / 2;
+	auto key = std::make_pair(f->ticker, ns);
+	auto it = g_mixer_pools.find(key);
+	if (it == g_mixer_pools.end()) {
+		MixerPool *p = new MixerPool(ns);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_mixer_pools.emplace(key, p).first;
+	}
+	s->pool = it->second;
+	s->slot = s->pool->acquire(f);
+	if (s->slot < 0) s->pool = nullptr;
+	mixer_push_controls(f, s);
+}
+void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot released at every detach)
+	MixerState *s = (MixerState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (s->pool) {
+		s->pool->release(s->slot);
+		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
+	}
+	s->pool = nullptr;
+	s->slot = -1;
+}
+
+void mixer_dispatch_output(MSFilter *f, MixerState *s, MSQueue *inq, int active_input) { // audiomixer.c:219-240
+	for (int i = 0; i < f->desc->noutputs; i++) {
+		MSQueue *outq = f->outputs[i];
+		Channel *chan = &s->channels[i];
+		if (outq && chan->output_enabled && (active_input != i || s->conf_mode == 0)) {
+			mblk_t *m;
+			if (s->single_output) {
+				while ((m = ms_queue_get(inq)) != NULL) ms_queue_put(outq, m);
+				break;
+			} else {
+				for (m = peekq(&inq->q); m != &inq->q._q_stopper && m != NULL; m = m->b_next) ms_queue_put(outq, dupmsg(m));
+			}
+		}
+	}
+	ms_queue_flush(inq);
+}
+
+bool_t mixer_check_bypass(MSFilter *f, MixerState *s) { // audiomixer.c:244-286
+	int active_cnt = 0, active_input = -1;
+	MSQueue *activeq = NULL;
+	const uint64_t curtime = f->ticker->time;
+	for (int i = 0; i < f->desc->ninputs; i++) {
+		MSQueue *q = f->inputs[i];
+		if (!q) continue;
+		Channel *chan = &s->channels[i];
+		if (!ms_queue_empty(q)) {
+			chan->last_activity = curtime;
+			activeq = q;
+			active_cnt++;
+			active_input = i;
+		} else if (chan->last_activity == (uint64_t)-1) {
+			chan->last_activity = curtime;
+		} else if (curtime - chan->last_activity < BYPASS_MODE_TIMEOUT) {
+			activeq = q;
+			active_cnt++;
+			active_input = i;
+		}
+	}
+	if (active_cnt == 1) {
+		if (!s->bypass_mode) {
+			s->bypass_mode = TRUE;
+			ms_message("MSAudioMixer [%p] is entering bypass mode.", (void *)f);
+		}
+		mixer_dispatch_output(f, s, activeq, active_input);
+		return TRUE;
+	} else if (active_cnt > 1) {
+		if (s->bypass_mode) {
+			s->bypass_mode = FALSE;
+			ms_message("MSAudioMixer [%p] is leaving bypass mode.", (void *)f);
+		}
+		return FALSE;
+	}
+	return TRUE;
+}
+
+int channel_flow_control(Channel *chan, int threshold, uint64_t time) { // audiomixer.c:92-111
+	int skip = 0;
+	if (chan->last_flow_control == (uint64_t)-1) {
+		chan->last_flow_control = time;
+		chan->min_fullness = -1;
+		return skip;
+	}
+	const int size = (int)ms_bufferizer_get_avail(&chan->bufferizer);
+	if (chan->min_fullness == -1 || size < chan->min_fullness) chan->min_fullness = size;
+	if (time - chan->last_flow_control >= 5000) {
+		if (chan->min_fullness >= threshold) {
+			skip = chan->min_fullness - (threshold / 2);
+			ms_bufferizer_skip_bytes(&chan->bufferizer, skip);
+		}
+		chan->last_flow_control = time;
+		chan->min_fullness = -1;
+	}
+	return skip;
+}
+
+void MixerPool::emit(MSFilter *f, int slot) {
+	MixerState *s = (MixerState *)f->data;
+	if (!ready[(size_t)slot]) return;
+	ready[(size_t)slot] = 0;
+	const int16_t *base = h_out + (size_t)slot * MIXER_MAX_CHANNELS * ns;
+	if (s->conf_mode == 0) { // one block shared by every enabled output (:321-334)
+		mblk_t *om = NULL;
+		for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+			MSQueue *q = f->outputs[i];
+			if (q && s->channels[i].output_enabled) {
+				if (om == NULL) {
+					om = allocb((size_t)ns * 2, 0);
+					memcpy(om->b_wptr, base, (size_t)ns * 2);
+					om->b_wptr += ns * 2;
+				} else {
+					om = dupb(om);
+				}
+				ms_queue_put(q, om);
+			}
+		}
+	} else { // :336-343
+		for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+			MSQueue *q = f->outputs[i];
+			if (q && s->channels[i].output_enabled) {
+				mblk_t *om = allocb((size_t)ns * 2, 0);
+				memcpy(om->b_wptr, base + (size_t)i * ns, (size_t)ns * 2);
+				om->b_wptr += ns * 2;
+				ms_queue_put(q, om);
+			}
+		}
+	}
+}
+
+void mixer_process(MSFilter *f) { // audiomixer.c:288-346
+	MixerState *s = (MixerState *)f->data;
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!s->pool) {
+		ms_filter_unlock(f);
+		return;
+	}
+	if (mixer_check_bypass(f, s)) {
+		ms_filter_unlock(f);
+		return;
+	}
+	MixerPool *p = s->pool;
+	const int nwords = s->bytespertick / 2;
+	int16_t *in = p->h_in + (size_t)s->slot * MIXER_MAX_CHANNELS * nwords;
+	uint8_t *has = p->h_has + (size_t)s->slot * MIXER_MAX_CHANNELS;
+	for (int i = 0; i < f->desc->ninputs; ++i) {
+		MSQueue *q = f->inputs[i];
+		has[i] = 0;
+		if (!q) continue;
+		Channel *chan = &s->channels[i];
+		ms_bufferizer_put_from_queue(&chan->bufferizer, q); // channel_process_in :78-90
+		has[i] = ms_bufferizer_read(&chan->bufferizer, (uint8_t *)(in + (size_t)i * nwords), (size_t)nwords * 2) != 0;
+		const int skip = channel_flow_control(chan, s->skip_threshold, f->ticker->time);
+		if (skip > 0)
+			ms_warning("Too much data in channel %i, %i ms in excess dropped", i, (skip * 1000) / (2 * s->nchannels * s->rate));
+	}
+	p->h_mode[(size_t)s->slot] = (uint8_t)(s->conf_mode != 0);
+	p->staged[(size_t)s->slot] = 1; // ALWAYS_STREAMOUT :315-317
+	request_flush(f);
+	ms_filter_unlock(f);
+}
+
+int mixer_set_rate(MSFilter *f, void *data) {
+	((MixerState *)f->data)->rate = *(int *)data;
+	return 0;
+}
+int mixer_get_rate(MSFilter *f, void *data) {
+	*(int *)data = ((MixerState *)f->data)->rate;
+	return 0;
+}
+int mixer_set_nchannels(MSFilter *f, void *data) {
+	((MixerState *)f->data)->nchannels = *(int *)data;
+	return 0;
+}
+int mixer_get_nchannels(MSFilter *f, void *data) {
+	*(int *)data = ((MixerState *)f->data)->nchannels;
+	return 0;
+}
+bool mixer_pin_ok(const char *who, int pin) {
+	if (pin < 0 || pin >= MIXER_MAX_CHANNELS) {
+		ms_warning("%s: invalid pin number %i", who, pin);
+		return false;
+	}
+	return true;
+}
+int mixer_set_input_gain(MSFilter *f, void *data) { // audiomixer.c:372-382
+	MixerState *s = (MixerState *)f->data;
+	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
+	if (!mixer_pin_ok("mixer_set_input_gain", ctl->pin)) return -1;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->channels[ctl->pin].gain = ctl->param.gain;
+	mixer_push_controls(f, s);
+	return 0;
+}
+int mixer_set_active(MSFilter *f, void *data) { // :384-393
+	MixerState *s = (MixerState *)f->data;
+	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
+	if (!mixer_pin_ok("mixer_set_active_gain", ctl->pin)) return -1;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->channels[ctl->pin].active = (bool_t)ctl->param.active;
+	mixer_push_controls(f, s);
+	return 0;
+}
+int mixer_enable_output(MSFilter *f, void *data) { // :395-408
+	MixerState *s = (MixerState *)f->data;
+	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
+	if (!mixer_pin_ok("mixer_enable_output", ctl->pin)) return -1;
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->channels[ctl->pin].output_enabled = (bool_t)ctl->param.enabled;
+	s->single_output = has_single_output(f, s);
+	mixer_push_controls(f, s);
+	ms_filter_unlock(f);
+	return 0;
+}
+int mixer_set_conference_mode(MSFilter *f, void *data) {
+	((MixerState *)f->data)->conf_mode = *(int *)data;
+	return 0;
+}
+int mixer_set_master_channel(MSFilter *f, void *data) {
+	((MixerState *)f->data)->master_channel = *(int *)data;
+	return 0;
+}
+MSFilterMethod mixer_methods[] = {{MS_FILTER_SET_NCHANNELS, mixer_set_nchannels},
+                                  {MS_FILTER_GET_NCHANNELS, mixer_get_nchannels},
+                                  {MS_FILTER_SET_SAMPLE_RATE, mixer_set_rate},
+                                  {MS_FILTER_GET_SAMPLE_RATE, mixer_get_rate},
+                                  {MS_AUDIO_MIXER_SET_INPUT_GAIN, mixer_set_input_gain},
+                                  {MS_AUDIO_MIXER_SET_ACTIVE, mixer_set_active},
+                                  {MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, mixer_set_conference_mode},
+                                  {MS_AUDIO_MIXER_SET_MASTER_CHANNEL, mixer_set_master_channel},
+                                  {MS_AUDIO_MIXER_ENABLE_OUTPUT, mixer_enable_output},
+                                  {0, NULL}};
+
+// ============================================================== echo canceller
+struct EcPool : Pool {
+	int rate, F, flen;
+	mi_aec *a = nullptr;
+	int16_t *h_mic, *h_ref, *h_out, *d_mic, *d_ref, *d_out;
+	uint8_t *h_run, *d_run;
+	std::vector<int> staged, ready;
+	EcPool(int r, int frame, int filter_length) : rate(r), F(frame), flen(filter_length) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_aec_create(g_hub.context(), capacity, rate, F, flen, &a));
+		const size_t c = (size_t)capacity;
+		h_mic = pinned<int16_t>(kMaxRounds * c * F);
+		h_ref = pinned<int16_t>(kMaxRounds * c * F);
+		h_out = pinned<int16_t>(kMaxRounds * c * F);
+		h_run = pinned<uint8_t>(kMaxRounds * c);
+		d_mic = devmem<int16_t>(c * F);
+		d_ref = devmem<int16_t>(c * F);
+		d_out = devmem<int16_t>(c * F);
+		d_run = devmem<uint8_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r = 0; r < maxr; ++r) {
+			for (int s = 0; s < capacity; ++s) h_run[r * c + s] = staged[(size_t)s] > r;
+			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * F, c * F * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * F, c * F * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r * c, c));
+			MI_MUST(mi_aec_process(a, d_mic, d_ref, d_out, F, d_run, MI_AEC_POSTFILTER));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * F, d_out, c * F * 2));
+		}
+		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override {
+		const size_t c = (size_t)capacity, sl = (size_t)slot;
+		for (int r = 0; r < ready[sl]; ++r) { // cleaned frames -> outputs[1] (speexec.c:303)
+			mblk_t *oecho = allocb((size_t)F * 2, 0);
+			memcpy(oecho->b_wptr, h_out + (r * c + sl) * F, (size_t)F * 2);
+			oecho->b_wptr += F * 2;
+			if (f->outputs[1]) ms_queue_put(f->outputs[1], oecho);
+			else freemsg(oecho);
+		}
+		ready[sl] = 0;
+	}
+};
+std::map<std::tuple<MSTicker *, int, int, int>, EcPool *> g_ec_pools;
+
+// MSFlowControlledBufferizer, src/base/msqueue.c:127-256 (SendEvent drop method)
+struct FlowBuf {
+	MSBufferizer base;
+	MSFilter *filter;
+	uint64_t flow_control_time;
+	uint32_t interval_ms, max_size_ms, granularity_ms, min_size_ms_during_interval;
+	int samplerate, nchannels;
+};
+void flowbuf_init(FlowBuf *o, MSFilter *f, int rate) {
+	ms_bufferizer_init(&o->base);
+	o->filter = f;
+	o->interval_ms = 5000;
+	o->max_size_ms = 100;
+	o->granularity_ms = 0;
+	o->flow_control_time = 0;
+	o->min_size_ms_during_interval = UINT32_MAX;
+	o->samplerate = rate;
+	o->nchannels = 1;
+}
+void flowbuf_put(FlowBuf *o, mblk_t *m) { // msqueue.c:193-256
+	const uint32_t accumulated_ms = (uint32_t)((o->base.size * 1000) / (size_t)o->samplerate / 2) / (uint32_t)o->nchannels;
+	if (accumulated_ms < o->min_size_ms_during_interval) o->min_size_ms_during_interval = accumulated_ms;
+	ms_bufferizer_put(&o->base, m);
+	const uint64_t now = o->filter->ticker->time;
+	const uint32_t since = (uint32_t)(now - o->flow_control_time);
+	if (o->flow_control_time == 0) o->flow_control_time = now;
+	if (since >= o->interval_ms) {
+		uint32_t diff_ms = 0;
+		bool trig = false;
+		if (o->min_size_ms_during_interval != UINT32_MAX && o->min_size_ms_during_interval > o->max_size_ms) {
+			diff_ms = o->min_size_ms_during_interval - o->max_size_ms;
+			trig = true;
+		} else if (accumulated_ms > o->max_size_ms * 4) {
+			diff_ms = (accumulated_ms - o->max_size_ms) / 2;
+			trig = true;
+		}
+		if (trig && diff_ms > o->granularity_ms / 2) {
+			MSAudioFlowControlDropEvent ev;
+			ev.flow_control_interval_ms = o->interval_ms;
+			ev.drop_ms = diff_ms - o->granularity_ms / 2;
+			if (ev.drop_ms > 0) ms_filter_notify(o->filter, MS_AUDIO_FLOW_CONTROL_DROP_EVENT, &ev);
+		}
+		o->flow_control_time = now;
+		o->min_size_ms_during_interval = UINT32_MAX;
+	}
+}
+
+struct SpeexECState { // speexec.c:49-72
+	MSBufferizer delayed_ref;
+	FlowBuf ref;
+	MSBufferizer echo;
+	int framesize, framesize_at_8000, filterlength, samplerate, delay_ms, tail_length_ms, nominal_ref_samples;
+	char *state_str;
+	bool_t echostarted, bypass_mode, using_zeroes;
+	EcPool *pool;
+	int slot;
+};
+
+void ec_init(MSFilter *f) { // speexec.c:74-109
+	SpeexECState *s = (SpeexECState *)ms_malloc0(sizeof(*s));
+	s->samplerate = 8000;
+	ms_bufferizer_init(&s->delayed_ref);
+	ms_bufferizer_init(&s->echo);
+	flowbuf_init(&s->ref, f, s->samplerate);
+	s->tail_length_ms = 250;
+	s->framesize_at_8000 = 64;
+	s->slot = -1;
+	f->data = s;
+}
+void ec_uninit(MSFilter *f) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	if (s->state_str) ms_free(s->state_str);
+	ms_bufferizer_uninit(&s->delayed_ref);
+	ms_free(s);
+}
+void ec_configure_flow(SpeexECState *s) { // speexec.c:182-186
+	s->ref.samplerate = s->samplerate;
+	s->ref.max_size_ms = (uint32_t)s->delay_ms;
+	s->ref.granularity_ms = (uint32_t)((s->framesize * 1000) / s->samplerate);
+}
+void ec_preprocess(MSFilter *f) { // speexec.c:188-216
+	SpeexECState *s = (SpeexECState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->echostarted = FALSE;
+	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
+	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
+	const int delay_samples = s->delay_ms * s->samplerate / 1000;
+	ms_message("Initializing mi355x echo canceler with framesize=%i, filterlength=%i, delay_samples=%i", s->framesize,
+	           s->filterlength, delay_samples);
+	auto key = std::make_tuple(f->ticker, s->samplerate, s->framesize, s->filterlength);
+	auto it = g_ec_pools.find(key);
+	if (it == g_ec_pools.end()) {
+		EcPool *p = new EcPool(s->samplerate, s->framesize, s->filterlength);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_ec_pools.emplace(key, p).first;
+	}
+	s->pool = it->second;
+	s->slot = s->pool->acquire(f);
+	if (s->slot < 0) s->pool = nullptr;
+	mblk_t *m = allocb((size_t)delay_samples * 2, 0); // zeroes for the time of the delay
+	memset(m->b_wptr, 0, (size_t)delay_samples * 2);
+	m->b_wptr += delay_samples * 2;
+	ms_bufferizer_put(&s->delayed_ref, m);
+	s->nominal_ref_samples = delay_samples;
+	if (s->state_str) ms_warning("mi355x echo canceller: state restoration (SPEEX_ECHO_SET_BLOB) is not supported");
+}
+void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at detach
+	SpeexECState *s = (SpeexECState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	ms_bufferizer_flush(&s->delayed_ref);
+	ms_bufferizer_flush(&s->echo);
+	ms_bufferizer_flush(&s->ref.base);
+	if (s->pool) {
+		MI_MUST(mi_aec_reset(s->pool->a, s->slot, 1));
+		s->pool->release(s->slot);
+		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
+	}
+	s->pool = nullptr;
+	s->slot = -1;
+}
+
+// inputs[0] far-end reference, inputs[1] mic; outputs[0] reference copy, outputs[1] cleaned mic (speexec.c:218-222)
+void ec_process(MSFilter *f) { // speexec.c:223-305
+	SpeexECState *s = (SpeexECState *)f->data;
+	const int nbytes = s->framesize * 2;
+	mblk_t *refm;
+	if (s->bypass_mode) { // :229-237
+		while ((refm = ms_queue_get(f->inputs[0])) != NULL) ms_queue_put(f->outputs[0], refm);
+		while ((refm = ms_queue_get(f->inputs[1])) != NULL) ms_queue_put(f->outputs[1], refm);
+		return;
+	}
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	EcPool *p = s->pool;
+	if (!p) {
+		ms_queue_flush(f->inputs[0]);
+		ms_queue_flush(f->inputs[1]);
+		return;
+	}
+	const size_t c = (size_t)p->capacity, sl = (size_t)s->slot;
+	const int F = p->F;
+	if (f->inputs[0] != NULL) { // :239-250
+		if (s->echostarted) {
+			while ((refm = ms_queue_get(f->inputs[0])) != NULL) {
+				ms_bufferizer_put(&s->delayed_ref, dupmsg(refm));
+				flowbuf_put(&s->ref, refm);
+			}
+		} else {
+			ms_warning("Getting reference signal but no echo to synchronize on.");
+			ms_queue_flush(f->inputs[0]);
+		}
+	}
+	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
+	while (p->staged[sl] < kMaxRounds && ms_bufferizer_get_avail(&s->echo) >= (size_t)nbytes) { // :256
+		int16_t *echo = p->h_mic + (p->staged[sl] * c + sl) * F;
+		int16_t *ref = p->h_ref + (p->staged[sl] * c + sl) * F;
+		ms_bufferizer_read(&s->echo, (uint8_t *)echo, (size_t)nbytes);
+		if (!s->echostarted) s->echostarted = TRUE;
+		if ((int)ms_bufferizer_get_avail(&s->delayed_ref) < ((s->nominal_ref_samples * 2) + nbytes)) {
+			refm = allocb((size_t)nbytes, 0); // not enough reference: inject silence (:261-272)
+			memset(refm->b_wptr, 0, (size_t)nbytes);
+			refm->b_wptr += nbytes;
+			ms_bufferizer_put(&s->delayed_ref, refm);
+			ms_queue_put(f->outputs[0], dupmsg(refm));
+			if (!s->using_zeroes) {
+				ms_warning("Not enough ref samples, using zeroes");
+				s->using_zeroes = TRUE;
+			}
+		} else {
+			if (s->using_zeroes) {
+				ms_message("Samples are back.");
+				s->using_zeroes = FALSE;
+			}
+			refm = allocb((size_t)nbytes, 0); // :279-284
+			if (ms_bufferizer_read(&s->ref.base, refm->b_wptr, (size_t)nbytes) == 0) {
+				ms_error("Should never happen");
+				abort();
+			}
+			refm->b_wptr += nbytes;
+			ms_queue_put(f->outputs[0], refm);
+		}
+		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)ref, (size_t)nbytes) == 0) { // :288
+			ms_error("Should never happen");
+			abort();
+		}
+		p->staged[sl]++;
+	}
+	if (p->staged[sl]) request_flush(f);
+}
+
+int ec_set_sr(MSFilter *f, void *arg) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->samplerate = *(int *)arg;
+	ec_configure_flow(s);
+	return 0;
+}
+int ec_set_framesize(MSFilter *f, void *arg) {
+	((SpeexECState *)f->data)->framesize_at_8000 = *(int *)arg;
+	return 0;
+}
+int ec_set_delay(MSFilter *f, void *arg) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->delay_ms = *(int *)arg;
+	ec_configure_flow(s);
+	return 0;
+}
+int ec_set_tail_length(MSFilter *f, void *arg) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->tail_length_ms = *(int *)arg;
+	ec_configure_flow(s);
+	return 0;
+}
+int ec_set_bypass_mode(MSFilter *f, void *arg) {
+	((SpeexECState *)f->data)->bypass_mode = *(bool_t *)arg;
+	return 0;
+}
+int ec_get_bypass_mode(MSFilter *f, void *arg) {
+	*(bool_t *)arg = ((SpeexECState *)f->data)->bypass_mode;
+	return 0;
+}
+int ec_set_state(MSFilter *f, void *arg) { // :361-365
+	SpeexECState *s = (SpeexECState *)f->data;
+	const size_t n = strlen((const char *)arg) + 1;
+	s->state_str = (char *)ms_malloc0(n);
+	memcpy(s->state_str, arg, n);
+	return 0;
+}
+int ec_get_state(MSFilter *f, void *arg) { // :367-374
+	*(char **)arg = ((SpeexECState *)f->data)->state_str;
+	return 0;
+}
+int ec_get_delay(MSFilter *f, void *arg) {
+	*(int *)arg = ((SpeexECState *)f->data)->delay_ms;
+	return 0;
+}
+MSFilterMethod ec_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, ec_set_sr},
+                               {MS_ECHO_CANCELLER_SET_TAIL_LENGTH, ec_set_tail_length},
+                               {MS_ECHO_CANCELLER_SET_DELAY, ec_set_delay},
+                               {MS_ECHO_CANCELLER_SET_FRAMESIZE, ec_set_framesize},
+                               {MS_ECHO_CANCELLER_SET_BYPASS_MODE, ec_set_bypass_mode},
+                               {MS_ECHO_CANCELLER_GET_BYPASS_MODE, ec_get_bypass_mode},
+                               {MS_ECHO_CANCELLER_GET_STATE_STRING, ec_get_state},
+                               {MS_ECHO_CANCELLER_SET_STATE_STRING, ec_set_state},
+                               {MS_ECHO_CANCELLER_GET_DELAY, ec_get_delay},
+                               {0, NULL}};
+
+} // namespace
+
+extern "C" {
+
+// Descriptors: same ids, names, pin counts and flags as the reference's, plus
+// MS_FILTER_IS_HW_ACCELERATED (msfilter.h:142).  Writable statics: the factory mutates flags.
+MSFilterDesc ms_mi355x_resample_desc = {MS_RESAMPLE_ID, "MSResample", "Audio resampler (MI355X batch)", MS_FILTER_OTHER,
+                                        NULL, 1, 1, resample_init, NULL, resample_process, NULL, resample_uninit,
+                                        resample_methods, MS_FILTER_IS_HW_ACCELERATED};
+MSFilterDesc ms_mi355x_audio_mixer_desc = {MS_AUDIO_MIXER_ID, "MSAudioMixer",
+                                           "A filter that mixes down 16 bit sample audio streams (MI355X batch)",
+                                           MS_FILTER_OTHER, NULL, MIXER_MAX_CHANNELS, MIXER_MAX_CHANNELS, mixer_init,
+                                           mixer_preprocess, mixer_process, mixer_postprocess, mixer_uninit,
+                                           mixer_methods, MS_FILTER_IS_PUMP | MS_FILTER_IS_HW_ACCELERATED};
+MSFilterDesc ms_mi355x_volume_desc = {MS_VOLUME_ID, "MSVolume", "A filter that controls and measure sound volume (MI355X batch)",
+                                      MS_FILTER_OTHER, NULL, 1, 1, volume_init, volume_preprocess, volume_process, NULL,
+                                      volume_uninit, volume_methods, MS_FILTER_IS_HW_ACCELERATED};
+MSFilterDesc ms_mi355x_equalizer_desc = {MS_EQUALIZER_ID, "MSEqualizer", "Parametric sound equalizer (MI355X batch)",
+                                         MS_FILTER_OTHER, NULL, 1, 1, equalizer_init, equalizer_preprocess, equalizer_process, NULL,
+                                         equalizer_uninit, equalizer_methods, MS_FILTER_IS_HW_ACCELERATED};
+MSFilterDesc ms_mi355x_speex_ec_desc = {MS_SPEEX_EC_ID, "MSSpeexEC", "Echo canceller, MDF + post-filter (MI355X batch)",
+                                        MS_FILTER_OTHER, NULL, 2, 2, ec_init, ec_preprocess, ec_process, ec_postprocess,
+                                        ec_uninit, ec_methods, MS_FILTER_IS_HW_ACCELERATED};
+
+void libmsmi355xfilters_init(MSFactory *factory) {
+	ms_factory_register_filter(factory, &ms_mi355x_resample_desc);
+	ms_factory_register_filter(factory, &ms_mi355x_audio_mixer_desc);
+	ms_factory_register_filter(factory, &ms_mi355x_volume_desc);
+	ms_factory_register_filter(factory, &ms_mi355x_equalizer_desc);
+	ms_factory_register_filter(factory, &ms_mi355x_speex_ec_desc);
+	ms_message("libmsmi355xfilters: MI355X batched filters registered (ABI %d)", mi_abi_version());
+}
+
+void ms_mi355x_flush(void) { flush_ticker(nullptr); }
+
+void ms_mi355x_shutdown(void) {
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	// pools keep their device objects for the life of the process (like the reference's plugins,
+	// there is no unload hook: src/base/msfactory.c:761-771); only the context is synchronised here
+	if (g_hub.ctx) mi_ctx_sync(g_hub.ctx);
+}
+
+} // extern "C"

@@ -1,0 +1,584 @@
+/* ms2shim.c -- a small host runtime with mediastreamer2's plugin-facing API, so the
+ * MI355X filter plugin can be loaded, linked into graphs and ticked in this
+ * repository's tests exactly the way the reference's factory / ticker would do it
+ * (include/ms2_plugin_abi.h lists what is mirrored and from where).  Our own code:
+ * it restates the BEHAVIOUR of src/base/{msfactory,msfilter,msticker,msqueue}.c
+ * that the plugin depends on (registration order, first-match lookup, method
+ * dispatch, bufferizer all-or-nothing reads, graph execution order), nothing more.
+ * In a deployment the real libmediastreamer/oRTP provide these symbols instead.
+ */
+#define _GNU_SOURCE
+#include "../../include/ms2_plugin_abi.h"
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ misc */
+void *ms_malloc0(size_t sz) { return calloc(1, sz ? sz : 1); }
+void ms_free(void *p) { free(p); }
+
+static int g_verbose = -1;
+static void vlog(const char *lvl, const char *fmt, va_list ap) {
+	if (g_verbose < 0) g_verbose = getenv("MS2SHIM_VERBOSE") ? 1 : 0;
+	if (!g_verbose && lvl[0] == 'm') return;
+	fprintf(stderr, "ms2shim-%s: ", lvl);
+	vfprintf(stderr, fmt, ap);
+	fputc('\n', stderr);
+}
+void ms_message(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vlog("message", fmt, ap); va_end(ap); }
+void ms_warning(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vlog("warning", fmt, ap); va_end(ap); }
+void ms_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vlog("error", fmt, ap); va_end(ap); }
+
+/* ------------------------------------------------------------ mblk / queue */
+mblk_t *allocb(size_t size, int unused) {
+	(void)unused;
+	mblk_t *m = (mblk_t *)calloc(1, sizeof(mblk_t));
+	dblk_t *d = (dblk_t *)malloc(sizeof(dblk_t) + size);
+	d->db_base = (unsigned char *)(d + 1);
+	d->db_lim = d->db_base + size;
+	d->db_freefn = NULL;
+	d->db_ref = 1;
+	m->b_datap = d;
+	m->b_rptr = m->b_wptr = d->db_base;
+	return m;
+}
+
+void freeb(mblk_t *m) {
+	if (!m) return;
+	if (m->b_datap && --m->b_datap->db_ref == 0) free(m->b_datap);
+	free(m);
+}
+
+void freemsg(mblk_t *m) {
+	while (m) {
+		mblk_t *n = m->b_cont;
+		freeb(m);
+		m = n;
+	}
+}
+
+mblk_t *dupb(mblk_t *m) {
+	mblk_t *n = (mblk_t *)calloc(1, sizeof(mblk_t));
+	m->b_datap->db_ref++;
+	n->b_datap = m->b_datap;
+	n->b_rptr = m->b_rptr;
+	n->b_wptr = m->b_wptr;
+	mblk_meta_copy(m, n);
+	return n;
+}
+
+mblk_t *dupmsg(mblk_t *m) {
+	mblk_t *head = dupb(m), *tail = head;
+	for (m = m->b_cont; m; m = m->b_cont) {
+		tail->b_cont = dupb(m);
+		tail = tail->b_cont;
+	}
+	return head;
+}
+
+size_t msgdsize(const mblk_t *m) {
+	size_t n = 0;
+	for (; m; m = m->b_cont) n += (size_t)(m->b_wptr - m->b_rptr);
+	return n;
+}
+
+void mblk_meta_copy(const mblk_t *src, mblk_t *dst) {
+	dst->reserved1 = src->reserved1;
+	dst->reserved2 = src->reserved2;
+	dst->ttl_or_hl = src->ttl_or_hl;
+}
+
+void qinit(queue_t *q) {
+	memset(q, 0, sizeof(*q));
+	q->_q_stopper.b_next = &q->_q_stopper;
+	q->_q_stopper.b_prev = &q->_q_stopper;
+}
+
+void putq(queue_t *q, mblk_t *m) {
+	m->b_next = &q->_q_stopper;
+	m->b_prev = q->_q_stopper.b_prev;
+	q->_q_stopper.b_prev->b_next = m;
+	q->_q_stopper.b_prev = m;
+	q->q_mcount++;
+}
+
+mblk_t *getq(queue_t *q) {
+	mblk_t *m = q->_q_stopper.b_next;
+	if (m == &q->_q_stopper) return NULL;
+	q->_q_stopper.b_next = m->b_next;
+	m->b_next->b_prev = &q->_q_stopper;
+	m->b_next = m->b_prev = NULL;
+	q->q_mcount--;
+	return m;
+}
+
+mblk_t *peekq(queue_t *q) {
+	mblk_t *m = q->_q_stopper.b_next;
+	return m == &q->_q_stopper ? NULL : m;
+}
+
+void flushq(queue_t *q, int how) {
+	(void)how;
+	mblk_t *m;
+	while ((m = getq(q)) != NULL) freemsg(m);
+}
+
+void ms_queue_flush(MSQueue *q) { flushq(&q->q, 0); }
+
+/* --------------------------------------------------------------- bufferizer
+ * behaviour of src/base/msqueue.c:54-113: byte FIFO over mblks, read is all-or-nothing */
+void ms_bufferizer_init(MSBufferizer *obj) {
+	qinit(&obj->q);
+	obj->size = 0;
+}
+MSBufferizer *ms_bufferizer_new(void) {
+	MSBufferizer *b = (MSBufferizer *)ms_malloc0(sizeof(*b));
+	ms_bufferizer_init(b);
+	return b;
+}
+void ms_bufferizer_put(MSBufferizer *obj, mblk_t *m) {
+	obj->size += msgdsize(m);
+	putq(&obj->q, m);
+}
+void ms_bufferizer_put_from_queue(MSBufferizer *obj, MSQueue *q) {
+	mblk_t *m;
+	while ((m = ms_queue_get(q)) != NULL) ms_bufferizer_put(obj, m);
+}
+size_t ms_bufferizer_read(MSBufferizer *obj, uint8_t *data, size_t datalen) {
+	size_t done = 0;
+	if (datalen == 0 || obj->size < datalen) return 0;
+	mblk_t *m = peekq(&obj->q);
+	mblk_meta_copy(m, &obj->q._q_stopper);
+	while (done < datalen) {
+		size_t avail = (size_t)(m->b_wptr - m->b_rptr);
+		size_t n = avail < datalen - done ? avail : datalen - done;
+		if (data) memcpy(data + done, m->b_rptr, n);
+		done += n;
+		m->b_rptr += n;
+		if (m->b_rptr == m->b_wptr) {
+			if (m->b_cont) {
+				m = m->b_cont;
+			} else {
+				freemsg(getq(&obj->q));
+				m = peekq(&obj->q);
+			}
+		}
+	}
+	obj->size -= datalen;
+	return datalen;
+}
+void ms_bufferizer_skip_bytes(MSBufferizer *obj, int bytes) { ms_bufferizer_read(obj, NULL, (size_t)bytes); }
+void ms_bufferizer_flush(MSBufferizer *obj) {
+	obj->size = 0;
+	flushq(&obj->q, 0);
+}
+void ms_bufferizer_uninit(MSBufferizer *obj) { flushq(&obj->q, 0); }
+void ms_bufferizer_destroy(MSBufferizer *obj) {
+	ms_bufferizer_uninit(obj);
+	ms_free(obj);
+}
+
+/* ------------------------------------------------------------------ factory */
+typedef struct DescNode {
+	MSFilterDesc *desc;
+	struct DescNode *next;
+} DescNode;
+
+struct _MSFactory {
+	DescNode *descs; /* most recently registered FIRST (msfactory.c:281) */
+	void *plugins[16];
+	int nplugins;
+};
+
+MSFactory *ms_factory_new(void) { return (MSFactory *)ms_malloc0(sizeof(MSFactory)); }
+
+void ms_factory_destroy(MSFactory *f) {
+	if (!f) return;
+	while (f->descs) {
+		DescNode *n = f->descs->next;
+		free(f->descs);
+		f->descs = n;
+	}
+	/* plugins stay mapped: like the reference there is no uninit hook on Unix (msfactory.c:761-771) */
+	free(f);
+}
+
+void ms_factory_register_filter(MSFactory *f, MSFilterDesc *desc) {
+	if (desc->id == MS_FILTER_NOT_SET_ID) {
+		ms_error("MSFilterId for %s not set !", desc->name);
+		abort(); /* ms_fatal, msfactory.c:260-262 */
+	}
+	desc->flags |= MS_FILTER_IS_ENABLED;
+	DescNode *n = (DescNode *)malloc(sizeof(*n));
+	n->desc = desc;
+	n->next = f->descs;
+	f->descs = n;
+}
+
+MSFilterDesc *ms_factory_lookup_filter_by_id(MSFactory *f, MSFilterId id) {
+	for (DescNode *n = f->descs; n; n = n->next)
+		if (n->desc->id == id) return n->desc;
+	return NULL;
+}
+
+MSFilterDesc *ms_factory_lookup_filter_by_name(MSFactory *f, const char *name) {
+	for (DescNode *n = f->descs; n; n = n->next)
+		if (strcmp(n->desc->name, name) == 0) return n->desc;
+	return NULL;
+}
+
+int ms_factory_load_plugin(MSFactory *f, const char *path) {
+	void *h = dlopen(path, RTLD_NOW);
+	if (!h) {
+		ms_error("ms_factory_load_plugin: %s", dlerror());
+		return -1;
+	}
+	const char *base = strrchr(path, '/');
+	base = base ? base + 1 : path;
+	char sym[256];
+	snprintf(sym, sizeof(sym), "%s", base);
+	char *dot = strstr(sym, ".so");
+	if (dot) *dot = 0;
+	strncat(sym, "_init", sizeof(sym) - strlen(sym) - 1);
+	void (*init)(MSFactory *) = (void (*)(MSFactory *))dlsym(h, sym);
+	if (!init) {
+		ms_error("plugin %s lacks %s()", path, sym);
+		dlclose(h);
+		return -1;
+	}
+	init(f);
+	if (f->nplugins < 16) f->plugins[f->nplugins++] = h;
+	return 0;
+}
+
+MSFilter *ms_factory_create_filter(MSFactory *fac, MSFilterId id) {
+	if (id == MS_FILTER_PLUGIN_ID) return NULL; /* msfactory.c:419-422 */
+	MSFilterDesc *d = ms_factory_lookup_filter_by_id(fac, id);
+	if (!d) {
+		ms_error("No such filter with id %i", (int)id);
+		return NULL;
+	}
+	MSFilter *f = (MSFilter *)ms_malloc0(sizeof(MSFilter));
+	pthread_mutex_init(&f->lock, NULL);
+	f->desc = d;
+	f->factory = fac;
+	if (d->ninputs > 0) f->inputs = (MSQueue **)ms_malloc0(sizeof(MSQueue *) * (size_t)d->ninputs);
+	if (d->noutputs > 0) f->outputs = (MSQueue **)ms_malloc0(sizeof(MSQueue *) * (size_t)d->noutputs);
+	if (d->init) d->init(f);
+	return f;
+}
+
+/* ------------------------------------------------------------------- filter */
+typedef struct Notify {
+	MSFilterNotifyFunc fn;
+	void *ud;
+	struct Notify *next;
+} Notify;
+
+void ms_filter_destroy(MSFilter *f) {
+	if (!f) return;
+	if (f->desc->uninit) f->desc->uninit(f);
+	for (Notify *n = (Notify *)f->notify_callbacks; n;) {
+		Notify *nx = n->next;
+		free(n);
+		n = nx;
+	}
+	free(f->inputs);
+	free(f->outputs);
+	pthread_mutex_destroy(&f->lock);
+	free(f);
+}
+
+int ms_filter_link(MSFilter *f1, int pin1, MSFilter *f2, int pin2) {
+	if (pin1 >= f1->desc->noutputs || pin2 >= f2->desc->ninputs) return -1;
+	if (f1->outputs[pin1] || f2->inputs[pin2]) return -1;
+	MSQueue *q = (MSQueue *)ms_malloc0(sizeof(MSQueue));
+	qinit(&q->q);
+	q->prev.filter = f1;
+	q->prev.pin = pin1;
+	q->next.filter = f2;
+	q->next.pin = pin2;
+	f1->outputs[pin1] = q;
+	f2->inputs[pin2] = q;
+	f1->n_connected_outputs++;
+	f2->n_connected_inputs++;
+	return 0;
+}
+
+int ms_filter_unlink(MSFilter *f1, int pin1, MSFilter *f2, int pin2) {
+	MSQueue *q = f1->outputs[pin1];
+	if (!q || q != f2->inputs[pin2]) return -1;
+	f1->outputs[pin1] = NULL;
+	f2->inputs[pin2] = NULL;
+	f1->n_connected_outputs--;
+	f2->n_connected_inputs--;
+	flushq(&q->q, 0);
+	free(q);
+	return 0;
+}
+
+int ms_filter_call_method(MSFilter *f, unsigned int id, void *arg) {
+	/* msfilter.c:171-197: the method's owner must be this filter, the base id or an interface */
+	unsigned int magic = id >> 16;
+	if (magic != (unsigned int)f->desc->id && magic != MS_FILTER_BASE_ID && magic <= MSFilterInterfaceBegin) {
+		ms_error("Method type checking failed when calling %u on filter %s", id, f->desc->name);
+		abort();
+	}
+	MSFilterMethod *m = f->desc->methods;
+	for (; m && m->method; ++m)
+		if (m->id == id) return m->method(f, arg);
+	if (magic != MS_FILTER_BASE_ID) ms_error("no such method on filter %s, fid=%u method index=%u", f->desc->name, magic, (id >> 8) & 0xff);
+	return -1;
+}
+
+void ms_filter_add_notify_callback(MSFilter *f, MSFilterNotifyFunc fn, void *ud, bool_t synchronous) {
+	(void)synchronous;
+	Notify *n = (Notify *)malloc(sizeof(*n));
+	n->fn = fn;
+	n->ud = ud;
+	n->next = (Notify *)f->notify_callbacks;
+	f->notify_callbacks = n;
+}
+
+void ms_filter_notify(MSFilter *f, unsigned int id, void *arg) {
+	for (Notify *n = (Notify *)f->notify_callbacks; n; n = n->next) n->fn(n->ud, f, id, arg);
+}
+
+/* ------------------------------------------------------------------- ticker */
+typedef struct Task {
+	MSFilter *f;
+	MSFilterFunc fn;
+	struct Task *next;
+} Task;
+
+typedef struct TickerImpl {
+	MSFilter *filters[4096]; /* every filter of the attached graphs */
+	int nfilters;
+	Task *tasks;
+} TickerImpl;
+
+MSTicker *ms_ticker_new(void) {
+	MSTicker *t = (MSTicker *)ms_malloc0(sizeof(*t));
+	t->interval = 10; /* TICKER_INTERVAL msticker.c:46 */
+	t->impl = ms_malloc0(sizeof(TickerImpl));
+	return t;
+}
+
+void ms_ticker_destroy(MSTicker *t) {
+	if (!t) return;
+	TickerImpl *ti = (TickerImpl *)t->impl;
+	while (ti->tasks) {
+		Task *n = ti->tasks->next;
+		free(ti->tasks);
+		ti->tasks = n;
+	}
+	free(ti);
+	free(t);
+}
+
+static void find_neighbours(MSFilter *f, TickerImpl *ti) { /* msfilter.c:303-344 */
+	if (f->seen) return;
+	f->seen = TRUE;
+	if (ti->nfilters < 4096) ti->filters[ti->nfilters++] = f;
+	for (int i = 0; i < f->desc->ninputs; ++i)
+		if (f->inputs[i]) find_neighbours(f->inputs[i]->prev.filter, ti);
+	for (int i = 0; i < f->desc->noutputs; ++i)
+		if (f->outputs[i]) find_neighbours(f->outputs[i]->next.filter, ti);
+}
+
+int ms_ticker_attach(MSTicker *t, MSFilter *f) {
+	TickerImpl *ti = (TickerImpl *)t->impl;
+	int first = ti->nfilters;
+	find_neighbours(f, ti);
+	for (int i = first; i < ti->nfilters; ++i) {
+		MSFilter *g = ti->filters[i];
+		g->ticker = t;
+		g->last_tick = 0;
+		if (g->desc->preprocess) g->desc->preprocess(g);
+	}
+	return 0;
+}
+
+int ms_ticker_detach(MSTicker *t, MSFilter *f) {
+	TickerImpl *ti = (TickerImpl *)t->impl;
+	/* detach the whole connected graph of f */
+	TickerImpl tmp;
+	memset(&tmp, 0, sizeof(tmp));
+	for (int i = 0; i < ti->nfilters; ++i) ti->filters[i]->seen = FALSE;
+	find_neighbours(f, &tmp);
+	for (int i = 0; i < tmp.nfilters; ++i) {
+		MSFilter *g = tmp.filters[i];
+		if (g->desc->postprocess) g->desc->postprocess(g);
+		g->ticker = NULL;
+		g->seen = FALSE;
+		for (int k = 0; k < ti->nfilters; ++k)
+			if (ti->filters[k] == g) {
+				ti->filters[k] = ti->filters[--ti->nfilters];
+				break;
+			}
+	}
+	for (int i = 0; i < ti->nfilters; ++i) ti->filters[i]->seen = TRUE;
+	return 0;
+}
+
+void ms_filter_postpone_task(MSFilter *f, MSFilterFunc task) {
+	if (!f->ticker) return;
+	TickerImpl *ti = (TickerImpl *)f->ticker->impl;
+	Task *t = (Task *)malloc(sizeof(*t));
+	t->f = f;
+	t->fn = task;
+	t->next = NULL;
+	Task **pp = &ti->tasks;
+	while (*pp) pp = &(*pp)->next;
+	*pp = t;
+	f->postponed_task++;
+}
+
+static int inputs_have_data(MSFilter *f) {
+	for (int i = 0; i < f->desc->ninputs; ++i)
+		if (f->inputs[i] && !ms_queue_empty(f->inputs[i])) return 1;
+	return 0;
+}
+
+static int can_process(MSFilter *f, uint32_t tick) { /* msticker.c:230-242 */
+	for (int i = 0; i < f->desc->ninputs; ++i)
+		if (f->inputs[i] && f->inputs[i]->prev.filter->last_tick != tick) return 0;
+	return 1;
+}
+
+static void call_process(MSFilter *f) { /* msticker.c:244-259 */
+	if (f->desc->ninputs == 0 || (f->desc->flags & MS_FILTER_IS_PUMP)) {
+		f->desc->process(f);
+	} else {
+		while (inputs_have_data(f)) {
+			f->desc->process(f);
+			if (f->postponed_task) break;
+		}
+	}
+}
+
+static void run_graph(MSFilter *f, MSTicker *t, MSFilter **unsched, int *nunsched, int force) { /* :261-282 */
+	if (f->last_tick == t->ticks) return;
+	if (can_process(f, t->ticks) || force) {
+		f->last_tick = t->ticks;
+		call_process(f);
+		for (int i = 0; i < f->desc->noutputs; ++i)
+			if (f->outputs[i]) run_graph(f->outputs[i]->next.filter, t, unsched, nunsched, force);
+	} else if (*nunsched < 256) {
+		unsched[(*nunsched)++] = f;
+	}
+}
+
+void ms_ticker_step(MSTicker *t) {
+	TickerImpl *ti = (TickerImpl *)t->impl;
+	MSFilter *unsched[256];
+	int nunsched = 0;
+	t->ticks++;
+	/* run_tasks msticker.c:301-312: postponed tasks run before the graphs */
+	Task *tasks = ti->tasks;
+	ti->tasks = NULL;
+	while (tasks) {
+		Task *n = tasks->next;
+		tasks->f->postponed_task--;
+		tasks->fn(tasks->f);
+		free(tasks);
+		tasks = n;
+	}
+	for (int i = 0; i < ti->nfilters; ++i)
+		if (ti->filters[i]->desc->ninputs == 0) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
+	/* filters inside loops: scheduled anyway on a second pass (msticker.c:284-299) */
+	for (int i = 0, n = nunsched, dummy = 0; i < n; ++i) run_graph(unsched[i], t, unsched, &dummy, 1);
+	t->time += (uint64_t)t->interval;
+}
+
+/* -------------------------------------------------- test source / sink filters
+ * (the role MS_VOID_SOURCE / file player / recorder play in the reference's testers) */
+#define SHIM_SOURCE_ID ((MSFilterId)9001)
+#define SHIM_SINK_ID ((MSFilterId)9002)
+
+typedef struct {
+	queue_t pending; /* blocks the test queued; one is emitted per tick */
+} SrcData;
+typedef struct {
+	uint8_t *buf;
+	size_t len, cap;
+	int nblocks;
+	uint32_t last_ts;
+} SinkData;
+
+static void src_init(MSFilter *f) {
+	SrcData *d = (SrcData *)ms_malloc0(sizeof(*d));
+	qinit(&d->pending);
+	f->data = d;
+}
+static void src_uninit(MSFilter *f) {
+	SrcData *d = (SrcData *)f->data;
+	flushq(&d->pending, 0);
+	free(d);
+}
+static void src_process(MSFilter *f) {
+	SrcData *d = (SrcData *)f->data;
+	mblk_t *m = getq(&d->pending);
+	if (m && f->outputs[0]) ms_queue_put(f->outputs[0], m);
+	else if (m) freemsg(m);
+}
+static void sink_init(MSFilter *f) { f->data = ms_malloc0(sizeof(SinkData)); }
+static void sink_uninit(MSFilter *f) {
+	SinkData *d = (SinkData *)f->data;
+	free(d->buf);
+	free(d);
+}
+static void sink_process(MSFilter *f) {
+	SinkData *d = (SinkData *)f->data;
+	mblk_t *m;
+	while ((m = ms_queue_get(f->inputs[0])) != NULL) {
+		size_t n = msgdsize(m);
+		if (d->len + n > d->cap) {
+			d->cap = (d->len + n) * 2 + 4096;
+			d->buf = (uint8_t *)realloc(d->buf, d->cap);
+		}
+		for (mblk_t *c = m; c; c = c->b_cont) {
+			memcpy(d->buf + d->len, c->b_rptr, (size_t)(c->b_wptr - c->b_rptr));
+			d->len += (size_t)(c->b_wptr - c->b_rptr);
+		}
+		d->last_ts = mblk_get_timestamp_info(m);
+		d->nblocks++;
+		freemsg(m);
+	}
+}
+
+static MSFilterDesc shim_source_desc = {SHIM_SOURCE_ID, "ShimSource", "test source", MS_FILTER_OTHER, NULL, 0, 1,
+                                        src_init, NULL, src_process, NULL, src_uninit, NULL, 0};
+static MSFilterDesc shim_sink_desc = {SHIM_SINK_ID, "ShimSink", "test sink", MS_FILTER_OTHER, NULL, 1, 0,
+                                      sink_init, NULL, sink_process, NULL, sink_uninit, NULL, 0};
+
+void ms2shim_register_test_filters(MSFactory *f) {
+	ms_factory_register_filter(f, &shim_source_desc);
+	ms_factory_register_filter(f, &shim_sink_desc);
+}
+MSFilter *ms2shim_new_source(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SOURCE_ID); }
+MSFilter *ms2shim_new_sink(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SINK_ID); }
+void ms2shim_source_push(MSFilter *src, const void *data, size_t nbytes) {
+	SrcData *d = (SrcData *)src->data;
+	mblk_t *m = allocb(nbytes, 0);
+	memcpy(m->b_wptr, data, nbytes);
+	m->b_wptr += nbytes;
+	putq(&d->pending, m);
+}
+size_t ms2shim_sink_size(MSFilter *sink) { return ((SinkData *)sink->data)->len; }
+int ms2shim_sink_blocks(MSFilter *sink) { return ((SinkData *)sink->data)->nblocks; }
+uint32_t ms2shim_sink_last_ts(MSFilter *sink) { return ((SinkData *)sink->data)->last_ts; }
+size_t ms2shim_sink_read(MSFilter *sink, void *dst, size_t cap) {
+	SinkData *d = (SinkData *)sink->data;
+	size_t n = d->len < cap ? d->len : cap;
+	memcpy(dst, d->buf, n);
+	memmove(d->buf, d->buf + n, d->len - n);
+	d->len -= n;
+	return n;
+}
+const char *ms2shim_filter_name(MSFilter *f) { return f->desc->name; }
+unsigned ms2shim_filter_flags(MSFilter *f) { return f->desc->flags; }
+unsigned ms2shim_method_id(int filter_id, int index, int argsize) { return MS_FILTER_METHOD_ID(filter_id, index, argsize); }

@@ -1,0 +1,292 @@
+"""Drop-in boundary on the GPU: the plugin library libmsmi355xfilters.so is loaded through a
+factory the way src/base/msfactory.c:531-586 loads plugins, its descriptors take over the
+reference's MS_*_ID (registration prepends, lookup is first-match), and graphs of
+source -> filter -> sink run tick by tick like the reference's testers build them
+(tester/mediastreamer2_basic_audio_tester.c, tester/mediastreamer2_aec3_tester.c).
+Outputs are compared with the CPU oracle; the only intended difference is the one-tick
+pipeline delay of the batched filters."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "mediastreamer2_amd")
+
+MS_FILTER_BASE_ID, MS_SPEEX_EC_ID, MS_RESAMPLE_ID, MS_VOLUME_ID, MS_EQUALIZER_ID, MS_AUDIO_MIXER_ID = 2, 28, 41, 43, 61, 68
+EC_IFACE = 16384 + 4
+MS_FILTER_IS_PUMP, MS_FILTER_IS_HW_ACCELERATED = 1, 2
+
+
+def mid(fid, idx, argsize):
+    return ((fid & 0xFFFF) << 16) | (idx << 8) | (argsize & 0xFF)
+
+
+SET_SAMPLE_RATE = mid(MS_FILTER_BASE_ID, 0, 4)
+SET_OUTPUT_SAMPLE_RATE = mid(MS_FILTER_BASE_ID, 13, 4)
+SET_NCHANNELS = mid(MS_FILTER_BASE_ID, 6, 4)
+
+
+class MixerCtl(C.Structure):
+    _fields_ = [("pin", C.c_int), ("param", C.c_float)]
+
+
+class EqGain(C.Structure):
+    _fields_ = [("frequency", C.c_float), ("gain", C.c_float), ("width", C.c_float)]
+
+
+class Host:
+    """ctypes view of the shim runtime (mediastreamer2_amd/host/ms2shim.c)."""
+
+    def __init__(self):
+        import torch  # noqa: F401  (one HIP runtime per process, see mediastreamer2_amd/_lib.py)
+        self.S = C.CDLL(os.path.join(PKG, "libms2shim.so"), mode=C.RTLD_GLOBAL)
+        S = self.S
+        vp = C.c_void_p
+        S.ms_factory_new.restype = vp
+        S.ms_factory_create_filter.restype = vp
+        S.ms_factory_create_filter.argtypes = [vp, C.c_int]
+        S.ms_factory_load_plugin.argtypes = [vp, C.c_char_p]
+        S.ms_factory_lookup_filter_by_id.restype = vp
+        S.ms_factory_lookup_filter_by_id.argtypes = [vp, C.c_int]
+        S.ms2shim_register_test_filters.argtypes = [vp]
+        S.ms2shim_new_source.restype = vp
+        S.ms2shim_new_source.argtypes = [vp]
+        S.ms2shim_new_sink.restype = vp
+        S.ms2shim_new_sink.argtypes = [vp]
+        S.ms2shim_source_push.argtypes = [vp, vp, C.c_size_t]
+        S.ms2shim_sink_read.restype = C.c_size_t
+        S.ms2shim_sink_read.argtypes = [vp, vp, C.c_size_t]
+        S.ms2shim_sink_size.restype = C.c_size_t
+        S.ms2shim_sink_size.argtypes = [vp]
+        S.ms2shim_sink_blocks.argtypes = [vp]
+        S.ms2shim_filter_name.restype = C.c_char_p
+        S.ms2shim_filter_name.argtypes = [vp]
+        S.ms2shim_filter_flags.restype = C.c_uint
+        S.ms2shim_filter_flags.argtypes = [vp]
+        S.ms_filter_link.argtypes = [vp, C.c_int, vp, C.c_int]
+        S.ms_filter_call_method.argtypes = [vp, C.c_uint, vp]
+        S.ms_filter_destroy.argtypes = [vp]
+        S.ms_ticker_new.restype = vp
+        S.ms_ticker_attach.argtypes = [vp, vp]
+        S.ms_ticker_detach.argtypes = [vp, vp]
+        S.ms_ticker_step.argtypes = [vp]
+        S.ms_ticker_destroy.argtypes = [vp]
+        self.fac = S.ms_factory_new()
+        S.ms2shim_register_test_filters(self.fac)
+        assert S.ms_factory_load_plugin(self.fac, os.path.join(PKG, "libmsmi355xfilters.so").encode()) == 0
+        self.ticker = S.ms_ticker_new()
+
+    def create(self, fid):
+        f = self.S.ms_factory_create_filter(self.fac, fid)
+        assert f
+        return f
+
+    def source(self):
+        return self.S.ms2shim_new_source(self.fac)
+
+    def sink(self):
+        return self.S.ms2shim_new_sink(self.fac)
+
+    def link(self, a, pa, b, pb):
+        assert self.S.ms_filter_link(a, pa, b, pb) == 0
+
+    def call_int(self, f, method, val):
+        v = C.c_int(val)
+        return self.S.ms_filter_call_method(f, method, C.byref(v))
+
+    def call(self, f, method, obj):
+        return self.S.ms_filter_call_method(f, method, C.byref(obj))
+
+    def push(self, src, samples):
+        a = np.ascontiguousarray(samples, np.int16)
+        self.S.ms2shim_source_push(src, a.ctypes.data, a.nbytes)
+
+    def drain(self, sink):
+        n = self.S.ms2shim_sink_size(sink)
+        buf = np.zeros(n // 2, np.int16)
+        if n:
+            self.S.ms2shim_sink_read(sink, buf.ctypes.data, n)
+        return buf
+
+    def step(self, n=1):
+        for _ in range(n):
+            self.S.ms_ticker_step(self.ticker)
+
+
+@pytest.fixture(scope="module")
+def host():
+    return Host()
+
+
+def test_plugin_overrides_reference_ids(host):
+    """msfactory.c:281 + :440-450: the plugin's descriptors win the lookup by id."""
+    for fid, name, pump in ((MS_RESAMPLE_ID, b"MSResample", 0), (MS_VOLUME_ID, b"MSVolume", 0),
+                            (MS_EQUALIZER_ID, b"MSEqualizer", 0), (MS_AUDIO_MIXER_ID, b"MSAudioMixer", 1),
+                            (MS_SPEEX_EC_ID, b"MSSpeexEC", 0)):
+        f = host.create(fid)
+        assert host.S.ms2shim_filter_name(f) == name
+        flags = host.S.ms2shim_filter_flags(f)
+        assert flags & MS_FILTER_IS_HW_ACCELERATED
+        assert bool(flags & MS_FILTER_IS_PUMP) == bool(pump)
+        host.S.ms_filter_destroy(f)
+
+
+def test_resample_graph_matches_oracle(host, oracle):
+    """source(16 kHz, 160 samples/tick) -> MSResample -> sink, configured through the reference's
+    methods (msresample.c:229-233)."""
+    src, rs, snk = host.source(), host.create(MS_RESAMPLE_ID), host.sink()
+    assert host.call_int(rs, SET_SAMPLE_RATE, 16000) == 0
+    assert host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 48000) == 0
+    host.link(src, 0, rs, 0)
+    host.link(rs, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    nt = 25
+    x = synth_pcm(1, 160 * nt, rate=16000)
+    for t in range(nt):
+        host.push(src, x[t * 160:(t + 1) * 160])
+    host.step(nt + 2)
+    got = host.drain(snk)
+    o = oracle.Resampler(16000, 48000)
+    ref = np.concatenate([o.process(x[t * 160:(t + 1) * 160]) for t in range(nt)])
+    assert len(got) == len(ref) == 480 * nt
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+    assert host.S.ms2shim_sink_blocks(snk) == nt
+    host.S.ms_ticker_detach(host.ticker, src)
+
+
+def test_volume_agc_graph_bit_exact(host, oracle):
+    src, vol, snk = host.source(), host.create(MS_VOLUME_ID), host.sink()
+    assert host.call_int(vol, SET_SAMPLE_RATE, 48000) == 0
+    assert host.call_int(vol, mid(MS_VOLUME_ID, 8, 4), 1) == 0  # MS_VOLUME_ENABLE_AGC
+    g = C.c_float(0.8)
+    assert host.call(vol, mid(MS_VOLUME_ID, 2, 4), g) == 0       # MS_VOLUME_SET_GAIN
+    host.link(src, 0, vol, 0)
+    host.link(vol, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    nt = 20
+    x = synth_pcm(2, 480 * nt, sigma=5000.0)
+    for t in range(nt):
+        host.push(src, x[t * 480:(t + 1) * 480])
+    host.step(nt + 2)
+    got = host.drain(snk)
+    o = oracle.Volume(48000)
+    o.v.agc_enabled = 1
+    oracle.lib().orc_volume_set_gain(o.v, 0.8)
+    ref = np.concatenate([o.chunk(x[t * 480:(t + 1) * 480]) for t in range(nt)])
+    np.testing.assert_array_equal(got, ref)
+    lin = C.c_float()
+    assert host.call(vol, mid(MS_VOLUME_ID, 1, 4), lin) == 0      # MS_VOLUME_GET_LINEAR
+    assert np.float32(lin.value) == np.float32(o.v.energy)
+    host.S.ms_ticker_detach(host.ticker, src)
+
+
+def test_equalizer_graph_bit_exact(host, oracle):
+    src, eq, snk = host.source(), host.create(MS_EQUALIZER_ID), host.sink()
+    assert host.call_int(eq, SET_SAMPLE_RATE, 16000) == 0           # rate first, gains after
+    assert host.call(eq, mid(MS_EQUALIZER_ID, 0, 12), EqGain(1000.0, 2.0, 500.0)) == 0
+    n = C.c_int()
+    assert host.call(eq, mid(MS_EQUALIZER_ID, 4, 4), n) == 0 and n.value == 128
+    host.link(src, 0, eq, 0)
+    host.link(eq, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    nt = 12
+    x = synth_pcm(3, 160 * nt, sigma=2500.0, rate=16000)
+    for t in range(nt):
+        host.push(src, x[t * 160:(t + 1) * 160])
+    host.step(nt + 2)
+    got = host.drain(snk)
+    o = oracle.Equalizer(16000)
+    o.set_gain(1000, 2.0, 500)
+    ref = np.concatenate([o.run(x[t * 160:(t + 1) * 160]) for t in range(nt)])
+    np.testing.assert_array_equal(got, ref)
+    host.S.ms_ticker_detach(host.ticker, src)
+
+
+def test_conference_mixer_graph_bit_exact(host, oracle):
+    """4 members on pins 0..3 of one MSAudioMixer in conference mode (audioconference.c:67-92)."""
+    mx = host.create(MS_AUDIO_MIXER_ID)
+    assert host.call_int(mx, SET_SAMPLE_RATE, 16000) == 0
+    assert host.call_int(mx, SET_NCHANNELS, 1) == 0
+    assert host.call_int(mx, mid(MS_AUDIO_MIXER_ID, 2, 4), 1) == 0       # ENABLE_CONFERENCE_MODE
+    ctl = MixerCtl(2, 0.5)
+    assert host.call(mx, mid(MS_AUDIO_MIXER_ID, 0, 8), ctl) == 0          # SET_INPUT_GAIN pin 2
+    bad = MixerCtl(77, 1.0)
+    assert host.call(mx, mid(MS_AUDIO_MIXER_ID, 0, 8), bad) == -1         # invalid pin -> -1 (audiomixer.c:375-378)
+    nm = 4
+    srcs, snks = [host.source() for _ in range(nm)], [host.sink() for _ in range(nm)]
+    for i in range(nm):
+        host.link(srcs[i], 0, mx, i)
+        host.link(mx, i, snks[i], 0)
+    host.S.ms_ticker_attach(host.ticker, mx)
+    nt, ns = 15, 160
+    x = np.stack([synth_pcm(10 + i, ns * nt, sigma=9000.0, rate=16000) for i in range(nm)])
+    for t in range(nt):
+        for i in range(nm):
+            host.push(srcs[i], x[i, t * ns:(t + 1) * ns])
+    host.step(nt + 2)
+    gain = np.array([1, 1, 0.5, 1], np.float32)
+    ref = np.concatenate([oracle.mixer_tick(x[:, t * ns:(t + 1) * ns], gain=gain)[0] for t in range(nt)], axis=1)
+    for i in range(nm):
+        got = host.drain(snks[i])
+        # ALWAYS_STREAMOUT: the pump also mixes the (silent) ticks after the sources ran dry
+        np.testing.assert_array_equal(got[:ns * nt], ref[i])
+        assert (got[ns * nt:] == 0).all()
+    host.S.ms_ticker_detach(host.ticker, mx)
+
+
+def test_speex_ec_graph_matches_oracle(host, oracle):
+    """ref + mic sources -> MSSpeexEC -> sinks, 16 kHz, tail 128 ms: the framing of speexec.c:223-305
+    (128-sample frames out of 160-sample ticks, zero injection while the reference is short) plus the
+    canceller and post-filter, compared with the same framing driven through the oracle."""
+    ec = host.create(MS_SPEEX_EC_ID)
+    assert host.call_int(ec, SET_SAMPLE_RATE, 16000) == 0
+    assert host.call_int(ec, mid(EC_IFACE, 2, 4), 128) == 0   # SET_TAIL_LENGTH
+    assert host.call_int(ec, mid(EC_IFACE, 0, 4), 0) == 0     # SET_DELAY
+    d = C.c_int(-1)
+    assert host.call(ec, mid(EC_IFACE, 7, 4), d) == 0 and d.value == 0
+    s_ref, s_mic, k_ref, k_mic = host.source(), host.source(), host.sink(), host.sink()
+    host.link(s_ref, 0, ec, 0)
+    host.link(s_mic, 0, ec, 1)
+    host.link(ec, 0, k_ref, 0)
+    host.link(ec, 1, k_mic, 0)
+    host.S.ms_ticker_attach(host.ticker, ec)
+    rate, F, nt, ns = 16000, 128, 40, 160
+    rng = np.random.default_rng(5)
+    far = np.clip(np.round(rng.normal(0, 3000, ns * nt)), -32767, 32767).astype(np.int16)
+    ir = rng.normal(0, 1, 48) * np.exp(-np.arange(48) / 10.0)
+    mic = np.clip(np.round(0.4 * np.convolve(far.astype(float), ir)[:ns * nt] + rng.normal(0, 50, ns * nt)),
+                  -32767, 32767).astype(np.int16)
+    for t in range(nt):
+        host.push(s_ref, far[t * ns:(t + 1) * ns])
+        host.push(s_mic, mic[t * ns:(t + 1) * ns])
+    host.step(nt + 3)
+    got = host.drain(k_mic)
+    ref_out = host.drain(k_ref)
+    # oracle-side restatement of the same framing
+    e = oracle.Echo(F, 128 * rate // 1000, rate)
+    pp = oracle.Preproc(F, rate, e)
+    echo_fifo, dref_fifo = np.zeros(0, np.int16), np.zeros(0, np.int16)
+    started, outs = False, []
+    for t in range(nt):
+        if started:
+            dref_fifo = np.concatenate([dref_fifo, far[t * ns:(t + 1) * ns]])
+        echo_fifo = np.concatenate([echo_fifo, mic[t * ns:(t + 1) * ns]])
+        while len(echo_fifo) >= F:
+            fr, echo_fifo = echo_fifo[:F], echo_fifo[F:]
+            started = True
+            if len(dref_fifo) < F:
+                dref_fifo = np.concatenate([dref_fifo, np.zeros(F, np.int16)])
+            r, dref_fifo = dref_fifo[:F], dref_fifo[F:]
+            outs.append(pp.run(e.cancel(fr, r)))
+    ref = np.concatenate(outs)
+    assert len(got) == len(ref)
+    d = got.astype(np.float64) - ref.astype(np.float64)
+    assert np.sqrt(np.mean(d ** 2)) / 32768.0 <= 1e-4
+    assert len(ref_out) == len(ref)   # one reference frame goes to the speaker per processed frame
+    host.S.ms_ticker_detach(host.ticker, ec)
