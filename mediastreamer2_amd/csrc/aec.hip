@@ -10,9 +10,9 @@
 // adaptive per-bin step size; then the Ephraim-Malah style post-filter with the
 // residual-echo estimate of the echo state.
 //
-// Mapping (MI355X-first, not how the CPU code is laid out):
-//   * one workgroup per stream, one lane per complex bin (frame = 256 lanes at
-//     48 kHz); all per-bin state lives in registers for the frame;
+// Mapping (MI355X-first, not how the CPU code is laid out; kernels in aec_wave.hpp):
+//   * one 64-lane wavefront per stream, each lane owning F/64 consecutive bins and time
+//     samples in registers (no workgroup barriers; the FFT is the only cross-lane exchange);
 //   * the far-end spectral history X is a RING in HBM (no (M+1)*N memmove per
 //     frame) and every spectrum is stored bin-interleaved ([DC,Nyq],[re1,im1],..)
 //     so each lane does one aligned 8-byte access per block, 2 KB contiguous
@@ -112,24 +112,6 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
 	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int F>
-struct Lds {
-	float fin[F];      // raw mic as float
-	float v[F];        // notch output
-	float input[F];    // pre-emphasised mic
-	float tbuf[2 * F]; // time-domain exchange
-	float2 zbuf[F];    // complex FFT work
-	float spec[2 * F]; // bin-interleaved spectrum exchange
-	float efg[F], ybg[F], e1[F], e2[F];
-	float2 tw[F], super[F];
-	uint16_t perm[F];
-	float prop[64];
-	float red[64];
-	float band[4 * NB_BANDS + 8]; // band-domain scratch (post-filter)
-	float wn[64 * 4];             // per-block, per-wave partial weight norms
-	int flag[4];
-};
-
 // kiss_fft factorisation (4s first, then 2), stages listed deepest first:
 // F=256: radix 4,4,4,4 with m = 1,4,16,64;  F=128: radix 2 (m=1) then 4,4,4 with m = 2,8,32.
 __host__ __device__ constexpr int plan_p(int F, int s) { return (F == 128 && s == 0) ? 2 : 4; }
@@ -138,166 +120,9 @@ __host__ __device__ constexpr int plan_m(int F, int s) {
 }
 __host__ __device__ constexpr int plan_fs(int F, int s) { return s == 0 ? 64 : (s == 1 ? 16 : (s == 2 ? 4 : 1)); }
 
-// ---- complex FFT of F points, in place on z (kiss order). All F lanes call it.
-template <int F>
-__device__ void cfft(Lds<F> &L, const float2 *src, bool inverse) {
-	const int tid = threadIdx.x;
-	float2 val = src[L.perm[tid]];
-	__syncthreads();
-	L.zbuf[tid] = val;
-	__syncthreads();
-#pragma unroll
-	for (int s = 0; s < 4; ++s) {
-		constexpr int FF = F;
-		const int p = plan_p(FF, s), m = plan_m(FF, s), fs = plan_fs(FF, s);
-		if (tid < F / p) {
-			const int i = tid / m, j = tid - i * m;
-			float2 *Fo = L.zbuf + i * (p * m) + j;
-			if (p == 2) {
-				float2 w = L.tw[j * fs];
-				if (inverse) w.y = -w.y;
-				const float2 t = cmulf(Fo[m], w);
-				const float2 a = Fo[0];
-				Fo[m] = make_float2(a.x - t.x, a.y - t.y);
-				Fo[0] = make_float2(a.x + t.x, a.y + t.y);
-			} else {
-				float2 w1 = L.tw[j * fs], w2 = L.tw[j * fs * 2], w3 = L.tw[j * fs * 3];
-				if (inverse) {
-					w1.y = -w1.y;
-					w2.y = -w2.y;
-					w3.y = -w3.y;
-				}
-				const float2 s0 = cmulf(Fo[m], w1);
-				const float2 s1 = cmulf(Fo[2 * m], w2);
-				const float2 s2 = cmulf(Fo[3 * m], w3);
-				float2 f0 = Fo[0];
-				const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
-				f0.x += s1.x;
-				f0.y += s1.y;
-				const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
-				const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
-				Fo[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
-				f0.x += s3.x;
-				f0.y += s3.y;
-				Fo[0] = f0;
-				if (inverse) {
-					Fo[m] = make_float2(s5.x - s4.y, s5.y + s4.x);
-					Fo[3 * m] = make_float2(s5.x + s4.y, s5.y - s4.x);
-				} else {
-					Fo[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
-					Fo[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
-				}
-			}
-		}
-		__syncthreads();
-	}
-}
-
-// time L.tbuf[2F] -> this lane's bin (scaled by 1/N like spx_fft / ms_fft).
-// bin 0 returns (DC, Nyquist).  Also leaves the interleaved spectrum in L.spec.
-template <int F>
-__device__ float2 rfft_forward(Lds<F> &L) {
-	const int tid = threadIdx.x;
-	cfft<F>(L, reinterpret_cast<const float2 *>(L.tbuf), false);
-	const float scale = 1.f / (2 * F);
-	if (tid == 0) {
-		const float2 t0 = L.zbuf[0];
-		L.spec[0] = (t0.x + t0.y) * scale;
-		L.spec[1] = (t0.x - t0.y) * scale;
-	} else if (tid <= F / 2) {
-		const int k = tid;
-		const float2 a = L.zbuf[k], b = L.zbuf[F - k];
-		const float2 sw = L.super[k];
-		const float f2r = a.x - b.x, f2i = a.y + b.y;
-		const float f1r = a.x + b.x, f1i = a.y - b.y;
-		const float twr = f2r * sw.x - f2i * sw.y;
-		const float twi = f2i * sw.x + f2r * sw.y;
-		if (k != F - k) {
-			L.spec[2 * k] = (.5f * (f1r + twr)) * scale;
-			L.spec[2 * k + 1] = (.5f * (f1i + twi)) * scale;
-		}
-		L.spec[2 * (F - k)] = (.5f * (f1r - twr)) * scale;
-		L.spec[2 * (F - k) + 1] = (.5f * (twi - f1i)) * scale;
-	}
-	__syncthreads();
-	const float2 r = make_float2(L.spec[2 * tid], L.spec[2 * tid + 1]);
-	return r;
-}
-
-// L.spec (interleaved spectrum, every lane has written its bin) -> time in L.tbuf, unscaled.
-template <int F>
-__device__ void rfft_inverse(Lds<F> &L) {
-	const int tid = threadIdx.x;
-	float2 *tmp = reinterpret_cast<float2 *>(L.tbuf); // staging for the pre-processed bins
-	__syncthreads();
-	if (tid == 0) {
-		tmp[0] = make_float2(L.spec[0] + L.spec[1], L.spec[0] - L.spec[1]);
-	} else if (tid <= F / 2) {
-		const int k = tid;
-		const float2 fk = make_float2(L.spec[2 * k], L.spec[2 * k + 1]);
-		const float2 fnkc = make_float2(L.spec[2 * (F - k)], -L.spec[2 * (F - k) + 1]);
-		float2 sw = L.super[k];
-		sw.y = -sw.y; // inverse super-twiddle = conjugate
-		const float2 fek = make_float2(fk.x + fnkc.x, fk.y + fnkc.y);
-		const float2 d = make_float2(fk.x - fnkc.x, fk.y - fnkc.y);
-		const float2 fok = cmulf(d, sw);
-		if (k != F - k) tmp[k] = make_float2(fek.x + fok.x, fek.y + fok.y);
-		float2 c = make_float2(fek.x - fok.x, fek.y - fok.y);
-		c.y *= -1;
-		tmp[F - k] = c;
-	}
-	__syncthreads();
-	cfft<F>(L, tmp, true);
-	// zbuf[n] = (t[2n], t[2n+1])
-	const float2 r = L.zbuf[tid];
-	L.tbuf[2 * tid] = r.x;
-	L.tbuf[2 * tid + 1] = r.y;
-	__syncthreads();
-}
-
 __device__ __forceinline__ float rdlane(float v, int l) {
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
-
-// Serial-order reductions executed by ONE wave: every lane owns K = F/64 consecutive
-// elements in registers, the products are formed lane-parallel (same values the
-// library's loop forms), and only the running sum walks the lanes in order via
-// v_readlane, so the dependent chain never waits on LDS.
-template <int F>
-struct WaveSeq {
-	static constexpr int K = F / 64;
-	// mdf_inner_prod: sum += (x0*y0 + x1*y1) over consecutive pairs
-	__device__ static float inner_prod(const float *x, const float *y, int lane) {
-		float part[K / 2];
-#pragma unroll
-		for (int k = 0; k < K; k += 2) {
-			float p = 0;
-			p = p + x[lane * K + k] * y[lane * K + k];
-			p = p + x[lane * K + k + 1] * y[lane * K + k + 1];
-			part[k / 2] = p;
-		}
-		float sum = 0;
-#pragma unroll
-		for (int l = 0; l < 64; ++l) {
-#pragma unroll
-			for (int k = 0; k < K / 2; ++k) sum = sum + rdlane(part[k], l);
-		}
-		return sum;
-	}
-	// acc = init; for j = F-1 .. 0: acc = acc + a[j]*b[j]   (descending)
-	__device__ static float dot_desc(float init, const float *a, const float *b, int lane) {
-		float p[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k) p[k] = a[lane * K + k] * b[lane * K + k];
-		float acc = init;
-#pragma unroll
-		for (int l = 63; l >= 0; --l) {
-#pragma unroll
-			for (int k = K - 1; k >= 0; --k) acc = acc + rdlane(p[k], l);
-		}
-		return acc;
-	}
-};
 
 __device__ __forceinline__ int16_t word2int(float x) {
 	if (x < -32767.5f) return (int16_t)-32768;
@@ -350,697 +175,40 @@ __device__ __forceinline__ float band_sum(const AecTables &t, int b, const float
 	return mel;
 }
 
-template <int F>
-__global__ __launch_bounds__(F) void aec_kernel(AecArgs a) {
-	__shared__ Lds<F> L;
-	using SL = SmallLayout<F>;
-	constexpr int N = 2 * F;
-	const int s = blockIdx.x;
-	if (a.run && !a.run[s]) return;
-	const int tid = threadIdx.x;
-	const int wave = tid >> 6, lane = tid & 63;
-	const int M = a.M;
-	float *sm = a.small + (size_t)s * a.small_stride;
-	float2 *Xs = reinterpret_cast<float2 *>(a.X + (size_t)s * (M + 1) * N);
-	float2 *Ws = reinterpret_cast<float2 *>(a.W + (size_t)s * M * N);
-	float2 *FGs = reinterpret_cast<float2 *>(a.FG + (size_t)s * M * N);
-	AecScalars sc = a.scal[s];
-
-	// ---------------------------------------------------------------- tables + inputs
-	L.tw[tid] = a.t.tw[tid];
-	L.super[tid] = a.t.super[tid];
-	L.perm[tid] = a.t.perm[tid];
-	if (tid < M) L.prop[tid] = sm[SL::PROP + tid];
-	const int16_t mic_i = a.mic[(size_t)s * a.stride + tid];
-	const int16_t far_i = a.ref[(size_t)s * a.stride + tid];
-	const float far_prev = (tid == 0) ? sc.memX : (float)a.ref[(size_t)s * a.stride + tid - 1];
-	L.fin[tid] = (float)mic_i;
-	L.tbuf[tid] = sm[SL::XPREV + tid];
-	const float xnew = (float)far_i - .9f * far_prev;
-	L.tbuf[F + tid] = xnew;
-	sm[SL::XPREV + tid] = xnew;
-	const int any_sat = __syncthreads_or(mic_i <= -32000 || mic_i >= 32000);
-	sc.cancel_count++;
-
-	// ---------------------------------------------------------------- serial: DC notch (wave 0), Sxx (wave 1 or lane 1)
-	float Sxx = 0;
-	constexpr int K = F / 64;
-	if (wave == 0) {
-		// filter_dc_notch16: a 2-state IIR, inherently serial; samples come out of registers
-		const float radius = a.notch_radius;
-		const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
-		float m0 = sc.notch0, m1 = sc.notch1;
-		float xin[K], yo[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k) xin[k] = L.fin[lane * K + k];
-#pragma unroll
-		for (int l = 0; l < 64; ++l) {
-#pragma unroll
-			for (int k = 0; k < K; ++k) {
-				const float vin = rdlane(xin[k], l);
-				const float vout = m0 + vin;
-				m0 = m1 + 2 * (-vin + radius * vout);
-				m1 = vin - den2 * vout;
-				const float y = radius * vout;
-				if (lane == l) yo[k] = y;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < K; ++k) L.v[lane * K + k] = yo[k];
-		if (lane == 0) {
-			L.red[0] = m0;
-			L.red[1] = m1;
-		}
-	} else if (wave == 1) {
-		const float r = WaveSeq<F>::inner_prod(L.tbuf + F, L.tbuf + F, lane);
-		if (lane == 0) L.red[2] = r;
-	}
-	__syncthreads();
-	sc.notch0 = L.red[0];
-	sc.notch1 = L.red[1];
-	Sxx = L.red[2];
-	{
-		const float vprev = (tid == 0) ? sc.memD : L.v[tid - 1];
-		L.input[tid] = L.v[tid] - .9f * vprev;
-	}
-	sc.memD = L.v[F - 1];
-	sc.memX = (float)a.ref[(size_t)s * a.stride + F - 1];
-
-	// ---------------------------------------------------------------- X0 = FFT(x), into the ring
-	const float2 X0 = rfft_forward<F>(L);
-	const int head = (sc.xhead + M) % (M + 1); // the slot of the oldest block becomes the newest
-	sc.xhead = head;
-	Xs[(size_t)head * F + tid] = X0;
-	auto xslot = [&](int j) { return (size_t)((head + j) % (M + 1)) * F + tid; };
-
-	// per-bin state
-	const float2 Eprev = reinterpret_cast<const float2 *>(sm + SL::E)[tid];
-	const float p1_k = sm[SL::POWER1 + tid];
-	const float p1_F = sm[SL::POWER1 + F]; // Nyquist weight (used by lane 0)
-
-	// ---------------------------------------------------------------- proportional step (mdf_adjust_prop)
-	if (sc.adapted) {
-		if (tid == 0) {
-			float max_sum = 1, prop_sum = 1;
-			for (int i = 0; i < M; ++i) {
-				const float p = (float)sqrt((double)(1.0f + sm[SL::WNORM + i]));
-				L.prop[i] = p;
-				if (p > max_sum) max_sum = p;
-			}
-			for (int i = 0; i < M; ++i) {
-				L.prop[i] += .1f * max_sum;
-				prop_sum += L.prop[i];
-			}
-			for (int i = 0; i < M; ++i) L.prop[i] = (.99f * L.prop[i]) / prop_sum;
-		}
-		__syncthreads();
-		if (tid < M) sm[SL::PROP + tid] = L.prop[tid];
-	}
-	const bool do_grad = (sc.saturated == 0);
-	if (!do_grad) sc.saturated--;
-
-	// gradient of one bin: W += p*w * conj-product(X, E)   (weighted_spectral_mul_conj)
-	auto grad = [&](float2 w, float2 x, float prop) -> float2 {
-		if (tid == 0) { // DC and Nyquist are real
-			const float W0 = prop * p1_k, WN = prop * p1_F;
-			w.x += W0 * (x.x * Eprev.x);
-			w.y += WN * (x.y * Eprev.y);
-		} else {
-			const float Wt = prop * p1_k;
-			w.x += Wt * ((x.x * Eprev.x) + x.y * Eprev.y);
-			w.y += Wt * (((-x.y) * Eprev.x) + x.x * Eprev.y);
-		}
-		return w;
-	};
-
-	// ---------------------------------------------------------------- AUMDF blocks first: j = 0 and the round-robin one
-	const int jc = (M > 1) ? (sc.cancel_count % (M - 1)) + 1 : -1;
-	float2 wsp0 = make_float2(0, 0), wspc = make_float2(0, 0);
-	for (int pass = 0; pass < 2; ++pass) {
-		const int jb = pass == 0 ? 0 : jc;
-		if (jb < 0) break;
-		float2 w = Ws[(size_t)jb * F + tid];
-		if (do_grad) w = grad(w, Xs[xslot(jb + 1)], L.prop[jb]);
-		L.spec[2 * tid] = w.x;
-		L.spec[2 * tid + 1] = w.y;
-		rfft_inverse<F>(L);
-		L.tbuf[F + tid] = 0.f;
-		__syncthreads();
-		w = rfft_forward<F>(L);
-		Ws[(size_t)jb * F + tid] = w;
-		if (pass == 0) wsp0 = w;
-		else wspc = w;
-	}
-
-	// ---------------------------------------------------------------- the one streaming pass over X, FG, W
-	float2 yfg = make_float2(0, 0), ybgs = make_float2(0, 0);
-	{
-		// software-pipelined: block j+1's three loads are in flight while block j is consumed
-		float2 xj = X0;
-		float2 xn = Xs[xslot(1)];
-		float2 fg = FGs[tid];
-		float2 wl = Ws[tid];
-		float nn_acc[64 / 4]; // weight norms, 4 blocks per register group (reduced after the loop)
-		for (int j = 0; j < M; ++j) {
-			float2 xn2 = xn, fg2 = fg, wl2 = wl;
-			if (j + 1 < M) {
-				xn2 = Xs[xslot(j + 2)];
-				fg2 = FGs[(size_t)(j + 1) * F + tid];
-				wl2 = Ws[(size_t)(j + 1) * F + tid];
-			}
-			float2 w;
-			if (j == 0) w = wsp0;
-			else if (j == jc) w = wspc;
-			else {
-				w = wl;
-				if (do_grad) {
-					w = grad(w, xn, L.prop[j]);
-					Ws[(size_t)j * F + tid] = w;
-				}
-			}
-			if (tid == 0) {
-				yfg.x += xj.x * fg.x;
-				yfg.y += xj.y * fg.y;
-				ybgs.x += xj.x * w.x;
-				ybgs.y += xj.y * w.y;
-			} else {
-				yfg.x += (xj.x * fg.x - xj.y * fg.y);
-				yfg.y += (xj.y * fg.x + xj.x * fg.y);
-				ybgs.x += (xj.x * w.x - xj.y * w.y);
-				ybgs.y += (xj.y * w.x + xj.x * w.y);
-			}
-			// per-block weight norm (tree reduction; only feeds the proportional step)
-			if (!(a.flags & 0x100)) {
-				float nn = w.x * w.x + w.y * w.y;
-				for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
-				if (lane == 0) L.wn[j * 4 + wave] = nn;
-			}
-			xj = xn;
-			xn = xn2;
-			fg = fg2;
-			wl = wl2;
-		}
-		(void)nn_acc;
-	}
-
-	// ---------------------------------------------------------------- time-domain responses
-	L.spec[2 * tid] = yfg.x;
-	L.spec[2 * tid + 1] = yfg.y;
-	rfft_inverse<F>(L);
-	L.efg[tid] = L.tbuf[F + tid];
-	L.e1[tid] = L.input[tid] - L.tbuf[F + tid]; // foreground error
-	__syncthreads();
-	L.spec[2 * tid] = ybgs.x;
-	L.spec[2 * tid + 1] = ybgs.y;
-	rfft_inverse<F>(L);
-	L.ybg[tid] = L.tbuf[F + tid];
-	L.e2[tid] = L.input[tid] - L.tbuf[F + tid]; // background error
-	L.v[tid] = L.efg[tid] - L.tbuf[F + tid];    // difference of the two responses
-	__syncthreads();
-	if (wave < 3 && wave < F / 64) {
-		const float *p = wave == 0 ? L.e1 : (wave == 1 ? L.v : L.e2);
-		const float r = WaveSeq<F>::inner_prod(p, p, lane);
-		if (lane == 0) L.red[wave] = r;
-	}
-	if (F / 64 < 3 && wave == 0) { // 2-wave workgroups: wave 0 takes the third sum
-		const float r = WaveSeq<F>::inner_prod(L.e2, L.e2, lane);
-		if (lane == 0) L.red[2] = r;
-	}
-	__syncthreads();
-	const float Sff = L.red[0];
-	const float Dbf = 10 + L.red[1];
-	float See = L.red[2];
-	__syncthreads();
-
-	// ---------------------------------------------------------------- two-path control (uniform)
-	sc.Davg1 = .6f * sc.Davg1 + .4f * (Sff - See);
-	sc.Davg2 = .85f * sc.Davg2 + .15f * (Sff - See);
-	sc.Dvar1 = .36f * sc.Dvar1 + (.4f * Sff) * (.4f * Dbf);
-	sc.Dvar2 = .7225f * sc.Dvar2 + (.15f * Sff) * (.15f * Dbf);
-	bool update_foreground = false;
-	if ((Sff - See) * fabsf(Sff - See) > Sff * Dbf) update_foreground = true;
-	else if (sc.Davg1 * fabsf(sc.Davg1) > .5f * sc.Dvar1) update_foreground = true;
-	else if (sc.Davg2 * fabsf(sc.Davg2) > .25f * sc.Dvar2) update_foreground = true;
-	bool wnorm_from_fg = false;
-	if (update_foreground) {
-		sc.Davg1 = sc.Davg2 = 0;
-		sc.Dvar1 = sc.Dvar2 = 0;
-		for (int j = 0; j < M; ++j) FGs[(size_t)j * F + tid] = Ws[(size_t)j * F + tid];
-		L.efg[tid] = a.t.hann[tid + F] * L.efg[tid] + a.t.hann[tid] * L.ybg[tid];
-	} else {
-		bool reset_background = false;
-		if ((-(Sff - See)) * fabsf(Sff - See) > 4.f * (Sff * Dbf)) reset_background = true;
-		if ((-sc.Davg1) * fabsf(sc.Davg1) > 4.f * sc.Dvar1) reset_background = true;
-		if ((-sc.Davg2) * fabsf(sc.Davg2) > 4.f * sc.Dvar2) reset_background = true;
-		if (reset_background) {
-			for (int j = 0; j < M; ++j) {
-				const float2 w = FGs[(size_t)j * F + tid];
-				Ws[(size_t)j * F + tid] = w;
-				float nn = w.x * w.x + w.y * w.y;
-				for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
-				if (lane == 0) L.wn[j * 4 + wave] = nn;
-			}
-			wnorm_from_fg = true;
-			L.ybg[tid] = L.efg[tid];
-			L.e2[tid] = L.input[tid] - L.efg[tid];
-			See = Sff;
-			sc.Davg1 = sc.Davg2 = 0;
-			sc.Dvar1 = sc.Dvar2 = 0;
-		}
-	}
-	(void)wnorm_from_fg;
-	__syncthreads();
-	if (tid < M) {
-		float t = 0;
-		for (int w = 0; w < F / 64; ++w) t += L.wn[tid * 4 + w];
-		sm[SL::WNORM + tid] = t;
-	}
-
-	// ---------------------------------------------------------------- output (serial de-emphasis) + correlations
-	L.v[tid] = L.input[tid] - L.efg[tid];
-	__syncthreads();
-	if (wave == 0) {
-		float memE = sc.memE;
-		float xin[K], yo[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k) xin[k] = L.v[lane * K + k];
-#pragma unroll
-		for (int l = 0; l < 64; ++l) {
-#pragma unroll
-			for (int k = 0; k < K; ++k) {
-				float t = rdlane(xin[k], l);
-				t = t + .9f * memE;
-				memE = t;
-				if (lane == l) yo[k] = t;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < K; ++k) L.tbuf[lane * K + k] = yo[k]; // tmp_out
-		if (lane == 0) L.red[3] = memE;
-		if (F / 64 < 3) { // 2-wave workgroups: Sdd here
-			const float r = WaveSeq<F>::inner_prod(L.input, L.input, lane);
-			if (lane == 0) L.red[2] = r;
-		}
-	} else if (wave == 1) {
-		const float r = WaveSeq<F>::inner_prod(L.e2, L.ybg, lane);
-		if (lane == 0) L.red[0] = r;
-		if (F / 64 < 3) {
-			const float r2 = WaveSeq<F>::inner_prod(L.ybg, L.ybg, lane);
-			if (lane == 0) L.red[1] = r2;
-		}
-	} else if (wave == 2) {
-		const float r = WaveSeq<F>::inner_prod(L.ybg, L.ybg, lane);
-		if (lane == 0) L.red[1] = r;
-	} else if (wave == 3) {
-		const float r = WaveSeq<F>::inner_prod(L.input, L.input, lane);
-		if (lane == 0) L.red[2] = r;
-	}
-	__syncthreads();
-	sc.memE = L.red[3];
-	const float Sey = L.red[0], Syy = L.red[1], Sdd = L.red[2];
-	if (any_sat && sc.saturated == 0) sc.saturated = 1;
-	int16_t out_i = word2int(L.tbuf[tid]);
-	__syncthreads();
-
-	// ---------------------------------------------------------------- error / response spectra
-	L.tbuf[tid] = 0.f;
-	L.tbuf[F + tid] = L.e2[tid];
-	__syncthreads();
-	const float2 Ecur = rfft_forward<F>(L);
-	__syncthreads();
-	L.tbuf[tid] = 0.f;
-	L.tbuf[F + tid] = L.ybg[tid];
-	__syncthreads();
-	const float2 Ycur = rfft_forward<F>(L);
-	reinterpret_cast<float2 *>(sm + SL::E)[tid] = Ecur;
-	float Rf_k, Yf_k, Xf_k, Rf_F = 0, Yf_F = 0, Xf_F = 0;
-	if (tid == 0) {
-		Rf_k = Ecur.x * Ecur.x;
-		Rf_F = Ecur.y * Ecur.y;
-		Yf_k = Ycur.x * Ycur.x;
-		Yf_F = Ycur.y * Ycur.y;
-		Xf_k = X0.x * X0.x;
-		Xf_F = X0.y * X0.y;
-	} else {
-		Rf_k = Ecur.x * Ecur.x + Ecur.y * Ecur.y;
-		Yf_k = Ycur.x * Ycur.x + Ycur.y * Ycur.y;
-		Xf_k = X0.x * X0.x + X0.y * X0.y;
-	}
-
-	// ---------------------------------------------------------------- sanity checks
-	bool zero_out = false;
-	if (!(Syy >= 0 && Sxx >= 0 && See >= 0) || !(Sff < N * 1e9 && Syy < N * 1e9 && Sxx < N * 1e9)) {
-		sc.screwed_up += 50;
-		zero_out = true;
-	} else if (Sff > Sdd + (float)(N * 10000)) {
-		sc.screwed_up++;
-	} else {
-		sc.screwed_up = 0;
-	}
-	if (zero_out) out_i = 0;
-	if (sc.screwed_up >= 50) {
-		// speex_echo_state_reset: everything back to the initial state
-		for (int j = 0; j < M; ++j) {
-			Ws[(size_t)j * F + tid] = make_float2(0, 0);
-			FGs[(size_t)j * F + tid] = make_float2(0, 0);
-		}
-		for (int j = 0; j <= M; ++j) Xs[(size_t)j * F + tid] = make_float2(0, 0);
-		sm[SL::POWER + tid] = 0;
-		sm[SL::POWER1 + tid] = 1.0f;
-		sm[SL::EH + tid] = 0;
-		sm[SL::YH + tid] = 0;
-		if (tid == 0) {
-			sm[SL::POWER + F] = 0;
-			sm[SL::POWER1 + F] = 1.0f;
-			sm[SL::EH + F] = 0;
-			sm[SL::YH + F] = 0;
-		}
-		sm[SL::LASTY + tid] = 0;
-		sm[SL::LASTY + F + tid] = 0;
-		reinterpret_cast<float2 *>(sm + SL::E)[tid] = make_float2(0, 0);
-		sm[SL::XPREV + tid] = 0;
-		if (tid < M) sm[SL::WNORM + tid] = 0;
-		AecScalars z = sc;
-		z.cancel_count = 0;
-		z.screwed_up = 0;
-		z.notch0 = z.notch1 = 0;
-		z.memD = z.memE = z.memX = 0;
-		z.saturated = 0;
-		z.adapted = 0;
-		z.sum_adapt = 0;
-		z.Pey = z.Pyy = 1.0f;
-		z.Davg1 = z.Davg2 = z.Dvar1 = z.Dvar2 = 0;
-		if (tid == 0) a.scal[s] = z;
-		a.out[(size_t)s * a.stride + tid] = out_i;
-		return;
-	}
-	if (See < (float)(N * 100)) See = (float)(N * 100);
-	Sxx += Sxx; // sic: the library accumulates the far-end energy a second time here
-
-	// ---------------------------------------------------------------- far-end power, leak estimate
-	float pw_k = sm[SL::POWER + tid];
-	pw_k = a.ss_1 * pw_k + 1 + a.ss * Xf_k;
-	sm[SL::POWER + tid] = pw_k;
-	float pw_F = 0;
-	if (tid == 0) {
-		pw_F = sm[SL::POWER + F];
-		pw_F = a.ss_1 * pw_F + 1 + a.ss * Xf_F;
-		sm[SL::POWER + F] = pw_F;
-	}
-	{
-		float eh = sm[SL::EH + tid], yh = sm[SL::YH + tid];
-		L.e1[tid] = Rf_k - eh; // Eh differences, index k
-		L.e2[tid] = Yf_k - yh;
-		sm[SL::EH + tid] = (1 - a.spec_average) * eh + a.spec_average * Rf_k;
-		sm[SL::YH + tid] = (1 - a.spec_average) * yh + a.spec_average * Yf_k;
-		if (tid == 0) {
-			eh = sm[SL::EH + F];
-			yh = sm[SL::YH + F];
-			L.red[8] = Rf_F - eh;
-			L.red[9] = Yf_F - yh;
-			sm[SL::EH + F] = (1 - a.spec_average) * eh + a.spec_average * Rf_F;
-			sm[SL::YH + F] = (1 - a.spec_average) * yh + a.spec_average * Yf_F;
-		}
-	}
-	__syncthreads();
-	if (wave < 2) {
-		// j = F down to 0, starting from FLOAT_ONE
-		const float eF = L.red[8], yF = L.red[9];
-		float acc = 1.0f;
-		acc = acc + (wave == 0 ? eF * yF : yF * yF);
-		acc = WaveSeq<F>::dot_desc(acc, wave == 0 ? L.e1 : L.e2, L.e2, lane);
-		if (lane == 0) L.red[wave] = acc;
-	}
-	__syncthreads();
-	float Pey = L.red[0], Pyy = L.red[1];
-	Pyy = (float)sqrt((double)Pyy);
-	Pey = Pey / Pyy;
-	float tmp32 = a.beta0 * Syy;
-	if (tmp32 > a.beta_max * See) tmp32 = a.beta_max * See;
-	const float alpha = tmp32 / See;
-	const float alpha_1 = 1.0f - alpha;
-	sc.Pey = alpha_1 * sc.Pey + alpha * Pey;
-	sc.Pyy = alpha_1 * sc.Pyy + alpha * Pyy;
-	if (sc.Pyy < 1.0f) sc.Pyy = 1.0f;
-	if (sc.Pey < .005f * sc.Pyy) sc.Pey = .005f * sc.Pyy;
-	if (sc.Pey > sc.Pyy) sc.Pey = sc.Pyy;
-	sc.leak_estimate = sc.Pey / sc.Pyy;
-	float RER = (float)((.0001 * Sxx + 3. * (sc.leak_estimate * Syy)) / See);
-	if (RER < Sey * Sey / (1 + See * Syy)) RER = Sey * Sey / (1 + See * Syy);
-	if (RER > .5) RER = .5;
-	if (!sc.adapted && sc.sum_adapt > (float)M && sc.leak_estimate * Syy > .03f * Syy) sc.adapted = 1;
-
-	auto step = [&](float Yf, float Rf, float pw) -> float {
-		float r = sc.leak_estimate * Yf;
-		const float e = Rf + 1;
-		if (r > .5 * e) r = (float)(.5 * e);
-		r = .7f * r + .3f * (float)(RER * e);
-		return r / (e * (pw + 10));
-	};
-	if (sc.adapted) {
-		sm[SL::POWER1 + tid] = step(Yf_k, Rf_k, pw_k);
-		if (tid == 0) sm[SL::POWER1 + F] = step(Yf_F, Rf_F, pw_F);
-	} else {
-		float adapt_rate = 0;
-		if (Sxx > (float)(N * 1000)) {
-			tmp32 = .25f * Sxx;
-			if (tmp32 > .25 * See) tmp32 = (float)(.25 * See);
-			adapt_rate = tmp32 / See;
-		}
-		sm[SL::POWER1 + tid] = adapt_rate / (pw_k + 10);
-		if (tid == 0) sm[SL::POWER1 + F] = adapt_rate / (pw_F + 10);
-		sc.sum_adapt = sc.sum_adapt + adapt_rate;
-	}
-
-	// last_y: the echo estimate used by the residual-echo spectrum
-	const float ly_old = sm[SL::LASTY + F + tid];
-	float ly_new = ly_old;
-	if (sc.adapted) ly_new = (float)((int)mic_i - (int)out_i);
-	sm[SL::LASTY + tid] = ly_old;
-	sm[SL::LASTY + F + tid] = ly_new;
-
-	// ================================================================ post-filter (speex_preprocess_run)
-	if (a.flags & MI_AEC_POSTFILTER) {
-		sc.nb_adapt++;
-		if (sc.nb_adapt > 20000) sc.nb_adapt = 20000;
-		sc.min_count++;
-		float beta = 1.0f / sc.nb_adapt;
-		if (beta < .03f) beta = .03f;
-		const float beta_1 = 1.0f - beta;
-
-		// residual echo spectrum (speex_echo_get_residual)
-		__syncthreads();
-		L.tbuf[tid] = a.t.hann[tid] * ly_old;
-		L.tbuf[F + tid] = a.t.hann[F + tid] * ly_new;
-		__syncthreads();
-		const float2 Yr = rfft_forward<F>(L);
-		float res = (tid == 0) ? Yr.x * Yr.x : Yr.x * Yr.x + Yr.y * Yr.y;
-		const float leak2 = (sc.leak_estimate > .5) ? 1.f : 2 * sc.leak_estimate;
-		res = (float)(int32_t)(leak2 * res);
-		const int bad = __syncthreads_or(tid == 0 && !(res >= 0 && res < F * 1e9f));
-		if (bad) res = 0;
-		float en = sm[SL::ECHON + tid];
-		{
-			const float c = .6f * en;
-			en = c > res ? c : res;
-		}
-		sm[SL::ECHON + tid] = en;
-		float *vec = L.e1; // per-bin exchange vector
-		float *pl = L.spec, *pr = L.spec + F; // per-bin filterbank products
-		const float wl = a.t.bfl[tid], wr = a.t.bfr[tid];
-		pl[tid] = wl * en;
-		pr[tid] = wr * en;
-		// analysis frame: [inbuf, x] * window
-		const float inb = sm[SL::INBUF + tid];
-		const float xcur = (float)out_i;
-		sm[SL::INBUF + tid] = xcur;
-		L.tbuf[tid] = inb * a.t.pwin[tid];
-		L.tbuf[F + tid] = xcur * a.t.pwin[F + tid];
-		__syncthreads();
-		float *bandv = L.band; // [0..24) echo_noise bands, [24..48) ps bands, [48..72) noise bands, [72..96) misc
-		if (tid < NB_BANDS) bandv[tid] = band_sum<F>(a.t, tid, pl, pr);
-		__syncthreads();
-		float2 ft = rfft_forward<F>(L);
-		const float ps = (tid == 0) ? ft.x * ft.x : ft.x * ft.x + ft.y * ft.y;
-		__syncthreads();
-		vec[tid] = ps;
-		pl[tid] = wl * ps;
-		pr[tid] = wr * ps;
-		__syncthreads();
-		if (tid < NB_BANDS) bandv[NB_BANDS + tid] = band_sum<F>(a.t, tid, pl, pr);
-		// update_noise_prob
-		float S = sm[SL::S_ + tid], Smin = sm[SL::SMIN + tid], Stmp = sm[SL::STMP + tid];
-		if (tid == 0 || tid == F - 1) S = .8f * S + .2f * ps;
-		else S = .8f * S + .05f * vec[tid - 1] + .1f * ps + .05f * vec[tid + 1];
-		if (sc.nb_adapt == 1) Smin = Stmp = 0;
-		int min_range;
-		if (sc.nb_adapt < 100) min_range = 15;
-		else if (sc.nb_adapt < 1000) min_range = 50;
-		else if (sc.nb_adapt < 10000) min_range = 150;
-		else min_range = 300;
-		if (sc.min_count > min_range) {
-			Smin = Stmp < S ? Stmp : S;
-			Stmp = S;
-		} else {
-			Smin = Smin < S ? Smin : S;
-			Stmp = Stmp < S ? Stmp : S;
-		}
-		const int update_prob = (.4f * S > Smin) ? 1 : 0;
-		sm[SL::S_ + tid] = S;
-		sm[SL::SMIN + tid] = Smin;
-		sm[SL::STMP + tid] = Stmp;
-		float noise = sm[SL::NOISE + tid];
-		if (!update_prob || ps < noise) {
-			const float v = beta_1 * noise + beta * ps;
-			noise = v > 0 ? v : 0;
-		}
-		sm[SL::NOISE + tid] = noise;
-		__syncthreads();
-		pl[tid] = wl * noise;
-		pr[tid] = wr * noise;
-		__syncthreads();
-		if (tid < NB_BANDS) bandv[2 * NB_BANDS + tid] = band_sum<F>(a.t, tid, pl, pr);
-		__syncthreads();
-		if (sc.min_count > min_range) sc.min_count = 0;
-
-		// a posteriori / a priori SNR, bins and bands
-		auto snr = [&](float psv, float noisev, float echov, float oldps, float &post, float &prior) {
-			const float tot_noise = 1.f + noisev + echov + 0.f;
-			post = psv / tot_noise - 1.f;
-			if (post > 100.f) post = 100.f;
-			const float t = oldps / (oldps + tot_noise);
-			const float gamma = .1f + .89f * (t * t);
-			prior = gamma * (post > 0 ? post : 0) + (1.0f - gamma) * (oldps / tot_noise);
-			if (prior > 100.f) prior = 100.f;
-		};
-		float old_ps = sm[SL::OLDPS + tid];
-		if (sc.nb_adapt == 1) old_ps = ps;
-		float post_k, prior_k;
-		snr(ps, noise, en, old_ps, post_k, prior_k);
-		float old_ps_b = 0, post_b = 0, prior_b = 0, ps_b = 0;
-		if (tid < NB_BANDS) {
-			ps_b = bandv[NB_BANDS + tid];
-			old_ps_b = sm[SL::OLDPS + F + tid];
-			if (sc.nb_adapt == 1) old_ps_b = ps_b;
-			snr(ps_b, bandv[2 * NB_BANDS + tid], bandv[tid], old_ps_b, post_b, prior_b);
-		}
-		__syncthreads();
-		vec[tid] = prior_k;
-		if (tid < NB_BANDS) bandv[3 * NB_BANDS + tid] = prior_b;
-		__syncthreads();
-		// zeta: recursive average of the a priori SNR
-		float zeta = sm[SL::ZETA + tid];
-		if (tid == 0) zeta = .7f * zeta + .3f * prior_k;
-		else if (tid < F - 1) zeta = .7f * zeta + .15f * prior_k + .075f * vec[tid - 1] + .075f * vec[tid + 1];
-		else zeta = .7f * zeta + .3f * prior_k;
-		sm[SL::ZETA + tid] = zeta;
-		float zeta_b = 0;
-		if (tid < NB_BANDS) {
-			zeta_b = .7f * sm[SL::ZETA + F + tid] + .3f * prior_b;
-			sm[SL::ZETA + F + tid] = zeta_b;
-		}
-		__syncthreads();
-		if (tid < NB_BANDS) bandv[3 * NB_BANDS + tid] = zeta_b;
-		__syncthreads();
-		float Zframe = 0;
-		for (int i = 0; i < NB_BANDS; ++i) Zframe = Zframe + bandv[3 * NB_BANDS + i];
-		const float Pframe = .1f + .899f * qcurve(Zframe / NB_BANDS);
-		const int eff_echo = (int)((1.0f - Pframe) * -40 + Pframe * -15);
-		__syncthreads();
-		// band gains
-		if (tid < NB_BANDS) {
-			const float noise_floor = (float)exp((double)(.2302585f * -15));
-			const float echo_floor = (float)exp((double)(.2302585f * eff_echo));
-			const float nb = bandv[2 * NB_BANDS + tid], eb = bandv[tid];
-			const float gfloor = (float)(sqrt((double)(noise_floor * nb + echo_floor * eb)) / sqrt((double)(1 + nb + eb)));
-			const float prior_ratio = prior_b / (prior_b + 1.f);
-			const float theta = prior_ratio * (1.f + post_b);
-			const float MM = hypergeom_gain(theta);
-			float g = prior_ratio * MM;
-			if (g > 1.f) g = 1.f;
-			old_ps_b = .2f * old_ps_b + (.8f * (g * g)) * ps_b;
-			sm[SL::OLDPS + F + tid] = old_ps_b;
-			const float P1 = .199f + .8f * qcurve(zeta_b);
-			const float q = 1.0f - Pframe * P1;
-			const float g2 = (float)(1 / (1.f + (q / (1.f - q)) * (1 + prior_b) * exp((double)(-theta))));
-			bandv[tid] = g2;                  // gain2 bands
-			bandv[NB_BANDS + tid] = g;        // gain bands
-			bandv[2 * NB_BANDS + tid] = gfloor; // gain_floor bands
-		}
-		__syncthreads();
-		// filterbank_compute_psd16: back to linear frequency
-		const int bl = a.t.bleft[tid], br = bl + 1;
-		auto psd = [&](const float *mel) -> float {
-			float t = mel[bl] * wl;
-			t += mel[br] * wr;
-			return t;
-		};
-		const float p = psd(bandv);
-		const float gain_bark = psd(bandv + NB_BANDS);
-		const float gfl = psd(bandv + 2 * NB_BANDS);
-		float gain2;
-		{
-			const float prior_ratio = prior_k / (prior_k + 1.f);
-			const float theta = prior_ratio * (1.f + post_k);
-			const float MM = hypergeom_gain(theta);
-			float g = prior_ratio * MM;
-			if (g > 1.f) g = 1.f;
-			if (.333f * g > gain_bark) g = 3 * gain_bark;
-			float gain = g;
-			old_ps = .2f * old_ps + (.8f * (gain * gain)) * ps;
-			if (gain < gfl) gain = gfl;
-			const float tmp = p * (float)sqrt((double)gain) + (1.0f - p) * (float)sqrt((double)gfl);
-			gain2 = tmp * tmp;
-		}
-		sm[SL::OLDPS + tid] = old_ps;
-		// apply: bin k scales (re,im); DC uses gain2[0]; Nyquist uses gain2[F-1]
-		__syncthreads();
-		vec[tid] = gain2;
-		__syncthreads();
-		if (tid == 0) {
-			ft.x = gain2 * ft.x;
-			ft.y = vec[F - 1] * ft.y;
-		} else {
-			ft.x = gain2 * ft.x;
-			ft.y = gain2 * ft.y;
-		}
-		L.spec[2 * tid] = ft.x;
-		L.spec[2 * tid + 1] = ft.y;
-		rfft_inverse<F>(L);
-		const float f_lo = L.tbuf[tid] * a.t.pwin[tid];
-		const float f_hi = L.tbuf[F + tid] * a.t.pwin[F + tid];
-		const float ob = sm[SL::OUTBUF + tid];
-		out_i = word2int(ob + f_lo);
-		sm[SL::OUTBUF + tid] = f_hi;
-	}
-
-	a.out[(size_t)s * a.stride + tid] = out_i;
-	if (tid == 0) a.scal[s] = sc;
-}
+#include "aec_wave.hpp"
 
 // ---- debug: forward/inverse transform of one 2F-point frame per block (parity of the FFT itself)
 template <int F>
-__global__ __launch_bounds__(F) void fft_debug_kernel(const float *in, float *out, int inverse, AecTables t) {
-	__shared__ Lds<F> L;
-	const int tid = threadIdx.x;
-	L.tw[tid] = t.tw[tid];
-	L.super[tid] = t.super[tid];
-	L.perm[tid] = t.perm[tid];
+__global__ __launch_bounds__(64) void fft_debug_kernel(const float *in, float *out, int inverse, AecTables t) {
+	__shared__ WLds<F> L;
+	constexpr int K = F / 64;
+	const int lane = threadIdx.x, e0 = lane * K;
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		L.tw[e0 + k] = t.tw[e0 + k];
+		L.super[e0 + k] = t.super[e0 + k];
+		L.perm[e0 + k] = t.perm[e0 + k];
+	}
 	const float *src = in + (size_t)blockIdx.x * 2 * F;
 	float *dst = out + (size_t)blockIdx.x * 2 * F;
 	if (!inverse) {
-		L.tbuf[tid] = src[tid];
-		L.tbuf[F + tid] = src[F + tid];
-		__syncthreads();
-		const float2 r = rfft_forward<F>(L);
-		dst[2 * tid] = r.x;
-		dst[2 * tid + 1] = r.y;
+		float lo[K], hi[K];
+		load_vec<K>(src + e0, lo);
+		load_vec<K>(src + F + e0, hi);
+		store_vec<K>(L.tbuf + e0, lo);
+		store_vec<K>(L.tbuf + F + e0, hi);
+		float2 r[K];
+		w_rfft_forward<F>(L, r);
+		store_bins<K>(reinterpret_cast<float2 *>(dst) + e0, r);
 	} else {
-		L.spec[2 * tid] = src[2 * tid];
-		L.spec[2 * tid + 1] = src[2 * tid + 1];
-		rfft_inverse<F>(L);
-		dst[tid] = L.tbuf[tid];
-		dst[F + tid] = L.tbuf[F + tid];
+		float2 r[K];
+		load_bins<K>(reinterpret_cast<const float2 *>(src) + e0, r);
+		w_rfft_inverse<F>(L, r);
+		float lo[K], hi[K];
+		load_vec<K>(L.tbuf + e0, lo);
+		load_vec<K>(L.tbuf + F + e0, hi);
+		store_vec<K>(dst + e0, lo);
+		store_vec<K>(dst + F + e0, hi);
 	}
 }
 
@@ -1368,9 +536,15 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	g.ss_1 = a->ss_1;
 	g.sampling_rate = a->rate;
 	g.t = a->t;
-	if (a->F == 256) hipLaunchKernelGGL(aec_kernel<256>, dim3(a->nstreams), dim3(256), 0, a->ctx->stream, g);
-	else hipLaunchKernelGGL(aec_kernel<128>, dim3(a->nstreams), dim3(128), 0, a->ctx->stream, g);
+	// one wavefront per stream: canceller, then (optionally) the post-filter as its own launch
+	if (a->F == 256) hipLaunchKernelGGL(aec_mdf_wave_kernel<256>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	else hipLaunchKernelGGL(aec_mdf_wave_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
 	MI_LAUNCH_CHECK();
+	if (flags & MI_AEC_POSTFILTER) {
+		if (a->F == 256) hipLaunchKernelGGL(aec_post_wave_kernel<256>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+		else hipLaunchKernelGGL(aec_post_wave_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+		MI_LAUNCH_CHECK();
+	}
 	return MI_OK;
 }
 
@@ -1461,9 +635,9 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int inverse) {
 	MI_CHECK_ARG(a && d_in && d_out && nframes > 0);
 	if (a->F == 256)
-		hipLaunchKernelGGL(fft_debug_kernel<256>, dim3(nframes), dim3(256), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
+		hipLaunchKernelGGL(fft_debug_kernel<256>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	else
-		hipLaunchKernelGGL(fft_debug_kernel<128>, dim3(nframes), dim3(128), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
+		hipLaunchKernelGGL(fft_debug_kernel<128>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }

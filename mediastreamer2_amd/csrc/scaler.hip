@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int SC_THREADS = 256;
+constexpr int SC_THREADS = 256; // generic (any-alignment) kernel
 
 struct PlaneMap {
 	int x0, dx, y0, dy; // 16.16
@@ -42,42 +42,102 @@ struct ScArgs {
 
 __device__ __forceinline__ int clamp8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
-// vertical blend of source rows (yi, yi+1) at 8-bit fraction yf into an LDS row
-__device__ __forceinline__ void blend_row(uint8_t *row, const uint8_t *plane, int stride, int w, int h, int y) {
+// one vertical-blend job: source rows (yi, yi+1) of a plane at 8-bit fraction yf -> an LDS row
+struct RowJob {
+	const uint8_t *r0, *r1;
+	uint8_t *dst;
+	int w, yf, nq; // nq = 16-byte groups
+};
+
+__device__ __forceinline__ RowJob make_job(uint8_t *dst, const uint8_t *plane, int stride, int w, int h, int y) {
 	const int max_y = (h - 1) << 16;
 	if (y > max_y) y = max_y;
 	if (y < 0) y = 0;
-	const int yi = y >> 16, yf = (y >> 8) & 255;
-	const uint8_t *r0 = plane + (size_t)yi * stride;
-	const uint8_t *r1 = (yi + 1 < h) ? r0 + stride : r0;
+	const int yi = y >> 16;
+	RowJob j;
+	j.r0 = plane + (size_t)yi * stride;
+	j.r1 = (yi + 1 < h) ? j.r0 + stride : j.r0;
+	j.dst = dst;
+	j.w = w;
+	j.yf = (y >> 8) & 255;
+	j.nq = (w + 15) >> 4;
+	return j;
+}
+
+__device__ __forceinline__ uint4 blend16(uint4 a, uint4 b, int yf) {
+	if (yf == 0) return a;
+	const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+	unsigned ov[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		unsigned r = 0;
+#pragma unroll
+		for (int byte = 0; byte < 4; ++byte) {
+			const int p0 = (av[k] >> (8 * byte)) & 255, p1 = (bv[k] >> (8 * byte)) & 255;
+			r |= (unsigned)((p0 * (256 - yf) + p1 * yf + 128) >> 8) << (8 * byte);
+		}
+		ov[k] = r;
+	}
+	return make_uint4(ov[0], ov[1], ov[2], ov[3]);
+}
+
+// All row jobs of one output row pair are flattened into one work list so that every lane has
+// its (up to 2) items' loads in flight before the first blend: one memory round trip per pair.
+__device__ __forceinline__ void run_jobs(const RowJob *jobs, int njobs, bool vec) {
 	const int tid = threadIdx.x;
-	if (((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(plane) & 15) == 0)) {
-		const int nq = (w + 15) >> 4; // stride multiple of 16 => whole groups are in-row
-		for (int q = tid; q < nq; q += SC_THREADS) {
-			const uint4 a = *reinterpret_cast<const uint4 *>(r0 + 16 * q);
-			uint4 o = a;
-			if (yf != 0) {
-				const uint4 b = *reinterpret_cast<const uint4 *>(r1 + 16 * q);
-				const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
-				unsigned ov[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					unsigned r = 0;
-#pragma unroll
-					for (int byte = 0; byte < 4; ++byte) {
-						const int p0 = (av[k] >> (8 * byte)) & 255, p1 = (bv[k] >> (8 * byte)) & 255;
-						r |= (unsigned)((p0 * (256 - yf) + p1 * yf + 128) >> 8) << (8 * byte);
-					}
-					ov[k] = r;
+	if (vec) {
+		int total = 0;
+		for (int j = 0; j < njobs; ++j) total += jobs[j].nq;
+		// two items per lane, both pairs of loads issued before the first blend
+		uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
+		uint8_t *d0 = nullptr, *d1 = nullptr;
+		int yf0 = 0, yf1 = 0;
+		{
+			int it = tid;
+			if (it < total) {
+				int j = 0, q = it;
+				while (q >= jobs[j].nq) {
+					q -= jobs[j].nq;
+					++j;
 				}
-				o = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+				yf0 = jobs[j].yf;
+				d0 = jobs[j].dst + 16 * q;
+				a0 = *reinterpret_cast<const uint4 *>(jobs[j].r0 + 16 * q);
+				b0 = yf0 ? *reinterpret_cast<const uint4 *>(jobs[j].r1 + 16 * q) : a0;
 			}
-			*reinterpret_cast<uint4 *>(row + 16 * q) = o;
+			it += SC_THREADS;
+			if (it < total) {
+				int j = 0, q = it;
+				while (q >= jobs[j].nq) {
+					q -= jobs[j].nq;
+					++j;
+				}
+				yf1 = jobs[j].yf;
+				d1 = jobs[j].dst + 16 * q;
+				a1 = *reinterpret_cast<const uint4 *>(jobs[j].r0 + 16 * q);
+				b1 = yf1 ? *reinterpret_cast<const uint4 *>(jobs[j].r1 + 16 * q) : a1;
+			}
+		}
+		if (d0) *reinterpret_cast<uint4 *>(d0) = blend16(a0, b0, yf0);
+		if (d1) *reinterpret_cast<uint4 *>(d1) = blend16(a1, b1, yf1);
+		// pictures wider than 2*SC_THREADS*16/… fall through to the generic loop for the remainder
+		for (int it = tid + 2 * SC_THREADS; it < total; it += SC_THREADS) {
+			int j = 0, q = it;
+			while (q >= jobs[j].nq) {
+				q -= jobs[j].nq;
+				++j;
+			}
+			const uint4 x = *reinterpret_cast<const uint4 *>(jobs[j].r0 + 16 * q);
+			const uint4 y = jobs[j].yf ? *reinterpret_cast<const uint4 *>(jobs[j].r1 + 16 * q) : x;
+			*reinterpret_cast<uint4 *>(jobs[j].dst + 16 * q) = blend16(x, y, jobs[j].yf);
 		}
 	} else {
-		for (int i = tid; i < w; i += SC_THREADS) {
-			const int p0 = r0[i], p1 = r1[i];
-			row[i] = (uint8_t)(yf == 0 ? p0 : ((p0 * (256 - yf) + p1 * yf + 128) >> 8));
+		for (int j = 0; j < njobs; ++j) {
+			const RowJob &J = jobs[j];
+			for (int i = tid; i < J.w; i += SC_THREADS) {
+				const int p0 = J.r0[i], p1 = J.r1[i];
+				J.dst[i] = (uint8_t)(J.yf == 0 ? p0 : ((p0 * (256 - J.yf) + p1 * J.yf + 128) >> 8));
+			}
 		}
 	}
 }
@@ -93,16 +153,31 @@ __device__ __forceinline__ int filter_col(const uint8_t *row, int sw, long long 
 	return a + ((f * (b - a) + 0x8000) >> 16);
 }
 
+// copy `n` bytes LDS -> global with 16-byte stores when both sides allow it
+__device__ __forceinline__ void store_row(uint8_t *dst, const uint8_t *lds, int n) {
+	const int tid = threadIdx.x;
+	if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (n & 15) == 0) {
+		for (int q = tid; q < (n >> 4); q += SC_THREADS)
+			*reinterpret_cast<uint4 *>(dst + 16 * q) = *reinterpret_cast<const uint4 *>(lds + 16 * q);
+	} else {
+		for (int i = tid; i < n; i += SC_THREADS) dst[i] = lds[i];
+	}
+}
+
 template <bool RGB>
 __global__ __launch_bounds__(SC_THREADS) void scaler_kernel(ScArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	__shared__ RowJob jobs[4];
 	const int lw = (a.sw + 31) & ~15, cwp = (a.scw + 31) & ~15;
+	const int ow = RGB ? ((a.dw * 3 + 15) & ~15) : ((a.dw + 15) & ~15); // staged output row
 	uint8_t *rowY0 = reinterpret_cast<uint8_t *>(smem);
 	uint8_t *rowY1 = rowY0 + lw;
 	uint8_t *rowU = rowY1 + lw;
 	uint8_t *rowV = rowU + cwp;
-	uint8_t *outU = rowV + cwp;          // filtered chroma row (dcw bytes)
+	uint8_t *outU = rowV + cwp; // filtered chroma rows (dcw bytes)
 	uint8_t *outV = outU + ((a.dcw + 15) & ~15);
+	uint8_t *out0 = outV + ((a.dcw + 15) & ~15); // staged output rows
+	uint8_t *out1 = out0 + ow;
 
 	const int frame = blockIdx.y;
 	const uint8_t *sY = a.src + (size_t)frame * a.src_pitch;
@@ -110,19 +185,28 @@ __global__ __launch_bounds__(SC_THREADS) void scaler_kernel(ScArgs a) {
 	const uint8_t *sV = sU + (size_t)a.scw * a.sch;
 	uint8_t *d = a.dst + (size_t)frame * a.dst_pitch;
 	const int tid = threadIdx.x;
+	const bool vec = ((a.sw & 15) == 0) && ((a.scw & 15) == 0) && ((reinterpret_cast<uintptr_t>(sY) & 15) == 0) &&
+	                 ((reinterpret_cast<uintptr_t>(sU) & 15) == 0) && ((reinterpret_cast<uintptr_t>(sV) & 15) == 0);
 
 	const int p_begin = blockIdx.x * a.pairs_per_block;
 	const int p_end = min(p_begin + a.pairs_per_block, a.npairs);
 	for (int pr = p_begin; pr < p_end; ++pr) {
 		const int oy0 = 2 * pr, oy1 = 2 * pr + 1;
 		const bool has1 = oy1 < a.dh;
-		__syncthreads(); // previous pair's LDS rows are free
-		blend_row(rowY0, sY, a.sw, a.sw, a.sh, a.ym.y0 + oy0 * a.ym.dy);
-		if (has1) blend_row(rowY1, sY, a.sw, a.sw, a.sh, a.ym.y0 + oy1 * a.ym.dy);
-		if (pr < a.dch) {
-			blend_row(rowU, sU, a.scw, a.scw, a.sch, a.cm.y0 + pr * a.cm.dy);
-			blend_row(rowV, sV, a.scw, a.scw, a.sch, a.cm.y0 + pr * a.cm.dy);
+		// the (uniform) job descriptors live in LDS: indexing a per-lane array would go to scratch
+		int nj = 1 + (has1 ? 1 : 0) + (pr < a.dch ? 2 : 0);
+		__syncthreads(); // previous pair's LDS rows and descriptors are free
+		if (tid == 0) {
+			int n = 0;
+			jobs[n++] = make_job(rowY0, sY, a.sw, a.sw, a.sh, a.ym.y0 + oy0 * a.ym.dy);
+			if (has1) jobs[n++] = make_job(rowY1, sY, a.sw, a.sw, a.sh, a.ym.y0 + oy1 * a.ym.dy);
+			if (pr < a.dch) {
+				jobs[n++] = make_job(rowU, sU, a.scw, a.scw, a.sch, a.cm.y0 + pr * a.cm.dy);
+				jobs[n++] = make_job(rowV, sV, a.scw, a.scw, a.sch, a.cm.y0 + pr * a.cm.dy);
+			}
 		}
+		__syncthreads();
+		run_jobs(jobs, nj, vec);
 		__syncthreads();
 		if (pr < a.dch) {
 			for (int x = tid; x < a.dcw; x += SC_THREADS) {
@@ -135,28 +219,25 @@ __global__ __launch_bounds__(SC_THREADS) void scaler_kernel(ScArgs a) {
 			uint8_t *dY = d, *dU = d + (size_t)a.dw * a.dh2, *dV = dU + (size_t)a.dcw * a.dch;
 			for (int x = tid; x < a.dw; x += SC_THREADS) {
 				const long long fx = (long long)a.ym.x0 + (long long)x * a.ym.dx;
-				dY[(size_t)oy0 * a.dw + x] = (uint8_t)filter_col(rowY0, a.sw, fx);
-				if (has1) dY[(size_t)oy1 * a.dw + x] = (uint8_t)filter_col(rowY1, a.sw, fx);
+				out0[x] = (uint8_t)filter_col(rowY0, a.sw, fx);
+				if (has1) out1[x] = (uint8_t)filter_col(rowY1, a.sw, fx);
 			}
 			__syncthreads();
+			store_row(dY + (size_t)oy0 * a.dw, out0, a.dw);
+			if (has1) store_row(dY + (size_t)oy1 * a.dw, out1, a.dw);
 			if (pr < a.dch) {
-				for (int x = tid; x < a.dcw; x += SC_THREADS) {
-					dU[(size_t)pr * a.dcw + x] = outU[x];
-					dV[(size_t)pr * a.dcw + x] = outV[x];
-				}
+				store_row(dU + (size_t)pr * a.dcw, outU, a.dcw);
+				store_row(dV + (size_t)pr * a.dcw, outV, a.dcw);
 			}
 		} else {
 			__syncthreads();
-			// 4 pixels (12 bytes) per lane per row
+			// 4 pixels (12 bytes) per lane per row, staged so the row leaves as 16-byte stores
 			const int groups = (a.dw + 3) >> 2;
-			const size_t pitch = (size_t)a.dw * 3;
-			const bool fast = ((a.dw & 3) == 0) && ((reinterpret_cast<uintptr_t>(d) & 3) == 0);
 			for (int g = tid; g < groups; g += SC_THREADS) {
 #pragma unroll
 				for (int rsel = 0; rsel < 2; ++rsel) {
 					if (rsel == 1 && !has1) break;
 					const uint8_t *rowY = rsel ? rowY1 : rowY0;
-					const int oy = rsel ? oy1 : oy0;
 					uint8_t px[12];
 #pragma unroll
 					for (int k = 0; k < 4; ++k) {
@@ -171,17 +252,205 @@ __global__ __launch_bounds__(SC_THREADS) void scaler_kernel(ScArgs a) {
 						px[3 * k + 1] = (uint8_t)clamp8((yy - 3203 * dd - 6660 * ee) >> 13);
 						px[3 * k + 2] = (uint8_t)clamp8((yy + 16531 * dd) >> 13);
 					}
-					uint8_t *o = d + (size_t)oy * pitch + (size_t)12 * g;
-					if (fast) {
-						uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-						o32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
-						o32[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
-						o32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
-					} else {
-						for (int k = 0; k < 12; ++k)
-							if (4 * g + k / 3 < a.dw) o[k] = px[k];
-					}
+					uint32_t *o32 = reinterpret_cast<uint32_t *>((rsel ? out1 : out0) + 12 * g);
+					o32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
+					o32[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
+					o32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
 				}
+			}
+			__syncthreads();
+			const size_t pitch = (size_t)a.dw * 3;
+			store_row(d + (size_t)oy0 * pitch, out0, a.dw * 3);
+			if (has1) store_row(d + (size_t)oy1 * pitch, out1, a.dw * 3);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast path: ONE wavefront per 256-pixel-wide strip of a band of output row pairs.  No
+// workgroup barriers: every wave has its own 16-byte source loads in flight (3-4 per lane per
+// row pair, all issued before the first blend), blends them into its private LDS rows, then
+// each lane filters and colour-converts its own 4x2 pixels (the two chroma samples it needs
+// are its own), and the strip leaves as 16-byte stores.  With ~3.5 KB of LDS per wave a CU
+// keeps 24-32 waves in different phases, which is what keeps HBM busy on a byte stream.
+constexpr int WS_LUMA_Q = 28;   // 16-byte groups of luma a strip may need per source row (<= 448 B)
+constexpr int WS_CHROMA_Q = 16; // same for a chroma row
+
+struct WsRow { // per-wave LDS image of one blended source row segment
+	int base;  // first source x held (multiple of 16)
+};
+
+template <bool RGB>
+__global__ __launch_bounds__(64) void scaler_wave_kernel(ScArgs a, int strips, int band_pairs) {
+	__shared__ __attribute__((aligned(16))) uint8_t rowY[2][WS_LUMA_Q * 16];
+	__shared__ __attribute__((aligned(16))) uint8_t rowC[2][WS_CHROMA_Q * 16];
+	__shared__ __attribute__((aligned(16))) uint8_t stage[2][256 * 3];
+	const int lane = threadIdx.x;
+	const int strip = blockIdx.x % strips, band = blockIdx.x / strips;
+	const int frame = blockIdx.y;
+	const uint8_t *sY = a.src + (size_t)frame * a.src_pitch;
+	const uint8_t *sU = sY + (size_t)a.sw * a.sh2;
+	const uint8_t *sV = sU + (size_t)a.scw * a.sch;
+	uint8_t *d = a.dst + (size_t)frame * a.dst_pitch;
+
+	const int ox0 = strip * 256;                        // first output luma x of the strip
+	const int npx = min(256, a.dw - ox0);               // luma pixels in this strip
+	const int ocx0 = ox0 >> 1, ncx = (npx + 1) >> 1;    // chroma
+	// source segments (16-byte aligned) the strip needs
+	const long long fy0 = (long long)a.ym.x0 + (long long)ox0 * a.ym.dx;
+	const long long fy1 = (long long)a.ym.x0 + (long long)(ox0 + npx - 1) * a.ym.dx;
+	const int ybase = max(0, (int)(fy0 >> 16)) & ~15;
+	const int yq = min((min(a.sw, (int)(fy1 >> 16) + 2) - ybase + 15) >> 4, WS_LUMA_Q);
+	const long long fc0 = (long long)a.cm.x0 + (long long)ocx0 * a.cm.dx;
+	const long long fc1 = (long long)a.cm.x0 + (long long)(ocx0 + ncx - 1) * a.cm.dx;
+	const int cbase = max(0, (int)(fc0 >> 16)) & ~15;
+	const int cq = min((min(a.scw, (int)(fc1 >> 16) + 2) - cbase + 15) >> 4, WS_CHROMA_Q);
+
+	const int p_begin = band * band_pairs, p_end = min(p_begin + band_pairs, a.npairs);
+	for (int pr = p_begin; pr < p_end; ++pr) {
+		const int oy0 = 2 * pr, oy1 = 2 * pr + 1;
+		const bool has1 = oy1 < a.dh;
+		const bool hasc = pr < a.dch;
+		// vertical positions (uniform)
+		auto vpos = [](int y, int h, int &yi, int &yf) {
+			const int max_y = (h - 1) << 16;
+			if (y > max_y) y = max_y;
+			if (y < 0) y = 0;
+			yi = y >> 16;
+			yf = (y >> 8) & 255;
+		};
+		int yi0, yf0, yi1, yf1, ci, cf;
+		vpos(a.ym.y0 + oy0 * a.ym.dy, a.sh, yi0, yf0);
+		vpos(a.ym.y0 + (has1 ? oy1 : oy0) * a.ym.dy, a.sh, yi1, yf1);
+		vpos(a.cm.y0 + (hasc ? pr : 0) * a.cm.dy, a.sch, ci, cf);
+		// ---- loads: work list [Y0: yq][Y1: yq][U: cq][V: cq], two items per lane, all in flight
+		// (prefetching the next pair's loads here was measured slower: +32 VGPRs cost a wave per SIMD)
+		const int total = 2 * yq + 2 * cq;
+		uint4 va[2], vb[2];
+		int item[2] = {lane, lane + 64};
+#pragma unroll
+		for (int n = 0; n < 2; ++n) {
+			va[n] = vb[n] = make_uint4(0, 0, 0, 0);
+			const int it = item[n];
+			if (it < total) {
+				const uint8_t *r0, *r1;
+				int yf;
+				if (it < 2 * yq) {
+					const int sel = it >= yq, q = it - sel * yq;
+					const int yi = sel ? yi1 : yi0;
+					yf = sel ? yf1 : yf0;
+					r0 = sY + (size_t)yi * a.sw + ybase + 16 * q;
+					r1 = (yi + 1 < a.sh) ? r0 + a.sw : r0;
+				} else {
+					const int t = it - 2 * yq, sel = t >= cq, q = t - sel * cq;
+					const uint8_t *pl = sel ? sV : sU;
+					yf = cf;
+					r0 = pl + (size_t)ci * a.scw + cbase + 16 * q;
+					r1 = (ci + 1 < a.sch) ? r0 + a.scw : r0;
+				}
+				va[n] = *reinterpret_cast<const uint4 *>(r0);
+				vb[n] = yf ? *reinterpret_cast<const uint4 *>(r1) : va[n];
+			}
+		}
+		__syncthreads(); // the previous pair's rows are no longer read
+#pragma unroll
+		for (int n = 0; n < 2; ++n) {
+			const int it = item[n];
+			if (it < total) {
+				uint8_t *dst;
+				int yf;
+				if (it < 2 * yq) {
+					const int sel = it >= yq, q = it - sel * yq;
+					yf = sel ? yf1 : yf0;
+					dst = rowY[sel] + 16 * q;
+				} else {
+					const int t = it - 2 * yq, sel = t >= cq, q = t - sel * cq;
+					yf = cf;
+					dst = rowC[sel] + 16 * q;
+				}
+				*reinterpret_cast<uint4 *>(dst) = blend16(va[n], vb[n], yf);
+			}
+		}
+		__syncthreads();
+		// ---- this lane's pixels: x = ox0 + 4*lane .. +3, chroma cx = ocx0 + 2*lane, +1
+		const int x0l = 4 * lane;
+		int cu[2] = {128, 128}, cv[2] = {128, 128};
+		if (hasc) {
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const int cx = min(ocx0 + 2 * lane + k, a.dcw - 1);
+				const long long fx = (long long)a.cm.x0 + (long long)cx * a.cm.dx;
+				int xi = (int)(fx >> 16), f = (int)(fx & 0xffff);
+				if (xi < 0) xi = 0, f = 0;
+				const int xn = xi + 1 < a.scw ? xi + 1 : a.scw - 1;
+				const int ua = rowC[0][xi - cbase], ub = rowC[0][xn - cbase];
+				const int wa = rowC[1][xi - cbase], wb = rowC[1][xn - cbase];
+				cu[k] = ua + ((f * (ub - ua) + 0x8000) >> 16);
+				cv[k] = wa + ((f * (wb - wa) + 0x8000) >> 16);
+			}
+		}
+		int yv[2][4];
+#pragma unroll
+		for (int r = 0; r < 2; ++r)
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int x = min(ox0 + x0l + k, a.dw - 1);
+				const long long fx = (long long)a.ym.x0 + (long long)x * a.ym.dx;
+				int xi = (int)(fx >> 16), f = (int)(fx & 0xffff);
+				if (xi < 0) xi = 0, f = 0;
+				const int xn = xi + 1 < a.sw ? xi + 1 : a.sw - 1;
+				const int pa = rowY[r][xi - ybase], pb = rowY[r][xn - ybase];
+				yv[r][k] = pa + ((f * (pb - pa) + 0x8000) >> 16);
+			}
+		if (RGB) {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				uint8_t px[12];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int c = yv[r][k] - 16, dd = cu[k >> 1] - 128, ee = cv[k >> 1] - 128;
+					const int yy = 9535 * c + 4096;
+					px[3 * k + 0] = (uint8_t)clamp8((yy + 13074 * ee) >> 13);
+					px[3 * k + 1] = (uint8_t)clamp8((yy - 3203 * dd - 6660 * ee) >> 13);
+					px[3 * k + 2] = (uint8_t)clamp8((yy + 16531 * dd) >> 13);
+				}
+				uint32_t *o32 = reinterpret_cast<uint32_t *>(stage[r] + 12 * lane);
+				o32[0] = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
+				o32[1] = px[4] | (px[5] << 8) | (px[6] << 16) | ((uint32_t)px[7] << 24);
+				o32[2] = px[8] | (px[9] << 8) | (px[10] << 16) | ((uint32_t)px[11] << 24);
+			}
+			__syncthreads();
+			const size_t pitch = (size_t)a.dw * 3;
+			const int nbytes = npx * 3;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				if (r == 1 && !has1) break;
+				uint8_t *o = d + (size_t)(r ? oy1 : oy0) * pitch + (size_t)ox0 * 3;
+				if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+					if (lane < (nbytes >> 4)) *reinterpret_cast<uint4 *>(o + 16 * lane) = *reinterpret_cast<const uint4 *>(stage[r] + 16 * lane);
+				} else {
+					for (int i = lane; i < nbytes; i += 64) o[i] = stage[r][i];
+				}
+			}
+		} else {
+			uint8_t *dY = d, *dU = d + (size_t)a.dw * a.dh2, *dV = dU + (size_t)a.dcw * a.dch;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				if (r == 1 && !has1) break;
+				uint8_t *o = dY + (size_t)(r ? oy1 : oy0) * a.dw + ox0 + x0l;
+				if (x0l + 4 <= npx && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+					*reinterpret_cast<uint32_t *>(o) = (uint32_t)yv[r][0] | (yv[r][1] << 8) | (yv[r][2] << 16) | ((uint32_t)yv[r][3] << 24);
+				} else {
+					for (int k = 0; k < 4; ++k)
+						if (x0l + k < npx) o[k] = (uint8_t)yv[r][k];
+				}
+			}
+			if (hasc) {
+				for (int k = 0; k < 2; ++k)
+					if (2 * lane + k < ncx && ocx0 + 2 * lane + k < a.dcw) {
+						dU[(size_t)pr * a.dcw + ocx0 + 2 * lane + k] = (uint8_t)cu[k];
+						dV[(size_t)pr * a.dcw + ocx0 + 2 * lane + k] = (uint8_t)cv[k];
+					}
 			}
 		}
 	}
@@ -235,7 +504,8 @@ int mi_scaler_create(mi_ctx *ctx, int sw, int sh, int dw, int dh, int dst_fmt, m
 	s->src_bytes = (size_t)sw * a.sh2 + 2 * (size_t)a.scw * a.sch;
 	s->dst_bytes = a.rgb ? (size_t)dw * dh * 3 : (size_t)dw * a.dh2 + 2 * (size_t)a.dcw * a.dch;
 	const int lw = (sw + 31) & ~15, cwp = (a.scw + 31) & ~15;
-	s->lds = (size_t)2 * lw + 2 * cwp + 2 * (size_t)((a.dcw + 15) & ~15);
+	const int ow = a.rgb ? ((dw * 3 + 15) & ~15) + 16 : ((dw + 15) & ~15) + 16;
+	s->lds = (size_t)2 * lw + 2 * cwp + 2 * (size_t)((a.dcw + 15) & ~15) + 2 * (size_t)ow;
 	if (s->lds > 64 * 1024) {
 		mi::set_error("source width %d too large for the scaler kernel's LDS rows", sw);
 		delete s;
@@ -260,6 +530,21 @@ int mi_scaler_process(mi_scaler *s, int nframes, const uint8_t *d_src, size_t sr
 	a.dst = d_dst;
 	a.src_pitch = src_pitch;
 	a.dst_pitch = dst_pitch;
+	// fast wave-per-strip path: 16-byte aligned planes/rows and strips that fit the per-wave LDS rows
+	const bool aligned = ((a.sw & 15) == 0) && ((a.scw & 15) == 0) && ((reinterpret_cast<uintptr_t>(d_src) & 15) == 0) &&
+	                     ((src_pitch & 15) == 0) && ((((size_t)a.sw * a.sh2) & 15) == 0) &&
+	                     ((((size_t)a.scw * a.sch) & 15) == 0);
+	const long long need_y = ((long long)255 * a.ym.dx >> 16) + 2 + 15 + 16;
+	const long long need_c = ((long long)127 * a.cm.dx >> 16) + 2 + 15 + 16;
+	if (aligned && a.ym.dx > 0 && a.cm.dx > 0 && need_y <= WS_LUMA_Q * 16 && need_c <= WS_CHROMA_Q * 16) {
+		const char *bp = getenv("MSMI355X_SCALER_BAND");
+		const int strips = mi::ceil_div(a.dw, 256), band_pairs = bp ? atoi(bp) : 4;
+		const dim3 grid((unsigned)(strips * mi::ceil_div(a.npairs, band_pairs)), (unsigned)nframes);
+		if (a.rgb) hipLaunchKernelGGL(scaler_wave_kernel<true>, grid, dim3(64), 0, s->ctx->stream, a, strips, band_pairs);
+		else hipLaunchKernelGGL(scaler_wave_kernel<false>, grid, dim3(64), 0, s->ctx->stream, a, strips, band_pairs);
+		MI_LAUNCH_CHECK();
+		return MI_OK;
+	}
 	const dim3 grid((unsigned)mi::ceil_div(a.npairs, a.pairs_per_block), (unsigned)nframes);
 	if (a.rgb) hipLaunchKernelGGL(scaler_kernel<true>, grid, dim3(SC_THREADS), s->lds, s->ctx->stream, a);
 	else hipLaunchKernelGGL(scaler_kernel<false>, grid, dim3(SC_THREADS), s->lds, s->ctx->stream, a);
