@@ -125,7 +125,7 @@ def make_resample_leg(ms, torch, ctx, nstreams):
     def launch(i):
         rs.process(ins[i], out=outs[i])
 
-    leg = Leg(ctx, "resample_up_kernel<3,48,8>", launch, ring, per_tick, nstreams, "stream-ticks")
+    leg = Leg(ctx, "resample_up_kernel<3,48,8,false>", launch, ring, per_tick, nstreams, "stream-ticks")
     leg.keep = (rs, ins, outs, host)
     return leg
 
@@ -205,7 +205,7 @@ def make_scaler_leg(ms, torch, ctx, nframes=64):
     def launch(i):
         sc.process(ins[i], out=outs[i])
 
-    leg = Leg(ctx, "scaler_kernel<true>", launch, ring, per_step, nframes, "frames")
+    leg = Leg(ctx, "scaler_wave_kernel<true>", launch, ring, per_step, nframes, "frames")
     leg.keep = (sc, ins, outs)
     leg.mpix_in = nframes * sw * sh / 1e6
     return leg
@@ -235,7 +235,7 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
     def launch(i):
         aec.process(mics[i], refs[i], out=outs[i])
 
-    leg = Leg(ctx, "aec_kernel<256>", launch, ring, per_frame, nstreams, "stream-frames (256 samples)")
+    leg = Leg(ctx, "aec_mdf_wave_kernel<256>+aec_post_wave_kernel<256>", launch, ring, per_frame, nstreams, "stream-frames (256 samples)")
     leg.keep = (aec, mics, refs, outs)
     leg.state_bytes = aec.state_bytes() * nstreams
     return leg
@@ -334,7 +334,11 @@ def main():
         if not a.no_extras:
             extras = []
             ksteps = max(20, min(a.steps, 100))
-            for mk in (make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg, make_scaler_leg):
+            def make_resample_65536(ms_, torch_, ctx_):  # same kernel, a deployment-sized batch
+                return make_resample_leg(ms_, torch_, ctx_, 65536)
+
+            for mk in (make_resample_65536, make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg,
+                       make_scaler_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)

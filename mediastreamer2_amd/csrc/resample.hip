@@ -9,17 +9,16 @@
 //
 // Kernels
 //   resample_up_kernel<DEN,FILT,R>  integer up-sampling (num_rate == 1, e.g.
-//       16k->48k, 8k->48k): each lane owns one polyphase row (FILT taps in
-//       VGPRs) and R consecutive input positions; the input window slides
-//       through registers, so one LDS read feeds R FMAs.  Input/history are
-//       staged in LDS as float with an (i + i/8) skew that makes the stride-R
-//       window reads bank-conflict free; outputs are staged in LDS and leave
-//       as 16-byte coalesced stores.
+//       16k->48k, 8k->48k): persistent wavefronts, one stream at a time per
+//       wave, next stream's row prefetched while the current one is computed.
+//       Each lane owns one polyphase row (FILT taps in VGPRs) and R consecutive
+//       input positions; the FILT-1+R sample window comes out of LDS with
+//       16-byte reads; outputs are staged in LDS and leave as 16-byte stores.
 //   resample_generic_kernel         any other ratio (direct table or the
 //       oversampled table + 4-point cubic interpolation), one block per stream.
 //
 // HBM traffic per stream-tick (16k->48k): 320 B in + 960 B out (+ 96 B history
-// read + 96 B written) -- the kernel is HBM/launch bound, not VALU bound.
+// read + 96 B written).
 #include "common.hpp"
 
 #include <cmath>
@@ -116,14 +115,15 @@ bool design_filter(uint32_t in_rate, uint32_t out_rate, int quality, Design &d) 
 }
 
 // ------------------------------------------------------------------- kernels
-// WORD2INT of the library: round half up in double, clamp to int16.
+// WORD2INT of the library: floor(.5 + x) evaluated in double, clamped to int16 (x < -32767.5 -> -32768,
+// x > 32766.5 -> 32767).  Exact float form: clamp to [-32768, 32767], then (floor(2x) + 1) >> 1 -- 2x is
+// exact, and floor((floor(2x) + 1) / 2) == floor(x + .5) for every real x.
 __device__ __forceinline__ int16_t word2int(float x) {
-	if (x < -32767.5f) return (int16_t)-32768;
-	if (x > 32766.5f) return (int16_t)32767;
-	return (int16_t)(int)floor(0.5 + (double)x);
+	x = __builtin_amdgcn_fmed3f(x, -32768.f, 32767.f);
+	return (int16_t)(((int)floorf(x + x) + 1) >> 1);
 }
 
-__device__ __forceinline__ int skew(int i) { return i + (i >> 3); }
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct UpArgs {
 	const int16_t *in;
@@ -134,124 +134,175 @@ struct UpArgs {
 	const uint8_t *run;
 	int in_len, in_stride, out_stride, hist_stride, nstreams;
 	int tiles; // ceil(in_len / R)
-	int spb;   // streams per block
-	int xs;    // floats of LDS per stream (skewed)
 };
 
-template <int DEN, int FILT, int R>
-__global__ __launch_bounds__(256) void resample_up_kernel(UpArgs a) {
+// Integer up-sampling (num == 1): out[m*DEN + p] = sum_j table[p][j] * x[m + j].
+// Persistent wavefronts, one stream at a time per wave, no workgroup barriers.  A wave walks streams
+// blockIdx.x, +gridDim.x, ...; the next stream's history and input (8-byte loads, at most two per lane)
+// are already in flight while the current one is computed, so a wave always has a row of HBM reads
+// outstanding.  Lane (tile, phase) owns one polyphase row (FILT taps in VGPRs, loaded once per wave)
+// and R consecutive input positions; its FILT-1+R sample window comes out of LDS with 16-byte reads
+// (window start = 32*tile bytes, DEN lanes per address -> broadcast), outputs are staged in LDS and
+// leave as 16-byte stores.
+// acc += splat(t.lo or t.hi) * w on both halves.  Written as asm so the FILT x R/2 issue order below is
+// the one executed: left to itself the scheduler finishes one accumulator at a time and spills the window.
+template <int HI>
+__device__ __forceinline__ void pk_fma_splat(f2 &acc, const f2 t, const f2 w) {
+	if (HI)
+		asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(t), "v"(w));
+	else
+		asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t), "v"(w));
+}
+
+// (a.hi, b.lo): the window pair at an odd offset, one issue slot
+__device__ __forceinline__ f2 pk_odd_pair(const f2 a, const f2 b) {
+	f2 d;
+	asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+	return d;
+}
+
+template <int DEN, int FILT, int R, bool MULTI, bool TWO>
+__global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float *xbuf = reinterpret_cast<float *>(smem);
-	const int out_per_stream = a.in_len * DEN;
-	const int ostage_stride = (out_per_stream + 7) & ~7;
-	int16_t *obuf = reinterpret_cast<int16_t *>(smem + (size_t)a.spb * a.xs * sizeof(float));
-
-	const int tid = threadIdx.x;
-	const int s0 = blockIdx.x * a.spb;
-	const int nloc = min(a.spb, a.nstreams - s0);
 	constexpr int HIST = FILT - 1;
-	auto live = [&](int sl) -> bool { return a.run == nullptr || a.run[s0 + sl] != 0; };
+	static_assert(R == 8 && FILT % 8 == 0, "window = FILT+R-1 samples read as 16-byte groups");
+	const int lane = threadIdx.x;
+	const int out_per_stream = a.in_len * DEN;
+	const int xn = ((HIST + a.in_len + R + 1) + 3) & ~3;
+	float *x = reinterpret_cast<float *>(smem);                         // [xn] history ++ input ++ zero slack
+	int16_t *obuf = reinterpret_cast<int16_t *>(smem + (size_t)xn * 4); // [out_per_stream]
 
-	// ---- stage history + input as float (coalesced 8-byte loads)
+	// ---- this lane's polyphase row (first trip); the table is L2-resident
+	const int nlanes = DEN * a.tiles;
+	f2 t2[FILT / 2]; // taps as register pairs: v_pk_fma_f32 broadcasts either half through op_sel
 	{
-		const int hq = a.hist_stride >> 2;
-		for (int i = tid; i < nloc * hq; i += 256) {
-			const int sl = i / hq, q = i - sl * hq;
-			const short4 v = *reinterpret_cast<const short4 *>(a.hist + (size_t)(s0 + sl) * a.hist_stride + 4 * q);
-			float *x = xbuf + sl * a.xs;
-			const int b = 4 * q;
-			if (b + 0 < HIST) x[skew(b + 0)] = (float)v.x;
-			if (b + 1 < HIST) x[skew(b + 1)] = (float)v.y;
-			if (b + 2 < HIST) x[skew(b + 2)] = (float)v.z;
-			if (b + 3 < HIST) x[skew(b + 3)] = (float)v.w;
-		}
-		if (((a.in_len | a.in_stride) & 3) == 0) {
-			const int iq = a.in_len >> 2;
-			for (int i = tid; i < nloc * iq; i += 256) {
-				const int sl = i / iq, q = i - sl * iq;
-				const short4 v = *reinterpret_cast<const short4 *>(a.in + (size_t)(s0 + sl) * a.in_stride + 4 * q);
-				float *x = xbuf + sl * a.xs;
-				const int b = HIST + 4 * q;
-				x[skew(b + 0)] = (float)v.x;
-				x[skew(b + 1)] = (float)v.y;
-				x[skew(b + 2)] = (float)v.z;
-				x[skew(b + 3)] = (float)v.w;
-			}
-		} else {
-			for (int i = tid; i < nloc * a.in_len; i += 256) {
-				const int sl = i / a.in_len, q = i - sl * a.in_len;
-				xbuf[sl * a.xs + skew(HIST + q)] = (float)a.in[(size_t)(s0 + sl) * a.in_stride + q];
-			}
-		}
-		// zero the slack the last (partial) tile reads
-		const int used = HIST + a.in_len;
-		for (int i = tid; i < nloc * R; i += 256) {
-			const int sl = i / R, q = i - sl * R;
-			xbuf[sl * a.xs + skew(used + q)] = 0.f;
-		}
-	}
-	__syncthreads();
-
-	// ---- compute: lane = (stream, tile, phase)
-	const int lps = DEN * a.tiles;
-	const int sl = tid / lps;
-	if (sl < nloc && live(sl)) {
-		const int rem = tid - sl * lps;
-		const int tile = rem / DEN, p = rem - tile * DEN;
-		const int m0 = tile * R;
-		float t[FILT];
-		const float4 *tp = reinterpret_cast<const float4 *>(a.table + p * FILT);
+		const int l0 = lane < nlanes ? lane : 0;
+		const int p0 = l0 - (l0 / DEN) * DEN;
+		const float4 *tp = reinterpret_cast<const float4 *>(a.table + p0 * FILT);
 #pragma unroll
 		for (int j = 0; j < FILT / 4; ++j) {
 			const float4 v = tp[j];
-			t[4 * j + 0] = v.x;
-			t[4 * j + 1] = v.y;
-			t[4 * j + 2] = v.z;
-			t[4 * j + 3] = v.w;
+			t2[2 * j] = (f2){v.x, v.y}, t2[2 * j + 1] = (f2){v.z, v.w};
 		}
-		const float *x = xbuf + sl * a.xs;
-		float w[R], acc[R];
-#pragma unroll
-		for (int r = 0; r < R; ++r) acc[r] = 0.f;
-#pragma unroll
-		for (int r = 0; r < R - 1; ++r) w[r] = x[skew(m0 + r)];
-#pragma unroll
-		for (int j = 0; j < FILT; ++j) {
-			w[(j + R - 1) % R] = x[skew(m0 + R - 1 + j)];
-#pragma unroll
-			for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(t[j], w[(j + r) % R], acc[r]);
-		}
-		int16_t *o = obuf + sl * ostage_stride;
-#pragma unroll
-		for (int r = 0; r < R; ++r)
-			if (m0 + r < a.in_len) o[(m0 + r) * DEN + p] = word2int(acc[r]);
 	}
-	__syncthreads();
+	// ---- staging plan: quads [0, hq) are history, [hq, hq+iq) input; lane takes quads lane and lane+64
+	const int hq = a.hist_stride >> 2, nq = hq + (a.in_len >> 2);
+	constexpr bool two = TWO; // nq > 64: a second staging quad per lane
+	auto quad_ptr = [&](int s, int i) -> const short4 * {
+		const int16_t *p = i < hq ? a.hist + (size_t)s * a.hist_stride + 4 * i
+		                          : a.in + (size_t)s * a.in_stride + 4 * (i - hq);
+		return reinterpret_cast<const short4 *>(p);
+	};
+	short4 v0 = make_short4(0, 0, 0, 0), v1 = v0;
+	int s = blockIdx.x;
+	bool act = true;
+	if (s < a.nstreams) {
+		act = !a.run || a.run[s];
+		if (lane < nq) v0 = *quad_ptr(s, lane);
+		if (two && lane + 64 < nq) v1 = *quad_ptr(s, lane + 64);
+	}
+	for (int i = HIST + a.in_len + lane; i < xn; i += 64) x[i] = 0.f; // slack stays zero for every stream
 
-	// ---- outputs: 16-byte coalesced stores when the layout allows
-	if (((out_per_stream | a.out_stride) & 7) == 0) {
-		const int oq = out_per_stream >> 3;
-		for (int i = tid; i < nloc * oq; i += 256) {
-			const int s = i / oq, q = i - s * oq;
-			if (!live(s)) continue;
-			const uint4 v = *reinterpret_cast<const uint4 *>(obuf + s * ostage_stride + 8 * q);
-			*reinterpret_cast<uint4 *>(a.out + (size_t)(s0 + s) * a.out_stride + 8 * q) = v;
+	for (; s < a.nstreams; s += gridDim.x) {
+		// ---- the prefetched row goes to LDS as float
+		if (lane < nq) {
+			const int b = 4 * lane - (lane < hq ? 0 : 4 * hq - HIST);
+			if (lane < hq) {
+				if (b + 0 < HIST) x[b + 0] = (float)v0.x;
+				if (b + 1 < HIST) x[b + 1] = (float)v0.y;
+				if (b + 2 < HIST) x[b + 2] = (float)v0.z;
+				if (b + 3 < HIST) x[b + 3] = (float)v0.w;
+			} else {
+				x[b + 0] = (float)v0.x, x[b + 1] = (float)v0.y, x[b + 2] = (float)v0.z, x[b + 3] = (float)v0.w;
+			}
 		}
-	} else {
-		for (int i = tid; i < nloc * out_per_stream; i += 256) {
-			const int s = i / out_per_stream, q = i - s * out_per_stream;
-			if (!live(s)) continue;
-			a.out[(size_t)(s0 + s) * a.out_stride + q] = obuf[s * ostage_stride + q];
+		if (two && lane + 64 < nq) {
+			const int b = HIST + 4 * (lane + 64 - hq);
+			x[b + 0] = (float)v1.x, x[b + 1] = (float)v1.y, x[b + 2] = (float)v1.z, x[b + 3] = (float)v1.w;
 		}
+		const bool cur_act = act;
+		// ---- next stream's row: in flight during this stream's arithmetic
+		const int sn = s + gridDim.x;
+		if (sn < a.nstreams) {
+			act = !a.run || a.run[sn];
+			if (lane < nq) v0 = *quad_ptr(sn, lane);
+			if (two && lane + 64 < nq) v1 = *quad_ptr(sn, lane + 64);
+		}
+		if (!cur_act) { // masked out: no output, state untouched
+			if (lane == 0 && a.out_len) a.out_len[s] = 0;
+			__syncthreads();
+			continue;
+		}
+		for (int base = 0; base < (MULTI ? nlanes : 1); base += 64) { // !MULTI: nlanes <= 64, one trip
+			const int l = base + lane;
+			const bool on = l < nlanes;
+			const int tile = on ? l / DEN : 0, p = on ? l - tile * DEN : 0;
+			const int m0 = tile * R;
+			if (MULTI) { // several trips: the phase pattern shifts by 64 % DEN, reload the row
+				const float4 *tp = reinterpret_cast<const float4 *>(a.table + p * FILT);
+#pragma unroll
+				for (int j = 0; j < FILT / 4; ++j) {
+					const float4 v = tp[j];
+					t2[2 * j] = (f2){v.x, v.y}, t2[2 * j + 1] = (f2){v.z, v.w};
+				}
+			}
+			__syncthreads(); // single wave: LDS fence between staging and the window reads
+			// The window slides through registers 8 taps at a time (16 floats live, the next 8 in flight).
+			// v_pk_fma_f32 does two positions per issue slot: the tap is broadcast by op_sel, even-offset
+			// window pairs are register pairs as loaded, odd-offset pairs cost one v_pk_mov_b32 each.
+			const float4 *wp = reinterpret_cast<const float4 *>(x + m0);
+			float4 c0 = wp[0], c1 = wp[1], c2 = wp[2], c3 = wp[3];
+			f2 acc2[R / 2];
+#pragma unroll
+			for (int q = 0; q < R / 2; ++q) acc2[q] = (f2){0.f, 0.f};
+			f2 od[7]; // odd-offset pairs (w[2i+1], w[2i+2]) of the 16 live floats
+#pragma unroll
+			for (int c = 0; c < FILT / 8; ++c) {
+				const f2 ev[8] = {(f2){c0.x, c0.y}, (f2){c0.z, c0.w}, (f2){c1.x, c1.y}, (f2){c1.z, c1.w},
+				                  (f2){c2.x, c2.y}, (f2){c2.z, c2.w}, (f2){c3.x, c3.y}, (f2){c3.z, c3.w}};
+#pragma unroll
+				for (int i = (c == 0 ? 0 : 3); i < 7; ++i) od[i] = pk_odd_pair(ev[i], ev[i + 1]);
+#pragma unroll
+				for (int jj = 0; jj < 8; ++jj) {
+					const f2 tp2 = t2[(8 * c + jj) / 2];
+#pragma unroll
+					for (int q = 0; q < R / 2; ++q) {
+						const int k = jj + 2 * q; // 0..13 within the 16 live floats
+						const f2 wk = (k & 1) ? od[k / 2] : ev[k / 2];
+						if (jj & 1)
+							pk_fma_splat<1>(acc2[q], tp2, wk);
+						else
+							pk_fma_splat<0>(acc2[q], tp2, wk);
+					}
+				}
+				od[0] = od[4], od[1] = od[5], od[2] = od[6];
+				c0 = c2, c1 = c3;
+				if (c + 1 < FILT / 8) c2 = wp[2 * c + 4], c3 = wp[2 * c + 5];
+			}
+			float acc[R];
+#pragma unroll
+			for (int q = 0; q < R / 2; ++q) acc[2 * q] = acc2[q].x, acc[2 * q + 1] = acc2[q].y;
+			if (on) {
+#pragma unroll
+				for (int r = 0; r < R; ++r)
+					if (m0 + r < a.in_len) obuf[(m0 + r) * DEN + p] = word2int(acc[r]);
+			}
+		}
+		__syncthreads();
+		// ---- outputs: 16-byte coalesced stores (launch_up checked the layout)
+		int16_t *o = a.out + (size_t)s * a.out_stride;
+		for (int q = lane; q < (out_per_stream >> 3); q += 64)
+			*reinterpret_cast<uint4 *>(o + 8 * q) = *reinterpret_cast<const uint4 *>(obuf + 8 * q);
+		// ---- new history = last FILT-1 samples of (history ++ input); the pad slot takes the zero slack
+		if (lane < hq) {
+			const float *hx = x + a.in_len + 4 * lane;
+			short4 h;
+			h.x = (int16_t)hx[0], h.y = (int16_t)hx[1], h.z = (int16_t)hx[2], h.w = (int16_t)hx[3];
+			*reinterpret_cast<short4 *>(a.hist + (size_t)s * a.hist_stride + 4 * lane) = h;
+		}
+		if (lane == 0 && a.out_len) a.out_len[s] = out_per_stream;
+		__syncthreads(); // LDS reads above complete before the next row overwrites x / obuf
 	}
-	// ---- new history = last FILT-1 samples of (history ++ input)
-	for (int i = tid; i < nloc * HIST; i += 256) {
-		const int s = i / HIST, h = i - s * HIST;
-		if (!live(s)) continue;
-		a.hist[(size_t)(s0 + s) * a.hist_stride + h] = (int16_t)xbuf[s * a.xs + skew(a.in_len + h)];
-	}
-	if (a.out_len)
-		for (int i = tid; i < nloc; i += 256) a.out_len[s0 + i] = live(i) ? out_per_stream : 0;
 }
 
 struct GenArgs {
@@ -366,15 +417,13 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
                      int out_stride, int32_t *d_out_len, const uint8_t *d_run, bool *done) {
 	*done = false;
 	const int tiles = mi::ceil_div(in_len, R);
-	const int lps = DEN * tiles;
-	if (lps > 256) return MI_OK;
-	const int spb = 256 / lps;
-	const int xn = FILT - 1 + in_len + R;
-	const int xs = xn + (xn >> 3) + 1;
-	const int ostage = (in_len * DEN + 7) & ~7;
-	const size_t lds = (size_t)spb * xs * sizeof(float) + (size_t)spb * ostage * sizeof(int16_t);
-	if (lds > 64 * 1024) return MI_OK;
-	// keep the int16 staging area 16-byte aligned
+	const int xn = ((FILT - 1 + in_len + R + 1) + 3) & ~3;
+	const size_t lds = (size_t)xn * sizeof(float) + (size_t)((in_len * DEN + 7) & ~7) * sizeof(int16_t);
+	const int nq = (r->hist_stride >> 2) + (in_len >> 2);
+	// 8-byte row loads (at most two per lane) and 16-byte output stores; any other layout takes the generic kernel
+	if (lds > 48 * 1024 || ((in_len | in_stride) & 3) != 0 || nq > 128 || (reinterpret_cast<uintptr_t>(d_in) & 7) != 0 ||
+	    (((in_len * DEN) | out_stride) & 7) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15) != 0)
+		return MI_OK;
 	UpArgs a;
 	a.in = d_in;
 	a.out = d_out;
@@ -388,11 +437,19 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
 	a.hist_stride = r->hist_stride;
 	a.nstreams = r->nstreams;
 	a.tiles = tiles;
-	a.spb = spb;
-	a.xs = (xs + 3) & ~3;
-	const size_t lds2 = (size_t)spb * a.xs * sizeof(float) + (size_t)spb * ostage * sizeof(int16_t);
-	const int grid = mi::ceil_div(r->nstreams, spb);
-	hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R>), dim3(grid), dim3(256), lds2, r->ctx->stream, a);
+	// persistent waves: enough to fill every SIMD, each walking the same number of streams
+	static const int waves_per_cu = [] {
+		const char *e = getenv("MSMI355X_RESAMPLE_WAVES_PER_CU");
+		const int v = e ? atoi(e) : 0;
+		return v > 0 ? v : 16;
+	}();
+	const int max_grid = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * waves_per_cu;
+	const int per_wave = mi::ceil_div(r->nstreams, max_grid);
+	const int grid = mi::ceil_div(r->nstreams, per_wave);
+	if (DEN * tiles <= 64 && nq <= 64)
+		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, false, false>), dim3(grid), dim3(64), lds, r->ctx->stream, a);
+	else
+		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, true, true>), dim3(grid), dim3(64), lds, r->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	*done = true;
 	return MI_OK;
