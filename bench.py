@@ -141,7 +141,7 @@ def make_mixer_leg(ms, torch, ctx, nconf=128, mm=32, ns=480):
     def launch(i):
         mx.process(ins[i], None, 1, out=outs[i])
 
-    leg = Leg(ctx, "mixer_kernel<32,0>", launch, ring, per_tick, nconf, "conference-ticks")
+    leg = Leg(ctx, "mixer_members_kernel", launch, ring, per_tick, nconf, "conference-ticks")
     leg.keep = (mx, ins, outs)
     return leg
 

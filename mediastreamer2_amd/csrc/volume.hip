@@ -10,12 +10,15 @@
 //   volume_noise_gate_process :240-260, apply_gain :409-445 (ramp, Q12 integer
 //   gain with C truncating division, symmetric +-32767 clamp, optional DC removal).
 //
-// Mapping: a 128-thread workgroup owns SPB=16 streams.  (A) all lanes stage the
-// 16 chunks into LDS with 16-byte coalesced loads (row pitch odd in dwords, so
-// the per-stream walks of phase B are bank-conflict free); (B) one lane per
-// stream walks its chunk serially -- the float accumulation ORDER is part of
-// the reference's result -- and runs the scalar control chain;
-// (C) all lanes apply the integer gain and store 16 bytes per lane.  Streams
+// Mapping: one wavefront owns SPB=4 streams (4096 streams -> one wave per SIMD).
+// (A) all lanes stage the chunks into LDS with 16-byte coalesced loads and do
+// everything that is order-free on the way: (float)(v*v) per sample into a
+// second LDS array, integer peak and DC sum through LDS atomics; (B) one lane
+// per stream adds the squares in sample order -- the float accumulation ORDER
+// is part of the reference's result, so this is a chain of n
+// dependent v_add_f32 fed by 16-byte LDS reads and nothing else -- and runs the
+// scalar control chain; (C) all lanes apply the integer gain and store 16 bytes
+// per lane.  Streams
 // whose gain is exactly 1 (and no DC removal) are not written back, as in the
 // reference (msvolume.c:440).  HBM traffic: 2 B/sample read, <= 2 B/sample
 // written, + ~100 B of per-stream state.
@@ -25,8 +28,8 @@
 
 namespace {
 
-constexpr int SPB = 16;      // streams per block
-constexpr int VTHREADS = 128;
+constexpr int SPB = 4;       // streams per block (one wavefront)
+constexpr int VTHREADS = 64;
 
 struct VolArgs {
 	int16_t *samples;
@@ -35,25 +38,37 @@ struct VolArgs {
 	mi_volume_state *state;
 	const float *energy_prev; // peers read last launch's energy
 	float *energy_next;
-	int nstreams, nsamples, stride, sample_rate, pitch_dw;
+	int nstreams, nsamples, stride, sample_rate, pitch_dw, pitch_f;
 };
 
 __device__ __forceinline__ int sat16(int v) { return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v); }
 
 __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	uint32_t *rows = reinterpret_cast<uint32_t *>(smem); // [SPB][pitch_dw]
-	__shared__ int s_intgain[SPB], s_dcoff[SPB], s_mode[SPB], s_n[SPB];
+	uint32_t *rows = reinterpret_cast<uint32_t *>(smem);                              // [SPB][pitch_dw] packed int16
+	float *sq = reinterpret_cast<float *>(smem + (size_t)SPB * a.pitch_dw * 4);       // [SPB][pitch_f] (float)(v*v)
+	__shared__ int s_intgain[SPB], s_dcoff[SPB], s_mode[SPB], s_n[SPB], s_pk[SPB], s_dc[SPB];
 
 	const int tid = threadIdx.x;
 	const int s0 = blockIdx.x * SPB;
 	const int nloc = min(SPB, a.nstreams - s0);
 	const float max_e = (32768 * 0.7f);
 
+	// per-stream parameters and state: requested first, needed only in phase B
+	mi_volume_params p;
+	mi_volume_state st;
+	float peer_energy = 0;
+	if (tid < nloc) {
+		p = a.params[s0 + tid];
+		st = a.state[s0 + tid];
+		if (p.peer >= 0) peer_energy = a.energy_prev[p.peer];
+	}
 	if (tid < SPB) {
 		int n = 0;
 		if (tid < nloc) n = a.nsamples_per_stream ? a.nsamples_per_stream[s0 + tid] : a.nsamples;
 		s_n[tid] = min(max(n, 0), a.nsamples);
+		s_pk[tid] = 0;
+		s_dc[tid] = 0;
 	}
 	__syncthreads();
 
@@ -61,22 +76,59 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	const bool vec = ((a.stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.samples) & 15) == 0);
 	if (vec) {
 		const int oct = (a.nsamples + 7) >> 3; // 16-byte groups per row
-		for (int i = tid; i < nloc * oct; i += VTHREADS) {
-			const int sl = i / oct, q = i - sl * oct;
-			if (8 * q < s_n[sl]) {
-				const uint4 v = *reinterpret_cast<const uint4 *>(a.samples + (size_t)(s0 + sl) * a.stride + 8 * q);
-				uint32_t *r = rows + sl * a.pitch_dw + 4 * q;
-				r[0] = v.x;
-				r[1] = v.y;
-				r[2] = v.z;
-				r[3] = v.w;
+		constexpr int NB = 4;                  // loads in flight per lane
+		for (int base = 0; base < nloc * oct; base += NB * VTHREADS) {
+			uint4 v[NB];
+			int sl[NB], q[NB];
+			bool on[NB];
+			const int last = nloc * oct - 1;
+#pragma unroll
+			for (int u = 0; u < NB; ++u) { // straight-line loads (index clamped, rows are `stride` long): all in flight at once
+				const int i = base + u * VTHREADS + tid;
+				const int ic = min(i, last);
+				sl[u] = ic / oct;
+				q[u] = ic - sl[u] * oct;
+				on[u] = i <= last;
+				v[u] = *reinterpret_cast<const uint4 *>(a.samples + (size_t)(s0 + sl[u]) * a.stride + 8 * q[u]);
+			}
+#pragma unroll
+			for (int u = 0; u < NB; ++u) on[u] = on[u] && 8 * q[u] < s_n[sl[u]];
+#pragma unroll
+			for (int u = 0; u < NB; ++u) {
+				if (!on[u]) continue;
+				const int n = s_n[sl[u]];
+				*reinterpret_cast<uint4 *>(rows + sl[u] * a.pitch_dw + 4 * q[u]) = v[u];
+				const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+				float f[8];
+				int pk = 0, dc = 0;
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					const int x = (int)(short)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
+					f[k] = (float)(x * x);
+					if (8 * q[u] + k < n) {
+						const int av = x < 0 ? -x : x;
+						pk = max(pk, av);
+						dc += x;
+					}
+				}
+				float *d = sq + sl[u] * a.pitch_f + 8 * q[u];
+				*reinterpret_cast<float4 *>(d) = make_float4(f[0], f[1], f[2], f[3]);
+				*reinterpret_cast<float4 *>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+				atomicMax(&s_pk[sl[u]], pk);
+				atomicAdd(&s_dc[sl[u]], dc);
 			}
 		}
 	} else {
 		int16_t *rows16 = reinterpret_cast<int16_t *>(rows);
 		for (int i = tid; i < nloc * a.nsamples; i += VTHREADS) {
 			const int sl = i / a.nsamples, q = i - sl * a.nsamples;
-			if (q < s_n[sl]) rows16[sl * a.pitch_dw * 2 + q] = a.samples[(size_t)(s0 + sl) * a.stride + q];
+			if (q < s_n[sl]) {
+				const int x = a.samples[(size_t)(s0 + sl) * a.stride + q];
+				rows16[sl * a.pitch_dw * 2 + q] = (int16_t)x;
+				sq[sl * a.pitch_f + q] = (float)(x * x);
+				atomicMax(&s_pk[sl], x < 0 ? -x : x);
+				atomicAdd(&s_dc[sl], x);
+			}
 		}
 	}
 	__syncthreads();
@@ -85,19 +137,37 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	if (tid < nloc && s_n[tid] > 0) {
 		const int s = s0 + tid;
 		const int n = s_n[tid];
-		const mi_volume_params p = a.params[s];
-		mi_volume_state st = a.state[s];
-		const int16_t *x = reinterpret_cast<const int16_t *>(rows + tid * a.pitch_dw);
+		const float *x2 = sq + tid * a.pitch_f;
 
+		// same additions in the same order as update_energy's loop; 32 samples per stage, the next stage's
+		// LDS reads in flight while this one is added
 		float acc = 0;
-		int pk = 0, dcsum = 0;
-		for (int i = 0; i < n; ++i) {
-			const int v = x[i];
-			acc += (float)(v * v);
-			const int av = v < 0 ? -v : v;
-			if (av > pk) pk = av;
-			dcsum += v;
+		int i = 0;
+		const float4 *p4 = reinterpret_cast<const float4 *>(x2);
+		const int nb = n >> 5;
+		if (nb > 0) {
+			float4 c[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) c[k] = p4[k];
+			for (int b = 0; b < nb; ++b) {
+				float4 nx[8];
+				const float4 *pn = p4 + 8 * min(b + 1, nb - 1);
+#pragma unroll
+				for (int k = 0; k < 8; ++k) nx[k] = pn[k];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					acc += c[k].x;
+					acc += c[k].y;
+					acc += c[k].z;
+					acc += c[k].w;
+				}
+#pragma unroll
+				for (int k = 0; k < 8; ++k) c[k] = nx[k];
+			}
+			i = nb << 5;
 		}
+		for (; i < n; ++i) acc += x2[i];
+		const int pk = s_pk[tid], dcsum = s_dc[tid];
 		const float en = (float)((sqrt((double)(acc / n)) + 1) / (double)max_e);
 		st.energy = (en * 0.2f) + st.energy * (1.0f - 0.2f);
 		st.level_pk = (float)pk / max_e;
@@ -105,7 +175,7 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 
 		float target = p.static_gain;
 		if (p.peer >= 0) { // echo limiter
-			const float peer_e = a.energy_prev[p.peer], peer_pk = peer_e;
+			const float peer_e = peer_energy, peer_pk = peer_e;
 			if (peer_pk > st.lt_speaker_en) st.lt_speaker_en = peer_pk;
 			else st.lt_speaker_en = (0.005f * peer_pk) + (0.995f * st.lt_speaker_en);
 			const float ratio = (st.energy / (st.lt_speaker_en + p.ea_thres));
@@ -177,13 +247,16 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 			const int16_t *r = reinterpret_cast<const int16_t *>(rows + sl * a.pitch_dw) + 8 * q;
 			int16_t *dst = a.samples + (size_t)(s0 + sl) * a.stride + 8 * q;
 			if (8 * q + 8 <= n) {
-				union {
-					uint4 v;
-					int16_t h[8];
-				} o;
+				const uint4 rv = *reinterpret_cast<const uint4 *>(r);
+				const unsigned w[4] = {rv.x, rv.y, rv.z, rv.w};
+				unsigned o[4];
 #pragma unroll
-				for (int k = 0; k < 8; ++k) o.h[k] = (int16_t)sat16(((r[k] - dc) * ig) / 4096);
-				*reinterpret_cast<uint4 *>(dst) = o.v;
+				for (int k = 0; k < 4; ++k) {
+					const int lo = sat16((((int)(short)(w[k] & 0xffffu) - dc) * ig) / 4096);
+					const int hi = sat16((((int)(short)(w[k] >> 16) - dc) * ig) / 4096);
+					o[k] = (unsigned)(lo & 0xffff) | ((unsigned)hi << 16);
+				}
+				*reinterpret_cast<uint4 *>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
 			} else {
 				for (int k = 0; 8 * q + k < n; ++k) dst[k] = (int16_t)sat16(((r[k] - dc) * ig) / 4096);
 			}
@@ -323,11 +396,18 @@ int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride
 	a.nsamples = nsamples;
 	a.stride = stride;
 	a.sample_rate = v->sample_rate;
-	// row pitch: whole 16-byte groups, then made odd in dwords (bank-conflict-free walks)
-	int pitch = ((nsamples + 7) >> 3) * 4;
-	pitch |= 1;
+	// packed rows: whole 16-byte groups.  Float rows: whole groups of 8, and an odd number of 16-byte
+	// groups per row so the SPB lanes of phase B read disjoint banks.
+	const int pitch = ((nsamples + 7) >> 3) * 4;
+	int pitch_f = ((nsamples + 7) >> 3) * 8;
+	if (((pitch_f >> 2) & 1) == 0) pitch_f += 4;
 	a.pitch_dw = pitch;
-	const size_t lds = (size_t)SPB * pitch * sizeof(uint32_t);
+	a.pitch_f = pitch_f;
+	const size_t lds = (size_t)SPB * pitch * sizeof(uint32_t) + (size_t)SPB * pitch_f * sizeof(float);
+	if (lds > 60 * 1024) {
+		mi::set_error("volume chunk of %d samples does not fit the LDS staging (max ~2500)", nsamples);
+		return MI_ENOTSUP;
+	}
 	hipLaunchKernelGGL(volume_kernel, dim3(mi::ceil_div(v->nstreams, SPB)), dim3(VTHREADS), lds, v->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	v->cur ^= 1;
