@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel roofline table")
+    ap.add_argument("--pipeline-streams", type=int, default=65536,
+                    help="streams for the all-kernels-per-tick probe (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -241,6 +243,56 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
     return leg
 
 
+def pipeline_probe(ms, torch, ctx, nstreams):
+    """north_star check: every per-tick kernel of the path for `nstreams` concurrent 48 kHz streams on one GPU --
+    MSResample 16k->48k, MSVolume (AGC), MSAudioMixer (nstreams/32 conferences of 32), MSSpeexEC (256-sample
+    frames, 128 ms tail, post-filter; 480 samples per tick = 15 frames per 8 ticks).  Kernels run back to back on
+    the one stream, each on its own synthetic buffers (no fusion between filters is assumed)."""
+    nconf = max(1, nstreams // 32)
+    rs = make_resample_leg(ms, torch, ctx, nstreams)
+    vol = make_volume_leg(ms, torch, ctx, nstreams=nstreams)
+    mix = make_mixer_leg(ms, torch, ctx, nconf=nconf)
+    aec = make_aec_leg(ms, torch, ctx, nstreams=nstreams)
+    torch.cuda.synchronize()
+    state = {"f": 0}
+
+    def tick(t, frames):
+        rs.launch(t % rs.ring)
+        vol.launch(t % vol.ring)
+        mix.launch(t % mix.ring)
+        for _ in range(frames):
+            aec.launch(state["f"] % aec.ring)
+            state["f"] += 1
+
+    def timed_graph(plan, reps=3):
+        for t, fr in enumerate(plan):
+            tick(t, fr)
+        ctx.sync()
+        ctx.capture_begin()
+        for t, fr in enumerate(plan):
+            tick(t, fr)
+        g = ctx.capture_end()
+        g.launch()
+        ctx.sync()
+        best = None
+        for _ in range(reps):
+            ctx.timer_start()
+            g.launch()
+            ms_ = ctx.timer_stop()
+            best = ms_ if best is None else min(best, ms_)
+        return best / len(plan)
+
+    avg = timed_graph([2, 2, 2, 2, 2, 2, 2, 1])
+    worst = timed_graph([2, 2, 2, 2])
+    out = {"streams": nstreams, "conferences": nconf, "tick_ms_avg": round(avg, 4), "tick_ms_two_frame_tick": round(worst, 4),
+           "tick_budget_ms": 10.0, "fits": bool(worst < 10.0),
+           "aec_resident_state_bytes": int(aec.state_bytes),
+           "kernels_per_tick": "resample_up + volume + mixer_members + 1.875 x (aec_mdf_wave + aec_post_wave)"}
+    del rs, vol, mix, aec
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline_resample(nstreams, seconds):
     """The oracle (CPU restatement of the reference path: one resampler object per stream,
     called tick by tick) on this host's cores -- 1 thread, bounded sample."""
@@ -359,6 +411,11 @@ def main():
                 except Exception as e:  # an optional leg must never take the headline down
                     extras.append({"kernel": mk.__name__, "error": str(e)[:200]})
             line["other_kernels"] = extras
+            if a.pipeline_streams > 0:
+                try:
+                    line["pipeline"] = pipeline_probe(ms, torch, ctx, a.pipeline_streams)
+                except Exception as e:
+                    line["pipeline"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
     if rank == 0:
