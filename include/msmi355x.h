@@ -250,6 +250,34 @@ int mi_scaler_process(mi_scaler *s, int nframes, const uint8_t *d_src, size_t sr
 int mi_scaler_process_host(mi_scaler *s, int nframes, const uint8_t *h_src, size_t src_pitch, uint8_t *h_dst,
                            size_t dst_pitch);
 
+/* MSScalerDesc.context_process with the reference's own argument shape (msvideo.h:476): three plane
+ * pointers + strides on the HOST, one frame, synchronous.  dst[1], dst[2] are ignored for MI_PIX_RGB24.
+ * Strides may exceed the width; planes need not be contiguous. */
+int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], const int src_strides[3],
+                                  uint8_t *const dst[3], const int dst_strides[3]);
+
+/* ------------------------------------------------------------- pixconv */
+/* Packed formats -> I420, what pixconv_process (src/videofilters/pixconv.c:62-94) obtains from
+ * ms_scaler_process with the libyuv implementation (yuv_scale src/voip/msvideo.c:542-581).
+ * Formats are named by MEMORY byte order. */
+typedef struct mi_pixconv mi_pixconv;
+#define MI_PIX_YUY2 2      /* MS_YUY2, MS_YUYV: Y0 U Y1 V      (YUY2ToI420,  msvideo.c:553) */
+#define MI_PIX_UYVY 3      /* MS_UYVY:          U Y0 V Y1      (UYVYToI420,  :558) */
+#define MI_PIX_BGR24 4     /* MS_RGB24:         B G R, full-range output (RGB24ToJ420, :562) */
+#define MI_PIX_RGB24_RAW 5 /* MS_RGB24_REV:     R G B          (RAWToI420,   :566) */
+#define MI_PIX_BGRA32 6    /* MS_RGBA32_REV:    B G R A        (ARGBToI420,  :570) */
+/* flip_vertical: read the source bottom-up (pixconv.c:78-81 does it for MS_RGB24_REV with a negative
+ * stride).  Width must be even.  Source rows are packed (stride = w * bytes per pixel, as
+ * ms_picture_init_from_mblk_with_size msvideo.c:121-160 sets them). */
+int mi_pixconv_create(mi_ctx *ctx, int w, int h, int src_fmt, int flip_vertical, mi_pixconv **out);
+void mi_pixconv_destroy(mi_pixconv *p);
+size_t mi_pixconv_src_bytes(const mi_pixconv *p);
+size_t mi_pixconv_dst_bytes(const mi_pixconv *p);
+int mi_pixconv_process(mi_pixconv *p, int nframes, const uint8_t *d_src, size_t src_pitch, uint8_t *d_dst,
+                       size_t dst_pitch);
+int mi_pixconv_process_host(mi_pixconv *p, int nframes, const uint8_t *h_src, size_t src_pitch, uint8_t *h_dst,
+                            size_t dst_pitch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,3 +370,43 @@ class ScalerBatch(_Batch):
             out = torch.zeros((nf, self.dst_bytes), dtype=torch.uint8, device=src.device)
         check(self.ctx.L.mi_scaler_process(self.h, nf, _ptr(src), src.stride(0), _ptr(out), out.stride(0)))
         return out
+
+    def process_planes(self, src_planes, src_strides, dst_planes, dst_strides):
+        """MSScalerDesc.context_process argument shape: numpy uint8 arrays per plane + strides (one frame)."""
+        vp = C.c_void_p
+        sp = (vp * 3)(*[vp(p.ctypes.data) for p in src_planes])
+        dp = (vp * 3)(*[vp(p.ctypes.data) if p is not None else vp(0) for p in (list(dst_planes) + [None, None])[:3]])
+        ss = (C.c_int32 * 3)(*src_strides)
+        ds = (C.c_int32 * 3)(*(list(dst_strides) + [0, 0])[:3])
+        check(self.ctx.L.mi_scaler_process_planes_host(self.h, sp, ss, dp, ds))
+
+
+MI_PIX_YUY2, MI_PIX_UYVY, MI_PIX_BGR24, MI_PIX_RGB24_RAW, MI_PIX_BGRA32 = 2, 3, 4, 5, 6
+
+
+class PixConvBatch(_Batch):
+    """MSPixConv's conversion (pixconv.c:62-94 through yuv_scale msvideo.c:542-581) for a batch of packed frames."""
+    _destroy = "mi_pixconv_destroy"
+
+    def __init__(self, ctx, w, h, src_fmt, flip=False):
+        self.ctx = ctx
+        self.w, self.height, self.fmt = w, h, src_fmt
+        hd = C.c_void_p()
+        check(ctx.L.mi_pixconv_create(ctx.h, w, h, src_fmt, 1 if flip else 0, C.byref(hd)))
+        self.h = hd
+        self.src_bytes = ctx.L.mi_pixconv_src_bytes(hd)
+        self.dst_bytes = ctx.L.mi_pixconv_dst_bytes(hd)
+
+    def process(self, src, out=None):
+        """src [nframes, src_bytes] uint8 -> [nframes, dst_bytes] I420."""
+        nf = src.shape[0]
+        if isinstance(src, np.ndarray):
+            src = np.ascontiguousarray(src, np.uint8)
+            out = np.zeros((nf, self.dst_bytes), np.uint8) if out is None else out
+            check(self.ctx.L.mi_pixconv_process_host(self.h, nf, _ptr(src), src.shape[1], _ptr(out), out.shape[1]))
+            return out
+        import torch
+        if out is None:
+            out = torch.zeros((nf, self.dst_bytes), dtype=torch.uint8, device=src.device)
+        check(self.ctx.L.mi_pixconv_process(self.h, nf, _ptr(src), src.stride(0), _ptr(out), out.stride(0)))
+        return out

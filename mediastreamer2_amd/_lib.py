@@ -40,7 +40,9 @@ EXPORTS = [
     "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process",
     "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_get",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
-    "mi_scaler_process", "mi_scaler_process_host",
+    "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
+    "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
+    "mi_pixconv_process", "mi_pixconv_process_host",
 ]
 
 
@@ -183,6 +185,17 @@ def load():
         L.mi_scaler_dst_bytes.restype = sz
         L.mi_scaler_process.argtypes = [vp, i32, vp, sz, vp, sz]
         L.mi_scaler_process_host.argtypes = [vp, i32, vp, sz, vp, sz]
+        L.mi_scaler_process_planes_host.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32)]
+    if hasattr(L, "mi_pixconv_create"):
+        L.mi_pixconv_create.argtypes = [vp, i32, i32, i32, i32, pp]
+        L.mi_pixconv_destroy.argtypes = [vp]
+        L.mi_pixconv_destroy.restype = None
+        L.mi_pixconv_src_bytes.argtypes = [vp]
+        L.mi_pixconv_src_bytes.restype = sz
+        L.mi_pixconv_dst_bytes.argtypes = [vp]
+        L.mi_pixconv_dst_bytes.restype = sz
+        L.mi_pixconv_process.argtypes = [vp, i32, vp, sz, vp, sz]
+        L.mi_pixconv_process_host.argtypes = [vp, i32, vp, sz, vp, sz]
     _lib = L
     return L
 

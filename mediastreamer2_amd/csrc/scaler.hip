@@ -570,4 +570,39 @@ int mi_scaler_process_host(mi_scaler *s, int nframes, const uint8_t *h_src, size
 	return MI_OK;
 }
 
+int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], const int src_strides[3],
+                                  uint8_t *const dst[3], const int dst_strides[3]) {
+	MI_CHECK_ARG(s && src && src_strides && dst && dst_strides && src[0] && src[1] && src[2] && dst[0]);
+	const ScArgs &a = s->a;
+	MI_CHECK_ARG(src_strides[0] >= a.sw && src_strides[1] >= a.scw && src_strides[2] >= a.scw);
+	MI_CHECK_ARG(a.rgb ? dst_strides[0] >= 3 * a.dw : (dst[1] && dst[2] && dst_strides[0] >= a.dw && dst_strides[1] >= a.dcw && dst_strides[2] >= a.dcw));
+	mi_ctx *c = s->ctx;
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	void *din, *dout;
+	int rc;
+	if ((rc = c->ensure_scratch(0, s->src_bytes + 32, &din)) != MI_OK) return rc;
+	if ((rc = c->ensure_scratch(1, s->dst_bytes + 32, &dout)) != MI_OK) return rc;
+	uint8_t *d = (uint8_t *)din, *o = (uint8_t *)dout;
+	// gather the three planes into the packed device layout (ms_yuv_buf_init order); rows beyond an odd
+	// height are the pad row of that layout and are never sampled by the kernels
+	const size_t ysz = (size_t)a.sw * a.sh2, csz = (size_t)a.scw * a.sch;
+	const int ch_rows = (a.sh + 1) / 2;
+	MI_HIP(hipMemcpy2DAsync(d, (size_t)a.sw, src[0], (size_t)src_strides[0], (size_t)a.sw, (size_t)a.sh, hipMemcpyHostToDevice, c->stream));
+	MI_HIP(hipMemcpy2DAsync(d + ysz, (size_t)a.scw, src[1], (size_t)src_strides[1], (size_t)a.scw, (size_t)ch_rows, hipMemcpyHostToDevice, c->stream));
+	MI_HIP(hipMemcpy2DAsync(d + ysz + csz, (size_t)a.scw, src[2], (size_t)src_strides[2], (size_t)a.scw, (size_t)ch_rows, hipMemcpyHostToDevice, c->stream));
+	rc = mi_scaler_process(s, 1, d, s->src_bytes, o, s->dst_bytes);
+	if (rc != MI_OK) return rc;
+	if (a.rgb) {
+		MI_HIP(hipMemcpy2DAsync(dst[0], (size_t)dst_strides[0], o, (size_t)a.dw * 3, (size_t)a.dw * 3, (size_t)a.dh, hipMemcpyDeviceToHost, c->stream));
+	} else {
+		const size_t dysz = (size_t)a.dw * a.dh2, dcsz = (size_t)a.dcw * a.dch;
+		const int dch_rows = (a.dh + 1) / 2;
+		MI_HIP(hipMemcpy2DAsync(dst[0], (size_t)dst_strides[0], o, (size_t)a.dw, (size_t)a.dw, (size_t)a.dh, hipMemcpyDeviceToHost, c->stream));
+		MI_HIP(hipMemcpy2DAsync(dst[1], (size_t)dst_strides[1], o + dysz, (size_t)a.dcw, (size_t)a.dcw, (size_t)dch_rows, hipMemcpyDeviceToHost, c->stream));
+		MI_HIP(hipMemcpy2DAsync(dst[2], (size_t)dst_strides[2], o + dysz + dcsz, (size_t)a.dcw, (size_t)a.dcw, (size_t)dch_rows, hipMemcpyDeviceToHost, c->stream));
+	}
+	MI_HIP(hipStreamSynchronize(c->stream));
+	return MI_OK;
+}
+
 } // extern "C"

@@ -93,6 +93,7 @@ def _declare(L):
     L.orc_i420_scale.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
     L.orc_i420_to_rgb24.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int]
     L.orc_i420_scale_to_rgb24.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+    L.orc_pixconv_to_i420.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, u8p]
     if hasattr(L, "orc_echo_new"):
         L.orc_echo_new.argtypes = [C.c_int, C.c_int, C.c_int]
         L.orc_echo_new.restype = C.c_void_p
@@ -297,3 +298,19 @@ class Preproc:
         x = np.array(x, dtype=np.int16, copy=True)
         lib().orc_preproc_run(self.h, _p(x, C.c_int16))
         return x
+
+
+PIX_YUY2, PIX_UYVY, PIX_BGR24, PIX_RGB24_RAW, PIX_BGRA32 = 2, 3, 4, 5, 6
+PIX_BPP = {PIX_YUY2: 2, PIX_UYVY: 2, PIX_BGR24: 3, PIX_RGB24_RAW: 3, PIX_BGRA32: 4}
+
+
+def pixconv_to_i420(fmt, src, w, h, flip=False):
+    """src: packed frame, w*h*bpp bytes; flip = walk it bottom-up (negative stride, pixconv.c:78-81)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros(i420_size(w, h), np.uint8)
+    stride = w * PIX_BPP[fmt]
+    base = src.ctypes.data + (stride * (h - 1) if flip else 0)
+    rc = lib().orc_pixconv_to_i420(fmt, C.c_void_p(base), -stride if flip else stride, w, h, _p(dst, C.c_uint8))
+    if rc != 0:
+        raise ValueError("orc_pixconv_to_i420 rejected the arguments")
+    return dst

@@ -138,6 +138,16 @@ void orc_i420_to_rgb24(const uint8_t *src, int w, int h, uint8_t *rgb, int rgb_s
 /* the fused pipeline the GPU kernel implements: scale then convert */
 void orc_i420_scale_to_rgb24(const uint8_t *src, int sw, int sh, uint8_t *rgb, int dw, int dh);
 
+/* Packed formats -> I420, what MSPixConv (src/videofilters/pixconv.c:62-94) gets from the libyuv
+ * scaler implementation (yuv_scale, src/voip/msvideo.c:542-581).  Formats named by MEMORY order. */
+#define ORC_PIX_YUY2 2      /* MS_YUY2 / MS_YUYV  -> YUY2ToI420  */
+#define ORC_PIX_UYVY 3      /* MS_UYVY            -> UYVYToI420  */
+#define ORC_PIX_BGR24 4     /* MS_RGB24           -> RGB24ToJ420 (full range) */
+#define ORC_PIX_RGB24_RAW 5 /* MS_RGB24_REV       -> RAWToI420   */
+#define ORC_PIX_BGRA32 6    /* MS_RGBA32_REV      -> ARGBToI420  */
+/* src_stride may be negative (pixconv.c:78-81 flips RGB24_REV); w must be even.  0 on success. */
+int orc_pixconv_to_i420(int fmt, const uint8_t *src, int src_stride, int w, int h, uint8_t *dst);
+
 /* -------------------------------------------------------------------- AEC */
 /* Restates libspeexdsp's MDF echo canceller (mdf.c, float build) and the
  * preprocessor residual-echo / denoise stage (preprocess.c) as called from

@@ -339,3 +339,53 @@ def test_aec_cancels_a_synthetic_echo(oracle):
     assert db(mic[tail]) - db(out[tail]) > 25.0       # linear canceller ERLE
     assert db(mic[tail]) - db(post[tail]) > 40.0      # + residual echo suppression
     assert ec.get("scalars", 16)[8] == 1.0            # adapted
+
+
+# ---------------------------------------------------------------- pixconv (packed -> I420)
+def test_pixconv_known_answers(oracle):
+    """BT.601 limited-range anchors of the libyuv rows (white/black/primaries), the JPEG set for MS_RGB24,
+    and the 4:2:2 chroma average with its +1 rounding."""
+    w, h = 4, 2
+
+    def solid(fmt, r, g, b):
+        px = {oracle.PIX_BGR24: [b, g, r], oracle.PIX_RGB24_RAW: [r, g, b], oracle.PIX_BGRA32: [b, g, r, 255]}[fmt]
+        out = oracle.pixconv_to_i420(fmt, np.array(px * (w * h), np.uint8), w, h)
+        return int(out[0]), int(out[w * h]), int(out[w * h + (w // 2) * (h // 2)])
+
+    assert solid(oracle.PIX_RGB24_RAW, 255, 255, 255) == (235, 128, 128)
+    assert solid(oracle.PIX_RGB24_RAW, 0, 0, 0) == (16, 128, 128)
+    assert solid(oracle.PIX_BGRA32, 255, 0, 0) == (82, 90, 240)     # red   (66*255+0x1080)>>8 = 82, hand-computed
+    assert solid(oracle.PIX_BGRA32, 0, 255, 0) == (144, 54, 34)     # green (129*255+0x1080)>>8 = 144
+    assert solid(oracle.PIX_BGRA32, 0, 0, 255) == (41, 240, 110)    # blue
+    assert solid(oracle.PIX_BGR24, 255, 255, 255) == (255, 128, 128)  # full range (J420)
+    assert solid(oracle.PIX_BGR24, 0, 0, 0) == (0, 128, 128)
+    # YUY2: luma is copied, chroma is the rounded mean of the two rows
+    row0 = [10, 100, 20, 200, 30, 101, 40, 201]
+    row1 = [50, 103, 60, 203, 70, 102, 80, 204]
+    out = oracle.pixconv_to_i420(oracle.PIX_YUY2, np.array(row0 + row1, np.uint8), 4, 2)
+    assert list(out[:8]) == [10, 20, 30, 40, 50, 60, 70, 80]
+    assert list(out[8:10]) == [(100 + 103 + 1) >> 1, (101 + 102 + 1) >> 1]
+    assert list(out[10:12]) == [(200 + 203 + 1) >> 1, (201 + 204 + 1) >> 1]
+    uy = oracle.pixconv_to_i420(oracle.PIX_UYVY, np.array([100, 10, 200, 20, 101, 30, 201, 40] + [103, 50, 203, 60, 102, 70, 204, 80], np.uint8), 4, 2)
+    np.testing.assert_array_equal(uy, out)
+
+
+def test_pixconv_matches_numpy_restatement(oracle):
+    """Independent vectorised restatement of the RGB rows (nested rounded averages, Q8 coefficients)."""
+    rng = np.random.default_rng(11)
+    w, h = 32, 17  # odd height: the last row pairs with itself
+    src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = oracle.pixconv_to_i420(oracle.PIX_RGB24_RAW, src.ravel(), w, h)
+    r, g, b = [src[..., k].astype(np.int64) for k in range(3)]
+    y = (66 * r + 129 * g + 25 * b + 0x1080) >> 8
+    np.testing.assert_array_equal(got[: w * h].reshape(h, w), y)
+    hp = h + 1
+    pad = np.concatenate([src, src[-1:]], 0).astype(np.int64)  # row h-1 again
+    avg = lambda a, c: (a + c + 1) >> 1
+    a2 = avg(avg(pad[0::2, 0::2], pad[1::2, 0::2]), avg(pad[0::2, 1::2], pad[1::2, 1::2]))
+    ar, ag, ab = a2[..., 0], a2[..., 1], a2[..., 2]
+    u = (112 * ab - 74 * ag - 38 * ar + 0x8080) >> 8
+    v = (112 * ar - 94 * ag - 18 * ab + 0x8080) >> 8
+    cw, chh = w // 2, hp // 2
+    np.testing.assert_array_equal(got[w * hp: w * hp + cw * chh].reshape(chh, cw), u)
+    np.testing.assert_array_equal(got[w * hp + cw * chh:].reshape(chh, cw), v)
