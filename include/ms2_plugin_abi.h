@@ -23,6 +23,7 @@
 #include <mediastreamer2/msfilter.h>
 #include <mediastreamer2/msinterfaces.h>
 #include <mediastreamer2/msticker.h>
+#include <mediastreamer2/msvideo.h>
 #include <mediastreamer2/msvolume.h>
 #else
 
@@ -279,6 +280,74 @@ typedef struct _MSAudioFlowControlDropEvent {
 } MSAudioFlowControlDropEvent;
 #define MS_AUDIO_FLOW_CONTROL_DROP_EVENT MS_FILTER_EVENT(MS_AUDIO_FLOW_CONTROL_ID, 0, MSAudioFlowControlDropEvent)
 
+/* ---- video (include/mediastreamer2/msvideo.h) ---- */
+#define MS_VIDEO_SIZE_CIF_W 352 /* msvideo.h:39-40 */
+#define MS_VIDEO_SIZE_CIF_H 288
+typedef struct MSVideoSize { /* msvideo.h:231-233 */
+	int width, height;
+} MSVideoSize;
+typedef enum MSVideoOrientation { MS_VIDEO_LANDSCAPE = 0, MS_VIDEO_PORTRAIT = 1 } MSVideoOrientation; /* :265 */
+typedef enum { /* msvideo.h:267-280 */
+	MS_PIX_FMT_UNKNOWN,
+	MS_YUV420P,
+	MS_YUYV,
+	MS_RGB24,
+	MS_RGB24_REV,
+	MS_MJPEG,
+	MS_UYVY,
+	MS_YUY2,
+	MS_RGBA32,
+	MS_RGB565,
+	MS_H264,
+	MS_RGBA32_REV
+} MSPixFmt;
+typedef struct _MSPicture { /* msvideo.h:282-288 */
+	int w, h;
+	uint8_t *planes[4];
+	int strides[4];
+} MSPicture;
+typedef struct _MSPicture YuvBuf;
+static inline MSVideoOrientation ms_video_size_get_orientation(MSVideoSize vs) { /* msvideo.h:453-455 */
+	return vs.width >= vs.height ? MS_VIDEO_LANDSCAPE : MS_VIDEO_PORTRAIT;
+}
+#define MS_SCALER_METHOD_NEIGHBOUR 1
+#define MS_SCALER_METHOD_BILINEAR (1 << 1)
+typedef struct _MSScalerContext MSScalerContext;
+typedef struct _MSScalerDesc { /* msvideo.h:473-478 */
+	MSScalerContext *(*create_context)(int src_w, int src_h, MSPixFmt src_fmt, int dst_w, int dst_h, MSPixFmt dst_fmt,
+	                                   int flags);
+	int (*context_process)(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t *dst[], int dst_strides[]);
+	void (*context_free)(MSScalerContext *ctx);
+} MSScalerDesc;
+/* src/voip/msvideo.c:702-725 */
+MSScalerContext *ms_scaler_create_context(int src_w, int src_h, MSPixFmt src_fmt, int dst_w, int dst_h, MSPixFmt dst_fmt,
+                                          int flags);
+int ms_scaler_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t *dst[], int dst_strides[]);
+void ms_scaler_context_free(MSScalerContext *ctx);
+void ms_video_set_scaler_impl(MSScalerDesc *desc);
+MSScalerDesc *ms_video_get_scaler_impl(void);
+/* frame layout and block helpers, src/voip/msvideo.c:79-99,:101-160,:162-176,:272-304 */
+void ms_yuv_buf_init(YuvBuf *buf, int w, int h, int stride, uint8_t *ptr);
+int ms_yuv_buf_init_from_mblk(YuvBuf *buf, mblk_t *m);
+int ms_yuv_buf_init_from_mblk_with_size(YuvBuf *buf, mblk_t *m, int w, int h);
+int ms_picture_init_from_mblk_with_size(MSPicture *buf, mblk_t *m, MSPixFmt fmt, int w, int h);
+mblk_t *ms_yuv_buf_alloc(YuvBuf *buf, int w, int h);
+typedef struct _MSYuvBufAllocator MSYuvBufAllocator;
+MSYuvBufAllocator *ms_yuv_buf_allocator_new(void);
+mblk_t *ms_yuv_buf_allocator_get(MSYuvBufAllocator *obj, MSPicture *buf, int w, int h);
+void ms_yuv_buf_allocator_free(MSYuvBufAllocator *obj);
+/* msvideo.h:615-622 */
+#define MS_FILTER_SET_VIDEO_SIZE MS_FILTER_BASE_METHOD(100, MSVideoSize)
+#define MS_FILTER_GET_VIDEO_SIZE MS_FILTER_BASE_METHOD(101, MSVideoSize)
+#define MS_FILTER_SET_PIX_FMT MS_FILTER_BASE_METHOD(102, MSPixFmt)
+#define MS_FILTER_GET_PIX_FMT MS_FILTER_BASE_METHOD(103, MSPixFmt)
+#define MS_FILTER_SET_FPS MS_FILTER_BASE_METHOD(104, float)
+#define MS_FILTER_GET_FPS MS_FILTER_BASE_METHOD(105, float)
+/* msfilter.h:631-633,:693-695 */
+#define MS_FILTER_EVENT_NO_ARG(_id_, _count_) MS_FILTER_METHOD_ID(_id_, _count_, 0)
+#define MS_FILTER_BASE_EVENT_NO_ARG(_count_) MS_FILTER_EVENT_NO_ARG(MS_FILTER_BASE_ID, _count_)
+#define MS_FILTER_OUTPUT_FMT_CHANGED MS_FILTER_BASE_EVENT_NO_ARG(0)
+
 /* ---- factory / filter API (msfactory.h, msfilter.h) ---- */
 MSFactory *ms_factory_new(void);
 void ms_factory_destroy(MSFactory *f);
@@ -293,6 +362,7 @@ int ms_filter_link(MSFilter *f1, int pin1, MSFilter *f2, int pin2);   /* src/bas
 int ms_filter_unlink(MSFilter *f1, int pin1, MSFilter *f2, int pin2);
 int ms_filter_call_method(MSFilter *f, unsigned int id, void *arg);    /* src/base/msfilter.c:171-197 */
 void ms_filter_notify(MSFilter *f, unsigned int id, void *arg);
+void ms_filter_notify_no_arg(MSFilter *f, unsigned int id); /* msfilter.h:725 */
 void ms_filter_add_notify_callback(MSFilter *f, MSFilterNotifyFunc fn, void *userdata, bool_t synchronous);
 void ms_filter_postpone_task(MSFilter *f, MSFilterFunc task);           /* src/base/msfilter.c:289-300 */
 
@@ -325,6 +395,12 @@ extern MSFilterDesc ms_mi355x_audio_mixer_desc; /* .id = MS_AUDIO_MIXER_ID, repl
 extern MSFilterDesc ms_mi355x_volume_desc;      /* .id = MS_VOLUME_ID,      replaces src/audiofilters/msvolume.c:538-548 */
 extern MSFilterDesc ms_mi355x_equalizer_desc;   /* .id = MS_EQUALIZER_ID,   replaces src/audiofilters/equalizer.c:366-375 */
 extern MSFilterDesc ms_mi355x_speex_ec_desc;    /* .id = MS_SPEEX_EC_ID,    replaces src/audiofilters/speexec.c:411-422 */
+extern MSFilterDesc ms_mi355x_size_conv_desc;   /* .id = MS_SIZE_CONV_ID,   replaces src/videofilters/sizeconv.c:221-247 */
+extern MSFilterDesc ms_mi355x_pix_conv_desc;    /* .id = MS_PIX_CONV_ID,    replaces src/videofilters/pixconv.c:112-138 */
+/* MSScalerDesc (msvideo.h:473-478) backed by the scaler / pixconv kernels; libmsmi355xfilters_init installs
+ * it with ms_video_set_scaler_impl (msvideo.c:719-721), so the reference's OWN MSSizeConv / MSPixConv /
+ * display filters reach the GPU too (one frame per call, synchronous, as that interface demands). */
+extern MSScalerDesc ms_mi355x_scaler_desc;
 /* Runs every staged batch (one launch per filter type) -- called once per tick after the
  * graphs have run; with a real MSTicker it is the task the filters postpone (msfilter.c:289-300). */
 void ms_mi355x_flush(void);

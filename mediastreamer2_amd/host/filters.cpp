@@ -1569,6 +1569,504 @@ MSFilterMethod ec_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, ec_set_sr},
                                {MS_ECHO_CANCELLER_GET_DELAY, ec_get_delay},
                                {0, NULL}};
 
+// ====================================================================== video
+// ---- MSScalerDesc (msvideo.h:473-478): the reference's synchronous, one-frame interface -------------
+// Dispatch on the SOURCE format like yuv_scale (src/voip/msvideo.c:542-581): I420 is scaled (dst RGB24
+// is honoured like the swscale implementation :672-681 does; libyuv's ignores it), packed formats are
+// converted to I420 at the same size.
+int pix_to_mi(MSPixFmt f) {
+	switch (f) {
+		case MS_YUY2:
+		case MS_YUYV: return MI_PIX_YUY2;
+		case MS_UYVY: return MI_PIX_UYVY;
+		case MS_RGB24: return MI_PIX_BGR24;
+		case MS_RGB24_REV: return MI_PIX_RGB24_RAW;
+		case MS_RGBA32_REV: return MI_PIX_BGRA32;
+		default: return -1;
+	}
+}
+int pix_bpp(MSPixFmt f) {
+	switch (f) {
+		case MS_YUY2:
+		case MS_YUYV:
+		case MS_UYVY: return 2;
+		case MS_RGB24:
+		case MS_RGB24_REV: return 3;
+		default: return 4;
+	}
+}
+
+struct ScalerCtx { // what MSScalerContext* points to
+	int sw, sh, dw, dh;
+	MSPixFmt sf, df;
+	mi_scaler *sc = nullptr;
+	mi_pixconv *pc[2] = {nullptr, nullptr}; // [flip]
+	std::vector<uint8_t> packed_in, packed_out;
+};
+
+MSScalerContext *sd_create(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt df, int flags) {
+	(void)flags; // bilinear either way, like yuv_create_scale_context msvideo.c:526-540
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	ScalerCtx *c = new ScalerCtx();
+	c->sw = sw, c->sh = sh, c->dw = dw, c->dh = dh, c->sf = sf, c->df = df;
+	if (sf == MS_YUV420P) {
+		const int fmt = (df == MS_RGB24) ? MI_PIX_RGB24 : MI_PIX_I420;
+		if ((df != MS_RGB24 && df != MS_YUV420P) || mi_scaler_create(g_hub.context(), sw, sh, dw, dh, fmt, &c->sc) != MI_OK) {
+			ms_error("msmi355x scaler: %dx%d fmt %d -> %dx%d fmt %d unsupported: %s", sw, sh, (int)sf, dw, dh, (int)df, mi_last_error());
+			delete c;
+			return NULL;
+		}
+	} else if (pix_to_mi(sf) < 0 || sw != dw || sh != dh) {
+		ms_warning("msmi355x scaler: unsupported format %d or size change on a packed source", (int)sf); // msvideo.c:574-576
+		delete c;
+		return NULL;
+	}
+	return (MSScalerContext *)c;
+}
+
+int sd_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t *dst[], int dst_strides[]) {
+	ScalerCtx *c = (ScalerCtx *)ctx;
+	if (!c) return -1;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (c->sc) {
+		const uint8_t *sp[3] = {src[0], src[1], src[2]};
+		uint8_t *dp[3] = {dst[0], dst[1], dst[2]};
+		return mi_scaler_process_planes_host(c->sc, sp, src_strides, dp, dst_strides) == MI_OK ? 0 : -1;
+	}
+	// packed -> I420.  A negative stride means the caller walks the bitmap bottom-up (pixconv.c:78-81).
+	const int bpp = pix_bpp(c->sf), rowb = c->sw * bpp;
+	const int flip = src_strides[0] < 0;
+	const int stride = flip ? -src_strides[0] : src_strides[0];
+	if (stride < rowb) return -1;
+	if (!c->pc[flip] && mi_pixconv_create(g_hub.context(), c->sw, c->sh, pix_to_mi(c->sf), flip, &c->pc[flip]) != MI_OK) {
+		ms_error("msmi355x scaler: %s", mi_last_error());
+		return -1;
+	}
+	const uint8_t *lowest = flip ? src[0] - (size_t)stride * (c->sh - 1) : src[0];
+	const uint8_t *in = lowest;
+	if (stride != rowb) { // pack the rows
+		c->packed_in.resize((size_t)rowb * c->sh);
+		for (int y = 0; y < c->sh; ++y) memcpy(c->packed_in.data() + (size_t)y * rowb, lowest + (size_t)y * stride, (size_t)rowb);
+		in = c->packed_in.data();
+	}
+	const size_t ob = mi_pixconv_dst_bytes(c->pc[flip]);
+	c->packed_out.resize(ob);
+	if (mi_pixconv_process_host(c->pc[flip], 1, in, mi_pixconv_src_bytes(c->pc[flip]), c->packed_out.data(), ob) != MI_OK) {
+		ms_error("msmi355x scaler: %s", mi_last_error());
+		return -1;
+	}
+	const int w = c->sw, h = c->sh, h2 = h + (h & 1), cw = w / 2, ch = (h + 1) / 2;
+	const uint8_t *o = c->packed_out.data();
+	for (int y = 0; y < h; ++y) memcpy(dst[0] + (size_t)y * dst_strides[0], o + (size_t)y * w, (size_t)w);
+	for (int y = 0; y < ch; ++y) {
+		memcpy(dst[1] + (size_t)y * dst_strides[1], o + (size_t)w * h2 + (size_t)y * cw, (size_t)cw);
+		memcpy(dst[2] + (size_t)y * dst_strides[2], o + (size_t)w * h2 + (size_t)cw * (h2 / 2) + (size_t)y * cw, (size_t)cw);
+	}
+	return 0;
+}
+
+void sd_free(MSScalerContext *ctx) {
+	ScalerCtx *c = (ScalerCtx *)ctx;
+	if (!c) return;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (c->sc) mi_scaler_destroy(c->sc);
+	for (int i = 0; i < 2; ++i)
+		if (c->pc[i]) mi_pixconv_destroy(c->pc[i]);
+	delete c;
+}
+
+// ---- frame pools: every MSSizeConv (or MSPixConv) of one geometry on one ticker shares a batch --------
+struct FramePool : Pool {
+	struct Staged {
+		MSFilter *f;
+		uint32_t ts;
+	};
+	size_t src_bytes = 0, dst_bytes = 0, src_pitch = 0, dst_pitch = 0;
+	int out_w = 0, out_h = 0;
+	uint8_t *h_src = nullptr, *h_dst = nullptr, *d_src = nullptr, *d_dst = nullptr;
+	std::vector<Staged> staged, ready;
+	virtual int launch(int nframes) = 0;
+	void alloc_buffers() {
+		src_pitch = (src_bytes + 31) & ~(size_t)15; // slack for the kernels' 16-byte row loads
+		dst_pitch = (dst_bytes + 15) & ~(size_t)15;
+		const size_t c = (size_t)capacity;
+		h_src = pinned<uint8_t>(c * src_pitch);
+		h_dst = pinned<uint8_t>(c * dst_pitch);
+		d_src = devmem<uint8_t>(c * src_pitch + 32);
+		d_dst = devmem<uint8_t>(c * dst_pitch + 32);
+	}
+	// next staging buffer, or NULL when `capacity` frames are already waiting for this tick's flush
+	uint8_t *stage(MSFilter *f, uint32_t ts) {
+		if ((int)staged.size() >= capacity) {
+			ms_error("msmi355x plugin: frame pool full (%d frames per tick; raise MSMI355X_SLOTS)", capacity);
+			return nullptr;
+		}
+		staged.push_back({f, ts});
+		return h_src + (staged.size() - 1) * src_pitch;
+	}
+	void flush() override {
+		ready.clear();
+		const int n = (int)staged.size();
+		if (!n) return;
+		mi_ctx *ctx = g_hub.context();
+		MI_MUST(mi_copy_h2d(ctx, d_src, h_src, (size_t)n * src_pitch));
+		MI_MUST(launch(n));
+		MI_MUST(mi_copy_d2h(ctx, h_dst, d_dst, (size_t)n * dst_pitch));
+		MI_MUST(mi_ctx_sync(ctx));
+		ready.swap(staged);
+	}
+	void emit(MSFilter *f, int slot) override;
+	void forget(MSFilter *f) { // the filter left the pool: its frames in flight are dropped
+		for (Staged &s : staged)
+			if (s.f == f) s.f = nullptr;
+		for (Staged &s : ready)
+			if (s.f == f) s.f = nullptr;
+	}
+};
+
+struct VideoOut { // what a frame-pool client exposes for result delivery
+	MSYuvBufAllocator *allocator;
+};
+
+void FramePool::emit(MSFilter *f, int slot) {
+	(void)slot;
+	for (size_t k = 0; k < ready.size(); ++k) {
+		if (ready[k].f != f) continue;
+		ready[k].f = nullptr;
+		VideoOut *vo = (VideoOut *)f->data; // first member of both filter states
+		YuvBuf ob;
+		mblk_t *om = ms_yuv_buf_allocator_get(vo->allocator, &ob, out_w, out_h);
+		if (om == NULL) continue;
+		// device layout == ms_yuv_buf_init layout (stride w, contiguous planes)
+		memcpy(ob.planes[0], h_dst + k * dst_pitch, dst_bytes);
+		mblk_set_timestamp_info(om, ready[k].ts);
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
+		else freemsg(om);
+	}
+}
+
+struct ScalerPool : FramePool {
+	mi_scaler *sc = nullptr;
+	ScalerPool(int sw, int sh, int dw, int dh) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_scaler_create(g_hub.context(), sw, sh, dw, dh, MI_PIX_I420, &sc));
+		src_bytes = mi_scaler_src_bytes(sc);
+		dst_bytes = mi_scaler_dst_bytes(sc);
+		out_w = dw, out_h = dh;
+		alloc_buffers();
+	}
+	int launch(int n) override { return mi_scaler_process(sc, n, d_src, src_pitch, d_dst, dst_pitch); }
+};
+std::map<std::tuple<MSTicker *, int, int, int, int>, ScalerPool *> g_scaler_pools;
+
+struct PixPool : FramePool {
+	mi_pixconv *pc = nullptr;
+	PixPool(int w, int h, int fmt, int flip) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_pixconv_create(g_hub.context(), w, h, fmt, flip, &pc));
+		src_bytes = mi_pixconv_src_bytes(pc);
+		dst_bytes = mi_pixconv_dst_bytes(pc);
+		out_w = w, out_h = h;
+		alloc_buffers();
+	}
+	int launch(int n) override { return mi_pixconv_process(pc, n, d_src, src_pitch, d_dst, dst_pitch); }
+};
+std::map<std::tuple<MSTicker *, int, int, int>, PixPool *> g_pix_pools;
+
+// ---- MSSizeConv (src/videofilters/sizeconv.c) ----------------------------------------------------------
+struct SizeConvState { // SizeConvState sizeconv.c:29-40
+	MSYuvBufAllocator *allocator; // first: VideoOut
+	MSVideoSize target_vsize;
+	MSVideoSize in_vsize;
+	float fps;
+	float start_time;
+	int frame_count;
+	queue_t rq;
+	bool_t needRefresh;
+	ScalerPool *pool;
+	int slot;
+};
+
+void size_conv_leave_pool(SizeConvState *s, MSFilter *f) {
+	if (s->pool) {
+		s->pool->forget(f);
+		s->pool->release(s->slot);
+	}
+	s->pool = nullptr;
+	s->slot = -1;
+}
+
+void size_conv_init(MSFilter *f) { // sizeconv.c:46-60
+	SizeConvState *s = (SizeConvState *)ms_malloc0(sizeof(SizeConvState));
+	s->target_vsize.width = MS_VIDEO_SIZE_CIF_W;
+	s->target_vsize.height = MS_VIDEO_SIZE_CIF_H;
+	s->allocator = ms_yuv_buf_allocator_new();
+	s->start_time = 0;
+	s->frame_count = -1;
+	s->needRefresh = FALSE;
+	s->fps = -1; /* default to process ALL frames */
+	s->slot = -1;
+	qinit(&s->rq);
+	f->data = s;
+}
+void size_conv_uninit(MSFilter *f) { // :62-66
+	SizeConvState *s = (SizeConvState *)f->data;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		size_conv_leave_pool(s, f);
+	}
+	ms_yuv_buf_allocator_free(s->allocator);
+	ms_free(s);
+}
+void size_conv_postprocess(MSFilter *f) { // :68-76 (the scaler context there == our pool membership)
+	SizeConvState *s = (SizeConvState *)f->data;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		size_conv_leave_pool(s, f);
+	}
+	flushq(&s->rq, 0);
+	s->frame_count = -1;
+}
+
+// get_resampler sizeconv.c:82-95: (re)join the pool of this geometry
+ScalerPool *size_conv_pool(MSFilter *f, SizeConvState *s, int w, int h) {
+	if (s->pool && s->in_vsize.width == w && s->in_vsize.height == h && s->pool->ticker == f->ticker &&
+	    s->pool->out_w == s->target_vsize.width && s->pool->out_h == s->target_vsize.height)
+		return s->pool;
+	size_conv_leave_pool(s, f);
+	auto key = std::make_tuple(f->ticker, w, h, s->target_vsize.width, s->target_vsize.height);
+	auto it = g_scaler_pools.find(key);
+	if (it == g_scaler_pools.end()) {
+		ScalerPool *p = new ScalerPool(w, h, s->target_vsize.width, s->target_vsize.height);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_scaler_pools.emplace(key, p).first;
+	}
+	s->pool = it->second;
+	s->slot = s->pool->acquire(f);
+	if (s->slot < 0) s->pool = nullptr;
+	s->in_vsize.width = w;
+	s->in_vsize.height = h;
+	ms_message("MSSizeConv: create new scaler context with w %d, h %d", w, h);
+	return s->pool;
+}
+
+void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
+	SizeConvState *s = (SizeConvState *)f->data;
+	YuvBuf inbuf;
+	mblk_t *im;
+	int cur_frame;
+
+	ms_filter_lock(f);
+	if (s->frame_count == -1) {
+		s->start_time = (float)f->ticker->time;
+		s->frame_count = 0;
+	}
+	while ((im = ms_queue_get(f->inputs[0])) != NULL) putq(&s->rq, im);
+
+	cur_frame = (int)((f->ticker->time - s->start_time) * s->fps / 1000.0);
+	if (cur_frame <= s->frame_count && s->fps >= 0) {
+		/* too much frame */
+		while (s->rq.q_mcount > 1) {
+			ms_message("MSSizeConv: extra frame removed.");
+			freemsg(getq(&s->rq));
+		}
+		ms_filter_unlock(f);
+		return;
+	}
+	if (cur_frame > s->frame_count && s->fps >= 0) {
+		/*keep the most recent frame if several frames have been captured */
+		while (s->rq.q_mcount > 1) {
+			ms_message("MSSizeConv: extra frame removed.");
+			freemsg(getq(&s->rq));
+		}
+	}
+	bool staged_any = false;
+	while ((im = getq(&s->rq)) != NULL) {
+		if (ms_yuv_buf_init_from_mblk(&inbuf, im) == 0) {
+			if (inbuf.w == s->target_vsize.width && inbuf.h == s->target_vsize.height) {
+				ms_queue_put(f->outputs[0], im);
+			} else {
+				int w = s->target_vsize.width;
+				int h = s->target_vsize.height;
+				// keep the same orientation
+				MSVideoSize in_sz = {inbuf.w, inbuf.h};
+				if (ms_video_size_get_orientation(in_sz) != ms_video_size_get_orientation(s->target_vsize)) {
+					s->target_vsize.width = h;
+					s->target_vsize.height = w;
+				}
+				// keep the aspect ratio of the input
+				if (inbuf.w * s->target_vsize.height / s->target_vsize.width != inbuf.h) {
+					if (inbuf.w > inbuf.h) s->target_vsize.height = inbuf.h * s->target_vsize.width / inbuf.w;
+					else s->target_vsize.width = inbuf.w * s->target_vsize.height / inbuf.h;
+				}
+				if (s->target_vsize.width != w || s->target_vsize.height != h) {
+					s->needRefresh = TRUE;
+					ms_filter_notify_no_arg(f, MS_FILTER_OUTPUT_FMT_CHANGED);
+				} else if (!s->needRefresh) {
+					std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+					ScalerPool *p = size_conv_pool(f, s, inbuf.w, inbuf.h);
+					uint8_t *dst = p ? p->stage(f, mblk_get_timestamp_info(im)) : nullptr;
+					if (dst) {
+						// gather the planes into the packed frame layout (they are contiguous in practice)
+						const int h2 = inbuf.h + (inbuf.h & 1), cw = inbuf.w / 2, chh = (inbuf.h + 1) / 2;
+						for (int y = 0; y < inbuf.h; ++y) memcpy(dst + (size_t)y * inbuf.w, inbuf.planes[0] + (size_t)y * inbuf.strides[0], (size_t)inbuf.w);
+						uint8_t *du = dst + (size_t)inbuf.w * h2, *dv = du + (size_t)cw * (h2 / 2);
+						for (int y = 0; y < chh; ++y) {
+							memcpy(du + (size_t)y * cw, inbuf.planes[1] + (size_t)y * inbuf.strides[1], (size_t)cw);
+							memcpy(dv + (size_t)y * cw, inbuf.planes[2] + (size_t)y * inbuf.strides[2], (size_t)cw);
+						}
+						staged_any = true;
+					} else {
+						ms_error("MSSizeConv: error in ms_scaler_process().");
+					}
+				} else {
+					ms_warning("MSSizeConv: output fmt changed, waiting.");
+				}
+				freemsg(im);
+			}
+			s->frame_count++;
+		} else {
+			ms_warning("size_conv_process(): bad buffer.");
+			freemsg(im);
+		}
+	}
+	ms_filter_unlock(f);
+	if (staged_any) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		request_flush(f);
+	}
+}
+
+int sizeconv_set_vsize(MSFilter *f, void *arg) { // sizeconv.c:186-197
+	SizeConvState *s = (SizeConvState *)f->data;
+	ms_filter_lock(f);
+	s->target_vsize = *(MSVideoSize *)arg;
+	ms_message("sizeconv_set_vsize(): set target size w %d, h %d", s->target_vsize.width, s->target_vsize.height);
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		size_conv_leave_pool(s, f);
+	}
+	ms_filter_unlock(f);
+	return 0;
+}
+int sizeconv_set_fps(MSFilter *f, void *arg) { // :199-204
+	SizeConvState *s = (SizeConvState *)f->data;
+	s->fps = *((float *)arg);
+	s->frame_count = -1; /* reset counter used for fps */
+	return 0;
+}
+int sizeconv_get_vsize(MSFilter *f, void *data) { // :206-212
+	SizeConvState *s = (SizeConvState *)f->data;
+	MSVideoSize *vsize = (MSVideoSize *)data;
+	vsize->width = s->target_vsize.width;
+	vsize->height = s->target_vsize.height;
+	return 0;
+}
+MSFilterMethod sizeconv_methods[] = {{MS_FILTER_SET_FPS, sizeconv_set_fps}, // sizeconv.c:214-217
+                                     {MS_FILTER_SET_VIDEO_SIZE, sizeconv_set_vsize},
+                                     {MS_FILTER_GET_VIDEO_SIZE, sizeconv_get_vsize},
+                                     {0, NULL}};
+
+// ---- MSPixConv (src/videofilters/pixconv.c) --------------------------------------------------------------
+struct PixConvState { // PixConvState pixconv.c:27-34
+	MSYuvBufAllocator *allocator; // first: VideoOut
+	MSVideoSize size;
+	MSPixFmt in_fmt;
+	MSPixFmt out_fmt;
+	PixPool *pool;
+	int slot;
+};
+
+void pixconv_leave_pool(PixConvState *s, MSFilter *f) {
+	if (s->pool) {
+		s->pool->forget(f);
+		s->pool->release(s->slot);
+	}
+	s->pool = nullptr;
+	s->slot = -1;
+}
+void pixconv_init(MSFilter *f) { // pixconv.c:36-45
+	PixConvState *s = (PixConvState *)ms_malloc0(sizeof(PixConvState));
+	s->allocator = ms_yuv_buf_allocator_new();
+	s->size.width = MS_VIDEO_SIZE_CIF_W;
+	s->size.height = MS_VIDEO_SIZE_CIF_H;
+	s->in_fmt = MS_YUV420P;
+	s->out_fmt = MS_YUV420P;
+	s->slot = -1;
+	f->data = s;
+}
+void pixconv_uninit(MSFilter *f) { // :47-55
+	PixConvState *s = (PixConvState *)f->data;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		pixconv_leave_pool(s, f);
+	}
+	ms_yuv_buf_allocator_free(s->allocator);
+	ms_free(s);
+}
+void pixconv_process(MSFilter *f) { // pixconv.c:62-94
+	PixConvState *s = (PixConvState *)f->data;
+	mblk_t *im;
+	bool staged_any = false;
+	while ((im = ms_queue_get(f->inputs[0])) != NULL) {
+		const uint32_t frame_ts = mblk_get_timestamp_info(im);
+		if (s->in_fmt == s->out_fmt) {
+			mblk_set_timestamp_info(im, frame_ts);
+			ms_queue_put(f->outputs[0], im);
+			continue;
+		}
+		MSPicture inbuf;
+		if (ms_picture_init_from_mblk_with_size(&inbuf, im, s->in_fmt, s->size.width, s->size.height) == 0) {
+			std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+			const int fmt = pix_to_mi(s->in_fmt);
+			const int flip = s->in_fmt == MS_RGB24_REV; // :78-81
+			if (fmt < 0 || (inbuf.w & 1)) {
+				ms_error("MSPixConv: Error in ms_sws_scale()."); // what a failing ms_scaler_process logs, :84
+			} else {
+				if (!s->pool || s->pool->ticker != f->ticker || s->pool->out_w != inbuf.w || s->pool->out_h != inbuf.h) {
+					pixconv_leave_pool(s, f);
+					auto key = std::make_tuple(f->ticker, inbuf.w, inbuf.h, (int)s->in_fmt);
+					auto it = g_pix_pools.find(key);
+					if (it == g_pix_pools.end()) {
+						PixPool *p = new PixPool(inbuf.w, inbuf.h, fmt, flip);
+						p->ticker = f->ticker;
+						g_hub.pools.push_back(p);
+						it = g_pix_pools.emplace(key, p).first;
+					}
+					s->pool = it->second;
+					s->slot = s->pool->acquire(f);
+					if (s->slot < 0) s->pool = nullptr;
+				}
+				uint8_t *dst = s->pool ? s->pool->stage(f, frame_ts) : nullptr;
+				if (dst) {
+					memcpy(dst, inbuf.planes[0], s->pool->src_bytes);
+					staged_any = true;
+				}
+			}
+		}
+		freemsg(im);
+	}
+	if (staged_any) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		request_flush(f);
+	}
+}
+int pixconv_set_vsize(MSFilter *f, void *arg) { // :96-100
+	((PixConvState *)f->data)->size = *(MSVideoSize *)arg;
+	return 0;
+}
+int pixconv_set_pixfmt(MSFilter *f, void *arg) { // :102-107
+	PixConvState *s = (PixConvState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->in_fmt = *(MSPixFmt *)arg;
+	pixconv_leave_pool(s, f);
+	return 0;
+}
+MSFilterMethod pixconv_methods[] = {{MS_FILTER_SET_VIDEO_SIZE, pixconv_set_vsize}, // pixconv.c:109-110
+                                    {MS_FILTER_SET_PIX_FMT, pixconv_set_pixfmt},
+                                    {0, NULL}};
+
 } // namespace
 
 extern "C" {
@@ -1593,12 +2091,23 @@ MSFilterDesc ms_mi355x_speex_ec_desc = {MS_SPEEX_EC_ID, "MSSpeexEC", "Echo cance
                                         MS_FILTER_OTHER, NULL, 2, 2, ec_init, ec_preprocess, ec_process, ec_postprocess,
                                         ec_uninit, ec_methods, MS_FILTER_IS_HW_ACCELERATED};
 
+MSFilterDesc ms_mi355x_size_conv_desc = {MS_SIZE_CONV_ID, "MSSizeConv", "A video size converter (MI355X batch)", MS_FILTER_OTHER,
+                                         NULL, 1, 1, size_conv_init, NULL, size_conv_process, size_conv_postprocess,
+                                         size_conv_uninit, sizeconv_methods, MS_FILTER_IS_HW_ACCELERATED};
+MSFilterDesc ms_mi355x_pix_conv_desc = {MS_PIX_CONV_ID, "MSPixConv", "A pixel format converter (MI355X batch)", MS_FILTER_OTHER,
+                                        NULL, 1, 1, pixconv_init, NULL, pixconv_process, NULL, pixconv_uninit,
+                                        pixconv_methods, MS_FILTER_IS_HW_ACCELERATED};
+MSScalerDesc ms_mi355x_scaler_desc = {sd_create, sd_process, sd_free};
+
 void libmsmi355xfilters_init(MSFactory *factory) {
 	ms_factory_register_filter(factory, &ms_mi355x_resample_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_audio_mixer_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_volume_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_equalizer_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_speex_ec_desc);
+	ms_factory_register_filter(factory, &ms_mi355x_size_conv_desc);
+	ms_factory_register_filter(factory, &ms_mi355x_pix_conv_desc);
+	ms_video_set_scaler_impl(&ms_mi355x_scaler_desc); // msvideo.c:719-721: the reference's own video filters follow
 	ms_message("libmsmi355xfilters: MI355X batched filters registered (ABI %d)", mi_abi_version());
 }
 

@@ -347,6 +347,109 @@ void ms_filter_notify(MSFilter *f, unsigned int id, void *arg) {
 	for (Notify *n = (Notify *)f->notify_callbacks; n; n = n->next) n->fn(n->ud, f, id, arg);
 }
 
+void ms_filter_notify_no_arg(MSFilter *f, unsigned int id) { ms_filter_notify(f, id, NULL); }
+
+/* -------------------------------------------------------------------- video */
+/* Frame layout, block header and scaler indirection of src/voip/msvideo.c (test runtime only). */
+typedef struct _mblk_video_header { /* msvideo.c:79-83 */
+	uint16_t w, h;
+	int pad[3];
+} mblk_video_header;
+
+void ms_yuv_buf_init(YuvBuf *buf, int w, int h, int stride, uint8_t *ptr) { /* msvideo.c:85-99 */
+	int ysize = stride * ((h & 1) ? h + 1 : h), usize = ysize / 4;
+	buf->w = w;
+	buf->h = h;
+	buf->planes[0] = ptr;
+	buf->planes[1] = buf->planes[0] + ysize;
+	buf->planes[2] = buf->planes[1] + usize;
+	buf->planes[3] = 0;
+	buf->strides[0] = stride;
+	buf->strides[1] = stride / 2;
+	buf->strides[2] = buf->strides[1];
+	buf->strides[3] = 0;
+}
+
+int ms_yuv_buf_init_from_mblk(YuvBuf *buf, mblk_t *m) { /* msvideo.c:101-113 */
+	mblk_video_header *hdr = (mblk_video_header *)m->b_datap->db_base;
+	int w = hdr->w, h = hdr->h;
+	if (m->b_cont == NULL) ms_yuv_buf_init(buf, w, h, w, m->b_rptr);
+	else ms_yuv_buf_init(buf, w, h, w, m->b_cont->b_rptr);
+	return 0;
+}
+
+int ms_yuv_buf_init_from_mblk_with_size(YuvBuf *buf, mblk_t *m, int w, int h) { /* msvideo.c:115-119 */
+	if (m->b_cont != NULL) m = m->b_cont;
+	ms_yuv_buf_init(buf, w, h, w, m->b_rptr);
+	return 0;
+}
+
+int ms_picture_init_from_mblk_with_size(MSPicture *buf, mblk_t *m, MSPixFmt fmt, int w, int h) { /* :121-160 */
+	if (m->b_cont != NULL) m = m->b_cont;
+	int bpp;
+	switch (fmt) {
+		case MS_YUV420P: return ms_yuv_buf_init_from_mblk_with_size(buf, m, w, h);
+		case MS_YUY2:
+		case MS_YUYV:
+		case MS_UYVY: bpp = 2; break;
+		case MS_RGB24:
+		case MS_RGB24_REV: bpp = 3; break;
+		case MS_RGBA32:
+		case MS_RGBA32_REV: bpp = 4; break;
+		default: ms_error("Unsupported format %i with %dx%d", fmt, w, h); return -1;
+	}
+	memset(buf, 0, sizeof(*buf));
+	buf->w = w;
+	buf->h = h;
+	buf->planes[0] = m->b_rptr;
+	buf->strides[0] = w * bpp;
+	return 0;
+}
+
+static mblk_t *yuv_block(int size, int w, int h) { /* ms_yuv_allocator_get msvideo.c:282-296 */
+	const int header_size = (int)sizeof(mblk_video_header), padding = 16;
+	mblk_t *msg = allocb((size_t)(header_size + size + padding), 0);
+	mblk_video_header *hdr = (mblk_video_header *)msg->b_wptr;
+	hdr->w = (uint16_t)w;
+	hdr->h = (uint16_t)h;
+	msg->b_rptr += header_size;
+	msg->b_wptr += header_size;
+	msg->b_wptr += size;
+	return msg;
+}
+
+mblk_t *ms_yuv_buf_alloc(YuvBuf *buf, int w, int h) { /* msvideo.c:162-176 */
+	int size = (w * ((h & 1) ? h + 1 : h) * 3) / 2;
+	mblk_t *msg = yuv_block(size, w, h);
+	ms_yuv_buf_init(buf, w, h, w, msg->b_rptr);
+	return msg;
+}
+
+struct _MSYuvBufAllocator {
+	int unused; /* the reference recycles blocks (msgb_allocator, <= 15 in flight); the shim just allocates */
+};
+MSYuvBufAllocator *ms_yuv_buf_allocator_new(void) { return (MSYuvBufAllocator *)ms_malloc0(sizeof(MSYuvBufAllocator)); }
+mblk_t *ms_yuv_buf_allocator_get(MSYuvBufAllocator *obj, MSPicture *buf, int w, int h) { /* msvideo.c:298-304 */
+	(void)obj;
+	return ms_yuv_buf_alloc(buf, w, h);
+}
+void ms_yuv_buf_allocator_free(MSYuvBufAllocator *obj) { ms_free(obj); }
+
+static MSScalerDesc *scaler_impl = NULL; /* msvideo.c:700 */
+MSScalerContext *ms_scaler_create_context(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt df, int flags) {
+	if (!scaler_impl) {
+		ms_error("No scaler implementation built-in, please supply one with ms_video_set_scaler_impl ()");
+		return NULL;
+	}
+	return scaler_impl->create_context(sw, sh, sf, dw, dh, df, flags);
+}
+int ms_scaler_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t *dst[], int dst_strides[]) {
+	return scaler_impl->context_process(ctx, src, src_strides, dst, dst_strides);
+}
+void ms_scaler_context_free(MSScalerContext *ctx) { scaler_impl->context_free(ctx); }
+void ms_video_set_scaler_impl(MSScalerDesc *desc) { scaler_impl = desc; }
+MSScalerDesc *ms_video_get_scaler_impl(void) { return scaler_impl; }
+
 /* ------------------------------------------------------------------- ticker */
 typedef struct Task {
 	MSFilter *f;
@@ -568,6 +671,33 @@ void ms2shim_source_push(MSFilter *src, const void *data, size_t nbytes) {
 	m->b_wptr += nbytes;
 	putq(&d->pending, m);
 }
+void ms2shim_source_push_ts(MSFilter *src, const void *data, size_t nbytes, uint32_t ts) {
+	SrcData *d = (SrcData *)src->data;
+	mblk_t *m = allocb(nbytes, 0);
+	memcpy(m->b_wptr, data, nbytes);
+	m->b_wptr += nbytes;
+	mblk_set_timestamp_info(m, ts);
+	putq(&d->pending, m);
+}
+/* an I420 frame as the reference's capture filters emit it: video header before b_rptr (msvideo.c:162-176) */
+void ms2shim_source_push_yuv(MSFilter *src, const void *i420, int w, int h, uint32_t ts) {
+	SrcData *d = (SrcData *)src->data;
+	YuvBuf buf;
+	mblk_t *m = ms_yuv_buf_alloc(&buf, w, h);
+	memcpy(buf.planes[0], i420, (size_t)(w * ((h & 1) ? h + 1 : h) * 3) / 2);
+	mblk_set_timestamp_info(m, ts);
+	putq(&d->pending, m);
+}
+static int g_notify_count;
+static unsigned g_notify_last;
+static void count_notify(void *ud, MSFilter *f, unsigned int id, void *arg) {
+	(void)ud, (void)f, (void)arg;
+	g_notify_count++;
+	g_notify_last = id;
+}
+void ms2shim_watch(MSFilter *f) { ms_filter_add_notify_callback(f, count_notify, NULL, TRUE); }
+int ms2shim_notify_count(void) { return g_notify_count; }
+unsigned ms2shim_notify_last(void) { return g_notify_last; }
 size_t ms2shim_sink_size(MSFilter *sink) { return ((SinkData *)sink->data)->len; }
 int ms2shim_sink_blocks(MSFilter *sink) { return ((SinkData *)sink->data)->nblocks; }
 uint32_t ms2shim_sink_last_ts(MSFilter *sink) { return ((SinkData *)sink->data)->last_ts; }
