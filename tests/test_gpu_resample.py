@@ -121,3 +121,25 @@ def test_resampler_full_size_config2_properties(ctx, oracle):
             ref = orc.process(base[s, t * in_len:(t + 1) * in_len])
             assert np.abs(outs[t][s].astype(int) - ref.astype(int)).max() <= 1
     rs.close()
+
+
+def test_resampler_on_the_reference_wav_pair(ctx, oracle):
+    """The reference ships one recording at 16 kHz and at 48 kHz (tester/sounds/test_silence_voice_*.wav, fixture
+    excerpt in tests/golden/resample_wav/): the 16 k file resampled on the GPU must reproduce the 48 k file with
+    the similarity the reference's tester demands of a resampled path (aec3_tester.c:743-758: >= 0.98), and
+    equal the oracle within 1 LSB."""
+    from test_oracle_cpu import reference_wav_pair, best_alignment_similarity
+    x16, x48 = reference_wav_pair()
+    rs = ms.ResamplerBatch(ctx, 3, 16000, 48000)
+    orc = oracle.Resampler(16000, 48000)
+    got, want = [], []
+    for i in range(0, len(x16), 160):
+        blk = np.stack([x16[i:i + 160], np.zeros(160, np.int16), x16[i:i + 160]])
+        out, olen = rs.process(blk)
+        assert list(olen) == [480, 480, 480]
+        np.testing.assert_array_equal(out[0], out[2])
+        got.append(out[0].copy())
+        want.append(orc.process(x16[i:i + 160]))
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert np.abs(got.astype(np.int32) - want).max() <= 1
+    assert best_alignment_similarity(got, x48[: len(got)]) >= 0.98

@@ -177,29 +177,35 @@ def _read_wav(path):
     raise ValueError(path)
 
 
-REF_SOUNDS = "/root/reference/tester/sounds"
+RESAMPLE_WAV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample_wav")
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_SOUNDS), reason="reference tree not present (GPU box)")
-def test_resampler_against_reference_wav_pair(oracle):
-    """The reference ships the SAME recording at 16 kHz and 48 kHz (tester/sounds/
-    test_silence_voice_{16000,48000}.wav).  Resampling the 16 k file must reproduce the 48 k one
-    up to the similarity threshold the reference's own tester uses for a resampled path
-    (aec3_tester.c:743-758: >= 0.98)."""
-    r16, _, x16 = _read_wav(os.path.join(REF_SOUNDS, "test_silence_voice_16000.wav"))
-    r48, _, x48 = _read_wav(os.path.join(REF_SOUNDS, "test_silence_voice_48000.wav"))
+def reference_wav_pair():
+    """Seconds 3..9 of the reference's tester/sounds/test_silence_voice_{16000,48000}.wav -- the SAME recording
+    shipped at two rates (fixture cut by tests/golden/make_resample_excerpts.py)."""
+    r16, _, x16 = _read_wav(os.path.join(RESAMPLE_WAV, "voice_16000_6s.wav"))
+    r48, _, x48 = _read_wav(os.path.join(RESAMPLE_WAV, "voice_48000_6s.wav"))
     assert (r16, r48) == (16000, 48000)
-    n = 160 * 600  # 6 s
-    start = 160 * 300
-    rs = oracle.Resampler(16000, 48000)
-    y = np.concatenate([rs.process(x16[start + i:start + i + 160]) for i in range(0, n, 160)]).astype(np.float64)
-    ref = x48[3 * start:3 * start + len(y)].astype(np.float64)
+    return x16[: 160 * 600], x48
+
+
+def best_alignment_similarity(y, ref, max_shift=200):
+    """normalised correlation at the best shift; the resampler delays by 24 input = 72 output samples"""
+    y, ref = y.astype(np.float64), ref.astype(np.float64)
     best = 0.0
-    for shift in range(0, 200):  # resampler delay = 24 input samples = 72 output samples (+ file alignment)
+    for shift in range(0, max_shift):
         a, b = y[shift:], ref[:len(y) - shift]
-        c = np.dot(a, b) / np.sqrt(np.dot(a, a) * np.dot(b, b) + 1e-9)
-        best = max(best, c)
-    assert best >= 0.98, best
+        best = max(best, np.dot(a, b) / np.sqrt(np.dot(a, a) * np.dot(b, b) + 1e-9))
+    return best
+
+
+def test_resampler_against_reference_wav_pair(oracle):
+    """Resampling the 16 k file must reproduce the 48 k one up to the similarity threshold the reference's own
+    tester uses for a resampled path (aec3_tester.c:743-758: >= 0.98)."""
+    x16, x48 = reference_wav_pair()
+    rs = oracle.Resampler(16000, 48000)
+    y = np.concatenate([rs.process(x16[i:i + 160]) for i in range(0, len(x16), 160)])
+    assert best_alignment_similarity(y, x48[: len(y)]) >= 0.98
 
 
 # -------------------------------------------------------------------- FFT
