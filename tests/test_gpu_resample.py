@@ -138,7 +138,7 @@ def test_resampler_on_the_reference_wav_pair(ctx, oracle):
         out, olen = rs.process(blk)
         assert list(olen) == [480, 480, 480]
         np.testing.assert_array_equal(out[0], out[2])
-        got.append(out[0].copy())
+        got.append(out[0][:480].copy())
         want.append(orc.process(x16[i:i + 160]))
     got, want = np.concatenate(got), np.concatenate(want)
     assert np.abs(got.astype(np.int32) - want).max() <= 1
