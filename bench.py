@@ -243,6 +243,29 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
     return leg
 
 
+def copy_ceiling(torch):
+    """Achievable HBM rate on this box: a 1 GiB device-to-device copy (read + write bytes / time), the
+    'measured ceiling' BASELINE.md section 4 asks to report beside the 8 TB/s vendor peak."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n, dtype=torch.uint8, device="cuda")
+    src.zero_()
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(5):
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_ = e0.elapsed_time(e1)
+        best = ms_ if best is None else min(best, ms_)
+    del src, dst
+    torch.cuda.empty_cache()
+    return round(2 * n / (best * 1e-3) / 1e9, 1)
+
+
 def pipeline_probe(ms, torch, ctx, nstreams):
     """north_star check: every per-tick kernel of the path for `nstreams` concurrent 48 kHz streams on one GPU --
     MSResample 16k->48k, MSVolume (AGC), MSAudioMixer (nstreams/32 conferences of 32), MSSpeexEC (256-sample
@@ -343,17 +366,24 @@ def main():
     leg = make_resample_leg(ms, torch, ctx, a.streams)
     graph = leg.run(a.steps, a.warmup, use_graph=not a.no_graph)
 
-    def fence():
+    def sync_local():
         ctx.sync()
         torch.cuda.synchronize()
+
+    def barrier():
         if dist is not None:
             dist.barrier()
 
-    fence()
+    # K steps bracketed by (synchronize + barrier) on both sides.  The clock stops after this rank's own
+    # synchronize and before the closing barrier: the MAX over ranks below is the slowest rank's K steps, and
+    # the barrier's own latency (tens of microseconds against a 7 microsecond step) stays out of every rank's time.
+    sync_local()
+    barrier()
     t0 = time.perf_counter()
     ev_ms = leg.timed(a.steps, graph)
-    fence()
+    sync_local()
     dt = time.perf_counter() - t0
+    barrier()
     if dist is not None:
         tt = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -411,6 +441,10 @@ def main():
                 except Exception as e:  # an optional leg must never take the headline down
                     extras.append({"kernel": mk.__name__, "error": str(e)[:200]})
             line["other_kernels"] = extras
+            try:
+                line["roofline"]["measured_copy_GBps"] = copy_ceiling(torch)
+            except Exception as e:
+                line["roofline"]["measured_copy_GBps"] = None
             if a.pipeline_streams > 0:
                 try:
                     line["pipeline"] = pipeline_probe(ms, torch, ctx, a.pipeline_streams)
