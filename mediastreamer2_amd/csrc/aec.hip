@@ -113,12 +113,16 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
 }
 
 // kiss_fft factorisation (4s first, then 2), stages listed deepest first:
-// F=256: radix 4,4,4,4 with m = 1,4,16,64;  F=128: radix 2 (m=1) then 4,4,4 with m = 2,8,32.
+// F=256: radix 4,4,4,4 with m = 1,4,16,64;  F=128: radix 2 (m=1) then 4,4,4 with m = 2,8,32;
+// F=64 (8 kHz): radix 4,4,4 with m = 1,4,16.
+__host__ __device__ constexpr int plan_n(int F) { return F == 64 ? 3 : 4; }
 __host__ __device__ constexpr int plan_p(int F, int s) { return (F == 128 && s == 0) ? 2 : 4; }
 __host__ __device__ constexpr int plan_m(int F, int s) {
 	return F == 128 ? (s == 0 ? 1 : (s == 1 ? 2 : (s == 2 ? 8 : 32))) : (s == 0 ? 1 : (s == 1 ? 4 : (s == 2 ? 16 : 64)));
 }
-__host__ __device__ constexpr int plan_fs(int F, int s) { return s == 0 ? 64 : (s == 1 ? 16 : (s == 2 ? 4 : 1)); }
+__host__ __device__ constexpr int plan_fs(int F, int s) {
+	return F == 64 ? (s == 0 ? 16 : (s == 1 ? 4 : 1)) : (s == 0 ? 64 : (s == 1 ? 16 : (s == 2 ? 4 : 1)));
+}
 
 __device__ __forceinline__ float rdlane(float v, int l) {
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -287,8 +291,8 @@ int build_tables(mi_aec *a) {
 		a->plan.fs[s] = stride[(size_t)L];
 	}
 	// the kernels carry this plan as compile-time constants; make sure both agree
-	if (a->plan.nstages != 4) return MI_ENOTSUP;
-	for (int s = 0; s < 4; ++s)
+	if (a->plan.nstages != plan_n(F)) return MI_ENOTSUP;
+	for (int s = 0; s < plan_n(F); ++s)
 		if (a->plan.p[s] != plan_p(F, s) || a->plan.m[s] != plan_m(F, s) || a->plan.fs[s] != plan_fs(F, s)) {
 			mi::set_error("FFT plan mismatch for F=%d stage %d", F, s);
 			return MI_ENOTSUP;
@@ -423,9 +427,9 @@ int mi_aec_framesize(int framesize_at_8000, int sample_rate) { // speexec.c:171-
 int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, int filter_length, mi_aec **out) {
 	MI_CHECK_ARG(ctx && out && nstreams > 0 && sample_rate > 0 && filter_length > 0);
 	*out = nullptr;
-	if (frame_size != 128 && frame_size != 256) {
-		mi::set_error("frame size %d not supported: the filter's 2^k sizing (speexec.c:171-180) gives 128 at 16 kHz "
-		              "and 256 at 32-48 kHz; 64 (8 kHz) is not built",
+	if (frame_size != 64 && frame_size != 128 && frame_size != 256) {
+		mi::set_error("frame size %d not supported: the filter's 2^k sizing (speexec.c:171-180) gives 64 at 8 kHz, "
+		              "128 at 16 kHz and 256 at 32-48 kHz",
 		              frame_size);
 		return MI_ENOTSUP;
 	}
@@ -459,7 +463,7 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		}
 		for (int i = M - 1; i >= 0; i--) a->h_prop0[(size_t)i] = (.8f * a->h_prop0[(size_t)i]) / sum;
 	}
-	a->small_stride = frame_size == 256 ? SmallLayout<256>::TOTAL : SmallLayout<128>::TOTAL;
+	a->small_stride = 28 * frame_size; // SmallLayout<F>::TOTAL
 	const size_t wn = (size_t)M * a->N, xn = (size_t)(M + 1) * a->N;
 	int rc = build_tables(a);
 	if (rc != MI_OK) {
@@ -500,7 +504,7 @@ int mi_aec_reset(mi_aec *a, int first, int count) {
 	MI_CHECK_ARG(a && first >= 0 && count >= 0 && first + count <= a->nstreams);
 	if (count == 0) return MI_OK;
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
-	return a->F == 256 ? init_state<256>(a, first, count) : init_state<128>(a, first, count);
+	return a->F == 256 ? init_state<256>(a, first, count) : (a->F == 128 ? init_state<128>(a, first, count) : init_state<64>(a, first, count));
 }
 
 size_t mi_aec_state_bytes(const mi_aec *a) {
@@ -538,11 +542,13 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	g.t = a->t;
 	// one wavefront per stream: canceller, then (optionally) the post-filter as its own launch
 	if (a->F == 256) hipLaunchKernelGGL(aec_mdf_wave_kernel<256>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
-	else hipLaunchKernelGGL(aec_mdf_wave_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	else if (a->F == 128) hipLaunchKernelGGL(aec_mdf_wave_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	else hipLaunchKernelGGL(aec_mdf_wave_kernel<64>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
 	MI_LAUNCH_CHECK();
 	if (flags & MI_AEC_POSTFILTER) {
 		if (a->F == 256) hipLaunchKernelGGL(aec_post_wave_kernel<256>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
-		else hipLaunchKernelGGL(aec_post_wave_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+		else if (a->F == 128) hipLaunchKernelGGL(aec_post_wave_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+		else hipLaunchKernelGGL(aec_post_wave_kernel<64>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
 		MI_LAUNCH_CHECK();
 	}
 	return MI_OK;
@@ -634,7 +640,9 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 // debug entry (not in the public header): raw transform parity
 int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int inverse) {
 	MI_CHECK_ARG(a && d_in && d_out && nframes > 0);
-	if (a->F == 256)
+	if (a->F == 64)
+		hipLaunchKernelGGL(fft_debug_kernel<64>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
+	else if (a->F == 256)
 		hipLaunchKernelGGL(fft_debug_kernel<256>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	else
 		hipLaunchKernelGGL(fft_debug_kernel<128>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);

@@ -39,7 +39,7 @@ __device__ void w_cfft(WLds<F> &L, const float2 *src, bool inverse) {
 	for (int k = 0; k < K; ++k) L.zbuf[lane * K + k] = val[k];
 	WSYNC();
 #pragma unroll
-	for (int s = 0; s < 4; ++s) {
+	for (int s = 0; s < plan_n(F); ++s) {
 		constexpr int FF = F;
 		const int p = plan_p(FF, s), m = plan_m(FF, s), fs = plan_fs(FF, s);
 		if (lane < F / p) {
@@ -175,21 +175,34 @@ __device__ void w_rfft_inverse(WLds<F> &L, const float2 (&in)[F / 64]) {
 template <int K>
 struct WSeq {
 	__device__ static float inner_prod(const float (&x)[K], const float (&y)[K]) {
-		float part[K / 2];
-#pragma unroll
-		for (int k = 0; k < K; k += 2) {
-			float p = 0;
-			p = p + x[k] * y[k];
-			p = p + x[k + 1] * y[k + 1];
-			part[k / 2] = p;
-		}
-		float sum = 0;
+		if constexpr (K == 1) { // the library's pairs (2i, 2i+1) are neighbouring lanes
+			const float pr = x[0] * y[0];
+			float sum = 0;
 #pragma unroll 2
-		for (int l = 0; l < 64; ++l) {
+			for (int l = 0; l < 64; l += 2) {
+				float p = 0;
+				p = p + rdlane(pr, l);
+				p = p + rdlane(pr, l + 1);
+				sum = sum + p;
+			}
+			return sum;
+		} else {
+			float part[K / 2];
 #pragma unroll
-			for (int k = 0; k < K / 2; ++k) sum = sum + rdlane(part[k], l);
+			for (int k = 0; k < K; k += 2) {
+				float p = 0;
+				p = p + x[k] * y[k];
+				p = p + x[k + 1] * y[k + 1];
+				part[k / 2] = p;
+			}
+			float sum = 0;
+#pragma unroll 2
+			for (int l = 0; l < 64; ++l) {
+#pragma unroll
+				for (int k = 0; k < K / 2; ++k) sum = sum + rdlane(part[k], l);
+			}
+			return sum;
 		}
-		return sum;
 	}
 	__device__ static float dot_desc(float init, const float (&a)[K], const float (&b)[K]) {
 		float p[K];
@@ -207,32 +220,43 @@ struct WSeq {
 
 template <int K>
 __device__ __forceinline__ void load_vec(const float *p, float (&v)[K]) {
-	if (K == 4) {
+	if constexpr (K == 4) {
 		const float4 t = *reinterpret_cast<const float4 *>(p);
 		v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
-	} else {
+	} else if constexpr (K == 2) {
 		const float2 t = *reinterpret_cast<const float2 *>(p);
 		v[0] = t.x, v[1] = t.y;
+	} else {
+		v[0] = *p;
 	}
 }
 template <int K>
 __device__ __forceinline__ void store_vec(float *p, const float (&v)[K]) {
-	if (K == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
-	else *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+	if constexpr (K == 4) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+	else if constexpr (K == 2) *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+	else *p = v[0];
 }
 template <int K>
 __device__ __forceinline__ void load_bins(const float2 *p, float2 (&v)[K]) {
+	if constexpr (K == 1) {
+		v[0] = *p;
+	} else {
 #pragma unroll
-	for (int k = 0; k < K; k += 2) {
-		const float4 t = *reinterpret_cast<const float4 *>(p + k);
-		v[k] = make_float2(t.x, t.y);
-		v[k + 1] = make_float2(t.z, t.w);
+		for (int k = 0; k < K; k += 2) {
+			const float4 t = *reinterpret_cast<const float4 *>(p + k);
+			v[k] = make_float2(t.x, t.y);
+			v[k + 1] = make_float2(t.z, t.w);
+		}
 	}
 }
 template <int K>
 __device__ __forceinline__ void store_bins(float2 *p, const float2 (&v)[K]) {
+	if constexpr (K == 1) {
+		*p = v[0];
+	} else {
 #pragma unroll
-	for (int k = 0; k < K; k += 2) *reinterpret_cast<float4 *>(p + k) = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
+		for (int k = 0; k < K; k += 2) *reinterpret_cast<float4 *>(p + k) = make_float4(v[k].x, v[k].y, v[k + 1].x, v[k + 1].y);
+	}
 }
 
 // ===================================================================== MDF canceller, one frame

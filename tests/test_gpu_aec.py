@@ -32,13 +32,13 @@ def make_echo_scene(seed, rate, nsamp, near_sigma=300.0, far_sigma=3000.0):
     return to16(mic), to16(far)
 
 
-@pytest.mark.parametrize("F", [256, 128])
+@pytest.mark.parametrize("F", [256, 128, 64])
 def test_fft_bit_exact(ctx, oracle, F):
     """The in-LDS real FFT == the kiss_fft float build restated in the oracle (ms_fft / ms_ifft)."""
     torch = pytest.importorskip("torch")
     L = _lib.load()
     L.mi_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-    rate = 48000 if F == 256 else 16000
+    rate = {256: 48000, 128: 16000, 64: 8000}[F]
     aec = ms.AecBatch(ctx, 1, rate, frame_size=F, filter_length=4 * F)
     N, nfr = 2 * F, 6
     rng = np.random.default_rng(3)
@@ -87,7 +87,7 @@ def _run_pair(ctx, oracle, rate, F, tail_ms, nstreams, nframes, postfilter, scen
     return aec, ecs, mic, far, got, ref
 
 
-@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128)])
+@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 128)])
 def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
     """First frames from zero state: outputs, W, foreground, X history and every control scalar
     equal the oracle's bit for bit (no tree-reduced quantity is in use yet)."""
@@ -108,25 +108,28 @@ def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
 
 
 @pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(48000, 256, 128, False), (48000, 256, 128, True),
-                                                      (16000, 128, 128, True), (16000, 128, 250, False)])
+                                                      (16000, 128, 128, True), (16000, 128, 250, False),
+                                                      (8000, 64, 250, True), (8000, 64, 128, False)])
 def test_aec_two_seconds_within_tolerance(ctx, oracle, rate, F, tail_ms, postfilter):
     """2 s from zero state (BASELINE config 3 geometry at 48 kHz): RMS error <= 1e-4 of full scale,
     same adaptation decisions, and the canceller actually cancels (ERLE)."""
     nframes = int(2.0 * rate / F)
     ns = 4
     aec, ecs, mic, far, got, ref = _run_pair(ctx, oracle, rate, F, tail_ms, ns, nframes, postfilter)
+    need_adapted = rate > 8000  # the 64-sample frames of 8 kHz take longer than 2 s to reach `adapted` on this scene
     for s in range(ns):
         d = got[s].astype(np.float64) - ref[s].astype(np.float64)
         rms = np.sqrt(np.mean(d ** 2)) / FULL_SCALE
         assert rms <= 1e-4, f"stream {s}: rms {rms:.3e}, max {np.abs(d).max()}"
         sg, so = aec.get(s, "scalars", 16), ecs[s].get("scalars", 16)
-        assert sg[8] == so[8] == 1.0, "both must have reached the adapted state"
+        assert sg[8] == so[8], "same adaptation decision"
+        assert (not need_adapted) or sg[8] == 1.0, "both must have reached the adapted state"
         assert sg[11] == so[11] == nframes
         tail = slice(-rate // 2, None)
         pw = lambda v: np.mean(v[tail].astype(np.float64) ** 2) + 1e-9
         erle, erle_ref = 10 * np.log10(pw(mic[s]) / pw(got[s])), 10 * np.log10(pw(mic[s]) / pw(ref[s]))
         # the scene's near-end noise (sigma 300 vs ~1500 rms echo) caps the linear canceller at ~14 dB
-        assert erle > (6.0 if not postfilter else 12.0), f"stream {s}: ERLE {erle:.1f} dB"
+        assert erle > ((6.0 if not postfilter else 12.0) if need_adapted else 3.0), f"stream {s}: ERLE {erle:.1f} dB"
         assert abs(erle - erle_ref) < 0.1, f"stream {s}: ERLE {erle:.2f} dB vs oracle {erle_ref:.2f} dB"
     aec.close()
 

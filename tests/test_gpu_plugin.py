@@ -240,12 +240,14 @@ def test_conference_mixer_graph_bit_exact(host, oracle):
     host.S.ms_ticker_detach(host.ticker, mx)
 
 
-def test_speex_ec_graph_matches_oracle(host, oracle):
-    """ref + mic sources -> MSSpeexEC -> sinks, 16 kHz, tail 128 ms: the framing of speexec.c:223-305
-    (128-sample frames out of 160-sample ticks, zero injection while the reference is short) plus the
-    canceller and post-filter, compared with the same framing driven through the oracle."""
+@pytest.mark.parametrize("rate,F", [(16000, 128), (8000, 64)])
+def test_speex_ec_graph_matches_oracle(host, oracle, rate, F):
+    """ref + mic sources -> MSSpeexEC -> sinks, tail 128 ms: the framing of speexec.c:223-305 (128-sample frames
+    out of 160-sample ticks at 16 kHz, 64 out of 80 at 8 kHz -- the filter's default rate --, zero injection while
+    the reference is short) plus the canceller and post-filter, compared with the same framing driven through
+    the oracle."""
     ec = host.create(MS_SPEEX_EC_ID)
-    assert host.call_int(ec, SET_SAMPLE_RATE, 16000) == 0
+    assert host.call_int(ec, SET_SAMPLE_RATE, rate) == 0
     assert host.call_int(ec, mid(EC_IFACE, 2, 4), 128) == 0   # SET_TAIL_LENGTH
     assert host.call_int(ec, mid(EC_IFACE, 0, 4), 0) == 0     # SET_DELAY
     d = C.c_int(-1)
@@ -256,7 +258,7 @@ def test_speex_ec_graph_matches_oracle(host, oracle):
     host.link(ec, 0, k_ref, 0)
     host.link(ec, 1, k_mic, 0)
     host.S.ms_ticker_attach(host.ticker, ec)
-    rate, F, nt, ns = 16000, 128, 40, 160
+    nt, ns = 40, rate // 100
     rng = np.random.default_rng(5)
     far = np.clip(np.round(rng.normal(0, 3000, ns * nt)), -32767, 32767).astype(np.int16)
     ir = rng.normal(0, 1, 48) * np.exp(-np.arange(48) / 10.0)
