@@ -185,7 +185,8 @@ struct ResampleData { // ResampleData msresample.c:33-42
 	uint32_t input_rate, output_rate;
 	int in_nchannels, out_nchannels;
 	ResamplePool *pool;
-	int slot;
+	int slot;                 // first channel's slot (the one that emits)
+	std::vector<int> *slots;  // one batch slot per input channel (speex keeps one state per channel too)
 };
 
 void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
@@ -195,16 +196,20 @@ void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
 	d->output_rate = 16000;
 	d->in_nchannels = d->out_nchannels = 1;
 	d->slot = -1;
+	d->slots = new std::vector<int>();
 	f->data = d;
 }
 
 void resample_release(ResampleData *d) {
-	if (d->pool && d->slot >= 0) {
+	if (d->pool) {
 		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-		d->pool->release(d->slot);
-		d->pool->staged[(size_t)d->slot] = d->pool->ready[(size_t)d->slot] = 0;
-		MI_MUST(mi_resampler_reset(d->pool->r, d->slot, 1));
+		for (int sl : *d->slots) {
+			d->pool->release(sl);
+			d->pool->staged[(size_t)sl] = d->pool->ready[(size_t)sl] = 0;
+			MI_MUST(mi_resampler_reset(d->pool->r, sl, 1));
+		}
 	}
+	d->slots->clear();
 	d->pool = nullptr;
 	d->slot = -1;
 }
@@ -213,6 +218,7 @@ void resample_uninit(MSFilter *f) {
 	ResampleData *d = (ResampleData *)f->data;
 	resample_release(d);
 	ms_bufferizer_destroy(d->bz);
+	delete d->slots;
 	ms_free(d);
 }
 
@@ -241,14 +247,9 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 	}
 	ms_filter_lock(f);
 	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-	if (d->in_nchannels != 1) {
-		ms_error("MSResample[mi355x]: %d input channels: only mono is batched", d->in_nchannels);
-		ms_queue_flush(f->inputs[0]);
-		ms_filter_unlock(f);
-		return;
-	}
-	if (d->pool && (d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate))
-		resample_release(d); // rates changed: the handle is re-created, history lost (:138-148)
+	const int nch = d->in_nchannels < 1 ? 1 : d->in_nchannels;
+	if (d->pool && (d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate || (int)d->slots->size() != nch))
+		resample_release(d); // rates / channels changed: the handle is re-created, history lost (:138-148)
 	if (!d->pool) {
 		auto key = std::make_tuple(f->ticker, d->input_rate, d->output_rate);
 		auto it = g_resample_pools.find(key);
@@ -259,23 +260,39 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 			it = g_resample_pools.emplace(key, p).first;
 		}
 		d->pool = it->second;
-		d->slot = d->pool->acquire(f);
-		if (d->slot < 0) {
-			d->pool = nullptr;
+		for (int ch = 0; ch < nch; ++ch) { // interleaved input: one state per channel, like speex_resampler_init(nb_channels)
+			const int sl = d->pool->acquire(f);
+			if (sl < 0) break;
+			d->slots->push_back(sl);
+		}
+		if ((int)d->slots->size() != nch) {
+			resample_release(d);
 			ms_queue_flush(f->inputs[0]);
 			ms_filter_unlock(f);
 			return;
 		}
+		d->slot = (*d->slots)[0];
 	}
 	ResamplePool *p = d->pool;
 	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
 	// this tick's input, re-framed to 10 ms blocks (a streaming filter: the sample sequence is
 	// independent of the blocking); the results are emitted by the flush task (ResamplePool::emit)
 	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
-	const size_t nbytes = (size_t)p->in_len * 2;
+	const size_t nbytes = (size_t)p->in_len * 2 * (size_t)nch;
+	std::vector<int16_t> frame;
 	while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->bz) >= nbytes) {
-		ms_bufferizer_read(d->bz, (uint8_t *)(p->h_in + (p->staged[s] * c + s) * p->in_len), nbytes);
-		p->staged[s]++;
+		const size_t round = (size_t)p->staged[s];
+		if (nch == 1) {
+			ms_bufferizer_read(d->bz, (uint8_t *)(p->h_in + (round * c + s) * p->in_len), nbytes);
+		} else { // de-interleave into the channels' rows
+			frame.resize((size_t)p->in_len * nch);
+			ms_bufferizer_read(d->bz, (uint8_t *)frame.data(), nbytes);
+			for (int ch = 0; ch < nch; ++ch) {
+				int16_t *row = p->h_in + (round * c + (size_t)(*d->slots)[(size_t)ch]) * p->in_len;
+				for (int i = 0; i < p->in_len; ++i) row[i] = frame[(size_t)i * nch + ch];
+			}
+		}
+		for (int sl : *d->slots) p->staged[(size_t)sl]++;
 	}
 	if (p->staged[s]) request_flush(f);
 	ms_filter_unlock(f);
@@ -283,18 +300,28 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 
 void ResamplePool::emit(MSFilter *f, int slot) {
 	ResampleData *d = (ResampleData *)f->data;
+	if (slot != d->slot) return; // the other channels' slots are emitted together with the first
 	const size_t c = (size_t)capacity, s = (size_t)slot;
+	const int nch = (int)d->slots->size();
 	for (int r = 0; r < ready[s]; ++r) {
 		const int outlen = h_olen[r * c + s];
-		mblk_t *om = allocb((size_t)outlen * 2, 0);
-		memcpy(om->b_wptr, h_out + (r * c + s) * ostride, (size_t)outlen * 2);
-		om->b_wptr += outlen * 2;
+		mblk_t *om = allocb((size_t)outlen * 2 * (size_t)nch, 0);
+		if (nch == 1) {
+			memcpy(om->b_wptr, h_out + (r * c + s) * ostride, (size_t)outlen * 2);
+		} else { // re-interleave (speex_resampler_process_interleaved_int's output layout)
+			int16_t *o = (int16_t *)om->b_wptr;
+			for (int ch = 0; ch < nch; ++ch) {
+				const int16_t *row = h_out + (r * c + (size_t)(*d->slots)[(size_t)ch]) * ostride;
+				for (int i = 0; i < outlen; ++i) o[(size_t)i * nch + ch] = row[i];
+			}
+		}
+		om->b_wptr += (size_t)outlen * 2 * (size_t)nch;
 		mblk_set_timestamp_info(om, d->ts); // msresample.c:168-169
 		d->ts += (uint32_t)outlen;
-		if (f->outputs[0]) ms_queue_put(f->outputs[0], channel_adapt(1, d->out_nchannels, om));
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], channel_adapt(nch, d->out_nchannels, om));
 		else freemsg(om);
 	}
-	ready[s] = 0;
+	for (int sl : *d->slots) ready[(size_t)sl] = 0;
 }
 
 int resample_set_sr(MSFilter *f, void *arg) { // :181-192

@@ -160,6 +160,49 @@ def test_resample_graph_matches_oracle(host, oracle):
     host.S.ms_ticker_detach(host.ticker, src)
 
 
+SET_OUTPUT_NCHANNELS = mid(MS_FILTER_BASE_ID, 28, 4)
+
+
+def test_resample_graph_stereo_and_channel_adapt(host, oracle):
+    """Interleaved stereo in (speex_resampler_process_interleaved_int, msresample.c:160-161): each channel is its own
+    stream; and the channel adaptation of :87-100 -- mono resampled then copied to both output channels."""
+    nt, n = 12, 80
+    L, R = synth_pcm(7, n * nt, rate=8000), synth_pcm(8, n * nt, rate=8000)
+    # (a) stereo -> stereo
+    src, rs, snk = host.source(), host.create(MS_RESAMPLE_ID), host.sink()
+    assert host.call_int(rs, SET_SAMPLE_RATE, 8000) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 48000) == 0
+    assert host.call_int(rs, SET_NCHANNELS, 2) == 0 and host.call_int(rs, SET_OUTPUT_NCHANNELS, 2) == 0
+    host.link(src, 0, rs, 0)
+    host.link(rs, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    inter = np.stack([L, R], 1).ravel()
+    for t in range(nt):
+        host.push(src, inter[t * 2 * n:(t + 1) * 2 * n])
+    host.step(nt + 2)
+    got = host.drain(snk).reshape(-1, 2)
+    oL, oR = oracle.Resampler(8000, 48000), oracle.Resampler(8000, 48000)
+    refL = np.concatenate([oL.process(L[t * n:(t + 1) * n]) for t in range(nt)])
+    refR = np.concatenate([oR.process(R[t * n:(t + 1) * n]) for t in range(nt)])
+    assert got.shape[0] == len(refL) == 480 * nt
+    assert np.abs(got[:, 0].astype(int) - refL).max() <= 1 and np.abs(got[:, 1].astype(int) - refR).max() <= 1
+    host.S.ms_ticker_detach(host.ticker, src)
+    # (b) mono -> stereo: first channel duplicated
+    src, rs, snk = host.source(), host.create(MS_RESAMPLE_ID), host.sink()
+    assert host.call_int(rs, SET_SAMPLE_RATE, 8000) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 48000) == 0
+    assert host.call_int(rs, SET_OUTPUT_NCHANNELS, 2) == 0
+    host.link(src, 0, rs, 0)
+    host.link(rs, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    for t in range(nt):
+        host.push(src, L[t * n:(t + 1) * n])
+    host.step(nt + 2)
+    got = host.drain(snk).reshape(-1, 2)
+    assert got.shape[0] == 480 * nt
+    np.testing.assert_array_equal(got[:, 0], got[:, 1])
+    assert np.abs(got[:, 0].astype(int) - refL).max() <= 1
+    host.S.ms_ticker_detach(host.ticker, src)
+
+
 def test_volume_agc_graph_bit_exact(host, oracle):
     src, vol, snk = host.source(), host.create(MS_VOLUME_ID), host.sink()
     assert host.call_int(vol, SET_SAMPLE_RATE, 48000) == 0
