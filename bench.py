@@ -338,6 +338,40 @@ def cpu_baseline_resample(nstreams, seconds):
             "us_per_stream_tick": round(t / (nstreams * nticks) * 1e6, 3)}
 
 
+def cpu_reference_times():
+    """The oracle (CPU restatement of the reference's process() bodies) timed per unit of work on ONE host core,
+    small bounded samples (about a second each): what the same tick costs on the reference's CPU path."""
+    import oracle
+    oracle.build()
+    L = oracle.lib()
+    i16p, u8p, llp = C.POINTER(C.c_int16), C.POINTER(C.c_uint8), C.POINTER(C.c_longlong)
+    for fn in ("orc_bench_mixer", "orc_bench_volume", "orc_bench_equalizer", "orc_bench_aec", "orc_bench_scaler"):
+        getattr(L, fn).restype = C.c_double
+    L.orc_bench_mixer.argtypes = [C.c_int] * 4 + [i16p, llp]
+    L.orc_bench_volume.argtypes = [C.c_int] * 5 + [i16p, llp]
+    L.orc_bench_equalizer.argtypes = [C.c_int] * 4 + [i16p, llp]
+    L.orc_bench_aec.argtypes = [C.c_int] * 5 + [i16p, i16p, llp]
+    L.orc_bench_scaler.argtypes = [C.c_int] * 5 + [u8p, llp]
+    out = {}
+    x = synth_pcm_batch(256, 480, 48000)
+    p = lambda a_, t=C.c_int16: a_.ctypes.data_as(C.POINTER(t))
+    t = L.orc_bench_mixer(8, 32, 480, 40, p(x), None)
+    out["mixer_members_kernel"] = {"cpu_us_per_unit": round(t / (8 * 40) * 1e6, 2), "unit": "conference-tick (32 x 480)"}
+    t = L.orc_bench_volume(256, 480, 40, 48000, 1, p(x), None)
+    out["volume_kernel"] = {"cpu_us_per_unit": round(t / (256 * 40) * 1e6, 3), "unit": "stream-tick (480 samples, AGC)"}
+    t = L.orc_bench_equalizer(32, 480, 10, 48000, p(x), None)
+    out["equalizer_kernel<512>"] = {"cpu_us_per_unit": round(t / (32 * 10) * 1e6, 2), "unit": "stream-tick (480 samples, 512 taps)"}
+    mic = synth_pcm_batch(8, 256, 48000)
+    ref = synth_pcm_batch(8, 256, 48000, sigma=2000.0)
+    t = L.orc_bench_aec(8, 256, 128 * 48, 48000, 60, p(mic), p(ref), None)
+    out["aec_mdf_wave_kernel<256>+aec_post_wave_kernel<256>"] = {"cpu_us_per_unit": round(t / (8 * 60) * 1e6, 2),
+                                                                 "unit": "stream-frame (256 samples, M=24)"}
+    frame = np.random.default_rng(1).integers(0, 256, 1920 * 1080 * 3 // 2, dtype=np.uint8)
+    t = L.orc_bench_scaler(4, 1920, 1080, 1280, 720, p(frame, C.c_uint8), None)
+    out["scaler_wave_kernel<true>"] = {"cpu_us_per_unit": round(t / 4 * 1e6, 1), "unit": "frame (1080p I420 -> 720p RGB24)"}
+    return out
+
+
 def main():
     a = parse()
     import torch
@@ -454,6 +488,14 @@ def main():
                     line["pipeline"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
+            if not a.no_extras:
+                try:
+                    ref_t = cpu_reference_times()
+                    for r in line.get("other_kernels", []):
+                        if r.get("kernel") in ref_t and "avg_launch_us" in r:
+                            r["cpu_port_1core"] = ref_t[r["kernel"]]
+                except Exception as e:
+                    line["cpu_reference_error"] = str(e)[:200]
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -135,3 +135,35 @@ double orc_bench_scaler(int nframes, int sw, int sh, int dw, int dh, const uint8
 	if (sink) *sink = acc;
 	return t1 - t0;
 }
+
+/* nstreams cancellers + post-filters (speexec.c:297-298), nframes frames each; mic/ref [nstreams][frame] reused */
+double orc_bench_aec(int nstreams, int frame, int filter_length, int rate, int nframes, const int16_t *mic,
+                     const int16_t *ref, long long *sink) {
+	OrcEcho **e = (OrcEcho **)malloc(sizeof(*e) * (size_t)nstreams);
+	OrcPreproc **p = (OrcPreproc **)malloc(sizeof(*p) * (size_t)nstreams);
+	int16_t *out = (int16_t *)malloc(sizeof(int16_t) * (size_t)frame);
+	long long acc = 0;
+	double t0, t1;
+	int s, t;
+	for (s = 0; s < nstreams; ++s) {
+		e[s] = orc_echo_new(frame, filter_length, rate);
+		p[s] = orc_preproc_new(frame, rate, e[s]);
+	}
+	t0 = now_s();
+	for (t = 0; t < nframes; ++t)
+		for (s = 0; s < nstreams; ++s) {
+			orc_echo_cancel(e[s], mic + (size_t)s * frame, ref + (size_t)s * frame, out);
+			orc_preproc_run(p[s], out);
+			acc += out[frame / 2];
+		}
+	t1 = now_s();
+	for (s = 0; s < nstreams; ++s) {
+		orc_preproc_free(p[s]);
+		orc_echo_free(e[s]);
+	}
+	free(e);
+	free(p);
+	free(out);
+	if (sink) *sink = acc;
+	return t1 - t0;
+}
