@@ -64,19 +64,22 @@ __device__ __forceinline__ RowJob make_job(uint8_t *dst, const uint8_t *plane, i
 	return j;
 }
 
+// InterpolateRow_C of libyuv on 16 bytes: (p0*(256-yf) + p1*yf + 128) >> 8 per byte.  Two bytes per 32-bit
+// operation: the even bytes of a dword sit in its two 16-bit halves (x & 0x00ff00ff), the odd ones after a
+// shift; each half's result is at most 255*256+128 < 65536, so nothing carries between the halves, and the
+// 24-bit multiplier (v_mad_u32_u24) takes 0x00ff00ff whole.
 __device__ __forceinline__ uint4 blend16(uint4 a, uint4 b, int yf) {
 	if (yf == 0) return a;
 	const unsigned av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+	const unsigned w1 = (unsigned)yf, w0 = 256u - w1;
 	unsigned ov[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
-		unsigned r = 0;
-#pragma unroll
-		for (int byte = 0; byte < 4; ++byte) {
-			const int p0 = (av[k] >> (8 * byte)) & 255, p1 = (bv[k] >> (8 * byte)) & 255;
-			r |= (unsigned)((p0 * (256 - yf) + p1 * yf + 128) >> 8) << (8 * byte);
-		}
-		ov[k] = r;
+		const unsigned ae = av[k] & 0x00ff00ffu, ao = (av[k] >> 8) & 0x00ff00ffu;
+		const unsigned be = bv[k] & 0x00ff00ffu, bo = (bv[k] >> 8) & 0x00ff00ffu;
+		const unsigned te = __umul24(be, w1) + (__umul24(ae, w0) + 0x00800080u);
+		const unsigned to = __umul24(bo, w1) + (__umul24(ao, w0) + 0x00800080u);
+		ov[k] = ((te >> 8) & 0x00ff00ffu) | (to & 0xff00ff00u);
 	}
 	return make_uint4(ov[0], ov[1], ov[2], ov[3]);
 }
@@ -281,7 +284,7 @@ struct WsRow { // per-wave LDS image of one blended source row segment
 };
 
 template <bool RGB>
-__global__ __launch_bounds__(64) void scaler_wave_kernel(ScArgs a, int strips, int band_pairs) {
+__global__ __launch_bounds__(64, 7) void scaler_wave_kernel(ScArgs a, int strips, int band_pairs) {
 	__shared__ __attribute__((aligned(16))) uint8_t rowY[2][WS_LUMA_Q * 16];
 	__shared__ __attribute__((aligned(16))) uint8_t rowC[2][WS_CHROMA_Q * 16];
 	__shared__ __attribute__((aligned(16))) uint8_t stage[2][256 * 3];
@@ -307,101 +310,109 @@ __global__ __launch_bounds__(64) void scaler_wave_kernel(ScArgs a, int strips, i
 	const int cq = min((min(a.scw, (int)(fc1 >> 16) + 2) - cbase + 15) >> 4, WS_CHROMA_Q);
 
 	const int p_begin = band * band_pairs, p_end = min(p_begin + band_pairs, a.npairs);
+	// vertical positions (uniform)
+	auto vpos = [](int y, int h, int &yi, int &yf) {
+		const int max_y = (h - 1) << 16;
+		if (y > max_y) y = max_y;
+		if (y < 0) y = 0;
+		yi = y >> 16;
+		yf = (y >> 8) & 255;
+	};
+	// ---- this lane's load items, fixed for the band: work list [Y0: yq][Y1: yq][U: cq][V: cq], two per lane
+	const int total = 2 * yq + 2 * cq;
+	int it_sel[2], it_col[2];
+	uint8_t *it_dst[2];
+#pragma unroll
+	for (int n = 0; n < 2; ++n) {
+		const int it = lane + 64 * n;
+		it_sel[n] = -1, it_col[n] = 0, it_dst[n] = rowY[0];
+		if (it < total) {
+			if (it < 2 * yq) {
+				const int sel = it >= yq, q = it - sel * yq;
+				it_sel[n] = sel, it_col[n] = ybase + 16 * q, it_dst[n] = rowY[sel] + 16 * q;
+			} else {
+				const int t = it - 2 * yq, sel = t >= cq, q = t - sel * cq;
+				it_sel[n] = 2 + sel, it_col[n] = cbase + 16 * q, it_dst[n] = rowC[sel] + 16 * q;
+			}
+		}
+	}
+	uint4 va[2], vb[2];
+	int yfs[2];
+	// all of a row pair's source loads (both rows of the vertical blend) go out together
+	auto issue = [&](int pr) {
+		const int oy0 = 2 * pr, oy1 = 2 * pr + 1;
+		int yi0, yf0, yi1, yf1, ci, cf;
+		vpos(a.ym.y0 + oy0 * a.ym.dy, a.sh, yi0, yf0);
+		vpos(a.ym.y0 + (oy1 < a.dh ? oy1 : oy0) * a.ym.dy, a.sh, yi1, yf1);
+		vpos(a.cm.y0 + (pr < a.dch ? pr : 0) * a.cm.dy, a.sch, ci, cf);
+#pragma unroll
+		for (int n = 0; n < 2; ++n) {
+			va[n] = vb[n] = make_uint4(0, 0, 0, 0);
+			yfs[n] = 0;
+			const int sel = it_sel[n];
+			if (sel >= 0) {
+				const uint8_t *r0, *r1;
+				if (sel < 2) {
+					const int yi = sel ? yi1 : yi0;
+					yfs[n] = sel ? yf1 : yf0;
+					r0 = sY + (size_t)yi * a.sw + it_col[n];
+					r1 = (yi + 1 < a.sh) ? r0 + a.sw : r0;
+				} else {
+					yfs[n] = cf;
+					r0 = (sel == 3 ? sV : sU) + (size_t)ci * a.scw + it_col[n];
+					r1 = (ci + 1 < a.sch) ? r0 + a.scw : r0;
+				}
+				va[n] = *reinterpret_cast<const uint4 *>(r0);
+				vb[n] = yfs[n] ? *reinterpret_cast<const uint4 *>(r1) : va[n];
+			}
+		}
+	};
 	for (int pr = p_begin; pr < p_end; ++pr) {
 		const int oy0 = 2 * pr, oy1 = 2 * pr + 1;
 		const bool has1 = oy1 < a.dh;
 		const bool hasc = pr < a.dch;
-		// vertical positions (uniform)
-		auto vpos = [](int y, int h, int &yi, int &yf) {
-			const int max_y = (h - 1) << 16;
-			if (y > max_y) y = max_y;
-			if (y < 0) y = 0;
-			yi = y >> 16;
-			yf = (y >> 8) & 255;
-		};
-		int yi0, yf0, yi1, yf1, ci, cf;
-		vpos(a.ym.y0 + oy0 * a.ym.dy, a.sh, yi0, yf0);
-		vpos(a.ym.y0 + (has1 ? oy1 : oy0) * a.ym.dy, a.sh, yi1, yf1);
-		vpos(a.cm.y0 + (hasc ? pr : 0) * a.cm.dy, a.sch, ci, cf);
-		// ---- loads: work list [Y0: yq][Y1: yq][U: cq][V: cq], two items per lane, all in flight
-		// (prefetching the next pair's loads here was measured slower: +32 VGPRs cost a wave per SIMD)
-		const int total = 2 * yq + 2 * cq;
-		uint4 va[2], vb[2];
-		int item[2] = {lane, lane + 64};
-#pragma unroll
-		for (int n = 0; n < 2; ++n) {
-			va[n] = vb[n] = make_uint4(0, 0, 0, 0);
-			const int it = item[n];
-			if (it < total) {
-				const uint8_t *r0, *r1;
-				int yf;
-				if (it < 2 * yq) {
-					const int sel = it >= yq, q = it - sel * yq;
-					const int yi = sel ? yi1 : yi0;
-					yf = sel ? yf1 : yf0;
-					r0 = sY + (size_t)yi * a.sw + ybase + 16 * q;
-					r1 = (yi + 1 < a.sh) ? r0 + a.sw : r0;
-				} else {
-					const int t = it - 2 * yq, sel = t >= cq, q = t - sel * cq;
-					const uint8_t *pl = sel ? sV : sU;
-					yf = cf;
-					r0 = pl + (size_t)ci * a.scw + cbase + 16 * q;
-					r1 = (ci + 1 < a.sch) ? r0 + a.scw : r0;
-				}
-				va[n] = *reinterpret_cast<const uint4 *>(r0);
-				vb[n] = yf ? *reinterpret_cast<const uint4 *>(r1) : va[n];
-			}
-		}
+		// (keeping the next pair's loads in flight during the arithmetic was measured slower twice: the 16 extra
+		// live VGPRs cost a wave per SIMD, and resident waves are what keeps HBM busy here)
+		issue(pr);
 		__syncthreads(); // the previous pair's rows are no longer read
 #pragma unroll
-		for (int n = 0; n < 2; ++n) {
-			const int it = item[n];
-			if (it < total) {
-				uint8_t *dst;
-				int yf;
-				if (it < 2 * yq) {
-					const int sel = it >= yq, q = it - sel * yq;
-					yf = sel ? yf1 : yf0;
-					dst = rowY[sel] + 16 * q;
-				} else {
-					const int t = it - 2 * yq, sel = t >= cq, q = t - sel * cq;
-					yf = cf;
-					dst = rowC[sel] + 16 * q;
-				}
-				*reinterpret_cast<uint4 *>(dst) = blend16(va[n], vb[n], yf);
-			}
-		}
+		for (int n = 0; n < 2; ++n)
+			if (it_sel[n] >= 0) *reinterpret_cast<uint4 *>(it_dst[n]) = blend16(va[n], vb[n], yfs[n]);
 		__syncthreads();
-		// ---- this lane's pixels: x = ox0 + 4*lane .. +3, chroma cx = ocx0 + 2*lane, +1
+		// ---- this lane's pixels: x = ox0 + 4*lane .. +3, chroma cx = ocx0 + 2*lane, +1.  Source positions in
+		// 32-bit fixed point RELATIVE to the strip's LDS segment: (x - ox0) * dx < 2^25 on this path (launch check).
 		const int x0l = 4 * lane;
 		int cu[2] = {128, 128}, cv[2] = {128, 128};
 		if (hasc) {
+			const int cfx0 = (int)(fc0 - ((long long)cbase << 16));
+			const int clast = a.dcw - 1 - ocx0, cmaxl = a.scw - 1 - cbase;
 #pragma unroll
 			for (int k = 0; k < 2; ++k) {
-				const int cx = min(ocx0 + 2 * lane + k, a.dcw - 1);
-				const long long fx = (long long)a.cm.x0 + (long long)cx * a.cm.dx;
-				int xi = (int)(fx >> 16), f = (int)(fx & 0xffff);
-				if (xi < 0) xi = 0, f = 0;
-				const int xn = xi + 1 < a.scw ? xi + 1 : a.scw - 1;
-				const int ua = rowC[0][xi - cbase], ub = rowC[0][xn - cbase];
-				const int wa = rowC[1][xi - cbase], wb = rowC[1][xn - cbase];
+				const int fx = cfx0 + min(2 * lane + k, clast) * a.cm.dx;
+				const int xi = fx >> 16, f = fx & 0xffff;
+				const int xn = min(xi + 1, cmaxl);
+				const int ua = rowC[0][xi], ub = rowC[0][xn];
+				const int wa = rowC[1][xi], wb = rowC[1][xn];
 				cu[k] = ua + ((f * (ub - ua) + 0x8000) >> 16);
 				cv[k] = wa + ((f * (wb - wa) + 0x8000) >> 16);
 			}
 		}
 		int yv[2][4];
-#pragma unroll
-		for (int r = 0; r < 2; ++r)
+		{
+			const int yfx0 = (int)(fy0 - ((long long)ybase << 16));
+			const int ylast = a.dw - 1 - ox0, ymaxl = a.sw - 1 - ybase;
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const int x = min(ox0 + x0l + k, a.dw - 1);
-				const long long fx = (long long)a.ym.x0 + (long long)x * a.ym.dx;
-				int xi = (int)(fx >> 16), f = (int)(fx & 0xffff);
-				if (xi < 0) xi = 0, f = 0;
-				const int xn = xi + 1 < a.sw ? xi + 1 : a.sw - 1;
-				const int pa = rowY[r][xi - ybase], pb = rowY[r][xn - ybase];
-				yv[r][k] = pa + ((f * (pb - pa) + 0x8000) >> 16);
+				const int fx = yfx0 + min(x0l + k, ylast) * a.ym.dx;
+				const int xi = fx >> 16, f = fx & 0xffff;
+				const int xn = min(xi + 1, ymaxl);
+#pragma unroll
+				for (int r = 0; r < 2; ++r) {
+					const int pa = rowY[r][xi], pb = rowY[r][xn];
+					yv[r][k] = pa + ((f * (pb - pa) + 0x8000) >> 16);
+				}
 			}
+		}
 		if (RGB) {
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
@@ -429,6 +440,7 @@ __global__ __launch_bounds__(64) void scaler_wave_kernel(ScArgs a, int strips, i
 				if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
 					if (lane < (nbytes >> 4)) *reinterpret_cast<uint4 *>(o + 16 * lane) = *reinterpret_cast<const uint4 *>(stage[r] + 16 * lane);
 				} else {
+#pragma unroll 1
 					for (int i = lane; i < nbytes; i += 64) o[i] = stage[r][i];
 				}
 			}
@@ -441,6 +453,7 @@ __global__ __launch_bounds__(64) void scaler_wave_kernel(ScArgs a, int strips, i
 				if (x0l + 4 <= npx && (reinterpret_cast<uintptr_t>(o) & 3) == 0) {
 					*reinterpret_cast<uint32_t *>(o) = (uint32_t)yv[r][0] | (yv[r][1] << 8) | (yv[r][2] << 16) | ((uint32_t)yv[r][3] << 24);
 				} else {
+#pragma unroll 1
 					for (int k = 0; k < 4; ++k)
 						if (x0l + k < npx) o[k] = (uint8_t)yv[r][k];
 				}
