@@ -388,12 +388,35 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
+    # one rank per GPU; MSMI355X_BENCH_DEVICE pins every rank to one device (only for exercising the N>1 control
+    # flow on a single-GPU box together with MSMI355X_BENCH_BACKEND=gloo)
+    if os.environ.get("MSMI355X_BENCH_DEVICE"):
+        local = int(os.environ["MSMI355X_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dist = None
+    control = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("MSMI355X_BENCH_BACKEND", "nccl")
+        # The shards exchange no data: the process group only carries the barriers and the MAX of two scalars.
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            control = backend
+        except Exception as e:  # RCCL unavailable: the timing protocol works over gloo just as well
+            print(f"bench.py: rank {rank}: {backend} control plane failed ({str(e)[:120]}); using gloo", file=sys.stderr)
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            control = "gloo"
 
     ctx = ms.Context(local)
     props = ctx.props()
@@ -419,7 +442,7 @@ def main():
     dt = time.perf_counter() - t0
     barrier()
     if dist is not None:
-        tt = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda" if control == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, ev_ms_max = float(tt[0]), float(tt[1])
     else:
@@ -440,7 +463,7 @@ def main():
                    "streams_per_gpu": a.streams, "in_samples": 160, "out_samples": 480,
                    "tick_ms": 10, "tick_budget_used": round(dt / a.steps / 0.010, 6),
                    "launch": "eager" if a.no_graph else "hipGraph replay of K ticks",
-                   "ring_ticks": leg.ring, "parallelism": f"{world} independent stream shards",
+                   "ring_ticks": leg.ring, "parallelism": f"{world} independent stream shards" + (f", {control} barriers only" if control else ""),
                    "device": props["name"], "cu_count": props["cu_count"]},
         "roofline": roofline(ev_ms_max, a.steps, leg.alg_bytes, pmc_traffic("resample_up_kernel")),
     }
