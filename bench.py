@@ -182,6 +182,11 @@ def make_equalizer_leg(ms, torch, ctx, nstreams=4096, ns=480):
 
     leg = Leg(ctx, "equalizer_kernel<512>", launch, ring, per_tick, nstreams, "stream-ticks")
     leg.keep = (eq, bufs)
+    # this one is VALU-bound, not HBM-bound: 512 taps x 480 samples, multiply and add issued separately because the
+    # reference's x86 build rounds the product (bit-exact output).  Peak = the unfused fp32 issue rate measured on
+    # this part (scripts/ubench/valu_rate.hip: 1.34 ns per wave-instruction per SIMD -> 48.9 Tflop/s over 1024 SIMDs).
+    leg.valu_flop = 2.0 * nstreams * ns * 512
+    leg.valu_peak_tflops = 1024 * 64 / 1.34e-9 / 1e12
     return leg
 
 
@@ -492,6 +497,11 @@ def main():
                     if hasattr(lg, "state_bytes"):
                         r["resident_state_bytes"] = int(lg.state_bytes)
                         r["streams_per_10ms_tick_at_this_rate"] = int(lg.units * 0.010 / (ms_ * 1e-3 / ksteps) / 1.875)
+                    if hasattr(lg, "valu_flop"):
+                        tf = lg.valu_flop / (ms_ * 1e-3 / ksteps) / 1e12
+                        r["valu"] = {"flop_per_launch": int(lg.valu_flop), "achieved_tflops": round(tf, 2),
+                                     "peak_unfused_fp32_tflops": round(lg.valu_peak_tflops, 1),
+                                     "frac": round(tf / lg.valu_peak_tflops, 3)}
                     if hasattr(lg, "mpix_in"):
                         r["mpix_per_s_in"] = round(lg.mpix_in / (ms_ * 1e-3 / ksteps), 1)
                     extras.append(r)
