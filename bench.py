@@ -180,13 +180,14 @@ def make_equalizer_leg(ms, torch, ctx, nstreams=4096, ns=480):
     def launch(i):
         eq.process(bufs[i])
 
-    leg = Leg(ctx, "equalizer_kernel<512>", launch, ring, per_tick, nstreams, "stream-ticks")
+    leg = Leg(ctx, "equalizer_pk_kernel<512>", launch, ring, per_tick, nstreams, "stream-ticks")
     leg.keep = (eq, bufs)
     # this one is VALU-bound, not HBM-bound: 512 taps x 480 samples, multiply and add issued separately because the
-    # reference's x86 build rounds the product (bit-exact output).  Peak = the unfused fp32 issue rate measured on
-    # this part (scripts/ubench/valu_rate.hip: 1.34 ns per wave-instruction per SIMD -> 48.9 Tflop/s over 1024 SIMDs).
+    # reference's x86 build rounds the product (bit-exact output).  Peak = the unfused PACKED fp32 issue rate measured
+    # on this part (scripts/ubench/valu_rate.hip: v_pk_*_f32 1.96 ns per wave-instruction per SIMD, two flops per lane
+    # -> 66.9 Tflop/s over 1024 SIMDs; the scalar forms give 48.9).
     leg.valu_flop = 2.0 * nstreams * ns * 512
-    leg.valu_peak_tflops = 1024 * 64 / 1.34e-9 / 1e12
+    leg.valu_peak_tflops = 1024 * 64 * 2 / 1.96e-9 / 1e12
     return leg
 
 
@@ -365,7 +366,7 @@ def cpu_reference_times():
     t = L.orc_bench_volume(256, 480, 40, 48000, 1, p(x), None)
     out["volume_kernel"] = {"cpu_us_per_unit": round(t / (256 * 40) * 1e6, 3), "unit": "stream-tick (480 samples, AGC)"}
     t = L.orc_bench_equalizer(32, 480, 10, 48000, p(x), None)
-    out["equalizer_kernel<512>"] = {"cpu_us_per_unit": round(t / (32 * 10) * 1e6, 2), "unit": "stream-tick (480 samples, 512 taps)"}
+    out["equalizer_pk_kernel<512>"] = {"cpu_us_per_unit": round(t / (32 * 10) * 1e6, 2), "unit": "stream-tick (480 samples, 512 taps)"}
     mic = synth_pcm_batch(8, 256, 48000)
     ref = synth_pcm_batch(8, 256, 48000, sigma=2000.0)
     t = L.orc_bench_aec(8, 256, 128 * 48, 48000, 60, p(mic), p(ref), None)
@@ -500,7 +501,7 @@ def main():
                     if hasattr(lg, "valu_flop"):
                         tf = lg.valu_flop / (ms_ * 1e-3 / ksteps) / 1e12
                         r["valu"] = {"flop_per_launch": int(lg.valu_flop), "achieved_tflops": round(tf, 2),
-                                     "peak_unfused_fp32_tflops": round(lg.valu_peak_tflops, 1),
+                                     "peak_unfused_packed_fp32_tflops": round(lg.valu_peak_tflops, 1),
                                      "frac": round(tf / lg.valu_peak_tflops, 3)}
                     if hasattr(lg, "mpix_in"):
                         r["mpix_per_s_in"] = round(lg.mpix_in / (ms_ * 1e-3 / ksteps), 1)

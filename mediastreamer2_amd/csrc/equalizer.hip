@@ -85,6 +85,71 @@ __global__ __launch_bounds__(EQ_THREADS) void equalizer_kernel(EqArgs a) {
 	for (int i = tid; i < ORD - 1; i += EQ_THREADS) hs[i] = (int16_t)buf[nsamples + i];
 }
 
+// Packed form: one wavefront per stream, 8 outputs per lane held as four register pairs.  v_pk_mul_f32 +
+// v_pk_add_f32 round exactly like the scalar multiply and add (the product is NOT fused into the sum, as in the
+// reference's x86 build), but issue two outputs per slot; the tap is wave-uniform, window pairs at even offsets
+// are register pairs as they come from 16-byte LDS reads, pairs at odd offsets cost one v_pk_mov_b32 each
+// (one per two taps).  Per-output accumulation order is the reference's (oldest sample first).
+typedef float eq_f2 __attribute__((ext_vector_type(2)));
+constexpr int EQ_PR = 8;
+
+template <int ORD>
+__global__ __launch_bounds__(64) void equalizer_pk_kernel(EqArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	float *buf = reinterpret_cast<float *>(smem); // [ORD-1 + nsamples + 16]
+	const int s = blockIdx.x;
+	if (!a.active[s]) return;
+	const int nsamples = a.nper ? min(max(a.nper[s], 0), a.nsamples) : a.nsamples;
+	if (nsamples == 0) return;
+	const int lane = threadIdx.x;
+	int16_t *xs = a.samples + (size_t)s * a.stride;
+	int16_t *hs = a.hist + (size_t)s * ORD;
+	const float *__restrict__ h = a.taps + (size_t)s * ORD;
+
+	for (int i = lane; i < ORD - 1; i += 64) buf[i] = (float)hs[i];
+	for (int i = lane; i < nsamples; i += 64) buf[ORD - 1 + i] = (float)xs[i];
+	for (int i = lane; i < 16; i += 64) buf[ORD - 1 + nsamples + i] = 0.f;
+	__syncthreads();
+
+	for (int n0 = lane * EQ_PR; n0 < nsamples; n0 += 64 * EQ_PR) {
+		const float4 *wp = reinterpret_cast<const float4 *>(buf + n0);
+		float4 c0 = wp[0], c1 = wp[1], c2 = wp[2], c3 = wp[3];
+		eq_f2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll 2
+		for (int c = 0; c < ORD / 8; ++c) {
+			const eq_f2 ev[8] = {{c0.x, c0.y}, {c0.z, c0.w}, {c1.x, c1.y}, {c1.z, c1.w},
+			                     {c2.x, c2.y}, {c2.z, c2.w}, {c3.x, c3.y}, {c3.z, c3.w}};
+			eq_f2 od[7];
+#pragma unroll
+			for (int i = 0; i < 7; ++i) od[i] = __builtin_shufflevector(ev[i], ev[i + 1], 1, 2);
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const float t = h[ORD - 1 - (8 * c + u)]; // wave-uniform: scalar load
+				const eq_f2 ts = {t, t};
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const int k = u + 2 * q;
+					const eq_f2 wk = (k & 1) ? od[k / 2] : ev[k / 2];
+					const eq_f2 p = ts * wk;
+					acc[q] = acc[q] + p;
+				}
+			}
+			c0 = c2, c1 = c3;
+			c2 = wp[2 * c + 4], c3 = wp[2 * c + 5]; // the last trip reads the zero slack
+		}
+#pragma unroll
+		for (int r = 0; r < EQ_PR; ++r) {
+			if (n0 + r < nsamples) {
+				const float v = (r & 1) ? acc[r / 2].y : acc[r / 2].x;
+				// (int16_t)float of the reference is UB out of range (equalizer.c:251-255); saturate
+				const int q = v >= 32767.f ? 32767 : (v <= -32768.f ? -32768 : (int)v);
+				xs[n0 + r] = (int16_t)q;
+			}
+		}
+	}
+	for (int i = lane; i < ORD - 1; i += 64) hs[i] = (int16_t)buf[nsamples + i];
+}
+
 struct HostEq { // EqualizerState equalizer.c:37-46 (design-side fields)
 	std::vector<float> spectrum; // fft_cpx, packed real
 	bool stale = true;
@@ -332,8 +397,19 @@ int mi_equalizer_process_masked(mi_equalizer *e, int16_t *d_samples, int nsample
 	a.nsamples = nsamples;
 	a.stride = stride;
 	a.ord = e->nfft;
-	const size_t lds = (size_t)(e->nfft - 1 + nsamples + EQ_R) * sizeof(float);
 	hipStream_t st = e->ctx->stream;
+	static const bool scalar_form = getenv("MSMI355X_EQ_SCALAR") != nullptr; // A/B switch for the older kernel
+	if (!scalar_form) {
+		const size_t lds_pk = (size_t)(e->nfft - 1 + nsamples + 16 + 3) * sizeof(float);
+		switch (e->nfft) {
+			case 128: hipLaunchKernelGGL(equalizer_pk_kernel<128>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
+			case 256: hipLaunchKernelGGL(equalizer_pk_kernel<256>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
+			default: hipLaunchKernelGGL(equalizer_pk_kernel<512>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
+		}
+		MI_LAUNCH_CHECK();
+		return MI_OK;
+	}
+	const size_t lds = (size_t)(e->nfft - 1 + nsamples + EQ_R) * sizeof(float);
 	switch (e->nfft) {
 		case 128: hipLaunchKernelGGL(equalizer_kernel<128>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
 		case 256: hipLaunchKernelGGL(equalizer_kernel<256>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
