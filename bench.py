@@ -103,10 +103,14 @@ def roofline(ev_ms, steps, alg_bytes, traffic=None):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if there is one."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if there is one ('a+b' = both kernels of a leg)."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
-        return json.load(open(p)).get(kernel, {}).get("hbm_bytes_per_launch")
+        d = json.load(open(p))
+        tot = 0
+        for k in kernel.split("+"):
+            tot += d[k.split("<")[0]]["hbm_bytes_per_launch"]
+        return tot
     except Exception:
         return None
 
@@ -492,7 +496,7 @@ def main():
                     ctx.sync()
                     # the PMC summary was taken at the bench sizes; the 65536-stream row has no counter pass
                     r = roofline(ms_, ksteps, lg.alg_bytes,
-                                 None if mk is make_resample_65536 else pmc_traffic(lg.name.split("<")[0]))
+                                 None if mk is make_resample_65536 else pmc_traffic(lg.name))
                     r["kernel"] = lg.name
                     r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
                     if hasattr(lg, "state_bytes"):
