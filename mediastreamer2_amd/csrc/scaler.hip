@@ -284,13 +284,22 @@ struct WsRow { // per-wave LDS image of one blended source row segment
 };
 
 template <bool RGB>
-__global__ __launch_bounds__(64, 7) void scaler_wave_kernel(ScArgs a, int strips, int band_pairs) {
+__global__ __launch_bounds__(64, 7) void scaler_wave_kernel(ScArgs a, int strips, int band_pairs, int bands, int total_items,
+                                                             int xcd_chunk) {
 	__shared__ __attribute__((aligned(16))) uint8_t rowY[2][WS_LUMA_Q * 16];
 	__shared__ __attribute__((aligned(16))) uint8_t rowC[2][WS_CHROMA_Q * 16];
 	__shared__ __attribute__((aligned(16))) uint8_t stage[2][256 * 3];
 	const int lane = threadIdx.x;
-	const int strip = blockIdx.x % strips, band = blockIdx.x / strips;
-	const int frame = blockIdx.y;
+	// Work item w = (frame, band, strip), strips fastest.  Workgroups are dealt round-robin to the 8 XCDs, each with
+	// its own L2: item = (id % 8) * chunk + id / 8 gives every XCD one contiguous run of items, so the bands above
+	// and below a band (which share a blended source row) and the neighbouring strips go through the same L2.
+	int w = blockIdx.x;
+	if (xcd_chunk > 0) w = (w & 7) * xcd_chunk + (w >> 3);
+	if (w >= total_items) return;
+	const int per_frame = strips * bands;
+	const int frame = w / per_frame;
+	const int rem = w - frame * per_frame;
+	const int band = rem / strips, strip = rem - band * strips;
 	const uint8_t *sY = a.src + (size_t)frame * a.src_pitch;
 	const uint8_t *sU = sY + (size_t)a.sw * a.sh2;
 	const uint8_t *sV = sU + (size_t)a.scw * a.sch;
@@ -552,9 +561,18 @@ int mi_scaler_process(mi_scaler *s, int nframes, const uint8_t *d_src, size_t sr
 	if (aligned && a.ym.dx > 0 && a.cm.dx > 0 && need_y <= WS_LUMA_Q * 16 && need_c <= WS_CHROMA_Q * 16) {
 		const char *bp = getenv("MSMI355X_SCALER_BAND");
 		const int strips = mi::ceil_div(a.dw, 256), band_pairs = bp ? atoi(bp) : 4;
-		const dim3 grid((unsigned)(strips * mi::ceil_div(a.npairs, band_pairs)), (unsigned)nframes);
-		if (a.rgb) hipLaunchKernelGGL(scaler_wave_kernel<true>, grid, dim3(64), 0, s->ctx->stream, a, strips, band_pairs);
-		else hipLaunchKernelGGL(scaler_wave_kernel<false>, grid, dim3(64), 0, s->ctx->stream, a, strips, band_pairs);
+		const int bands = mi::ceil_div(a.npairs, band_pairs);
+		const long long total_ll = (long long)strips * bands * nframes;
+		if (total_ll > 0x7fffffffLL - 8) {
+			mi::set_error("scaler batch too large for one launch");
+			return MI_ENOTSUP;
+		}
+		const int total = (int)total_ll;
+		static const bool xcd_map = getenv("MSMI355X_SCALER_NO_XCD_MAP") == nullptr;
+		const int chunk = xcd_map ? mi::ceil_div(total, 8) : 0;
+		const dim3 grid((unsigned)(xcd_map ? chunk * 8 : total));
+		if (a.rgb) hipLaunchKernelGGL(scaler_wave_kernel<true>, grid, dim3(64), 0, s->ctx->stream, a, strips, band_pairs, bands, total, chunk);
+		else hipLaunchKernelGGL(scaler_wave_kernel<false>, grid, dim3(64), 0, s->ctx->stream, a, strips, band_pairs, bands, total, chunk);
 		MI_LAUNCH_CHECK();
 		return MI_OK;
 	}
