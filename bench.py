@@ -348,6 +348,31 @@ def cpu_baseline_resample(nstreams, seconds):
             "us_per_stream_tick": round(t / (nstreams * nticks) * 1e6, 3)}
 
 
+def cpu_baseline_resample_all_cores(nstreams, seconds):
+    """Same oracle loop on every host core the process may use (one group of streams per thread)."""
+    import oracle
+    oracle.build()
+    L = oracle.lib()
+    L.orc_bench_resample_mt.restype = C.c_double
+    L.orc_bench_resample_mt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_int16), C.c_int,
+                                        C.POINTER(C.c_longlong)]
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, nstreams))
+    x = synth_pcm_batch(nstreams, 160, 16000)
+    xp = x.ctypes.data_as(C.POINTER(C.c_int16))
+    L.orc_bench_resample_mt(nstreams, 160, 4, 16000, 48000, xp, ncores, None)  # cold pass: page-in, first touch
+    t = L.orc_bench_resample_mt(nstreams, 160, 16, 16000, 48000, xp, ncores, None)
+    nticks = max(16, int(seconds / (t / 16)))
+    t = L.orc_bench_resample_mt(nstreams, 160, nticks, 16000, 48000, xp, ncores, None)
+    return {"value": round(nstreams * nticks / t / TICKS_PER_S, 1),
+            "unit": "concurrent 48 kHz streams (10 ms ticks in real time)", "cores": ncores, "kind": "port",
+            "sample": f"{nstreams} streams x {nticks} ticks of 160 samples 16k->48k, oracle/resample.c, "
+                      f"{t:.1f} s wall on {ncores} threads"}
+
+
 def cpu_reference_times():
     """The oracle (CPU restatement of the reference's process() bodies) timed per unit of work on ONE host core,
     small bounded samples (about a second each): what the same tick costs on the reference's CPU path."""
@@ -526,6 +551,10 @@ def main():
                     line["pipeline"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
+            try:
+                line["cpu_baseline_all_cores"] = cpu_baseline_resample_all_cores(a.streams, min(a.cpu_seconds, 5.0))
+            except Exception as e:
+                line["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
             if not a.no_extras:
                 try:
                     ref_t = cpu_reference_times()

@@ -167,3 +167,73 @@ double orc_bench_aec(int nstreams, int frame, int filter_length, int rate, int n
 	if (sink) *sink = acc;
 	return t1 - t0;
 }
+
+/* The same loop on `nthreads` host threads, streams split evenly (each thread owns its streams' filter objects, as one
+ * MSTicker thread per group of calls would).  Returns the wall time of the slowest thread's span. */
+#include <pthread.h>
+typedef struct {
+	int first, count, in_len, nticks;
+	uint32_t in_rate, out_rate;
+	const int16_t *in;
+	long long acc;
+	pthread_barrier_t *bar;
+	double t0, t1;
+} RsJob;
+
+static void *rs_worker(void *arg) {
+	RsJob *j = (RsJob *)arg;
+	OrcResampler **r = (OrcResampler **)malloc(sizeof(*r) * (size_t)(j->count > 0 ? j->count : 1));
+	uint32_t cap = orc_msresample_outcap((uint32_t)j->in_len, j->in_rate, j->out_rate);
+	int16_t *out = (int16_t *)malloc(sizeof(int16_t) * cap);
+	int s, t;
+	long long acc = 0; /* thread-local: no shared cache line is written inside the timed loop */
+	for (s = 0; s < j->count; ++s) r[s] = orc_resampler_new(j->in_rate, j->out_rate, 3);
+	pthread_barrier_wait(j->bar);
+	j->t0 = now_s();
+	for (t = 0; t < j->nticks; ++t)
+		for (s = 0; s < j->count; ++s) {
+			uint32_t il = (uint32_t)j->in_len, ol = cap;
+			orc_resampler_process(r[s], j->in + (size_t)(j->first + s) * j->in_len, &il, out, &ol);
+			acc += out[ol / 2];
+		}
+	j->t1 = now_s();
+	j->acc = acc;
+	for (s = 0; s < j->count; ++s) orc_resampler_free(r[s]);
+	free(r);
+	free(out);
+	return NULL;
+}
+
+double orc_bench_resample_mt(int nstreams, int in_len, int nticks, uint32_t in_rate, uint32_t out_rate, const int16_t *in,
+                             int nthreads, long long *sink) {
+	pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+	RsJob *jobs = (RsJob *)calloc((size_t)nthreads, sizeof(RsJob));
+	pthread_barrier_t bar;
+	double t0 = 1e300, t1 = 0;
+	long long acc = 0;
+	int i;
+	pthread_barrier_init(&bar, NULL, (unsigned)nthreads);
+	for (i = 0; i < nthreads; ++i) {
+		const int lo = (int)((long long)nstreams * i / nthreads), hi = (int)((long long)nstreams * (i + 1) / nthreads);
+		jobs[i].first = lo;
+		jobs[i].count = hi - lo;
+		jobs[i].in_len = in_len;
+		jobs[i].nticks = nticks;
+		jobs[i].in_rate = in_rate;
+		jobs[i].out_rate = out_rate;
+		jobs[i].in = in;
+		jobs[i].bar = &bar;
+		pthread_create(&th[i], NULL, rs_worker, &jobs[i]);
+	}
+	for (i = 0; i < nthreads; ++i) {
+		pthread_join(th[i], NULL);
+		if (jobs[i].t0 < t0) t0 = jobs[i].t0;
+		if (jobs[i].t1 > t1) t1 = jobs[i].t1;
+		acc += jobs[i].acc;
+	}
+	pthread_barrier_destroy(&bar);
+	free(th);
+	free(jobs);
+	if (sink) *sink = acc;
+	return t1 - t0;
+}
