@@ -335,3 +335,52 @@ def test_speex_ec_graph_matches_oracle(host, oracle, rate, F):
     assert np.sqrt(np.mean(d ** 2)) / 32768.0 <= 1e-4
     assert len(ref_out) == len(ref)   # one reference frame goes to the speaker per processed frame
     host.S.ms_ticker_detach(host.ticker, ec)
+
+
+def test_two_ticker_threads_run_concurrently(host, oracle):
+    """SURVEY 8(b) threading: different tickers run different filter instances on different threads; the plugin
+    keeps one set of pools per ticker and serialises the device context.  Two ticker threads step their own
+    resample + volume graphs at the same time; every stream must still match the oracle."""
+    import threading
+    S = host.S
+    tickers = [host.ticker, S.ms_ticker_new()]
+    nper, nt = 6, 30
+    graphs = []
+    for ti, tk in enumerate(tickers):
+        for k in range(nper):
+            src, rs, vol, snk = host.source(), host.create(MS_RESAMPLE_ID), host.create(MS_VOLUME_ID), host.sink()
+            assert host.call_int(rs, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 48000) == 0
+            assert host.call_int(vol, SET_SAMPLE_RATE, 48000) == 0
+            g = C.c_float(0.5)
+            assert S.ms_filter_call_method(vol, mid(MS_VOLUME_ID, 2, 4), C.byref(g)) == 0   # MS_VOLUME_SET_GAIN
+            host.link(src, 0, rs, 0)
+            host.link(rs, 0, vol, 0)
+            host.link(vol, 0, snk, 0)
+            assert S.ms_ticker_attach(tk, src) == 0
+            x = synth_pcm(100 * ti + k, 160 * nt, rate=16000)
+            for t in range(nt):
+                host.push(src, x[t * 160:(t + 1) * 160])
+            graphs.append((tk, src, snk, x))
+    errs = []
+
+    def run(tk):
+        try:
+            for _ in range(nt + 4):
+                S.ms_ticker_step(tk)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(tk,)) for tk in tickers]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    for tk, src, snk, x in graphs:
+        got = host.drain(snk)
+        o, v = oracle.Resampler(16000, 48000), oracle.Volume(48000)
+        oracle.lib().orc_volume_set_gain(v.v, 0.5)
+        ref = np.concatenate([v.chunk(o.process(x[t * 160:(t + 1) * 160])) for t in range(nt)])
+        assert len(got) == len(ref)
+        assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+        S.ms_ticker_detach(tk, src)
