@@ -1878,88 +1878,87 @@ ScalerPool *size_conv_pool(MSFilter *f, SizeConvState *s, int w, int h) {
 	return s->pool;
 }
 
-void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
-	SizeConvState *s = (SizeConvState *)f->data;
-	YuvBuf inbuf;
-	mblk_t *im;
-	int cur_frame;
-
-	ms_filter_lock(f);
-	if (s->frame_count == -1) {
+// -- the three decisions of sizeconv.c:97-184, one helper each ------------------------------------------------
+// (1) frame-rate limiter, :107-132: which queued frames survive this tick.  Returns false when the tick must not
+//     emit at all (the frame period has not elapsed); in both throttled cases only the newest frame is kept.
+bool size_conv_rate_gate(MSFilter *f, SizeConvState *s) {
+	if (s->frame_count == -1) { // first tick after a (re)start
 		s->start_time = (float)f->ticker->time;
 		s->frame_count = 0;
 	}
-	while ((im = ms_queue_get(f->inputs[0])) != NULL) putq(&s->rq, im);
+	if (s->fps < 0) return true; // unlimited: every frame goes through
+	const int due = (int)((f->ticker->time - s->start_time) * s->fps / 1000.0);
+	while (s->rq.q_mcount > 1) { // older captures are dropped, the most recent one stays
+		ms_message("MSSizeConv: extra frame removed.");
+		freemsg(getq(&s->rq));
+	}
+	return due > s->frame_count;
+}
 
-	cur_frame = (int)((f->ticker->time - s->start_time) * s->fps / 1000.0);
-	if (cur_frame <= s->frame_count && s->fps >= 0) {
-		/* too much frame */
-		while (s->rq.q_mcount > 1) {
-			ms_message("MSSizeConv: extra frame removed.");
-			freemsg(getq(&s->rq));
-		}
+// (2) geometry fix-up, :139-157: same orientation as the input, same aspect ratio.  Returns true when the
+//     target had to change (the application is told and must re-negotiate before frames flow again).
+bool size_conv_adapt_target(SizeConvState *s, int in_w, int in_h) {
+	const MSVideoSize before = s->target_vsize, in_sz = {in_w, in_h};
+	MSVideoSize &t = s->target_vsize;
+	if (ms_video_size_get_orientation(in_sz) != ms_video_size_get_orientation(t)) std::swap(t.width, t.height);
+	if (in_w * t.height / t.width != in_h) {
+		if (in_w > in_h) t.height = in_h * t.width / in_w;
+		else t.width = in_w * t.height / in_h;
+	}
+	return t.width != before.width || t.height != before.height;
+}
+
+// (3) hand one frame to the batch (the ms_scaler_process call of :161): planes gathered into the packed layout
+bool size_conv_stage(MSFilter *f, SizeConvState *s, const YuvBuf &in, uint32_t ts) {
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	ScalerPool *p = size_conv_pool(f, s, in.w, in.h);
+	uint8_t *dst = p ? p->stage(f, ts) : nullptr;
+	if (!dst) return false;
+	const int h2 = in.h + (in.h & 1), cw = in.w / 2, crows = (in.h + 1) / 2;
+	uint8_t *du = dst + (size_t)in.w * h2, *dv = du + (size_t)cw * (h2 / 2);
+	for (int y = 0; y < in.h; ++y) memcpy(dst + (size_t)y * in.w, in.planes[0] + (size_t)y * in.strides[0], (size_t)in.w);
+	for (int y = 0; y < crows; ++y) {
+		memcpy(du + (size_t)y * cw, in.planes[1] + (size_t)y * in.strides[1], (size_t)cw);
+		memcpy(dv + (size_t)y * cw, in.planes[2] + (size_t)y * in.strides[2], (size_t)cw);
+	}
+	return true;
+}
+
+void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
+	SizeConvState *s = (SizeConvState *)f->data;
+	bool staged = false;
+	ms_filter_lock(f);
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) putq(&s->rq, m);
+	if (!size_conv_rate_gate(f, s)) {
 		ms_filter_unlock(f);
 		return;
 	}
-	if (cur_frame > s->frame_count && s->fps >= 0) {
-		/*keep the most recent frame if several frames have been captured */
-		while (s->rq.q_mcount > 1) {
-			ms_message("MSSizeConv: extra frame removed.");
-			freemsg(getq(&s->rq));
-		}
-	}
-	bool staged_any = false;
-	while ((im = getq(&s->rq)) != NULL) {
-		if (ms_yuv_buf_init_from_mblk(&inbuf, im) == 0) {
-			if (inbuf.w == s->target_vsize.width && inbuf.h == s->target_vsize.height) {
-				ms_queue_put(f->outputs[0], im);
-			} else {
-				int w = s->target_vsize.width;
-				int h = s->target_vsize.height;
-				// keep the same orientation
-				MSVideoSize in_sz = {inbuf.w, inbuf.h};
-				if (ms_video_size_get_orientation(in_sz) != ms_video_size_get_orientation(s->target_vsize)) {
-					s->target_vsize.width = h;
-					s->target_vsize.height = w;
-				}
-				// keep the aspect ratio of the input
-				if (inbuf.w * s->target_vsize.height / s->target_vsize.width != inbuf.h) {
-					if (inbuf.w > inbuf.h) s->target_vsize.height = inbuf.h * s->target_vsize.width / inbuf.w;
-					else s->target_vsize.width = inbuf.w * s->target_vsize.height / inbuf.h;
-				}
-				if (s->target_vsize.width != w || s->target_vsize.height != h) {
-					s->needRefresh = TRUE;
-					ms_filter_notify_no_arg(f, MS_FILTER_OUTPUT_FMT_CHANGED);
-				} else if (!s->needRefresh) {
-					std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-					ScalerPool *p = size_conv_pool(f, s, inbuf.w, inbuf.h);
-					uint8_t *dst = p ? p->stage(f, mblk_get_timestamp_info(im)) : nullptr;
-					if (dst) {
-						// gather the planes into the packed frame layout (they are contiguous in practice)
-						const int h2 = inbuf.h + (inbuf.h & 1), cw = inbuf.w / 2, chh = (inbuf.h + 1) / 2;
-						for (int y = 0; y < inbuf.h; ++y) memcpy(dst + (size_t)y * inbuf.w, inbuf.planes[0] + (size_t)y * inbuf.strides[0], (size_t)inbuf.w);
-						uint8_t *du = dst + (size_t)inbuf.w * h2, *dv = du + (size_t)cw * (h2 / 2);
-						for (int y = 0; y < chh; ++y) {
-							memcpy(du + (size_t)y * cw, inbuf.planes[1] + (size_t)y * inbuf.strides[1], (size_t)cw);
-							memcpy(dv + (size_t)y * cw, inbuf.planes[2] + (size_t)y * inbuf.strides[2], (size_t)cw);
-						}
-						staged_any = true;
-					} else {
-						ms_error("MSSizeConv: error in ms_scaler_process().");
-					}
-				} else {
-					ms_warning("MSSizeConv: output fmt changed, waiting.");
-				}
-				freemsg(im);
-			}
-			s->frame_count++;
-		} else {
+	for (mblk_t *im; (im = getq(&s->rq)) != NULL;) {
+		YuvBuf in;
+		if (ms_yuv_buf_init_from_mblk(&in, im) != 0) {
 			ms_warning("size_conv_process(): bad buffer.");
 			freemsg(im);
+			continue;
 		}
+		s->frame_count++;
+		if (in.w == s->target_vsize.width && in.h == s->target_vsize.height) {
+			ms_queue_put(f->outputs[0], im); // already the right size: forwarded as is, this tick
+			continue;
+		}
+		if (size_conv_adapt_target(s, in.w, in.h)) {
+			s->needRefresh = TRUE;
+			ms_filter_notify_no_arg(f, MS_FILTER_OUTPUT_FMT_CHANGED);
+		} else if (s->needRefresh) {
+			ms_warning("MSSizeConv: output fmt changed, waiting.");
+		} else if (size_conv_stage(f, s, in, mblk_get_timestamp_info(im))) {
+			staged = true;
+		} else {
+			ms_error("MSSizeConv: error in ms_scaler_process().");
+		}
+		freemsg(im);
 	}
 	ms_filter_unlock(f);
-	if (staged_any) {
+	if (staged) {
 		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
 		request_flush(f);
 	}
