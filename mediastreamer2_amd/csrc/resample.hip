@@ -172,19 +172,6 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 	float *x = reinterpret_cast<float *>(smem);                         // [xn] history ++ input ++ zero slack
 	int16_t *obuf = reinterpret_cast<int16_t *>(smem + (size_t)xn * 4); // [out_per_stream]
 
-	// ---- this lane's polyphase row (first trip); the table is L2-resident
-	const int nlanes = DEN * a.tiles;
-	f2 t2[FILT / 2]; // taps as register pairs: v_pk_fma_f32 broadcasts either half through op_sel
-	{
-		const int l0 = lane < nlanes ? lane : 0;
-		const int p0 = l0 - (l0 / DEN) * DEN;
-		const float4 *tp = reinterpret_cast<const float4 *>(a.table + p0 * FILT);
-#pragma unroll
-		for (int j = 0; j < FILT / 4; ++j) {
-			const float4 v = tp[j];
-			t2[2 * j] = (f2){v.x, v.y}, t2[2 * j + 1] = (f2){v.z, v.w};
-		}
-	}
 	// ---- staging plan: quads [0, hq) are history, [hq, hq+iq) input; lane takes quads lane and lane+64
 	const int hq = a.hist_stride >> 2, nq = hq + (a.in_len >> 2);
 	constexpr bool two = TWO; // nq > 64: a second staging quad per lane
@@ -193,15 +180,36 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 		                          : a.in + (size_t)s * a.in_stride + 4 * (i - hq);
 		return reinterpret_cast<const short4 *>(p);
 	};
+	// ---- the first stream's row goes out FIRST (it is the HBM miss on the critical path of a one-stream wave), the
+	// run flag next, the L2-resident tap rows last; nothing waits before the row is needed for staging
 	short4 v0 = make_short4(0, 0, 0, 0), v1 = v0;
 	int s = blockIdx.x;
-	bool act = true;
+	int runv = 1;
 	if (s < a.nstreams) {
-		act = !a.run || a.run[s];
 		if (lane < nq) v0 = *quad_ptr(s, lane);
 		if (two && lane + 64 < nq) v1 = *quad_ptr(s, lane + 64);
+		if (a.run) runv = a.run[s];
 	}
+	// ---- the polyphase table (DEN x FILT floats, L2-resident) goes through LDS: one 16-byte load per lane instead of
+	// FILT/4 per lane (every lane of a phase would fetch the same row: 12 KB per wave through the vector L1)
+	const int nlanes = DEN * a.tiles;
+	float4 *tab4 = reinterpret_cast<float4 *>(smem + (size_t)xn * 4 + (size_t)((out_per_stream + 7) & ~7) * 2);
+	for (int i = lane; i < DEN * FILT / 4; i += 64) tab4[i] = reinterpret_cast<const float4 *>(a.table)[i];
+	f2 t2[FILT / 2]; // taps as register pairs: v_pk_fma_f32 broadcasts either half through op_sel
+	auto load_row = [&](int p) {
+		const float4 *tp = tab4 + p * (FILT / 4);
+#pragma unroll
+		for (int j = 0; j < FILT / 4; ++j) {
+			const float4 v = tp[j];
+			t2[2 * j] = (f2){v.x, v.y}, t2[2 * j + 1] = (f2){v.z, v.w};
+		}
+	};
 	for (int i = HIST + a.in_len + lane; i < xn; i += 64) x[i] = 0.f; // slack stays zero for every stream
+	__syncthreads(); // single wave: LDS fence, the table is in place
+	if (!MULTI) {
+		const int l0 = lane < nlanes ? lane : 0;
+		load_row(l0 - (l0 / DEN) * DEN);
+	}
 
 	for (; s < a.nstreams; s += gridDim.x) {
 		// ---- the prefetched row goes to LDS as float
@@ -220,15 +228,15 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 			const int b = HIST + 4 * (lane + 64 - hq);
 			x[b + 0] = (float)v1.x, x[b + 1] = (float)v1.y, x[b + 2] = (float)v1.z, x[b + 3] = (float)v1.w;
 		}
-		const bool cur_act = act;
+		const int cur_run = runv;
 		// ---- next stream's row: in flight during this stream's arithmetic
 		const int sn = s + gridDim.x;
 		if (sn < a.nstreams) {
-			act = !a.run || a.run[sn];
 			if (lane < nq) v0 = *quad_ptr(sn, lane);
 			if (two && lane + 64 < nq) v1 = *quad_ptr(sn, lane + 64);
+			if (a.run) runv = a.run[sn];
 		}
-		if (!cur_act) { // masked out: no output, state untouched
+		if (!cur_run) { // masked out: no output, state untouched
 			if (lane == 0 && a.out_len) a.out_len[s] = 0;
 			__syncthreads();
 			continue;
@@ -238,14 +246,7 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 			const bool on = l < nlanes;
 			const int tile = on ? l / DEN : 0, p = on ? l - tile * DEN : 0;
 			const int m0 = tile * R;
-			if (MULTI) { // several trips: the phase pattern shifts by 64 % DEN, reload the row
-				const float4 *tp = reinterpret_cast<const float4 *>(a.table + p * FILT);
-#pragma unroll
-				for (int j = 0; j < FILT / 4; ++j) {
-					const float4 v = tp[j];
-					t2[2 * j] = (f2){v.x, v.y}, t2[2 * j + 1] = (f2){v.z, v.w};
-				}
-			}
+			if (MULTI) load_row(p); // several trips: the phase pattern shifts by 64 % DEN
 			__syncthreads(); // single wave: LDS fence between staging and the window reads
 			// The window slides through registers 8 taps at a time (16 floats live, the next 8 in flight).
 			// v_pk_fma_f32 does two positions per issue slot: the tap is broadcast by op_sel, even-offset
@@ -418,7 +419,8 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
 	*done = false;
 	const int tiles = mi::ceil_div(in_len, R);
 	const int xn = ((FILT - 1 + in_len + R + 1) + 3) & ~3;
-	const size_t lds = (size_t)xn * sizeof(float) + (size_t)((in_len * DEN + 7) & ~7) * sizeof(int16_t);
+	const size_t lds = (size_t)xn * sizeof(float) + (size_t)((in_len * DEN + 7) & ~7) * sizeof(int16_t) +
+	                   (size_t)DEN * FILT * sizeof(float); // window, output staging, polyphase table
 	const int nq = (r->hist_stride >> 2) + (in_len >> 2);
 	// 8-byte row loads (at most two per lane) and 16-byte output stores; any other layout takes the generic kernel
 	if (lds > 48 * 1024 || ((in_len | in_stride) & 3) != 0 || nq > 128 || (reinterpret_cast<uintptr_t>(d_in) & 7) != 0 ||
