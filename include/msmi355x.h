@@ -256,6 +256,27 @@ int mi_scaler_process_host(mi_scaler *s, int nframes, const uint8_t *h_src, size
 int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], const int src_strides[3],
                                   uint8_t *const dst[3], const int dst_strides[3]);
 
+/* ---------------------------------------------------------------- fifo */
+/* MSBufferizer (include/mediastreamer2/msqueue.h:131-134, src/base/msqueue.c:70-113) for a batch of streams, resident
+ * on the device: lets filters with different block sizes be chained without a host round trip (480-sample ticks
+ * from the resampler -> 256-sample frames for the echo canceller, speexec.c:252-257 -> ticks for the mixer). */
+typedef struct mi_fifo mi_fifo;
+int mi_fifo_create(mi_ctx *ctx, int nstreams, int capacity_samples, mi_fifo **out);
+void mi_fifo_destroy(mi_fifo *f);
+/* ms_bufferizer_put for every stream: row s of d_in ([nstreams][stride]); d_count[s] samples (NULL = nsamples each;
+ * 0 = nothing for that stream).  A block that does not fit is refused and counted (mi_fifo_overflows). */
+int mi_fifo_push(mi_fifo *f, const int16_t *d_in, int nsamples, int stride, const int32_t *d_count);
+/* the same with a byte mask: only streams with d_gate[s] != 0 push (NULL = all) -- takes the `ok` mask of a pop or the
+ * `run` mask of mi_aec_process as is */
+int mi_fifo_push_gated(mi_fifo *f, const int16_t *d_in, int nsamples, int stride, const uint8_t *d_gate);
+/* ms_bufferizer_read, all-or-nothing (msqueue.c:83): streams holding >= frame samples (and with d_gate[s] != 0 when a
+ * gate is given) get them in row s of d_out and d_ok[s] = 1; the others keep their samples, d_ok[s] = 0 and, if
+ * zero_fill, a row of zeros (the silence the filters inject: speexec.c:261-272, audiomixer.c:88). */
+int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok, const uint8_t *d_gate, int zero_fill);
+int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, in samples */
+int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
+int mi_fifo_reset(mi_fifo *f);
+
 /* ------------------------------------------------------------- pixconv */
 /* Packed formats -> I420, what pixconv_process (src/videofilters/pixconv.c:62-94) obtains from
  * ms_scaler_process with the libyuv implementation (yuv_scale src/voip/msvideo.c:542-581).

@@ -410,3 +410,38 @@ class PixConvBatch(_Batch):
             out = torch.zeros((nf, self.dst_bytes), dtype=torch.uint8, device=src.device)
         check(self.ctx.L.mi_pixconv_process(self.h, nf, _ptr(src), src.stride(0), _ptr(out), out.stride(0)))
         return out
+
+
+class FifoBatch(_Batch):
+    """nstreams device-resident MSBufferizers (msqueue.c:70-113): torch tensors in, torch tensors out."""
+    _destroy = "mi_fifo_destroy"
+
+    def __init__(self, ctx, nstreams, capacity):
+        self.ctx, self.nstreams, self.capacity = ctx, nstreams, capacity
+        h = C.c_void_p()
+        check(ctx.L.mi_fifo_create(ctx.h, nstreams, capacity, C.byref(h)))
+        self.h = h
+
+    def push(self, x, nsamples=None, count=None, gate=None):
+        """x [nstreams, >=nsamples] int16 (device); count [nstreams] int32 or gate [nstreams] uint8 (device) or None."""
+        n = x.shape[1] if nsamples is None else nsamples
+        if gate is not None:
+            check(self.ctx.L.mi_fifo_push_gated(self.h, _ptr(x), n, x.stride(0), _ptr(gate)))
+        else:
+            check(self.ctx.L.mi_fifo_push(self.h, _ptr(x), n, x.stride(0), _ptr(count)))
+
+    def pop(self, frame, out, ok=None, gate=None, zero_fill=True):
+        check(self.ctx.L.mi_fifo_pop(self.h, frame, _ptr(out), out.stride(0), _ptr(ok), _ptr(gate), 1 if zero_fill else 0))
+        return out
+
+    def levels(self, out):
+        check(self.ctx.L.mi_fifo_levels(self.h, _ptr(out)))
+        return out
+
+    def overflows(self):
+        n = C.c_int32(0)
+        check(self.ctx.L.mi_fifo_overflows(self.h, C.byref(n)))
+        return n.value
+
+    def reset(self):
+        check(self.ctx.L.mi_fifo_reset(self.h))

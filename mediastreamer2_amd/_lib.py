@@ -43,6 +43,7 @@ EXPORTS = [
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
     "mi_pixconv_process", "mi_pixconv_process_host",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset",
 ]
 
 
@@ -186,6 +187,16 @@ def load():
         L.mi_scaler_process.argtypes = [vp, i32, vp, sz, vp, sz]
         L.mi_scaler_process_host.argtypes = [vp, i32, vp, sz, vp, sz]
         L.mi_scaler_process_planes_host.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32)]
+    if hasattr(L, "mi_fifo_create"):
+        L.mi_fifo_create.argtypes = [vp, i32, i32, pp]
+        L.mi_fifo_destroy.argtypes = [vp]
+        L.mi_fifo_destroy.restype = None
+        L.mi_fifo_push.argtypes = [vp, vp, i32, i32, vp]
+        L.mi_fifo_push_gated.argtypes = [vp, vp, i32, i32, vp]
+        L.mi_fifo_pop.argtypes = [vp, i32, vp, i32, vp, vp, i32]
+        L.mi_fifo_levels.argtypes = [vp, vp]
+        L.mi_fifo_overflows.argtypes = [vp, C.POINTER(i32)]
+        L.mi_fifo_reset.argtypes = [vp]
     if hasattr(L, "mi_pixconv_create"):
         L.mi_pixconv_create.argtypes = [vp, i32, i32, i32, i32, pp]
         L.mi_pixconv_destroy.argtypes = [vp]

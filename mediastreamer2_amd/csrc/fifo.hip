@@ -1,0 +1,206 @@
+// fifo.hip -- batched per-stream sample FIFOs on the device: MSBufferizer (src/base/msqueue.c:70-113) for a whole
+// batch of streams, so that filters with different block sizes can be chained without leaving HBM -- the resampler
+// hands over 480-sample ticks, the echo canceller eats 256-sample frames (speexec.c:252-257,:288), the mixer
+// wants ticks again (audiomixer.c:78-90).
+//
+// One ring of `capacity` int16 samples per stream, [nstreams][capacity] in HBM, plus (head, tail) counters.
+// push appends a block (optionally a per-stream count: 0 = nothing this round); pop is all-or-nothing like
+// ms_bufferizer_read (msqueue.c:83): a stream with fewer than `frame` samples keeps them and reports ok = 0
+// (its output row is zero-filled on request, the way the filters inject silence: speexec.c:261-272, audiomixer.c:88).
+// One wavefront per stream; pure copies, HBM-bound.
+#include "common.hpp"
+
+namespace {
+
+struct FifoArgs {
+	int16_t *ring;
+	int2 *pos; // (head, tail) as free-running sample counters
+	int nstreams, capacity;
+	const int16_t *in;
+	const int32_t *count; // per-stream samples to push, or null = nsamples for all
+	int16_t *out;
+	uint8_t *ok;
+	const uint8_t *gate; // pop only where gate != 0 (others: ok = 0), or null
+	int nsamples, stride, zero_fill;
+	int32_t *levels;
+	int32_t *overflow; // number of pushes refused because the ring was full
+};
+
+__global__ __launch_bounds__(64) void fifo_push_kernel(FifoArgs a) {
+	const int s = blockIdx.x, lane = threadIdx.x;
+	if (a.gate && !a.gate[s]) return;
+	const int n = a.count ? min(max(a.count[s], 0), a.nsamples) : a.nsamples;
+	if (n == 0) return;
+	const int2 p = a.pos[s];
+	if (p.y - p.x + n > a.capacity) { // would overwrite unread samples: refuse the block, count it
+		if (lane == 0) atomicAdd(a.overflow, 1);
+		return;
+	}
+	int16_t *r = a.ring + (size_t)s * a.capacity;
+	const int16_t *src = a.in + (size_t)s * a.stride;
+	const unsigned base = (unsigned)p.y % (unsigned)a.capacity;
+	for (int i = lane; i < n; i += 64) {
+		unsigned k = base + (unsigned)i;
+		if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+		r[k] = src[i];
+	}
+	if (lane == 0) a.pos[s] = make_int2(p.x, p.y + n);
+}
+
+__global__ __launch_bounds__(64) void fifo_pop_kernel(FifoArgs a) {
+	const int s = blockIdx.x, lane = threadIdx.x;
+	const int n = a.nsamples;
+	const int2 p = a.pos[s];
+	const bool take = (!a.gate || a.gate[s]) && (p.y - p.x >= n);
+	int16_t *dst = a.out + (size_t)s * a.stride;
+	if (take) {
+		const int16_t *r = a.ring + (size_t)s * a.capacity;
+		const unsigned base = (unsigned)p.x % (unsigned)a.capacity;
+		for (int i = lane; i < n; i += 64) {
+			unsigned k = base + (unsigned)i;
+			if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+			dst[i] = r[k];
+		}
+		if (lane == 0) a.pos[s] = make_int2(p.x + n, p.y);
+	} else if (a.zero_fill) {
+		for (int i = lane; i < n; i += 64) dst[i] = 0;
+	}
+	if (lane == 0 && a.ok) a.ok[s] = take ? 1 : 0;
+}
+
+__global__ void fifo_level_kernel(FifoArgs a) {
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s < a.nstreams) {
+		const int2 p = a.pos[s];
+		a.levels[s] = p.y - p.x;
+	}
+}
+
+} // namespace
+
+struct mi_fifo {
+	mi_ctx *ctx = nullptr;
+	int nstreams = 0, capacity = 0;
+	int16_t *d_ring = nullptr;
+	int2 *d_pos = nullptr;
+	int32_t *d_overflow = nullptr;
+};
+
+extern "C" {
+
+int mi_fifo_create(mi_ctx *ctx, int nstreams, int capacity_samples, mi_fifo **out) {
+	MI_CHECK_ARG(ctx && out && nstreams > 0 && capacity_samples > 0);
+	*out = nullptr;
+	if (ctx->activate() != MI_OK) return MI_ENODEV;
+	mi_fifo *f = new mi_fifo();
+	f->ctx = ctx;
+	f->nstreams = nstreams;
+	f->capacity = capacity_samples;
+	if (hipMalloc((void **)&f->d_ring, (size_t)nstreams * capacity_samples * sizeof(int16_t)) != hipSuccess ||
+	    hipMalloc((void **)&f->d_pos, (size_t)nstreams * sizeof(int2)) != hipSuccess ||
+	    hipMalloc((void **)&f->d_overflow, sizeof(int32_t)) != hipSuccess) {
+		mi::set_error("hipMalloc failed for %d FIFOs of %d samples", nstreams, capacity_samples);
+		mi_fifo_destroy(f);
+		return MI_ENOMEM;
+	}
+	if (hipMemsetAsync(f->d_pos, 0, (size_t)nstreams * sizeof(int2), ctx->stream) != hipSuccess ||
+	    hipMemsetAsync(f->d_overflow, 0, sizeof(int32_t), ctx->stream) != hipSuccess ||
+	    hipStreamSynchronize(ctx->stream) != hipSuccess) {
+		mi::set_error("FIFO state reset failed");
+		mi_fifo_destroy(f);
+		return MI_ENODEV;
+	}
+	*out = f;
+	return MI_OK;
+}
+
+void mi_fifo_destroy(mi_fifo *f) {
+	if (!f) return;
+	(void)hipSetDevice(f->ctx->device);
+	if (f->d_ring) (void)hipFree(f->d_ring);
+	if (f->d_pos) (void)hipFree(f->d_pos);
+	if (f->d_overflow) (void)hipFree(f->d_overflow);
+	delete f;
+}
+
+static void fifo_args(mi_fifo *f, FifoArgs &a) {
+	memset(&a, 0, sizeof(a));
+	a.ring = f->d_ring;
+	a.pos = f->d_pos;
+	a.nstreams = f->nstreams;
+	a.capacity = f->capacity;
+	a.overflow = f->d_overflow;
+}
+
+int mi_fifo_push(mi_fifo *f, const int16_t *d_in, int nsamples, int stride, const int32_t *d_count) {
+	MI_CHECK_ARG(f && d_in && nsamples > 0 && stride >= nsamples && nsamples <= f->capacity);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.in = d_in;
+	a.count = d_count;
+	a.nsamples = nsamples;
+	a.stride = stride;
+	hipLaunchKernelGGL(fifo_push_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_push_gated(mi_fifo *f, const int16_t *d_in, int nsamples, int stride, const uint8_t *d_gate) {
+	MI_CHECK_ARG(f && d_in && nsamples > 0 && stride >= nsamples && nsamples <= f->capacity);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.in = d_in;
+	a.gate = d_gate;
+	a.nsamples = nsamples;
+	a.stride = stride;
+	hipLaunchKernelGGL(fifo_push_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok, const uint8_t *d_gate, int zero_fill) {
+	MI_CHECK_ARG(f && d_out && frame > 0 && stride >= frame);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.out = d_out;
+	a.ok = d_ok;
+	a.gate = d_gate;
+	a.nsamples = frame;
+	a.stride = stride;
+	a.zero_fill = zero_fill;
+	hipLaunchKernelGGL(fifo_pop_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_levels(mi_fifo *f, int32_t *d_levels) {
+	MI_CHECK_ARG(f && d_levels);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.levels = d_levels;
+	hipLaunchKernelGGL(fifo_level_kernel, dim3(mi::ceil_div(f->nstreams, 256)), dim3(256), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_overflows(mi_fifo *f, int32_t *h_count) {
+	MI_CHECK_ARG(f && h_count);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipMemcpyAsync(h_count, f->d_overflow, sizeof(int32_t), hipMemcpyDeviceToHost, f->ctx->stream));
+	MI_HIP(hipStreamSynchronize(f->ctx->stream));
+	return MI_OK;
+}
+
+int mi_fifo_reset(mi_fifo *f) {
+	MI_CHECK_ARG(f != nullptr);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipMemsetAsync(f->d_pos, 0, (size_t)f->nstreams * sizeof(int2), f->ctx->stream));
+	MI_HIP(hipMemsetAsync(f->d_overflow, 0, sizeof(int32_t), f->ctx->stream));
+	return MI_OK;
+}
+
+} // extern "C"

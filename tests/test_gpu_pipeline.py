@@ -1,0 +1,170 @@
+"""The chained hot path, device-resident end to end: MSResample 16k->48k -> (device FIFO: 480-sample ticks -> 256-sample
+frames) -> MSSpeexEC -> (device FIFO: frames -> ticks) -> MSVolume (AGC) -> MSAudioMixer (conferences of 32), one tick
+after another with no host round trip between the stages -- the north_star path of BASELINE.json.
+
+Parity is stage-wise: every stage's GPU output is compared with the oracle stage fed with the SAME input the GPU stage
+consumed (read back from the device), so each bar is the stage's own (<= 1 LSB resampler, <= 1e-4 RMS canceller,
+bit-exact volume / mixer / FIFO) and nothing hides behind an accumulated tolerance."""
+import numpy as np
+import pytest
+
+import mediastreamer2_amd as ms
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+class NpFifo:
+    """MSBufferizer semantics (msqueue.c:70-113) for a batch, in numpy."""
+
+    def __init__(self, n):
+        self.q = [np.zeros(0, np.int16) for _ in range(n)]
+
+    def push(self, x, count=None):
+        for s in range(len(self.q)):
+            k = x.shape[1] if count is None else int(count[s])
+            self.q[s] = np.concatenate([self.q[s], x[s, :k]])
+
+    def pop(self, frame, gate=None):
+        n = len(self.q)
+        out, ok = np.zeros((n, frame), np.int16), np.zeros(n, np.uint8)
+        for s in range(n):
+            if (gate is None or gate[s]) and len(self.q[s]) >= frame:
+                out[s], self.q[s] = self.q[s][:frame], self.q[s][frame:]
+                ok[s] = 1
+        return out, ok
+
+
+def test_fifo_matches_bufferizer_model(ctx):
+    torch = pytest.importorskip("torch")
+    n, cap = 37, 1000
+    f, m = ms.FifoBatch(ctx, n, cap), NpFifo(n)
+    rng = np.random.default_rng(1)
+    out = torch.zeros((n, 520), dtype=torch.int16, device="cuda")
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    lv = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for step in range(60):
+        blk = rng.integers(-32768, 32768, (n, 488), dtype=np.int16)
+        cnt = rng.choice([0, 160, 480, 37], n).astype(np.int32)
+        cnt[[len(q) + c > cap for q, c in zip(m.q, cnt)]] = 0          # the model never overflows; nor does the test
+        d_blk, d_cnt = torch.from_numpy(blk).cuda(), torch.from_numpy(cnt).cuda()
+        d_gate = None
+        torch.cuda.synchronize()
+        f.push(d_blk, nsamples=480, count=d_cnt)
+        m.push(blk, cnt)
+        frame = int(rng.choice([256, 480, 128]))
+        gate = (rng.random(n) > 0.2).astype(np.uint8)
+        d_gate = torch.from_numpy(gate).cuda()
+        torch.cuda.synchronize()
+        f.pop(frame, out, ok=ok, gate=d_gate, zero_fill=True)
+        want, wok = m.pop(frame, gate)
+        ctx.sync()
+        np.testing.assert_array_equal(ok.cpu().numpy(), wok)
+        np.testing.assert_array_equal(out.cpu().numpy()[:, :frame], want)
+        f.levels(lv)
+        ctx.sync()
+        np.testing.assert_array_equal(lv.cpu().numpy(), [len(q) for q in m.q])
+    assert f.overflows() == 0
+    # a block that does not fit is refused, counted, and leaves the ring intact
+    big = torch.zeros((n, cap), dtype=torch.int16, device="cuda")
+    f.push(big, nsamples=cap)
+    assert f.overflows() == sum(1 for q in m.q if len(q) > 0)
+    f.close()
+
+
+def test_chained_tick_pipeline_stage_parity(ctx, oracle):
+    torch = pytest.importorskip("torch")
+    nconf, mm = 2, 32
+    n, nticks, F = nconf * mm, 40, 256
+    rate = 48000
+    rs = ms.ResamplerBatch(ctx, n, 16000, rate)
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
+    vol = ms.VolumeBatch(ctx, n, rate)
+    p = vol.default_params()
+    p.agc_enabled = 1
+    vol.set_params([p] * n)
+    mix = ms.MixerBatch(ctx, nconf, mm, 480)
+    f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, 2048) for _ in range(3))
+    # oracle side: one object per stream per stage
+    o_rs = [oracle.Resampler(16000, rate) for _ in range(n)]
+    o_ec = [oracle.Echo(F, 128 * rate // 1000, rate) for _ in range(n)]
+    o_pp = [oracle.Preproc(F, rate, o_ec[s]) for s in range(n)]
+    o_vol = [oracle.Volume(rate) for _ in range(n)]
+    for v in o_vol:
+        v.v.agc_enabled = 1
+    m_mic, m_ref, m_out = NpFifo(n), NpFifo(n), NpFifo(n)
+
+    mic16 = np.stack([synth_pcm(s, 160 * nticks, rate=16000, sigma=2500.0) for s in range(n)])
+    ref48 = np.stack([synth_pcm(1000 + s, 480 * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    micf = torch.zeros((n, F), dtype=torch.int16, device="cuda")
+    reff = torch.zeros((n, F), dtype=torch.int16, device="cuda")
+    clean = torch.zeros((n, F), dtype=torch.int16, device="cuda")
+    okm = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    tick = torch.zeros((n, 480), dtype=torch.int16, device="cuda")
+    okt = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    up = torch.zeros((n, 488), dtype=torch.int16, device="cuda")
+    mixed = torch.zeros((nconf, mm, 480), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()  # torch fills these on ITS stream; the kernels below run on the context's stream
+    aec_sq, aec_cnt, frames_done, ticks_out = 0.0, 0, 0, 0
+    for t in range(nticks):
+        # ---- resample, device resident
+        mic_t = dev(mic16[:, t * 160:(t + 1) * 160])
+        torch.cuda.synchronize()
+        rs.process(mic_t, out=up)
+        ctx.sync()
+        g_up = up.cpu().numpy()[:, :480]
+        want = np.stack([o_rs[s].process(mic16[s, t * 160:(t + 1) * 160]) for s in range(n)])
+        assert np.abs(g_up.astype(int) - want).max() <= 1
+        f_mic.push(up, nsamples=480)
+        ref_t = dev(ref48[:, t * 480:(t + 1) * 480])
+        torch.cuda.synchronize()
+        f_ref.push(ref_t)
+        m_mic.push(g_up)                      # the model continues from what the GPU stage produced
+        m_ref.push(ref48[:, t * 480:(t + 1) * 480])
+        # ---- 480-sample ticks -> 256-sample frames: one or two frames per tick
+        for _ in range(2):
+            f_mic.pop(F, micf, ok=okm, zero_fill=False)
+            f_ref.pop(F, reff, gate=okm, zero_fill=True)
+            aec.process(micf, reff, out=clean, run=okm)
+            f_out.push(clean, gate=okm)
+            w_mic, w_ok = m_mic.pop(F)
+            w_ref, _ = m_ref.pop(F, gate=w_ok)
+            ctx.sync()
+            np.testing.assert_array_equal(okm.cpu().numpy(), w_ok)
+            if not w_ok.any():
+                continue
+            np.testing.assert_array_equal(micf.cpu().numpy()[w_ok == 1], w_mic[w_ok == 1])
+            np.testing.assert_array_equal(reff.cpu().numpy()[w_ok == 1], w_ref[w_ok == 1])
+            g_clean = clean.cpu().numpy()
+            w_clean = np.zeros((n, F), np.int16)
+            for s in range(n):
+                if w_ok[s]:
+                    w_clean[s] = o_pp[s].run(o_ec[s].cancel(w_mic[s], w_ref[s]))
+            d = (g_clean[w_ok == 1].astype(np.float64) - w_clean[w_ok == 1]) / 32768.0
+            aec_sq += float((d * d).sum())
+            aec_cnt += d.size
+            frames_done += 1
+            m_out.push(g_clean, count=w_ok.astype(np.int32) * F)
+        # ---- frames -> ticks, AGC, conference mix
+        f_out.pop(480, tick, ok=okt, zero_fill=True)
+        w_tick, w_okt = m_out.pop(480)
+        ctx.sync()
+        np.testing.assert_array_equal(okt.cpu().numpy(), w_okt)
+        np.testing.assert_array_equal(tick.cpu().numpy(), w_tick)
+        vol.process(tick)
+        ctx.sync()
+        g_vol = tick.cpu().numpy()
+        w_vol = np.stack([o_vol[s].chunk(w_tick[s]) for s in range(n)])
+        np.testing.assert_array_equal(g_vol, w_vol)
+        mix.process(tick.view(nconf, mm, 480), out=mixed)
+        ctx.sync()
+        g_mix = mixed.cpu().numpy()
+        for c in range(nconf):
+            w_mix, _ = oracle.mixer_tick(g_vol[c * mm:(c + 1) * mm])
+            np.testing.assert_array_equal(g_mix[c], w_mix)
+        ticks_out += int(w_okt.all())
+    assert frames_done == (480 * nticks) // F               # 1.875 frames per tick
+    assert ticks_out >= nticks - 2                          # the frame->tick FIFO delays the first ticks only
+    assert np.sqrt(aec_sq / aec_cnt) <= 1e-4
+    assert f_mic.overflows() == f_ref.overflows() == f_out.overflows() == 0
