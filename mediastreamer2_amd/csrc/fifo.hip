@@ -22,6 +22,7 @@ struct FifoArgs {
 	uint8_t *ok;
 	const uint8_t *gate; // pop only where gate != 0 (others: ok = 0), or null
 	int nsamples, stride, zero_fill;
+	int vec; // 16-byte copies allowed: capacity, stride multiples of 8 and 16-byte aligned rows
 	int32_t *levels;
 	int32_t *overflow; // number of pushes refused because the ring was full
 };
@@ -39,10 +40,18 @@ __global__ __launch_bounds__(64) void fifo_push_kernel(FifoArgs a) {
 	int16_t *r = a.ring + (size_t)s * a.capacity;
 	const int16_t *src = a.in + (size_t)s * a.stride;
 	const unsigned base = (unsigned)p.y % (unsigned)a.capacity;
-	for (int i = lane; i < n; i += 64) {
-		unsigned k = base + (unsigned)i;
-		if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
-		r[k] = src[i];
+	if (a.vec && ((n | base) & 7) == 0) { // whole 16-byte groups, also across the wrap (capacity % 8 == 0)
+		for (int i = lane; i < (n >> 3); i += 64) {
+			unsigned k = base + 8u * (unsigned)i;
+			if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+			*reinterpret_cast<uint4 *>(r + k) = *reinterpret_cast<const uint4 *>(src + 8 * i);
+		}
+	} else {
+		for (int i = lane; i < n; i += 64) {
+			unsigned k = base + (unsigned)i;
+			if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+			r[k] = src[i];
+		}
 	}
 	if (lane == 0) a.pos[s] = make_int2(p.x, p.y + n);
 }
@@ -56,14 +65,26 @@ __global__ __launch_bounds__(64) void fifo_pop_kernel(FifoArgs a) {
 	if (take) {
 		const int16_t *r = a.ring + (size_t)s * a.capacity;
 		const unsigned base = (unsigned)p.x % (unsigned)a.capacity;
-		for (int i = lane; i < n; i += 64) {
-			unsigned k = base + (unsigned)i;
-			if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
-			dst[i] = r[k];
+		if (a.vec && ((n | base) & 7) == 0) {
+			for (int i = lane; i < (n >> 3); i += 64) {
+				unsigned k = base + 8u * (unsigned)i;
+				if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+				*reinterpret_cast<uint4 *>(dst + 8 * i) = *reinterpret_cast<const uint4 *>(r + k);
+			}
+		} else {
+			for (int i = lane; i < n; i += 64) {
+				unsigned k = base + (unsigned)i;
+				if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+				dst[i] = r[k];
+			}
 		}
 		if (lane == 0) a.pos[s] = make_int2(p.x + n, p.y);
 	} else if (a.zero_fill) {
-		for (int i = lane; i < n; i += 64) dst[i] = 0;
+		if (a.vec && (n & 7) == 0) {
+			for (int i = lane; i < (n >> 3); i += 64) *reinterpret_cast<uint4 *>(dst + 8 * i) = make_uint4(0, 0, 0, 0);
+		} else {
+			for (int i = lane; i < n; i += 64) dst[i] = 0;
+		}
 	}
 	if (lane == 0 && a.ok) a.ok[s] = take ? 1 : 0;
 }
@@ -141,6 +162,7 @@ int mi_fifo_push(mi_fifo *f, const int16_t *d_in, int nsamples, int stride, cons
 	a.count = d_count;
 	a.nsamples = nsamples;
 	a.stride = stride;
+	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
 	hipLaunchKernelGGL(fifo_push_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
@@ -155,6 +177,7 @@ int mi_fifo_push_gated(mi_fifo *f, const int16_t *d_in, int nsamples, int stride
 	a.gate = d_gate;
 	a.nsamples = nsamples;
 	a.stride = stride;
+	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
 	hipLaunchKernelGGL(fifo_push_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
@@ -171,6 +194,7 @@ int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok
 	a.nsamples = frame;
 	a.stride = stride;
 	a.zero_fill = zero_fill;
+	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
 	hipLaunchKernelGGL(fifo_pop_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
