@@ -391,6 +391,19 @@ def cpu_baseline_resample_all_cores(nstreams, seconds):
         ncores = len(os.sched_getaffinity(0))
     except Exception:
         ncores = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max") and txt[0] != "max":
+                quota = float(txt[0]) / float(txt[1])
+            elif path.endswith("cfs_quota_us") and int(txt[0]) > 0:
+                quota = int(txt[0]) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota:  # a container may see every host CPU and still be allowed only a few cores' worth of time
+        ncores = max(1, min(ncores, int(quota + 0.5)))
     ncores = max(1, min(ncores, nstreams))
     x = synth_pcm_batch(nstreams, 160, 16000)
     xp = x.ctypes.data_as(C.POINTER(C.c_int16))
@@ -400,6 +413,7 @@ def cpu_baseline_resample_all_cores(nstreams, seconds):
     t = L.orc_bench_resample_mt(nstreams, 160, nticks, 16000, 48000, xp, ncores, None)
     return {"value": round(nstreams * nticks / t / TICKS_PER_S, 1),
             "unit": "concurrent 48 kHz streams (10 ms ticks in real time)", "cores": ncores, "kind": "port",
+            "cgroup_cpu_quota_cores": quota,
             "sample": f"{nstreams} streams x {nticks} ticks of 160 samples 16k->48k, oracle/resample.c, "
                       f"{t:.1f} s wall on {ncores} threads"}
 
