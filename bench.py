@@ -454,6 +454,9 @@ def cpu_reference_times():
 
 def main():
     a = parse()
+    if not os.path.exists(os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355x.so")):
+        import __graft_entry__ as entry  # build artefacts are git-ignored: a fresh checkout compiles them first
+        entry.build()
     import torch
     import mediastreamer2_amd as ms
 
