@@ -134,6 +134,7 @@ struct UpArgs {
 	const uint8_t *run;
 	int in_len, in_stride, out_stride, hist_stride, nstreams;
 	int tiles; // ceil(in_len / R)
+	int lds_per_wave;
 };
 
 // Integer up-sampling (num == 1): out[m*DEN + p] = sum_j table[p][j] * x[m + j].
@@ -144,6 +145,15 @@ struct UpArgs {
 // and R consecutive input positions; its FILT-1+R sample window comes out of LDS with 16-byte reads
 // (window start = 32*tile bytes, DEN lanes per address -> broadcast), outputs are staged in LDS and
 // leave as 16-byte stores.
+constexpr int UP_WAVES = 2; // wavefronts per workgroup of resample_up_kernel
+
+// LDS hand-over inside ONE wavefront: the LDS unit executes a wave's instructions in order, so only the compiler has
+// to be kept from moving accesses across this point (no s_barrier: the waves of a workgroup are independent here)
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
 // acc += splat(t.lo or t.hi) * w on both halves.  Written as asm so the FILT x R/2 issue order below is
 // the one executed: left to itself the scheduler finishes one accumulator at a time and spills the window.
 template <int HI>
@@ -162,11 +172,14 @@ __device__ __forceinline__ f2 pk_odd_pair(const f2 a, const f2 b) {
 }
 
 template <int DEN, int FILT, int R, bool MULTI, bool TWO>
-__global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+__global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_all[];
+	// UP_WAVES independent wavefronts share a workgroup only to halve the number of workgroups the dispatcher has to
+	// place (0.4 us of a 6.7 us launch at 4096 streams); each has its own LDS slice and never waits for the other.
+	char *smem = smem_all + (size_t)(threadIdx.x >> 6) * a.lds_per_wave;
 	constexpr int HIST = FILT - 1;
 	static_assert(R == 8 && FILT % 8 == 0, "window = FILT+R-1 samples read as 16-byte groups");
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;
 	const int out_per_stream = a.in_len * DEN;
 	const int xn = ((HIST + a.in_len + R + 1) + 3) & ~3;
 	float *x = reinterpret_cast<float *>(smem);                         // [xn] history ++ input ++ zero slack
@@ -183,7 +196,8 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 	// ---- the first stream's row goes out FIRST (it is the HBM miss on the critical path of a one-stream wave), the
 	// run flag next, the L2-resident tap rows last; nothing waits before the row is needed for staging
 	short4 v0 = make_short4(0, 0, 0, 0), v1 = v0;
-	int s = blockIdx.x;
+	const int nwaves = gridDim.x * UP_WAVES;
+	int s = blockIdx.x * UP_WAVES + (threadIdx.x >> 6);
 	int runv = 1;
 	if (s < a.nstreams) {
 		if (lane < nq) v0 = *quad_ptr(s, lane);
@@ -205,13 +219,13 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 		}
 	};
 	for (int i = HIST + a.in_len + lane; i < xn; i += 64) x[i] = 0.f; // slack stays zero for every stream
-	__syncthreads(); // single wave: LDS fence, the table is in place
+	wave_sync(); // single wave: LDS fence, the table is in place
 	if (!MULTI) {
 		const int l0 = lane < nlanes ? lane : 0;
 		load_row(l0 - (l0 / DEN) * DEN);
 	}
 
-	for (; s < a.nstreams; s += gridDim.x) {
+	for (; s < a.nstreams; s += nwaves) {
 		// ---- the prefetched row goes to LDS as float
 		if (lane < nq) {
 			const int b = 4 * lane - (lane < hq ? 0 : 4 * hq - HIST);
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 		}
 		const int cur_run = runv;
 		// ---- next stream's row: in flight during this stream's arithmetic
-		const int sn = s + gridDim.x;
+		const int sn = s + nwaves;
 		if (sn < a.nstreams) {
 			if (lane < nq) v0 = *quad_ptr(sn, lane);
 			if (two && lane + 64 < nq) v1 = *quad_ptr(sn, lane + 64);
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 		}
 		if (!cur_run) { // masked out: no output, state untouched
 			if (lane == 0 && a.out_len) a.out_len[s] = 0;
-			__syncthreads();
+			wave_sync();
 			continue;
 		}
 		for (int base = 0; base < (MULTI ? nlanes : 1); base += 64) { // !MULTI: nlanes <= 64, one trip
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 			const int tile = on ? l / DEN : 0, p = on ? l - tile * DEN : 0;
 			const int m0 = tile * R;
 			if (MULTI) load_row(p); // several trips: the phase pattern shifts by 64 % DEN
-			__syncthreads(); // single wave: LDS fence between staging and the window reads
+			wave_sync(); // single wave: LDS fence between staging and the window reads
 			// The window slides through registers 8 taps at a time (16 floats live, the next 8 in flight).
 			// v_pk_fma_f32 does two positions per issue slot: the tap is broadcast by op_sel, even-offset
 			// window pairs are register pairs as loaded, odd-offset pairs cost one v_pk_mov_b32 each.
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 					if (m0 + r < a.in_len) obuf[(m0 + r) * DEN + p] = word2int(acc[r]);
 			}
 		}
-		__syncthreads();
+		wave_sync();
 		// ---- outputs: 16-byte coalesced stores (launch_up checked the layout)
 		int16_t *o = a.out + (size_t)s * a.out_stride;
 		for (int q = lane; q < (out_per_stream >> 3); q += 64)
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(64, 4) void resample_up_kernel(UpArgs a) {
 			*reinterpret_cast<short4 *>(a.hist + (size_t)s * a.hist_stride + 4 * lane) = h;
 		}
 		if (lane == 0 && a.out_len) a.out_len[s] = out_per_stream;
-		__syncthreads(); // LDS reads above complete before the next row overwrites x / obuf
+		wave_sync(); // LDS reads above complete before the next row overwrites x / obuf
 	}
 }
 
@@ -445,13 +459,17 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
 		const int v = e ? atoi(e) : 0;
 		return v > 0 ? v : 16;
 	}();
-	const int max_grid = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * waves_per_cu;
-	const int per_wave = mi::ceil_div(r->nstreams, max_grid);
-	const int grid = mi::ceil_div(r->nstreams, per_wave);
+	const int max_waves = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * waves_per_cu;
+	const int per_wave = mi::ceil_div(r->nstreams, max_waves);
+	const int nwaves = mi::ceil_div(r->nstreams, per_wave);
+	const int grid = mi::ceil_div(nwaves, UP_WAVES);
+	a.lds_per_wave = (int)((lds + 15) & ~(size_t)15);
 	if (DEN * tiles <= 64 && nq <= 64)
-		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, false, false>), dim3(grid), dim3(64), lds, r->ctx->stream, a);
+		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, false, false>), dim3(grid), dim3(64 * UP_WAVES),
+		                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
 	else
-		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, true, true>), dim3(grid), dim3(64), lds, r->ctx->stream, a);
+		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, true, true>), dim3(grid), dim3(64 * UP_WAVES),
+		                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	*done = true;
 	return MI_OK;
