@@ -27,8 +27,11 @@ struct FifoArgs {
 	int32_t *overflow; // number of pushes refused because the ring was full
 };
 
-__global__ __launch_bounds__(64) void fifo_push_kernel(FifoArgs a) {
-	const int s = blockIdx.x, lane = threadIdx.x;
+constexpr int FIFO_WAVES = 4; // independent wavefronts (streams) per workgroup: 4x fewer workgroups to dispatch
+
+__global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_push_kernel(FifoArgs a) {
+	const int s = blockIdx.x * FIFO_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (s >= a.nstreams) return;
 	if (a.gate && !a.gate[s]) return;
 	const int n = a.count ? min(max(a.count[s], 0), a.nsamples) : a.nsamples;
 	if (n == 0) return;
@@ -56,8 +59,9 @@ __global__ __launch_bounds__(64) void fifo_push_kernel(FifoArgs a) {
 	if (lane == 0) a.pos[s] = make_int2(p.x, p.y + n);
 }
 
-__global__ __launch_bounds__(64) void fifo_pop_kernel(FifoArgs a) {
-	const int s = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_pop_kernel(FifoArgs a) {
+	const int s = blockIdx.x * FIFO_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (s >= a.nstreams) return;
 	const int n = a.nsamples;
 	const int2 p = a.pos[s];
 	const bool take = (!a.gate || a.gate[s]) && (p.y - p.x >= n);
@@ -163,7 +167,7 @@ int mi_fifo_push(mi_fifo *f, const int16_t *d_in, int nsamples, int stride, cons
 	a.nsamples = nsamples;
 	a.stride = stride;
 	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
-	hipLaunchKernelGGL(fifo_push_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
+	hipLaunchKernelGGL(fifo_push_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
@@ -178,7 +182,7 @@ int mi_fifo_push_gated(mi_fifo *f, const int16_t *d_in, int nsamples, int stride
 	a.nsamples = nsamples;
 	a.stride = stride;
 	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
-	hipLaunchKernelGGL(fifo_push_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
+	hipLaunchKernelGGL(fifo_push_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
@@ -195,7 +199,7 @@ int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok
 	a.stride = stride;
 	a.zero_fill = zero_fill;
 	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
-	hipLaunchKernelGGL(fifo_pop_kernel, dim3(f->nstreams), dim3(64), 0, f->ctx->stream, a);
+	hipLaunchKernelGGL(fifo_pop_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
