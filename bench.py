@@ -357,6 +357,32 @@ def pipeline_probe(ms, torch, ctx, nstreams):
     return out
 
 
+def session_probe(ms, ctx, nstreams, ticks=40):
+    """mi_session end to end: host buffers in, host buffers out, uploads / kernels / downloads overlapped on three HIP
+    streams, three ticks in flight -- the PCIe-inclusive rate of the chained path (never part of `value`)."""
+    se = ms.Session(ctx, nstreams, use_graphs=False)
+    mic = synth_pcm_batch(nstreams, 160, 16000)
+    ref = synth_pcm_batch(nstreams, 480, 48000, sigma=2000.0)
+    for _ in range(3):
+        m, r = se.acquire()
+        m[:], r[:] = mic, ref
+        se.submit()
+    for _ in range(3):
+        se.collect()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        if se.in_flight() == 3:
+            se.collect()
+        se.acquire()
+        se.submit()
+    while se.in_flight():
+        se.collect()
+    dt = (time.perf_counter() - t0) / ticks
+    se.close()
+    return {"streams": nstreams, "tick_ms_end_to_end": round(dt * 1e3, 4), "pcie_bytes_per_tick": nstreams * (320 + 960 + 960),
+            "fits": bool(dt < 0.010), "note": "mi_session: pinned host buffers -> H2D | kernels | D2H on three streams, 3 ticks in flight"}
+
+
 def cpu_baseline_resample(nstreams, seconds):
     """The oracle (CPU restatement of the reference path: one resampler object per stream,
     called tick by tick) on this host's cores -- 1 thread, bounded sample."""
@@ -597,6 +623,10 @@ def main():
                     line["pipeline"] = pipeline_probe(ms, torch, ctx, a.pipeline_streams)
                 except Exception as e:
                     line["pipeline"] = {"error": str(e)[:200]}
+                try:
+                    line["session_pcie_inclusive"] = session_probe(ms, ctx, a.pipeline_streams)
+                except Exception as e:
+                    line["session_pcie_inclusive"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
             try:

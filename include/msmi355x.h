@@ -277,6 +277,36 @@ int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, i
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_reset(mi_fifo *f);
 
+/* ------------------------------------------------------------- session */
+/* The chained path of BASELINE.json's north_star for a batch of call legs, fed from host buffers, one 10 ms tick per
+ * submit: MSResample in_rate->rate (msresample.c:122-179) -> FIFO -> MSSpeexEC + post-filter (speexec.c:223-305) ->
+ * FIFO -> MSVolume with AGC (msvolume.c:471-514) -> MSAudioMixer in conference mode (audiomixer.c:288-346; stream
+ * s = conference * members + member).  Uploads, kernels and downloads run on three HIP streams, up to three ticks
+ * in flight; the kernel sequence is a hipGraph per buffer slot.  Outputs equal the same C ABI objects called one by
+ * one (tests/test_gpu_pipeline.py). */
+typedef struct mi_session mi_session;
+typedef struct mi_session_config {
+	int32_t nstreams;               /* multiple of members_per_conference */
+	int32_t members_per_conference; /* <= MI_MIXER_MAX_CHANNELS */
+	int32_t in_rate;                /* microphone rate; == rate skips the resampler */
+	int32_t rate;                   /* processing / output rate */
+	int32_t tail_ms;                /* MS_ECHO_CANCELLER_SET_TAIL_LENGTH */
+	int32_t agc;                    /* MS_VOLUME_ENABLE_AGC */
+	int32_t use_graphs;             /* 1: replay a hipGraph per tick, 0: launch the kernels one by one */
+} mi_session_config;
+void mi_session_default_config(mi_session_config *c);
+int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **out);
+void mi_session_destroy(mi_session *s);
+int mi_session_tick_samples(const mi_session *s, int *in_samples, int *out_samples);
+/* pinned staging of the NEXT tick, to be filled in place: mic [nstreams][in_rate/100], far-end reference
+ * [nstreams][rate/100] */
+int mi_session_acquire(mi_session *s, int16_t **h_mic, int16_t **h_ref);
+int mi_session_submit(mi_session *s);
+/* the OLDEST tick in flight: waits for its download, returns the pinned output [nstreams][rate/100] (valid until
+ * three more ticks have been submitted) */
+int mi_session_collect(mi_session *s, const int16_t **h_out);
+int mi_session_in_flight(const mi_session *s);
+
 /* ------------------------------------------------------------- pixconv */
 /* Packed formats -> I420, what pixconv_process (src/videofilters/pixconv.c:62-94) obtains from
  * ms_scaler_process with the libyuv implementation (yuv_scale src/voip/msvideo.c:542-581).

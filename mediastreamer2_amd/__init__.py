@@ -445,3 +445,46 @@ class FifoBatch(_Batch):
 
     def reset(self):
         check(self.ctx.L.mi_fifo_reset(self.h))
+
+
+class SessionConfig(C.Structure):
+    _fields_ = [("nstreams", C.c_int32), ("members_per_conference", C.c_int32), ("in_rate", C.c_int32),
+                ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32)]
+
+
+class Session(_Batch):
+    """mi_session: the chained path (resample -> AEC -> AGC -> conference mix) fed from host buffers, three ticks
+    in flight on three HIP streams."""
+    _destroy = "mi_session_destroy"
+
+    def __init__(self, ctx, nstreams, members=32, in_rate=16000, rate=48000, tail_ms=128, agc=True, use_graphs=True):
+        self.ctx = ctx
+        cfg = SessionConfig()
+        ctx.L.mi_session_default_config(C.byref(cfg))
+        cfg.nstreams, cfg.members_per_conference, cfg.in_rate, cfg.rate = nstreams, members, in_rate, rate
+        cfg.tail_ms, cfg.agc, cfg.use_graphs = tail_ms, int(agc), int(use_graphs)
+        h = C.c_void_p()
+        check(ctx.L.mi_session_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.n, self.in_len, self.len = nstreams, in_rate // 100, rate // 100
+
+    def _view(self, ptr, cols):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(self.n, cols))
+
+    def acquire(self):
+        """numpy views of the pinned staging of the next tick: (mic [n, in_len], ref [n, len])."""
+        pm, pr = C.c_void_p(), C.c_void_p()
+        check(self.ctx.L.mi_session_acquire(self.h, C.byref(pm), C.byref(pr)))
+        return self._view(pm, self.in_len), self._view(pr, self.len)
+
+    def submit(self):
+        check(self.ctx.L.mi_session_submit(self.h))
+
+    def collect(self):
+        """numpy view of the oldest in-flight tick's output [n, len] (pinned; valid for three more submits)."""
+        po = C.c_void_p()
+        check(self.ctx.L.mi_session_collect(self.h, C.byref(po)))
+        return self._view(po, self.len)
+
+    def in_flight(self):
+        return self.ctx.L.mi_session_in_flight(self.h)

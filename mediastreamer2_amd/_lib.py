@@ -43,6 +43,8 @@ EXPORTS = [
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
     "mi_pixconv_process", "mi_pixconv_process_host",
+    "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples",
+    "mi_session_acquire", "mi_session_submit", "mi_session_collect", "mi_session_in_flight",
     "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset",
 ]
 
@@ -187,6 +189,17 @@ def load():
         L.mi_scaler_process.argtypes = [vp, i32, vp, sz, vp, sz]
         L.mi_scaler_process_host.argtypes = [vp, i32, vp, sz, vp, sz]
         L.mi_scaler_process_planes_host.argtypes = [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(vp), C.POINTER(i32)]
+    if hasattr(L, "mi_session_create"):
+        L.mi_session_default_config.argtypes = [vp]
+        L.mi_session_default_config.restype = None
+        L.mi_session_create.argtypes = [vp, vp, pp]
+        L.mi_session_destroy.argtypes = [vp]
+        L.mi_session_destroy.restype = None
+        L.mi_session_tick_samples.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        L.mi_session_acquire.argtypes = [vp, pp, pp]
+        L.mi_session_submit.argtypes = [vp]
+        L.mi_session_collect.argtypes = [vp, pp]
+        L.mi_session_in_flight.argtypes = [vp]
     if hasattr(L, "mi_fifo_create"):
         L.mi_fifo_create.argtypes = [vp, i32, i32, pp]
         L.mi_fifo_destroy.argtypes = [vp]

@@ -36,8 +36,9 @@ struct VolArgs {
 	const int32_t *nsamples_per_stream; // or null
 	const mi_volume_params *params;
 	mi_volume_state *state;
-	const float *energy_prev; // peers read last launch's energy
-	float *energy_next;
+	float *energy[2];  // double buffer: peers read the PREVIOUS launch's energy (msvolume.c:206-207 reads its peer's field)
+	const int *parity; // which of the two holds the previous launch's values; flipped on the device after each launch,
+	                   // so a captured hipGraph replays correctly (a host-side flip would be frozen into the graph)
 	int nstreams, nsamples, stride, sample_rate, pitch_dw, pitch_f;
 };
 
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	if (tid < nloc) {
 		p = a.params[s0 + tid];
 		st = a.state[s0 + tid];
-		if (p.peer >= 0) peer_energy = a.energy_prev[p.peer];
+		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
 	}
 	if (tid < SPB) {
 		int n = 0;
@@ -229,10 +230,10 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 			s_mode[tid] = (gain != 1) ? 1 : 0;
 		}
 		a.state[s] = st;
-		a.energy_next[s] = st.energy;
+		a.energy[*a.parity ^ 1][s] = st.energy;
 	} else if (tid < SPB) {
 		s_mode[tid] = 0;
-		if (tid < nloc) a.energy_next[s0 + tid] = a.state[s0 + tid].energy;
+		if (tid < nloc) a.energy[*a.parity ^ 1][s0 + tid] = a.state[s0 + tid].energy;
 	}
 	__syncthreads();
 
@@ -274,6 +275,8 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	}
 }
 
+__global__ void volume_flip_kernel(int *parity) { *parity ^= 1; }
+
 } // namespace
 
 struct mi_volume {
@@ -282,7 +285,8 @@ struct mi_volume {
 	mi_volume_params *d_params = nullptr;
 	mi_volume_state *d_state = nullptr;
 	float *d_energy[2] = {nullptr, nullptr};
-	int cur = 0;
+	int *d_parity = nullptr;
+	bool has_peers = false; // conservative: set once any stream names a peer
 };
 
 extern "C" {
@@ -315,7 +319,8 @@ int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out
 	if (hipMalloc((void **)&v->d_params, sizeof(mi_volume_params) * (size_t)nstreams) != hipSuccess ||
 	    hipMalloc((void **)&v->d_state, sizeof(mi_volume_state) * (size_t)nstreams) != hipSuccess ||
 	    hipMalloc((void **)&v->d_energy[0], sizeof(float) * (size_t)nstreams) != hipSuccess ||
-	    hipMalloc((void **)&v->d_energy[1], sizeof(float) * (size_t)nstreams) != hipSuccess) {
+	    hipMalloc((void **)&v->d_energy[1], sizeof(float) * (size_t)nstreams) != hipSuccess ||
+	    hipMalloc((void **)&v->d_parity, sizeof(int)) != hipSuccess) {
 		mi::set_error("hipMalloc failed for volume state");
 		mi_volume_destroy(v);
 		return MI_ENOMEM;
@@ -331,7 +336,8 @@ int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out
 	if (hipMemcpy(v->d_params, hp.data(), sizeof(dp) * hp.size(), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(v->d_state, hs.data(), sizeof(ds) * hs.size(), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemset(v->d_energy[0], 0, sizeof(float) * (size_t)nstreams) != hipSuccess ||
-	    hipMemset(v->d_energy[1], 0, sizeof(float) * (size_t)nstreams) != hipSuccess) {
+	    hipMemset(v->d_energy[1], 0, sizeof(float) * (size_t)nstreams) != hipSuccess ||
+	    hipMemset(v->d_parity, 0, sizeof(int)) != hipSuccess) {
 		mi::set_error("volume state upload failed");
 		mi_volume_destroy(v);
 		return MI_ENODEV;
@@ -347,12 +353,15 @@ void mi_volume_destroy(mi_volume *v) {
 	if (v->d_state) (void)hipFree(v->d_state);
 	if (v->d_energy[0]) (void)hipFree(v->d_energy[0]);
 	if (v->d_energy[1]) (void)hipFree(v->d_energy[1]);
+	if (v->d_parity) (void)hipFree(v->d_parity);
 	delete v;
 }
 
 int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_params *h) {
 	MI_CHECK_ARG(v && h && first >= 0 && count >= 0 && first + count <= v->nstreams);
 	for (int i = 0; i < count; ++i) MI_CHECK_ARG(h[i].peer < v->nstreams);
+	for (int i = 0; i < count; ++i)
+		if (h[i].peer >= 0) v->has_peers = true;
 	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(v->ctx->stream));
 	MI_HIP(hipMemcpy(v->d_params + first, h, sizeof(*h) * (size_t)count, hipMemcpyHostToDevice));
@@ -374,7 +383,9 @@ int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_stat
 	MI_HIP(hipMemcpy(v->d_state + first, h, sizeof(*h) * (size_t)count, hipMemcpyHostToDevice));
 	std::vector<float> e((size_t)count);
 	for (int i = 0; i < count; ++i) e[(size_t)i] = h[i].energy;
-	MI_HIP(hipMemcpy(v->d_energy[v->cur] + first, e.data(), sizeof(float) * (size_t)count, hipMemcpyHostToDevice));
+	// both halves: whichever the device-side parity says is "previous" must show these energies to the peers
+	MI_HIP(hipMemcpy(v->d_energy[0] + first, e.data(), sizeof(float) * (size_t)count, hipMemcpyHostToDevice));
+	MI_HIP(hipMemcpy(v->d_energy[1] + first, e.data(), sizeof(float) * (size_t)count, hipMemcpyHostToDevice));
 	return MI_OK;
 }
 
@@ -390,8 +401,9 @@ int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride
 	a.nsamples_per_stream = d_nsamples;
 	a.params = v->d_params;
 	a.state = v->d_state;
-	a.energy_prev = v->d_energy[v->cur];
-	a.energy_next = v->d_energy[v->cur ^ 1];
+	a.energy[0] = v->d_energy[0];
+	a.energy[1] = v->d_energy[1];
+	a.parity = v->d_parity;
 	a.nstreams = v->nstreams;
 	a.nsamples = nsamples;
 	a.stride = stride;
@@ -410,7 +422,10 @@ int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride
 	}
 	hipLaunchKernelGGL(volume_kernel, dim3(mi::ceil_div(v->nstreams, SPB)), dim3(VTHREADS), lds, v->ctx->stream, a);
 	MI_LAUNCH_CHECK();
-	v->cur ^= 1;
+	if (v->has_peers) { // without peers nobody reads the previous energies: no flip, no extra launch
+		hipLaunchKernelGGL(volume_flip_kernel, dim3(1), dim3(1), 0, v->ctx->stream, v->d_parity);
+		MI_LAUNCH_CHECK();
+	}
 	return MI_OK;
 }
 

@@ -168,3 +168,62 @@ def test_chained_tick_pipeline_stage_parity(ctx, oracle):
     assert ticks_out >= nticks - 2                          # the frame->tick FIFO delays the first ticks only
     assert np.sqrt(aec_sq / aec_cnt) <= 1e-4
     assert f_mic.overflows() == f_ref.overflows() == f_out.overflows() == 0
+
+
+@pytest.mark.parametrize("use_graphs", [True, False])
+def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs):
+    """mi_session (three streams, up to three ticks in flight, hipGraph per slot) must produce exactly what the same
+    C ABI objects produce when called one after the other on one stream -- it only adds plumbing."""
+    torch = pytest.importorskip("torch")
+    nconf, mm, nticks, F, rate = 3, 32, 25, 256, 48000
+    n = nconf * mm
+    mic16 = np.stack([synth_pcm(s, 160 * nticks, rate=16000, sigma=2500.0) for s in range(n)])
+    ref48 = np.stack([synth_pcm(500 + s, 480 * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+    # ---- reference run: the individual objects, synchronous
+    rs = ms.ResamplerBatch(ctx, n, 16000, rate)
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
+    vol = ms.VolumeBatch(ctx, n, rate)
+    p = vol.default_params()
+    p.agc_enabled = 1
+    vol.set_params([p] * n)
+    mix = ms.MixerBatch(ctx, nconf, mm, 480)
+    cap = (2 * 480 + 2 * F + 7) & ~7
+    f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, cap) for _ in range(3))
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    up, micf, reff, clean, tick, mixed = z(n, 488), z(n, F), z(n, F), z(n, F), z(n, 480), z(nconf, mm, 480)
+    okm = z(n, dt=torch.uint8)
+    want = []
+    for t in range(nticks):
+        d_mic = torch.from_numpy(np.ascontiguousarray(mic16[:, t * 160:(t + 1) * 160])).cuda()
+        d_ref = torch.from_numpy(np.ascontiguousarray(ref48[:, t * 480:(t + 1) * 480])).cuda()
+        torch.cuda.synchronize()
+        rs.process(d_mic, out=up)
+        f_mic.push(up, nsamples=480)
+        f_ref.push(d_ref)
+        for _ in range(2):
+            f_mic.pop(F, micf, ok=okm, zero_fill=False)
+            f_ref.pop(F, reff, gate=okm, zero_fill=True)
+            aec.process(micf, reff, out=clean, run=okm)
+            f_out.push(clean, gate=okm)
+        f_out.pop(480, tick, zero_fill=True)
+        vol.process(tick)
+        mix.process(tick.view(nconf, mm, 480), out=mixed)
+        ctx.sync()
+        want.append(mixed.cpu().numpy().reshape(n, 480).copy())
+    # ---- the session, pipelined: keep up to three ticks in flight
+    se = ms.Session(ctx, n, members=mm, in_rate=16000, rate=rate, tail_ms=128, agc=True, use_graphs=use_graphs)
+    got = []
+    for t in range(nticks):
+        if se.in_flight() == 3:
+            got.append(se.collect().copy())
+        h_mic, h_ref = se.acquire()
+        h_mic[:] = mic16[:, t * 160:(t + 1) * 160]
+        h_ref[:] = ref48[:, t * 480:(t + 1) * 480]
+        se.submit()
+    while se.in_flight():
+        got.append(se.collect().copy())
+    assert len(got) == nticks
+    for t in range(nticks):
+        np.testing.assert_array_equal(got[t], want[t], err_msg=f"tick {t}")
+    assert any(g.any() for g in got)
+    se.close()
