@@ -6,7 +6,7 @@
 // YUY2ToI420 / UYVYToI420 / RGB24ToJ420 / RAWToI420 / ARGBToI420 (libyuv, un-vendored, unpinned; the
 // portable C rows of the r1750+ era: BT.601 limited-range Q8 luma (66,129,25)+0x1080, chroma on the
 // nested-AVGB 2x2 average with +0x8080, the JPEG full-range set (77,150,29)+128 for RGB24ToJ420, and
-// the rounded vertical chroma average of the 4:2:2 rows).  Integer only, bit-exact against oracle/pixconv.c.
+// the rounded vertical chroma average of the 4:2:2 rows).  Integer only; parity is checked bit for bit in tests/test_gpu_pixconv.py.
 //
 // Mapping: byte streaming, HBM-bound.  One lane owns 8 pixels of one row PAIR: it loads the two
 // 16/24/32-byte row segments with 8/16-byte loads, and stores 2 x 8 bytes of luma and 4 + 4 bytes of
