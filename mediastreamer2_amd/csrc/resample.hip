@@ -14,6 +14,10 @@
 //       Each lane owns one polyphase row (FILT taps in VGPRs) and R consecutive
 //       input positions; the FILT-1+R sample window comes out of LDS with
 //       16-byte reads; outputs are staged in LDS and leave as 16-byte stores.
+//   resample_down_kernel<NUM,48,8>  integer down-sampling (den_rate == 1, e.g.
+//       48k->16k, 48k->8k, 16k->8k): the input is split by phase while it is
+//       staged and each lane (tile, phase) runs the same 48-tap tile FIR on its
+//       phase; the NUM shares of an output meet in LDS.
 //   resample_generic_kernel         any other ratio (direct table or the
 //       oversampled table + 4-point cubic interpolation), one block per stream.
 //
@@ -171,6 +175,41 @@ __device__ __forceinline__ f2 pk_odd_pair(const f2 a, const f2 b) {
 	return d;
 }
 
+// acc2[q] += sum_j t[j] * (xwin[j + 2q], xwin[j + 2q + 1]) for j < FILT: R = 8 consecutive positions of one polyphase
+// row.  The window slides through registers 8 taps at a time (16 floats live, the next 8 in flight); v_pk_fma_f32 does
+// two positions per issue slot: the tap is broadcast by op_sel, even-offset window pairs are register pairs as loaded
+// (xwin is 16-byte aligned), odd-offset pairs cost one v_pk_mov_b32 each.  Reads xwin[0 .. FILT+R-1].
+template <int FILT, int R>
+__device__ __forceinline__ void fir_tile(const float *xwin, const f2 (&t2)[FILT / 2], f2 (&acc2)[R / 2]) {
+	static_assert(R == 8 && FILT % 8 == 0, "window = FILT+R-1 samples read as 16-byte groups");
+	const float4 *wp = reinterpret_cast<const float4 *>(xwin);
+	float4 c0 = wp[0], c1 = wp[1], c2 = wp[2], c3 = wp[3];
+	f2 od[7]; // odd-offset pairs (w[2i+1], w[2i+2]) of the 16 live floats
+#pragma unroll
+	for (int c = 0; c < FILT / 8; ++c) {
+		const f2 ev[8] = {(f2){c0.x, c0.y}, (f2){c0.z, c0.w}, (f2){c1.x, c1.y}, (f2){c1.z, c1.w},
+		                  (f2){c2.x, c2.y}, (f2){c2.z, c2.w}, (f2){c3.x, c3.y}, (f2){c3.z, c3.w}};
+#pragma unroll
+		for (int i = (c == 0 ? 0 : 3); i < 7; ++i) od[i] = pk_odd_pair(ev[i], ev[i + 1]);
+#pragma unroll
+		for (int jj = 0; jj < 8; ++jj) {
+			const f2 tp2 = t2[(8 * c + jj) / 2];
+#pragma unroll
+			for (int q = 0; q < R / 2; ++q) {
+				const int k = jj + 2 * q; // 0..13 within the 16 live floats
+				const f2 wk = (k & 1) ? od[k / 2] : ev[k / 2];
+				if (jj & 1)
+					pk_fma_splat<1>(acc2[q], tp2, wk);
+				else
+					pk_fma_splat<0>(acc2[q], tp2, wk);
+			}
+		}
+		od[0] = od[4], od[1] = od[5], od[2] = od[6];
+		c0 = c2, c1 = c3;
+		if (c + 1 < FILT / 8) c2 = wp[2 * c + 4], c3 = wp[2 * c + 5];
+	}
+}
+
 template <int DEN, int FILT, int R, bool MULTI, bool TWO>
 __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -178,7 +217,6 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a)
 	// place (0.4 us of a 6.7 us launch at 4096 streams); each has its own LDS slice and never waits for the other.
 	char *smem = smem_all + (size_t)(threadIdx.x >> 6) * a.lds_per_wave;
 	constexpr int HIST = FILT - 1;
-	static_assert(R == 8 && FILT % 8 == 0, "window = FILT+R-1 samples read as 16-byte groups");
 	const int lane = threadIdx.x & 63;
 	const int out_per_stream = a.in_len * DEN;
 	const int xn = ((HIST + a.in_len + R + 1) + 3) & ~3;
@@ -262,38 +300,10 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a)
 			const int m0 = tile * R;
 			if (MULTI) load_row(p); // several trips: the phase pattern shifts by 64 % DEN
 			wave_sync(); // single wave: LDS fence between staging and the window reads
-			// The window slides through registers 8 taps at a time (16 floats live, the next 8 in flight).
-			// v_pk_fma_f32 does two positions per issue slot: the tap is broadcast by op_sel, even-offset
-			// window pairs are register pairs as loaded, odd-offset pairs cost one v_pk_mov_b32 each.
-			const float4 *wp = reinterpret_cast<const float4 *>(x + m0);
-			float4 c0 = wp[0], c1 = wp[1], c2 = wp[2], c3 = wp[3];
 			f2 acc2[R / 2];
 #pragma unroll
 			for (int q = 0; q < R / 2; ++q) acc2[q] = (f2){0.f, 0.f};
-			f2 od[7]; // odd-offset pairs (w[2i+1], w[2i+2]) of the 16 live floats
-#pragma unroll
-			for (int c = 0; c < FILT / 8; ++c) {
-				const f2 ev[8] = {(f2){c0.x, c0.y}, (f2){c0.z, c0.w}, (f2){c1.x, c1.y}, (f2){c1.z, c1.w},
-				                  (f2){c2.x, c2.y}, (f2){c2.z, c2.w}, (f2){c3.x, c3.y}, (f2){c3.z, c3.w}};
-#pragma unroll
-				for (int i = (c == 0 ? 0 : 3); i < 7; ++i) od[i] = pk_odd_pair(ev[i], ev[i + 1]);
-#pragma unroll
-				for (int jj = 0; jj < 8; ++jj) {
-					const f2 tp2 = t2[(8 * c + jj) / 2];
-#pragma unroll
-					for (int q = 0; q < R / 2; ++q) {
-						const int k = jj + 2 * q; // 0..13 within the 16 live floats
-						const f2 wk = (k & 1) ? od[k / 2] : ev[k / 2];
-						if (jj & 1)
-							pk_fma_splat<1>(acc2[q], tp2, wk);
-						else
-							pk_fma_splat<0>(acc2[q], tp2, wk);
-					}
-				}
-				od[0] = od[4], od[1] = od[5], od[2] = od[6];
-				c0 = c2, c1 = c3;
-				if (c + 1 < FILT / 8) c2 = wp[2 * c + 4], c3 = wp[2 * c + 5];
-			}
+			fir_tile<FILT, R>(x + m0, t2, acc2);
 			float acc[R];
 #pragma unroll
 			for (int q = 0; q < R / 2; ++q) acc[2 * q] = acc2[q].x, acc[2 * q + 1] = acc2[q].y;
@@ -317,6 +327,137 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a)
 		}
 		if (lane == 0 && a.out_len) a.out_len[s] = out_per_stream;
 		wave_sync(); // LDS reads above complete before the next row overwrites x / obuf
+	}
+}
+
+// Integer down-sampling (den == 1, e.g. 48k->16k, 48k->8k, 16k->8k): out[k] = sum_j T[j] * X[NUM*k + j] with
+// FILT*NUM taps, X = history ++ input.  Split by input phase, X_p[m] = X[NUM*m + p], it is NUM stride-1 FIRs of FILT
+// taps each, out[k] = sum_p sum_i T[NUM*i + p] * X_p[k + i] -- the up-sampler's tile FIR with the roles of the phases
+// turned around: lane (tile, phase) computes phase p's share of R = 8 consecutive outputs, the NUM shares meet in LDS.
+// One wavefront per stream (persistent, UP_WAVES per workgroup), input de-interleaved by phase while it is staged.
+// Accumulation is phase-major (the library runs j upward): within 1 LSB of it, like the FMA contraction already is.
+struct DownArgs {
+	const int16_t *in;
+	int16_t *out;
+	int32_t *out_len;
+	int16_t *hist;
+	const float *table; // natural order, FILT*NUM taps
+	const uint8_t *run;
+	int in_len, in_stride, out_stride, hist_stride, nstreams;
+	int tiles;  // ceil(out_len / R)
+	int plen;   // floats per phase array (multiple of 4)
+	int lds_per_wave;
+};
+
+template <int NUM, int FILT, int R>
+__global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_down_kernel(DownArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_all[];
+	char *smem = smem_all + (size_t)(threadIdx.x >> 6) * a.lds_per_wave;
+	constexpr int NT = NUM * FILT, HIST = NT - 1;
+	const int lane = threadIdx.x & 63;
+	const int out_len = a.in_len / NUM;
+	float *xp = reinterpret_cast<float *>(smem);                       // [NUM][plen] phase arrays of history ++ input
+	float *part = xp + (size_t)NUM * a.plen;                           // [tiles*R][NUM] partial sums
+	float4 *tab4 = reinterpret_cast<float4 *>(part + (size_t)a.tiles * R * NUM); // [NUM][FILT] taps, phase-major
+	{
+		float *tab = reinterpret_cast<float *>(tab4);
+		for (int i = lane; i < NT; i += 64) tab[(i % NUM) * FILT + i / NUM] = a.table[i];
+	}
+	// zero the tails of the phase arrays once (slack the window reads may touch)
+	for (int i = lane; i < NUM * a.plen; i += 64) xp[i] = 0.f;
+	wave_sync();
+	const int hq = a.hist_stride >> 2, nq = hq + (a.in_len >> 2);
+	const int nlanes = NUM * a.tiles;
+	const int nwaves = gridDim.x * UP_WAVES;
+	f2 t2[FILT / 2];
+	auto load_row = [&](int p) {
+		const float4 *tp = tab4 + p * (FILT / 4);
+#pragma unroll
+		for (int j = 0; j < FILT / 4; ++j) {
+			const float4 v = tp[j];
+			t2[2 * j] = (f2){v.x, v.y}, t2[2 * j + 1] = (f2){v.z, v.w};
+		}
+	};
+	if (nlanes <= 64) {
+		const int l0 = lane < nlanes ? lane : 0;
+		load_row(l0 - (l0 / NUM) * NUM);
+	}
+	for (int s = blockIdx.x * UP_WAVES + (threadIdx.x >> 6); s < a.nstreams; s += nwaves) {
+		if (a.run && !a.run[s]) {
+			if (lane == 0 && a.out_len) a.out_len[s] = 0;
+			continue;
+		}
+		// ---- stage history ++ input, de-interleaved by phase; up to three 8-byte loads per lane, all issued first
+		const int16_t *hs = a.hist + (size_t)s * a.hist_stride, *xin = a.in + (size_t)s * a.in_stride;
+		short4 v[3];
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int q = lane + 64 * u;
+			v[u] = make_short4(0, 0, 0, 0);
+			if (q < nq) v[u] = *reinterpret_cast<const short4 *>(q < hq ? hs + 4 * q : xin + 4 * (q - hq));
+		}
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int q = lane + 64 * u;
+			if (q < nq) {
+				const int b = q < hq ? 4 * q : HIST + 4 * (q - hq); // index in history ++ input
+				const short e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int i = b + k;
+					if (q >= hq || i < HIST) xp[(i % NUM) * a.plen + i / NUM] = (float)e[k];
+				}
+			}
+		}
+		for (int base = 0; base < nlanes; base += 64) {
+			const int l = base + lane;
+			const bool on = l < nlanes;
+			const int tile = on ? l / NUM : 0, p = on ? l - tile * NUM : 0;
+			if (nlanes > 64) load_row(p);
+			wave_sync();
+			f2 acc2[R / 2];
+#pragma unroll
+			for (int q = 0; q < R / 2; ++q) acc2[q] = (f2){0.f, 0.f};
+			fir_tile<FILT, R>(xp + (size_t)p * a.plen + tile * R, t2, acc2);
+			if (on) {
+				float *d = part + ((size_t)tile * R) * NUM + p;
+#pragma unroll
+				for (int q = 0; q < R / 2; ++q) d[(2 * q) * NUM] = acc2[q].x, d[(2 * q + 1) * NUM] = acc2[q].y;
+			}
+		}
+		wave_sync();
+		// ---- the NUM shares of each output meet, 8 outputs = one 16-byte store per lane
+		int16_t *o = a.out + (size_t)s * a.out_stride;
+		for (int g = lane; g < (out_len >> 3); g += 64) {
+			const float *ps = part + (size_t)g * 8 * NUM;
+			short r16[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				float sum = 0.f;
+#pragma unroll
+				for (int p = 0; p < NUM; ++p) sum += ps[k * NUM + p];
+				r16[k] = word2int(sum);
+			}
+			uint4 pk;
+			pk.x = (unsigned)(r16[0] & 0xffff) | ((unsigned)r16[1] << 16);
+			pk.y = (unsigned)(r16[2] & 0xffff) | ((unsigned)r16[3] << 16);
+			pk.z = (unsigned)(r16[4] & 0xffff) | ((unsigned)r16[5] << 16);
+			pk.w = (unsigned)(r16[6] & 0xffff) | ((unsigned)r16[7] << 16);
+			*reinterpret_cast<uint4 *>(o + 8 * g) = pk;
+		}
+		// ---- new history = last HIST samples of (history ++ input); the pad slot of the row takes a zero
+		for (int q = lane; q < hq; q += 64) {
+			short4 h;
+			short *hp = &h.x;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int i = a.in_len + 4 * q + k;
+				hp[k] = (4 * q + k < HIST) ? (short)xp[(i % NUM) * a.plen + i / NUM] : (short)0;
+			}
+			*reinterpret_cast<short4 *>(a.hist + (size_t)s * a.hist_stride + 4 * q) = h;
+		}
+		if (lane == 0 && a.out_len) a.out_len[s] = out_len;
+		wave_sync(); // LDS reads above complete before the next stream is staged
 	}
 }
 
@@ -425,6 +566,7 @@ struct mi_resampler {
 	int16_t *d_hist = nullptr;
 	int2 *d_pos = nullptr;
 	float *d_table = nullptr;
+	bool phase_zero = true; // every stream's (last_sample, frac) is (0, 0): all blocks so far were whole output periods
 };
 
 template <int DEN, int FILT, int R>
@@ -470,6 +612,43 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
 	else
 		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, true, true>), dim3(grid), dim3(64 * UP_WAVES),
 		                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	*done = true;
+	return MI_OK;
+}
+
+template <int NUM, int FILT, int R>
+static int launch_down(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out, int out_stride,
+                       int32_t *d_out_len, const uint8_t *d_run, bool *done) {
+	*done = false;
+	const int out_len = in_len / NUM;
+	const int nq = (r->hist_stride >> 2) + (in_len >> 2);
+	if ((in_len % NUM) != 0 || ((in_len | in_stride) & 3) != 0 || nq > 192 || ((out_len | out_stride) & 7) != 0 ||
+	    (reinterpret_cast<uintptr_t>(d_in) & 7) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15) != 0 || !r->phase_zero)
+		return MI_OK; // the generic kernel takes every other layout (and any stream state off the phase grid)
+	DownArgs a;
+	a.in = d_in;
+	a.out = d_out;
+	a.out_len = d_out_len;
+	a.hist = r->d_hist;
+	a.table = r->d_table;
+	a.run = d_run;
+	a.in_len = in_len;
+	a.in_stride = in_stride;
+	a.out_stride = out_stride;
+	a.hist_stride = r->hist_stride;
+	a.nstreams = r->nstreams;
+	a.tiles = mi::ceil_div(out_len, R);
+	const int xlen = NUM * FILT - 1 + in_len;
+	a.plen = (mi::ceil_div(xlen, NUM) + R + 8 + 3) & ~3;
+	const size_t lds = ((size_t)NUM * a.plen + (size_t)a.tiles * R * NUM + (size_t)NUM * FILT) * sizeof(float);
+	if (lds > 30 * 1024) return MI_OK;
+	a.lds_per_wave = (int)((lds + 15) & ~(size_t)15);
+	const int max_waves = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * 16;
+	const int per_wave = mi::ceil_div(r->nstreams, max_waves);
+	const int nwaves = mi::ceil_div(r->nstreams, per_wave);
+	hipLaunchKernelGGL((resample_down_kernel<NUM, FILT, R>), dim3(mi::ceil_div(nwaves, UP_WAVES)), dim3(64 * UP_WAVES),
+	                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	*done = true;
 	return MI_OK;
@@ -539,6 +718,7 @@ int mi_resampler_reset(mi_resampler *r, int first, int count) {
 	hipLaunchKernelGGL(fill_pos_kernel, dim3(mi::ceil_div(count, 256)), dim3(256), 0, r->ctx->stream, r->d_pos,
 	                   first, count);
 	MI_LAUNCH_CHECK();
+	if (first == 0 && count == r->nstreams) r->phase_zero = true;
 	return MI_OK;
 }
 
@@ -590,6 +770,22 @@ int mi_resampler_process_masked(mi_resampler *r, const int16_t *d_in, int in_len
 		}
 		if (rc != MI_OK) return rc;
 		if (done) return MI_OK;
+	}
+
+	if (r->d.den == 1 && r->d.direct && r->d.filt_len == 48 * r->d.num) {
+		bool done = false;
+		int rc = MI_OK;
+		switch (r->d.num) {
+			case 2: rc = launch_down<2, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			case 3: rc = launch_down<3, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			case 4: rc = launch_down<4, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			case 6: rc = launch_down<6, 48, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done); break;
+			default: break;
+		}
+		if (rc != MI_OK) return rc;
+		if (done) return MI_OK;
+		// a block that is not a whole number of output periods leaves (last_sample, frac) off zero for good
+		if (in_len % (int)r->d.num) r->phase_zero = false;
 	}
 
 	GenArgs a;

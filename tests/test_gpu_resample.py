@@ -42,6 +42,9 @@ def _run_both(ctx, oracle, in_rate, out_rate, nstreams, in_len, nticks, sigma=30
     (44100, 48000, 441),   # interpolated (non-direct) table
     (16000, 8000, 160),
     (48000, 44100, 480),
+    (48000, 8000, 480),    # integer down-sampling fast kernel, 6 input phases (288 taps)
+    (32000, 8000, 320),    # 4 phases
+    (48000, 24000, 480),   # 2 phases
 ])
 def test_resampler_matches_oracle(ctx, oracle, in_rate, out_rate, in_len):
     worst, rms = _run_both(ctx, oracle, in_rate, out_rate, nstreams=9, in_len=in_len, nticks=12)
@@ -143,3 +146,30 @@ def test_resampler_on_the_reference_wav_pair(ctx, oracle):
     got, want = np.concatenate(got), np.concatenate(want)
     assert np.abs(got.astype(np.int32) - want).max() <= 1
     assert best_alignment_similarity(got, x48[: len(got)]) >= 0.98
+
+
+def test_downsampler_fast_and_generic_paths_interleave(ctx, oracle):
+    # The integer down-sampling kernel needs every stream on the output-period grid; a ragged block hands the batch to
+    # the generic kernel for good (the library's (last_sample, frac) leaves zero), a reset brings it back.  Either way
+    # the stream of samples must keep matching the oracle.
+    n = 5
+    rs = ms.ResamplerBatch(ctx, n, 48000, 16000)
+    orcs = [oracle.Resampler(48000, 16000) for _ in range(n)]
+    x = np.stack([synth_pcm(40 + s, 480 * 12, rate=48000) for s in range(n)])
+    pos = 0
+    for blk in (480, 480, 479, 481, 480, 240, 480):
+        out, olen = rs.process(np.ascontiguousarray(x[:, pos:pos + blk]))
+        for s in range(n):
+            ref = orcs[s].process(x[s, pos:pos + blk])
+            assert olen[s] == len(ref)
+            assert np.abs(out[s, :olen[s]].astype(int) - ref).max() <= 1
+        pos += blk
+    rs.reset()
+    orcs = [oracle.Resampler(48000, 16000) for _ in range(n)]
+    for t in range(3):
+        out, olen = rs.process(np.ascontiguousarray(x[:, t * 480:(t + 1) * 480]))
+        for s in range(n):
+            ref = orcs[s].process(x[s, t * 480:(t + 1) * 480])
+            assert olen[s] == len(ref) == 160
+            assert np.abs(out[s, :160].astype(int) - ref).max() <= 1
+    rs.close()
