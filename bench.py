@@ -223,6 +223,26 @@ def make_scaler_leg(ms, torch, ctx, nframes=64):
     return leg
 
 
+def make_pixconv_leg(ms, torch, ctx, nframes=64, fmt=None, w=1920, h=1080):
+    """MSPixConv: packed YUY2 1080p frames -> I420 (the capture-side conversion, pixconv.c:62-94)."""
+    fmt = ms.MI_PIX_YUY2 if fmt is None else fmt
+    pc = ms.PixConvBatch(ctx, w, h, fmt)
+    per_step = nframes * (pc.src_bytes + pc.dst_bytes)
+    ring = 2
+    rng = np.random.default_rng(7)
+    host = rng.integers(0, 256, (4, pc.src_bytes), dtype=np.uint8)
+    ins = [torch.from_numpy(np.ascontiguousarray(host[np.arange(nframes) % 4])).cuda() for _ in range(ring)]
+    outs = [torch.zeros((nframes, pc.dst_bytes), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+
+    def launch(i):
+        pc.process(ins[i], out=outs[i])
+
+    leg = Leg(ctx, "pixconv_kernel<2>", launch, ring, per_step, nframes, "frames (1080p YUY2 -> I420)")
+    leg.keep = (pc, ins, outs)
+    leg.mpix_in = nframes * w * h / 1e6
+    return leg
+
+
 def make_aec_leg(ms, torch, ctx, nstreams=4096):
     """BASELINE configs[2] geometry: 48 kHz, 256-sample frames, 128 ms tail (M=24, N=512), post-filter on."""
     rate, F = 48000, 256
@@ -586,7 +606,7 @@ def main():
                 return make_resample_leg(ms_, torch_, ctx_, 65536)
 
             for mk in (make_resample_65536, make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg,
-                       make_scaler_leg):
+                       make_scaler_leg, make_pixconv_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
