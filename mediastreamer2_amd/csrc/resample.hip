@@ -18,6 +18,8 @@
 //       48k->16k, 48k->8k, 16k->8k): the input is split by phase while it is
 //       staged and each lane (tile, phase) runs the same 48-tap tile FIR on its
 //       phase; the NUM shares of an output meet in LDS.
+//   resample_ratio_kernel<L,M,24,8> L/M = 3/2 or 2/3 (32k<->48k, 16k<->24k, ...):
+//       M input phases x L output residues, the same tile FIR with 24 taps.
 //   resample_generic_kernel         any other ratio (direct table or the
 //       oversampled table + 4-point cubic interpolation), one block per stream.
 //
@@ -461,6 +463,139 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_down_kernel(DownArg
 	}
 }
 
+// Rational ratios L/M with a direct table (32k<->48k, 16k<->24k, 8k<->12k: L/M = 3/2 or 2/3).  Output n = q*L + r reads
+// table row ph_r = (r*M) % L at input position q*M + off_r, off_r = (r*M) / L: for a fixed residue r consecutive q shift
+// the window by M samples, so -- as in the down-sampler -- the input is split into M phases X_p[m] = X[m*M + p] and tap
+// j = i*M + p' of row ph_r meets X_{u % M}[q + i + u / M], u = off_r + p'.  Lane (tile, r, p') runs the shared tile FIR
+// with FT = filt_len / M taps over 8 consecutive q; u / M is 0 or 1, and a window must start on a 16-byte boundary, so
+// every phase array is staged twice, the second copy one float early.  The M shares of an output meet in LDS.
+struct RatioArgs {
+	const int16_t *in;
+	int16_t *out;
+	int32_t *out_len;
+	int16_t *hist;
+	const float *table; // [L][filt_len]
+	const uint8_t *run;
+	int in_len, in_stride, out_stride, hist_stride, nstreams;
+	int tiles; // ceil(periods / R), periods = in_len / M
+	int plen;  // floats per phase array copy (multiple of 4)
+	int lds_per_wave;
+};
+
+template <int L, int M, int FT, int R>
+__global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_ratio_kernel(RatioArgs a) {
+	extern __shared__ __attribute__((aligned(16))) char smem_all[];
+	char *smem = smem_all + (size_t)(threadIdx.x >> 6) * a.lds_per_wave;
+	constexpr int NT = FT * M, HIST = NT - 1, ROWS = L * M;
+	const int lane = threadIdx.x & 63;
+	const int periods = a.in_len / M, out_len = periods * L;
+	float *xp = reinterpret_cast<float *>(smem);                // [2][M][plen]: copy c holds X_p[m] at index m + c
+	float *part = xp + (size_t)2 * M * a.plen;                  // [tiles*R][L][M] partial sums
+	float4 *tab4 = reinterpret_cast<float4 *>(part + (size_t)a.tiles * R * ROWS); // [L*M][FT] taps per (r, p')
+	{
+		float *tab = reinterpret_cast<float *>(tab4);
+		for (int i = lane; i < ROWS * FT; i += 64) {
+			const int row = i / FT, k = i - row * FT, r = row / M, pp = row - r * M;
+			tab[i] = a.table[((r * M) % L) * NT + k * M + pp];
+		}
+	}
+	for (int i = lane; i < 2 * M * a.plen; i += 64) xp[i] = 0.f;
+	wave_sync();
+	const int hq = a.hist_stride >> 2, nq = hq + (a.in_len >> 2);
+	const int nlanes = ROWS * a.tiles;
+	const int nwaves = gridDim.x * UP_WAVES;
+	f2 t2[FT / 2];
+	for (int s = blockIdx.x * UP_WAVES + (threadIdx.x >> 6); s < a.nstreams; s += nwaves) {
+		if (a.run && !a.run[s]) {
+			if (lane == 0 && a.out_len) a.out_len[s] = 0;
+			continue;
+		}
+		const int16_t *hs = a.hist + (size_t)s * a.hist_stride, *xin = a.in + (size_t)s * a.in_stride;
+		short4 v[3];
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int q = lane + 64 * u;
+			v[u] = make_short4(0, 0, 0, 0);
+			if (q < nq) v[u] = *reinterpret_cast<const short4 *>(q < hq ? hs + 4 * q : xin + 4 * (q - hq));
+		}
+#pragma unroll
+		for (int u = 0; u < 3; ++u) {
+			const int q = lane + 64 * u;
+			if (q < nq) {
+				const int b = q < hq ? 4 * q : HIST + 4 * (q - hq);
+				const short e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int i = b + k;
+					if (q >= hq || i < HIST) {
+						const int ph = i % M, m = i / M;
+						const float f = (float)e[k];
+						xp[ph * a.plen + m] = f;                       // copy 0
+						if (m >= 1) xp[(M + ph) * a.plen + m - 1] = f; // copy 1: X_p[m] at m - 1, i.e. window start + 1
+					}
+				}
+			}
+		}
+		for (int base = 0; base < nlanes; base += 64) {
+			const int l = base + lane;
+			const bool on = l < nlanes;
+			const int tile = on ? l / ROWS : 0, row = on ? l - tile * ROWS : 0;
+			const int r = row / M, pp = row - r * M;
+			const int u = (r * M) / L + pp; // off_r + p'
+			{
+				const float4 *tp = tab4 + row * (FT / 4);
+#pragma unroll
+				for (int j = 0; j < FT / 4; ++j) {
+					const float4 w = tp[j];
+					t2[2 * j] = (f2){w.x, w.y}, t2[2 * j + 1] = (f2){w.z, w.w};
+				}
+			}
+			wave_sync();
+			f2 acc2[R / 2];
+#pragma unroll
+			for (int q = 0; q < R / 2; ++q) acc2[q] = (f2){0.f, 0.f};
+			fir_tile<FT, R>(xp + (size_t)((u / M) * M + (u % M)) * a.plen + tile * R, t2, acc2);
+			if (on) {
+				float *d = part + ((size_t)tile * R) * ROWS + row;
+#pragma unroll
+				for (int q = 0; q < R / 2; ++q) d[(2 * q) * ROWS] = acc2[q].x, d[(2 * q + 1) * ROWS] = acc2[q].y;
+			}
+		}
+		wave_sync();
+		// ---- output n = q*L + r = the sum over p' of part[q][r][p']: consecutive n are consecutive (q, r) pairs
+		int16_t *o = a.out + (size_t)s * a.out_stride;
+		for (int g = lane; g < (out_len >> 3); g += 64) {
+			const float *ps = part + (size_t)g * 8 * M;
+			short r16[8];
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				float sum = 0.f;
+#pragma unroll
+				for (int pq = 0; pq < M; ++pq) sum += ps[k * M + pq];
+				r16[k] = word2int(sum);
+			}
+			uint4 pk;
+			pk.x = (unsigned)(r16[0] & 0xffff) | ((unsigned)r16[1] << 16);
+			pk.y = (unsigned)(r16[2] & 0xffff) | ((unsigned)r16[3] << 16);
+			pk.z = (unsigned)(r16[4] & 0xffff) | ((unsigned)r16[5] << 16);
+			pk.w = (unsigned)(r16[6] & 0xffff) | ((unsigned)r16[7] << 16);
+			*reinterpret_cast<uint4 *>(o + 8 * g) = pk;
+		}
+		for (int q = lane; q < hq; q += 64) {
+			short4 h;
+			short *hp = &h.x;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int i = a.in_len + 4 * q + k;
+				hp[k] = (4 * q + k < HIST) ? (short)xp[(i % M) * a.plen + i / M] : (short)0;
+			}
+			*reinterpret_cast<short4 *>(a.hist + (size_t)s * a.hist_stride + 4 * q) = h;
+		}
+		if (lane == 0 && a.out_len) a.out_len[s] = out_len;
+		wave_sync();
+	}
+}
+
 struct GenArgs {
 	const int16_t *in;
 	int16_t *out;
@@ -654,6 +789,43 @@ static int launch_down(mi_resampler *r, const int16_t *d_in, int in_len, int in_
 	return MI_OK;
 }
 
+template <int L, int M, int FT, int R>
+static int launch_ratio(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out, int out_stride,
+                        int32_t *d_out_len, const uint8_t *d_run, bool *done) {
+	*done = false;
+	const int periods = in_len / M, out_len = periods * L;
+	const int nq = (r->hist_stride >> 2) + (in_len >> 2);
+	if ((in_len % M) != 0 || ((in_len | in_stride) & 3) != 0 || nq > 192 || ((out_len | out_stride) & 7) != 0 ||
+	    (reinterpret_cast<uintptr_t>(d_in) & 7) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15) != 0 || !r->phase_zero)
+		return MI_OK;
+	RatioArgs a;
+	a.in = d_in;
+	a.out = d_out;
+	a.out_len = d_out_len;
+	a.hist = r->d_hist;
+	a.table = r->d_table;
+	a.run = d_run;
+	a.in_len = in_len;
+	a.in_stride = in_stride;
+	a.out_stride = out_stride;
+	a.hist_stride = r->hist_stride;
+	a.nstreams = r->nstreams;
+	a.tiles = mi::ceil_div(periods, R);
+	const int xlen = FT * M - 1 + in_len;
+	a.plen = (mi::ceil_div(xlen, M) + R + 8 + 3) & ~3;
+	const size_t lds = ((size_t)2 * M * a.plen + (size_t)a.tiles * R * L * M + (size_t)L * M * FT) * sizeof(float);
+	if (lds > 30 * 1024) return MI_OK;
+	a.lds_per_wave = (int)((lds + 15) & ~(size_t)15);
+	const int max_waves = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * 16;
+	const int per_wave = mi::ceil_div(r->nstreams, max_waves);
+	const int nwaves = mi::ceil_div(r->nstreams, per_wave);
+	hipLaunchKernelGGL((resample_ratio_kernel<L, M, FT, R>), dim3(mi::ceil_div(nwaves, UP_WAVES)), dim3(64 * UP_WAVES),
+	                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	*done = true;
+	return MI_OK;
+}
+
 extern "C" {
 
 int mi_resampler_create(mi_ctx *ctx, int nstreams, uint32_t in_rate, uint32_t out_rate, int quality,
@@ -785,6 +957,15 @@ int mi_resampler_process_masked(mi_resampler *r, const int16_t *d_in, int in_len
 		if (rc != MI_OK) return rc;
 		if (done) return MI_OK;
 		// a block that is not a whole number of output periods leaves (last_sample, frac) off zero for good
+		if (in_len % (int)r->d.num) r->phase_zero = false;
+	}
+
+	if (r->d.direct && ((r->d.den == 3 && r->d.num == 2 && r->d.filt_len == 48) || (r->d.den == 2 && r->d.num == 3 && r->d.filt_len == 72))) {
+		bool done = false;
+		const int rc = (r->d.den == 3) ? launch_ratio<3, 2, 24, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done)
+		                               : launch_ratio<2, 3, 24, 8>(r, d_in, in_len, in_stride, d_out, out_stride, d_out_len, d_run, &done);
+		if (rc != MI_OK) return rc;
+		if (done) return MI_OK;
 		if (in_len % (int)r->d.num) r->phase_zero = false;
 	}
 

@@ -6,7 +6,7 @@ import mediastreamer2_amd as ms
 import bench
 ctx = ms.Context(0)
 n = 4096
-for (ir, orate) in ((48000, 16000), (48000, 8000), (16000, 8000), (44100, 48000), (8000, 48000), (16000, 48000), (8000, 16000), (32000, 48000)):
+for (ir, orate) in ((48000, 16000), (48000, 8000), (16000, 8000), (44100, 48000), (8000, 48000), (16000, 48000), (8000, 16000), (32000, 48000), (48000, 32000), (24000, 16000)):
     in_len = ir // 100
     rs = ms.ResamplerBatch(ctx, n, ir, orate)
     x = torch.from_numpy(bench.synth_pcm_batch(n, in_len, ir)).cuda()

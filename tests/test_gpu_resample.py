@@ -45,6 +45,10 @@ def _run_both(ctx, oracle, in_rate, out_rate, nstreams, in_len, nticks, sigma=30
     (48000, 8000, 480),    # integer down-sampling fast kernel, 6 input phases (288 taps)
     (32000, 8000, 320),    # 4 phases
     (48000, 24000, 480),   # 2 phases
+    (32000, 48000, 320),   # rational 3/2 kernel
+    (48000, 32000, 480),   # rational 2/3 kernel (72 taps)
+    (16000, 24000, 160),
+    (12000, 8000, 120),
 ])
 def test_resampler_matches_oracle(ctx, oracle, in_rate, out_rate, in_len):
     worst, rms = _run_both(ctx, oracle, in_rate, out_rate, nstreams=9, in_len=in_len, nticks=12)
