@@ -65,6 +65,12 @@ struct Design {
 	int int_advance = 0, frac_advance = 0, direct = 0;
 	float cutoff = 0;
 	std::vector<float> table;
+	// For the interpolated mode (filt_len*den > filt_len*oversample + 8, e.g. 44.1k <-> 48k): the library evaluates four
+	// partial sums against the oversampled table and blends them with cubic weights that depend only on the output's
+	// phase.  The same filter, blended ONCE per phase on the host: row ph = sum_k interp_k(ph) * table[.. + k].  The
+	// kernels then run it like a direct table (one FMA per tap instead of four); the result differs from the library's
+	// evaluation order by float rounding only (tolerance of the float path, tests hold it to 1 LSB / 1e-4 RMS).
+	std::vector<float> phase_table; // [den][filt_len], empty when the table is direct or too large to be worth it
 };
 
 uint32_t gcd_u32(uint32_t a, uint32_t b) {
@@ -116,6 +122,23 @@ bool design_filter(uint32_t in_rate, uint32_t out_rate, int quality, Design &d) 
 		d.table.resize((size_t)d.filt_len * d.oversample + 8);
 		for (int32_t k = -4; k < (int32_t)(d.oversample * d.filt_len + 4); k++)
 			d.table[k + 4] = windowed_sinc(d.cutoff, (k / (float)d.oversample - d.filt_len / 2), (int)d.filt_len);
+		if ((size_t)d.den * d.filt_len * sizeof(float) <= 256 * 1024) {
+			d.phase_table.resize((size_t)d.den * d.filt_len);
+			for (uint32_t ph = 0; ph < d.den; ++ph) {
+				const int offset = (int)(ph * d.oversample / d.den);
+				const float fr = ((float)((ph * d.oversample) % d.den)) / d.den;
+				// cubic_coef of the library, in its float arithmetic
+				const float i0 = -0.16667f * fr + 0.16667f * fr * fr * fr;
+				const float i1 = fr + 0.5f * fr * fr - 0.5f * fr * fr * fr;
+				const float i3 = -0.33333f * fr + 0.5f * fr * fr - 0.16667f * fr * fr * fr;
+				const float i2 = (float)(1. - i0 - i1 - i3);
+				for (uint32_t j = 0; j < d.filt_len; ++j) {
+					const float *tt = d.table.data() + 4 + (j + 1) * d.oversample - offset;
+					d.phase_table[(size_t)ph * d.filt_len + j] =
+					    (float)((double)i0 * tt[-2] + (double)i1 * tt[-1] + (double)i2 * tt[0] + (double)i3 * tt[1]);
+				}
+			}
+		}
 	}
 	return true;
 }
@@ -702,6 +725,9 @@ struct mi_resampler {
 	int2 *d_pos = nullptr;
 	float *d_table = nullptr;
 	bool phase_zero = true; // every stream's (last_sample, frac) is (0, 0): all blocks so far were whole output periods
+	// what the kernels read: the direct table, or the per-phase blend of the interpolated one
+	const std::vector<float> &dev_table() const { return d.phase_table.empty() ? d.table : d.phase_table; }
+	bool dev_direct() const { return d.direct || !d.phase_table.empty(); }
 };
 
 template <int DEN, int FILT, int R>
@@ -855,14 +881,14 @@ int mi_resampler_create(mi_ctx *ctx, int nstreams, uint32_t in_rate, uint32_t ou
 	const size_t hb = (size_t)nstreams * r->hist_stride * sizeof(int16_t);
 	if (hipMalloc((void **)&r->d_hist, hb) != hipSuccess ||
 	    hipMalloc((void **)&r->d_pos, (size_t)nstreams * sizeof(int2)) != hipSuccess ||
-	    hipMalloc((void **)&r->d_table, r->d.table.size() * sizeof(float)) != hipSuccess) {
+	    hipMalloc((void **)&r->d_table, r->dev_table().size() * sizeof(float)) != hipSuccess) {
 		mi::set_error("hipMalloc failed for resampler state");
 		mi_resampler_destroy(r);
 		return MI_ENOMEM;
 	}
 	if (hipMemsetAsync(r->d_hist, 0, hb, ctx->stream) != hipSuccess ||
 	    hipMemsetAsync(r->d_pos, 0, (size_t)nstreams * sizeof(int2), ctx->stream) != hipSuccess ||
-	    hipMemcpyAsync(r->d_table, r->d.table.data(), r->d.table.size() * sizeof(float), hipMemcpyHostToDevice,
+	    hipMemcpyAsync(r->d_table, r->dev_table().data(), r->dev_table().size() * sizeof(float), hipMemcpyHostToDevice,
 	                   ctx->stream) != hipSuccess ||
 	    hipStreamSynchronize(ctx->stream) != hipSuccess) {
 		mi::set_error("resampler state upload failed");
@@ -977,7 +1003,7 @@ int mi_resampler_process_masked(mi_resampler *r, const int16_t *d_in, int in_len
 	a.pos = r->d_pos;
 	a.table = r->d_table;
 	a.run = d_run;
-	a.table_len = (int)r->d.table.size();
+	a.table_len = (int)r->dev_table().size();
 	a.in_len = in_len;
 	a.in_stride = in_stride;
 	a.out_stride = out_stride;
@@ -988,7 +1014,7 @@ int mi_resampler_process_masked(mi_resampler *r, const int16_t *d_in, int in_len
 	a.num = (int)r->d.num;
 	a.den = (int)r->d.den;
 	a.oversample = (int)r->d.oversample;
-	a.direct = r->d.direct;
+	a.direct = r->dev_direct() ? 1 : 0;
 	const size_t xbytes = (size_t)((a.filt_len - 1 + in_len + 3) & ~3) * sizeof(float);
 	const size_t tbytes = (size_t)a.table_len * sizeof(float);
 	a.table_in_lds = (xbytes + tbytes <= 60 * 1024) ? 1 : 0;
