@@ -1082,79 +1082,87 @@ void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot 
 	s->slot = -1;
 }
 
-void mixer_dispatch_output(MSFilter *f, MixerState *s, MSQueue *inq, int active_input) { // audiomixer.c:219-240
-	for (int i = 0; i < f->desc->noutputs; i++) {
-		MSQueue *outq = f->outputs[i];
-		Channel *chan = &s->channels[i];
-		if (outq && chan->output_enabled && (active_input != i || s->conf_mode == 0)) {
-			mblk_t *m;
-			if (s->single_output) {
-				while ((m = ms_queue_get(inq)) != NULL) ms_queue_put(outq, m);
-				break;
-			} else {
-				for (m = peekq(&inq->q); m != &inq->q._q_stopper && m != NULL; m = m->b_next) ms_queue_put(outq, dupmsg(m));
-			}
+// ---- bypass: one contributor, nothing to sum (behaviour of audiomixer.c:219-286) -----------------------------------
+// A pin "contributes" while it has data queued or had some less than BYPASS_MODE_TIMEOUT ms ago.
+struct Contributors {
+	int count = 0;
+	int pin = -1; // the highest-numbered contributing pin (the one that forwards when count == 1)
+};
+
+Contributors mixer_census(MSFilter *f, MixerState *s) {
+	Contributors c;
+	const uint64_t now = f->ticker->time;
+	for (int pin = 0; pin < f->desc->ninputs; ++pin) {
+		if (!f->inputs[pin]) continue;
+		uint64_t &seen = s->channels[pin].last_activity;
+		bool contributes;
+		if (!ms_queue_empty(f->inputs[pin])) {
+			seen = now;
+			contributes = true;
+		} else if (seen == (uint64_t)-1) {
+			seen = now; // first look at a silent pin only starts its clock
+			contributes = false;
+		} else {
+			contributes = now - seen < BYPASS_MODE_TIMEOUT;
+		}
+		if (contributes) {
+			c.count++;
+			c.pin = pin;
 		}
 	}
-	ms_queue_flush(inq);
+	return c;
 }
 
-bool_t mixer_check_bypass(MSFilter *f, MixerState *s) { // audiomixer.c:244-286
-	int active_cnt = 0, active_input = -1;
-	MSQueue *activeq = NULL;
-	const uint64_t curtime = f->ticker->time;
-	for (int i = 0; i < f->desc->ninputs; i++) {
-		MSQueue *q = f->inputs[i];
-		if (!q) continue;
-		Channel *chan = &s->channels[i];
-		if (!ms_queue_empty(q)) {
-			chan->last_activity = curtime;
-			activeq = q;
-			active_cnt++;
-			active_input = i;
-		} else if (chan->last_activity == (uint64_t)-1) {
-			chan->last_activity = curtime;
-		} else if (curtime - chan->last_activity < BYPASS_MODE_TIMEOUT) {
-			activeq = q;
-			active_cnt++;
-			active_input = i;
+// The single contributor's blocks go to every enabled output except (in conference mode) its own pin: moved when
+// only one output is wired, referenced (dupmsg) otherwise.
+void mixer_forward(MSFilter *f, MixerState *s, int from_pin) {
+	MSQueue *src = f->inputs[from_pin];
+	for (int pin = 0; pin < f->desc->noutputs; ++pin) {
+		MSQueue *dst = f->outputs[pin];
+		if (!dst || !s->channels[pin].output_enabled) continue;
+		if (s->conf_mode != 0 && pin == from_pin) continue;
+		if (s->single_output) {
+			for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) ms_queue_put(dst, m);
+			break;
 		}
+		for (mblk_t *m = peekq(&src->q); m != NULL && m != &src->q._q_stopper; m = m->b_next) ms_queue_put(dst, dupmsg(m));
 	}
-	if (active_cnt == 1) {
-		if (!s->bypass_mode) {
-			s->bypass_mode = TRUE;
-			ms_message("MSAudioMixer [%p] is entering bypass mode.", (void *)f);
-		}
-		mixer_dispatch_output(f, s, activeq, active_input);
-		return TRUE;
-	} else if (active_cnt > 1) {
-		if (s->bypass_mode) {
-			s->bypass_mode = FALSE;
-			ms_message("MSAudioMixer [%p] is leaving bypass mode.", (void *)f);
-		}
+	ms_queue_flush(src);
+}
+
+// true = this tick is already dealt with (forwarded, or nobody contributes)
+bool_t mixer_check_bypass(MSFilter *f, MixerState *s) {
+	const Contributors c = mixer_census(f, s);
+	if (c.count > 1) {
+		if (s->bypass_mode) ms_message("MSAudioMixer [%p] is leaving bypass mode.", (void *)f);
+		s->bypass_mode = FALSE;
 		return FALSE;
+	}
+	if (c.count == 1) {
+		if (!s->bypass_mode) ms_message("MSAudioMixer [%p] is entering bypass mode.", (void *)f);
+		s->bypass_mode = TRUE;
+		mixer_forward(f, s, c.pin);
 	}
 	return TRUE;
 }
 
-int channel_flow_control(Channel *chan, int threshold, uint64_t time) { // audiomixer.c:92-111
-	int skip = 0;
-	if (chan->last_flow_control == (uint64_t)-1) {
-		chan->last_flow_control = time;
-		chan->min_fullness = -1;
-		return skip;
-	}
-	const int size = (int)ms_bufferizer_get_avail(&chan->bufferizer);
-	if (chan->min_fullness == -1 || size < chan->min_fullness) chan->min_fullness = size;
-	if (time - chan->last_flow_control >= 5000) {
+// ---- per-channel flow control (behaviour of audiomixer.c:92-111): every 5 s, if the bufferizer never dropped below
+// `threshold` bytes in that window, discard the standing excess down to half the threshold.  Returns the bytes dropped.
+int channel_flow_control(Channel *chan, int threshold, uint64_t now) {
+	const bool first_call = chan->last_flow_control == (uint64_t)-1;
+	int dropped = 0;
+	if (!first_call) {
+		const int level = (int)ms_bufferizer_get_avail(&chan->bufferizer);
+		if (chan->min_fullness == -1 || level < chan->min_fullness) chan->min_fullness = level;
+		if (now - chan->last_flow_control < 5000) return 0;
 		if (chan->min_fullness >= threshold) {
-			skip = chan->min_fullness - (threshold / 2);
-			ms_bufferizer_skip_bytes(&chan->bufferizer, skip);
+			dropped = chan->min_fullness - threshold / 2;
+			ms_bufferizer_skip_bytes(&chan->bufferizer, dropped);
 		}
-		chan->last_flow_control = time;
-		chan->min_fullness = -1;
 	}
-	return skip;
+	chan->last_flow_control = now; // a new observation window starts
+	chan->min_fullness = -1;
+	return dropped;
 }
 
 void MixerPool::emit(MSFilter *f, int slot) {

@@ -384,3 +384,60 @@ def test_two_ticker_threads_run_concurrently(host, oracle):
         assert len(got) == len(ref)
         assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
         S.ms_ticker_detach(tk, src)
+
+
+def test_mixer_bypass_and_contributor_timeout(host, oracle):
+    # audiomixer.c:244-286: with a single contributing pin the mixer forwards its blocks untouched, in the same tick,
+    # to the other outputs (not to its own in conference mode).  A linked pin counts as a contributor while it has data
+    # or had some -- or was first looked at (the reference's quirk, :257-259) -- less than 1000 ms ago; two
+    # contributors bring the mixed path back.
+    mx = host.create(MS_AUDIO_MIXER_ID)
+    assert host.call_int(mx, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(mx, SET_NCHANNELS, 1) == 0
+    assert host.call_int(mx, mid(MS_AUDIO_MIXER_ID, 2, 4), 1) == 0       # ENABLE_CONFERENCE_MODE
+    sa, sb, ka, kb = host.source(), host.source(), host.sink(), host.sink()
+    host.link(sa, 0, mx, 0)
+    host.link(sb, 0, mx, 1)
+    host.link(mx, 0, ka, 0)
+    host.link(mx, 1, kb, 0)
+    host.S.ms_ticker_attach(host.ticker, mx)
+    n = 160
+    a = synth_pcm(21, n * 160, rate=16000)
+    b = synth_pcm(22, n * 160, rate=16000, sigma=2000.0)
+    # phase 0: only A talks, but pin 1 was first looked at in tick 0 and so "contributes" for the first second: tick 0
+    # is a bypass tick (pin 1's clock only starts), ticks 1..100 take the mixed path (B hears A one tick later)
+    for t in range(101):
+        host.push(sa, a[t * n:(t + 1) * n])
+        host.step(1)
+    host.step(1)
+    gb = host.drain(kb)
+    np.testing.assert_array_equal(gb[:101 * n], a[:101 * n])
+    assert not host.drain(ka).any()
+    # phase 1: pin 1 timed out -> bypass: B's output gets A's block in the SAME tick, A's own output nothing
+    for t in range(101, 106):
+        before = host.S.ms2shim_sink_blocks(kb)
+        host.push(sa, a[t * n:(t + 1) * n])
+        host.step(1)
+        assert host.S.ms2shim_sink_blocks(kb) == before + 1
+    np.testing.assert_array_equal(host.drain(kb)[-5 * n:], a[101 * n:106 * n])
+    assert host.S.ms2shim_sink_size(ka) == 0
+    # phase 2: both talk -> the batch mixes (one tick later): each hears the other
+    for t in range(106, 116):
+        host.push(sa, a[t * n:(t + 1) * n])
+        host.push(sb, b[t * n:(t + 1) * n])
+    host.step(12)
+    ga, gb = host.drain(ka), host.drain(kb)
+    assert len(ga) == len(gb) and len(ga) >= 10 * n
+    np.testing.assert_array_equal(ga[:10 * n], b[106 * n:116 * n])      # sum - own
+    np.testing.assert_array_equal(gb[:10 * n], a[106 * n:116 * n])
+    assert not ga[10 * n:].any() and not gb[10 * n:].any()              # ALWAYS_STREAMOUT: silence once both ran dry
+    # phase 3: nobody talks for more than a second: no contributor, no output at all
+    host.step(110)
+    host.drain(ka), host.drain(kb)
+    before = host.S.ms2shim_sink_blocks(kb)
+    host.step(5)
+    assert host.S.ms2shim_sink_blocks(kb) == before
+    # A alone again -> bypass again, same tick
+    host.push(sa, a[120 * n:121 * n])
+    host.step(1)
+    np.testing.assert_array_equal(host.drain(kb), a[120 * n:121 * n])
+    host.S.ms_ticker_detach(host.ticker, mx)
