@@ -1481,13 +1481,57 @@ void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at deta
 }
 
 // inputs[0] far-end reference, inputs[1] mic; outputs[0] reference copy, outputs[1] cleaned mic (speexec.c:218-222)
-void ec_process(MSFilter *f) { // speexec.c:223-305
+// ---- the framing of speexec.c:223-305, in three steps ---------------------------------------------------------------
+// (1) far-end blocks: kept twice once the microphone has started -- in `delayed_ref` (what the canceller will be fed,
+//     behind the configured delay) and in the flow-controlled `ref` (what goes on to the speaker, frame by frame).
+void ec_take_far_end(MSFilter *f, SpeexECState *s) {
+	if (!f->inputs[0]) return;
+	if (!s->echostarted) {
+		ms_warning("Getting reference signal but no echo to synchronize on.");
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) {
+		ms_bufferizer_put(&s->delayed_ref, dupmsg(m));
+		flowbuf_put(&s->ref, m);
+	}
+}
+
+mblk_t *ec_block(size_t nbytes) {
+	mblk_t *m = allocb(nbytes, 0);
+	memset(m->b_wptr, 0, nbytes);
+	m->b_wptr += nbytes;
+	return m;
+}
+
+// (2) one speaker frame per microphone frame: from `ref` when the delay line holds more than the nominal delay plus a
+//     frame, otherwise a frame of silence that is ALSO appended to the delay line (the canceller then sees zeros too).
+void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
+	const size_t needed = (size_t)s->nominal_ref_samples * 2 + nbytes;
+	if (ms_bufferizer_get_avail(&s->delayed_ref) < needed) {
+		mblk_t *silence = ec_block(nbytes);
+		ms_bufferizer_put(&s->delayed_ref, silence);
+		ms_queue_put(f->outputs[0], dupmsg(silence));
+		if (!s->using_zeroes) ms_warning("Not enough ref samples, using zeroes");
+		s->using_zeroes = TRUE;
+		return;
+	}
+	if (s->using_zeroes) ms_message("Samples are back.");
+	s->using_zeroes = FALSE;
+	mblk_t *m = ec_block(nbytes);
+	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) {
+		ms_error("Should never happen");
+		abort();
+	}
+	ms_queue_put(f->outputs[0], m);
+}
+
+// (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
+void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	const int nbytes = s->framesize * 2;
-	mblk_t *refm;
-	if (s->bypass_mode) { // :229-237
-		while ((refm = ms_queue_get(f->inputs[0])) != NULL) ms_queue_put(f->outputs[0], refm);
-		while ((refm = ms_queue_get(f->inputs[1])) != NULL) ms_queue_put(f->outputs[1], refm);
+	if (s->bypass_mode) { // both pins straight through
+		for (int pin = 0; pin < 2; ++pin)
+			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
 		return;
 	}
 	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
@@ -1497,55 +1541,21 @@ void ec_process(MSFilter *f) { // speexec.c:223-305
 		ms_queue_flush(f->inputs[1]);
 		return;
 	}
-	const size_t c = (size_t)p->capacity, sl = (size_t)s->slot;
-	const int F = p->F;
-	if (f->inputs[0] != NULL) { // :239-250
-		if (s->echostarted) {
-			while ((refm = ms_queue_get(f->inputs[0])) != NULL) {
-				ms_bufferizer_put(&s->delayed_ref, dupmsg(refm));
-				flowbuf_put(&s->ref, refm);
-			}
-		} else {
-			ms_warning("Getting reference signal but no echo to synchronize on.");
-			ms_queue_flush(f->inputs[0]);
-		}
-	}
+	const size_t nbytes = (size_t)s->framesize * 2, cap = (size_t)p->capacity, slot = (size_t)s->slot;
+	ec_take_far_end(f, s);
 	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
-	while (p->staged[sl] < kMaxRounds && ms_bufferizer_get_avail(&s->echo) >= (size_t)nbytes) { // :256
-		int16_t *echo = p->h_mic + (p->staged[sl] * c + sl) * F;
-		int16_t *ref = p->h_ref + (p->staged[sl] * c + sl) * F;
-		ms_bufferizer_read(&s->echo, (uint8_t *)echo, (size_t)nbytes);
-		if (!s->echostarted) s->echostarted = TRUE;
-		if ((int)ms_bufferizer_get_avail(&s->delayed_ref) < ((s->nominal_ref_samples * 2) + nbytes)) {
-			refm = allocb((size_t)nbytes, 0); // not enough reference: inject silence (:261-272)
-			memset(refm->b_wptr, 0, (size_t)nbytes);
-			refm->b_wptr += nbytes;
-			ms_bufferizer_put(&s->delayed_ref, refm);
-			ms_queue_put(f->outputs[0], dupmsg(refm));
-			if (!s->using_zeroes) {
-				ms_warning("Not enough ref samples, using zeroes");
-				s->using_zeroes = TRUE;
-			}
-		} else {
-			if (s->using_zeroes) {
-				ms_message("Samples are back.");
-				s->using_zeroes = FALSE;
-			}
-			refm = allocb((size_t)nbytes, 0); // :279-284
-			if (ms_bufferizer_read(&s->ref.base, refm->b_wptr, (size_t)nbytes) == 0) {
-				ms_error("Should never happen");
-				abort();
-			}
-			refm->b_wptr += nbytes;
-			ms_queue_put(f->outputs[0], refm);
-		}
-		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)ref, (size_t)nbytes) == 0) { // :288
+	while (p->staged[slot] < kMaxRounds && ms_bufferizer_get_avail(&s->echo) >= nbytes) {
+		const size_t row = ((size_t)p->staged[slot] * cap + slot) * (size_t)p->F;
+		ms_bufferizer_read(&s->echo, (uint8_t *)(p->h_mic + row), nbytes);
+		s->echostarted = TRUE;
+		ec_emit_speaker_frame(f, s, nbytes);
+		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)(p->h_ref + row), nbytes) == 0) {
 			ms_error("Should never happen");
 			abort();
 		}
-		p->staged[sl]++;
+		p->staged[slot]++;
 	}
-	if (p->staged[sl]) request_flush(f);
+	if (p->staged[slot]) request_flush(f);
 }
 
 int ec_set_sr(MSFilter *f, void *arg) {
