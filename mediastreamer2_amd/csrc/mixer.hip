@@ -236,6 +236,56 @@ __global__ __launch_bounds__(256) void mixer_members_kernel(MixMArgs ma) {
 	}
 }
 
+
+// Any tick length (ticks of 44.1 kHz audio are 441 samples): one lane per sample, 2-byte accesses.  Same arithmetic as
+// mixer_kernel; only reached when nsamples is not a multiple of 4.
+template <int MODE>
+__global__ __launch_bounds__(256) void mixer_scalar_kernel(MixArgs a) {
+	const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+	if (g >= (long long)a.nconf * a.ns) return;
+	const int c = (int)(g / a.ns), i = (int)(g - (long long)c * a.ns);
+	if (a.run && !a.run[c]) return;
+	const int conf_mode = a.conf_modes ? a.conf_modes[c] : a.conf_mode;
+	const uint8_t *fl = a.flags + (size_t)c * a.mm;
+	auto contrib = [&](int m, bool &summed) -> int {
+		summed = false;
+		const int cm = c * a.mm + m;
+		const unsigned f = fl[m];
+		if (!(f & MI_MIX_LINKED) || (a.has_data && !a.has_data[cm])) return 0;
+		int v = a.in[(size_t)cm * a.ns + i];
+		if (f & MI_MIX_ACTIVE) {
+			const float gn = a.gain[cm];
+			if (gn != 1.0f) v = sat16((int)(gn * (float)v));
+			summed = true;
+		}
+		return v;
+	};
+	int sum = 0;
+	if (MODE == 2) {
+		sum = a.sum_in[(size_t)c * a.ns + i];
+	} else {
+		for (int m = 0; m < a.mm; ++m) {
+			bool summed;
+			const int v = contrib(m, summed);
+			if (summed) sum += v;
+		}
+	}
+	if (MODE == 1) {
+		a.sum_out[(size_t)c * a.ns + i] = sum;
+		return;
+	}
+	if (conf_mode == 0) {
+		a.out[(size_t)c * a.out_conf_stride + i] = (int16_t)sat16(sum);
+		return;
+	}
+	for (int m = 0; m < a.mm; ++m)
+		if (fl[m] & MI_MIX_OUTPUT) {
+			bool summed;
+			const int own = contrib(m, summed);
+			a.out[(size_t)(c * a.mm + m) * a.ns + i] = (int16_t)sat16(sum - (summed ? own : 0));
+		}
+}
+
 } // namespace
 
 struct mi_mixer {
@@ -264,6 +314,12 @@ static bool launch_members(mi_mixer *m, const MixArgs &a) {
 
 template <int MODE>
 static int launch_mixer(mi_mixer *m, MixArgs &a) {
+	if (a.ns % 4) {
+		const long long lanes = (long long)a.nconf * a.ns;
+		hipLaunchKernelGGL(mixer_scalar_kernel<MODE>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, m->ctx->stream, a);
+		MI_LAUNCH_CHECK();
+		return MI_OK;
+	}
 	if (MODE == 0 && launch_members(m, a)) {
 		MI_LAUNCH_CHECK();
 		return MI_OK;
@@ -303,11 +359,6 @@ int mi_mixer_create(mi_ctx *ctx, int nconf, int max_members, int nsamples, mi_mi
 	MI_CHECK_ARG(ctx && out && nconf > 0 && max_members > 0 && max_members <= MI_MIXER_MAX_CHANNELS);
 	MI_CHECK_ARG(nsamples > 0);
 	*out = nullptr;
-	if (nsamples % 4) {
-		mi::set_error("nsamples per tick must be a multiple of 4 (got %d); every rate*10ms the filter uses is",
-		              nsamples);
-		return MI_ENOTSUP;
-	}
 	if (ctx->activate() != MI_OK) return MI_ENODEV;
 	mi_mixer *m = new mi_mixer();
 	m->ctx = ctx;

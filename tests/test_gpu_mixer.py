@@ -18,7 +18,8 @@ def _oracle_conf(oracle, x, flags, gain, has, conf_mode):
     return out, s
 
 
-@pytest.mark.parametrize("nconf,mm,ns", [(3, 32, 480), (5, 4, 160), (2, 50, 480), (4, 9, 80), (1, 17, 320)])
+@pytest.mark.parametrize("nconf,mm,ns", [(3, 32, 480), (5, 4, 160), (2, 50, 480), (4, 9, 80), (1, 17, 320),
+                                         (3, 5, 441), (2, 12, 110)])  # 44.1 / 11.025 kHz ticks: not multiples of 4
 @pytest.mark.parametrize("conf_mode", [1, 0])
 def test_mixer_bit_exact(ctx, oracle, nconf, mm, ns, conf_mode):
     rng = np.random.default_rng(nconf * 1000 + mm)

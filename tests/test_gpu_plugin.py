@@ -441,3 +441,27 @@ def test_mixer_bypass_and_contributor_timeout(host, oracle):
     host.step(1)
     np.testing.assert_array_equal(host.drain(kb), a[120 * n:121 * n])
     host.S.ms_ticker_detach(host.ticker, mx)
+
+
+def test_mixer_graph_at_44100_hz(host, oracle):
+    # 10 ms of 44.1 kHz audio is 441 samples -- not a multiple of 4: the batch takes the any-length kernel, never aborts
+    mx = host.create(MS_AUDIO_MIXER_ID)
+    assert host.call_int(mx, SET_SAMPLE_RATE, 44100) == 0 and host.call_int(mx, SET_NCHANNELS, 1) == 0
+    assert host.call_int(mx, mid(MS_AUDIO_MIXER_ID, 2, 4), 1) == 0       # ENABLE_CONFERENCE_MODE
+    srcs = [host.source() for _ in range(3)]
+    snks = [host.sink() for _ in range(3)]
+    for i in range(3):
+        host.link(srcs[i], 0, mx, i)
+        host.link(mx, i, snks[i], 0)
+    host.S.ms_ticker_attach(host.ticker, mx)
+    n, nt = 441, 8
+    x = np.stack([synth_pcm(60 + i, n * nt, rate=44100) for i in range(3)])
+    for t in range(nt):
+        for i in range(3):
+            host.push(srcs[i], x[i, t * n:(t + 1) * n])
+    host.step(nt + 2)
+    for i in range(3):
+        got = host.drain(snks[i])
+        want = np.concatenate([oracle.mixer_tick(x[:, t * n:(t + 1) * n])[0][i] for t in range(nt)])
+        np.testing.assert_array_equal(got[:n * nt], want)
+    host.S.ms_ticker_detach(host.ticker, mx)
