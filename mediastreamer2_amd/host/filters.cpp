@@ -455,6 +455,7 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	int sample_rate, nsamples;
 	MSFilter *peer;
 	MSBufferizer *buffer;
+	MSBufferizer *spill; // light path: the part of an over-long block that did not fit this tick's rounds
 	Extremum min, max;
 	VolumePool *pool;
 	int slot;
@@ -469,6 +470,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->nsamples = 80;
 	d->peer = NULL;
 	d->buffer = ms_bufferizer_new();
+	d->spill = ms_bufferizer_new();
 	d->max.period = 1000;
 	d->min.period = 30000;
 	d->pool = nullptr;
@@ -483,6 +485,7 @@ void volume_uninit(MSFilter *f) {
 		d->pool->release(d->slot);
 	}
 	ms_bufferizer_destroy(d->buffer);
+	ms_bufferizer_destroy(d->spill);
 	delete d;
 }
 
@@ -564,17 +567,29 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 			p->h_n[p->staged[s] * c + s] = d->nsamples;
 			p->staged[s]++;
 		}
-	} else { // :505-512 light path: one chunk per mblk, whatever its size
-		while (p->staged[s] < kMaxRounds && (m = ms_queue_get(f->inputs[0])) != NULL) {
-			int n = (int)(msgdsize(m) / 2);
-			if (n > p->cap_samples) {
-				ms_warning("MSVolume[mi355x]: block of %d samples truncated to %d", n, p->cap_samples);
-				n = p->cap_samples;
+	} else { // :505-512 light path: one chunk per mblk.  A block longer than a batch row (20 ms and more than 960 samples)
+		// is cut into row-sized chunks -- no sample is dropped; the meter then sees those chunks, not the whole block.
+		for (;;) {
+			if (p->staged[s] >= kMaxRounds) break;
+			int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
+			int n = 0;
+			const size_t spilled = ms_bufferizer_get_avail(d->spill);
+			if (spilled) {
+				n = (int)std::min(spilled / 2, (size_t)p->cap_samples);
+				ms_bufferizer_read(d->spill, (uint8_t *)row, (size_t)n * 2);
+			} else if ((m = ms_queue_get(f->inputs[0])) != NULL) {
+				n = (int)(msgdsize(m) / 2);
+				if (n > p->cap_samples) {
+					ms_bufferizer_put(d->spill, m); // served chunk by chunk from the top of the loop
+					continue;
+				}
+				memcpy(row, m->b_rptr, (size_t)n * 2);
+				freemsg(m);
+			} else {
+				break;
 			}
-			memcpy(p->h_buf + (p->staged[s] * c + s) * p->cap_samples, m->b_rptr, (size_t)n * 2);
 			p->h_n[p->staged[s] * c + s] = n;
 			p->staged[s]++;
-			freemsg(m);
 		}
 	}
 	if (p->staged[s]) request_flush(f);
@@ -800,6 +815,7 @@ struct EqualizerData {
 	EqualizerPool *pool;
 	int slot;
 	std::vector<MSEqualizerGain> *pending; // gains since the last rate change, in call order
+	MSBufferizer *spill;                   // the part of an over-long block that did not fit this tick's rounds
 };
 
 // Gains set before the filter is attached to a ticker are kept in `pending` and replayed, in
@@ -838,6 +854,7 @@ void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
 	d->active = true;
 	d->slot = -1;
 	d->pending = new std::vector<MSEqualizerGain>();
+	d->spill = ms_bufferizer_new();
 	f->data = d;
 }
 void equalizer_preprocess(MSFilter *f) { equalizer_attach(f); }
@@ -848,6 +865,7 @@ void equalizer_uninit(MSFilter *f) {
 		d->pool->release(d->slot);
 	}
 	delete d->pending;
+	ms_bufferizer_destroy(d->spill);
 	ms_free(d);
 }
 void equalizer_process(MSFilter *f) { // equalizer.c:279-288
@@ -861,13 +879,29 @@ void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	}
 	EqualizerPool *p = d->pool;
 	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
-	while (p->staged[s] < kMaxRounds && (m = ms_queue_get(f->inputs[0])) != NULL) {
-		int n = (int)(msgdsize(m) / 2);
-		if (n > p->cap_samples) n = p->cap_samples;
-		memcpy(p->h_buf + (p->staged[s] * c + s) * p->cap_samples, m->b_rptr, (size_t)n * 2);
+	// one FIR block per mblk; a block longer than a batch row is cut into row-sized pieces (a streaming filter: the
+	// sample sequence does not depend on the blocking), nothing is dropped
+	for (;;) {
+		if (p->staged[s] >= kMaxRounds) break;
+		int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
+		int n = 0;
+		const size_t spilled = ms_bufferizer_get_avail(d->spill);
+		if (spilled) {
+			n = (int)std::min(spilled / 2, (size_t)p->cap_samples);
+			ms_bufferizer_read(d->spill, (uint8_t *)row, (size_t)n * 2);
+		} else if ((m = ms_queue_get(f->inputs[0])) != NULL) {
+			n = (int)(msgdsize(m) / 2);
+			if (n > p->cap_samples) {
+				ms_bufferizer_put(d->spill, m);
+				continue;
+			}
+			memcpy(row, m->b_rptr, (size_t)n * 2);
+			freemsg(m);
+		} else {
+			break;
+		}
 		p->h_n[p->staged[s] * c + s] = n;
 		p->staged[s]++;
-		freemsg(m);
 	}
 	if (p->staged[s]) request_flush(f);
 }

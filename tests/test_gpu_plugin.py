@@ -465,3 +465,44 @@ def test_mixer_graph_at_44100_hz(host, oracle):
         want = np.concatenate([oracle.mixer_tick(x[:, t * n:(t + 1) * n])[0][i] for t in range(nt)])
         np.testing.assert_array_equal(got[:n * nt], want)
     host.S.ms_ticker_detach(host.ticker, mx)
+
+
+def test_overlong_blocks_are_split_not_dropped(host, oracle):
+    # 60 ms blocks (2880 samples at 48 kHz, e.g. long codec frames) exceed a batch row: the facades cut them into
+    # row-sized pieces over as many rounds / ticks as it takes.  Equalizer: the FIR does not care about the blocking, so
+    # the samples equal the oracle fed the whole blocks.  Volume (static gain, light path): every sample comes out
+    # scaled, none is lost.
+    n, nb = 2880, 4
+    x = synth_pcm(77, n * nb, rate=48000, sigma=2500.0)
+    src, eq, snk = host.source(), host.create(MS_EQUALIZER_ID), host.sink()
+    assert host.call_int(eq, SET_SAMPLE_RATE, 48000) == 0
+    assert host.call(eq, mid(MS_EQUALIZER_ID, 0, 12), EqGain(2000.0, 1.5, 800.0)) == 0
+    host.link(src, 0, eq, 0)
+    host.link(eq, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    for b in range(nb):
+        host.push(src, x[b * n:(b + 1) * n])
+    host.step(nb + 3)
+    got = host.drain(snk)
+    o = oracle.Equalizer(48000)
+    o.set_gain(2000, 1.5, 800)
+    want = np.concatenate([o.run(x[b * n:(b + 1) * n]) for b in range(nb)])
+    np.testing.assert_array_equal(got, want)
+    host.S.ms_ticker_detach(host.ticker, src)
+
+    src, vol, snk = host.source(), host.create(MS_VOLUME_ID), host.sink()
+    assert host.call_int(vol, SET_SAMPLE_RATE, 48000) == 0
+    g = C.c_float(0.25)
+    assert host.call(vol, mid(MS_VOLUME_ID, 2, 4), g) == 0           # MS_VOLUME_SET_GAIN
+    host.link(src, 0, vol, 0)
+    host.link(vol, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, src)
+    for b in range(nb):
+        host.push(src, x[b * n:(b + 1) * n])
+    host.step(nb + 3)
+    got = host.drain(snk)
+    assert len(got) == n * nb
+    # gain 0.25 from the first chunk on (set_gain also sets the current gain): (s * 1024) / 4096 with C division
+    want = (np.abs(x.astype(np.int64)) * 1024 // 4096 * np.sign(x)).astype(np.int16)
+    np.testing.assert_array_equal(got, want)
+    host.S.ms_ticker_detach(host.ticker, src)
