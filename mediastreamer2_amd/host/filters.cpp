@@ -1762,13 +1762,14 @@ struct FramePool : Pool {
 	};
 	size_t src_bytes = 0, dst_bytes = 0, src_pitch = 0, dst_pitch = 0;
 	int out_w = 0, out_h = 0;
+	int frame_cap = 0; // frames per tick the staging holds (filters that may attach: `capacity`)
 	uint8_t *h_src = nullptr, *h_dst = nullptr, *d_src = nullptr, *d_dst = nullptr;
 	std::vector<Staged> staged, ready;
 	virtual int launch(int nframes) = 0;
 	void alloc_buffers() {
 		src_pitch = (src_bytes + 31) & ~(size_t)15; // slack for the kernels' 16-byte row loads
 		dst_pitch = (dst_bytes + 15) & ~(size_t)15;
-		const size_t c = (size_t)capacity;
+		const size_t c = (size_t)frame_cap;
 		h_src = pinned<uint8_t>(c * src_pitch);
 		h_dst = pinned<uint8_t>(c * dst_pitch);
 		d_src = devmem<uint8_t>(c * src_pitch + 32);
@@ -1776,8 +1777,8 @@ struct FramePool : Pool {
 	}
 	// next staging buffer, or NULL when `capacity` frames are already waiting for this tick's flush
 	uint8_t *stage(MSFilter *f, uint32_t ts) {
-		if ((int)staged.size() >= capacity) {
-			ms_error("msmi355x plugin: frame pool full (%d frames per tick; raise MSMI355X_SLOTS)", capacity);
+		if ((int)staged.size() >= frame_cap) {
+			ms_error("msmi355x plugin: frame pool full (%d frames per tick; raise MSMI355X_FRAME_SLOTS)", frame_cap);
 			return nullptr;
 		}
 		staged.push_back({f, ts});
@@ -1824,11 +1825,18 @@ void FramePool::emit(MSFilter *f, int slot) {
 	}
 }
 
+// frames per geometry and tick (MSMI355X_FRAME_SLOTS, default 32): a 1080p row is 3 MB of pinned memory
+int frame_slots() {
+	const char *e = getenv("MSMI355X_FRAME_SLOTS");
+	const int v = e ? atoi(e) : 0;
+	return v > 0 ? v : 32;
+}
+
 struct ScalerPool : FramePool {
 	mi_scaler *sc = nullptr;
-	ScalerPool(int sw, int sh, int dw, int dh) {
+	ScalerPool(mi_scaler *created, int dw, int dh) : sc(created) {
 		init_slots(g_hub.capacity);
-		MI_MUST(mi_scaler_create(g_hub.context(), sw, sh, dw, dh, MI_PIX_I420, &sc));
+		frame_cap = frame_slots();
 		src_bytes = mi_scaler_src_bytes(sc);
 		dst_bytes = mi_scaler_dst_bytes(sc);
 		out_w = dw, out_h = dh;
@@ -1840,9 +1848,9 @@ std::map<std::tuple<MSTicker *, int, int, int, int>, ScalerPool *> g_scaler_pool
 
 struct PixPool : FramePool {
 	mi_pixconv *pc = nullptr;
-	PixPool(int w, int h, int fmt, int flip) {
+	PixPool(mi_pixconv *created, int w, int h) : pc(created) {
 		init_slots(g_hub.capacity);
-		MI_MUST(mi_pixconv_create(g_hub.context(), w, h, fmt, flip, &pc));
+		frame_cap = frame_slots();
 		src_bytes = mi_pixconv_src_bytes(pc);
 		dst_bytes = mi_pixconv_dst_bytes(pc);
 		out_w = w, out_h = h;
@@ -1916,7 +1924,14 @@ ScalerPool *size_conv_pool(MSFilter *f, SizeConvState *s, int w, int h) {
 	auto key = std::make_tuple(f->ticker, w, h, s->target_vsize.width, s->target_vsize.height);
 	auto it = g_scaler_pools.find(key);
 	if (it == g_scaler_pools.end()) {
-		ScalerPool *p = new ScalerPool(w, h, s->target_vsize.width, s->target_vsize.height);
+		// a geometry the kernels cannot take is not fatal: the frame is dropped with an error, as a failing
+		// ms_scaler_process is in the reference (sizeconv.c:162-166)
+		mi_scaler *sc = nullptr;
+		if (mi_scaler_create(g_hub.context(), w, h, s->target_vsize.width, s->target_vsize.height, MI_PIX_I420, &sc) != MI_OK) {
+			ms_error("MSSizeConv: %dx%d -> %dx%d: %s", w, h, s->target_vsize.width, s->target_vsize.height, mi_last_error());
+			return nullptr;
+		}
+		ScalerPool *p = new ScalerPool(sc, s->target_vsize.width, s->target_vsize.height);
 		p->ticker = f->ticker;
 		g_hub.pools.push_back(p);
 		it = g_scaler_pools.emplace(key, p).first;
@@ -2107,7 +2122,13 @@ void pixconv_process(MSFilter *f) { // pixconv.c:62-94
 					auto key = std::make_tuple(f->ticker, inbuf.w, inbuf.h, (int)s->in_fmt);
 					auto it = g_pix_pools.find(key);
 					if (it == g_pix_pools.end()) {
-						PixPool *p = new PixPool(inbuf.w, inbuf.h, fmt, flip);
+						mi_pixconv *pc = nullptr;
+						if (mi_pixconv_create(g_hub.context(), inbuf.w, inbuf.h, fmt, flip, &pc) != MI_OK) {
+							ms_error("MSPixConv: %dx%d format %d: %s", inbuf.w, inbuf.h, (int)s->in_fmt, mi_last_error());
+							freemsg(im);
+							continue;
+						}
+						PixPool *p = new PixPool(pc, inbuf.w, inbuf.h);
 						p->ticker = f->ticker;
 						g_hub.pools.push_back(p);
 						it = g_pix_pools.emplace(key, p).first;
