@@ -1478,6 +1478,11 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	s->echostarted = FALSE;
 	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
 	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
+	if (s->filterlength > 64 * s->framesize) { // the kernels hold at most 64 filter blocks (341 ms at 48 kHz, 512 ms at 8/16 kHz)
+		ms_warning("mi355x echo canceller: tail of %d ms shortened to %d ms (64 blocks of %d samples)", s->tail_length_ms,
+		           64 * s->framesize * 1000 / s->samplerate, s->framesize);
+		s->filterlength = 64 * s->framesize;
+	}
 	const int delay_samples = s->delay_ms * s->samplerate / 1000;
 	ms_message("Initializing mi355x echo canceler with framesize=%i, filterlength=%i, delay_samples=%i", s->framesize,
 	           s->filterlength, delay_samples);
