@@ -1478,6 +1478,13 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	s->echostarted = FALSE;
 	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
 	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
+	if (s->framesize != 64 && s->framesize != 128 && s->framesize != 256) {
+		// e.g. 96 kHz would need 512-sample frames: audio keeps flowing uncancelled rather than the process dying
+		ms_error("mi355x echo canceller: frame size %d (rate %d) is not built; the filter forwards both pins untouched",
+		         s->framesize, s->samplerate);
+		s->bypass_mode = TRUE;
+		return;
+	}
 	if (s->filterlength > 64 * s->framesize) { // the kernels hold at most 64 filter blocks (341 ms at 48 kHz, 512 ms at 8/16 kHz)
 		ms_warning("mi355x echo canceller: tail of %d ms shortened to %d ms (64 blocks of %d samples)", s->tail_length_ms,
 		           64 * s->framesize * 1000 / s->samplerate, s->framesize);
