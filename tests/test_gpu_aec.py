@@ -87,7 +87,9 @@ def _run_pair(ctx, oracle, rate, F, tail_ms, nstreams, nframes, postfilter, scen
     return aec, ecs, mic, far, got, ref
 
 
-@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 128)])
+@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 128),
+                                          (16000, 128, 512),   # M = 64 blocks: the kernels' limit
+                                          (48000, 256, 341)])  # M = 64 at 48 kHz
 def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
     """First frames from zero state: outputs, W, foreground, X history and every control scalar
     equal the oracle's bit for bit (no tree-reduced quantity is in use yet)."""
@@ -109,7 +111,8 @@ def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
 
 @pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(48000, 256, 128, False), (48000, 256, 128, True),
                                                       (16000, 128, 128, True), (16000, 128, 250, False),
-                                                      (8000, 64, 250, True), (8000, 64, 128, False)])
+                                                      (8000, 64, 250, True), (8000, 64, 128, False),
+                                                      (16000, 128, 8, False)])   # M = 1: tail no longer than a frame
 def test_aec_two_seconds_within_tolerance(ctx, oracle, rate, F, tail_ms, postfilter):
     """2 s from zero state (BASELINE config 3 geometry at 48 kHz): RMS error <= 1e-4 of full scale,
     same adaptation decisions, and the canceller actually cancels (ERLE)."""
@@ -129,7 +132,8 @@ def test_aec_two_seconds_within_tolerance(ctx, oracle, rate, F, tail_ms, postfil
         pw = lambda v: np.mean(v[tail].astype(np.float64) ** 2) + 1e-9
         erle, erle_ref = 10 * np.log10(pw(mic[s]) / pw(got[s])), 10 * np.log10(pw(mic[s]) / pw(ref[s]))
         # the scene's near-end noise (sigma 300 vs ~1500 rms echo) caps the linear canceller at ~14 dB
-        assert erle > ((6.0 if not postfilter else 12.0) if need_adapted else 3.0), f"stream {s}: ERLE {erle:.1f} dB"
+        if tail_ms >= 32:  # a tail shorter than the scene's 20 ms echo delay cannot cancel it: parity only
+            assert erle > ((6.0 if not postfilter else 12.0) if need_adapted else 3.0), f"stream {s}: ERLE {erle:.1f} dB"
         assert abs(erle - erle_ref) < 0.1, f"stream {s}: ERLE {erle:.2f} dB vs oracle {erle_ref:.2f} dB"
     aec.close()
 
