@@ -29,6 +29,10 @@ SIZES = [
     (176, 144, 352, 288),
     (642, 362, 318, 182),      # sizes that are not multiples of 16/4
     (64, 64, 64, 64),          # identity
+    (3840, 2160, 1920, 1080),  # 4K source: the widest rows the strip kernel stages
+    (3840, 2160, 1280, 720),   # 3x down: source span per 256-pixel strip beyond the fast path -> generic kernel
+    (16, 16, 2, 2),            # smallest output
+    (1280, 720, 1920, 1080),   # 1.5x up
 ]
 
 
@@ -36,7 +40,7 @@ SIZES = [
 def test_scale_to_rgb24_bit_exact(ctx, oracle, sw, sh, dw, dh):
     sc = ms.ScalerBatch(ctx, sw, sh, dw, dh, ms.MI_PIX_RGB24)
     assert sc.src_bytes == oracle.i420_size(sw, sh)
-    nf = 3 if sw >= 1920 else 5
+    nf = 3 if sw >= 1280 else 5
     src = np.stack([synth_i420(i, sw, sh) for i in range(nf)])
     if nf > 2:
         src[1][:] = 0
