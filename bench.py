@@ -37,7 +37,7 @@ TICKS_PER_S = 100.0    # MSTicker interval 10 ms (src/base/msticker.c:46)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU (configs[1]: 4096)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
