@@ -306,6 +306,13 @@ int mi_session_submit(mi_session *s);
  * three more ticks have been submitted) */
 int mi_session_collect(mi_session *s, const int16_t **h_out);
 int mi_session_in_flight(const mi_session *s);
+/* conference control plane: per-stream mixer flags (MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT: mute = clear ACTIVE,
+ * MS_AUDIO_MIXER_SET_ACTIVE audiomixer.c:384-393; listen-only / no return = MS_AUDIO_MIXER_ENABLE_OUTPUT :404-414) and
+ * input gains (MS_AUDIO_MIXER_SET_INPUT_GAIN :372-382), either may be NULL; arrays of [nstreams].  Takes effect for the
+ * ticks submitted afterwards (waits for the ones in flight). */
+int mi_session_set_controls(mi_session *s, const uint8_t *h_flags, const float *h_gain);
+/* MS_VOLUME_GET_LINEAR of every stream (msvolume.c:129-134): what an active-speaker detector polls */
+int mi_session_get_levels(mi_session *s, float *h_linear);
 
 /* ------------------------------------------------------------- pixconv */
 /* Packed formats -> I420, what pixconv_process (src/videofilters/pixconv.c:62-94) obtains from

@@ -488,3 +488,13 @@ class Session(_Batch):
 
     def in_flight(self):
         return self.ctx.L.mi_session_in_flight(self.h)
+
+    def set_controls(self, flags=None, gain=None):
+        f = None if flags is None else np.ascontiguousarray(flags, np.uint8)
+        g = None if gain is None else np.ascontiguousarray(gain, np.float32)
+        check(self.ctx.L.mi_session_set_controls(self.h, _ptr(f), _ptr(g)))
+
+    def levels(self):
+        out = np.zeros(self.n, np.float32)
+        check(self.ctx.L.mi_session_get_levels(self.h, _ptr(out)))
+        return out

@@ -45,6 +45,7 @@ EXPORTS = [
     "mi_pixconv_process", "mi_pixconv_process_host",
     "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples",
     "mi_session_acquire", "mi_session_submit", "mi_session_collect", "mi_session_in_flight",
+    "mi_session_set_controls", "mi_session_get_levels",
     "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset",
 ]
 
@@ -200,6 +201,8 @@ def load():
         L.mi_session_submit.argtypes = [vp]
         L.mi_session_collect.argtypes = [vp, pp]
         L.mi_session_in_flight.argtypes = [vp]
+        L.mi_session_set_controls.argtypes = [vp, vp, vp]
+        L.mi_session_get_levels.argtypes = [vp, vp]
     if hasattr(L, "mi_fifo_create"):
         L.mi_fifo_create.argtypes = [vp, i32, i32, pp]
         L.mi_fifo_destroy.argtypes = [vp]

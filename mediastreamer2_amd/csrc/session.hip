@@ -262,4 +262,21 @@ int mi_session_collect(mi_session *s, const int16_t **h_out) {
 
 int mi_session_in_flight(const mi_session *s) { return s ? (int)(s->submitted - s->collected) : 0; }
 
+// ---- conference control plane (what MSAudioConference drives through the mixer's methods, src/voip/audioconference.c:
+// mute = MS_AUDIO_MIXER_SET_ACTIVE 0, listen-only = MS_AUDIO_MIXER_ENABLE_OUTPUT ..., per-member input gain) and the level
+// meter read-out (MS_VOLUME_GET_LINEAR) an active-speaker detector polls.  Both wait for the ticks already submitted.
+int mi_session_set_controls(mi_session *s, const uint8_t *h_flags, const float *h_gain) {
+	MI_CHECK_ARG(s && (h_flags || h_gain));
+	return mi_mixer_set_controls(s->mix, h_flags, h_gain); // [nconf][members] == [nstreams]
+}
+
+int mi_session_get_levels(mi_session *s, float *h_linear) {
+	MI_CHECK_ARG(s && h_linear);
+	std::vector<mi_volume_state> st((size_t)s->n);
+	const int rc = mi_volume_get_state(s->vol, 0, s->n, st.data());
+	if (rc != MI_OK) return rc;
+	for (int i = 0; i < s->n; ++i) h_linear[i] = st[(size_t)i].energy; // volume_get_linear msvolume.c:129-134
+	return MI_OK;
+}
+
 } // extern "C"

@@ -227,3 +227,44 @@ def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs):
         np.testing.assert_array_equal(got[t], want[t], err_msg=f"tick {t}")
     assert any(g.any() for g in got)
     se.close()
+
+
+def test_session_mute_and_levels(ctx):
+    # Conference control plane: muting a member (MS_AUDIO_MIXER_SET_ACTIVE 0) removes it from everybody's mix from
+    # the next submitted tick on; the level read-out follows MS_VOLUME_GET_LINEAR.
+    nconf, mm = 2, 8
+    n = nconf * mm
+    se = ms.Session(ctx, n, members=mm, in_rate=48000, rate=48000, agc=False)
+    rng = np.random.default_rng(3)
+    L, A, O = ms.MI_MIX_LINKED, ms.MI_MIX_ACTIVE, ms.MI_MIX_OUTPUT
+
+    def run(ticks):
+        outs = []
+        for _ in range(ticks):
+            m, r = se.acquire()
+            m[:] = tone
+            r[:] = 0                      # silent far end: the canceller passes the microphone through
+            se.submit()
+            outs.append(se.collect().copy())
+        return outs
+
+    # one loud talker per conference (member 3), everybody else silent
+    tone = np.zeros((n, 480), np.int16)
+    for c in range(nconf):
+        tone[c * mm + 3] = (8000 * np.sin(2 * np.pi * 440 * np.arange(480) / 48000)).astype(np.int16)
+    outs = run(12)
+    last = outs[-1].reshape(nconf, mm, 480)
+    for c in range(nconf):
+        assert np.abs(last[c, 0]).max() > 4000          # the others hear the talker
+        assert np.abs(last[c, 3]).max() < 50            # the talker does not hear itself (sum - own)
+    lv = se.levels().reshape(nconf, mm)
+    assert (lv[:, 3] > 10 * lv[:, 0]).all()             # the meter singles the talker out
+    # mute member 3 of conference 0 only
+    flags = np.full(n, L | A | O, np.uint8)
+    flags[3] = L | O
+    se.set_controls(flags=flags)
+    outs = run(6)
+    last = outs[-1].reshape(nconf, mm, 480)
+    assert np.abs(last[0, 0]).max() < 50                 # conference 0 went quiet
+    assert np.abs(last[1, 0]).max() > 4000               # conference 1 did not
+    se.close()
