@@ -276,6 +276,7 @@ int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok
 int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, in samples */
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_reset(mi_fifo *f);
+int mi_fifo_reset_range(mi_fifo *f, int first, int count); /* empty the FIFOs of streams [first, first+count) */
 
 /* ------------------------------------------------------------- session */
 /* The chained path of BASELINE.json's north_star for a batch of call legs, fed from host buffers, one 10 ms tick per
@@ -311,6 +312,9 @@ int mi_session_in_flight(const mi_session *s);
  * input gains (MS_AUDIO_MIXER_SET_INPUT_GAIN :372-382), either may be NULL; arrays of [nstreams].  Takes effect for the
  * ticks submitted afterwards (waits for the ones in flight). */
 int mi_session_set_controls(mi_session *s, const uint8_t *h_flags, const float *h_gain);
+/* a call leg was replaced: streams [first, first+count) start over (resampler history, canceller, meter, FIFOs) as
+ * newly created filters would; the other streams are untouched */
+int mi_session_reset_streams(mi_session *s, int first, int count);
 /* MS_VOLUME_GET_LINEAR of every stream (msvolume.c:129-134): what an active-speaker detector polls */
 int mi_session_get_levels(mi_session *s, float *h_linear);
 

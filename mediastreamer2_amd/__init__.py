@@ -494,6 +494,9 @@ class Session(_Batch):
         g = None if gain is None else np.ascontiguousarray(gain, np.float32)
         check(self.ctx.L.mi_session_set_controls(self.h, _ptr(f), _ptr(g)))
 
+    def reset_streams(self, first, count):
+        check(self.ctx.L.mi_session_reset_streams(self.h, first, count))
+
     def levels(self):
         out = np.zeros(self.n, np.float32)
         check(self.ctx.L.mi_session_get_levels(self.h, _ptr(out)))

@@ -45,8 +45,8 @@ EXPORTS = [
     "mi_pixconv_process", "mi_pixconv_process_host",
     "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples",
     "mi_session_acquire", "mi_session_submit", "mi_session_collect", "mi_session_in_flight",
-    "mi_session_set_controls", "mi_session_get_levels",
-    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset",
+    "mi_session_set_controls", "mi_session_get_levels", "mi_session_reset_streams",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
 ]
 
 
@@ -203,6 +203,7 @@ def load():
         L.mi_session_in_flight.argtypes = [vp]
         L.mi_session_set_controls.argtypes = [vp, vp, vp]
         L.mi_session_get_levels.argtypes = [vp, vp]
+        L.mi_session_reset_streams.argtypes = [vp, i32, i32]
     if hasattr(L, "mi_fifo_create"):
         L.mi_fifo_create.argtypes = [vp, i32, i32, pp]
         L.mi_fifo_destroy.argtypes = [vp]
@@ -213,6 +214,7 @@ def load():
         L.mi_fifo_levels.argtypes = [vp, vp]
         L.mi_fifo_overflows.argtypes = [vp, C.POINTER(i32)]
         L.mi_fifo_reset.argtypes = [vp]
+        L.mi_fifo_reset_range.argtypes = [vp, i32, i32]
     if hasattr(L, "mi_pixconv_create"):
         L.mi_pixconv_create.argtypes = [vp, i32, i32, i32, i32, pp]
         L.mi_pixconv_destroy.argtypes = [vp]

@@ -223,6 +223,13 @@ int mi_fifo_overflows(mi_fifo *f, int32_t *h_count) {
 	return MI_OK;
 }
 
+int mi_fifo_reset_range(mi_fifo *f, int first, int count) {
+	MI_CHECK_ARG(f && first >= 0 && count >= 0 && first + count <= f->nstreams);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	if (count) MI_HIP(hipMemsetAsync(f->d_pos + first, 0, (size_t)count * sizeof(int2), f->ctx->stream));
+	return MI_OK;
+}
+
 int mi_fifo_reset(mi_fifo *f) {
 	MI_CHECK_ARG(f != nullptr);
 	if (f->ctx->activate() != MI_OK) return MI_ENODEV;

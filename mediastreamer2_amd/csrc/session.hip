@@ -270,6 +270,26 @@ int mi_session_set_controls(mi_session *s, const uint8_t *h_flags, const float *
 	return mi_mixer_set_controls(s->mix, h_flags, h_gain); // [nconf][members] == [nstreams]
 }
 
+// A call leg leaves and another takes its place: every per-stream state of the chain goes back to its initial value
+// (what destroying and re-creating the leg's filters does in the reference), the other streams are not touched.
+int mi_session_reset_streams(mi_session *s, int first, int count) {
+	MI_CHECK_ARG(s && first >= 0 && count >= 0 && first + count <= s->n);
+	if (count == 0) return MI_OK;
+	int rc;
+	if (s->rs && (rc = mi_resampler_reset(s->rs, first, count)) != MI_OK) return rc;
+	if ((rc = mi_aec_reset(s->aec, first, count)) != MI_OK) return rc;
+	mi_volume_state st;
+	memset(&st, 0, sizeof(st));
+	st.gain = st.target_gain = 1; // volume_init msvolume.c:92
+	st.ng_gain = 1;               // :112
+	std::vector<mi_volume_state> all((size_t)count, st);
+	if ((rc = mi_volume_set_state(s->vol, first, count, all.data())) != MI_OK) return rc;
+	if ((rc = mi_fifo_reset_range(s->f_mic, first, count)) != MI_OK || (rc = mi_fifo_reset_range(s->f_ref, first, count)) != MI_OK ||
+	    (rc = mi_fifo_reset_range(s->f_out, first, count)) != MI_OK)
+		return rc;
+	return MI_OK;
+}
+
 int mi_session_get_levels(mi_session *s, float *h_linear) {
 	MI_CHECK_ARG(s && h_linear);
 	std::vector<mi_volume_state> st((size_t)s->n);

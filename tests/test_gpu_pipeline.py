@@ -268,3 +268,32 @@ def test_session_mute_and_levels(ctx):
     assert np.abs(last[0, 0]).max() < 50                 # conference 0 went quiet
     assert np.abs(last[1, 0]).max() > 4000               # conference 1 did not
     se.close()
+
+
+def test_session_reset_streams_starts_a_leg_over(ctx):
+    # A leg is replaced in its slot: after mi_session_reset_streams the slot behaves like a leg of a brand-new session
+    # (resampler history, canceller, meter and FIFO phase all back to their initial state), the others are untouched.
+    mm = 8
+    x = synth_pcm(5, 160 * 30, rate=16000, sigma=2500.0)
+    y = synth_pcm(6, 160 * 20, rate=16000, sigma=2500.0)
+
+    def feed(se, sig, t, slot=5):
+        m, r = se.acquire()
+        m[:] = 0
+        r[:] = 0
+        m[slot] = sig[t * 160:(t + 1) * 160]
+        se.submit()
+        return se.collect().copy()
+
+    a = ms.Session(ctx, mm, members=mm, agc=False)
+    for t in range(13):                      # 13 ticks of the first leg: odd FIFO phase, adapted state, history
+        feed(a, x, t)
+    a.reset_streams(5, 1)
+    got = [feed(a, y, t) for t in range(12)]
+    b = ms.Session(ctx, mm, members=mm, agc=False)
+    want = [feed(b, y, t) for t in range(12)]
+    for t in range(12):
+        np.testing.assert_array_equal(got[t], want[t], err_msg=f"tick {t}")
+    assert any(g[0].any() for g in got)       # member 0 does hear the new leg
+    a.close()
+    b.close()
