@@ -243,6 +243,31 @@ def make_pixconv_leg(ms, torch, ctx, nframes=64, fmt=None, w=1920, h=1080):
     return leg
 
 
+def make_g711_leg(ms, torch, ctx, nstreams=65536, n=480, law=None, encode=False):
+    """MSAlawDec / MSUlawDec (alaw.c:208-221) or the encoders' sample loop (alaw.c:77-82): one block of n samples per
+    stream per launch, 1 B of code word <-> 2 B of PCM per sample."""
+    law = ms.MI_LAW_PCMA if law is None else law
+    ring = 2
+    g = torch.Generator(device="cpu").manual_seed(11)
+    codes = [torch.randint(0, 256, (nstreams, n), dtype=torch.uint8, generator=g).cuda() for _ in range(ring)]
+    pcm = [torch.zeros((nstreams, n), dtype=torch.int16, device="cuda") for _ in range(ring)]
+    if encode:
+        for i in range(ring):
+            ms.g711_decode(ctx, law, codes[i], pcm[i])
+        ctx.sync()
+
+    def launch(i):
+        if encode:
+            ms.g711_encode(ctx, law, pcm[i], codes[i])
+        else:
+            ms.g711_decode(ctx, law, codes[i], pcm[i])
+
+    name = ("g711_encode_kernel<%d>" if encode else "g711_decode_kernel<%d>") % law
+    leg = Leg(ctx, name, launch, ring, nstreams * n * 3, nstreams, "stream-blocks (%d samples)" % n)
+    leg.keep = (codes, pcm)
+    return leg
+
+
 def make_aec_leg(ms, torch, ctx, nstreams=4096):
     """BASELINE configs[2] geometry: 48 kHz, 256-sample frames, 128 ms tail (M=24, N=512), post-filter on."""
     rate, F = 48000, 256

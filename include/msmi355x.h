@@ -278,6 +278,44 @@ int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_reset(mi_fifo *f);
 int mi_fifo_reset_range(mi_fifo *f, int first, int count); /* empty the FIFOs of streams [first, first+count) */
 
+/* ------------------------------------- codecs, channel adapter, flow control */
+/* The per-stream stages either side of the hot path in an AudioStream graph (src/voip/audiostream.c:1798-1832;
+ * SURVEY.md 8(f) rank 3).  Stateless conversions over `rows` rows of `len` samples; strides are in ELEMENTS of the
+ * respective type; d_len (nullable) holds a per-row sample count <= len, samples beyond it are left untouched.
+ * 16-byte aligned bases with codes_stride % 16 == 0 and pcm_stride % 8 == 0 take the vector path. */
+#define MI_LAW_PCMA 0 /* MSAlawDec / MSAlawEnc: src/audiofilters/alaw.c:208-221, :56-90; Snack_* g711.c:113-166 */
+#define MI_LAW_PCMU 1 /* MSUlawDec / MSUlawEnc: src/audiofilters/ulaw.c; Snack_* g711.c:200-255 */
+int mi_g711_decode(mi_ctx *ctx, int law, const uint8_t *d_codes, size_t codes_stride, int16_t *d_pcm, size_t pcm_stride,
+                   const int32_t *d_len, int len, size_t rows);
+int mi_g711_encode(mi_ctx *ctx, int law, const int16_t *d_pcm, size_t pcm_stride, uint8_t *d_codes, size_t codes_stride,
+                   const int32_t *d_len, int len, size_t rows);
+/* MSL16Enc / MSL16Dec sample loop (src/audiofilters/l16.c:58-70,:86,:196): byte order of every sample; in place allowed */
+int mi_l16_swap(mi_ctx *ctx, const int16_t *d_in, int16_t *d_out, size_t nsamples);
+/* MSChannelAdapter (src/audiofilters/chanadapt.c): frames = samples per channel */
+#define MI_CHAN_MONO_TO_STEREO 0     /* :110-113  d_out[2 * frames] */
+#define MI_CHAN_STEREO_TO_MONO 1     /* :118-121  keeps the left sample; d_a[2 * frames] -> d_out[frames] */
+#define MI_CHAN_TWO_MONO_TO_STEREO 2 /* :81-90    d_b nullable = that side is silent */
+int mi_chan_adapt(mi_ctx *ctx, int mode, const int16_t *d_a, const int16_t *d_b, int16_t *d_out, size_t frames);
+
+/* MSAudioFlowControl for a batch of streams: ms_audio_flow_controller_process (src/audiofilters/flowcontrol.c:107-152)
+ * with discard_well_choosed_samples (:56-89) and compute_frame_power (:97-105); state = MSAudioFlowController
+ * (include/mediastreamer2/flowcontrol.h:40-46) per stream on the device. */
+typedef struct mi_flowctl mi_flowctl;
+#define MI_FLOWCTL_BASIC 0 /* MSAudioFlowControlBasic */
+#define MI_FLOWCTL_SOFT 1  /* MSAudioFlowControlSoft (default, silent_threshold 0.02: flowcontrol.c:37-41) */
+int mi_flowctl_create(mi_ctx *ctx, int nstreams, int max_block /* samples, 3..2048 */, mi_flowctl **out);
+void mi_flowctl_destroy(mi_flowctl *f);
+int mi_flowctl_set_config(mi_flowctl *f, int first, int count, int strategy, float silent_threshold); /* MS_AUDIO_FLOW_CONTROL_SET_CONFIG */
+/* MS_AUDIO_FLOW_CONTROL_DROP (:209-219) for every stream with a non-zero request; ignored, like there, by streams
+ * that are still dropping.  Host arrays [nstreams], in samples (drop_ms * rate * nchannels / 1000). */
+int mi_flowctl_request_drop(mi_flowctl *f, const uint32_t *h_samples_to_drop, const uint32_t *h_total_samples);
+/* one block per stream (d_len[s] == 0: no block this round); d_out_len[s] = samples left, 0 = block dropped.
+ * d_out may be d_in. */
+int mi_flowctl_process(mi_flowctl *f, const int16_t *d_in, size_t in_stride, const int32_t *d_len, int len, int16_t *d_out,
+                       size_t out_stride, int32_t *d_out_len);
+int mi_flowctl_get_state(mi_flowctl *f, int stream, uint32_t out4[4]); /* target, total, pos, dropped */
+int mi_flowctl_reset(mi_flowctl *f, int first, int count);             /* ms_audio_flow_controller_reset :30-35 */
+
 /* ------------------------------------------------------------- session */
 /* The chained path of BASELINE.json's north_star for a batch of call legs, fed from host buffers, one 10 ms tick per
  * submit: MSResample in_rate->rate (msresample.c:122-179) -> FIFO -> MSSpeexEC + post-filter (speexec.c:223-305) ->

@@ -447,6 +447,68 @@ class FifoBatch(_Batch):
         check(self.ctx.L.mi_fifo_reset(self.h))
 
 
+MI_LAW_PCMA, MI_LAW_PCMU = 0, 1
+MI_CHAN_MONO_TO_STEREO, MI_CHAN_STEREO_TO_MONO, MI_CHAN_TWO_MONO_TO_STEREO = 0, 1, 2
+MI_FLOWCTL_BASIC, MI_FLOWCTL_SOFT = 0, 1
+
+
+def g711_decode(ctx, law, codes, pcm, length=None, lens=None):
+    """codes [rows, >=length] uint8 -> pcm [rows, >=length] int16, device tensors; lens [rows] int32 (device) or None."""
+    n = codes.shape[1] if length is None else length
+    check(ctx.L.mi_g711_decode(ctx.h, law, _ptr(codes), codes.stride(0), _ptr(pcm), pcm.stride(0), _ptr(lens), n, codes.shape[0]))
+    return pcm
+
+
+def g711_encode(ctx, law, pcm, codes, length=None, lens=None):
+    n = pcm.shape[1] if length is None else length
+    check(ctx.L.mi_g711_encode(ctx.h, law, _ptr(pcm), pcm.stride(0), _ptr(codes), codes.stride(0), _ptr(lens), n, pcm.shape[0]))
+    return codes
+
+
+def l16_swap(ctx, x, out):
+    check(ctx.L.mi_l16_swap(ctx.h, _ptr(x), _ptr(out), x.numel()))
+    return out
+
+
+def chan_adapt(ctx, mode, a, out, b=None):
+    frames = a.numel() // 2 if mode == MI_CHAN_STEREO_TO_MONO else a.numel()
+    check(ctx.L.mi_chan_adapt(ctx.h, mode, _ptr(a), _ptr(b), _ptr(out), frames))
+    return out
+
+
+class FlowControlBatch(_Batch):
+    """nstreams MSAudioFlowControllers (flowcontrol.c:30-152) with their state on the device."""
+    _destroy = "mi_flowctl_destroy"
+
+    def __init__(self, ctx, nstreams, max_block):
+        self.ctx, self.nstreams = ctx, nstreams
+        h = C.c_void_p()
+        check(ctx.L.mi_flowctl_create(ctx.h, nstreams, max_block, C.byref(h)))
+        self.h = h
+
+    def set_config(self, strategy, silent_threshold, first=0, count=None):
+        check(self.ctx.L.mi_flowctl_set_config(self.h, first, self.nstreams - first if count is None else count, strategy, silent_threshold))
+
+    def request_drop(self, samples_to_drop, total_samples):
+        d = np.ascontiguousarray(samples_to_drop, np.uint32)
+        t = np.ascontiguousarray(total_samples, np.uint32)
+        assert d.size == self.nstreams and t.size == self.nstreams
+        check(self.ctx.L.mi_flowctl_request_drop(self.h, d.ctypes.data, t.ctypes.data))
+
+    def process(self, x, out, out_len, length=None, lens=None):
+        n = x.shape[1] if length is None else length
+        check(self.ctx.L.mi_flowctl_process(self.h, _ptr(x), x.stride(0), _ptr(lens), n, _ptr(out), out.stride(0), _ptr(out_len)))
+        return out, out_len
+
+    def state(self, stream):
+        v = (C.c_uint32 * 4)()
+        check(self.ctx.L.mi_flowctl_get_state(self.h, stream, v))
+        return dict(target=v[0], total=v[1], pos=v[2], dropped=v[3])
+
+    def reset(self, first=0, count=None):
+        check(self.ctx.L.mi_flowctl_reset(self.h, first, self.nstreams - first if count is None else count))
+
+
 class SessionConfig(C.Structure):
     _fields_ = [("nstreams", C.c_int32), ("members_per_conference", C.c_int32), ("in_rate", C.c_int32),
                 ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32)]

@@ -46,6 +46,9 @@ EXPORTS = [
     "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples",
     "mi_session_acquire", "mi_session_submit", "mi_session_collect", "mi_session_in_flight",
     "mi_session_set_controls", "mi_session_get_levels", "mi_session_reset_streams",
+    "mi_g711_decode", "mi_g711_encode", "mi_l16_swap", "mi_chan_adapt",
+    "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
+    "mi_flowctl_get_state", "mi_flowctl_reset",
     "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
 ]
 
@@ -215,6 +218,19 @@ def load():
         L.mi_fifo_overflows.argtypes = [vp, C.POINTER(i32)]
         L.mi_fifo_reset.argtypes = [vp]
         L.mi_fifo_reset_range.argtypes = [vp, i32, i32]
+    if hasattr(L, "mi_g711_decode"):
+        L.mi_g711_decode.argtypes = [vp, i32, vp, sz, vp, sz, vp, i32, sz]
+        L.mi_g711_encode.argtypes = [vp, i32, vp, sz, vp, sz, vp, i32, sz]
+        L.mi_l16_swap.argtypes = [vp, vp, vp, sz]
+        L.mi_chan_adapt.argtypes = [vp, i32, vp, vp, vp, sz]
+        L.mi_flowctl_create.argtypes = [vp, i32, i32, pp]
+        L.mi_flowctl_destroy.argtypes = [vp]
+        L.mi_flowctl_destroy.restype = None
+        L.mi_flowctl_set_config.argtypes = [vp, i32, i32, i32, C.c_float]
+        L.mi_flowctl_request_drop.argtypes = [vp, vp, vp]
+        L.mi_flowctl_process.argtypes = [vp, vp, sz, vp, i32, vp, sz, vp]
+        L.mi_flowctl_get_state.argtypes = [vp, i32, C.POINTER(C.c_uint32)]
+        L.mi_flowctl_reset.argtypes = [vp, i32, i32]
     if hasattr(L, "mi_pixconv_create"):
         L.mi_pixconv_create.argtypes = [vp, i32, i32, i32, i32, pp]
         L.mi_pixconv_destroy.argtypes = [vp]

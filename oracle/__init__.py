@@ -7,6 +7,7 @@ from nowhere else; the product package never touches it.
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -22,7 +23,7 @@ def build(force=False):
         for f in os.listdir(_HERE)
         if f.endswith((".c", ".h"))
     ):
-        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True, stdout=sys.stderr)
     return so
 
 
@@ -314,3 +315,97 @@ def pixconv_to_i420(fmt, src, w, h, flip=False):
     if rc != 0:
         raise ValueError("orc_pixconv_to_i420 rejected the arguments")
     return dst
+
+
+# ---------------------------------------------------------------- codecs / adapters / flow control
+LAW_PCMA, LAW_PCMU = 0, 1
+
+
+def _declare_codecs(L):
+    i16p, u8p = C.POINTER(C.c_int16), C.POINTER(C.c_uint8)
+    L.orc_g711_encode.argtypes = [C.c_int, i16p, C.c_size_t, u8p]
+    L.orc_g711_decode.argtypes = [C.c_int, u8p, C.c_size_t, i16p]
+    L.orc_l16_swap.argtypes = [i16p, C.c_size_t, i16p]
+    L.orc_chan_adapt.argtypes = [C.c_int, i16p, i16p, C.c_size_t, i16p]
+    L.orc_flowctl_init.argtypes = [C.POINTER(OrcFlowCtl)]
+    L.orc_flowctl_set_target.argtypes = [C.POINTER(OrcFlowCtl), C.c_uint32, C.c_uint32]
+    L.orc_flowctl_process.argtypes = [C.POINTER(OrcFlowCtl), i16p, C.c_size_t]
+    L.orc_flowctl_process.restype = C.c_size_t
+    L._codecs_declared = True
+
+
+def _clib():
+    L = lib()
+    if not getattr(L, "_codecs_declared", False):
+        _declare_codecs(L)
+    return L
+
+
+def g711_encode(law, pcm):
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    out = np.empty(pcm.shape, np.uint8)
+    _clib().orc_g711_encode(law, _p(pcm, C.c_int16), pcm.size, _p(out, C.c_uint8))
+    return out
+
+
+def g711_decode(law, codes):
+    codes = np.ascontiguousarray(codes, np.uint8)
+    out = np.empty(codes.shape, np.int16)
+    _clib().orc_g711_decode(law, _p(codes, C.c_uint8), codes.size, _p(out, C.c_int16))
+    return out
+
+
+def l16_swap(x):
+    x = np.ascontiguousarray(x, np.int16)
+    out = np.empty_like(x)
+    _clib().orc_l16_swap(_p(x, C.c_int16), x.size, _p(out, C.c_int16))
+    return out
+
+
+def chan_adapt(mode, a, b=None):
+    """mode 0 mono->stereo, 1 stereo->mono (left kept), 2 two monos -> interleaved stereo (b None = silence)."""
+    a = np.ascontiguousarray(a, np.int16)
+    n = a.size // 2 if mode == 1 else a.size
+    out = np.empty(n if mode == 1 else 2 * n, np.int16)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.int16)
+        bp = _p(b, C.c_int16)
+    _clib().orc_chan_adapt(mode, _p(a, C.c_int16), bp, n, _p(out, C.c_int16))
+    return out
+
+
+class OrcFlowCtl(C.Structure):
+    _fields_ = [("strategy", C.c_int), ("silent_threshold", C.c_float), ("target_samples", C.c_uint32),
+                ("total_samples", C.c_uint32), ("current_pos", C.c_uint32), ("current_dropped", C.c_uint32)]
+
+
+class FlowCtl:
+    """MSAudioFlowController (flowcontrol.c:37-152): set_target() then process() block by block."""
+
+    def __init__(self, strategy=1, silent_threshold=0.02):
+        self.c = OrcFlowCtl()
+        _clib().orc_flowctl_init(C.byref(self.c))
+        self.c.strategy = strategy
+        self.c.silent_threshold = silent_threshold
+
+    def set_target(self, samples_to_drop, total_samples):
+        _clib().orc_flowctl_set_target(C.byref(self.c), samples_to_drop, total_samples)
+
+    def process(self, block):
+        x = np.array(block, dtype=np.int16, copy=True)
+        n = _clib().orc_flowctl_process(C.byref(self.c), _p(x, C.c_int16), x.size)
+        return x[:n]
+
+
+def g711_ref():
+    """The reference's own g711.c compiled by oracle/build_ref.sh, or None when it was never built."""
+    so = os.path.join(_HERE, "_ref", "libg711_ref.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    R.Snack_Lin2Alaw.argtypes = R.Snack_Lin2Mulaw.argtypes = [C.c_short]
+    R.Snack_Lin2Alaw.restype = R.Snack_Lin2Mulaw.restype = C.c_ubyte
+    R.Snack_Alaw2Lin.argtypes = R.Snack_Mulaw2Lin.argtypes = [C.c_ubyte]
+    R.Snack_Alaw2Lin.restype = R.Snack_Mulaw2Lin.restype = C.c_short
+    return R

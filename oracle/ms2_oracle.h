@@ -165,6 +165,28 @@ OrcPreproc *orc_preproc_new(int frame_size, int sample_rate, OrcEcho *echo);
 void orc_preproc_free(OrcPreproc *st);
 void orc_preproc_run(OrcPreproc *st, int16_t *x);
 
+/* ------------------------------------------- codecs / channel adapter / flow control */
+/* oracle/g711.c.  The four G.711 conversions ARE pinned: oracle/_ref/libg711_ref.so is the
+ * reference's own src/audiofilters/g711.c compiled unmodified (oracle/build_ref.sh). */
+uint8_t orc_lin2alaw(int16_t pcm);  /* Snack_Lin2Alaw  g711.c:113-141 */
+int16_t orc_alaw2lin(uint8_t code); /* Snack_Alaw2Lin  g711.c:147-166 */
+uint8_t orc_lin2ulaw(int16_t pcm);  /* Snack_Lin2Mulaw g711.c:200-231 */
+int16_t orc_ulaw2lin(uint8_t code); /* Snack_Mulaw2Lin g711.c:242-255 */
+void orc_g711_encode(int law, const int16_t *pcm, size_t n, uint8_t *codes); /* law 0 = PCMA, 1 = PCMU */
+void orc_g711_decode(int law, const uint8_t *codes, size_t n, int16_t *pcm);
+void orc_l16_swap(const int16_t *in, size_t n, int16_t *out); /* l16.c:58-70 */
+void orc_chan_adapt(int mode, const int16_t *a, const int16_t *b, size_t n, int16_t *out); /* chanadapt.c:87-121 */
+
+/* MSAudioFlowController, include/mediastreamer2/flowcontrol.h:30-46 */
+typedef struct OrcFlowCtl {
+	int strategy; /* 0 basic, 1 soft */
+	float silent_threshold;
+	uint32_t target_samples, total_samples, current_pos, current_dropped;
+} OrcFlowCtl;
+void orc_flowctl_init(OrcFlowCtl *c);
+void orc_flowctl_set_target(OrcFlowCtl *c, uint32_t samples_to_drop, uint32_t total_samples);
+size_t orc_flowctl_process(OrcFlowCtl *c, int16_t *samples, size_t n); /* flowcontrol.c:107-152 */
+
 #ifdef __cplusplus
 }
 #endif

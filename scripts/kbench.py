@@ -9,6 +9,9 @@ which = sys.argv[1:] or ["resample", "mixer", "volume", "equalizer", "aec", "sca
 mk = {"resample": lambda: bench.make_resample_leg(ms, torch, ctx, 4096), "mixer": lambda: bench.make_mixer_leg(ms, torch, ctx),
       "volume": lambda: bench.make_volume_leg(ms, torch, ctx), "equalizer": lambda: bench.make_equalizer_leg(ms, torch, ctx),
       "aec": lambda: bench.make_aec_leg(ms, torch, ctx), "scaler": lambda: bench.make_scaler_leg(ms, torch, ctx), "pixconv": lambda: bench.make_pixconv_leg(ms, torch, ctx),
+      "g711_dec": lambda: bench.make_g711_leg(ms, torch, ctx), "g711_enc": lambda: bench.make_g711_leg(ms, torch, ctx, encode=True),
+      "ulaw_dec": lambda: bench.make_g711_leg(ms, torch, ctx, law=ms.MI_LAW_PCMU), "ulaw_enc": lambda: bench.make_g711_leg(ms, torch, ctx, law=ms.MI_LAW_PCMU, encode=True),
+      "g711_dec_8k": lambda: bench.make_g711_leg(ms, torch, ctx, n=80),
       "pixconv_rgb": lambda: bench.make_pixconv_leg(ms, torch, ctx, fmt=ms.MI_PIX_BGR24)}
 for w in which:
     lg = mk[w]()
