@@ -122,6 +122,10 @@ typedef enum MSFilterId {
 	MS_FILTER_NOT_SET_ID = 0,
 	MS_FILTER_PLUGIN_ID = 1,
 	MS_FILTER_BASE_ID = 2,
+	MS_ULAW_ENC_ID = 7,
+	MS_ULAW_DEC_ID = 8,
+	MS_ALAW_ENC_ID = 9,
+	MS_ALAW_DEC_ID = 10,
 	MS_SPEEX_EC_ID = 28,
 	MS_PIX_CONV_ID = 29,
 	MS_SIZE_CONV_ID = 31,
@@ -130,14 +134,22 @@ typedef enum MSFilterId {
 	MS_VOID_SOURCE_ID = 56,
 	MS_VOID_SINK_ID = 57,
 	MS_EQUALIZER_ID = 61,
+	MS_CHANNEL_ADAPTER_ID = 67,
 	MS_AUDIO_MIXER_ID = 68,
-	MS_AUDIO_FLOW_CONTROL_ID = 90 /* only used to form the drop event id; value irrelevant in shim mode */
+	MS_L16_ENC_ID = 107,
+	MS_L16_DEC_ID = 108,
+	MS_AUDIO_FLOW_CONTROL_ID = 141
 } MSFilterId;
 
 /* msfilter.h:76-95 */
-enum { MSFilterInterfaceBegin = 16384, MSFilterEchoCancellerInterface = 16384 + 4 };
+enum {
+	MSFilterInterfaceBegin = 16384,
+	MSFilterEchoCancellerInterface = 16384 + 4,
+	MSFilterAudioDecoderInterface = 16384 + 7,
+	MSFilterAudioEncoderInterface = 16384 + 11
+};
 
-typedef enum _MSFilterCategory { MS_FILTER_OTHER = 0 } MSFilterCategory;
+typedef enum _MSFilterCategory { MS_FILTER_OTHER = 0, MS_FILTER_ENCODER = 1, MS_FILTER_DECODER = 2 } MSFilterCategory; /* msfilter.h:111-122 */
 enum _MSFilterFlags { MS_FILTER_IS_PUMP = 1, MS_FILTER_IS_HW_ACCELERATED = 1 << 1, MS_FILTER_IS_ENABLED = 1u << 31 };
 
 typedef void (*MSFilterFunc)(struct _MSFilter *f);                 /* msfilter.h:51 */
@@ -211,6 +223,14 @@ typedef struct _MSFactory MSFactory;
 #define MS_FILTER_GET_SAMPLE_RATE MS_FILTER_BASE_METHOD(1, int)
 #define MS_FILTER_GET_NCHANNELS MS_FILTER_BASE_METHOD(5, int)
 #define MS_FILTER_SET_NCHANNELS MS_FILTER_BASE_METHOD(6, int)
+#define MS_FILTER_ADD_FMTP MS_FILTER_BASE_METHOD(7, const char) /* msfilter.h:660 */
+#define MS_FILTER_ADD_ATTR MS_FILTER_BASE_METHOD(8, const char) /* msfilter.h:662 */
+#define MS_AUDIO_DECODER_HAVE_PLC MS_FILTER_METHOD(MSFilterAudioDecoderInterface, 0, int) /* msinterfaces.h:214-216 */
+#define MS_DECODER_HAVE_PLC MS_AUDIO_DECODER_HAVE_PLC
+#define MS_AUDIO_ENCODER_GET_PTIME MS_FILTER_METHOD(MSFilterAudioEncoderInterface, 1, int) /* msinterfaces.h:285 */
+#define MS_CHANNEL_ADAPTER_SET_OUTPUT_NCHANNELS MS_FILTER_METHOD(MS_CHANNEL_ADAPTER_ID, 0, int) /* mschanadapter.h:25-26 */
+#define MS_CHANNEL_ADAPTER_GET_OUTPUT_NCHANNELS MS_FILTER_METHOD(MS_CHANNEL_ADAPTER_ID, 1, int)
+#define MS_DEFAULT_MAX_PTIME 140 /* mscommon.h */
 #define MS_FILTER_SET_OUTPUT_SAMPLE_RATE MS_FILTER_BASE_METHOD(13, int)
 #define MS_FILTER_SET_OUTPUT_NCHANNELS MS_FILTER_BASE_METHOD(28, int)
 
@@ -279,6 +299,14 @@ typedef struct _MSAudioFlowControlDropEvent {
 	uint32_t drop_ms;
 } MSAudioFlowControlDropEvent;
 #define MS_AUDIO_FLOW_CONTROL_DROP_EVENT MS_FILTER_EVENT(MS_AUDIO_FLOW_CONTROL_ID, 0, MSAudioFlowControlDropEvent)
+/* flowcontrol.h:25-38, :75-80 */
+typedef enum _MSAudioFlowControlStrategy { MSAudioFlowControlBasic, MSAudioFlowControlSoft } MSAudioFlowControlStrategy;
+typedef struct _MSAudioFlowControlConfig {
+	MSAudioFlowControlStrategy strategy;
+	float silent_threshold;
+} MSAudioFlowControlConfig;
+#define MS_AUDIO_FLOW_CONTROL_SET_CONFIG MS_FILTER_METHOD(MS_AUDIO_FLOW_CONTROL_ID, 0, MSAudioFlowControlConfig)
+#define MS_AUDIO_FLOW_CONTROL_DROP MS_FILTER_METHOD(MS_AUDIO_FLOW_CONTROL_ID, 1, MSAudioFlowControlDropEvent)
 
 /* ---- video (include/mediastreamer2/msvideo.h) ---- */
 #define MS_VIDEO_SIZE_CIF_W 352 /* msvideo.h:39-40 */
@@ -397,6 +425,14 @@ extern MSFilterDesc ms_mi355x_equalizer_desc;   /* .id = MS_EQUALIZER_ID,   repl
 extern MSFilterDesc ms_mi355x_speex_ec_desc;    /* .id = MS_SPEEX_EC_ID,    replaces src/audiofilters/speexec.c:411-422 */
 extern MSFilterDesc ms_mi355x_size_conv_desc;   /* .id = MS_SIZE_CONV_ID,   replaces src/videofilters/sizeconv.c:221-247 */
 extern MSFilterDesc ms_mi355x_pix_conv_desc;    /* .id = MS_PIX_CONV_ID,    replaces src/videofilters/pixconv.c:112-138 */
+extern MSFilterDesc ms_mi355x_alaw_dec_desc;   /* .id = MS_ALAW_DEC_ID, replaces src/audiofilters/alaw.c:235-246 */
+extern MSFilterDesc ms_mi355x_ulaw_dec_desc;   /* .id = MS_ULAW_DEC_ID, replaces src/audiofilters/ulaw.c (same shape) */
+extern MSFilterDesc ms_mi355x_alaw_enc_desc;   /* .id = MS_ALAW_ENC_ID, replaces src/audiofilters/alaw.c:193-204 */
+extern MSFilterDesc ms_mi355x_ulaw_enc_desc;   /* .id = MS_ULAW_ENC_ID */
+extern MSFilterDesc ms_mi355x_l16_enc_desc;    /* .id = MS_L16_ENC_ID,  replaces src/audiofilters/l16.c:162-174 */
+extern MSFilterDesc ms_mi355x_l16_dec_desc;    /* .id = MS_L16_DEC_ID,  replaces src/audiofilters/l16.c:241-252 */
+extern MSFilterDesc ms_mi355x_channel_adapter_desc;    /* .id = MS_CHANNEL_ADAPTER_ID,    replaces src/audiofilters/chanadapt.c:190-203 */
+extern MSFilterDesc ms_mi355x_audio_flow_control_desc; /* .id = MS_AUDIO_FLOW_CONTROL_ID, replaces src/audiofilters/flowcontrol.c:262-277 */
 /* MSScalerDesc (msvideo.h:473-478) backed by the scaler / pixconv kernels; libmsmi355xfilters_init installs
  * it with ms_video_set_scaler_impl (msvideo.c:719-721), so the reference's OWN MSSizeConv / MSPixConv /
  * display filters reach the GPU too (one frame per call, synchronous, as that interface demands). */
