@@ -332,17 +332,28 @@ typedef struct mi_session_config {
 	int32_t tail_ms;                /* MS_ECHO_CANCELLER_SET_TAIL_LENGTH */
 	int32_t agc;                    /* MS_VOLUME_ENABLE_AGC */
 	int32_t use_graphs;             /* 1: replay a hipGraph per tick, 0: launch the kernels one by one */
+	/* the legs as a SIP trunk delivers them (all 0 = 16-bit PCM in, 16-bit PCM at `rate` out, reference from the host) */
+	int32_t mic_codec;    /* MI_SESSION_PCM16 | MI_SESSION_PCMA | MI_SESSION_PCMU: G.711 code words at in_rate (MSAlawDec / MSUlawDec) */
+	int32_t out_rate;     /* 0 = rate; else each leg's mix is resampled rate -> out_rate (MSResample) before it leaves */
+	int32_t out_codec;    /* as mic_codec: the output leaves as G.711 code words (MSAlawEnc / MSUlawEnc) */
+	int32_t ref_loopback; /* 1: a leg's far-end reference is the mix this session sent it on the previous tick: no upload */
+	int32_t ref_delay_ms; /* MS_ECHO_CANCELLER_SET_DELAY: the reference FIFO starts with this much silence (speexec.c:205-208) */
 } mi_session_config;
+#define MI_SESSION_PCM16 0
+#define MI_SESSION_PCMA 1
+#define MI_SESSION_PCMU 2
 void mi_session_default_config(mi_session_config *c);
 int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **out);
 void mi_session_destroy(mi_session *s);
 int mi_session_tick_samples(const mi_session *s, int *in_samples, int *out_samples);
-/* pinned staging of the NEXT tick, to be filled in place: mic [nstreams][in_rate/100], far-end reference
- * [nstreams][rate/100] */
+/* bytes per stream and tick of the three host buffers (mic, reference, output); the reference is 0 with ref_loopback */
+int mi_session_tick_bytes(const mi_session *s, int *mic_bytes, int *ref_bytes, int *out_bytes);
+/* pinned staging of the NEXT tick, to be filled in place: mic [nstreams][in_rate/100] int16 (or uint8 code words with
+ * mic_codec), far-end reference [nstreams][rate/100] int16 (*h_ref = NULL with ref_loopback) */
 int mi_session_acquire(mi_session *s, int16_t **h_mic, int16_t **h_ref);
 int mi_session_submit(mi_session *s);
-/* the OLDEST tick in flight: waits for its download, returns the pinned output [nstreams][rate/100] (valid until
- * three more ticks have been submitted) */
+/* the OLDEST tick in flight: waits for its download, returns the pinned output [nstreams][(out_rate or rate)/100]
+ * int16, or uint8 code words with out_codec (valid until three more ticks have been submitted) */
 int mi_session_collect(mi_session *s, const int16_t **h_out);
 int mi_session_in_flight(const mi_session *s);
 /* conference control plane: per-stream mixer flags (MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT: mute = clear ACTIVE,

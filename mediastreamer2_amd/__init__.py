@@ -511,42 +511,59 @@ class FlowControlBatch(_Batch):
 
 class SessionConfig(C.Structure):
     _fields_ = [("nstreams", C.c_int32), ("members_per_conference", C.c_int32), ("in_rate", C.c_int32),
-                ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32)]
+                ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32),
+                ("mic_codec", C.c_int32), ("out_rate", C.c_int32), ("out_codec", C.c_int32),
+                ("ref_loopback", C.c_int32), ("ref_delay_ms", C.c_int32)]
+
+
+MI_SESSION_PCM16, MI_SESSION_PCMA, MI_SESSION_PCMU = 0, 1, 2
 
 
 class Session(_Batch):
-    """mi_session: the chained path (resample -> AEC -> AGC -> conference mix) fed from host buffers, three ticks
-    in flight on three HIP streams."""
+    """mi_session: the chained path ([G.711 ->] resample -> AEC -> AGC -> conference mix [-> resample -> G.711]) fed
+    from host buffers, three ticks in flight on three HIP streams."""
     _destroy = "mi_session_destroy"
 
-    def __init__(self, ctx, nstreams, members=32, in_rate=16000, rate=48000, tail_ms=128, agc=True, use_graphs=True):
+    def __init__(self, ctx, nstreams, members=32, in_rate=16000, rate=48000, tail_ms=128, agc=True, use_graphs=True,
+                 mic_codec=0, out_rate=0, out_codec=0, ref_loopback=False, ref_delay_ms=0):
         self.ctx = ctx
         cfg = SessionConfig()
         ctx.L.mi_session_default_config(C.byref(cfg))
         cfg.nstreams, cfg.members_per_conference, cfg.in_rate, cfg.rate = nstreams, members, in_rate, rate
         cfg.tail_ms, cfg.agc, cfg.use_graphs = tail_ms, int(agc), int(use_graphs)
+        cfg.mic_codec, cfg.out_rate, cfg.out_codec = mic_codec, out_rate, out_codec
+        cfg.ref_loopback, cfg.ref_delay_ms = int(ref_loopback), ref_delay_ms
         h = C.c_void_p()
         check(ctx.L.mi_session_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
         self.n, self.in_len, self.len = nstreams, in_rate // 100, rate // 100
+        self.out_len = (out_rate or rate) // 100
+        self.mic_dtype = C.c_uint8 if mic_codec else C.c_int16
+        self.out_dtype = C.c_uint8 if out_codec else C.c_int16
+        self.loopback = bool(ref_loopback)
 
-    def _view(self, ptr, cols):
-        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(self.n, cols))
+    def _view(self, ptr, cols, ctype=C.c_int16):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(self.n, cols))
+
+    def tick_bytes(self):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.ctx.L.mi_session_tick_bytes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def acquire(self):
-        """numpy views of the pinned staging of the next tick: (mic [n, in_len], ref [n, len])."""
+        """numpy views of the pinned staging of the next tick: (mic [n, in_len], ref [n, len] or None with loopback)."""
         pm, pr = C.c_void_p(), C.c_void_p()
         check(self.ctx.L.mi_session_acquire(self.h, C.byref(pm), C.byref(pr)))
-        return self._view(pm, self.in_len), self._view(pr, self.len)
+        return self._view(pm, self.in_len, self.mic_dtype), (None if self.loopback else self._view(pr, self.len))
 
     def submit(self):
         check(self.ctx.L.mi_session_submit(self.h))
 
     def collect(self):
-        """numpy view of the oldest in-flight tick's output [n, len] (pinned; valid for three more submits)."""
+        """numpy view of the oldest in-flight tick's output [n, out_len] (pinned; valid for three more submits)."""
         po = C.c_void_p()
         check(self.ctx.L.mi_session_collect(self.h, C.byref(po)))
-        return self._view(po, self.len)
+        return self._view(po, self.out_len, self.out_dtype)
 
     def in_flight(self):
         return self.ctx.L.mi_session_in_flight(self.h)

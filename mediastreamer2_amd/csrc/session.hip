@@ -19,7 +19,11 @@ struct mi_session {
 	mi_ctx *ctx = nullptr;
 	mi_session_config cfg;
 	int n = 0, nconf = 0, in_len = 0, len = 0, frame = 0, up_stride = 0;
-	mi_resampler *rs = nullptr;
+	int out_len = 0, down_stride = 0;               // samples per tick leaving, row pitch of the down-sampled mix
+	size_t mic_bytes = 0, ref_bytes = 0, out_bytes = 0; // per stream and tick, on the host side
+	mi_resampler *rs = nullptr, *rs_out = nullptr;
+	int16_t *d_pcm = nullptr, *d_down = nullptr, *d_zero = nullptr;
+	int16_t *d_mix[SLOTS] = {}; // the mix at `rate` per slot when it is not what leaves (out_rate / out_codec / loopback)
 	mi_aec *aec = nullptr;
 	mi_volume *vol = nullptr;
 	mi_mixer *mix = nullptr;
@@ -40,13 +44,23 @@ namespace {
 
 int run_tick_kernels(mi_session *s, int slot) { // everything on the context's stream
 	int rc;
+	const mi_session_config &cf = s->cfg;
+	const int16_t *mic = s->d_mic[slot];
+	if (cf.mic_codec) { // MSAlawDec / MSUlawDec
+		if ((rc = mi_g711_decode(s->ctx, cf.mic_codec == MI_SESSION_PCMA ? MI_LAW_PCMA : MI_LAW_PCMU, (const uint8_t *)s->d_mic[slot],
+		                         (size_t)s->in_len, s->d_pcm, (size_t)s->in_len, nullptr, s->in_len, (size_t)s->n)) != MI_OK)
+			return rc;
+		mic = s->d_pcm;
+	}
 	if (s->rs) {
-		if ((rc = mi_resampler_process(s->rs, s->d_mic[slot], s->in_len, s->in_len, s->d_up, s->up_stride, nullptr)) != MI_OK) return rc;
+		if ((rc = mi_resampler_process(s->rs, mic, s->in_len, s->in_len, s->d_up, s->up_stride, nullptr)) != MI_OK) return rc;
 		if ((rc = mi_fifo_push(s->f_mic, s->d_up, s->len, s->up_stride, nullptr)) != MI_OK) return rc;
 	} else {
-		if ((rc = mi_fifo_push(s->f_mic, s->d_mic[slot], s->len, s->len, nullptr)) != MI_OK) return rc;
+		if ((rc = mi_fifo_push(s->f_mic, mic, s->len, s->len, nullptr)) != MI_OK) return rc;
 	}
-	if ((rc = mi_fifo_push(s->f_ref, s->d_ref[slot], s->len, s->len, nullptr)) != MI_OK) return rc;
+	// far end: from the host, or what this leg was sent one tick ago
+	const int16_t *ref = cf.ref_loopback ? s->d_mix[(slot + SLOTS - 1) % SLOTS] : s->d_ref[slot];
+	if ((rc = mi_fifo_push(s->f_ref, ref, s->len, s->len, nullptr)) != MI_OK) return rc;
 	const int rounds = (s->len + s->frame - 1) / s->frame; // frames a tick can complete (480 / 256 -> 2)
 	for (int r = 0; r < rounds; ++r) {
 		if ((rc = mi_fifo_pop(s->f_mic, s->frame, s->d_micf, s->frame, s->d_ok, nullptr, 0)) != MI_OK) return rc;
@@ -56,7 +70,22 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 	}
 	if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
 	if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
-	return mi_mixer_process(s->mix, s->d_tick, nullptr, 1, s->d_out[slot]);
+	int16_t *mix = s->d_mix[slot] ? s->d_mix[slot] : s->d_out[slot];
+	if ((rc = mi_mixer_process(s->mix, s->d_tick, nullptr, 1, mix)) != MI_OK) return rc;
+	const int16_t *leaving = mix;
+	int pitch = s->len;
+	if (s->rs_out) { // MSResample rate -> out_rate
+		if ((rc = mi_resampler_process(s->rs_out, mix, s->len, s->len, s->d_down, s->down_stride, nullptr)) != MI_OK) return rc;
+		leaving = s->d_down;
+		pitch = s->down_stride;
+	}
+	if (cf.out_codec) // MSAlawEnc / MSUlawEnc
+		return mi_g711_encode(s->ctx, cf.out_codec == MI_SESSION_PCMA ? MI_LAW_PCMA : MI_LAW_PCMU, leaving, (size_t)pitch,
+		                      (uint8_t *)s->d_out[slot], (size_t)s->out_len, nullptr, s->out_len, (size_t)s->n);
+	if (leaving != s->d_out[slot]) // 16-bit output that went through the down-sampler (or a kept mix): pack the rows
+		MI_HIP(hipMemcpy2DAsync(s->d_out[slot], (size_t)s->out_len * 2, leaving, (size_t)pitch * 2, (size_t)s->out_len * 2, (size_t)s->n,
+		                        hipMemcpyDeviceToDevice, s->ctx->stream));
+	return MI_OK;
 }
 
 } // namespace
@@ -90,14 +119,16 @@ void mi_session_destroy(mi_session *s) {
 		if (s->d_mic[i]) mi_dev_free(c, s->d_mic[i]);
 		if (s->d_ref[i]) mi_dev_free(c, s->d_ref[i]);
 		if (s->d_out[i]) mi_dev_free(c, s->d_out[i]);
+		if (s->d_mix[i]) mi_dev_free(c, s->d_mix[i]);
 		if (s->ev_up[i]) (void)hipEventDestroy(s->ev_up[i]);
 		if (s->ev_done[i]) (void)hipEventDestroy(s->ev_done[i]);
 		if (s->ev_down[i]) (void)hipEventDestroy(s->ev_down[i]);
 	}
-	void *dv[] = {s->d_up, s->d_micf, s->d_reff, s->d_clean, s->d_tick, s->d_ok};
+	void *dv[] = {s->d_up, s->d_micf, s->d_reff, s->d_clean, s->d_tick, s->d_ok, s->d_pcm, s->d_down, s->d_zero};
 	for (void *p : dv)
 		if (p) mi_dev_free(c, p);
 	if (s->rs) mi_resampler_destroy(s->rs);
+	if (s->rs_out) mi_resampler_destroy(s->rs_out);
 	if (s->aec) mi_aec_destroy(s->aec);
 	if (s->vol) mi_volume_destroy(s->vol);
 	if (s->mix) mi_mixer_destroy(s->mix);
@@ -114,6 +145,9 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	*out = nullptr;
 	MI_CHECK_ARG(cfg->nstreams > 0 && cfg->members_per_conference > 0 && cfg->nstreams % cfg->members_per_conference == 0);
 	MI_CHECK_ARG(cfg->rate > 0 && cfg->in_rate > 0 && cfg->rate % 100 == 0 && cfg->in_rate % 100 == 0 && cfg->tail_ms > 0);
+	MI_CHECK_ARG(cfg->mic_codec >= MI_SESSION_PCM16 && cfg->mic_codec <= MI_SESSION_PCMU && cfg->out_codec >= MI_SESSION_PCM16 &&
+	             cfg->out_codec <= MI_SESSION_PCMU);
+	MI_CHECK_ARG(cfg->out_rate >= 0 && cfg->out_rate % 100 == 0 && cfg->ref_delay_ms >= 0 && cfg->ref_delay_ms <= 1000);
 	if (ctx->activate() != MI_OK) return MI_ENODEV;
 	mi_session *s = new mi_session();
 	s->ctx = ctx;
@@ -122,6 +156,11 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	s->nconf = cfg->nstreams / cfg->members_per_conference;
 	s->in_len = cfg->in_rate / 100;
 	s->len = cfg->rate / 100;
+	const bool down = cfg->out_rate != 0 && cfg->out_rate != cfg->rate;
+	s->out_len = (down ? cfg->out_rate : cfg->rate) / 100;
+	s->mic_bytes = (size_t)s->in_len * (cfg->mic_codec ? 1 : 2);
+	s->ref_bytes = cfg->ref_loopback ? 0 : (size_t)s->len * 2;
+	s->out_bytes = (size_t)s->out_len * (cfg->out_codec ? 1 : 2);
 	s->frame = mi_aec_framesize(64, cfg->rate); // speexec.c:41,171-180
 	int rc = MI_OK;
 	auto fail = [&](int code) {
@@ -131,6 +170,10 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	if (cfg->in_rate != cfg->rate) {
 		if ((rc = mi_resampler_create(ctx, s->n, (uint32_t)cfg->in_rate, (uint32_t)cfg->rate, 3, &s->rs)) != MI_OK) return fail(rc);
 		s->up_stride = (mi_resampler_out_capacity(s->rs, s->in_len) + 7) & ~7;
+	}
+	if (down) {
+		if ((rc = mi_resampler_create(ctx, s->n, (uint32_t)cfg->rate, (uint32_t)cfg->out_rate, 3, &s->rs_out)) != MI_OK) return fail(rc);
+		s->down_stride = (mi_resampler_out_capacity(s->rs_out, s->len) + 7) & ~7;
 	}
 	if ((rc = mi_aec_create(ctx, s->n, cfg->rate, s->frame, cfg->tail_ms * cfg->rate / 1000, &s->aec)) != MI_OK) return fail(rc);
 	if ((rc = mi_volume_create(ctx, s->n, cfg->rate, &s->vol)) != MI_OK) return fail(rc);
@@ -143,7 +186,9 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	}
 	if ((rc = mi_mixer_create(ctx, s->nconf, cfg->members_per_conference, s->len, &s->mix)) != MI_OK) return fail(rc);
 	const int cap = ((2 * s->len + 2 * s->frame) + 7) & ~7;
-	if ((rc = mi_fifo_create(ctx, s->n, cap, &s->f_mic)) != MI_OK || (rc = mi_fifo_create(ctx, s->n, cap, &s->f_ref)) != MI_OK ||
+	const int delay = cfg->ref_delay_ms * cfg->rate / 1000;
+	const int ref_cap = (cap + delay + 7) & ~7;
+	if ((rc = mi_fifo_create(ctx, s->n, cap, &s->f_mic)) != MI_OK || (rc = mi_fifo_create(ctx, s->n, ref_cap, &s->f_ref)) != MI_OK ||
 	    (rc = mi_fifo_create(ctx, s->n, cap, &s->f_out)) != MI_OK)
 		return fail(rc);
 	if (hipStreamCreateWithFlags(&s->s_up, hipStreamNonBlocking) != hipSuccess ||
@@ -153,13 +198,21 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	}
 	const size_t n = (size_t)s->n;
 	for (int i = 0; i < SLOTS; ++i) {
-		s->h_mic[i] = (int16_t *)mi_host_alloc(ctx, n * s->in_len * 2);
-		s->h_ref[i] = (int16_t *)mi_host_alloc(ctx, n * s->len * 2);
-		s->h_out[i] = (int16_t *)mi_host_alloc(ctx, n * s->len * 2);
-		s->d_mic[i] = (int16_t *)mi_dev_alloc(ctx, n * s->in_len * 2);
-		s->d_ref[i] = (int16_t *)mi_dev_alloc(ctx, n * s->len * 2);
-		s->d_out[i] = (int16_t *)mi_dev_alloc(ctx, n * s->len * 2);
-		if (!s->h_mic[i] || !s->h_ref[i] || !s->h_out[i] || !s->d_mic[i] || !s->d_ref[i] || !s->d_out[i]) return fail(MI_ENOMEM);
+		s->h_mic[i] = (int16_t *)mi_host_alloc(ctx, n * s->mic_bytes);
+		s->h_out[i] = (int16_t *)mi_host_alloc(ctx, n * s->out_bytes);
+		s->d_mic[i] = (int16_t *)mi_dev_alloc(ctx, n * s->mic_bytes);
+		s->d_out[i] = (int16_t *)mi_dev_alloc(ctx, n * s->out_bytes);
+		if (!s->h_mic[i] || !s->h_out[i] || !s->d_mic[i] || !s->d_out[i]) return fail(MI_ENOMEM);
+		if (!cfg->ref_loopback) {
+			s->h_ref[i] = (int16_t *)mi_host_alloc(ctx, n * s->ref_bytes);
+			s->d_ref[i] = (int16_t *)mi_dev_alloc(ctx, n * s->ref_bytes);
+			if (!s->h_ref[i] || !s->d_ref[i]) return fail(MI_ENOMEM);
+		}
+		if (cfg->ref_loopback || down || cfg->out_codec) { // the mix at `rate` is kept: next tick's reference and / or the encoder's input
+			s->d_mix[i] = (int16_t *)mi_dev_alloc(ctx, n * s->len * 2);
+			if (!s->d_mix[i]) return fail(MI_ENOMEM);
+			MI_HIP(hipMemsetAsync(s->d_mix[i], 0, n * s->len * 2, ctx->stream));
+		}
 		if (hipEventCreateWithFlags(&s->ev_up[i], hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_done[i], hipEventDisableTiming) != hipSuccess ||
 		    hipEventCreateWithFlags(&s->ev_down[i], hipEventDisableTiming) != hipSuccess) {
@@ -174,6 +227,13 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	s->d_tick = (int16_t *)mi_dev_alloc(ctx, n * s->len * 2);
 	s->d_ok = (uint8_t *)mi_dev_alloc(ctx, n);
 	if ((s->rs && !s->d_up) || !s->d_micf || !s->d_reff || !s->d_clean || !s->d_tick || !s->d_ok) return fail(MI_ENOMEM);
+	if (cfg->mic_codec && !(s->d_pcm = (int16_t *)mi_dev_alloc(ctx, n * s->in_len * 2))) return fail(MI_ENOMEM);
+	if (s->rs_out && !(s->d_down = (int16_t *)mi_dev_alloc(ctx, n * s->down_stride * 2))) return fail(MI_ENOMEM);
+	if (delay > 0) { // speexec.c:205-208: delay_ms of silence ahead of the reference
+		if (!(s->d_zero = (int16_t *)mi_dev_alloc(ctx, n * (size_t)delay * 2))) return fail(MI_ENOMEM);
+		MI_HIP(hipMemsetAsync(s->d_zero, 0, n * (size_t)delay * 2, ctx->stream));
+		if ((rc = mi_fifo_push(s->f_ref, s->d_zero, delay, delay, nullptr)) != MI_OK) return fail(rc);
+	}
 	MI_HIP(hipStreamSynchronize(ctx->stream));
 	*out = s;
 	return MI_OK;
@@ -183,6 +243,14 @@ int mi_session_tick_samples(const mi_session *s, int *in_samples, int *out_sampl
 	MI_CHECK_ARG(s != nullptr);
 	if (in_samples) *in_samples = s->in_len;
 	if (out_samples) *out_samples = s->len;
+	return MI_OK;
+}
+
+int mi_session_tick_bytes(const mi_session *s, int *mic_bytes, int *ref_bytes, int *out_bytes) {
+	MI_CHECK_ARG(s != nullptr);
+	if (mic_bytes) *mic_bytes = (int)s->mic_bytes;
+	if (ref_bytes) *ref_bytes = (int)s->ref_bytes;
+	if (out_bytes) *out_bytes = (int)s->out_bytes;
 	return MI_OK;
 }
 
@@ -213,8 +281,8 @@ int mi_session_submit(mi_session *s) {
 	const int slot = (int)(s->submitted % SLOTS);
 	const size_t n = (size_t)s->n;
 	// upload on its own stream
-	MI_HIP(hipMemcpyAsync(s->d_mic[slot], s->h_mic[slot], n * s->in_len * 2, hipMemcpyHostToDevice, s->s_up));
-	MI_HIP(hipMemcpyAsync(s->d_ref[slot], s->h_ref[slot], n * s->len * 2, hipMemcpyHostToDevice, s->s_up));
+	MI_HIP(hipMemcpyAsync(s->d_mic[slot], s->h_mic[slot], n * s->mic_bytes, hipMemcpyHostToDevice, s->s_up));
+	if (s->ref_bytes) MI_HIP(hipMemcpyAsync(s->d_ref[slot], s->h_ref[slot], n * s->ref_bytes, hipMemcpyHostToDevice, s->s_up));
 	MI_HIP(hipEventRecord(s->ev_up[slot], s->s_up));
 	// kernels wait for this tick's upload and for the download that last read this slot's output buffer
 	MI_HIP(hipStreamWaitEvent(c->stream, s->ev_up[slot], 0));
@@ -238,7 +306,7 @@ int mi_session_submit(mi_session *s) {
 	MI_HIP(hipEventRecord(s->ev_done[slot], c->stream));
 	// download on its own stream
 	MI_HIP(hipStreamWaitEvent(s->s_down, s->ev_done[slot], 0));
-	MI_HIP(hipMemcpyAsync(s->h_out[slot], s->d_out[slot], n * s->len * 2, hipMemcpyDeviceToHost, s->s_down));
+	MI_HIP(hipMemcpyAsync(s->h_out[slot], s->d_out[slot], n * s->out_bytes, hipMemcpyDeviceToHost, s->s_down));
 	MI_HIP(hipEventRecord(s->ev_down[slot], s->s_down));
 	s->used[slot] = true;
 	s->submitted++;
@@ -287,6 +355,18 @@ int mi_session_reset_streams(mi_session *s, int first, int count) {
 	if ((rc = mi_fifo_reset_range(s->f_mic, first, count)) != MI_OK || (rc = mi_fifo_reset_range(s->f_ref, first, count)) != MI_OK ||
 	    (rc = mi_fifo_reset_range(s->f_out, first, count)) != MI_OK)
 		return rc;
+	if (s->rs_out && (rc = mi_resampler_reset(s->rs_out, first, count)) != MI_OK) return rc;
+	if (s->cfg.ref_loopback) // the new leg was not sent anything yet
+		for (int i = 0; i < SLOTS; ++i)
+			MI_HIP(hipMemsetAsync(s->d_mix[i] + (size_t)first * s->len, 0, (size_t)count * s->len * 2, s->ctx->stream));
+	if (s->d_zero) { // its reference FIFO starts with the configured delay again
+		const int delay = s->cfg.ref_delay_ms * s->cfg.rate / 1000;
+		std::vector<uint8_t> gate((size_t)s->n, 0);
+		for (int i = 0; i < count; ++i) gate[(size_t)(first + i)] = 1;
+		MI_HIP(hipMemcpyAsync(s->d_ok, gate.data(), (size_t)s->n, hipMemcpyHostToDevice, s->ctx->stream));
+		if ((rc = mi_fifo_push_gated(s->f_ref, s->d_zero, delay, delay, s->d_ok)) != MI_OK) return rc;
+		MI_HIP(hipStreamSynchronize(s->ctx->stream)); // gate is a stack-lifetime buffer
+	}
 	return MI_OK;
 }
 

@@ -297,3 +297,114 @@ def test_session_reset_streams_starts_a_leg_over(ctx):
     assert any(g[0].any() for g in got)       # member 0 does hear the new leg
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("law", [ms.MI_LAW_PCMA, ms.MI_LAW_PCMU])
+def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, law):
+    """The legs as a SIP trunk delivers them: G.711 at 8 kHz in and out, the far-end reference = what the leg was sent on
+    the previous tick (delayed by ref_delay_ms), nothing but 80 + 80 bytes per leg and tick crossing PCIe.  Must equal
+    MSAlawDec -> MSResample 8k->48k -> FIFO -> MSSpeexEC -> FIFO -> MSVolume -> MSAudioMixer -> MSResample 48k->8k ->
+    MSAlawEnc built from the individual C ABI objects."""
+    torch = pytest.importorskip("torch")
+    nconf, mm, nticks, F, rate, delay_ms = 2, 16, 24, 256, 48000, 20
+    n = nconf * mm
+    pcm8 = np.stack([synth_pcm(40 + s, 80 * nticks, rate=8000, sigma=2500.0) for s in range(n)])
+    codes = oracle.g711_encode(law, pcm8)
+    # ---- the individual objects
+    rs = ms.ResamplerBatch(ctx, n, 8000, rate)
+    rs_out = ms.ResamplerBatch(ctx, n, rate, 8000)
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
+    vol = ms.VolumeBatch(ctx, n, rate)
+    p = vol.default_params()
+    p.agc_enabled = 1
+    vol.set_params([p] * n)
+    mix = ms.MixerBatch(ctx, nconf, mm, 480)
+    cap = (2 * 480 + 2 * F + 7) & ~7
+    delay = delay_ms * rate // 1000
+    f_mic, f_out = ms.FifoBatch(ctx, n, cap), ms.FifoBatch(ctx, n, cap)
+    f_ref = ms.FifoBatch(ctx, n, (cap + delay + 7) & ~7)
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    pcm, up, micf, reff, clean, tick = z(n, 80), z(n, 488), z(n, F), z(n, F), z(n, F), z(n, 480)
+    mixed, prev, down, enc = z(nconf, mm, 480), z(n, 480), z(n, 88), z(n, 80, dt=torch.uint8)
+    okm = z(n, dt=torch.uint8)
+    torch.cuda.synchronize()
+    f_ref.push(z(n, delay))
+    want = []
+    for t in range(nticks):
+        d_codes = torch.from_numpy(np.ascontiguousarray(codes[:, t * 80:(t + 1) * 80])).cuda()
+        torch.cuda.synchronize()
+        ms.g711_decode(ctx, law, d_codes, pcm)
+        rs.process(pcm, out=up)
+        f_mic.push(up, nsamples=480)
+        f_ref.push(prev)
+        for _ in range(2):
+            f_mic.pop(F, micf, ok=okm, zero_fill=False)
+            f_ref.pop(F, reff, gate=okm, zero_fill=True)
+            aec.process(micf, reff, out=clean, run=okm)
+            f_out.push(clean, gate=okm)
+        f_out.pop(480, tick, zero_fill=True)
+        vol.process(tick)
+        mix.process(tick.view(nconf, mm, 480), out=mixed)
+        ctx.sync()
+        prev = mixed.view(n, 480).clone()
+        torch.cuda.synchronize()
+        rs_out.process(prev, out=down)
+        ms.g711_encode(ctx, law, down, enc, length=80)
+        ctx.sync()
+        want.append(enc.cpu().numpy().copy())
+    # ---- the session
+    kind = ms.MI_SESSION_PCMA if law == ms.MI_LAW_PCMA else ms.MI_SESSION_PCMU
+    se = ms.Session(ctx, n, members=mm, in_rate=8000, rate=rate, tail_ms=128, agc=True, use_graphs=False,
+                    mic_codec=kind, out_rate=8000, out_codec=kind, ref_loopback=True, ref_delay_ms=delay_ms)
+    assert se.tick_bytes() == (80, 0, 80)
+    got = []
+    for t in range(nticks):
+        if se.in_flight() == 3:
+            got.append(se.collect().copy())
+        h_mic, h_ref = se.acquire()
+        assert h_ref is None and h_mic.dtype == np.uint8
+        h_mic[:] = codes[:, t * 80:(t + 1) * 80]
+        se.submit()
+    while se.in_flight():
+        got.append(se.collect().copy())
+    assert len(got) == nticks
+    for t in range(nticks):
+        np.testing.assert_array_equal(got[t], want[t], err_msg=f"tick {t}")
+    # the legs do hear each other: decoded output is not silence
+    assert np.abs(oracle.g711_decode(law, got[-1])).max() > 500
+    se.close()
+
+
+def test_session_downsampled_pcm_output_and_reset(ctx):
+    """16-bit output through the down-sampler (no codec): rows are packed to out_rate/100 samples; a reset leg starts over
+    (its loop-back reference and delay line included)."""
+    mm = 8
+    x = synth_pcm(5, 160 * 24, rate=16000, sigma=2500.0)
+    y = synth_pcm(6, 160 * 12, rate=16000, sigma=2500.0)
+
+    def mk():
+        return ms.Session(ctx, mm, members=mm, agc=False, use_graphs=False, out_rate=16000, ref_loopback=True, ref_delay_ms=10)
+
+    def feed(se, sig, t, slot=2):
+        m, r = se.acquire()
+        assert r is None
+        m[:] = 0
+        m[slot] = sig[t * 160:(t + 1) * 160]
+        se.submit()
+        return se.collect().copy()
+
+    a = mk()
+    assert a.tick_bytes() == (320, 0, 320)
+    for t in range(13):
+        out = feed(a, x, t)
+    assert out.shape == (mm, 160) and out[0].any()
+    a.reset_streams(2, 1)
+    b = mk()
+    # the other members of `a` still carry what leg 2 said before the reset in their own loop-back state, so only the new
+    # leg's own row is compared: it hears nothing but silence from the others in both sessions after a few ticks
+    got = [feed(a, y, t) for t in range(12)]
+    want = [feed(b, y, t) for t in range(12)]
+    for t in range(4, 12):
+        np.testing.assert_array_equal(got[t][0], want[t][0], err_msg=f"tick {t}")
+    a.close()
+    b.close()
