@@ -402,15 +402,25 @@ def pipeline_probe(ms, torch, ctx, nstreams):
     return out
 
 
-def session_probe(ms, ctx, nstreams, ticks=40):
+def session_probe(ms, ctx, nstreams, ticks=40, trunk=False):
     """mi_session end to end: host buffers in, host buffers out, uploads / kernels / downloads overlapped on three HIP
-    streams, three ticks in flight -- the PCIe-inclusive rate of the chained path (never part of `value`)."""
-    se = ms.Session(ctx, nstreams, use_graphs=False)
-    mic = synth_pcm_batch(nstreams, 160, 16000)
-    ref = synth_pcm_batch(nstreams, 480, 48000, sigma=2000.0)
+    streams, three ticks in flight -- the PCIe-inclusive rate of the chained path (never part of `value`).
+    trunk: G.711 at 8 kHz in and out, far-end reference looped back on the device (160 B per leg and tick over PCIe)."""
+    if trunk:
+        se = ms.Session(ctx, nstreams, in_rate=8000, use_graphs=False, mic_codec=ms.MI_SESSION_PCMA, out_rate=8000,
+                        out_codec=ms.MI_SESSION_PCMA, ref_loopback=True, ref_delay_ms=40)
+        mic = np.random.default_rng(1).integers(0, 256, (nstreams, 80), dtype=np.uint8)
+        ref = None
+    else:
+        se = ms.Session(ctx, nstreams, use_graphs=False)
+        mic = synth_pcm_batch(nstreams, 160, 16000)
+        ref = synth_pcm_batch(nstreams, 480, 48000, sigma=2000.0)
+    per_tick = sum(se.tick_bytes()) * nstreams
     for _ in range(3):
         m, r = se.acquire()
-        m[:], r[:] = mic, ref
+        m[:] = mic
+        if r is not None:
+            r[:] = ref
         se.submit()
     for _ in range(3):
         se.collect()
@@ -424,8 +434,11 @@ def session_probe(ms, ctx, nstreams, ticks=40):
         se.collect()
     dt = (time.perf_counter() - t0) / ticks
     se.close()
-    return {"streams": nstreams, "tick_ms_end_to_end": round(dt * 1e3, 4), "pcie_bytes_per_tick": nstreams * (320 + 960 + 960),
-            "fits": bool(dt < 0.010), "note": "mi_session: pinned host buffers -> H2D | kernels | D2H on three streams, 3 ticks in flight"}
+    note = "mi_session: pinned host buffers -> H2D | kernels | D2H on three streams, 3 ticks in flight"
+    if trunk:
+        note += "; trunk mode: PCMA 8 kHz in -> 48 kHz chain -> PCMA 8 kHz out, far-end reference looped back on the device"
+    return {"streams": nstreams, "tick_ms_end_to_end": round(dt * 1e3, 4), "pcie_bytes_per_tick": int(per_tick),
+            "fits": bool(dt < 0.010), "note": note}
 
 
 def cpu_baseline_resample(nstreams, seconds):
@@ -517,6 +530,20 @@ def cpu_reference_times():
     t = L.orc_bench_aec(8, 256, 128 * 48, 48000, 60, p(mic), p(ref), None)
     out["aec_mdf_wave_kernel<256>+aec_post_wave_kernel<256>"] = {"cpu_us_per_unit": round(t / (8 * 60) * 1e6, 2),
                                                                  "unit": "stream-frame (256 samples, M=24)"}
+    # G.711: the reference's OWN conversions where oracle/_ref was built (kind "reference"), else the oracle's
+    R = oracle.g711_ref()
+    L.orc_bench_g711_decode.restype = L.orc_bench_g711_encode.restype = C.c_double
+    L.orc_bench_g711_decode.argtypes = [C.c_void_p, u8p, C.c_size_t, C.c_int, llp]
+    L.orc_bench_g711_encode.argtypes = [C.c_void_p, i16p, C.c_size_t, C.c_int, llp]
+    codes = np.random.default_rng(2).integers(0, 256, 480 * 1024, dtype=np.uint8)
+    pcm = oracle.g711_decode(0, codes)
+    fd = C.cast(R.Snack_Alaw2Lin if R is not None else L.orc_alaw2lin, C.c_void_p)
+    fe = C.cast(R.Snack_Lin2Alaw if R is not None else L.orc_lin2alaw, C.c_void_p)
+    kind = "reference (src/audiofilters/g711.c compiled unmodified)" if R is not None else "port"
+    t = L.orc_bench_g711_decode(fd, p(codes, C.c_uint8), codes.size, 20, None)
+    out["g711_decode_kernel<0>"] = {"cpu_us_per_unit": round(t / (1024 * 20) * 1e6, 3), "unit": "stream-block (480 samples)", "kind": kind}
+    t = L.orc_bench_g711_encode(fe, p(pcm), pcm.size, 20, None)
+    out["g711_encode_kernel<0>"] = {"cpu_us_per_unit": round(t / (1024 * 20) * 1e6, 3), "unit": "stream-block (480 samples)", "kind": kind}
     frame = np.random.default_rng(1).integers(0, 256, 1920 * 1080 * 3 // 2, dtype=np.uint8)
     t = L.orc_bench_scaler(4, 1920, 1080, 1280, 720, p(frame, C.c_uint8), None)
     out["scaler_wave_kernel<true>"] = {"cpu_us_per_unit": round(t / 4 * 1e6, 1), "unit": "frame (1080p I420 -> 720p RGB24)"}
@@ -630,8 +657,11 @@ def main():
             def make_resample_65536(ms_, torch_, ctx_):  # same kernel, a deployment-sized batch
                 return make_resample_leg(ms_, torch_, ctx_, 65536)
 
+            def make_g711_encode(ms_, torch_, ctx_):
+                return make_g711_leg(ms_, torch_, ctx_, encode=True)
+
             for mk in (make_resample_65536, make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg,
-                       make_scaler_leg, make_pixconv_leg):
+                       make_scaler_leg, make_pixconv_leg, make_g711_leg, make_g711_encode):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
@@ -672,6 +702,10 @@ def main():
                     line["session_pcie_inclusive"] = session_probe(ms, ctx, a.pipeline_streams)
                 except Exception as e:
                     line["session_pcie_inclusive"] = {"error": str(e)[:200]}
+                try:
+                    line["session_trunk_g711"] = session_probe(ms, ctx, a.pipeline_streams, trunk=True)
+                except Exception as e:
+                    line["session_trunk_g711"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
             try:

@@ -237,3 +237,25 @@ double orc_bench_resample_mt(int nstreams, int in_len, int nticks, uint32_t in_r
 	if (sink) *sink = acc;
 	return t1 - t0;
 }
+
+/* G.711 sample loops of MSAlawDec / MSAlawEnc (alaw.c:213-217, :77-82) timed through a function pointer, so that the
+ * conversion can be the reference's own Snack_* from oracle/_ref/libg711_ref.so ("reference") or this oracle's ("port"):
+ * either way one external call per sample, as in the reference.  Returns seconds for `reps` passes over n samples. */
+double orc_bench_g711_decode(short (*fn)(unsigned char), const uint8_t *codes, size_t n, int reps, long long *sink) {
+	long long acc = 0;
+	const double t0 = now_s();
+	for (int r = 0; r < reps; ++r)
+		for (size_t i = 0; i < n; ++i) acc += fn(codes[i]);
+	const double t1 = now_s();
+	if (sink) *sink = acc;
+	return t1 - t0;
+}
+double orc_bench_g711_encode(unsigned char (*fn)(short), const int16_t *pcm, size_t n, int reps, long long *sink) {
+	long long acc = 0;
+	const double t0 = now_s();
+	for (int r = 0; r < reps; ++r)
+		for (size_t i = 0; i < n; ++i) acc += fn(pcm[i]);
+	const double t1 = now_s();
+	if (sink) *sink = acc;
+	return t1 - t0;
+}
