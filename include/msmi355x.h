@@ -316,6 +316,21 @@ int mi_flowctl_process(mi_flowctl *f, const int16_t *d_in, size_t in_stride, con
 int mi_flowctl_get_state(mi_flowctl *f, int stream, uint32_t out4[4]); /* target, total, pos, dropped */
 int mi_flowctl_reset(mi_flowctl *f, int first, int count);             /* ms_audio_flow_controller_reset :30-35 */
 
+/* MSGenericPLC for a batch of streams: generic_plc_process (src/audiofilters/msgenericplc.c:59-167) over plc_context_t
+ * (src/audiofilters/genericplc.c:29-241).  Mono, 16-bit; rates whose nb = rate/20 (rounded down to 100) factors into
+ * 2, 3, 5 (8, 16, 24, 32, 48 kHz; 44.1 kHz needs kiss_fft's radix-11 butterfly: MI_ENOTSUP). */
+typedef struct mi_plc mi_plc;
+#define MI_PLC_NONE 0       /* no event for the stream this round */
+#define MI_PLC_RECEIVED 1   /* a block of d_len[s] samples arrived: edited in place (delayed 5 ms, cross-faded after a loss) :63-116 */
+#define MI_PLC_CONCEAL 2    /* nothing arrived: d_len[s] samples are generated into the row :150-156, genericplc.c:123-197 */
+#define MI_PLC_CNG_RESUME 4 /* with RECEIVED: the stream was in comfort noise (silence without bcg729) :76-89 */
+int mi_plc_create(mi_ctx *ctx, int nstreams, int rate, int max_block, mi_plc **out);
+void mi_plc_destroy(mi_plc *p);
+int mi_plc_reset(mi_plc *p, int first, int count);
+/* d_blocks [nstreams][stride] int16 in/out, d_len [nstreams] int32, d_mode [nstreams] uint8 (MI_PLC_*) */
+int mi_plc_process(mi_plc *p, int16_t *d_blocks, size_t stride, const int32_t *d_len, const uint8_t *d_mode);
+int mi_plc_info(mi_plc *p, int stream, int32_t out3[3]); /* plc_buffer_samples_nb, plc_index, plc_samples_used */
+
 /* ------------------------------------------------------------- session */
 /* The chained path of BASELINE.json's north_star for a batch of call legs, fed from host buffers, one 10 ms tick per
  * submit: MSResample in_rate->rate (msresample.c:122-179) -> FIFO -> MSSpeexEC + post-filter (speexec.c:223-305) ->

@@ -509,6 +509,32 @@ class FlowControlBatch(_Batch):
         check(self.ctx.L.mi_flowctl_reset(self.h, first, self.nstreams - first if count is None else count))
 
 
+MI_PLC_NONE, MI_PLC_RECEIVED, MI_PLC_CONCEAL, MI_PLC_CNG_RESUME = 0, 1, 2, 4
+
+
+class PlcBatch(_Batch):
+    """nstreams plc_context_t (genericplc.c) on the device: process(rows, lens, modes) edits / fills the rows in place."""
+    _destroy = "mi_plc_destroy"
+
+    def __init__(self, ctx, nstreams, rate, max_block=960):
+        self.ctx, self.nstreams, self.rate = ctx, nstreams, rate
+        h = C.c_void_p()
+        check(ctx.L.mi_plc_create(ctx.h, nstreams, rate, max_block, C.byref(h)))
+        self.h = h
+
+    def process(self, rows, lens, modes):
+        check(self.ctx.L.mi_plc_process(self.h, _ptr(rows), rows.stride(0), _ptr(lens), _ptr(modes)))
+        return rows
+
+    def info(self, stream):
+        v = (C.c_int32 * 3)()
+        check(self.ctx.L.mi_plc_info(self.h, stream, v))
+        return dict(nb=v[0], index=v[1], used=v[2])
+
+    def reset(self, first=0, count=None):
+        check(self.ctx.L.mi_plc_reset(self.h, first, self.nstreams - first if count is None else count))
+
+
 class SessionConfig(C.Structure):
     _fields_ = [("nstreams", C.c_int32), ("members_per_conference", C.c_int32), ("in_rate", C.c_int32),
                 ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32),

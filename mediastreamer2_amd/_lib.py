@@ -49,6 +49,7 @@ EXPORTS = [
     "mi_g711_decode", "mi_g711_encode", "mi_l16_swap", "mi_chan_adapt",
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
+    "mi_plc_create", "mi_plc_destroy", "mi_plc_reset", "mi_plc_process", "mi_plc_info",
     "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
 ]
 
@@ -232,6 +233,13 @@ def load():
         L.mi_flowctl_process.argtypes = [vp, vp, sz, vp, i32, vp, sz, vp]
         L.mi_flowctl_get_state.argtypes = [vp, i32, C.POINTER(C.c_uint32)]
         L.mi_flowctl_reset.argtypes = [vp, i32, i32]
+    if hasattr(L, "mi_plc_create"):
+        L.mi_plc_create.argtypes = [vp, i32, i32, i32, pp]
+        L.mi_plc_destroy.argtypes = [vp]
+        L.mi_plc_destroy.restype = None
+        L.mi_plc_reset.argtypes = [vp, i32, i32]
+        L.mi_plc_process.argtypes = [vp, vp, sz, vp, vp]
+        L.mi_plc_info.argtypes = [vp, i32, C.POINTER(i32)]
     if hasattr(L, "mi_pixconv_create"):
         L.mi_pixconv_create.argtypes = [vp, i32, i32, i32, i32, pp]
         L.mi_pixconv_destroy.argtypes = [vp]

@@ -409,3 +409,91 @@ def g711_ref():
     R.Snack_Alaw2Lin.argtypes = R.Snack_Mulaw2Lin.argtypes = [C.c_ubyte]
     R.Snack_Alaw2Lin.restype = R.Snack_Mulaw2Lin.restype = C.c_short
     return R
+
+
+# ---------------------------------------------------------------- MSGenericPLC
+class OrcConcealer(C.Structure):
+    _fields_ = [("sample_time", C.c_int64), ("plc_start_time", C.c_int64), ("total_number_for_plc", C.c_ulong),
+                ("max_plc_time", C.c_uint32)]
+
+
+def _declare_plc(L):
+    i16p = C.POINTER(C.c_int16)
+    L.orc_plc_new.restype = C.c_void_p
+    L.orc_plc_new.argtypes = [C.c_int]
+    L.orc_plc_free.argtypes = [C.c_void_p]
+    L.orc_plc_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_plc_received.argtypes = [C.c_void_p, i16p, C.c_size_t, C.c_int]
+    L.orc_plc_conceal.argtypes = [C.c_void_p, i16p, C.c_uint16]
+    L.orc_plc_transition_mix.argtypes = [i16p, i16p, C.c_uint16]
+    L.orc_concealer_init.argtypes = [C.POINTER(OrcConcealer), C.c_uint32]
+    L.orc_concealer_inc_sample_time.argtypes = [C.POINTER(OrcConcealer), C.c_uint64, C.c_uint32, C.c_int]
+    L.orc_concealer_inc_sample_time.restype = C.c_uint32
+    L.orc_concealer_required.argtypes = [C.POINTER(OrcConcealer), C.c_uint64]
+    L._plc_declared = True
+
+
+class Plc:
+    """plc_context_t (genericplc.c) for one stream: received() for a block that arrived, conceal() for a missing tick."""
+
+    def __init__(self, rate):
+        L = lib()
+        if not getattr(L, "_plc_declared", False):
+            _declare_plc(L)
+        self.L, self.rate = L, rate
+        self.h = L.orc_plc_new(rate)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_plc_free(self.h)
+            self.h = None
+
+    def info(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_plc_info(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(nb=a.value, index=b.value, used=c.value)
+
+    def received(self, block, cng_resume=False):
+        x = np.array(block, dtype=np.int16, copy=True)
+        self.L.orc_plc_received(self.h, _p(x, C.c_int16), x.size, int(cng_resume))
+        return x
+
+    def conceal(self, n):
+        x = np.zeros(n, np.int16)
+        self.L.orc_plc_conceal(self.h, _p(x, C.c_int16), n)
+        return x
+
+
+class GenericPlcFilter:
+    """generic_plc_process (msgenericplc.c:59-167, build without bcg729) for one mono stream: feed tick(now_ms,
+    blocks) once per ticker interval, get the list of blocks the filter emits."""
+
+    def __init__(self, rate, interval_ms=10):
+        self.plc = Plc(rate)
+        self.rate, self.interval = rate, interval_ms
+        self.con = OrcConcealer()
+        self.plc.L.orc_concealer_init(C.byref(self.con), 0xFFFFFFFF)  # MAX_PLC_COUNT = UINT32_MAX (:43)
+        self.cng_set = self.cng_running = False
+
+    def set_cn(self):  # MS_GENERIC_PLC_SET_CN (:196-201)
+        self.cng_set = True
+
+    def tick(self, now_ms, blocks):
+        L, out = self.plc.L, []
+        for b in blocks:
+            ms = (1000 * b.size * 2) // (self.rate * 2)  # :66 for one channel
+            L.orc_concealer_inc_sample_time(C.byref(self.con), now_ms, ms, 1)
+            out.append(self.plc.received(b, cng_resume=self.cng_running))
+            if self.cng_running:
+                self.cng_running = self.cng_set = False
+        if L.orc_concealer_required(C.byref(self.con), now_ms):
+            n = self.rate * self.interval // 1000
+            if self.cng_set:
+                self.cng_set, self.cng_running = False, True
+                out.append(np.zeros(n, np.int16))
+            elif self.cng_running:
+                out.append(np.zeros(n, np.int16))
+            else:
+                out.append(self.plc.conceal(n))
+            L.orc_concealer_inc_sample_time(C.byref(self.con), now_ms, self.interval, 0)
+        return out

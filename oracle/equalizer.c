@@ -140,13 +140,119 @@ static void bfly4(cpx *base, size_t fstride, const CFft *st, int m, int N, int m
 	}
 }
 
+/* kf_bfly3 kiss_fft.c:150-190 (float build: HALF_OF(x) = x * .5f, no C_FIXDIV) */
+static void bfly3(cpx *F, size_t fstride, const CFft *st, int m) {
+	const size_t m2 = 2 * (size_t)m;
+	const cpx *t1 = st->tw, *t2 = st->tw;
+	const float e = st->tw[fstride * (size_t)m].i;
+	int j;
+	for (j = 0; j < m; j++) {
+		cpx s0, s1, s2, s3;
+		cmul(&s1, &F[m], t1);
+		cmul(&s2, &F[m2], t2);
+		s3.r = s1.r + s2.r;
+		s3.i = s1.i + s2.i;
+		s0.r = s1.r - s2.r;
+		s0.i = s1.i - s2.i;
+		t1 += fstride;
+		t2 += fstride * 2;
+		F[m].r = F->r - s3.r * .5f;
+		F[m].i = F->i - s3.i * .5f;
+		s0.r *= e;
+		s0.i *= e;
+		F->r += s3.r;
+		F->i += s3.i;
+		F[m2].r = F[m].r + s0.i;
+		F[m2].i = F[m].i - s0.r;
+		F[m].r -= s0.i;
+		F[m].i += s0.r;
+		++F;
+	}
+}
+
+/* kf_bfly5 kiss_fft.c:192-256 */
+static void bfly5(cpx *F, size_t fstride, const CFft *st, int m) {
+	cpx *F0 = F, *F1 = F + m, *F2 = F + 2 * m, *F3 = F + 3 * m, *F4 = F + 4 * m;
+	const cpx ya = st->tw[fstride * (size_t)m], yb = st->tw[fstride * 2 * (size_t)m];
+	int u;
+	for (u = 0; u < m; ++u) {
+		cpx s0 = *F0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12;
+		cmul(&s1, F1, &st->tw[(size_t)u * fstride]);
+		cmul(&s2, F2, &st->tw[2 * (size_t)u * fstride]);
+		cmul(&s3, F3, &st->tw[3 * (size_t)u * fstride]);
+		cmul(&s4, F4, &st->tw[4 * (size_t)u * fstride]);
+		s7.r = s1.r + s4.r;
+		s7.i = s1.i + s4.i;
+		s10.r = s1.r - s4.r;
+		s10.i = s1.i - s4.i;
+		s8.r = s2.r + s3.r;
+		s8.i = s2.i + s3.i;
+		s9.r = s2.r - s3.r;
+		s9.i = s2.i - s3.i;
+		F0->r += s7.r + s8.r;
+		F0->i += s7.i + s8.i;
+		s5.r = s0.r + s7.r * ya.r + s8.r * yb.r;
+		s5.i = s0.i + s7.i * ya.r + s8.i * yb.r;
+		s6.r = s10.i * ya.i + s9.i * yb.i;
+		s6.i = -(s10.r * ya.i) - s9.r * yb.i;
+		F1->r = s5.r - s6.r;
+		F1->i = s5.i - s6.i;
+		F4->r = s5.r + s6.r;
+		F4->i = s5.i + s6.i;
+		s11.r = s0.r + s7.r * yb.r + s8.r * ya.r;
+		s11.i = s0.i + s7.i * yb.r + s8.i * ya.r;
+		s12.r = -(s10.i * yb.i) + s9.i * ya.i;
+		s12.i = s10.r * yb.i - s9.r * ya.i;
+		F2->r = s11.r + s12.r;
+		F2->i = s11.i + s12.i;
+		F3->r = s11.r - s12.r;
+		F3->i = s11.i - s12.i;
+		++F0, ++F1, ++F2, ++F3, ++F4;
+	}
+}
+
+/* kf_bfly_generic kiss_fft.c:258-290 (radix up to 17) */
+static void bfly_generic(cpx *F, size_t fstride, const CFft *st, int m, int p) {
+	cpx buf[17];
+	int u, k, q1, q;
+	if (p > 17) abort();
+	for (u = 0; u < m; ++u) {
+		k = u;
+		for (q1 = 0; q1 < p; ++q1) {
+			buf[q1] = F[k];
+			k += m;
+		}
+		k = u;
+		for (q1 = 0; q1 < p; ++q1) {
+			int twidx = 0;
+			F[k] = buf[0];
+			for (q = 1; q < p; ++q) {
+				cpx t;
+				twidx += (int)(fstride * (size_t)k);
+				if (twidx >= st->n) twidx -= st->n;
+				cmul(&t, &buf[q], &st->tw[twidx]);
+				F[k].r += t.r;
+				F[k].i += t.i;
+			}
+			k += m;
+		}
+	}
+}
+
 /* kf_work kiss_fft.c:320-408: deepest stage first */
 static void work(cpx *out, size_t fstride, const int *fac, const CFft *st, int N, int m2) {
 	const int p = fac[0], m = fac[1];
 	if (m != 1) work(out, fstride * p, fac + 2, st, N * p, m);
 	if (p == 2) bfly2(out, fstride, st, m, N, m2);
 	else if (p == 4) bfly4(out, fstride, st, m, N, m2);
-	else abort(); /* sizes on this path are 2^k */
+	else { /* :383-405: the odd radices take one sub-transform at a time */
+		int i;
+		for (i = 0; i < N; i++) {
+			if (p == 3) bfly3(out + (size_t)i * m2, fstride, st, m);
+			else if (p == 5) bfly5(out + (size_t)i * m2, fstride, st, m);
+			else bfly_generic(out + (size_t)i * m2, fstride, st, m, p);
+		}
+	}
 }
 
 static void cfft(const CFft *st, const cpx *in, cpx *out) {

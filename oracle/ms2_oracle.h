@@ -187,6 +187,27 @@ void orc_flowctl_init(OrcFlowCtl *c);
 void orc_flowctl_set_target(OrcFlowCtl *c, uint32_t samples_to_drop, uint32_t total_samples);
 size_t orc_flowctl_process(OrcFlowCtl *c, int16_t *samples, size_t n); /* flowcontrol.c:107-152 */
 
+/* ------------------------------------------------------------ MSGenericPLC */
+/* oracle/plc.c: src/audiofilters/genericplc.c + msgenericplc.c:59-167 + MSConcealerContext (mscommon.c:315-366) */
+typedef struct OrcPlc OrcPlc; /* uses the OrcFft handles above: any even size whose factors are <= 17 */
+OrcPlc *orc_plc_new(int rate);
+void orc_plc_free(OrcPlc *c);
+int orc_plc_info(const OrcPlc *c, int *nb, int *index, int *used);
+void orc_plc_transition_mix(int16_t *inout, const int16_t *continuity, uint16_t n);
+void orc_plc_update_history(OrcPlc *c, const int16_t *data, size_t n);
+void orc_plc_update_continuity(OrcPlc *c, int16_t *data, size_t n);
+void orc_plc_generate(OrcPlc *c, int16_t *data, uint16_t n);
+void orc_plc_received(OrcPlc *c, int16_t *data, size_t n, int cng_resume); /* a block arrived (edited in place) */
+void orc_plc_conceal(OrcPlc *c, int16_t *data, uint16_t n);                /* a tick without one */
+typedef struct OrcConcealer {
+	int64_t sample_time, plc_start_time;
+	unsigned long total_number_for_plc;
+	uint32_t max_plc_time;
+} OrcConcealer;
+void orc_concealer_init(OrcConcealer *o, uint32_t max_plc_time);
+uint32_t orc_concealer_inc_sample_time(OrcConcealer *o, uint64_t now, uint32_t increment, int got_packet);
+int orc_concealer_required(OrcConcealer *o, uint64_t now);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,148 @@
+"""MSGenericPLC (genericplc.c + msgenericplc.c:59-167) through the C ABI vs the oracle: bit-exact.
+
+The generated samples go through kiss_fft transforms of 200 .. 2400 complex points with radix 4, 2, 3 and 5 stages;
+the kernel evaluates them in the reference's operation order, so even the float -> int16 truncations agree."""
+import numpy as np
+import pytest
+import torch
+
+import mediastreamer2_amd as ms
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+R, C_, G = ms.MI_PLC_RECEIVED, ms.MI_PLC_CONCEAL, ms.MI_PLC_CNG_RESUME
+
+
+def voiced(seed, n, rate):
+    t = np.arange(n)
+    rng = np.random.default_rng(seed)
+    f0 = 110 + 7 * seed
+    x = sum(a * np.sin(2 * np.pi * f0 * k * t / rate + k) for k, a in ((1, 5000), (2, 2500), (3, 1200), (5, 600)))
+    x = x * (0.6 + 0.4 * np.sin(2 * np.pi * t / (rate * 0.13))) + rng.normal(0, 200, n)
+    return np.clip(np.round(x), -32768, 32767).astype(np.int16)
+
+
+def run_scenario(ctx, oracle, rate, n, events, streams_signal, cap=None):
+    """events[t][s] in {R, C_, R|G, 0}; returns nothing, asserts equality tick by tick."""
+    S = len(streams_signal)
+    cap = cap or n
+    plc = ms.PlcBatch(ctx, S, rate, max_block=cap)
+    refs = [oracle.Plc(rate) for _ in range(S)]
+    rows = torch.zeros((S, cap), dtype=torch.int16, device="cuda")
+    lens = torch.zeros(S, dtype=torch.int32, device="cuda")
+    modes = torch.zeros(S, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    pos = [0] * S
+    for t, ev in enumerate(events):
+        host = np.zeros((S, cap), np.int16)
+        want = [None] * S
+        L = np.zeros(S, np.int32)
+        for s in range(S):
+            e = ev[s]
+            if e & 3 == R:
+                blk = streams_signal[s][pos[s]: pos[s] + n]
+                pos[s] += n
+                host[s, :n] = blk
+                want[s] = refs[s].received(blk, cng_resume=bool(e & G))
+                L[s] = n
+            elif e & 3 == C_:
+                pos[s] += n  # the lost packet's samples are gone
+                want[s] = refs[s].conceal(n)
+                L[s] = n
+        rows.copy_(torch.from_numpy(host))
+        lens.copy_(torch.from_numpy(L))
+        modes.copy_(torch.from_numpy(np.array(ev, np.uint8)))
+        torch.cuda.synchronize()
+        plc.process(rows, lens, modes)
+        ctx.sync()
+        got = rows.cpu().numpy()
+        for s in range(S):
+            if want[s] is None:
+                continue
+            np.testing.assert_array_equal(got[s, :n], want[s], err_msg=f"rate {rate} tick {t} stream {s} event {ev[s]}")
+            gi, oi = plc.info(s), refs[s].info()
+            assert (gi["nb"], gi["index"], gi["used"]) == (oi["nb"], oi["index"], oi["used"]), (t, s)
+    return plc, refs
+
+
+@pytest.mark.parametrize("rate", [8000, 16000, 32000, 48000])
+def test_plc_loss_patterns_bit_exact(ctx, oracle, rate):
+    """10 ms blocks; streams with: no loss, single losses, a 60 ms burst (the generated signal is extended from itself),
+    a 250 ms outage (fade between 100 and 150 ms, silence after), loss on the very first tick, random 15 % loss."""
+    n, ticks = rate // 100, 70
+    rng = np.random.default_rng(rate)
+    pat = [[R] * ticks for _ in range(6)]
+    for t in (10, 25, 40):
+        pat[1][t] = C_
+    for t in range(20, 26):
+        pat[2][t] = C_
+    for t in range(15, 40):
+        pat[3][t] = C_
+    pat[4][0] = pat[4][1] = C_   # nothing was ever heard (the concealer context has no history): zeros in, zeros out
+    for t in range(ticks):
+        if rng.random() < 0.15:
+            pat[5][t] = C_
+    events = [[pat[s][t] for s in range(6)] for t in range(ticks)]
+    sig = [voiced(s, n * ticks, rate) for s in range(6)]
+    plc, refs = run_scenario(ctx, oracle, rate, n, events, sig)
+    assert refs[3].info()["used"] == 0  # back to normal after the outage
+
+
+def test_plc_generated_signal_is_not_trivial(ctx, oracle):
+    """The concealment is a real signal (not silence, not a copy): a fraction of the level of what was heard."""
+    rate, n = 8000, 80
+    sig = [voiced(3, n * 30, rate)]
+    events = [[R]] * 12 + [[C_]] * 4
+    S = 1
+    plc = ms.PlcBatch(ctx, S, rate, max_block=n)
+    rows = torch.zeros((S, n), dtype=torch.int16, device="cuda")
+    lens = torch.full((S,), n, dtype=torch.int32, device="cuda")
+    outs = []
+    for t, ev in enumerate(events):
+        rows.copy_(torch.from_numpy(sig[0][t * n:(t + 1) * n][None, :].copy()))
+        modes = torch.tensor([ev[0]], dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        plc.process(rows, lens, modes)
+        ctx.sync()
+        outs.append(rows.cpu().numpy()[0].copy())
+    heard = np.concatenate(outs[:12]).astype(float)
+    concealed = np.concatenate(outs[12:]).astype(float)
+    assert 0.1 < concealed.std() / heard.std() < 1.2
+    assert np.abs(concealed).max() > 1000
+
+
+def test_plc_short_blocks_cng_resume_and_counter_wrap(ctx, oracle):
+    """5 ms blocks at 16 kHz (shorter than two transition delays: the cross-fade happens inside the continuity buffer,
+    msgenericplc.c:104-111), a comfort-noise resume, and an outage long enough for the 16-bit counters to wrap
+    (genericplc.h:52-53: 65 536 samples = 4.1 s at 16 kHz)."""
+    rate = 16000
+    n = 80
+    ticks = 60
+    pat = [[R] * ticks for _ in range(2)]
+    for t in range(20, 30):
+        pat[0][t] = C_
+    pat[1][30] = R | G
+    events = [[pat[s][t] for s in range(2)] for t in range(ticks)]
+    run_scenario(ctx, oracle, rate, n, events, [voiced(s + 10, n * ticks, rate) for s in range(2)])
+    n = 160
+    ticks = 440
+    pat = [[R] * 8 + [C_] * (ticks - 16) + [R] * 8]
+    events = [[pat[0][t]] for t in range(ticks)]
+    run_scenario(ctx, oracle, rate, n, events, [voiced(21, n * ticks, rate)])
+
+
+def test_plc_ragged_and_unsupported_rates(ctx):
+    with pytest.raises(ms.MiError):
+        ms.PlcBatch(ctx, 4, 44100)  # nb = 2200 = 2^3 5^2 11: kiss_fft's generic butterfly is not built
+    plc = ms.PlcBatch(ctx, 3, 8000, max_block=160)
+    rows = torch.zeros((3, 160), dtype=torch.int16, device="cuda")
+    rows[1, :] = 1234
+    lens = torch.tensor([80, 0, 160], dtype=torch.int32, device="cuda")
+    modes = torch.tensor([R, R, 0], dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    plc.process(rows, lens, modes)
+    ctx.sync()
+    got = rows.cpu().numpy()
+    assert (got[1] == 1234).all()       # zero-length event: untouched
+    assert (got[2] == 0).all() and plc.info(2)["used"] == 0

@@ -105,3 +105,69 @@ def test_flow_controller_silent_and_oversized_requests(oracle):
     basic.set_target(320, 1600)
     sizes = [basic.process(loud(rng, 160)).size for _ in range(4)]
     assert sizes == [0, 0, 160, 160]  # basic: whole blocks until the target is reached (:115-121)
+
+
+def _voiced(seed, n, rate):
+    t = np.arange(n)
+    x = 5000 * np.sin(2 * np.pi * (120 + seed) * t / rate) + 2000 * np.sin(2 * np.pi * 3 * (120 + seed) * t / rate + 1)
+    return np.round(x).astype(np.int16)
+
+
+@pytest.mark.parametrize("rate", [8000, 16000, 48000])
+def test_plc_clean_stream_is_a_pure_delay(oracle, rate):
+    """Without losses MSGenericPLC only delays the stream by TRANSITION_DELAY = 5 ms (genericplc.c:212-231)."""
+    n, T = rate // 100, rate * 5 // 1000
+    x = _voiced(1, n * 20, rate)
+    p = oracle.Plc(rate)
+    assert p.info()["nb"] == rate // 20
+    y = np.concatenate([p.received(x[k * n:(k + 1) * n]) for k in range(20)])
+    np.testing.assert_array_equal(y[T:], x[:-T])
+    assert (y[:T] == 0).all()
+
+
+def test_plc_concealment_shape(oracle):
+    """First loss: the generated signal continues the delayed stream without a jump, keeps roughly the level, fades
+    out between 100 and 150 ms and is silent afterwards (genericplc.c:187-203); the first good block cross-fades."""
+    rate, n = 8000, 80
+    x = _voiced(2, n * 60, rate)
+    p = oracle.Plc(rate)
+    heard = [p.received(x[k * n:(k + 1) * n]) for k in range(12)]
+    lost = [p.conceal(n) for _ in range(20)]
+    y = np.concatenate(heard + lost).astype(np.int32)
+    jump = np.abs(np.diff(y))[12 * n - 3: 12 * n + 3].max()
+    assert jump < 2 * np.abs(np.diff(np.concatenate(heard).astype(np.int32))).max()
+    lvl = [np.abs(b).max() for b in lost]
+    assert lvl[0] > 2000 and lvl[9] > 1000           # 0 .. 100 ms: full level x 0.85 per regeneration
+    assert lvl[13] < max(lvl[:10]) / 2 and lvl[14] < max(lvl[:10]) / 10  # fading out from 100 ms on ...
+    assert all(v == 0 for v in lvl[15:])                                  # ... silence from 150 ms on
+    assert p.info()["used"] == 20 * n
+    back = p.received(x[32 * n:33 * n])
+    assert p.info()["used"] == 0 and back.shape == (n,)
+
+
+def test_plc_filter_concealer_timing(oracle):
+    """generic_plc_process + MSConcealerContext (mscommon.c:328-366): concealment starts on the first tick whose packet
+    did not come, one block per tick, and stops when audio is back; blocks arriving in a burst are all forwarded."""
+    rate, n = 8000, 80
+    x = _voiced(3, n * 40, rate)
+    f = oracle.GenericPlcFilter(rate)
+    out_sizes = []
+    k = 0
+    for t in range(30):
+        now = 1000 + 10 * t
+        if 10 <= t < 14:
+            blocks = []                      # four packets lost
+        elif t == 20:
+            blocks = []                      # late ...
+        elif t == 21:
+            blocks = [x[k * n:(k + 1) * n], x[(k + 1) * n:(k + 2) * n]]  # ... then both at once
+            k += 2
+        else:
+            blocks = [x[k * n:(k + 1) * n]]
+            k += 1
+        out = f.tick(now, blocks)
+        out_sizes.append([b.size for b in out])
+    assert out_sizes[9] == [n] and out_sizes[10:14] == [[n]] * 4 and out_sizes[14] == [n]
+    assert out_sizes[20] == [n]        # concealed
+    assert out_sizes[21] == [n, n]     # the burst: both forwarded, no concealment on top (sample_time ran ahead)
+    assert f.con.total_number_for_plc == 5
