@@ -138,6 +138,7 @@ typedef enum MSFilterId {
 	MS_AUDIO_MIXER_ID = 68,
 	MS_L16_ENC_ID = 107,
 	MS_L16_DEC_ID = 108,
+	MS_GENERIC_PLC_ID = 111,
 	MS_AUDIO_FLOW_CONTROL_ID = 141
 } MSFilterId;
 
@@ -231,6 +232,11 @@ typedef struct _MSFactory MSFactory;
 #define MS_CHANNEL_ADAPTER_SET_OUTPUT_NCHANNELS MS_FILTER_METHOD(MS_CHANNEL_ADAPTER_ID, 0, int) /* mschanadapter.h:25-26 */
 #define MS_CHANNEL_ADAPTER_GET_OUTPUT_NCHANNELS MS_FILTER_METHOD(MS_CHANNEL_ADAPTER_ID, 1, int)
 #define MS_DEFAULT_MAX_PTIME 140 /* mscommon.h */
+typedef struct _MSCngData { /* msvaddtx.h:26-29 */
+	int datasize;
+	uint8_t data[32];
+} MSCngData;
+#define MS_GENERIC_PLC_SET_CN MS_FILTER_METHOD(MS_GENERIC_PLC_ID, 0, MSCngData) /* msgenericplc.h:26 */
 #define MS_FILTER_SET_OUTPUT_SAMPLE_RATE MS_FILTER_BASE_METHOD(13, int)
 #define MS_FILTER_SET_OUTPUT_NCHANNELS MS_FILTER_BASE_METHOD(28, int)
 
@@ -432,6 +438,7 @@ extern MSFilterDesc ms_mi355x_ulaw_enc_desc;   /* .id = MS_ULAW_ENC_ID */
 extern MSFilterDesc ms_mi355x_l16_enc_desc;    /* .id = MS_L16_ENC_ID,  replaces src/audiofilters/l16.c:162-174 */
 extern MSFilterDesc ms_mi355x_l16_dec_desc;    /* .id = MS_L16_DEC_ID,  replaces src/audiofilters/l16.c:241-252 */
 extern MSFilterDesc ms_mi355x_channel_adapter_desc;    /* .id = MS_CHANNEL_ADAPTER_ID,    replaces src/audiofilters/chanadapt.c:190-203 */
+extern MSFilterDesc ms_mi355x_generic_plc_desc;        /* .id = MS_GENERIC_PLC_ID,        replaces src/audiofilters/msgenericplc.c:224-248 */
 extern MSFilterDesc ms_mi355x_audio_flow_control_desc; /* .id = MS_AUDIO_FLOW_CONTROL_ID, replaces src/audiofilters/flowcontrol.c:262-277 */
 /* MSScalerDesc (msvideo.h:473-478) backed by the scaler / pixconv kernels; libmsmi355xfilters_init installs
  * it with ms_video_set_scaler_impl (msvideo.c:719-721), so the reference's OWN MSSizeConv / MSPixConv /

@@ -222,3 +222,52 @@ def test_flow_control_graph_follows_the_oracle(host, oracle, strategy):
     want = np.concatenate(want)
     assert want.size == n * nt - 2 * 160  # two completed requests of 10 ms each
     np.testing.assert_array_equal(out.view(np.int16), want)
+
+
+MS_GENERIC_PLC_ID = 111
+PLC_SET_CN = mid(MS_GENERIC_PLC_ID, 0, 36)
+
+
+class CngData(C.Structure):
+    _fields_ = [("datasize", C.c_int), ("data", C.c_uint8 * 32)]
+
+
+@pytest.mark.parametrize("rate", [8000, 16000])
+def test_generic_plc_graph_follows_the_oracle(host, oracle, rate):
+    """source -> MSGenericPLC -> sink with packets missing on some ticks, a late burst and a comfort-noise period:
+    the filter emits what generic_plc_process (msgenericplc.c:59-167) emits, block for block."""
+    n, nt = rate // 100, 60
+    x = synth_pcm(50 + rate // 8000, n * nt, rate=rate, sigma=1500.0)
+    src, plc, snk = host.source(), host.create(MS_GENERIC_PLC_ID), host.sink()
+    assert host.S.ms2shim_filter_name(plc) == b"MSGenericPLC"
+    assert host.call_int(plc, SET_SAMPLE_RATE, rate) == 0 and host.call_int(plc, SET_NCHANNELS, 1) == 0
+    ref = oracle.GenericPlcFilter(rate)
+    lost = set(range(10, 13)) | {20} | set(range(30, 48))   # 30 ms, one packet, 180 ms (fade and silence)
+    late = {25: 26}                                         # tick 25's packet arrives together with tick 26's
+    cn_at = 52
+    want, k = [], [0]
+
+    def feed(t):
+        blocks = []
+        if t == cn_at:
+            assert host.call(plc, PLC_SET_CN, CngData()) == 0
+            ref.set_cn()
+        if t in lost or t in late or t in (cn_at, cn_at + 1):
+            pass
+        else:
+            cnt = 2 if t in late.values() else 1
+            for _ in range(cnt):
+                blocks.append(x[k[0] * n:(k[0] + 1) * n])
+                k[0] += 1
+        for b in blocks:
+            host.push(src, b)
+        want.extend(ref.tick(1000 + 10 * t, blocks))
+
+    out = run_graph(host, [src, plc, snk], feed, nt)
+    for t in range(nt, nt + 3):  # run_graph's three draining ticks: a pump filter keeps concealing through them
+        want.extend(ref.tick(1000 + 10 * t, []))
+    want = np.concatenate(want)
+    got = out.view(np.int16)
+    assert want.size - n <= got.size <= want.size  # the last tick's block is still staged (one tick of latency)
+    np.testing.assert_array_equal(got, want[: got.size])
+    assert ref.con.total_number_for_plc >= 3 + 1 + 18 + 1
