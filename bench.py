@@ -268,6 +268,30 @@ def make_g711_leg(ms, torch, ctx, nstreams=65536, n=480, law=None, encode=False)
     return leg
 
 
+def make_plc_leg(ms, torch, ctx, nstreams=65536, rate=8000, loss=0.05):
+    """MSGenericPLC (msgenericplc.c:59-167) behind a G.711 decoder: one 10 ms block per leg and launch, a fraction `loss`
+    of the legs missing theirs (alternating sets, so every loss is a FIRST loss: window, FFT nb, IFFT 2 nb)."""
+    n = rate // 100
+    plc = ms.PlcBatch(ctx, nstreams, rate, max_block=n)
+    rng = np.random.default_rng(5)
+    ring = 2
+    rows = [torch.from_numpy(synth_pcm_batch(nstreams, n, rate)).cuda() for _ in range(ring)]
+    lens = torch.full((nstreams,), n, dtype=torch.int32, device="cuda")
+    pick = rng.random(nstreams) < 2 * loss
+    half = rng.random(nstreams) < 0.5
+    modes = [torch.from_numpy(np.where(pick & (half == bool(i)), ms.MI_PLC_CONCEAL, ms.MI_PLC_RECEIVED).astype(np.uint8)).cuda()
+             for i in range(ring)]
+
+    def launch(i):
+        plc.process(rows[i], lens, modes[i])
+
+    # per leg: the block in and out, the history write, the continuity buffer both ways
+    leg = Leg(ctx, "plc_kernel", launch, ring, nstreams * (2 * n * 2 + n * 2 + 2 * (2 * rate * 5 // 1000) * 2), nstreams,
+              "leg-ticks (%d samples, %.0f %% lost)" % (n, 100 * loss))
+    leg.keep = (plc, rows, lens, modes)
+    return leg
+
+
 def make_aec_leg(ms, torch, ctx, nstreams=4096):
     """BASELINE configs[2] geometry: 48 kHz, 256-sample frames, 128 ms tail (M=24, N=512), post-filter on."""
     rate, F = 48000, 256

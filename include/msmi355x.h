@@ -353,6 +353,7 @@ typedef struct mi_session_config {
 	int32_t out_codec;    /* as mic_codec: the output leaves as G.711 code words (MSAlawEnc / MSUlawEnc) */
 	int32_t ref_loopback; /* 1: a leg's far-end reference is the mix this session sent it on the previous tick: no upload */
 	int32_t ref_delay_ms; /* MS_ECHO_CANCELLER_SET_DELAY: the reference FIFO starts with this much silence (speexec.c:205-208) */
+	int32_t plc;          /* 1: MSGenericPLC behind the decoder (msgenericplc.c): legs flagged lost for a tick are concealed */
 } mi_session_config;
 #define MI_SESSION_PCM16 0
 #define MI_SESSION_PCMA 1
@@ -366,6 +367,9 @@ int mi_session_tick_bytes(const mi_session *s, int *mic_bytes, int *ref_bytes, i
 /* pinned staging of the NEXT tick, to be filled in place: mic [nstreams][in_rate/100] int16 (or uint8 code words with
  * mic_codec), far-end reference [nstreams][rate/100] int16 (*h_ref = NULL with ref_loopback) */
 int mi_session_acquire(mi_session *s, int16_t **h_mic, int16_t **h_ref);
+/* with cfg.plc: the per-leg event bytes of the tick being filled, [nstreams], preset to MI_PLC_RECEIVED; set a leg to
+ * MI_PLC_CONCEAL when its packet did not arrive (its mic row is then ignored).  Valid between acquire and submit. */
+int mi_session_events(mi_session *s, uint8_t **h_events);
 int mi_session_submit(mi_session *s);
 /* the OLDEST tick in flight: waits for its download, returns the pinned output [nstreams][(out_rate or rate)/100]
  * int16, or uint8 code words with out_codec (valid until three more ticks have been submitted) */

@@ -539,7 +539,7 @@ class SessionConfig(C.Structure):
     _fields_ = [("nstreams", C.c_int32), ("members_per_conference", C.c_int32), ("in_rate", C.c_int32),
                 ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32),
                 ("mic_codec", C.c_int32), ("out_rate", C.c_int32), ("out_codec", C.c_int32),
-                ("ref_loopback", C.c_int32), ("ref_delay_ms", C.c_int32)]
+                ("ref_loopback", C.c_int32), ("ref_delay_ms", C.c_int32), ("plc", C.c_int32)]
 
 
 MI_SESSION_PCM16, MI_SESSION_PCMA, MI_SESSION_PCMU = 0, 1, 2
@@ -551,14 +551,14 @@ class Session(_Batch):
     _destroy = "mi_session_destroy"
 
     def __init__(self, ctx, nstreams, members=32, in_rate=16000, rate=48000, tail_ms=128, agc=True, use_graphs=True,
-                 mic_codec=0, out_rate=0, out_codec=0, ref_loopback=False, ref_delay_ms=0):
+                 mic_codec=0, out_rate=0, out_codec=0, ref_loopback=False, ref_delay_ms=0, plc=False):
         self.ctx = ctx
         cfg = SessionConfig()
         ctx.L.mi_session_default_config(C.byref(cfg))
         cfg.nstreams, cfg.members_per_conference, cfg.in_rate, cfg.rate = nstreams, members, in_rate, rate
         cfg.tail_ms, cfg.agc, cfg.use_graphs = tail_ms, int(agc), int(use_graphs)
         cfg.mic_codec, cfg.out_rate, cfg.out_codec = mic_codec, out_rate, out_codec
-        cfg.ref_loopback, cfg.ref_delay_ms = int(ref_loopback), ref_delay_ms
+        cfg.ref_loopback, cfg.ref_delay_ms, cfg.plc = int(ref_loopback), ref_delay_ms, int(plc)
         h = C.c_void_p()
         check(ctx.L.mi_session_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
@@ -581,6 +581,12 @@ class Session(_Batch):
         pm, pr = C.c_void_p(), C.c_void_p()
         check(self.ctx.L.mi_session_acquire(self.h, C.byref(pm), C.byref(pr)))
         return self._view(pm, self.in_len, self.mic_dtype), (None if self.loopback else self._view(pr, self.len))
+
+    def events(self):
+        """numpy view [n] uint8 of the tick being filled (plc sessions): MI_PLC_RECEIVED preset, set MI_PLC_CONCEAL for lost legs."""
+        pe = C.c_void_p()
+        check(self.ctx.L.mi_session_events(self.h, C.byref(pe)))
+        return np.ctypeslib.as_array(C.cast(pe, C.POINTER(C.c_uint8)), shape=(self.n,))
 
     def submit(self):
         check(self.ctx.L.mi_session_submit(self.h))

@@ -43,7 +43,7 @@ EXPORTS = [
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
     "mi_pixconv_process", "mi_pixconv_process_host",
-    "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples", "mi_session_tick_bytes",
+    "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples", "mi_session_tick_bytes", "mi_session_events",
     "mi_session_acquire", "mi_session_submit", "mi_session_collect", "mi_session_in_flight",
     "mi_session_set_controls", "mi_session_get_levels", "mi_session_reset_streams",
     "mi_g711_decode", "mi_g711_encode", "mi_l16_swap", "mi_chan_adapt",
@@ -202,6 +202,7 @@ def load():
         L.mi_session_destroy.restype = None
         L.mi_session_tick_samples.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         L.mi_session_tick_bytes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.mi_session_events.argtypes = [vp, pp]
         L.mi_session_acquire.argtypes = [vp, pp, pp]
         L.mi_session_submit.argtypes = [vp]
         L.mi_session_collect.argtypes = [vp, pp]

@@ -22,6 +22,9 @@ struct mi_session {
 	int out_len = 0, down_stride = 0;               // samples per tick leaving, row pitch of the down-sampled mix
 	size_t mic_bytes = 0, ref_bytes = 0, out_bytes = 0; // per stream and tick, on the host side
 	mi_resampler *rs = nullptr, *rs_out = nullptr;
+	mi_plc *plc = nullptr;
+	uint8_t *h_ev[SLOTS] = {}, *d_ev[SLOTS] = {};
+	int32_t *d_evlen = nullptr;
 	int16_t *d_pcm = nullptr, *d_down = nullptr, *d_zero = nullptr;
 	int16_t *d_mix[SLOTS] = {}; // the mix at `rate` per slot when it is not what leaves (out_rate / out_codec / loopback)
 	mi_aec *aec = nullptr;
@@ -51,6 +54,10 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 		                         (size_t)s->in_len, s->d_pcm, (size_t)s->in_len, nullptr, s->in_len, (size_t)s->n)) != MI_OK)
 			return rc;
 		mic = s->d_pcm;
+	}
+	if (s->plc) { // MSGenericPLC behind the decoder: lost legs are concealed, the others delayed by 5 ms (edits the rows in place)
+		int16_t *rows = cf.mic_codec ? s->d_pcm : s->d_mic[slot];
+		if ((rc = mi_plc_process(s->plc, rows, (size_t)s->in_len, s->d_evlen, s->d_ev[slot])) != MI_OK) return rc;
 	}
 	if (s->rs) {
 		if ((rc = mi_resampler_process(s->rs, mic, s->in_len, s->in_len, s->d_up, s->up_stride, nullptr)) != MI_OK) return rc;
@@ -120,15 +127,18 @@ void mi_session_destroy(mi_session *s) {
 		if (s->d_ref[i]) mi_dev_free(c, s->d_ref[i]);
 		if (s->d_out[i]) mi_dev_free(c, s->d_out[i]);
 		if (s->d_mix[i]) mi_dev_free(c, s->d_mix[i]);
+		if (s->h_ev[i]) mi_host_free(c, s->h_ev[i]);
+		if (s->d_ev[i]) mi_dev_free(c, s->d_ev[i]);
 		if (s->ev_up[i]) (void)hipEventDestroy(s->ev_up[i]);
 		if (s->ev_done[i]) (void)hipEventDestroy(s->ev_done[i]);
 		if (s->ev_down[i]) (void)hipEventDestroy(s->ev_down[i]);
 	}
-	void *dv[] = {s->d_up, s->d_micf, s->d_reff, s->d_clean, s->d_tick, s->d_ok, s->d_pcm, s->d_down, s->d_zero};
+	void *dv[] = {s->d_up, s->d_micf, s->d_reff, s->d_clean, s->d_tick, s->d_ok, s->d_pcm, s->d_down, s->d_zero, s->d_evlen};
 	for (void *p : dv)
 		if (p) mi_dev_free(c, p);
 	if (s->rs) mi_resampler_destroy(s->rs);
 	if (s->rs_out) mi_resampler_destroy(s->rs_out);
+	if (s->plc) mi_plc_destroy(s->plc);
 	if (s->aec) mi_aec_destroy(s->aec);
 	if (s->vol) mi_volume_destroy(s->vol);
 	if (s->mix) mi_mixer_destroy(s->mix);
@@ -229,6 +239,17 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	if ((s->rs && !s->d_up) || !s->d_micf || !s->d_reff || !s->d_clean || !s->d_tick || !s->d_ok) return fail(MI_ENOMEM);
 	if (cfg->mic_codec && !(s->d_pcm = (int16_t *)mi_dev_alloc(ctx, n * s->in_len * 2))) return fail(MI_ENOMEM);
 	if (s->rs_out && !(s->d_down = (int16_t *)mi_dev_alloc(ctx, n * s->down_stride * 2))) return fail(MI_ENOMEM);
+	if (cfg->plc) {
+		if ((rc = mi_plc_create(ctx, s->n, cfg->in_rate, s->in_len, &s->plc)) != MI_OK) return fail(rc);
+		std::vector<int32_t> lens(n, s->in_len);
+		if (!(s->d_evlen = (int32_t *)mi_dev_alloc(ctx, n * 4))) return fail(MI_ENOMEM);
+		MI_HIP(hipMemcpy(s->d_evlen, lens.data(), n * 4, hipMemcpyHostToDevice));
+		for (int i = 0; i < SLOTS; ++i) {
+			s->h_ev[i] = (uint8_t *)mi_host_alloc(ctx, n);
+			s->d_ev[i] = (uint8_t *)mi_dev_alloc(ctx, n);
+			if (!s->h_ev[i] || !s->d_ev[i]) return fail(MI_ENOMEM);
+		}
+	}
 	if (delay > 0) { // speexec.c:205-208: delay_ms of silence ahead of the reference
 		if (!(s->d_zero = (int16_t *)mi_dev_alloc(ctx, n * (size_t)delay * 2))) return fail(MI_ENOMEM);
 		MI_HIP(hipMemsetAsync(s->d_zero, 0, n * (size_t)delay * 2, ctx->stream));
@@ -266,7 +287,18 @@ int mi_session_acquire(mi_session *s, int16_t **h_mic, int16_t **h_ref) {
 	if (s->used[slot]) MI_HIP(hipEventSynchronize(s->ev_done[slot]));
 	*h_mic = s->h_mic[slot];
 	*h_ref = s->h_ref[slot];
+	if (s->plc) memset(s->h_ev[slot], MI_PLC_RECEIVED, (size_t)s->n);
 	s->acquired = true;
+	return MI_OK;
+}
+
+int mi_session_events(mi_session *s, uint8_t **h_events) {
+	MI_CHECK_ARG(s && h_events);
+	if (!s->plc || !s->acquired) {
+		mi::set_error(s->plc ? "mi_session_events outside acquire .. submit" : "the session was created without plc");
+		return MI_EINVAL;
+	}
+	*h_events = s->h_ev[(int)(s->submitted % SLOTS)];
 	return MI_OK;
 }
 
@@ -283,6 +315,7 @@ int mi_session_submit(mi_session *s) {
 	// upload on its own stream
 	MI_HIP(hipMemcpyAsync(s->d_mic[slot], s->h_mic[slot], n * s->mic_bytes, hipMemcpyHostToDevice, s->s_up));
 	if (s->ref_bytes) MI_HIP(hipMemcpyAsync(s->d_ref[slot], s->h_ref[slot], n * s->ref_bytes, hipMemcpyHostToDevice, s->s_up));
+	if (s->plc) MI_HIP(hipMemcpyAsync(s->d_ev[slot], s->h_ev[slot], n, hipMemcpyHostToDevice, s->s_up));
 	MI_HIP(hipEventRecord(s->ev_up[slot], s->s_up));
 	// kernels wait for this tick's upload and for the download that last read this slot's output buffer
 	MI_HIP(hipStreamWaitEvent(c->stream, s->ev_up[slot], 0));
@@ -356,6 +389,7 @@ int mi_session_reset_streams(mi_session *s, int first, int count) {
 	    (rc = mi_fifo_reset_range(s->f_out, first, count)) != MI_OK)
 		return rc;
 	if (s->rs_out && (rc = mi_resampler_reset(s->rs_out, first, count)) != MI_OK) return rc;
+	if (s->plc && (rc = mi_plc_reset(s->plc, first, count)) != MI_OK) return rc;
 	if (s->cfg.ref_loopback) // the new leg was not sent anything yet
 		for (int i = 0; i < SLOTS; ++i)
 			MI_HIP(hipMemsetAsync(s->d_mix[i] + (size_t)first * s->len, 0, (size_t)count * s->len * 2, s->ctx->stream));

@@ -12,6 +12,8 @@ mk = {"resample": lambda: bench.make_resample_leg(ms, torch, ctx, 4096), "mixer"
       "g711_dec": lambda: bench.make_g711_leg(ms, torch, ctx), "g711_enc": lambda: bench.make_g711_leg(ms, torch, ctx, encode=True),
       "ulaw_dec": lambda: bench.make_g711_leg(ms, torch, ctx, law=ms.MI_LAW_PCMU), "ulaw_enc": lambda: bench.make_g711_leg(ms, torch, ctx, law=ms.MI_LAW_PCMU, encode=True),
       "g711_dec_8k": lambda: bench.make_g711_leg(ms, torch, ctx, n=80),
+      "plc": lambda: bench.make_plc_leg(ms, torch, ctx), "plc_clean": lambda: bench.make_plc_leg(ms, torch, ctx, loss=0.0),
+      "plc_half": lambda: bench.make_plc_leg(ms, torch, ctx, loss=0.5), "plc48": lambda: bench.make_plc_leg(ms, torch, ctx, nstreams=16384, rate=48000),
       "pixconv_rgb": lambda: bench.make_pixconv_leg(ms, torch, ctx, fmt=ms.MI_PIX_BGR24)}
 for w in which:
     lg = mk[w]()

@@ -299,12 +299,12 @@ def test_session_reset_streams_starts_a_leg_over(ctx):
     b.close()
 
 
-@pytest.mark.parametrize("law", [ms.MI_LAW_PCMA, ms.MI_LAW_PCMU])
-def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, law):
+@pytest.mark.parametrize("law,plc", [(ms.MI_LAW_PCMA, False), (ms.MI_LAW_PCMU, False), (ms.MI_LAW_PCMA, True)])
+def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, law, plc):
     """The legs as a SIP trunk delivers them: G.711 at 8 kHz in and out, the far-end reference = what the leg was sent on
     the previous tick (delayed by ref_delay_ms), nothing but 80 + 80 bytes per leg and tick crossing PCIe.  Must equal
     MSAlawDec -> MSResample 8k->48k -> FIFO -> MSSpeexEC -> FIFO -> MSVolume -> MSAudioMixer -> MSResample 48k->8k ->
-    MSAlawEnc built from the individual C ABI objects."""
+    MSAlawEnc built from the individual C ABI objects.  plc: MSGenericPLC behind the decoder, 10 % of the packets lost."""
     torch = pytest.importorskip("torch")
     nconf, mm, nticks, F, rate, delay_ms = 2, 16, 24, 256, 48000, 20
     n = nconf * mm
@@ -327,13 +327,20 @@ def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, la
     pcm, up, micf, reff, clean, tick = z(n, 80), z(n, 488), z(n, F), z(n, F), z(n, F), z(n, 480)
     mixed, prev, down, enc = z(nconf, mm, 480), z(n, 480), z(n, 88), z(n, 80, dt=torch.uint8)
     okm = z(n, dt=torch.uint8)
+    lost = np.random.default_rng(9).random((nticks, n)) < (0.1 if plc else 0.0)
+    lost[:3] = False
+    plcb = ms.PlcBatch(ctx, n, 8000, max_block=80) if plc else None
+    lens80 = torch.full((n,), 80, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     f_ref.push(z(n, delay))
     want = []
     for t in range(nticks):
         d_codes = torch.from_numpy(np.ascontiguousarray(codes[:, t * 80:(t + 1) * 80])).cuda()
+        ev = torch.from_numpy(np.where(lost[t], ms.MI_PLC_CONCEAL, ms.MI_PLC_RECEIVED).astype(np.uint8)).cuda()
         torch.cuda.synchronize()
         ms.g711_decode(ctx, law, d_codes, pcm)
+        if plc:
+            plcb.process(pcm, lens80, ev)
         rs.process(pcm, out=up)
         f_mic.push(up, nsamples=480)
         f_ref.push(prev)
@@ -355,7 +362,7 @@ def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, la
     # ---- the session
     kind = ms.MI_SESSION_PCMA if law == ms.MI_LAW_PCMA else ms.MI_SESSION_PCMU
     se = ms.Session(ctx, n, members=mm, in_rate=8000, rate=rate, tail_ms=128, agc=True, use_graphs=False,
-                    mic_codec=kind, out_rate=8000, out_codec=kind, ref_loopback=True, ref_delay_ms=delay_ms)
+                    mic_codec=kind, out_rate=8000, out_codec=kind, ref_loopback=True, ref_delay_ms=delay_ms, plc=plc)
     assert se.tick_bytes() == (80, 0, 80)
     got = []
     for t in range(nticks):
@@ -364,6 +371,8 @@ def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, la
         h_mic, h_ref = se.acquire()
         assert h_ref is None and h_mic.dtype == np.uint8
         h_mic[:] = codes[:, t * 80:(t + 1) * 80]
+        if plc:
+            se.events()[lost[t]] = ms.MI_PLC_CONCEAL
         se.submit()
     while se.in_flight():
         got.append(se.collect().copy())
