@@ -685,7 +685,7 @@ def main():
                 return make_g711_leg(ms_, torch_, ctx_, encode=True)
 
             for mk in (make_resample_65536, make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg,
-                       make_scaler_leg, make_pixconv_leg, make_g711_leg, make_g711_encode):
+                       make_scaler_leg, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)

@@ -97,7 +97,7 @@ uint32_t orc_msresample_outcap(uint32_t inlen, uint32_t in_rate, uint32_t out_ra
 /* kiss_fft real transforms, float build: src/utils/kiss_fft.c:38-149 (bfly2/4),
  * :320-408 (kf_work), :412-475 (factor/alloc), src/utils/kiss_fftr.c:40-81,
  * :175-259 (kiss_fftr2), :261-296 (kiss_fftri2); wrappers ms_fft/ms_ifft
- * src/utils/dsptools.c:333-376. nfft must be even, factors of 4 and 2 only. */
+ * src/utils/dsptools.c:333-376. nfft must be even; radix 4, 2, 3, 5 and generic (<= 17) stages (kiss_fft.c:150-290). */
 typedef struct OrcFft OrcFft; /* ms_fft_init handle */
 OrcFft *orc_fft_new(int nfft);
 void orc_fft_free(OrcFft *t);

@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "aec" in k or "resample" in k or "scaler" in k or "mixer" in k or "volume" in k or "equalizer" in k or "pixconv" in k or "fifo" in k or "g711" in k:
+    if "aec" in k or "resample" in k or "scaler" in k or "mixer" in k or "volume" in k or "equalizer" in k or "pixconv" in k or "fifo" in k or "g711" in k or "plc" in k:
         print(k)
         for c, v in d.items():
             print("   %-28s n=%4d mean=%.4g" % (c, len(v), sum(v) / len(v)))
