@@ -231,6 +231,13 @@ int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, i
                         const uint8_t *h_run, unsigned flags);
 /* state bytes per stream (for DESIGN/roofline accounting) */
 size_t mi_aec_state_bytes(const mi_aec *a);
+/* One stream's whole state as a host blob, and back: what fetch_config / apply_config (src/audiofilters/speexec.c:119-167)
+ * do with SPEEX_ECHO_GET_BLOB / SET_BLOB of the reference's speex fork, so a converged canceller survives the end of a
+ * call (MS_ECHO_CANCELLER_GET/SET_STATE_STRING).  The format is this library's (the fork's is not published); import checks
+ * rate / frame / tail and refuses a blob of another shape.  A restored stream continues bit for bit. */
+size_t mi_aec_blob_bytes(const mi_aec *a);
+int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap);
+int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size);
 /* debug/parity read-back of one stream's float arrays: "W","foreground","X","power" ... */
 int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap);
 

@@ -318,6 +318,18 @@ class AecBatch(_Batch):
     def state_bytes(self):
         return self.ctx.L.mi_aec_state_bytes(self.h)
 
+    def export_state(self, stream):
+        """One stream's whole state as bytes (speexec.c:145-167 fetch_config)."""
+        n = self.ctx.L.mi_aec_blob_bytes(self.h)
+        buf = np.zeros(n, np.uint8)
+        check(self.ctx.L.mi_aec_export_state(self.h, stream, buf.ctypes.data, n))
+        return buf.tobytes()
+
+    def import_state(self, stream, blob):
+        """speexec.c:121-143 apply_config: raises MiError for a blob of another shape."""
+        buf = np.frombuffer(blob, np.uint8).copy()
+        check(self.ctx.L.mi_aec_import_state(self.h, stream, buf.ctypes.data, buf.size))
+
     def reset(self, first=0, count=None):
         check(self.ctx.L.mi_aec_reset(self.h, first, self.nstreams - first if count is None else count))
 

@@ -637,6 +637,70 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	return n;
 }
 
+// ---- state blob: what SPEEX_ECHO_GET_BLOB / SET_BLOB of the reference's speex fork serve in fetch_config / apply_config
+// (src/audiofilters/speexec.c:119-167): a converged canceller survives the end of a call.  The blob is the stream's whole
+// state (history ring, both filters, the per-bin arrays, the scalars), so a restored stream continues bit for bit.
+namespace {
+struct BlobHeader {
+	char magic[4];
+	uint32_t version, rate, F, M, N, small_stride, scal_bytes;
+};
+} // namespace
+
+size_t mi_aec_blob_bytes(const mi_aec *a) { return a ? sizeof(BlobHeader) + mi_aec_state_bytes(a) : 0; }
+
+int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap) {
+	MI_CHECK_ARG(a && h_blob && stream >= 0 && stream < a->nstreams && cap >= mi_aec_blob_bytes(a));
+	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(a->ctx->stream));
+	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
+	BlobHeader h = {{'M', 'I', 'E', 'C'}, 1u, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
+	uint8_t *p = (uint8_t *)h_blob;
+	memcpy(p, &h, sizeof(h));
+	p += sizeof(h);
+	MI_HIP(hipMemcpy(p, a->d_X + (size_t)stream * xn, xn * 4, hipMemcpyDeviceToHost));
+	p += xn * 4;
+	MI_HIP(hipMemcpy(p, a->d_W + (size_t)stream * wn, wn * 4, hipMemcpyDeviceToHost));
+	p += wn * 4;
+	MI_HIP(hipMemcpy(p, a->d_FG + (size_t)stream * wn, wn * 4, hipMemcpyDeviceToHost));
+	p += wn * 4;
+	MI_HIP(hipMemcpy(p, a->d_small + (size_t)stream * sn, sn * 4, hipMemcpyDeviceToHost));
+	p += sn * 4;
+	MI_HIP(hipMemcpy(p, a->d_scal + stream, sizeof(AecScalars), hipMemcpyDeviceToHost));
+	return MI_OK;
+}
+
+int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) {
+	MI_CHECK_ARG(a && h_blob && stream >= 0 && stream < a->nstreams);
+	BlobHeader h;
+	if (size < sizeof(h)) {
+		mi::set_error("mi_aec_import_state: blob of %zu bytes is too short", size);
+		return MI_EINVAL;
+	}
+	memcpy(&h, h_blob, sizeof(h));
+	if (memcmp(h.magic, "MIEC", 4) != 0 || h.version != 1 || h.rate != (uint32_t)a->rate || h.F != (uint32_t)a->F || h.M != (uint32_t)a->M ||
+	    h.N != (uint32_t)a->N || h.small_stride != (uint32_t)a->small_stride || h.scal_bytes != sizeof(AecScalars) ||
+	    size != mi_aec_blob_bytes(a)) {
+		mi::set_error("mi_aec_import_state: the blob was taken from a canceller of another shape (rate %u, frame %u, %u blocks) or is damaged",
+		              h.rate, h.F, h.M);
+		return MI_EINVAL;
+	}
+	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(a->ctx->stream));
+	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
+	const uint8_t *p = (const uint8_t *)h_blob + sizeof(h);
+	MI_HIP(hipMemcpy(a->d_X + (size_t)stream * xn, p, xn * 4, hipMemcpyHostToDevice));
+	p += xn * 4;
+	MI_HIP(hipMemcpy(a->d_W + (size_t)stream * wn, p, wn * 4, hipMemcpyHostToDevice));
+	p += wn * 4;
+	MI_HIP(hipMemcpy(a->d_FG + (size_t)stream * wn, p, wn * 4, hipMemcpyHostToDevice));
+	p += wn * 4;
+	MI_HIP(hipMemcpy(a->d_small + (size_t)stream * sn, p, sn * 4, hipMemcpyHostToDevice));
+	p += sn * 4;
+	MI_HIP(hipMemcpy(a->d_scal + stream, p, sizeof(AecScalars), hipMemcpyHostToDevice));
+	return MI_OK;
+}
+
 // debug entry (not in the public header): raw transform parity
 int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int inverse) {
 	MI_CHECK_ARG(a && d_in && d_out && nframes > 0);

@@ -1478,6 +1478,45 @@ void ec_configure_flow(SpeexECState *s) { // speexec.c:182-186
 	s->ref.max_size_ms = (uint32_t)s->delay_ms;
 	s->ref.granularity_ms = (uint32_t)((s->framesize * 1000) / s->samplerate);
 }
+// ---- the canceller's state as a string: fetch_config / apply_config, speexec.c:119-167 (there a SpeexEchoStateBlob of the
+// speex fork through bctbx_base64_*; here the blob of mi_aec_export_state through a local RFC 4648 codec)
+const char kB64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+char *b64_encode(const uint8_t *p, size_t n) {
+	char *out = (char *)ms_malloc0(4 * ((n + 2) / 3) + 1), *o = out;
+	for (size_t i = 0; i < n; i += 3) {
+		const uint32_t v = ((uint32_t)p[i] << 16) | ((i + 1 < n ? (uint32_t)p[i + 1] : 0u) << 8) | (i + 2 < n ? (uint32_t)p[i + 2] : 0u);
+		*o++ = kB64[(v >> 18) & 63];
+		*o++ = kB64[(v >> 12) & 63];
+		*o++ = i + 1 < n ? kB64[(v >> 6) & 63] : '=';
+		*o++ = i + 2 < n ? kB64[v & 63] : '=';
+	}
+	*o = 0;
+	return out;
+}
+bool b64_decode(const char *txt, std::vector<uint8_t> &out) {
+	int8_t rev[256];
+	memset(rev, -1, sizeof(rev));
+	for (int i = 0; i < 64; ++i) rev[(uint8_t)kB64[i]] = (int8_t)i;
+	out.clear();
+	uint32_t acc = 0;
+	int bits = 0;
+	for (const char *c = txt; *c && *c != '='; ++c) {
+		if (*c == '\n' || *c == '\r' || *c == ' ') continue;
+		const int v = rev[(uint8_t)*c];
+		if (v < 0) return false;
+		acc = (acc << 6) | (uint32_t)v;
+		bits += 6;
+		if (bits >= 8) {
+			bits -= 8;
+			out.push_back((uint8_t)(acc >> bits));
+		}
+	}
+	return true;
+}
+struct SpeexECState;
+void ec_apply_config(SpeexECState *s);
+void ec_fetch_config(SpeexECState *s);
+
 void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	SpeexECState *s = (SpeexECState *)f->data;
 	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
@@ -1515,7 +1554,30 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	m->b_wptr += delay_samples * 2;
 	ms_bufferizer_put(&s->delayed_ref, m);
 	s->nominal_ref_samples = delay_samples;
-	if (s->state_str) ms_warning("mi355x echo canceller: state restoration (SPEEX_ECHO_SET_BLOB) is not supported");
+	ec_apply_config(s); // :209-211
+}
+void ec_apply_config(SpeexECState *s) { // :121-143
+	if (s->state_str == NULL || s->pool == nullptr) return;
+	std::vector<uint8_t> blob;
+	if (!b64_decode(s->state_str, blob)) {
+		ms_error("Could not decode base64 %.32s...", s->state_str);
+		return;
+	}
+	if (mi_aec_import_state(s->pool->a, s->slot, blob.data(), blob.size()) != MI_OK) {
+		ms_error("Could not apply mi355x echo blob: %s", mi_last_error()); // e.g. saved at another rate or tail length
+		return;
+	}
+	ms_message("mi355x echo state restored.");
+}
+void ec_fetch_config(SpeexECState *s) { // :145-167
+	if (s->pool == nullptr) return;
+	std::vector<uint8_t> blob(mi_aec_blob_bytes(s->pool->a));
+	if (mi_aec_export_state(s->pool->a, s->slot, blob.data(), blob.size()) != MI_OK) {
+		ms_error("Could not retrieve mi355x echo blob: %s", mi_last_error());
+		return;
+	}
+	if (s->state_str) ms_free(s->state_str);
+	s->state_str = b64_encode(blob.data(), blob.size());
 }
 void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at detach
 	SpeexECState *s = (SpeexECState *)f->data;
@@ -1640,15 +1702,21 @@ int ec_get_bypass_mode(MSFilter *f, void *arg) {
 	*(bool_t *)arg = ((SpeexECState *)f->data)->bypass_mode;
 	return 0;
 }
-int ec_set_state(MSFilter *f, void *arg) { // :361-365
+int ec_set_state(MSFilter *f, void *arg) { // :361-365 (the previous string leaks there; freed here)
 	SpeexECState *s = (SpeexECState *)f->data;
 	const size_t n = strlen((const char *)arg) + 1;
+	if (s->state_str) ms_free(s->state_str);
 	s->state_str = (char *)ms_malloc0(n);
 	memcpy(s->state_str, arg, n);
 	return 0;
 }
-int ec_get_state(MSFilter *f, void *arg) { // :367-374
-	*(char **)arg = ((SpeexECState *)f->data)->state_str;
+int ec_get_state(MSFilter *f, void *arg) { // :367-374: the CURRENT state while attached, the stored string otherwise
+	SpeexECState *s = (SpeexECState *)f->data;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		ec_fetch_config(s);
+	}
+	*(char **)arg = s->state_str;
 	return 0;
 }
 int ec_get_delay(MSFilter *f, void *arg) {

@@ -186,3 +186,42 @@ def test_aec_full_size_4096_streams(ctx, oracle):
         for s, e in ecs.items():
             np.testing.assert_array_equal(out[s], e.cancel(mic[s, sl], far[s, sl]), err_msg=f"frame {f} stream {s}")
     aec.close()
+
+
+@pytest.mark.parametrize("rate,F", [(16000, 128), (48000, 256)])
+def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
+    """fetch_config / apply_config (speexec.c:119-167): a stream's state is exported, imported into another stream of
+    another batch, and both continue identically -- canceller and post-filter state included."""
+    flen = 128 * rate // 1000
+    nfr = 120
+    mic, far = make_echo_scene(3, rate, F * nfr)
+    a = ms.AecBatch(ctx, 2, rate, frame_size=F, filter_length=flen)
+    m2, f2 = np.stack([mic, mic]), np.stack([far, far])
+    fl = ms.MI_AEC_POSTFILTER
+    for f in range(80):
+        sl = slice(f * F, (f + 1) * F)
+        a.process(np.ascontiguousarray(m2[:, sl]), np.ascontiguousarray(f2[:, sl]), flags=fl)
+    blob = a.export_state(1)
+    assert len(blob) == a.state_bytes() + 32
+    b = ms.AecBatch(ctx, 3, rate, frame_size=F, filter_length=flen)
+    b.import_state(2, blob)
+    m3, f3 = np.stack([mic] * 3), np.stack([far] * 3)
+    cold_err, warm_err = 0.0, 0.0
+    for f in range(80, nfr):
+        sl = slice(f * F, (f + 1) * F)
+        oa = a.process(np.ascontiguousarray(m2[:, sl]), np.ascontiguousarray(f2[:, sl]), flags=fl)
+        ob = b.process(np.ascontiguousarray(m3[:, sl]), np.ascontiguousarray(f3[:, sl]), flags=fl)
+        np.testing.assert_array_equal(ob[2], oa[1], err_msg=f"frame {f}")   # restored == never interrupted
+        cold_err += float((ob[0].astype(float) ** 2).sum())
+        warm_err += float((ob[2].astype(float) ** 2).sum())
+    assert warm_err < 0.5 * cold_err  # and it pays: the cold stream is still converging
+    # a blob of another shape is refused, a damaged one too
+    c = ms.AecBatch(ctx, 1, rate, frame_size=F, filter_length=flen // 2)
+    with pytest.raises(ms.MiError):
+        c.import_state(0, blob)
+    with pytest.raises(ms.MiError):
+        b.import_state(0, blob[:-4])
+    with pytest.raises(ms.MiError):
+        b.import_state(0, b"XXXX" + blob[4:])
+    for x in (a, b, c):
+        x.close()

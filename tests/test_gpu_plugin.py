@@ -506,3 +506,50 @@ def test_overlong_blocks_are_split_not_dropped(host, oracle):
     want = (np.abs(x.astype(np.int64)) * 1024 // 4096 * np.sign(x)).astype(np.int16)
     np.testing.assert_array_equal(got, want)
     host.S.ms_ticker_detach(host.ticker, src)
+
+
+def test_speex_ec_state_string_carries_convergence_over(host):
+    """MS_ECHO_CANCELLER_GET_STATE_STRING / SET_STATE_STRING (speexec.c:361-374 with fetch_config / apply_config :119-167):
+    the string taken from a converged canceller, given to a NEW filter before it is attached, makes that one start
+    converged; a string that does not fit (another tail length) is refused with an error and the filter starts cold."""
+    rate, ns, nt = 16000, 160, 150
+    GET_STATE, SET_STATE = mid(EC_IFACE, 5, 8), mid(EC_IFACE, 6, 1)
+    rng = np.random.default_rng(8)
+    far = np.clip(np.round(rng.normal(0, 3000, ns * nt)), -32767, 32767).astype(np.int16)
+    ir = rng.normal(0, 1, 48) * np.exp(-np.arange(48) / 10.0)
+    mic = np.clip(np.round(0.4 * np.convolve(far.astype(float), ir)[:ns * nt] + rng.normal(0, 30, ns * nt)), -32767, 32767).astype(np.int16)
+
+    def run(state=None, tail=128, ticks=nt):
+        ec = host.create(MS_SPEEX_EC_ID)
+        assert host.call_int(ec, SET_SAMPLE_RATE, rate) == 0 and host.call_int(ec, mid(EC_IFACE, 2, 4), tail) == 0
+        if state is not None:
+            assert host.S.ms_filter_call_method(ec, SET_STATE, C.c_char_p(state)) == 0
+        s_ref, s_mic, k_ref, k_mic = host.source(), host.source(), host.sink(), host.sink()
+        host.link(s_ref, 0, ec, 0)
+        host.link(s_mic, 0, ec, 1)
+        host.link(ec, 0, k_ref, 0)
+        host.link(ec, 1, k_mic, 0)
+        host.S.ms_ticker_attach(host.ticker, ec)
+        for t in range(ticks):
+            host.push(s_ref, far[t * ns:(t + 1) * ns])
+            host.push(s_mic, mic[t * ns:(t + 1) * ns])
+            host.step()
+        host.step(2)
+        p = C.c_char_p()
+        assert host.S.ms_filter_call_method(ec, GET_STATE, C.byref(p)) == 0
+        txt = p.value
+        out = host.drain(k_mic)
+        host.S.ms_ticker_detach(host.ticker, ec)
+        return out, txt
+
+    out_cold, state = run()
+    assert state and len(state) > 10000 and set(state) <= set(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/=")
+    head = slice(ns * 5, ns * 45)  # the first 400 ms after start-up
+    e_mic = float((mic[head].astype(float) ** 2).mean())
+    e_cold = float((out_cold[head].astype(float) ** 2).mean())
+    out_warm, _ = run(state=state, ticks=50)
+    e_warm = float((out_warm[head].astype(float) ** 2).mean())
+    assert e_warm < 0.1 * e_cold and e_warm < 0.05 * e_mic   # converged from the first frames (-13 dB or better at once)
+    out_bad, _ = run(state=state, tail=64, ticks=50)       # the blob is for 128 ms: refused, cold start
+    e_bad = float((out_bad[head].astype(float) ** 2).mean())
+    assert e_bad > 5 * e_warm
