@@ -299,8 +299,9 @@ def test_session_reset_streams_starts_a_leg_over(ctx):
     b.close()
 
 
-@pytest.mark.parametrize("law,plc", [(ms.MI_LAW_PCMA, False), (ms.MI_LAW_PCMU, False), (ms.MI_LAW_PCMA, True)])
-def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, law, plc):
+@pytest.mark.parametrize("law,plc,graphs", [(ms.MI_LAW_PCMA, False, False), (ms.MI_LAW_PCMU, False, False),
+                                            (ms.MI_LAW_PCMA, True, False), (ms.MI_LAW_PCMU, True, True)])
+def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, law, plc, graphs):
     """The legs as a SIP trunk delivers them: G.711 at 8 kHz in and out, the far-end reference = what the leg was sent on
     the previous tick (delayed by ref_delay_ms), nothing but 80 + 80 bytes per leg and tick crossing PCIe.  Must equal
     MSAlawDec -> MSResample 8k->48k -> FIFO -> MSSpeexEC -> FIFO -> MSVolume -> MSAudioMixer -> MSResample 48k->8k ->
@@ -361,7 +362,7 @@ def test_session_trunk_mode_equals_the_chain_called_step_by_step(ctx, oracle, la
         want.append(enc.cpu().numpy().copy())
     # ---- the session
     kind = ms.MI_SESSION_PCMA if law == ms.MI_LAW_PCMA else ms.MI_SESSION_PCMU
-    se = ms.Session(ctx, n, members=mm, in_rate=8000, rate=rate, tail_ms=128, agc=True, use_graphs=False,
+    se = ms.Session(ctx, n, members=mm, in_rate=8000, rate=rate, tail_ms=128, agc=True, use_graphs=graphs,
                     mic_codec=kind, out_rate=8000, out_codec=kind, ref_loopback=True, ref_delay_ms=delay_ms, plc=plc)
     assert se.tick_bytes() == (80, 0, 80)
     got = []
