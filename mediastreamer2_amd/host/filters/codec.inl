@@ -1,0 +1,499 @@
+// filters/codec.inl -- G.711 / L16 / MSChannelAdapter facades (src/audiofilters/alaw.c, ulaw.c, l16.c, chanadapt.c).
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the pool / hub
+// infrastructure); not compiled on its own.
+
+// ============================================ codecs, channel adapter, flow control
+// Element-wise stages.  Every block any instance stages during a tick is packed, 16-element aligned, into ONE flat
+// buffer per (ticker, operation): a tick of any number of decoders is one copy in, one launch, one copy out.
+enum MapOp { OP_ALAW_DEC, OP_ULAW_DEC, OP_ALAW_ENC, OP_ULAW_ENC, OP_L16_SWAP, OP_MONO_TO_STEREO, OP_STEREO_TO_MONO, OP_TWO_MONO_TO_STEREO, OP_COUNT };
+struct MapOpInfo {
+	size_t in_bpe, out_bpe; // bytes per element (code word / sample / frame) on either side
+};
+const MapOpInfo kMapOps[OP_COUNT] = {{1, 2}, {1, 2}, {2, 1}, {2, 1}, {2, 2}, {2, 4}, {4, 2}, {2, 4}};
+
+struct MapBlock {
+	size_t off, n; // element offset into the flat buffers, element count
+	mblk_t *meta;  // the input block when its meta data travel with the samples (decoders, L16 decoder), else NULL
+	uint32_t ts;   // timestamp the encoders stamp (alaw.c:84-85, l16.c:89-91)
+	bool set_ts;
+};
+
+struct MapPool : Pool {
+	MapOp op;
+	size_t cap, used = 0; // elements
+	uint8_t *h_in, *h_in2 = nullptr, *h_out, *d_in, *d_in2 = nullptr, *d_out;
+	std::vector<std::vector<MapBlock>> staged, ready;
+	explicit MapPool(MapOp o) : op(o) {
+		init_slots(g_hub.capacity);
+		cap = (size_t)capacity * kMaxRounds * 1024; // elements; a pool that fills up flushes early (reserve())
+		const MapOpInfo &k = kMapOps[op];
+		h_in = pinned<uint8_t>(cap * k.in_bpe);
+		h_out = pinned<uint8_t>(cap * k.out_bpe);
+		d_in = devmem<uint8_t>(cap * k.in_bpe);
+		d_out = devmem<uint8_t>(cap * k.out_bpe);
+		if (op == OP_TWO_MONO_TO_STEREO) {
+			h_in2 = pinned<uint8_t>(cap * k.in_bpe);
+			d_in2 = devmem<uint8_t>(cap * k.in_bpe);
+		}
+		staged.resize((size_t)capacity);
+		ready.resize((size_t)capacity);
+	}
+	// room for n elements of `slot`; the caller fills n * in_bpe bytes at the returned address (and at *second)
+	uint8_t *reserve(int slot, size_t n, mblk_t *meta, bool set_ts, uint32_t ts, uint8_t **second = nullptr) {
+		const size_t need = (n + 15) & ~(size_t)15;
+		if (need > cap) return nullptr;
+		if (used + need > cap) { // full: what is staged goes out now, one tick early
+			flush();
+			emit_all();
+		}
+		staged[(size_t)slot].push_back(MapBlock{used, n, meta, ts, set_ts});
+		uint8_t *p = h_in + used * kMapOps[op].in_bpe;
+		if (second) *second = h_in2 + used * kMapOps[op].in_bpe;
+		used += need;
+		return p;
+	}
+	void flush() override {
+		if (used) {
+			mi_ctx *ctx = g_hub.context();
+			const MapOpInfo &k = kMapOps[op];
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, used * k.in_bpe));
+			if (d_in2) MI_MUST(mi_copy_h2d(ctx, d_in2, h_in2, used * k.in_bpe));
+			switch (op) {
+			case OP_ALAW_DEC:
+			case OP_ULAW_DEC:
+				MI_MUST(mi_g711_decode(ctx, op == OP_ALAW_DEC ? MI_LAW_PCMA : MI_LAW_PCMU, d_in, used, (int16_t *)d_out, used, nullptr, (int)used, 1));
+				break;
+			case OP_ALAW_ENC:
+			case OP_ULAW_ENC:
+				MI_MUST(mi_g711_encode(ctx, op == OP_ALAW_ENC ? MI_LAW_PCMA : MI_LAW_PCMU, (const int16_t *)d_in, used, d_out, used, nullptr, (int)used, 1));
+				break;
+			case OP_L16_SWAP:
+				MI_MUST(mi_l16_swap(ctx, (const int16_t *)d_in, (int16_t *)d_out, used));
+				break;
+			case OP_MONO_TO_STEREO:
+				MI_MUST(mi_chan_adapt(ctx, MI_CHAN_MONO_TO_STEREO, (const int16_t *)d_in, nullptr, (int16_t *)d_out, used));
+				break;
+			case OP_STEREO_TO_MONO:
+				MI_MUST(mi_chan_adapt(ctx, MI_CHAN_STEREO_TO_MONO, (const int16_t *)d_in, nullptr, (int16_t *)d_out, used));
+				break;
+			case OP_TWO_MONO_TO_STEREO:
+				MI_MUST(mi_chan_adapt(ctx, MI_CHAN_TWO_MONO_TO_STEREO, (const int16_t *)d_in, (const int16_t *)d_in2, (int16_t *)d_out, used));
+				break;
+			default:
+				break;
+			}
+			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, used * k.out_bpe));
+			MI_MUST(mi_ctx_sync(ctx));
+		}
+		for (int s = 0; s < capacity; ++s) {
+			auto &st = staged[(size_t)s], &rd = ready[(size_t)s];
+			rd.insert(rd.end(), st.begin(), st.end());
+			st.clear();
+		}
+		used = 0;
+	}
+	void emit(MSFilter *f, int slot) override {
+		const size_t bpe = kMapOps[op].out_bpe;
+		for (const MapBlock &b : ready[(size_t)slot]) {
+			mblk_t *o = allocb(b.n * bpe, 0);
+			memcpy(o->b_wptr, h_out + b.off * bpe, b.n * bpe);
+			o->b_wptr += b.n * bpe;
+			if (b.meta) {
+				mblk_meta_copy(b.meta, o);
+				freemsg(b.meta);
+			}
+			if (b.set_ts) mblk_set_timestamp_info(o, b.ts);
+			if (f->outputs[0]) ms_queue_put(f->outputs[0], o);
+			else freemsg(o);
+		}
+		ready[(size_t)slot].clear();
+	}
+	void drop_slot(int slot) {
+		for (auto *v : {&staged[(size_t)slot], &ready[(size_t)slot]}) {
+			for (MapBlock &b : *v)
+				if (b.meta) freemsg(b.meta);
+			v->clear();
+		}
+	}
+};
+std::map<std::pair<MSTicker *, int>, MapPool *> g_map_pools;
+
+struct MapFilter { // AlawEncData alaw.c:25-30 / EncState l16.c:22-29 / AdapterState chanadapt.c:29-38, one shape for all
+	MapPool *pool;
+	int slot;
+	MSBufferizer *bz; // encoders re-frame to ptime
+	int law;          // 0 A-law, 1 mu-law
+	int ptime, maxptime;
+	uint32_t ts;
+	int rate, nchannels, out_nchannels;
+	size_t nbytes;      // L16 encoder packet size
+	size_t buffer_size; // channel adapter, two-input mode: bytes per tick and side
+	FlowBuf *side[2];
+};
+
+MapFilter *map_new(MSFilter *f) {
+	MapFilter *d = (MapFilter *)ms_malloc0(sizeof(MapFilter));
+	d->slot = -1;
+	d->rate = 8000;
+	d->nchannels = d->out_nchannels = 1;
+	f->data = d;
+	return d;
+}
+
+void map_release(MapFilter *d) {
+	if (!d->pool) return;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	d->pool->drop_slot(d->slot);
+	d->pool->release(d->slot);
+	d->pool = nullptr;
+	d->slot = -1;
+}
+
+// the pool of (this ticker, op) and a slot in it; false when the pool is exhausted
+bool map_attach(MSFilter *f, MapFilter *d, MapOp op) {
+	if (d->pool && d->pool->op == op && d->pool->ticker == f->ticker) return true;
+	map_release(d);
+	auto key = std::make_pair(f->ticker, (int)op);
+	auto it = g_map_pools.find(key);
+	if (it == g_map_pools.end()) {
+		MapPool *p = new MapPool(op);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_map_pools.emplace(key, p).first;
+	}
+	const int sl = it->second->acquire(f);
+	if (sl < 0) return false;
+	d->pool = it->second;
+	d->slot = sl;
+	return true;
+}
+
+void map_uninit(MSFilter *f) {
+	MapFilter *d = (MapFilter *)f->data;
+	map_release(d);
+	if (d->bz) ms_bufferizer_destroy(d->bz);
+	ms_free(d);
+}
+
+// copies a (possibly chained) block's payload: what msgpullup(m, -1) would make contiguous (alaw.c:211)
+void copy_payload(const mblk_t *m, uint8_t *dst) {
+	for (; m; m = m->b_cont) {
+		const size_t n = (size_t)(m->b_wptr - m->b_rptr);
+		memcpy(dst, m->b_rptr, n);
+		dst += n;
+	}
+}
+
+// ---- G.711 decoders: alaw_dec_process alaw.c:208-221 (ulaw.c the same with Snack_Mulaw2Lin)
+void g711_dec_init_a(MSFilter *f) { map_new(f)->law = 0; }
+void g711_dec_init_u(MSFilter *f) { map_new(f)->law = 1; }
+void g711_dec_process(MSFilter *f) {
+	MapFilter *d = (MapFilter *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!map_attach(f, d, d->law ? OP_ULAW_DEC : OP_ALAW_DEC)) {
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	mblk_t *m;
+	bool any = false;
+	while ((m = ms_queue_get(f->inputs[0])) != NULL) {
+		const size_t n = msgdsize(m);
+		uint8_t *dst = n ? d->pool->reserve(d->slot, n, m, false, 0) : nullptr;
+		if (!dst) { // empty (or absurdly large) packet: the reference emits an empty block for the former
+			if (n == 0) {
+				mblk_t *o = allocb(0, 0);
+				mblk_meta_copy(m, o);
+				ms_queue_put(f->outputs[0], o);
+			} else ms_error("msmi355x plugin: %s: packet of %zu bytes refused", f->desc->name, n);
+			freemsg(m);
+			continue;
+		}
+		copy_payload(m, dst);
+		any = true;
+	}
+	if (any) request_flush(f);
+}
+
+// ---- G.711 encoders: alaw_enc_process alaw.c:56-90
+void g711_enc_new(MSFilter *f, int law) { // alaw_enc_data_new alaw.c:32-39
+	MapFilter *d = map_new(f);
+	d->law = law;
+	d->bz = ms_bufferizer_new();
+	d->ptime = 0;
+	d->maxptime = std::min(MS_DEFAULT_MAX_PTIME, 140);
+}
+void g711_enc_init_a(MSFilter *f) { g711_enc_new(f, 0); }
+void g711_enc_init_u(MSFilter *f) { g711_enc_new(f, 1); }
+void g711_enc_process(MSFilter *f) {
+	MapFilter *d = (MapFilter *)f->data;
+	int frame_per_packet = 2;
+	if (d->ptime >= 10) frame_per_packet = d->ptime / 10;
+	if (frame_per_packet <= 0) frame_per_packet = 1;
+	if (frame_per_packet > 14) frame_per_packet = 14; // 140 ms max (:68-69)
+	const size_t size_of_pcm = (size_t)160 * (size_t)frame_per_packet;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
+	if (ms_bufferizer_get_avail(d->bz) < size_of_pcm) return;
+	if (!map_attach(f, d, d->law ? OP_ULAW_ENC : OP_ALAW_ENC)) {
+		ms_bufferizer_flush(d->bz);
+		return;
+	}
+	while (ms_bufferizer_get_avail(d->bz) >= size_of_pcm) {
+		uint8_t *dst = d->pool->reserve(d->slot, size_of_pcm / 2, nullptr, true, d->ts);
+		if (!dst) break;
+		ms_bufferizer_read(d->bz, dst, size_of_pcm);
+		d->ts += (uint32_t)(size_of_pcm / 2);
+	}
+	request_flush(f);
+}
+
+// "key=value" out of an fmtp line "a=1;key=value; b=2" (what oRTP's fmtp_get_value does for the callers in alaw.c:92-105)
+bool fmtp_value(const char *fmtp, const char *key, char *out, size_t cap) {
+	const size_t klen = strlen(key);
+	for (const char *p = fmtp; p && *p;) {
+		while (*p == ' ' || *p == ';' || *p == '\t') ++p;
+		const char *end = strchr(p, ';');
+		const size_t len = end ? (size_t)(end - p) : strlen(p);
+		if (len > klen && strncmp(p, key, klen) == 0 && p[klen] == '=') {
+			const size_t vlen = std::min(len - klen - 1, cap - 1);
+			memcpy(out, p + klen + 1, vlen);
+			out[vlen] = 0;
+			return true;
+		}
+		p = end;
+	}
+	return false;
+}
+int g711_enc_add_fmtp(MSFilter *f, void *arg) { // alaw.c:92-105
+	MapFilter *d = (MapFilter *)f->data;
+	char tmp[30];
+	if (fmtp_value((const char *)arg, "maxptime", tmp, sizeof(tmp))) d->maxptime = std::min(atoi(tmp), MS_DEFAULT_MAX_PTIME);
+	if (fmtp_value((const char *)arg, "ptime", tmp, sizeof(tmp))) d->ptime = std::min(atoi(tmp), d->maxptime);
+	return 0;
+}
+int g711_enc_add_attr(MSFilter *f, void *arg) { // alaw.c:107-140: the first of "ptime:10", "ptime:20", .. "ptime:140" found anywhere in the line
+	MapFilter *d = (MapFilter *)f->data;
+	for (int v = 10; v <= 140; v += 10) { // in this order, so "ptime:100" already matches "ptime:10", exactly as there
+		char key[16];
+		snprintf(key, sizeof(key), "ptime:%d", v);
+		if (strstr((const char *)arg, key) != NULL) {
+			d->ptime = v;
+			break;
+		}
+	}
+	return 0;
+}
+int g711_get_sr(MSFilter *, void *arg) {
+	*(int *)arg = 8000;
+	return 0;
+}
+int g711_get_nch(MSFilter *, void *arg) {
+	*(int *)arg = 1;
+	return 0;
+}
+int g711_have_plc(MSFilter *, void *arg) {
+	*(int *)arg = 0;
+	return 0;
+}
+int g711_get_ptime(MSFilter *f, void *arg) {
+	*(int *)arg = ((MapFilter *)f->data)->ptime;
+	return 0;
+}
+MSFilterMethod g711_enc_methods[] = {{MS_FILTER_ADD_ATTR, g711_enc_add_attr}, {MS_FILTER_ADD_FMTP, g711_enc_add_fmtp},
+                                     {MS_FILTER_GET_NCHANNELS, g711_get_nch}, {MS_FILTER_GET_SAMPLE_RATE, g711_get_sr},
+                                     {MS_AUDIO_ENCODER_GET_PTIME, g711_get_ptime}, {0, NULL}};
+MSFilterMethod g711_dec_methods[] = {{MS_FILTER_GET_NCHANNELS, g711_get_nch}, {MS_FILTER_GET_SAMPLE_RATE, g711_get_sr},
+                                     {MS_DECODER_HAVE_PLC, g711_have_plc}, {0, NULL}};
+
+// ---- L16: enc_process l16.c:76-93, dec_process :192-199
+void l16_enc_init(MSFilter *f) { // :31-39
+	MapFilter *d = map_new(f);
+	d->bz = ms_bufferizer_new();
+	d->ptime = 10;
+}
+void l16_enc_update(MapFilter *d) { d->nbytes = (size_t)((2 * d->nchannels * d->rate * d->ptime) / 1000); } // :48-50
+void l16_enc_preprocess(MSFilter *f) { l16_enc_update((MapFilter *)f->data); }
+void l16_enc_process(MSFilter *f) {
+	MapFilter *d = (MapFilter *)f->data;
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
+	if (d->nbytes >= 2 && ms_bufferizer_get_avail(d->bz) >= d->nbytes) {
+		if (!map_attach(f, d, OP_L16_SWAP)) ms_bufferizer_flush(d->bz);
+		while (d->pool && ms_bufferizer_get_avail(d->bz) >= d->nbytes) {
+			uint8_t *dst = d->pool->reserve(d->slot, d->nbytes / 2, nullptr, true, d->ts);
+			if (!dst) break;
+			ms_bufferizer_read(d->bz, dst, d->nbytes);
+			d->ts += (uint32_t)(d->nbytes / (2 * (size_t)d->nchannels));
+		}
+		request_flush(f);
+	}
+	ms_filter_unlock(f);
+}
+void l16_set_ptime(MapFilter *d, int value) { // :95-101
+	if (value > 0 && value <= 100) {
+		d->ptime = value;
+		l16_enc_update(d);
+	}
+}
+int l16_enc_add_attr(MSFilter *f, void *arg) { // :103-112 (reads the number right after the first six characters, as there)
+	const char *fmtp = (const char *)arg;
+	if (strstr(fmtp, "ptime:")) {
+		ms_filter_lock(f);
+		l16_set_ptime((MapFilter *)f->data, atoi(fmtp + 6));
+		ms_filter_unlock(f);
+	}
+	return 0;
+}
+int l16_enc_add_fmtp(MSFilter *f, void *arg) { // :114-124
+	char tmp[16] = {0};
+	if (fmtp_value((const char *)arg, "ptime", tmp, sizeof(tmp))) {
+		ms_filter_lock(f);
+		l16_set_ptime((MapFilter *)f->data, atoi(tmp));
+		ms_filter_unlock(f);
+	}
+	return 0;
+}
+void l16_dec_init(MSFilter *f) { map_new(f); }
+void l16_dec_process(MSFilter *f) {
+	MapFilter *d = (MapFilter *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!map_attach(f, d, OP_L16_SWAP)) {
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	mblk_t *m;
+	bool any = false;
+	while ((m = ms_queue_get(f->inputs[0])) != NULL) {
+		const size_t n = msgdsize(m) / 2;
+		uint8_t *dst = n ? d->pool->reserve(d->slot, n, m, false, 0) : nullptr;
+		if (!dst) {
+			if (n == 0) ms_queue_put(f->outputs[0], m);
+			else freemsg(m);
+			continue;
+		}
+		std::vector<uint8_t> flat(msgdsize(m));
+		copy_payload(m, flat.data());
+		memcpy(dst, flat.data(), n * 2);
+		any = true;
+	}
+	if (any) request_flush(f);
+}
+int map_set_sr(MSFilter *f, void *arg) {
+	((MapFilter *)f->data)->rate = *(int *)arg;
+	return 0;
+}
+int map_get_sr(MSFilter *f, void *arg) {
+	*(int *)arg = ((MapFilter *)f->data)->rate;
+	return 0;
+}
+int map_set_nch(MSFilter *f, void *arg) {
+	((MapFilter *)f->data)->nchannels = *(int *)arg;
+	return 0;
+}
+int map_get_nch(MSFilter *f, void *arg) {
+	*(int *)arg = ((MapFilter *)f->data)->nchannels;
+	return 0;
+}
+MSFilterMethod l16_enc_methods[] = {{MS_FILTER_ADD_ATTR, l16_enc_add_attr},   {MS_FILTER_ADD_FMTP, l16_enc_add_fmtp},
+                                    {MS_FILTER_SET_SAMPLE_RATE, map_set_sr},  {MS_FILTER_SET_NCHANNELS, map_set_nch},
+                                    {MS_FILTER_GET_SAMPLE_RATE, map_get_sr},  {MS_FILTER_GET_NCHANNELS, map_get_nch},
+                                    {0, NULL}};
+MSFilterMethod l16_dec_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, map_set_sr}, {MS_FILTER_GET_SAMPLE_RATE, map_get_sr},
+                                    {MS_FILTER_GET_NCHANNELS, map_get_nch},  {MS_FILTER_SET_NCHANNELS, map_set_nch},
+                                    {0, NULL}};
+
+// ---- MSChannelAdapter chanadapt.c
+void adapter_init(MSFilter *f) { map_new(f); } // :40-46
+void adapter_free_sides(MapFilter *d) {
+	for (FlowBuf *&b : d->side)
+		if (b) {
+			ms_bufferizer_uninit(&b->base);
+			ms_free(b);
+			b = nullptr;
+		}
+}
+void adapter_preprocess(MSFilter *f) { // :53-66; the two-input buffers are needed whenever both pins are linked
+	MapFilter *d = (MapFilter *)f->data;
+	if ((f->inputs[0] && f->inputs[1]) || (d->nchannels == 2 && d->out_nchannels == 1)) {
+		d->buffer_size = (size_t)((f->ticker->interval * d->rate) / 1000) * 2;
+		for (FlowBuf *&b : d->side) {
+			b = (FlowBuf *)ms_malloc0(sizeof(FlowBuf));
+			flowbuf_init(b, f, d->rate);
+			b->immediate_drop = true;
+			b->max_size_ms = (uint32_t)f->ticker->interval * 2;
+		}
+	}
+}
+void adapter_postprocess(MSFilter *f) { // :125-135
+	MapFilter *d = (MapFilter *)f->data;
+	adapter_free_sides(d);
+	map_release(d);
+}
+void adapter_uninit(MSFilter *f) {
+	adapter_free_sides((MapFilter *)f->data);
+	map_uninit(f);
+}
+void adapter_two_inputs(MSFilter *f, MapFilter *d) { // adapter_process_2_inputs_to_single_stereo_output :68-93
+	flowbuf_put(d->side[0], nullptr, f->inputs[0]);
+	flowbuf_put(d->side[1], nullptr, f->inputs[1]);
+	const size_t a = ms_bufferizer_get_avail(&d->side[0]->base), b = ms_bufferizer_get_avail(&d->side[1]->base);
+	if (d->buffer_size == 0 || (a < d->buffer_size && b < d->buffer_size)) return;
+	if (!map_attach(f, d, OP_TWO_MONO_TO_STEREO)) return;
+	uint8_t *second = nullptr;
+	uint8_t *first = d->pool->reserve(d->slot, d->buffer_size / 2, nullptr, false, 0, &second);
+	if (!first) return;
+	if (a < d->buffer_size) memset(first, 0, d->buffer_size); // a short side is silent for the tick (:81-82)
+	else ms_bufferizer_read(&d->side[0]->base, first, d->buffer_size);
+	if (b < d->buffer_size) memset(second, 0, d->buffer_size);
+	else ms_bufferizer_read(&d->side[1]->base, second, d->buffer_size);
+	request_flush(f);
+}
+void adapter_process(MSFilter *f) { // :95-123
+	MapFilter *d = (MapFilter *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (f->inputs[0] != NULL && f->inputs[1] != NULL && d->side[0]) {
+		adapter_two_inputs(f, d);
+		return;
+	}
+	mblk_t *im;
+	bool any = false;
+	while ((im = ms_queue_get(f->inputs[0])) != NULL) {
+		if (d->nchannels == d->out_nchannels) {
+			ms_queue_put(f->outputs[0], im);
+			continue;
+		}
+		const bool widen = d->out_nchannels == 2;
+		if (!widen && d->nchannels != 2) { // neither branch of the reference takes it: the block is leaked there, freed here
+			freemsg(im);
+			continue;
+		}
+		const size_t frames = msgdsize(im) / (widen ? 2 : 4);
+		uint8_t *dst = (frames && map_attach(f, d, widen ? OP_MONO_TO_STEREO : OP_STEREO_TO_MONO))
+		                   ? d->pool->reserve(d->slot, frames, nullptr, false, 0)
+		                   : nullptr;
+		if (dst) {
+			std::vector<uint8_t> flat(msgdsize(im));
+			copy_payload(im, flat.data());
+			memcpy(dst, flat.data(), frames * (widen ? 2 : 4));
+			any = true;
+		}
+		freemsg(im); // no meta data cross this filter (:108-121 allocate a bare block)
+	}
+	if (any) request_flush(f);
+}
+int adapter_set_out_nch(MSFilter *f, void *arg) {
+	((MapFilter *)f->data)->out_nchannels = *(int *)arg;
+	return 0;
+}
+int adapter_get_out_nch(MSFilter *f, void *arg) {
+	*(int *)arg = ((MapFilter *)f->data)->out_nchannels;
+	return 0;
+}
+MSFilterMethod adapter_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, map_set_sr},
+                                    {MS_FILTER_GET_SAMPLE_RATE, map_get_sr},
+                                    {MS_FILTER_SET_NCHANNELS, map_set_nch},
+                                    {MS_FILTER_GET_NCHANNELS, map_get_nch},
+                                    {MS_CHANNEL_ADAPTER_SET_OUTPUT_NCHANNELS, adapter_set_out_nch},
+                                    {MS_CHANNEL_ADAPTER_GET_OUTPUT_NCHANNELS, adapter_get_out_nch},
+                                    {0, NULL}};

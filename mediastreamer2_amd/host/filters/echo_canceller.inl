@@ -1,0 +1,400 @@
+// filters/echo_canceller.inl -- MSSpeexEC facade (src/audiofilters/speexec.c).
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the pool / hub
+// infrastructure); not compiled on its own.
+
+// ============================================================== echo canceller
+struct EcPool : Pool {
+	int rate, F, flen;
+	mi_aec *a = nullptr;
+	int16_t *h_mic, *h_ref, *h_out, *d_mic, *d_ref, *d_out;
+	uint8_t *h_run, *d_run;
+	std::vector<int> staged, ready;
+	EcPool(int r, int frame, int filter_length) : rate(r), F(frame), flen(filter_length) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_aec_create(g_hub.context(), capacity, rate, F, flen, &a));
+		const size_t c = (size_t)capacity;
+		h_mic = pinned<int16_t>(kMaxRounds * c * F);
+		h_ref = pinned<int16_t>(kMaxRounds * c * F);
+		h_out = pinned<int16_t>(kMaxRounds * c * F);
+		h_run = pinned<uint8_t>(kMaxRounds * c);
+		d_mic = devmem<int16_t>(c * F);
+		d_ref = devmem<int16_t>(c * F);
+		d_out = devmem<int16_t>(c * F);
+		d_run = devmem<uint8_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r = 0; r < maxr; ++r) {
+			for (int s = 0; s < capacity; ++s) h_run[r * c + s] = staged[(size_t)s] > r;
+			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * F, c * F * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * F, c * F * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r * c, c));
+			MI_MUST(mi_aec_process(a, d_mic, d_ref, d_out, F, d_run, MI_AEC_POSTFILTER));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * F, d_out, c * F * 2));
+		}
+		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override {
+		const size_t c = (size_t)capacity, sl = (size_t)slot;
+		for (int r = 0; r < ready[sl]; ++r) { // cleaned frames -> outputs[1] (speexec.c:303)
+			mblk_t *oecho = allocb((size_t)F * 2, 0);
+			memcpy(oecho->b_wptr, h_out + (r * c + sl) * F, (size_t)F * 2);
+			oecho->b_wptr += F * 2;
+			if (f->outputs[1]) ms_queue_put(f->outputs[1], oecho);
+			else freemsg(oecho);
+		}
+		ready[sl] = 0;
+	}
+};
+std::map<std::tuple<MSTicker *, int, int, int>, EcPool *> g_ec_pools;
+
+// MSFlowControlledBufferizer, src/base/msqueue.c:127-256 (SendEvent drop method)
+struct FlowBuf {
+	MSBufferizer base;
+	MSFilter *filter;
+	uint64_t flow_control_time;
+	uint32_t interval_ms, max_size_ms, granularity_ms, min_size_ms_during_interval;
+	int samplerate, nchannels;
+	bool immediate_drop; // MSFlowControlledBufferizerImmediateDrop instead of SendEvent (msqueue.c:213-218)
+};
+void flowbuf_init(FlowBuf *o, MSFilter *f, int rate) {
+	ms_bufferizer_init(&o->base);
+	o->filter = f;
+	o->interval_ms = 5000;
+	o->max_size_ms = 100;
+	o->granularity_ms = 0;
+	o->flow_control_time = 0;
+	o->min_size_ms_during_interval = UINT32_MAX;
+	o->samplerate = rate;
+	o->nchannels = 1;
+	o->immediate_drop = false;
+}
+void flowbuf_put(FlowBuf *o, mblk_t *m, MSQueue *q = nullptr) { // msqueue.c:193-256 (m, or everything queued on q)
+	const uint32_t accumulated_ms = (uint32_t)((o->base.size * 1000) / (size_t)o->samplerate / 2) / (uint32_t)o->nchannels;
+	if (accumulated_ms < o->min_size_ms_during_interval) o->min_size_ms_during_interval = accumulated_ms;
+	if (q) ms_bufferizer_put_from_queue(&o->base, q);
+	else ms_bufferizer_put(&o->base, m);
+	const uint64_t now = o->filter->ticker->time;
+	const uint32_t since = (uint32_t)(now - o->flow_control_time);
+	if (o->flow_control_time == 0) o->flow_control_time = now;
+	if (since >= o->interval_ms) {
+		uint32_t diff_ms = 0;
+		bool trig = false;
+		if (o->min_size_ms_during_interval != UINT32_MAX && o->min_size_ms_during_interval > o->max_size_ms) {
+			diff_ms = o->min_size_ms_during_interval - o->max_size_ms;
+			trig = true;
+		} else if (accumulated_ms > o->max_size_ms * 4) {
+			diff_ms = (accumulated_ms - o->max_size_ms) / 2;
+			trig = true;
+		}
+		if (trig && diff_ms > o->granularity_ms / 2) {
+			MSAudioFlowControlDropEvent ev;
+			ev.flow_control_interval_ms = o->interval_ms;
+			ev.drop_ms = diff_ms - o->granularity_ms / 2;
+			if (ev.drop_ms > 0) {
+				if (o->immediate_drop) ms_bufferizer_skip_bytes(&o->base, (int)((ev.drop_ms * 2 * (uint32_t)o->nchannels * (uint32_t)o->samplerate) / 1000));
+				else ms_filter_notify(o->filter, MS_AUDIO_FLOW_CONTROL_DROP_EVENT, &ev);
+			}
+		}
+		o->flow_control_time = now;
+		o->min_size_ms_during_interval = UINT32_MAX;
+	}
+}
+
+struct SpeexECState { // speexec.c:49-72
+	MSBufferizer delayed_ref;
+	FlowBuf ref;
+	MSBufferizer echo;
+	int framesize, framesize_at_8000, filterlength, samplerate, delay_ms, tail_length_ms, nominal_ref_samples;
+	char *state_str;
+	bool_t echostarted, bypass_mode, using_zeroes;
+	EcPool *pool;
+	int slot;
+};
+
+void ec_init(MSFilter *f) { // speexec.c:74-109
+	SpeexECState *s = (SpeexECState *)ms_malloc0(sizeof(*s));
+	s->samplerate = 8000;
+	ms_bufferizer_init(&s->delayed_ref);
+	ms_bufferizer_init(&s->echo);
+	flowbuf_init(&s->ref, f, s->samplerate);
+	s->tail_length_ms = 250;
+	s->framesize_at_8000 = 64;
+	s->slot = -1;
+	f->data = s;
+}
+void ec_uninit(MSFilter *f) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	if (s->state_str) ms_free(s->state_str);
+	ms_bufferizer_uninit(&s->delayed_ref);
+	ms_free(s);
+}
+void ec_configure_flow(SpeexECState *s) { // speexec.c:182-186
+	s->ref.samplerate = s->samplerate;
+	s->ref.max_size_ms = (uint32_t)s->delay_ms;
+	s->ref.granularity_ms = (uint32_t)((s->framesize * 1000) / s->samplerate);
+}
+// ---- the canceller's state as a string: fetch_config / apply_config, speexec.c:119-167 (there a SpeexEchoStateBlob of the
+// speex fork through bctbx_base64_*; here the blob of mi_aec_export_state through a local RFC 4648 codec)
+const char kB64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+char *b64_encode(const uint8_t *p, size_t n) {
+	char *out = (char *)ms_malloc0(4 * ((n + 2) / 3) + 1), *o = out;
+	for (size_t i = 0; i < n; i += 3) {
+		const uint32_t v = ((uint32_t)p[i] << 16) | ((i + 1 < n ? (uint32_t)p[i + 1] : 0u) << 8) | (i + 2 < n ? (uint32_t)p[i + 2] : 0u);
+		*o++ = kB64[(v >> 18) & 63];
+		*o++ = kB64[(v >> 12) & 63];
+		*o++ = i + 1 < n ? kB64[(v >> 6) & 63] : '=';
+		*o++ = i + 2 < n ? kB64[v & 63] : '=';
+	}
+	*o = 0;
+	return out;
+}
+bool b64_decode(const char *txt, std::vector<uint8_t> &out) {
+	int8_t rev[256];
+	memset(rev, -1, sizeof(rev));
+	for (int i = 0; i < 64; ++i) rev[(uint8_t)kB64[i]] = (int8_t)i;
+	out.clear();
+	uint32_t acc = 0;
+	int bits = 0;
+	for (const char *c = txt; *c && *c != '='; ++c) {
+		if (*c == '\n' || *c == '\r' || *c == ' ') continue;
+		const int v = rev[(uint8_t)*c];
+		if (v < 0) return false;
+		acc = (acc << 6) | (uint32_t)v;
+		bits += 6;
+		if (bits >= 8) {
+			bits -= 8;
+			out.push_back((uint8_t)(acc >> bits));
+		}
+	}
+	return true;
+}
+struct SpeexECState;
+void ec_apply_config(SpeexECState *s);
+void ec_fetch_config(SpeexECState *s);
+
+void ec_preprocess(MSFilter *f) { // speexec.c:188-216
+	SpeexECState *s = (SpeexECState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->echostarted = FALSE;
+	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
+	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
+	if (s->framesize != 64 && s->framesize != 128 && s->framesize != 256) {
+		// e.g. 96 kHz would need 512-sample frames: audio keeps flowing uncancelled rather than the process dying
+		ms_error("mi355x echo canceller: frame size %d (rate %d) is not built; the filter forwards both pins untouched",
+		         s->framesize, s->samplerate);
+		s->bypass_mode = TRUE;
+		return;
+	}
+	if (s->filterlength > 64 * s->framesize) { // the kernels hold at most 64 filter blocks (341 ms at 48 kHz, 512 ms at 8/16 kHz)
+		ms_warning("mi355x echo canceller: tail of %d ms shortened to %d ms (64 blocks of %d samples)", s->tail_length_ms,
+		           64 * s->framesize * 1000 / s->samplerate, s->framesize);
+		s->filterlength = 64 * s->framesize;
+	}
+	const int delay_samples = s->delay_ms * s->samplerate / 1000;
+	ms_message("Initializing mi355x echo canceler with framesize=%i, filterlength=%i, delay_samples=%i", s->framesize,
+	           s->filterlength, delay_samples);
+	auto key = std::make_tuple(f->ticker, s->samplerate, s->framesize, s->filterlength);
+	auto it = g_ec_pools.find(key);
+	if (it == g_ec_pools.end()) {
+		EcPool *p = new EcPool(s->samplerate, s->framesize, s->filterlength);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_ec_pools.emplace(key, p).first;
+	}
+	s->pool = it->second;
+	s->slot = s->pool->acquire(f);
+	if (s->slot < 0) s->pool = nullptr;
+	mblk_t *m = allocb((size_t)delay_samples * 2, 0); // zeroes for the time of the delay
+	memset(m->b_wptr, 0, (size_t)delay_samples * 2);
+	m->b_wptr += delay_samples * 2;
+	ms_bufferizer_put(&s->delayed_ref, m);
+	s->nominal_ref_samples = delay_samples;
+	ec_apply_config(s); // :209-211
+}
+void ec_apply_config(SpeexECState *s) { // :121-143
+	if (s->state_str == NULL || s->pool == nullptr) return;
+	std::vector<uint8_t> blob;
+	if (!b64_decode(s->state_str, blob)) {
+		ms_error("Could not decode base64 %.32s...", s->state_str);
+		return;
+	}
+	if (mi_aec_import_state(s->pool->a, s->slot, blob.data(), blob.size()) != MI_OK) {
+		ms_error("Could not apply mi355x echo blob: %s", mi_last_error()); // e.g. saved at another rate or tail length
+		return;
+	}
+	ms_message("mi355x echo state restored.");
+}
+void ec_fetch_config(SpeexECState *s) { // :145-167
+	if (s->pool == nullptr) return;
+	std::vector<uint8_t> blob(mi_aec_blob_bytes(s->pool->a));
+	if (mi_aec_export_state(s->pool->a, s->slot, blob.data(), blob.size()) != MI_OK) {
+		ms_error("Could not retrieve mi355x echo blob: %s", mi_last_error());
+		return;
+	}
+	if (s->state_str) ms_free(s->state_str);
+	s->state_str = b64_encode(blob.data(), blob.size());
+}
+void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at detach
+	SpeexECState *s = (SpeexECState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	ms_bufferizer_flush(&s->delayed_ref);
+	ms_bufferizer_flush(&s->echo);
+	ms_bufferizer_flush(&s->ref.base);
+	if (s->pool) {
+		MI_MUST(mi_aec_reset(s->pool->a, s->slot, 1));
+		s->pool->release(s->slot);
+		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
+	}
+	s->pool = nullptr;
+	s->slot = -1;
+}
+
+// inputs[0] far-end reference, inputs[1] mic; outputs[0] reference copy, outputs[1] cleaned mic (speexec.c:218-222)
+// ---- the framing of speexec.c:223-305, in three steps ---------------------------------------------------------------
+// (1) far-end blocks: kept twice once the microphone has started -- in `delayed_ref` (what the canceller will be fed,
+//     behind the configured delay) and in the flow-controlled `ref` (what goes on to the speaker, frame by frame).
+void ec_take_far_end(MSFilter *f, SpeexECState *s) {
+	if (!f->inputs[0]) return;
+	if (!s->echostarted) {
+		ms_warning("Getting reference signal but no echo to synchronize on.");
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) {
+		ms_bufferizer_put(&s->delayed_ref, dupmsg(m));
+		flowbuf_put(&s->ref, m);
+	}
+}
+
+mblk_t *ec_block(size_t nbytes) {
+	mblk_t *m = allocb(nbytes, 0);
+	memset(m->b_wptr, 0, nbytes);
+	m->b_wptr += nbytes;
+	return m;
+}
+
+// (2) one speaker frame per microphone frame: from `ref` when the delay line holds more than the nominal delay plus a
+//     frame, otherwise a frame of silence that is ALSO appended to the delay line (the canceller then sees zeros too).
+void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
+	const size_t needed = (size_t)s->nominal_ref_samples * 2 + nbytes;
+	if (ms_bufferizer_get_avail(&s->delayed_ref) < needed) {
+		mblk_t *silence = ec_block(nbytes);
+		ms_bufferizer_put(&s->delayed_ref, silence);
+		ms_queue_put(f->outputs[0], dupmsg(silence));
+		if (!s->using_zeroes) ms_warning("Not enough ref samples, using zeroes");
+		s->using_zeroes = TRUE;
+		return;
+	}
+	if (s->using_zeroes) ms_message("Samples are back.");
+	s->using_zeroes = FALSE;
+	mblk_t *m = ec_block(nbytes);
+	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) {
+		ms_error("Should never happen");
+		abort();
+	}
+	ms_queue_put(f->outputs[0], m);
+}
+
+// (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
+void ec_process(MSFilter *f) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	if (s->bypass_mode) { // both pins straight through
+		for (int pin = 0; pin < 2; ++pin)
+			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
+		return;
+	}
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	EcPool *p = s->pool;
+	if (!p) {
+		ms_queue_flush(f->inputs[0]);
+		ms_queue_flush(f->inputs[1]);
+		return;
+	}
+	const size_t nbytes = (size_t)s->framesize * 2, cap = (size_t)p->capacity, slot = (size_t)s->slot;
+	ec_take_far_end(f, s);
+	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
+	while (p->staged[slot] < kMaxRounds && ms_bufferizer_get_avail(&s->echo) >= nbytes) {
+		const size_t row = ((size_t)p->staged[slot] * cap + slot) * (size_t)p->F;
+		ms_bufferizer_read(&s->echo, (uint8_t *)(p->h_mic + row), nbytes);
+		s->echostarted = TRUE;
+		ec_emit_speaker_frame(f, s, nbytes);
+		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)(p->h_ref + row), nbytes) == 0) {
+			ms_error("Should never happen");
+			abort();
+		}
+		p->staged[slot]++;
+	}
+	if (p->staged[slot]) request_flush(f);
+}
+
+int ec_set_sr(MSFilter *f, void *arg) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->samplerate = *(int *)arg;
+	ec_configure_flow(s);
+	return 0;
+}
+int ec_set_framesize(MSFilter *f, void *arg) {
+	((SpeexECState *)f->data)->framesize_at_8000 = *(int *)arg;
+	return 0;
+}
+int ec_set_delay(MSFilter *f, void *arg) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->delay_ms = *(int *)arg;
+	ec_configure_flow(s);
+	return 0;
+}
+int ec_set_tail_length(MSFilter *f, void *arg) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->tail_length_ms = *(int *)arg;
+	ec_configure_flow(s);
+	return 0;
+}
+int ec_set_bypass_mode(MSFilter *f, void *arg) {
+	((SpeexECState *)f->data)->bypass_mode = *(bool_t *)arg;
+	return 0;
+}
+int ec_get_bypass_mode(MSFilter *f, void *arg) {
+	*(bool_t *)arg = ((SpeexECState *)f->data)->bypass_mode;
+	return 0;
+}
+int ec_set_state(MSFilter *f, void *arg) { // :361-365 (the previous string leaks there; freed here)
+	SpeexECState *s = (SpeexECState *)f->data;
+	const size_t n = strlen((const char *)arg) + 1;
+	if (s->state_str) ms_free(s->state_str);
+	s->state_str = (char *)ms_malloc0(n);
+	memcpy(s->state_str, arg, n);
+	return 0;
+}
+int ec_get_state(MSFilter *f, void *arg) { // :367-374: the CURRENT state while attached, the stored string otherwise
+	SpeexECState *s = (SpeexECState *)f->data;
+	{
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		ec_fetch_config(s);
+	}
+	*(char **)arg = s->state_str;
+	return 0;
+}
+int ec_get_delay(MSFilter *f, void *arg) {
+	*(int *)arg = ((SpeexECState *)f->data)->delay_ms;
+	return 0;
+}
+MSFilterMethod ec_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, ec_set_sr},
+                               {MS_ECHO_CANCELLER_SET_TAIL_LENGTH, ec_set_tail_length},
+                               {MS_ECHO_CANCELLER_SET_DELAY, ec_set_delay},
+                               {MS_ECHO_CANCELLER_SET_FRAMESIZE, ec_set_framesize},
+                               {MS_ECHO_CANCELLER_SET_BYPASS_MODE, ec_set_bypass_mode},
+                               {MS_ECHO_CANCELLER_GET_BYPASS_MODE, ec_get_bypass_mode},
+                               {MS_ECHO_CANCELLER_GET_STATE_STRING, ec_get_state},
+                               {MS_ECHO_CANCELLER_SET_STATE_STRING, ec_set_state},
+                               {MS_ECHO_CANCELLER_GET_DELAY, ec_get_delay},
+                               {0, NULL}};

@@ -1,0 +1,210 @@
+// filters/equalizer.inl -- MSEqualizer facade (src/audiofilters/equalizer.c).
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the pool / hub
+// infrastructure); not compiled on its own.
+
+// =================================================================== equalizer
+struct EqualizerPool : Pool {
+	int rate, cap_samples;
+	mi_equalizer *e = nullptr;
+	int16_t *h_buf, *d_buf;
+	int32_t *h_n, *d_n;
+	std::vector<int> staged, ready;
+	EqualizerPool(int r) : rate(r) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_equalizer_create(g_hub.context(), capacity, rate, &e));
+		cap_samples = (std::max(960, rate / 100 * 2) + 7) & ~7;
+		const size_t c = (size_t)capacity;
+		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
+		h_n = pinned<int32_t>(kMaxRounds * c);
+		d_buf = devmem<int16_t>(c * cap_samples);
+		d_n = devmem<int32_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r = 0; r < maxr; ++r) {
+			for (int s = 0; s < capacity; ++s)
+				if (staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, c * cap_samples * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
+			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, c * cap_samples * 2));
+		}
+		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override {
+		const size_t c = (size_t)capacity, s = (size_t)slot;
+		for (int r = 0; r < ready[s]; ++r) {
+			const int n = h_n[r * c + s];
+			mblk_t *om = allocb((size_t)n * 2, 0);
+			memcpy(om->b_wptr, h_buf + (r * c + s) * cap_samples, (size_t)n * 2);
+			om->b_wptr += n * 2;
+			if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
+			else freemsg(om);
+		}
+		ready[s] = 0;
+	}
+};
+std::map<std::pair<MSTicker *, int>, EqualizerPool *> g_equalizer_pools;
+
+struct EqualizerData {
+	int rate;
+	bool active;
+	EqualizerPool *pool;
+	int slot;
+	std::vector<MSEqualizerGain> *pending; // gains since the last rate change, in call order
+	MSBufferizer *spill;                   // the part of an over-long block that did not fit this tick's rounds
+};
+
+// Gains set before the filter is attached to a ticker are kept in `pending` and replayed, in
+// order, when the slot is acquired (the reference keeps them in its own fft_cpx array).
+void equalizer_attach(MSFilter *f) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (d->pool && d->pool->rate == d->rate && d->pool->ticker == f->ticker) return;
+	if (d->pool) d->pool->release(d->slot);
+	d->pool = nullptr;
+	d->slot = -1;
+	if (!f->ticker) return;
+	auto key = std::make_pair(f->ticker, d->rate);
+	auto it = g_equalizer_pools.find(key);
+	if (it == g_equalizer_pools.end()) {
+		EqualizerPool *p = new EqualizerPool(d->rate);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_equalizer_pools.emplace(key, p).first;
+	}
+	d->pool = it->second;
+	d->slot = d->pool->acquire(f);
+	if (d->slot < 0) {
+		d->pool = nullptr;
+		return;
+	}
+	MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot)); // equalizer_rate_update flattens
+	MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
+	for (const MSEqualizerGain &g : *d->pending)
+		MI_MUST(mi_equalizer_set_gain(d->pool->e, d->slot, g.frequency, g.gain, g.width));
+}
+
+void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
+	EqualizerData *d = (EqualizerData *)ms_malloc0(sizeof(*d));
+	d->rate = 8000;
+	d->active = true;
+	d->slot = -1;
+	d->pending = new std::vector<MSEqualizerGain>();
+	d->spill = ms_bufferizer_new();
+	f->data = d;
+}
+void equalizer_preprocess(MSFilter *f) { equalizer_attach(f); }
+void equalizer_uninit(MSFilter *f) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	if (d->pool) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		d->pool->release(d->slot);
+	}
+	delete d->pending;
+	ms_bufferizer_destroy(d->spill);
+	ms_free(d);
+}
+void equalizer_process(MSFilter *f) { // equalizer.c:279-288
+	EqualizerData *d = (EqualizerData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mblk_t *m;
+	if (!d->pool) equalizer_attach(f);
+	if (!d->pool) {
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	EqualizerPool *p = d->pool;
+	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
+	// one FIR block per mblk; a block longer than a batch row is cut into row-sized pieces (a streaming filter: the
+	// sample sequence does not depend on the blocking), nothing is dropped
+	for (;;) {
+		if (p->staged[s] >= kMaxRounds) break;
+		int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
+		int n = 0;
+		const size_t spilled = ms_bufferizer_get_avail(d->spill);
+		if (spilled) {
+			n = (int)std::min(spilled / 2, (size_t)p->cap_samples);
+			ms_bufferizer_read(d->spill, (uint8_t *)row, (size_t)n * 2);
+		} else if ((m = ms_queue_get(f->inputs[0])) != NULL) {
+			n = (int)(msgdsize(m) / 2);
+			if (n > p->cap_samples) {
+				ms_bufferizer_put(d->spill, m);
+				continue;
+			}
+			memcpy(row, m->b_rptr, (size_t)n * 2);
+			freemsg(m);
+		} else {
+			break;
+		}
+		p->h_n[p->staged[s] * c + s] = n;
+		p->staged[s]++;
+	}
+	if (p->staged[s]) request_flush(f);
+}
+int equalizer_set_gain(MSFilter *f, void *arg) { // equalizer.c:290-295
+	EqualizerData *d = (EqualizerData *)f->data;
+	MSEqualizerGain *g = (MSEqualizerGain *)arg;
+	d->pending->push_back(*g);
+	if (!d->pool) return 0;
+	return mi_equalizer_set_gain(d->pool->e, d->slot, g->frequency, g->gain, g->width) == MI_OK ? 0 : -1;
+}
+int equalizer_get_gain(MSFilter *f, void *arg) { // equalizer.c:297-303 incl. its slot-indexing quirk
+	EqualizerData *d = (EqualizerData *)f->data;
+	MSEqualizerGain *g = (MSEqualizerGain *)arg;
+	g->width = 0;
+	g->gain = 0;
+	if (!d->pool) return -1;
+	const int nfft = mi_equalizer_fir_len(d->pool->e);
+	std::vector<float> dump((size_t)nfft / 2);
+	if (mi_equalizer_dump(d->pool->e, d->slot, dump.data(), nfft / 2) != MI_OK) return -1;
+	int hz = (int)g->frequency;
+	if (hz >= 0) {
+		if (hz > d->rate / 2) hz = d->rate / 2;
+		int idx = ((hz * nfft) + (d->rate / 2)) / d->rate;
+		if (idx == nfft / 2) idx = nfft / 2 - 1;
+		// the reference reads fft_cpx[idx*2]: an imaginary slot, 0 for idx >= 1; DC slot for idx == 0
+		g->gain = idx == 0 ? dump[0] * nfft : 0.f;
+	}
+	return 0;
+}
+int equalizer_set_rate(MSFilter *f, void *arg) { // equalizer.c:305-309
+	EqualizerData *d = (EqualizerData *)f->data;
+	d->rate = *(int *)arg;
+	d->pending->clear(); // equalizer_rate_update re-allocates a flat spectrum
+	if (d->pool && d->pool->rate == d->rate) MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot));
+	else equalizer_attach(f);
+	return 0;
+}
+int equalizer_set_active(MSFilter *f, void *arg) { // equalizer.c:311-315: arg read as bool_t
+	EqualizerData *d = (EqualizerData *)f->data;
+	d->active = *(bool_t *)arg != 0;
+	if (d->pool) MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
+	return 0;
+}
+int equalizer_dump(MSFilter *f, void *arg) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	if (!d->pool) return -1;
+	return mi_equalizer_dump(d->pool->e, d->slot, (float *)arg, mi_equalizer_fir_len(d->pool->e) / 2) == MI_OK ? 0 : -1;
+}
+int equalizer_get_nfreqs(MSFilter *f, void *arg) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	*(int *)arg = (d->rate < 16000 ? 128 : (d->rate < 32000 ? 256 : 512)) / 2;
+	return 0;
+}
+MSFilterMethod equalizer_methods[] = {{MS_EQUALIZER_SET_GAIN, equalizer_set_gain},
+                                      {MS_EQUALIZER_GET_GAIN, equalizer_get_gain},
+                                      {MS_EQUALIZER_SET_ACTIVE, equalizer_set_active},
+                                      {MS_FILTER_SET_SAMPLE_RATE, equalizer_set_rate},
+                                      {MS_EQUALIZER_DUMP_STATE, equalizer_dump},
+                                      {MS_EQUALIZER_GET_NUM_FREQUENCIES, equalizer_get_nfreqs},
+                                      {0, NULL}};

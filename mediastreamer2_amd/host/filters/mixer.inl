@@ -1,0 +1,377 @@
+// filters/mixer.inl -- MSAudioMixer facade (src/audiofilters/audiomixer.c).
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the pool / hub
+// infrastructure); not compiled on its own.
+
+// ======================================================================= mixer
+constexpr int MIXER_MAX_CHANNELS = MI_MIXER_MAX_CHANNELS; // audiomixer.c:29
+constexpr uint64_t BYPASS_MODE_TIMEOUT = 1000;            // audiomixer.c:31
+
+struct MixerPool : Pool {
+	int ns; // samples per tick (all channels interleaved)
+	mi_mixer *m = nullptr;
+	int16_t *h_in, *h_out, *d_in, *d_out;
+	uint8_t *h_has, *d_has, *h_run, *d_run, *h_mode, *d_mode;
+	std::vector<uint8_t> flags;
+	std::vector<float> gain;
+	bool ctl_dirty = true;
+	std::vector<uint8_t> staged, ready;
+	MixerPool(int nsamples) : ns(nsamples) {
+		init_slots(std::max(1, g_hub.capacity / 8));
+		MI_MUST(mi_mixer_create(g_hub.context(), capacity, MIXER_MAX_CHANNELS, ns, &m));
+		const size_t c = (size_t)capacity, n = c * MIXER_MAX_CHANNELS;
+		h_in = pinned<int16_t>(n * ns);
+		h_out = pinned<int16_t>(n * ns);
+		d_in = devmem<int16_t>(n * ns);
+		d_out = devmem<int16_t>(n * ns);
+		h_has = pinned<uint8_t>(n);
+		d_has = devmem<uint8_t>(n);
+		h_run = pinned<uint8_t>(c);
+		d_run = devmem<uint8_t>(c);
+		h_mode = pinned<uint8_t>(c);
+		d_mode = devmem<uint8_t>(c);
+		flags.assign(n, 0);
+		gain.assign(n, 1.0f);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity, n = c * MIXER_MAX_CHANNELS;
+		bool any = false;
+		for (size_t s = 0; s < c; ++s) {
+			h_run[s] = staged[s];
+			any |= staged[s] != 0;
+		}
+		if (ctl_dirty) {
+			MI_MUST(mi_mixer_set_controls(m, flags.data(), gain.data()));
+			ctl_dirty = false;
+		}
+		if (any) {
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, n * ns * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_has, h_has, n));
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, c));
+			MI_MUST(mi_copy_h2d(ctx, d_mode, h_mode, c));
+			MI_MUST(mi_mixer_process_masked(m, d_in, d_has, 1, d_mode, d_out, d_run));
+			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, n * ns * 2));
+			MI_MUST(mi_ctx_sync(ctx));
+		}
+		for (size_t s = 0; s < c; ++s) {
+			ready[s] = staged[s];
+			staged[s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override;
+};
+std::map<std::pair<MSTicker *, int>, MixerPool *> g_mixer_pools;
+
+struct Channel { // audiomixer.c:53-63
+	MSBufferizer bufferizer;
+	float gain;
+	int min_fullness;
+	uint64_t last_flow_control, last_activity;
+	bool_t active, output_enabled;
+};
+struct MixerState { // audiomixer.c:132-143
+	int nchannels, rate, bytespertick;
+	Channel channels[MIXER_MAX_CHANNELS];
+	int conf_mode, skip_threshold, master_channel;
+	bool_t bypass_mode, single_output;
+	MixerPool *pool;
+	int slot;
+};
+
+void mixer_init(MSFilter *f) { // audiomixer.c:145-156
+	MixerState *s = (MixerState *)ms_malloc0(sizeof(*s));
+	s->conf_mode = FALSE;
+	s->nchannels = 1;
+	s->rate = 44100;
+	s->master_channel = -1;
+	s->slot = -1;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+		ms_bufferizer_init(&s->channels[i].bufferizer);
+		s->channels[i].gain = 1.0;
+		s->channels[i].active = TRUE;
+		s->channels[i].output_enabled = TRUE;
+	}
+	f->data = s;
+}
+void mixer_uninit(MSFilter *f) {
+	MixerState *s = (MixerState *)f->data;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) ms_bufferizer_uninit(&s->channels[i].bufferizer);
+	ms_free(s);
+}
+bool_t has_single_output(MSFilter *f, MixerState *s) { // audiomixer.c:167-176
+	int count = 0;
+	for (int i = 0; i < f->desc->noutputs; ++i)
+		if (f->outputs[i] && s->channels[i].output_enabled) count++;
+	return count == 1;
+}
+void mixer_push_controls(MSFilter *f, MixerState *s) {
+	if (!s->pool) return;
+	MixerPool *p = s->pool;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+		uint8_t fl = 0;
+		if (f->inputs[i]) fl |= MI_MIX_LINKED;
+		if (s->channels[i].active) fl |= MI_MIX_ACTIVE;
+		if (f->outputs[i] && s->channels[i].output_enabled) fl |= MI_MIX_OUTPUT;
+		p->flags[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = fl;
+		p->gain[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = s->channels[i].gain;
+	}
+	p->ctl_dirty = true;
+}
+void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
+	MixerState *s = (MixerState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->bytespertick = (2 * s->nchannels * s->rate * f->ticker->interval) / 1000;
+	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+		s->channels[i].last_flow_control = (uint64_t)-1;
+		s->channels[i].last_activity = (uint64_t)-1;
+	}
+	s->skip_threshold = s->bytespertick * 2;
+	s->bypass_mode = FALSE;
+	s->single_output = has_single_output(f, s);
+	const int ns = s->bytespertick / 2;
+	auto key = std::make_pair(f->ticker, ns);
+	auto it = g_mixer_pools.find(key);
+	if (it == g_mixer_pools.end()) {
+		MixerPool *p = new MixerPool(ns);
+		p->ticker = f->ticker;
+		g_hub.pools.push_back(p);
+		it = g_mixer_pools.emplace(key, p).first;
+	}
+	s->pool = it->second;
+	s->slot = s->pool->acquire(f);
+	if (s->slot < 0) s->pool = nullptr;
+	mixer_push_controls(f, s);
+}
+void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot released at every detach)
+	MixerState *s = (MixerState *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (s->pool) {
+		s->pool->release(s->slot);
+		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
+	}
+	s->pool = nullptr;
+	s->slot = -1;
+}
+
+// ---- bypass: one contributor, nothing to sum (behaviour of audiomixer.c:219-286) -----------------------------------
+// A pin "contributes" while it has data queued or had some less than BYPASS_MODE_TIMEOUT ms ago.
+struct Contributors {
+	int count = 0;
+	int pin = -1; // the highest-numbered contributing pin (the one that forwards when count == 1)
+};
+
+Contributors mixer_census(MSFilter *f, MixerState *s) {
+	Contributors c;
+	const uint64_t now = f->ticker->time;
+	for (int pin = 0; pin < f->desc->ninputs; ++pin) {
+		if (!f->inputs[pin]) continue;
+		uint64_t &seen = s->channels[pin].last_activity;
+		bool contributes;
+		if (!ms_queue_empty(f->inputs[pin])) {
+			seen = now;
+			contributes = true;
+		} else if (seen == (uint64_t)-1) {
+			seen = now; // first look at a silent pin only starts its clock
+			contributes = false;
+		} else {
+			contributes = now - seen < BYPASS_MODE_TIMEOUT;
+		}
+		if (contributes) {
+			c.count++;
+			c.pin = pin;
+		}
+	}
+	return c;
+}
+
+// The single contributor's blocks go to every enabled output except (in conference mode) its own pin: moved when
+// only one output is wired, referenced (dupmsg) otherwise.
+void mixer_forward(MSFilter *f, MixerState *s, int from_pin) {
+	MSQueue *src = f->inputs[from_pin];
+	for (int pin = 0; pin < f->desc->noutputs; ++pin) {
+		MSQueue *dst = f->outputs[pin];
+		if (!dst || !s->channels[pin].output_enabled) continue;
+		if (s->conf_mode != 0 && pin == from_pin) continue;
+		if (s->single_output) {
+			for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) ms_queue_put(dst, m);
+			break;
+		}
+		for (mblk_t *m = peekq(&src->q); m != NULL && m != &src->q._q_stopper; m = m->b_next) ms_queue_put(dst, dupmsg(m));
+	}
+	ms_queue_flush(src);
+}
+
+// true = this tick is already dealt with (forwarded, or nobody contributes)
+bool_t mixer_check_bypass(MSFilter *f, MixerState *s) {
+	const Contributors c = mixer_census(f, s);
+	if (c.count > 1) {
+		if (s->bypass_mode) ms_message("MSAudioMixer [%p] is leaving bypass mode.", (void *)f);
+		s->bypass_mode = FALSE;
+		return FALSE;
+	}
+	if (c.count == 1) {
+		if (!s->bypass_mode) ms_message("MSAudioMixer [%p] is entering bypass mode.", (void *)f);
+		s->bypass_mode = TRUE;
+		mixer_forward(f, s, c.pin);
+	}
+	return TRUE;
+}
+
+// ---- per-channel flow control (behaviour of audiomixer.c:92-111): every 5 s, if the bufferizer never dropped below
+// `threshold` bytes in that window, discard the standing excess down to half the threshold.  Returns the bytes dropped.
+int channel_flow_control(Channel *chan, int threshold, uint64_t now) {
+	const bool first_call = chan->last_flow_control == (uint64_t)-1;
+	int dropped = 0;
+	if (!first_call) {
+		const int level = (int)ms_bufferizer_get_avail(&chan->bufferizer);
+		if (chan->min_fullness == -1 || level < chan->min_fullness) chan->min_fullness = level;
+		if (now - chan->last_flow_control < 5000) return 0;
+		if (chan->min_fullness >= threshold) {
+			dropped = chan->min_fullness - threshold / 2;
+			ms_bufferizer_skip_bytes(&chan->bufferizer, dropped);
+		}
+	}
+	chan->last_flow_control = now; // a new observation window starts
+	chan->min_fullness = -1;
+	return dropped;
+}
+
+void MixerPool::emit(MSFilter *f, int slot) {
+	MixerState *s = (MixerState *)f->data;
+	if (!ready[(size_t)slot]) return;
+	ready[(size_t)slot] = 0;
+	const int16_t *base = h_out + (size_t)slot * MIXER_MAX_CHANNELS * ns;
+	if (s->conf_mode == 0) { // one block shared by every enabled output (:321-334)
+		mblk_t *om = NULL;
+		for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+			MSQueue *q = f->outputs[i];
+			if (q && s->channels[i].output_enabled) {
+				if (om == NULL) {
+					om = allocb((size_t)ns * 2, 0);
+					memcpy(om->b_wptr, base, (size_t)ns * 2);
+					om->b_wptr += ns * 2;
+				} else {
+					om = dupb(om);
+				}
+				ms_queue_put(q, om);
+			}
+		}
+	} else { // :336-343
+		for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+			MSQueue *q = f->outputs[i];
+			if (q && s->channels[i].output_enabled) {
+				mblk_t *om = allocb((size_t)ns * 2, 0);
+				memcpy(om->b_wptr, base + (size_t)i * ns, (size_t)ns * 2);
+				om->b_wptr += ns * 2;
+				ms_queue_put(q, om);
+			}
+		}
+	}
+}
+
+void mixer_process(MSFilter *f) { // audiomixer.c:288-346
+	MixerState *s = (MixerState *)f->data;
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!s->pool) {
+		ms_filter_unlock(f);
+		return;
+	}
+	if (mixer_check_bypass(f, s)) {
+		ms_filter_unlock(f);
+		return;
+	}
+	MixerPool *p = s->pool;
+	const int nwords = s->bytespertick / 2;
+	int16_t *in = p->h_in + (size_t)s->slot * MIXER_MAX_CHANNELS * nwords;
+	uint8_t *has = p->h_has + (size_t)s->slot * MIXER_MAX_CHANNELS;
+	for (int i = 0; i < f->desc->ninputs; ++i) {
+		MSQueue *q = f->inputs[i];
+		has[i] = 0;
+		if (!q) continue;
+		Channel *chan = &s->channels[i];
+		ms_bufferizer_put_from_queue(&chan->bufferizer, q); // channel_process_in :78-90
+		has[i] = ms_bufferizer_read(&chan->bufferizer, (uint8_t *)(in + (size_t)i * nwords), (size_t)nwords * 2) != 0;
+		const int skip = channel_flow_control(chan, s->skip_threshold, f->ticker->time);
+		if (skip > 0)
+			ms_warning("Too much data in channel %i, %i ms in excess dropped", i, (skip * 1000) / (2 * s->nchannels * s->rate));
+	}
+	p->h_mode[(size_t)s->slot] = (uint8_t)(s->conf_mode != 0);
+	p->staged[(size_t)s->slot] = 1; // ALWAYS_STREAMOUT :315-317
+	request_flush(f);
+	ms_filter_unlock(f);
+}
+
+int mixer_set_rate(MSFilter *f, void *data) {
+	((MixerState *)f->data)->rate = *(int *)data;
+	return 0;
+}
+int mixer_get_rate(MSFilter *f, void *data) {
+	*(int *)data = ((MixerState *)f->data)->rate;
+	return 0;
+}
+int mixer_set_nchannels(MSFilter *f, void *data) {
+	((MixerState *)f->data)->nchannels = *(int *)data;
+	return 0;
+}
+int mixer_get_nchannels(MSFilter *f, void *data) {
+	*(int *)data = ((MixerState *)f->data)->nchannels;
+	return 0;
+}
+bool mixer_pin_ok(const char *who, int pin) {
+	if (pin < 0 || pin >= MIXER_MAX_CHANNELS) {
+		ms_warning("%s: invalid pin number %i", who, pin);
+		return false;
+	}
+	return true;
+}
+int mixer_set_input_gain(MSFilter *f, void *data) { // audiomixer.c:372-382
+	MixerState *s = (MixerState *)f->data;
+	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
+	if (!mixer_pin_ok("mixer_set_input_gain", ctl->pin)) return -1;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->channels[ctl->pin].gain = ctl->param.gain;
+	mixer_push_controls(f, s);
+	return 0;
+}
+int mixer_set_active(MSFilter *f, void *data) { // :384-393
+	MixerState *s = (MixerState *)f->data;
+	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
+	if (!mixer_pin_ok("mixer_set_active_gain", ctl->pin)) return -1;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->channels[ctl->pin].active = (bool_t)ctl->param.active;
+	mixer_push_controls(f, s);
+	return 0;
+}
+int mixer_enable_output(MSFilter *f, void *data) { // :395-408
+	MixerState *s = (MixerState *)f->data;
+	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
+	if (!mixer_pin_ok("mixer_enable_output", ctl->pin)) return -1;
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	s->channels[ctl->pin].output_enabled = (bool_t)ctl->param.enabled;
+	s->single_output = has_single_output(f, s);
+	mixer_push_controls(f, s);
+	ms_filter_unlock(f);
+	return 0;
+}
+int mixer_set_conference_mode(MSFilter *f, void *data) {
+	((MixerState *)f->data)->conf_mode = *(int *)data;
+	return 0;
+}
+int mixer_set_master_channel(MSFilter *f, void *data) {
+	((MixerState *)f->data)->master_channel = *(int *)data;
+	return 0;
+}
+MSFilterMethod mixer_methods[] = {{MS_FILTER_SET_NCHANNELS, mixer_set_nchannels},
+                                  {MS_FILTER_GET_NCHANNELS, mixer_get_nchannels},
+                                  {MS_FILTER_SET_SAMPLE_RATE, mixer_set_rate},
+                                  {MS_FILTER_GET_SAMPLE_RATE, mixer_get_rate},
+                                  {MS_AUDIO_MIXER_SET_INPUT_GAIN, mixer_set_input_gain},
+                                  {MS_AUDIO_MIXER_SET_ACTIVE, mixer_set_active},
+                                  {MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, mixer_set_conference_mode},
+                                  {MS_AUDIO_MIXER_SET_MASTER_CHANNEL, mixer_set_master_channel},
+                                  {MS_AUDIO_MIXER_ENABLE_OUTPUT, mixer_enable_output},
+                                  {0, NULL}};

@@ -1,0 +1,231 @@
+// filters/resample.inl -- MSResample facade (src/audiofilters/msresample.c).
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the pool / hub
+// infrastructure); not compiled on its own.
+
+// =================================================================== resampler
+struct ResamplePool : Pool {
+	uint32_t in_rate, out_rate;
+	int in_len, ostride;
+	mi_resampler *r = nullptr;
+	int16_t *h_in, *h_out, *d_in, *d_out;
+	int32_t *h_olen, *d_olen;
+	uint8_t *h_run, *d_run;
+	std::vector<int> staged, ready;
+	ResamplePool(uint32_t ir, uint32_t orate) : in_rate(ir), out_rate(orate) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_resampler_create(g_hub.context(), capacity, ir, orate, 3 /* SPEEX_RESAMPLER_QUALITY_VOIP */, &r));
+		in_len = (int)(ir / 100);
+		ostride = (mi_resampler_out_capacity(r, in_len) + 7) & ~7;
+		const size_t c = (size_t)capacity;
+		h_in = pinned<int16_t>(kMaxRounds * c * in_len);
+		h_out = pinned<int16_t>(kMaxRounds * c * ostride);
+		h_olen = pinned<int32_t>(kMaxRounds * c);
+		h_run = pinned<uint8_t>(kMaxRounds * c);
+		d_in = devmem<int16_t>(c * in_len);
+		d_out = devmem<int16_t>(c * ostride);
+		d_olen = devmem<int32_t>(c);
+		d_run = devmem<uint8_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r_ = 0; r_ < maxr; ++r_) {
+			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = staged[(size_t)s] > r_;
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in + r_ * c * in_len, c * in_len * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r_ * c, c));
+			MI_MUST(mi_resampler_process_masked(r, d_in, in_len, in_len, d_out, ostride, d_olen, d_run));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r_ * c * ostride, d_out, c * ostride * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_olen + r_ * c, d_olen, c * 4));
+		}
+		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override;
+};
+std::map<std::tuple<MSTicker *, uint32_t, uint32_t>, ResamplePool *> g_resample_pools;
+
+struct ResampleData { // ResampleData msresample.c:33-42
+	MSBufferizer *bz;
+	uint32_t ts;
+	uint32_t input_rate, output_rate;
+	int in_nchannels, out_nchannels;
+	ResamplePool *pool;
+	int slot;                 // first channel's slot (the one that emits)
+	std::vector<int> *slots;  // one batch slot per input channel (speex keeps one state per channel too)
+};
+
+void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
+	ResampleData *d = (ResampleData *)ms_malloc0(sizeof(*d));
+	d->bz = ms_bufferizer_new();
+	d->input_rate = 8000;
+	d->output_rate = 16000;
+	d->in_nchannels = d->out_nchannels = 1;
+	d->slot = -1;
+	d->slots = new std::vector<int>();
+	f->data = d;
+}
+
+void resample_release(ResampleData *d) {
+	if (d->pool) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		for (int sl : *d->slots) {
+			d->pool->release(sl);
+			d->pool->staged[(size_t)sl] = d->pool->ready[(size_t)sl] = 0;
+			MI_MUST(mi_resampler_reset(d->pool->r, sl, 1));
+		}
+	}
+	d->slots->clear();
+	d->pool = nullptr;
+	d->slot = -1;
+}
+
+void resample_uninit(MSFilter *f) {
+	ResampleData *d = (ResampleData *)f->data;
+	resample_release(d);
+	ms_bufferizer_destroy(d->bz);
+	delete d->slots;
+	ms_free(d);
+}
+
+// msresample.c:87-100: first input channel copied to every output channel
+mblk_t *channel_adapt(int in_nch, int out_nch, mblk_t *im) {
+	if (out_nch == in_nch) return im;
+	const size_t n = msgdsize(im) / (2 * (size_t)in_nch);
+	mblk_t *om = allocb(n * 2 * (size_t)out_nch, 0);
+	const int16_t *s = (const int16_t *)im->b_rptr;
+	int16_t *o = (int16_t *)om->b_wptr;
+	for (size_t i = 0; i < n; ++i)
+		for (int c = 0; c < out_nch; ++c) o[i * out_nch + c] = s[i * in_nch];
+	om->b_wptr += n * 2 * (size_t)out_nch;
+	mblk_meta_copy(im, om);
+	freemsg(im);
+	return om;
+}
+
+void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-179
+	ResampleData *d = (ResampleData *)f->data;
+	mblk_t *im;
+	if (d->output_rate == d->input_rate) { // :126-135 pass-through
+		while ((im = ms_queue_get(f->inputs[0])) != NULL)
+			ms_queue_put(f->outputs[0], channel_adapt(d->in_nchannels, d->out_nchannels, im));
+		return;
+	}
+	ms_filter_lock(f);
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	const int nch = d->in_nchannels < 1 ? 1 : d->in_nchannels;
+	if (d->pool && (d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate || (int)d->slots->size() != nch))
+		resample_release(d); // rates / channels changed: the handle is re-created, history lost (:138-148)
+	if (!d->pool) {
+		auto key = std::make_tuple(f->ticker, d->input_rate, d->output_rate);
+		auto it = g_resample_pools.find(key);
+		if (it == g_resample_pools.end()) {
+			ResamplePool *p = new ResamplePool(d->input_rate, d->output_rate);
+			p->ticker = f->ticker;
+			g_hub.pools.push_back(p);
+			it = g_resample_pools.emplace(key, p).first;
+		}
+		d->pool = it->second;
+		for (int ch = 0; ch < nch; ++ch) { // interleaved input: one state per channel, like speex_resampler_init(nb_channels)
+			const int sl = d->pool->acquire(f);
+			if (sl < 0) break;
+			d->slots->push_back(sl);
+		}
+		if ((int)d->slots->size() != nch) {
+			resample_release(d);
+			ms_queue_flush(f->inputs[0]);
+			ms_filter_unlock(f);
+			return;
+		}
+		d->slot = (*d->slots)[0];
+	}
+	ResamplePool *p = d->pool;
+	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
+	// this tick's input, re-framed to 10 ms blocks (a streaming filter: the sample sequence is
+	// independent of the blocking); the results are emitted by the flush task (ResamplePool::emit)
+	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
+	const size_t nbytes = (size_t)p->in_len * 2 * (size_t)nch;
+	std::vector<int16_t> frame;
+	while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->bz) >= nbytes) {
+		const size_t round = (size_t)p->staged[s];
+		if (nch == 1) {
+			ms_bufferizer_read(d->bz, (uint8_t *)(p->h_in + (round * c + s) * p->in_len), nbytes);
+		} else { // de-interleave into the channels' rows
+			frame.resize((size_t)p->in_len * nch);
+			ms_bufferizer_read(d->bz, (uint8_t *)frame.data(), nbytes);
+			for (int ch = 0; ch < nch; ++ch) {
+				int16_t *row = p->h_in + (round * c + (size_t)(*d->slots)[(size_t)ch]) * p->in_len;
+				for (int i = 0; i < p->in_len; ++i) row[i] = frame[(size_t)i * nch + ch];
+			}
+		}
+		for (int sl : *d->slots) p->staged[(size_t)sl]++;
+	}
+	if (p->staged[s]) request_flush(f);
+	ms_filter_unlock(f);
+}
+
+void ResamplePool::emit(MSFilter *f, int slot) {
+	ResampleData *d = (ResampleData *)f->data;
+	if (slot != d->slot) return; // the other channels' slots are emitted together with the first
+	const size_t c = (size_t)capacity, s = (size_t)slot;
+	const int nch = (int)d->slots->size();
+	for (int r = 0; r < ready[s]; ++r) {
+		const int outlen = h_olen[r * c + s];
+		mblk_t *om = allocb((size_t)outlen * 2 * (size_t)nch, 0);
+		if (nch == 1) {
+			memcpy(om->b_wptr, h_out + (r * c + s) * ostride, (size_t)outlen * 2);
+		} else { // re-interleave (speex_resampler_process_interleaved_int's output layout)
+			int16_t *o = (int16_t *)om->b_wptr;
+			for (int ch = 0; ch < nch; ++ch) {
+				const int16_t *row = h_out + (r * c + (size_t)(*d->slots)[(size_t)ch]) * ostride;
+				for (int i = 0; i < outlen; ++i) o[(size_t)i * nch + ch] = row[i];
+			}
+		}
+		om->b_wptr += (size_t)outlen * 2 * (size_t)nch;
+		mblk_set_timestamp_info(om, d->ts); // msresample.c:168-169
+		d->ts += (uint32_t)outlen;
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], channel_adapt(nch, d->out_nchannels, om));
+		else freemsg(om);
+	}
+	for (int sl : *d->slots) ready[(size_t)sl] = 0;
+}
+
+int resample_set_sr(MSFilter *f, void *arg) { // :181-192
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->input_rate = *(unsigned int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+int resample_set_output_sr(MSFilter *f, void *arg) { // :194-205
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->output_rate = *(unsigned int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+int resample_set_in_nch(MSFilter *f, void *arg) {
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->in_nchannels = *(int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+int resample_set_out_nch(MSFilter *f, void *arg) {
+	ResampleData *d = (ResampleData *)f->data;
+	ms_filter_lock(f);
+	d->out_nchannels = *(int *)arg;
+	ms_filter_unlock(f);
+	return 0;
+}
+MSFilterMethod resample_methods[] = {{MS_FILTER_SET_SAMPLE_RATE, resample_set_sr},
+                                     {MS_FILTER_SET_OUTPUT_SAMPLE_RATE, resample_set_output_sr},
+                                     {MS_FILTER_SET_NCHANNELS, resample_set_in_nch},
+                                     {MS_FILTER_SET_OUTPUT_NCHANNELS, resample_set_out_nch},
+                                     {0, NULL}};

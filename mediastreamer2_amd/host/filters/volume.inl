@@ -1,0 +1,401 @@
+// filters/volume.inl -- MSVolume facade (src/audiofilters/msvolume.c).
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the pool / hub
+// infrastructure); not compiled on its own.
+
+// ====================================================================== volume
+struct Extremum { // OrtpExtremum (oRTP utils): windowed min/max, period in ms
+	float current = 0, last_stable = 0;
+	uint64_t t0 = (uint64_t)-1;
+	int period;
+	void reset() {
+		current = last_stable = 0;
+		t0 = (uint64_t)-1;
+	}
+	bool check_init(uint64_t now, float v) {
+		if (t0 != (uint64_t)-1 && (int)(now - t0) > period) {
+			last_stable = current;
+			t0 = (uint64_t)-1;
+		}
+		if (t0 == (uint64_t)-1) {
+			current = v;
+			t0 = now;
+			return true;
+		}
+		return false;
+	}
+	void record_min(uint64_t now, float v) {
+		check_init(now, v);
+		if (v < current) current = v;
+	}
+	void record_max(uint64_t now, float v) {
+		check_init(now, v);
+		if (v > current) current = v;
+	}
+};
+
+struct VolumePool : Pool {
+	int rate, cap_samples;
+	mi_volume *v = nullptr;
+	int16_t *h_buf, *d_buf;
+	int32_t *h_n, *d_n;
+	std::vector<int> staged, ready;
+	std::vector<mi_volume_params> params;
+	std::vector<mi_volume_state> state;
+	std::vector<uint8_t> params_dirty, state_dirty;
+	VolumePool(int r) : rate(r) {
+		init_slots(g_hub.capacity);
+		MI_MUST(mi_volume_create(g_hub.context(), capacity, rate, &v));
+		cap_samples = std::max(960, rate / 100 * 2);
+		cap_samples = (cap_samples + 7) & ~7;
+		const size_t c = (size_t)capacity;
+		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
+		h_n = pinned<int32_t>(kMaxRounds * c);
+		d_buf = devmem<int16_t>(c * cap_samples);
+		d_n = devmem<int32_t>(c);
+		staged.assign(c, 0);
+		ready.assign(c, 0);
+		mi_volume_params p;
+		mi_volume_default_params(&p);
+		params.assign(c, p);
+		state.resize(c);
+		MI_MUST(mi_volume_get_state(v, 0, capacity, state.data()));
+		params_dirty.assign(c, 0);
+		state_dirty.assign(c, 0);
+	}
+	void flush() override {
+		mi_ctx *ctx = g_hub.context();
+		const size_t c = (size_t)capacity;
+		for (int s = 0; s < capacity; ++s) {
+			if (params_dirty[(size_t)s]) MI_MUST(mi_volume_set_params(v, s, 1, &params[(size_t)s]));
+			if (state_dirty[(size_t)s]) MI_MUST(mi_volume_set_state(v, s, 1, &state[(size_t)s]));
+			params_dirty[(size_t)s] = state_dirty[(size_t)s] = 0;
+		}
+		int maxr = 0;
+		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int r = 0; r < maxr; ++r) {
+			for (int s = 0; s < capacity; ++s)
+				if (staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, c * cap_samples * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
+			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, c * cap_samples * 2));
+		}
+		if (maxr) {
+			MI_MUST(mi_ctx_sync(ctx));
+			MI_MUST(mi_volume_get_state(v, 0, capacity, state.data())); // meters for the app thread
+		}
+		for (int s = 0; s < capacity; ++s) {
+			ready[(size_t)s] = staged[(size_t)s];
+			staged[(size_t)s] = 0;
+		}
+	}
+	void emit(MSFilter *f, int slot) override;
+};
+std::map<std::pair<MSTicker *, int>, VolumePool *> g_volume_pools;
+
+struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
+	mi_volume_params p;
+	float gain, target_gain; // pending values for a slot not yet acquired
+	int sample_rate, nsamples;
+	MSFilter *peer;
+	MSBufferizer *buffer;
+	MSBufferizer *spill; // light path: the part of an over-long block that did not fit this tick's rounds
+	Extremum min, max;
+	VolumePool *pool;
+	int slot;
+	bool ng_soft_start;
+};
+
+void volume_init(MSFilter *f) { // msvolume.c:88-118
+	VolumeData *d = new VolumeData();
+	mi_volume_default_params(&d->p);
+	d->gain = d->target_gain = 1;
+	d->sample_rate = 8000;
+	d->nsamples = 80;
+	d->peer = NULL;
+	d->buffer = ms_bufferizer_new();
+	d->spill = ms_bufferizer_new();
+	d->max.period = 1000;
+	d->min.period = 30000;
+	d->pool = nullptr;
+	d->slot = -1;
+	f->data = d;
+}
+
+void volume_uninit(MSFilter *f) {
+	VolumeData *d = (VolumeData *)f->data;
+	if (d->pool && d->slot >= 0) {
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		d->pool->release(d->slot);
+	}
+	ms_bufferizer_destroy(d->buffer);
+	ms_bufferizer_destroy(d->spill);
+	delete d;
+}
+
+mi_volume_state *vstate(VolumeData *d) { return (d->pool && d->slot >= 0) ? &d->pool->state[(size_t)d->slot] : nullptr; }
+
+void volume_push_params(VolumeData *d) {
+	if (!d->pool || d->slot < 0) return;
+	d->pool->params[(size_t)d->slot] = d->p;
+	d->pool->params_dirty[(size_t)d->slot] = 1;
+}
+
+void volume_attach_slot(MSFilter *f) {
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (d->pool && (d->pool->rate != d->sample_rate || d->pool->ticker != f->ticker)) {
+		d->pool->release(d->slot);
+		d->pool = nullptr;
+		d->slot = -1;
+	}
+	if (!d->pool) {
+		auto key = std::make_pair(f->ticker, d->sample_rate);
+		auto it = g_volume_pools.find(key);
+		if (it == g_volume_pools.end()) {
+			VolumePool *p = new VolumePool(d->sample_rate);
+			p->ticker = f->ticker;
+			g_hub.pools.push_back(p);
+			it = g_volume_pools.emplace(key, p).first;
+		}
+		d->pool = it->second;
+		d->slot = d->pool->acquire(f);
+		if (d->slot < 0) {
+			d->pool = nullptr;
+			return;
+		}
+		// fresh slot: volume_init state, then whatever the methods set before attach
+		mi_volume_state st;
+		memset(&st, 0, sizeof(st));
+		st.gain = d->gain;
+		st.target_gain = d->target_gain;
+		st.ng_gain = 1;
+		d->pool->state[(size_t)d->slot] = st;
+		d->pool->state_dirty[(size_t)d->slot] = 1;
+	}
+	// the peer is addressed by its slot in the same pool
+	d->p.peer = -1;
+	if (d->peer) {
+		VolumeData *pd = (VolumeData *)d->peer->data;
+		if (pd->pool == d->pool && pd->slot >= 0) d->p.peer = pd->slot;
+		else ms_warning("MSVolume[mi355x]: peer not in the same batch yet (different rate or not attached)");
+	}
+	volume_push_params(d);
+}
+
+void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
+	VolumeData *d = (VolumeData *)f->data;
+	d->nsamples = (int)(0.01 * (float)d->sample_rate);
+	d->min.reset();
+	d->max.reset();
+	volume_attach_slot(f);
+}
+
+void volume_process(MSFilter *f) { // msvolume.c:471-514
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!d->pool) volume_attach_slot(f);
+	if (!d->pool) {
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	if (d->peer && d->p.peer < 0) volume_attach_slot(f);
+	VolumePool *p = d->pool;
+	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
+	mblk_t *m;
+	if (d->p.agc_enabled || d->peer != NULL) { // :480-503 re-framed to 10 ms chunks
+		const size_t nbytes = (size_t)d->nsamples * 2;
+		ms_bufferizer_put_from_queue(d->buffer, f->inputs[0]);
+		while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->buffer) >= nbytes) {
+			ms_bufferizer_read(d->buffer, (uint8_t *)(p->h_buf + (p->staged[s] * c + s) * p->cap_samples), nbytes);
+			p->h_n[p->staged[s] * c + s] = d->nsamples;
+			p->staged[s]++;
+		}
+	} else { // :505-512 light path: one chunk per mblk.  A block longer than a batch row (20 ms and more than 960 samples)
+		// is cut into row-sized chunks -- no sample is dropped; the meter then sees those chunks, not the whole block.
+		for (;;) {
+			if (p->staged[s] >= kMaxRounds) break;
+			int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
+			int n = 0;
+			const size_t spilled = ms_bufferizer_get_avail(d->spill);
+			if (spilled) {
+				n = (int)std::min(spilled / 2, (size_t)p->cap_samples);
+				ms_bufferizer_read(d->spill, (uint8_t *)row, (size_t)n * 2);
+			} else if ((m = ms_queue_get(f->inputs[0])) != NULL) {
+				n = (int)(msgdsize(m) / 2);
+				if (n > p->cap_samples) {
+					ms_bufferizer_put(d->spill, m); // served chunk by chunk from the top of the loop
+					continue;
+				}
+				memcpy(row, m->b_rptr, (size_t)n * 2);
+				freemsg(m);
+			} else {
+				break;
+			}
+			p->h_n[p->staged[s] * c + s] = n;
+			p->staged[s]++;
+		}
+	}
+	if (p->staged[s]) request_flush(f);
+}
+
+void VolumePool::emit(MSFilter *f, int slot) {
+	VolumeData *d = (VolumeData *)f->data;
+	const size_t c = (size_t)capacity, s = (size_t)slot;
+	for (int r = 0; r < ready[s]; ++r) {
+		const int n = h_n[r * c + s];
+		mblk_t *om = allocb((size_t)n * 2, 0);
+		memcpy(om->b_wptr, h_buf + (r * c + s) * cap_samples, (size_t)n * 2);
+		om->b_wptr += n * 2;
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
+		else freemsg(om);
+	}
+	if (ready[s] && f->ticker) { // meters (update_energy msvolume.c:405-406)
+		d->max.record_max(f->ticker->time, state[s].energy);
+		d->min.record_min(f->ticker->time, state[s].energy);
+	}
+	ready[s] = 0;
+}
+
+float linear_to_dbm0(float linear) { // ms_volume_linear_to_dbm0 msvolume.c:565-568
+	if (linear == 0) return MS_VOLUME_DB_LOWEST;
+	return 10 * log10f(linear);
+}
+
+int volume_get(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mi_volume_state *st = vstate(d);
+	*(float *)arg = linear_to_dbm0(st ? st->energy : 0.f);
+	return 0;
+}
+int volume_get_linear(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mi_volume_state *st = vstate(d);
+	*(float *)arg = st ? st->energy : 0.f;
+	return 0;
+}
+int volume_get_min(MSFilter *f, void *arg) {
+	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->min.current);
+	return 0;
+}
+int volume_get_max(MSFilter *f, void *arg) {
+	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->max.current);
+	return 0;
+}
+void volume_set_gains(VolumeData *d, bool also_target) {
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	mi_volume_state *st = vstate(d);
+	if (st) {
+		st->gain = d->gain;
+		if (also_target) st->target_gain = d->target_gain;
+		d->pool->state_dirty[(size_t)d->slot] = 1;
+	}
+	volume_push_params(d);
+}
+int volume_set_gain(MSFilter *f, void *arg) { // :270-276
+	VolumeData *d = (VolumeData *)f->data;
+	d->gain = d->target_gain = d->p.static_gain = *(float *)arg;
+	volume_set_gains(d, true);
+	return 0;
+}
+int volume_set_db_gain(MSFilter *f, void *arg) { // :262-268 (power ratio)
+	VolumeData *d = (VolumeData *)f->data;
+	d->gain = d->p.static_gain = (float)pow(10, (*(float *)arg) / 10);
+	volume_set_gains(d, false);
+	return 0;
+}
+int volume_get_gain(MSFilter *f, void *arg) {
+	*(float *)arg = ((VolumeData *)f->data)->p.static_gain;
+	return 0;
+}
+int volume_get_gain_db(MSFilter *f, void *arg) {
+	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->p.static_gain);
+	return 0;
+}
+int volume_set_peer(MSFilter *f, void *arg) { // :292-297 stores the MSFilter*
+	VolumeData *d = (VolumeData *)f->data;
+	d->peer = (MSFilter *)arg;
+	if (d->pool) volume_attach_slot(f);
+	return 0;
+}
+int volume_set_rate(MSFilter *f, void *arg) {
+	((VolumeData *)f->data)->sample_rate = *(int *)arg;
+	return 0;
+}
+#define VOL_FLOAT_SETTER(name, field, check)                       \
+	int name(MSFilter *f, void *arg) {                             \
+		VolumeData *d = (VolumeData *)f->data;                     \
+		const float val = *(float *)arg;                           \
+		if (!(check)) {                                            \
+			ms_error("MSVolume: parameter out of range");          \
+			return -1;                                             \
+		}                                                          \
+		d->p.field = val;                                          \
+		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);        \
+		volume_push_params(d);                                     \
+		return 0;                                                  \
+	}
+VOL_FLOAT_SETTER(volume_set_ea_threshold, ea_thres, val >= 0 && val <= 1) // :305-314
+VOL_FLOAT_SETTER(volume_set_ea_speed, vol_upramp, val >= 0 && val <= .5)  // :324-333
+VOL_FLOAT_SETTER(volume_set_ea_force, force, true)
+VOL_FLOAT_SETTER(volume_set_ea_transmit, ea_transmit_thres, true)
+VOL_FLOAT_SETTER(volume_set_ng_threshold, ng_threshold, true)
+int volume_set_ea_sustain(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.sustain_time = *(int *)arg;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	volume_push_params(d);
+	return 0;
+}
+int volume_set_agc(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.agc_enabled = *(int *)arg;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	volume_push_params(d);
+	return 0;
+}
+int volume_enable_noise_gate(MSFilter *f, void *arg) { // :352-359
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.noise_gate_enabled = *(bool_t *)arg;
+	if (d->p.noise_gate_enabled) d->gain = d->target_gain = d->p.ng_floorgain;
+	volume_set_gains(d, d->p.noise_gate_enabled != 0);
+	return 0;
+}
+int volume_set_ng_floorgain(MSFilter *f, void *arg) { // :367-378
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.ng_floorgain = *(float *)arg;
+	if (d->p.ng_floorgain < 0.005f) d->p.ng_floorgain = 0.005f;
+	if (d->p.noise_gate_enabled) d->gain = d->target_gain = d->p.ng_floorgain;
+	volume_set_gains(d, d->p.noise_gate_enabled != 0);
+	return 0;
+}
+int volume_remove_dc(MSFilter *f, void *arg) {
+	VolumeData *d = (VolumeData *)f->data;
+	d->p.remove_dc = *(int *)arg;
+	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	volume_push_params(d);
+	return 0;
+}
+MSFilterMethod volume_methods[] = {{MS_VOLUME_GET, volume_get},
+                                   {MS_VOLUME_GET_LINEAR, volume_get_linear},
+                                   {MS_VOLUME_SET_GAIN, volume_set_gain},
+                                   {MS_VOLUME_SET_PEER, volume_set_peer},
+                                   {MS_VOLUME_SET_EA_THRESHOLD, volume_set_ea_threshold},
+                                   {MS_VOLUME_SET_EA_SPEED, volume_set_ea_speed},
+                                   {MS_VOLUME_SET_EA_FORCE, volume_set_ea_force},
+                                   {MS_VOLUME_SET_EA_SUSTAIN, volume_set_ea_sustain},
+                                   {MS_VOLUME_SET_EA_TRANSMIT_THRESHOLD, volume_set_ea_transmit},
+                                   {MS_FILTER_SET_SAMPLE_RATE, volume_set_rate},
+                                   {MS_VOLUME_ENABLE_AGC, volume_set_agc},
+                                   {MS_VOLUME_ENABLE_NOISE_GATE, volume_enable_noise_gate},
+                                   {MS_VOLUME_SET_NOISE_GATE_THRESHOLD, volume_set_ng_threshold},
+                                   {MS_VOLUME_SET_NOISE_GATE_FLOORGAIN, volume_set_ng_floorgain},
+                                   {MS_VOLUME_SET_DB_GAIN, volume_set_db_gain},
+                                   {MS_VOLUME_GET_GAIN, volume_get_gain},
+                                   {MS_VOLUME_GET_GAIN_DB, volume_get_gain_db},
+                                   {MS_VOLUME_REMOVE_DC, volume_remove_dc},
+                                   {MS_VOLUME_GET_MIN, volume_get_min},
+                                   {MS_VOLUME_GET_MAX, volume_get_max},
+                                   {0, NULL}};
