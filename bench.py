@@ -690,13 +690,18 @@ def main():
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
                     ctx.sync()
-                    ms_ = min(lg.timed(ksteps, g) for _ in range(3))  # per-kernel table: best of three replays
+                    reps = [lg.timed(ksteps, g) for _ in range(7)]
+                    ms_ = min(reps)  # per-kernel table: best replay; the spread goes into `replay_stats_us`
                     ctx.sync()
                     # the PMC summary was taken at the bench sizes; the 65536-stream row has no counter pass
                     r = roofline(ms_, ksteps, lg.alg_bytes,
                                  None if mk is make_resample_65536 else pmc_traffic(lg.name))
                     r["kernel"] = lg.name
                     r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
+                    per = np.array(reps) * 1e3 / ksteps  # the reference's profiler prints count/min/mean/max/sd per filter
+                    r["replay_stats_us"] = {"count": len(reps), "launches_per_replay": ksteps, "min": round(float(per.min()), 3),
+                                            "mean": round(float(per.mean()), 3), "max": round(float(per.max()), 3),
+                                            "sd": round(float(per.std()), 3)}  # (src/base/msfactory.c ms_factory_log_statistics)
                     if hasattr(lg, "state_bytes"):
                         r["resident_state_bytes"] = int(lg.state_bytes)
                         r["streams_per_10ms_tick_at_this_rate"] = int(lg.units * 0.010 / (ms_ * 1e-3 / ksteps) / 1.875)
