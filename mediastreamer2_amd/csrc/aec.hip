@@ -136,6 +136,11 @@ __device__ __forceinline__ int16_t word2int(float x) {
 
 __device__ __forceinline__ float qcurve(float x) { return 1.f / (1.f + .15f / x); }
 
+// (float)sqrt((double)x), which is what the library's spx_sqrt gives for a float argument, equals the correctly
+// rounded single-precision square root bit for bit: rounding a square root twice is innocuous once the wider
+// format has at least 2 p + 2 digits (53 >= 50).  The float form is a third of the instructions and none of them f64.
+__device__ __forceinline__ float sqrt_via_double(float x) { return sqrtf(x); } // correctly rounded (hipcc default); __fsqrt_rn is the native approximation
+
 __constant__ float kHypergeom[21] = {0.82157f, 1.02017f, 1.20461f, 1.37534f, 1.53363f, 1.68092f, 1.81865f,
                                      1.94811f, 2.07038f, 2.18638f, 2.29688f, 2.40255f, 2.50391f, 2.60144f,
                                      2.69551f, 2.78647f, 2.87458f, 2.96015f, 3.04333f, 3.12431f, 3.20326f};

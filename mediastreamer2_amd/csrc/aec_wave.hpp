@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64, 3) void aec_mdf_wave_kernel(AecArgs a) {
 		if (lane == 0) {
 			float max_sum = 1, prop_sum = 1;
 			for (int i = 0; i < M; ++i) {
-				const float p = (float)sqrt((double)(1.0f + sm[SL::WNORM + i]));
+				const float p = sqrt_via_double(1.0f + sm[SL::WNORM + i]);
 				L.prop[i] = p;
 				if (p > max_sum) max_sum = p;
 			}
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64, 3) void aec_mdf_wave_kernel(AecArgs a) {
 	Pyy = Pyy + Yhd_F * Yhd_F;
 	Pey = WSeq<K>::dot_desc(Pey, Ehd, Yhd);
 	Pyy = WSeq<K>::dot_desc(Pyy, Yhd, Yhd);
-	Pyy = (float)sqrt((double)Pyy);
+	Pyy = sqrt_via_double(Pyy);
 	Pey = Pey / Pyy;
 	float tmp32 = a.beta0 * Syy;
 	if (tmp32 > a.beta_max * See) tmp32 = a.beta_max * See;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(64) void aec_post_wave_kernel(AecArgs a) {
 		float gain = g;
 		old_ps[k] = .2f * old_ps[k] + (.8f * (gain * gain)) * ps[k];
 		if (gain < gfl) gain = gfl;
-		const float tmp = p * (float)sqrt((double)gain) + (1.0f - p) * (float)sqrt((double)gfl);
+		const float tmp = p * sqrt_via_double(gain) + (1.0f - p) * sqrt_via_double(gfl);
 		gain2[k] = tmp * tmp;
 	}
 	store_vec<K>(sm + SL::OLDPS + e0, old_ps);

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * FLOW_WAVES) void flowctl_kernel(FlowArgs a) {
 						const int v = blk[i];
 						acc += (float)(v * v);
 					}
-					const float p = __fdiv_rn(__fsqrt_rn(__fdiv_rn(acc, (float)nsamples)), 32768 * 0.7f);
+					const float p = sqrtf(acc / (float)nsamples) / (32768 * 0.7f); // correctly rounded sqrt and divides (hipcc default)
 					silent = p < cfg.silent_threshold;
 				}
 				if (silent) {
