@@ -553,3 +553,39 @@ def test_speex_ec_state_string_carries_convergence_over(host):
     out_bad, _ = run(state=state, tail=64, ticks=50)       # the blob is for 128 ms: refused, cold start
     e_bad = float((out_bad[head].astype(float) ** 2).mean())
     assert e_bad > 5 * e_warm
+
+
+@pytest.mark.parametrize("kind", ["simple", "double"])
+def test_speex_ec_plugin_meets_the_reference_testers_thresholds(host, kind):
+    """The reference's echo-canceller tester scenario (tester/mediastreamer2_aec3_tester.c:654-739) run through the
+    drop-in plugin: far-end recording on pin 0, near-end + echo on pin 1, 10 ms ticks, the cleaned output graded with
+    the tester's own metric and thresholds (energy in the near-end's silences < 1, similarity in speech > 0.99 / 0.83;
+    audiodiff.c:442-576 restated in oracle/audiodiff.py).  See tests/test_aec_recordings.py for the DC-notch caveat."""
+    from test_aec_recordings import CASES, RATE, TAIL_MS, grade, load, notch
+    near, far, mic = load(kind)
+    ns = RATE // 100
+    nt = len(mic) // ns
+    ec = host.create(MS_SPEEX_EC_ID)
+    assert host.call_int(ec, SET_SAMPLE_RATE, RATE) == 0
+    assert host.call_int(ec, mid(EC_IFACE, 2, 4), TAIL_MS) == 0
+    s_ref, s_mic, k_ref, k_mic = host.source(), host.source(), host.sink(), host.sink()
+    host.link(s_ref, 0, ec, 0)
+    host.link(s_mic, 0, ec, 1)
+    host.link(ec, 0, k_ref, 0)
+    host.link(ec, 1, k_mic, 0)
+    host.S.ms_ticker_attach(host.ticker, ec)
+    for t in range(nt):
+        host.push(s_ref, far[t * ns:(t + 1) * ns])
+        host.push(s_mic, mic[t * ns:(t + 1) * ns])
+        host.step()
+    host.step(3)
+    out = host.drain(k_mic)
+    host.S.ms_ticker_detach(host.ticker, ec)
+    assert len(out) >= (nt - 3) * ns
+    _, _, _, thr_sim, thr_en = CASES[kind]
+    n = min(len(out), len(near))
+    sim, energy, _ = grade(notch(near)[:n], out[:n], kind)
+    _, energy_unprocessed, _ = grade(near[:n], mic[:n], kind)
+    assert energy_unprocessed > 50.0
+    assert energy < thr_en, energy
+    assert thr_sim < sim <= 1.0, sim
