@@ -177,3 +177,32 @@ def test_downsampler_fast_and_generic_paths_interleave(ctx, oracle):
             assert olen[s] == len(ref) == 160
             assert np.abs(out[s, :160].astype(int) - ref).max() <= 1
     rs.close()
+
+
+from test_oracle_cpu import WAV_FAMILY_PAIRS  # noqa: E402
+
+
+@pytest.mark.parametrize("a,b", WAV_FAMILY_PAIRS)
+def test_resampler_on_the_reference_wav_family(ctx, oracle, a, b):
+    """The reference ships ONE recording at 8 / 16 / 32 / 44.1 / 48 kHz (tester/sounds/test_silence_voice_*.wav, excerpts in
+    tests/golden/resample_wav/).  For every ratio family the kernels special-case, the file at rate a resampled on the GPU
+    must reproduce the file at rate b with the similarity the reference's tester demands of a resampled path (>= 0.98),
+    and equal the oracle within 1 LSB."""
+    from test_oracle_cpu import check_wav_family, reference_wav_family
+    x = reference_wav_family(a)
+    n = a // 100
+    rs = ms.ResamplerBatch(ctx, 2, a, b)
+    orc = oracle.Resampler(a, b)
+    got, want = [], []
+    for i in range(0, len(x) - n + 1, n):
+        blk = np.stack([x[i:i + n], x[i:i + n]])
+        out, olen = rs.process(blk)
+        assert olen[0] == olen[1]
+        np.testing.assert_array_equal(out[0], out[1])
+        got.append(out[0][:olen[0]].copy())
+        want.append(orc.process(x[i:i + n]))
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert got.size == want.size
+    assert np.abs(got.astype(np.int32) - want).max() <= 1
+    check_wav_family(got, a, b)
+    rs.close()
