@@ -286,7 +286,7 @@ def make_plc_leg(ms, torch, ctx, nstreams=65536, rate=8000, loss=0.05):
         plc.process(rows[i], lens, modes[i])
 
     # per leg: the block in and out, the history write, the continuity buffer both ways
-    leg = Leg(ctx, "plc_kernel", launch, ring, nstreams * (2 * n * 2 + n * 2 + 2 * (2 * rate * 5 // 1000) * 2), nstreams,
+    leg = Leg(ctx, "plc_list_kernel+plc_received_kernel+plc_conceal_kernel", launch, ring, nstreams * (2 * n * 2 + n * 2 + 2 * (2 * rate * 5 // 1000) * 2), nstreams,
               "leg-ticks (%d samples, %.0f %% lost)" % (n, 100 * loss))
     leg.keep = (plc, rows, lens, modes)
     return leg

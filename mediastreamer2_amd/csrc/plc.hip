@@ -41,7 +41,8 @@ struct PlcArgs {
 	const float2 *tw1, *sup1, *tw2, *sup2; // forward (nb/2 complex) and inverse (nb complex) twiddles + real-FFT super twiddles
 	Factors f1, f2;
 	int nb, T, rate, nstreams, cap;
-	int lds_floats; // LDS of one wavefront (stream), in floats
+	int light_floats; // LDS of one wavefront of the RECEIVED kernel, in floats
+	int *count, *list; // streams to conceal this tick (filled by plc_received_kernel)
 	int16_t *blocks;
 	size_t stride;
 	const int32_t *len;
@@ -214,32 +215,36 @@ __device__ void update_history(int16_t *hist, uint32_t &head, const int16_t *dat
 	}
 }
 
-constexpr int PLC_WAVES = 1; // wavefronts (streams) per workgroup: 4 measured slower (48 -> 52 us clean, 83 -> 128 us at 5 % loss: a workgroup keeps its LDS until its one concealing wave is done)
+// A tick is three launches.  plc_list_kernel compacts the ids of the streams to conceal (one atomic per 64 streams);
+// plc_received_kernel serves the RECEIVED ones (a pass over the block: tiny LDS, four streams per workgroup);
+// plc_conceal_kernel walks the list with a bounded grid, one stream per wavefront with the transform buffers in LDS.  (One kernel for both, sized for the transforms, kept
+// 18 workgroups per CU for work that needs 1 KB: 48 us for 65 536 clean legs.)
+constexpr int PLC_LIGHT_WAVES = 4;
 
-__global__ __launch_bounds__(64 * PLC_WAVES) void plc_kernel(PlcArgs a) {
-	extern __shared__ float lds_all[];
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int s = blockIdx.x * (blockDim.x >> 6) + wave;
-	if (s >= a.nstreams) return;
-	float *lds_f = lds_all + (size_t)wave * a.lds_floats;
-	const int mode = a.mode[s];
-	if ((mode & 3) == 0) return;
+template <bool CONCEAL>
+__device__ __forceinline__ void plc_stream(const PlcArgs &a, float *lds_f, int s, int mode, int len, uint4 meta, int lane) {
 	const int nb = a.nb, T = a.T;
 	Lds L;
-	L.A = lds_f;
-	L.B = L.A + 2 * nb;
-	L.gen = reinterpret_cast<int16_t *>(L.B + 2 * nb);
-	L.cont = L.gen + 2 * nb;
+	if (CONCEAL) {
+		L.A = lds_f;
+		L.B = L.A + 2 * nb;
+		L.gen = reinterpret_cast<int16_t *>(L.B + 2 * nb);
+		L.cont = L.gen + 2 * nb;
+	} else { // a received block needs no transform buffers
+		L.A = L.B = nullptr;
+		L.gen = nullptr;
+		L.cont = reinterpret_cast<int16_t *>(lds_f);
+	}
 	L.blk = L.cont + 2 * T;
 	L.out = L.blk + a.cap;
 	int16_t *g_cont = a.cont + (size_t)s * 2 * T, *g_hist = a.hist + (size_t)s * nb, *g_gen = a.gen + (size_t)s * 2 * nb;
 	int16_t *row = a.blocks + (size_t)s * a.stride;
-	const int n = min(max(a.len[s], 0), a.cap);
-	uint32_t index = a.meta[4 * s] & 0xffffu, used = a.meta[4 * s + 1] & 0xffffu, head = a.meta[4 * s + 2];
+	const int n = min(max(len, 0), a.cap);
+	uint32_t index = meta.x & 0xffffu, used = meta.y & 0xffffu, head = meta.z;
 	if (n == 0) return;
 	for (int i = lane; i < 2 * T; i += 64) L.cont[i] = g_cont[i];
 
-	if ((mode & 3) == 1) { // ---- a block arrived: msgenericplc.c:63-116
+	if constexpr (!CONCEAL) { // ---- a block arrived: msgenericplc.c:63-116
 		for (int i = lane; i < n; i += 64) L.blk[i] = row[i];
 		wave_sync();
 		update_history(g_hist, head, L.blk, n, nb, lane);
@@ -332,6 +337,41 @@ __global__ __launch_bounds__(64 * PLC_WAVES) void plc_kernel(PlcArgs a) {
 	}
 }
 
+// the streams to conceal this tick, compacted: one atomic per wavefront of 64 streams
+__global__ __launch_bounds__(256) void plc_list_kernel(PlcArgs a) {
+	const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+	const bool c = s < a.nstreams && (a.mode[s] & 3) == 2 && a.len[s] > 0;
+	const unsigned long long mask = __ballot(c);
+	if (mask == 0) return;
+	int base = 0;
+	if (lane == 0) base = atomicAdd(a.count, __popcll(mask));
+	base = __shfl(base, 0);
+	if (c) a.list[base + __popcll(mask & ((1ull << lane) - 1ull))] = s;
+}
+
+__global__ __launch_bounds__(64 * PLC_LIGHT_WAVES) void plc_received_kernel(PlcArgs a) {
+	extern __shared__ float lds_all[];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int s = blockIdx.x * PLC_LIGHT_WAVES + wave;
+	if (s >= a.nstreams) return;
+	// one round trip for everything the decision needs
+	const int mode = a.mode[s], len = a.len[s];
+	const uint4 meta = reinterpret_cast<const uint4 *>(a.meta)[s];
+	if ((mode & 3) != 1) return;
+	plc_stream<false>(a, lds_all + (size_t)wave * a.light_floats, s, mode, len, meta, lane);
+}
+
+__global__ __launch_bounds__(64) void plc_conceal_kernel(PlcArgs a) {
+	extern __shared__ float lds_all[];
+	const int lane = threadIdx.x;
+	const int count = *a.count;
+	for (int k = blockIdx.x; k < count; k += gridDim.x) {
+		const int s = a.list[k];
+		plc_stream<true>(a, lds_all, s, MI_PLC_CONCEAL, a.len[s], reinterpret_cast<const uint4 *>(a.meta)[s], lane);
+		wave_sync(); // the next stream reuses the LDS
+	}
+}
+
 // kf_factor kiss_fft.c:412-435: 4s first, then 2, 3, 5, ...
 bool factorize(int n, Factors *f) {
 	f->n = n;
@@ -381,8 +421,8 @@ struct mi_plc {
 	uint32_t *d_meta = nullptr;
 	float *d_window = nullptr;
 	float2 *d_tw1 = nullptr, *d_sup1 = nullptr, *d_tw2 = nullptr, *d_sup2 = nullptr;
-	size_t lds = 0;
-	int waves = 1;
+	size_t lds = 0, lds_light = 0;
+	int *d_count = nullptr, *d_list = nullptr;
 };
 
 extern "C" {
@@ -391,7 +431,7 @@ void mi_plc_destroy(mi_plc *p) {
 	if (!p) return;
 	if (p->ctx->activate() == MI_OK) {
 		(void)hipStreamSynchronize(p->ctx->stream);
-		void *dv[] = {p->d_cont, p->d_hist, p->d_gen, p->d_meta, p->d_window, p->d_tw1, p->d_sup1, p->d_tw2, p->d_sup2};
+		void *dv[] = {p->d_cont, p->d_hist, p->d_gen, p->d_meta, p->d_window, p->d_tw1, p->d_sup1, p->d_tw2, p->d_sup2, p->d_count, p->d_list};
 		for (void *v : dv)
 			if (v) (void)hipFree(v);
 	}
@@ -416,7 +456,7 @@ int mi_plc_create(mi_ctx *c, int nstreams, int rate, int max_block, mi_plc **out
 	const size_t n = (size_t)nstreams;
 	p->lds = sizeof(float) * 4 * (size_t)p->nb + sizeof(int16_t) * (2 * (size_t)p->nb + 2 * (size_t)p->T + 2 * (size_t)p->cap);
 	p->lds = (p->lds + 15) & ~(size_t)15;
-	p->waves = (int)std::max<size_t>(1, std::min<size_t>(PLC_WAVES, (64 * 1024) / p->lds));
+	p->lds_light = (sizeof(int16_t) * (2 * (size_t)p->T + 2 * (size_t)p->cap) + 15) & ~(size_t)15;
 	if (p->lds > 64 * 1024) {
 		mi::set_error("mi_plc_create: %zu bytes of LDS per stream (rate %d, blocks of %d) exceed 64 KB", p->lds, rate, max_block);
 		delete p;
@@ -430,7 +470,8 @@ int mi_plc_create(mi_ctx *c, int nstreams, int rate, int max_block, mi_plc **out
 	    hipMalloc(&p->d_gen, n * 2 * p->nb * 2) != hipSuccess || hipMalloc(&p->d_meta, n * 16) != hipSuccess ||
 	    hipMalloc(&p->d_window, sizeof(float) * p->nb) != hipSuccess || hipMalloc(&p->d_tw1, sizeof(float2) * (p->nb / 2)) != hipSuccess ||
 	    hipMalloc(&p->d_sup1, sizeof(float2) * (p->nb / 2)) != hipSuccess || hipMalloc(&p->d_tw2, sizeof(float2) * p->nb) != hipSuccess ||
-	    hipMalloc(&p->d_sup2, sizeof(float2) * p->nb) != hipSuccess) {
+	    hipMalloc(&p->d_sup2, sizeof(float2) * p->nb) != hipSuccess || hipMalloc(&p->d_count, sizeof(int)) != hipSuccess ||
+	    hipMalloc(&p->d_list, sizeof(int) * n) != hipSuccess) {
 		mi::set_error("mi_plc_create: out of device memory");
 		return fail(MI_ENOMEM);
 	}
@@ -471,8 +512,16 @@ int mi_plc_process(mi_plc *p, int16_t *d_blocks, size_t stride, const int32_t *d
 	a.f1 = p->f1, a.f2 = p->f2;
 	a.nb = p->nb, a.T = p->T, a.rate = p->rate, a.nstreams = p->nstreams, a.cap = (int)std::min<size_t>((size_t)p->cap, stride);
 	a.blocks = d_blocks, a.stride = stride, a.len = d_len, a.mode = d_mode;
-	a.lds_floats = (int)(p->lds / sizeof(float));
-	hipLaunchKernelGGL(plc_kernel, dim3((p->nstreams + p->waves - 1) / p->waves), dim3(64 * p->waves), p->lds * p->waves, p->ctx->stream, a);
+	a.light_floats = (int)(p->lds_light / sizeof(float));
+	a.count = p->d_count, a.list = p->d_list;
+	MI_HIP(hipMemsetAsync(p->d_count, 0, sizeof(int), p->ctx->stream));
+	hipLaunchKernelGGL(plc_list_kernel, dim3((p->nstreams + 255) / 256), dim3(256), 0, p->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	hipLaunchKernelGGL(plc_received_kernel, dim3((p->nstreams + PLC_LIGHT_WAVES - 1) / PLC_LIGHT_WAVES), dim3(64 * PLC_LIGHT_WAVES),
+	                   p->lds_light * PLC_LIGHT_WAVES, p->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	const int grid = std::min(p->nstreams, (p->ctx->cu_count > 0 ? p->ctx->cu_count : 256) * 16);
+	hipLaunchKernelGGL(plc_conceal_kernel, dim3(grid), dim3(64), p->lds, p->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
