@@ -22,6 +22,17 @@
  *                   called from src/audiofilters/speexec.c:200-203,:297-298
  *   mi_scaler_*     replaces MSScalerDesc.context_process,
  *                   include/mediastreamer2/msvideo.h:473-478, src/voip/msvideo.c:542-581
+ *   mi_pixconv_*    replaces the packed -> I420 conversions yuv_scale reaches for MSPixConv,
+ *                   src/voip/msvideo.c:553-571 (src/videofilters/pixconv.c:62-94)
+ *   mi_g711_*, mi_l16_swap, mi_chan_adapt
+ *                   replace the sample loops of MSAlawDec/Enc, MSUlawDec/Enc (src/audiofilters/alaw.c,
+ *                   ulaw.c, g711.c), MSL16Enc/Dec (l16.c:58-70) and MSChannelAdapter (chanadapt.c:87-121)
+ *   mi_flowctl_*    replaces ms_audio_flow_controller_process, src/audiofilters/flowcontrol.c:107-152
+ *   mi_plc_*        replaces the plc_context_t calls of generic_plc_process,
+ *                   src/audiofilters/msgenericplc.c:59-167 (genericplc.c:83-241)
+ *   mi_fifo_*       MSBufferizer (src/base/msqueue.c:70-113) for a batch of streams, on the device
+ *   mi_session_*    the chained path of a batch of call legs behind one call per tick (no reference
+ *                   counterpart: what a server does instead of one MSTicker graph per call)
  *
  * (all paths relative to the mediastreamer2 5.5.0 tree).
  *
