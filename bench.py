@@ -673,6 +673,9 @@ def main():
         "roofline": roofline(ev_ms_max, a.steps, leg.alg_bytes, pmc_traffic("resample_up_kernel")),
     }
     line["roofline"]["kernel"] = leg.name
+    line["roofline"]["note"] = ("configs[1] is a %.1f MB tick: %.2f us of HBM time at peak against a ~1.9 us empty-kernel floor for this grid, "
+                                "so the launch is latency-bound; the same kernel on a deployment-sized batch is other_kernels[0]"
+                                % (leg.alg_bytes / 1e6, leg.alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e6))
 
     if rank == 0 and world == 1:
         if not a.no_extras:
