@@ -174,7 +174,8 @@ struct UpArgs {
 // and R consecutive input positions; its FILT-1+R sample window comes out of LDS with 16-byte reads
 // (window start = 32*tile bytes, DEN lanes per address -> broadcast), outputs are staged in LDS and
 // leave as 16-byte stores.
-constexpr int UP_WAVES = 2; // wavefronts per workgroup of resample_up_kernel
+constexpr int UP_WAVES = 4; // most wavefronts per workgroup of the one-wave-per-stream kernels (the launchers pick 2 or 4)
+inline int waves_per_workgroup(int nstreams) { return nstreams <= 16384 ? UP_WAVES : 2; }
 
 // LDS hand-over inside ONE wavefront: the LDS unit executes a wave's instructions in order, so only the compiler has
 // to be kept from moving accesses across this point (no s_barrier: the waves of a workgroup are independent here)
@@ -238,8 +239,10 @@ __device__ __forceinline__ void fir_tile(const float *xwin, const f2 (&t2)[FILT 
 template <int DEN, int FILT, int R, bool MULTI, bool TWO>
 __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem_all[];
-	// UP_WAVES independent wavefronts share a workgroup only to halve the number of workgroups the dispatcher has to
-	// place (0.4 us of a 6.7 us launch at 4096 streams); each has its own LDS slice and never waits for the other.
+	// Two or four independent wavefronts share a workgroup only to cut the number of workgroups the dispatcher has to
+	// place (0.4 us, then another 0.25 us, of a 6.6 us launch at 4096 streams); each has its own LDS slice and never
+	// waits for the others.  Four per workgroup lose 10 % on big batches (62 vs 56 us at 65 536 streams), so the
+	// launchers take four up to 16 384 streams and two above.
 	char *smem = smem_all + (size_t)(threadIdx.x >> 6) * a.lds_per_wave;
 	constexpr int HIST = FILT - 1;
 	const int lane = threadIdx.x & 63;
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a)
 	// ---- the first stream's row goes out FIRST (it is the HBM miss on the critical path of a one-stream wave), the
 	// run flag next, the L2-resident tap rows last; nothing waits before the row is needed for staging
 	short4 v0 = make_short4(0, 0, 0, 0), v1 = v0;
-	const int nwaves = gridDim.x * UP_WAVES;
-	int s = blockIdx.x * UP_WAVES + (threadIdx.x >> 6);
+	const int nwaves = gridDim.x * (blockDim.x >> 6);
+	int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	int runv = 1;
 	if (s < a.nstreams) {
 		if (lane < nq) v0 = *quad_ptr(s, lane);
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_down_kernel(DownArg
 	wave_sync();
 	const int hq = a.hist_stride >> 2, nq = hq + (a.in_len >> 2);
 	const int nlanes = NUM * a.tiles;
-	const int nwaves = gridDim.x * UP_WAVES;
+	const int nwaves = gridDim.x * (blockDim.x >> 6);
 	f2 t2[FILT / 2];
 	auto load_row = [&](int p) {
 		const float4 *tp = tab4 + p * (FILT / 4);
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_down_kernel(DownArg
 		const int l0 = lane < nlanes ? lane : 0;
 		load_row(l0 - (l0 / NUM) * NUM);
 	}
-	for (int s = blockIdx.x * UP_WAVES + (threadIdx.x >> 6); s < a.nstreams; s += nwaves) {
+	for (int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < a.nstreams; s += nwaves) {
 		if (a.run && !a.run[s]) {
 			if (lane == 0 && a.out_len) a.out_len[s] = 0;
 			continue;
@@ -526,9 +529,9 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_ratio_kernel(RatioA
 	wave_sync();
 	const int hq = a.hist_stride >> 2, nq = hq + (a.in_len >> 2);
 	const int nlanes = ROWS * a.tiles;
-	const int nwaves = gridDim.x * UP_WAVES;
+	const int nwaves = gridDim.x * (blockDim.x >> 6);
 	f2 t2[FT / 2];
-	for (int s = blockIdx.x * UP_WAVES + (threadIdx.x >> 6); s < a.nstreams; s += nwaves) {
+	for (int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < a.nstreams; s += nwaves) {
 		if (a.run && !a.run[s]) {
 			if (lane == 0 && a.out_len) a.out_len[s] = 0;
 			continue;
@@ -765,14 +768,15 @@ static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_st
 	const int max_waves = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * waves_per_cu;
 	const int per_wave = mi::ceil_div(r->nstreams, max_waves);
 	const int nwaves = mi::ceil_div(r->nstreams, per_wave);
-	const int grid = mi::ceil_div(nwaves, UP_WAVES);
+	const int wpw = waves_per_workgroup(r->nstreams);
+	const int grid = mi::ceil_div(nwaves, wpw);
 	a.lds_per_wave = (int)((lds + 15) & ~(size_t)15);
 	if (DEN * tiles <= 64 && nq <= 64)
-		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, false, false>), dim3(grid), dim3(64 * UP_WAVES),
-		                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
+		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, false, false>), dim3(grid), dim3(64 * wpw),
+		                   (size_t)a.lds_per_wave * wpw, r->ctx->stream, a);
 	else
-		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, true, true>), dim3(grid), dim3(64 * UP_WAVES),
-		                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
+		hipLaunchKernelGGL((resample_up_kernel<DEN, FILT, R, true, true>), dim3(grid), dim3(64 * wpw),
+		                   (size_t)a.lds_per_wave * wpw, r->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	*done = true;
 	return MI_OK;
@@ -808,8 +812,9 @@ static int launch_down(mi_resampler *r, const int16_t *d_in, int in_len, int in_
 	const int max_waves = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * 16;
 	const int per_wave = mi::ceil_div(r->nstreams, max_waves);
 	const int nwaves = mi::ceil_div(r->nstreams, per_wave);
-	hipLaunchKernelGGL((resample_down_kernel<NUM, FILT, R>), dim3(mi::ceil_div(nwaves, UP_WAVES)), dim3(64 * UP_WAVES),
-	                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
+	const int wpw = waves_per_workgroup(r->nstreams);
+	hipLaunchKernelGGL((resample_down_kernel<NUM, FILT, R>), dim3(mi::ceil_div(nwaves, wpw)), dim3(64 * wpw),
+	                   (size_t)a.lds_per_wave * wpw, r->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	*done = true;
 	return MI_OK;
@@ -845,8 +850,9 @@ static int launch_ratio(mi_resampler *r, const int16_t *d_in, int in_len, int in
 	const int max_waves = (r->ctx->cu_count > 0 ? r->ctx->cu_count : 256) * 16;
 	const int per_wave = mi::ceil_div(r->nstreams, max_waves);
 	const int nwaves = mi::ceil_div(r->nstreams, per_wave);
-	hipLaunchKernelGGL((resample_ratio_kernel<L, M, FT, R>), dim3(mi::ceil_div(nwaves, UP_WAVES)), dim3(64 * UP_WAVES),
-	                   (size_t)a.lds_per_wave * UP_WAVES, r->ctx->stream, a);
+	const int wpw = waves_per_workgroup(r->nstreams);
+	hipLaunchKernelGGL((resample_ratio_kernel<L, M, FT, R>), dim3(mi::ceil_div(nwaves, wpw)), dim3(64 * wpw),
+	                   (size_t)a.lds_per_wave * wpw, r->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	*done = true;
 	return MI_OK;
