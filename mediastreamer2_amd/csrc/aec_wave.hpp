@@ -261,7 +261,7 @@ __device__ __forceinline__ void store_bins(float2 *p, const float2 (&v)[K]) {
 
 // ===================================================================== MDF canceller, one frame
 template <int F>
-__global__ __launch_bounds__(64, 3) void aec_mdf_wave_kernel(AecArgs a) {
+__global__ __launch_bounds__(64, (F == 256 ? 3 : (F == 128 ? 5 : 6))) void aec_mdf_wave_kernel(AecArgs a) {
 	__shared__ WLds<F> L;
 	using SL = SmallLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
