@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 3 : (F == 128 ? 5 : 6))) void aec_m
 	__shared__ WLds<F> L;
 	using SL = SmallLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
-	const int s = blockIdx.x;
+	const int s = a.first + blockIdx.x;
 	if (a.run && !a.run[s]) return;
 	const int lane = threadIdx.x;
 	const int e0 = lane * K; // first element (sample / bin) this lane owns
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(64) void aec_post_wave_kernel(AecArgs a) {
 	__shared__ WLds<F> L;
 	using SL = SmallLayout<F>;
 	constexpr int K = F / 64;
-	const int s = blockIdx.x;
+	const int s = a.first + blockIdx.x;
 	if (a.run && !a.run[s]) return;
 	const int lane = threadIdx.x;
 	const int e0 = lane * K;
