@@ -241,6 +241,10 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
                         const uint8_t *h_run, unsigned flags);
 /* state bytes per stream (for DESIGN/roofline accounting) */
+/* How mi_aec_process schedules the post-filter: -1 automatic (at 256-sample frames and >= 16 384 streams the batch is cut
+ * in two and the first half's post-filter runs on a second HIP stream next to the second half's canceller), 0 never,
+ * 2..8 always with that many chunks.  Results do not depend on it. */
+int mi_aec_set_overlap(mi_aec *a, int chunks);
 size_t mi_aec_state_bytes(const mi_aec *a);
 /* One stream's whole state as a host blob, and back: what fetch_config / apply_config (src/audiofilters/speexec.c:119-167)
  * do with SPEEX_ECHO_GET_BLOB / SET_BLOB of the reference's speex fork, so a converged canceller survives the end of a

@@ -318,6 +318,10 @@ class AecBatch(_Batch):
     def state_bytes(self):
         return self.ctx.L.mi_aec_state_bytes(self.h)
 
+    def set_overlap(self, chunks):
+        """-1 automatic, 0 off, 2..8 chunks: the post-filter of a chunk on a second stream next to the next chunk's canceller."""
+        check(self.ctx.L.mi_aec_set_overlap(self.h, chunks))
+
     def export_state(self, stream):
         """One stream's whole state as bytes (speexec.c:145-167 fetch_config)."""
         n = self.ctx.L.mi_aec_blob_bytes(self.h)

@@ -240,6 +240,7 @@ struct mi_aec {
 	// the post-filter of a chunk runs on a second stream while the canceller works on the next chunk
 	hipStream_t s_post = nullptr;
 	hipEvent_t ev_chunk[AEC_CHUNKS] = {}, ev_post = nullptr;
+	int overlap_chunks = -1; // -1: automatic (two chunks at F = 256 from 16 384 streams on), 0: off, 2..AEC_CHUNKS: forced
 };
 
 namespace {
@@ -537,6 +538,12 @@ int mi_aec_reset(mi_aec *a, int first, int count) {
 	return a->F == 256 ? init_state<256>(a, first, count) : (a->F == 128 ? init_state<128>(a, first, count) : init_state<64>(a, first, count));
 }
 
+int mi_aec_set_overlap(mi_aec *a, int chunks) {
+	MI_CHECK_ARG(a && (chunks == -1 || chunks == 0 || (chunks >= 2 && chunks <= AEC_CHUNKS)));
+	a->overlap_chunks = chunks;
+	return MI_OK;
+}
+
 size_t mi_aec_state_bytes(const mi_aec *a) {
 	if (!a) return 0;
 	return ((size_t)(a->M + 1) * a->N + 2 * (size_t)a->M * a->N + (size_t)a->small_stride) * sizeof(float) +
@@ -588,8 +595,17 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 		else hipLaunchKernelGGL(aec_post_wave_kernel<64>, dim3(count), dim3(64), 0, st, g);
 	};
 	static const bool no_overlap = getenv("MSMI355X_AEC_NO_OVERLAP") != nullptr; // A/B switch
+	static const int env_chunks = [] {
+		const char *e = getenv("MSMI355X_AEC_CHUNKS");
+		const int v = e ? atoi(e) : 0;
+		return v >= 2 && v <= AEC_CHUNKS ? v : 2;
+	}();
 	const bool post = (flags & MI_AEC_POSTFILTER) != 0;
-	if (!post || a->F != 256 || a->nstreams < 16384 || no_overlap) { // measured: +5 % at F=256, nothing at 128, -6 % at 64
+	int nchunks = a->overlap_chunks;
+	if (nchunks < 0) // measured: +5 % at F=256, nothing at 128, -6 % at 64
+		nchunks = (a->F == 256 && a->nstreams >= 16384 && !no_overlap) ? env_chunks : 0;
+	nchunks = std::min(nchunks, a->nstreams);
+	if (!post || nchunks < 2) {
 		launch_mdf(0, a->nstreams);
 		MI_LAUNCH_CHECK();
 		if (post) {
@@ -598,11 +614,6 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 		}
 		return MI_OK;
 	}
-	static const int nchunks = [] {
-		const char *e = getenv("MSMI355X_AEC_CHUNKS");
-		const int v = e ? atoi(e) : 0;
-		return v >= 2 && v <= AEC_CHUNKS ? v : 2;
-	}();
 	const int per = (a->nstreams + nchunks - 1) / nchunks;
 	for (int c = 0; c < nchunks; ++c) {
 		const int first = c * per, count = std::min(per, a->nstreams - first);

@@ -225,3 +225,48 @@ def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
         b.import_state(0, b"XXXX" + blob[4:])
     for x in (a, b, c):
         x.close()
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 8])
+def test_aec_chunked_post_filter_overlap_changes_nothing(ctx, chunks):
+    """mi_aec_set_overlap: the batch cut in chunks, each chunk's post-filter on a second HIP stream next to the following
+    chunk's canceller (the automatic schedule from 16 384 streams on at 256-sample frames) must give the same bits as the
+    plain schedule -- eagerly, with a run mask, and replayed from a hipGraph."""
+    rate, F, n, nfr = 48000, 256, 37, 24
+    flen = 64 * rate // 1000
+    scenes = [make_echo_scene(s, rate, F * nfr) for s in range(n)]
+    mic = np.stack([m for m, _ in scenes])
+    far = np.stack([f for _, f in scenes])
+    a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    b = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    a.set_overlap(0)
+    b.set_overlap(chunks)
+    rng = np.random.default_rng(chunks)
+    fl = ms.MI_AEC_POSTFILTER
+    for f in range(nfr - 8):
+        sl = slice(f * F, (f + 1) * F)
+        run = (rng.random(n) < 0.8).astype(np.uint8) if f % 3 == 2 else None
+        oa = a.process(np.ascontiguousarray(mic[:, sl]), np.ascontiguousarray(far[:, sl]), flags=fl, run=run,
+                       out=np.full((n, F), 555, np.int16))
+        ob = b.process(np.ascontiguousarray(mic[:, sl]), np.ascontiguousarray(far[:, sl]), flags=fl, run=run,
+                       out=np.full((n, F), 555, np.int16))
+        np.testing.assert_array_equal(oa, ob, err_msg=f"frame {f}")
+    # the same through a captured graph: 8 frames per replay, device-resident buffers
+    import torch
+    d_mic = torch.from_numpy(np.ascontiguousarray(mic[:, (nfr - 8) * F:]).reshape(n, 8, F).transpose(1, 0, 2).copy()).cuda()
+    d_far = torch.from_numpy(np.ascontiguousarray(far[:, (nfr - 8) * F:]).reshape(n, 8, F).transpose(1, 0, 2).copy()).cuda()
+    outs = {}
+    for name, obj in (("plain", a), ("chunked", b)):
+        d_out = torch.zeros((8, n, F), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        ctx.capture_begin()
+        for k in range(8):
+            obj.process(d_mic[k], d_far[k], out=d_out[k], flags=fl)
+        g = ctx.capture_end()
+        g.launch()
+        ctx.sync()
+        outs[name] = d_out.cpu().numpy()
+    np.testing.assert_array_equal(outs["plain"], outs["chunked"])
+    assert outs["plain"].any()
+    a.close()
+    b.close()
