@@ -368,10 +368,12 @@ def pipeline_probe(ms, torch, ctx, nstreams):
     d_mic = [torch.from_numpy(np.ascontiguousarray(mic16[:, r * 160:(r + 1) * 160])).cuda() for r in range(ring)]
     d_ref = [torch.from_numpy(np.ascontiguousarray(ref48[:, r * 480:(r + 1) * 480])).cuda() for r in range(ring)]
     up = torch.zeros((n, 488), dtype=torch.int16, device="cuda")
-    micf = torch.zeros((n, F), dtype=torch.int16, device="cuda")
-    reff = torch.zeros((n, F), dtype=torch.int16, device="cuda")
-    clean = torch.zeros((n, F), dtype=torch.int16, device="cuda")
-    okm = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    # one set of frame buffers per canceller round of a tick: the join of a round is deferred (mi_session does the same),
+    # so its trailing post-filter runs next to the next round's canceller
+    micf = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
+    reff = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
+    clean = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
+    okm = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(2)]
     tick_buf = torch.zeros((nconf, 32, 480), dtype=torch.int16, device="cuda")
     mixed = torch.zeros((nconf, 32, 480), dtype=torch.int16, device="cuda")
     torch.cuda.synchronize()
@@ -380,11 +382,13 @@ def pipeline_probe(ms, torch, ctx, nstreams):
         rs.process(d_mic[t % ring], out=up)
         f_mic.push(up, nsamples=480)
         f_ref.push(d_ref[t % ring])
-        for _ in range(2):
-            f_mic.pop(F, micf, ok=okm, zero_fill=False)
-            f_ref.pop(F, reff, gate=okm, zero_fill=True)
-            aec.process(micf, reff, out=clean, run=okm)
-            f_out.push(clean, gate=okm)
+        for r in range(2):
+            f_mic.pop(F, micf[r], ok=okm[r], zero_fill=False)
+            f_ref.pop(F, reff[r], gate=okm[r], zero_fill=True)
+            aec.process(micf[r], reff[r], out=clean[r], run=okm[r], flags=ms.MI_AEC_POSTFILTER | ms.MI_AEC_DEFER_JOIN)
+        aec.join()
+        for r in range(2):
+            f_out.push(clean[r], gate=okm[r])
         f_out.pop(480, tick_buf.view(n, 480), zero_fill=True)
         vol.process(tick_buf.view(n, 480))
         mix.process(tick_buf, out=mixed)

@@ -236,6 +236,8 @@ int mi_aec_reset(mi_aec *a, int first, int count);
  * d_run [nstreams] u8: 0 = this stream has no full frame this tick (A23), NULL = all run.
  * flags bit0: also run the residual-echo/denoise post-filter (speex_preprocess_run). */
 #define MI_AEC_POSTFILTER 1u
+#define MI_AEC_DEFER_JOIN 2u /* the output rows may be read on the context's stream only after mi_aec_join(): lets the last chunk's
+                             * post-filter of this call run next to the first chunk's canceller of the next call */
 int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
                    const uint8_t *d_run, unsigned flags);
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
@@ -245,6 +247,7 @@ int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, i
  * in two and the first half's post-filter runs on a second HIP stream next to the second half's canceller), 0 never,
  * 2..8 always with that many chunks.  Results do not depend on it. */
 int mi_aec_set_overlap(mi_aec *a, int chunks);
+int mi_aec_join(mi_aec *a); /* after MI_AEC_DEFER_JOIN calls: the context's stream waits for every post-filter launched so far */
 size_t mi_aec_state_bytes(const mi_aec *a);
 /* One stream's whole state as a host blob, and back: what fetch_config / apply_config (src/audiofilters/speexec.c:119-167)
  * do with SPEEX_ECHO_GET_BLOB / SET_BLOB of the reference's speex fork, so a converged canceller survives the end of a

@@ -19,7 +19,7 @@ from ._lib import MiError, VolumeParams, VolumeState, check, load  # noqa: F401
 
 MI_MIX_LINKED, MI_MIX_ACTIVE, MI_MIX_OUTPUT = 1, 2, 4
 MI_PIX_I420, MI_PIX_RGB24 = 0, 1
-MI_AEC_POSTFILTER = 1
+MI_AEC_POSTFILTER, MI_AEC_DEFER_JOIN = 1, 2
 
 
 def _is_torch(x):
@@ -317,6 +317,10 @@ class AecBatch(_Batch):
 
     def state_bytes(self):
         return self.ctx.L.mi_aec_state_bytes(self.h)
+
+    def join(self):
+        """after process(..., flags=MI_AEC_POSTFILTER | MI_AEC_DEFER_JOIN) calls: outputs become readable on the context's stream"""
+        check(self.ctx.L.mi_aec_join(self.h))
 
     def set_overlap(self, chunks):
         """-1 automatic, 0 off, 2..8 chunks: the post-filter of a chunk on a second stream next to the next chunk's canceller."""

@@ -38,7 +38,7 @@ EXPORTS = [
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
     "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process",
-    "mi_aec_process_host", "mi_aec_set_overlap", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
+    "mi_aec_process_host", "mi_aec_set_overlap", "mi_aec_join", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
@@ -181,6 +181,7 @@ def load():
         L.mi_aec_process.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_process_host.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_set_overlap.argtypes = [vp, i32]
+        L.mi_aec_join.argtypes = [vp]
         L.mi_aec_state_bytes.argtypes = [vp]
         L.mi_aec_state_bytes.restype = sz
         L.mi_aec_blob_bytes.argtypes = [vp]

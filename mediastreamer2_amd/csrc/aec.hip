@@ -240,6 +240,8 @@ struct mi_aec {
 	// the post-filter of a chunk runs on a second stream while the canceller works on the next chunk
 	hipStream_t s_post = nullptr;
 	hipEvent_t ev_chunk[AEC_CHUNKS] = {}, ev_post = nullptr;
+	hipEvent_t ev_postdone[AEC_CHUNKS] = {}; // per chunk: its post-filter finished (deferred joins)
+	int deferred_chunks = 0;                 // chunks of the last call whose join was deferred (0 = none pending)
 	int overlap_chunks = -1; // -1: automatic (two chunks at F = 256 from 16 384 streams on), 0: off, 2..AEC_CHUNKS: forced
 };
 
@@ -416,6 +418,7 @@ int init_state(mi_aec *a, int first, int count) {
 	std::vector<AecScalars> scs((size_t)count, sc);
 	for (int i = 0; i < count; ++i) memcpy(all.data() + (size_t)i * a->small_stride, small.data(), small.size() * sizeof(float));
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
+	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	MI_HIP(hipMemcpy(a->d_small + (size_t)first * a->small_stride, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
 	MI_HIP(hipMemcpy(a->d_scal + first, scs.data(), scs.size() * sizeof(AecScalars), hipMemcpyHostToDevice));
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N;
@@ -497,8 +500,9 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		mi_aec_destroy(a);
 		return MI_ENODEV;
 	}
-	for (hipEvent_t &e : a->ev_chunk)
-		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+	for (hipEvent_t *arr : {a->ev_chunk, a->ev_postdone})
+	for (int i = 0; i < AEC_CHUNKS; ++i)
+		if (hipEventCreateWithFlags(&arr[i], hipEventDisableTiming) != hipSuccess) {
 			mi::set_error("mi_aec_create: event creation failed");
 			mi_aec_destroy(a);
 			return MI_ENODEV;
@@ -526,6 +530,8 @@ void mi_aec_destroy(mi_aec *a) {
 		(void)hipStreamDestroy(a->s_post);
 	}
 	for (hipEvent_t e : a->ev_chunk)
+		if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : a->ev_postdone)
 		if (e) (void)hipEventDestroy(e);
 	if (a->ev_post) (void)hipEventDestroy(a->ev_post);
 	delete a;
@@ -605,6 +611,12 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	if (nchunks < 0) // measured: +5 % at F=256, nothing at 128, -6 % at 64
 		nchunks = (a->F == 256 && a->nstreams >= 16384 && !no_overlap) ? env_chunks : 0;
 	nchunks = std::min(nchunks, a->nstreams);
+	if (!post || nchunks < 2 || (a->deferred_chunks && a->deferred_chunks != nchunks)) {
+		if (a->deferred_chunks) { // a deferred join is pending and this call is not chunked the same way: join first
+			MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0));
+			a->deferred_chunks = 0;
+		}
+	}
 	if (!post || nchunks < 2) {
 		launch_mdf(0, a->nstreams);
 		MI_LAUNCH_CHECK();
@@ -618,15 +630,33 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	for (int c = 0; c < nchunks; ++c) {
 		const int first = c * per, count = std::min(per, a->nstreams - first);
 		if (count <= 0) break;
+		// after a deferred join this chunk's previous post-filter may still run: its canceller state is read by it
+		if (a->deferred_chunks) MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_postdone[c], 0));
 		launch_mdf(first, count);
 		MI_LAUNCH_CHECK();
 		MI_HIP(hipEventRecord(a->ev_chunk[c], a->ctx->stream));
 		MI_HIP(hipStreamWaitEvent(a->s_post, a->ev_chunk[c], 0));
 		launch_post(first, count, a->s_post);
 		MI_LAUNCH_CHECK();
+		MI_HIP(hipEventRecord(a->ev_postdone[c], a->s_post));
 	}
 	MI_HIP(hipEventRecord(a->ev_post, a->s_post));
-	MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0)); // the caller's stream continues after the last post-filter
+	static const bool no_defer = getenv("MSMI355X_AEC_NO_DEFER") != nullptr; // A/B switch
+	if ((flags & MI_AEC_DEFER_JOIN) && !no_defer) {
+		a->deferred_chunks = nchunks; // the caller reads the outputs after mi_aec_join(); the next call orders itself per chunk
+	} else {
+		MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0)); // the caller's stream continues after the last post-filter
+		a->deferred_chunks = 0;
+	}
+	return MI_OK;
+}
+
+int mi_aec_join(mi_aec *a) {
+	MI_CHECK_ARG(a != nullptr);
+	if (!a->deferred_chunks) return MI_OK;
+	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0));
+	a->deferred_chunks = 0;
 	return MI_OK;
 }
 
@@ -634,6 +664,7 @@ int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, i
                         const uint8_t *h_run, unsigned flags) {
 	MI_CHECK_ARG(a && h_mic && h_ref && h_out);
 	mi_ctx *c = a->ctx;
+	flags &= ~MI_AEC_DEFER_JOIN; // the copy back follows at once
 	if (c->activate() != MI_OK) return MI_ENODEV;
 	const size_t b = (size_t)a->nstreams * stride * sizeof(int16_t);
 	void *dm, *dr, *dout, *drun = nullptr;
@@ -661,6 +692,7 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	MI_CHECK_ARG(a && what && h_dst && stream >= 0 && stream < a->nstreams);
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
+	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const int F = a->F, N = a->N, M = a->M;
 	auto unpack = [&](const float *src, float *dst) { // [DC,Nyq,re1,im1,..] -> [DC,re1,im1,..,Nyq]
 		dst[0] = src[0];
@@ -729,6 +761,7 @@ int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap) {
 	MI_CHECK_ARG(a && h_blob && stream >= 0 && stream < a->nstreams && cap >= mi_aec_blob_bytes(a));
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
+	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
 	BlobHeader h = {{'M', 'I', 'E', 'C'}, 1u, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
 	uint8_t *p = (uint8_t *)h_blob;
@@ -763,6 +796,7 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 	}
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
+	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
 	const uint8_t *p = (const uint8_t *)h_blob + sizeof(h);
 	MI_HIP(hipMemcpy(a->d_X + (size_t)stream * xn, p, xn * 4, hipMemcpyHostToDevice));

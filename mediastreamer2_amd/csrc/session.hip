@@ -34,8 +34,12 @@ struct mi_session {
 	hipStream_t s_up = nullptr, s_down = nullptr;
 	int16_t *h_mic[SLOTS] = {}, *h_ref[SLOTS] = {}, *h_out[SLOTS] = {};
 	int16_t *d_mic[SLOTS] = {}, *d_ref[SLOTS] = {}, *d_out[SLOTS] = {};
-	int16_t *d_up = nullptr, *d_micf = nullptr, *d_reff = nullptr, *d_clean = nullptr, *d_tick = nullptr;
-	uint8_t *d_ok = nullptr;
+	int16_t *d_up = nullptr, *d_tick = nullptr;
+	// per canceller round of a tick (a tick completes up to ROUNDS_MAX frames): frames in, cleaned frame out, who had one
+	static constexpr int ROUNDS_MAX = 4;
+	int rounds = 0;
+	int16_t *d_micf[ROUNDS_MAX] = {}, *d_reff[ROUNDS_MAX] = {}, *d_clean[ROUNDS_MAX] = {};
+	uint8_t *d_ok[ROUNDS_MAX] = {};
 	hipEvent_t ev_up[SLOTS] = {}, ev_done[SLOTS] = {}, ev_down[SLOTS] = {};
 	bool used[SLOTS] = {};
 	mi_graph *graph[SLOTS] = {};
@@ -68,13 +72,18 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 	// far end: from the host, or what this leg was sent one tick ago
 	const int16_t *ref = cf.ref_loopback ? s->d_mix[(slot + SLOTS - 1) % SLOTS] : s->d_ref[slot];
 	if ((rc = mi_fifo_push(s->f_ref, ref, s->len, s->len, nullptr)) != MI_OK) return rc;
-	const int rounds = (s->len + s->frame - 1) / s->frame; // frames a tick can complete (480 / 256 -> 2)
-	for (int r = 0; r < rounds; ++r) {
-		if ((rc = mi_fifo_pop(s->f_mic, s->frame, s->d_micf, s->frame, s->d_ok, nullptr, 0)) != MI_OK) return rc;
-		if ((rc = mi_fifo_pop(s->f_ref, s->frame, s->d_reff, s->frame, nullptr, s->d_ok, 1)) != MI_OK) return rc;
-		if ((rc = mi_aec_process(s->aec, s->d_micf, s->d_reff, s->d_clean, s->frame, s->d_ok, MI_AEC_POSTFILTER)) != MI_OK) return rc;
-		if ((rc = mi_fifo_push_gated(s->f_out, s->d_clean, s->frame, s->frame, s->d_ok)) != MI_OK) return rc;
+	// frames a tick can complete (480 / 256 -> 2).  Each round has its own buffers and the canceller's join is deferred to
+	// after the last one, so a round's trailing post-filter runs next to the next round's canceller (mi_aec_process).
+	for (int r = 0; r < s->rounds; ++r) {
+		if ((rc = mi_fifo_pop(s->f_mic, s->frame, s->d_micf[r], s->frame, s->d_ok[r], nullptr, 0)) != MI_OK) return rc;
+		if ((rc = mi_fifo_pop(s->f_ref, s->frame, s->d_reff[r], s->frame, nullptr, s->d_ok[r], 1)) != MI_OK) return rc;
+		if ((rc = mi_aec_process(s->aec, s->d_micf[r], s->d_reff[r], s->d_clean[r], s->frame, s->d_ok[r],
+		                         MI_AEC_POSTFILTER | MI_AEC_DEFER_JOIN)) != MI_OK)
+			return rc;
 	}
+	if ((rc = mi_aec_join(s->aec)) != MI_OK) return rc;
+	for (int r = 0; r < s->rounds; ++r)
+		if ((rc = mi_fifo_push_gated(s->f_out, s->d_clean[r], s->frame, s->frame, s->d_ok[r])) != MI_OK) return rc;
 	if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
 	if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
 	int16_t *mix = s->d_mix[slot] ? s->d_mix[slot] : s->d_out[slot];
@@ -133,9 +142,12 @@ void mi_session_destroy(mi_session *s) {
 		if (s->ev_done[i]) (void)hipEventDestroy(s->ev_done[i]);
 		if (s->ev_down[i]) (void)hipEventDestroy(s->ev_down[i]);
 	}
-	void *dv[] = {s->d_up, s->d_micf, s->d_reff, s->d_clean, s->d_tick, s->d_ok, s->d_pcm, s->d_down, s->d_zero, s->d_evlen};
+	void *dv[] = {s->d_up, s->d_tick, s->d_pcm, s->d_down, s->d_zero, s->d_evlen};
 	for (void *p : dv)
 		if (p) mi_dev_free(c, p);
+	for (int r = 0; r < mi_session::ROUNDS_MAX; ++r)
+		for (void *p : {(void *)s->d_micf[r], (void *)s->d_reff[r], (void *)s->d_clean[r], (void *)s->d_ok[r]})
+			if (p) mi_dev_free(c, p);
 	if (s->rs) mi_resampler_destroy(s->rs);
 	if (s->rs_out) mi_resampler_destroy(s->rs_out);
 	if (s->plc) mi_plc_destroy(s->plc);
@@ -231,12 +243,17 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 		}
 	}
 	if (s->rs) s->d_up = (int16_t *)mi_dev_alloc(ctx, n * s->up_stride * 2);
-	s->d_micf = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
-	s->d_reff = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
-	s->d_clean = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
+	s->rounds = (s->len + s->frame - 1) / s->frame;
+	if (s->rounds > mi_session::ROUNDS_MAX) return fail(MI_ENOTSUP);
+	for (int r = 0; r < s->rounds; ++r) {
+		s->d_micf[r] = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
+		s->d_reff[r] = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
+		s->d_clean[r] = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
+		s->d_ok[r] = (uint8_t *)mi_dev_alloc(ctx, n);
+		if (!s->d_micf[r] || !s->d_reff[r] || !s->d_clean[r] || !s->d_ok[r]) return fail(MI_ENOMEM);
+	}
 	s->d_tick = (int16_t *)mi_dev_alloc(ctx, n * s->len * 2);
-	s->d_ok = (uint8_t *)mi_dev_alloc(ctx, n);
-	if ((s->rs && !s->d_up) || !s->d_micf || !s->d_reff || !s->d_clean || !s->d_tick || !s->d_ok) return fail(MI_ENOMEM);
+	if ((s->rs && !s->d_up) || !s->d_tick) return fail(MI_ENOMEM);
 	if (cfg->mic_codec && !(s->d_pcm = (int16_t *)mi_dev_alloc(ctx, n * s->in_len * 2))) return fail(MI_ENOMEM);
 	if (s->rs_out && !(s->d_down = (int16_t *)mi_dev_alloc(ctx, n * s->down_stride * 2))) return fail(MI_ENOMEM);
 	if (cfg->plc) {
@@ -397,8 +414,8 @@ int mi_session_reset_streams(mi_session *s, int first, int count) {
 		const int delay = s->cfg.ref_delay_ms * s->cfg.rate / 1000;
 		std::vector<uint8_t> gate((size_t)s->n, 0);
 		for (int i = 0; i < count; ++i) gate[(size_t)(first + i)] = 1;
-		MI_HIP(hipMemcpyAsync(s->d_ok, gate.data(), (size_t)s->n, hipMemcpyHostToDevice, s->ctx->stream));
-		if ((rc = mi_fifo_push_gated(s->f_ref, s->d_zero, delay, delay, s->d_ok)) != MI_OK) return rc;
+		MI_HIP(hipMemcpyAsync(s->d_ok[0], gate.data(), (size_t)s->n, hipMemcpyHostToDevice, s->ctx->stream));
+		if ((rc = mi_fifo_push_gated(s->f_ref, s->d_zero, delay, delay, s->d_ok[0])) != MI_OK) return rc;
 		MI_HIP(hipStreamSynchronize(s->ctx->stream)); // gate is a stack-lifetime buffer
 	}
 	return MI_OK;

@@ -260,13 +260,24 @@ def test_aec_chunked_post_filter_overlap_changes_nothing(ctx, chunks):
         d_out = torch.zeros((8, n, F), dtype=torch.int16, device="cuda")
         torch.cuda.synchronize()
         ctx.capture_begin()
-        for k in range(8):
-            obj.process(d_mic[k], d_far[k], out=d_out[k], flags=fl)
+        for k in range(8):  # the chunked object also defers its joins: frame k's last post-filter next to frame k+1's canceller
+            obj.process(d_mic[k], d_far[k], out=d_out[k], flags=fl | (ms.MI_AEC_DEFER_JOIN if name == "chunked" else 0))
+        obj.join()
         g = ctx.capture_end()
         g.launch()
         ctx.sync()
         outs[name] = d_out.cpu().numpy()
     np.testing.assert_array_equal(outs["plain"], outs["chunked"])
     assert outs["plain"].any()
+    # deferred joins eagerly, interleaved with a call that cannot be chunked the same way (no post-filter: joins first)
+    d_o1, d_o2 = torch.zeros((n, F), dtype=torch.int16, device="cuda"), torch.zeros((n, F), dtype=torch.int16, device="cuda")
+    p_o1, p_o2 = torch.zeros_like(d_o1), torch.zeros_like(d_o2)
+    torch.cuda.synchronize()
+    b.process(d_mic[0], d_far[0], out=d_o1, flags=fl | ms.MI_AEC_DEFER_JOIN)
+    b.process(d_mic[1], d_far[1], out=d_o2, flags=0)
+    a.process(d_mic[0], d_far[0], out=p_o1, flags=fl)
+    a.process(d_mic[1], d_far[1], out=p_o2, flags=0)
+    ctx.sync()
+    assert torch.equal(d_o1, p_o1) and torch.equal(d_o2, p_o2)
     a.close()
     b.close()
