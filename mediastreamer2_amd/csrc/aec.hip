@@ -626,9 +626,16 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 		}
 		return MI_OK;
 	}
+	static const int split_pct = [] { // two chunks: share of the first one (A/B knob, default below)
+		const char *e = getenv("MSMI355X_AEC_SPLIT");
+		const int v = e ? atoi(e) : 0;
+		return v >= 10 && v <= 95 ? v : 50;
+	}();
 	const int per = (a->nstreams + nchunks - 1) / nchunks;
+	const int cut = nchunks == 2 ? std::max(1, std::min(a->nstreams - 1, (int)((long long)a->nstreams * split_pct / 100))) : 0;
 	for (int c = 0; c < nchunks; ++c) {
-		const int first = c * per, count = std::min(per, a->nstreams - first);
+		const int first = nchunks == 2 ? (c == 0 ? 0 : cut) : c * per;
+		const int count = nchunks == 2 ? (c == 0 ? cut : a->nstreams - cut) : std::min(per, a->nstreams - first);
 		if (count <= 0) break;
 		// after a deferred join this chunk's previous post-filter may still run: its canceller state is read by it
 		if (a->deferred_chunks) MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_postdone[c], 0));
