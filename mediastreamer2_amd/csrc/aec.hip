@@ -587,7 +587,8 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	// the canceller is HBM-bound with the VALUs a third busy and the post-filter VALU-bound with HBM a third busy: a big
 	// batch is cut in two, the cancellers run back to back on the context's stream and the first half's post-filter on a
 	// second stream next to the second half's canceller (65 536 streams: 3.76 -> 3.53 ms per frame round, the chained
-	// tick 7.4 -> 7.04 ms; more chunks lose it again to launch tails: 8 chunks 4.07 ms).
+	// tick 7.4 -> 7.04 ms; more chunks lose it again to launch tails: 8 chunks 4.07 ms; a high-priority stream for the
+	// post-filter makes it worse: 7.9 against 7.2 ms per tick).
 	auto launch_mdf = [&](int first, int count) {
 		g.first = first;
 		if (a->F == 256) hipLaunchKernelGGL(aec_mdf_wave_kernel<256>, dim3(count), dim3(64), 0, a->ctx->stream, g);
