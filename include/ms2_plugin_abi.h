@@ -18,9 +18,11 @@
 #include <mediastreamer2/allfilters.h>
 #include <mediastreamer2/flowcontrol.h>
 #include <mediastreamer2/msaudiomixer.h>
+#include <mediastreamer2/mschanadapter.h>
 #include <mediastreamer2/msequalizer.h>
 #include <mediastreamer2/msfactory.h>
 #include <mediastreamer2/msfilter.h>
+#include <mediastreamer2/msgenericplc.h>
 #include <mediastreamer2/msinterfaces.h>
 #include <mediastreamer2/msticker.h>
 #include <mediastreamer2/msvideo.h>
