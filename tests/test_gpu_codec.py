@@ -203,3 +203,78 @@ def test_flow_controller_ragged_blocks_and_in_place(ctx, oracle):
             np.testing.assert_array_equal(got[s, : gl[s]], want)
     fc.reset()
     assert fc.state(0) == dict(target=0, total=0, pos=0, dropped=0)
+
+
+def test_flow_controller_randomised_scenarios(ctx, oracle):
+    """Seeded random scenarios: block sizes 9..640, targets from one sample to several blocks, totals around the
+    boundaries of the rules (todrop * 8 < nsamples, nsamples <= target, current_pos >= total), both strategies, thresholds
+    that make some frames 'silent'.  Every block must come out as the oracle's."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        S = int(rng.integers(1, 9))
+        n = int(rng.integers(9, 641))
+        strategy = int(rng.integers(0, 2))
+        thr = float(rng.choice([0.02, 0.2, 0.0005]))
+        fc = ms.FlowControlBatch(ctx, S, 640)
+        fc.set_config(strategy, thr)
+        refs = [oracle.FlowCtl(strategy, thr) for _ in range(S)]
+        x = torch.zeros((S, 640), dtype=torch.int16, device="cuda")
+        out = torch.zeros((S, 640), dtype=torch.int16, device="cuda")
+        olen = torch.zeros(S, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for t in range(14):
+            if t in (1, 6, 9):
+                drop = rng.integers(0, 3 * n, S).astype(np.uint32) * (rng.random(S) < 0.8)
+                total = rng.integers(1, 12 * n, S).astype(np.uint32)
+                fc.request_drop(drop, total)
+                for s in range(S):
+                    if (drop[s] or total[s]) and not (refs[s].c.total_samples > 0 and refs[s].c.target_samples > 0):
+                        refs[s].set_target(int(drop[s]), int(total[s]))
+            amp = rng.choice([30.0, 3000.0, 12000.0], S)
+            blocks = np.stack([np.clip(np.round(rng.normal(0, amp[s], n) + 2000 * np.sin(np.arange(n) * 0.05 * (s + 1))),
+                                       -32768, 32767).astype(np.int16) for s in range(S)])
+            x[:, :n].copy_(torch.from_numpy(blocks))
+            torch.cuda.synchronize()
+            fc.process(x, out, olen, length=n)
+            ctx.sync()
+            got, gl = out.cpu().numpy(), olen.cpu().numpy()
+            for s in range(S):
+                want = refs[s].process(blocks[s])
+                assert gl[s] == want.size, (case, t, s, n, strategy)
+                np.testing.assert_array_equal(got[s, : gl[s]], want, err_msg=f"case {case} tick {t} stream {s}")
+        fc.close()
+
+
+def test_g711_randomised_layouts(ctx, oracle):
+    """Seeded random (rows, length, stride, per-row counts, base offsets): vector and scalar paths, tails, both laws and
+    directions."""
+    rng = np.random.default_rng(711)
+    for case in range(40):
+        rows, n = int(rng.integers(1, 40)), int(rng.integers(1, 700))
+        stride = n + int(rng.integers(0, 40))
+        off = int(rng.choice([0, 0, 1, 8, 16]))
+        law = int(rng.integers(0, 2))
+        codes = rng.integers(0, 256, (rows, stride), dtype=np.uint8)
+        lens = rng.integers(0, n + 1, rows).astype(np.int32)
+        big_c = torch.zeros(rows * stride + 64, dtype=torch.uint8, device="cuda")
+        big_p = torch.full((rows * stride + 64,), 777, dtype=torch.int16, device="cuda")
+        d_codes = big_c[off: off + rows * stride].view(rows, stride)
+        d_pcm = big_p[off: off + rows * stride].view(rows, stride)
+        d_codes.copy_(torch.from_numpy(codes))
+        d_lens = torch.from_numpy(lens).cuda()
+        torch.cuda.synchronize()
+        ms.g711_decode(ctx, law, d_codes, d_pcm, length=n, lens=d_lens)
+        ctx.sync()
+        got = d_pcm.cpu().numpy()
+        for r in range(rows):
+            np.testing.assert_array_equal(got[r, : lens[r]], oracle.g711_decode(law, codes[r, : lens[r]]), err_msg=f"case {case} row {r}")
+            assert (got[r, lens[r]:] == 777).all()
+        back = torch.full((rows * stride + 64,), 0xAB, dtype=torch.uint8, device="cuda")
+        d_back = back[off: off + rows * stride].view(rows, stride)
+        torch.cuda.synchronize()
+        ms.g711_encode(ctx, law, d_pcm, d_back, length=n, lens=d_lens)
+        ctx.sync()
+        enc = d_back.cpu().numpy()
+        for r in range(rows):
+            np.testing.assert_array_equal(enc[r, : lens[r]], oracle.g711_encode(law, got[r, : lens[r]]), err_msg=f"case {case} row {r}")
+            assert (enc[r, lens[r]:] == 0xAB).all()

@@ -146,3 +146,18 @@ def test_plc_ragged_and_unsupported_rates(ctx):
     got = rows.cpu().numpy()
     assert (got[1] == 1234).all()       # zero-length event: untouched
     assert (got[2] == 0).all() and plc.info(2)["used"] == 0
+
+
+def test_plc_randomised_scenarios(ctx, oracle):
+    """Seeded random rates (8 / 16 / 24 / 48 kHz: transforms with radix 2, 3, 4 and 5 stages), block lengths (5 / 10 / 20 ms)
+    and loss rates (5 .. 60 %), four streams each: bit-exact against the oracle tick by tick."""
+    rng = np.random.default_rng(99)
+    for case in range(8):
+        rate = int(rng.choice([8000, 16000, 24000, 48000]))
+        n = rate // int(rng.choice([200, 100, 50]))
+        p = float(rng.choice([0.05, 0.3, 0.6]))
+        ticks = 45
+        S = 4
+        events = [[(C_ if (rng.random() < p and t > 2) else R) for _ in range(S)] for t in range(ticks)]
+        sig = [voiced(case * 10 + s, n * ticks, rate) for s in range(S)]
+        run_scenario(ctx, oracle, rate, n, events, sig)
