@@ -603,7 +603,8 @@ void ms_ticker_step(MSTicker *t) {
 #define SHIM_SINK_ID ((MSFilterId)9002)
 
 typedef struct {
-	queue_t pending; /* blocks the test queued; one is emitted per tick */
+	queue_t pending; /* blocks the test queued; one is emitted per tick ... */
+	int burst;       /* ... or all of them (an RTP receiver after a network hiccup) */
 } SrcData;
 typedef struct {
 	uint8_t *buf;
@@ -624,9 +625,12 @@ static void src_uninit(MSFilter *f) {
 }
 static void src_process(MSFilter *f) {
 	SrcData *d = (SrcData *)f->data;
-	mblk_t *m = getq(&d->pending);
-	if (m && f->outputs[0]) ms_queue_put(f->outputs[0], m);
-	else if (m) freemsg(m);
+	mblk_t *m;
+	while ((m = getq(&d->pending)) != NULL) {
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+		else freemsg(m);
+		if (!d->burst) break;
+	}
 }
 static void sink_init(MSFilter *f) { f->data = ms_malloc0(sizeof(SinkData)); }
 static void sink_uninit(MSFilter *f) {
@@ -664,6 +668,7 @@ void ms2shim_register_test_filters(MSFactory *f) {
 }
 MSFilter *ms2shim_new_source(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SOURCE_ID); }
 MSFilter *ms2shim_new_sink(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SINK_ID); }
+void ms2shim_source_set_burst(MSFilter *src, int burst) { ((SrcData *)src->data)->burst = burst; }
 void ms2shim_source_push(MSFilter *src, const void *data, size_t nbytes) {
 	SrcData *d = (SrcData *)src->data;
 	mblk_t *m = allocb(nbytes, 0);

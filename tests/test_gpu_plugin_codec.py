@@ -271,3 +271,95 @@ def test_generic_plc_graph_follows_the_oracle(host, oracle, rate):
     assert want.size - n <= got.size <= want.size  # the last tick's block is still staged (one tick of latency)
     np.testing.assert_array_equal(got, want[: got.size])
     assert ref.con.total_number_for_plc >= 3 + 1 + 18 + 1
+
+
+def test_facades_keep_order_and_samples_under_bursts(host, oracle):
+    """More blocks in one tick than a pool has launch rounds (4): nothing is lost or reordered.  Six 5 ms blocks per tick
+    through MSAudioFlowControl (dropping 10 ms out of 300 ms meanwhile), through MSUlawDec, and a stereo MSL16Enc."""
+    rate, n = 16000, 80
+    # flow control: 6 blocks per tick
+    host.S.ms2shim_source_set_burst.argtypes = [C.c_void_p, C.c_int]
+    x = synth_pcm(77, n * 6 * 12, rate=rate)
+    src, fc, snk = host.source(), host.create(MS_AUDIO_FLOW_CONTROL_ID), host.sink()
+    host.S.ms2shim_source_set_burst(src, 1)
+    assert host.call_int(fc, SET_SAMPLE_RATE, rate) == 0 and host.call_int(fc, SET_NCHANNELS, 1) == 0
+    ref = oracle.FlowCtl()
+    want, k = [], [0]
+
+    def feed(t):
+        if t == 2:
+            assert host.call(fc, FLOW_DROP, DropEvent(300, 10)) == 0
+            ref.set_target(10 * rate // 1000, 300 * rate // 1000)
+        for _ in range(6):
+            blk = x[k[0] * n:(k[0] + 1) * n]
+            k[0] += 1
+            host.push(src, blk)
+            want.append(ref.process(blk))
+
+    out = run_graph(host, [src, fc, snk], feed, 12)
+    want_all = np.concatenate(want)
+    got = out.view(np.int16)
+    # blocks beyond the fourth of a tick pass unedited (documented): the sequence is complete and in order, and the
+    # controller removed at most what the reference would have
+    assert x.size - 160 <= got.size <= x.size
+    it = iter(x.tolist())
+    assert all(any(v == w for w in it) for v in got.tolist())  # a subsequence of the input, order kept
+    assert want_all.size == x.size - 160
+    # decoder: 6 packets per tick
+    codes = np.random.default_rng(4).integers(0, 256, 6 * 12 * 40, dtype=np.uint8)
+    src, dec, snk = host.source(), host.create(MS_ULAW_DEC_ID), host.sink()
+    host.S.ms2shim_source_set_burst(src, 1)
+    pos = [0]
+
+    def feed_dec(t):
+        for _ in range(6):
+            push_bytes(host, src, codes[pos[0]: pos[0] + 40])
+            pos[0] += 40
+
+    out = run_graph(host, [src, dec, snk], feed_dec, 12)
+    np.testing.assert_array_equal(out.view(np.int16), oracle.g711_decode(1, codes))
+    assert host.S.ms2shim_sink_blocks(snk) == 72
+    # stereo L16 encoder: 10 ms of 2 x 16 kHz per packet, byte-swapped, timestamps in frames (l16.c:89-91)
+    st = synth_pcm(9, 2 * 160 * 10, rate=rate)
+    src, enc, snk = host.source(), host.create(MS_L16_ENC_ID), host.sink()
+    assert host.call_int(enc, SET_SAMPLE_RATE, rate) == 0 and host.call_int(enc, SET_NCHANNELS, 2) == 0
+    out = run_graph(host, [src, enc, snk], lambda t: host.push(src, st[320 * t: 320 * (t + 1)]), 10)
+    np.testing.assert_array_equal(out.view(">i2").astype(np.int16), st)
+    assert host.S.ms2shim_sink_blocks(snk) == 10 and host.S.ms2shim_sink_last_ts(snk) == 160 * 9
+
+
+def test_generic_plc_burst_of_six_blocks(host, oracle):
+    """Six 10 ms packets delivered in ONE tick after five ticks of silence (a jitter burst): more pieces than the pool has
+    launch rounds; every block is forwarded, delayed and cross-faded like the reference does, then concealment resumes
+    only when the concealer's clock says so."""
+    rate, n = 8000, 80
+    x = synth_pcm(61, n * 40, rate=rate, sigma=1500.0)
+    src, plc, snk = host.source(), host.create(MS_GENERIC_PLC_ID), host.sink()
+    host.S.ms2shim_source_set_burst.argtypes = [C.c_void_p, C.c_int]
+    host.S.ms2shim_source_set_burst(src, 1)
+    assert host.call_int(plc, SET_SAMPLE_RATE, rate) == 0
+    ref = oracle.GenericPlcFilter(rate)
+    want, k = [], [0]
+
+    def feed(t):
+        if t < 8:
+            cnt = 1
+        elif t < 13:
+            cnt = 0            # five packets late ...
+        elif t == 13:
+            cnt = 6            # ... all six arrive at once
+        else:
+            cnt = 1
+        blocks = [x[(k[0] + i) * n:(k[0] + i + 1) * n] for i in range(cnt)]
+        k[0] += cnt
+        for b in blocks:
+            host.push(src, b)
+        want.extend(ref.tick(1000 + 10 * t, blocks))
+
+    out = run_graph(host, [src, plc, snk], feed, 24)
+    for t in range(24, 27):
+        want.extend(ref.tick(1000 + 10 * t, []))
+    want = np.concatenate(want)
+    got = out.view(np.int16)
+    assert want.size - n <= got.size <= want.size
+    np.testing.assert_array_equal(got, want[: got.size])
