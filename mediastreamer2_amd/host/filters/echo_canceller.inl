@@ -323,7 +323,11 @@ void ec_process(MSFilter *f) {
 	const size_t nbytes = (size_t)s->framesize * 2, cap = (size_t)p->capacity, slot = (size_t)s->slot;
 	ec_take_far_end(f, s);
 	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
-	while (p->staged[slot] < kMaxRounds && ms_bufferizer_get_avail(&s->echo) >= nbytes) {
+	while (ms_bufferizer_get_avail(&s->echo) >= nbytes) {
+		if (p->staged[slot] >= kMaxRounds) { // a burst of more frames than launch rounds: what is staged goes out now
+			p->flush();
+			p->emit_all();
+		}
 		const size_t row = ((size_t)p->staged[slot] * cap + slot) * (size_t)p->F;
 		ms_bufferizer_read(&s->echo, (uint8_t *)(p->h_mic + row), nbytes);
 		s->echostarted = TRUE;

@@ -128,7 +128,11 @@ void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	// one FIR block per mblk; a block longer than a batch row is cut into row-sized pieces (a streaming filter: the
 	// sample sequence does not depend on the blocking), nothing is dropped
 	for (;;) {
-		if (p->staged[s] >= kMaxRounds) break;
+		if (p->staged[s] >= kMaxRounds) {
+			if (ms_bufferizer_get_avail(d->spill) == 0 && ms_queue_empty(f->inputs[0])) break;
+			p->flush(); // more pieces than launch rounds in one tick: what is staged goes out now
+			p->emit_all();
+		}
 		int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
 		int n = 0;
 		const size_t spilled = ms_bufferizer_get_avail(d->spill);

@@ -152,7 +152,11 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	const size_t nbytes = (size_t)p->in_len * 2 * (size_t)nch;
 	std::vector<int16_t> frame;
-	while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->bz) >= nbytes) {
+	while (ms_bufferizer_get_avail(d->bz) >= nbytes) {
+		if (p->staged[s] >= kMaxRounds) { // a burst of more blocks than launch rounds: what is staged goes out now
+			p->flush();
+			p->emit_all();
+		}
 		const size_t round = (size_t)p->staged[s];
 		if (nch == 1) {
 			ms_bufferizer_read(d->bz, (uint8_t *)(p->h_in + (round * c + s) * p->in_len), nbytes);

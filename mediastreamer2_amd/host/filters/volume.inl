@@ -206,7 +206,11 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 	if (d->p.agc_enabled || d->peer != NULL) { // :480-503 re-framed to 10 ms chunks
 		const size_t nbytes = (size_t)d->nsamples * 2;
 		ms_bufferizer_put_from_queue(d->buffer, f->inputs[0]);
-		while (p->staged[s] < kMaxRounds && ms_bufferizer_get_avail(d->buffer) >= nbytes) {
+		while (ms_bufferizer_get_avail(d->buffer) >= nbytes) {
+			if (p->staged[s] >= kMaxRounds) { // a burst of more chunks than launch rounds: what is staged goes out now
+				p->flush();
+				p->emit_all();
+			}
 			ms_bufferizer_read(d->buffer, (uint8_t *)(p->h_buf + (p->staged[s] * c + s) * p->cap_samples), nbytes);
 			p->h_n[p->staged[s] * c + s] = d->nsamples;
 			p->staged[s]++;
@@ -214,7 +218,11 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 	} else { // :505-512 light path: one chunk per mblk.  A block longer than a batch row (20 ms and more than 960 samples)
 		// is cut into row-sized chunks -- no sample is dropped; the meter then sees those chunks, not the whole block.
 		for (;;) {
-			if (p->staged[s] >= kMaxRounds) break;
+			if (p->staged[s] >= kMaxRounds) {
+				if (ms_bufferizer_get_avail(d->spill) == 0 && ms_queue_empty(f->inputs[0])) break;
+				p->flush(); // more chunks than launch rounds in one tick: what is staged goes out now
+				p->emit_all();
+			}
 			int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
 			int n = 0;
 			const size_t spilled = ms_bufferizer_get_avail(d->spill);

@@ -589,3 +589,64 @@ def test_speex_ec_plugin_meets_the_reference_testers_thresholds(host, kind):
     assert energy_unprocessed > 50.0
     assert energy < thr_en, energy
     assert thr_sim < sim <= 1.0, sim
+
+
+def test_bursts_through_the_batched_facades(host, oracle):
+    """A source that hands over everything it holds (an RTP receiver after a hiccup): seven 10 ms blocks in one tick --
+    more than a pool's four launch rounds -- through MSResample, MSVolume (AGC and light path) and MSEqualizer.  The
+    sample stream must be the oracle's, complete and in order."""
+    host.S.ms2shim_source_set_burst.argtypes = [C.c_void_p, C.c_int]
+
+    def run(filt, x, n, per_tick):
+        src, snk = host.source(), host.sink()
+        host.S.ms2shim_source_set_burst(src, 1)
+        host.link(src, 0, filt, 0)
+        host.link(filt, 0, snk, 0)
+        host.S.ms_ticker_attach(host.ticker, src)
+        k = 0
+        for cnt in per_tick:
+            for _ in range(cnt):
+                host.push(src, x[k * n:(k + 1) * n])
+                k += 1
+            host.step()
+        host.step(3)
+        out = host.drain(snk)
+        host.S.ms_ticker_detach(host.ticker, src)
+        return out, k
+
+    pattern = [1, 1, 7, 0, 0, 1, 9, 1, 1]
+    nblk = sum(pattern)
+    # resampler 16k -> 48k
+    x = synth_pcm(90, 160 * nblk, rate=16000)
+    rs = host.create(MS_RESAMPLE_ID)
+    assert host.call_int(rs, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 48000) == 0
+    got, k = run(rs, x, 160, pattern)
+    o = oracle.Resampler(16000, 48000)
+    ref = np.concatenate([o.process(x[t * 160:(t + 1) * 160]) for t in range(k)])
+    assert len(got) == len(ref) and np.abs(got.astype(int) - ref.astype(int)).max() <= 1
+    # volume with AGC (re-framed to 10 ms chunks)
+    x = synth_pcm(91, 480 * nblk, sigma=5000.0)
+    vol = host.create(MS_VOLUME_ID)
+    assert host.call_int(vol, SET_SAMPLE_RATE, 48000) == 0 and host.call_int(vol, mid(MS_VOLUME_ID, 8, 4), 1) == 0
+    got, k = run(vol, x, 480, pattern)
+    o = oracle.Volume(48000)
+    o.v.agc_enabled = 1
+    np.testing.assert_array_equal(got, np.concatenate([o.chunk(x[t * 480:(t + 1) * 480]) for t in range(k)]))
+    # volume, light path (one chunk per block), static gain
+    vol = host.create(MS_VOLUME_ID)
+    assert host.call_int(vol, SET_SAMPLE_RATE, 48000) == 0
+    g = C.c_float(0.5)
+    assert host.call(vol, mid(MS_VOLUME_ID, 2, 4), g) == 0
+    got, k = run(vol, x, 480, pattern)
+    o = oracle.Volume(48000)
+    oracle.lib().orc_volume_set_gain(o.v, 0.5)
+    np.testing.assert_array_equal(got, np.concatenate([o.chunk(x[t * 480:(t + 1) * 480]) for t in range(k)]))
+    # equalizer
+    x = synth_pcm(92, 160 * nblk, sigma=2500.0, rate=16000)
+    eq = host.create(MS_EQUALIZER_ID)
+    assert host.call_int(eq, SET_SAMPLE_RATE, 16000) == 0
+    assert host.call(eq, mid(MS_EQUALIZER_ID, 0, 12), EqGain(1000.0, 2.0, 500.0)) == 0
+    got, k = run(eq, x, 160, pattern)
+    o = oracle.Equalizer(16000)
+    o.set_gain(1000, 2.0, 500)
+    np.testing.assert_array_equal(got, np.concatenate([o.run(x[t * 160:(t + 1) * 160]) for t in range(k)]))
