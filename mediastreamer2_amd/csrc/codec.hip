@@ -432,6 +432,8 @@ int mi_chan_adapt(mi_ctx *c, int mode, const int16_t *d_a, const int16_t *d_b, i
 	return MI_OK;
 }
 
+void mi_flowctl_destroy(mi_flowctl *f);
+
 int mi_flowctl_create(mi_ctx *c, int nstreams, int max_block, mi_flowctl **out) {
 	MI_CHECK_ARG(c && out && nstreams > 0);
 	MI_CHECK_ARG(max_block >= 3 && max_block <= FLOW_MAX_BLOCK);
@@ -439,13 +441,17 @@ int mi_flowctl_create(mi_ctx *c, int nstreams, int max_block, mi_flowctl **out) 
 	if ((rc = c->activate()) != MI_OK) return rc;
 	mi_flowctl *f = new mi_flowctl();
 	f->ctx = c, f->nstreams = nstreams, f->cap = max_block;
-	MI_HIP(hipMalloc(&f->d_state, sizeof(FlowState) * (size_t)nstreams));
-	MI_HIP(hipMalloc(&f->d_cfg, sizeof(FlowCfg) * (size_t)nstreams));
-	MI_HIP(hipMalloc(&f->d_arm, sizeof(uint2) * (size_t)nstreams));
-	MI_HIP(hipMemsetAsync(f->d_state, 0, sizeof(FlowState) * (size_t)nstreams, c->stream));
 	f->h_cfg.assign((size_t)nstreams, FlowCfg{1, 0.02f}); // ms_audio_flow_controller_init :37-41
-	MI_HIP(hipMemcpyAsync(f->d_cfg, f->h_cfg.data(), sizeof(FlowCfg) * (size_t)nstreams, hipMemcpyHostToDevice, c->stream));
-	MI_HIP(hipStreamSynchronize(c->stream));
+	const size_t n = (size_t)nstreams;
+	if (hipMalloc(&f->d_state, sizeof(FlowState) * n) != hipSuccess || hipMalloc(&f->d_cfg, sizeof(FlowCfg) * n) != hipSuccess ||
+	    hipMalloc(&f->d_arm, sizeof(uint2) * n) != hipSuccess ||
+	    hipMemsetAsync(f->d_state, 0, sizeof(FlowState) * n, c->stream) != hipSuccess ||
+	    hipMemcpyAsync(f->d_cfg, f->h_cfg.data(), sizeof(FlowCfg) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+	    hipStreamSynchronize(c->stream) != hipSuccess) {
+		mi::set_error("mi_flowctl_create: device allocation / initialisation failed for %d streams", nstreams);
+		mi_flowctl_destroy(f);
+		return MI_ENOMEM;
+	}
 	*out = f;
 	return MI_OK;
 }

@@ -480,13 +480,17 @@ int mi_plc_create(mi_ctx *c, int nstreams, int rate, int max_block, mi_plc **out
 	std::vector<float2> tw1, sup1, tw2, sup2;
 	twiddles(p->nb / 2, false, tw1, sup1);
 	twiddles(p->nb, true, tw2, sup2);
-	MI_HIP(hipMemcpy(p->d_window, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice));
-	MI_HIP(hipMemcpy(p->d_tw1, tw1.data(), sizeof(float2) * tw1.size(), hipMemcpyHostToDevice));
-	MI_HIP(hipMemcpy(p->d_sup1, sup1.data(), sizeof(float2) * sup1.size(), hipMemcpyHostToDevice));
-	MI_HIP(hipMemcpy(p->d_tw2, tw2.data(), sizeof(float2) * tw2.size(), hipMemcpyHostToDevice));
-	MI_HIP(hipMemcpy(p->d_sup2, sup2.data(), sizeof(float2) * sup2.size(), hipMemcpyHostToDevice));
+	if (hipMemcpy(p->d_window, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(p->d_tw1, tw1.data(), sizeof(float2) * tw1.size(), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(p->d_sup1, sup1.data(), sizeof(float2) * sup1.size(), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(p->d_tw2, tw2.data(), sizeof(float2) * tw2.size(), hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(p->d_sup2, sup2.data(), sizeof(float2) * sup2.size(), hipMemcpyHostToDevice) != hipSuccess) {
+		mi::set_error("mi_plc_create: table upload failed");
+		return fail(MI_ENODEV);
+	}
+	if ((rc = mi_plc_reset(p, 0, nstreams)) != MI_OK) return fail(rc);
 	*out = p;
-	return mi_plc_reset(p, 0, nstreams);
+	return MI_OK;
 }
 
 int mi_plc_reset(mi_plc *p, int first, int count) { // a fresh plc_context_t: everything zero (ms_malloc0, genericplc.c:42-57)
