@@ -363,3 +363,70 @@ def test_generic_plc_burst_of_six_blocks(host, oracle):
     got = out.view(np.int16)
     assert want.size - n <= got.size <= want.size
     np.testing.assert_array_equal(got, want[: got.size])
+
+
+def test_receive_path_graph_of_an_audio_stream(host, oracle):
+    """The receive half of the reference's AudioStream graph (src/voip/audiostream.c:1798-1832) built from the plugin's
+    facades: RTP payloads (PCMU, 10 ms, some lost) -> MSUlawDec -> MSGenericPLC -> MSResample 8k->16k -> MSVolume (static
+    gain) -> sink.  Every facade adds a tick of latency, none changes the samples: the output is the oracle's chain."""
+    from test_gpu_plugin import MS_RESAMPLE_ID, MS_VOLUME_ID, SET_OUTPUT_SAMPLE_RATE
+    rate, n, nt = 8000, 80, 50
+    pcm = synth_pcm(71, n * nt, rate=rate, sigma=2000.0)
+    payloads = oracle.g711_encode(1, pcm)
+    lost = {7, 8, 20, 33, 34, 35}
+    src, dec, plc, rs, vol, snk = (host.source(), host.create(MS_ULAW_DEC_ID), host.create(MS_GENERIC_PLC_ID),
+                                   host.create(MS_RESAMPLE_ID), host.create(MS_VOLUME_ID), host.sink())
+    assert host.call_int(plc, SET_SAMPLE_RATE, rate) == 0
+    assert host.call_int(rs, SET_SAMPLE_RATE, rate) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 16000) == 0
+    assert host.call_int(vol, SET_SAMPLE_RATE, 16000) == 0
+    g = C.c_float(0.5)
+    assert host.call(vol, mid(MS_VOLUME_ID, 2, 4), g) == 0  # MS_VOLUME_SET_GAIN
+
+    def feed(t):
+        if t not in lost:
+            push_bytes(host, src, payloads[t * n:(t + 1) * n])
+
+    out = run_graph(host, [src, dec, plc, rs, vol, snk], feed, nt)
+    got = out.view(np.int16)
+    # the oracle's chain on the same timeline (the decoder's tick of latency shifts the whole pattern, nothing else)
+    ref_plc = oracle.GenericPlcFilter(rate)
+    ref_rs = oracle.Resampler(rate, 16000)
+    ref_vol = oracle.Volume(16000)
+    oracle.lib().orc_volume_set_gain(ref_vol.v, 0.5)
+    want = []
+    for t in range(nt + 3):
+        blocks = [] if (t in lost or t >= nt) else [oracle.g711_decode(1, payloads[t * n:(t + 1) * n])]
+        for b in ref_plc.tick(1000 + 10 * t, blocks):
+            want.append(ref_vol.chunk(ref_rs.process(b)))
+    want = np.concatenate(want)
+    assert got.size > 0.9 * want.size
+    m = min(got.size, want.size)
+    # the resampler is within 1 LSB of the library's order, the static gain halves that
+    assert np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32)).max() <= 1
+    assert ref_plc.con.total_number_for_plc >= len(lost)
+
+
+def test_send_path_graph_of_an_audio_stream(host, oracle):
+    """The send half: 16 kHz capture -> MSVolume (AGC) -> MSResample 16k->8k -> MSUlawEnc (ptime 20) -> RTP payloads.
+    AGC is bit-exact; the resampler's 1-LSB freedom can move a sample across a mu-law decision level, so the payloads
+    are the oracle's except for rare neighbouring code words."""
+    from test_gpu_plugin import MS_RESAMPLE_ID, MS_VOLUME_ID, SET_OUTPUT_SAMPLE_RATE
+    nt = 60
+    x = synth_pcm(72, 160 * nt, rate=16000, sigma=4000.0)
+    src, vol, rs, enc, snk = (host.source(), host.create(MS_VOLUME_ID), host.create(MS_RESAMPLE_ID),
+                              host.create(MS_ULAW_ENC_ID), host.sink())
+    assert host.call_int(vol, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(vol, mid(MS_VOLUME_ID, 8, 4), 1) == 0
+    assert host.call_int(rs, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 8000) == 0
+    assert host.S.ms_filter_call_method(enc, ADD_FMTP, C.c_char_p(b"ptime=20")) == 0
+    out = run_graph(host, [src, vol, rs, enc, snk], lambda t: host.push(src, x[160 * t: 160 * (t + 1)]), nt)
+    assert host.S.ms2shim_sink_blocks(snk) >= nt // 2 - 2 and out.size % 160 == 0   # 20 ms packets of 160 code words
+    o_vol = oracle.Volume(16000)
+    o_vol.v.agc_enabled = 1
+    o_rs = oracle.Resampler(16000, 8000)
+    pcm8 = np.concatenate([o_rs.process(o_vol.chunk(x[160 * t: 160 * (t + 1)])) for t in range(nt)])
+    want = oracle.g711_encode(1, pcm8)[: out.size]
+    same = out == want
+    assert same.mean() > 0.995
+    # where they differ it is the neighbouring code word (magnitude index +- 1)
+    mag = lambda c: (~c) & 0x7F
+    assert (np.abs(mag(out[~same]).astype(int) - mag(want[~same]).astype(int)) <= 1).all()
