@@ -696,10 +696,13 @@ def main():
             def make_resample_65536(ms_, torch_, ctx_):  # same kernel, a deployment-sized batch
                 return make_resample_leg(ms_, torch_, ctx_, 65536)
 
+            def make_mixer_1024(ms_, torch_, ctx_):  # BASELINE configs[3] at its full size: 1024 conferences x 32 members
+                return make_mixer_leg(ms_, torch_, ctx_, nconf=1024)
+
             def make_g711_encode(ms_, torch_, ctx_):
                 return make_g711_leg(ms_, torch_, ctx_, encode=True)
 
-            for mk in (make_resample_65536, make_mixer_leg, make_volume_leg, make_equalizer_leg, make_aec_leg,
+            for mk in (make_resample_65536, make_mixer_leg, make_mixer_1024, make_volume_leg, make_equalizer_leg, make_aec_leg,
                        make_scaler_leg, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
                 try:
                     lg = mk(ms, torch, ctx)
@@ -710,7 +713,7 @@ def main():
                     ctx.sync()
                     # the PMC summary was taken at the bench sizes; the 65536-stream row has no counter pass
                     r = roofline(ms_, ksteps, lg.alg_bytes,
-                                 None if mk is make_resample_65536 else pmc_traffic(lg.name))
+                                 None if mk in (make_resample_65536, make_mixer_1024) else pmc_traffic(lg.name))
                     r["kernel"] = lg.name
                     r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
                     per = np.array(reps) * 1e3 / ksteps  # the reference's profiler prints count/min/mean/max/sd per filter
