@@ -281,3 +281,39 @@ def test_aec_chunked_post_filter_overlap_changes_nothing(ctx, chunks):
     assert torch.equal(d_o1, p_o1) and torch.equal(d_o2, p_o2)
     a.close()
     b.close()
+
+
+def test_aec_automatic_overlap_at_scale_is_bit_identical(ctx):
+    """16 384 streams at 256-sample frames: the automatic schedule (two chunks, second stream, deferred joins across two
+    rounds like mi_session does) against the plain one, 12 frames, every output sample compared on the device."""
+    import torch
+    rate, F, n = 48000, 256, 16384
+    flen = 128 * rate // 1000
+    a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    b = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    a.set_overlap(0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    far = (torch.randn((64, 12 * F), generator=g) * 3000).round().clamp(-32767, 32767).to(torch.int16)
+    mic = (0.4 * far.float() + torch.randn((64, 12 * F), generator=g) * 80).round().clamp(-32767, 32767).to(torch.int16)
+    far = far.repeat(n // 64, 1).cuda()
+    mic = mic.repeat(n // 64, 1).cuda()
+    # every 64th stream gets its own gain so the streams are not all alike
+    mic[::64] = (mic[::64].float() * 0.5).to(torch.int16)
+    oa = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
+    ob = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
+    # persistent frame tensors: the launches run on the context's stream, which torch's allocator knows nothing about
+    mics = [mic[:, k * F:(k + 1) * F].contiguous() for k in range(12)]
+    fars = [far[:, k * F:(k + 1) * F].contiguous() for k in range(12)]
+    torch.cuda.synchronize()
+    fl = ms.MI_AEC_POSTFILTER
+    for f in range(0, 12, 2):
+        for r in range(2):
+            a.process(mics[f + r], fars[f + r], out=oa[r], flags=fl)
+            b.process(mics[f + r], fars[f + r], out=ob[r], flags=fl | ms.MI_AEC_DEFER_JOIN)
+        b.join()
+        ctx.sync()
+        torch.cuda.synchronize()
+        assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1]), f"frames {f}, {f + 1}"
+    assert oa[1].any()
+    a.close()
+    b.close()
