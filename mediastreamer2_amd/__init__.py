@@ -9,6 +9,11 @@ the product is the shared library and the MSFilter facades in host/.
 Numpy arrays go through the *_host entry points (H2D + kernel + D2H);
 torch CUDA(HIP) tensors and raw device pointers go through the device-resident
 entry points and stay asynchronous on the context stream.
+
+Lifetime rule for device tensors: a Context created without `stream=` launches on its OWN HIP stream, which
+torch's caching allocator does not know about -- keep every tensor handed to a process() call alive (and do
+not write to it from torch) until ctx.sync(); temporaries such as `x[:, a:b].contiguous()` passed inline are
+freed and reused by torch while the kernel may still be reading them.
 """
 import ctypes as C
 
