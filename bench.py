@@ -390,6 +390,7 @@ def pipeline_probe(ms, torch, ctx, nstreams):
         for r in range(2):
             f_mic.pop(F, micf[r], ok=okm[r], zero_fill=False)
             f_ref.pop(F, reff[r], gate=okm[r], zero_fill=True)
+        for r in range(2):
             aec.process(micf[r], reff[r], out=clean[r], run=okm[r], flags=ms.MI_AEC_POSTFILTER | ms.MI_AEC_DEFER_JOIN)
         aec.join()
         for r in range(2):

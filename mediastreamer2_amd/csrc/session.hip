@@ -74,13 +74,16 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 	if ((rc = mi_fifo_push(s->f_ref, ref, s->len, s->len, nullptr)) != MI_OK) return rc;
 	// frames a tick can complete (480 / 256 -> 2).  Each round has its own buffers and the canceller's join is deferred to
 	// after the last one, so a round's trailing post-filter runs next to the next round's canceller (mi_aec_process).
+	// (the frames of every round are popped first -- the FIFOs do not depend on the canceller -- so the cancellers of
+	// consecutive rounds follow each other without a gap)
 	for (int r = 0; r < s->rounds; ++r) {
 		if ((rc = mi_fifo_pop(s->f_mic, s->frame, s->d_micf[r], s->frame, s->d_ok[r], nullptr, 0)) != MI_OK) return rc;
 		if ((rc = mi_fifo_pop(s->f_ref, s->frame, s->d_reff[r], s->frame, nullptr, s->d_ok[r], 1)) != MI_OK) return rc;
+	}
+	for (int r = 0; r < s->rounds; ++r)
 		if ((rc = mi_aec_process(s->aec, s->d_micf[r], s->d_reff[r], s->d_clean[r], s->frame, s->d_ok[r],
 		                         MI_AEC_POSTFILTER | MI_AEC_DEFER_JOIN)) != MI_OK)
 			return rc;
-	}
 	if ((rc = mi_aec_join(s->aec)) != MI_OK) return rc;
 	for (int r = 0; r < s->rounds; ++r)
 		if ((rc = mi_fifo_push_gated(s->f_out, s->d_clean[r], s->frame, s->frame, s->d_ok[r])) != MI_OK) return rc;
