@@ -650,3 +650,58 @@ def test_bursts_through_the_batched_facades(host, oracle):
     o = oracle.Equalizer(16000)
     o.set_gain(1000, 2.0, 500)
     np.testing.assert_array_equal(got, np.concatenate([o.run(x[t * 160:(t + 1) * 160]) for t in range(k)]))
+
+
+def test_speex_ec_burst_of_frames_in_one_tick(host, oracle):
+    """Five ticks' worth of microphone and far-end audio delivered in ONE tick (more canceller frames than the pool has
+    launch rounds): the filter must still produce exactly the frame sequence the reference's framing produces."""
+    rate, F, ns = 16000, 128, 160
+    host.S.ms2shim_source_set_burst.argtypes = [C.c_void_p, C.c_int]
+    ec = host.create(MS_SPEEX_EC_ID)
+    assert host.call_int(ec, SET_SAMPLE_RATE, rate) == 0 and host.call_int(ec, mid(EC_IFACE, 2, 4), 128) == 0
+    s_ref, s_mic, k_ref, k_mic = host.source(), host.source(), host.sink(), host.sink()
+    host.S.ms2shim_source_set_burst(s_ref, 1)
+    host.S.ms2shim_source_set_burst(s_mic, 1)
+    host.link(s_ref, 0, ec, 0)
+    host.link(s_mic, 0, ec, 1)
+    host.link(ec, 0, k_ref, 0)
+    host.link(ec, 1, k_mic, 0)
+    host.S.ms_ticker_attach(host.ticker, ec)
+    pattern = [1, 1, 1, 5, 0, 0, 1, 6, 1, 1]
+    nblk = sum(pattern)
+    rng = np.random.default_rng(6)
+    far = np.clip(np.round(rng.normal(0, 3000, ns * nblk)), -32767, 32767).astype(np.int16)
+    ir = rng.normal(0, 1, 48) * np.exp(-np.arange(48) / 10.0)
+    mic = np.clip(np.round(0.4 * np.convolve(far.astype(float), ir)[:ns * nblk] + rng.normal(0, 50, ns * nblk)),
+                  -32767, 32767).astype(np.int16)
+    k = 0
+    e = oracle.Echo(F, 128 * rate // 1000, rate)
+    pp = oracle.Preproc(F, rate, e)
+    echo_fifo, dref_fifo = np.zeros(0, np.int16), np.zeros(0, np.int16)
+    started, outs = False, []
+    for cnt in pattern:
+        for _ in range(cnt):
+            host.push(s_ref, far[k * ns:(k + 1) * ns])
+            host.push(s_mic, mic[k * ns:(k + 1) * ns])
+            k += 1
+        host.step()
+        # the same framing through the oracle: far-end blocks of the tick first (kept only once the microphone started),
+        # then the microphone blocks, then every complete frame (speexec.c:241-305)
+        lo, hi = (k - cnt) * ns, k * ns
+        if started:
+            dref_fifo = np.concatenate([dref_fifo, far[lo:hi]])
+        echo_fifo = np.concatenate([echo_fifo, mic[lo:hi]])
+        while len(echo_fifo) >= F:
+            fr, echo_fifo = echo_fifo[:F], echo_fifo[F:]
+            started = True
+            if len(dref_fifo) < F:
+                dref_fifo = np.concatenate([dref_fifo, np.zeros(F, np.int16)])
+            r, dref_fifo = dref_fifo[:F], dref_fifo[F:]
+            outs.append(pp.run(e.cancel(fr, r)))
+    host.step(3)
+    got = host.drain(k_mic)
+    ref = np.concatenate(outs)
+    host.S.ms_ticker_detach(host.ticker, ec)
+    assert len(got) == len(ref)
+    d = got.astype(np.float64) - ref.astype(np.float64)
+    assert np.sqrt(np.mean(d ** 2)) / 32768.0 <= 1e-4
