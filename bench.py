@@ -200,9 +200,12 @@ def make_equalizer_leg(ms, torch, ctx, nstreams=4096, ns=480):
     return leg
 
 
-def make_scaler_leg(ms, torch, ctx, nframes=64):
+def make_scaler_leg(ms, torch, ctx, nframes=64, fmt=None):
+    """1080p I420 -> 720p, to RGB24 (BASELINE configs[4]) or to I420 (fmt=MI_PIX_I420: what MSSizeConv asks of the scaler,
+    sizeconv.c:97-184 -- libyuv ignores the destination format for I420 sources, msvideo.c:547-551)."""
     sw, sh, dw, dh = 1920, 1080, 1280, 720
-    sc = ms.ScalerBatch(ctx, sw, sh, dw, dh, ms.MI_PIX_RGB24)
+    fmt = ms.MI_PIX_RGB24 if fmt is None else fmt
+    sc = ms.ScalerBatch(ctx, sw, sh, dw, dh, fmt)
     per_step = nframes * (sc.src_bytes + sc.dst_bytes)
     ring = 2  # 2 x 376 MB already exceeds the Infinity Cache
     rng = np.random.default_rng(0x5EED)
@@ -222,7 +225,8 @@ def make_scaler_leg(ms, torch, ctx, nframes=64):
     def launch(i):
         sc.process(ins[i], out=outs[i])
 
-    leg = Leg(ctx, "scaler_wave_kernel<true>", launch, ring, per_step, nframes, "frames")
+    leg = Leg(ctx, "scaler_wave_kernel<true>" if fmt == ms.MI_PIX_RGB24 else "scaler_wave_kernel<false>", launch, ring, per_step,
+              nframes, "frames" if fmt == ms.MI_PIX_RGB24 else "frames (1080p I420 -> 720p I420)")
     leg.keep = (sc, ins, outs)
     leg.mpix_in = nframes * sw * sh / 1e6
     return leg
@@ -700,11 +704,14 @@ def main():
             def make_mixer_1024(ms_, torch_, ctx_):  # BASELINE configs[3] at its full size: 1024 conferences x 32 members
                 return make_mixer_leg(ms_, torch_, ctx_, nconf=1024)
 
+            def make_scaler_i420(ms_, torch_, ctx_):  # the MSSizeConv case: I420 in, I420 out
+                return make_scaler_leg(ms_, torch_, ctx_, fmt=ms_.MI_PIX_I420)
+
             def make_g711_encode(ms_, torch_, ctx_):
                 return make_g711_leg(ms_, torch_, ctx_, encode=True)
 
             for mk in (make_resample_65536, make_mixer_leg, make_mixer_1024, make_volume_leg, make_equalizer_leg, make_aec_leg,
-                       make_scaler_leg, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
+                       make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
@@ -714,7 +721,7 @@ def main():
                     ctx.sync()
                     # the PMC summary was taken at the bench sizes; the 65536-stream row has no counter pass
                     r = roofline(ms_, ksteps, lg.alg_bytes,
-                                 None if mk in (make_resample_65536, make_mixer_1024) else pmc_traffic(lg.name))
+                                 None if mk in (make_resample_65536, make_mixer_1024, make_scaler_i420) else pmc_traffic(lg.name))
                     r["kernel"] = lg.name
                     r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
                     per = np.array(reps) * 1e3 / ksteps  # the reference's profiler prints count/min/mean/max/sd per filter

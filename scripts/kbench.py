@@ -14,6 +14,7 @@ mk = {"resample": lambda: bench.make_resample_leg(ms, torch, ctx, 4096), "mixer"
       "g711_dec_8k": lambda: bench.make_g711_leg(ms, torch, ctx, n=80),
       "plc": lambda: bench.make_plc_leg(ms, torch, ctx), "plc_clean": lambda: bench.make_plc_leg(ms, torch, ctx, loss=0.0),
       "plc_half": lambda: bench.make_plc_leg(ms, torch, ctx, loss=0.5), "plc48": lambda: bench.make_plc_leg(ms, torch, ctx, nstreams=16384, rate=48000),
+      "scaler_i420": lambda: bench.make_scaler_leg(ms, torch, ctx, fmt=ms.MI_PIX_I420),
       "pixconv_rgb": lambda: bench.make_pixconv_leg(ms, torch, ctx, fmt=ms.MI_PIX_BGR24)}
 for w in which:
     lg = mk[w]()
