@@ -5,18 +5,31 @@ Contract (see DESIGN.md "Measurement"):
   python bench.py --gpus N --steps K --warmup W
 prints ONE JSON line on rank 0.
 
-Workload at every N: BASELINE.json configs[1] per GPU -- 4096 concurrent mono
-streams, polyphase resample 16 kHz -> 48 kHz (MSResample, quality 3).  A
-"step" is one 10 ms tick of the whole batch = one kernel launch: 4096 x 160
-int16 in, 4096 x 480 int16 out, inputs already resident in HBM.  Streams are
-independent, so N GPUs run N independent shards (weak scaling, no collective
-in the data path); value = real-time stream capacity of the whole job
-= streams processed per second / 100 ticks per second.
+Workload: the north_star hot path, chained on the device, per call leg and
+10 ms tick (src/base/msticker.c:46): MSResample 16k->48k -> FIFO -> MSSpeexEC
+(48 kHz, 256-sample frames, 128 ms tail, canceller + post-filter) -> FIFO ->
+MSVolume (AGC) -> MSAudioMixer (conferences of 32).  A "step" is one tick of
+every leg on the GPU; inputs are resident in HBM.
 
-To keep the measurement honest for a 5 MB/tick working set, the K steps walk
-a ring of distinct input/output tick buffers larger than the 256 MiB
-Infinity Cache, and the K launches are replayed from one hipGraph so the
-host's per-launch cost (Python + hipLaunch) is not what is timed.
+value = concurrent 48 kHz legs the job sustains: the largest leg count per GPU
+(capacity sweep) whose WORST single tick stays under the 10 ms interval, summed
+over the ranks; ms_per_step = the average tick at that count over the timed
+region (whole 8-tick cycles, at least 0.5 s, replayed from a hipGraph so the
+host's launch cost is not what is timed).  Every tick streams the cancellers'
+resident state (~180 KB per leg, gigabytes per GPU), so nothing of the working
+set survives in the 256 MiB Infinity Cache between ticks.
+
+N > 1 (one rank per GPU, torch.distributed.run): legs and whole conferences are
+sharded statically (no collective); in addition 64 conferences are split over
+ALL ranks and mixed through the path's one exchange step every tick:
+mi_mixer_partial_sum -> int32 all-reduce over RCCL (explicit events between the
+kernel stream and the collective's stream) -> mi_mixer_finalize, checked bit
+for bit against the single-GPU mix on rank 0.  RCCL failure = non-zero exit.
+
+roofline = the canceller + post-filter kernel pair at the headline leg count,
+HIP events on the launch stream; cpu_baseline = the oracle's same chain on the
+host's cores (bounded sample).  other_kernels: BASELINE configs[1]-[4] and the
+adjacent stages, each with its own roofline object.
 """
 import argparse
 import ctypes as C
@@ -37,14 +50,16 @@ TICKS_PER_S = 100.0    # MSTicker interval 10 ms (src/base/msticker.c:46)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU (configs[1]: 4096)")
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=0, help="call legs per GPU; 0 = capacity sweep (largest count whose worst tick < 10 ms)")
+    ap.add_argument("--sweep-lo", type=int, default=49152)
+    ap.add_argument("--sweep-hi", type=int, default=131072)
+    ap.add_argument("--min-timed-s", type=float, default=0.5, help="the timed region is at least this long, whatever --steps says")
+    ap.add_argument("--no-session", action="store_true", help="skip the PCIe-inclusive mi_session probes")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel roofline table")
-    ap.add_argument("--pipeline-streams", type=int, default=65536,
-                    help="streams for the all-kernels-per-tick probe (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -307,8 +322,9 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
     aec = ms.AecBatch(ctx, nstreams, rate, frame_size=F, filter_length=128 * rate // 1000)
     # per 256-sample frame mic+ref+out 1536 B, W read+write 2x49152, foreground 49152,
     # X history read 51200, newest X block 2048
-    per_frame = nstreams * 202240
+    per_frame = nstreams * AEC_FRAME_BYTES
     rng = np.random.default_rng(0x5EED)
+    nfull, nstreams = nstreams, min(nstreams, 4096)  # distinct signals for 4096 streams, repeated for the rest
     far = synth_pcm_batch(nstreams, F * 4, rate)
     ir = rng.normal(0, 1, 64) * np.exp(-np.arange(64) / 12.0)
     ir /= np.sqrt((ir ** 2).sum())
@@ -318,9 +334,11 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
         f = far[:, r * F:(r + 1) * F].astype(np.float32)
         echo = 0.5 * np.apply_along_axis(lambda v: np.convolve(v, ir)[:F], 1, f[:256])
         mic = np.tile(echo, (nstreams // 256 + 1, 1))[:nstreams] + rng.normal(0, 300, (nstreams, F))
-        mics.append(torch.from_numpy(np.clip(np.round(mic), -32767, 32767).astype(np.int16)).cuda())
-        refs.append(torch.from_numpy(np.ascontiguousarray(far[:, r * F:(r + 1) * F])).cuda())
-        outs.append(torch.zeros((nstreams, F), dtype=torch.int16, device="cuda"))
+        reps = -(-nfull // nstreams)
+        mics.append(torch.from_numpy(np.clip(np.round(mic), -32767, 32767).astype(np.int16)).cuda().repeat(reps, 1)[:nfull].contiguous())
+        refs.append(torch.from_numpy(np.ascontiguousarray(far[:, r * F:(r + 1) * F])).cuda().repeat(reps, 1)[:nfull].contiguous())
+        outs.append(torch.zeros((nfull, F), dtype=torch.int16, device="cuda"))
+    nstreams = nfull
 
     def launch(i):
         aec.process(mics[i], refs[i], out=outs[i])
@@ -354,89 +372,205 @@ def copy_ceiling(torch):
     return round(2 * n / (best * 1e-3) / 1e9, 1)
 
 
+CHAIN_DESC = ("MSResample 16k->48k -> device FIFO (480-sample ticks -> 256-sample frames) -> MSSpeexEC (128 ms tail, "
+              "canceller + post-filter; 15 frames per 8 ticks) -> device FIFO (frames -> ticks) -> MSVolume (AGC) -> "
+              "MSAudioMixer (conferences of 32), device resident")
+AEC_FRAME_BYTES = 202240  # mic+ref+out 1536, W read+write 2 x 49152, foreground 49152, X history 51200, newest X 2048
+AEC_FRAMES_PER_TICK = 1.875  # 480 / 256 (speexec.c:171-180: 256-sample frames at 48 kHz)
+SPLIT_CONFERENCES = 64  # at N > 1: conferences whose 32 members are spread over all ranks (the RCCL exchange step)
+
+
+class ChainRig:
+    """The north_star hot path for `n` concurrent 48 kHz call legs on ONE GPU, device resident from end to end
+    (tests/test_gpu_pipeline.py checks the same chain stage by stage against the oracle).  One tick() = one 10 ms
+    MSTicker interval (src/base/msticker.c:46) of every leg:
+      MSResample 16k->48k (msresample.c:122-179) -> device FIFO -> MSSpeexEC at 256-sample frames, 128 ms tail,
+      canceller + post-filter (speexec.c:171-180,223-305; two frame rounds per tick, the second one masked off by the
+      FIFO level in one tick out of eight) -> device FIFO -> MSVolume with AGC (msvolume.c:471-514) -> MSAudioMixer,
+      conferences of 32 (audiomixer.c:288-346).
+    With world > 1 the last `nsplit` conferences of every rank are SPLIT ones: their 32 members are spread over all
+    ranks (32 / world local members each), the rank computes int32 partial sums (mi_mixer_partial_sum), the caller
+    all-reduces them (RCCL) and finalize() writes the local members' outputs (audiomixer.c:304-314 across GPUs)."""
+
+    F, RATE, MEMBERS, RING = 256, 48000, 32, 4
+
+    def __init__(self, ms, torch, ctx, nstreams, world=1, rank=0, nsplit=0):
+        self.ms, self.torch, self.ctx = ms, torch, ctx
+        F, rate, mm = self.F, self.RATE, self.MEMBERS
+        self.mloc = mm // world if nsplit else 0
+        self.nsplit = nsplit
+        nsplit_streams = nsplit * self.mloc
+        self.nconf = max(1, (nstreams - nsplit_streams) // mm)
+        self.n = n = self.nconf * mm + nsplit_streams
+        self.rs = ms.ResamplerBatch(ctx, n, 16000, rate)
+        self.aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
+        self.vol = ms.VolumeBatch(ctx, n, rate)
+        p = self.vol.default_params()
+        p.agc_enabled = 1
+        self.vol.set_params([p] * n)
+        self.mix = ms.MixerBatch(ctx, self.nconf, mm, 480)
+        self.f_mic, self.f_ref, self.f_out = (ms.FifoBatch(ctx, n, 1024) for _ in range(3))
+        ring = self.RING
+        base = min(n, 4096)  # distinct signals for 4096 legs, rotated for the rest (the kernels do not care)
+        mic16 = synth_pcm_batch(base, 160 * ring, 16000, seed0=0x5EED + 7919 * rank)
+        ref48 = synth_pcm_batch(base, 480 * ring, rate, seed0=0xFA2 + 7919 * rank, sigma=2000.0)
+        reps = -(-n // base)
+        def spread(a, r, w):
+            t = torch.from_numpy(np.ascontiguousarray(a[:, r * w:(r + 1) * w])).cuda()
+            return t.repeat(reps, 1)[:n].contiguous() if reps > 1 else t
+        self.d_mic = [spread(mic16, r, 160) for r in range(ring)]
+        self.d_ref = [spread(ref48, r, 480) for r in range(ring)]
+        z = lambda *shape, dt=torch.int16: torch.zeros(shape, dtype=dt, device="cuda")
+        self.up = z(n, 488)
+        # one set of frame buffers per canceller round of a tick: the join of a round is deferred (mi_session does the
+        # same), so its trailing post-filter runs next to the next round's canceller
+        self.micf = [z(n, F) for _ in range(2)]
+        self.reff = [z(n, F) for _ in range(2)]
+        self.clean = [z(n, F) for _ in range(2)]
+        self.okm = [z(n, dt=torch.uint8) for _ in range(2)]
+        self.tick_buf = z(n, 480)
+        self.mixed = z(n, 480)
+        nw = self.nconf * mm
+        self.whole_in = self.tick_buf[:nw].view(self.nconf, mm, 480)
+        self.whole_out = self.mixed[:nw].view(self.nconf, mm, 480)
+        if nsplit:
+            self.mixs = ms.MixerBatch(ctx, nsplit, self.mloc, 480)
+            self.split_in = self.tick_buf[nw:].view(nsplit, self.mloc, 480)
+            self.split_out = self.mixed[nw:].view(nsplit, self.mloc, 480)
+            self.d_sum = z(nsplit, 480, dt=torch.int32)
+        torch.cuda.synchronize()
+
+    def tick(self, t):
+        ms, F, n = self.ms, self.F, self.n
+        self.rs.process(self.d_mic[t % self.RING], out=self.up)
+        self.f_mic.push(self.up, nsamples=480)
+        self.f_ref.push(self.d_ref[t % self.RING])
+        for r in range(2):
+            self.f_mic.pop(F, self.micf[r], ok=self.okm[r], zero_fill=False)
+            self.f_ref.pop(F, self.reff[r], gate=self.okm[r], zero_fill=True)
+        for r in range(2):
+            self.aec.process(self.micf[r], self.reff[r], out=self.clean[r], run=self.okm[r],
+                             flags=ms.MI_AEC_POSTFILTER | ms.MI_AEC_DEFER_JOIN)
+        self.aec.join()
+        for r in range(2):
+            self.f_out.push(self.clean[r], gate=self.okm[r])
+        self.f_out.pop(480, self.tick_buf, zero_fill=True)
+        self.vol.process(self.tick_buf)
+        self.mix.process(self.whole_in, out=self.whole_out)
+        if self.nsplit:
+            self.mixs.partial_sum(self.split_in, self.d_sum)
+
+    def finalize(self):
+        """after the all-reduce of d_sum: the split conferences' local outputs"""
+        if self.nsplit:
+            self.mixs.finalize(self.split_in, self.d_sum, self.split_out)
+
+    def capture(self, ticks):
+        self.ctx.capture_begin()
+        for t in ticks:
+            self.tick(t)
+            if self.nsplit and len(ticks) > 1:
+                raise RuntimeError("a tick with a collective in it is captured alone")
+        return self.ctx.capture_end()
+
+    def warm(self, nt=8):
+        for t in range(nt):  # 15 frames per 8 ticks: the FIFO levels return to where they started
+            self.tick(t)
+            self.finalize()
+        self.ctx.sync()
+
+    def overflows(self):
+        return self.f_mic.overflows() + self.f_ref.overflows() + self.f_out.overflows()
+
+    def state_bytes(self):
+        return int(self.aec.state_bytes() * self.n)
+
+    def close(self):
+        for o in ("rs", "aec", "vol", "mix", "f_mic", "f_ref", "f_out", "mixs"):
+            if hasattr(self, o):
+                getattr(self, o).close()
+        self.__dict__.clear()
+
+
+def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25):
+    """avg and worst tick of the chain at `nstreams` legs on this GPU.  avg: one hipGraph of 8 ticks replayed for at
+    least `min_s` seconds; worst: single-tick graphs timed one by one over two 8-tick cycles (no overlap between
+    ticks, the GPU drains after each: conservative)."""
+    rig = ChainRig(ms, torch, ctx, nstreams)
+    try:
+        rig.warm()
+        g8 = rig.capture(range(8))
+        g8.launch()
+        ctx.sync()
+        ctx.timer_start()
+        g8.launch()
+        one = ctx.timer_stop()
+        reps = max(2, int(np.ceil(min_s * 1e3 / max(one, 1e-3))))
+        ctx.timer_start()
+        for _ in range(reps):
+            g8.launch()
+        avg = ctx.timer_stop() / (8 * reps)
+        g1 = [rig.capture([t]) for t in range(rig.RING)]
+        per = []
+        for t in range(16):
+            ctx.timer_start()
+            g1[t % rig.RING].launch()
+            per.append(ctx.timer_stop())
+        out = {"streams": rig.n, "conferences": rig.nconf, "tick_ms_avg": round(avg, 4), "tick_ms_worst": round(max(per), 4),
+               "tick_ms_single_median": round(float(np.median(per)), 4), "fits": bool(max(per) < 10.0),
+               "fifo_overflows": int(rig.overflows()), "aec_resident_state_bytes": rig.state_bytes()}
+        del g8, g1
+    finally:
+        rig.close()
+        torch.cuda.empty_cache()
+    return out
+
+
+def find_capacity(ms, torch, ctx, lo=32768, hi=131072, coarse=8192, fine=2048, log=None):
+    """Largest stream count (multiple of `fine`) whose WORST tick of the chain stays under the 10 ms MSTicker interval.
+    Coarse steps up from `lo` while the tick fits, then bisection down to `fine`.  Returns (streams, points measured)."""
+    pts = []
+    def fits(n):
+        try:
+            p = chain_capacity_point(ms, torch, ctx, n)
+        except Exception as e:  # out of memory counts as "does not fit"
+            p = {"streams": n, "fits": False, "error": str(e)[:160]}
+        pts.append(p)
+        if log:
+            log(p)
+        return p["fits"]
+    good, bad = None, None
+    n = lo
+    while n <= hi:
+        if fits(n):
+            good = n
+            n += coarse
+        else:
+            bad = n
+            break
+    if good is None:  # even `lo` is too many for this device: walk down
+        n = lo // 2
+        while n >= fine and not fits(n):
+            bad = n
+            n //= 2
+        good = n if n >= fine else 0
+    if bad is None:
+        return good, pts
+    while bad - good > fine:
+        mid = (good + bad) // 2 // fine * fine
+        if mid <= good or mid >= bad:
+            break
+        if fits(mid):
+            good = mid
+        else:
+            bad = mid
+    return good, pts
+
+
 def pipeline_probe(ms, torch, ctx, nstreams):
-    """north_star check: the chained per-tick path for `nstreams` concurrent 48 kHz streams on one GPU, device
-    resident from end to end (tests/test_gpu_pipeline.py checks the same chain stage by stage against the oracle):
-    MSResample 16k->48k -> device FIFO (480-sample ticks -> 256-sample frames) -> MSSpeexEC (128 ms tail, post-filter;
-    two frame rounds per tick, the second one masked off by the FIFO level in one tick out of eight) -> device FIFO
-    (frames -> ticks) -> MSVolume (AGC) -> MSAudioMixer (nstreams/32 conferences of 32)."""
-    F, rate = 256, 48000
-    nconf = max(1, nstreams // 32)
-    n = nconf * 32
-    rs = ms.ResamplerBatch(ctx, n, 16000, rate)
-    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
-    vol = ms.VolumeBatch(ctx, n, rate)
-    p = vol.default_params()
-    p.agc_enabled = 1
-    vol.set_params([p] * n)
-    mix = ms.MixerBatch(ctx, nconf, 32, 480)
-    f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, 1024) for _ in range(3))
-    ring = 4
-    mic16 = synth_pcm_batch(n, 160 * ring, 16000)
-    ref48 = synth_pcm_batch(n, 480 * ring, rate, sigma=2000.0)
-    d_mic = [torch.from_numpy(np.ascontiguousarray(mic16[:, r * 160:(r + 1) * 160])).cuda() for r in range(ring)]
-    d_ref = [torch.from_numpy(np.ascontiguousarray(ref48[:, r * 480:(r + 1) * 480])).cuda() for r in range(ring)]
-    up = torch.zeros((n, 488), dtype=torch.int16, device="cuda")
-    # one set of frame buffers per canceller round of a tick: the join of a round is deferred (mi_session does the same),
-    # so its trailing post-filter runs next to the next round's canceller
-    micf = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
-    reff = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
-    clean = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
-    okm = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    tick_buf = torch.zeros((nconf, 32, 480), dtype=torch.int16, device="cuda")
-    mixed = torch.zeros((nconf, 32, 480), dtype=torch.int16, device="cuda")
-    torch.cuda.synchronize()
-
-    def tick(t):
-        rs.process(d_mic[t % ring], out=up)
-        f_mic.push(up, nsamples=480)
-        f_ref.push(d_ref[t % ring])
-        for r in range(2):
-            f_mic.pop(F, micf[r], ok=okm[r], zero_fill=False)
-            f_ref.pop(F, reff[r], gate=okm[r], zero_fill=True)
-        for r in range(2):
-            aec.process(micf[r], reff[r], out=clean[r], run=okm[r], flags=ms.MI_AEC_POSTFILTER | ms.MI_AEC_DEFER_JOIN)
-        aec.join()
-        for r in range(2):
-            f_out.push(clean[r], gate=okm[r])
-        f_out.pop(480, tick_buf.view(n, 480), zero_fill=True)
-        vol.process(tick_buf.view(n, 480))
-        mix.process(tick_buf, out=mixed)
-
-    nt = 8  # 15 frames per 8 ticks: the FIFO levels return to where they started
-    for t in range(nt):
-        tick(t)
-    ctx.sync()
-    ctx.capture_begin()
-    for t in range(nt):
-        tick(t)
-    g = ctx.capture_end()
-    g.launch()
-    ctx.sync()
-    best = None
-    for _ in range(3):
-        ctx.timer_start()
-        g.launch()
-        ms_ = ctx.timer_stop()
-        best = ms_ if best is None else min(best, ms_)
-    avg = best / nt
-    # the worst tick carries two full frame rounds: measured alone
-    ctx.capture_begin()
-    tick(0)
-    g1 = ctx.capture_end()
-    worst = 0.0
-    for t in range(nt):
-        ctx.timer_start()
-        g1.launch()
-        worst = max(worst, ctx.timer_stop())
-    overflow = f_mic.overflows() + f_ref.overflows() + f_out.overflows()
-    out = {"streams": n, "conferences": nconf, "tick_ms_avg": round(avg, 4), "tick_ms_worst_of_8": round(worst, 4),
-           "tick_budget_ms": 10.0, "fits": bool(worst < 10.0), "fifo_overflows": int(overflow),
-           "aec_resident_state_bytes": int(aec.state_bytes() * n),
-           "chain": "resample_up -> fifo -> 2 x (fifo pop, aec_mdf_wave + aec_post_wave, fifo push) -> fifo -> volume -> "
-                    "mixer_members, device resident, one hipGraph of 8 ticks"}
-    del rs, vol, mix, aec, f_mic, f_ref, f_out
-    torch.cuda.empty_cache()
+    """one point of the capacity curve (dev tools: scripts/pipe_probe.py)"""
+    out = chain_capacity_point(ms, torch, ctx, nstreams)
+    out["chain"] = CHAIN_DESC
     return out
 
 
@@ -479,36 +613,8 @@ def session_probe(ms, ctx, nstreams, ticks=40, trunk=False):
             "fits": bool(dt < 0.010), "note": note}
 
 
-def cpu_baseline_resample(nstreams, seconds):
-    """The oracle (CPU restatement of the reference path: one resampler object per stream,
-    called tick by tick) on this host's cores -- 1 thread, bounded sample."""
-    import oracle
-    oracle.build()
-    L = oracle.lib()
-    L.orc_bench_resample.restype = C.c_double
-    L.orc_bench_resample.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
-                                     C.POINTER(C.c_int16), C.POINTER(C.c_longlong)]
-    x = synth_pcm_batch(nstreams, 160, 16000)
-    xp = x.ctypes.data_as(C.POINTER(C.c_int16))
-    t = L.orc_bench_resample(nstreams, 160, 2, 16000, 48000, xp, None)
-    nticks = max(2, int(seconds / (t / 2)))
-    t = L.orc_bench_resample(nstreams, 160, nticks, 16000, 48000, xp, None)
-    stream_ticks_per_s = nstreams * nticks / t
-    return {"value": round(stream_ticks_per_s / TICKS_PER_S, 1), "unit": "concurrent 48 kHz streams (10 ms ticks in real time)",
-            "cores": 1, "kind": "port",
-            "sample": f"{nstreams} streams x {nticks} ticks of 160 samples 16k->48k, oracle/resample.c, "
-                      f"{t:.1f} s on 1 of {os.cpu_count()} host cores",
-            "us_per_stream_tick": round(t / (nstreams * nticks) * 1e6, 3)}
-
-
-def cpu_baseline_resample_all_cores(nstreams, seconds):
-    """Same oracle loop on every host core the process may use (one group of streams per thread)."""
-    import oracle
-    oracle.build()
-    L = oracle.lib()
-    L.orc_bench_resample_mt.restype = C.c_double
-    L.orc_bench_resample_mt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_int16), C.c_int,
-                                        C.POINTER(C.c_longlong)]
+def _host_cores():
+    """threads the process may really use: affinity mask, clipped by the cgroup CPU quota"""
     try:
         ncores = len(os.sched_getaffinity(0))
     except Exception:
@@ -526,18 +632,32 @@ def cpu_baseline_resample_all_cores(nstreams, seconds):
             continue
     if quota:  # a container may see every host CPU and still be allowed only a few cores' worth of time
         ncores = max(1, min(ncores, int(quota + 0.5)))
-    ncores = max(1, min(ncores, nstreams))
-    x = synth_pcm_batch(nstreams, 160, 16000)
-    xp = x.ctypes.data_as(C.POINTER(C.c_int16))
-    L.orc_bench_resample_mt(nstreams, 160, 4, 16000, 48000, xp, ncores, None)  # cold pass: page-in, first touch
-    t = L.orc_bench_resample_mt(nstreams, 160, 16, 16000, 48000, xp, ncores, None)
-    nticks = max(16, int(seconds / (t / 16)))
-    t = L.orc_bench_resample_mt(nstreams, 160, nticks, 16000, 48000, xp, ncores, None)
-    return {"value": round(nstreams * nticks / t / TICKS_PER_S, 1),
-            "unit": "concurrent 48 kHz streams (10 ms ticks in real time)", "cores": ncores, "kind": "port",
-            "cgroup_cpu_quota_cores": quota,
-            "sample": f"{nstreams} streams x {nticks} ticks of 160 samples 16k->48k, oracle/resample.c, "
-                      f"{t:.1f} s wall on {ncores} threads"}
+    return ncores, quota
+
+
+def cpu_baseline_chain(seconds, threads=1):
+    """The oracle's CHAIN (CPU restatement of the reference path: one resampler, canceller + post-filter, volume object
+    per call leg, one mixer per conference of 32, driven tick by tick as an MSTicker thread would) on this host's
+    cores: a bounded sample of the headline workload."""
+    import oracle
+    oracle.build()
+    L = oracle.lib()
+    i16p = C.POINTER(C.c_int16)
+    L.orc_bench_chain_mt.restype = C.c_double
+    L.orc_bench_chain_mt.argtypes = [C.c_int] * 4 + [i16p, i16p, C.c_int, C.POINTER(C.c_longlong)]
+    nconf = max(1, threads)
+    mic = synth_pcm_batch(nconf * 32, 160, 16000)
+    ref = synth_pcm_batch(nconf * 32, 480, 48000, seed0=0xFA2, sigma=2000.0)
+    run = lambda nt: L.orc_bench_chain_mt(nconf, 32, nt, 128, mic.ctypes.data_as(i16p), ref.ctypes.data_as(i16p), threads, None)
+    t = run(4)
+    nticks = max(8, int(seconds / (t / 4)))
+    t = run(nticks)
+    per = t / (nconf * 32 * nticks) * threads  # core-seconds per stream-tick
+    return {"value": round(nconf * 32 * nticks / t / TICKS_PER_S, 1),
+            "unit": "concurrent 48 kHz streams (10 ms ticks in real time)", "cores": threads, "kind": "port",
+            "sample": f"{nconf} conference(s) x 32 legs x {nticks} ticks of the chain (resample 16k->48k, MSSpeexEC 128 ms + "
+                      f"post-filter, AGC, 32-party mix), oracle/*.c, {t:.1f} s wall on {threads} of {os.cpu_count()} host CPUs",
+            "us_per_stream_tick_per_core": round(per * 1e6, 2)}
 
 
 def cpu_reference_times():
@@ -588,6 +708,139 @@ def cpu_reference_times():
     return out
 
 
+def init_distributed(torch, rank, world, local):
+    """One process per GPU.  The data path's collective is RCCL (backend "nccl"); there is no fallback: if RCCL cannot
+    be brought up the run fails.  MSMI355X_BENCH_BACKEND=gloo exists only to exercise this control flow on a box with
+    fewer GPUs than ranks (tests), and is named in config.parallelism."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("MSMI355X_BENCH_BACKEND", "nccl")
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        probe = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"all-reduce probe returned {int(probe.item())}, expected {world}")
+    except Exception as e:
+        print(f"bench.py: rank {rank}: {backend} process group failed: {str(e)[:300]}", file=sys.stderr)
+        sys.exit(3)
+    return dist, backend
+
+
+class Headline:
+    """The timed region: K ticks of the chain at `nstreams` legs per GPU."""
+
+    def __init__(self, ms, torch, ctx, nstreams, world, rank, dist, local):
+        self.ms, self.torch, self.ctx, self.world, self.dist = ms, torch, ctx, world, dist
+        self.rig = ChainRig(ms, torch, ctx, nstreams, world=world, rank=rank, nsplit=SPLIT_CONFERENCES if world > 1 else 0)
+        self.exchange = None
+        if world > 1:
+            from mediastreamer2_amd.sharding import PartialSumExchange
+            self.exchange = PartialSumExchange(ctx.stream, local)
+
+    def prepare(self, warmup):
+        rig = self.rig
+        for t in range(max(8, -(-warmup // 8) * 8)):  # whole 8-tick cycles: the FIFO levels return to where they started
+            self.eager_tick(t)
+        self.ctx.sync()
+        if self.world == 1:
+            self.g8 = rig.capture(range(8))
+            self.g8.launch()  # untimed: uploads the graph, 8 more warm ticks
+        else:
+            self.g1 = [rig.capture([t]) for t in range(rig.RING)]
+            self.ctx.capture_begin()
+            rig.finalize()
+            self.gfin = self.ctx.capture_end()
+            for t in range(8):
+                self.graph_tick(t)
+        self.ctx.sync()
+
+    def eager_tick(self, t):
+        self.rig.tick(t)
+        if self.exchange:
+            self.exchange(self.rig.d_sum)
+        self.rig.finalize()
+
+    def graph_tick(self, t):
+        self.g1[t % self.rig.RING].launch()
+        self.exchange(self.rig.d_sum)
+        self.gfin.launch()
+
+    def run(self, steps):
+        """`steps` ticks (a multiple of 8); returns HIP-event ms on the launch stream"""
+        self.ctx.timer_start()
+        if self.world == 1:
+            for _ in range(steps // 8):
+                self.g8.launch()
+        else:
+            for t in range(steps):
+                self.graph_tick(t)
+        return self.ctx.timer_stop()
+
+    def worst_tick(self, nticks=16):
+        per = []
+        if self.world == 1:
+            g1 = [self.rig.capture([t]) for t in range(self.rig.RING)]
+        for t in range(nticks):
+            self.ctx.timer_start()
+            if self.world == 1:
+                g1[t % self.rig.RING].launch()
+            else:
+                self.graph_tick(t)
+            per.append(self.ctx.timer_stop())
+        return max(per), float(np.median(per))
+
+    def allreduce_alone_us(self, reps=200):
+        """the exchange step by itself: event -> all-reduce of the [split conferences][480] int32 sums -> event"""
+        if not self.exchange:
+            return None
+        for _ in range(10):
+            self.exchange(self.rig.d_sum)
+        self.ctx.sync()
+        self.ctx.timer_start()
+        for _ in range(reps):
+            self.exchange(self.rig.d_sum)
+        return self.ctx.timer_stop() * 1e3 / reps
+
+    def check_split_mix(self, rank):
+        """One more tick, then rank 0 gathers every rank's split-conference inputs, mixes the 32 members on ONE GPU
+        (mi_mixer_process) and compares its own local outputs bit for bit."""
+        torch, dist, rig = self.torch, self.dist, self.rig
+        self.eager_tick(0)
+        self.ctx.sync()
+        mine = rig.split_in.contiguous().view(torch.uint8)  # NCCL has no int16: ship bytes
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        torch.cuda.synchronize()
+        ok = 1
+        if rank == 0:
+            full = torch.cat([p.view(torch.int16).view(rig.nsplit, rig.mloc, 480) for p in parts], dim=1).contiguous()
+            mx = self.ms.MixerBatch(self.ctx, rig.nsplit, rig.MEMBERS, 480)
+            ref = torch.zeros_like(full)
+            torch.cuda.synchronize()  # `full` and `ref` were produced on torch's stream, the mixer runs on the context's
+            mx.process(full, out=ref)
+            self.ctx.sync()
+            ok = int(torch.equal(ref[:, :rig.mloc].contiguous(), rig.split_out.contiguous()))
+            mx.close()
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.broadcast(flag, 0)
+        return bool(flag.item())
+
+    def close(self):
+        for g in ("g8", "gfin"):
+            if hasattr(self, g):
+                getattr(self, g).close()
+        for g in getattr(self, "g1", []):
+            g.close()
+        self.rig.close()
+        self.torch.cuda.empty_cache()
+
+
 def main():
     a = parse()
     if not os.path.exists(os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355x.so")):
@@ -601,9 +854,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         # the driver launches N ranks for --gpus N; a bare `--gpus N` without torchrun is a usage error
-        if world == 1 and a.gpus > 1:
-            print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE is {world})", file=sys.stderr)
+        sys.exit(2)
+    if ChainRig.MEMBERS % world:
+        print(f"bench.py: {world} ranks do not divide a 32-party conference", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
@@ -612,35 +867,43 @@ def main():
     if os.environ.get("MSMI355X_BENCH_DEVICE"):
         local = int(os.environ["MSMI355X_BENCH_DEVICE"])
     torch.cuda.set_device(local)
-    dist = None
-    control = None
+    dist, backend = (None, None)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MSMI355X_BENCH_BACKEND", "nccl")
-        # The shards exchange no data: the process group only carries the barriers and the MAX of two scalars.
-        try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-                probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
-            control = backend
-        except Exception as e:  # RCCL unavailable: the timing protocol works over gloo just as well
-            print(f"bench.py: rank {rank}: {backend} control plane failed ({str(e)[:120]}); using gloo", file=sys.stderr)
-            try:
-                dist.destroy_process_group()
-            except Exception:
-                pass
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            control = "gloo"
+        dist, backend = init_distributed(torch, rank, world, local)
 
     ctx = ms.Context(local)
     props = ctx.props()
-    leg = make_resample_leg(ms, torch, ctx, a.streams)
-    graph = leg.run(a.steps, a.warmup, use_graph=not a.no_graph)
+
+    def reduce_scalar(v, op):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return float(t.item())
+
+    # ---- capacity: the largest leg count whose worst tick fits the 10 ms interval (every rank measures its own GPU)
+    sweep = []
+    if a.streams > 0:
+        streams = a.streams // 32 * 32
+    else:
+        streams, sweep = find_capacity(ms, torch, ctx, lo=a.sweep_lo, hi=a.sweep_hi,
+                                       log=(lambda p: print("bench.py: sweep", json.dumps(p), file=sys.stderr, flush=True)) if rank == 0 else None)
+    streams = int(reduce_scalar(float(streams), "MIN"))
+    if streams <= 0:
+        print("bench.py: no stream count fits the 10 ms tick on this device", file=sys.stderr)
+        sys.exit(1)
+
+    # ---- the timed region, at that leg count (stepped down if the deployed tick -- with the exchange at N > 1 -- is late)
+    for attempt in range(4):
+        head = Headline(ms, torch, ctx, streams, world, rank, dist, local)
+        head.prepare(a.warmup)
+        worst, median_single = head.worst_tick()
+        worst = reduce_scalar(worst, "MAX")
+        if worst < 10.0 or a.streams > 0 or streams <= 4096:
+            break
+        head.close()
+        streams -= 2048
+    rig = head.rig
 
     def sync_local():
         ctx.sync()
@@ -650,56 +913,119 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # K steps bracketed by (synchronize + barrier) on both sides.  The clock stops after this rank's own
-    # synchronize and before the closing barrier: the MAX over ranks below is the slowest rank's K steps, and
-    # the barrier's own latency (tens of microseconds against a 7 microsecond step) stays out of every rank's time.
+    # K steps bracketed by (synchronize + barrier) on both sides.  A step is one 10 ms tick of every leg; the steps are
+    # whole 8-tick cycles (15 canceller frames per leg) and at least --min-timed-s seconds, whatever --steps says.
+    ctx.timer_start()
+    head.run(8)
+    est = ctx.timer_stop() / 8
+    steps = -(-max(a.steps, int(np.ceil(a.min_timed_s * 1e3 / max(est, 1e-3)))) // 8) * 8
+    if dist is not None:
+        steps = int(reduce_scalar(float(steps), "MAX"))
     sync_local()
     barrier()
     t0 = time.perf_counter()
-    ev_ms = leg.timed(a.steps, graph)
+    ev_ms = head.run(steps)
     sync_local()
     dt = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        tt = torch.tensor([dt, ev_ms], dtype=torch.float64, device="cuda" if control == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ev_ms_max = float(tt[0]), float(tt[1])
-    else:
-        ev_ms_max = ev_ms
+    dt = reduce_scalar(dt, "MAX")
+    ev_ms = reduce_scalar(ev_ms, "MAX")
 
-    total_streams = a.streams * world
-    stream_ticks_per_s = total_streams * a.steps / dt
+    total_streams = int(reduce_scalar(float(rig.n), "SUM"))
+    tick_ms = dt / steps * 1e3
+    fits = worst < 10.0
+    ar_us = head.allreduce_alone_us() if world > 1 else None
+    split_ok = head.check_split_mix(rank) if world > 1 else None
+    overflows = rig.overflows()
+    n_local, nconf_local, state_bytes = rig.n, rig.nconf, rig.state_bytes()
+    if world > 1 and not split_ok:
+        print("bench.py: the split conferences' all-reduced mix differs from the single-GPU mix", file=sys.stderr)
+        sys.exit(4)
+
+    parallelism = "1 GPU"
+    if world > 1:
+        parallelism = (f"{world} ranks, one per GPU; legs and whole conferences sharded statically (no collective), "
+                       f"{SPLIT_CONFERENCES} conferences split over all ranks: int32 partial sums -> {backend} "
+                       f"all-reduce ({'RCCL over xGMI' if backend == 'nccl' else 'TEST BACKEND, not RCCL'}) -> finalize, every tick")
     line = {
         "metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale",
-        "value": round(stream_ticks_per_s / TICKS_PER_S, 1),
-        "unit": "concurrent 48 kHz streams (10 ms ticks sustained in real time)",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 6),
+        "value": total_streams if fits else 0,
+        "unit": "concurrent 48 kHz streams (resample + AEC + AGC + 32-party mix every 10 ms tick, worst tick < 10 ms)",
+        "n_gpus": world, "steps": steps, "steps_requested": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(tick_ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: 4096 concurrent mono streams/GPU, MSResample polyphase 16k->48k, "
-                               "one 10 ms tick per step",
-                   "streams_per_gpu": a.streams, "in_samples": 160, "out_samples": 480,
-                   "tick_ms": 10, "tick_budget_used": round(dt / a.steps / 0.010, 6),
-                   "launch": "eager" if a.no_graph else "hipGraph replay of K ticks",
-                   "ring_ticks": leg.ring, "parallelism": f"{world} independent stream shards" + (f", {control} barriers only" if control else ""),
-                   "device": props["name"], "cu_count": props["cu_count"]},
-        "roofline": roofline(ev_ms_max, a.steps, leg.alg_bytes, pmc_traffic("resample_up_kernel")),
+        "config": {"workload": "north_star chain per call leg and 10 ms tick: " + CHAIN_DESC + "; configs[2]'s canceller "
+                               "geometry (48 kHz, 128 ms tail, post-filter) fed by configs[1]'s resampler and mixed as configs[3]",
+                   "value_definition": "largest leg count (capacity sweep, step 2048) whose WORST single tick stays under the "
+                                       "10 ms MSTicker interval; ms_per_step = average tick over the timed region at that count",
+                   "streams_per_gpu": n_local, "conferences_per_gpu": nconf_local + (SPLIT_CONFERENCES if world > 1 else 0),
+                   "tick_ms": 10, "worst_tick_ms": round(worst, 4), "single_tick_median_ms": round(median_single, 4),
+                   "fits": bool(fits), "tick_budget_used": round(tick_ms / 10.0, 4),
+                   "rate_equivalent_streams": int(total_streams * 10.0 / tick_ms),
+                   "fifo_overflows": int(overflows), "aec_resident_state_bytes_per_gpu": state_bytes,
+                   "working_set_note": "every tick streams the cancellers' resident state (far larger than the 256 MiB "
+                                       "Infinity Cache); the input ring is 4 ticks",
+                   "launch": "hipGraph of 8 ticks replayed" if world == 1 else "hipGraph per tick + all-reduce + finalize graph",
+                   "parallelism": parallelism, "device": props["name"], "cu_count": props["cu_count"]},
     }
-    line["roofline"]["kernel"] = leg.name
-    tf_ = leg.valu_flop / (ev_ms_max * 1e-3 / a.steps) / 1e12
-    line["roofline"]["valu"] = {"flop_per_launch": int(leg.valu_flop), "achieved_tflops": round(tf_, 2),
-                                leg.valu_peak_name: round(leg.valu_peak_tflops, 1), "frac": round(tf_ / leg.valu_peak_tflops, 3)}
-    line["roofline"]["note"] = ("configs[1] is a %.1f MB tick: %.2f us of HBM time at peak against a ~1.9 us empty-kernel floor for this grid, "
-                                "so the launch is latency-bound; the same kernel on a deployment-sized batch is other_kernels[0]"
-                                % (leg.alg_bytes / 1e6, leg.alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e6))
+    if sweep and rank == 0:
+        line["config"]["capacity_sweep"] = [{k: p.get(k) for k in ("streams", "tick_ms_avg", "tick_ms_worst", "fits", "error") if k in p}
+                                            for p in sweep]
+    if world > 1:
+        line["config"]["split_conferences"] = {"count": SPLIT_CONFERENCES, "members_per_rank": rig.mloc,
+                                               "allreduce_bytes_per_tick": SPLIT_CONFERENCES * 480 * 4,
+                                               "allreduce_alone_us": round(ar_us, 2) if ar_us else None,
+                                               "mix_bit_exact_vs_single_gpu": bool(split_ok), "backend": backend}
+    head.close()
+
+    # ---- roofline of the dominant kernel pair, live HIP events on the launch stream: the canceller + post-filter on
+    # their own at the headline's leg count (one launch = one 256-sample frame of every leg), and the tick as a whole
+    if rank == 0:
+        try:
+            lg = make_aec_leg(ms, torch, ctx, n_local)
+            rounds = 16
+            g = lg.run(rounds, 4)
+            ctx.sync()
+            one = lg.timed(rounds, g)
+            reps = max(1, int(np.ceil(0.3e3 / max(one, 1e-3))))
+            ctx.timer_start()
+            for _ in range(reps):
+                g.launch()
+            ms_round = ctx.timer_stop() / (reps * rounds)
+            per_frame = pmc_traffic(lg.name)
+            r = roofline(ms_round, 1, lg.alg_bytes, int(per_frame / 4096 * n_local) if per_frame else None)
+            r["kernel"] = lg.name
+            r["units_per_launch"] = f"{n_local} stream-frames (256 samples; 48 kHz, 128 ms tail, post-filter on)"
+            r["timed_launches"] = reps * rounds
+            r["traffic_source"] = ("profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a 4096-frame launch, "
+                                   "scaled to this launch's frame count (not measured by this run)")
+            del lg, g
+            torch.cuda.empty_cache()
+        except Exception as e:
+            r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "error": str(e)[:200]}
+        tick_alg = n_local * (AEC_FRAMES_PER_TICK * AEC_FRAME_BYTES + 1280 + 1920 + 1920)
+        r["tick"] = {"algorithmic_bytes_per_tick": int(tick_alg), "achieved": round(tick_alg / (ev_ms * 1e-3 / steps) / 1e9, 2),
+                     "frac": round(tick_alg / (ev_ms * 1e-3 / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "whole tick of the chain over the timed region: 1.875 canceller frames + resampler 1280 B + volume 1920 B + "
+                             "mixer 1920 B per leg, HIP events on the launch stream"}
+        r["mfma"] = ("not used: the one candidate, the scaler's 3x3 BT.601 colour matrix, is 9 integer MACs per pixel inside a "
+                     "byte-streaming kernel at ~80 % of the measured copy ceiling; v_mfma_f32_16x16x4 would use 3 of 16 columns")
+        line["roofline"] = r
 
     if rank == 0 and world == 1:
         if not a.no_extras:
             extras = []
-            ksteps = max(20, min(a.steps, 100))
+            ksteps = 100
+
+            def make_resample_4096(ms_, torch_, ctx_):  # BASELINE configs[1]
+                return make_resample_leg(ms_, torch_, ctx_, 4096)
+
             def make_resample_65536(ms_, torch_, ctx_):  # same kernel, a deployment-sized batch
                 return make_resample_leg(ms_, torch_, ctx_, 65536)
+
+            def make_aec_4096(ms_, torch_, ctx_):  # BASELINE configs[2]
+                return make_aec_leg(ms_, torch_, ctx_, 4096)
 
             def make_mixer_1024(ms_, torch_, ctx_):  # BASELINE configs[3] at its full size: 1024 conferences x 32 members
                 return make_mixer_leg(ms_, torch_, ctx_, nconf=1024)
@@ -710,8 +1036,9 @@ def main():
             def make_g711_encode(ms_, torch_, ctx_):
                 return make_g711_leg(ms_, torch_, ctx_, encode=True)
 
-            for mk in (make_resample_65536, make_mixer_leg, make_mixer_1024, make_volume_leg, make_equalizer_leg, make_aec_leg,
-                       make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
+            no_pmc = (make_resample_65536, make_mixer_1024, make_scaler_i420)
+            for mk in (make_resample_4096, make_resample_65536, make_mixer_leg, make_mixer_1024, make_volume_leg, make_equalizer_leg,
+                       make_aec_4096, make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
@@ -719,9 +1046,8 @@ def main():
                     reps = [lg.timed(ksteps, g) for _ in range(7)]
                     ms_ = min(reps)  # per-kernel table: best replay; the spread goes into `replay_stats_us`
                     ctx.sync()
-                    # the PMC summary was taken at the bench sizes; the 65536-stream row has no counter pass
-                    r = roofline(ms_, ksteps, lg.alg_bytes,
-                                 None if mk in (make_resample_65536, make_mixer_1024, make_scaler_i420) else pmc_traffic(lg.name))
+                    r = roofline(ms_, ksteps, lg.alg_bytes, None if mk in no_pmc else pmc_traffic(lg.name))
+                    r["traffic_source"] = None if r["traffic"] is None else "profiles/pmc_summary.json"
                     r["kernel"] = lg.name
                     r["units_per_launch"] = f"{lg.units} {lg.unit_name}"
                     per = np.array(reps) * 1e3 / ksteps  # the reference's profiler prints count/min/mean/max/sd per filter
@@ -730,7 +1056,6 @@ def main():
                                             "sd": round(float(per.std()), 3)}  # (src/base/msfactory.c ms_factory_log_statistics)
                     if hasattr(lg, "state_bytes"):
                         r["resident_state_bytes"] = int(lg.state_bytes)
-                        r["streams_per_10ms_tick_at_this_rate"] = int(lg.units * 0.010 / (ms_ * 1e-3 / ksteps) / 1.875)
                     if hasattr(lg, "valu_flop"):
                         tf = lg.valu_flop / (ms_ * 1e-3 / ksteps) / 1e12
                         r["valu"] = {"flop_per_launch": int(lg.valu_flop), "achieved_tflops": round(tf, 2),
@@ -738,6 +1063,10 @@ def main():
                                      "frac": round(tf / lg.valu_peak_tflops, 3)}
                     if hasattr(lg, "mpix_in"):
                         r["mpix_per_s_in"] = round(lg.mpix_in / (ms_ * 1e-3 / ksteps), 1)
+                        if mk is make_scaler_leg:  # the metric's second half: 1080p I420 -> 720p RGB24 (configs[4])
+                            line["scaler_mpix_per_s"] = {"value": r["mpix_per_s_in"], "unit": "Mpix/s of 1080p input, YUV420 -> RGB24 + bilinear 720p",
+                                                         "frames_per_s": round(lg.units / (ms_ * 1e-3 / ksteps), 1),
+                                                         "hbm_frac": r["frac"], "streams_1080p30": int(lg.units / (ms_ * 1e-3 / ksteps) / 30)}
                     extras.append(r)
                     del lg, g
                     torch.cuda.empty_cache()
@@ -746,25 +1075,20 @@ def main():
             line["other_kernels"] = extras
             try:
                 line["roofline"]["measured_copy_GBps"] = copy_ceiling(torch)
-            except Exception as e:
+            except Exception:
                 line["roofline"]["measured_copy_GBps"] = None
-            if a.pipeline_streams > 0:
-                try:
-                    line["pipeline"] = pipeline_probe(ms, torch, ctx, a.pipeline_streams)
-                except Exception as e:
-                    line["pipeline"] = {"error": str(e)[:200]}
-                try:
-                    line["session_pcie_inclusive"] = session_probe(ms, ctx, a.pipeline_streams)
-                except Exception as e:
-                    line["session_pcie_inclusive"] = {"error": str(e)[:200]}
-                try:
-                    line["session_trunk_g711"] = session_probe(ms, ctx, a.pipeline_streams, trunk=True)
-                except Exception as e:
-                    line["session_trunk_g711"] = {"error": str(e)[:200]}
+            if not a.no_session:
+                for key, kw in (("session_pcie_inclusive", {}), ("session_trunk_g711", {"trunk": True})):
+                    try:
+                        line[key] = session_probe(ms, ctx, n_local, **kw)
+                    except Exception as e:
+                        line[key] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_resample(a.streams, a.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline_chain(a.cpu_seconds, threads=1)
             try:
-                line["cpu_baseline_all_cores"] = cpu_baseline_resample_all_cores(a.streams, min(a.cpu_seconds, 5.0))
+                ncores, quota = _host_cores()
+                line["cpu_baseline_all_cores"] = cpu_baseline_chain(min(a.cpu_seconds, 8.0), threads=ncores)
+                line["cpu_baseline_all_cores"]["cgroup_cpu_quota_cores"] = quota
             except Exception as e:
                 line["cpu_baseline_all_cores"] = {"error": str(e)[:200]}
             if not a.no_extras:

@@ -40,10 +40,53 @@ def place_conferences(n_conf: int, members: int, world: int, rank: int,
 
 
 def allreduce_partial_sums(partial, group=None):
-    """In-place int32 SUM all-reduce of the partial mixes of the split conferences."""
+    """In-place int32 SUM all-reduce of the partial mixes of the split conferences (host tensors, or device tensors
+    whose producer and consumer run on torch's current stream)."""
     import torch
     import torch.distributed as dist
     assert partial.dtype == torch.int32
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
     return partial
+
+
+def split_members(members: int, world: int, rank: int):
+    """Member range [lo, hi) of every split conference this rank holds (equal shares; `world` must divide `members`)."""
+    if members % world:
+        raise ValueError(f"{members} members do not split evenly over {world} ranks")
+    per = members // world
+    return rank * per, (rank + 1) * per
+
+
+class PartialSumExchange:
+    """The conference mixer's one exchange step on the device: `mi_mixer_partial_sum` (enqueued on the kernel
+    library's stream) -> int32 SUM all-reduce (RCCL over xGMI with backend "nccl") -> `mi_mixer_finalize` (same
+    stream again).  The kernels run on the mi_ctx stream, the collective on a stream of its own; the two are ordered
+    by an explicit event in each direction, recorded and waited on the device -- the host never blocks.
+
+        ex = PartialSumExchange(ctx.stream, device)
+        mixer.partial_sum(x, d_sum); ex(d_sum); mixer.finalize(x, d_sum, out)
+    """
+
+    def __init__(self, ctx_stream_handle, device, group=None):
+        import torch
+        self.group = group
+        self.device = torch.device("cuda", device) if isinstance(device, int) else device
+        self.kernel_stream = torch.cuda.ExternalStream(int(ctx_stream_handle), device=self.device)
+        self.coll_stream = torch.cuda.Stream(device=self.device)
+        self.produced = torch.cuda.Event()
+        self.reduced = torch.cuda.Event()
+
+    def __call__(self, partial):
+        import torch
+        import torch.distributed as dist
+        assert partial.dtype == torch.int32 and partial.is_cuda and partial.is_contiguous()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return partial
+        self.produced.record(self.kernel_stream)      # the partial sums are complete on the kernel stream
+        self.coll_stream.wait_event(self.produced)
+        with torch.cuda.stream(self.coll_stream):
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group)
+        self.reduced.record(self.coll_stream)         # the totals are in place
+        self.kernel_stream.wait_event(self.reduced)   # mi_mixer_finalize may follow on the kernel stream
+        return partial

@@ -259,3 +259,135 @@ double orc_bench_g711_encode(unsigned char (*fn)(short), const int16_t *pcm, siz
 	if (sink) *sink = acc;
 	return t1 - t0;
 }
+
+/* ---- the north_star chain on the CPU: what one MSTicker thread does per 10 ms tick for a group of conferences.
+ * Per call leg: MSResample 16k -> 48k (msresample.c:122-179) -> MSSpeexEC at 48 kHz (256-sample frames through the
+ * filter's bufferizers, zero reference when the far end is short: speexec.c:223-305; canceller + post-filter) ->
+ * MSVolume with AGC on 10 ms chunks (msvolume.c:471-514); per conference of `members` legs: MSAudioMixer in conference
+ * mode (audiomixer.c:288-346).  mic16 [nstreams][160] and ref48 [nstreams][480] are reused every tick. */
+typedef struct {
+	int first_conf, nconf, members, nticks, tail_ms;
+	const int16_t *mic16, *ref48;
+	pthread_barrier_t *bar;
+	long long acc;
+	double t0, t1;
+} ChainJob;
+
+typedef struct {
+	int16_t buf[2048];
+	int n;
+} ChainFifo;
+
+static void cf_push(ChainFifo *f, const int16_t *x, int n) {
+	if (f->n + n > 2048) return;
+	memcpy(f->buf + f->n, x, sizeof(int16_t) * (size_t)n);
+	f->n += n;
+}
+static int cf_pop(ChainFifo *f, int16_t *x, int n) { /* all-or-nothing, msqueue.c:83 */
+	if (f->n < n) return 0;
+	memcpy(x, f->buf, sizeof(int16_t) * (size_t)n);
+	f->n -= n;
+	memmove(f->buf, f->buf + n, sizeof(int16_t) * (size_t)f->n);
+	return 1;
+}
+
+static void *chain_worker(void *arg) {
+	ChainJob *j = (ChainJob *)arg;
+	const int rate = 48000, F = 256, ns = 480, mm = j->members;
+	const int nst = j->nconf * mm;
+	OrcResampler **rs = (OrcResampler **)malloc(sizeof(*rs) * (size_t)(nst > 0 ? nst : 1));
+	OrcEcho **ec = (OrcEcho **)malloc(sizeof(*ec) * (size_t)(nst > 0 ? nst : 1));
+	OrcPreproc **pp = (OrcPreproc **)malloc(sizeof(*pp) * (size_t)(nst > 0 ? nst : 1));
+	OrcVolume *vol = (OrcVolume *)malloc(sizeof(OrcVolume) * (size_t)(nst > 0 ? nst : 1));
+	ChainFifo *fm = (ChainFifo *)calloc((size_t)(nst > 0 ? nst : 1), sizeof(ChainFifo));
+	ChainFifo *fr = (ChainFifo *)calloc((size_t)(nst > 0 ? nst : 1), sizeof(ChainFifo));
+	ChainFifo *fo = (ChainFifo *)calloc((size_t)(nst > 0 ? nst : 1), sizeof(ChainFifo));
+	int16_t *tick = (int16_t *)malloc(sizeof(int16_t) * (size_t)mm * ns);
+	int16_t *mixed = (int16_t *)malloc(sizeof(int16_t) * (size_t)mm * ns);
+	uint8_t *ones = (uint8_t *)malloc((size_t)mm);
+	float *gain = (float *)malloc(sizeof(float) * (size_t)mm);
+	int16_t up[488], mf[256], rf[256], cl[256];
+	long long acc = 0;
+	int s, t, c, m;
+	for (m = 0; m < mm; ++m) ones[m] = 1, gain[m] = 1.0f;
+	for (s = 0; s < nst; ++s) {
+		rs[s] = orc_resampler_new(16000, (uint32_t)rate, 3);
+		ec[s] = orc_echo_new(F, j->tail_ms * rate / 1000, rate);
+		pp[s] = orc_preproc_new(F, rate, ec[s]);
+		orc_volume_init(&vol[s]);
+		orc_volume_set_rate(&vol[s], rate);
+		vol[s].agc_enabled = 1;
+	}
+	pthread_barrier_wait(j->bar);
+	j->t0 = now_s();
+	for (t = 0; t < j->nticks; ++t)
+		for (c = 0; c < j->nconf; ++c) {
+			for (m = 0; m < mm; ++m) {
+				const int ls = c * mm + m;
+				const size_t gs = (size_t)(j->first_conf + c) * mm + m;
+				uint32_t il = 160, ol = 488;
+				orc_resampler_process(rs[ls], j->mic16 + gs * 160, &il, up, &ol);
+				cf_push(&fm[ls], up, (int)ol);
+				cf_push(&fr[ls], j->ref48 + gs * ns, ns);
+				while (cf_pop(&fm[ls], mf, F)) {
+					if (!cf_pop(&fr[ls], rf, F)) memset(rf, 0, sizeof(rf)); /* speexec.c:261-272 */
+					orc_echo_cancel(ec[ls], mf, rf, cl);
+					orc_preproc_run(pp[ls], cl);
+					cf_push(&fo[ls], cl, F);
+				}
+				if (!cf_pop(&fo[ls], tick + (size_t)m * ns, ns)) memset(tick + (size_t)m * ns, 0, sizeof(int16_t) * ns);
+				orc_volume_chunk(&vol[ls], tick + (size_t)m * ns, ns, 0.f);
+			}
+			orc_mixer_tick(tick, ones, gain, ones, ones, mm, ns, 1, mixed, NULL);
+			acc += mixed[ns / 2];
+		}
+	j->t1 = now_s();
+	j->acc = acc;
+	for (s = 0; s < nst; ++s) {
+		orc_preproc_free(pp[s]);
+		orc_echo_free(ec[s]);
+		orc_resampler_free(rs[s]);
+	}
+	free(rs), free(ec), free(pp), free(vol), free(fm), free(fr), free(fo), free(tick), free(mixed), free(ones), free(gain);
+	return NULL;
+}
+
+/* nconf conferences of `members` legs for nticks ticks on nthreads threads (whole conferences per thread).
+ * Returns the wall time from the first thread's start to the last thread's end. */
+double orc_bench_chain_mt(int nconf, int members, int nticks, int tail_ms, const int16_t *mic16, const int16_t *ref48,
+                          int nthreads, long long *sink) {
+	pthread_t *th;
+	ChainJob *jobs;
+	pthread_barrier_t bar;
+	double t0 = 1e300, t1 = 0;
+	long long acc = 0;
+	int i;
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > nconf) nthreads = nconf;
+	th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+	jobs = (ChainJob *)calloc((size_t)nthreads, sizeof(ChainJob));
+	pthread_barrier_init(&bar, NULL, (unsigned)nthreads);
+	for (i = 0; i < nthreads; ++i) {
+		const int lo = (int)((long long)nconf * i / nthreads), hi = (int)((long long)nconf * (i + 1) / nthreads);
+		jobs[i].first_conf = lo;
+		jobs[i].nconf = hi - lo;
+		jobs[i].members = members;
+		jobs[i].nticks = nticks;
+		jobs[i].tail_ms = tail_ms;
+		jobs[i].mic16 = mic16;
+		jobs[i].ref48 = ref48;
+		jobs[i].bar = &bar;
+		pthread_create(&th[i], NULL, chain_worker, &jobs[i]);
+	}
+	for (i = 0; i < nthreads; ++i) {
+		pthread_join(th[i], NULL);
+		if (jobs[i].t0 < t0) t0 = jobs[i].t0;
+		if (jobs[i].t1 > t1) t1 = jobs[i].t1;
+		acc += jobs[i].acc;
+	}
+	pthread_barrier_destroy(&bar);
+	free(th);
+	free(jobs);
+	if (sink) *sink = acc;
+	return t1 - t0;
+}
