@@ -385,8 +385,7 @@ class ChainRig:
     (tests/test_gpu_pipeline.py checks the same chain stage by stage against the oracle).  One tick() = one 10 ms
     MSTicker interval (src/base/msticker.c:46) of every leg:
       MSResample 16k->48k (msresample.c:122-179) -> device FIFO -> MSSpeexEC at 256-sample frames, 128 ms tail,
-      canceller + post-filter (speexec.c:171-180,223-305; two frame rounds per tick, the second one masked off by the
-      FIFO level in one tick out of eight) -> device FIFO -> MSVolume with AGC (msvolume.c:471-514) -> MSAudioMixer,
+      canceller + post-filter (speexec.c:171-180,223-305; one launch per tick for the one or two frames a leg has ready) -> device FIFO -> MSVolume with AGC (msvolume.c:471-514) -> MSAudioMixer,
       conferences of 32 (audiomixer.c:288-346).
     With world > 1 the last `nsplit` conferences of every rank are SPLIT ones: their 32 members are spread over all
     ranks (32 / world local members each), the rank computes int32 partial sums (mi_mixer_partial_sum), the caller
@@ -422,12 +421,9 @@ class ChainRig:
         self.d_ref = [spread(ref48, r, 480) for r in range(ring)]
         z = lambda *shape, dt=torch.int16: torch.zeros(shape, dtype=dt, device="cuda")
         self.up = z(n, 488)
-        # one set of frame buffers per canceller round of a tick: the join of a round is deferred (mi_session does the
-        # same), so its trailing post-filter runs next to the next round's canceller
-        self.micf = [z(n, F) for _ in range(2)]
-        self.reff = [z(n, F) for _ in range(2)]
-        self.clean = [z(n, F) for _ in range(2)]
-        self.okm = [z(n, dt=torch.uint8) for _ in range(2)]
+        # the canceller's frames of a tick (one or two per leg: 15 frames per 8 ticks), back to back in one row per leg
+        self.micf, self.reff, self.clean = z(n, 2 * F), z(n, 2 * F), z(n, 2 * F)
+        self.cnt = z(n, dt=torch.uint8)
         self.tick_buf = z(n, 480)
         self.mixed = z(n, 480)
         nw = self.nconf * mm
@@ -445,15 +441,10 @@ class ChainRig:
         self.rs.process(self.d_mic[t % self.RING], out=self.up)
         self.f_mic.push(self.up, nsamples=480)
         self.f_ref.push(self.d_ref[t % self.RING])
-        for r in range(2):
-            self.f_mic.pop(F, self.micf[r], ok=self.okm[r], zero_fill=False)
-            self.f_ref.pop(F, self.reff[r], gate=self.okm[r], zero_fill=True)
-        for r in range(2):
-            self.aec.process(self.micf[r], self.reff[r], out=self.clean[r], run=self.okm[r],
-                             flags=ms.MI_AEC_POSTFILTER | ms.MI_AEC_DEFER_JOIN)
-        self.aec.join()
-        for r in range(2):
-            self.f_out.push(self.clean[r], gate=self.okm[r])
+        self.f_mic.pop_frames(F, 2, self.micf, nframes_out=self.cnt)          # the while loop of speexec.c:256, whole tick
+        self.f_ref.pop_frames(F, 2, self.reff, wanted=self.cnt, zero_fill=True)  # short far end: silence, speexec.c:261-272
+        self.aec.process_frames(self.micf, self.reff, self.clean, self.cnt, max_frames=2, flags=ms.MI_AEC_POSTFILTER)
+        self.f_out.push_frames(self.clean, F, 2, self.cnt)
         self.f_out.pop(480, self.tick_buf, zero_fill=True)
         self.vol.process(self.tick_buf)
         self.mix.process(self.whole_in, out=self.whole_out)

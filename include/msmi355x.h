@@ -240,6 +240,14 @@ int mi_aec_reset(mi_aec *a, int first, int count);
                              * post-filter of this call run next to the first chunk's canceller of the next call */
 int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
                    const uint8_t *d_run, unsigned flags);
+/* The frames of one TICK in one launch (the form the chained path uses): row s of d_mic / d_ref / d_out holds up to
+ * max_frames frames back to back (stride >= max_frames * frame_size), d_count[s] (0 .. max_frames) says how many the
+ * stream has ready -- at 48 kHz the filter's 256-sample frames make that one or two per 10 ms tick (speexec.c:256 runs
+ * its while loop that often).  Results equal d_count[s] consecutive mi_aec_process calls; the per-stream state crosses
+ * HBM once per tick instead of once per frame and the foreground filter is streamed once for both frames. */
+#define MI_AEC_MAX_TICK_FRAMES 2
+int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
+                          const uint8_t *d_count, int max_frames, unsigned flags);
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
                         const uint8_t *h_run, unsigned flags);
 /* state bytes per stream (for DESIGN/roofline accounting) */
@@ -298,6 +306,16 @@ int mi_fifo_push_gated(mi_fifo *f, const int16_t *d_in, int nsamples, int stride
  * gate is given) get them in row s of d_out and d_ok[s] = 1; the others keep their samples, d_ok[s] = 0 and, if
  * zero_fill, a row of zeros (the silence the filters inject: speexec.c:261-272, audiomixer.c:88). */
 int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok, const uint8_t *d_gate, int zero_fill);
+/* A whole tick's frames in one launch (the `while` of speex_ec_process, speexec.c:256): up to max_frames frames of
+ * `frame` samples, back to back in row s of d_out (stride >= frame * max_frames).
+ *  - d_nframes_wanted == NULL: every stream delivers the whole frames it holds (<= max_frames); d_nframes_out[s] says
+ *    how many -- the per-stream count mi_aec_process_frames takes;
+ *  - d_nframes_wanted != NULL: stream s is asked for that many frames; frames it cannot supply are zero-filled when
+ *    zero_fill is set (speexec.c:261-272), d_nframes_out (nullable) reports the frames really popped. */
+int mi_fifo_pop_frames(mi_fifo *f, int frame, int max_frames, int16_t *d_out, int stride, uint8_t *d_nframes_out,
+                       const uint8_t *d_nframes_wanted, int zero_fill);
+/* d_nframes[s] * frame samples of row s are appended (0 = nothing for that stream) */
+int mi_fifo_push_frames(mi_fifo *f, const int16_t *d_in, int frame, int max_frames, int stride, const uint8_t *d_nframes);
 int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, in samples */
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_reset(mi_fifo *f);

@@ -369,6 +369,13 @@ class AecBatch(_Batch):
         return out
 
 
+    def process_frames(self, mic, ref, out, count, max_frames=2, flags=MI_AEC_POSTFILTER):
+        """The frames of one tick in one launch: rows of mic / ref / out hold up to max_frames frames back to back,
+        count [nstreams] uint8 (device) = frames ready per stream.  Device tensors only."""
+        check(self.ctx.L.mi_aec_process_frames(self.h, _ptr(mic), _ptr(ref), _ptr(out), mic.stride(0), _ptr(count), max_frames, flags))
+        return out
+
+
 class ScalerBatch(_Batch):
     """MSScalerDesc context (msvideo.h:473-478) for a batch of I420 frames."""
     _destroy = "mi_scaler_destroy"
@@ -458,6 +465,15 @@ class FifoBatch(_Batch):
     def pop(self, frame, out, ok=None, gate=None, zero_fill=True):
         check(self.ctx.L.mi_fifo_pop(self.h, frame, _ptr(out), out.stride(0), _ptr(ok), _ptr(gate), 1 if zero_fill else 0))
         return out
+
+    def pop_frames(self, frame, max_frames, out, nframes_out=None, wanted=None, zero_fill=True):
+        """up to max_frames whole frames per stream, back to back in out's rows; see mi_fifo_pop_frames"""
+        check(self.ctx.L.mi_fifo_pop_frames(self.h, frame, max_frames, _ptr(out), out.stride(0), _ptr(nframes_out), _ptr(wanted),
+                                            1 if zero_fill else 0))
+        return out
+
+    def push_frames(self, x, frame, max_frames, nframes):
+        check(self.ctx.L.mi_fifo_push_frames(self.h, _ptr(x), frame, max_frames, x.stride(0), _ptr(nframes)))
 
     def levels(self, out):
         check(self.ctx.L.mi_fifo_levels(self.h, _ptr(out)))

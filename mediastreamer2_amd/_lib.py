@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
-    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process",
+    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames",
     "mi_aec_process_host", "mi_aec_set_overlap", "mi_aec_join", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
@@ -50,7 +50,7 @@ EXPORTS = [
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
     "mi_plc_create", "mi_plc_destroy", "mi_plc_reset", "mi_plc_process", "mi_plc_info",
-    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
 ]
 
 
@@ -180,6 +180,7 @@ def load():
         L.mi_aec_reset.argtypes = [vp, i32, i32]
         L.mi_aec_process.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_process_host.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
+        L.mi_aec_process_frames.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_uint]
         L.mi_aec_set_overlap.argtypes = [vp, i32]
         L.mi_aec_join.argtypes = [vp]
         L.mi_aec_state_bytes.argtypes = [vp]
@@ -223,6 +224,8 @@ def load():
         L.mi_fifo_push.argtypes = [vp, vp, i32, i32, vp]
         L.mi_fifo_push_gated.argtypes = [vp, vp, i32, i32, vp]
         L.mi_fifo_pop.argtypes = [vp, i32, vp, i32, vp, vp, i32]
+        L.mi_fifo_pop_frames.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32]
+        L.mi_fifo_push_frames.argtypes = [vp, vp, i32, i32, i32, vp]
         L.mi_fifo_levels.argtypes = [vp, vp]
         L.mi_fifo_overflows.argtypes = [vp, C.POINTER(i32)]
         L.mi_fifo_reset.argtypes = [vp]

@@ -66,13 +66,19 @@ struct AecScalars {
 	float memX, memD, memE, notch0, notch1;
 	int adapted, saturated, screwed_up, cancel_count, xhead;
 	int nb_adapt, min_count;
+	int ly_slot;     // newest slot of the echo-estimate ring (TickLayout::LASTY)
+	int tick_frames; // frames the canceller ran in its last launch (the post-filter of that tick reads it)
+	float leak0;     // leak estimate after the first frame of that launch
+	int pad_;
 };
-static_assert(sizeof(AecScalars) == 80, "scalar record");
+static_assert(sizeof(AecScalars) == 96, "scalar record");
 
 struct AecArgs {
 	const int16_t *mic, *ref;
 	int16_t *out;
-	const uint8_t *run;
+	const uint8_t *run;   // per-frame entry: 0 = the stream has no frame this call
+	const uint8_t *count; // per-tick entry: frames ready for the stream (0 .. max_frames), rows hold them back to back
+	int max_frames;
 	int stride, nstreams, M, flags;
 	int first;             // first stream of this launch (a launch may cover a chunk of the batch)
 	float *X, *W, *FG;     // [nstreams][(M+1) or M][N]
@@ -82,31 +88,6 @@ struct AecArgs {
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
 	int sampling_rate;
 	AecTables t;
-};
-
-// offsets (in floats) inside the per-stream small-state block, as multiples of F
-// xprev F | E 2F | power F+1.. (padded to 2F each) ...
-template <int F>
-struct SmallLayout {
-	static constexpr int XPREV = 0;
-	static constexpr int E = F;                 // 2F
-	static constexpr int POWER = 3 * F;         // F+1 (uses 2 slots of F: [0..F) + extra at +F)
-	static constexpr int POWER1 = 5 * F;
-	static constexpr int EH = 7 * F;
-	static constexpr int YH = 9 * F;
-	static constexpr int LASTY = 11 * F;        // 2F
-	static constexpr int PROP = 13 * F;         // M (<= F)
-	static constexpr int WNORM = 14 * F;        // M
-	static constexpr int INBUF = 15 * F;
-	static constexpr int OUTBUF = 16 * F;
-	static constexpr int NOISE = 17 * F;        // F + 24 (2 slots)
-	static constexpr int ECHON = 19 * F;
-	static constexpr int OLDPS = 21 * F;
-	static constexpr int ZETA = 23 * F;
-	static constexpr int S_ = 25 * F;
-	static constexpr int SMIN = 26 * F;
-	static constexpr int STMP = 27 * F;
-	static constexpr int TOTAL = 28 * F;
 };
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
@@ -186,6 +167,7 @@ __device__ __forceinline__ float band_sum(const AecTables &t, int b, const float
 }
 
 #include "aec_wave.hpp"
+#include "aec_tick.hpp"
 
 // ---- debug: forward/inverse transform of one 2F-point frame per block (parity of the FFT itself)
 template <int F>
@@ -208,12 +190,12 @@ __global__ __launch_bounds__(64) void fft_debug_kernel(const float *in, float *o
 		store_vec<K>(L.tbuf + e0, lo);
 		store_vec<K>(L.tbuf + F + e0, hi);
 		float2 r[K];
-		w_rfft_forward<F>(L, r);
+		w_rfft_forward<F>(L, t, r);
 		store_bins<K>(reinterpret_cast<float2 *>(dst) + e0, r);
 	} else {
 		float2 r[K];
 		load_bins<K>(reinterpret_cast<const float2 *>(src) + e0, r);
-		w_rfft_inverse<F>(L, r);
+		w_rfft_inverse<F>(L, t, r);
 		float lo[K], hi[K];
 		load_vec<K>(L.tbuf + e0, lo);
 		load_vec<K>(L.tbuf + F + e0, hi);
@@ -403,14 +385,16 @@ int build_tables(mi_aec *a) {
 
 template <int F>
 int init_state(mi_aec *a, int first, int count) {
-	using SL = SmallLayout<F>;
+	using SL = TickLayout<F>;
 	std::vector<float> small((size_t)a->small_stride, 0.f);
-	for (int i = 0; i <= F; ++i) small[(size_t)SL::POWER1 + i] = 1.0f;
+	for (int i = 0; i < F; ++i) small[(size_t)SL::POWER1 + i] = 1.0f;
+	small[(size_t)SL::TAIL + 1] = 1.0f; // power_1[F]
 	for (int i = 0; i < a->M; ++i) small[(size_t)SL::PROP + i] = a->h_prop0[(size_t)i];
-	for (int i = 0; i < F + NB_BANDS; ++i) {
+	for (int i = 0; i < F; ++i) {
 		small[(size_t)SL::NOISE + i] = 1.f;
 		small[(size_t)SL::OLDPS + i] = 1.f;
 	}
+	for (int i = 0; i < NB_BANDS; ++i) small[(size_t)SL::OLDPS_B + i] = 1.f;
 	AecScalars sc;
 	memset(&sc, 0, sizeof(sc));
 	sc.Pey = sc.Pyy = 1.0f;
@@ -478,7 +462,7 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		}
 		for (int i = M - 1; i >= 0; i--) a->h_prop0[(size_t)i] = (.8f * a->h_prop0[(size_t)i]) / sum;
 	}
-	a->small_stride = 28 * frame_size; // SmallLayout<F>::TOTAL
+	a->small_stride = 19 * frame_size + 192; // TickLayout<F>::TOTAL
 	const size_t wn = (size_t)M * a->N, xn = (size_t)(M + 1) * a->N;
 	int rc = build_tables(a);
 	if (rc != MI_OK) {
@@ -556,15 +540,16 @@ size_t mi_aec_state_bytes(const mi_aec *a) {
 	       sizeof(AecScalars);
 }
 
-int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
-                   const uint8_t *d_run, unsigned flags) {
-	MI_CHECK_ARG(a && d_mic && d_ref && d_out && stride >= a->F);
+static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride, const uint8_t *d_run,
+                      const uint8_t *d_count, int max_frames, unsigned flags) {
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	AecArgs g;
 	g.mic = d_mic;
 	g.ref = d_ref;
 	g.out = d_out;
 	g.run = d_run;
+	g.count = d_count;
+	g.max_frames = max_frames;
 	g.stride = stride;
 	g.nstreams = a->nstreams;
 	g.M = a->M;
@@ -583,23 +568,21 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	g.ss_1 = a->ss_1;
 	g.sampling_rate = a->rate;
 	g.t = a->t;
-	// One wavefront per stream: canceller, then (optionally) the post-filter as its own launch.  At 256-sample frames
-	// the canceller is HBM-bound with the VALUs a third busy and the post-filter VALU-bound with HBM a third busy: a big
-	// batch is cut in two, the cancellers run back to back on the context's stream and the first half's post-filter on a
-	// second stream next to the second half's canceller (65 536 streams: 3.76 -> 3.53 ms per frame round, the chained
-	// tick 7.4 -> 7.04 ms; more chunks lose it again to launch tails: 8 chunks 4.07 ms; a high-priority stream for the
-	// post-filter makes it worse: 7.9 against 7.2 ms per tick).
+	// One wavefront per stream and TICK: the canceller for every frame the stream has ready, then (optionally) the
+	// post-filter for the same frames as its own launch.  At 256-sample frames the canceller is HBM-bound with the VALUs
+	// partly idle and the post-filter VALU-bound with HBM mostly idle: a big batch is cut into chunks, the cancellers run
+	// back to back on the context's stream and a chunk's post-filter on a second stream next to the next chunk's canceller.
 	auto launch_mdf = [&](int first, int count) {
 		g.first = first;
-		if (a->F == 256) hipLaunchKernelGGL(aec_mdf_wave_kernel<256>, dim3(count), dim3(64), 0, a->ctx->stream, g);
-		else if (a->F == 128) hipLaunchKernelGGL(aec_mdf_wave_kernel<128>, dim3(count), dim3(64), 0, a->ctx->stream, g);
-		else hipLaunchKernelGGL(aec_mdf_wave_kernel<64>, dim3(count), dim3(64), 0, a->ctx->stream, g);
+		if (a->F == 256) hipLaunchKernelGGL(aec_mdf_tick_kernel<256>, dim3(count), dim3(64), 0, a->ctx->stream, g);
+		else if (a->F == 128) hipLaunchKernelGGL(aec_mdf_tick_kernel<128>, dim3(count), dim3(64), 0, a->ctx->stream, g);
+		else hipLaunchKernelGGL(aec_mdf_tick_kernel<64>, dim3(count), dim3(64), 0, a->ctx->stream, g);
 	};
 	auto launch_post = [&](int first, int count, hipStream_t st) {
 		g.first = first;
-		if (a->F == 256) hipLaunchKernelGGL(aec_post_wave_kernel<256>, dim3(count), dim3(64), 0, st, g);
-		else if (a->F == 128) hipLaunchKernelGGL(aec_post_wave_kernel<128>, dim3(count), dim3(64), 0, st, g);
-		else hipLaunchKernelGGL(aec_post_wave_kernel<64>, dim3(count), dim3(64), 0, st, g);
+		if (a->F == 256) hipLaunchKernelGGL(aec_post_tick_kernel<256>, dim3(count), dim3(64), 0, st, g);
+		else if (a->F == 128) hipLaunchKernelGGL(aec_post_tick_kernel<128>, dim3(count), dim3(64), 0, st, g);
+		else hipLaunchKernelGGL(aec_post_tick_kernel<64>, dim3(count), dim3(64), 0, st, g);
 	};
 	static const bool no_overlap = getenv("MSMI355X_AEC_NO_OVERLAP") != nullptr; // A/B switch
 	static const int env_chunks = [] {
@@ -659,6 +642,19 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 	return MI_OK;
 }
 
+int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
+                   const uint8_t *d_run, unsigned flags) {
+	MI_CHECK_ARG(a && d_mic && d_ref && d_out && stride >= a->F);
+	return aec_launch(a, d_mic, d_ref, d_out, stride, d_run, nullptr, 1, flags);
+}
+
+int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
+                          const uint8_t *d_count, int max_frames, unsigned flags) {
+	MI_CHECK_ARG(a && d_mic && d_ref && d_out && d_count && max_frames >= 1 && max_frames <= MI_AEC_MAX_TICK_FRAMES &&
+	             stride >= max_frames * a->F);
+	return aec_launch(a, d_mic, d_ref, d_out, stride, nullptr, d_count, max_frames, flags);
+}
+
 int mi_aec_join(mi_aec *a) {
 	MI_CHECK_ARG(a != nullptr);
 	if (!a->deferred_chunks) return MI_OK;
@@ -715,7 +711,12 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	std::vector<float> small((size_t)a->small_stride);
 	MI_HIP(hipMemcpy(small.data(), a->d_small + (size_t)stream * a->small_stride, small.size() * sizeof(float),
 	                 hipMemcpyDeviceToHost));
-	const int o_e = F, o_pw = 3 * F, o_p1 = 5 * F, o_eh = 7 * F, o_yh = 9 * F, o_ly = 11 * F, o_prop = 13 * F;
+	const int o_e = F, o_pw = 3 * F, o_p1 = 4 * F, o_eh = 5 * F, o_yh = 6 * F, o_ly = 7 * F, o_misc = 19 * F, o_prop = o_misc, o_tail = o_misc + 128;
+	auto with_tail = [&](int off, int t) { // the per-bin array plus its Nyquist entry
+		std::vector<float> v(small.begin() + off, small.begin() + off + F);
+		v.push_back(small[(size_t)o_tail + t]);
+		return v;
+	};
 	std::vector<float> res;
 	if (!strcmp(what, "W") || !strcmp(what, "foreground")) {
 		std::vector<float> raw((size_t)M * N);
@@ -733,12 +734,15 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	} else if (!strcmp(what, "E")) {
 		res.resize((size_t)N);
 		unpack(small.data() + o_e, res.data());
-	} else if (!strcmp(what, "power")) res.assign(small.begin() + o_pw, small.begin() + o_pw + F + 1);
-	else if (!strcmp(what, "power_1")) res.assign(small.begin() + o_p1, small.begin() + o_p1 + F + 1);
-	else if (!strcmp(what, "Eh")) res.assign(small.begin() + o_eh, small.begin() + o_eh + F + 1);
-	else if (!strcmp(what, "Yh")) res.assign(small.begin() + o_yh, small.begin() + o_yh + F + 1);
-	else if (!strcmp(what, "last_y")) res.assign(small.begin() + o_ly, small.begin() + o_ly + N);
-	else if (!strcmp(what, "prop")) res.assign(small.begin() + o_prop, small.begin() + o_prop + M);
+	} else if (!strcmp(what, "power")) res = with_tail(o_pw, 0);
+	else if (!strcmp(what, "power_1")) res = with_tail(o_p1, 1);
+	else if (!strcmp(what, "Eh")) res = with_tail(o_eh, 2);
+	else if (!strcmp(what, "Yh")) res = with_tail(o_yh, 3);
+	else if (!strcmp(what, "last_y")) { // [older frame | newest frame] out of the ring of three
+		const int nw = sc.ly_slot, od = (sc.ly_slot + 2) % 3;
+		res.assign(small.begin() + o_ly + od * F, small.begin() + o_ly + od * F + F);
+		res.insert(res.end(), small.begin() + o_ly + nw * F, small.begin() + o_ly + nw * F + F);
+	} else if (!strcmp(what, "prop")) res.assign(small.begin() + o_prop, small.begin() + o_prop + M);
 	else if (!strcmp(what, "scalars")) {
 		res = {sc.Davg1, sc.Davg2, sc.Dvar1, sc.Dvar2, sc.Pey, sc.Pyy, sc.sum_adapt, sc.leak_estimate,
 		       (float)sc.adapted, (float)sc.saturated, (float)sc.screwed_up, (float)sc.cancel_count,
@@ -771,7 +775,7 @@ int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap) {
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
 	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
-	BlobHeader h = {{'M', 'I', 'E', 'C'}, 1u, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
+	BlobHeader h = {{'M', 'I', 'E', 'C'}, 2u, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
 	uint8_t *p = (uint8_t *)h_blob;
 	memcpy(p, &h, sizeof(h));
 	p += sizeof(h);
@@ -795,7 +799,7 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 		return MI_EINVAL;
 	}
 	memcpy(&h, h_blob, sizeof(h));
-	if (memcmp(h.magic, "MIEC", 4) != 0 || h.version != 1 || h.rate != (uint32_t)a->rate || h.F != (uint32_t)a->F || h.M != (uint32_t)a->M ||
+	if (memcmp(h.magic, "MIEC", 4) != 0 || h.version != 2 || h.rate != (uint32_t)a->rate || h.F != (uint32_t)a->F || h.M != (uint32_t)a->M ||
 	    h.N != (uint32_t)a->N || h.small_stride != (uint32_t)a->small_stride || h.scal_bytes != sizeof(AecScalars) ||
 	    size != mi_aec_blob_bytes(a)) {
 		mi::set_error("mi_aec_import_state: the blob was taken from a canceller of another shape (rate %u, frame %u, %u blocks) or is damaged",

@@ -1,0 +1,1082 @@
+// aec_tick.hpp -- the AEC kernels in their per-TICK form (included by aec.hip after aec_wave.hpp, whose FFT / ordered-sum
+// helpers they share).  One launch serves every frame a stream has ready in this 10 ms tick: at 48 kHz the filter's
+// 256-sample frames (speexec.c:171-180) make that one or two frames (15 per 8 ticks).
+//
+// Why per tick: the canceller is HBM-bound, and with both frames of a tick inside one wavefront
+//   * the per-stream "small" state (error spectrum, step sizes, power / Eh / Yh, post-filter estimates: ~40 KB moved per
+//     frame by the per-frame kernels) is read once and written once per TICK -- it lives in registers in between;
+//   * the foreground filter is streamed ONCE for both frames: frame 2's foreground response sum_j X'(j) FG(j) uses the
+//     same FG blocks as frame 1's (X'(j) = X(j-1)), so it is accumulated in frame 1's pass -- "speculatively": if frame
+//     1 decides to copy the background into the foreground (update_foreground), frame 2's response is instead
+//     sum_j X'(j) W1(j), which frame 2's own pass over W yields for free (W1(j) is what it loads before updating it),
+//     and the copy itself degenerates into stores of the blocks that pass already holds (no second read of W);
+//   * nothing else changes: every sum keeps the library's operand order, so results are bit-identical to the per-frame
+//     kernels (tests/test_gpu_aec.py compares both with the oracle).
+// Cost: the second frame's far-end spectrum is needed early, and ~50 more live registers: 2 waves per SIMD at F = 256
+// instead of 3 (measured on the per-frame kernel: 1.5 % slower per launch at that occupancy; the bytes saved are ~15 %).
+
+template <int F>
+struct TickLayout { // offsets in floats inside the per-stream small-state block
+	static constexpr int XPREV = 0;          // F   pre-emphasised far end of the last frame (first half of the next FFT input)
+	static constexpr int E = F;              // 2F  error spectrum of the last frame, bin-interleaved
+	static constexpr int POWER = 3 * F;      // F   (+1 in TAIL)
+	static constexpr int POWER1 = 4 * F;
+	static constexpr int EH = 5 * F;
+	static constexpr int YH = 6 * F;
+	static constexpr int LASTY = 7 * F;      // 3F  ring of three echo-estimate frames (AecScalars::ly_slot = newest)
+	static constexpr int ECHON = 10 * F;     // post-filter
+	static constexpr int INBUF = 11 * F;
+	static constexpr int OUTBUF = 12 * F;
+	static constexpr int NOISE = 13 * F;
+	static constexpr int OLDPS = 14 * F;
+	static constexpr int ZETA = 15 * F;
+	static constexpr int S_ = 16 * F;
+	static constexpr int SMIN = 17 * F;
+	static constexpr int STMP = 18 * F;
+	static constexpr int MISC = 19 * F;
+	static constexpr int PROP = MISC;        // M <= 64
+	static constexpr int WNORM = MISC + 64;  // M
+	static constexpr int TAIL = MISC + 128;  // POWER[F], POWER1[F], EH[F], YH[F]
+	static constexpr int OLDPS_B = MISC + 136; // 24 Bark bands
+	static constexpr int ZETA_B = MISC + 160;
+	static constexpr int TOTAL = 19 * F + 192;
+};
+
+// LDS of the canceller kernel: FFT work space + tables and the per-bin state parked while the blocks stream (none of the
+// post-filter's arrays): 16.3 KB at F = 256.  (Tables read from global instead -- w_cfft<F, true> -- cost 24 % of the kernel
+// at 2 waves per SIMD: 6.35 against 5.14 ms per tick of 65 536 legs.)
+#ifndef AEC_TICK_GLOBAL_TABLES
+#define AEC_TICK_GLOBAL_TABLES 0
+#endif
+template <int F>
+struct alignas(16) TLds {
+	float2 zbuf[F];      // complex FFT work
+	float tbuf[2 * F];   // time-domain exchange / inverse-transform staging
+	float spec[2 * F];   // bin-interleaved spectrum exchange
+#if !AEC_TICK_GLOBAL_TABLES
+	float2 tw[F], super[F];
+	uint16_t perm[F];
+#endif
+	float prop[64], wnorm[64];
+	// per-bin state that is not needed while the blocks stream: parked here instead of in registers
+	float pw[F], eh[F], yh[F], lprev[F], input[F];
+};
+
+
+// ---- buffer addressing: one 128-bit descriptor (SGPRs) per per-stream array + ONE per-lane byte offset + a scalar
+// offset, instead of a 64-bit per-lane address (two VGPRs) per array and block: the canceller touches ~25 arrays
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+#ifndef AEC_TICK_FLAT
+#define AEC_TICK_FLAT 0
+#endif
+#if AEC_TICK_FLAT
+// A/B: the same accessors over plain 64-bit addresses
+struct rsrc_t {
+	char *p;
+};
+__device__ __forceinline__ rsrc_t mk_rsrc(const void *p, unsigned) { return rsrc_t{const_cast<char *>((const char *)p)}; }
+#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) (*reinterpret_cast<const u4v *>((r).p + (size_t)(v) + (size_t)(s)))
+#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) (*reinterpret_cast<const u2v *>((r).p + (size_t)(v) + (size_t)(s)))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) (*reinterpret_cast<const unsigned *>((r).p + (size_t)(v) + (size_t)(s)))
+#define __builtin_amdgcn_raw_buffer_store_b128(x, r, v, s, a) (*reinterpret_cast<u4v *>((r).p + (size_t)(v) + (size_t)(s)) = (x))
+#define __builtin_amdgcn_raw_buffer_store_b64(x, r, v, s, a) (*reinterpret_cast<u2v *>((r).p + (size_t)(v) + (size_t)(s)) = (x))
+#define __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, a) (*reinterpret_cast<unsigned *>((r).p + (size_t)(v) + (size_t)(s)) = (x))
+#else
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void *p, unsigned bytes) {
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+#endif
+__device__ __forceinline__ float u2f(unsigned v) { return __uint_as_float(v); }
+__device__ __forceinline__ unsigned f2u(float v) { return __float_as_uint(v); }
+template <int K>
+__device__ __forceinline__ void bload_bins(rsrc_t r, unsigned voff, unsigned soff, float2 (&v)[K]) {
+	if constexpr (K == 1) {
+		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+		v[0] = make_float2(u2f(t.x), u2f(t.y));
+	} else {
+#pragma unroll
+		for (int k = 0; k < K; k += 2) {
+			const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 8 * k, soff, 0);
+			v[k] = make_float2(u2f(t.x), u2f(t.y));
+			v[k + 1] = make_float2(u2f(t.z), u2f(t.w));
+		}
+	}
+}
+template <int K>
+__device__ __forceinline__ void bstore_bins(rsrc_t r, unsigned voff, unsigned soff, const float2 (&v)[K]) {
+	if constexpr (K == 1) {
+		u2v t = {f2u(v[0].x), f2u(v[0].y)};
+		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+	} else {
+#pragma unroll
+		for (int k = 0; k < K; k += 2) {
+			u4v t = {f2u(v[k].x), f2u(v[k].y), f2u(v[k + 1].x), f2u(v[k + 1].y)};
+			__builtin_amdgcn_raw_buffer_store_b128(t, r, voff + 8 * k, soff, 0);
+		}
+	}
+}
+template <int K>
+__device__ __forceinline__ void bload_vec(rsrc_t r, unsigned voff, unsigned soff, float (&v)[K]) {
+	if constexpr (K == 4) {
+		const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+		v[0] = u2f(t.x), v[1] = u2f(t.y), v[2] = u2f(t.z), v[3] = u2f(t.w);
+	} else if constexpr (K == 2) {
+		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+		v[0] = u2f(t.x), v[1] = u2f(t.y);
+	} else {
+		v[0] = u2f(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+	}
+}
+template <int K>
+__device__ __forceinline__ void bstore_vec(rsrc_t r, unsigned voff, unsigned soff, const float (&v)[K]) {
+	if constexpr (K == 4) {
+		u4v t = {f2u(v[0]), f2u(v[1]), f2u(v[2]), f2u(v[3])};
+		__builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+	} else if constexpr (K == 2) {
+		u2v t = {f2u(v[0]), f2u(v[1])};
+		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+	} else {
+		__builtin_amdgcn_raw_buffer_store_b32(f2u(v[0]), r, voff, soff, 0);
+	}
+}
+
+template <int K>
+__device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K], const float2 (&w)[K], int e0) {
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (e0 + k == 0) { // bin 0 holds (DC, Nyquist): two real products
+			acc[k].x += x[k].x * w[k].x;
+			acc[k].y += x[k].y * w[k].y;
+		} else {
+			acc[k].x += (x[k].x * w[k].x - x[k].y * w[k].y);
+			acc[k].y += (x[k].y * w[k].x + x[k].x * w[k].y);
+		}
+	}
+}
+
+#ifndef AEC_TICK_OCC256
+#define AEC_TICK_OCC256 2
+#endif
+#ifndef AEC_TICK_PF
+#define AEC_TICK_PF 1 /* blocks in flight behind the one at hand: 1 or 2 */
+#endif
+
+// ===================================================================== MDF canceller, the frames of one tick
+template <int F>
+__global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4))) void aec_mdf_tick_kernel(AecArgs a) {
+	__shared__ TLds<F> L;
+	using SL = TickLayout<F>;
+	constexpr int N = 2 * F, K = F / 64;
+	const int s = a.first + blockIdx.x;
+	int nf = a.count ? (int)a.count[s] : ((a.run && !a.run[s]) ? 0 : 1);
+	if (nf > a.max_frames) nf = a.max_frames;
+	if (nf <= 0) return;
+	const int lane = threadIdx.x;
+	const int e0 = lane * K; // first element (sample / bin) this lane owns
+	const int M = a.M;
+	float *sm = a.small + (size_t)s * a.small_stride;
+	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
+	const rsrc_t rX = mk_rsrc(a.X + (size_t)s * (M + 1) * N, (unsigned)((M + 1) * N) * 4u);
+	const rsrc_t rW = mk_rsrc(a.W + (size_t)s * M * N, (unsigned)(M * N) * 4u);
+	const rsrc_t rF = mk_rsrc(a.FG + (size_t)s * M * N, (unsigned)(M * N) * 4u);
+	const unsigned vb4 = (unsigned)e0 * 4u, vb8 = (unsigned)e0 * 8u; // this lane's byte offset into a float / a bin array
+	AecScalars sc = a.scal[s];
+
+	// ---- tables, per-block step / norm, the per-bin state that stays in registers for the whole tick
+#if !AEC_TICK_GLOBAL_TABLES
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		L.tw[e0 + k] = a.t.tw[e0 + k];
+		L.super[e0 + k] = a.t.super[e0 + k];
+		L.perm[e0 + k] = a.t.perm[e0 + k];
+	}
+#endif
+	if (lane < M) {
+		L.prop[lane] = sm[SL::PROP + lane];
+		L.wnorm[lane] = sm[SL::WNORM + lane];
+	}
+	float2 Eprev[K];
+	float p1[K];
+	bload_bins<K>(rS, vb8, SL::E * 4, Eprev);
+	bload_vec<K>(rS, vb4, SL::POWER1 * 4, p1);
+	{ // each lane parks and later fetches its own K elements: no cross-lane traffic, program order suffices
+		float t[K];
+		bload_vec<K>(rS, vb4, SL::POWER * 4, t);
+		store_vec<K>(L.pw + e0, t);
+		bload_vec<K>(rS, vb4, SL::EH * 4, t);
+		store_vec<K>(L.eh + e0, t);
+		bload_vec<K>(rS, vb4, SL::YH * 4, t);
+		store_vec<K>(L.yh + e0, t);
+		bload_vec<K>(rS, vb4, (SL::LASTY + (sc.ly_slot) * F) * 4, t);
+		store_vec<K>(L.lprev + e0, t);
+	}
+	float pw_F = sm[SL::TAIL + 0], p1_F = sm[SL::TAIL + 1], eh_F = sm[SL::TAIL + 2], yh_F = sm[SL::TAIL + 3];
+	bool prop_dirty = false;
+
+	// far end of frame f: pre-emphasis, energy, spectrum of [previous frame | this frame]
+	auto prep_far = [&](int f, const float (&xp)[K], float (&xn)[K], float2 (&X0)[K], float &Sxx) {
+		const int16_t *rp = a.ref + (size_t)s * a.stride + f * F + e0;
+		float far[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) far[k] = (float)rp[k];
+		float prev = __shfl_up(far[K - 1], 1);
+		if (lane == 0) prev = sc.memX;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			xn[k] = far[k] - .9f * prev;
+			prev = far[k];
+		}
+		sc.memX = rdlane(far[K - 1], 63);
+		Sxx = WSeq<K>::inner_prod(xn, xn);
+		WSYNC();
+		store_vec<K>(L.tbuf + e0, xp);
+		store_vec<K>(L.tbuf + F + e0, xn);
+		w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, X0);
+	};
+
+	float2 X0[K], X0B[K]; // far-end spectrum of the frame at hand / of the frame behind it
+	float Sxx = 0, SxxB = 0;
+	{
+		float xp[K], xa[K], xb[K];
+		bload_vec<K>(rS, vb4, SL::XPREV * 4, xp);
+		prep_far(0, xp, xa, X0, Sxx);
+		if (nf > 1) {
+			prep_far(1, xa, xb, X0B, SxxB);
+			bstore_vec<K>(rS, vb4, SL::XPREV * 4, xb);
+		} else {
+			bstore_vec<K>(rS, vb4, SL::XPREV * 4, xa);
+#pragma unroll
+			for (int k = 0; k < K; ++k) X0B[k] = make_float2(0, 0);
+		}
+	}
+
+	float2 spec2[K]; // frame 2's foreground response, accumulated over frame 1's pass
+#pragma unroll
+	for (int k = 0; k < K; ++k) spec2[k] = make_float2(0, 0);
+	bool pendingFG = false; // frame 1 asked for foreground := background; frame 2's pass carries the copy out
+	float leak0 = sc.leak_estimate;
+
+	for (int f = 0; f < nf; ++f) {
+		// ---- near end: saturation flag, DC notch (serial IIR), pre-emphasis
+		int any_sat;
+		{
+			float input[K];
+			const int16_t *mp = a.mic + (size_t)s * a.stride + f * F + e0;
+			float fin[K];
+			bool satl = false;
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				const int m = mp[k];
+				fin[k] = (float)m;
+				satl |= (m <= -32000 || m >= 32000);
+			}
+			any_sat = __any(satl);
+			const float radius = a.notch_radius;
+			const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
+			float m0 = sc.notch0, m1 = sc.notch1;
+			float v[K];
+#pragma unroll 2
+			for (int l = 0; l < 64; ++l) {
+#pragma unroll
+				for (int k = 0; k < K; ++k) {
+					const float vin = rdlane(fin[k], l);
+					const float vout = m0 + vin;
+					m0 = m1 + 2 * (-vin + radius * vout);
+					m1 = vin - den2 * vout;
+					const float y = radius * vout;
+					if (lane == l) v[k] = y;
+				}
+			}
+			sc.notch0 = m0;
+			sc.notch1 = m1;
+			float vprev = __shfl_up(v[K - 1], 1);
+			if (lane == 0) vprev = sc.memD;
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				input[k] = v[k] - .9f * vprev;
+				vprev = v[k];
+			}
+			sc.memD = rdlane(v[K - 1], 63);
+			store_vec<K>(L.input + e0, input);
+		}
+		sc.cancel_count++;
+
+		// ---- newest far-end spectrum into the ring; its power spectrum is all the rest of the frame needs of it
+		const int head = (sc.xhead + M) % (M + 1);
+		sc.xhead = head;
+		bstore_bins<K>(rX, vb8, (unsigned)head * (F * 8), X0);
+		auto xoff = [&](int j) { return (unsigned)((head + j) % (M + 1)) * (unsigned)(F * 8); };
+		float Xf[K], Xf_F = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (e0 + k == 0) {
+				Xf[k] = X0[k].x * X0[k].x;
+				Xf_F = X0[k].y * X0[k].y;
+			} else {
+				Xf[k] = X0[k].x * X0[k].x + X0[k].y * X0[k].y;
+			}
+		}
+		Xf_F = rdlane(Xf_F, 0);
+
+		// ---- proportional step
+		if (sc.adapted) {
+			WSYNC();
+			if (lane == 0) {
+				float max_sum = 1, prop_sum = 1;
+				for (int i = 0; i < M; ++i) {
+					const float p = sqrt_via_double(1.0f + L.wnorm[i]);
+					L.prop[i] = p;
+					if (p > max_sum) max_sum = p;
+				}
+				for (int i = 0; i < M; ++i) {
+					L.prop[i] += .1f * max_sum;
+					prop_sum += L.prop[i];
+				}
+				for (int i = 0; i < M; ++i) L.prop[i] = (.99f * L.prop[i]) / prop_sum;
+			}
+			prop_dirty = true;
+		}
+		WSYNC();
+		const bool do_grad = (sc.saturated == 0);
+		if (!do_grad) sc.saturated--;
+
+		auto grad = [&](float2 (&w)[K], const float2 (&x)[K], float prop) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				if (e0 + k == 0) {
+					const float W0 = prop * p1[k], WN = prop * p1_F;
+					w[k].x += W0 * (x[k].x * Eprev[k].x);
+					w[k].y += WN * (x[k].y * Eprev[k].y);
+				} else {
+					const float Wt = prop * p1[k];
+					w[k].x += Wt * ((x[k].x * Eprev[k].x) + x[k].y * Eprev[k].y);
+					w[k].y += Wt * (((-x[k].y) * Eprev[k].x) + x[k].x * Eprev[k].y);
+				}
+			}
+		};
+
+		// ---- one streaming pass over the blocks (next block's loads in flight).  Block 0 and the round-robin block jc get
+		// the AUMDF constraint (IFFT, zero the second half, FFT) where the pass meets them: the blocks are independent of each
+		// other, only the sums over j have an order, and it stays ascending.
+		const int jc = (M > 1) ? (sc.cancel_count % (M - 1)) + 1 : -1;
+		auto constrain = [&](float2 (&w)[K]) {
+			w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w);
+			float z[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) z[k] = 0.f;
+			store_vec<K>(L.tbuf + F + e0, z);
+			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w);
+		};
+		float2 yfg[K], ybgs[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) yfg[k] = ybgs[k] = make_float2(0, 0);
+		auto norm_of = [&](const float2 (&w)[K], int j) {
+			float nn = 0;
+#pragma unroll
+			for (int k = 0; k < K; ++k) nn += w[k].x * w[k].x + w[k].y * w[k].y;
+			for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
+			if (lane == 0) L.wnorm[j] = nn; // feeds the NEXT frame's proportional step
+		};
+		if (f == 0) {
+			// frame 1: X, foreground and background; with a second frame behind it also that frame's foreground response
+			const bool spec = nf > 1;
+			float2 xj[K], xn[K], fg[K], wl[K], xm1[K]; // xm1: the block before xj = frame 2's block at this position
+#pragma unroll
+			for (int k = 0; k < K; ++k) xj[k] = X0[k], xm1[k] = X0B[k];
+			bload_bins<K>(rX, vb8, xoff(1), xn);
+			bload_bins<K>(rF, vb8, 0, fg);
+			bload_bins<K>(rW, vb8, 0, wl);
+#if AEC_TICK_PF == 2
+			float2 xn2[K], fg2[K], wl2[K]; // two blocks in flight behind the one at hand
+#pragma unroll
+			for (int k = 0; k < K; ++k) xn2[k] = fg2[k] = wl2[k] = make_float2(0, 0);
+			if (M > 1) {
+				bload_bins<K>(rX, vb8, xoff(2), xn2);
+				bload_bins<K>(rF, vb8, (unsigned)(F * 8), fg2);
+				bload_bins<K>(rW, vb8, (unsigned)(F * 8), wl2);
+			}
+#endif
+			for (int j = 0; j < M; ++j) {
+#if AEC_TICK_PF == 2
+				float2 xn3[K], fg3[K], wl3[K];
+				if (j + 2 < M) {
+					bload_bins<K>(rX, vb8, xoff(j + 3), xn3);
+					bload_bins<K>(rF, vb8, (unsigned)(j + 2) * (F * 8), fg3);
+					bload_bins<K>(rW, vb8, (unsigned)(j + 2) * (F * 8), wl3);
+				} else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) xn3[k] = xn2[k], fg3[k] = fg2[k], wl3[k] = wl2[k];
+				}
+#else
+				float2 xn2[K], fg2[K], wl2[K];
+				if (j + 1 < M) {
+					bload_bins<K>(rX, vb8, xoff(j + 2), xn2);
+					bload_bins<K>(rF, vb8, (unsigned)(j + 1) * (F * 8), fg2);
+					bload_bins<K>(rW, vb8, (unsigned)(j + 1) * (F * 8), wl2);
+				} else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) xn2[k] = xn[k], fg2[k] = fg[k], wl2[k] = wl[k];
+				}
+#endif
+				const bool aumdf = (j == 0 || j == jc);
+				if (do_grad) grad(wl, xn, L.prop[j]);
+				if (aumdf) constrain(wl);
+				if (do_grad || aumdf) bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), wl);
+				cmac_bins<K>(yfg, xj, fg, e0);
+				cmac_bins<K>(ybgs, xj, wl, e0);
+				if (spec) cmac_bins<K>(spec2, xm1, fg, e0);
+				norm_of(wl, j);
+#pragma unroll
+				for (int k = 0; k < K; ++k) xm1[k] = xj[k], xj[k] = xn[k], xn[k] = xn2[k], fg[k] = fg2[k], wl[k] = wl2[k];
+#if AEC_TICK_PF == 2
+#pragma unroll
+				for (int k = 0; k < K; ++k) xn2[k] = xn3[k], fg2[k] = fg3[k], wl2[k] = wl3[k];
+#endif
+			}
+		} else {
+			// frame 2: X and the background only.  alt = sum_j X(j) W1(j) with W1 the background as frame 1 left it: the
+			// foreground response when frame 1 updated the foreground; the same blocks are then stored as the foreground.
+			float2 alt[K], xj[K], xn[K], wl[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) xj[k] = X0[k], alt[k] = make_float2(0, 0);
+			bload_bins<K>(rX, vb8, xoff(1), xn);
+			bload_bins<K>(rW, vb8, 0, wl);
+#if AEC_TICK_PF == 2
+			float2 xn2[K], wl2[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) xn2[k] = wl2[k] = make_float2(0, 0);
+			if (M > 1) {
+				bload_bins<K>(rX, vb8, xoff(2), xn2);
+				bload_bins<K>(rW, vb8, (unsigned)(F * 8), wl2);
+			}
+#endif
+			for (int j = 0; j < M; ++j) {
+#if AEC_TICK_PF == 2
+				float2 xn3[K], wl3[K];
+				if (j + 2 < M) {
+					bload_bins<K>(rX, vb8, xoff(j + 3), xn3);
+					bload_bins<K>(rW, vb8, (unsigned)(j + 2) * (F * 8), wl3);
+				} else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) xn3[k] = xn2[k], wl3[k] = wl2[k];
+				}
+#else
+				float2 xn2[K], wl2[K];
+				if (j + 1 < M) {
+					bload_bins<K>(rX, vb8, xoff(j + 2), xn2);
+					bload_bins<K>(rW, vb8, (unsigned)(j + 1) * (F * 8), wl2);
+				} else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) xn2[k] = xn[k], wl2[k] = wl[k];
+				}
+#endif
+				if (pendingFG) bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), wl);
+				cmac_bins<K>(alt, xj, wl, e0);
+				const bool aumdf = (j == 0 || j == jc);
+				if (do_grad) grad(wl, xn, L.prop[j]);
+				if (aumdf) constrain(wl);
+				if (do_grad || aumdf) bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), wl);
+				cmac_bins<K>(ybgs, xj, wl, e0);
+				norm_of(wl, j);
+#pragma unroll
+				for (int k = 0; k < K; ++k) xj[k] = xn[k], xn[k] = xn2[k], wl[k] = wl2[k];
+#if AEC_TICK_PF == 2
+#pragma unroll
+				for (int k = 0; k < K; ++k) xn2[k] = xn3[k], wl2[k] = wl3[k];
+#endif
+			}
+#pragma unroll
+			for (int k = 0; k < K; ++k) yfg[k] = pendingFG ? alt[k] : spec2[k];
+			pendingFG = false;
+		}
+
+		// ---- time-domain responses
+		float efg[K], ybg[K], e1[K], e2[K], dresp[K], input[K];
+		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, yfg);
+		load_vec<K>(L.tbuf + F + e0, efg);
+		load_vec<K>(L.input + e0, input);
+#pragma unroll
+		for (int k = 0; k < K; ++k) e1[k] = input[k] - efg[k];
+		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, ybgs);
+		load_vec<K>(L.tbuf + F + e0, ybg);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			e2[k] = input[k] - ybg[k];
+			dresp[k] = efg[k] - ybg[k];
+		}
+		const float Sff = WSeq<K>::inner_prod(e1, e1);
+		const float Dbf = 10 + WSeq<K>::inner_prod(dresp, dresp);
+		float See = WSeq<K>::inner_prod(e2, e2);
+
+		// ---- two-path control
+		sc.Davg1 = .6f * sc.Davg1 + .4f * (Sff - See);
+		sc.Davg2 = .85f * sc.Davg2 + .15f * (Sff - See);
+		sc.Dvar1 = .36f * sc.Dvar1 + (.4f * Sff) * (.4f * Dbf);
+		sc.Dvar2 = .7225f * sc.Dvar2 + (.15f * Sff) * (.15f * Dbf);
+		bool update_foreground = false;
+		if ((Sff - See) * fabsf(Sff - See) > Sff * Dbf) update_foreground = true;
+		else if (sc.Davg1 * fabsf(sc.Davg1) > .5f * sc.Dvar1) update_foreground = true;
+		else if (sc.Davg2 * fabsf(sc.Davg2) > .25f * sc.Dvar2) update_foreground = true;
+		if (update_foreground) {
+			sc.Davg1 = sc.Davg2 = 0;
+			sc.Dvar1 = sc.Dvar2 = 0;
+			if (f + 1 < nf) {
+				pendingFG = true; // the next frame's pass stores the blocks it loads anyway
+			} else {
+				for (int j = 0; j < M; ++j) {
+					float2 w[K];
+					bload_bins<K>(rW, vb8, (unsigned)(j) * (F * 8), w);
+					bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), w);
+				}
+			}
+			float h0[K], h1[K];
+			load_vec<K>(a.t.hann + e0, h0);
+			load_vec<K>(a.t.hann + F + e0, h1);
+#pragma unroll
+			for (int k = 0; k < K; ++k) efg[k] = h1[k] * efg[k] + h0[k] * ybg[k];
+		} else {
+			bool reset_background = false;
+			if ((-(Sff - See)) * fabsf(Sff - See) > 4.f * (Sff * Dbf)) reset_background = true;
+			if ((-sc.Davg1) * fabsf(sc.Davg1) > 4.f * sc.Dvar1) reset_background = true;
+			if ((-sc.Davg2) * fabsf(sc.Davg2) > 4.f * sc.Dvar2) reset_background = true;
+			if (reset_background) {
+				for (int j = 0; j < M; ++j) {
+					float2 w[K];
+					bload_bins<K>(rF, vb8, (unsigned)(j) * (F * 8), w);
+					bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), w);
+					norm_of(w, j);
+				}
+#pragma unroll
+				for (int k = 0; k < K; ++k) {
+					ybg[k] = efg[k];
+					e2[k] = input[k] - efg[k];
+				}
+				See = Sff;
+				sc.Davg1 = sc.Davg2 = 0;
+				sc.Dvar1 = sc.Dvar2 = 0;
+			}
+		}
+
+		// ---- output (serial de-emphasis) and correlations
+		int out_i[K];
+		{
+			float d[K], tout[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) d[k] = input[k] - efg[k];
+			float memE = sc.memE;
+#pragma unroll 2
+			for (int l = 0; l < 64; ++l) {
+#pragma unroll
+				for (int k = 0; k < K; ++k) {
+					float t = rdlane(d[k], l);
+					t = t + .9f * memE;
+					memE = t;
+					if (lane == l) tout[k] = t;
+				}
+			}
+			sc.memE = memE;
+#pragma unroll
+			for (int k = 0; k < K; ++k) out_i[k] = word2int(tout[k]);
+		}
+		const float Sey = WSeq<K>::inner_prod(e2, ybg);
+		const float Syy = WSeq<K>::inner_prod(ybg, ybg);
+		const float Sdd = WSeq<K>::inner_prod(input, input);
+		if (any_sat && sc.saturated == 0) sc.saturated = 1;
+
+		// ---- error / response spectra
+		float2 Ecur[K], Ycur[K];
+		{
+			float z[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) z[k] = 0.f;
+			WSYNC();
+			store_vec<K>(L.tbuf + e0, z);
+			store_vec<K>(L.tbuf + F + e0, e2);
+			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, Ecur);
+			store_vec<K>(L.tbuf + e0, z);
+			store_vec<K>(L.tbuf + F + e0, ybg);
+			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, Ycur);
+		}
+		float Rf[K], Yf[K], Rf_F = 0, Yf_F = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (e0 + k == 0) {
+				Rf[k] = Ecur[k].x * Ecur[k].x;
+				Rf_F = Ecur[k].y * Ecur[k].y;
+				Yf[k] = Ycur[k].x * Ycur[k].x;
+				Yf_F = Ycur[k].y * Ycur[k].y;
+			} else {
+				Rf[k] = Ecur[k].x * Ecur[k].x + Ecur[k].y * Ecur[k].y;
+				Yf[k] = Ycur[k].x * Ycur[k].x + Ycur[k].y * Ycur[k].y;
+			}
+		}
+		// the Nyquist powers live in lane 0; everyone needs them for the ordered sums below
+		Rf_F = rdlane(Rf_F, 0);
+		Yf_F = rdlane(Yf_F, 0);
+#pragma unroll
+		for (int k = 0; k < K; ++k) Eprev[k] = Ecur[k];
+
+		// ---- sanity checks
+		bool zero_out = false;
+		if (!(Syy >= 0 && Sxx >= 0 && See >= 0) || !(Sff < N * 1e9 && Syy < N * 1e9 && Sxx < N * 1e9)) {
+			sc.screwed_up += 50;
+			zero_out = true;
+		} else if (Sff > Sdd + (float)(N * 10000)) {
+			sc.screwed_up++;
+		} else {
+			sc.screwed_up = 0;
+		}
+		if (zero_out) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) out_i[k] = 0;
+		}
+		int16_t *op = a.out + (size_t)s * a.stride + f * F + e0;
+		const int ly_new = (sc.ly_slot + 1) % 3;
+		if (sc.screwed_up >= 50) { // speex_echo_state_reset
+			float z[K];
+			float2 z2[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) z[k] = 0.f, z2[k] = make_float2(0, 0);
+			for (int j = 0; j < M; ++j) {
+				bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), z2);
+				bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), z2);
+			}
+			for (int j = 0; j <= M; ++j) bstore_bins<K>(rX, vb8, (unsigned)j * (F * 8), z2);
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				p1[k] = 1.0f;
+				Eprev[k] = make_float2(0, 0);
+				spec2[k] = make_float2(0, 0);
+			}
+			store_vec<K>(L.pw + e0, z);
+			store_vec<K>(L.eh + e0, z);
+			store_vec<K>(L.yh + e0, z);
+			store_vec<K>(L.lprev + e0, z);
+			pw_F = eh_F = yh_F = 0.f;
+			p1_F = 1.0f;
+			WSYNC();
+			if (lane < M) L.wnorm[lane] = 0;
+			bstore_vec<K>(rS, vb4, SL::LASTY * 4, z);
+			bstore_vec<K>(rS, vb4, (SL::LASTY + F) * 4, z);
+			bstore_vec<K>(rS, vb4, (SL::LASTY + (2) * F) * 4, z);
+			sc.cancel_count = 0;
+			sc.screwed_up = 0;
+			sc.notch0 = sc.notch1 = 0;
+			sc.memD = sc.memE = sc.memX = 0;
+			sc.saturated = 0;
+			sc.adapted = 0;
+			sc.sum_adapt = 0;
+			sc.Pey = sc.Pyy = 1.0f;
+			sc.Davg1 = sc.Davg2 = sc.Dvar1 = sc.Dvar2 = 0;
+			sc.ly_slot = ly_new;
+			pendingFG = false;
+			if (f == 0) leak0 = sc.leak_estimate;
+#pragma unroll
+			for (int k = 0; k < K; ++k) op[k] = (int16_t)out_i[k];
+			if (f + 1 < nf) { // the next frame starts from the reset far-end state
+				float xn[K];
+				prep_far(f + 1, z, xn, X0, Sxx);
+				bstore_vec<K>(rS, vb4, SL::XPREV * 4, xn);
+			} else {
+				bstore_vec<K>(rS, vb4, SL::XPREV * 4, z);
+			}
+			continue;
+		}
+		if (See < (float)(N * 100)) See = (float)(N * 100);
+		float Sxx2 = Sxx + Sxx; // sic: the library accumulates the far-end energy a second time here
+
+		// ---- far-end power, leak estimate
+		float pw[K];
+		load_vec<K>(L.pw + e0, pw);
+#pragma unroll
+		for (int k = 0; k < K; ++k) pw[k] = a.ss_1 * pw[k] + 1 + a.ss * Xf[k];
+		store_vec<K>(L.pw + e0, pw);
+		pw_F = a.ss_1 * pw_F + 1 + a.ss * Xf_F;
+		float Ehd[K], Yhd[K], Ehd_F, Yhd_F;
+		{
+			float eh[K], yh[K];
+			load_vec<K>(L.eh + e0, eh);
+			load_vec<K>(L.yh + e0, yh);
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				Ehd[k] = Rf[k] - eh[k];
+				Yhd[k] = Yf[k] - yh[k];
+				eh[k] = (1 - a.spec_average) * eh[k] + a.spec_average * Rf[k];
+				yh[k] = (1 - a.spec_average) * yh[k] + a.spec_average * Yf[k];
+			}
+			store_vec<K>(L.eh + e0, eh);
+			store_vec<K>(L.yh + e0, yh);
+		}
+		Ehd_F = Rf_F - eh_F;
+		Yhd_F = Yf_F - yh_F;
+		eh_F = (1 - a.spec_average) * eh_F + a.spec_average * Rf_F;
+		yh_F = (1 - a.spec_average) * yh_F + a.spec_average * Yf_F;
+		float Pey = 1.0f, Pyy = 1.0f;
+		Pey = Pey + Ehd_F * Yhd_F;
+		Pyy = Pyy + Yhd_F * Yhd_F;
+		Pey = WSeq<K>::dot_desc(Pey, Ehd, Yhd);
+		Pyy = WSeq<K>::dot_desc(Pyy, Yhd, Yhd);
+		Pyy = sqrt_via_double(Pyy);
+		Pey = Pey / Pyy;
+		float tmp32 = a.beta0 * Syy;
+		if (tmp32 > a.beta_max * See) tmp32 = a.beta_max * See;
+		const float alpha = tmp32 / See;
+		const float alpha_1 = 1.0f - alpha;
+		sc.Pey = alpha_1 * sc.Pey + alpha * Pey;
+		sc.Pyy = alpha_1 * sc.Pyy + alpha * Pyy;
+		if (sc.Pyy < 1.0f) sc.Pyy = 1.0f;
+		if (sc.Pey < .005f * sc.Pyy) sc.Pey = .005f * sc.Pyy;
+		if (sc.Pey > sc.Pyy) sc.Pey = sc.Pyy;
+		sc.leak_estimate = sc.Pey / sc.Pyy;
+		float RER = (float)((.0001 * Sxx2 + 3. * (sc.leak_estimate * Syy)) / See);
+		if (RER < Sey * Sey / (1 + See * Syy)) RER = Sey * Sey / (1 + See * Syy);
+		if (RER > .5) RER = .5;
+		if (!sc.adapted && sc.sum_adapt > (float)M && sc.leak_estimate * Syy > .03f * Syy) sc.adapted = 1;
+
+		auto step = [&](float Yfv, float Rfv, float pwv) -> float {
+			float r = sc.leak_estimate * Yfv;
+			const float e = Rfv + 1;
+			if (r > .5 * e) r = (float)(.5 * e);
+			r = .7f * r + .3f * (float)(RER * e);
+			return r / (e * (pwv + 10));
+		};
+		if (sc.adapted) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) p1[k] = step(Yf[k], Rf[k], pw[k]);
+			p1_F = step(Yf_F, Rf_F, pw_F);
+		} else {
+			float adapt_rate = 0;
+			if (Sxx2 > (float)(N * 1000)) {
+				tmp32 = .25f * Sxx2;
+				if (tmp32 > .25 * See) tmp32 = (float)(.25 * See);
+				adapt_rate = tmp32 / See;
+			}
+#pragma unroll
+			for (int k = 0; k < K; ++k) p1[k] = adapt_rate / (pw[k] + 10);
+			p1_F = adapt_rate / (pw_F + 10);
+			sc.sum_adapt = sc.sum_adapt + adapt_rate;
+		}
+
+		// ---- echo estimate of this frame for the residual-echo stage (ring of three frames)
+		{
+			float ln[K], lprev[K];
+			load_vec<K>(L.lprev + e0, lprev);
+			const int16_t *mp = a.mic + (size_t)s * a.stride + f * F + e0;
+#pragma unroll
+			for (int k = 0; k < K; ++k) ln[k] = sc.adapted ? (float)((int)mp[k] - out_i[k]) : lprev[k];
+			bstore_vec<K>(rS, vb4, (SL::LASTY + (ly_new) * F) * 4, ln);
+			store_vec<K>(L.lprev + e0, ln);
+			sc.ly_slot = ly_new;
+		}
+		if (f == 0) leak0 = sc.leak_estimate;
+#pragma unroll
+		for (int k = 0; k < K; ++k) op[k] = (int16_t)out_i[k];
+#pragma unroll
+		for (int k = 0; k < K; ++k) X0[k] = X0B[k]; // the frame behind this one, if any
+		Sxx = SxxB;
+	}
+
+	// ---- the tick's state back to HBM, once
+	bstore_bins<K>(rS, vb8, SL::E * 4, Eprev);
+	bstore_vec<K>(rS, vb4, SL::POWER1 * 4, p1);
+	{
+		float t[K];
+		load_vec<K>(L.pw + e0, t);
+		bstore_vec<K>(rS, vb4, SL::POWER * 4, t);
+		load_vec<K>(L.eh + e0, t);
+		bstore_vec<K>(rS, vb4, SL::EH * 4, t);
+		load_vec<K>(L.yh + e0, t);
+		bstore_vec<K>(rS, vb4, SL::YH * 4, t);
+	}
+	WSYNC();
+	if (lane < M) {
+		sm[SL::WNORM + lane] = L.wnorm[lane];
+		if (prop_dirty) sm[SL::PROP + lane] = L.prop[lane];
+	}
+	if (lane == 0) {
+		sm[SL::TAIL + 0] = pw_F;
+		sm[SL::TAIL + 1] = p1_F;
+		sm[SL::TAIL + 2] = eh_F;
+		sm[SL::TAIL + 3] = yh_F;
+		sc.leak0 = leak0;
+		sc.tick_frames = nf;
+		a.scal[s] = sc;
+	}
+}
+
+// ===================================================================== post-filter, the frames of one tick
+template <int F>
+__global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
+	__shared__ WLds<F> L;
+	using SL = TickLayout<F>;
+	constexpr int K = F / 64;
+	const int s = a.first + blockIdx.x;
+	int nf = a.count ? (int)a.count[s] : ((a.run && !a.run[s]) ? 0 : 1);
+	if (nf > a.max_frames) nf = a.max_frames;
+	if (nf <= 0) return;
+	const int lane = threadIdx.x;
+	const int e0 = lane * K;
+	float *sm = a.small + (size_t)s * a.small_stride;
+	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
+	const unsigned vb4 = (unsigned)e0 * 4u;
+	AecScalars sc = a.scal[s];
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		L.tw[e0 + k] = a.t.tw[e0 + k];
+		L.super[e0 + k] = a.t.super[e0 + k];
+		L.perm[e0 + k] = a.t.perm[e0 + k];
+	}
+	// per-bin state of the tick, in registers
+	float en[K], inb[K], S[K], Smin[K], Stmp[K], noise[K], old_ps[K], zeta[K], ob[K], wl[K], wr[K], h0[K], h1[K], w0[K], w1[K];
+	bload_vec<K>(rS, vb4, SL::ECHON * 4, en);
+	bload_vec<K>(rS, vb4, SL::INBUF * 4, inb);
+	bload_vec<K>(rS, vb4, SL::S_ * 4, S);
+	bload_vec<K>(rS, vb4, SL::SMIN * 4, Smin);
+	bload_vec<K>(rS, vb4, SL::STMP * 4, Stmp);
+	bload_vec<K>(rS, vb4, SL::NOISE * 4, noise);
+	bload_vec<K>(rS, vb4, SL::OLDPS * 4, old_ps);
+	bload_vec<K>(rS, vb4, SL::ZETA * 4, zeta);
+	bload_vec<K>(rS, vb4, SL::OUTBUF * 4, ob);
+	load_vec<K>(a.t.bfl + e0, wl);
+	load_vec<K>(a.t.bfr + e0, wr);
+	load_vec<K>(a.t.hann + e0, h0);
+	load_vec<K>(a.t.hann + F + e0, h1);
+	load_vec<K>(a.t.pwin + e0, w0);
+	load_vec<K>(a.t.pwin + F + e0, w1);
+	float old_ps_b = 0, zeta_b = 0;
+	if (lane < NB_BANDS) {
+		old_ps_b = sm[SL::OLDPS_B + lane];
+		zeta_b = sm[SL::ZETA_B + lane];
+	}
+	// echo-estimate ring: the canceller left its newest frame in slot ly_slot; frame f of this tick reads slots
+	// (base + f, base + f + 1) with base = ly_slot - frames it wrote
+	const int base = (sc.ly_slot - sc.tick_frames + 6) % 3;
+	float *pl = L.spec, *pr = L.spec + F;
+	float *bandv = L.band;
+
+	for (int f = 0; f < nf; ++f) {
+		sc.nb_adapt++;
+		if (sc.nb_adapt > 20000) sc.nb_adapt = 20000;
+		sc.min_count++;
+		float beta = 1.0f / sc.nb_adapt;
+		if (beta < .03f) beta = .03f;
+		const float beta_1 = 1.0f - beta;
+		const float leak = (f + 1 < sc.tick_frames) ? sc.leak0 : sc.leak_estimate;
+
+		// residual echo spectrum (speex_echo_get_residual)
+		{
+			float lo[K], ln[K];
+			bload_vec<K>(rS, vb4, (SL::LASTY + (((base + f) % 3)) * F) * 4, lo);
+			bload_vec<K>(rS, vb4, (SL::LASTY + (((base + f + 1) % 3)) * F) * 4, ln);
+#pragma unroll
+			for (int k = 0; k < K; ++k) lo[k] = h0[k] * lo[k], ln[k] = h1[k] * ln[k];
+			WSYNC();
+			store_vec<K>(L.tbuf + e0, lo);
+			store_vec<K>(L.tbuf + F + e0, ln);
+		}
+		float2 Yr[K];
+		w_rfft_forward<F>(L, a.t, Yr);
+		const float leak2 = (leak > .5) ? 1.f : 2 * leak;
+		float res[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const float r = (e0 + k == 0) ? Yr[k].x * Yr[k].x : Yr[k].x * Yr[k].x + Yr[k].y * Yr[k].y;
+			res[k] = (float)(int32_t)(leak2 * r);
+		}
+		const float res0 = rdlane(res[0], 0);
+		const bool bad = !(res0 >= 0 && res0 < F * 1e9f);
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const float rr = bad ? 0.f : res[k];
+			const float c = .6f * en[k];
+			en[k] = c > rr ? c : rr;
+			pl[e0 + k] = wl[k] * en[k];
+			pr[e0 + k] = wr[k] * en[k];
+		}
+		// analysis frame [inbuf, x] * window
+		int16_t *op = a.out + (size_t)s * a.stride + f * F + e0;
+		{
+			float xcur[K], a0[K], a1[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				xcur[k] = (float)op[k];
+				a0[k] = inb[k] * w0[k];
+				a1[k] = xcur[k] * w1[k];
+				inb[k] = xcur[k];
+			}
+			store_vec<K>(L.tbuf + e0, a0);
+			store_vec<K>(L.tbuf + F + e0, a1);
+		}
+		WSYNC();
+		if (lane < NB_BANDS) bandv[lane] = band_sum<F>(a.t, lane, pl, pr);
+		float2 ft[K];
+		w_rfft_forward<F>(L, a.t, ft);
+		float ps[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			ps[k] = (e0 + k == 0) ? ft[k].x * ft[k].x : ft[k].x * ft[k].x + ft[k].y * ft[k].y;
+			L.vec[e0 + k] = ps[k];
+			pl[e0 + k] = wl[k] * ps[k];
+			pr[e0 + k] = wr[k] * ps[k];
+		}
+		WSYNC();
+		if (lane < NB_BANDS) bandv[NB_BANDS + lane] = band_sum<F>(a.t, lane, pl, pr);
+		// update_noise_prob
+		int min_range;
+		if (sc.nb_adapt < 100) min_range = 15;
+		else if (sc.nb_adapt < 1000) min_range = 50;
+		else if (sc.nb_adapt < 10000) min_range = 150;
+		else min_range = 300;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int b = e0 + k;
+			if (b == 0 || b == F - 1) S[k] = .8f * S[k] + .2f * ps[k];
+			else S[k] = .8f * S[k] + .05f * L.vec[b - 1] + .1f * ps[k] + .05f * L.vec[b + 1];
+			if (sc.nb_adapt == 1) Smin[k] = Stmp[k] = 0;
+			if (sc.min_count > min_range) {
+				Smin[k] = Stmp[k] < S[k] ? Stmp[k] : S[k];
+				Stmp[k] = S[k];
+			} else {
+				Smin[k] = Smin[k] < S[k] ? Smin[k] : S[k];
+				Stmp[k] = Stmp[k] < S[k] ? Stmp[k] : S[k];
+			}
+			const int update_prob = (.4f * S[k] > Smin[k]) ? 1 : 0;
+			if (!update_prob || ps[k] < noise[k]) {
+				const float v = beta_1 * noise[k] + beta * ps[k];
+				noise[k] = v > 0 ? v : 0;
+			}
+		}
+		if (sc.min_count > min_range) sc.min_count = 0;
+		WSYNC();
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			pl[e0 + k] = wl[k] * noise[k];
+			pr[e0 + k] = wr[k] * noise[k];
+		}
+		WSYNC();
+		if (lane < NB_BANDS) bandv[2 * NB_BANDS + lane] = band_sum<F>(a.t, lane, pl, pr);
+		WSYNC();
+
+		auto snr = [&](float psv, float noisev, float echov, float oldps, float &post, float &prior) {
+			const float tot_noise = 1.f + noisev + echov + 0.f;
+			post = psv / tot_noise - 1.f;
+			if (post > 100.f) post = 100.f;
+			const float t = oldps / (oldps + tot_noise);
+			const float gamma = .1f + .89f * (t * t);
+			prior = gamma * (post > 0 ? post : 0) + (1.0f - gamma) * (oldps / tot_noise);
+			if (prior > 100.f) prior = 100.f;
+		};
+		float post[K], prior[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (sc.nb_adapt == 1) old_ps[k] = ps[k];
+			snr(ps[k], noise[k], en[k], old_ps[k], post[k], prior[k]);
+			L.vec[e0 + k] = prior[k];
+		}
+		float post_b = 0, prior_b = 0, ps_b = 0;
+		if (lane < NB_BANDS) {
+			ps_b = bandv[NB_BANDS + lane];
+			if (sc.nb_adapt == 1) old_ps_b = ps_b;
+			snr(ps_b, bandv[2 * NB_BANDS + lane], bandv[lane], old_ps_b, post_b, prior_b);
+		}
+		WSYNC();
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int b = e0 + k;
+			if (b == 0 || b >= F - 1) zeta[k] = .7f * zeta[k] + .3f * prior[k];
+			else zeta[k] = .7f * zeta[k] + .15f * prior[k] + .075f * L.vec[b - 1] + .075f * L.vec[b + 1];
+		}
+		if (lane < NB_BANDS) zeta_b = .7f * zeta_b + .3f * prior_b;
+		float Zframe = 0;
+#pragma unroll
+		for (int i = 0; i < NB_BANDS; ++i) Zframe = Zframe + rdlane(zeta_b, i);
+		const float Pframe = .1f + .899f * qcurve(Zframe / NB_BANDS);
+		const int eff_echo = (int)((1.0f - Pframe) * -40 + Pframe * -15);
+		if (lane < NB_BANDS) {
+			const float noise_floor = (float)exp((double)(.2302585f * -15));
+			const float echo_floor = (float)exp((double)(.2302585f * eff_echo));
+			const float nb = bandv[2 * NB_BANDS + lane], eb = bandv[lane];
+			const float gfloor = (float)(sqrt((double)(noise_floor * nb + echo_floor * eb)) / sqrt((double)(1 + nb + eb)));
+			const float prior_ratio = prior_b / (prior_b + 1.f);
+			const float theta = prior_ratio * (1.f + post_b);
+			const float MM = hypergeom_gain(theta);
+			float g = prior_ratio * MM;
+			if (g > 1.f) g = 1.f;
+			old_ps_b = .2f * old_ps_b + (.8f * (g * g)) * ps_b;
+			const float P1 = .199f + .8f * qcurve(zeta_b);
+			const float q = 1.0f - Pframe * P1;
+			const float g2 = (float)(1 / (1.f + (q / (1.f - q)) * (1 + prior_b) * exp((double)(-theta))));
+			bandv[lane] = g2;
+			bandv[NB_BANDS + lane] = g;
+			bandv[2 * NB_BANDS + lane] = gfloor;
+		}
+		WSYNC();
+		float gain2[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			const int bl = a.t.bleft[e0 + k], br = bl + 1;
+			auto psd = [&](const float *mel) -> float {
+				float t = mel[bl] * wl[k];
+				t += mel[br] * wr[k];
+				return t;
+			};
+			const float p = psd(bandv);
+			const float gain_bark = psd(bandv + NB_BANDS);
+			const float gfl = psd(bandv + 2 * NB_BANDS);
+			const float prior_ratio = prior[k] / (prior[k] + 1.f);
+			const float theta = prior_ratio * (1.f + post[k]);
+			const float MM = hypergeom_gain(theta);
+			float g = prior_ratio * MM;
+			if (g > 1.f) g = 1.f;
+			if (.333f * g > gain_bark) g = 3 * gain_bark;
+			float gain = g;
+			old_ps[k] = .2f * old_ps[k] + (.8f * (gain * gain)) * ps[k];
+			if (gain < gfl) gain = gfl;
+			const float tmp = p * sqrt_via_double(gain) + (1.0f - p) * sqrt_via_double(gfl);
+			gain2[k] = tmp * tmp;
+		}
+		const float g_last = rdlane(gain2[K - 1], 63); // gain2[F-1] scales the Nyquist term
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			if (e0 + k == 0) {
+				ft[k].x = gain2[k] * ft[k].x;
+				ft[k].y = g_last * ft[k].y;
+			} else {
+				ft[k].x = gain2[k] * ft[k].x;
+				ft[k].y = gain2[k] * ft[k].y;
+			}
+		}
+		w_rfft_inverse<F>(L, a.t, ft);
+		{
+			float lo[K], hi[K];
+			load_vec<K>(L.tbuf + e0, lo);
+			load_vec<K>(L.tbuf + F + e0, hi);
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				op[k] = word2int(ob[k] + lo[k] * w0[k]);
+				ob[k] = hi[k] * w1[k];
+			}
+		}
+		WSYNC();
+	}
+
+	bstore_vec<K>(rS, vb4, SL::ECHON * 4, en);
+	bstore_vec<K>(rS, vb4, SL::INBUF * 4, inb);
+	bstore_vec<K>(rS, vb4, SL::S_ * 4, S);
+	bstore_vec<K>(rS, vb4, SL::SMIN * 4, Smin);
+	bstore_vec<K>(rS, vb4, SL::STMP * 4, Stmp);
+	bstore_vec<K>(rS, vb4, SL::NOISE * 4, noise);
+	bstore_vec<K>(rS, vb4, SL::OLDPS * 4, old_ps);
+	bstore_vec<K>(rS, vb4, SL::ZETA * 4, zeta);
+	bstore_vec<K>(rS, vb4, SL::OUTBUF * 4, ob);
+	if (lane < NB_BANDS) {
+		sm[SL::OLDPS_B + lane] = old_ps_b;
+		sm[SL::ZETA_B + lane] = zeta_b;
+	}
+	if (lane == 0) {
+		a.scal[s].nb_adapt = sc.nb_adapt;
+		a.scal[s].min_count = sc.min_count;
+	}
+}

@@ -3,7 +3,9 @@
 // hands over 480-sample ticks, the echo canceller eats 256-sample frames (speexec.c:252-257,:288), the mixer
 // wants ticks again (audiomixer.c:78-90).
 //
-// One ring of `capacity` int16 samples per stream, [nstreams][capacity] in HBM, plus (head, tail) counters.
+// One ring of `capacity` int16 samples per stream, [nstreams][capacity] in HBM, plus (head index, fill level) per
+// stream -- both always below `capacity`, so a stream can run for any length of time (free-running sample counters
+// would wrap after 2^32 samples = 24.8 h at 48 kHz and, with a capacity that is no power of two, land on another slot).
 // push appends a block (optionally a per-stream count: 0 = nothing this round); pop is all-or-nothing like
 // ms_bufferizer_read (msqueue.c:83): a stream with fewer than `frame` samples keeps them and reports ok = 0
 // (its output row is zero-filled on request, the way the filters inject silence: speexec.c:261-272, audiomixer.c:88).
@@ -14,7 +16,10 @@ namespace {
 
 struct FifoArgs {
 	int16_t *ring;
-	int2 *pos; // (head, tail) as free-running sample counters
+	int2 *pos; // x = head (index of the oldest sample, < capacity), y = level (samples held, <= capacity)
+	const uint8_t *nframes; // push_frames: frames to push per stream; pop_frames with a gate: frames wanted per stream
+	uint8_t *nframes_out;   // pop_frames: frames delivered per stream
+	int max_frames;
 	int nstreams, capacity;
 	const int16_t *in;
 	const int32_t *count; // per-stream samples to push, or null = nsamples for all
@@ -33,16 +38,18 @@ __global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_push_kernel(FifoArgs a) 
 	const int s = blockIdx.x * FIFO_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (s >= a.nstreams) return;
 	if (a.gate && !a.gate[s]) return;
-	const int n = a.count ? min(max(a.count[s], 0), a.nsamples) : a.nsamples;
+	const int n = a.nframes ? min((int)a.nframes[s], a.max_frames) * a.nsamples
+	                        : (a.count ? min(max(a.count[s], 0), a.nsamples) : a.nsamples);
 	if (n == 0) return;
 	const int2 p = a.pos[s];
-	if (p.y - p.x + n > a.capacity) { // would overwrite unread samples: refuse the block, count it
+	if (p.y + n > a.capacity) { // would overwrite unread samples: refuse the block, count it
 		if (lane == 0) atomicAdd(a.overflow, 1);
 		return;
 	}
 	int16_t *r = a.ring + (size_t)s * a.capacity;
 	const int16_t *src = a.in + (size_t)s * a.stride;
-	const unsigned base = (unsigned)p.y % (unsigned)a.capacity;
+	unsigned base = (unsigned)p.x + (unsigned)p.y;
+	if (base >= (unsigned)a.capacity) base -= (unsigned)a.capacity;
 	if (a.vec && ((n | base) & 7) == 0) { // whole 16-byte groups, also across the wrap (capacity % 8 == 0)
 		for (int i = lane; i < (n >> 3); i += 64) {
 			unsigned k = base + 8u * (unsigned)i;
@@ -64,11 +71,11 @@ __global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_pop_kernel(FifoArgs a) {
 	if (s >= a.nstreams) return;
 	const int n = a.nsamples;
 	const int2 p = a.pos[s];
-	const bool take = (!a.gate || a.gate[s]) && (p.y - p.x >= n);
+	const bool take = (!a.gate || a.gate[s]) && (p.y >= n);
 	int16_t *dst = a.out + (size_t)s * a.stride;
 	if (take) {
 		const int16_t *r = a.ring + (size_t)s * a.capacity;
-		const unsigned base = (unsigned)p.x % (unsigned)a.capacity;
+		const unsigned base = (unsigned)p.x;
 		if (a.vec && ((n | base) & 7) == 0) {
 			for (int i = lane; i < (n >> 3); i += 64) {
 				unsigned k = base + 8u * (unsigned)i;
@@ -82,7 +89,11 @@ __global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_pop_kernel(FifoArgs a) {
 				dst[i] = r[k];
 			}
 		}
-		if (lane == 0) a.pos[s] = make_int2(p.x + n, p.y);
+		if (lane == 0) {
+			unsigned h = base + (unsigned)n;
+			if (h >= (unsigned)a.capacity) h -= (unsigned)a.capacity;
+			a.pos[s] = make_int2((int)h, p.y - n);
+		}
 	} else if (a.zero_fill) {
 		if (a.vec && (n & 7) == 0) {
 			for (int i = lane; i < (n >> 3); i += 64) *reinterpret_cast<uint4 *>(dst + 8 * i) = make_uint4(0, 0, 0, 0);
@@ -93,12 +104,49 @@ __global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_pop_kernel(FifoArgs a) {
 	if (lane == 0 && a.ok) a.ok[s] = take ? 1 : 0;
 }
 
+// Up to max_frames whole frames per stream in one launch, back to back in the output row: the `while` of
+// speex_ec_process (speexec.c:256) for a whole tick.  Without a gate a stream delivers as many whole frames as it holds
+// (reported in nframes_out: this is the canceller's per-stream frame count); with a gate it is asked for gate[s] frames
+// and every frame it cannot supply is zero-filled (the silence injected for a short far end, speexec.c:261-272).
+__global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_pop_frames_kernel(FifoArgs a) {
+	const int s = blockIdx.x * FIFO_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (s >= a.nstreams) return;
+	const int n = a.nsamples;
+	const int2 p = a.pos[s];
+	const int have = min(p.y / n, a.max_frames);
+	const int want = a.nframes ? min((int)a.nframes[s], a.max_frames) : have;
+	const int take = min(have, want);
+	int16_t *dst = a.out + (size_t)s * a.stride;
+	const int16_t *r = a.ring + (size_t)s * a.capacity;
+	const int tn = take * n;
+	if (a.vec && ((n | p.x) & 7) == 0) {
+		for (int i = lane; i < (tn >> 3); i += 64) {
+			unsigned k = (unsigned)p.x + 8u * (unsigned)i;
+			if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+			*reinterpret_cast<uint4 *>(dst + 8 * i) = *reinterpret_cast<const uint4 *>(r + k);
+		}
+	} else {
+		for (int i = lane; i < tn; i += 64) {
+			unsigned k = (unsigned)p.x + (unsigned)i;
+			if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+			dst[i] = r[k];
+		}
+	}
+	if (a.zero_fill)
+		for (int i = tn + lane; i < want * n; i += 64) dst[i] = 0;
+	if (lane == 0) {
+		if (take) {
+			unsigned h = (unsigned)p.x + (unsigned)tn;
+			if (h >= (unsigned)a.capacity) h -= (unsigned)a.capacity;
+			a.pos[s] = make_int2((int)h, p.y - tn);
+		}
+		if (a.nframes_out) a.nframes_out[s] = (uint8_t)take;
+	}
+}
+
 __global__ void fifo_level_kernel(FifoArgs a) {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s < a.nstreams) {
-		const int2 p = a.pos[s];
-		a.levels[s] = p.y - p.x;
-	}
+	if (s < a.nstreams) a.levels[s] = a.pos[s].y;
 }
 
 } // namespace
@@ -200,6 +248,41 @@ int mi_fifo_pop(mi_fifo *f, int frame, int16_t *d_out, int stride, uint8_t *d_ok
 	a.zero_fill = zero_fill;
 	a.vec = ((f->capacity | stride) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
 	hipLaunchKernelGGL(fifo_pop_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_push_frames(mi_fifo *f, const int16_t *d_in, int frame, int max_frames, int stride, const uint8_t *d_nframes) {
+	MI_CHECK_ARG(f && d_in && d_nframes && frame > 0 && max_frames > 0 && stride >= frame * max_frames && frame * max_frames <= f->capacity);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.in = d_in;
+	a.nframes = d_nframes;
+	a.max_frames = max_frames;
+	a.nsamples = frame;
+	a.stride = stride;
+	a.vec = ((f->capacity | stride | frame) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15) == 0;
+	hipLaunchKernelGGL(fifo_push_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_pop_frames(mi_fifo *f, int frame, int max_frames, int16_t *d_out, int stride, uint8_t *d_nframes_out,
+                       const uint8_t *d_nframes_wanted, int zero_fill) {
+	MI_CHECK_ARG(f && d_out && frame > 0 && max_frames > 0 && stride >= frame * max_frames && (d_nframes_out || d_nframes_wanted));
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.out = d_out;
+	a.nframes_out = d_nframes_out;
+	a.nframes = d_nframes_wanted;
+	a.max_frames = max_frames;
+	a.nsamples = frame;
+	a.stride = stride;
+	a.zero_fill = zero_fill;
+	a.vec = ((f->capacity | stride | frame) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
+	hipLaunchKernelGGL(fifo_pop_frames_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }

@@ -317,3 +317,65 @@ def test_aec_automatic_overlap_at_scale_is_bit_identical(ctx):
     assert oa[1].any()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 64)])
+def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
+    """mi_aec_process_frames (all the frames of a tick in ONE launch: per-stream state in registers across them, the
+    foreground filter streamed once, the foreground update carried out by the second frame's pass) == the same frames
+    through mi_aec_process one by one: outputs and every state array bit for bit, with per-stream frame counts 0 / 1 / 2
+    changing every tick, through convergence (foreground updates) and a saturating burst (no-gradient frames)."""
+    torch = pytest.importorskip("torch")
+    n, nticks = 6, 150
+    flen = tail_ms * rate // 1000
+    a_tick = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    a_ref = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    rng = np.random.default_rng(17)
+    total = 2 * nticks
+    scenes = [make_echo_scene(40 + s, rate, F * total) for s in range(n)]
+    mic = np.stack([m for m, _ in scenes]).reshape(n, total, F)
+    far = np.stack([f for _, f in scenes]).reshape(n, total, F)
+    mic[2, 60:64] = 32767  # saturation: the gradient is skipped for the following frames
+    pos = np.zeros(n, int)
+    M = (flen + F - 1) // F
+    for t in range(nticks):
+        cnt = rng.integers(0, 3, n).astype(np.uint8)
+        cnt[0] = 2  # one stream always runs two frames
+        cnt[1] = 1
+        m2 = np.zeros((n, 2 * F), np.int16)
+        f2 = np.zeros((n, 2 * F), np.int16)
+        for s in range(n):
+            for k in range(int(cnt[s])):
+                m2[s, k * F:(k + 1) * F] = mic[s, pos[s] + k]
+                f2[s, k * F:(k + 1) * F] = far[s, pos[s] + k]
+        dm, df, dc = torch.from_numpy(m2).cuda(), torch.from_numpy(f2).cuda(), torch.from_numpy(cnt).cuda()
+        out_t = torch.zeros_like(dm)
+        torch.cuda.synchronize()
+        a_tick.process_frames(dm, df, out_t, dc, max_frames=2)
+        out_r = torch.zeros_like(dm)
+        torch.cuda.synchronize()
+        for k in range(2):
+            run = torch.from_numpy((cnt > k).astype(np.uint8)).cuda()
+            mk, fk = dm[:, k * F:(k + 1) * F].contiguous(), df[:, k * F:(k + 1) * F].contiguous()
+            ok = torch.zeros_like(mk)
+            torch.cuda.synchronize()
+            a_ref.process(mk, fk, out=ok, run=run)
+            ctx.sync()
+            out_r[:, k * F:(k + 1) * F] = torch.where(run[:, None].bool(), ok, out_r[:, k * F:(k + 1) * F])
+        ctx.sync()
+        torch.cuda.synchronize()
+        got, ref = out_t.cpu().numpy(), out_r.cpu().numpy()
+        for s in range(n):
+            w = int(cnt[s]) * F
+            assert np.array_equal(got[s, :w], ref[s, :w]), f"tick {t} stream {s} ({cnt[s]} frames)"
+        pos += cnt.astype(int)
+        if t % 25 == 24 or t == nticks - 1:
+            for s in range(n):
+                for what, ln in (("W", M * 2 * F), ("foreground", M * 2 * F), ("X", (M + 1) * 2 * F), ("E", 2 * F), ("power", F + 1),
+                                 ("power_1", F + 1), ("Eh", F + 1), ("Yh", F + 1), ("last_y", 2 * F), ("prop", M), ("scalars", 16)):
+                    x, y = a_tick.get(s, what, ln), a_ref.get(s, what, ln)
+                    assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"tick {t} stream {s}: {what}"
+    adapted = [a_tick.get(s, "scalars", 16)[8] for s in range(n)]
+    assert any(v == 1.0 for v in adapted), "the scene should take at least one stream through adaptation"
+    a_tick.close()
+    a_ref.close()
