@@ -66,10 +66,7 @@ struct AecScalars {
 	float memX, memD, memE, notch0, notch1;
 	int adapted, saturated, screwed_up, cancel_count, xhead;
 	int nb_adapt, min_count;
-	int ly_slot;     // newest slot of the echo-estimate ring (TickLayout::LASTY)
-	int tick_frames; // frames the canceller ran in its last launch (the post-filter of that tick reads it)
-	float leak0;     // leak estimate after the first frame of that launch
-	int pad_;
+	int pad_[4];
 };
 static_assert(sizeof(AecScalars) == 96, "scalar record");
 
@@ -206,8 +203,6 @@ __global__ __launch_bounds__(64) void fft_debug_kernel(const float *in, float *o
 
 } // namespace
 
-constexpr int AEC_CHUNKS = 8;
-
 struct mi_aec {
 	mi_ctx *ctx = nullptr;
 	int nstreams = 0, rate = 0, F = 0, N = 0, M = 0;
@@ -219,12 +214,6 @@ struct mi_aec {
 	int small_stride = 0;
 	std::vector<float> h_prop0;
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
-	// the post-filter of a chunk runs on a second stream while the canceller works on the next chunk
-	hipStream_t s_post = nullptr;
-	hipEvent_t ev_chunk[AEC_CHUNKS] = {}, ev_post = nullptr;
-	hipEvent_t ev_postdone[AEC_CHUNKS] = {}; // per chunk: its post-filter finished (deferred joins)
-	int deferred_chunks = 0;                 // chunks of the last call whose join was deferred (0 = none pending)
-	int overlap_chunks = -1; // -1: automatic (two chunks at F = 256 from 16 384 streams on), 0: off, 2..AEC_CHUNKS: forced
 };
 
 namespace {
@@ -402,7 +391,6 @@ int init_state(mi_aec *a, int first, int count) {
 	std::vector<AecScalars> scs((size_t)count, sc);
 	for (int i = 0; i < count; ++i) memcpy(all.data() + (size_t)i * a->small_stride, small.data(), small.size() * sizeof(float));
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
-	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	MI_HIP(hipMemcpy(a->d_small + (size_t)first * a->small_stride, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
 	MI_HIP(hipMemcpy(a->d_scal + first, scs.data(), scs.size() * sizeof(AecScalars), hipMemcpyHostToDevice));
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N;
@@ -478,19 +466,6 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		mi_aec_destroy(a);
 		return MI_ENOMEM;
 	}
-	if (hipStreamCreateWithFlags(&a->s_post, hipStreamNonBlocking) != hipSuccess ||
-	    hipEventCreateWithFlags(&a->ev_post, hipEventDisableTiming) != hipSuccess) {
-		mi::set_error("mi_aec_create: stream / event creation failed");
-		mi_aec_destroy(a);
-		return MI_ENODEV;
-	}
-	for (hipEvent_t *arr : {a->ev_chunk, a->ev_postdone})
-	for (int i = 0; i < AEC_CHUNKS; ++i)
-		if (hipEventCreateWithFlags(&arr[i], hipEventDisableTiming) != hipSuccess) {
-			mi::set_error("mi_aec_create: event creation failed");
-			mi_aec_destroy(a);
-			return MI_ENODEV;
-		}
 	rc = mi_aec_reset(a, 0, nstreams);
 	if (rc != MI_OK) {
 		mi_aec_destroy(a);
@@ -509,15 +484,6 @@ void mi_aec_destroy(mi_aec *a) {
 	if (a->d_small) (void)hipFree(a->d_small);
 	if (a->d_scal) (void)hipFree(a->d_scal);
 	if (a->d_tables) (void)hipFree(a->d_tables);
-	if (a->s_post) {
-		(void)hipStreamSynchronize(a->s_post);
-		(void)hipStreamDestroy(a->s_post);
-	}
-	for (hipEvent_t e : a->ev_chunk)
-		if (e) (void)hipEventDestroy(e);
-	for (hipEvent_t e : a->ev_postdone)
-		if (e) (void)hipEventDestroy(e);
-	if (a->ev_post) (void)hipEventDestroy(a->ev_post);
 	delete a;
 }
 
@@ -528,9 +494,8 @@ int mi_aec_reset(mi_aec *a, int first, int count) {
 	return a->F == 256 ? init_state<256>(a, first, count) : (a->F == 128 ? init_state<128>(a, first, count) : init_state<64>(a, first, count));
 }
 
-int mi_aec_set_overlap(mi_aec *a, int chunks) {
-	MI_CHECK_ARG(a && (chunks == -1 || chunks == 0 || (chunks >= 2 && chunks <= AEC_CHUNKS)));
-	a->overlap_chunks = chunks;
+int mi_aec_set_overlap(mi_aec *a, int chunks) { // kept for ABI 1 callers: there is no second launch to overlap any more
+	MI_CHECK_ARG(a && (chunks == -1 || chunks == 0 || (chunks >= 2 && chunks <= 8)));
 	return MI_OK;
 }
 
@@ -568,77 +533,13 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.ss_1 = a->ss_1;
 	g.sampling_rate = a->rate;
 	g.t = a->t;
-	// One wavefront per stream and TICK: the canceller for every frame the stream has ready, then (optionally) the
-	// post-filter for the same frames as its own launch.  At 256-sample frames the canceller is HBM-bound with the VALUs
-	// partly idle and the post-filter VALU-bound with HBM mostly idle: a big batch is cut into chunks, the cancellers run
-	// back to back on the context's stream and a chunk's post-filter on a second stream next to the next chunk's canceller.
-	auto launch_mdf = [&](int first, int count) {
-		g.first = first;
-		if (a->F == 256) hipLaunchKernelGGL(aec_mdf_tick_kernel<256>, dim3(count), dim3(64), 0, a->ctx->stream, g);
-		else if (a->F == 128) hipLaunchKernelGGL(aec_mdf_tick_kernel<128>, dim3(count), dim3(64), 0, a->ctx->stream, g);
-		else hipLaunchKernelGGL(aec_mdf_tick_kernel<64>, dim3(count), dim3(64), 0, a->ctx->stream, g);
-	};
-	auto launch_post = [&](int first, int count, hipStream_t st) {
-		g.first = first;
-		if (a->F == 256) hipLaunchKernelGGL(aec_post_tick_kernel<256>, dim3(count), dim3(64), 0, st, g);
-		else if (a->F == 128) hipLaunchKernelGGL(aec_post_tick_kernel<128>, dim3(count), dim3(64), 0, st, g);
-		else hipLaunchKernelGGL(aec_post_tick_kernel<64>, dim3(count), dim3(64), 0, st, g);
-	};
-	static const bool no_overlap = getenv("MSMI355X_AEC_NO_OVERLAP") != nullptr; // A/B switch
-	static const int env_chunks = [] {
-		const char *e = getenv("MSMI355X_AEC_CHUNKS");
-		const int v = e ? atoi(e) : 0;
-		return v >= 2 && v <= AEC_CHUNKS ? v : 2;
-	}();
-	const bool post = (flags & MI_AEC_POSTFILTER) != 0;
-	int nchunks = a->overlap_chunks;
-	if (nchunks < 0) // measured: +5 % at F=256, nothing at 128, -6 % at 64
-		nchunks = (a->F == 256 && a->nstreams >= 16384 && !no_overlap) ? env_chunks : 0;
-	nchunks = std::min(nchunks, a->nstreams);
-	if (!post || nchunks < 2 || (a->deferred_chunks && a->deferred_chunks != nchunks)) {
-		if (a->deferred_chunks) { // a deferred join is pending and this call is not chunked the same way: join first
-			MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0));
-			a->deferred_chunks = 0;
-		}
-	}
-	if (!post || nchunks < 2) {
-		launch_mdf(0, a->nstreams);
-		MI_LAUNCH_CHECK();
-		if (post) {
-			launch_post(0, a->nstreams, a->ctx->stream);
-			MI_LAUNCH_CHECK();
-		}
-		return MI_OK;
-	}
-	static const int split_pct = [] { // two chunks: share of the first one (A/B knob, default below)
-		const char *e = getenv("MSMI355X_AEC_SPLIT");
-		const int v = e ? atoi(e) : 0;
-		return v >= 10 && v <= 95 ? v : 50;
-	}();
-	const int per = (a->nstreams + nchunks - 1) / nchunks;
-	const int cut = nchunks == 2 ? std::max(1, std::min(a->nstreams - 1, (int)((long long)a->nstreams * split_pct / 100))) : 0;
-	for (int c = 0; c < nchunks; ++c) {
-		const int first = nchunks == 2 ? (c == 0 ? 0 : cut) : c * per;
-		const int count = nchunks == 2 ? (c == 0 ? cut : a->nstreams - cut) : std::min(per, a->nstreams - first);
-		if (count <= 0) break;
-		// after a deferred join this chunk's previous post-filter may still run: its canceller state is read by it
-		if (a->deferred_chunks) MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_postdone[c], 0));
-		launch_mdf(first, count);
-		MI_LAUNCH_CHECK();
-		MI_HIP(hipEventRecord(a->ev_chunk[c], a->ctx->stream));
-		MI_HIP(hipStreamWaitEvent(a->s_post, a->ev_chunk[c], 0));
-		launch_post(first, count, a->s_post);
-		MI_LAUNCH_CHECK();
-		MI_HIP(hipEventRecord(a->ev_postdone[c], a->s_post));
-	}
-	MI_HIP(hipEventRecord(a->ev_post, a->s_post));
-	static const bool no_defer = getenv("MSMI355X_AEC_NO_DEFER") != nullptr; // A/B switch
-	if ((flags & MI_AEC_DEFER_JOIN) && !no_defer) {
-		a->deferred_chunks = nchunks; // the caller reads the outputs after mi_aec_join(); the next call orders itself per chunk
-	} else {
-		MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0)); // the caller's stream continues after the last post-filter
-		a->deferred_chunks = 0;
-	}
+	// One wavefront per stream and TICK: the canceller for every frame the stream has ready and, with MI_AEC_POSTFILTER, the
+	// post-filter of the same frames as the wave's tail phase (aec_tick.hpp).  One launch, on the context's stream.
+	g.first = 0;
+	if (a->F == 256) hipLaunchKernelGGL(aec_tick_kernel<256>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	else if (a->F == 128) hipLaunchKernelGGL(aec_tick_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	else hipLaunchKernelGGL(aec_tick_kernel<64>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
 
@@ -655,12 +556,8 @@ int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref,
 	return aec_launch(a, d_mic, d_ref, d_out, stride, nullptr, d_count, max_frames, flags);
 }
 
-int mi_aec_join(mi_aec *a) {
+int mi_aec_join(mi_aec *a) { // kept for ABI 1 callers: the post-filter is part of the one launch, nothing is ever pending
 	MI_CHECK_ARG(a != nullptr);
-	if (!a->deferred_chunks) return MI_OK;
-	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
-	MI_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_post, 0));
-	a->deferred_chunks = 0;
 	return MI_OK;
 }
 
@@ -668,7 +565,6 @@ int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, i
                         const uint8_t *h_run, unsigned flags) {
 	MI_CHECK_ARG(a && h_mic && h_ref && h_out);
 	mi_ctx *c = a->ctx;
-	flags &= ~MI_AEC_DEFER_JOIN; // the copy back follows at once
 	if (c->activate() != MI_OK) return MI_ENODEV;
 	const size_t b = (size_t)a->nstreams * stride * sizeof(int16_t);
 	void *dm, *dr, *dout, *drun = nullptr;
@@ -696,7 +592,6 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	MI_CHECK_ARG(a && what && h_dst && stream >= 0 && stream < a->nstreams);
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
-	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const int F = a->F, N = a->N, M = a->M;
 	auto unpack = [&](const float *src, float *dst) { // [DC,Nyq,re1,im1,..] -> [DC,re1,im1,..,Nyq]
 		dst[0] = src[0];
@@ -738,11 +633,8 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	else if (!strcmp(what, "power_1")) res = with_tail(o_p1, 1);
 	else if (!strcmp(what, "Eh")) res = with_tail(o_eh, 2);
 	else if (!strcmp(what, "Yh")) res = with_tail(o_yh, 3);
-	else if (!strcmp(what, "last_y")) { // [older frame | newest frame] out of the ring of three
-		const int nw = sc.ly_slot, od = (sc.ly_slot + 2) % 3;
-		res.assign(small.begin() + o_ly + od * F, small.begin() + o_ly + od * F + F);
-		res.insert(res.end(), small.begin() + o_ly + nw * F, small.begin() + o_ly + nw * F + F);
-	} else if (!strcmp(what, "prop")) res.assign(small.begin() + o_prop, small.begin() + o_prop + M);
+	else if (!strcmp(what, "last_y")) res.assign(small.begin() + o_ly, small.begin() + o_ly + N); // [older | newest]
+	else if (!strcmp(what, "prop")) res.assign(small.begin() + o_prop, small.begin() + o_prop + M);
 	else if (!strcmp(what, "scalars")) {
 		res = {sc.Davg1, sc.Davg2, sc.Dvar1, sc.Dvar2, sc.Pey, sc.Pyy, sc.sum_adapt, sc.leak_estimate,
 		       (float)sc.adapted, (float)sc.saturated, (float)sc.screwed_up, (float)sc.cancel_count,
@@ -773,7 +665,6 @@ int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap) {
 	MI_CHECK_ARG(a && h_blob && stream >= 0 && stream < a->nstreams && cap >= mi_aec_blob_bytes(a));
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
-	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
 	BlobHeader h = {{'M', 'I', 'E', 'C'}, 2u, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
 	uint8_t *p = (uint8_t *)h_blob;
@@ -808,7 +699,6 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 	}
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
-	if (a->s_post) MI_HIP(hipStreamSynchronize(a->s_post)); // post-filters of a deferred join may still be running
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
 	const uint8_t *p = (const uint8_t *)h_blob + sizeof(h);
 	MI_HIP(hipMemcpy(a->d_X + (size_t)stream * xn, p, xn * 4, hipMemcpyHostToDevice));

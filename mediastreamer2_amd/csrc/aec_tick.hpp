@@ -12,8 +12,13 @@
 //     and the copy itself degenerates into stores of the blocks that pass already holds (no second read of W);
 //   * nothing else changes: every sum keeps the library's operand order, so results are bit-identical to the per-frame
 //     kernels (tests/test_gpu_aec.py compares both with the oracle).
+//   * the residual-echo / noise post-filter (speex_preprocess_run) runs as the TAIL PHASE of the same wavefront: the
+//     canceller is HBM-bound and the post-filter VALU-bound, so waves in their post-filter phase leave the memory system
+//     to the waves that are streaming -- the overlap two launches on two HIP streams only approximated (a separate
+//     post-filter launch kept HBM idle for 17 % of the tick); the canceller's output frames and echo estimates reach the
+//     post-filter through LDS instead of HBM.
 // Cost: the second frame's far-end spectrum is needed early, and ~50 more live registers: 2 waves per SIMD at F = 256
-// instead of 3 (measured on the per-frame kernel: 1.5 % slower per launch at that occupancy; the bytes saved are ~15 %).
+// instead of 3 (measured on the per-frame kernel: 1.5 % slower per launch at that occupancy; the bytes saved are ~20 %).
 
 template <int F>
 struct TickLayout { // offsets in floats inside the per-stream small-state block
@@ -23,7 +28,7 @@ struct TickLayout { // offsets in floats inside the per-stream small-state block
 	static constexpr int POWER1 = 4 * F;
 	static constexpr int EH = 5 * F;
 	static constexpr int YH = 6 * F;
-	static constexpr int LASTY = 7 * F;      // 3F  ring of three echo-estimate frames (AecScalars::ly_slot = newest)
+	static constexpr int LASTY = 7 * F;      // 2F  echo estimate of the last two frames [older | newest] (3F reserved)
 	static constexpr int ECHON = 10 * F;     // post-filter
 	static constexpr int INBUF = 11 * F;
 	static constexpr int OUTBUF = 12 * F;
@@ -59,7 +64,13 @@ struct alignas(16) TLds {
 #endif
 	float prop[64], wnorm[64];
 	// per-bin state that is not needed while the blocks stream: parked here instead of in registers
-	float pw[F], eh[F], yh[F], lprev[F], input[F];
+	float pw[F], eh[F], yh[F], input[F];
+	// canceller -> post-filter hand-over: echo estimates [before the tick | after frame 1 | after frame 2], output frames
+	float ly[3][F];
+	int16_t outf[2][F];
+	// the post-filter phase reuses the parked arrays (their contents are in HBM by then)
+	__device__ float *vec() { return pw; }        // F
+	__device__ float *band() { return eh; }       // 4 * NB_BANDS + 8
 };
 
 
@@ -159,13 +170,16 @@ __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K]
 #ifndef AEC_TICK_OCC256
 #define AEC_TICK_OCC256 2
 #endif
-#ifndef AEC_TICK_PF
-#define AEC_TICK_PF 1 /* blocks in flight behind the one at hand: 1 or 2 */
+#ifndef AEC_TICK_PF_A
+#define AEC_TICK_PF_A 1 /* blocks in flight behind the one at hand, frame 1's pass (X, FG, W): 1 or 2 */
+#endif
+#ifndef AEC_TICK_PF_B
+#define AEC_TICK_PF_B 1 /* the same for frame 2's pass (X, W) */
 #endif
 
 // ===================================================================== MDF canceller, the frames of one tick
 template <int F>
-__global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4))) void aec_mdf_tick_kernel(AecArgs a) {
+__global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
 	using SL = TickLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
@@ -209,8 +223,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		store_vec<K>(L.eh + e0, t);
 		bload_vec<K>(rS, vb4, SL::YH * 4, t);
 		store_vec<K>(L.yh + e0, t);
-		bload_vec<K>(rS, vb4, (SL::LASTY + (sc.ly_slot) * F) * 4, t);
-		store_vec<K>(L.lprev + e0, t);
+		bload_vec<K>(rS, vb4, (SL::LASTY + F) * 4, t);
+		store_vec<K>(L.ly[0] + e0, t);
 	}
 	float pw_F = sm[SL::TAIL + 0], p1_F = sm[SL::TAIL + 1], eh_F = sm[SL::TAIL + 2], yh_F = sm[SL::TAIL + 3];
 	bool prop_dirty = false;
@@ -256,7 +270,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 #pragma unroll
 	for (int k = 0; k < K; ++k) spec2[k] = make_float2(0, 0);
 	bool pendingFG = false; // frame 1 asked for foreground := background; frame 2's pass carries the copy out
-	float leak0 = sc.leak_estimate;
+	const bool postfilter = (a.flags & 1) != 0; // MI_AEC_POSTFILTER
+	float leakf[2] = {sc.leak_estimate, sc.leak_estimate}; // leak estimate after each frame (post-filter input)
+	bool resetf[2] = {false, false};                       // the frame reset the canceller: its echo estimate is zero
 
 	for (int f = 0; f < nf; ++f) {
 		// ---- near end: saturation flag, DC notch (serial IIR), pre-emphasis
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			bload_bins<K>(rX, vb8, xoff(1), xn);
 			bload_bins<K>(rF, vb8, 0, fg);
 			bload_bins<K>(rW, vb8, 0, wl);
-#if AEC_TICK_PF == 2
+#if AEC_TICK_PF_A == 2
 			float2 xn2[K], fg2[K], wl2[K]; // two blocks in flight behind the one at hand
 #pragma unroll
 			for (int k = 0; k < K; ++k) xn2[k] = fg2[k] = wl2[k] = make_float2(0, 0);
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 #endif
 			for (int j = 0; j < M; ++j) {
-#if AEC_TICK_PF == 2
+#if AEC_TICK_PF_A == 2
 				float2 xn3[K], fg3[K], wl3[K];
 				if (j + 2 < M) {
 					bload_bins<K>(rX, vb8, xoff(j + 3), xn3);
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 				norm_of(wl, j);
 #pragma unroll
 				for (int k = 0; k < K; ++k) xm1[k] = xj[k], xj[k] = xn[k], xn[k] = xn2[k], fg[k] = fg2[k], wl[k] = wl2[k];
-#if AEC_TICK_PF == 2
+#if AEC_TICK_PF_A == 2
 #pragma unroll
 				for (int k = 0; k < K; ++k) xn2[k] = xn3[k], fg2[k] = fg3[k], wl2[k] = wl3[k];
 #endif
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			for (int k = 0; k < K; ++k) xj[k] = X0[k], alt[k] = make_float2(0, 0);
 			bload_bins<K>(rX, vb8, xoff(1), xn);
 			bload_bins<K>(rW, vb8, 0, wl);
-#if AEC_TICK_PF == 2
+#if AEC_TICK_PF_B == 2
 			float2 xn2[K], wl2[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) xn2[k] = wl2[k] = make_float2(0, 0);
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 #endif
 			for (int j = 0; j < M; ++j) {
-#if AEC_TICK_PF == 2
+#if AEC_TICK_PF_B == 2
 				float2 xn3[K], wl3[K];
 				if (j + 2 < M) {
 					bload_bins<K>(rX, vb8, xoff(j + 3), xn3);
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 				norm_of(wl, j);
 #pragma unroll
 				for (int k = 0; k < K; ++k) xj[k] = xn[k], xn[k] = xn2[k], wl[k] = wl2[k];
-#if AEC_TICK_PF == 2
+#if AEC_TICK_PF_B == 2
 #pragma unroll
 				for (int k = 0; k < K; ++k) xn2[k] = xn3[k], wl2[k] = wl3[k];
 #endif
@@ -633,7 +649,13 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			for (int k = 0; k < K; ++k) out_i[k] = 0;
 		}
 		int16_t *op = a.out + (size_t)s * a.stride + f * F + e0;
-		const int ly_new = (sc.ly_slot + 1) % 3;
+		auto emit = [&](const int (&o)[K]) { // to the post-filter phase through LDS, else straight out
+#pragma unroll
+			for (int k = 0; k < K; ++k) {
+				if (postfilter) L.outf[f][e0 + k] = (int16_t)o[k];
+				else op[k] = (int16_t)o[k];
+			}
+		};
 		if (sc.screwed_up >= 50) { // speex_echo_state_reset
 			float z[K];
 			float2 z2[K];
@@ -653,7 +675,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			store_vec<K>(L.pw + e0, z);
 			store_vec<K>(L.eh + e0, z);
 			store_vec<K>(L.yh + e0, z);
-			store_vec<K>(L.lprev + e0, z);
+			store_vec<K>(L.ly[f + 1] + e0, z);
 			pw_F = eh_F = yh_F = 0.f;
 			p1_F = 1.0f;
 			WSYNC();
@@ -670,11 +692,10 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			sc.sum_adapt = 0;
 			sc.Pey = sc.Pyy = 1.0f;
 			sc.Davg1 = sc.Davg2 = sc.Dvar1 = sc.Dvar2 = 0;
-			sc.ly_slot = ly_new;
 			pendingFG = false;
-			if (f == 0) leak0 = sc.leak_estimate;
-#pragma unroll
-			for (int k = 0; k < K; ++k) op[k] = (int16_t)out_i[k];
+			if (f) resetf[1] = true, leakf[1] = sc.leak_estimate;
+			else resetf[0] = true, leakf[0] = sc.leak_estimate;
+			emit(out_i);
 			if (f + 1 < nf) { // the next frame starts from the reset far-end state
 				float xn[K];
 				prep_far(f + 1, z, xn, X0, Sxx);
@@ -762,17 +783,15 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		// ---- echo estimate of this frame for the residual-echo stage (ring of three frames)
 		{
 			float ln[K], lprev[K];
-			load_vec<K>(L.lprev + e0, lprev);
+			load_vec<K>(L.ly[f] + e0, lprev);
 			const int16_t *mp = a.mic + (size_t)s * a.stride + f * F + e0;
 #pragma unroll
 			for (int k = 0; k < K; ++k) ln[k] = sc.adapted ? (float)((int)mp[k] - out_i[k]) : lprev[k];
-			bstore_vec<K>(rS, vb4, (SL::LASTY + (ly_new) * F) * 4, ln);
-			store_vec<K>(L.lprev + e0, ln);
-			sc.ly_slot = ly_new;
+			store_vec<K>(L.ly[f + 1] + e0, ln);
 		}
-		if (f == 0) leak0 = sc.leak_estimate;
-#pragma unroll
-		for (int k = 0; k < K; ++k) op[k] = (int16_t)out_i[k];
+		if (f) leakf[1] = sc.leak_estimate;
+		else leakf[0] = sc.leak_estimate;
+		emit(out_i);
 #pragma unroll
 		for (int k = 0; k < K; ++k) X0[k] = X0B[k]; // the frame behind this one, if any
 		Sxx = SxxB;
@@ -795,39 +814,29 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		sm[SL::WNORM + lane] = L.wnorm[lane];
 		if (prop_dirty) sm[SL::PROP + lane] = L.prop[lane];
 	}
+	{ // echo estimate of the last frame's pair [older | newest]
+		float lo[K], ln[K];
+		load_vec<K>(L.ly[nf - 1] + e0, lo);
+		load_vec<K>(L.ly[nf] + e0, ln);
+		if (nf > 1 ? resetf[1] : resetf[0]) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) lo[k] = 0.f;
+		}
+		bstore_vec<K>(rS, vb4, SL::LASTY * 4, lo);
+		bstore_vec<K>(rS, vb4, (SL::LASTY + F) * 4, ln);
+	}
 	if (lane == 0) {
 		sm[SL::TAIL + 0] = pw_F;
 		sm[SL::TAIL + 1] = p1_F;
 		sm[SL::TAIL + 2] = eh_F;
 		sm[SL::TAIL + 3] = yh_F;
-		sc.leak0 = leak0;
-		sc.tick_frames = nf;
-		a.scal[s] = sc;
 	}
-}
+	if (!postfilter) {
+		if (lane == 0) a.scal[s] = sc;
+		return;
+	}
+	WSYNC(); // the parked arrays are re-used from here on
 
-// ===================================================================== post-filter, the frames of one tick
-template <int F>
-__global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
-	__shared__ WLds<F> L;
-	using SL = TickLayout<F>;
-	constexpr int K = F / 64;
-	const int s = a.first + blockIdx.x;
-	int nf = a.count ? (int)a.count[s] : ((a.run && !a.run[s]) ? 0 : 1);
-	if (nf > a.max_frames) nf = a.max_frames;
-	if (nf <= 0) return;
-	const int lane = threadIdx.x;
-	const int e0 = lane * K;
-	float *sm = a.small + (size_t)s * a.small_stride;
-	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
-	const unsigned vb4 = (unsigned)e0 * 4u;
-	AecScalars sc = a.scal[s];
-#pragma unroll
-	for (int k = 0; k < K; ++k) {
-		L.tw[e0 + k] = a.t.tw[e0 + k];
-		L.super[e0 + k] = a.t.super[e0 + k];
-		L.perm[e0 + k] = a.t.perm[e0 + k];
-	}
 	// per-bin state of the tick, in registers
 	float en[K], inb[K], S[K], Smin[K], Stmp[K], noise[K], old_ps[K], zeta[K], ob[K], wl[K], wr[K], h0[K], h1[K], w0[K], w1[K];
 	bload_vec<K>(rS, vb4, SL::ECHON * 4, en);
@@ -850,11 +859,9 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 		old_ps_b = sm[SL::OLDPS_B + lane];
 		zeta_b = sm[SL::ZETA_B + lane];
 	}
-	// echo-estimate ring: the canceller left its newest frame in slot ly_slot; frame f of this tick reads slots
-	// (base + f, base + f + 1) with base = ly_slot - frames it wrote
-	const int base = (sc.ly_slot - sc.tick_frames + 6) % 3;
 	float *pl = L.spec, *pr = L.spec + F;
-	float *bandv = L.band;
+	float *bandv = L.band();
+	float *lvec = L.vec();
 
 	for (int f = 0; f < nf; ++f) {
 		sc.nb_adapt++;
@@ -863,15 +870,16 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 		float beta = 1.0f / sc.nb_adapt;
 		if (beta < .03f) beta = .03f;
 		const float beta_1 = 1.0f - beta;
-		const float leak = (f + 1 < sc.tick_frames) ? sc.leak0 : sc.leak_estimate;
+		const float leak = f ? leakf[1] : leakf[0];
+		const bool was_reset = f ? resetf[1] : resetf[0];
 
 		// residual echo spectrum (speex_echo_get_residual)
 		{
 			float lo[K], ln[K];
-			bload_vec<K>(rS, vb4, (SL::LASTY + (((base + f) % 3)) * F) * 4, lo);
-			bload_vec<K>(rS, vb4, (SL::LASTY + (((base + f + 1) % 3)) * F) * 4, ln);
+			load_vec<K>(L.ly[f] + e0, lo);
+			load_vec<K>(L.ly[f + 1] + e0, ln);
 #pragma unroll
-			for (int k = 0; k < K; ++k) lo[k] = h0[k] * lo[k], ln[k] = h1[k] * ln[k];
+			for (int k = 0; k < K; ++k) lo[k] = h0[k] * (was_reset ? 0.f : lo[k]), ln[k] = h1[k] * ln[k];
 			WSYNC();
 			store_vec<K>(L.tbuf + e0, lo);
 			store_vec<K>(L.tbuf + F + e0, ln);
@@ -901,7 +909,7 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 			float xcur[K], a0[K], a1[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
-				xcur[k] = (float)op[k];
+				xcur[k] = (float)L.outf[f][e0 + k];
 				a0[k] = inb[k] * w0[k];
 				a1[k] = xcur[k] * w1[k];
 				inb[k] = xcur[k];
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			ps[k] = (e0 + k == 0) ? ft[k].x * ft[k].x : ft[k].x * ft[k].x + ft[k].y * ft[k].y;
-			L.vec[e0 + k] = ps[k];
+			lvec[e0 + k] = ps[k];
 			pl[e0 + k] = wl[k] * ps[k];
 			pr[e0 + k] = wr[k] * ps[k];
 		}
@@ -933,7 +941,7 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 		for (int k = 0; k < K; ++k) {
 			const int b = e0 + k;
 			if (b == 0 || b == F - 1) S[k] = .8f * S[k] + .2f * ps[k];
-			else S[k] = .8f * S[k] + .05f * L.vec[b - 1] + .1f * ps[k] + .05f * L.vec[b + 1];
+			else S[k] = .8f * S[k] + .05f * lvec[b - 1] + .1f * ps[k] + .05f * lvec[b + 1];
 			if (sc.nb_adapt == 1) Smin[k] = Stmp[k] = 0;
 			if (sc.min_count > min_range) {
 				Smin[k] = Stmp[k] < S[k] ? Stmp[k] : S[k];
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 		for (int k = 0; k < K; ++k) {
 			if (sc.nb_adapt == 1) old_ps[k] = ps[k];
 			snr(ps[k], noise[k], en[k], old_ps[k], post[k], prior[k]);
-			L.vec[e0 + k] = prior[k];
+			lvec[e0 + k] = prior[k];
 		}
 		float post_b = 0, prior_b = 0, ps_b = 0;
 		if (lane < NB_BANDS) {
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 		for (int k = 0; k < K; ++k) {
 			const int b = e0 + k;
 			if (b == 0 || b >= F - 1) zeta[k] = .7f * zeta[k] + .3f * prior[k];
-			else zeta[k] = .7f * zeta[k] + .15f * prior[k] + .075f * L.vec[b - 1] + .075f * L.vec[b + 1];
+			else zeta[k] = .7f * zeta[k] + .15f * prior[k] + .075f * lvec[b - 1] + .075f * lvec[b + 1];
 		}
 		if (lane < NB_BANDS) zeta_b = .7f * zeta_b + .3f * prior_b;
 		float Zframe = 0;
@@ -1075,8 +1083,7 @@ __global__ __launch_bounds__(64) void aec_post_tick_kernel(AecArgs a) {
 		sm[SL::OLDPS_B + lane] = old_ps_b;
 		sm[SL::ZETA_B + lane] = zeta_b;
 	}
-	if (lane == 0) {
-		a.scal[s].nb_adapt = sc.nb_adapt;
-		a.scal[s].min_count = sc.min_count;
-	}
+
+	if (lane == 0) a.scal[s] = sc;
 }
+

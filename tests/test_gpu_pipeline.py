@@ -72,6 +72,63 @@ def test_fifo_matches_bufferizer_model(ctx):
     f.close()
 
 
+def test_fifo_frame_ops_for_a_whole_tick_match_the_frame_by_frame_ones(ctx):
+    """pop_frames / push_frames (the while loop of speexec.c:256 for a whole tick in one launch) == the model popped and
+    pushed one frame at a time: as many whole frames as a stream holds (<= 2), the far end asked for the same number with
+    silence for the frames it cannot supply (speexec.c:261-272), rings of a capacity that is no power of two wrapping
+    many times."""
+    torch = pytest.importorskip("torch")
+    n, cap, F = 29, 1480, 256
+    f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, cap) for _ in range(3))
+    m_mic, m_ref, m_out = NpFifo(n), NpFifo(n), NpFifo(n)
+    rng = np.random.default_rng(5)
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    micf, reff, cnt, got = z(n, 2 * F), z(n, 2 * F), z(n, dt=torch.uint8), z(n, dt=torch.uint8)
+    tick, okt = z(n, 480), z(n, dt=torch.uint8)
+    for step in range(200):
+        blk = rng.integers(-32768, 32768, (n, 480), dtype=np.int16)
+        rblk = rng.integers(-32768, 32768, (n, 480), dtype=np.int16)
+        rcnt = rng.choice([480, 480, 480, 0, 200], n).astype(np.int32)  # the far end sometimes runs short
+        d_blk, d_rblk, d_rcnt = torch.from_numpy(blk).cuda(), torch.from_numpy(rblk).cuda(), torch.from_numpy(rcnt).cuda()
+        torch.cuda.synchronize()
+        f_mic.push(d_blk)
+        f_ref.push(d_rblk, nsamples=480, count=d_rcnt)
+        m_mic.push(blk)
+        m_ref.push(rblk, rcnt)
+        f_mic.pop_frames(F, 2, micf, nframes_out=cnt)
+        f_ref.pop_frames(F, 2, reff, nframes_out=got, wanted=cnt, zero_fill=True)
+        f_out.push_frames(micf, F, 2, cnt)  # what a canceller would hand on: here the frames themselves
+        f_out.pop(480, tick, ok=okt, zero_fill=True)
+        ctx.sync()
+        w_cnt = np.zeros(n, np.uint8)
+        w_mic, w_ref = np.zeros((n, 2 * F), np.int16), np.zeros((n, 2 * F), np.int16)
+        w_got = np.zeros(n, np.uint8)
+        for r in range(2):
+            a, ok = m_mic.pop(F)
+            b, okr = m_ref.pop(F, gate=ok)
+            for s in range(n):
+                if ok[s]:
+                    w_mic[s, r * F:(r + 1) * F] = a[s]
+                    w_ref[s, r * F:(r + 1) * F] = b[s]  # zeros when the far end was short
+                    w_cnt[s] += 1
+                    w_got[s] += okr[s]
+            m_out.push(a, ok.astype(np.int32) * F)
+        w_tick, w_okt = m_out.pop(480)
+        c = cnt.cpu().numpy()
+        np.testing.assert_array_equal(c, w_cnt)
+        np.testing.assert_array_equal(got.cpu().numpy(), w_got)
+        gm, gr = micf.cpu().numpy(), reff.cpu().numpy()
+        for s in range(n):
+            np.testing.assert_array_equal(gm[s, :int(c[s]) * F], w_mic[s, :int(c[s]) * F])
+            np.testing.assert_array_equal(gr[s, :int(c[s]) * F], w_ref[s, :int(c[s]) * F])
+        np.testing.assert_array_equal(okt.cpu().numpy(), w_okt)
+        np.testing.assert_array_equal(tick.cpu().numpy(), w_tick)
+    assert f_mic.overflows() + f_ref.overflows() + f_out.overflows() == 0
+    assert (np.array([len(q) for q in m_mic.q]) < F).all()
+    for f in (f_mic, f_ref, f_out):
+        f.close()
+
+
 def test_chained_tick_pipeline_stage_parity(ctx, oracle):
     torch = pytest.importorskip("torch")
     nconf, mm = 2, 32
