@@ -14,121 +14,309 @@
 // graphs of the next tick, msticker.c:301-312) launches every staged pool: one kernel per
 // filter type for all streams.  Cost: one tick (10 ms) of added latency per GPU filter; this
 // is the only scheduling-compatible option without touching the ticker.
+//
+// Runtime: everything is per TICKER.  A TickerHub owns the pools of the filters one MSTicker
+// thread runs, its own mi_ctx (HIP stream) and its own mutex: process() of filters on different tickers never contend.
+// Pools are banks of geometrically growing capacity (16, 64, 256, ... slots): a ticker with one call uploads 16 rows, a
+// ticker with ten thousand legs gets there in six banks; a bank is destroyed (device objects, pinned buffers) when its
+// last slot is released and the hub with its last bank.  No runtime error aborts the host process: a failing kernel
+// library call marks the bank failed, its filters drop their blocks and count a late event, and when no HIP device
+// can be opened at load time the plugin registers nothing and the reference's own filters stay in charge.
 #include "../../include/ms2_plugin_abi.h"
 #include "../../include/msmi355x.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
+#include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 namespace {
 
 constexpr int kMaxRounds = 4; // blocks one stream may hand over within a single tick
 
-[[noreturn]] void die(const char *what) {
+struct TickerHub;
+struct Pool;
+thread_local Pool *tl_building = nullptr; // the bank whose constructor is running (allocations register with it)
+std::atomic<uint64_t> g_late_events{0};   // blocks dropped or passed through because the GPU path failed
+
+// A kernel-library call failed: no abort (this plugin sits inside a media server).  The bank under construction / at
+// hand is marked failed by the caller; the event is logged and counted.
+bool mi_failed(const char *what) {
 	ms_error("msmi355x plugin: %s: %s", what, mi_last_error());
-	fprintf(stderr, "msmi355x plugin: %s: %s (there is no CPU fallback)\n", what, mi_last_error());
-	abort();
+	g_late_events.fetch_add(1, std::memory_order_relaxed);
+	return true;
 }
-#define MI_MUST(expr)                     \
-	do {                                  \
-		if ((expr) != MI_OK) die(#expr);  \
+
+// a kernel-library call that must not fail: logged and counted, never fatal.  Inside a bank's member functions
+// (constructor, flush) name lookup finds Pool::mark_failed and the bank stops being used; elsewhere the free function.
+inline void mark_failed() {}
+#define MI_MUST(expr)              \
+	do {                           \
+		if ((expr) != MI_OK) {     \
+			mi_failed(#expr);      \
+			mark_failed();         \
+		}                          \
 	} while (0)
 
 struct Pool {
-	virtual ~Pool() {}
-	virtual void flush() = 0;               // launch the staged blocks, fetch the results
-	virtual void emit(MSFilter *f, int slot) = 0; // hand a slot's results to its filter's output queues
-	std::vector<uint8_t> used;
+	virtual ~Pool();
+	virtual void flush() = 0;                      // launch the staged blocks, fetch the results
+	virtual void emit(MSFilter *f, int slot) = 0;  // hand a slot's results to its filter's output queues
+	TickerHub *hub = nullptr;
+	std::string key;
 	std::vector<MSFilter *> owner;
-	MSTicker *ticker = nullptr; // a pool serves the filters of ONE ticker thread
-	int capacity = 0;
+	std::vector<int> free_list; // O(1) acquire / release
+	std::vector<void *> host_allocs, dev_allocs;
+	int capacity = 0, in_use = 0;
+	int hi = 0;          // slots [0, hi) have been handed out at some point: what flush() needs to look at
+	bool failed = false; // a kernel-library call failed: the bank's filters stop using the GPU path
+	void mark_failed() { failed = true; }
 	void init_slots(int cap) {
 		capacity = cap;
-		used.assign((size_t)cap, 0);
 		owner.assign((size_t)cap, nullptr);
+		free_list.resize((size_t)cap);
+		for (int i = 0; i < cap; ++i) free_list[(size_t)i] = cap - 1 - i; // lowest slot first
 	}
 	int acquire(MSFilter *f) {
-		for (int i = 0; i < capacity; ++i)
-			if (!used[(size_t)i]) {
-				used[(size_t)i] = 1;
-				owner[(size_t)i] = f;
-				return i;
-			}
-		ms_error("msmi355x plugin: pool exhausted (%d slots; raise MSMI355X_SLOTS)", capacity);
-		return -1;
+		if (free_list.empty() || failed) return -1;
+		const int s = free_list.back();
+		free_list.pop_back();
+		owner[(size_t)s] = f;
+		hi = std::max(hi, s + 1);
+		++in_use;
+		return s;
 	}
-	void release(int slot) {
-		used[(size_t)slot] = 0;
-		owner[(size_t)slot] = nullptr;
-	}
+	void release(int slot); // may destroy the bank (and the hub): do not touch either afterwards
 	void emit_all() {
-		for (int i = 0; i < capacity; ++i)
-			if (used[(size_t)i] && owner[(size_t)i]) emit(owner[(size_t)i], i);
+		for (int i = 0; i < hi; ++i)
+			if (owner[(size_t)i]) emit(owner[(size_t)i], i);
 	}
+	mi_ctx *ctx() const;
+	template <typename T>
+	T *pinned(size_t n) {
+		void *p = failed ? nullptr : mi_host_alloc(ctx(), n * sizeof(T));
+		if (!p) {
+			failed = mi_failed("mi_host_alloc");
+			p = calloc(n ? n : 1, sizeof(T)); // keeps the constructors' pointer arithmetic valid; never used for a launch
+			host_fallback.push_back(p);
+			return (T *)p;
+		}
+		memset(p, 0, n * sizeof(T));
+		host_allocs.push_back(p);
+		return (T *)p;
+	}
+	template <typename T>
+	T *devmem(size_t n) {
+		void *p = failed ? nullptr : mi_dev_alloc(ctx(), n * sizeof(T));
+		if (!p) {
+			failed = mi_failed("mi_dev_alloc");
+			return nullptr;
+		}
+		dev_allocs.push_back(p);
+		return (T *)p;
+	}
+	std::vector<void *> host_fallback;
 };
 
-struct Hub {
+struct TickerHub {
 	std::recursive_mutex mu;
+	MSTicker *ticker = nullptr;
 	mi_ctx *ctx = nullptr;
-	int capacity = 256;
-	std::map<MSTicker *, bool> flush_pending;
-	std::vector<Pool *> pools;
-	mi_ctx *context() {
-		if (!ctx) {
-			const char *cap = getenv("MSMI355X_SLOTS");
-			if (cap && atoi(cap) > 0) capacity = atoi(cap);
-			const char *dev = getenv("MSMI355X_DEVICE");
-			if (mi_ctx_create(dev ? atoi(dev) : 0, nullptr, &ctx) != MI_OK) die("mi_ctx_create");
-		}
-		return ctx;
-	}
+	std::vector<Pool *> pools;         // flush order = creation order
+	MSFilter *flush_owner = nullptr;   // the filter whose postponed task will flush this ticker's pools (NULL: none pending)
+	bool dead = false;                 // no banks left: removed from the registry, deleted by the last HubLock
+	int locks = 0;
 };
-Hub g_hub;
 
-template <typename T>
-T *pinned(size_t n) {
-	void *p = mi_host_alloc(g_hub.context(), n * sizeof(T));
-	if (!p) die("mi_host_alloc");
-	memset(p, 0, n * sizeof(T));
-	return (T *)p;
-}
-template <typename T>
-T *devmem(size_t n) {
-	void *p = mi_dev_alloc(g_hub.context(), n * sizeof(T));
-	if (!p) die("mi_dev_alloc");
-	return (T *)p;
+mi_ctx *Pool::ctx() const { return hub->ctx; }
+
+std::shared_mutex g_registry_mu;
+std::unordered_map<MSTicker *, TickerHub *> g_hubs;          // the hub of a ticker
+struct FilterRef {
+	TickerHub *hub;
+	int slots;
+};
+std::unordered_map<MSFilter *, FilterRef> g_filter_hubs; // the hub a filter holds slots in (it may be detached by now)
+thread_local TickerHub *tl_hub = nullptr;
+int g_device = 0;
+
+TickerHub *hub_for(MSFilter *f, bool create) {
+	{
+		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+		auto fi = g_filter_hubs.find(f);
+		if (fi != g_filter_hubs.end()) return fi->second.hub;
+		auto hi = g_hubs.find(f ? f->ticker : nullptr);
+		if (hi != g_hubs.end()) return hi->second;
+	}
+	if (!create) return nullptr;
+	std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+	MSTicker *t = f ? f->ticker : nullptr;
+	auto hi = g_hubs.find(t);
+	if (hi != g_hubs.end()) return hi->second;
+	TickerHub *h = new TickerHub();
+	h->ticker = t;
+	if (mi_ctx_create(g_device, nullptr, &h->ctx) != MI_OK) {
+		mi_failed("mi_ctx_create");
+		h->ctx = nullptr; // banks created on this hub fail at their first allocation and their filters fall back
+	}
+	g_hubs[t] = h;
+	return h;
 }
 
-void flush_ticker(MSTicker *t) {
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-	if (t == nullptr) g_hub.flush_pending.clear(); // the requesting filter was detached meanwhile: flush everything
-	else g_hub.flush_pending[t] = false;
-	for (Pool *p : g_hub.pools)
-		if (t == nullptr || p->ticker == t) {
-			p->flush();
-			p->emit_all();
+// Scope of every facade entry point: finds (or creates) the hub the filter belongs to, locks it, makes it the thread's
+// current hub.  process() / preprocess() / the flush task run on the ticker thread; methods and uninit on any thread.
+struct HubLock {
+	TickerHub *h, *prev;
+	explicit HubLock(MSFilter *f) : h(hub_for(f, true)), prev(tl_hub) {
+		h->mu.lock();
+		++h->locks;
+		tl_hub = h;
+	}
+	explicit HubLock(TickerHub *hub) : h(hub), prev(tl_hub) {
+		h->mu.lock();
+		++h->locks;
+		tl_hub = h;
+	}
+	~HubLock() {
+		tl_hub = prev;
+		const bool last = --h->locks == 0 && h->dead;
+		h->mu.unlock();
+		if (last) {
+			if (h->ctx) mi_ctx_destroy(h->ctx);
+			delete h;
 		}
+	}
+	HubLock(const HubLock &) = delete;
+	HubLock &operator=(const HubLock &) = delete;
+};
+#define g_hub (*tl_hub)
+
+Pool::~Pool() {
+	for (void *p : host_allocs) mi_host_free(hub->ctx, p);
+	for (void *p : dev_allocs) mi_dev_free(hub->ctx, p);
+	for (void *p : host_fallback) free(p);
+}
+
+void Pool::release(int slot) {
+	if (slot < 0 || slot >= capacity || !owner[(size_t)slot]) return;
+	MSFilter *f = owner[(size_t)slot];
+	owner[(size_t)slot] = nullptr;
+	free_list.push_back(slot);
+	--in_use;
+	TickerHub *h = hub;
+	{
+		std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+		auto fi = g_filter_hubs.find(f);
+		if (fi != g_filter_hubs.end() && --fi->second.slots <= 0) g_filter_hubs.erase(fi);
+	}
+	if (in_use == 0) { // last slot of the bank: its device objects and pinned buffers go
+		if (h->ctx) mi_ctx_sync(h->ctx);
+		h->pools.erase(std::find(h->pools.begin(), h->pools.end(), this));
+		delete this;
+		if (h->pools.empty()) { // and with the last bank the hub (its stream): a ticker per call must not leak one
+			std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+			auto it = g_hubs.find(h->ticker);
+			if (it != g_hubs.end() && it->second == h) g_hubs.erase(it);
+			h->dead = true; // deleted by the HubLock that is on the stack
+			h->flush_owner = nullptr;
+		}
+	}
+}
+
+// A bank of pool type P for `key` on the current hub with at least `need` free slots, created on demand with the next
+// capacity of the series 16, 64, 256, 1024, 4096, 16384 (MSMI355X_SLOTS caps or fixes the first one).
+template <typename P>
+P *bank(const std::string &key, int need, const std::function<P *(int cap)> &make) {
+	TickerHub &h = g_hub;
+	int nbanks = 0;
+	for (Pool *p : h.pools)
+		if (p->key == key) {
+			++nbanks;
+			if (!p->failed && (int)p->free_list.size() >= need) return static_cast<P *>(p);
+		}
+	static const int first = [] {
+		const char *e = getenv("MSMI355X_SLOTS");
+		const int v = e ? atoi(e) : 0;
+		return v > 0 ? v : 16;
+	}();
+	long long cap = first;
+	for (int i = 0; i < nbanks && cap < 16384; ++i) cap *= 4;
+	cap = std::max<long long>(cap, need);
+	P *p = make((int)cap);
+	p->key = key;
+	if (p->failed) { // the device refused: the caller falls back (pass-through / drop + late event)
+		delete p;
+		return nullptr;
+	}
+	h.pools.push_back(p);
+	return p;
+}
+
+// Pool constructors call this first: wires the bank to the current hub so that its allocations use the hub's context
+struct Building {
+	Pool *prev;
+	explicit Building(Pool *p, int cap) : prev(tl_building) {
+		p->hub = tl_hub;
+		p->init_slots(cap);
+		tl_building = p;
+		if (!p->hub->ctx) p->failed = true;
+	}
+	~Building() { tl_building = prev; }
+};
+
+void note_slot(MSFilter *f) { // the filter holds one more slot on the current hub (so a detached filter still finds it)
+	std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+	FilterRef &r = g_filter_hubs[f];
+	r.hub = tl_hub;
+	r.slots++;
+}
+
+void flush_hub(TickerHub &h) {
+	// banks flushed in creation order; a facade may stage into a later bank while an earlier one emits (chained facades)
+	for (size_t i = 0; i < h.pools.size(); ++i) {
+		Pool *p = h.pools[i];
+		if (p->failed) continue;
+		p->flush();
+		p->emit_all();
+	}
 }
 
 // Runs on the ticker thread at the start of the next tick, before any process() (msticker.c:301-312):
 // one launch per staged pool, then the results go straight into the owners' output queues, so the
 // downstream filters see them in this tick's graph run even if the owner itself gets no new input.
-void flush_task(MSFilter *f) { flush_ticker(f->ticker); }
+void flush_task(MSFilter *f) {
+	HubLock lk(f);
+	g_hub.flush_owner = nullptr;
+	flush_hub(g_hub);
+}
 
-// called by a filter that staged work this tick
+// called by a filter that staged work this tick (hub locked)
 void request_flush(MSFilter *f) {
-	if (!g_hub.flush_pending[f->ticker]) {
-		g_hub.flush_pending[f->ticker] = true;
+	if (!g_hub.flush_owner) {
+		g_hub.flush_owner = f;
 		ms_filter_postpone_task(f, flush_task);
 	}
 }
+
+// Every facade's postprocess ends here: the ticker drops a detached filter's postponed tasks (msticker.c:187-190,
+// :314-324), so if this filter owned the pending flush nobody will run it -- the next request must post a new one.
+void facade_detached(MSFilter *f) {
+	TickerHub *h = hub_for(f, false);
+	if (!h) return;
+	HubLock lk(h);
+	if (h->flush_owner == f) h->flush_owner = nullptr;
+}
+void generic_postprocess(MSFilter *f) { facade_detached(f); }
 
 #include "filters/resample.inl"
 #include "filters/volume.inl"
@@ -147,7 +335,7 @@ extern "C" {
 // Descriptors: same ids, names, pin counts and flags as the reference's, plus
 // MS_FILTER_IS_HW_ACCELERATED (msfilter.h:142).  Writable statics: the factory mutates flags.
 MSFilterDesc ms_mi355x_resample_desc = {MS_RESAMPLE_ID, "MSResample", "Audio resampler (MI355X batch)", MS_FILTER_OTHER,
-                                        NULL, 1, 1, resample_init, NULL, resample_process, NULL, resample_uninit,
+                                        NULL, 1, 1, resample_init, NULL, resample_process, generic_postprocess, resample_uninit,
                                         resample_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_audio_mixer_desc = {MS_AUDIO_MIXER_ID, "MSAudioMixer",
                                            "A filter that mixes down 16 bit sample audio streams (MI355X batch)",
@@ -155,10 +343,10 @@ MSFilterDesc ms_mi355x_audio_mixer_desc = {MS_AUDIO_MIXER_ID, "MSAudioMixer",
                                            mixer_preprocess, mixer_process, mixer_postprocess, mixer_uninit,
                                            mixer_methods, MS_FILTER_IS_PUMP | MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_volume_desc = {MS_VOLUME_ID, "MSVolume", "A filter that controls and measure sound volume (MI355X batch)",
-                                      MS_FILTER_OTHER, NULL, 1, 1, volume_init, volume_preprocess, volume_process, NULL,
+                                      MS_FILTER_OTHER, NULL, 1, 1, volume_init, volume_preprocess, volume_process, generic_postprocess,
                                       volume_uninit, volume_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_equalizer_desc = {MS_EQUALIZER_ID, "MSEqualizer", "Parametric sound equalizer (MI355X batch)",
-                                         MS_FILTER_OTHER, NULL, 1, 1, equalizer_init, equalizer_preprocess, equalizer_process, NULL,
+                                         MS_FILTER_OTHER, NULL, 1, 1, equalizer_init, equalizer_preprocess, equalizer_process, generic_postprocess,
                                          equalizer_uninit, equalizer_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_speex_ec_desc = {MS_SPEEX_EC_ID, "MSSpeexEC", "Echo canceller, MDF + post-filter (MI355X batch)",
                                         MS_FILTER_OTHER, NULL, 2, 2, ec_init, ec_preprocess, ec_process, ec_postprocess,
@@ -168,23 +356,23 @@ MSFilterDesc ms_mi355x_size_conv_desc = {MS_SIZE_CONV_ID, "MSSizeConv", "A video
                                          NULL, 1, 1, size_conv_init, NULL, size_conv_process, size_conv_postprocess,
                                          size_conv_uninit, sizeconv_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_pix_conv_desc = {MS_PIX_CONV_ID, "MSPixConv", "A pixel format converter (MI355X batch)", MS_FILTER_OTHER,
-                                        NULL, 1, 1, pixconv_init, NULL, pixconv_process, NULL, pixconv_uninit,
+                                        NULL, 1, 1, pixconv_init, NULL, pixconv_process, generic_postprocess, pixconv_uninit,
                                         pixconv_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSScalerDesc ms_mi355x_scaler_desc = {sd_create, sd_process, sd_free};
 
 // the stages either side of the path
 MSFilterDesc ms_mi355x_alaw_dec_desc = {MS_ALAW_DEC_ID, "MSAlawDec", "ITU-G.711 alaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcma", 1, 1,
-                                        g711_dec_init_a, NULL, g711_dec_process, NULL, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_dec_init_a, NULL, g711_dec_process, generic_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_dec_desc = {MS_ULAW_DEC_ID, "MSUlawDec", "ITU-G.711 ulaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcmu", 1, 1,
-                                        g711_dec_init_u, NULL, g711_dec_process, NULL, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_dec_init_u, NULL, g711_dec_process, generic_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_alaw_enc_desc = {MS_ALAW_ENC_ID, "MSAlawEnc", "ITU-G.711 alaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcma", 1, 1,
-                                        g711_enc_init_a, NULL, g711_enc_process, NULL, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_enc_init_a, NULL, g711_enc_process, generic_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_enc_desc = {MS_ULAW_ENC_ID, "MSUlawEnc", "ITU-G.711 ulaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcmu", 1, 1,
-                                        g711_enc_init_u, NULL, g711_enc_process, NULL, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_enc_init_u, NULL, g711_enc_process, generic_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_l16_enc_desc = {MS_L16_ENC_ID, "MSL16Enc", "L16 dummy encoder (MI355X batch)", MS_FILTER_ENCODER, "L16", 1, 1,
-                                       l16_enc_init, l16_enc_preprocess, l16_enc_process, NULL, map_uninit, l16_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                       l16_enc_init, l16_enc_preprocess, l16_enc_process, generic_postprocess, map_uninit, l16_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_l16_dec_desc = {MS_L16_DEC_ID, "MSL16Dec", "L16 dummy decoder (MI355X batch)", MS_FILTER_DECODER, "L16", 1, 1,
-                                       l16_dec_init, NULL, l16_dec_process, NULL, map_uninit, l16_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                       l16_dec_init, NULL, l16_dec_process, generic_postprocess, map_uninit, l16_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_channel_adapter_desc = {MS_CHANNEL_ADAPTER_ID, "MSChannelAdapter",
                                                "A filter that converts from mono to stereo and vice versa (MI355X batch)", MS_FILTER_OTHER, NULL, 2, 1,
                                                adapter_init, adapter_preprocess, adapter_process, adapter_postprocess, adapter_uninit,
@@ -198,6 +386,21 @@ MSFilterDesc ms_mi355x_audio_flow_control_desc = {MS_AUDIO_FLOW_CONTROL_ID, "MSA
                                                   flowctl_uninit, flowctl_methods, MS_FILTER_IS_HW_ACCELERATED};
 
 void libmsmi355xfilters_init(MSFactory *factory) {
+	// No usable HIP device: register NOTHING -- the reference's own CPU filters stay in charge (src/base/msfactory.c:281:
+	// registration prepends, so not registering is how a plugin steps aside).  There is no CPU path in this library.
+	const char *dev = getenv("MSMI355X_DEVICE");
+	g_device = dev ? atoi(dev) : 0;
+	mi_ctx *probe = nullptr;
+	if (mi_ctx_create(g_device, nullptr, &probe) != MI_OK) {
+		// MSMI355X_REGISTER_WITHOUT_DEVICE=1: register all the same (descriptor inspection on a box without a GPU; every
+		// filter then passes through or drops, see the bank failure path)
+		if (!getenv("MSMI355X_REGISTER_WITHOUT_DEVICE")) {
+			ms_error("libmsmi355xfilters: no HIP device %d (%s): the MI355X filters are NOT registered", g_device, mi_last_error());
+			return;
+		}
+	} else {
+		mi_ctx_destroy(probe);
+	}
 	ms_factory_register_filter(factory, &ms_mi355x_resample_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_audio_mixer_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_volume_desc);
@@ -213,13 +416,50 @@ void libmsmi355xfilters_init(MSFactory *factory) {
 	ms_message("libmsmi355xfilters: MI355X batched filters registered (ABI %d)", mi_abi_version());
 }
 
-void ms_mi355x_flush(void) { flush_ticker(nullptr); }
+// every hub's staged work, now (tests; an application that wants the last tick's results before tearing a graph down)
+void ms_mi355x_flush(void) {
+	std::vector<TickerHub *> hubs;
+	{
+		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+		for (auto &kv : g_hubs) hubs.push_back(kv.second);
+	}
+	for (TickerHub *h : hubs) {
+		HubLock lk(h);
+		h->flush_owner = nullptr;
+		flush_hub(*h);
+	}
+}
+
+// blocks dropped or passed through unprocessed because a kernel-library call failed (0 in a healthy process)
+unsigned long long ms_mi355x_late_events(void) { return (unsigned long long)g_late_events.load(); }
+// hubs (tickers with live banks) and banks alive: what a leak check looks at
+void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use) {
+	int nh = 0, nb = 0, ns = 0;
+	std::vector<TickerHub *> all;
+	{
+		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+		for (auto &kv : g_hubs) all.push_back(kv.second);
+	}
+	for (TickerHub *h : all) {
+		HubLock lk(h);
+		++nh;
+		for (Pool *p : h->pools) ++nb, ns += p->in_use;
+	}
+	if (hubs) *hubs = nh;
+	if (banks) *banks = nb;
+	if (slots_in_use) *slots_in_use = ns;
+}
 
 void ms_mi355x_shutdown(void) {
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-	// pools keep their device objects for the life of the process (like the reference's plugins,
-	// there is no unload hook: src/base/msfactory.c:761-771); only the context is synchronised here
-	if (g_hub.ctx) mi_ctx_sync(g_hub.ctx);
+	std::vector<TickerHub *> hubs;
+	{
+		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+		for (auto &kv : g_hubs) hubs.push_back(kv.second);
+	}
+	for (TickerHub *h : hubs) {
+		HubLock lk(h);
+		if (h->ctx) mi_ctx_sync(h->ctx);
+	}
 }
 
 } // extern "C"

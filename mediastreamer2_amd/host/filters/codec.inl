@@ -23,8 +23,8 @@ struct MapPool : Pool {
 	size_t cap, used = 0; // elements
 	uint8_t *h_in, *h_in2 = nullptr, *h_out, *d_in, *d_in2 = nullptr, *d_out;
 	std::vector<std::vector<MapBlock>> staged, ready;
-	explicit MapPool(MapOp o) : op(o) {
-		init_slots(g_hub.capacity);
+	MapPool(int cap_slots, MapOp o) : op(o) {
+		Building b(this, cap_slots);
 		cap = (size_t)capacity * kMaxRounds * 1024; // elements; a pool that fills up flushes early (reserve())
 		const MapOpInfo &k = kMapOps[op];
 		h_in = pinned<uint8_t>(cap * k.in_bpe);
@@ -53,8 +53,8 @@ struct MapPool : Pool {
 		return p;
 	}
 	void flush() override {
-		if (used) {
-			mi_ctx *ctx = g_hub.context();
+		if (used && !failed) {
+			mi_ctx *ctx = hub->ctx;
 			const MapOpInfo &k = kMapOps[op];
 			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, used * k.in_bpe));
 			if (d_in2) MI_MUST(mi_copy_h2d(ctx, d_in2, h_in2, used * k.in_bpe));
@@ -85,9 +85,14 @@ struct MapPool : Pool {
 			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, used * k.out_bpe));
 			MI_MUST(mi_ctx_sync(ctx));
 		}
-		for (int s = 0; s < capacity; ++s) {
+		for (int s = 0; s < hi; ++s) {
 			auto &st = staged[(size_t)s], &rd = ready[(size_t)s];
-			rd.insert(rd.end(), st.begin(), st.end());
+			if (failed) { // nothing was converted: the blocks are lost (counted), their meta blocks freed
+				for (MapBlock &b : st)
+					if (b.meta) freemsg(b.meta);
+			} else {
+				rd.insert(rd.end(), st.begin(), st.end());
+			}
 			st.clear();
 		}
 		used = 0;
@@ -116,7 +121,6 @@ struct MapPool : Pool {
 		}
 	}
 };
-std::map<std::pair<MSTicker *, int>, MapPool *> g_map_pools;
 
 struct MapFilter { // AlawEncData alaw.c:25-30 / EncState l16.c:22-29 / AdapterState chanadapt.c:29-38, one shape for all
 	MapPool *pool;
@@ -142,28 +146,31 @@ MapFilter *map_new(MSFilter *f) {
 
 void map_release(MapFilter *d) {
 	if (!d->pool) return;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(d->pool->hub);
 	d->pool->drop_slot(d->slot);
-	d->pool->release(d->slot);
+	d->pool->release(d->slot); // the last release of a bank destroys it
 	d->pool = nullptr;
 	d->slot = -1;
 }
 
+// a filter that was moved to another ticker gives its slot back under the OLD hub's lock before anything else
+void map_rehome(MSFilter *f, MapFilter *d) {
+	if (d->pool && d->pool->hub->ticker != f->ticker) map_release(d);
+}
+
 // the pool of (this ticker, op) and a slot in it; false when the pool is exhausted
 bool map_attach(MSFilter *f, MapFilter *d, MapOp op) {
-	if (d->pool && d->pool->op == op && d->pool->ticker == f->ticker) return true;
+	if (d->pool && !d->pool->failed && d->pool->op == op && d->pool->hub->ticker == f->ticker) return true;
 	map_release(d);
-	auto key = std::make_pair(f->ticker, (int)op);
-	auto it = g_map_pools.find(key);
-	if (it == g_map_pools.end()) {
-		MapPool *p = new MapPool(op);
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_map_pools.emplace(key, p).first;
+	HubLock lk(f); // the hub of the ticker the filter runs on now (callers hold it already: recursive)
+	MapPool *p = bank<MapPool>("map:" + std::to_string((int)op), 1, [&](int cap) { return new MapPool(cap, op); });
+	const int sl = p ? p->acquire(f) : -1;
+	if (sl < 0) {
+		g_late_events.fetch_add(1, std::memory_order_relaxed);
+		return false;
 	}
-	const int sl = it->second->acquire(f);
-	if (sl < 0) return false;
-	d->pool = it->second;
+	note_slot(f);
+	d->pool = p;
 	d->slot = sl;
 	return true;
 }
@@ -189,7 +196,8 @@ void g711_dec_init_a(MSFilter *f) { map_new(f)->law = 0; }
 void g711_dec_init_u(MSFilter *f) { map_new(f)->law = 1; }
 void g711_dec_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	map_rehome(f, d);
+	HubLock lk(f);
 	if (!map_attach(f, d, d->law ? OP_ULAW_DEC : OP_ALAW_DEC)) {
 		ms_queue_flush(f->inputs[0]);
 		return;
@@ -231,7 +239,8 @@ void g711_enc_process(MSFilter *f) {
 	if (frame_per_packet <= 0) frame_per_packet = 1;
 	if (frame_per_packet > 14) frame_per_packet = 14; // 140 ms max (:68-69)
 	const size_t size_of_pcm = (size_t)160 * (size_t)frame_per_packet;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	map_rehome(f, d);
+	HubLock lk(f);
 	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	if (ms_bufferizer_get_avail(d->bz) < size_of_pcm) return;
 	if (!map_attach(f, d, d->law ? OP_ULAW_ENC : OP_ALAW_ENC)) {
@@ -316,7 +325,8 @@ void l16_enc_preprocess(MSFilter *f) { l16_enc_update((MapFilter *)f->data); }
 void l16_enc_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
 	ms_filter_lock(f);
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	map_rehome(f, d);
+	HubLock lk(f);
 	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	if (d->nbytes >= 2 && ms_bufferizer_get_avail(d->bz) >= d->nbytes) {
 		if (!map_attach(f, d, OP_L16_SWAP)) ms_bufferizer_flush(d->bz);
@@ -357,7 +367,8 @@ int l16_enc_add_fmtp(MSFilter *f, void *arg) { // :114-124
 void l16_dec_init(MSFilter *f) { map_new(f); }
 void l16_dec_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	map_rehome(f, d);
+	HubLock lk(f);
 	if (!map_attach(f, d, OP_L16_SWAP)) {
 		ms_queue_flush(f->inputs[0]);
 		return;
@@ -451,7 +462,8 @@ void adapter_two_inputs(MSFilter *f, MapFilter *d) { // adapter_process_2_inputs
 }
 void adapter_process(MSFilter *f) { // :95-123
 	MapFilter *d = (MapFilter *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	map_rehome(f, d);
+	HubLock lk(f);
 	if (f->inputs[0] != NULL && f->inputs[1] != NULL && d->side[0]) {
 		adapter_two_inputs(f, d);
 		return;

@@ -9,9 +9,9 @@ struct EcPool : Pool {
 	int16_t *h_mic, *h_ref, *h_out, *d_mic, *d_ref, *d_out;
 	uint8_t *h_run, *d_run;
 	std::vector<int> staged, ready;
-	EcPool(int r, int frame, int filter_length) : rate(r), F(frame), flen(filter_length) {
-		init_slots(g_hub.capacity);
-		MI_MUST(mi_aec_create(g_hub.context(), capacity, rate, F, flen, &a));
+	EcPool(int cap, int r, int frame, int filter_length) : rate(r), F(frame), flen(filter_length) {
+		Building b(this, cap);
+		if (!failed) MI_MUST(mi_aec_create(hub->ctx, capacity, rate, F, flen, &a));
 		const size_t c = (size_t)capacity;
 		h_mic = pinned<int16_t>(kMaxRounds * c * F);
 		h_ref = pinned<int16_t>(kMaxRounds * c * F);
@@ -24,21 +24,26 @@ struct EcPool : Pool {
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 	}
+	~EcPool() override {
+		if (a) mi_aec_destroy(a);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
-		const size_t c = (size_t)capacity;
+		mi_ctx *ctx = hub->ctx;
+		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
-		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r = 0; r < maxr; ++r) {
-			for (int s = 0; s < capacity; ++s) h_run[r * c + s] = staged[(size_t)s] > r;
-			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * F, c * F * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * F, c * F * 2));
+			for (int s = 0; s < capacity; ++s) h_run[r * c + s] = s < hi && staged[(size_t)s] > r;
+			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * F, u * F * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * F, u * F * 2));
 			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r * c, c));
 			MI_MUST(mi_aec_process(a, d_mic, d_ref, d_out, F, d_run, MI_AEC_POSTFILTER));
-			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * F, d_out, c * F * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * F, d_out, u * F * 2));
 		}
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
-		for (int s = 0; s < capacity; ++s) {
+		if (failed) // the launch did not happen: the microphone frames leave uncancelled (what bypass mode does, speexec.c:229-237)
+			for (int r = 0; r < maxr; ++r) memcpy(h_out + r * c * F, h_mic + r * c * F, u * F * 2);
+		for (int s = 0; s < hi; ++s) {
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;
 		}
@@ -55,7 +60,6 @@ struct EcPool : Pool {
 		ready[sl] = 0;
 	}
 };
-std::map<std::tuple<MSTicker *, int, int, int>, EcPool *> g_ec_pools;
 
 // MSFlowControlledBufferizer, src/base/msqueue.c:127-256 (SendEvent drop method)
 struct FlowBuf {
@@ -117,6 +121,7 @@ struct SpeexECState { // speexec.c:49-72
 	int framesize, framesize_at_8000, filterlength, samplerate, delay_ms, tail_length_ms, nominal_ref_samples;
 	char *state_str;
 	bool_t echostarted, bypass_mode, using_zeroes;
+	bool_t unsupported; // the attached rate needs a frame size the kernels do not have: both pins pass (internal, not the user's flag)
 	EcPool *pool;
 	int slot;
 };
@@ -184,7 +189,7 @@ void ec_fetch_config(SpeexECState *s);
 
 void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	SpeexECState *s = (SpeexECState *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	s->echostarted = FALSE;
 	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
 	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
@@ -192,9 +197,10 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 		// e.g. 96 kHz would need 512-sample frames: audio keeps flowing uncancelled rather than the process dying
 		ms_error("mi355x echo canceller: frame size %d (rate %d) is not built; the filter forwards both pins untouched",
 		         s->framesize, s->samplerate);
-		s->bypass_mode = TRUE;
+		s->unsupported = TRUE; // internal: the user's MS_ECHO_CANCELLER_SET_BYPASS_MODE value stays what it was
 		return;
 	}
+	s->unsupported = FALSE;
 	if (s->filterlength > 64 * s->framesize) { // the kernels hold at most 64 filter blocks (341 ms at 48 kHz, 512 ms at 8/16 kHz)
 		ms_warning("mi355x echo canceller: tail of %d ms shortened to %d ms (64 blocks of %d samples)", s->tail_length_ms,
 		           64 * s->framesize * 1000 / s->samplerate, s->framesize);
@@ -203,17 +209,14 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	const int delay_samples = s->delay_ms * s->samplerate / 1000;
 	ms_message("Initializing mi355x echo canceler with framesize=%i, filterlength=%i, delay_samples=%i", s->framesize,
 	           s->filterlength, delay_samples);
-	auto key = std::make_tuple(f->ticker, s->samplerate, s->framesize, s->filterlength);
-	auto it = g_ec_pools.find(key);
-	if (it == g_ec_pools.end()) {
-		EcPool *p = new EcPool(s->samplerate, s->framesize, s->filterlength);
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_ec_pools.emplace(key, p).first;
+	{
+		const int rate = s->samplerate, F = s->framesize, flen = s->filterlength;
+		s->pool = bank<EcPool>("ec:" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen), 1,
+		                       [&](int cap) { return new EcPool(cap, rate, F, flen); });
 	}
-	s->pool = it->second;
-	s->slot = s->pool->acquire(f);
-	if (s->slot < 0) s->pool = nullptr;
+	s->slot = s->pool ? s->pool->acquire(f) : -1;
+	if (s->slot < 0) s->pool = nullptr; // no canceller to be had: process() forwards both pins, like bypass mode
+	else note_slot(f);
 	mblk_t *m = allocb((size_t)delay_samples * 2, 0); // zeroes for the time of the delay
 	memset(m->b_wptr, 0, (size_t)delay_samples * 2);
 	m->b_wptr += delay_samples * 2;
@@ -246,14 +249,16 @@ void ec_fetch_config(SpeexECState *s) { // :145-167
 }
 void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at detach
 	SpeexECState *s = (SpeexECState *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	facade_detached(f);
+	HubLock lk(f);
 	ms_bufferizer_flush(&s->delayed_ref);
 	ms_bufferizer_flush(&s->echo);
 	ms_bufferizer_flush(&s->ref.base);
 	if (s->pool) {
-		MI_MUST(mi_aec_reset(s->pool->a, s->slot, 1));
-		s->pool->release(s->slot);
-		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
+		EcPool *p = s->pool;
+		p->staged[(size_t)s->slot] = p->ready[(size_t)s->slot] = 0;
+		if (p->in_use > 1 && !p->failed && mi_aec_reset(p->a, s->slot, 1) != MI_OK) p->failed = mi_failed("mi_aec_reset");
+		p->release(s->slot); // the last release of a bank destroys it
 	}
 	s->pool = nullptr;
 	s->slot = -1;
@@ -298,9 +303,9 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 	if (s->using_zeroes) ms_message("Samples are back.");
 	s->using_zeroes = FALSE;
 	mblk_t *m = ec_block(nbytes);
-	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) {
-		ms_error("Should never happen");
-		abort();
+	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) { // the reference treats this as fatal (speexec.c:281-283); a frame of
+		ms_error("mi355x echo canceller: the far-end bufferizer ran dry; silence sent to the speaker"); // silence is kinder to a server
+		memset(m->b_rptr, 0, nbytes);
 	}
 	ms_queue_put(f->outputs[0], m);
 }
@@ -308,18 +313,13 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 // (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
 void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	if (s->bypass_mode) { // both pins straight through
+	if (s->bypass_mode || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)
 		for (int pin = 0; pin < 2; ++pin)
 			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
 		return;
 	}
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	EcPool *p = s->pool;
-	if (!p) {
-		ms_queue_flush(f->inputs[0]);
-		ms_queue_flush(f->inputs[1]);
-		return;
-	}
 	const size_t nbytes = (size_t)s->framesize * 2, cap = (size_t)p->capacity, slot = (size_t)s->slot;
 	ec_take_far_end(f, s);
 	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
@@ -333,8 +333,8 @@ void ec_process(MSFilter *f) {
 		s->echostarted = TRUE;
 		ec_emit_speaker_frame(f, s, nbytes);
 		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)(p->h_ref + row), nbytes) == 0) {
-			ms_error("Should never happen");
-			abort();
+			ms_error("mi355x echo canceller: the delayed reference ran dry (speexec.c:291-294 calls this impossible); silence used");
+			memset(p->h_ref + row, 0, nbytes);
 		}
 		p->staged[slot]++;
 	}
@@ -382,7 +382,7 @@ int ec_set_state(MSFilter *f, void *arg) { // :361-365 (the previous string leak
 int ec_get_state(MSFilter *f, void *arg) { // :367-374: the CURRENT state while attached, the stored string otherwise
 	SpeexECState *s = (SpeexECState *)f->data;
 	{
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		ec_fetch_config(s);
 	}
 	*(char **)arg = s->state_str;

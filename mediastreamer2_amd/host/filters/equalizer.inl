@@ -9,9 +9,9 @@ struct EqualizerPool : Pool {
 	int16_t *h_buf, *d_buf;
 	int32_t *h_n, *d_n;
 	std::vector<int> staged, ready;
-	EqualizerPool(int r) : rate(r) {
-		init_slots(g_hub.capacity);
-		MI_MUST(mi_equalizer_create(g_hub.context(), capacity, rate, &e));
+	EqualizerPool(int cap, int r) : rate(r) {
+		Building b(this, cap);
+		if (!failed) MI_MUST(mi_equalizer_create(hub->ctx, capacity, rate, &e));
 		cap_samples = (std::max(960, rate / 100 * 2) + 7) & ~7;
 		const size_t c = (size_t)capacity;
 		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
@@ -21,21 +21,24 @@ struct EqualizerPool : Pool {
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 	}
+	~EqualizerPool() override {
+		if (e) mi_equalizer_destroy(e);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
-		const size_t c = (size_t)capacity;
+		mi_ctx *ctx = hub->ctx;
+		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
-		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r = 0; r < maxr; ++r) {
 			for (int s = 0; s < capacity; ++s)
-				if (staged[(size_t)s] <= r) h_n[r * c + s] = 0;
-			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, c * cap_samples * 2));
+				if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
 			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
 			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
-			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, c * cap_samples * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
-		for (int s = 0; s < capacity; ++s) {
+		for (int s = 0; s < hi; ++s) { // after a failed launch the staged blocks leave as they came (flat response)
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;
 		}
@@ -53,7 +56,6 @@ struct EqualizerPool : Pool {
 		ready[s] = 0;
 	}
 };
-std::map<std::pair<MSTicker *, int>, EqualizerPool *> g_equalizer_pools;
 
 struct EqualizerData {
 	int rate;
@@ -68,26 +70,23 @@ struct EqualizerData {
 // order, when the slot is acquired (the reference keeps them in its own fft_cpx array).
 void equalizer_attach(MSFilter *f) {
 	EqualizerData *d = (EqualizerData *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-	if (d->pool && d->pool->rate == d->rate && d->pool->ticker == f->ticker) return;
-	if (d->pool) d->pool->release(d->slot);
-	d->pool = nullptr;
-	d->slot = -1;
-	if (!f->ticker) return;
-	auto key = std::make_pair(f->ticker, d->rate);
-	auto it = g_equalizer_pools.find(key);
-	if (it == g_equalizer_pools.end()) {
-		EqualizerPool *p = new EqualizerPool(d->rate);
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_equalizer_pools.emplace(key, p).first;
+	if (d->pool) { // the slot goes back under ITS hub's lock when the rate or the ticker changed, or its bank failed
+		HubLock old(f);
+		if (!d->pool->failed && d->pool->rate == d->rate && d->pool->hub->ticker == f->ticker) return;
+		d->pool->release(d->slot);
+		d->pool = nullptr;
+		d->slot = -1;
 	}
-	d->pool = it->second;
-	d->slot = d->pool->acquire(f);
+	if (!f->ticker) return;
+	HubLock lk(f);
+	const int rate = d->rate;
+	d->pool = bank<EqualizerPool>("equalizer:" + std::to_string(rate), 1, [&](int cap) { return new EqualizerPool(cap, rate); });
+	d->slot = d->pool ? d->pool->acquire(f) : -1;
 	if (d->slot < 0) {
 		d->pool = nullptr;
 		return;
 	}
+	note_slot(f);
 	MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot)); // equalizer_rate_update flattens
 	MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
 	for (const MSEqualizerGain &g : *d->pending)
@@ -107,7 +106,7 @@ void equalizer_preprocess(MSFilter *f) { equalizer_attach(f); }
 void equalizer_uninit(MSFilter *f) {
 	EqualizerData *d = (EqualizerData *)f->data;
 	if (d->pool) {
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		d->pool->release(d->slot);
 	}
 	delete d->pending;
@@ -116,7 +115,7 @@ void equalizer_uninit(MSFilter *f) {
 }
 void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	EqualizerData *d = (EqualizerData *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	mblk_t *m;
 	if (!d->pool) equalizer_attach(f);
 	if (!d->pool) {

@@ -14,9 +14,9 @@ struct FlowPool : Pool {
 	bool have_req = false;
 	std::vector<int> staged, ready;
 	std::vector<std::vector<mblk_t *>> held, done; // the blocks themselves: the dropper edits them in place
-	FlowPool() {
-		init_slots(g_hub.capacity);
-		MI_MUST(mi_flowctl_create(g_hub.context(), capacity, kFlowBlock, &fc));
+	explicit FlowPool(int cap) {
+		Building b(this, cap);
+		if (!failed) MI_MUST(mi_flowctl_create(hub->ctx, capacity, kFlowBlock, &fc));
 		const size_t c = (size_t)capacity;
 		h_in = pinned<int16_t>(kMaxRounds * c * kFlowBlock);
 		h_out = pinned<int16_t>(kMaxRounds * c * kFlowBlock);
@@ -36,8 +36,11 @@ struct FlowPool : Pool {
 		held.resize(c);
 		done.resize(c);
 	}
+	~FlowPool() override {
+		if (fc) mi_flowctl_destroy(fc);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
+		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity;
 		// MS_AUDIO_FLOW_CONTROL_DROP calls since the last launch (:199-211) take effect exactly where they fell in the
 		// stream's block sequence: before round r for a request that r staged blocks preceded (last = everything left).
@@ -93,7 +96,6 @@ struct FlowPool : Pool {
 		done[s].clear();
 	}
 };
-std::map<MSTicker *, FlowPool *> g_flow_pools;
 
 struct FlowFilter { // MSAudioFlowControlState :154-158
 	FlowPool *pool;
@@ -111,7 +113,7 @@ void flowctl_init(MSFilter *f) { // :160-164
 }
 void flowctl_release(FlowFilter *d) {
 	if (!d->pool) return;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(d->pool->hub);
 	const size_t s = (size_t)d->slot;
 	for (auto *v : {&d->pool->held[s], &d->pool->done[s]}) {
 		for (mblk_t *m : *v) freemsg(m);
@@ -124,18 +126,14 @@ void flowctl_release(FlowFilter *d) {
 	d->slot = -1;
 }
 bool flowctl_attach(MSFilter *f, FlowFilter *d) {
-	if (d->pool && d->pool->ticker == f->ticker) return true;
+	if (d->pool && !d->pool->failed && d->pool->hub->ticker == f->ticker) return true;
 	flowctl_release(d);
-	auto it = g_flow_pools.find(f->ticker);
-	if (it == g_flow_pools.end()) {
-		FlowPool *p = new FlowPool();
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_flow_pools.emplace(f->ticker, p).first;
-	}
-	const int sl = it->second->acquire(f);
+	HubLock lk(f);
+	FlowPool *p = bank<FlowPool>("flowctl", 1, [&](int cap) { return new FlowPool(cap); });
+	const int sl = p ? p->acquire(f) : -1;
 	if (sl < 0) return false;
-	d->pool = it->second;
+	note_slot(f);
+	d->pool = p;
 	d->slot = sl;
 	MI_MUST(mi_flowctl_reset(d->pool->fc, sl, 1));
 	MI_MUST(mi_flowctl_set_config(d->pool->fc, sl, 1, d->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT,
@@ -144,13 +142,13 @@ bool flowctl_attach(MSFilter *f, FlowFilter *d) {
 }
 void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_reset
 	FlowFilter *d = (FlowFilter *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	if (flowctl_attach(f, d)) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1));
 }
 void flowctl_process(MSFilter *f) { // :171-183
 	FlowFilter *d = (FlowFilter *)f->data;
 	ms_filter_lock(f);
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	if (!flowctl_attach(f, d)) {
 		ms_queue_flush(f->inputs[0]);
 		ms_filter_unlock(f);
@@ -181,14 +179,17 @@ void flowctl_process(MSFilter *f) { // :171-183
 	if (p->staged[s]) request_flush(f);
 	ms_filter_unlock(f);
 }
-void flowctl_postprocess(MSFilter *f) { flowctl_release((FlowFilter *)f->data); }
+void flowctl_postprocess(MSFilter *f) {
+	facade_detached(f);
+	flowctl_release((FlowFilter *)f->data);
+}
 void flowctl_uninit(MSFilter *f) { // :188-191
 	flowctl_release((FlowFilter *)f->data);
 	ms_free(f->data);
 }
 int flowctl_set_config(MSFilter *f, void *arg) { // :193-197
 	FlowFilter *d = (FlowFilter *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	d->config = *(MSAudioFlowControlConfig *)arg;
 	if (d->pool)
 		MI_MUST(mi_flowctl_set_config(d->pool->fc, d->slot, 1, d->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT,
@@ -200,7 +201,7 @@ int flowctl_drop(MSFilter *f, void *arg) { // :199-211; applied by the next laun
 	const MSAudioFlowControlDropEvent *ev = (const MSAudioFlowControlDropEvent *)arg;
 	ms_filter_lock(f);
 	{
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		if (d->pool && d->pool->req_drop[(size_t)d->slot] == 0 && d->pool->req_total[(size_t)d->slot] == 0) {
 			d->pool->req_drop[(size_t)d->slot] = (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;
 			d->pool->req_total[(size_t)d->slot] = (ev->flow_control_interval_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;

@@ -44,9 +44,9 @@ struct PlcPool : Pool {
 	uint8_t *h_mode, *d_mode;
 	std::vector<int> staged;
 	std::vector<std::vector<PlcEntry>> pending, done;
-	explicit PlcPool(int r) : rate(r) {
-		init_slots(g_hub.capacity);
-		MI_MUST(mi_plc_create(g_hub.context(), capacity, rate, kPlcBlock, &plc));
+	PlcPool(int cap, int r) : rate(r) {
+		Building b(this, cap);
+		if (!failed) MI_MUST(mi_plc_create(hub->ctx, capacity, rate, kPlcBlock, &plc));
 		const size_t c = (size_t)capacity;
 		h_rows = pinned<int16_t>(kMaxRounds * c * kPlcBlock);
 		h_len = pinned<int32_t>(kMaxRounds * c);
@@ -69,8 +69,11 @@ struct PlcPool : Pool {
 		h_mode[r * c + s] = (uint8_t)mode;
 		return h_rows + (r * c + s) * kPlcBlock;
 	}
+	~PlcPool() override {
+		if (plc) mi_plc_destroy(plc);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
+		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity;
 		int maxr = 0;
 		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
@@ -109,7 +112,6 @@ struct PlcPool : Pool {
 		done[s].clear();
 	}
 };
-std::map<std::pair<MSTicker *, int>, PlcPool *> g_plc_pools;
 
 struct PlcFilter { // generic_plc_struct msgenericplc.c:30-41
 	PlcPool *pool;
@@ -128,7 +130,7 @@ void plc_init(MSFilter *f) { // :45-53
 }
 void plc_release(PlcFilter *d) {
 	if (!d->pool) return;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(d->pool->hub);
 	const size_t s = (size_t)d->slot;
 	for (auto *v : {&d->pool->pending[s], &d->pool->done[s]}) {
 		for (PlcEntry &e : *v)
@@ -141,36 +143,27 @@ void plc_release(PlcFilter *d) {
 	d->slot = -1;
 }
 bool plc_attach(MSFilter *f, PlcFilter *d) { // generic_plc_preprocess :55-58: a context for the configured rate
-	if (d->pool && d->pool->ticker == f->ticker && d->pool->rate == d->rate) return true;
+	if (d->pool && !d->pool->failed && d->pool->hub->ticker == f->ticker && d->pool->rate == d->rate) return true;
 	plc_release(d);
-	auto key = std::make_pair(f->ticker, d->rate);
-	auto it = g_plc_pools.find(key);
-	if (it == g_plc_pools.end()) {
-		mi_plc *probe = nullptr; // a rate the kernel does not take (44.1 kHz family) must not abort the process: pass-through
-		if (mi_plc_create(g_hub.context(), 1, d->rate, kPlcBlock, &probe) != MI_OK) {
-			ms_error("msmi355x plugin: MSGenericPLC at %d Hz: %s; audio is forwarded without concealment", d->rate, mi_last_error());
-			return false;
-		}
-		mi_plc_destroy(probe);
-		PlcPool *p = new PlcPool(d->rate);
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_plc_pools.emplace(key, p).first;
-	}
-	const int sl = it->second->acquire(f);
+	HubLock lk(f);
+	const int rate = d->rate;
+	// a rate the kernel does not take fails the bank's constructor: no abort, the audio is forwarded without concealment
+	PlcPool *p = bank<PlcPool>("plc:" + std::to_string(rate), 1, [&](int cap) { return new PlcPool(cap, rate); });
+	const int sl = p ? p->acquire(f) : -1;
 	if (sl < 0) return false;
-	d->pool = it->second;
+	note_slot(f);
+	d->pool = p;
 	d->slot = sl;
 	MI_MUST(mi_plc_reset(d->pool->plc, sl, 1));
 	return true;
 }
 void plc_preprocess(MSFilter *f) {
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	plc_attach(f, (PlcFilter *)f->data);
 }
 void plc_process(MSFilter *f) { // generic_plc_process :59-167
 	PlcFilter *d = (PlcFilter *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	if (d->rate <= 0 || !plc_attach(f, d)) { // no usable context: the stream passes as it is
 		mblk_t *m;
 		while ((m = ms_queue_get(f->inputs[0])) != NULL) ms_queue_put(f->outputs[0], m);
@@ -231,7 +224,10 @@ void plc_process(MSFilter *f) { // generic_plc_process :59-167
 	}
 	if (any) request_flush(f);
 }
-void plc_postprocess(MSFilter *f) { plc_release((PlcFilter *)f->data); }
+void plc_postprocess(MSFilter *f) {
+	facade_detached(f);
+	plc_release((PlcFilter *)f->data);
+}
 void plc_uninit(MSFilter *f) { // :169-178
 	PlcFilter *d = (PlcFilter *)f->data;
 	plc_release(d);

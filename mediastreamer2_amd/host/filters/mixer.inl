@@ -15,9 +15,9 @@ struct MixerPool : Pool {
 	std::vector<float> gain;
 	bool ctl_dirty = true;
 	std::vector<uint8_t> staged, ready;
-	MixerPool(int nsamples) : ns(nsamples) {
-		init_slots(std::max(1, g_hub.capacity / 8));
-		MI_MUST(mi_mixer_create(g_hub.context(), capacity, MIXER_MAX_CHANNELS, ns, &m));
+	MixerPool(int cap, int nsamples) : ns(nsamples) {
+		Building b(this, std::max(1, cap / 8)); // a mixer slot carries 50 channel rows
+		if (!failed) MI_MUST(mi_mixer_create(hub->ctx, capacity, MIXER_MAX_CHANNELS, ns, &m));
 		const size_t c = (size_t)capacity, n = c * MIXER_MAX_CHANNELS;
 		h_in = pinned<int16_t>(n * ns);
 		h_out = pinned<int16_t>(n * ns);
@@ -34,9 +34,12 @@ struct MixerPool : Pool {
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 	}
+	~MixerPool() override {
+		if (m) mi_mixer_destroy(m);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
-		const size_t c = (size_t)capacity, n = c * MIXER_MAX_CHANNELS;
+		mi_ctx *ctx = hub->ctx;
+		const size_t c = (size_t)capacity;
 		bool any = false;
 		for (size_t s = 0; s < c; ++s) {
 			h_run[s] = staged[s];
@@ -47,12 +50,13 @@ struct MixerPool : Pool {
 			ctl_dirty = false;
 		}
 		if (any) {
-			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, n * ns * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_has, h_has, n));
+			const size_t un = (size_t)hi * MIXER_MAX_CHANNELS; // channel rows of the slots ever handed out
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, un * ns * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_has, h_has, un));
 			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, c));
 			MI_MUST(mi_copy_h2d(ctx, d_mode, h_mode, c));
 			MI_MUST(mi_mixer_process_masked(m, d_in, d_has, 1, d_mode, d_out, d_run));
-			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, n * ns * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, un * ns * 2));
 			MI_MUST(mi_ctx_sync(ctx));
 		}
 		for (size_t s = 0; s < c; ++s) {
@@ -62,7 +66,6 @@ struct MixerPool : Pool {
 	}
 	void emit(MSFilter *f, int slot) override;
 };
-std::map<std::pair<MSTicker *, int>, MixerPool *> g_mixer_pools;
 
 struct Channel { // audiomixer.c:53-63
 	MSBufferizer bufferizer;
@@ -78,7 +81,20 @@ struct MixerState { // audiomixer.c:132-143
 	bool_t bypass_mode, single_output;
 	MixerPool *pool;
 	int slot;
+	// Blocks forwarded in bypass mode leave one tick later, like mixed ones (which come out of the next tick's flush): the
+	// filter's latency does not jump by 10 ms when a second contributor appears or the last but one falls silent -- a
+	// canceller behind two mixers would otherwise see its two inputs slip against each other (aec3_tester.c graph).
+	std::vector<std::pair<int, mblk_t *>> *held;
 };
+
+void mixer_release_held(MSFilter *f, MixerState *s, bool deliver) {
+	for (auto &pm : *s->held) {
+		MSQueue *q = deliver ? f->outputs[pm.first] : NULL;
+		if (q) ms_queue_put(q, pm.second);
+		else freemsg(pm.second);
+	}
+	s->held->clear();
+}
 
 void mixer_init(MSFilter *f) { // audiomixer.c:145-156
 	MixerState *s = (MixerState *)ms_malloc0(sizeof(*s));
@@ -87,6 +103,7 @@ void mixer_init(MSFilter *f) { // audiomixer.c:145-156
 	s->rate = 44100;
 	s->master_channel = -1;
 	s->slot = -1;
+	s->held = new std::vector<std::pair<int, mblk_t *>>();
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
 		ms_bufferizer_init(&s->channels[i].bufferizer);
 		s->channels[i].gain = 1.0;
@@ -98,6 +115,8 @@ void mixer_init(MSFilter *f) { // audiomixer.c:145-156
 void mixer_uninit(MSFilter *f) {
 	MixerState *s = (MixerState *)f->data;
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) ms_bufferizer_uninit(&s->channels[i].bufferizer);
+	mixer_release_held(f, s, false);
+	delete s->held;
 	ms_free(s);
 }
 bool_t has_single_output(MSFilter *f, MixerState *s) { // audiomixer.c:167-176
@@ -121,7 +140,7 @@ void mixer_push_controls(MSFilter *f, MixerState *s) {
 }
 void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
 	MixerState *s = (MixerState *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	s->bytespertick = (2 * s->nchannels * s->rate * f->ticker->interval) / 1000;
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
 		s->channels[i].last_flow_control = (uint64_t)-1;
@@ -131,25 +150,20 @@ void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
 	s->bypass_mode = FALSE;
 	s->single_output = has_single_output(f, s);
 	const int ns = s->bytespertick / 2;
-	auto key = std::make_pair(f->ticker, ns);
-	auto it = g_mixer_pools.find(key);
-	if (it == g_mixer_pools.end()) {
-		MixerPool *p = new MixerPool(ns);
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_mixer_pools.emplace(key, p).first;
-	}
-	s->pool = it->second;
-	s->slot = s->pool->acquire(f);
+	s->pool = bank<MixerPool>("mixer:" + std::to_string(ns), 1, [&](int cap) { return new MixerPool(cap, ns); });
+	s->slot = s->pool ? s->pool->acquire(f) : -1;
 	if (s->slot < 0) s->pool = nullptr;
+	else note_slot(f);
 	mixer_push_controls(f, s);
 }
 void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot released at every detach)
 	MixerState *s = (MixerState *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	facade_detached(f);
+	HubLock lk(f);
+	mixer_release_held(f, s, false);
 	if (s->pool) {
-		s->pool->release(s->slot);
 		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
+		s->pool->release(s->slot); // the last release of a bank destroys it
 	}
 	s->pool = nullptr;
 	s->slot = -1;
@@ -195,10 +209,10 @@ void mixer_forward(MSFilter *f, MixerState *s, int from_pin) {
 		if (!dst || !s->channels[pin].output_enabled) continue;
 		if (s->conf_mode != 0 && pin == from_pin) continue;
 		if (s->single_output) {
-			for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) ms_queue_put(dst, m);
+			for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) s->held->push_back({pin, m});
 			break;
 		}
-		for (mblk_t *m = peekq(&src->q); m != NULL && m != &src->q._q_stopper; m = m->b_next) ms_queue_put(dst, dupmsg(m));
+		for (mblk_t *m = peekq(&src->q); m != NULL && m != &src->q._q_stopper; m = m->b_next) s->held->push_back({pin, dupmsg(m)});
 	}
 	ms_queue_flush(src);
 }
@@ -274,7 +288,8 @@ void MixerPool::emit(MSFilter *f, int slot) {
 void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
 	ms_filter_lock(f);
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
+	mixer_release_held(f, s, true); // what bypass mode forwarded on the previous tick
 	if (!s->pool) {
 		ms_filter_unlock(f);
 		return;
@@ -331,7 +346,7 @@ int mixer_set_input_gain(MSFilter *f, void *data) { // audiomixer.c:372-382
 	MixerState *s = (MixerState *)f->data;
 	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
 	if (!mixer_pin_ok("mixer_set_input_gain", ctl->pin)) return -1;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	s->channels[ctl->pin].gain = ctl->param.gain;
 	mixer_push_controls(f, s);
 	return 0;
@@ -340,7 +355,7 @@ int mixer_set_active(MSFilter *f, void *data) { // :384-393
 	MixerState *s = (MixerState *)f->data;
 	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
 	if (!mixer_pin_ok("mixer_set_active_gain", ctl->pin)) return -1;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	s->channels[ctl->pin].active = (bool_t)ctl->param.active;
 	mixer_push_controls(f, s);
 	return 0;
@@ -350,7 +365,7 @@ int mixer_enable_output(MSFilter *f, void *data) { // :395-408
 	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
 	if (!mixer_pin_ok("mixer_enable_output", ctl->pin)) return -1;
 	ms_filter_lock(f);
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	s->channels[ctl->pin].output_enabled = (bool_t)ctl->param.enabled;
 	s->single_output = has_single_output(f, s);
 	mixer_push_controls(f, s);

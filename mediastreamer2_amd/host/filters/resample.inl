@@ -11,11 +11,11 @@ struct ResamplePool : Pool {
 	int32_t *h_olen, *d_olen;
 	uint8_t *h_run, *d_run;
 	std::vector<int> staged, ready;
-	ResamplePool(uint32_t ir, uint32_t orate) : in_rate(ir), out_rate(orate) {
-		init_slots(g_hub.capacity);
-		MI_MUST(mi_resampler_create(g_hub.context(), capacity, ir, orate, 3 /* SPEEX_RESAMPLER_QUALITY_VOIP */, &r));
+	ResamplePool(int cap, uint32_t ir, uint32_t orate) : in_rate(ir), out_rate(orate) {
+		Building b(this, cap);
+		if (!failed) MI_MUST(mi_resampler_create(hub->ctx, capacity, ir, orate, 3 /* SPEEX_RESAMPLER_QUALITY_VOIP */, &r));
 		in_len = (int)(ir / 100);
-		ostride = (mi_resampler_out_capacity(r, in_len) + 7) & ~7;
+		ostride = r ? (mi_resampler_out_capacity(r, in_len) + 7) & ~7 : 8;
 		const size_t c = (size_t)capacity;
 		h_in = pinned<int16_t>(kMaxRounds * c * in_len);
 		h_out = pinned<int16_t>(kMaxRounds * c * ostride);
@@ -28,28 +28,30 @@ struct ResamplePool : Pool {
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 	}
+	~ResamplePool() override {
+		if (r) mi_resampler_destroy(r);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
-		const size_t c = (size_t)capacity;
+		mi_ctx *ctx = hub->ctx;
+		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
-		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r_ = 0; r_ < maxr; ++r_) {
-			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = staged[(size_t)s] > r_;
-			MI_MUST(mi_copy_h2d(ctx, d_in, h_in + r_ * c * in_len, c * in_len * 2));
+			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = s < hi && staged[(size_t)s] > r_;
+			MI_MUST(mi_copy_h2d(ctx, d_in, h_in + r_ * c * in_len, u * in_len * 2));
 			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r_ * c, c));
 			MI_MUST(mi_resampler_process_masked(r, d_in, in_len, in_len, d_out, ostride, d_olen, d_run));
-			MI_MUST(mi_copy_d2h(ctx, h_out + r_ * c * ostride, d_out, c * ostride * 2));
-			MI_MUST(mi_copy_d2h(ctx, h_olen + r_ * c, d_olen, c * 4));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r_ * c * ostride, d_out, u * ostride * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_olen + r_ * c, d_olen, u * 4));
 		}
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
-		for (int s = 0; s < capacity; ++s) {
-			ready[(size_t)s] = staged[(size_t)s];
+		for (int s = 0; s < hi; ++s) {
+			ready[(size_t)s] = failed ? 0 : staged[(size_t)s]; // a failed launch delivers nothing (late event counted)
 			staged[(size_t)s] = 0;
 		}
 	}
 	void emit(MSFilter *f, int slot) override;
 };
-std::map<std::tuple<MSTicker *, uint32_t, uint32_t>, ResamplePool *> g_resample_pools;
 
 struct ResampleData { // ResampleData msresample.c:33-42
 	MSBufferizer *bz;
@@ -72,13 +74,16 @@ void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
 	f->data = d;
 }
 
-void resample_release(ResampleData *d) {
+void resample_release(ResampleData *d) { // hub locked by the caller
 	if (d->pool) {
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-		for (int sl : *d->slots) {
-			d->pool->release(sl);
-			d->pool->staged[(size_t)sl] = d->pool->ready[(size_t)sl] = 0;
-			MI_MUST(mi_resampler_reset(d->pool->r, sl, 1));
+		ResamplePool *p = d->pool;
+		std::vector<int> sl = *d->slots;
+		for (size_t i = 0; i < sl.size(); ++i) {
+			p->staged[(size_t)sl[i]] = p->ready[(size_t)sl[i]] = 0;
+			if (i + 1 < sl.size() || p->in_use > 1) { // the bank lives on: the slot's next owner starts from a fresh handle
+				if (!p->failed && mi_resampler_reset(p->r, sl[i], 1) != MI_OK) p->failed = mi_failed("mi_resampler_reset");
+			}
+			p->release(sl[i]); // the last release of a bank destroys it
 		}
 	}
 	d->slots->clear();
@@ -88,7 +93,10 @@ void resample_release(ResampleData *d) {
 
 void resample_uninit(MSFilter *f) {
 	ResampleData *d = (ResampleData *)f->data;
-	resample_release(d);
+	{
+		HubLock lk(f);
+		resample_release(d);
+	}
 	ms_bufferizer_destroy(d->bz);
 	delete d->slots;
 	ms_free(d);
@@ -118,27 +126,27 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 		return;
 	}
 	ms_filter_lock(f);
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (d->pool && d->pool->hub->ticker != f->ticker) { // the filter moved to another ticker: its slots go back under the OLD hub's lock
+		HubLock old(d->pool->hub);
+		resample_release(d);
+	}
+	HubLock lk(f);
 	const int nch = d->in_nchannels < 1 ? 1 : d->in_nchannels;
-	if (d->pool && (d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate || (int)d->slots->size() != nch))
+	if (d->pool && (d->pool->failed || d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate || (int)d->slots->size() != nch))
 		resample_release(d); // rates / channels changed: the handle is re-created, history lost (:138-148)
 	if (!d->pool) {
-		auto key = std::make_tuple(f->ticker, d->input_rate, d->output_rate);
-		auto it = g_resample_pools.find(key);
-		if (it == g_resample_pools.end()) {
-			ResamplePool *p = new ResamplePool(d->input_rate, d->output_rate);
-			p->ticker = f->ticker;
-			g_hub.pools.push_back(p);
-			it = g_resample_pools.emplace(key, p).first;
-		}
-		d->pool = it->second;
-		for (int ch = 0; ch < nch; ++ch) { // interleaved input: one state per channel, like speex_resampler_init(nb_channels)
+		const uint32_t ir = d->input_rate, orate = d->output_rate;
+		d->pool = bank<ResamplePool>("resample:" + std::to_string(ir) + ":" + std::to_string(orate), nch,
+		                             [&](int cap) { return new ResamplePool(cap, ir, orate); });
+		for (int ch = 0; d->pool && ch < nch; ++ch) { // interleaved input: one state per channel, like speex_resampler_init(nb_channels)
 			const int sl = d->pool->acquire(f);
 			if (sl < 0) break;
 			d->slots->push_back(sl);
+			note_slot(f);
 		}
-		if ((int)d->slots->size() != nch) {
+		if (!d->pool || (int)d->slots->size() != nch) { // the device refused: this tick's audio is lost, counted, and retried next tick
 			resample_release(d);
+			g_late_events.fetch_add(1, std::memory_order_relaxed);
 			ms_queue_flush(f->inputs[0]);
 			ms_filter_unlock(f);
 			return;

@@ -39,12 +39,12 @@ struct ScalerCtx { // what MSScalerContext* points to
 
 MSScalerContext *sd_create(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt df, int flags) {
 	(void)flags; // bilinear either way, like yuv_create_scale_context msvideo.c:526-540
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk((MSFilter *)nullptr); // MSScalerDesc callers have no ticker: the process-wide hub
 	ScalerCtx *c = new ScalerCtx();
 	c->sw = sw, c->sh = sh, c->dw = dw, c->dh = dh, c->sf = sf, c->df = df;
 	if (sf == MS_YUV420P) {
 		const int fmt = (df == MS_RGB24) ? MI_PIX_RGB24 : MI_PIX_I420;
-		if ((df != MS_RGB24 && df != MS_YUV420P) || mi_scaler_create(g_hub.context(), sw, sh, dw, dh, fmt, &c->sc) != MI_OK) {
+		if ((df != MS_RGB24 && df != MS_YUV420P) || !g_hub.ctx || mi_scaler_create(g_hub.ctx, sw, sh, dw, dh, fmt, &c->sc) != MI_OK) {
 			ms_error("msmi355x scaler: %dx%d fmt %d -> %dx%d fmt %d unsupported: %s", sw, sh, (int)sf, dw, dh, (int)df, mi_last_error());
 			delete c;
 			return NULL;
@@ -60,7 +60,7 @@ MSScalerContext *sd_create(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt
 int sd_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t *dst[], int dst_strides[]) {
 	ScalerCtx *c = (ScalerCtx *)ctx;
 	if (!c) return -1;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk((MSFilter *)nullptr);
 	if (c->sc) {
 		const uint8_t *sp[3] = {src[0], src[1], src[2]};
 		uint8_t *dp[3] = {dst[0], dst[1], dst[2]};
@@ -71,7 +71,7 @@ int sd_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t 
 	const int flip = src_strides[0] < 0;
 	const int stride = flip ? -src_strides[0] : src_strides[0];
 	if (stride < rowb) return -1;
-	if (!c->pc[flip] && mi_pixconv_create(g_hub.context(), c->sw, c->sh, pix_to_mi(c->sf), flip, &c->pc[flip]) != MI_OK) {
+	if (!c->pc[flip] && mi_pixconv_create(g_hub.ctx, c->sw, c->sh, pix_to_mi(c->sf), flip, &c->pc[flip]) != MI_OK) {
 		ms_error("msmi355x scaler: %s", mi_last_error());
 		return -1;
 	}
@@ -101,7 +101,7 @@ int sd_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t 
 void sd_free(MSScalerContext *ctx) {
 	ScalerCtx *c = (ScalerCtx *)ctx;
 	if (!c) return;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk((MSFilter *)nullptr);
 	if (c->sc) mi_scaler_destroy(c->sc);
 	for (int i = 0; i < 2; ++i)
 		if (c->pc[i]) mi_pixconv_destroy(c->pc[i]);
@@ -142,12 +142,13 @@ struct FramePool : Pool {
 		ready.clear();
 		const int n = (int)staged.size();
 		if (!n) return;
-		mi_ctx *ctx = g_hub.context();
+		mi_ctx *ctx = hub->ctx;
 		MI_MUST(mi_copy_h2d(ctx, d_src, h_src, (size_t)n * src_pitch));
 		MI_MUST(launch(n));
 		MI_MUST(mi_copy_d2h(ctx, h_dst, d_dst, (size_t)n * dst_pitch));
 		MI_MUST(mi_ctx_sync(ctx));
-		ready.swap(staged);
+		if (failed) staged.clear(); // the frames are dropped, like a failing ms_scaler_process (sizeconv.c:162-166)
+		else ready.swap(staged);
 	}
 	void emit(MSFilter *f, int slot) override;
 	void forget(MSFilter *f) { // the filter left the pool: its frames in flight are dropped
@@ -188,31 +189,47 @@ int frame_slots() {
 
 struct ScalerPool : FramePool {
 	mi_scaler *sc = nullptr;
-	ScalerPool(mi_scaler *created, int dw, int dh) : sc(created) {
-		init_slots(g_hub.capacity);
+	ScalerPool(int cap, int w, int h, int dw, int dh) {
+		Building b(this, cap);
+		// a geometry the kernels cannot take is not fatal: the bank fails and the frame is dropped with an error, as a
+		// failing ms_scaler_process is in the reference (sizeconv.c:162-166)
+		if (!failed && mi_scaler_create(hub->ctx, w, h, dw, dh, MI_PIX_I420, &sc) != MI_OK) {
+			ms_error("MSSizeConv: %dx%d -> %dx%d: %s", w, h, dw, dh, mi_last_error());
+			failed = true;
+		}
+		if (failed) return;
 		frame_cap = frame_slots();
 		src_bytes = mi_scaler_src_bytes(sc);
 		dst_bytes = mi_scaler_dst_bytes(sc);
 		out_w = dw, out_h = dh;
 		alloc_buffers();
 	}
+	~ScalerPool() override {
+		if (sc) mi_scaler_destroy(sc);
+	}
 	int launch(int n) override { return mi_scaler_process(sc, n, d_src, src_pitch, d_dst, dst_pitch); }
 };
-std::map<std::tuple<MSTicker *, int, int, int, int>, ScalerPool *> g_scaler_pools;
 
 struct PixPool : FramePool {
 	mi_pixconv *pc = nullptr;
-	PixPool(mi_pixconv *created, int w, int h) : pc(created) {
-		init_slots(g_hub.capacity);
+	PixPool(int cap, int w, int h, int fmt, int flip, int ms_fmt) {
+		Building b(this, cap);
+		if (!failed && mi_pixconv_create(hub->ctx, w, h, fmt, flip, &pc) != MI_OK) {
+			ms_error("MSPixConv: %dx%d format %d: %s", w, h, ms_fmt, mi_last_error());
+			failed = true;
+		}
+		if (failed) return;
 		frame_cap = frame_slots();
 		src_bytes = mi_pixconv_src_bytes(pc);
 		dst_bytes = mi_pixconv_dst_bytes(pc);
 		out_w = w, out_h = h;
 		alloc_buffers();
 	}
+	~PixPool() override {
+		if (pc) mi_pixconv_destroy(pc);
+	}
 	int launch(int n) override { return mi_pixconv_process(pc, n, d_src, src_pitch, d_dst, dst_pitch); }
 };
-std::map<std::tuple<MSTicker *, int, int, int>, PixPool *> g_pix_pools;
 
 // ---- MSSizeConv (src/videofilters/sizeconv.c) ----------------------------------------------------------
 struct SizeConvState { // SizeConvState sizeconv.c:29-40
@@ -253,7 +270,7 @@ void size_conv_init(MSFilter *f) { // sizeconv.c:46-60
 void size_conv_uninit(MSFilter *f) { // :62-66
 	SizeConvState *s = (SizeConvState *)f->data;
 	{
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		size_conv_leave_pool(s, f);
 	}
 	ms_yuv_buf_allocator_free(s->allocator);
@@ -262,7 +279,7 @@ void size_conv_uninit(MSFilter *f) { // :62-66
 void size_conv_postprocess(MSFilter *f) { // :68-76 (the scaler context there == our pool membership)
 	SizeConvState *s = (SizeConvState *)f->data;
 	{
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		size_conv_leave_pool(s, f);
 	}
 	flushq(&s->rq, 0);
@@ -271,28 +288,17 @@ void size_conv_postprocess(MSFilter *f) { // :68-76 (the scaler context there ==
 
 // get_resampler sizeconv.c:82-95: (re)join the pool of this geometry
 ScalerPool *size_conv_pool(MSFilter *f, SizeConvState *s, int w, int h) {
-	if (s->pool && s->in_vsize.width == w && s->in_vsize.height == h && s->pool->ticker == f->ticker &&
+	if (s->pool && !s->pool->failed && s->in_vsize.width == w && s->in_vsize.height == h && s->pool->hub->ticker == f->ticker &&
 	    s->pool->out_w == s->target_vsize.width && s->pool->out_h == s->target_vsize.height)
 		return s->pool;
 	size_conv_leave_pool(s, f);
-	auto key = std::make_tuple(f->ticker, w, h, s->target_vsize.width, s->target_vsize.height);
-	auto it = g_scaler_pools.find(key);
-	if (it == g_scaler_pools.end()) {
-		// a geometry the kernels cannot take is not fatal: the frame is dropped with an error, as a failing
-		// ms_scaler_process is in the reference (sizeconv.c:162-166)
-		mi_scaler *sc = nullptr;
-		if (mi_scaler_create(g_hub.context(), w, h, s->target_vsize.width, s->target_vsize.height, MI_PIX_I420, &sc) != MI_OK) {
-			ms_error("MSSizeConv: %dx%d -> %dx%d: %s", w, h, s->target_vsize.width, s->target_vsize.height, mi_last_error());
-			return nullptr;
-		}
-		ScalerPool *p = new ScalerPool(sc, s->target_vsize.width, s->target_vsize.height);
-		p->ticker = f->ticker;
-		g_hub.pools.push_back(p);
-		it = g_scaler_pools.emplace(key, p).first;
-	}
-	s->pool = it->second;
+	const int dw = s->target_vsize.width, dh = s->target_vsize.height;
+	s->pool = bank<ScalerPool>("scaler:" + std::to_string(w) + "x" + std::to_string(h) + ">" + std::to_string(dw) + "x" + std::to_string(dh), 1,
+	                           [&](int cap) { return new ScalerPool(cap, w, h, dw, dh); });
+	if (!s->pool) return nullptr;
 	s->slot = s->pool->acquire(f);
 	if (s->slot < 0) s->pool = nullptr;
+	else note_slot(f);
 	s->in_vsize.width = w;
 	s->in_vsize.height = h;
 	ms_message("MSSizeConv: create new scaler context with w %d, h %d", w, h);
@@ -331,7 +337,7 @@ bool size_conv_adapt_target(SizeConvState *s, int in_w, int in_h) {
 
 // (3) hand one frame to the batch (the ms_scaler_process call of :161): planes gathered into the packed layout
 bool size_conv_stage(MSFilter *f, SizeConvState *s, const YuvBuf &in, uint32_t ts) {
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	ScalerPool *p = size_conv_pool(f, s, in.w, in.h);
 	uint8_t *dst = p ? p->stage(f, ts) : nullptr;
 	if (!dst) return false;
@@ -380,7 +386,7 @@ void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
 	}
 	ms_filter_unlock(f);
 	if (staged) {
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		request_flush(f);
 	}
 }
@@ -391,7 +397,7 @@ int sizeconv_set_vsize(MSFilter *f, void *arg) { // sizeconv.c:186-197
 	s->target_vsize = *(MSVideoSize *)arg;
 	ms_message("sizeconv_set_vsize(): set target size w %d, h %d", s->target_vsize.width, s->target_vsize.height);
 	{
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		size_conv_leave_pool(s, f);
 	}
 	ms_filter_unlock(f);
@@ -446,7 +452,7 @@ void pixconv_init(MSFilter *f) { // pixconv.c:36-45
 void pixconv_uninit(MSFilter *f) { // :47-55
 	PixConvState *s = (PixConvState *)f->data;
 	{
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		pixconv_leave_pool(s, f);
 	}
 	ms_yuv_buf_allocator_free(s->allocator);
@@ -465,31 +471,24 @@ void pixconv_process(MSFilter *f) { // pixconv.c:62-94
 		}
 		MSPicture inbuf;
 		if (ms_picture_init_from_mblk_with_size(&inbuf, im, s->in_fmt, s->size.width, s->size.height) == 0) {
-			std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+			HubLock lk(f);
 			const int fmt = pix_to_mi(s->in_fmt);
 			const int flip = s->in_fmt == MS_RGB24_REV; // :78-81
 			if (fmt < 0 || (inbuf.w & 1)) {
 				ms_error("MSPixConv: Error in ms_sws_scale()."); // what a failing ms_scaler_process logs, :84
 			} else {
-				if (!s->pool || s->pool->ticker != f->ticker || s->pool->out_w != inbuf.w || s->pool->out_h != inbuf.h) {
+				if (!s->pool || s->pool->failed || s->pool->hub->ticker != f->ticker || s->pool->out_w != inbuf.w || s->pool->out_h != inbuf.h) {
 					pixconv_leave_pool(s, f);
-					auto key = std::make_tuple(f->ticker, inbuf.w, inbuf.h, (int)s->in_fmt);
-					auto it = g_pix_pools.find(key);
-					if (it == g_pix_pools.end()) {
-						mi_pixconv *pc = nullptr;
-						if (mi_pixconv_create(g_hub.context(), inbuf.w, inbuf.h, fmt, flip, &pc) != MI_OK) {
-							ms_error("MSPixConv: %dx%d format %d: %s", inbuf.w, inbuf.h, (int)s->in_fmt, mi_last_error());
-							freemsg(im);
-							continue;
-						}
-						PixPool *p = new PixPool(pc, inbuf.w, inbuf.h);
-						p->ticker = f->ticker;
-						g_hub.pools.push_back(p);
-						it = g_pix_pools.emplace(key, p).first;
+					const int w = inbuf.w, h = inbuf.h, msfmt = (int)s->in_fmt;
+					s->pool = bank<PixPool>("pixconv:" + std::to_string(w) + "x" + std::to_string(h) + ":" + std::to_string(msfmt), 1,
+					                        [&](int cap) { return new PixPool(cap, w, h, fmt, flip, msfmt); });
+					if (!s->pool) {
+						freemsg(im);
+						continue;
 					}
-					s->pool = it->second;
 					s->slot = s->pool->acquire(f);
 					if (s->slot < 0) s->pool = nullptr;
+					else note_slot(f);
 				}
 				uint8_t *dst = s->pool ? s->pool->stage(f, frame_ts) : nullptr;
 				if (dst) {
@@ -501,7 +500,7 @@ void pixconv_process(MSFilter *f) { // pixconv.c:62-94
 		freemsg(im);
 	}
 	if (staged_any) {
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		request_flush(f);
 	}
 }
@@ -511,7 +510,7 @@ int pixconv_set_vsize(MSFilter *f, void *arg) { // :96-100
 }
 int pixconv_set_pixfmt(MSFilter *f, void *arg) { // :102-107
 	PixConvState *s = (PixConvState *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	s->in_fmt = *(MSPixFmt *)arg;
 	pixconv_leave_pool(s, f);
 	return 0;

@@ -42,9 +42,9 @@ struct VolumePool : Pool {
 	std::vector<mi_volume_params> params;
 	std::vector<mi_volume_state> state;
 	std::vector<uint8_t> params_dirty, state_dirty;
-	VolumePool(int r) : rate(r) {
-		init_slots(g_hub.capacity);
-		MI_MUST(mi_volume_create(g_hub.context(), capacity, rate, &v));
+	VolumePool(int cap, int r) : rate(r) {
+		Building b(this, cap);
+		if (!failed) MI_MUST(mi_volume_create(hub->ctx, capacity, rate, &v));
 		cap_samples = std::max(960, rate / 100 * 2);
 		cap_samples = (cap_samples + 7) & ~7;
 		const size_t c = (size_t)capacity;
@@ -58,40 +58,42 @@ struct VolumePool : Pool {
 		mi_volume_default_params(&p);
 		params.assign(c, p);
 		state.resize(c);
-		MI_MUST(mi_volume_get_state(v, 0, capacity, state.data()));
+		if (!failed) MI_MUST(mi_volume_get_state(v, 0, capacity, state.data()));
 		params_dirty.assign(c, 0);
 		state_dirty.assign(c, 0);
 	}
+	~VolumePool() override {
+		if (v) mi_volume_destroy(v);
+	}
 	void flush() override {
-		mi_ctx *ctx = g_hub.context();
-		const size_t c = (size_t)capacity;
-		for (int s = 0; s < capacity; ++s) {
+		mi_ctx *ctx = hub->ctx;
+		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
+		for (int s = 0; s < hi; ++s) {
 			if (params_dirty[(size_t)s]) MI_MUST(mi_volume_set_params(v, s, 1, &params[(size_t)s]));
 			if (state_dirty[(size_t)s]) MI_MUST(mi_volume_set_state(v, s, 1, &state[(size_t)s]));
 			params_dirty[(size_t)s] = state_dirty[(size_t)s] = 0;
 		}
 		int maxr = 0;
-		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r = 0; r < maxr; ++r) {
 			for (int s = 0; s < capacity; ++s)
-				if (staged[(size_t)s] <= r) h_n[r * c + s] = 0;
-			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, c * cap_samples * 2));
+				if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
 			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
 			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
-			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, c * cap_samples * 2));
+			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
 		if (maxr) {
 			MI_MUST(mi_ctx_sync(ctx));
-			MI_MUST(mi_volume_get_state(v, 0, capacity, state.data())); // meters for the app thread
+			if (!failed) MI_MUST(mi_volume_get_state(v, 0, hi, state.data())); // meters for the app thread
 		}
-		for (int s = 0; s < capacity; ++s) {
-			ready[(size_t)s] = staged[(size_t)s];
+		for (int s = 0; s < hi; ++s) {
+			ready[(size_t)s] = staged[(size_t)s]; // after a failed launch the staged blocks leave as they came (unity gain)
 			staged[(size_t)s] = 0;
 		}
 	}
 	void emit(MSFilter *f, int slot) override;
 };
-std::map<std::pair<MSTicker *, int>, VolumePool *> g_volume_pools;
 
 struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	mi_volume_params p;
@@ -125,7 +127,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 void volume_uninit(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
 	if (d->pool && d->slot >= 0) {
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+		HubLock lk(f);
 		d->pool->release(d->slot);
 	}
 	ms_bufferizer_destroy(d->buffer);
@@ -143,27 +145,24 @@ void volume_push_params(VolumeData *d) {
 
 void volume_attach_slot(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
-	if (d->pool && (d->pool->rate != d->sample_rate || d->pool->ticker != f->ticker)) {
-		d->pool->release(d->slot);
-		d->pool = nullptr;
-		d->slot = -1;
-	}
-	if (!d->pool) {
-		auto key = std::make_pair(f->ticker, d->sample_rate);
-		auto it = g_volume_pools.find(key);
-		if (it == g_volume_pools.end()) {
-			VolumePool *p = new VolumePool(d->sample_rate);
-			p->ticker = f->ticker;
-			g_hub.pools.push_back(p);
-			it = g_volume_pools.emplace(key, p).first;
+	if (d->pool) { // rate changed, moved to another ticker, or the bank failed: the slot goes back (under ITS hub's lock)
+		HubLock old(f);
+		if (d->pool->failed || d->pool->rate != d->sample_rate || d->pool->hub->ticker != f->ticker) {
+			d->pool->release(d->slot);
+			d->pool = nullptr;
+			d->slot = -1;
 		}
-		d->pool = it->second;
-		d->slot = d->pool->acquire(f);
+	}
+	HubLock lk(f);
+	if (!d->pool) {
+		const int rate = d->sample_rate;
+		d->pool = bank<VolumePool>("volume:" + std::to_string(rate), 1, [&](int cap) { return new VolumePool(cap, rate); });
+		d->slot = d->pool ? d->pool->acquire(f) : -1;
 		if (d->slot < 0) {
 			d->pool = nullptr;
 			return;
 		}
+		note_slot(f);
 		// fresh slot: volume_init state, then whatever the methods set before attach
 		mi_volume_state st;
 		memset(&st, 0, sizeof(st));
@@ -193,7 +192,7 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 
 void volume_process(MSFilter *f) { // msvolume.c:471-514
 	VolumeData *d = (VolumeData *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	if (!d->pool) volume_attach_slot(f);
 	if (!d->pool) {
 		ms_queue_flush(f->inputs[0]);
@@ -272,14 +271,14 @@ float linear_to_dbm0(float linear) { // ms_volume_linear_to_dbm0 msvolume.c:565-
 
 int volume_get(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	mi_volume_state *st = vstate(d);
 	*(float *)arg = linear_to_dbm0(st ? st->energy : 0.f);
 	return 0;
 }
 int volume_get_linear(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	mi_volume_state *st = vstate(d);
 	*(float *)arg = st ? st->energy : 0.f;
 	return 0;
@@ -293,7 +292,8 @@ int volume_get_max(MSFilter *f, void *arg) {
 	return 0;
 }
 void volume_set_gains(VolumeData *d, bool also_target) {
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	if (!d->pool) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
+	HubLock lk(d->pool->hub);
 	mi_volume_state *st = vstate(d);
 	if (st) {
 		st->gain = d->gain;
@@ -341,7 +341,7 @@ int volume_set_rate(MSFilter *f, void *arg) {
 			return -1;                                             \
 		}                                                          \
 		d->p.field = val;                                          \
-		std::lock_guard<std::recursive_mutex> lk(g_hub.mu);        \
+		HubLock lk(f);        \
 		volume_push_params(d);                                     \
 		return 0;                                                  \
 	}
@@ -353,14 +353,14 @@ VOL_FLOAT_SETTER(volume_set_ng_threshold, ng_threshold, true)
 int volume_set_ea_sustain(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
 	d->p.sustain_time = *(int *)arg;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	volume_push_params(d);
 	return 0;
 }
 int volume_set_agc(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
 	d->p.agc_enabled = *(int *)arg;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	volume_push_params(d);
 	return 0;
 }
@@ -382,7 +382,7 @@ int volume_set_ng_floorgain(MSFilter *f, void *arg) { // :367-378
 int volume_remove_dc(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
 	d->p.remove_dc = *(int *)arg;
-	std::lock_guard<std::recursive_mutex> lk(g_hub.mu);
+	HubLock lk(f);
 	volume_push_params(d);
 	return 0;
 }

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "host", "libms2shim.so")  # test-only host runtime (tests/host/ms2shim.c)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -18,7 +19,8 @@ def pytest_sessionstart(session):
     build step does -- hipcc cross-compiles gfx950 without a GPU.  Building is not a fallback: nothing below computes
     without the HIP library."""
     pkg = os.path.join(ROOT, "mediastreamer2_amd")
-    need = [os.path.join(pkg, n) for n in ("libmsmi355x.so", "libms2shim.so", "libmsmi355xfilters.so")]
+    need = [os.path.join(pkg, n) for n in ("libmsmi355x.so", "libmsmi355xfilters.so")]
+    need.append(os.path.join(ROOT, "tests", "host", "libms2shim.so"))
     need.append(os.path.join(ROOT, "oracle", "liboracle.so"))
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__ as entry

@@ -278,8 +278,10 @@ typedef struct Notify {
 	struct Notify *next;
 } Notify;
 
+static void ms2shim_purge_tasks(MSFilter *f);
 void ms_filter_destroy(MSFilter *f) {
 	if (!f) return;
+	if (f->ticker && f->postponed_task) ms2shim_purge_tasks(f); /* never leave a task pointing at freed memory */
 	if (f->desc->uninit) f->desc->uninit(f);
 	for (Notify *n = (Notify *)f->notify_callbacks; n;) {
 		Notify *nx = n->next;
@@ -505,6 +507,20 @@ int ms_ticker_attach(MSTicker *t, MSFilter *f) {
 	return 0;
 }
 
+static void remove_tasks_for_filter(TickerImpl *ti, MSFilter *f) { /* msticker.c:314-324 */
+	Task **pp = &ti->tasks;
+	while (*pp) {
+		if ((*pp)->f == f) {
+			Task *dead = *pp;
+			*pp = dead->next;
+			free(dead);
+		} else pp = &(*pp)->next;
+	}
+	f->postponed_task = 0;
+}
+
+static void ms2shim_purge_tasks(MSFilter *f) { remove_tasks_for_filter((TickerImpl *)f->ticker->impl, f); }
+
 int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	/* detach the whole connected graph of f */
@@ -514,6 +530,7 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 	find_neighbours(f, &tmp);
 	for (int i = 0; i < tmp.nfilters; ++i) {
 		MSFilter *g = tmp.filters[i];
+		if (g->postponed_task) remove_tasks_for_filter(ti, g); /* call_postprocess msticker.c:187-190: BEFORE postprocess */
 		if (g->desc->postprocess) g->desc->postprocess(g);
 		g->ticker = NULL;
 		g->seen = FALSE;

@@ -41,11 +41,11 @@ class EqGain(C.Structure):
 
 
 class Host:
-    """ctypes view of the shim runtime (mediastreamer2_amd/host/ms2shim.c)."""
+    """ctypes view of the shim runtime (tests/host/ms2shim.c)."""
 
     def __init__(self):
         import torch  # noqa: F401  (one HIP runtime per process, see mediastreamer2_amd/_lib.py)
-        self.S = C.CDLL(os.path.join(PKG, "libms2shim.so"), mode=C.RTLD_GLOBAL)
+        self.S = C.CDLL(os.path.join(ROOT, "tests", "host", "libms2shim.so"), mode=C.RTLD_GLOBAL)
         S = self.S
         vp = C.c_void_p
         S.ms_factory_new.restype = vp
@@ -387,8 +387,9 @@ def test_two_ticker_threads_run_concurrently(host, oracle):
 
 
 def test_mixer_bypass_and_contributor_timeout(host, oracle):
-    # audiomixer.c:244-286: with a single contributing pin the mixer forwards its blocks untouched, in the same tick,
-    # to the other outputs (not to its own in conference mode).  A linked pin counts as a contributor while it has data
+    # audiomixer.c:244-286: with a single contributing pin the mixer forwards its blocks untouched to the other outputs
+    # (not to its own in conference mode) -- in this facade ONE TICK LATER, like mixed blocks, so that its latency does not
+    # jump when the mode changes (mixer.inl, MixerState::held).  A linked pin counts as a contributor while it has data
     # or had some -- or was first looked at (the reference's quirk, :257-259) -- less than 1000 ms ago; two
     # contributors bring the mixed path back.
     mx = host.create(MS_AUDIO_MIXER_ID)
@@ -404,7 +405,7 @@ def test_mixer_bypass_and_contributor_timeout(host, oracle):
     a = synth_pcm(21, n * 160, rate=16000)
     b = synth_pcm(22, n * 160, rate=16000, sigma=2000.0)
     # phase 0: only A talks, but pin 1 was first looked at in tick 0 and so "contributes" for the first second: tick 0
-    # is a bypass tick (pin 1's clock only starts), ticks 1..100 take the mixed path (B hears A one tick later)
+    # is a bypass tick (pin 1's clock only starts), ticks 1..100 take the mixed path; either way B hears A one tick later
     for t in range(101):
         host.push(sa, a[t * n:(t + 1) * n])
         host.step(1)
@@ -412,12 +413,14 @@ def test_mixer_bypass_and_contributor_timeout(host, oracle):
     gb = host.drain(kb)
     np.testing.assert_array_equal(gb[:101 * n], a[:101 * n])
     assert not host.drain(ka).any()
-    # phase 1: pin 1 timed out -> bypass: B's output gets A's block in the SAME tick, A's own output nothing
+    # phase 1: pin 1 timed out -> bypass: B's output gets A's block of the PREVIOUS tick (constant one-tick latency),
+    # A's own output nothing
     for t in range(101, 106):
         before = host.S.ms2shim_sink_blocks(kb)
         host.push(sa, a[t * n:(t + 1) * n])
         host.step(1)
-        assert host.S.ms2shim_sink_blocks(kb) == before + 1
+        assert host.S.ms2shim_sink_blocks(kb) == before + (1 if t > 101 else 0)
+    host.step(1)
     np.testing.assert_array_equal(host.drain(kb)[-5 * n:], a[101 * n:106 * n])
     assert host.S.ms2shim_sink_size(ka) == 0
     # phase 2: both talk -> the batch mixes (one tick later): each hears the other
@@ -436,8 +439,10 @@ def test_mixer_bypass_and_contributor_timeout(host, oracle):
     before = host.S.ms2shim_sink_blocks(kb)
     host.step(5)
     assert host.S.ms2shim_sink_blocks(kb) == before
-    # A alone again -> bypass again, same tick
+    # A alone again -> bypass again, out one tick later
     host.push(sa, a[120 * n:121 * n])
+    host.step(1)
+    assert host.S.ms2shim_sink_size(kb) == 0
     host.step(1)
     np.testing.assert_array_equal(host.drain(kb), a[120 * n:121 * n])
     host.S.ms_ticker_detach(host.ticker, mx)
@@ -705,3 +710,88 @@ def test_speex_ec_burst_of_frames_in_one_tick(host, oracle):
     assert len(got) == len(ref)
     d = got.astype(np.float64) - ref.astype(np.float64)
     assert np.sqrt(np.mean(d ** 2)) / 32768.0 <= 1e-4
+
+
+def _runtime_stats(host):
+    P = C.CDLL(os.path.join(PKG, "libmsmi355xfilters.so"))
+    P.ms_mi355x_late_events.restype = C.c_ulonglong
+    h, b, s = C.c_int(), C.c_int(), C.c_int()
+    P.ms_mi355x_runtime_stats(C.byref(h), C.byref(b), C.byref(s))
+    return h.value, b.value, s.value, P.ms_mi355x_late_events()
+
+
+def test_mixer_keeps_mixing_after_detach_and_reattach_on_the_same_ticker(host):
+    """MSAudioConference detaches and re-attaches its mixer on the same ticker at every member add / remove
+    (src/voip/audioconference.c:325-327,:369-374), and the ticker drops a detached filter's postponed tasks
+    (src/base/msticker.c:187-190,:314-324): the flush request the mixer had pending dies with the detach.  The plugin must
+    post a new one afterwards -- with a sticky 'flush pending' flag the mixer never emitted another block."""
+    mx = host.create(MS_AUDIO_MIXER_ID)
+    assert host.call_int(mx, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(mx, SET_NCHANNELS, 1) == 0
+    assert host.call_int(mx, mid(MS_AUDIO_MIXER_ID, 2, 4), 1) == 0       # ENABLE_CONFERENCE_MODE
+    sa, sb, ka, kb = host.source(), host.source(), host.sink(), host.sink()
+    host.link(sa, 0, mx, 0)
+    host.link(sb, 0, mx, 1)
+    host.link(mx, 0, ka, 0)
+    host.link(mx, 1, kb, 0)
+    n = 160
+    a = synth_pcm(31, n * 60, rate=16000)
+    b = synth_pcm(32, n * 60, rate=16000, sigma=2000.0)
+    pos = 0
+    for round_ in range(3):
+        host.S.ms_ticker_attach(host.ticker, mx)
+        for t in range(10):
+            host.push(sa, a[(pos + t) * n:(pos + t + 1) * n])
+            host.push(sb, b[(pos + t) * n:(pos + t + 1) * n])
+            host.step(1)
+        # detach right after a tick that staged work: the mixer's flush request is pending and is dropped by the ticker
+        host.S.ms_ticker_detach(host.ticker, mx)
+        ga, gb = host.drain(ka), host.drain(kb)
+        assert len(ga) >= 8 * n, f"round {round_}: the mixer delivered {len(ga)} samples"   # the last tick may die with the detach
+        np.testing.assert_array_equal(ga[:8 * n], b[pos * n:(pos + 8) * n])
+        np.testing.assert_array_equal(gb[:8 * n], a[pos * n:(pos + 8) * n])
+        pos += 10
+    for f in (mx, sa, sb, ka, kb):
+        host.S.ms_filter_destroy(f)
+
+
+def test_banks_grow_and_are_freed_with_their_last_slot(host, oracle):
+    """40 MSVolume filters on one ticker: banks of 16 and 64 slots (no 'pool exhausted'), every filter served; once the
+    filters are destroyed the banks (device objects, pinned buffers) and the ticker's hub are gone -- a ticker per call
+    must not leak one pool set per call."""
+    h0, b0, s0, late0 = _runtime_stats(host)
+    S = host.S
+    tk = S.ms_ticker_new()
+    chains = []
+    for i in range(40):
+        v = host.create(MS_VOLUME_ID)
+        assert host.call_int(v, SET_SAMPLE_RATE, 16000) == 0
+        g = C.c_float(0.5)
+        assert host.call(v, mid(MS_VOLUME_ID, 2, 4), g) == 0  # MS_VOLUME_SET_GAIN
+        src, snk = host.source(), host.sink()
+        host.link(src, 0, v, 0)
+        host.link(v, 0, snk, 0)
+        S.ms_ticker_attach(tk, v)
+        chains.append((src, v, snk))
+    h1, b1, s1, _ = _runtime_stats(host)
+    assert s1 - s0 == 40 and b1 - b0 == 2 and h1 - h0 == 1
+    x = [synth_pcm(100 + i, 160 * 4, rate=16000) for i in range(40)]
+    for t in range(4):
+        for i, (src, _, _) in enumerate(chains):
+            host.push(src, x[i][t * 160:(t + 1) * 160])
+        S.ms_ticker_step(tk)
+    S.ms_ticker_step(tk)
+    for i, (_, _, snk) in enumerate(chains):
+        got = host.drain(snk)
+        vo = oracle.Volume(16000)
+        oracle.lib().orc_volume_set_gain(vo.v, 0.5)
+        want = np.concatenate([vo.chunk(x[i][t * 160:(t + 1) * 160].copy()) for t in range(4)])
+        np.testing.assert_array_equal(got, want)
+    for src, v, snk in chains:
+        S.ms_ticker_detach(tk, v)
+    for src, v, snk in chains:
+        for f in (src, v, snk):
+            S.ms_filter_destroy(f)
+    S.ms_ticker_destroy(tk)
+    h2, b2, s2, late2 = _runtime_stats(host)
+    assert (h2, b2, s2) == (h0, b0, s0), "banks / hub of the destroyed ticker are still alive"
+    assert late2 == late0

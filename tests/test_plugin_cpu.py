@@ -16,9 +16,10 @@ def mid(fid, idx, argsize):
 
 @pytest.fixture(scope="module")
 def shim():
-    for lib in ("libms2shim.so", "libmsmi355xfilters.so", "libmsmi355x.so"):
+    for lib in ("libmsmi355xfilters.so", "libmsmi355x.so"):
         assert os.path.exists(os.path.join(PKG, lib)), f"{lib} not built (run __graft_entry__.build())"
-    S = C.CDLL(os.path.join(PKG, "libms2shim.so"), mode=C.RTLD_GLOBAL)
+    assert os.path.exists(os.path.join(ROOT, "tests", "host", "libms2shim.so")), "tests/host/libms2shim.so not built"
+    S = C.CDLL(os.path.join(ROOT, "tests", "host", "libms2shim.so"), mode=C.RTLD_GLOBAL)
     vp = C.c_void_p
     S.ms_factory_new.restype = vp
     S.ms_factory_create_filter.restype = vp
@@ -32,13 +33,16 @@ def shim():
     S.ms_filter_destroy.argtypes = [vp]
     S.ms2shim_method_id.restype = C.c_uint
     fac = S.ms_factory_new()
+    # without a HIP device the plugin registers nothing (the reference's filters stay in charge); this module inspects
+    # the descriptors on a CPU-only box, so it asks for registration all the same
+    os.environ["MSMI355X_REGISTER_WITHOUT_DEVICE"] = "1"
     assert S.ms_factory_load_plugin(fac, os.path.join(PKG, "libmsmi355xfilters.so").encode()) == 0
     return S, fac
 
 
 def test_plugin_exports_the_loader_entry_point():
     """src/base/msfactory.c:549-555: "<file name up to .so>_init"."""
-    P = C.CDLL(os.path.join(PKG, "libms2shim.so"), mode=C.RTLD_GLOBAL)  # provides the ms2 symbols the plugin needs
+    P = C.CDLL(os.path.join(ROOT, "tests", "host", "libms2shim.so"), mode=C.RTLD_GLOBAL)  # provides the ms2 symbols the plugin needs
     L = C.CDLL(os.path.join(PKG, "libmsmi355xfilters.so"))
     assert hasattr(L, "libmsmi355xfilters_init")
     for d in ("ms_mi355x_resample_desc", "ms_mi355x_audio_mixer_desc", "ms_mi355x_volume_desc",
@@ -97,3 +101,27 @@ def test_method_tables_host_side(shim):
     b = C.c_ubyte(1)
     assert S.ms_filter_call_method(ec, mid(16388, 3, 1), C.byref(b)) == 0     # bypass mode
     S.ms_filter_destroy(ec)
+
+
+def test_without_a_device_the_plugin_steps_aside():
+    """No HIP device and no override: libmsmi355xfilters_init registers nothing, so the factory keeps handing out whatever
+    was registered before it (the reference's CPU filters in a real host; nothing at all in the test runtime) -- run in a
+    child process so that the override of the fixture above does not apply."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, os, sys\n"
+        "os.environ.pop('MSMI355X_REGISTER_WITHOUT_DEVICE', None)\n"
+        "os.environ['HIP_VISIBLE_DEVICES'] = ''\n"
+        f"S = C.CDLL({os.path.join(ROOT, 'tests', 'host', 'libms2shim.so')!r}, mode=C.RTLD_GLOBAL)\n"
+        "S.ms_factory_new.restype = C.c_void_p\n"
+        "S.ms_factory_load_plugin.argtypes = [C.c_void_p, C.c_char_p]\n"
+        "S.ms_factory_lookup_filter_by_id.restype = C.c_void_p\n"
+        "S.ms_factory_lookup_filter_by_id.argtypes = [C.c_void_p, C.c_int]\n"
+        "fac = S.ms_factory_new()\n"
+        f"assert S.ms_factory_load_plugin(fac, {os.path.join(PKG, 'libmsmi355xfilters.so')!r}.encode()) == 0\n"
+        "sys.exit(0 if not S.ms_factory_lookup_filter_by_id(fac, 41) else 7)\n"
+    )
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "NOT registered" in p.stderr
