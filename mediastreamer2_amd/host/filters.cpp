@@ -134,6 +134,12 @@ struct TickerHub {
 	mi_ctx *ctx = nullptr;
 	std::vector<Pool *> pools;         // flush order = creation order
 	MSFilter *flush_owner = nullptr;   // the filter whose postponed task will flush this ticker's pools (NULL: none pending)
+	// chain linking: while the flush task runs, a facade that emits into a queue read by ANOTHER facade of this ticker has
+	// that one run right away (then its bank is flushed in the same task): a chain of GPU filters costs one tick, not one
+	// tick per filter
+	bool in_flush = false;
+	std::vector<MSFilter *> touched, touched_pumps;
+	std::unordered_map<MSFilter *, uint64_t> pumped; // pump facades run early by the flush task, and for which tick
 	bool dead = false;                 // no banks left: removed from the registry, deleted by the last HubLock
 	int locks = 0;
 };
@@ -178,6 +184,12 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 struct HubLock {
 	TickerHub *h, *prev;
 	explicit HubLock(MSFilter *f) : h(hub_for(f, true)), prev(tl_hub) {
+		h->mu.lock();
+		++h->locks;
+		tl_hub = h;
+	}
+	// hot path: a filter that holds a slot knows its hub through the bank -- no registry lookup
+	HubLock(MSFilter *f, Pool *p) : h(p ? p->hub : hub_for(f, true)), prev(tl_hub) {
 		h->mu.lock();
 		++h->locks;
 		tl_hub = h;
@@ -281,14 +293,72 @@ void note_slot(MSFilter *f) { // the filter holds one more slot on the current h
 	r.slots++;
 }
 
+bool is_ours(const MSFilterDesc *d); // one of the descriptors below
+
+// every ms_queue_put of the facades goes through here (macro below): during the flush task it also notes the reader
+inline void emit_to(MSQueue *q, mblk_t *m) {
+	ms_queue_put(q, m);
+	TickerHub *h = tl_hub;
+	if (!h || !h->in_flush) return;
+	MSFilter *g = q->next.filter;
+	if (!g || g->ticker != h->ticker || !h->ticker || !is_ours(g->desc)) return;
+	std::vector<MSFilter *> &v = (g->desc->flags & MS_FILTER_IS_PUMP) ? h->touched_pumps : h->touched;
+	if (std::find(v.begin(), v.end(), g) == v.end()) v.push_back(g);
+}
+
+bool inputs_waiting(MSFilter *g) {
+	for (int i = 0; i < g->desc->ninputs; ++i)
+		if (g->inputs[i] && !ms_queue_empty(g->inputs[i])) return true;
+	return false;
+}
+
+// a pump facade (mixer, PLC, channel adapter) may run ahead of the graph only if everything it reads comes from facades
+// of this plugin: a CPU filter's block for this tick has not been produced yet when the tasks run
+bool all_inputs_ours(MSFilter *g) {
+	for (int i = 0; i < g->desc->ninputs; ++i)
+		if (g->inputs[i] && (!g->inputs[i]->prev.filter || !is_ours(g->inputs[i]->prev.filter->desc))) return false;
+	return true;
+}
+
+// pump facades call this first in process(): true = the flush task already ran them for this tick
+bool already_ran_this_tick(MSFilter *f) {
+	TickerHub &h = g_hub;
+	if (h.in_flush || !f->ticker) return false;
+	auto it = h.pumped.find(f);
+	return it != h.pumped.end() && it->second == f->ticker->time;
+}
+
 void flush_hub(TickerHub &h) {
-	// banks flushed in creation order; a facade may stage into a later bank while an earlier one emits (chained facades)
-	for (size_t i = 0; i < h.pools.size(); ++i) {
-		Pool *p = h.pools[i];
-		if (p->failed) continue;
-		p->flush();
-		p->emit_all();
+	static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr; // A/B switch: one tick per facade again
+	h.in_flush = !no_chain;
+	h.touched.clear();
+	h.touched_pumps.clear();
+	for (int round = 0; round < 16; ++round) { // chains deeper than this finish on the next tick
+		// banks flushed in creation order; a facade may stage into any bank while another one emits
+		for (size_t i = 0; i < h.pools.size(); ++i) {
+			Pool *p = h.pools[i];
+			if (p->failed) continue;
+			p->flush();
+			p->emit_all();
+		}
+		if (!h.in_flush) break;
+		std::vector<MSFilter *> run;
+		run.swap(h.touched);
+		if (run.empty()) { // nothing but pumps left: they go last, once everything that feeds them has arrived
+			for (MSFilter *g : h.touched_pumps)
+				if (all_inputs_ours(g) && g->ticker) {
+					h.pumped[g] = g->ticker->time;
+					run.push_back(g);
+				}
+			h.touched_pumps.clear();
+			if (run.empty()) break;
+			for (MSFilter *g : run) g->desc->process(g);
+			continue;
+		}
+		for (MSFilter *g : run) // call_process msticker.c:244-259: while there is input (a filter that staged stops)
+			for (int n = 0; n < 64 && inputs_waiting(g); ++n) g->desc->process(g);
 	}
+	h.in_flush = false;
 }
 
 // Runs on the ticker thread at the start of the next tick, before any process() (msticker.c:301-312):
@@ -302,6 +372,7 @@ void flush_task(MSFilter *f) {
 
 // called by a filter that staged work this tick (hub locked)
 void request_flush(MSFilter *f) {
+	if (g_hub.in_flush) return; // staged from inside the flush task (chain linking): the task's loop gets to it
 	if (!g_hub.flush_owner) {
 		g_hub.flush_owner = f;
 		ms_filter_postpone_task(f, flush_task);
@@ -315,8 +386,11 @@ void facade_detached(MSFilter *f) {
 	if (!h) return;
 	HubLock lk(h);
 	if (h->flush_owner == f) h->flush_owner = nullptr;
+	h->pumped.erase(f);
 }
 void generic_postprocess(MSFilter *f) { facade_detached(f); }
+
+#define ms_queue_put(q, m) emit_to((q), (m)) /* the facades' queue puts, see emit_to */
 
 #include "filters/resample.inl"
 #include "filters/volume.inl"
@@ -384,6 +458,20 @@ MSFilterDesc ms_mi355x_audio_flow_control_desc = {MS_AUDIO_FLOW_CONTROL_ID, "MSA
                                                   "Flow control filter to drop sample in the audio graph if too many samples are queued (MI355X batch)",
                                                   MS_FILTER_OTHER, NULL, 1, 1, flowctl_init, flowctl_preprocess, flowctl_process, flowctl_postprocess,
                                                   flowctl_uninit, flowctl_methods, MS_FILTER_IS_HW_ACCELERATED};
+
+} // extern "C"
+namespace {
+bool is_ours(const MSFilterDesc *d) {
+	for (const MSFilterDesc *o : {&ms_mi355x_resample_desc, &ms_mi355x_audio_mixer_desc, &ms_mi355x_volume_desc, &ms_mi355x_equalizer_desc,
+	                              &ms_mi355x_speex_ec_desc, &ms_mi355x_size_conv_desc, &ms_mi355x_pix_conv_desc, &ms_mi355x_alaw_dec_desc,
+	                              &ms_mi355x_ulaw_dec_desc, &ms_mi355x_alaw_enc_desc, &ms_mi355x_ulaw_enc_desc, &ms_mi355x_l16_enc_desc,
+	                              &ms_mi355x_l16_dec_desc, &ms_mi355x_channel_adapter_desc, &ms_mi355x_audio_flow_control_desc,
+	                              &ms_mi355x_generic_plc_desc})
+		if (o == d) return true;
+	return false;
+}
+} // namespace
+extern "C" {
 
 void libmsmi355xfilters_init(MSFactory *factory) {
 	// No usable HIP device: register NOTHING -- the reference's own CPU filters stay in charge (src/base/msfactory.c:281:

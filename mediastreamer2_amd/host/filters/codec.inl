@@ -464,6 +464,7 @@ void adapter_process(MSFilter *f) { // :95-123
 	MapFilter *d = (MapFilter *)f->data;
 	map_rehome(f, d);
 	HubLock lk(f);
+	if (already_ran_this_tick(f)) return; // pumped by the flush task right behind the facades that feed it
 	if (f->inputs[0] != NULL && f->inputs[1] != NULL && d->side[0]) {
 		adapter_two_inputs(f, d);
 		return;

@@ -318,7 +318,7 @@ void ec_process(MSFilter *f) {
 			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
 		return;
 	}
-	HubLock lk(f);
+	HubLock lk(f, s->pool);
 	EcPool *p = s->pool;
 	const size_t nbytes = (size_t)s->framesize * 2, cap = (size_t)p->capacity, slot = (size_t)s->slot;
 	ec_take_far_end(f, s);

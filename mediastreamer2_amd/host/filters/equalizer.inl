@@ -115,7 +115,7 @@ void equalizer_uninit(MSFilter *f) {
 }
 void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	EqualizerData *d = (EqualizerData *)f->data;
-	HubLock lk(f);
+	HubLock lk(f, d->pool);
 	mblk_t *m;
 	if (!d->pool) equalizer_attach(f);
 	if (!d->pool) {

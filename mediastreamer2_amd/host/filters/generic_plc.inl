@@ -164,6 +164,7 @@ void plc_preprocess(MSFilter *f) {
 void plc_process(MSFilter *f) { // generic_plc_process :59-167
 	PlcFilter *d = (PlcFilter *)f->data;
 	HubLock lk(f);
+	if (already_ran_this_tick(f)) return; // pumped by the flush task right behind the decoder that feeds it
 	if (d->rate <= 0 || !plc_attach(f, d)) { // no usable context: the stream passes as it is
 		mblk_t *m;
 		while ((m = ms_queue_get(f->inputs[0])) != NULL) ms_queue_put(f->outputs[0], m);

@@ -288,7 +288,11 @@ void MixerPool::emit(MSFilter *f, int slot) {
 void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
 	ms_filter_lock(f);
-	HubLock lk(f);
+	HubLock lk(f, s->pool);
+	if (already_ran_this_tick(f)) { // the flush task pumped this mixer right behind the facades that feed it
+		ms_filter_unlock(f);
+		return;
+	}
 	mixer_release_held(f, s, true); // what bypass mode forwarded on the previous tick
 	if (!s->pool) {
 		ms_filter_unlock(f);

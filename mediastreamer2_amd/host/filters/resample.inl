@@ -130,7 +130,7 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 		HubLock old(d->pool->hub);
 		resample_release(d);
 	}
-	HubLock lk(f);
+	HubLock lk(f, d->pool);
 	const int nch = d->in_nchannels < 1 ? 1 : d->in_nchannels;
 	if (d->pool && (d->pool->failed || d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate || (int)d->slots->size() != nch))
 		resample_release(d); // rates / channels changed: the handle is re-created, history lost (:138-148)

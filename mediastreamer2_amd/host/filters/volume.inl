@@ -192,7 +192,7 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 
 void volume_process(MSFilter *f) { // msvolume.c:471-514
 	VolumeData *d = (VolumeData *)f->data;
-	HubLock lk(f);
+	HubLock lk(f, d->pool);
 	if (!d->pool) volume_attach_slot(f);
 	if (!d->pool) {
 		ms_queue_flush(f->inputs[0]);

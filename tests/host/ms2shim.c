@@ -460,10 +460,18 @@ typedef struct Task {
 } Task;
 
 typedef struct TickerImpl {
-	MSFilter *filters[4096]; /* every filter of the attached graphs */
-	int nfilters;
+	MSFilter **filters; /* every filter of the attached graphs */
+	int nfilters, cap;
 	Task *tasks;
 } TickerImpl;
+
+static void ti_add(TickerImpl *ti, MSFilter *f) {
+	if (ti->nfilters == ti->cap) {
+		ti->cap = ti->cap ? 2 * ti->cap : 1024;
+		ti->filters = (MSFilter **)realloc(ti->filters, sizeof(MSFilter *) * (size_t)ti->cap);
+	}
+	ti->filters[ti->nfilters++] = f;
+}
 
 MSTicker *ms_ticker_new(void) {
 	MSTicker *t = (MSTicker *)ms_malloc0(sizeof(*t));
@@ -480,6 +488,7 @@ void ms_ticker_destroy(MSTicker *t) {
 		free(ti->tasks);
 		ti->tasks = n;
 	}
+	free(ti->filters);
 	free(ti);
 	free(t);
 }
@@ -487,7 +496,7 @@ void ms_ticker_destroy(MSTicker *t) {
 static void find_neighbours(MSFilter *f, TickerImpl *ti) { /* msfilter.c:303-344 */
 	if (f->seen) return;
 	f->seen = TRUE;
-	if (ti->nfilters < 4096) ti->filters[ti->nfilters++] = f;
+	ti_add(ti, f);
 	for (int i = 0; i < f->desc->ninputs; ++i)
 		if (f->inputs[i]) find_neighbours(f->inputs[i]->prev.filter, ti);
 	for (int i = 0; i < f->desc->noutputs; ++i)
@@ -534,11 +543,13 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 		if (g->desc->postprocess) g->desc->postprocess(g);
 		g->ticker = NULL;
 		g->seen = FALSE;
-		for (int k = 0; k < ti->nfilters; ++k)
-			if (ti->filters[k] == g) {
-				ti->filters[k] = ti->filters[--ti->nfilters];
-				break;
-			}
+	}
+	free(tmp.filters);
+	{ /* one compaction pass: what is still scheduled by this ticker stays */
+		int j = 0;
+		for (int i = 0; i < ti->nfilters; ++i)
+			if (ti->filters[i]->ticker == t) ti->filters[j++] = ti->filters[i];
+		ti->nfilters = j;
 	}
 	for (int i = 0; i < ti->nfilters; ++i) ti->filters[i]->seen = TRUE;
 	return 0;
@@ -628,6 +639,7 @@ typedef struct {
 	size_t len, cap;
 	int nblocks;
 	uint32_t last_ts;
+	int discard;
 } SinkData;
 
 static void src_init(MSFilter *f) {
@@ -660,6 +672,13 @@ static void sink_process(MSFilter *f) {
 	mblk_t *m;
 	while ((m = ms_queue_get(f->inputs[0])) != NULL) {
 		size_t n = msgdsize(m);
+		if (d->discard) { /* rate measurements: count, do not keep */
+			d->len += n;
+			d->last_ts = mblk_get_timestamp_info(m);
+			d->nblocks++;
+			freemsg(m);
+			continue;
+		}
 		if (d->len + n > d->cap) {
 			d->cap = (d->len + n) * 2 + 4096;
 			d->buf = (uint8_t *)realloc(d->buf, d->cap);
@@ -678,6 +697,8 @@ static MSFilterDesc shim_source_desc = {SHIM_SOURCE_ID, "ShimSource", "test sour
                                         src_init, NULL, src_process, NULL, src_uninit, NULL, 0};
 static MSFilterDesc shim_sink_desc = {SHIM_SINK_ID, "ShimSink", "test sink", MS_FILTER_OTHER, NULL, 1, 0,
                                       sink_init, NULL, sink_process, NULL, sink_uninit, NULL, 0};
+
+void ms2shim_sink_set_discard(MSFilter *f, int on) { ((SinkData *)f->data)->discard = on; }
 
 void ms2shim_register_test_filters(MSFactory *f) {
 	ms_factory_register_filter(f, &shim_source_desc);

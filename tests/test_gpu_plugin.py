@@ -795,3 +795,47 @@ def test_banks_grow_and_are_freed_with_their_last_slot(host, oracle):
     h2, b2, s2, late2 = _runtime_stats(host)
     assert (h2, b2, s2) == (h0, b0, s0), "banks / hub of the destroyed ticker are still alive"
     assert late2 == late0
+
+
+def test_a_chain_of_gpu_facades_costs_one_tick_in_total(host, oracle):
+    """source -> MSResample 8k->16k -> MSVolume (gain 0.5) -> MSEqualizer (flat) -> sink: the flush task at the start of
+    the next tick runs the resampler's bank, hands its output to the volume facade, runs that bank, and so on -- the
+    block pushed in tick t is at the sink after tick t+1, not t+3 (src/base/msticker.c:301-312 runs tasks before graphs).
+    Content: the chain of oracles."""
+    rs, vol, eq = host.create(MS_RESAMPLE_ID), host.create(MS_VOLUME_ID), host.create(MS_EQUALIZER_ID)
+    assert host.call_int(rs, SET_SAMPLE_RATE, 8000) == 0 and host.call_int(rs, SET_OUTPUT_SAMPLE_RATE, 16000) == 0
+    assert host.call_int(vol, SET_SAMPLE_RATE, 16000) == 0 and host.call_int(eq, SET_SAMPLE_RATE, 16000) == 0
+    g = C.c_float(0.5)
+    assert host.call(vol, mid(MS_VOLUME_ID, 2, 4), g) == 0  # MS_VOLUME_SET_GAIN
+    src, snk = host.source(), host.sink()
+    host.link(src, 0, rs, 0)
+    host.link(rs, 0, vol, 0)
+    host.link(vol, 0, eq, 0)
+    host.link(eq, 0, snk, 0)
+    host.S.ms_ticker_attach(host.ticker, rs)
+    nt = 12
+    x = synth_pcm(77, 80 * nt, rate=8000)
+    arrived = []
+    for t in range(nt):
+        host.push(src, x[t * 80:(t + 1) * 80])
+        host.step(1)
+        arrived.append(host.S.ms2shim_sink_blocks(snk))
+    host.step(1)
+    arrived.append(host.S.ms2shim_sink_blocks(snk))
+    assert arrived[0] == 0 and arrived[1] == 1, f"blocks at the sink after each tick: {arrived}"   # one tick for three facades
+    assert arrived[-1] == nt
+    got = host.drain(snk)
+    r = oracle.Resampler(8000, 16000)
+    vo = oracle.Volume(16000)
+    oracle.lib().orc_volume_set_gain(vo.v, 0.5)
+    eqo = oracle.Equalizer(16000)
+    want = []
+    for t in range(nt):
+        up = r.process(x[t * 80:(t + 1) * 80])
+        want.append(eqo.run(vo.chunk(up.copy())))
+    want = np.concatenate(want)
+    assert len(got) == len(want)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1   # the resampler's 1 LSB (FMA order)
+    host.S.ms_ticker_detach(host.ticker, rs)
+    for f in (rs, vol, eq, src, snk):
+        host.S.ms_filter_destroy(f)
