@@ -200,10 +200,21 @@ typedef struct _MSFilter { /* msfilter.h:186-210 */
 	bool_t seen;
 } MSFilter;
 
-typedef struct _MSTicker { /* only what filters read: msfilter.h:203, msticker.c:46 */
-	uint64_t time;   /* ms */
-	int interval;    /* ms, 10 */
+/* include/mediastreamer2/msticker.h:73-98, field for field up to `time` (the last field a filter reads: `interval`,
+ * `ticks`, `time`): ms_mutex_t / ms_cond_t / ms_thread_t are the pthread types on Linux (ortp/port.h), MSList is
+ * bctbx_list_t.  What follows `time` in the reference is never touched by filters; the test runtime keeps its own state
+ * behind `impl` there. */
+typedef struct _MSTicker {
+	pthread_mutex_t lock;  /* main lock protecting the filter execution list */
+	pthread_cond_t cond;
+	void *execution_list;  /* MSList * of source filters */
+	void *task_list;       /* MSList * of postponed tasks (ms_filter_postpone_task) */
+	pthread_t thread;
+	int interval;          /* ms, TICKER_INTERVAL = 10 (msticker.c:46) */
+	int exec_id;
 	uint32_t ticks;
+	uint64_t time;         /* ms since the ticker started */
+	/* -- end of the part filters see -- */
 	void *impl;
 } MSTicker;
 

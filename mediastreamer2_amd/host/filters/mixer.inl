@@ -221,12 +221,12 @@ void mixer_forward(MSFilter *f, MixerState *s, int from_pin) {
 bool_t mixer_check_bypass(MSFilter *f, MixerState *s) {
 	const Contributors c = mixer_census(f, s);
 	if (c.count > 1) {
-		if (s->bypass_mode) ms_message("MSAudioMixer [%p] is leaving bypass mode.", (void *)f);
+		if (s->bypass_mode) ms_message("mi355x mixer %p: two or more contributors, mixing on the device again", (void *)f);
 		s->bypass_mode = FALSE;
 		return FALSE;
 	}
 	if (c.count == 1) {
-		if (!s->bypass_mode) ms_message("MSAudioMixer [%p] is entering bypass mode.", (void *)f);
+		if (!s->bypass_mode) ms_message("mi355x mixer %p: a single contributor, forwarding its blocks", (void *)f);
 		s->bypass_mode = TRUE;
 		mixer_forward(f, s, c.pin);
 	}
@@ -315,7 +315,7 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 		has[i] = ms_bufferizer_read(&chan->bufferizer, (uint8_t *)(in + (size_t)i * nwords), (size_t)nwords * 2) != 0;
 		const int skip = channel_flow_control(chan, s->skip_threshold, f->ticker->time);
 		if (skip > 0)
-			ms_warning("Too much data in channel %i, %i ms in excess dropped", i, (skip * 1000) / (2 * s->nchannels * s->rate));
+			ms_warning("mi355x mixer: pin %i kept more than two ticks queued for 5 s; %i ms discarded", i, (skip * 1000) / (2 * s->nchannels * s->rate));
 	}
 	p->h_mode[(size_t)s->slot] = (uint8_t)(s->conf_mode != 0);
 	p->staged[(size_t)s->slot] = 1; // ALWAYS_STREAMOUT :315-317
@@ -341,7 +341,7 @@ int mixer_get_nchannels(MSFilter *f, void *data) {
 }
 bool mixer_pin_ok(const char *who, int pin) {
 	if (pin < 0 || pin >= MIXER_MAX_CHANNELS) {
-		ms_warning("%s: invalid pin number %i", who, pin);
+		ms_warning("mi355x mixer, %s: there is no pin %i", who, pin);
 		return false;
 	}
 	return true;

@@ -301,7 +301,7 @@ ScalerPool *size_conv_pool(MSFilter *f, SizeConvState *s, int w, int h) {
 	else note_slot(f);
 	s->in_vsize.width = w;
 	s->in_vsize.height = h;
-	ms_message("MSSizeConv: create new scaler context with w %d, h %d", w, h);
+	ms_message("mi355x size converter: joined the %dx%d -> %dx%d batch", w, h, dw, dh);
 	return s->pool;
 }
 
@@ -316,7 +316,7 @@ bool size_conv_rate_gate(MSFilter *f, SizeConvState *s) {
 	if (s->fps < 0) return true; // unlimited: every frame goes through
 	const int due = (int)((f->ticker->time - s->start_time) * s->fps / 1000.0);
 	while (s->rq.q_mcount > 1) { // older captures are dropped, the most recent one stays
-		ms_message("MSSizeConv: extra frame removed.");
+		ms_message("mi355x size converter: a frame beyond the configured fps was dropped");
 		freemsg(getq(&s->rq));
 	}
 	return due > s->frame_count;
@@ -363,7 +363,7 @@ void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
 	for (mblk_t *im; (im = getq(&s->rq)) != NULL;) {
 		YuvBuf in;
 		if (ms_yuv_buf_init_from_mblk(&in, im) != 0) {
-			ms_warning("size_conv_process(): bad buffer.");
+			ms_warning("mi355x size converter: the input block is no I420 frame (header / size mismatch); dropped");
 			freemsg(im);
 			continue;
 		}
@@ -376,11 +376,11 @@ void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
 			s->needRefresh = TRUE;
 			ms_filter_notify_no_arg(f, MS_FILTER_OUTPUT_FMT_CHANGED);
 		} else if (s->needRefresh) {
-			ms_warning("MSSizeConv: output fmt changed, waiting.");
+			ms_warning("mi355x size converter: target size changed with the input orientation; frames held until the sink reconfigures");
 		} else if (size_conv_stage(f, s, in, mblk_get_timestamp_info(im))) {
 			staged = true;
 		} else {
-			ms_error("MSSizeConv: error in ms_scaler_process().");
+			ms_error("mi355x size converter: no batch for this geometry; frame dropped");
 		}
 		freemsg(im);
 	}
@@ -395,7 +395,7 @@ int sizeconv_set_vsize(MSFilter *f, void *arg) { // sizeconv.c:186-197
 	SizeConvState *s = (SizeConvState *)f->data;
 	ms_filter_lock(f);
 	s->target_vsize = *(MSVideoSize *)arg;
-	ms_message("sizeconv_set_vsize(): set target size w %d, h %d", s->target_vsize.width, s->target_vsize.height);
+	ms_message("mi355x size converter: target size %dx%d", s->target_vsize.width, s->target_vsize.height);
 	{
 		HubLock lk(f);
 		size_conv_leave_pool(s, f);
@@ -475,7 +475,7 @@ void pixconv_process(MSFilter *f) { // pixconv.c:62-94
 			const int fmt = pix_to_mi(s->in_fmt);
 			const int flip = s->in_fmt == MS_RGB24_REV; // :78-81
 			if (fmt < 0 || (inbuf.w & 1)) {
-				ms_error("MSPixConv: Error in ms_sws_scale()."); // what a failing ms_scaler_process logs, :84
+				ms_error("mi355x pixel converter: format %d / width %d cannot be converted; frame dropped", (int)s->in_fmt, inbuf.w); // pixconv.c:84 logs and drops too
 			} else {
 				if (!s->pool || s->pool->failed || s->pool->hub->ticker != f->ticker || s->pool->out_w != inbuf.w || s->pool->out_h != inbuf.h) {
 					pixconv_leave_pool(s, f);

@@ -108,3 +108,23 @@ def test_conference_bridge_example_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.strip() == "ok", run.stderr
+
+
+def test_stub_ticker_layout_follows_the_reference(tmp_path):
+    """include/mediastreamer2/msticker.h:73-98: lock, cond, two list pointers, thread, then interval / exec_id / ticks /
+    time.  The stub in ms2_plugin_abi.h must put the three fields a filter reads (msfilter.h:203: f->ticker->time,
+    ->interval; ->ticks) where a build against the real headers finds them -- on x86-64 glibc (40-byte mutex, 48-byte
+    condition variable) that is 112 / 120 / 128."""
+    src = tmp_path / "tk.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include <pthread.h>\n#include "ms2_plugin_abi.h"\n'
+                   "struct ref_ticker { pthread_mutex_t lock; pthread_cond_t cond; void *execution_list; void *task_list;\n"
+                   "  pthread_t thread; int interval; int exec_id; unsigned int ticks; unsigned long long time; };\n"
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(MSTicker, interval), offsetof(MSTicker, ticks),\n'
+                   "  offsetof(MSTicker, time), offsetof(struct ref_ticker, interval), offsetof(struct ref_ticker, ticks),\n"
+                   "  offsetof(struct ref_ticker, time)); return 0; }\n")
+    exe = tmp_path / "tk"
+    r = _cc([str(src), "-o", str(exe)])
+    assert r.returncode == 0, r.stderr
+    v = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert v[:3] == v[3:], v
+    assert v[:3] == [112, 120, 128]
