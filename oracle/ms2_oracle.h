@@ -208,6 +208,15 @@ void orc_concealer_init(OrcConcealer *o, uint32_t max_plc_time);
 uint32_t orc_concealer_inc_sample_time(OrcConcealer *o, uint64_t now, uint32_t increment, int got_packet);
 int orc_concealer_required(OrcConcealer *o, uint64_t now);
 
+/* ------------------------------------------------- recording metrics (oracle/audiodiff.c)
+ * src/utils/audiodiff.c on WAV files (read with include/ms2_mediaio.h: sizes from the file length).
+ * MSAudioDiffParams {max_shift_percent, chunk_size_ms} are passed as two ints. */
+int orc_audio_diff(const char *ref_file, const char *matched_file, double *ret, int max_shift_percent, int chunk_size_ms); /* :578-651 */
+int orc_audio_compare_silence_and_speech(const char *ref_file, const char *matched_file, double *ret, double *energy,
+                                         int max_shift_percent, int chunk_size_ms, int start_time_short_ms,
+                                         int stop_time_short_ms, int start_time_ms); /* :442-576 */
+int orc_audio_energy(const char *file, double *energy); /* :653-682 */
+
 #ifdef __cplusplus
 }
 #endif
