@@ -360,8 +360,8 @@ int mi_flowctl_get_state(mi_flowctl *f, int stream, uint32_t out4[4]); /* target
 int mi_flowctl_reset(mi_flowctl *f, int first, int count);             /* ms_audio_flow_controller_reset :30-35 */
 
 /* MSGenericPLC for a batch of streams: generic_plc_process (src/audiofilters/msgenericplc.c:59-167) over plc_context_t
- * (src/audiofilters/genericplc.c:29-241).  Mono, 16-bit; rates whose nb = rate/20 (rounded down to 100) factors into
- * 2, 3, 5 (8, 16, 24, 32, 48 kHz; 44.1 kHz needs kiss_fft's radix-11 butterfly: MI_ENOTSUP). */
+ * (src/audiofilters/genericplc.c:29-241).  Mono, 16-bit; any rate whose nb = rate/20 (rounded down to 100) has no prime
+ * factor above 17, kiss_fft's own limit (8 .. 48 kHz incl. 22.05 / 44.1 kHz: radix 11 through the generic butterfly). */
 typedef struct mi_plc mi_plc;
 #define MI_PLC_NONE 0       /* no event for the stream this round */
 #define MI_PLC_RECEIVED 1   /* a block of d_len[s] samples arrived: edited in place (delayed 5 ms, cross-faded after a loss) :63-116 */
@@ -428,6 +428,19 @@ int mi_session_set_controls(mi_session *s, const uint8_t *h_flags, const float *
 int mi_session_reset_streams(mi_session *s, int first, int count);
 /* MS_VOLUME_GET_LINEAR of every stream (msvolume.c:129-134): what an active-speaker detector polls */
 int mi_session_get_levels(mi_session *s, float *h_linear);
+/* MSAudioConference membership (src/voip/audioconference.c:322-374).  A session is created full (every stream a member);
+ * remove_member unplumbs a stream's mixer pin (it neither contributes nor hears; its output row is no longer written),
+ * add_member plumbs it again for a NEW endpoint: that stream's resampler history, canceller, meter and FIFOs start
+ * over, the other members keep theirs (the reference re-attaches the conference graph around both calls; the filters of
+ * the remaining members survive that).  Both wait for the ticks in flight. */
+int mi_session_add_member(mi_session *s, int stream);
+int mi_session_remove_member(mi_session *s, int stream);
+int mi_session_member_count(const mi_session *s, int conference); /* plumbed pins, or MI_EINVAL */
+/* The active-speaker election of a conference in mixer mode (audioconference.c:436-452): per conference the plumbed,
+ * unmuted member with the largest MS_VOLUME_GET_MAX (maximum of the smoothed energy over a one-second window, dBm0)
+ * above -30 dB; h_winner[conf] = its stream index or -1, h_max_db[conf] (nullable) its level.  Call it as often as the
+ * application polls (the reference: every process_events); now_ms is the caller's clock. */
+int mi_session_active_speakers(mi_session *s, uint64_t now_ms, int32_t *h_winner, float *h_max_db);
 
 /* ------------------------------------------------------------- pixconv */
 /* Packed formats -> I420, what pixconv_process (src/videofilters/pixconv.c:62-94) obtains from

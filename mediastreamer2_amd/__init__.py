@@ -604,6 +604,7 @@ class Session(_Batch):
         check(ctx.L.mi_session_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
         self.n, self.in_len, self.len = nstreams, in_rate // 100, rate // 100
+        self.members = members
         self.out_len = (out_rate or rate) // 100
         self.mic_dtype = C.c_uint8 if mic_codec else C.c_int16
         self.out_dtype = C.c_uint8 if out_codec else C.c_int16
@@ -653,3 +654,24 @@ class Session(_Batch):
         out = np.zeros(self.n, np.float32)
         check(self.ctx.L.mi_session_get_levels(self.h, _ptr(out)))
         return out
+
+    def add_member(self, stream):
+        """ms_audio_conference_add_member: a NEW endpoint takes the slot (fresh per-leg state), its mixer pin is plumbed."""
+        check(self.ctx.L.mi_session_add_member(self.h, int(stream)))
+
+    def remove_member(self, stream):
+        """ms_audio_conference_remove_member: the pin is unplumbed; the other members carry on untouched."""
+        check(self.ctx.L.mi_session_remove_member(self.h, int(stream)))
+
+    def member_count(self, conference):
+        n = self.ctx.L.mi_session_member_count(self.h, int(conference))
+        check(min(n, 0))
+        return n
+
+    def active_speakers(self, now_ms):
+        """(winner stream per conference or -1, its MS_VOLUME_GET_MAX in dBm0): audioconference.c:436-452"""
+        nconf = self.n // self.members
+        win = np.zeros(nconf, np.int32)
+        db = np.zeros(nconf, np.float32)
+        check(self.ctx.L.mi_session_active_speakers(self.h, C.c_uint64(int(now_ms)), _ptr(win), _ptr(db)))
+        return win, db

@@ -45,7 +45,7 @@ EXPORTS = [
     "mi_pixconv_process", "mi_pixconv_process_host",
     "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples", "mi_session_tick_bytes", "mi_session_events",
     "mi_session_acquire", "mi_session_submit", "mi_session_collect", "mi_session_in_flight",
-    "mi_session_set_controls", "mi_session_get_levels", "mi_session_reset_streams",
+    "mi_session_set_controls", "mi_session_get_levels", "mi_session_add_member", "mi_session_remove_member", "mi_session_member_count", "mi_session_active_speakers", "mi_session_reset_streams",
     "mi_g711_decode", "mi_g711_encode", "mi_l16_swap", "mi_chan_adapt",
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
@@ -216,6 +216,10 @@ def load():
         L.mi_session_in_flight.argtypes = [vp]
         L.mi_session_set_controls.argtypes = [vp, vp, vp]
         L.mi_session_get_levels.argtypes = [vp, vp]
+        L.mi_session_add_member.argtypes = [vp, i32]
+        L.mi_session_remove_member.argtypes = [vp, i32]
+        L.mi_session_member_count.argtypes = [vp, i32]
+        L.mi_session_active_speakers.argtypes = [vp, C.c_uint64, vp, vp]
         L.mi_session_reset_streams.argtypes = [vp, i32, i32]
     if hasattr(L, "mi_fifo_create"):
         L.mi_fifo_create.argtypes = [vp, i32, i32, pp]

@@ -14,7 +14,8 @@
 // One wavefront per stream, everything it touches in LDS.  The transforms are kiss_fft's (src/utils/kiss_fft.c) evaluated
 // in ITS operation order -- digit permutation, then radix 4 / 2 / 3 / 5 stages from the innermost factor outwards, each
 // butterfly the reference's expression sequence, compiled with -ffp-contract=off -- so the generated samples are the
-// reference's bit for bit (sizes: nb/2 = 200 .. 1200 and nb = 400 .. 2400 complex points: factors 4, 2, 3, 5).
+// reference's bit for bit (sizes: nb/2 = 200 .. 1200 and nb = 400 .. 2400 complex points: factors 4, 2, 3, 5, and 11 at
+// 22.05 / 44.1 kHz through the generic butterfly).
 // Butterflies of a stage are independent: lanes take them round-robin.  Twiddles and window come from the host (double
 // cos/sin rounded to float, kiss_fft.c:464-471, kiss_fftr.c:68-81, genericplc.c:63-65).
 // Concealment is rare (a stream only computes FFTs on the tick its packet went missing and every ~nb samples
@@ -116,7 +117,7 @@ __device__ void cfft(float2 *buf, const Factors &f, const float2 *tw, bool inver
 				fm.x -= s0.y;
 				fm.y += s0.x;
 				F[m] = fm;
-			} else { // kf_bfly5 :192-256
+			} else if (p == 5) { // kf_bfly5 :192-256
 				const float2 ya = tw[fs * m], yb = tw[fs * 2 * m];
 				const float2 s0 = F[0];
 				const float2 s1 = cmul(F[m], tw[j * fs]), s2 = cmul(F[2 * m], tw[2 * j * fs]);
@@ -131,6 +132,22 @@ __device__ void cfft(float2 *buf, const Factors &f, const float2 *tw, bool inver
 				const float2 s12 = make_float2(-(s10.y * yb.y) + s9.y * ya.y, s10.x * yb.y - s9.x * ya.y);
 				F[2 * m] = cadd(s11, s12);
 				F[3 * m] = csub(s11, s12);
+			} else { // kf_bfly_generic :259-291 (radix 7, 11, 13, 17: the 44.1 kHz family has a factor 11); C_FIXDIV is a no-op
+				float2 sc[17]; // in floats; the twiddle index walks the FULL transform's table modulo its size
+				const int norig = f.n;
+				for (int q = 0; q < p; ++q) sc[q] = F[q * m];
+				int k = j;
+				for (int q1 = 0; q1 < p; ++q1) {
+					int twidx = 0;
+					float2 acc = sc[0];
+					for (int q = 1; q < p; ++q) {
+						twidx += fs * k;
+						if (twidx >= norig) twidx -= norig;
+						acc = cadd(acc, cmul(sc[q], tw[twidx]));
+					}
+					F[q1 * m] = acc;
+					k += m;
+				}
 			}
 		}
 		wave_sync();
@@ -387,7 +404,7 @@ bool factorize(int n, Factors *f) {
 			if (p > 32000 || p * p > left) p = left;
 		}
 		left /= p;
-		if (p > 5 || f->count >= MAXFAC) return false;
+		if (p > 17 || f->count >= MAXFAC) return false; // kiss_fft.c:266: the generic butterfly takes a radix up to 17
 		f->p[f->count] = p;
 		f->m[f->count] = left;
 		f->fs[f->count] = stride;
@@ -448,7 +465,7 @@ int mi_plc_create(mi_ctx *c, int nstreams, int rate, int max_block, mi_plc **out
 	p->nb = ((rate * 2 / 40) / 100) * 100; // generic_plc_create_context genericplc.c:46-48 (PLC_BUFFER_LEN is the tokens 2 / 40)
 	p->T = rate * TRANSITION_DELAY / 1000;
 	if (p->nb < 4 || (p->nb & 1) || p->T > 256 || !factorize(p->nb / 2, &p->f1) || !factorize(p->nb, &p->f2)) {
-		mi::set_error("mi_plc_create: %d Hz gives transforms of %d / %d points with a factor above 5 (kiss_fft's generic butterfly is not built)",
+		mi::set_error("mi_plc_create: %d Hz gives transforms of %d / %d points with a prime factor above 17 (kiss_fft itself refuses those)",
 		              rate, p->nb / 2, p->nb);
 		delete p;
 		return MI_ENOTSUP;

@@ -11,6 +11,8 @@
 // kernel sequence.  Pinned host buffers belong to the session: the caller fills / reads them in place.
 #include "common.hpp"
 
+#include <cmath>
+
 namespace {
 constexpr int SLOTS = 3; // upload | compute | download can each hold a different tick
 }
@@ -46,6 +48,13 @@ struct mi_session {
 	mi_graph *graph[SLOTS] = {};
 	long long submitted = 0, collected = 0;
 	bool acquired = false;
+	// conference membership / active-speaker election (MSAudioConference, src/voip/audioconference.c)
+	std::vector<uint8_t> flags;      // MI_MIX_* per stream as last set (default: every pin linked, active, output on)
+	struct Window {                   // OrtpExtremum with a 1000 ms period, the window behind MS_VOLUME_GET_MAX (msvolume.c:115,:143-148)
+		float current = 0;
+		long long t0 = -1;
+	};
+	std::vector<Window> level_max;
 };
 
 namespace {
@@ -174,6 +183,8 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	s->cfg = *cfg;
 	s->n = cfg->nstreams;
 	s->nconf = cfg->nstreams / cfg->members_per_conference;
+	s->flags.assign((size_t)s->n, (uint8_t)(MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT));
+	s->level_max.assign((size_t)s->n, mi_session::Window());
 	s->in_len = cfg->in_rate / 100;
 	s->len = cfg->rate / 100;
 	const bool down = cfg->out_rate != 0 && cfg->out_rate != cfg->rate;
@@ -383,7 +394,92 @@ int mi_session_in_flight(const mi_session *s) { return s ? (int)(s->submitted - 
 // meter read-out (MS_VOLUME_GET_LINEAR) an active-speaker detector polls.  Both wait for the ticks already submitted.
 int mi_session_set_controls(mi_session *s, const uint8_t *h_flags, const float *h_gain) {
 	MI_CHECK_ARG(s && (h_flags || h_gain));
+	if (h_flags) s->flags.assign(h_flags, h_flags + s->n);
 	return mi_mixer_set_controls(s->mix, h_flags, h_gain); // [nconf][members] == [nstreams]
+}
+
+// ms_audio_conference_add_member (src/voip/audioconference.c:322-345): a NEW endpoint joins -- its own filters are fresh
+// (resampler history, canceller, meter, FIFOs: mi_session_reset_streams), its mixer pin becomes linked / active / output
+// enabled.  The conference graph is detached and re-attached around this (:325-327): the other members' filters keep
+// their state (their MSFilter objects survive) and so do their streams here.
+int mi_session_add_member(mi_session *s, int stream) {
+	MI_CHECK_ARG(s && stream >= 0 && stream < s->n);
+	if (s->flags[(size_t)stream] & MI_MIX_LINKED) {
+		mi::set_error("mi_session_add_member: stream %d is a member already", stream);
+		return MI_EINVAL;
+	}
+	const int rc = mi_session_reset_streams(s, stream, 1);
+	if (rc != MI_OK) return rc;
+	s->flags[(size_t)stream] = MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT;
+	s->level_max[(size_t)stream] = mi_session::Window();
+	return mi_mixer_set_controls(s->mix, s->flags.data(), nullptr);
+}
+
+// ms_audio_conference_remove_member (:366-374): the pin is unplumbed -- it neither contributes nor receives; the row of
+// its output is left alone from now on (zeros in a fresh download buffer).  The others carry on.
+int mi_session_remove_member(mi_session *s, int stream) {
+	MI_CHECK_ARG(s && stream >= 0 && stream < s->n);
+	if (!(s->flags[(size_t)stream] & MI_MIX_LINKED)) {
+		mi::set_error("mi_session_remove_member: stream %d is no member", stream);
+		return MI_EINVAL;
+	}
+	s->flags[(size_t)stream] = 0;
+	const int rc = mi_mixer_set_controls(s->mix, s->flags.data(), nullptr);
+	if (rc != MI_OK) return rc;
+	// the mixer leaves an unplumbed pin's row alone: what the departed leg last heard must not linger in the buffers
+	MI_HIP(hipStreamSynchronize(s->ctx->stream));
+	if (s->s_down) MI_HIP(hipStreamSynchronize(s->s_down));
+	for (int i = 0; i < SLOTS; ++i) {
+		if (s->d_out[i]) MI_HIP(hipMemsetAsync((uint8_t *)s->d_out[i] + (size_t)stream * s->out_bytes, 0, s->out_bytes, s->ctx->stream));
+		if (s->d_mix[i]) MI_HIP(hipMemsetAsync(s->d_mix[i] + (size_t)stream * s->len, 0, (size_t)s->len * 2, s->ctx->stream));
+		if (s->h_out[i]) memset((uint8_t *)s->h_out[i] + (size_t)stream * s->out_bytes, 0, s->out_bytes);
+	}
+	return MI_OK;
+}
+
+int mi_session_member_count(const mi_session *s, int conference) {
+	if (!s || conference < 0 || conference >= s->nconf) return MI_EINVAL;
+	const int mm = s->cfg.members_per_conference;
+	int c = 0;
+	for (int m = 0; m < mm; ++m) c += (s->flags[(size_t)conference * mm + m] & MI_MIX_LINKED) != 0;
+	return c;
+}
+
+// ms_audio_conference_process_events' election in mixer mode (:436-452): per conference the unmuted member whose
+// MS_VOLUME_GET_MAX -- the maximum of the smoothed energy over a one-second window (msvolume.c:143-148,:402-406), in
+// dBm0 -- is the largest and above -30 dB (audioconference.c:31).  now_ms: the caller's clock (the ticker's time).
+int mi_session_active_speakers(mi_session *s, uint64_t now_ms, int32_t *h_winner, float *h_max_db) {
+	MI_CHECK_ARG(s && h_winner);
+	std::vector<mi_volume_state> st((size_t)s->n);
+	const int rc = mi_volume_get_state(s->vol, 0, s->n, st.data());
+	if (rc != MI_OK) return rc;
+	const int mm = s->cfg.members_per_conference;
+	for (int i = 0; i < s->n; ++i) { // ortp_extremum_record_max, period 1000 ms
+		mi_session::Window &w = s->level_max[(size_t)i];
+		const float v = st[(size_t)i].energy;
+		if (w.t0 != -1 && (long long)now_ms - w.t0 > 1000) w.t0 = -1;
+		if (w.t0 == -1) {
+			w.current = v;
+			w.t0 = (long long)now_ms;
+		} else if (v > w.current) {
+			w.current = v;
+		}
+	}
+	for (int c = 0; c < s->nconf; ++c) {
+		float best = -120.f; // MS_VOLUME_DB_LOWEST
+		int win = -1;
+		for (int m = 0; m < mm; ++m) {
+			const size_t i = (size_t)c * mm + m;
+			const uint8_t f = s->flags[i];
+			if (!(f & MI_MIX_LINKED) || !(f & MI_MIX_ACTIVE)) continue; // not plumbed / muted (:445)
+			const float lin = s->level_max[i].current;
+			const float db = lin == 0 ? -120.f : 10 * log10f(lin); // ms_volume_linear_to_dbm0 msvolume.c:565-568
+			if (db > -30.0f && db > best) best = db, win = (int)i;
+		}
+		h_winner[c] = win;
+		if (h_max_db) h_max_db[c] = best;
+	}
+	return MI_OK;
 }
 
 // A call leg leaves and another takes its place: every per-stream state of the chain goes back to its initial value

@@ -327,6 +327,89 @@ def test_session_mute_and_levels(ctx):
     se.close()
 
 
+def test_session_members_join_and_leave_like_msaudioconference(ctx):
+    """ms_audio_conference_remove_member / add_member (src/voip/audioconference.c:322-374) on a running session.
+    A leg that leaves neither contributes nor hears: the remaining members' rows equal those of a twin session in which
+    that leg merely went silent (their own per-leg state is untouched: the reference's filters survive the detach /
+    re-attach of the conference graph), its own row reads zeros, the other conference never notices.
+    A NEW leg joining the free slot starts from fresh filters: what member 0 hears of it equals what it hears in a
+    brand-new session.  Then the active-speaker election (:436-452): the loudest plumbed, unmuted member above -30 dB."""
+    mm, n, rate = 8, 16, 48000
+    sig = [synth_pcm(50 + s, 480 * 40, rate=rate, sigma=1500.0 + 300 * s) for s in range(n)]
+
+    def tick(se, t, silent=(), only=None):
+        m, r = se.acquire()
+        m[:] = 0
+        r[:] = 0
+        for s in range(n):
+            if only is not None:
+                if s == only[0]:
+                    m[s] = only[1][t * 480:(t + 1) * 480]
+            elif s not in silent:
+                m[s] = sig[s][t * 480:(t + 1) * 480]
+        se.submit()
+        return se.collect().copy().reshape(2, mm, 480)
+
+    mk = lambda: ms.Session(ctx, n, members=mm, in_rate=rate, rate=rate, agc=False)
+    a, c = mk(), mk()
+    for t in range(10):
+        np.testing.assert_array_equal(tick(a, t), tick(c, t))
+    assert a.member_count(0) == mm and a.member_count(1) == mm
+    a.remove_member(3)
+    assert a.member_count(0) == mm - 1 and a.member_count(1) == mm
+    with pytest.raises(ms.MiError):
+        a.remove_member(3)
+    for t in range(10, 20):
+        oa, oc = tick(a, t), tick(c, t, silent=(3,))
+        np.testing.assert_array_equal(oa[1], oc[1])             # the other conference never notices
+        assert not oa[0, 3].any()                               # the departed leg hears nothing
+        if t >= 14:                                             # in the twin, leg 3's canceller tail has died by now
+            for m in (0, 1, 2, 4, 5, 6, 7):
+                np.testing.assert_array_equal(oa[0, m], oc[0, m], err_msg=f"tick {t} member {m}")
+    # a NEW leg joins slot 3: fresh state for that leg, everybody else silent from here on
+    a.add_member(3)
+    assert a.member_count(0) == mm
+    with pytest.raises(ms.MiError):
+        a.add_member(3)
+    fresh = mk()
+    newsig = synth_pcm(999, 480 * 12, rate=rate, sigma=2500.0)
+    for t in range(12):
+        oa = tick(a, t, only=(3, newsig))
+        of = tick(fresh, t, only=(3, newsig))
+        if t >= 5:  # the others' cancellers went silent at the join: their tails are gone after a few frames
+            np.testing.assert_array_equal(oa[0, 0], of[0, 0], err_msg=f"tick {t}: the joiner as member 0 hears it")
+            assert np.abs(oa[0, 0]).max() > 1000
+    # ---- active speaker: member 5 of conference 0 and member 2 of conference 1 shout; 5 is muted, then mm + 2 leaves
+    e = mk()
+    loud = np.zeros((n, 480), np.int16)
+    loud[5] = (12000 * np.sin(2 * np.pi * 500 * np.arange(480) / rate)).astype(np.int16)
+    loud[mm + 2] = (9000 * np.sin(2 * np.pi * 700 * np.arange(480) / rate)).astype(np.int16)
+    loud[1] = (3000 * np.sin(2 * np.pi * 300 * np.arange(480) / rate)).astype(np.int16)   # audible, but not the loudest
+
+    def shout(ticks, now):
+        for _ in range(ticks):
+            m, r = e.acquire()
+            m[:] = loud
+            r[:] = 0
+            e.submit()
+            e.collect()
+        return e.active_speakers(now)
+
+    win, db = shout(30, 300)
+    assert list(win) == [5, mm + 2] and (db > -30).all()
+    L, A, O = ms.MI_MIX_LINKED, ms.MI_MIX_ACTIVE, ms.MI_MIX_OUTPUT
+    flags = np.full(n, L | A | O, np.uint8)
+    flags[5] = L | O                                 # muted (MS_AUDIO_MIXER_SET_ACTIVE 0): skipped by the election (:445)
+    e.set_controls(flags=flags)
+    win, db = shout(5, 350)
+    assert win[0] == 1 and win[1] == mm + 2          # the next loudest takes over
+    e.remove_member(mm + 2)
+    win, db = shout(5, 400)
+    assert win[1] == -1                              # nobody else in conference 1 makes a sound
+    for se in (a, c, fresh, e):
+        se.close()
+
+
 def test_session_reset_streams_starts_a_leg_over(ctx):
     # A leg is replaced in its slot: after mi_session_reset_streams the slot behaves like a leg of a brand-new session
     # (resampler history, canceller, meter and FIFO phase all back to their initial state), the others are untouched.

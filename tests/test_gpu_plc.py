@@ -66,7 +66,7 @@ def run_scenario(ctx, oracle, rate, n, events, streams_signal, cap=None):
     return plc, refs
 
 
-@pytest.mark.parametrize("rate", [8000, 16000, 32000, 48000])
+@pytest.mark.parametrize("rate", [8000, 16000, 22050, 32000, 44100, 48000])  # 22.05 / 44.1 kHz: kiss_fft's generic radix-11 butterfly
 def test_plc_loss_patterns_bit_exact(ctx, oracle, rate):
     """10 ms blocks; streams with: no loss, single losses, a 60 ms burst (the generated signal is extended from itself),
     a 250 ms outage (fade between 100 and 150 ms, silence after), loss on the very first tick, random 15 % loss."""
@@ -134,7 +134,7 @@ def test_plc_short_blocks_cng_resume_and_counter_wrap(ctx, oracle):
 
 def test_plc_ragged_and_unsupported_rates(ctx):
     with pytest.raises(ms.MiError):
-        ms.PlcBatch(ctx, 4, 44100)  # nb = 2200 = 2^3 5^2 11: kiss_fft's generic butterfly is not built
+        ms.PlcBatch(ctx, 4, 46000)  # nb = 2300 = 2^2 5^2 23: a radix above 17, which kiss_fft itself refuses (kiss_fft.c:266)
     plc = ms.PlcBatch(ctx, 3, 8000, max_block=160)
     rows = torch.zeros((3, 160), dtype=torch.int16, device="cuda")
     rows[1, :] = 1234
