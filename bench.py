@@ -377,7 +377,8 @@ def copy_ceiling(torch):
 
 CHAIN_DESC = ("MSResample 16k->48k -> device FIFO (480-sample ticks -> 256-sample frames) -> MSSpeexEC (128 ms tail, "
               "canceller + post-filter; 15 frames per 8 ticks) -> device FIFO (frames -> ticks) -> MSVolume (AGC) -> "
-              "MSAudioMixer (conferences of 32), device resident")
+              "MSAudioMixer (conferences of 32), device resident; four launches per tick (the FIFO appends / pops happen "
+              "inside the canceller and the volume kernel)")
 AEC_FRAME_BYTES = 202240  # mic+ref+out 1536, W read+write 2 x 49152, foreground 49152, X history 51200, newest X 2048
 AEC_FRAMES_PER_TICK = 1.875  # 480 / 256 (speexec.c:171-180: 256-sample frames at 48 kHz)
 SPLIT_CONFERENCES = 64  # at N > 1: conferences whose 32 members are spread over all ranks (the RCCL exchange step)
@@ -411,7 +412,7 @@ class ChainRig:
         p.agc_enabled = 1
         self.vol.set_params([p] * n)
         self.mix = ms.MixerBatch(ctx, self.nconf, mm, 480)
-        self.f_mic, self.f_ref, self.f_out = (ms.FifoBatch(ctx, n, 1024) for _ in range(3))
+        self.f_mic, self.f_ref, self.f_out = (ms.FifoBatch(ctx, n, 1024) for _ in range(3))  # whole frames: 4 x 256
         ring = self.RING
         base = min(n, 4096)  # distinct signals for 4096 legs, rotated for the rest (the kernels do not care)
         mic16 = synth_pcm_batch(base, 160 * ring, 16000, seed0=0x5EED + 7919 * rank)
@@ -442,14 +443,10 @@ class ChainRig:
     def tick(self, t):
         ms, F, n = self.ms, self.F, self.n
         self.rs.process(self.d_mic[t % self.RING], out=self.up)
-        self.f_mic.push(self.up, nsamples=480)
-        self.f_ref.push(self.d_ref[t % self.RING])
-        self.f_mic.pop_frames(F, 2, self.micf, nframes_out=self.cnt)          # the while loop of speexec.c:256, whole tick
-        self.f_ref.pop_frames(F, 2, self.reff, wanted=self.cnt, zero_fill=True)  # short far end: silence, speexec.c:261-272
-        self.aec.process_frames(self.micf, self.reff, self.clean, self.cnt, max_frames=2, flags=ms.MI_AEC_POSTFILTER)
-        self.f_out.push_frames(self.clean, F, 2, self.cnt)
-        self.f_out.pop(480, self.tick_buf, zero_fill=True)
-        self.vol.process(self.tick_buf)
+        # MSSpeexEC for the tick with its bufferizers folded in: both blocks queued, the one or two whole frames a leg then
+        # holds cancelled + post-filtered, the cleaned frames queued towards the mixer -- one launch
+        self.aec.process_fifos(self.f_mic, self.up, self.f_ref, self.d_ref[t % self.RING], self.f_out, tick_len=480, max_frames=2)
+        self.vol.process_fifo(self.f_out, self.tick_buf)  # the tick popped from the output FIFO inside the volume kernel
         self.mix.process(self.whole_in, out=self.whole_out)
         if self.nsplit:
             self.mixs.partial_sum(self.split_in, self.d_sum)

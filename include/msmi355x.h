@@ -201,6 +201,11 @@ int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_stat
 int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples);
 int mi_volume_process_host(mi_volume *v, int16_t *h_samples, int nsamples, int stride,
                            const int32_t *h_nsamples);
+/* The chunk comes out of a device FIFO (mi_fifo, below): stream s pops nsamples from f_src -- all or nothing, a stream
+ * holding less gets silence, like mi_fifo_pop with zero_fill -- and the processed chunk is written to row s of d_out.
+ * Equals mi_fifo_pop + mi_volume_process without the separate launch and copy.  Multiples of 8 samples throughout. */
+struct mi_fifo;
+int mi_volume_process_fifo(mi_volume *v, struct mi_fifo *f_src, int16_t *d_out, int nsamples, int stride);
 
 /* ----------------------------------------------------------- equalizer */
 typedef struct mi_equalizer mi_equalizer;
@@ -248,6 +253,18 @@ int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_
 #define MI_AEC_MAX_TICK_FRAMES 2
 int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
                           const uint8_t *d_count, int max_frames, unsigned flags);
+/* The same with the FIFOs folded in (what mi_session runs): stream s's new microphone block (row s of d_mic_tick,
+ * tick_len samples) and far-end block are appended to f_mic / f_ref, every whole frame f_mic then holds (<= max_frames)
+ * is cancelled against the frame f_ref supplies -- silence where it cannot (speexec.c:261-272) --, and the cleaned frames
+ * are appended to f_out: ms_bufferizer_put x 2, the while loop of speexec.c:256-305 and the queue put of :303, one
+ * launch.  Results equal mi_fifo_push x 2, mi_fifo_pop_frames x 2, mi_aec_process_frames, mi_fifo_push_frames.
+ * FIFO capacities must be multiples of the frame size.  d_ref_len (nullable): per-stream length of the far-end block
+ * this tick, 0 = the far end delivered nothing (then, or later, the canceller runs on injected silence); NULL = tick_len
+ * for all.  d_count_out (nullable): frames each stream ran. */
+typedef struct mi_fifo mi_fifo;
+int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
+                         const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
+                         int max_frames, unsigned flags, uint8_t *d_count_out);
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
                         const uint8_t *h_run, unsigned flags);
 /* state bytes per stream (for DESIGN/roofline accounting) */
@@ -293,7 +310,6 @@ int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], con
 /* MSBufferizer (include/mediastreamer2/msqueue.h:131-134, src/base/msqueue.c:70-113) for a batch of streams, resident
  * on the device: lets filters with different block sizes be chained without a host round trip (480-sample ticks
  * from the resampler -> 256-sample frames for the echo canceller, speexec.c:252-257 -> ticks for the mixer). */
-typedef struct mi_fifo mi_fifo;
 int mi_fifo_create(mi_ctx *ctx, int nstreams, int capacity_samples, mi_fifo **out);
 void mi_fifo_destroy(mi_fifo *f);
 /* ms_bufferizer_put for every stream: row s of d_in ([nstreams][stride]); d_count[s] samples (NULL = nsamples each;

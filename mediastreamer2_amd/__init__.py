@@ -260,6 +260,13 @@ class VolumeBatch(_Batch):
         return x
 
 
+    def process_fifo(self, fifo, out, nsamples=None):
+        """pop one chunk per stream from a FifoBatch (silence where it holds less), process, write to out's rows"""
+        n = out.shape[1] if nsamples is None else nsamples
+        check(self.ctx.L.mi_volume_process_fifo(self.h, fifo.h, _ptr(out), n, out.stride(0)))
+        return out
+
+
 class EqualizerBatch(_Batch):
     """nstreams MSEqualizer FIRs (equalizer.c:263-288, dsptools.c:253-268)."""
     _destroy = "mi_equalizer_destroy"
@@ -368,6 +375,14 @@ class AecBatch(_Batch):
         check(self.ctx.L.mi_aec_process(self.h, _ptr(mic), _ptr(ref), _ptr(out), mic.stride(0), _ptr(run), flags))
         return out
 
+
+    def process_fifos(self, f_mic, mic_tick, f_ref, ref_tick, f_out, tick_len=None, max_frames=2, flags=MI_AEC_POSTFILTER, count_out=None,
+                      ref_len=None):
+        """The tick with the FIFOs folded in: both new blocks queued, every whole frame cancelled, the results queued on
+        f_out -- one launch (mi_aec_process_fifos).  FifoBatch objects whose capacities are multiples of the frame size."""
+        n = mic_tick.shape[1] if tick_len is None else tick_len
+        check(self.ctx.L.mi_aec_process_fifos(self.h, f_mic.h, _ptr(mic_tick), mic_tick.stride(0), f_ref.h, _ptr(ref_tick),
+                                              ref_tick.stride(0), _ptr(ref_len), n, f_out.h, max_frames, flags, _ptr(count_out)))
 
     def process_frames(self, mic, ref, out, count, max_frames=2, flags=MI_AEC_POSTFILTER):
         """The frames of one tick in one launch: rows of mic / ref / out hold up to max_frames frames back to back,

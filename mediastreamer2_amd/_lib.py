@@ -33,11 +33,11 @@ EXPORTS = [
     "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
-    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_process", "mi_volume_process_host",
+    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
-    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames",
+    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos",
     "mi_aec_process_host", "mi_aec_set_overlap", "mi_aec_join", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
@@ -158,6 +158,7 @@ def load():
     L.mi_volume_set_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
     L.mi_volume_process.argtypes = [vp, vp, i32, i32, vp]
     L.mi_volume_process_host.argtypes = [vp, vp, i32, i32, vp]
+    L.mi_volume_process_fifo.argtypes = [vp, vp, vp, i32, i32]
 
     if hasattr(L, "mi_equalizer_create"):
         L.mi_equalizer_create.argtypes = [vp, i32, i32, pp]
@@ -181,6 +182,7 @@ def load():
         L.mi_aec_process.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_process_host.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_process_frames.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_uint]
+        L.mi_aec_process_fifos.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, C.c_uint, vp]
         L.mi_aec_set_overlap.argtypes = [vp, i32]
         L.mi_aec_join.argtypes = [vp]
         L.mi_aec_state_bytes.argtypes = [vp]

@@ -76,6 +76,13 @@ struct AecArgs {
 	const uint8_t *run;   // per-frame entry: 0 = the stream has no frame this call
 	const uint8_t *count; // per-tick entry: frames ready for the stream (0 .. max_frames), rows hold them back to back
 	int max_frames;
+	// FIFO entry (fmic.ring != NULL): the tick's new blocks are appended to the microphone / far-end rings, every whole
+	// frame they then hold is processed, the cleaned frames are appended to the output ring -- all inside the kernel
+	FifoView fmic, fref, fout;
+	const int16_t *mic_tick, *ref_tick; // [nstreams][*_tick_stride], tick_len new samples per stream
+	int tick_len, mic_tick_stride, ref_tick_stride;
+	const int32_t *ref_len; // nullable: per-stream length of the far-end block (0 .. tick_len)
+	uint8_t *count_out; // nullable: frames each stream ran
 	int stride, nstreams, M, flags;
 	int first;             // first stream of this launch (a launch may cover a chunk of the batch)
 	float *X, *W, *FG;     // [nstreams][(M+1) or M][N]
@@ -505,8 +512,16 @@ size_t mi_aec_state_bytes(const mi_aec *a) {
 	       sizeof(AecScalars);
 }
 
+struct AecFifoCall {
+	mi_fifo *f_mic, *f_ref, *f_out;
+	const int16_t *d_mic_tick, *d_ref_tick;
+	int tick_len, mic_stride, ref_stride;
+	const int32_t *d_ref_len;
+	uint8_t *d_count_out;
+};
+
 static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride, const uint8_t *d_run,
-                      const uint8_t *d_count, int max_frames, unsigned flags) {
+                      const uint8_t *d_count, int max_frames, unsigned flags, const AecFifoCall *fifo = nullptr) {
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	AecArgs g;
 	g.mic = d_mic;
@@ -515,6 +530,23 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.run = d_run;
 	g.count = d_count;
 	g.max_frames = max_frames;
+	g.fmic = g.fref = g.fout = fifo_view(nullptr);
+	g.mic_tick = g.ref_tick = nullptr;
+	g.tick_len = g.mic_tick_stride = g.ref_tick_stride = 0;
+	g.count_out = nullptr;
+	g.ref_len = nullptr;
+	if (fifo) {
+		g.ref_len = fifo->d_ref_len;
+		g.fmic = fifo_view(fifo->f_mic);
+		g.fref = fifo_view(fifo->f_ref);
+		g.fout = fifo_view(fifo->f_out);
+		g.mic_tick = fifo->d_mic_tick;
+		g.ref_tick = fifo->d_ref_tick;
+		g.tick_len = fifo->tick_len;
+		g.mic_tick_stride = fifo->mic_stride;
+		g.ref_tick_stride = fifo->ref_stride;
+		g.count_out = fifo->d_count_out;
+	}
 	g.stride = stride;
 	g.nstreams = a->nstreams;
 	g.M = a->M;
@@ -554,6 +586,26 @@ int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref,
 	MI_CHECK_ARG(a && d_mic && d_ref && d_out && d_count && max_frames >= 1 && max_frames <= MI_AEC_MAX_TICK_FRAMES &&
 	             stride >= max_frames * a->F);
 	return aec_launch(a, d_mic, d_ref, d_out, stride, nullptr, d_count, max_frames, flags);
+}
+
+int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
+                         const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
+                         int max_frames, unsigned flags, uint8_t *d_count_out) {
+	MI_CHECK_ARG(a && f_mic && f_ref && f_out && d_mic_tick && d_ref_tick && tick_len > 0 && mic_stride >= tick_len &&
+	             ref_stride >= tick_len && max_frames >= 1 && max_frames <= MI_AEC_MAX_TICK_FRAMES);
+	MI_CHECK_ARG(f_mic->nstreams == a->nstreams && f_ref->nstreams == a->nstreams && f_out->nstreams == a->nstreams);
+	const int K = a->F / 64;
+	for (const mi_fifo *f : {f_mic, f_ref, f_out})
+		if (f->capacity % a->F || f->capacity < max_frames * a->F) {
+			mi::set_error("mi_aec_process_fifos: FIFO capacities must be multiples of the frame size %d (got %d)", a->F, f->capacity);
+			return MI_EINVAL;
+		}
+	if (tick_len % K) { // a lane's K samples must not straddle the boundary between queued and new samples
+		mi::set_error("mi_aec_process_fifos: blocks of %d samples with %d-sample frames are not supported", tick_len, a->F);
+		return MI_ENOTSUP;
+	}
+	AecFifoCall fc = {f_mic, f_ref, f_out, d_mic_tick, d_ref_tick, tick_len, mic_stride, ref_stride, d_ref_len, d_count_out};
+	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
 }
 
 int mi_aec_join(mi_aec *a) { // kept for ABI 1 callers: the post-filter is part of the one launch, nothing is ever pending

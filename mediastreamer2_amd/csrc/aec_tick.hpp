@@ -184,11 +184,95 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	using SL = TickLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
 	const int s = a.first + blockIdx.x;
-	int nf = a.count ? (int)a.count[s] : ((a.run && !a.run[s]) ? 0 : 1);
-	if (nf > a.max_frames) nf = a.max_frames;
-	if (nf <= 0) return;
 	const int lane = threadIdx.x;
 	const int e0 = lane * K; // first element (sample / bin) this lane owns
+	// ---- where the frames come from and go to: rows (per-frame / per-tick entries) or the three FIFOs
+	const bool fifo = a.fmic.ring != nullptr;
+	int nf, ref_frames = 0;
+	int2 qm = make_int2(0, 0), qr = make_int2(0, 0), qo = make_int2(0, 0); // (head, level) before this tick
+	bool mic_new = false, ref_new = false;                                 // the tick's blocks were taken
+	if (fifo) {
+		qm = a.fmic.pos[s], qr = a.fref.pos[s], qo = a.fout.pos[s];
+		// ms_bufferizer_put of the tick's blocks (a block that does not fit is refused and counted, like mi_fifo_push)
+		auto append = [&](const FifoView &q, int2 p, const int16_t *row, int len) -> bool {
+			if (len <= 0) return false;
+			if (p.y + len > q.cap) {
+				if (lane == 0) atomicAdd(q.overflow, 1);
+				return false;
+			}
+			int16_t *ring = q.ring + (size_t)s * q.cap;
+			unsigned tail = (unsigned)p.x + (unsigned)p.y;
+			if (tail >= (unsigned)q.cap) tail -= (unsigned)q.cap;
+			if (((tail | (unsigned)len) & 7u) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+				// whole 16-byte groups (capacities are multiples of the frame size, so of 8): one per lane, 60 lanes at 480 samples
+				for (int i = lane; i < (len >> 3); i += 64) {
+					unsigned w = tail + 8u * (unsigned)i;
+					if (w >= (unsigned)q.cap) w -= (unsigned)q.cap;
+					*reinterpret_cast<uint4 *>(ring + w) = *reinterpret_cast<const uint4 *>(row + 8 * i);
+				}
+			} else {
+				for (int i = lane; i < len; i += 64) {
+					unsigned w = tail + (unsigned)i;
+					if (w >= (unsigned)q.cap) w -= (unsigned)q.cap;
+					ring[w] = row[i];
+				}
+			}
+			return true;
+		};
+		int rlen = a.ref_len ? a.ref_len[s] : a.tick_len; // the far end's block may be missing or short this tick
+		rlen = rlen < 0 ? 0 : (rlen > a.tick_len ? a.tick_len : rlen) / K * K;
+		mic_new = append(a.fmic, qm, a.mic_tick + (size_t)s * a.mic_tick_stride, a.tick_len);
+		ref_new = append(a.fref, qr, a.ref_tick + (size_t)s * a.ref_tick_stride, rlen);
+		if (!ref_new) rlen = 0;
+		nf = (qm.y + (mic_new ? a.tick_len : 0)) / F;
+		if (nf > a.max_frames) nf = a.max_frames;
+		ref_frames = (qr.y + rlen) / F; // frames the far end can supply; the rest is silence
+		if (ref_frames > nf) ref_frames = nf;
+		if (qo.y + nf * F > a.fout.cap) { // no room for the results: nothing runs (counted), the inputs stay queued
+			if (lane == 0) atomicAdd(a.fout.overflow, 1);
+			nf = 0;
+		}
+		if (lane == 0) {
+			if (a.count_out) a.count_out[s] = (uint8_t)nf;
+			const int rf = nf ? ref_frames : 0;
+			a.fmic.pos[s] = make_int2((qm.x + nf * F) % a.fmic.cap, qm.y + (mic_new ? a.tick_len : 0) - nf * F);
+			a.fref.pos[s] = make_int2((qr.x + rf * F) % a.fref.cap, qr.y + rlen - rf * F);
+			a.fout.pos[s] = make_int2(qo.x, qo.y + nf * F);
+		}
+	} else {
+		nf = a.count ? (int)a.count[s] : ((a.run && !a.run[s]) ? 0 : 1);
+		if (nf > a.max_frames) nf = a.max_frames;
+	}
+	if (nf <= 0) return;
+	// sample e (< F) of frame f.  FIFO: position f * F + e of the queue = the ring while it is inside what was queued
+	// before this tick, the tick's own block after that (read from the caller's row: nothing this wave wrote is read back)
+	// Position p of a queue: the ring while p lies inside what was queued before this tick, the tick's own block after
+	// that.  (No integer division: one add and two conditional subtractions, p < 2 F <= capacity.)
+	auto ring_at = [&](const FifoView &q, int head, int p) -> int {
+		unsigned at = (unsigned)head + (unsigned)p;
+		if (at >= (unsigned)q.cap) at -= (unsigned)q.cap;
+		if (at >= (unsigned)q.cap) at -= (unsigned)q.cap;
+		return q.ring[(size_t)s * q.cap + at];
+	};
+	auto mic_at = [&](int f, int e) -> int {
+		if (!fifo) return a.mic[(size_t)s * a.stride + f * F + e];
+		const int p = f * F + e;
+		if (p < qm.y) return ring_at(a.fmic, qm.x, p);
+		return a.mic_tick[(size_t)s * a.mic_tick_stride + (p - qm.y)];
+	};
+	auto ref_at = [&](int f, int e) -> int {
+		if (!fifo) return a.ref[(size_t)s * a.stride + f * F + e];
+		if (f >= ref_frames) return 0; // speexec.c:261-272: a frame of zeros when the far end runs short
+		const int p = f * F + e;
+		if (p < qr.y) return ring_at(a.fref, qr.x, p);
+		return a.ref_tick[(size_t)s * a.ref_tick_stride + (p - qr.y)];
+	};
+	auto out_ptr = [&](int f) -> int16_t * { // where this lane's K cleaned samples of frame f go
+		if (!fifo) return a.out + (size_t)s * a.stride + f * F + e0;
+		unsigned tail = (unsigned)(qo.x + qo.y) + (unsigned)(f * F); // the output FIFO is popped in ticks: its tail is what is F-aligned
+		while (tail >= (unsigned)a.fout.cap) tail -= (unsigned)a.fout.cap;
+		return a.fout.ring + (size_t)s * a.fout.cap + tail + e0; // K samples never wrap
+	};
 	const int M = a.M;
 	float *sm = a.small + (size_t)s * a.small_stride;
 	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
@@ -231,10 +315,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 
 	// far end of frame f: pre-emphasis, energy, spectrum of [previous frame | this frame]
 	auto prep_far = [&](int f, const float (&xp)[K], float (&xn)[K], float2 (&X0)[K], float &Sxx) {
-		const int16_t *rp = a.ref + (size_t)s * a.stride + f * F + e0;
 		float far[K];
 #pragma unroll
-		for (int k = 0; k < K; ++k) far[k] = (float)rp[k];
+		for (int k = 0; k < K; ++k) far[k] = (float)ref_at(f, e0 + k);
 		float prev = __shfl_up(far[K - 1], 1);
 		if (lane == 0) prev = sc.memX;
 #pragma unroll
@@ -279,12 +362,11 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		int any_sat;
 		{
 			float input[K];
-			const int16_t *mp = a.mic + (size_t)s * a.stride + f * F + e0;
 			float fin[K];
 			bool satl = false;
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
-				const int m = mp[k];
+				const int m = mic_at(f, e0 + k);
 				fin[k] = (float)m;
 				satl |= (m <= -32000 || m >= 32000);
 			}
@@ -648,7 +730,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 #pragma unroll
 			for (int k = 0; k < K; ++k) out_i[k] = 0;
 		}
-		int16_t *op = a.out + (size_t)s * a.stride + f * F + e0;
+		int16_t *op = out_ptr(f);
 		auto emit = [&](const int (&o)[K]) { // to the post-filter phase through LDS, else straight out
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
@@ -784,9 +866,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		{
 			float ln[K], lprev[K];
 			load_vec<K>(L.ly[f] + e0, lprev);
-			const int16_t *mp = a.mic + (size_t)s * a.stride + f * F + e0;
 #pragma unroll
-			for (int k = 0; k < K; ++k) ln[k] = sc.adapted ? (float)((int)mp[k] - out_i[k]) : lprev[k];
+			for (int k = 0; k < K; ++k) ln[k] = sc.adapted ? (float)(mic_at(f, e0 + k) - out_i[k]) : lprev[k];
 			store_vec<K>(L.ly[f + 1] + e0, ln);
 		}
 		if (f) leakf[1] = sc.leak_estimate;
@@ -904,7 +985,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			pr[e0 + k] = wr[k] * en[k];
 		}
 		// analysis frame [inbuf, x] * window
-		int16_t *op = a.out + (size_t)s * a.stride + f * F + e0;
+		int16_t *op = out_ptr(f);
 		{
 			float xcur[K], a0[K], a1[K];
 #pragma unroll

@@ -54,6 +54,31 @@ struct mi_graph {
 	hipGraphExec_t exec = nullptr;
 };
 
+// MSBufferizer for a batch of streams on the device (fifo.hip).  Defined here because the canceller and the volume
+// kernel read / write the rings directly (no separate pop / push launch).
+struct mi_fifo {
+	struct mi_ctx *ctx = nullptr;
+	int nstreams = 0, capacity = 0;
+	int16_t *d_ring = nullptr; // [nstreams][capacity]
+	int2 *d_pos = nullptr;     // x = head (index of the oldest sample, < capacity), y = level (samples held)
+	int32_t *d_overflow = nullptr;
+};
+// what a kernel needs of one
+struct FifoView {
+	int16_t *ring;
+	int2 *pos;
+	int32_t *overflow;
+	int cap;
+};
+inline FifoView fifo_view(const mi_fifo *f) {
+	FifoView v;
+	v.ring = f ? f->d_ring : nullptr;
+	v.pos = f ? f->d_pos : nullptr;
+	v.overflow = f ? f->d_overflow : nullptr;
+	v.cap = f ? f->capacity : 0;
+	return v;
+}
+
 struct mi_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;

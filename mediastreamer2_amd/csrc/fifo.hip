@@ -151,13 +151,7 @@ __global__ void fifo_level_kernel(FifoArgs a) {
 
 } // namespace
 
-struct mi_fifo {
-	mi_ctx *ctx = nullptr;
-	int nstreams = 0, capacity = 0;
-	int16_t *d_ring = nullptr;
-	int2 *d_pos = nullptr;
-	int32_t *d_overflow = nullptr;
-};
+// struct mi_fifo: common.hpp
 
 extern "C" {
 

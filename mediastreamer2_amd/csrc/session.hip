@@ -73,26 +73,29 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 		int16_t *rows = cf.mic_codec ? s->d_pcm : s->d_mic[slot];
 		if ((rc = mi_plc_process(s->plc, rows, (size_t)s->in_len, s->d_evlen, s->d_ev[slot])) != MI_OK) return rc;
 	}
+	// the microphone block at the processing rate
+	const int16_t *mic_tick = mic;
+	int mic_stride = s->len;
 	if (s->rs) {
 		if ((rc = mi_resampler_process(s->rs, mic, s->in_len, s->in_len, s->d_up, s->up_stride, nullptr)) != MI_OK) return rc;
-		if ((rc = mi_fifo_push(s->f_mic, s->d_up, s->len, s->up_stride, nullptr)) != MI_OK) return rc;
-	} else {
-		if ((rc = mi_fifo_push(s->f_mic, mic, s->len, s->len, nullptr)) != MI_OK) return rc;
+		mic_tick = s->d_up;
+		mic_stride = s->up_stride;
 	}
 	// far end: from the host, or what this leg was sent one tick ago
 	const int16_t *ref = cf.ref_loopback ? s->d_mix[(slot + SLOTS - 1) % SLOTS] : s->d_ref[slot];
-	if ((rc = mi_fifo_push(s->f_ref, ref, s->len, s->len, nullptr)) != MI_OK) return rc;
-	// the frames a tick completes (480 / 256 -> one or two per leg) in one launch each: pop them back to back into one row
-	// per leg, cancel + post-filter them (state once per tick, mi_aec_process_frames), push what was produced
-	const int fstride = s->rounds * s->frame;
-	if ((rc = mi_fifo_pop_frames(s->f_mic, s->frame, s->rounds, s->d_micf[0], fstride, s->d_ok[0], nullptr, 0)) != MI_OK) return rc;
-	if ((rc = mi_fifo_pop_frames(s->f_ref, s->frame, s->rounds, s->d_reff[0], fstride, nullptr, s->d_ok[0], 1)) != MI_OK) return rc;
-	if ((rc = mi_aec_process_frames(s->aec, s->d_micf[0], s->d_reff[0], s->d_clean[0], fstride, s->d_ok[0], s->rounds,
-	                                MI_AEC_POSTFILTER)) != MI_OK)
+	// MSSpeexEC for the tick, FIFOs included: both blocks are queued, the one or two whole frames (480 / 256) a leg then holds
+	// are cancelled + post-filtered, the cleaned frames queued for the mixer side -- one launch (mi_aec_process_fifos)
+	if ((rc = mi_aec_process_fifos(s->aec, s->f_mic, mic_tick, mic_stride, s->f_ref, ref, s->len, nullptr, s->len, s->f_out, s->rounds,
+	                               MI_AEC_POSTFILTER, nullptr)) != MI_OK)
 		return rc;
-	if ((rc = mi_fifo_push_frames(s->f_out, s->d_clean[0], s->frame, s->rounds, fstride, s->d_ok[0])) != MI_OK) return rc;
-	if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
-	if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
+	// MSVolume on the tick the mixer side reads: popped from the canceller's output FIFO inside the kernel where the sizes
+	// allow 16-byte groups (every rate in use), else pop + process
+	if ((s->len & 7) == 0) {
+		if ((rc = mi_volume_process_fifo(s->vol, s->f_out, s->d_tick, s->len, s->len)) != MI_OK) return rc;
+	} else {
+		if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
+		if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
+	}
 	int16_t *mix = s->d_mix[slot] ? s->d_mix[slot] : s->d_out[slot];
 	if ((rc = mi_mixer_process(s->mix, s->d_tick, nullptr, 1, mix)) != MI_OK) return rc;
 	const int16_t *leaving = mix;
@@ -216,9 +219,10 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 		if ((rc = mi_volume_set_params(s->vol, 0, s->n, all.data())) != MI_OK) return fail(rc);
 	}
 	if ((rc = mi_mixer_create(ctx, s->nconf, cfg->members_per_conference, s->len, &s->mix)) != MI_OK) return fail(rc);
-	const int cap = ((2 * s->len + 2 * s->frame) + 7) & ~7;
+	// capacities: whole frames (the canceller reads / writes the rings frame-wise, mi_aec_process_fifos), two ticks + two frames
+	const int cap = (2 * s->len + 2 * s->frame + s->frame - 1) / s->frame * s->frame;
 	const int delay = cfg->ref_delay_ms * cfg->rate / 1000;
-	const int ref_cap = (cap + delay + 7) & ~7;
+	const int ref_cap = (cap + delay + s->frame - 1) / s->frame * s->frame;
 	if ((rc = mi_fifo_create(ctx, s->n, cap, &s->f_mic)) != MI_OK || (rc = mi_fifo_create(ctx, s->n, ref_cap, &s->f_ref)) != MI_OK ||
 	    (rc = mi_fifo_create(ctx, s->n, cap, &s->f_out)) != MI_OK)
 		return fail(rc);

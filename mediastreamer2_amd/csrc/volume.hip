@@ -40,6 +40,9 @@ struct VolArgs {
 	const int *parity; // which of the two holds the previous launch's values; flipped on the device after each launch,
 	                   // so a captured hipGraph replays correctly (a host-side flip would be frozen into the graph)
 	int nstreams, nsamples, stride, sample_rate, pitch_dw, pitch_f;
+	// src.ring != NULL: the chunk is popped from a device FIFO (all-or-nothing, zeros when it holds less: what
+	// mi_fifo_pop(..., zero_fill) delivers) and the result is written to `samples` -- no separate pop launch, no copy
+	FifoView src;
 };
 
 __device__ __forceinline__ int sat16(int v) { return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v); }
@@ -49,6 +52,8 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	uint32_t *rows = reinterpret_cast<uint32_t *>(smem);                              // [SPB][pitch_dw] packed int16
 	float *sq = reinterpret_cast<float *>(smem + (size_t)SPB * a.pitch_dw * 4);       // [SPB][pitch_f] (float)(v*v)
 	__shared__ int s_intgain[SPB], s_dcoff[SPB], s_mode[SPB], s_n[SPB], s_pk[SPB], s_dc[SPB];
+	__shared__ int s_head[SPB]; // FIFO source: index of the chunk's first sample in the stream's ring, -1 = not enough queued
+	const bool from_fifo = a.src.ring != nullptr;
 
 	const int tid = threadIdx.x;
 	const int s0 = blockIdx.x * SPB;
@@ -70,6 +75,14 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 		s_n[tid] = min(max(n, 0), a.nsamples);
 		s_pk[tid] = 0;
 		s_dc[tid] = 0;
+		s_head[tid] = -1;
+		if (from_fifo && tid < nloc) { // ms_bufferizer_read, all-or-nothing (msqueue.c:83); the position moves on at once
+			const int2 q = a.src.pos[s0 + tid];
+			if (q.y >= a.nsamples) {
+				s_head[tid] = q.x;
+				a.src.pos[s0 + tid] = make_int2((q.x + a.nsamples) % a.src.cap, q.y - a.nsamples);
+			}
+		}
 	}
 	__syncthreads();
 
@@ -90,7 +103,15 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 				sl[u] = ic / oct;
 				q[u] = ic - sl[u] * oct;
 				on[u] = i <= last;
-				v[u] = *reinterpret_cast<const uint4 *>(a.samples + (size_t)(s0 + sl[u]) * a.stride + 8 * q[u]);
+				if (!from_fifo) {
+					v[u] = *reinterpret_cast<const uint4 *>(a.samples + (size_t)(s0 + sl[u]) * a.stride + 8 * q[u]);
+				} else { // ring capacity and head are multiples of 8 (checked by the caller): a group never wraps
+					const int h = s_head[sl[u]];
+					unsigned at = (unsigned)(h < 0 ? 0 : h) + 8u * (unsigned)q[u];
+					if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
+					v[u] = *reinterpret_cast<const uint4 *>(a.src.ring + (size_t)(s0 + sl[u]) * a.src.cap + at);
+					if (h < 0) v[u] = make_uint4(0, 0, 0, 0);
+				}
 			}
 #pragma unroll
 			for (int u = 0; u < NB; ++u) on[u] = on[u] && 8 * q[u] < s_n[sl[u]];
@@ -243,10 +264,18 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 		for (int i = tid; i < nloc * oct; i += VTHREADS) {
 			const int sl = i / oct, q = i - sl * oct;
 			const int mode = s_mode[sl], n = s_n[sl];
-			if (mode == 0 || 8 * q >= n) continue;
-			const int ig = s_intgain[sl], dc = (mode == 2) ? s_dcoff[sl] : 0;
+			if (8 * q >= n) continue;
 			const int16_t *r = reinterpret_cast<const int16_t *>(rows + sl * a.pitch_dw) + 8 * q;
 			int16_t *dst = a.samples + (size_t)(s0 + sl) * a.stride + 8 * q;
+			if (mode == 0) { // gain 1: in place nothing to do (msvolume.c:440); popped from a FIFO the chunk still has to land
+				if (from_fifo) {
+					if (8 * q + 8 <= n) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(r);
+					else
+						for (int k = 0; 8 * q + k < n; ++k) dst[k] = r[k];
+				}
+				continue;
+			}
+			const int ig = s_intgain[sl], dc = (mode == 2) ? s_dcoff[sl] : 0;
 			if (8 * q + 8 <= n) {
 				const uint4 rv = *reinterpret_cast<const uint4 *>(r);
 				const unsigned w[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -389,7 +418,22 @@ int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_stat
 	return MI_OK;
 }
 
+static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src);
+
 int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples) {
+	return volume_launch(v, d_samples, nsamples, stride, d_nsamples, nullptr);
+}
+
+int mi_volume_process_fifo(mi_volume *v, mi_fifo *f_src, int16_t *d_out, int nsamples, int stride) {
+	MI_CHECK_ARG(v && f_src && f_src->nstreams == v->nstreams);
+	if ((f_src->capacity & 7) || (nsamples & 7) || (stride & 7) || (reinterpret_cast<uintptr_t>(d_out) & 15)) {
+		mi::set_error("mi_volume_process_fifo: capacity, chunk and stride must be multiples of 8 samples, rows 16-byte aligned");
+		return MI_ENOTSUP;
+	}
+	return volume_launch(v, d_out, nsamples, stride, nullptr, f_src);
+}
+
+static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src) {
 	MI_CHECK_ARG(v && d_samples && nsamples > 0 && stride >= nsamples);
 	if (nsamples > 3840) {
 		mi::set_error("chunk of %d samples exceeds the volume kernel's LDS staging (max 3840)", nsamples);
@@ -408,6 +452,7 @@ int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride
 	a.nsamples = nsamples;
 	a.stride = stride;
 	a.sample_rate = v->sample_rate;
+	a.src = fifo_view(src);
 	// packed rows: whole 16-byte groups.  Float rows: whole groups of 8, and an odd number of 16-byte
 	// groups per row so the SPB lanes of phase B read disjoint banks.
 	const int pitch = ((nsamples + 7) >> 3) * 4;

@@ -129,6 +129,73 @@ def test_fifo_frame_ops_for_a_whole_tick_match_the_frame_by_frame_ones(ctx):
         f.close()
 
 
+def test_canceller_with_the_fifos_folded_in_equals_the_separate_launches(ctx):
+    """mi_aec_process_fifos (blocks queued, frames popped, cancelled, results queued: ONE launch) == mi_fifo_push x 2,
+    mi_fifo_pop_frames x 2, mi_aec_process_frames, mi_fifo_push_frames: FIFO levels, what the output FIFO delivers and the
+    canceller's state, bit for bit -- with a far end that sometimes skips a block (silence is injected for the frames it
+    cannot supply) and one that starts with a delay line of silence (MS_ECHO_CANCELLER_SET_DELAY), 48 and 16 kHz."""
+    torch = pytest.importorskip("torch")
+    for rate, F, tail in ((48000, 256, 128), (16000, 128, 128)):
+        n, ns, nticks = 12, rate // 100, 60
+        cap = 4 * F
+        flen = tail * rate // 1000
+        M = (flen + F - 1) // F
+        rng = np.random.default_rng(rate)
+        mic = np.stack([synth_pcm(200 + s, ns * nticks, rate=rate, sigma=2500.0) for s in range(n)])
+        ref = np.stack([synth_pcm(300 + s, ns * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+        z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+
+        def rig():
+            a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+            fm, fr, fo = (ms.FifoBatch(ctx, n, cap) for _ in range(3))
+            delay = z(n, 2 * F)
+            gate = torch.from_numpy((np.arange(n) % 3 == 0).astype(np.uint8)).cuda()   # every third leg: a far-end delay line
+            torch.cuda.synchronize()
+            fr.push(delay, nsamples=F + 32, gate=gate)
+            return a, fm, fr, fo
+
+        a1, fm1, fr1, fo1 = rig()
+        a2, fm2, fr2, fo2 = rig()
+        micf, reff, clean, cnt = z(n, 2 * F), z(n, 2 * F), z(n, 2 * F), z(n, dt=torch.uint8)
+        cnt2 = z(n, dt=torch.uint8)
+        t1, t2, ok1, ok2 = z(n, ns), z(n, ns), z(n, dt=torch.uint8), z(n, dt=torch.uint8)
+        lv1, lv2 = z(n, dt=torch.int32), z(n, dt=torch.int32)
+        for t in range(nticks):
+            dm = torch.from_numpy(np.ascontiguousarray(mic[:, t * ns:(t + 1) * ns])).cuda()
+            rblk = ref[:, t * ns:(t + 1) * ns].copy()
+            skip = rng.random(n) < 0.15           # the far end of these legs delivers nothing this tick ...
+            dr = torch.from_numpy(rblk).cuda()
+            rc = torch.from_numpy(np.where(skip, 0, ns).astype(np.int32)).cuda()
+            torch.cuda.synchronize()
+            # separate launches
+            fm1.push(dm)
+            fr1.push(dr, nsamples=ns, count=rc)
+            fm1.pop_frames(F, 2, micf, nframes_out=cnt)
+            fr1.pop_frames(F, 2, reff, wanted=cnt, zero_fill=True)
+            a1.process_frames(micf, reff, clean, cnt, max_frames=2)
+            fo1.push_frames(clean, F, 2, cnt)
+            fo1.pop(ns, t1, ok=ok1, zero_fill=True)
+            # folded in
+            a2.process_fifos(fm2, dm, fr2, dr, fo2, tick_len=ns, max_frames=2, count_out=cnt2, ref_len=rc)
+            fo2.pop(ns, t2, ok=ok2, zero_fill=True)
+            for f1, f2 in ((fm1, fm2), (fr1, fr2), (fo1, fo2)):
+                f1.levels(lv1)
+                f2.levels(lv2)
+                ctx.sync()
+                np.testing.assert_array_equal(lv1.cpu().numpy(), lv2.cpu().numpy(), err_msg=f"rate {rate} tick {t}")
+            ctx.sync()
+            np.testing.assert_array_equal(cnt.cpu().numpy(), cnt2.cpu().numpy())
+            np.testing.assert_array_equal(ok1.cpu().numpy(), ok2.cpu().numpy())
+            np.testing.assert_array_equal(t1.cpu().numpy(), t2.cpu().numpy(), err_msg=f"rate {rate} tick {t}")
+        for s_ in range(n):
+            for what, ln in (("W", M * 2 * F), ("foreground", M * 2 * F), ("X", (M + 1) * 2 * F), ("E", 2 * F), ("power_1", F + 1), ("scalars", 16)):
+                x, y = a1.get(s_, what, ln), a2.get(s_, what, ln)
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"rate {rate} stream {s_}: {what}"
+        assert fm2.overflows() + fr2.overflows() + fo2.overflows() == 0
+        for o in (a1, a2, fm1, fr1, fo1, fm2, fr2, fo2):
+            o.close()
+
+
 def test_chained_tick_pipeline_stage_parity(ctx, oracle):
     torch = pytest.importorskip("torch")
     nconf, mm = 2, 32

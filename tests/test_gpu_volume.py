@@ -161,3 +161,51 @@ def test_volume_full_size_4096_streams_agc(ctx, oracle):
     for s, o in orcs.items():
         _cmp_state(st[s], o.v, s)
     vb.close()
+
+
+def test_volume_pops_its_chunk_from_a_fifo(ctx):
+    """mi_volume_process_fifo == mi_fifo_pop (zero fill) + mi_volume_process: samples, meter state and FIFO levels bit for
+    bit, streams that run dry get silence (and meter it), unity-gain streams still have their chunk delivered."""
+    import torch
+    n, ns, cap = 37, 480, 1024
+    rng = np.random.default_rng(8)
+    v1, v2 = ms.VolumeBatch(ctx, n, 48000), ms.VolumeBatch(ctx, n, 48000)
+    ps = []
+    for s in range(n):
+        p = v1.default_params()
+        p.agc_enabled = int(s % 3 == 0)
+        p.noise_gate_enabled = int(s % 5 == 0)
+        p.remove_dc = int(s % 7 == 0)
+        if s % 4 == 1:
+            p.static_gain = 0.5
+        ps.append(p)
+    v1.set_params(ps)
+    v2.set_params(ps)
+    if any(p.static_gain != 1 for p in ps):
+        st = v1.get_state()
+        for s in range(n):
+            st[s].gain = st[s].target_gain = ps[s].static_gain
+        v1.set_state(st)
+        v2.set_state(st)
+    f1, f2 = ms.FifoBatch(ctx, n, cap), ms.FifoBatch(ctx, n, cap)
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    t1, t2, lv1, lv2 = z(n, ns), z(n, ns), z(n, dt=torch.int32), z(n, dt=torch.int32)
+    for t in range(40):
+        blk = rng.integers(-20000, 20000, (n, 512), dtype=np.int16)
+        cnt = rng.choice([0, 256, 512], n, p=[0.2, 0.3, 0.5]).astype(np.int32)   # frames of 256 arrive irregularly
+        d, c = torch.from_numpy(blk).cuda(), torch.from_numpy(cnt).cuda()
+        torch.cuda.synchronize()
+        f1.push(d, nsamples=512, count=c)
+        f2.push(d, nsamples=512, count=c)
+        f1.pop(ns, t1, zero_fill=True)
+        v1.process(t1)
+        v2.process_fifo(f2, t2)
+        f1.levels(lv1)
+        f2.levels(lv2)
+        ctx.sync()
+        np.testing.assert_array_equal(t1.cpu().numpy(), t2.cpu().numpy(), err_msg=f"tick {t}")
+        np.testing.assert_array_equal(lv1.cpu().numpy(), lv2.cpu().numpy())
+        s1, s2 = v1.get_state(), v2.get_state()
+        for s in range(n):
+            assert bytes(s1[s]) == bytes(s2[s]), f"tick {t} stream {s}"
+    assert f1.overflows() == f2.overflows()
