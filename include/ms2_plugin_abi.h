@@ -457,10 +457,14 @@ extern MSFilterDesc ms_mi355x_audio_flow_control_desc; /* .id = MS_AUDIO_FLOW_CO
  * it with ms_video_set_scaler_impl (msvideo.c:719-721), so the reference's OWN MSSizeConv / MSPixConv /
  * display filters reach the GPU too (one frame per call, synchronous, as that interface demands). */
 extern MSScalerDesc ms_mi355x_scaler_desc;
-/* Runs every staged batch (one launch per filter type) -- called once per tick after the
- * graphs have run; with a real MSTicker it is the task the filters postpone (msfilter.c:289-300). */
+/* Runs every ticker hub's staged work now.  Normally unnecessary: the facades postpone that task on their ticker
+ * themselves (msfilter.c:289-300); for an application that wants the last tick's results before tearing a graph down. */
 void ms_mi355x_flush(void);
-/* Releases the device context and all pools (tests). */
+/* Blocks dropped or passed through unprocessed because a HIP call failed (0 in a healthy process). */
+unsigned long long ms_mi355x_late_events(void);
+/* Tickers with live banks, banks alive, bank slots held by filters (any pointer may be NULL): a leak check's view. */
+void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use);
+/* Waits for every hub's stream (tests, orderly shutdown). */
 void ms_mi355x_shutdown(void);
 #ifdef __cplusplus
 }
