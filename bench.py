@@ -522,7 +522,7 @@ def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25):
         del g8, g1
     finally:
         rig.close()
-        torch.cuda.empty_cache()
+        PLATFORM.release(torch)
     return out
 
 
@@ -708,6 +708,38 @@ def cpu_reference_times():
     return out
 
 
+class HipPlatform:
+    """The device-specific calls of the headline's control flow, in one place.  The product path is this class: HIP
+    device, libmsmi355x kernels, RCCL exchange.  tests/bench_cpu_double.py substitutes a double (and a stand-in for
+    ChainRig) to drive main()'s multi-rank control flow -- capacity agreement, step counts, barriers, the per-tick
+    exchange, the split-mix check, exit codes -- over gloo on a box without a GPU."""
+    device = "cuda"
+    backend = "nccl"
+
+    def available(self, torch):
+        return torch.cuda.is_available()
+
+    def select(self, torch, local):
+        torch.cuda.set_device(local)
+
+    def sync(self, torch):
+        torch.cuda.synchronize()
+
+    def release(self, torch):
+        torch.cuda.empty_cache()
+
+    def load(self):
+        import mediastreamer2_amd as ms
+        return ms
+
+    def exchange(self, ctx, local):
+        from mediastreamer2_amd.sharding import PartialSumExchange
+        return PartialSumExchange(ctx.stream, local)
+
+
+PLATFORM = HipPlatform()
+
+
 def init_distributed(torch, rank, world, local):
     """One process per GPU.  The data path's collective is RCCL (backend "nccl"); there is no fallback: if RCCL cannot
     be brought up the run fails.  MSMI355X_BENCH_BACKEND=gloo exists only to exercise this control flow on a box with
@@ -715,15 +747,15 @@ def init_distributed(torch, rank, world, local):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    backend = os.environ.get("MSMI355X_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("MSMI355X_BENCH_BACKEND", PLATFORM.backend)
     try:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-        probe = torch.ones(1, dtype=torch.int32, device="cuda")
+        probe = torch.ones(1, dtype=torch.int32, device=PLATFORM.device)
         dist.all_reduce(probe)
-        torch.cuda.synchronize()
+        PLATFORM.sync(torch)
         if int(probe.item()) != world:
             raise RuntimeError(f"all-reduce probe returned {int(probe.item())}, expected {world}")
     except Exception as e:
@@ -740,8 +772,7 @@ class Headline:
         self.rig = ChainRig(ms, torch, ctx, nstreams, world=world, rank=rank, nsplit=SPLIT_CONFERENCES if world > 1 else 0)
         self.exchange = None
         if world > 1:
-            from mediastreamer2_amd.sharding import PartialSumExchange
-            self.exchange = PartialSumExchange(ctx.stream, local)
+            self.exchange = PLATFORM.exchange(ctx, local)
 
     def prepare(self, warmup):
         rig = self.rig
@@ -825,18 +856,18 @@ class Headline:
         mine = rig.split_in.contiguous().view(torch.uint8)  # NCCL has no int16: ship bytes
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
-        torch.cuda.synchronize()
+        PLATFORM.sync(torch)
         ok = 1
         if rank == 0:
             full = torch.cat([p.view(torch.int16).view(rig.nsplit, rig.mloc, 480) for p in parts], dim=1).contiguous()
             mx = self.ms.MixerBatch(self.ctx, rig.nsplit, rig.MEMBERS, 480)
             ref = torch.zeros_like(full)
-            torch.cuda.synchronize()  # `full` and `ref` were produced on torch's stream, the mixer runs on the context's
+            PLATFORM.sync(torch)  # `full` and `ref` were produced on torch's stream, the mixer runs on the context's
             mx.process(full, out=ref)
             self.ctx.sync()
             ok = int(torch.equal(ref[:, :rig.mloc].contiguous(), rig.split_out.contiguous()))
             mx.close()
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=PLATFORM.device)
         dist.broadcast(flag, 0)
         return bool(flag.item())
 
@@ -847,7 +878,7 @@ class Headline:
         for g in getattr(self, "g1", []):
             g.close()
         self.rig.close()
-        self.torch.cuda.empty_cache()
+        PLATFORM.release(self.torch)
 
 
 def main():
@@ -856,7 +887,7 @@ def main():
         import __graft_entry__ as entry  # build artefacts are git-ignored: a fresh checkout compiles them first
         entry.build()
     import torch
-    import mediastreamer2_amd as ms
+    ms = PLATFORM.load()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -868,14 +899,14 @@ def main():
     if ChainRig.MEMBERS % world:
         print(f"bench.py: {world} ranks do not divide a 32-party conference", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
+    if not PLATFORM.available(torch):
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
     # one rank per GPU; MSMI355X_BENCH_DEVICE pins every rank to one device (only for exercising the N>1 control
     # flow on a single-GPU box together with MSMI355X_BENCH_BACKEND=gloo)
     if os.environ.get("MSMI355X_BENCH_DEVICE"):
         local = int(os.environ["MSMI355X_BENCH_DEVICE"])
-    torch.cuda.set_device(local)
+    PLATFORM.select(torch, local)
     dist, backend = (None, None)
     if world > 1:
         dist, backend = init_distributed(torch, rank, world, local)
@@ -886,7 +917,7 @@ def main():
     def reduce_scalar(v, op):
         if dist is None:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        t = torch.tensor([v], dtype=torch.float64, device=PLATFORM.device)
         dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
         return float(t.item())
 
@@ -916,7 +947,7 @@ def main():
 
     def sync_local():
         ctx.sync()
-        torch.cuda.synchronize()
+        PLATFORM.sync(torch)
 
     def barrier():
         if dist is not None:

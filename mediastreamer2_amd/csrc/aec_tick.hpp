@@ -101,15 +101,25 @@ __device__ __forceinline__ rsrc_t mk_rsrc(const void *p, unsigned bytes) {
 #endif
 __device__ __forceinline__ float u2f(unsigned v) { return __uint_as_float(v); }
 __device__ __forceinline__ unsigned f2u(float v) { return __float_as_uint(v); }
+// cache policy of the spectra's loads / stores (A/B switches; buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef AEC_TICK_AUX_LD
+#define AEC_TICK_AUX_LD 0
+#endif
+#ifndef AEC_TICK_AUX_ST
+#define AEC_TICK_AUX_ST 0
+#endif
+#ifndef AEC_TICK_PRIO
+#define AEC_TICK_PRIO 0 /* s_setprio while a wave streams its filter blocks */
+#endif
 template <int K>
 __device__ __forceinline__ void bload_bins(rsrc_t r, unsigned voff, unsigned soff, float2 (&v)[K]) {
 	if constexpr (K == 1) {
-		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AEC_TICK_AUX_LD);
 		v[0] = make_float2(u2f(t.x), u2f(t.y));
 	} else {
 #pragma unroll
 		for (int k = 0; k < K; k += 2) {
-			const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 8 * k, soff, 0);
+			const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 8 * k, soff, AEC_TICK_AUX_LD);
 			v[k] = make_float2(u2f(t.x), u2f(t.y));
 			v[k + 1] = make_float2(u2f(t.z), u2f(t.w));
 		}
@@ -119,12 +129,12 @@ template <int K>
 __device__ __forceinline__ void bstore_bins(rsrc_t r, unsigned voff, unsigned soff, const float2 (&v)[K]) {
 	if constexpr (K == 1) {
 		u2v t = {f2u(v[0].x), f2u(v[0].y)};
-		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, AEC_TICK_AUX_ST);
 	} else {
 #pragma unroll
 		for (int k = 0; k < K; k += 2) {
 			u4v t = {f2u(v[k].x), f2u(v[k].y), f2u(v[k + 1].x), f2u(v[k + 1].y)};
-			__builtin_amdgcn_raw_buffer_store_b128(t, r, voff + 8 * k, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(t, r, voff + 8 * k, soff, AEC_TICK_AUX_ST);
 		}
 	}
 }
@@ -477,6 +487,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
 			if (lane == 0) L.wnorm[j] = nn; // feeds the NEXT frame's proportional step
 		};
+#if AEC_TICK_PRIO
+		__builtin_amdgcn_s_setprio(AEC_TICK_PRIO);
+#endif
 		if (f == 0) {
 			// frame 1: X, foreground and background; with a second frame behind it also that frame's foreground response
 			const bool spec = nf > 1;
@@ -590,6 +603,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			pendingFG = false;
 		}
 
+#if AEC_TICK_PRIO
+		__builtin_amdgcn_s_setprio(0);
+#endif
 		// ---- time-domain responses
 		float efg[K], ybg[K], e1[K], e2[K], dresp[K], input[K];
 		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, yfg);

@@ -1,0 +1,83 @@
+"""bench.py's multi-rank control flow on a box without a GPU: two ranks over gloo, the device side replaced by
+tests/bench_cpu_double.py (virtual clock, plain-torch conference mix).  What is checked is what the 8-GPU run depends on
+and no single-GPU run exercises: every rank agrees on the leg count (the slowest rank's capacity), on the step count,
+the exchange runs every tick, the split conferences' mix is verified, rank 0 prints one line with the whole-job value,
+and failures exit non-zero on every rank instead of hanging."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOUBLE = os.path.join(ROOT, "tests", "bench_cpu_double.py")
+COMMON = ["--steps", "16", "--warmup", "8", "--sweep-lo", "16384", "--sweep-hi", "65536", "--no-extras", "--no-cpu-baseline"]
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run(nranks, extra_env=None, args=()):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    env.pop("MSMI355X_BENCH_BACKEND", None)
+    if nranks == 1:
+        cmd = [sys.executable, DOUBLE, "--gpus", "1", *COMMON, *args]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), DOUBLE, "--gpus", str(nranks), *COMMON, *args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+
+
+def the_line(r):
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])  # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_one_rank_sweep_settles_on_the_doubles_capacity():
+    r = run(1)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = the_line(r)
+    assert d["n_gpus"] == 1 and d["value"] == 22528  # 10 ms at 24 000 legs, sweep granularity 2048
+    assert d["config"]["fits"] and d["config"]["worst_tick_ms"] < 10.0
+    assert d["steps"] % 8 == 0 and d["steps"] >= 16 and d["steps_requested"] == 16
+    assert [p["streams"] for p in d["config"]["capacity_sweep"]][:2] == [16384, 24576]
+    assert "split_conferences" not in d["config"]
+
+
+def test_two_ranks_agree_on_the_slower_ranks_capacity_and_exchange_every_tick():
+    r = run(2, {"DOUBLE_SLOW_RANK1": "1.25"})  # rank 1's device carries 19 200 legs in 10 ms -> 18 432
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = the_line(r)
+    sc = d["config"]["split_conferences"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    per_rank = d["config"]["streams_per_gpu"]
+    # 18 432 is the slower rank's sweep result; with the 64 split conferences' 16 local members the rig rounds to whole
+    # conferences, and the deployed tick (exchange included) may step down by 2048 once
+    assert per_rank in (18432, 18432 - 2048) and d["value"] == 2 * per_rank
+    assert sc["count"] == 64 and sc["members_per_rank"] == 16 and sc["mix_bit_exact_vs_single_gpu"] is True
+    assert sc["backend"] == "gloo" and "TEST BACKEND" in d["config"]["parallelism"]
+    assert sc["allreduce_bytes_per_tick"] == 64 * 480 * 4 and sc["allreduce_alone_us"] is not None
+    assert d["steps"] % 8 == 0
+    assert d["config"]["worst_tick_ms"] < 10.0
+
+
+def test_a_wrong_partial_sum_fails_every_rank():
+    r = run(2, {"DOUBLE_BREAK_RANK": "1"}, args=["--streams", "8192"])
+    assert r.returncode != 0
+    assert "differs from the single-GPU mix" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_gpus_flag_without_the_launcher_is_a_usage_error():
+    r = subprocess.run([sys.executable, DOUBLE, "--gpus", "2", *COMMON], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 2 and "needs torch.distributed.run" in r.stderr
+
+
+def test_ranks_that_do_not_divide_a_conference_are_refused():
+    r = run(3, args=["--streams", "4096"])
+    assert r.returncode != 0 and "do not divide a 32-party conference" in r.stderr
