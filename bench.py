@@ -397,7 +397,7 @@ class ChainRig:
 
     F, RATE, MEMBERS, RING = 256, 48000, 32, 4
 
-    def __init__(self, ms, torch, ctx, nstreams, world=1, rank=0, nsplit=0):
+    def __init__(self, ms, torch, ctx, nstreams, world=1, rank=0, nsplit=0, stagger=False):
         self.ms, self.torch, self.ctx = ms, torch, ctx
         F, rate, mm = self.F, self.RATE, self.MEMBERS
         self.mloc = mm // world if nsplit else 0
@@ -412,7 +412,10 @@ class ChainRig:
         p.agc_enabled = 1
         self.vol.set_params([p] * n)
         self.mix = ms.MixerBatch(ctx, self.nconf, mm, 480)
-        self.f_mic, self.f_ref, self.f_out = (ms.FifoBatch(ctx, n, 1024) for _ in range(3))  # whole frames: 4 x 256
+        # whole frames: 4 x 256.  Legs out of phase with each other can miss one pop at start-up and then run one frame
+        # fuller for good (ms_bufferizer_read is all-or-nothing, msqueue.c:83): their output ring gets two frames more
+        self.f_mic, self.f_ref = (ms.FifoBatch(ctx, n, 1024) for _ in range(2))
+        self.f_out = ms.FifoBatch(ctx, n, 1536 if stagger else 1024)
         ring = self.RING
         base = min(n, 4096)  # distinct signals for 4096 legs, rotated for the rest (the kernels do not care)
         mic16 = synth_pcm_batch(base, 160 * ring, 16000, seed0=0x5EED + 7919 * rank)
@@ -433,6 +436,19 @@ class ChainRig:
         nw = self.nconf * mm
         self.whole_in = self.tick_buf[:nw].view(self.nconf, mm, 480)
         self.whole_out = self.mixed[:nw].view(self.nconf, mm, 480)
+        if stagger:
+            # legs that joined at different ticks: leg s starts with 32 * phase(s) samples queued on both pins, so in every
+            # tick one leg in eight has ONE whole frame to cancel and seven have two (aligned legs: all two, or all one).
+            # The phases are a seeded shuffle, as arrival times are: a regular pattern aliases with the placement of
+            # workgroups (block b on XCD b % 8, round-robin over its CUs) -- with phase = s % 8, or (s + s / 8) % 8, a
+            # tick's short legs all land on one XCD, or on four CUs of each, which then idle (scripts/aec_mix_probe.py)
+            perm = np.random.default_rng(0xA11C).permutation(n)
+            lead = torch.from_numpy((32 * (perm % 8)).astype(np.int32)).cuda()
+            zeros = z(n, 224)
+            torch.cuda.synchronize()
+            self.f_mic.push(zeros, count=lead)
+            self.f_ref.push(zeros, count=lead)
+            ctx.sync()
         if nsplit:
             self.mixs = ms.MixerBatch(ctx, nsplit, self.mloc, 480)
             self.split_in = self.tick_buf[nw:].view(nsplit, self.mloc, 480)
@@ -483,13 +499,13 @@ class ChainRig:
         self.__dict__.clear()
 
 
-def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25):
+def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25, stagger=False):
     """avg and worst tick of the chain at `nstreams` legs on this GPU.  avg: one hipGraph of 8 ticks replayed for at
     least `min_s` seconds; worst: single-tick graphs timed one by one over two 8-tick cycles (no overlap between
     ticks, the GPU drains after each: conservative)."""
-    rig = ChainRig(ms, torch, ctx, nstreams)
+    rig = ChainRig(ms, torch, ctx, nstreams, stagger=True) if stagger else ChainRig(ms, torch, ctx, nstreams)
     try:
-        rig.warm()
+        rig.warm(16 if stagger else 8)
         g8 = rig.capture(range(8))
         g8.launch()
         ctx.sync()
@@ -1118,6 +1134,21 @@ def main():
                 line["roofline"]["measured_copy_GBps"] = copy_ceiling(torch)
             except Exception:
                 line["roofline"]["measured_copy_GBps"] = None
+            try:  # the same chain with the legs' bufferizers out of phase (a live bridge: legs join at different ticks)
+                best, n_try = None, n_local + 4096
+                while n_try <= n_local + 20480:
+                    p = chain_capacity_point(ms, torch, ctx, n_try, stagger=True)
+                    if not p["fits"] or p["fifo_overflows"]:
+                        break
+                    best, n_try = p, n_try + 4096
+                line["config"]["legs_out_of_phase"] = {
+                    "streams": best["streams"] if best else n_local, "tick_ms_avg": best["tick_ms_avg"] if best else None,
+                    "tick_ms_worst": best["tick_ms_worst"] if best else None, "step": 4096,
+                    "note": "not `value`: `value` is measured with every leg's 480 -> 256 re-framing in the SAME phase (all legs "
+                            "have two frames in seven ticks of eight, one in the eighth), the worst case for the worst tick; "
+                            "here the legs start 0, 32, .. 224 samples ahead (a seeded shuffle, one eighth each), so every tick carries 15/8 frames per leg"}
+            except Exception as e:
+                line["config"]["legs_out_of_phase"] = {"error": str(e)[:200]}
             if not a.no_session:
                 for key, kw in (("session_pcie_inclusive", {}), ("session_trunk_g711", {"trunk": True})):
                     try:

@@ -44,6 +44,13 @@ void set_error(const char *fmt, ...);
 	} while (0)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// Workgroups are observed to be dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.  A
+// kernel whose neighbouring work items touch the same cache lines (rows of 960 bytes are not multiples of the 128-byte
+// line) launches xcd_grid(n) blocks and turns blockIdx.x into its work item with xcd_item(): every XCD then owns one
+// contiguous run of items, and a line two neighbours share is fetched into one L2 instead of two.  Speed only -- any
+// placement computes the same thing.  Items >= n (the padding of the last run) return at once.
+inline unsigned xcd_grid(unsigned n) { return (n + 7u) / 8u * 8u; }
+__device__ __forceinline__ unsigned xcd_item(unsigned block, unsigned grid) { return (block & 7u) * (grid >> 3) + (block >> 3); }
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 } // namespace mi

@@ -152,8 +152,12 @@ struct MixMArgs {
 __global__ __launch_bounds__(256) void mixer_members_kernel(MixMArgs ma) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const MixArgs &a = ma.a;
-	const int c = blockIdx.x / ma.cblocks;
-	const int g0 = (blockIdx.x - c * ma.cblocks) * ma.gb;
+	// the column blocks of a conference (and the conferences next to it) on one XCD: a member row of 960 bytes starts in
+	// the middle of a cache line every other time, and the neighbouring column block needs the other half of that line
+	const unsigned item = mi::xcd_item(blockIdx.x, gridDim.x);
+	if (item >= (unsigned)(a.nconf * ma.cblocks)) return;
+	const int c = item / ma.cblocks;
+	const int g0 = (item - c * ma.cblocks) * ma.gb;
 	if (a.run && !a.run[c]) return;
 	const int conf_mode = a.conf_modes ? a.conf_modes[c] : a.conf_mode;
 	const int ncol = ma.gb * 8;
@@ -308,7 +312,7 @@ static bool launch_members(mi_mixer *m, const MixArgs &a) {
 	ma.q = std::max(1, std::min(256 / ncol, a.mm));
 	ma.per = mi::ceil_div(a.mm, ma.q);
 	const size_t lds = (size_t)a.mm * ncol * 2 + (size_t)(ma.q + 1) * ncol * 4;
-	hipLaunchKernelGGL(mixer_members_kernel, dim3(a.nconf * ma.cblocks), dim3(256), lds, m->ctx->stream, ma);
+	hipLaunchKernelGGL(mixer_members_kernel, dim3(mi::xcd_grid((unsigned)(a.nconf * ma.cblocks))), dim3(256), lds, m->ctx->stream, ma);
 	return true;
 }
 

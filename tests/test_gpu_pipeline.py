@@ -625,3 +625,37 @@ def test_session_downsampled_pcm_output_and_reset(ctx):
         np.testing.assert_array_equal(got[t][0], want[t][0], err_msg=f"tick {t}")
     a.close()
     b.close()
+
+
+def test_bench_rig_with_legs_out_of_phase(ctx):
+    """bench.py's chain with the legs' 480 -> 256 re-framing spread over the eight phases (a seeded shuffle): every tick one leg in eight has
+    one whole frame and seven have two, nothing overflows (the output ring is two frames larger: a leg that misses its
+    first pop stays one frame fuller), and after the start-up every leg delivers a tick per tick."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rig = bench.ChainRig(ms, torch, ctx, 256, stagger=True)
+    try:
+        lv = torch.zeros(rig.n, dtype=torch.int32, device="cuda")
+        for t in range(24):
+            rig.tick(t)
+            rig.f_mic.levels(lv)
+            ctx.sync()
+            got = np.bincount(lv.cpu().numpy() // 32, minlength=8)
+            assert (lv.cpu().numpy() % 32 == 0).all() and (got == rig.n // 8).all(), (t, got)  # one eighth of the legs in every phase
+        assert rig.overflows() == 0
+        rig.f_out.levels(lv)
+        ctx.sync()
+        out = lv.cpu().numpy()
+        assert out.min() >= 0 and out.max() <= 1536 - 512
+        # steady state: the output of a full cycle is not silence for any leg
+        heard = np.zeros(rig.n, bool)
+        for t in range(24, 32):
+            rig.tick(t)
+            ctx.sync()
+            heard |= (rig.tick_buf.cpu().numpy() != 0).any(axis=1)
+        assert heard.all()
+    finally:
+        rig.close()
