@@ -383,22 +383,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			any_sat = __any(satl);
 			const float radius = a.notch_radius;
 			const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
-			float m0 = sc.notch0, m1 = sc.notch1;
 			float v[K];
-#pragma unroll 2
-			for (int l = 0; l < 64; ++l) {
-#pragma unroll
-				for (int k = 0; k < K; ++k) {
-					const float vin = rdlane(fin[k], l);
-					const float vout = m0 + vin;
-					m0 = m1 + 2 * (-vin + radius * vout);
-					m1 = vin - den2 * vout;
-					const float y = radius * vout;
-					if (lane == l) v[k] = y;
-				}
-			}
-			sc.notch0 = m0;
-			sc.notch1 = m1;
+			w_dc_notch<K>(fin, radius, den2, sc.notch0, sc.notch1, v);
 			float vprev = __shfl_up(v[K - 1], 1);
 			if (lane == 0) vprev = sc.memD;
 #pragma unroll
@@ -620,9 +606,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			e2[k] = input[k] - ybg[k];
 			dresp[k] = efg[k] - ybg[k];
 		}
-		const float Sff = WSeq<K>::inner_prod(e1, e1);
-		const float Dbf = 10 + WSeq<K>::inner_prod(dresp, dresp);
-		float See = WSeq<K>::inner_prod(e2, e2);
+		float Sff, Dbf, See;
+		WSeq<K>::inner_prod3(e1, e1, dresp, dresp, e2, e2, Sff, Dbf, See);
+		Dbf = 10 + Dbf;
 
 		// ---- two-path control
 		sc.Davg1 = .6f * sc.Davg1 + .4f * (Sff - See);
@@ -679,24 +665,12 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			float d[K], tout[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) d[k] = input[k] - efg[k];
-			float memE = sc.memE;
-#pragma unroll 2
-			for (int l = 0; l < 64; ++l) {
-#pragma unroll
-				for (int k = 0; k < K; ++k) {
-					float t = rdlane(d[k], l);
-					t = t + .9f * memE;
-					memE = t;
-					if (lane == l) tout[k] = t;
-				}
-			}
-			sc.memE = memE;
+			w_deemphasis<K>(d, sc.memE, tout);
 #pragma unroll
 			for (int k = 0; k < K; ++k) out_i[k] = word2int(tout[k]);
 		}
-		const float Sey = WSeq<K>::inner_prod(e2, ybg);
-		const float Syy = WSeq<K>::inner_prod(ybg, ybg);
-		const float Sdd = WSeq<K>::inner_prod(input, input);
+		float Sey, Syy, Sdd;
+		WSeq<K>::inner_prod3(e2, ybg, ybg, ybg, input, input, Sey, Syy, Sdd);
 		if (any_sat && sc.saturated == 0) sc.saturated = 1;
 
 		// ---- error / response spectra
@@ -835,8 +809,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		float Pey = 1.0f, Pyy = 1.0f;
 		Pey = Pey + Ehd_F * Yhd_F;
 		Pyy = Pyy + Yhd_F * Yhd_F;
-		Pey = WSeq<K>::dot_desc(Pey, Ehd, Yhd);
-		Pyy = WSeq<K>::dot_desc(Pyy, Yhd, Yhd);
+		WSeq<K>::dot_desc2(Pey, Ehd, Yhd, Pyy, Yhd, Yhd, Pey, Pyy);
 		Pyy = sqrt_via_double(Pyy);
 		Pey = Pey / Pyy;
 		float tmp32 = a.beta0 * Syy;
