@@ -339,9 +339,10 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
     out = torch.zeros((nfull, 2 * F), dtype=torch.int16, device="cuda")
     two = torch.full((nfull,), 2, dtype=torch.uint8, device="cuda")
     one = torch.full((nfull,), 1, dtype=torch.uint8, device="cuda")
+    flags = ms.MI_AEC_POSTFILTER if os.environ.get("AEC_PROBE_POST", "1") != "0" else 0  # dev probes only (scripts/aec_phase_probe.sh)
 
     def launch(i):
-        aec.process_frames(mics[i % 4], refs[i % 4], out, one if i % 8 == 7 else two, max_frames=2)
+        aec.process_frames(mics[i % 4], refs[i % 4], out, one if i % 8 == 7 else two, max_frames=2, flags=flags)
 
     # per 256-sample frame mic+ref+out 1536 B, W read+write 2x49152, foreground 49152, X history read 51200,
     # newest X block 2048 = 202 240 B; a launch (tick) carries 15/8 frames per leg on average

@@ -165,6 +165,9 @@ __device__ __forceinline__ void bstore_vec(rsrc_t r, unsigned voff, unsigned sof
 
 template <int K>
 __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K], const float2 (&w)[K], int e0) {
+#ifdef AEC_PROF_NO_STREAM_MATH
+	return;
+#endif
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
 		if (e0 + k == 0) { // bin 0 holds (DC, Nyquist): two real products
@@ -437,6 +440,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		if (!do_grad) sc.saturated--;
 
 		auto grad = [&](float2 (&w)[K], const float2 (&x)[K], float prop) {
+#ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: the streaming pass without its arithmetic */
+			return;
+#endif
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
 				if (e0 + k == 0) {

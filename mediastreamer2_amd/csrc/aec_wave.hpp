@@ -97,6 +97,9 @@ __device__ void w_cfft(LT &L, const AecTables &T, const float2 *src, bool invers
 // L.tbuf (2F time samples) -> this lane's K bins, scaled 1/N.  Bin 0 = (DC, Nyquist).
 template <int F, bool GT = false, typename LT>
 __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64]) {
+#ifdef AEC_PROF_NO_FFT /* dev profiling only (scripts/aec_phase_probe.sh): instruction counts without the transforms */
+	return;
+#endif
 	constexpr int K = F / 64;
 	const int lane = threadIdx.x;
 	WSYNC();
@@ -130,6 +133,9 @@ __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64])
 // this lane's K bins -> L.tbuf (2F time samples), unscaled
 template <int F, bool GT = false, typename LT>
 __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F / 64]) {
+#ifdef AEC_PROF_NO_FFT /* dev profiling only (scripts/aec_phase_probe.sh): instruction counts without the transforms */
+	return;
+#endif
 	constexpr int K = F / 64;
 	const int lane = threadIdx.x;
 	WSYNC();
