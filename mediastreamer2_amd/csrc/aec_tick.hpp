@@ -419,20 +419,17 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 
 		// ---- proportional step
 		if (sc.adapted) {
+			// mdf_adjust_prop, one block per lane: prop = sqrt(1 + |W_j|^2); the maximum is exact in any order; the sum
+			// 1 + prop_0 + prop_1 + .. is the library's serial loop, run as a systolic chain over the first M lanes
 			WSYNC();
-			if (lane == 0) {
-				float max_sum = 1, prop_sum = 1;
-				for (int i = 0; i < M; ++i) {
-					const float p = sqrt_via_double(1.0f + L.wnorm[i]);
-					L.prop[i] = p;
-					if (p > max_sum) max_sum = p;
-				}
-				for (int i = 0; i < M; ++i) {
-					L.prop[i] += .1f * max_sum;
-					prop_sum += L.prop[i];
-				}
-				for (int i = 0; i < M; ++i) L.prop[i] = (.99f * L.prop[i]) / prop_sum;
-			}
+			float p = sqrt_via_double(1.0f + (lane < M ? L.wnorm[lane] : 0.f));
+			const float max_sum = wave_tree(lane < M ? p : 1.f, [](float x, float y) { return y > x ? y : x; });
+			p = p + .1f * max_sum;
+			float run = 1.f;
+			for (int i = 0; i < M; ++i) run = dpp_shr1(1.f, run) + p;
+			const float prop_sum = rdlane(run, M - 1);
+			WSYNC();
+			if (lane < M) L.prop[lane] = (.99f * p) / prop_sum;
 			prop_dirty = true;
 		}
 		WSYNC();
@@ -476,7 +473,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			float nn = 0;
 #pragma unroll
 			for (int k = 0; k < K; ++k) nn += w[k].x * w[k].x + w[k].y * w[k].y;
-			for (int o = 32; o > 0; o >>= 1) nn += __shfl_down(nn, o);
+			nn = wave_tree(nn, [](float x, float y) { return x + y; });
 			if (lane == 0) L.wnorm[j] = nn; // feeds the NEXT frame's proportional step
 		};
 #if AEC_TICK_PRIO

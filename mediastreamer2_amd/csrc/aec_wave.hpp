@@ -197,6 +197,7 @@ __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F /
 // steps only recompute the same value: 64 steps leave the result in lane 63 (lane 0 descending) -- bit for bit the
 // sequential loop, at one VALU instruction per operation instead of v_readlane + operation (2.5x faster measured,
 // scripts/micro/dpp_chain.hip).  Independent chains are stepped in one loop so that each fills the other's DPP latency.
+typedef float v2f __attribute__((ext_vector_type(2))); // a register pair for v_pk_*_f32
 __device__ __forceinline__ float dpp_shr1_zero(float v) { // lane l <- lane l-1, lane 0 <- 0.0f
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
@@ -205,6 +206,22 @@ __device__ __forceinline__ float dpp_shr1(float first, float v) { // lane l <- l
 }
 __device__ __forceinline__ float dpp_shl1(float last, float v) { // lane l <- lane l+1, lane 63 <- last
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+// Sum / maximum over the 64 lanes in a fixed butterfly order, in registers: four DPP exchanges inside the rows of 16
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then row_bcast:15 and row_bcast:31 -- no LDS, no index arithmetic.
+// For values whose summation order the library does not fix (a tree either way).  The result is in every lane (readlane 63).
+template <typename Op>
+__device__ __forceinline__ float wave_tree(float v, Op op) {
+	auto dpp = [](float x, auto ctrl) {
+		return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+	};
+	v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));  // quad_perm [1,0,3,2]
+	v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));  // quad_perm [2,3,0,1]
+	v = op(v, dpp(v, std::integral_constant<int, 0x141>{})); // row_half_mirror
+	v = op(v, dpp(v, std::integral_constant<int, 0x140>{})); // row_mirror: every lane of a row holds the row's result
+	const float r0 = rdlane(v, 0), r1 = rdlane(v, 16), r2 = rdlane(v, 32), r3 = rdlane(v, 48);
+	return op(op(r0, r1), op(r2, r3));
 }
 
 template <int K>
@@ -271,11 +288,11 @@ struct WSeq {
 		for (int k = 0; k < K; ++k) p0[k] = a0[k] * b0[k], p1[k] = a1[k] * b1[k];
 		float s0 = init0, s1 = init1;
 #pragma unroll 4
-		for (int l = 0; l < 64; ++l) {
-			float t0 = dpp_shl1(init0, s0), t1 = dpp_shl1(init1, s1);
+		for (int l = 0; l < 64; ++l) { // the two chains ride in one register pair: K packed additions per step
+			v2f t = {dpp_shl1(init0, s0), dpp_shl1(init1, s1)};
 #pragma unroll
-			for (int k = K - 1; k >= 0; --k) t0 = t0 + p0[k], t1 = t1 + p1[k];
-			s0 = t0, s1 = t1;
+			for (int k = K - 1; k >= 0; --k) t = t + (v2f){p0[k], p1[k]};
+			s0 = t.x, s1 = t.y;
 		}
 		r0 = rdlane(s0, 0), r1 = rdlane(s1, 0);
 	}
@@ -283,20 +300,39 @@ struct WSeq {
 
 // filter_dc_notch16 of the library: vout = m0 + vin; m0 = m1 + 2 (-vin + radius vout); m1 = vin - den2 vout; out = radius vout,
 // sample after sample.  (m0, m1) come in as the state before the frame and go out as the state after it (all lanes alike).
+// One sample of the notch in four instructions: add, packed multiply, packed add with source modifiers, fma.
+//   tu = (radius vout, den2 vout);  am = (tu.x + (-vin), (-tu.y) + vin) = (-vin + radius vout, vin - den2 vout) bit for bit;
+//   m0' = fma(2, am.x, m1) = m1 + 2 am.x bit for bit (2 x is exact).  HI selects the half of `pair` that holds vin.
+template <bool HI>
+__device__ __forceinline__ void notch_sample(v2f rc, v2f pair, float vin, float &a0, float &a1, float &out) {
+	v2f vo, tu, am;
+	vo.x = a0 + vin;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(tu) : "v"(rc), "v"(vo));
+	if constexpr (HI) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(am) : "v"(tu), "v"(pair));
+	else asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(am) : "v"(tu), "v"(pair));
+	a0 = __builtin_fmaf(2.f, am.x, a1);
+	a1 = am.y;
+	out = tu.x;
+}
 template <int K>
 __device__ __forceinline__ void w_dc_notch(const float (&in)[K], float radius, float den2, float &m0io, float &m1io, float (&out)[K]) {
 	const float i0 = m0io, i1 = m1io;
 	float m0 = i0, m1 = i1;
+	const v2f rc = {radius, den2};
+	constexpr int NP = (K + 1) / 2;
+	v2f pr[NP];
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		if (k & 1) pr[k / 2].y = in[k];
+		else pr[k / 2].x = in[k];
+	}
 #pragma unroll 2
 	for (int l = 0; l < 64; ++l) {
 		float a0 = dpp_shr1(i0, m0), a1 = dpp_shr1(i1, m1);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
-			const float vin = in[k];
-			const float vout = a0 + vin;
-			a0 = a1 + 2 * (-vin + radius * vout);
-			a1 = vin - den2 * vout;
-			out[k] = radius * vout;
+			if (k & 1) notch_sample<true>(rc, pr[k / 2], in[k], a0, a1, out[k]);
+			else notch_sample<false>(rc, pr[k / 2], in[k], a0, a1, out[k]);
 		}
 		m0 = a0, m1 = a1;
 	}
