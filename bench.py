@@ -951,15 +951,16 @@ def main():
         sys.exit(1)
 
     # ---- the timed region, at that leg count (stepped down if the deployed tick -- with the exchange at N > 1 -- is late)
-    for attempt in range(4):
+    for attempt in range(12):
         head = Headline(ms, torch, ctx, streams, world, rank, dist, local)
         head.prepare(a.warmup)
         worst, median_single = head.worst_tick()
         worst = reduce_scalar(worst, "MAX")
-        if worst < 10.0 or a.streams > 0 or streams <= 4096:
+        if worst < 10.0 or a.streams > 0 or streams <= 8192:
             break
         head.close()
-        streams -= 2048
+        streams -= 2048 * (1 + attempt // 2)  # 2048, 2048, 4096, 4096, ...: a late exchange must not end in "does not fit"
+        streams = max(streams, 8192)
     rig = head.rig
 
     def sync_local():

@@ -165,7 +165,7 @@ class CpuDouble(bench.HipPlatform):
 
         def exchange(d_sum):
             dist.all_reduce(d_sum)
-            Clock.now_ms += 0.02  # the exchange's share of the virtual tick
+            Clock.now_ms += float(os.environ.get("DOUBLE_EXCHANGE_MS", "0.02"))  # the exchange's share of the virtual tick
 
         return exchange
 

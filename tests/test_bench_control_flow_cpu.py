@@ -65,6 +65,19 @@ def test_two_ranks_agree_on_the_slower_ranks_capacity_and_exchange_every_tick():
     assert d["config"]["worst_tick_ms"] < 10.0
 
 
+def test_a_slow_exchange_steps_the_leg_count_down_until_the_deployed_tick_fits():
+    """The sweep measures the chain alone; the deployed tick carries the exchange too.  With 1.5 ms of exchange per tick
+    the sweep's 22 528 legs (9.4 ms) no longer fit: the run must come down (2048 at a time, then faster) and still report
+    a count that fits, not zero."""
+    r = run(2, {"DOUBLE_EXCHANGE_MS": "1.5"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = the_line(r)
+    per_rank = d["config"]["streams_per_gpu"]
+    assert d["config"]["fits"] and d["config"]["worst_tick_ms"] < 10.0
+    assert 16384 <= per_rank <= 20480 and d["value"] == 2 * per_rank
+    assert abs(d["config"]["worst_tick_ms"] - (per_rank / 2400.0 + 1.5)) < 0.05
+
+
 def test_a_wrong_partial_sum_fails_every_rank():
     r = run(2, {"DOUBLE_BREAK_RANK": "1"}, args=["--streams", "8192"])
     assert r.returncode != 0
