@@ -201,8 +201,8 @@ __global__ __launch_bounds__(64) void fft_debug_kernel(const float *in, float *o
 		load_bins<K>(reinterpret_cast<const float2 *>(src) + e0, r);
 		w_rfft_inverse<F>(L, t, r);
 		float lo[K], hi[K];
-		load_vec<K>(L.tbuf + e0, lo);
-		load_vec<K>(L.tbuf + F + e0, hi);
+		load_vec<K>(w_time(L) + e0, lo);
+		load_vec<K>(w_time(L) + F + e0, hi);
 		store_vec<K>(dst + e0, lo);
 		store_vec<K>(dst + F + e0, hi);
 	}

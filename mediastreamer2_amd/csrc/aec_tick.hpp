@@ -165,7 +165,8 @@ __device__ __forceinline__ void bstore_vec(rsrc_t r, unsigned voff, unsigned sof
 
 template <int K>
 __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K], const float2 (&w)[K], int e0) {
-#ifdef AEC_PROF_NO_STREAM_MATH
+#ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: one add per 16-byte load keeps the loads alive */
+	for (int k = 0; k < K; k += 2) acc[k].x += x[k].x + w[k].x;
 	return;
 #endif
 #pragma unroll
@@ -437,7 +438,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		if (!do_grad) sc.saturated--;
 
 		auto grad = [&](float2 (&w)[K], const float2 (&x)[K], float prop) {
-#ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: the streaming pass without its arithmetic */
+#ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: the streaming pass without its arithmetic (every load still consumed) */
+			for (int k = 0; k < K; k += 2) w[k].x += x[k].x * prop;
 			return;
 #endif
 #pragma unroll
@@ -463,8 +465,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			float z[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) z[k] = 0.f;
-			store_vec<K>(L.tbuf + F + e0, z);
-			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w);
+			store_vec<K>(w_time(L) + F + e0, z);
+			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w, w_time(L));
 		};
 		float2 yfg[K], ybgs[K];
 #pragma unroll
@@ -598,12 +600,12 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		// ---- time-domain responses
 		float efg[K], ybg[K], e1[K], e2[K], dresp[K], input[K];
 		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, yfg);
-		load_vec<K>(L.tbuf + F + e0, efg);
+		load_vec<K>(w_time(L) + F + e0, efg);
 		load_vec<K>(L.input + e0, input);
 #pragma unroll
 		for (int k = 0; k < K; ++k) e1[k] = input[k] - efg[k];
 		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, ybgs);
-		load_vec<K>(L.tbuf + F + e0, ybg);
+		load_vec<K>(w_time(L) + F + e0, ybg);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			e2[k] = input[k] - ybg[k];
@@ -1132,8 +1134,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		w_rfft_inverse<F>(L, a.t, ft);
 		{
 			float lo[K], hi[K];
-			load_vec<K>(L.tbuf + e0, lo);
-			load_vec<K>(L.tbuf + F + e0, hi);
+			load_vec<K>(w_time(L) + e0, lo);
+			load_vec<K>(w_time(L) + F + e0, hi);
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
 				op[k] = word2int(ob[k] + lo[k] * w0[k]);

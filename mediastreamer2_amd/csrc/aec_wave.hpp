@@ -27,6 +27,10 @@ struct alignas(16) WLds {
 
 #define WSYNC() __syncthreads() /* one wave per workgroup: an LDS fence, no cross-wave wait */
 
+// where w_rfft_inverse leaves its 2F time samples (re, im interleaved = consecutive samples): no copy into L.tbuf
+template <typename LT>
+__device__ __forceinline__ float *w_time(LT &L) { return reinterpret_cast<float *>(L.zbuf); }
+
 // GT = true: twiddles / super-twiddles / digit permutation are read from the device-wide tables in global memory (L1 / L2
 // resident: 4.5 KB shared by every wave) instead of a per-wave LDS copy -- frees that much LDS per wave.
 template <int F, bool GT = false, typename LT>
@@ -39,12 +43,48 @@ __device__ void w_cfft(LT &L, const AecTables &T, const float2 *src, bool invers
 		if constexpr (GT) val[k] = src[T.perm[lane * K + k]];
 		else val[k] = src[L.perm[lane * K + k]];
 	}
+	// The deepest stage (m = 1) of lane i works on elements i p .. i p + p - 1: with K = p those are the K values the lane has
+	// just gathered, so the stage runs in registers (same expressions, twiddle tw[0]) and one LDS round trip is gone.
+	constexpr bool kRegStage0 = (K == plan_p(F, 0));
+	if constexpr (kRegStage0) {
+		float2 w0;
+		if constexpr (GT) w0 = T.tw[0];
+		else w0 = L.tw[0];
+		if (inverse) w0.y = -w0.y;
+		if constexpr (K == 2) {
+			const float2 t = cmulf(val[1], w0);
+			const float2 a = val[0];
+			val[1] = make_float2(a.x - t.x, a.y - t.y);
+			val[0] = make_float2(a.x + t.x, a.y + t.y);
+		} else {
+			const float2 s0 = cmulf(val[1], w0);
+			const float2 s1 = cmulf(val[2], w0);
+			const float2 s2 = cmulf(val[3], w0);
+			float2 f0 = val[0];
+			const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
+			f0.x += s1.x;
+			f0.y += s1.y;
+			const float2 s3 = make_float2(s0.x + s2.x, s0.y + s2.y);
+			const float2 s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
+			val[2] = make_float2(f0.x - s3.x, f0.y - s3.y);
+			f0.x += s3.x;
+			f0.y += s3.y;
+			val[0] = f0;
+			if (inverse) {
+				val[1] = make_float2(s5.x - s4.y, s5.y + s4.x);
+				val[3] = make_float2(s5.x + s4.y, s5.y - s4.x);
+			} else {
+				val[1] = make_float2(s5.x + s4.y, s5.y - s4.x);
+				val[3] = make_float2(s5.x - s4.y, s5.y + s4.x);
+			}
+		}
+	}
 	WSYNC();
 #pragma unroll
 	for (int k = 0; k < K; ++k) L.zbuf[lane * K + k] = val[k];
 	WSYNC();
 #pragma unroll
-	for (int s = 0; s < plan_n(F); ++s) {
+	for (int s = kRegStage0 ? 1 : 0; s < plan_n(F); ++s) {
 		constexpr int FF = F;
 		const int p = plan_p(FF, s), m = plan_m(FF, s), fs = plan_fs(FF, s);
 		if (lane < F / p) {
@@ -95,15 +135,21 @@ __device__ void w_cfft(LT &L, const AecTables &T, const float2 *src, bool invers
 }
 
 // L.tbuf (2F time samples) -> this lane's K bins, scaled 1/N.  Bin 0 = (DC, Nyquist).
+// src: the 2F time samples -- L.tbuf (the default) or L.zbuf, where the inverse transform leaves its result
 template <int F, bool GT = false, typename LT>
-__device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64]) {
-#ifdef AEC_PROF_NO_FFT /* dev profiling only (scripts/aec_phase_probe.sh): instruction counts without the transforms */
+__device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64], const float *src = nullptr) {
+	if (src == nullptr) src = L.tbuf;
+#ifdef AEC_PROF_NO_FFT /* dev profiling only (scripts/aec_phase_probe.sh): the kernel without the transforms' work -- the
+                          data still flows (every value defined, nothing downstream becomes dead code), the results are wrong */
+	WSYNC();
+	for (int k = 0; k < F / 64; ++k) out[k] = make_float2(src[threadIdx.x * (F / 64) + k], src[F + threadIdx.x * (F / 64) + k]);
+	WSYNC();
 	return;
 #endif
 	constexpr int K = F / 64;
 	const int lane = threadIdx.x;
 	WSYNC();
-	w_cfft<F, GT>(L, T, reinterpret_cast<const float2 *>(L.tbuf), false);
+	w_cfft<F, GT>(L, T, reinterpret_cast<const float2 *>(src), false);
 	const float scale = 1.f / (2 * F);
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
@@ -130,10 +176,13 @@ __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64])
 	WSYNC();
 }
 
-// this lane's K bins -> L.tbuf (2F time samples), unscaled
+// this lane's K bins -> 2F time samples in w_time(L), unscaled
 template <int F, bool GT = false, typename LT>
 __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F / 64]) {
-#ifdef AEC_PROF_NO_FFT /* dev profiling only (scripts/aec_phase_probe.sh): instruction counts without the transforms */
+#ifdef AEC_PROF_NO_FFT
+	WSYNC();
+	for (int k = 0; k < F / 64; ++k) w_time(L)[threadIdx.x * (F / 64) + k] = in[k].x, w_time(L)[F + threadIdx.x * (F / 64) + k] = in[k].y;
+	WSYNC();
 	return;
 #endif
 	constexpr int K = F / 64;
@@ -177,18 +226,9 @@ __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F /
 #pragma unroll
 	for (int k = 0; k < K; ++k) tmp[lane * K + k] = t[k];
 	WSYNC();
-	w_cfft<F, GT>(L, T, tmp, true);
-	float2 r[K];
-#pragma unroll
-	for (int k = 0; k < K; ++k) r[k] = L.zbuf[lane * K + k];
-	WSYNC();
-#pragma unroll
-	for (int k = 0; k < K; ++k) {
-		L.tbuf[2 * (lane * K + k)] = r[k].x;
-		L.tbuf[2 * (lane * K + k) + 1] = r[k].y;
-	}
-	WSYNC();
+	w_cfft<F, GT>(L, T, tmp, true); // ends with an LDS fence: the 2F time samples are in L.zbuf (see w_time)
 }
+
 
 // ---- the library's SERIAL loops over a frame (sums in C loop order, the DC notch and de-emphasis recurrences), element
 // index = lane * K + k.  Each is a chain of dependent float operations across the 64 lanes.  It runs SYSTOLICALLY: in every
