@@ -94,8 +94,31 @@ struct AecArgs {
 	AecTables t;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2))); // a register pair for v_pk_*_f32
+
+// Complex arithmetic on register pairs, three packed instructions per product.  The halves a packed instruction reads and
+// the signs it applies are operand modifiers (op_sel / op_sel_hi / neg_lo / neg_hi), so the scalar form's four products,
+// their rounding and the order of the two additions are kept exactly:
+//   p = (a.x b.x, a.y b.x)   q = (a.y b.y, a.x b.y)   a b = (p.x - q.x, p.y + q.y)
+// (left to itself the compiler forms both p + q and p - q and moves one half over: five instructions and a wait state)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b) {
+	v2f p, q, r;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));
+	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));
+	return r;
+}
+// conj(a) b = (a.x b.x + a.y b.y, (-a.y) b.x + a.x b.y)
+__device__ __forceinline__ v2f pk_cmul_conj(v2f a, v2f b) {
+	v2f p, q, r;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(q) : "v"(a), "v"(b));
+	asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
+	return r;
+}
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+	const v2f r = pk_cmul((v2f){a.x, a.y}, (v2f){b.x, b.y}); // (a.x b.x - a.y b.y, a.y b.x + a.x b.y)
+	return make_float2(r.x, r.y);
 }
 
 // kiss_fft factorisation (4s first, then 2), stages listed deepest first:

@@ -163,6 +163,7 @@ __device__ __forceinline__ void bstore_vec(rsrc_t r, unsigned voff, unsigned sof
 	}
 }
 
+// acc += x w, bin by bin; bin 0 (lane 0's first) holds (DC, Nyquist): two real products there
 template <int K>
 __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K], const float2 (&w)[K], int e0) {
 #ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: one add per 16-byte load keeps the loads alive */
@@ -171,13 +172,14 @@ __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K]
 #endif
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
-		if (e0 + k == 0) { // bin 0 holds (DC, Nyquist): two real products
-			acc[k].x += x[k].x * w[k].x;
-			acc[k].y += x[k].y * w[k].y;
-		} else {
-			acc[k].x += (x[k].x * w[k].x - x[k].y * w[k].y);
-			acc[k].y += (x[k].y * w[k].x + x[k].x * w[k].y);
+		const v2f xv = {x[k].x, x[k].y}, wv = {w[k].x, w[k].y};
+		v2f pr = pk_cmul(xv, wv); // (x.x w.x - x.y w.y, x.y w.x + x.x w.y)
+		if (k == 0) {
+			const v2f dc = xv * wv; // (x.x w.x, x.y w.y)
+			if (e0 == 0) pr = dc;
 		}
+		const v2f a = (v2f){acc[k].x, acc[k].y} + pr;
+		acc[k] = make_float2(a.x, a.y);
 	}
 }
 
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		const bool do_grad = (sc.saturated == 0);
 		if (!do_grad) sc.saturated--;
 
+		// W += prop p1 conj(X) E, bin by bin (weighted_spectral_mul_conj); bin 0 = (DC, Nyquist): real products with their own steps
 		auto grad = [&](float2 (&w)[K], const float2 (&x)[K], float prop) {
 #ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: the streaming pass without its arithmetic (every load still consumed) */
 			for (int k = 0; k < K; k += 2) w[k].x += x[k].x * prop;
@@ -444,15 +447,15 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 #endif
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
-				if (e0 + k == 0) {
-					const float W0 = prop * p1[k], WN = prop * p1_F;
-					w[k].x += W0 * (x[k].x * Eprev[k].x);
-					w[k].y += WN * (x[k].y * Eprev[k].y);
-				} else {
-					const float Wt = prop * p1[k];
-					w[k].x += Wt * ((x[k].x * Eprev[k].x) + x[k].y * Eprev[k].y);
-					w[k].y += Wt * (((-x[k].y) * Eprev[k].x) + x[k].x * Eprev[k].y);
+				const v2f xv = {x[k].x, x[k].y}, ev = {Eprev[k].x, Eprev[k].y};
+				const float Wt = prop * p1[k];
+				v2f st = pk_cmul_conj(xv, ev) * (v2f){Wt, Wt}; // Wt (x.x E.x + x.y E.y), Wt ((-x.y) E.x + x.x E.y)
+				if (k == 0) {
+					const v2f dc = (xv * ev) * (v2f){Wt, prop * p1_F}; // W0 (x.x E.x), WN (x.y E.y)
+					if (e0 == 0) st = dc;
 				}
+				const v2f r = (v2f){w[k].x, w[k].y} + st;
+				w[k] = make_float2(r.x, r.y);
 			}
 		};
 

@@ -237,7 +237,6 @@ __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F /
 // steps only recompute the same value: 64 steps leave the result in lane 63 (lane 0 descending) -- bit for bit the
 // sequential loop, at one VALU instruction per operation instead of v_readlane + operation (2.5x faster measured,
 // scripts/micro/dpp_chain.hip).  Independent chains are stepped in one loop so that each fills the other's DPP latency.
-typedef float v2f __attribute__((ext_vector_type(2))); // a register pair for v_pk_*_f32
 __device__ __forceinline__ float dpp_shr1_zero(float v) { // lane l <- lane l-1, lane 0 <- 0.0f
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
