@@ -165,12 +165,18 @@ __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64],
 			float2 sw;
 			if constexpr (GT) sw = T.super[kk];
 			else sw = L.super[kk];
-			const float f2r = a.x - c.x, f2i = a.y + c.y;
-			const float f1r = a.x + c.x, f1i = a.y - c.y;
-			const float twr = f2r * sw.x - f2i * sw.y;
-			const float twi = f2i * sw.x + f2r * sw.y;
-			if (!upper) out[k] = make_float2((.5f * (f1r + twr)) * scale, (.5f * (f1i + twi)) * scale);
-			else out[k] = make_float2((.5f * (f1r - twr)) * scale, (.5f * (twi - f1i)) * scale);
+			// f1 = (a.x + c.x, a.y - c.y), f2 = (a.x - c.x, a.y + c.y), tw = f2 sw; lower bins (f1 + tw) / 2, upper bins
+			// (f1.x - tw.x, tw.y - f1.y) / 2: the upper form is the lower one with the signs of f1.y and tw.x flipped (exact)
+			const v2f av = {a.x, a.y}, cv = {c.x, c.y};
+			v2f f1, f2;
+			asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(f1) : "v"(av), "v"(cv));
+			asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(f2) : "v"(av), "v"(cv));
+			v2f tw = pk_cmul(f2, (v2f){sw.x, sw.y}); // (f2r sw.x - f2i sw.y, f2i sw.x + f2r sw.y)
+			const unsigned flip = upper ? 0x80000000u : 0u;
+			f1.y = __uint_as_float(__float_as_uint(f1.y) ^ flip);
+			tw.x = __uint_as_float(__float_as_uint(tw.x) ^ flip);
+			const v2f r = (((v2f){.5f, .5f}) * (f1 + tw)) * (v2f){scale, scale};
+			out[k] = make_float2(r.x, r.y);
 		}
 	}
 	WSYNC();
@@ -204,22 +210,27 @@ __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F /
 		} else {
 			const bool upper = i >= F - i;
 			const int kk = upper ? F - i : i;
-			const float2 fk = make_float2(L.spec[2 * kk], L.spec[2 * kk + 1]);
-			const float2 fnkc = make_float2(L.spec[2 * (F - kk)], -L.spec[2 * (F - kk) + 1]);
+			// fnkc = conj(spec[F - kk]); fek = fk + fnkc; d = fk - fnkc; fok = d conj(sw); lower bins fek + fok, upper bins
+			// conj(fek - fok) -- the conjugations are operand signs, the upper form is the lower one with fok negated and the
+			// imaginary part of the result negated (sign flips: exact)
+			const v2f fk = {L.spec[2 * kk], L.spec[2 * kk + 1]};
+			const v2f s2 = {L.spec[2 * (F - kk)], L.spec[2 * (F - kk) + 1]};
 			float2 sw;
 			if constexpr (GT) sw = T.super[kk];
 			else sw = L.super[kk];
-			sw.y = -sw.y;
-			const float2 fek = make_float2(fk.x + fnkc.x, fk.y + fnkc.y);
-			const float2 d = make_float2(fk.x - fnkc.x, fk.y - fnkc.y);
-			const float2 fok = cmulf(d, sw);
-			if (!upper) {
-				t[k] = make_float2(fek.x + fok.x, fek.y + fok.y);
-			} else {
-				float2 c = make_float2(fek.x - fok.x, fek.y - fok.y);
-				c.y *= -1;
-				t[k] = c;
-			}
+			const v2f sv = {sw.x, sw.y};
+			v2f fek, d, p, q, fok;
+			asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(fek) : "v"(fk), "v"(s2)); // (fk.x + s2.x, fk.y - s2.y)
+			asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(fk), "v"(s2));   // (fk.x - s2.x, fk.y + s2.y)
+			asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(d), "v"(sv));                                            // (d.x sw.x, d.y sw.x)
+			asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(q) : "v"(d), "v"(sv)); // (d.y (-sw.y), d.x (-sw.y))
+			asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(fok) : "v"(p), "v"(q));
+			const unsigned flip = upper ? 0x80000000u : 0u;
+			fok.x = __uint_as_float(__float_as_uint(fok.x) ^ flip);
+			fok.y = __uint_as_float(__float_as_uint(fok.y) ^ flip);
+			v2f r = fek + fok;
+			r.y = __uint_as_float(__float_as_uint(r.y) ^ flip);
+			t[k] = make_float2(r.x, r.y);
 		}
 	}
 	WSYNC();
