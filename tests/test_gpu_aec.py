@@ -112,11 +112,13 @@ def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
 @pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(48000, 256, 128, False), (48000, 256, 128, True),
                                                       (16000, 128, 128, True), (16000, 128, 250, False),
                                                       (8000, 64, 250, True), (8000, 64, 128, False),
-                                                      (16000, 128, 8, False)])   # M = 1: tail no longer than a frame
+                                                      (16000, 128, 8, False),    # M = 1: tail no longer than a frame
+                                                      (16000, 128, 512, True)])  # M = 64: the proportional step's chain over all 64 lanes
 def test_aec_two_seconds_within_tolerance(ctx, oracle, rate, F, tail_ms, postfilter):
-    """2 s from zero state (BASELINE config 3 geometry at 48 kHz): RMS error <= 1e-4 of full scale,
+    """2 s from zero state (8 s for the 64-block filter) (BASELINE config 3 geometry at 48 kHz): RMS error <= 1e-4 of full scale,
     same adaptation decisions, and the canceller actually cancels (ERLE)."""
-    nframes = int(2.0 * rate / F)
+    secs = 2.0 if tail_ms < 512 else 8.0  # 64 blocks take four times as long to reach `adapted` (sum_adapt > M)
+    nframes = int(secs * rate / F)
     ns = 4
     aec, ecs, mic, far, got, ref = _run_pair(ctx, oracle, rate, F, tail_ms, ns, nframes, postfilter)
     need_adapted = rate > 8000  # the 64-sample frames of 8 kHz take longer than 2 s to reach `adapted` on this scene
