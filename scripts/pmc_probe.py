@@ -11,7 +11,7 @@ mk = {"resample": lambda: bench.make_resample_leg(ms, torch, ctx, n or 4096),
       "mixer": lambda: bench.make_mixer_leg(ms, torch, ctx, nconf=n or 128),
       "volume": lambda: bench.make_volume_leg(ms, torch, ctx, nstreams=n or 4096),
       "equalizer": lambda: bench.make_equalizer_leg(ms, torch, ctx),
-      "aec": lambda: bench.make_aec_leg(ms, torch, ctx), "scaler": lambda: bench.make_scaler_leg(ms, torch, ctx), "pixconv": lambda: bench.make_pixconv_leg(ms, torch, ctx),
+      "aec": lambda: bench.make_aec_leg(ms, torch, ctx, n or 4096), "scaler": lambda: bench.make_scaler_leg(ms, torch, ctx), "pixconv": lambda: bench.make_pixconv_leg(ms, torch, ctx),
       "g711dec": lambda: bench.make_g711_leg(ms, torch, ctx), "g711enc": lambda: bench.make_g711_leg(ms, torch, ctx, encode=True),
       "plc": lambda: bench.make_plc_leg(ms, torch, ctx)}
 lg = mk[which]()
