@@ -140,8 +140,11 @@ struct TickerHub {
 	bool in_flush = false;
 	std::vector<MSFilter *> touched, touched_pumps;
 	std::unordered_map<MSFilter *, uint64_t> pumped; // pump facades run early by the flush task, and for which tick
-	bool dead = false;                 // no banks left: removed from the registry, deleted by the last HubLock
-	int locks = 0;
+	bool dead = false;                 // no banks left: removed from the registry (read and written under `mu`)
+	// Scopes that hold or are about to take `mu`.  Taken under the registry lock (hub_for) or while a slot of the hub is
+	// held, so a hub found in the registry cannot be freed between the look-up and the lock; whoever drops the last
+	// reference of a dead hub deletes it.
+	std::atomic<int> refs{0};
 };
 
 mi_ctx *Pool::ctx() const { return hub->ctx; }
@@ -160,16 +163,17 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 	{
 		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
 		auto fi = g_filter_hubs.find(f);
-		if (fi != g_filter_hubs.end()) return fi->second.hub;
+		if (fi != g_filter_hubs.end()) return fi->second.hub->refs.fetch_add(1), fi->second.hub;
 		auto hi = g_hubs.find(f ? f->ticker : nullptr);
-		if (hi != g_hubs.end()) return hi->second;
+		if (hi != g_hubs.end()) return hi->second->refs.fetch_add(1), hi->second;
 	}
 	if (!create) return nullptr;
 	std::unique_lock<std::shared_mutex> wl(g_registry_mu);
 	MSTicker *t = f ? f->ticker : nullptr;
 	auto hi = g_hubs.find(t);
-	if (hi != g_hubs.end()) return hi->second;
+	if (hi != g_hubs.end()) return hi->second->refs.fetch_add(1), hi->second;
 	TickerHub *h = new TickerHub();
+	h->refs.fetch_add(1);
 	h->ticker = t;
 	if (mi_ctx_create(g_device, nullptr, &h->ctx) != MI_OK) {
 		mi_failed("mi_ctx_create");
@@ -183,30 +187,56 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 // current hub.  process() / preprocess() / the flush task run on the ticker thread; methods and uninit on any thread.
 struct HubLock {
 	TickerHub *h, *prev;
-	explicit HubLock(MSFilter *f) : h(hub_for(f, true)), prev(tl_hub) {
-		h->mu.lock();
-		++h->locks;
+	static void unref(TickerHub *hub, bool dead) { // `dead` as seen under the hub's lock
+		if (hub->refs.fetch_sub(1) == 1 && dead) {
+			if (hub->ctx) mi_ctx_destroy(hub->ctx);
+			delete hub;
+		}
+	}
+	explicit HubLock(MSFilter *f) : h(nullptr), prev(tl_hub) {
+		for (;;) { // hub_for hands the hub over with a reference taken under the registry lock
+			h = hub_for(f, true);
+			h->mu.lock();
+			if (!h->dead) break;
+			// its last bank went between the look-up and the lock: it is out of the registry, look again (a new hub)
+			h->mu.unlock();
+			unref(h, true);
+		}
 		tl_hub = h;
 	}
-	// hot path: a filter that holds a slot knows its hub through the bank -- no registry lookup
-	HubLock(MSFilter *f, Pool *p) : h(p ? p->hub : hub_for(f, true)), prev(tl_hub) {
-		h->mu.lock();
-		++h->locks;
+	// hot path: a filter that holds a slot knows its hub through the bank -- no registry lookup (and the slot keeps the hub alive)
+	HubLock(MSFilter *f, Pool *p) : h(nullptr), prev(tl_hub) {
+		if (p) {
+			h = p->hub;
+			h->refs.fetch_add(1);
+			h->mu.lock();
+		} else {
+			for (;;) {
+				h = hub_for(f, true);
+				h->mu.lock();
+				if (!h->dead) break;
+				h->mu.unlock();
+				unref(h, true);
+			}
+		}
 		tl_hub = h;
 	}
-	explicit HubLock(TickerHub *hub) : h(hub), prev(tl_hub) {
+	explicit HubLock(TickerHub *hub) : h(hub), prev(tl_hub) { // the caller holds a slot of `hub`: it cannot go away
+		h->refs.fetch_add(1);
 		h->mu.lock();
-		++h->locks;
 		tl_hub = h;
 	}
+	struct Adopt {};
+	HubLock(TickerHub *hub, Adopt) : h(hub), prev(tl_hub) { // the reference was taken under the registry lock (hub_for, referenced_hubs)
+		h->mu.lock();
+		tl_hub = h;
+	}
+	bool dead() const { return h->dead; } // the hub's last bank went before this scope got the lock: nothing to do on it
 	~HubLock() {
 		tl_hub = prev;
-		const bool last = --h->locks == 0 && h->dead;
+		const bool dead = h->dead;
 		h->mu.unlock();
-		if (last) {
-			if (h->ctx) mi_ctx_destroy(h->ctx);
-			delete h;
-		}
+		unref(h, dead);
 	}
 	HubLock(const HubLock &) = delete;
 	HubLock &operator=(const HubLock &) = delete;
@@ -384,7 +414,8 @@ void request_flush(MSFilter *f) {
 void facade_detached(MSFilter *f) {
 	TickerHub *h = hub_for(f, false);
 	if (!h) return;
-	HubLock lk(h);
+	HubLock lk(h, HubLock::Adopt{});
+	if (lk.dead()) return;
 	if (h->flush_owner == f) h->flush_owner = nullptr;
 	h->pumped.erase(f);
 }
@@ -504,15 +535,22 @@ void libmsmi355xfilters_init(MSFactory *factory) {
 	ms_message("libmsmi355xfilters: MI355X batched filters registered (ABI %d)", mi_abi_version());
 }
 
+// every hub in the registry, each with a reference taken under the registry lock (to be adopted by a HubLock)
+static std::vector<TickerHub *> referenced_hubs() {
+	std::vector<TickerHub *> hubs;
+	std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+	for (auto &kv : g_hubs) {
+		kv.second->refs.fetch_add(1);
+		hubs.push_back(kv.second);
+	}
+	return hubs;
+}
+
 // every hub's staged work, now (tests; an application that wants the last tick's results before tearing a graph down)
 void ms_mi355x_flush(void) {
-	std::vector<TickerHub *> hubs;
-	{
-		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
-		for (auto &kv : g_hubs) hubs.push_back(kv.second);
-	}
-	for (TickerHub *h : hubs) {
-		HubLock lk(h);
+	for (TickerHub *h : referenced_hubs()) {
+		HubLock lk(h, HubLock::Adopt{});
+		if (lk.dead()) continue;
 		h->flush_owner = nullptr;
 		flush_hub(*h);
 	}
@@ -523,13 +561,9 @@ unsigned long long ms_mi355x_late_events(void) { return (unsigned long long)g_la
 // hubs (tickers with live banks) and banks alive: what a leak check looks at
 void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use) {
 	int nh = 0, nb = 0, ns = 0;
-	std::vector<TickerHub *> all;
-	{
-		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
-		for (auto &kv : g_hubs) all.push_back(kv.second);
-	}
-	for (TickerHub *h : all) {
-		HubLock lk(h);
+	for (TickerHub *h : referenced_hubs()) {
+		HubLock lk(h, HubLock::Adopt{});
+		if (lk.dead()) continue;
 		++nh;
 		for (Pool *p : h->pools) ++nb, ns += p->in_use;
 	}
@@ -539,13 +573,9 @@ void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use) {
 }
 
 void ms_mi355x_shutdown(void) {
-	std::vector<TickerHub *> hubs;
-	{
-		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
-		for (auto &kv : g_hubs) hubs.push_back(kv.second);
-	}
-	for (TickerHub *h : hubs) {
-		HubLock lk(h);
+	for (TickerHub *h : referenced_hubs()) {
+		HubLock lk(h, HubLock::Adopt{});
+		if (lk.dead()) continue;
 		if (h->ctx) mi_ctx_sync(h->ctx);
 	}
 }

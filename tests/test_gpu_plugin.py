@@ -797,6 +797,64 @@ def test_banks_grow_and_are_freed_with_their_last_slot(host, oracle):
     assert late2 == late0
 
 
+def test_hubs_come_and_go_under_a_thread_that_walks_them(host):
+    """Three threads each run 'calls': a ticker of their own, a few MSVolume graphs, some ticks, everything destroyed --
+    the ticker's hub (lock, HIP stream, banks) dies with its last slot -- while the main thread keeps walking every hub
+    (ms_mi355x_runtime_stats, ms_mi355x_flush).  A hub found in the registry must stay valid until the walker has locked
+    and released it (reference taken under the registry lock), and a walker that gets a hub whose last bank has just gone
+    must leave it alone."""
+    import threading
+    S = host.S
+    P = C.CDLL(os.path.join(PKG, "libmsmi355xfilters.so"))
+    h0, b0, s0, late0 = _runtime_stats(host)
+    stop = threading.Event()
+    errors = []
+    x = synth_pcm(77, 160, rate=16000)
+
+    def calls(seed):
+        try:
+            for rep in range(12):
+                tk = S.ms_ticker_new()
+                chains = []
+                for i in range(3 + (seed + rep) % 3):
+                    v = host.create(MS_VOLUME_ID)
+                    host.call_int(v, SET_SAMPLE_RATE, 16000)
+                    src, snk = host.source(), host.sink()
+                    host.link(src, 0, v, 0)
+                    host.link(v, 0, snk, 0)
+                    S.ms_ticker_attach(tk, v)
+                    chains.append((src, v, snk))
+                for t in range(3):
+                    for src, _, _ in chains:
+                        S.ms2shim_source_push(src, x.ctypes.data, x.nbytes)
+                    S.ms_ticker_step(tk)
+                for src, v, snk in chains:
+                    S.ms_ticker_detach(tk, v)
+                for src, v, snk in chains:
+                    for f in (src, v, snk):
+                        S.ms_filter_destroy(f)
+                S.ms_ticker_destroy(tk)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=calls, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    walks = 0
+    while any(t.is_alive() for t in th):
+        hh, bb, ss = C.c_int(), C.c_int(), C.c_int()
+        P.ms_mi355x_runtime_stats(C.byref(hh), C.byref(bb), C.byref(ss))
+        assert hh.value >= 0 and bb.value >= 0 and ss.value >= 0
+        walks += 1
+    for t in th:
+        t.join()
+    stop.set()
+    assert not errors, errors
+    assert walks > 10
+    h2, b2, s2, late2 = _runtime_stats(host)
+    assert (h2, b2, s2) == (h0, b0, s0) and late2 == late0
+
+
 def test_a_chain_of_gpu_facades_costs_one_tick_in_total(host, oracle):
     """source -> MSResample 8k->16k -> MSVolume (gain 0.5) -> MSEqualizer (flat) -> sink: the flush task at the start of
     the next tick runs the resampler's bank, hands its output to the volume facade, runs that bank, and so on -- the
