@@ -83,6 +83,7 @@ struct AecArgs {
 	int tick_len, mic_tick_stride, ref_tick_stride;
 	const int32_t *ref_len; // nullable: per-stream length of the far-end block (0 .. tick_len)
 	uint8_t *count_out; // nullable: frames each stream ran
+	unsigned long long *prof; // dev builds with -DAEC_PROF_TIMING: [nstreams][16] shader-clock stamps per phase, else unused
 	int stride, nstreams, M, flags;
 	int first;             // first stream of this launch (a launch may cover a chunk of the batch)
 	float *X, *W, *FG;     // [nstreams][(M+1) or M][N]
@@ -192,6 +193,32 @@ __device__ __forceinline__ float band_sum(const AecTables &t, int b, const float
 	for (; i < l1; ++i) mel += pl[i];
 	return mel;
 }
+// Three spectra through the filterbank at once (the post-filter needs the echo estimate's, the frame's and the noise
+// estimate's band energies): each band's sum is a serial chain of up to ~180 additions fed by LDS reads -- latency, not
+// work -- so the three independent chains run interleaved in one loop and cost what one of them costs.  sp[j] = products
+// of spectrum j, left halves at [0, F), right halves at [F, 2F).  Same additions in the same order as band_sum.
+template <int F>
+__device__ __forceinline__ void band_sum3(const AecTables &t, int b, const float *s0, const float *s1, const float *s2, float &m0, float &m1,
+                                          float &m2) {
+	float a = 0, c = 0, d = 0;
+	const int r0 = t.brange[4 * b + 0], r1 = t.brange[4 * b + 1];
+	const int l0 = t.brange[4 * b + 2], l1 = t.brange[4 * b + 3];
+	auto range = [&](int off, int i, int e) {
+		for (; i + 4 <= e; i += 4) {
+			const float a0 = s0[off + i], a1 = s0[off + i + 1], a2 = s0[off + i + 2], a3 = s0[off + i + 3];
+			const float c0 = s1[off + i], c1 = s1[off + i + 1], c2 = s1[off + i + 2], c3 = s1[off + i + 3];
+			const float d0 = s2[off + i], d1 = s2[off + i + 1], d2 = s2[off + i + 2], d3 = s2[off + i + 3];
+			a += a0, c += c0, d += d0;
+			a += a1, c += c1, d += d1;
+			a += a2, c += c2, d += d2;
+			a += a3, c += c3, d += d3;
+		}
+		for (; i < e; ++i) a += s0[off + i], c += s1[off + i], d += s2[off + i];
+	};
+	range(F, r0, r1); // the bins this band is the RIGHT neighbour of come first (lower bins), then those it is the left one of
+	range(0, l0, l1);
+	m0 = a, m1 = c, m2 = d;
+}
 
 #include "aec_wave.hpp"
 #include "aec_tick.hpp"
@@ -244,6 +271,7 @@ struct mi_aec {
 	int small_stride = 0;
 	std::vector<float> h_prop0;
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
+	unsigned long long *d_prof = nullptr; // dev builds only (AEC_PROF_TIMING): per-stream phase stamps
 };
 
 namespace {
@@ -514,8 +542,25 @@ void mi_aec_destroy(mi_aec *a) {
 	if (a->d_small) (void)hipFree(a->d_small);
 	if (a->d_scal) (void)hipFree(a->d_scal);
 	if (a->d_tables) (void)hipFree(a->d_tables);
+	if (a->d_prof) (void)hipFree(a->d_prof);
 	delete a;
 }
+
+#ifdef AEC_PROF_TIMING
+// Dev builds only (not in the header): per-stream shader-clock stamps of the last launch, [nstreams][16] (aec_tick.hpp: PROF)
+extern "C" int mi_aec_debug_profile(mi_aec *a, unsigned long long *h_out) {
+	if (!a) return MI_EINVAL;
+	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
+	const size_t bytes = (size_t)a->nstreams * 16 * sizeof(unsigned long long);
+	if (!a->d_prof) {
+		if (hipMalloc((void **)&a->d_prof, bytes) != hipSuccess) return MI_ENOMEM;
+		(void)hipMemset(a->d_prof, 0, bytes);
+		return MI_OK; // first call arms the collection
+	}
+	(void)hipStreamSynchronize(a->ctx->stream);
+	return hipMemcpy(h_out, a->d_prof, bytes, hipMemcpyDeviceToHost) == hipSuccess ? MI_OK : MI_ENODEV;
+}
+#endif
 
 int mi_aec_reset(mi_aec *a, int first, int count) {
 	MI_CHECK_ARG(a && first >= 0 && count >= 0 && first + count <= a->nstreams);
@@ -558,6 +603,7 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.tick_len = g.mic_tick_stride = g.ref_tick_stride = 0;
 	g.count_out = nullptr;
 	g.ref_len = nullptr;
+	g.prof = a->d_prof;
 	if (fifo) {
 		g.ref_len = fifo->d_ref_len;
 		g.fmic = fifo_view(fifo->f_mic);

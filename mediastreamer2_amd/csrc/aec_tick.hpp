@@ -194,6 +194,24 @@ __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K]
 #endif
 
 // ===================================================================== MDF canceller, the frames of one tick
+#ifdef AEC_PROF_TIMING /* dev builds: shader-clock stamps at the phase boundaries, one row of 16 per stream (mi_aec_debug_profile) */
+#define PROF(i)                                                                                         \
+	do {                                                                                                \
+		if (a.prof && threadIdx.x == 0) a.prof[(size_t)(a.first + blockIdx.x) * 16 + (i)] = wall_clock64(); \
+	} while (0)
+#else
+#define PROF(i) ((void)0)
+#endif
+#if defined(AEC_PROF_TIMING) && defined(AEC_PROF_TAIL) /* the same slots, stamps inside the post-filter tail of the last frame */
+#undef PROF
+#define PROF(i) ((void)0)
+#define PROFT(i)                                                                                        \
+	do {                                                                                                \
+		if (a.prof && threadIdx.x == 0) a.prof[(size_t)(a.first + blockIdx.x) * 16 + (i)] = wall_clock64(); \
+	} while (0)
+#else
+#define PROFT(i) ((void)0)
+#endif
 template <int F>
 __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
@@ -289,6 +307,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		while (tail >= (unsigned)a.fout.cap) tail -= (unsigned)a.fout.cap;
 		return a.fout.ring + (size_t)s * a.fout.cap + tail + e0; // K samples never wrap
 	};
+	PROF(0); // FIFOs done
 	const int M = a.M;
 	float *sm = a.small + (size_t)s * a.small_stride;
 	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
@@ -373,7 +392,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	float leakf[2] = {sc.leak_estimate, sc.leak_estimate}; // leak estimate after each frame (post-filter input)
 	bool resetf[2] = {false, false};                       // the frame reset the canceller: its echo estimate is zero
 
+	PROF(1); // state loaded, far-end spectra of both frames ready
 	for (int f = 0; f < nf; ++f) {
+		PROF(2 + 5 * f); // frame start
 		// ---- near end: saturation flag, DC notch (serial IIR), pre-emphasis
 		int any_sat;
 		{
@@ -481,6 +502,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			nn = wave_tree(nn, [](float x, float y) { return x + y; });
 			if (lane == 0) L.wnorm[j] = nn; // feeds the NEXT frame's proportional step
 		};
+		PROF(3 + 5 * f); // notch, ring store, proportional step done: the pass starts
 #if AEC_TICK_PRIO
 		__builtin_amdgcn_s_setprio(AEC_TICK_PRIO);
 #endif
@@ -597,6 +619,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			pendingFG = false;
 		}
 
+		PROF(4 + 5 * f); // the pass is over
 #if AEC_TICK_PRIO
 		__builtin_amdgcn_s_setprio(0);
 #endif
@@ -667,6 +690,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 		}
 
+		PROF(5 + 5 * f); // responses, two-path control done
 		// ---- output (serial de-emphasis) and correlations
 		int out_i[K];
 		{
@@ -873,7 +897,9 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 #pragma unroll
 		for (int k = 0; k < K; ++k) X0[k] = X0B[k]; // the frame behind this one, if any
 		Sxx = SxxB;
+		PROF(6 + 5 * f); // frame end (spectra, power, adaptation)
 	}
+	PROF(12); // both frames done
 
 	// ---- the tick's state back to HBM, once
 	bstore_bins<K>(rS, vb8, SL::E * 4, Eprev);
@@ -916,6 +942,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	WSYNC(); // the parked arrays are re-used from here on
 
 	// per-bin state of the tick, in registers
+	PROFT(0);
 	float en[K], inb[K], S[K], Smin[K], Stmp[K], noise[K], old_ps[K], zeta[K], ob[K], wl[K], wr[K], h0[K], h1[K], w0[K], w1[K];
 	bload_vec<K>(rS, vb4, SL::ECHON * 4, en);
 	bload_vec<K>(rS, vb4, SL::INBUF * 4, inb);
@@ -942,6 +969,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	float *lvec = L.vec();
 
 	for (int f = 0; f < nf; ++f) {
+		PROFT(1); // tail frame start (the first frame's includes the wait for the state loads)
 		sc.nb_adapt++;
 		if (sc.nb_adapt > 20000) sc.nb_adapt = 20000;
 		sc.min_count++;
@@ -964,6 +992,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		}
 		float2 Yr[K];
 		w_rfft_forward<F>(L, a.t, Yr);
+		PROFT(2); // residual-echo transform done
 		const float leak2 = (leak > .5) ? 1.f : 2 * leak;
 		float res[K];
 #pragma unroll
@@ -995,20 +1024,21 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			store_vec<K>(L.tbuf + e0, a0);
 			store_vec<K>(L.tbuf + F + e0, a1);
 		}
-		WSYNC();
-		if (lane < NB_BANDS) bandv[lane] = band_sum<F>(a.t, lane, pl, pr);
+		PROFT(3);
+		PROFT(4);
 		float2 ft[K];
 		w_rfft_forward<F>(L, a.t, ft);
+		PROFT(5); // analysis transform
 		float ps[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			ps[k] = (e0 + k == 0) ? ft[k].x * ft[k].x : ft[k].x * ft[k].x + ft[k].y * ft[k].y;
 			lvec[e0 + k] = ps[k];
-			pl[e0 + k] = wl[k] * ps[k];
-			pr[e0 + k] = wr[k] * ps[k];
+			L.tbuf[e0 + k] = wl[k] * ps[k];     // the analysis transform is done with its input: the frame's filterbank
+			L.tbuf[F + e0 + k] = wr[k] * ps[k]; // products wait there (left halves, right halves) for the fused band sums
 		}
 		WSYNC();
-		if (lane < NB_BANDS) bandv[NB_BANDS + lane] = band_sum<F>(a.t, lane, pl, pr);
+		PROFT(6);
 		// update_noise_prob
 		int min_range;
 		if (sc.nb_adapt < 100) min_range = 15;
@@ -1035,15 +1065,20 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 		}
 		if (sc.min_count > min_range) sc.min_count = 0;
-		WSYNC();
+		{
+			float *np = w_time(L); // free between the analysis and the synthesis transform
 #pragma unroll
-		for (int k = 0; k < K; ++k) {
-			pl[e0 + k] = wl[k] * noise[k];
-			pr[e0 + k] = wr[k] * noise[k];
+			for (int k = 0; k < K; ++k) {
+				np[e0 + k] = wl[k] * noise[k];
+				np[F + e0 + k] = wr[k] * noise[k];
+			}
+			WSYNC();
+			PROFT(7); // noise update
+			// echo estimate (products in L.spec since the start of the frame), frame, noise: three band sums in one loop
+			if (lane < NB_BANDS) band_sum3<F>(a.t, lane, L.spec, L.tbuf, np, bandv[lane], bandv[NB_BANDS + lane], bandv[2 * NB_BANDS + lane]);
 		}
 		WSYNC();
-		if (lane < NB_BANDS) bandv[2 * NB_BANDS + lane] = band_sum<F>(a.t, lane, pl, pr);
-		WSYNC();
+		PROFT(8); // the three band sums
 
 		auto snr = [&](float psv, float noisev, float echov, float oldps, float &post, float &prior) {
 			const float tot_noise = 1.f + noisev + echov + 0.f;
@@ -1075,6 +1110,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			else zeta[k] = .7f * zeta[k] + .15f * prior[k] + .075f * lvec[b - 1] + .075f * lvec[b + 1];
 		}
 		if (lane < NB_BANDS) zeta_b = .7f * zeta_b + .3f * prior_b;
+		PROFT(9); // a-priori / a-posteriori SNR, zeta
 		float Zframe = 0;
 #pragma unroll
 		for (int i = 0; i < NB_BANDS; ++i) Zframe = Zframe + rdlane(zeta_b, i);
@@ -1099,6 +1135,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			bandv[2 * NB_BANDS + lane] = gfloor;
 		}
 		WSYNC();
+		PROFT(10); // band gains (exp, hypergeometric gain in double)
 		float gain2[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -1123,6 +1160,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			const float tmp = p * sqrt_via_double(gain) + (1.0f - p) * sqrt_via_double(gfl);
 			gain2[k] = tmp * tmp;
 		}
+		PROFT(11); // per-bin gains
 		const float g_last = rdlane(gain2[K - 1], 63); // gain2[F-1] scales the Nyquist term
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -1146,6 +1184,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 		}
 		WSYNC();
+		PROFT(12); // synthesis transform, overlap-add, output
 	}
 
 	bstore_vec<K>(rS, vb4, SL::ECHON * 4, en);
@@ -1163,5 +1202,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	}
 
 	if (lane == 0) a.scal[s] = sc;
+	PROF(13); // post-filter tail and state stores issued
+	PROFT(13);
 }
-
