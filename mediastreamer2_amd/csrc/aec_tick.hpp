@@ -565,55 +565,42 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		} else {
 			// frame 2: X and the background only.  alt = sum_j X(j) W1(j) with W1 the background as frame 1 left it: the
 			// foreground response when frame 1 updated the foreground; the same blocks are then stored as the foreground.
-			float2 alt[K], xj[K], xn[K], wl[K];
+			// Two blocks per iteration: every iteration ends in ONE wait for everything in flight (loads and stores share a
+			// counter and may complete out of order with each other, so with a store in flight the only wait is vmcnt(0)), a
+			// full memory round trip that the iteration's arithmetic does not cover.  This pass has no foreground blocks in
+			// flight, so it has the registers to take the blocks in pairs: half as many round trips.
+			float2 alt[K], xj[K], xn[K], xn2[K], wl[K], wl2[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) xj[k] = X0[k], alt[k] = make_float2(0, 0);
-			bload_bins<K>(rX, vb8, xoff(1), xn);
-			bload_bins<K>(rW, vb8, 0, wl);
-#if AEC_TICK_PF_B == 2
-			float2 xn2[K], wl2[K];
-#pragma unroll
-			for (int k = 0; k < K; ++k) xn2[k] = wl2[k] = make_float2(0, 0);
-			if (M > 1) {
-				bload_bins<K>(rX, vb8, xoff(2), xn2);
-				bload_bins<K>(rW, vb8, (unsigned)(F * 8), wl2);
-			}
-#endif
-			for (int j = 0; j < M; ++j) {
-#if AEC_TICK_PF_B == 2
-				float2 xn3[K], wl3[K];
-				if (j + 2 < M) {
-					bload_bins<K>(rX, vb8, xoff(j + 3), xn3);
-					bload_bins<K>(rW, vb8, (unsigned)(j + 2) * (F * 8), wl3);
-				} else {
-#pragma unroll
-					for (int k = 0; k < K; ++k) xn3[k] = xn2[k], wl3[k] = wl2[k];
-				}
-#else
-				float2 xn2[K], wl2[K];
-				if (j + 1 < M) {
-					bload_bins<K>(rX, vb8, xoff(j + 2), xn2);
-					bload_bins<K>(rW, vb8, (unsigned)(j + 1) * (F * 8), wl2);
-				} else {
-#pragma unroll
-					for (int k = 0; k < K; ++k) xn2[k] = xn[k], wl2[k] = wl[k];
-				}
-#endif
-				if (pendingFG) bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), wl);
-				cmac_bins<K>(alt, xj, wl, e0);
+			auto xclamp = [&](int i) { return xoff(i < M ? i : M); };
+			auto wclamp = [&](int i) { return (unsigned)(i < M ? i : M - 1) * (unsigned)(F * 8); };
+			bload_bins<K>(rX, vb8, xclamp(1), xn);
+			bload_bins<K>(rX, vb8, xclamp(2), xn2);
+			bload_bins<K>(rW, vb8, wclamp(0), wl);
+			bload_bins<K>(rW, vb8, wclamp(1), wl2);
+			auto block = [&](int j, float2 (&w)[K], const float2 (&xa)[K], const float2 (&xb)[K]) { // xa = X(j), xb = X(j+1)
+				if (pendingFG) bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), w);
+				cmac_bins<K>(alt, xa, w, e0);
 				const bool aumdf = (j == 0 || j == jc);
-				if (do_grad) grad(wl, xn, L.prop[j]);
-				if (aumdf) constrain(wl);
-				if (do_grad || aumdf) bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), wl);
-				cmac_bins<K>(ybgs, xj, wl, e0);
-				norm_of(wl, j);
+				if (do_grad) grad(w, xb, L.prop[j]);
+				if (aumdf) constrain(w);
+				if (do_grad || aumdf) bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), w);
+				cmac_bins<K>(ybgs, xa, w, e0);
+				norm_of(w, j);
+			};
+			int j = 0;
+			for (; j + 1 < M; j += 2) {
+				float2 xa[K], xb[K], wa[K], wb[K]; // the next pair: X(j+3), X(j+4), W(j+2), W(j+3) (clamped at the end: dropped)
+				bload_bins<K>(rX, vb8, xclamp(j + 3), xa);
+				bload_bins<K>(rX, vb8, xclamp(j + 4), xb);
+				bload_bins<K>(rW, vb8, wclamp(j + 2), wa);
+				bload_bins<K>(rW, vb8, wclamp(j + 3), wb);
+				block(j, wl, xj, xn);
+				block(j + 1, wl2, xn, xn2);
 #pragma unroll
-				for (int k = 0; k < K; ++k) xj[k] = xn[k], xn[k] = xn2[k], wl[k] = wl2[k];
-#if AEC_TICK_PF_B == 2
-#pragma unroll
-				for (int k = 0; k < K; ++k) xn2[k] = xn3[k], wl2[k] = wl3[k];
-#endif
+				for (int k = 0; k < K; ++k) xj[k] = xn2[k], xn[k] = xa[k], xn2[k] = xb[k], wl[k] = wa[k], wl2[k] = wb[k];
 			}
+			if (j < M) block(j, wl, xj, xn); // an odd block count leaves one
 #pragma unroll
 			for (int k = 0; k < K; ++k) yfg[k] = pendingFG ? alt[k] : spec2[k];
 			pendingFG = false;
