@@ -395,6 +395,21 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	PROF(1); // state loaded, far-end spectra of both frames ready
 	for (int f = 0; f < nf; ++f) {
 		PROF(2 + 5 * f); // frame start
+		// Frame 2's first blocks are asked for NOW (frame 1's pass wrote them long ago): the notch and the proportional step
+		// below -- 5 us of serial chains that touch no HBM -- cover their round trip.  (Not frame 1's: with the far-end
+		// spectra of both frames and the speculation accumulators live, the 24 registers spill; measured, no gain.)
+		const int head = (sc.xhead + M) % (M + 1);
+		auto xoff = [&](int j) { return (unsigned)((head + j) % (M + 1)) * (unsigned)(F * 8); };
+		float2 pre0[K], pre1[K], pre2[K], pre3[K];
+		if (f == 0) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) pre0[k] = pre1[k] = pre2[k] = pre3[k] = make_float2(0, 0);
+		} else {
+			bload_bins<K>(rX, vb8, xoff(1), pre0);
+			bload_bins<K>(rX, vb8, xoff(2 < M ? 2 : M), pre1);
+			bload_bins<K>(rW, vb8, 0, pre2);
+			bload_bins<K>(rW, vb8, (unsigned)(1 < M ? 1 : 0) * (unsigned)(F * 8), pre3);
+		}
 		// ---- near end: saturation flag, DC notch (serial IIR), pre-emphasis
 		int any_sat;
 		{
@@ -425,10 +440,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		sc.cancel_count++;
 
 		// ---- newest far-end spectrum into the ring; its power spectrum is all the rest of the frame needs of it
-		const int head = (sc.xhead + M) % (M + 1);
 		sc.xhead = head;
 		bstore_bins<K>(rX, vb8, (unsigned)head * (F * 8), X0);
-		auto xoff = [&](int j) { return (unsigned)((head + j) % (M + 1)) * (unsigned)(F * 8); };
 		float Xf[K], Xf_F = 0;
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -574,10 +587,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			for (int k = 0; k < K; ++k) xj[k] = X0[k], alt[k] = make_float2(0, 0);
 			auto xclamp = [&](int i) { return xoff(i < M ? i : M); };
 			auto wclamp = [&](int i) { return (unsigned)(i < M ? i : M - 1) * (unsigned)(F * 8); };
-			bload_bins<K>(rX, vb8, xclamp(1), xn);
-			bload_bins<K>(rX, vb8, xclamp(2), xn2);
-			bload_bins<K>(rW, vb8, wclamp(0), wl);
-			bload_bins<K>(rW, vb8, wclamp(1), wl2);
+#pragma unroll
+			for (int k = 0; k < K; ++k) xn[k] = pre0[k], xn2[k] = pre1[k], wl[k] = pre2[k], wl2[k] = pre3[k];
 			auto block = [&](int j, float2 (&w)[K], const float2 (&xa)[K], const float2 (&xb)[K]) { // xa = X(j), xb = X(j+1)
 				if (pendingFG) bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), w);
 				cmac_bins<K>(alt, xa, w, e0);
