@@ -12,6 +12,7 @@ import bench  # noqa: E402
 import mediastreamer2_amd as ms  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+FLAGS = ms.MI_AEC_POSTFILTER if os.environ.get("AEC_PROBE_POST", "1") != "0" else 0  # 0: the canceller without its post-filter tail
 ctx = ms.Context(0)
 leg = bench.make_aec_leg(ms, torch, ctx, n)
 aec, mics, refs, out, two, one = leg.keep
@@ -35,11 +36,11 @@ ts = {k: [] for k in pats}
 for rep in range(6):  # patterns interleaved, several passes: clock / thermal drift hits them all alike
     for name, cnt in cnts.items():
         for i in range(2):
-            aec.process_frames(mics[i % 4], refs[i % 4], out, cnt, max_frames=2)
+            aec.process_frames(mics[i % 4], refs[i % 4], out, cnt, max_frames=2, flags=FLAGS)
         ctx.sync()
         for i in range(4):
             ctx.timer_start()
-            aec.process_frames(mics[i % 4], refs[i % 4], out, cnt, max_frames=2)
+            aec.process_frames(mics[i % 4], refs[i % 4], out, cnt, max_frames=2, flags=FLAGS)
             ts[name].append(ctx.timer_stop())
 for name, c in pats.items():
     v = ts[name]
