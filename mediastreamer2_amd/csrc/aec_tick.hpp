@@ -111,22 +111,29 @@ __device__ __forceinline__ unsigned f2u(float v) { return __float_as_uint(v); }
 #ifndef AEC_TICK_PRIO
 #define AEC_TICK_PRIO 0 /* s_setprio while a wave streams its filter blocks */
 #endif
-template <int K>
-__device__ __forceinline__ void bload_bins(rsrc_t r, unsigned voff, unsigned soff, float2 (&v)[K]) {
+template <typename T>
+__device__ __forceinline__ T mk2(float x, float y) {
+	T t;
+	t.x = x, t.y = y;
+	return t;
+}
+// T = float2, or v2f: a 64-bit register pair per bin, so that whole bins move with one v_mov_b64 / feed v_pk_* directly
+template <int K, typename T>
+__device__ __forceinline__ void bload_bins(rsrc_t r, unsigned voff, unsigned soff, T (&v)[K]) {
 	if constexpr (K == 1) {
 		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AEC_TICK_AUX_LD);
-		v[0] = make_float2(u2f(t.x), u2f(t.y));
+		v[0] = mk2<T>(u2f(t.x), u2f(t.y));
 	} else {
 #pragma unroll
 		for (int k = 0; k < K; k += 2) {
 			const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 8 * k, soff, AEC_TICK_AUX_LD);
-			v[k] = make_float2(u2f(t.x), u2f(t.y));
-			v[k + 1] = make_float2(u2f(t.z), u2f(t.w));
+			v[k] = mk2<T>(u2f(t.x), u2f(t.y));
+			v[k + 1] = mk2<T>(u2f(t.z), u2f(t.w));
 		}
 	}
 }
-template <int K>
-__device__ __forceinline__ void bstore_bins(rsrc_t r, unsigned voff, unsigned soff, const float2 (&v)[K]) {
+template <int K, typename T>
+__device__ __forceinline__ void bstore_bins(rsrc_t r, unsigned voff, unsigned soff, const T (&v)[K]) {
 	if constexpr (K == 1) {
 		u2v t = {f2u(v[0].x), f2u(v[0].y)};
 		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, AEC_TICK_AUX_ST);
@@ -164,8 +171,8 @@ __device__ __forceinline__ void bstore_vec(rsrc_t r, unsigned voff, unsigned sof
 }
 
 // acc += x w, bin by bin; bin 0 (lane 0's first) holds (DC, Nyquist): two real products there
-template <int K>
-__device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K], const float2 (&w)[K], int e0) {
+template <int K, typename TA, typename TX, typename TW>
+__device__ __forceinline__ void cmac_bins(TA (&acc)[K], const TX (&x)[K], const TW (&w)[K], int e0) {
 #ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: one add per 16-byte load keeps the loads alive */
 	for (int k = 0; k < K; k += 2) acc[k].x += x[k].x + w[k].x;
 	return;
@@ -179,21 +186,13 @@ __device__ __forceinline__ void cmac_bins(float2 (&acc)[K], const float2 (&x)[K]
 			if (e0 == 0) pr = dc;
 		}
 		const v2f a = (v2f){acc[k].x, acc[k].y} + pr;
-		acc[k] = make_float2(a.x, a.y);
+		acc[k] = mk2<TA>(a.x, a.y);
 	}
 }
 
 #ifndef AEC_TICK_OCC256
 #define AEC_TICK_OCC256 2
 #endif
-#ifndef AEC_TICK_PF_A
-#define AEC_TICK_PF_A 1 /* blocks in flight behind the one at hand, frame 1's pass (X, FG, W): 1 or 2 */
-#endif
-#ifndef AEC_TICK_PF_B
-#define AEC_TICK_PF_B 1 /* the same for frame 2's pass (X, W) */
-#endif
-
-// ===================================================================== MDF canceller, the frames of one tick
 #ifdef AEC_PROF_TIMING /* dev builds: shader-clock stamps at the phase boundaries, one row of 16 per stream (mi_aec_debug_profile) */
 #define PROF(i)                                                                                         \
 	do {                                                                                                \
@@ -400,10 +399,10 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		// spectra of both frames and the speculation accumulators live, the 24 registers spill; measured, no gain.)
 		const int head = (sc.xhead + M) % (M + 1);
 		auto xoff = [&](int j) { return (unsigned)((head + j) % (M + 1)) * (unsigned)(F * 8); };
-		float2 pre0[K], pre1[K], pre2[K], pre3[K];
+		v2f pre0[K], pre1[K], pre2[K], pre3[K];
 		if (f == 0) {
 #pragma unroll
-			for (int k = 0; k < K; ++k) pre0[k] = pre1[k] = pre2[k] = pre3[k] = make_float2(0, 0);
+			for (int k = 0; k < K; ++k) pre0[k] = pre1[k] = pre2[k] = pre3[k] = (v2f){0.f, 0.f};
 		} else {
 			bload_bins<K>(rX, vb8, xoff(1), pre0);
 			bload_bins<K>(rX, vb8, xoff(2 < M ? 2 : M), pre1);
@@ -474,7 +473,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		if (!do_grad) sc.saturated--;
 
 		// W += prop p1 conj(X) E, bin by bin (weighted_spectral_mul_conj); bin 0 = (DC, Nyquist): real products with their own steps
-		auto grad = [&](float2 (&w)[K], const float2 (&x)[K], float prop) {
+		auto grad = [&](auto (&w)[K], const auto (&x)[K], float prop) {
 #ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: the streaming pass without its arithmetic (every load still consumed) */
 			for (int k = 0; k < K; k += 2) w[k].x += x[k].x * prop;
 			return;
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 					if (e0 == 0) st = dc;
 				}
 				const v2f r = (v2f){w[k].x, w[k].y} + st;
-				w[k] = make_float2(r.x, r.y);
+				w[k].x = r.x, w[k].y = r.y;
 			}
 		};
 
@@ -497,18 +496,23 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		// the AUMDF constraint (IFFT, zero the second half, FFT) where the pass meets them: the blocks are independent of each
 		// other, only the sums over j have an order, and it stays ascending.
 		const int jc = (M > 1) ? (sc.cancel_count % (M - 1)) + 1 : -1;
-		auto constrain = [&](float2 (&w)[K]) {
+		auto constrain = [&](auto (&wv)[K]) {
+			float2 w[K];
+#pragma unroll
+			for (int k = 0; k < K; ++k) w[k] = make_float2(wv[k].x, wv[k].y);
 			w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w);
 			float z[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) z[k] = 0.f;
 			store_vec<K>(w_time(L) + F + e0, z);
 			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w, w_time(L));
+#pragma unroll
+			for (int k = 0; k < K; ++k) wv[k].x = w[k].x, wv[k].y = w[k].y;
 		};
 		float2 yfg[K], ybgs[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) yfg[k] = ybgs[k] = make_float2(0, 0);
-		auto norm_of = [&](const float2 (&w)[K], int j) {
+		auto norm_of = [&](const auto (&w)[K], int j) {
 			float nn = 0;
 #pragma unroll
 			for (int k = 0; k < K; ++k) nn += w[k].x * w[k].x + w[k].y * w[k].y;
@@ -522,35 +526,14 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		if (f == 0) {
 			// frame 1: X, foreground and background; with a second frame behind it also that frame's foreground response
 			const bool spec = nf > 1;
-			float2 xj[K], xn[K], fg[K], wl[K], xm1[K]; // xm1: the block before xj = frame 2's block at this position
+			v2f xj[K], xn[K], fg[K], wl[K], xm1[K]; // xm1: the block before xj = frame 2's block at this position (register pairs)
 #pragma unroll
-			for (int k = 0; k < K; ++k) xj[k] = X0[k], xm1[k] = X0B[k];
+			for (int k = 0; k < K; ++k) xj[k] = (v2f){X0[k].x, X0[k].y}, xm1[k] = (v2f){X0B[k].x, X0B[k].y};
 			bload_bins<K>(rX, vb8, xoff(1), xn);
 			bload_bins<K>(rF, vb8, 0, fg);
 			bload_bins<K>(rW, vb8, 0, wl);
-#if AEC_TICK_PF_A == 2
-			float2 xn2[K], fg2[K], wl2[K]; // two blocks in flight behind the one at hand
-#pragma unroll
-			for (int k = 0; k < K; ++k) xn2[k] = fg2[k] = wl2[k] = make_float2(0, 0);
-			if (M > 1) {
-				bload_bins<K>(rX, vb8, xoff(2), xn2);
-				bload_bins<K>(rF, vb8, (unsigned)(F * 8), fg2);
-				bload_bins<K>(rW, vb8, (unsigned)(F * 8), wl2);
-			}
-#endif
 			for (int j = 0; j < M; ++j) {
-#if AEC_TICK_PF_A == 2
-				float2 xn3[K], fg3[K], wl3[K];
-				if (j + 2 < M) {
-					bload_bins<K>(rX, vb8, xoff(j + 3), xn3);
-					bload_bins<K>(rF, vb8, (unsigned)(j + 2) * (F * 8), fg3);
-					bload_bins<K>(rW, vb8, (unsigned)(j + 2) * (F * 8), wl3);
-				} else {
-#pragma unroll
-					for (int k = 0; k < K; ++k) xn3[k] = xn2[k], fg3[k] = fg2[k], wl3[k] = wl2[k];
-				}
-#else
-				float2 xn2[K], fg2[K], wl2[K];
+				v2f xn2[K], fg2[K], wl2[K];
 				if (j + 1 < M) {
 					bload_bins<K>(rX, vb8, xoff(j + 2), xn2);
 					bload_bins<K>(rF, vb8, (unsigned)(j + 1) * (F * 8), fg2);
@@ -559,7 +542,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 #pragma unroll
 					for (int k = 0; k < K; ++k) xn2[k] = xn[k], fg2[k] = fg[k], wl2[k] = wl[k];
 				}
-#endif
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(wl, xn, L.prop[j]);
 				if (aumdf) constrain(wl);
@@ -570,10 +552,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 				norm_of(wl, j);
 #pragma unroll
 				for (int k = 0; k < K; ++k) xm1[k] = xj[k], xj[k] = xn[k], xn[k] = xn2[k], fg[k] = fg2[k], wl[k] = wl2[k];
-#if AEC_TICK_PF_A == 2
-#pragma unroll
-				for (int k = 0; k < K; ++k) xn2[k] = xn3[k], fg2[k] = fg3[k], wl2[k] = wl3[k];
-#endif
 			}
 		} else {
 			// frame 2: X and the background only.  alt = sum_j X(j) W1(j) with W1 the background as frame 1 left it: the
@@ -582,14 +560,15 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			// counter and may complete out of order with each other, so with a store in flight the only wait is vmcnt(0)), a
 			// full memory round trip that the iteration's arithmetic does not cover.  This pass has no foreground blocks in
 			// flight, so it has the registers to take the blocks in pairs: half as many round trips.
-			float2 alt[K], xj[K], xn[K], xn2[K], wl[K], wl2[K];
+			float2 alt[K];
+			v2f xj[K], xn[K], xn2[K], wl[K], wl2[K]; // register pairs: a bin moves with one instruction
 #pragma unroll
-			for (int k = 0; k < K; ++k) xj[k] = X0[k], alt[k] = make_float2(0, 0);
+			for (int k = 0; k < K; ++k) xj[k] = (v2f){X0[k].x, X0[k].y}, alt[k] = make_float2(0, 0);
 			auto xclamp = [&](int i) { return xoff(i < M ? i : M); };
 			auto wclamp = [&](int i) { return (unsigned)(i < M ? i : M - 1) * (unsigned)(F * 8); };
 #pragma unroll
 			for (int k = 0; k < K; ++k) xn[k] = pre0[k], xn2[k] = pre1[k], wl[k] = pre2[k], wl2[k] = pre3[k];
-			auto block = [&](int j, float2 (&w)[K], const float2 (&xa)[K], const float2 (&xb)[K]) { // xa = X(j), xb = X(j+1)
+			auto block = [&](int j, v2f (&w)[K], const v2f (&xa)[K], const v2f (&xb)[K]) { // xa = X(j), xb = X(j+1)
 				if (pendingFG) bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), w);
 				cmac_bins<K>(alt, xa, w, e0);
 				const bool aumdf = (j == 0 || j == jc);
@@ -601,7 +580,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			};
 			int j = 0;
 			for (; j + 1 < M; j += 2) {
-				float2 xa[K], xb[K], wa[K], wb[K]; // the next pair: X(j+3), X(j+4), W(j+2), W(j+3) (clamped at the end: dropped)
+				v2f xa[K], xb[K], wa[K], wb[K]; // the next pair: X(j+3), X(j+4), W(j+2), W(j+3) (clamped at the end: dropped)
 				bload_bins<K>(rX, vb8, xclamp(j + 3), xa);
 				bload_bins<K>(rX, vb8, xclamp(j + 4), xb);
 				bload_bins<K>(rW, vb8, wclamp(j + 2), wa);
