@@ -6,10 +6,11 @@ Contract (see DESIGN.md "Measurement"):
 prints ONE JSON line on rank 0.
 
 Workload: the north_star hot path, chained on the device, per call leg and
-10 ms tick (src/base/msticker.c:46): MSResample 16k->48k -> FIFO -> MSSpeexEC
-(48 kHz, 256-sample frames, 128 ms tail, canceller + post-filter) -> FIFO ->
-MSVolume (AGC) -> MSAudioMixer (conferences of 32).  A "step" is one tick of
-every leg on the GPU; inputs are resident in HBM.
+10 ms tick (src/base/msticker.c:46): MSResample 16k->48k -> MSSpeexEC (48 kHz,
+256-sample frames, 128 ms tail, canceller + post-filter, its bufferizers
+folded into the kernel) -> MSVolume (AGC) -> MSAudioMixer (conferences of 32):
+four launches.  A "step" is one tick of every leg on the GPU; inputs are
+resident in HBM.
 
 value = concurrent 48 kHz legs the job sustains: the largest leg count per GPU
 (capacity sweep) whose WORST single tick stays under the 10 ms interval, summed
@@ -26,8 +27,10 @@ mi_mixer_partial_sum -> int32 all-reduce over RCCL (explicit events between the
 kernel stream and the collective's stream) -> mi_mixer_finalize, checked bit
 for bit against the single-GPU mix on rank 0.  RCCL failure = non-zero exit.
 
-roofline = the canceller + post-filter kernel pair at the headline leg count,
-HIP events on the launch stream; cpu_baseline = the oracle's same chain on the
+roofline = the canceller's tick kernel (canceller + post-filter, one launch) at
+the headline leg count, HIP events on the launch stream; config.legs_out_of_phase
+= the capacity with the legs' 480 -> 256 re-framing phases shuffled (not `value`:
+`value` is the aligned worst case); cpu_baseline = the oracle's same chain on the
 host's cores (bounded sample).  other_kernels: BASELINE configs[1]-[4] and the
 adjacent stages, each with its own roofline object.
 """
