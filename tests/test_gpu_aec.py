@@ -109,6 +109,37 @@ def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
     aec.close()
 
 
+@pytest.mark.parametrize("rate,F", [(48000, 256), (16000, 128)])
+def test_reset_on_far_end_overload_matches_the_oracle(ctx, oracle, rate, F):
+    """speex_echo_cancellation resets itself when an energy leaves its range (mdf.c: Sxx >= N * 1e9 -> screwed_up += 50):
+    a frame of alternating full-scale far end does it.  Outputs, filters and control state after the reset and the frames
+    that follow equal the oracle's bit for bit (the filter is not adapted yet: nothing tree-reduced is in use)."""
+    tail_ms, nframes, ns = 128, 14, 2
+    flen = tail_ms * rate // 1000
+    aec = ms.AecBatch(ctx, ns, rate, frame_size=F, filter_length=flen)
+    ecs = [oracle.Echo(F, flen, rate) for _ in range(ns)]
+    scenes = [make_echo_scene(70 + s, rate, F * nframes) for s in range(ns)]
+    mic = np.stack([m for m, _ in scenes])
+    far = np.stack([f for _, f in scenes])
+    far[0, 6 * F:7 * F] = np.where(np.arange(F) % 2 == 0, 32767, -32767)
+    M, N = (flen + F - 1) // F, 2 * F
+    for f in range(nframes):
+        sl = slice(f * F, (f + 1) * F)
+        got = aec.process(np.ascontiguousarray(mic[:, sl]), np.ascontiguousarray(far[:, sl]), flags=0)
+        for s in range(ns):
+            ref = ecs[s].cancel(mic[s, sl], far[s, sl])
+            np.testing.assert_array_equal(got[s], ref, err_msg=f"frame {f} stream {s}")
+        if f in (6, 7, nframes - 1):
+            for s in range(ns):
+                np.testing.assert_array_equal(aec.get(s, "scalars", 16).view(np.uint32), ecs[s].get("scalars", 16).view(np.uint32),
+                                              err_msg=f"frame {f} stream {s} scalars")
+                for what, n in (("W", M * N), ("foreground", M * N), ("X", (M + 1) * N), ("E", N), ("power", F + 1), ("last_y", N)):
+                    np.testing.assert_array_equal(aec.get(s, what, n).view(np.uint32), ecs[s].get(what, n).view(np.uint32),
+                                                  err_msg=f"frame {f} stream {s} {what}")
+    assert ecs[0].get("scalars", 16)[11] < nframes, "the overload must have reset the frame counter of stream 0"
+    aec.close()
+
+
 @pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(48000, 256, 128, False), (48000, 256, 128, True),
                                                       (16000, 128, 128, True), (16000, 128, 250, False),
                                                       (8000, 64, 250, True), (8000, 64, 128, False),
@@ -326,7 +357,8 @@ def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
     """mi_aec_process_frames (all the frames of a tick in ONE launch: per-stream state in registers across them, the
     foreground filter streamed once, the foreground update carried out by the second frame's pass) == the same frames
     through mi_aec_process one by one: outputs and every state array bit for bit, with per-stream frame counts 0 / 1 / 2
-    changing every tick, through convergence (foreground updates) and a saturating burst (no-gradient frames)."""
+    changing every tick, through convergence (foreground updates), a saturating burst (no-gradient frames) and far-end
+    overloads that make the library reset the canceller in the first or the second frame of a tick."""
     torch = pytest.importorskip("torch")
     n, nticks = 6, 150
     flen = tail_ms * rate // 1000
@@ -338,6 +370,8 @@ def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
     mic = np.stack([m for m, _ in scenes]).reshape(n, total, F)
     far = np.stack([f for _, f in scenes]).reshape(n, total, F)
     mic[2, 60:64] = 32767  # saturation: the gradient is skipped for the following frames
+    far[3, 90] = np.where(np.arange(F) % 2 == 0, 32767, -32767)  # far-end overload: the library resets the canceller (Sxx >= N * 1e9)
+    far[4, 121] = np.where(np.arange(F) % 2 == 0, 32767, -32767)  # (odd position: the reset falls on the other frame of its ticks)
     pos = np.zeros(n, int)
     M = (flen + F - 1) // F
     for t in range(nticks):
