@@ -8,7 +8,7 @@
  * behind them) are NOT available in this repository's build image, so by default
  * the declarations below restate, field for field and macro for macro, what the
  * plugin uses, each with the reference location it mirrors; the host shim
- * (mediastreamer2_amd/host/ms2shim.c) implements the functions for the tests.
+ * (tests/host/ms2shim.c, test infrastructure) implements the functions for the tests.
  * The layouts are ABI-plausible, not ABI-verified.
  */
 #ifndef MS2_PLUGIN_ABI_H
@@ -464,6 +464,9 @@ void ms_mi355x_flush(void);
 unsigned long long ms_mi355x_late_events(void);
 /* Tickers with live banks, banks alive, bank slots held by filters (any pointer may be NULL): a leak check's view. */
 void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use);
+/* The device of every ticker hub that has opened a context (the hubs of one process spread over MSMI355X_DEVICES,
+ * default: every visible device); returns their number, fills at most `cap` entries. */
+int ms_mi355x_hub_devices(int *devices, int cap);
 /* Waits for every hub's stream (tests, orderly shutdown). */
 void ms_mi355x_shutdown(void);
 #ifdef __cplusplus

@@ -64,13 +64,17 @@ extern "C" {
 #define MI_ENOMEM (-3)
 #define MI_ENOTSUP (-4) /* configuration outside what the reference path uses */
 
-#define MSMI355X_ABI_VERSION 1
+#define MSMI355X_ABI_VERSION 3
 
 int mi_abi_version(void);
 const char *mi_last_error(void);
 
 /* ------------------------------------------------------------- context */
 typedef struct mi_ctx mi_ctx;
+/* HIP devices visible to the process (0 when there is none or the runtime cannot be initialised).  Every object
+ * belongs to the device of the context it was created on and every entry point makes that device current for the
+ * calling thread first, so one process -- one thread or many -- can drive contexts on all GPUs of a node. */
+int mi_device_count(void);
 /* hip_stream: an existing hipStream_t to launch on (e.g. the caller's
  * framework stream), or NULL to create a private non-blocking stream. */
 int mi_ctx_create(int device, void *hip_stream, mi_ctx **out);
@@ -195,6 +199,12 @@ void mi_volume_default_params(mi_volume_params *p);          /* volume_init msvo
 int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_params *h_params);
 int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h_state); /* syncs */
 int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_state *h_state);
+/* MS_VOLUME_GET_MAX (linear): the maximum of the smoothed energy over the last second, recorded on the device by every
+ * process call like ortp_extremum_record_max in update_energy (msvolume.c:115,:143-148,:404) -- a peak between two polls
+ * is not missed.  A stream's own chunks are its clock (one chunk per tick).  Syncs.  reset_max starts the windows over
+ * (a new filter). */
+int mi_volume_get_max(mi_volume *v, int first, int count, float *h_max);
+int mi_volume_reset_max(mi_volume *v, int first, int count);
 /* One chunk per stream, in place: d_samples [nstreams][stride].
  * d_nsamples [nstreams] int32 per-stream chunk length (0 = stream idle this
  * tick), or NULL -> every stream processes `nsamples`. */
@@ -241,8 +251,6 @@ int mi_aec_reset(mi_aec *a, int first, int count);
  * d_run [nstreams] u8: 0 = this stream has no full frame this tick (A23), NULL = all run.
  * flags bit0: also run the residual-echo/denoise post-filter (speex_preprocess_run). */
 #define MI_AEC_POSTFILTER 1u
-#define MI_AEC_DEFER_JOIN 2u /* the output rows may be read on the context's stream only after mi_aec_join(): lets the last chunk's
-                             * post-filter of this call run next to the first chunk's canceller of the next call */
 int mi_aec_process(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride,
                    const uint8_t *d_run, unsigned flags);
 /* The frames of one TICK in one launch (the form the chained path uses): row s of d_mic / d_ref / d_out holds up to
@@ -268,11 +276,6 @@ int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, i
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
                         const uint8_t *h_run, unsigned flags);
 /* state bytes per stream (for DESIGN/roofline accounting) */
-/* How mi_aec_process schedules the post-filter: -1 automatic (at 256-sample frames and >= 16 384 streams the batch is cut
- * in two and the first half's post-filter runs on a second HIP stream next to the second half's canceller), 0 never,
- * 2..8 always with that many chunks.  Results do not depend on it. */
-int mi_aec_set_overlap(mi_aec *a, int chunks);
-int mi_aec_join(mi_aec *a); /* after MI_AEC_DEFER_JOIN calls: the context's stream waits for every post-filter launched so far */
 size_t mi_aec_state_bytes(const mi_aec *a);
 /* One stream's whole state as a host blob, and back: what fetch_config / apply_config (src/audiofilters/speexec.c:119-167)
  * do with SPEEX_ECHO_GET_BLOB / SET_BLOB of the reference's speex fork, so a converged canceller survives the end of a
@@ -454,8 +457,9 @@ int mi_session_remove_member(mi_session *s, int stream);
 int mi_session_member_count(const mi_session *s, int conference); /* plumbed pins, or MI_EINVAL */
 /* The active-speaker election of a conference in mixer mode (audioconference.c:436-452): per conference the plumbed,
  * unmuted member with the largest MS_VOLUME_GET_MAX (maximum of the smoothed energy over a one-second window, dBm0)
- * above -30 dB; h_winner[conf] = its stream index or -1, h_max_db[conf] (nullable) its level.  Call it as often as the
- * application polls (the reference: every process_events); now_ms is the caller's clock. */
+ * above -30 dB; h_winner[conf] = its stream index or -1, h_max_db[conf] (nullable) its level.  The windows are kept on
+ * the device and fed by every tick (mi_volume_get_max), so the result does not depend on how often the application
+ * polls; now_ms is not needed for that any more and is ignored (the ticks are the clock, 10 ms each). */
 int mi_session_active_speakers(mi_session *s, uint64_t now_ms, int32_t *h_winner, float *h_max_db);
 
 /* ------------------------------------------------------------- pixconv */

@@ -24,7 +24,7 @@ from ._lib import MiError, VolumeParams, VolumeState, check, load  # noqa: F401
 
 MI_MIX_LINKED, MI_MIX_ACTIVE, MI_MIX_OUTPUT = 1, 2, 4
 MI_PIX_I420, MI_PIX_RGB24 = 0, 1
-MI_AEC_POSTFILTER, MI_AEC_DEFER_JOIN = 1, 2
+MI_AEC_POSTFILTER = 1
 
 
 def _is_torch(x):
@@ -247,6 +247,16 @@ class VolumeBatch(_Batch):
         arr = (VolumeState * len(states))(*states)
         check(self.ctx.L.mi_volume_set_state(self.h, first, len(states), arr))
 
+    def get_max(self, first=0, count=None):
+        """MS_VOLUME_GET_MAX, linear: maximum of the smoothed energy over the last second (device-side window)"""
+        count = self.nstreams - first if count is None else count
+        out = np.zeros(count, np.float32)
+        check(self.ctx.L.mi_volume_get_max(self.h, first, count, out.ctypes.data))
+        return out
+
+    def reset_max(self, first=0, count=None):
+        check(self.ctx.L.mi_volume_reset_max(self.h, first, self.nstreams - first if count is None else count))
+
     def process(self, x, nsamples=None, per_stream=None):
         """x [nstreams, stride] int16, modified in place (numpy: returns the array)."""
         n, stride = x.shape
@@ -329,14 +339,6 @@ class AecBatch(_Batch):
 
     def state_bytes(self):
         return self.ctx.L.mi_aec_state_bytes(self.h)
-
-    def join(self):
-        """after process(..., flags=MI_AEC_POSTFILTER | MI_AEC_DEFER_JOIN) calls: outputs become readable on the context's stream"""
-        check(self.ctx.L.mi_aec_join(self.h))
-
-    def set_overlap(self, chunks):
-        """-1 automatic, 0 off, 2..8 chunks: the post-filter of a chunk on a second stream next to the next chunk's canceller."""
-        check(self.ctx.L.mi_aec_set_overlap(self.h, chunks))
 
     def export_state(self, stream):
         """One stream's whole state as bytes (speexec.c:145-167 fetch_config)."""

@@ -22,7 +22,7 @@ class MiError(RuntimeError):
 
 # every symbol include/msmi355x.h declares (tests check the export table against this)
 EXPORTS = [
-    "mi_abi_version", "mi_last_error",
+    "mi_abi_version", "mi_last_error", "mi_device_count",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
     "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
@@ -33,12 +33,12 @@ EXPORTS = [
     "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
-    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo",
+    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
     "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos",
-    "mi_aec_process_host", "mi_aec_set_overlap", "mi_aec_join", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
+    "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
@@ -156,6 +156,8 @@ def load():
     L.mi_volume_set_params.argtypes = [vp, i32, i32, C.POINTER(VolumeParams)]
     L.mi_volume_get_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
     L.mi_volume_set_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
+    L.mi_volume_get_max.argtypes = [vp, i32, i32, vp]
+    L.mi_volume_reset_max.argtypes = [vp, i32, i32]
     L.mi_volume_process.argtypes = [vp, vp, i32, i32, vp]
     L.mi_volume_process_host.argtypes = [vp, vp, i32, i32, vp]
     L.mi_volume_process_fifo.argtypes = [vp, vp, vp, i32, i32]
@@ -183,8 +185,6 @@ def load():
         L.mi_aec_process_host.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_process_frames.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_uint]
         L.mi_aec_process_fifos.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, C.c_uint, vp]
-        L.mi_aec_set_overlap.argtypes = [vp, i32]
-        L.mi_aec_join.argtypes = [vp]
         L.mi_aec_state_bytes.argtypes = [vp]
         L.mi_aec_state_bytes.restype = sz
         L.mi_aec_blob_bytes.argtypes = [vp]

@@ -83,7 +83,6 @@ struct AecArgs {
 	int tick_len, mic_tick_stride, ref_tick_stride;
 	const int32_t *ref_len; // nullable: per-stream length of the far-end block (0 .. tick_len)
 	uint8_t *count_out; // nullable: frames each stream ran
-	unsigned long long *prof; // dev builds with -DAEC_PROF_TIMING: [nstreams][16] shader-clock stamps per phase, else unused
 	int stride, nstreams, M, flags;
 	int first;             // first stream of this launch (a launch may cover a chunk of the batch)
 	float *X, *W, *FG;     // [nstreams][(M+1) or M][N]
@@ -271,7 +270,6 @@ struct mi_aec {
 	int small_stride = 0;
 	std::vector<float> h_prop0;
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
-	unsigned long long *d_prof = nullptr; // dev builds only (AEC_PROF_TIMING): per-stream phase stamps
 };
 
 namespace {
@@ -542,36 +540,14 @@ void mi_aec_destroy(mi_aec *a) {
 	if (a->d_small) (void)hipFree(a->d_small);
 	if (a->d_scal) (void)hipFree(a->d_scal);
 	if (a->d_tables) (void)hipFree(a->d_tables);
-	if (a->d_prof) (void)hipFree(a->d_prof);
 	delete a;
 }
-
-#ifdef AEC_PROF_TIMING
-// Dev builds only (not in the header): per-stream shader-clock stamps of the last launch, [nstreams][16] (aec_tick.hpp: PROF)
-extern "C" int mi_aec_debug_profile(mi_aec *a, unsigned long long *h_out) {
-	if (!a) return MI_EINVAL;
-	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
-	const size_t bytes = (size_t)a->nstreams * 16 * sizeof(unsigned long long);
-	if (!a->d_prof) {
-		if (hipMalloc((void **)&a->d_prof, bytes) != hipSuccess) return MI_ENOMEM;
-		(void)hipMemset(a->d_prof, 0, bytes);
-		return MI_OK; // first call arms the collection
-	}
-	(void)hipStreamSynchronize(a->ctx->stream);
-	return hipMemcpy(h_out, a->d_prof, bytes, hipMemcpyDeviceToHost) == hipSuccess ? MI_OK : MI_ENODEV;
-}
-#endif
 
 int mi_aec_reset(mi_aec *a, int first, int count) {
 	MI_CHECK_ARG(a && first >= 0 && count >= 0 && first + count <= a->nstreams);
 	if (count == 0) return MI_OK;
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	return a->F == 256 ? init_state<256>(a, first, count) : (a->F == 128 ? init_state<128>(a, first, count) : init_state<64>(a, first, count));
-}
-
-int mi_aec_set_overlap(mi_aec *a, int chunks) { // kept for ABI 1 callers: there is no second launch to overlap any more
-	MI_CHECK_ARG(a && (chunks == -1 || chunks == 0 || (chunks >= 2 && chunks <= 8)));
-	return MI_OK;
 }
 
 size_t mi_aec_state_bytes(const mi_aec *a) {
@@ -603,7 +579,6 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.tick_len = g.mic_tick_stride = g.ref_tick_stride = 0;
 	g.count_out = nullptr;
 	g.ref_len = nullptr;
-	g.prof = a->d_prof;
 	if (fifo) {
 		g.ref_len = fifo->d_ref_len;
 		g.fmic = fifo_view(fifo->f_mic);
@@ -663,23 +638,13 @@ int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, i
 	MI_CHECK_ARG(a && f_mic && f_ref && f_out && d_mic_tick && d_ref_tick && tick_len > 0 && mic_stride >= tick_len &&
 	             ref_stride >= tick_len && max_frames >= 1 && max_frames <= MI_AEC_MAX_TICK_FRAMES);
 	MI_CHECK_ARG(f_mic->nstreams == a->nstreams && f_ref->nstreams == a->nstreams && f_out->nstreams == a->nstreams);
-	const int K = a->F / 64;
 	for (const mi_fifo *f : {f_mic, f_ref, f_out})
 		if (f->capacity % a->F || f->capacity < max_frames * a->F) {
 			mi::set_error("mi_aec_process_fifos: FIFO capacities must be multiples of the frame size %d (got %d)", a->F, f->capacity);
 			return MI_EINVAL;
 		}
-	if (tick_len % K) { // a lane's K samples must not straddle the boundary between queued and new samples
-		mi::set_error("mi_aec_process_fifos: blocks of %d samples with %d-sample frames are not supported", tick_len, a->F);
-		return MI_ENOTSUP;
-	}
 	AecFifoCall fc = {f_mic, f_ref, f_out, d_mic_tick, d_ref_tick, tick_len, mic_stride, ref_stride, d_ref_len, d_count_out};
 	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
-}
-
-int mi_aec_join(mi_aec *a) { // kept for ABI 1 callers: the post-filter is part of the one launch, nothing is ever pending
-	MI_CHECK_ARG(a != nullptr);
-	return MI_OK;
 }
 
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
@@ -837,6 +802,7 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 // debug entry (not in the public header): raw transform parity
 int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int inverse) {
 	MI_CHECK_ARG(a && d_in && d_out && nframes > 0);
+	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	if (a->F == 64)
 		hipLaunchKernelGGL(fft_debug_kernel<64>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	else if (a->F == 256)

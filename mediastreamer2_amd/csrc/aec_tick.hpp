@@ -48,20 +48,15 @@ struct TickLayout { // offsets in floats inside the per-stream small-state block
 };
 
 // LDS of the canceller kernel: FFT work space + tables and the per-bin state parked while the blocks stream (none of the
-// post-filter's arrays): 16.3 KB at F = 256.  (Tables read from global instead -- w_cfft<F, true> -- cost 24 % of the kernel
-// at 2 waves per SIMD: 6.35 against 5.14 ms per tick of 65 536 legs.)
-#ifndef AEC_TICK_GLOBAL_TABLES
-#define AEC_TICK_GLOBAL_TABLES 0
-#endif
+// post-filter's arrays): 16.3 KB at F = 256.  (Tables read from global memory instead cost 24 % of the kernel at 2 waves
+// per SIMD: 6.35 against 5.14 ms per tick of 65 536 legs.)
 template <int F>
 struct alignas(16) TLds {
 	float2 zbuf[F];      // complex FFT work
 	float tbuf[2 * F];   // time-domain exchange / inverse-transform staging
 	float spec[2 * F];   // bin-interleaved spectrum exchange
-#if !AEC_TICK_GLOBAL_TABLES
 	float2 tw[F], super[F];
 	uint16_t perm[F];
-#endif
 	float prop[64], wnorm[64];
 	// per-bin state that is not needed while the blocks stream: parked here instead of in registers
 	float pw[F], eh[F], yh[F], input[F];
@@ -78,39 +73,12 @@ struct alignas(16) TLds {
 // offset, instead of a 64-bit per-lane address (two VGPRs) per array and block: the canceller touches ~25 arrays
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-#ifndef AEC_TICK_FLAT
-#define AEC_TICK_FLAT 0
-#endif
-#if AEC_TICK_FLAT
-// A/B: the same accessors over plain 64-bit addresses
-struct rsrc_t {
-	char *p;
-};
-__device__ __forceinline__ rsrc_t mk_rsrc(const void *p, unsigned) { return rsrc_t{const_cast<char *>((const char *)p)}; }
-#define __builtin_amdgcn_raw_buffer_load_b128(r, v, s, a) (*reinterpret_cast<const u4v *>((r).p + (size_t)(v) + (size_t)(s)))
-#define __builtin_amdgcn_raw_buffer_load_b64(r, v, s, a) (*reinterpret_cast<const u2v *>((r).p + (size_t)(v) + (size_t)(s)))
-#define __builtin_amdgcn_raw_buffer_load_b32(r, v, s, a) (*reinterpret_cast<const unsigned *>((r).p + (size_t)(v) + (size_t)(s)))
-#define __builtin_amdgcn_raw_buffer_store_b128(x, r, v, s, a) (*reinterpret_cast<u4v *>((r).p + (size_t)(v) + (size_t)(s)) = (x))
-#define __builtin_amdgcn_raw_buffer_store_b64(x, r, v, s, a) (*reinterpret_cast<u2v *>((r).p + (size_t)(v) + (size_t)(s)) = (x))
-#define __builtin_amdgcn_raw_buffer_store_b32(x, r, v, s, a) (*reinterpret_cast<unsigned *>((r).p + (size_t)(v) + (size_t)(s)) = (x))
-#else
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t mk_rsrc(const void *p, unsigned bytes) {
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
-#endif
 __device__ __forceinline__ float u2f(unsigned v) { return __uint_as_float(v); }
 __device__ __forceinline__ unsigned f2u(float v) { return __float_as_uint(v); }
-// cache policy of the spectra's loads / stores (A/B switches; buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1)
-#ifndef AEC_TICK_AUX_LD
-#define AEC_TICK_AUX_LD 0
-#endif
-#ifndef AEC_TICK_AUX_ST
-#define AEC_TICK_AUX_ST 0
-#endif
-#ifndef AEC_TICK_PRIO
-#define AEC_TICK_PRIO 0 /* s_setprio while a wave streams its filter blocks */
-#endif
 template <typename T>
 __device__ __forceinline__ T mk2(float x, float y) {
 	T t;
@@ -121,12 +89,12 @@ __device__ __forceinline__ T mk2(float x, float y) {
 template <int K, typename T>
 __device__ __forceinline__ void bload_bins(rsrc_t r, unsigned voff, unsigned soff, T (&v)[K]) {
 	if constexpr (K == 1) {
-		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AEC_TICK_AUX_LD);
+		const u2v t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
 		v[0] = mk2<T>(u2f(t.x), u2f(t.y));
 	} else {
 #pragma unroll
 		for (int k = 0; k < K; k += 2) {
-			const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 8 * k, soff, AEC_TICK_AUX_LD);
+			const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 8 * k, soff, 0);
 			v[k] = mk2<T>(u2f(t.x), u2f(t.y));
 			v[k + 1] = mk2<T>(u2f(t.z), u2f(t.w));
 		}
@@ -136,12 +104,12 @@ template <int K, typename T>
 __device__ __forceinline__ void bstore_bins(rsrc_t r, unsigned voff, unsigned soff, const T (&v)[K]) {
 	if constexpr (K == 1) {
 		u2v t = {f2u(v[0].x), f2u(v[0].y)};
-		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, AEC_TICK_AUX_ST);
+		__builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
 	} else {
 #pragma unroll
 		for (int k = 0; k < K; k += 2) {
 			u4v t = {f2u(v[k].x), f2u(v[k].y), f2u(v[k + 1].x), f2u(v[k + 1].y)};
-			__builtin_amdgcn_raw_buffer_store_b128(t, r, voff + 8 * k, soff, AEC_TICK_AUX_ST);
+			__builtin_amdgcn_raw_buffer_store_b128(t, r, voff + 8 * k, soff, 0);
 		}
 	}
 }
@@ -173,10 +141,6 @@ __device__ __forceinline__ void bstore_vec(rsrc_t r, unsigned voff, unsigned sof
 // acc += x w, bin by bin; bin 0 (lane 0's first) holds (DC, Nyquist): two real products there
 template <int K, typename TA, typename TX, typename TW>
 __device__ __forceinline__ void cmac_bins(TA (&acc)[K], const TX (&x)[K], const TW (&w)[K], int e0) {
-#ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: one add per 16-byte load keeps the loads alive */
-	for (int k = 0; k < K; k += 2) acc[k].x += x[k].x + w[k].x;
-	return;
-#endif
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
 		const v2f xv = {x[k].x, x[k].y}, wv = {w[k].x, w[k].y};
@@ -190,29 +154,8 @@ __device__ __forceinline__ void cmac_bins(TA (&acc)[K], const TX (&x)[K], const 
 	}
 }
 
-#ifndef AEC_TICK_OCC256
-#define AEC_TICK_OCC256 2
-#endif
-#ifdef AEC_PROF_TIMING /* dev builds: shader-clock stamps at the phase boundaries, one row of 16 per stream (mi_aec_debug_profile) */
-#define PROF(i)                                                                                         \
-	do {                                                                                                \
-		if (a.prof && threadIdx.x == 0) a.prof[(size_t)(a.first + blockIdx.x) * 16 + (i)] = wall_clock64(); \
-	} while (0)
-#else
-#define PROF(i) ((void)0)
-#endif
-#if defined(AEC_PROF_TIMING) && defined(AEC_PROF_TAIL) /* the same slots, stamps inside the post-filter tail of the last frame */
-#undef PROF
-#define PROF(i) ((void)0)
-#define PROFT(i)                                                                                        \
-	do {                                                                                                \
-		if (a.prof && threadIdx.x == 0) a.prof[(size_t)(a.first + blockIdx.x) * 16 + (i)] = wall_clock64(); \
-	} while (0)
-#else
-#define PROFT(i) ((void)0)
-#endif
 template <int F>
-__global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
+__global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
 	using SL = TickLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
@@ -253,7 +196,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			return true;
 		};
 		int rlen = a.ref_len ? a.ref_len[s] : a.tick_len; // the far end's block may be missing or short this tick
-		rlen = rlen < 0 ? 0 : (rlen > a.tick_len ? a.tick_len : rlen) / K * K;
+		rlen = rlen < 0 ? 0 : (rlen > a.tick_len ? a.tick_len : rlen);
 		mic_new = append(a.fmic, qm, a.mic_tick + (size_t)s * a.mic_tick_stride, a.tick_len);
 		ref_new = append(a.fref, qr, a.ref_tick + (size_t)s * a.ref_tick_stride, rlen);
 		if (!ref_new) rlen = 0;
@@ -306,7 +249,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		while (tail >= (unsigned)a.fout.cap) tail -= (unsigned)a.fout.cap;
 		return a.fout.ring + (size_t)s * a.fout.cap + tail + e0; // K samples never wrap
 	};
-	PROF(0); // FIFOs done
 	const int M = a.M;
 	float *sm = a.small + (size_t)s * a.small_stride;
 	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
@@ -317,14 +259,12 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	AecScalars sc = a.scal[s];
 
 	// ---- tables, per-block step / norm, the per-bin state that stays in registers for the whole tick
-#if !AEC_TICK_GLOBAL_TABLES
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
 		L.tw[e0 + k] = a.t.tw[e0 + k];
 		L.super[e0 + k] = a.t.super[e0 + k];
 		L.perm[e0 + k] = a.t.perm[e0 + k];
 	}
-#endif
 	if (lane < M) {
 		L.prop[lane] = sm[SL::PROP + lane];
 		L.wnorm[lane] = sm[SL::WNORM + lane];
@@ -364,7 +304,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		WSYNC();
 		store_vec<K>(L.tbuf + e0, xp);
 		store_vec<K>(L.tbuf + F + e0, xn);
-		w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, X0);
+		w_rfft_forward<F>(L, a.t, X0);
 	};
 
 	float2 X0[K], X0B[K]; // far-end spectrum of the frame at hand / of the frame behind it
@@ -391,9 +331,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	float leakf[2] = {sc.leak_estimate, sc.leak_estimate}; // leak estimate after each frame (post-filter input)
 	bool resetf[2] = {false, false};                       // the frame reset the canceller: its echo estimate is zero
 
-	PROF(1); // state loaded, far-end spectra of both frames ready
 	for (int f = 0; f < nf; ++f) {
-		PROF(2 + 5 * f); // frame start
 		// Frame 2's first blocks are asked for NOW (frame 1's pass wrote them long ago): the notch and the proportional step
 		// below -- 5 us of serial chains that touch no HBM -- cover their round trip.  (Not frame 1's: with the far-end
 		// spectra of both frames and the speculation accumulators live, the 24 registers spill; measured, no gain.)
@@ -474,10 +412,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 
 		// W += prop p1 conj(X) E, bin by bin (weighted_spectral_mul_conj); bin 0 = (DC, Nyquist): real products with their own steps
 		auto grad = [&](auto (&w)[K], const auto (&x)[K], float prop) {
-#ifdef AEC_PROF_NO_STREAM_MATH /* dev profiling only: the streaming pass without its arithmetic (every load still consumed) */
-			for (int k = 0; k < K; k += 2) w[k].x += x[k].x * prop;
-			return;
-#endif
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
 				const v2f xv = {x[k].x, x[k].y}, ev = {Eprev[k].x, Eprev[k].y};
@@ -500,12 +434,12 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			float2 w[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) w[k] = make_float2(wv[k].x, wv[k].y);
-			w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w);
+			w_rfft_inverse<F>(L, a.t, w);
 			float z[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) z[k] = 0.f;
 			store_vec<K>(w_time(L) + F + e0, z);
-			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, w, w_time(L));
+			w_rfft_forward<F>(L, a.t, w, w_time(L));
 #pragma unroll
 			for (int k = 0; k < K; ++k) wv[k].x = w[k].x, wv[k].y = w[k].y;
 		};
@@ -519,10 +453,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			nn = wave_tree(nn, [](float x, float y) { return x + y; });
 			if (lane == 0) L.wnorm[j] = nn; // feeds the NEXT frame's proportional step
 		};
-		PROF(3 + 5 * f); // notch, ring store, proportional step done: the pass starts
-#if AEC_TICK_PRIO
-		__builtin_amdgcn_s_setprio(AEC_TICK_PRIO);
-#endif
 		if (f == 0) {
 			// frame 1: X, foreground and background; with a second frame behind it also that frame's foreground response
 			const bool spec = nf > 1;
@@ -596,18 +526,14 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			pendingFG = false;
 		}
 
-		PROF(4 + 5 * f); // the pass is over
-#if AEC_TICK_PRIO
-		__builtin_amdgcn_s_setprio(0);
-#endif
 		// ---- time-domain responses
 		float efg[K], ybg[K], e1[K], e2[K], dresp[K], input[K];
-		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, yfg);
+		w_rfft_inverse<F>(L, a.t, yfg);
 		load_vec<K>(w_time(L) + F + e0, efg);
 		load_vec<K>(L.input + e0, input);
 #pragma unroll
 		for (int k = 0; k < K; ++k) e1[k] = input[k] - efg[k];
-		w_rfft_inverse<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, ybgs);
+		w_rfft_inverse<F>(L, a.t, ybgs);
 		load_vec<K>(w_time(L) + F + e0, ybg);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -667,7 +593,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 		}
 
-		PROF(5 + 5 * f); // responses, two-path control done
 		// ---- output (serial de-emphasis) and correlations
 		int out_i[K];
 		{
@@ -691,10 +616,10 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			WSYNC();
 			store_vec<K>(L.tbuf + e0, z);
 			store_vec<K>(L.tbuf + F + e0, e2);
-			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, Ecur);
+			w_rfft_forward<F>(L, a.t, Ecur);
 			store_vec<K>(L.tbuf + e0, z);
 			store_vec<K>(L.tbuf + F + e0, ybg);
-			w_rfft_forward<F, AEC_TICK_GLOBAL_TABLES != 0>(L, a.t, Ycur);
+			w_rfft_forward<F>(L, a.t, Ycur);
 		}
 		float Rf[K], Yf[K], Rf_F = 0, Yf_F = 0;
 #pragma unroll
@@ -874,9 +799,7 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 #pragma unroll
 		for (int k = 0; k < K; ++k) X0[k] = X0B[k]; // the frame behind this one, if any
 		Sxx = SxxB;
-		PROF(6 + 5 * f); // frame end (spectra, power, adaptation)
 	}
-	PROF(12); // both frames done
 
 	// ---- the tick's state back to HBM, once
 	bstore_bins<K>(rS, vb8, SL::E * 4, Eprev);
@@ -919,7 +842,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	WSYNC(); // the parked arrays are re-used from here on
 
 	// per-bin state of the tick, in registers
-	PROFT(0);
 	float en[K], inb[K], S[K], Smin[K], Stmp[K], noise[K], old_ps[K], zeta[K], ob[K], wl[K], wr[K], h0[K], h1[K], w0[K], w1[K];
 	bload_vec<K>(rS, vb4, SL::ECHON * 4, en);
 	bload_vec<K>(rS, vb4, SL::INBUF * 4, inb);
@@ -946,7 +868,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	float *lvec = L.vec();
 
 	for (int f = 0; f < nf; ++f) {
-		PROFT(1); // tail frame start (the first frame's includes the wait for the state loads)
 		sc.nb_adapt++;
 		if (sc.nb_adapt > 20000) sc.nb_adapt = 20000;
 		sc.min_count++;
@@ -969,7 +890,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 		}
 		float2 Yr[K];
 		w_rfft_forward<F>(L, a.t, Yr);
-		PROFT(2); // residual-echo transform done
 		const float leak2 = (leak > .5) ? 1.f : 2 * leak;
 		float res[K];
 #pragma unroll
@@ -1001,11 +921,8 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			store_vec<K>(L.tbuf + e0, a0);
 			store_vec<K>(L.tbuf + F + e0, a1);
 		}
-		PROFT(3);
-		PROFT(4);
 		float2 ft[K];
 		w_rfft_forward<F>(L, a.t, ft);
-		PROFT(5); // analysis transform
 		float ps[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -1015,7 +932,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			L.tbuf[F + e0 + k] = wr[k] * ps[k]; // products wait there (left halves, right halves) for the fused band sums
 		}
 		WSYNC();
-		PROFT(6);
 		// update_noise_prob
 		int min_range;
 		if (sc.nb_adapt < 100) min_range = 15;
@@ -1050,12 +966,10 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 				np[F + e0 + k] = wr[k] * noise[k];
 			}
 			WSYNC();
-			PROFT(7); // noise update
 			// echo estimate (products in L.spec since the start of the frame), frame, noise: three band sums in one loop
 			if (lane < NB_BANDS) band_sum3<F>(a.t, lane, L.spec, L.tbuf, np, bandv[lane], bandv[NB_BANDS + lane], bandv[2 * NB_BANDS + lane]);
 		}
 		WSYNC();
-		PROFT(8); // the three band sums
 
 		auto snr = [&](float psv, float noisev, float echov, float oldps, float &post, float &prior) {
 			const float tot_noise = 1.f + noisev + echov + 0.f;
@@ -1087,7 +1001,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			else zeta[k] = .7f * zeta[k] + .15f * prior[k] + .075f * lvec[b - 1] + .075f * lvec[b + 1];
 		}
 		if (lane < NB_BANDS) zeta_b = .7f * zeta_b + .3f * prior_b;
-		PROFT(9); // a-priori / a-posteriori SNR, zeta
 		float Zframe = 0;
 #pragma unroll
 		for (int i = 0; i < NB_BANDS; ++i) Zframe = Zframe + rdlane(zeta_b, i);
@@ -1112,7 +1025,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			bandv[2 * NB_BANDS + lane] = gfloor;
 		}
 		WSYNC();
-		PROFT(10); // band gains (exp, hypergeometric gain in double)
 		float gain2[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -1137,7 +1049,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			const float tmp = p * sqrt_via_double(gain) + (1.0f - p) * sqrt_via_double(gfl);
 			gain2[k] = tmp * tmp;
 		}
-		PROFT(11); // per-bin gains
 		const float g_last = rdlane(gain2[K - 1], 63); // gain2[F-1] scales the Nyquist term
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -1161,7 +1072,6 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 			}
 		}
 		WSYNC();
-		PROFT(12); // synthesis transform, overlap-add, output
 	}
 
 	bstore_vec<K>(rS, vb4, SL::ECHON * 4, en);
@@ -1179,6 +1089,4 @@ __global__ __launch_bounds__(64, (F == 256 ? AEC_TICK_OCC256 : (F == 128 ? 3 : 4
 	}
 
 	if (lane == 0) a.scal[s] = sc;
-	PROF(13); // post-filter tail and state stores issued
-	PROFT(13);
 }

@@ -31,25 +31,20 @@ struct alignas(16) WLds {
 template <typename LT>
 __device__ __forceinline__ float *w_time(LT &L) { return reinterpret_cast<float *>(L.zbuf); }
 
-// GT = true: twiddles / super-twiddles / digit permutation are read from the device-wide tables in global memory (L1 / L2
-// resident: 4.5 KB shared by every wave) instead of a per-wave LDS copy -- frees that much LDS per wave.
-template <int F, bool GT = false, typename LT>
+template <int F, typename LT>
 __device__ void w_cfft(LT &L, const AecTables &T, const float2 *src, bool inverse) {
 	constexpr int K = F / 64;
 	const int lane = threadIdx.x;
 	float2 val[K];
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
-		if constexpr (GT) val[k] = src[T.perm[lane * K + k]];
-		else val[k] = src[L.perm[lane * K + k]];
+		val[k] = src[L.perm[lane * K + k]];
 	}
 	// The deepest stage (m = 1) of lane i works on elements i p .. i p + p - 1: with K = p those are the K values the lane has
 	// just gathered, so the stage runs in registers (same expressions, twiddle tw[0]) and one LDS round trip is gone.
 	constexpr bool kRegStage0 = (K == plan_p(F, 0));
 	if constexpr (kRegStage0) {
-		float2 w0;
-		if constexpr (GT) w0 = T.tw[0];
-		else w0 = L.tw[0];
+		float2 w0 = L.tw[0];
 		if (inverse) w0.y = -w0.y;
 		if constexpr (K == 2) {
 			const float2 t = cmulf(val[1], w0);
@@ -91,18 +86,14 @@ __device__ void w_cfft(LT &L, const AecTables &T, const float2 *src, bool invers
 			const int i = lane / m, j = lane - i * m;
 			float2 *Fo = L.zbuf + i * (p * m) + j;
 			if (p == 2) {
-				float2 w;
-				if constexpr (GT) w = T.tw[j * fs];
-				else w = L.tw[j * fs];
+				float2 w = L.tw[j * fs];
 				if (inverse) w.y = -w.y;
 				const float2 t = cmulf(Fo[m], w);
 				const float2 a = Fo[0];
 				Fo[m] = make_float2(a.x - t.x, a.y - t.y);
 				Fo[0] = make_float2(a.x + t.x, a.y + t.y);
 			} else {
-				float2 w1, w2, w3;
-				if constexpr (GT) w1 = T.tw[j * fs], w2 = T.tw[j * fs * 2], w3 = T.tw[j * fs * 3];
-				else w1 = L.tw[j * fs], w2 = L.tw[j * fs * 2], w3 = L.tw[j * fs * 3];
+				float2 w1 = L.tw[j * fs], w2 = L.tw[j * fs * 2], w3 = L.tw[j * fs * 3];
 				if (inverse) {
 					w1.y = -w1.y;
 					w2.y = -w2.y;
@@ -136,20 +127,13 @@ __device__ void w_cfft(LT &L, const AecTables &T, const float2 *src, bool invers
 
 // L.tbuf (2F time samples) -> this lane's K bins, scaled 1/N.  Bin 0 = (DC, Nyquist).
 // src: the 2F time samples -- L.tbuf (the default) or L.zbuf, where the inverse transform leaves its result
-template <int F, bool GT = false, typename LT>
+template <int F, typename LT>
 __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64], const float *src = nullptr) {
 	if (src == nullptr) src = L.tbuf;
-#ifdef AEC_PROF_NO_FFT /* dev profiling only (scripts/aec_phase_probe.sh): the kernel without the transforms' work -- the
-                          data still flows (every value defined, nothing downstream becomes dead code), the results are wrong */
-	WSYNC();
-	for (int k = 0; k < F / 64; ++k) out[k] = make_float2(src[threadIdx.x * (F / 64) + k], src[F + threadIdx.x * (F / 64) + k]);
-	WSYNC();
-	return;
-#endif
 	constexpr int K = F / 64;
 	const int lane = threadIdx.x;
 	WSYNC();
-	w_cfft<F, GT>(L, T, reinterpret_cast<const float2 *>(src), false);
+	w_cfft<F>(L, T, reinterpret_cast<const float2 *>(src), false);
 	const float scale = 1.f / (2 * F);
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
@@ -162,9 +146,7 @@ __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64],
 			const bool upper = b >= F - b; // bins >= F/2 take the "F-kk" formulas (F/2 itself: the later write)
 			const int kk = upper ? F - b : b;
 			const float2 a = L.zbuf[kk], c = L.zbuf[F - kk];
-			float2 sw;
-			if constexpr (GT) sw = T.super[kk];
-			else sw = L.super[kk];
+			const float2 sw = L.super[kk];
 			// f1 = (a.x + c.x, a.y - c.y), f2 = (a.x - c.x, a.y + c.y), tw = f2 sw; lower bins (f1 + tw) / 2, upper bins
 			// (f1.x - tw.x, tw.y - f1.y) / 2: the upper form is the lower one with the signs of f1.y and tw.x flipped (exact)
 			const v2f av = {a.x, a.y}, cv = {c.x, c.y};
@@ -183,14 +165,8 @@ __device__ void w_rfft_forward(LT &L, const AecTables &T, float2 (&out)[F / 64],
 }
 
 // this lane's K bins -> 2F time samples in w_time(L), unscaled
-template <int F, bool GT = false, typename LT>
+template <int F, typename LT>
 __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F / 64]) {
-#ifdef AEC_PROF_NO_FFT
-	WSYNC();
-	for (int k = 0; k < F / 64; ++k) w_time(L)[threadIdx.x * (F / 64) + k] = in[k].x, w_time(L)[F + threadIdx.x * (F / 64) + k] = in[k].y;
-	WSYNC();
-	return;
-#endif
 	constexpr int K = F / 64;
 	const int lane = threadIdx.x;
 	WSYNC();
@@ -215,9 +191,7 @@ __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F /
 			// imaginary part of the result negated (sign flips: exact)
 			const v2f fk = {L.spec[2 * kk], L.spec[2 * kk + 1]};
 			const v2f s2 = {L.spec[2 * (F - kk)], L.spec[2 * (F - kk) + 1]};
-			float2 sw;
-			if constexpr (GT) sw = T.super[kk];
-			else sw = L.super[kk];
+			const float2 sw = L.super[kk];
 			const v2f sv = {sw.x, sw.y};
 			v2f fek, d, p, q, fok;
 			asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(fek) : "v"(fk), "v"(s2)); // (fk.x + s2.x, fk.y - s2.y)
@@ -237,7 +211,7 @@ __device__ void w_rfft_inverse(LT &L, const AecTables &T, const float2 (&in)[F /
 #pragma unroll
 	for (int k = 0; k < K; ++k) tmp[lane * K + k] = t[k];
 	WSYNC();
-	w_cfft<F, GT>(L, T, tmp, true); // ends with an LDS fence: the 2F time samples are in L.zbuf (see w_time)
+	w_cfft<F>(L, T, tmp, true); // ends with an LDS fence: the 2F time samples are in L.zbuf (see w_time)
 }
 
 

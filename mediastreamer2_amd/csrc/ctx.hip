@@ -33,6 +33,11 @@ extern "C" {
 int mi_abi_version(void) { return MSMI355X_ABI_VERSION; }
 const char *mi_last_error(void) { return mi::g_err; }
 
+int mi_device_count(void) {
+	int ndev = 0;
+	return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+}
+
 int mi_ctx_create(int device, void *hip_stream, mi_ctx **out) {
 	MI_CHECK_ARG(out != nullptr);
 	*out = nullptr;
@@ -87,6 +92,7 @@ void mi_ctx_destroy(mi_ctx *c) {
 
 int mi_ctx_sync(mi_ctx *c) {
 	MI_CHECK_ARG(c != nullptr);
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(c->stream));
 	return MI_OK;
 }
@@ -130,23 +136,27 @@ void *mi_host_alloc(mi_ctx *c, size_t bytes) {
 
 void mi_host_free(mi_ctx *c, void *p) {
 	if (!c || !p) return;
+	(void)hipSetDevice(c->device);
 	(void)hipHostFree(p);
 }
 
 int mi_copy_h2d(mi_ctx *c, void *d, const void *h, size_t n) {
 	MI_CHECK_ARG(c && d && h);
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, c->stream));
 	return MI_OK;
 }
 
 int mi_copy_d2h(mi_ctx *c, void *h, const void *d, size_t n) {
 	MI_CHECK_ARG(c && d && h);
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
 	return MI_OK;
 }
 
 int mi_memset(mi_ctx *c, void *d, int value, size_t n) {
 	MI_CHECK_ARG(c && d);
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipMemsetAsync(d, value, n, c->stream));
 	return MI_OK;
 }
@@ -161,6 +171,7 @@ int mi_ctx_capture_begin(mi_ctx *c) {
 int mi_ctx_capture_end(mi_ctx *c, mi_graph **out) {
 	MI_CHECK_ARG(c && out);
 	*out = nullptr;
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	hipGraph_t graph = nullptr;
 	MI_HIP(hipStreamEndCapture(c->stream, &graph));
 	mi_graph *g = new mi_graph();
@@ -179,12 +190,14 @@ int mi_ctx_capture_end(mi_ctx *c, mi_graph **out) {
 
 int mi_graph_launch(mi_graph *g) {
 	MI_CHECK_ARG(g != nullptr);
+	if (g->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
 	return MI_OK;
 }
 
 void mi_graph_destroy(mi_graph *g) {
 	if (!g) return;
+	(void)hipSetDevice(g->ctx->device);
 	if (g->exec) (void)hipGraphExecDestroy(g->exec);
 	if (g->graph) (void)hipGraphDestroy(g->graph);
 	delete g;
@@ -192,12 +205,14 @@ void mi_graph_destroy(mi_graph *g) {
 
 int mi_timer_start(mi_ctx *c) {
 	MI_CHECK_ARG(c != nullptr);
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipEventRecord(c->ev0, c->stream));
 	return MI_OK;
 }
 
 int mi_timer_stop(mi_ctx *c, float *ms) {
 	MI_CHECK_ARG(c && ms);
+	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipEventRecord(c->ev1, c->stream));
 	MI_HIP(hipEventSynchronize(c->ev1));
 	MI_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));

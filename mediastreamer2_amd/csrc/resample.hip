@@ -917,6 +917,7 @@ void mi_resampler_destroy(mi_resampler *r) {
 int mi_resampler_reset(mi_resampler *r, int first, int count) {
 	MI_CHECK_ARG(r && first >= 0 && count >= 0 && first + count <= r->nstreams);
 	if (count == 0) return MI_OK;
+	if (r->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipMemsetAsync(r->d_hist + (size_t)first * r->hist_stride, 0,
 	                      (size_t)count * r->hist_stride * sizeof(int16_t), r->ctx->stream));
 	hipLaunchKernelGGL(fill_pos_kernel, dim3(mi::ceil_div(count, 256)), dim3(256), 0, r->ctx->stream, r->d_pos,

@@ -50,11 +50,6 @@ struct mi_session {
 	bool acquired = false;
 	// conference membership / active-speaker election (MSAudioConference, src/voip/audioconference.c)
 	std::vector<uint8_t> flags;      // MI_MIX_* per stream as last set (default: every pin linked, active, output on)
-	struct Window {                   // OrtpExtremum with a 1000 ms period, the window behind MS_VOLUME_GET_MAX (msvolume.c:115,:143-148)
-		float current = 0;
-		long long t0 = -1;
-	};
-	std::vector<Window> level_max;
 };
 
 namespace {
@@ -187,7 +182,6 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	s->n = cfg->nstreams;
 	s->nconf = cfg->nstreams / cfg->members_per_conference;
 	s->flags.assign((size_t)s->n, (uint8_t)(MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT));
-	s->level_max.assign((size_t)s->n, mi_session::Window());
 	s->in_len = cfg->in_rate / 100;
 	s->len = cfg->rate / 100;
 	const bool down = cfg->out_rate != 0 && cfg->out_rate != cfg->rate;
@@ -415,7 +409,6 @@ int mi_session_add_member(mi_session *s, int stream) {
 	const int rc = mi_session_reset_streams(s, stream, 1);
 	if (rc != MI_OK) return rc;
 	s->flags[(size_t)stream] = MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT;
-	s->level_max[(size_t)stream] = mi_session::Window();
 	return mi_mixer_set_controls(s->mix, s->flags.data(), nullptr);
 }
 
@@ -430,6 +423,7 @@ int mi_session_remove_member(mi_session *s, int stream) {
 	s->flags[(size_t)stream] = 0;
 	const int rc = mi_mixer_set_controls(s->mix, s->flags.data(), nullptr);
 	if (rc != MI_OK) return rc;
+	if (s->ctx->activate() != MI_OK) return MI_ENODEV;
 	// the mixer leaves an unplumbed pin's row alone: what the departed leg last heard must not linger in the buffers
 	MI_HIP(hipStreamSynchronize(s->ctx->stream));
 	if (s->s_down) MI_HIP(hipStreamSynchronize(s->s_down));
@@ -454,21 +448,11 @@ int mi_session_member_count(const mi_session *s, int conference) {
 // dBm0 -- is the largest and above -30 dB (audioconference.c:31).  now_ms: the caller's clock (the ticker's time).
 int mi_session_active_speakers(mi_session *s, uint64_t now_ms, int32_t *h_winner, float *h_max_db) {
 	MI_CHECK_ARG(s && h_winner);
-	std::vector<mi_volume_state> st((size_t)s->n);
-	const int rc = mi_volume_get_state(s->vol, 0, s->n, st.data());
+	(void)now_ms; // the windows run on the device, one record per tick (msvolume.c:404)
+	std::vector<float> mx((size_t)s->n);
+	const int rc = mi_volume_get_max(s->vol, 0, s->n, mx.data());
 	if (rc != MI_OK) return rc;
 	const int mm = s->cfg.members_per_conference;
-	for (int i = 0; i < s->n; ++i) { // ortp_extremum_record_max, period 1000 ms
-		mi_session::Window &w = s->level_max[(size_t)i];
-		const float v = st[(size_t)i].energy;
-		if (w.t0 != -1 && (long long)now_ms - w.t0 > 1000) w.t0 = -1;
-		if (w.t0 == -1) {
-			w.current = v;
-			w.t0 = (long long)now_ms;
-		} else if (v > w.current) {
-			w.current = v;
-		}
-	}
 	for (int c = 0; c < s->nconf; ++c) {
 		float best = -120.f; // MS_VOLUME_DB_LOWEST
 		int win = -1;
@@ -476,7 +460,7 @@ int mi_session_active_speakers(mi_session *s, uint64_t now_ms, int32_t *h_winner
 			const size_t i = (size_t)c * mm + m;
 			const uint8_t f = s->flags[i];
 			if (!(f & MI_MIX_LINKED) || !(f & MI_MIX_ACTIVE)) continue; // not plumbed / muted (:445)
-			const float lin = s->level_max[i].current;
+			const float lin = mx[i];
 			const float db = lin == 0 ? -120.f : 10 * log10f(lin); // ms_volume_linear_to_dbm0 msvolume.c:565-568
 			if (db > -30.0f && db > best) best = db, win = (int)i;
 		}
@@ -492,6 +476,7 @@ int mi_session_reset_streams(mi_session *s, int first, int count) {
 	MI_CHECK_ARG(s && first >= 0 && count >= 0 && first + count <= s->n);
 	if (count == 0) return MI_OK;
 	int rc;
+	if (s->ctx->activate() != MI_OK) return MI_ENODEV;
 	if (s->rs && (rc = mi_resampler_reset(s->rs, first, count)) != MI_OK) return rc;
 	if ((rc = mi_aec_reset(s->aec, first, count)) != MI_OK) return rc;
 	mi_volume_state st;
@@ -500,6 +485,7 @@ int mi_session_reset_streams(mi_session *s, int first, int count) {
 	st.ng_gain = 1;               // :112
 	std::vector<mi_volume_state> all((size_t)count, st);
 	if ((rc = mi_volume_set_state(s->vol, first, count, all.data())) != MI_OK) return rc;
+	if ((rc = mi_volume_reset_max(s->vol, first, count)) != MI_OK) return rc;
 	if ((rc = mi_fifo_reset_range(s->f_mic, first, count)) != MI_OK || (rc = mi_fifo_reset_range(s->f_ref, first, count)) != MI_OK ||
 	    (rc = mi_fifo_reset_range(s->f_out, first, count)) != MI_OK)
 		return rc;

@@ -40,6 +40,10 @@ struct VolArgs {
 	const int *parity; // which of the two holds the previous launch's values; flipped on the device after each launch,
 	                   // so a captured hipGraph replays correctly (a host-side flip would be frozen into the graph)
 	int nstreams, nsamples, stride, sample_rate, pitch_dw, pitch_f;
+	// the one-second maximum of the smoothed energy behind MS_VOLUME_GET_MAX (ortp_extremum_record_max on every
+	// process(), msvolume.c:115,:404): x = current maximum, y = ms since the window started (< 0: not started).  The
+	// stream's own chunks are its clock, as the ticker's time is the filter's (one chunk per tick).
+	float2 *win;
 	// src.ring != NULL: the chunk is popped from a device FIFO (all-or-nothing, zeros when it holds less: what
 	// mi_fifo_pop(..., zero_fill) delivers) and the result is written to `samples` -- no separate pop launch, no copy
 	FifoView src;
@@ -105,11 +109,26 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 				on[u] = i <= last;
 				if (!from_fifo) {
 					v[u] = *reinterpret_cast<const uint4 *>(a.samples + (size_t)(s0 + sl[u]) * a.stride + 8 * q[u]);
-				} else { // ring capacity and head are multiples of 8 (checked by the caller): a group never wraps
+				} else {
+					// the ring's capacity is a multiple of 8 (checked by the caller); while its head is one too -- every FIFO that is
+					// only ever popped in chunks like this one -- a group is one aligned load that never wraps.  A head left
+					// elsewhere by a pop of another size (mi_fifo_pop / _pop_frames allow any) takes the samples one by one.
 					const int h = s_head[sl[u]];
 					unsigned at = (unsigned)(h < 0 ? 0 : h) + 8u * (unsigned)q[u];
 					if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
-					v[u] = *reinterpret_cast<const uint4 *>(a.src.ring + (size_t)(s0 + sl[u]) * a.src.cap + at);
+					const int16_t *ring = a.src.ring + (size_t)(s0 + sl[u]) * a.src.cap;
+					if ((h & 7) == 0 || h < 0) {
+						v[u] = *reinterpret_cast<const uint4 *>(ring + (at & ~7u));
+					} else {
+						unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+						for (int k = 0; k < 8; ++k) {
+							unsigned p = at + (unsigned)k;
+							if (p >= (unsigned)a.src.cap) p -= (unsigned)a.src.cap;
+							w[k >> 1] |= (unsigned)(uint16_t)ring[p] << (16 * (k & 1));
+						}
+						v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+					}
 					if (h < 0) v[u] = make_uint4(0, 0, 0, 0);
 				}
 			}
@@ -252,6 +271,16 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 		}
 		a.state[s] = st;
 		a.energy[*a.parity ^ 1][s] = st.energy;
+		{ // ortp_extremum_record_max(&v->max, curtime, v->energy), period 1000 ms
+			float2 w = a.win[s];
+			if (w.y >= 0) {
+				w.y += (float)((n * 1000) / a.sample_rate);
+				if (w.y > 1000.f) w.y = -1.f; // (int)(now - start) > period: the old maximum is dropped
+			}
+			if (w.y < 0) w = make_float2(st.energy, 0.f);
+			if (st.energy > w.x) w.x = st.energy;
+			a.win[s] = w;
+		}
 	} else if (tid < SPB) {
 		s_mode[tid] = 0;
 		if (tid < nloc) a.energy[*a.parity ^ 1][s0 + tid] = a.state[s0 + tid].energy;
@@ -313,6 +342,7 @@ struct mi_volume {
 	int nstreams = 0, sample_rate = 0;
 	mi_volume_params *d_params = nullptr;
 	mi_volume_state *d_state = nullptr;
+	float2 *d_win = nullptr;
 	float *d_energy[2] = {nullptr, nullptr};
 	int *d_parity = nullptr;
 	bool has_peers = false; // conservative: set once any stream names a peer
@@ -349,7 +379,8 @@ int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out
 	    hipMalloc((void **)&v->d_state, sizeof(mi_volume_state) * (size_t)nstreams) != hipSuccess ||
 	    hipMalloc((void **)&v->d_energy[0], sizeof(float) * (size_t)nstreams) != hipSuccess ||
 	    hipMalloc((void **)&v->d_energy[1], sizeof(float) * (size_t)nstreams) != hipSuccess ||
-	    hipMalloc((void **)&v->d_parity, sizeof(int)) != hipSuccess) {
+	    hipMalloc((void **)&v->d_parity, sizeof(int)) != hipSuccess ||
+	    hipMalloc((void **)&v->d_win, sizeof(float2) * (size_t)nstreams) != hipSuccess) {
 		mi::set_error("hipMalloc failed for volume state");
 		mi_volume_destroy(v);
 		return MI_ENOMEM;
@@ -366,7 +397,7 @@ int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out
 	    hipMemcpy(v->d_state, hs.data(), sizeof(ds) * hs.size(), hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemset(v->d_energy[0], 0, sizeof(float) * (size_t)nstreams) != hipSuccess ||
 	    hipMemset(v->d_energy[1], 0, sizeof(float) * (size_t)nstreams) != hipSuccess ||
-	    hipMemset(v->d_parity, 0, sizeof(int)) != hipSuccess) {
+	    hipMemset(v->d_parity, 0, sizeof(int)) != hipSuccess || mi_volume_reset_max(v, 0, nstreams) != MI_OK) {
 		mi::set_error("volume state upload failed");
 		mi_volume_destroy(v);
 		return MI_ENODEV;
@@ -383,6 +414,7 @@ void mi_volume_destroy(mi_volume *v) {
 	if (v->d_energy[0]) (void)hipFree(v->d_energy[0]);
 	if (v->d_energy[1]) (void)hipFree(v->d_energy[1]);
 	if (v->d_parity) (void)hipFree(v->d_parity);
+	if (v->d_win) (void)hipFree(v->d_win);
 	delete v;
 }
 
@@ -418,6 +450,25 @@ int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_stat
 	return MI_OK;
 }
 
+int mi_volume_get_max(mi_volume *v, int first, int count, float *h_max) {
+	MI_CHECK_ARG(v && h_max && first >= 0 && count >= 0 && first + count <= v->nstreams);
+	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(v->ctx->stream));
+	std::vector<float2> w((size_t)count);
+	MI_HIP(hipMemcpy(w.data(), v->d_win + first, sizeof(float2) * (size_t)count, hipMemcpyDeviceToHost));
+	for (int i = 0; i < count; ++i) h_max[i] = w[(size_t)i].y < 0 ? 0.f : w[(size_t)i].x; // ortp_extremum_init: 0 before the first record
+	return MI_OK;
+}
+
+int mi_volume_reset_max(mi_volume *v, int first, int count) {
+	MI_CHECK_ARG(v && first >= 0 && count >= 0 && first + count <= v->nstreams);
+	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(v->ctx->stream));
+	std::vector<float2> w((size_t)count, make_float2(0.f, -1.f));
+	MI_HIP(hipMemcpy(v->d_win + first, w.data(), sizeof(float2) * (size_t)count, hipMemcpyHostToDevice));
+	return MI_OK;
+}
+
 static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src);
 
 int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples) {
@@ -445,6 +496,7 @@ static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int str
 	a.nsamples_per_stream = d_nsamples;
 	a.params = v->d_params;
 	a.state = v->d_state;
+	a.win = v->d_win;
 	a.energy[0] = v->d_energy[0];
 	a.energy[1] = v->d_energy[1];
 	a.parity = v->d_parity;

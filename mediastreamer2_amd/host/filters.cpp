@@ -131,7 +131,14 @@ struct Pool {
 struct TickerHub {
 	std::recursive_mutex mu;
 	MSTicker *ticker = nullptr;
+	// the hub's device context (HIP stream), opened by the first bank or scaler context on the least-loaded device of
+	// MSMI355X_DEVICES -- one mediastreamer2 process runs a ticker per stream / per conference (mediastream.c:237,
+	// audioconference.c:72), so its tickers spread over the node's GPUs; a hub that never gets a bank opens none
 	mi_ctx *ctx = nullptr;
+	int device = -1;
+	bool ctx_failed = false;
+	mi_ctx *ensure_ctx();
+	int pins = 0; // objects outside the banks that use `ctx` (MSScalerDesc contexts): the hub stays while there are any
 	std::vector<Pool *> pools;         // flush order = creation order
 	MSFilter *flush_owner = nullptr;   // the filter whose postponed task will flush this ticker's pools (NULL: none pending)
 	// chain linking: while the flush task runs, a facade that emits into a queue read by ANOTHER facade of this ticker has
@@ -140,7 +147,10 @@ struct TickerHub {
 	bool in_flush = false;
 	std::vector<MSFilter *> touched, touched_pumps;
 	std::unordered_map<MSFilter *, uint64_t> pumped; // pump facades run early by the flush task, and for which tick
-	bool dead = false;                 // no banks left: removed from the registry (read and written under `mu`)
+	// no banks left: removed from the registry.  Written under `mu` and the registry lock by a scope that holds a
+	// reference; atomic because the scope that drops the LAST reference re-reads it after its decrement (it may have
+	// sampled it before another scope retired the hub)
+	std::atomic<bool> dead{false};
 	// Scopes that hold or are about to take `mu`.  Taken under the registry lock (hub_for) or while a slot of the hub is
 	// held, so a hub found in the registry cannot be freed between the look-up and the lock; whoever drops the last
 	// reference of a dead hub deletes it.
@@ -157,7 +167,62 @@ struct FilterRef {
 };
 std::unordered_map<MSFilter *, FilterRef> g_filter_hubs; // the hub a filter holds slots in (it may be detached by now)
 thread_local TickerHub *tl_hub = nullptr;
-int g_device = 0;
+// devices the hubs are spread over: MSMI355X_DEVICES="0,1,.." (default: every visible device), or the one of the older
+// MSMI355X_DEVICE; g_device_hubs counts the live contexts per device
+std::vector<int> g_devices;
+std::atomic<int> g_device_hubs[64];
+std::atomic<unsigned> g_device_rr{0};
+
+void parse_devices() {
+	g_devices.clear();
+	const char *list = getenv("MSMI355X_DEVICES"), *one = getenv("MSMI355X_DEVICE");
+	if (list && *list) {
+		for (const char *p = list; *p;) {
+			char *end = nullptr;
+			const long v = strtol(p, &end, 10);
+			if (end == p) break;
+			if (v >= 0 && v < 64) g_devices.push_back((int)v);
+			p = (*end == ',') ? end + 1 : end;
+			if (*end != ',' ) break;
+		}
+	} else if (one && *one) {
+		g_devices.push_back(atoi(one));
+	}
+	if (g_devices.empty()) {
+		const int n = mi_device_count();
+		for (int i = 0; i < n && i < 64; ++i) g_devices.push_back(i);
+	}
+	if (g_devices.empty()) g_devices.push_back(0); // no device: mi_ctx_create reports it
+}
+
+mi_ctx *TickerHub::ensure_ctx() {
+	if (ctx || ctx_failed) return ctx;
+	if (g_devices.empty()) parse_devices();
+	// least-loaded device, ties broken round-robin (tickers come and go with the calls they serve)
+	const unsigned start = g_device_rr.fetch_add(1, std::memory_order_relaxed);
+	int best = g_devices[start % g_devices.size()];
+	for (size_t i = 0; i < g_devices.size(); ++i) {
+		const int d = g_devices[(start + i) % g_devices.size()];
+		if (g_device_hubs[d].load(std::memory_order_relaxed) < g_device_hubs[best].load(std::memory_order_relaxed)) best = d;
+	}
+	if (mi_ctx_create(best, nullptr, &ctx) != MI_OK) {
+		mi_failed("mi_ctx_create");
+		ctx = nullptr; // banks created on this hub fail at their first allocation and their filters fall back
+		ctx_failed = true;
+		return nullptr;
+	}
+	device = best;
+	g_device_hubs[best].fetch_add(1, std::memory_order_relaxed);
+	return ctx;
+}
+
+void destroy_hub(TickerHub *hub) { // the last scope of a retired hub
+	if (hub->ctx) {
+		mi_ctx_destroy(hub->ctx);
+		g_device_hubs[hub->device].fetch_sub(1, std::memory_order_relaxed);
+	}
+	delete hub;
+}
 
 TickerHub *hub_for(MSFilter *f, bool create) {
 	{
@@ -175,10 +240,6 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 	TickerHub *h = new TickerHub();
 	h->refs.fetch_add(1);
 	h->ticker = t;
-	if (mi_ctx_create(g_device, nullptr, &h->ctx) != MI_OK) {
-		mi_failed("mi_ctx_create");
-		h->ctx = nullptr; // banks created on this hub fail at their first allocation and their filters fall back
-	}
 	g_hubs[t] = h;
 	return h;
 }
@@ -187,11 +248,23 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 // current hub.  process() / preprocess() / the flush task run on the ticker thread; methods and uninit on any thread.
 struct HubLock {
 	TickerHub *h, *prev;
-	static void unref(TickerHub *hub, bool dead) { // `dead` as seen under the hub's lock
-		if (hub->refs.fetch_sub(1) == 1 && dead) {
-			if (hub->ctx) mi_ctx_destroy(hub->ctx);
-			delete hub;
-		}
+	// The decrement is acq_rel and `dead` is read AFTER it: whichever scope turns out to be the last one sees a retirement
+	// another scope carried out in between (a value sampled before the unlock could be stale, and then nobody deleted).
+	static void unref(TickerHub *hub) {
+		if (hub->refs.fetch_sub(1, std::memory_order_acq_rel) == 1 && hub->dead.load(std::memory_order_acquire)) destroy_hub(hub);
+	}
+	// A hub that holds no bank when its last scope ends (a filter at an unsupported configuration, a failed bank, a method
+	// call on a filter that never ran) must not stay in the registry with its HIP stream: retired here, under the hub's
+	// lock.  With the registry locked exclusively nobody can take a new reference (hub_for / referenced_hubs take theirs
+	// under it, the slot-based constructors need a bank), so refs == 1 means this scope is the only one.
+	static void retire_if_idle(TickerHub *hub) {
+		if (hub->dead.load(std::memory_order_relaxed) || !hub->pools.empty() || hub->pins > 0) return;
+		std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+		if (hub->refs.load(std::memory_order_acquire) != 1) return;
+		auto it = g_hubs.find(hub->ticker);
+		if (it != g_hubs.end() && it->second == hub) g_hubs.erase(it);
+		hub->flush_owner = nullptr;
+		hub->dead.store(true, std::memory_order_release);
 	}
 	explicit HubLock(MSFilter *f) : h(nullptr), prev(tl_hub) {
 		for (;;) { // hub_for hands the hub over with a reference taken under the registry lock
@@ -200,7 +273,7 @@ struct HubLock {
 			if (!h->dead) break;
 			// its last bank went between the look-up and the lock: it is out of the registry, look again (a new hub)
 			h->mu.unlock();
-			unref(h, true);
+			unref(h);
 		}
 		tl_hub = h;
 	}
@@ -216,7 +289,7 @@ struct HubLock {
 				h->mu.lock();
 				if (!h->dead) break;
 				h->mu.unlock();
-				unref(h, true);
+				unref(h);
 			}
 		}
 		tl_hub = h;
@@ -234,9 +307,9 @@ struct HubLock {
 	bool dead() const { return h->dead; } // the hub's last bank went before this scope got the lock: nothing to do on it
 	~HubLock() {
 		tl_hub = prev;
-		const bool dead = h->dead;
+		retire_if_idle(h);
 		h->mu.unlock();
-		unref(h, dead);
+		unref(h);
 	}
 	HubLock(const HubLock &) = delete;
 	HubLock &operator=(const HubLock &) = delete;
@@ -265,11 +338,11 @@ void Pool::release(int slot) {
 		if (h->ctx) mi_ctx_sync(h->ctx);
 		h->pools.erase(std::find(h->pools.begin(), h->pools.end(), this));
 		delete this;
-		if (h->pools.empty()) { // and with the last bank the hub (its stream): a ticker per call must not leak one
+		if (h->pools.empty() && h->pins == 0) { // and with the last bank the hub (its stream): a ticker per call must not leak one
 			std::unique_lock<std::shared_mutex> wl(g_registry_mu);
 			auto it = g_hubs.find(h->ticker);
 			if (it != g_hubs.end() && it->second == h) g_hubs.erase(it);
-			h->dead = true; // deleted by the HubLock that is on the stack
+			h->dead.store(true, std::memory_order_release); // deleted by the last HubLock scope to end
 			h->flush_owner = nullptr;
 		}
 	}
@@ -311,7 +384,7 @@ struct Building {
 		p->hub = tl_hub;
 		p->init_slots(cap);
 		tl_building = p;
-		if (!p->hub->ctx) p->failed = true;
+		if (!p->hub->ensure_ctx()) p->failed = true;
 	}
 	~Building() { tl_building = prev; }
 };
@@ -507,14 +580,13 @@ extern "C" {
 void libmsmi355xfilters_init(MSFactory *factory) {
 	// No usable HIP device: register NOTHING -- the reference's own CPU filters stay in charge (src/base/msfactory.c:281:
 	// registration prepends, so not registering is how a plugin steps aside).  There is no CPU path in this library.
-	const char *dev = getenv("MSMI355X_DEVICE");
-	g_device = dev ? atoi(dev) : 0;
+	parse_devices();
 	mi_ctx *probe = nullptr;
-	if (mi_ctx_create(g_device, nullptr, &probe) != MI_OK) {
+	if (mi_ctx_create(g_devices[0], nullptr, &probe) != MI_OK) {
 		// MSMI355X_REGISTER_WITHOUT_DEVICE=1: register all the same (descriptor inspection on a box without a GPU; every
 		// filter then passes through or drops, see the bank failure path)
 		if (!getenv("MSMI355X_REGISTER_WITHOUT_DEVICE")) {
-			ms_error("libmsmi355xfilters: no HIP device %d (%s): the MI355X filters are NOT registered", g_device, mi_last_error());
+			ms_error("libmsmi355xfilters: no HIP device %d (%s): the MI355X filters are NOT registered", g_devices[0], mi_last_error());
 			return;
 		}
 	} else {
@@ -532,7 +604,7 @@ void libmsmi355xfilters_init(MSFactory *factory) {
 	                        &ms_mi355x_generic_plc_desc})
 		ms_factory_register_filter(factory, d);
 	ms_video_set_scaler_impl(&ms_mi355x_scaler_desc); // msvideo.c:719-721: the reference's own video filters follow
-	ms_message("libmsmi355xfilters: MI355X batched filters registered (ABI %d)", mi_abi_version());
+	ms_message("libmsmi355xfilters: MI355X batched filters registered (ABI %d, %d device(s))", mi_abi_version(), (int)g_devices.size());
 }
 
 // every hub in the registry, each with a reference taken under the registry lock (to be adopted by a HubLock)
@@ -570,6 +642,18 @@ void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use) {
 	if (hubs) *hubs = nh;
 	if (banks) *banks = nb;
 	if (slots_in_use) *slots_in_use = ns;
+}
+
+// the device of every hub that has opened a context (tests: tickers spread over MSMI355X_DEVICES); returns their number
+int ms_mi355x_hub_devices(int *devices, int cap) {
+	int n = 0;
+	for (TickerHub *h : referenced_hubs()) {
+		HubLock lk(h, HubLock::Adopt{});
+		if (lk.dead() || !h->ctx) continue;
+		if (devices && n < cap) devices[n] = h->device;
+		++n;
+	}
+	return n;
 }
 
 void ms_mi355x_shutdown(void) {

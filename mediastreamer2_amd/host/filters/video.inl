@@ -35,6 +35,7 @@ struct ScalerCtx { // what MSScalerContext* points to
 	mi_scaler *sc = nullptr;
 	mi_pixconv *pc[2] = {nullptr, nullptr}; // [flip]
 	std::vector<uint8_t> packed_in, packed_out;
+	TickerHub *hub = nullptr; // the hub whose context the objects above were created on (pinned while this lives)
 };
 
 MSScalerContext *sd_create(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt df, int flags) {
@@ -44,7 +45,7 @@ MSScalerContext *sd_create(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt
 	c->sw = sw, c->sh = sh, c->dw = dw, c->dh = dh, c->sf = sf, c->df = df;
 	if (sf == MS_YUV420P) {
 		const int fmt = (df == MS_RGB24) ? MI_PIX_RGB24 : MI_PIX_I420;
-		if ((df != MS_RGB24 && df != MS_YUV420P) || !g_hub.ctx || mi_scaler_create(g_hub.ctx, sw, sh, dw, dh, fmt, &c->sc) != MI_OK) {
+		if ((df != MS_RGB24 && df != MS_YUV420P) || !g_hub.ensure_ctx() || mi_scaler_create(g_hub.ctx, sw, sh, dw, dh, fmt, &c->sc) != MI_OK) {
 			ms_error("msmi355x scaler: %dx%d fmt %d -> %dx%d fmt %d unsupported: %s", sw, sh, (int)sf, dw, dh, (int)df, mi_last_error());
 			delete c;
 			return NULL;
@@ -53,14 +54,19 @@ MSScalerContext *sd_create(int sw, int sh, MSPixFmt sf, int dw, int dh, MSPixFmt
 		ms_warning("msmi355x scaler: unsupported format %d or size change on a packed source", (int)sf); // msvideo.c:574-576
 		delete c;
 		return NULL;
+	} else if (!g_hub.ensure_ctx()) {
+		delete c;
+		return NULL;
 	}
+	c->hub = &g_hub;
+	g_hub.pins++;
 	return (MSScalerContext *)c;
 }
 
 int sd_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t *dst[], int dst_strides[]) {
 	ScalerCtx *c = (ScalerCtx *)ctx;
 	if (!c) return -1;
-	HubLock lk((MSFilter *)nullptr);
+	HubLock lk(c->hub);
 	if (c->sc) {
 		const uint8_t *sp[3] = {src[0], src[1], src[2]};
 		uint8_t *dp[3] = {dst[0], dst[1], dst[2]};
@@ -101,10 +107,11 @@ int sd_process(MSScalerContext *ctx, uint8_t *src[], int src_strides[], uint8_t 
 void sd_free(MSScalerContext *ctx) {
 	ScalerCtx *c = (ScalerCtx *)ctx;
 	if (!c) return;
-	HubLock lk((MSFilter *)nullptr);
+	HubLock lk(c->hub);
 	if (c->sc) mi_scaler_destroy(c->sc);
 	for (int i = 0; i < 2; ++i)
 		if (c->pc[i]) mi_pixconv_destroy(c->pc[i]);
+	c->hub->pins--; // the scope's end retires the hub if this was the last thing on it
 	delete c;
 }
 

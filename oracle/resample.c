@@ -26,7 +26,7 @@
 
 /* Kaiser window, beta = 8, sampled at x = (i-1)/32; the last two entries are
  * the library's guard values.  (Entries 0..33 equal I0(8*sqrt(1-x^2))/I0(8)
- * to 8 decimals -- checked in tests/test_oracle_resample.py.) */
+ * to 8 decimals -- checked in tests/test_oracle_cpu.py.) */
 static const double kaiser8_table[36] = {
     0.99635258, 1.00000000, 0.99635258, 0.98548012, 0.96759014, 0.94302200, 0.91223751, 0.87580811,
     0.83439927, 0.78875245, 0.73966538, 0.68797126, 0.63451750, 0.58014482, 0.52566725, 0.47185369,

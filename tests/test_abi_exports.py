@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     missing = [s for s in _header_symbols() if not hasattr(L, s)]
     assert not missing, f"libmsmi355x.so lacks {missing}"
-    assert L.mi_abi_version() == 1
+    assert L.mi_abi_version() == 3
 
 
 def test_library_is_in_tree_and_has_gfx950_code():

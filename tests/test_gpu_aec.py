@@ -260,98 +260,6 @@ def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
         x.close()
 
 
-@pytest.mark.parametrize("chunks", [2, 3, 8])
-def test_aec_chunked_post_filter_overlap_changes_nothing(ctx, chunks):
-    """mi_aec_set_overlap: the batch cut in chunks, each chunk's post-filter on a second HIP stream next to the following
-    chunk's canceller (the automatic schedule from 16 384 streams on at 256-sample frames) must give the same bits as the
-    plain schedule -- eagerly, with a run mask, and replayed from a hipGraph."""
-    rate, F, n, nfr = 48000, 256, 37, 24
-    flen = 64 * rate // 1000
-    scenes = [make_echo_scene(s, rate, F * nfr) for s in range(n)]
-    mic = np.stack([m for m, _ in scenes])
-    far = np.stack([f for _, f in scenes])
-    a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
-    b = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
-    a.set_overlap(0)
-    b.set_overlap(chunks)
-    rng = np.random.default_rng(chunks)
-    fl = ms.MI_AEC_POSTFILTER
-    for f in range(nfr - 8):
-        sl = slice(f * F, (f + 1) * F)
-        run = (rng.random(n) < 0.8).astype(np.uint8) if f % 3 == 2 else None
-        oa = a.process(np.ascontiguousarray(mic[:, sl]), np.ascontiguousarray(far[:, sl]), flags=fl, run=run,
-                       out=np.full((n, F), 555, np.int16))
-        ob = b.process(np.ascontiguousarray(mic[:, sl]), np.ascontiguousarray(far[:, sl]), flags=fl, run=run,
-                       out=np.full((n, F), 555, np.int16))
-        np.testing.assert_array_equal(oa, ob, err_msg=f"frame {f}")
-    # the same through a captured graph: 8 frames per replay, device-resident buffers
-    import torch
-    d_mic = torch.from_numpy(np.ascontiguousarray(mic[:, (nfr - 8) * F:]).reshape(n, 8, F).transpose(1, 0, 2).copy()).cuda()
-    d_far = torch.from_numpy(np.ascontiguousarray(far[:, (nfr - 8) * F:]).reshape(n, 8, F).transpose(1, 0, 2).copy()).cuda()
-    outs = {}
-    for name, obj in (("plain", a), ("chunked", b)):
-        d_out = torch.zeros((8, n, F), dtype=torch.int16, device="cuda")
-        torch.cuda.synchronize()
-        ctx.capture_begin()
-        for k in range(8):  # the chunked object also defers its joins: frame k's last post-filter next to frame k+1's canceller
-            obj.process(d_mic[k], d_far[k], out=d_out[k], flags=fl | (ms.MI_AEC_DEFER_JOIN if name == "chunked" else 0))
-        obj.join()
-        g = ctx.capture_end()
-        g.launch()
-        ctx.sync()
-        outs[name] = d_out.cpu().numpy()
-    np.testing.assert_array_equal(outs["plain"], outs["chunked"])
-    assert outs["plain"].any()
-    # deferred joins eagerly, interleaved with a call that cannot be chunked the same way (no post-filter: joins first)
-    d_o1, d_o2 = torch.zeros((n, F), dtype=torch.int16, device="cuda"), torch.zeros((n, F), dtype=torch.int16, device="cuda")
-    p_o1, p_o2 = torch.zeros_like(d_o1), torch.zeros_like(d_o2)
-    torch.cuda.synchronize()
-    b.process(d_mic[0], d_far[0], out=d_o1, flags=fl | ms.MI_AEC_DEFER_JOIN)
-    b.process(d_mic[1], d_far[1], out=d_o2, flags=0)
-    a.process(d_mic[0], d_far[0], out=p_o1, flags=fl)
-    a.process(d_mic[1], d_far[1], out=p_o2, flags=0)
-    ctx.sync()
-    assert torch.equal(d_o1, p_o1) and torch.equal(d_o2, p_o2)
-    a.close()
-    b.close()
-
-
-def test_aec_automatic_overlap_at_scale_is_bit_identical(ctx):
-    """16 384 streams at 256-sample frames: the automatic schedule (two chunks, second stream, deferred joins across two
-    rounds like mi_session does) against the plain one, 12 frames, every output sample compared on the device."""
-    import torch
-    rate, F, n = 48000, 256, 16384
-    flen = 128 * rate // 1000
-    a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
-    b = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
-    a.set_overlap(0)
-    g = torch.Generator(device="cpu").manual_seed(5)
-    far = (torch.randn((64, 12 * F), generator=g) * 3000).round().clamp(-32767, 32767).to(torch.int16)
-    mic = (0.4 * far.float() + torch.randn((64, 12 * F), generator=g) * 80).round().clamp(-32767, 32767).to(torch.int16)
-    far = far.repeat(n // 64, 1).cuda()
-    mic = mic.repeat(n // 64, 1).cuda()
-    # every 64th stream gets its own gain so the streams are not all alike
-    mic[::64] = (mic[::64].float() * 0.5).to(torch.int16)
-    oa = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
-    ob = [torch.zeros((n, F), dtype=torch.int16, device="cuda") for _ in range(2)]
-    # persistent frame tensors: the launches run on the context's stream, which torch's allocator knows nothing about
-    mics = [mic[:, k * F:(k + 1) * F].contiguous() for k in range(12)]
-    fars = [far[:, k * F:(k + 1) * F].contiguous() for k in range(12)]
-    torch.cuda.synchronize()
-    fl = ms.MI_AEC_POSTFILTER
-    for f in range(0, 12, 2):
-        for r in range(2):
-            a.process(mics[f + r], fars[f + r], out=oa[r], flags=fl)
-            b.process(mics[f + r], fars[f + r], out=ob[r], flags=fl | ms.MI_AEC_DEFER_JOIN)
-        b.join()
-        ctx.sync()
-        torch.cuda.synchronize()
-        assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1]), f"frames {f}, {f + 1}"
-    assert oa[1].any()
-    a.close()
-    b.close()
-
-
 @pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 64)])
 def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
     """mi_aec_process_frames (all the frames of a tick in ONE launch: per-stream state in registers across them, the

@@ -133,9 +133,11 @@ def test_canceller_with_the_fifos_folded_in_equals_the_separate_launches(ctx):
     """mi_aec_process_fifos (blocks queued, frames popped, cancelled, results queued: ONE launch) == mi_fifo_push x 2,
     mi_fifo_pop_frames x 2, mi_aec_process_frames, mi_fifo_push_frames: FIFO levels, what the output FIFO delivers and the
     canceller's state, bit for bit -- with a far end that sometimes skips a block (silence is injected for the frames it
-    cannot supply) and one that starts with a delay line of silence (MS_ECHO_CANCELLER_SET_DELAY), 48 and 16 kHz."""
+    cannot supply) and one that starts with a delay line of silence (MS_ECHO_CANCELLER_SET_DELAY), 48 and 16 kHz -- and
+    44.1 kHz, whose 441-sample ticks are no multiple of anything the lanes own (every sample finds its own source), with
+    far-end blocks of odd lengths."""
     torch = pytest.importorskip("torch")
-    for rate, F, tail in ((48000, 256, 128), (16000, 128, 128)):
+    for rate, F, tail in ((48000, 256, 128), (16000, 128, 128), (44100, 256, 100)):
         n, ns, nticks = 12, rate // 100, 60
         cap = 4 * F
         flen = tail * rate // 1000
@@ -165,7 +167,8 @@ def test_canceller_with_the_fifos_folded_in_equals_the_separate_launches(ctx):
             rblk = ref[:, t * ns:(t + 1) * ns].copy()
             skip = rng.random(n) < 0.15           # the far end of these legs delivers nothing this tick ...
             dr = torch.from_numpy(rblk).cuda()
-            rc = torch.from_numpy(np.where(skip, 0, ns).astype(np.int32)).cuda()
+            short = rng.integers(1, ns, n) if rate == 44100 else np.full(n, ns)      # ... or a short block of any length
+            rc = torch.from_numpy(np.where(skip, 0, np.where(rng.random(n) < 0.2, short, ns)).astype(np.int32)).cuda()
             torch.cuda.synchronize()
             # separate launches
             fm1.push(dm)
@@ -294,15 +297,16 @@ def test_chained_tick_pipeline_stage_parity(ctx, oracle):
     assert f_mic.overflows() == f_ref.overflows() == f_out.overflows() == 0
 
 
-@pytest.mark.parametrize("use_graphs", [True, False])
-def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs):
+@pytest.mark.parametrize("use_graphs,rate", [(True, 48000), (False, 48000), (False, 44100)])
+def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs, rate):
     """mi_session (three streams, up to three ticks in flight, hipGraph per slot) must produce exactly what the same
-    C ABI objects produce when called one after the other on one stream -- it only adds plumbing."""
+    C ABI objects produce when called one after the other on one stream -- it only adds plumbing.  44.1 kHz: ticks of 441
+    samples against 256-sample frames (the rates msresample.c serves on a sound card's side)."""
     torch = pytest.importorskip("torch")
-    nconf, mm, nticks, F, rate = 3, 32, 25, 256, 48000
-    n = nconf * mm
+    nconf, mm, nticks, F = 3, 32, 25, 256
+    n, ns = nconf * mm, rate // 100
     mic16 = np.stack([synth_pcm(s, 160 * nticks, rate=16000, sigma=2500.0) for s in range(n)])
-    ref48 = np.stack([synth_pcm(500 + s, 480 * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+    ref48 = np.stack([synth_pcm(500 + s, ns * nticks, rate=rate, sigma=3000.0) for s in range(n)])
     # ---- reference run: the individual objects, synchronous
     rs = ms.ResamplerBatch(ctx, n, 16000, rate)
     aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
@@ -310,30 +314,30 @@ def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs):
     p = vol.default_params()
     p.agc_enabled = 1
     vol.set_params([p] * n)
-    mix = ms.MixerBatch(ctx, nconf, mm, 480)
-    cap = (2 * 480 + 2 * F + 7) & ~7
+    mix = ms.MixerBatch(ctx, nconf, mm, ns)
+    cap = (2 * ns + 3 * F - 1) // F * F
     f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, cap) for _ in range(3))
     z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
-    up, micf, reff, clean, tick, mixed = z(n, 488), z(n, F), z(n, F), z(n, F), z(n, 480), z(nconf, mm, 480)
+    up, micf, reff, clean, tick, mixed = z(n, 488), z(n, F), z(n, F), z(n, F), z(n, ns), z(nconf, mm, ns)
     okm = z(n, dt=torch.uint8)
     want = []
     for t in range(nticks):
         d_mic = torch.from_numpy(np.ascontiguousarray(mic16[:, t * 160:(t + 1) * 160])).cuda()
-        d_ref = torch.from_numpy(np.ascontiguousarray(ref48[:, t * 480:(t + 1) * 480])).cuda()
+        d_ref = torch.from_numpy(np.ascontiguousarray(ref48[:, t * ns:(t + 1) * ns])).cuda()
         torch.cuda.synchronize()
         rs.process(d_mic, out=up)
-        f_mic.push(up, nsamples=480)
+        f_mic.push(up, nsamples=ns)
         f_ref.push(d_ref)
         for _ in range(2):
             f_mic.pop(F, micf, ok=okm, zero_fill=False)
             f_ref.pop(F, reff, gate=okm, zero_fill=True)
             aec.process(micf, reff, out=clean, run=okm)
             f_out.push(clean, gate=okm)
-        f_out.pop(480, tick, zero_fill=True)
+        f_out.pop(ns, tick, zero_fill=True)
         vol.process(tick)
-        mix.process(tick.view(nconf, mm, 480), out=mixed)
+        mix.process(tick.view(nconf, mm, ns), out=mixed)
         ctx.sync()
-        want.append(mixed.cpu().numpy().reshape(n, 480).copy())
+        want.append(mixed.cpu().numpy().reshape(n, ns).copy())
     # ---- the session, pipelined: keep up to three ticks in flight
     se = ms.Session(ctx, n, members=mm, in_rate=16000, rate=rate, tail_ms=128, agc=True, use_graphs=use_graphs)
     got = []
@@ -342,7 +346,7 @@ def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs):
             got.append(se.collect().copy())
         h_mic, h_ref = se.acquire()
         h_mic[:] = mic16[:, t * 160:(t + 1) * 160]
-        h_ref[:] = ref48[:, t * 480:(t + 1) * 480]
+        h_ref[:] = ref48[:, t * ns:(t + 1) * ns]
         se.submit()
     while se.in_flight():
         got.append(se.collect().copy())
@@ -473,6 +477,26 @@ def test_session_members_join_and_leave_like_msaudioconference(ctx):
     e.remove_member(mm + 2)
     win, db = shout(5, 400)
     assert win[1] == -1                              # nobody else in conference 1 makes a sound
+    # MS_VOLUME_GET_MAX is a one-second window fed by EVERY tick (msvolume.c:404), not by the polls: a burst that ended
+    # 300 ms before the only poll still elects its speaker; a second later the window has started over and nobody is above -30 dB
+    e2 = mk()
+
+    def run(se, ticks, sig):
+        for _ in range(ticks):
+            m, r = se.acquire()
+            m[:] = sig
+            r[:] = 0
+            se.submit()
+            se.collect()
+
+    run(e2, 12, loud)
+    run(e2, 30, 0)
+    win, db = e2.active_speakers(0)
+    assert list(win) == [5, mm + 2] and (db > -30).all()
+    run(e2, 110, 0)
+    win, db = e2.active_speakers(0)
+    assert list(win) == [-1, -1]
+    e2.close()
     for se in (a, c, fresh, e):
         se.close()
 

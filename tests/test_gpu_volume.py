@@ -163,9 +163,12 @@ def test_volume_full_size_4096_streams_agc(ctx, oracle):
     vb.close()
 
 
-def test_volume_pops_its_chunk_from_a_fifo(ctx):
+@pytest.mark.parametrize("odd_head", [False, True])
+def test_volume_pops_its_chunk_from_a_fifo(ctx, odd_head):
     """mi_volume_process_fifo == mi_fifo_pop (zero fill) + mi_volume_process: samples, meter state and FIFO levels bit for
-    bit, streams that run dry get silence (and meter it), unity-gain streams still have their chunk delivered."""
+    bit, streams that run dry get silence (and meter it), unity-gain streams still have their chunk delivered.
+    odd_head: the ring was popped by some other reader before (mi_fifo_pop of 3 / 5 samples), so its head is no multiple
+    of 8 any more and a 16-byte group may straddle the end of the ring: those streams take the sample-by-sample read."""
     import torch
     n, ns, cap = 37, 480, 1024
     rng = np.random.default_rng(8)
@@ -190,6 +193,17 @@ def test_volume_pops_its_chunk_from_a_fifo(ctx):
     f1, f2 = ms.FifoBatch(ctx, n, cap), ms.FifoBatch(ctx, n, cap)
     z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
     t1, t2, lv1, lv2 = z(n, ns), z(n, ns), z(n, dt=torch.int32), z(n, dt=torch.int32)
+    if odd_head:
+        pre = torch.from_numpy(rng.integers(-20000, 20000, (n, 8), dtype=np.int16)).cuda()
+        gate = torch.from_numpy((np.arange(n) % 2).astype(np.uint8)).cuda()  # every other stream
+        gate2 = torch.from_numpy((np.arange(n) % 4 == 1).astype(np.uint8)).cuda()
+        junk = z(n, 8)
+        torch.cuda.synchronize()
+        for f in (f1, f2):
+            f.push(pre, nsamples=8)
+            f.pop(3, junk, gate=gate)
+            f.pop(5, junk, gate=gate2)
+        ctx.sync()
     for t in range(40):
         blk = rng.integers(-20000, 20000, (n, 512), dtype=np.int16)
         cnt = rng.choice([0, 256, 512], n, p=[0.2, 0.3, 0.5]).astype(np.int32)   # frames of 256 arrive irregularly
