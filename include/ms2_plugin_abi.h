@@ -442,6 +442,7 @@ extern MSFilterDesc ms_mi355x_audio_mixer_desc; /* .id = MS_AUDIO_MIXER_ID, repl
 extern MSFilterDesc ms_mi355x_volume_desc;      /* .id = MS_VOLUME_ID,      replaces src/audiofilters/msvolume.c:538-548 */
 extern MSFilterDesc ms_mi355x_equalizer_desc;   /* .id = MS_EQUALIZER_ID,   replaces src/audiofilters/equalizer.c:366-375 */
 extern MSFilterDesc ms_mi355x_speex_ec_desc;    /* .id = MS_SPEEX_EC_ID,    replaces src/audiofilters/speexec.c:411-422 */
+extern MSFilterDesc ms_mi355x_webrtc_aec_name_desc; /* .id = MS_FILTER_PLUGIN_ID, name "MSWebRTCAEC": only with MSMI355X_CLAIM_WEBRTC_AEC=1 (audiostream.c:2128-2158); not AEC3 */
 extern MSFilterDesc ms_mi355x_size_conv_desc;   /* .id = MS_SIZE_CONV_ID,   replaces src/videofilters/sizeconv.c:221-247 */
 extern MSFilterDesc ms_mi355x_pix_conv_desc;    /* .id = MS_PIX_CONV_ID,    replaces src/videofilters/pixconv.c:112-138 */
 extern MSFilterDesc ms_mi355x_alaw_dec_desc;   /* .id = MS_ALAW_DEC_ID, replaces src/audiofilters/alaw.c:235-246 */

@@ -273,18 +273,44 @@ typedef struct mi_fifo mi_fifo;
 int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
                          const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
                          int max_frames, unsigned flags, uint8_t *d_count_out);
+/* Spreading the load of mi_aec_process_fifos over the ticks.  Ticks of tick_len samples against frames of frame_size
+ * leave a leg's microphone FIFO at a level that cycles through the multiples of gcd(tick_len, frame_size) -- at 48 kHz
+ * (480 / 256) eight levels -- and a leg has one frame less to cancel in the tick it passes level 0.  Legs that start
+ * together pass it together (seven heavy ticks, one light).  mi_aec_stagger_fifos gives streams [first, first + count)
+ * -- freshly created or reset, both FIFOs empty or holding only a delay line -- a lead of unit * phase(stream) samples of
+ * silence in BOTH queues (so the echo path the canceller sees is unchanged; the leg's audio is `lead` samples later):
+ * every tick then carries the same share of light legs.  phase(stream) = mi_fifo_phase_of(stream, phases), a bijective
+ * hash of the slot index, so any regular arrangement of slots still gets all phases.  The output FIFO of a staggered leg
+ * can stand one frame fuller: size it tick_len * 2 + frame_size * 3 or more.  (The launch itself serves the legs in an
+ * order sorted by the frames they have -- long ones first, evenly over the XCDs -- whatever their phases are; that needs
+ * no call.)  mi_aec_stagger_info: the lead's unit and the number of phases for this frame size and tick. */
+int mi_aec_stagger_info(const mi_aec *a, int tick_len, int *unit, int *phases);
+int mi_aec_stagger_fifos(mi_aec *a, mi_fifo *f_mic, mi_fifo *f_ref, int tick_len, int first, int count);
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
                         const uint8_t *h_run, unsigned flags);
 /* state bytes per stream (for DESIGN/roofline accounting) */
 size_t mi_aec_state_bytes(const mi_aec *a);
 /* One stream's whole state as a host blob, and back: what fetch_config / apply_config (src/audiofilters/speexec.c:119-167)
  * do with SPEEX_ECHO_GET_BLOB / SET_BLOB of the reference's speex fork, so a converged canceller survives the end of a
- * call (MS_ECHO_CANCELLER_GET/SET_STATE_STRING).  The format is this library's (the fork's is not published); import checks
- * rate / frame / tail and refuses a blob of another shape.  A restored stream continues bit for bit. */
+ * call (MS_ECHO_CANCELLER_GET/SET_STATE_STRING).  The fork's blob format is not published, so the two are NOT
+ * interchangeable: a string saved by the reference's MSSpeexEC is refused here with a clear message (and vice versa the
+ * reference refuses ours: speex_echo_state_blob_new_from_memory fails on it) and the canceller starts from scratch, as
+ * after any failed restore (speexec.c:137-139).  Format, version MI_AEC_BLOB_VERSION, little-endian:
+ *   char magic[4] = "MIEC"; uint32 version, rate, frame_size F, blocks M, N = 2F, small_state_floats, scalar_bytes;
+ *   float X[(M+1) N] (ring, bin-interleaved), W[M N], foreground[M N], small_state[19 F + 192]; scalar record.
+ * Import checks tag, version, rate / frame / tail and the size, and refuses anything else; a restored stream continues
+ * bit for bit. */
+#define MI_AEC_BLOB_VERSION 2u
 size_t mi_aec_blob_bytes(const mi_aec *a);
 int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap);
 int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size);
-/* debug/parity read-back of one stream's float arrays: "W","foreground","X","power" ... */
+/* The state of `count` streams of `src` from src_first on, copied on the device into `dst` from dst_first on (same rate /
+ * frame / tail, same device; src == dst allowed for disjoint ranges): a canceller converged for an endpoint serves as the
+ * starting point of other legs of that endpoint without the host round trip of export / import.  Ordered after what was
+ * enqueued on src's stream; asynchronous on dst's. */
+int mi_aec_copy_state(mi_aec *dst, int dst_first, const mi_aec *src, int src_first, int count);
+/* debug/parity read-back of one stream's float arrays: "W","foreground","X","power" ...; "counters": foreground updates,
+ * background resets, state resets, frames cancelled since the stream's last reset */
 int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap);
 
 /* -------------------------------------------------------------- scaler */
@@ -335,6 +361,9 @@ int mi_fifo_pop_frames(mi_fifo *f, int frame, int max_frames, int16_t *d_out, in
                        const uint8_t *d_nframes_wanted, int zero_fill);
 /* d_nframes[s] * frame samples of row s are appended (0 = nothing for that stream) */
 int mi_fifo_push_frames(mi_fifo *f, const int16_t *d_in, int frame, int max_frames, int stride, const uint8_t *d_nframes);
+/* unit * mi_fifo_phase_of(s, phases) samples of silence appended to streams [first, first + count) (see mi_aec_stagger_fifos) */
+int mi_fifo_push_lead(mi_fifo *f, int first, int count, int unit, int phases);
+int mi_fifo_phase_of(int stream, int phases); /* 0 .. phases-1 */
 int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, in samples */
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_reset(mi_fifo *f);
@@ -416,6 +445,9 @@ typedef struct mi_session_config {
 	int32_t ref_loopback; /* 1: a leg's far-end reference is the mix this session sent it on the previous tick: no upload */
 	int32_t ref_delay_ms; /* MS_ECHO_CANCELLER_SET_DELAY: the reference FIFO starts with this much silence (speexec.c:205-208) */
 	int32_t plc;          /* 1: MSGenericPLC behind the decoder (msgenericplc.c): legs flagged lost for a tick are concealed */
+	int32_t stagger;      /* 1 (default): every leg starts -- at creation, on reset / add_member -- with the re-framing lead of
+	                       * mi_aec_stagger_fifos (0 .. 7/8 of a frame of silence in its microphone and reference queues), so that
+	                       * legs which start together do not all have their light tick together; 0: legs start empty */
 } mi_session_config;
 #define MI_SESSION_PCM16 0
 #define MI_SESSION_PCMA 1

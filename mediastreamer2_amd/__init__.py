@@ -347,6 +347,21 @@ class AecBatch(_Batch):
         check(self.ctx.L.mi_aec_export_state(self.h, stream, buf.ctypes.data, n))
         return buf.tobytes()
 
+    def stagger_info(self, tick_len):
+        u, p = C.c_int(), C.c_int()
+        check(self.ctx.L.mi_aec_stagger_info(self.h, tick_len, C.byref(u), C.byref(p)))
+        return u.value, p.value
+
+    def stagger_fifos(self, f_mic, f_ref, tick_len, first=0, count=None):
+        """lead of unit * phase(stream) samples of silence in both queues of (freshly reset) legs: mi_aec_stagger_fifos"""
+        count = self.nstreams - first if count is None else count
+        check(self.ctx.L.mi_aec_stagger_fifos(self.h, f_mic.h, f_ref.h, tick_len, first, count))
+
+    def copy_state_from(self, src, src_first=0, dst_first=0, count=None):
+        """device-to-device copy of `count` streams' whole state from another batch of the same shape"""
+        count = min(src.nstreams - src_first, self.nstreams - dst_first) if count is None else count
+        check(self.ctx.L.mi_aec_copy_state(self.h, dst_first, src.h, src_first, count))
+
     def import_state(self, stream, blob):
         """speexec.c:121-143 apply_config: raises MiError for a blob of another shape."""
         buf = np.frombuffer(blob, np.uint8).copy()
@@ -501,6 +516,9 @@ class FifoBatch(_Batch):
         check(self.ctx.L.mi_fifo_overflows(self.h, C.byref(n)))
         return n.value
 
+    def reset_range(self, first, count):
+        check(self.ctx.L.mi_fifo_reset_range(self.h, first, count))
+
     def reset(self):
         check(self.ctx.L.mi_fifo_reset(self.h))
 
@@ -597,7 +615,7 @@ class SessionConfig(C.Structure):
     _fields_ = [("nstreams", C.c_int32), ("members_per_conference", C.c_int32), ("in_rate", C.c_int32),
                 ("rate", C.c_int32), ("tail_ms", C.c_int32), ("agc", C.c_int32), ("use_graphs", C.c_int32),
                 ("mic_codec", C.c_int32), ("out_rate", C.c_int32), ("out_codec", C.c_int32),
-                ("ref_loopback", C.c_int32), ("ref_delay_ms", C.c_int32), ("plc", C.c_int32)]
+                ("ref_loopback", C.c_int32), ("ref_delay_ms", C.c_int32), ("plc", C.c_int32), ("stagger", C.c_int32)]
 
 
 MI_SESSION_PCM16, MI_SESSION_PCMA, MI_SESSION_PCMU = 0, 1, 2
@@ -609,7 +627,7 @@ class Session(_Batch):
     _destroy = "mi_session_destroy"
 
     def __init__(self, ctx, nstreams, members=32, in_rate=16000, rate=48000, tail_ms=128, agc=True, use_graphs=True,
-                 mic_codec=0, out_rate=0, out_codec=0, ref_loopback=False, ref_delay_ms=0, plc=False):
+                 mic_codec=0, out_rate=0, out_codec=0, ref_loopback=False, ref_delay_ms=0, plc=False, stagger=False):
         self.ctx = ctx
         cfg = SessionConfig()
         ctx.L.mi_session_default_config(C.byref(cfg))
@@ -617,6 +635,7 @@ class Session(_Batch):
         cfg.tail_ms, cfg.agc, cfg.use_graphs = tail_ms, int(agc), int(use_graphs)
         cfg.mic_codec, cfg.out_rate, cfg.out_codec = mic_codec, out_rate, out_codec
         cfg.ref_loopback, cfg.ref_delay_ms, cfg.plc = int(ref_loopback), ref_delay_ms, int(plc)
+        cfg.stagger = int(stagger)  # (the C default is 1; the wrapper's tests compare with hand-made chains that start empty)
         h = C.c_void_p()
         check(ctx.L.mi_session_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h

@@ -38,7 +38,7 @@ EXPORTS = [
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
     "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos",
-    "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_get",
+    "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_copy_state", "mi_aec_get", "mi_aec_stagger_info", "mi_aec_stagger_fifos",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
@@ -50,7 +50,7 @@ EXPORTS = [
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
     "mi_plc_create", "mi_plc_destroy", "mi_plc_reset", "mi_plc_process", "mi_plc_info",
-    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
 ]
 
 
@@ -156,6 +156,11 @@ def load():
     L.mi_volume_set_params.argtypes = [vp, i32, i32, C.POINTER(VolumeParams)]
     L.mi_volume_get_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
     L.mi_volume_set_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
+    L.mi_aec_copy_state.argtypes = [vp, i32, vp, i32, i32]
+    L.mi_aec_stagger_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.mi_aec_stagger_fifos.argtypes = [vp, vp, vp, i32, i32, i32]
+    L.mi_fifo_push_lead.argtypes = [vp, i32, i32, i32, i32]
+    L.mi_fifo_phase_of.argtypes = [i32, i32]
     L.mi_volume_get_max.argtypes = [vp, i32, i32, vp]
     L.mi_volume_reset_max.argtypes = [vp, i32, i32]
     L.mi_volume_process.argtypes = [vp, vp, i32, i32, vp]

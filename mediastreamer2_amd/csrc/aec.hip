@@ -66,7 +66,11 @@ struct AecScalars {
 	float memX, memD, memE, notch0, notch1;
 	int adapted, saturated, screwed_up, cancel_count, xhead;
 	int nb_adapt, min_count;
-	int pad_[4];
+	// event counters since the last reset of the stream (diagnostics: how often the data-dependent paths run)
+	int fg_updates;   // foreground := background (two-path control)
+	int bg_resets;    // background := foreground
+	int state_resets; // speex_echo_state_reset after persistent divergence
+	int frames;       // frames cancelled
 };
 static_assert(sizeof(AecScalars) == 96, "scalar record");
 
@@ -85,6 +89,9 @@ struct AecArgs {
 	uint8_t *count_out; // nullable: frames each stream ran
 	int stride, nstreams, M, flags;
 	int first;             // first stream of this launch (a launch may cover a chunk of the batch)
+	// FIFO entry: leg order of this launch / of the next one, [2][8][cap8] (aec_tick.hpp: TickOrder); null = block b serves leg b
+	int *order, *ctl;
+	int cap8;
 	float *X, *W, *FG;     // [nstreams][(M+1) or M][N]
 	float *small;          // [nstreams][small_stride]
 	AecScalars *scal;      // [nstreams]
@@ -268,6 +275,8 @@ struct mi_aec {
 	AecTables t;
 	FftPlan plan;
 	int small_stride = 0;
+	int *d_order = nullptr, *d_ctl = nullptr; // leg order of the FIFO entry's launches (aec_tick.hpp: TickOrder)
+	int cap8 = 0;
 	std::vector<float> h_prop0;
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
 };
@@ -527,6 +536,19 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		mi_aec_destroy(a);
 		return rc;
 	}
+	{ // the FIFO entry's leg lists start as the identity: class c = legs c, c + 8, ..
+		a->cap8 = (nstreams + 7) / 8;
+		std::vector<int> ord((size_t)2 * 8 * a->cap8, 0), ctl(TickOrder::WORDS, 0);
+		for (int p = 0; p < 2; ++p)
+			for (int s = 0; s < nstreams; ++s) ord[((size_t)p * 8 + (size_t)(s & 7)) * a->cap8 + (size_t)(s >> 3)] = s;
+		if (hipMalloc((void **)&a->d_order, ord.size() * sizeof(int)) != hipSuccess || hipMalloc((void **)&a->d_ctl, ctl.size() * sizeof(int)) != hipSuccess ||
+		    hipMemcpy(a->d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(a->d_ctl, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+			mi::set_error("hipMalloc failed for the canceller's leg lists");
+			mi_aec_destroy(a);
+			return MI_ENOMEM;
+		}
+	}
 	*out = a;
 	return MI_OK;
 }
@@ -540,6 +562,8 @@ void mi_aec_destroy(mi_aec *a) {
 	if (a->d_small) (void)hipFree(a->d_small);
 	if (a->d_scal) (void)hipFree(a->d_scal);
 	if (a->d_tables) (void)hipFree(a->d_tables);
+	if (a->d_order) (void)hipFree(a->d_order);
+	if (a->d_ctl) (void)hipFree(a->d_ctl);
 	delete a;
 }
 
@@ -579,6 +603,8 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.tick_len = g.mic_tick_stride = g.ref_tick_stride = 0;
 	g.count_out = nullptr;
 	g.ref_len = nullptr;
+	g.order = g.ctl = nullptr;
+	g.cap8 = a->cap8;
 	if (fifo) {
 		g.ref_len = fifo->d_ref_len;
 		g.fmic = fifo_view(fifo->f_mic);
@@ -590,6 +616,8 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 		g.mic_tick_stride = fifo->mic_stride;
 		g.ref_tick_stride = fifo->ref_stride;
 		g.count_out = fifo->d_count_out;
+		g.order = a->d_order;
+		g.ctl = a->d_ctl;
 	}
 	g.stride = stride;
 	g.nstreams = a->nstreams;
@@ -645,6 +673,36 @@ int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, i
 		}
 	AecFifoCall fc = {f_mic, f_ref, f_out, d_mic_tick, d_ref_tick, tick_len, mic_stride, ref_stride, d_ref_len, d_count_out};
 	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
+}
+
+// The re-framing phase of a leg: ticks of tick_len samples against frames of F leave a leg's microphone FIFO at a level
+// that cycles through the multiples of g = gcd(tick_len, F) -- at 48 kHz (480 / 256) eight levels, and in the tick a leg
+// passes level 0 it has one frame to cancel instead of two.  Legs that all start empty pass it together: seven heavy
+// ticks and a light one.  A lead of unit * phase(s) samples of silence in BOTH queues (the echo path between them is
+// unchanged) spreads the light ticks evenly: every tick then carries 15/8 frames per leg.
+int mi_aec_stagger_info(const mi_aec *a, int tick_len, int *unit, int *phases) {
+	MI_CHECK_ARG(a && tick_len > 0);
+	int g = a->F, t = tick_len % a->F;
+	while (t) { // gcd(F, tick_len): a power of two, F is one
+		const int r = g % t;
+		g = t;
+		t = r;
+	}
+	const int p = std::min(8, a->F / g);
+	if (unit) *unit = a->F / p;
+	if (phases) *phases = p;
+	return MI_OK;
+}
+
+int mi_aec_stagger_fifos(mi_aec *a, mi_fifo *f_mic, mi_fifo *f_ref, int tick_len, int first, int count) {
+	MI_CHECK_ARG(a && f_mic && f_ref && first >= 0 && count >= 0 && first + count <= a->nstreams && f_mic->nstreams == a->nstreams &&
+	             f_ref->nstreams == a->nstreams);
+	int unit = 0, phases = 0;
+	int rc = mi_aec_stagger_info(a, tick_len, &unit, &phases);
+	if (rc != MI_OK) return rc;
+	if (phases < 2) return MI_OK; // ticks of whole frames: nothing to spread
+	if ((rc = mi_fifo_push_lead(f_mic, first, count, unit, phases)) != MI_OK) return rc;
+	return mi_fifo_push_lead(f_ref, first, count, unit, phases);
 }
 
 int mi_aec_process_host(mi_aec *a, const int16_t *h_mic, const int16_t *h_ref, int16_t *h_out, int stride,
@@ -721,6 +779,15 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	else if (!strcmp(what, "Yh")) res = with_tail(o_yh, 3);
 	else if (!strcmp(what, "last_y")) res.assign(small.begin() + o_ly, small.begin() + o_ly + N); // [older | newest]
 	else if (!strcmp(what, "prop")) res.assign(small.begin() + o_prop, small.begin() + o_prop + M);
+	else if (!strcmp(what, "order")) { // the list the next launch of the FIFO entry will serve the legs in, class after class
+		std::vector<int> ctl(TickOrder::WORDS), ord((size_t)2 * 8 * a->cap8);
+		MI_HIP(hipMemcpy(ctl.data(), a->d_ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost));
+		MI_HIP(hipMemcpy(ord.data(), a->d_order, ord.size() * sizeof(int), hipMemcpyDeviceToHost));
+		for (int c = 0; c < 8; ++c) {
+			const size_t par = (size_t)ctl[(size_t)c * TickOrder::STRIDE + TickOrder::PARITY];
+			for (int i = 0; i < (a->nstreams - c + 7) / 8; ++i) res.push_back((float)ord[(par * 8 + (size_t)c) * a->cap8 + (size_t)i]);
+		}
+	} else if (!strcmp(what, "counters")) res = {(float)sc.fg_updates, (float)sc.bg_resets, (float)sc.state_resets, (float)sc.frames};
 	else if (!strcmp(what, "scalars")) {
 		res = {sc.Davg1, sc.Davg2, sc.Dvar1, sc.Dvar2, sc.Pey, sc.Pyy, sc.sum_adapt, sc.leak_estimate,
 		       (float)sc.adapted, (float)sc.saturated, (float)sc.screwed_up, (float)sc.cancel_count,
@@ -752,7 +819,7 @@ int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap) {
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
 	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N, sn = (size_t)a->small_stride;
-	BlobHeader h = {{'M', 'I', 'E', 'C'}, 2u, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
+	BlobHeader h = {{'M', 'I', 'E', 'C'}, MI_AEC_BLOB_VERSION, (uint32_t)a->rate, (uint32_t)a->F, (uint32_t)a->M, (uint32_t)a->N, (uint32_t)sn, (uint32_t)sizeof(AecScalars)};
 	uint8_t *p = (uint8_t *)h_blob;
 	memcpy(p, &h, sizeof(h));
 	p += sizeof(h);
@@ -776,11 +843,20 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 		return MI_EINVAL;
 	}
 	memcpy(&h, h_blob, sizeof(h));
-	if (memcmp(h.magic, "MIEC", 4) != 0 || h.version != 2 || h.rate != (uint32_t)a->rate || h.F != (uint32_t)a->F || h.M != (uint32_t)a->M ||
-	    h.N != (uint32_t)a->N || h.small_stride != (uint32_t)a->small_stride || h.scal_bytes != sizeof(AecScalars) ||
-	    size != mi_aec_blob_bytes(a)) {
-		mi::set_error("mi_aec_import_state: the blob was taken from a canceller of another shape (rate %u, frame %u, %u blocks) or is damaged",
-		              h.rate, h.F, h.M);
+	if (memcmp(h.magic, "MIEC", 4) != 0) { // e.g. a SPEEX_ECHO_GET_BLOB blob saved by the reference's own MSSpeexEC
+		mi::set_error("mi_aec_import_state: not a blob of this library (no 'MIEC' tag): a state saved by another echo canceller "
+		              "cannot be loaded, the canceller keeps its current state");
+		return MI_EINVAL;
+	}
+	if (h.version != MI_AEC_BLOB_VERSION) {
+		mi::set_error("mi_aec_import_state: blob format version %u, this library reads version %u", h.version, (unsigned)MI_AEC_BLOB_VERSION);
+		return MI_EINVAL;
+	}
+	if (h.rate != (uint32_t)a->rate || h.F != (uint32_t)a->F || h.M != (uint32_t)a->M || h.N != (uint32_t)a->N ||
+	    h.small_stride != (uint32_t)a->small_stride || h.scal_bytes != sizeof(AecScalars) || size != mi_aec_blob_bytes(a)) {
+		mi::set_error("mi_aec_import_state: the blob was taken from a canceller of another shape (rate %u, frame %u, %u blocks; this one: "
+		              "rate %d, frame %d, %d blocks) or is damaged",
+		              h.rate, h.F, h.M, a->rate, a->F, a->M);
 		return MI_EINVAL;
 	}
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
@@ -796,6 +872,25 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 	MI_HIP(hipMemcpy(a->d_small + (size_t)stream * sn, p, sn * 4, hipMemcpyHostToDevice));
 	p += sn * 4;
 	MI_HIP(hipMemcpy(a->d_scal + stream, p, sizeof(AecScalars), hipMemcpyHostToDevice));
+	return MI_OK;
+}
+
+int mi_aec_copy_state(mi_aec *dst, int dst_first, const mi_aec *src, int src_first, int count) {
+	MI_CHECK_ARG(dst && src && count >= 0 && dst_first >= 0 && src_first >= 0 && dst_first + count <= dst->nstreams && src_first + count <= src->nstreams);
+	if (dst->rate != src->rate || dst->F != src->F || dst->M != src->M || dst->ctx->device != src->ctx->device) {
+		mi::set_error("mi_aec_copy_state: the two batches differ in rate / frame / tail or live on different devices");
+		return MI_EINVAL;
+	}
+	if (count == 0) return MI_OK;
+	if (dst->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(src->ctx->stream)); // the source's state as of everything enqueued on its stream so far
+	const size_t wn = (size_t)dst->M * dst->N, xn = (size_t)(dst->M + 1) * dst->N, sn = (size_t)dst->small_stride, c = (size_t)count;
+	hipStream_t st = dst->ctx->stream;
+	MI_HIP(hipMemcpyAsync(dst->d_X + dst_first * xn, src->d_X + src_first * xn, c * xn * 4, hipMemcpyDeviceToDevice, st));
+	MI_HIP(hipMemcpyAsync(dst->d_W + dst_first * wn, src->d_W + src_first * wn, c * wn * 4, hipMemcpyDeviceToDevice, st));
+	MI_HIP(hipMemcpyAsync(dst->d_FG + dst_first * wn, src->d_FG + src_first * wn, c * wn * 4, hipMemcpyDeviceToDevice, st));
+	MI_HIP(hipMemcpyAsync(dst->d_small + dst_first * sn, src->d_small + src_first * sn, c * sn * 4, hipMemcpyDeviceToDevice, st));
+	MI_HIP(hipMemcpyAsync(dst->d_scal + dst_first, src->d_scal + src_first, c * sizeof(AecScalars), hipMemcpyDeviceToDevice, st));
 	return MI_OK;
 }
 

@@ -154,12 +154,26 @@ __device__ __forceinline__ void cmac_bins(TA (&acc)[K], const TX (&x)[K], const 
 	}
 }
 
+// words of AecArgs::ctl (the list hand-over between consecutive launches of the FIFO entry)
+struct TickOrder { // per class: one 128-byte line
+	static constexpr int STRIDE = 32, PARITY = 0, PLACED = 2, WORDS = 8 * STRIDE; // PLACED: 64 bits, front | back << 32
+};
+
 template <int F>
 __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
 	using SL = TickLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
-	const int s = a.first + blockIdx.x;
+	// ---- which leg this wavefront serves.  Rows / per-frame entries: leg = block.  FIFO entry: the leg comes out of a list
+	// the PREVIOUS tick's launch sorted (TickOrder below) -- legs that will run two frames first, the short ones last, one
+	// list per class b % 8 (workgroup b runs on XCD b % 8): every XCD gets the same mix whatever pattern the legs' phases
+	// follow, and the long legs are started first.
+	const bool sched = a.order != nullptr;
+	int s = a.first + blockIdx.x, par = 0;
+	if (sched) {
+		par = a.ctl[(blockIdx.x & 7u) * TickOrder::STRIDE + TickOrder::PARITY];
+		s = a.order[(size_t)par * 8 * a.cap8 + (blockIdx.x & 7u) * a.cap8 + (blockIdx.x >> 3)];
+	}
 	const int lane = threadIdx.x;
 	const int e0 = lane * K; // first element (sample / bin) this lane owns
 	// ---- where the frames come from and go to: rows (per-frame / per-tick entries) or the three FIFOs
@@ -207,6 +221,27 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		if (qo.y + nf * F > a.fout.cap) { // no room for the results: nothing runs (counted), the inputs stay queued
 			if (lane == 0) atomicAdd(a.fout.overflow, 1);
 			nf = 0;
+		}
+		if (sched && lane == 0) {
+			// this leg's place in the NEXT tick's list: every leg is handed a block every tick, so the frames it will then
+			// have follow from what it keeps now (a wrong guess -- a refused block -- only costs placement).  Front of its
+			// class for two frames, back for fewer: ONE 64-bit atomic per leg on its class's own cache line (entries placed at
+			// the front in the low half, at the back in the high half; atomics on one line serialise at ~18 ns each, so the
+			// eight classes must not share one).  The wave that completes its class's list (all others of the class have read
+			// `par` and their entry before they got here: s, and through it the level, depend on both) hands it over.
+			const int keep = qm.y + (mic_new ? a.tick_len : 0) - nf * F;
+			int next = (keep + a.tick_len) / F;
+			if (next > a.max_frames) next = a.max_frames;
+			const unsigned c = blockIdx.x & 7u, in_class = ((unsigned)a.nstreams - c + 7u) >> 3;
+			int *dst = a.order + (size_t)(par ^ 1) * 8 * a.cap8 + c * a.cap8;
+			unsigned long long *placed = reinterpret_cast<unsigned long long *>(a.ctl + c * TickOrder::STRIDE + TickOrder::PLACED);
+			const unsigned long long old = atomicAdd(placed, next >= 2 ? 1ull : (1ull << 32));
+			const unsigned front = (unsigned)old, back = (unsigned)(old >> 32);
+			dst[next >= 2 ? front : in_class - 1u - back] = s;
+			if (front + back == in_class - 1u) {
+				*placed = 0ull;
+				a.ctl[c * TickOrder::STRIDE + TickOrder::PARITY] = par ^ 1;
+			}
 		}
 		if (lane == 0) {
 			if (a.count_out) a.count_out[s] = (uint8_t)nf;
@@ -375,6 +410,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			store_vec<K>(L.input + e0, input);
 		}
 		sc.cancel_count++;
+		sc.frames++;
 
 		// ---- newest far-end spectrum into the ring; its power spectrum is all the rest of the frame needs of it
 		sc.xhead = head;
@@ -554,6 +590,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		else if (sc.Davg1 * fabsf(sc.Davg1) > .5f * sc.Dvar1) update_foreground = true;
 		else if (sc.Davg2 * fabsf(sc.Davg2) > .25f * sc.Dvar2) update_foreground = true;
 		if (update_foreground) {
+			sc.fg_updates++;
 			sc.Davg1 = sc.Davg2 = 0;
 			sc.Dvar1 = sc.Dvar2 = 0;
 			if (f + 1 < nf) {
@@ -576,6 +613,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			if ((-sc.Davg1) * fabsf(sc.Davg1) > 4.f * sc.Dvar1) reset_background = true;
 			if ((-sc.Davg2) * fabsf(sc.Davg2) > 4.f * sc.Dvar2) reset_background = true;
 			if (reset_background) {
+				sc.bg_resets++;
 				for (int j = 0; j < M; ++j) {
 					float2 w[K];
 					bload_bins<K>(rF, vb8, (unsigned)(j) * (F * 8), w);
@@ -689,6 +727,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			bstore_vec<K>(rS, vb4, SL::LASTY * 4, z);
 			bstore_vec<K>(rS, vb4, (SL::LASTY + F) * 4, z);
 			bstore_vec<K>(rS, vb4, (SL::LASTY + (2) * F) * 4, z);
+			sc.state_resets++;
 			sc.cancel_count = 0;
 			sc.screwed_up = 0;
 			sc.notch0 = sc.notch1 = 0;

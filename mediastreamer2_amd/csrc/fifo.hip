@@ -32,6 +32,33 @@ struct FifoArgs {
 	int32_t *overflow; // number of pushes refused because the ring was full
 };
 
+// Stream s's share of `phases` re-framing phases: a multiplicative hash (a bijection of the 32-bit slot index) decides,
+// so that ANY regular arrangement of slots -- consecutive legs of a conference, every eighth slot, one bank -- gets every
+// phase equally often.  Host and device use the same function.
+__host__ __device__ inline unsigned fifo_phase_of(unsigned s, unsigned phases) { return ((s * 0x9E3779B1u) >> 16) % phases; }
+
+// `unit * phase(s)` samples of silence appended to streams [first, first + count): the lead a leg starts with
+__global__ void fifo_lead_kernel(FifoArgs a, int first, int count, int unit, int phases) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	const int s = first + i;
+	const int n = unit * (int)fifo_phase_of((unsigned)s, (unsigned)phases);
+	const int2 p = a.pos[s];
+	if (n == 0) return;
+	if (p.y + n > a.capacity) {
+		atomicAdd(a.overflow, 1);
+		return;
+	}
+	int16_t *r = a.ring + (size_t)s * a.capacity;
+	unsigned k = (unsigned)p.x + (unsigned)p.y;
+	if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+	for (int j = 0; j < n; ++j) {
+		r[k] = 0;
+		if (++k == (unsigned)a.capacity) k = 0;
+	}
+	a.pos[s] = make_int2(p.x, p.y + n);
+}
+
 constexpr int FIFO_WAVES = 4; // independent wavefronts (streams) per workgroup: 4x fewer workgroups to dispatch
 
 __global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_push_kernel(FifoArgs a) {
@@ -277,6 +304,19 @@ int mi_fifo_pop_frames(mi_fifo *f, int frame, int max_frames, int16_t *d_out, in
 	a.zero_fill = zero_fill;
 	a.vec = ((f->capacity | stride | frame) & 7) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0;
 	hipLaunchKernelGGL(fifo_pop_frames_kernel, dim3(mi::ceil_div(f->nstreams, FIFO_WAVES)), dim3(64 * FIFO_WAVES), 0, f->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_phase_of(int stream, int phases) { return phases > 0 ? (int)fifo_phase_of((unsigned)stream, (unsigned)phases) : 0; }
+
+int mi_fifo_push_lead(mi_fifo *f, int first, int count, int unit, int phases) {
+	MI_CHECK_ARG(f && first >= 0 && count >= 0 && first + count <= f->nstreams && unit > 0 && phases > 0 && unit * (phases - 1) <= f->capacity);
+	if (count == 0) return MI_OK;
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	hipLaunchKernelGGL(fifo_lead_kernel, dim3(mi::ceil_div(count, 256)), dim3(256), 0, f->ctx->stream, a, first, count, unit, phases);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }

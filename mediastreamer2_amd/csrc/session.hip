@@ -122,6 +122,7 @@ void mi_session_default_config(mi_session_config *c) {
 	c->rate = 48000;
 	c->tail_ms = 128;
 	c->agc = 1;
+	c->stagger = 1;
 	c->use_graphs = 0; // per-tick graphs cost more to launch than ~17 kernels do (0.99 vs 0.68 ms at 4096 streams); no gain at 65536
 }
 
@@ -213,8 +214,9 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 		if ((rc = mi_volume_set_params(s->vol, 0, s->n, all.data())) != MI_OK) return fail(rc);
 	}
 	if ((rc = mi_mixer_create(ctx, s->nconf, cfg->members_per_conference, s->len, &s->mix)) != MI_OK) return fail(rc);
-	// capacities: whole frames (the canceller reads / writes the rings frame-wise, mi_aec_process_fifos), two ticks + two frames
-	const int cap = (2 * s->len + 2 * s->frame + s->frame - 1) / s->frame * s->frame;
+	// capacities: whole frames (the canceller reads / writes the rings frame-wise, mi_aec_process_fifos), two ticks + two
+	// frames, + one frame for the lead of a staggered leg (its output queue stands one frame fuller)
+	const int cap = (2 * s->len + (cfg->stagger ? 3 : 2) * s->frame + s->frame - 1) / s->frame * s->frame;
 	const int delay = cfg->ref_delay_ms * cfg->rate / 1000;
 	const int ref_cap = (cap + delay + s->frame - 1) / s->frame * s->frame;
 	if ((rc = mi_fifo_create(ctx, s->n, cap, &s->f_mic)) != MI_OK || (rc = mi_fifo_create(ctx, s->n, ref_cap, &s->f_ref)) != MI_OK ||
@@ -279,6 +281,7 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 		MI_HIP(hipMemsetAsync(s->d_zero, 0, n * (size_t)delay * 2, ctx->stream));
 		if ((rc = mi_fifo_push(s->f_ref, s->d_zero, delay, delay, nullptr)) != MI_OK) return fail(rc);
 	}
+	if (cfg->stagger && (rc = mi_aec_stagger_fifos(s->aec, s->f_mic, s->f_ref, s->len, 0, s->n)) != MI_OK) return fail(rc);
 	MI_HIP(hipStreamSynchronize(ctx->stream));
 	*out = s;
 	return MI_OK;
@@ -502,6 +505,7 @@ int mi_session_reset_streams(mi_session *s, int first, int count) {
 		if ((rc = mi_fifo_push_gated(s->f_ref, s->d_zero, delay, delay, s->d_ok[0])) != MI_OK) return rc;
 		MI_HIP(hipStreamSynchronize(s->ctx->stream)); // gate is a stack-lifetime buffer
 	}
+	if (s->cfg.stagger && (rc = mi_aec_stagger_fifos(s->aec, s->f_mic, s->f_ref, s->len, first, count)) != MI_OK) return rc;
 	return MI_OK;
 }
 

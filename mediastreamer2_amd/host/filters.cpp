@@ -530,6 +530,17 @@ MSFilterDesc ms_mi355x_speex_ec_desc = {MS_SPEEX_EC_ID, "MSSpeexEC", "Echo cance
                                         MS_FILTER_OTHER, NULL, 2, 2, ec_init, ec_preprocess, ec_process, ec_postprocess,
                                         ec_uninit, ec_methods, MS_FILTER_IS_HW_ACCELERATED};
 
+// The factory's default echo-canceller NAME is "MSWebRTCAEC" (src/base/msfactory.c:245): audio_stream_new_with_sessions looks
+// that name up first and only falls back to MS_SPEEX_EC_ID when no such filter exists (src/voip/audiostream.c:2128-2158).
+// Where the mswebrtc plugin is installed an AudioStream therefore never reaches MS_SPEEX_EC_ID.  With
+// MSMI355X_CLAIM_WEBRTC_AEC=1 this descriptor is registered as well (prepended: it wins the look-up by name) so that such
+// streams land on the GPU canceller.  It is NOT AEC3: the same speex-class MDF canceller + post-filter under that name,
+// and the text says so.
+MSFilterDesc ms_mi355x_webrtc_aec_name_desc = {MS_FILTER_PLUGIN_ID, "MSWebRTCAEC",
+                                               "NOT WebRTC AEC3: speex-class MDF echo canceller + post-filter (MI355X batch) answering to this name",
+                                               MS_FILTER_OTHER, NULL, 2, 2, ec_init, ec_preprocess, ec_process, ec_postprocess,
+                                               ec_uninit, ec_methods, MS_FILTER_IS_HW_ACCELERATED};
+
 MSFilterDesc ms_mi355x_size_conv_desc = {MS_SIZE_CONV_ID, "MSSizeConv", "A video size converter (MI355X batch)", MS_FILTER_OTHER,
                                          NULL, 1, 1, size_conv_init, NULL, size_conv_process, size_conv_postprocess,
                                          size_conv_uninit, sizeconv_methods, MS_FILTER_IS_HW_ACCELERATED};
@@ -567,7 +578,7 @@ MSFilterDesc ms_mi355x_audio_flow_control_desc = {MS_AUDIO_FLOW_CONTROL_ID, "MSA
 namespace {
 bool is_ours(const MSFilterDesc *d) {
 	for (const MSFilterDesc *o : {&ms_mi355x_resample_desc, &ms_mi355x_audio_mixer_desc, &ms_mi355x_volume_desc, &ms_mi355x_equalizer_desc,
-	                              &ms_mi355x_speex_ec_desc, &ms_mi355x_size_conv_desc, &ms_mi355x_pix_conv_desc, &ms_mi355x_alaw_dec_desc,
+	                              &ms_mi355x_speex_ec_desc, &ms_mi355x_webrtc_aec_name_desc, &ms_mi355x_size_conv_desc, &ms_mi355x_pix_conv_desc, &ms_mi355x_alaw_dec_desc,
 	                              &ms_mi355x_ulaw_dec_desc, &ms_mi355x_alaw_enc_desc, &ms_mi355x_ulaw_enc_desc, &ms_mi355x_l16_enc_desc,
 	                              &ms_mi355x_l16_dec_desc, &ms_mi355x_channel_adapter_desc, &ms_mi355x_audio_flow_control_desc,
 	                              &ms_mi355x_generic_plc_desc})
@@ -597,6 +608,11 @@ void libmsmi355xfilters_init(MSFactory *factory) {
 	ms_factory_register_filter(factory, &ms_mi355x_volume_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_equalizer_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_speex_ec_desc);
+	if (const char *claim = getenv("MSMI355X_CLAIM_WEBRTC_AEC"))
+		if (atoi(claim) != 0) {
+			ms_factory_register_filter(factory, &ms_mi355x_webrtc_aec_name_desc);
+			ms_warning("libmsmi355xfilters: answering to the name MSWebRTCAEC with the speex-class MDF canceller (this is not AEC3)");
+		}
 	ms_factory_register_filter(factory, &ms_mi355x_size_conv_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_pix_conv_desc);
 	for (MSFilterDesc *d : {&ms_mi355x_alaw_dec_desc, &ms_mi355x_ulaw_dec_desc, &ms_mi355x_alaw_enc_desc, &ms_mi355x_ulaw_enc_desc,

@@ -377,6 +377,12 @@ int ec_set_state(MSFilter *f, void *arg) { // :361-365 (the previous string leak
 	if (s->state_str) ms_free(s->state_str);
 	s->state_str = (char *)ms_malloc0(n);
 	memcpy(s->state_str, arg, n);
+	// base64("MIEC..") starts with "TUlFQ": anything else was saved by another canceller (the reference's MSSpeexEC stores its
+	// speex fork's SPEEX_ECHO_GET_BLOB, a format of its own) and will be refused when the filter is next prepared
+	if (n > 1 && strncmp(s->state_str, "TUlFQ", 5) != 0)
+		ms_warning("MSSpeexEC (mi355x): the state string was not saved by this filter (format 'MIEC' v%u expected): it will be ignored "
+		           "and the canceller will converge from scratch",
+		           (unsigned)MI_AEC_BLOB_VERSION);
 	return 0;
 }
 int ec_get_state(MSFilter *f, void *arg) { // :367-374: the CURRENT state while attached, the stored string otherwise

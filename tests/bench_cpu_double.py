@@ -80,9 +80,9 @@ class MixerBatch:
 
 class Rig:
     """stands in for bench.ChainRig: same attributes and calls, a virtual cost per tick, a real split-conference mix"""
-    MEMBERS, RING = 32, 4
+    MEMBERS, RING = 32, 16
 
-    def __init__(self, ms, torch, ctx, nstreams, world=1, rank=0, nsplit=0):
+    def __init__(self, ms, torch, ctx, nstreams, world=1, rank=0, nsplit=0, stagger=True):
         self.torch, self.ctx, self.nsplit = torch, ctx, nsplit
         self.mloc = self.MEMBERS // world if nsplit else 0
         self.nconf = max(1, (nstreams - nsplit * self.mloc) // self.MEMBERS)
@@ -104,7 +104,7 @@ class Rig:
             if os.environ.get("DOUBLE_BREAK_RANK") == str(self.rank):
                 self.d_sum[0, 0] += 1  # a rank contributing a wrong partial sum must be caught by the split-mix check
 
-    def tick(self, t):
+    def tick(self, t, parts=None):
         self._tick(t)
 
     def _finalize(self):
@@ -122,8 +122,8 @@ class Rig:
             raise RuntimeError("a tick with a collective in it is captured alone")
         return Graph([(lambda t=t: self._tick(t)) for t in ticks])
 
-    def warm(self, nt=8):
-        for t in range(nt):
+    def warm(self, nt=None):
+        for t in range(nt or self.RING):
             self._tick(t)
 
     def overflows(self):
@@ -159,6 +159,9 @@ class CpuDouble(bench.HipPlatform):
 
     def load(self):
         return KernelLibraryDouble
+
+    def converged(self, ms, torch, ctx, rank):
+        return None  # no canceller to converge: the double's ticks cost the same in any state
 
     def exchange(self, ctx, local):
         import torch.distributed as dist

@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOUBLE = os.path.join(ROOT, "tests", "bench_cpu_double.py")
-COMMON = ["--steps", "16", "--warmup", "8", "--sweep-lo", "16384", "--sweep-hi", "65536", "--no-extras", "--no-cpu-baseline"]
+COMMON = ["--steps", "16", "--warmup", "8", "--sweep-lo", "16384", "--sweep-hi", "65536", "--no-extras", "--no-cpu-baseline", "--worst-ticks", "200"]
 
 
 def free_port():

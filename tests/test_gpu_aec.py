@@ -254,8 +254,10 @@ def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
         c.import_state(0, blob)
     with pytest.raises(ms.MiError):
         b.import_state(0, blob[:-4])
-    with pytest.raises(ms.MiError):
+    with pytest.raises(ms.MiError, match="not a blob of this library"):   # e.g. the reference's own SPEEX_ECHO_GET_BLOB
         b.import_state(0, b"XXXX" + blob[4:])
+    with pytest.raises(ms.MiError, match="format version 7"):
+        b.import_state(0, blob[:4] + (7).to_bytes(4, "little") + blob[8:])
     for x in (a, b, c):
         x.close()
 

@@ -652,9 +652,10 @@ def test_session_downsampled_pcm_output_and_reset(ctx):
 
 
 def test_bench_rig_with_legs_out_of_phase(ctx):
-    """bench.py's chain with the legs' 480 -> 256 re-framing spread over the eight phases (a seeded shuffle): every tick one leg in eight has
-    one whole frame and seven have two, nothing overflows (the output ring is two frames larger: a leg that misses its
-    first pop stays one frame fuller), and after the start-up every leg delivers a tick per tick."""
+    """bench.py's chain with the product's stagger (mi_aec_stagger_fifos: a lead of 32 x phase samples of silence in both
+    queues, phase = a hash of the slot): in every tick about one leg in eight has ONE whole frame and the others two, nothing
+    overflows (the output ring is two frames larger: a leg that misses its first pop stays one frame fuller), and after the
+    start-up every leg delivers a tick per tick.  The phases come out of mi_fifo_phase_of, the same function on the host."""
     import os
     import sys
     import torch
@@ -668,7 +669,9 @@ def test_bench_rig_with_legs_out_of_phase(ctx):
             rig.f_mic.levels(lv)
             ctx.sync()
             got = np.bincount(lv.cpu().numpy() // 32, minlength=8)
-            assert (lv.cpu().numpy() % 32 == 0).all() and (got == rig.n // 8).all(), (t, got)  # one eighth of the legs in every phase
+            want = np.bincount([(ctx.L.mi_fifo_phase_of(s, 8) - t - 1) % 8 for s in range(rig.n)], minlength=8)
+            assert (lv.cpu().numpy() % 32 == 0).all() and (got == want).all(), (t, got, want)
+            assert got.min() >= rig.n // 16 and got.max() <= rig.n // 4  # about one eighth of the legs in every phase
         assert rig.overflows() == 0
         rig.f_out.levels(lv)
         ctx.sync()
@@ -683,3 +686,139 @@ def test_bench_rig_with_legs_out_of_phase(ctx):
         assert heard.all()
     finally:
         rig.close()
+
+
+def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
+    """mi_aec_process_fifos keeps, per class b % 8 (the XCD a workgroup lands on), a list of its legs that every launch
+    re-sorts for the next one: legs that will have two frames first, the others last.  After any number of ticks the list is
+    a permutation of the class's legs, sorted by what the legs really have in the next tick -- here with the product's stagger
+-- and the results do not depend on the order (same outputs as a batch
+    whose legs are arranged the other way round)."""
+    torch = pytest.importorskip("torch")
+    rate, F, n, ns = 48000, 256, 203, 480
+    flen = 32 * rate // 1000
+    mic = np.stack([synth_pcm(400 + s, ns * 30, rate=rate, sigma=2500.0) for s in range(n)])
+    ref = np.stack([synth_pcm(700 + s, ns * 30, rate=rate, sigma=3000.0) for s in range(n)])
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+
+    def rig(rev):
+        a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+        fm, fr, fo = (ms.FifoBatch(ctx, n, 1536) for _ in range(3))
+        return a, fm, fr, fo, (np.arange(n)[::-1].copy() if rev else np.arange(n))
+
+    outs = []
+    for rev in (False, True):
+        a, fm, fr, fo, perm = rig(rev)
+        # the same lead for the same SIGNAL in both arrangements: leads set by hand from the forward batch's phases
+        lead = np.array([32 * ctx.L.mi_fifo_phase_of(int(perm[s]), 8) for s in range(n)], np.int32)
+        zeros, d_lead = z(n, 256), torch.from_numpy(lead).cuda()
+        torch.cuda.synchronize()
+        fm.push(zeros, nsamples=224, count=d_lead)
+        fr.push(zeros, nsamples=224, count=d_lead)
+        cnt, tick, lv = z(n, dt=torch.uint8), z(n, ns), z(n, dt=torch.int32)
+        got = []
+        for t in range(30):
+            dm = torch.from_numpy(np.ascontiguousarray(mic[perm, t * ns:(t + 1) * ns])).cuda()
+            dr = torch.from_numpy(np.ascontiguousarray(ref[perm, t * ns:(t + 1) * ns])).cuda()
+            torch.cuda.synchronize()
+            a.process_fifos(fm, dm, fr, dr, fo, tick_len=ns, max_frames=2, count_out=cnt)
+            fo.pop(ns, tick, zero_fill=True)
+            fm.levels(lv)
+            ctx.sync()
+            got.append(tick.cpu().numpy()[np.argsort(perm)].copy())
+            order = a.get(0, "order", n).astype(int)
+            nxt = (lv.cpu().numpy() + ns) // F          # frames every leg will have in the next tick
+            pos = 0
+            for c in range(8):
+                k = len(range(c, n, 8))
+                lst = order[pos:pos + k]
+                pos += k
+                assert sorted(lst) == list(range(c, n, 8)), (t, c)           # a permutation of the class's legs
+                fr_next = nxt[lst]
+                assert (np.diff((fr_next >= 2).astype(int)) <= 0).all(), (t, c, fr_next)  # two-frame legs first
+        outs.append(np.stack(got))
+        assert fm.overflows() + fr.overflows() + fo.overflows() == 0
+        for o in (a, fm, fr, fo):
+            o.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert outs[0].any()
+
+
+def test_canceller_state_copied_on_the_device_continues_bit_for_bit(ctx):
+    """mi_aec_copy_state: a batch seeded from another one's converged legs continues exactly as they do."""
+    rate, F, n = 16000, 128, 6
+    flen = 64 * rate // 1000
+    x = np.stack([synth_pcm(40 + s, F * 60, rate=rate, sigma=3000.0) for s in range(n)])
+    m = np.stack([(0.4 * x[s] + synth_pcm(90 + s, F * 60, rate=rate, sigma=100.0)).astype(np.int16) for s in range(n)])
+    a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    b = ms.AecBatch(ctx, 2 * n + 1, rate, frame_size=F, filter_length=flen)
+    for f in range(40):
+        a.process(np.ascontiguousarray(m[:, f * F:(f + 1) * F]), np.ascontiguousarray(x[:, f * F:(f + 1) * F]), flags=ms.MI_AEC_POSTFILTER)
+    b.copy_state_from(a, 0, 0, n)
+    b.copy_state_from(a, 0, n + 1, n)       # leg n of b stays as created
+    with pytest.raises(ms.MiError):
+        b.copy_state_from(a, 0, n + 2, n)   # does not fit
+    for f in range(40, 60):
+        sl = slice(f * F, (f + 1) * F)
+        oa = a.process(np.ascontiguousarray(m[:, sl]), np.ascontiguousarray(x[:, sl]), flags=ms.MI_AEC_POSTFILTER)
+        mb = np.concatenate([m[:, sl], m[:1, sl], m[:, sl]])
+        xb = np.concatenate([x[:, sl], x[:1, sl], x[:, sl]])
+        ob = b.process(np.ascontiguousarray(mb), np.ascontiguousarray(xb), flags=ms.MI_AEC_POSTFILTER)
+        np.testing.assert_array_equal(ob[:n], oa)
+        np.testing.assert_array_equal(ob[n + 1:], oa)
+    assert a.get(0, "counters", 4)[3] == 60 and b.get(0, "counters", 4)[3] == 60 and b.get(n, "counters", 4)[3] == 20
+    a.close()
+    b.close()
+
+
+def test_session_with_the_products_stagger_equals_the_chain_given_the_same_leads(ctx):
+    """mi_session_config.stagger (the C default): every leg starts with mi_aec_stagger_fifos' lead; a leg that is reset gets
+    its lead again.  Output == the chain of individual objects whose queues were given the same leads."""
+    torch = pytest.importorskip("torch")
+    nconf, mm, nticks, F, rate, ns = 2, 8, 20, 256, 48000, 480
+    n = nconf * mm
+    mic16 = np.stack([synth_pcm(s, 160 * nticks, rate=16000, sigma=2500.0) for s in range(n)])
+    ref48 = np.stack([synth_pcm(500 + s, ns * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+    rs = ms.ResamplerBatch(ctx, n, 16000, rate)
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=128 * rate // 1000)
+    vol = ms.VolumeBatch(ctx, n, rate)
+    p = vol.default_params()
+    p.agc_enabled = 1
+    vol.set_params([p] * n)
+    mix = ms.MixerBatch(ctx, nconf, mm, ns)
+    f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, 1536) for _ in range(3))
+    assert aec.stagger_info(ns) == (32, 8) and ms.AecBatch(ctx, 1, 16000).stagger_info(160) == (32, 4)
+    aec.stagger_fifos(f_mic, f_ref, ns)
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    up, tick, mixed = z(n, 488), z(n, ns), z(nconf, mm, ns)
+    want = []
+    for t in range(nticks):
+        d_mic = torch.from_numpy(np.ascontiguousarray(mic16[:, t * 160:(t + 1) * 160])).cuda()
+        d_ref = torch.from_numpy(np.ascontiguousarray(ref48[:, t * ns:(t + 1) * ns])).cuda()
+        torch.cuda.synchronize()
+        if t == 9:  # leg 3 is replaced in its slot
+            ctx.sync()
+            rs.reset(3, 1)
+            aec.reset(3, 1)
+            fresh = ms.VolumeBatch(ctx, 1, rate).get_state()[0]
+            vol.set_state([fresh], first=3)
+            vol.reset_max(3, 1)
+            for f in (f_mic, f_ref, f_out):
+                f.reset_range(3, 1)
+            aec.stagger_fifos(f_mic, f_ref, ns, first=3, count=1)
+        rs.process(d_mic, out=up)
+        aec.process_fifos(f_mic, up, f_ref, d_ref, f_out, tick_len=ns, max_frames=2)
+        vol.process_fifo(f_out, tick)
+        mix.process(tick.view(nconf, mm, ns), out=mixed)
+        ctx.sync()
+        want.append(mixed.cpu().numpy().reshape(n, ns).copy())
+    se = ms.Session(ctx, n, members=mm, in_rate=16000, rate=rate, tail_ms=128, agc=True, use_graphs=False, stagger=True)
+    for t in range(nticks):
+        if t == 9:
+            se.reset_streams(3, 1)
+        h_mic, h_ref = se.acquire()
+        h_mic[:] = mic16[:, t * 160:(t + 1) * 160]
+        h_ref[:] = ref48[:, t * ns:(t + 1) * ns]
+        se.submit()
+        np.testing.assert_array_equal(se.collect(), want[t], err_msg=f"tick {t}")
+    se.close()

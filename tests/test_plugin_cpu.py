@@ -125,3 +125,34 @@ def test_without_a_device_the_plugin_steps_aside():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "NOT registered" in p.stderr
+
+
+@pytest.mark.parametrize("claim", [False, True])
+def test_webrtc_aec_name_is_claimed_only_on_request(claim):
+    """The factory's default echo-canceller NAME is "MSWebRTCAEC" (msfactory.c:245); audio_stream_new_with_sessions looks the
+    name up and falls back to MS_SPEEX_EC_ID (audiostream.c:2128-2158).  By default the plugin does not answer to that name;
+    with MSMI355X_CLAIM_WEBRTC_AEC=1 it does, with a descriptor whose text says it is not AEC3 and whose methods are the
+    speex-class canceller's."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, os, sys\n"
+        "os.environ['MSMI355X_REGISTER_WITHOUT_DEVICE'] = '1'\n"
+        + ("os.environ['MSMI355X_CLAIM_WEBRTC_AEC'] = '1'\n" if claim else "os.environ.pop('MSMI355X_CLAIM_WEBRTC_AEC', None)\n") +
+        f"S = C.CDLL({os.path.join(ROOT, 'tests', 'host', 'libms2shim.so')!r}, mode=C.RTLD_GLOBAL)\n"
+        "S.ms_factory_new.restype = C.c_void_p\n"
+        "S.ms_factory_load_plugin.argtypes = [C.c_void_p, C.c_char_p]\n"
+        "S.ms_factory_lookup_filter_by_name.restype = C.c_void_p\n"
+        "S.ms_factory_lookup_filter_by_name.argtypes = [C.c_void_p, C.c_char_p]\n"
+        "fac = S.ms_factory_new()\n"
+        f"assert S.ms_factory_load_plugin(fac, {os.path.join(PKG, 'libmsmi355xfilters.so')!r}.encode()) == 0\n"
+        "d = S.ms_factory_lookup_filter_by_name(fac, b'MSWebRTCAEC')\n"
+        "assert S.ms_factory_lookup_filter_by_name(fac, b'MSSpeexEC')\n"
+        "if d:\n"
+        "    text = C.cast(C.c_void_p.from_address(d + 16).value, C.c_char_p).value\n"  # MSFilterDesc.text (msfilter.h:161-178)
+        "    assert b'NOT WebRTC AEC3' in text, text\n"
+        "sys.exit(1 if d else 0)\n"
+    )
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == (1 if claim else 0), p.stdout + p.stderr
+    assert ("this is not AEC3" in p.stderr) == claim
