@@ -29,9 +29,10 @@ between ticks.  The legs' re-framing phases are the product's own
 N > 1 (one rank per GPU, torch.distributed.run): legs and whole conferences are
 sharded statically (no collective); in addition 64 conferences are split over
 ALL ranks and mixed through the path's one exchange step every tick:
-mi_mixer_partial_sum -> int32 all-reduce over RCCL (explicit events between the
-kernel stream and the collective's stream) -> mi_mixer_finalize, checked bit
-for bit against the single-GPU mix on rank 0.  RCCL failure = non-zero exit.
+mi_mixer_partial_sum -> mi_exchange_allreduce_i32 (C ABI, straight on RCCL, on
+the kernel stream: torch.distributed only launches the ranks and carries the
+128-byte id) -> mi_mixer_finalize, checked bit for bit against the single-GPU
+mix on rank 0.  RCCL failure = non-zero exit.
 
 roofline = the canceller's tick kernel (canceller + post-filter + FIFOs, one
 launch) INSIDE the running chain at the headline leg count, HIP events on the
@@ -862,9 +863,21 @@ class HipPlatform:
         import mediastreamer2_amd as ms
         return ms
 
-    def exchange(self, ctx, local):
-        from mediastreamer2_amd.sharding import PartialSumExchange
-        return PartialSumExchange(ctx.stream, local)
+    def exchange(self, ctx, local, dist, rank, world, backend):
+        """the split conferences' all-reduce: mi_exchange (C ABI, straight on RCCL, enqueued on the context's stream).
+        torch.distributed only carries the 128-byte id from rank 0 to the others.  A test backend (gloo, ranks sharing
+        one GPU -- RCCL refuses that) goes through torch instead and is named in the line."""
+        if backend != "nccl":
+            from mediastreamer2_amd.sharding import PartialSumExchange
+            return PartialSumExchange(ctx.stream, local)
+        import torch
+        ms = self.load()
+        idt = torch.zeros(128, dtype=torch.uint8, device=self.device)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(ms.Exchange.unique_id(ctx)), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        self.sync(torch)
+        return ms.Exchange(ctx, world, rank, idt.cpu().numpy().tobytes())
 
     def converged(self, ms, torch, ctx, rank):
         return Converged(ms, torch, ctx, rank)
@@ -900,12 +913,10 @@ def init_distributed(torch, rank, world, local):
 class Headline:
     """The timed region: K ticks of the chain at `nstreams` legs per GPU."""
 
-    def __init__(self, ms, torch, ctx, nstreams, world, rank, dist, local):
+    def __init__(self, ms, torch, ctx, nstreams, world, rank, dist, local, exchange=None):
         self.ms, self.torch, self.ctx, self.world, self.dist = ms, torch, ctx, world, dist
         self.rig = ChainRig(ms, torch, ctx, nstreams, world=world, rank=rank, nsplit=SPLIT_CONFERENCES if world > 1 else 0)
-        self.exchange = None
-        if world > 1:
-            self.exchange = PLATFORM.exchange(ctx, local)
+        self.exchange = exchange  # N > 1: the callable that all-reduces the split conferences' partial sums in place
 
     def prepare(self, warmup, converged=None):
         rig, P = self.rig, self.rig.RING
@@ -1059,6 +1070,13 @@ def main():
 
     ctx = ms.Context(local)
     props = ctx.props()
+    exchange = None
+    if world > 1:
+        try:  # one communicator for the whole run; any RCCL failure ends the run (no fallback transport)
+            exchange = PLATFORM.exchange(ctx, local, dist, rank, world, backend)
+        except Exception as e:
+            print(f"bench.py: rank {rank}: the conference exchange (mi_exchange on RCCL) could not be set up: {str(e)[:300]}", file=sys.stderr)
+            sys.exit(3)
 
     def reduce_scalar(v, op):
         if dist is None:
@@ -1097,7 +1115,7 @@ def main():
         zero_ok = zero is None or zero["tick_ms_worst"] < 10.0
         head = None
         if zero_ok or a.streams > 0 or streams <= 8192:
-            head = Headline(ms, torch, ctx, streams, world, rank, dist, local)
+            head = Headline(ms, torch, ctx, streams, world, rank, dist, local, exchange)
             head.prepare(a.warmup, converged)
             fg0 = head.rig.canceller_stats() if hasattr(head.rig, "canceller_stats") else None
             series = head.tick_series(a.worst_ticks)
@@ -1157,8 +1175,9 @@ def main():
     parallelism = "1 GPU"
     if world > 1:
         parallelism = (f"{world} ranks, one per GPU; legs and whole conferences sharded statically (no collective), "
-                       f"{SPLIT_CONFERENCES} conferences split over all ranks: int32 partial sums -> {backend} "
-                       f"all-reduce ({'RCCL over xGMI' if backend == 'nccl' else 'TEST BACKEND, not RCCL'}) -> finalize, every tick")
+                       f"{SPLIT_CONFERENCES} conferences split over all ranks: int32 partial sums -> "
+                       f"{'mi_exchange_allreduce_i32 (C ABI, RCCL over xGMI, on the kernel stream)' if backend == 'nccl' else backend + ' all-reduce (TEST BACKEND, not RCCL)'} "
+                       "-> finalize, every tick")
     line = {
         "metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale",
         "value": total_streams if fits else 0,

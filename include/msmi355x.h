@@ -172,6 +172,24 @@ int mi_mixer_partial_sum(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_
 int mi_mixer_finalize(mi_mixer *m, const int16_t *d_in, const uint8_t *d_has_data, const int32_t *d_sum,
                       int conf_mode, int16_t *d_out);
 
+/* ------------------------------------------------------------ exchange */
+/* The one cross-GPU step of the path: the int32 all-reduce between mi_mixer_partial_sum and mi_mixer_finalize when a
+ * conference's members live on several GPUs (audiomixer.c:304-314 across devices), directly on RCCL (xGMI
+ * inside a node).  One exchange rank per context; the ranks may be threads of one process or processes.
+ *   rank 0:      mi_exchange_unique_id(id) and hands the 128 bytes to the others (any transport);
+ *   every rank:  mi_exchange_create(ctx, nranks, rank, id, &x)   -- returns when all ranks have joined;
+ *   every tick:  mi_mixer_partial_sum(.., d_sum); mi_exchange_allreduce_i32(x, d_sum, n); mi_mixer_finalize(.., d_sum, ..)
+ * The collective is enqueued on the context's own stream: stream order puts it after the partial sums and before the
+ * finalize, nothing blocks the host.  librccl is loaded on first use; any RCCL failure is MI_ENODEV with RCCL's message
+ * in mi_last_error() -- there is no fallback transport. */
+typedef struct mi_exchange mi_exchange;
+#define MI_EXCHANGE_ID_BYTES 128
+int mi_exchange_unique_id(void *id_out, size_t cap);
+int mi_exchange_create(mi_ctx *ctx, int nranks, int rank, const void *unique_id, mi_exchange **out);
+void mi_exchange_destroy(mi_exchange *x);
+int mi_exchange_ranks(const mi_exchange *x, int *nranks, int *rank);
+int mi_exchange_allreduce_i32(mi_exchange *x, int32_t *d_buf, size_t count); /* in place, sum over the ranks */
+
 /* -------------------------------------------------------------- volume */
 typedef struct mi_volume mi_volume;
 /* user-settable fields of struct Volume (msvolume.c:48-86), set by the
@@ -300,7 +318,7 @@ size_t mi_aec_state_bytes(const mi_aec *a);
  *   float X[(M+1) N] (ring, bin-interleaved), W[M N], foreground[M N], small_state[19 F + 192]; scalar record.
  * Import checks tag, version, rate / frame / tail and the size, and refuses anything else; a restored stream continues
  * bit for bit. */
-#define MI_AEC_BLOB_VERSION 2u
+#define MI_AEC_BLOB_VERSION 3u
 size_t mi_aec_blob_bytes(const mi_aec *a);
 int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap);
 int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size);

@@ -217,6 +217,32 @@ class MixerBatch(_Batch):
         return out
 
 
+class Exchange(_Batch):
+    """mi_exchange: the split conferences' int32 all-reduce on RCCL, enqueued on the context's stream."""
+    _destroy = "mi_exchange_destroy"
+
+    @staticmethod
+    def unique_id(ctx):
+        buf = np.zeros(128, np.uint8)
+        check(ctx.L.mi_exchange_unique_id(buf.ctypes.data, buf.size))
+        return buf.tobytes()
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        self.ctx, self.nranks, self.rank = ctx, nranks, rank
+        buf = np.frombuffer(unique_id, np.uint8).copy()
+        assert buf.size == 128
+        h = C.c_void_p()
+        check(ctx.L.mi_exchange_create(ctx.h, nranks, rank, buf.ctypes.data, C.byref(h)))
+        self.h = h
+
+    def allreduce(self, d_sum):
+        """d_sum: contiguous int32 device tensor, summed in place over the ranks"""
+        check(self.ctx.L.mi_exchange_allreduce_i32(self.h, _ptr(d_sum), d_sum.numel()))
+        return d_sum
+
+    __call__ = allreduce
+
+
 class VolumeBatch(_Batch):
     """nstreams MSVolume chunks (msvolume.c:471-514)."""
     _destroy = "mi_volume_destroy"

@@ -32,6 +32,7 @@ EXPORTS = [
     "mi_resampler_process_masked", "mi_mixer_process_masked", "mi_equalizer_process_masked",
     "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
+    "mi_exchange_unique_id", "mi_exchange_create", "mi_exchange_destroy", "mi_exchange_ranks", "mi_exchange_allreduce_i32",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
     "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
@@ -156,6 +157,12 @@ def load():
     L.mi_volume_set_params.argtypes = [vp, i32, i32, C.POINTER(VolumeParams)]
     L.mi_volume_get_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
     L.mi_volume_set_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
+    L.mi_exchange_unique_id.argtypes = [vp, sz]
+    L.mi_exchange_create.argtypes = [vp, i32, i32, vp, pp]
+    L.mi_exchange_destroy.argtypes = [vp]
+    L.mi_exchange_destroy.restype = None
+    L.mi_exchange_ranks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.mi_exchange_allreduce_i32.argtypes = [vp, vp, sz]
     L.mi_aec_copy_state.argtypes = [vp, i32, vp, i32, i32]
     L.mi_aec_stagger_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.mi_aec_stagger_fifos.argtypes = [vp, vp, vp, i32, i32, i32]

@@ -36,6 +36,7 @@
 
 #pragma clang fp contract(off)
 
+
 namespace {
 
 constexpr int NB_BANDS = 24;
@@ -71,8 +72,14 @@ struct AecScalars {
 	int bg_resets;    // background := foreground
 	int state_resets; // speex_echo_state_reset after persistent divergence
 	int frames;       // frames cancelled
+	// the last frame asked for foreground := background and no pass over the filter has run since: the foreground array
+	// in HBM is stale, the background array is what it has to become (aec_tick.hpp: pendingFG)
+	int fg_pending;
+	int bg_pending; // the same the other way round: background := foreground waits for the next pass
+	int wsel;       // which half of the stream's filter memory holds the background (the other one the foreground)
+	int pad_[1];
 };
-static_assert(sizeof(AecScalars) == 96, "scalar record");
+static_assert(sizeof(AecScalars) == 112, "scalar record");
 
 struct AecArgs {
 	const int16_t *mic, *ref;
@@ -92,7 +99,8 @@ struct AecArgs {
 	// FIFO entry: leg order of this launch / of the next one, [2][8][cap8] (aec_tick.hpp: TickOrder); null = block b serves leg b
 	int *order, *ctl;
 	int cap8;
-	float *X, *W, *FG;     // [nstreams][(M+1) or M][N]
+	float *X;              // [nstreams][M+1][N] far-end spectra (ring)
+	float *WF;             // [nstreams][2][M][N]: background filter, then foreground filter, of each stream back to back
 	float *small;          // [nstreams][small_stride]
 	AecScalars *scal;      // [nstreams]
 	int small_stride;
@@ -269,7 +277,11 @@ __global__ __launch_bounds__(64) void fft_debug_kernel(const float *in, float *o
 struct mi_aec {
 	mi_ctx *ctx = nullptr;
 	int nstreams = 0, rate = 0, F = 0, N = 0, M = 0;
-	float *d_X = nullptr, *d_W = nullptr, *d_FG = nullptr, *d_small = nullptr;
+	float *d_X = nullptr, *d_WF = nullptr, *d_small = nullptr;
+	// stream s owns two halves of M N floats at d_WF + 2 s M N: one holds the background filter, the other the foreground;
+	// AecScalars::wsel says which (the halves swap roles on update_foreground, aec_tick.hpp)
+	size_t wf_stride() const { return (size_t)2 * M * N; }
+	float *half(int s, int h) const { return d_WF + wf_stride() * s + (size_t)h * M * N; }
 	AecScalars *d_scal = nullptr;
 	void *d_tables = nullptr;
 	AecTables t;
@@ -458,9 +470,8 @@ int init_state(mi_aec *a, int first, int count) {
 	MI_HIP(hipStreamSynchronize(a->ctx->stream));
 	MI_HIP(hipMemcpy(a->d_small + (size_t)first * a->small_stride, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
 	MI_HIP(hipMemcpy(a->d_scal + first, scs.data(), scs.size() * sizeof(AecScalars), hipMemcpyHostToDevice));
-	const size_t wn = (size_t)a->M * a->N, xn = (size_t)(a->M + 1) * a->N;
-	MI_HIP(hipMemset(a->d_W + first * wn, 0, (size_t)count * wn * sizeof(float)));
-	MI_HIP(hipMemset(a->d_FG + first * wn, 0, (size_t)count * wn * sizeof(float)));
+	const size_t xn = (size_t)(a->M + 1) * a->N;
+	MI_HIP(hipMemset(a->half(first, 0), 0, (size_t)count * a->wf_stride() * sizeof(float)));
 	MI_HIP(hipMemset(a->d_X + first * xn, 0, (size_t)count * xn * sizeof(float)));
 	return MI_OK;
 }
@@ -515,16 +526,15 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		}
 		for (int i = M - 1; i >= 0; i--) a->h_prop0[(size_t)i] = (.8f * a->h_prop0[(size_t)i]) / sum;
 	}
-	a->small_stride = 19 * frame_size + 192; // TickLayout<F>::TOTAL
-	const size_t wn = (size_t)M * a->N, xn = (size_t)(M + 1) * a->N;
+	a->small_stride = 19 * frame_size + 256; // TickLayout<F>::TOTAL
+	const size_t xn = (size_t)(M + 1) * a->N;
 	int rc = build_tables(a);
 	if (rc != MI_OK) {
 		mi_aec_destroy(a);
 		return rc;
 	}
 	if (hipMalloc((void **)&a->d_X, (size_t)nstreams * xn * sizeof(float)) != hipSuccess ||
-	    hipMalloc((void **)&a->d_W, (size_t)nstreams * wn * sizeof(float)) != hipSuccess ||
-	    hipMalloc((void **)&a->d_FG, (size_t)nstreams * wn * sizeof(float)) != hipSuccess ||
+	    hipMalloc((void **)&a->d_WF, (size_t)nstreams * a->wf_stride() * sizeof(float)) != hipSuccess ||
 	    hipMalloc((void **)&a->d_small, (size_t)nstreams * a->small_stride * sizeof(float)) != hipSuccess ||
 	    hipMalloc((void **)&a->d_scal, (size_t)nstreams * sizeof(AecScalars)) != hipSuccess) {
 		mi::set_error("hipMalloc failed for AEC state (%zu bytes per stream)", mi_aec_state_bytes(a));
@@ -557,8 +567,7 @@ void mi_aec_destroy(mi_aec *a) {
 	if (!a) return;
 	(void)hipSetDevice(a->ctx->device);
 	if (a->d_X) (void)hipFree(a->d_X);
-	if (a->d_W) (void)hipFree(a->d_W);
-	if (a->d_FG) (void)hipFree(a->d_FG);
+	if (a->d_WF) (void)hipFree(a->d_WF);
 	if (a->d_small) (void)hipFree(a->d_small);
 	if (a->d_scal) (void)hipFree(a->d_scal);
 	if (a->d_tables) (void)hipFree(a->d_tables);
@@ -624,8 +633,7 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.M = a->M;
 	g.flags = (int)flags;
 	g.X = a->d_X;
-	g.W = a->d_W;
-	g.FG = a->d_FG;
+	g.WF = a->d_WF;
 	g.small = a->d_small;
 	g.scal = a->d_scal;
 	g.small_stride = a->small_stride;
@@ -759,7 +767,10 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 	std::vector<float> res;
 	if (!strcmp(what, "W") || !strcmp(what, "foreground")) {
 		std::vector<float> raw((size_t)M * N);
-		const float *src = (!strcmp(what, "W") ? a->d_W : a->d_FG) + (size_t)stream * M * N;
+		// a foreground update that waits for the next pass over the filter: the foreground IS the background by then
+		const bool want_w = !strcmp(what, "W");
+		// the half that holds the background / the foreground; a copy still waiting for its pass is looked through
+		const float *src = a->half(stream, ((want_w && !sc.bg_pending) || (!want_w && sc.fg_pending)) ? sc.wsel : sc.wsel ^ 1);
 		MI_HIP(hipMemcpy(raw.data(), src, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
 		res.resize(raw.size());
 		for (int j = 0; j < M; ++j) unpack(raw.data() + (size_t)j * N, res.data() + (size_t)j * N);
@@ -825,13 +836,17 @@ int mi_aec_export_state(mi_aec *a, int stream, void *h_blob, size_t cap) {
 	p += sizeof(h);
 	MI_HIP(hipMemcpy(p, a->d_X + (size_t)stream * xn, xn * 4, hipMemcpyDeviceToHost));
 	p += xn * 4;
-	MI_HIP(hipMemcpy(p, a->d_W + (size_t)stream * wn, wn * 4, hipMemcpyDeviceToHost));
+	AecScalars sc;
+	MI_HIP(hipMemcpy(&sc, a->d_scal + stream, sizeof(sc), hipMemcpyDeviceToHost));
+	// a filter copy still waiting for its pass is carried out in the blob: the blob holds the filters as they are meant
+	MI_HIP(hipMemcpy(p, a->half(stream, sc.bg_pending ? sc.wsel ^ 1 : sc.wsel), wn * 4, hipMemcpyDeviceToHost));
 	p += wn * 4;
-	MI_HIP(hipMemcpy(p, a->d_FG + (size_t)stream * wn, wn * 4, hipMemcpyDeviceToHost));
+	MI_HIP(hipMemcpy(p, a->half(stream, sc.fg_pending ? sc.wsel : sc.wsel ^ 1), wn * 4, hipMemcpyDeviceToHost));
+	sc.fg_pending = sc.bg_pending = sc.wsel = 0; // in the blob: background first, foreground second, nothing waiting
 	p += wn * 4;
 	MI_HIP(hipMemcpy(p, a->d_small + (size_t)stream * sn, sn * 4, hipMemcpyDeviceToHost));
 	p += sn * 4;
-	MI_HIP(hipMemcpy(p, a->d_scal + stream, sizeof(AecScalars), hipMemcpyDeviceToHost));
+	memcpy(p, &sc, sizeof(sc));
 	return MI_OK;
 }
 
@@ -865,9 +880,9 @@ int mi_aec_import_state(mi_aec *a, int stream, const void *h_blob, size_t size) 
 	const uint8_t *p = (const uint8_t *)h_blob + sizeof(h);
 	MI_HIP(hipMemcpy(a->d_X + (size_t)stream * xn, p, xn * 4, hipMemcpyHostToDevice));
 	p += xn * 4;
-	MI_HIP(hipMemcpy(a->d_W + (size_t)stream * wn, p, wn * 4, hipMemcpyHostToDevice));
+	MI_HIP(hipMemcpy(a->half(stream, 0), p, wn * 4, hipMemcpyHostToDevice));
 	p += wn * 4;
-	MI_HIP(hipMemcpy(a->d_FG + (size_t)stream * wn, p, wn * 4, hipMemcpyHostToDevice));
+	MI_HIP(hipMemcpy(a->half(stream, 1), p, wn * 4, hipMemcpyHostToDevice));
 	p += wn * 4;
 	MI_HIP(hipMemcpy(a->d_small + (size_t)stream * sn, p, sn * 4, hipMemcpyHostToDevice));
 	p += sn * 4;
@@ -884,11 +899,10 @@ int mi_aec_copy_state(mi_aec *dst, int dst_first, const mi_aec *src, int src_fir
 	if (count == 0) return MI_OK;
 	if (dst->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(src->ctx->stream)); // the source's state as of everything enqueued on its stream so far
-	const size_t wn = (size_t)dst->M * dst->N, xn = (size_t)(dst->M + 1) * dst->N, sn = (size_t)dst->small_stride, c = (size_t)count;
+	const size_t xn = (size_t)(dst->M + 1) * dst->N, sn = (size_t)dst->small_stride, c = (size_t)count;
 	hipStream_t st = dst->ctx->stream;
 	MI_HIP(hipMemcpyAsync(dst->d_X + dst_first * xn, src->d_X + src_first * xn, c * xn * 4, hipMemcpyDeviceToDevice, st));
-	MI_HIP(hipMemcpyAsync(dst->d_W + dst_first * wn, src->d_W + src_first * wn, c * wn * 4, hipMemcpyDeviceToDevice, st));
-	MI_HIP(hipMemcpyAsync(dst->d_FG + dst_first * wn, src->d_FG + src_first * wn, c * wn * 4, hipMemcpyDeviceToDevice, st));
+	MI_HIP(hipMemcpyAsync(dst->half(dst_first, 0), src->half(src_first, 0), c * dst->wf_stride() * 4, hipMemcpyDeviceToDevice, st));
 	MI_HIP(hipMemcpyAsync(dst->d_small + dst_first * sn, src->d_small + src_first * sn, c * sn * 4, hipMemcpyDeviceToDevice, st));
 	MI_HIP(hipMemcpyAsync(dst->d_scal + dst_first, src->d_scal + src_first, c * sizeof(AecScalars), hipMemcpyDeviceToDevice, st));
 	return MI_OK;

@@ -44,7 +44,8 @@ struct TickLayout { // offsets in floats inside the per-stream small-state block
 	static constexpr int TAIL = MISC + 128;  // POWER[F], POWER1[F], EH[F], YH[F]
 	static constexpr int OLDPS_B = MISC + 136; // 24 Bark bands
 	static constexpr int ZETA_B = MISC + 160;
-	static constexpr int TOTAL = 19 * F + 192;
+	static constexpr int FGNORM = MISC + 192; // M: |foreground block|^2, what WNORM becomes when the background is reset to it
+	static constexpr int TOTAL = 19 * F + 256;
 };
 
 // LDS of the canceller kernel: FFT work space + tables and the per-bin state parked while the blocks stream (none of the
@@ -288,10 +289,14 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	float *sm = a.small + (size_t)s * a.small_stride;
 	const rsrc_t rS = mk_rsrc(sm, (unsigned)a.small_stride * 4u);
 	const rsrc_t rX = mk_rsrc(a.X + (size_t)s * (M + 1) * N, (unsigned)((M + 1) * N) * 4u);
-	const rsrc_t rW = mk_rsrc(a.W + (size_t)s * M * N, (unsigned)(M * N) * 4u);
-	const rsrc_t rF = mk_rsrc(a.FG + (size_t)s * M * N, (unsigned)(M * N) * 4u);
+	// The two filters of a stream lie back to back in two equal halves: ONE descriptor, a half is chosen by a scalar offset.
+	// Which half holds the background and which the foreground is per-stream state (sc.wsel): it is how the library's two
+	// filter copies cost nothing here (see pendingFG below).
+	const rsrc_t rWF = mk_rsrc(a.WF + (size_t)s * 2 * M * N, (unsigned)(2 * M * N) * 4u);
+	const unsigned HALF = (unsigned)(M * N) * 4u;
 	const unsigned vb4 = (unsigned)e0 * 4u, vb8 = (unsigned)e0 * 8u; // this lane's byte offset into a float / a bin array
 	AecScalars sc = a.scal[s];
+	unsigned wo = sc.wsel ? HALF : 0u, fo = HALF - wo; // byte offset of the background / foreground half
 
 	// ---- tables, per-block step / norm, the per-bin state that stays in registers for the whole tick
 #pragma unroll
@@ -361,7 +366,18 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	float2 spec2[K]; // frame 2's foreground response, accumulated over frame 1's pass
 #pragma unroll
 	for (int k = 0; k < K; ++k) spec2[k] = make_float2(0, 0);
-	bool pendingFG = false; // frame 1 asked for foreground := background; frame 2's pass carries the copy out
+	// The library's two filter copies are never passes of their own, and neither moves a byte that was not moving anyway:
+	//  * foreground := background (update_foreground).  The NEXT pass over the filter -- this tick's second frame's, or the
+	//    first frame's of the next tick (the request then waits in the scalars) -- reads the background's half, which IS the
+	//    foreground from now on, and writes the updated background into the OTHER half: the halves swap roles (sc.wsel).
+	//    That pass reads one filter instead of two; nothing is copied.  (A pass of its own cost 98 KB per request and made the
+	//    ticks in which many legs ask at once -- every ~12th with SURVEY 8(d)'s scene -- 10 % longer than the others.)
+	//  * background := foreground (reset_background).  The next pass reads the foreground's half as the background too and
+	//    writes the updated blocks to the background's half as it always does.  The block norms the proportional step needs
+	//    in between are the foreground's, kept alongside (fgnorm: taken from wnorm whenever the foreground is set).
+	// Until that pass one half in HBM is stale; fg_pending / bg_pending say so (mi_aec_get / export_state resolve it).
+	bool pendingFG = sc.fg_pending != 0, pendingBG = sc.bg_pending != 0;
+	float fgnorm = lane < M ? sm[SL::FGNORM + lane] : 0.f; // lane j: |foreground block j|^2 (one register for the whole tick)
 	const bool postfilter = (a.flags & 1) != 0; // MI_AEC_POSTFILTER
 	float leakf[2] = {sc.leak_estimate, sc.leak_estimate}; // leak estimate after each frame (post-filter input)
 	bool resetf[2] = {false, false};                       // the frame reset the canceller: its echo estimate is zero
@@ -379,8 +395,9 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		} else {
 			bload_bins<K>(rX, vb8, xoff(1), pre0);
 			bload_bins<K>(rX, vb8, xoff(2 < M ? 2 : M), pre1);
-			bload_bins<K>(rW, vb8, 0, pre2);
-			bload_bins<K>(rW, vb8, (unsigned)(1 < M ? 1 : 0) * (unsigned)(F * 8), pre3);
+			const unsigned wpre = pendingBG ? fo : wo; // frame 1 reset the background: its blocks are the foreground's
+			bload_bins<K>(rWF, vb8, wpre, pre2);
+			bload_bins<K>(rWF, vb8, wpre + (unsigned)(1 < M ? 1 : 0) * (unsigned)(F * 8), pre3);
 		}
 		// ---- near end: saturation flag, DC notch (serial IIR), pre-emphasis
 		int any_sat;
@@ -495,15 +512,20 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			v2f xj[K], xn[K], fg[K], wl[K], xm1[K]; // xm1: the block before xj = frame 2's block at this position (register pairs)
 #pragma unroll
 			for (int k = 0; k < K; ++k) xj[k] = (v2f){X0[k].x, X0[k].y}, xm1[k] = (v2f){X0B[k].x, X0B[k].y};
+			// a filter copy the previous tick's last frame asked for (see pendingFG above): which half is read as what, and where
+			// the updated background goes
+			const bool carryFG = pendingFG, carryBG = pendingBG;
+			pendingFG = pendingBG = false;
+			const unsigned fsrc = carryFG ? wo : fo, wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
 			bload_bins<K>(rX, vb8, xoff(1), xn);
-			bload_bins<K>(rF, vb8, 0, fg);
-			bload_bins<K>(rW, vb8, 0, wl);
+			bload_bins<K>(rWF, vb8, fsrc, fg);
+			bload_bins<K>(rWF, vb8, wsrc, wl);
 			for (int j = 0; j < M; ++j) {
 				v2f xn2[K], fg2[K], wl2[K];
 				if (j + 1 < M) {
 					bload_bins<K>(rX, vb8, xoff(j + 2), xn2);
-					bload_bins<K>(rF, vb8, (unsigned)(j + 1) * (F * 8), fg2);
-					bload_bins<K>(rW, vb8, (unsigned)(j + 1) * (F * 8), wl2);
+					bload_bins<K>(rWF, vb8, fsrc + (unsigned)(j + 1) * (F * 8), fg2);
+					bload_bins<K>(rWF, vb8, wsrc + (unsigned)(j + 1) * (F * 8), wl2);
 				} else {
 #pragma unroll
 					for (int k = 0; k < K; ++k) xn2[k] = xn[k], fg2[k] = fg[k], wl2[k] = wl[k];
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(wl, xn, L.prop[j]);
 				if (aumdf) constrain(wl);
-				if (do_grad || aumdf) bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), wl);
+				if (do_grad || aumdf || carryBG || carryFG) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), wl);
 				cmac_bins<K>(yfg, xj, fg, e0);
 				cmac_bins<K>(ybgs, xj, wl, e0);
 				if (spec) cmac_bins<K>(spec2, xm1, fg, e0);
@@ -519,9 +541,15 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 #pragma unroll
 				for (int k = 0; k < K; ++k) xm1[k] = xj[k], xj[k] = xn[k], xn[k] = xn2[k], fg[k] = fg2[k], wl[k] = wl2[k];
 			}
+			if (carryFG) { // the halves have swapped roles
+				const unsigned t = wo;
+				wo = fo, fo = t;
+				sc.wsel ^= 1;
+			}
 		} else {
 			// frame 2: X and the background only.  alt = sum_j X(j) W1(j) with W1 the background as frame 1 left it: the
-			// foreground response when frame 1 updated the foreground; the same blocks are then stored as the foreground.
+			// foreground response when frame 1 updated the foreground (its half then stays behind as the foreground and the
+			// updated blocks go to the other half).
 			// Two blocks per iteration: every iteration ends in ONE wait for everything in flight (loads and stores share a
 			// counter and may complete out of order with each other, so with a store in flight the only wait is vmcnt(0)), a
 			// full memory round trip that the iteration's arithmetic does not cover.  This pass has no foreground blocks in
@@ -532,34 +560,39 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			for (int k = 0; k < K; ++k) xj[k] = (v2f){X0[k].x, X0[k].y}, alt[k] = make_float2(0, 0);
 			auto xclamp = [&](int i) { return xoff(i < M ? i : M); };
 			auto wclamp = [&](int i) { return (unsigned)(i < M ? i : M - 1) * (unsigned)(F * 8); };
+			const bool carryBG = pendingBG, carryFG = pendingFG; // frame 1 reset the background / updated the foreground
+			pendingBG = false;
+			const unsigned wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
 #pragma unroll
 			for (int k = 0; k < K; ++k) xn[k] = pre0[k], xn2[k] = pre1[k], wl[k] = pre2[k], wl2[k] = pre3[k];
 			auto block = [&](int j, v2f (&w)[K], const v2f (&xa)[K], const v2f (&xb)[K]) { // xa = X(j), xb = X(j+1)
-				if (pendingFG) bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), w);
 				cmac_bins<K>(alt, xa, w, e0);
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(w, xb, L.prop[j]);
 				if (aumdf) constrain(w);
-				if (do_grad || aumdf) bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), w);
+				if (do_grad || aumdf || carryBG || carryFG) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), w);
 				cmac_bins<K>(ybgs, xa, w, e0);
 				norm_of(w, j);
 			};
-			int j = 0;
-			for (; j + 1 < M; j += 2) {
+			for (int j = 0; j < M; j += 2) { // an odd block count: the last round serves one block (no third copy of `block` in the code)
 				v2f xa[K], xb[K], wa[K], wb[K]; // the next pair: X(j+3), X(j+4), W(j+2), W(j+3) (clamped at the end: dropped)
 				bload_bins<K>(rX, vb8, xclamp(j + 3), xa);
 				bload_bins<K>(rX, vb8, xclamp(j + 4), xb);
-				bload_bins<K>(rW, vb8, wclamp(j + 2), wa);
-				bload_bins<K>(rW, vb8, wclamp(j + 3), wb);
+				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 2), wa);
+				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 3), wb);
 				block(j, wl, xj, xn);
-				block(j + 1, wl2, xn, xn2);
+				if (j + 1 < M) block(j + 1, wl2, xn, xn2);
 #pragma unroll
 				for (int k = 0; k < K; ++k) xj[k] = xn2[k], xn[k] = xa[k], xn2[k] = xb[k], wl[k] = wa[k], wl2[k] = wb[k];
 			}
-			if (j < M) block(j, wl, xj, xn); // an odd block count leaves one
 #pragma unroll
-			for (int k = 0; k < K; ++k) yfg[k] = pendingFG ? alt[k] : spec2[k];
+			for (int k = 0; k < K; ++k) yfg[k] = carryFG ? alt[k] : spec2[k];
 			pendingFG = false;
+			if (carryFG) {
+				const unsigned t = wo;
+				wo = fo, fo = t;
+				sc.wsel ^= 1;
+			}
 		}
 
 		// ---- time-domain responses
@@ -593,15 +626,9 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			sc.fg_updates++;
 			sc.Davg1 = sc.Davg2 = 0;
 			sc.Dvar1 = sc.Dvar2 = 0;
-			if (f + 1 < nf) {
-				pendingFG = true; // the next frame's pass stores the blocks it loads anyway
-			} else {
-				for (int j = 0; j < M; ++j) {
-					float2 w[K];
-					bload_bins<K>(rW, vb8, (unsigned)(j) * (F * 8), w);
-					bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), w);
-				}
-			}
+			pendingFG = true; // the next pass over the filter (this tick's or the next one's) carries the copy out
+			WSYNC();
+			if (lane < M) fgnorm = L.wnorm[lane];
 			float h0[K], h1[K];
 			load_vec<K>(a.t.hann + e0, h0);
 			load_vec<K>(a.t.hann + F + e0, h1);
@@ -614,12 +641,9 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			if ((-sc.Davg2) * fabsf(sc.Davg2) > 4.f * sc.Dvar2) reset_background = true;
 			if (reset_background) {
 				sc.bg_resets++;
-				for (int j = 0; j < M; ++j) {
-					float2 w[K];
-					bload_bins<K>(rF, vb8, (unsigned)(j) * (F * 8), w);
-					bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), w);
-					norm_of(w, j);
-				}
+				pendingBG = true; // the next pass reads the foreground's blocks as the background's
+				WSYNC();
+				if (lane < M) L.wnorm[lane] = fgnorm;
 #pragma unroll
 				for (int k = 0; k < K; ++k) {
 					ybg[k] = efg[k];
@@ -706,8 +730,8 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 #pragma unroll
 			for (int k = 0; k < K; ++k) z[k] = 0.f, z2[k] = make_float2(0, 0);
 			for (int j = 0; j < M; ++j) {
-				bstore_bins<K>(rW, vb8, (unsigned)j * (F * 8), z2);
-				bstore_bins<K>(rF, vb8, (unsigned)j * (F * 8), z2);
+				bstore_bins<K>(rWF, vb8, (unsigned)j * (F * 8), z2);
+				bstore_bins<K>(rWF, vb8, HALF + (unsigned)j * (F * 8), z2);
 			}
 			for (int j = 0; j <= M; ++j) bstore_bins<K>(rX, vb8, (unsigned)j * (F * 8), z2);
 #pragma unroll
@@ -724,6 +748,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			p1_F = 1.0f;
 			WSYNC();
 			if (lane < M) L.wnorm[lane] = 0;
+			fgnorm = 0.f;
 			bstore_vec<K>(rS, vb4, SL::LASTY * 4, z);
 			bstore_vec<K>(rS, vb4, (SL::LASTY + F) * 4, z);
 			bstore_vec<K>(rS, vb4, (SL::LASTY + (2) * F) * 4, z);
@@ -737,7 +762,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			sc.sum_adapt = 0;
 			sc.Pey = sc.Pyy = 1.0f;
 			sc.Davg1 = sc.Davg2 = sc.Dvar1 = sc.Dvar2 = 0;
-			pendingFG = false;
+			pendingFG = pendingBG = false;
 			if (f) resetf[1] = true, leakf[1] = sc.leak_estimate;
 			else resetf[0] = true, leakf[0] = sc.leak_estimate;
 			emit(out_i);
@@ -855,6 +880,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	WSYNC();
 	if (lane < M) {
 		sm[SL::WNORM + lane] = L.wnorm[lane];
+		sm[SL::FGNORM + lane] = fgnorm;
 		if (prop_dirty) sm[SL::PROP + lane] = L.prop[lane];
 	}
 	{ // echo estimate of the last frame's pair [older | newest]
@@ -875,6 +901,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		sm[SL::TAIL + 3] = yh_F;
 	}
 	if (!postfilter) {
+		sc.fg_pending = pendingFG ? 1 : 0, sc.bg_pending = pendingBG ? 1 : 0;
 		if (lane == 0) a.scal[s] = sc;
 		return;
 	}
@@ -1127,5 +1154,6 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		sm[SL::ZETA_B + lane] = zeta_b;
 	}
 
+	sc.fg_pending = pendingFG ? 1 : 0, sc.bg_pending = pendingBG ? 1 : 0;
 	if (lane == 0) a.scal[s] = sc;
 }

@@ -35,7 +35,12 @@ const char *mi_last_error(void) { return mi::g_err; }
 
 int mi_device_count(void) {
 	int ndev = 0;
-	return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+	const hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0) {
+		mi::set_error("no HIP device available (%s); libmsmi355x has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+		return 0;
+	}
+	return ndev;
 }
 
 int mi_ctx_create(int device, void *hip_stream, mi_ctx **out) {

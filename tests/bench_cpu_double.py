@@ -163,7 +163,7 @@ class CpuDouble(bench.HipPlatform):
     def converged(self, ms, torch, ctx, rank):
         return None  # no canceller to converge: the double's ticks cost the same in any state
 
-    def exchange(self, ctx, local):
+    def exchange(self, ctx, local, dist_, rank, world, backend):
         import torch.distributed as dist
 
         def exchange(d_sum):

@@ -27,7 +27,8 @@ def _run(world, env_extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--streams", "4096",
-           "--steps", "8", "--warmup", "8", "--min-timed-s", "0.05", "--no-extras", "--no-cpu-baseline"]
+           "--steps", "8", "--warmup", "8", "--min-timed-s", "0.05", "--no-extras", "--no-cpu-baseline",
+           "--worst-ticks", "200", "--zero-ticks", "32", "--roofline-ticks", "8"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
