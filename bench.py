@@ -616,6 +616,10 @@ def tick_series(ctx, graphs, nticks, after=None):
     return v
 
 
+def rig_period(head):
+    return head.rig.RING
+
+
 def series_stats(v):
     return {"ticks": int(v.size), "p50_ms": round(float(np.percentile(v, 50)), 4), "p99_ms": round(float(np.percentile(v, 99)), 4),
             "p99_9_ms": round(float(np.percentile(v, 99.9)), 4), "max_ms": round(float(v.max()), 4), "mean_ms": round(float(v.mean()), 4)}
@@ -1118,6 +1122,11 @@ def main():
             head = Headline(ms, torch, ctx, streams, world, rank, dist, local, exchange)
             head.prepare(a.warmup, converged)
             fg0 = head.rig.canceller_stats() if hasattr(head.rig, "canceller_stats") else None
+            # the read-backs above left the GPU idle for tens of ms and its clocks down: in service a tick follows the
+            # previous one within a millisecond or two.  One untimed scene period brings the device back to its running
+            # state; from there on every tick counts (scripts/outlier_probe.py: after 0.5 s of idle the first tick takes
+            # +1.7 ms, the second +0.6, then nothing)
+            head.tick_series(rig_period(head))
             series = head.tick_series(a.worst_ticks)
             worst = reduce_scalar(float(series.max()), "MAX")
             if log:

@@ -459,7 +459,9 @@ extern MSFilterDesc ms_mi355x_audio_flow_control_desc; /* .id = MS_AUDIO_FLOW_CO
  * display filters reach the GPU too (one frame per call, synchronous, as that interface demands). */
 extern MSScalerDesc ms_mi355x_scaler_desc;
 /* Runs every ticker hub's staged work now.  Normally unnecessary: the facades postpone that task on their ticker
- * themselves (msfilter.c:289-300); for an application that wants the last tick's results before tearing a graph down. */
+ * themselves (msfilter.c:289-300); for an application that wants the last tick's results before tearing a graph down.
+ * It emits into the filters' output queues like the ticker's own task does: call it on the ticker's thread or while the
+ * tickers of the graphs concerned are not running (MSQueue has no lock, src/base/msqueue.c). */
 void ms_mi355x_flush(void);
 /* Blocks dropped or passed through unprocessed because a HIP call failed (0 in a healthy process). */
 unsigned long long ms_mi355x_late_events(void);

@@ -147,14 +147,18 @@ struct TickerHub {
 	bool in_flush = false;
 	std::vector<MSFilter *> touched, touched_pumps;
 	std::unordered_map<MSFilter *, uint64_t> pumped; // pump facades run early by the flush task, and for which tick
-	// no banks left: removed from the registry.  Written under `mu` and the registry lock by a scope that holds a
-	// reference; atomic because the scope that drops the LAST reference re-reads it after its decrement (it may have
-	// sampled it before another scope retired the hub)
-	std::atomic<bool> dead{false};
-	// Scopes that hold or are about to take `mu`.  Taken under the registry lock (hub_for) or while a slot of the hub is
-	// held, so a hub found in the registry cannot be freed between the look-up and the lock; whoever drops the last
-	// reference of a dead hub deletes it.
-	std::atomic<int> refs{0};
+	// Lifetime: ONE atomic word = the number of scopes that hold or are about to take `mu` (references: taken under the
+	// registry lock -- hub_for, referenced_hubs -- or while a slot / pin of the hub is held, so a hub found in the registry
+	// cannot be freed between the look-up and the lock) + the RETIRED bit (no banks left: out of the registry; set under
+	// `mu` and the registry lock by a scope that holds a reference).  Whoever drops the last reference of a retired hub
+	// deletes it, and learns both facts from the value its decrement returns: after the decrement a scope must not touch
+	// the hub any more (another scope may have retired and deleted it in between -- ThreadSanitizer found exactly that
+	// read-after-decrement in an earlier form with a separate flag).
+	static constexpr unsigned RETIRED = 1u << 30;
+	std::atomic<unsigned> life{0};
+	void ref() { life.fetch_add(1, std::memory_order_acq_rel); }
+	bool retired() const { return (life.load(std::memory_order_acquire) & RETIRED) != 0; }
+	unsigned refs() const { return life.load(std::memory_order_acquire) & (RETIRED - 1); }
 };
 
 mi_ctx *Pool::ctx() const { return hub->ctx; }
@@ -228,17 +232,17 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 	{
 		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
 		auto fi = g_filter_hubs.find(f);
-		if (fi != g_filter_hubs.end()) return fi->second.hub->refs.fetch_add(1), fi->second.hub;
+		if (fi != g_filter_hubs.end()) return fi->second.hub->ref(), fi->second.hub;
 		auto hi = g_hubs.find(f ? f->ticker : nullptr);
-		if (hi != g_hubs.end()) return hi->second->refs.fetch_add(1), hi->second;
+		if (hi != g_hubs.end()) return hi->second->ref(), hi->second;
 	}
 	if (!create) return nullptr;
 	std::unique_lock<std::shared_mutex> wl(g_registry_mu);
 	MSTicker *t = f ? f->ticker : nullptr;
 	auto hi = g_hubs.find(t);
-	if (hi != g_hubs.end()) return hi->second->refs.fetch_add(1), hi->second;
+	if (hi != g_hubs.end()) return hi->second->ref(), hi->second;
 	TickerHub *h = new TickerHub();
-	h->refs.fetch_add(1);
+	h->ref();
 	h->ticker = t;
 	g_hubs[t] = h;
 	return h;
@@ -248,29 +252,27 @@ TickerHub *hub_for(MSFilter *f, bool create) {
 // current hub.  process() / preprocess() / the flush task run on the ticker thread; methods and uninit on any thread.
 struct HubLock {
 	TickerHub *h, *prev;
-	// The decrement is acq_rel and `dead` is read AFTER it: whichever scope turns out to be the last one sees a retirement
-	// another scope carried out in between (a value sampled before the unlock could be stale, and then nobody deleted).
 	static void unref(TickerHub *hub) {
-		if (hub->refs.fetch_sub(1, std::memory_order_acq_rel) == 1 && hub->dead.load(std::memory_order_acquire)) destroy_hub(hub);
+		if (hub->life.fetch_sub(1, std::memory_order_acq_rel) == (TickerHub::RETIRED | 1u)) destroy_hub(hub); // last scope of a retired hub
 	}
 	// A hub that holds no bank when its last scope ends (a filter at an unsupported configuration, a failed bank, a method
 	// call on a filter that never ran) must not stay in the registry with its HIP stream: retired here, under the hub's
 	// lock.  With the registry locked exclusively nobody can take a new reference (hub_for / referenced_hubs take theirs
 	// under it, the slot-based constructors need a bank), so refs == 1 means this scope is the only one.
 	static void retire_if_idle(TickerHub *hub) {
-		if (hub->dead.load(std::memory_order_relaxed) || !hub->pools.empty() || hub->pins > 0) return;
+		if (hub->retired() || !hub->pools.empty() || hub->pins > 0) return;
 		std::unique_lock<std::shared_mutex> wl(g_registry_mu);
-		if (hub->refs.load(std::memory_order_acquire) != 1) return;
+		if (hub->refs() != 1) return;
 		auto it = g_hubs.find(hub->ticker);
 		if (it != g_hubs.end() && it->second == hub) g_hubs.erase(it);
 		hub->flush_owner = nullptr;
-		hub->dead.store(true, std::memory_order_release);
+		hub->life.fetch_or(TickerHub::RETIRED, std::memory_order_acq_rel);
 	}
 	explicit HubLock(MSFilter *f) : h(nullptr), prev(tl_hub) {
 		for (;;) { // hub_for hands the hub over with a reference taken under the registry lock
 			h = hub_for(f, true);
 			h->mu.lock();
-			if (!h->dead) break;
+			if (!h->retired()) break;
 			// its last bank went between the look-up and the lock: it is out of the registry, look again (a new hub)
 			h->mu.unlock();
 			unref(h);
@@ -281,13 +283,13 @@ struct HubLock {
 	HubLock(MSFilter *f, Pool *p) : h(nullptr), prev(tl_hub) {
 		if (p) {
 			h = p->hub;
-			h->refs.fetch_add(1);
+			h->ref();
 			h->mu.lock();
 		} else {
 			for (;;) {
 				h = hub_for(f, true);
 				h->mu.lock();
-				if (!h->dead) break;
+				if (!h->retired()) break;
 				h->mu.unlock();
 				unref(h);
 			}
@@ -295,7 +297,7 @@ struct HubLock {
 		tl_hub = h;
 	}
 	explicit HubLock(TickerHub *hub) : h(hub), prev(tl_hub) { // the caller holds a slot of `hub`: it cannot go away
-		h->refs.fetch_add(1);
+		h->ref();
 		h->mu.lock();
 		tl_hub = h;
 	}
@@ -304,7 +306,7 @@ struct HubLock {
 		h->mu.lock();
 		tl_hub = h;
 	}
-	bool dead() const { return h->dead; } // the hub's last bank went before this scope got the lock: nothing to do on it
+	bool dead() const { return h->retired(); } // the hub's last bank went before this scope got the lock: nothing to do on it
 	~HubLock() {
 		tl_hub = prev;
 		retire_if_idle(h);
@@ -342,7 +344,7 @@ void Pool::release(int slot) {
 			std::unique_lock<std::shared_mutex> wl(g_registry_mu);
 			auto it = g_hubs.find(h->ticker);
 			if (it != g_hubs.end() && it->second == h) g_hubs.erase(it);
-			h->dead.store(true, std::memory_order_release); // deleted by the last HubLock scope to end
+			h->life.fetch_or(TickerHub::RETIRED, std::memory_order_acq_rel); // deleted by the last HubLock scope to end
 			h->flush_owner = nullptr;
 		}
 	}
@@ -628,7 +630,7 @@ static std::vector<TickerHub *> referenced_hubs() {
 	std::vector<TickerHub *> hubs;
 	std::shared_lock<std::shared_mutex> rl(g_registry_mu);
 	for (auto &kv : g_hubs) {
-		kv.second->refs.fetch_add(1);
+		kv.second->ref();
 		hubs.push_back(kv.second);
 	}
 	return hubs;

@@ -1,0 +1,27 @@
+"""Dev probe: N consecutive single ticks of the steady-state chain; prints the largest ones with their position."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+import mediastreamer2_amd as ms  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 122880
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+ctx = ms.Context(0)
+conv = bench.Converged(ms, torch, ctx)
+head = bench.Headline(ms, torch, ctx, n, 1, 0, None, 0)
+head.prepare(16, conv)
+import time
+for rep in range(3):
+    if rep == 1:
+        head.rig.canceller_stats()   # host read-backs: the GPU idles for a while
+    if rep == 2:
+        time.sleep(0.5)
+    v = head.tick_series(nt)
+    top = np.argsort(v)[-8:][::-1]
+    print(json.dumps({"rep": rep, **bench.series_stats(v), "top": [(int(i), round(float(v[i]), 3)) for i in top]}), flush=True)

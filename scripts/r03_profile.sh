@@ -23,7 +23,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 	timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python3 scripts/headline_probe.py $N --state $ST --ticks 16 --settle 16 > $OUT/pmc_$c/stdout.log 2> $OUT/pmc_$c/stderr.log
 done
 python3 - $OUT $N <<'PY'
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, re, sys, collections
 out, n = sys.argv[1], int(sys.argv[2])
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -31,7 +31,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(out, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c:
-                agg[r["Kernel_Name"].split("(")[0][-60:]].append(float(r["Counter_Value"]))
+                m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+                if m and "anonymous" in r["Kernel_Name"]:  # this library's kernels
+                    agg[m.group(1)].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res.setdefault(k, {})[c + "_KB"] = round(sum(v) / len(v), 1)
         res[k]["launches"] = len(v)

@@ -1,0 +1,269 @@
+/*
+ * san_stress.c -- TEST INFRASTRUCTURE: the plugin's threaded host runtime (mediastreamer2_amd/host/filters.cpp: one hub
+ * per ticker with its own lock, a registry under a shared mutex, reference-counted banks that grow and die) driven hard
+ * from several threads, to be run under ThreadSanitizer and AddressSanitizer + UBSan.  The kernel library behind the
+ * plugin is the host-memory double (mi_double.cpp), so this runs on a box without a GPU; the test runtime (ms2shim.c) is
+ * compiled into this executable and exports the ms_* symbols the plugin resolves (-rdynamic).
+ *
+ *   san_stress <plugin.so> [rounds]
+ *
+ * Threads:
+ *   callers x3   each: a ticker of its own, a few source -> MSResample -> MSVolume -> sink chains (plus an MSSpeexEC and a
+ *                conference mixer now and then), some ticks, detach, destroy everything -- the hub dies with its last bank;
+ *   grower       one ticker, 150 filters attached one after the other (banks of 16, 64, 256 slots open), ticks, half of
+ *                them detached and destroyed, ticks, the rest destroyed, all over again;
+ *   walker       ms_mi355x_runtime_stats / ms_mi355x_hub_devices over every hub, all the time (ms_mi355x_flush is for a
+ *                stopped graph: it emits into the filters' queues and is called once, at the end).
+ * Ends with the runtime where it started (no hub, no bank, no slot) and no late events; prints "ok".
+ */
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/ms2_plugin_abi.h"
+
+MSFilter *ms2shim_new_source(MSFactory *f);
+MSFilter *ms2shim_new_sink(MSFactory *f);
+void ms2shim_register_test_filters(MSFactory *f);
+void ms2shim_source_push(MSFilter *src, const void *data, size_t nbytes);
+void ms2shim_sink_set_discard(MSFilter *f, int on);
+
+static MSFactory *g_fac;
+static int g_rounds = 12;
+static volatile int g_stop;
+static int g_fail;
+static void (*p_stats)(int *, int *, int *);
+static void (*p_flush)(void);
+static int (*p_hub_devices)(int *, int);
+static unsigned long long (*p_late)(void);
+
+#define CHECK(c)                                                        \
+	do {                                                                \
+		if (!(c)) {                                                     \
+			fprintf(stderr, "san_stress: %s:%d: %s\n", __FILE__, __LINE__, #c); \
+			__atomic_store_n(&g_fail, 1, __ATOMIC_SEQ_CST);             \
+		}                                                               \
+	} while (0)
+
+static int set_int(MSFilter *f, unsigned int id, int v) { return ms_filter_call_method(f, id, &v); }
+
+typedef struct {
+	MSFilter *src, *rs, *vol, *snk;
+} chain_t;
+
+static void chain_make(chain_t *c, int in_rate) {
+	float g = 0.5f;
+	c->src = ms2shim_new_source(g_fac);
+	c->rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
+	c->vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+	c->snk = ms2shim_new_sink(g_fac);
+	CHECK(c->src && c->rs && c->vol && c->snk);
+	ms2shim_sink_set_discard(c->snk, 1);
+	CHECK(set_int(c->rs, MS_FILTER_SET_SAMPLE_RATE, in_rate) == 0);
+	CHECK(set_int(c->rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000) == 0);
+	CHECK(set_int(c->vol, MS_FILTER_SET_SAMPLE_RATE, 48000) == 0);
+	CHECK(ms_filter_call_method(c->vol, MS_VOLUME_SET_GAIN, &g) == 0);
+	ms_filter_link(c->src, 0, c->rs, 0);
+	ms_filter_link(c->rs, 0, c->vol, 0);
+	ms_filter_link(c->vol, 0, c->snk, 0);
+}
+static void chain_destroy(chain_t *c) {
+	ms_filter_unlink(c->src, 0, c->rs, 0);
+	ms_filter_unlink(c->rs, 0, c->vol, 0);
+	ms_filter_unlink(c->vol, 0, c->snk, 0);
+	ms_filter_destroy(c->src);
+	ms_filter_destroy(c->rs);
+	ms_filter_destroy(c->vol);
+	ms_filter_destroy(c->snk);
+}
+
+static void *caller(void *arg) {
+	const int seed = (int)(intptr_t)arg;
+	int16_t block[160];
+	for (int i = 0; i < 160; ++i) block[i] = (int16_t)((i * 37 + seed * 101) % 2000 - 1000);
+	for (int rep = 0; rep < g_rounds; ++rep) {
+		MSTicker *tk = ms_ticker_new();
+		int n = 3 + (seed + rep) % 4;
+		chain_t ch[8];
+		MSFilter *ec = NULL, *ecs[2] = {NULL, NULL}, *eck[2] = {NULL, NULL};
+		for (int i = 0; i < n; ++i) {
+			chain_make(&ch[i], 16000);
+			CHECK(ms_ticker_attach(tk, ch[i].src) == 0);
+		}
+		if ((seed + rep) % 2 == 0) { /* an echo canceller: far end -> pin 0, microphone -> pin 1 */
+			ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
+			CHECK(ec != NULL);
+			set_int(ec, MS_FILTER_SET_SAMPLE_RATE, 16000);
+			for (int k = 0; k < 2; ++k) {
+				ecs[k] = ms2shim_new_source(g_fac);
+				eck[k] = ms2shim_new_sink(g_fac);
+				ms2shim_sink_set_discard(eck[k], 1);
+				ms_filter_link(ecs[k], 0, ec, k);
+				ms_filter_link(ec, k, eck[k], 0);
+			}
+			CHECK(ms_ticker_attach(tk, ec) == 0);
+		}
+		MSFilter *mx = NULL, *mxs[3] = {NULL, NULL, NULL}, *mxk[3] = {NULL, NULL, NULL};
+		if ((seed + rep) % 2 == 1) { /* a three-party conference: the mixer is a pump facade */
+			mx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+			CHECK(mx != NULL);
+			set_int(mx, MS_FILTER_SET_SAMPLE_RATE, 16000);
+			set_int(mx, MS_FILTER_SET_NCHANNELS, 1);
+			set_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
+			for (int k = 0; k < 3; ++k) {
+				mxs[k] = ms2shim_new_source(g_fac);
+				mxk[k] = ms2shim_new_sink(g_fac);
+				ms2shim_sink_set_discard(mxk[k], 1);
+				ms_filter_link(mxs[k], 0, mx, k);
+				ms_filter_link(mx, k, mxk[k], 0);
+			}
+			CHECK(ms_ticker_attach(tk, mx) == 0);
+		}
+		for (int t = 0; t < 6; ++t) {
+			for (int i = 0; i < n; ++i) ms2shim_source_push(ch[i].src, block, sizeof block);
+			if (ec)
+				for (int k = 0; k < 2; ++k) ms2shim_source_push(ecs[k], block, sizeof block);
+			if (mx)
+				for (int k = 0; k < 3; ++k) ms2shim_source_push(mxs[k], block, sizeof block);
+			ms_ticker_step(tk);
+			if (t == 3 && n > 3) { /* one call ends mid-way */
+				ms_ticker_detach(tk, ch[n - 1].src);
+				chain_destroy(&ch[n - 1]);
+				--n;
+			}
+		}
+		for (int i = 0; i < n; ++i) ms_ticker_detach(tk, ch[i].src);
+		if (ec) {
+			char *state = NULL;
+			ms_ticker_detach(tk, ec);
+			ms_filter_call_method(ec, MS_ECHO_CANCELLER_GET_STATE_STRING, &state); /* on a detached filter: a hub that never gets a bank */
+			for (int k = 0; k < 2; ++k) {
+				ms_filter_unlink(ecs[k], 0, ec, k);
+				ms_filter_unlink(ec, k, eck[k], 0);
+				ms_filter_destroy(ecs[k]);
+				ms_filter_destroy(eck[k]);
+			}
+			ms_filter_destroy(ec);
+		}
+		if (mx) {
+			ms_ticker_detach(tk, mx);
+			for (int k = 0; k < 3; ++k) {
+				ms_filter_unlink(mxs[k], 0, mx, k);
+				ms_filter_unlink(mx, k, mxk[k], 0);
+				ms_filter_destroy(mxs[k]);
+				ms_filter_destroy(mxk[k]);
+			}
+			ms_filter_destroy(mx);
+		}
+		for (int i = 0; i < n; ++i) chain_destroy(&ch[i]);
+		ms_ticker_destroy(tk);
+	}
+	return NULL;
+}
+
+static void *grower(void *arg) {
+	enum { NF = 150 };
+	int16_t block[480];
+	(void)arg;
+	for (int i = 0; i < 480; ++i) block[i] = (int16_t)(i * 13 % 3000 - 1500);
+	for (int rep = 0; rep < (g_rounds + 3) / 4; ++rep) {
+		MSTicker *tk = ms_ticker_new();
+		MSFilter *src[NF], *vol[NF], *snk[NF];
+		for (int i = 0; i < NF; ++i) { /* banks of 16, 64 and 256 slots open as the filters come */
+			src[i] = ms2shim_new_source(g_fac);
+			vol[i] = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+			snk[i] = ms2shim_new_sink(g_fac);
+			ms2shim_sink_set_discard(snk[i], 1);
+			set_int(vol[i], MS_FILTER_SET_SAMPLE_RATE, 48000);
+			ms_filter_link(src[i], 0, vol[i], 0);
+			ms_filter_link(vol[i], 0, snk[i], 0);
+			CHECK(ms_ticker_attach(tk, src[i]) == 0);
+			if (i % 25 == 24) {
+				for (int k = 0; k <= i; ++k) ms2shim_source_push(src[k], block, sizeof block);
+				ms_ticker_step(tk);
+			}
+		}
+		for (int t = 0; t < 3; ++t) {
+			for (int i = 0; i < NF; ++i) ms2shim_source_push(src[i], block, sizeof block);
+			ms_ticker_step(tk);
+		}
+		for (int i = 0; i < NF; i += 2) { /* every other call ends: slots return, a bank may empty */
+			ms_ticker_detach(tk, src[i]);
+			ms_filter_unlink(src[i], 0, vol[i], 0);
+			ms_filter_unlink(vol[i], 0, snk[i], 0);
+			ms_filter_destroy(src[i]), ms_filter_destroy(vol[i]), ms_filter_destroy(snk[i]);
+		}
+		for (int t = 0; t < 3; ++t) {
+			for (int i = 1; i < NF; i += 2) ms2shim_source_push(src[i], block, sizeof block);
+			ms_ticker_step(tk);
+		}
+		for (int i = 1; i < NF; i += 2) {
+			ms_ticker_detach(tk, src[i]);
+			ms_filter_unlink(src[i], 0, vol[i], 0);
+			ms_filter_unlink(vol[i], 0, snk[i], 0);
+			ms_filter_destroy(src[i]), ms_filter_destroy(vol[i]), ms_filter_destroy(snk[i]);
+		}
+		ms_ticker_destroy(tk);
+	}
+	return NULL;
+}
+
+static void *walker(void *arg) {
+	long walks = 0;
+	(void)arg;
+	while (!__atomic_load_n(&g_stop, __ATOMIC_SEQ_CST)) {
+		int h = -1, b = -1, s = -1, dev[64];
+		p_stats(&h, &b, &s);
+		CHECK(h >= 0 && b >= 0 && s >= 0);
+		CHECK(p_hub_devices(dev, 64) >= 0);
+		++walks;
+	}
+	return (void *)(intptr_t)walks;
+}
+
+int main(int argc, char **argv) {
+	pthread_t th[5];
+	void *walks = NULL;
+	int h, b, s;
+	if (argc < 2) {
+		fprintf(stderr, "usage: san_stress <libmsmi355xfilters.so> [rounds]\n");
+		return 2;
+	}
+	if (argc > 2) g_rounds = atoi(argv[2]);
+	g_fac = ms_factory_new();
+	ms2shim_register_test_filters(g_fac);
+	if (ms_factory_load_plugin(g_fac, argv[1]) != 0) {
+		fprintf(stderr, "san_stress: cannot load %s\n", argv[1]);
+		return 2;
+	}
+	{
+		void *so = dlopen(argv[1], RTLD_NOW | RTLD_NOLOAD);
+		if (!so) so = dlopen(argv[1], RTLD_NOW);
+		p_stats = (void (*)(int *, int *, int *))dlsym(so, "ms_mi355x_runtime_stats");
+		p_flush = (void (*)(void))dlsym(so, "ms_mi355x_flush");
+		p_hub_devices = (int (*)(int *, int))dlsym(so, "ms_mi355x_hub_devices");
+		p_late = (unsigned long long (*)(void))dlsym(so, "ms_mi355x_late_events");
+		if (!p_stats || !p_flush || !p_hub_devices || !p_late) {
+			fprintf(stderr, "san_stress: plugin entry points missing\n");
+			return 2;
+		}
+	}
+	pthread_create(&th[3], NULL, walker, NULL);
+	for (int i = 0; i < 3; ++i) pthread_create(&th[i], NULL, caller, (void *)(intptr_t)(i + 1));
+	pthread_create(&th[4], NULL, grower, NULL);
+	for (int i = 0; i < 3; ++i) pthread_join(th[i], NULL);
+	pthread_join(th[4], NULL);
+	__atomic_store_n(&g_stop, 1, __ATOMIC_SEQ_CST);
+	pthread_join(th[3], &walks);
+	p_flush(); /* nothing is running any more */
+	p_stats(&h, &b, &s);
+	CHECK(h == 0 && b == 0 && s == 0);
+	CHECK(p_late() == 0);
+	CHECK((long)(intptr_t)walks > 10);
+	if (g_fail) return 1;
+	printf("ok %ld walks, %d rounds\n", (long)(intptr_t)walks, g_rounds);
+	return 0;
+}
