@@ -410,8 +410,8 @@ def copy_ceiling(torch):
 
 CHAIN_DESC = ("MSResample 16k->48k -> device FIFO (480-sample ticks -> 256-sample frames) -> MSSpeexEC (128 ms tail, "
               "canceller + post-filter; 15 frames per 8 ticks) -> device FIFO (frames -> ticks) -> MSVolume (AGC) -> "
-              "MSAudioMixer (conferences of 32), device resident; four launches per tick (the FIFO appends / pops happen "
-              "inside the canceller and the volume kernel)")
+              "MSAudioMixer (conferences of 32), device resident; launches per tick: resampler + FIFO appends + canceller + "
+              "post-filter in one, then volume / mixer")
 AEC_FRAME_BYTES = 202240  # mic+ref+out 1536, W read+write 2 x 49152, foreground 49152, X history 51200, newest X 2048
 AEC_FRAMES_PER_TICK = 1.875  # 480 / 256 (speexec.c:171-180: 256-sample frames at 48 kHz)
 SPLIT_CONFERENCES = 64  # at N > 1: conferences whose 32 members are spread over all ranks (the RCCL exchange step)
@@ -500,7 +500,6 @@ class ChainRig:
         self.d_mic = [spread(mic16, r, 160) for r in range(ring)]
         self.d_ref = [spread(ref48, r, 480) for r in range(ring)]
         z = lambda *shape, dt=torch.int16: torch.zeros(shape, dtype=dt, device="cuda")
-        self.up = z(n, 488)
         self.cnt = z(n, dt=torch.uint8)  # frames each leg cancelled in the last tick
         self.tick_buf = z(n, 480)
         self.mixed = z(n, 480)
@@ -521,12 +520,13 @@ class ChainRig:
     def tick(self, t, parts=None):
         """parts: a callback(stage) called before / after the canceller's launch (the roofline's HIP events)"""
         r = t % self.RING
-        self.rs.process(self.d_mic[r], out=self.up)
-        # MSSpeexEC for the tick with its bufferizers folded in: both blocks queued, the one or two whole frames a leg then
-        # holds cancelled + post-filtered, the cleaned frames queued towards the mixer -- one launch
+        # MSResample + MSSpeexEC for the tick in ONE launch: the leg's wavefront up-samples its 16 kHz block (the resampler's
+        # own tile FIR, history and table), queues it and the far-end block, cancels + post-filters the one or two whole frames
+        # the leg then holds and queues the cleaned frames towards the mixer
         if parts:
             parts("aec_begin")
-        self.aec.process_fifos(self.f_mic, self.up, self.f_ref, self.d_ref[r], self.f_out, tick_len=480, max_frames=2, count_out=self.cnt)
+        self.aec.process_fifos_resampled(self.rs, self.d_mic[r], self.f_mic, self.f_ref, self.d_ref[r], self.f_out, max_frames=2,
+                                         count_out=self.cnt)
         if parts:
             parts("aec_end")
         self.vol.process_fifo(self.f_out, self.tick_buf)  # the tick popped from the output FIFO inside the volume kernel

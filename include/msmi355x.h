@@ -291,6 +291,16 @@ typedef struct mi_fifo mi_fifo;
 int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
                          const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
                          int max_frames, unsigned flags, uint8_t *d_count_out);
+/* mi_aec_process_fifos with the leg's MSResample folded into the same launch (the chain's first two filters as one kernel):
+ * row s of d_mic_in holds in_len samples at the resampler's input rate; the wavefront that serves leg s up-samples them
+ * itself -- the resampler's own tile FIR on its own history and table: the samples queued are bit for bit those of
+ * mi_resampler_process, whose state advances as if it had been called -- and carries on as mi_aec_process_fifos with a
+ * block of in_len * (out_rate / in_rate) samples.  The up-sampled block touches HBM once (into the FIFO) instead of three
+ * times.  For integer up-sampling ratios at quality 3 with in_len * ratio / 8 <= 64 (16k -> 48k, 8k -> 48k, 8k -> 16k ticks);
+ * MI_ENOTSUP otherwise: call mi_resampler_process and mi_aec_process_fifos then. */
+int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
+                                   mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
+                                   int max_frames, unsigned flags, uint8_t *d_count_out);
 /* Spreading the load of mi_aec_process_fifos over the ticks.  Ticks of tick_len samples against frames of frame_size
  * leave a leg's microphone FIFO at a level that cycles through the multiples of gcd(tick_len, frame_size) -- at 48 kHz
  * (480 / 256) eight levels -- and a leg has one frame less to cancel in the tick it passes level 0.  Legs that start

@@ -427,6 +427,14 @@ class AecBatch(_Batch):
         check(self.ctx.L.mi_aec_process_fifos(self.h, f_mic.h, _ptr(mic_tick), mic_tick.stride(0), f_ref.h, _ptr(ref_tick),
                                               ref_tick.stride(0), _ptr(ref_len), n, f_out.h, max_frames, flags, _ptr(count_out)))
 
+    def process_fifos_resampled(self, rs, mic_in, f_mic, f_ref, ref_tick, f_out, in_len=None, max_frames=2, flags=MI_AEC_POSTFILTER,
+                                count_out=None, ref_len=None):
+        """process_fifos with the leg's up-sampler (a ResamplerBatch) folded into the same launch: mic_in holds the block at
+        the resampler's input rate (mi_aec_process_fifos_resampled)."""
+        n = mic_in.shape[1] if in_len is None else in_len
+        check(self.ctx.L.mi_aec_process_fifos_resampled(self.h, rs.h, _ptr(mic_in), n, mic_in.stride(0), f_mic.h, f_ref.h, _ptr(ref_tick),
+                                                        ref_tick.stride(0), _ptr(ref_len), f_out.h, max_frames, flags, _ptr(count_out)))
+
     def process_frames(self, mic, ref, out, count, max_frames=2, flags=MI_AEC_POSTFILTER):
         """The frames of one tick in one launch: rows of mic / ref / out hold up to max_frames frames back to back,
         count [nstreams] uint8 (device) = frames ready per stream.  Device tensors only."""

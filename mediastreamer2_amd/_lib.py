@@ -38,7 +38,7 @@ EXPORTS = [
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
-    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos",
+    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos", "mi_aec_process_fifos_resampled",
     "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_copy_state", "mi_aec_get", "mi_aec_stagger_info", "mi_aec_stagger_fifos",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
@@ -163,6 +163,7 @@ def load():
     L.mi_exchange_destroy.restype = None
     L.mi_exchange_ranks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.mi_exchange_allreduce_i32.argtypes = [vp, vp, sz]
+    L.mi_aec_process_fifos_resampled.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, u32, vp]
     L.mi_aec_copy_state.argtypes = [vp, i32, vp, i32, i32]
     L.mi_aec_stagger_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.mi_aec_stagger_fifos.argtypes = [vp, vp, vp, i32, i32, i32]

@@ -93,6 +93,12 @@ struct AecArgs {
 	const int16_t *mic_tick, *ref_tick; // [nstreams][*_tick_stride], tick_len new samples per stream
 	int tick_len, mic_tick_stride, ref_tick_stride;
 	const int32_t *ref_len; // nullable: per-stream length of the far-end block (0 .. tick_len)
+	// MSResample folded in (rs_in != NULL): the tick's microphone block is NOT read from mic_tick; the wave up-samples the
+	// leg's rs_in_len input samples by rs_den itself (the resampler's own tile FIR, history and table) and queues the result
+	const int16_t *rs_in;
+	int16_t *rs_hist;
+	const float *rs_table;
+	int rs_in_len, rs_in_stride, rs_hist_stride, rs_den;
 	uint8_t *count_out; // nullable: frames each stream ran
 	int stride, nstreams, M, flags;
 	int first;             // first stream of this launch (a launch may cover a chunk of the batch)
@@ -234,6 +240,7 @@ __device__ __forceinline__ void band_sum3(const AecTables &t, int b, const float
 	m0 = a, m1 = c, m2 = d;
 }
 
+#include "resample_tile.hpp"
 #include "aec_wave.hpp"
 #include "aec_tick.hpp"
 
@@ -590,6 +597,9 @@ size_t mi_aec_state_bytes(const mi_aec *a) {
 }
 
 struct AecFifoCall {
+	ResamplerView rs; // rs.ok: the microphone block is up-sampled inside the launch from rs_in
+	const int16_t *rs_in = nullptr;
+	int rs_in_len = 0, rs_in_stride = 0;
 	mi_fifo *f_mic, *f_ref, *f_out;
 	const int16_t *d_mic_tick, *d_ref_tick;
 	int tick_len, mic_stride, ref_stride;
@@ -614,6 +624,10 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.ref_len = nullptr;
 	g.order = g.ctl = nullptr;
 	g.cap8 = a->cap8;
+	g.rs_in = nullptr;
+	g.rs_hist = nullptr;
+	g.rs_table = nullptr;
+	g.rs_in_len = g.rs_in_stride = g.rs_hist_stride = g.rs_den = 0;
 	if (fifo) {
 		g.ref_len = fifo->d_ref_len;
 		g.fmic = fifo_view(fifo->f_mic);
@@ -627,6 +641,15 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 		g.count_out = fifo->d_count_out;
 		g.order = a->d_order;
 		g.ctl = a->d_ctl;
+		if (fifo->rs.ok) {
+			g.rs_in = fifo->rs_in;
+			g.rs_in_len = fifo->rs_in_len;
+			g.rs_in_stride = fifo->rs_in_stride;
+			g.rs_hist = fifo->rs.hist;
+			g.rs_hist_stride = fifo->rs.hist_stride;
+			g.rs_table = fifo->rs.table;
+			g.rs_den = fifo->rs.den;
+		}
 	}
 	g.stride = stride;
 	g.nstreams = a->nstreams;
@@ -679,7 +702,44 @@ int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, i
 			mi::set_error("mi_aec_process_fifos: FIFO capacities must be multiples of the frame size %d (got %d)", a->F, f->capacity);
 			return MI_EINVAL;
 		}
-	AecFifoCall fc = {f_mic, f_ref, f_out, d_mic_tick, d_ref_tick, tick_len, mic_stride, ref_stride, d_ref_len, d_count_out};
+	AecFifoCall fc;
+	fc.f_mic = f_mic, fc.f_ref = f_ref, fc.f_out = f_out;
+	fc.d_mic_tick = d_mic_tick, fc.d_ref_tick = d_ref_tick;
+	fc.tick_len = tick_len, fc.mic_stride = mic_stride, fc.ref_stride = ref_stride;
+	fc.d_ref_len = d_ref_len, fc.d_count_out = d_count_out;
+	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
+}
+
+int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
+                                   mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
+                                   int max_frames, unsigned flags, uint8_t *d_count_out) {
+	MI_CHECK_ARG(a && rs && d_mic_in && f_mic && f_ref && f_out && d_ref_tick && in_len > 0 && in_stride >= in_len && max_frames >= 1 &&
+	             max_frames <= MI_AEC_MAX_TICK_FRAMES);
+	MI_CHECK_ARG(f_mic->nstreams == a->nstreams && f_ref->nstreams == a->nstreams && f_out->nstreams == a->nstreams);
+	AecFifoCall fc;
+	mi_resampler_view(rs, &fc.rs);
+	const int tiles = (in_len + 7) / 8;
+	// what the in-launch up-sampler handles: an integer ratio with the 48-tap direct table, one (tile, phase) per lane, rows
+	// of whole 8-byte groups, every stream on a whole output period; anything else: call the resampler, then mi_aec_process_fifos
+	if (!fc.rs.ok || fc.rs.nstreams != a->nstreams || fc.rs.device != a->ctx->device || fc.rs.den * tiles > 64 ||
+	    ((in_len | in_stride) & 3) != 0 || (fc.rs.hist_stride >> 2) + (in_len >> 2) > 64 || (reinterpret_cast<uintptr_t>(d_mic_in) & 7) != 0 ||
+	    ((in_len * fc.rs.den) & 7) != 0 || (size_t)(48 + in_len + 12) * 4 + (size_t)in_len * fc.rs.den * 2 + (size_t)fc.rs.den * 48 * 4 > (size_t)6 * a->F * 4) {
+		mi::set_error("mi_aec_process_fifos_resampled: this resampler / block shape is not one the canceller's launch can up-sample itself "
+		              "(integer ratio, 48-tap table, <= 64 (tile, phase) lanes, blocks of whole 8-byte groups)");
+		return MI_ENOTSUP;
+	}
+	const int tick_len = in_len * fc.rs.den;
+	MI_CHECK_ARG(ref_stride >= tick_len);
+	for (const mi_fifo *f : {f_mic, f_ref, f_out})
+		if (f->capacity % a->F || f->capacity < max_frames * a->F || (f->capacity & 7)) {
+			mi::set_error("mi_aec_process_fifos_resampled: FIFO capacities must be multiples of the frame size %d (got %d)", a->F, f->capacity);
+			return MI_EINVAL;
+		}
+	fc.rs_in = d_mic_in, fc.rs_in_len = in_len, fc.rs_in_stride = in_stride;
+	fc.f_mic = f_mic, fc.f_ref = f_ref, fc.f_out = f_out;
+	fc.d_mic_tick = nullptr, fc.d_ref_tick = d_ref_tick;
+	fc.tick_len = tick_len, fc.mic_stride = 0, fc.ref_stride = ref_stride;
+	fc.d_ref_len = d_ref_len, fc.d_count_out = d_count_out;
 	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
 }
 

@@ -210,9 +210,61 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			}
 			return true;
 		};
+		// ---- MSResample folded in (msresample.c:122-179 for this leg's block): out[m den + p] = sum_j table[p][j] x[m + j] over
+		// history ++ input, lane (tile, phase) = 8 consecutive input positions of one polyphase row (resample_tile.hpp: the
+		// resampler kernel's own tile FIR, so the samples are bit for bit what mi_resampler_process delivers).  Window, table
+		// and output staging live in the transform work space, which nothing uses yet.
+		const int16_t *mic_row = a.mic_tick + (size_t)s * a.mic_tick_stride;
+		if (a.rs_in) {
+			constexpr int RS_FILT = 48, RS_R = 8, RS_HIST = RS_FILT - 1;
+			const int den = a.rs_den, in_len = a.rs_in_len;
+			float *x = reinterpret_cast<float *>(L.zbuf);                    // [xn] history ++ input ++ zero slack
+			const int xn = ((RS_HIST + in_len + RS_R + 1) + 3) & ~3;
+			int16_t *obuf = reinterpret_cast<int16_t *>(x + xn);             // [in_len * den]
+			float4 *tab4 = reinterpret_cast<float4 *>(obuf + ((in_len * den + 7) & ~7));
+			const int hq = a.rs_hist_stride >> 2, nq = hq + (in_len >> 2);
+			int16_t *hist = a.rs_hist + (size_t)s * a.rs_hist_stride;
+			short4 v0 = make_short4(0, 0, 0, 0);
+			if (lane < nq)
+				v0 = *reinterpret_cast<const short4 *>(lane < hq ? hist + 4 * lane : a.rs_in + (size_t)s * a.rs_in_stride + 4 * (lane - hq));
+			for (int i = lane; i < den * RS_FILT / 4; i += 64) tab4[i] = reinterpret_cast<const float4 *>(a.rs_table)[i];
+			for (int i = RS_HIST + in_len + lane; i < xn; i += 64) x[i] = 0.f;
+			if (lane < nq) {
+				const int b = 4 * lane - (lane < hq ? 0 : 4 * hq - RS_HIST);
+				if (lane < hq) {
+					if (b + 0 < RS_HIST) x[b + 0] = (float)v0.x;
+					if (b + 1 < RS_HIST) x[b + 1] = (float)v0.y;
+					if (b + 2 < RS_HIST) x[b + 2] = (float)v0.z;
+					if (b + 3 < RS_HIST) x[b + 3] = (float)v0.w;
+				} else {
+					x[b + 0] = (float)v0.x, x[b + 1] = (float)v0.y, x[b + 2] = (float)v0.z, x[b + 3] = (float)v0.w;
+				}
+			}
+			wave_sync();
+			const int nlanes = den * ((in_len + RS_R - 1) / RS_R);
+			const bool on = lane < nlanes;
+			const int tile = on ? lane / den : 0, ph = on ? lane - tile * den : 0, m0 = tile * RS_R;
+			f2 acc2[RS_R / 2];
+#pragma unroll
+			for (int q = 0; q < RS_R / 2; ++q) acc2[q] = (f2){0.f, 0.f};
+			fir_tile_rolled<RS_FILT, RS_R>(x + m0, reinterpret_cast<const float *>(tab4 + ph * (RS_FILT / 4)), acc2);
+			if (on) {
+#pragma unroll
+				for (int r = 0; r < RS_R; ++r)
+					if (m0 + r < in_len) obuf[(m0 + r) * den + ph] = rs_word2int((r & 1) ? acc2[r / 2].y : acc2[r / 2].x);
+			}
+			if (lane < hq) { // new history = the last 47 samples of (history ++ input); the pad slot takes the zero slack
+				const float *hx = x + in_len + 4 * lane;
+				short4 h;
+				h.x = (int16_t)hx[0], h.y = (int16_t)hx[1], h.z = (int16_t)hx[2], h.w = (int16_t)hx[3];
+				*reinterpret_cast<short4 *>(hist + 4 * lane) = h;
+			}
+			wave_sync();
+			mic_row = obuf;
+		}
 		int rlen = a.ref_len ? a.ref_len[s] : a.tick_len; // the far end's block may be missing or short this tick
 		rlen = rlen < 0 ? 0 : (rlen > a.tick_len ? a.tick_len : rlen);
-		mic_new = append(a.fmic, qm, a.mic_tick + (size_t)s * a.mic_tick_stride, a.tick_len);
+		mic_new = append(a.fmic, qm, mic_row, a.tick_len);
 		ref_new = append(a.fref, qr, a.ref_tick + (size_t)s * a.ref_tick_stride, rlen);
 		if (!ref_new) rlen = 0;
 		nf = (qm.y + (mic_new ? a.tick_len : 0)) / F;
@@ -269,7 +321,8 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	auto mic_at = [&](int f, int e) -> int {
 		if (!fifo) return a.mic[(size_t)s * a.stride + f * F + e];
 		const int p = f * F + e;
-		if (p < qm.y) return ring_at(a.fmic, qm.x, p);
+		// (up-sampled in this launch: the block exists nowhere but in the ring it was queued in)
+		if (p < qm.y || a.rs_in) return ring_at(a.fmic, qm.x, p);
 		return a.mic_tick[(size_t)s * a.mic_tick_stride + (p - qm.y)];
 	};
 	auto ref_at = [&](int f, int e) -> int {

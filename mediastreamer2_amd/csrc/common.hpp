@@ -86,6 +86,19 @@ inline FifoView fifo_view(const mi_fifo *f) {
 	return v;
 }
 
+// What the canceller's tick kernel needs of an up-sampling mi_resampler to run it as its own first phase (MSResample folded
+// into MSSpeexEC's launch, mi_aec_process_fifos_resampled).  Filled by mi_resampler_view (resample.hip); ok = the resampler
+// is an integer up-sampler with the 48-tap direct table whose streams all sit on a whole output period.
+struct ResamplerView {
+	int16_t *hist = nullptr;     // [nstreams][hist_stride] the last filt-1 input samples of every stream
+	const float *table = nullptr; // [den][filt] polyphase rows
+	int hist_stride = 0, den = 0, filt = 0, nstreams = 0;
+	int device = -1;
+	bool ok = false;
+};
+struct mi_resampler;
+void mi_resampler_view(mi_resampler *r, ResamplerView *v);
+
 struct mi_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;

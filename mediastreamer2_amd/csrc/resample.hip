@@ -144,15 +144,8 @@ bool design_filter(uint32_t in_rate, uint32_t out_rate, int quality, Design &d) 
 }
 
 // ------------------------------------------------------------------- kernels
-// WORD2INT of the library: floor(.5 + x) evaluated in double, clamped to int16 (x < -32767.5 -> -32768,
-// x > 32766.5 -> 32767).  Exact float form: clamp to [-32768, 32767], then (floor(2x) + 1) >> 1 -- 2x is
-// exact, and floor((floor(2x) + 1) / 2) == floor(x + .5) for every real x.
-__device__ __forceinline__ int16_t word2int(float x) {
-	x = __builtin_amdgcn_fmed3f(x, -32768.f, 32767.f);
-	return (int16_t)(((int)floorf(x + x) + 1) >> 1);
-}
+#include "resample_tile.hpp"
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct UpArgs {
 	const int16_t *in;
@@ -176,65 +169,6 @@ struct UpArgs {
 // leave as 16-byte stores.
 constexpr int UP_WAVES = 4; // most wavefronts per workgroup of the one-wave-per-stream kernels (the launchers pick 2 or 4)
 inline int waves_per_workgroup(int nstreams) { return nstreams <= 16384 ? UP_WAVES : 2; }
-
-// LDS hand-over inside ONE wavefront: the LDS unit executes a wave's instructions in order, so only the compiler has
-// to be kept from moving accesses across this point (no s_barrier: the waves of a workgroup are independent here)
-__device__ __forceinline__ void wave_sync() {
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
-
-// acc += splat(t.lo or t.hi) * w on both halves.  Written as asm so the FILT x R/2 issue order below is
-// the one executed: left to itself the scheduler finishes one accumulator at a time and spills the window.
-template <int HI>
-__device__ __forceinline__ void pk_fma_splat(f2 &acc, const f2 t, const f2 w) {
-	if (HI)
-		asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(t), "v"(w));
-	else
-		asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(t), "v"(w));
-}
-
-// (a.hi, b.lo): the window pair at an odd offset, one issue slot
-__device__ __forceinline__ f2 pk_odd_pair(const f2 a, const f2 b) {
-	f2 d;
-	asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-	return d;
-}
-
-// acc2[q] += sum_j t[j] * (xwin[j + 2q], xwin[j + 2q + 1]) for j < FILT: R = 8 consecutive positions of one polyphase
-// row.  The window slides through registers 8 taps at a time (16 floats live, the next 8 in flight); v_pk_fma_f32 does
-// two positions per issue slot: the tap is broadcast by op_sel, even-offset window pairs are register pairs as loaded
-// (xwin is 16-byte aligned), odd-offset pairs cost one v_pk_mov_b32 each.  Reads xwin[0 .. FILT+R-1].
-template <int FILT, int R>
-__device__ __forceinline__ void fir_tile(const float *xwin, const f2 (&t2)[FILT / 2], f2 (&acc2)[R / 2]) {
-	static_assert(R == 8 && FILT % 8 == 0, "window = FILT+R-1 samples read as 16-byte groups");
-	const float4 *wp = reinterpret_cast<const float4 *>(xwin);
-	float4 c0 = wp[0], c1 = wp[1], c2 = wp[2], c3 = wp[3];
-	f2 od[7]; // odd-offset pairs (w[2i+1], w[2i+2]) of the 16 live floats
-#pragma unroll
-	for (int c = 0; c < FILT / 8; ++c) {
-		const f2 ev[8] = {(f2){c0.x, c0.y}, (f2){c0.z, c0.w}, (f2){c1.x, c1.y}, (f2){c1.z, c1.w},
-		                  (f2){c2.x, c2.y}, (f2){c2.z, c2.w}, (f2){c3.x, c3.y}, (f2){c3.z, c3.w}};
-#pragma unroll
-		for (int i = (c == 0 ? 0 : 3); i < 7; ++i) od[i] = pk_odd_pair(ev[i], ev[i + 1]);
-#pragma unroll
-		for (int jj = 0; jj < 8; ++jj) {
-			const f2 tp2 = t2[(8 * c + jj) / 2];
-#pragma unroll
-			for (int q = 0; q < R / 2; ++q) {
-				const int k = jj + 2 * q; // 0..13 within the 16 live floats
-				const f2 wk = (k & 1) ? od[k / 2] : ev[k / 2];
-				if (jj & 1)
-					pk_fma_splat<1>(acc2[q], tp2, wk);
-				else
-					pk_fma_splat<0>(acc2[q], tp2, wk);
-			}
-		}
-		od[0] = od[4], od[1] = od[5], od[2] = od[6];
-		c0 = c2, c1 = c3;
-		if (c + 1 < FILT / 8) c2 = wp[2 * c + 4], c3 = wp[2 * c + 5];
-	}
-}
 
 template <int DEN, int FILT, int R, bool MULTI, bool TWO>
 __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a) {
@@ -338,7 +272,7 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_up_kernel(UpArgs a)
 			if (on) {
 #pragma unroll
 				for (int r = 0; r < R; ++r)
-					if (m0 + r < a.in_len) obuf[(m0 + r) * DEN + p] = word2int(acc[r]);
+					if (m0 + r < a.in_len) obuf[(m0 + r) * DEN + p] = rs_word2int(acc[r]);
 			}
 		}
 		wave_sync();
@@ -464,7 +398,7 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_down_kernel(DownArg
 				float sum = 0.f;
 #pragma unroll
 				for (int p = 0; p < NUM; ++p) sum += ps[k * NUM + p];
-				r16[k] = word2int(sum);
+				r16[k] = rs_word2int(sum);
 			}
 			uint4 pk;
 			pk.x = (unsigned)(r16[0] & 0xffff) | ((unsigned)r16[1] << 16);
@@ -598,7 +532,7 @@ __global__ __launch_bounds__(64 * UP_WAVES, 2) void resample_ratio_kernel(RatioA
 				float sum = 0.f;
 #pragma unroll
 				for (int pq = 0; pq < M; ++pq) sum += ps[k * M + pq];
-				r16[k] = word2int(sum);
+				r16[k] = rs_word2int(sum);
 			}
 			uint4 pk;
 			pk.x = (unsigned)(r16[0] & 0xffff) | ((unsigned)r16[1] << 16);
@@ -695,7 +629,7 @@ __global__ __launch_bounds__(256) void resample_generic_kernel(GenArgs a) {
 			const float i2 = (float)(1. - i0 - i1 - i3);
 			sum = i0 * a0 + i1 * a1 + i2 * a2 + i3 * a3;
 		}
-		o[k] = word2int(sum);
+		o[k] = rs_word2int(sum);
 	}
 	__syncthreads();
 	// carry state exactly like speex_resampler_process_native
@@ -732,6 +666,19 @@ struct mi_resampler {
 	const std::vector<float> &dev_table() const { return d.phase_table.empty() ? d.table : d.phase_table; }
 	bool dev_direct() const { return d.direct || !d.phase_table.empty(); }
 };
+
+void mi_resampler_view(mi_resampler *r, ResamplerView *v) {
+	*v = ResamplerView();
+	if (!r) return;
+	v->hist = r->d_hist;
+	v->table = r->d_table;
+	v->hist_stride = r->hist_stride;
+	v->den = (int)r->d.den;
+	v->filt = (int)r->d.filt_len;
+	v->nstreams = r->nstreams;
+	v->device = r->ctx->device;
+	v->ok = r->d.num == 1 && r->d.den > 1 && r->dev_direct() && r->d.phase_table.empty() && r->d.filt_len == 48 && r->phase_zero;
+}
 
 template <int DEN, int FILT, int R>
 static int launch_up(mi_resampler *r, const int16_t *d_in, int in_len, int in_stride, int16_t *d_out,

@@ -37,6 +37,7 @@ struct mi_session {
 	int16_t *h_mic[SLOTS] = {}, *h_ref[SLOTS] = {}, *h_out[SLOTS] = {};
 	int16_t *d_mic[SLOTS] = {}, *d_ref[SLOTS] = {}, *d_out[SLOTS] = {};
 	int16_t *d_up = nullptr, *d_tick = nullptr;
+	bool fold_resampler = true; // the canceller's launch runs the up-sampler too (until it says it cannot)
 	// the canceller's frames of a tick (up to ROUNDS_MAX per leg, back to back in one row): frames in, cleaned frames out,
 	// frames each leg had ready (buffers [0] only; the arrays are kept for the reset helpers)
 	static constexpr int ROUNDS_MAX = MI_AEC_MAX_TICK_FRAMES;
@@ -68,21 +69,29 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 		int16_t *rows = cf.mic_codec ? s->d_pcm : s->d_mic[slot];
 		if ((rc = mi_plc_process(s->plc, rows, (size_t)s->in_len, s->d_evlen, s->d_ev[slot])) != MI_OK) return rc;
 	}
-	// the microphone block at the processing rate
-	const int16_t *mic_tick = mic;
-	int mic_stride = s->len;
-	if (s->rs) {
-		if ((rc = mi_resampler_process(s->rs, mic, s->in_len, s->in_len, s->d_up, s->up_stride, nullptr)) != MI_OK) return rc;
-		mic_tick = s->d_up;
-		mic_stride = s->up_stride;
-	}
 	// far end: from the host, or what this leg was sent one tick ago
 	const int16_t *ref = cf.ref_loopback ? s->d_mix[(slot + SLOTS - 1) % SLOTS] : s->d_ref[slot];
-	// MSSpeexEC for the tick, FIFOs included: both blocks are queued, the one or two whole frames (480 / 256) a leg then holds
-	// are cancelled + post-filtered, the cleaned frames queued for the mixer side -- one launch (mi_aec_process_fifos)
-	if ((rc = mi_aec_process_fifos(s->aec, s->f_mic, mic_tick, mic_stride, s->f_ref, ref, s->len, nullptr, s->len, s->f_out, s->rounds,
-	                               MI_AEC_POSTFILTER, nullptr)) != MI_OK)
-		return rc;
+	// MSResample + MSSpeexEC for the tick, FIFOs included: the microphone block is up-sampled, both blocks are queued, the one
+	// or two whole frames (480 / 256) a leg then holds are cancelled + post-filtered, the cleaned frames queued for the mixer
+	// side -- ONE launch where the canceller's kernel can run the up-sampler itself (integer ratios: 16k -> 48k, 8k -> 48k,
+	// 8k -> 16k), else the resampler's launch and then the canceller's
+	rc = MI_ENOTSUP;
+	if (s->rs && s->fold_resampler)
+		rc = mi_aec_process_fifos_resampled(s->aec, s->rs, mic, s->in_len, s->in_len, s->f_mic, s->f_ref, ref, s->len, nullptr, s->f_out,
+		                                    s->rounds, MI_AEC_POSTFILTER, nullptr);
+	if (rc == MI_ENOTSUP) {
+		s->fold_resampler = false; // decided once: the shapes do not change
+		const int16_t *mic_tick = mic; // the microphone block at the processing rate
+		int mic_stride = s->len;
+		if (s->rs) {
+			if ((rc = mi_resampler_process(s->rs, mic, s->in_len, s->in_len, s->d_up, s->up_stride, nullptr)) != MI_OK) return rc;
+			mic_tick = s->d_up;
+			mic_stride = s->up_stride;
+		}
+		rc = mi_aec_process_fifos(s->aec, s->f_mic, mic_tick, mic_stride, s->f_ref, ref, s->len, nullptr, s->len, s->f_out, s->rounds,
+		                          MI_AEC_POSTFILTER, nullptr);
+	}
+	if (rc != MI_OK) return rc;
 	// MSVolume on the tick the mixer side reads: popped from the canceller's output FIFO inside the kernel where the sizes
 	// allow 16-byte groups (every rate in use), else pop + process
 	if ((s->len & 7) == 0) {

@@ -822,3 +822,56 @@ def test_session_with_the_products_stagger_equals_the_chain_given_the_same_leads
         se.submit()
         np.testing.assert_array_equal(se.collect(), want[t], err_msg=f"tick {t}")
     se.close()
+
+
+@pytest.mark.parametrize("in_rate,rate,F", [(16000, 48000, 256), (8000, 48000, 256), (8000, 16000, 128)])
+def test_canceller_launch_with_the_resampler_folded_in_equals_the_two_launches(ctx, in_rate, rate, F):
+    """mi_aec_process_fifos_resampled (MSResample + MSSpeexEC of a leg in ONE launch: the wavefront up-samples the block
+    with the resampler's own tile FIR, history and table) == mi_resampler_process followed by mi_aec_process_fifos: what
+    the output FIFO delivers, the FIFO levels, and the resampler's state afterwards (it carries on bit for bit)."""
+    torch = pytest.importorskip("torch")
+    n, nticks, nin, ns = 37, 40, in_rate // 100, rate // 100
+    flen = 64 * rate // 1000
+    mic = np.stack([synth_pcm(900 + s, nin * (nticks + 2), rate=in_rate, sigma=2500.0) for s in range(n)])
+    ref = np.stack([synth_pcm(950 + s, ns * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+
+    def rig():
+        return (ms.ResamplerBatch(ctx, n, in_rate, rate), ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen),
+                *(ms.FifoBatch(ctx, n, 6 * F) for _ in range(3)))
+
+    (rs1, a1, fm1, fr1, fo1), (rs2, a2, fm2, fr2, fo2) = rig(), rig()
+    for a, fm, fr in ((a1, fm1, fr1), (a2, fm2, fr2)):
+        a.stagger_fifos(fm, fr, ns)
+    up = z(n, (ns + 8 + 7) & ~7)
+    t1, t2, lv1, lv2 = z(n, ns), z(n, ns), z(n, dt=torch.int32), z(n, dt=torch.int32)
+    for t in range(nticks):
+        dm = torch.from_numpy(np.ascontiguousarray(mic[:, t * nin:(t + 1) * nin])).cuda()
+        dr = torch.from_numpy(np.ascontiguousarray(ref[:, t * ns:(t + 1) * ns])).cuda()
+        torch.cuda.synchronize()
+        rs1.process(dm, out=up)
+        a1.process_fifos(fm1, up, fr1, dr, fo1, tick_len=ns, max_frames=2)
+        a2.process_fifos_resampled(rs2, dm, fm2, fr2, dr, fo2, max_frames=2)
+        fo1.pop(ns, t1, zero_fill=True)
+        fo2.pop(ns, t2, zero_fill=True)
+        fm1.levels(lv1)
+        fm2.levels(lv2)
+        ctx.sync()
+        np.testing.assert_array_equal(t1.cpu().numpy(), t2.cpu().numpy(), err_msg=f"tick {t}")
+        np.testing.assert_array_equal(lv1.cpu().numpy(), lv2.cpu().numpy())
+    assert t1.cpu().numpy().any()
+    # the folded resampler's state went along: both carry on alike
+    for t in range(nticks, nticks + 2):
+        dm = torch.from_numpy(np.ascontiguousarray(mic[:, t * nin:(t + 1) * nin])).cuda()
+        torch.cuda.synchronize()
+        o1, _ = rs1.process(dm)
+        o2, _ = rs2.process(dm)
+        ctx.sync()
+        np.testing.assert_array_equal(o1.cpu().numpy()[:, :ns], o2.cpu().numpy()[:, :ns])
+    assert fm2.overflows() + fr2.overflows() + fo2.overflows() == 0
+    # a ratio the launch cannot up-sample itself is refused, not approximated
+    rs3 = ms.ResamplerBatch(ctx, n, 16000, 44100)
+    with pytest.raises(ms.MiError):
+        a2.process_fifos_resampled(rs3, z(n, 160), fm2, fr2, z(n, 448), fo2)
+    for o in (rs1, a1, fm1, fr1, fo1, rs2, a2, fm2, fr2, fo2, rs3):
+        o.close()
