@@ -410,8 +410,8 @@ def copy_ceiling(torch):
 
 CHAIN_DESC = ("MSResample 16k->48k -> device FIFO (480-sample ticks -> 256-sample frames) -> MSSpeexEC (128 ms tail, "
               "canceller + post-filter; 15 frames per 8 ticks) -> device FIFO (frames -> ticks) -> MSVolume (AGC) -> "
-              "MSAudioMixer (conferences of 32), device resident; launches per tick: resampler + FIFO appends + canceller + "
-              "post-filter in one, then volume / mixer")
+              "MSAudioMixer (conferences of 32), device resident; TWO launches per tick: resampler + FIFO appends + canceller + "
+              "post-filter, then volume + conference mix")
 AEC_FRAME_BYTES = 202240  # mic+ref+out 1536, W read+write 2 x 49152, foreground 49152, X history 51200, newest X 2048
 AEC_FRAMES_PER_TICK = 1.875  # 480 / 256 (speexec.c:171-180: 256-sample frames at 48 kHz)
 SPLIT_CONFERENCES = 64  # at N > 1: conferences whose 32 members are spread over all ranks (the RCCL exchange step)
@@ -529,9 +529,10 @@ class ChainRig:
                                          count_out=self.cnt)
         if parts:
             parts("aec_end")
-        self.vol.process_fifo(self.f_out, self.tick_buf)  # the tick popped from the output FIFO inside the volume kernel
-        self.mix.process(self.whole_in, out=self.whole_out)
-        if self.nsplit:
+        # MSVolume + MSAudioMixer of the whole conferences: one launch (ticks popped from the output FIFO, levelled, mixed)
+        self.mix.process_volume_fifo(self.vol, self.f_out, self.whole_out)
+        if self.nsplit:  # the split conferences' local members: levelled here, summed here, mixed after the exchange
+            self.vol.process_fifo(self.f_out, self.tick_buf, first=self.nconf * self.MEMBERS)
             self.mixs.partial_sum(self.split_in, self.d_sum)
 
     def finalize(self):

@@ -234,6 +234,17 @@ int mi_volume_process_host(mi_volume *v, int16_t *h_samples, int nsamples, int s
  * Equals mi_fifo_pop + mi_volume_process without the separate launch and copy.  Multiples of 8 samples throughout. */
 struct mi_fifo;
 int mi_volume_process_fifo(mi_volume *v, struct mi_fifo *f_src, int16_t *d_out, int nsamples, int stride);
+/* the same for streams [first, first + count) only (rows of d_out are still indexed by stream) */
+int mi_volume_process_fifo_range(mi_volume *v, struct mi_fifo *f_src, int16_t *d_out, int nsamples, int stride, int first, int count);
+/* MSVolume + MSAudioMixer of whole conferences in ONE launch (the chain's last two filters): pin k of conference c is
+ * stream first_stream + c * max_members + k of the volume batch; its chunk of `nsamples` (the mixer's tick) is popped from
+ * f_src as in mi_volume_process_fifo, metered and levelled, and the conference is mixed in conference mode from the
+ * levelled chunks: d_out [nconf][max_members][nsamples] as mi_mixer_process(.., conf_mode 1, ..) writes it.  The levelled
+ * audio never leaves the chip: a leg's tick crosses HBM twice instead of four times.  Results equal
+ * mi_volume_process_fifo + mi_mixer_process bit for bit (samples, meter state, FIFO positions).  Ticks and FIFO capacities
+ * in multiples of 8 samples. */
+struct mi_mixer;
+int mi_mixer_process_volume_fifo(struct mi_mixer *m, mi_volume *v, int first_stream, struct mi_fifo *f_src, int16_t *d_out);
 
 /* ----------------------------------------------------------- equalizer */
 typedef struct mi_equalizer mi_equalizer;

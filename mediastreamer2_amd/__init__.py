@@ -208,6 +208,12 @@ class MixerBatch(_Batch):
         check(self.ctx.L.mi_mixer_process(self.h, _ptr(x), _ptr(has_data), int(conf_mode), _ptr(out)))
         return out
 
+    def process_volume_fifo(self, vol, fifo, out, first_stream=0):
+        """MSVolume + the conference mix in one launch: every pin's chunk popped from `fifo`, levelled by `vol` (stream
+        first_stream + conference * members + pin), mixed in conference mode into out [nconf, mm, ns]"""
+        check(self.ctx.L.mi_mixer_process_volume_fifo(self.h, vol.h, first_stream, fifo.h, _ptr(out)))
+        return out
+
     def partial_sum(self, x, d_sum, has_data=None):
         check(self.ctx.L.mi_mixer_partial_sum(self.h, _ptr(x), _ptr(has_data), _ptr(d_sum)))
         return d_sum
@@ -296,10 +302,15 @@ class VolumeBatch(_Batch):
         return x
 
 
-    def process_fifo(self, fifo, out, nsamples=None):
-        """pop one chunk per stream from a FifoBatch (silence where it holds less), process, write to out's rows"""
+    def process_fifo(self, fifo, out, nsamples=None, first=None, count=None):
+        """pop one chunk per stream from a FifoBatch (silence where it holds less), process, write to out's rows;
+        first / count: only that range of streams"""
         n = out.shape[1] if nsamples is None else nsamples
-        check(self.ctx.L.mi_volume_process_fifo(self.h, fifo.h, _ptr(out), n, out.stride(0)))
+        if first is None:
+            check(self.ctx.L.mi_volume_process_fifo(self.h, fifo.h, _ptr(out), n, out.stride(0)))
+        else:
+            check(self.ctx.L.mi_volume_process_fifo_range(self.h, fifo.h, _ptr(out), n, out.stride(0), first,
+                                                          self.nstreams - first if count is None else count))
         return out
 
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
     "mi_exchange_unique_id", "mi_exchange_create", "mi_exchange_destroy", "mi_exchange_ranks", "mi_exchange_allreduce_i32",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
-    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo",
+    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo", "mi_volume_process_fifo_range", "mi_mixer_process_volume_fifo",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
@@ -169,6 +169,8 @@ def load():
     L.mi_aec_stagger_fifos.argtypes = [vp, vp, vp, i32, i32, i32]
     L.mi_fifo_push_lead.argtypes = [vp, i32, i32, i32, i32]
     L.mi_fifo_phase_of.argtypes = [i32, i32]
+    L.mi_volume_process_fifo_range.argtypes = [vp, vp, vp, i32, i32, i32, i32]
+    L.mi_mixer_process_volume_fifo.argtypes = [vp, vp, i32, vp, vp]
     L.mi_volume_get_max.argtypes = [vp, i32, i32, vp]
     L.mi_volume_reset_max.argtypes = [vp, i32, i32]
     L.mi_volume_process.argtypes = [vp, vp, i32, i32, vp]

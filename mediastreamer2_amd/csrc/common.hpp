@@ -99,6 +99,15 @@ struct ResamplerView {
 struct mi_resampler;
 void mi_resampler_view(mi_resampler *r, ResamplerView *v);
 
+// What the fused volume + conference mix kernel (volume.hip) needs of an mi_mixer: its per-pin controls
+struct MixerView {
+	const uint8_t *flags = nullptr; // [nconf][mm] MI_MIX_*
+	const float *gain = nullptr;    // [nconf][mm]
+	int nconf = 0, mm = 0, ns = 0, device = -1;
+};
+struct mi_mixer;
+void mi_mixer_view(const mi_mixer *m, MixerView *v);
+
 struct mi_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;

@@ -357,6 +357,15 @@ static void fill_args(mi_mixer *m, MixArgs &a, const int16_t *d_in, const uint8_
 	a.conf_mode = conf_mode;
 }
 
+void mi_mixer_view(const mi_mixer *m, MixerView *v) {
+	*v = MixerView();
+	if (!m) return;
+	v->flags = m->d_flags;
+	v->gain = m->d_gain;
+	v->nconf = m->nconf, v->mm = m->mm, v->ns = m->ns;
+	v->device = m->ctx->device;
+}
+
 extern "C" {
 
 int mi_mixer_create(mi_ctx *ctx, int nconf, int max_members, int nsamples, mi_mixer **out) {

@@ -38,6 +38,7 @@ struct mi_session {
 	int16_t *d_mic[SLOTS] = {}, *d_ref[SLOTS] = {}, *d_out[SLOTS] = {};
 	int16_t *d_up = nullptr, *d_tick = nullptr;
 	bool fold_resampler = true; // the canceller's launch runs the up-sampler too (until it says it cannot)
+	bool fuse_mix = true;       // volume + conference mix in one launch (likewise)
 	// the canceller's frames of a tick (up to ROUNDS_MAX per leg, back to back in one row): frames in, cleaned frames out,
 	// frames each leg had ready (buffers [0] only; the arrays are kept for the reset helpers)
 	static constexpr int ROUNDS_MAX = MI_AEC_MAX_TICK_FRAMES;
@@ -94,14 +95,21 @@ int run_tick_kernels(mi_session *s, int slot) { // everything on the context's s
 	if (rc != MI_OK) return rc;
 	// MSVolume on the tick the mixer side reads: popped from the canceller's output FIFO inside the kernel where the sizes
 	// allow 16-byte groups (every rate in use), else pop + process
-	if ((s->len & 7) == 0) {
-		if ((rc = mi_volume_process_fifo(s->vol, s->f_out, s->d_tick, s->len, s->len)) != MI_OK) return rc;
-	} else {
-		if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
-		if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
-	}
 	int16_t *mix = s->d_mix[slot] ? s->d_mix[slot] : s->d_out[slot];
-	if ((rc = mi_mixer_process(s->mix, s->d_tick, nullptr, 1, mix)) != MI_OK) return rc;
+	// MSVolume + MSAudioMixer: one launch (every leg's tick popped from the canceller's output FIFO, levelled, the conference
+	// mixed from the levelled ticks on the chip) where the sizes allow 16-byte groups (every rate in use); else pop, level, mix
+	rc = s->fuse_mix ? mi_mixer_process_volume_fifo(s->mix, s->vol, 0, s->f_out, mix) : MI_ENOTSUP;
+	if (rc == MI_ENOTSUP) {
+		s->fuse_mix = false;
+		if ((s->len & 7) == 0) {
+			if ((rc = mi_volume_process_fifo(s->vol, s->f_out, s->d_tick, s->len, s->len)) != MI_OK) return rc;
+		} else {
+			if ((rc = mi_fifo_pop(s->f_out, s->len, s->d_tick, s->len, nullptr, nullptr, 1)) != MI_OK) return rc;
+			if ((rc = mi_volume_process(s->vol, s->d_tick, s->len, s->len, nullptr)) != MI_OK) return rc;
+		}
+		rc = mi_mixer_process(s->mix, s->d_tick, nullptr, 1, mix);
+	}
+	if (rc != MI_OK) return rc;
 	const int16_t *leaving = mix;
 	int pitch = s->len;
 	if (s->rs_out) { // MSResample rate -> out_rate

@@ -40,6 +40,7 @@ struct VolArgs {
 	const int *parity; // which of the two holds the previous launch's values; flipped on the device after each launch,
 	                   // so a captured hipGraph replays correctly (a host-side flip would be frozen into the graph)
 	int nstreams, nsamples, stride, sample_rate, pitch_dw, pitch_f;
+	int first; // the launch serves streams [first, nstreams): block b owns SPB streams from first + b * SPB on
 	// the one-second maximum of the smoothed energy behind MS_VOLUME_GET_MAX (ortp_extremum_record_max on every
 	// process(), msvolume.c:115,:404): x = current maximum, y = ms since the window started (< 0: not started).  The
 	// stream's own chunks are its clock, as the ticker's time is the filter's (one chunk per tick).
@@ -51,6 +52,91 @@ struct VolArgs {
 
 __device__ __forceinline__ int sat16(int v) { return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v); }
 
+// What update_energy leaves behind and everything volume_process derives from it for one chunk (msvolume.c:388-407,
+// :172-260, :409-445's gain ramp): the smoothed energy, the echo limiter / AGC / noise gate targets, the ramped gain as the
+// Q12 integer the samples are scaled with, the DC estimate, the one-second maximum.  acc = the float32 sum of the squares
+// in sample order, pk / dcsum = integer peak and sum of the chunk.  One lane per stream; shared by volume_kernel and the
+// fused volume + conference mix kernel below.
+struct VolCtl {
+	int intgain, dcoff, mode; // mode 0: samples untouched (gain exactly 1), 1: gain, 2: DC removal + gain
+};
+__device__ __forceinline__ VolCtl volume_control(const mi_volume_params &p, mi_volume_state &st, float peer_energy, float acc, int n, int pk,
+                                                 int dcsum, int sample_rate, float2 &win) {
+	const float max_e = (32768 * 0.7f);
+	VolCtl o;
+	const float en = (float)((sqrt((double)(acc / n)) + 1) / (double)max_e);
+	st.energy = (en * 0.2f) + st.energy * (1.0f - 0.2f);
+	st.level_pk = (float)pk / max_e;
+	st.instant_energy = en;
+
+	float target = p.static_gain;
+	if (p.peer >= 0) { // echo limiter
+		const float peer_e = peer_energy, peer_pk = peer_e;
+		if (peer_pk > st.lt_speaker_en) st.lt_speaker_en = peer_pk;
+		else st.lt_speaker_en = (0.005f * peer_pk) + (0.995f * st.lt_speaker_en);
+		const float ratio = (st.energy / (st.lt_speaker_en + p.ea_thres));
+		if (peer_e > p.ea_thres) {
+			if (ratio > p.ea_transmit_thres) {
+				st.target_gain = p.static_gain;
+				st.fast_upramp = 1;
+			} else {
+				st.target_gain = p.static_gain / (1 + (peer_e * p.force));
+				st.sustain_dur = p.sustain_time;
+			}
+		} else {
+			if (st.sustain_dur > 0) {
+				st.sustain_dur -= (n * 1000) / sample_rate;
+			} else {
+				st.target_gain = p.static_gain;
+				st.fast_upramp = 1;
+			}
+		}
+		target = st.target_gain;
+	}
+	if (p.agc_enabled) target /= (0.5f + st.level_pk) / 1;
+	if (p.noise_gate_enabled) {
+		float tgain = p.ng_floorgain;
+		if (st.instant_energy > p.ng_threshold) {
+			st.ng_noise_dur = p.ng_cut_time;
+			tgain = 1.0f;
+		} else if (st.ng_noise_dur > 0) {
+			st.ng_noise_dur -= (n * 1000) / sample_rate;
+			tgain = 1.0f;
+		}
+		st.ng_gain = st.ng_gain * 0.75f + tgain * 0.25f;
+	}
+	// apply_gain: multiplicative ramp toward target
+	if (st.gain < target) {
+		if (st.gain < p.ng_floorgain) st.gain = p.ng_floorgain;
+		st.gain *= 1 + (st.fast_upramp ? p.vol_fast_upramp : p.vol_upramp);
+		if (st.gain > target) st.gain = target;
+	} else if (st.gain > target) {
+		st.gain *= 1 - p.vol_downramp;
+		if (st.gain < target) st.gain = target;
+		st.fast_upramp = 0;
+	}
+	const float gain = st.gain * st.ng_gain;
+	o.intgain = (int32_t)(gain * 4096);
+	o.dcoff = st.dc_offset;
+	if (p.remove_dc) {
+		o.mode = 2;
+		st.dc_offset = (st.dc_offset * 7 + dcsum * 2 / (2 * n)) / 8;
+	} else {
+		o.mode = (gain != 1) ? 1 : 0;
+	}
+	{ // ortp_extremum_record_max(&v->max, curtime, v->energy), period 1000 ms
+		float2 w = win;
+		if (w.y >= 0) {
+			w.y += (float)((n * 1000) / sample_rate);
+			if (w.y > 1000.f) w.y = -1.f; // (int)(now - start) > period: the old maximum is dropped
+		}
+		if (w.y < 0) w = make_float2(st.energy, 0.f);
+		if (st.energy > w.x) w.x = st.energy;
+		win = w;
+	}
+	return o;
+}
+
 __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	uint32_t *rows = reinterpret_cast<uint32_t *>(smem);                              // [SPB][pitch_dw] packed int16
@@ -60,10 +146,8 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 	const bool from_fifo = a.src.ring != nullptr;
 
 	const int tid = threadIdx.x;
-	const int s0 = blockIdx.x * SPB;
+	const int s0 = a.first + blockIdx.x * SPB;
 	const int nloc = min(SPB, a.nstreams - s0);
-	const float max_e = (32768 * 0.7f);
-
 	// per-stream parameters and state: requested first, needed only in phase B
 	mi_volume_params p;
 	mi_volume_state st;
@@ -208,79 +292,12 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 			i = nb << 5;
 		}
 		for (; i < n; ++i) acc += x2[i];
-		const int pk = s_pk[tid], dcsum = s_dc[tid];
-		const float en = (float)((sqrt((double)(acc / n)) + 1) / (double)max_e);
-		st.energy = (en * 0.2f) + st.energy * (1.0f - 0.2f);
-		st.level_pk = (float)pk / max_e;
-		st.instant_energy = en;
-
-		float target = p.static_gain;
-		if (p.peer >= 0) { // echo limiter
-			const float peer_e = peer_energy, peer_pk = peer_e;
-			if (peer_pk > st.lt_speaker_en) st.lt_speaker_en = peer_pk;
-			else st.lt_speaker_en = (0.005f * peer_pk) + (0.995f * st.lt_speaker_en);
-			const float ratio = (st.energy / (st.lt_speaker_en + p.ea_thres));
-			if (peer_e > p.ea_thres) {
-				if (ratio > p.ea_transmit_thres) {
-					st.target_gain = p.static_gain;
-					st.fast_upramp = 1;
-				} else {
-					st.target_gain = p.static_gain / (1 + (peer_e * p.force));
-					st.sustain_dur = p.sustain_time;
-				}
-			} else {
-				if (st.sustain_dur > 0) {
-					st.sustain_dur -= (n * 1000) / a.sample_rate;
-				} else {
-					st.target_gain = p.static_gain;
-					st.fast_upramp = 1;
-				}
-			}
-			target = st.target_gain;
-		}
-		if (p.agc_enabled) target /= (0.5f + st.level_pk) / 1;
-		if (p.noise_gate_enabled) {
-			float tgain = p.ng_floorgain;
-			if (st.instant_energy > p.ng_threshold) {
-				st.ng_noise_dur = p.ng_cut_time;
-				tgain = 1.0f;
-			} else if (st.ng_noise_dur > 0) {
-				st.ng_noise_dur -= (n * 1000) / a.sample_rate;
-				tgain = 1.0f;
-			}
-			st.ng_gain = st.ng_gain * 0.75f + tgain * 0.25f;
-		}
-		// apply_gain: multiplicative ramp toward target
-		if (st.gain < target) {
-			if (st.gain < p.ng_floorgain) st.gain = p.ng_floorgain;
-			st.gain *= 1 + (st.fast_upramp ? p.vol_fast_upramp : p.vol_upramp);
-			if (st.gain > target) st.gain = target;
-		} else if (st.gain > target) {
-			st.gain *= 1 - p.vol_downramp;
-			if (st.gain < target) st.gain = target;
-			st.fast_upramp = 0;
-		}
-		const float gain = st.gain * st.ng_gain;
-		s_intgain[tid] = (int32_t)(gain * 4096);
-		s_dcoff[tid] = st.dc_offset;
-		if (p.remove_dc) {
-			s_mode[tid] = 2;
-			st.dc_offset = (st.dc_offset * 7 + dcsum * 2 / (2 * n)) / 8;
-		} else {
-			s_mode[tid] = (gain != 1) ? 1 : 0;
-		}
+		float2 win = a.win[s];
+		const VolCtl o = volume_control(p, st, peer_energy, acc, n, s_pk[tid], s_dc[tid], a.sample_rate, win);
+		s_intgain[tid] = o.intgain, s_dcoff[tid] = o.dcoff, s_mode[tid] = o.mode;
 		a.state[s] = st;
 		a.energy[*a.parity ^ 1][s] = st.energy;
-		{ // ortp_extremum_record_max(&v->max, curtime, v->energy), period 1000 ms
-			float2 w = a.win[s];
-			if (w.y >= 0) {
-				w.y += (float)((n * 1000) / a.sample_rate);
-				if (w.y > 1000.f) w.y = -1.f; // (int)(now - start) > period: the old maximum is dropped
-			}
-			if (w.y < 0) w = make_float2(st.energy, 0.f);
-			if (st.energy > w.x) w.x = st.energy;
-			a.win[s] = w;
-		}
+		a.win[s] = win;
 	} else if (tid < SPB) {
 		s_mode[tid] = 0;
 		if (tid < nloc) a.energy[*a.parity ^ 1][s0 + tid] = a.state[s0 + tid].energy;
@@ -334,6 +351,163 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 }
 
 __global__ void volume_flip_kernel(int *parity) { *parity ^= 1; }
+
+// ---- MSVolume + MSAudioMixer of a conference in ONE kernel (the chain's last two filters: every leg's chunk is popped
+// from its canceller's output FIFO, metered and levelled (volume_process, msvolume.c:471-514), and the conference is mixed
+// from the levelled chunks (mixer_process in conference mode, audiomixer.c:288-346) without the levelled audio ever
+// leaving the chip: a leg's tick crosses HBM twice (FIFO read, mix write) instead of four times.
+// One workgroup = one conference; the members' chunks live in LDS as packed int16 rows (pitch: an odd number of 8-byte
+// words, so the lanes that walk one row each in the serial meter read disjoint banks).
+//   (0) lane m < members: parameters, state, peer energy, mixer controls, ms_bufferizer_read of its FIFO (all or nothing);
+//   (A) all lanes: the chunks into LDS, 16 bytes at a time; integer peak and DC sum through LDS atomics;
+//   (B) lane m: the float32 sum of squares IN SAMPLE ORDER (the order is part of the reference's result) and the control
+//       chain (volume_control) -- one member per lane, all members at once;
+//   (C) all lanes: the Q12 gain, then the mixer's input stage (channel_process_in: pin active? input gain) in place;
+//   (D) lane = a pair of columns: the int32 sum over the members, and for every pin with its output enabled
+//       saturate(sum - own) (channel_process_out), 4 bytes per lane and row, rows contiguous.
+struct VolMixArgs {
+	VolArgs v;            // the volume batch (params, state, energy double buffer, window) and the source FIFO
+	const uint8_t *flags; // mixer controls [nconf][mm]
+	const float *gain;
+	int16_t *out;         // [nconf][mm][ns]
+	int mm, row_w;        // members per conference; row pitch in 8-byte words (odd)
+};
+constexpr int VM_THREADS = 256, VM_MAXM = MI_MIXER_MAX_CHANNELS;
+
+__global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const VolArgs &a = va.v;
+	uint2 *rows = reinterpret_cast<uint2 *>(smem); // [mm][row_w] four samples per word
+	__shared__ int s_intgain[VM_MAXM], s_dcoff[VM_MAXM], s_mode[VM_MAXM], s_pk[VM_MAXM], s_dc[VM_MAXM], s_head[VM_MAXM], s_flag[VM_MAXM];
+	__shared__ float s_mgain[VM_MAXM];
+	const int t = threadIdx.x, c = blockIdx.x, mm = va.mm, ns = a.nsamples, nw = ns >> 2, ng = ns >> 3;
+	const int s0 = a.first + c * mm;
+
+	mi_volume_params p;
+	mi_volume_state st;
+	float peer_energy = 0;
+	if (t < mm) {
+		const int s = s0 + t;
+		p = a.params[s];
+		st = a.state[s];
+		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
+		s_flag[t] = va.flags[c * mm + t];
+		s_mgain[t] = va.gain[c * mm + t];
+		s_pk[t] = 0, s_dc[t] = 0;
+		const int2 q = a.src.pos[s]; // ms_bufferizer_read, all-or-nothing (msqueue.c:83); a leg that runs dry hears and meters silence
+		int head = -1;
+		if (q.y >= ns) {
+			head = q.x;
+			a.src.pos[s] = make_int2((q.x + ns) % a.src.cap, q.y - ns);
+		}
+		s_head[t] = head;
+	}
+	__syncthreads();
+
+	// ---- (A)
+	for (int i = t; i < mm * ng; i += VM_THREADS) {
+		const int m = i / ng, g = i - m * ng, h = s_head[m];
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (h >= 0) {
+			const int16_t *ring = a.src.ring + (size_t)(s0 + m) * a.src.cap;
+			unsigned at = (unsigned)h + 8u * (unsigned)g;
+			if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
+			if ((h & 7) == 0) {
+				v = *reinterpret_cast<const uint4 *>(ring + at);
+			} else { // a head some other reader left off the 16-byte grid: sample by sample, wrap-aware
+				unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					unsigned q = at + (unsigned)k;
+					if (q >= (unsigned)a.src.cap) q -= (unsigned)a.src.cap;
+					w[k >> 1] |= (unsigned)(uint16_t)ring[q] << (16 * (k & 1));
+				}
+				v = make_uint4(w[0], w[1], w[2], w[3]);
+			}
+		}
+		rows[m * va.row_w + 2 * g] = make_uint2(v.x, v.y);
+		rows[m * va.row_w + 2 * g + 1] = make_uint2(v.z, v.w);
+		const unsigned w[4] = {v.x, v.y, v.z, v.w};
+		int pk = 0, dc = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const int x = (int)(short)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
+			pk = max(pk, x < 0 ? -x : x);
+			dc += x;
+		}
+		atomicMax(&s_pk[m], pk);
+		atomicAdd(&s_dc[m], dc);
+	}
+	__syncthreads();
+
+	// ---- (B)
+	if (t < mm) {
+		const uint2 *r = rows + t * va.row_w;
+		float acc = 0;
+		uint2 cur = r[0];
+		for (int i = 0; i < nw; ++i) { // same additions in the same order as update_energy's loop
+			const uint2 nx = r[min(i + 1, nw - 1)];
+			const int x0 = (int)(short)(cur.x & 0xffffu), x1 = (int)(short)(cur.x >> 16);
+			const int x2 = (int)(short)(cur.y & 0xffffu), x3 = (int)(short)(cur.y >> 16);
+			acc += (float)(x0 * x0);
+			acc += (float)(x1 * x1);
+			acc += (float)(x2 * x2);
+			acc += (float)(x3 * x3);
+			cur = nx;
+		}
+		const int s = s0 + t;
+		float2 win = a.win[s];
+		const VolCtl o = volume_control(p, st, peer_energy, acc, ns, s_pk[t], s_dc[t], a.sample_rate, win);
+		s_intgain[t] = o.intgain, s_dcoff[t] = o.dcoff, s_mode[t] = o.mode;
+		a.state[s] = st;
+		a.energy[*a.parity ^ 1][s] = st.energy;
+		a.win[s] = win;
+	}
+	__syncthreads();
+
+	// ---- (C) Q12 gain (apply_gain), then the pin's contribution as channel_process_in leaves it (0 unless linked and active)
+	for (int i = t; i < mm * nw; i += VM_THREADS) {
+		const int m = i / nw, j = i - m * nw;
+		const unsigned f = (unsigned)s_flag[m];
+		uint2 o = make_uint2(0, 0);
+		if ((f & MI_MIX_LINKED) && (f & MI_MIX_ACTIVE)) {
+			const uint2 r = rows[m * va.row_w + j];
+			int x[4] = {(int)(short)(r.x & 0xffffu), (int)(short)(r.x >> 16), (int)(short)(r.y & 0xffffu), (int)(short)(r.y >> 16)};
+			const int mode = s_mode[m];
+			if (mode != 0) {
+				const int ig = s_intgain[m], dc = (mode == 2) ? s_dcoff[m] : 0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) x[k] = sat16(((x[k] - dc) * ig) / 4096);
+			}
+			const float gn = s_mgain[m];
+			if (gn != 1.0f) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k) x[k] = sat16((int)(gn * (float)x[k]));
+			}
+			o.x = (unsigned)(x[0] & 0xffff) | ((unsigned)x[1] << 16);
+			o.y = (unsigned)(x[2] & 0xffff) | ((unsigned)x[3] << 16);
+		}
+		rows[m * va.row_w + j] = o;
+	}
+	__syncthreads();
+
+	// ---- (D)
+	const unsigned *r32 = reinterpret_cast<const unsigned *>(rows);
+	for (int j = t; j < (ns >> 1); j += VM_THREADS) {
+		int lo = 0, hi = 0;
+		for (int m = 0; m < mm; ++m) {
+			const unsigned w = r32[m * va.row_w * 2 + j];
+			lo += (int)(short)(w & 0xffffu);
+			hi += (int)(short)(w >> 16);
+		}
+		for (int m = 0; m < mm; ++m) {
+			if (!((unsigned)s_flag[m] & MI_MIX_OUTPUT)) continue;
+			const unsigned w = r32[m * va.row_w * 2 + j];
+			const int ol = sat16(lo - (int)(short)(w & 0xffffu)), oh = sat16(hi - (int)(short)(w >> 16));
+			*reinterpret_cast<unsigned *>(va.out + ((size_t)(c * mm + m) * ns) + 2 * j) = (unsigned)(ol & 0xffff) | ((unsigned)oh << 16);
+		}
+	}
+}
 
 } // namespace
 
@@ -469,7 +643,8 @@ int mi_volume_reset_max(mi_volume *v, int first, int count) {
 	return MI_OK;
 }
 
-static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src);
+static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src,
+                         int first = 0, int count = -1);
 
 int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples) {
 	return volume_launch(v, d_samples, nsamples, stride, d_nsamples, nullptr);
@@ -484,7 +659,75 @@ int mi_volume_process_fifo(mi_volume *v, mi_fifo *f_src, int16_t *d_out, int nsa
 	return volume_launch(v, d_out, nsamples, stride, nullptr, f_src);
 }
 
-static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src) {
+int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f_src, int16_t *d_out, int nsamples, int stride, int first, int count) {
+	MI_CHECK_ARG(v && f_src && f_src->nstreams == v->nstreams && first >= 0 && count >= 0 && first + count <= v->nstreams);
+	if ((f_src->capacity & 7) || (nsamples & 7) || (stride & 7) || (reinterpret_cast<uintptr_t>(d_out) & 15)) {
+		mi::set_error("mi_volume_process_fifo_range: capacity, chunk and stride must be multiples of 8 samples, rows 16-byte aligned");
+		return MI_ENOTSUP;
+	}
+	if (count == 0) return MI_OK;
+	if (v->has_peers && count != v->nstreams) {
+		mi::set_error("mi_volume_process_fifo_range: a batch with echo-limiter peers is processed whole (the peers read each other's "
+		              "energy of the previous launch, msvolume.c:206-207)");
+		return MI_ENOTSUP;
+	}
+	return volume_launch(v, d_out, nsamples, stride, nullptr, f_src, first, count);
+}
+
+int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first_stream, mi_fifo *f_src, int16_t *d_out) {
+	MI_CHECK_ARG(m && v && f_src && d_out && first_stream >= 0);
+	MixerView mv;
+	mi_mixer_view(m, &mv);
+	MI_CHECK_ARG(f_src->nstreams == v->nstreams && first_stream + mv.nconf * mv.mm <= v->nstreams && mv.device == v->ctx->device);
+	const int row_w = (mv.ns >> 2) | 1; // 8-byte words per row, odd
+	const size_t lds = (size_t)mv.mm * row_w * 8;
+	if ((mv.ns & 7) || (f_src->capacity & 7) || (reinterpret_cast<uintptr_t>(d_out) & 3) || lds > 120 * 1024) {
+		mi::set_error("mi_mixer_process_volume_fifo: ticks and FIFO capacities must be multiples of 8 samples and a conference's tick must "
+		              "fit the LDS (%d members x %d samples)", mv.mm, mv.ns);
+		return MI_ENOTSUP;
+	}
+	if (v->has_peers && mv.nconf * mv.mm != v->nstreams) {
+		mi::set_error("mi_mixer_process_volume_fifo: a volume batch with echo-limiter peers must be covered by the conferences entirely");
+		return MI_ENOTSUP;
+	}
+	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
+	VolMixArgs a;
+	a.v.samples = nullptr;
+	a.v.nsamples_per_stream = nullptr;
+	a.v.params = v->d_params;
+	a.v.state = v->d_state;
+	a.v.win = v->d_win;
+	a.v.energy[0] = v->d_energy[0];
+	a.v.energy[1] = v->d_energy[1];
+	a.v.parity = v->d_parity;
+	a.v.nstreams = v->nstreams;
+	a.v.nsamples = mv.ns;
+	a.v.stride = mv.ns;
+	a.v.sample_rate = v->sample_rate;
+	a.v.pitch_dw = a.v.pitch_f = 0;
+	a.v.first = first_stream;
+	a.v.src = fifo_view(f_src);
+	a.flags = mv.flags;
+	a.gain = mv.gain;
+	a.out = d_out;
+	a.mm = mv.mm;
+	a.row_w = row_w;
+	static bool big_lds = false; // more than 64 KB of dynamic LDS needs the attribute once
+	if (lds > 64 * 1024 && !big_lds) {
+		MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(volmix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+		big_lds = true;
+	}
+	hipLaunchKernelGGL(volmix_kernel, dim3(mv.nconf), dim3(VM_THREADS), lds, v->ctx->stream, a);
+	MI_LAUNCH_CHECK();
+	if (v->has_peers) {
+		hipLaunchKernelGGL(volume_flip_kernel, dim3(1), dim3(1), 0, v->ctx->stream, v->d_parity);
+		MI_LAUNCH_CHECK();
+	}
+	return MI_OK;
+}
+
+static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src,
+                         int first, int count) {
 	MI_CHECK_ARG(v && d_samples && nsamples > 0 && stride >= nsamples);
 	if (nsamples > 3840) {
 		mi::set_error("chunk of %d samples exceeds the volume kernel's LDS staging (max 3840)", nsamples);
@@ -500,7 +743,9 @@ static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int str
 	a.energy[0] = v->d_energy[0];
 	a.energy[1] = v->d_energy[1];
 	a.parity = v->d_parity;
-	a.nstreams = v->nstreams;
+	if (count < 0) count = v->nstreams - first;
+	a.first = first;
+	a.nstreams = first + count; // the kernel's upper bound
 	a.nsamples = nsamples;
 	a.stride = stride;
 	a.sample_rate = v->sample_rate;
@@ -517,7 +762,7 @@ static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int str
 		mi::set_error("volume chunk of %d samples does not fit the LDS staging (max ~2500)", nsamples);
 		return MI_ENOTSUP;
 	}
-	hipLaunchKernelGGL(volume_kernel, dim3(mi::ceil_div(v->nstreams, SPB)), dim3(VTHREADS), lds, v->ctx->stream, a);
+	hipLaunchKernelGGL(volume_kernel, dim3(mi::ceil_div(count, SPB)), dim3(VTHREADS), lds, v->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	if (v->has_peers) { // without peers nobody reads the previous energies: no flip, no extra launch
 		hipLaunchKernelGGL(volume_flip_kernel, dim3(1), dim3(1), 0, v->ctx->stream, v->d_parity);

@@ -121,3 +121,90 @@ def test_mixer_full_size_config4_shard(ctx, oracle):
         ref, _ = oracle.mixer_tick(x[c])
         np.testing.assert_array_equal(out[c], ref)
     mx.close()
+
+
+@pytest.mark.parametrize("mm,ns,rate", [(32, 480, 48000), (50, 160, 16000), (3, 80, 8000)])
+def test_volume_and_conference_mix_in_one_launch_equal_the_two_launches(ctx, mm, ns, rate):
+    """mi_mixer_process_volume_fifo (every pin's chunk popped from its FIFO, metered and levelled, the conference mixed from
+    the levelled chunks, nothing in between written to HBM) == mi_volume_process_fifo + mi_mixer_process: mixed samples,
+    the meters' whole state incl. the one-second maximum, FIFO levels -- with AGC, noise gate, DC removal, an echo-limiter
+    pair (when the conferences cover the whole batch), muted / listen-only / unplumbed pins, pin gains, legs that run dry and ring heads off the 16-byte grid; the
+    conferences start at stream `first` of a larger volume batch whose other streams are served by the ranged volume call."""
+    import mediastreamer2_amd as ms
+    torch = pytest.importorskip("torch")
+    nconf, first, extra = (5, 8, 3) if mm != 3 else (5, 0, 0)   # the small case: conferences = the whole batch, with peers
+    n = first + nconf * mm + extra
+    rng = np.random.default_rng(mm)
+    L, A, O = ms.MI_MIX_LINKED, ms.MI_MIX_ACTIVE, ms.MI_MIX_OUTPUT
+    flags = np.full((nconf, mm), L | A | O, np.uint8)
+    flags[0, 1] = L | O          # muted
+    flags[1, 0] = L | A          # no return audio
+    flags[2, 2] = 0              # unplumbed
+    gain = np.ones((nconf, mm), np.float32)
+    gain[3, 1] = 0.5
+    gain[4, 2] = 1.7
+
+    def rig():
+        v = ms.VolumeBatch(ctx, n, rate)
+        ps = []
+        for s in range(n):
+            p = v.default_params()
+            p.agc_enabled = int(s % 3 == 0)
+            p.noise_gate_enabled = int(s % 5 == 1)
+            p.remove_dc = int(s % 7 == 2)
+            if s % 4 == 1:
+                p.static_gain = 0.5
+            ps.append(p)
+        if extra == 0:  # an echo-limiter pair inside conference 0 (peers need the batch processed whole)
+            ps[first + 1].peer = first + 2
+            ps[first + 2].peer = first + 1
+        v.set_params(ps)
+        st = v.get_state()
+        for s in range(n):
+            st[s].gain = st[s].target_gain = ps[s].static_gain
+        v.set_state(st)
+        m = ms.MixerBatch(ctx, nconf, mm, ns)
+        m.set_controls(flags, gain)
+        f = ms.FifoBatch(ctx, n, 4 * ns + 64)
+        return v, m, f
+
+    (v1, m1, f1), (v2, m2, f2) = rig(), rig()
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    pre, junk = torch.from_numpy(rng.integers(-9000, 9000, (n, 8), dtype=np.int16)).cuda(), z(n, 8)
+    odd = torch.from_numpy((np.arange(n) % 3 == 1).astype(np.uint8)).cuda()
+    torch.cuda.synchronize()
+    for f in (f1, f2):  # a third of the rings get a head that is no multiple of 8
+        f.push(pre, nsamples=8)
+        f.pop(3, junk, gate=odd)
+    t1, o1, o2 = z(n, ns), z(nconf, mm, ns), z(nconf, mm, ns)
+    t2 = z(n, ns)
+    lv1, lv2 = z(n, dt=torch.int32), z(n, dt=torch.int32)
+    for t in range(30):
+        blk = rng.integers(-20000, 20000, (n, ns), dtype=np.int16)
+        blk[:, ::7] += 900  # some DC
+        cnt = rng.choice([0, ns], n, p=[0.15, 0.85]).astype(np.int32)  # now and then a leg delivers nothing: it runs dry
+        d, c = torch.from_numpy(blk).cuda(), torch.from_numpy(cnt).cuda()
+        torch.cuda.synchronize()
+        f1.push(d, nsamples=ns, count=c)
+        f2.push(d, nsamples=ns, count=c)
+        v1.process_fifo(f1, t1)
+        m1.process(t1[first:first + nconf * mm].view(nconf, mm, ns), out=o1)
+        m2.process_volume_fifo(v2, f2, o2, first_stream=first)
+        if extra:
+            v2.process_fifo(f2, t2, first=0, count=first)                    # the streams around the conferences
+            v2.process_fifo(f2, t2, first=first + nconf * mm, count=extra)
+        f1.levels(lv1)
+        f2.levels(lv2)
+        ctx.sync()
+        np.testing.assert_array_equal(o1.cpu().numpy(), o2.cpu().numpy(), err_msg=f"tick {t}")
+        np.testing.assert_array_equal(lv1.cpu().numpy(), lv2.cpu().numpy())
+        a, b = t1.cpu().numpy(), t2.cpu().numpy()
+        np.testing.assert_array_equal(a[:first], b[:first])
+        np.testing.assert_array_equal(a[first + nconf * mm:], b[first + nconf * mm:])
+        s1, s2 = v1.get_state(), v2.get_state()
+        for s in range(n):
+            assert bytes(s1[s]) == bytes(s2[s]), f"tick {t} stream {s}"
+        np.testing.assert_array_equal(v1.get_max().view(np.uint32), v2.get_max().view(np.uint32))
+    assert o1.cpu().numpy().any() and not o2.cpu().numpy()[2, 2].any() and not o2.cpu().numpy()[1, 0].any()
+    for o in (v1, m1, f1, v2, m2, f2):
+        o.close()
