@@ -979,23 +979,33 @@ class Headline:
 
     def canceller_launches(self, nticks):
         """the canceller's launch inside the running chain, HIP events on the launch stream around that launch alone:
-        (total ms, launches, frames cancelled).  Eager ticks: the events cannot sit inside a captured graph."""
+        (total ms, launches, frames cancelled).  Eager ticks (the events cannot sit inside a captured graph); the only host
+        wait per tick is the one on the event behind the canceller's launch, the volume + mix launch that follows runs while
+        the host queues the next tick, so the canceller starts right behind it and its clocks never drop.
+        Frames: over whole 8-tick re-framing cycles every leg cancels exactly 15 (480 / 256 samples), whatever its phase;
+        checked once against the per-leg counts the kernel reports before anything is timed."""
         rig, ctx = self.rig, self.ctx
-        tot, frames = 0.0, 0
-        for t in range(nticks):
-            acc = []
+        nticks = max(8, nticks // 8 * 8)
+        counted = 0
+        for t in range(8):
+            rig.tick(t)
+            rig.finalize()
+            ctx.sync()
+            counted += int(rig.cnt.sum().item())
+        if counted != 15 * rig.n:
+            raise RuntimeError(f"{counted} frames cancelled in an 8-tick cycle of {rig.n} legs, expected {15 * rig.n}")
+        acc = []
 
-            def parts(stage):
-                if stage == "aec_begin":
-                    ctx.timer_start()
-                else:
-                    acc.append(ctx.timer_stop())  # synchronises: the launch is over
+        def parts(stage):
+            if stage == "aec_begin":
+                ctx.timer_start()
+            else:
+                acc.append(ctx.timer_stop())  # waits for the event behind the launch
+        for t in range(nticks):
             rig.tick(t, parts)
             rig.finalize()
-            tot += acc[0]
-            frames += int(rig.cnt.sum().item())
         ctx.sync()
-        return tot, nticks, frames
+        return float(sum(acc)), nticks, 15 * rig.n * (nticks // 8)
 
     def allreduce_alone_us(self, reps=200):
         """the exchange step by itself: event -> all-reduce of the [split conferences][480] int32 sums -> event"""

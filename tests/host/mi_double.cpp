@@ -532,6 +532,10 @@ int mi_aec_process_frames(mi_aec *a, const int16_t *mic, const int16_t *ref, int
 int mi_aec_process_fifos(mi_aec *, mi_fifo *, const int16_t *, int, mi_fifo *, const int16_t *, int, const int32_t *, int, mi_fifo *, int, unsigned, uint8_t *) {
 	return fail(MI_ENOTSUP, "the FIFO entry is not modelled by the double");
 }
+int mi_aec_process_fifos_resampled(mi_aec *, mi_resampler *, const int16_t *, int, int, mi_fifo *, mi_fifo *, const int16_t *, int, const int32_t *,
+                                   mi_fifo *, int, unsigned, uint8_t *) {
+	return fail(MI_ENOTSUP, "the FIFO entry is not modelled by the double");
+}
 int mi_aec_stagger_info(const mi_aec *a, int tick_len, int *unit, int *phases) {
 	ARG(a && tick_len > 0);
 	if (unit) *unit = a->F / 8;
@@ -692,6 +696,26 @@ int mi_volume_process_fifo(mi_volume *v, mi_fifo *f, int16_t *out, int ns, int s
 	ARG(v && f && out && f->n == v->n);
 	const int rc = mi_fifo_pop(f, ns, out, stride, nullptr, nullptr, 1);
 	return rc != MI_OK ? rc : mi_volume_process(v, out, ns, stride, nullptr);
+}
+
+int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f, int16_t *out, int ns, int stride, int first, int count) {
+	ARG(v && f && out && f->n == v->n && first >= 0 && count >= 0 && first + count <= v->n);
+	for (int s = first; s < first + count; ++s) {
+		std::vector<int16_t> &q = f->q[(size_t)s];
+		if ((int)q.size() >= ns) {
+			std::copy(q.begin(), q.begin() + ns, out + (size_t)s * stride);
+			q.erase(q.begin(), q.begin() + ns);
+		} else {
+			memset(out + (size_t)s * stride, 0, (size_t)ns * 2);
+		}
+	}
+	return MI_OK;
+}
+int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out) {
+	ARG(m && v && f && out && first >= 0 && first + m->nconf * m->mm <= v->n && f->n == v->n);
+	std::vector<int16_t> ticks((size_t)v->n * m->ns);
+	const int rc = mi_volume_process_fifo_range(v, f, ticks.data(), m->ns, m->ns, first, m->nconf * m->mm);
+	return rc != MI_OK ? rc : mi_mixer_process(m, ticks.data() + (size_t)first * m->ns, nullptr, 1, out);
 }
 
 // ---- codecs and friends
