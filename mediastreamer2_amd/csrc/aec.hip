@@ -553,11 +553,11 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		mi_aec_destroy(a);
 		return rc;
 	}
-	{ // the FIFO entry's leg lists start as the identity: class c = legs c, c + 8, ..
-		a->cap8 = (nstreams + 7) / 8;
+	{ // the FIFO entry's leg lists start as the identity: class c = legs c, c + 8, .. (all entered from the front)
+		a->cap8 = (nstreams + 7) / 8 + TickOrder::SLACK;
 		std::vector<int> ord((size_t)2 * 8 * a->cap8, 0), ctl(TickOrder::WORDS, 0);
-		for (int p = 0; p < 2; ++p)
-			for (int s = 0; s < nstreams; ++s) ord[((size_t)p * 8 + (size_t)(s & 7)) * a->cap8 + (size_t)(s >> 3)] = s;
+		for (int s = 0; s < nstreams; ++s) ord[(size_t)(s & 7) * a->cap8 + (size_t)(s >> 3)] = s;
+		for (int c = 0; c < 8; ++c) ctl[(size_t)c * TickOrder::STRIDE + TickOrder::LEN] = (nstreams - c + 7) / 8; // parity 0: front = all, back = 0
 		if (hipMalloc((void **)&a->d_order, ord.size() * sizeof(int)) != hipSuccess || hipMalloc((void **)&a->d_ctl, ctl.size() * sizeof(int)) != hipSuccess ||
 		    hipMemcpy(a->d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(a->d_ctl, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
@@ -671,9 +671,11 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	// One wavefront per stream and TICK: the canceller for every frame the stream has ready and, with MI_AEC_POSTFILTER, the
 	// post-filter of the same frames as the wave's tail phase (aec_tick.hpp).  One launch, on the context's stream.
 	g.first = 0;
-	if (a->F == 256) hipLaunchKernelGGL(aec_tick_kernel<256>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
-	else if (a->F == 128) hipLaunchKernelGGL(aec_tick_kernel<128>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
-	else hipLaunchKernelGGL(aec_tick_kernel<64>, dim3(a->nstreams), dim3(64), 0, a->ctx->stream, g);
+	// the FIFO entry: one workgroup per list SLOT (8 classes x cap8; the few empty slots leave at once), else one per stream
+	const dim3 grid(fifo ? 8 * a->cap8 : a->nstreams);
+	if (a->F == 256) hipLaunchKernelGGL(aec_tick_kernel<256>, grid, dim3(64), 0, a->ctx->stream, g);
+	else if (a->F == 128) hipLaunchKernelGGL(aec_tick_kernel<128>, grid, dim3(64), 0, a->ctx->stream, g);
+	else hipLaunchKernelGGL(aec_tick_kernel<64>, grid, dim3(64), 0, a->ctx->stream, g);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
@@ -854,9 +856,13 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 		std::vector<int> ctl(TickOrder::WORDS), ord((size_t)2 * 8 * a->cap8);
 		MI_HIP(hipMemcpy(ctl.data(), a->d_ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost));
 		MI_HIP(hipMemcpy(ord.data(), a->d_order, ord.size() * sizeof(int), hipMemcpyDeviceToHost));
+		// class after class: the entries from the front, then those from the back, each class closed by a -1
+		const size_t par = (size_t)ctl[TickOrder::GLOBAL + TickOrder::PARITY];
 		for (int c = 0; c < 8; ++c) {
-			const size_t par = (size_t)ctl[(size_t)c * TickOrder::STRIDE + TickOrder::PARITY];
-			for (int i = 0; i < (a->nstreams - c + 7) / 8; ++i) res.push_back((float)ord[(par * 8 + (size_t)c) * a->cap8 + (size_t)i]);
+			const int front = ctl[(size_t)c * TickOrder::STRIDE + TickOrder::LEN + 2 * par], back = ctl[(size_t)c * TickOrder::STRIDE + TickOrder::LEN + 2 * par + 1];
+			for (int i = 0; i < front; ++i) res.push_back((float)ord[(par * 8 + (size_t)c) * a->cap8 + (size_t)i]);
+			for (int i = a->cap8 - back; i < a->cap8; ++i) res.push_back((float)ord[(par * 8 + (size_t)c) * a->cap8 + (size_t)i]);
+			res.push_back(-1.f);
 		}
 	} else if (!strcmp(what, "counters")) res = {(float)sc.fg_updates, (float)sc.bg_resets, (float)sc.state_resets, (float)sc.frames};
 	else if (!strcmp(what, "scalars")) {

@@ -156,8 +156,17 @@ __device__ __forceinline__ void cmac_bins(TA (&acc)[K], const TX (&x)[K], const 
 }
 
 // words of AecArgs::ctl (the list hand-over between consecutive launches of the FIFO entry)
-struct TickOrder { // per class: one 128-byte line
-	static constexpr int STRIDE = 32, PARITY = 0, PLACED = 2, WORDS = 8 * STRIDE; // PLACED: 64 bits, front | back << 32
+// Eight lists (classes), one per XCD (workgroup b runs on XCD b % 8).  A list has room for cap8 entries: legs that will run
+// two frames are entered from the front, the others from the back, the slots in between stay empty (their workgroups leave
+// at once).  Every class has its own 128-byte line of control words (the atomics of different classes do not queue up behind
+// each other) and a ninth line is shared:
+//   PLACED  64 bits: entries placed into this class's NEXT list so far, front | back << 32
+//   DONE    legs of this class's CURRENT list that have entered themselves into a next list
+//   LEN     [parity][front, back]: how many entries the list of that parity holds
+//   global line: PARITY (which set of lists this launch serves), CLASSES (classes whose legs are all done)
+struct TickOrder {
+	static constexpr int STRIDE = 32, PLACED = 0, DONE = 2, LEN = 4, GLOBAL = 8 * STRIDE, PARITY = 0, CLASSES = 1, WORDS = 9 * STRIDE;
+	static constexpr int SLACK = 32; // a class's share of the legs wanders by a few around nstreams / 8 (see the mixing rule below)
 };
 
 template <int F>
@@ -166,14 +175,18 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	using SL = TickLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
 	// ---- which leg this wavefront serves.  Rows / per-frame entries: leg = block.  FIFO entry: the leg comes out of a list
-	// the PREVIOUS tick's launch sorted (TickOrder below) -- legs that will run two frames first, the short ones last, one
-	// list per class b % 8 (workgroup b runs on XCD b % 8): every XCD gets the same mix whatever pattern the legs' phases
-	// follow, and the long legs are started first.
+	// the PREVIOUS tick's launch sorted (TickOrder above) -- legs that will run two frames first, the short ones last, one
+	// list per class b % 8: every XCD gets the same mix whatever pattern the legs' phases follow, and the long legs are
+	// started first.
 	const bool sched = a.order != nullptr;
-	int s = a.first + blockIdx.x, par = 0;
+	int s = a.first + blockIdx.x, par = 0, own_len = 0;
 	if (sched) {
-		par = a.ctl[(blockIdx.x & 7u) * TickOrder::STRIDE + TickOrder::PARITY];
-		s = a.order[(size_t)par * 8 * a.cap8 + (blockIdx.x & 7u) * a.cap8 + (blockIdx.x >> 3)];
+		const unsigned c = blockIdx.x & 7u, i = blockIdx.x >> 3;
+		par = a.ctl[TickOrder::GLOBAL + TickOrder::PARITY];
+		const int front = a.ctl[c * TickOrder::STRIDE + TickOrder::LEN + 2 * par], back = a.ctl[c * TickOrder::STRIDE + TickOrder::LEN + 2 * par + 1];
+		if (i >= (unsigned)front && i < (unsigned)(a.cap8 - back)) return; // an empty slot between the two ends of the list
+		own_len = front + back;
+		s = a.order[(size_t)par * 8 * a.cap8 + c * a.cap8 + i];
 	}
 	const int lane = threadIdx.x;
 	const int e0 = lane * K; // first element (sample / bin) this lane owns
@@ -276,24 +289,40 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			nf = 0;
 		}
 		if (sched && lane == 0) {
-			// this leg's place in the NEXT tick's list: every leg is handed a block every tick, so the frames it will then
-			// have follow from what it keeps now (a wrong guess -- a refused block -- only costs placement).  Front of its
-			// class for two frames, back for fewer: ONE 64-bit atomic per leg on its class's own cache line (entries placed at
-			// the front in the low half, at the back in the high half; atomics on one line serialise at ~18 ns each, so the
-			// eight classes must not share one).  The wave that completes its class's list (all others of the class have read
-			// `par` and their entry before they got here: s, and through it the level, depend on both) hands it over.
+			// This leg's place in the NEXT tick's lists: every leg is handed a block every tick, so the frames it will then have
+			// follow from what it keeps now (a wrong guess -- a refused block -- only costs placement).  WHICH list: class
+			// (c + i) % 8 for the leg at position i of class c -- a class's legs are dealt out over all eight classes every
+			// tick, so legs that share a phase cannot stay together on one XCD however the slots were arranged (phase =
+			// slot % 8 kept every tick's light legs on ONE XCD with per-class lists that never mixed: +4 % on the launch), and
+			// every class keeps nstreams / 8 legs give or take a few.  Front of the list for two frames, back for fewer: one
+			// 64-bit atomic on the destination class's line; then one on the source class's line to say this leg is done.
+			// The wave that completes the last class (every leg has read `par`, its list's length and its entry before it got
+			// here: s, and through it the level, depend on them) publishes the new lengths and turns the lists over.
 			const int keep = qm.y + (mic_new ? a.tick_len : 0) - nf * F;
 			int next = (keep + a.tick_len) / F;
 			if (next > a.max_frames) next = a.max_frames;
-			const unsigned c = blockIdx.x & 7u, in_class = ((unsigned)a.nstreams - c + 7u) >> 3;
-			int *dst = a.order + (size_t)(par ^ 1) * 8 * a.cap8 + c * a.cap8;
-			unsigned long long *placed = reinterpret_cast<unsigned long long *>(a.ctl + c * TickOrder::STRIDE + TickOrder::PLACED);
+			const unsigned c = blockIdx.x & 7u, i = blockIdx.x >> 3, d = (c + i) & 7u;
+			int *dst = a.order + (size_t)(par ^ 1) * 8 * a.cap8 + d * a.cap8;
+			unsigned long long *placed = reinterpret_cast<unsigned long long *>(a.ctl + d * TickOrder::STRIDE + TickOrder::PLACED);
 			const unsigned long long old = atomicAdd(placed, next >= 2 ? 1ull : (1ull << 32));
 			const unsigned front = (unsigned)old, back = (unsigned)(old >> 32);
-			dst[next >= 2 ? front : in_class - 1u - back] = s;
-			if (front + back == in_class - 1u) {
-				*placed = 0ull;
-				a.ctl[c * TickOrder::STRIDE + TickOrder::PARITY] = par ^ 1;
+			dst[next >= 2 ? front : (unsigned)a.cap8 - 1u - back] = s;
+			// the second atomic only after the first has been performed (it has, once its value is back).  Not a
+			// __threadfence(): that writes back and invalidates caches -- per wave it doubled the launch time
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (atomicAdd(&a.ctl[c * TickOrder::STRIDE + TickOrder::DONE], 1) == own_len - 1 &&
+			    atomicAdd(&a.ctl[TickOrder::GLOBAL + TickOrder::CLASSES], 1) == 7) {
+#pragma nounroll
+				for (int k = 0; k < 8; ++k) {
+					int *cl = a.ctl + k * TickOrder::STRIDE;
+					const unsigned long long p = atomicAdd(reinterpret_cast<unsigned long long *>(cl + TickOrder::PLACED), 0ull); // (read where the atomics are performed)
+					cl[TickOrder::LEN + 2 * (par ^ 1)] = (int)(unsigned)p;
+					cl[TickOrder::LEN + 2 * (par ^ 1) + 1] = (int)(unsigned)(p >> 32);
+					*reinterpret_cast<unsigned long long *>(cl + TickOrder::PLACED) = 0ull;
+					cl[TickOrder::DONE] = 0;
+				}
+				a.ctl[TickOrder::GLOBAL + TickOrder::CLASSES] = 0;
+				a.ctl[TickOrder::GLOBAL + TickOrder::PARITY] = par ^ 1;
 			}
 		}
 		if (lane == 0) {

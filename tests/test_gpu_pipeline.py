@@ -689,11 +689,12 @@ def test_bench_rig_with_legs_out_of_phase(ctx):
 
 
 def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
-    """mi_aec_process_fifos keeps, per class b % 8 (the XCD a workgroup lands on), a list of its legs that every launch
-    re-sorts for the next one: legs that will have two frames first, the others last.  After any number of ticks the list is
-    a permutation of the class's legs, sorted by what the legs really have in the next tick -- here with the product's stagger
--- and the results do not depend on the order (same outputs as a batch
-    whose legs are arranged the other way round)."""
+    """mi_aec_process_fifos keeps eight lists of legs (one per class b % 8 = the XCD a workgroup lands on) that every launch
+    rebuilds for the next one: each leg enters itself into class (own class + own position) % 8, from the front if it will
+    have two frames, from the back otherwise.  After any number of ticks the lists hold every leg exactly once, are sorted by
+    what the legs really have in the next tick, stay even in size, and spread the light legs evenly over the classes -- here
+    with phase = slot % 8, the arrangement that used to keep a tick's light legs on ONE XCD -- and the results do not depend
+    on the order (same outputs as a batch whose legs are arranged the other way round)."""
     torch = pytest.importorskip("torch")
     rate, F, n, ns = 48000, 256, 203, 480
     flen = 32 * rate // 1000
@@ -709,8 +710,8 @@ def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
     outs = []
     for rev in (False, True):
         a, fm, fr, fo, perm = rig(rev)
-        # the same lead for the same SIGNAL in both arrangements: leads set by hand from the forward batch's phases
-        lead = np.array([32 * ctx.L.mi_fifo_phase_of(int(perm[s]), 8) for s in range(n)], np.int32)
+        # the same lead for the same SIGNAL in both arrangements; phase = (forward) slot % 8
+        lead = np.array([32 * (int(perm[s]) % 8) for s in range(n)], np.int32)
         zeros, d_lead = z(n, 256), torch.from_numpy(lead).cuda()
         torch.cuda.synchronize()
         fm.push(zeros, nsamples=224, count=d_lead)
@@ -726,16 +727,23 @@ def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
             fm.levels(lv)
             ctx.sync()
             got.append(tick.cpu().numpy()[np.argsort(perm)].copy())
-            order = a.get(0, "order", n).astype(int)
-            nxt = (lv.cpu().numpy() + ns) // F          # frames every leg will have in the next tick
-            pos = 0
-            for c in range(8):
-                k = len(range(c, n, 8))
-                lst = order[pos:pos + k]
-                pos += k
-                assert sorted(lst) == list(range(c, n, 8)), (t, c)           # a permutation of the class's legs
+            order = a.get(0, "order", n + 8).astype(int)   # class after class, each closed by -1
+            nxt = (lv.cpu().numpy() + ns) // F              # frames every leg will have in the next tick
+            classes, cur = [], []
+            for v in order:
+                if v < 0:
+                    classes.append(cur)
+                    cur = []
+                else:
+                    cur.append(int(v))
+            assert len(classes) == 8 and sorted(x for cl in classes for x in cl) == list(range(n)), t   # every leg exactly once
+            for c, lst in enumerate(classes):
+                assert abs(len(lst) - n / 8) <= 8, (t, c, len(lst))               # the classes stay even
                 fr_next = nxt[lst]
-                assert (np.diff((fr_next >= 2).astype(int)) <= 0).all(), (t, c, fr_next)  # two-frame legs first
+                assert (np.diff((fr_next >= 2).astype(int)) <= 0).all(), (t, c, fr_next)   # two-frame legs first
+            if t >= 2:  # a class's legs are dealt out over all classes every tick: the light legs end up spread evenly
+                light = [int((nxt[lst] < 2).sum()) for lst in classes]
+                assert max(light) - min(light) <= max(10, n // 16), (t, light)   # (with phase = slot % 8 and no mixing: n / 8 against 0)
         outs.append(np.stack(got))
         assert fm.overflows() + fr.overflows() + fo.overflows() == 0
         for o in (a, fm, fr, fo):
