@@ -882,7 +882,14 @@ class HipPlatform:
             idt.copy_(torch.frombuffer(bytearray(ms.Exchange.unique_id(ctx)), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         self.sync(torch)
-        return ms.Exchange(ctx, world, rank, idt.cpu().numpy().tobytes())
+        ex = ms.Exchange(ctx, world, rank, idt.cpu().numpy().tobytes())
+        probe = torch.ones(4, dtype=torch.int32, device=self.device)  # every rank contributes 1: the sum is the world size
+        self.sync(torch)
+        ex(probe)
+        ctx.sync()
+        if probe.tolist() != [world] * 4:
+            raise RuntimeError(f"mi_exchange probe returned {probe.tolist()}, expected {world}")
+        return ex
 
     def converged(self, ms, torch, ctx, rank):
         return Converged(ms, torch, ctx, rank)
