@@ -622,8 +622,12 @@ def rig_period(head):
 
 
 def series_stats(v):
+    """late = ticks that reached the interval; slowest = [position in the series, ms] of the four longest (a machine
+    event -- profiles/r03_outlier_probe.txt -- shows as one tick ~1 ms over the median and the next 0.2-0.4 over)"""
+    top = np.argsort(v)[-4:][::-1]
     return {"ticks": int(v.size), "p50_ms": round(float(np.percentile(v, 50)), 4), "p99_ms": round(float(np.percentile(v, 99)), 4),
-            "p99_9_ms": round(float(np.percentile(v, 99.9)), 4), "max_ms": round(float(v.max()), 4), "mean_ms": round(float(v.mean()), 4)}
+            "p99_9_ms": round(float(np.percentile(v, 99.9)), 4), "max_ms": round(float(v.max()), 4), "mean_ms": round(float(v.mean()), 4),
+            "late": int((v >= 10.0).sum()), "slowest": [[int(i), round(float(v[i]), 3)] for i in top]}
 
 
 def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25, stagger=True, converged=None, worst_ticks=64):
@@ -1128,6 +1132,7 @@ def main():
     #  (2) --worst-ticks (default 3000) CONSECUTIVE deployed ticks in steady state -- with the exchange at N > 1 -- none
     #      of which may reach the 10 ms interval: a late tick is a fault (src/base/msticker.c:46,441-443).
     zero = None
+    tried = []  # the counts that did not pass, with what they measured: the step-downs are part of the result
     for attempt in range(12):
         if a.zero_ticks > 0 and converged is not None:
             zero = chain_capacity_point(ms, torch, ctx, streams, converged=None, worst_ticks=a.zero_ticks)
@@ -1151,7 +1156,10 @@ def main():
                 log({"streams": head.rig.n, "test": f"{a.worst_ticks} consecutive ticks", **series_stats(series)})
             if (worst < 10.0 and zero_ok) or a.streams > 0 or streams <= 8192:
                 break
+            tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"]})
             head.close()
+        else:
+            tried.append({"streams": streams, "from_reset_worst_ms": zero["tick_ms_worst"]})
         streams -= 2048 * (1 + attempt // 2)  # 2048, 2048, 4096, 4096, ...: a late exchange must not end in "does not fit"
         streams = max(streams, 8192)
     rig = head.rig
@@ -1222,7 +1230,7 @@ def main():
                                        "tick over the timed region at that count",
                    "streams_per_gpu": n_local, "conferences_per_gpu": nconf_local + (SPLIT_CONFERENCES if world > 1 else 0),
                    "tick_ms": 10, "worst_tick_ms": round(worst, 4), "single_tick_median_ms": round(median_single, 4),
-                   "consecutive_ticks": stats,
+                   "consecutive_ticks": stats, "consecutive_ticks_failed_at": tried,
                    "fits": bool(fits), "tick_budget_used": round(tick_ms / 10.0, 4),
                    "rate_equivalent_streams": int(total_streams * 10.0 / tick_ms),
                    "fifo_overflows": int(overflows), "aec_resident_state_bytes_per_gpu": state_bytes,

@@ -25,3 +25,24 @@ for rep in range(3):
     v = head.tick_series(nt)
     top = np.argsort(v)[-8:][::-1]
     print(json.dumps({"rep": rep, **bench.series_stats(v), "top": [(int(i), round(float(v[i]), 3)) for i in top]}), flush=True)
+
+# The same series with the host kept two ticks ahead of the GPU (events from torch on the library's stream): a tick's
+# interval then starts when the GPU finishes the tick before it, so a host stall between "record" and "launch" -- which
+# the series above charges to the tick -- cannot show.  Outliers in both = the GPU's; only above = the host's.
+stream = torch.cuda.ExternalStream(ctx.stream)
+for rep in range(2):
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(nt)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(nt)]
+    for t in range(nt):
+        e0[t].record(stream)
+        head.g1[t % len(head.g1)].launch()
+        e1[t].record(stream)
+        if t >= 2:
+            e1[t - 2].synchronize()
+    ctx.sync()
+    v = np.array([e0[t].elapsed_time(e1[t]) for t in range(nt)])
+    top = np.argsort(v)[-8:][::-1]
+    print(json.dumps({"rep": f"host two ticks ahead {rep}", **bench.series_stats(v), "top": [(int(i), round(float(v[i]), 3)) for i in top]}), flush=True)
+    v = head.tick_series(nt)
+    top = np.argsort(v)[-8:][::-1]
+    print(json.dumps({"rep": f"as the bench {rep}", **bench.series_stats(v), "top": [(int(i), round(float(v[i]), 3)) for i in top]}), flush=True)
