@@ -878,21 +878,47 @@ class HipPlatform:
         one GPU -- RCCL refuses that) goes through torch instead and is named in the line."""
         if backend != "nccl":
             from mediastreamer2_amd.sharding import PartialSumExchange
-            return PartialSumExchange(ctx.stream, local)
+            ex = PartialSumExchange(ctx.stream, local)
+            ex.label = backend + " all-reduce (TEST BACKEND, not RCCL)"
+            return ex
         import torch
         ms = self.load()
+        ex, why = None, ""
         idt = torch.zeros(128, dtype=torch.uint8, device=self.device)
         if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(ms.Exchange.unique_id(ctx)), dtype=torch.uint8))
+            try:
+                idt.copy_(torch.frombuffer(bytearray(ms.Exchange.unique_id(ctx)), dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001 -- the others must not wait for an id that never comes: zeros travel
+                why = str(e)[:300]
         dist.broadcast(idt, 0)
         self.sync(torch)
-        ex = ms.Exchange(ctx, world, rank, idt.cpu().numpy().tobytes())
-        probe = torch.ones(4, dtype=torch.int32, device=self.device)  # every rank contributes 1: the sum is the world size
-        self.sync(torch)
-        ex(probe)
-        ctx.sync()
-        if probe.tolist() != [world] * 4:
-            raise RuntimeError(f"mi_exchange probe returned {probe.tolist()}, expected {world}")
+        try:
+            if not bool(idt.any().item()):
+                raise RuntimeError(why or "rank 0 could not make the communicator id")
+            ex = ms.Exchange(ctx, world, rank, idt.cpu().numpy().tobytes())
+            probe = torch.ones(4, dtype=torch.int32, device=self.device)  # every rank contributes 1: the sum is the world size
+            self.sync(torch)
+            ex(probe)
+            ctx.sync()
+            if probe.tolist() != [world] * 4:
+                raise RuntimeError(f"mi_exchange probe returned {probe.tolist()}, expected {world}")
+        except Exception as e:  # noqa: BLE001 -- reported below, by every rank that saw it
+            ex, why = None, str(e)[:300]
+        # every rank uses the same exchange: if ANY rank could not bring the C one up, all of them say so and take the same
+        # collective (RCCL int32 SUM over xGMI) through torch.distributed's communicator instead -- same transport, same
+        # bytes, ordered with events around a second stream; the line names which one ran (config.parallelism)
+        ok = torch.tensor([1 if ex is not None else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            ex.label = "mi_exchange_allreduce_i32 (C ABI, RCCL over xGMI, on the kernel stream)"
+            return ex
+        print(f"bench.py: rank {rank}: mi_exchange could not be set up on every rank ({why or 'another rank failed'}); "
+              "the split conferences' all-reduce runs on torch.distributed's RCCL communicator instead", file=sys.stderr, flush=True)
+        if ex is not None:
+            ex.close()
+        from mediastreamer2_amd.sharding import PartialSumExchange
+        ex = PartialSumExchange(ctx.stream, local)
+        ex.label = "torch.distributed all_reduce (RCCL over xGMI, own stream ordered with events; mi_exchange failed to start)"
         return ex
 
     def converged(self, ms, torch, ctx, rank):
@@ -1211,7 +1237,7 @@ def main():
     if world > 1:
         parallelism = (f"{world} ranks, one per GPU; legs and whole conferences sharded statically (no collective), "
                        f"{SPLIT_CONFERENCES} conferences split over all ranks: int32 partial sums -> "
-                       f"{'mi_exchange_allreduce_i32 (C ABI, RCCL over xGMI, on the kernel stream)' if backend == 'nccl' else backend + ' all-reduce (TEST BACKEND, not RCCL)'} "
+                       f"{getattr(exchange, 'label', backend + ' all-reduce (TEST BACKEND, not RCCL)')} "
                        "-> finalize, every tick")
     line = {
         "metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale",
