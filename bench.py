@@ -247,14 +247,15 @@ def make_equalizer_leg(ms, torch, ctx, nstreams=4096, ns=480):
     return leg
 
 
-def make_scaler_leg(ms, torch, ctx, nframes=64, fmt=None):
+def make_scaler_leg(ms, torch, ctx, nframes=256, fmt=None):
     """1080p I420 -> 720p, to RGB24 (BASELINE configs[4]) or to I420 (fmt=MI_PIX_I420: what MSSizeConv asks of the scaler,
-    sizeconv.c:97-184 -- libyuv ignores the destination format for I420 sources, msvideo.c:547-551)."""
+    sizeconv.c:97-184 -- libyuv ignores the destination format for I420 sources, msvideo.c:547-551).  256 frames per launch:
+    configs[4]'s 2048 concurrent 1080p streams over 8 GPUs, one frame of each per launch (a launch per 33 ms frame period)."""
     sw, sh, dw, dh = 1920, 1080, 1280, 720
     fmt = ms.MI_PIX_RGB24 if fmt is None else fmt
     sc = ms.ScalerBatch(ctx, sw, sh, dw, dh, fmt)
     per_step = nframes * (sc.src_bytes + sc.dst_bytes)
-    ring = 2  # 2 x 376 MB already exceeds the Infinity Cache
+    ring = 2  # 2 x 1.5 GB: far beyond the Infinity Cache
     rng = np.random.default_rng(0x5EED)
     yy, xx = np.mgrid[0:sh, 0:sw]
     y = (16 + 200 * (xx + yy) / (sw + sh)).astype(np.float32)
@@ -265,8 +266,8 @@ def make_scaler_leg(ms, torch, ctx, nframes=64, fmt=None):
         v = (128 + 100 * np.cos(2 * np.pi * np.arange(sh // 2) / (sh // 2) + f))[:, None].repeat(sw // 2, 1)
         frames.append(np.concatenate([yf.ravel(), u.clip(0, 255).astype(np.uint8).ravel(),
                                       v.clip(0, 255).astype(np.uint8).ravel()]))
-    host = np.stack([frames[i % 4] for i in range(nframes)])
-    ins = [torch.from_numpy(host).cuda() for _ in range(ring)]
+    four = torch.from_numpy(np.stack(frames)).cuda()
+    ins = [four[torch.arange(nframes, device="cuda") % 4].contiguous() for _ in range(ring)]
     outs = [torch.zeros((nframes, sc.dst_bytes), dtype=torch.uint8, device="cuda") for _ in range(ring)]
 
     def launch(i):
