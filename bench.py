@@ -1185,9 +1185,15 @@ def main():
                 break
             tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"]})
             head.close()
+            # the next count to try: the one whose median leaves room for this series' longest tick (a tick costs in
+            # proportion to the legs; what a machine event adds does not) -- rounded UP to the step, so the estimate can
+            # only be optimistic and the series at that count decides; never less than one step down
+            p50 = reduce_scalar(float(np.median(series)), "MAX")
+            room = int(streams * max(9.95 - (worst - p50), 1.0) / p50) // 2048 * 2048 + 2048
+            streams = min(streams - 2048 * (1 + attempt // 2), room)  # at least 2048, 2048, 4096, 4096, ... down
         else:
             tried.append({"streams": streams, "from_reset_worst_ms": zero["tick_ms_worst"]})
-        streams -= 2048 * (1 + attempt // 2)  # 2048, 2048, 4096, 4096, ...: a late exchange must not end in "does not fit"
+            streams -= 2048 * (1 + attempt // 2)
         streams = max(streams, 8192)
     rig = head.rig
     median_single = float(np.median(series))
