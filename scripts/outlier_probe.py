@@ -46,3 +46,29 @@ for rep in range(2):
     v = head.tick_series(nt)
     top = np.argsort(v)[-8:][::-1]
     print(json.dumps({"rep": f"as the bench {rep}", **bench.series_stats(v), "top": [(int(i), round(float(v[i]), 3)) for i in top]}), flush=True)
+
+# Where is the host when a long tick happens?  The bench's loop again with wall-clock stamps: for the longest ticks, the
+# GPU time, the wall time of the same iteration and the host's gap before it (the GPU idles for that long); then the
+# same with Python's garbage collector off.
+import gc
+for label in ("gc on", "gc off"):
+    if label == "gc off":
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+    v = np.empty(nt)
+    ta = np.empty(nt)
+    tb = np.empty(nt)
+    for t in range(nt):
+        ta[t] = time.perf_counter()
+        ctx.timer_start()
+        head.g1[t % len(head.g1)].launch()
+        v[t] = ctx.timer_stop()
+        tb[t] = time.perf_counter()
+    gap = np.concatenate([[0.0], (ta[1:] - tb[:-1]) * 1e3])
+    wall = (tb - ta) * 1e3
+    top = np.argsort(v)[-6:][::-1]
+    print(json.dumps({"rep": label, **bench.series_stats(v), "gap_ms_p50": round(float(np.median(gap)), 4), "gap_ms_max": round(float(gap.max()), 3),
+                      "gap_argmax": int(gap.argmax()), "wall_minus_gpu_p50": round(float(np.median(wall - v)), 4),
+                      "top": [{"i": int(i), "gpu": round(float(v[i]), 3), "wall": round(float(wall[i]), 3), "gap_before": round(float(gap[i]), 3),
+                               "gap_before_prev": round(float(gap[i - 1]), 3) if i else None} for i in top]}), flush=True)
