@@ -463,6 +463,16 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	const bool postfilter = (a.flags & 1) != 0; // MI_AEC_POSTFILTER
 	float leakf[2] = {sc.leak_estimate, sc.leak_estimate}; // leak estimate after each frame (post-filter input)
 	bool resetf[2] = {false, false};                       // the frame reset the canceller: its echo estimate is zero
+	// Frame 1 of a two-frame tick does not write its updated background: frame 2's pass reads W0(j) again and redoes frame
+	// 1's gradient step on it (same operands, same operations: the same bits) before its own -- a block read and a few
+	// multiply-adds instead of a block written and read (a written byte costs the memory system 1.75 read ones).  What
+	// frame 1 still writes: the blocks it constrained (0 and jc) and the last one, whose far-end block leaves the ring.
+	bool lazy1 = false;
+	int jc1 = -1;
+	float2 E1s[K];
+	float p1s[K], p1s_F = 0.f;
+#pragma unroll
+	for (int k = 0; k < K; ++k) E1s[k] = make_float2(0, 0), p1s[k] = 0.f;
 
 	for (int f = 0; f < nf; ++f) {
 		// Frame 2's first blocks are asked for NOW (frame 1's pass wrote them long ago): the notch and the proportional step
@@ -546,20 +556,21 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		if (!do_grad) sc.saturated--;
 
 		// W += prop p1 conj(X) E, bin by bin (weighted_spectral_mul_conj); bin 0 = (DC, Nyquist): real products with their own steps
-		auto grad = [&](auto (&w)[K], const auto (&x)[K], float prop) {
+		auto grad_with = [&](auto (&w)[K], const auto (&x)[K], float prop, const float2 (&E)[K], const float (&pp)[K], float pp_F) {
 #pragma unroll
 			for (int k = 0; k < K; ++k) {
-				const v2f xv = {x[k].x, x[k].y}, ev = {Eprev[k].x, Eprev[k].y};
-				const float Wt = prop * p1[k];
+				const v2f xv = {x[k].x, x[k].y}, ev = {E[k].x, E[k].y};
+				const float Wt = prop * pp[k];
 				v2f st = pk_cmul_conj(xv, ev) * (v2f){Wt, Wt}; // Wt (x.x E.x + x.y E.y), Wt ((-x.y) E.x + x.x E.y)
 				if (k == 0) {
-					const v2f dc = (xv * ev) * (v2f){Wt, prop * p1_F}; // W0 (x.x E.x), WN (x.y E.y)
+					const v2f dc = (xv * ev) * (v2f){Wt, prop * pp_F}; // W0 (x.x E.x), WN (x.y E.y)
 					if (e0 == 0) st = dc;
 				}
 				const v2f r = (v2f){w[k].x, w[k].y} + st;
 				w[k].x = r.x, w[k].y = r.y;
 			}
 		};
+		auto grad = [&](auto (&w)[K], const auto (&x)[K], float prop) { grad_with(w, x, prop, Eprev, p1, p1_F); };
 
 		// ---- one streaming pass over the blocks (next block's loads in flight).  Block 0 and the round-robin block jc get
 		// the AUMDF constraint (IFFT, zero the second half, FFT) where the pass meets them: the blocks are independent of each
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			const bool carryFG = pendingFG, carryBG = pendingBG;
 			pendingFG = pendingBG = false;
 			const unsigned fsrc = carryFG ? wo : fo, wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
+			const bool lazy = spec && do_grad && !carryBG && !carryFG && M <= 32; // (the block weights wait in L.prop[32..])
 			bload_bins<K>(rX, vb8, xoff(1), xn);
 			bload_bins<K>(rWF, vb8, fsrc, fg);
 			bload_bins<K>(rWF, vb8, wsrc, wl);
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(wl, xn, L.prop[j]);
 				if (aumdf) constrain(wl);
-				if (do_grad || aumdf || carryBG || carryFG) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), wl);
+				if (lazy ? (aumdf || j == M - 1) : (do_grad || aumdf || carryBG || carryFG)) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), wl);
 				cmac_bins<K>(yfg, xj, fg, e0);
 				cmac_bins<K>(ybgs, xj, wl, e0);
 				if (spec) cmac_bins<K>(spec2, xm1, fg, e0);
@@ -627,6 +639,16 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 				const unsigned t = wo;
 				wo = fo, fo = t;
 				sc.wsel ^= 1;
+			}
+			if (lazy) { // what frame 2's pass needs to redo this frame's step: the error spectrum, the steps, the block weights
+				lazy1 = true;
+				jc1 = jc;
+				p1s_F = p1_F;
+#pragma unroll
+				for (int k = 0; k < K; ++k) E1s[k] = Eprev[k], p1s[k] = p1[k];
+				WSYNC();
+				if (lane < M) L.prop[32 + lane] = L.prop[lane];
+				WSYNC();
 			}
 		} else {
 			// frame 2: X and the background only.  alt = sum_j X(j) W1(j) with W1 the background as frame 1 left it: the
@@ -647,12 +669,18 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			const unsigned wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
 #pragma unroll
 			for (int k = 0; k < K; ++k) xn[k] = pre0[k], xn2[k] = pre1[k], wl[k] = pre2[k], wl2[k] = pre3[k];
-			auto block = [&](int j, v2f (&w)[K], const v2f (&xa)[K], const v2f (&xb)[K]) { // xa = X(j), xb = X(j+1)
+			const bool redo = lazy1 && !carryBG; // frame 1 left its updated blocks unwritten (all but 0, jc1 and the last)
+			const bool keepW1 = redo && carryFG;  // ... and then made them the foreground: they must exist in that half
+			auto block = [&](int j, v2f (&w)[K], const v2f (&xa)[K], const v2f (&xb)[K], const v2f (&xc)[K]) { // X(j), X(j+1), X(j+2)
+				if (redo && j != 0 && j != jc1 && j != M - 1) {
+					grad_with(w, xc, L.prop[32 + j], E1s, p1s, p1s_F);
+					if (keepW1) bstore_bins<K>(rWF, vb8, wo + (unsigned)j * (F * 8), w);
+				}
 				cmac_bins<K>(alt, xa, w, e0);
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(w, xb, L.prop[j]);
 				if (aumdf) constrain(w);
-				if (do_grad || aumdf || carryBG || carryFG) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), w);
+				if (do_grad || aumdf || carryBG || carryFG || lazy1) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), w);
 				cmac_bins<K>(ybgs, xa, w, e0);
 				norm_of(w, j);
 			};
@@ -662,14 +690,15 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 				bload_bins<K>(rX, vb8, xclamp(j + 4), xb);
 				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 2), wa);
 				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 3), wb);
-				block(j, wl, xj, xn);
-				if (j + 1 < M) block(j + 1, wl2, xn, xn2);
+				block(j, wl, xj, xn, xn2);
+				if (j + 1 < M) block(j + 1, wl2, xn, xn2, xa);
 #pragma unroll
 				for (int k = 0; k < K; ++k) xj[k] = xn2[k], xn[k] = xa[k], xn2[k] = xb[k], wl[k] = wa[k], wl2[k] = wb[k];
 			}
 #pragma unroll
 			for (int k = 0; k < K; ++k) yfg[k] = carryFG ? alt[k] : spec2[k];
 			pendingFG = false;
+			lazy1 = false;
 			if (carryFG) {
 				const unsigned t = wo;
 				wo = fo, fo = t;
@@ -822,6 +851,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 				Eprev[k] = make_float2(0, 0);
 				spec2[k] = make_float2(0, 0);
 			}
+			lazy1 = false; // both halves are zero in HBM: nothing of frame 1's step is left to redo
 			store_vec<K>(L.pw + e0, z);
 			store_vec<K>(L.eh + e0, z);
 			store_vec<K>(L.yh + e0, z);

@@ -284,6 +284,11 @@ def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
     far[4, 121] = np.where(np.arange(F) % 2 == 0, 32767, -32767)  # (odd position: the reset falls on the other frame of its ticks)
     pos = np.zeros(n, int)
     M = (flen + F - 1) // F
+    # which frame of a two-frame tick the library's filter copies fall on (read off the frame-by-frame canceller): frame 1
+    # of such a tick leaves its updated background unwritten for frame 2's pass to redo, so a copy decided by frame 1
+    # (foreground := that background, or background := foreground) is the case to see
+    first_frame = {"fg_updates": 0, "bg_resets": 0}
+    last = np.stack([a_ref.get(s, "counters", 4) for s in range(n)])
     for t in range(nticks):
         cnt = rng.integers(0, 3, n).astype(np.uint8)
         cnt[0] = 2  # one stream always runs two frames
@@ -308,6 +313,11 @@ def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
             a_ref.process(mk, fk, out=ok, run=run)
             ctx.sync()
             out_r[:, k * F:(k + 1) * F] = torch.where(run[:, None].bool(), ok, out_r[:, k * F:(k + 1) * F])
+            now = np.stack([a_ref.get(s, "counters", 4) for s in range(n)])
+            if k == 0:
+                first_frame["fg_updates"] += int(((now[:, 0] > last[:, 0]) & (cnt == 2)).sum())
+                first_frame["bg_resets"] += int(((now[:, 1] > last[:, 1]) & (cnt == 2)).sum())
+            last = now
         ctx.sync()
         torch.cuda.synchronize()
         got, ref = out_t.cpu().numpy(), out_r.cpu().numpy()
@@ -323,5 +333,6 @@ def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
                     assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"tick {t} stream {s}: {what}"
     adapted = [a_tick.get(s, "scalars", 16)[8] for s in range(n)]
     assert any(v == 1.0 for v in adapted), "the scene should take at least one stream through adaptation"
+    assert first_frame["fg_updates"] >= 1, f"no foreground update fell on the first frame of a two-frame tick: {first_frame}"
     a_tick.close()
     a_ref.close()
