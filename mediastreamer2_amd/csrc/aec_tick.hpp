@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		// spectra of both frames and the speculation accumulators live, the 24 registers spill; measured, no gain.)
 		const int head = (sc.xhead + M) % (M + 1);
 		auto xoff = [&](int j) { return (unsigned)((head + j) % (M + 1)) * (unsigned)(F * 8); };
-		v2f pre0[K], pre1[K], pre2[K], pre3[K];
+		v2f pre0[K], pre1[K], pre2[K], pre3[K]; // frame 2's pass takes them over as its first far-end and background blocks
 		if (f == 0) {
 #pragma unroll
 			for (int k = 0; k < K; ++k) pre0[k] = pre1[k] = pre2[k] = pre3[k] = (v2f){0.f, 0.f};
@@ -616,13 +616,11 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			bload_bins<K>(rWF, vb8, wsrc, wl);
 			for (int j = 0; j < M; ++j) {
 				v2f xn2[K], fg2[K], wl2[K];
-				if (j + 1 < M) {
-					bload_bins<K>(rX, vb8, xoff(j + 2), xn2);
-					bload_bins<K>(rWF, vb8, fsrc + (unsigned)(j + 1) * (F * 8), fg2);
-					bload_bins<K>(rWF, vb8, wsrc + (unsigned)(j + 1) * (F * 8), wl2);
-				} else {
-#pragma unroll
-					for (int k = 0; k < K; ++k) xn2[k] = xn[k], fg2[k] = fg[k], wl2[k] = wl[k];
+				{ // (behind the last block: its own again, dropped)
+					const int jn = j + 1 < M ? j + 1 : j;
+					bload_bins<K>(rX, vb8, xoff(jn + 1), xn2);
+					bload_bins<K>(rWF, vb8, fsrc + (unsigned)jn * (F * 8), fg2);
+					bload_bins<K>(rWF, vb8, wsrc + (unsigned)jn * (F * 8), wl2);
 				}
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(wl, xn, L.prop[j]);
@@ -658,17 +656,23 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			// counter and may complete out of order with each other, so with a store in flight the only wait is vmcnt(0)), a
 			// full memory round trip that the iteration's arithmetic does not cover.  This pass has no foreground blocks in
 			// flight, so it has the registers to take the blocks in pairs: half as many round trips.
-			float2 alt[K];
-			v2f xj[K], xn[K], xn2[K], wl[K], wl2[K]; // register pairs: a bin moves with one instruction
+			v2f xj[K], xn3[K]; // register pairs: a bin moves with one instruction
+			v2f(&xn)[K] = pre0, (&xn2)[K] = pre1, (&wl)[K] = pre2, (&wl2)[K] = pre3;
 #pragma unroll
-			for (int k = 0; k < K; ++k) xj[k] = (v2f){X0[k].x, X0[k].y}, alt[k] = make_float2(0, 0);
+			for (int k = 0; k < K; ++k) xj[k] = (v2f){X0[k].x, X0[k].y};
 			auto xclamp = [&](int i) { return xoff(i < M ? i : M); };
 			auto wclamp = [&](int i) { return (unsigned)(i < M ? i : M - 1) * (unsigned)(F * 8); };
 			const bool carryBG = pendingBG, carryFG = pendingFG; // frame 1 reset the background / updated the foreground
 			pendingBG = false;
-			const unsigned wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
+			if (carryFG) { // the speculated foreground response is void: its registers take alt
 #pragma unroll
-			for (int k = 0; k < K; ++k) xn[k] = pre0[k], xn2[k] = pre1[k], wl[k] = pre2[k], wl2[k] = pre3[k];
+				for (int k = 0; k < K; ++k) spec2[k] = make_float2(0, 0);
+			}
+			const unsigned wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
+			// a block's redo needs the far-end block two places on: four landed far-end blocks per pair, the next two in flight.
+			// The fourth of the first pair is waited for HERE, once, so that no iteration waits in its middle.
+			bload_bins<K>(rX, vb8, xclamp(3), xn3);
+			__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 			const bool redo = lazy1 && !carryBG; // frame 1 left its updated blocks unwritten (all but 0, jc1 and the last)
 			const bool keepW1 = redo && carryFG;  // ... and then made them the foreground: they must exist in that half
 			auto block = [&](int j, v2f (&w)[K], const v2f (&xa)[K], const v2f (&xb)[K], const v2f (&xc)[K]) { // X(j), X(j+1), X(j+2)
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 					grad_with(w, xc, L.prop[32 + j], E1s, p1s, p1s_F);
 					if (keepW1) bstore_bins<K>(rWF, vb8, wo + (unsigned)j * (F * 8), w);
 				}
-				cmac_bins<K>(alt, xa, w, e0);
+				if (carryFG) cmac_bins<K>(spec2, xa, w, e0);
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(w, xb, L.prop[j]);
 				if (aumdf) constrain(w);
@@ -686,17 +690,17 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			};
 			for (int j = 0; j < M; j += 2) { // an odd block count: the last round serves one block (no third copy of `block` in the code)
 				v2f xa[K], xb[K], wa[K], wb[K]; // the next pair: X(j+3), X(j+4), W(j+2), W(j+3) (clamped at the end: dropped)
-				bload_bins<K>(rX, vb8, xclamp(j + 3), xa);
-				bload_bins<K>(rX, vb8, xclamp(j + 4), xb);
+				bload_bins<K>(rX, vb8, xclamp(j + 4), xa);
+				bload_bins<K>(rX, vb8, xclamp(j + 5), xb);
 				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 2), wa);
 				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 3), wb);
 				block(j, wl, xj, xn, xn2);
-				if (j + 1 < M) block(j + 1, wl2, xn, xn2, xa);
+				if (j + 1 < M) block(j + 1, wl2, xn, xn2, xn3);
 #pragma unroll
-				for (int k = 0; k < K; ++k) xj[k] = xn2[k], xn[k] = xa[k], xn2[k] = xb[k], wl[k] = wa[k], wl2[k] = wb[k];
+				for (int k = 0; k < K; ++k) xj[k] = xn2[k], xn[k] = xn3[k], xn2[k] = xa[k], xn3[k] = xb[k], wl[k] = wa[k], wl2[k] = wb[k];
 			}
 #pragma unroll
-			for (int k = 0; k < K; ++k) yfg[k] = carryFG ? alt[k] : spec2[k];
+			for (int k = 0; k < K; ++k) yfg[k] = spec2[k];
 			pendingFG = false;
 			lazy1 = false;
 			if (carryFG) {
