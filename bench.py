@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="the timed region is at least this long, whatever --steps says")
     ap.add_argument("--worst-ticks", type=int, default=3000, help="consecutive single ticks the worst tick is taken over")
     ap.add_argument("--zero-ticks", type=int, default=256, help="ticks of the from-reset test at the chosen count (0 = skip)")
+    ap.add_argument("--paced-ticks", type=int, default=1000, help="ticks of the series run at the 10 ms cadence of an MSTicker (reported, not `value`; 0 = skip)")
     ap.add_argument("--roofline-ticks", type=int, default=32, help="eager ticks with HIP events around the canceller's launch")
     ap.add_argument("--from-reset", action="store_true", help="measure cancellers that start from reset instead of steady state")
     ap.add_argument("--no-session", action="store_true", help="skip the PCIe-inclusive mi_session probes")
@@ -1346,6 +1347,24 @@ def main():
         r["mfma"] = ("not used: the one candidate, the scaler's 3x3 BT.601 colour matrix, is 9 integer MACs per pixel inside a "
                      "byte-streaming kernel at ~80 % of the measured copy ceiling; v_mfma_f32_16x16x4 would use 3 of 16 columns")
         line["roofline"] = r
+        if world == 1 and a.paced_ticks > 0 and hasattr(head, "g1") and PLATFORM.device != "cpu":
+            # the same ticks at an MSTicker's cadence -- one per 10 ms of wall time, the GPU idle for the rest of each
+            # interval -- reported beside the back-to-back series, not part of `value`: the idle gaps let the clocks
+            # drop (scripts/throttle_probe.sh: +0.2-0.3 ms per tick) and the device averages less power
+            try:
+                v = np.empty(a.paced_ticks)
+                nxt = time.perf_counter()
+                for t in range(a.paced_ticks):
+                    while time.perf_counter() < nxt:
+                        pass
+                    nxt += 0.010
+                    ctx.timer_start()
+                    head.g1[t % len(head.g1)].launch()
+                    v[t] = ctx.timer_stop()
+                line["config"]["paced_ticks"] = dict(series_stats(v), cadence_ms=10,
+                                                     note="one tick per 10 ms of wall time (not `value`: that is the back-to-back series)")
+            except Exception as e:
+                line["config"]["paced_ticks"] = {"error": str(e)[:200]}
     head.close()
     if converged is not None:
         converged.close()
