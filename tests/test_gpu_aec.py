@@ -262,7 +262,7 @@ def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
         x.close()
 
 
-@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 64)])
+@pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 64), (48000, 256, 200)])  # (200 ms: 38 blocks -- more than the 32 whose weights the redo has LDS for: frame 1 writes as it always did)
 def test_tick_form_equals_frame_by_frame(ctx, rate, F, tail_ms):
     """mi_aec_process_frames (all the frames of a tick in ONE launch: per-stream state in registers across them, the
     foreground filter streamed once, the foreground update carried out by the second frame's pass) == the same frames
