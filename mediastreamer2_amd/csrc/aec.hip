@@ -557,7 +557,7 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 		a->cap8 = (nstreams + 7) / 8 + TickOrder::SLACK;
 		std::vector<int> ord((size_t)2 * 8 * a->cap8, 0), ctl(TickOrder::WORDS, 0);
 		for (int s = 0; s < nstreams; ++s) ord[(size_t)(s & 7) * a->cap8 + (size_t)(s >> 3)] = s;
-		for (int c = 0; c < 8; ++c) ctl[(size_t)c * TickOrder::STRIDE + TickOrder::LEN] = (nstreams - c + 7) / 8; // parity 0: front = all, back = 0
+		for (int c = 0; c < 8; ++c) ctl[(size_t)c * TickOrder::STRIDE + TickOrder::PLACED] = (nstreams - c + 7) / 8; // parity 0: front = all, back = 0
 		if (hipMalloc((void **)&a->d_order, ord.size() * sizeof(int)) != hipSuccess || hipMalloc((void **)&a->d_ctl, ctl.size() * sizeof(int)) != hipSuccess ||
 		    hipMemcpy(a->d_order, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(a->d_ctl, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
@@ -677,6 +677,10 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	else if (a->F == 128) hipLaunchKernelGGL(aec_tick_kernel<128>, grid, dim3(64), 0, a->ctx->stream, g);
 	else hipLaunchKernelGGL(aec_tick_kernel<64>, grid, dim3(64), 0, a->ctx->stream, g);
 	MI_LAUNCH_CHECK();
+	if (fifo) { // the leg lists this launch filled become the ones the next launch serves (aec_tick.hpp: TickOrder)
+		hipLaunchKernelGGL(aec_tick_advance_kernel, dim3(1), dim3(64), 0, a->ctx->stream, a->d_ctl);
+		MI_LAUNCH_CHECK();
+	}
 	return MI_OK;
 }
 
@@ -859,7 +863,7 @@ int mi_aec_get(mi_aec *a, int stream, const char *what, float *h_dst, int cap) {
 		// class after class: the entries from the front, then those from the back, each class closed by a -1
 		const size_t par = (size_t)ctl[TickOrder::GLOBAL + TickOrder::PARITY];
 		for (int c = 0; c < 8; ++c) {
-			const int front = ctl[(size_t)c * TickOrder::STRIDE + TickOrder::LEN + 2 * par], back = ctl[(size_t)c * TickOrder::STRIDE + TickOrder::LEN + 2 * par + 1];
+			const int front = ctl[(size_t)c * TickOrder::STRIDE + TickOrder::PLACED + 2 * par], back = ctl[(size_t)c * TickOrder::STRIDE + TickOrder::PLACED + 2 * par + 1];
 			for (int i = 0; i < front; ++i) res.push_back((float)ord[(par * 8 + (size_t)c) * a->cap8 + (size_t)i]);
 			for (int i = a->cap8 - back; i < a->cap8; ++i) res.push_back((float)ord[(par * 8 + (size_t)c) * a->cap8 + (size_t)i]);
 			res.push_back(-1.f);

@@ -156,18 +156,32 @@ __device__ __forceinline__ void cmac_bins(TA (&acc)[K], const TX (&x)[K], const 
 }
 
 // words of AecArgs::ctl (the list hand-over between consecutive launches of the FIFO entry)
-// Eight lists (classes), one per XCD (workgroup b runs on XCD b % 8).  A list has room for cap8 entries: legs that will run
+// Eight lists (classes), one per XCD (workgroup b runs on XCD b % 8), in two sets: the set of parity p is served by this
+// launch, the set of parity p ^ 1 is filled by it for the next one.  A list has room for cap8 entries: legs that will run
 // two frames are entered from the front, the others from the back, the slots in between stay empty (their workgroups leave
 // at once).  Every class has its own 128-byte line of control words (the atomics of different classes do not queue up behind
 // each other) and a ninth line is shared:
-//   PLACED  64 bits: entries placed into this class's NEXT list so far, front | back << 32
-//   DONE    legs of this class's CURRENT list that have entered themselves into a next list
-//   LEN     [parity][front, back]: how many entries the list of that parity holds
-//   global line: PARITY (which set of lists this launch serves), CLASSES (classes whose legs are all done)
+//   PLACED  [parity] 64 bits: entries of this class's list of that parity, front | back << 32 -- counted up by the atomics of
+//           the launch that fills the list, read as the list's lengths by the launch that serves it
+//   global line: PARITY (which set of lists the next launch serves)
+// Nothing inside a launch depends on another workgroup's progress: a launch only READS the parity and its own set's lengths
+// and only ADDS to the other set's.  The turn-over -- the served set's counts back to zero, the parity flipped -- is a
+// launch of its own right behind (aec_tick_advance_kernel: one wavefront, stream order does the rest).  (Rounds 2-3 had the
+// last wave of the tick kernel do it, found through per-class completion counts: a class whose list was empty never
+// completed -- batches of fewer than 8 legs froze on their first lists, and the counts grew past the lists -- and workgroups
+// on empty slots read words the turn-over might already have rewritten.)
 struct TickOrder {
-	static constexpr int STRIDE = 32, PLACED = 0, DONE = 2, LEN = 4, GLOBAL = 8 * STRIDE, PARITY = 0, CLASSES = 1, WORDS = 9 * STRIDE;
-	static constexpr int SLACK = 32; // a class's share of the legs wanders by a few around nstreams / 8 (see the mixing rule below)
+	static constexpr int STRIDE = 32, PLACED = 0, GLOBAL = 8 * STRIDE, PARITY = 0, WORDS = 9 * STRIDE;
+	// a class's share of the legs wanders by fewer than 16 around nstreams / 8 (the mixing rule below deals every list out
+	// over all eight: sixteen roundings of an eighth of a front or back run), whatever the history
+	static constexpr int SLACK = 32;
 };
+
+__global__ __launch_bounds__(64) void aec_tick_advance_kernel(int *ctl) {
+	const int par = ctl[TickOrder::GLOBAL + TickOrder::PARITY];
+	if (threadIdx.x < 8) *reinterpret_cast<unsigned long long *>(ctl + threadIdx.x * TickOrder::STRIDE + TickOrder::PLACED + 2 * par) = 0ull;
+	if (threadIdx.x == 0) ctl[TickOrder::GLOBAL + TickOrder::PARITY] = par ^ 1;
+}
 
 template <int F>
 __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
@@ -179,13 +193,12 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	// list per class b % 8: every XCD gets the same mix whatever pattern the legs' phases follow, and the long legs are
 	// started first.
 	const bool sched = a.order != nullptr;
-	int s = a.first + blockIdx.x, par = 0, own_len = 0;
+	int s = a.first + blockIdx.x, par = 0;
 	if (sched) {
 		const unsigned c = blockIdx.x & 7u, i = blockIdx.x >> 3;
 		par = a.ctl[TickOrder::GLOBAL + TickOrder::PARITY];
-		const int front = a.ctl[c * TickOrder::STRIDE + TickOrder::LEN + 2 * par], back = a.ctl[c * TickOrder::STRIDE + TickOrder::LEN + 2 * par + 1];
+		const int front = a.ctl[c * TickOrder::STRIDE + TickOrder::PLACED + 2 * par], back = a.ctl[c * TickOrder::STRIDE + TickOrder::PLACED + 2 * par + 1];
 		if (i >= (unsigned)front && i < (unsigned)(a.cap8 - back)) return; // an empty slot between the two ends of the list
-		own_len = front + back;
 		s = a.order[(size_t)par * 8 * a.cap8 + c * a.cap8 + i];
 	}
 	const int lane = threadIdx.x;
@@ -294,36 +307,17 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			// (c + i) % 8 for the leg at position i of class c -- a class's legs are dealt out over all eight classes every
 			// tick, so legs that share a phase cannot stay together on one XCD however the slots were arranged (phase =
 			// slot % 8 kept every tick's light legs on ONE XCD with per-class lists that never mixed: +4 % on the launch), and
-			// every class keeps nstreams / 8 legs give or take a few.  Front of the list for two frames, back for fewer: one
-			// 64-bit atomic on the destination class's line; then one on the source class's line to say this leg is done.
-			// The wave that completes the last class (every leg has read `par`, its list's length and its entry before it got
-			// here: s, and through it the level, depend on them) publishes the new lengths and turns the lists over.
+			// every class keeps nstreams / 8 legs give or take fewer than 16.  Front of the list for two frames, back for
+			// fewer: one 64-bit atomic on the destination class's line.
 			const int keep = qm.y + (mic_new ? a.tick_len : 0) - nf * F;
 			int next = (keep + a.tick_len) / F;
 			if (next > a.max_frames) next = a.max_frames;
 			const unsigned c = blockIdx.x & 7u, i = blockIdx.x >> 3, d = (c + i) & 7u;
 			int *dst = a.order + (size_t)(par ^ 1) * 8 * a.cap8 + d * a.cap8;
-			unsigned long long *placed = reinterpret_cast<unsigned long long *>(a.ctl + d * TickOrder::STRIDE + TickOrder::PLACED);
+			unsigned long long *placed = reinterpret_cast<unsigned long long *>(a.ctl + d * TickOrder::STRIDE + TickOrder::PLACED + 2 * (par ^ 1));
 			const unsigned long long old = atomicAdd(placed, next >= 2 ? 1ull : (1ull << 32));
-			const unsigned front = (unsigned)old, back = (unsigned)(old >> 32);
-			dst[next >= 2 ? front : (unsigned)a.cap8 - 1u - back] = s;
-			// the second atomic only after the first has been performed (it has, once its value is back).  Not a
-			// __threadfence(): that writes back and invalidates caches -- per wave it doubled the launch time
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (atomicAdd(&a.ctl[c * TickOrder::STRIDE + TickOrder::DONE], 1) == own_len - 1 &&
-			    atomicAdd(&a.ctl[TickOrder::GLOBAL + TickOrder::CLASSES], 1) == 7) {
-#pragma nounroll
-				for (int k = 0; k < 8; ++k) {
-					int *cl = a.ctl + k * TickOrder::STRIDE;
-					const unsigned long long p = atomicAdd(reinterpret_cast<unsigned long long *>(cl + TickOrder::PLACED), 0ull); // (read where the atomics are performed)
-					cl[TickOrder::LEN + 2 * (par ^ 1)] = (int)(unsigned)p;
-					cl[TickOrder::LEN + 2 * (par ^ 1) + 1] = (int)(unsigned)(p >> 32);
-					*reinterpret_cast<unsigned long long *>(cl + TickOrder::PLACED) = 0ull;
-					cl[TickOrder::DONE] = 0;
-				}
-				a.ctl[TickOrder::GLOBAL + TickOrder::CLASSES] = 0;
-				a.ctl[TickOrder::GLOBAL + TickOrder::PARITY] = par ^ 1;
-			}
+			const unsigned at = next >= 2 ? (unsigned)old : (unsigned)a.cap8 - 1u - (unsigned)(old >> 32);
+			if (at < (unsigned)a.cap8) dst[at] = s; // (it always is: the bound at TickOrder::SLACK)
 		}
 		if (lane == 0) {
 			if (a.count_out) a.count_out[s] = (uint8_t)nf;

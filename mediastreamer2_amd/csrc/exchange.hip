@@ -9,10 +9,13 @@
 // one of them travels by whatever means the host has (shared memory, a socket, torch's store in bench.py).
 //
 // librccl is opened on first use (dlopen): a host that never splits a conference does not load it, and a box without
-// it still runs everything else.  Failure is loud: every entry point returns MI_ENODEV with RCCL's own message.
+// the LIBRARY still runs everything else (the header rccl/rccl.h is needed to build: the types are RCCL's).  Failure is
+// loud: every entry point returns MI_ENODEV with RCCL's -- or the loader's -- own message.
 #include "common.hpp"
 
 #include <dlfcn.h>
+#include <mutex>
+#include <string>
 #include <rccl/rccl.h>
 
 namespace {
@@ -25,6 +28,7 @@ struct Rccl {
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
 	bool ok = false;
+	std::string why; // the loader's message, captured where dlopen failed (dlerror() is per thread and cleared by reading)
 };
 
 Rccl &rccl() {
@@ -36,6 +40,7 @@ Rccl &rccl() {
 			if (!name || !*name) continue;
 			r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
 			if (r.lib) break;
+			if (const char *e = dlerror()) r.why += (r.why.empty() ? "" : "; ") + std::string(e);
 		}
 		if (!r.lib) return;
 		r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
@@ -44,12 +49,13 @@ Rccl &rccl() {
 		r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
 		r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
 		r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+		if (!r.ok) r.why = "an ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / GetErrorString symbol is missing";
 	});
 	return r;
 }
 
 int rccl_missing() {
-	mi::set_error("librccl could not be loaded (%s): the cross-GPU conference exchange is unavailable", dlerror() ? dlerror() : "symbols missing");
+	mi::set_error("librccl could not be loaded (%s): the cross-GPU conference exchange is unavailable", rccl().why.c_str());
 	return MI_ENODEV;
 }
 

@@ -190,7 +190,10 @@ void parse_devices() {
 			if (*end != ',' ) break;
 		}
 	} else if (one && *one) {
-		g_devices.push_back(atoi(one));
+		char *end = nullptr;
+		const long v = strtol(one, &end, 10);
+		if (end != one && v >= 0 && v < 64) g_devices.push_back((int)v); // same bound as the list: g_device_hubs[64]
+		else ms_error("msmi355x plugin: MSMI355X_DEVICE=%s is not a device index (0..63); using every visible device", one);
 	}
 	if (g_devices.empty()) {
 		const int n = mi_device_count();

@@ -752,6 +752,54 @@ def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
     assert outs[0].any()
 
 
+@pytest.mark.parametrize("n", [1, 4, 9, 12, 20])
+def test_small_batches_keep_their_leg_lists_over_thousands_of_ticks(ctx, n):
+    """Batches whose eight leg lists are not all populated -- fewer than 8 legs, or classes the dealing empties for a tick
+    (n = 9, 12, 20 with the product's stagger) -- must turn their lists over like any other: round 3's hand-over waited for
+    every class to complete and an empty class never did (the lists froze on tick 0 and the placement counts grew past them
+    after ~190 ticks).  2 200 ticks: every probe finds each leg exactly once in the lists, every leg was served once per
+    tick (its frame counter is what its queue level implies), and the ticks' outputs equal those of the same legs inside a
+    LARGER batch (whose lists are populated)."""
+    torch = pytest.importorskip("torch")
+    rate, F, ns, nticks = 48000, 256, 480, 2200
+    flen = 16 * rate // 1000
+    big = 64
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    gen = torch.Generator(device="cpu").manual_seed(1234 + n)
+    block = (torch.randn((8, 2, big, ns), generator=gen) * 2500).round().clamp(-32767, 32767).to(torch.int16).cuda()   # 8 ticks, cycled
+    rigs = []
+    for m in (n, big):
+        a = ms.AecBatch(ctx, m, rate, frame_size=F, filter_length=flen)
+        fm, fr, fo = (ms.FifoBatch(ctx, m, 1792) for _ in range(3))
+        a.stagger_fifos(fm, fr, ns)
+        rigs.append((a, fm, fr, fo, z(m, ns), z(m, dt=torch.int32)))
+    # leg s of the small batch must see the lead leg s of the big one has: the phases depend on the slot only
+    torch.cuda.synchronize()
+    for t in range(nticks):
+        outs = []
+        for (a, fm, fr, fo, tick, lv), m in zip(rigs, (n, big)):
+            dm, dr = block[t % 8, 0, :m], block[t % 8, 1, :m]
+            a.process_fifos(fm, dm, fr, dr, fo, tick_len=ns, max_frames=2)
+            fo.pop(ns, tick, zero_fill=True)
+            outs.append(tick)
+        if t % 97 == 0 or t >= nticks - 3:
+            ctx.sync()
+            np.testing.assert_array_equal(outs[0].cpu().numpy(), outs[1].cpu().numpy()[:n], err_msg=f"tick {t}")
+            a = rigs[0][0]
+            order = a.get(0, "order", n + 8).astype(int)
+            assert sorted(int(v) for v in order if v >= 0) == list(range(n)) and (order < 0).sum() == 8, (t, order)
+    a, fm, fr, fo, tick, lv = rigs[0]
+    fm.levels(lv)
+    ctx.sync()
+    lead = [32 * ctx.L.mi_fifo_phase_of(s, 8) for s in range(n)]
+    for s in range(n):
+        assert int(a.get(s, "counters", 4)[3]) == (lead[s] + nticks * ns - int(lv[s])) // F, s
+    assert fm.overflows() + fr.overflows() + fo.overflows() == 0
+    for rig_ in rigs:
+        for o in rig_[:4]:
+            o.close()
+
+
 def test_canceller_state_copied_on_the_device_continues_bit_for_bit(ctx):
     """mi_aec_copy_state: a batch seeded from another one's converged legs continues exactly as they do."""
     rate, F, n = 16000, 128, 6
