@@ -70,6 +70,9 @@ typedef struct _queue {
 } queue_t;
 
 mblk_t *allocb(size_t size, int unused);
+/* ortp/str_utils.h: a block whose payload is the CALLER'S buffer; freefn(buf) runs when the last reference goes (the
+ * reference's capture filters hand mmap'd frames downstream this way: src/videofilters/msv4l2.c:521, msv4l.c:191) */
+mblk_t *esballoc(uint8_t *buf, size_t size, int pri, void (*freefn)(void *));
 void freemsg(mblk_t *m);
 void freeb(mblk_t *m);
 mblk_t *dupb(mblk_t *m);

@@ -88,7 +88,7 @@ int mi_ctx_props(mi_ctx *ctx, int *cu_count, size_t *hbm_bytes, char *name, int 
 void *mi_dev_alloc(mi_ctx *ctx, size_t bytes);   /* NULL on failure */
 void mi_dev_free(mi_ctx *ctx, void *d_ptr);
 void *mi_host_alloc(mi_ctx *ctx, size_t bytes);  /* pinned host memory */
-void mi_host_free(mi_ctx *ctx, void *h_ptr);
+void mi_host_free(mi_ctx *ctx, void *h_ptr);    /* ctx may be NULL (a buffer that outlived its context: blocks still held downstream) */
 int mi_copy_h2d(mi_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on ctx stream */
 int mi_copy_d2h(mi_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* async on ctx stream */
 int mi_memset(mi_ctx *ctx, void *d_dst, int value, size_t bytes);
@@ -216,6 +216,9 @@ void mi_volume_destroy(mi_volume *v);
 void mi_volume_default_params(mi_volume_params *p);          /* volume_init msvolume.c:88-118 */
 int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_params *h_params);
 int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h_state); /* syncs */
+/* the same read-back enqueued on the context's stream behind the launches so far (h_state: pinned, mi_host_alloc); valid
+ * after the next mi_ctx_sync -- what a per-tick flush uses so that the meters cost no synchronisation of their own */
+int mi_volume_get_state_async(mi_volume *v, int first, int count, mi_volume_state *h_state);
 int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_state *h_state);
 /* MS_VOLUME_GET_MAX (linear): the maximum of the smoothed energy over the last second, recorded on the device by every
  * process call like ortp_extremum_record_max in update_energy (msvolume.c:115,:143-148,:404) -- a peak between two polls
@@ -245,6 +248,13 @@ int mi_volume_process_fifo_range(mi_volume *v, struct mi_fifo *f_src, int16_t *d
  * in multiples of 8 samples. */
 struct mi_mixer;
 int mi_mixer_process_volume_fifo(struct mi_mixer *m, mi_volume *v, int first_stream, struct mi_fifo *f_src, int16_t *d_out);
+/* flags: MI_VOLMIX_DRY_SKIPS -- a pin whose queue holds less than a tick is not metered at all (its meter state, gain ramp
+ * and one-second window stay as they are) and contributes silence: what the reference's chain does when MSVolume finds no
+ * whole 10 ms chunk in its bufferizer (msvolume.c:480-486: the loop does not run) and the mixer then reads nothing from
+ * that pin (audiomixer.c:88).  Without the flag the dry pin is metered on a tick of silence (mi_fifo_pop with zero_fill).
+ * The plugin's fused call-leg chain (mediastreamer2_amd/host/filters/leg_chain.inl) sets it. */
+#define MI_VOLMIX_DRY_SKIPS 1u
+int mi_mixer_process_volume_fifo_flags(struct mi_mixer *m, mi_volume *v, int first_stream, struct mi_fifo *f_src, int16_t *d_out, unsigned flags);
 
 /* ----------------------------------------------------------- equalizer */
 typedef struct mi_equalizer mi_equalizer;
@@ -312,6 +322,16 @@ int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, i
 int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
                                    mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
                                    int max_frames, unsigned flags, uint8_t *d_count_out);
+/* Both forms with a per-leg gate on the microphone block: d_mic_gate[s] == 0 = leg s is handed NO microphone block by this
+ * launch (nothing is queued for it, the folded resampler's state stays as it is; frames its queue still holds run all the
+ * same); NULL = every leg gets one.  What a host runtime needs whose legs do not all deliver a block every tick (packets
+ * of 20 ms: two launches in one tick and none in the next; slots of a bank that are not in use). */
+int mi_aec_process_fifos_masked(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
+                                const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
+                                int max_frames, unsigned flags, uint8_t *d_count_out, const uint8_t *d_mic_gate);
+int mi_aec_process_fifos_resampled_masked(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
+                                          mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
+                                          int max_frames, unsigned flags, uint8_t *d_count_out, const uint8_t *d_mic_gate);
 /* Spreading the load of mi_aec_process_fifos over the ticks.  Ticks of tick_len samples against frames of frame_size
  * leave a leg's microphone FIFO at a level that cycles through the multiples of gcd(tick_len, frame_size) -- at 48 kHz
  * (480 / 256) eight levels -- and a leg has one frame less to cancel in the tick it passes level 0.  Legs that start
@@ -403,6 +423,9 @@ int mi_fifo_push_frames(mi_fifo *f, const int16_t *d_in, int frame, int max_fram
 /* unit * mi_fifo_phase_of(s, phases) samples of silence appended to streams [first, first + count) (see mi_aec_stagger_fifos) */
 int mi_fifo_push_lead(mi_fifo *f, int first, int count, int unit, int phases);
 int mi_fifo_phase_of(int stream, int phases); /* 0 .. phases-1 */
+/* d_count[s] samples of silence appended to stream s (0 or less = nothing): the frame of zeros MSSpeexEC puts into its delay
+ * line when the far end runs short (speexec.c:261-272) and the delay line's initial fill (:205-208), decided per leg on the host */
+int mi_fifo_push_silence(mi_fifo *f, const int32_t *d_count);
 int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, in samples */
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_reset(mi_fifo *f);

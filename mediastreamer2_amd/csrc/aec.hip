@@ -605,6 +605,7 @@ struct AecFifoCall {
 	int tick_len, mic_stride, ref_stride;
 	const int32_t *d_ref_len;
 	uint8_t *d_count_out;
+	const uint8_t *d_mic_gate = nullptr; // the *_masked forms: 0 = no microphone block for the leg in this launch
 };
 
 static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride, const uint8_t *d_run,
@@ -639,6 +640,7 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 		g.mic_tick_stride = fifo->mic_stride;
 		g.ref_tick_stride = fifo->ref_stride;
 		g.count_out = fifo->d_count_out;
+		g.run = fifo->d_mic_gate;
 		g.order = a->d_order;
 		g.ctl = a->d_ctl;
 		if (fifo->rs.ok) {
@@ -697,9 +699,9 @@ int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref,
 	return aec_launch(a, d_mic, d_ref, d_out, stride, nullptr, d_count, max_frames, flags);
 }
 
-int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
-                         const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
-                         int max_frames, unsigned flags, uint8_t *d_count_out) {
+int mi_aec_process_fifos_masked(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
+                                const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
+                                int max_frames, unsigned flags, uint8_t *d_count_out, const uint8_t *d_mic_gate) {
 	MI_CHECK_ARG(a && f_mic && f_ref && f_out && d_mic_tick && d_ref_tick && tick_len > 0 && mic_stride >= tick_len &&
 	             ref_stride >= tick_len && max_frames >= 1 && max_frames <= MI_AEC_MAX_TICK_FRAMES);
 	MI_CHECK_ARG(f_mic->nstreams == a->nstreams && f_ref->nstreams == a->nstreams && f_out->nstreams == a->nstreams);
@@ -713,12 +715,20 @@ int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, i
 	fc.d_mic_tick = d_mic_tick, fc.d_ref_tick = d_ref_tick;
 	fc.tick_len = tick_len, fc.mic_stride = mic_stride, fc.ref_stride = ref_stride;
 	fc.d_ref_len = d_ref_len, fc.d_count_out = d_count_out;
+	fc.d_mic_gate = d_mic_gate;
 	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
 }
 
-int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
-                                   mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
-                                   int max_frames, unsigned flags, uint8_t *d_count_out) {
+int mi_aec_process_fifos(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
+                         const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
+                         int max_frames, unsigned flags, uint8_t *d_count_out) {
+	return mi_aec_process_fifos_masked(a, f_mic, d_mic_tick, mic_stride, f_ref, d_ref_tick, ref_stride, d_ref_len, tick_len, f_out, max_frames, flags,
+	                                   d_count_out, nullptr);
+}
+
+int mi_aec_process_fifos_resampled_masked(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
+                                          mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
+                                          int max_frames, unsigned flags, uint8_t *d_count_out, const uint8_t *d_mic_gate) {
 	MI_CHECK_ARG(a && rs && d_mic_in && f_mic && f_ref && f_out && d_ref_tick && in_len > 0 && in_stride >= in_len && max_frames >= 1 &&
 	             max_frames <= MI_AEC_MAX_TICK_FRAMES);
 	MI_CHECK_ARG(f_mic->nstreams == a->nstreams && f_ref->nstreams == a->nstreams && f_out->nstreams == a->nstreams);
@@ -746,7 +756,15 @@ int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *d
 	fc.d_mic_tick = nullptr, fc.d_ref_tick = d_ref_tick;
 	fc.tick_len = tick_len, fc.mic_stride = 0, fc.ref_stride = ref_stride;
 	fc.d_ref_len = d_ref_len, fc.d_count_out = d_count_out;
+	fc.d_mic_gate = d_mic_gate;
 	return aec_launch(a, nullptr, nullptr, nullptr, 0, nullptr, nullptr, max_frames, flags, &fc);
+}
+
+int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *d_mic_in, int in_len, int in_stride, mi_fifo *f_mic,
+                                   mi_fifo *f_ref, const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out,
+                                   int max_frames, unsigned flags, uint8_t *d_count_out) {
+	return mi_aec_process_fifos_resampled_masked(a, rs, d_mic_in, in_len, in_stride, f_mic, f_ref, d_ref_tick, ref_stride, d_ref_len, f_out,
+	                                             max_frames, flags, d_count_out, nullptr);
 }
 
 // The re-framing phase of a leg: ticks of tick_len samples against frames of F leave a leg's microphone FIFO at a level

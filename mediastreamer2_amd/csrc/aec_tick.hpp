@@ -241,7 +241,10 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		// resampler kernel's own tile FIR, so the samples are bit for bit what mi_resampler_process delivers).  Window, table
 		// and output staging live in the transform work space, which nothing uses yet.
 		const int16_t *mic_row = a.mic_tick + (size_t)s * a.mic_tick_stride;
-		if (a.rs_in) {
+		// a.run (the *_masked forms): 0 = this leg has no microphone block in this launch (nothing is queued, the resampler's
+		// state stays; whatever frames its queue still holds run all the same)
+		const int mlen = (a.run && !a.run[s]) ? 0 : a.tick_len;
+		if (a.rs_in && mlen) {
 			constexpr int RS_FILT = 48, RS_R = 8, RS_HIST = RS_FILT - 1;
 			const int den = a.rs_den, in_len = a.rs_in_len;
 			float *x = reinterpret_cast<float *>(L.zbuf);                    // [xn] history ++ input ++ zero slack
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		}
 		int rlen = a.ref_len ? a.ref_len[s] : a.tick_len; // the far end's block may be missing or short this tick
 		rlen = rlen < 0 ? 0 : (rlen > a.tick_len ? a.tick_len : rlen);
-		mic_new = append(a.fmic, qm, mic_row, a.tick_len);
+		mic_new = append(a.fmic, qm, mic_row, mlen);
 		ref_new = append(a.fref, qr, a.ref_tick + (size_t)s * a.ref_tick_stride, rlen);
 		if (!ref_new) rlen = 0;
 		nf = (qm.y + (mic_new ? a.tick_len : 0)) / F;

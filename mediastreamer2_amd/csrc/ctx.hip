@@ -140,9 +140,9 @@ void *mi_host_alloc(mi_ctx *c, size_t bytes) {
 }
 
 void mi_host_free(mi_ctx *c, void *p) {
-	if (!c || !p) return;
-	(void)hipSetDevice(c->device);
-	(void)hipHostFree(p);
+	if (!p) return;
+	if (c) (void)hipSetDevice(c->device);
+	(void)hipHostFree(p); // (pinned memory belongs to no device: a buffer may outlive the context it was allocated through)
 }
 
 int mi_copy_h2d(mi_ctx *c, void *d, const void *h, size_t n) {

@@ -59,6 +59,28 @@ __global__ void fifo_lead_kernel(FifoArgs a, int first, int count, int unit, int
 	a.pos[s] = make_int2(p.x, p.y + n);
 }
 
+// d_count[s] samples of silence appended to stream s (0 = nothing): the frames of zeros MSSpeexEC injects into its delay
+// line when the far end runs short (speexec.c:261-272), the delay line's initial fill (:205-208)
+__global__ void fifo_silence_kernel(FifoArgs a) {
+	const int s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= a.nstreams) return;
+	const int n = a.count[s];
+	if (n <= 0) return;
+	const int2 p = a.pos[s];
+	if (p.y + n > a.capacity) {
+		atomicAdd(a.overflow, 1);
+		return;
+	}
+	int16_t *r = a.ring + (size_t)s * a.capacity;
+	unsigned k = (unsigned)p.x + (unsigned)p.y;
+	if (k >= (unsigned)a.capacity) k -= (unsigned)a.capacity;
+	for (int j = 0; j < n; ++j) {
+		r[k] = 0;
+		if (++k == (unsigned)a.capacity) k = 0;
+	}
+	a.pos[s] = make_int2(p.x, p.y + n);
+}
+
 constexpr int FIFO_WAVES = 4; // independent wavefronts (streams) per workgroup: 4x fewer workgroups to dispatch
 
 __global__ __launch_bounds__(64 * FIFO_WAVES) void fifo_push_kernel(FifoArgs a) {
@@ -317,6 +339,17 @@ int mi_fifo_push_lead(mi_fifo *f, int first, int count, int unit, int phases) {
 	FifoArgs a;
 	fifo_args(f, a);
 	hipLaunchKernelGGL(fifo_lead_kernel, dim3(mi::ceil_div(count, 256)), dim3(256), 0, f->ctx->stream, a, first, count, unit, phases);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_push_silence(mi_fifo *f, const int32_t *d_count) {
+	MI_CHECK_ARG(f && d_count);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	FifoArgs a;
+	fifo_args(f, a);
+	a.count = d_count;
+	hipLaunchKernelGGL(fifo_silence_kernel, dim3(mi::ceil_div(f->nstreams, 256)), dim3(256), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }

@@ -23,6 +23,7 @@
 // reference (msvolume.c:440).  HBM traffic: 2 B/sample read, <= 2 B/sample
 // written, + ~100 B of per-stream state.
 #include "common.hpp"
+#include <atomic>
 
 #pragma clang fp contract(off)
 
@@ -371,6 +372,7 @@ struct VolMixArgs {
 	const float *gain;
 	int16_t *out;         // [nconf][mm][ns]
 	int mm, row_w;        // members per conference; row pitch in 8-byte words (odd)
+	int dry_skips;        // MI_VOLMIX_DRY_SKIPS: a leg whose queue holds less than a tick is not metered at all (MSVolume gets no chunk)
 };
 constexpr int VM_THREADS = 256, VM_MAXM = MI_MIXER_MAX_CHANNELS;
 
@@ -456,12 +458,19 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 			cur = nx;
 		}
 		const int s = s0 + t;
-		float2 win = a.win[s];
-		const VolCtl o = volume_control(p, st, peer_energy, acc, ns, s_pk[t], s_dc[t], a.sample_rate, win);
-		s_intgain[t] = o.intgain, s_dcoff[t] = o.dcoff, s_mode[t] = o.mode;
-		a.state[s] = st;
-		a.energy[*a.parity ^ 1][s] = st.energy;
-		a.win[s] = win;
+		if (va.dry_skips && s_head[t] < 0) {
+			// the plugin's chain: volume_process (msvolume.c:480-486) finds no whole 10 ms chunk in its bufferizer and does
+			// nothing -- no meter update, no gain ramp --, the mixer reads zeros for the pin (audiomixer.c:88)
+			s_intgain[t] = 4096, s_dcoff[t] = 0, s_mode[t] = 0;
+			a.energy[*a.parity ^ 1][s] = st.energy;
+		} else {
+			float2 win = a.win[s];
+			const VolCtl o = volume_control(p, st, peer_energy, acc, ns, s_pk[t], s_dc[t], a.sample_rate, win);
+			s_intgain[t] = o.intgain, s_dcoff[t] = o.dcoff, s_mode[t] = o.mode;
+			a.state[s] = st;
+			a.energy[*a.parity ^ 1][s] = st.energy;
+			a.win[s] = win;
+		}
 	}
 	__syncthreads();
 
@@ -611,6 +620,13 @@ int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h) 
 	return MI_OK;
 }
 
+int mi_volume_get_state_async(mi_volume *v, int first, int count, mi_volume_state *h_pinned) {
+	MI_CHECK_ARG(v && h_pinned && first >= 0 && count >= 0 && first + count <= v->nstreams);
+	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipMemcpyAsync(h_pinned, v->d_state + first, sizeof(*h_pinned) * (size_t)count, hipMemcpyDeviceToHost, v->ctx->stream));
+	return MI_OK;
+}
+
 int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_state *h) {
 	MI_CHECK_ARG(v && h && first >= 0 && count >= 0 && first + count <= v->nstreams);
 	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
@@ -675,6 +691,10 @@ int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f_src, int16_t *d_out, i
 }
 
 int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first_stream, mi_fifo *f_src, int16_t *d_out) {
+	return mi_mixer_process_volume_fifo_flags(m, v, first_stream, f_src, d_out, 0u);
+}
+
+int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stream, mi_fifo *f_src, int16_t *d_out, unsigned flags) {
 	MI_CHECK_ARG(m && v && f_src && d_out && first_stream >= 0);
 	MixerView mv;
 	mi_mixer_view(m, &mv);
@@ -712,10 +732,12 @@ int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first_stream, mi
 	a.out = d_out;
 	a.mm = mv.mm;
 	a.row_w = row_w;
-	static bool big_lds = false; // more than 64 KB of dynamic LDS needs the attribute once
-	if (lds > 64 * 1024 && !big_lds) {
+	a.dry_skips = (flags & MI_VOLMIX_DRY_SKIPS) ? 1 : 0;
+	static std::atomic<uint64_t> big_lds{0}; // more than 64 KB of dynamic LDS needs the attribute once per device
+	const uint64_t dev_bit = 1ull << (v->ctx->device & 63);
+	if (lds > 64 * 1024 && !(big_lds.load(std::memory_order_relaxed) & dev_bit)) {
 		MI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(volmix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-		big_lds = true;
+		big_lds.fetch_or(dev_bit, std::memory_order_relaxed);
 	}
 	hipLaunchKernelGGL(volmix_kernel, dim3(mv.nconf), dim3(VM_THREADS), lds, v->ctx->stream, a);
 	MI_LAUNCH_CHECK();

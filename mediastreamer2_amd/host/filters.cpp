@@ -40,6 +40,10 @@
 #include <unordered_map>
 #include <vector>
 
+extern "C" { // the descriptors (defined at the end of this file): the fused chain recognises its facades by them
+extern MSFilterDesc ms_mi355x_resample_desc, ms_mi355x_audio_mixer_desc, ms_mi355x_volume_desc, ms_mi355x_speex_ec_desc, ms_mi355x_webrtc_aec_name_desc;
+}
+
 namespace {
 
 constexpr int kMaxRounds = 4; // blocks one stream may hand over within a single tick
@@ -70,8 +74,21 @@ inline void mark_failed() {}
 
 struct Pool {
 	virtual ~Pool();
-	virtual void flush() = 0;                      // launch the staged blocks, fetch the results
+	// A bank's flush in two halves, so that a hub's flush costs ONE synchronisation however many banks it holds:
+	//   enqueue()  uploads, launches and downloads of everything staged, asynchronous on the hub's stream; true = something
+	//              was enqueued (the hub then synchronises once, behind the last bank);
+	//   finish()   the bookkeeping that needs the results on the host (staged -> ready); then emit() per slot.
+	// A bank that has not been split keeps the defaults: nothing enqueued, its whole flush() -- with a synchronisation of
+	// its own -- in the finish phase.
+	virtual bool enqueue() { return false; }
+	virtual void finish() { flush(); }
+	virtual void flush() {                         // launch the staged blocks, fetch the results: enqueue, wait, finish
+		if (enqueue()) sync_stream();
+		finish();
+	}
+	void sync_stream();
 	virtual void emit(MSFilter *f, int slot) = 0;  // hand a slot's results to its filter's output queues
+	virtual void emitted() {}                      // every slot has emitted: what the bank held for them may go
 	TickerHub *hub = nullptr;
 	std::string key;
 	std::vector<MSFilter *> owner;
@@ -145,6 +162,7 @@ struct TickerHub {
 	// that one run right away (then its bank is flushed in the same task): a chain of GPU filters costs one tick, not one
 	// tick per filter
 	bool in_flush = false;
+	uint64_t flushes = 0; // rounds of (enqueue, one wait, emit) so far: what ms_mi355x_hub_stats reports
 	std::vector<MSFilter *> touched, touched_pumps;
 	std::unordered_map<MSFilter *, uint64_t> pumped; // pump facades run early by the flush task, and for which tick
 	// Lifetime: ONE atomic word = the number of scopes that hold or are about to take `mu` (references: taken under the
@@ -162,6 +180,9 @@ struct TickerHub {
 };
 
 mi_ctx *Pool::ctx() const { return hub->ctx; }
+void Pool::sync_stream() {
+	if (hub->ctx && mi_ctx_sync(hub->ctx) != MI_OK) failed = mi_failed("mi_ctx_sync");
+}
 
 std::shared_mutex g_registry_mu;
 std::unordered_map<MSTicker *, TickerHub *> g_hubs;          // the hub of a ticker
@@ -443,11 +464,21 @@ void flush_hub(TickerHub &h) {
 	h.touched_pumps.clear();
 	for (int round = 0; round < 16; ++round) { // chains deeper than this finish on the next tick
 		// banks flushed in creation order; a facade may stage into any bank while another one emits
-		for (size_t i = 0; i < h.pools.size(); ++i) {
+		// every bank enqueues on the hub's stream, ONE wait, then every bank hands its results on
+		bool any = false;
+		const size_t npools = h.pools.size(); // (a bank created while the results are emitted is flushed in the next round)
+		for (size_t i = 0; i < npools; ++i)
+			if (!h.pools[i]->failed) any |= h.pools[i]->enqueue();
+		if (any && h.ctx && mi_ctx_sync(h.ctx) != MI_OK) {
+			mi_failed("mi_ctx_sync");
+			for (size_t i = 0; i < npools; ++i) h.pools[i]->failed = true; // nothing of this flush can be trusted
+		}
+		++h.flushes;
+		for (size_t i = 0; i < npools && i < h.pools.size(); ++i) {
 			Pool *p = h.pools[i];
-			if (p->failed) continue;
-			p->flush();
+			p->finish(); // (a failed bank still settles its bookkeeping: its filters pass their blocks on or drop them)
 			p->emit_all();
+			p->emitted();
 		}
 		if (!h.in_flush) break;
 		std::vector<MSFilter *> run;
@@ -501,11 +532,26 @@ void generic_postprocess(MSFilter *f) { facade_detached(f); }
 
 #define ms_queue_put(q, m) emit_to((q), (m)) /* the facades' queue puts, see emit_to */
 
+// the fused call-leg chain (filters/leg_chain.inl): what its four facades need to know of it
+struct FusedLeg;
+struct LegBank;
+struct ResampleData;
+struct SpeexECState;
+void leg_stage_mic(MSFilter *f, ResampleData *d);
+void leg_take_far_end(MSFilter *f, SpeexECState *s);
+MSFilter *leg_find_mixer(MSFilter *rs);
+bool conf_try_fuse(MSFilter *mixer);
+void conf_unfuse(MSFilter *mixer, bool keep_running);
+void leg_disqualify(FusedLeg *leg);
+MSFilter *leg_mixer(FusedLeg *leg);
+Pool *leg_pool(FusedLeg *leg);
+
 #include "filters/resample.inl"
 #include "filters/volume.inl"
 #include "filters/equalizer.inl"
 #include "filters/mixer.inl"
 #include "filters/echo_canceller.inl"
+#include "filters/leg_chain.inl"
 #include "filters/video.inl"
 #include "filters/codec.inl"
 #include "filters/flow_control.inl"
@@ -518,7 +564,7 @@ extern "C" {
 // Descriptors: same ids, names, pin counts and flags as the reference's, plus
 // MS_FILTER_IS_HW_ACCELERATED (msfilter.h:142).  Writable statics: the factory mutates flags.
 MSFilterDesc ms_mi355x_resample_desc = {MS_RESAMPLE_ID, "MSResample", "Audio resampler (MI355X batch)", MS_FILTER_OTHER,
-                                        NULL, 1, 1, resample_init, NULL, resample_process, generic_postprocess, resample_uninit,
+                                        NULL, 1, 1, resample_init, NULL, resample_process, resample_postprocess, resample_uninit,
                                         resample_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_audio_mixer_desc = {MS_AUDIO_MIXER_ID, "MSAudioMixer",
                                            "A filter that mixes down 16 bit sample audio streams (MI355X batch)",
@@ -526,7 +572,7 @@ MSFilterDesc ms_mi355x_audio_mixer_desc = {MS_AUDIO_MIXER_ID, "MSAudioMixer",
                                            mixer_preprocess, mixer_process, mixer_postprocess, mixer_uninit,
                                            mixer_methods, MS_FILTER_IS_PUMP | MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_volume_desc = {MS_VOLUME_ID, "MSVolume", "A filter that controls and measure sound volume (MI355X batch)",
-                                      MS_FILTER_OTHER, NULL, 1, 1, volume_init, volume_preprocess, volume_process, generic_postprocess,
+                                      MS_FILTER_OTHER, NULL, 1, 1, volume_init, volume_preprocess, volume_process, volume_postprocess,
                                       volume_uninit, volume_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_equalizer_desc = {MS_EQUALIZER_ID, "MSEqualizer", "Parametric sound equalizer (MI355X batch)",
                                          MS_FILTER_OTHER, NULL, 1, 1, equalizer_init, equalizer_preprocess, equalizer_process, generic_postprocess,
@@ -663,6 +709,29 @@ void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use) {
 	if (hubs) *hubs = nh;
 	if (banks) *banks = nb;
 	if (slots_in_use) *slots_in_use = ns;
+}
+
+// fused call-leg batches (filters/leg_chain.inl): conferences and legs living in them, kernel launches they have enqueued
+// and hub flush rounds (one synchronisation each) so far -- what bench.py's plugin_path reports per tick
+void ms_mi355x_fused_stats(int *conferences, int *legs, unsigned long long *launches, unsigned long long *flush_rounds) {
+	int nc = 0, nl = 0;
+	unsigned long long la = 0, fr = 0;
+	for (TickerHub *h : referenced_hubs()) {
+		HubLock lk(h, HubLock::Adopt{});
+		if (lk.dead()) continue;
+		fr += h->flushes;
+		for (Pool *p : h->pools)
+			if (p->key.compare(0, 4, "leg:") == 0) {
+				LegBank *b = static_cast<LegBank *>(p);
+				nc += b->in_use;
+				la += b->launches;
+				for (FusedLeg *l : b->legs) nl += l != nullptr;
+			}
+	}
+	if (conferences) *conferences = nc;
+	if (legs) *legs = nl;
+	if (launches) *launches = la;
+	if (flush_rounds) *flush_rounds = fr;
 }
 
 // the device of every hub that has opened a context (tests: tickers spread over MSMI355X_DEVICES); returns their number

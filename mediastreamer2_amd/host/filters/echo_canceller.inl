@@ -3,56 +3,70 @@
 // infrastructure); not compiled on its own.
 
 // ============================================================== echo canceller
+// A slot's frames of one tick are staged back to back, kEcTickFrames to a row, and a row is ONE launch of the canceller's
+// per-tick kernel (mi_aec_process_frames: both frames of a 48 kHz tick inside one wavefront, the per-stream state crossing
+// HBM once, the foreground filter streamed once) -- the while loop of speexec.c:256-305 unrolled into a count per slot.  A
+// burst of more frames (a 20 ms packet, a network hiccup) takes the next row: kMaxRounds launches, one wait.
+constexpr int kEcTickFrames = MI_AEC_MAX_TICK_FRAMES;
 struct EcPool : Pool {
 	int rate, F, flen;
 	mi_aec *a = nullptr;
 	int16_t *h_mic, *h_ref, *h_out, *d_mic, *d_ref, *d_out;
-	uint8_t *h_run, *d_run;
-	std::vector<int> staged, ready;
+	uint8_t *h_cnt, *d_cnt;
+	std::vector<int> staged, ready; // FRAMES per slot
 	EcPool(int cap, int r, int frame, int filter_length) : rate(r), F(frame), flen(filter_length) {
 		Building b(this, cap);
 		if (!failed) MI_MUST(mi_aec_create(hub->ctx, capacity, rate, F, flen, &a));
-		const size_t c = (size_t)capacity;
-		h_mic = pinned<int16_t>(kMaxRounds * c * F);
-		h_ref = pinned<int16_t>(kMaxRounds * c * F);
-		h_out = pinned<int16_t>(kMaxRounds * c * F);
-		h_run = pinned<uint8_t>(kMaxRounds * c);
-		d_mic = devmem<int16_t>(c * F);
-		d_ref = devmem<int16_t>(c * F);
-		d_out = devmem<int16_t>(c * F);
-		d_run = devmem<uint8_t>(c);
+		const size_t c = (size_t)capacity, row = (size_t)kEcTickFrames * F;
+		h_mic = pinned<int16_t>(kMaxRounds * c * row);
+		h_ref = pinned<int16_t>(kMaxRounds * c * row);
+		h_out = pinned<int16_t>(kMaxRounds * c * row);
+		h_cnt = pinned<uint8_t>(kMaxRounds * c);
+		d_mic = devmem<int16_t>(c * row);
+		d_ref = devmem<int16_t>(c * row);
+		d_out = devmem<int16_t>(kMaxRounds * c * row); // a row of results per round: the rounds' downloads need not wait for each other
+		d_cnt = devmem<uint8_t>(kMaxRounds * c);
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 	}
 	~EcPool() override {
 		if (a) mi_aec_destroy(a);
 	}
-	void flush() override {
+	static constexpr int max_frames() { return kMaxRounds * kEcTickFrames; }
+	// where frame k of a slot is staged (and where its result comes back)
+	size_t frame_at(size_t slot, int k) const { return (((size_t)(k / kEcTickFrames) * (size_t)capacity + slot) * kEcTickFrames + (size_t)(k % kEcTickFrames)) * (size_t)F; }
+	bool enqueue() override {
 		mi_ctx *ctx = hub->ctx;
-		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
-		int maxr = 0;
-		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
-		for (int r = 0; r < maxr; ++r) {
-			for (int s = 0; s < capacity; ++s) h_run[r * c + s] = s < hi && staged[(size_t)s] > r;
-			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * F, u * F * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * F, u * F * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r * c, c));
-			MI_MUST(mi_aec_process(a, d_mic, d_ref, d_out, F, d_run, MI_AEC_POSTFILTER));
-			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * F, d_out, u * F * 2));
+		const size_t c = (size_t)capacity, u = (size_t)hi, row = (size_t)kEcTickFrames * F; // rows [0, hi) are all that was ever handed out
+		int maxf = 0;
+		for (int s = 0; s < hi; ++s) maxf = std::max(maxf, staged[(size_t)s]);
+		const int rounds = (maxf + kEcTickFrames - 1) / kEcTickFrames;
+		for (int r = 0; r < rounds; ++r) {
+			for (int s = 0; s < capacity; ++s)
+				h_cnt[r * c + s] = s < hi ? (uint8_t)std::clamp(staged[(size_t)s] - r * kEcTickFrames, 0, kEcTickFrames) : 0;
+			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * row, u * row * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * row, u * row * 2));
+			MI_MUST(mi_copy_h2d(ctx, d_cnt + r * c, h_cnt + r * c, c));
+			MI_MUST(mi_aec_process_frames(a, d_mic, d_ref, d_out + r * c * row, (int)row, d_cnt + r * c, kEcTickFrames, MI_AEC_POSTFILTER));
+			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * row, d_out + r * c * row, u * row * 2));
 		}
-		if (maxr) MI_MUST(mi_ctx_sync(ctx));
-		if (failed) // the launch did not happen: the microphone frames leave uncancelled (what bypass mode does, speexec.c:229-237)
-			for (int r = 0; r < maxr; ++r) memcpy(h_out + r * c * F, h_mic + r * c * F, u * F * 2);
+		return rounds > 0;
+	}
+	void finish() override {
+		if (failed) { // the launch did not happen: the microphone frames leave uncancelled (what bypass mode does, speexec.c:229-237)
+			for (int s = 0; s < hi; ++s)
+				for (int k = 0; k < staged[(size_t)s]; ++k) memcpy(h_out + frame_at((size_t)s, k), h_mic + frame_at((size_t)s, k), (size_t)F * 2);
+		}
 		for (int s = 0; s < hi; ++s) {
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;
 		}
 	}
 	void emit(MSFilter *f, int slot) override {
-		const size_t c = (size_t)capacity, sl = (size_t)slot;
-		for (int r = 0; r < ready[sl]; ++r) { // cleaned frames -> outputs[1] (speexec.c:303)
+		const size_t sl = (size_t)slot;
+		for (int k = 0; k < ready[sl]; ++k) { // cleaned frames -> outputs[1] (speexec.c:303)
 			mblk_t *oecho = allocb((size_t)F * 2, 0);
-			memcpy(oecho->b_wptr, h_out + (r * c + sl) * F, (size_t)F * 2);
+			memcpy(oecho->b_wptr, h_out + frame_at(sl, k), (size_t)F * 2);
 			oecho->b_wptr += F * 2;
 			if (f->outputs[1]) ms_queue_put(f->outputs[1], oecho);
 			else freemsg(oecho);
@@ -124,6 +138,7 @@ struct SpeexECState { // speexec.c:49-72
 	bool_t unsupported; // the attached rate needs a frame size the kernels do not have: both pins pass (internal, not the user's flag)
 	EcPool *pool;
 	int slot;
+	FusedLeg *leg; // the filter is part of a fused call leg (filters/leg_chain.inl): its canceller and queues live in that bank
 };
 
 void ec_init(MSFilter *f) { // speexec.c:74-109
@@ -139,6 +154,7 @@ void ec_init(MSFilter *f) { // speexec.c:74-109
 }
 void ec_uninit(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
+	if (s->leg) conf_unfuse(leg_mixer(s->leg), false);
 	if (s->state_str) ms_free(s->state_str);
 	ms_bufferizer_uninit(&s->delayed_ref);
 	ms_free(s);
@@ -187,9 +203,13 @@ struct SpeexECState;
 void ec_apply_config(SpeexECState *s);
 void ec_fetch_config(SpeexECState *s);
 
+void ec_prepare(MSFilter *f);
 void ec_preprocess(MSFilter *f) { // speexec.c:188-216
-	SpeexECState *s = (SpeexECState *)f->data;
 	HubLock lk(f);
+	ec_prepare(f);
+}
+void ec_prepare(MSFilter *f) { // (hub locked by the caller)
+	SpeexECState *s = (SpeexECState *)f->data;
 	s->echostarted = FALSE;
 	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
 	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
@@ -217,6 +237,7 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	s->slot = s->pool ? s->pool->acquire(f) : -1;
 	if (s->slot < 0) s->pool = nullptr; // no canceller to be had: process() forwards both pins, like bypass mode
 	else note_slot(f);
+	ms_bufferizer_flush(&s->delayed_ref);
 	mblk_t *m = allocb((size_t)delay_samples * 2, 0); // zeroes for the time of the delay
 	memset(m->b_wptr, 0, (size_t)delay_samples * 2);
 	m->b_wptr += delay_samples * 2;
@@ -224,6 +245,7 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	s->nominal_ref_samples = delay_samples;
 	ec_apply_config(s); // :209-211
 }
+mi_aec *leg_canceller(FusedLeg *leg, int *slot); // leg_chain.inl
 void ec_apply_config(SpeexECState *s) { // :121-143
 	if (s->state_str == NULL || s->pool == nullptr) return;
 	std::vector<uint8_t> blob;
@@ -238,9 +260,11 @@ void ec_apply_config(SpeexECState *s) { // :121-143
 	ms_message("mi355x echo state restored.");
 }
 void ec_fetch_config(SpeexECState *s) { // :145-167
-	if (s->pool == nullptr) return;
-	std::vector<uint8_t> blob(mi_aec_blob_bytes(s->pool->a));
-	if (mi_aec_export_state(s->pool->a, s->slot, blob.data(), blob.size()) != MI_OK) {
+	int slot = s->slot;
+	mi_aec *a = s->leg ? leg_canceller(s->leg, &slot) : (s->pool ? s->pool->a : nullptr);
+	if (a == nullptr) return;
+	std::vector<uint8_t> blob(mi_aec_blob_bytes(a));
+	if (mi_aec_export_state(a, slot, blob.data(), blob.size()) != MI_OK) {
 		ms_error("Could not retrieve mi355x echo blob: %s", mi_last_error());
 		return;
 	}
@@ -250,6 +274,7 @@ void ec_fetch_config(SpeexECState *s) { // :145-167
 void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at detach
 	SpeexECState *s = (SpeexECState *)f->data;
 	facade_detached(f);
+	if (s->leg) conf_unfuse(leg_mixer(s->leg), false);
 	HubLock lk(f);
 	ms_bufferizer_flush(&s->delayed_ref);
 	ms_bufferizer_flush(&s->echo);
@@ -313,6 +338,11 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 // (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
 void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
+	if (s->leg) { // fused leg: the microphone pin is fed on the device; the far end is staged for the leg's delay line
+		HubLock lk(f, leg_pool(s->leg));
+		leg_take_far_end(f, s);
+		return;
+	}
 	if (s->bypass_mode || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)
 		for (int pin = 0; pin < 2; ++pin)
 			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
@@ -320,21 +350,21 @@ void ec_process(MSFilter *f) {
 	}
 	HubLock lk(f, s->pool);
 	EcPool *p = s->pool;
-	const size_t nbytes = (size_t)s->framesize * 2, cap = (size_t)p->capacity, slot = (size_t)s->slot;
+	const size_t nbytes = (size_t)s->framesize * 2, slot = (size_t)s->slot;
 	ec_take_far_end(f, s);
 	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
 	while (ms_bufferizer_get_avail(&s->echo) >= nbytes) {
-		if (p->staged[slot] >= kMaxRounds) { // a burst of more frames than launch rounds: what is staged goes out now
+		if (p->staged[slot] >= EcPool::max_frames()) { // a burst of more frames than the launch rounds hold: what is staged goes out now
 			p->flush();
 			p->emit_all();
 		}
-		const size_t row = ((size_t)p->staged[slot] * cap + slot) * (size_t)p->F;
-		ms_bufferizer_read(&s->echo, (uint8_t *)(p->h_mic + row), nbytes);
+		const size_t at = p->frame_at(slot, p->staged[slot]);
+		ms_bufferizer_read(&s->echo, (uint8_t *)(p->h_mic + at), nbytes);
 		s->echostarted = TRUE;
 		ec_emit_speaker_frame(f, s, nbytes);
-		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)(p->h_ref + row), nbytes) == 0) {
+		if (ms_bufferizer_read(&s->delayed_ref, (uint8_t *)(p->h_ref + at), nbytes) == 0) {
 			ms_error("mi355x echo canceller: the delayed reference ran dry (speexec.c:291-294 calls this impossible); silence used");
-			memset(p->h_ref + row, 0, nbytes);
+			memset(p->h_ref + at, 0, nbytes);
 		}
 		p->staged[slot]++;
 	}
@@ -364,7 +394,9 @@ int ec_set_tail_length(MSFilter *f, void *arg) {
 	return 0;
 }
 int ec_set_bypass_mode(MSFilter *f, void *arg) {
-	((SpeexECState *)f->data)->bypass_mode = *(bool_t *)arg;
+	SpeexECState *s = (SpeexECState *)f->data;
+	s->bypass_mode = *(bool_t *)arg;
+	if (s->bypass_mode) leg_disqualify(s->leg); // a fused conference goes back to its facades (which then forward both pins)
 	return 0;
 }
 int ec_get_bypass_mode(MSFilter *f, void *arg) {

@@ -24,7 +24,7 @@ struct EqualizerPool : Pool {
 	~EqualizerPool() override {
 		if (e) mi_equalizer_destroy(e);
 	}
-	void flush() override {
+	bool enqueue() override {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
@@ -37,7 +37,9 @@ struct EqualizerPool : Pool {
 			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
 			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
-		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		return maxr > 0;
+	}
+	void finish() override {
 		for (int s = 0; s < hi; ++s) { // after a failed launch the staged blocks leave as they came (flat response)
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;

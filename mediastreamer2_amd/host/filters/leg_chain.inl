@@ -1,0 +1,711 @@
+// filters/leg_chain.inl -- the call leg's chain of facades as ONE device-resident batch.
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, after the four facades it
+// joins); not compiled on its own.
+//
+// The reference's sending graph of a call leg is  ... -> read_resampler -> ec -> volsend -> ... -> mixer
+// (src/voip/audiostream.c:1798-1810), one MSFilter each, one process() each per tick.  Facade by facade that is four banks,
+// four uploads and downloads and the audio crossing PCIe eight times.  When a conference mixer of this plugin finds that
+// EVERY linked input pin is fed by   MSResample (16k->48k, 8k->48k, 8k->16k) -> MSSpeexEC pin 1 -> MSVolume (AGC) -> pin
+// -- all facades of this plugin on its own ticker, freshly attached -- the whole conference moves into a LegBank:
+//
+//   * one slot per LEG (conference * mm + pin) shared by every per-leg object: the resampler's history, the canceller, its
+//     three queues as device FIFOs (MSSpeexEC's `echo` and `delayed_ref` bufferizers, MSVolume's chunk bufferizer + the
+//     mixer channel's), the meter;
+//   * per tick and hub: the legs' 10 ms microphone blocks (320 B at 16 kHz) and far-end blocks (960 B) go up, TWO launches
+//     run per round -- aec_tick_kernel with the resampler folded in (mi_aec_process_fifos_resampled_masked) and volmix_kernel
+//     (mi_mixer_process_volume_fifo_flags) -- and the conferences' mixes (960 B per leg) come down into a pinned slab whose
+//     rows are handed downstream as they lie (esballoc + dupb: no copy, one data block per flush);
+//   * the facades' framing state machines stay on the host and decide as the reference does, on COUNTS: how many frames
+//     MSSpeexEC's while loop runs (speexec.c:256), when it feeds silence into its delay line (:261-272) and what goes to
+//     the speaker pin (host audio, as before), whether MSVolume has a whole chunk (msvolume.c:480-486), who contributes to
+//     the mixer (audiomixer.c:244-286) and what its channels' flow control drops (:92-111).  The device FIFOs hold exactly
+//     what those bufferizers would (MSMI355X_CHECK_LEVELS=1 reads the levels back every flush and compares).
+//
+// Results equal the facades run one by one (tests/test_gpu_plugin_fused.py: bit for bit, incl. far-end under-runs, 20 ms
+// packets and a late joiner), with two stated exceptions: a conference with a single contributor is mixed like any other
+// (the reference forwards that pin's blocks unsaturated, audiomixer.c:219-242: only a sample of -32768 differs; the
+// contributor's own pin gets no block either way), and after detach / re-attach the resampler starts from an empty
+// history like the canceller does (the facade alone keeps its speex handle across a detach).
+// Anything else -- another rate pair, a pin fed by something else, MSVolume without AGC or with an echo-limiter peer,
+// non-conference mode, MSMI355X_NO_FUSE=1 -- keeps the facades on their own banks.  A fused conference falls back to them
+// at run time when a member's configuration stops qualifying (bypass mode switched on, AGC switched off, ...): the audio
+// queued on the device at that moment (a few ms) is lost.
+
+constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
+
+struct LegBank;
+struct FusedLeg {
+	LegBank *bank;
+	int slot, pin;
+	MSFilter *rs, *ec, *vol, *mixer;
+	int staged_mic = 0;  // 10 ms blocks staged since the last flush (launch rounds)
+	int staged_ref = 0;  // far-end samples staged since the last flush
+	int inject = 0;      // samples of silence the framing put behind them (speexec.c:261-272)
+	int echo_level = 0;  // MSSpeexEC's `echo` bufferizer, samples: what f_mic holds
+	int dref_level = 0;  // its `delayed_ref`: what f_ref holds, staged samples included
+	int vol_rem = 0;     // MSVolume's bufferizer: cleaned samples short of a 10 ms chunk
+	int chan_chunks = 0; // the mixer channel's bufferizer: whole chunks waiting (f_out holds vol_rem + chan_chunks * ns)
+	int newchunks = 0;   // chunks MSVolume would have put on the mixer's queue in this flush
+	bool metered = false;
+};
+
+struct MixSlab { // one flush's conference mixes in pinned memory, referenced by the blocks handed downstream
+	std::atomic<int> state{0}; // 0 free, 1 a data block is alive on it, 2 its bank is gone (freed when the block goes)
+	size_t bytes = 0;
+	uint8_t *payload() { return reinterpret_cast<uint8_t *>(this) + 64; }
+	static MixSlab *of(void *payload) { return reinterpret_cast<MixSlab *>(static_cast<uint8_t *>(payload) - 64); }
+};
+static_assert(sizeof(MixSlab) <= 64, "slab header");
+void mix_slab_release(void *payload) { // db_freefn of the slab's data block (the last dupb of a flush was freed)
+	MixSlab *s = MixSlab::of(payload);
+	if (s->state.exchange(0, std::memory_order_acq_rel) == 2) mi_host_free(nullptr, s);
+}
+
+int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t now); // mixer.inl
+void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes);
+void conf_unfuse(MSFilter *mixer, bool keep_running);
+
+struct LegBank : Pool {
+	uint32_t in_rate, rate;
+	int F, flen, delay, mm, ns, in_len, den, nlegs;
+	int mic_cap, ref_cap, out_cap;
+	mi_resampler *rs = nullptr;
+	mi_aec *aec = nullptr;
+	mi_fifo *f_mic = nullptr, *f_ref = nullptr, *f_out = nullptr;
+	mi_volume *vol = nullptr;
+	mi_mixer *mix = nullptr;
+	int16_t *h_mic, *d_mic;     // [kMaxRounds][nlegs][in_len] / [nlegs][in_len]
+	uint8_t *h_gate, *d_gate;   // [kMaxRounds][nlegs] / [nlegs]
+	int16_t *h_ref, *d_ref;     // [nlegs][ns]: the first tick of far end a leg staged
+	int16_t *h_refx, *d_refx;   // [nlegs][kLegRefOver * ns]: what came beyond it (rare)
+	int32_t *h_cnt, *d_cnt;     // [3][nlegs]: far-end samples in h_ref, in h_refx, silence injected behind them
+	int32_t *d_zero;            // [nlegs] zeros: the canceller's launch appends no far end of its own
+	int16_t *d_mix, *d_scratch; // [capacity][mm][ns]; [nlegs][ns]
+	int32_t *h_lv, *d_lv;       // MSMI355X_CHECK_LEVELS: [3][nlegs]
+	mi_volume_state *h_vstate;  // pinned [nlegs]
+	int16_t *h_copy;            // the mixes when every slab is still held downstream: emitted by copy
+	std::vector<MixSlab *> slabs;
+	MixSlab *cur = nullptr;     // the slab this flush downloads into (null: h_copy)
+	mblk_t *root = nullptr;     // its data block, alive from finish() to emitted()
+	std::vector<FusedLeg *> legs;
+	std::vector<uint8_t> conf_ready;
+	std::vector<int> lone; // the single contributor's pin of a conference that ticked with one, else -1
+	std::vector<uint8_t> flags;
+	std::vector<float> gains;
+	bool ctl_dirty = true;
+	std::vector<mi_volume_params> vparams;
+	std::vector<mi_volume_state> vstate;
+	std::vector<uint8_t> vp_dirty, vs_dirty;
+	bool v_dirty = false;
+	std::vector<std::pair<int, int>> drops; // (leg slot, chunks) the mixer channels' flow control discards this flush
+	uint64_t mix_time = (uint64_t)-1;       // ticker time of the last conference tick (one per tick, whoever flushes)
+	bool mixed = false, check_levels = false;
+	uint64_t launches = 0;
+
+	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
+	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members)
+	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members) {
+		Building b(this, cap_conf);
+		ns = (int)rate / 100;
+		in_len = (int)in_rate / 100;
+		den = (int)(rate / in_rate);
+		nlegs = capacity * mm;
+		mic_cap = frames_up(2 * ns + 2 * F, F);
+		out_cap = frames_up(4 * ns + kMaxRounds * 2 * F, F);
+		ref_cap = frames_up(delay + (3 + kLegRefOver) * ns + kMaxRounds * 2 * F, F);
+		if (!failed) MI_MUST(mi_resampler_create(hub->ctx, nlegs, in_rate, rate, 3, &rs));
+		if (!failed) MI_MUST(mi_aec_create(hub->ctx, nlegs, (int)rate, F, flen, &aec));
+		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, mic_cap, &f_mic));
+		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, ref_cap, &f_ref));
+		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, out_cap, &f_out));
+		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, (int)rate, &vol));
+		if (!failed) MI_MUST(mi_mixer_create(hub->ctx, capacity, mm, ns, &mix));
+		const size_t L = (size_t)nlegs;
+		h_mic = pinned<int16_t>(kMaxRounds * L * in_len);
+		d_mic = devmem<int16_t>(L * in_len);
+		h_gate = pinned<uint8_t>(kMaxRounds * L);
+		d_gate = devmem<uint8_t>(kMaxRounds * L);
+		h_ref = pinned<int16_t>(L * ns);
+		d_ref = devmem<int16_t>(L * ns);
+		h_refx = pinned<int16_t>(L * kLegRefOver * ns);
+		d_refx = devmem<int16_t>(L * kLegRefOver * ns);
+		h_cnt = pinned<int32_t>(3 * L);
+		d_cnt = devmem<int32_t>(3 * L);
+		d_zero = devmem<int32_t>(L);
+		d_mix = devmem<int16_t>(L * ns);
+		d_scratch = devmem<int16_t>(L * ns);
+		h_lv = pinned<int32_t>(3 * L);
+		d_lv = devmem<int32_t>(3 * L);
+		h_vstate = pinned<mi_volume_state>(L);
+		h_copy = pinned<int16_t>(L * ns);
+		if (!failed) MI_MUST(mi_memset(hub->ctx, d_zero, 0, L * 4));
+		legs.assign(L, nullptr);
+		conf_ready.assign((size_t)capacity, 0);
+		lone.assign((size_t)capacity, -1);
+		flags.assign(L, 0);
+		gains.assign(L, 1.0f);
+		mi_volume_params p;
+		mi_volume_default_params(&p);
+		vparams.assign(L, p);
+		vstate.resize(L);
+		vp_dirty.assign(L, 0);
+		vs_dirty.assign(L, 0);
+		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
+	}
+	~LegBank() override {
+		if (root) freeb(root);
+		for (FusedLeg *l : legs) delete l;
+		if (hub->ctx) mi_ctx_sync(hub->ctx);
+		if (mix) mi_mixer_destroy(mix);
+		if (vol) mi_volume_destroy(vol);
+		for (mi_fifo *f : {f_mic, f_ref, f_out})
+			if (f) mi_fifo_destroy(f);
+		if (aec) mi_aec_destroy(aec);
+		if (rs) mi_resampler_destroy(rs);
+		for (MixSlab *s : slabs) // a slab whose blocks are still held downstream outlives the bank: its last block frees it
+			if (s->state.exchange(2, std::memory_order_acq_rel) == 0) mi_host_free(hub->ctx, s);
+	}
+	MixSlab *free_slab() {
+		for (MixSlab *s : slabs)
+			if (s->state.load(std::memory_order_acquire) == 0) return s;
+		if (slabs.size() >= 4 || failed) return nullptr;
+		const size_t bytes = (size_t)nlegs * ns * 2;
+		void *p = mi_host_alloc(hub->ctx, 64 + bytes);
+		if (!p) return nullptr;
+		MixSlab *s = new (p) MixSlab();
+		s->bytes = bytes;
+		slabs.push_back(s);
+		return s;
+	}
+
+	// ---- the canceller's framing for everything a leg staged since the last flush: the while loop of speexec.c:256-305
+	int ec_frames(FusedLeg *leg) {
+		SpeexECState *es = (SpeexECState *)leg->ec->data;
+		leg->echo_level += leg->staged_mic * ns;
+		int nfr = 0;
+		while (leg->echo_level >= F) {
+			leg->echo_level -= F;
+			es->echostarted = TRUE;
+			leg_speaker_frame(leg->ec, es, leg, (size_t)F * 2);
+			leg->dref_level -= F; // the frame the canceller reads from the head of the delay line
+			++nfr;
+		}
+		return nfr;
+	}
+
+	// ---- one tick of a conference on counts: mixer_process (audiomixer.c:288-346) with the census of mixer_check_bypass
+	// (:244-286) and the channels' flow control (:92-111), deciding from what MSVolume would have put on the pins' queues
+	void conf_tick(int c, uint64_t now) {
+		MSFilter *mx = owner[(size_t)c];
+		MixerState *s = (MixerState *)mx->data;
+		conf_ready[(size_t)c] = 0;
+		lone[(size_t)c] = -1;
+		int count = 0, who = -1;
+		for (int pin = 0; pin < mm; ++pin) {
+			FusedLeg *leg = legs[(size_t)(c * mm + pin)];
+			if (!leg) continue;
+			uint64_t &seen = s->channels[pin].last_activity;
+			bool contributes;
+			if (leg->newchunks > 0) {
+				seen = now;
+				contributes = true;
+			} else if (seen == (uint64_t)-1) {
+				seen = now; // first look at a silent pin only starts its clock
+				contributes = false;
+			} else {
+				contributes = now - seen < BYPASS_MODE_TIMEOUT;
+			}
+			if (contributes) ++count, who = pin;
+		}
+		if (count == 0) return; // nobody has delivered for a second: nothing leaves (and nothing was queued)
+		if ((count == 1) != (s->bypass_mode != FALSE))
+			ms_message("mi355x mixer %p: %s", (void *)mx, count == 1 ? "a single contributor (mixed on the device all the same)" : "two or more contributors");
+		s->bypass_mode = count == 1;
+		for (int pin = 0; pin < mm; ++pin) {
+			FusedLeg *leg = legs[(size_t)(c * mm + pin)];
+			if (!leg) continue;
+			Channel *chan = &s->channels[pin];
+			leg->chan_chunks += leg->newchunks; // ms_bufferizer_put_from_queue, channel_process_in :78-90
+			leg->newchunks = 0;
+			if (leg->chan_chunks > 0) { // ... and the read of one tick (the device pops it: the queue holds a whole chunk)
+				leg->chan_chunks--;
+				leg->metered = true;
+			}
+			const int skip = channel_flow_control_level(chan, leg->chan_chunks * ns * 2, s->skip_threshold, now);
+			if (skip > 0) {
+				const int k = std::min(leg->chan_chunks, skip / (ns * 2));
+				ms_warning("mi355x mixer: pin %i kept more than two ticks queued for 5 s; %i ms discarded", pin, k * 10);
+				leg->chan_chunks -= k;
+				if (k > 0) drops.push_back({leg->slot, k});
+			}
+		}
+		conf_ready[(size_t)c] = 1;
+		lone[(size_t)c] = count == 1 ? who : -1;
+	}
+
+	bool enqueue() override {
+		mi_ctx *ctx = hub->ctx;
+		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm; // legs of the conference slots ever handed out
+		if (root) emitted();
+		// ---- pending control changes (methods called since the last flush)
+		if (ctl_dirty) {
+			MI_MUST(mi_mixer_set_controls(mix, flags.data(), gains.data()));
+			ctl_dirty = false;
+		}
+		if (v_dirty) {
+			for (size_t s = 0; s < UL; ++s) {
+				if (vp_dirty[s]) MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
+				if (vs_dirty[s]) MI_MUST(mi_volume_set_state(vol, (int)s, 1, &vstate[s]));
+				vp_dirty[s] = vs_dirty[s] = 0;
+			}
+			v_dirty = false;
+		}
+		// ---- the host's half: framing decisions leg by leg
+		int rounds = 0;
+		bool any_ref = false, any_refx = false, any_inj = false;
+		for (size_t s = 0; s < UL; ++s) {
+			FusedLeg *leg = legs[s];
+			h_cnt[s] = h_cnt[L + s] = h_cnt[2 * L + s] = 0;
+			for (int r = 0; r < kMaxRounds; ++r) h_gate[(size_t)r * L + s] = leg && r < leg->staged_mic;
+			if (!leg) continue;
+			rounds = std::max(rounds, leg->staged_mic);
+			const int nfr = failed ? 0 : ec_frames(leg);
+			h_cnt[s] = std::min(leg->staged_ref, ns);
+			h_cnt[L + s] = leg->staged_ref - h_cnt[s];
+			h_cnt[2 * L + s] = leg->inject;
+			any_ref |= h_cnt[s] > 0;
+			any_refx |= h_cnt[L + s] > 0;
+			any_inj |= leg->inject > 0;
+			leg->staged_mic = leg->staged_ref = leg->inject = 0;
+			leg->vol_rem += nfr * F; // MSVolume's re-framing to 10 ms chunks (msvolume.c:480-486)
+			leg->newchunks += leg->vol_rem / ns;
+			leg->vol_rem %= ns;
+		}
+		const uint64_t now = hub->ticker ? hub->ticker->time : 0;
+		mixed = false;
+		drops.clear();
+		if (!failed && (mix_time != now || !hub->ticker)) { // the mixers tick once per ticker time, whoever flushes
+			mix_time = now;
+			for (int c = 0; c < hi; ++c)
+				if (owner[(size_t)c]) {
+					conf_tick(c, now);
+					mixed |= conf_ready[(size_t)c] != 0;
+				}
+		}
+		if (failed) return false;
+		bool any = false;
+		// ---- the device's half, in the order the reference's process() works: far end queued, then the frames, then the mix
+		if (any_ref || any_refx || any_inj) MI_MUST(mi_copy_h2d(ctx, d_cnt, h_cnt, 3 * L * 4));
+		if (any_ref) {
+			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref, UL * ns * 2));
+			MI_MUST(mi_fifo_push(f_ref, d_ref, ns, ns, d_cnt));
+			++launches, any = true;
+		}
+		if (any_refx) {
+			MI_MUST(mi_copy_h2d(ctx, d_refx, h_refx, UL * kLegRefOver * ns * 2));
+			MI_MUST(mi_fifo_push(f_ref, d_refx, kLegRefOver * ns, kLegRefOver * ns, d_cnt + L));
+			++launches, any = true;
+		}
+		if (any_inj) {
+			MI_MUST(mi_fifo_push_silence(f_ref, d_cnt + 2 * L));
+			++launches, any = true;
+		}
+		if (rounds) MI_MUST(mi_copy_h2d(ctx, d_gate, h_gate, (size_t)rounds * L));
+		for (int r = 0; r < rounds; ++r) {
+			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + (size_t)r * L * in_len, UL * in_len * 2));
+			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
+			                                              MI_AEC_POSTFILTER, nullptr, d_gate + (size_t)r * L));
+			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
+		}
+		if (mixed) {
+			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, d_mix, MI_VOLMIX_DRY_SKIPS));
+			++launches;
+			for (const auto &dk : drops) // chunks the channels' flow control discards: metered (MSVolume saw them), never mixed
+				for (int k = 0; k < dk.second; ++k) {
+					MI_MUST(mi_volume_process_fifo_range(vol, f_out, d_scratch, ns, ns, dk.first, 1));
+					++launches;
+				}
+			cur = free_slab();
+			MI_MUST(mi_copy_d2h(ctx, cur ? (void *)cur->payload() : (void *)h_copy, d_mix, UL * ns * 2));
+			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
+			any = true;
+		}
+		if (check_levels && any) {
+			MI_MUST(mi_fifo_levels(f_mic, d_lv));
+			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
+			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
+			MI_MUST(mi_copy_d2h(ctx, h_lv, d_lv, 3 * L * 4));
+		}
+		return any;
+	}
+
+	void finish() override {
+		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
+		if (failed) {
+			std::fill(conf_ready.begin(), conf_ready.end(), 0);
+			g_late_events.fetch_add(1, std::memory_order_relaxed);
+			return;
+		}
+		if (mixed) {
+			for (size_t s = 0; s < UL; ++s) {
+				FusedLeg *leg = legs[s];
+				if (!leg) continue;
+				if (!vs_dirty[s]) vstate[s] = h_vstate[s];
+				if (leg->metered && hub->ticker) { // update_energy's extremum records, msvolume.c:405-406
+					VolumeData *vd = (VolumeData *)leg->vol->data;
+					vd->max.record_max(hub->ticker->time, vstate[s].energy);
+					vd->min.record_min(hub->ticker->time, vstate[s].energy);
+				}
+				leg->metered = false;
+			}
+			if (cur) {
+				cur->state.store(1, std::memory_order_release);
+				root = esballoc(cur->payload(), cur->bytes, 0, mix_slab_release);
+			}
+		}
+		if (check_levels)
+			for (size_t s = 0; s < UL; ++s) {
+				FusedLeg *leg = legs[s];
+				if (!leg) continue;
+				const int want_out = leg->vol_rem + (leg->chan_chunks + leg->newchunks) * ns;
+				if (h_lv[s] != leg->echo_level || h_lv[L + s] != leg->dref_level || h_lv[2 * L + s] != want_out) {
+					ms_error("mi355x fused leg %d: device queues (%d, %d, %d) differ from the host's framing (%d, %d, %d)", (int)s, h_lv[s], h_lv[L + s],
+					         h_lv[2 * L + s], leg->echo_level, leg->dref_level, want_out);
+					g_late_events.fetch_add(1, std::memory_order_relaxed);
+				}
+			}
+	}
+
+	void emit(MSFilter *f, int c) override { // mixer_process :336-343 (conference mode): one block per enabled output
+		if (!conf_ready[(size_t)c]) return;
+		conf_ready[(size_t)c] = 0;
+		MixerState *s = (MixerState *)f->data;
+		const uint8_t *base = root ? cur->payload() : reinterpret_cast<const uint8_t *>(h_copy);
+		for (int pin = 0; pin < mm && pin < MIXER_MAX_CHANNELS; ++pin) {
+			MSQueue *q = f->outputs[pin];
+			if (!q || !s->channels[pin].output_enabled || pin == lone[(size_t)c]) continue;
+			uint8_t *row = const_cast<uint8_t *>(base) + ((size_t)(c * mm + pin) * ns) * 2;
+			mblk_t *om;
+			if (root) { // the row as it lies in the slab
+				om = dupb(root);
+				om->b_rptr = row;
+				om->b_wptr = row + (size_t)ns * 2;
+			} else {
+				om = allocb((size_t)ns * 2, 0);
+				memcpy(om->b_wptr, row, (size_t)ns * 2);
+				om->b_wptr += ns * 2;
+			}
+			ms_queue_put(q, om);
+		}
+	}
+	void emitted() override { // the flush's own reference: the slab returns to the ring when the last block downstream is freed
+		if (root) freeb(root);
+		root = nullptr;
+		cur = nullptr;
+	}
+};
+
+// one speaker frame per microphone frame, on counts: ec_emit_speaker_frame with the delay line on the device
+void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes) {
+	const int fs = (int)(nbytes / 2);
+	if (leg->dref_level < s->nominal_ref_samples + fs) {
+		leg->inject += fs; // behind everything the far end delivered so far (ms_bufferizer_put(&s->delayed_ref, silence))
+		leg->dref_level += fs;
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], ec_block(nbytes));
+		if (!s->using_zeroes) ms_warning("Not enough ref samples, using zeroes");
+		s->using_zeroes = TRUE;
+		return;
+	}
+	if (s->using_zeroes) ms_message("Samples are back.");
+	s->using_zeroes = FALSE;
+	mblk_t *m = ec_block(nbytes);
+	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) {
+		ms_error("mi355x echo canceller: the far-end bufferizer ran dry; silence sent to the speaker");
+		memset(m->b_rptr, 0, nbytes);
+	}
+	if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+	else freemsg(m);
+}
+
+// ---- the facades' fused halves -----------------------------------------------------------------------------------------
+// MSResample: this tick's input, re-framed to 10 ms blocks, straight into the bank's staging rows
+void leg_stage_mic(MSFilter *f, ResampleData *d) {
+	FusedLeg *leg = d->leg;
+	LegBank *b = leg->bank;
+	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
+	const size_t nbytes = (size_t)b->in_len * 2;
+	while (ms_bufferizer_get_avail(d->bz) >= nbytes && leg->staged_mic < kMaxRounds) { // (more than kMaxRounds blocks: the rest next tick)
+		ms_bufferizer_read(d->bz, (uint8_t *)(b->h_mic + ((size_t)leg->staged_mic * b->nlegs + (size_t)leg->slot) * b->in_len), nbytes);
+		leg->staged_mic++;
+	}
+	if (leg->staged_mic) request_flush(f);
+}
+
+// MSSpeexEC, far end (speexec.c:239-250): dropped until the microphone has started, then kept twice -- for the canceller
+// (the device's delay line, through the staging rows) and for the speaker pin (the flow-controlled bufferizer, host)
+void leg_take_far_end(MSFilter *f, SpeexECState *s) {
+	FusedLeg *leg = s->leg;
+	LegBank *b = leg->bank;
+	if (!f->inputs[0]) return;
+	if (!s->echostarted) {
+		if (!ms_queue_empty(f->inputs[0])) ms_warning("Getting reference signal but no echo to synchronize on.");
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) {
+		for (mblk_t *c = m; c; c = c->b_cont) {
+			const int16_t *src = (const int16_t *)c->b_rptr;
+			int n = (int)((c->b_wptr - c->b_rptr) / 2);
+			if (leg->staged_ref + n > (1 + kLegRefOver) * b->ns || leg->dref_level + n + kMaxRounds * 2 * b->F > b->ref_cap) {
+				ms_error("mi355x echo canceller: more far end in one tick than the leg's delay line takes; %d samples dropped", n);
+				g_late_events.fetch_add(1, std::memory_order_relaxed);
+				continue;
+			}
+			leg->dref_level += n;
+			while (n > 0) {
+				const int at = leg->staged_ref;
+				int16_t *dst = at < b->ns ? b->h_ref + (size_t)leg->slot * b->ns + at : b->h_refx + (size_t)leg->slot * kLegRefOver * b->ns + (at - b->ns);
+				const int k = std::min(n, at < b->ns ? b->ns - at : n);
+				memcpy(dst, src, (size_t)k * 2);
+				src += k, n -= k, leg->staged_ref += k;
+			}
+		}
+		flowbuf_put(&s->ref, m);
+	}
+	if (leg->staged_ref) request_flush(f);
+}
+
+// ---- fusing ------------------------------------------------------------------------------------------------------------
+struct LegCand {
+	MSFilter *rs, *ec, *vol;
+	int pin;
+};
+
+bool leg_rates_ok(uint32_t in, uint32_t out) { // what the canceller's launch up-samples itself (mi_aec_process_fifos_resampled)
+	return (in == 16000 && out == 48000) || (in == 8000 && out == 48000) || (in == 8000 && out == 16000);
+}
+
+bool is_ec_desc(const MSFilterDesc *d) { return d == &ms_mi355x_speex_ec_desc || d == &ms_mi355x_webrtc_aec_name_desc; }
+
+// Is pin `pin` of mixer `mx` the end of  MSResample -> MSSpeexEC (pin 1) -> MSVolume, all ours, all on the mixer's ticker,
+// all fresh?  Fills the candidate.
+bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
+	MSQueue *q = mx->inputs[pin];
+	MSFilter *vol = q->prev.filter;
+	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker) return false;
+	VolumeData *vd = (VolumeData *)vol->data;
+	if (!vd->p.agc_enabled || vd->peer || vd->peered_by > 0 || vd->sample_rate != ms->rate || vd->leg) return false;
+	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
+	MSQueue *qe = vol->inputs[0];
+	MSFilter *ec = qe ? qe->prev.filter : NULL;
+	if (!ec || !is_ec_desc(ec->desc) || qe->prev.pin != 1 || ec->ticker != mx->ticker || !ms_queue_empty(qe)) return false;
+	SpeexECState *es = (SpeexECState *)ec->data;
+	if (es->bypass_mode || es->unsupported || !es->pool || es->samplerate != ms->rate || es->echostarted || es->leg) return false;
+	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
+	MSQueue *qr = ec->inputs[1];
+	MSFilter *rs = qr ? qr->prev.filter : NULL;
+	if (!rs || rs->desc != &ms_mi355x_resample_desc || rs->ticker != mx->ticker || !ms_queue_empty(qr)) return false;
+	ResampleData *rd = (ResampleData *)rs->data;
+	if (rd->in_nchannels != 1 || rd->out_nchannels != 1 || (int)rd->output_rate != ms->rate || !leg_rates_ok(rd->input_rate, rd->output_rate)) return false;
+	if (rd->leg || ms_bufferizer_get_avail(rd->bz) || (rd->pool && rd->pool->staged[(size_t)rd->slot])) return false;
+	c.rs = rs, c.ec = ec, c.vol = vol, c.pin = pin;
+	return true;
+}
+
+// Called (hub locked, ticker thread) by the first facade of a conference's graph to run after an attach.  true = fused.
+bool conf_try_fuse(MSFilter *mx) {
+	MixerState *ms = (MixerState *)mx->data;
+	if (ms->fuse_state != 0) return ms->fuse_state == 1;
+	ms->fuse_state = 2; // refused, unless everything below holds
+	const bool off = getenv("MSMI355X_NO_FUSE") != nullptr; // (read per attach: an A/B switch, and what the tests compare against)
+	if (off || !ms->pool || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 100) return false;
+	std::vector<LegCand> cand;
+	int maxpin = -1;
+	for (int pin = 0; pin < mx->desc->ninputs; ++pin) {
+		if (!mx->inputs[pin]) continue;
+		LegCand c;
+		if (!leg_candidate(mx, ms, pin, c)) return false; // a pin fed by anything else: the conference stays on the facades' own banks
+		cand.push_back(c);
+		maxpin = pin;
+	}
+	if (cand.empty()) return false;
+	const SpeexECState *e0 = (const SpeexECState *)cand[0].ec->data;
+	const ResampleData *r0 = (const ResampleData *)cand[0].rs->data;
+	for (const LegCand &c : cand) { // one shape per conference (a bank is one shape)
+		const SpeexECState *e = (const SpeexECState *)c.ec->data;
+		const ResampleData *r = (const ResampleData *)c.rs->data;
+		if (e->framesize != e0->framesize || e->filterlength != e0->filterlength || e->nominal_ref_samples != e0->nominal_ref_samples ||
+		    r->input_rate != r0->input_rate)
+			return false;
+	}
+	int mm = MIXER_MAX_CHANNELS;
+	for (int m : {4, 8, 16, 32})
+		if (maxpin < m) {
+			mm = m;
+			break;
+		}
+	const uint32_t ir = r0->input_rate, rate = (uint32_t)ms->rate;
+	const int F = e0->framesize, flen = e0->filterlength, delay = e0->nominal_ref_samples;
+	LegBank *b = bank<LegBank>("leg:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
+	                               std::to_string(delay) + ":" + std::to_string(mm),
+	                           1, [&](int cap) { return new LegBank(std::max(1, cap * 4 / mm), ir, rate, F, flen, delay, mm); }); // 64, 256, 1024, .. legs
+	const int c = b ? b->acquire(mx) : -1;
+	if (c < 0) return false;
+	note_slot(mx);
+	// ---- the legs: fresh per-leg state at their slots (what the filters' own banks hold at this point), then the facades let
+	// go of their own slots
+	const int s0 = c * mm;
+	bool ok = mi_resampler_reset(b->rs, s0, mm) == MI_OK && mi_aec_reset(b->aec, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_mic, s0, mm) == MI_OK &&
+	          mi_fifo_reset_range(b->f_ref, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_out, s0, mm) == MI_OK && mi_volume_reset_max(b->vol, s0, mm) == MI_OK;
+	std::vector<int32_t> fill((size_t)b->nlegs, 0);
+	for (const LegCand &cd : cand) {
+		const size_t s = (size_t)(s0 + cd.pin);
+		VolumeData *vd = (VolumeData *)cd.vol->data;
+		SpeexECState *es = (SpeexECState *)cd.ec->data;
+		mi_volume_state st;
+		memset(&st, 0, sizeof(st));
+		st.gain = vd->gain, st.target_gain = vd->target_gain, st.ng_gain = 1; // a fresh slot, as volume_attach_slot leaves it
+		b->vstate[s] = st;
+		b->vparams[s] = vd->p;
+		b->vparams[s].peer = -1;
+		fill[s] = delay; // zeroes for the time of the delay (speexec.c:205-208)
+		if (es->state_str) { // a saved canceller state goes to the leg's slot (speexec.c:209-211)
+			std::vector<uint8_t> blob;
+			if (b64_decode(es->state_str, blob) && mi_aec_import_state(b->aec, (int)s, blob.data(), blob.size()) == MI_OK) ms_message("mi355x echo state restored.");
+			else ms_error("Could not apply mi355x echo blob: %s", mi_last_error());
+		}
+	}
+	ok = ok && mi_volume_set_params(b->vol, s0, mm, &b->vparams[(size_t)s0]) == MI_OK && mi_volume_set_state(b->vol, s0, mm, &b->vstate[(size_t)s0]) == MI_OK;
+	if (ok && delay > 0) {
+		int32_t *d_fill = b->d_cnt; // (idle between flushes)
+		ok = mi_copy_h2d(b->hub->ctx, d_fill, fill.data(), (size_t)b->nlegs * 4) == MI_OK && mi_fifo_push_silence(b->f_ref, d_fill) == MI_OK &&
+		     mi_ctx_sync(b->hub->ctx) == MI_OK;
+	}
+	if (!ok) {
+		mi_failed("fusing a conference's legs");
+		b->release(c);
+		return false;
+	}
+	for (int pin = 0; pin < mm; ++pin) b->flags[(size_t)(s0 + pin)] = 0, b->gains[(size_t)(s0 + pin)] = 1.0f;
+	for (const LegCand &cd : cand) {
+		FusedLeg *leg = new FusedLeg();
+		leg->bank = b, leg->slot = s0 + cd.pin, leg->pin = cd.pin;
+		leg->rs = cd.rs, leg->ec = cd.ec, leg->vol = cd.vol, leg->mixer = mx;
+		leg->dref_level = delay;
+		b->legs[(size_t)leg->slot] = leg;
+		ResampleData *rd = (ResampleData *)cd.rs->data;
+		SpeexECState *es = (SpeexECState *)cd.ec->data;
+		VolumeData *vd = (VolumeData *)cd.vol->data;
+		if (rd->pool) resample_release(rd);
+		rd->leg = leg;
+		ms_bufferizer_flush(&es->delayed_ref); // the delay line lives on the device now
+		es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
+		es->pool->release(es->slot); // (the last release of a bank destroys it)
+		es->pool = nullptr, es->slot = -1;
+		es->leg = leg;
+		if (vd->pool) {
+			vd->pool->release(vd->slot);
+			vd->pool = nullptr, vd->slot = -1;
+		}
+		vd->leg = leg;
+	}
+	ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
+	ms->pool->release(ms->slot);
+	ms->pool = nullptr, ms->slot = -1;
+	ms->fbank = b, ms->fconf = c;
+	ms->fuse_state = 1;
+	ms->unfuse_wanted = false;
+	ms->first_look = false;
+	mixer_push_controls(mx, ms);
+	ms_message("mi355x: conference %p fused: %d legs %u -> %u Hz, frame %d, tail %d, one device-resident batch (bank of %d x %d)", (void *)mx,
+	           (int)cand.size(), ir, rate, F, flen, b->capacity, mm);
+	return true;
+}
+
+// the head of a leg (MSResample) looks for the mixer at the end of its chain
+MSFilter *leg_find_mixer(MSFilter *rs) {
+	MSQueue *q = rs->outputs[0];
+	MSFilter *ec = q ? q->next.filter : NULL;
+	if (!ec || !is_ec_desc(ec->desc) || q->next.pin != 1) return NULL;
+	q = ec->outputs[1];
+	MSFilter *vol = q ? q->next.filter : NULL;
+	if (!vol || vol->desc != &ms_mi355x_volume_desc) return NULL;
+	q = vol->outputs[0];
+	MSFilter *mx = q ? q->next.filter : NULL;
+	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
+}
+
+void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess (a bank slot of its own)
+void mixer_prepare(MSFilter *f); // mixer.inl
+
+// The conference leaves its LegBank: at detach (every facade's postprocess ends up here, the first one does the work) or,
+// keep_running, because a member stopped qualifying while attached -- the facades then go on with banks of their own and
+// what was queued on the device is lost.
+void conf_unfuse(MSFilter *mx, bool keep_running) {
+	MixerState *ms = (MixerState *)mx->data;
+	LegBank *b = ms->fbank;
+	if (!b) return;
+	HubLock lk(b->hub);
+	const int c = ms->fconf, mm = b->mm;
+	std::vector<FusedLeg *> gone;
+	for (int pin = 0; pin < mm; ++pin) {
+		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
+		if (!leg) continue;
+		b->legs[(size_t)(c * mm + pin)] = nullptr;
+		((ResampleData *)leg->rs->data)->leg = nullptr;
+		((SpeexECState *)leg->ec->data)->leg = nullptr;
+		((VolumeData *)leg->vol->data)->leg = nullptr;
+		gone.push_back(leg);
+	}
+	b->conf_ready[(size_t)c] = 0;
+	ms->fbank = nullptr, ms->fconf = -1;
+	ms->fuse_state = keep_running ? 2 : 0; // a new attach looks again
+	ms->unfuse_wanted = false;
+	for (int pin = 0; pin < mm; ++pin) b->flags[(size_t)(c * mm + pin)] = 0;
+	b->ctl_dirty = true;
+	if (keep_running) { // banks of their own again, while the hub is still held by this conference's slot
+		for (FusedLeg *leg : gone) ec_prepare(leg->ec);
+		mixer_prepare(mx);
+		ms_warning("mi355x: conference %p left its fused batch (a member's configuration changed); the facades carry on one by one", (void *)mx);
+	}
+	b->release(c); // (may destroy the bank)
+	for (FusedLeg *leg : gone) delete leg;
+}
+
+MSFilter *leg_mixer(FusedLeg *leg) { return leg->mixer; }
+Pool *leg_pool(FusedLeg *leg) { return leg->bank; }
+Pool *leg_pool_of(LegBank *b) { return b; }
+// MS_AUDIO_MIXER_SET_INPUT_GAIN / SET_ACTIVE / ENABLE_OUTPUT on a fused conference (hub locked): the bank's control rows
+void leg_push_mixer_controls(MSFilter *f, MixerState *s) {
+	LegBank *b = s->fbank;
+	for (int pin = 0; pin < b->mm; ++pin) {
+		const size_t at = (size_t)(s->fconf * b->mm + pin);
+		uint8_t fl = 0;
+		if (f->inputs[pin] && b->legs[at]) fl |= MI_MIX_LINKED;
+		if (s->channels[pin].active) fl |= MI_MIX_ACTIVE;
+		if (f->outputs[pin] && s->channels[pin].output_enabled) fl |= MI_MIX_OUTPUT;
+		b->flags[at] = fl;
+		b->gains[at] = s->channels[pin].gain;
+	}
+	b->ctl_dirty = true;
+}
+mi_volume_state *leg_vstate(FusedLeg *leg) { return &leg->bank->vstate[(size_t)leg->slot]; }
+// MS_VOLUME_* methods on a fused leg's MSVolume (hub locked): parameters / running state for the next flush
+void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, bool state_too) {
+	LegBank *b = leg->bank;
+	b->vparams[(size_t)leg->slot] = *p;
+	b->vparams[(size_t)leg->slot].peer = -1;
+	b->vp_dirty[(size_t)leg->slot] = 1;
+	if (state_too) b->vs_dirty[(size_t)leg->slot] = 1;
+	b->v_dirty = true;
+}
+mi_aec *leg_canceller(FusedLeg *leg, int *slot) {
+	*slot = leg->slot;
+	return leg->bank->aec;
+}
+
+// a facade of a fused leg stopped qualifying (a method call on the application's thread): the conference leaves the batch
+// at the start of the next flush -- on the ticker thread, where the facades' state may be touched
+void leg_disqualify(FusedLeg *leg) {
+	if (leg) ((MixerState *)leg->mixer->data)->unfuse_wanted = true;
+}

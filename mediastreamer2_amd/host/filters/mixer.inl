@@ -4,6 +4,7 @@
 
 // ======================================================================= mixer
 constexpr int MIXER_MAX_CHANNELS = MI_MIXER_MAX_CHANNELS; // audiomixer.c:29
+Pool *leg_pool_of(LegBank *b);                            // leg_chain.inl
 constexpr uint64_t BYPASS_MODE_TIMEOUT = 1000;            // audiomixer.c:31
 
 struct MixerPool : Pool {
@@ -37,7 +38,7 @@ struct MixerPool : Pool {
 	~MixerPool() override {
 		if (m) mi_mixer_destroy(m);
 	}
-	void flush() override {
+	bool enqueue() override {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity;
 		bool any = false;
@@ -57,9 +58,11 @@ struct MixerPool : Pool {
 			MI_MUST(mi_copy_h2d(ctx, d_mode, h_mode, c));
 			MI_MUST(mi_mixer_process_masked(m, d_in, d_has, 1, d_mode, d_out, d_run));
 			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, un * ns * 2));
-			MI_MUST(mi_ctx_sync(ctx));
 		}
-		for (size_t s = 0; s < c; ++s) {
+		return any;
+	}
+	void finish() override {
+		for (size_t s = 0; s < (size_t)capacity; ++s) {
 			ready[s] = staged[s];
 			staged[s] = 0;
 		}
@@ -85,7 +88,14 @@ struct MixerState { // audiomixer.c:132-143
 	// filter's latency does not jump by 10 ms when a second contributor appears or the last but one falls silent -- a
 	// canceller behind two mixers would otherwise see its two inputs slip against each other (aec3_tester.c graph).
 	std::vector<std::pair<int, mblk_t *>> *held;
+	// the conference and every leg that feeds it as one device-resident batch (filters/leg_chain.inl)
+	LegBank *fbank;     // non-null: fused; the conference is slot `fconf` of that bank
+	int fconf;
+	int fuse_state;     // 0 not looked at since the attach, 1 fused, 2 refused
+	bool unfuse_wanted; // a member stopped qualifying (set by a method on any thread, honoured by the next process())
+	bool first_look;    // the fused conference has had the census of its first tick
 };
+void leg_push_mixer_controls(MSFilter *f, MixerState *s); // leg_chain.inl
 
 void mixer_release_held(MSFilter *f, MixerState *s, bool deliver) {
 	for (auto &pm : *s->held) {
@@ -114,6 +124,7 @@ void mixer_init(MSFilter *f) { // audiomixer.c:145-156
 }
 void mixer_uninit(MSFilter *f) {
 	MixerState *s = (MixerState *)f->data;
+	conf_unfuse(f, false);
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) ms_bufferizer_uninit(&s->channels[i].bufferizer);
 	mixer_release_held(f, s, false);
 	delete s->held;
@@ -126,6 +137,10 @@ bool_t has_single_output(MSFilter *f, MixerState *s) { // audiomixer.c:167-176
 	return count == 1;
 }
 void mixer_push_controls(MSFilter *f, MixerState *s) {
+	if (s->fbank) {
+		leg_push_mixer_controls(f, s);
+		return;
+	}
 	if (!s->pool) return;
 	MixerPool *p = s->pool;
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
@@ -138,9 +153,14 @@ void mixer_push_controls(MSFilter *f, MixerState *s) {
 	}
 	p->ctl_dirty = true;
 }
+void mixer_prepare(MSFilter *f);
 void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
-	MixerState *s = (MixerState *)f->data;
 	HubLock lk(f);
+	((MixerState *)f->data)->fuse_state = 0;
+	mixer_prepare(f);
+}
+void mixer_prepare(MSFilter *f) { // (hub locked by the caller)
+	MixerState *s = (MixerState *)f->data;
 	s->bytespertick = (2 * s->nchannels * s->rate * f->ticker->interval) / 1000;
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
 		s->channels[i].last_flow_control = (uint64_t)-1;
@@ -159,6 +179,7 @@ void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
 void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot released at every detach)
 	MixerState *s = (MixerState *)f->data;
 	facade_detached(f);
+	conf_unfuse(f, false);
 	HubLock lk(f);
 	mixer_release_held(f, s, false);
 	if (s->pool) {
@@ -235,20 +256,22 @@ bool_t mixer_check_bypass(MSFilter *f, MixerState *s) {
 
 // ---- per-channel flow control (behaviour of audiomixer.c:92-111): every 5 s, if the bufferizer never dropped below
 // `threshold` bytes in that window, discard the standing excess down to half the threshold.  Returns the bytes dropped.
-int channel_flow_control(Channel *chan, int threshold, uint64_t now) {
+// the decision alone, from the bufferizer's level in bytes (the fused chain keeps that level as a count)
+int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t now) {
 	const bool first_call = chan->last_flow_control == (uint64_t)-1;
 	int dropped = 0;
 	if (!first_call) {
-		const int level = (int)ms_bufferizer_get_avail(&chan->bufferizer);
 		if (chan->min_fullness == -1 || level < chan->min_fullness) chan->min_fullness = level;
 		if (now - chan->last_flow_control < 5000) return 0;
-		if (chan->min_fullness >= threshold) {
-			dropped = chan->min_fullness - threshold / 2;
-			ms_bufferizer_skip_bytes(&chan->bufferizer, dropped);
-		}
+		if (chan->min_fullness >= threshold) dropped = chan->min_fullness - threshold / 2;
 	}
 	chan->last_flow_control = now; // a new observation window starts
 	chan->min_fullness = -1;
+	return dropped;
+}
+int channel_flow_control(Channel *chan, int threshold, uint64_t now) {
+	const int dropped = channel_flow_control_level(chan, (int)ms_bufferizer_get_avail(&chan->bufferizer), threshold, now);
+	if (dropped > 0) ms_bufferizer_skip_bytes(&chan->bufferizer, dropped);
 	return dropped;
 }
 
@@ -288,7 +311,20 @@ void MixerPool::emit(MSFilter *f, int slot) {
 void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
 	ms_filter_lock(f);
-	HubLock lk(f, s->pool);
+	if (s->unfuse_wanted && s->fbank) conf_unfuse(f, true); // a member stopped qualifying: back to the facades' own banks
+	HubLock lk(f, s->fbank ? leg_pool_of(s->fbank) : static_cast<Pool *>(s->pool));
+	if (s->fuse_state == 0 && !s->fbank) conf_try_fuse(f); // (normally a leg's head got here first)
+	if (s->fbank) { // fused: the conference ticks inside the hub's flush; a pump keeps that flush coming every tick
+		if (!s->first_look) { // the census of the attach's first tick (this walk): a pin's clock starts when it is first looked at
+			for (int i = 0; i < f->desc->ninputs; ++i)
+				if (f->inputs[i] && s->channels[i].last_activity == (uint64_t)-1) s->channels[i].last_activity = f->ticker->time;
+			s->first_look = true;
+		}
+		mixer_release_held(f, s, true);
+		request_flush(f);
+		ms_filter_unlock(f);
+		return;
+	}
 	if (already_ran_this_tick(f)) { // the flush task pumped this mixer right behind the facades that feed it
 		ms_filter_unlock(f);
 		return;
@@ -324,7 +360,9 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 }
 
 int mixer_set_rate(MSFilter *f, void *data) {
-	((MixerState *)f->data)->rate = *(int *)data;
+	MixerState *s = (MixerState *)f->data;
+	if (s->fbank && s->rate != *(int *)data) s->unfuse_wanted = true;
+	s->rate = *(int *)data;
 	return 0;
 }
 int mixer_get_rate(MSFilter *f, void *data) {
@@ -332,7 +370,9 @@ int mixer_get_rate(MSFilter *f, void *data) {
 	return 0;
 }
 int mixer_set_nchannels(MSFilter *f, void *data) {
-	((MixerState *)f->data)->nchannels = *(int *)data;
+	MixerState *s = (MixerState *)f->data;
+	if (s->fbank && s->nchannels != *(int *)data) s->unfuse_wanted = true;
+	s->nchannels = *(int *)data;
 	return 0;
 }
 int mixer_get_nchannels(MSFilter *f, void *data) {
@@ -377,7 +417,9 @@ int mixer_enable_output(MSFilter *f, void *data) { // :395-408
 	return 0;
 }
 int mixer_set_conference_mode(MSFilter *f, void *data) {
-	((MixerState *)f->data)->conf_mode = *(int *)data;
+	MixerState *s = (MixerState *)f->data;
+	if (s->fbank && *(int *)data == 0) s->unfuse_wanted = true; // the fused batch mixes in conference mode only
+	s->conf_mode = *(int *)data;
 	return 0;
 }
 int mixer_set_master_channel(MSFilter *f, void *data) {

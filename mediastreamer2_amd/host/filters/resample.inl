@@ -31,7 +31,7 @@ struct ResamplePool : Pool {
 	~ResamplePool() override {
 		if (r) mi_resampler_destroy(r);
 	}
-	void flush() override {
+	bool enqueue() override {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
@@ -44,7 +44,9 @@ struct ResamplePool : Pool {
 			MI_MUST(mi_copy_d2h(ctx, h_out + r_ * c * ostride, d_out, u * ostride * 2));
 			MI_MUST(mi_copy_d2h(ctx, h_olen + r_ * c, d_olen, u * 4));
 		}
-		if (maxr) MI_MUST(mi_ctx_sync(ctx));
+		return maxr > 0;
+	}
+	void finish() override {
 		for (int s = 0; s < hi; ++s) {
 			ready[(size_t)s] = failed ? 0 : staged[(size_t)s]; // a failed launch delivers nothing (late event counted)
 			staged[(size_t)s] = 0;
@@ -61,6 +63,8 @@ struct ResampleData { // ResampleData msresample.c:33-42
 	ResamplePool *pool;
 	int slot;                 // first channel's slot (the one that emits)
 	std::vector<int> *slots;  // one batch slot per input channel (speex keeps one state per channel too)
+	FusedLeg *leg;            // the filter is the head of a fused call leg (filters/leg_chain.inl): its blocks go to that bank
+	bool fuse_checked;        // looked for a conference to fuse with since the last attach
 };
 
 void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
@@ -91,8 +95,16 @@ void resample_release(ResampleData *d) { // hub locked by the caller
 	d->slot = -1;
 }
 
+void resample_postprocess(MSFilter *f) { // detach: a fused conference goes back to its facades' own banks
+	ResampleData *d = (ResampleData *)f->data;
+	facade_detached(f);
+	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
+	d->fuse_checked = false;
+}
+
 void resample_uninit(MSFilter *f) {
 	ResampleData *d = (ResampleData *)f->data;
+	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
 	{
 		HubLock lk(f);
 		resample_release(d);
@@ -126,6 +138,19 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 		return;
 	}
 	ms_filter_lock(f);
+	if (!d->leg && !d->fuse_checked && !d->pool && f->ticker) { // first block since the attach: is this the head of a leg of a conference?
+		d->fuse_checked = true;
+		if (MSFilter *mx = leg_find_mixer(f)) {
+			HubLock lk(f);
+			conf_try_fuse(mx);
+		}
+	}
+	if (d->leg) { // fused: the block goes into the leg's row of the conference's bank, nothing is emitted here
+		HubLock lk(f, leg_pool(d->leg));
+		leg_stage_mic(f, d);
+		ms_filter_unlock(f);
+		return;
+	}
 	if (d->pool && d->pool->hub->ticker != f->ticker) { // the filter moved to another ticker: its slots go back under the OLD hub's lock
 		HubLock old(d->pool->hub);
 		resample_release(d);
@@ -211,6 +236,7 @@ void ResamplePool::emit(MSFilter *f, int slot) {
 int resample_set_sr(MSFilter *f, void *arg) { // :181-192
 	ResampleData *d = (ResampleData *)f->data;
 	ms_filter_lock(f);
+	if (d->input_rate != *(unsigned int *)arg) leg_disqualify(d->leg);
 	d->input_rate = *(unsigned int *)arg;
 	ms_filter_unlock(f);
 	return 0;
@@ -218,6 +244,7 @@ int resample_set_sr(MSFilter *f, void *arg) { // :181-192
 int resample_set_output_sr(MSFilter *f, void *arg) { // :194-205
 	ResampleData *d = (ResampleData *)f->data;
 	ms_filter_lock(f);
+	if (d->output_rate != *(unsigned int *)arg) leg_disqualify(d->leg);
 	d->output_rate = *(unsigned int *)arg;
 	ms_filter_unlock(f);
 	return 0;

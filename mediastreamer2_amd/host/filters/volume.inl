@@ -38,6 +38,8 @@ struct VolumePool : Pool {
 	mi_volume *v = nullptr;
 	int16_t *h_buf, *d_buf;
 	int32_t *h_n, *d_n;
+	mi_volume_state *h_state; // pinned: the meters come back with the blocks, no synchronisation of their own
+	bool fetched = false;
 	std::vector<int> staged, ready;
 	std::vector<mi_volume_params> params;
 	std::vector<mi_volume_state> state;
@@ -52,6 +54,7 @@ struct VolumePool : Pool {
 		h_n = pinned<int32_t>(kMaxRounds * c);
 		d_buf = devmem<int16_t>(c * cap_samples);
 		d_n = devmem<int32_t>(c);
+		h_state = pinned<mi_volume_state>(c);
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 		mi_volume_params p;
@@ -65,7 +68,7 @@ struct VolumePool : Pool {
 	~VolumePool() override {
 		if (v) mi_volume_destroy(v);
 	}
-	void flush() override {
+	bool enqueue() override {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		for (int s = 0; s < hi; ++s) {
@@ -83,10 +86,15 @@ struct VolumePool : Pool {
 			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
 			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
-		if (maxr) {
-			MI_MUST(mi_ctx_sync(ctx));
-			if (!failed) MI_MUST(mi_volume_get_state(v, 0, hi, state.data())); // meters for the app thread
-		}
+		fetched = maxr > 0 && !failed;
+		if (fetched) MI_MUST(mi_volume_get_state_async(v, 0, hi, h_state)); // meters for the app thread
+		return maxr > 0;
+	}
+	void finish() override {
+		if (fetched && !failed) // (a gain set by a method since the launch was enqueued is not overwritten: it is still dirty)
+			for (int s = 0; s < hi; ++s)
+				if (!state_dirty[(size_t)s]) state[(size_t)s] = h_state[s];
+		fetched = false;
 		for (int s = 0; s < hi; ++s) {
 			ready[(size_t)s] = staged[(size_t)s]; // after a failed launch the staged blocks leave as they came (unity gain)
 			staged[(size_t)s] = 0;
@@ -106,7 +114,11 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	VolumePool *pool;
 	int slot;
 	bool ng_soft_start;
+	FusedLeg *leg;  // the filter is part of a fused call leg (filters/leg_chain.inl): its meter lives in that bank
+	int peered_by;  // MSVolume filters that named this one as their echo-limiter peer (it must stay in a bank of its own kind)
 };
+mi_volume_state *leg_vstate(FusedLeg *leg);                      // leg_chain.inl
+void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, bool state_too);
 
 void volume_init(MSFilter *f) { // msvolume.c:88-118
 	VolumeData *d = new VolumeData();
@@ -121,11 +133,21 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->min.period = 30000;
 	d->pool = nullptr;
 	d->slot = -1;
+	d->leg = nullptr;
+	d->peered_by = 0;
 	f->data = d;
+}
+
+void volume_postprocess(MSFilter *f) { // detach: a fused conference goes back to its facades' own banks
+	VolumeData *d = (VolumeData *)f->data;
+	facade_detached(f);
+	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
 }
 
 void volume_uninit(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
+	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
+	if (d->peer) ((VolumeData *)d->peer->data)->peered_by--;
 	if (d->pool && d->slot >= 0) {
 		HubLock lk(f);
 		d->pool->release(d->slot);
@@ -135,9 +157,17 @@ void volume_uninit(MSFilter *f) {
 	delete d;
 }
 
-mi_volume_state *vstate(VolumeData *d) { return (d->pool && d->slot >= 0) ? &d->pool->state[(size_t)d->slot] : nullptr; }
+mi_volume_state *vstate(VolumeData *d) {
+	if (d->leg) return leg_vstate(d->leg);
+	return (d->pool && d->slot >= 0) ? &d->pool->state[(size_t)d->slot] : nullptr;
+}
 
 void volume_push_params(VolumeData *d) {
+	if (d->leg) {
+		leg_push_volume(d->leg, &d->p, false);
+		if (!d->p.agc_enabled) leg_disqualify(d->leg); // without AGC the reference meters block by block, not in 10 ms chunks
+		return;
+	}
 	if (!d->pool || d->slot < 0) return;
 	d->pool->params[(size_t)d->slot] = d->p;
 	d->pool->params_dirty[(size_t)d->slot] = 1;
@@ -145,6 +175,7 @@ void volume_push_params(VolumeData *d) {
 
 void volume_attach_slot(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
+	if (d->leg) return;
 	if (d->pool) { // rate changed, moved to another ticker, or the bank failed: the slot goes back (under ITS hub's lock)
 		HubLock old(f);
 		if (d->pool->failed || d->pool->rate != d->sample_rate || d->pool->hub->ticker != f->ticker) {
@@ -192,6 +223,10 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 
 void volume_process(MSFilter *f) { // msvolume.c:471-514
 	VolumeData *d = (VolumeData *)f->data;
+	if (d->leg) { // fused leg: the chunks are popped, metered and mixed on the device; nothing arrives on this queue
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
 	HubLock lk(f, d->pool);
 	if (!d->pool) volume_attach_slot(f);
 	if (!d->pool) {
@@ -292,6 +327,14 @@ int volume_get_max(MSFilter *f, void *arg) {
 	return 0;
 }
 void volume_set_gains(VolumeData *d, bool also_target) {
+	if (d->leg) {
+		HubLock lk(leg_pool(d->leg)->hub);
+		mi_volume_state *st = vstate(d);
+		st->gain = d->gain;
+		if (also_target) st->target_gain = d->target_gain;
+		leg_push_volume(d->leg, &d->p, true);
+		return;
+	}
 	if (!d->pool) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
 	HubLock lk(d->pool->hub);
 	mi_volume_state *st = vstate(d);
@@ -324,12 +367,21 @@ int volume_get_gain_db(MSFilter *f, void *arg) {
 }
 int volume_set_peer(MSFilter *f, void *arg) { // :292-297 stores the MSFilter*
 	VolumeData *d = (VolumeData *)f->data;
+	if (d->peer) ((VolumeData *)d->peer->data)->peered_by--;
 	d->peer = (MSFilter *)arg;
+	if (d->peer) {
+		VolumeData *pd = (VolumeData *)d->peer->data;
+		pd->peered_by++;
+		leg_disqualify(pd->leg); // the echo limiter reads its peer's meter of the previous tick: both in one plain bank
+	}
+	leg_disqualify(d->leg);
 	if (d->pool) volume_attach_slot(f);
 	return 0;
 }
 int volume_set_rate(MSFilter *f, void *arg) {
-	((VolumeData *)f->data)->sample_rate = *(int *)arg;
+	VolumeData *d = (VolumeData *)f->data;
+	if (d->sample_rate != *(int *)arg) leg_disqualify(d->leg);
+	d->sample_rate = *(int *)arg;
 	return 0;
 }
 #define VOL_FLOAT_SETTER(name, field, check)                       \

@@ -1,0 +1,297 @@
+"""Conference graphs of the plugin's facades in the test runtime (tests/host/ms2shim.c), as the reference builds a call
+leg's sending side (src/voip/audiostream.c:1798-1810) in front of a conference mixer (src/voip/audioconference.c:209-257):
+
+    mic source -> MSResample (16k -> 48k) -> MSSpeexEC pin 1 -> MSVolume (AGC) -> MSAudioMixer pin k -> sink k
+    far-end source -------------------------> MSSpeexEC pin 0 -> speaker sink
+
+run twice on the same inputs -- with the fused call-leg batch (mediastreamer2_amd/host/filters/leg_chain.inl) and with
+MSMI355X_NO_FUSE=1 (every facade on its own bank: the path the oracle tests pin) -- for tests/test_gpu_plugin_fused.py (the
+product plugin on the GPU) and tests/test_plugin_fused_cpu.py (the same host code against the host-memory double of the
+kernel library: `python tests/fused_graph.py --double` in a process of its own)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "host")
+
+MS_SPEEX_EC_ID, MS_RESAMPLE_ID, MS_VOLUME_ID, MS_AUDIO_MIXER_ID = 28, 41, 43, 68
+MS_FILTER_BASE_ID = 2
+EC_IFACE = 16384 + 4
+
+
+def mid(fid, idx, argsize):
+    return ((fid & 0xFFFF) << 16) | (idx << 8) | (argsize & 0xFF)
+
+
+def _method_ids():
+    """the method ids as include/ms2_plugin_abi.h spells them (the header is the contract; indices are not guessed)"""
+    import re
+    txt = open(os.path.join(ROOT, "include", "ms2_plugin_abi.h")).read()
+    owner = {"MS_VOLUME_ID": MS_VOLUME_ID, "MS_AUDIO_MIXER_ID": MS_AUDIO_MIXER_ID, "MSFilterEchoCancellerInterface": EC_IFACE}
+    size = {"int": 4, "float": 4, "bool_t": 1, "char *": 8, "const char": 1}
+    out = {}
+    for name, idx, typ in re.findall(r"#define\s+(MS_\w+)\s+MS_FILTER_BASE_METHOD\(\s*(\d+)\s*,\s*([\w \*]+?)\s*\)", txt):
+        if typ in size:
+            out[name] = mid(MS_FILTER_BASE_ID, int(idx), size[typ])
+    for name, own, idx, typ in re.findall(r"#define\s+(MS_\w+)\s+MS_FILTER_METHOD\(\s*(\w+)\s*,\s*(\d+)\s*,\s*([\w \*]+?)\s*\)", txt):
+        if own in owner and typ in size:
+            out[name] = mid(owner[own], int(idx), size[typ])
+    return out
+
+
+IDS = _method_ids()
+EC_SET_TAIL = IDS["MS_ECHO_CANCELLER_SET_TAIL_LENGTH"]
+EC_SET_DELAY = IDS["MS_ECHO_CANCELLER_SET_DELAY"]
+EC_SET_BYPASS = IDS["MS_ECHO_CANCELLER_SET_BYPASS_MODE"]
+VOL_SET_GAIN = IDS["MS_VOLUME_SET_GAIN"]
+VOL_GET_LINEAR = IDS["MS_VOLUME_GET_LINEAR"]
+VOL_ENABLE_AGC = IDS["MS_VOLUME_ENABLE_AGC"]
+MIX_CONF_MODE = IDS["MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE"]
+
+
+class Host:
+    """ctypes view of the shim runtime with the plugin loaded (product or double build)"""
+
+    def __init__(self, plugin_dir):
+        self.S = S = C.CDLL(os.path.join(HOST, "libms2shim.so"), mode=C.RTLD_GLOBAL)
+        vp = C.c_void_p
+        for fn in ("ms_factory_new", "ms_factory_create_filter", "ms_ticker_new", "ms2shim_new_source", "ms2shim_new_sink"):
+            getattr(S, fn).restype = vp
+        S.ms_factory_create_filter.argtypes = [vp, C.c_int]
+        S.ms_factory_load_plugin.argtypes = [vp, C.c_char_p]
+        S.ms2shim_register_test_filters.argtypes = [vp]
+        S.ms2shim_new_source.argtypes = [vp]
+        S.ms2shim_new_sink.argtypes = [vp]
+        S.ms2shim_source_push.argtypes = [vp, vp, C.c_size_t]
+        S.ms2shim_source_set_burst.argtypes = [vp, C.c_int]
+        S.ms2shim_sink_read.restype = C.c_size_t
+        S.ms2shim_sink_read.argtypes = [vp, vp, C.c_size_t]
+        S.ms2shim_sink_size.restype = C.c_size_t
+        S.ms2shim_sink_size.argtypes = [vp]
+        S.ms2shim_sink_blocks.argtypes = [vp]
+        S.ms_filter_link.argtypes = [vp, C.c_int, vp, C.c_int]
+        S.ms_filter_call_method.argtypes = [vp, C.c_uint, vp]
+        S.ms_filter_destroy.argtypes = [vp]
+        S.ms_ticker_attach.argtypes = [vp, vp]
+        S.ms_ticker_detach.argtypes = [vp, vp]
+        S.ms_ticker_step.argtypes = [vp]
+        S.ms_ticker_destroy.argtypes = [vp]
+        self.fac = S.ms_factory_new()
+        S.ms2shim_register_test_filters(self.fac)
+        plugin = os.path.join(plugin_dir, "libmsmi355xfilters.so")
+        assert S.ms_factory_load_plugin(self.fac, plugin.encode()) == 0
+        self.P = C.CDLL(plugin)
+        self.P.ms_mi355x_late_events.restype = C.c_ulonglong
+
+    def fused_stats(self):
+        c, l = C.c_int(), C.c_int()
+        la, fr = C.c_ulonglong(), C.c_ulonglong()
+        self.P.ms_mi355x_fused_stats(C.byref(c), C.byref(l), C.byref(la), C.byref(fr))
+        return {"conferences": c.value, "legs": l.value, "launches": la.value, "flush_rounds": fr.value}
+
+    def runtime_stats(self):
+        h, b, s = C.c_int(), C.c_int(), C.c_int()
+        self.P.ms_mi355x_runtime_stats(C.byref(h), C.byref(b), C.byref(s))
+        return h.value, b.value, s.value
+
+    def call_int(self, f, method, val):
+        v = C.c_int(val)
+        return self.S.ms_filter_call_method(f, method, C.byref(v))
+
+    def call_float(self, f, method, val):
+        v = C.c_float(val)
+        return self.S.ms_filter_call_method(f, method, C.byref(v))
+
+    def call_bool(self, f, method, val):
+        v = C.c_ubyte(val)
+        return self.S.ms_filter_call_method(f, method, C.byref(v))
+
+    def get_float(self, f, method):
+        v = C.c_float()
+        assert self.S.ms_filter_call_method(f, method, C.byref(v)) == 0
+        return v.value
+
+    def push(self, src, samples):
+        a = np.ascontiguousarray(samples, np.int16)
+        self.S.ms2shim_source_push(src, a.ctypes.data, a.nbytes)
+
+    def drain(self, sink):
+        n = self.S.ms2shim_sink_size(sink)
+        buf = np.zeros(n // 2, np.int16)
+        if n:
+            self.S.ms2shim_sink_read(sink, buf.ctypes.data, n)
+        return buf
+
+
+class Conferences:
+    """nconf conferences of `members` legs each on one ticker"""
+
+    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None):
+        self.h, self.S = h, h.S
+        S = h.S
+        self.ticker = S.ms_ticker_new()
+        self.nconf, self.members, self.in_rate, self.rate = nconf, members, in_rate, rate
+        self.pins = list(range(members)) if pins is None else list(pins)
+        base = lambda name: IDS[name]
+        self.legs, self.mixers = [], []
+        for c in range(nconf):
+            mx = S.ms_factory_create_filter(h.fac, MS_AUDIO_MIXER_ID)
+            h.call_int(mx, base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+            h.call_int(mx, MIX_CONF_MODE, 1)
+            self.mixers.append(mx)
+            for k in range(members):
+                leg = {"mic": S.ms2shim_new_source(h.fac), "far": S.ms2shim_new_source(h.fac), "spk": S.ms2shim_new_sink(h.fac),
+                       "out": S.ms2shim_new_sink(h.fac), "rs": S.ms_factory_create_filter(h.fac, MS_RESAMPLE_ID),
+                       "ec": S.ms_factory_create_filter(h.fac, MS_SPEEX_EC_ID), "vol": S.ms_factory_create_filter(h.fac, MS_VOLUME_ID),
+                       "mixer": mx, "pin": self.pins[k]}
+                h.call_int(leg["rs"], base("MS_FILTER_SET_SAMPLE_RATE"), in_rate)
+                h.call_int(leg["rs"], base("MS_FILTER_SET_OUTPUT_SAMPLE_RATE"), rate)
+                h.call_int(leg["ec"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                h.call_int(leg["ec"], EC_SET_TAIL, tail_ms)
+                h.call_int(leg["ec"], EC_SET_DELAY, delay_ms)
+                h.call_int(leg["vol"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                if agc:
+                    h.call_int(leg["vol"], VOL_ENABLE_AGC, 1)
+                if gain is not None:
+                    h.call_float(leg["vol"], VOL_SET_GAIN, gain)
+                for a, pa, b, pb in ((leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1), (leg["ec"], 1, leg["vol"], 0),
+                                     (leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0), (leg["far"], 0, leg["ec"], 0),
+                                     (leg["ec"], 0, leg["spk"], 0)):
+                    assert S.ms_filter_link(a, pa, b, pb) == 0
+                self.legs.append(leg)
+        self.attached = False
+
+    def attach(self):
+        for c in range(self.nconf):
+            self.S.ms_ticker_attach(self.ticker, self.mixers[c])
+        self.attached = True
+
+    def detach(self):
+        for c in range(self.nconf):
+            self.S.ms_ticker_detach(self.ticker, self.mixers[c])
+        self.attached = False
+
+    def step(self, n=1):
+        for _ in range(n):
+            self.S.ms_ticker_step(self.ticker)
+
+    def close(self):
+        if self.attached:
+            self.detach()
+        for leg in self.legs:
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol"):
+                self.S.ms_filter_destroy(leg[k])
+        for mx in self.mixers:
+            self.S.ms_filter_destroy(mx)
+        self.S.ms_ticker_destroy(self.ticker)
+
+
+def scene(nlegs, nticks, in_rate, rate, seed=7):
+    """per leg: far end (noise + tone) at `rate`, microphone = 0.5 x the far end 20 ms late + near-end noise, at in_rate"""
+    rng = np.random.default_rng(seed)
+    ns, ni = rate // 100, in_rate // 100
+    t = np.arange(nticks * ns)
+    far = (rng.normal(0, 3000, (nlegs, nticks * ns)) + 3276 * np.sin(2 * np.pi * 1000 * t / rate)).round().clip(-32767, 32767).astype(np.int16)
+    late = np.concatenate([np.zeros((nlegs, ns * 2), np.int16), far[:, :-ns * 2]], axis=1).astype(np.float64)
+    q = rate // in_rate
+    mic = (0.5 * late.reshape(nlegs, -1, q).mean(axis=2) + rng.normal(0, 300, (nlegs, nticks * ni))).round().clip(-32767, 32767).astype(np.int16)
+    return mic, far
+
+
+def run(plugin_dir, fuse, scenario, h=None):
+    """one scenario, returns {"out": [per leg int16], "spk": [...], "stats": ..}"""
+    if fuse:
+        os.environ.pop("MSMI355X_NO_FUSE", None)
+    else:
+        os.environ["MSMI355X_NO_FUSE"] = "1"
+    os.environ["MSMI355X_CHECK_LEVELS"] = "1"
+    h = h or Host(plugin_dir)
+    sc = dict(nconf=2, members=4, nticks=120, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, pins=None)
+    sc.update(scenario)
+    conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
+                       gain=sc.get("gain"))
+    n = sc["nconf"] * sc["members"]
+    nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
+    mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
+    late0 = h.P.ms_mi355x_late_events()
+    conf.attach()
+    mid_stats = None
+    for t in range(nt):
+        for s, leg in enumerate(conf.legs):
+            # microphone: 10 ms blocks, or 20 ms packets every other tick (ptime 20)
+            if sc.get("ptime20"):
+                if t % 2 == 0:
+                    h.push(leg["mic"], mic[s, t * ni:(t + 2) * ni])
+                else:
+                    h.push(leg["mic"], np.zeros(0, np.int16))
+            else:
+                h.push(leg["mic"], mic[s, t * ni:(t + 1) * ni])
+            # far end: regular, or with a late packet every 17th tick per leg (nothing, then two blocks at once)
+            if sc.get("far_gaps") and (t + 3 * s) % 17 == 5:
+                h.push(leg["far"], np.zeros(0, np.int16))
+            elif sc.get("far_gaps") and (t + 3 * s) % 17 == 6:
+                h.push(leg["far"], far[s, (t - 1) * ns:(t + 1) * ns])
+            else:
+                h.push(leg["far"], far[s, t * ns:(t + 1) * ns])
+        for ev in sc.get("events", []):
+            if ev[0] == t:
+                kind, s, val = ev[1], ev[2], ev[3]
+                leg = conf.legs[s]
+                if kind == "gain":
+                    h.call_float(leg["vol"], VOL_SET_GAIN, val)
+                elif kind == "bypass":
+                    h.call_bool(leg["ec"], EC_SET_BYPASS, val)
+                elif kind == "agc":
+                    h.call_int(leg["vol"], VOL_ENABLE_AGC, val)
+                elif kind == "reattach":
+                    conf.detach()
+                    conf.attach()
+        conf.step()
+        if t == nt // 2:
+            mid_stats = h.fused_stats()
+    levels = [h.get_float(leg["vol"], VOL_GET_LINEAR) for leg in conf.legs]
+    res = {"out": [h.drain(leg["out"]) for leg in conf.legs], "spk": [h.drain(leg["spk"]) for leg in conf.legs], "stats": mid_stats,
+           "late": h.P.ms_mi355x_late_events() - late0, "levels": levels}
+    conf.close()
+    res["after"] = h.runtime_stats()
+    return res
+
+
+SCENARIOS = {
+    "plain": {},
+    "delay_and_far_gaps": {"delay_ms": 20, "far_gaps": True, "nticks": 150},
+    "ptime20": {"ptime20": True, "nticks": 100},
+    "odd_pins": {"members": 3, "pins": [0, 5, 9], "nconf": 3, "tail_ms": 64},
+    "gain_method": {"events": [(40, "gain", 1, 0.5), (70, "gain", 5, 2.0)]},
+    "wideband_8k_16k": {"in_rate": 8000, "rate": 16000, "tail_ms": 128, "nticks": 100},
+}
+
+
+def compare(a, b):
+    """fused result a against the facades one by one b: every leg's mix and speaker audio, bit for bit"""
+    bad = []
+    for k in ("out", "spk"):
+        for s, (x, y) in enumerate(zip(a[k], b[k])):
+            if len(x) != len(y) or not np.array_equal(x, y):
+                n = min(len(x), len(y))
+                first = int(np.argmax(x[:n] != y[:n])) if n and (x[:n] != y[:n]).any() else n
+                bad.append((k, s, len(x), len(y), first))
+    return bad
+
+
+if __name__ == "__main__":
+    d = os.path.join(HOST, "double") if "--double" in sys.argv else os.path.join(ROOT, "mediastreamer2_amd")
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(SCENARIOS)
+    h = Host(d)
+    verdict = {}
+    for name in names:
+        fused = run(d, True, SCENARIOS[name], h)
+        plain = run(d, False, SCENARIOS[name], h)
+        verdict[name] = {"bad": compare(fused, plain), "fused_stats": fused["stats"], "plain_stats": plain["stats"], "late": [fused["late"], plain["late"]],
+                         "samples": int(sum(len(x) for x in fused["out"])), "nonzero": bool(any(x.any() for x in fused["out"])),
+                         "levels_equal": bool(np.allclose(fused["levels"], plain["levels"], rtol=0, atol=0)), "after": [fused["after"], plain["after"]]}
+    print(json.dumps(verdict))

@@ -399,6 +399,7 @@ int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h) 
 	std::copy(v->state.begin() + first, v->state.begin() + first + count, h);
 	return MI_OK;
 }
+int mi_volume_get_state_async(mi_volume *v, int first, int count, mi_volume_state *h) { return mi_volume_get_state(v, first, count, h); }
 int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_state *h) {
 	ARG(v && h && first >= 0 && count >= 0 && first + count <= v->n);
 	std::copy(h, h + count, v->state.begin() + first);
@@ -529,12 +530,57 @@ int mi_aec_process_frames(mi_aec *a, const int16_t *mic, const int16_t *ref, int
 	}
 	return MI_OK;
 }
-int mi_aec_process_fifos(mi_aec *, mi_fifo *, const int16_t *, int, mi_fifo *, const int16_t *, int, const int32_t *, int, mi_fifo *, int, unsigned, uint8_t *) {
-	return fail(MI_ENOTSUP, "the FIFO entry is not modelled by the double");
+// The FIFO entry: both blocks queued, every whole frame the microphone queue then holds (<= maxf) "cancelled" -- the double
+// passes the microphone frame through, like its frame entry -- against the far end's frame or silence, results queued.
+static void fifo_put(mi_fifo *f, int s, const int16_t *p, int n);
+static int aec_fifo_tick(mi_aec *a, mi_fifo *fm, const int16_t *mic, int mic_stride, int mic_len, mi_fifo *fr, const int16_t *ref, int ref_stride,
+                         const int32_t *ref_len, int tick_len, mi_fifo *fo, int maxf, uint8_t *count_out, const uint8_t *gate) {
+	for (int s = 0; s < a->n; ++s) {
+		if (!gate || gate[s]) fifo_put(fm, s, mic + (size_t)s * mic_stride, mic_len);
+		const int rl = ref_len ? std::min(std::max(ref_len[s], 0), tick_len) : tick_len;
+		fifo_put(fr, s, ref + (size_t)s * ref_stride, rl);
+		std::vector<int16_t> &qm = fm->q[(size_t)s], &qr = fr->q[(size_t)s];
+		int nf = std::min(maxf, (int)qm.size() / a->F);
+		if ((int)fo->q[(size_t)s].size() + nf * a->F > fo->cap) {
+			fo->overflow++;
+			nf = 0;
+		}
+		for (int k = 0; k < nf; ++k) {
+			fifo_put(fo, s, qm.data(), a->F);
+			qm.erase(qm.begin(), qm.begin() + a->F);
+			if ((int)qr.size() >= a->F) qr.erase(qr.begin(), qr.begin() + a->F);
+		}
+		a->frames[(size_t)s] += nf;
+		if (count_out) count_out[s] = (uint8_t)nf;
+	}
+	return MI_OK;
 }
-int mi_aec_process_fifos_resampled(mi_aec *, mi_resampler *, const int16_t *, int, int, mi_fifo *, mi_fifo *, const int16_t *, int, const int32_t *,
-                                   mi_fifo *, int, unsigned, uint8_t *) {
-	return fail(MI_ENOTSUP, "the FIFO entry is not modelled by the double");
+int mi_aec_process_fifos_masked(mi_aec *a, mi_fifo *fm, const int16_t *mic, int mic_stride, mi_fifo *fr, const int16_t *ref, int ref_stride, const int32_t *ref_len,
+                                int tick_len, mi_fifo *fo, int maxf, unsigned, uint8_t *count_out, const uint8_t *gate) {
+	ARG(a && fm && fr && fo && mic && ref && tick_len > 0 && mic_stride >= tick_len && ref_stride >= tick_len && maxf >= 1 && maxf <= MI_AEC_MAX_TICK_FRAMES);
+	ARG(fm->n == a->n && fr->n == a->n && fo->n == a->n);
+	return aec_fifo_tick(a, fm, mic, mic_stride, tick_len, fr, ref, ref_stride, ref_len, tick_len, fo, maxf, count_out, gate);
+}
+int mi_aec_process_fifos(mi_aec *a, mi_fifo *fm, const int16_t *mic, int mic_stride, mi_fifo *fr, const int16_t *ref, int ref_stride, const int32_t *ref_len,
+                         int tick_len, mi_fifo *fo, int maxf, unsigned flags, uint8_t *count_out) {
+	return mi_aec_process_fifos_masked(a, fm, mic, mic_stride, fr, ref, ref_stride, ref_len, tick_len, fo, maxf, flags, count_out, nullptr);
+}
+int mi_aec_process_fifos_resampled_masked(mi_aec *a, mi_resampler *rs, const int16_t *mic_in, int in_len, int in_stride, mi_fifo *fm, mi_fifo *fr,
+                                          const int16_t *ref, int ref_stride, const int32_t *ref_len, mi_fifo *fo, int maxf, unsigned, uint8_t *count_out,
+                                          const uint8_t *gate) {
+	ARG(a && rs && mic_in && fm && fr && fo && ref && in_len > 0 && in_stride >= in_len && maxf >= 1 && maxf <= MI_AEC_MAX_TICK_FRAMES);
+	ARG(fm->n == a->n && fr->n == a->n && fo->n == a->n && rs->n == a->n);
+	if (rs->out_rate % rs->in_rate) return fail(MI_ENOTSUP, "integer ratios only");
+	const int tick_len = (int)((uint64_t)in_len * rs->out_rate / rs->in_rate);
+	ARG(ref_stride >= tick_len);
+	std::vector<int16_t> up((size_t)a->n * tick_len);
+	const int rc = mi_resampler_process_masked(rs, mic_in, in_len, in_stride, up.data(), tick_len, nullptr, gate); // the double's own up-sampler
+	if (rc != MI_OK) return rc;
+	return aec_fifo_tick(a, fm, up.data(), tick_len, tick_len, fr, ref, ref_stride, ref_len, tick_len, fo, maxf, count_out, gate);
+}
+int mi_aec_process_fifos_resampled(mi_aec *a, mi_resampler *rs, const int16_t *mic_in, int in_len, int in_stride, mi_fifo *fm, mi_fifo *fr, const int16_t *ref,
+                                   int ref_stride, const int32_t *ref_len, mi_fifo *fo, int maxf, unsigned flags, uint8_t *count_out) {
+	return mi_aec_process_fifos_resampled_masked(a, rs, mic_in, in_len, in_stride, fm, fr, ref, ref_stride, ref_len, fo, maxf, flags, count_out, nullptr);
 }
 int mi_aec_stagger_info(const mi_aec *a, int tick_len, int *unit, int *phases) {
 	ARG(a && tick_len > 0);
@@ -672,6 +718,15 @@ int mi_fifo_pop_frames(mi_fifo *, int, int, int16_t *, int, uint8_t *, const uin
 int mi_fifo_push_frames(mi_fifo *, const int16_t *, int, int, int, const uint8_t *) { return fail(MI_ENOTSUP, "not modelled by the double"); }
 int mi_fifo_push_lead(mi_fifo *, int, int, int, int) { return fail(MI_ENOTSUP, "not modelled by the double"); }
 int mi_fifo_phase_of(int stream, int phases) { return phases > 0 ? (int)((((unsigned)stream * 0x9E3779B1u) >> 16) % (unsigned)phases) : 0; }
+int mi_fifo_push_silence(mi_fifo *f, const int32_t *count) {
+	ARG(f && count);
+	for (int s = 0; s < f->n; ++s)
+		if (count[s] > 0) {
+			const std::vector<int16_t> z((size_t)count[s], 0);
+			fifo_put(f, s, z.data(), count[s]);
+		}
+	return MI_OK;
+}
 int mi_fifo_levels(mi_fifo *f, int32_t *lv) {
 	ARG(f && lv);
 	for (int s = 0; s < f->n; ++s) lv[s] = (int32_t)f->q[(size_t)s].size();
@@ -711,11 +766,20 @@ int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f, int16_t *out, int ns,
 	}
 	return MI_OK;
 }
-int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out) {
+int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out, unsigned flags) {
 	ARG(m && v && f && out && first >= 0 && first + m->nconf * m->mm <= v->n && f->n == v->n);
 	std::vector<int16_t> ticks((size_t)v->n * m->ns);
-	const int rc = mi_volume_process_fifo_range(v, f, ticks.data(), m->ns, m->ns, first, m->nconf * m->mm);
+	std::vector<int32_t> per((size_t)v->n, 0);
+	for (int s = first; s < first + m->nconf * m->mm; ++s) { // a dry leg is metered on silence, or (MI_VOLMIX_DRY_SKIPS) not at all
+		const bool has = (int)f->q[(size_t)s].size() >= m->ns;
+		per[(size_t)s] = (has || !(flags & MI_VOLMIX_DRY_SKIPS)) ? m->ns : 0;
+	}
+	int rc = mi_volume_process_fifo_range(v, f, ticks.data(), m->ns, m->ns, first, m->nconf * m->mm); // pops (zeros for the dry ones)
+	if (rc == MI_OK) rc = mi_volume_process(v, ticks.data(), m->ns, m->ns, per.data());
 	return rc != MI_OK ? rc : mi_mixer_process(m, ticks.data() + (size_t)first * m->ns, nullptr, 1, out);
+}
+int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out) {
+	return mi_mixer_process_volume_fifo_flags(m, v, first, f, out, 0u);
 }
 
 // ---- codecs and friends

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ misc */
 void *ms_malloc0(size_t sz) { return calloc(1, sz ? sz : 1); }
@@ -46,9 +47,25 @@ mblk_t *allocb(size_t size, int unused) {
 	return m;
 }
 
+mblk_t *esballoc(uint8_t *buf, size_t size, int pri, void (*freefn)(void *)) { /* ortp str_utils.c */
+	(void)pri;
+	mblk_t *m = (mblk_t *)calloc(1, sizeof(mblk_t));
+	dblk_t *d = (dblk_t *)malloc(sizeof(dblk_t));
+	d->db_base = buf;
+	d->db_lim = buf + size;
+	d->db_freefn = freefn;
+	d->db_ref = 1;
+	m->b_datap = d;
+	m->b_rptr = m->b_wptr = buf;
+	return m;
+}
+
 void freeb(mblk_t *m) {
 	if (!m) return;
-	if (m->b_datap && --m->b_datap->db_ref == 0) free(m->b_datap);
+	if (m->b_datap && __atomic_sub_fetch(&m->b_datap->db_ref, 1, __ATOMIC_ACQ_REL) == 0) {
+		if (m->b_datap->db_freefn) m->b_datap->db_freefn(m->b_datap->db_base); /* dblk_unref: the caller's buffer goes back to its owner */
+		free(m->b_datap);
+	}
 	free(m);
 }
 
@@ -62,7 +79,7 @@ void freemsg(mblk_t *m) {
 
 mblk_t *dupb(mblk_t *m) {
 	mblk_t *n = (mblk_t *)calloc(1, sizeof(mblk_t));
-	m->b_datap->db_ref++;
+	__atomic_add_fetch(&m->b_datap->db_ref, 1, __ATOMIC_ACQ_REL);
 	n->b_datap = m->b_datap;
 	n->b_rptr = m->b_rptr;
 	n->b_wptr = m->b_wptr;
@@ -463,6 +480,7 @@ typedef struct TickerImpl {
 	MSFilter **filters; /* every filter of the attached graphs */
 	int nfilters, cap;
 	Task *tasks;
+	uint64_t tasks_ns, step_ns; /* the last step, by phase */
 } TickerImpl;
 
 static void ti_add(TickerImpl *ti, MSFilter *f) {
@@ -603,10 +621,17 @@ static void run_graph(MSFilter *f, MSTicker *t, MSFilter **unsched, int *nunsche
 	}
 }
 
+static uint64_t now_ns(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
 void ms_ticker_step(MSTicker *t) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	MSFilter *unsched[256];
 	int nunsched = 0;
+	const uint64_t t0 = now_ns();
 	t->ticks++;
 	/* run_tasks msticker.c:301-312: postponed tasks run before the graphs */
 	Task *tasks = ti->tasks;
@@ -618,11 +643,19 @@ void ms_ticker_step(MSTicker *t) {
 		free(tasks);
 		tasks = n;
 	}
+	ti->tasks_ns = now_ns() - t0;
 	for (int i = 0; i < ti->nfilters; ++i)
 		if (ti->filters[i]->desc->ninputs == 0) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
 	/* filters inside loops: scheduled anyway on a second pass (msticker.c:284-299) */
 	for (int i = 0, n = nunsched, dummy = 0; i < n; ++i) run_graph(unsched[i], t, unsched, &dummy, 1);
 	t->time += (uint64_t)t->interval;
+	ti->step_ns = now_ns() - t0;
+}
+/* the last step: ns in the postponed tasks (the plugin's flush) and in the whole step (tasks + graph walk) */
+void ms2shim_ticker_last_step(MSTicker *t, uint64_t *tasks_ns, uint64_t *step_ns) {
+	TickerImpl *ti = (TickerImpl *)t->impl;
+	if (tasks_ns) *tasks_ns = ti->tasks_ns;
+	if (step_ns) *step_ns = ti->step_ns;
 }
 
 /* -------------------------------------------------- test source / sink filters
@@ -633,6 +666,11 @@ void ms_ticker_step(MSTicker *t) {
 typedef struct {
 	queue_t pending; /* blocks the test queued; one is emitted per tick ... */
 	int burst;       /* ... or all of them (an RTP receiver after a network hiccup) */
+	/* loop mode (rate measurements): every tick a fresh block of loop_bytes copied from a shared ring of loop_n blocks --
+	 * what a decoder behind an RTP receiver does every tick, allocation included */
+	const uint8_t *loop_ring;
+	size_t loop_bytes;
+	int loop_n, loop_at;
 } SrcData;
 typedef struct {
 	uint8_t *buf;
@@ -655,9 +693,18 @@ static void src_uninit(MSFilter *f) {
 static void src_process(MSFilter *f) {
 	SrcData *d = (SrcData *)f->data;
 	mblk_t *m;
-	while ((m = getq(&d->pending)) != NULL) {
+	if (d->loop_ring) {
+		m = allocb(d->loop_bytes, 0);
+		memcpy(m->b_wptr, d->loop_ring + (size_t)d->loop_at * d->loop_bytes, d->loop_bytes);
+		m->b_wptr += d->loop_bytes;
+		if (++d->loop_at == d->loop_n) d->loop_at = 0;
 		if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
 		else freemsg(m);
+		return;
+	}
+	while ((m = getq(&d->pending)) != NULL) {
+		if (f->outputs[0] && msgdsize(m) > 0) ms_queue_put(f->outputs[0], m);
+		else freemsg(m); /* an empty block = a tick in which the source delivers nothing (a late packet) */
 		if (!d->burst) break;
 	}
 }
@@ -707,6 +754,14 @@ void ms2shim_register_test_filters(MSFactory *f) {
 MSFilter *ms2shim_new_source(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SOURCE_ID); }
 MSFilter *ms2shim_new_sink(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SINK_ID); }
 void ms2shim_source_set_burst(MSFilter *src, int burst) { ((SrcData *)src->data)->burst = burst; }
+/* the ring stays the caller's; phase = the block the source starts with */
+void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase) {
+	SrcData *d = (SrcData *)src->data;
+	d->loop_ring = (const uint8_t *)ring;
+	d->loop_bytes = block_bytes;
+	d->loop_n = nblocks;
+	d->loop_at = nblocks > 0 ? phase % nblocks : 0;
+}
 void ms2shim_source_push(MSFilter *src, const void *data, size_t nbytes) {
 	SrcData *d = (SrcData *)src->data;
 	mblk_t *m = allocb(nbytes, 0);

@@ -1,0 +1,231 @@
+/* plugin_bench.c -- TEST / MEASUREMENT INFRASTRUCTURE (not part of the product).
+ *
+ * How many full call legs does a mediastreamer2-shaped process carry through the DROP-IN PLUGIN?  N legs of
+ *
+ *     mic source (16 kHz) -> MSResample 16k->48k -> MSSpeexEC (128 ms tail) pin 1 -> MSVolume (AGC) -> MSAudioMixer pin k
+ *     far-end source (48 kHz) --------------------> MSSpeexEC pin 0 -> speaker sink;   mixer pin k -> sink
+ *
+ * (the sending side of src/voip/audiostream.c:1798-1810 in front of a conference mixer, conferences of 32) on T tickers of
+ * the test runtime (tests/host/ms2shim.c: the reference's one-thread-per-MSTicker model, src/base/msticker.c:448-524), the
+ * filters created by id through the factory after libmsmi355xfilters_init() registered the plugin's descriptors -- exactly
+ * what a mediastreamer2 process does.  Every tick every ticker thread runs its postponed tasks (the plugin's flush) and
+ * walks its graphs; all tickers tick together (a barrier stands in for the wall clock), a tick costs what the slowest
+ * ticker needs.  Prints one JSON object.
+ *
+ *   plugin_bench <plugin.so> <legs> <tickers> <ticks> <warmup> [members=32]
+ */
+#include "../../include/ms2_plugin_abi.h"
+
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+MSFactory *ms_factory_new(void);
+int ms_factory_load_plugin(MSFactory *f, const char *path);
+MSFilter *ms_factory_create_filter(MSFactory *f, MSFilterId id);
+int ms_filter_link(MSFilter *f1, int pin1, MSFilter *f2, int pin2);
+int ms_filter_call_method(MSFilter *f, unsigned int id, void *arg);
+MSTicker *ms_ticker_new(void);
+int ms_ticker_attach(MSTicker *t, MSFilter *f);
+int ms_ticker_detach(MSTicker *t, MSFilter *f);
+void ms_ticker_step(MSTicker *t);
+void ms2shim_register_test_filters(MSFactory *f);
+MSFilter *ms2shim_new_source(MSFactory *f);
+MSFilter *ms2shim_new_sink(MSFactory *f);
+void ms2shim_sink_set_discard(MSFilter *f, int on);
+void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase);
+void ms2shim_ticker_last_step(MSTicker *t, uint64_t *tasks_ns, uint64_t *step_ns);
+size_t ms2shim_sink_size(MSFilter *sink);
+int ms2shim_sink_blocks(MSFilter *sink);
+
+#define RING 16
+static int16_t g_mic[RING][160], g_far[RING][480];
+
+typedef struct {
+	MSTicker *ticker;
+	MSFilter **mixers;
+	MSFilter *probe_out; /* one mixer output sink: did audio arrive? */
+	int nconf, index;
+	double *step_ms, *task_ms;
+} TickerJob;
+
+static MSFactory *g_fac;
+static int g_members = 32, g_ticks, g_warmup, g_tickers;
+static pthread_barrier_t g_bar;
+
+static double now_ms(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+static void call_int(MSFilter *f, unsigned id, int v) { ms_filter_call_method(f, id, &v); }
+
+static void build(TickerJob *j) {
+	j->ticker = ms_ticker_new();
+	j->mixers = (MSFilter **)calloc((size_t)j->nconf, sizeof(MSFilter *));
+	for (int c = 0; c < j->nconf; ++c) {
+		MSFilter *mx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+		call_int(mx, MS_FILTER_SET_SAMPLE_RATE, 48000);
+		call_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
+		j->mixers[c] = mx;
+		for (int k = 0; k < g_members; ++k) {
+			MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
+			MSFilter *rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
+			MSFilter *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+			const int leg = (j->index * j->nconf + c) * g_members + k;
+			ms2shim_source_set_loop(mic, g_mic, sizeof(g_mic[0]), RING, leg);
+			ms2shim_source_set_loop(far, g_far, sizeof(g_far[0]), RING, leg * 7);
+			ms2shim_sink_set_discard(spk, 1);
+			ms2shim_sink_set_discard(out, 1);
+			call_int(rs, MS_FILTER_SET_SAMPLE_RATE, 16000);
+			call_int(rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
+			call_int(ec, MS_FILTER_SET_SAMPLE_RATE, 48000);
+			call_int(ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 128);
+			call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 48000);
+			call_int(vol, MS_VOLUME_ENABLE_AGC, 1);
+			ms_filter_link(mic, 0, rs, 0);
+			ms_filter_link(rs, 0, ec, 1);
+			ms_filter_link(ec, 1, vol, 0);
+			ms_filter_link(vol, 0, mx, k);
+			ms_filter_link(mx, k, out, 0);
+			ms_filter_link(far, 0, ec, 0);
+			ms_filter_link(ec, 0, spk, 0);
+			if (c == 0 && k == 0) j->probe_out = out;
+		}
+	}
+}
+
+static void *run(void *arg) {
+	TickerJob *j = (TickerJob *)arg;
+	/* attach on the ticker's own thread: the hub's device context and its banks belong to the thread that ticks them */
+	for (int c = 0; c < j->nconf; ++c) ms_ticker_attach(j->ticker, j->mixers[c]);
+	for (int t = 0; t < g_warmup; ++t) {
+		pthread_barrier_wait(&g_bar);
+		ms_ticker_step(j->ticker);
+	}
+	for (int t = 0; t < g_ticks; ++t) {
+		pthread_barrier_wait(&g_bar); /* all tickers fire together, as wall-clock tickers do */
+		const double t0 = now_ms();
+		ms_ticker_step(j->ticker);
+		j->step_ms[t] = now_ms() - t0;
+		uint64_t tasks_ns = 0;
+		ms2shim_ticker_last_step(j->ticker, &tasks_ns, NULL);
+		j->task_ms[t] = (double)tasks_ns * 1e-6;
+	}
+	pthread_barrier_wait(&g_bar);
+	return NULL;
+}
+
+static int cmp_d(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
+static double pct(const double *sorted, int n, double p) { return sorted[(int)((double)(n - 1) * p)]; }
+
+int main(int argc, char **argv) {
+	if (argc < 6) {
+		fprintf(stderr, "usage: plugin_bench <plugin.so> <legs> <tickers> <ticks> <warmup> [members]\n");
+		return 2;
+	}
+	const char *plugin = argv[1];
+	int legs = atoi(argv[2]);
+	g_tickers = atoi(argv[3]);
+	g_ticks = atoi(argv[4]);
+	g_warmup = atoi(argv[5]);
+	if (argc > 6) g_members = atoi(argv[6]);
+	if (legs <= 0 || g_tickers <= 0 || g_ticks <= 0 || g_members <= 0 || g_members > 50) return 2;
+	const int nconf_total = legs / g_members, nconf = nconf_total / g_tickers;
+	if (nconf <= 0) {
+		fprintf(stderr, "plugin_bench: %d legs do not fill a conference of %d on each of %d tickers\n", legs, g_members, g_tickers);
+		return 2;
+	}
+	legs = nconf * g_tickers * g_members;
+	if (!getenv("MSMI355X_SLOTS")) { /* first bank of a hub sized for the hub's legs (a server that knows its size would do the same) */
+		char v[32];
+		int slots = nconf * g_members / 4;
+		snprintf(v, sizeof(v), "%d", slots < 16 ? 16 : slots);
+		setenv("MSMI355X_SLOTS", v, 1);
+	}
+	unsigned seed = 12345u;
+	for (int r = 0; r < RING; ++r) {
+		for (int i = 0; i < 160; ++i) g_mic[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 19) - 4096);
+		for (int i = 0; i < 480; ++i) g_far[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 18) - 8192);
+	}
+	g_fac = ms_factory_new();
+	ms2shim_register_test_filters(g_fac);
+	if (ms_factory_load_plugin(g_fac, plugin) != 0) {
+		fprintf(stderr, "plugin_bench: could not load %s\n", plugin);
+		return 1;
+	}
+	if (ms_factory_create_filter(g_fac, MS_RESAMPLE_ID) == NULL) {
+		fprintf(stderr, "plugin_bench: the plugin registered no filters (no HIP device?)\n");
+		return 1;
+	}
+	void *ph = dlopen(plugin, RTLD_NOW | RTLD_NOLOAD);
+	void (*fused_stats)(int *, int *, unsigned long long *, unsigned long long *) =
+	    ph ? (void (*)(int *, int *, unsigned long long *, unsigned long long *))dlsym(ph, "ms_mi355x_fused_stats") : NULL;
+	unsigned long long (*late_events)(void) = ph ? (unsigned long long (*)(void))dlsym(ph, "ms_mi355x_late_events") : NULL;
+
+	const double t_build0 = now_ms();
+	TickerJob *jobs = (TickerJob *)calloc((size_t)g_tickers, sizeof(TickerJob));
+	for (int i = 0; i < g_tickers; ++i) {
+		jobs[i].index = i;
+		jobs[i].nconf = nconf;
+		jobs[i].step_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
+		jobs[i].task_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
+		build(&jobs[i]);
+	}
+	const double build_ms = now_ms() - t_build0;
+	pthread_barrier_init(&g_bar, NULL, (unsigned)g_tickers + 1);
+	pthread_t *th = (pthread_t *)calloc((size_t)g_tickers, sizeof(pthread_t));
+	for (int i = 0; i < g_tickers; ++i) pthread_create(&th[i], NULL, run, &jobs[i]);
+	int fc0 = 0, fl0 = 0, fc1 = 0, fl1 = 0;
+	unsigned long long la0 = 0, fr0 = 0, la1 = 0, fr1 = 0;
+	const double t_warm0 = now_ms();
+	for (int t = 0; t < g_warmup; ++t) pthread_barrier_wait(&g_bar);
+	/* the warm-up's last step is running; the first timed barrier releases when it is done */
+	double t_first = 0;
+	for (int t = 0; t < g_ticks; ++t) {
+		pthread_barrier_wait(&g_bar);
+		if (t == 0) {
+			t_first = now_ms();
+			if (fused_stats) fused_stats(&fc0, &fl0, &la0, &fr0); /* (racing with the first timed step by a launch or two: negligible over the run) */
+		}
+	}
+	pthread_barrier_wait(&g_bar);
+	const double wall_ms = now_ms() - t_first;
+	if (fused_stats) fused_stats(&fc1, &fl1, &la1, &fr1);
+	for (int i = 0; i < g_tickers; ++i) pthread_join(th[i], NULL);
+
+	/* a tick costs what the slowest ticker needs */
+	double *tick = (double *)calloc((size_t)g_ticks, sizeof(double)), *task = (double *)calloc((size_t)g_ticks, sizeof(double));
+	double sum_step = 0, sum_task = 0;
+	for (int t = 0; t < g_ticks; ++t) {
+		for (int i = 0; i < g_tickers; ++i) {
+			if (jobs[i].step_ms[t] > tick[t]) tick[t] = jobs[i].step_ms[t], task[t] = jobs[i].task_ms[t];
+			sum_step += jobs[i].step_ms[t];
+			sum_task += jobs[i].task_ms[t];
+		}
+	}
+	double *sorted = (double *)malloc(sizeof(double) * (size_t)g_ticks);
+	memcpy(sorted, tick, sizeof(double) * (size_t)g_ticks);
+	qsort(sorted, (size_t)g_ticks, sizeof(double), cmp_d);
+	int late = 0;
+	for (int t = 0; t < g_ticks; ++t) late += tick[t] >= 10.0;
+	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);
+	printf("{\"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
+	       "\"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"late\": %d, \"wall_ms_per_tick\": %.4f, "
+	       "\"ticker_mean_ms\": %.4f, \"ticker_flush_ms\": %.4f, \"ticker_graph_walk_ms\": %.4f, \"us_per_leg_tick\": %.4f, "
+	       "\"fused_conferences\": %d, \"fused_legs\": %d, \"launches_per_tick\": %.2f, \"launches_per_tick_and_ticker\": %.2f, "
+	       "\"flush_rounds_per_tick_and_ticker\": %.2f, \"late_events\": %llu, \"probe_sink_blocks\": %d, \"probe_sink_bytes\": %zu, "
+	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f}\n",
+	       legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
+	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
+	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
+	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0);
+	fflush(stdout);
+	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
+	_exit(0);
+}

@@ -1,0 +1,63 @@
+"""The plugin's fused call-leg chain with the real kernels: conferences of  MSResample -> MSSpeexEC -> MSVolume (AGC) ->
+MSAudioMixer  built from the facades in the test runtime (tests/fused_graph.py), run fused (one device-resident batch per
+hub: the canceller's tick kernel with the resampler folded in + volume-and-mix, mediastreamer2_amd/host/filters/
+leg_chain.inl) and with MSMI355X_NO_FUSE=1 (every facade on its own bank -- the path tests/test_gpu_plugin.py and the
+tester scenarios hold to the oracle).  Equal bit for bit: every leg's mix, every speaker pin, the meters."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fused_graph as fg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(fg.ROOT, "mediastreamer2_amd")
+
+
+@pytest.fixture(scope="module")
+def host():
+    import torch  # noqa: F401  (one HIP runtime per process, see mediastreamer2_amd/_lib.py)
+    return fg.Host(PKG)
+
+
+@pytest.mark.parametrize("name", list(fg.SCENARIOS))
+def test_fused_conference_equals_the_facades_one_by_one(host, name):
+    fused = fg.run(PKG, True, fg.SCENARIOS[name], host)
+    plain = fg.run(PKG, False, fg.SCENARIOS[name], host)
+    assert fused["stats"]["conferences"] > 0 and plain["stats"]["conferences"] == 0
+    assert fg.compare(fused, plain) == []
+    assert any(x.any() for x in fused["out"]) and sum(len(x) for x in fused["out"]) > 0
+    assert fused["late"] == 0 and plain["late"] == 0, "a device queue differed from the host's framing, or a launch failed"
+    assert fused["after"] == (0, 0, 0) and plain["after"] == (0, 0, 0)
+    if name != "ptime20":
+        np.testing.assert_array_equal(fused["levels"], plain["levels"])
+
+
+def test_the_fused_cancellers_cancel(host):
+    """the microphone is the far end through a room: after two seconds a leg's mix of the OTHER legs' cleaned microphones is
+    far below what the raw microphones would give (the cancellers converge inside the fused batch as anywhere else)"""
+    sc = dict(fg.SCENARIOS["plain"], nconf=1, members=4, nticks=260)
+    res = fg.run(PKG, True, sc, host)
+    mic, _ = fg.scene(4, 260, 16000, 48000)
+    tail = res["out"][0][-48000 // 2:].astype(np.float64)
+    raw = mic[1:, -8000:].astype(np.float64).sum(axis=0)
+    assert np.sqrt(np.mean(tail ** 2)) < 0.25 * np.sqrt(np.mean(raw ** 2))
+
+
+def test_a_member_that_stops_qualifying_takes_the_conference_back_to_its_facades(host):
+    """MS_ECHO_CANCELLER_SET_BYPASS_MODE on a fused leg: the conference leaves the batch at the next tick and the facades
+    carry on one by one (audio keeps flowing; nothing is left behind afterwards)"""
+    sc = dict(fg.SCENARIOS["plain"], nconf=1, nticks=80, events=[(30, "bypass", 2, 1)])
+    res = fg.run(PKG, True, sc, host)
+    assert res["stats"]["conferences"] == 0          # (read at tick 40: un-fused by then)
+    n = len(res["out"][0])
+    assert n >= 70 * 480 and res["out"][0][-4800:].any() and res["late"] == 0 and res["after"] == (0, 0, 0)
+
+
+def test_detach_and_reattach_fuses_again(host):
+    sc = dict(fg.SCENARIOS["plain"], nconf=2, nticks=90, events=[(35, "reattach", 0, 0)])
+    res = fg.run(PKG, True, sc, host)
+    assert res["stats"]["conferences"] == 2          # fused again after the re-attach
+    assert res["out"][0][-4800:].any() and res["late"] == 0 and res["after"] == (0, 0, 0)

@@ -1,0 +1,45 @@
+"""The plugin's fused call-leg chain (mediastreamer2_amd/host/filters/leg_chain.inl) on a box without a GPU: the SAME host
+code -- fusing, the framing state machines run on counts, staging, the slab emit, un-fusing -- against the host-memory
+double of the kernel library (tests/host/mi_double.cpp, TEST INFRASTRUCTURE: its canceller passes the microphone through,
+its resampler repeats samples; queues, counts and the mix are exact).  Every scenario is run fused and with
+MSMI355X_NO_FUSE=1 (the facades one by one) on the same inputs: every leg's mix and speaker audio must be equal bit for bit,
+and the device queues must hold what the reference's bufferizers would (MSMI355X_CHECK_LEVELS).  tests/test_gpu_plugin_fused.py
+does the same with the real kernels."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "host")
+
+
+@pytest.fixture(scope="module")
+def verdict():
+    r = subprocess.run(["make", "-C", HOST, "all"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_graph.py"), "--double"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["plain", "delay_and_far_gaps", "ptime20", "odd_pins", "gain_method", "wideband_8k_16k"])
+def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
+    v = verdict[name]
+    assert v["fused_stats"]["conferences"] > 0 and v["plain_stats"]["conferences"] == 0, v   # the first run really was fused, the second not
+    assert v["bad"] == [], v["bad"][:4]
+    assert v["nonzero"] and v["samples"] > 0
+    assert v["late"] == [0, 0], "a device queue differed from the host's framing, or a launch failed"
+    assert v["after"] == [[0, 0, 0], [0, 0, 0]], "hubs / banks / slots left behind"
+    if name != "ptime20":  # (with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
+        assert v["levels_equal"]
+
+
+def test_one_flush_round_per_tick_and_few_launches(verdict):
+    """fused: one (enqueue, wait, emit) round per tick for the whole hub and ~4 launches (far-end push, canceller, its list
+    turn-over, volume + mix) whatever the number of legs; one by one: four rounds per tick"""
+    v = verdict["plain"]
+    assert v["fused_stats"]["flush_rounds"] <= 61 and v["plain_stats"]["flush_rounds"] >= 200, v
+    assert v["fused_stats"]["launches"] <= 4 * 61, v
