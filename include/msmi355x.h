@@ -428,6 +428,9 @@ int mi_fifo_phase_of(int stream, int phases); /* 0 .. phases-1 */
 int mi_fifo_push_silence(mi_fifo *f, const int32_t *d_count);
 int mi_fifo_levels(mi_fifo *f, int32_t *d_levels); /* ms_bufferizer_get_avail, in samples */
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
+/* debug / parity read-back (like mi_aec_get): the rings as they lie, [nstreams][capacity], and per stream the read position
+ * and the level -- the samples a fused launch queued can be checked without popping them.  Any pointer may be NULL.  Syncs. */
+int mi_fifo_snapshot(mi_fifo *f, int16_t *h_rings, int32_t *h_head, int32_t *h_level);
 int mi_fifo_reset(mi_fifo *f);
 int mi_fifo_reset_range(mi_fifo *f, int first, int count); /* empty the FIFOs of streams [first, first+count) */
 

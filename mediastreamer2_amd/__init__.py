@@ -208,10 +208,11 @@ class MixerBatch(_Batch):
         check(self.ctx.L.mi_mixer_process(self.h, _ptr(x), _ptr(has_data), int(conf_mode), _ptr(out)))
         return out
 
-    def process_volume_fifo(self, vol, fifo, out, first_stream=0):
+    def process_volume_fifo(self, vol, fifo, out, first_stream=0, dry_skips=False):
         """MSVolume + the conference mix in one launch: every pin's chunk popped from `fifo`, levelled by `vol` (stream
-        first_stream + conference * members + pin), mixed in conference mode into out [nconf, mm, ns]"""
-        check(self.ctx.L.mi_mixer_process_volume_fifo(self.h, vol.h, first_stream, fifo.h, _ptr(out)))
+        first_stream + conference * members + pin), mixed in conference mode into out [nconf, mm, ns]; dry_skips: a pin
+        whose queue holds less than a tick is not metered (MI_VOLMIX_DRY_SKIPS)"""
+        check(self.ctx.L.mi_mixer_process_volume_fifo_flags(self.h, vol.h, first_stream, fifo.h, _ptr(out), 1 if dry_skips else 0))
         return out
 
     def partial_sum(self, x, d_sum, has_data=None):
@@ -439,12 +440,12 @@ class AecBatch(_Batch):
                                               ref_tick.stride(0), _ptr(ref_len), n, f_out.h, max_frames, flags, _ptr(count_out)))
 
     def process_fifos_resampled(self, rs, mic_in, f_mic, f_ref, ref_tick, f_out, in_len=None, max_frames=2, flags=MI_AEC_POSTFILTER,
-                                count_out=None, ref_len=None):
+                                count_out=None, ref_len=None, mic_gate=None):
         """process_fifos with the leg's up-sampler (a ResamplerBatch) folded into the same launch: mic_in holds the block at
-        the resampler's input rate (mi_aec_process_fifos_resampled)."""
+        the resampler's input rate (mi_aec_process_fifos_resampled[_masked]: mic_gate [nstreams] uint8, 0 = no block for that leg)."""
         n = mic_in.shape[1] if in_len is None else in_len
-        check(self.ctx.L.mi_aec_process_fifos_resampled(self.h, rs.h, _ptr(mic_in), n, mic_in.stride(0), f_mic.h, f_ref.h, _ptr(ref_tick),
-                                                        ref_tick.stride(0), _ptr(ref_len), f_out.h, max_frames, flags, _ptr(count_out)))
+        check(self.ctx.L.mi_aec_process_fifos_resampled_masked(self.h, rs.h, _ptr(mic_in), n, mic_in.stride(0), f_mic.h, f_ref.h, _ptr(ref_tick),
+                                                               ref_tick.stride(0), _ptr(ref_len), f_out.h, max_frames, flags, _ptr(count_out), _ptr(mic_gate)))
 
     def process_frames(self, mic, ref, out, count, max_frames=2, flags=MI_AEC_POSTFILTER):
         """The frames of one tick in one launch: rows of mic / ref / out hold up to max_frames frames back to back,
@@ -560,6 +561,17 @@ class FifoBatch(_Batch):
         n = C.c_int32(0)
         check(self.ctx.L.mi_fifo_overflows(self.h, C.byref(n)))
         return n.value
+
+    def snapshot(self):
+        """(rings [nstreams, capacity] int16, head [nstreams], level [nstreams]) as they lie on the device (parity read-back; syncs)"""
+        rings = np.zeros((self.nstreams, self.capacity), np.int16)
+        head, level = np.zeros(self.nstreams, np.int32), np.zeros(self.nstreams, np.int32)
+        check(self.ctx.L.mi_fifo_snapshot(self.h, _ptr(rings), _ptr(head), _ptr(level)))
+        return rings, head, level
+
+    def push_silence(self, count):
+        """count [nstreams] int32 (device): samples of silence appended per stream (mi_fifo_push_silence)"""
+        check(self.ctx.L.mi_fifo_push_silence(self.h, _ptr(count)))
 
     def reset_range(self, first, count):
         check(self.ctx.L.mi_fifo_reset_range(self.h, first, count))

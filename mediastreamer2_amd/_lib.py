@@ -34,11 +34,11 @@ EXPORTS = [
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
     "mi_exchange_unique_id", "mi_exchange_create", "mi_exchange_destroy", "mi_exchange_ranks", "mi_exchange_allreduce_i32",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
-    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo", "mi_volume_process_fifo_range", "mi_mixer_process_volume_fifo",
+    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo", "mi_volume_process_fifo_range", "mi_mixer_process_volume_fifo", "mi_mixer_process_volume_fifo_flags", "mi_volume_get_state_async",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
-    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos", "mi_aec_process_fifos_resampled",
+    "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos", "mi_aec_process_fifos_resampled", "mi_aec_process_fifos_masked", "mi_aec_process_fifos_resampled_masked",
     "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_copy_state", "mi_aec_get", "mi_aec_stagger_info", "mi_aec_stagger_fifos",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
@@ -51,7 +51,7 @@ EXPORTS = [
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
     "mi_plc_create", "mi_plc_destroy", "mi_plc_reset", "mi_plc_process", "mi_plc_info",
-    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range", "mi_fifo_push_silence", "mi_fifo_snapshot",
 ]
 
 
@@ -164,6 +164,7 @@ def load():
     L.mi_exchange_ranks.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.mi_exchange_allreduce_i32.argtypes = [vp, vp, sz]
     L.mi_aec_process_fifos_resampled.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, u32, vp]
+    L.mi_aec_process_fifos_resampled_masked.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, u32, vp, vp]
     L.mi_aec_copy_state.argtypes = [vp, i32, vp, i32, i32]
     L.mi_aec_stagger_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.mi_aec_stagger_fifos.argtypes = [vp, vp, vp, i32, i32, i32]
@@ -171,6 +172,8 @@ def load():
     L.mi_fifo_phase_of.argtypes = [i32, i32]
     L.mi_volume_process_fifo_range.argtypes = [vp, vp, vp, i32, i32, i32, i32]
     L.mi_mixer_process_volume_fifo.argtypes = [vp, vp, i32, vp, vp]
+    L.mi_mixer_process_volume_fifo_flags.argtypes = [vp, vp, i32, vp, vp, u32]
+    L.mi_volume_get_state_async.argtypes = [vp, i32, i32, vp]
     L.mi_volume_get_max.argtypes = [vp, i32, i32, vp]
     L.mi_volume_reset_max.argtypes = [vp, i32, i32]
     L.mi_volume_process.argtypes = [vp, vp, i32, i32, vp]
@@ -200,6 +203,7 @@ def load():
         L.mi_aec_process_host.argtypes = [vp, vp, vp, vp, i32, vp, C.c_uint]
         L.mi_aec_process_frames.argtypes = [vp, vp, vp, vp, i32, vp, i32, C.c_uint]
         L.mi_aec_process_fifos.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, C.c_uint, vp]
+        L.mi_aec_process_fifos_masked.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, C.c_uint, vp, vp]
         L.mi_aec_state_bytes.argtypes = [vp]
         L.mi_aec_state_bytes.restype = sz
         L.mi_aec_blob_bytes.argtypes = [vp]
@@ -251,6 +255,8 @@ def load():
         L.mi_fifo_overflows.argtypes = [vp, C.POINTER(i32)]
         L.mi_fifo_reset.argtypes = [vp]
         L.mi_fifo_reset_range.argtypes = [vp, i32, i32]
+        L.mi_fifo_push_silence.argtypes = [vp, vp]
+        L.mi_fifo_snapshot.argtypes = [vp, vp, vp, vp]
     if hasattr(L, "mi_g711_decode"):
         L.mi_g711_decode.argtypes = [vp, i32, vp, sz, vp, sz, vp, i32, sz]
         L.mi_g711_encode.argtypes = [vp, i32, vp, sz, vp, sz, vp, i32, sz]

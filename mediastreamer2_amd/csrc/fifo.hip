@@ -11,6 +11,7 @@
 // (its output row is zero-filled on request, the way the filters inject silence: speexec.c:261-272, audiomixer.c:88).
 // One wavefront per stream; pure copies, HBM-bound.
 #include "common.hpp"
+#include <vector>
 
 namespace {
 
@@ -362,6 +363,22 @@ int mi_fifo_levels(mi_fifo *f, int32_t *d_levels) {
 	a.levels = d_levels;
 	hipLaunchKernelGGL(fifo_level_kernel, dim3(mi::ceil_div(f->nstreams, 256)), dim3(256), 0, f->ctx->stream, a);
 	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+
+int mi_fifo_snapshot(mi_fifo *f, int16_t *h_rings, int32_t *h_head, int32_t *h_level) {
+	MI_CHECK_ARG(f != nullptr);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(f->ctx->stream));
+	if (h_rings) MI_HIP(hipMemcpy(h_rings, f->d_ring, (size_t)f->nstreams * f->capacity * sizeof(int16_t), hipMemcpyDeviceToHost));
+	if (h_head || h_level) {
+		std::vector<int2> pos((size_t)f->nstreams);
+		MI_HIP(hipMemcpy(pos.data(), f->d_pos, pos.size() * sizeof(int2), hipMemcpyDeviceToHost));
+		for (int s = 0; s < f->nstreams; ++s) {
+			if (h_head) h_head[s] = pos[(size_t)s].x;
+			if (h_level) h_level[s] = pos[(size_t)s].y;
+		}
+	}
 	return MI_OK;
 }
 

@@ -732,6 +732,18 @@ int mi_fifo_levels(mi_fifo *f, int32_t *lv) {
 	for (int s = 0; s < f->n; ++s) lv[s] = (int32_t)f->q[(size_t)s].size();
 	return MI_OK;
 }
+int mi_fifo_snapshot(mi_fifo *f, int16_t *rings, int32_t *head, int32_t *level) { // (the double's queues start at 0)
+	ARG(f);
+	for (int s = 0; s < f->n; ++s) {
+		if (rings) {
+			memset(rings + (size_t)s * f->cap, 0, (size_t)f->cap * 2);
+			std::copy(f->q[(size_t)s].begin(), f->q[(size_t)s].end(), rings + (size_t)s * f->cap);
+		}
+		if (head) head[s] = 0;
+		if (level) level[s] = (int32_t)f->q[(size_t)s].size();
+	}
+	return MI_OK;
+}
 int mi_fifo_overflows(mi_fifo *f, int32_t *h) {
 	ARG(f && h);
 	*h = f->overflow;

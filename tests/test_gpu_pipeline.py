@@ -297,6 +297,114 @@ def test_chained_tick_pipeline_stage_parity(ctx, oracle):
     assert f_mic.overflows() == f_ref.overflows() == f_out.overflows() == 0
 
 
+def test_the_headline_two_launch_tick_against_the_oracle_chain(ctx, oracle):
+    """The tick exactly AS THE HEADLINE RUNS IT -- mi_aec_process_fifos_resampled (the leg's MSResample 16k->48k, both FIFO
+    appends, every whole 256-sample frame through canceller + post-filter, the output FIFO append: one launch) and
+    mi_mixer_process_volume_fifo (FIFO pop, AGC, 32-party mix: one launch) -- at the headline's own configuration: 128 ms
+    tail (24 filter blocks), conferences of 32, the product's stagger, SURVEY 8(d)'s echo scene (bench.echo_scene), long
+    enough (416 ticks) for every canceller to adapt and for both kinds of filter copy to occur.  Held DIRECTLY to the chain
+    of oracle objects, stage by stage on what the two launches themselves queued (mi_fifo_snapshot reads the rings as they
+    lie): <= 1 LSB for the up-sampled block, <= 1e-4 RMS for the cleaned frames (speexec.c:297-298), bit-exact meter +
+    mix given those frames (msvolume.c:471-514, audiomixer.c:288-346)."""
+    torch = pytest.importorskip("torch")
+    import bench
+    nconf, mm, F, rate, ns, nticks = 2, 32, 256, 48000, 480, 416
+    n, flen = nconf * mm, 128 * rate // 1000
+    mic16, ref48 = bench.echo_scene()
+    P = bench.SCENE_TICKS
+    rs = ms.ResamplerBatch(ctx, n, 16000, rate)
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    vol = ms.VolumeBatch(ctx, n, rate)
+    p = vol.default_params()
+    p.agc_enabled = 1
+    vol.set_params([p] * n)
+    mix = ms.MixerBatch(ctx, nconf, mm, ns)
+    cap = (2 * ns + 3 * F + F - 1) // F * F
+    f_mic, f_ref, f_out = (ms.FifoBatch(ctx, n, cap) for _ in range(3))
+    aec.stagger_fifos(f_mic, f_ref, ns)                       # the product's re-framing leads
+    lead = [32 * ctx.L.mi_fifo_phase_of(s, 8) for s in range(n)]
+    assert len(set(lead)) == 8
+    o_rs = [oracle.Resampler(16000, rate) for _ in range(n)]
+    o_ec = [oracle.Echo(F, flen, rate) for _ in range(n)]
+    o_pp = [oracle.Preproc(F, rate, o_ec[s]) for s in range(n)]
+    o_vol = [oracle.Volume(rate) for _ in range(n)]
+    for v in o_vol:
+        v.v.agc_enabled = 1
+    q_mic = [np.zeros(lead[s], np.int16) for s in range(n)]
+    q_ref = [np.zeros(lead[s], np.int16) for s in range(n)]
+    q_out = [np.zeros(0, np.int16) for _ in range(n)]
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+    cnt, mixed = z(n, dt=torch.uint8), z(nconf, mm, ns)
+    d_mic = [torch.from_numpy(np.ascontiguousarray(mic16[:n, k * 160:(k + 1) * 160])).cuda() for k in range(P)]
+    d_ref = [torch.from_numpy(np.ascontiguousarray(ref48[:n, k * ns:(k + 1) * ns])).cuda() for k in range(P)]
+    torch.cuda.synchronize()
+
+    def tail_of(snap, s, k):
+        """the k samples most recently queued on stream s"""
+        rings, head, level = snap
+        end = int(head[s]) + int(level[s])
+        idx = (np.arange(end - k, end)) % rings.shape[1]
+        return rings[s, idx]
+
+    sq, cnt_s, frames, up_worst, two_frame_ticks = 0.0, 0, 0, 0, 0
+    for t in range(nticks):
+        k = t % P
+        aec.process_fifos_resampled(rs, d_mic[k], f_mic, f_ref, d_ref[k], f_out, max_frames=2, count_out=cnt)
+        ctx.sync()
+        s_mic, s_out = f_mic.snapshot(), f_out.snapshot()
+        g_cnt = cnt.cpu().numpy()
+        for s in range(n):
+            # (the consumed frames still lie in the ring behind the read position: the tick's block is the last ns queued)
+            rings, head, level = s_mic
+            end = int(head[s]) + int(level[s])
+            g_up = rings[s, np.arange(end - ns, end) % cap]
+            want = o_rs[s].process(mic16[s, k * 160:(k + 1) * 160])[:ns]
+            up_worst = max(up_worst, int(np.abs(g_up.astype(int) - want.astype(int)).max()))
+            q_mic[s] = np.concatenate([q_mic[s], g_up])            # the oracle continues from what the launch queued
+            q_ref[s] = np.concatenate([q_ref[s], ref48[s, k * ns:(k + 1) * ns]])
+            nf = 0
+            w_clean = []
+            while len(q_mic[s]) >= F and nf < 2:                   # speexec.c:256
+                m, q_mic[s] = q_mic[s][:F], q_mic[s][F:]
+                r, q_ref[s] = q_ref[s][:F], q_ref[s][F:]
+                w_clean.append(o_pp[s].run(o_ec[s].cancel(m, r)))
+                nf += 1
+            assert nf == int(g_cnt[s]), (t, s)
+            two_frame_ticks += nf == 2
+            if nf:
+                g_clean = tail_of(s_out, s, nf * F)
+                d = (g_clean.astype(np.float64) - np.concatenate(w_clean)) / 32768.0
+                sq += float((d * d).sum())
+                cnt_s += d.size
+                frames += nf
+                q_out[s] = np.concatenate([q_out[s], g_clean])
+        mix.process_volume_fifo(vol, f_out, mixed)
+        ctx.sync()
+        g_mix = mixed.cpu().numpy()
+        w_vol = np.zeros((n, ns), np.int16)
+        for s in range(n):
+            chunk = np.zeros(ns, np.int16)
+            if len(q_out[s]) >= ns:                                # ms_bufferizer_read, all or nothing; a dry leg meters silence
+                chunk, q_out[s] = q_out[s][:ns], q_out[s][ns:]
+            w_vol[s] = o_vol[s].chunk(chunk)
+        for c in range(nconf):
+            w_mix, _ = oracle.mixer_tick(w_vol[c * mm:(c + 1) * mm])
+            np.testing.assert_array_equal(g_mix[c], w_mix, err_msg=f"tick {t} conference {c}")
+    assert up_worst <= 1
+    assert np.sqrt(sq / cnt_s) <= 1e-4, np.sqrt(sq / cnt_s)
+    assert frames == sum((lead[s] + nticks * ns) // F for s in range(n)) and two_frame_ticks > n * nticks * 0.8
+    counters = np.array([aec.get(s, "counters", 4) for s in range(n)])
+    adapted = np.array([aec.get(s, "scalars", 16)[8] for s in range(n)])
+    assert (adapted == 1).all(), "every leg's canceller has adapted on the echo scene"
+    assert (counters[:, 0] > 0).all() and counters[:, 1].sum() > 0 and counters[:, 2].sum() == 0, counters[:4]   # foreground updates on every leg, background resets seen, no state reset
+    assert (counters[:, 3] == [(lead[s] + nticks * ns) // F for s in range(n)]).all()
+    o_adapt = np.array([o_ec[s].get("scalars", 16)[8] for s in range(n)])
+    assert (o_adapt == 1).all()
+    assert f_mic.overflows() + f_ref.overflows() + f_out.overflows() == 0
+    for o in (rs, aec, vol, mix, f_mic, f_ref, f_out):
+        o.close()
+
+
 @pytest.mark.parametrize("use_graphs,rate", [(True, 48000), (False, 48000), (False, 44100)])
 def test_session_equals_the_chain_called_step_by_step(ctx, use_graphs, rate):
     """mi_session (three streams, up to three ticks in flight, hipGraph per slot) must produce exactly what the same
