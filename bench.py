@@ -67,7 +67,11 @@ def parse():
     ap.add_argument("--min-timed-s", type=float, default=0.5, help="the timed region is at least this long, whatever --steps says")
     ap.add_argument("--worst-ticks", type=int, default=3000, help="consecutive single ticks the worst tick is taken over")
     ap.add_argument("--zero-ticks", type=int, default=256, help="ticks of the from-reset test at the chosen count (0 = skip)")
-    ap.add_argument("--paced-ticks", type=int, default=1000, help="ticks of the series run at the 10 ms cadence of an MSTicker (reported, not `value`; 0 = skip)")
+    ap.add_argument("--paced-ticks", type=int, default=3000, help="ticks of the series run at the 10 ms cadence of an MSTicker, one per 10 ms of wall time: part of `value`'s criterion (0 = skip)")
+    ap.add_argument("--no-keepalive", action="store_true", help="paced series without the product's keep-alive between the ticks (mi_ctx_keepalive)")
+    ap.add_argument("--no-plugin-path", action="store_true", help="skip the rate of full call legs through the drop-in plugin (tests/host/plugin_bench)")
+    ap.add_argument("--plugin-legs", type=int, default=32768, help="full call legs the plugin path is first tried with (config[3]: 1024 conferences x 32)")
+    ap.add_argument("--no-video-host", action="store_true", help="skip the PCIe-inclusive video probe (config 5)")
     ap.add_argument("--roofline-ticks", type=int, default=32, help="eager ticks with HIP events around the canceller's launch")
     ap.add_argument("--from-reset", action="store_true", help="measure cancellers that start from reset instead of steady state")
     ap.add_argument("--no-session", action="store_true", help="skip the PCIe-inclusive mi_session probes")
@@ -777,6 +781,71 @@ def _host_cores():
     return ncores, quota
 
 
+def plugin_path_probe(first_legs, ticks=300, warmup=40, log=None):
+    """How many FULL call legs a mediastreamer2-shaped process carries through the DROP-IN PLUGIN (never part of `value`):
+    tests/host/plugin_bench builds N legs of  source -> MSResample 16k->48k -> MSSpeexEC (128 ms) -> MSVolume (AGC) ->
+    MSAudioMixer (conferences of 32)  from the factory's ids after libmsmi355xfilters_init (audiostream.c:1798-1810 in
+    front of a conference mixer), spread over T ticker threads of the test runtime (one thread per MSTicker, as the
+    reference runs them; T = the cores this process is granted), all tickers ticking together.  A tick costs what the
+    slowest ticker needs.  The first count is config[3]'s 1024 x 32; if a tick is late the count steps down until none is."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
+    plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host"), "plugin_bench"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ncores, quota = _host_cores()
+    tickers = max(1, min(16, ncores))
+
+    def run(legs, nt, extra_env=None):
+        env = dict(os.environ)
+        env.pop("MSMI355X_NO_FUSE", None)
+        env.update(extra_env or {})
+        r = subprocess.run([exe, plugin, str(legs), str(tickers), str(nt), str(warmup)], capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0 or not r.stdout.strip():
+            raise RuntimeError(f"plugin_bench exit {r.returncode}: {r.stderr[-300:]}")
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        d["fits"] = bool(d["late"] == 0 and d["max_ms"] < 10.0)
+        return d
+
+    keep = ("legs", "tickers", "p50_ms", "p99_ms", "max_ms", "late", "fits", "us_per_leg_tick", "ticker_flush_ms", "ticker_graph_walk_ms",
+            "launches_per_tick_and_ticker", "flush_rounds_per_tick_and_ticker", "fused_legs", "late_events")
+    tried, best, legs = [], None, first_legs
+    step = tickers * 32
+    for _ in range(5):
+        d = run(legs, ticks)
+        if log:
+            log({"plugin_path": {k: d[k] for k in keep}})
+        tried.append({k: d[k] for k in keep})
+        if d["fits"]:
+            best = d
+            break
+        legs = max(step, int(legs * min(0.9, 9.3 / max(d["max_ms"], d["p99_ms"]))) // step * step)
+    out = {"what": "full call legs through the drop-in plugin, PCIe included: source -> MSResample 16k->48k -> MSSpeexEC (128 ms tail) -> MSVolume (AGC) "
+                   "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
+                   "libmsmi355xfilters_init, one ticker thread per MSTicker in the test runtime (tests/host/plugin_bench.c); the plugin runs each "
+                   "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl)",
+           "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
+    if best is not None:
+        out.update({"legs": best["legs"], "tickers": best["tickers"], "p50_ms": best["p50_ms"], "p99_ms": best["p99_ms"], "max_ms": best["max_ms"],
+                    "us_per_leg_tick": best["us_per_leg_tick"], "launches_per_tick": best["launches_per_tick_and_ticker"],
+                    "syncs_per_tick": best["flush_rounds_per_tick_and_ticker"], "fits": True,
+                    "where_the_time_goes": {"per_ticker_mean_ms": {"plugin_flush": best["ticker_flush_ms"], "graph_walk": best["ticker_graph_walk_ms"]},
+                                            "note": "plugin_flush = the postponed task at the start of a tick: results of the launches enqueued at the end of the "
+                                                    "previous graph walk are waited for and handed on (one wait per ticker); graph_walk = every filter's process(): "
+                                                    "sources, staging into pinned rows, MSSpeexEC's speaker pin, sinks, then the bank's uploads and launches; the tick "
+                                                    "is the slowest of the ticker threads, all ticking together"}})
+    else:
+        out.update({"fits": False, "legs": 0})
+    try:  # the same graph with every facade on its own bank (MSMI355X_NO_FUSE=1: four uploads, launches and waits per chain), for scale
+        d = run(4096, 100, {"MSMI355X_NO_FUSE": "1"})
+        out["facades_one_by_one_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
+        d = run(4096, 100)
+        out["fused_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
+    except Exception as e:
+        out["facades_one_by_one_4096_legs"] = {"error": str(e)[:200]}
+    return out
+
+
 def cpu_baseline_chain(seconds, threads=1):
     """The oracle's CHAIN (CPU restatement of the reference path: one resampler, canceller + post-filter, volume object
     per call leg, one mixer per conference of 32, driven tick by tick as an MSTicker thread would) on this host's
@@ -876,8 +945,9 @@ class HipPlatform:
 
     def exchange(self, ctx, local, dist, rank, world, backend):
         """the split conferences' all-reduce: mi_exchange (C ABI, straight on RCCL, enqueued on the context's stream).
-        torch.distributed only carries the 128-byte id from rank 0 to the others.  A test backend (gloo, ranks sharing
-        one GPU -- RCCL refuses that) goes through torch instead and is named in the line."""
+        torch.distributed only carries the 128-byte id from rank 0 to the others.  There is no substitute transport: if any
+        rank cannot bring it up, every rank raises (main() exits 3).  Only the TEST backend (MSMI355X_BENCH_BACKEND=gloo:
+        ranks sharing one GPU, which RCCL refuses) goes through torch, and the line says so."""
         if backend != "nccl":
             from mediastreamer2_amd.sharding import PartialSumExchange
             ex = PartialSumExchange(ctx.stream, local)
@@ -894,34 +964,39 @@ class HipPlatform:
                 why = str(e)[:300]
         dist.broadcast(idt, 0)
         self.sync(torch)
+        def agreed(flag):  # a MIN over the ranks (torch's communicator): every rank learns whether ALL of them got this far
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+
         try:
             if not bool(idt.any().item()):
                 raise RuntimeError(why or "rank 0 could not make the communicator id")
             ex = ms.Exchange(ctx, world, rank, idt.cpu().numpy().tobytes())
-            probe = torch.ones(4, dtype=torch.int32, device=self.device)  # every rank contributes 1: the sum is the world size
-            self.sync(torch)
-            ex(probe)
-            ctx.sync()
-            if probe.tolist() != [world] * 4:
-                raise RuntimeError(f"mi_exchange probe returned {probe.tolist()}, expected {world}")
-        except Exception as e:  # noqa: BLE001 -- reported below, by every rank that saw it
+        except Exception as e:  # noqa: BLE001 -- reported below, by every rank
             ex, why = None, str(e)[:300]
-        # every rank uses the same exchange: if ANY rank could not bring the C one up, all of them say so and take the same
-        # collective (RCCL int32 SUM over xGMI) through torch.distributed's communicator instead -- same transport, same
-        # bytes, ordered with events around a second stream; the line names which one ran (config.parallelism)
-        ok = torch.tensor([1 if ex is not None else 0], dtype=torch.int32, device=self.device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
+        if agreed(ex is not None):  # (a rank whose communicator did not start cannot take part in the probe: agree first)
+            try:
+                probe = torch.ones(4, dtype=torch.int32, device=self.device)  # every rank contributes 1: the sum is the world size
+                self.sync(torch)
+                ex(probe)
+                ctx.sync()
+                if probe.tolist() != [world] * 4:
+                    raise RuntimeError(f"mi_exchange probe returned {probe.tolist()}, expected {world}")
+            except Exception as e:  # noqa: BLE001
+                ex.close()
+                ex, why = None, str(e)[:300]
+        elif ex is not None:
+            ex.close()
+            ex = None
+        # ONE contract: the exchange is mi_exchange on RCCL or the run fails -- on every rank together (so that nobody waits in
+        # a collective for a rank that has left): main() exits 3, RCCL's reason on stderr.  No substitute transport.
+        if agreed(ex is not None):
             ex.label = "mi_exchange_allreduce_i32 (C ABI, RCCL over xGMI, on the kernel stream)"
             return ex
-        print(f"bench.py: rank {rank}: mi_exchange could not be set up on every rank ({why or 'another rank failed'}); "
-              "the split conferences' all-reduce runs on torch.distributed's RCCL communicator instead", file=sys.stderr, flush=True)
         if ex is not None:
             ex.close()
-        from mediastreamer2_amd.sharding import PartialSumExchange
-        ex = PartialSumExchange(ctx.stream, local)
-        ex.label = "torch.distributed all_reduce (RCCL over xGMI, own stream ordered with events; mi_exchange failed to start)"
-        return ex
+        raise RuntimeError(why or "another rank could not bring mi_exchange up")
 
     def converged(self, ms, torch, ctx, rank):
         return Converged(ms, torch, ctx, rank)
@@ -1014,6 +1089,28 @@ class Headline:
             self.ctx.timer_start()
             self.graph_tick(t)
             v[t] = self.ctx.timer_stop()
+        return v
+
+    def paced_series(self, nticks, keepalive=True):
+        """`nticks` deployed ticks at an MSTicker's cadence: one per 10 ms of wall time (src/base/msticker.c:419-443,496-515),
+        the device idle for the rest of each interval -- unless the product's keep-alive holds its clocks (mi_ctx_keepalive:
+        what mi_session_submit and the plugin's hub flush call before a tick's launches).  Each tick timed alone."""
+        v = np.empty(nticks)
+        nxt = time.perf_counter()
+        for t in range(nticks):
+            while time.perf_counter() < nxt:
+                pass
+            nxt = max(nxt + 0.010, time.perf_counter() - 0.050)  # (a late tick is followed at once, like wait_next_tick does)
+            if keepalive:
+                self.ctx.keepalive(15000)
+            self.ctx.timer_start()
+            if self.world == 1:
+                self.g1[t % len(self.g1)].launch()
+            else:
+                self.graph_tick(t)
+            v[t] = self.ctx.timer_stop()
+        if keepalive:
+            self.ctx.keepalive(0)
         return v
 
     def canceller_launches(self, nticks):
@@ -1160,6 +1257,7 @@ def main():
     #  (2) --worst-ticks (default 3000) CONSECUTIVE deployed ticks in steady state -- with the exchange at N > 1 -- none
     #      of which may reach the 10 ms interval: a late tick is a fault (src/base/msticker.c:46,441-443).
     zero = None
+    paced, paced_on = None, a.paced_ticks > 0 and PLATFORM.device != "cpu"
     tried = []  # the counts that did not pass, with what they measured: the step-downs are part of the result
     best = None  # (streams, zero, head, series, fg0, worst) of a count that passed while a larger one is being tried
     ups = 0
@@ -1184,6 +1282,14 @@ def main():
             worst = reduce_scalar(float(series.max()), "MAX")
             if log:
                 log({"streams": head.rig.n, "test": f"{a.worst_ticks} consecutive ticks", **series_stats(series)})
+            # (3) the same number of ticks at the DEPLOYED cadence -- one per 10 ms of wall time, as an MSTicker fires them --
+            # with the product's keep-alive between them; only run when the back-to-back series passed
+            paced = None
+            if paced_on and (worst < 10.0 or a.streams > 0):
+                paced = head.paced_series(a.paced_ticks, keepalive=not a.no_keepalive)
+                if log:
+                    log({"streams": head.rig.n, "test": f"{a.paced_ticks} paced ticks (one per 10 ms)", **series_stats(paced)})
+                worst = max(worst, reduce_scalar(float(paced.max()), "MAX"))
             if a.streams > 0 or streams <= 8192:
                 break
             if worst < 10.0 and zero_ok:
@@ -1194,33 +1300,52 @@ def main():
                     best[2].close()
                     best = None
                 if worst < 9.75 and ups < 3 and streams + 2048 <= a.sweep_hi:
-                    best = (streams, zero, head, series, fg0, worst)
+                    best = (streams, zero, head, series, fg0, worst, paced)
                     ups += 1
                     streams += 2048
                     continue
                 break
-            tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"]})
+            tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"],
+                          "paced": series_stats(paced) if paced is not None else None})
             head.close()
+            head = None
             if best is not None:  # the step up did not pass: the count below it stands
-                streams, zero, head, series, fg0, worst = best
+                streams, zero, head, series, fg0, worst, paced = best
                 best = None
                 break
             # the next count to try: the one whose median leaves room for this series' longest tick (a tick costs in
             # proportion to the legs; what a machine event adds does not) -- rounded UP to the step, so the estimate can
             # only be optimistic and the series at that count decides; never less than one step down
-            p50 = reduce_scalar(float(np.median(series)), "MAX")
+            decisive = paced if (paced is not None and paced.max() >= series.max()) else series  # the series that failed the count
+            p50 = reduce_scalar(float(np.median(decisive)), "MAX")
             room = int(streams * max(9.95 - (worst - p50), 1.0) / p50) // 2048 * 2048 + 2048
             streams = min(streams - 2048 * (1 + attempt // 2), room)  # at least 2048, 2048, 4096, 4096, ... down
         else:
             tried.append({"streams": streams, "from_reset_worst_ms": zero["tick_ms_worst"]})
             if best is not None:
-                streams, zero, head, series, fg0, worst = best
+                streams, zero, head, series, fg0, worst, paced = best
                 best = None
                 break
             streams -= 2048 * (1 + attempt // 2)
         streams = max(streams, 8192)
     if best is not None:  # (the attempts ran out on the way up: the last count that passed stands)
-        streams, zero, head, series, fg0, worst = best
+        if head is not None and head is not best[2]:
+            head.close()
+        streams, zero, head, series, fg0, worst, paced = best
+    if head is None:
+        # every attempt failed and the last one's rig is gone: the line reports what was tried, value 0 (nothing below is
+        # measured on a closed rig)
+        if rank == 0:
+            print(json.dumps({"metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale", "value": 0,
+                              "unit": "concurrent 48 kHz streams (resample + AEC + AGC + 32-party mix every 10 ms tick, worst tick < 10 ms)",
+                              "n_gpus": world, "steps": 0, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "north_star chain per call leg and 10 ms tick: " + CHAIN_DESC, "fits": False,
+                                         "consecutive_ticks_failed_at": tried}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(1)
     rig = head.rig
     median_single = float(np.median(series))
     stats = series_stats(series)
@@ -1283,8 +1408,9 @@ def main():
         "config": {"workload": "north_star chain per call leg and 10 ms tick: " + CHAIN_DESC + "; configs[2]'s canceller "
                                "geometry (48 kHz, 128 ms tail, post-filter) fed by configs[1]'s resampler and mixed as configs[3]; "
                                "input: SURVEY 8(d)'s echo scene (microphone = 0.5 x far end, 20 ms late, through a 64-tap room + noise)",
-                   "value_definition": "largest leg count (capacity sweep in steady state, step 2048, then stepped down -- or up, while the series leaves room -- until the verdict changes) at which BOTH hold: no tick of "
-                                       f"{a.worst_ticks} consecutive deployed ticks in steady state reaches the 10 ms MSTicker interval, "
+                   "value_definition": "largest leg count (capacity sweep in steady state, step 2048, then stepped down -- or up, while the series leaves room -- until the verdict changes) at which ALL hold: no tick of "
+                                       f"{a.worst_ticks} consecutive back-to-back ticks in steady state reaches the 10 ms MSTicker interval, none of "
+                                       f"{a.paced_ticks if paced is not None else 0} ticks PACED one per 10 ms of wall time does either (the deployed cadence), "
                                        "and neither does any tick when every leg starts from reset at once; ms_per_step = average "
                                        "tick over the timed region at that count",
                    "streams_per_gpu": n_local, "conferences_per_gpu": nconf_local + (SPLIT_CONFERENCES if world > 1 else 0),
@@ -1347,24 +1473,19 @@ def main():
         r["mfma"] = ("not used: the one candidate, the scaler's 3x3 BT.601 colour matrix, is 9 integer MACs per pixel inside a "
                      "byte-streaming kernel at ~80 % of the measured copy ceiling; v_mfma_f32_16x16x4 would use 3 of 16 columns")
         line["roofline"] = r
-        if world == 1 and a.paced_ticks > 0 and hasattr(head, "g1") and PLATFORM.device != "cpu":
-            # the same ticks at an MSTicker's cadence -- one per 10 ms of wall time, the GPU idle for the rest of each
-            # interval -- reported beside the back-to-back series, not part of `value`: the idle gaps let the clocks
-            # drop (scripts/throttle_probe.sh: +0.2-0.3 ms per tick) and the device averages less power
-            try:
-                v = np.empty(a.paced_ticks)
-                nxt = time.perf_counter()
-                for t in range(a.paced_ticks):
-                    while time.perf_counter() < nxt:
-                        pass
-                    nxt += 0.010
-                    ctx.timer_start()
-                    head.g1[t % len(head.g1)].launch()
-                    v[t] = ctx.timer_stop()
-                line["config"]["paced_ticks"] = dict(series_stats(v), cadence_ms=10,
-                                                     note="one tick per 10 ms of wall time (not `value`: that is the back-to-back series)")
-            except Exception as e:
-                line["config"]["paced_ticks"] = {"error": str(e)[:200]}
+        if paced is not None:
+            kept = "the product's keep-alive (mi_ctx_keepalive: one sleeping wavefront in flight across the idle gap) between the ticks"
+            line["config"]["paced_ticks"] = dict(series_stats(paced), cadence_ms=10, keepalive=not a.no_keepalive,
+                                                 note="one tick per 10 ms of wall time, as an MSTicker fires them, " +
+                                                      ("without the keep-alive" if a.no_keepalive else "with " + kept) +
+                                                      "; part of `value`'s criterion: no tick of this series may reach 10 ms either")
+            if world == 1 and not a.no_keepalive and a.paced_ticks >= 500:
+                try:  # the same cadence with the device left idle between the ticks: what the keep-alive buys
+                    v = head.paced_series(1000, keepalive=False)
+                    line["config"]["paced_ticks_idle_gaps"] = dict(series_stats(v), cadence_ms=10, keepalive=False,
+                                                                   note="not `value`: the same cadence without the keep-alive (the clocks drop in every gap)")
+                except Exception as e:
+                    line["config"]["paced_ticks_idle_gaps"] = {"error": str(e)[:200]}
     head.close()
     if converged is not None:
         converged.close()
@@ -1448,6 +1569,11 @@ def main():
                         line[key] = session_probe(ms, ctx, n_local, **kw)
                     except Exception as e:
                         line[key] = {"error": str(e)[:200]}
+        if not a.no_plugin_path:
+            try:
+                line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)
+            except Exception as e:
+                line["plugin_path"] = {"error": str(e)[:300]}
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_chain(a.cpu_seconds, threads=1)
             try:

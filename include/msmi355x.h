@@ -80,6 +80,13 @@ int mi_device_count(void);
 int mi_ctx_create(int device, void *hip_stream, mi_ctx **out);
 void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_sync(mi_ctx *ctx);
+/* Keeps the device at its clocks across the idle gap between two ticks of a PACED deployment (an MSTicker fires every
+ * 10 ms, src/base/msticker.c:419-443,496-515; a tick of 9 ms leaves the GPU idle for a millisecond, its clocks drop and the
+ * next tick starts slow): one wavefront, asleep in s_sleep almost all the time, stays in flight on a stream of its own
+ * until the next call -- which tells it to leave and starts its successor -- or for max_us microseconds at most (a host
+ * that stops ticking leaves nothing behind).  max_us == 0 only stops the one in flight.  Call it once per tick, before the
+ * tick's launches; mi_session_submit and the plugin's hub flush do (MSMI355X_KEEPALIVE=0 turns that off). */
+int mi_ctx_keepalive(mi_ctx *ctx, int max_us);
 void *mi_ctx_stream(mi_ctx *ctx);
 int mi_ctx_device(mi_ctx *ctx);
 /* device properties the bench reports: CU count, HBM bytes, name */
@@ -254,7 +261,10 @@ int mi_mixer_process_volume_fifo(struct mi_mixer *m, mi_volume *v, int first_str
  * that pin (audiomixer.c:88).  Without the flag the dry pin is metered on a tick of silence (mi_fifo_pop with zero_fill).
  * The plugin's fused call-leg chain (mediastreamer2_amd/host/filters/leg_chain.inl) sets it. */
 #define MI_VOLMIX_DRY_SKIPS 1u
-int mi_mixer_process_volume_fifo_flags(struct mi_mixer *m, mi_volume *v, int first_stream, struct mi_fifo *f_src, int16_t *d_out, unsigned flags);
+/* d_run (nullable) [nconf]: conferences with 0 do not tick in this launch -- nothing is popped, metered or written for them
+ * (a mixer that is not due: mixer_check_bypass found nobody contributing, audiomixer.c:244-286; a conference slot not in use) */
+int mi_mixer_process_volume_fifo_flags(struct mi_mixer *m, mi_volume *v, int first_stream, struct mi_fifo *f_src, int16_t *d_out, unsigned flags,
+                                       const uint8_t *d_run);
 
 /* ----------------------------------------------------------- equalizer */
 typedef struct mi_equalizer mi_equalizer;

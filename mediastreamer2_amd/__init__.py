@@ -69,6 +69,10 @@ class Context:
     def sync(self):
         check(self.L.mi_ctx_sync(self.h))
 
+    def keepalive(self, max_us=15000):
+        """one sleeping wavefront in flight until the next call (or max_us): the device keeps its clocks between paced ticks"""
+        check(self.L.mi_ctx_keepalive(self.h, int(max_us)))
+
     @property
     def stream(self):
         return self.L.mi_ctx_stream(self.h)
@@ -208,11 +212,11 @@ class MixerBatch(_Batch):
         check(self.ctx.L.mi_mixer_process(self.h, _ptr(x), _ptr(has_data), int(conf_mode), _ptr(out)))
         return out
 
-    def process_volume_fifo(self, vol, fifo, out, first_stream=0, dry_skips=False):
+    def process_volume_fifo(self, vol, fifo, out, first_stream=0, dry_skips=False, run=None):
         """MSVolume + the conference mix in one launch: every pin's chunk popped from `fifo`, levelled by `vol` (stream
         first_stream + conference * members + pin), mixed in conference mode into out [nconf, mm, ns]; dry_skips: a pin
         whose queue holds less than a tick is not metered (MI_VOLMIX_DRY_SKIPS)"""
-        check(self.ctx.L.mi_mixer_process_volume_fifo_flags(self.h, vol.h, first_stream, fifo.h, _ptr(out), 1 if dry_skips else 0))
+        check(self.ctx.L.mi_mixer_process_volume_fifo_flags(self.h, vol.h, first_stream, fifo.h, _ptr(out), 1 if dry_skips else 0, _ptr(run)))
         return out
 
     def partial_sum(self, x, d_sum, has_data=None):

@@ -23,7 +23,7 @@ class MiError(RuntimeError):
 # every symbol include/msmi355x.h declares (tests check the export table against this)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count",
-    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_keepalive", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
     "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
     "mi_timer_start", "mi_timer_stop",
@@ -172,7 +172,8 @@ def load():
     L.mi_fifo_phase_of.argtypes = [i32, i32]
     L.mi_volume_process_fifo_range.argtypes = [vp, vp, vp, i32, i32, i32, i32]
     L.mi_mixer_process_volume_fifo.argtypes = [vp, vp, i32, vp, vp]
-    L.mi_mixer_process_volume_fifo_flags.argtypes = [vp, vp, i32, vp, vp, u32]
+    L.mi_mixer_process_volume_fifo_flags.argtypes = [vp, vp, i32, vp, vp, u32, vp]
+    L.mi_ctx_keepalive.argtypes = [vp, i32]
     L.mi_volume_get_state_async.argtypes = [vp, i32, i32, vp]
     L.mi_volume_get_max.argtypes = [vp, i32, i32, vp]
     L.mi_volume_reset_max.argtypes = [vp, i32, i32]

@@ -373,6 +373,7 @@ struct VolMixArgs {
 	int16_t *out;         // [nconf][mm][ns]
 	int mm, row_w;        // members per conference; row pitch in 8-byte words (odd)
 	int dry_skips;        // MI_VOLMIX_DRY_SKIPS: a leg whose queue holds less than a tick is not metered at all (MSVolume gets no chunk)
+	const uint8_t *run;   // nullable [nconf]: 0 = the conference does not tick in this launch (nothing popped, nothing written)
 };
 constexpr int VM_THREADS = 256, VM_MAXM = MI_MIXER_MAX_CHANNELS;
 
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	__shared__ int s_intgain[VM_MAXM], s_dcoff[VM_MAXM], s_mode[VM_MAXM], s_pk[VM_MAXM], s_dc[VM_MAXM], s_head[VM_MAXM], s_flag[VM_MAXM];
 	__shared__ float s_mgain[VM_MAXM];
 	const int t = threadIdx.x, c = blockIdx.x, mm = va.mm, ns = a.nsamples, nw = ns >> 2, ng = ns >> 3;
+	if (va.run && !va.run[c]) return;
 	const int s0 = a.first + c * mm;
 
 	mi_volume_params p;
@@ -691,10 +693,11 @@ int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f_src, int16_t *d_out, i
 }
 
 int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first_stream, mi_fifo *f_src, int16_t *d_out) {
-	return mi_mixer_process_volume_fifo_flags(m, v, first_stream, f_src, d_out, 0u);
+	return mi_mixer_process_volume_fifo_flags(m, v, first_stream, f_src, d_out, 0u, nullptr);
 }
 
-int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stream, mi_fifo *f_src, int16_t *d_out, unsigned flags) {
+int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stream, mi_fifo *f_src, int16_t *d_out, unsigned flags,
+                                       const uint8_t *d_run) {
 	MI_CHECK_ARG(m && v && f_src && d_out && first_stream >= 0);
 	MixerView mv;
 	mi_mixer_view(m, &mv);
@@ -733,6 +736,7 @@ int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stre
 	a.mm = mv.mm;
 	a.row_w = row_w;
 	a.dry_skips = (flags & MI_VOLMIX_DRY_SKIPS) ? 1 : 0;
+	a.run = d_run;
 	static std::atomic<uint64_t> big_lds{0}; // more than 64 KB of dynamic LDS needs the attribute once per device
 	const uint64_t dev_bit = 1ull << (v->ctx->device & 63);
 	if (lds > 64 * 1024 && !(big_lds.load(std::memory_order_relaxed) & dev_bit)) {

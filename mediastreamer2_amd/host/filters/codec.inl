@@ -324,9 +324,9 @@ void l16_enc_update(MapFilter *d) { d->nbytes = (size_t)((2 * d->nchannels * d->
 void l16_enc_preprocess(MSFilter *f) { l16_enc_update((MapFilter *)f->data); }
 void l16_enc_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
-	ms_filter_lock(f);
 	map_rehome(f, d);
-	HubLock lk(f);
+	HubLock lk(f); // lock order everywhere: the hub first, the filter's own lock inside it
+	ms_filter_lock(f);
 	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	if (d->nbytes >= 2 && ms_bufferizer_get_avail(d->bz) >= d->nbytes) {
 		if (!map_attach(f, d, OP_L16_SWAP)) ms_bufferizer_flush(d->bz);

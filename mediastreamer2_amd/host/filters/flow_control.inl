@@ -147,8 +147,8 @@ void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_rese
 }
 void flowctl_process(MSFilter *f) { // :171-183
 	FlowFilter *d = (FlowFilter *)f->data;
+	HubLock lk(f); // lock order everywhere: the hub first, the filter's own lock inside it
 	ms_filter_lock(f);
-	HubLock lk(f);
 	if (!flowctl_attach(f, d)) {
 		ms_queue_flush(f->inputs[0]);
 		ms_filter_unlock(f);
@@ -199,9 +199,9 @@ int flowctl_set_config(MSFilter *f, void *arg) { // :193-197
 int flowctl_drop(MSFilter *f, void *arg) { // :199-211; applied by the next launch at this point of the block sequence
 	FlowFilter *d = (FlowFilter *)f->data;
 	const MSAudioFlowControlDropEvent *ev = (const MSAudioFlowControlDropEvent *)arg;
+	HubLock lk(f);
 	ms_filter_lock(f);
 	{
-		HubLock lk(f);
 		if (d->pool && d->pool->req_drop[(size_t)d->slot] == 0 && d->pool->req_total[(size_t)d->slot] == 0) {
 			d->pool->req_drop[(size_t)d->slot] = (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;
 			d->pool->req_total[(size_t)d->slot] = (ev->flow_control_interval_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;

@@ -64,6 +64,7 @@ void mix_slab_release(void *payload) { // db_freefn of the slab's data block (th
 int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t now); // mixer.inl
 void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
+void leg_conf_walked(LegBank *b, int c);
 
 struct LegBank : Pool {
 	uint32_t in_rate, rate;
@@ -98,9 +99,17 @@ struct LegBank : Pool {
 	std::vector<uint8_t> vp_dirty, vs_dirty;
 	bool v_dirty = false;
 	std::vector<std::pair<int, int>> drops; // (leg slot, chunks) the mixer channels' flow control discards this flush
-	uint64_t mix_time = (uint64_t)-1;       // ticker time of the last conference tick (one per tick, whoever flushes)
+	std::vector<uint64_t> conf_time;        // ticker time of a conference's last tick (one per tick, whoever enqueues)
+	std::vector<uint32_t> walk_tick;        // ticker tick in which a conference's mixer was last walked
+	uint32_t walk_epoch = 0;
+	uint8_t *h_run, *d_run;                 // [capacity]: conferences that tick in this launch of the volume + mix kernel
+	bool staged_since = false;              // something was staged (or a conference joined) since the last enqueue
+	bool outstanding = false;               // an enqueue has not been waited for yet
 	bool mixed = false, check_levels = false;
 	uint64_t launches = 0;
+	std::vector<std::pair<MSQueue *, mblk_t *>> spk; // speaker-pin frames of this flush (MSSpeexEC pin 0: host audio), handed on in finish()
+	int walked = 0;                                  // conferences whose mixer has run in this tick's graph walk
+	bool early = false, early_any = false;           // this tick's work was enqueued at the end of the walk (leg_conf_walked)
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
 	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members)
@@ -138,6 +147,10 @@ struct LegBank : Pool {
 		d_lv = devmem<int32_t>(3 * L);
 		h_vstate = pinned<mi_volume_state>(L);
 		h_copy = pinned<int16_t>(L * ns);
+		h_run = pinned<uint8_t>((size_t)capacity);
+		d_run = devmem<uint8_t>((size_t)capacity);
+		conf_time.assign((size_t)capacity, (uint64_t)-1);
+		walk_tick.assign((size_t)capacity, 0);
 		if (!failed) MI_MUST(mi_memset(hub->ctx, d_zero, 0, L * 4));
 		legs.assign(L, nullptr);
 		conf_ready.assign((size_t)capacity, 0);
@@ -154,6 +167,7 @@ struct LegBank : Pool {
 	}
 	~LegBank() override {
 		if (root) freeb(root);
+		for (auto &qm : spk) freemsg(qm.second);
 		for (FusedLeg *l : legs) delete l;
 		if (hub->ctx) mi_ctx_sync(hub->ctx);
 		if (mix) mi_mixer_destroy(mix);
@@ -244,8 +258,22 @@ struct LegBank : Pool {
 	}
 
 	bool enqueue() override {
+		bool any = false;
+		const bool was_early = early;
+		if (early) { // already out since the end of the last graph walk
+			early = false;
+			any = early_any;
+		}
+		// (what was staged after an early enqueue -- a conference that joined the bank later in that walk -- goes out now)
+		if (!was_early || staged_since) any |= enqueue_at(hub->ticker ? hub->ticker->time : 0);
+		outstanding = false; // the hub waits for the stream right behind this
+		return any;
+	}
+	bool enqueue_at(uint64_t now) {
 		mi_ctx *ctx = hub->ctx;
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm; // legs of the conference slots ever handed out
+		if (outstanding) sync_stream(); // (rare: a second enqueue in one flush) the staging arrays are about to be rewritten
+		staged_since = false;
 		if (root) emitted();
 		// ---- pending control changes (methods called since the last flush)
 		if (ctl_dirty) {
@@ -281,17 +309,17 @@ struct LegBank : Pool {
 			leg->newchunks += leg->vol_rem / ns;
 			leg->vol_rem %= ns;
 		}
-		const uint64_t now = hub->ticker ? hub->ticker->time : 0;
-		mixed = false;
 		drops.clear();
-		if (!failed && (mix_time != now || !hub->ticker)) { // the mixers tick once per ticker time, whoever flushes
-			mix_time = now;
-			for (int c = 0; c < hi; ++c)
-				if (owner[(size_t)c]) {
-					conf_tick(c, now);
-					mixed |= conf_ready[(size_t)c] != 0;
-				}
+		bool ticked = false;
+		for (int c = 0; c < capacity; ++c) { // a mixer ticks once per ticker time, whoever enqueues
+			h_run[c] = 0;
+			if (failed || c >= hi || !owner[(size_t)c] || conf_time[(size_t)c] == now) continue;
+			conf_time[(size_t)c] = now;
+			conf_tick(c, now);
+			h_run[c] = conf_ready[(size_t)c];
+			ticked |= conf_ready[(size_t)c] != 0;
 		}
+		mixed |= ticked;
 		if (failed) return false;
 		bool any = false;
 		// ---- the device's half, in the order the reference's process() works: far end queued, then the frames, then the mix
@@ -317,15 +345,16 @@ struct LegBank : Pool {
 			                                              MI_AEC_POSTFILTER, nullptr, d_gate + (size_t)r * L));
 			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
 		}
-		if (mixed) {
-			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, d_mix, MI_VOLMIX_DRY_SKIPS));
+		if (ticked) {
+			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, (size_t)capacity));
+			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, d_mix, MI_VOLMIX_DRY_SKIPS, d_run));
 			++launches;
 			for (const auto &dk : drops) // chunks the channels' flow control discards: metered (MSVolume saw them), never mixed
 				for (int k = 0; k < dk.second; ++k) {
 					MI_MUST(mi_volume_process_fifo_range(vol, f_out, d_scratch, ns, ns, dk.first, 1));
 					++launches;
 				}
-			cur = free_slab();
+			if (!cur) cur = free_slab();
 			MI_MUST(mi_copy_d2h(ctx, cur ? (void *)cur->payload() : (void *)h_copy, d_mix, UL * ns * 2));
 			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 			any = true;
@@ -336,11 +365,14 @@ struct LegBank : Pool {
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
 			MI_MUST(mi_copy_d2h(ctx, h_lv, d_lv, 3 * L * 4));
 		}
+		outstanding |= any;
 		return any;
 	}
 
 	void finish() override {
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
+		for (auto &qm : spk) ms_queue_put(qm.first, qm.second); // MSSpeexEC's speaker pin: one frame per microphone frame (speexec.c:261-284)
+		spk.clear();
 		if (failed) {
 			std::fill(conf_ready.begin(), conf_ready.end(), 0);
 			g_late_events.fetch_add(1, std::memory_order_relaxed);
@@ -362,6 +394,7 @@ struct LegBank : Pool {
 				cur->state.store(1, std::memory_order_release);
 				root = esballoc(cur->payload(), cur->bytes, 0, mix_slab_release);
 			}
+			mixed = false;
 		}
 		if (check_levels)
 			for (size_t s = 0; s < UL; ++s) {
@@ -408,10 +441,11 @@ struct LegBank : Pool {
 // one speaker frame per microphone frame, on counts: ec_emit_speaker_frame with the delay line on the device
 void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes) {
 	const int fs = (int)(nbytes / 2);
+	LegBank *b = leg->bank;
 	if (leg->dref_level < s->nominal_ref_samples + fs) {
 		leg->inject += fs; // behind everything the far end delivered so far (ms_bufferizer_put(&s->delayed_ref, silence))
 		leg->dref_level += fs;
-		if (f->outputs[0]) ms_queue_put(f->outputs[0], ec_block(nbytes));
+		if (f->outputs[0]) b->spk.push_back({f->outputs[0], ec_block(nbytes)});
 		if (!s->using_zeroes) ms_warning("Not enough ref samples, using zeroes");
 		s->using_zeroes = TRUE;
 		return;
@@ -423,8 +457,25 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 		ms_error("mi355x echo canceller: the far-end bufferizer ran dry; silence sent to the speaker");
 		memset(m->b_rptr, 0, nbytes);
 	}
-	if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+	if (f->outputs[0]) b->spk.push_back({f->outputs[0], m}); // (handed on with the flush's results, see LegBank::finish)
 	else freemsg(m);
+}
+
+// Every conference of the bank has been walked in this tick (its mixer runs behind all of its legs in the ticker's
+// depth-first order, msticker.c:261-282, so everything the tick will stage IS staged): the bank's uploads and launches go
+// out NOW, at the end of the graph walk, instead of at the start of the next tick -- the device works through the idle
+// part of the interval and the next tick's flush finds the results waiting.  Same results, same one tick of latency; the
+// launches just leave the tick's critical path.  (A tick in which some mixer did not run falls back to the flush.)
+void leg_conf_walked(LegBank *b, int c) {
+	static const bool off = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr;
+	if (off || b->failed || b->early || !b->hub->ticker) return;
+	const uint32_t tick = b->hub->ticker->ticks;
+	if (b->walk_epoch != tick) b->walk_epoch = tick, b->walked = 0;
+	if (b->walk_tick[(size_t)c] == tick) return;
+	b->walk_tick[(size_t)c] = tick;
+	if (++b->walked < b->in_use) return;
+	b->early_any = b->enqueue_at(b->hub->ticker->time + (uint64_t)b->hub->ticker->interval); // the mixers' clock reads what the flush would
+	b->early = true;
 }
 
 // ---- the facades' fused halves -----------------------------------------------------------------------------------------
@@ -438,7 +489,10 @@ void leg_stage_mic(MSFilter *f, ResampleData *d) {
 		ms_bufferizer_read(d->bz, (uint8_t *)(b->h_mic + ((size_t)leg->staged_mic * b->nlegs + (size_t)leg->slot) * b->in_len), nbytes);
 		leg->staged_mic++;
 	}
-	if (leg->staged_mic) request_flush(f);
+	if (leg->staged_mic) {
+		b->staged_since = true;
+		request_flush(f);
+	}
 }
 
 // MSSpeexEC, far end (speexec.c:239-250): dropped until the microphone has started, then kept twice -- for the canceller
@@ -472,7 +526,10 @@ void leg_take_far_end(MSFilter *f, SpeexECState *s) {
 		}
 		flowbuf_put(&s->ref, m);
 	}
-	if (leg->staged_ref) request_flush(f);
+	if (leg->staged_ref) {
+		b->staged_since = true;
+		request_flush(f);
+	}
 }
 
 // ---- fusing ------------------------------------------------------------------------------------------------------------
@@ -613,6 +670,8 @@ bool conf_try_fuse(MSFilter *mx) {
 	ms->pool->release(ms->slot);
 	ms->pool = nullptr, ms->slot = -1;
 	ms->fbank = b, ms->fconf = c;
+	b->conf_time[(size_t)c] = (uint64_t)-1;
+	b->staged_since = true;
 	ms->fuse_state = 1;
 	ms->unfuse_wanted = false;
 	ms->first_look = false;

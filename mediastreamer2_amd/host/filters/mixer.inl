@@ -5,6 +5,7 @@
 // ======================================================================= mixer
 constexpr int MIXER_MAX_CHANNELS = MI_MIXER_MAX_CHANNELS; // audiomixer.c:29
 Pool *leg_pool_of(LegBank *b);                            // leg_chain.inl
+void leg_conf_walked(LegBank *b, int c);
 constexpr uint64_t BYPASS_MODE_TIMEOUT = 1000;            // audiomixer.c:31
 
 struct MixerPool : Pool {
@@ -310,9 +311,10 @@ void MixerPool::emit(MSFilter *f, int slot) {
 
 void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
+	// lock order everywhere: the hub first, the filter's own lock inside it (the flush task pumps this filter with the hub held)
+	HubLock lk(f, s->fbank ? leg_pool_of(s->fbank) : static_cast<Pool *>(s->pool));
 	ms_filter_lock(f);
 	if (s->unfuse_wanted && s->fbank) conf_unfuse(f, true); // a member stopped qualifying: back to the facades' own banks
-	HubLock lk(f, s->fbank ? leg_pool_of(s->fbank) : static_cast<Pool *>(s->pool));
 	if (s->fuse_state == 0 && !s->fbank) conf_try_fuse(f); // (normally a leg's head got here first)
 	if (s->fbank) { // fused: the conference ticks inside the hub's flush; a pump keeps that flush coming every tick
 		if (!s->first_look) { // the census of the attach's first tick (this walk): a pin's clock starts when it is first looked at
@@ -322,6 +324,7 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 		}
 		mixer_release_held(f, s, true);
 		request_flush(f);
+		leg_conf_walked(s->fbank, s->fconf); // the last conference of the bank to be walked sends the bank's work to the device right away
 		ms_filter_unlock(f);
 		return;
 	}
@@ -408,8 +411,8 @@ int mixer_enable_output(MSFilter *f, void *data) { // :395-408
 	MixerState *s = (MixerState *)f->data;
 	MSAudioMixerCtl *ctl = (MSAudioMixerCtl *)data;
 	if (!mixer_pin_ok("mixer_enable_output", ctl->pin)) return -1;
-	ms_filter_lock(f);
 	HubLock lk(f);
+	ms_filter_lock(f);
 	s->channels[ctl->pin].output_enabled = (bool_t)ctl->param.enabled;
 	s->single_output = has_single_output(f, s);
 	mixer_push_controls(f, s);

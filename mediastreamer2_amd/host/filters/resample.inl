@@ -137,25 +137,22 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 			ms_queue_put(f->outputs[0], channel_adapt(d->in_nchannels, d->out_nchannels, im));
 		return;
 	}
-	ms_filter_lock(f);
-	if (!d->leg && !d->fuse_checked && !d->pool && f->ticker) { // first block since the attach: is this the head of a leg of a conference?
-		d->fuse_checked = true;
-		if (MSFilter *mx = leg_find_mixer(f)) {
-			HubLock lk(f);
-			conf_try_fuse(mx);
-		}
-	}
-	if (d->leg) { // fused: the block goes into the leg's row of the conference's bank, nothing is emitted here
-		HubLock lk(f, leg_pool(d->leg));
-		leg_stage_mic(f, d);
-		ms_filter_unlock(f);
-		return;
-	}
+	// lock order everywhere: the hub first, the filter's own lock inside it (the flush task calls process() with the hub held)
 	if (d->pool && d->pool->hub->ticker != f->ticker) { // the filter moved to another ticker: its slots go back under the OLD hub's lock
 		HubLock old(d->pool->hub);
 		resample_release(d);
 	}
-	HubLock lk(f, d->pool);
+	HubLock lk(f, d->leg ? leg_pool(d->leg) : static_cast<Pool *>(d->pool));
+	ms_filter_lock(f);
+	if (!d->leg && !d->fuse_checked && !d->pool && f->ticker) { // first block since the attach: is this the head of a leg of a conference?
+		d->fuse_checked = true;
+		if (MSFilter *mx = leg_find_mixer(f)) conf_try_fuse(mx);
+	}
+	if (d->leg) { // fused: the block goes into the leg's row of the conference's bank, nothing is emitted here
+		leg_stage_mic(f, d);
+		ms_filter_unlock(f);
+		return;
+	}
 	const int nch = d->in_nchannels < 1 ? 1 : d->in_nchannels;
 	if (d->pool && (d->pool->failed || d->pool->in_rate != d->input_rate || d->pool->out_rate != d->output_rate || (int)d->slots->size() != nch))
 		resample_release(d); // rates / channels changed: the handle is re-created, history lost (:138-148)

@@ -361,6 +361,7 @@ bool size_conv_stage(MSFilter *f, SizeConvState *s, const YuvBuf &in, uint32_t t
 void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
 	SizeConvState *s = (SizeConvState *)f->data;
 	bool staged = false;
+	HubLock lk(f); // lock order everywhere: the hub first, the filter's own lock inside it
 	ms_filter_lock(f);
 	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) putq(&s->rq, m);
 	if (!size_conv_rate_gate(f, s)) {
@@ -392,21 +393,16 @@ void size_conv_process(MSFilter *f) { // sizeconv.c:97-184
 		freemsg(im);
 	}
 	ms_filter_unlock(f);
-	if (staged) {
-		HubLock lk(f);
-		request_flush(f);
-	}
+	if (staged) request_flush(f);
 }
 
 int sizeconv_set_vsize(MSFilter *f, void *arg) { // sizeconv.c:186-197
 	SizeConvState *s = (SizeConvState *)f->data;
+	HubLock lk(f);
 	ms_filter_lock(f);
 	s->target_vsize = *(MSVideoSize *)arg;
 	ms_message("mi355x size converter: target size %dx%d", s->target_vsize.width, s->target_vsize.height);
-	{
-		HubLock lk(f);
-		size_conv_leave_pool(s, f);
-	}
+	size_conv_leave_pool(s, f);
 	ms_filter_unlock(f);
 	return 0;
 }

@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 nproc > gpurun_out/r04b_env.txt; lscpu | grep "Model name" >> gpurun_out/r04b_env.txt
-timeout 1500 python -m pytest tests/test_gpu_plugin_fused.py tests/test_gpu_plugin.py tests/test_gpu_plugin_codec.py tests/test_aec_tester_scenarios.py -m gpu -q -x 2>&1 | tail -30 | tee gpurun_out/r04b_pytest.log
+timeout 1800 python -m pytest tests/test_gpu_plugin_fused.py tests/test_gpu_plugin.py tests/test_gpu_plugin_codec.py tests/test_aec_tester_scenarios.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | grep -v "^ms2shim" | tail -40 | tee gpurun_out/r04b_pytest.log
 PB=tests/host/plugin_bench; PL=mediastreamer2_amd/libmsmi355xfilters.so
 for cfg in "4096 4" "16384 8" "32768 8" "32768 16" "65536 16"; do
   set -- $cfg

@@ -136,9 +136,33 @@ class Rig:
         pass
 
 
+class Exchange:
+    """stands in for mediastreamer2_amd.Exchange (mi_exchange on RCCL) so that bench.HipPlatform.exchange's own control flow --
+    the id from rank 0, the probe, the agreement of the ranks, ONE contract: it works everywhere or the run fails everywhere
+    -- runs over gloo (DOUBLE_EXCHANGE_C=1); DOUBLE_EXCHANGE_FAIL_RANK=r makes rank r's communicator fail to start"""
+
+    @staticmethod
+    def unique_id(ctx):
+        return bytes([7]) * 128
+
+    def __init__(self, ctx, world, rank, idb):
+        if os.environ.get("DOUBLE_EXCHANGE_FAIL_RANK") == str(rank):
+            raise RuntimeError("ncclCommInitRank: unhandled system error (the double's)")
+        assert idb == bytes([7]) * 128
+
+    def __call__(self, d_sum):
+        import torch.distributed as dist
+        dist.all_reduce(d_sum)
+        Clock.now_ms += float(os.environ.get("DOUBLE_EXCHANGE_MS", "0.02"))
+
+    def close(self):
+        pass
+
+
 class KernelLibraryDouble:
     Context = Context
     MixerBatch = MixerBatch
+    Exchange = Exchange
 
 
 class CpuDouble(bench.HipPlatform):
@@ -165,6 +189,8 @@ class CpuDouble(bench.HipPlatform):
 
     def exchange(self, ctx, local, dist_, rank, world, backend):
         import torch.distributed as dist
+        if os.environ.get("DOUBLE_EXCHANGE_C"):  # the product's own bring-up code, with the double's communicator behind it
+            return bench.HipPlatform.exchange(self, ctx, local, dist_, rank, world, "nccl")
 
         def exchange(d_sum):
             dist.all_reduce(d_sum)

@@ -168,6 +168,10 @@ int mi_copy_d2h(mi_ctx *c, void *h, const void *d, size_t n) {
 	memcpy(h, d, n);
 	return MI_OK;
 }
+int mi_ctx_keepalive(mi_ctx *c, int max_us) {
+	ARG(c && max_us >= 0);
+	return MI_OK; // nothing to keep awake
+}
 int mi_memset(mi_ctx *c, void *d, int v, size_t n) {
 	ARG(c && d);
 	memset(d, v, n);
@@ -778,20 +782,31 @@ int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f, int16_t *out, int ns,
 	}
 	return MI_OK;
 }
-int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out, unsigned flags) {
+int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out, unsigned flags, const uint8_t *run) {
 	ARG(m && v && f && out && first >= 0 && first + m->nconf * m->mm <= v->n && f->n == v->n);
 	std::vector<int16_t> ticks((size_t)v->n * m->ns);
 	std::vector<int32_t> per((size_t)v->n, 0);
-	for (int s = first; s < first + m->nconf * m->mm; ++s) { // a dry leg is metered on silence, or (MI_VOLMIX_DRY_SKIPS) not at all
-		const bool has = (int)f->q[(size_t)s].size() >= m->ns;
-		per[(size_t)s] = (has || !(flags & MI_VOLMIX_DRY_SKIPS)) ? m->ns : 0;
+	for (int c = 0; c < m->nconf; ++c) {
+		if (run && !run[c]) continue; // the conference does not tick: nothing popped, nothing written
+		const int s0 = first + c * m->mm;
+		for (int s = s0; s < s0 + m->mm; ++s) { // a dry leg is metered on silence, or (MI_VOLMIX_DRY_SKIPS) not at all
+			const bool has = (int)f->q[(size_t)s].size() >= m->ns;
+			per[(size_t)s] = (has || !(flags & MI_VOLMIX_DRY_SKIPS)) ? m->ns : 0;
+		}
+		int rc = mi_volume_process_fifo_range(v, f, ticks.data(), m->ns, m->ns, s0, m->mm); // pops (zeros for the dry ones)
+		if (rc != MI_OK) return rc;
 	}
-	int rc = mi_volume_process_fifo_range(v, f, ticks.data(), m->ns, m->ns, first, m->nconf * m->mm); // pops (zeros for the dry ones)
-	if (rc == MI_OK) rc = mi_volume_process(v, ticks.data(), m->ns, m->ns, per.data());
-	return rc != MI_OK ? rc : mi_mixer_process(m, ticks.data() + (size_t)first * m->ns, nullptr, 1, out);
+	int rc = mi_volume_process(v, ticks.data(), m->ns, m->ns, per.data());
+	if (rc != MI_OK) return rc;
+	std::vector<uint8_t> all;
+	std::vector<int16_t> mixed((size_t)m->nconf * m->mm * m->ns);
+	rc = mi_mixer_process(m, ticks.data() + (size_t)first * m->ns, nullptr, 1, mixed.data());
+	for (int c = 0; c < m->nconf && rc == MI_OK; ++c)
+		if (!run || run[c]) memcpy(out + (size_t)c * m->mm * m->ns, mixed.data() + (size_t)c * m->mm * m->ns, (size_t)m->mm * m->ns * 2);
+	return rc;
 }
 int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first, mi_fifo *f, int16_t *out) {
-	return mi_mixer_process_volume_fifo_flags(m, v, first, f, out, 0u);
+	return mi_mixer_process_volume_fifo_flags(m, v, first, f, out, 0u, nullptr);
 }
 
 // ---- codecs and friends

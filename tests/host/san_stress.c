@@ -12,6 +12,10 @@
  *                conference mixer now and then), some ticks, detach, destroy everything -- the hub dies with its last bank;
  *   grower       one ticker, 150 filters attached one after the other (banks of 16, 64, 256 slots open), ticks, half of
  *                them detached and destroyed, ticks, the rest destroyed, all over again;
+ *   conferences  one ticker, two conferences of  source -> MSResample -> MSSpeexEC -> MSVolume (AGC) -> MSAudioMixer  legs: the
+ *                plugin fuses each into its device-resident batch (filters/leg_chain.inl); ticks, a volume method from this
+ *                thread between ticks, one leg's canceller switched to bypass (the conference leaves the batch and goes on
+ *                facade by facade), detach, re-attach (fuses again), ticks, everything destroyed;
  *   walker       ms_mi355x_runtime_stats / ms_mi355x_hub_devices over every hub, all the time (ms_mi355x_flush is for a
  *                stopped graph: it emits into the filters' queues and is called once, at the end).
  * Ends with the runtime where it started (no hub, no bank, no slot) and no late events; prints "ok".
@@ -211,6 +215,77 @@ static void *grower(void *arg) {
 	return NULL;
 }
 
+typedef struct {
+	MSFilter *mic, *far, *rs, *ec, *vol, *spk, *out;
+} leg_t;
+
+static void *conferences(void *arg) {
+	enum { NC = 2, NM = 5 };
+	int16_t mic[160], far[480];
+	void (*p_fused)(int *, int *, unsigned long long *, unsigned long long *) = (void (*)(int *, int *, unsigned long long *, unsigned long long *))arg;
+	for (int i = 0; i < 160; ++i) mic[i] = (int16_t)(i * 91 % 4000 - 2000);
+	for (int i = 0; i < 480; ++i) far[i] = (int16_t)(i * 57 % 6000 - 3000);
+	for (int rep = 0; rep < (g_rounds + 1) / 2; ++rep) {
+		MSTicker *tk = ms_ticker_new();
+		MSFilter *mx[NC];
+		leg_t leg[NC][NM];
+		for (int c = 0; c < NC; ++c) {
+			mx[c] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+			set_int(mx[c], MS_FILTER_SET_SAMPLE_RATE, 48000);
+			set_int(mx[c], MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
+			for (int k = 0; k < NM; ++k) {
+				leg_t *l = &leg[c][k];
+				l->mic = ms2shim_new_source(g_fac), l->far = ms2shim_new_source(g_fac);
+				l->spk = ms2shim_new_sink(g_fac), l->out = ms2shim_new_sink(g_fac);
+				l->rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
+				l->ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
+				l->vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+				ms2shim_sink_set_discard(l->spk, 1), ms2shim_sink_set_discard(l->out, 1);
+				set_int(l->rs, MS_FILTER_SET_SAMPLE_RATE, 16000), set_int(l->rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
+				set_int(l->ec, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
+				set_int(l->vol, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->vol, MS_VOLUME_ENABLE_AGC, 1);
+				ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1), ms_filter_link(l->ec, 1, l->vol, 0);
+				ms_filter_link(l->vol, 0, mx[c], k), ms_filter_link(mx[c], k, l->out, 0);
+				ms_filter_link(l->far, 0, l->ec, 0), ms_filter_link(l->ec, 0, l->spk, 0);
+			}
+			CHECK(ms_ticker_attach(tk, mx[c]) == 0);
+		}
+		for (int t = 0; t < 14; ++t) {
+			for (int c = 0; c < NC; ++c)
+				for (int k = 0; k < NM; ++k) {
+					ms2shim_source_push(leg[c][k].mic, mic, sizeof mic);
+					ms2shim_source_push(leg[c][k].far, far, sizeof far);
+				}
+			ms_ticker_step(tk);
+			if (t == 2) { /* both conferences live in the fused batch by now */
+				int nc = 0, nl = 0;
+				p_fused(&nc, &nl, NULL, NULL);
+				CHECK(nc >= NC && nl >= NC * NM);
+			}
+			if (t == 4) { float g = 0.7f; ms_filter_call_method(leg[0][1].vol, MS_VOLUME_SET_GAIN, &g); } /* a method between ticks */
+			if (t == 6) { bool_t on = TRUE; ms_filter_call_method(leg[1][2].ec, MS_ECHO_CANCELLER_SET_BYPASS_MODE, &on); } /* conference 1 leaves the batch */
+			if (t == 9) { /* the whole graph of conference 0 detached and attached again: fuses again */
+				ms_ticker_detach(tk, mx[0]);
+				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
+			}
+		}
+		for (int c = 0; c < NC; ++c) {
+			ms_ticker_detach(tk, mx[c]);
+			for (int k = 0; k < NM; ++k) {
+				leg_t *l = &leg[c][k];
+				ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1), ms_filter_unlink(l->ec, 1, l->vol, 0);
+				ms_filter_unlink(l->vol, 0, mx[c], k), ms_filter_unlink(mx[c], k, l->out, 0);
+				ms_filter_unlink(l->far, 0, l->ec, 0), ms_filter_unlink(l->ec, 0, l->spk, 0);
+				ms_filter_destroy(l->mic), ms_filter_destroy(l->far), ms_filter_destroy(l->rs), ms_filter_destroy(l->ec);
+				ms_filter_destroy(l->vol), ms_filter_destroy(l->spk), ms_filter_destroy(l->out);
+			}
+			ms_filter_destroy(mx[c]);
+		}
+		ms_ticker_destroy(tk);
+	}
+	return NULL;
+}
+
 static void *walker(void *arg) {
 	long walks = 0;
 	(void)arg;
@@ -225,7 +300,8 @@ static void *walker(void *arg) {
 }
 
 int main(int argc, char **argv) {
-	pthread_t th[5];
+	pthread_t th[6];
+	void *p_fused = NULL;
 	void *walks = NULL;
 	int h, b, s;
 	if (argc < 2) {
@@ -246,7 +322,8 @@ int main(int argc, char **argv) {
 		p_flush = (void (*)(void))dlsym(so, "ms_mi355x_flush");
 		p_hub_devices = (int (*)(int *, int))dlsym(so, "ms_mi355x_hub_devices");
 		p_late = (unsigned long long (*)(void))dlsym(so, "ms_mi355x_late_events");
-		if (!p_stats || !p_flush || !p_hub_devices || !p_late) {
+		p_fused = dlsym(so, "ms_mi355x_fused_stats");
+		if (!p_stats || !p_flush || !p_hub_devices || !p_late || !p_fused) {
 			fprintf(stderr, "san_stress: plugin entry points missing\n");
 			return 2;
 		}
@@ -254,8 +331,10 @@ int main(int argc, char **argv) {
 	pthread_create(&th[3], NULL, walker, NULL);
 	for (int i = 0; i < 3; ++i) pthread_create(&th[i], NULL, caller, (void *)(intptr_t)(i + 1));
 	pthread_create(&th[4], NULL, grower, NULL);
+	pthread_create(&th[5], NULL, conferences, p_fused);
 	for (int i = 0; i < 3; ++i) pthread_join(th[i], NULL);
 	pthread_join(th[4], NULL);
+	pthread_join(th[5], NULL);
 	__atomic_store_n(&g_stop, 1, __ATOMIC_SEQ_CST);
 	pthread_join(th[3], &walks);
 	p_flush(); /* nothing is running any more */

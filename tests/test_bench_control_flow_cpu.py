@@ -94,3 +94,20 @@ def test_gpus_flag_without_the_launcher_is_a_usage_error():
 def test_ranks_that_do_not_divide_a_conference_are_refused():
     r = run(3, args=["--streams", "4096"])
     assert r.returncode != 0 and "do not divide a 32-party conference" in r.stderr
+
+
+def test_the_c_exchange_comes_up_on_every_rank_or_the_run_fails_on_every_rank():
+    """ONE multi-GPU contract (bench.HipPlatform.exchange, the code the 8-GPU run executes, here with the double's communicator
+    behind it): rank 0's id reaches the others, every rank probes its communicator, the ranks agree -- and if ANY rank could
+    not bring mi_exchange up, EVERY rank leaves with exit code 3 and RCCL's reason on stderr: no substitute transport, no
+    rank left waiting in a collective, no JSON line."""
+    ok = run(2, {"DOUBLE_EXCHANGE_C": "1"}, args=["--streams", "8192"])
+    assert ok.returncode == 0, ok.stderr[-3000:]
+    d = the_line(ok)
+    assert "mi_exchange_allreduce_i32 (C ABI, RCCL over xGMI" in d["config"]["parallelism"]
+    assert d["config"]["split_conferences"]["mix_bit_exact_vs_single_gpu"] is True
+    bad = run(2, {"DOUBLE_EXCHANGE_C": "1", "DOUBLE_EXCHANGE_FAIL_RANK": "1"}, args=["--streams", "8192"])
+    assert bad.returncode != 0
+    assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+    assert bad.stderr.count("could not be set up") >= 2 and "unhandled system error" in bad.stderr   # both ranks said so, with the reason
+    assert "torch.distributed's RCCL communicator instead" not in bad.stderr

@@ -102,7 +102,9 @@ def test_ticker_hubs_spread_over_the_devices_of_one_process(built, env, tickers,
     assert len(eval(lines["after"])) == after
 
 
-def test_split_conference_through_the_c_entry_points_with_a_rank_per_thread(built):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_split_conference_through_the_c_entry_points_with_a_rank_per_thread(built, world):
+    """(8 ranks on 8 devices: the shape of the driver's 8-GPU run of the exchange step, one thread and one device per rank)"""
     L = C.CDLL(os.path.join(DOUBLE, "libmsmi355x.so"))
     vp, pp = C.c_void_p, C.POINTER(C.c_void_p)
     L.mi_ctx_create.argtypes = [C.c_int, vp, pp]
@@ -115,8 +117,9 @@ def test_split_conference_through_the_c_entry_points_with_a_rank_per_thread(buil
     L.mi_exchange_allreduce_i32.argtypes = [vp, vp, C.c_size_t]
     L.mi_exchange_destroy.argtypes = [vp]
     L.mi_last_error.restype = C.c_char_p
-    os.environ["MSMI355X_DOUBLE_DEVICES"] = "4"
-    world, nconf, mm, ns, ticks = 4, 6, 32, 480, 5
+    os.environ["MSMI355X_DOUBLE_DEVICES"] = "8"
+    nconf, mm, ns, ticks = 6, 32, 480, 5
+    per = mm // world
     rng = np.random.default_rng(11)
     x = rng.integers(-16000, 16000, (ticks, nconf, mm, ns), dtype=np.int16)
     uid = (C.c_ubyte * 128)()
@@ -131,7 +134,7 @@ def test_split_conference_through_the_c_entry_points_with_a_rank_per_thread(buil
             assert L.mi_exchange_create(ctx, world, r, uid, C.byref(ex)) == 0, L.mi_last_error()   # returns when all four are in
             got = []
             for t in range(ticks):
-                mine = np.ascontiguousarray(x[t, :, r * 8:(r + 1) * 8])
+                mine = np.ascontiguousarray(x[t, :, r * per:(r + 1) * per])
                 total = np.zeros((nconf, ns), np.int32)
                 out = np.zeros_like(mine)
                 assert L.mi_mixer_partial_sum(mx, mine.ctypes.data, None, total.ctypes.data) == 0
@@ -157,6 +160,6 @@ def test_split_conference_through_the_c_entry_points_with_a_rank_per_thread(buil
         want = (x[t].astype(np.int64).sum(1, keepdims=True) - x[t]).clip(-32767, 32767)   # audiomixer.c:33-51,:301-344
         np.testing.assert_array_equal(ref, want)
         for r in range(world):
-            np.testing.assert_array_equal(outs[r][t], ref[:, r * 8:(r + 1) * 8])
+            np.testing.assert_array_equal(outs[r][t], ref[:, r * per:(r + 1) * per])
     bad = vp()
-    assert L.mi_exchange_create(ctx, 2, 7, uid, C.byref(bad)) != 0   # rank outside the communicator
+    assert L.mi_exchange_create(ctx, 2, 9, uid, C.byref(bad)) != 0   # rank outside the communicator
