@@ -68,7 +68,6 @@ def parse():
     ap.add_argument("--worst-ticks", type=int, default=3000, help="consecutive single ticks the worst tick is taken over")
     ap.add_argument("--zero-ticks", type=int, default=256, help="ticks of the from-reset test at the chosen count (0 = skip)")
     ap.add_argument("--paced-ticks", type=int, default=3000, help="ticks of the series run at the 10 ms cadence of an MSTicker, one per 10 ms of wall time: part of `value`'s criterion (0 = skip)")
-    ap.add_argument("--no-keepalive", action="store_true", help="paced series without the product's keep-alive between the ticks (mi_ctx_keepalive)")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the rate of full call legs through the drop-in plugin (tests/host/plugin_bench)")
     ap.add_argument("--plugin-legs", type=int, default=32768, help="full call legs the plugin path is first tried with (config[3]: 1024 conferences x 32)")
     ap.add_argument("--no-video-host", action="store_true", help="skip the PCIe-inclusive video probe (config 5)")
@@ -781,6 +780,52 @@ def _host_cores():
     return ncores, quota
 
 
+def video_host_probe(ms, ctx, seconds=2.0, batch=32, depth=3):
+    """BASELINE config 5 end to end on ONE GPU, PCIe included: 1080p I420 frames in pinned host buffers -> 720p RGB24 frames in
+    pinned host buffers through mi_scaler_pipe (batches of `batch` frames, `depth` in flight; upload | kernel | download on
+    three streams).  config 5's share per GPU is 2048 / 8 = 256 streams x 30 fps = 7 680 frames/s.  The producer writes into
+    the staging in place (acquire hands out the pinned buffer: a decoder's output buffer), so no host copy is timed."""
+    sc = ms.ScalerBatch(ctx, 1920, 1080, 1280, 720, ms.MI_PIX_RGB24)
+    pipe = ms.ScalerPipe(sc, batch, depth)
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, sc.src_bytes, dtype=np.uint8)
+    for _ in range(depth):  # every staging buffer of the ring holds frames; then the ring drains
+        buf = pipe.acquire()
+        buf[:, :sc.src_bytes] = frame
+        pipe.submit(batch)
+    first = None
+    while pipe.in_flight():
+        out = pipe.collect()
+        if first is None:
+            first = out[0, :sc.dst_bytes].copy()
+    want = sc.process(frame[None, :])[0]
+    exact = bool(np.array_equal(first, np.asarray(want)))
+    nb = 0
+    for _ in range(depth - 1):
+        pipe.acquire()
+        pipe.submit(batch)
+    t0 = time.perf_counter()
+    while True:
+        pipe.acquire()
+        pipe.submit(batch)
+        pipe.collect()
+        nb += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    while pipe.in_flight():
+        pipe.collect()
+    fps = nb * batch / dt
+    pipe.close()
+    sc.close()
+    return {"frames_per_s": round(fps, 1), "h2d_GBps": round(fps * sc.src_bytes / 1e9, 2), "d2h_GBps": round(fps * sc.dst_bytes / 1e9, 2),
+            "streams_1080p30": int(fps / 30), "fits_256x30fps": bool(fps >= 7680.0), "needed_frames_per_s": 7680,
+            "batch_frames": batch, "batches_in_flight": depth, "bit_exact_vs_synchronous": exact, "mpix_per_s_in": round(fps * 1920 * 1080 / 1e6, 1),
+            "what": "1080p I420 in pinned host memory -> 720p RGB24 in pinned host memory per frame, mi_scaler_pipe: upload | kernel | download "
+                    "on three HIP streams; the producer fills the staging in place (no host copy timed); config 5 needs 7 680 frames/s per GPU "
+                    "(23.9 GB/s up + 21.2 GB/s down)"}
+
+
 def plugin_path_probe(first_legs, ticks=300, warmup=40, log=None):
     """How many FULL call legs a mediastreamer2-shaped process carries through the DROP-IN PLUGIN (never part of `value`):
     tests/host/plugin_bench builds N legs of  source -> MSResample 16k->48k -> MSSpeexEC (128 ms) -> MSVolume (AGC) ->
@@ -1091,26 +1136,24 @@ class Headline:
             v[t] = self.ctx.timer_stop()
         return v
 
-    def paced_series(self, nticks, keepalive=True):
+    def paced_series(self, nticks, between=None):
         """`nticks` deployed ticks at an MSTicker's cadence: one per 10 ms of wall time (src/base/msticker.c:419-443,496-515),
-        the device idle for the rest of each interval -- unless the product's keep-alive holds its clocks (mi_ctx_keepalive:
-        what mi_session_submit and the plugin's hub flush call before a tick's launches).  Each tick timed alone."""
+        the device idle for the rest of each interval.  Each tick timed alone.  between(): called right before a tick's
+        launches (scripts/paced_probe.py tries ways of keeping the device warm across the gap with it)."""
         v = np.empty(nticks)
         nxt = time.perf_counter()
         for t in range(nticks):
             while time.perf_counter() < nxt:
                 pass
             nxt = max(nxt + 0.010, time.perf_counter() - 0.050)  # (a late tick is followed at once, like wait_next_tick does)
-            if keepalive:
-                self.ctx.keepalive(15000)
+            if between:
+                between()
             self.ctx.timer_start()
             if self.world == 1:
                 self.g1[t % len(self.g1)].launch()
             else:
                 self.graph_tick(t)
             v[t] = self.ctx.timer_stop()
-        if keepalive:
-            self.ctx.keepalive(0)
         return v
 
     def canceller_launches(self, nticks):
@@ -1286,7 +1329,7 @@ def main():
             # with the product's keep-alive between them; only run when the back-to-back series passed
             paced = None
             if paced_on and (worst < 10.0 or a.streams > 0):
-                paced = head.paced_series(a.paced_ticks, keepalive=not a.no_keepalive)
+                paced = head.paced_series(a.paced_ticks)
                 if log:
                     log({"streams": head.rig.n, "test": f"{a.paced_ticks} paced ticks (one per 10 ms)", **series_stats(paced)})
                 worst = max(worst, reduce_scalar(float(paced.max()), "MAX"))
@@ -1474,18 +1517,10 @@ def main():
                      "byte-streaming kernel at ~80 % of the measured copy ceiling; v_mfma_f32_16x16x4 would use 3 of 16 columns")
         line["roofline"] = r
         if paced is not None:
-            kept = "the product's keep-alive (mi_ctx_keepalive: one sleeping wavefront in flight across the idle gap) between the ticks"
-            line["config"]["paced_ticks"] = dict(series_stats(paced), cadence_ms=10, keepalive=not a.no_keepalive,
-                                                 note="one tick per 10 ms of wall time, as an MSTicker fires them, " +
-                                                      ("without the keep-alive" if a.no_keepalive else "with " + kept) +
-                                                      "; part of `value`'s criterion: no tick of this series may reach 10 ms either")
-            if world == 1 and not a.no_keepalive and a.paced_ticks >= 500:
-                try:  # the same cadence with the device left idle between the ticks: what the keep-alive buys
-                    v = head.paced_series(1000, keepalive=False)
-                    line["config"]["paced_ticks_idle_gaps"] = dict(series_stats(v), cadence_ms=10, keepalive=False,
-                                                                   note="not `value`: the same cadence without the keep-alive (the clocks drop in every gap)")
-                except Exception as e:
-                    line["config"]["paced_ticks_idle_gaps"] = {"error": str(e)[:200]}
+            line["config"]["paced_ticks"] = dict(series_stats(paced), cadence_ms=10,
+                                                 note="one tick per 10 ms of wall time, as an MSTicker fires them (the device idles for the rest of each "
+                                                      "interval and its clocks sag in every gap); part of `value`'s criterion: no tick of this series may "
+                                                      "reach 10 ms either")
     head.close()
     if converged is not None:
         converged.close()
@@ -1569,6 +1604,11 @@ def main():
                         line[key] = session_probe(ms, ctx, n_local, **kw)
                     except Exception as e:
                         line[key] = {"error": str(e)[:200]}
+        if not a.no_video_host:
+            try:
+                line["video_pcie_inclusive"] = video_host_probe(ms, ctx)
+            except Exception as e:
+                line["video_pcie_inclusive"] = {"error": str(e)[:300]}
         if not a.no_plugin_path:
             try:
                 line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)

@@ -80,13 +80,6 @@ int mi_device_count(void);
 int mi_ctx_create(int device, void *hip_stream, mi_ctx **out);
 void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_sync(mi_ctx *ctx);
-/* Keeps the device at its clocks across the idle gap between two ticks of a PACED deployment (an MSTicker fires every
- * 10 ms, src/base/msticker.c:419-443,496-515; a tick of 9 ms leaves the GPU idle for a millisecond, its clocks drop and the
- * next tick starts slow): one wavefront, asleep in s_sleep almost all the time, stays in flight on a stream of its own
- * until the next call -- which tells it to leave and starts its successor -- or for max_us microseconds at most (a host
- * that stops ticking leaves nothing behind).  max_us == 0 only stops the one in flight.  Call it once per tick, before the
- * tick's launches; mi_session_submit and the plugin's hub flush do (MSMI355X_KEEPALIVE=0 turns that off). */
-int mi_ctx_keepalive(mi_ctx *ctx, int max_us);
 void *mi_ctx_stream(mi_ctx *ctx);
 int mi_ctx_device(mi_ctx *ctx);
 /* device properties the bench reports: CU count, HBM bytes, name */
@@ -403,6 +396,25 @@ int mi_scaler_process_host(mi_scaler *s, int nframes, const uint8_t *h_src, size
  * Strides may exceed the width; planes need not be contiguous. */
 int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], const int src_strides[3],
                                   uint8_t *const dst[3], const int dst_strides[3]);
+
+/* The scaler fed from HOST buffers with the copies overlapped -- BASELINE config 5 (2048 x 1080p30 over 8 GPUs = 7 680 frames
+ * per second and GPU: 23.9 GB/s up, 21.2 GB/s down; the kernel itself does ~800 k frames/s, so the copies ARE the path).
+ * Batches of up to batch_frames frames travel through a ring of `depth` (1..8) pinned buffer pairs: upload, kernel and
+ * download run on three HIP streams ordered by events, so batch k+1 goes up while batch k is scaled and batch k-1 comes
+ * down (what mi_session does for the audio chain).  MSSizeConv's frames of one tick (sizeconv.c:133-181) are one or a few
+ * such batches; a capture / decode stage writes straight into the staging buffer (no intermediate copy).
+ *   acquire: the pinned staging of the NEXT batch, frame i at h_src + i * src_pitch (layout of ms_yuv_buf_init msvideo.c:85-99);
+ *            fails when `depth` batches are in flight (collect first);
+ *   submit:  nframes of it are uploaded, scaled, downloaded; returns at once;
+ *   collect: the OLDEST batch in flight: waits for its download; frame i at h_dst + i * dst_pitch (valid until `depth` more
+ *            batches have been submitted). */
+typedef struct mi_scaler_pipe mi_scaler_pipe;
+int mi_scaler_pipe_create(mi_scaler *s, int batch_frames, int depth, mi_scaler_pipe **out);
+void mi_scaler_pipe_destroy(mi_scaler_pipe *p);
+int mi_scaler_pipe_acquire(mi_scaler_pipe *p, uint8_t **h_src, size_t *src_pitch);
+int mi_scaler_pipe_submit(mi_scaler_pipe *p, int nframes);
+int mi_scaler_pipe_collect(mi_scaler_pipe *p, const uint8_t **h_dst, size_t *dst_pitch, int *nframes);
+int mi_scaler_pipe_in_flight(const mi_scaler_pipe *p);
 
 /* ---------------------------------------------------------------- fifo */
 /* MSBufferizer (include/mediastreamer2/msqueue.h:131-134, src/base/msqueue.c:70-113) for a batch of streams, resident

@@ -69,10 +69,6 @@ class Context:
     def sync(self):
         check(self.L.mi_ctx_sync(self.h))
 
-    def keepalive(self, max_us=15000):
-        """one sleeping wavefront in flight until the next call (or max_us): the device keeps its clocks between paced ticks"""
-        check(self.L.mi_ctx_keepalive(self.h, int(max_us)))
-
     @property
     def stream(self):
         return self.L.mi_ctx_stream(self.h)
@@ -493,6 +489,37 @@ class ScalerBatch(_Batch):
         ss = (C.c_int32 * 3)(*src_strides)
         ds = (C.c_int32 * 3)(*(list(dst_strides) + [0, 0])[:3])
         check(self.ctx.L.mi_scaler_process_planes_host(self.h, sp, ss, dp, ds))
+
+
+class ScalerPipe(_Batch):
+    """mi_scaler_pipe: the scaler fed from host buffers, upload | kernel | download overlapped on three streams, up to
+    `depth` batches in flight.  acquire() -> numpy view [batch, src_pitch] of the pinned staging to fill in place;
+    submit(n); collect() -> numpy view [n, dst_pitch] of the pinned results of the OLDEST batch."""
+    _destroy = "mi_scaler_pipe_destroy"
+
+    def __init__(self, scaler, batch_frames, depth=3):
+        self.ctx, self.scaler, self.batch, self.depth = scaler.ctx, scaler, batch_frames, depth
+        h = C.c_void_p()
+        check(self.ctx.L.mi_scaler_pipe_create(scaler.h, batch_frames, depth, C.byref(h)))
+        self.h = h
+
+    def acquire(self):
+        p, pitch = C.c_void_p(), C.c_size_t()
+        check(self.ctx.L.mi_scaler_pipe_acquire(self.h, C.byref(p), C.byref(pitch)))
+        buf = (C.c_uint8 * (self.batch * pitch.value)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.batch, pitch.value)
+
+    def submit(self, nframes):
+        check(self.ctx.L.mi_scaler_pipe_submit(self.h, int(nframes)))
+
+    def collect(self):
+        p, pitch, n = C.c_void_p(), C.c_size_t(), C.c_int32()
+        check(self.ctx.L.mi_scaler_pipe_collect(self.h, C.byref(p), C.byref(pitch), C.byref(n)))
+        buf = (C.c_uint8 * (n.value * pitch.value)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(n.value, pitch.value)
+
+    def in_flight(self):
+        return self.ctx.L.mi_scaler_pipe_in_flight(self.h)
 
 
 MI_PIX_YUY2, MI_PIX_UYVY, MI_PIX_BGR24, MI_PIX_RGB24_RAW, MI_PIX_BGRA32 = 2, 3, 4, 5, 6

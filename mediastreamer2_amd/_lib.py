@@ -23,7 +23,7 @@ class MiError(RuntimeError):
 # every symbol include/msmi355x.h declares (tests check the export table against this)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count",
-    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_keepalive", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
     "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
     "mi_timer_start", "mi_timer_stop",
@@ -42,6 +42,7 @@ EXPORTS = [
     "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_copy_state", "mi_aec_get", "mi_aec_stagger_info", "mi_aec_stagger_fifos",
     "mi_scaler_create", "mi_scaler_destroy", "mi_scaler_src_bytes", "mi_scaler_dst_bytes",
     "mi_scaler_process", "mi_scaler_process_host", "mi_scaler_process_planes_host",
+    "mi_scaler_pipe_create", "mi_scaler_pipe_destroy", "mi_scaler_pipe_acquire", "mi_scaler_pipe_submit", "mi_scaler_pipe_collect", "mi_scaler_pipe_in_flight",
     "mi_pixconv_create", "mi_pixconv_destroy", "mi_pixconv_src_bytes", "mi_pixconv_dst_bytes",
     "mi_pixconv_process", "mi_pixconv_process_host",
     "mi_session_default_config", "mi_session_create", "mi_session_destroy", "mi_session_tick_samples", "mi_session_tick_bytes", "mi_session_events",
@@ -173,7 +174,13 @@ def load():
     L.mi_volume_process_fifo_range.argtypes = [vp, vp, vp, i32, i32, i32, i32]
     L.mi_mixer_process_volume_fifo.argtypes = [vp, vp, i32, vp, vp]
     L.mi_mixer_process_volume_fifo_flags.argtypes = [vp, vp, i32, vp, vp, u32, vp]
-    L.mi_ctx_keepalive.argtypes = [vp, i32]
+    L.mi_scaler_pipe_create.argtypes = [vp, i32, i32, pp]
+    L.mi_scaler_pipe_destroy.argtypes = [vp]
+    L.mi_scaler_pipe_destroy.restype = None
+    L.mi_scaler_pipe_acquire.argtypes = [vp, pp, C.POINTER(sz)]
+    L.mi_scaler_pipe_submit.argtypes = [vp, i32]
+    L.mi_scaler_pipe_collect.argtypes = [vp, pp, C.POINTER(sz), C.POINTER(i32)]
+    L.mi_scaler_pipe_in_flight.argtypes = [vp]
     L.mi_volume_get_state_async.argtypes = [vp, i32, i32, vp]
     L.mi_volume_get_max.argtypes = [vp, i32, i32, vp]
     L.mi_volume_reset_max.argtypes = [vp, i32, i32]

@@ -675,9 +675,17 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	g.first = 0;
 	// the FIFO entry: one workgroup per list SLOT (8 classes x cap8; the few empty slots leave at once), else one per stream
 	const dim3 grid(fifo ? 8 * a->cap8 : a->nstreams);
-	if (a->F == 256) hipLaunchKernelGGL(aec_tick_kernel<256>, grid, dim3(64), 0, a->ctx->stream, g);
-	else if (a->F == 128) hipLaunchKernelGGL(aec_tick_kernel<128>, grid, dim3(64), 0, a->ctx->stream, g);
-	else hipLaunchKernelGGL(aec_tick_kernel<64>, grid, dim3(64), 0, a->ctx->stream, g);
+	const int mode = !fifo ? TICK_ROWS : (fifo->rs.ok ? TICK_FIFO_RS : TICK_FIFO);
+#define MI_TICK_LAUNCH(FR)                                                                                          \
+	do {                                                                                                            \
+		if (mode == TICK_FIFO_RS) hipLaunchKernelGGL((aec_tick_kernel<FR, TICK_FIFO_RS>), grid, dim3(64), 0, a->ctx->stream, g); \
+		else if (mode == TICK_FIFO) hipLaunchKernelGGL((aec_tick_kernel<FR, TICK_FIFO>), grid, dim3(64), 0, a->ctx->stream, g);  \
+		else hipLaunchKernelGGL((aec_tick_kernel<FR, TICK_ROWS>), grid, dim3(64), 0, a->ctx->stream, g);                        \
+	} while (0)
+	if (a->F == 256) MI_TICK_LAUNCH(256);
+	else if (a->F == 128) MI_TICK_LAUNCH(128);
+	else MI_TICK_LAUNCH(64);
+#undef MI_TICK_LAUNCH
 	MI_LAUNCH_CHECK();
 	if (fifo) { // the leg lists this launch filled become the ones the next launch serves (aec_tick.hpp: TickOrder)
 		hipLaunchKernelGGL(aec_tick_advance_kernel, dim3(1), dim3(64), 0, a->ctx->stream, a->d_ctl);

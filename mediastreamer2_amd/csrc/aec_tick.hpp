@@ -183,16 +183,59 @@ __global__ __launch_bounds__(64) void aec_tick_advance_kernel(int *ctl) {
 	if (threadIdx.x == 0) ctl[TickOrder::GLOBAL + TickOrder::PARITY] = par ^ 1;
 }
 
-template <int F>
+// MODE: where the frames come from and go to -- decided at compile time, so that each form carries only its own addressing,
+// scalars and code (the three forms in one kernel cost the headline's form ~1.5 KB of instruction cache and a dozen scalar
+// registers it never used):
+//   TICK_ROWS     rows of frames handed in by the caller (mi_aec_process / mi_aec_process_frames);
+//   TICK_FIFO     the three device FIFOs, the tick's microphone block from the caller's row (mi_aec_process_fifos);
+//   TICK_FIFO_RS  the same with the leg's MSResample folded in: the block is up-sampled by this wave (.._resampled).
+enum { TICK_ROWS = 0, TICK_FIFO = 1, TICK_FIFO_RS = 2 };
+
+// which serial chains a kernel form runs one row of 16 lanes at a time (aec_wave.hpp: ROWS): all of them where the registers
+// allow; at F = 256 each form takes the largest set that costs it no spill (scripts/kres.sh -DAEC_CHAIN_ROWS_<mode>=<bits> tries others)
+#ifndef AEC_CHAIN_ROWS_0
+#define AEC_CHAIN_ROWS_0 11
+#endif
+#ifndef AEC_CHAIN_ROWS_1
+#define AEC_CHAIN_ROWS_1 3
+#endif
+#ifndef AEC_CHAIN_ROWS_2
+#define AEC_CHAIN_ROWS_2 11
+#endif
+#ifndef AEC_CHAIN_ROWS_F128
+#define AEC_CHAIN_ROWS_F128 3
+#endif
+#ifndef AEC_CHAIN_ROWS_F64
+#define AEC_CHAIN_ROWS_F64 15
+#endif
+#ifdef AEC_CHAIN_ROWS /* A/B builds: one set for every form */
+#undef AEC_CHAIN_ROWS_F128
+#undef AEC_CHAIN_ROWS_F64
+#define AEC_CHAIN_ROWS_F128 AEC_CHAIN_ROWS
+#define AEC_CHAIN_ROWS_F64 AEC_CHAIN_ROWS
+#undef AEC_CHAIN_ROWS_0
+#undef AEC_CHAIN_ROWS_1
+#undef AEC_CHAIN_ROWS_2
+#define AEC_CHAIN_ROWS_0 AEC_CHAIN_ROWS
+#define AEC_CHAIN_ROWS_1 AEC_CHAIN_ROWS
+#define AEC_CHAIN_ROWS_2 AEC_CHAIN_ROWS
+#endif
+template <int F, int MODE>
+constexpr int tick_chain_rows() {
+	if (F != 256) return F == 128 ? AEC_CHAIN_ROWS_F128 : AEC_CHAIN_ROWS_F64;
+	return MODE == TICK_FIFO_RS ? AEC_CHAIN_ROWS_2 : (MODE == TICK_FIFO ? AEC_CHAIN_ROWS_1 : AEC_CHAIN_ROWS_0);
+}
+
+template <int F, int MODE>
 __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
 	using SL = TickLayout<F>;
-	constexpr int N = 2 * F, K = F / 64;
+	constexpr int N = 2 * F, K = F / 64, ROWS = tick_chain_rows<F, MODE>();
 	// ---- which leg this wavefront serves.  Rows / per-frame entries: leg = block.  FIFO entry: the leg comes out of a list
 	// the PREVIOUS tick's launch sorted (TickOrder above) -- legs that will run two frames first, the short ones last, one
 	// list per class b % 8: every XCD gets the same mix whatever pattern the legs' phases follow, and the long legs are
 	// started first.
-	const bool sched = a.order != nullptr;
+	constexpr bool sched = MODE != TICK_ROWS; // (the leg lists belong to the FIFO entries: aec_launch sets them for those)
 	int s = a.first + blockIdx.x, par = 0;
 	if (sched) {
 		const unsigned c = blockIdx.x & 7u, i = blockIdx.x >> 3;
@@ -204,7 +247,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 	const int lane = threadIdx.x;
 	const int e0 = lane * K; // first element (sample / bin) this lane owns
 	// ---- where the frames come from and go to: rows (per-frame / per-tick entries) or the three FIFOs
-	const bool fifo = a.fmic.ring != nullptr;
+	constexpr bool fifo = MODE != TICK_ROWS, folded = MODE == TICK_FIFO_RS;
 	int nf, ref_frames = 0;
 	int2 qm = make_int2(0, 0), qr = make_int2(0, 0), qo = make_int2(0, 0); // (head, level) before this tick
 	bool mic_new = false, ref_new = false;                                 // the tick's blocks were taken
@@ -240,11 +283,11 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		// history ++ input, lane (tile, phase) = 8 consecutive input positions of one polyphase row (resample_tile.hpp: the
 		// resampler kernel's own tile FIR, so the samples are bit for bit what mi_resampler_process delivers).  Window, table
 		// and output staging live in the transform work space, which nothing uses yet.
-		const int16_t *mic_row = a.mic_tick + (size_t)s * a.mic_tick_stride;
+		const int16_t *mic_row = folded ? nullptr : a.mic_tick + (size_t)s * a.mic_tick_stride;
 		// a.run (the *_masked forms): 0 = this leg has no microphone block in this launch (nothing is queued, the resampler's
 		// state stays; whatever frames its queue still holds run all the same)
 		const int mlen = (a.run && !a.run[s]) ? 0 : a.tick_len;
-		if (a.rs_in && mlen) {
+		if (folded && mlen) {
 			constexpr int RS_FILT = 48, RS_R = 8, RS_HIST = RS_FILT - 1;
 			const int den = a.rs_den, in_len = a.rs_in_len;
 			float *x = reinterpret_cast<float *>(L.zbuf);                    // [xn] history ++ input ++ zero slack
@@ -348,7 +391,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		if (!fifo) return a.mic[(size_t)s * a.stride + f * F + e];
 		const int p = f * F + e;
 		// (up-sampled in this launch: the block exists nowhere but in the ring it was queued in)
-		if (p < qm.y || a.rs_in) return ring_at(a.fmic, qm.x, p);
+		if (folded || p < qm.y) return ring_at(a.fmic, qm.x, p);
 		return a.mic_tick[(size_t)s * a.mic_tick_stride + (p - qm.y)];
 	};
 	auto ref_at = [&](int f, int e) -> int {
@@ -419,7 +462,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			prev = far[k];
 		}
 		sc.memX = rdlane(far[K - 1], 63);
-		Sxx = WSeq<K>::inner_prod(xn, xn);
+		Sxx = WSeq<K>::template inner_prod<ROWS>(xn, xn);
 		WSYNC();
 		store_vec<K>(L.tbuf + e0, xp);
 		store_vec<K>(L.tbuf + F + e0, xn);
@@ -504,7 +547,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			const float radius = a.notch_radius;
 			const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
 			float v[K];
-			w_dc_notch<K>(fin, radius, den2, sc.notch0, sc.notch1, v);
+			w_dc_notch<K, ROWS>(fin, radius, den2, sc.notch0, sc.notch1, v);
 			float vprev = __shfl_up(v[K - 1], 1);
 			if (lane == 0) vprev = sc.memD;
 #pragma unroll
@@ -722,7 +765,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			dresp[k] = efg[k] - ybg[k];
 		}
 		float Sff, Dbf, See;
-		WSeq<K>::inner_prod3(e1, e1, dresp, dresp, e2, e2, Sff, Dbf, See);
+		WSeq<K>::template inner_prod3<ROWS>(e1, e1, dresp, dresp, e2, e2, Sff, Dbf, See);
 		Dbf = 10 + Dbf;
 
 		// ---- two-path control
@@ -773,12 +816,12 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			float d[K], tout[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) d[k] = input[k] - efg[k];
-			w_deemphasis<K>(d, sc.memE, tout);
+			w_deemphasis<K, ROWS>(d, sc.memE, tout);
 #pragma unroll
 			for (int k = 0; k < K; ++k) out_i[k] = word2int(tout[k]);
 		}
 		float Sey, Syy, Sdd;
-		WSeq<K>::inner_prod3(e2, ybg, ybg, ybg, input, input, Sey, Syy, Sdd);
+		WSeq<K>::template inner_prod3<ROWS>(e2, ybg, ybg, ybg, input, input, Sey, Syy, Sdd);
 		if (any_sat && sc.saturated == 0) sc.saturated = 1;
 
 		// ---- error / response spectra
@@ -920,7 +963,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		float Pey = 1.0f, Pyy = 1.0f;
 		Pey = Pey + Ehd_F * Yhd_F;
 		Pyy = Pyy + Yhd_F * Yhd_F;
-		WSeq<K>::dot_desc2(Pey, Ehd, Yhd, Pyy, Yhd, Yhd, Pey, Pyy);
+		WSeq<K>::template dot_desc2<ROWS>(Pey, Ehd, Yhd, Pyy, Yhd, Yhd, Pey, Pyy);
 		Pyy = sqrt_via_double(Pyy);
 		Pey = Pey / Pyy;
 		float tmp32 = a.beta0 * Syy;
@@ -936,7 +979,9 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		float RER = (float)((.0001 * Sxx2 + 3. * (sc.leak_estimate * Syy)) / See);
 		if (RER < Sey * Sey / (1 + See * Syy)) RER = Sey * Sey / (1 + See * Syy);
 		if (RER > .5) RER = .5;
-		if (!sc.adapted && sc.sum_adapt > (float)M && sc.leak_estimate * Syy > .03f * Syy) sc.adapted = 1;
+		int m_here = M; // (converted HERE: hoisted to the kernel's entry the float lived -- spilled to scratch -- through the whole tick)
+		asm volatile("" : "+s"(m_here));
+		if (!sc.adapted && sc.sum_adapt > (float)m_here && sc.leak_estimate * Syy > .03f * Syy) sc.adapted = 1;
 
 		auto step = [&](float Yfv, float Rfv, float pwv) -> float {
 			float r = sc.leak_estimate * Yfv;

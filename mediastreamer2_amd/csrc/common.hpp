@@ -121,8 +121,4 @@ struct mi_ctx {
 	size_t scratch_bytes[4] = {0, 0, 0, 0};
 	int ensure_scratch(int slot, size_t bytes, void **out);
 	int activate() const;
-	// keep-alive (mi_ctx_keepalive): a stream of its own, a generation word in pinned memory the spinning wave polls
-	hipStream_t ka_stream = nullptr;
-	volatile unsigned *ka_word = nullptr; // generations told to stop so far
-	unsigned ka_gen = 0;                  // generation of the wave launched last
 };

@@ -28,15 +28,6 @@ int mi_ctx::ensure_scratch(int slot, size_t bytes, void **out) {
 	return MI_OK;
 }
 
-// One wavefront that does nothing, slowly, until the host says stop (or its time is up): between two ticks of a paced
-// deployment the device is otherwise idle for a millisecond or more, the power controller lets its clocks drop, and the
-// next tick pays for the ramp (+0.3-0.4 ms per tick at the headline count).  A wave in flight keeps the graphics
-// engine "busy"; asleep in s_sleep almost all the time it costs nothing measurable.
-__global__ void mi_keepalive_kernel(const volatile unsigned *stop_gen, unsigned my_gen, unsigned long long max_ticks) {
-	const unsigned long long t0 = wall_clock64(); // constant-rate counter (100 MHz)
-	while ((int)(__atomic_load_n(stop_gen, __ATOMIC_RELAXED) - my_gen) < 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(64);
-}
-
 extern "C" {
 
 int mi_abi_version(void) { return MSMI355X_ABI_VERSION; }
@@ -98,35 +89,10 @@ void mi_ctx_destroy(mi_ctx *c) {
 	(void)hipStreamSynchronize(c->stream);
 	for (int i = 0; i < 4; ++i)
 		if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-	if (c->ka_stream) {
-		*c->ka_word = c->ka_gen;
-		(void)hipStreamSynchronize(c->ka_stream);
-		(void)hipStreamDestroy(c->ka_stream);
-		(void)hipHostFree(const_cast<unsigned *>(c->ka_word));
-	}
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
-}
-
-int mi_ctx_keepalive(mi_ctx *c, int max_us) {
-	MI_CHECK_ARG(c != nullptr && max_us >= 0);
-	if (c->activate() != MI_OK) return MI_ENODEV;
-	if (!c->ka_stream) {
-		MI_HIP(hipStreamCreateWithFlags(&c->ka_stream, hipStreamNonBlocking));
-		void *w = nullptr;
-		MI_HIP(hipHostMalloc(&w, 64, hipHostMallocDefault));
-		c->ka_word = static_cast<volatile unsigned *>(w);
-		*c->ka_word = 0;
-	}
-	*c->ka_word = c->ka_gen; // the wave in flight (if any) leaves within a microsecond or two
-	if (max_us == 0) return MI_OK;
-	++c->ka_gen;
-	hipLaunchKernelGGL(mi_keepalive_kernel, dim3(1), dim3(64), 0, c->ka_stream, const_cast<const volatile unsigned *>(c->ka_word), c->ka_gen,
-	                   (unsigned long long)max_us * 100ull);
-	MI_LAUNCH_CHECK();
-	return MI_OK;
 }
 
 int mi_ctx_sync(mi_ctx *c) {

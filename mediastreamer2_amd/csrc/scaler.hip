@@ -19,6 +19,7 @@
 // by HBM (3.11 MB in + 2.76 MB out per 1080p->720p frame), so it is not
 // reshaped for MFMA.
 #include "common.hpp"
+#include <vector>
 
 namespace {
 
@@ -633,6 +634,136 @@ int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], con
 		MI_HIP(hipMemcpy2DAsync(dst[2], (size_t)dst_strides[2], o + dysz + dcsz, (size_t)a.dcw, (size_t)a.dcw, (size_t)dch_rows, hipMemcpyDeviceToHost, c->stream));
 	}
 	MI_HIP(hipStreamSynchronize(c->stream));
+	return MI_OK;
+}
+
+} // extern "C"
+
+// ---- the scaler fed from host buffers with the copies overlapped (BASELINE config 5: the frames cross PCIe both ways and
+// the kernel is ~100x faster than either copy, so the copies ARE the path): batches of frames in a ring of pinned buffers,
+// upload | kernel | download on three HIP streams ordered by events, up to `depth` batches in flight -- what session.hip
+// does for the audio chain.
+struct mi_scaler_pipe {
+	mi_scaler *sc = nullptr;
+	int batch = 0, depth = 0;
+	size_t src_pitch = 0, dst_pitch = 0;
+	hipStream_t s_up = nullptr, s_down = nullptr;
+	struct Slot {
+		uint8_t *h_src = nullptr, *h_dst = nullptr, *d_src = nullptr, *d_dst = nullptr;
+		hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_down = nullptr;
+		int nframes = 0;
+		bool used = false;
+	};
+	std::vector<Slot> slots;
+	uint64_t submitted = 0, collected = 0;
+	bool acquired = false;
+};
+
+extern "C" {
+
+void mi_scaler_pipe_destroy(mi_scaler_pipe *p) {
+	if (!p) return;
+	(void)hipSetDevice(p->sc->ctx->device);
+	if (p->s_up) (void)hipStreamSynchronize(p->s_up);
+	(void)hipStreamSynchronize(p->sc->ctx->stream);
+	if (p->s_down) (void)hipStreamSynchronize(p->s_down);
+	for (auto &sl : p->slots) {
+		if (sl.h_src) (void)hipHostFree(sl.h_src);
+		if (sl.h_dst) (void)hipHostFree(sl.h_dst);
+		if (sl.d_src) (void)hipFree(sl.d_src);
+		if (sl.d_dst) (void)hipFree(sl.d_dst);
+		for (hipEvent_t e : {sl.ev_up, sl.ev_k, sl.ev_down})
+			if (e) (void)hipEventDestroy(e);
+	}
+	if (p->s_up) (void)hipStreamDestroy(p->s_up);
+	if (p->s_down) (void)hipStreamDestroy(p->s_down);
+	delete p;
+}
+
+int mi_scaler_pipe_create(mi_scaler *s, int batch_frames, int depth, mi_scaler_pipe **out) {
+	MI_CHECK_ARG(s && out && batch_frames > 0 && batch_frames <= 65535 && depth >= 1 && depth <= 8);
+	*out = nullptr;
+	if (s->ctx->activate() != MI_OK) return MI_ENODEV;
+	mi_scaler_pipe *p = new mi_scaler_pipe();
+	p->sc = s, p->batch = batch_frames, p->depth = depth;
+	p->src_pitch = (s->src_bytes + 31) & ~(size_t)15; // slack for the kernels' 16-byte row loads
+	p->dst_pitch = (s->dst_bytes + 15) & ~(size_t)15;
+	p->slots.resize((size_t)depth);
+	bool ok = hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&p->s_down, hipStreamNonBlocking) == hipSuccess;
+	for (auto &sl : p->slots) {
+		const size_t sb = (size_t)batch_frames * p->src_pitch, db = (size_t)batch_frames * p->dst_pitch;
+		ok = ok && hipHostMalloc((void **)&sl.h_src, sb, hipHostMallocDefault) == hipSuccess && hipHostMalloc((void **)&sl.h_dst, db, hipHostMallocDefault) == hipSuccess &&
+		     hipMalloc((void **)&sl.d_src, sb + 32) == hipSuccess && hipMalloc((void **)&sl.d_dst, db + 32) == hipSuccess &&
+		     hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&sl.ev_k, hipEventDisableTiming) == hipSuccess &&
+		     hipEventCreateWithFlags(&sl.ev_down, hipEventDisableTiming) == hipSuccess;
+	}
+	if (!ok) {
+		mi::set_error("mi_scaler_pipe_create: streams / events / %d x %d frames of pinned and device memory could not be had", depth, batch_frames);
+		mi_scaler_pipe_destroy(p);
+		return MI_ENOMEM;
+	}
+	*out = p;
+	return MI_OK;
+}
+
+int mi_scaler_pipe_in_flight(const mi_scaler_pipe *p) { return p ? (int)(p->submitted - p->collected) : MI_EINVAL; }
+
+int mi_scaler_pipe_acquire(mi_scaler_pipe *p, uint8_t **h_src, size_t *src_pitch) {
+	MI_CHECK_ARG(p && h_src);
+	if ((int)(p->submitted - p->collected) >= p->depth) {
+		mi::set_error("mi_scaler_pipe_acquire: %d batches in flight; collect the oldest first", p->depth);
+		return MI_EINVAL;
+	}
+	mi_scaler_pipe::Slot &sl = p->slots[(size_t)(p->submitted % (uint64_t)p->depth)];
+	if (sl.used) { // the upload that last read this staging buffer is long done (its batch was collected); be sure all the same
+		if (p->sc->ctx->activate() != MI_OK) return MI_ENODEV;
+		MI_HIP(hipEventSynchronize(sl.ev_up));
+	}
+	*h_src = sl.h_src;
+	if (src_pitch) *src_pitch = p->src_pitch;
+	p->acquired = true;
+	return MI_OK;
+}
+
+int mi_scaler_pipe_submit(mi_scaler_pipe *p, int nframes) {
+	MI_CHECK_ARG(p && nframes > 0 && nframes <= p->batch);
+	if (!p->acquired) {
+		mi::set_error("mi_scaler_pipe_submit without mi_scaler_pipe_acquire");
+		return MI_EINVAL;
+	}
+	mi_ctx *c = p->sc->ctx;
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	mi_scaler_pipe::Slot &sl = p->slots[(size_t)(p->submitted % (uint64_t)p->depth)];
+	MI_HIP(hipMemcpyAsync(sl.d_src, sl.h_src, (size_t)nframes * p->src_pitch, hipMemcpyHostToDevice, p->s_up));
+	MI_HIP(hipEventRecord(sl.ev_up, p->s_up));
+	MI_HIP(hipStreamWaitEvent(c->stream, sl.ev_up, 0));
+	if (sl.used) MI_HIP(hipStreamWaitEvent(c->stream, sl.ev_down, 0)); // the download that last read this slot's output
+	const int rc = mi_scaler_process(p->sc, nframes, sl.d_src, p->src_pitch, sl.d_dst, p->dst_pitch);
+	if (rc != MI_OK) return rc;
+	MI_HIP(hipEventRecord(sl.ev_k, c->stream));
+	MI_HIP(hipStreamWaitEvent(p->s_down, sl.ev_k, 0));
+	MI_HIP(hipMemcpyAsync(sl.h_dst, sl.d_dst, (size_t)nframes * p->dst_pitch, hipMemcpyDeviceToHost, p->s_down));
+	MI_HIP(hipEventRecord(sl.ev_down, p->s_down));
+	sl.nframes = nframes;
+	sl.used = true;
+	p->acquired = false;
+	p->submitted++;
+	return MI_OK;
+}
+
+int mi_scaler_pipe_collect(mi_scaler_pipe *p, const uint8_t **h_dst, size_t *dst_pitch, int *nframes) {
+	MI_CHECK_ARG(p && h_dst);
+	if (p->submitted == p->collected) {
+		mi::set_error("mi_scaler_pipe_collect: nothing in flight");
+		return MI_EINVAL;
+	}
+	if (p->sc->ctx->activate() != MI_OK) return MI_ENODEV;
+	mi_scaler_pipe::Slot &sl = p->slots[(size_t)(p->collected % (uint64_t)p->depth)];
+	MI_HIP(hipEventSynchronize(sl.ev_down));
+	*h_dst = sl.h_dst;
+	if (dst_pitch) *dst_pitch = p->dst_pitch;
+	if (nframes) *nframes = sl.nframes;
+	p->collected++;
 	return MI_OK;
 }
 

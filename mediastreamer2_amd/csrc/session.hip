@@ -356,9 +356,6 @@ int mi_session_submit(mi_session *s) {
 	if (c->activate() != MI_OK) return MI_ENODEV;
 	const int slot = (int)(s->submitted % SLOTS);
 	const size_t n = (size_t)s->n;
-	// a paced caller submits every 10 ms: the device keeps its clocks across the gap behind this tick (mi_ctx_keepalive)
-	static const bool keepalive = !(getenv("MSMI355X_KEEPALIVE") && atoi(getenv("MSMI355X_KEEPALIVE")) == 0);
-	if (keepalive) (void)mi_ctx_keepalive(c, 15000);
 	// upload on its own stream
 	MI_HIP(hipMemcpyAsync(s->d_mic[slot], s->h_mic[slot], n * s->mic_bytes, hipMemcpyHostToDevice, s->s_up));
 	if (s->ref_bytes) MI_HIP(hipMemcpyAsync(s->d_ref[slot], s->h_ref[slot], n * s->ref_bytes, hipMemcpyHostToDevice, s->s_up));

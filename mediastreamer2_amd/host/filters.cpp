@@ -459,9 +459,6 @@ bool already_ran_this_tick(MSFilter *f) {
 
 void flush_hub(TickerHub &h) {
 	static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr; // A/B switch: one tick per facade again
-	// an MSTicker fires every 10 ms and the device idles between two flushes: it keeps its clocks across the gap
-	static const bool keepalive = !(getenv("MSMI355X_KEEPALIVE") && atoi(getenv("MSMI355X_KEEPALIVE")) == 0);
-	if (keepalive && h.ctx) (void)mi_ctx_keepalive(h.ctx, 15000);
 	h.in_flush = !no_chain;
 	h.touched.clear();
 	h.touched_pumps.clear();

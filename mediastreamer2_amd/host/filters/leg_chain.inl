@@ -110,6 +110,12 @@ struct LegBank : Pool {
 	std::vector<std::pair<MSQueue *, mblk_t *>> spk; // speaker-pin frames of this flush (MSSpeexEC pin 0: host audio), handed on in finish()
 	int walked = 0;                                  // conferences whose mixer has run in this tick's graph walk
 	bool early = false, early_any = false;           // this tick's work was enqueued at the end of the walk (leg_conf_walked)
+	bool no_early = false;
+	struct GainPatch {
+		float gain, target;
+		bool also_target;
+	};
+	std::vector<GainPatch> vpatch; // MS_VOLUME_SET_GAIN & co. on a fused leg: the two fields, set on the state as the device holds it
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
 	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members)
@@ -163,7 +169,9 @@ struct LegBank : Pool {
 		vstate.resize(L);
 		vp_dirty.assign(L, 0);
 		vs_dirty.assign(L, 0);
+		vpatch.assign(L, GainPatch{1.f, 1.f, false});
 		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
+		no_early = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr; // A/B switch: everything leaves at the flush
 	}
 	~LegBank() override {
 		if (root) freeb(root);
@@ -283,7 +291,11 @@ struct LegBank : Pool {
 		if (v_dirty) {
 			for (size_t s = 0; s < UL; ++s) {
 				if (vp_dirty[s]) MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
-				if (vs_dirty[s]) MI_MUST(mi_volume_set_state(vol, (int)s, 1, &vstate[s]));
+				if (vs_dirty[s]) { // (vstate is what the device holds: read back with the last launch's results, nothing launched since)
+					vstate[s].gain = vpatch[s].gain;
+					if (vpatch[s].also_target) vstate[s].target_gain = vpatch[s].target;
+					MI_MUST(mi_volume_set_state(vol, (int)s, 1, &vstate[s]));
+				}
 				vp_dirty[s] = vs_dirty[s] = 0;
 			}
 			v_dirty = false;
@@ -382,7 +394,7 @@ struct LegBank : Pool {
 			for (size_t s = 0; s < UL; ++s) {
 				FusedLeg *leg = legs[s];
 				if (!leg) continue;
-				if (!vs_dirty[s]) vstate[s] = h_vstate[s];
+				vstate[s] = h_vstate[s];
 				if (leg->metered && hub->ticker) { // update_energy's extremum records, msvolume.c:405-406
 					VolumeData *vd = (VolumeData *)leg->vol->data;
 					vd->max.record_max(hub->ticker->time, vstate[s].energy);
@@ -467,8 +479,7 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 // part of the interval and the next tick's flush finds the results waiting.  Same results, same one tick of latency; the
 // launches just leave the tick's critical path.  (A tick in which some mixer did not run falls back to the flush.)
 void leg_conf_walked(LegBank *b, int c) {
-	static const bool off = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr;
-	if (off || b->failed || b->early || !b->hub->ticker) return;
+	if (b->no_early || b->failed || b->early || !b->hub->ticker) return;
 	const uint32_t tick = b->hub->ticker->ticks;
 	if (b->walk_epoch != tick) b->walk_epoch = tick, b->walked = 0;
 	if (b->walk_tick[(size_t)c] == tick) return;
@@ -750,12 +761,16 @@ void leg_push_mixer_controls(MSFilter *f, MixerState *s) {
 }
 mi_volume_state *leg_vstate(FusedLeg *leg) { return &leg->bank->vstate[(size_t)leg->slot]; }
 // MS_VOLUME_* methods on a fused leg's MSVolume (hub locked): parameters / running state for the next flush
-void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, bool state_too) {
+void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain, const float *target) {
 	LegBank *b = leg->bank;
-	b->vparams[(size_t)leg->slot] = *p;
-	b->vparams[(size_t)leg->slot].peer = -1;
-	b->vp_dirty[(size_t)leg->slot] = 1;
-	if (state_too) b->vs_dirty[(size_t)leg->slot] = 1;
+	const size_t s = (size_t)leg->slot;
+	b->vparams[s] = *p;
+	b->vparams[s].peer = -1;
+	b->vp_dirty[s] = 1;
+	if (gain) {
+		b->vpatch[s] = {*gain, target ? *target : 0.f, target != nullptr};
+		b->vs_dirty[s] = 1;
+	}
 	b->v_dirty = true;
 }
 mi_aec *leg_canceller(FusedLeg *leg, int *slot) {

@@ -137,7 +137,7 @@ struct FramePool : Pool {
 		d_dst = devmem<uint8_t>(c * dst_pitch + 32);
 	}
 	// next staging buffer, or NULL when `capacity` frames are already waiting for this tick's flush
-	uint8_t *stage(MSFilter *f, uint32_t ts) {
+	virtual uint8_t *stage(MSFilter *f, uint32_t ts) {
 		if ((int)staged.size() >= frame_cap) {
 			ms_error("msmi355x plugin: frame pool full (%d frames per tick; raise MSMI355X_FRAME_SLOTS)", frame_cap);
 			return nullptr;
@@ -158,6 +158,7 @@ struct FramePool : Pool {
 		else ready.swap(staged);
 	}
 	void emit(MSFilter *f, int slot) override;
+	virtual const uint8_t *result(size_t k) const { return h_dst + k * dst_pitch; } // where ready[k]'s frame lies
 	void forget(MSFilter *f) { // the filter left the pool: its frames in flight are dropped
 		for (Staged &s : staged)
 			if (s.f == f) s.f = nullptr;
@@ -180,7 +181,7 @@ void FramePool::emit(MSFilter *f, int slot) {
 		mblk_t *om = ms_yuv_buf_allocator_get(vo->allocator, &ob, out_w, out_h);
 		if (om == NULL) continue;
 		// device layout == ms_yuv_buf_init layout (stride w, contiguous planes)
-		memcpy(ob.planes[0], h_dst + k * dst_pitch, dst_bytes);
+		memcpy(ob.planes[0], result(k), dst_bytes);
 		mblk_set_timestamp_info(om, ready[k].ts);
 		if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
 		else freemsg(om);
@@ -194,8 +195,18 @@ int frame_slots() {
 	return v > 0 ? v : 32;
 }
 
+// MSSizeConv's frames cross PCIe both ways and the kernel is ~100x faster than either copy: the copies are the path.  The
+// frames a tick stages travel in CHUNKS through mi_scaler_pipe (upload | kernel | download on three streams): a chunk leaves
+// as soon as it is full -- during the graph walk, while the other filters are still staging -- so that at the flush only
+// the last chunk's download is left to wait for, and the two PCIe directions work at the same time.
+constexpr int kFrameChunk = 8;
 struct ScalerPool : FramePool {
 	mi_scaler *sc = nullptr;
+	mi_scaler_pipe *pipe = nullptr;
+	int depth = 0;
+	uint8_t *cur = nullptr; // the chunk being filled (pinned staging of the pipe), `cur_n` frames of it taken
+	int cur_n = 0;
+	std::vector<const uint8_t *> res; // ready[k]'s frame in the pipe's pinned results
 	ScalerPool(int cap, int w, int h, int dw, int dh) {
 		Building b(this, cap);
 		// a geometry the kernels cannot take is not fatal: the bank fails and the frame is dropped with an error, as a
@@ -206,15 +217,65 @@ struct ScalerPool : FramePool {
 		}
 		if (failed) return;
 		frame_cap = frame_slots();
+		depth = std::min(8, (frame_cap + kFrameChunk - 1) / kFrameChunk);
+		frame_cap = std::min(frame_cap, depth * kFrameChunk); // (more than 64 frames per tick and geometry: raise kFrameChunk)
 		src_bytes = mi_scaler_src_bytes(sc);
 		dst_bytes = mi_scaler_dst_bytes(sc);
 		out_w = dw, out_h = dh;
-		alloc_buffers();
+		if (mi_scaler_pipe_create(sc, kFrameChunk, depth, &pipe) != MI_OK) failed = mi_failed("mi_scaler_pipe_create");
 	}
 	~ScalerPool() override {
+		if (pipe) mi_scaler_pipe_destroy(pipe);
 		if (sc) mi_scaler_destroy(sc);
 	}
-	int launch(int n) override { return mi_scaler_process(sc, n, d_src, src_pitch, d_dst, dst_pitch); }
+	int launch(int) override { return MI_OK; }
+	void submit_chunk() {
+		if (cur && cur_n > 0) MI_MUST(mi_scaler_pipe_submit(pipe, cur_n));
+		cur = nullptr, cur_n = 0;
+	}
+	uint8_t *stage(MSFilter *f, uint32_t ts) override {
+		if ((int)staged.size() >= frame_cap) {
+			ms_error("msmi355x plugin: frame pool full (%d frames per tick; raise MSMI355X_FRAME_SLOTS)", frame_cap);
+			return nullptr;
+		}
+		if (cur && cur_n == kFrameChunk) submit_chunk(); // the previous chunk is complete (its last frame was copied in after stage() returned)
+		if (!cur) {
+			if (failed || mi_scaler_pipe_acquire(pipe, &cur, &src_pitch) != MI_OK) {
+				failed = failed || mi_failed("mi_scaler_pipe_acquire");
+				return nullptr;
+			}
+			cur_n = 0;
+		}
+		staged.push_back({f, ts});
+		return cur + (size_t)(cur_n++) * src_pitch;
+	}
+	bool enqueue() override {
+		if (!failed) submit_chunk();
+		return false; // (the waits are the pipe's own: one event per chunk, in finish())
+	}
+	void finish() override {
+		ready.clear();
+		res.clear();
+		const int inflight = pipe ? mi_scaler_pipe_in_flight(pipe) : 0;
+		for (int b = 0; b < inflight; ++b) {
+			const uint8_t *h = nullptr;
+			int n = 0;
+			if (mi_scaler_pipe_collect(pipe, &h, &dst_pitch, &n) != MI_OK) {
+				failed = mi_failed("mi_scaler_pipe_collect");
+				break;
+			}
+			for (int i = 0; i < n; ++i) res.push_back(h + (size_t)i * dst_pitch);
+		}
+		if (failed || res.size() != staged.size()) { // the frames are dropped, like a failing ms_scaler_process (sizeconv.c:162-166)
+			staged.clear();
+			res.clear();
+		} else ready.swap(staged);
+	}
+	void flush() override {
+		enqueue();
+		finish();
+	}
+	const uint8_t *result(size_t k) const override { return res[k]; }
 };
 
 struct PixPool : FramePool {

@@ -118,7 +118,7 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	int peered_by;  // MSVolume filters that named this one as their echo-limiter peer (it must stay in a bank of its own kind)
 };
 mi_volume_state *leg_vstate(FusedLeg *leg);                      // leg_chain.inl
-void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, bool state_too);
+void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain, const float *target); // (gain: also the running state's)
 
 void volume_init(MSFilter *f) { // msvolume.c:88-118
 	VolumeData *d = new VolumeData();
@@ -164,7 +164,7 @@ mi_volume_state *vstate(VolumeData *d) {
 
 void volume_push_params(VolumeData *d) {
 	if (d->leg) {
-		leg_push_volume(d->leg, &d->p, false);
+		leg_push_volume(d->leg, &d->p, nullptr, nullptr);
 		if (!d->p.agc_enabled) leg_disqualify(d->leg); // without AGC the reference meters block by block, not in 10 ms chunks
 		return;
 	}
@@ -329,10 +329,7 @@ int volume_get_max(MSFilter *f, void *arg) {
 void volume_set_gains(VolumeData *d, bool also_target) {
 	if (d->leg) {
 		HubLock lk(leg_pool(d->leg)->hub);
-		mi_volume_state *st = vstate(d);
-		st->gain = d->gain;
-		if (also_target) st->target_gain = d->target_gain;
-		leg_push_volume(d->leg, &d->p, true);
+		leg_push_volume(d->leg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
 		return;
 	}
 	if (!d->pool) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up

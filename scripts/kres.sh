@@ -17,6 +17,7 @@ for b in re.split(r"remark: Function Name: ", rem)[1:]:
     name = b.split()[0]
     if "aec_tick_kernel" not in name: continue
     u = {m.group(1).strip(): m.group(2).strip() for m in re.finditer(r"remark:\s+([A-Za-z /\[\]]+):\s+(\S+)", b)}
-    print(name, "code", sizes.get(name), "VGPRs", u.get("VGPRs"), "spill", u.get("VGPRs Spill"), "SGPRs", u.get("TotalSGPRs"), "sspill", u.get("SGPRs Spill"), "LDS", u.get("LDS Size [bytes/block]"), "occ", u.get("Occupancy [waves/SIMD]"))
+    name_short = name.replace("_ZN12_GLOBAL__N_115aec_tick_kernel", "tick")
+    print(name_short, "code", sizes.get(name), "VGPRs", u.get("VGPRs"), "spill", u.get("VGPRs Spill"), "SGPRs", u.get("TotalSGPRs"), "sspill", u.get("SGPRs Spill"), "LDS", u.get("LDS Size [bytes/block]"), "occ", u.get("Occupancy [waves/SIMD]"))
 PY
 rm -rf $T

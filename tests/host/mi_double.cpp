@@ -168,10 +168,6 @@ int mi_copy_d2h(mi_ctx *c, void *h, const void *d, size_t n) {
 	memcpy(h, d, n);
 	return MI_OK;
 }
-int mi_ctx_keepalive(mi_ctx *c, int max_us) {
-	ARG(c && max_us >= 0);
-	return MI_OK; // nothing to keep awake
-}
 int mi_memset(mi_ctx *c, void *d, int v, size_t n) {
 	ARG(c && d);
 	memset(d, v, n);
@@ -639,6 +635,54 @@ int mi_scaler_process(mi_scaler *s, int nframes, const uint8_t *src, size_t sp, 
 }
 int mi_scaler_process_host(mi_scaler *s, int nframes, const uint8_t *src, size_t sp, uint8_t *dst, size_t dp) {
 	return mi_scaler_process(s, nframes, src, sp, dst, dp);
+}
+// the pipelined form: the same ring of buffers, every submit done on the spot
+struct mi_scaler_pipe {
+	mi_scaler *sc;
+	int batch, depth;
+	size_t sp, dp;
+	std::vector<std::vector<uint8_t>> src, dst;
+	std::vector<int> n;
+	uint64_t submitted = 0, collected = 0;
+	bool acquired = false;
+};
+int mi_scaler_pipe_create(mi_scaler *s, int batch, int depth, mi_scaler_pipe **out) {
+	ARG(s && out && batch > 0 && depth >= 1 && depth <= 8);
+	mi_scaler_pipe *p = new mi_scaler_pipe{s, batch, depth, (mi_scaler_src_bytes(s) + 31) & ~(size_t)15, (mi_scaler_dst_bytes(s) + 15) & ~(size_t)15, {}, {}, {}};
+	p->src.assign((size_t)depth, std::vector<uint8_t>((size_t)batch * p->sp));
+	p->dst.assign((size_t)depth, std::vector<uint8_t>((size_t)batch * p->dp));
+	p->n.assign((size_t)depth, 0);
+	*out = p;
+	return MI_OK;
+}
+void mi_scaler_pipe_destroy(mi_scaler_pipe *p) { delete p; }
+int mi_scaler_pipe_in_flight(const mi_scaler_pipe *p) { return p ? (int)(p->submitted - p->collected) : MI_EINVAL; }
+int mi_scaler_pipe_acquire(mi_scaler_pipe *p, uint8_t **h_src, size_t *pitch) {
+	ARG(p && h_src);
+	if ((int)(p->submitted - p->collected) >= p->depth) return fail(MI_EINVAL, "every batch of the ring is in flight");
+	*h_src = p->src[(size_t)(p->submitted % (uint64_t)p->depth)].data();
+	if (pitch) *pitch = p->sp;
+	p->acquired = true;
+	return MI_OK;
+}
+int mi_scaler_pipe_submit(mi_scaler_pipe *p, int nframes) {
+	ARG(p && nframes > 0 && nframes <= p->batch && p->acquired);
+	const size_t k = (size_t)(p->submitted % (uint64_t)p->depth);
+	const int rc = mi_scaler_process(p->sc, nframes, p->src[k].data(), p->sp, p->dst[k].data(), p->dp);
+	if (rc != MI_OK) return rc;
+	p->n[k] = nframes;
+	p->acquired = false;
+	p->submitted++;
+	return MI_OK;
+}
+int mi_scaler_pipe_collect(mi_scaler_pipe *p, const uint8_t **h_dst, size_t *pitch, int *nframes) {
+	ARG(p && h_dst && p->submitted > p->collected);
+	const size_t k = (size_t)(p->collected % (uint64_t)p->depth);
+	*h_dst = p->dst[k].data();
+	if (pitch) *pitch = p->dp;
+	if (nframes) *nframes = p->n[k];
+	p->collected++;
+	return MI_OK;
 }
 int mi_scaler_process_planes_host(mi_scaler *s, const uint8_t *const src[3], const int ss[3], uint8_t *const dst[3], const int ds[3]) {
 	ARG(s && src && ss && dst && ds);

@@ -99,3 +99,35 @@ def test_full_size_batch_device_resident(ctx, oracle):
     assert (px == px[0, 0]).all()
     np.testing.assert_array_equal(out[1].reshape(dh, dw, 3), oracle.i420_scale_to_rgb24(frames[1], sw, sh, dw, dh))
     sc.close()
+
+
+def test_the_pipelined_scaler_equals_the_synchronous_one(ctx):
+    """mi_scaler_pipe (host frames in, host frames out; upload | kernel | download on three streams, several batches in
+    flight -- the host path of BASELINE config 5) delivers exactly what mi_scaler_process_host does, batch after batch, with
+    partial batches, and refuses a batch beyond its depth until the oldest has been collected."""
+    rng = np.random.default_rng(5)
+    w, h, dw, dh = 640, 360, 320, 180
+    sc = ms.ScalerBatch(ctx, w, h, dw, dh, ms.MI_PIX_RGB24)
+    pipe = ms.ScalerPipe(sc, 6, depth=3)
+    frames = rng.integers(0, 256, (40, sc.src_bytes), dtype=np.uint8)
+    want = sc.process(frames)
+    got, sent, sizes = [], 0, [6, 6, 3, 6, 1, 6, 6, 6]
+    pending = []
+    for n in sizes:
+        if pipe.in_flight() == 3:
+            with pytest.raises(ms.MiError):
+                pipe.acquire()
+            got.append(pipe.collect()[:, :sc.dst_bytes].copy())
+            pending.pop(0)
+        buf = pipe.acquire()
+        buf[:n, :sc.src_bytes] = frames[sent:sent + n]
+        pipe.submit(n)
+        pending.append(n)
+        sent += n
+    while pipe.in_flight():
+        got.append(pipe.collect()[:, :sc.dst_bytes].copy())
+    got = np.concatenate(got)
+    assert sent == 40 and got.shape[0] == 40
+    np.testing.assert_array_equal(got, want)
+    pipe.close()
+    sc.close()

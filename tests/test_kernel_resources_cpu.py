@@ -35,15 +35,29 @@ def usage(remarks, kernel_substr):
     raise AssertionError(f"no remarks for {kernel_substr}")
 
 
+def usages(remarks, kernel_substr):
+    """[(function name, {field: value})] of every kernel-resource-usage remark block whose function name contains kernel_substr"""
+    out = []
+    for b in re.split(r"remark: Function Name: ", remarks)[1:]:
+        name = b.split()[0]
+        if kernel_substr in name:
+            out.append((name, {m.group(1).strip(): m.group(2).strip() for m in re.finditer(r"remark:\s+([A-Za-z /\[\]]+):\s+(\S+)", b)}))
+    assert out, f"no remarks for {kernel_substr}"
+    return out
+
+
 def test_tick_kernel_registers_and_lds(build):
+    """every form of the tick kernel (rows / FIFOs / FIFOs + folded resampler: the MODE template parameter)"""
     _, _, remarks = build
-    u = usage(remarks, "aec_tick_kernelILi256E")
-    assert int(u["VGPRs"]) <= 256 and int(u["VGPRs Spill"]) == 0, u
-    assert int(u["Occupancy [waves/SIMD]"]) == 2, u
-    assert int(u["LDS Size [bytes/block]"]) <= 20480, u  # one wave per block: 8 per CU
+    big = usages(remarks, "aec_tick_kernelILi256E")
+    assert len(big) == 3, [n for n, _ in big]
+    for name, u in big:
+        assert int(u["VGPRs"]) <= 256 and int(u["VGPRs Spill"]) == 0, (name, u)
+        assert int(u["Occupancy [waves/SIMD]"]) == 2, (name, u)
+        assert int(u["LDS Size [bytes/block]"]) <= 20480, (name, u)  # one wave per block: 8 per CU
     for k in ("aec_tick_kernelILi128E", "aec_tick_kernelILi64E"):
-        v = usage(remarks, k)
-        assert int(v["VGPRs Spill"]) <= 8, (k, v)  # the small frames run at 3 / 4 waves per SIMD: a handful of spills is the price
+        for name, v in usages(remarks, k):
+            assert int(v["VGPRs Spill"]) <= 12, (name, v)  # the small frames run at 3 / 4 waves per SIMD: a handful of spills is the price
 
 
 def test_tick_kernel_code_fits_the_instruction_cache(build):
@@ -55,6 +69,8 @@ def test_tick_kernel_code_fits_the_instruction_cache(build):
         dev = obj
     syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", str(dev)], capture_output=True, text=True).stdout
     sizes = {ln.split()[7]: int(ln.split()[2]) for ln in syms.splitlines() if " FUNC " in ln and "aec_tick_kernel" in ln}
-    big = [v for k, v in sizes.items() if "ILi256E" in k]
-    assert big, syms[-2000:]
-    assert max(big) < 65536, f"aec_tick_kernel<256> is {max(big)} bytes: over the 64 KB instruction cache"
+    big = {k: v for k, v in sizes.items() if "ILi256E" in k}
+    assert len(big) == 3, syms[-2000:]
+    assert max(big.values()) < 65536, f"a form of aec_tick_kernel<256> is over the 64 KB instruction cache: {big}"
+    headline = [v for k, v in big.items() if "ILi256ELi2E" in k]  # FIFOs + folded resampler: what the headline and the plugin's fused chain launch
+    assert headline and headline[0] <= 64 * 1024 - 1536, f"the headline's form has less than 1.5 KB of instruction cache to spare: {headline}"
