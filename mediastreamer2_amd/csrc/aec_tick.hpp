@@ -191,46 +191,11 @@ __global__ __launch_bounds__(64) void aec_tick_advance_kernel(int *ctl) {
 //   TICK_FIFO_RS  the same with the leg's MSResample folded in: the block is up-sampled by this wave (.._resampled).
 enum { TICK_ROWS = 0, TICK_FIFO = 1, TICK_FIFO_RS = 2 };
 
-// which serial chains a kernel form runs one row of 16 lanes at a time (aec_wave.hpp: ROWS): all of them where the registers
-// allow; at F = 256 each form takes the largest set that costs it no spill (scripts/kres.sh -DAEC_CHAIN_ROWS_<mode>=<bits> tries others)
-#ifndef AEC_CHAIN_ROWS_0
-#define AEC_CHAIN_ROWS_0 11
-#endif
-#ifndef AEC_CHAIN_ROWS_1
-#define AEC_CHAIN_ROWS_1 3
-#endif
-#ifndef AEC_CHAIN_ROWS_2
-#define AEC_CHAIN_ROWS_2 11
-#endif
-#ifndef AEC_CHAIN_ROWS_F128
-#define AEC_CHAIN_ROWS_F128 3
-#endif
-#ifndef AEC_CHAIN_ROWS_F64
-#define AEC_CHAIN_ROWS_F64 15
-#endif
-#ifdef AEC_CHAIN_ROWS /* A/B builds: one set for every form */
-#undef AEC_CHAIN_ROWS_F128
-#undef AEC_CHAIN_ROWS_F64
-#define AEC_CHAIN_ROWS_F128 AEC_CHAIN_ROWS
-#define AEC_CHAIN_ROWS_F64 AEC_CHAIN_ROWS
-#undef AEC_CHAIN_ROWS_0
-#undef AEC_CHAIN_ROWS_1
-#undef AEC_CHAIN_ROWS_2
-#define AEC_CHAIN_ROWS_0 AEC_CHAIN_ROWS
-#define AEC_CHAIN_ROWS_1 AEC_CHAIN_ROWS
-#define AEC_CHAIN_ROWS_2 AEC_CHAIN_ROWS
-#endif
-template <int F, int MODE>
-constexpr int tick_chain_rows() {
-	if (F != 256) return F == 128 ? AEC_CHAIN_ROWS_F128 : AEC_CHAIN_ROWS_F64;
-	return MODE == TICK_FIFO_RS ? AEC_CHAIN_ROWS_2 : (MODE == TICK_FIFO ? AEC_CHAIN_ROWS_1 : AEC_CHAIN_ROWS_0);
-}
-
 template <int F, int MODE>
 __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
 	using SL = TickLayout<F>;
-	constexpr int N = 2 * F, K = F / 64, ROWS = tick_chain_rows<F, MODE>();
+	constexpr int N = 2 * F, K = F / 64;
 	// ---- which leg this wavefront serves.  Rows / per-frame entries: leg = block.  FIFO entry: the leg comes out of a list
 	// the PREVIOUS tick's launch sorted (TickOrder above) -- legs that will run two frames first, the short ones last, one
 	// list per class b % 8: every XCD gets the same mix whatever pattern the legs' phases follow, and the long legs are
@@ -462,7 +427,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			prev = far[k];
 		}
 		sc.memX = rdlane(far[K - 1], 63);
-		Sxx = WSeq<K>::template inner_prod<ROWS>(xn, xn);
+		Sxx = WSeq<K>::inner_prod(xn, xn);
 		WSYNC();
 		store_vec<K>(L.tbuf + e0, xp);
 		store_vec<K>(L.tbuf + F + e0, xn);
@@ -547,7 +512,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			const float radius = a.notch_radius;
 			const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
 			float v[K];
-			w_dc_notch<K, ROWS>(fin, radius, den2, sc.notch0, sc.notch1, v);
+			w_dc_notch<K>(fin, radius, den2, sc.notch0, sc.notch1, v);
 			float vprev = __shfl_up(v[K - 1], 1);
 			if (lane == 0) vprev = sc.memD;
 #pragma unroll
@@ -765,7 +730,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			dresp[k] = efg[k] - ybg[k];
 		}
 		float Sff, Dbf, See;
-		WSeq<K>::template inner_prod3<ROWS>(e1, e1, dresp, dresp, e2, e2, Sff, Dbf, See);
+		WSeq<K>::inner_prod3(e1, e1, dresp, dresp, e2, e2, Sff, Dbf, See);
 		Dbf = 10 + Dbf;
 
 		// ---- two-path control
@@ -816,12 +781,12 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 			float d[K], tout[K];
 #pragma unroll
 			for (int k = 0; k < K; ++k) d[k] = input[k] - efg[k];
-			w_deemphasis<K, ROWS>(d, sc.memE, tout);
+			w_deemphasis<K>(d, sc.memE, tout);
 #pragma unroll
 			for (int k = 0; k < K; ++k) out_i[k] = word2int(tout[k]);
 		}
 		float Sey, Syy, Sdd;
-		WSeq<K>::template inner_prod3<ROWS>(e2, ybg, ybg, ybg, input, input, Sey, Syy, Sdd);
+		WSeq<K>::inner_prod3(e2, ybg, ybg, ybg, input, input, Sey, Syy, Sdd);
 		if (any_sat && sc.saturated == 0) sc.saturated = 1;
 
 		// ---- error / response spectra
@@ -963,7 +928,7 @@ __global__ __launch_bounds__(64, (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_t
 		float Pey = 1.0f, Pyy = 1.0f;
 		Pey = Pey + Ehd_F * Yhd_F;
 		Pyy = Pyy + Yhd_F * Yhd_F;
-		WSeq<K>::template dot_desc2<ROWS>(Pey, Ehd, Yhd, Pyy, Yhd, Yhd, Pey, Pyy);
+		WSeq<K>::dot_desc2(Pey, Ehd, Yhd, Pyy, Yhd, Yhd, Pey, Pyy);
 		Pyy = sqrt_via_double(Pyy);
 		Pey = Pey / Pyy;
 		float tmp32 = a.beta0 * Syy;

@@ -232,22 +232,6 @@ __device__ __forceinline__ float dpp_shl1(float last, float v) { // lane l <- la
 	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
 
-// ---- the same chains ONE ROW OF 16 LANES AT A TIME (AEC_CHAIN_ROWS, the default).  In the 64-step form a step is new work
-// for one lane and the other 63 recompute what they have; the board runs at its power limit, so every lane-
-// operation not executed is clock.  Here the wave walks its four rows in turn with the other three masked off: 16 steps of
-// row_shr:1 / row_shl:1 inside the row, whose first (last) lane takes the running value of the row before -- read from that
-// row's final lane -- as the DPP's `old` operand.  Same operations on the same operands in the same order: bit for bit the
-// sequential loop, a quarter of the lane-operations.  (tests/test_gpu_aec.py holds both forms to the oracle.)
-// ROWS (a template parameter of the chains): bits 1 the ordered sums, 2 the descending dot products, 4 the DC notch, 8 the
-// de-emphasis; which of them a kernel runs row by row is chosen per kernel form (aec_tick.hpp: tick_chain_rows) -- the
-// F = 256 forms sit at 256 registers and each takes the set that costs it no spill.
-__device__ __forceinline__ float dpp_row_shr1(float first, float v) { // lane l of a row <- lane l-1 of it, the row's lane 0 <- first
-	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x111, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_row_shl1(float last, float v) { // lane l of a row <- lane l+1 of it, the row's lane 15 <- last
-	return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x101, 0xf, 0xf, false));
-}
-
 // Sum / maximum over the 64 lanes in a fixed butterfly order, in registers: four DPP exchanges inside the rows of 16
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then row_bcast:15 and row_bcast:31 -- no LDS, no index arithmetic.
 // For values whose summation order the library does not fix (a tree either way).  The result is in every lane (readlane 63).
@@ -288,35 +272,11 @@ struct WSeq {
 		}
 	}
 	// NC sums at once: sum = 0; for l in 0..63: for k: sum += part[k] of lane l
-	template <int NC, int ROWS>
+	template <int NC>
 	__device__ static void chain_up(const float (&part)[NC][KP], float (&sum)[NC]) {
 		float s[NC];
 #pragma unroll
 		for (int c = 0; c < NC; ++c) s[c] = 0;
-		if constexpr ((ROWS & 1) != 0) {
-		float carry[NC];
-#pragma unroll
-		for (int c = 0; c < NC; ++c) carry[c] = 0;
-		const int row = (int)threadIdx.x >> 4;
-#pragma nounroll
-		for (int r = 0; r < 4; ++r) {
-			if (row == r) {
-#pragma unroll 4
-				for (int l = 0; l < 16; ++l) {
-#pragma unroll
-					for (int c = 0; c < NC; ++c) {
-						s[c] = dpp_row_shr1(carry[c], s[c]) + part[c][0];
-#pragma unroll
-						for (int k = 1; k < KP; ++k) s[c] = s[c] + part[c][k];
-					}
-				}
-			}
-#pragma unroll
-			for (int c = 0; c < NC; ++c) carry[c] = rdlane(s[c], 16 * r + 15);
-		}
-#pragma unroll
-		for (int c = 0; c < NC; ++c) sum[c] = carry[c];
-		} else {
 #pragma unroll 4
 		for (int l = 0; l < 64; ++l) {
 #pragma unroll
@@ -328,51 +288,29 @@ struct WSeq {
 		}
 #pragma unroll
 		for (int c = 0; c < NC; ++c) sum[c] = rdlane(s[c], 63);
-		}
 	}
-	template <int ROWS>
 	__device__ static float inner_prod(const float (&x)[K], const float (&y)[K]) {
 		float part[1][KP], sum[1];
 		pairs(x, y, part[0]);
-		chain_up<1, ROWS>(part, sum);
+		chain_up<1>(part, sum);
 		return sum[0];
 	}
-	template <int ROWS>
 	__device__ static void inner_prod3(const float (&x0)[K], const float (&y0)[K], const float (&x1)[K], const float (&y1)[K],
 	                                   const float (&x2)[K], const float (&y2)[K], float &r0, float &r1, float &r2) {
 		float part[3][KP], sum[3];
 		pairs(x0, y0, part[0]);
 		pairs(x1, y1, part[1]);
 		pairs(x2, y2, part[2]);
-		chain_up<3, ROWS>(part, sum);
+		chain_up<3>(part, sum);
 		r0 = sum[0], r1 = sum[1], r2 = sum[2];
 	}
 	// two descending dot products at once: acc = init; for l = 63..0: for k = K-1..0: acc += a[k] b[k] of lane l
-	template <int ROWS>
 	__device__ static void dot_desc2(float init0, const float (&a0)[K], const float (&b0)[K], float init1, const float (&a1)[K],
 	                                 const float (&b1)[K], float &r0, float &r1) {
 		float p0[K], p1[K];
 #pragma unroll
 		for (int k = 0; k < K; ++k) p0[k] = a0[k] * b0[k], p1[k] = a1[k] * b1[k];
 		float s0 = init0, s1 = init1;
-		if constexpr ((ROWS & 2) != 0) {
-		float c0 = init0, c1 = init1;
-		const int row = (int)threadIdx.x >> 4;
-#pragma nounroll
-		for (int r = 3; r >= 0; --r) {
-			if (row == r) {
-#pragma unroll 4
-				for (int l = 0; l < 16; ++l) { // the two chains ride in one register pair: K packed additions per step
-					v2f t = {dpp_row_shl1(c0, s0), dpp_row_shl1(c1, s1)};
-#pragma unroll
-					for (int k = K - 1; k >= 0; --k) t = t + (v2f){p0[k], p1[k]};
-					s0 = t.x, s1 = t.y;
-				}
-			}
-			c0 = rdlane(s0, 16 * r), c1 = rdlane(s1, 16 * r);
-		}
-		r0 = c0, r1 = c1;
-		} else {
 #pragma unroll 4
 		for (int l = 0; l < 64; ++l) { // the two chains ride in one register pair: K packed additions per step
 			v2f t = {dpp_shl1(init0, s0), dpp_shl1(init1, s1)};
@@ -381,7 +319,6 @@ struct WSeq {
 			s0 = t.x, s1 = t.y;
 		}
 		r0 = rdlane(s0, 0), r1 = rdlane(s1, 0);
-		}
 	}
 };
 
@@ -401,7 +338,7 @@ __device__ __forceinline__ void notch_sample(v2f rc, v2f pair, float vin, float 
 	a1 = am.y;
 	out = tu.x;
 }
-template <int K, int ROWS>
+template <int K>
 __device__ __forceinline__ void w_dc_notch(const float (&in)[K], float radius, float den2, float &m0io, float &m1io, float (&out)[K]) {
 	const float i0 = m0io, i1 = m1io;
 	float m0 = i0, m1 = i1;
@@ -413,28 +350,6 @@ __device__ __forceinline__ void w_dc_notch(const float (&in)[K], float radius, f
 		if (k & 1) pr[k / 2].y = in[k];
 		else pr[k / 2].x = in[k];
 	}
-	if constexpr ((ROWS & 4) != 0) {
-	float c0 = i0, c1 = i1;
-	const int row = (int)threadIdx.x >> 4;
-#pragma nounroll
-	for (int r = 0; r < 4; ++r) {
-		if (row == r) {
-#pragma unroll 2
-			for (int l = 0; l < 16; ++l) {
-				float a0 = dpp_row_shr1(c0, m0), a1 = dpp_row_shr1(c1, m1);
-#pragma unroll
-				for (int k = 0; k < K; ++k) {
-					if (k & 1) notch_sample<true>(rc, pr[k / 2], in[k], a0, a1, out[k]);
-					else notch_sample<false>(rc, pr[k / 2], in[k], a0, a1, out[k]);
-				}
-				m0 = a0, m1 = a1;
-			}
-		}
-		c0 = rdlane(m0, 16 * r + 15), c1 = rdlane(m1, 16 * r + 15);
-	}
-	m0io = c0;
-	m1io = c1;
-	} else {
 #pragma unroll 2
 	for (int l = 0; l < 64; ++l) {
 		float a0 = dpp_shr1(i0, m0), a1 = dpp_shr1(i1, m1);
@@ -447,36 +362,13 @@ __device__ __forceinline__ void w_dc_notch(const float (&in)[K], float radius, f
 	}
 	m0io = rdlane(m0, 63);
 	m1io = rdlane(m1, 63);
-	}
 }
 
 // de-emphasis of the output: t = d + 0.9 mem; mem = t, sample after sample
-template <int K, int ROWS>
+template <int K>
 __device__ __forceinline__ void w_deemphasis(const float (&d)[K], float &memio, float (&out)[K]) {
 	const float init = memio;
 	float m = init;
-	if constexpr ((ROWS & 8) != 0) {
-	float c = init;
-	const int row = (int)threadIdx.x >> 4;
-#pragma nounroll
-	for (int r = 0; r < 4; ++r) {
-		if (row == r) {
-#pragma unroll 2
-			for (int l = 0; l < 16; ++l) {
-				float a = dpp_row_shr1(c, m);
-#pragma unroll
-				for (int k = 0; k < K; ++k) {
-					const float t = d[k] + .9f * a;
-					a = t;
-					out[k] = t;
-				}
-				m = a;
-			}
-		}
-		c = rdlane(m, 16 * r + 15);
-	}
-	memio = c;
-	} else {
 #pragma unroll 2
 	for (int l = 0; l < 64; ++l) {
 		float a = dpp_shr1(init, m);
@@ -489,7 +381,6 @@ __device__ __forceinline__ void w_deemphasis(const float (&d)[K], float &memio, 
 		m = a;
 	}
 	memio = rdlane(m, 63);
-	}
 }
 
 template <int K>

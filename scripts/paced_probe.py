@@ -70,9 +70,16 @@ def trickle_copy(mb):
     return f
 
 
+def copy_continuous():  # the memory system kept as busy as a tick keeps it: 64 MB device copies one behind the other until the tick starts
+    if side.query():
+        with torch.cuda.stream(side):
+            b.copy_(a)
+            b.copy_(a)
+
+
 out = {"streams": head.rig.n, "back_to_back": bench.series_stats(head.tick_series(nticks))}
 for name, fill in (("idle_gap", None), ("spinning_wave", sleeping_wave), ("tiny_kernels", tiny_kernels), ("copy_4MB_per_100us", trickle_copy(4)),
-                   ("copy_32MB_per_100us", trickle_copy(32)), ("idle_gap_again", None)):
+                   ("copy_32MB_per_100us", trickle_copy(32)), ("copy_continuous_full_rate", copy_continuous), ("idle_gap_again", None)):
     s = bench.series_stats(paced(fill))
     torch.cuda.synchronize()
     out[name] = {k: s[k] for k in ("p50_ms", "p99_ms", "max_ms", "late")}

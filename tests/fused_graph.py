@@ -224,6 +224,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
     late0 = h.P.ms_mi355x_late_events()
+    before = h.runtime_stats()   # (other graphs of the same process may be alive: what this run leaves behind is the difference)
     conf.attach()
     mid_stats = None
     for t in range(nt):
@@ -263,7 +264,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     res = {"out": [h.drain(leg["out"]) for leg in conf.legs], "spk": [h.drain(leg["spk"]) for leg in conf.legs], "stats": mid_stats,
            "late": h.P.ms_mi355x_late_events() - late0, "levels": levels}
     conf.close()
-    res["after"] = h.runtime_stats()
+    res["after"] = tuple(a - b for a, b in zip(h.runtime_stats(), before))
     return res
 
 
