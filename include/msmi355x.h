@@ -237,6 +237,9 @@ int mi_volume_process_host(mi_volume *v, int16_t *h_samples, int nsamples, int s
  * Equals mi_fifo_pop + mi_volume_process without the separate launch and copy.  Multiples of 8 samples throughout. */
 struct mi_fifo;
 int mi_volume_process_fifo(mi_volume *v, struct mi_fifo *f_src, int16_t *d_out, int nsamples, int stride);
+/* flags: MI_VOLMIX_DRY_SKIPS (below) -- a stream whose queue holds less than the chunk is left alone: no meter update, no gain
+ * ramp, its row of d_out is not written (MSVolume finds no whole 10 ms chunk in its bufferizer, msvolume.c:480-486) */
+int mi_volume_process_fifo_flags(mi_volume *v, struct mi_fifo *f_src, int16_t *d_out, int nsamples, int stride, unsigned flags);
 /* the same for streams [first, first + count) only (rows of d_out are still indexed by stream) */
 int mi_volume_process_fifo_range(mi_volume *v, struct mi_fifo *f_src, int16_t *d_out, int nsamples, int stride, int first, int count);
 /* MSVolume + MSAudioMixer of whole conferences in ONE launch (the chain's last two filters): pin k of conference c is

@@ -174,6 +174,7 @@ class ResamplerBatch(_Batch):
         import torch
         if out is None:
             out = torch.zeros((n, ostride), dtype=torch.int16, device=x.device)
+            torch.cuda.current_stream().synchronize()  # torch filled it on ITS stream; the kernel below writes it on the context's
         check(self.ctx.L.mi_resampler_process(self.h, _ptr(x), in_len, x.stride(0), _ptr(out), out.stride(0), _ptr(out_len)))
         return out, out_len
 
@@ -205,6 +206,7 @@ class MixerBatch(_Batch):
         import torch
         if out is None:
             out = torch.zeros(tuple(x.shape) if conf_mode else (self.nconf, self.ns), dtype=torch.int16, device=x.device)
+            torch.cuda.current_stream().synchronize()  # torch filled it on ITS stream; the kernel below writes it on the context's
         check(self.ctx.L.mi_mixer_process(self.h, _ptr(x), _ptr(has_data), int(conf_mode), _ptr(out)))
         return out
 
@@ -427,6 +429,7 @@ class AecBatch(_Batch):
         import torch
         if out is None:
             out = torch.zeros_like(mic)
+            torch.cuda.current_stream().synchronize()  # torch filled it on ITS stream; the kernel below writes it on the context's
         check(self.ctx.L.mi_aec_process(self.h, _ptr(mic), _ptr(ref), _ptr(out), mic.stride(0), _ptr(run), flags))
         return out
 
@@ -478,6 +481,7 @@ class ScalerBatch(_Batch):
         import torch
         if out is None:
             out = torch.zeros((nf, self.dst_bytes), dtype=torch.uint8, device=src.device)
+            torch.cuda.current_stream().synchronize()  # torch filled it on ITS stream; the kernel below writes it on the context's
         check(self.ctx.L.mi_scaler_process(self.h, nf, _ptr(src), src.stride(0), _ptr(out), out.stride(0)))
         return out
 
@@ -549,6 +553,7 @@ class PixConvBatch(_Batch):
         import torch
         if out is None:
             out = torch.zeros((nf, self.dst_bytes), dtype=torch.uint8, device=src.device)
+            torch.cuda.current_stream().synchronize()  # torch filled it on ITS stream; the kernel below writes it on the context's
         check(self.ctx.L.mi_pixconv_process(self.h, nf, _ptr(src), src.stride(0), _ptr(out), out.stride(0)))
         return out
 

@@ -49,6 +49,7 @@ struct VolArgs {
 	// src.ring != NULL: the chunk is popped from a device FIFO (all-or-nothing, zeros when it holds less: what
 	// mi_fifo_pop(..., zero_fill) delivers) and the result is written to `samples` -- no separate pop launch, no copy
 	FifoView src;
+	int src_dry_skips; // MI_VOLMIX_DRY_SKIPS: a stream whose queue holds less than the chunk is left alone (no meter update, no output)
 };
 
 __device__ __forceinline__ int sat16(int v) { return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v); }
@@ -170,6 +171,8 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 			if (q.y >= a.nsamples) {
 				s_head[tid] = q.x;
 				a.src.pos[s0 + tid] = make_int2((q.x + a.nsamples) % a.src.cap, q.y - a.nsamples);
+			} else if (a.src_dry_skips) {
+				s_n[tid] = 0; // volume_process finds no whole chunk in its bufferizer and does nothing (msvolume.c:480-486)
 			}
 		}
 	}
@@ -662,7 +665,7 @@ int mi_volume_reset_max(mi_volume *v, int first, int count) {
 }
 
 static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src,
-                         int first = 0, int count = -1);
+                         int first = 0, int count = -1, unsigned flags = 0);
 
 int mi_volume_process(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples) {
 	return volume_launch(v, d_samples, nsamples, stride, d_nsamples, nullptr);
@@ -675,6 +678,15 @@ int mi_volume_process_fifo(mi_volume *v, mi_fifo *f_src, int16_t *d_out, int nsa
 		return MI_ENOTSUP;
 	}
 	return volume_launch(v, d_out, nsamples, stride, nullptr, f_src);
+}
+
+int mi_volume_process_fifo_flags(mi_volume *v, mi_fifo *f_src, int16_t *d_out, int nsamples, int stride, unsigned flags) {
+	MI_CHECK_ARG(v && f_src && f_src->nstreams == v->nstreams);
+	if ((f_src->capacity & 7) || (nsamples & 7) || (stride & 7) || (reinterpret_cast<uintptr_t>(d_out) & 15)) {
+		mi::set_error("mi_volume_process_fifo_flags: capacity, chunk and stride must be multiples of 8 samples, rows 16-byte aligned");
+		return MI_ENOTSUP;
+	}
+	return volume_launch(v, d_out, nsamples, stride, nullptr, f_src, 0, -1, flags);
 }
 
 int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f_src, int16_t *d_out, int nsamples, int stride, int first, int count) {
@@ -730,6 +742,7 @@ int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stre
 	a.v.pitch_dw = a.v.pitch_f = 0;
 	a.v.first = first_stream;
 	a.v.src = fifo_view(f_src);
+	a.v.src_dry_skips = 0;
 	a.flags = mv.flags;
 	a.gain = mv.gain;
 	a.out = d_out;
@@ -753,7 +766,7 @@ int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stre
 }
 
 static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int stride, const int32_t *d_nsamples, const mi_fifo *src,
-                         int first, int count) {
+                         int first, int count, unsigned flags) {
 	MI_CHECK_ARG(v && d_samples && nsamples > 0 && stride >= nsamples);
 	if (nsamples > 3840) {
 		mi::set_error("chunk of %d samples exceeds the volume kernel's LDS staging (max 3840)", nsamples);
@@ -776,6 +789,7 @@ static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int str
 	a.stride = stride;
 	a.sample_rate = v->sample_rate;
 	a.src = fifo_view(src);
+	a.src_dry_skips = (flags & MI_VOLMIX_DRY_SKIPS) ? 1 : 0;
 	// packed rows: whole 16-byte groups.  Float rows: whole groups of 8, and an odd number of 16-byte
 	// groups per row so the SPB lanes of phase B read disjoint banks.
 	const int pitch = ((nsamples + 7) >> 3) * 4;

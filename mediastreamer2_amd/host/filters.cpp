@@ -543,7 +543,9 @@ MSFilter *leg_find_mixer(MSFilter *rs);
 bool conf_try_fuse(MSFilter *mixer);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
 void leg_disqualify(FusedLeg *leg);
-MSFilter *leg_mixer(FusedLeg *leg);
+void leg_release(FusedLeg *leg, bool keep_running); // the leg (and, in a conference, everybody with it) leaves its fused batch
+bool leg_try_fuse_plain(MSFilter *rs);
+bool leg_wants_out(FusedLeg *leg);
 Pool *leg_pool(FusedLeg *leg);
 
 #include "filters/resample.inl"
@@ -721,9 +723,9 @@ void ms_mi355x_fused_stats(int *conferences, int *legs, unsigned long long *laun
 		if (lk.dead()) continue;
 		fr += h->flushes;
 		for (Pool *p : h->pools)
-			if (p->key.compare(0, 4, "leg:") == 0) {
+			if (p->key.compare(0, 3, "leg") == 0) { // "leg:" conferences, "legp:" legs without a mixer
 				LegBank *b = static_cast<LegBank *>(p);
-				nc += b->in_use;
+				nc += b->plain ? 0 : b->in_use;
 				la += b->launches;
 				for (FusedLeg *l : b->legs) nl += l != nullptr;
 			}

@@ -154,7 +154,7 @@ void ec_init(MSFilter *f) { // speexec.c:74-109
 }
 void ec_uninit(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	if (s->leg) conf_unfuse(leg_mixer(s->leg), false);
+	if (s->leg) leg_release(s->leg, false);
 	if (s->state_str) ms_free(s->state_str);
 	ms_bufferizer_uninit(&s->delayed_ref);
 	ms_free(s);
@@ -274,7 +274,7 @@ void ec_fetch_config(SpeexECState *s) { // :145-167
 void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at detach
 	SpeexECState *s = (SpeexECState *)f->data;
 	facade_detached(f);
-	if (s->leg) conf_unfuse(leg_mixer(s->leg), false);
+	if (s->leg) leg_release(s->leg, false);
 	HubLock lk(f);
 	ms_bufferizer_flush(&s->delayed_ref);
 	ms_bufferizer_flush(&s->echo);

@@ -32,6 +32,7 @@
 // queued on the device at that moment (a few ms) is lost.
 
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
+constexpr int kLegMaxChunks = 5; // 10 ms chunks MSVolume can complete in one flush of a leg without a mixer (kMaxRounds blocks of 10 ms + what it held)
 
 struct LegBank;
 struct FusedLeg {
@@ -47,6 +48,8 @@ struct FusedLeg {
 	int chan_chunks = 0; // the mixer channel's bufferizer: whole chunks waiting (f_out holds vol_rem + chan_chunks * ns)
 	int newchunks = 0;   // chunks MSVolume would have put on the mixer's queue in this flush
 	bool metered = false;
+	bool unfuse_wanted = false; // (a leg without a mixer: set by a method on any thread, honoured by the head's next process())
+	uint32_t far_tick = 0;      // ticker tick in which the far end was last taken (a bank without mixers leaves early on these)
 };
 
 struct MixSlab { // one flush's conference mixes in pinned memory, referenced by the blocks handed downstream
@@ -65,6 +68,7 @@ int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t
 void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
 void leg_conf_walked(LegBank *b, int c);
+void leg_far_walked(LegBank *b, FusedLeg *leg);
 
 struct LegBank : Pool {
 	uint32_t in_rate, rate;
@@ -111,6 +115,11 @@ struct LegBank : Pool {
 	int walked = 0;                                  // conferences whose mixer has run in this tick's graph walk
 	bool early = false, early_any = false;           // this tick's work was enqueued at the end of the walk (leg_conf_walked)
 	bool no_early = false;
+	// A bank WITHOUT mixers (plain): legs  MSResample -> MSSpeexEC -> MSVolume -> any other filter  -- the sending side of an
+	// AudioStream (audiostream.c:1798-1810) whose streams share a ticker.  One slot = one leg (mm = 1), owned by its MSVolume,
+	// which hands the levelled 10 ms chunks on as they come out of mi_volume_process_fifo_flags (up to kLegMaxChunks a flush).
+	bool plain = false;
+	std::vector<int> nout, nready; // chunks a leg's MSVolume completes in this flush / has ready to hand on
 	struct GainPatch {
 		float gain, target;
 		bool also_target;
@@ -118,8 +127,8 @@ struct LegBank : Pool {
 	std::vector<GainPatch> vpatch; // MS_VOLUME_SET_GAIN & co. on a fused leg: the two fields, set on the state as the device holds it
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
-	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members)
-	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members) {
+	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false)
+	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer) {
 		Building b(this, cap_conf);
 		ns = (int)rate / 100;
 		in_len = (int)in_rate / 100;
@@ -134,7 +143,7 @@ struct LegBank : Pool {
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, ref_cap, &f_ref));
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, out_cap, &f_out));
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, (int)rate, &vol));
-		if (!failed) MI_MUST(mi_mixer_create(hub->ctx, capacity, mm, ns, &mix));
+		if (!failed && !plain) MI_MUST(mi_mixer_create(hub->ctx, capacity, mm, ns, &mix));
 		const size_t L = (size_t)nlegs;
 		h_mic = pinned<int16_t>(kMaxRounds * L * in_len);
 		d_mic = devmem<int16_t>(L * in_len);
@@ -147,12 +156,14 @@ struct LegBank : Pool {
 		h_cnt = pinned<int32_t>(3 * L);
 		d_cnt = devmem<int32_t>(3 * L);
 		d_zero = devmem<int32_t>(L);
-		d_mix = devmem<int16_t>(L * ns);
+		d_mix = devmem<int16_t>((plain ? kLegMaxChunks : 1) * L * ns);
 		d_scratch = devmem<int16_t>(L * ns);
 		h_lv = pinned<int32_t>(3 * L);
 		d_lv = devmem<int32_t>(3 * L);
 		h_vstate = pinned<mi_volume_state>(L);
-		h_copy = pinned<int16_t>(L * ns);
+		h_copy = pinned<int16_t>((plain ? kLegMaxChunks : 1) * L * ns);
+		nout.assign(L, 0);
+		nready.assign(L, 0);
 		h_run = pinned<uint8_t>((size_t)capacity);
 		d_run = devmem<uint8_t>((size_t)capacity);
 		conf_time.assign((size_t)capacity, (uint64_t)-1);
@@ -191,7 +202,7 @@ struct LegBank : Pool {
 		for (MixSlab *s : slabs)
 			if (s->state.load(std::memory_order_acquire) == 0) return s;
 		if (slabs.size() >= 4 || failed) return nullptr;
-		const size_t bytes = (size_t)nlegs * ns * 2;
+		const size_t bytes = (size_t)(plain ? kLegMaxChunks : 1) * nlegs * ns * 2;
 		void *p = mi_host_alloc(hub->ctx, 64 + bytes);
 		if (!p) return nullptr;
 		MixSlab *s = new (p) MixSlab();
@@ -265,6 +276,73 @@ struct LegBank : Pool {
 		lone[(size_t)c] = count == 1 ? who : -1;
 	}
 
+	// the device's half up to the cleaned frames, in the order the reference's process() works: far end queued, then the frames
+	bool enqueue_cancellers(bool any_ref, bool any_refx, bool any_inj, int rounds) {
+		mi_ctx *ctx = hub->ctx;
+		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
+		bool any = false;
+		if (any_ref || any_refx || any_inj) MI_MUST(mi_copy_h2d(ctx, d_cnt, h_cnt, 3 * L * 4));
+		if (any_ref) {
+			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref, UL * ns * 2));
+			MI_MUST(mi_fifo_push(f_ref, d_ref, ns, ns, d_cnt));
+			++launches, any = true;
+		}
+		if (any_refx) {
+			MI_MUST(mi_copy_h2d(ctx, d_refx, h_refx, UL * kLegRefOver * ns * 2));
+			MI_MUST(mi_fifo_push(f_ref, d_refx, kLegRefOver * ns, kLegRefOver * ns, d_cnt + L));
+			++launches, any = true;
+		}
+		if (any_inj) {
+			MI_MUST(mi_fifo_push_silence(f_ref, d_cnt + 2 * L));
+			++launches, any = true;
+		}
+		if (rounds) MI_MUST(mi_copy_h2d(ctx, d_gate, h_gate, (size_t)rounds * L));
+		for (int r = 0; r < rounds; ++r) {
+			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + (size_t)r * L * in_len, UL * in_len * 2));
+			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
+			                                              MI_AEC_POSTFILTER, nullptr, d_gate + (size_t)r * L));
+			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
+		}
+		return any;
+	}
+	// a bank without mixers: every chunk MSVolume completes in this flush is levelled at once (volume_process's loop,
+	// msvolume.c:480-503) and handed on by its owner -- one launch per chunk round, legs without a whole chunk skipped
+	bool enqueue_plain(bool any_ref, bool any_refx, bool any_inj, int rounds) {
+		mi_ctx *ctx = hub->ctx;
+		const size_t L = (size_t)nlegs, UL = (size_t)hi;
+		int maxc = 0;
+		for (size_t s = 0; s < UL; ++s) {
+			FusedLeg *leg = legs[s];
+			if (!leg || failed || nout[s] > 0) continue; // (nout > 0: an earlier enqueue of this flush already levelled this leg's chunks)
+			nout[s] = std::min(leg->newchunks, kLegMaxChunks); // (more than that in one flush: the rest waits in the queue)
+			leg->newchunks -= nout[s];
+			leg->metered |= nout[s] > 0;
+			maxc = std::max(maxc, nout[s]);
+		}
+		if (failed) return false;
+		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
+		if (maxc) {
+			if (!cur) cur = free_slab();
+			uint8_t *dst = cur ? cur->payload() : reinterpret_cast<uint8_t *>(h_copy);
+			for (int r = 0; r < maxc; ++r) { // (rows of round r start behind what a leg still has ready from an earlier enqueue of this flush)
+				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, d_mix + (size_t)r * L * ns, ns, ns, MI_VOLMIX_DRY_SKIPS));
+				++launches;
+			}
+			MI_MUST(mi_copy_d2h(ctx, dst, d_mix, ((size_t)(maxc - 1) * L + UL) * ns * 2));
+			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
+			mixed = true;
+			any = true;
+		}
+		if (check_levels && any) {
+			MI_MUST(mi_fifo_levels(f_mic, d_lv));
+			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
+			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
+			MI_MUST(mi_copy_d2h(ctx, h_lv, d_lv, 3 * L * 4));
+		}
+		outstanding |= any;
+		return any;
+	}
+
 	bool enqueue() override {
 		bool any = false;
 		const bool was_early = early;
@@ -284,10 +362,8 @@ struct LegBank : Pool {
 		staged_since = false;
 		if (root) emitted();
 		// ---- pending control changes (methods called since the last flush)
-		if (ctl_dirty) {
-			MI_MUST(mi_mixer_set_controls(mix, flags.data(), gains.data()));
-			ctl_dirty = false;
-		}
+		if (ctl_dirty && mix) MI_MUST(mi_mixer_set_controls(mix, flags.data(), gains.data()));
+		ctl_dirty = false;
 		if (v_dirty) {
 			for (size_t s = 0; s < UL; ++s) {
 				if (vp_dirty[s]) MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
@@ -322,6 +398,7 @@ struct LegBank : Pool {
 			leg->vol_rem %= ns;
 		}
 		drops.clear();
+		if (plain) return enqueue_plain(any_ref, any_refx, any_inj, rounds);
 		bool ticked = false;
 		for (int c = 0; c < capacity; ++c) { // a mixer ticks once per ticker time, whoever enqueues
 			h_run[c] = 0;
@@ -333,30 +410,7 @@ struct LegBank : Pool {
 		}
 		mixed |= ticked;
 		if (failed) return false;
-		bool any = false;
-		// ---- the device's half, in the order the reference's process() works: far end queued, then the frames, then the mix
-		if (any_ref || any_refx || any_inj) MI_MUST(mi_copy_h2d(ctx, d_cnt, h_cnt, 3 * L * 4));
-		if (any_ref) {
-			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref, UL * ns * 2));
-			MI_MUST(mi_fifo_push(f_ref, d_ref, ns, ns, d_cnt));
-			++launches, any = true;
-		}
-		if (any_refx) {
-			MI_MUST(mi_copy_h2d(ctx, d_refx, h_refx, UL * kLegRefOver * ns * 2));
-			MI_MUST(mi_fifo_push(f_ref, d_refx, kLegRefOver * ns, kLegRefOver * ns, d_cnt + L));
-			++launches, any = true;
-		}
-		if (any_inj) {
-			MI_MUST(mi_fifo_push_silence(f_ref, d_cnt + 2 * L));
-			++launches, any = true;
-		}
-		if (rounds) MI_MUST(mi_copy_h2d(ctx, d_gate, h_gate, (size_t)rounds * L));
-		for (int r = 0; r < rounds; ++r) {
-			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + (size_t)r * L * in_len, UL * in_len * 2));
-			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
-			                                              MI_AEC_POSTFILTER, nullptr, d_gate + (size_t)r * L));
-			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
-		}
+		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
 		if (ticked) {
 			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, (size_t)capacity));
 			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, d_mix, MI_VOLMIX_DRY_SKIPS, d_run));
@@ -407,6 +461,8 @@ struct LegBank : Pool {
 				root = esballoc(cur->payload(), cur->bytes, 0, mix_slab_release);
 			}
 			mixed = false;
+			if (plain)
+				for (size_t s = 0; s < UL; ++s) nready[s] = nout[s], nout[s] = 0;
 		}
 		if (check_levels)
 			for (size_t s = 0; s < UL; ++s) {
@@ -422,6 +478,26 @@ struct LegBank : Pool {
 	}
 
 	void emit(MSFilter *f, int c) override { // mixer_process :336-343 (conference mode): one block per enabled output
+		if (plain) { // the leg's MSVolume hands its levelled chunks on (volume_process :500-502)
+			const uint8_t *base = root ? cur->payload() : reinterpret_cast<const uint8_t *>(h_copy);
+			for (int r = 0; r < nready[(size_t)c]; ++r) {
+				uint8_t *row = const_cast<uint8_t *>(base) + (((size_t)r * nlegs + (size_t)c) * ns) * 2;
+				mblk_t *om;
+				if (root) {
+					om = dupb(root);
+					om->b_rptr = row;
+					om->b_wptr = row + (size_t)ns * 2;
+				} else {
+					om = allocb((size_t)ns * 2, 0);
+					memcpy(om->b_wptr, row, (size_t)ns * 2);
+					om->b_wptr += ns * 2;
+				}
+				if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
+				else freemsg(om);
+			}
+			nready[(size_t)c] = 0;
+			return;
+		}
 		if (!conf_ready[(size_t)c]) return;
 		conf_ready[(size_t)c] = 0;
 		MixerState *s = (MixerState *)f->data;
@@ -489,6 +565,20 @@ void leg_conf_walked(LegBank *b, int c) {
 	b->early = true;
 }
 
+// A bank without mixers has no filter that is walked behind all of a leg's facades; its legs' cancellers are (MSSpeexEC runs
+// when both the resampler and the far end have, msticker.c:230-242): once every leg of the bank has taken its far end in this
+// tick the bank's work leaves, as above.  (A tick in which some far end is late falls back to the flush.)
+void leg_far_walked(LegBank *b, FusedLeg *leg) {
+	if (b->no_early || b->failed || b->early || !b->hub->ticker) return;
+	const uint32_t tick = b->hub->ticker->ticks;
+	if (b->walk_epoch != tick) b->walk_epoch = tick, b->walked = 0;
+	if (leg->far_tick == tick) return;
+	leg->far_tick = tick;
+	if (++b->walked < b->in_use) return;
+	b->early_any = b->enqueue_at(b->hub->ticker->time + (uint64_t)b->hub->ticker->interval);
+	b->early = true;
+}
+
 // ---- the facades' fused halves -----------------------------------------------------------------------------------------
 // MSResample: this tick's input, re-framed to 10 ms blocks, straight into the bank's staging rows
 void leg_stage_mic(MSFilter *f, ResampleData *d) {
@@ -541,6 +631,7 @@ void leg_take_far_end(MSFilter *f, SpeexECState *s) {
 		b->staged_since = true;
 		request_flush(f);
 	}
+	if (b->plain) leg_far_walked(b, leg);
 }
 
 // ---- fusing ------------------------------------------------------------------------------------------------------------
@@ -742,7 +833,103 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 	for (FusedLeg *leg : gone) delete leg;
 }
 
-MSFilter *leg_mixer(FusedLeg *leg) { return leg->mixer; }
+// ---- a leg WITHOUT a mixer:  MSResample -> MSSpeexEC pin 1 -> MSVolume (AGC) -> any other filter, all ours on one ticker
+bool leg_try_fuse_plain(MSFilter *rs) {
+	if (getenv("MSMI355X_NO_FUSE") != nullptr || !rs->ticker || rs->ticker->interval != 10) return false;
+	ResampleData *rd = (ResampleData *)rs->data;
+	MSQueue *q = rs->outputs[0];
+	MSFilter *ec = q ? q->next.filter : NULL;
+	if (!ec || !is_ec_desc(ec->desc) || q->next.pin != 1 || ec->ticker != rs->ticker || !ms_queue_empty(q)) return false;
+	SpeexECState *es = (SpeexECState *)ec->data;
+	if (es->bypass_mode || es->unsupported || !es->pool || es->echostarted || es->leg || (uint32_t)es->samplerate != rd->output_rate) return false;
+	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
+	MSQueue *qv = ec->outputs[1];
+	MSFilter *vol = qv ? qv->next.filter : NULL;
+	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != rs->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
+	VolumeData *vd = (VolumeData *)vol->data;
+	if (!vd->p.agc_enabled || vd->peer || vd->peered_by > 0 || vd->sample_rate != es->samplerate || vd->leg) return false;
+	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
+	if (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz)) return false;
+	const uint32_t ir = rd->input_rate, rate = rd->output_rate;
+	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;
+	LegBank *b = bank<LegBank>("legp:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
+	                               std::to_string(delay),
+	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true); }); // 64, 256, 1024, .. legs
+	const int s = b ? b->acquire(vol) : -1;
+	if (s < 0) return false;
+	note_slot(vol);
+	bool ok = mi_resampler_reset(b->rs, s, 1) == MI_OK && mi_aec_reset(b->aec, s, 1) == MI_OK && mi_fifo_reset_range(b->f_mic, s, 1) == MI_OK &&
+	          mi_fifo_reset_range(b->f_ref, s, 1) == MI_OK && mi_fifo_reset_range(b->f_out, s, 1) == MI_OK && mi_volume_reset_max(b->vol, s, 1) == MI_OK;
+	mi_volume_state st;
+	memset(&st, 0, sizeof(st));
+	st.gain = vd->gain, st.target_gain = vd->target_gain, st.ng_gain = 1;
+	b->vstate[(size_t)s] = st;
+	b->vparams[(size_t)s] = vd->p;
+	b->vparams[(size_t)s].peer = -1;
+	if (es->state_str) {
+		std::vector<uint8_t> blob;
+		if (b64_decode(es->state_str, blob) && mi_aec_import_state(b->aec, s, blob.data(), blob.size()) == MI_OK) ms_message("mi355x echo state restored.");
+		else ms_error("Could not apply mi355x echo blob: %s", mi_last_error());
+	}
+	ok = ok && mi_volume_set_params(b->vol, s, 1, &b->vparams[(size_t)s]) == MI_OK && mi_volume_set_state(b->vol, s, 1, &b->vstate[(size_t)s]) == MI_OK;
+	if (ok && delay > 0) {
+		std::vector<int32_t> fill((size_t)b->nlegs, 0);
+		fill[(size_t)s] = delay;
+		ok = mi_copy_h2d(b->hub->ctx, b->d_cnt, fill.data(), (size_t)b->nlegs * 4) == MI_OK && mi_fifo_push_silence(b->f_ref, b->d_cnt) == MI_OK &&
+		     mi_ctx_sync(b->hub->ctx) == MI_OK;
+	}
+	if (!ok) {
+		mi_failed("fusing a call leg");
+		b->release(s);
+		return false;
+	}
+	FusedLeg *leg = new FusedLeg();
+	leg->bank = b, leg->slot = s, leg->pin = 0;
+	leg->rs = rs, leg->ec = ec, leg->vol = vol, leg->mixer = nullptr;
+	leg->dref_level = delay;
+	b->legs[(size_t)s] = leg;
+	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
+	if (rd->pool) resample_release(rd);
+	rd->leg = leg;
+	ms_bufferizer_flush(&es->delayed_ref);
+	es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
+	es->pool->release(es->slot);
+	es->pool = nullptr, es->slot = -1;
+	es->leg = leg;
+	if (vd->pool) {
+		vd->pool->release(vd->slot);
+		vd->pool = nullptr, vd->slot = -1;
+	}
+	vd->leg = leg;
+	b->staged_since = true;
+	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (MSResample -> MSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen);
+	return true;
+}
+
+void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
+	LegBank *b = leg->bank;
+	HubLock lk(b->hub);
+	const int s = leg->slot;
+	b->legs[(size_t)s] = nullptr;
+	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
+	((ResampleData *)leg->rs->data)->leg = nullptr;
+	((SpeexECState *)leg->ec->data)->leg = nullptr;
+	((VolumeData *)leg->vol->data)->leg = nullptr;
+	if (keep_running) {
+		ec_prepare(leg->ec); // a bank slot of its own again, while the hub is still held by this leg's slot
+		ms_warning("mi355x: call leg %p left its fused batch (a member's configuration changed); the facades carry on one by one", (void *)leg->vol);
+	}
+	b->release(s); // (may destroy the bank)
+	delete leg;
+}
+
+void leg_release(FusedLeg *leg, bool keep_running) {
+	if (!leg) return;
+	if (leg->mixer) conf_unfuse(leg->mixer, keep_running);
+	else leg_unfuse_plain(leg, keep_running);
+}
+bool leg_wants_out(FusedLeg *leg) { return leg && !leg->mixer && leg->unfuse_wanted; }
+
 Pool *leg_pool(FusedLeg *leg) { return leg->bank; }
 Pool *leg_pool_of(LegBank *b) { return b; }
 // MS_AUDIO_MIXER_SET_INPUT_GAIN / SET_ACTIVE / ENABLE_OUTPUT on a fused conference (hub locked): the bank's control rows
@@ -781,5 +968,7 @@ mi_aec *leg_canceller(FusedLeg *leg, int *slot) {
 // a facade of a fused leg stopped qualifying (a method call on the application's thread): the conference leaves the batch
 // at the start of the next flush -- on the ticker thread, where the facades' state may be touched
 void leg_disqualify(FusedLeg *leg) {
-	if (leg) ((MixerState *)leg->mixer->data)->unfuse_wanted = true;
+	if (!leg) return;
+	if (leg->mixer) ((MixerState *)leg->mixer->data)->unfuse_wanted = true;
+	else leg->unfuse_wanted = true; // (honoured by the leg's MSResample at its next block)
 }

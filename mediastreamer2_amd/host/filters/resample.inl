@@ -98,13 +98,13 @@ void resample_release(ResampleData *d) { // hub locked by the caller
 void resample_postprocess(MSFilter *f) { // detach: a fused conference goes back to its facades' own banks
 	ResampleData *d = (ResampleData *)f->data;
 	facade_detached(f);
-	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
+	if (d->leg) leg_release(d->leg, false);
 	d->fuse_checked = false;
 }
 
 void resample_uninit(MSFilter *f) {
 	ResampleData *d = (ResampleData *)f->data;
-	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
+	if (d->leg) leg_release(d->leg, false);
 	{
 		HubLock lk(f);
 		resample_release(d);
@@ -147,7 +147,9 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 	if (!d->leg && !d->fuse_checked && !d->pool && f->ticker) { // first block since the attach: is this the head of a leg of a conference?
 		d->fuse_checked = true;
 		if (MSFilter *mx = leg_find_mixer(f)) conf_try_fuse(mx);
+		else leg_try_fuse_plain(f); // MSResample -> MSSpeexEC -> MSVolume -> anything else: an AudioStream's sending side (audiostream.c:1798-1810)
 	}
+	if (d->leg && leg_wants_out(d->leg)) leg_release(d->leg, true); // a member stopped qualifying (a method call): back to the facades' own banks
 	if (d->leg) { // fused: the block goes into the leg's row of the conference's bank, nothing is emitted here
 		leg_stage_mic(f, d);
 		ms_filter_unlock(f);

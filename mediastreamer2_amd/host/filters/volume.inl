@@ -141,12 +141,12 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 void volume_postprocess(MSFilter *f) { // detach: a fused conference goes back to its facades' own banks
 	VolumeData *d = (VolumeData *)f->data;
 	facade_detached(f);
-	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
+	if (d->leg) leg_release(d->leg, false);
 }
 
 void volume_uninit(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
-	if (d->leg) conf_unfuse(leg_mixer(d->leg), false);
+	if (d->leg) leg_release(d->leg, false);
 	if (d->peer) ((VolumeData *)d->peer->data)->peered_by--;
 	if (d->pool && d->slot >= 0) {
 		HubLock lk(f);

@@ -130,7 +130,7 @@ class Host:
 class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
-    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None):
+    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -138,11 +138,14 @@ class Conferences:
         self.pins = list(range(members)) if pins is None else list(pins)
         base = lambda name: IDS[name]
         self.legs, self.mixers = [], []
+        self.with_mixer = mixer
         for c in range(nconf):
-            mx = S.ms_factory_create_filter(h.fac, MS_AUDIO_MIXER_ID)
-            h.call_int(mx, base("MS_FILTER_SET_SAMPLE_RATE"), rate)
-            h.call_int(mx, MIX_CONF_MODE, 1)
-            self.mixers.append(mx)
+            mx = None
+            if mixer:  # else: an AudioStream's sending side on a shared ticker -- MSVolume's output goes straight to the sink
+                mx = S.ms_factory_create_filter(h.fac, MS_AUDIO_MIXER_ID)
+                h.call_int(mx, base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                h.call_int(mx, MIX_CONF_MODE, 1)
+                self.mixers.append(mx)
             for k in range(members):
                 leg = {"mic": S.ms2shim_new_source(h.fac), "far": S.ms2shim_new_source(h.fac), "spk": S.ms2shim_new_sink(h.fac),
                        "out": S.ms2shim_new_sink(h.fac), "rs": S.ms_factory_create_filter(h.fac, MS_RESAMPLE_ID),
@@ -158,21 +161,25 @@ class Conferences:
                     h.call_int(leg["vol"], VOL_ENABLE_AGC, 1)
                 if gain is not None:
                     h.call_float(leg["vol"], VOL_SET_GAIN, gain)
-                for a, pa, b, pb in ((leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1), (leg["ec"], 1, leg["vol"], 0),
-                                     (leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0), (leg["far"], 0, leg["ec"], 0),
-                                     (leg["ec"], 0, leg["spk"], 0)):
+                links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1), (leg["ec"], 1, leg["vol"], 0), (leg["far"], 0, leg["ec"], 0),
+                         (leg["ec"], 0, leg["spk"], 0)]
+                links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
+                for a, pa, b, pb in links:
                     assert S.ms_filter_link(a, pa, b, pb) == 0
                 self.legs.append(leg)
         self.attached = False
 
+    def roots(self):
+        return self.mixers if self.with_mixer else [leg["mic"] for leg in self.legs]
+
     def attach(self):
-        for c in range(self.nconf):
-            self.S.ms_ticker_attach(self.ticker, self.mixers[c])
+        for f in self.roots():
+            self.S.ms_ticker_attach(self.ticker, f)
         self.attached = True
 
     def detach(self):
-        for c in range(self.nconf):
-            self.S.ms_ticker_detach(self.ticker, self.mixers[c])
+        for f in self.roots():
+            self.S.ms_ticker_detach(self.ticker, f)
         self.attached = False
 
     def step(self, n=1):
@@ -219,7 +226,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc = dict(nconf=2, members=4, nticks=120, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, pins=None)
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
-                       gain=sc.get("gain"))
+                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -276,6 +283,9 @@ SCENARIOS = {
     "gain_method": {"events": [(40, "gain", 1, 0.5), (70, "gain", 5, 2.0)], "no_early_launch": True},
     "gain_method_early": {"events": [(40, "gain", 1, 0.5), (70, "gain", 5, 2.0)]},
     "wideband_8k_16k": {"in_rate": 8000, "rate": 16000, "tail_ms": 128, "nticks": 100},
+    # an AudioStream's sending side, several streams on one ticker: MSVolume's chunks go on to another filter, there is no mixer
+    "no_mixer": {"no_mixer": True, "nconf": 1, "members": 6, "delay_ms": 10, "far_gaps": True},
+    "no_mixer_ptime20": {"no_mixer": True, "nconf": 1, "members": 5, "ptime20": True, "nticks": 100},
 }
 
 

@@ -813,6 +813,22 @@ int mi_volume_process_fifo(mi_volume *v, mi_fifo *f, int16_t *out, int ns, int s
 	return rc != MI_OK ? rc : mi_volume_process(v, out, ns, stride, nullptr);
 }
 
+int mi_volume_process_fifo_flags(mi_volume *v, mi_fifo *f, int16_t *out, int ns, int stride, unsigned flags) {
+	ARG(v && f && out && f->n == v->n);
+	std::vector<int32_t> per((size_t)v->n, 0);
+	for (int s = 0; s < v->n; ++s) {
+		std::vector<int16_t> &q = f->q[(size_t)s];
+		const bool has = (int)q.size() >= ns;
+		if (has) {
+			std::copy(q.begin(), q.begin() + ns, out + (size_t)s * stride);
+			q.erase(q.begin(), q.begin() + ns);
+		} else if (!(flags & MI_VOLMIX_DRY_SKIPS)) {
+			memset(out + (size_t)s * stride, 0, (size_t)ns * 2);
+		}
+		per[(size_t)s] = (has || !(flags & MI_VOLMIX_DRY_SKIPS)) ? ns : 0;
+	}
+	return mi_volume_process(v, out, ns, stride, per.data());
+}
 int mi_volume_process_fifo_range(mi_volume *v, mi_fifo *f, int16_t *out, int ns, int stride, int first, int count) {
 	ARG(v && f && out && f->n == v->n && first >= 0 && count >= 0 && first + count <= v->n);
 	for (int s = first; s < first + count; ++s) {

@@ -250,7 +250,29 @@ static void *conferences(void *arg) {
 			}
 			CHECK(ms_ticker_attach(tk, mx[c]) == 0);
 		}
+		/* three call legs WITHOUT a mixer on the same ticker (an AudioStream's sending side): fused leg by leg */
+		leg_t solo[3];
+		for (int k = 0; k < 3; ++k) {
+			leg_t *l = &solo[k];
+			l->mic = ms2shim_new_source(g_fac), l->far = ms2shim_new_source(g_fac);
+			l->spk = ms2shim_new_sink(g_fac), l->out = ms2shim_new_sink(g_fac);
+			l->rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
+			l->ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
+			l->vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+			ms2shim_sink_set_discard(l->spk, 1), ms2shim_sink_set_discard(l->out, 1);
+			set_int(l->rs, MS_FILTER_SET_SAMPLE_RATE, 16000), set_int(l->rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
+			set_int(l->ec, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
+			set_int(l->vol, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->vol, MS_VOLUME_ENABLE_AGC, 1);
+			ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1), ms_filter_link(l->ec, 1, l->vol, 0);
+			ms_filter_link(l->vol, 0, l->out, 0), ms_filter_link(l->far, 0, l->ec, 0), ms_filter_link(l->ec, 0, l->spk, 0);
+			CHECK(ms_ticker_attach(tk, l->mic) == 0);
+		}
 		for (int t = 0; t < 14; ++t) {
+			for (int k = 0; k < 3; ++k) {
+				ms2shim_source_push(solo[k].mic, mic, sizeof mic);
+				if (t != 5 || k != 1) ms2shim_source_push(solo[k].far, far, sizeof far); /* a far end that skips a tick */
+			}
+			if (t == 7) { int off = 0; ms_filter_call_method(solo[2].vol, MS_VOLUME_ENABLE_AGC, &off); } /* that leg goes back to its facades */
 			for (int c = 0; c < NC; ++c)
 				for (int k = 0; k < NM; ++k) {
 					ms2shim_source_push(leg[c][k].mic, mic, sizeof mic);
@@ -268,6 +290,14 @@ static void *conferences(void *arg) {
 				ms_ticker_detach(tk, mx[0]);
 				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
 			}
+		}
+		for (int k = 0; k < 3; ++k) {
+			leg_t *l = &solo[k];
+			ms_ticker_detach(tk, l->mic);
+			ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1), ms_filter_unlink(l->ec, 1, l->vol, 0);
+			ms_filter_unlink(l->vol, 0, l->out, 0), ms_filter_unlink(l->far, 0, l->ec, 0), ms_filter_unlink(l->ec, 0, l->spk, 0);
+			ms_filter_destroy(l->mic), ms_filter_destroy(l->far), ms_filter_destroy(l->rs), ms_filter_destroy(l->ec);
+			ms_filter_destroy(l->vol), ms_filter_destroy(l->spk), ms_filter_destroy(l->out);
 		}
 		for (int c = 0; c < NC; ++c) {
 			ms_ticker_detach(tk, mx[c]);

@@ -81,6 +81,7 @@ def test_mixer_split_form_equals_fused(ctx, oracle):
         m = ms.MixerBatch(ctx, nconf, half, ns)
         d = torch.from_numpy(sh).cuda()
         s = torch.zeros((nconf, ns), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()  # torch fills `d` and `s` on ITS stream; the kernels below run on the context's stream
         m.partial_sum(d, s)
         ctx.sync()
         sums.append(s)
