@@ -363,12 +363,13 @@ __global__ void volume_flip_kernel(int *parity) { *parity ^= 1; }
 // One workgroup = one conference; the members' chunks live in LDS as packed int16 rows (pitch: an odd number of 8-byte
 // words, so the lanes that walk one row each in the serial meter read disjoint banks).
 //   (0) lane m < members: parameters, state, peer energy, mixer controls, ms_bufferizer_read of its FIFO (all or nothing);
-//   (A) all lanes: the chunks into LDS, 16 bytes at a time; integer peak and DC sum through LDS atomics;
+//   (A) eight lanes per member: the chunks into LDS, 16 bytes at a time; integer peak and DC sum in packed 16-bit
+//       arithmetic, reduced over the eight lanes in registers;
 //   (B) lane m: the float32 sum of squares IN SAMPLE ORDER (the order is part of the reference's result) and the control
 //       chain (volume_control) -- one member per lane, all members at once;
-//   (C) all lanes: the Q12 gain, then the mixer's input stage (channel_process_in: pin active? input gain) in place;
-//   (D) lane = a pair of columns: the int32 sum over the members, and for every pin with its output enabled
-//       saturate(sum - own) (channel_process_out), 4 bytes per lane and row, rows contiguous.
+//   (C + D) lane = four columns: the Q12 gain, then the mixer's input stage (channel_process_in: pin active? input gain)
+//       in place and the int32 sum over the members; then for every pin with its output enabled saturate(sum - own)
+//       (channel_process_out), 8 bytes per lane and row, rows contiguous.
 struct VolMixArgs {
 	VolArgs v;            // the volume batch (params, state, energy double buffer, window) and the source FIFO
 	const uint8_t *flags; // mixer controls [nconf][mm]
@@ -379,13 +380,14 @@ struct VolMixArgs {
 	const uint8_t *run;   // nullable [nconf]: 0 = the conference does not tick in this launch (nothing popped, nothing written)
 };
 constexpr int VM_THREADS = 256, VM_MAXM = MI_MIXER_MAX_CHANNELS;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const VolArgs &a = va.v;
 	uint2 *rows = reinterpret_cast<uint2 *>(smem); // [mm][row_w] four samples per word
-	__shared__ int s_intgain[VM_MAXM], s_dcoff[VM_MAXM], s_mode[VM_MAXM], s_pk[VM_MAXM], s_dc[VM_MAXM], s_head[VM_MAXM], s_flag[VM_MAXM];
-	__shared__ float s_mgain[VM_MAXM];
+	__shared__ int s_pk[VM_MAXM], s_dc[VM_MAXM], s_head[VM_MAXM];
+	__shared__ int4 s_par[VM_MAXM]; // what (C + D) needs of a member, one 16-byte broadcast read: (flags | mode << 8, Q12 gain, DC offset, pin gain)
 	const int t = threadIdx.x, c = blockIdx.x, mm = va.mm, ns = a.nsamples, nw = ns >> 2, ng = ns >> 3;
 	if (va.run && !va.run[c]) return;
 	const int s0 = a.first + c * mm;
@@ -393,14 +395,15 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	mi_volume_params p;
 	mi_volume_state st;
 	float peer_energy = 0;
+	unsigned mflag = 0; // the member's mixer controls
+	int mgain_bits = 0;
 	if (t < mm) {
 		const int s = s0 + t;
 		p = a.params[s];
 		st = a.state[s];
 		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
-		s_flag[t] = va.flags[c * mm + t];
-		s_mgain[t] = va.gain[c * mm + t];
-		s_pk[t] = 0, s_dc[t] = 0;
+		mflag = va.flags[c * mm + t];
+		mgain_bits = __float_as_int(va.gain[c * mm + t]);
 		const int2 q = a.src.pos[s]; // ms_bufferizer_read, all-or-nothing (msqueue.c:83); a leg that runs dry hears and meters silence
 		int head = -1;
 		if (q.y >= ns) {
@@ -411,39 +414,64 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	}
 	__syncthreads();
 
-	// ---- (A)
-	for (int i = t; i < mm * ng; i += VM_THREADS) {
-		const int m = i / ng, g = i - m * ng, h = s_head[m];
-		uint4 v = make_uint4(0, 0, 0, 0);
-		if (h >= 0) {
+	// ---- (A) eight lanes per member (lane q takes the 16-byte groups q, q + 8, ..: 128 contiguous bytes per member and
+	// round), peak and DC sum in packed 16-bit arithmetic -- the peak as max(max x, -min x), exact for -32768 too --,
+	// reduced over the eight lanes in registers (DPP): one plain LDS word per member and quantity, no LDS atomics
+	// (two per group, most of a wave on ONE address, were a fifth of the kernel)
+	for (int mb = 0; mb < mm; mb += VM_THREADS / 8) {
+		const int m = mb + (t >> 3), q = t & 7;
+		const bool valid = m < mm;
+		s16x2 pmax = {0, 0}, pmin = {0, 0};
+		int dc = 0;
+		if (valid) {
+			const int h = s_head[m];
 			const int16_t *ring = a.src.ring + (size_t)(s0 + m) * a.src.cap;
-			unsigned at = (unsigned)h + 8u * (unsigned)g;
-			if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
-			if ((h & 7) == 0) {
-				v = *reinterpret_cast<const uint4 *>(ring + at);
-			} else { // a head some other reader left off the 16-byte grid: sample by sample, wrap-aware
-				unsigned w[4] = {0, 0, 0, 0};
+			for (int g = q; g < ng; g += 8) {
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (h >= 0) {
+					unsigned at = (unsigned)h + 8u * (unsigned)g;
+					if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
+					if ((h & 7) == 0) {
+						v = *reinterpret_cast<const uint4 *>(ring + at);
+					} else { // a head some other reader left off the 16-byte grid: sample by sample, wrap-aware
+						unsigned w[4] = {0, 0, 0, 0};
 #pragma unroll
-				for (int k = 0; k < 8; ++k) {
-					unsigned q = at + (unsigned)k;
-					if (q >= (unsigned)a.src.cap) q -= (unsigned)a.src.cap;
-					w[k >> 1] |= (unsigned)(uint16_t)ring[q] << (16 * (k & 1));
+						for (int k = 0; k < 8; ++k) {
+							unsigned qq = at + (unsigned)k;
+							if (qq >= (unsigned)a.src.cap) qq -= (unsigned)a.src.cap;
+							w[k >> 1] |= (unsigned)(uint16_t)ring[qq] << (16 * (k & 1));
+						}
+						v = make_uint4(w[0], w[1], w[2], w[3]);
+					}
 				}
-				v = make_uint4(w[0], w[1], w[2], w[3]);
+				rows[m * va.row_w + 2 * g] = make_uint2(v.x, v.y);
+				rows[m * va.row_w + 2 * g + 1] = make_uint2(v.z, v.w);
+				const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const s16x2 x = __builtin_bit_cast(s16x2, w[k]);
+					pmax = __builtin_elementwise_max(pmax, x);
+					pmin = __builtin_elementwise_min(pmin, x);
+					dc = __builtin_amdgcn_sdot2(x, (s16x2){1, 1}, dc, false);
+				}
 			}
 		}
-		rows[m * va.row_w + 2 * g] = make_uint2(v.x, v.y);
-		rows[m * va.row_w + 2 * g + 1] = make_uint2(v.z, v.w);
-		const unsigned w[4] = {v.x, v.y, v.z, v.w};
-		int pk = 0, dc = 0;
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const int x = (int)(short)((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu));
-			pk = max(pk, x < 0 ? -x : x);
-			dc += x;
+		unsigned umax = __builtin_bit_cast(unsigned, pmax), umin = __builtin_bit_cast(unsigned, pmin);
+#define VM_DPP(x, ctrl) __builtin_amdgcn_update_dpp((int)(x), (int)(x), ctrl, 0xf, 0xf, false)
+#define VM_STEP(ctrl)                                                                                                                            \
+	umax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, umax), __builtin_bit_cast(s16x2, (unsigned)VM_DPP(umax, ctrl)))); \
+	umin = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s16x2, umin), __builtin_bit_cast(s16x2, (unsigned)VM_DPP(umin, ctrl)))); \
+	dc += VM_DPP(dc, ctrl);
+		VM_STEP(0xB1)  // quad_perm [1,0,3,2]
+		VM_STEP(0x4E)  // quad_perm [2,3,0,1]
+		VM_STEP(0x141) // row_half_mirror: the other quad of the eight
+#undef VM_STEP
+#undef VM_DPP
+		if (valid && q == 0) {
+			const s16x2 hi = __builtin_bit_cast(s16x2, umax), lo = __builtin_bit_cast(s16x2, umin);
+			s_pk[m] = max(max((int)hi.x, (int)hi.y), -min((int)lo.x, (int)lo.y));
+			s_dc[m] = dc;
 		}
-		atomicMax(&s_pk[m], pk);
-		atomicAdd(&s_dc[m], dc);
 	}
 	__syncthreads();
 
@@ -466,12 +494,12 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 		if (va.dry_skips && s_head[t] < 0) {
 			// the plugin's chain: volume_process (msvolume.c:480-486) finds no whole 10 ms chunk in its bufferizer and does
 			// nothing -- no meter update, no gain ramp --, the mixer reads zeros for the pin (audiomixer.c:88)
-			s_intgain[t] = 4096, s_dcoff[t] = 0, s_mode[t] = 0;
+			s_par[t] = make_int4((int)mflag, 4096, 0, mgain_bits);
 			a.energy[*a.parity ^ 1][s] = st.energy;
 		} else {
 			float2 win = a.win[s];
 			const VolCtl o = volume_control(p, st, peer_energy, acc, ns, s_pk[t], s_dc[t], a.sample_rate, win);
-			s_intgain[t] = o.intgain, s_dcoff[t] = o.dcoff, s_mode[t] = o.mode;
+			s_par[t] = make_int4((int)mflag | (o.mode << 8), o.intgain, o.dcoff, mgain_bits);
 			a.state[s] = st;
 			a.energy[*a.parity ^ 1][s] = st.energy;
 			a.win[s] = win;
@@ -479,46 +507,45 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	}
 	__syncthreads();
 
-	// ---- (C) Q12 gain (apply_gain), then the pin's contribution as channel_process_in leaves it (0 unless linked and active)
-	for (int i = t; i < mm * nw; i += VM_THREADS) {
-		const int m = i / nw, j = i - m * nw;
-		const unsigned f = (unsigned)s_flag[m];
-		uint2 o = make_uint2(0, 0);
-		if ((f & MI_MIX_LINKED) && (f & MI_MIX_ACTIVE)) {
-			const uint2 r = rows[m * va.row_w + j];
-			int x[4] = {(int)(short)(r.x & 0xffffu), (int)(short)(r.x >> 16), (int)(short)(r.y & 0xffffu), (int)(short)(r.y >> 16)};
-			const int mode = s_mode[m];
-			if (mode != 0) {
-				const int ig = s_intgain[m], dc = (mode == 2) ? s_dcoff[m] : 0;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) x[k] = sat16(((x[k] - dc) * ig) / 4096);
-			}
-			const float gn = s_mgain[m];
-			if (gn != 1.0f) {
-#pragma unroll
-				for (int k = 0; k < 4; ++k) x[k] = sat16((int)(gn * (float)x[k]));
-			}
-			o.x = (unsigned)(x[0] & 0xffff) | ((unsigned)x[1] << 16);
-			o.y = (unsigned)(x[2] & 0xffff) | ((unsigned)x[3] << 16);
-		}
-		rows[m * va.row_w + j] = o;
-	}
-	__syncthreads();
-
-	// ---- (D)
-	const unsigned *r32 = reinterpret_cast<const unsigned *>(rows);
-	for (int j = t; j < (ns >> 1); j += VM_THREADS) {
-		int lo = 0, hi = 0;
+	// ---- (C + D) lane = four columns.  First loop over the members: the Q12 gain (apply_gain), then the pin's contribution as
+	// channel_process_in leaves it (0 unless linked and active) -- back into the row, in place -- and the int32 sum over
+	// the members; second loop: for every pin with its output enabled saturate(sum - own) (channel_process_out), 8 bytes
+	// per lane and row, rows contiguous.  A lane only re-reads what it wrote itself: no barrier in between, no index
+	// arithmetic per element (the two phases as loops over (member, word) items divided by a run-time width per item).
+	for (int j = t; j < nw; j += VM_THREADS) {
+		int sum[4] = {0, 0, 0, 0};
 		for (int m = 0; m < mm; ++m) {
-			const unsigned w = r32[m * va.row_w * 2 + j];
-			lo += (int)(short)(w & 0xffffu);
-			hi += (int)(short)(w >> 16);
+			const int4 pr = s_par[m]; // (flags | mode << 8, Q12 gain, DC offset, pin gain)
+			const unsigned f = (unsigned)pr.x & 0xffu;
+			uint2 o = make_uint2(0, 0);
+			if ((f & MI_MIX_LINKED) && (f & MI_MIX_ACTIVE)) {
+				const uint2 r = rows[m * va.row_w + j];
+				int x[4] = {(int)(short)(r.x & 0xffffu), (int)(short)(r.x >> 16), (int)(short)(r.y & 0xffffu), (int)(short)(r.y >> 16)};
+				const int mode = pr.x >> 8;
+				if (mode != 0) {
+					const int ig = pr.y, dc = (mode == 2) ? pr.z : 0;
+#pragma unroll
+					for (int k = 0; k < 4; ++k) x[k] = sat16(((x[k] - dc) * ig) / 4096);
+				}
+				const float gn = __int_as_float(pr.w);
+				if (gn != 1.0f) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) x[k] = sat16((int)(gn * (float)x[k]));
+				}
+#pragma unroll
+				for (int k = 0; k < 4; ++k) sum[k] += x[k];
+				o.x = (unsigned)(x[0] & 0xffff) | ((unsigned)x[1] << 16);
+				o.y = (unsigned)(x[2] & 0xffff) | ((unsigned)x[3] << 16);
+			}
+			rows[m * va.row_w + j] = o;
 		}
 		for (int m = 0; m < mm; ++m) {
-			if (!((unsigned)s_flag[m] & MI_MIX_OUTPUT)) continue;
-			const unsigned w = r32[m * va.row_w * 2 + j];
-			const int ol = sat16(lo - (int)(short)(w & 0xffffu)), oh = sat16(hi - (int)(short)(w >> 16));
-			*reinterpret_cast<unsigned *>(va.out + ((size_t)(c * mm + m) * ns) + 2 * j) = (unsigned)(ol & 0xffff) | ((unsigned)oh << 16);
+			if (!((unsigned)s_par[m].x & MI_MIX_OUTPUT)) continue;
+			const uint2 w = rows[m * va.row_w + j];
+			const int o0 = sat16(sum[0] - (int)(short)(w.x & 0xffffu)), o1 = sat16(sum[1] - (int)(short)(w.x >> 16));
+			const int o2 = sat16(sum[2] - (int)(short)(w.y & 0xffffu)), o3 = sat16(sum[3] - (int)(short)(w.y >> 16));
+			*reinterpret_cast<uint2 *>(va.out + ((size_t)(c * mm + m) * ns) + 4 * j) =
+			    make_uint2((unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16), (unsigned)(o2 & 0xffff) | ((unsigned)o3 << 16));
 		}
 	}
 }
@@ -716,7 +743,7 @@ int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stre
 	MI_CHECK_ARG(f_src->nstreams == v->nstreams && first_stream + mv.nconf * mv.mm <= v->nstreams && mv.device == v->ctx->device);
 	const int row_w = (mv.ns >> 2) | 1; // 8-byte words per row, odd
 	const size_t lds = (size_t)mv.mm * row_w * 8;
-	if ((mv.ns & 7) || (f_src->capacity & 7) || (reinterpret_cast<uintptr_t>(d_out) & 3) || lds > 120 * 1024) {
+	if ((mv.ns & 7) || (f_src->capacity & 7) || (reinterpret_cast<uintptr_t>(d_out) & 7) || lds > 120 * 1024) {
 		mi::set_error("mi_mixer_process_volume_fifo: ticks and FIFO capacities must be multiples of 8 samples and a conference's tick must "
 		              "fit the LDS (%d members x %d samples)", mv.mm, mv.ns);
 		return MI_ENOTSUP;

@@ -110,6 +110,20 @@ struct LegBank : Pool {
 	bool staged_since = false;              // something was staged (or a conference joined) since the last enqueue
 	bool outstanding = false;               // an enqueue has not been waited for yet
 	bool mixed = false, check_levels = false;
+	double trace_ms = 0;          // MSMI355X_TRACE_SLOW_MS: an enqueue that takes longer says where (stderr)
+	uint64_t tr[8] = {0};
+	std::vector<std::pair<const char *, uint64_t>> trc; // ... and call by call inside the device's half
+	static uint64_t trace_now() {
+		struct timespec ts;
+		clock_gettime(CLOCK_MONOTONIC, &ts);
+		return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+	}
+	void mark(int i) {
+		if (trace_ms > 0) tr[i] = trace_now();
+	}
+	void step(const char *what) {
+		if (trace_ms > 0) trc.emplace_back(what, trace_now());
+	}
 	uint64_t launches = 0;
 	std::vector<std::pair<MSQueue *, mblk_t *>> spk; // speaker-pin frames of this flush (MSSpeexEC pin 0: host audio), handed on in finish()
 	int walked = 0;                                  // conferences whose mixer has run in this tick's graph walk
@@ -182,6 +196,7 @@ struct LegBank : Pool {
 		vs_dirty.assign(L, 0);
 		vpatch.assign(L, GainPatch{1.f, 1.f, false});
 		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
+		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
 		no_early = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr; // A/B switch: everything leaves at the flush
 	}
 	~LegBank() override {
@@ -281,10 +296,15 @@ struct LegBank : Pool {
 		mi_ctx *ctx = hub->ctx;
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
 		bool any = false;
+		trc.clear();
+		step("start");
 		if (any_ref || any_refx || any_inj) MI_MUST(mi_copy_h2d(ctx, d_cnt, h_cnt, 3 * L * 4));
+		step("counts up");
 		if (any_ref) {
 			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref, UL * ns * 2));
+			step("far end up");
 			MI_MUST(mi_fifo_push(f_ref, d_ref, ns, ns, d_cnt));
+			step("far end queued");
 			++launches, any = true;
 		}
 		if (any_refx) {
@@ -297,10 +317,13 @@ struct LegBank : Pool {
 			++launches, any = true;
 		}
 		if (rounds) MI_MUST(mi_copy_h2d(ctx, d_gate, h_gate, (size_t)rounds * L));
+		step("gates up");
 		for (int r = 0; r < rounds; ++r) {
 			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + (size_t)r * L * in_len, UL * in_len * 2));
+			step("microphones up");
 			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
 			                                              MI_AEC_POSTFILTER, nullptr, d_gate + (size_t)r * L));
+			step("cancellers launched");
 			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
 		}
 		return any;
@@ -358,6 +381,7 @@ struct LegBank : Pool {
 	bool enqueue_at(uint64_t now) {
 		mi_ctx *ctx = hub->ctx;
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm; // legs of the conference slots ever handed out
+		mark(0);
 		if (outstanding) sync_stream(); // (rare: a second enqueue in one flush) the staging arrays are about to be rewritten
 		staged_since = false;
 		if (root) emitted();
@@ -398,6 +422,7 @@ struct LegBank : Pool {
 			leg->vol_rem %= ns;
 		}
 		drops.clear();
+		mark(1);
 		if (plain) return enqueue_plain(any_ref, any_refx, any_inj, rounds);
 		bool ticked = false;
 		for (int c = 0; c < capacity; ++c) { // a mixer ticks once per ticker time, whoever enqueues
@@ -410,10 +435,13 @@ struct LegBank : Pool {
 		}
 		mixed |= ticked;
 		if (failed) return false;
+		mark(2);
 		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
+		mark(3);
 		if (ticked) {
 			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, (size_t)capacity));
 			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, d_mix, MI_VOLMIX_DRY_SKIPS, d_run));
+			mark(4);
 			++launches;
 			for (const auto &dk : drops) // chunks the channels' flow control discards: metered (MSVolume saw them), never mixed
 				for (int k = 0; k < dk.second; ++k) {
@@ -421,9 +449,17 @@ struct LegBank : Pool {
 					++launches;
 				}
 			if (!cur) cur = free_slab();
+			mark(5);
 			MI_MUST(mi_copy_d2h(ctx, cur ? (void *)cur->payload() : (void *)h_copy, d_mix, UL * ns * 2));
 			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
+			mark(6);
 			any = true;
+			if (trace_ms > 0 && (double)(tr[6] - tr[0]) * 1e-6 > trace_ms)
+				fprintf(stderr, "mi355x leg bank %p: enqueue took %.2f ms: controls + framing %.2f, conference ticks %.2f, far end + cancellers %.2f (%d rounds), run mask + volmix %.2f, slab %.2f, downloads %.2f\n",
+				        (void *)this, (double)(tr[6] - tr[0]) * 1e-6, (double)(tr[1] - tr[0]) * 1e-6, (double)(tr[2] - tr[1]) * 1e-6, (double)(tr[3] - tr[2]) * 1e-6, rounds,
+				        (double)(tr[4] - tr[3]) * 1e-6, (double)(tr[5] - tr[4]) * 1e-6, (double)(tr[6] - tr[5]) * 1e-6);
+			if (trace_ms > 0 && (double)(tr[6] - tr[0]) * 1e-6 > trace_ms)
+				for (size_t i = 1; i < trc.size(); ++i) fprintf(stderr, "    %-22s %.3f ms\n", trc[i].first, (double)(trc[i].second - trc[i - 1].second) * 1e-6);
 		}
 		if (check_levels && any) {
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));

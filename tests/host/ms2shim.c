@@ -481,6 +481,10 @@ typedef struct TickerImpl {
 	int nfilters, cap;
 	Task *tasks;
 	uint64_t tasks_ns, step_ns; /* the last step, by phase */
+	/* MS2SHIM_PROFILE=1: the last step's process() calls by filter id (time summed, the longest single call) */
+	int prof_ids[16];
+	uint64_t prof_ns[16], max_call_ns;
+	int max_call_id;
 } TickerImpl;
 
 static void ti_add(TickerImpl *ti, MSFilter *f) {
@@ -598,7 +602,36 @@ static int can_process(MSFilter *f, uint32_t tick) { /* msticker.c:230-242 */
 	return 1;
 }
 
+static uint64_t now_ns(void);
+static int g_profile = -1;
+static void call_process_profiled(MSFilter *f) {
+	TickerImpl *ti = (TickerImpl *)f->ticker->impl;
+	const uint64_t t0 = now_ns();
+	f->desc->process(f);
+	const uint64_t d = now_ns() - t0;
+	const int id = (int)f->desc->id;
+	for (int i = 0; i < 16; ++i) {
+		if (ti->prof_ids[i] == id || ti->prof_ids[i] == 0) {
+			ti->prof_ids[i] = id;
+			ti->prof_ns[i] += d;
+			break;
+		}
+	}
+	if (d > ti->max_call_ns) ti->max_call_ns = d, ti->max_call_id = id;
+}
+
 static void call_process(MSFilter *f) { /* msticker.c:244-259 */
+	if (g_profile > 0) {
+		if (f->desc->ninputs == 0 || (f->desc->flags & MS_FILTER_IS_PUMP)) {
+			call_process_profiled(f);
+		} else {
+			while (inputs_have_data(f)) {
+				call_process_profiled(f);
+				if (f->postponed_task) break;
+			}
+		}
+		return;
+	}
 	if (f->desc->ninputs == 0 || (f->desc->flags & MS_FILTER_IS_PUMP)) {
 		f->desc->process(f);
 	} else {
@@ -631,6 +664,11 @@ void ms_ticker_step(MSTicker *t) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	MSFilter *unsched[256];
 	int nunsched = 0;
+	if (g_profile < 0) g_profile = getenv("MS2SHIM_PROFILE") ? 1 : 0;
+	if (g_profile > 0) {
+		memset(ti->prof_ns, 0, sizeof(ti->prof_ns));
+		ti->max_call_ns = 0, ti->max_call_id = 0;
+	}
 	const uint64_t t0 = now_ns();
 	t->ticks++;
 	/* run_tasks msticker.c:301-312: postponed tasks run before the graphs */
@@ -656,6 +694,16 @@ void ms2shim_ticker_last_step(MSTicker *t, uint64_t *tasks_ns, uint64_t *step_ns
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	if (tasks_ns) *tasks_ns = ti->tasks_ns;
 	if (step_ns) *step_ns = ti->step_ns;
+}
+
+/* MS2SHIM_PROFILE=1: the last step's process() time by filter id (up to 16 ids; returns how many) and its longest single call */
+int ms2shim_ticker_profile(MSTicker *t, int *ids, uint64_t *ns, int cap, int *max_id, uint64_t *max_ns) {
+	TickerImpl *ti = (TickerImpl *)t->impl;
+	int n = 0;
+	for (int i = 0; i < 16 && n < cap && ti->prof_ids[i]; ++i, ++n) ids[n] = ti->prof_ids[i], ns[n] = ti->prof_ns[i];
+	if (max_id) *max_id = ti->max_call_id;
+	if (max_ns) *max_ns = ti->max_call_ns;
+	return n;
 }
 
 /* -------------------------------------------------- test source / sink filters

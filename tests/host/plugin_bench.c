@@ -14,6 +14,7 @@
  *
  *   plugin_bench <plugin.so> <legs> <tickers> <ticks> <warmup> [members=32]
  */
+#define _GNU_SOURCE /* RUSAGE_THREAD */
 #include "../../include/ms2_plugin_abi.h"
 
 #include <dlfcn.h>
@@ -21,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -39,6 +41,7 @@ MSFilter *ms2shim_new_sink(MSFactory *f);
 void ms2shim_sink_set_discard(MSFilter *f, int on);
 void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase);
 void ms2shim_ticker_last_step(MSTicker *t, uint64_t *tasks_ns, uint64_t *step_ns);
+int ms2shim_ticker_profile(MSTicker *t, int *ids, uint64_t *ns, int cap, int *max_id, uint64_t *max_ns);
 size_t ms2shim_sink_size(MSFilter *sink);
 int ms2shim_sink_blocks(MSFilter *sink);
 
@@ -50,16 +53,27 @@ typedef struct {
 	MSFilter **mixers;
 	MSFilter *probe_out; /* one mixer output sink: did audio arrive? */
 	int nconf, index;
-	double *step_ms, *task_ms;
+	double *step_ms, *task_ms, *cpu_ms; /* per tick: wall time of the step, of its postponed tasks, CPU time of the thread */
+	double slowest_ms;
+	int slowest_tick, prof_n, prof_ids[16], max_id;
+	uint64_t prof_ns[16], max_ns;
+	int *nvcsw, *nivcsw, *minflt;        /* per tick: voluntary / involuntary context switches, minor page faults of the thread */
 } TickerJob;
 
 static MSFactory *g_fac;
 static int g_members = 32, g_ticks, g_warmup, g_tickers;
 static pthread_barrier_t g_bar;
 
+static int g_profile;
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+static double thread_cpu_ms(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
 	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
 
@@ -110,12 +124,26 @@ static void *run(void *arg) {
 	}
 	for (int t = 0; t < g_ticks; ++t) {
 		pthread_barrier_wait(&g_bar); /* all tickers fire together, as wall-clock tickers do */
+		struct rusage ru0;
+		getrusage(RUSAGE_THREAD, &ru0);
+		const double c0 = thread_cpu_ms();
 		const double t0 = now_ms();
 		ms_ticker_step(j->ticker);
 		j->step_ms[t] = now_ms() - t0;
+		struct rusage ru1;
+		getrusage(RUSAGE_THREAD, &ru1);
+		j->cpu_ms[t] = thread_cpu_ms() - c0;
+		j->nvcsw[t] = (int)(ru1.ru_nvcsw - ru0.ru_nvcsw);
+		j->nivcsw[t] = (int)(ru1.ru_nivcsw - ru0.ru_nivcsw);
+		j->minflt[t] = (int)(ru1.ru_minflt - ru0.ru_minflt);
 		uint64_t tasks_ns = 0;
 		ms2shim_ticker_last_step(j->ticker, &tasks_ns, NULL);
 		j->task_ms[t] = (double)tasks_ns * 1e-6;
+		if (g_profile && j->step_ms[t] > j->slowest_ms) { /* MS2SHIM_PROFILE=1: where this thread's slowest step went, by filter id */
+			j->slowest_ms = j->step_ms[t];
+			j->slowest_tick = t;
+			j->prof_n = ms2shim_ticker_profile(j->ticker, j->prof_ids, j->prof_ns, 16, &j->max_id, &j->max_ns);
+		}
 	}
 	pthread_barrier_wait(&g_bar);
 	return NULL;
@@ -129,6 +157,7 @@ int main(int argc, char **argv) {
 		fprintf(stderr, "usage: plugin_bench <plugin.so> <legs> <tickers> <ticks> <warmup> [members]\n");
 		return 2;
 	}
+	g_profile = getenv("MS2SHIM_PROFILE") != NULL;
 	const char *plugin = argv[1];
 	int legs = atoi(argv[2]);
 	g_tickers = atoi(argv[3]);
@@ -175,6 +204,10 @@ int main(int argc, char **argv) {
 		jobs[i].nconf = nconf;
 		jobs[i].step_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		jobs[i].task_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
+		jobs[i].cpu_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
+		jobs[i].nvcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
+		jobs[i].nivcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
+		jobs[i].minflt = (int *)calloc((size_t)g_ticks, sizeof(int));
 		build(&jobs[i]);
 	}
 	const double build_ms = now_ms() - t_build0;
@@ -229,6 +262,39 @@ int main(int argc, char **argv) {
 		if (backlog > max_backlog) max_backlog = backlog;
 		ref_late_events += backlog > 50.0;
 	}
+	/* the ticks that took longest: was the slowest thread running (cpu_ms ~ ms), blocked (voluntary switches) or pushed off its core? */
+	char slow[1024];
+	int so = 0;
+	{
+		double *copy = (double *)malloc(sizeof(double) * (size_t)g_ticks);
+		memcpy(copy, tick, sizeof(double) * (size_t)g_ticks);
+		for (int n = 0; n < 5 && n < g_ticks; ++n) {
+			int bt = 0, bi = 0;
+			for (int t = 0; t < g_ticks; ++t)
+				if (copy[t] > copy[bt]) bt = t;
+			for (int i = 0; i < g_tickers; ++i)
+				if (jobs[i].step_ms[bt] > jobs[bi].step_ms[bt]) bi = i;
+			int others = 0; /* how many OTHER tickers were also over 8 ms in that tick: one thread's mishap or everybody's */
+			for (int i = 0; i < g_tickers; ++i) others += (i != bi && jobs[i].step_ms[bt] > 8.0);
+			so += snprintf(slow + so, sizeof(slow) - (size_t)so, "%s{\"index\": %d, \"ticker\": %d, \"ms\": %.2f, \"cpu_ms\": %.2f, \"flush_ms\": %.2f, \"nvcsw\": %d, \"nivcsw\": %d, \"minflt\": %d, \"others_over_8ms\": %d}",
+			               n ? ", " : "", bt, bi, jobs[bi].step_ms[bt], jobs[bi].cpu_ms[bt], jobs[bi].task_ms[bt], jobs[bi].nvcsw[bt], jobs[bi].nivcsw[bt], jobs[bi].minflt[bt], others);
+			copy[bt] = 0;
+		}
+		free(copy);
+	}
+	double sum_cpu = 0;
+	long sum_flt = 0, sum_nv = 0, sum_niv = 0;
+	for (int i = 0; i < g_tickers; ++i)
+		for (int t = 0; t < g_ticks; ++t) sum_cpu += jobs[i].cpu_ms[t], sum_flt += jobs[i].minflt[t], sum_nv += jobs[i].nvcsw[t], sum_niv += jobs[i].nivcsw[t];
+	if (g_profile) { /* stderr: the slowest step of the slowest thread, by filter id */
+		int bi = 0;
+		for (int i = 0; i < g_tickers; ++i)
+			if (jobs[i].slowest_ms > jobs[bi].slowest_ms) bi = i;
+		fprintf(stderr, "plugin_bench profile: ticker %d tick %d took %.2f ms; longest single process(): id %d %.3f ms; by id:", bi, jobs[bi].slowest_tick,
+		        jobs[bi].slowest_ms, jobs[bi].max_id, (double)jobs[bi].max_ns * 1e-6);
+		for (int k = 0; k < jobs[bi].prof_n; ++k) fprintf(stderr, " %d=%.3fms", jobs[bi].prof_ids[k], (double)jobs[bi].prof_ns[k] * 1e-6);
+		fprintf(stderr, "\n");
+	}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);
 	printf("{\"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
 	       "\"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"late\": %d, \"wall_ms_per_tick\": %.4f, "
@@ -236,13 +302,15 @@ int main(int argc, char **argv) {
 	       "\"fused_conferences\": %d, \"fused_legs\": %d, \"launches_per_tick\": %.2f, \"launches_per_tick_and_ticker\": %.2f, "
 	       "\"flush_rounds_per_tick_and_ticker\": %.2f, \"late_events\": %llu, \"probe_sink_blocks\": %d, \"probe_sink_bytes\": %zu, "
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
-	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d}\n",
+	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
+	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s]}\n",
 	       legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
 	       worst_t, worst_i, jobs[worst_i].step_ms[worst_t], jobs[worst_i].task_ms[worst_t], pct(sorted, g_ticks, 0.999), wall_ms / g_ticks,
-	       max_backlog, ref_late_events);
+	       max_backlog, ref_late_events, sum_cpu / ((double)g_ticks * g_tickers), (double)sum_flt / ((double)g_ticks * g_tickers),
+	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow);
 	fflush(stdout);
 	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
 	_exit(0);
