@@ -386,7 +386,7 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const VolArgs &a = va.v;
 	uint2 *rows = reinterpret_cast<uint2 *>(smem); // [mm][row_w] four samples per word
-	__shared__ int s_pk[VM_MAXM], s_dc[VM_MAXM], s_head[VM_MAXM];
+	__shared__ int s_pk[VM_MAXM], s_dc[VM_MAXM];
 	__shared__ int4 s_par[VM_MAXM]; // what (C + D) needs of a member, one 16-byte broadcast read: (flags | mode << 8, Q12 gain, DC offset, pin gain)
 	const int t = threadIdx.x, c = blockIdx.x, mm = va.mm, ns = a.nsamples, nw = ns >> 2, ng = ns >> 3;
 	if (va.run && !va.run[c]) return;
@@ -397,6 +397,8 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	float peer_energy = 0;
 	unsigned mflag = 0; // the member's mixer controls
 	int mgain_bits = 0;
+	int2 qpos = make_int2(0, 0); // its queue (head, level) before this tick
+	float2 win = make_float2(0, 0);
 	if (t < mm) {
 		const int s = s0 + t;
 		p = a.params[s];
@@ -404,18 +406,14 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
 		mflag = va.flags[c * mm + t];
 		mgain_bits = __float_as_int(va.gain[c * mm + t]);
-		const int2 q = a.src.pos[s]; // ms_bufferizer_read, all-or-nothing (msqueue.c:83); a leg that runs dry hears and meters silence
-		int head = -1;
-		if (q.y >= ns) {
-			head = q.x;
-			a.src.pos[s] = make_int2((q.x + ns) % a.src.cap, q.y - ns);
-		}
-		s_head[t] = head;
+		win = a.win[s];
+		qpos = a.src.pos[s]; // ms_bufferizer_read, all-or-nothing (msqueue.c:83); a leg that runs dry hears and meters silence
 	}
-	__syncthreads();
 
 	// ---- (A) eight lanes per member (lane q takes the 16-byte groups q, q + 8, ..: 128 contiguous bytes per member and
-	// round), peak and DC sum in packed 16-bit arithmetic -- the peak as max(max x, -min x), exact for -32768 too --,
+	// round), every lane reading its member's queue position itself (the pop is written back in (B), behind the barrier)
+	// and asking for all of its groups at once -- up to eight loads in flight per lane instead of one round trip per
+	// group --; peak and DC sum in packed 16-bit arithmetic -- the peak as max(max x, -min x), exact for -32768 too --,
 	// reduced over the eight lanes in registers (DPP): one plain LDS word per member and quantity, no LDS atomics
 	// (two per group, most of a wave on ONE address, were a fifth of the kernel)
 	for (int mb = 0; mb < mm; mb += VM_THREADS / 8) {
@@ -423,36 +421,50 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 		const bool valid = m < mm;
 		s16x2 pmax = {0, 0}, pmin = {0, 0};
 		int dc = 0;
+		auto take = [&](int g, uint4 v) { // group g of member m: into its row, into the statistics
+			rows[m * va.row_w + 2 * g] = make_uint2(v.x, v.y);
+			rows[m * va.row_w + 2 * g + 1] = make_uint2(v.z, v.w);
+			const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const s16x2 x = __builtin_bit_cast(s16x2, w[k]);
+				pmax = __builtin_elementwise_max(pmax, x);
+				pmin = __builtin_elementwise_min(pmin, x);
+				dc = __builtin_amdgcn_sdot2(x, (s16x2){1, 1}, dc, false);
+			}
+		};
 		if (valid) {
-			const int h = s_head[m];
+			const int2 qp = a.src.pos[s0 + m];
+			const int h = qp.y >= ns ? qp.x : -1;
 			const int16_t *ring = a.src.ring + (size_t)(s0 + m) * a.src.cap;
-			for (int g = q; g < ng; g += 8) {
-				uint4 v = make_uint4(0, 0, 0, 0);
-				if (h >= 0) {
+			if (h < 0 || (h & 7) == 0) {
+				for (int g = q; g < ng; g += 64) { // eight groups per lane and round: one round at 480 samples
+					uint4 v[8];
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						v[i] = make_uint4(0, 0, 0, 0);
+						if (h >= 0 && g + 8 * i < ng) {
+							unsigned at = (unsigned)h + 8u * (unsigned)(g + 8 * i);
+							if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
+							v[i] = *reinterpret_cast<const uint4 *>(ring + at);
+						}
+					}
+#pragma unroll
+					for (int i = 0; i < 8; ++i)
+						if (g + 8 * i < ng) take(g + 8 * i, v[i]);
+				}
+			} else { // a head some other reader left off the 16-byte grid: sample by sample, wrap-aware
+				for (int g = q; g < ng; g += 8) {
 					unsigned at = (unsigned)h + 8u * (unsigned)g;
 					if (at >= (unsigned)a.src.cap) at -= (unsigned)a.src.cap;
-					if ((h & 7) == 0) {
-						v = *reinterpret_cast<const uint4 *>(ring + at);
-					} else { // a head some other reader left off the 16-byte grid: sample by sample, wrap-aware
-						unsigned w[4] = {0, 0, 0, 0};
+					unsigned w[4] = {0, 0, 0, 0};
 #pragma unroll
-						for (int k = 0; k < 8; ++k) {
-							unsigned qq = at + (unsigned)k;
-							if (qq >= (unsigned)a.src.cap) qq -= (unsigned)a.src.cap;
-							w[k >> 1] |= (unsigned)(uint16_t)ring[qq] << (16 * (k & 1));
-						}
-						v = make_uint4(w[0], w[1], w[2], w[3]);
+					for (int k = 0; k < 8; ++k) {
+						unsigned qq = at + (unsigned)k;
+						if (qq >= (unsigned)a.src.cap) qq -= (unsigned)a.src.cap;
+						w[k >> 1] |= (unsigned)(uint16_t)ring[qq] << (16 * (k & 1));
 					}
-				}
-				rows[m * va.row_w + 2 * g] = make_uint2(v.x, v.y);
-				rows[m * va.row_w + 2 * g + 1] = make_uint2(v.z, v.w);
-				const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					const s16x2 x = __builtin_bit_cast(s16x2, w[k]);
-					pmax = __builtin_elementwise_max(pmax, x);
-					pmin = __builtin_elementwise_min(pmin, x);
-					dc = __builtin_amdgcn_sdot2(x, (s16x2){1, 1}, dc, false);
+					take(g, make_uint4(w[0], w[1], w[2], w[3]));
 				}
 			}
 		}
@@ -479,25 +491,38 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	if (t < mm) {
 		const uint2 *r = rows + t * va.row_w;
 		float acc = 0;
-		uint2 cur = r[0];
-		for (int i = 0; i < nw; ++i) { // same additions in the same order as update_energy's loop
-			const uint2 nx = r[min(i + 1, nw - 1)];
-			const int x0 = (int)(short)(cur.x & 0xffffu), x1 = (int)(short)(cur.x >> 16);
-			const int x2 = (int)(short)(cur.y & 0xffffu), x3 = (int)(short)(cur.y >> 16);
-			acc += (float)(x0 * x0);
-			acc += (float)(x1 * x1);
-			acc += (float)(x2 * x2);
-			acc += (float)(x3 * x3);
-			cur = nx;
+		// same additions in the same order as update_energy's loop; a sample's square as the product of two floats -- the
+		// exact integer below 2^31 rounded once, what the conversion of the integer product gives -- eight samples a round
+		auto sq = [&](unsigned w) {
+			const float lo = (float)(int)(short)(w & 0xffffu), hi = (float)(int)(short)(w >> 16);
+			acc += lo * lo;
+			acc += hi * hi;
+		};
+		// The next round's four words are asked for BEFORE this round's 16 dependent operations and waited for behind them: by
+		// hand, because the compiler sinks the read to its first use and then waits at once -- an LDS round trip per round, a
+		// third of this phase, and this phase is the longest stretch of a conference's workgroup (one wave busy, three waiting).
+		typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+		const unsigned r_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)r;
+		u32x4 cur, nxt;
+		asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cur) : "v"(r_lds));
+		for (int i = 0; i < nw; i += 2) {
+			const int in = min(i + 2, nw - 2);
+			asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=&v"(nxt) : "v"(r_lds + 8u * (unsigned)in));
+			__builtin_amdgcn_sched_barrier(0);
+			sq(cur.x), sq(cur.y), sq(cur.z), sq(cur.w);
+			__builtin_amdgcn_sched_barrier(0);
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt));
+			cur = nxt;
 		}
 		const int s = s0 + t;
-		if (va.dry_skips && s_head[t] < 0) {
+		const bool dry = qpos.y < ns;
+		if (!dry) a.src.pos[s] = make_int2((qpos.x + ns) % a.src.cap, qpos.y - ns); // (every lane of (A) has read the old position: the barrier)
+		if (va.dry_skips && dry) {
 			// the plugin's chain: volume_process (msvolume.c:480-486) finds no whole 10 ms chunk in its bufferizer and does
 			// nothing -- no meter update, no gain ramp --, the mixer reads zeros for the pin (audiomixer.c:88)
 			s_par[t] = make_int4((int)mflag, 4096, 0, mgain_bits);
 			a.energy[*a.parity ^ 1][s] = st.energy;
 		} else {
-			float2 win = a.win[s];
 			const VolCtl o = volume_control(p, st, peer_energy, acc, ns, s_pk[t], s_dc[t], a.sample_rate, win);
 			s_par[t] = make_int4((int)mflag | (o.mode << 8), o.intgain, o.dcoff, mgain_bits);
 			a.state[s] = st;

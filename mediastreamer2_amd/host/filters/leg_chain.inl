@@ -455,8 +455,8 @@ struct LegBank : Pool {
 			mark(6);
 			any = true;
 			if (trace_ms > 0 && (double)(tr[6] - tr[0]) * 1e-6 > trace_ms)
-				fprintf(stderr, "mi355x leg bank %p: enqueue took %.2f ms: controls + framing %.2f, conference ticks %.2f, far end + cancellers %.2f (%d rounds), run mask + volmix %.2f, slab %.2f, downloads %.2f\n",
-				        (void *)this, (double)(tr[6] - tr[0]) * 1e-6, (double)(tr[1] - tr[0]) * 1e-6, (double)(tr[2] - tr[1]) * 1e-6, (double)(tr[3] - tr[2]) * 1e-6, rounds,
+				fprintf(stderr, "mi355x leg bank %p tick %u (%zu slabs): enqueue took %.2f ms: controls + framing %.2f, conference ticks %.2f, far end + cancellers %.2f (%d rounds), run mask + volmix %.2f, slab %.2f, downloads %.2f\n",
+				        (void *)this, hub->ticker ? (unsigned)hub->ticker->ticks : 0u, slabs.size(), (double)(tr[6] - tr[0]) * 1e-6, (double)(tr[1] - tr[0]) * 1e-6, (double)(tr[2] - tr[1]) * 1e-6, (double)(tr[3] - tr[2]) * 1e-6, rounds,
 				        (double)(tr[4] - tr[3]) * 1e-6, (double)(tr[5] - tr[4]) * 1e-6, (double)(tr[6] - tr[5]) * 1e-6);
 			if (trace_ms > 0 && (double)(tr[6] - tr[0]) * 1e-6 > trace_ms)
 				for (size_t i = 1; i < trc.size(); ++i) fprintf(stderr, "    %-22s %.3f ms\n", trc[i].first, (double)(trc[i].second - trc[i - 1].second) * 1e-6);
@@ -590,6 +590,8 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 // out NOW, at the end of the graph walk, instead of at the start of the next tick -- the device works through the idle
 // part of the interval and the next tick's flush finds the results waiting.  Same results, same one tick of latency; the
 // launches just leave the tick's critical path.  (A tick in which some mixer did not run falls back to the flush.)
+double leg_trace_ms(LegBank *b) { return b->trace_ms; }
+uint64_t leg_trace_now() { return LegBank::trace_now(); }
 void leg_conf_walked(LegBank *b, int c) {
 	if (b->no_early || b->failed || b->early || !b->hub->ticker) return;
 	const uint32_t tick = b->hub->ticker->ticks;

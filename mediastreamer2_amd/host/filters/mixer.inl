@@ -6,6 +6,8 @@
 constexpr int MIXER_MAX_CHANNELS = MI_MIXER_MAX_CHANNELS; // audiomixer.c:29
 Pool *leg_pool_of(LegBank *b);                            // leg_chain.inl
 void leg_conf_walked(LegBank *b, int c);
+double leg_trace_ms(LegBank *b);
+uint64_t leg_trace_now();
 constexpr uint64_t BYPASS_MODE_TIMEOUT = 1000;            // audiomixer.c:31
 
 struct MixerPool : Pool {
@@ -311,9 +313,12 @@ void MixerPool::emit(MSFilter *f, int slot) {
 
 void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
+	const double trace_ms = s->fbank ? leg_trace_ms(s->fbank) : 0.0; // MSMI355X_TRACE_SLOW_MS
+	const uint64_t tr0 = trace_ms > 0 ? leg_trace_now() : 0;
 	// lock order everywhere: the hub first, the filter's own lock inside it (the flush task pumps this filter with the hub held)
 	HubLock lk(f, s->fbank ? leg_pool_of(s->fbank) : static_cast<Pool *>(s->pool));
 	ms_filter_lock(f);
+	const uint64_t tr1 = trace_ms > 0 ? leg_trace_now() : 0;
 	if (s->unfuse_wanted && s->fbank) conf_unfuse(f, true); // a member stopped qualifying: back to the facades' own banks
 	if (s->fuse_state == 0 && !s->fbank) conf_try_fuse(f); // (normally a leg's head got here first)
 	if (s->fbank) { // fused: the conference ticks inside the hub's flush; a pump keeps that flush coming every tick
@@ -324,8 +329,15 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 		}
 		mixer_release_held(f, s, true);
 		request_flush(f);
+		const uint64_t tr2 = trace_ms > 0 ? leg_trace_now() : 0;
 		leg_conf_walked(s->fbank, s->fconf); // the last conference of the bank to be walked sends the bank's work to the device right away
 		ms_filter_unlock(f);
+		if (trace_ms > 0) {
+			const uint64_t tr3 = leg_trace_now();
+			if ((double)(tr3 - tr0) * 1e-6 > trace_ms)
+				fprintf(stderr, "mi355x mixer %p tick %u: process() took %.2f ms: locks %.2f, census + flush request %.2f, bank walked / enqueue %.2f\n", (void *)f,
+				        (unsigned)f->ticker->ticks, (double)(tr3 - tr0) * 1e-6, (double)(tr1 - tr0) * 1e-6, (double)(tr2 - tr1) * 1e-6, (double)(tr3 - tr2) * 1e-6);
+		}
 		return;
 	}
 	if (already_ran_this_tick(f)) { // the flush task pumped this mixer right behind the facades that feed it
