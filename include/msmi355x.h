@@ -91,6 +91,10 @@ void *mi_host_alloc(mi_ctx *ctx, size_t bytes);  /* pinned host memory */
 void mi_host_free(mi_ctx *ctx, void *h_ptr);    /* ctx may be NULL (a buffer that outlived its context: blocks still held downstream) */
 int mi_copy_h2d(mi_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on ctx stream */
 int mi_copy_d2h(mi_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* async on ctx stream */
+/* the same for host memory from mi_host_alloc, as a kernel of this library on the context's stream (a launch, never a call
+ * into the runtime's copy path: what the plugin's tick path uses).  MSMI355X_COPY=hip: hipMemcpyAsync again. */
+int mi_copy_h2d_pinned(mi_ctx *ctx, void *d_dst, const void *h_pinned_src, size_t bytes);
+int mi_copy_d2h_pinned(mi_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes);
 int mi_memset(mi_ctx *ctx, void *d_dst, int value, size_t bytes);
 
 /* hipGraph capture of everything the mi_* calls enqueue on the context stream

@@ -24,7 +24,7 @@ class MiError(RuntimeError):
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count",
     "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
-    "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_memset",
+    "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_pinned", "mi_copy_d2h_pinned", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
     "mi_timer_start", "mi_timer_stop",
     "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_out_capacity",
@@ -119,6 +119,8 @@ def load():
     L.mi_host_free.restype = None
     L.mi_copy_h2d.argtypes = [vp, vp, vp, sz]
     L.mi_copy_d2h.argtypes = [vp, vp, vp, sz]
+    L.mi_copy_h2d_pinned.argtypes = [vp, vp, vp, sz]
+    L.mi_copy_d2h_pinned.argtypes = [vp, vp, vp, sz]
     L.mi_memset.argtypes = [vp, vp, i32, sz]
     L.mi_ctx_capture_begin.argtypes = [vp]
     L.mi_ctx_capture_end.argtypes = [vp, pp]

@@ -32,6 +32,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #pragma clang fp contract(off)
@@ -243,6 +244,7 @@ __device__ __forceinline__ void band_sum3(const AecTables &t, int b, const float
 #include "resample_tile.hpp"
 #include "aec_wave.hpp"
 #include "aec_tick.hpp"
+#include "aec_group.hpp"
 
 // ---- debug: forward/inverse transform of one 2F-point frame per block (parity of the FFT itself)
 template <int F>
@@ -271,6 +273,41 @@ __global__ __launch_bounds__(64) void fft_debug_kernel(const float *in, float *o
 		float2 r[K];
 		load_bins<K>(reinterpret_cast<const float2 *>(src) + e0, r);
 		w_rfft_inverse<F>(L, t, r);
+		float lo[K], hi[K];
+		load_vec<K>(w_time(L) + e0, lo);
+		load_vec<K>(w_time(L) + F + e0, hi);
+		store_vec<K>(dst + e0, lo);
+		store_vec<K>(dst + F + e0, hi);
+	}
+}
+
+// the same through the transforms of the several-legs-per-wavefront form (aec_group.hpp): frame blockIdx.x * LPW + leg
+template <int F>
+__global__ __launch_bounds__(64) void fft_debug_group_kernel(const float *in, float *out, int inverse, int nframes, AecTables t) {
+	using GP = Grp<F>;
+	constexpr int K = GP::K, LPW = GP::LPW;
+	__shared__ GLds<F> LW;
+	const int lane = GP::lane(), e0 = lane * K;
+	auto &L = LW.leg[GP::index()];
+	for (int i = threadIdx.x; i < F; i += 64) LW.tw[i] = t.tw[i], LW.super[i] = t.super[i], LW.perm[i] = t.perm[i];
+	WSYNC();
+	int fr = (int)blockIdx.x * LPW + GP::index();
+	if (fr >= nframes) fr = nframes - 1; // (every lane takes part in the transforms; the spare legs redo the last frame)
+	const float *src = in + (size_t)fr * 2 * F;
+	float *dst = out + (size_t)fr * 2 * F;
+	if (!inverse) {
+		float lo[K], hi[K];
+		load_vec<K>(src + e0, lo);
+		load_vec<K>(src + F + e0, hi);
+		store_vec<K>(L.tbuf + e0, lo);
+		store_vec<K>(L.tbuf + F + e0, hi);
+		float2 r[K];
+		g_rfft_forward<F>(L, LW, r);
+		store_bins<K>(reinterpret_cast<float2 *>(dst) + e0, r);
+	} else {
+		float2 r[K];
+		load_bins<K>(reinterpret_cast<const float2 *>(src) + e0, r);
+		g_rfft_inverse<F>(L, LW, r);
 		float lo[K], hi[K];
 		load_vec<K>(w_time(L) + e0, lo);
 		load_vec<K>(w_time(L) + F + e0, hi);
@@ -596,6 +633,8 @@ size_t mi_aec_state_bytes(const mi_aec *a) {
 	       sizeof(AecScalars);
 }
 
+static std::atomic<int> g_group_form{-1}; // -1: ask the environment on first use (MSMI355X_AEC_GROUP); mi_debug_aec_group_form sets it
+
 struct AecFifoCall {
 	ResamplerView rs; // rs.ok: the microphone block is up-sampled inside the launch from rs_in
 	const int16_t *rs_in = nullptr;
@@ -676,6 +715,23 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 	// the FIFO entry: one workgroup per list SLOT (8 classes x cap8; the few empty slots leave at once), else one per stream
 	const dim3 grid(fifo ? 8 * a->cap8 : a->nstreams);
 	const int mode = !fifo ? TICK_ROWS : (fifo->rs.ok ? TICK_FIFO_RS : TICK_FIFO);
+	// The small frame sizes handed in as rows: several legs per wavefront, one launch per frame of the tick (aec_group.hpp).
+	// MSMI355X_AEC_GROUP=0: the one-leg-per-wavefront tick form for them too (A/B; the state in HBM is the same).
+	if (g_group_form.load(std::memory_order_relaxed) < 0) {
+		const char *e = getenv("MSMI355X_AEC_GROUP");
+		g_group_form.store(e && e[0] == '0' ? 0 : 1, std::memory_order_relaxed);
+	}
+	// (its lanes take their four samples of a row as one 8-byte access: rows that start off that grid stay on the tick form)
+	const bool rows8 = !fifo && (stride & 3) == 0 &&
+	                   ((reinterpret_cast<uintptr_t>(d_mic) | reinterpret_cast<uintptr_t>(d_ref) | reinterpret_cast<uintptr_t>(d_out)) & 7) == 0;
+	if (rows8 && a->F != 256 && g_group_form.load(std::memory_order_relaxed) > 0) {
+		for (int frame = 0; frame < max_frames; ++frame) {
+			if (a->F == 128) hipLaunchKernelGGL(aec_group_kernel<128>, dim3((a->nstreams + 1) / 2), dim3(64), 0, a->ctx->stream, g, frame);
+			else hipLaunchKernelGGL(aec_group_kernel<64>, dim3((a->nstreams + 3) / 4), dim3(64), 0, a->ctx->stream, g, frame);
+			MI_LAUNCH_CHECK();
+		}
+		return MI_OK;
+	}
 #define MI_TICK_LAUNCH(FR)                                                                                          \
 	do {                                                                                                            \
 		if (mode == TICK_FIFO_RS) hipLaunchKernelGGL((aec_tick_kernel<FR, TICK_FIFO_RS>), grid, dim3(64), 0, a->ctx->stream, g); \
@@ -1008,6 +1064,13 @@ int mi_aec_copy_state(mi_aec *dst, int dst_first, const mi_aec *src, int src_fir
 int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int inverse) {
 	MI_CHECK_ARG(a && d_in && d_out && nframes > 0);
 	if (a->ctx->activate() != MI_OK) return MI_ENODEV;
+	if ((inverse & 2) && a->F != 256) { // bit 1: the several-legs-per-wavefront transforms
+		if (a->F == 64) hipLaunchKernelGGL(fft_debug_group_kernel<64>, dim3((nframes + 3) / 4), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse & 1, nframes, a->t);
+		else hipLaunchKernelGGL(fft_debug_group_kernel<128>, dim3((nframes + 1) / 2), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse & 1, nframes, a->t);
+		MI_LAUNCH_CHECK();
+		return MI_OK;
+	}
+	inverse &= 1;
 	if (a->F == 64)
 		hipLaunchKernelGGL(fft_debug_kernel<64>, dim3(nframes), dim3(64), 0, a->ctx->stream, d_in, d_out, inverse, a->t);
 	else if (a->F == 256)
@@ -1017,5 +1080,9 @@ int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int in
 	MI_LAUNCH_CHECK();
 	return MI_OK;
 }
+
+// debug entry: 1 / 0 = the small frame sizes handed in as rows run several legs per wavefront (aec_group.hpp) / one leg per
+// wavefront (aec_tick.hpp); the state in HBM is the same, a batch may change between launches
+void mi_debug_aec_group_form(int on) { g_group_form.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 } // extern "C"

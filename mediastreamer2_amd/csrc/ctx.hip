@@ -1,6 +1,8 @@
 // ctx.hip -- context, memory and timing entry points of the C ABI.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace mi {
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
@@ -27,6 +29,40 @@ int mi_ctx::ensure_scratch(int slot, size_t bytes, void **out) {
 	*out = scratch[slot];
 	return MI_OK;
 }
+
+// ---- copies between PINNED host memory (mi_host_alloc: mapped into the device's address space) and device memory as a
+// kernel of this library on the context's stream, not hipMemcpyAsync.  Why: the plugin's tick path is a handful of small
+// copies around its launches, and now and then ONE hipMemcpyAsync of a few KB keeps its caller on the CPU for ~10 ms inside
+// the runtime (an ioctl under the HSA copy path in one thread, sched_yield loops in the threads beside it; tests/host/
+// plugin_bench PLUGIN_BENCH_STACKS, profiles/r04_plugin_stacks.txt) -- longer than the tick it belongs to.  A kernel launch is
+// one AQL packet: nothing to allocate, map or wait for on the way.  MSMI355X_COPY=hip puts hipMemcpyAsync back (A/B).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void copy_kernel(T *__restrict__ dst, const T *__restrict__ src, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+bool copy_by_kernel() {
+	static const bool v = [] {
+		const char *e = getenv("MSMI355X_COPY");
+		return !(e && strcmp(e, "hip") == 0);
+	}();
+	return v;
+}
+int copy_mapped(mi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyKind kind) {
+	if (n == 0) return MI_OK;
+	if (!copy_by_kernel()) {
+		MI_HIP(hipMemcpyAsync(dst, src, n, kind, c->stream));
+		return MI_OK;
+	}
+	const uintptr_t al = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | (uintptr_t)n;
+	auto grid = [](size_t units) { return dim3((unsigned)std::min<size_t>((units + 255) / 256, 2048)); };
+	if ((al & 15) == 0) hipLaunchKernelGGL(copy_kernel<uint4>, grid(n / 16), dim3(256), 0, c->stream, (uint4 *)dst, (const uint4 *)src, n / 16);
+	else if ((al & 3) == 0) hipLaunchKernelGGL(copy_kernel<uint32_t>, grid(n / 4), dim3(256), 0, c->stream, (uint32_t *)dst, (const uint32_t *)src, n / 4);
+	else hipLaunchKernelGGL(copy_kernel<uint8_t>, grid(n), dim3(256), 0, c->stream, (uint8_t *)dst, (const uint8_t *)src, n);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+} // namespace
 
 extern "C" {
 
@@ -157,6 +193,18 @@ int mi_copy_d2h(mi_ctx *c, void *h, const void *d, size_t n) {
 	if (c->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
 	return MI_OK;
+}
+
+int mi_copy_h2d_pinned(mi_ctx *c, void *d, const void *h_pinned, size_t n) {
+	MI_CHECK_ARG(c && d && h_pinned);
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	return copy_mapped(c, d, h_pinned, n, hipMemcpyHostToDevice);
+}
+
+int mi_copy_d2h_pinned(mi_ctx *c, void *h_pinned, const void *d, size_t n) {
+	MI_CHECK_ARG(c && d && h_pinned);
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	return copy_mapped(c, h_pinned, d, n, hipMemcpyDeviceToHost);
 }
 
 int mi_memset(mi_ctx *c, void *d, int value, size_t n) {

@@ -537,22 +537,34 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 	// the members; second loop: for every pin with its output enabled saturate(sum - own) (channel_process_out), 8 bytes
 	// per lane and row, rows contiguous.  A lane only re-reads what it wrote itself: no barrier in between, no index
 	// arithmetic per element (the two phases as loops over (member, word) items divided by a run-time width per item).
+	// a member's record as scalars: lane m of every wave holds member m's (mm <= 50 < 64), v_readlane hands it to the wave --
+	// no LDS round trip per member in front of the row's, uniform branches, scalar operands
+	const int wl = t & 63;
+	const int4 mine = wl < mm ? s_par[wl] : make_int4(0, 0, 0, 0);
+	typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+	const unsigned rows_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)rows;
+	const unsigned pitch = 8u * (unsigned)va.row_w;
 	for (int j = t; j < nw; j += VM_THREADS) {
+		// (the next member's word is asked for before this member's arithmetic and waited for behind it, by hand as in (B))
+		const unsigned col = rows_lds + 8u * (unsigned)j;
 		int sum[4] = {0, 0, 0, 0};
+		u32x2 cur, nxt;
+		asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cur) : "v"(col));
+		nxt = cur;
 		for (int m = 0; m < mm; ++m) {
-			const int4 pr = s_par[m]; // (flags | mode << 8, Q12 gain, DC offset, pin gain)
-			const unsigned f = (unsigned)pr.x & 0xffu;
+			if (m + 1 < mm) asm volatile("ds_read_b64 %0, %1" : "=&v"(nxt) : "v"(col + (unsigned)(m + 1) * pitch));
+			const int px = __builtin_amdgcn_readlane(mine.x, m);
+			const unsigned f = (unsigned)px & 0xffu;
 			uint2 o = make_uint2(0, 0);
 			if ((f & MI_MIX_LINKED) && (f & MI_MIX_ACTIVE)) {
-				const uint2 r = rows[m * va.row_w + j];
-				int x[4] = {(int)(short)(r.x & 0xffffu), (int)(short)(r.x >> 16), (int)(short)(r.y & 0xffffu), (int)(short)(r.y >> 16)};
-				const int mode = pr.x >> 8;
+				int x[4] = {(int)(short)(cur.x & 0xffffu), (int)(short)(cur.x >> 16), (int)(short)(cur.y & 0xffffu), (int)(short)(cur.y >> 16)};
+				const int mode = px >> 8;
 				if (mode != 0) {
-					const int ig = pr.y, dc = (mode == 2) ? pr.z : 0;
+					const int ig = __builtin_amdgcn_readlane(mine.y, m), dc = (mode == 2) ? __builtin_amdgcn_readlane(mine.z, m) : 0;
 #pragma unroll
 					for (int k = 0; k < 4; ++k) x[k] = sat16(((x[k] - dc) * ig) / 4096);
 				}
-				const float gn = __int_as_float(pr.w);
+				const float gn = __int_as_float(__builtin_amdgcn_readlane(mine.w, m));
 				if (gn != 1.0f) {
 #pragma unroll
 					for (int k = 0; k < 4; ++k) x[k] = sat16((int)(gn * (float)x[k]));
@@ -563,14 +575,21 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 				o.y = (unsigned)(x[2] & 0xffff) | ((unsigned)x[3] << 16);
 			}
 			rows[m * va.row_w + j] = o;
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt));
+			cur = nxt;
 		}
+		asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cur) : "v"(col) : "memory");
+		nxt = cur;
 		for (int m = 0; m < mm; ++m) {
-			if (!((unsigned)s_par[m].x & MI_MIX_OUTPUT)) continue;
-			const uint2 w = rows[m * va.row_w + j];
-			const int o0 = sat16(sum[0] - (int)(short)(w.x & 0xffffu)), o1 = sat16(sum[1] - (int)(short)(w.x >> 16));
-			const int o2 = sat16(sum[2] - (int)(short)(w.y & 0xffffu)), o3 = sat16(sum[3] - (int)(short)(w.y >> 16));
-			*reinterpret_cast<uint2 *>(va.out + ((size_t)(c * mm + m) * ns) + 4 * j) =
-			    make_uint2((unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16), (unsigned)(o2 & 0xffff) | ((unsigned)o3 << 16));
+			if (m + 1 < mm) asm volatile("ds_read_b64 %0, %1" : "=&v"(nxt) : "v"(col + (unsigned)(m + 1) * pitch));
+			if ((unsigned)__builtin_amdgcn_readlane(mine.x, m) & MI_MIX_OUTPUT) {
+				const int o0 = sat16(sum[0] - (int)(short)(cur.x & 0xffffu)), o1 = sat16(sum[1] - (int)(short)(cur.x >> 16));
+				const int o2 = sat16(sum[2] - (int)(short)(cur.y & 0xffffu)), o3 = sat16(sum[3] - (int)(short)(cur.y >> 16));
+				*reinterpret_cast<uint2 *>(va.out + ((size_t)(c * mm + m) * ns) + 4 * j) =
+				    make_uint2((unsigned)(o0 & 0xffff) | ((unsigned)o1 << 16), (unsigned)(o2 & 0xffff) | ((unsigned)o3 << 16));
+			}
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt));
+			cur = nxt;
 		}
 	}
 }
@@ -680,8 +699,7 @@ int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h) 
 int mi_volume_get_state_async(mi_volume *v, int first, int count, mi_volume_state *h_pinned) {
 	MI_CHECK_ARG(v && h_pinned && first >= 0 && count >= 0 && first + count <= v->nstreams);
 	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
-	MI_HIP(hipMemcpyAsync(h_pinned, v->d_state + first, sizeof(*h_pinned) * (size_t)count, hipMemcpyDeviceToHost, v->ctx->stream));
-	return MI_OK;
+	return mi_copy_d2h_pinned(v->ctx, h_pinned, v->d_state + first, sizeof(*h_pinned) * (size_t)count);
 }
 
 int mi_volume_set_state(mi_volume *v, int first, int count, const mi_volume_state *h) {

@@ -56,8 +56,8 @@ struct MapPool : Pool {
 		if (used && !failed) {
 			mi_ctx *ctx = hub->ctx;
 			const MapOpInfo &k = kMapOps[op];
-			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, used * k.in_bpe));
-			if (d_in2) MI_MUST(mi_copy_h2d(ctx, d_in2, h_in2, used * k.in_bpe));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in, used * k.in_bpe));
+			if (d_in2) MI_MUST(mi_copy_h2d_pinned(ctx, d_in2, h_in2, used * k.in_bpe));
 			switch (op) {
 			case OP_ALAW_DEC:
 			case OP_ULAW_DEC:
@@ -82,7 +82,7 @@ struct MapPool : Pool {
 			default:
 				break;
 			}
-			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, used * k.out_bpe));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_out, d_out, used * k.out_bpe));
 			MI_MUST(mi_ctx_sync(ctx));
 		}
 		for (int s = 0; s < hi; ++s) {

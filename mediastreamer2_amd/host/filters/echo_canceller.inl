@@ -44,11 +44,11 @@ struct EcPool : Pool {
 		for (int r = 0; r < rounds; ++r) {
 			for (int s = 0; s < capacity; ++s)
 				h_cnt[r * c + s] = s < hi ? (uint8_t)std::clamp(staged[(size_t)s] - r * kEcTickFrames, 0, kEcTickFrames) : 0;
-			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + r * c * row, u * row * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref + r * c * row, u * row * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_cnt + r * c, h_cnt + r * c, c));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_mic, h_mic + r * c * row, u * row * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_ref, h_ref + r * c * row, u * row * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_cnt + r * c, h_cnt + r * c, c));
 			MI_MUST(mi_aec_process_frames(a, d_mic, d_ref, d_out + r * c * row, (int)row, d_cnt + r * c, kEcTickFrames, MI_AEC_POSTFILTER));
-			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * row, d_out + r * c * row, u * row * 2));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_out + r * c * row, d_out + r * c * row, u * row * 2));
 		}
 		return rounds > 0;
 	}

@@ -32,10 +32,10 @@ struct EqualizerPool : Pool {
 		for (int r = 0; r < maxr; ++r) {
 			for (int s = 0; s < capacity; ++s)
 				if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
-			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, h_n + r * c, c * 4));
 			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
-			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
 		return maxr > 0;
 	}

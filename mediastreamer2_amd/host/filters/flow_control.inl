@@ -66,11 +66,11 @@ struct FlowPool : Pool {
 			arm(r, false);
 			for (int s = 0; s < capacity; ++s)
 				if (staged[(size_t)s] <= r) h_len[r * c + s] = 0;
-			MI_MUST(mi_copy_h2d(ctx, d_in, h_in + r * c * kFlowBlock, c * kFlowBlock * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_len, h_len + r * c, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in + r * c * kFlowBlock, c * kFlowBlock * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_len, h_len + r * c, c * 4));
 			MI_MUST(mi_flowctl_process(fc, d_in, kFlowBlock, d_len, kFlowBlock, d_out, kFlowBlock, d_olen));
-			MI_MUST(mi_copy_d2h(ctx, h_out + r * c * kFlowBlock, d_out, c * kFlowBlock * 2));
-			MI_MUST(mi_copy_d2h(ctx, h_olen + r * c, d_olen, c * 4));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_out + r * c * kFlowBlock, d_out, c * kFlowBlock * 2));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_olen + r * c, d_olen, c * 4));
 		}
 		arm(maxr, true);
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));

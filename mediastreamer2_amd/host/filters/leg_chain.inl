@@ -109,6 +109,10 @@ struct LegBank : Pool {
 	uint8_t *h_run, *d_run;                 // [capacity]: conferences that tick in this launch of the volume + mix kernel
 	bool staged_since = false;              // something was staged (or a conference joined) since the last enqueue
 	bool outstanding = false;               // an enqueue has not been waited for yet
+	// The staging rows and the mixes' slab are pinned host memory the device addresses itself: by default the launches read
+	// and write them where they lie (a few hundred bytes per leg, once) and the tick path makes no copy at all -- four
+	// launches and the meters' read-back.  MSMI355X_ZERO_COPY=0: staged through device buffers by copy launches (A/B).
+	bool zero_copy = true;
 	bool mixed = false, check_levels = false;
 	double trace_ms = 0;          // MSMI355X_TRACE_SLOW_MS: an enqueue that takes longer says where (stderr)
 	uint64_t tr[8] = {0};
@@ -197,6 +201,7 @@ struct LegBank : Pool {
 		vpatch.assign(L, GainPatch{1.f, 1.f, false});
 		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
 		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
+		if (const char *e = getenv("MSMI355X_ZERO_COPY")) zero_copy = e[0] != '0';
 		no_early = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr; // A/B switch: everything leaves at the flush
 	}
 	~LegBank() override {
@@ -298,31 +303,34 @@ struct LegBank : Pool {
 		bool any = false;
 		trc.clear();
 		step("start");
-		if (any_ref || any_refx || any_inj) MI_MUST(mi_copy_h2d(ctx, d_cnt, h_cnt, 3 * L * 4));
+		const bool zc = zero_copy;
+		const int32_t *cnt = zc ? h_cnt : d_cnt;
+		if (!zc && (any_ref || any_refx || any_inj)) MI_MUST(mi_copy_h2d_pinned(ctx, d_cnt, h_cnt, 3 * L * 4));
 		step("counts up");
 		if (any_ref) {
-			MI_MUST(mi_copy_h2d(ctx, d_ref, h_ref, UL * ns * 2));
+			if (!zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_ref, h_ref, UL * ns * 2));
 			step("far end up");
-			MI_MUST(mi_fifo_push(f_ref, d_ref, ns, ns, d_cnt));
+			MI_MUST(mi_fifo_push(f_ref, zc ? h_ref : d_ref, ns, ns, cnt));
 			step("far end queued");
 			++launches, any = true;
 		}
 		if (any_refx) {
-			MI_MUST(mi_copy_h2d(ctx, d_refx, h_refx, UL * kLegRefOver * ns * 2));
-			MI_MUST(mi_fifo_push(f_ref, d_refx, kLegRefOver * ns, kLegRefOver * ns, d_cnt + L));
+			if (!zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_refx, h_refx, UL * kLegRefOver * ns * 2));
+			MI_MUST(mi_fifo_push(f_ref, zc ? h_refx : d_refx, kLegRefOver * ns, kLegRefOver * ns, cnt + L));
 			++launches, any = true;
 		}
 		if (any_inj) {
-			MI_MUST(mi_fifo_push_silence(f_ref, d_cnt + 2 * L));
+			MI_MUST(mi_fifo_push_silence(f_ref, cnt + 2 * L));
 			++launches, any = true;
 		}
-		if (rounds) MI_MUST(mi_copy_h2d(ctx, d_gate, h_gate, (size_t)rounds * L));
+		if (rounds && !zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_gate, h_gate, (size_t)rounds * L));
 		step("gates up");
 		for (int r = 0; r < rounds; ++r) {
-			MI_MUST(mi_copy_h2d(ctx, d_mic, h_mic + (size_t)r * L * in_len, UL * in_len * 2));
+			const int16_t *mic_r = h_mic + (size_t)r * L * in_len;
+			if (!zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_mic, mic_r, UL * in_len * 2));
 			step("microphones up");
-			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
-			                                              MI_AEC_POSTFILTER, nullptr, d_gate + (size_t)r * L));
+			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, zc ? mic_r : d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
+			                                              MI_AEC_POSTFILTER, nullptr, (zc ? h_gate : d_gate) + (size_t)r * L));
 			step("cancellers launched");
 			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
 		}
@@ -347,11 +355,12 @@ struct LegBank : Pool {
 		if (maxc) {
 			if (!cur) cur = free_slab();
 			uint8_t *dst = cur ? cur->payload() : reinterpret_cast<uint8_t *>(h_copy);
+			int16_t *rows = zero_copy ? reinterpret_cast<int16_t *>(dst) : d_mix;
 			for (int r = 0; r < maxc; ++r) { // (rows of round r start behind what a leg still has ready from an earlier enqueue of this flush)
-				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, d_mix + (size_t)r * L * ns, ns, ns, MI_VOLMIX_DRY_SKIPS));
+				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, rows + (size_t)r * L * ns, ns, ns, MI_VOLMIX_DRY_SKIPS));
 				++launches;
 			}
-			MI_MUST(mi_copy_d2h(ctx, dst, d_mix, ((size_t)(maxc - 1) * L + UL) * ns * 2));
+			if (!zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, dst, d_mix, ((size_t)(maxc - 1) * L + UL) * ns * 2));
 			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 			mixed = true;
 			any = true;
@@ -360,7 +369,7 @@ struct LegBank : Pool {
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
-			MI_MUST(mi_copy_d2h(ctx, h_lv, d_lv, 3 * L * 4));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, 3 * L * 4));
 		}
 		outstanding |= any;
 		return any;
@@ -439,8 +448,10 @@ struct LegBank : Pool {
 		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
 		mark(3);
 		if (ticked) {
-			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, (size_t)capacity));
-			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, d_mix, MI_VOLMIX_DRY_SKIPS, d_run));
+			if (!cur) cur = free_slab();
+			int16_t *host_rows = reinterpret_cast<int16_t *>(cur ? (void *)cur->payload() : (void *)h_copy);
+			if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_run, h_run, (size_t)capacity));
+			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, zero_copy ? host_rows : d_mix, MI_VOLMIX_DRY_SKIPS, zero_copy ? h_run : d_run));
 			mark(4);
 			++launches;
 			for (const auto &dk : drops) // chunks the channels' flow control discards: metered (MSVolume saw them), never mixed
@@ -448,9 +459,8 @@ struct LegBank : Pool {
 					MI_MUST(mi_volume_process_fifo_range(vol, f_out, d_scratch, ns, ns, dk.first, 1));
 					++launches;
 				}
-			if (!cur) cur = free_slab();
 			mark(5);
-			MI_MUST(mi_copy_d2h(ctx, cur ? (void *)cur->payload() : (void *)h_copy, d_mix, UL * ns * 2));
+			if (!zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, host_rows, d_mix, UL * ns * 2));
 			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 			mark(6);
 			any = true;
@@ -465,7 +475,7 @@ struct LegBank : Pool {
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
-			MI_MUST(mi_copy_d2h(ctx, h_lv, d_lv, 3 * L * 4));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, 3 * L * 4));
 		}
 		outstanding |= any;
 		return any;

@@ -55,12 +55,12 @@ struct MixerPool : Pool {
 		}
 		if (any) {
 			const size_t un = (size_t)hi * MIXER_MAX_CHANNELS; // channel rows of the slots ever handed out
-			MI_MUST(mi_copy_h2d(ctx, d_in, h_in, un * ns * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_has, h_has, un));
-			MI_MUST(mi_copy_h2d(ctx, d_run, h_run, c));
-			MI_MUST(mi_copy_h2d(ctx, d_mode, h_mode, c));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in, un * ns * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_has, h_has, un));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_run, h_run, c));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_mode, h_mode, c));
 			MI_MUST(mi_mixer_process_masked(m, d_in, d_has, 1, d_mode, d_out, d_run));
-			MI_MUST(mi_copy_d2h(ctx, h_out, d_out, un * ns * 2));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_out, d_out, un * ns * 2));
 		}
 		return any;
 	}

@@ -38,11 +38,11 @@ struct ResamplePool : Pool {
 		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r_ = 0; r_ < maxr; ++r_) {
 			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = s < hi && staged[(size_t)s] > r_;
-			MI_MUST(mi_copy_h2d(ctx, d_in, h_in + r_ * c * in_len, u * in_len * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_run, h_run + r_ * c, c));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in + r_ * c * in_len, u * in_len * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_run, h_run + r_ * c, c));
 			MI_MUST(mi_resampler_process_masked(r, d_in, in_len, in_len, d_out, ostride, d_olen, d_run));
-			MI_MUST(mi_copy_d2h(ctx, h_out + r_ * c * ostride, d_out, u * ostride * 2));
-			MI_MUST(mi_copy_d2h(ctx, h_olen + r_ * c, d_olen, u * 4));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_out + r_ * c * ostride, d_out, u * ostride * 2));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_olen + r_ * c, d_olen, u * 4));
 		}
 		return maxr > 0;
 	}

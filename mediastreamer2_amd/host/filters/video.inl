@@ -150,9 +150,9 @@ struct FramePool : Pool {
 		const int n = (int)staged.size();
 		if (!n) return;
 		mi_ctx *ctx = hub->ctx;
-		MI_MUST(mi_copy_h2d(ctx, d_src, h_src, (size_t)n * src_pitch));
+		MI_MUST(mi_copy_h2d_pinned(ctx, d_src, h_src, (size_t)n * src_pitch));
 		MI_MUST(launch(n));
-		MI_MUST(mi_copy_d2h(ctx, h_dst, d_dst, (size_t)n * dst_pitch));
+		MI_MUST(mi_copy_d2h_pinned(ctx, h_dst, d_dst, (size_t)n * dst_pitch));
 		MI_MUST(mi_ctx_sync(ctx));
 		if (failed) staged.clear(); // the frames are dropped, like a failing ms_scaler_process (sizeconv.c:162-166)
 		else ready.swap(staged);

@@ -81,10 +81,10 @@ struct VolumePool : Pool {
 		for (int r = 0; r < maxr; ++r) {
 			for (int s = 0; s < capacity; ++s)
 				if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
-			MI_MUST(mi_copy_h2d(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
-			MI_MUST(mi_copy_h2d(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, h_n + r * c, c * 4));
 			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
-			MI_MUST(mi_copy_d2h(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
 		fetched = maxr > 0 && !failed;
 		if (fetched) MI_MUST(mi_volume_get_state_async(v, 0, hi, h_state)); // meters for the app thread

@@ -168,6 +168,8 @@ int mi_copy_d2h(mi_ctx *c, void *h, const void *d, size_t n) {
 	memcpy(h, d, n);
 	return MI_OK;
 }
+int mi_copy_h2d_pinned(mi_ctx *c, void *d, const void *h, size_t n) { return mi_copy_h2d(c, d, h, n); }
+int mi_copy_d2h_pinned(mi_ctx *c, void *h, const void *d, size_t n) { return mi_copy_d2h(c, h, d, n); }
 int mi_memset(mi_ctx *c, void *d, int v, size_t n) {
 	ARG(c && d);
 	memset(d, v, n);

@@ -18,6 +18,8 @@
 #include "../../include/ms2_plugin_abi.h"
 
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -114,6 +116,43 @@ static void build(TickerJob *j) {
 	}
 }
 
+/* PLUGIN_BENCH_STACKS=<ms>: a watchdog signals a ticker thread whose step has been running for that long; the handler prints
+ * where the thread is (backtrace: exported symbols of the HIP / HSA runtime included) -- what a rare long step is waiting in */
+static volatile uint64_t g_step_start[256]; /* per ticker: start of the running step (ns), 0 = not in a step */
+static pthread_t g_threads[256];
+static double g_stack_ms;
+static volatile int g_stack_dumps, g_done;
+static uint64_t mono_ns(void) {
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+static void stack_handler(int sig) {
+	(void)sig;
+	void *buf[48];
+	const int n = backtrace(buf, 48);
+	static const char head[] = "---- plugin_bench: a step is taking long; this thread is in:\n";
+	if (write(2, head, sizeof(head) - 1) < 0) return;
+	backtrace_symbols_fd(buf, n, 2);
+}
+static void *watchdog(void *arg) {
+	(void)arg;
+	uint64_t dumped[256] = {0};
+	while (!g_done && g_stack_dumps < 8) {
+		const uint64_t now = mono_ns();
+		for (int i = 0; i < g_tickers; ++i) {
+			const uint64_t st = g_step_start[i];
+			if (st && st != dumped[i] && (double)(now - st) * 1e-6 > g_stack_ms) {
+				dumped[i] = st;
+				++g_stack_dumps;
+				pthread_kill(g_threads[i], SIGUSR1);
+			}
+		}
+		usleep(300);
+	}
+	return NULL;
+}
+
 static void *run(void *arg) {
 	TickerJob *j = (TickerJob *)arg;
 	/* attach on the ticker's own thread: the hub's device context and its banks belong to the thread that ticks them */
@@ -128,7 +167,9 @@ static void *run(void *arg) {
 		getrusage(RUSAGE_THREAD, &ru0);
 		const double c0 = thread_cpu_ms();
 		const double t0 = now_ms();
+		if (g_stack_ms > 0 && t > 50) g_step_start[j->index] = mono_ns();
 		ms_ticker_step(j->ticker);
+		g_step_start[j->index] = 0;
 		j->step_ms[t] = now_ms() - t0;
 		struct rusage ru1;
 		getrusage(RUSAGE_THREAD, &ru1);
@@ -214,6 +255,15 @@ int main(int argc, char **argv) {
 	pthread_barrier_init(&g_bar, NULL, (unsigned)g_tickers + 1);
 	pthread_t *th = (pthread_t *)calloc((size_t)g_tickers, sizeof(pthread_t));
 	for (int i = 0; i < g_tickers; ++i) pthread_create(&th[i], NULL, run, &jobs[i]);
+	pthread_t wd;
+	if (getenv("PLUGIN_BENCH_STACKS") && g_tickers <= 256) {
+		g_stack_ms = atof(getenv("PLUGIN_BENCH_STACKS"));
+		void *warm[4];
+		backtrace(warm, 4); /* (loads libgcc now, not inside the handler) */
+		signal(SIGUSR1, stack_handler);
+		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
+		pthread_create(&wd, NULL, watchdog, NULL);
+	}
 	int fc0 = 0, fl0 = 0, fc1 = 0, fl1 = 0;
 	unsigned long long la0 = 0, fr0 = 0, la1 = 0, fr1 = 0;
 	const double t_warm0 = now_ms();
@@ -231,6 +281,7 @@ int main(int argc, char **argv) {
 	const double wall_ms = now_ms() - t_first;
 	if (fused_stats) fused_stats(&fc1, &fl1, &la1, &fr1);
 	for (int i = 0; i < g_tickers; ++i) pthread_join(th[i], NULL);
+	g_done = 1;
 
 	/* a tick costs what the slowest ticker needs */
 	double *tick = (double *)calloc((size_t)g_ticks, sizeof(double)), *task = (double *)calloc((size_t)g_ticks, sizeof(double));

@@ -32,9 +32,10 @@ def make_echo_scene(seed, rate, nsamp, near_sigma=300.0, far_sigma=3000.0):
     return to16(mic), to16(far)
 
 
-@pytest.mark.parametrize("F", [256, 128, 64])
-def test_fft_bit_exact(ctx, oracle, F):
-    """The in-LDS real FFT == the kiss_fft float build restated in the oracle (ms_fft / ms_ifft)."""
+@pytest.mark.parametrize("F,group", [(256, 0), (128, 0), (64, 0), (128, 2), (64, 2)])
+def test_fft_bit_exact(ctx, oracle, F, group):
+    """The in-LDS real FFT == the kiss_fft float build restated in the oracle (ms_fft / ms_ifft); group = 2: the transforms of
+    the several-legs-per-wavefront form (aec_group.hpp: a leg in 16 / 32 lanes, 6 frames over 4 / 2 legs per wavefront)."""
     torch = pytest.importorskip("torch")
     L = _lib.load()
     L.mi_debug_fft.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -48,7 +49,7 @@ def test_fft_bit_exact(ctx, oracle, F):
     x[2, 5] = 1.0
     d = torch.from_numpy(x).cuda()
     o = torch.zeros_like(d)
-    assert L.mi_debug_fft(aec.h, d.data_ptr(), o.data_ptr(), nfr, 0) == 0
+    assert L.mi_debug_fft(aec.h, d.data_ptr(), o.data_ptr(), nfr, 0 | group) == 0
     ctx.sync()
     spec = o.cpu().numpy()
     for i in range(nfr):
@@ -58,7 +59,7 @@ def test_fft_bit_exact(ctx, oracle, F):
         got[1:N - 1] = spec[i, 2:]
         np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32), err_msg=f"fwd frame {i}")
     t = torch.zeros_like(d)
-    assert L.mi_debug_fft(aec.h, o.data_ptr(), t.data_ptr(), nfr, 1) == 0
+    assert L.mi_debug_fft(aec.h, o.data_ptr(), t.data_ptr(), nfr, 1 | group) == 0
     ctx.sync()
     back = t.cpu().numpy()
     for i in range(nfr):
@@ -260,6 +261,71 @@ def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
         b.import_state(0, blob[:4] + (7).to_bytes(4, "little") + blob[8:])
     for x in (a, b, c):
         x.close()
+
+
+@pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(16000, 128, 128, True), (8000, 64, 128, True), (8000, 64, 250, False), (16000, 128, 512, True)])
+def test_group_form_equals_one_leg_per_wavefront(ctx, rate, F, tail_ms, postfilter):
+    """The small frame sizes handed in as rows run several legs per wavefront (aec_group.hpp: four at 8 kHz, two at 16 kHz);
+    the FIFO entries and MSMI355X_AEC_GROUP=0 keep one leg per wavefront (aec_tick.hpp).  Same arithmetic in the same order
+    on the same state: outputs and every state array bit for bit, frame after frame -- through convergence, a saturating
+    burst, a far-end overload that resets the canceller, legs gated off by the run mask, a batch that does not fill its
+    last wavefront (7 legs), up to 64 filter blocks (512 ms at 16 kHz) -- and a batch may change form between launches."""
+    torch = pytest.importorskip("torch")
+    L = _lib.load()
+    L.mi_debug_aec_group_form.argtypes = [C.c_int]
+    L.mi_debug_aec_group_form.restype = None
+    n, nframes = 7, 260
+    flen = tail_ms * rate // 1000
+    a_grp = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    a_one = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    a_mix = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)   # changes form every 7 frames
+    rng = np.random.default_rng(23)
+    scenes = [make_echo_scene(70 + s, rate, F * nframes) for s in range(n)]
+    mic = np.stack([m for m, _ in scenes]).reshape(n, nframes, F).copy()
+    far = np.stack([f for _, f in scenes]).reshape(n, nframes, F).copy()
+    mic[2, 60:64] = 32767
+    far[3, 90] = np.where(np.arange(F) % 2 == 0, 32767, -32767)
+    M = (flen + F - 1) // F
+    flags = ms.MI_AEC_POSTFILTER if postfilter else 0
+    try:
+        for f in range(nframes):
+            run = (rng.random(n) > 0.12).astype(np.uint8)
+            run[0] = 1
+            dm = torch.from_numpy(np.ascontiguousarray(mic[:, f])).cuda()
+            df = torch.from_numpy(np.ascontiguousarray(far[:, f])).cuda()
+            dr = torch.from_numpy(run).cuda()
+            outs = []
+            for a, form in ((a_grp, 1), (a_one, 0), (a_mix, (f // 7) & 1)):
+                o = torch.full_like(dm, 77)
+                torch.cuda.synchronize()
+                L.mi_debug_aec_group_form(form)
+                a.process(dm, df, out=o, run=dr, flags=flags)
+                ctx.sync()
+                outs.append(o.cpu().numpy())
+            for s in range(n):
+                if run[s]:
+                    assert np.array_equal(outs[0][s], outs[1][s]), f"frame {f} stream {s}"
+                    assert np.array_equal(outs[2][s], outs[1][s]), f"frame {f} stream {s} (changing form)"
+                else:
+                    assert (outs[0][s] == 77).all() and (outs[1][s] == 77).all(), f"frame {f}: a gated leg's row was written"
+            if f % 20 == 19 or f == nframes - 1:
+                for s in range(n):
+                    for what, ln in (("W", M * 2 * F), ("foreground", M * 2 * F), ("X", (M + 1) * 2 * F), ("E", 2 * F), ("power", F + 1),
+                                     ("power_1", F + 1), ("Eh", F + 1), ("Yh", F + 1), ("last_y", 2 * F), ("prop", M), ("scalars", 16), ("counters", 4)):
+                        x, y, z = a_grp.get(s, what, ln), a_one.get(s, what, ln), a_mix.get(s, what, ln)
+                        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"frame {f} stream {s}: {what}"
+                        assert np.array_equal(z.view(np.uint32), y.view(np.uint32)), f"frame {f} stream {s}: {what} (changing form)"
+                if postfilter:  # the post-filter's state: everything the blob holds
+                    for s in range(n):
+                        assert a_grp.export_state(s) == a_one.export_state(s), f"frame {f} stream {s}: state blob"
+        adapted = [a_grp.get(s, "scalars", 16)[8] for s in range(n)]
+        counters = np.array([a_grp.get(s, "counters", 4) for s in range(n)])
+        assert any(v == 1.0 for v in adapted), "the scene should take at least one stream through adaptation"
+        assert counters[:, 0].sum() > 0 and counters[3, 2] >= 1, counters   # foreground updates; the overload's reset
+    finally:
+        L.mi_debug_aec_group_form(1)
+    for a in (a_grp, a_one, a_mix):
+        a.close()
 
 
 @pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 64), (48000, 256, 200)])  # (200 ms: 38 blocks -- more than the 32 whose weights the redo has LDS for: frame 1 writes as it always did)
