@@ -393,6 +393,26 @@ def make_aec_leg(ms, torch, ctx, nstreams=4096):
     return leg
 
 
+def make_aec_small_leg(ms, torch, ctx, rate, F, nstreams=65536):
+    """The canceller at the small frame sizes (speexec.c:171-180: 8 kHz -> 64, 16 kHz -> 128 samples), 128 ms tail, post-filter on,
+    one frame per launch handed in as rows (mi_aec_process: what the plugin's MSSpeexEC bank launches for such legs): several
+    legs per wavefront (aec_group.hpp).  Bytes per frame as SURVEY 8(d) counts them: io + W read / write + foreground + X
+    history + the newest block."""
+    M = (128 * rate // 1000 + F - 1) // F
+    N = 2 * F
+    aec = ms.AecBatch(ctx, nstreams, rate, frame_size=F, filter_length=128 * rate // 1000)
+    mic = torch.from_numpy(synth_pcm_batch(nstreams, F, rate)).cuda()
+    ref = torch.from_numpy(synth_pcm_batch(nstreams, F, rate, sigma=2000.0)).cuda()
+    out = torch.zeros_like(mic)
+    torch.cuda.synchronize()
+    per_frame = 3 * F * 2 + (3 * M * N + (M + 1) * N + N) * 4
+    leg = Leg(ctx, f"aec_group_kernel<{F}>", lambda i: aec.process(mic, ref, out=out, flags=ms.MI_AEC_POSTFILTER), 1, nstreams * per_frame, nstreams,
+              f"stream-frames ({F} samples at {rate} Hz, {M} filter blocks; {256 // F} legs per wavefront)")
+    leg.keep = (aec, mic, ref, out)
+    leg.state_bytes = aec.state_bytes() * nstreams
+    return leg
+
+
 def copy_ceiling(torch):
     """Achievable HBM rate on this box: a 1 GiB device-to-device copy (read + write bytes / time), the
     'measured ceiling' BASELINE.md section 4 asks to report beside the 8 TB/s vendor peak."""
@@ -1563,9 +1583,15 @@ def main():
             def make_g711_encode(ms_, torch_, ctx_):
                 return make_g711_leg(ms_, torch_, ctx_, encode=True)
 
-            no_pmc = (make_resample_65536, make_mixer_1024, make_scaler_i420)
+            def make_aec_8k(ms_, torch_, ctx_):
+                return make_aec_small_leg(ms_, torch_, ctx_, 8000, 64)
+
+            def make_aec_16k(ms_, torch_, ctx_):
+                return make_aec_small_leg(ms_, torch_, ctx_, 16000, 128)
+
+            no_pmc = (make_resample_65536, make_mixer_1024, make_scaler_i420, make_aec_8k, make_aec_16k)
             for mk in (make_resample_4096, make_resample_65536, make_mixer_leg, make_mixer_1024, make_volume_leg, make_equalizer_leg,
-                       make_aec_4096, make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
+                       make_aec_4096, make_aec_8k, make_aec_16k, make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)

@@ -603,7 +603,8 @@ static int can_process(MSFilter *f, uint32_t tick) { /* msticker.c:230-242 */
 }
 
 static uint64_t now_ns(void);
-static int g_profile = -1;
+static int g_profile;
+__attribute__((constructor)) static void profile_init(void) { g_profile = getenv("MS2SHIM_PROFILE") ? 1 : 0; }
 static void call_process_profiled(MSFilter *f) {
 	TickerImpl *ti = (TickerImpl *)f->ticker->impl;
 	const uint64_t t0 = now_ns();
@@ -664,7 +665,6 @@ void ms_ticker_step(MSTicker *t) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	MSFilter *unsched[256];
 	int nunsched = 0;
-	if (g_profile < 0) g_profile = getenv("MS2SHIM_PROFILE") ? 1 : 0;
 	if (g_profile > 0) {
 		memset(ti->prof_ns, 0, sizeof(ti->prof_ns));
 		ti->max_call_ns = 0, ti->max_call_id = 0;

@@ -74,3 +74,21 @@ def test_tick_kernel_code_fits_the_instruction_cache(build):
     assert max(big.values()) < 65536, f"a form of aec_tick_kernel<256> is over the 64 KB instruction cache: {big}"
     headline = [v for k, v in big.items() if "ILi256ELi2E" in k]  # FIFOs + folded resampler: what the headline and the plugin's fused chain launch
     assert headline and headline[0] <= 64 * 1024 - 1536, f"the headline's form has less than 1.5 KB of instruction cache to spare: {headline}"
+
+
+def test_group_kernels_registers_lds_and_code(build):
+    """the small-frame cancellers with several legs per wavefront (aec_group.hpp): the per-leg scalars live in registers, so
+    the kernels sit close to the 256 of two waves per SIMD -- nothing may spill to scratch; LDS for eight waves per CU; code
+    inside the instruction cache"""
+    d, obj, remarks = build
+    for k in ("aec_group_kernelILi128E", "aec_group_kernelILi64E"):
+        (name, u), = usages(remarks, k)
+        assert int(u["VGPRs"]) <= 256 and int(u["VGPRs Spill"]) == 0 and int(u["ScratchSize [bytes/lane]"]) == 0, (name, u)
+        assert int(u["Occupancy [waves/SIMD]"]) >= 2, (name, u)
+        assert int(u["LDS Size [bytes/block]"]) <= 20480, (name, u)
+    dev = d / "aec_gfx950.o"
+    if not dev.exists():
+        dev = obj
+    syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", str(dev)], capture_output=True, text=True).stdout
+    sizes = {ln.split()[7]: int(ln.split()[2]) for ln in syms.splitlines() if " FUNC " in ln and "aec_group_kernel" in ln}
+    assert len(sizes) == 2 and max(sizes.values()) < 65536, sizes
