@@ -881,7 +881,7 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
 
     keep = ("legs", "tickers", "ticks", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "msticker_late_events", "fits",
             "us_per_leg_tick", "ticker_flush_ms", "ticker_graph_walk_ms", "launches_per_tick_and_ticker", "flush_rounds_per_tick_and_ticker",
-            "fused_legs", "late_events", "worst_tick")
+            "fused_legs", "late_events", "worst_tick", "slow_ticks")
     tried, best, legs = [], None, first_legs
     step = tickers * 32
     for _ in range(5):
@@ -903,9 +903,11 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
                     "max_ms": best["max_ms"], "ticks_over_10ms": best["ticks_over_10ms"], "max_backlog_ms": best["max_backlog_ms"],
                     "msticker_late_events": best["msticker_late_events"],
                     "fits_definition": "p99 tick < 10 ms and the ticker never a whole interval behind (a long tick is caught up by the short ones after it, "
-                                       "as an MSTicker does: msticker.c:419-443); ticks_over_10ms is the strict count beside it -- here they are the graph "
-                                       "walk of ONE ticker thread taking ~10 ms once in a few hundred ticks whatever the leg count (worst_tick: flush_ms "
-                                       "shows the plugin's part of it), on a host whose 256 CPUs are shared",
+                                       "as an MSTicker does: msticker.c:419-443); ticks_over_10ms is the strict count beside it.  slow_ticks lists the five "
+                                       "longest with the slowest thread's CPU time, context switches and page faults: cpu_ms well below ms with involuntary "
+                                       "switches = the thread was pushed off its core (the host's 256 CPUs are shared); the ~13 ms steps that one "
+                                       "hipMemcpyAsync caused (cpu_ms = ms, ~4 100 page faults) are gone with the runtime copies (DESIGN 6.3)",
+                    "slow_ticks": best.get("slow_ticks"),
                     "us_per_leg_tick": best["us_per_leg_tick"], "launches_per_tick": best["launches_per_tick_and_ticker"],
                     "syncs_per_tick": best["flush_rounds_per_tick_and_ticker"], "fits": True,
                     "where_the_time_goes": {"per_ticker_mean_ms": {"plugin_flush": best["ticker_flush_ms"], "graph_walk": best["ticker_graph_walk_ms"]},
