@@ -52,8 +52,18 @@ struct Grp { // the leg's lanes inside the wave
 	__device__ static __forceinline__ float from_lane(float v, int from) {
 		return __int_as_float(__builtin_amdgcn_ds_bpermute(((threadIdx.x & ~(G - 1)) + from) << 2, __float_as_int(v)));
 	}
-	__device__ static __forceinline__ float first(float v) { return from_lane(v, 0); }
-	__device__ static __forceinline__ float last(float v) { return from_lane(v, G - 1); }
+	// ... of its first / last lane: one DPP move inside a row of 16 (row_newbcast), two v_readlane and a select for a leg of two rows
+	template <int WHICH>
+	__device__ static __forceinline__ float edge(float v) {
+		if constexpr (G == 16) {
+			return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), WHICH ? 0x15F : 0x150, 0xf, 0xf, false));
+		} else {
+			const float a = rdlane(v, WHICH ? G - 1 : 0), b = rdlane(v, G + (WHICH ? G - 1 : 0));
+			return threadIdx.x < G ? a : b;
+		}
+	}
+	__device__ static __forceinline__ float first(float v) { return edge<0>(v); }
+	__device__ static __forceinline__ float last(float v) { return edge<1>(v); }
 	// lane l <- lane l - 1 of the leg, its first lane <- `head`
 	__device__ static __forceinline__ float shr1(float head, float v) {
 		if constexpr (G == 16) {
@@ -463,8 +473,7 @@ __global__ __launch_bounds__(64, 2) void aec_group_kernel(AecArgs a, int frame) 
 		float xp[K], far[K], xn[K];
 		bload_vec<K>(rS, vb4, SL::XPREV * 4, xp);
 		load_row(rRef, far);
-		float prev = __shfl_up(far[K - 1], 1);
-		if (lane == 0) prev = sc.memX;
+		float prev = GP::shr1(sc.memX, far[K - 1]);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			xn[k] = far[k] - .9f * prev;
@@ -494,8 +503,7 @@ __global__ __launch_bounds__(64, 2) void aec_group_kernel(AecArgs a, int frame) 
 		const float den2 = (float)(radius * radius + .7 * (1 - radius) * (1 - radius));
 		float v[K];
 		GSeq<F>::dc_notch(micf, radius, den2, sc.notch0, sc.notch1, v);
-		float vprev = __shfl_up(v[K - 1], 1);
-		if (lane == 0) vprev = sc.memD;
+		float vprev = GP::shr1(sc.memD, v[K - 1]);
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
 			input[k] = v[k] - .9f * vprev;
