@@ -531,6 +531,16 @@ void facade_detached(MSFilter *f) {
 }
 void generic_postprocess(MSFilter *f) { facade_detached(f); }
 
+// MSMI355X_ZERO_COPY (default on): banks whose launches can take their rows from pinned host memory directly hand those over
+// instead of staging through device buffers (the fused leg bank, MSSpeexEC's bank); 0 = copy launches around the kernels
+bool zero_copy_rows() {
+	static const bool v = [] {
+		const char *e = getenv("MSMI355X_ZERO_COPY");
+		return !(e && e[0] == '0');
+	}();
+	return v;
+}
+
 #define ms_queue_put(q, m) emit_to((q), (m)) /* the facades' queue puts, see emit_to */
 
 // the fused call-leg chain (filters/leg_chain.inl): what its four facades need to know of it

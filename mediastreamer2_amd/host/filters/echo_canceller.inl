@@ -44,6 +44,10 @@ struct EcPool : Pool {
 		for (int r = 0; r < rounds; ++r) {
 			for (int s = 0; s < capacity; ++s)
 				h_cnt[r * c + s] = s < hi ? (uint8_t)std::clamp(staged[(size_t)s] - r * kEcTickFrames, 0, kEcTickFrames) : 0;
+			if (zero_copy_rows()) { // the launch reads the pinned rows and writes the results where they lie: no copy at all (leg_chain.inl says why)
+				MI_MUST(mi_aec_process_frames(a, h_mic + r * c * row, h_ref + r * c * row, h_out + r * c * row, (int)row, h_cnt + r * c, kEcTickFrames, MI_AEC_POSTFILTER));
+				continue;
+			}
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_mic, h_mic + r * c * row, u * row * 2));
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_ref, h_ref + r * c * row, u * row * 2));
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_cnt + r * c, h_cnt + r * c, c));

@@ -201,7 +201,7 @@ struct LegBank : Pool {
 		vpatch.assign(L, GainPatch{1.f, 1.f, false});
 		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
 		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
-		if (const char *e = getenv("MSMI355X_ZERO_COPY")) zero_copy = e[0] != '0';
+		zero_copy = zero_copy_rows();
 		no_early = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr; // A/B switch: everything leaves at the flush
 	}
 	~LegBank() override {

@@ -222,6 +222,50 @@ def test_aec_full_size_4096_streams(ctx, oracle):
     aec.close()
 
 
+@pytest.mark.parametrize("rate,F", [(8000, 64), (16000, 128)])
+def test_small_frame_cancellers_at_full_batch_size(ctx, oracle, rate, F):
+    """65 536 legs of 8 / 16 kHz cancellers (four / two legs per wavefront, aec_group.hpp), device-resident, post-filter on,
+    through adaptation: legs fed the same scene give the same bytes wherever they sit in the batch -- and in their wavefront
+    (7 scenes tiled over the slots, so the four / two legs of a wavefront never all run the same scene) -- a sampled leg
+    equals the oracle's canceller + post-filter within the tolerance, and the run mask leaves a gated leg's row alone."""
+    torch = pytest.importorskip("torch")
+    n, nframes, nsc = 65536, 200, 7
+    flen = 128 * rate // 1000
+    aec = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+    scenes = [make_echo_scene(200 + s, rate, F * nframes) for s in range(nsc)]
+    idx = np.arange(n) % nsc
+    mic = torch.from_numpy(np.stack([m for m, _ in scenes])).cuda()[torch.from_numpy(idx).cuda()]
+    far = torch.from_numpy(np.stack([f for _, f in scenes])).cuda()[torch.from_numpy(idx).cuda()]
+    ec = oracle.Echo(F, flen, rate)
+    pp = oracle.Preproc(F, rate, ec)
+    run = torch.ones(n, dtype=torch.uint8, device="cuda")
+    run[12345] = 0                                      # one leg sits the whole run out
+    out = torch.full((n, F), 77, dtype=torch.int16, device="cuda")
+    sq, cnt = 0.0, 0
+    torch.cuda.synchronize()
+    for f in range(nframes):
+        sl = slice(f * F, (f + 1) * F)
+        aec.process(mic[:, sl].contiguous(), far[:, sl].contiguous(), out=out, run=run, flags=ms.MI_AEC_POSTFILTER)
+        ctx.sync()
+        want = pp.run(ec.cancel(scenes[3][0][sl], scenes[3][1][sl]))
+        if f % 8 == 7 or f == nframes - 1:
+            o = out.cpu().numpy()
+            assert (o[12345] == 77).all()
+            for k in range(nsc):
+                rows = o[k::nsc]
+                rows = rows[np.arange(k, n, nsc) != 12345]
+                assert (rows == rows[:1]).all(), f"frame {f}: legs on scene {k} differ"
+            got = o[3 + 7 * 4001]
+        else:
+            got = out[3 + 7 * 4001].cpu().numpy()
+        d = (got.astype(np.float64) - want) / 32768.0
+        sq += float((d * d).sum())
+        cnt += d.size
+    assert np.sqrt(sq / cnt) <= 1e-4, np.sqrt(sq / cnt)
+    assert aec.get(3, "scalars", 16)[8] == 1.0, "the scene should take the sampled leg through adaptation"
+    aec.close()
+
+
 @pytest.mark.parametrize("rate,F", [(16000, 128), (48000, 256)])
 def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
     """fetch_config / apply_config (speexec.c:119-167): a stream's state is exported, imported into another stream of
