@@ -245,7 +245,9 @@ def test_small_frame_cancellers_at_full_batch_size(ctx, oracle, rate, F):
     torch.cuda.synchronize()
     for f in range(nframes):
         sl = slice(f * F, (f + 1) * F)
-        aec.process(mic[:, sl].contiguous(), far[:, sl].contiguous(), out=out, run=run, flags=ms.MI_AEC_POSTFILTER)
+        m, r = mic[:, sl].contiguous(), far[:, sl].contiguous()
+        torch.cuda.synchronize()  # torch cuts the frames out on ITS stream; the canceller runs on the context's
+        aec.process(m, r, out=out, run=run, flags=ms.MI_AEC_POSTFILTER)
         ctx.sync()
         want = pp.run(ec.cancel(scenes[3][0][sl], scenes[3][1][sl]))
         if f % 8 == 7 or f == nframes - 1:
