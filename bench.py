@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--worst-ticks", type=int, default=3000, help="consecutive single ticks the worst tick is taken over")
     ap.add_argument("--zero-ticks", type=int, default=256, help="ticks of the from-reset test at the chosen count (0 = skip)")
     ap.add_argument("--paced-ticks", type=int, default=3000, help="ticks of the series run at the 10 ms cadence of an MSTicker, one per 10 ms of wall time: part of `value`'s criterion (0 = skip)")
+    ap.add_argument("--accept-seconds", type=float, default=200.0, help="wall time the step-downs of the acceptance series may take before the next count is chosen with room for the largest machine event seen on this hardware (1.8 ms)")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the rate of full call legs through the drop-in plugin (tests/host/plugin_bench)")
     ap.add_argument("--plugin-legs", type=int, default=32768, help="full call legs the plugin path is first tried with (config[3]: 1024 conferences x 32)")
     ap.add_argument("--no-video-host", action="store_true", help="skip the PCIe-inclusive video probe (config 5)")
@@ -1340,6 +1341,7 @@ def main():
     tried = []  # the counts that did not pass, with what they measured: the step-downs are part of the result
     best = None  # (streams, zero, head, series, fg0, worst) of a count that passed while a larger one is being tried
     ups = 0
+    t_accept0 = time.perf_counter()
     for attempt in range(12):
         if a.zero_ticks > 0 and converged is not None:
             zero = chain_capacity_point(ms, torch, ctx, streams, converged=None, worst_ticks=a.zero_ticks)
@@ -1397,7 +1399,11 @@ def main():
             # only be optimistic and the series at that count decides; never less than one step down
             decisive = paced if (paced is not None and paced.max() >= series.max()) else series  # the series that failed the count
             p50 = reduce_scalar(float(np.median(decisive)), "MAX")
-            room = int(streams * max(9.95 - (worst - p50), 1.0) / p50) // 2048 * 2048 + 2048
+            # (a box that keeps producing events would have the default run step down for a quarter of an hour, a minute a try:
+            # once --accept-seconds are spent the next count leaves room for the LARGEST event seen on this hardware, 1.8 ms)
+            over = time.perf_counter() - t_accept0 > a.accept_seconds
+            event = max(worst - p50, 1.8) if over else worst - p50
+            room = int(streams * max(9.95 - event, 1.0) / p50) // 2048 * 2048 + (0 if over else 2048)
             streams = min(streams - 2048 * (1 + attempt // 2), room)  # at least 2048, 2048, 4096, 4096, ... down
         else:
             tried.append({"streams": streams, "from_reset_worst_ms": zero["tick_ms_worst"]})
