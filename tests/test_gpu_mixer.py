@@ -209,3 +209,35 @@ def test_volume_and_conference_mix_in_one_launch_equal_the_two_launches(ctx, mm,
     assert o1.cpu().numpy().any() and not o2.cpu().numpy()[2, 2].any() and not o2.cpu().numpy()[1, 0].any()
     for o in (v1, m1, f1, v2, m2, f2):
         o.close()
+
+
+def test_pinned_copies_as_kernels_move_every_byte(ctx):
+    """mi_copy_h2d_pinned / mi_copy_d2h_pinned (the plugin's copies: kernels of this library on the context's stream instead of
+    the runtime's copy path) at every alignment class the facades produce: 16-byte, 4-byte and odd byte counts and offsets."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    L = ctx.L
+    n = 1 << 16
+    hp = L.mi_host_alloc(ctx.h, n + 64)
+    hq = L.mi_host_alloc(ctx.h, n + 64)
+    assert hp and hq
+    src = (C.c_uint8 * (n + 64)).from_address(hp)
+    dst = (C.c_uint8 * (n + 64)).from_address(hq)
+    pattern = np.random.default_rng(5).integers(0, 256, n + 64, dtype=np.uint8)
+    np.frombuffer(src, np.uint8)[:] = pattern
+    dev = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for off_h, off_d, nbytes in ((0, 0, n), (16, 32, 4096), (4, 8, 1000), (1, 3, 999), (2, 0, 2), (0, 0, 16), (7, 5, 1)):
+        dev.zero_()
+        np.frombuffer(dst, np.uint8)[:] = 0
+        torch.cuda.synchronize()
+        assert L.mi_copy_h2d_pinned(ctx.h, dev.data_ptr() + off_d, hp + off_h, nbytes) == 0
+        assert L.mi_copy_d2h_pinned(ctx.h, hq + off_h, dev.data_ptr() + off_d, nbytes) == 0
+        ctx.sync()
+        got = np.frombuffer(dst, np.uint8)
+        np.testing.assert_array_equal(got[off_h:off_h + nbytes], pattern[off_h:off_h + nbytes], err_msg=str((off_h, off_d, nbytes)))
+        assert not got[:off_h].any() and not got[off_h + nbytes:].any(), "bytes outside the range were written"
+        d = dev.cpu().numpy()
+        assert not d[:off_d].any() and not d[off_d + nbytes:].any()
+    L.mi_host_free(ctx.h, hp)
+    L.mi_host_free(ctx.h, hq)
