@@ -55,6 +55,7 @@ typedef struct {
 	MSFilter **mixers;
 	MSFilter *probe_out; /* one mixer output sink: did audio arrive? */
 	int nconf, index;
+	double *late_ms;                     /* paced: how far behind its schedule the step STARTED */
 	double *step_ms, *task_ms, *cpu_ms; /* per tick: wall time of the step, of its postponed tasks, CPU time of the thread */
 	double slowest_ms;
 	int slowest_tick, prof_n, prof_ids[16], max_id;
@@ -64,6 +65,8 @@ typedef struct {
 
 static MSFactory *g_fac;
 static int g_members = 32, g_ticks, g_warmup, g_tickers;
+static int g_paced;            /* PLUGIN_BENCH_PACED=1: every ticker fires at t0 + k x 10 ms of wall time, as an MSTicker does */
+static volatile uint64_t g_t0; /* ... the schedule's origin (ns, CLOCK_MONOTONIC) */
 static pthread_barrier_t g_bar;
 
 static int g_profile;
@@ -161,8 +164,20 @@ static void *run(void *arg) {
 		pthread_barrier_wait(&g_bar);
 		ms_ticker_step(j->ticker);
 	}
+	if (g_paced) pthread_barrier_wait(&g_bar); /* (the schedule's origin is set; from here on the wall clock fires the ticks) */
 	for (int t = 0; t < g_ticks; ++t) {
-		pthread_barrier_wait(&g_bar); /* all tickers fire together, as wall-clock tickers do */
+		if (!g_paced) {
+			pthread_barrier_wait(&g_bar); /* back to back: all tickers fire together as soon as the slowest is done */
+		} else { /* msticker.c:419-443,496-515: sleep until the tick's time; no sleep while behind (the late ticks are caught up) */
+			const uint64_t sched = g_t0 + (uint64_t)t * 10000000ull;
+			uint64_t now = mono_ns();
+			if (now < sched) {
+				struct timespec ts = {(time_t)(sched / 1000000000ull), (long)(sched % 1000000000ull)};
+				clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, NULL);
+				now = mono_ns();
+			}
+			j->late_ms[t] = now > sched ? (double)(now - sched) * 1e-6 : 0.0;
+		}
 		struct rusage ru0;
 		getrusage(RUSAGE_THREAD, &ru0);
 		const double c0 = thread_cpu_ms();
@@ -199,6 +214,7 @@ int main(int argc, char **argv) {
 		return 2;
 	}
 	g_profile = getenv("MS2SHIM_PROFILE") != NULL;
+	g_paced = getenv("PLUGIN_BENCH_PACED") != NULL;
 	const char *plugin = argv[1];
 	int legs = atoi(argv[2]);
 	g_tickers = atoi(argv[3]);
@@ -246,6 +262,7 @@ int main(int argc, char **argv) {
 		jobs[i].step_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		jobs[i].task_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		jobs[i].cpu_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
+		jobs[i].late_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		jobs[i].nvcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
 		jobs[i].nivcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
 		jobs[i].minflt = (int *)calloc((size_t)g_ticks, sizeof(int));
@@ -270,11 +287,18 @@ int main(int argc, char **argv) {
 	for (int t = 0; t < g_warmup; ++t) pthread_barrier_wait(&g_bar);
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
-	for (int t = 0; t < g_ticks; ++t) {
+	if (g_paced) {
+		g_t0 = mono_ns() + 20000000ull; /* the first tick fires 20 ms from now */
 		pthread_barrier_wait(&g_bar);
-		if (t == 0) {
-			t_first = now_ms();
-			if (fused_stats) fused_stats(&fc0, &fl0, &la0, &fr0); /* (racing with the first timed step by a launch or two: negligible over the run) */
+		t_first = now_ms() + 20.0;
+		if (fused_stats) fused_stats(&fc0, &fl0, &la0, &fr0);
+	} else {
+		for (int t = 0; t < g_ticks; ++t) {
+			pthread_barrier_wait(&g_bar);
+			if (t == 0) {
+				t_first = now_ms();
+				if (fused_stats) fused_stats(&fc0, &fl0, &la0, &fr0); /* (racing with the first timed step by a launch or two: negligible over the run) */
+			}
 		}
 	}
 	pthread_barrier_wait(&g_bar);
@@ -307,11 +331,19 @@ int main(int argc, char **argv) {
 	 * tick is caught up by the short ones after it; it reports a late event once it is more than 5 intervals behind */
 	double backlog = 0, max_backlog = 0;
 	int ref_late_events = 0;
-	for (int t = 0; t < g_ticks; ++t) {
-		backlog += tick[t] - 10.0;
-		if (backlog < 0) backlog = 0;
-		if (backlog > max_backlog) max_backlog = backlog;
-		ref_late_events += backlog > 50.0;
+	if (g_paced) { /* measured, not modelled: how far behind its schedule a ticker's step started */
+		for (int i = 0; i < g_tickers; ++i)
+			for (int t = 0; t < g_ticks; ++t) {
+				if (jobs[i].late_ms[t] > max_backlog) max_backlog = jobs[i].late_ms[t];
+				ref_late_events += jobs[i].late_ms[t] > 50.0;
+			}
+	} else {
+		for (int t = 0; t < g_ticks; ++t) {
+			backlog += tick[t] - 10.0;
+			if (backlog < 0) backlog = 0;
+			if (backlog > max_backlog) max_backlog = backlog;
+			ref_late_events += backlog > 50.0;
+		}
 	}
 	/* the ticks that took longest: was the slowest thread running (cpu_ms ~ ms), blocked (voluntary switches) or pushed off its core? */
 	char slow[1024];
@@ -347,7 +379,7 @@ int main(int argc, char **argv) {
 		fprintf(stderr, "\n");
 	}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);
-	printf("{\"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
+	printf("{\"paced\": %s, \"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
 	       "\"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"late\": %d, \"wall_ms_per_tick\": %.4f, "
 	       "\"ticker_mean_ms\": %.4f, \"ticker_flush_ms\": %.4f, \"ticker_graph_walk_ms\": %.4f, \"us_per_leg_tick\": %.4f, "
 	       "\"fused_conferences\": %d, \"fused_legs\": %d, \"launches_per_tick\": %.2f, \"launches_per_tick_and_ticker\": %.2f, "
@@ -355,7 +387,7 @@ int main(int argc, char **argv) {
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
 	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
 	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s]}\n",
-	       legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
+	       g_paced ? "true" : "false", legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
