@@ -895,6 +895,19 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
             best = d
             break
         legs = max(step, int(legs * min(0.9, 9.0 / max(d["p99_ms"], 1e-3))) // step * step)
+    if best is not None and best["legs"] == first_legs:  # config[3]'s count fits: how far does it go?  (half as many again, twice)
+        for _ in range(2):
+            up = int(best["legs"] * 1.5) // step * step
+            try:
+                d = run(up, ticks, paced_env)
+            except Exception:
+                break
+            if log:
+                log({"plugin_path": {k: d[k] for k in keep}})
+            tried.append({k: d[k] for k in keep})
+            if not d["fits"]:
+                break
+            best = d
     out = {"cadence": "paced: one tick per 10 ms of wall time on every ticker, as deployed (the launches leave at the end of a walk, the device works "
                       "through the idle part of the interval); `back_to_back` = the same count with every tick fired as soon as the slowest ticker is "
                       "done (the device never idle: a throughput figure, each tick waits for the previous one's launches)",
