@@ -895,9 +895,9 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
             best = d
             break
         legs = max(step, int(legs * min(0.9, 9.0 / max(d["p99_ms"], 1e-3))) // step * step)
-    if best is not None and best["legs"] == first_legs:  # config[3]'s count fits: how far does it go?  (half as many again, twice)
-        for _ in range(2):
-            up = int(best["legs"] * 1.5) // step * step
+    if best is not None and best["legs"] == first_legs:  # config[3]'s count fits: how far does it go?  (a quarter more, up to three times)
+        for _ in range(3):
+            up = int(best["legs"] * 1.25) // step * step
             try:
                 d = run(up, ticks, paced_env)
             except Exception:
