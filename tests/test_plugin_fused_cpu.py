@@ -43,3 +43,23 @@ def test_one_flush_round_per_tick_and_few_launches(verdict):
     v = verdict["plain"]
     assert v["fused_stats"]["flush_rounds"] <= 61 and v["plain_stats"]["flush_rounds"] >= 200, v
     assert v["fused_stats"]["launches"] <= 4 * 62 + 8, v   # (the bank's work for tick t+1 leaves at the end of walk t; a conference that joins mid-walk costs a second batch once)
+
+
+@pytest.mark.parametrize("paced", [False, True])
+def test_plugin_bench_runs_full_legs_through_the_double(verdict, paced):
+    """tests/host/plugin_bench (bench.py's plugin_path) against the double: every leg fused, four launches and one flush round per
+    ticker and tick, a probe sink that received every tick's mix; paced: the tickers fire on the wall clock's 10 ms grid."""
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(HOST, "double"))
+    env.pop("MSMI355X_NO_FUSE", None)
+    if paced:
+        env["PLUGIN_BENCH_PACED"] = "1"
+    r = subprocess.run([os.path.join(HOST, "plugin_bench"), os.path.join(HOST, "double", "libmsmi355xfilters.so"), "256", "2", "40", "10"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["paced"] is paced and d["legs"] == 256 and d["fused_legs"] == 256 and d["fused_conferences"] == 8
+    assert abs(d["launches_per_tick_and_ticker"] - 4.0) < 0.3 and abs(d["flush_rounds_per_tick_and_ticker"] - 1.0) < 0.1, d
+    assert d["probe_sink_blocks"] >= 40 and d["late_events"] == 0
+    assert len(d["slow_ticks"]) == 5 and {"cpu_ms", "nvcsw", "nivcsw", "minflt"} <= set(d["slow_ticks"][0])
+    if paced:
+        assert 9.0 < d["wall_ms_per_tick"] < 12.0, d["wall_ms_per_tick"]   # 40 ticks on the 10 ms grid (+ the 20 ms lead)
