@@ -946,6 +946,11 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
         out["facades_one_by_one_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
         d = run(4096, 200)
         out["fused_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
+        # ... and that the two are the same audio: every leg's mix and speaker frames of a whole run folded into one number each
+        a_, b_ = run(4096, 200, {"PLUGIN_BENCH_CHECKSUM": "1"}), run(4096, 200, {"PLUGIN_BENCH_CHECKSUM": "1", "MSMI355X_NO_FUSE": "1"})
+        out["fused_equals_one_by_one_4096_legs"] = {"equal": a_["mix_checksum"] == b_["mix_checksum"] and a_["speaker_checksum"] == b_["speaker_checksum"],
+                                                    "mix_checksum": [a_["mix_checksum"], b_["mix_checksum"]], "mix_bytes": a_["mix_bytes"],
+                                                    "what": "FNV-1a over every leg's mix (and speaker audio) of 240 ticks, byte for byte and in order, summed over the legs"}
     except Exception as e:
         out["facades_one_by_one_4096_legs"] = {"error": str(e)[:200]}
     return out

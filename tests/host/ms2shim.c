@@ -725,7 +725,8 @@ typedef struct {
 	size_t len, cap;
 	int nblocks;
 	uint32_t last_ts;
-	int discard;
+	int discard;      /* 1: count, do not keep; 2: count and fold every byte into `sum` (a run's output as one number per sink) */
+	uint64_t sum;
 } SinkData;
 
 static void src_init(MSFilter *f) {
@@ -768,6 +769,10 @@ static void sink_process(MSFilter *f) {
 	while ((m = ms_queue_get(f->inputs[0])) != NULL) {
 		size_t n = msgdsize(m);
 		if (d->discard) { /* rate measurements: count, do not keep */
+			if (d->discard == 2) { /* ... but remember what went by: order-sensitive, byte-exact */
+				for (mblk_t *c = m; c; c = c->b_cont)
+					for (const uint8_t *q = c->b_rptr; q < c->b_wptr; ++q) d->sum = (d->sum ^ *q) * 1099511628211ull; /* FNV-1a */
+			}
 			d->len += n;
 			d->last_ts = mblk_get_timestamp_info(m);
 			d->nblocks++;
@@ -844,6 +849,7 @@ static void count_notify(void *ud, MSFilter *f, unsigned int id, void *arg) {
 void ms2shim_watch(MSFilter *f) { ms_filter_add_notify_callback(f, count_notify, NULL, TRUE); }
 int ms2shim_notify_count(void) { return g_notify_count; }
 unsigned ms2shim_notify_last(void) { return g_notify_last; }
+uint64_t ms2shim_sink_sum(MSFilter *sink) { return ((SinkData *)sink->data)->sum; }
 size_t ms2shim_sink_size(MSFilter *sink) { return ((SinkData *)sink->data)->len; }
 int ms2shim_sink_blocks(MSFilter *sink) { return ((SinkData *)sink->data)->nblocks; }
 uint32_t ms2shim_sink_last_ts(MSFilter *sink) { return ((SinkData *)sink->data)->last_ts; }

@@ -43,6 +43,7 @@ MSFilter *ms2shim_new_sink(MSFactory *f);
 void ms2shim_sink_set_discard(MSFilter *f, int on);
 void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase);
 void ms2shim_ticker_last_step(MSTicker *t, uint64_t *tasks_ns, uint64_t *step_ns);
+uint64_t ms2shim_sink_sum(MSFilter *sink);
 int ms2shim_ticker_profile(MSTicker *t, int *ids, uint64_t *ns, int cap, int *max_id, uint64_t *max_ns);
 size_t ms2shim_sink_size(MSFilter *sink);
 int ms2shim_sink_blocks(MSFilter *sink);
@@ -57,6 +58,7 @@ typedef struct {
 	int nconf, index;
 	double *late_ms;                     /* paced: how far behind its schedule the step STARTED */
 	double *step_ms, *task_ms, *cpu_ms; /* per tick: wall time of the step, of its postponed tasks, CPU time of the thread */
+	MSFilter **outs, **spks; /* PLUGIN_BENCH_CHECKSUM=1: every leg's two sinks (mix back to the leg, speaker pin) */
 	double slowest_ms;
 	int slowest_tick, prof_n, prof_ids[16], max_id;
 	uint64_t prof_ns[16], max_ns;
@@ -69,7 +71,7 @@ static int g_paced;            /* PLUGIN_BENCH_PACED=1: every ticker fires at t0
 static volatile uint64_t g_t0; /* ... the schedule's origin (ns, CLOCK_MONOTONIC) */
 static pthread_barrier_t g_bar;
 
-static int g_profile;
+static int g_profile, g_checksum;
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -87,6 +89,8 @@ static void call_int(MSFilter *f, unsigned id, int v) { ms_filter_call_method(f,
 static void build(TickerJob *j) {
 	j->ticker = ms_ticker_new();
 	j->mixers = (MSFilter **)calloc((size_t)j->nconf, sizeof(MSFilter *));
+	j->outs = (MSFilter **)calloc((size_t)j->nconf * (size_t)g_members, sizeof(MSFilter *));
+	j->spks = (MSFilter **)calloc((size_t)j->nconf * (size_t)g_members, sizeof(MSFilter *));
 	for (int c = 0; c < j->nconf; ++c) {
 		MSFilter *mx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
 		call_int(mx, MS_FILTER_SET_SAMPLE_RATE, 48000);
@@ -99,8 +103,10 @@ static void build(TickerJob *j) {
 			const int leg = (j->index * j->nconf + c) * g_members + k;
 			ms2shim_source_set_loop(mic, g_mic, sizeof(g_mic[0]), RING, leg);
 			ms2shim_source_set_loop(far, g_far, sizeof(g_far[0]), RING, leg * 7);
-			ms2shim_sink_set_discard(spk, 1);
-			ms2shim_sink_set_discard(out, 1);
+			ms2shim_sink_set_discard(spk, g_checksum ? 2 : 1);
+			ms2shim_sink_set_discard(out, g_checksum ? 2 : 1);
+			j->outs[c * g_members + k] = out;
+			j->spks[c * g_members + k] = spk;
 			call_int(rs, MS_FILTER_SET_SAMPLE_RATE, 16000);
 			call_int(rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
 			call_int(ec, MS_FILTER_SET_SAMPLE_RATE, 48000);
@@ -215,6 +221,7 @@ int main(int argc, char **argv) {
 	}
 	g_profile = getenv("MS2SHIM_PROFILE") != NULL;
 	g_paced = getenv("PLUGIN_BENCH_PACED") != NULL;
+	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
 	const char *plugin = argv[1];
 	int legs = atoi(argv[2]);
 	g_tickers = atoi(argv[3]);
@@ -378,6 +385,16 @@ int main(int argc, char **argv) {
 		for (int k = 0; k < jobs[bi].prof_n; ++k) fprintf(stderr, " %d=%.3fms", jobs[bi].prof_ids[k], (double)jobs[bi].prof_ns[k] * 1e-6);
 		fprintf(stderr, "\n");
 	}
+	/* PLUGIN_BENCH_CHECKSUM=1: the whole run's output as two numbers -- every leg's mix and speaker audio, byte for byte and in
+	 * order, folded per sink (FNV-1a) and summed over the legs: equal between two runs iff (to 2^-64) every leg heard the same */
+	unsigned long long mix_sum = 0, spk_sum = 0, out_bytes = 0;
+	if (g_checksum)
+		for (int i = 0; i < g_tickers; ++i)
+			for (int k = 0; k < jobs[i].nconf * g_members; ++k) {
+				mix_sum += ms2shim_sink_sum(jobs[i].outs[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
+				spk_sum += ms2shim_sink_sum(jobs[i].spks[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
+				out_bytes += ms2shim_sink_size(jobs[i].outs[k]);
+			}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);
 	printf("{\"paced\": %s, \"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
 	       "\"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"late\": %d, \"wall_ms_per_tick\": %.4f, "
@@ -386,14 +403,15 @@ int main(int argc, char **argv) {
 	       "\"flush_rounds_per_tick_and_ticker\": %.2f, \"late_events\": %llu, \"probe_sink_blocks\": %d, \"probe_sink_bytes\": %zu, "
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
 	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
-	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s]}\n",
+	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s], "
+	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu}\n",
 	       g_paced ? "true" : "false", legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
 	       worst_t, worst_i, jobs[worst_i].step_ms[worst_t], jobs[worst_i].task_ms[worst_t], pct(sorted, g_ticks, 0.999), wall_ms / g_ticks,
 	       max_backlog, ref_late_events, sum_cpu / ((double)g_ticks * g_tickers), (double)sum_flt / ((double)g_ticks * g_tickers),
-	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow);
+	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes);
 	fflush(stdout);
 	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
 	if (getenv("PLUGIN_BENCH_CLEAN_EXIT")) exit(0); /* (under rocprofv3: its summary is written by an exit handler) */
