@@ -899,7 +899,7 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
         for _ in range(3):
             up = int(best["legs"] * 1.25) // step * step
             try:
-                d = run(up, ticks, paced_env)
+                d = run(up, min(ticks, 600), paced_env)
             except Exception:
                 break
             if log:
