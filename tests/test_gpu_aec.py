@@ -90,6 +90,7 @@ def _run_pair(ctx, oracle, rate, F, tail_ms, nstreams, nframes, postfilter, scen
 
 @pytest.mark.parametrize("rate,F,tail_ms", [(48000, 256, 128), (16000, 128, 128), (8000, 64, 128),
                                           (16000, 128, 512),   # M = 64 blocks: the kernels' limit
+                                          (8000, 64, 512),     # ... over the 16 lanes a leg has at 8 kHz
                                           (48000, 256, 341)])  # M = 64 at 48 kHz
 def test_mdf_bit_exact_before_adaptation(ctx, oracle, rate, F, tail_ms):
     """First frames from zero state: outputs, W, foreground, X history and every control scalar
@@ -309,7 +310,8 @@ def test_aec_state_blob_resumes_bit_for_bit(ctx, rate, F):
         x.close()
 
 
-@pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(16000, 128, 128, True), (8000, 64, 128, True), (8000, 64, 250, False), (16000, 128, 512, True)])
+@pytest.mark.parametrize("rate,F,tail_ms,postfilter", [(16000, 128, 128, True), (8000, 64, 128, True), (8000, 64, 250, False), (16000, 128, 512, True),
+                                                       (8000, 64, 512, True)])  # (64 blocks over 16 lanes: four blocks' norms and steps per lane)
 def test_group_form_equals_one_leg_per_wavefront(ctx, rate, F, tail_ms, postfilter):
     """The small frame sizes handed in as rows run several legs per wavefront (aec_group.hpp: four at 8 kHz, two at 16 kHz);
     the FIFO entries and MSMI355X_AEC_GROUP=0 keep one leg per wavefront (aec_tick.hpp).  Same arithmetic in the same order
@@ -320,8 +322,8 @@ def test_group_form_equals_one_leg_per_wavefront(ctx, rate, F, tail_ms, postfilt
     L = _lib.load()
     L.mi_debug_aec_group_form.argtypes = [C.c_int]
     L.mi_debug_aec_group_form.restype = None
-    n, nframes = 7, 260
     flen = tail_ms * rate // 1000
+    n, nframes = 7, (260 if flen // F <= 32 else 460)  # (the library's adaptation flag needs more than one frame per filter block)
     a_grp = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
     a_one = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
     a_mix = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)   # changes form every 7 frames
