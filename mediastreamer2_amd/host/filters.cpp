@@ -550,6 +550,10 @@ struct ResampleData;
 struct SpeexECState;
 void leg_stage_mic(MSFilter *f, ResampleData *d);
 void leg_take_far_end(MSFilter *f, SpeexECState *s);
+void leg_stage_mic_ec(MSFilter *f, SpeexECState *s);
+MSFilter *leg_find_mixer_ec(MSFilter *ec);
+bool leg_try_fuse_plain_ec(MSFilter *ec);
+bool leg_has_resampler(FusedLeg *leg);
 MSFilter *leg_find_mixer(MSFilter *rs);
 bool conf_try_fuse(MSFilter *mixer);
 void conf_unfuse(MSFilter *mixer, bool keep_running);

@@ -143,6 +143,7 @@ struct SpeexECState { // speexec.c:49-72
 	EcPool *pool;
 	int slot;
 	FusedLeg *leg; // the filter is part of a fused call leg (filters/leg_chain.inl): its canceller and queues live in that bank
+	bool fuse_checked; // as the HEAD of a leg (no MSResample of ours in front): looked for a chain to fuse with since the last attach
 };
 
 void ec_init(MSFilter *f) { // speexec.c:74-109
@@ -215,6 +216,7 @@ void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 void ec_prepare(MSFilter *f) { // (hub locked by the caller)
 	SpeexECState *s = (SpeexECState *)f->data;
 	s->echostarted = FALSE;
+	s->fuse_checked = false;
 	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
 	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
 	if (s->framesize != 64 && s->framesize != 128 && s->framesize != 256) {
@@ -279,6 +281,7 @@ void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at deta
 	SpeexECState *s = (SpeexECState *)f->data;
 	facade_detached(f);
 	if (s->leg) leg_release(s->leg, false);
+	s->fuse_checked = false;
 	HubLock lk(f);
 	ms_bufferizer_flush(&s->delayed_ref);
 	ms_bufferizer_flush(&s->echo);
@@ -342,9 +345,22 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 // (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
 void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	if (s->leg) { // fused leg: the microphone pin is fed on the device; the far end is staged for the leg's delay line
+	if (!s->leg && !s->fuse_checked && s->pool && f->ticker && !s->bypass_mode && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
+		// the first microphone block since the attach, and no MSResample of ours in front (behind one, the resampler is the leg's
+		// head and has looked already): is this the head of  MSSpeexEC -> MSVolume (AGC) -> [conference mixer | anything else] ?
+		s->fuse_checked = true;
+		MSFilter *prev = f->inputs[1]->prev.filter;
+		if (prev && prev->desc != &ms_mi355x_resample_desc) {
+			HubLock lk(f, s->pool);
+			if (MSFilter *mx = leg_find_mixer_ec(f)) conf_try_fuse(mx);
+			else leg_try_fuse_plain_ec(f);
+		}
+	}
+	if (s->leg && !leg_has_resampler(s->leg) && leg_wants_out(s->leg)) leg_release(s->leg, true); // (behind an MSResample that filter does this)
+	if (s->leg) { // fused leg: the microphone is staged (by the leg's MSResample, or here) for the device, the far end for the leg's delay line
 		HubLock lk(f, leg_pool(s->leg));
 		leg_take_far_end(f, s);
+		if (!leg_has_resampler(s->leg)) leg_stage_mic_ec(f, s);
 		return;
 	}
 	if (s->bypass_mode || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)

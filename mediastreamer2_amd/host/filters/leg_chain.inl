@@ -40,6 +40,8 @@ struct FusedLeg {
 	int slot, pin;
 	MSFilter *rs, *ec, *vol, *mixer;
 	int staged_mic = 0;  // 10 ms blocks staged since the last flush (launch rounds)
+	int framed_mic = 0;  // ... of which the framing below has already counted (a leg headed by MSSpeexEC frames as it stages)
+	int pre_frames = 0;  // frames that framing found since the last flush
 	int staged_ref = 0;  // far-end samples staged since the last flush
 	int inject = 0;      // samples of silence the framing put behind them (speexec.c:261-272)
 	int echo_level = 0;  // MSSpeexEC's `echo` bufferizer, samples: what f_mic holds
@@ -65,7 +67,7 @@ void mix_slab_release(void *payload) { // db_freefn of the slab's data block (th
 }
 
 int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t now); // mixer.inl
-void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes);
+void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes, bool immediate);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
 void leg_conf_walked(LegBank *b, int c);
 void leg_far_walked(LegBank *b, FusedLeg *leg);
@@ -155,7 +157,7 @@ struct LegBank : Pool {
 		mic_cap = frames_up(2 * ns + 2 * F, F);
 		out_cap = frames_up(4 * ns + kMaxRounds * 2 * F, F);
 		ref_cap = frames_up(delay + (3 + kLegRefOver) * ns + kMaxRounds * 2 * F, F);
-		if (!failed) MI_MUST(mi_resampler_create(hub->ctx, nlegs, in_rate, rate, 3, &rs));
+		if (!failed && in_rate != rate) MI_MUST(mi_resampler_create(hub->ctx, nlegs, in_rate, rate, 3, &rs)); // (no MSResample in front: the microphone arrives at the canceller's rate)
 		if (!failed) MI_MUST(mi_aec_create(hub->ctx, nlegs, (int)rate, F, flen, &aec));
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, mic_cap, &f_mic));
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, ref_cap, &f_ref));
@@ -232,14 +234,17 @@ struct LegBank : Pool {
 	}
 
 	// ---- the canceller's framing for everything a leg staged since the last flush: the while loop of speexec.c:256-305
-	int ec_frames(FusedLeg *leg) {
+	// immediate: called from MSSpeexEC's own process() (it is the leg's head): the speaker frames leave in that tick, as they do
+	// from the reference's filter; otherwise (behind an MSResample, whose output reaches the canceller a tick later) with the flush
+	int ec_frames(FusedLeg *leg, bool immediate = false) {
 		SpeexECState *es = (SpeexECState *)leg->ec->data;
-		leg->echo_level += leg->staged_mic * ns;
+		leg->echo_level += (leg->staged_mic - leg->framed_mic) * ns;
+		leg->framed_mic = leg->staged_mic;
 		int nfr = 0;
 		while (leg->echo_level >= F) {
 			leg->echo_level -= F;
 			es->echostarted = TRUE;
-			leg_speaker_frame(leg->ec, es, leg, (size_t)F * 2);
+			leg_speaker_frame(leg->ec, es, leg, (size_t)F * 2, immediate);
 			leg->dref_level -= F; // the frame the canceller reads from the head of the delay line
 			++nfr;
 		}
@@ -329,8 +334,12 @@ struct LegBank : Pool {
 			const int16_t *mic_r = h_mic + (size_t)r * L * in_len;
 			if (!zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_mic, mic_r, UL * in_len * 2));
 			step("microphones up");
-			MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, zc ? mic_r : d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
-			                                              MI_AEC_POSTFILTER, nullptr, (zc ? h_gate : d_gate) + (size_t)r * L));
+			if (rs)
+				MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, zc ? mic_r : d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
+				                                              MI_AEC_POSTFILTER, nullptr, (zc ? h_gate : d_gate) + (size_t)r * L));
+			else // the microphone block as it came: queued by the same launch, no up-sampler in front
+				MI_MUST(mi_aec_process_fifos_masked(aec, f_mic, zc ? mic_r : d_mic, in_len, f_ref, d_ref, ns, d_zero, ns, f_out, MI_AEC_MAX_TICK_FRAMES,
+				                                    MI_AEC_POSTFILTER, nullptr, (zc ? h_gate : d_gate) + (size_t)r * L));
 			step("cancellers launched");
 			launches += 2, any = true; // (the canceller's launch and the turn-over of its leg lists behind it)
 		}
@@ -418,7 +427,8 @@ struct LegBank : Pool {
 			for (int r = 0; r < kMaxRounds; ++r) h_gate[(size_t)r * L + s] = leg && r < leg->staged_mic;
 			if (!leg) continue;
 			rounds = std::max(rounds, leg->staged_mic);
-			const int nfr = failed ? 0 : ec_frames(leg);
+			const int nfr = failed ? 0 : ec_frames(leg) + leg->pre_frames;
+			leg->pre_frames = leg->framed_mic = 0;
 			h_cnt[s] = std::min(leg->staged_ref, ns);
 			h_cnt[L + s] = leg->staged_ref - h_cnt[s];
 			h_cnt[2 * L + s] = leg->inject;
@@ -573,13 +583,18 @@ struct LegBank : Pool {
 };
 
 // one speaker frame per microphone frame, on counts: ec_emit_speaker_frame with the delay line on the device
-void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes) {
+void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes, bool immediate) {
 	const int fs = (int)(nbytes / 2);
 	LegBank *b = leg->bank;
+	auto hand_on = [&](mblk_t *m) {
+		if (!f->outputs[0]) freemsg(m);
+		else if (immediate) ms_queue_put(f->outputs[0], m); // (inside MSSpeexEC's process())
+		else b->spk.push_back({f->outputs[0], m});          // (handed on with the flush's results, see LegBank::finish)
+	};
 	if (leg->dref_level < s->nominal_ref_samples + fs) {
 		leg->inject += fs; // behind everything the far end delivered so far (ms_bufferizer_put(&s->delayed_ref, silence))
 		leg->dref_level += fs;
-		if (f->outputs[0]) b->spk.push_back({f->outputs[0], ec_block(nbytes)});
+		hand_on(ec_block(nbytes));
 		if (!s->using_zeroes) ms_warning("Not enough ref samples, using zeroes");
 		s->using_zeroes = TRUE;
 		return;
@@ -591,8 +606,7 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 		ms_error("mi355x echo canceller: the far-end bufferizer ran dry; silence sent to the speaker");
 		memset(m->b_rptr, 0, nbytes);
 	}
-	if (f->outputs[0]) b->spk.push_back({f->outputs[0], m}); // (handed on with the flush's results, see LegBank::finish)
-	else freemsg(m);
+	hand_on(m);
 }
 
 // Every conference of the bank has been walked in this tick (its mixer runs behind all of its legs in the ticker's
@@ -639,6 +653,24 @@ void leg_stage_mic(MSFilter *f, ResampleData *d) {
 		leg->staged_mic++;
 	}
 	if (leg->staged_mic) {
+		b->staged_since = true;
+		request_flush(f);
+	}
+}
+
+// MSSpeexEC as the HEAD of a leg (no MSResample in front of it: the sound card or decoder already runs at the canceller's rate):
+// its microphone pin's blocks, re-framed to 10 ms through the filter's own `echo` bufferizer, into the bank's staging rows
+void leg_stage_mic_ec(MSFilter *f, SpeexECState *s) {
+	FusedLeg *leg = s->leg;
+	LegBank *b = leg->bank;
+	ms_bufferizer_put_from_queue(&s->echo, f->inputs[1]);
+	const size_t nbytes = (size_t)b->in_len * 2;
+	while (ms_bufferizer_get_avail(&s->echo) >= nbytes && leg->staged_mic < kMaxRounds) { // (more than kMaxRounds blocks: the rest next tick)
+		ms_bufferizer_read(&s->echo, (uint8_t *)(b->h_mic + ((size_t)leg->staged_mic * b->nlegs + (size_t)leg->slot) * b->in_len), nbytes);
+		leg->staged_mic++;
+	}
+	if (leg->staged_mic) {
+		leg->pre_frames += b->ec_frames(leg, true); // speexec.c:256-288 for the blocks just staged: their speaker frames leave now
 		b->staged_since = true;
 		request_flush(f);
 	}
@@ -711,7 +743,12 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
-	if (!rs || rs->desc != &ms_mi355x_resample_desc || rs->ticker != mx->ticker || !ms_queue_empty(qr)) return false;
+	if (!rs || rs->ticker != mx->ticker) return false;
+	if (rs->desc != &ms_mi355x_resample_desc) { // anything else feeds the canceller at its own rate: MSSpeexEC is the leg's head
+		c.rs = nullptr, c.ec = ec, c.vol = vol, c.pin = pin;
+		return true;
+	}
+	if (!ms_queue_empty(qr)) return false;
 	ResampleData *rd = (ResampleData *)rs->data;
 	if (rd->in_nchannels != 1 || rd->out_nchannels != 1 || (int)rd->output_rate != ms->rate || !leg_rates_ok(rd->input_rate, rd->output_rate)) return false;
 	if (rd->leg || ms_bufferizer_get_avail(rd->bz) || (rd->pool && rd->pool->staged[(size_t)rd->slot])) return false;
@@ -737,12 +774,12 @@ bool conf_try_fuse(MSFilter *mx) {
 	}
 	if (cand.empty()) return false;
 	const SpeexECState *e0 = (const SpeexECState *)cand[0].ec->data;
-	const ResampleData *r0 = (const ResampleData *)cand[0].rs->data;
+	const uint32_t ir0 = cand[0].rs ? ((const ResampleData *)cand[0].rs->data)->input_rate : (uint32_t)ms->rate; // (no MSResample: the leg comes in at the mixer's rate)
 	for (const LegCand &c : cand) { // one shape per conference (a bank is one shape)
 		const SpeexECState *e = (const SpeexECState *)c.ec->data;
-		const ResampleData *r = (const ResampleData *)c.rs->data;
+		const uint32_t ir_c = c.rs ? ((const ResampleData *)c.rs->data)->input_rate : (uint32_t)ms->rate;
 		if (e->framesize != e0->framesize || e->filterlength != e0->filterlength || e->nominal_ref_samples != e0->nominal_ref_samples ||
-		    r->input_rate != r0->input_rate)
+		    ir_c != ir0 || (c.rs == nullptr) != (cand[0].rs == nullptr))
 			return false;
 	}
 	int mm = MIXER_MAX_CHANNELS;
@@ -751,7 +788,7 @@ bool conf_try_fuse(MSFilter *mx) {
 			mm = m;
 			break;
 		}
-	const uint32_t ir = r0->input_rate, rate = (uint32_t)ms->rate;
+	const uint32_t ir = ir0, rate = (uint32_t)ms->rate;
 	const int F = e0->framesize, flen = e0->filterlength, delay = e0->nominal_ref_samples;
 	LegBank *b = bank<LegBank>("leg:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
 	                               std::to_string(delay) + ":" + std::to_string(mm),
@@ -762,7 +799,7 @@ bool conf_try_fuse(MSFilter *mx) {
 	// ---- the legs: fresh per-leg state at their slots (what the filters' own banks hold at this point), then the facades let
 	// go of their own slots
 	const int s0 = c * mm;
-	bool ok = mi_resampler_reset(b->rs, s0, mm) == MI_OK && mi_aec_reset(b->aec, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_mic, s0, mm) == MI_OK &&
+	bool ok = (!b->rs || mi_resampler_reset(b->rs, s0, mm) == MI_OK) && mi_aec_reset(b->aec, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_mic, s0, mm) == MI_OK &&
 	          mi_fifo_reset_range(b->f_ref, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_out, s0, mm) == MI_OK && mi_volume_reset_max(b->vol, s0, mm) == MI_OK;
 	std::vector<int32_t> fill((size_t)b->nlegs, 0);
 	for (const LegCand &cd : cand) {
@@ -800,11 +837,13 @@ bool conf_try_fuse(MSFilter *mx) {
 		leg->rs = cd.rs, leg->ec = cd.ec, leg->vol = cd.vol, leg->mixer = mx;
 		leg->dref_level = delay;
 		b->legs[(size_t)leg->slot] = leg;
-		ResampleData *rd = (ResampleData *)cd.rs->data;
 		SpeexECState *es = (SpeexECState *)cd.ec->data;
 		VolumeData *vd = (VolumeData *)cd.vol->data;
-		if (rd->pool) resample_release(rd);
-		rd->leg = leg;
+		if (cd.rs) {
+			ResampleData *rd = (ResampleData *)cd.rs->data;
+			if (rd->pool) resample_release(rd);
+			rd->leg = leg;
+		}
 		ms_bufferizer_flush(&es->delayed_ref); // the delay line lives on the device now
 		es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
 		es->pool->release(es->slot); // (the last release of a bank destroys it)
@@ -844,6 +883,16 @@ MSFilter *leg_find_mixer(MSFilter *rs) {
 	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
 }
 
+// ... and MSSpeexEC, when it is the head itself
+MSFilter *leg_find_mixer_ec(MSFilter *ec) {
+	MSQueue *q = ec->outputs[1];
+	MSFilter *vol = q ? q->next.filter : NULL;
+	if (!vol || vol->desc != &ms_mi355x_volume_desc) return NULL;
+	q = vol->outputs[0];
+	MSFilter *mx = q ? q->next.filter : NULL;
+	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
+}
+
 void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess (a bank slot of its own)
 void mixer_prepare(MSFilter *f); // mixer.inl
 
@@ -861,7 +910,7 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
 		if (!leg) continue;
 		b->legs[(size_t)(c * mm + pin)] = nullptr;
-		((ResampleData *)leg->rs->data)->leg = nullptr;
+		if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
 		((SpeexECState *)leg->ec->data)->leg = nullptr;
 		((VolumeData *)leg->vol->data)->leg = nullptr;
 		gone.push_back(leg);
@@ -882,23 +931,30 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 }
 
 // ---- a leg WITHOUT a mixer:  MSResample -> MSSpeexEC pin 1 -> MSVolume (AGC) -> any other filter, all ours on one ticker
+bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec);
 bool leg_try_fuse_plain(MSFilter *rs) {
-	if (getenv("MSMI355X_NO_FUSE") != nullptr || !rs->ticker || rs->ticker->interval != 10) return false;
-	ResampleData *rd = (ResampleData *)rs->data;
 	MSQueue *q = rs->outputs[0];
 	MSFilter *ec = q ? q->next.filter : NULL;
-	if (!ec || !is_ec_desc(ec->desc) || q->next.pin != 1 || ec->ticker != rs->ticker || !ms_queue_empty(q)) return false;
+	if (!ec || !is_ec_desc(ec->desc) || q->next.pin != 1 || !ms_queue_empty(q)) return false;
+	return leg_fuse_plain_at(rs, ec);
+}
+// the same with MSSpeexEC as the head (its microphone pin fed by anything but our MSResample)
+bool leg_try_fuse_plain_ec(MSFilter *ec) { return leg_fuse_plain_at(nullptr, ec); }
+bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
+	MSFilter *head = rs ? rs : ec;
+	if (getenv("MSMI355X_NO_FUSE") != nullptr || !head->ticker || head->ticker->interval != 10 || ec->ticker != head->ticker) return false;
+	ResampleData *rd = rs ? (ResampleData *)rs->data : nullptr;
 	SpeexECState *es = (SpeexECState *)ec->data;
-	if (es->bypass_mode || es->unsupported || !es->pool || es->echostarted || es->leg || (uint32_t)es->samplerate != rd->output_rate) return false;
+	if (es->bypass_mode || es->unsupported || !es->pool || es->echostarted || es->leg || (rd && (uint32_t)es->samplerate != rd->output_rate) || es->samplerate % 100) return false;
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	MSQueue *qv = ec->outputs[1];
 	MSFilter *vol = qv ? qv->next.filter : NULL;
-	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != rs->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
+	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != head->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (!vd->p.agc_enabled || vd->peer || vd->peered_by > 0 || vd->sample_rate != es->samplerate || vd->leg) return false;
 	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
-	if (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz)) return false;
-	const uint32_t ir = rd->input_rate, rate = rd->output_rate;
+	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
+	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
 	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;
 	LegBank *b = bank<LegBank>("legp:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
 	                               std::to_string(delay),
@@ -906,7 +962,7 @@ bool leg_try_fuse_plain(MSFilter *rs) {
 	const int s = b ? b->acquire(vol) : -1;
 	if (s < 0) return false;
 	note_slot(vol);
-	bool ok = mi_resampler_reset(b->rs, s, 1) == MI_OK && mi_aec_reset(b->aec, s, 1) == MI_OK && mi_fifo_reset_range(b->f_mic, s, 1) == MI_OK &&
+	bool ok = (!b->rs || mi_resampler_reset(b->rs, s, 1) == MI_OK) && mi_aec_reset(b->aec, s, 1) == MI_OK && mi_fifo_reset_range(b->f_mic, s, 1) == MI_OK &&
 	          mi_fifo_reset_range(b->f_ref, s, 1) == MI_OK && mi_fifo_reset_range(b->f_out, s, 1) == MI_OK && mi_volume_reset_max(b->vol, s, 1) == MI_OK;
 	mi_volume_state st;
 	memset(&st, 0, sizeof(st));
@@ -937,8 +993,10 @@ bool leg_try_fuse_plain(MSFilter *rs) {
 	leg->dref_level = delay;
 	b->legs[(size_t)s] = leg;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
-	if (rd->pool) resample_release(rd);
-	rd->leg = leg;
+	if (rd) {
+		if (rd->pool) resample_release(rd);
+		rd->leg = leg;
+	}
 	ms_bufferizer_flush(&es->delayed_ref);
 	es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
 	es->pool->release(es->slot);
@@ -950,7 +1008,8 @@ bool leg_try_fuse_plain(MSFilter *rs) {
 	}
 	vd->leg = leg;
 	b->staged_since = true;
-	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (MSResample -> MSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen);
+	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (%sMSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen,
+	           rs ? "MSResample -> " : "");
 	return true;
 }
 
@@ -960,7 +1019,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	const int s = leg->slot;
 	b->legs[(size_t)s] = nullptr;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
-	((ResampleData *)leg->rs->data)->leg = nullptr;
+	if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
 	((SpeexECState *)leg->ec->data)->leg = nullptr;
 	((VolumeData *)leg->vol->data)->leg = nullptr;
 	if (keep_running) {
@@ -977,6 +1036,7 @@ void leg_release(FusedLeg *leg, bool keep_running) {
 	else leg_unfuse_plain(leg, keep_running);
 }
 bool leg_wants_out(FusedLeg *leg) { return leg && !leg->mixer && leg->unfuse_wanted; }
+bool leg_has_resampler(FusedLeg *leg) { return leg && leg->rs != nullptr; }
 
 Pool *leg_pool(FusedLeg *leg) { return leg->bank; }
 Pool *leg_pool_of(LegBank *b) { return b; }

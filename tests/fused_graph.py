@@ -130,7 +130,7 @@ class Host:
 class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
-    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True):
+    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -161,8 +161,10 @@ class Conferences:
                     h.call_int(leg["vol"], VOL_ENABLE_AGC, 1)
                 if gain is not None:
                     h.call_float(leg["vol"], VOL_SET_GAIN, gain)
-                links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1), (leg["ec"], 1, leg["vol"], 0), (leg["far"], 0, leg["ec"], 0),
-                         (leg["ec"], 0, leg["spk"], 0)]
+                # (resampler=False: the sound card / decoder already runs at the canceller's rate -- MSSpeexEC is the head of the leg; the
+                # MSResample is created all the same and stays unlinked)
+                links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1)] if resampler else [(leg["mic"], 0, leg["ec"], 1)]
+                links += [(leg["ec"], 1, leg["vol"], 0), (leg["far"], 0, leg["ec"], 0), (leg["ec"], 0, leg["spk"], 0)]
                 links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
                 for a, pa, b, pb in links:
                     assert S.ms_filter_link(a, pa, b, pb) == 0
@@ -226,7 +228,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc = dict(nconf=2, members=4, nticks=120, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, pins=None)
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
-                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"))
+                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -286,6 +288,10 @@ SCENARIOS = {
     # an AudioStream's sending side, several streams on one ticker: MSVolume's chunks go on to another filter, there is no mixer
     "no_mixer": {"no_mixer": True, "nconf": 1, "members": 6, "delay_ms": 10, "far_gaps": True},
     "no_mixer_ptime20": {"no_mixer": True, "nconf": 1, "members": 5, "ptime20": True, "nticks": 100},
+    # no MSResample in front of the canceller (the card or the decoder runs at its rate already): MSSpeexEC is the head of the leg
+    "no_resampler": {"no_resampler": True, "in_rate": 48000, "delay_ms": 10, "far_gaps": True},
+    "no_resampler_16k_ptime20": {"no_resampler": True, "in_rate": 16000, "rate": 16000, "ptime20": True, "nticks": 100, "members": 3, "pins": [0, 2, 7]},
+    "no_resampler_no_mixer": {"no_resampler": True, "in_rate": 48000, "no_mixer": True, "nconf": 1, "members": 5, "far_gaps": True},
 }
 
 

@@ -263,13 +263,16 @@ static void *conferences(void *arg) {
 			set_int(l->rs, MS_FILTER_SET_SAMPLE_RATE, 16000), set_int(l->rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
 			set_int(l->ec, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
 			set_int(l->vol, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->vol, MS_VOLUME_ENABLE_AGC, 1);
-			ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1), ms_filter_link(l->ec, 1, l->vol, 0);
+			if (k == 0) ms_filter_link(l->mic, 0, l->ec, 1); /* no MSResample in front: MSSpeexEC is this leg's head (48 kHz microphone) */
+			else ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1);
+			ms_filter_link(l->ec, 1, l->vol, 0);
 			ms_filter_link(l->vol, 0, l->out, 0), ms_filter_link(l->far, 0, l->ec, 0), ms_filter_link(l->ec, 0, l->spk, 0);
 			CHECK(ms_ticker_attach(tk, l->mic) == 0);
 		}
 		for (int t = 0; t < 14; ++t) {
 			for (int k = 0; k < 3; ++k) {
-				ms2shim_source_push(solo[k].mic, mic, sizeof mic);
+				if (k == 0) ms2shim_source_push(solo[k].mic, far, sizeof far); /* (a 48 kHz block) */
+				else ms2shim_source_push(solo[k].mic, mic, sizeof mic);
 				if (t != 5 || k != 1) ms2shim_source_push(solo[k].far, far, sizeof far); /* a far end that skips a tick */
 			}
 			if (t == 7) { int off = 0; ms_filter_call_method(solo[2].vol, MS_VOLUME_ENABLE_AGC, &off); } /* that leg goes back to its facades */
@@ -294,7 +297,9 @@ static void *conferences(void *arg) {
 		for (int k = 0; k < 3; ++k) {
 			leg_t *l = &solo[k];
 			ms_ticker_detach(tk, l->mic);
-			ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1), ms_filter_unlink(l->ec, 1, l->vol, 0);
+			if (k == 0) ms_filter_unlink(l->mic, 0, l->ec, 1);
+			else ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1);
+			ms_filter_unlink(l->ec, 1, l->vol, 0);
 			ms_filter_unlink(l->vol, 0, l->out, 0), ms_filter_unlink(l->far, 0, l->ec, 0), ms_filter_unlink(l->ec, 0, l->spk, 0);
 			ms_filter_destroy(l->mic), ms_filter_destroy(l->far), ms_filter_destroy(l->rs), ms_filter_destroy(l->ec);
 			ms_filter_destroy(l->vol), ms_filter_destroy(l->spk), ms_filter_destroy(l->out);
