@@ -891,6 +891,11 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
         if log:
             log({"plugin_path": {k: d[k] for k in keep}})
         tried.append({k: d[k] for k in keep})
+        if not d["fits"]:  # the host's CPUs are shared with other tenants: a count gets a second run before it is given up (both are listed)
+            d = run(legs, ticks, paced_env)
+            if log:
+                log({"plugin_path": {k: d[k] for k in keep}})
+            tried.append({k: d[k] for k in keep})
         if d["fits"]:
             best = d
             break
@@ -909,7 +914,7 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
                 break
             best = d
     out = {"cadence": "paced: one tick per 10 ms of wall time on every ticker, as deployed (the launches leave at the end of a walk, the device works "
-                      "through the idle part of the interval); `back_to_back` = the same count with every tick fired as soon as the slowest ticker is "
+                      "through the idle part of the interval); `back_to_back` = config[3]'s count with every tick fired as soon as the slowest ticker is "
                       "done (the device never idle: a throughput figure, each tick waits for the previous one's launches)",
            "what": "full call legs through the drop-in plugin, PCIe included: source -> MSResample 16k->48k -> MSSpeexEC (128 ms tail) -> MSVolume (AGC) "
                    "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
@@ -934,13 +939,14 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
                                                     "previous graph walk are waited for and handed on (one wait per ticker); graph_walk = every filter's process(): "
                                                     "sources, staging into pinned rows, MSSpeexEC's speaker pin, sinks, then the bank's uploads and launches; the tick "
                                                     "is the slowest of the ticker threads, all ticking together"}})
-        try:
-            b = run(best["legs"], 600)
-            out["back_to_back"] = {k: b[k] for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "ticker_flush_ms", "ticker_graph_walk_ms", "us_per_leg_tick")}
-        except Exception as e:
-            out["back_to_back"] = {"error": str(e)[:200]}
     else:
         out.update({"fits": False, "legs": 0})
+    try:  # config[3]'s count fired back to back, whatever the paced verdict on this host was
+        b = run(first_legs, 600)
+        out["back_to_back"] = {k: b[k] for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "ticker_flush_ms",
+                                                  "ticker_graph_walk_ms", "us_per_leg_tick", "slow_ticks")}
+    except Exception as e:
+        out["back_to_back"] = {"error": str(e)[:200]}
     try:  # the same graph with every facade on its own bank (MSMI355X_NO_FUSE=1: four uploads, launches and waits per chain), for scale
         d = run(4096, 200, {"MSMI355X_NO_FUSE": "1"})
         out["facades_one_by_one_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
