@@ -32,6 +32,7 @@
 // queued on the device at that moment (a few ms) is lost.
 
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
+constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one enqueue: kMaxRounds blocks of 10 ms in frames
 constexpr int kLegMaxChunks = 5; // 10 ms chunks MSVolume can complete in one flush of a leg without a mixer (kMaxRounds blocks of 10 ms + what it held)
 
 struct LegBank;
@@ -49,6 +50,10 @@ struct FusedLeg {
 	int vol_rem = 0;     // MSVolume's bufferizer: cleaned samples short of a 10 ms chunk
 	int chan_chunks = 0; // the mixer channel's bufferizer: whole chunks waiting (f_out holds vol_rem + chan_chunks * ns)
 	int newchunks = 0;   // chunks MSVolume would have put on the mixer's queue in this flush
+	// MSVolume WITHOUT AGC (LegBank::light): the canceller's frames pass it one by one, the mixer channel holds samples
+	int lt_frames = 0;    // frames MSVolume meters in this enqueue
+	int new_samples = 0;  // samples it put on the mixer's queue since the mixer last looked
+	int chan_samples = 0; // the mixer channel's bufferizer, samples (what f_chan holds)
 	bool metered = false;
 	bool unfuse_wanted = false; // (a leg without a mixer: set by a method on any thread, honoured by the head's next process())
 	uint32_t far_tick = 0;      // ticker tick in which the far end was last taken (a bank without mixers leaves early on these)
@@ -139,6 +144,20 @@ struct LegBank : Pool {
 	// AudioStream (audiostream.c:1798-1810) whose streams share a ticker.  One slot = one leg (mm = 1), owned by its MSVolume,
 	// which hands the levelled 10 ms chunks on as they come out of mi_volume_process_fifo_flags (up to kLegMaxChunks a flush).
 	bool plain = false;
+	// A bank whose MSVolumes run WITHOUT AGC (the reference's default: audio_stream_enable_automatic_gain_control is off unless
+	// asked for): volume_process then meters and levels every incoming block as it is -- the canceller's frames of F samples -- and
+	// has no bufferizer (msvolume.c:505-513).  The frames are levelled where they lie in the output queue, one launch per frame
+	// of the tick (mi_volume_process_fifo_flags on F samples), and go on to the mixer channel's queue on the device (f_chan), from
+	// which the conference is mixed (volmix_kernel with an identity volume batch: pop + mix); without a mixer they are handed on
+	// frame by frame (chunk = F).
+	bool light = false;
+	int chunk = 0;                 // samples of a block MSVolume hands on: 10 ms with AGC, a canceller frame without
+	mi_volume *vol_id = nullptr;   // identity batch (gain 1, nothing enabled): volmix_kernel's volume half for the levelled queue
+	mi_fifo *f_chan = nullptr;     // the mixer channels' bufferizers
+	int16_t *d_lev = nullptr;      // [nlegs][F] a round's levelled frames
+	int32_t *h_fcnt = nullptr, *d_fcnt = nullptr; // [kLegLightRounds][nlegs]: F where the leg has a frame in that round, else 0
+	uint8_t *h_dgate = nullptr, *d_dgate = nullptr; // [nlegs]: the leg the channels' flow control drops samples of (rare)
+	std::vector<std::pair<int, int>> sdrops;      // (leg slot, samples) of those drops
 	std::vector<int> nout, nready; // chunks a leg's MSVolume completes in this flush / has ready to hand on
 	struct GainPatch {
 		float gain, target;
@@ -147,10 +166,11 @@ struct LegBank : Pool {
 	std::vector<GainPatch> vpatch; // MS_VOLUME_SET_GAIN & co. on a fused leg: the two fields, set on the state as the device holds it
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
-	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false)
-	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer) {
+	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false, bool no_agc = false)
+	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer), light(no_agc) {
 		Building b(this, cap_conf);
 		ns = (int)rate / 100;
+		chunk = light ? F : ns;
 		in_len = (int)in_rate / 100;
 		den = (int)(rate / in_rate);
 		nlegs = capacity * mm;
@@ -165,6 +185,15 @@ struct LegBank : Pool {
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, (int)rate, &vol));
 		if (!failed && !plain) MI_MUST(mi_mixer_create(hub->ctx, capacity, mm, ns, &mix));
 		const size_t L = (size_t)nlegs;
+		if (light && !plain) {
+			if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, (int)rate, &vol_id));
+			if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, out_cap, &f_chan));
+			d_lev = devmem<int16_t>(L * F);
+			h_fcnt = pinned<int32_t>(kLegLightRounds * L);
+			d_fcnt = devmem<int32_t>(kLegLightRounds * L);
+			h_dgate = pinned<uint8_t>(L);
+			d_dgate = devmem<uint8_t>(L);
+		}
 		h_mic = pinned<int16_t>(kMaxRounds * L * in_len);
 		d_mic = devmem<int16_t>(L * in_len);
 		h_gate = pinned<uint8_t>(kMaxRounds * L);
@@ -178,8 +207,8 @@ struct LegBank : Pool {
 		d_zero = devmem<int32_t>(L);
 		d_mix = devmem<int16_t>((plain ? kLegMaxChunks : 1) * L * ns);
 		d_scratch = devmem<int16_t>(L * ns);
-		h_lv = pinned<int32_t>(3 * L);
-		d_lv = devmem<int32_t>(3 * L);
+		h_lv = pinned<int32_t>(4 * L);
+		d_lv = devmem<int32_t>(4 * L);
 		h_vstate = pinned<mi_volume_state>(L);
 		h_copy = pinned<int16_t>((plain ? kLegMaxChunks : 1) * L * ns);
 		nout.assign(L, 0);
@@ -213,6 +242,8 @@ struct LegBank : Pool {
 		if (hub->ctx) mi_ctx_sync(hub->ctx);
 		if (mix) mi_mixer_destroy(mix);
 		if (vol) mi_volume_destroy(vol);
+		if (vol_id) mi_volume_destroy(vol_id);
+		if (f_chan) mi_fifo_destroy(f_chan);
 		for (mi_fifo *f : {f_mic, f_ref, f_out})
 			if (f) mi_fifo_destroy(f);
 		if (aec) mi_aec_destroy(aec);
@@ -264,7 +295,7 @@ struct LegBank : Pool {
 			if (!leg) continue;
 			uint64_t &seen = s->channels[pin].last_activity;
 			bool contributes;
-			if (leg->newchunks > 0) {
+			if (light ? leg->new_samples > 0 : leg->newchunks > 0) {
 				seen = now;
 				contributes = true;
 			} else if (seen == (uint64_t)-1) {
@@ -283,6 +314,19 @@ struct LegBank : Pool {
 			FusedLeg *leg = legs[(size_t)(c * mm + pin)];
 			if (!leg) continue;
 			Channel *chan = &s->channels[pin];
+			if (light) { // the channel's bufferizer holds the levelled frames, the tick reads 10 ms of them or nothing (:78-90)
+				leg->chan_samples += leg->new_samples;
+				leg->new_samples = 0;
+				if (leg->chan_samples >= ns) leg->chan_samples -= ns;
+				const int skip = channel_flow_control_level(chan, leg->chan_samples * 2, s->skip_threshold, now);
+				if (skip > 0) {
+					const int k = std::min(leg->chan_samples, skip / 2);
+					ms_warning("mi355x mixer: pin %i kept more than two ticks queued for 5 s; %i samples discarded", pin, k);
+					leg->chan_samples -= k;
+					if (k > 0) sdrops.push_back({leg->slot, k});
+				}
+				continue;
+			}
 			leg->chan_chunks += leg->newchunks; // ms_bufferizer_put_from_queue, channel_process_in :78-90
 			leg->newchunks = 0;
 			if (leg->chan_chunks > 0) { // ... and the read of one tick (the device pops it: the queue holds a whole chunk)
@@ -366,10 +410,10 @@ struct LegBank : Pool {
 			uint8_t *dst = cur ? cur->payload() : reinterpret_cast<uint8_t *>(h_copy);
 			int16_t *rows = zero_copy ? reinterpret_cast<int16_t *>(dst) : d_mix;
 			for (int r = 0; r < maxc; ++r) { // (rows of round r start behind what a leg still has ready from an earlier enqueue of this flush)
-				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, rows + (size_t)r * L * ns, ns, ns, MI_VOLMIX_DRY_SKIPS));
+				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, rows + (size_t)r * L * chunk, chunk, chunk, MI_VOLMIX_DRY_SKIPS));
 				++launches;
 			}
-			if (!zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, dst, d_mix, ((size_t)(maxc - 1) * L + UL) * ns * 2));
+			if (!zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, dst, d_mix, ((size_t)(maxc - 1) * L + UL) * chunk * 2));
 			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 			mixed = true;
 			any = true;
@@ -419,11 +463,13 @@ struct LegBank : Pool {
 			v_dirty = false;
 		}
 		// ---- the host's half: framing decisions leg by leg
-		int rounds = 0;
+		int rounds = 0, light_rounds = 0;
 		bool any_ref = false, any_refx = false, any_inj = false;
 		for (size_t s = 0; s < UL; ++s) {
 			FusedLeg *leg = legs[s];
 			h_cnt[s] = h_cnt[L + s] = h_cnt[2 * L + s] = 0;
+			if (light && !plain && !leg)
+				for (int r = 0; r < kLegLightRounds; ++r) h_fcnt[(size_t)r * L + s] = 0;
 			for (int r = 0; r < kMaxRounds; ++r) h_gate[(size_t)r * L + s] = leg && r < leg->staged_mic;
 			if (!leg) continue;
 			rounds = std::max(rounds, leg->staged_mic);
@@ -436,11 +482,22 @@ struct LegBank : Pool {
 			any_refx |= h_cnt[L + s] > 0;
 			any_inj |= leg->inject > 0;
 			leg->staged_mic = leg->staged_ref = leg->inject = 0;
-			leg->vol_rem += nfr * F; // MSVolume's re-framing to 10 ms chunks (msvolume.c:480-486)
-			leg->newchunks += leg->vol_rem / ns;
-			leg->vol_rem %= ns;
+			if (light && plain) {
+				leg->newchunks += nfr; // (handed on frame by frame: a "chunk" of this bank is a frame)
+			} else if (light) {
+				leg->lt_frames = std::min(nfr, kLegLightRounds);
+				leg->new_samples += leg->lt_frames * F;
+				leg->metered |= nfr > 0;
+				light_rounds = std::max(light_rounds, leg->lt_frames);
+				for (int r = 0; r < kLegLightRounds; ++r) h_fcnt[(size_t)r * L + s] = r < leg->lt_frames ? F : 0;
+			} else {
+				leg->vol_rem += nfr * F; // MSVolume's re-framing to 10 ms chunks (msvolume.c:480-486)
+				leg->newchunks += leg->vol_rem / ns;
+				leg->vol_rem %= ns;
+			}
 		}
 		drops.clear();
+		sdrops.clear();
 		mark(1);
 		if (plain) return enqueue_plain(any_ref, any_refx, any_inj, rounds);
 		bool ticked = false;
@@ -457,11 +514,31 @@ struct LegBank : Pool {
 		mark(2);
 		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
 		mark(3);
+		if (light && light_rounds) { // MSVolume without AGC: every frame of the tick metered and levelled as a block of its own, then on to the channel's queue
+			if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_fcnt, h_fcnt, (size_t)light_rounds * L * 4));
+			for (int r = 0; r < light_rounds; ++r) {
+				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, d_lev, F, F, MI_VOLMIX_DRY_SKIPS));
+				MI_MUST(mi_fifo_push(f_chan, d_lev, F, F, (zero_copy ? h_fcnt : d_fcnt) + (size_t)r * L));
+				launches += 2;
+			}
+			if (!ticked) MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
+			mixed = true;
+			any = true;
+		}
 		if (ticked) {
 			if (!cur) cur = free_slab();
 			int16_t *host_rows = reinterpret_cast<int16_t *>(cur ? (void *)cur->payload() : (void *)h_copy);
 			if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_run, h_run, (size_t)capacity));
-			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol, 0, f_out, zero_copy ? host_rows : d_mix, MI_VOLMIX_DRY_SKIPS, zero_copy ? h_run : d_run));
+			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, light ? vol_id : vol, 0, light ? f_chan : f_out, zero_copy ? host_rows : d_mix, MI_VOLMIX_DRY_SKIPS,
+			                                           zero_copy ? h_run : d_run));
+			for (const auto &dk : sdrops) { // samples the channels' flow control discards (rare: a pin that kept two ticks queued for 5 s)
+				memset(h_dgate, 0, L);
+				h_dgate[(size_t)dk.first] = 1;
+				if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_dgate, h_dgate, L));
+				for (int left = dk.second; left > 0; left -= std::min(left, ns))
+					MI_MUST(mi_fifo_pop(f_chan, std::min(left, ns), d_scratch, ns, nullptr, zero_copy ? h_dgate : d_dgate, 0));
+				sync_stream(); // (the gate row is rewritten for the next one)
+			}
 			mark(4);
 			++launches;
 			for (const auto &dk : drops) // chunks the channels' flow control discards: metered (MSVolume saw them), never mixed
@@ -485,7 +562,8 @@ struct LegBank : Pool {
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
-			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, 3 * L * 4));
+			if (f_chan) MI_MUST(mi_fifo_levels(f_chan, d_lv + 3 * L));
+			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, 4 * L * 4));
 		}
 		outstanding |= any;
 		return any;
@@ -524,7 +602,11 @@ struct LegBank : Pool {
 			for (size_t s = 0; s < UL; ++s) {
 				FusedLeg *leg = legs[s];
 				if (!leg) continue;
-				const int want_out = leg->vol_rem + (leg->chan_chunks + leg->newchunks) * ns;
+				const int want_out = light ? (plain ? leg->newchunks * F : 0) : leg->vol_rem + (leg->chan_chunks + leg->newchunks) * ns;
+				if (light && !plain && h_lv[3 * L + s] != leg->chan_samples + leg->new_samples) {
+					ms_error("mi355x fused leg %d: the mixer channel's queue holds %d samples, the host's framing says %d", (int)s, h_lv[3 * L + s], leg->chan_samples + leg->new_samples);
+					g_late_events.fetch_add(1, std::memory_order_relaxed);
+				}
 				if (h_lv[s] != leg->echo_level || h_lv[L + s] != leg->dref_level || h_lv[2 * L + s] != want_out) {
 					ms_error("mi355x fused leg %d: device queues (%d, %d, %d) differ from the host's framing (%d, %d, %d)", (int)s, h_lv[s], h_lv[L + s],
 					         h_lv[2 * L + s], leg->echo_level, leg->dref_level, want_out);
@@ -537,16 +619,16 @@ struct LegBank : Pool {
 		if (plain) { // the leg's MSVolume hands its levelled chunks on (volume_process :500-502)
 			const uint8_t *base = root ? cur->payload() : reinterpret_cast<const uint8_t *>(h_copy);
 			for (int r = 0; r < nready[(size_t)c]; ++r) {
-				uint8_t *row = const_cast<uint8_t *>(base) + (((size_t)r * nlegs + (size_t)c) * ns) * 2;
+				uint8_t *row = const_cast<uint8_t *>(base) + (((size_t)r * nlegs + (size_t)c) * chunk) * 2;
 				mblk_t *om;
 				if (root) {
 					om = dupb(root);
 					om->b_rptr = row;
-					om->b_wptr = row + (size_t)ns * 2;
+					om->b_wptr = row + (size_t)chunk * 2;
 				} else {
-					om = allocb((size_t)ns * 2, 0);
-					memcpy(om->b_wptr, row, (size_t)ns * 2);
-					om->b_wptr += ns * 2;
+					om = allocb((size_t)chunk * 2, 0);
+					memcpy(om->b_wptr, row, (size_t)chunk * 2);
+					om->b_wptr += chunk * 2;
 				}
 				if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
 				else freemsg(om);
@@ -733,7 +815,7 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	MSFilter *vol = q->prev.filter;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (!vd->p.agc_enabled || vd->peer || vd->peered_by > 0 || vd->sample_rate != ms->rate || vd->leg) return false;
+	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
 	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
 	MSQueue *qe = vol->inputs[0];
 	MSFilter *ec = qe ? qe->prev.filter : NULL;
@@ -779,9 +861,11 @@ bool conf_try_fuse(MSFilter *mx) {
 		const SpeexECState *e = (const SpeexECState *)c.ec->data;
 		const uint32_t ir_c = c.rs ? ((const ResampleData *)c.rs->data)->input_rate : (uint32_t)ms->rate;
 		if (e->framesize != e0->framesize || e->filterlength != e0->filterlength || e->nominal_ref_samples != e0->nominal_ref_samples ||
-		    ir_c != ir0 || (c.rs == nullptr) != (cand[0].rs == nullptr))
+		    ir_c != ir0 || (c.rs == nullptr) != (cand[0].rs == nullptr) ||
+		    (((VolumeData *)c.vol->data)->p.agc_enabled != 0) != (((VolumeData *)cand[0].vol->data)->p.agc_enabled != 0))
 			return false;
 	}
+	const bool no_agc = !((VolumeData *)cand[0].vol->data)->p.agc_enabled;
 	int mm = MIXER_MAX_CHANNELS;
 	for (int m : {4, 8, 16, 32})
 		if (maxpin < m) {
@@ -791,8 +875,8 @@ bool conf_try_fuse(MSFilter *mx) {
 	const uint32_t ir = ir0, rate = (uint32_t)ms->rate;
 	const int F = e0->framesize, flen = e0->filterlength, delay = e0->nominal_ref_samples;
 	LegBank *b = bank<LegBank>("leg:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
-	                               std::to_string(delay) + ":" + std::to_string(mm),
-	                           1, [&](int cap) { return new LegBank(std::max(1, cap * 4 / mm), ir, rate, F, flen, delay, mm); }); // 64, 256, 1024, .. legs
+	                               std::to_string(delay) + ":" + std::to_string(mm) + (no_agc ? ":light" : ""),
+	                           1, [&](int cap) { return new LegBank(std::max(1, cap * 4 / mm), ir, rate, F, flen, delay, mm, false, no_agc); }); // 64, 256, 1024, .. legs
 	const int c = b ? b->acquire(mx) : -1;
 	if (c < 0) return false;
 	note_slot(mx);
@@ -800,7 +884,8 @@ bool conf_try_fuse(MSFilter *mx) {
 	// go of their own slots
 	const int s0 = c * mm;
 	bool ok = (!b->rs || mi_resampler_reset(b->rs, s0, mm) == MI_OK) && mi_aec_reset(b->aec, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_mic, s0, mm) == MI_OK &&
-	          mi_fifo_reset_range(b->f_ref, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_out, s0, mm) == MI_OK && mi_volume_reset_max(b->vol, s0, mm) == MI_OK;
+	          mi_fifo_reset_range(b->f_ref, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_out, s0, mm) == MI_OK && mi_volume_reset_max(b->vol, s0, mm) == MI_OK &&
+	          (!b->f_chan || mi_fifo_reset_range(b->f_chan, s0, mm) == MI_OK);
 	std::vector<int32_t> fill((size_t)b->nlegs, 0);
 	for (const LegCand &cd : cand) {
 		const size_t s = (size_t)(s0 + cd.pin);
@@ -951,14 +1036,15 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	MSFilter *vol = qv ? qv->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != head->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (!vd->p.agc_enabled || vd->peer || vd->peered_by > 0 || vd->sample_rate != es->samplerate || vd->leg) return false;
+	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != es->samplerate || vd->leg) return false;
 	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
+	const bool no_agc = !vd->p.agc_enabled;
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
 	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;
 	LegBank *b = bank<LegBank>("legp:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
-	                               std::to_string(delay),
-	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true); }); // 64, 256, 1024, .. legs
+	                               std::to_string(delay) + (no_agc ? ":light" : ""),
+	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true, no_agc); }); // 64, 256, 1024, .. legs
 	const int s = b ? b->acquire(vol) : -1;
 	if (s < 0) return false;
 	note_slot(vol);
@@ -1037,6 +1123,7 @@ void leg_release(FusedLeg *leg, bool keep_running) {
 }
 bool leg_wants_out(FusedLeg *leg) { return leg && !leg->mixer && leg->unfuse_wanted; }
 bool leg_has_resampler(FusedLeg *leg) { return leg && leg->rs != nullptr; }
+bool leg_runs_agc(FusedLeg *leg) { return leg && !leg->bank->light; }
 
 Pool *leg_pool(FusedLeg *leg) { return leg->bank; }
 Pool *leg_pool_of(LegBank *b) { return b; }

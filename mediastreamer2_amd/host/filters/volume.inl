@@ -165,7 +165,7 @@ mi_volume_state *vstate(VolumeData *d) {
 void volume_push_params(VolumeData *d) {
 	if (d->leg) {
 		leg_push_volume(d->leg, &d->p, nullptr, nullptr);
-		if (!d->p.agc_enabled) leg_disqualify(d->leg); // without AGC the reference meters block by block, not in 10 ms chunks
+		if ((d->p.agc_enabled != 0) != leg_runs_agc(d->leg)) leg_disqualify(d->leg); // AGC switched: with it the reference meters 10 ms chunks, without it block by block -- another bank
 		return;
 	}
 	if (!d->pool || d->slot < 0) return;

@@ -228,7 +228,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc = dict(nconf=2, members=4, nticks=120, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, pins=None)
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
-                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"))
+                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -292,6 +292,11 @@ SCENARIOS = {
     "no_resampler": {"no_resampler": True, "in_rate": 48000, "delay_ms": 10, "far_gaps": True},
     "no_resampler_16k_ptime20": {"no_resampler": True, "in_rate": 16000, "rate": 16000, "ptime20": True, "nticks": 100, "members": 3, "pins": [0, 2, 7]},
     "no_resampler_no_mixer": {"no_resampler": True, "in_rate": 48000, "no_mixer": True, "nconf": 1, "members": 5, "far_gaps": True},
+    # MSVolume WITHOUT AGC (the reference's default): it meters and levels the canceller's frames one by one, no 10 ms re-framing
+    "no_agc": {"no_agc": True, "gain": 0.7, "delay_ms": 10, "far_gaps": True},
+    "no_agc_ptime20_16k": {"no_agc": True, "in_rate": 8000, "rate": 16000, "ptime20": True, "nticks": 100},
+    # ... the sending side of a default AudioStream: sound card at the stream's rate -> MSSpeexEC -> MSVolume (meter only) -> encoder
+    "no_agc_no_resampler_no_mixer": {"no_agc": True, "no_resampler": True, "in_rate": 48000, "no_mixer": True, "nconf": 1, "members": 5, "far_gaps": True},
 }
 
 
