@@ -262,7 +262,8 @@ static void *conferences(void *arg) {
 			ms2shim_sink_set_discard(l->spk, 1), ms2shim_sink_set_discard(l->out, 1);
 			set_int(l->rs, MS_FILTER_SET_SAMPLE_RATE, 16000), set_int(l->rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
 			set_int(l->ec, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
-			set_int(l->vol, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(l->vol, MS_VOLUME_ENABLE_AGC, 1);
+			set_int(l->vol, MS_FILTER_SET_SAMPLE_RATE, 48000);
+			if (k != 1) set_int(l->vol, MS_VOLUME_ENABLE_AGC, 1); /* leg 1: MSVolume without AGC (the default): fused into a bank of the other kind */
 			if (k == 0) ms_filter_link(l->mic, 0, l->ec, 1); /* no MSResample in front: MSSpeexEC is this leg's head (48 kHz microphone) */
 			else ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1);
 			ms_filter_link(l->ec, 1, l->vol, 0);
