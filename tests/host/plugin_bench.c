@@ -58,6 +58,7 @@ typedef struct {
 	int nconf, index;
 	double *late_ms;                     /* paced: how far behind its schedule the step STARTED */
 	double *step_ms, *task_ms, *cpu_ms; /* per tick: wall time of the step, of its postponed tasks, CPU time of the thread */
+	MSFilter **heads;        /* PLUGIN_BENCH_SHAPE nomixer: every leg's source, the root its graph is attached by */
 	MSFilter **outs, **spks; /* PLUGIN_BENCH_CHECKSUM=1: every leg's two sinks (mix back to the leg, speaker pin) */
 	double slowest_ms;
 	int slowest_tick, prof_n, prof_ids[16], max_id;
@@ -72,6 +73,7 @@ static volatile uint64_t g_t0; /* ... the schedule's origin (ns, CLOCK_MONOTONIC
 static pthread_barrier_t g_bar;
 
 static int g_profile, g_checksum;
+static int g_nors, g_noagc, g_nomixer; /* PLUGIN_BENCH_SHAPE: words of "nors noagc nomixer" -- the leg without MSResample / without AGC / without a conference mixer */
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -90,6 +92,7 @@ static void build(TickerJob *j) {
 	j->ticker = ms_ticker_new();
 	j->mixers = (MSFilter **)calloc((size_t)j->nconf, sizeof(MSFilter *));
 	j->outs = (MSFilter **)calloc((size_t)j->nconf * (size_t)g_members, sizeof(MSFilter *));
+	j->heads = (MSFilter **)calloc((size_t)j->nconf * (size_t)g_members, sizeof(MSFilter *));
 	j->spks = (MSFilter **)calloc((size_t)j->nconf * (size_t)g_members, sizeof(MSFilter *));
 	for (int c = 0; c < j->nconf; ++c) {
 		MSFilter *mx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
@@ -101,7 +104,8 @@ static void build(TickerJob *j) {
 			MSFilter *rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
 			MSFilter *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
 			const int leg = (j->index * j->nconf + c) * g_members + k;
-			ms2shim_source_set_loop(mic, g_mic, sizeof(g_mic[0]), RING, leg);
+			if (g_nors) ms2shim_source_set_loop(mic, g_far, sizeof(g_far[0]), RING, leg * 3 + 1); /* a 48 kHz microphone: the card runs at the canceller's rate */
+			else ms2shim_source_set_loop(mic, g_mic, sizeof(g_mic[0]), RING, leg);
 			ms2shim_source_set_loop(far, g_far, sizeof(g_far[0]), RING, leg * 7);
 			ms2shim_sink_set_discard(spk, g_checksum ? 2 : 1);
 			ms2shim_sink_set_discard(out, g_checksum ? 2 : 1);
@@ -112,12 +116,21 @@ static void build(TickerJob *j) {
 			call_int(ec, MS_FILTER_SET_SAMPLE_RATE, 48000);
 			call_int(ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 128);
 			call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 48000);
-			call_int(vol, MS_VOLUME_ENABLE_AGC, 1);
-			ms_filter_link(mic, 0, rs, 0);
-			ms_filter_link(rs, 0, ec, 1);
+			if (!g_noagc) call_int(vol, MS_VOLUME_ENABLE_AGC, 1);
+			if (g_nors) {
+				ms_filter_link(mic, 0, ec, 1);
+			} else {
+				ms_filter_link(mic, 0, rs, 0);
+				ms_filter_link(rs, 0, ec, 1);
+			}
 			ms_filter_link(ec, 1, vol, 0);
-			ms_filter_link(vol, 0, mx, k);
-			ms_filter_link(mx, k, out, 0);
+			if (g_nomixer) { /* an AudioStream's sending side: MSVolume's blocks go straight on (to the encoder; here a sink) */
+				ms_filter_link(vol, 0, out, 0);
+				j->heads[c * g_members + k] = mic;
+			} else {
+				ms_filter_link(vol, 0, mx, k);
+				ms_filter_link(mx, k, out, 0);
+			}
 			ms_filter_link(far, 0, ec, 0);
 			ms_filter_link(ec, 0, spk, 0);
 			if (c == 0 && k == 0) j->probe_out = out;
@@ -165,7 +178,10 @@ static void *watchdog(void *arg) {
 static void *run(void *arg) {
 	TickerJob *j = (TickerJob *)arg;
 	/* attach on the ticker's own thread: the hub's device context and its banks belong to the thread that ticks them */
-	for (int c = 0; c < j->nconf; ++c) ms_ticker_attach(j->ticker, j->mixers[c]);
+	if (g_nomixer)
+		for (int k = 0; k < j->nconf * g_members; ++k) ms_ticker_attach(j->ticker, j->heads[k]);
+	else
+		for (int c = 0; c < j->nconf; ++c) ms_ticker_attach(j->ticker, j->mixers[c]);
 	for (int t = 0; t < g_warmup; ++t) {
 		pthread_barrier_wait(&g_bar);
 		ms_ticker_step(j->ticker);
@@ -221,6 +237,10 @@ int main(int argc, char **argv) {
 	}
 	g_profile = getenv("MS2SHIM_PROFILE") != NULL;
 	g_paced = getenv("PLUGIN_BENCH_PACED") != NULL;
+	if (getenv("PLUGIN_BENCH_SHAPE")) {
+		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
+		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL;
+	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
 	const char *plugin = argv[1];
 	int legs = atoi(argv[2]);
