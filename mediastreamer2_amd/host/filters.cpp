@@ -554,6 +554,7 @@ void leg_stage_mic_ec(MSFilter *f, SpeexECState *s);
 MSFilter *leg_find_mixer_ec(MSFilter *ec);
 bool leg_try_fuse_plain_ec(MSFilter *ec);
 bool leg_has_resampler(FusedLeg *leg);
+void leg_head_done(FusedLeg *leg);
 bool leg_runs_agc(FusedLeg *leg);
 MSFilter *leg_find_mixer(MSFilter *rs);
 bool conf_try_fuse(MSFilter *mixer);

@@ -360,7 +360,10 @@ void ec_process(MSFilter *f) {
 	if (s->leg) { // fused leg: the microphone is staged (by the leg's MSResample, or here) for the device, the far end for the leg's delay line
 		HubLock lk(f, leg_pool(s->leg));
 		leg_take_far_end(f, s);
-		if (!leg_has_resampler(s->leg)) leg_stage_mic_ec(f, s);
+		if (!leg_has_resampler(s->leg)) {
+			leg_stage_mic_ec(f, s);
+			leg_head_done(s->leg);
+		}
 		return;
 	}
 	if (s->bypass_mode || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)

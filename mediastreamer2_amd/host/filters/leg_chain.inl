@@ -793,7 +793,11 @@ void leg_take_far_end(MSFilter *f, SpeexECState *s) {
 		b->staged_since = true;
 		request_flush(f);
 	}
-	if (b->plain) leg_far_walked(b, leg);
+	if (b->plain && leg->rs) leg_far_walked(b, leg); // (headed by MSSpeexEC the leg is done when its microphone is staged too: leg_head_done)
+}
+// MSSpeexEC as a leg's head has taken its far end AND staged its microphone blocks in this tick
+void leg_head_done(FusedLeg *leg) {
+	if (leg->bank->plain) leg_far_walked(leg->bank, leg);
 }
 
 // ---- fusing ------------------------------------------------------------------------------------------------------------
