@@ -17,8 +17,9 @@ STATE: converged on their scenes before anything is timed (class Converged).
 value = concurrent 48 kHz legs the job sustains: the largest leg count per GPU
 (capacity sweep) at which no tick of --worst-ticks (3000) CONSECUTIVE single
 ticks reaches the 10 ms interval (p50 / p99 / p99.9 / max in the line; nothing
-is discarded or repeated), and none does either when every leg starts from
-reset at once; summed over the ranks.  ms_per_step = the average tick at that
+is discarded or repeated), none of --paced-ticks (3000) ticks fired one per
+10 ms of wall time does (the deployed cadence: config.paced_ticks), and none
+does either when every leg starts from reset at once; summed over the ranks.  ms_per_step = the average tick at that
 count over the timed region (whole 16-tick scene periods, at least 0.5 s,
 replayed from a hipGraph so the host's launch cost is not what is timed).
 Every tick streams the cancellers' resident state (~180 KB per leg, gigabytes
@@ -37,8 +38,11 @@ mix on rank 0.  RCCL failure = non-zero exit.
 roofline = the canceller's tick kernel (canceller + post-filter + FIFOs, one
 launch) INSIDE the running chain at the headline leg count, HIP events on the
 launch stream around that launch; cpu_baseline = the oracle's same chain on the
-host's cores (bounded sample).  other_kernels: BASELINE configs[1]-[4] and the
-adjacent stages, each with its own roofline object.
+host's cores (bounded sample).  other_kernels: BASELINE configs[1]-[4], the
+small-frame cancellers and the adjacent stages, each with its own roofline object.
+plugin_path: full call legs through the DROP-IN PLUGIN (tests/host/plugin_bench:
+filters by id from the factory, 16 ticker threads paced at 10 ms; never part of
+`value`); video_pcie_inclusive: config 5 from and to host memory.
 """
 import argparse
 import ctypes as C
