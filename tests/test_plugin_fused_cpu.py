@@ -65,3 +65,26 @@ def test_plugin_bench_runs_full_legs_through_the_double(verdict, paced):
     assert len(d["slow_ticks"]) == 5 and {"cpu_ms", "nvcsw", "nivcsw", "minflt"} <= set(d["slow_ticks"][0])
     if paced:
         assert 9.0 < d["wall_ms_per_tick"] < 12.0, d["wall_ms_per_tick"]   # 40 ticks on the 10 ms grid (+ the 20 ms lead)
+
+
+@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nomixer", "nors noagc nomixer"])
+def test_plugin_bench_shapes_fused_equal_one_by_one_by_checksum(verdict, shape):
+    """every leg shape the fused chain takes (PLUGIN_BENCH_SHAPE: without MSResample / without AGC / without a conference mixer):
+    256 legs x 70 ticks against the double, every leg's mix and speaker audio folded into one number per run -- fused ==
+    the facades one by one == staged through device buffers; the device queues hold what the host's framing says throughout"""
+    def run(**extra):
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(HOST, "double"), PLUGIN_BENCH_CHECKSUM="1", PLUGIN_BENCH_SHAPE=shape,
+                   MSMI355X_CHECK_LEVELS="1", **extra)
+        if "MSMI355X_NO_FUSE" not in extra:
+            env.pop("MSMI355X_NO_FUSE", None)
+        r = subprocess.run([os.path.join(HOST, "plugin_bench"), os.path.join(HOST, "double", "libmsmi355xfilters.so"), "256", "2", "60", "10"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    fused, plain, staged = run(), run(MSMI355X_NO_FUSE="1"), run(MSMI355X_ZERO_COPY="0")
+    assert fused["fused_legs"] == 256 and plain["fused_legs"] == 0 and staged["fused_legs"] == 256
+    assert fused["mix_bytes"] == plain["mix_bytes"] > 0
+    assert fused["mix_checksum"] == plain["mix_checksum"] == staged["mix_checksum"]
+    assert fused["speaker_checksum"] == plain["speaker_checksum"] == staged["speaker_checksum"]
+    assert fused["late_events"] == 0 and staged["late_events"] == 0
