@@ -5,16 +5,21 @@
 // The reference's sending graph of a call leg is  ... -> read_resampler -> ec -> volsend -> ... -> mixer
 // (src/voip/audiostream.c:1798-1810), one MSFilter each, one process() each per tick.  Facade by facade that is four banks,
 // four uploads and downloads and the audio crossing PCIe eight times.  When a conference mixer of this plugin finds that
-// EVERY linked input pin is fed by   MSResample (16k->48k, 8k->48k, 8k->16k) -> MSSpeexEC pin 1 -> MSVolume (AGC) -> pin
-// -- all facades of this plugin on its own ticker, freshly attached -- the whole conference moves into a LegBank:
+// EVERY linked input pin is fed by   [MSResample (16k->48k, 8k->48k, 8k->16k) ->] MSSpeexEC pin 1 -> MSVolume -> pin
+// -- with or without the resampler (the reference creates it only when the card's rate differs), with or without AGC (off
+// unless the application asks), the same shape on every pin, all facades of this plugin on the mixer's ticker, freshly
+// attached -- the whole conference moves into a LegBank; a leg whose MSVolume feeds anything else (an AudioStream's sending
+// side) moves into a mixer-less one on its own:
 //
 //   * one slot per LEG (conference * mm + pin) shared by every per-leg object: the resampler's history, the canceller, its
 //     three queues as device FIFOs (MSSpeexEC's `echo` and `delayed_ref` bufferizers, MSVolume's chunk bufferizer + the
 //     mixer channel's), the meter;
-//   * per tick and hub: the legs' 10 ms microphone blocks (320 B at 16 kHz) and far-end blocks (960 B) go up, TWO launches
-//     run per round -- aec_tick_kernel with the resampler folded in (mi_aec_process_fifos_resampled_masked) and volmix_kernel
-//     (mi_mixer_process_volume_fifo_flags) -- and the conferences' mixes (960 B per leg) come down into a pinned slab whose
-//     rows are handed downstream as they lie (esballoc + dupb: no copy, one data block per flush);
+//   * per tick and hub: the legs' 10 ms microphone blocks (320 B at 16 kHz) and far-end blocks (960 B) are staged in pinned
+//     rows the launches read where they lie, TWO launches run per round -- aec_tick_kernel with the resampler folded in
+//     (mi_aec_process_fifos_resampled_masked; mi_aec_process_fifos_masked without one) and volmix_kernel
+//     (mi_mixer_process_volume_fifo_flags) -- and the conferences' mixes (960 B per leg) are written into a pinned slab whose
+//     rows are handed downstream as they lie (esballoc + dupb: no copy, one data block per flush).  Without AGC MSVolume
+//     meters the canceller's frames one by one (LegBank::light: a levelling launch per frame of the tick, a fourth queue);
 //   * the facades' framing state machines stay on the host and decide as the reference does, on COUNTS: how many frames
 //     MSSpeexEC's while loop runs (speexec.c:256), when it feeds silence into its delay line (:261-272) and what goes to
 //     the speaker pin (host audio, as before), whether MSVolume has a whole chunk (msvolume.c:480-486), who contributes to
@@ -26,10 +31,10 @@
 // (the reference forwards that pin's blocks unsaturated, audiomixer.c:219-242: only a sample of -32768 differs; the
 // contributor's own pin gets no block either way), and after detach / re-attach the resampler starts from an empty
 // history like the canceller does (the facade alone keeps its speex handle across a detach).
-// Anything else -- another rate pair, a pin fed by something else, MSVolume without AGC or with an echo-limiter peer,
-// non-conference mode, MSMI355X_NO_FUSE=1 -- keeps the facades on their own banks.  A fused conference falls back to them
-// at run time when a member's configuration stops qualifying (bypass mode switched on, AGC switched off, ...): the audio
-// queued on the device at that moment (a few ms) is lost.
+// Anything else -- another rate pair, pins of different shapes, MSVolume with an echo-limiter peer, non-conference mode,
+// MSMI355X_NO_FUSE=1 -- keeps the facades on their own banks.  A fused conference falls back to them at run time when a
+// member's configuration stops qualifying (bypass mode switched on, AGC switched, ...): the audio queued on the device at
+// that moment (a few ms) is lost.
 
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
 constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one enqueue: kMaxRounds blocks of 10 ms in frames
