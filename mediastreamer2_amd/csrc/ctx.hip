@@ -64,7 +64,27 @@ int copy_mapped(mi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyKind k
 }
 } // namespace
 
+namespace {
+__global__ void stamp_kernel(unsigned long long *dst) { *dst = wall_clock64(); }
+} // namespace
+
 extern "C" {
+
+// debug entries (not in the public header): the device's constant-rate clock written by a one-thread launch on the context's
+// stream -- inside a captured graph it brackets the graph's work on the DEVICE's time line (scripts/paced_events_probe.py tells a
+// tick the device took long over from one the host was slow to submit); the clock's rate in kHz
+int mi_debug_stamp(mi_ctx *c, unsigned long long *d_dst) {
+	MI_CHECK_ARG(c && d_dst);
+	if (c->activate() != MI_OK) return MI_ENODEV;
+	hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, c->stream, d_dst);
+	MI_LAUNCH_CHECK();
+	return MI_OK;
+}
+int mi_debug_wall_clock_khz(mi_ctx *c) {
+	int khz = 0;
+	if (!c || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess) return 0;
+	return khz;
+}
 
 int mi_abi_version(void) { return MSMI355X_ABI_VERSION; }
 const char *mi_last_error(void) { return mi::g_err; }
