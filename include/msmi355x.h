@@ -462,6 +462,11 @@ int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 int mi_fifo_snapshot(mi_fifo *f, int16_t *h_rings, int32_t *h_head, int32_t *h_level);
 int mi_fifo_reset(mi_fifo *f);
 int mi_fifo_reset_range(mi_fifo *f, int first, int count); /* empty the FIFOs of streams [first, first+count) */
+/* ... empty, with the read position at ring offset `head` (a multiple of 8, < capacity).  The canceller's launches append whole
+ * frames to their output FIFO at a tail they take to be frame-aligned (mi_aec_process_fifos*): a queue that is to START with r
+ * samples short of a frame -- what an MSVolume's bufferizer held when its graph was detached (msvolume.c keeps it; the plugin's
+ * fused leg hands it over) -- is emptied at head = capacity - r and given those r samples, which leaves its tail at offset 0. */
+int mi_fifo_reset_range_at(mi_fifo *f, int first, int count, int head);
 
 /* ------------------------------------- codecs, channel adapter, flow control */
 /* The per-stream stages either side of the hot path in an AudioStream graph (src/voip/audiostream.c:1798-1832;

@@ -612,6 +612,9 @@ class FifoBatch(_Batch):
     def reset_range(self, first, count):
         check(self.ctx.L.mi_fifo_reset_range(self.h, first, count))
 
+    def reset_range_at(self, first, count, head):
+        check(self.ctx.L.mi_fifo_reset_range_at(self.h, first, count, head))
+
     def reset(self):
         check(self.ctx.L.mi_fifo_reset(self.h))
 

@@ -52,7 +52,7 @@ EXPORTS = [
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
     "mi_plc_create", "mi_plc_destroy", "mi_plc_reset", "mi_plc_process", "mi_plc_info",
-    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range", "mi_fifo_push_silence", "mi_fifo_snapshot",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range", "mi_fifo_reset_range_at", "mi_fifo_push_silence", "mi_fifo_snapshot",
 ]
 
 
@@ -266,6 +266,7 @@ def load():
         L.mi_fifo_overflows.argtypes = [vp, C.POINTER(i32)]
         L.mi_fifo_reset.argtypes = [vp]
         L.mi_fifo_reset_range.argtypes = [vp, i32, i32]
+        L.mi_fifo_reset_range_at.argtypes = [vp, i32, i32, i32]
         L.mi_fifo_push_silence.argtypes = [vp, vp]
         L.mi_fifo_snapshot.argtypes = [vp, vp, vp, vp]
     if hasattr(L, "mi_g711_decode"):

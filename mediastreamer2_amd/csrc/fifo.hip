@@ -39,6 +39,11 @@ struct FifoArgs {
 __host__ __device__ inline unsigned fifo_phase_of(unsigned s, unsigned phases) { return ((s * 0x9E3779B1u) >> 16) % phases; }
 
 // `unit * phase(s)` samples of silence appended to streams [first, first + count): the lead a leg starts with
+__global__ void fifo_rewind_kernel(int2 *pos, int count, int head) { // mi_fifo_reset_range_at
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i < count) pos[i] = make_int2(head, 0);
+}
+
 __global__ void fifo_lead_kernel(FifoArgs a, int first, int count, int unit, int phases) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= count) return;
@@ -394,6 +399,16 @@ int mi_fifo_reset_range(mi_fifo *f, int first, int count) {
 	MI_CHECK_ARG(f && first >= 0 && count >= 0 && first + count <= f->nstreams);
 	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
 	if (count) MI_HIP(hipMemsetAsync(f->d_pos + first, 0, (size_t)count * sizeof(int2), f->ctx->stream));
+	return MI_OK;
+}
+
+int mi_fifo_reset_range_at(mi_fifo *f, int first, int count, int head) {
+	MI_CHECK_ARG(f && first >= 0 && count >= 0 && first + count <= f->nstreams && head >= 0 && head < f->capacity && (head & 7) == 0);
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	if (count) {
+		hipLaunchKernelGGL(fifo_rewind_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, f->ctx->stream, f->d_pos + first, count, head);
+		MI_LAUNCH_CHECK();
+	}
 	return MI_OK;
 }
 

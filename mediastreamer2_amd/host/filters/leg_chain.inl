@@ -38,6 +38,7 @@
 
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
 constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one enqueue: kMaxRounds blocks of 10 ms in frames
+constexpr int kLegMeterRounds = 8; // rounds before the last of a flush whose meter state is read back (kLegLightRounds, kLegMaxChunks fit)
 constexpr int kLegMaxChunks = 5; // 10 ms chunks MSVolume can complete in one flush of a leg without a mixer (kMaxRounds blocks of 10 ms + what it held)
 
 struct LegBank;
@@ -100,6 +101,12 @@ struct LegBank : Pool {
 	int16_t *d_mix, *d_scratch; // [capacity][mm][ns]; [nlegs][ns]
 	int32_t *h_lv, *d_lv;       // MSMI355X_CHECK_LEVELS: [3][nlegs]
 	mi_volume_state *h_vstate;  // pinned [nlegs]
+	// MSVolume records EVERY chunk's energy in its extrema (update_energy, msvolume.c:405-406): when a flush levels more than one
+	// chunk of a leg, the state behind each round but the last comes back too (kLegMeterRounds rows of [nlegs]; vhas: the leg had a
+	// chunk in that round)
+	mi_volume_state *h_vround = nullptr;
+	std::vector<uint8_t> vhas;
+	int vrounds = 0;
 	int16_t *h_copy;            // the mixes when every slab is still held downstream: emitted by copy
 	std::vector<MixSlab *> slabs;
 	MixSlab *cur = nullptr;     // the slab this flush downloads into (null: h_copy)
@@ -215,6 +222,8 @@ struct LegBank : Pool {
 		h_lv = pinned<int32_t>(4 * L);
 		d_lv = devmem<int32_t>(4 * L);
 		h_vstate = pinned<mi_volume_state>(L);
+		h_vround = pinned<mi_volume_state>((size_t)kLegMeterRounds * L);
+		vhas.assign((size_t)kLegMeterRounds * L, 0);
 		h_copy = pinned<int16_t>((plain ? kLegMaxChunks : 1) * L * ns);
 		nout.assign(L, 0);
 		nready.assign(L, 0);
@@ -396,6 +405,102 @@ struct LegBank : Pool {
 	}
 	// a bank without mixers: every chunk MSVolume completes in this flush is levelled at once (volume_process's loop,
 	// msvolume.c:480-503) and handed on by its owner -- one launch per chunk round, legs without a whole chunk skipped
+	// Legs [s0, s0 + count) leave the bank (detach): what the reference's filters would still hold goes back to them.  The chunks
+	// waiting whole in f_out have passed MSVolume in the reference (metered, levelled) and sit in the mixer channel, which drops
+	// them at its postprocess (audiomixer.c:186-208): metered here, dropped.  The samples short of a chunk stay in MSVolume's
+	// bufferizer (msvolume.c:480-486; no postprocess touches it): read back into the filter's.
+	void take_remainders(int s0, int count) {
+		if (failed || light) return; // (without AGC MSVolume holds nothing between blocks)
+		mi_ctx *ctx = hub->ctx;
+		const size_t L = (size_t)nlegs;
+		int whole = 0;
+		for (int s = s0; s < s0 + count; ++s) {
+			FusedLeg *leg = legs[(size_t)s];
+			if (!leg) continue;
+			for (int k = 0; k < leg->chan_chunks + leg->newchunks; ++k, ++whole)
+				MI_MUST(mi_volume_process_fifo_range(vol, f_out, d_scratch, chunk, chunk, s, 1));
+			leg->chan_chunks = leg->newchunks = 0;
+		}
+		if (whole) {
+			MI_MUST(mi_volume_get_state_async(vol, 0, (int)L, h_vstate));
+			sync_stream();
+			if (failed) return;
+			for (int s = s0; s < s0 + count; ++s)
+				if (legs[(size_t)s] && !vs_dirty[(size_t)s]) vstate[(size_t)s] = h_vstate[s];
+		}
+		std::vector<int> rems;
+		for (int s = s0; s < s0 + count; ++s)
+			if (legs[(size_t)s] && legs[(size_t)s]->vol_rem > 0 && std::find(rems.begin(), rems.end(), legs[(size_t)s]->vol_rem) == rems.end())
+				rems.push_back(legs[(size_t)s]->vol_rem);
+		std::vector<uint8_t> gate(L);
+		std::vector<int16_t> rows((size_t)count * chunk);
+		for (int rem : rems) { // one all-or-nothing read per distinct length (members that joined together share theirs)
+			std::fill(gate.begin(), gate.end(), 0);
+			for (int s = s0; s < s0 + count; ++s) gate[(size_t)s] = legs[(size_t)s] && legs[(size_t)s]->vol_rem == rem;
+			MI_MUST(mi_copy_h2d(ctx, d_dgate_any(), gate.data(), L));
+			MI_MUST(mi_fifo_pop(f_out, rem, d_scratch, chunk, nullptr, d_dgate_any(), 0));
+			MI_MUST(mi_copy_d2h(ctx, rows.data(), d_scratch + (size_t)s0 * chunk, (size_t)count * chunk * 2));
+			sync_stream();
+			if (failed) return;
+			for (int s = s0; s < s0 + count; ++s) {
+				if (!gate[(size_t)s]) continue;
+				VolumeData *vd = (VolumeData *)legs[(size_t)s]->vol->data;
+				mblk_t *m = allocb((size_t)rem * 2, 0);
+				memcpy(m->b_wptr, rows.data() + (size_t)(s - s0) * chunk, (size_t)rem * 2);
+				m->b_wptr += rem * 2;
+				ms_bufferizer_put(vd->buffer, m);
+				legs[(size_t)s]->vol_rem = 0;
+			}
+		}
+	}
+	// ... and the other way round when a leg joins the bank at slot s with samples in its MSVolume's bufferizer
+	bool give_remainder(int s, VolumeData *vd, FusedLeg *leg) {
+		const int rem = (int)(ms_bufferizer_get_avail(vd->buffer) / 2);
+		if (rem <= 0 || light) return true;
+		mi_ctx *ctx = hub->ctx;
+		const size_t L = (size_t)nlegs;
+		std::vector<int16_t> row((size_t)chunk, 0);
+		ms_bufferizer_read(vd->buffer, (uint8_t *)row.data(), (size_t)rem * 2);
+		std::vector<int32_t> cnt(L, 0);
+		cnt[(size_t)s] = rem;
+		// (the canceller appends whole frames at a tail it takes to be frame-aligned: the queue starts `rem` short of the ring's end)
+		const bool ok = mi_fifo_reset_range_at(f_out, s, 1, out_cap - rem) == MI_OK && mi_copy_h2d(ctx, d_scratch + (size_t)s * chunk, row.data(), (size_t)chunk * 2) == MI_OK &&
+		                mi_copy_h2d(ctx, d_cnt, cnt.data(), L * 4) == MI_OK && mi_fifo_push(f_out, d_scratch, chunk, chunk, d_cnt) == MI_OK && mi_ctx_sync(ctx) == MI_OK;
+		if (ok) leg->vol_rem = rem;
+		return ok;
+	}
+	uint8_t *d_dgate_any() {
+		if (!d_takegate) d_takegate = devmem<uint8_t>((size_t)nlegs);
+		return d_takegate;
+	}
+	uint8_t *d_takegate = nullptr;
+	// A slot's owner leaves while the bank's work for the coming tick is already out (it left at the end of the last graph walk):
+	// the reference's filters would have handed that tick's audio on in the walk itself, so it goes out now -- the speaker frames
+	// of every leg (LegBank::finish), the owner's own mix or chunks; the others' follow with the hub's flush as usual.
+	void deliver_in_flight(MSFilter *owner_filter, int slot) {
+		if (failed || (!outstanding && !early)) return;
+		sync_stream();
+		if (failed) return;
+		outstanding = false;
+		finish();
+		emit(owner_filter, slot);
+	}
+	// vstate as the device holds it NOW (a leg is about to leave with its MSVolume's running state): launches that are out and not
+	// waited for yet are waited for, their read-back taken
+	void settle_meters() {
+		if (!outstanding && !early) return;
+		if (failed) return;
+		sync_stream();
+		if (failed || !mixed) return;
+		for (size_t s = 0; s < (size_t)nlegs; ++s)
+			if (legs[s] && !vs_dirty[s]) vstate[s] = h_vstate[s];
+	}
+	// the meters behind a levelling round that is not the flush's last (read back with the round's results: finish() records them)
+	void meter_round(size_t UL) {
+		if (vrounds >= kLegMeterRounds || failed) return;
+		MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vround + (size_t)vrounds * nlegs));
+		++vrounds;
+	}
 	bool enqueue_plain(bool any_ref, bool any_refx, bool any_inj, int rounds) {
 		mi_ctx *ctx = hub->ctx;
 		const size_t L = (size_t)nlegs, UL = (size_t)hi;
@@ -407,6 +512,7 @@ struct LegBank : Pool {
 			leg->newchunks -= nout[s];
 			leg->metered |= nout[s] > 0;
 			maxc = std::max(maxc, nout[s]);
+			for (int r = 0; r + 1 < nout[s] && vrounds + r < kLegMeterRounds; ++r) vhas[(size_t)(vrounds + r) * L + s] = 1;
 		}
 		if (failed) return false;
 		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
@@ -417,6 +523,7 @@ struct LegBank : Pool {
 			for (int r = 0; r < maxc; ++r) { // (rows of round r start behind what a leg still has ready from an earlier enqueue of this flush)
 				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, rows + (size_t)r * L * chunk, chunk, chunk, MI_VOLMIX_DRY_SKIPS));
 				++launches;
+				if (r + 1 < maxc) meter_round(UL);
 			}
 			if (!zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, dst, d_mix, ((size_t)(maxc - 1) * L + UL) * chunk * 2));
 			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
@@ -495,6 +602,7 @@ struct LegBank : Pool {
 				leg->metered |= nfr > 0;
 				light_rounds = std::max(light_rounds, leg->lt_frames);
 				for (int r = 0; r < kLegLightRounds; ++r) h_fcnt[(size_t)r * L + s] = r < leg->lt_frames ? F : 0;
+				for (int r = 0; r + 1 < leg->lt_frames && vrounds + r < kLegMeterRounds; ++r) vhas[(size_t)(vrounds + r) * L + s] = 1;
 			} else {
 				leg->vol_rem += nfr * F; // MSVolume's re-framing to 10 ms chunks (msvolume.c:480-486)
 				leg->newchunks += leg->vol_rem / ns;
@@ -525,6 +633,7 @@ struct LegBank : Pool {
 				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, d_lev, F, F, MI_VOLMIX_DRY_SKIPS));
 				MI_MUST(mi_fifo_push(f_chan, d_lev, F, F, (zero_copy ? h_fcnt : d_fcnt) + (size_t)r * L));
 				launches += 2;
+				if (r + 1 < light_rounds) meter_round(UL);
 			}
 			if (!ticked) MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 			mixed = true;
@@ -588,13 +697,20 @@ struct LegBank : Pool {
 				FusedLeg *leg = legs[s];
 				if (!leg) continue;
 				vstate[s] = h_vstate[s];
-				if (leg->metered && hub->ticker) { // update_energy's extremum records, msvolume.c:405-406
+				if (leg->metered && hub->ticker) { // update_energy's extremum records, msvolume.c:405-406: one per chunk, in order
 					VolumeData *vd = (VolumeData *)leg->vol->data;
+					for (int r = 0; r < vrounds; ++r)
+						if (vhas[(size_t)r * L + s]) {
+							vd->max.record_max(hub->ticker->time, h_vround[(size_t)r * L + s].energy);
+							vd->min.record_min(hub->ticker->time, h_vround[(size_t)r * L + s].energy);
+						}
 					vd->max.record_max(hub->ticker->time, vstate[s].energy);
 					vd->min.record_min(hub->ticker->time, vstate[s].energy);
 				}
 				leg->metered = false;
 			}
+			std::fill(vhas.begin(), vhas.end(), 0);
+			vrounds = 0;
 			if (cur) {
 				cur->state.store(1, std::memory_order_release);
 				root = esballoc(cur->payload(), cur->bytes, 0, mix_slab_release);
@@ -811,6 +927,12 @@ struct LegCand {
 	int pin;
 };
 
+// MSVolume's bufferizer survives a detach (msvolume.c has no postprocess): with AGC it may hold samples short of a 10 ms chunk
+bool leg_remainder_ok(const VolumeData *vd) {
+	const size_t avail = ms_bufferizer_get_avail(vd->buffer);
+	return avail == 0 || (vd->p.agc_enabled && avail < (size_t)(vd->sample_rate / 100) * 2 && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
+}
+
 bool leg_rates_ok(uint32_t in, uint32_t out) { // what the canceller's launch up-samples itself (mi_aec_process_fifos_resampled)
 	return (in == 16000 && out == 48000) || (in == 8000 && out == 48000) || (in == 8000 && out == 16000);
 }
@@ -825,7 +947,8 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
-	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
+	// (MSVolume's bufferizer may hold samples short of a 10 ms chunk from before a detach: they move to the device, leg_give_remainder)
+	if (!leg_remainder_ok(vd) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
 	MSQueue *qe = vol->inputs[0];
 	MSFilter *ec = qe ? qe->prev.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || qe->prev.pin != 1 || ec->ticker != mx->ticker || !ms_queue_empty(qe)) return false;
@@ -900,10 +1023,8 @@ bool conf_try_fuse(MSFilter *mx) {
 		const size_t s = (size_t)(s0 + cd.pin);
 		VolumeData *vd = (VolumeData *)cd.vol->data;
 		SpeexECState *es = (SpeexECState *)cd.ec->data;
-		mi_volume_state st;
-		memset(&st, 0, sizeof(st));
-		st.gain = vd->gain, st.target_gain = vd->target_gain, st.ng_gain = 1; // a fresh slot, as volume_attach_slot leaves it
-		b->vstate[s] = st;
+		volume_keep_state(vd); // (its bank is on this hub, which is held)
+		b->vstate[s] = volume_start_state(vd); // as volume_attach_slot starts a slot: MSVolume's running state, if it has one already
 		b->vparams[s] = vd->p;
 		b->vparams[s].peer = -1;
 		fill[s] = delay; // zeroes for the time of the delay (speexec.c:205-208)
@@ -948,6 +1069,7 @@ bool conf_try_fuse(MSFilter *mx) {
 			vd->pool = nullptr, vd->slot = -1;
 		}
 		vd->leg = leg;
+		if (!b->give_remainder(leg->slot, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
 	}
 	ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
 	ms->pool->release(ms->slot);
@@ -990,6 +1112,20 @@ MSFilter *leg_find_mixer_ec(MSFilter *ec) {
 void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess (a bank slot of its own)
 void mixer_prepare(MSFilter *f); // mixer.inl
 
+// MSVolume's running state goes with the filter, not with the bank slot (volume.inl: VolumeData::kept)
+void leg_keep_volume(FusedLeg *leg) {
+	VolumeData *vd = (VolumeData *)leg->vol->data;
+	if (leg->bank->failed) return;
+	LegBank *b = leg->bank;
+	const size_t s = (size_t)leg->slot;
+	vd->kept = b->vstate[s];
+	if (b->vs_dirty[s]) { // a gain method since the last launch: not on the device yet
+		vd->kept.gain = b->vpatch[s].gain;
+		if (b->vpatch[s].also_target) vd->kept.target_gain = b->vpatch[s].target;
+	}
+	vd->has_kept = true;
+}
+
 // The conference leaves its LegBank: at detach (every facade's postprocess ends up here, the first one does the work) or,
 // keep_running, because a member stopped qualifying while attached -- the facades then go on with banks of their own and
 // what was queued on the device is lost.
@@ -1000,9 +1136,13 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 	HubLock lk(b->hub);
 	const int c = ms->fconf, mm = b->mm;
 	std::vector<FusedLeg *> gone;
+	b->deliver_in_flight(mx, c);
+	b->settle_meters();
+	b->take_remainders(c * mm, mm);
 	for (int pin = 0; pin < mm; ++pin) {
 		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
 		if (!leg) continue;
+		leg_keep_volume(leg);
 		b->legs[(size_t)(c * mm + pin)] = nullptr;
 		if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
 		((SpeexECState *)leg->ec->data)->leg = nullptr;
@@ -1046,7 +1186,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != head->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != es->samplerate || vd->leg) return false;
-	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
+	if (!leg_remainder_ok(vd) || ms_bufferizer_get_avail(vd->spill)) return false;
 	const bool no_agc = !vd->p.agc_enabled;
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
@@ -1059,10 +1199,8 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	note_slot(vol);
 	bool ok = (!b->rs || mi_resampler_reset(b->rs, s, 1) == MI_OK) && mi_aec_reset(b->aec, s, 1) == MI_OK && mi_fifo_reset_range(b->f_mic, s, 1) == MI_OK &&
 	          mi_fifo_reset_range(b->f_ref, s, 1) == MI_OK && mi_fifo_reset_range(b->f_out, s, 1) == MI_OK && mi_volume_reset_max(b->vol, s, 1) == MI_OK;
-	mi_volume_state st;
-	memset(&st, 0, sizeof(st));
-	st.gain = vd->gain, st.target_gain = vd->target_gain, st.ng_gain = 1;
-	b->vstate[(size_t)s] = st;
+	volume_keep_state(vd); // (its bank is on this hub, which is held)
+	b->vstate[(size_t)s] = volume_start_state(vd);
 	b->vparams[(size_t)s] = vd->p;
 	b->vparams[(size_t)s].peer = -1;
 	if (es->state_str) {
@@ -1102,6 +1240,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 		vd->pool = nullptr, vd->slot = -1;
 	}
 	vd->leg = leg;
+	if (!b->give_remainder(s, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
 	b->staged_since = true;
 	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (%sMSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen,
 	           rs ? "MSResample -> " : "");
@@ -1112,6 +1251,10 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	LegBank *b = leg->bank;
 	HubLock lk(b->hub);
 	const int s = leg->slot;
+	b->deliver_in_flight(leg->vol, s);
+	b->settle_meters();
+	b->take_remainders(s, 1);
+	leg_keep_volume(leg);
 	b->legs[(size_t)s] = nullptr;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
 	if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;

@@ -40,6 +40,7 @@ struct VolumePool : Pool {
 	int32_t *h_n, *d_n;
 	mi_volume_state *h_state; // pinned: the meters come back with the blocks, no synchronisation of their own
 	bool fetched = false;
+	int rounds_fetched = 0;
 	std::vector<int> staged, ready;
 	std::vector<mi_volume_params> params;
 	std::vector<mi_volume_state> state;
@@ -54,7 +55,7 @@ struct VolumePool : Pool {
 		h_n = pinned<int32_t>(kMaxRounds * c);
 		d_buf = devmem<int16_t>(c * cap_samples);
 		d_n = devmem<int32_t>(c);
-		h_state = pinned<mi_volume_state>(c);
+		h_state = pinned<mi_volume_state>(kMaxRounds * c); // row r: the meters behind round r (every chunk's energy is recorded, msvolume.c:405-406)
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 		mi_volume_params p;
@@ -85,15 +86,16 @@ struct VolumePool : Pool {
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, h_n + r * c, c * 4));
 			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			if (!failed) MI_MUST(mi_volume_get_state_async(v, 0, hi, h_state + r * c)); // meters for the app thread
 		}
 		fetched = maxr > 0 && !failed;
-		if (fetched) MI_MUST(mi_volume_get_state_async(v, 0, hi, h_state)); // meters for the app thread
+		rounds_fetched = fetched ? maxr : 0;
 		return maxr > 0;
 	}
 	void finish() override {
 		if (fetched && !failed) // (a gain set by a method since the launch was enqueued is not overwritten: it is still dirty)
 			for (int s = 0; s < hi; ++s)
-				if (!state_dirty[(size_t)s]) state[(size_t)s] = h_state[s];
+				if (!state_dirty[(size_t)s]) state[(size_t)s] = h_state[(size_t)(rounds_fetched - 1) * capacity + s];
 		fetched = false;
 		for (int s = 0; s < hi; ++s) {
 			ready[(size_t)s] = staged[(size_t)s]; // after a failed launch the staged blocks leave as they came (unity gain)
@@ -111,6 +113,12 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	MSBufferizer *buffer;
 	MSBufferizer *spill; // light path: the part of an over-long block that did not fit this tick's rounds
 	Extremum min, max;
+	// struct Volume lives as long as the filter: energy, the gain ramp, the noise gate's and the echo limiter's counters all survive a
+	// detach / re-attach of the graph (msvolume.c:88-118 sets them once, :447-469 only resets the extrema).  Here the running state
+	// lives in a bank slot: `kept` carries it from a slot that is given up (the graph re-plumbed, a conference fused or un-fused)
+	// to the next one
+	mi_volume_state kept;
+	bool has_kept;
 	VolumePool *pool;
 	int slot;
 	bool ng_soft_start;
@@ -135,6 +143,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->slot = -1;
 	d->leg = nullptr;
 	d->peered_by = 0;
+	d->has_kept = false;
 	f->data = d;
 }
 
@@ -155,6 +164,23 @@ void volume_uninit(MSFilter *f) {
 	ms_bufferizer_destroy(d->buffer);
 	ms_bufferizer_destroy(d->spill);
 	delete d;
+}
+
+// the slot's running state as of the last flush, before the slot is given up (hub locked)
+void volume_keep_state(VolumeData *d) {
+	if (!d->pool || d->slot < 0 || d->pool->failed) return;
+	d->kept = d->pool->state[(size_t)d->slot];
+	d->has_kept = true;
+}
+// what a new slot starts from: volume_init's state (msvolume.c:88-118) with the gains the methods set, or what the last slot held
+mi_volume_state volume_start_state(const VolumeData *d) {
+	mi_volume_state st;
+	if (d->has_kept) return d->kept;
+	memset(&st, 0, sizeof(st));
+	st.gain = d->gain;
+	st.target_gain = d->target_gain;
+	st.ng_gain = 1;
+	return st;
 }
 
 mi_volume_state *vstate(VolumeData *d) {
@@ -179,6 +205,7 @@ void volume_attach_slot(MSFilter *f) {
 	if (d->pool) { // rate changed, moved to another ticker, or the bank failed: the slot goes back (under ITS hub's lock)
 		HubLock old(f);
 		if (d->pool->failed || d->pool->rate != d->sample_rate || d->pool->hub->ticker != f->ticker) {
+			volume_keep_state(d);
 			d->pool->release(d->slot);
 			d->pool = nullptr;
 			d->slot = -1;
@@ -194,13 +221,8 @@ void volume_attach_slot(MSFilter *f) {
 			return;
 		}
 		note_slot(f);
-		// fresh slot: volume_init state, then whatever the methods set before attach
-		mi_volume_state st;
-		memset(&st, 0, sizeof(st));
-		st.gain = d->gain;
-		st.target_gain = d->target_gain;
-		st.ng_gain = 1;
-		d->pool->state[(size_t)d->slot] = st;
+		// new slot: volume_init's state and whatever the methods set before attach, or the running state the last slot held
+		d->pool->state[(size_t)d->slot] = volume_start_state(d);
 		d->pool->state_dirty[(size_t)d->slot] = 1;
 	}
 	// the peer is addressed by its slot in the same pool
@@ -292,7 +314,11 @@ void VolumePool::emit(MSFilter *f, int slot) {
 		if (f->outputs[0]) ms_queue_put(f->outputs[0], om);
 		else freemsg(om);
 	}
-	if (ready[s] && f->ticker) { // meters (update_energy msvolume.c:405-406)
+	if (ready[s] && f->ticker) { // meters (update_energy msvolume.c:405-406): every chunk's energy, in order
+		for (int r = 0; r + 1 < std::min(ready[s], rounds_fetched); ++r) {
+			d->max.record_max(f->ticker->time, h_state[r * c + s].energy);
+			d->min.record_min(f->ticker->time, h_state[r * c + s].energy);
+		}
 		d->max.record_max(f->ticker->time, state[s].energy);
 		d->min.record_min(f->ticker->time, state[s].energy);
 	}
@@ -331,6 +357,10 @@ void volume_set_gains(VolumeData *d, bool also_target) {
 		HubLock lk(leg_pool(d->leg)->hub);
 		leg_push_volume(d->leg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
 		return;
+	}
+	if (d->has_kept) { // (a state waiting for its next slot follows the methods too)
+		d->kept.gain = d->gain;
+		if (also_target) d->kept.target_gain = d->target_gain;
 	}
 	if (!d->pool) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
 	HubLock lk(d->pool->hub);

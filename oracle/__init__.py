@@ -497,3 +497,109 @@ class GenericPlcFilter:
                 out.append(self.plc.conceal(n))
             L.orc_concealer_inc_sample_time(C.byref(self.con), now_ms, self.interval, 0)
         return out
+
+
+# ------------------------------------------------------------------ conference glue (oracle/conference.c)
+class OrcExtremum(C.Structure):
+    _fields_ = [("current_extremum", C.c_float), ("last_stable", C.c_float), ("extremum_time", C.c_uint64), ("period", C.c_int)]
+
+
+class OrcConference(C.Structure):
+    _fields_ = [("nmembers", C.c_int), ("active_speaker", C.c_int), ("plumbed", C.c_uint8 * 50), ("muted", C.c_uint8 * 50)]
+
+
+def _declare_conference(L):
+    if getattr(L, "_conference_declared", False):
+        return L
+    ep, cp = C.POINTER(OrcExtremum), C.POINTER(OrcConference)
+    L.orc_extremum_init.argtypes = [ep, C.c_int]
+    L.orc_extremum_reset.argtypes = [ep]
+    L.orc_extremum_record_min.argtypes = [ep, C.c_uint64, C.c_float]
+    L.orc_extremum_record_max.argtypes = [ep, C.c_uint64, C.c_float]
+    L.orc_extremum_get_current.argtypes = [ep]
+    L.orc_extremum_get_current.restype = C.c_float
+    L.orc_volume_linear_to_dbm0.argtypes = [C.c_float]
+    L.orc_volume_linear_to_dbm0.restype = C.c_float
+    L.orc_conference_init.argtypes = [cp]
+    L.orc_conference_add_member.argtypes = [cp, C.c_int]
+    L.orc_conference_remove_member.argtypes = [cp, C.c_int]
+    L.orc_conference_mute_member.argtypes = [cp, C.c_int, C.c_int]
+    L.orc_conference_get_size.argtypes = [cp]
+    L.orc_conference_participant_volume.argtypes = [cp, C.c_int, C.c_float]
+    L.orc_conference_process_events.argtypes = [cp, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    L._conference_declared = True
+    return L
+
+
+def linear_to_dbm0(x):
+    return _declare_conference(lib()).orc_volume_linear_to_dbm0(float(x))
+
+
+class Extremum:
+    """OrtpExtremum as MSVolume feeds it (msvolume.c:115-116,405-406)"""
+
+    def __init__(self, period_ms):
+        self.L = _declare_conference(lib())
+        self.e = OrcExtremum()
+        self.L.orc_extremum_init(C.byref(self.e), int(period_ms))
+
+    def reset(self):
+        self.L.orc_extremum_reset(C.byref(self.e))
+
+    def record_max(self, now_ms, v):
+        return self.L.orc_extremum_record_max(C.byref(self.e), int(now_ms), float(v))
+
+    def record_min(self, now_ms, v):
+        return self.L.orc_extremum_record_min(C.byref(self.e), int(now_ms), float(v))
+
+    @property
+    def current(self):
+        return self.L.orc_extremum_get_current(C.byref(self.e))
+
+
+class Conference:
+    """MSAudioConference's bookkeeping in mixer mode (src/voip/audioconference.c); members are named by their mixer pin"""
+
+    def __init__(self):
+        self.L = _declare_conference(lib())
+        self.c = OrcConference()
+        self.L.orc_conference_init(C.byref(self.c))
+        self.order = []   # the conference's member list, in joining order
+
+    def add_member(self, muted=False):
+        pin = self.L.orc_conference_add_member(C.byref(self.c), int(muted))
+        if pin >= 0:
+            self.order.append(pin)
+        return pin
+
+    def remove_member(self, pin):
+        self.L.orc_conference_remove_member(C.byref(self.c), int(pin))
+        self.order.remove(pin)
+
+    def mute_member(self, pin, muted):
+        self.L.orc_conference_mute_member(C.byref(self.c), int(pin), int(muted))
+
+    def muted(self, pin):
+        return bool(self.c.muted[pin])
+
+    @property
+    def size(self):
+        return self.L.orc_conference_get_size(C.byref(self.c))
+
+    @property
+    def active_speaker(self):
+        return self.c.active_speaker
+
+    def participant_volume(self, pin, volume_db):
+        return self.L.orc_conference_participant_volume(C.byref(self.c), int(pin), float(volume_db))
+
+    def process_events(self, max_db_by_pin):
+        """max_db_by_pin: {pin: MS_VOLUME_GET_MAX of that member}.  -> (changed, winner pin or -1, its dB)"""
+        order = (C.c_int * max(1, len(self.order)))(*self.order)
+        db = (C.c_float * 50)(*([-120.0] * 50))
+        for pin, v in max_db_by_pin.items():
+            db[pin] = v
+        wp, wd = C.c_int(), C.c_float()
+        ch = self.L.orc_conference_process_events(C.byref(self.c), order, db, C.byref(wp), C.byref(wd))
+        return bool(ch), wp.value, wd.value
+

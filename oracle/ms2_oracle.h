@@ -208,6 +208,35 @@ void orc_concealer_init(OrcConcealer *o, uint32_t max_plc_time);
 uint32_t orc_concealer_inc_sample_time(OrcConcealer *o, uint64_t now, uint32_t increment, int got_packet);
 int orc_concealer_required(OrcConcealer *o, uint64_t now);
 
+/* ------------------------------------------------- conference glue (oracle/conference.c)
+ * OrtpExtremum as MSVolume uses it (msvolume.c:115-116,405-406; oRTP itself is not under /root/reference: parity unpinned)
+ * and MSAudioConference's bookkeeping in mixer mode (src/voip/audioconference.c). */
+#define ORC_MIXER_MAX_CHANNELS 50   /* audiomixer.c:29 */
+#define ORC_VOLUME_DB_LOWEST (-120) /* msvolume.h */
+#define ORC_VOLUMES_NOT_FOUND (-32768) /* AUDIOSTREAMVOLUMES_NOT_FOUND = INT16_MIN, mediastream.h:1131 */
+typedef struct OrcExtremum {
+	float current_extremum, last_stable;
+	uint64_t extremum_time;
+	int period;
+} OrcExtremum;
+void orc_extremum_init(OrcExtremum *e, int period);
+void orc_extremum_reset(OrcExtremum *e);
+int orc_extremum_record_min(OrcExtremum *e, uint64_t curtime, float value);
+int orc_extremum_record_max(OrcExtremum *e, uint64_t curtime, float value);
+float orc_extremum_get_current(const OrcExtremum *e);
+float orc_volume_linear_to_dbm0(float linear); /* msvolume.c:565-568 */
+typedef struct OrcConference {
+	int nmembers, active_speaker; /* active speaker: its mixer pin, -1 = none elected yet */
+	uint8_t plumbed[ORC_MIXER_MAX_CHANNELS], muted[ORC_MIXER_MAX_CHANNELS];
+} OrcConference;
+void orc_conference_init(OrcConference *c);                             /* audioconference.c:67-92 */
+int orc_conference_add_member(OrcConference *c, int muted);              /* :198-207,322-345 -> the member's pin */
+void orc_conference_remove_member(OrcConference *c, int pin);            /* :366-374 */
+void orc_conference_mute_member(OrcConference *c, int pin, int muted);   /* :376-388 */
+int orc_conference_get_size(const OrcConference *c);                     /* :390-392 */
+int orc_conference_participant_volume(const OrcConference *c, int pin, float volume_db); /* :394-418 */
+int orc_conference_process_events(OrcConference *c, const int *order, const float *max_db, int *winner_pin, float *winner_db); /* :419-464 */
+
 /* ------------------------------------------------- recording metrics (oracle/audiodiff.c)
  * src/utils/audiodiff.c on WAV files (read with include/ms2_mediaio.h: sizes from the file length).
  * MSAudioDiffParams {max_shift_percent, chunk_size_ms} are passed as two ints. */

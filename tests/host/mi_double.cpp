@@ -804,6 +804,10 @@ int mi_fifo_reset_range(mi_fifo *f, int first, int count) {
 	for (int s = first; s < first + count; ++s) f->q[(size_t)s].clear();
 	return MI_OK;
 }
+int mi_fifo_reset_range_at(mi_fifo *f, int first, int count, int head) { // (the double's queues have no ring: the offset is moot)
+	ARG(f && head >= 0 && (head & 7) == 0);
+	return mi_fifo_reset_range(f, first, count);
+}
 int mi_fifo_reset(mi_fifo *f) {
 	ARG(f);
 	f->overflow = 0;

@@ -796,6 +796,60 @@ def test_bench_rig_with_legs_out_of_phase(ctx):
         rig.close()
 
 
+def test_an_output_queue_that_starts_short_of_a_frame(ctx):
+    """mi_fifo_reset_range_at: the canceller's launches append whole frames to their output FIFO at a tail they take to be
+    frame-aligned.  A queue that starts with r samples short of a frame (what an MSVolume held when its conference graph was
+    detached, handed to the plugin's fused leg: leg_chain.inl give_remainder) is emptied at head = capacity - r and given those
+    r samples: its tail then lies at offset 0.  Every leg's popped stream = its r samples followed by exactly what a rig without
+    them delivers, over 16+ wraps of the ring -- and the neighbours' rings are untouched (a frame written across the ring's end
+    would land in the next leg's)."""
+    torch = pytest.importorskip("torch")
+    rate, F, ns, n, nticks = 48000, 256, 480, 6, 150
+    cap, flen = 8 * F, 64 * rate // 1000
+    mic = np.stack([synth_pcm(700 + s, ns * nticks, rate=rate, sigma=2500.0) for s in range(n)])
+    ref = np.stack([synth_pcm(800 + s, ns * nticks, rate=rate, sigma=3000.0) for s in range(n)])
+    rem = [0, 32, 224, 448, 8, 96]
+    head = np.stack([synth_pcm(900 + s, ns, rate=rate, sigma=1000.0) for s in range(n)])
+    z = lambda *sh, dt=torch.int16: torch.zeros(sh, dtype=dt, device="cuda")
+
+    def run(with_rem):
+        a = ms.AecBatch(ctx, n, rate, frame_size=F, filter_length=flen)
+        fm, fr, fo = (ms.FifoBatch(ctx, n, cap) for _ in range(3))
+        if with_rem:
+            for s in range(n):
+                if rem[s]:
+                    fo.reset_range_at(s, 1, cap - rem[s])
+            cnt = torch.from_numpy(np.array(rem, np.int32)).cuda()
+            fo.push(torch.from_numpy(head).cuda(), nsamples=ns, count=cnt)
+            _, h0, l0 = fo.snapshot()
+            assert list(l0) == rem and list(h0) == [(cap - r) % cap for r in rem]
+        out, ok, cnt8 = z(n, ns), z(n, dt=torch.uint8), z(n, dt=torch.uint8)
+        got = [[] for _ in range(n)]
+        for t in range(nticks):
+            dm = torch.from_numpy(np.ascontiguousarray(mic[:, t * ns:(t + 1) * ns])).cuda()
+            dr = torch.from_numpy(np.ascontiguousarray(ref[:, t * ns:(t + 1) * ns])).cuda()
+            torch.cuda.synchronize()
+            a.process_fifos(fm, dm, fr, dr, fo, tick_len=ns, max_frames=2, count_out=cnt8)
+            fo.pop(ns, out, ok=ok, zero_fill=False)
+            ctx.sync()
+            o, k = out.cpu().numpy(), ok.cpu().numpy()
+            for s in range(n):
+                if k[s]:
+                    got[s].append(o[s].copy())
+        assert fm.overflows() + fr.overflows() + fo.overflows() == 0
+        for o in (a, fm, fr, fo):
+            o.close()
+        return [np.concatenate(g) for g in got]
+
+    plain, shifted = run(False), run(True)
+    for s in range(n):
+        r = rem[s]
+        np.testing.assert_array_equal(shifted[s][:r], head[s][:r], err_msg=f"leg {s}: the samples it started with")
+        m = min(len(shifted[s]) - r, len(plain[s]))
+        assert m > 140 * ns
+        np.testing.assert_array_equal(shifted[s][r:r + m], plain[s][:m], err_msg=f"leg {s} (r = {r})")
+
+
 def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
     """mi_aec_process_fifos keeps eight lists of legs (one per class b % 8 = the XCD a workgroup lands on) that every launch
     rebuilds for the next one: each leg enters itself into class (own class + own position) % 8, from the front if it will

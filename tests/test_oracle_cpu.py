@@ -440,3 +440,46 @@ def test_pixconv_matches_numpy_restatement(oracle):
     cw, chh = w // 2, hp // 2
     np.testing.assert_array_equal(got[w * hp: w * hp + cw * chh].reshape(chh, cw), u)
     np.testing.assert_array_equal(got[w * hp + cw * chh:].reshape(chh, cw), v)
+
+
+def test_oracle_extremum_windows(oracle):
+    """OrtpExtremum as MSVolume uses it (msvolume.c:115-116,405-406; oracle/conference.c): the extremum of the window a value was
+    recorded in; a record more than `period` ms after the window's first one closes it and opens the next with itself"""
+    e = oracle.Extremum(1000)
+    assert e.current == 0.0
+    seen = []
+    for t, v in [(0, .1), (500, .3), (900, .2), (1000, .25), (1001, .05), (1500, .04), (2001, .02), (2002, .01), (2003, .5)]:
+        e.record_max(t, v)
+        seen.append(round(e.current, 3))
+    assert seen == [.1, .3, .3, .3, .05, .05, .05, .01, .5]     # (1000 is not MORE than the period; 2001 is not either, counted from 1001; 2002 is)
+    assert abs(e.e.last_stable - .05) < 1e-6
+    m = oracle.Extremum(30000)                                  # the minimum, 30 s windows (msvolume.c:116)
+    for t, v in [(10, .2), (20, .1), (30000, .3), (30011, .4), (30012, .35)]:
+        m.record_min(t, v)
+    assert abs(m.current - .35) < 1e-6 and abs(m.e.last_stable - .1) < 1e-6
+    e.reset()
+    assert e.current == 0.0                                     # volume_preprocess (:467-468): nothing recorded yet reads as 0 -> -120 dB
+    assert oracle.linear_to_dbm0(0.0) == -120 and abs(oracle.linear_to_dbm0(0.001) + 30) < 1e-5
+
+
+def test_oracle_conference_bookkeeping_and_election(oracle):
+    """src/voip/audioconference.c in mixer mode as oracle/conference.c restates it: the lowest free pin (:198-207), sizes (:390-392),
+    muting (:376-388), a participant's volume (:394-418), the election (:419-464)"""
+    c = oracle.Conference()
+    assert [c.add_member() for _ in range(4)] == [0, 1, 2, 3] and c.size == 4 and c.active_speaker == -1
+    c.remove_member(1)
+    assert c.size == 3 and c.add_member() == 1 and c.order == [0, 2, 3, 1]         # the freed pin is taken again; the list appends
+    # strictly above -30 dB, strictly above the best so far: of two equals the first in the LIST wins (pin 2 joined before pin 1)
+    assert c.process_events({0: -40.0, 1: -20.0, 2: -20.0, 3: -50.0}) == (True, 2, -20.0) and c.active_speaker == 2
+    assert c.process_events({0: -40.0, 1: -20.0, 2: -20.0, 3: -50.0}) == (False, 2, -20.0)
+    assert c.process_events({0: -30.0, 1: -30.0, 2: -31.0, 3: -120.0}) == (False, -1, -120.0) and c.active_speaker == 2   # -30 itself is not above: nobody; the speaker stays
+    c.mute_member(2, True)
+    assert c.process_events({0: -40.0, 1: -25.0, 2: -5.0, 3: -50.0}) == (True, 1, -25.0)      # a muted member is passed over (:445)
+    assert c.participant_volume(2, -5.0) == -120 and c.participant_volume(1, -25.7) == -25 and c.participant_volume(7, 0.0) == -32768
+    c.mute_member(2, False)
+    assert c.process_events({0: -40.0, 1: -25.0, 2: -5.0, 3: -50.0}) == (True, 2, -5.0)
+    c.remove_member(2)
+    assert c.active_speaker == 2 and c.size == 3                                   # the pointer to the one who left stays until somebody wins (:460-464)
+    assert c.process_events({0: -10.0, 1: -25.0, 3: -50.0}) == (True, 0, -10.0)
+    full = oracle.Conference()
+    assert [full.add_member() for _ in range(50)] == list(range(50)) and full.add_member() == -1     # MIXER_MAX_CHANNELS (audiomixer.c:29); the reference aborts

@@ -88,3 +88,41 @@ def test_plugin_bench_shapes_fused_equal_one_by_one_by_checksum(verdict, shape):
     assert fused["mix_checksum"] == plain["mix_checksum"] == staged["mix_checksum"]
     assert fused["speaker_checksum"] == plain["speaker_checksum"] == staged["speaker_checksum"]
     assert fused["late_events"] == 0 and staged["late_events"] == 0
+
+
+@pytest.fixture(scope="module")
+def glue(verdict):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "conference_glue.py"), "--double"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_msaudioconference_glue_over_fused_legs(glue):
+    """tests/conference_glue.py: two conferences driven the way src/voip/audioconference.c drives its mixer -- members plumbed to the
+    lowest free pin with the graph detached and attached around it (:198-257,322-345), one leaving from the middle and the next
+    joiner taking its pin (:366-374), the loudest member muted and un-muted (:376-388), the active-speaker election over
+    MS_VOLUME_GET_MAX every 50 ms (:419-464; bookkeeping and election by oracle/conference.c) -- fused against the facades one
+    by one (host-memory double)."""
+    g = glue
+    assert g["plain_fused_legs_seen"] == 0 and min(g["fused_legs_seen"]) >= 7 and max(g["fused_legs_seen"]) == 8   # fused again after every re-plumbing
+    assert g["late"] == 0 and g["plain_late"] == 0 and g["after"] == [0, 0, 0] and g["plain_after"] == [0, 0, 0]
+    assert g["pins"] == {"a0": 0, "a1": 1, "a2": -1, "a3": 3, "b0": 0, "b1": -1, "b2": 2, "b3": 3, "b4": 1} and g["sizes"][-1] == [3, 4]
+    # the same samples until the graph is first re-plumbed ...
+    assert g["differ_before_replumb"] == []
+    # ... afterwards the same audio shifted by less than a tick (the fused form had already cancelled the tick in flight at the
+    # detach, the facades had not: one or two frames of MSVolume's re-framing), bit for bit at that shift
+    for name, (lag, left) in g["lag_after_leave"].items():
+        assert abs(lag) < 480 and left == 0.0, (name, lag, left)
+    # the election: never another winner; the 1 s maxima within 1 dB (their windows open a tick apart)
+    assert g["winner_differs"] == [] and g["worst_db_gap"] < 1.0
+    assert len(g["polls_differ_before_replumb"]) <= 2, g["polls_differ_before_replumb"]   # (the poll at which a window rolls over)
+    a, b = g["winners"]["a"], g["winners"]["b"]
+    assert a[10] == 1 and a[20] == 2 and a[30] == 0 and a[50] == 0 and a[63] == 2 and a[-1] == 1      # a1 | muted: a2 | a0's loud period, whose 1 s maximum outlasts it | a2's | a2 gone: a1
+    assert a[66] == -1 and g["speakers"]["a"][66] == 2    # right after the re-plumbing the maxima start over: nobody is elected, the speaker stays (:460-464)
+    assert b[10] == 1 and b[35] == 3 and b[60] == 1 and b[-1] == 0      # b1 | b3 joined (pin 3) | b3 quiet, b1 gone: b4 on pin 1 | b0's loud period
+    # a muted member is not heard, and is reported at the lowest level (:403)
+    r = g["a0_mix_rms"]
+    assert r["a1_muted"] < 0.5 * r["a1_talking"] and r["a1_back"] > 0.8 * r["a1_talking"] and g["volume_of_muted"] == -120
+    # MSVolume's meter reads on across the re-plumbing (struct Volume outlives the detach, msvolume.c:88-118)
+    for k in ("a1_meter_across_leave", "a1_meter_across_leave_plain"):
+        assert abs(g[k][0] - g[k][1]) < 1.0 and g[k][1] > -30, g[k]
