@@ -52,6 +52,8 @@ struct mi_session {
 	bool acquired = false;
 	// conference membership / active-speaker election (MSAudioConference, src/voip/audioconference.c)
 	std::vector<uint8_t> flags;      // MI_MIX_* per stream as last set (default: every pin linked, active, output on)
+	std::vector<uint32_t> joined;    // the conference's member LIST is in joining order (bctbx_list_append, audioconference.c:328): of two
+	uint32_t join_seq = 0;           // equally loud members the election takes the one that joined first (:449 compares strictly)
 };
 
 namespace {
@@ -200,6 +202,8 @@ int mi_session_create(mi_ctx *ctx, const mi_session_config *cfg, mi_session **ou
 	s->n = cfg->nstreams;
 	s->nconf = cfg->nstreams / cfg->members_per_conference;
 	s->flags.assign((size_t)s->n, (uint8_t)(MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT));
+	s->joined.resize((size_t)s->n);
+	for (int i = 0; i < s->n; ++i) s->joined[(size_t)i] = ++s->join_seq; // a session is created full: joined in pin order
 	s->in_len = cfg->in_rate / 100;
 	s->len = cfg->rate / 100;
 	const bool down = cfg->out_rate != 0 && cfg->out_rate != cfg->rate;
@@ -429,6 +433,7 @@ int mi_session_add_member(mi_session *s, int stream) {
 	const int rc = mi_session_reset_streams(s, stream, 1);
 	if (rc != MI_OK) return rc;
 	s->flags[(size_t)stream] = MI_MIX_LINKED | MI_MIX_ACTIVE | MI_MIX_OUTPUT;
+	s->joined[(size_t)stream] = ++s->join_seq; // appended to the member list
 	return mi_mixer_set_controls(s->mix, s->flags.data(), nullptr);
 }
 
@@ -476,13 +481,16 @@ int mi_session_active_speakers(mi_session *s, uint64_t now_ms, int32_t *h_winner
 	for (int c = 0; c < s->nconf; ++c) {
 		float best = -120.f; // MS_VOLUME_DB_LOWEST
 		int win = -1;
+		uint32_t win_joined = 0;
 		for (int m = 0; m < mm; ++m) {
 			const size_t i = (size_t)c * mm + m;
 			const uint8_t f = s->flags[i];
 			if (!(f & MI_MIX_LINKED) || !(f & MI_MIX_ACTIVE)) continue; // not plumbed / muted (:445)
 			const float lin = mx[i];
 			const float db = lin == 0 ? -120.f : 10 * log10f(lin); // ms_volume_linear_to_dbm0 msvolume.c:565-568
-			if (db > -30.0f && db > best) best = db, win = (int)i;
+			if (db <= -30.0f) continue;
+			// the list is walked in joining order and a later member must be strictly louder (:449): of equals, the earliest joiner
+			if (db > best || (db == best && win >= 0 && s->joined[i] < win_joined)) best = db, win = (int)i, win_joined = s->joined[i];
 		}
 		h_winner[c] = win;
 		if (h_max_db) h_max_db[c] = best;

@@ -33,8 +33,13 @@
 // history like the canceller does (the facade alone keeps its speex handle across a detach).
 // Anything else -- another rate pair, pins of different shapes, MSVolume with an echo-limiter peer, non-conference mode,
 // MSMI355X_NO_FUSE=1 -- keeps the facades on their own banks.  A fused conference falls back to them at run time when a
-// member's configuration stops qualifying (bypass mode switched on, AGC switched, ...): the audio queued on the device at
-// that moment (a few ms) is lost.
+// member's configuration stops qualifying (bypass mode switched on, AGC switched, ...).
+//
+// MSAudioConference re-plumbs a conference around every join and leave (detach, link / unlink one endpoint, attach:
+// src/voip/audioconference.c:322-374), so every member's filters see postprocess + preprocess.  What the reference's filters keep
+// across that goes with the FILTERS, not with the bank slot (conf_unfuse / conf_try_fuse): the tick already out is waited for and
+// delivered (deliver_in_flight), MSVolume's running state and the samples its bufferizer holds short of a chunk move to the next
+// slot (leg_keep_volume / volume_start_state, take_remainders / give_remainder); the canceller starts over as its preprocess does.
 
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
 constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one enqueue: kMaxRounds blocks of 10 ms in frames
@@ -1128,7 +1133,7 @@ void leg_keep_volume(FusedLeg *leg) {
 
 // The conference leaves its LegBank: at detach (every facade's postprocess ends up here, the first one does the work) or,
 // keep_running, because a member stopped qualifying while attached -- the facades then go on with banks of their own and
-// what was queued on the device is lost.
+// the canceller's queues on the device are dropped (its postprocess flushes them, speexec.c:305-319).
 void conf_unfuse(MSFilter *mx, bool keep_running) {
 	MixerState *ms = (MixerState *)mx->data;
 	LegBank *b = ms->fbank;

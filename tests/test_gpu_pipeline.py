@@ -1093,3 +1093,107 @@ def test_canceller_launch_with_the_resampler_folded_in_equals_the_two_launches(c
         a2.process_fifos_resampled(rs3, z(n, 160), fm2, fr2, z(n, 448), fo2)
     for o in (rs1, a1, fm1, fr1, fo1, rs2, a2, fm2, fr2, fo2, rs3):
         o.close()
+
+
+def test_session_elects_what_the_oracle_conference_elects(ctx, oracle):
+    """mi_session's own conference glue (mi_session_add_member / remove_member / set_controls / active_speakers) against the
+    ORACLE's MSAudioConference (oracle/conference.c: pins, list order, the election of audioconference.c:419-464) fed by the chain
+    of oracle objects on the same audio (Echo + Preproc -> Volume with AGC -> its 1 s OrtpExtremum): two conferences of 8, talkers
+    whose loudness is scripted, the loudest muted and un-muted, one member leaving and a NEW one taking its slot.  Every poll
+    (50 ms apart): the same winner -- polls in which the oracle's two loudest are within 0.5 dB of each other or of the -30 dB
+    threshold left out -- and the winner's maximum within 0.2 dB."""
+    mm, n, rate, ns, F, nticks = 8, 16, 48000, 480, 256, 330
+    rng = np.random.default_rng(21)
+    t = np.arange(nticks * ns)
+    loud = np.full((n, 5), 150.0)                       # sigma per leg and 66-tick period
+    loud[2] = [3000, 3000, 3000, 3000, 3000]
+    loud[5] = [800, 800, 9000, 800, 800]
+    loud[6] = [1500, 1500, 1500, 1500, 6000]
+    loud[mm + 1] = [2500, 2500, 2500, 2500, 2500]
+    loud[mm + 4] = [700, 700, 700, 5000, 5000]
+    far = np.stack([(rng.normal(0, 1200, nticks * ns) + 800 * np.sin(2 * np.pi * (300 + 40 * s) * t / rate)) for s in range(n)])
+    echo = 0.3 * np.concatenate([np.zeros((n, 2 * ns)), far[:, :-2 * ns]], axis=1)
+    env = np.repeat(loud, 66 * ns, axis=1)[:, :nticks * ns]
+    talk = env * (0.6 * rng.normal(0, 1, (n, nticks * ns)) + np.sin(2 * np.pi * 170 * t / rate))
+    mic = (echo + talk).round().clip(-32767, 32767).astype(np.int16)
+    far = far.round().clip(-32767, 32767).astype(np.int16)
+    script = {70: ("mute", 2, True), 150: ("leave", mm + 1), 200: ("mute", 2, False), 240: ("join", mm + 1)}
+    joiner = (2200 * (0.6 * rng.normal(0, 1, nticks * ns) + np.sin(2 * np.pi * 210 * t / rate))).round().clip(-32767, 32767).astype(np.int16)
+
+    se = ms.Session(ctx, n, members=mm, in_rate=rate, rate=rate, tail_ms=64, agc=True)
+    L, A, O = ms.MI_MIX_LINKED, ms.MI_MIX_ACTIVE, ms.MI_MIX_OUTPUT
+    flags = np.full(n, L | A | O, np.uint8)
+    flen = 64 * rate // 1000
+
+    class OLeg:
+        def __init__(self):
+            self.ec = oracle.Echo(F, flen, rate)
+            self.pp = oracle.Preproc(F, rate, self.ec)
+            self.vol = oracle.Volume(rate)
+            self.vol.v.agc_enabled = 1
+            self.max = oracle.Extremum(1000)
+            self.qm, self.qr, self.qv = (np.zeros(0, np.int16) for _ in range(3))
+
+        def tick(self, now, m, r):
+            self.qm, self.qr = np.concatenate([self.qm, m]), np.concatenate([self.qr, r])
+            while len(self.qm) >= F:
+                self.qv = np.concatenate([self.qv, self.pp.run(self.ec.cancel(self.qm[:F], self.qr[:F]))])
+                self.qm, self.qr = self.qm[F:], self.qr[F:]
+            if len(self.qv) >= ns:          # the session's volume + mix launch takes one chunk per tick (a dry leg is metered on silence)
+                ch, self.qv = self.qv[:ns], self.qv[ns:]
+            else:
+                ch = np.zeros(ns, np.int16)
+            self.vol.chunk(ch)
+            self.max.record_max(now, self.vol.v.energy)
+
+    legs = [OLeg() for _ in range(n)]
+    books = [oracle.Conference(), oracle.Conference()]
+    for c in range(2):
+        assert [books[c].add_member() for _ in range(mm)] == list(range(mm))
+    present = np.ones(n, bool)
+    checked = skipped = 0
+    for k in range(nticks):
+        ev = script.get(k)
+        if ev:
+            s = ev[1]
+            if ev[0] == "mute":
+                flags[s] = (L | O) if ev[2] else (L | A | O)
+                se.set_controls(flags=flags)
+                books[s // mm].mute_member(s % mm, ev[2])
+            elif ev[0] == "leave":
+                se.remove_member(s)
+                books[s // mm].remove_member(s % mm)
+                present[s] = False
+                flags[s] = 0
+            else:
+                se.add_member(s)
+                assert books[s // mm].add_member() == s % mm            # the lowest free pin is the slot that was given up
+                legs[s] = OLeg()                                         # a NEW endpoint: fresh filters
+                present[s] = True
+                flags[s] = L | A | O
+                mic[s, k * ns:] = joiner[k * ns:]
+        m, r = se.acquire()
+        m[:] = mic[:, k * ns:(k + 1) * ns]
+        r[:] = far[:, k * ns:(k + 1) * ns]
+        m[~present] = 0
+        se.submit()
+        se.collect()
+        for s in range(n):
+            if present[s]:
+                legs[s].tick(10 * k, mic[s, k * ns:(k + 1) * ns], far[s, k * ns:(k + 1) * ns])
+        if k % 5 == 4:
+            win, db = se.active_speakers(10 * k)
+            for c in range(2):
+                want = {p: oracle.linear_to_dbm0(legs[c * mm + p].max.current) for p in books[c].order}
+                _, wpin, wdb = books[c].process_events(want)
+                top = sorted(want.values(), reverse=True)
+                if top[0] - top[1] < 0.5 or any(abs(v + 30.0) < 0.5 for v in top[:2]):
+                    skipped += 1
+                    continue
+                checked += 1
+                assert (win[c] - c * mm if win[c] >= 0 else -1) == wpin, (k, c, win[c], wpin, want)
+                if wpin >= 0:
+                    assert abs(db[c] - wdb) < 0.2, (k, c, db[c], wdb)
+    assert checked > 0.8 * 2 * (nticks // 5), (checked, skipped)
+    assert se.member_count(0) == books[0].size == mm and se.member_count(1) == books[1].size == mm
+    se.close()
