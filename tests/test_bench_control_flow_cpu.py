@@ -111,3 +111,30 @@ def test_the_c_exchange_comes_up_on_every_rank_or_the_run_fails_on_every_rank():
     assert not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
     assert bad.stderr.count("could not be set up") >= 2 and "unhandled system error" in bad.stderr   # both ranks said so, with the reason
     assert "torch.distributed's RCCL communicator instead" not in bad.stderr
+
+
+def test_a_late_tick_that_was_the_submitting_threads_stall_is_told_from_one_the_device_took_long_over():
+    """bench.TickTimes keeps, beside every tick's HIP-event time, the host's own time from before the first event's record to the
+    return of the launch call; host_stalls_only(): every late tick of the series is covered (>= 90 % of its excess over the
+    median) by that -- the acceptance loop then tries the count once more instead of stepping down (a stall of the box would
+    make a tick of one leg late); series_stats() carries the evidence into the line."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    v = bench.TickTimes(3000)
+    v[:] = 9.1
+    v.submit[:] = 0.02
+    assert not bench.host_stalls_only(v)                      # nothing late
+    v[93], v.submit[93] = 21.3, 12.25                         # the thread was held up for 12 ms between the event and the launch
+    assert bench.host_stalls_only(v)
+    st = bench.series_stats(v)
+    assert st["late"] == 1 and st["slowest"][0] == [93, 21.3] and st["slowest_host_submit_ms"][0] == 12.25 and st["host_submit_max_ms"] == 12.25
+    v[700], v.submit[700] = 10.4, 0.02                        # ... and one the DEVICE took long over: the series is a verdict again
+    assert not bench.host_stalls_only(v)
+    w = bench.TickTimes(100)
+    w[:] = 9.0
+    w.submit[:] = 0.02
+    w[5], w.submit[5] = 11.0, 0.6                             # a small hiccup that explains a third of the lateness does not excuse it
+    assert not bench.host_stalls_only(w)
+    assert not bench.host_stalls_only(np.full(10, 11.0))      # a plain array (no host times): never excused
+    assert float(np.median(v)) == 9.1 and float(v.max()) == 21.3 and isinstance(v[1:5], bench.TickTimes)
