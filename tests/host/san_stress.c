@@ -294,6 +294,23 @@ static void *conferences(void *arg) {
 				ms_ticker_detach(tk, mx[0]);
 				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
 			}
+			/* ms_audio_conference_remove_member / add_member (audioconference.c:322-374): the conference graph detached, a member from
+			 * the middle un-plumbed, attached again (MSVolume's state and queued samples move from slot to slot, the tick in flight is
+			 * delivered); a tick later it joins again on the pin it gave up */
+			if (t == 10) {
+				ms_ticker_detach(tk, mx[0]);
+				ms_filter_unlink(leg[0][2].vol, 0, mx[0], 2), ms_filter_unlink(mx[0], 2, leg[0][2].out, 0);
+				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
+			}
+			if (t == 11) {
+				ms_ticker_detach(tk, mx[0]);
+				ms_filter_link(leg[0][2].vol, 0, mx[0], 2), ms_filter_link(mx[0], 2, leg[0][2].out, 0);
+				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
+			}
+			if (t == 12) { /* a leg without a mixer detached and attached again (its chunks and speaker frames in flight are handed on) */
+				ms_ticker_detach(tk, solo[0].mic);
+				CHECK(ms_ticker_attach(tk, solo[0].mic) == 0);
+			}
 		}
 		for (int k = 0; k < 3; ++k) {
 			leg_t *l = &solo[k];
