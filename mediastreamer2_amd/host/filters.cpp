@@ -560,6 +560,7 @@ MSFilter *leg_find_mixer(MSFilter *rs);
 bool conf_try_fuse(MSFilter *mixer);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
 void leg_disqualify(FusedLeg *leg);
+void leg_forwarder_changed(MSFilter *rs); // a forwarding MSResample between a fused leg's MSVolume and its mixer pin is given other rates
 void leg_release(FusedLeg *leg, bool keep_running); // the leg (and, in a conference, everybody with it) leaves its fused batch
 bool leg_try_fuse_plain(MSFilter *rs);
 bool leg_wants_out(FusedLeg *leg);

@@ -946,9 +946,44 @@ bool is_ec_desc(const MSFilterDesc *d) { return d == &ms_mi355x_speex_ec_desc ||
 
 // Is pin `pin` of mixer `mx` the end of  MSResample -> MSSpeexEC (pin 1) -> MSVolume, all ours, all on the mixer's ticker,
 // all fresh?  Fills the candidate.
+// MSAudioConference plumbs every endpoint through a resampler pair: mixer_in -> in_resampler -> mixer pin -> out_resampler ->
+// mixer_out (src/voip/audioconference.c:209-257).  For an endpoint that already runs at the conference's rate they forward their
+// blocks untouched (msresample.c:126-135): such an MSResample of ours between MSVolume and the pin is looked through -- while the
+// leg is fused nothing passes it, after un-fusing MSVolume's chunks pass it again as before.
+bool is_pass_resampler(MSFilter *f, MSTicker *ticker) {
+	if (!f || f->desc != &ms_mi355x_resample_desc || f->ticker != ticker) return false;
+	const ResampleData *rd = (const ResampleData *)f->data;
+	return rd->input_rate == rd->output_rate && rd->in_nchannels == rd->out_nchannels && !rd->leg && !rd->pool && ms_bufferizer_get_avail(rd->bz) == 0;
+}
+// the filter MSVolume's output ends up in, behind a forwarding in_resampler if there is one
+MSFilter *leg_volume_sink(MSFilter *vol) {
+	MSQueue *q = vol->outputs[0];
+	MSFilter *g = q ? q->next.filter : NULL;
+	if (g && is_pass_resampler(g, vol->ticker) && ms_queue_empty(q)) {
+		q = g->outputs[0];
+		g = q ? q->next.filter : NULL;
+	}
+	return g;
+}
+
+// ... and when such a forwarder is told to resample after all, the conference behind it goes back to its facades (the mixer's next
+// process() honours it)
+void leg_forwarder_changed(MSFilter *rs) {
+	MSQueue *q = rs->outputs[0];
+	MSFilter *mx = q ? q->next.filter : NULL;
+	if (!mx || mx->desc != &ms_mi355x_audio_mixer_desc) return;
+	MixerState *ms = (MixerState *)mx->data;
+	if (ms->fbank) ms->unfuse_wanted = true;
+}
+
 bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	MSQueue *q = mx->inputs[pin];
 	MSFilter *vol = q->prev.filter;
+	if (is_pass_resampler(vol, mx->ticker)) { // the endpoint's in_resampler, forwarding
+		if (!ms_queue_empty(q)) return false;
+		q = vol->inputs[0];
+		vol = q ? q->prev.filter : NULL;
+	}
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
@@ -1099,8 +1134,7 @@ MSFilter *leg_find_mixer(MSFilter *rs) {
 	q = ec->outputs[1];
 	MSFilter *vol = q ? q->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc) return NULL;
-	q = vol->outputs[0];
-	MSFilter *mx = q ? q->next.filter : NULL;
+	MSFilter *mx = leg_volume_sink(vol);
 	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
 }
 
@@ -1109,8 +1143,7 @@ MSFilter *leg_find_mixer_ec(MSFilter *ec) {
 	MSQueue *q = ec->outputs[1];
 	MSFilter *vol = q ? q->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc) return NULL;
-	q = vol->outputs[0];
-	MSFilter *mx = q ? q->next.filter : NULL;
+	MSFilter *mx = leg_volume_sink(vol);
 	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
 }
 

@@ -235,7 +235,7 @@ void ResamplePool::emit(MSFilter *f, int slot) {
 int resample_set_sr(MSFilter *f, void *arg) { // :181-192
 	ResampleData *d = (ResampleData *)f->data;
 	ms_filter_lock(f);
-	if (d->input_rate != *(unsigned int *)arg) leg_disqualify(d->leg);
+	if (d->input_rate != *(unsigned int *)arg) leg_disqualify(d->leg), leg_forwarder_changed(f);
 	d->input_rate = *(unsigned int *)arg;
 	ms_filter_unlock(f);
 	return 0;
@@ -243,7 +243,7 @@ int resample_set_sr(MSFilter *f, void *arg) { // :181-192
 int resample_set_output_sr(MSFilter *f, void *arg) { // :194-205
 	ResampleData *d = (ResampleData *)f->data;
 	ms_filter_lock(f);
-	if (d->output_rate != *(unsigned int *)arg) leg_disqualify(d->leg);
+	if (d->output_rate != *(unsigned int *)arg) leg_disqualify(d->leg), leg_forwarder_changed(f);
 	d->output_rate = *(unsigned int *)arg;
 	ms_filter_unlock(f);
 	return 0;
@@ -251,6 +251,7 @@ int resample_set_output_sr(MSFilter *f, void *arg) { // :194-205
 int resample_set_in_nch(MSFilter *f, void *arg) {
 	ResampleData *d = (ResampleData *)f->data;
 	ms_filter_lock(f);
+	if (d->in_nchannels != *(int *)arg) leg_forwarder_changed(f);
 	d->in_nchannels = *(int *)arg;
 	ms_filter_unlock(f);
 	return 0;
@@ -258,6 +259,7 @@ int resample_set_in_nch(MSFilter *f, void *arg) {
 int resample_set_out_nch(MSFilter *f, void *arg) {
 	ResampleData *d = (ResampleData *)f->data;
 	ms_filter_lock(f);
+	if (d->out_nchannels != *(int *)arg) leg_forwarder_changed(f);
 	d->out_nchannels = *(int *)arg;
 	ms_filter_unlock(f);
 	return 0;

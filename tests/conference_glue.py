@@ -2,7 +2,7 @@
 conference in mixer mode -- members plumbed to the lowest free mixer pin with the mixer detached and re-attached around it
 (:198-257,322-345), members leaving (:366-374), muting (MS_AUDIO_MIXER_SET_ACTIVE, :376-388), the active-speaker election
 over MS_VOLUME_GET_MAX of every member's MSVolume (:419-464) -- driven against call legs of
-MSResample -> MSSpeexEC -> MSVolume(AGC) -> mixer pin, one ticker per conference (:70-73).
+MSResample -> MSSpeexEC -> MSVolume(AGC) -> in_resampler -> mixer pin -> out_resampler, one ticker per conference (:70-73).
 
 The bookkeeping (pins, list order, election) is the oracle's restatement (oracle/conference.c); the filters are the plugin's.
 run() plays one scripted conference call and returns every leg's audio and every poll; oracle_polls() predicts the polls from
@@ -55,10 +55,13 @@ class Leg:
         for a, pa, b, pb in ((self.mic, 0, self.rs, 0), (self.rs, 0, self.ec, 1), (self.ec, 1, self.vol, 0), (self.far, 0, self.ec, 0),
                              (self.ec, 0, self.spk, 0)):
             assert S.ms_filter_link(a, pa, b, pb) == 0
+        # the endpoint's resampler pair (ms_audio_endpoint_new, audioconference.c:473-474): conference rate on both sides here, so
+        # both forward their blocks untouched (msresample.c:126-135)
+        self.in_rs, self.out_rs = (S.ms_factory_create_filter(h.fac, fg.MS_RESAMPLE_ID) for _ in range(2))
         self.pin = -1
 
     def destroy(self):
-        for f in (self.mic, self.far, self.spk, self.out, self.rs, self.ec, self.vol):
+        for f in (self.mic, self.far, self.spk, self.out, self.rs, self.ec, self.vol, self.in_rs, self.out_rs):
             self.h.S.ms_filter_destroy(f)
 
 
@@ -78,16 +81,19 @@ class GlueConference:
         if self.book.size > 0:
             self.S.ms_ticker_detach(self.ticker, self.mixer)
         leg.pin = self.book.add_member(muted)
-        assert self.S.ms_filter_link(leg.vol, 0, self.mixer, leg.pin) == 0     # plumb_to_conf :209-257 (the resampler pair of
-        assert self.S.ms_filter_link(self.mixer, leg.pin, leg.out, 0) == 0     # an endpoint is the leg's own MSResample here)
+        # plumb_to_conf :209-257: mixer_in -> in_resampler -> pin, pin -> out_resampler -> mixer_out, then the resamplers' rates
+        for a, pa, b, pb in ((leg.vol, 0, leg.in_rs, 0), (leg.in_rs, 0, self.mixer, leg.pin), (self.mixer, leg.pin, leg.out_rs, 0), (leg.out_rs, 0, leg.out, 0)):
+            assert self.S.ms_filter_link(a, pa, b, pb) == 0
+        for f, m in ((leg.in_rs, SET_OUT_RATE), (leg.out_rs, SET_RATE), (leg.in_rs, SET_RATE), (leg.out_rs, SET_OUT_RATE)):
+            self.h.call_int(f, m, RATE)
         self.S.ms_ticker_attach(self.ticker, self.mixer)
         self.by_pin[leg.pin] = leg
         self.mute_member(leg, muted)
 
     def remove_member(self, leg):             # :366-374
         self.S.ms_ticker_detach(self.ticker, self.mixer)
-        assert self.S.ms_filter_unlink(leg.vol, 0, self.mixer, leg.pin) == 0
-        assert self.S.ms_filter_unlink(self.mixer, leg.pin, leg.out, 0) == 0
+        for a, pa, b, pb in ((leg.vol, 0, leg.in_rs, 0), (leg.in_rs, 0, self.mixer, leg.pin), (self.mixer, leg.pin, leg.out_rs, 0), (leg.out_rs, 0, leg.out, 0)):
+            assert self.S.ms_filter_unlink(a, pa, b, pb) == 0                  # unplumb_from_conf :347-364
         self.book.remove_member(leg.pin)
         del self.by_pin[leg.pin]
         leg.pin = -1

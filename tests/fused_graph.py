@@ -130,7 +130,8 @@ class Host:
 class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
-    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True):
+    def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
+                 endpoint_resamplers=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -165,7 +166,16 @@ class Conferences:
                 # MSResample is created all the same and stays unlinked)
                 links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1)] if resampler else [(leg["mic"], 0, leg["ec"], 1)]
                 links += [(leg["ec"], 1, leg["vol"], 0), (leg["far"], 0, leg["ec"], 0), (leg["ec"], 0, leg["spk"], 0)]
-                links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
+                if mixer and endpoint_resamplers:
+                    # MSAudioConference's plumbing (audioconference.c:209-257): in_resampler in front of the pin, out_resampler behind it --
+                    # both at the conference's rate here: they forward (msresample.c:126-135)
+                    leg["in_rs"], leg["out_rs"] = (S.ms_factory_create_filter(h.fac, MS_RESAMPLE_ID) for _ in range(2))
+                    for f in (leg["in_rs"], leg["out_rs"]):
+                        h.call_int(f, base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                        h.call_int(f, base("MS_FILTER_SET_OUTPUT_SAMPLE_RATE"), rate)
+                    links += [(leg["vol"], 0, leg["in_rs"], 0), (leg["in_rs"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out_rs"], 0), (leg["out_rs"], 0, leg["out"], 0)]
+                else:
+                    links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
                 for a, pa, b, pb in links:
                     assert S.ms_filter_link(a, pa, b, pb) == 0
                 self.legs.append(leg)
@@ -192,8 +202,9 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol"):
-                self.S.ms_filter_destroy(leg[k])
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs"):
+                if k in leg:
+                    self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
             self.S.ms_filter_destroy(mx)
         self.S.ms_ticker_destroy(self.ticker)
@@ -228,7 +239,8 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc = dict(nconf=2, members=4, nticks=120, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, pins=None)
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
-                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"))
+                       gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -263,6 +275,8 @@ def run(plugin_dir, fuse, scenario, h=None):
                     h.call_bool(leg["ec"], EC_SET_BYPASS, val)
                 elif kind == "agc":
                     h.call_int(leg["vol"], VOL_ENABLE_AGC, val)
+                elif kind == "in_rs_rate":   # the endpoint's in_resampler is told to resample after all
+                    h.call_int(leg["in_rs"], IDS["MS_FILTER_SET_SAMPLE_RATE"], val)
                 elif kind == "reattach":
                     conf.detach()
                     conf.attach()
@@ -285,6 +299,9 @@ SCENARIOS = {
     "gain_method": {"events": [(40, "gain", 1, 0.5), (70, "gain", 5, 2.0)], "no_early_launch": True},
     "gain_method_early": {"events": [(40, "gain", 1, 0.5), (70, "gain", 5, 2.0)]},
     "wideband_8k_16k": {"in_rate": 8000, "rate": 16000, "tail_ms": 128, "nticks": 100},
+    # the conference as MSAudioConference plumbs it: a forwarding in_resampler in front of every pin, an out_resampler behind it
+    "endpoint_resamplers": {"endpoint_resamplers": True, "delay_ms": 10, "far_gaps": True},
+    "endpoint_resamplers_no_agc_no_resampler": {"endpoint_resamplers": True, "no_agc": True, "no_resampler": True, "in_rate": 48000, "members": 3, "pins": [1, 4, 6]},
     # an AudioStream's sending side, several streams on one ticker: MSVolume's chunks go on to another filter, there is no mixer
     "no_mixer": {"no_mixer": True, "nconf": 1, "members": 6, "delay_ms": 10, "far_gaps": True},
     "no_mixer_ptime20": {"no_mixer": True, "nconf": 1, "members": 5, "ptime20": True, "nticks": 100},

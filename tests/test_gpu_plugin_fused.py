@@ -56,6 +56,16 @@ def test_a_member_that_stops_qualifying_takes_the_conference_back_to_its_facades
     assert n >= 70 * 480 and res["out"][0][-4800:].any() and res["late"] == 0 and res["after"] == (0, 0, 0)
 
 
+def test_a_forwarding_in_resampler_that_is_told_to_resample_sends_the_conference_back_to_its_facades(host):
+    """MSAudioConference's in_resampler in front of every pin (audioconference.c:209-257) forwards while the endpoint runs at the
+    conference's rate, and the fused batch looks through it; given another input rate it must resample again: the conference
+    leaves the batch at the next tick and the facades carry on."""
+    sc = dict(fg.SCENARIOS["endpoint_resamplers"], nconf=1, nticks=80, events=[(30, "in_rs_rate", 2, 44100)])
+    res = fg.run(PKG, True, sc, host)
+    assert res["stats"]["conferences"] == 0          # (read at tick 40: un-fused by then)
+    assert len(res["out"][0]) >= 70 * 480 and res["out"][0][-4800:].any() and res["late"] == 0 and res["after"] == (0, 0, 0)
+
+
 def test_detach_and_reattach_fuses_again(host):
     sc = dict(fg.SCENARIOS["plain"], nconf=2, nticks=90, events=[(35, "reattach", 0, 0)])
     res = fg.run(PKG, True, sc, host)

@@ -27,7 +27,8 @@ def verdict():
 
 @pytest.mark.parametrize("name", ["plain", "delay_and_far_gaps", "ptime20", "odd_pins", "gain_method", "wideband_8k_16k", "no_mixer", "no_mixer_ptime20",
                                   "no_resampler", "no_resampler_16k_ptime20", "no_resampler_no_mixer",
-                                  "no_agc", "no_agc_ptime20_16k", "no_agc_no_resampler_no_mixer"])
+                                  "no_agc", "no_agc_ptime20_16k", "no_agc_no_resampler_no_mixer",
+                                  "endpoint_resamplers", "endpoint_resamplers_no_agc_no_resampler"])
 def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
     v = verdict[name]
     assert v["fused_stats"]["legs"] > 0 and v["plain_stats"]["legs"] == 0, v   # the first run really was fused, the second not
