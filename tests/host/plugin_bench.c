@@ -74,6 +74,7 @@ static pthread_barrier_t g_bar;
 
 static int g_profile, g_checksum;
 static int g_nors, g_noagc, g_nomixer; /* PLUGIN_BENCH_SHAPE: words of "nors noagc nomixer" -- the leg without MSResample / without AGC / without a conference mixer */
+static int g_eprs; /* ... "eprs": every pin behind an in_resampler, in front of an out_resampler, as MSAudioConference plumbs its endpoints (audioconference.c:209-257) */
 static double now_ms(void) {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -127,6 +128,12 @@ static void build(TickerJob *j) {
 			if (g_nomixer) { /* an AudioStream's sending side: MSVolume's blocks go straight on (to the encoder; here a sink) */
 				ms_filter_link(vol, 0, out, 0);
 				j->heads[c * g_members + k] = mic;
+			} else if (g_eprs) { /* both at the conference's rate: they forward (msresample.c:126-135) */
+				MSFilter *in_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *out_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
+				call_int(in_rs, MS_FILTER_SET_SAMPLE_RATE, 48000), call_int(in_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
+				call_int(out_rs, MS_FILTER_SET_SAMPLE_RATE, 48000), call_int(out_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
+				ms_filter_link(vol, 0, in_rs, 0), ms_filter_link(in_rs, 0, mx, k);
+				ms_filter_link(mx, k, out_rs, 0), ms_filter_link(out_rs, 0, out, 0);
 			} else {
 				ms_filter_link(vol, 0, mx, k);
 				ms_filter_link(mx, k, out, 0);
@@ -239,7 +246,7 @@ int main(int argc, char **argv) {
 	g_paced = getenv("PLUGIN_BENCH_PACED") != NULL;
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
-		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL;
+		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL;
 	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
 	const char *plugin = argv[1];

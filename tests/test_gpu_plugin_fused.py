@@ -93,7 +93,7 @@ def test_a_volume_method_on_a_fused_leg_takes_effect_within_a_tick(host):
     assert fused["late"] == 0 and plain["late"] == 0
 
 
-@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nors noagc nomixer"])
+@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nors noagc nomixer", "eprs"])
 def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape):
     """4 096 full legs (128 conferences of 32, four tickers) for 190 ticks through tests/host/plugin_bench, fused and with the
     facades one by one (MSMI355X_NO_FUSE=1): every leg's mix and every leg's speaker audio, byte for byte and in order, folded
