@@ -122,6 +122,12 @@ int mi_resampler_create(mi_ctx *ctx, int nstreams, uint32_t in_rate, uint32_t ou
                         mi_resampler **out);
 void mi_resampler_destroy(mi_resampler *r);
 int mi_resampler_reset(mi_resampler *r, int first, int count);
+/* one stream's running state -- (last_sample, frac) and the history of input samples: what a speex resampler handle carries from
+ * call to call (msresample.c:117-120 keeps its handle across a detach) -- to and from host memory; mi_resampler_state_bytes(r)
+ * bytes, valid between resamplers of the same rates and quality.  Both wait for the context's stream. */
+int mi_resampler_state_bytes(const mi_resampler *r);
+int mi_resampler_get_state(mi_resampler *r, int stream, void *h_state, size_t cap);
+int mi_resampler_set_state(mi_resampler *r, int stream, const void *h_state, size_t bytes);
 /* msresample.c:151-152: in_len*out_rate/in_rate + 1 */
 int mi_resampler_out_capacity(const mi_resampler *r, int in_len);
 /* filter facts for tests/DESIGN: taps per phase, phases (den_rate), num_rate,

@@ -155,6 +155,17 @@ class ResamplerBatch(_Batch):
     def out_capacity(self, in_len):
         return self.ctx.L.mi_resampler_out_capacity(self.h, in_len)
 
+    def get_state(self, stream):
+        """one stream's running state (position + history) as bytes: mi_resampler_get_state"""
+        n = self.ctx.L.mi_resampler_state_bytes(self.h)
+        buf = (C.c_uint8 * n)()
+        check(self.ctx.L.mi_resampler_get_state(self.h, int(stream), buf, n))
+        return bytes(buf)
+
+    def set_state(self, stream, state):
+        buf = (C.c_uint8 * len(state)).from_buffer_copy(state)
+        check(self.ctx.L.mi_resampler_set_state(self.h, int(stream), buf, len(state)))
+
     def reset(self, first=0, count=None):
         check(self.ctx.L.mi_resampler_reset(self.h, first, self.nstreams - first if count is None else count))
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_pinned", "mi_copy_d2h_pinned", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
     "mi_timer_start", "mi_timer_stop",
-    "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_out_capacity",
+    "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_state_bytes", "mi_resampler_get_state", "mi_resampler_set_state", "mi_resampler_out_capacity",
     "mi_resampler_info", "mi_resampler_get_table", "mi_resampler_process", "mi_resampler_process_host",
     "mi_resampler_process_masked", "mi_mixer_process_masked", "mi_equalizer_process_masked",
     "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
@@ -134,6 +134,9 @@ def load():
     L.mi_resampler_destroy.argtypes = [vp]
     L.mi_resampler_destroy.restype = None
     L.mi_resampler_reset.argtypes = [vp, i32, i32]
+    L.mi_resampler_state_bytes.argtypes = [vp]
+    L.mi_resampler_get_state.argtypes = [vp, i32, vp, C.c_size_t]
+    L.mi_resampler_set_state.argtypes = [vp, i32, vp, C.c_size_t]
     L.mi_resampler_out_capacity.argtypes = [vp, i32]
     L.mi_resampler_info.argtypes = [vp] + [C.POINTER(i32)] * 4
     L.mi_resampler_get_table.argtypes = [vp, vp, i32]

@@ -874,6 +874,32 @@ int mi_resampler_reset(mi_resampler *r, int first, int count) {
 	return MI_OK;
 }
 
+// One stream's running state -- (last_sample, frac) and the history row -- to and from host memory: what a speex resampler handle
+// carries from call to call (msresample.c keeps its handle across a detach of the graph; the plugin's fused legs move the state from
+// bank slot to bank slot with it).  Both wait for the stream.
+int mi_resampler_state_bytes(const mi_resampler *r) { return r ? (int)(sizeof(int2) + (size_t)r->hist_stride * sizeof(int16_t)) : MI_EINVAL; }
+int mi_resampler_get_state(mi_resampler *r, int stream, void *h_state, size_t cap) {
+	MI_CHECK_ARG(r && h_state && stream >= 0 && stream < r->nstreams && cap >= (size_t)mi_resampler_state_bytes(r));
+	if (r->ctx->activate() != MI_OK) return MI_ENODEV;
+	uint8_t *dst = static_cast<uint8_t *>(h_state);
+	MI_HIP(hipStreamSynchronize(r->ctx->stream));
+	MI_HIP(hipMemcpy(dst, r->d_pos + stream, sizeof(int2), hipMemcpyDeviceToHost));
+	MI_HIP(hipMemcpy(dst + sizeof(int2), r->d_hist + (size_t)stream * r->hist_stride, (size_t)r->hist_stride * sizeof(int16_t), hipMemcpyDeviceToHost));
+	return MI_OK;
+}
+int mi_resampler_set_state(mi_resampler *r, int stream, const void *h_state, size_t bytes) {
+	MI_CHECK_ARG(r && h_state && stream >= 0 && stream < r->nstreams && bytes == (size_t)mi_resampler_state_bytes(r));
+	if (r->ctx->activate() != MI_OK) return MI_ENODEV;
+	const uint8_t *src = static_cast<const uint8_t *>(h_state);
+	int2 pos;
+	memcpy(&pos, src, sizeof(pos));
+	MI_HIP(hipStreamSynchronize(r->ctx->stream));
+	MI_HIP(hipMemcpy(r->d_pos + stream, src, sizeof(int2), hipMemcpyHostToDevice));
+	MI_HIP(hipMemcpy(r->d_hist + (size_t)stream * r->hist_stride, src + sizeof(int2), (size_t)r->hist_stride * sizeof(int16_t), hipMemcpyHostToDevice));
+	if (pos.x != 0 || pos.y != 0) r->phase_zero = false;
+	return MI_OK;
+}
+
 int mi_resampler_out_capacity(const mi_resampler *r, int in_len) {
 	if (!r || in_len < 0) return MI_EINVAL;
 	return (int)((((uint32_t)in_len * r->out_rate) / r->in_rate) + 1);

@@ -27,10 +27,9 @@
 //     what those bufferizers would (MSMI355X_CHECK_LEVELS=1 reads the levels back every flush and compares).
 //
 // Results equal the facades run one by one (tests/test_gpu_plugin_fused.py: bit for bit, incl. far-end under-runs, 20 ms
-// packets and a late joiner), with two stated exceptions: a conference with a single contributor is mixed like any other
+// packets and a late joiner), with one stated exception: a conference with a single contributor is mixed like any other
 // (the reference forwards that pin's blocks unsaturated, audiomixer.c:219-242: only a sample of -32768 differs; the
-// contributor's own pin gets no block either way), and after detach / re-attach the resampler starts from an empty
-// history like the canceller does (the facade alone keeps its speex handle across a detach).
+// contributor's own pin gets no block either way).
 // Anything else -- another rate pair, pins of different shapes, MSVolume with an echo-limiter peer, non-conference mode,
 // MSMI355X_NO_FUSE=1 -- keeps the facades on their own banks.  A fused conference falls back to them at run time when a
 // member's configuration stops qualifying (bypass mode switched on, AGC switched, ...).
@@ -39,7 +38,8 @@
 // src/voip/audioconference.c:322-374), so every member's filters see postprocess + preprocess.  What the reference's filters keep
 // across that goes with the FILTERS, not with the bank slot (conf_unfuse / conf_try_fuse): the tick already out is waited for and
 // delivered (deliver_in_flight), MSVolume's running state and the samples its bufferizer holds short of a chunk move to the next
-// slot (leg_keep_volume / volume_start_state, take_remainders / give_remainder); the canceller starts over as its preprocess does.
+// slot (leg_keep_volume / volume_start_state, take_remainders / give_remainder), MSResample's position and history too
+// (resample_keep_from / resample_restore_to: the speex handle outlives a detach); the canceller starts over as its preprocess does.
 
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
 constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one enqueue: kMaxRounds blocks of 10 ms in frames
@@ -1096,7 +1096,11 @@ bool conf_try_fuse(MSFilter *mx) {
 		VolumeData *vd = (VolumeData *)cd.vol->data;
 		if (cd.rs) {
 			ResampleData *rd = (ResampleData *)cd.rs->data;
-			if (rd->pool) resample_release(rd);
+			if (rd->pool) {
+				if (rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
+				resample_release(rd);
+			}
+			resample_restore_to(rd, b->rs, leg->slot, b->in_rate, b->rate, true);
 			rd->leg = leg;
 		}
 		ms_bufferizer_flush(&es->delayed_ref); // the delay line lives on the device now
@@ -1181,6 +1185,7 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
 		if (!leg) continue;
 		leg_keep_volume(leg);
+		if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, leg->slot, b->in_rate, b->rate);
 		b->legs[(size_t)(c * mm + pin)] = nullptr;
 		if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
 		((SpeexECState *)leg->ec->data)->leg = nullptr;
@@ -1265,7 +1270,11 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	b->legs[(size_t)s] = leg;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
 	if (rd) {
-		if (rd->pool) resample_release(rd);
+		if (rd->pool) {
+			if (rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
+			resample_release(rd);
+		}
+		resample_restore_to(rd, b->rs, s, b->in_rate, b->rate, true);
 		rd->leg = leg;
 	}
 	ms_bufferizer_flush(&es->delayed_ref);
@@ -1293,6 +1302,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	b->settle_meters();
 	b->take_remainders(s, 1);
 	leg_keep_volume(leg);
+	if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, s, b->in_rate, b->rate);
 	b->legs[(size_t)s] = nullptr;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
 	if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;

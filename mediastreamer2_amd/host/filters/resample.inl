@@ -65,7 +65,34 @@ struct ResampleData { // ResampleData msresample.c:33-42
 	std::vector<int> *slots;  // one batch slot per input channel (speex keeps one state per channel too)
 	FusedLeg *leg;            // the filter is the head of a fused call leg (filters/leg_chain.inl): its blocks go to that bank
 	bool fuse_checked;        // looked for a conference to fuse with since the last attach
+	// the speex handle lives as long as the filter (msresample.c:117-120: a detach keeps it): the running state of a mono filter
+	// travels from a bank slot that is given up (a conference fused or un-fused) to the next one of the same rates
+	std::vector<uint8_t> *kept;
+	uint32_t kept_in, kept_out;
 };
+
+// the state of the mono filter's slot in resampler `r` (hub locked), before the slot is given up
+void resample_keep_from(ResampleData *d, mi_resampler *r, int slot, uint32_t in_rate, uint32_t out_rate) {
+	const int n = r ? mi_resampler_state_bytes(r) : 0;
+	d->kept->clear();
+	if (n <= 0 || d->in_nchannels != 1) return;
+	d->kept->resize((size_t)n);
+	if (mi_resampler_get_state(r, slot, d->kept->data(), d->kept->size()) != MI_OK) d->kept->clear();
+	d->kept_in = in_rate, d->kept_out = out_rate;
+}
+// ... and into the slot the filter gets next.  whole_periods_only: the fused leg's launch up-samples whole output periods (its
+// resampler never leaves phase (0, 0)): a state that stands elsewhere is not taken over
+bool resample_restore_to(ResampleData *d, mi_resampler *r, int slot, uint32_t in_rate, uint32_t out_rate, bool whole_periods_only) {
+	if (!r || d->kept->empty() || d->kept_in != in_rate || d->kept_out != out_rate || (int)d->kept->size() != mi_resampler_state_bytes(r)) return false;
+	if (whole_periods_only) {
+		int32_t pos[2];
+		memcpy(pos, d->kept->data(), sizeof(pos));
+		if (pos[0] != 0 || pos[1] != 0) return false;
+	}
+	const bool ok = mi_resampler_set_state(r, slot, d->kept->data(), d->kept->size()) == MI_OK;
+	d->kept->clear();
+	return ok;
+}
 
 void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
 	ResampleData *d = (ResampleData *)ms_malloc0(sizeof(*d));
@@ -75,6 +102,7 @@ void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
 	d->in_nchannels = d->out_nchannels = 1;
 	d->slot = -1;
 	d->slots = new std::vector<int>();
+	d->kept = new std::vector<uint8_t>();
 	f->data = d;
 }
 
@@ -111,6 +139,7 @@ void resample_uninit(MSFilter *f) {
 	}
 	ms_bufferizer_destroy(d->bz);
 	delete d->slots;
+	delete d->kept;
 	ms_free(d);
 }
 
@@ -176,6 +205,7 @@ void resample_process(MSFilter *f) { // resample_process_ms2 msresample.c:122-17
 			return;
 		}
 		d->slot = (*d->slots)[0];
+		if (nch == 1) resample_restore_to(d, d->pool->r, d->slot, d->input_rate, d->output_rate, false); // (a leg that left its fused batch carries on where it was)
 	}
 	ResamplePool *p = d->pool;
 	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;

@@ -192,6 +192,17 @@ int mi_resampler_create(mi_ctx *ctx, int n, uint32_t in_rate, uint32_t out_rate,
 	return MI_OK;
 }
 void mi_resampler_destroy(mi_resampler *r) { delete r; }
+// (the double's resampler repeats samples: it has no history -- a state of eight zero bytes)
+int mi_resampler_state_bytes(const mi_resampler *r) { return r ? 8 : MI_EINVAL; }
+int mi_resampler_get_state(mi_resampler *r, int stream, void *h_state, size_t cap) {
+	ARG(r && h_state && stream >= 0 && stream < r->n && cap >= 8);
+	memset(h_state, 0, 8);
+	return MI_OK;
+}
+int mi_resampler_set_state(mi_resampler *r, int stream, const void *h_state, size_t bytes) {
+	ARG(r && h_state && stream >= 0 && stream < r->n && bytes == 8);
+	return MI_OK;
+}
 int mi_resampler_reset(mi_resampler *r, int first, int count) {
 	ARG(r && first >= 0 && count >= 0 && first + count <= r->n);
 	return MI_OK;

@@ -206,3 +206,39 @@ def test_resampler_on_the_reference_wav_family(ctx, oracle, a, b):
     assert np.abs(got.astype(np.int32) - want).max() <= 1
     check_wav_family(got, a, b)
     rs.close()
+
+
+@pytest.mark.parametrize("in_rate,out_rate,in_len", [(16000, 48000, 160), (44100, 48000, 441), (48000, 16000, 480)])
+def test_a_streams_state_moves_to_another_resampler(ctx, in_rate, out_rate, in_len):
+    """mi_resampler_get_state / set_state: what a speex handle carries from call to call (position + history).  A stream resampled
+    in one object, and the same stream whose state is moved to a slot of ANOTHER object half-way (what the plugin's fused call leg
+    does when its conference is re-plumbed: msresample.c keeps the handle across a detach), deliver the same samples."""
+    n, nticks = 3, 12
+    x = np.stack([synth_pcm(40 + s, in_len * nticks, sigma=3000.0, rate=in_rate) for s in range(n)])
+    a = ms.ResamplerBatch(ctx, n, in_rate, out_rate)
+    want = []
+    for t in range(nticks):
+        out, olen = a.process(np.ascontiguousarray(x[:, t * in_len:(t + 1) * in_len]))
+        want.append([out[s, :olen[s]].copy() for s in range(n)])
+    a.close()
+    b, c = ms.ResamplerBatch(ctx, n, in_rate, out_rate), ms.ResamplerBatch(ctx, 5, in_rate, out_rate)
+    got = []
+    for t in range(nticks // 2):
+        out, olen = b.process(np.ascontiguousarray(x[:, t * in_len:(t + 1) * in_len]))
+        got.append([out[s, :olen[s]].copy() for s in range(n)])
+    where = [4, 0, 2]                                         # stream s of b carries on in slot where[s] of c
+    for s in range(n):
+        st = b.get_state(s)
+        assert len(st) == ctx.L.mi_resampler_state_bytes(b.h)
+        c.set_state(where[s], st)
+    for t in range(nticks // 2, nticks):
+        blk = np.zeros((5, in_len), np.int16)
+        for s in range(n):
+            blk[where[s]] = x[s, t * in_len:(t + 1) * in_len]
+        out, olen = c.process(blk)
+        got.append([out[where[s], :olen[where[s]]].copy() for s in range(n)])
+    for t in range(nticks):
+        for s in range(n):
+            np.testing.assert_array_equal(got[t][s], want[t][s], err_msg=f"tick {t} stream {s}")
+    b.close()
+    c.close()
