@@ -727,10 +727,16 @@ def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25, stagger=True, con
         avg = ctx.timer_stop() / (P * reps)
         g1 = [rig.capture([t]) for t in range(P)]
         per = tick_series(ctx, g1, worst_ticks)
+        stalled = None
+        if host_stalls_only(per):  # every late tick was the submitting thread's stall (TickTimes.submit): no verdict on the count -- once more
+            stalled = {"tick_ms_worst": round(float(per.max()), 4), "host_submit_max_ms": round(float(per.submit.max()), 3)}
+            per = tick_series(ctx, g1, worst_ticks)
         out = {"streams": rig.n, "conferences": rig.nconf, "tick_ms_avg": round(avg, 4), "tick_ms_worst": round(float(per.max()), 4),
                "tick_ms_single_median": round(float(np.median(per)), 4), "fits": bool(per.max() < 10.0),
                "fifo_overflows": int(rig.overflows()), "aec_resident_state_bytes": rig.state_bytes(),
                "state": "steady" if converged is not None else "from reset", "staggered": bool(stagger)}
+        if stalled:
+            out["first_series_held_a_host_stall"] = stalled
         del gp, g1
     finally:
         rig.close()
@@ -1465,7 +1471,9 @@ def main():
                 if worst < 9.75 and ups < 3 and streams + 2048 <= a.sweep_hi:
                     best = (streams, zero, head, series, fg0, worst, paced)
                     ups += 1
-                    streams += 2048
+                    # one step -- or, where the longest tick leaves a lot of room (the sweep's proposal was held down by one event), the
+                    # count whose longest tick would be ~9.6 ms, a tick costing in proportion to the legs
+                    streams = min(a.sweep_hi // 2048 * 2048, streams + max(2048, int(streams * (9.6 / worst - 1.0)) // 2048 * 2048))
                     continue
                 break
             tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"],
@@ -1480,7 +1488,12 @@ def main():
                 retried.add(streams)
                 tried[-1]["late_ticks_were_host_stalls"] = "the count is tried again"
                 continue
-            if best is not None:  # the step up did not pass: the count below it stands
+            if best is not None:  # the step up did not pass: the count below it stands ...
+                gap = streams - best[0]
+                if gap > 2048 and ups < 3:  # ... unless the step was a large one: half of it is tried (the count that passed stays in hand)
+                    ups += 1
+                    streams = best[0] + max(2048, gap // 2 // 2048 * 2048)
+                    continue
                 streams, zero, head, series, fg0, worst, paced = best
                 best = None
                 break
