@@ -726,6 +726,9 @@ def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25, stagger=True, con
             gp.launch()
         avg = ctx.timer_stop() / (P * reps)
         g1 = [rig.capture([t]) for t in range(P)]
+        for g in g1:  # one untimed scene period, as before the acceptance series: a graph's first launch uploads it
+            g.launch()
+        ctx.sync()
         per = tick_series(ctx, g1, worst_ticks)
         stalled = None
         if host_stalls_only(per):  # every late tick was the submitting thread's stall (TickTimes.submit): no verdict on the count -- once more
