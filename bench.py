@@ -731,15 +731,20 @@ def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25, stagger=True, con
         ctx.sync()
         per = tick_series(ctx, g1, worst_ticks)
         stalled = None
-        if host_stalls_only(per):  # every late tick was the submitting thread's stall (TickTimes.submit): no verdict on the count -- once more
-            stalled = {"tick_ms_worst": round(float(per.max()), 4), "host_submit_max_ms": round(float(per.submit.max()), 3)}
+        a = np.asarray(per)
+        # a point's series is measured once more when its late ticks say nothing about the count: every one of them the submitting
+        # thread's stall (TickTimes.submit), or ONE tick more than 5 ms over the median -- no event of the power controller is that
+        # long (<= 2.1 ms seen); some boxes hold the device for 35-45 ms once, early in a process's first sustained load
+        # (profiles/r04_bench_low_sweep.json).  The sweep only proposes: the acceptance series decide, and excuse host stalls only.
+        if host_stalls_only(per) or (int((a >= 10.0).sum()) == 1 and float(a.max() - np.median(a)) > 5.0):
+            stalled = {"tick_ms_worst": round(float(a.max()), 4), "at": int(np.argmax(a)), "host_submit_ms": round(float(per.submit[int(np.argmax(a))]), 3)}
             per = tick_series(ctx, g1, worst_ticks)
         out = {"streams": rig.n, "conferences": rig.nconf, "tick_ms_avg": round(avg, 4), "tick_ms_worst": round(float(per.max()), 4),
                "tick_ms_single_median": round(float(np.median(per)), 4), "fits": bool(per.max() < 10.0),
                "fifo_overflows": int(rig.overflows()), "aec_resident_state_bytes": rig.state_bytes(),
                "state": "steady" if converged is not None else "from reset", "staggered": bool(stagger)}
         if stalled:
-            out["first_series_held_a_host_stall"] = stalled
+            out["first_series_held_a_stall"] = stalled
         del gp, g1
     finally:
         rig.close()
