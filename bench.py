@@ -1640,7 +1640,7 @@ def main():
                                         "tick_ms_avg": zero["tick_ms_avg"], "ticks": a.zero_ticks,
                                         "how": "every leg's canceller starts from reset in the same tick; the ticks right after"}
     if sweep and rank == 0:
-        line["config"]["capacity_sweep"] = [{k: p.get(k) for k in ("streams", "tick_ms_avg", "tick_ms_worst", "fits", "error") if k in p}
+        line["config"]["capacity_sweep"] = [{k: p.get(k) for k in ("streams", "tick_ms_avg", "tick_ms_worst", "fits", "error", "first_series_held_a_stall") if k in p}
                                             for p in sweep]
     if world > 1:
         line["config"]["split_conferences"] = {"count": SPLIT_CONFERENCES, "members_per_rank": rig.mloc,

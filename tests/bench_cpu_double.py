@@ -47,10 +47,18 @@ class Context:
     def sync(self):
         pass
 
+    timer_stops = 0
+
     def timer_start(self):
         self.t0 = Clock.now_ms
 
     def timer_stop(self):
+        # DOUBLE_STALL_AT_TIMER="k:ms": the k-th timed interval of the process comes out `ms` longer (a one-off stall of the device:
+        # k = 3 is the first tick of the sweep's first point)
+        Context.timer_stops += 1
+        at, _, extra = os.environ.get("DOUBLE_STALL_AT_TIMER", "0:0").partition(":")
+        if Context.timer_stops == int(at):
+            Clock.now_ms += float(extra)
         return Clock.now_ms - self.t0
 
     def capture_begin(self):

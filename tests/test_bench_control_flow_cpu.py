@@ -138,3 +138,16 @@ def test_a_late_tick_that_was_the_submitting_threads_stall_is_told_from_one_the_
     assert not bench.host_stalls_only(w)
     assert not bench.host_stalls_only(np.full(10, 11.0))      # a plain array (no host times): never excused
     assert float(np.median(v)) == 9.1 and float(v.max()) == 21.3 and isinstance(v[1:5], bench.TickTimes)
+
+
+def test_a_one_off_stall_in_the_sweeps_first_point_does_not_lower_the_proposal():
+    """some boxes hold the device for 35-45 ms once, at the first timed tick of the sweep's first point: a point whose
+    series holds ONE tick more than 5 ms over its median is measured once more -- the proposal, and with it `value`, is what it
+    is without the stall; the point says what it saw"""
+    r = run(1, {"DOUBLE_STALL_AT_TIMER": "3:38"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = the_line(r)
+    first = d["config"]["capacity_sweep"][0]
+    assert first["streams"] == 16384 and first["fits"] and first["first_series_held_a_stall"]["at"] == 0
+    assert first["first_series_held_a_stall"]["tick_ms_worst"] > 38.0
+    assert d["value"] == 22528
