@@ -48,6 +48,7 @@ filters by id from the factory, 16 ticker threads paced at 10 ms; never part of
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -653,18 +654,33 @@ class TickTimes(np.ndarray):
         self.submit = getattr(obj, "submit", None)
 
 
+class quiet_interpreter:
+    """around a timed series: the cyclic garbage collector runs first and stays off inside (a collection that drops a device
+    buffer in the middle of a series frees it there and then -- the device is held while the driver unmaps it)"""
+
+    def __enter__(self):
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+
+
 def tick_series(ctx, graphs, nticks, after=None):
     """`nticks` CONSECUTIVE single ticks, each timed on its own with HIP events on the launch stream (the GPU drains after
     every tick: conservative).  No tick is discarded or repeated."""
     v = TickTimes(nticks)
-    for t in range(nticks):
-        t0 = time.perf_counter()
-        ctx.timer_start()
-        graphs[t % len(graphs)].launch()
-        if after:
-            after()
-        v.submit[t] = (time.perf_counter() - t0) * 1e3
-        v[t] = ctx.timer_stop()
+    with quiet_interpreter():
+        for t in range(nticks):
+            t0 = time.perf_counter()
+            ctx.timer_start()
+            graphs[t % len(graphs)].launch()
+            if after:
+                after()
+            v.submit[t] = (time.perf_counter() - t0) * 1e3
+            v[t] = ctx.timer_stop()
     return v
 
 
@@ -1258,12 +1274,13 @@ class Headline:
         if self.world == 1:
             return tick_series(self.ctx, self.g1, nticks)
         v = TickTimes(nticks)
-        for t in range(nticks):
-            t0 = time.perf_counter()
-            self.ctx.timer_start()
-            self.graph_tick(t)
-            v.submit[t] = (time.perf_counter() - t0) * 1e3
-            v[t] = self.ctx.timer_stop()
+        with quiet_interpreter():
+            for t in range(nticks):
+                t0 = time.perf_counter()
+                self.ctx.timer_start()
+                self.graph_tick(t)
+                v.submit[t] = (time.perf_counter() - t0) * 1e3
+                v[t] = self.ctx.timer_stop()
         return v
 
     def paced_series(self, nticks, between=None):
@@ -1271,21 +1288,22 @@ class Headline:
         the device idle for the rest of each interval.  Each tick timed alone.  between(): called right before a tick's
         launches (scripts/paced_probe.py tries ways of keeping the device warm across the gap with it)."""
         v = TickTimes(nticks)
-        nxt = time.perf_counter()
-        for t in range(nticks):
-            while time.perf_counter() < nxt:
-                pass
-            nxt = max(nxt + 0.010, time.perf_counter() - 0.050)  # (a late tick is followed at once, like wait_next_tick does)
-            if between:
-                between()
-            t0 = time.perf_counter()
-            self.ctx.timer_start()
-            if self.world == 1:
-                self.g1[t % len(self.g1)].launch()
-            else:
-                self.graph_tick(t)
-            v.submit[t] = (time.perf_counter() - t0) * 1e3
-            v[t] = self.ctx.timer_stop()
+        with quiet_interpreter():
+            nxt = time.perf_counter()
+            for t in range(nticks):
+                while time.perf_counter() < nxt:
+                    pass
+                nxt = max(nxt + 0.010, time.perf_counter() - 0.050)  # (a late tick is followed at once, like wait_next_tick does)
+                if between:
+                    between()
+                t0 = time.perf_counter()
+                self.ctx.timer_start()
+                if self.world == 1:
+                    self.g1[t % len(self.g1)].launch()
+                else:
+                    self.graph_tick(t)
+                v.submit[t] = (time.perf_counter() - t0) * 1e3
+                v[t] = self.ctx.timer_stop()
         return v
 
     def canceller_launches(self, nticks):
@@ -1312,10 +1330,11 @@ class Headline:
                 ctx.timer_start()
             else:
                 acc.append(ctx.timer_stop())  # waits for the event behind the launch
-        for t in range(nticks):
-            rig.tick(t, parts)
-            rig.finalize()
-        ctx.sync()
+        with quiet_interpreter():
+            for t in range(nticks):
+                rig.tick(t, parts)
+                rig.finalize()
+            ctx.sync()
         return float(sum(acc)), nticks, 15 * rig.n * (nticks // 8)
 
     def allreduce_alone_us(self, reps=200):
