@@ -655,13 +655,20 @@ class TickTimes(np.ndarray):
 
 
 class quiet_interpreter:
-    """around a timed series: the cyclic garbage collector runs first and stays off inside (a collection that drops a device
-    buffer in the middle of a series frees it there and then -- the device is held while the driver unmaps it)"""
+    """around a timed series: Python's cyclic garbage collector stays off inside (a collection that drops a device buffer in the
+    middle of a series frees it there and then -- the device is held while the driver unmaps it: 35-45 ms, seen).  It runs
+    BEFORE the series instead, and `warm` (one untimed scene period of the same ticks) runs after it: the collection takes the
+    host tens of ms, and a device that idled that long pays for it in its next two ticks (+1.7 / +0.6 ms, LOG.md)."""
+
+    def __init__(self, warm=None):
+        self.warm = warm
 
     def __enter__(self):
         gc.collect()
         self.was = gc.isenabled()
         gc.disable()
+        if self.warm:
+            self.warm()
 
     def __exit__(self, *exc):
         if self.was:
@@ -672,7 +679,11 @@ def tick_series(ctx, graphs, nticks, after=None):
     """`nticks` CONSECUTIVE single ticks, each timed on its own with HIP events on the launch stream (the GPU drains after
     every tick: conservative).  No tick is discarded or repeated."""
     v = TickTimes(nticks)
-    with quiet_interpreter():
+
+    def period():  # (whole scene periods leave the rig's queues and input ring where they were)
+        for g in graphs:
+            g.launch()
+    with quiet_interpreter(period):
         for t in range(nticks):
             t0 = time.perf_counter()
             ctx.timer_start()
@@ -742,10 +753,7 @@ def chain_capacity_point(ms, torch, ctx, nstreams, min_s=0.25, stagger=True, con
             gp.launch()
         avg = ctx.timer_stop() / (P * reps)
         g1 = [rig.capture([t]) for t in range(P)]
-        for g in g1:  # one untimed scene period, as before the acceptance series: a graph's first launch uploads it
-            g.launch()
-        ctx.sync()
-        per = tick_series(ctx, g1, worst_ticks)
+        per = tick_series(ctx, g1, worst_ticks)  # (one untimed scene period first: quiet_interpreter)
         stalled = None
         a = np.asarray(per)
         # a point's series is measured once more when its late ticks say nothing about the count: every one of them the submitting
@@ -1274,7 +1282,11 @@ class Headline:
         if self.world == 1:
             return tick_series(self.ctx, self.g1, nticks)
         v = TickTimes(nticks)
-        with quiet_interpreter():
+
+        def period():
+            for t in range(rig_period(self)):
+                self.graph_tick(t)
+        with quiet_interpreter(period):
             for t in range(nticks):
                 t0 = time.perf_counter()
                 self.ctx.timer_start()
@@ -1288,7 +1300,14 @@ class Headline:
         the device idle for the rest of each interval.  Each tick timed alone.  between(): called right before a tick's
         launches (scripts/paced_probe.py tries ways of keeping the device warm across the gap with it)."""
         v = TickTimes(nticks)
-        with quiet_interpreter():
+
+        def period():
+            for t in range(rig_period(self)):
+                if self.world == 1:
+                    self.g1[t % len(self.g1)].launch()
+                else:
+                    self.graph_tick(t)
+        with quiet_interpreter(period):
             nxt = time.perf_counter()
             for t in range(nticks):
                 while time.perf_counter() < nxt:
@@ -1330,7 +1349,11 @@ class Headline:
                 ctx.timer_start()
             else:
                 acc.append(ctx.timer_stop())  # waits for the event behind the launch
-        with quiet_interpreter():
+        def cycle():  # (one untimed re-framing cycle: the device is busy again when the first timed launch starts)
+            for t in range(8):
+                rig.tick(t)
+                rig.finalize()
+        with quiet_interpreter(cycle):
             for t in range(nticks):
                 rig.tick(t, parts)
                 rig.finalize()
