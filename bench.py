@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel roofline table")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (everything the short stdout line leaves out)")
     return ap.parse_args()
 
 
@@ -448,6 +450,8 @@ CHAIN_DESC = ("MSResample 16k->48k -> device FIFO (480-sample ticks -> 256-sampl
               "canceller + post-filter; 15 frames per 8 ticks) -> device FIFO (frames -> ticks) -> MSVolume (AGC) -> "
               "MSAudioMixer (conferences of 32), device resident; TWO launches per tick: resampler + FIFO appends + canceller + "
               "post-filter, then volume + conference mix")
+WORKLOAD_SHORT = ("north_star chain per call leg and 10 ms tick: MSResample 16k->48k -> MSSpeexEC 48 kHz 128 ms tail + post-filter -> "
+                  "MSVolume AGC -> MSAudioMixer 32-party (configs[1]+[2]+[3] chained, echo scene, steady state)")
 AEC_FRAME_BYTES = 202240  # mic+ref+out 1536, W read+write 2 x 49152, foreground 49152, X history 51200, newest X 2048
 AEC_FRAMES_PER_TICK = 1.875  # 480 / 256 (speexec.c:171-180: 256-sample frames at 48 kHz)
 SPLIT_CONFERENCES = 64  # at N > 1: conferences whose 32 members are spread over all ranks (the RCCL exchange step)
@@ -1062,7 +1066,8 @@ def cpu_baseline_chain(seconds, threads=1):
     t = run(nticks)
     per = t / (nconf * 32 * nticks) * threads  # core-seconds per stream-tick
     return {"value": round(nconf * 32 * nticks / t / TICKS_PER_S, 1),
-            "unit": "concurrent 48 kHz streams (10 ms ticks in real time)", "cores": threads, "kind": "port",
+            "unit": "concurrent 48 kHz streams", "cores": threads, "kind": "port",
+            "sample_short": f"{nconf}x32 legs x {nticks} ticks of the oracle chain, {t:.1f} s wall",
             "sample": f"{nconf} conference(s) x 32 legs x {nticks} ticks of the chain (resample 16k->48k, MSSpeexEC 128 ms + "
                       f"post-filter, AGC, 32-party mix), oracle/*.c, {t:.1f} s wall on {threads} of {os.cpu_count()} host CPUs",
             "us_per_stream_tick_per_core": round(per * 1e6, 2)}
@@ -1190,6 +1195,7 @@ class HipPlatform:
         # a collective for a rank that has left): main() exits 3, RCCL's reason on stderr.  No substitute transport.
         if agreed(ex is not None):
             ex.label = "mi_exchange_allreduce_i32 (C ABI, RCCL over xGMI, on the kernel stream)"
+            ex.label_short = "mi_exchange_allreduce_i32 (RCCL)"
             return ex
         if ex is not None:
             ex.close()
@@ -1405,6 +1411,104 @@ class Headline:
         self.rig.close()
         PLATFORM.release(self.torch)
 
+LINE_LIMIT = 6000  # the driver keeps the last 7 999 characters of stdout: the line stays well inside that
+
+
+def _pick(d, *keys):
+    """the named keys of a dict that are there and are numbers, booleans or short identifiers"""
+    out = {}
+    for k in keys:
+        v = (d or {}).get(k)
+        if isinstance(v, (bool, int, float)) or v is None and k in (d or {}):
+            out[k] = v
+        elif isinstance(v, str):
+            out[k] = v[:96]
+    return out
+
+
+def short_line(full, detail_name):
+    """The ONE stdout line: numbers and short identifiers only.  `full` (every series, every rejected count, every kernel's
+    table row, every note) goes to the detail file; nothing is measured here."""
+    cfg = full.get("config", {})
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["unit"] = "concurrent 48 kHz streams"
+    c = {"workload": WORKLOAD_SHORT}
+    c.update(_pick(cfg, "streams_per_gpu", "conferences_per_gpu", "worst_tick_ms", "single_tick_median_ms", "fits",
+                   "tick_budget_used", "fifo_overflows", "launch", "device", "cu_count"))
+    c["parallelism"] = cfg.get("parallelism_short", cfg.get("parallelism", ""))[:96]
+    if "consecutive_ticks" in cfg:
+        c["consecutive"] = _pick(cfg["consecutive_ticks"], "ticks", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "late")
+    if "paced_ticks" in cfg:
+        c["paced"] = _pick(cfg["paced_ticks"], "ticks", "p50_ms", "p99_ms", "max_ms", "late")
+    if "from_reset" in cfg:
+        c["from_reset"] = _pick(cfg["from_reset"], "worst_tick_ms", "ticks")
+    if "steady_state" in cfg:
+        c["steady_state"] = _pick(cfg["steady_state"], "adapted_fraction", "fg_updates_per_s")
+    if cfg.get("consecutive_ticks_failed_at"):
+        c["rejected_counts"] = [t.get("streams") for t in cfg["consecutive_ticks_failed_at"]][:12]
+    if "split_conferences" in cfg:
+        c["split_conferences"] = _pick(cfg["split_conferences"], "count", "members_per_rank", "allreduce_bytes_per_tick",
+                                       "allreduce_alone_us", "mix_bit_exact_vs_single_gpu", "backend")
+    c["detail"] = detail_name
+    out["config"] = c
+    if "roofline" in full:
+        r = full["roofline"]
+        out["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                                "algorithmic_bytes_per_launch", "kernel", "timed_launches", "measured_copy_GBps", "error")
+        out["roofline"]["units_per_launch"] = r.get("units_short")
+        if "tick" in r:
+            out["roofline"]["tick_frac"] = r["tick"].get("frac")
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = _pick(full["cpu_baseline"], "value", "unit", "cores", "kind", "us_per_stream_tick_per_core")
+        out["cpu_baseline"]["sample"] = full["cpu_baseline"].get("sample_short", "")
+        if "cpu_baseline_all_cores" in full:
+            out["cpu_baseline"]["all_cores"] = _pick(full["cpu_baseline_all_cores"], "value", "cores")
+    pp = full.get("plugin_path")
+    if pp:
+        out["plugin_path"] = _pick(pp, "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
+                                   "launches_per_tick", "syncs_per_tick", "max_backlog_ms", "host_cores_granted",
+                                   "legs_per_host_core", "host_cores_for_value", "fits", "error")
+        eq = pp.get("fused_equals_one_by_one_4096_legs")
+        if eq:
+            out["plugin_path"]["fused_equals_one_by_one"] = eq.get("equal")
+    for key in ("plugin_path_server",):
+        if full.get(key):
+            out[key] = _pick(full[key], "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
+                             "launches_per_tick", "pcie_bytes_per_leg_tick", "fits", "error")
+    if "scaler_mpix_per_s" in full:
+        sc = full["scaler_mpix_per_s"]
+        out["scaler"] = {"mpix_per_s": sc.get("value"), "frac": sc.get("hbm_frac"), "frames_per_s": sc.get("frames_per_s")}
+    if "video_pcie_inclusive" in full:
+        out["video_pcie_inclusive"] = _pick(full["video_pcie_inclusive"], "frames_per_s", "mpix_per_s_in", "h2d_GBps", "d2h_GBps", "error")
+    for key in ("session_pcie_inclusive", "session_trunk_g711"):
+        if key in full:
+            out[key] = _pick(full[key], "streams", "tick_ms_end_to_end", "fits", "error")
+    if full.get("other_kernels"):
+        # kernel -> [avg launch us, frac of the HBM peak]; the table's rows are in the detail file
+        out["other_kernels"] = {f"{r.get('kernel', '?')}@{str(r.get('units_per_launch', '')).split(' ')[0]}":
+                                [r.get("avg_launch_us"), r.get("frac")] for r in full["other_kernels"]}
+    return out
+
+
+def emit(full, detail_path):
+    """Write the full record beside the line (and say where on stderr), then print the short line -- the only stdout output."""
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(full, f, indent=1)
+        print(f"bench.py: detail written to {detail_path} ({os.path.getsize(detail_path)} bytes)", file=sys.stderr, flush=True)
+    except OSError as e:
+        print(f"bench.py: the detail file could not be written ({e}); the full record follows on stderr", file=sys.stderr)
+        print("bench.py: detail " + json.dumps(full), file=sys.stderr, flush=True)
+    out = short_line(full, os.path.basename(detail_path))
+    s = json.dumps(out, separators=(",", ":"))
+    for k in ("other_kernels", "session_trunk_g711", "session_pcie_inclusive", "video_pcie_inclusive", "plugin_path_server"):
+        if len(s) < LINE_LIMIT:
+            break
+        out.pop(k, None)  # (never reached with today's keys: the line is ~3 KB; a guard, so that growth cannot cut the head off)
+        s = json.dumps(out, separators=(",", ":"))
+    print(s, flush=True)
+
 
 def main():
     a = parse()
@@ -1576,12 +1680,12 @@ def main():
         # every attempt failed and the last one's rig is gone: the line reports what was tried, value 0 (nothing below is
         # measured on a closed rig)
         if rank == 0:
-            print(json.dumps({"metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale", "value": 0,
-                              "unit": "concurrent 48 kHz streams (resample + AEC + AGC + 32-party mix every 10 ms tick, worst tick < 10 ms)",
-                              "n_gpus": world, "steps": 0, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": "north_star chain per call leg and 10 ms tick: " + CHAIN_DESC, "fits": False,
-                                         "consecutive_ticks_failed_at": tried}}), flush=True)
+            emit({"metric": "concurrent 48 kHz streams/node at <10 ms tick; Mpix/s YUV scale", "value": 0,
+                  "unit": "concurrent 48 kHz streams (resample + AEC + AGC + 32-party mix every 10 ms tick, worst tick < 10 ms)",
+                  "n_gpus": world, "steps": 0, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": "north_star chain per call leg and 10 ms tick: " + CHAIN_DESC, "fits": False,
+                             "consecutive_ticks_failed_at": tried}}, a.detail)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -1631,8 +1735,10 @@ def main():
         print("bench.py: the split conferences' all-reduced mix differs from the single-GPU mix", file=sys.stderr)
         sys.exit(4)
 
-    parallelism = "1 GPU"
+    parallelism = parallelism_short = "1 GPU"
     if world > 1:
+        parallelism_short = (f"{world} ranks: static shards + {SPLIT_CONFERENCES} split conferences over "
+                             f"{getattr(exchange, 'label_short', backend + ' (TEST BACKEND)')}")
         parallelism = (f"{world} ranks, one per GPU; legs and whole conferences sharded statically (no collective), "
                        f"{SPLIT_CONFERENCES} conferences split over all ranks: int32 partial sums -> "
                        f"{getattr(exchange, 'label', backend + ' all-reduce (TEST BACKEND, not RCCL)')} "
@@ -1664,7 +1770,7 @@ def main():
                    "working_set_note": "every tick streams the cancellers' resident state (far larger than the 256 MiB "
                                        "Infinity Cache); the input ring is one scene period (16 ticks)",
                    "launch": "hipGraph of 16 ticks replayed" if world == 1 else "hipGraph per tick + all-reduce + finalize graph",
-                   "parallelism": parallelism, "device": props["name"], "cu_count": props["cu_count"]},
+                   "parallelism": parallelism, "parallelism_short": parallelism_short, "device": props["name"], "cu_count": props["cu_count"]},
     }
     if converged is not None and fg1 is not None:
         nleg = fg1[3]
@@ -1701,6 +1807,7 @@ def main():
             r["kernel"] = "aec_tick_kernel<256>"
             r["units_per_launch"] = (f"{n_local} leg-ticks = {frames / launches:.0f} stream-frames on average "
                                      "(256 samples; 48 kHz, 128 ms tail, canceller + post-filter + FIFOs in one launch)")
+            r["units_short"] = f"{n_local} leg-ticks = {frames / launches:.0f} frames of 256 samples"
             r["timed_launches"] = launches
             r["traffic_source"] = pmc[1] if pmc else None
         except Exception as e:
@@ -1834,7 +1941,7 @@ def main():
                 except Exception as e:
                     line["cpu_reference_error"] = str(e)[:200]
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line, a.detail)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

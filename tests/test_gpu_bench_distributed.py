@@ -46,7 +46,8 @@ def _check(line, world, backend):
     sc = line["config"]["split_conferences"]
     assert sc["mix_bit_exact_vs_single_gpu"] is True and sc["backend"] == backend and sc["members_per_rank"] == 32 // world
     assert sc["allreduce_alone_us"] > 0
-    assert backend in line["config"]["parallelism"]
+    assert ("gloo (TEST BACKEND)" if backend == "gloo" else "mi_exchange_allreduce_i32 (RCCL)") in line["config"]["parallelism"]
+    assert len(json.dumps(line)) < 6000
     assert line["roofline"]["frac"] > 0
 
 
