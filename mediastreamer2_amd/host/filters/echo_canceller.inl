@@ -345,7 +345,7 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 // (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
 void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	if (!s->leg && !s->fuse_checked && s->pool && f->ticker && !s->bypass_mode && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
+	if (!s->leg && !s->fuse_checked && s->pool && f->ticker && !__atomic_load_n(&s->bypass_mode, __ATOMIC_RELAXED) && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
 		// the first microphone block since the attach, and no MSResample of ours in front (behind one, the resampler is the leg's
 		// head and has looked already): is this the head of  MSSpeexEC -> MSVolume (AGC) -> [conference mixer | anything else] ?
 		s->fuse_checked = true;
@@ -366,7 +366,7 @@ void ec_process(MSFilter *f) {
 		}
 		return;
 	}
-	if (s->bypass_mode || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)
+	if (__atomic_load_n(&s->bypass_mode, __ATOMIC_RELAXED) || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)
 		for (int pin = 0; pin < 2; ++pin)
 			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
 		return;
@@ -418,7 +418,8 @@ int ec_set_tail_length(MSFilter *f, void *arg) {
 }
 int ec_set_bypass_mode(MSFilter *f, void *arg) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	s->bypass_mode = *(bool_t *)arg;
+	HubLock lk(f);
+	__atomic_store_n(&s->bypass_mode, *(bool_t *)arg, __ATOMIC_RELAXED); // (read by process() on the ticker thread, as speexec.c:229 does; s->leg only under the hub's lock)
 	if (s->bypass_mode) leg_disqualify(s->leg); // a fused conference goes back to its facades (which then forward both pins)
 	return 0;
 }

@@ -62,6 +62,16 @@ struct FlowPool : Pool {
 		};
 		int maxr = 0;
 		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		if (failed) { // a broken context is not given more work: the staged blocks leave as they came, nothing dropped
+			for (int r = 0; r < maxr; ++r) {
+				memcpy(h_out + r * c * kFlowBlock, h_in + r * c * kFlowBlock, c * kFlowBlock * 2);
+				for (int s = 0; s < capacity; ++s) h_olen[r * c + s] = staged[(size_t)s] > r ? h_len[r * c + s] : 0;
+			}
+			have_req = false;
+			std::fill(req_drop.begin(), req_drop.end(), 0u);
+			std::fill(req_total.begin(), req_total.end(), 0u);
+			maxr = 0;
+		}
 		for (int r = 0; r < maxr; ++r) {
 			arm(r, false);
 			for (int s = 0; s < capacity; ++s)
@@ -72,7 +82,7 @@ struct FlowPool : Pool {
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_out + r * c * kFlowBlock, d_out, c * kFlowBlock * 2));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_olen + r * c, d_olen, c * 4));
 		}
-		arm(maxr, true);
+		if (!failed) arm(maxr, true);
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
 		for (int s = 0; s < capacity; ++s) {
 			ready[(size_t)s] = staged[(size_t)s];

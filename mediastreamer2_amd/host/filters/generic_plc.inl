@@ -77,6 +77,12 @@ struct PlcPool : Pool {
 		const size_t c = (size_t)capacity;
 		int maxr = 0;
 		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		if (failed) { // a broken context is not given more work: received blocks pass as they came, a concealment is silence
+			for (int r = 0; r < maxr; ++r)
+				for (int s = 0; s < capacity; ++s)
+					if (staged[(size_t)s] > r && h_mode[r * c + s] == MI_PLC_CONCEAL) memset(h_rows + (r * c + s) * kPlcBlock, 0, (size_t)kPlcBlock * 2);
+			maxr = 0;
+		}
 		for (int r = 0; r < maxr; ++r) {
 			for (int s = 0; s < capacity; ++s)
 				if (staged[(size_t)s] <= r) h_mode[r * c + s] = MI_PLC_NONE, h_len[r * c + s] = 0;

@@ -66,7 +66,7 @@ struct FusedLeg {
 	int new_samples = 0;  // samples it put on the mixer's queue since the mixer last looked
 	int chan_samples = 0; // the mixer channel's bufferizer, samples (what f_chan holds)
 	bool metered = false;
-	bool unfuse_wanted = false; // (a leg without a mixer: set by a method on any thread, honoured by the head's next process())
+	std::atomic<bool> unfuse_wanted{false}; // (a leg without a mixer: set by a method on any thread under the hub's lock, honoured by the head's next process())
 	uint32_t far_tick = 0;      // ticker tick in which the far end was last taken (a bank without mixers leaves early on these)
 };
 
@@ -986,7 +986,7 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	}
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
+	if (volume_is_peered(vd) || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
 	// (MSVolume's bufferizer may hold samples short of a 10 ms chunk from before a detach: they move to the device, leg_give_remainder)
 	if (!leg_remainder_ok(vd) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
 	MSQueue *qe = vol->inputs[0];
@@ -1027,6 +1027,10 @@ bool conf_try_fuse(MSFilter *mx) {
 		maxpin = pin;
 	}
 	if (cand.empty()) return false;
+	// an output-only pin above the last input (a listener's or recorder's tap, served at audiomixer.c:336-343) gets its mix too:
+	// the conference's width follows the highest linked pin of either kind
+	for (int pin = 0; pin < mx->desc->noutputs; ++pin)
+		if (mx->outputs[pin]) maxpin = std::max(maxpin, pin);
 	const SpeexECState *e0 = (const SpeexECState *)cand[0].ec->data;
 	const uint32_t ir0 = cand[0].rs ? ((const ResampleData *)cand[0].rs->data)->input_rate : (uint32_t)ms->rate; // (no MSResample: the leg comes in at the mixer's rate)
 	for (const LegCand &c : cand) { // one shape per conference (a bank is one shape)
@@ -1228,7 +1232,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	MSFilter *vol = qv ? qv->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != head->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (vd->peer || vd->peered_by > 0 || vd->sample_rate != es->samplerate || vd->leg) return false;
+	if (volume_is_peered(vd) || vd->sample_rate != es->samplerate || vd->leg) return false;
 	if (!leg_remainder_ok(vd) || ms_bufferizer_get_avail(vd->spill)) return false;
 	const bool no_agc = !vd->p.agc_enabled;
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;

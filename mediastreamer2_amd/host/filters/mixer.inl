@@ -95,7 +95,7 @@ struct MixerState { // audiomixer.c:132-143
 	LegBank *fbank;     // non-null: fused; the conference is slot `fconf` of that bank
 	int fconf;
 	int fuse_state;     // 0 not looked at since the attach, 1 fused, 2 refused
-	bool unfuse_wanted; // a member stopped qualifying (set by a method on any thread, honoured by the next process())
+	std::atomic<bool> unfuse_wanted; // a member stopped qualifying (set by a method on any thread, honoured by the next process())
 	bool first_look;    // the fused conference has had the census of its first tick
 };
 void leg_push_mixer_controls(MSFilter *f, MixerState *s); // leg_chain.inl

@@ -264,6 +264,7 @@ void ResamplePool::emit(MSFilter *f, int slot) {
 
 int resample_set_sr(MSFilter *f, void *arg) { // :181-192
 	ResampleData *d = (ResampleData *)f->data;
+	HubLock lk(f); // hub first, the filter's lock inside it; d->leg is only read under the hub's lock (the ticker thread deletes legs under it)
 	ms_filter_lock(f);
 	if (d->input_rate != *(unsigned int *)arg) leg_disqualify(d->leg), leg_forwarder_changed(f);
 	d->input_rate = *(unsigned int *)arg;
@@ -272,6 +273,7 @@ int resample_set_sr(MSFilter *f, void *arg) { // :181-192
 }
 int resample_set_output_sr(MSFilter *f, void *arg) { // :194-205
 	ResampleData *d = (ResampleData *)f->data;
+	HubLock lk(f); // hub first, the filter's lock inside it; d->leg is only read under the hub's lock (the ticker thread deletes legs under it)
 	ms_filter_lock(f);
 	if (d->output_rate != *(unsigned int *)arg) leg_disqualify(d->leg), leg_forwarder_changed(f);
 	d->output_rate = *(unsigned int *)arg;

@@ -149,6 +149,10 @@ struct FramePool : Pool {
 		ready.clear();
 		const int n = (int)staged.size();
 		if (!n) return;
+		if (failed) { // a broken context is not given more work: the frames are dropped (sizeconv.c:162-166)
+			staged.clear();
+			return;
+		}
 		mi_ctx *ctx = hub->ctx;
 		MI_MUST(mi_copy_h2d_pinned(ctx, d_src, h_src, (size_t)n * src_pitch));
 		MI_MUST(launch(n));

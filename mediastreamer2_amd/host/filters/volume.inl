@@ -123,8 +123,17 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	int slot;
 	bool ng_soft_start;
 	FusedLeg *leg;  // the filter is part of a fused call leg (filters/leg_chain.inl): its meter lives in that bank
-	int peered_by;  // MSVolume filters that named this one as their echo-limiter peer (it must stay in a bank of its own kind)
+	// MSVolume filters that named this one as their echo-limiter peer (it must stay in a bank of its own kind).  Back-pointers,
+	// under g_peer_mu: a peer that is destroyed FIRST -- audio_stream_free destroys volrecv before volsend, audiostream.c:357-358,
+	// and volsend's peer is volrecv (:2240) -- is forgotten by those who named it; nobody ever reaches into a freed filter
+	std::vector<MSFilter *> peered_by;
+	std::atomic<bool> peer_gone; // the peer was destroyed: the slot's parameters follow at the next block
 };
+std::mutex g_peer_mu;
+bool volume_is_peered(VolumeData *d) {
+	std::lock_guard<std::mutex> g(g_peer_mu);
+	return d->peer != NULL || !d->peered_by.empty();
+}
 mi_volume_state *leg_vstate(FusedLeg *leg);                      // leg_chain.inl
 void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain, const float *target); // (gain: also the running state's)
 
@@ -142,7 +151,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->pool = nullptr;
 	d->slot = -1;
 	d->leg = nullptr;
-	d->peered_by = 0;
+	d->peer_gone = false;
 	d->has_kept = false;
 	f->data = d;
 }
@@ -156,7 +165,19 @@ void volume_postprocess(MSFilter *f) { // detach: a fused conference goes back t
 void volume_uninit(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
 	if (d->leg) leg_release(d->leg, false);
-	if (d->peer) ((VolumeData *)d->peer->data)->peered_by--;
+	{
+		std::lock_guard<std::mutex> g(g_peer_mu);
+		if (d->peer) { // (alive: had it died first it would have cleared this pointer below)
+			std::vector<MSFilter *> &v = ((VolumeData *)d->peer->data)->peered_by;
+			v.erase(std::remove(v.begin(), v.end(), f), v.end());
+		}
+		for (MSFilter *a : d->peered_by) {
+			VolumeData *ad = (VolumeData *)a->data;
+			ad->peer = NULL;
+			ad->peer_gone.store(true, std::memory_order_release);
+		}
+		d->peered_by.clear();
+	}
 	if (d->pool && d->slot >= 0) {
 		HubLock lk(f);
 		d->pool->release(d->slot);
@@ -255,7 +276,7 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 		ms_queue_flush(f->inputs[0]);
 		return;
 	}
-	if (d->peer && d->p.peer < 0) volume_attach_slot(f);
+	if ((d->peer && d->p.peer < 0) || d->peer_gone.exchange(false, std::memory_order_acq_rel)) volume_attach_slot(f);
 	VolumePool *p = d->pool;
 	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
 	mblk_t *m;
@@ -352,9 +373,10 @@ int volume_get_max(MSFilter *f, void *arg) {
 	*(float *)arg = linear_to_dbm0(((VolumeData *)f->data)->max.current);
 	return 0;
 }
-void volume_set_gains(VolumeData *d, bool also_target) {
+void volume_set_gains(MSFilter *f, VolumeData *d, bool also_target) {
+	// methods run on the application's thread: the hub first (the ticker thread un-fuses and deletes legs under it), THEN d->leg
+	HubLock lk(f);
 	if (d->leg) {
-		HubLock lk(leg_pool(d->leg)->hub);
 		leg_push_volume(d->leg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
 		return;
 	}
@@ -363,7 +385,6 @@ void volume_set_gains(VolumeData *d, bool also_target) {
 		if (also_target) d->kept.target_gain = d->target_gain;
 	}
 	if (!d->pool) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
-	HubLock lk(d->pool->hub);
 	mi_volume_state *st = vstate(d);
 	if (st) {
 		st->gain = d->gain;
@@ -374,14 +395,16 @@ void volume_set_gains(VolumeData *d, bool also_target) {
 }
 int volume_set_gain(MSFilter *f, void *arg) { // :270-276
 	VolumeData *d = (VolumeData *)f->data;
+	HubLock lk(f); // (recursive: volume_set_gains takes it again; the ticker thread reads d->p and the gains under it)
 	d->gain = d->target_gain = d->p.static_gain = *(float *)arg;
-	volume_set_gains(d, true);
+	volume_set_gains(f, d, true);
 	return 0;
 }
 int volume_set_db_gain(MSFilter *f, void *arg) { // :262-268 (power ratio)
 	VolumeData *d = (VolumeData *)f->data;
+	HubLock lk(f);
 	d->gain = d->p.static_gain = (float)pow(10, (*(float *)arg) / 10);
-	volume_set_gains(d, false);
+	volume_set_gains(f, d, false);
 	return 0;
 }
 int volume_get_gain(MSFilter *f, void *arg) {
@@ -394,19 +417,28 @@ int volume_get_gain_db(MSFilter *f, void *arg) {
 }
 int volume_set_peer(MSFilter *f, void *arg) { // :292-297 stores the MSFilter*
 	VolumeData *d = (VolumeData *)f->data;
-	if (d->peer) ((VolumeData *)d->peer->data)->peered_by--;
-	d->peer = (MSFilter *)arg;
-	if (d->peer) {
-		VolumeData *pd = (VolumeData *)d->peer->data;
-		pd->peered_by++;
-		leg_disqualify(pd->leg); // the echo limiter reads its peer's meter of the previous tick: both in one plain bank
+	MSFilter *peer = (MSFilter *)arg;
+	{
+		std::lock_guard<std::mutex> g(g_peer_mu);
+		if (d->peer) {
+			std::vector<MSFilter *> &v = ((VolumeData *)d->peer->data)->peered_by;
+			v.erase(std::remove(v.begin(), v.end(), f), v.end());
+		}
+		d->peer = peer;
+		if (peer) ((VolumeData *)peer->data)->peered_by.push_back(f);
 	}
+	if (peer) { // the echo limiter reads its peer's meter of the previous tick: both in one plain bank
+		HubLock lk(peer);
+		leg_disqualify(((VolumeData *)peer->data)->leg);
+	}
+	HubLock lk(f);
 	leg_disqualify(d->leg);
 	if (d->pool) volume_attach_slot(f);
 	return 0;
 }
 int volume_set_rate(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
+	HubLock lk(f);
 	if (d->sample_rate != *(int *)arg) leg_disqualify(d->leg);
 	d->sample_rate = *(int *)arg;
 	return 0;
@@ -419,8 +451,8 @@ int volume_set_rate(MSFilter *f, void *arg) {
 			ms_error("MSVolume: parameter out of range");          \
 			return -1;                                             \
 		}                                                          \
+		HubLock lk(f); /* (the ticker thread reads d->p under it) */ \
 		d->p.field = val;                                          \
-		HubLock lk(f);        \
 		volume_push_params(d);                                     \
 		return 0;                                                  \
 	}
@@ -431,37 +463,39 @@ VOL_FLOAT_SETTER(volume_set_ea_transmit, ea_transmit_thres, true)
 VOL_FLOAT_SETTER(volume_set_ng_threshold, ng_threshold, true)
 int volume_set_ea_sustain(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
-	d->p.sustain_time = *(int *)arg;
 	HubLock lk(f);
+	d->p.sustain_time = *(int *)arg;
 	volume_push_params(d);
 	return 0;
 }
 int volume_set_agc(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
-	d->p.agc_enabled = *(int *)arg;
 	HubLock lk(f);
+	d->p.agc_enabled = *(int *)arg;
 	volume_push_params(d);
 	return 0;
 }
 int volume_enable_noise_gate(MSFilter *f, void *arg) { // :352-359
 	VolumeData *d = (VolumeData *)f->data;
+	HubLock lk(f);
 	d->p.noise_gate_enabled = *(bool_t *)arg;
 	if (d->p.noise_gate_enabled) d->gain = d->target_gain = d->p.ng_floorgain;
-	volume_set_gains(d, d->p.noise_gate_enabled != 0);
+	volume_set_gains(f, d, d->p.noise_gate_enabled != 0);
 	return 0;
 }
 int volume_set_ng_floorgain(MSFilter *f, void *arg) { // :367-378
 	VolumeData *d = (VolumeData *)f->data;
+	HubLock lk(f);
 	d->p.ng_floorgain = *(float *)arg;
 	if (d->p.ng_floorgain < 0.005f) d->p.ng_floorgain = 0.005f;
 	if (d->p.noise_gate_enabled) d->gain = d->target_gain = d->p.ng_floorgain;
-	volume_set_gains(d, d->p.noise_gate_enabled != 0);
+	volume_set_gains(f, d, d->p.noise_gate_enabled != 0);
 	return 0;
 }
 int volume_remove_dc(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
-	d->p.remove_dc = *(int *)arg;
 	HubLock lk(f);
+	d->p.remove_dc = *(int *)arg;
 	volume_push_params(d);
 	return 0;
 }

@@ -22,6 +22,7 @@
  */
 #include <dlfcn.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -97,6 +98,9 @@ static void *caller(void *arg) {
 			chain_make(&ch[i], 16000);
 			CHECK(ms_ticker_attach(tk, ch[i].src) == 0);
 		}
+		/* an echo-limiter pair (audiostream.c:2240): chain 0's MSVolume (volsend) names chain 1's (volrecv) as its peer */
+		const int peered = (seed + rep) % 3 == 0;
+		if (peered) CHECK(ms_filter_call_method(ch[0].vol, MS_VOLUME_SET_PEER, ch[1].vol) == 0);
 		if ((seed + rep) % 2 == 0) { /* an echo canceller: far end -> pin 0, microphone -> pin 1 */
 			ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
 			CHECK(ec != NULL);
@@ -140,6 +144,13 @@ static void *caller(void *arg) {
 			}
 		}
 		for (int i = 0; i < n; ++i) ms_ticker_detach(tk, ch[i].src);
+		if (peered) { /* audio_stream_free's order (audiostream.c:357-358): the PEER (volrecv) is destroyed before the filter that named it */
+			chain_destroy(&ch[1]);
+			chain_destroy(&ch[0]);
+			ch[0] = ch[n - 1], --n;
+			if (n > 1) ch[1] = ch[n - 1], --n;
+			else n = 0;
+		}
 		if (ec) {
 			char *state = NULL;
 			ms_ticker_detach(tk, ec);
@@ -219,6 +230,37 @@ typedef struct {
 	MSFilter *mic, *far, *rs, *ec, *vol, *spk, *out;
 } leg_t;
 
+/* Methods from the APPLICATION's thread while the ticker thread walks (d->leg / s->leg must only be read under the
+ * hub's lock -- the walking thread un-fuses and deletes legs).  Topology changes (detach / attach / link) are the application's
+ * too and never overlap its own method calls: g_topo serialises the two, the walk itself runs free. */
+typedef struct {
+	pthread_mutex_t topo;
+	volatile int stop;
+	MSFilter *vol_conf, *vol_other, *ec_conf, *ec_bypass, *vol_solo;
+} meddle_t;
+static void *meddler(void *arg) {
+	meddle_t *m = (meddle_t *)arg;
+	int k = 0;
+	while (!__atomic_load_n(&m->stop, __ATOMIC_SEQ_CST)) {
+		float g = 0.4f + 0.05f * (float)(k % 8), v = 0;
+		char *state = NULL;
+		int off = 0, on = 1;
+		bool_t byp = (bool_t)(k % 5 == 4);
+		pthread_mutex_lock(&m->topo);
+		ms_filter_call_method(m->vol_conf, MS_VOLUME_SET_GAIN, &g);
+		ms_filter_call_method(m->vol_other, MS_VOLUME_GET, &v);
+		ms_filter_call_method(m->ec_conf, MS_ECHO_CANCELLER_GET_STATE_STRING, &state);
+		ms_filter_call_method(m->vol_solo, MS_VOLUME_ENABLE_AGC, k % 2 ? &on : &off); /* the leg leaves its batch ... */
+		ms_filter_call_method(m->vol_solo, MS_VOLUME_SET_GAIN, &g);                   /* ... and is addressed again at once */
+		ms_filter_call_method(m->vol_solo, MS_VOLUME_GET_LINEAR, &v);
+		ms_filter_call_method(m->ec_bypass, MS_ECHO_CANCELLER_SET_BYPASS_MODE, &byp);
+		pthread_mutex_unlock(&m->topo);
+		++k;
+		sched_yield();
+	}
+	return NULL;
+}
+
 static void *conferences(void *arg) {
 	enum { NC = 2, NM = 5 };
 	int16_t mic[160], far[480];
@@ -270,19 +312,31 @@ static void *conferences(void *arg) {
 			ms_filter_link(l->vol, 0, l->out, 0), ms_filter_link(l->far, 0, l->ec, 0), ms_filter_link(l->ec, 0, l->spk, 0);
 			CHECK(ms_ticker_attach(tk, l->mic) == 0);
 		}
+		meddle_t med;
+		pthread_t med_th;
+		pthread_mutex_init(&med.topo, NULL);
+		med.stop = 0;
+		med.vol_conf = leg[0][1].vol, med.vol_other = leg[1][0].vol, med.ec_conf = leg[0][0].ec, med.ec_bypass = leg[1][3].ec, med.vol_solo = solo[2].vol;
 		for (int t = 0; t < 14; ++t) {
+			if (t == 3) CHECK(pthread_create(&med_th, NULL, meddler, &med) == 0); /* (after the census at t == 2) */
 			for (int k = 0; k < 3; ++k) {
 				if (k == 0) ms2shim_source_push(solo[k].mic, far, sizeof far); /* (a 48 kHz block) */
 				else ms2shim_source_push(solo[k].mic, mic, sizeof mic);
 				if (t != 5 || k != 1) ms2shim_source_push(solo[k].far, far, sizeof far); /* a far end that skips a tick */
 			}
-			if (t == 7) { int off = 0; ms_filter_call_method(solo[2].vol, MS_VOLUME_ENABLE_AGC, &off); } /* that leg goes back to its facades */
+			if (t == 7) { /* that leg goes back to its facades */
+				int off = 0;
+				pthread_mutex_lock(&med.topo);
+				ms_filter_call_method(solo[2].vol, MS_VOLUME_ENABLE_AGC, &off);
+				pthread_mutex_unlock(&med.topo);
+			}
 			for (int c = 0; c < NC; ++c)
 				for (int k = 0; k < NM; ++k) {
 					ms2shim_source_push(leg[c][k].mic, mic, sizeof mic);
 					ms2shim_source_push(leg[c][k].far, far, sizeof far);
 				}
 			ms_ticker_step(tk);
+			pthread_mutex_lock(&med.topo); /* (the application's own calls from here to the end of the tick) */
 			if (t == 2) { /* both conferences live in the fused batch by now */
 				int nc = 0, nl = 0;
 				p_fused(&nc, &nl, NULL, NULL);
@@ -311,7 +365,11 @@ static void *conferences(void *arg) {
 				ms_ticker_detach(tk, solo[0].mic);
 				CHECK(ms_ticker_attach(tk, solo[0].mic) == 0);
 			}
+			pthread_mutex_unlock(&med.topo);
 		}
+		__atomic_store_n(&med.stop, 1, __ATOMIC_SEQ_CST);
+		pthread_join(med_th, NULL);
+		pthread_mutex_destroy(&med.topo);
 		for (int k = 0; k < 3; ++k) {
 			leg_t *l = &solo[k];
 			ms_ticker_detach(tk, l->mic);
