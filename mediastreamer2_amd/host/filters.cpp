@@ -39,6 +39,7 @@
 #include <string>
 #include <tuple>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 extern "C" { // the descriptors (defined at the end of this file): the fused chain recognises its facades by them
@@ -90,6 +91,11 @@ struct Pool {
 	void sync_stream();
 	virtual void emit(MSFilter *f, int slot) = 0;  // hand a slot's results to its filter's output queues
 	virtual void emitted() {}                      // every slot has emitted: what the bank held for them may go
+	// A graph that is being detached has its tick in flight delivered before its filters let go (TickerHub::scope): a bank that
+	// can flush the slots of that graph alone -- every other slot's staged rows, counts and state left exactly as they are, for
+	// the ticker's own flush -- says so here and asks parked(slot) wherever it looks at what a slot staged
+	virtual bool scoped() const { return false; }
+	bool parked(int slot) const;
 	TickerHub *hub = nullptr;
 	std::string key;
 	std::vector<MSFilter *> owner;
@@ -117,7 +123,7 @@ struct Pool {
 	void release(int slot); // may destroy the bank (and the hub): do not touch either afterwards
 	void emit_all() {
 		for (int i = 0; i < hi; ++i)
-			if (owner[(size_t)i]) emit(owner[(size_t)i], i);
+			if (owner[(size_t)i] && !parked(i)) emit(owner[(size_t)i], i);
 	}
 	mi_ctx *ctx() const;
 	template <typename T>
@@ -166,6 +172,14 @@ struct TickerHub {
 	uint64_t flushes = 0; // rounds of (enqueue, one wait, emit) so far: what ms_mi355x_hub_stats reports
 	std::vector<MSFilter *> touched, touched_pumps;
 	std::unordered_map<MSFilter *, uint64_t> pumped; // pump facades run early by the flush task, and for which tick
+	// The reference's filters are synchronous: ms_ticker_detach finds nothing in flight (msticker.c:197-218).  Here a walk's blocks
+	// are staged and come back with the next tick's flush, so the FIRST postprocess of a graph that is being detached flushes that
+	// graph -- and only it: `scope` holds its filters while that flush runs (on the application's thread, under `mu`; the ticker
+	// thread may be walking the ticker's other graphs, whose staged work, queues and filters are not touched).  drained /
+	// drained_seq: the graph flushed last and the staging count it was flushed at (the graph's other postprocess calls find it there)
+	const std::unordered_set<MSFilter *> *scope = nullptr;
+	std::unordered_set<MSFilter *> drained;
+	uint64_t stage_seq = 0, drained_seq = (uint64_t)-1;
 	// Lifetime: ONE atomic word = the number of scopes that hold or are about to take `mu` (references: taken under the
 	// registry lock -- hub_for, referenced_hubs -- or while a slot / pin of the hub is held, so a hub found in the registry
 	// cannot be freed between the look-up and the lock) + the RETIRED bit (no banks left: out of the registry; set under
@@ -181,6 +195,7 @@ struct TickerHub {
 };
 
 mi_ctx *Pool::ctx() const { return hub->ctx; }
+bool Pool::parked(int slot) const { return hub->scope && !(owner[(size_t)slot] && hub->scope->count(owner[(size_t)slot])); }
 void Pool::sync_stream() {
 	if (hub->ctx && mi_ctx_sync(hub->ctx) != MI_OK) failed = mi_failed("mi_ctx_sync");
 }
@@ -432,6 +447,7 @@ inline void emit_to(MSQueue *q, mblk_t *m) {
 	if (!h || !h->in_flush) return;
 	MSFilter *g = q->next.filter;
 	if (!g || g->ticker != h->ticker || !h->ticker || !is_ours(g->desc)) return;
+	if (h->scope && !h->scope->count(g)) return; // (a detaching graph's flush runs nobody else's process())
 	std::vector<MSFilter *> &v = (g->desc->flags & MS_FILTER_IS_PUMP) ? h->touched_pumps : h->touched;
 	if (std::find(v.begin(), v.end(), g) == v.end()) v.push_back(g);
 }
@@ -458,25 +474,30 @@ bool already_ran_this_tick(MSFilter *f) {
 	return it != h.pumped.end() && it->second == f->ticker->time;
 }
 
+void deliver_fused_in_scope(TickerHub &h); // leg_chain.inl
 void flush_hub(TickerHub &h) {
 	static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr; // A/B switch: one tick per facade again
-	h.in_flush = !no_chain;
+	h.in_flush = !no_chain || h.scope; // (a detaching graph's flush always runs its chain to the end: there is no next tick for it)
 	h.touched.clear();
 	h.touched_pumps.clear();
+	if (h.scope) deliver_fused_in_scope(h); // fused conferences / legs of the graph: the launches already out are waited for, their results handed on
+	auto takes_part = [&](Pool *p) { return !h.scope || p->scoped(); };
 	for (int round = 0; round < 16; ++round) { // chains deeper than this finish on the next tick
 		// banks flushed in creation order; a facade may stage into any bank while another one emits
 		// every bank enqueues on the hub's stream, ONE wait, then every bank hands its results on
 		bool any = false;
 		const size_t npools = h.pools.size(); // (a bank created while the results are emitted is flushed in the next round)
 		for (size_t i = 0; i < npools; ++i)
-			if (!h.pools[i]->failed) any |= h.pools[i]->enqueue();
+			if (!h.pools[i]->failed && takes_part(h.pools[i])) any |= h.pools[i]->enqueue();
 		if (any && h.ctx && mi_ctx_sync(h.ctx) != MI_OK) {
 			mi_failed("mi_ctx_sync");
-			for (size_t i = 0; i < npools; ++i) h.pools[i]->failed = true; // nothing of this flush can be trusted
+			for (size_t i = 0; i < npools; ++i)
+				if (takes_part(h.pools[i])) h.pools[i]->failed = true; // nothing of this flush can be trusted
 		}
 		++h.flushes;
 		for (size_t i = 0; i < npools && i < h.pools.size(); ++i) {
 			Pool *p = h.pools[i];
+			if (!takes_part(p)) continue;
 			p->finish(); // (a failed bank still settles its bookkeeping: its filters pass their blocks on or drop them)
 			p->emit_all();
 			p->emitted();
@@ -512,6 +533,7 @@ void flush_task(MSFilter *f) {
 
 // called by a filter that staged work this tick (hub locked)
 void request_flush(MSFilter *f) {
+	++g_hub.stage_seq;
 	if (g_hub.in_flush) return; // staged from inside the flush task (chain linking): the task's loop gets to it
 	if (!g_hub.flush_owner) {
 		g_hub.flush_owner = f;
@@ -521,11 +543,36 @@ void request_flush(MSFilter *f) {
 
 // Every facade's postprocess ends here: the ticker drops a detached filter's postponed tasks (msticker.c:187-190,
 // :314-324), so if this filter owned the pending flush nobody will run it -- the next request must post a new one.
+// ... and it BEGINS by delivering the tick in flight: the first postprocess of a detaching graph flushes the graph's own staged
+// work through its chain (TickerHub::scope), so that what the reference's synchronous filters would have handed on in the last walk
+// is handed on before any of them drops its queues or state.
+void graph_of(MSFilter *f, std::unordered_set<MSFilter *> &out) { // every filter linked to f, whoever made it (ms_filter_find_neighbours)
+	std::vector<MSFilter *> todo{f};
+	out.insert(f);
+	while (!todo.empty()) {
+		MSFilter *g = todo.back();
+		todo.pop_back();
+		for (int i = 0; i < g->desc->ninputs; ++i)
+			if (g->inputs[i] && g->inputs[i]->prev.filter && out.insert(g->inputs[i]->prev.filter).second) todo.push_back(g->inputs[i]->prev.filter);
+		for (int i = 0; i < g->desc->noutputs; ++i)
+			if (g->outputs[i] && g->outputs[i]->next.filter && out.insert(g->outputs[i]->next.filter).second) todo.push_back(g->outputs[i]->next.filter);
+	}
+}
 void facade_detached(MSFilter *f) {
 	TickerHub *h = hub_for(f, false);
 	if (!h) return;
 	HubLock lk(h, HubLock::Adopt{});
 	if (lk.dead()) return;
+	static const bool drop = getenv("MSMI355X_DROP_AT_DETACH") != nullptr; // A/B switch: the tick in flight is dropped, as up to round 4
+	if (!drop && f->ticker && h->ticker == f->ticker && !h->in_flush && !(h->drained_seq == h->stage_seq && h->drained.count(f))) {
+		std::unordered_set<MSFilter *> graph;
+		graph_of(f, graph);
+		h->scope = &graph;
+		flush_hub(*h);
+		h->scope = nullptr;
+		h->drained.swap(graph);
+		h->drained_seq = h->stage_seq;
+	}
 	if (h->flush_owner == f) h->flush_owner = nullptr;
 	h->pumped.erase(f);
 }

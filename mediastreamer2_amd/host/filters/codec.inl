@@ -85,8 +85,13 @@ struct MapPool : Pool {
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_out, d_out, used * k.out_bpe));
 			MI_MUST(mi_ctx_sync(ctx));
 		}
+		bool kept = false; // a detaching graph's slots alone leave: the others' blocks stay where they lie, converted again by their own flush (a pure map)
 		for (int s = 0; s < hi; ++s) {
 			auto &st = staged[(size_t)s], &rd = ready[(size_t)s];
+			if (parked(s)) {
+				kept |= !st.empty();
+				continue;
+			}
 			if (failed) { // nothing was converted: the blocks are lost (counted), their meta blocks freed
 				for (MapBlock &b : st)
 					if (b.meta) freemsg(b.meta);
@@ -95,8 +100,9 @@ struct MapPool : Pool {
 			}
 			st.clear();
 		}
-		used = 0;
+		if (!kept) used = 0;
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override {
 		const size_t bpe = kMapOps[op].out_bpe;
 		for (const MapBlock &b : ready[(size_t)slot]) {

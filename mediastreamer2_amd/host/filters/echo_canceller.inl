@@ -39,11 +39,12 @@ struct EcPool : Pool {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi, row = (size_t)kEcTickFrames * F; // rows [0, hi) are all that was ever handed out
 		int maxf = 0;
-		for (int s = 0; s < hi; ++s) maxf = std::max(maxf, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s)
+			if (!parked(s)) maxf = std::max(maxf, staged[(size_t)s]);
 		const int rounds = (maxf + kEcTickFrames - 1) / kEcTickFrames;
 		for (int r = 0; r < rounds; ++r) {
 			for (int s = 0; s < capacity; ++s)
-				h_cnt[r * c + s] = s < hi ? (uint8_t)std::clamp(staged[(size_t)s] - r * kEcTickFrames, 0, kEcTickFrames) : 0;
+				h_cnt[r * c + s] = s < hi && !parked(s) ? (uint8_t)std::clamp(staged[(size_t)s] - r * kEcTickFrames, 0, kEcTickFrames) : 0;
 			if (zero_copy_rows()) { // the launch reads the pinned rows and writes the results where they lie: no copy at all (leg_chain.inl says why)
 				MI_MUST(mi_aec_process_frames(a, h_mic + r * c * row, h_ref + r * c * row, h_out + r * c * row, (int)row, h_cnt + r * c, kEcTickFrames, MI_AEC_POSTFILTER));
 				continue;
@@ -59,13 +60,15 @@ struct EcPool : Pool {
 	void finish() override {
 		if (failed) { // the launch did not happen: the microphone frames leave uncancelled (what bypass mode does, speexec.c:229-237)
 			for (int s = 0; s < hi; ++s)
-				for (int k = 0; k < staged[(size_t)s]; ++k) memcpy(h_out + frame_at((size_t)s, k), h_mic + frame_at((size_t)s, k), (size_t)F * 2);
+				for (int k = 0; k < staged[(size_t)s] && !parked(s); ++k) memcpy(h_out + frame_at((size_t)s, k), h_mic + frame_at((size_t)s, k), (size_t)F * 2);
 		}
 		for (int s = 0; s < hi; ++s) {
+			if (parked(s)) continue;
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override {
 		const size_t sl = (size_t)slot;
 		for (int k = 0; k < ready[sl]; ++k) { // cleaned frames -> outputs[1] (speexec.c:303)

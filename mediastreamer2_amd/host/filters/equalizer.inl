@@ -7,7 +7,7 @@ struct EqualizerPool : Pool {
 	int rate, cap_samples;
 	mi_equalizer *e = nullptr;
 	int16_t *h_buf, *d_buf;
-	int32_t *h_n, *d_n;
+	int32_t *h_n, *d_n, *h_nsc; // (h_nsc: as VolumePool's)
 	std::vector<int> staged, ready;
 	EqualizerPool(int cap, int r) : rate(r) {
 		Building b(this, cap);
@@ -16,6 +16,7 @@ struct EqualizerPool : Pool {
 		const size_t c = (size_t)capacity;
 		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
 		h_n = pinned<int32_t>(kMaxRounds * c);
+		h_nsc = pinned<int32_t>(kMaxRounds * c);
 		d_buf = devmem<int16_t>(c * cap_samples);
 		d_n = devmem<int32_t>(c);
 		staged.assign(c, 0);
@@ -28,12 +29,19 @@ struct EqualizerPool : Pool {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
-		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s)
+			if (!parked(s)) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r = 0; r < maxr; ++r) {
-			for (int s = 0; s < capacity; ++s)
-				if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			const int32_t *nrow = h_n + r * c;
+			if (hub->scope) { // a detaching graph's slots alone (see VolumePool::enqueue)
+				for (int s = 0; s < capacity; ++s) h_nsc[r * c + s] = (s < hi && staged[(size_t)s] > r && !parked(s)) ? h_n[r * c + s] : 0;
+				nrow = h_nsc + r * c;
+			} else {
+				for (int s = 0; s < capacity; ++s)
+					if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			}
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, nrow, c * 4));
 			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 		}
@@ -41,10 +49,12 @@ struct EqualizerPool : Pool {
 	}
 	void finish() override {
 		for (int s = 0; s < hi; ++s) { // after a failed launch the staged blocks leave as they came (flat response)
+			if (parked(s)) continue;
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override {
 		const size_t c = (size_t)capacity, s = (size_t)slot;
 		for (int r = 0; r < ready[s]; ++r) {

@@ -8,6 +8,7 @@ struct FlowPool : Pool {
 	mi_flowctl *fc = nullptr;
 	int16_t *h_in, *h_out, *d_in, *d_out;
 	int32_t *h_len, *h_olen, *d_len, *d_olen;
+	int32_t *h_lensc; // the rounds' length rows while a detaching graph's slots alone are flushed (see VolumePool::enqueue)
 	std::vector<uint32_t> req_drop, req_total; // pending MS_AUDIO_FLOW_CONTROL_DROP requests ...
 	std::vector<int> req_round;                // ... and how many staged blocks of the stream precede each
 	std::vector<uint32_t> arm_drop, arm_total;
@@ -21,6 +22,7 @@ struct FlowPool : Pool {
 		h_in = pinned<int16_t>(kMaxRounds * c * kFlowBlock);
 		h_out = pinned<int16_t>(kMaxRounds * c * kFlowBlock);
 		h_len = pinned<int32_t>(kMaxRounds * c);
+		h_lensc = pinned<int32_t>(kMaxRounds * c);
 		h_olen = pinned<int32_t>(kMaxRounds * c);
 		d_in = devmem<int16_t>(c * kFlowBlock);
 		d_out = devmem<int16_t>(c * kFlowBlock);
@@ -51,6 +53,10 @@ struct FlowPool : Pool {
 			for (int s = 0; s < capacity; ++s) {
 				arm_drop[(size_t)s] = arm_total[(size_t)s] = 0;
 				if (req_drop[(size_t)s] == 0 && req_total[(size_t)s] == 0) continue;
+				if (s < hi && parked(s)) { // (not this flush's business: the request waits for the slot's own)
+					left = true;
+					continue;
+				}
 				if (last || req_round[(size_t)s] <= r) {
 					arm_drop[(size_t)s] = req_drop[(size_t)s], arm_total[(size_t)s] = req_total[(size_t)s];
 					req_drop[(size_t)s] = req_total[(size_t)s] = 0;
@@ -61,11 +67,13 @@ struct FlowPool : Pool {
 			have_req = left;
 		};
 		int maxr = 0;
-		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s)
+			if (!parked(s)) maxr = std::max(maxr, staged[(size_t)s]);
 		if (failed) { // a broken context is not given more work: the staged blocks leave as they came, nothing dropped
 			for (int r = 0; r < maxr; ++r) {
 				memcpy(h_out + r * c * kFlowBlock, h_in + r * c * kFlowBlock, c * kFlowBlock * 2);
-				for (int s = 0; s < capacity; ++s) h_olen[r * c + s] = staged[(size_t)s] > r ? h_len[r * c + s] : 0;
+				for (int s = 0; s < hi; ++s)
+					if (!parked(s)) h_olen[r * c + s] = staged[(size_t)s] > r ? h_len[r * c + s] : 0;
 			}
 			have_req = false;
 			std::fill(req_drop.begin(), req_drop.end(), 0u);
@@ -74,10 +82,16 @@ struct FlowPool : Pool {
 		}
 		for (int r = 0; r < maxr; ++r) {
 			arm(r, false);
-			for (int s = 0; s < capacity; ++s)
-				if (staged[(size_t)s] <= r) h_len[r * c + s] = 0;
+			const int32_t *lrow = h_len + r * c;
+			if (hub->scope) {
+				for (int s = 0; s < capacity; ++s) h_lensc[r * c + s] = (s < hi && staged[(size_t)s] > r && !parked(s)) ? h_len[r * c + s] : 0;
+				lrow = h_lensc + r * c;
+			} else {
+				for (int s = 0; s < capacity; ++s)
+					if (staged[(size_t)s] <= r) h_len[r * c + s] = 0;
+			}
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in + r * c * kFlowBlock, c * kFlowBlock * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_len, h_len + r * c, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_len, lrow, c * 4));
 			MI_MUST(mi_flowctl_process(fc, d_in, kFlowBlock, d_len, kFlowBlock, d_out, kFlowBlock, d_olen));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_out + r * c * kFlowBlock, d_out, c * kFlowBlock * 2));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_olen + r * c, d_olen, c * 4));
@@ -85,12 +99,14 @@ struct FlowPool : Pool {
 		if (!failed) arm(maxr, true);
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
 		for (int s = 0; s < capacity; ++s) {
+			if (s < hi && parked(s)) continue;
 			ready[(size_t)s] = staged[(size_t)s];
 			staged[(size_t)s] = 0;
 			done[(size_t)s].swap(held[(size_t)s]);
 			held[(size_t)s].clear();
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override {
 		const size_t c = (size_t)capacity, s = (size_t)slot;
 		for (int r = 0; r < ready[s]; ++r) {

@@ -40,8 +40,8 @@ struct PlcPool : Pool {
 	int rate;
 	mi_plc *plc = nullptr;
 	int16_t *h_rows, *d_rows;
-	int32_t *h_len, *d_len;
-	uint8_t *h_mode, *d_mode;
+	int32_t *h_len, *d_len, *h_lensc;   // (h_lensc / h_modesc: the rounds' rows while a detaching graph's slots alone are flushed)
+	uint8_t *h_mode, *d_mode, *h_modesc;
 	std::vector<int> staged;
 	std::vector<std::vector<PlcEntry>> pending, done;
 	PlcPool(int cap, int r) : rate(r) {
@@ -51,6 +51,8 @@ struct PlcPool : Pool {
 		h_rows = pinned<int16_t>(kMaxRounds * c * kPlcBlock);
 		h_len = pinned<int32_t>(kMaxRounds * c);
 		h_mode = pinned<uint8_t>(kMaxRounds * c);
+		h_lensc = pinned<int32_t>(kMaxRounds * c);
+		h_modesc = pinned<uint8_t>(kMaxRounds * c);
 		d_rows = devmem<int16_t>(c * kPlcBlock);
 		d_len = devmem<int32_t>(c);
 		d_mode = devmem<uint8_t>(c);
@@ -76,30 +78,44 @@ struct PlcPool : Pool {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity;
 		int maxr = 0;
-		for (int s = 0; s < capacity; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s)
+			if (!parked(s)) maxr = std::max(maxr, staged[(size_t)s]);
 		if (failed) { // a broken context is not given more work: received blocks pass as they came, a concealment is silence
 			for (int r = 0; r < maxr; ++r)
-				for (int s = 0; s < capacity; ++s)
-					if (staged[(size_t)s] > r && h_mode[r * c + s] == MI_PLC_CONCEAL) memset(h_rows + (r * c + s) * kPlcBlock, 0, (size_t)kPlcBlock * 2);
+				for (int s = 0; s < hi; ++s)
+					if (!parked(s) && staged[(size_t)s] > r && h_mode[r * c + s] == MI_PLC_CONCEAL) memset(h_rows + (r * c + s) * kPlcBlock, 0, (size_t)kPlcBlock * 2);
 			maxr = 0;
 		}
 		for (int r = 0; r < maxr; ++r) {
-			for (int s = 0; s < capacity; ++s)
-				if (staged[(size_t)s] <= r) h_mode[r * c + s] = MI_PLC_NONE, h_len[r * c + s] = 0;
+			const int32_t *lrow = h_len + r * c;
+			const uint8_t *mrow = h_mode + r * c;
+			if (hub->scope) {
+				for (int s = 0; s < capacity; ++s) {
+					const bool in = s < hi && staged[(size_t)s] > r && !parked(s);
+					h_lensc[r * c + s] = in ? h_len[r * c + s] : 0;
+					h_modesc[r * c + s] = in ? h_mode[r * c + s] : (uint8_t)MI_PLC_NONE;
+				}
+				lrow = h_lensc + r * c, mrow = h_modesc + r * c;
+			} else {
+				for (int s = 0; s < capacity; ++s)
+					if (staged[(size_t)s] <= r) h_mode[r * c + s] = MI_PLC_NONE, h_len[r * c + s] = 0;
+			}
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_rows, h_rows + r * c * kPlcBlock, c * kPlcBlock * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_len, h_len + r * c, c * 4));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_mode, h_mode + r * c, c));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_len, lrow, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_mode, mrow, c));
 			MI_MUST(mi_plc_process(plc, d_rows, kPlcBlock, d_len, d_mode));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_rows + r * c * kPlcBlock, d_rows, c * kPlcBlock * 2));
 		}
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
 		for (int s = 0; s < capacity; ++s) {
+			if (s < hi && parked(s)) continue;
 			auto &p = pending[(size_t)s], &d = done[(size_t)s];
 			d.insert(d.end(), p.begin(), p.end());
 			p.clear();
 			staged[(size_t)s] = 0;
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override {
 		const size_t c = (size_t)capacity, s = (size_t)slot;
 		for (const PlcEntry &e : done[s]) {

@@ -690,8 +690,20 @@ struct LegBank : Pool {
 
 	void finish() override {
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
-		for (auto &qm : spk) ms_queue_put(qm.first, qm.second); // MSSpeexEC's speaker pin: one frame per microphone frame (speexec.c:261-284)
-		spk.clear();
+		// MSSpeexEC's speaker pin: one frame per microphone frame (speexec.c:261-284).  While a detaching graph is being delivered
+		// (TickerHub::scope, the application's thread) only ITS legs' frames go: the others' readers may be walking on the ticker thread,
+		// their frames follow with the ticker's own flush
+		if (hub->scope) {
+			std::vector<std::pair<MSQueue *, mblk_t *>> later;
+			for (auto &qm : spk) {
+				if (qm.first->prev.filter && hub->scope->count(qm.first->prev.filter)) ms_queue_put(qm.first, qm.second);
+				else later.push_back(qm);
+			}
+			spk.swap(later);
+		} else {
+			for (auto &qm : spk) ms_queue_put(qm.first, qm.second);
+			spk.clear();
+		}
 		if (failed) {
 			std::fill(conf_ready.begin(), conf_ready.end(), 0);
 			g_late_events.fetch_add(1, std::memory_order_relaxed);
@@ -815,6 +827,18 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 		memset(m->b_rptr, 0, nbytes);
 	}
 	hand_on(m);
+}
+
+// A graph is being detached (facade_detached, filters.cpp): its fused conferences' and legs' tick in flight is waited for and handed
+// on -- speaker frames, mixes / chunks -- before any of its facades lets go (the scoped flush then carries those blocks on through
+// whatever facades of the graph sit behind: an encoder, a resampler)
+void deliver_fused_in_scope(TickerHub &h) {
+	for (Pool *p : h.pools) {
+		if (p->key.compare(0, 3, "leg") != 0) continue;
+		LegBank *b = static_cast<LegBank *>(p);
+		for (int s = 0; s < b->hi; ++s)
+			if (b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s])) b->deliver_in_flight(b->owner[(size_t)s], s);
+	}
 }
 
 // Every conference of the bank has been walked in this tick (its mixer runs behind all of its legs in the ticker's
@@ -1127,7 +1151,6 @@ bool conf_try_fuse(MSFilter *mx) {
 	b->staged_since = true;
 	ms->fuse_state = 1;
 	ms->unfuse_wanted = false;
-	ms->first_look = false;
 	mixer_push_controls(mx, ms);
 	ms_message("mi355x: conference %p fused: %d legs %u -> %u Hz, frame %d, tail %d, one device-resident batch (bank of %d x %d)", (void *)mx,
 	           (int)cand.size(), ir, rate, F, flen, b->capacity, mm);

@@ -46,8 +46,8 @@ struct MixerPool : Pool {
 		const size_t c = (size_t)capacity;
 		bool any = false;
 		for (size_t s = 0; s < c; ++s) {
-			h_run[s] = staged[s];
-			any |= staged[s] != 0;
+			h_run[s] = (int)s < hi && !parked((int)s) ? staged[s] : 0;
+			any |= h_run[s] != 0;
 		}
 		if (ctl_dirty) {
 			MI_MUST(mi_mixer_set_controls(m, flags.data(), gain.data()));
@@ -66,10 +66,12 @@ struct MixerPool : Pool {
 	}
 	void finish() override {
 		for (size_t s = 0; s < (size_t)capacity; ++s) {
+			if ((int)s < hi && parked((int)s)) continue;
 			ready[s] = staged[s];
 			staged[s] = 0;
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override;
 };
 
@@ -96,7 +98,7 @@ struct MixerState { // audiomixer.c:132-143
 	int fconf;
 	int fuse_state;     // 0 not looked at since the attach, 1 fused, 2 refused
 	std::atomic<bool> unfuse_wanted; // a member stopped qualifying (set by a method on any thread, honoured by the next process())
-	bool first_look;    // the fused conference has had the census of its first tick
+	bool first_walk;    // the walk right after an attach is still to come (see mixer_process)
 };
 void leg_push_mixer_controls(MSFilter *f, MixerState *s); // leg_chain.inl
 
@@ -170,6 +172,7 @@ void mixer_prepare(MSFilter *f) { // (hub locked by the caller)
 		s->channels[i].last_activity = (uint64_t)-1;
 	}
 	s->skip_threshold = s->bytespertick * 2;
+	s->first_walk = true;
 	s->bypass_mode = FALSE;
 	s->single_output = has_single_output(f, s);
 	const int ns = s->bytespertick / 2;
@@ -322,11 +325,8 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	if (s->unfuse_wanted && s->fbank) conf_unfuse(f, true); // a member stopped qualifying: back to the facades' own banks
 	if (s->fuse_state == 0 && !s->fbank) conf_try_fuse(f); // (normally a leg's head got here first)
 	if (s->fbank) { // fused: the conference ticks inside the hub's flush; a pump keeps that flush coming every tick
-		if (!s->first_look) { // the census of the attach's first tick (this walk): a pin's clock starts when it is first looked at
-			for (int i = 0; i < f->desc->ninputs; ++i)
-				if (f->inputs[i] && s->channels[i].last_activity == (uint64_t)-1) s->channels[i].last_activity = f->ticker->time;
-			s->first_look = true;
-		}
+		// (no census here: what the members staged in THIS walk meets the mixer in LegBank::conf_tick, whose three cases are
+		// mixer_check_bypass's, audiomixer.c:244-286 -- a pin's clock starts at its first look there, without counting yet)
 		mixer_release_held(f, s, true);
 		request_flush(f);
 		const uint64_t tr2 = trace_ms > 0 ? leg_trace_now() : 0;
@@ -344,6 +344,19 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 		ms_filter_unlock(f);
 		return;
 	}
+	// Fed by facades of this plugin only, the mixer meets a walk's blocks one tick later: pumped by the flush that delivers them,
+	// or -- when that flush brought it nothing -- in the next walk.  The walk right after an attach has no such predecessor: a
+	// census here would start every pin's clock a tick before the walk it belongs to and make the conference "contribute" (and
+	// stream out 10 ms of silence) where the reference's first walk finds only first looks (audiomixer.c:258-260)
+	if (s->first_walk && !g_hub.in_flush) {
+		s->first_walk = false;
+		static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr;
+		if (!no_chain && all_inputs_ours(f) && !inputs_waiting(f)) {
+			ms_filter_unlock(f);
+			return;
+		}
+	}
+	s->first_walk = false;
 	mixer_release_held(f, s, true); // what bypass mode forwarded on the previous tick
 	if (!s->pool) {
 		ms_filter_unlock(f);

@@ -35,9 +35,10 @@ struct ResamplePool : Pool {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		int maxr = 0;
-		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s)
+			if (!parked(s)) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r_ = 0; r_ < maxr; ++r_) {
-			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = s < hi && staged[(size_t)s] > r_;
+			for (int s = 0; s < capacity; ++s) h_run[r_ * c + s] = s < hi && staged[(size_t)s] > r_ && !parked(s);
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in + r_ * c * in_len, u * in_len * 2));
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_run, h_run + r_ * c, c));
 			MI_MUST(mi_resampler_process_masked(r, d_in, in_len, in_len, d_out, ostride, d_olen, d_run));
@@ -48,10 +49,12 @@ struct ResamplePool : Pool {
 	}
 	void finish() override {
 		for (int s = 0; s < hi; ++s) {
+			if (parked(s)) continue;
 			ready[(size_t)s] = failed ? 0 : staged[(size_t)s]; // a failed launch delivers nothing (late event counted)
 			staged[(size_t)s] = 0;
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override;
 };
 

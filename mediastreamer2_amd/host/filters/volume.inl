@@ -38,6 +38,7 @@ struct VolumePool : Pool {
 	mi_volume *v = nullptr;
 	int16_t *h_buf, *d_buf;
 	int32_t *h_n, *d_n;
+	int32_t *h_nsc; // the rounds' count rows while a detaching graph's slots alone are flushed (the others' h_n rows stay as staged)
 	mi_volume_state *h_state; // pinned: the meters come back with the blocks, no synchronisation of their own
 	bool fetched = false;
 	int rounds_fetched = 0;
@@ -53,6 +54,7 @@ struct VolumePool : Pool {
 		const size_t c = (size_t)capacity;
 		h_buf = pinned<int16_t>(kMaxRounds * c * cap_samples);
 		h_n = pinned<int32_t>(kMaxRounds * c);
+		h_nsc = pinned<int32_t>(kMaxRounds * c);
 		d_buf = devmem<int16_t>(c * cap_samples);
 		d_n = devmem<int32_t>(c);
 		h_state = pinned<mi_volume_state>(kMaxRounds * c); // row r: the meters behind round r (every chunk's energy is recorded, msvolume.c:405-406)
@@ -78,12 +80,19 @@ struct VolumePool : Pool {
 			params_dirty[(size_t)s] = state_dirty[(size_t)s] = 0;
 		}
 		int maxr = 0;
-		for (int s = 0; s < hi; ++s) maxr = std::max(maxr, staged[(size_t)s]);
+		for (int s = 0; s < hi; ++s)
+			if (!parked(s)) maxr = std::max(maxr, staged[(size_t)s]);
 		for (int r = 0; r < maxr; ++r) {
-			for (int s = 0; s < capacity; ++s)
-				if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			const int32_t *nrow = h_n + r * c;
+			if (hub->scope) { // a detaching graph's slots alone: everybody else counts as empty in THIS launch and keeps what it staged
+				for (int s = 0; s < capacity; ++s) h_nsc[r * c + s] = (s < hi && staged[(size_t)s] > r && !parked(s)) ? h_n[r * c + s] : 0;
+				nrow = h_nsc + r * c;
+			} else {
+				for (int s = 0; s < capacity; ++s)
+					if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
+			}
 			MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, h_n + r * c, c * 4));
+			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, nrow, c * 4));
 			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
 			if (!failed) MI_MUST(mi_volume_get_state_async(v, 0, hi, h_state + r * c)); // meters for the app thread
@@ -98,10 +107,12 @@ struct VolumePool : Pool {
 				if (!state_dirty[(size_t)s]) state[(size_t)s] = h_state[(size_t)(rounds_fetched - 1) * capacity + s];
 		fetched = false;
 		for (int s = 0; s < hi; ++s) {
+			if (parked(s)) continue;
 			ready[(size_t)s] = staged[(size_t)s]; // after a failed launch the staged blocks leave as they came (unity gain)
 			staged[(size_t)s] = 0;
 		}
 	}
+	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override;
 };
 

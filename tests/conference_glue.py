@@ -214,7 +214,75 @@ def run(plugin_dir, fuse, oracle, h=None, trace=None):
 
 
 # ---------------------------------------------------------------------------------------------------- the oracle's prediction
-def oracle_polls(oracle, F=256, latency=1, trace=None):
+class OracleMixer:
+    """MSAudioMixer in conference mode on the oracle's arithmetic (oracle.mixer_tick: accumulate / saturate / own contribution
+    removed, audiomixer.c:33-51,120-131) with the filter's bookkeeping restated: per-pin bufferizers (channel_process_in :78-90),
+    the census of mixer_check_bypass (:244-286: a pin counts while it delivered within the last second; a pin that is looked at
+    for the first time only starts its clock), the channels' flow control (:92-111), ALWAYS_STREAMOUT (:29,315-317), and what a
+    detach does to it (mixer_postprocess :200-208 drops every channel's queue, preprocess :186-198 restarts the clocks).
+    A single contributor is MIXED here like any other, as the plugin's fused conference does (the reference forwards that pin's
+    blocks unsaturated, :219-242: only a sample of -32768 would differ -- the stated exception of leg_chain.inl)."""
+    TIMEOUT, NS = 1000, RATE // 100
+
+    def __init__(self, oracle):
+        self.o = oracle
+        self.q = {}          # pin -> queued samples (the channel's bufferizer + its input queue)
+        self.seen = {}       # pin -> last_activity
+        self.fc = {}         # pin -> [last_flow_control, min_fullness]
+        self.active = {}     # pin -> MS_AUDIO_MIXER_SET_ACTIVE
+
+    def link(self, pin):
+        self.q[pin], self.seen[pin], self.fc[pin] = np.zeros(0, np.int16), None, [None, -1]
+        self.active.setdefault(pin, True)
+
+    def unlink(self, pin):
+        for d in (self.q, self.seen, self.fc, self.active):
+            d.pop(pin, None)
+
+    def reattached(self):
+        for pin in self.q:
+            self.q[pin], self.seen[pin], self.fc[pin] = np.zeros(0, np.int16), None, [None, -1]
+
+    def tick(self, now, arrived):
+        """arrived: pin -> samples MSVolume put on the pin's queue in this walk; -> {pin: 10 ms of mix} (empty: nothing left)"""
+        count = 0
+        for pin in self.q:
+            got = len(arrived.get(pin, ())) > 0
+            if got:
+                self.seen[pin] = now
+                count += 1
+            elif self.seen[pin] is None:
+                self.seen[pin] = now
+            elif now - self.seen[pin] < self.TIMEOUT:
+                count += 1
+        for pin, x in arrived.items():
+            self.q[pin] = np.concatenate([self.q[pin], x])
+        if count == 0:
+            for pin in self.q:   # (mixer_check_bypass returns before anything is read: the queues keep what arrived)
+                pass
+            return {}
+        pins = sorted(self.q)
+        rows, has = np.zeros((len(pins), self.NS), np.int16), np.zeros(len(pins), np.uint8)
+        for k, pin in enumerate(pins):
+            if len(self.q[pin]) >= self.NS:
+                rows[k], self.q[pin], has[k] = self.q[pin][:self.NS], self.q[pin][self.NS:], 1
+            last, minf = self.fc[pin]
+            if last is None:
+                self.fc[pin] = [now, -1]
+            else:
+                size = len(self.q[pin]) * 2
+                minf = size if (minf == -1 or size < minf) else minf
+                if now - last >= 5000:
+                    if minf >= self.NS * 4:
+                        self.q[pin] = self.q[pin][(minf - self.NS * 2) // 2:]
+                    last, minf = now, -1
+                self.fc[pin] = [last, minf]
+        act = np.array([1 if self.active[p] else 0 for p in pins], np.uint8)
+        out, _ = self.o.mixer_tick(rows, has_data=has, active=act)
+        return {pin: out[k] for k, pin in enumerate(pins)}
+
+
+def oracle_polls(oracle, F=256, latency=1, trace=None, mixes=None):
     """the same call through the chain of oracle objects: per leg Resampler -> the canceller's framing (speexec.c:223-305) ->
     Echo + Preproc -> MSVolume's 10 ms chunks with AGC (msvolume.c:471-514) feeding its 1 s maximum (:115,405); per conference
     the bookkeeping and election of oracle/conference.c.  -> [(tick, conference, poll)] like run().
@@ -234,6 +302,7 @@ def oracle_polls(oracle, F=256, latency=1, trace=None):
             self.max = oracle.Extremum(1000)                      # msvolume.c:115
             self.q_mic, self.q_ref, self.q_vol = (np.zeros(0, np.int16) for _ in range(3))
             self.started, self.pin = False, -1
+            self.sent = np.zeros(0, np.int16)                     # what MSVolume handed on in this walk
 
         def reattached(self):
             """the conference graph was detached and attached again (audioconference.c:325-327,369-374): MSVolume's preprocess
@@ -259,12 +328,14 @@ def oracle_polls(oracle, F=256, latency=1, trace=None):
                 self.q_vol = np.concatenate([self.q_vol, self.pp.run(self.ec.cancel(fr, r))])
             while len(self.q_vol) >= ns:                          # msvolume.c:480-497
                 ch, self.q_vol = self.q_vol[:ns], self.q_vol[ns:]
-                self.vol.chunk(ch)
+                self.sent = np.concatenate([self.sent, self.vol.chunk(ch)])
                 self.max.record_max(now, self.vol.v.energy)
 
     legs = {n: OLeg() for n in LEGS}
     books = {"a": oracle.Conference(), "b": oracle.Conference()}
     by_pin = {"a": {}, "b": {}}
+    mixers = {"a": OracleMixer(oracle), "b": OracleMixer(oracle)}
+    heard = {n: [] for n in LEGS}
     polls, hist = [], []
     for t in range(NTICKS):
         for ev in SCRIPT:
@@ -275,19 +346,31 @@ def oracle_polls(oracle, F=256, latency=1, trace=None):
                 if books[c].size > 0:
                     for l in by_pin[c].values():
                         l.reattached()
+                    mixers[c].reattached()
                 leg.pin = books[c].add_member(False)
                 by_pin[c][leg.pin] = leg
+                mixers[c].link(leg.pin)
             elif ev[1] == "leave":
                 books[c].remove_member(leg.pin)
+                mixers[c].unlink(leg.pin)
                 del by_pin[c][leg.pin]
                 leg.pin = -1
                 for l in by_pin[c].values():
                     l.reattached()
+                mixers[c].reattached()
             elif ev[1] == "mute":
                 books[c].mute_member(leg.pin, ev[3])
+                mixers[c].active[leg.pin] = not ev[3]
         for name, leg in legs.items():
             if leg.pin >= 0:
                 leg.tick(10 * t, mic[name][t * ni:(t + 1) * ni], far[name][t * ns:(t + 1) * ns])
+        names_of = {id(l): n for n, l in legs.items()}
+        for c in ("a", "b"):   # the mixer is walked behind all of its members (msticker.c:261-282)
+            arrived = {}
+            for pin, l in by_pin[c].items():
+                arrived[pin], l.sent = l.sent, np.zeros(0, np.int16)
+            for pin, row in mixers[c].tick(10 * t, arrived).items():
+                heard[names_of[id(by_pin[c][pin])]].append(row)
         hist.append({n: (l.max.current, l.vol.v.energy) for n, l in legs.items()})
         if trace is not None:
             trace.append({n: oracle.linear_to_dbm0(l.vol.v.energy) for n, l in legs.items() if l.pin >= 0})
@@ -300,6 +383,8 @@ def oracle_polls(oracle, F=256, latency=1, trace=None):
                 polls.append((t, c, {"changed": changed, "winner": winner, "winner_db": wdb, "speaker": books[c].active_speaker,
                                      "db": {names[id(by_pin[c][p])]: v for p, v in db.items()},
                                      "now_db": {names[id(l)]: oracle.linear_to_dbm0(then[names[id(l)]][1]) for l in by_pin[c].values()}}))
+    if mixes is not None:   # every member's mix over the call, block after block as its out_resampler -> mixer_out would have seen them
+        mixes.update({n: (np.concatenate(v) if v else np.zeros(0, np.int16)) for n, v in heard.items()})
     return polls
 
 
@@ -371,6 +456,27 @@ def verdict(fused, plain):
         if not np.array_equal(sx[:m], sy[:m]):
             bad.append(name + ":spk")
     v["differ_before_replumb"] = bad
+    # (1b) ... and after it: the reference's filters are synchronous, a detach finds nothing in flight (msticker.c:197-218); here the
+    # tick in flight is delivered at the detach by both forms, so the whole call is sample for sample the same (the blocks around
+    # a mute left out as above; b3 / b4 from their joins on)
+    bad = []
+    for name in LEGS:
+        c = name[0]
+        x, y = fused["out"][name], plain["out"][name]
+        n = min(len(x), len(y))
+        skip = np.zeros(n, bool)
+        for t in EVENT_TICKS[c]:
+            if t not in REPLUMBED[c]:
+                skip[max(0, (t - 3) * ns):(t + 1) * ns] = True
+        if len(x) != len(y) or ((x[:n] != y[:n]) & ~skip).any():
+            d = np.flatnonzero((x[:n] != y[:n]) & ~skip)
+            bad.append((name, len(x), len(y), int(d[0]) // ns if len(d) else -1, int(len(d))))
+        sx, sy = fused["spk"][name], plain["spk"][name]
+        if len(sx) != len(sy) or not np.array_equal(sx, sy):
+            m = min(len(sx), len(sy))
+            d = np.flatnonzero(sx[:m] != sy[:m])
+            bad.append((name + ":spk", len(sx), len(sy), int(d[0]) // ns if len(d) else -1, int(len(d))))
+    v["differ_after_replumb"] = bad
     # (2) after a member left conference a: the same audio, shifted by the framing of the one tick that was in flight at the detach
     v["lag_after_leave"] = {name: best_lag(fused["out"][name], plain["out"][name], 345) for name in ("a0", "a1", "a3")}
     v["level_after"] = {name: [rms(fused["out"][name], 345, 415), rms(plain["out"][name], 345, 415)] for name in ("a0", "a1", "a3", "b0", "b2")}
