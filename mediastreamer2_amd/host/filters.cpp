@@ -91,6 +91,7 @@ struct Pool {
 	void sync_stream();
 	virtual void emit(MSFilter *f, int slot) = 0;  // hand a slot's results to its filter's output queues
 	virtual void emitted() {}                      // every slot has emitted: what the bank held for them may go
+	virtual void flushed() {}                      // a hub flush is through, all of its rounds (flush_hub)
 	// A graph that is being detached has its tick in flight delivered before its filters let go (TickerHub::scope): a bank that
 	// can flush the slots of that graph alone -- every other slot's staged rows, counts and state left exactly as they are, for
 	// the ticker's own flush -- says so here and asks parked(slot) wherever it looks at what a slot staged
@@ -519,6 +520,8 @@ void flush_hub(TickerHub &h) {
 		for (MSFilter *g : run) // call_process msticker.c:244-259: while there is input (a filter that staged stops)
 			for (int n = 0; n < 64 && inputs_waiting(g); ++n) g->desc->process(g);
 	}
+	for (Pool *p : h.pools)
+		if (takes_part(p)) p->flushed();
 	h.in_flush = false;
 }
 

@@ -18,6 +18,13 @@ struct MixerPool : Pool {
 	std::vector<uint8_t> flags;
 	std::vector<float> gain;
 	bool ctl_dirty = true;
+	// A method between two ticks (MS_AUDIO_MIXER_SET_ACTIVE, SET_INPUT_GAIN, ENABLE_OUTPUT) meets the NEXT walk's blocks in the
+	// reference.  Here the last walk's blocks are still on their way to this bank (they are mixed by the coming flush, in one of
+	// its rounds -- and a tick the mixer staged in that walk itself in another), so what a method sets waits in next_* and goes
+	// live when that flush is through (flushed()): the walk the call preceded is the first it is heard in
+	std::vector<uint8_t> next_flags, next_set;
+	std::vector<float> next_gain;
+	bool next_any = false;
 	std::vector<uint8_t> staged, ready;
 	MixerPool(int cap, int nsamples) : ns(nsamples) {
 		Building b(this, std::max(1, cap / 8)); // a mixer slot carries 50 channel rows
@@ -35,6 +42,9 @@ struct MixerPool : Pool {
 		d_mode = devmem<uint8_t>(c);
 		flags.assign(n, 0);
 		gain.assign(n, 1.0f);
+		next_flags.assign(n, 0);
+		next_gain.assign(n, 1.0f);
+		next_set.assign(c, 0);
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 	}
@@ -73,6 +83,23 @@ struct MixerPool : Pool {
 	}
 	bool scoped() const override { return true; }
 	void emit(MSFilter *f, int slot) override;
+	void flushed() override { // the whole flush is through (every round of its chain: the last walk's blocks have all been mixed)
+		if (!next_any) return;
+		bool left = false;
+		for (int s = 0; s < hi; ++s) {
+			if (!next_set[(size_t)s]) continue;
+			if (parked(s)) { // (a detaching graph's flush is not this conference's)
+				left = true;
+				continue;
+			}
+			const size_t at = (size_t)s * MIXER_MAX_CHANNELS;
+			std::copy(next_flags.begin() + at, next_flags.begin() + at + MIXER_MAX_CHANNELS, flags.begin() + at);
+			std::copy(next_gain.begin() + at, next_gain.begin() + at + MIXER_MAX_CHANNELS, gain.begin() + at);
+			next_set[(size_t)s] = 0;
+			ctl_dirty = true;
+		}
+		next_any = left;
+	}
 };
 
 struct Channel { // audiomixer.c:53-63
@@ -141,22 +168,32 @@ bool_t has_single_output(MSFilter *f, MixerState *s) { // audiomixer.c:167-176
 		if (f->outputs[i] && s->channels[i].output_enabled) count++;
 	return count == 1;
 }
-void mixer_push_controls(MSFilter *f, MixerState *s) {
+// from_method: set by a method on a running filter -- live behind the coming flush (MixerPool::next_*); otherwise (attach) at once
+void mixer_push_controls(MSFilter *f, MixerState *s, bool from_method = false) {
 	if (s->fbank) {
 		leg_push_mixer_controls(f, s);
 		return;
 	}
 	if (!s->pool) return;
 	MixerPool *p = s->pool;
+	const bool later = from_method && f->ticker != NULL && !s->first_walk; // (before the attach's first walk nothing older is on its way)
+	std::vector<uint8_t> &fl_row = later ? p->next_flags : p->flags;
+	std::vector<float> &g_row = later ? p->next_gain : p->gain;
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
 		uint8_t fl = 0;
 		if (f->inputs[i]) fl |= MI_MIX_LINKED;
 		if (s->channels[i].active) fl |= MI_MIX_ACTIVE;
 		if (f->outputs[i] && s->channels[i].output_enabled) fl |= MI_MIX_OUTPUT;
-		p->flags[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = fl;
-		p->gain[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = s->channels[i].gain;
+		fl_row[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = fl;
+		g_row[(size_t)s->slot * MIXER_MAX_CHANNELS + i] = s->channels[i].gain;
 	}
-	p->ctl_dirty = true;
+	if (later) {
+		p->next_set[(size_t)s->slot] = 1;
+		p->next_any = true;
+	} else {
+		p->next_set[(size_t)s->slot] = 0; // (an attach supersedes what a method left waiting)
+		p->ctl_dirty = true;
+	}
 }
 void mixer_prepare(MSFilter *f);
 void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
@@ -286,6 +323,7 @@ void MixerPool::emit(MSFilter *f, int slot) {
 	if (!ready[(size_t)slot]) return;
 	ready[(size_t)slot] = 0;
 	const int16_t *base = h_out + (size_t)slot * MIXER_MAX_CHANNELS * ns;
+
 	if (s->conf_mode == 0) { // one block shared by every enabled output (:321-334)
 		mblk_t *om = NULL;
 		for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
@@ -420,7 +458,7 @@ int mixer_set_input_gain(MSFilter *f, void *data) { // audiomixer.c:372-382
 	if (!mixer_pin_ok("mixer_set_input_gain", ctl->pin)) return -1;
 	HubLock lk(f);
 	s->channels[ctl->pin].gain = ctl->param.gain;
-	mixer_push_controls(f, s);
+	mixer_push_controls(f, s, true);
 	return 0;
 }
 int mixer_set_active(MSFilter *f, void *data) { // :384-393
@@ -429,7 +467,7 @@ int mixer_set_active(MSFilter *f, void *data) { // :384-393
 	if (!mixer_pin_ok("mixer_set_active_gain", ctl->pin)) return -1;
 	HubLock lk(f);
 	s->channels[ctl->pin].active = (bool_t)ctl->param.active;
-	mixer_push_controls(f, s);
+	mixer_push_controls(f, s, true);
 	return 0;
 }
 int mixer_enable_output(MSFilter *f, void *data) { // :395-408
@@ -440,7 +478,7 @@ int mixer_enable_output(MSFilter *f, void *data) { // :395-408
 	ms_filter_lock(f);
 	s->channels[ctl->pin].output_enabled = (bool_t)ctl->param.enabled;
 	s->single_output = has_single_output(f, s);
-	mixer_push_controls(f, s);
+	mixer_push_controls(f, s, true);
 	ms_filter_unlock(f);
 	return 0;
 }

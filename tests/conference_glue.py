@@ -432,6 +432,9 @@ def rms(x, t0, t1):
     return float(np.sqrt(np.mean(x[t0 * ns:t1 * ns].astype(np.float64) ** 2)))
 
 
+SKIP_AROUND_METHODS = False   # (up to round 4 the blocks around a mute were left out: the two forms applied a method a tick apart)
+
+
 def verdict(fused, plain):
     """what the tests assert on (fused run against the facades one by one), as plain data"""
     ns = RATE // 100
@@ -448,7 +451,7 @@ def verdict(fused, plain):
         n = min(len(x), len(y))
         skip = np.zeros(n, bool)
         for t in EVENT_TICKS[c]:
-            skip[max(0, (t - 3) * ns):(t + 1) * ns] = True
+            skip[max(0, (t - 3) * ns):(t + 1) * ns] = SKIP_AROUND_METHODS
         if len(x) != len(y) or ((x[:n] != y[:n]) & ~skip).any():
             bad.append(name)
         sx, sy = fused["spk"][name], plain["spk"][name]
@@ -467,7 +470,7 @@ def verdict(fused, plain):
         skip = np.zeros(n, bool)
         for t in EVENT_TICKS[c]:
             if t not in REPLUMBED[c]:
-                skip[max(0, (t - 3) * ns):(t + 1) * ns] = True
+                skip[max(0, (t - 3) * ns):(t + 1) * ns] = SKIP_AROUND_METHODS
         if len(x) != len(y) or ((x[:n] != y[:n]) & ~skip).any():
             d = np.flatnonzero((x[:n] != y[:n]) & ~skip)
             bad.append((name, len(x), len(y), int(d[0]) // ns if len(d) else -1, int(len(d))))

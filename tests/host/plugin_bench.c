@@ -63,6 +63,8 @@ typedef struct {
 	double slowest_ms;
 	int slowest_tick, prof_n, prof_ids[16], max_id;
 	uint64_t prof_ns[16], max_ns;
+	int tot_ids[16];        /* MS2SHIM_PROFILE=1: every timed step's process() time by filter id, summed */
+	uint64_t tot_ns[16];
 	int *nvcsw, *nivcsw, *minflt;        /* per tick: voluntary / involuntary context switches, minor page faults of the thread */
 } TickerJob;
 
@@ -224,10 +226,23 @@ static void *run(void *arg) {
 		uint64_t tasks_ns = 0;
 		ms2shim_ticker_last_step(j->ticker, &tasks_ns, NULL);
 		j->task_ms[t] = (double)tasks_ns * 1e-6;
-		if (g_profile && j->step_ms[t] > j->slowest_ms) { /* MS2SHIM_PROFILE=1: where this thread's slowest step went, by filter id */
-			j->slowest_ms = j->step_ms[t];
-			j->slowest_tick = t;
-			j->prof_n = ms2shim_ticker_profile(j->ticker, j->prof_ids, j->prof_ns, 16, &j->max_id, &j->max_ns);
+		if (g_profile) {
+			int ids[16], mid = 0;
+			uint64_t ns[16], mns = 0;
+			const int n = ms2shim_ticker_profile(j->ticker, ids, ns, 16, &mid, &mns);
+			for (int k = 0; k < n; ++k)
+				for (int q = 0; q < 16; ++q)
+					if (j->tot_ids[q] == ids[k] || j->tot_ids[q] == 0) {
+						j->tot_ids[q] = ids[k];
+						j->tot_ns[q] += ns[k];
+						break;
+					}
+			if (j->step_ms[t] > j->slowest_ms) { /* ... and where this thread's slowest step went */
+				j->slowest_ms = j->step_ms[t];
+				j->slowest_tick = t;
+				j->prof_n = n, j->max_id = mid, j->max_ns = mns;
+				memcpy(j->prof_ids, ids, sizeof(ids)), memcpy(j->prof_ns, ns, sizeof(ns));
+			}
 		}
 	}
 	pthread_barrier_wait(&g_bar);
@@ -412,6 +427,23 @@ int main(int argc, char **argv) {
 		for (int k = 0; k < jobs[bi].prof_n; ++k) fprintf(stderr, " %d=%.3fms", jobs[bi].prof_ids[k], (double)jobs[bi].prof_ns[k] * 1e-6);
 		fprintf(stderr, "\n");
 	}
+	/* MS2SHIM_PROFILE=1: the graph walk by filter id, us per leg and tick over all tickers and timed steps (9001 / 9002: the test
+	 * runtime's sources / sinks -- the HARNESS's share; the rest are the plugin's facades; the timer itself costs ~0.05 us per call) */
+	char byid[512] = "";
+	if (g_profile) {
+		int ids[16] = {0}, bo = 0;
+		double us[16] = {0};
+		for (int i = 0; i < g_tickers; ++i)
+			for (int q = 0; q < 16 && jobs[i].tot_ids[q]; ++q)
+				for (int k = 0; k < 16; ++k)
+					if (ids[k] == jobs[i].tot_ids[q] || ids[k] == 0) {
+						ids[k] = jobs[i].tot_ids[q];
+						us[k] += (double)jobs[i].tot_ns[q] * 1e-3;
+						break;
+					}
+		for (int k = 0; k < 16 && ids[k]; ++k)
+			bo += snprintf(byid + bo, sizeof(byid) - (size_t)bo, "%s\"%d\": %.4f", k ? ", " : "", ids[k], us[k] / ((double)g_ticks * legs));
+	}
 	/* PLUGIN_BENCH_CHECKSUM=1: the whole run's output as two numbers -- every leg's mix and speaker audio, byte for byte and in
 	 * order, folded per sink (FNV-1a) and summed over the legs: equal between two runs iff (to 2^-64) every leg heard the same */
 	unsigned long long mix_sum = 0, spk_sum = 0, out_bytes = 0;
@@ -431,14 +463,14 @@ int main(int argc, char **argv) {
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
 	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
 	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s], "
-	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu}\n",
+	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}}\n",
 	       g_paced ? "true" : "false", legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
 	       worst_t, worst_i, jobs[worst_i].step_ms[worst_t], jobs[worst_i].task_ms[worst_t], pct(sorted, g_ticks, 0.999), wall_ms / g_ticks,
 	       max_backlog, ref_late_events, sum_cpu / ((double)g_ticks * g_tickers), (double)sum_flt / ((double)g_ticks * g_tickers),
-	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes);
+	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid);
 	fflush(stdout);
 	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
 	if (getenv("PLUGIN_BENCH_CLEAN_EXIT")) exit(0); /* (under rocprofv3: its summary is written by an exit handler) */
