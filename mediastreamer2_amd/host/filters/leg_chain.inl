@@ -82,6 +82,21 @@ void mix_slab_release(void *payload) { // db_freefn of the slab's data block (th
 	if (s->state.exchange(0, std::memory_order_acq_rel) == 2) mi_host_free(nullptr, s);
 }
 
+// MSSpeexEC's speaker-pin frames of one flush (one frame per microphone frame, speexec.c:261-284): cut from ONE host buffer per
+// bank and flush -- esballoc for the buffer, a dupb per frame pointing at its piece -- instead of an allocb per frame (two
+// allocations and a memset each, ~2 per leg and tick).  Plain host memory: the device never sees it.
+struct SpkSlab {
+	std::atomic<int> state{0}; // 0 free, 1 a data block is alive on it, 2 its bank is gone (freed when the block goes)
+	size_t bytes = 0, used = 0;
+	uint8_t *payload() { return reinterpret_cast<uint8_t *>(this) + 64; }
+	static SpkSlab *of(void *payload) { return reinterpret_cast<SpkSlab *>(static_cast<uint8_t *>(payload) - 64); }
+};
+static_assert(sizeof(SpkSlab) <= 64, "slab header");
+void spk_slab_release(void *payload) {
+	SpkSlab *s = SpkSlab::of(payload);
+	if (s->state.exchange(0, std::memory_order_acq_rel) == 2) free(s);
+}
+
 int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t now); // mixer.inl
 void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes, bool immediate);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
@@ -154,6 +169,9 @@ struct LegBank : Pool {
 	}
 	uint64_t launches = 0;
 	std::vector<std::pair<MSQueue *, mblk_t *>> spk; // speaker-pin frames of this flush (MSSpeexEC pin 0: host audio), handed on in finish()
+	std::vector<SpkSlab *> spk_slabs;                // ... cut from one of these (a ring: a slab returns when its last frame is freed downstream)
+	SpkSlab *spk_cur = nullptr;
+	mblk_t *spk_root = nullptr;
 	int walked = 0;                                  // conferences whose mixer has run in this tick's graph walk
 	bool early = false, early_any = false;           // this tick's work was enqueued at the end of the walk (leg_conf_walked)
 	bool no_early = false;
@@ -257,6 +275,9 @@ struct LegBank : Pool {
 	~LegBank() override {
 		if (root) freeb(root);
 		for (auto &qm : spk) freemsg(qm.second);
+		if (spk_root) freeb(spk_root);
+		for (SpkSlab *s : spk_slabs)
+			if (s->state.exchange(2, std::memory_order_acq_rel) == 0) free(s);
 		for (FusedLeg *l : legs) delete l;
 		if (hub->ctx) mi_ctx_sync(hub->ctx);
 		if (mix) mi_mixer_destroy(mix);
@@ -269,6 +290,42 @@ struct LegBank : Pool {
 		if (rs) mi_resampler_destroy(rs);
 		for (MixSlab *s : slabs) // a slab whose blocks are still held downstream outlives the bank: its last block frees it
 			if (s->state.exchange(2, std::memory_order_acq_rel) == 0) mi_host_free(hub->ctx, s);
+	}
+	// a frame of `nbytes` for the speaker pin: a piece of this flush's slab (NULL: no slab to be had, the caller allocates)
+	mblk_t *spk_frame(size_t nbytes) {
+		static const bool off = getenv("MSMI355X_NO_SPK_SLAB") != nullptr; // A/B switch
+		if (off) return nullptr;
+		if (!spk_cur) {
+			for (SpkSlab *s : spk_slabs)
+				if (s->state.load(std::memory_order_acquire) == 0) {
+					spk_cur = s;
+					break;
+				}
+			if (!spk_cur && spk_slabs.size() < 6) {
+				const size_t bytes = (size_t)nlegs * kMaxRounds * 2 * (size_t)F * 2; // every leg's frames of a burst of kMaxRounds blocks
+				void *p = malloc(64 + bytes);
+				if (p) {
+					spk_cur = new (p) SpkSlab();
+					spk_cur->bytes = bytes;
+					spk_slabs.push_back(spk_cur);
+				}
+			}
+			if (!spk_cur) return nullptr;
+			spk_cur->used = 0;
+			spk_cur->state.store(1, std::memory_order_release);
+			spk_root = esballoc(spk_cur->payload(), spk_cur->bytes, 0, spk_slab_release);
+		}
+		if (spk_cur->used + nbytes > spk_cur->bytes) return nullptr;
+		mblk_t *m = dupb(spk_root);
+		m->b_rptr = spk_cur->payload() + spk_cur->used;
+		m->b_wptr = m->b_rptr + nbytes;
+		spk_cur->used += nbytes;
+		return m;
+	}
+	void spk_flush_done() { // the flush's own reference: the slab returns to the ring when the last frame downstream is freed
+		if (spk_root) freeb(spk_root);
+		spk_root = nullptr;
+		spk_cur = nullptr;
 	}
 	MixSlab *free_slab() {
 		for (MixSlab *s : slabs)
@@ -704,6 +761,7 @@ struct LegBank : Pool {
 			for (auto &qm : spk) ms_queue_put(qm.first, qm.second);
 			spk.clear();
 		}
+		if (spk.empty()) spk_flush_done();
 		if (failed) {
 			std::fill(conf_ready.begin(), conf_ready.end(), 0);
 			g_late_events.fetch_add(1, std::memory_order_relaxed);
@@ -811,17 +869,23 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 		else if (immediate) ms_queue_put(f->outputs[0], m); // (inside MSSpeexEC's process())
 		else b->spk.push_back({f->outputs[0], m});          // (handed on with the flush's results, see LegBank::finish)
 	};
+	auto frame = [&](bool zeroed) { // (from the flush's slab; a bank that has none to give allocates as before)
+		mblk_t *m = b->spk_frame(nbytes);
+		if (!m) return ec_block(nbytes);
+		if (zeroed) memset(m->b_rptr, 0, nbytes);
+		return m;
+	};
 	if (leg->dref_level < s->nominal_ref_samples + fs) {
 		leg->inject += fs; // behind everything the far end delivered so far (ms_bufferizer_put(&s->delayed_ref, silence))
 		leg->dref_level += fs;
-		hand_on(ec_block(nbytes));
+		hand_on(frame(true));
 		if (!s->using_zeroes) ms_warning("Not enough ref samples, using zeroes");
 		s->using_zeroes = TRUE;
 		return;
 	}
 	if (s->using_zeroes) ms_message("Samples are back.");
 	s->using_zeroes = FALSE;
-	mblk_t *m = ec_block(nbytes);
+	mblk_t *m = frame(false);
 	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) {
 		ms_error("mi355x echo canceller: the far-end bufferizer ran dry; silence sent to the speaker");
 		memset(m->b_rptr, 0, nbytes);
@@ -878,8 +942,17 @@ void leg_far_walked(LegBank *b, FusedLeg *leg) {
 void leg_stage_mic(MSFilter *f, ResampleData *d) {
 	FusedLeg *leg = d->leg;
 	LegBank *b = leg->bank;
-	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	const size_t nbytes = (size_t)b->in_len * 2;
+	// the usual case -- nothing held back, one whole 10 ms block on the queue -- goes from the block to its row in one copy
+	while (ms_bufferizer_get_avail(d->bz) == 0 && leg->staged_mic < kMaxRounds) {
+		mblk_t *m = peekq(&f->inputs[0]->q);
+		if (!m || m->b_cont || (size_t)(m->b_wptr - m->b_rptr) != nbytes) break;
+		getq(&f->inputs[0]->q);
+		memcpy(b->h_mic + ((size_t)leg->staged_mic * b->nlegs + (size_t)leg->slot) * b->in_len, m->b_rptr, nbytes);
+		freemsg(m);
+		leg->staged_mic++;
+	}
+	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	while (ms_bufferizer_get_avail(d->bz) >= nbytes && leg->staged_mic < kMaxRounds) { // (more than kMaxRounds blocks: the rest next tick)
 		ms_bufferizer_read(d->bz, (uint8_t *)(b->h_mic + ((size_t)leg->staged_mic * b->nlegs + (size_t)leg->slot) * b->in_len), nbytes);
 		leg->staged_mic++;
