@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--paced-ticks", type=int, default=3000, help="ticks of the series run at the 10 ms cadence of an MSTicker, one per 10 ms of wall time: part of `value`'s criterion (0 = skip)")
     ap.add_argument("--accept-seconds", type=float, default=200.0, help="wall time the step-downs of the acceptance series may take before the next count is chosen with room for the largest machine event seen on this hardware (1.8 ms)")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the rate of full call legs through the drop-in plugin (tests/host/plugin_bench)")
-    ap.add_argument("--plugin-legs", type=int, default=32768, help="full call legs the plugin path is first tried with (config[3]: 1024 conferences x 32)")
+    ap.add_argument("--plugin-legs", type=int, default=49152, help="full call legs the plugin path is first tried with (config[3] is 32 768: 1024 conferences x 32)")
     ap.add_argument("--no-video-host", action="store_true", help="skip the PCIe-inclusive video probe (config 5)")
     ap.add_argument("--roofline-ticks", type=int, default=32, help="eager ticks with HIP events around the canceller's launch")
     ap.add_argument("--from-reset", action="store_true", help="measure cancellers that start from reset instead of steady state")
@@ -939,9 +939,18 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
     """How many FULL call legs a mediastreamer2-shaped process carries through the DROP-IN PLUGIN (never part of `value`):
     tests/host/plugin_bench builds N legs of  source -> MSResample 16k->48k -> MSSpeexEC (128 ms) -> MSVolume (AGC) ->
     MSAudioMixer (conferences of 32)  from the factory's ids after libmsmi355xfilters_init (audiostream.c:1798-1810 in
-    front of a conference mixer), spread over T ticker threads of the test runtime (one thread per MSTicker, as the
-    reference runs them; T = the cores this process is granted), all tickers ticking together.  A tick costs what the
-    slowest ticker needs.  The first count is config[3]'s 1024 x 32; if a tick is late the count steps down until none is."""
+    front of a conference mixer) on T ticker threads of the test runtime (one thread per MSTicker, as the reference runs
+    them; T = the cores this process is granted, at most 16), every ticker PACED at one tick per 10 ms of wall time.
+
+    The rules, all of them:
+      * a run = `warmup` paced ticks from the attach on (reported apart as from_attach: a start-up stall is visible, not folded
+        into capacity), then `ticks` (1000) paced ticks; a tick costs what the slowest ticker needs;
+      * a count FITS when no tick of the run reaches 10 ms (ticks_over_10ms == 0) and no ticker ever started a step a whole
+        interval late (max_backlog_ms < 10, msticker_late_events == 0).  Strict: p99 is reported, not the criterion;
+      * every count is measured the same way whether the search comes from below or from above: one run, and a second one if
+        the first did not fit (the host's CPUs are shared; both runs are listed) -- it fits if either did;
+      * the search starts at `first_legs`, steps of 8192 legs (16 conferences of 32 per ticker): up while the count fits (to
+        98 304 at most), else down until one fits; `legs` is the largest count that fit."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
     plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
@@ -949,96 +958,96 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host"), "plugin_bench"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     ncores, quota = _host_cores()
     tickers = max(1, min(16, ncores))
+    keep = ("paced", "legs", "tickers", "ticks", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "msticker_late_events", "fits",
+            "us_per_leg_tick", "ticker_flush_ms", "ticker_graph_walk_ms", "launches_per_tick_and_ticker", "flush_rounds_per_tick_and_ticker",
+            "fused_legs", "late_events", "worst_tick", "slow_ticks", "from_attach")
 
-    def run(legs, nt, extra_env=None):
+    def run(legs, nt, extra_env=None, paced=True):
         env = dict(os.environ)
         env.pop("MSMI355X_NO_FUSE", None)
+        if paced:
+            env["PLUGIN_BENCH_PACED"] = "1"  # every ticker fires at t0 + k x 10 ms of wall time, as an MSTicker does (msticker.c:419-443)
         env.update(extra_env or {})
         r = subprocess.run([exe, plugin, str(legs), str(tickers), str(nt), str(warmup)], capture_output=True, text=True, timeout=600, env=env)
         if r.returncode != 0 or not r.stdout.strip():
             raise RuntimeError(f"plugin_bench exit {r.returncode}: {r.stderr[-300:]}")
         d = json.loads(r.stdout.strip().splitlines()[-1])
-        # sustained: the median and the 99th percentile tick inside the interval and the ticker never more than one interval
-        # behind (an MSTicker catches a long tick up with the short ones after it and reports a late event only beyond five
-        # intervals, msticker.c:419-443,496-515); `ticks_over_10ms` counts the strict reading beside it
-        d["fits"] = bool(d["p99_ms"] < 10.0 and d["max_backlog_ms"] < 10.0 and d["msticker_late_events"] == 0)
         d["ticks_over_10ms"] = d["late"]
+        d["fits"] = bool(d["late"] == 0 and d["max_backlog_ms"] < 10.0 and d["msticker_late_events"] == 0)
         return d
 
-    keep = ("paced", "legs", "tickers", "ticks", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "msticker_late_events", "fits",
-            "us_per_leg_tick", "ticker_flush_ms", "ticker_graph_walk_ms", "launches_per_tick_and_ticker", "flush_rounds_per_tick_and_ticker",
-            "fused_legs", "late_events", "worst_tick", "slow_ticks")
-    tried, best, legs = [], None, first_legs
-    step = tickers * 32
-    paced_env = {"PLUGIN_BENCH_PACED": "1"}  # every ticker fires at t0 + k x 10 ms of wall time, as an MSTicker does (msticker.c:419-443)
-    for _ in range(5):
-        d = run(legs, ticks, paced_env)
-        if log:
-            log({"plugin_path": {k: d[k] for k in keep}})
-        tried.append({k: d[k] for k in keep})
-        if not d["fits"]:  # the host's CPUs are shared with other tenants: a count gets a second run before it is given up (both are listed)
-            d = run(legs, ticks, paced_env)
+    tried = []
+
+    def measure(legs):
+        """one count by the rule: a run, and a second one if the first did not fit"""
+        best = None
+        for _ in range(2):
+            d = run(legs, ticks)
+            tried.append({k: d.get(k) for k in keep})
             if log:
-                log({"plugin_path": {k: d[k] for k in keep}})
-            tried.append({k: d[k] for k in keep})
-        if d["fits"]:
-            best = d
-            break
-        legs = max(step, int(legs * 0.75) // step * step)  # (three quarters: on a noisy host the long ticks say little about where the limit is)
-    if best is not None and best["legs"] == first_legs:  # config[3]'s count fits: how far does it go?  (a quarter more, up to three times)
-        for _ in range(3):
-            up = int(best["legs"] * 1.25) // step * step
-            try:
-                d = run(up, min(ticks, 600), paced_env)
-            except Exception:
+                log({"plugin_path": {k: d.get(k) for k in keep if k != "slow_ticks"}})
+            best = d if best is None or d["fits"] else best
+            if d["fits"]:
                 break
-            if log:
-                log({"plugin_path": {k: d[k] for k in keep}})
-            tried.append({k: d[k] for k in keep})
+        return best
+
+    step = max(tickers * 32, 8192 // (tickers * 32) * (tickers * 32))
+    legs = max(step, first_legs // step * step)
+    best, d = None, measure(legs)
+    if d["fits"]:
+        best = d
+        while legs + step <= 98304:
+            d = measure(legs + step)
             if not d["fits"]:
                 break
-            best = d
-    out = {"cadence": "paced: one tick per 10 ms of wall time on every ticker, as deployed (the launches leave at the end of a walk, the device works "
-                      "through the idle part of the interval); `back_to_back` = config[3]'s count with every tick fired as soon as the slowest ticker is "
-                      "done (the device never idle: a throughput figure, each tick waits for the previous one's launches)",
+            best, legs = d, legs + step
+    else:
+        while legs > step:
+            legs -= step
+            d = measure(legs)
+            if d["fits"]:
+                best = d
+                break
+    out = {"cadence": "paced: one tick per 10 ms of wall time on every ticker, warm-up included",
            "what": "full call legs through the drop-in plugin, PCIe included: source -> MSResample 16k->48k -> MSSpeexEC (128 ms tail) -> MSVolume (AGC) "
                    "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
                    "libmsmi355xfilters_init, one ticker thread per MSTicker in the test runtime (tests/host/plugin_bench.c); the plugin runs each "
                    "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl)",
+           "fits_definition": "no tick of 1000 paced ticks reaches 10 ms, no step starts a whole interval late; see the function's docstring",
            "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
-    if best is not None:
-        out.update({"legs": best["legs"], "tickers": best["tickers"], "p50_ms": best["p50_ms"], "p99_ms": best["p99_ms"], "p99_9_ms": best["p99_9_ms"],
-                    "max_ms": best["max_ms"], "ticks_over_10ms": best["ticks_over_10ms"], "max_backlog_ms": best["max_backlog_ms"],
-                    "msticker_late_events": best["msticker_late_events"],
-                    "fits_definition": "p99 step < 10 ms and no ticker ever a whole interval behind its schedule (max_backlog_ms: measured -- how late a step "
-                                       "started; a long step is caught up by the short ones after it, as an MSTicker does: msticker.c:419-443); "
-                                       "ticks_over_10ms is the strict count beside it.  slow_ticks lists the five "
-                                       "longest with the slowest thread's CPU time, context switches and page faults: cpu_ms well below ms with involuntary "
-                                       "switches = the thread was pushed off its core (the host's 256 CPUs are shared); the ~13 ms steps that one "
-                                       "hipMemcpyAsync caused (cpu_ms = ms, ~4 100 page faults) are gone with the runtime copies (DESIGN 6.3)",
-                    "slow_ticks": best.get("slow_ticks"),
-                    "us_per_leg_tick": best["us_per_leg_tick"], "launches_per_tick": best["launches_per_tick_and_ticker"],
-                    "syncs_per_tick": best["flush_rounds_per_tick_and_ticker"], "fits": True,
-                    "where_the_time_goes": {"per_ticker_mean_ms": {"plugin_flush": best["ticker_flush_ms"], "graph_walk": best["ticker_graph_walk_ms"]},
-                                            "note": "plugin_flush = the postponed task at the start of a tick: results of the launches enqueued at the end of the "
-                                                    "previous graph walk are waited for and handed on (one wait per ticker); graph_walk = every filter's process(): "
-                                                    "sources, staging into pinned rows, MSSpeexEC's speaker pin, sinks, then the bank's uploads and launches; the tick "
-                                                    "is the slowest of the ticker threads, all ticking together"}})
-    else:
+    if best is None:
         out.update({"fits": False, "legs": 0})
-    try:  # config[3]'s count fired back to back, whatever the paced verdict on this host was
-        b = run(first_legs, 600)
-        out["back_to_back"] = {k: b[k] for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "ticker_flush_ms",
+        return out
+    out.update({k: best[k] for k in ("legs", "tickers", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "msticker_late_events",
+                                      "slow_ticks", "us_per_leg_tick", "from_attach")})
+    out.update({"launches_per_tick": best["launches_per_tick_and_ticker"], "syncs_per_tick": best["flush_rounds_per_tick_and_ticker"], "fits": True,
+                "where_the_time_goes": {"per_ticker_mean_ms": {"plugin_flush": best["ticker_flush_ms"], "graph_walk": best["ticker_graph_walk_ms"]}}})
+    # what a host core carries: the ticker threads' mean busy time per tick against the 10 ms interval
+    busy = best["ticker_flush_ms"] + best["ticker_graph_walk_ms"]
+    out["legs_per_host_core"] = int(best["legs"] / tickers * 10.0 / max(busy, 1e-3))          # a core kept busy the whole interval
+    out["legs_per_host_core_at_this_load"] = int(best["legs"] / tickers)
+    try:  # the walk by filter id (MS2SHIM_PROFILE: a timer around every process()): the plugin's facades vs the test runtime's sources and sinks
+        pr = run(best["legs"], 300, {"MS2SHIM_PROFILE": "1"})
+        by = pr.get("walk_us_per_leg_tick_by_filter_id", {})
+        harness = sum(v for k, v in by.items() if k in ("9001", "9002"))
+        out["walk_split_us_per_leg_tick"] = {"plugin_facades": round(sum(by.values()) - harness, 4), "harness_sources_and_sinks": round(harness, 4),
+                                             "plugin_flush": round(pr["ticker_flush_ms"] * 1e3 * tickers / pr["legs"], 4), "by_filter_id": by,
+                                             "ids": "41 MSResample, 28 MSSpeexEC, 43 MSVolume, 68 MSAudioMixer (+ the bank's enqueue), 9001 / 9002 the test runtime's sources / sinks"}
+    except Exception as e:
+        out["walk_split_us_per_leg_tick"] = {"error": str(e)[:200]}
+    try:  # config[3]'s count fired back to back (every tick as soon as the slowest ticker is done: a throughput figure)
+        b = run(32768, 600, paced=False)
+        out["back_to_back"] = {k: b[k] for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "ticker_flush_ms",
                                                   "ticker_graph_walk_ms", "us_per_leg_tick", "slow_ticks")}
     except Exception as e:
         out["back_to_back"] = {"error": str(e)[:200]}
     try:  # the same graph with every facade on its own bank (MSMI355X_NO_FUSE=1: four uploads, launches and waits per chain), for scale
-        d = run(4096, 200, {"MSMI355X_NO_FUSE": "1"})
+        d = run(4096, 200, {"MSMI355X_NO_FUSE": "1"}, paced=False)
         out["facades_one_by_one_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
-        d = run(4096, 200)
+        d = run(4096, 200, paced=False)
         out["fused_4096_legs"] = {k: d[k] for k in ("legs", "tickers", "p50_ms", "max_ms", "us_per_leg_tick", "flush_rounds_per_tick_and_ticker")}
         # ... and that the two are the same audio: every leg's mix and speaker frames of a whole run folded into one number each
-        a_, b_ = run(4096, 200, {"PLUGIN_BENCH_CHECKSUM": "1"}), run(4096, 200, {"PLUGIN_BENCH_CHECKSUM": "1", "MSMI355X_NO_FUSE": "1"})
+        a_, b_ = run(4096, 200, {"PLUGIN_BENCH_CHECKSUM": "1"}, paced=False), run(4096, 200, {"PLUGIN_BENCH_CHECKSUM": "1", "MSMI355X_NO_FUSE": "1"}, paced=False)
         out["fused_equals_one_by_one_4096_legs"] = {"equal": a_["mix_checksum"] == b_["mix_checksum"] and a_["speaker_checksum"] == b_["speaker_checksum"],
                                                     "mix_checksum": [a_["mix_checksum"], b_["mix_checksum"]], "mix_bytes": a_["mix_bytes"],
                                                     "what": "FNV-1a over every leg's mix (and speaker audio) of 240 ticks, byte for byte and in order, summed over the legs"}
@@ -1472,6 +1481,11 @@ def short_line(full, detail_name):
         eq = pp.get("fused_equals_one_by_one_4096_legs")
         if eq:
             out["plugin_path"]["fused_equals_one_by_one"] = eq.get("equal")
+        if isinstance(pp.get("from_attach"), dict):
+            out["plugin_path"]["from_attach"] = _pick(pp["from_attach"], "ticks", "p50_ms", "max_ms", "ticks_over_10ms")
+        if isinstance(pp.get("walk_split_us_per_leg_tick"), dict):
+            out["plugin_path"]["walk_split_us"] = _pick(pp["walk_split_us_per_leg_tick"], "plugin_facades", "harness_sources_and_sinks", "plugin_flush")
+        out["plugin_path"]["rejected_counts"] = sorted({t["legs"] for t in pp.get("tried", []) if not t.get("fits")})
     for key in ("plugin_path_server",):
         if full.get(key):
             out[key] = _pick(full[key], "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
@@ -1922,6 +1936,9 @@ def main():
         if not a.no_plugin_path:
             try:
                 line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)
+                pp = line["plugin_path"]
+                if pp.get("legs"):  # the ticker threads (one core each) it would take to bring `value` legs through the boundary at this load per core
+                    pp["host_cores_for_value"] = int(-(-line["value"] // max(1, pp["legs"] // pp["tickers"])))
             except Exception as e:
                 line["plugin_path"] = {"error": str(e)[:300]}
         if not a.no_cpu_baseline:

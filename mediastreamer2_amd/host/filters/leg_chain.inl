@@ -46,11 +46,28 @@ constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one 
 constexpr int kLegMeterRounds = 8; // rounds before the last of a flush whose meter state is read back (kLegLightRounds, kLegMaxChunks fit)
 constexpr int kLegMaxChunks = 5; // 10 ms chunks MSVolume can complete in one flush of a leg without a mixer (kMaxRounds blocks of 10 ms + what it held)
 
+// The walk of a ticker with thousands of legs touches a few KB of scattered host memory per leg (filters, queues, blocks, the
+// facades' states) -- tens of MB per ticker, far more than a core's caches hold from one tick to the next: the walk is a chain
+// of cache misses.  A leg's facades therefore ask for the NEXT leg's lines while they work on their own (legs are walked in the
+// order they were attached, which is the order of their slots).  MSMI355X_NO_PREFETCH=1: off (A/B).
+inline bool leg_prefetch_on() {
+	static const bool on = getenv("MSMI355X_NO_PREFETCH") == nullptr;
+	return on;
+}
+inline void pf(const void *p) {
+	if (p) __builtin_prefetch(p, 0, 1);
+}
+inline void pf2(const void *p, size_t bytes) { // a struct or row of `bytes`
+	if (!p) return;
+	for (size_t o = 0; o < bytes; o += 64) __builtin_prefetch(static_cast<const char *>(p) + o, 0, 1);
+}
+
 struct LegBank;
 struct FusedLeg {
 	LegBank *bank;
 	int slot, pin;
 	MSFilter *rs, *ec, *vol, *mixer;
+	void *rs_data = nullptr, *ec_data = nullptr, *vol_data = nullptr; // the facades' states (f->data), known here so that a prefetch needs no cold load
 	int staged_mic = 0;  // 10 ms blocks staged since the last flush (launch rounds)
 	int framed_mic = 0;  // ... of which the framing below has already counted (a leg headed by MSSpeexEC frames as it stages)
 	int pre_frames = 0;  // frames that framing found since the last flush
@@ -639,8 +656,15 @@ struct LegBank : Pool {
 		// ---- the host's half: framing decisions leg by leg
 		int rounds = 0, light_rounds = 0;
 		bool any_ref = false, any_refx = false, any_inj = false;
+		const bool pfon = leg_prefetch_on();
 		for (size_t s = 0; s < UL; ++s) {
 			FusedLeg *leg = legs[s];
+			if (pfon) { // two legs ahead: the leg; one ahead: its canceller's state (the far end's queue for the speaker frames) and first block
+				if (s + 2 < UL) pf2(legs[s + 2], sizeof(FusedLeg));
+				if (s + 1 < UL && legs[s + 1]) {
+					pf2(legs[s + 1]->ec_data, sizeof(SpeexECState));
+				}
+			}
 			h_cnt[s] = h_cnt[L + s] = h_cnt[2 * L + s] = 0;
 			if (light && !plain && !leg)
 				for (int r = 0; r < kLegLightRounds; ++r) h_fcnt[(size_t)r * L + s] = 0;
@@ -768,8 +792,11 @@ struct LegBank : Pool {
 			return;
 		}
 		if (mixed) {
+			const bool pfon = leg_prefetch_on();
 			for (size_t s = 0; s < UL; ++s) {
 				FusedLeg *leg = legs[s];
+				if (pfon && s + 2 < UL) pf2(legs[s + 2], sizeof(FusedLeg));
+				if (pfon && s + 1 < UL && legs[s + 1]) pf2(legs[s + 1]->vol_data, sizeof(VolumeData));
 				if (!leg) continue;
 				vstate[s] = h_vstate[s];
 				if (leg->metered && hub->ticker) { // update_energy's extremum records, msvolume.c:405-406: one per chunk, in order
@@ -943,6 +970,15 @@ void leg_stage_mic(MSFilter *f, ResampleData *d) {
 	FusedLeg *leg = d->leg;
 	LegBank *b = leg->bank;
 	const size_t nbytes = (size_t)b->in_len * 2;
+	if (leg_prefetch_on() && leg->slot + 1 < b->nlegs) { // the next leg's head: its filter, its state, the block waiting on its queue
+		if (const FusedLeg *nx = b->legs[(size_t)leg->slot + 1]) {
+			pf2(nx->rs, sizeof(MSFilter));
+			pf2(nx->rs_data, sizeof(ResampleData));
+			pf2(nx->ec, sizeof(MSFilter));
+			pf2(nx->ec_data, 192);
+		}
+		if (leg->slot + 2 < b->nlegs) pf2(b->legs[(size_t)leg->slot + 2], sizeof(FusedLeg));
+	}
 	// the usual case -- nothing held back, one whole 10 ms block on the queue -- goes from the block to its row in one copy
 	while (ms_bufferizer_get_avail(d->bz) == 0 && leg->staged_mic < kMaxRounds) {
 		mblk_t *m = peekq(&f->inputs[0]->q);
@@ -987,6 +1023,11 @@ void leg_take_far_end(MSFilter *f, SpeexECState *s) {
 	FusedLeg *leg = s->leg;
 	LegBank *b = leg->bank;
 	if (!f->inputs[0]) return;
+	if (leg_prefetch_on() && leg->slot + 1 < b->nlegs)
+		if (const FusedLeg *nx = b->legs[(size_t)leg->slot + 1]) {
+			pf2(static_cast<const char *>(nx->ec_data) + 192, sizeof(SpeexECState) > 192 ? sizeof(SpeexECState) - 192 : 0);
+			pf2(nx->vol, sizeof(MSFilter));
+		}
 	if (!s->echostarted) {
 		if (!ms_queue_empty(f->inputs[0])) ms_warning("Getting reference signal but no echo to synchronize on.");
 		ms_queue_flush(f->inputs[0]);
@@ -1191,6 +1232,7 @@ bool conf_try_fuse(MSFilter *mx) {
 		FusedLeg *leg = new FusedLeg();
 		leg->bank = b, leg->slot = s0 + cd.pin, leg->pin = cd.pin;
 		leg->rs = cd.rs, leg->ec = cd.ec, leg->vol = cd.vol, leg->mixer = mx;
+		leg->rs_data = cd.rs ? cd.rs->data : nullptr, leg->ec_data = cd.ec->data, leg->vol_data = cd.vol->data;
 		leg->dref_level = delay;
 		b->legs[(size_t)leg->slot] = leg;
 		SpeexECState *es = (SpeexECState *)cd.ec->data;
@@ -1366,6 +1408,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	FusedLeg *leg = new FusedLeg();
 	leg->bank = b, leg->slot = s, leg->pin = 0;
 	leg->rs = rs, leg->ec = ec, leg->vol = vol, leg->mixer = nullptr;
+	leg->rs_data = rs ? rs->data : nullptr, leg->ec_data = ec->data, leg->vol_data = vol->data;
 	leg->dref_level = delay;
 	b->legs[(size_t)s] = leg;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;

@@ -60,6 +60,7 @@ typedef struct {
 	double *step_ms, *task_ms, *cpu_ms; /* per tick: wall time of the step, of its postponed tasks, CPU time of the thread */
 	MSFilter **heads;        /* PLUGIN_BENCH_SHAPE nomixer: every leg's source, the root its graph is attached by */
 	MSFilter **outs, **spks; /* PLUGIN_BENCH_CHECKSUM=1: every leg's two sinks (mix back to the leg, speaker pin) */
+	double *warm_ms;                     /* the steps from the attach on (the warm-up): reported apart as `from_attach` */
 	double slowest_ms;
 	int slowest_tick, prof_n, prof_ids[16], max_id;
 	uint64_t prof_ns[16], max_ns;
@@ -72,6 +73,7 @@ static MSFactory *g_fac;
 static int g_members = 32, g_ticks, g_warmup, g_tickers;
 static int g_paced;            /* PLUGIN_BENCH_PACED=1: every ticker fires at t0 + k x 10 ms of wall time, as an MSTicker does */
 static volatile uint64_t g_t0; /* ... the schedule's origin (ns, CLOCK_MONOTONIC) */
+static volatile uint64_t g_w0; /* ... and the warm-up's */
 static pthread_barrier_t g_bar;
 
 static int g_profile, g_checksum;
@@ -184,6 +186,12 @@ static void *watchdog(void *arg) {
 	return NULL;
 }
 
+/* Paced: ticker k fires at origin + k x (10 ms / T) + n x 10 ms.  A server's MSTickers are created one by one with their conferences
+ * (audioconference.c:70-73) and each paces itself from its own start (msticker.c:419-443,496-515): their phases are spread over the
+ * interval, they do not all fire in the same instant.  PLUGIN_BENCH_ALIGNED=1: all at once (the worst case; every tick before round 5) */
+static int g_aligned;
+static uint64_t phase_ns(int index) { return g_aligned ? 0 : (uint64_t)index * (10000000ull / (uint64_t)g_tickers); }
+
 static void *run(void *arg) {
 	TickerJob *j = (TickerJob *)arg;
 	/* attach on the ticker's own thread: the hub's device context and its banks belong to the thread that ticks them */
@@ -191,16 +199,30 @@ static void *run(void *arg) {
 		for (int k = 0; k < j->nconf * g_members; ++k) ms_ticker_attach(j->ticker, j->heads[k]);
 	else
 		for (int c = 0; c < j->nconf; ++c) ms_ticker_attach(j->ticker, j->mixers[c]);
+	/* the steps from the attach on are timed too (a start-up stall -- fusing, banks opening, slabs, a cold device -- must be visible,
+	 * not folded into capacity): paced like the rest when PLUGIN_BENCH_PACED (a schedule of its own, origin g_w0) */
+	if (g_paced) pthread_barrier_wait(&g_bar); /* (g_w0 is set) */
 	for (int t = 0; t < g_warmup; ++t) {
-		pthread_barrier_wait(&g_bar);
+		if (!g_paced) {
+			pthread_barrier_wait(&g_bar);
+		} else {
+			const uint64_t sched = g_w0 + phase_ns(j->index) + (uint64_t)t * 10000000ull;
+			if (mono_ns() < sched) {
+				struct timespec ts = {(time_t)(sched / 1000000000ull), (long)(sched % 1000000000ull)};
+				clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &ts, NULL);
+			}
+		}
+		const double w0 = now_ms();
 		ms_ticker_step(j->ticker);
+		j->warm_ms[t] = now_ms() - w0;
 	}
+	if (g_paced) pthread_barrier_wait(&g_bar); /* (the warm-up is through on every ticker) */
 	if (g_paced) pthread_barrier_wait(&g_bar); /* (the schedule's origin is set; from here on the wall clock fires the ticks) */
 	for (int t = 0; t < g_ticks; ++t) {
 		if (!g_paced) {
 			pthread_barrier_wait(&g_bar); /* back to back: all tickers fire together as soon as the slowest is done */
 		} else { /* msticker.c:419-443,496-515: sleep until the tick's time; no sleep while behind (the late ticks are caught up) */
-			const uint64_t sched = g_t0 + (uint64_t)t * 10000000ull;
+			const uint64_t sched = g_t0 + phase_ns(j->index) + (uint64_t)t * 10000000ull;
 			uint64_t now = mono_ns();
 			if (now < sched) {
 				struct timespec ts = {(time_t)(sched / 1000000000ull), (long)(sched % 1000000000ull)};
@@ -259,6 +281,7 @@ int main(int argc, char **argv) {
 	}
 	g_profile = getenv("MS2SHIM_PROFILE") != NULL;
 	g_paced = getenv("PLUGIN_BENCH_PACED") != NULL;
+	g_aligned = getenv("PLUGIN_BENCH_ALIGNED") != NULL;
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL;
@@ -312,6 +335,7 @@ int main(int argc, char **argv) {
 		jobs[i].task_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		jobs[i].cpu_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		jobs[i].late_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
+		jobs[i].warm_ms = (double *)calloc((size_t)g_warmup + 1, sizeof(double));
 		jobs[i].nvcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
 		jobs[i].nivcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
 		jobs[i].minflt = (int *)calloc((size_t)g_ticks, sizeof(int));
@@ -333,7 +357,13 @@ int main(int argc, char **argv) {
 	int fc0 = 0, fl0 = 0, fc1 = 0, fl1 = 0;
 	unsigned long long la0 = 0, fr0 = 0, la1 = 0, fr1 = 0;
 	const double t_warm0 = now_ms();
-	for (int t = 0; t < g_warmup; ++t) pthread_barrier_wait(&g_bar);
+	if (g_paced) {
+		g_w0 = mono_ns() + 20000000ull;
+		pthread_barrier_wait(&g_bar);
+		pthread_barrier_wait(&g_bar); /* every ticker has done its warm-up steps */
+	} else {
+		for (int t = 0; t < g_warmup; ++t) pthread_barrier_wait(&g_bar);
+	}
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
 	if (g_paced) {
@@ -427,6 +457,32 @@ int main(int argc, char **argv) {
 		for (int k = 0; k < jobs[bi].prof_n; ++k) fprintf(stderr, " %d=%.3fms", jobs[bi].prof_ids[k], (double)jobs[bi].prof_ns[k] * 1e-6);
 		fprintf(stderr, "\n");
 	}
+	/* from the attach on: the warm-up's steps (the slowest ticker's per step), their five longest */
+	char fa[640];
+	{
+		double *w = (double *)calloc((size_t)g_warmup + 1, sizeof(double)), *ws = (double *)calloc((size_t)g_warmup + 1, sizeof(double));
+		int over = 0, fo = 0;
+		for (int t = 0; t < g_warmup; ++t) {
+			for (int i = 0; i < g_tickers; ++i)
+				if (jobs[i].warm_ms[t] > w[t]) w[t] = jobs[i].warm_ms[t];
+			over += w[t] >= 10.0;
+			ws[t] = w[t];
+		}
+		qsort(ws, (size_t)g_warmup, sizeof(double), cmp_d);
+		fo += snprintf(fa, sizeof(fa), "{\"ticks\": %d, \"paced\": %s, \"p50_ms\": %.3f, \"max_ms\": %.3f, \"ticks_over_10ms\": %d, \"first_ms\": [", g_warmup, g_paced ? "true" : "false",
+		               g_warmup ? pct(ws, g_warmup, 0.5) : 0.0, g_warmup ? ws[g_warmup - 1] : 0.0, over);
+		for (int t = 0; t < g_warmup && t < 8; ++t) fo += snprintf(fa + fo, sizeof(fa) - (size_t)fo, "%s%.2f", t ? ", " : "", w[t]);
+		fo += snprintf(fa + fo, sizeof(fa) - (size_t)fo, "], \"slowest\": [");
+		for (int n = 0; n < 5 && n < g_warmup; ++n) {
+			int bt = 0;
+			for (int t = 0; t < g_warmup; ++t)
+				if (w[t] > w[bt]) bt = t;
+			fo += snprintf(fa + fo, sizeof(fa) - (size_t)fo, "%s[%d, %.2f]", n ? ", " : "", bt, w[bt]);
+			w[bt] = 0;
+		}
+		snprintf(fa + fo, sizeof(fa) - (size_t)fo, "]}");
+		free(w), free(ws);
+	}
 	/* MS2SHIM_PROFILE=1: the graph walk by filter id, us per leg and tick over all tickers and timed steps (9001 / 9002: the test
 	 * runtime's sources / sinks -- the HARNESS's share; the rest are the plugin's facades; the timer itself costs ~0.05 us per call) */
 	char byid[512] = "";
@@ -455,7 +511,7 @@ int main(int argc, char **argv) {
 				out_bytes += ms2shim_sink_size(jobs[i].outs[k]);
 			}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);
-	printf("{\"paced\": %s, \"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
+	printf("{\"paced\": %s, \"phases\": \"%s\", \"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
 	       "\"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"late\": %d, \"wall_ms_per_tick\": %.4f, "
 	       "\"ticker_mean_ms\": %.4f, \"ticker_flush_ms\": %.4f, \"ticker_graph_walk_ms\": %.4f, \"us_per_leg_tick\": %.4f, "
 	       "\"fused_conferences\": %d, \"fused_legs\": %d, \"launches_per_tick\": %.2f, \"launches_per_tick_and_ticker\": %.2f, "
@@ -463,14 +519,14 @@ int main(int argc, char **argv) {
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
 	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
 	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s], "
-	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}}\n",
-	       g_paced ? "true" : "false", legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
+	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}, \"from_attach\": %s}\n",
+	       g_paced ? "true" : "false", !g_paced ? "barrier" : (g_aligned ? "aligned" : "spread"), legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
 	       worst_t, worst_i, jobs[worst_i].step_ms[worst_t], jobs[worst_i].task_ms[worst_t], pct(sorted, g_ticks, 0.999), wall_ms / g_ticks,
 	       max_backlog, ref_late_events, sum_cpu / ((double)g_ticks * g_tickers), (double)sum_flt / ((double)g_ticks * g_tickers),
-	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid);
+	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid, fa);
 	fflush(stdout);
 	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
 	if (getenv("PLUGIN_BENCH_CLEAN_EXIT")) exit(0); /* (under rocprofv3: its summary is written by an exit handler) */
