@@ -935,7 +935,7 @@ def video_host_probe(ms, ctx, seconds=2.0, batch=32, depth=3):
                     "(23.9 GB/s up + 21.2 GB/s down)"}
 
 
-def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
+def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None, shape="", step_legs=8192, max_legs=98304, extras=True):
     """How many FULL call legs a mediastreamer2-shaped process carries through the DROP-IN PLUGIN (never part of `value`):
     tests/host/plugin_bench builds N legs of  source -> MSResample 16k->48k -> MSSpeexEC (128 ms) -> MSVolume (AGC) ->
     MSAudioMixer (conferences of 32)  from the factory's ids after libmsmi355xfilters_init (audiostream.c:1798-1810 in
@@ -965,6 +965,8 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
     def run(legs, nt, extra_env=None, paced=True):
         env = dict(os.environ)
         env.pop("MSMI355X_NO_FUSE", None)
+        if shape:
+            env["PLUGIN_BENCH_SHAPE"] = shape
         if paced:
             env["PLUGIN_BENCH_PACED"] = "1"  # every ticker fires at t0 + k x 10 ms of wall time, as an MSTicker does (msticker.c:419-443)
         env.update(extra_env or {})
@@ -991,12 +993,12 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
                 break
         return best
 
-    step = max(tickers * 32, 8192 // (tickers * 32) * (tickers * 32))
+    step = max(tickers * 32, step_legs // (tickers * 32) * (tickers * 32))
     legs = max(step, first_legs // step * step)
     best, d = None, measure(legs)
     if d["fits"]:
         best = d
-        while legs + step <= 98304:
+        while legs + step <= max_legs:
             d = measure(legs + step)
             if not d["fits"]:
                 break
@@ -1026,6 +1028,8 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None):
     busy = best["ticker_flush_ms"] + best["ticker_graph_walk_ms"]
     out["legs_per_host_core"] = int(best["legs"] / tickers * 10.0 / max(busy, 1e-3))          # a core kept busy the whole interval
     out["legs_per_host_core_at_this_load"] = int(best["legs"] / tickers)
+    if not extras:
+        return out
     try:  # the walk by filter id (MS2SHIM_PROFILE: a timer around every process()): the plugin's facades vs the test runtime's sources and sinks
         pr = run(best["legs"], 300, {"MS2SHIM_PROFILE": "1"})
         by = pr.get("walk_us_per_leg_tick_by_filter_id", {})
@@ -1936,6 +1940,15 @@ def main():
         if not a.no_plugin_path:
             try:
                 line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)
+                try:  # a conference SERVER's remote members (volrecv -> mixer -> G.711 encoder, no canceller: filters/server_leg.inl)
+                    sv = plugin_path_probe(65536, log=log, shape="server", step_legs=16384, max_legs=196608, extras=False)
+                    sv["what"] = ("a conference server's REMOTE members through the plugin, PCIe included: 8 kHz source (decoder .. dtmfgen) -> MSVolume (volrecv) -> "
+                                  "in_resampler -> MSAudioMixer (conferences of 32) -> out_resampler -> MSUlawEnc -> sink (audioconference.c:121-179,209-257); metered, "
+                                  "queued, mixed and ENCODED in one batch per ticker")
+                    sv["pcie_bytes_per_leg_tick"] = 160 + 80 + 4   # PCM up, G.711 down, the block's length
+                    line["plugin_path_server"] = sv
+                except Exception as e:
+                    line["plugin_path_server"] = {"error": str(e)[:300]}
                 pp = line["plugin_path"]
                 if pp.get("legs"):  # the ticker threads (one core each) it would take to bring `value` legs through the boundary at this load per core
                     pp["host_cores_for_value"] = int(-(-line["value"] // max(1, pp["legs"] // pp["tickers"])))

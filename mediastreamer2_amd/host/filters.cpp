@@ -44,6 +44,7 @@
 
 extern "C" { // the descriptors (defined at the end of this file): the fused chain recognises its facades by them
 extern MSFilterDesc ms_mi355x_resample_desc, ms_mi355x_audio_mixer_desc, ms_mi355x_volume_desc, ms_mi355x_speex_ec_desc, ms_mi355x_webrtc_aec_name_desc;
+extern MSFilterDesc ms_mi355x_alaw_enc_desc, ms_mi355x_ulaw_enc_desc;
 }
 
 namespace {
@@ -97,6 +98,10 @@ struct Pool {
 	// the ticker's own flush -- says so here and asks parked(slot) wherever it looks at what a slot staged
 	virtual bool scoped() const { return false; }
 	bool parked(int slot) const;
+	// A method between two walks meets the NEXT walk's blocks in the reference.  Here the last walk's blocks may still be waiting
+	// for the coming flush (staged, or on their way down a chain of facades): what a method sets then waits too and goes live
+	// when that flush is through (flushed()); with nothing waiting it is live at once.
+	bool work_waiting() const;
 	TickerHub *hub = nullptr;
 	std::string key;
 	std::vector<MSFilter *> owner;
@@ -196,6 +201,7 @@ struct TickerHub {
 };
 
 mi_ctx *Pool::ctx() const { return hub->ctx; }
+bool Pool::work_waiting() const { return hub->flush_owner != nullptr && !hub->in_flush; }
 bool Pool::parked(int slot) const { return hub->scope && !(owner[(size_t)slot] && hub->scope->count(owner[(size_t)slot])); }
 void Pool::sync_stream() {
 	if (hub->ctx && mi_ctx_sync(hub->ctx) != MI_OK) failed = mi_failed("mi_ctx_sync");
@@ -475,12 +481,14 @@ bool already_ran_this_tick(MSFilter *f) {
 	return it != h.pumped.end() && it->second == f->ticker->time;
 }
 
-void deliver_fused_in_scope(TickerHub &h); // leg_chain.inl
+void deliver_fused_in_scope(TickerHub &h);  // leg_chain.inl
+void deliver_server_in_scope(TickerHub &h); // server_leg.inl
 void flush_hub(TickerHub &h) {
 	static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr; // A/B switch: one tick per facade again
 	h.in_flush = !no_chain || h.scope; // (a detaching graph's flush always runs its chain to the end: there is no next tick for it)
 	h.touched.clear();
 	h.touched_pumps.clear();
+	if (h.scope) deliver_server_in_scope(h);
 	if (h.scope) deliver_fused_in_scope(h); // fused conferences / legs of the graph: the launches already out are waited for, their results handed on
 	auto takes_part = [&](Pool *p) { return !h.scope || p->scoped(); };
 	for (int round = 0; round < 16; ++round) { // chains deeper than this finish on the next tick
@@ -615,6 +623,18 @@ void leg_release(FusedLeg *leg, bool keep_running); // the leg (and, in a confer
 bool leg_try_fuse_plain(MSFilter *rs);
 bool leg_wants_out(FusedLeg *leg);
 Pool *leg_pool(FusedLeg *leg);
+// a conference server's members as one batch (filters/server_leg.inl): what MSVolume, the mixer and the G.711 encoders need to know of it
+struct ServerLeg;
+struct ServerBank;
+struct VolumeData;
+void server_stage(MSFilter *vol, VolumeData *d);
+void server_release(ServerLeg *leg, bool keep_running);
+void server_disqualify(ServerLeg *leg);
+bool server_wants_out(ServerLeg *leg);
+Pool *server_pool(ServerLeg *leg);
+Pool *server_pool_of(ServerBank *b);
+void server_conf_walked(ServerBank *b, int c);
+void server_unfuse(MSFilter *mixer, bool keep_running);
 
 #include "filters/resample.inl"
 #include "filters/volume.inl"
@@ -624,6 +644,7 @@ Pool *leg_pool(FusedLeg *leg);
 #include "filters/leg_chain.inl"
 #include "filters/video.inl"
 #include "filters/codec.inl"
+#include "filters/server_leg.inl"
 #include "filters/flow_control.inl"
 #include "filters/generic_plc.inl"
 
@@ -676,9 +697,9 @@ MSFilterDesc ms_mi355x_alaw_dec_desc = {MS_ALAW_DEC_ID, "MSAlawDec", "ITU-G.711 
 MSFilterDesc ms_mi355x_ulaw_dec_desc = {MS_ULAW_DEC_ID, "MSUlawDec", "ITU-G.711 ulaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcmu", 1, 1,
                                         g711_dec_init_u, NULL, g711_dec_process, generic_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_alaw_enc_desc = {MS_ALAW_ENC_ID, "MSAlawEnc", "ITU-G.711 alaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcma", 1, 1,
-                                        g711_enc_init_a, NULL, g711_enc_process, generic_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_enc_init_a, NULL, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_enc_desc = {MS_ULAW_ENC_ID, "MSUlawEnc", "ITU-G.711 ulaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcmu", 1, 1,
-                                        g711_enc_init_u, NULL, g711_enc_process, generic_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_enc_init_u, NULL, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_l16_enc_desc = {MS_L16_ENC_ID, "MSL16Enc", "L16 dummy encoder (MI355X batch)", MS_FILTER_ENCODER, "L16", 1, 1,
                                        l16_enc_init, l16_enc_preprocess, l16_enc_process, generic_postprocess, map_uninit, l16_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_l16_dec_desc = {MS_L16_DEC_ID, "MSL16Dec", "L16 dummy decoder (MI355X batch)", MS_FILTER_DECODER, "L16", 1, 1,
@@ -796,6 +817,11 @@ void ms_mi355x_fused_stats(int *conferences, int *legs, unsigned long long *laun
 				nc += b->plain ? 0 : b->in_use;
 				la += b->launches;
 				for (FusedLeg *l : b->legs) nl += l != nullptr;
+			} else if (p->key.compare(0, 4, "srv:") == 0) { // a server's conferences of remote members (server_leg.inl)
+				ServerBank *b = static_cast<ServerBank *>(p);
+				nc += b->in_use;
+				la += b->launches;
+				for (ServerLeg *l : b->legs) nl += l != nullptr;
 			}
 	}
 	if (conferences) *conferences = nc;

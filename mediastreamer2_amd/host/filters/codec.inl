@@ -16,6 +16,7 @@ struct MapBlock {
 	mblk_t *meta;  // the input block when its meta data travel with the samples (decoders, L16 decoder), else NULL
 	uint32_t ts;   // timestamp the encoders stamp (alaw.c:84-85, l16.c:89-91)
 	bool set_ts;
+	mblk_t *prefix = nullptr; // G.711 encoders: codes of this packet that were already made (by a fused conference the encoder has left since)
 };
 
 struct MapPool : Pool {
@@ -106,7 +107,13 @@ struct MapPool : Pool {
 	void emit(MSFilter *f, int slot) override {
 		const size_t bpe = kMapOps[op].out_bpe;
 		for (const MapBlock &b : ready[(size_t)slot]) {
-			mblk_t *o = allocb(b.n * bpe, 0);
+			const size_t pre = b.prefix ? (size_t)(b.prefix->b_wptr - b.prefix->b_rptr) : 0;
+			mblk_t *o = allocb(pre + b.n * bpe, 0);
+			if (pre) {
+				memcpy(o->b_wptr, b.prefix->b_rptr, pre);
+				o->b_wptr += pre;
+				freemsg(b.prefix);
+			}
 			memcpy(o->b_wptr, h_out + b.off * bpe, b.n * bpe);
 			o->b_wptr += b.n * bpe;
 			if (b.meta) {
@@ -121,8 +128,10 @@ struct MapPool : Pool {
 	}
 	void drop_slot(int slot) {
 		for (auto *v : {&staged[(size_t)slot], &ready[(size_t)slot]}) {
-			for (MapBlock &b : *v)
+			for (MapBlock &b : *v) {
 				if (b.meta) freemsg(b.meta);
+				if (b.prefix) freemsg(b.prefix);
+			}
 			v->clear();
 		}
 	}
@@ -139,7 +148,14 @@ struct MapFilter { // AlawEncData alaw.c:25-30 / EncState l16.c:22-29 / AdapterS
 	size_t nbytes;      // L16 encoder packet size
 	size_t buffer_size; // channel adapter, two-input mode: bytes per tick and side
 	FlowBuf *side[2];
+	// G.711 encoders behind a conference whose members live in a ServerBank (filters/server_leg.inl): the pin's mix is encoded in
+	// that batch, the facade only packs the codes to its ptime -- `pending` is the packet being filled (it survives the conference
+	// leaving its batch: the facade's own next packet starts with it)
+	bool sleg;
+	void *sleg_bank;
+	mblk_t *pending;
 };
+void server_encoder_gone(MSFilter *e); // server_leg.inl
 
 MapFilter *map_new(MSFilter *f) {
 	MapFilter *d = (MapFilter *)ms_malloc0(sizeof(MapFilter));
@@ -183,6 +199,8 @@ bool map_attach(MSFilter *f, MapFilter *d, MapOp op) {
 
 void map_uninit(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
+	if (d->sleg) server_encoder_gone(f);
+	if (d->pending) freemsg(d->pending);
 	map_release(d);
 	if (d->bz) ms_bufferizer_destroy(d->bz);
 	ms_free(d);
@@ -254,12 +272,21 @@ void g711_enc_process(MSFilter *f) {
 		return;
 	}
 	while (ms_bufferizer_get_avail(d->bz) >= size_of_pcm) {
-		uint8_t *dst = d->pool->reserve(d->slot, size_of_pcm / 2, nullptr, true, d->ts);
+		// (a packet a fused conference had begun: its codes stand, the PCM of the rest completes it)
+		const size_t have = d->pending ? std::min((size_t)(d->pending->b_wptr - d->pending->b_rptr), size_of_pcm / 2) : 0;
+		const size_t need = size_of_pcm - 2 * have;
+		uint8_t *dst = d->pool->reserve(d->slot, need / 2, nullptr, true, d->ts);
 		if (!dst) break;
-		ms_bufferizer_read(d->bz, dst, size_of_pcm);
+		ms_bufferizer_read(d->bz, dst, need);
+		d->pool->staged[(size_t)d->slot].back().prefix = d->pending;
+		d->pending = nullptr;
 		d->ts += (uint32_t)(size_of_pcm / 2);
 	}
 	request_flush(f);
+}
+void g711_enc_postprocess(MSFilter *f) { // (alaw.c has none: the bufferizer -- here also the packet being filled -- outlives a detach)
+	facade_detached(f);
+	if (((MapFilter *)f->data)->sleg) server_encoder_gone(f);
 }
 
 // "key=value" out of an fmtp line "a=1;key=value; b=2" (what oRTP's fmtp_get_value does for the callers in alaw.c:92-105)
@@ -444,6 +471,7 @@ void adapter_preprocess(MSFilter *f) { // :53-66; the two-input buffers are need
 }
 void adapter_postprocess(MSFilter *f) { // :125-135
 	MapFilter *d = (MapFilter *)f->data;
+	facade_detached(f);
 	adapter_free_sides(d);
 	map_release(d);
 }

@@ -154,6 +154,11 @@ struct LegBank : Pool {
 	std::vector<uint8_t> flags;
 	std::vector<float> gains;
 	bool ctl_dirty = true;
+	// what a method set while the last walk's blocks were still waiting for the coming flush (Pool::work_waiting): live when that flush is
+	// through (flushed()).  vp_dirty / vs_dirty: 1 = goes to the device with the next enqueue, 2 = waits for flushed() first
+	std::vector<uint8_t> next_flags, next_conf;
+	std::vector<float> next_gains;
+	bool next_any = false;
 	std::vector<mi_volume_params> vparams;
 	std::vector<mi_volume_state> vstate;
 	std::vector<uint8_t> vp_dirty, vs_dirty;
@@ -277,6 +282,9 @@ struct LegBank : Pool {
 		lone.assign((size_t)capacity, -1);
 		flags.assign(L, 0);
 		gains.assign(L, 1.0f);
+		next_flags.assign(L, 0);
+		next_gains.assign(L, 1.0f);
+		next_conf.assign((size_t)capacity, 0);
 		mi_volume_params p;
 		mi_volume_default_params(&p);
 		vparams.assign(L, p);
@@ -643,15 +651,18 @@ struct LegBank : Pool {
 		ctl_dirty = false;
 		if (v_dirty) {
 			for (size_t s = 0; s < UL; ++s) {
-				if (vp_dirty[s]) MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
-				if (vs_dirty[s]) { // (vstate is what the device holds: read back with the last launch's results, nothing launched since)
+				if (vp_dirty[s] == 1) {
+					MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
+					vp_dirty[s] = 0;
+				}
+				if (vs_dirty[s] == 1) { // (vstate is what the device holds: read back with the last launch's results, nothing launched since)
 					vstate[s].gain = vpatch[s].gain;
 					if (vpatch[s].also_target) vstate[s].target_gain = vpatch[s].target;
 					MI_MUST(mi_volume_set_state(vol, (int)s, 1, &vstate[s]));
+					vs_dirty[s] = 0;
 				}
-				vp_dirty[s] = vs_dirty[s] = 0;
 			}
-			v_dirty = false;
+			v_dirty = false; // (entries at 2 wait for flushed(), which raises v_dirty again)
 		}
 		// ---- the host's half: framing decisions leg by leg
 		int rounds = 0, light_rounds = 0;
@@ -884,6 +895,23 @@ struct LegBank : Pool {
 		if (root) freeb(root);
 		root = nullptr;
 		cur = nullptr;
+	}
+	void flushed() override { // the coming flush is through: what the methods set while its blocks were waiting goes live
+		const size_t UL = (size_t)hi * mm;
+		for (size_t s = 0; s < UL; ++s) {
+			if (vp_dirty[s] == 2) vp_dirty[s] = 1, v_dirty = true;
+			if (vs_dirty[s] == 2) vs_dirty[s] = 1, v_dirty = true;
+		}
+		if (!next_any) return;
+		for (int c = 0; c < hi; ++c) {
+			if (!next_conf[(size_t)c]) continue;
+			const size_t at = (size_t)c * mm;
+			std::copy(next_flags.begin() + at, next_flags.begin() + at + mm, flags.begin() + at);
+			std::copy(next_gains.begin() + at, next_gains.begin() + at + mm, gains.begin() + at);
+			next_conf[(size_t)c] = 0;
+			ctl_dirty = true;
+		}
+		next_any = false;
 	}
 };
 
@@ -1148,11 +1176,19 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	return true;
 }
 
-// Called (hub locked, ticker thread) by the first facade of a conference's graph to run after an attach.  true = fused.
+// Called (hub locked, ticker thread) by the first facade of a conference's graph to run after an attach.  true = fused:
+// as a conference of sending legs (below), else as one of a server's remote members (server_leg.inl)
+bool conf_try_fuse_sending(MSFilter *mx);
+bool server_try_fuse(MSFilter *mx);
 bool conf_try_fuse(MSFilter *mx) {
 	MixerState *ms = (MixerState *)mx->data;
 	if (ms->fuse_state != 0) return ms->fuse_state == 1;
-	ms->fuse_state = 2; // refused, unless everything below holds
+	ms->fuse_state = 2; // refused, unless one of the two shapes holds
+	if (conf_try_fuse_sending(mx) || server_try_fuse(mx)) ms->fuse_state = 1;
+	return ms->fuse_state == 1;
+}
+bool conf_try_fuse_sending(MSFilter *mx) {
+	MixerState *ms = (MixerState *)mx->data;
 	const bool off = getenv("MSMI355X_NO_FUSE") != nullptr; // (read per attach: an A/B switch, and what the tests compare against)
 	if (off || !ms->pool || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 100) return false;
 	std::vector<LegCand> cand;
@@ -1264,7 +1300,6 @@ bool conf_try_fuse(MSFilter *mx) {
 	ms->fbank = b, ms->fconf = c;
 	b->conf_time[(size_t)c] = (uint64_t)-1;
 	b->staged_since = true;
-	ms->fuse_state = 1;
 	ms->unfuse_wanted = false;
 	mixer_push_controls(mx, ms);
 	ms_message("mi355x: conference %p fused: %d legs %u -> %u Hz, frame %d, tail %d, one device-resident batch (bank of %d x %d)", (void *)mx,
@@ -1316,7 +1351,10 @@ void leg_keep_volume(FusedLeg *leg) {
 void conf_unfuse(MSFilter *mx, bool keep_running) {
 	MixerState *ms = (MixerState *)mx->data;
 	LegBank *b = ms->fbank;
-	if (!b) return;
+	if (!b) {
+		server_unfuse(mx, keep_running);
+		return;
+	}
 	HubLock lk(b->hub);
 	const int c = ms->fconf, mm = b->mm;
 	std::vector<FusedLeg *> gone;
@@ -1471,30 +1509,35 @@ bool leg_runs_agc(FusedLeg *leg) { return leg && !leg->bank->light; }
 Pool *leg_pool(FusedLeg *leg) { return leg->bank; }
 Pool *leg_pool_of(LegBank *b) { return b; }
 // MS_AUDIO_MIXER_SET_INPUT_GAIN / SET_ACTIVE / ENABLE_OUTPUT on a fused conference (hub locked): the bank's control rows
-void leg_push_mixer_controls(MSFilter *f, MixerState *s) {
+void leg_push_mixer_controls(MSFilter *f, MixerState *s, bool from_method) {
 	LegBank *b = s->fbank;
+	const bool later = from_method && b->work_waiting();
+	std::vector<uint8_t> &fl_row = later ? b->next_flags : b->flags;
+	std::vector<float> &g_row = later ? b->next_gains : b->gains;
 	for (int pin = 0; pin < b->mm; ++pin) {
 		const size_t at = (size_t)(s->fconf * b->mm + pin);
 		uint8_t fl = 0;
 		if (f->inputs[pin] && b->legs[at]) fl |= MI_MIX_LINKED;
 		if (s->channels[pin].active) fl |= MI_MIX_ACTIVE;
 		if (f->outputs[pin] && s->channels[pin].output_enabled) fl |= MI_MIX_OUTPUT;
-		b->flags[at] = fl;
-		b->gains[at] = s->channels[pin].gain;
+		fl_row[at] = fl;
+		g_row[at] = s->channels[pin].gain;
 	}
-	b->ctl_dirty = true;
+	if (later) b->next_conf[(size_t)s->fconf] = 1, b->next_any = true;
+	else b->next_conf[(size_t)s->fconf] = 0, b->ctl_dirty = true;
 }
 mi_volume_state *leg_vstate(FusedLeg *leg) { return &leg->bank->vstate[(size_t)leg->slot]; }
 // MS_VOLUME_* methods on a fused leg's MSVolume (hub locked): parameters / running state for the next flush
 void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain, const float *target) {
 	LegBank *b = leg->bank;
 	const size_t s = (size_t)leg->slot;
+	const uint8_t when = b->work_waiting() ? 2 : 1; // (2: behind the coming flush, LegBank::flushed)
 	b->vparams[s] = *p;
 	b->vparams[s].peer = -1;
-	b->vp_dirty[s] = 1;
+	b->vp_dirty[s] = when;
 	if (gain) {
 		b->vpatch[s] = {*gain, target ? *target : 0.f, target != nullptr};
-		b->vs_dirty[s] = 1;
+		b->vs_dirty[s] = when;
 	}
 	b->v_dirty = true;
 }

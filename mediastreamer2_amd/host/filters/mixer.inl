@@ -123,11 +123,14 @@ struct MixerState { // audiomixer.c:132-143
 	// the conference and every leg that feeds it as one device-resident batch (filters/leg_chain.inl)
 	LegBank *fbank;     // non-null: fused; the conference is slot `fconf` of that bank
 	int fconf;
+	ServerBank *sbank;  // non-null: fused as a conference of remote members (filters/server_leg.inl), slot `sconf`
+	int sconf;
 	int fuse_state;     // 0 not looked at since the attach, 1 fused, 2 refused
 	std::atomic<bool> unfuse_wanted; // a member stopped qualifying (set by a method on any thread, honoured by the next process())
 	bool first_walk;    // the walk right after an attach is still to come (see mixer_process)
 };
-void leg_push_mixer_controls(MSFilter *f, MixerState *s); // leg_chain.inl
+void leg_push_mixer_controls(MSFilter *f, MixerState *s, bool from_method); // leg_chain.inl
+void server_push_mixer_controls(MSFilter *f, MixerState *s, bool from_method); // server_leg.inl
 
 void mixer_release_held(MSFilter *f, MixerState *s, bool deliver) {
 	for (auto &pm : *s->held) {
@@ -171,12 +174,16 @@ bool_t has_single_output(MSFilter *f, MixerState *s) { // audiomixer.c:167-176
 // from_method: set by a method on a running filter -- live behind the coming flush (MixerPool::next_*); otherwise (attach) at once
 void mixer_push_controls(MSFilter *f, MixerState *s, bool from_method = false) {
 	if (s->fbank) {
-		leg_push_mixer_controls(f, s);
+		leg_push_mixer_controls(f, s, from_method);
+		return;
+	}
+	if (s->sbank) {
+		server_push_mixer_controls(f, s, from_method);
 		return;
 	}
 	if (!s->pool) return;
 	MixerPool *p = s->pool;
-	const bool later = from_method && f->ticker != NULL && !s->first_walk; // (before the attach's first walk nothing older is on its way)
+	const bool later = from_method && f->ticker != NULL && p->work_waiting();
 	std::vector<uint8_t> &fl_row = later ? p->next_flags : p->flags;
 	std::vector<float> &g_row = later ? p->next_gain : p->gain;
 	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
@@ -357,11 +364,18 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	const double trace_ms = s->fbank ? leg_trace_ms(s->fbank) : 0.0; // MSMI355X_TRACE_SLOW_MS
 	const uint64_t tr0 = trace_ms > 0 ? leg_trace_now() : 0;
 	// lock order everywhere: the hub first, the filter's own lock inside it (the flush task pumps this filter with the hub held)
-	HubLock lk(f, s->fbank ? leg_pool_of(s->fbank) : static_cast<Pool *>(s->pool));
+	HubLock lk(f, s->fbank ? leg_pool_of(s->fbank) : (s->sbank ? server_pool_of(s->sbank) : static_cast<Pool *>(s->pool)));
 	ms_filter_lock(f);
 	const uint64_t tr1 = trace_ms > 0 ? leg_trace_now() : 0;
-	if (s->unfuse_wanted && s->fbank) conf_unfuse(f, true); // a member stopped qualifying: back to the facades' own banks
-	if (s->fuse_state == 0 && !s->fbank) conf_try_fuse(f); // (normally a leg's head got here first)
+	if (s->unfuse_wanted && (s->fbank || s->sbank)) conf_unfuse(f, true); // a member stopped qualifying: back to the facades' own banks
+	if (s->fuse_state == 0 && !s->fbank && !s->sbank) conf_try_fuse(f); // (normally a leg's head got here first)
+	if (s->sbank) { // a conference of remote members: as below, on its own kind of bank
+		mixer_release_held(f, s, true);
+		request_flush(f);
+		server_conf_walked(s->sbank, s->sconf);
+		ms_filter_unlock(f);
+		return;
+	}
 	if (s->fbank) { // fused: the conference ticks inside the hub's flush; a pump keeps that flush coming every tick
 		// (no census here: what the members staged in THIS walk meets the mixer in LegBank::conf_tick, whose three cases are
 		// mixer_check_bypass's, audiomixer.c:244-286 -- a pin's clock starts at its first look there, without counting yet)
@@ -427,7 +441,7 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 
 int mixer_set_rate(MSFilter *f, void *data) {
 	MixerState *s = (MixerState *)f->data;
-	if (s->fbank && s->rate != *(int *)data) s->unfuse_wanted = true;
+	if ((s->fbank || s->sbank) && s->rate != *(int *)data) s->unfuse_wanted = true;
 	s->rate = *(int *)data;
 	return 0;
 }
@@ -437,7 +451,7 @@ int mixer_get_rate(MSFilter *f, void *data) {
 }
 int mixer_set_nchannels(MSFilter *f, void *data) {
 	MixerState *s = (MixerState *)f->data;
-	if (s->fbank && s->nchannels != *(int *)data) s->unfuse_wanted = true;
+	if ((s->fbank || s->sbank) && s->nchannels != *(int *)data) s->unfuse_wanted = true;
 	s->nchannels = *(int *)data;
 	return 0;
 }
@@ -484,7 +498,7 @@ int mixer_enable_output(MSFilter *f, void *data) { // :395-408
 }
 int mixer_set_conference_mode(MSFilter *f, void *data) {
 	MixerState *s = (MixerState *)f->data;
-	if (s->fbank && *(int *)data == 0) s->unfuse_wanted = true; // the fused batch mixes in conference mode only
+	if ((s->fbank || s->sbank) && *(int *)data == 0) s->unfuse_wanted = true; // the fused batch mixes in conference mode only
 	s->conf_mode = *(int *)data;
 	return 0;
 }

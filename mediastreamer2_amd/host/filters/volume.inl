@@ -45,7 +45,15 @@ struct VolumePool : Pool {
 	std::vector<int> staged, ready;
 	std::vector<mi_volume_params> params;
 	std::vector<mi_volume_state> state;
+	// params_dirty / state_dirty: 1 = to the device with the next enqueue, 2 = set by a method while the last walk's blocks were still
+	// waiting for the coming flush (Pool::work_waiting): behind that flush (flushed()).  A gain method patches two fields of the running
+	// state as the device holds it (gain_patch), it does not replace the state
 	std::vector<uint8_t> params_dirty, state_dirty;
+	struct GainPatch {
+		float gain, target;
+		bool also_gain, also_target, whole; // whole: `state[slot]` itself is to be written (a new slot's start state)
+	};
+	std::vector<GainPatch> gain_patch;
 	VolumePool(int cap, int r) : rate(r) {
 		Building b(this, cap);
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, capacity, rate, &v));
@@ -67,6 +75,7 @@ struct VolumePool : Pool {
 		if (!failed) MI_MUST(mi_volume_get_state(v, 0, capacity, state.data()));
 		params_dirty.assign(c, 0);
 		state_dirty.assign(c, 0);
+		gain_patch.assign(c, GainPatch{1.f, 1.f, false, false, false});
 	}
 	~VolumePool() override {
 		if (v) mi_volume_destroy(v);
@@ -75,9 +84,18 @@ struct VolumePool : Pool {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
 		for (int s = 0; s < hi; ++s) {
-			if (params_dirty[(size_t)s]) MI_MUST(mi_volume_set_params(v, s, 1, &params[(size_t)s]));
-			if (state_dirty[(size_t)s]) MI_MUST(mi_volume_set_state(v, s, 1, &state[(size_t)s]));
-			params_dirty[(size_t)s] = state_dirty[(size_t)s] = 0;
+			if (params_dirty[(size_t)s] == 1) {
+				MI_MUST(mi_volume_set_params(v, s, 1, &params[(size_t)s]));
+				params_dirty[(size_t)s] = 0;
+			}
+			if (state_dirty[(size_t)s] == 1) {
+				GainPatch &g = gain_patch[(size_t)s];
+				if (g.also_gain) state[(size_t)s].gain = g.gain;
+				if (g.also_target) state[(size_t)s].target_gain = g.target;
+				MI_MUST(mi_volume_set_state(v, s, 1, &state[(size_t)s]));
+				g = GainPatch{1.f, 1.f, false, false, false};
+				state_dirty[(size_t)s] = 0;
+			}
 		}
 		int maxr = 0;
 		for (int s = 0; s < hi; ++s)
@@ -102,9 +120,9 @@ struct VolumePool : Pool {
 		return maxr > 0;
 	}
 	void finish() override {
-		if (fetched && !failed) // (a gain set by a method since the launch was enqueued is not overwritten: it is still dirty)
+		if (fetched && !failed) // (a new slot's start state that has not gone to the device yet is not overwritten)
 			for (int s = 0; s < hi; ++s)
-				if (!state_dirty[(size_t)s]) state[(size_t)s] = h_state[(size_t)(rounds_fetched - 1) * capacity + s];
+				if (!(state_dirty[(size_t)s] && gain_patch[(size_t)s].whole)) state[(size_t)s] = h_state[(size_t)(rounds_fetched - 1) * capacity + s];
 		fetched = false;
 		for (int s = 0; s < hi; ++s) {
 			if (parked(s)) continue;
@@ -113,6 +131,13 @@ struct VolumePool : Pool {
 		}
 	}
 	bool scoped() const override { return true; }
+	void flushed() override {
+		for (int s = 0; s < hi; ++s) {
+			if (parked(s)) continue;
+			if (params_dirty[(size_t)s] == 2) params_dirty[(size_t)s] = 1;
+			if (state_dirty[(size_t)s] == 2) state_dirty[(size_t)s] = 1;
+		}
+	}
 	void emit(MSFilter *f, int slot) override;
 };
 
@@ -134,6 +159,8 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	int slot;
 	bool ng_soft_start;
 	FusedLeg *leg;  // the filter is part of a fused call leg (filters/leg_chain.inl): its meter lives in that bank
+	ServerLeg *sleg; // ... or a conference server's member (filters/server_leg.inl): volrecv as the head of the leg
+	bool fuse_checked; // looked for a conference of remote members to fuse with since the last attach
 	// MSVolume filters that named this one as their echo-limiter peer (it must stay in a bank of its own kind).  Back-pointers,
 	// under g_peer_mu: a peer that is destroyed FIRST -- audio_stream_free destroys volrecv before volsend, audiostream.c:357-358,
 	// and volsend's peer is volrecv (:2240) -- is forgotten by those who named it; nobody ever reaches into a freed filter
@@ -147,6 +174,9 @@ bool volume_is_peered(VolumeData *d) {
 }
 mi_volume_state *leg_vstate(FusedLeg *leg);                      // leg_chain.inl
 void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain, const float *target); // (gain: also the running state's)
+mi_volume_state *server_vstate(ServerLeg *leg);                  // server_leg.inl
+void server_push_volume(ServerLeg *leg, const mi_volume_params *p, const float *gain, const float *target);
+MSFilter *leg_volume_sink(MSFilter *vol);
 
 void volume_init(MSFilter *f) { // msvolume.c:88-118
 	VolumeData *d = new VolumeData();
@@ -162,6 +192,8 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->pool = nullptr;
 	d->slot = -1;
 	d->leg = nullptr;
+	d->sleg = nullptr;
+	d->fuse_checked = false;
 	d->peer_gone = false;
 	d->has_kept = false;
 	f->data = d;
@@ -171,11 +203,14 @@ void volume_postprocess(MSFilter *f) { // detach: a fused conference goes back t
 	VolumeData *d = (VolumeData *)f->data;
 	facade_detached(f);
 	if (d->leg) leg_release(d->leg, false);
+	if (d->sleg) server_release(d->sleg, false);
+	d->fuse_checked = false;
 }
 
 void volume_uninit(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
 	if (d->leg) leg_release(d->leg, false);
+	if (d->sleg) server_release(d->sleg, false);
 	{
 		std::lock_guard<std::mutex> g(g_peer_mu);
 		if (d->peer) { // (alive: had it died first it would have cleared this pointer below)
@@ -202,6 +237,11 @@ void volume_uninit(MSFilter *f) {
 void volume_keep_state(VolumeData *d) {
 	if (!d->pool || d->slot < 0 || d->pool->failed) return;
 	d->kept = d->pool->state[(size_t)d->slot];
+	if (d->pool->state_dirty[(size_t)d->slot]) { // a gain method that has not reached the device yet
+		const VolumePool::GainPatch &g = d->pool->gain_patch[(size_t)d->slot];
+		if (g.also_gain) d->kept.gain = g.gain;
+		if (g.also_target) d->kept.target_gain = g.target;
+	}
 	d->has_kept = true;
 }
 // what a new slot starts from: volume_init's state (msvolume.c:88-118) with the gains the methods set, or what the last slot held
@@ -217,23 +257,29 @@ mi_volume_state volume_start_state(const VolumeData *d) {
 
 mi_volume_state *vstate(VolumeData *d) {
 	if (d->leg) return leg_vstate(d->leg);
+	if (d->sleg) return server_vstate(d->sleg);
 	return (d->pool && d->slot >= 0) ? &d->pool->state[(size_t)d->slot] : nullptr;
 }
 
-void volume_push_params(VolumeData *d) {
+void volume_push_params(VolumeData *d, bool f_method = true) {
 	if (d->leg) {
 		leg_push_volume(d->leg, &d->p, nullptr, nullptr);
 		if ((d->p.agc_enabled != 0) != leg_runs_agc(d->leg)) leg_disqualify(d->leg); // AGC switched: with it the reference meters 10 ms chunks, without it block by block -- another bank
 		return;
 	}
+	if (d->sleg) {
+		server_push_volume(d->sleg, &d->p, nullptr, nullptr);
+		if (d->p.agc_enabled) server_disqualify(d->sleg); // with AGC the reference meters re-framed 10 ms chunks: the facades' own banks
+		return;
+	}
 	if (!d->pool || d->slot < 0) return;
 	d->pool->params[(size_t)d->slot] = d->p;
-	d->pool->params_dirty[(size_t)d->slot] = 1;
+	d->pool->params_dirty[(size_t)d->slot] = (f_method && d->pool->work_waiting()) ? 2 : 1;
 }
 
 void volume_attach_slot(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
-	if (d->leg) return;
+	if (d->leg || d->sleg) return;
 	if (d->pool) { // rate changed, moved to another ticker, or the bank failed: the slot goes back (under ITS hub's lock)
 		HubLock old(f);
 		if (d->pool->failed || d->pool->rate != d->sample_rate || d->pool->hub->ticker != f->ticker) {
@@ -256,6 +302,7 @@ void volume_attach_slot(MSFilter *f) {
 		// new slot: volume_init's state and whatever the methods set before attach, or the running state the last slot held
 		d->pool->state[(size_t)d->slot] = volume_start_state(d);
 		d->pool->state_dirty[(size_t)d->slot] = 1;
+		d->pool->gain_patch[(size_t)d->slot] = VolumePool::GainPatch{1.f, 1.f, false, false, true};
 	}
 	// the peer is addressed by its slot in the same pool
 	d->p.peer = -1;
@@ -264,7 +311,7 @@ void volume_attach_slot(MSFilter *f) {
 		if (pd->pool == d->pool && pd->slot >= 0) d->p.peer = pd->slot;
 		else ms_warning("MSVolume[mi355x]: peer not in the same batch yet (different rate or not attached)");
 	}
-	volume_push_params(d);
+	volume_push_params(d, false); // (a slot's first parameters: at once)
 }
 
 void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
@@ -279,6 +326,21 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 	VolumeData *d = (VolumeData *)f->data;
 	if (d->leg) { // fused leg: the chunks are popped, metered and mixed on the device; nothing arrives on this queue
 		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	if (!d->sleg && !d->fuse_checked && f->ticker && f->inputs[0] && !ms_queue_empty(f->inputs[0])) {
+		// the first block since the attach: is this volrecv in front of a conference mixer whose members are all of that shape?
+		d->fuse_checked = true;
+		MSFilter *mx = leg_volume_sink(f);
+		if (mx && mx->desc == &ms_mi355x_audio_mixer_desc) {
+			HubLock lk(f, d->pool);
+			conf_try_fuse(mx);
+		}
+	}
+	if (d->sleg && server_wants_out(d->sleg)) server_release(d->sleg, true); // a member stopped qualifying: the first of them to be walked takes the conference out, before anything of this walk is staged
+	if (d->sleg) { // a conference server's member: the block goes into the leg's row of the conference's bank
+		HubLock lk(f, server_pool(d->sleg));
+		server_stage(f, d);
 		return;
 	}
 	HubLock lk(f, d->pool);
@@ -391,16 +453,26 @@ void volume_set_gains(MSFilter *f, VolumeData *d, bool also_target) {
 		leg_push_volume(d->leg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
 		return;
 	}
+	if (d->sleg) {
+		server_push_volume(d->sleg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
+		return;
+	}
 	if (d->has_kept) { // (a state waiting for its next slot follows the methods too)
 		d->kept.gain = d->gain;
 		if (also_target) d->kept.target_gain = d->target_gain;
 	}
-	if (!d->pool) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
-	mi_volume_state *st = vstate(d);
-	if (st) {
-		st->gain = d->gain;
-		if (also_target) st->target_gain = d->target_gain;
-		d->pool->state_dirty[(size_t)d->slot] = 1;
+	if (!d->pool || d->slot < 0) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
+	{
+		VolumePool *p = d->pool;
+		const size_t s = (size_t)d->slot;
+		VolumePool::GainPatch &g = p->gain_patch[s];
+		g.gain = d->gain, g.also_gain = true;
+		if (also_target) g.target = d->target_gain, g.also_target = true;
+		if (g.whole) { // (the slot's start state has not gone to the device yet: the method edits it)
+			p->state[s].gain = d->gain;
+			if (also_target) p->state[s].target_gain = d->target_gain;
+		}
+		if (p->state_dirty[s] != 1) p->state_dirty[s] = p->work_waiting() ? 2 : 1;
 	}
 	volume_push_params(d);
 }
@@ -441,16 +513,18 @@ int volume_set_peer(MSFilter *f, void *arg) { // :292-297 stores the MSFilter*
 	if (peer) { // the echo limiter reads its peer's meter of the previous tick: both in one plain bank
 		HubLock lk(peer);
 		leg_disqualify(((VolumeData *)peer->data)->leg);
+		server_disqualify(((VolumeData *)peer->data)->sleg);
 	}
 	HubLock lk(f);
 	leg_disqualify(d->leg);
+	server_disqualify(d->sleg);
 	if (d->pool) volume_attach_slot(f);
 	return 0;
 }
 int volume_set_rate(MSFilter *f, void *arg) {
 	VolumeData *d = (VolumeData *)f->data;
 	HubLock lk(f);
-	if (d->sample_rate != *(int *)arg) leg_disqualify(d->leg);
+	if (d->sample_rate != *(int *)arg) leg_disqualify(d->leg), server_disqualify(d->sleg);
 	d->sample_rate = *(int *)arg;
 	return 0;
 }

@@ -222,10 +222,11 @@ class OracleMixer:
     detach does to it (mixer_postprocess :200-208 drops every channel's queue, preprocess :186-198 restarts the clocks).
     A single contributor is MIXED here like any other, as the plugin's fused conference does (the reference forwards that pin's
     blocks unsaturated, :219-242: only a sample of -32768 would differ -- the stated exception of leg_chain.inl)."""
-    TIMEOUT, NS = 1000, RATE // 100
+    TIMEOUT = 1000
 
-    def __init__(self, oracle):
+    def __init__(self, oracle, ns=RATE // 100):
         self.o = oracle
+        self.NS = ns
         self.q = {}          # pin -> queued samples (the channel's bufferizer + its input queue)
         self.seen = {}       # pin -> last_activity
         self.fc = {}         # pin -> [last_flow_control, min_fullness]

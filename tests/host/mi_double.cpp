@@ -276,7 +276,7 @@ int mi_mixer_finalize(mi_mixer *m, const int16_t *in, const uint8_t *hd, const i
 	for (int c = 0; c < m->nconf; ++c)
 		for (int k = 0; k < (conf_mode ? m->mm : 1); ++k) {
 			const size_t p = (size_t)c * m->mm + k;
-			if (conf_mode && (m->flags[p] & (MI_MIX_LINKED | MI_MIX_OUTPUT)) != (MI_MIX_LINKED | MI_MIX_OUTPUT)) continue;
+			if (conf_mode && !(m->flags[p] & MI_MIX_OUTPUT)) continue; /* (an output-only pin -- a listener -- hears everybody: mixer.hip) */
 			for (int i = 0; i < m->ns; ++i)
 				out[(conf_mode ? p : (size_t)c) * m->ns + i] = (int16_t)sat((int64_t)sum[(size_t)c * m->ns + i] - (conf_mode ? contrib(m, in, hd, c, k, i) : 0));
 		}
@@ -296,7 +296,7 @@ int mi_mixer_process_masked(mi_mixer *m, const int16_t *in, const uint8_t *hd, i
 		}
 		for (int k = 0; k < (cm ? m->mm : 1); ++k) {
 			const size_t p = (size_t)c * m->mm + k;
-			if (cm && (m->flags[p] & (MI_MIX_LINKED | MI_MIX_OUTPUT)) != (MI_MIX_LINKED | MI_MIX_OUTPUT)) continue;
+			if (cm && !(m->flags[p] & MI_MIX_OUTPUT)) continue;
 			for (int i = 0; i < m->ns; ++i) out[p * m->ns + i] = (int16_t)sat((int64_t)sum[(size_t)i] - (cm ? contrib(m, in, hd, c, k, i) : 0));
 		}
 	}

@@ -49,7 +49,7 @@ size_t ms2shim_sink_size(MSFilter *sink);
 int ms2shim_sink_blocks(MSFilter *sink);
 
 #define RING 16
-static int16_t g_mic[RING][160], g_far[RING][480];
+static int16_t g_mic[RING][160], g_far[RING][480], g_pcm8[RING][80];
 
 typedef struct {
 	MSTicker *ticker;
@@ -78,6 +78,7 @@ static pthread_barrier_t g_bar;
 
 static int g_profile, g_checksum;
 static int g_nors, g_noagc, g_nomixer; /* PLUGIN_BENCH_SHAPE: words of "nors noagc nomixer" -- the leg without MSResample / without AGC / without a conference mixer */
+static int g_server; /* ... "server": a conference server's REMOTE members (audioconference.c:121-179,209-257): 8 kHz source (decoder .. dtmfgen) -> MSVolume -> in_resampler -> pin -> out_resampler -> MSUlawEnc -> sink, no canceller */
 static int g_eprs; /* ... "eprs": every pin behind an in_resampler, in front of an out_resampler, as MSAudioConference plumbs its endpoints (audioconference.c:209-257) */
 static double now_ms(void) {
 	struct timespec ts;
@@ -104,6 +105,26 @@ static void build(TickerJob *j) {
 		call_int(mx, MS_FILTER_SET_SAMPLE_RATE, 48000);
 		call_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
 		j->mixers[c] = mx;
+		if (g_server) { /* the conference at the G.711 endpoints' rate: both resamplers forward (msresample.c:126-135) */
+			call_int(mx, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			for (int k = 0; k < g_members; ++k) {
+				MSFilter *src = ms2shim_new_source(g_fac), *out = ms2shim_new_sink(g_fac), *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+				MSFilter *in_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *out_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
+				MSFilter *enc = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
+				const int leg = (j->index * j->nconf + c) * g_members + k;
+				ms2shim_source_set_loop(src, g_pcm8, sizeof(g_pcm8[0]), RING, leg);
+				ms2shim_sink_set_discard(out, g_checksum ? 2 : 1);
+				j->outs[c * g_members + k] = out;
+				j->spks[c * g_members + k] = NULL;
+				call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 8000);
+				call_int(in_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(in_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
+				call_int(out_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(out_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
+				ms_filter_link(src, 0, vol, 0), ms_filter_link(vol, 0, in_rs, 0), ms_filter_link(in_rs, 0, mx, k);
+				ms_filter_link(mx, k, out_rs, 0), ms_filter_link(out_rs, 0, enc, 0), ms_filter_link(enc, 0, out, 0);
+				if (c == 0 && k == 0) j->probe_out = out;
+			}
+			continue;
+		}
 		for (int k = 0; k < g_members; ++k) {
 			MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
 			MSFilter *rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
@@ -284,7 +305,7 @@ int main(int argc, char **argv) {
 	g_aligned = getenv("PLUGIN_BENCH_ALIGNED") != NULL;
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
-		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL;
+		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL;
 	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
 	const char *plugin = argv[1];
@@ -310,6 +331,7 @@ int main(int argc, char **argv) {
 	for (int r = 0; r < RING; ++r) {
 		for (int i = 0; i < 160; ++i) g_mic[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 19) - 4096);
 		for (int i = 0; i < 480; ++i) g_far[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 18) - 8192);
+		for (int i = 0; i < 80; ++i) g_pcm8[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 19) - 4096);
 	}
 	g_fac = ms_factory_new();
 	ms2shim_register_test_filters(g_fac);
@@ -507,7 +529,7 @@ int main(int argc, char **argv) {
 		for (int i = 0; i < g_tickers; ++i)
 			for (int k = 0; k < jobs[i].nconf * g_members; ++k) {
 				mix_sum += ms2shim_sink_sum(jobs[i].outs[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
-				spk_sum += ms2shim_sink_sum(jobs[i].spks[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
+				if (jobs[i].spks[k]) spk_sum += ms2shim_sink_sum(jobs[i].spks[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
 				out_bytes += ms2shim_sink_size(jobs[i].outs[k]);
 			}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);

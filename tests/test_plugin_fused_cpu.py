@@ -68,7 +68,7 @@ def test_plugin_bench_runs_full_legs_through_the_double(verdict, paced):
         assert 9.0 < d["wall_ms_per_tick"] < 12.0, d["wall_ms_per_tick"]   # 40 ticks on the 10 ms grid (+ the 20 ms lead)
 
 
-@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nomixer", "nors noagc nomixer", "eprs"])
+@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nomixer", "nors noagc nomixer", "eprs", "server"])
 def test_plugin_bench_shapes_fused_equal_one_by_one_by_checksum(verdict, shape):
     """every leg shape the fused chain takes (PLUGIN_BENCH_SHAPE: without MSResample / without AGC / without a conference mixer):
     256 legs x 70 ticks against the double, every leg's mix and speaker audio folded into one number per run -- fused ==
@@ -84,6 +84,7 @@ def test_plugin_bench_shapes_fused_equal_one_by_one_by_checksum(verdict, shape):
         return json.loads(r.stdout.strip().splitlines()[-1])
 
     fused, plain, staged = run(), run(MSMI355X_NO_FUSE="1"), run(MSMI355X_ZERO_COPY="0")
+    # ("server": a conference server's remote members -- volrecv -> in_resampler -> pin -> out_resampler -> MSUlawEnc, filters/server_leg.inl)
     assert fused["fused_legs"] == 256 and plain["fused_legs"] == 0 and staged["fused_legs"] == 256
     assert fused["mix_bytes"] == plain["mix_bytes"] > 0
     assert fused["mix_checksum"] == plain["mix_checksum"] == staged["mix_checksum"]
