@@ -94,7 +94,7 @@ struct ServerBank : Pool {
 		Building b(this, cap_conf);
 		ns = rate / 100;
 		nlegs = capacity * mm;
-		cap = (6 * ns + 7) & ~7; // 60 ms: three 20 ms packets a jitter buffer lets go at once; a longer block is cut (server_stage)
+		cap = std::min((6 * ns + 7) & ~7, 2400); // 60 ms (three 20 ms packets a jitter buffer lets go at once), and what the volume kernel's LDS staging takes (50 ms at 48 kHz); a longer block is cut (server_stage)
 		const size_t L = (size_t)nlegs;
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, rate, &vol));
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, rate, &vol_id));
@@ -486,8 +486,16 @@ void server_stage(MSFilter *f, VolumeData *d) {
 	ServerLeg *leg = d->sleg;
 	ServerBank *b = leg->bank;
 	const size_t L = (size_t)b->nlegs;
+	if (b->failed) { // no batch to be had: the blocks are lost, counted (the queue must be emptied: the ticker calls process() while there is input)
+		if (!ms_queue_empty(f->inputs[0])) g_late_events.fetch_add(1, std::memory_order_relaxed);
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	// whole blocks wait in `backlog` (block by block: MSVolume without AGC meters each as it came) when a tick brings more than the
+	// launch rounds take; the input queue is always emptied (msticker.c:244-259 calls process() while there is input)
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) putq(&d->backlog->q, m);
 	for (;;) {
-		if (leg->staged >= kMaxRounds) break; // (more blocks in one tick than launch rounds: the rest waits on the queue for the next)
+		if (leg->staged >= kMaxRounds) break;
 		int16_t *row = b->h_in + ((size_t)leg->staged * L + (size_t)leg->slot) * b->cap;
 		int n = 0;
 		const size_t spilled = ms_bufferizer_get_avail(d->spill);
@@ -495,7 +503,7 @@ void server_stage(MSFilter *f, VolumeData *d) {
 		if (spilled) {
 			n = (int)std::min(spilled / 2, (size_t)b->cap);
 			ms_bufferizer_read(d->spill, (uint8_t *)row, (size_t)n * 2);
-		} else if ((m = ms_queue_get(f->inputs[0])) != NULL) {
+		} else if ((m = getq(&d->backlog->q)) != NULL) {
 			n = (int)(msgdsize(m) / 2);
 			if (n > b->cap) { // longer than a row: cut into row-sized blocks, as the facade's light path does
 				ms_bufferizer_put(d->spill, m);
@@ -685,6 +693,8 @@ void server_unfuse(MSFilter *mx, bool keep_running) {
 			m->b_wptr += n * 2;
 			ms_bufferizer_put(vd->spill, m);
 		}
+		// (blocks still waiting in the backlog go to the facade's own path through its input queue's place: its spill)
+		for (mblk_t *m; (m = getq(&vd->backlog->q)) != NULL;) ms_bufferizer_put(vd->spill, m);
 		vd->sleg = nullptr;
 		b->legs[s] = nullptr;
 		gone.push_back(leg);

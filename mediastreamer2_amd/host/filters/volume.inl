@@ -148,6 +148,7 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	MSFilter *peer;
 	MSBufferizer *buffer;
 	MSBufferizer *spill; // light path: the part of an over-long block that did not fit this tick's rounds
+	MSBufferizer *backlog; // a conference server's member (server_leg.inl): whole blocks beyond a tick's launch rounds, kept block by block
 	Extremum min, max;
 	// struct Volume lives as long as the filter: energy, the gain ramp, the noise gate's and the echo limiter's counters all survive a
 	// detach / re-attach of the graph (msvolume.c:88-118 sets them once, :447-469 only resets the extrema).  Here the running state
@@ -187,6 +188,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->peer = NULL;
 	d->buffer = ms_bufferizer_new();
 	d->spill = ms_bufferizer_new();
+	d->backlog = ms_bufferizer_new();
 	d->max.period = 1000;
 	d->min.period = 30000;
 	d->pool = nullptr;
@@ -230,6 +232,7 @@ void volume_uninit(MSFilter *f) {
 	}
 	ms_bufferizer_destroy(d->buffer);
 	ms_bufferizer_destroy(d->spill);
+	ms_bufferizer_destroy(d->backlog);
 	delete d;
 }
 
