@@ -162,6 +162,10 @@ struct LegBank : Pool {
 	std::vector<mi_volume_params> vparams;
 	std::vector<mi_volume_state> vstate;
 	std::vector<uint8_t> vp_dirty, vs_dirty;
+	// ... and in a conference with AGC the chunks MSVolume has already handed to the mixer's channel are levelled here only when the
+	// mixer takes them (volmix_kernel pops, meters and mixes): what a method sets must pass those by -- v_delay: chunks of the leg
+	// that were produced before the call and are still to be taken; the change goes to the device when it is down to zero
+	std::vector<int> v_delay;
 	bool v_dirty = false;
 	std::vector<std::pair<int, int>> drops; // (leg slot, chunks) the mixer channels' flow control discards this flush
 	std::vector<uint64_t> conf_time;        // ticker time of a conference's last tick (one per tick, whoever enqueues)
@@ -291,6 +295,7 @@ struct LegBank : Pool {
 		vstate.resize(L);
 		vp_dirty.assign(L, 0);
 		vs_dirty.assign(L, 0);
+		v_delay.assign(L, 0);
 		vpatch.assign(L, GainPatch{1.f, 1.f, false});
 		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
 		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
@@ -433,6 +438,7 @@ struct LegBank : Pool {
 			if (leg->chan_chunks > 0) { // ... and the read of one tick (the device pops it: the queue holds a whole chunk)
 				leg->chan_chunks--;
 				leg->metered = true;
+				if (v_delay[(size_t)leg->slot] > 0) --v_delay[(size_t)leg->slot];
 			}
 			const int skip = channel_flow_control_level(chan, leg->chan_chunks * ns * 2, s->skip_threshold, now);
 			if (skip > 0) {
@@ -650,7 +656,12 @@ struct LegBank : Pool {
 		if (ctl_dirty && mix) MI_MUST(mi_mixer_set_controls(mix, flags.data(), gains.data()));
 		ctl_dirty = false;
 		if (v_dirty) {
+			bool held = false;
 			for (size_t s = 0; s < UL; ++s) {
+				if (v_delay[s] > 0 && (vp_dirty[s] == 1 || vs_dirty[s] == 1)) { // chunks from before the call are still to be taken: not yet
+					held = true;
+					continue;
+				}
 				if (vp_dirty[s] == 1) {
 					MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
 					vp_dirty[s] = 0;
@@ -662,7 +673,7 @@ struct LegBank : Pool {
 					vs_dirty[s] = 0;
 				}
 			}
-			v_dirty = false; // (entries at 2 wait for flushed(), which raises v_dirty again)
+			v_dirty = held; // (entries at 2 wait for flushed(), which raises v_dirty again)
 		}
 		// ---- the host's half: framing decisions leg by leg
 		int rounds = 0, light_rounds = 0;
@@ -899,8 +910,11 @@ struct LegBank : Pool {
 	void flushed() override { // the coming flush is through: what the methods set while its blocks were waiting goes live
 		const size_t UL = (size_t)hi * mm;
 		for (size_t s = 0; s < UL; ++s) {
-			if (vp_dirty[s] == 2) vp_dirty[s] = 1, v_dirty = true;
-			if (vs_dirty[s] == 2) vs_dirty[s] = 1, v_dirty = true;
+			if (vp_dirty[s] != 2 && vs_dirty[s] != 2) continue;
+			if (vp_dirty[s] == 2) vp_dirty[s] = 1;
+			if (vs_dirty[s] == 2) vs_dirty[s] = 1;
+			v_delay[s] = chunks_waiting(s);
+			v_dirty = true;
 		}
 		if (!next_any) return;
 		for (int c = 0; c < hi; ++c) {
@@ -912,6 +926,11 @@ struct LegBank : Pool {
 			ctl_dirty = true;
 		}
 		next_any = false;
+	}
+	// chunks leg s's MSVolume has produced that the mixer has not taken yet (a conference with AGC: they are levelled when taken)
+	int chunks_waiting(size_t s) const {
+		const FusedLeg *leg = legs[s];
+		return (leg && !plain && !light) ? leg->chan_chunks + leg->newchunks : 0;
 	}
 };
 
@@ -1532,6 +1551,7 @@ void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain
 	LegBank *b = leg->bank;
 	const size_t s = (size_t)leg->slot;
 	const uint8_t when = b->work_waiting() ? 2 : 1; // (2: behind the coming flush, LegBank::flushed)
+	if (when == 1) b->v_delay[s] = b->chunks_waiting(s);
 	b->vparams[s] = *p;
 	b->vparams[s].peer = -1;
 	b->vp_dirty[s] = when;

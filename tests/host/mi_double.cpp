@@ -376,7 +376,8 @@ int mi_exchange_allreduce_i32(mi_exchange *x, int32_t *buf, size_t count) {
 	return MI_OK;
 }
 
-// ---- volume: unity gain, a plain energy meter
+// ---- volume: the running gain applied chunk by chunk (it follows its target), a plain energy meter scaled by the static gain --
+// not MSVolume's arithmetic, but enough of it that WHEN a method's gain or parameter reaches the batch shows in samples and meters
 void mi_volume_default_params(mi_volume_params *p) {
 	if (!p) return;
 	memset(p, 0, sizeof *p);
@@ -434,8 +435,15 @@ int mi_volume_process(mi_volume *v, int16_t *x, int ns, int stride, const int32_
 		const int n = per ? std::min(std::max(per[s], 0), ns) : ns;
 		if (!n) continue;
 		double acc = 0;
-		for (int i = 0; i < n; ++i) acc += (double)x[(size_t)s * stride + i] * x[(size_t)s * stride + i];
-		v->state[(size_t)s].energy = (float)(acc / n / (32768.0 * 32768.0));
+		mi_volume_state &st = v->state[(size_t)s];
+		for (int i = 0; i < n; ++i) {
+			int16_t &smp = x[(size_t)s * stride + i];
+			acc += (double)smp * smp;
+			const float y = (float)smp * st.gain;
+			smp = (int16_t)(y > 32767.f ? 32767 : (y < -32767.f ? -32767 : (int)y));
+		}
+		st.gain += 0.25f * (st.target_gain - st.gain);
+		v->state[(size_t)s].energy = (float)(acc / n / (32768.0 * 32768.0)) * v->params[(size_t)s].static_gain;
 		v->mx[(size_t)s] = std::max(v->mx[(size_t)s], v->state[(size_t)s].energy);
 	}
 	return MI_OK;

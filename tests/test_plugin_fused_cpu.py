@@ -25,7 +25,7 @@ def verdict():
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("name", ["plain", "delay_and_far_gaps", "ptime20", "odd_pins", "gain_method", "wideband_8k_16k", "no_mixer", "no_mixer_ptime20",
+@pytest.mark.parametrize("name", ["plain", "delay_and_far_gaps", "ptime20", "odd_pins", "gain_method", "gain_method_early", "wideband_8k_16k", "no_mixer", "no_mixer_ptime20",
                                   "no_resampler", "no_resampler_16k_ptime20", "no_resampler_no_mixer",
                                   "no_agc", "no_agc_ptime20_16k", "no_agc_no_resampler_no_mixer",
                                   "endpoint_resamplers", "endpoint_resamplers_no_agc_no_resampler"])
