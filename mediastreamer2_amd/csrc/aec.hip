@@ -732,6 +732,36 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 		}
 		return MI_OK;
 	}
+	// EXPERIMENT (MSMI355X_AEC_W_IN_LDS=1): the headline form with frame 1's updated background resident in LDS (aec_tick.hpp: WLDS)
+	static const bool w_in_lds = [] {
+		const char *e = getenv("MSMI355X_AEC_W_IN_LDS");
+		return e && e[0] == '1';
+	}();
+	if (w_in_lds && a->F == 256 && mode == TICK_FIFO_RS && a->M * 256 * 8 <= 49152) {
+		static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&aec_tick_kernel<256, TICK_FIFO_RS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 49152) == hipSuccess;
+		if (ok) {
+			hipLaunchKernelGGL((aec_tick_kernel<256, TICK_FIFO_RS, true>), grid, dim3(64), 49152, a->ctx->stream, g);
+			MI_LAUNCH_CHECK();
+			hipLaunchKernelGGL(aec_tick_advance_kernel, dim3(1), dim3(64), 0, a->ctx->stream, a->d_ctl);
+			MI_LAUNCH_CHECK();
+			return MI_OK;
+		}
+	}
+	// (MSMI355X_AEC_LDS_PAD=<bytes>: the PRODUCT form launched with that much dynamic LDS it never touches -- what the footprint alone costs)
+	static const int lds_pad = [] {
+		const char *e = getenv("MSMI355X_AEC_LDS_PAD");
+		return e ? atoi(e) : 0;
+	}();
+	if (lds_pad > 0 && a->F == 256 && mode == TICK_FIFO_RS) {
+		static const bool okp = hipFuncSetAttribute(reinterpret_cast<const void *>(&aec_tick_kernel<256, TICK_FIFO_RS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad) == hipSuccess;
+		if (okp) {
+			hipLaunchKernelGGL((aec_tick_kernel<256, TICK_FIFO_RS, false>), grid, dim3(64), (size_t)lds_pad, a->ctx->stream, g);
+			MI_LAUNCH_CHECK();
+			hipLaunchKernelGGL(aec_tick_advance_kernel, dim3(1), dim3(64), 0, a->ctx->stream, a->d_ctl);
+			MI_LAUNCH_CHECK();
+			return MI_OK;
+		}
+	}
 #define MI_TICK_LAUNCH(FR)                                                                                          \
 	do {                                                                                                            \
 		if (mode == TICK_FIFO_RS) hipLaunchKernelGGL((aec_tick_kernel<FR, TICK_FIFO_RS>), grid, dim3(64), 0, a->ctx->stream, g); \
