@@ -423,6 +423,34 @@ def make_aec_small_leg(ms, torch, ctx, rate, F, nstreams=65536):
     return leg
 
 
+def make_aec_small_fifo_leg(ms, torch, ctx, rate, F, nstreams=65536):
+    """The same canceller through its FIFO ENTRY (mi_aec_process_fifos: what the plugin's fused legs and mi_session launch for 8 / 16 kHz
+    legs): a whole 10 ms tick per launch sequence -- blocks queued, every whole frame popped, cancelled by aec_group_kernel, results
+    queued (aec.hip: aec_fifos_group).  ns / F = 1.25 frames per leg and tick on average, the legs' re-framing phases spread."""
+    M = (128 * rate // 1000 + F - 1) // F
+    N, ns = 2 * F, rate // 100
+    aec = ms.AecBatch(ctx, nstreams, rate, frame_size=F, filter_length=128 * rate // 1000)
+    cap = (4 * ns + 4 * F + F - 1) // F * F
+    fm, fr, fo = (ms.FifoBatch(ctx, nstreams, cap) for _ in range(3))
+    aec.stagger_fifos(fm, fr, ns) if hasattr(aec, "stagger_fifos") else None
+    ring = 8
+    mic = [torch.from_numpy(synth_pcm_batch(nstreams, ns, rate, seed0=0x5EED + i)).cuda() for i in range(ring)]
+    ref = [torch.from_numpy(synth_pcm_batch(nstreams, ns, rate, seed0=0xFA2 + i, sigma=2000.0)).cuda() for i in range(ring)]
+    sink = torch.zeros((nstreams, ns), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    per_frame = 3 * F * 2 + (3 * M * N + (M + 1) * N + N) * 4
+
+    def launch(i):
+        aec.process_fifos(fm, mic[i % ring], fr, ref[i % ring], fo, tick_len=ns, max_frames=2, flags=ms.MI_AEC_POSTFILTER)
+        fo.pop(ns, sink, zero_fill=True)   # (the mixer's side of the queue: keeps it from filling up)
+
+    leg = Leg(ctx, f"aec_fifo_tick<{F}>", launch, ring, nstreams * per_frame * ns / F, nstreams,
+              f"leg-ticks ({ns} samples at {rate} Hz = {ns / F:.2f} frames of {F}; FIFO entry -> aec_group_kernel)")
+    leg.keep = (aec, fm, fr, fo, mic, ref, sink)
+    leg.state_bytes = aec.state_bytes() * nstreams
+    return leg
+
+
 def copy_ceiling(torch):
     """Achievable HBM rate on this box: a 1 GiB device-to-device copy (read + write bytes / time), the
     'measured ceiling' BASELINE.md section 4 asks to report beside the 8 TB/s vendor peak."""
@@ -1877,9 +1905,15 @@ def main():
             def make_aec_16k(ms_, torch_, ctx_):
                 return make_aec_small_leg(ms_, torch_, ctx_, 16000, 128)
 
-            no_pmc = (make_resample_65536, make_mixer_1024, make_scaler_i420, make_aec_8k, make_aec_16k)
+            def make_aec_fifo_8k(ms_, torch_, ctx_):
+                return make_aec_small_fifo_leg(ms_, torch_, ctx_, 8000, 64)
+
+            def make_aec_fifo_16k(ms_, torch_, ctx_):
+                return make_aec_small_fifo_leg(ms_, torch_, ctx_, 16000, 128)
+
+            no_pmc = (make_resample_65536, make_mixer_1024, make_scaler_i420, make_aec_8k, make_aec_16k, make_aec_fifo_8k, make_aec_fifo_16k)
             for mk in (make_resample_4096, make_resample_65536, make_mixer_leg, make_mixer_1024, make_volume_leg, make_equalizer_leg,
-                       make_aec_4096, make_aec_8k, make_aec_16k, make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
+                       make_aec_4096, make_aec_8k, make_aec_16k, make_aec_fifo_8k, make_aec_fifo_16k, make_scaler_leg, make_scaler_i420, make_pixconv_leg, make_g711_leg, make_g711_encode, make_plc_leg):
                 try:
                     lg = mk(ms, torch, ctx)
                     g = lg.run(ksteps, 3, use_graph=not a.no_graph)
