@@ -963,7 +963,30 @@ def video_host_probe(ms, ctx, seconds=2.0, batch=32, depth=3):
                     "(23.9 GB/s up + 21.2 GB/s down)"}
 
 
-def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None, shape="", step_legs=8192, max_legs=98304, extras=True):
+def search_counts(measure, counts, start):
+    """the largest of `counts` (ascending) that fits, by plugin_path_probe's rule: from counts[start] up a step at a time while the
+    count fits (three more at most), else the counts below are bisected.  measure(count) -> {"fits": bool, ..}; -> the best run or None"""
+    best, d = None, measure(counts[start])
+    if d["fits"]:
+        best = d
+        for i in range(start + 1, min(start + 4, len(counts))):
+            d = measure(counts[i])
+            if not d["fits"]:
+                break
+            best = d
+    else:  # (a noisy host must not cost a run per step)
+        lo, hi = -1, start
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            d = measure(counts[mid])
+            if d["fits"]:
+                best, lo = d, mid
+            else:
+                hi = mid
+    return best
+
+
+def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step_legs=8192, max_legs=98304, extras=True):
     """How many FULL call legs a mediastreamer2-shaped process carries through the DROP-IN PLUGIN (never part of `value`):
     tests/host/plugin_bench builds N legs of  source -> MSResample 16k->48k -> MSSpeexEC (128 ms) -> MSVolume (AGC) ->
     MSAudioMixer (conferences of 32)  from the factory's ids after libmsmi355xfilters_init (audiostream.c:1798-1810 in
@@ -972,13 +995,14 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None, shape="", ste
 
     The rules, all of them:
       * a run = `warmup` paced ticks from the attach on (reported apart as from_attach: a start-up stall is visible, not folded
-        into capacity), then `ticks` (1000) paced ticks; a tick costs what the slowest ticker needs;
+        into capacity), then `ticks` (600) paced ticks; a tick costs what the slowest ticker needs;
       * a count FITS when no tick of the run reaches 10 ms (ticks_over_10ms == 0) and no ticker ever started a step a whole
         interval late (max_backlog_ms < 10, msticker_late_events == 0).  Strict: p99 is reported, not the criterion;
       * every count is measured the same way whether the search comes from below or from above: one run, and a second one if
         the first did not fit (the host's CPUs are shared; both runs are listed) -- it fits if either did;
-      * the search starts at `first_legs`, steps of 8192 legs (16 conferences of 32 per ticker): up while the count fits (to
-        98 304 at most), else down until one fits; `legs` is the largest count that fit."""
+      * the search starts at `first_legs`, steps of 8192 legs (16 conferences of 32 per ticker): up a step at a time while the
+        count fits (three more at most), else the counts below are bisected; `legs` is the largest count that fit;
+        `legs_p99_criterion` reads the same runs by round 4's rule (p99 < 10 ms, never a whole interval behind)."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
     plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
@@ -1013,31 +1037,20 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None, shape="", ste
         best = None
         for _ in range(2):
             d = run(legs, ticks)
-            tried.append({k: d.get(k) for k in keep})
+            # round 4's criterion beside the strict one (so that the two rounds' figures can be compared): p99 < 10 ms, never a whole interval behind
+            d["fits_p99"] = bool(d["p99_ms"] < 10.0 and d["max_backlog_ms"] < 10.0 and d["msticker_late_events"] == 0)
+            tried.append({k: d.get(k) for k in keep + ("fits_p99",)})
             if log:
-                log({"plugin_path": {k: d.get(k) for k in keep if k != "slow_ticks"}})
+                log({"plugin_path" + ("_" + shape if shape else ""): {k: d.get(k) for k in keep + ("fits_p99",) if k != "slow_ticks"}})
             best = d if best is None or d["fits"] else best
             if d["fits"]:
                 break
         return best
 
     step = max(tickers * 32, step_legs // (tickers * 32) * (tickers * 32))
-    legs = max(step, first_legs // step * step)
-    best, d = None, measure(legs)
-    if d["fits"]:
-        best = d
-        while legs + step <= max_legs:
-            d = measure(legs + step)
-            if not d["fits"]:
-                break
-            best, legs = d, legs + step
-    else:
-        while legs > step:
-            legs -= step
-            d = measure(legs)
-            if d["fits"]:
-                best = d
-                break
+    counts = list(range(step, max_legs + 1, step))
+    start = min(range(len(counts)), key=lambda i: abs(counts[i] - first_legs))
+    best = search_counts(measure, counts, start)
     out = {"cadence": "paced: one tick per 10 ms of wall time on every ticker, warm-up included",
            "what": "full call legs through the drop-in plugin, PCIe included: source -> MSResample 16k->48k -> MSSpeexEC (128 ms tail) -> MSVolume (AGC) "
                    "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
@@ -1045,6 +1058,8 @@ def plugin_path_probe(first_legs, ticks=1000, warmup=40, log=None, shape="", ste
                    "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl)",
            "fits_definition": "no tick of 1000 paced ticks reaches 10 ms, no step starts a whole interval late; see the function's docstring",
            "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
+    p99_ok = [t["legs"] for t in tried if t.get("fits_p99")]
+    out["legs_p99_criterion"] = max(p99_ok) if p99_ok else 0   # round 4's reading of the same runs: the largest count tried with p99 < 10 ms
     if best is None:
         out.update({"fits": False, "legs": 0})
         return out
@@ -1509,7 +1524,7 @@ def short_line(full, detail_name):
     if pp:
         out["plugin_path"] = _pick(pp, "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
                                    "launches_per_tick", "syncs_per_tick", "max_backlog_ms", "host_cores_granted",
-                                   "legs_per_host_core", "host_cores_for_value", "fits", "error")
+                                   "legs_per_host_core", "host_cores_for_value", "legs_p99_criterion", "fits", "error")
         eq = pp.get("fused_equals_one_by_one_4096_legs")
         if eq:
             out["plugin_path"]["fused_equals_one_by_one"] = eq.get("equal")
@@ -1521,7 +1536,7 @@ def short_line(full, detail_name):
     for key in ("plugin_path_server",):
         if full.get(key):
             out[key] = _pick(full[key], "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
-                             "launches_per_tick", "pcie_bytes_per_leg_tick", "fits", "error")
+                             "launches_per_tick", "pcie_bytes_per_leg_tick", "legs_p99_criterion", "fits", "error")
     if "scaler_mpix_per_s" in full:
         sc = full["scaler_mpix_per_s"]
         out["scaler"] = {"mpix_per_s": sc.get("value"), "frac": sc.get("hbm_frac"), "frames_per_s": sc.get("frames_per_s")}
@@ -1975,7 +1990,7 @@ def main():
             try:
                 line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)
                 try:  # a conference SERVER's remote members (volrecv -> mixer -> G.711 encoder, no canceller: filters/server_leg.inl)
-                    sv = plugin_path_probe(65536, log=log, shape="server", step_legs=16384, max_legs=196608, extras=False)
+                    sv = plugin_path_probe(65536, log=log, shape="server", step_legs=32768, max_legs=131072, extras=False)
                     sv["what"] = ("a conference server's REMOTE members through the plugin, PCIe included: 8 kHz source (decoder .. dtmfgen) -> MSVolume (volrecv) -> "
                                   "in_resampler -> MSAudioMixer (conferences of 32) -> out_resampler -> MSUlawEnc -> sink (audioconference.c:121-179,209-257); metered, "
                                   "queued, mixed and ENCODED in one batch per ticker")

@@ -208,3 +208,20 @@ def test_a_one_off_stall_in_the_sweeps_first_point_does_not_lower_the_proposal()
     assert first["streams"] == 16384 and first["fits"] and first["first_series_held_a_stall"]["at"] == 0
     assert first["first_series_held_a_stall"]["tick_ms_worst"] > 38.0
     assert d["value"] == 22528
+
+
+def test_the_plugin_probes_search_goes_up_by_steps_and_down_by_bisection():
+    """bench.search_counts (plugin_path_probe's search): from the first count up a step at a time while it fits, three more at most;
+    a first count that does not fit has the counts below it bisected -- every count measured by the same function"""
+    sys.path.insert(0, ROOT)
+    import bench
+    counts = list(range(8192, 98304 + 1, 8192))
+    for limit, want, most in ((60000, 57344, 3), (49152, 49152, 2), (30000, 24576, 4), (9000, 8192, 4), (4000, None, 4), (200000, 73728, 4)):
+        seen = []
+
+        def measure(c):
+            seen.append(c)
+            return {"fits": c <= limit, "legs": c}
+        got = bench.search_counts(measure, counts, counts.index(49152))
+        assert (got and got["legs"]) == want, (limit, got, seen)
+        assert seen[0] == 49152 and len(seen) <= most and len(set(seen)) == len(seen), (limit, seen)
