@@ -397,6 +397,72 @@ static void *conferences(void *arg) {
 	return NULL;
 }
 
+/* A conference SERVER's members (filters/server_leg.inl): source -> MSVolume -> in_resampler -> mixer pin -> out_resampler -> MSUlawEnc ->
+ * sink at 8 kHz, one PCM listener; fused into a ServerBank, methods between ticks, a burst of blocks beyond the launch rounds, a
+ * re-plumbing in mid-packet, AGC switched on (the conference leaves its batch), teardown with the encoders destroyed first. */
+static void *server_conferences(void *arg) {
+	enum { NM = 6 };
+	int16_t pcm[80];
+	void (*p_fused)(int *, int *, unsigned long long *, unsigned long long *) = (void (*)(int *, int *, unsigned long long *, unsigned long long *))arg;
+	for (int i = 0; i < 80; ++i) pcm[i] = (int16_t)(i * 131 % 5000 - 2500);
+	for (int rep = 0; rep < (g_rounds + 1) / 2; ++rep) {
+		MSTicker *tk = ms_ticker_new();
+		MSFilter *mx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+		MSFilter *src[NM], *vol[NM], *irs[NM], *ors[NM], *enc[NM], *snk[NM], *tap = ms2shim_new_sink(g_fac);
+		set_int(mx, MS_FILTER_SET_SAMPLE_RATE, 8000);
+		set_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
+		ms2shim_sink_set_discard(tap, 1);
+		for (int k = 0; k < NM; ++k) {
+			src[k] = ms2shim_new_source(g_fac), snk[k] = ms2shim_new_sink(g_fac);
+			vol[k] = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+			irs[k] = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), ors[k] = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
+			enc[k] = ms_factory_create_filter(g_fac, k % 2 ? MS_ALAW_ENC_ID : MS_ULAW_ENC_ID);
+			CHECK(src[k] && snk[k] && vol[k] && irs[k] && ors[k] && enc[k]);
+			ms2shim_sink_set_discard(snk[k], 1);
+			set_int(vol[k], MS_FILTER_SET_SAMPLE_RATE, 8000);
+			set_int(irs[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(irs[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
+			set_int(ors[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(ors[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
+			ms_filter_link(src[k], 0, vol[k], 0), ms_filter_link(vol[k], 0, irs[k], 0), ms_filter_link(irs[k], 0, mx, k);
+			ms_filter_link(mx, k, ors[k], 0), ms_filter_link(ors[k], 0, enc[k], 0), ms_filter_link(enc[k], 0, snk[k], 0);
+		}
+		ms_filter_link(mx, NM + 1, tap, 0); /* a listener above the members */
+		CHECK(ms_ticker_attach(tk, mx) == 0);
+		for (int t = 0; t < 16; ++t) {
+			for (int k = 0; k < NM; ++k) {
+				const int blocks = (t == 6 && k == 2) ? 7 : 1; /* a burst: more blocks in one tick than the bank has launch rounds */
+				for (int b = 0; b < blocks; ++b) ms2shim_source_push(src[k], pcm, sizeof pcm);
+			}
+			ms_ticker_step(tk);
+			if (t == 2) {
+				int nc = 0, nl = 0;
+				p_fused(&nc, &nl, NULL, NULL);
+				CHECK(nc >= 1 && nl >= NM);
+			}
+			if (t == 4) { float g = 0.5f; ms_filter_call_method(vol[1], MS_VOLUME_SET_GAIN, &g); }
+			if (t == 5) { MSAudioMixerCtl ctl; ctl.pin = 3; ctl.param.active = 0; ms_filter_call_method(mx, MS_AUDIO_MIXER_SET_ACTIVE, &ctl); }
+			if (t == 9) { /* re-plumbed with half a packet filled: fuses again */
+				ms_ticker_detach(tk, mx);
+				CHECK(ms_ticker_attach(tk, mx) == 0);
+			}
+			if (t == 12) { int on = 1; ms_filter_call_method(vol[4], MS_VOLUME_ENABLE_AGC, &on); } /* the conference leaves its batch */
+		}
+		ms_ticker_detach(tk, mx);
+		for (int k = 0; k < NM; ++k) { /* the encoders go first */
+			ms_filter_unlink(ors[k], 0, enc[k], 0), ms_filter_unlink(enc[k], 0, snk[k], 0);
+			ms_filter_destroy(enc[k]);
+		}
+		for (int k = 0; k < NM; ++k) {
+			ms_filter_unlink(src[k], 0, vol[k], 0), ms_filter_unlink(vol[k], 0, irs[k], 0), ms_filter_unlink(irs[k], 0, mx, k), ms_filter_unlink(mx, k, ors[k], 0);
+			ms_filter_destroy(src[k]), ms_filter_destroy(vol[k]), ms_filter_destroy(irs[k]), ms_filter_destroy(ors[k]), ms_filter_destroy(snk[k]);
+		}
+		ms_filter_unlink(mx, NM + 1, tap, 0);
+		ms_filter_destroy(tap);
+		ms_filter_destroy(mx);
+		ms_ticker_destroy(tk);
+	}
+	return NULL;
+}
+
 static void *walker(void *arg) {
 	long walks = 0;
 	(void)arg;
@@ -411,7 +477,7 @@ static void *walker(void *arg) {
 }
 
 int main(int argc, char **argv) {
-	pthread_t th[6];
+	pthread_t th[7];
 	void *p_fused = NULL;
 	void *walks = NULL;
 	int h, b, s;
@@ -443,9 +509,11 @@ int main(int argc, char **argv) {
 	for (int i = 0; i < 3; ++i) pthread_create(&th[i], NULL, caller, (void *)(intptr_t)(i + 1));
 	pthread_create(&th[4], NULL, grower, NULL);
 	pthread_create(&th[5], NULL, conferences, p_fused);
+	pthread_create(&th[6], NULL, server_conferences, p_fused);
 	for (int i = 0; i < 3; ++i) pthread_join(th[i], NULL);
 	pthread_join(th[4], NULL);
 	pthread_join(th[5], NULL);
+	pthread_join(th[6], NULL);
 	__atomic_store_n(&g_stop, 1, __ATOMIC_SEQ_CST);
 	pthread_join(th[3], &walks);
 	p_flush(); /* nothing is running any more */
