@@ -53,7 +53,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def the_line(r):
     """stdout is exactly ONE line, JSON, short enough for the driver to keep whole (it keeps the last 7 999 characters; round 4's
     26.5 KB line lost its head and the round went unmeasured), with the contract's keys; the full record is in the detail file"""
-    lines = [ln for ln in r.stdout.splitlines() if "peer ranks" not in ln]  # (the test transport's own chatter, interleaved between ranks)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and "peer ranks" not in ln]  # (the test transport's own chatter, interleaved between ranks, its newlines)
     assert len(lines) == 1 and lines[0].startswith("{"), (r.stdout[-2000:], r.stderr[-2000:])  # ONE line, from rank 0 only
     assert len(lines[0]) < 6000, len(lines[0])
     d = json.loads(lines[0])
