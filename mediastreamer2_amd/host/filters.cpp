@@ -44,7 +44,7 @@
 
 extern "C" { // the descriptors (defined at the end of this file): the fused chain recognises its facades by them
 extern MSFilterDesc ms_mi355x_resample_desc, ms_mi355x_audio_mixer_desc, ms_mi355x_volume_desc, ms_mi355x_speex_ec_desc, ms_mi355x_webrtc_aec_name_desc;
-extern MSFilterDesc ms_mi355x_alaw_enc_desc, ms_mi355x_ulaw_enc_desc;
+extern MSFilterDesc ms_mi355x_alaw_enc_desc, ms_mi355x_ulaw_enc_desc, ms_mi355x_alaw_dec_desc, ms_mi355x_ulaw_dec_desc;
 }
 
 namespace {
@@ -693,9 +693,9 @@ MSScalerDesc ms_mi355x_scaler_desc = {sd_create, sd_process, sd_free};
 
 // the stages either side of the path
 MSFilterDesc ms_mi355x_alaw_dec_desc = {MS_ALAW_DEC_ID, "MSAlawDec", "ITU-G.711 alaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcma", 1, 1,
-                                        g711_dec_init_a, NULL, g711_dec_process, generic_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_dec_init_a, NULL, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_dec_desc = {MS_ULAW_DEC_ID, "MSUlawDec", "ITU-G.711 ulaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcmu", 1, 1,
-                                        g711_dec_init_u, NULL, g711_dec_process, generic_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_dec_init_u, NULL, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_alaw_enc_desc = {MS_ALAW_ENC_ID, "MSAlawEnc", "ITU-G.711 alaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcma", 1, 1,
                                         g711_enc_init_a, NULL, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_enc_desc = {MS_ULAW_ENC_ID, "MSUlawEnc", "ITU-G.711 ulaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcmu", 1, 1,

@@ -153,9 +153,14 @@ struct MapFilter { // AlawEncData alaw.c:25-30 / EncState l16.c:22-29 / AdapterS
 	// leaving its batch: the facade's own next packet starts with it)
 	bool sleg;
 	void *sleg_bank;
+	void *sleg_leg; // a DECODER that heads a fused member: its ServerLeg
 	mblk_t *pending;
+	bool fuse_checked; // a decoder: looked for a conference to fuse with since the last attach
 };
 void server_encoder_gone(MSFilter *e); // server_leg.inl
+void server_stage_codes(MSFilter *f, MapFilter *d);
+Pool *server_pool_of_map(MapFilter *d);
+MSFilter *leg_volume_sink(MSFilter *vol);
 
 MapFilter *map_new(MSFilter *f) {
 	MapFilter *d = (MapFilter *)ms_malloc0(sizeof(MapFilter));
@@ -218,8 +223,29 @@ void copy_payload(const mblk_t *m, uint8_t *dst) {
 // ---- G.711 decoders: alaw_dec_process alaw.c:208-221 (ulaw.c the same with Snack_Mulaw2Lin)
 void g711_dec_init_a(MSFilter *f) { map_new(f)->law = 0; }
 void g711_dec_init_u(MSFilter *f) { map_new(f)->law = 1; }
+void g711_dec_postprocess(MSFilter *f) {
+	MapFilter *d = (MapFilter *)f->data;
+	facade_detached(f);
+	if (d->sleg) server_encoder_gone(f);
+	d->fuse_checked = false;
+}
 void g711_dec_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
+	if (!d->sleg && !d->fuse_checked && f->ticker && f->inputs[0] && !ms_queue_empty(f->inputs[0])) {
+		// the first packet since the attach: decoder -> MSVolume -> [in_resampler ->] a conference mixer whose members are all remote endpoints?
+		d->fuse_checked = true;
+		MSFilter *vol = f->outputs[0] ? f->outputs[0]->next.filter : NULL;
+		MSFilter *mx = (vol && vol->desc == &ms_mi355x_volume_desc) ? leg_volume_sink(vol) : NULL;
+		if (mx && mx->desc == &ms_mi355x_audio_mixer_desc) {
+			HubLock lk(f);
+			conf_try_fuse(mx);
+		}
+	}
+	if (d->sleg) { // the head of a conference server's member: the packet goes into the conference's bank as it is
+		HubLock lk(f, server_pool_of_map(d));
+		server_stage_codes(f, d);
+		return;
+	}
 	map_rehome(f, d);
 	HubLock lk(f);
 	if (!map_attach(f, d, d->law ? OP_ULAW_DEC : OP_ALAW_DEC)) {

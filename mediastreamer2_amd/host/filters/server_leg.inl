@@ -36,6 +36,7 @@ struct ServerLeg {
 	int slot, pin;
 	MSFilter *vol, *mixer;
 	MSFilter *enc = nullptr;   // the pin's output is encoded in the batch (MSAlawEnc / MSUlawEnc of this plugin), else PCM
+	MSFilter *dec = nullptr;   // the leg's HEAD is MSAlawDec / MSUlawDec of this plugin right in front of MSVolume: its packets are staged as they are and decoded in the batch
 	int staged = 0;            // blocks staged since the last enqueue (launch rounds)
 	int new_samples = 0;       // samples MSVolume put on the mixer's queue since the mixer last looked
 	int chan_samples = 0;      // the mixer channel's bufferizer, samples (what f_chan holds)
@@ -50,6 +51,11 @@ struct ServerBank : Pool {
 	mi_mixer *mix = nullptr;
 	int16_t *h_in, *d_in;        // [kMaxRounds][nlegs][cap] / [nlegs][cap]
 	int32_t *h_n, *d_n;          // [kMaxRounds][nlegs]
+	// legs headed by a G.711 decoder: the packets' bytes [kMaxRounds][nlegs][cap], and the rounds' counts by kind -- [0] MSVolume-headed,
+	// [1] A-law, [2] mu-law, [3] either law -- built at enqueue from h_n (only while the bank holds such legs: ndec)
+	uint8_t *h_cin = nullptr;
+	int32_t *h_nk[4] = {nullptr, nullptr, nullptr, nullptr};
+	int ndec = 0;
 	int16_t *d_mix, *d_scratch;  // [capacity][mm][ns]; [nlegs][ns]
 	uint8_t *h_codes, *d_codes;  // [nlegs][ns]: the encoded pins' G.711 bytes of this flush
 	int32_t *h_len[2], *d_len[2]; // [nlegs] per law: ns where the pin's mix is encoded with that law in this launch, else 0
@@ -106,6 +112,8 @@ struct ServerBank : Pool {
 		d_n = devmem<int32_t>(kMaxRounds * L);
 		d_mix = devmem<int16_t>(L * ns);
 		d_scratch = devmem<int16_t>(L * ns);
+		h_cin = pinned<uint8_t>(kMaxRounds * L * cap);
+		for (int k = 0; k < 4; ++k) h_nk[k] = pinned<int32_t>(kMaxRounds * L);
 		h_codes = pinned<uint8_t>(L * ns);
 		d_codes = devmem<uint8_t>(L * ns);
 		for (int law = 0; law < 2; ++law) {
@@ -279,10 +287,43 @@ struct ServerBank : Pool {
 			ticked |= conf_ready[(size_t)c] != 0;
 		}
 		if (failed) return false;
-		bool any = false;
+		bool any = false, any_dev = false;
 		// ---- the device's half: every block metered and levelled as a block, then on to the channel's queue
+		if (ndec > 0 && rounds) { // the rounds' counts by kind of head
+			for (int r = 0; r < rounds; ++r)
+				for (size_t s = 0; s < UL; ++s) {
+					const ServerLeg *leg = legs[s];
+					const int n = h_n[(size_t)r * L + s];
+					const int kind = (leg && leg->dec) ? 1 + ((MapFilter *)leg->dec->data)->law : 0;
+					for (int k = 0; k < 3; ++k) h_nk[k][(size_t)r * L + s] = k == kind ? n : 0;
+					h_nk[3][(size_t)r * L + s] = kind ? n : 0;
+				}
+		}
 		if (rounds && !zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_n, h_n, (size_t)rounds * L * 4));
-		for (int r = 0; r < rounds; ++r) {
+		for (int r = 0; ndec > 0 && r < rounds; ++r) { // banks with decoder-headed legs: decode, then level and queue the two kinds of rows apart
+			const size_t ro = (size_t)r * L;
+			bool any[4] = {false, false, false, false};
+			for (size_t s = 0; s < UL; ++s)
+				for (int k = 0; k < 4; ++k) any[k] |= h_nk[k][ro + s] > 0;
+			for (int law = 0; law < 2; ++law)
+				if (any[1 + law]) {
+					MI_MUST(mi_g711_decode(ctx, law ? MI_LAW_PCMU : MI_LAW_PCMA, h_cin + ro * cap, (size_t)cap, d_in, (size_t)cap, h_nk[1 + law] + ro, cap, UL));
+					++launches;
+				}
+			if (any[3]) {
+				MI_MUST(mi_volume_process(vol, d_in, cap, cap, h_nk[3] + ro));
+				MI_MUST(mi_fifo_push(f_chan, d_in, cap, cap, h_nk[3] + ro));
+				launches += 2;
+			}
+			if (any[0]) {
+				MI_MUST(mi_volume_process(vol, h_in + ro * cap, cap, cap, h_nk[0] + ro));
+				MI_MUST(mi_fifo_push(f_chan, h_in + ro * cap, cap, cap, h_nk[0] + ro));
+				launches += 2;
+			}
+			if (r + 1 < rounds) meter_round(UL);
+			any_dev = mixed = true;
+		}
+		for (int r = 0; ndec == 0 && r < rounds; ++r) {
 			// (zero copy: the launches read the block's n samples where they lie in pinned memory and level them in place -- what
 			// crosses PCIe is the audio, not the rows' capacity)
 			const int32_t *cnt = (zero_copy ? h_n : d_n) + (size_t)r * L;
@@ -294,6 +335,7 @@ struct ServerBank : Pool {
 			if (r + 1 < rounds) meter_round(UL);
 			any = mixed = true;
 		}
+		any |= any_dev;
 		if (ticked) {
 			if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_run, h_run, (size_t)capacity));
 			MI_MUST(mi_mixer_process_volume_fifo_flags(mix, vol_id, 0, f_chan, d_mix, MI_VOLMIX_DRY_SKIPS, zero_copy ? h_run : d_run));
@@ -523,6 +565,39 @@ void server_stage(MSFilter *f, VolumeData *d) {
 	}
 }
 
+// MSAlawDec / MSUlawDec as the leg's head: every packet it is handed becomes a row of code bytes (alaw_dec_process, alaw.c:208-221:
+// one output block per packet -- which MSVolume without AGC then meters as a block)
+void server_stage_codes(MSFilter *f, MapFilter *d) {
+	ServerLeg *leg = (ServerLeg *)d->sleg_leg;
+	ServerBank *b = leg->bank;
+	const size_t L = (size_t)b->nlegs;
+	if (b->failed) {
+		if (!ms_queue_empty(f->inputs[0])) g_late_events.fetch_add(1, std::memory_order_relaxed);
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
+	if (!d->bz) d->bz = ms_bufferizer_new(); // (a queue of whole packets beyond a tick's launch rounds)
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) putq(&d->bz->q, m);
+	while (leg->staged < kMaxRounds) {
+		mblk_t *m = getq(&d->bz->q);
+		if (!m) break;
+		const size_t n = msgdsize(m);
+		if (n == 0 || n > (size_t)b->cap) { // an empty packet makes an empty block (nothing to meter or mix); an absurdly long one is refused as the facade refuses it
+			if (n) ms_error("msmi355x plugin: %s: packet of %zu bytes refused", f->desc->name, n);
+			freemsg(m);
+			continue;
+		}
+		copy_payload(m, b->h_cin + ((size_t)leg->staged * L + (size_t)leg->slot) * b->cap);
+		freemsg(m);
+		b->h_n[(size_t)leg->staged * L + (size_t)leg->slot] = (int)n;
+		leg->staged++;
+	}
+	if (leg->staged) {
+		b->staged_since = true;
+		request_flush(f);
+	}
+}
+
 // every conference of the bank has been walked in this tick: the bank's work leaves now (leg_conf_walked)
 void server_conf_walked(ServerBank *b, int c) {
 	if (b->no_early || b->failed || b->early || !b->hub->ticker) return;
@@ -553,7 +628,9 @@ MSFilter *server_find_encoder(MSFilter *mx, int pin, int rate) {
 	return g;
 }
 
-bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out) {
+bool is_g711_dec(const MSFilterDesc *d) { return d == &ms_mi355x_alaw_dec_desc || d == &ms_mi355x_ulaw_dec_desc; }
+
+bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out, MSFilter **dec_out) {
 	MSQueue *q = mx->inputs[pin];
 	MSFilter *vol = q->prev.filter;
 	if (is_pass_resampler(vol, mx->ticker)) { // the endpoint's in_resampler, forwarding
@@ -565,8 +642,19 @@ bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out)
 	// MSVolume must be handed its blocks IN the graph walk -- by a filter that is not one of this plugin's (dtmfgen stands in front
 	// of volrecv in an AudioStream, audiostream.c:1826; a CPU decoder; a sound card): a facade of ours delivers with the flush, a tick
 	// later, and the conference would tick before its members' blocks arrive.  Such a conference keeps its facades.
+	// ... unless that facade is a G.711 decoder of ours which is itself handed its packets in the walk (rtprecv in front of it): then
+	// the DECODER is the leg's head -- its packets are staged as they are and decoded in the batch (80 bytes per 10 ms up instead of 160)
 	MSQueue *qin = vol->inputs[0];
-	if (!qin || !qin->prev.filter || is_ours(qin->prev.filter->desc)) return false;
+	*dec_out = nullptr;
+	if (!qin || !qin->prev.filter) return false;
+	if (is_ours(qin->prev.filter->desc)) {
+		MSFilter *dec = qin->prev.filter;
+		MapFilter *dd = (MapFilter *)dec->data;
+		MSQueue *qd = dec->inputs[0];
+		if (!is_g711_dec(dec->desc) || dec->ticker != mx->ticker || ms->rate != 8000 || !ms_queue_empty(qin) || !qd || !qd->prev.filter || is_ours(qd->prev.filter->desc)) return false;
+		if (dd->sleg || (dd->pool && (!dd->pool->staged[(size_t)dd->slot].empty() || !dd->pool->ready[(size_t)dd->slot].empty()))) return false;
+		*dec_out = dec;
+	}
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (volume_is_peered(vd) || vd->sample_rate != ms->rate || vd->leg || vd->sleg || vd->p.agc_enabled) return false;
 	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
@@ -581,12 +669,14 @@ bool server_try_fuse(MSFilter *mx) {
 	if (getenv("MSMI355X_NO_FUSE") != nullptr || getenv("MSMI355X_NO_FUSE_SERVER") != nullptr) return false;
 	if (!ms->pool || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 800) return false;
 	std::vector<std::pair<int, MSFilter *>> cand;
+	std::vector<MSFilter *> heads; // per candidate: the decoder that heads the leg, or NULL (MSVolume does)
 	int maxpin = -1;
 	for (int pin = 0; pin < mx->desc->ninputs; ++pin) {
 		if (!mx->inputs[pin]) continue;
-		MSFilter *vol = nullptr;
-		if (!server_candidate(mx, ms, pin, &vol)) return false;
+		MSFilter *vol = nullptr, *dec = nullptr;
+		if (!server_candidate(mx, ms, pin, &vol, &dec)) return false;
 		cand.push_back({pin, vol});
+		heads.push_back(dec);
 		maxpin = pin;
 	}
 	if (cand.empty()) return false;
@@ -633,11 +723,18 @@ bool server_try_fuse(MSFilter *mx) {
 				((MapFilter *)e->data)->sleg = true;
 				++nenc;
 			}
-	for (const auto &pv : cand) {
+	for (size_t ci = 0; ci < cand.size(); ++ci) {
+		const auto &pv = cand[ci];
 		ServerLeg *leg = new ServerLeg();
 		leg->bank = b, leg->slot = s0 + pv.first, leg->pin = pv.first;
 		leg->vol = pv.second, leg->mixer = mx;
 		leg->enc = b->encs[(size_t)leg->slot];
+		if (MSFilter *dec = heads[ci]) {
+			MapFilter *dd = (MapFilter *)dec->data;
+			leg->dec = dec;
+			dd->sleg = true, dd->sleg_bank = b, dd->sleg_leg = leg;
+			b->ndec++;
+		}
 		b->legs[(size_t)leg->slot] = leg;
 		VolumeData *vd = (VolumeData *)pv.second->data;
 		if (vd->pool) {
@@ -678,6 +775,25 @@ void server_unfuse(MSFilter *mx, bool keep_running) {
 		ServerLeg *leg = b->legs[s];
 		if (!leg) continue;
 		VolumeData *vd = (VolumeData *)leg->vol->data;
+		if (leg->dec) { // the decoder takes back what it staged in a walk whose launches never left, and what waited behind that
+			MapFilter *dd = (MapFilter *)leg->dec->data;
+			for (int r = 0; r < leg->staged; ++r) {
+				const int n = b->h_n[(size_t)r * b->nlegs + s];
+				mblk_t *m = allocb((size_t)n, 0);
+				memcpy(m->b_wptr, b->h_cin + ((size_t)r * b->nlegs + s) * b->cap, (size_t)n);
+				m->b_wptr += n;
+				if (leg->dec->inputs[0]) putq(&leg->dec->inputs[0]->q, m);
+				else freemsg(m);
+			}
+			leg->staged = 0;
+			if (dd->bz)
+				for (mblk_t *m; (m = getq(&dd->bz->q)) != NULL;) {
+					if (leg->dec->inputs[0]) putq(&leg->dec->inputs[0]->q, m);
+					else freemsg(m);
+				}
+			dd->sleg = false, dd->sleg_bank = nullptr, dd->sleg_leg = nullptr;
+			b->ndec--;
+		}
 		if (!b->failed) { // MSVolume's running state goes with the filter (volume.inl: VolumeData::kept)
 			vd->kept = b->vstate[s];
 			if (b->vs_dirty[s]) {
@@ -722,6 +838,7 @@ void server_disqualify(ServerLeg *leg) {
 bool server_wants_out(ServerLeg *leg) { return leg && ((MixerState *)leg->mixer->data)->unfuse_wanted; }
 Pool *server_pool(ServerLeg *leg) { return leg->bank; }
 Pool *server_pool_of(ServerBank *b) { return b; }
+Pool *server_pool_of_map(MapFilter *d) { return (ServerBank *)d->sleg_bank; }
 mi_volume_state *server_vstate(ServerLeg *leg) { return &leg->bank->vstate[(size_t)leg->slot]; }
 void server_push_volume(ServerLeg *leg, const mi_volume_params *p, const float *gain, const float *target) {
 	ServerBank *b = leg->bank;
@@ -754,12 +871,12 @@ void server_push_mixer_controls(MSFilter *f, MixerState *s, bool from_method) {
 	else b->next_conf[(size_t)s->sconf] = 0, b->ctl_dirty = true;
 }
 // the encoder of a fused pin was detached or destroyed: its conference leaves the batch
-void server_encoder_gone(MSFilter *e) {
+void server_encoder_gone(MSFilter *e) { // (an encoder OR a decoder of a fused member)
 	MapFilter *d = (MapFilter *)e->data;
 	if (!d->sleg || !d->sleg_bank) return;
 	ServerBank *b = (ServerBank *)d->sleg_bank;
-	MSFilter *mx = nullptr;
-	{
+	MSFilter *mx = d->sleg_leg ? ((ServerLeg *)d->sleg_leg)->mixer : nullptr;
+	if (!mx) {
 		HubLock lk(b->hub);
 		for (size_t s = 0; s < b->encs.size() && !mx; ++s)
 			if (b->encs[s] == e) mx = b->owner[s / (size_t)b->mm];

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fused_graph as fg  # noqa: E402
 
 IDS = fg.IDS
-MS_ULAW_ENC_ID, MS_ALAW_ENC_ID = 7, 9
+MS_ULAW_ENC_ID, MS_ULAW_DEC_ID, MS_ALAW_ENC_ID, MS_ALAW_DEC_ID = 7, 8, 9, 10
 SET_RATE, SET_OUT_RATE = IDS["MS_FILTER_SET_SAMPLE_RATE"], IDS["MS_FILTER_SET_OUTPUT_SAMPLE_RATE"]
 ADD_FMTP = IDS["MS_FILTER_ADD_FMTP"]
 MIX_SET_ACTIVE = fg.mid(fg.MS_AUDIO_MIXER_ID, 1, 8)
@@ -36,7 +36,8 @@ class MixerCtl(C.Structure):
 class ServerConferences:
     """nconf conferences of `members` remote endpoints each on one ticker"""
 
-    def __init__(self, h, nconf, members, rate=8000, law="u", ptime=0, endpoint_resamplers=True, pcm_pins=(), pins=None, gain=None, listener=False):
+    def __init__(self, h, nconf, members, rate=8000, law="u", ptime=0, endpoint_resamplers=True, pcm_pins=(), pins=None, gain=None, listener=False,
+                 decoders=()):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -51,7 +52,10 @@ class ServerConferences:
             for k in range(members):
                 pin = self.pins[k]
                 leg = {"src": S.ms2shim_new_source(h.fac), "vol": S.ms_factory_create_filter(h.fac, fg.MS_VOLUME_ID), "out": S.ms2shim_new_sink(h.fac),
-                       "mixer": mx, "pin": pin, "enc": None}
+                       "mixer": mx, "pin": pin, "enc": None, "dec": None}
+                leg["law"] = law if law in ("a", "u") else ("a" if k % 2 else "u")   # "mixed": alternate
+                if rate == 8000 and (decoders is True or k in decoders):   # the source hands over G.711 packets (rtprecv): MSAlawDec / MSUlawDec of the plugin in front of volrecv
+                    leg["dec"] = S.ms_factory_create_filter(h.fac, MS_ALAW_DEC_ID if leg["law"] == "a" else MS_ULAW_DEC_ID)
                 h.call_int(leg["vol"], SET_RATE, rate)
                 if gain is not None:
                     h.call_float(leg["vol"], fg.VOL_SET_GAIN, gain)
@@ -68,16 +72,15 @@ class ServerConferences:
                     links += [(leg["vol"], 0, mx, pin)]
                     tail = (mx, pin)
                 if rate == 8000 and k not in pcm_pins:
-                    this_law = law if law in ("a", "u") else ("a" if k % 2 else "u")   # "mixed": alternate
+                    this_law = leg["law"]
                     leg["enc"] = S.ms_factory_create_filter(h.fac, MS_ALAW_ENC_ID if this_law == "a" else MS_ULAW_ENC_ID)
-                    leg["law"] = this_law
                     if ptime:
                         fmtp = f"ptime={ptime}".encode()
                         assert S.ms_filter_call_method(leg["enc"], ADD_FMTP, C.c_char_p(fmtp)) == 0
                     links += [(tail[0], tail[1], leg["enc"], 0), (leg["enc"], 0, leg["out"], 0)]
                 else:
                     links += [(tail[0], tail[1], leg["out"], 0)]
-                links = [(leg["src"], 0, leg["vol"], 0)] + links
+                links = ([(leg["src"], 0, leg["dec"], 0), (leg["dec"], 0, leg["vol"], 0)] if leg["dec"] else [(leg["src"], 0, leg["vol"], 0)]) + links
                 for a, pa, b, pb in links:
                     assert S.ms_filter_link(a, pa, b, pb) == 0, (a, pa, b, pb)
                 self.legs.append(leg)
@@ -104,7 +107,7 @@ class ServerConferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("src", "vol", "out", "in_rs", "out_rs", "enc"):
+            for k in ("src", "vol", "out", "in_rs", "out_rs", "enc", "dec"):
                 if leg.get(k):
                     self.S.ms_filter_destroy(leg[k])
         for f in self.mixers + self.extra:
@@ -135,12 +138,22 @@ def run(plugin_dir, fuse, scenario, h=None):
         os.environ["MSMI355X_NO_EARLY_LAUNCH"] = "1"
     os.environ["MSMI355X_CHECK_LEVELS"] = "1"
     h = h or fg.Host(plugin_dir)
-    sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, endpoint_resamplers=True, pcm_pins=(), pins=None, gain=None, listener=False)
+    sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, endpoint_resamplers=True, pcm_pins=(), pins=None, gain=None, listener=False,
+              decoders=())
     sc.update(scenario)
     conf = ServerConferences(h, sc["nconf"], sc["members"], sc["rate"], sc["law"], sc["ptime"], sc["endpoint_resamplers"], sc["pcm_pins"], sc["pins"], sc["gain"],
-                             sc["listener"])
+                             sc["listener"], sc["decoders"])
     n, nt, ns = sc["nconf"] * sc["members"], sc["nticks"], sc["rate"] // 100
     pcm = signals(n, nt, sc["rate"], seed=sc.get("seed", 5))
+    codes = {}
+    if any(leg["dec"] for leg in conf.legs):   # what the endpoints send: their audio as G.711 (the oracle's encoder, pinned against the reference's g711.c)
+        import oracle
+        oracle.build()
+        codes = {s: oracle.g711_encode(0 if leg["law"] == "a" else 1, pcm[s]) for s, leg in enumerate(conf.legs) if leg["dec"]}
+
+    def push(leg, s, lo, hi):
+        a = np.ascontiguousarray(codes[s][lo:hi] if leg["dec"] else pcm[s, lo:hi])
+        h.S.ms2shim_source_push(leg["src"], a.ctypes.data, a.nbytes)
     late0, before = h.P.ms_mi355x_late_events(), h.runtime_stats()
     conf.attach()
     mid_stats, meters = None, []
@@ -151,14 +164,14 @@ def run(plugin_dir, fuse, scenario, h=None):
                 continue
             if sc.get("ptime20_in"):   # 20 ms packets: a block of two ticks every other tick
                 if (t + s) % 2 == 0:
-                    h.push(leg["src"], pcm[s, t * ns:(t + 2) * ns])
+                    push(leg, s, t * ns, (t + 2) * ns)
             elif sc.get("burst") and (t + 5 * s) % 23 == 7:
                 continue                                                         # a late packet ...
             elif sc.get("burst") and (t + 5 * s) % 23 == 8:
-                h.push(leg["src"], pcm[s, (t - 1) * ns:t * ns])                  # ... arrives with the next one: two blocks in one tick
-                h.push(leg["src"], pcm[s, t * ns:(t + 1) * ns])
+                push(leg, s, (t - 1) * ns, t * ns)                               # ... arrives with the next one: two blocks in one tick
+                push(leg, s, t * ns, (t + 1) * ns)
             else:
-                h.push(leg["src"], pcm[s, t * ns:(t + 1) * ns])
+                push(leg, s, t * ns, (t + 1) * ns)
         for ev in sc.get("events", []):
             if ev[0] != t:
                 continue
@@ -182,7 +195,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     res = {"out": [h.drain(leg["out"]).view(np.uint8) if leg["enc"] else h.drain(leg["out"]) for leg in conf.legs],
            "taps": [h.drain(t_) for t_ in conf.extra], "stats": mid_stats, "late": h.P.ms_mi355x_late_events() - late0,
            "levels": [h.get_float(leg["vol"], IDS["MS_VOLUME_GET_LINEAR"]) for leg in conf.legs], "meters": meters,
-           "laws": [leg.get("law") for leg in conf.legs]}
+           "laws": [leg.get("law") for leg in conf.legs], "decoded": sorted(codes)}
     conf.close()
     res["after"] = tuple(a - b for a, b in zip(h.runtime_stats(), before))
     res["pcm"] = pcm
@@ -202,6 +215,9 @@ SCENARIOS = {
     "reattach": {"events": [(41, "reattach", 0, 0), (77, "reattach", 0, 0)]},  # 41: half a 20 ms packet is filled when the graph is re-plumbed
     "agc_switched_on": {"events": [(50, "agc", 2, 1)]},                      # the conference leaves its batch and carries on one by one
     "wideband_pcm_48k": {"rate": 48000, "nticks": 80},                       # no encoder runs at this rate: every pin gets its PCM from the slab
+    # a G.711 bridge end to end: the endpoints' PACKETS in (MSUlawDec / MSAlawDec of the plugin head the legs), packets out; 80 + 80 bytes per member and tick
+    "g711_bridge_packets_of_20ms": {"decoders": True, "ptime20_in": True, "law": "mixed", "nticks": 100},
+    "g711_bridge_some_members_pcm": {"decoders": (0, 2), "burst": True, "nticks": 140, "events": [(60, "reattach", 0, 0)]},
 }
 
 

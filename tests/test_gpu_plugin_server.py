@@ -3,8 +3,9 @@ volrecv -> [in_resampler] -> mixer pin, pin -> [out_resampler] -> MSUlawEnc / MS
 209-257) -- (1) fused into a ServerBank (filters/server_leg.inl: metered, queued, mixed and ENCODED in one batch), (2) the facades one
 by one, and (3) as the chain of ORACLE objects predicts them: oracle.Volume per member (the meter and gain of msvolume.c, no AGC: every
 block as it comes), conference_glue.OracleMixer (audiomixer.c's census, queues and arithmetic), oracle.g711_encode -- which is pinned
-against the reference's own g711.c (oracle/_ref) -- packed to the encoder's ptime.  Bit for bit: this path is integer work and
-MSVolume's float chain, both bit-exact by north_star."""
+against the reference's own g711.c (oracle/_ref) -- packed to the encoder's ptime; where MSAlawDec / MSUlawDec of the plugin head the
+legs (a G.711 bridge end to end) the oracle decodes the same packets first.  Bit for bit: this path is integer work and MSVolume's
+float chain, both bit-exact by north_star."""
 import os
 import sys
 
@@ -50,11 +51,17 @@ def test_fused_server_conference_equals_the_facades_one_by_one(host, runs, name)
 
 def oracle_server(oracle, sc_in):
     """the scenario through the chain of oracle objects -> every member's output stream (G.711 bytes or PCM) as run() returns them"""
-    sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, pcm_pins=(), pins=None, gain=None)
+    sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, pcm_pins=(), pins=None, gain=None, decoders=())
     sc.update(sc_in)
     n, nt, ns, rate = sc["nconf"] * sc["members"], sc["nticks"], sc["rate"] // 100, sc["rate"]
     pins = list(range(sc["members"])) if sc["pins"] is None else list(sc["pins"])
     pcm = sg.signals(n, nt, rate, seed=sc.get("seed", 5))
+    law_of = lambda k: sc["law"] if sc["law"] in ("a", "u") else ("a" if k % 2 else "u")
+    for s in range(n):   # a member whose packets pass MSAlawDec / MSUlawDec: what volrecv sees is the decoded audio (g711.c:113-166,200-255)
+        k = s % sc["members"]
+        if rate == 8000 and (sc["decoders"] is True or k in sc["decoders"]):
+            L = 0 if law_of(k) == "a" else 1
+            pcm[s] = oracle.g711_decode(L, oracle.g711_encode(L, pcm[s]))
     vols = [oracle.Volume(rate) for _ in range(n)]
     for v in vols:
         if sc["gain"] is not None:   # MS_VOLUME_SET_GAIN before the attach (msvolume.c:270-276)
@@ -99,8 +106,7 @@ def oracle_server(oracle, sc_in):
         k = s % sc["members"]
         x = np.concatenate(heard[s]) if heard[s] else np.zeros(0, np.int16)
         if rate == 8000 and k not in sc["pcm_pins"]:
-            law = sc["law"] if sc["law"] in ("a", "u") else ("a" if k % 2 else "u")
-            codes = oracle.g711_encode(0 if law == "a" else 1, x)
+            codes = oracle.g711_encode(0 if law_of(k) == "a" else 1, x)
             packet = 80 * (sc["ptime"] // 10 if sc["ptime"] >= 10 else 2)   # alaw.c:56-90: whole packets only
             out.append(codes[:len(codes) // packet * packet])
         else:

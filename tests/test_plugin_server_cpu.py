@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "tests", "host")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["ulaw_ptime20", "alaw_ptime10_direct", "mixed_laws_and_a_pcm_pin", "packets_of_20ms_in", "late_packets", "a_member_falls_silent",
-         "all_but_one_fall_silent", "mute_and_gain", "mute_and_gain_early", "reattach", "agc_switched_on", "wideband_pcm_48k"]
+         "all_but_one_fall_silent", "mute_and_gain", "mute_and_gain_early", "reattach", "agc_switched_on", "wideband_pcm_48k",
+         "g711_bridge_packets_of_20ms", "g711_bridge_some_members_pcm"]
 
 
 @pytest.fixture(scope="module")
