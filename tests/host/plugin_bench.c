@@ -50,6 +50,7 @@ int ms2shim_sink_blocks(MSFilter *sink);
 
 #define RING 16
 static int16_t g_mic[RING][160], g_far[RING][480], g_pcm8[RING][80];
+static uint8_t g_codes8[RING][80];
 
 typedef struct {
 	MSTicker *ticker;
@@ -79,6 +80,7 @@ static pthread_barrier_t g_bar;
 static int g_profile, g_checksum;
 static int g_nors, g_noagc, g_nomixer; /* PLUGIN_BENCH_SHAPE: words of "nors noagc nomixer" -- the leg without MSResample / without AGC / without a conference mixer */
 static int g_server; /* ... "server": a conference server's REMOTE members (audioconference.c:121-179,209-257): 8 kHz source (decoder .. dtmfgen) -> MSVolume -> in_resampler -> pin -> out_resampler -> MSUlawEnc -> sink, no canceller */
+static int g_dec; /* ... with "server": "dec" -- the sources hand over G.711 PACKETS (rtprecv) and MSUlawDec of the plugin heads every leg */
 static int g_eprs; /* ... "eprs": every pin behind an in_resampler, in front of an out_resampler, as MSAudioConference plumbs its endpoints (audioconference.c:209-257) */
 static double now_ms(void) {
 	struct timespec ts;
@@ -112,14 +114,18 @@ static void build(TickerJob *j) {
 				MSFilter *in_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *out_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
 				MSFilter *enc = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
 				const int leg = (j->index * j->nconf + c) * g_members + k;
-				ms2shim_source_set_loop(src, g_pcm8, sizeof(g_pcm8[0]), RING, leg);
+				MSFilter *dec = g_dec ? ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID) : NULL;
+				if (dec) ms2shim_source_set_loop(src, g_codes8, sizeof(g_codes8[0]), RING, leg);
+				else ms2shim_source_set_loop(src, g_pcm8, sizeof(g_pcm8[0]), RING, leg);
 				ms2shim_sink_set_discard(out, g_checksum ? 2 : 1);
 				j->outs[c * g_members + k] = out;
 				j->spks[c * g_members + k] = NULL;
 				call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 8000);
 				call_int(in_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(in_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
 				call_int(out_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(out_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
-				ms_filter_link(src, 0, vol, 0), ms_filter_link(vol, 0, in_rs, 0), ms_filter_link(in_rs, 0, mx, k);
+				if (dec) ms_filter_link(src, 0, dec, 0), ms_filter_link(dec, 0, vol, 0);
+				else ms_filter_link(src, 0, vol, 0);
+				ms_filter_link(vol, 0, in_rs, 0), ms_filter_link(in_rs, 0, mx, k);
 				ms_filter_link(mx, k, out_rs, 0), ms_filter_link(out_rs, 0, enc, 0), ms_filter_link(enc, 0, out, 0);
 				if (c == 0 && k == 0) j->probe_out = out;
 			}
@@ -305,7 +311,7 @@ int main(int argc, char **argv) {
 	g_aligned = getenv("PLUGIN_BENCH_ALIGNED") != NULL;
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
-		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL;
+		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
 	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
 	const char *plugin = argv[1];
@@ -332,6 +338,7 @@ int main(int argc, char **argv) {
 		for (int i = 0; i < 160; ++i) g_mic[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 19) - 4096);
 		for (int i = 0; i < 480; ++i) g_far[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 18) - 8192);
 		for (int i = 0; i < 80; ++i) g_pcm8[r][i] = (int16_t)((int)((seed = seed * 1664525u + 1013904223u) >> 19) - 4096);
+		for (int i = 0; i < 80; ++i) g_codes8[r][i] = (uint8_t)((seed = seed * 1664525u + 1013904223u) >> 24);
 	}
 	g_fac = ms_factory_new();
 	ms2shim_register_test_filters(g_fac);
