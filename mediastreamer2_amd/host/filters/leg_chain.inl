@@ -62,6 +62,59 @@ inline void pf2(const void *p, size_t bytes) { // a struct or row of `bytes`
 	for (size_t o = 0; o < bytes; o += 64) __builtin_prefetch(static_cast<const char *>(p) + o, 0, 1);
 }
 
+// A conference leaves its device-resident batch, or joins one: what the reference's filters hold ACROSS a detach -- the mixer
+// channels' bufferizers (audiomixer.c:64-76,132-135: channel_prepare / channel_unprepare touch only the tick buffer and the
+// clocks; the queues go at uninit), MSVolume's bufferizer (msvolume.c has no postprocess) -- moves between the device queues and
+// the filters' own host bufferizers.  Rare and synchronous.
+// take: streams [s0, s0 + want.size()) hand want[k] of their samples to got(), in pieces of at most `row` samples: one
+// all-or-nothing pop per distinct piece length and round (d_rows: [nlegs][row], d_gate: [nlegs], both idle between flushes)
+bool fifo_take(mi_ctx *ctx, mi_fifo *fifo, int nlegs, int s0, int row, int16_t *d_rows, uint8_t *d_gate, std::vector<int> want,
+               const std::function<void(int, const int16_t *, int)> &got) {
+	const int count = (int)want.size();
+	std::vector<uint8_t> gate((size_t)nlegs);
+	std::vector<int16_t> rows((size_t)count * (size_t)row);
+	for (;;) {
+		std::vector<int> lens;
+		for (int k = 0; k < count; ++k) {
+			const int n = std::min(want[(size_t)k], row);
+			if (n > 0 && std::find(lens.begin(), lens.end(), n) == lens.end()) lens.push_back(n);
+		}
+		if (lens.empty()) return true;
+		for (int n : lens) {
+			std::fill(gate.begin(), gate.end(), 0);
+			bool any = false;
+			for (int k = 0; k < count; ++k) any |= (gate[(size_t)(s0 + k)] = std::min(want[(size_t)k], row) == n) != 0;
+			if (!any) continue;
+			if (mi_copy_h2d(ctx, d_gate, gate.data(), (size_t)nlegs) != MI_OK || mi_fifo_pop(fifo, n, d_rows, row, nullptr, d_gate, 0) != MI_OK ||
+			    mi_copy_d2h(ctx, rows.data(), d_rows + (size_t)s0 * row, rows.size() * 2) != MI_OK || mi_ctx_sync(ctx) != MI_OK)
+				return false;
+			for (int k = 0; k < count; ++k)
+				if (gate[(size_t)(s0 + k)]) {
+					got(s0 + k, rows.data() + (size_t)k * row, n);
+					want[(size_t)k] -= n;
+				}
+		}
+	}
+}
+// give: n samples appended to stream s (d_cnt: [nlegs] int32, idle)
+bool fifo_give(mi_ctx *ctx, mi_fifo *fifo, int nlegs, int s, int row, int16_t *d_rows, int32_t *d_cnt, const int16_t *x, int n) {
+	std::vector<int32_t> cnt((size_t)nlegs, 0);
+	for (int at = 0; at < n; at += row) {
+		const int k = std::min(row, n - at);
+		cnt[(size_t)s] = k;
+		if (mi_copy_h2d(ctx, d_rows + (size_t)s * row, x + at, (size_t)k * 2) != MI_OK || mi_copy_h2d(ctx, d_cnt, cnt.data(), (size_t)nlegs * 4) != MI_OK ||
+		    mi_fifo_push(fifo, d_rows, row, row, d_cnt) != MI_OK || mi_ctx_sync(ctx) != MI_OK)
+			return false;
+	}
+	return true;
+}
+void bufferizer_put_samples(MSBufferizer *bz, const int16_t *x, int n) {
+	mblk_t *m = allocb((size_t)n * 2, 0);
+	memcpy(m->b_wptr, x, (size_t)n * 2);
+	m->b_wptr += n * 2;
+	ms_bufferizer_put(bz, m);
+}
+
 struct LegBank;
 struct FusedLeg {
 	LegBank *bank;
@@ -178,7 +231,7 @@ struct LegBank : Pool {
 	// and write them where they lie (a few hundred bytes per leg, once) and the tick path makes no copy at all -- four
 	// launches and the meters' read-back.  MSMI355X_ZERO_COPY=0: staged through device buffers by copy launches (A/B).
 	bool zero_copy = true;
-	bool mixed = false, check_levels = false;
+	bool mixed = false, check_levels = false, lv_fresh = false;
 	double trace_ms = 0;          // MSMI355X_TRACE_SLOW_MS: an enqueue that takes longer says where (stderr)
 	uint64_t tr[8] = {0};
 	std::vector<std::pair<const char *, uint64_t>> trc; // ... and call by call inside the device's half
@@ -496,71 +549,90 @@ struct LegBank : Pool {
 		}
 		return any;
 	}
-	// a bank without mixers: every chunk MSVolume completes in this flush is levelled at once (volume_process's loop,
-	// msvolume.c:480-503) and handed on by its owner -- one launch per chunk round, legs without a whole chunk skipped
-	// Legs [s0, s0 + count) leave the bank (detach): what the reference's filters would still hold goes back to them.  The chunks
-	// waiting whole in f_out have passed MSVolume in the reference (metered, levelled) and sit in the mixer channel, which drops
-	// them at its postprocess (audiomixer.c:186-208): metered here, dropped.  The samples short of a chunk stay in MSVolume's
-	// bufferizer (msvolume.c:480-486; no postprocess touches it): read back into the filter's.
-	void take_remainders(int s0, int count) {
-		if (failed || light) return; // (without AGC MSVolume holds nothing between blocks)
+	// Legs [s0, s0 + count) leave the bank: what the reference's filters would still hold goes back to them.
+	//  - The chunks waiting whole in f_out have passed MSVolume in the reference and sit in the mixer channel's bufferizer, which
+	//    outlives a detach (audiomixer.c:64-76,132-135,200-208: postprocess frees the tick buffers, the queues go at uninit).  When the
+	//    facades carry on one by one (keep_running) they are levelled now and put into that bufferizer (MixerState::channels, which the
+	//    facade's mixer reads); at a detach they go back RAW, in front of the samples short of a chunk, into MSVolume's bufferizer
+	//    (msvolume.c:480-486; no postprocess touches it): the attach that follows fuses again and the queue is rebuilt as it was
+	//    (give_remainder) -- levelled when the mixer takes them, as everything in this bank is.
+	//  - Without AGC (light) the channel's queue is f_chan, levelled already: into the mixer channel's bufferizer either way.
+	void take_remainders(int s0, int count, bool keep_running) {
+		if (failed || (plain && light)) return; // (without AGC MSVolume holds nothing between blocks; a leg without a mixer has no channel)
 		mi_ctx *ctx = hub->ctx;
 		const size_t L = (size_t)nlegs;
-		int whole = 0;
-		for (int s = s0; s < s0 + count; ++s) {
+		auto channel_of = [&](int s) -> MSBufferizer * {
 			FusedLeg *leg = legs[(size_t)s];
-			if (!leg) continue;
-			for (int k = 0; k < leg->chan_chunks + leg->newchunks; ++k, ++whole)
-				MI_MUST(mi_volume_process_fifo_range(vol, f_out, d_scratch, chunk, chunk, s, 1));
-			leg->chan_chunks = leg->newchunks = 0;
-		}
-		if (whole) {
-			MI_MUST(mi_volume_get_state_async(vol, 0, (int)L, h_vstate));
-			sync_stream();
-			if (failed) return;
+			return &((MixerState *)leg->mixer->data)->channels[leg->pin].bufferizer;
+		};
+		std::vector<int> want((size_t)count, 0);
+		if (light) {
 			for (int s = s0; s < s0 + count; ++s)
-				if (legs[(size_t)s] && !vs_dirty[(size_t)s]) vstate[(size_t)s] = h_vstate[s];
+				if (FusedLeg *leg = legs[(size_t)s]) {
+					want[(size_t)(s - s0)] = leg->chan_samples + leg->new_samples;
+					leg->chan_samples = leg->new_samples = 0;
+				}
+			if (!fifo_take(ctx, f_chan, nlegs, s0, ns, d_scratch, d_dgate_any(), want, [&](int s, const int16_t *x, int n) { bufferizer_put_samples(channel_of(s), x, n); }))
+				mi_failed("taking the mixer channels' queues back");
+			return;
 		}
-		std::vector<int> rems;
-		for (int s = s0; s < s0 + count; ++s)
-			if (legs[(size_t)s] && legs[(size_t)s]->vol_rem > 0 && std::find(rems.begin(), rems.end(), legs[(size_t)s]->vol_rem) == rems.end())
-				rems.push_back(legs[(size_t)s]->vol_rem);
-		std::vector<uint8_t> gate(L);
-		std::vector<int16_t> rows((size_t)count * chunk);
-		for (int rem : rems) { // one all-or-nothing read per distinct length (members that joined together share theirs)
-			std::fill(gate.begin(), gate.end(), 0);
-			for (int s = s0; s < s0 + count; ++s) gate[(size_t)s] = legs[(size_t)s] && legs[(size_t)s]->vol_rem == rem;
-			MI_MUST(mi_copy_h2d(ctx, d_dgate_any(), gate.data(), L));
-			MI_MUST(mi_fifo_pop(f_out, rem, d_scratch, chunk, nullptr, d_dgate_any(), 0));
-			MI_MUST(mi_copy_d2h(ctx, rows.data(), d_scratch + (size_t)s0 * chunk, (size_t)count * chunk * 2));
-			sync_stream();
-			if (failed) return;
-			for (int s = s0; s < s0 + count; ++s) {
-				if (!gate[(size_t)s]) continue;
-				VolumeData *vd = (VolumeData *)legs[(size_t)s]->vol->data;
-				mblk_t *m = allocb((size_t)rem * 2, 0);
-				memcpy(m->b_wptr, rows.data() + (size_t)(s - s0) * chunk, (size_t)rem * 2);
-				m->b_wptr += rem * 2;
-				ms_bufferizer_put(vd->buffer, m);
-				legs[(size_t)s]->vol_rem = 0;
+		if (keep_running) {
+			int rounds = 0;
+			for (int s = s0; s < s0 + count; ++s)
+				if (legs[(size_t)s]) rounds = std::max(rounds, legs[(size_t)s]->chan_chunks + legs[(size_t)s]->newchunks);
+			std::vector<int16_t> rows((size_t)count * chunk);
+			for (int k = 0; k < rounds; ++k) {
+				for (int s = s0; s < s0 + count; ++s)
+					if (legs[(size_t)s] && legs[(size_t)s]->chan_chunks + legs[(size_t)s]->newchunks > k) MI_MUST(mi_volume_process_fifo_range(vol, f_out, d_scratch, chunk, chunk, s, 1));
+				MI_MUST(mi_copy_d2h(ctx, rows.data(), d_scratch + (size_t)s0 * chunk, rows.size() * 2));
+				sync_stream();
+				if (failed) return;
+				for (int s = s0; s < s0 + count; ++s)
+					if (legs[(size_t)s] && legs[(size_t)s]->chan_chunks + legs[(size_t)s]->newchunks > k) bufferizer_put_samples(channel_of(s), rows.data() + (size_t)(s - s0) * chunk, chunk);
 			}
+			if (rounds) {
+				MI_MUST(mi_volume_get_state_async(vol, 0, (int)L, h_vstate));
+				sync_stream();
+				if (failed) return;
+				for (int s = s0; s < s0 + count; ++s)
+					if (legs[(size_t)s] && !vs_dirty[(size_t)s]) vstate[(size_t)s] = h_vstate[s];
+			}
+			for (int s = s0; s < s0 + count; ++s)
+				if (legs[(size_t)s]) legs[(size_t)s]->chan_chunks = legs[(size_t)s]->newchunks = 0;
 		}
+		for (int s = s0; s < s0 + count; ++s)
+			if (FusedLeg *leg = legs[(size_t)s]) {
+				want[(size_t)(s - s0)] = (leg->chan_chunks + leg->newchunks) * chunk + leg->vol_rem;
+				leg->chan_chunks = leg->newchunks = leg->vol_rem = 0;
+			}
+		if (!fifo_take(ctx, f_out, nlegs, s0, chunk, d_scratch, d_dgate_any(), want,
+		               [&](int s, const int16_t *x, int n) { bufferizer_put_samples(((VolumeData *)legs[(size_t)s]->vol->data)->buffer, x, n); }))
+			mi_failed("taking MSVolume's queued samples back");
 	}
-	// ... and the other way round when a leg joins the bank at slot s with samples in its MSVolume's bufferizer
+	// ... and the other way round when a leg joins the bank at slot s: the samples in its MSVolume's bufferizer (whole chunks in front
+	// of them: what the mixer channel held at the detach), the mixer channel's bufferizer of a bank without AGC
 	bool give_remainder(int s, VolumeData *vd, FusedLeg *leg) {
-		const int rem = (int)(ms_bufferizer_get_avail(vd->buffer) / 2);
-		if (rem <= 0 || light) return true;
 		mi_ctx *ctx = hub->ctx;
-		const size_t L = (size_t)nlegs;
-		std::vector<int16_t> row((size_t)chunk, 0);
-		ms_bufferizer_read(vd->buffer, (uint8_t *)row.data(), (size_t)rem * 2);
-		std::vector<int32_t> cnt(L, 0);
-		cnt[(size_t)s] = rem;
+		if (light) {
+			if (plain) return true;
+			MSBufferizer *cb = &((MixerState *)leg->mixer->data)->channels[leg->pin].bufferizer;
+			const int n = (int)(ms_bufferizer_get_avail(cb) / 2);
+			if (n <= 0) return true;
+			std::vector<int16_t> x((size_t)n);
+			ms_bufferizer_read(cb, (uint8_t *)x.data(), (size_t)n * 2);
+			if (!fifo_give(ctx, f_chan, nlegs, s, ns, d_scratch, d_cnt, x.data(), n)) return false;
+			leg->chan_samples = n;
+			return true;
+		}
+		const int rem = (int)(ms_bufferizer_get_avail(vd->buffer) / 2);
+		if (rem <= 0) return true;
+		std::vector<int16_t> x((size_t)rem);
+		ms_bufferizer_read(vd->buffer, (uint8_t *)x.data(), (size_t)rem * 2);
 		// (the canceller appends whole frames at a tail it takes to be frame-aligned: the queue starts `rem` short of the ring's end)
-		const bool ok = mi_fifo_reset_range_at(f_out, s, 1, out_cap - rem) == MI_OK && mi_copy_h2d(ctx, d_scratch + (size_t)s * chunk, row.data(), (size_t)chunk * 2) == MI_OK &&
-		                mi_copy_h2d(ctx, d_cnt, cnt.data(), L * 4) == MI_OK && mi_fifo_push(f_out, d_scratch, chunk, chunk, d_cnt) == MI_OK && mi_ctx_sync(ctx) == MI_OK;
-		if (ok) leg->vol_rem = rem;
-		return ok;
+		if (mi_fifo_reset_range_at(f_out, s, 1, out_cap - rem) != MI_OK || !fifo_give(ctx, f_out, nlegs, s, chunk, d_scratch, d_cnt, x.data(), rem)) return false;
+		leg->chan_chunks = plain ? 0 : rem / chunk;
+		leg->vol_rem = rem - leg->chan_chunks * chunk;
+		return true;
 	}
 	uint8_t *d_dgate_any() {
 		if (!d_takegate) d_takegate = devmem<uint8_t>((size_t)nlegs);
@@ -570,6 +642,15 @@ struct LegBank : Pool {
 	// A slot's owner leaves while the bank's work for the coming tick is already out (it left at the end of the last graph walk):
 	// the reference's filters would have handed that tick's audio on in the walk itself, so it goes out now -- the speaker frames
 	// of every leg (LegBank::finish), the owner's own mix or chunks; the others' follow with the hub's flush as usual.
+	// a graph is being detached between two ticks (deliver_*_in_scope): rows staged in the last walk whose launches have not left --
+	// a bank without early launch, a conference that joined the bank mid-walk -- leave now, as the coming flush would send them
+	// (the walks are over and the ticker's clock reads what that flush would read): the tick in flight includes them
+	void launch_staged() {
+		if (failed || !staged_since || !hub->ticker) return;
+		const bool more = enqueue_at(hub->ticker->time);
+		early_any = early ? (early_any || more) : more;
+		early = true;
+	}
 	void deliver_in_flight(MSFilter *owner_filter, int slot) {
 		if (failed || (!outstanding && !early)) return;
 		sync_stream();
@@ -624,6 +705,7 @@ struct LegBank : Pool {
 			any = true;
 		}
 		if (check_levels && any) {
+			lv_fresh = true;
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
@@ -781,6 +863,7 @@ struct LegBank : Pool {
 				for (size_t i = 1; i < trc.size(); ++i) fprintf(stderr, "    %-22s %.3f ms\n", trc[i].first, (double)(trc[i].second - trc[i - 1].second) * 1e-6);
 		}
 		if (check_levels && any) {
+			lv_fresh = true;
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
@@ -843,7 +926,9 @@ struct LegBank : Pool {
 			if (plain)
 				for (size_t s = 0; s < UL; ++s) nready[s] = nout[s], nout[s] = 0;
 		}
-		if (check_levels)
+		const bool lv_now = lv_fresh; // (a flush that launched nothing read no levels)
+		lv_fresh = false;
+		if (check_levels && lv_now)
 			for (size_t s = 0; s < UL; ++s) {
 				FusedLeg *leg = legs[s];
 				if (!leg) continue;
@@ -974,6 +1059,9 @@ void deliver_fused_in_scope(TickerHub &h) {
 	for (Pool *p : h.pools) {
 		if (p->key.compare(0, 3, "leg") != 0) continue;
 		LegBank *b = static_cast<LegBank *>(p);
+		bool ours = false;
+		for (int s = 0; s < b->hi && !ours; ++s) ours = b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s]);
+		if (ours) b->launch_staged();
 		for (int s = 0; s < b->hi; ++s)
 			if (b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s])) b->deliver_in_flight(b->owner[(size_t)s], s);
 	}
@@ -1118,9 +1206,10 @@ struct LegCand {
 };
 
 // MSVolume's bufferizer survives a detach (msvolume.c has no postprocess): with AGC it may hold samples short of a 10 ms chunk
-bool leg_remainder_ok(const VolumeData *vd) {
+// ... in front of them, whole chunks that waited in the mixer channel when a fused conference was detached (LegBank::take_remainders)
+bool leg_remainder_ok(const VolumeData *vd, int max_chunks) {
 	const size_t avail = ms_bufferizer_get_avail(vd->buffer);
-	return avail == 0 || (vd->p.agc_enabled && avail < (size_t)(vd->sample_rate / 100) * 2 && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
+	return avail == 0 || (vd->p.agc_enabled && avail < (size_t)(vd->sample_rate / 100) * 2 * (size_t)max_chunks && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
 }
 
 bool leg_rates_ok(uint32_t in, uint32_t out) { // what the canceller's launch up-samples itself (mi_aec_process_fifos_resampled)
@@ -1173,7 +1262,11 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (volume_is_peered(vd) || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
 	// (MSVolume's bufferizer may hold samples short of a 10 ms chunk from before a detach: they move to the device, leg_give_remainder)
-	if (!leg_remainder_ok(vd) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
+	if (!leg_remainder_ok(vd, 3) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
+	// the mixer channel's own bufferizer (the facades ran one by one before this attach, or a batch without AGC was left): levelled
+	// samples -- a batch without AGC takes them into its channel queue, one with AGC queues in front of MSVolume and cannot
+	const size_t held = ms_bufferizer_get_avail(&ms->channels[pin].bufferizer);
+	if (held && (vd->p.agc_enabled || held % 16 || held > (size_t)(vd->sample_rate / 100) * 2 * 3)) return false;
 	MSQueue *qe = vol->inputs[0];
 	MSFilter *ec = qe ? qe->prev.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || qe->prev.pin != 1 || ec->ticker != mx->ticker || !ms_queue_empty(qe)) return false;
@@ -1379,7 +1472,7 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 	std::vector<FusedLeg *> gone;
 	b->deliver_in_flight(mx, c);
 	b->settle_meters();
-	b->take_remainders(c * mm, mm);
+	b->take_remainders(c * mm, mm, keep_running);
 	for (int pin = 0; pin < mm; ++pin) {
 		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
 		if (!leg) continue;
@@ -1428,7 +1521,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != head->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (volume_is_peered(vd) || vd->sample_rate != es->samplerate || vd->leg) return false;
-	if (!leg_remainder_ok(vd) || ms_bufferizer_get_avail(vd->spill)) return false;
+	if (!leg_remainder_ok(vd, 1) || ms_bufferizer_get_avail(vd->spill)) return false;
 	const bool no_agc = !vd->p.agc_enabled;
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
@@ -1500,7 +1593,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	const int s = leg->slot;
 	b->deliver_in_flight(leg->vol, s);
 	b->settle_meters();
-	b->take_remainders(s, 1);
+	b->take_remainders(s, 1, keep_running);
 	leg_keep_volume(leg);
 	if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, s, b->in_rate, b->rate);
 	b->legs[(size_t)s] = nullptr;

@@ -93,7 +93,7 @@ struct ServerBank : Pool {
 	uint32_t walk_epoch = 0;
 	int walked = 0;
 	bool staged_since = false, outstanding = false, early = false, early_any = false, no_early = false;
-	bool mixed = false, pcm_out = false, check_levels = false, zero_copy = true;
+	bool mixed = false, pcm_out = false, check_levels = false, lv_fresh = false, zero_copy = true;
 	uint64_t launches = 0;
 
 	ServerBank(int cap_conf, int r, int members) : rate(r), mm(members) {
@@ -378,6 +378,7 @@ struct ServerBank : Pool {
 		}
 		if (any) MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 		if (check_levels && any) {
+			lv_fresh = true;
 			MI_MUST(mi_fifo_levels(f_chan, d_lv));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, L * 4));
 		}
@@ -417,7 +418,9 @@ struct ServerBank : Pool {
 			cur->state.store(1, std::memory_order_release);
 			root = esballoc(cur->payload(), cur->bytes, 0, mix_slab_release);
 		}
-		if (check_levels)
+		const bool lv_now = lv_fresh; // (a flush that launched nothing read no levels)
+		lv_fresh = false;
+		if (check_levels && lv_now)
 			for (size_t s = 0; s < UL; ++s)
 				if (legs[s] && h_lv[s] != legs[s]->chan_samples + legs[s]->new_samples) {
 					ms_error("mi355x server leg %d: the mixer channel's queue holds %d samples, the host's framing says %d", (int)s, h_lv[s],
@@ -451,6 +454,15 @@ struct ServerBank : Pool {
 		next_any = false;
 	}
 	// a slot's owner leaves while the bank's work for the coming tick is already out: LegBank::deliver_in_flight
+	// a graph is being detached between two ticks (deliver_server_in_scope): rows staged in the last walk whose launches have not left --
+	// a bank without early launch, a conference that joined the bank mid-walk -- leave now, as the coming flush would send them
+	// (the walks are over and the ticker's clock reads what that flush would read): the tick in flight includes them
+	void launch_staged() {
+		if (failed || !staged_since || !hub->ticker) return;
+		const bool more = enqueue_at(hub->ticker->time);
+		early_any = early ? (early_any || more) : more;
+		early = true;
+	}
 	void deliver_in_flight(MSFilter *owner_filter, int slot) {
 		if (failed || (!outstanding && !early)) return;
 		sync_stream();
@@ -658,6 +670,8 @@ bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out,
 	VolumeData *vd = (VolumeData *)vol->data;
 	if (volume_is_peered(vd) || vd->sample_rate != ms->rate || vd->leg || vd->sleg || vd->p.agc_enabled) return false;
 	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
+	const size_t held = ms_bufferizer_get_avail(&ms->channels[pin].bufferizer); // (from before this attach: it moves to the bank's channel queue)
+	if (held % 16 || held > (size_t)(ms->rate / 100) * 2 * 3) return false;
 	if (vd->pool && (vd->pool->staged[(size_t)vd->slot] || vd->pool->ready[(size_t)vd->slot])) return false; // (a block of its own in flight)
 	*vol_out = vol;
 	return true;
@@ -737,6 +751,12 @@ bool server_try_fuse(MSFilter *mx) {
 		}
 		b->legs[(size_t)leg->slot] = leg;
 		VolumeData *vd = (VolumeData *)pv.second->data;
+		if (const int held = (int)(ms_bufferizer_get_avail(&ms->channels[leg->pin].bufferizer) / 2)) { // the channel's queue as the last detach left it
+			std::vector<int16_t> x((size_t)held);
+			ms_bufferizer_read(&ms->channels[leg->pin].bufferizer, (uint8_t *)x.data(), (size_t)held * 2);
+			if (fifo_give(b->hub->ctx, b->f_chan, b->nlegs, leg->slot, b->ns, b->d_scratch, b->d_n, x.data(), held)) leg->chan_samples = held;
+			else mi_failed("moving a mixer channel's queue to the device");
+		}
 		if (vd->pool) {
 			vd->pool->release(vd->slot);
 			vd->pool = nullptr, vd->slot = -1;
@@ -764,6 +784,17 @@ void server_unfuse(MSFilter *mx, bool keep_running) {
 	const int c = ms->sconf, mm = b->mm;
 	b->deliver_in_flight(mx, c);
 	b->settle_meters();
+	if (!b->failed) { // what the channels' queues hold goes back into the mixer's own bufferizers, which outlive a detach (audiomixer.c:64-76,132-135,200-208)
+		std::vector<int> want((size_t)mm, 0);
+		for (int pin = 0; pin < mm; ++pin)
+			if (ServerLeg *leg = b->legs[(size_t)(c * mm + pin)]) {
+				want[(size_t)pin] = leg->chan_samples + leg->new_samples;
+				leg->chan_samples = leg->new_samples = 0;
+			}
+		if (!fifo_take(b->hub->ctx, b->f_chan, b->nlegs, c * mm, b->ns, b->d_scratch, b->d_dgate, want,
+		               [&](int s, const int16_t *x, int n) { bufferizer_put_samples(&ms->channels[s - c * mm].bufferizer, x, n); }))
+			mi_failed("taking the mixer channels' queues back");
+	}
 	std::vector<ServerLeg *> gone;
 	for (int pin = 0; pin < mm; ++pin) {
 		const size_t s = (size_t)(c * mm + pin);
@@ -887,6 +918,9 @@ void deliver_server_in_scope(TickerHub &h) {
 	for (Pool *p : h.pools) {
 		if (p->key.compare(0, 4, "srv:") != 0) continue;
 		ServerBank *b = static_cast<ServerBank *>(p);
+		bool ours = false;
+		for (int s = 0; s < b->hi && !ours; ++s) ours = b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s]);
+		if (ours) b->launch_staged();
 		for (int s = 0; s < b->hi; ++s)
 			if (b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s])) b->deliver_in_flight(b->owner[(size_t)s], s);
 	}

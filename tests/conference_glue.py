@@ -219,7 +219,8 @@ class OracleMixer:
     removed, audiomixer.c:33-51,120-131) with the filter's bookkeeping restated: per-pin bufferizers (channel_process_in :78-90),
     the census of mixer_check_bypass (:244-286: a pin counts while it delivered within the last second; a pin that is looked at
     for the first time only starts its clock), the channels' flow control (:92-111), ALWAYS_STREAMOUT (:29,315-317), and what a
-    detach does to it (mixer_postprocess :200-208 drops every channel's queue, preprocess :186-198 restarts the clocks).
+    detach does to it (mixer_postprocess :200-208 / channel_unprepare :132-135 free the tick buffers and keep every channel's
+    queue -- those go at uninit, :137-139 -- and preprocess :186-198 / channel_prepare :72-76 restarts the clocks).
     A single contributor is MIXED here like any other, as the plugin's fused conference does (the reference forwards that pin's
     blocks unsaturated, :219-242: only a sample of -32768 would differ -- the stated exception of leg_chain.inl)."""
     TIMEOUT = 1000
@@ -242,7 +243,7 @@ class OracleMixer:
 
     def reattached(self):
         for pin in self.q:
-            self.q[pin], self.seen[pin], self.fc[pin] = np.zeros(0, np.int16), None, [None, -1]
+            self.seen[pin], self.fc[pin] = None, [None, -1]
 
     def tick(self, now, arrived):
         """arrived: pin -> samples MSVolume put on the pin's queue in this walk; -> {pin: 10 ms of mix} (empty: nothing left)"""

@@ -314,16 +314,29 @@ SCENARIOS = {
     "no_agc_ptime20_16k": {"no_agc": True, "in_rate": 8000, "rate": 16000, "ptime20": True, "nticks": 100},
     # ... the sending side of a default AudioStream: sound card at the stream's rate -> MSSpeexEC -> MSVolume (meter only) -> encoder
     "no_agc_no_resampler_no_mixer": {"no_agc": True, "no_resampler": True, "in_rate": 48000, "no_mixer": True, "nconf": 1, "members": 5, "far_gaps": True},
+    # the conferences re-plumbed (detached, attached again) while chunks WAIT in the mixer channels -- 20 ms packets leave one there
+    # every other tick; the channel's bufferizer outlives the detach (audiomixer.c:64-76,132-135,200-208) and so must the batch's queues
+    "replumbed": {"nticks": 100, "events": [(41, "reattach", 0, 0), (70, "reattach", 0, 0)], "tail_blocks": 1},
+    "ptime20_replumbed": {"ptime20": True, "nticks": 100, "events": [(41, "reattach", 0, 0), (60, "reattach", 0, 0)], "tail_blocks": 1},
+    "ptime20_replumbed_no_early_launch": {"ptime20": True, "nticks": 100, "no_early_launch": True, "events": [(41, "reattach", 0, 0), (42, "reattach", 0, 0), (60, "reattach", 0, 0)],
+                                          "tail_blocks": 1},
+    "no_agc_replumbed": {"no_agc": True, "gain": 0.7, "nticks": 100, "events": [(41, "reattach", 0, 0)], "tail_blocks": 1},
+    "no_agc_ptime20_16k_replumbed": {"no_agc": True, "in_rate": 8000, "rate": 16000, "ptime20": True, "nticks": 100, "events": [(41, "reattach", 0, 0), (52, "reattach", 0, 0)],
+                                     "tail_blocks": 1},
 }
 
 
-def compare(a, b):
-    """fused result a against the facades one by one b: every leg's mix and speaker audio, bit for bit"""
+def compare(a, b, tail_blocks=0, block=480):
+    """fused result a against the facades one by one b: every leg's mix and speaker audio, bit for bit.  tail_blocks: the two
+    forms' latencies through a re-plumbing may differ by a tick (the one-by-one mixer is pumped by the flush that brings it blocks):
+    the shorter stream must be the other's beginning, short by at most that many blocks at the END of the run"""
     bad = []
     for k in ("out", "spk"):
         for s, (x, y) in enumerate(zip(a[k], b[k])):
+            n = min(len(x), len(y))
+            if tail_blocks and abs(len(x) - len(y)) <= tail_blocks * block and n > 0 and np.array_equal(x[:n], y[:n]):
+                continue
             if len(x) != len(y) or not np.array_equal(x, y):
-                n = min(len(x), len(y))
                 first = int(np.argmax(x[:n] != y[:n])) if n and (x[:n] != y[:n]).any() else n
                 bad.append((k, s, len(x), len(y), first))
     return bad
@@ -337,7 +350,8 @@ if __name__ == "__main__":
     for name in names:
         fused = run(d, True, SCENARIOS[name], h)
         plain = run(d, False, SCENARIOS[name], h)
-        verdict[name] = {"bad": compare(fused, plain), "fused_stats": fused["stats"], "plain_stats": plain["stats"], "late": [fused["late"], plain["late"]],
+        sc_ = SCENARIOS[name]
+        verdict[name] = {"bad": compare(fused, plain, sc_.get("tail_blocks", 0), sc_.get("rate", 48000) // 100), "fused_stats": fused["stats"], "plain_stats": plain["stats"], "late": [fused["late"], plain["late"]],
                          "samples": int(sum(len(x) for x in fused["out"])), "nonzero": bool(any(x.any() for x in fused["out"])),
                          "levels_equal": bool(np.allclose(fused["levels"], plain["levels"], rtol=0, atol=0)), "after": [fused["after"], plain["after"]]}
     print(json.dumps(verdict))

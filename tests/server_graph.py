@@ -51,7 +51,7 @@ class ServerConferences:
             self.mixers.append(mx)
             for k in range(members):
                 pin = self.pins[k]
-                leg = {"src": S.ms2shim_new_source(h.fac), "vol": S.ms_factory_create_filter(h.fac, fg.MS_VOLUME_ID), "out": S.ms2shim_new_sink(h.fac),
+                leg = {"src": self.new_source(), "vol": S.ms_factory_create_filter(h.fac, fg.MS_VOLUME_ID), "out": S.ms2shim_new_sink(h.fac),
                        "mixer": mx, "pin": pin, "enc": None, "dec": None}
                 leg["law"] = law if law in ("a", "u") else ("a" if k % 2 else "u")   # "mixed": alternate
                 if rate == 8000 and (decoders is True or k in decoders):   # the source hands over G.711 packets (rtprecv): MSAlawDec / MSUlawDec of the plugin in front of volrecv
@@ -89,6 +89,12 @@ class ServerConferences:
                 assert S.ms_filter_link(mx, max(self.pins) + 2, tap, 0) == 0
                 self.extra.append(tap)
         self.attached = False
+
+    def new_source(self):
+        """an RTP receiver / decoder: it hands on everything it has in a walk (two packets after a late one)"""
+        src = self.S.ms2shim_new_source(self.h.fac)
+        self.S.ms2shim_source_set_burst(src, 1)
+        return src
 
     def attach(self):
         for f in self.mixers:
@@ -217,6 +223,11 @@ SCENARIOS = {
     "wideband_pcm_48k": {"rate": 48000, "nticks": 80},                       # no encoder runs at this rate: every pin gets its PCM from the slab
     # a G.711 bridge end to end: the endpoints' PACKETS in (MSUlawDec / MSAlawDec of the plugin head the legs), packets out; 80 + 80 bytes per member and tick
     "g711_bridge_packets_of_20ms": {"decoders": True, "ptime20_in": True, "law": "mixed", "nticks": 100},
+    # late packets leave a block waiting in a mixer channel: it outlives a re-plumbing (audiomixer.c:64-76,132-135,200-208), and the
+    # conference leaving its batch while attached (a member's AGC switched on)
+    "late_packets_replumbed": {"burst": True, "nticks": 140, "events": [(50, "reattach", 0, 0), (51, "reattach", 0, 0), (90, "reattach", 0, 0)]},
+    "late_packets_replumbed_no_early_launch": {"burst": True, "nticks": 120, "no_early_launch": True, "events": [(50, "reattach", 0, 0), (51, "reattach", 0, 0)]},
+    "late_packets_agc_switched_on": {"burst": True, "nticks": 140, "events": [(50, "agc", 2, 1)]},
     "g711_bridge_some_members_pcm": {"decoders": (0, 2), "burst": True, "nticks": 140, "events": [(60, "reattach", 0, 0)]},
 }
 

@@ -20,7 +20,7 @@ HOST = os.path.join(ROOT, "tests", "host")
 def verdict():
     r = subprocess.run(["make", "-C", HOST, "all"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_graph.py"), "--double"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_graph.py"), "--double"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -28,7 +28,8 @@ def verdict():
 @pytest.mark.parametrize("name", ["plain", "delay_and_far_gaps", "ptime20", "odd_pins", "gain_method", "gain_method_early", "wideband_8k_16k", "no_mixer", "no_mixer_ptime20",
                                   "no_resampler", "no_resampler_16k_ptime20", "no_resampler_no_mixer",
                                   "no_agc", "no_agc_ptime20_16k", "no_agc_no_resampler_no_mixer",
-                                  "endpoint_resamplers", "endpoint_resamplers_no_agc_no_resampler"])
+                                  "endpoint_resamplers", "endpoint_resamplers_no_agc_no_resampler",
+                                  "replumbed", "ptime20_replumbed", "ptime20_replumbed_no_early_launch", "no_agc_replumbed", "no_agc_ptime20_16k_replumbed"])
 def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
     v = verdict[name]
     assert v["fused_stats"]["legs"] > 0 and v["plain_stats"]["legs"] == 0, v   # the first run really was fused, the second not
@@ -36,7 +37,7 @@ def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
     assert v["nonzero"] and v["samples"] > 0
     assert v["late"] == [0, 0], "a device queue differed from the host's framing, or a launch failed"
     assert v["after"] == [[0, 0, 0], [0, 0, 0]], "hubs / banks / slots left behind"
-    if "ptime20" not in name:  # (with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
+    if "ptime20" not in name and name != "replumbed":  # (a run that ends a tick apart, fused_graph.compare; with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
         assert v["levels_equal"]
 
 

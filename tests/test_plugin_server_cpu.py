@@ -17,14 +17,14 @@ HOST = os.path.join(ROOT, "tests", "host")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["ulaw_ptime20", "alaw_ptime10_direct", "mixed_laws_and_a_pcm_pin", "packets_of_20ms_in", "late_packets", "a_member_falls_silent",
          "all_but_one_fall_silent", "mute_and_gain", "mute_and_gain_early", "reattach", "agc_switched_on", "wideband_pcm_48k",
-         "g711_bridge_packets_of_20ms", "g711_bridge_some_members_pcm"]
+         "g711_bridge_packets_of_20ms", "g711_bridge_some_members_pcm", "late_packets_replumbed", "late_packets_replumbed_no_early_launch", "late_packets_agc_switched_on"]
 
 
 @pytest.fixture(scope="module")
 def verdict():
     r = subprocess.run(["make", "-C", HOST, "all"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "server_graph.py"), "--double"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "server_graph.py"), "--double"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
