@@ -212,8 +212,9 @@ typedef struct mi_volume_params {
 	int32_t ng_cut_time;
 	float ng_threshold, ng_floorgain;                 /* MS_VOLUME_SET_NOISE_GATE_* */
 	int32_t agc_enabled, noise_gate_enabled, remove_dc;
-	int32_t peer; /* index (same batch) of the MS_VOLUME_SET_PEER filter, -1 = none */
+	int32_t peer; /* index (same batch) of the MS_VOLUME_SET_PEER filter, -1 = none, MI_VOLUME_PEER_EXTERNAL = see mi_volume_set_peer_batch */
 } mi_volume_params;
+#define MI_VOLUME_PEER_EXTERNAL (-2)
 /* running state (msvolume.c:49-53,:58-62,:79) -- read back every tick for
  * MS_VOLUME_GET / GET_LINEAR / GET_MIN / GET_MAX */
 typedef struct mi_volume_state {
@@ -225,6 +226,11 @@ int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out
 void mi_volume_destroy(mi_volume *v);
 void mi_volume_default_params(mi_volume_params *p);          /* volume_init msvolume.c:88-118 */
 int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_params *h_params);
+/* The echo limiter's peer in ANOTHER batch (msvolume.c:201-238 reads `((Volume *)v->peer->data)->energy`, whatever filter that is):
+ * stream s of `v` whose params.peer is MI_VOLUME_PEER_EXTERNAL reads the smoothed energy of stream s of `peers`, as the last launch on
+ * `peers` left it (launch order on the context's stream decides; both on one context).  NULL = none.  The plugin's fused call leg keeps
+ * volsend in its chain's batch and meters volrecv in a batch beside it (leg_chain.inl). */
+int mi_volume_set_peer_batch(mi_volume *v, mi_volume *peers);
 int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h_state); /* syncs */
 /* the same read-back enqueued on the context's stream behind the launches so far (h_state: pinned, mi_host_alloc); valid
  * after the next mi_ctx_sync -- what a per-tick flush uses so that the meters cost no synchronisation of their own */

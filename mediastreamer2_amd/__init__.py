@@ -283,6 +283,11 @@ class VolumeBatch(_Batch):
         arr = (VolumeParams * len(params))(*params)
         check(self.ctx.L.mi_volume_set_params(self.h, first, len(params), arr))
 
+    def set_peer_batch(self, peers):
+        """streams whose params.peer is PEER_EXTERNAL (-2) read the energy of the same index in `peers` (another VolumeBatch, or None):
+        msvolume.c:201-238 reads its peer FILTER's energy, whatever batch that filter lives in"""
+        check(self.ctx.L.mi_volume_set_peer_batch(self.h, peers.h if peers is not None else None))
+
     def get_state(self, first=0, count=None):
         count = self.nstreams - first if count is None else count
         arr = (VolumeState * count)()

@@ -34,7 +34,7 @@ EXPORTS = [
     "mi_mixer_process_host", "mi_mixer_partial_sum", "mi_mixer_finalize",
     "mi_exchange_unique_id", "mi_exchange_create", "mi_exchange_destroy", "mi_exchange_ranks", "mi_exchange_allreduce_i32",
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
-    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo", "mi_volume_process_fifo_range", "mi_volume_process_fifo_flags", "mi_mixer_process_volume_fifo", "mi_mixer_process_volume_fifo_flags", "mi_volume_get_state_async",
+    "mi_volume_get_state", "mi_volume_set_state", "mi_volume_set_peer_batch", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo", "mi_volume_process_fifo_range", "mi_volume_process_fifo_flags", "mi_mixer_process_volume_fifo", "mi_mixer_process_volume_fifo_flags", "mi_volume_get_state_async",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
     "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_process", "mi_equalizer_process_host",
@@ -163,6 +163,7 @@ def load():
     L.mi_volume_set_params.argtypes = [vp, i32, i32, C.POINTER(VolumeParams)]
     L.mi_volume_get_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
     L.mi_volume_set_state.argtypes = [vp, i32, i32, C.POINTER(VolumeState)]
+    L.mi_volume_set_peer_batch.argtypes = [vp, vp]
     L.mi_exchange_unique_id.argtypes = [vp, sz]
     L.mi_exchange_create.argtypes = [vp, i32, i32, vp, pp]
     L.mi_exchange_destroy.argtypes = [vp]

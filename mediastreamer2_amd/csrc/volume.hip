@@ -38,6 +38,9 @@ struct VolArgs {
 	const mi_volume_params *params;
 	mi_volume_state *state;
 	float *energy[2];  // double buffer: peers read the PREVIOUS launch's energy (msvolume.c:206-207 reads its peer's field)
+	// a stream whose peer is MI_VOLUME_PEER_EXTERNAL reads the energy of the SAME index in another batch (mi_volume_set_peer_batch),
+	// as that batch's last launch left it: the plugin's fused leg keeps volsend in one batch and meters volrecv in another
+	const mi_volume_state *ext_state;
 	const int *parity; // which of the two holds the previous launch's values; flipped on the device after each launch,
 	                   // so a captured hipGraph replays correctly (a host-side flip would be frozen into the graph)
 	int nstreams, nsamples, stride, sample_rate, pitch_dw, pitch_f;
@@ -72,7 +75,7 @@ __device__ __forceinline__ VolCtl volume_control(const mi_volume_params &p, mi_v
 	st.instant_energy = en;
 
 	float target = p.static_gain;
-	if (p.peer >= 0) { // echo limiter
+	if (p.peer != -1) { // echo limiter
 		const float peer_e = peer_energy, peer_pk = peer_e;
 		if (peer_pk > st.lt_speaker_en) st.lt_speaker_en = peer_pk;
 		else st.lt_speaker_en = (0.005f * peer_pk) + (0.995f * st.lt_speaker_en);
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 		p = a.params[s0 + tid];
 		st = a.state[s0 + tid];
 		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
+		else if (p.peer == MI_VOLUME_PEER_EXTERNAL && a.ext_state) peer_energy = a.ext_state[s0 + tid].energy;
 	}
 	if (tid < SPB) {
 		int n = 0;
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 		p = a.params[s];
 		st = a.state[s];
 		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
+		else if (p.peer == MI_VOLUME_PEER_EXTERNAL && a.ext_state) peer_energy = a.ext_state[s].energy;
 		mflag = va.flags[c * mm + t];
 		mgain_bits = __float_as_int(va.gain[c * mm + t]);
 		win = a.win[s];
@@ -605,6 +610,7 @@ struct mi_volume {
 	float *d_energy[2] = {nullptr, nullptr};
 	int *d_parity = nullptr;
 	bool has_peers = false; // conservative: set once any stream names a peer
+	const mi_volume *ext = nullptr; // mi_volume_set_peer_batch
 };
 
 extern "C" {
@@ -679,12 +685,18 @@ void mi_volume_destroy(mi_volume *v) {
 
 int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_params *h) {
 	MI_CHECK_ARG(v && h && first >= 0 && count >= 0 && first + count <= v->nstreams);
-	for (int i = 0; i < count; ++i) MI_CHECK_ARG(h[i].peer < v->nstreams);
+	for (int i = 0; i < count; ++i) MI_CHECK_ARG(h[i].peer < v->nstreams && h[i].peer >= MI_VOLUME_PEER_EXTERNAL);
 	for (int i = 0; i < count; ++i)
 		if (h[i].peer >= 0) v->has_peers = true;
 	if (v->ctx->activate() != MI_OK) return MI_ENODEV;
 	MI_HIP(hipStreamSynchronize(v->ctx->stream));
 	MI_HIP(hipMemcpy(v->d_params + first, h, sizeof(*h) * (size_t)count, hipMemcpyHostToDevice));
+	return MI_OK;
+}
+
+int mi_volume_set_peer_batch(mi_volume *v, mi_volume *peers) {
+	MI_CHECK_ARG(v && (!peers || (peers->nstreams >= v->nstreams && peers->ctx == v->ctx && peers != v)));
+	v->ext = peers;
 	return MI_OK;
 }
 
@@ -802,6 +814,7 @@ int mi_mixer_process_volume_fifo_flags(mi_mixer *m, mi_volume *v, int first_stre
 	a.v.params = v->d_params;
 	a.v.state = v->d_state;
 	a.v.win = v->d_win;
+	a.v.ext_state = v->ext ? v->ext->d_state : nullptr;
 	a.v.energy[0] = v->d_energy[0];
 	a.v.energy[1] = v->d_energy[1];
 	a.v.parity = v->d_parity;
@@ -849,6 +862,7 @@ static int volume_launch(mi_volume *v, int16_t *d_samples, int nsamples, int str
 	a.params = v->d_params;
 	a.state = v->d_state;
 	a.win = v->d_win;
+	a.ext_state = v->ext ? v->ext->d_state : nullptr;
 	a.energy[0] = v->d_energy[0];
 	a.energy[1] = v->d_energy[1];
 	a.parity = v->d_parity;

@@ -604,6 +604,7 @@ bool zero_copy_rows() {
 // the fused call-leg chain (filters/leg_chain.inl): what its four facades need to know of it
 struct FusedLeg;
 struct LegBank;
+struct VolumeData;
 struct ResampleData;
 struct SpeexECState;
 void leg_stage_mic(MSFilter *f, ResampleData *d);
@@ -613,7 +614,9 @@ MSFilter *leg_find_mixer_ec(MSFilter *ec);
 bool leg_try_fuse_plain_ec(MSFilter *ec);
 bool leg_has_resampler(FusedLeg *leg);
 void leg_head_done(FusedLeg *leg);
-bool leg_runs_agc(FusedLeg *leg);
+bool leg_frames_chunks(FusedLeg *leg);
+void leg_stage_peer(MSFilter *vol, VolumeData *d); // an echo limiter's peer metered beside a fused leg
+void copy_payload(const mblk_t *m, uint8_t *dst); // codec.inl
 MSFilter *leg_find_mixer(MSFilter *rs);
 bool conf_try_fuse(MSFilter *mixer);
 void conf_unfuse(MSFilter *mixer, bool keep_running);

@@ -136,6 +136,11 @@ struct FusedLeg {
 	int new_samples = 0;  // samples it put on the mixer's queue since the mixer last looked
 	int chan_samples = 0; // the mixer channel's bufferizer, samples (what f_chan holds)
 	bool metered = false;
+	// MSVolume's echo limiter (msvolume.c:201-238): volsend reads the energy of its peer, volrecv -- which this leg METERS beside its
+	// chain (LegBank::vol_peer): the peer facade hands its blocks on untouched in the walk and stages a copy of each for the meter
+	MSFilter *peer = nullptr;
+	int peer_staged = 0; // blocks of the peer staged since the last launch
+	bool peer_metered = false;
 	std::atomic<bool> unfuse_wanted{false}; // (a leg without a mixer: set by a method on any thread under the hub's lock, honoured by the head's next process())
 	uint32_t far_tick = 0;      // ticker tick in which the far end was last taken (a bank without mixers leaves early on these)
 };
@@ -197,6 +202,17 @@ struct LegBank : Pool {
 	mi_volume_state *h_vround = nullptr;
 	std::vector<uint8_t> vhas;
 	int vrounds = 0;
+	// the legs' echo-limiter peers (FusedLeg::peer), metered block by block as volrecv without AGC meters (msvolume.c:505-513) BEFORE the
+	// chain's MSVolume runs in the same enqueue -- volsend reads what volrecv's process() of the same tick left, as in the reference,
+	// where volrecv stands upstream of the canceller (audiostream.c:1812-1826).  Created when the first such leg joins.
+	mi_volume *vol_peer = nullptr;
+	int pcap = 0;                    // samples of a staged peer block (longer ones are cut, as the facade's light path cuts them)
+	int16_t *h_pk = nullptr, *d_pk = nullptr;   // [kMaxRounds][nlegs][pcap] pinned; [nlegs][pcap]
+	int32_t *h_pn = nullptr, *d_pn = nullptr;   // [kMaxRounds][nlegs]; [nlegs]
+	mi_volume_state *h_pround = nullptr;        // [kMaxRounds][nlegs]: the peers' meters behind every round
+	std::vector<mi_volume_state> pstate;        // the peers' running state as of the last flush
+	int prounds = 0;                 // rounds of the launch that is out
+	int npeers = 0;
 	int16_t *h_copy;            // the mixes when every slab is still held downstream: emitted by copy
 	std::vector<MixSlab *> slabs;
 	MixSlab *cur = nullptr;     // the slab this flush downloads into (null: h_copy)
@@ -365,6 +381,7 @@ struct LegBank : Pool {
 		if (hub->ctx) mi_ctx_sync(hub->ctx);
 		if (mix) mi_mixer_destroy(mix);
 		if (vol) mi_volume_destroy(vol);
+		if (vol_peer) mi_volume_destroy(vol_peer);
 		if (vol_id) mi_volume_destroy(vol_id);
 		if (f_chan) mi_fifo_destroy(f_chan);
 		for (mi_fifo *f : {f_mic, f_ref, f_out})
@@ -642,6 +659,75 @@ struct LegBank : Pool {
 	// A slot's owner leaves while the bank's work for the coming tick is already out (it left at the end of the last graph walk):
 	// the reference's filters would have handed that tick's audio on in the walk itself, so it goes out now -- the speaker frames
 	// of every leg (LegBank::finish), the owner's own mix or chunks; the others' follow with the hub's flush as usual.
+	bool want_peers() { // (hub locked) the meter batch and its rows, on first use
+		if (vol_peer) return true;
+		if (failed) return false;
+		const size_t Ln = (size_t)nlegs;
+		pcap = (std::max(960, 2 * ns) + 7) & ~7; // (VolumePool::cap_samples: the facade's own rows, so that over-long blocks are cut alike)
+		if (mi_volume_create(hub->ctx, nlegs, (int)rate, &vol_peer) != MI_OK || mi_volume_set_peer_batch(vol, vol_peer) != MI_OK) {
+			mi_failed("the echo limiter's peer batch");
+			return false;
+		}
+		h_pk = pinned<int16_t>(kMaxRounds * Ln * pcap);
+		d_pk = devmem<int16_t>(Ln * pcap);
+		h_pn = pinned<int32_t>(kMaxRounds * Ln);
+		d_pn = devmem<int32_t>(Ln);
+		h_pround = pinned<mi_volume_state>(kMaxRounds * Ln);
+		pstate.resize(Ln);
+		if (!failed) {
+			memset(h_pn, 0, kMaxRounds * Ln * 4);
+			MI_MUST(mi_volume_get_state(vol_peer, 0, nlegs, pstate.data()));
+		}
+		return !failed;
+	}
+	// the peers' blocks of this walk: metered round by round, ahead of everything the chain's MSVolume does in this enqueue
+	bool enqueue_peers() {
+		if (!vol_peer || npeers == 0 || failed) return false;
+		const size_t Ln = (size_t)nlegs, UL = (size_t)hi * mm;
+		int rounds = 0;
+		for (size_t s = 0; s < UL; ++s) {
+			FusedLeg *leg = legs[s];
+			const int st = (leg && leg->peer) ? leg->peer_staged : 0;
+			for (int r = st; r < kMaxRounds; ++r) h_pn[(size_t)r * Ln + s] = 0;
+			if (st) leg->peer_metered = true, leg->peer_staged = 0;
+			rounds = std::max(rounds, st);
+		}
+		for (int r = 0; r < rounds; ++r) {
+			if (zero_copy) {
+				MI_MUST(mi_volume_process(vol_peer, h_pk + (size_t)r * Ln * pcap, pcap, pcap, h_pn + (size_t)r * Ln));
+			} else {
+				MI_MUST(mi_copy_h2d_pinned(hub->ctx, d_pk, h_pk + (size_t)r * Ln * pcap, UL * pcap * 2));
+				MI_MUST(mi_copy_h2d_pinned(hub->ctx, d_pn, h_pn + (size_t)r * Ln, Ln * 4));
+				MI_MUST(mi_volume_process(vol_peer, d_pk, pcap, pcap, d_pn));
+			}
+			MI_MUST(mi_volume_get_state_async(vol_peer, 0, (int)UL, h_pround + (size_t)r * Ln));
+			++launches;
+		}
+		prounds = rounds;
+		return rounds > 0;
+	}
+	void finish_peers() { // update_energy's extremum records, msvolume.c:405-406: one per block, in order
+		if (!prounds || failed) {
+			prounds = 0;
+			return;
+		}
+		const size_t Ln = (size_t)nlegs, UL = (size_t)hi * mm;
+		for (size_t s = 0; s < UL; ++s) {
+			FusedLeg *leg = legs[s];
+			if (!leg || !leg->peer || !leg->peer_metered) continue;
+			leg->peer_metered = false;
+			VolumeData *pd = (VolumeData *)leg->peer->data;
+			for (int r = 0; r < prounds; ++r) {
+				if (h_pn[(size_t)r * Ln + s] <= 0) continue;
+				pstate[s] = h_pround[(size_t)r * Ln + s];
+				if (hub->ticker) {
+					pd->max.record_max(hub->ticker->time, pstate[s].energy);
+					pd->min.record_min(hub->ticker->time, pstate[s].energy);
+				}
+			}
+		}
+		prounds = 0;
+	}
 	// a graph is being detached between two ticks (deliver_*_in_scope): rows staged in the last walk whose launches have not left --
 	// a bank without early launch, a conference that joined the bank mid-walk -- leave now, as the coming flush would send them
 	// (the walks are over and the ticker's clock reads what that flush would read): the tick in flight includes them
@@ -802,7 +888,12 @@ struct LegBank : Pool {
 		drops.clear();
 		sdrops.clear();
 		mark(1);
-		if (plain) return enqueue_plain(any_ref, any_refx, any_inj, rounds);
+		const bool pany = enqueue_peers();
+		if (plain) {
+			const bool a = enqueue_plain(any_ref, any_refx, any_inj, rounds);
+			outstanding |= pany;
+			return a || pany;
+		}
 		bool ticked = false;
 		for (int c = 0; c < capacity; ++c) { // a mixer ticks once per ticker time, whoever enqueues
 			h_run[c] = 0;
@@ -870,6 +961,7 @@ struct LegBank : Pool {
 			if (f_chan) MI_MUST(mi_fifo_levels(f_chan, d_lv + 3 * L));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, 4 * L * 4));
 		}
+		any |= pany;
 		outstanding |= any;
 		return any;
 	}
@@ -896,6 +988,7 @@ struct LegBank : Pool {
 			g_late_events.fetch_add(1, std::memory_order_relaxed);
 			return;
 		}
+		finish_peers();
 		if (mixed) {
 			const bool pfon = leg_prefetch_on();
 			for (size_t s = 0; s < UL; ++s) {
@@ -1203,13 +1296,41 @@ void leg_head_done(FusedLeg *leg) {
 struct LegCand {
 	MSFilter *rs, *ec, *vol;
 	int pin;
+	MSFilter *peer = nullptr; // MSVolume's echo-limiter peer, to be metered beside the leg
 };
+
+// MSVolume (volsend) names an echo-limiter peer (audio_stream_enable_echo_limiter, audiostream.c:2236-2240: volrecv): the leg can take
+// it along if that peer is one of ours on the same ticker and rate, a meter and nothing else, named by nobody else, with nothing of its
+// own in flight but blocks staged in THIS walk (they move to the leg's meter rows).  *peer = NULL: no peer.  false: the leg keeps its facades.
+bool leg_peer_ok(MSFilter *vol, VolumeData *vd, MSFilter **peer) {
+	std::lock_guard<std::mutex> g(g_peer_mu);
+	*peer = nullptr;
+	if (!vd->peered_by.empty()) return false; // (somebody's limiter reads THIS filter's meter: it stays where they find it)
+	if (!vd->peer) return true;
+	static const bool off = getenv("MSMI355X_NO_FUSE_PEER") != nullptr; // A/B switch: a leg with an echo limiter keeps its facades, as up to round 5
+	MSFilter *pf = vd->peer;
+	if (off || pf->desc != &ms_mi355x_volume_desc || pf->ticker != vol->ticker) return false;
+	VolumeData *pd = (VolumeData *)pf->data;
+	if (pd->sample_rate != vd->sample_rate || pd->leg || pd->sleg || pd->meter_leg || pd->peered_by.size() != 1 || pd->peer != NULL) return false;
+	if (ms_bufferizer_get_avail(pd->buffer) || ms_bufferizer_get_avail(pd->spill)) return false;
+	if (pd->pool && (pd->pool->failed || pd->pool->ready[(size_t)pd->slot] || pd->pool->params_dirty[(size_t)pd->slot] == 2 || pd->pool->state_dirty[(size_t)pd->slot] == 2)) return false;
+	mi_volume_state st = volume_start_state(pd);
+	if (pd->pool && pd->slot >= 0 && !(pd->pool->state_dirty[(size_t)pd->slot] && pd->pool->gain_patch[(size_t)pd->slot].whole)) {
+		st = pd->pool->state[(size_t)pd->slot];
+		const VolumePool::GainPatch &gp = pd->pool->gain_patch[(size_t)pd->slot];
+		if (pd->pool->state_dirty[(size_t)pd->slot] && gp.also_gain) st.gain = gp.gain;
+		if (pd->pool->state_dirty[(size_t)pd->slot] && gp.also_target) st.target_gain = gp.target;
+	}
+	if (pd->p.agc_enabled || pd->p.noise_gate_enabled || pd->p.remove_dc || pd->p.static_gain != 1.f || st.gain != 1.f || st.target_gain != 1.f || st.ng_gain != 1.f) return false;
+	*peer = pf;
+	return true;
+}
 
 // MSVolume's bufferizer survives a detach (msvolume.c has no postprocess): with AGC it may hold samples short of a 10 ms chunk
 // ... in front of them, whole chunks that waited in the mixer channel when a fused conference was detached (LegBank::take_remainders)
 bool leg_remainder_ok(const VolumeData *vd, int max_chunks) {
 	const size_t avail = ms_bufferizer_get_avail(vd->buffer);
-	return avail == 0 || (vd->p.agc_enabled && avail < (size_t)(vd->sample_rate / 100) * 2 * (size_t)max_chunks && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
+	return avail == 0 || (volume_chunks(vd) && avail < (size_t)(vd->sample_rate / 100) * 2 * (size_t)max_chunks && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
 }
 
 bool leg_rates_ok(uint32_t in, uint32_t out) { // what the canceller's launch up-samples itself (mi_aec_process_fifos_resampled)
@@ -1260,13 +1381,15 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	}
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (volume_is_peered(vd) || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
+	// (an echo-limiter peer keeps a CONFERENCE member on its facades: this bank levels a chunk when the mixer takes it, and a chunk that
+	// waited a tick in the channel would meet the peer's NEXT meter reading -- a leg without a mixer levels every chunk as it completes)
+	if (!leg_peer_ok(vol, vd, &c.peer) || c.peer || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
 	// (MSVolume's bufferizer may hold samples short of a 10 ms chunk from before a detach: they move to the device, leg_give_remainder)
 	if (!leg_remainder_ok(vd, 3) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
 	// the mixer channel's own bufferizer (the facades ran one by one before this attach, or a batch without AGC was left): levelled
 	// samples -- a batch without AGC takes them into its channel queue, one with AGC queues in front of MSVolume and cannot
 	const size_t held = ms_bufferizer_get_avail(&ms->channels[pin].bufferizer);
-	if (held && (vd->p.agc_enabled || held % 16 || held > (size_t)(vd->sample_rate / 100) * 2 * 3)) return false;
+	if (held && (volume_chunks(vd) || held % 16 || held > (size_t)(vd->sample_rate / 100) * 2 * 3)) return false;
 	MSQueue *qe = vol->inputs[0];
 	MSFilter *ec = qe ? qe->prev.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || qe->prev.pin != 1 || ec->ticker != mx->ticker || !ms_queue_empty(qe)) return false;
@@ -1287,6 +1410,101 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	c.rs = rs, c.ec = ec, c.vol = vol, c.pin = pin;
 	return true;
 }
+
+// The leg takes its MSVolume's echo-limiter peer along (hub locked): the peer gives up its bank slot, its running state starts the
+// meter's slot; blocks it staged earlier in THIS walk move to the leg's meter rows and are handed on now -- from here on it hands
+// its blocks on in the walk (leg_stage_peer), so that the far end still meets the microphone block of the same walk in the canceller
+bool leg_take_peer(LegBank *b, FusedLeg *leg, MSFilter *pf) {
+	if (!b->want_peers()) return false;
+	VolumeData *pd = (VolumeData *)pf->data;
+	const size_t s = (size_t)leg->slot, Ln = (size_t)b->nlegs;
+	volume_keep_state(pd);
+	const mi_volume_state st = volume_start_state(pd);
+	mi_volume_params pp = pd->p;
+	pp.peer = -1;
+	if (mi_volume_set_params(b->vol_peer, (int)s, 1, &pp) != MI_OK || mi_volume_set_state(b->vol_peer, (int)s, 1, &st) != MI_OK || mi_volume_reset_max(b->vol_peer, (int)s, 1) != MI_OK)
+		return false;
+	b->pstate[s] = st;
+	leg->peer = pf;
+	leg->peer_staged = 0;
+	leg->peer_metered = false;
+	b->npeers++;
+	pd->meter_leg = leg;
+	if (VolumePool *p = pd->pool) {
+		const size_t c = (size_t)p->capacity, ps = (size_t)pd->slot;
+		for (int r = 0; r < p->staged[ps]; ++r) {
+			const int n = p->h_n[(size_t)r * c + ps];
+			const int16_t *row = p->h_buf + ((size_t)r * c + ps) * p->cap_samples;
+			if (n <= 0) continue;
+			if (leg->peer_staged < kMaxRounds && n <= b->pcap) {
+				memcpy(b->h_pk + ((size_t)leg->peer_staged * Ln + s) * b->pcap, row, (size_t)n * 2);
+				b->h_pn[(size_t)leg->peer_staged * Ln + s] = n;
+				leg->peer_staged++;
+			}
+			mblk_t *m = allocb((size_t)n * 2, 0);
+			memcpy(m->b_wptr, row, (size_t)n * 2);
+			m->b_wptr += n * 2;
+			if (pf->outputs[0]) ms_queue_put(pf->outputs[0], m);
+			else freemsg(m);
+		}
+		p->staged[ps] = 0;
+		p->release(pd->slot);
+		pd->pool = nullptr, pd->slot = -1;
+	}
+	if (leg->peer_staged) b->staged_since = true;
+	return true;
+}
+// ... and lets go of it (the leg leaves its bank): MSVolume's running state goes with the filter, which finds a bank slot of its own
+// at its next block or attach
+void leg_drop_peer(LegBank *b, FusedLeg *leg) {
+	if (!leg->peer) return;
+	VolumeData *pd = (VolumeData *)leg->peer->data;
+	if (!b->failed && b->vol_peer) {
+		pd->kept = b->pstate[(size_t)leg->slot];
+		pd->kept.gain = pd->gain, pd->kept.target_gain = pd->target_gain; // (a gain method while it was metered took the leg out: the gains follow)
+		pd->has_kept = true;
+	}
+	pd->meter_leg = nullptr;
+	leg->peer = nullptr;
+	leg->peer_staged = 0;
+	b->npeers--;
+}
+// the peer facade's process(): every block on as it came, a copy in the leg's meter rows (cut like the facade's own rows)
+void leg_stage_peer(MSFilter *f, VolumeData *d) {
+	FusedLeg *leg = d->meter_leg;
+	LegBank *b = leg->bank;
+	const size_t Ln = (size_t)b->nlegs, s = (size_t)leg->slot;
+	for (mblk_t *m; (m = ms_queue_get(f->inputs[0])) != NULL;) {
+		const int n = (int)(msgdsize(m) / 2);
+		if (!b->failed && n > 0) {
+			std::vector<int16_t> flat;
+			const int16_t *src = (const int16_t *)m->b_rptr;
+			if (m->b_cont || n > b->pcap) {
+				flat.resize((size_t)n);
+				copy_payload(m, (uint8_t *)flat.data());
+				src = flat.data();
+			}
+			for (int at = 0; at < n; at += b->pcap) {
+				const int k = std::min(b->pcap, n - at);
+				if (leg->peer_staged >= kMaxRounds) { // more blocks than launch rounds in one tick: these go unmetered (counted)
+					g_late_events.fetch_add(1, std::memory_order_relaxed);
+					break;
+				}
+				memcpy(b->h_pk + ((size_t)leg->peer_staged * Ln + s) * b->pcap, src + at, (size_t)k * 2);
+				b->h_pn[(size_t)leg->peer_staged * Ln + s] = k;
+				leg->peer_staged++;
+			}
+		}
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+		else freemsg(m);
+	}
+	if (leg->peer_staged) {
+		b->staged_since = true;
+		request_flush(f);
+	}
+}
+mi_volume_state *leg_pstate(FusedLeg *leg) { return leg->bank->vol_peer ? &leg->bank->pstate[(size_t)leg->slot] : nullptr; }
+bool leg_frames_chunks(FusedLeg *leg) { return leg && !leg->bank->light; }
 
 // Called (hub locked, ticker thread) by the first facade of a conference's graph to run after an attach.  true = fused:
 // as a conference of sending legs (below), else as one of a server's remote members (server_leg.inl)
@@ -1324,10 +1542,10 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		const uint32_t ir_c = c.rs ? ((const ResampleData *)c.rs->data)->input_rate : (uint32_t)ms->rate;
 		if (e->framesize != e0->framesize || e->filterlength != e0->filterlength || e->nominal_ref_samples != e0->nominal_ref_samples ||
 		    ir_c != ir0 || (c.rs == nullptr) != (cand[0].rs == nullptr) ||
-		    (((VolumeData *)c.vol->data)->p.agc_enabled != 0) != (((VolumeData *)cand[0].vol->data)->p.agc_enabled != 0))
+		    volume_chunks((VolumeData *)c.vol->data) != volume_chunks((VolumeData *)cand[0].vol->data))
 			return false;
 	}
-	const bool no_agc = !((VolumeData *)cand[0].vol->data)->p.agc_enabled;
+	const bool no_agc = !volume_chunks((VolumeData *)cand[0].vol->data); // (10 ms chunks with AGC or an echo-limiter peer, msvolume.c:480)
 	int mm = MIXER_MAX_CHANNELS;
 	for (int m : {4, 8, 16, 32})
 		if (maxpin < m) {
@@ -1356,7 +1574,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		volume_keep_state(vd); // (its bank is on this hub, which is held)
 		b->vstate[s] = volume_start_state(vd); // as volume_attach_slot starts a slot: MSVolume's running state, if it has one already
 		b->vparams[s] = vd->p;
-		b->vparams[s].peer = -1;
+		b->vparams[s].peer = cd.peer ? MI_VOLUME_PEER_EXTERNAL : -1;
 		fill[s] = delay; // zeroes for the time of the delay (speexec.c:205-208)
 		if (es->state_str) { // a saved canceller state goes to the leg's slot (speexec.c:209-211)
 			std::vector<uint8_t> blob;
@@ -1405,6 +1623,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		}
 		vd->leg = leg;
 		if (!b->give_remainder(leg->slot, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
+		if (cd.peer && !leg_take_peer(b, leg, cd.peer)) mi_failed("taking the echo limiter's peer into the batch");
 	}
 	ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
 	ms->pool->release(ms->slot);
@@ -1477,6 +1696,7 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
 		if (!leg) continue;
 		leg_keep_volume(leg);
+		leg_drop_peer(b, leg);
 		if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, leg->slot, b->in_rate, b->rate);
 		b->legs[(size_t)(c * mm + pin)] = nullptr;
 		if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
@@ -1520,9 +1740,10 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	MSFilter *vol = qv ? qv->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != head->ticker || !ms_queue_empty(qv) || !vol->outputs[0]) return false;
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (volume_is_peered(vd) || vd->sample_rate != es->samplerate || vd->leg) return false;
+	MSFilter *peer = nullptr;
+	if (!leg_peer_ok(vol, vd, &peer) || vd->sample_rate != es->samplerate || vd->leg) return false;
 	if (!leg_remainder_ok(vd, 1) || ms_bufferizer_get_avail(vd->spill)) return false;
-	const bool no_agc = !vd->p.agc_enabled;
+	const bool no_agc = !volume_chunks(vd); // (10 ms chunks with AGC or an echo-limiter peer, msvolume.c:480)
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
 	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;
@@ -1537,7 +1758,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	volume_keep_state(vd); // (its bank is on this hub, which is held)
 	b->vstate[(size_t)s] = volume_start_state(vd);
 	b->vparams[(size_t)s] = vd->p;
-	b->vparams[(size_t)s].peer = -1;
+	b->vparams[(size_t)s].peer = peer ? MI_VOLUME_PEER_EXTERNAL : -1;
 	if (es->state_str) {
 		std::vector<uint8_t> blob;
 		if (b64_decode(es->state_str, blob) && mi_aec_import_state(b->aec, s, blob.data(), blob.size()) == MI_OK) ms_message("mi355x echo state restored.");
@@ -1581,6 +1802,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	}
 	vd->leg = leg;
 	if (!b->give_remainder(s, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
+	if (peer && !leg_take_peer(b, leg, peer)) mi_failed("taking the echo limiter's peer into the batch");
 	b->staged_since = true;
 	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (%sMSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen,
 	           rs ? "MSResample -> " : "");
@@ -1595,6 +1817,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	b->settle_meters();
 	b->take_remainders(s, 1, keep_running);
 	leg_keep_volume(leg);
+	leg_drop_peer(b, leg);
 	if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, s, b->in_rate, b->rate);
 	b->legs[(size_t)s] = nullptr;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
@@ -1616,7 +1839,6 @@ void leg_release(FusedLeg *leg, bool keep_running) {
 }
 bool leg_wants_out(FusedLeg *leg) { return leg && !leg->mixer && leg->unfuse_wanted; }
 bool leg_has_resampler(FusedLeg *leg) { return leg && leg->rs != nullptr; }
-bool leg_runs_agc(FusedLeg *leg) { return leg && !leg->bank->light; }
 
 Pool *leg_pool(FusedLeg *leg) { return leg->bank; }
 Pool *leg_pool_of(LegBank *b) { return b; }
@@ -1646,7 +1868,7 @@ void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain
 	const uint8_t when = b->work_waiting() ? 2 : 1; // (2: behind the coming flush, LegBank::flushed)
 	if (when == 1) b->v_delay[s] = b->chunks_waiting(s);
 	b->vparams[s] = *p;
-	b->vparams[s].peer = -1;
+	b->vparams[s].peer = leg->peer ? MI_VOLUME_PEER_EXTERNAL : -1;
 	b->vp_dirty[s] = when;
 	if (gain) {
 		b->vpatch[s] = {*gain, target ? *target : 0.f, target != nullptr};

@@ -161,6 +161,9 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	bool ng_soft_start;
 	FusedLeg *leg;  // the filter is part of a fused call leg (filters/leg_chain.inl): its meter lives in that bank
 	ServerLeg *sleg; // ... or a conference server's member (filters/server_leg.inl): volrecv as the head of the leg
+	// ... or the echo-limiter PEER of a fused leg's MSVolume (volrecv of an AudioStream whose volsend names it, audiostream.c:2240):
+	// metered in that leg's bank (LegBank::vol_peer); this facade hands its blocks on untouched, in the walk
+	FusedLeg *meter_leg;
 	bool fuse_checked; // looked for a conference of remote members to fuse with since the last attach
 	// MSVolume filters that named this one as their echo-limiter peer (it must stay in a bank of its own kind).  Back-pointers,
 	// under g_peer_mu: a peer that is destroyed FIRST -- audio_stream_free destroys volrecv before volsend, audiostream.c:357-358,
@@ -174,6 +177,7 @@ bool volume_is_peered(VolumeData *d) {
 	return d->peer != NULL || !d->peered_by.empty();
 }
 mi_volume_state *leg_vstate(FusedLeg *leg);                      // leg_chain.inl
+mi_volume_state *leg_pstate(FusedLeg *leg);                      // (the state of the leg's metered peer)
 void leg_push_volume(FusedLeg *leg, const mi_volume_params *p, const float *gain, const float *target); // (gain: also the running state's)
 mi_volume_state *server_vstate(ServerLeg *leg);                  // server_leg.inl
 void server_push_volume(ServerLeg *leg, const mi_volume_params *p, const float *gain, const float *target);
@@ -195,6 +199,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	d->slot = -1;
 	d->leg = nullptr;
 	d->sleg = nullptr;
+	d->meter_leg = nullptr;
 	d->fuse_checked = false;
 	d->peer_gone = false;
 	d->has_kept = false;
@@ -205,6 +210,7 @@ void volume_postprocess(MSFilter *f) { // detach: a fused conference goes back t
 	VolumeData *d = (VolumeData *)f->data;
 	facade_detached(f);
 	if (d->leg) leg_release(d->leg, false);
+	if (d->meter_leg) leg_release(d->meter_leg, false);
 	if (d->sleg) server_release(d->sleg, false);
 	d->fuse_checked = false;
 }
@@ -212,6 +218,7 @@ void volume_postprocess(MSFilter *f) { // detach: a fused conference goes back t
 void volume_uninit(MSFilter *f) {
 	VolumeData *d = (VolumeData *)f->data;
 	if (d->leg) leg_release(d->leg, false);
+	if (d->meter_leg) leg_release(d->meter_leg, false);
 	if (d->sleg) server_release(d->sleg, false);
 	{
 		std::lock_guard<std::mutex> g(g_peer_mu);
@@ -258,8 +265,12 @@ mi_volume_state volume_start_state(const VolumeData *d) {
 	return st;
 }
 
+// MSVolume re-frames to 10 ms chunks with AGC or an echo-limiter peer (msvolume.c:480), else it takes every block as it is (:505)
+bool volume_chunks(const VolumeData *d) { return d->p.agc_enabled != 0 || d->peer != NULL; }
+
 mi_volume_state *vstate(VolumeData *d) {
 	if (d->leg) return leg_vstate(d->leg);
+	if (d->meter_leg) return leg_pstate(d->meter_leg);
 	if (d->sleg) return server_vstate(d->sleg);
 	return (d->pool && d->slot >= 0) ? &d->pool->state[(size_t)d->slot] : nullptr;
 }
@@ -267,7 +278,11 @@ mi_volume_state *vstate(VolumeData *d) {
 void volume_push_params(VolumeData *d, bool f_method = true) {
 	if (d->leg) {
 		leg_push_volume(d->leg, &d->p, nullptr, nullptr);
-		if ((d->p.agc_enabled != 0) != leg_runs_agc(d->leg)) leg_disqualify(d->leg); // AGC switched: with it the reference meters 10 ms chunks, without it block by block -- another bank
+		if (volume_chunks(d) != leg_frames_chunks(d->leg)) leg_disqualify(d->leg); // AGC switched: with it the reference meters 10 ms chunks, without it block by block -- another bank
+		return;
+	}
+	if (d->meter_leg) { // a metered peer is a meter and nothing else: any other configuration goes back to a bank slot of its own
+		leg_disqualify(d->meter_leg);
 		return;
 	}
 	if (d->sleg) {
@@ -338,6 +353,13 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 		if (mx && mx->desc == &ms_mi355x_audio_mixer_desc) {
 			HubLock lk(f, d->pool);
 			conf_try_fuse(mx);
+		}
+	}
+	if (d->meter_leg) { // the echo-limiter peer of a fused leg: handed on as it came, a copy staged for the leg's meter
+		HubLock lk(f, leg_pool(d->meter_leg));
+		if (d->meter_leg) {
+			leg_stage_peer(f, d);
+			return;
 		}
 	}
 	if (d->sleg && server_wants_out(d->sleg)) server_release(d->sleg, true); // a member stopped qualifying: the first of them to be walked takes the conference out, before anything of this walk is staged
@@ -456,6 +478,10 @@ void volume_set_gains(MSFilter *f, VolumeData *d, bool also_target) {
 		leg_push_volume(d->leg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
 		return;
 	}
+	if (d->meter_leg) { // (its running state comes back with the leg's un-fusing: the gains follow there)
+		leg_disqualify(d->meter_leg);
+		return;
+	}
 	if (d->sleg) {
 		server_push_volume(d->sleg, &d->p, &d->gain, also_target ? &d->target_gain : nullptr);
 		return;
@@ -513,9 +539,10 @@ int volume_set_peer(MSFilter *f, void *arg) { // :292-297 stores the MSFilter*
 		d->peer = peer;
 		if (peer) ((VolumeData *)peer->data)->peered_by.push_back(f);
 	}
-	if (peer) { // the echo limiter reads its peer's meter of the previous tick: both in one plain bank
+	if (peer) { // the echo limiter reads its peer's meter: both in one plain bank, or the peer metered beside a fused leg (set at the next attach)
 		HubLock lk(peer);
 		leg_disqualify(((VolumeData *)peer->data)->leg);
+		leg_disqualify(((VolumeData *)peer->data)->meter_leg);
 		server_disqualify(((VolumeData *)peer->data)->sleg);
 	}
 	HubLock lk(f);

@@ -68,6 +68,7 @@ class Host:
         S.ms2shim_new_sink.argtypes = [vp]
         S.ms2shim_source_push.argtypes = [vp, vp, C.c_size_t]
         S.ms2shim_source_set_burst.argtypes = [vp, C.c_int]
+        S.ms2shim_volume_set_peer.argtypes = [vp, vp]
         S.ms2shim_sink_read.restype = C.c_size_t
         S.ms2shim_sink_read.argtypes = [vp, vp, C.c_size_t]
         S.ms2shim_sink_size.restype = C.c_size_t
@@ -131,7 +132,7 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False):
+                 endpoint_resamplers=False, echo_limiter=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -165,7 +166,16 @@ class Conferences:
                 # (resampler=False: the sound card / decoder already runs at the canceller's rate -- MSSpeexEC is the head of the leg; the
                 # MSResample is created all the same and stays unlinked)
                 links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1)] if resampler else [(leg["mic"], 0, leg["ec"], 1)]
-                links += [(leg["ec"], 1, leg["vol"], 0), (leg["far"], 0, leg["ec"], 0), (leg["ec"], 0, leg["spk"], 0)]
+                links += [(leg["ec"], 1, leg["vol"], 0), (leg["ec"], 0, leg["spk"], 0)]
+                if echo_limiter:   # audio_stream_enable_echo_limiter (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer
+                    leg["volrecv"] = S.ms_factory_create_filter(h.fac, MS_VOLUME_ID)
+                    h.call_int(leg["volrecv"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                    assert S.ms2shim_volume_set_peer(leg["vol"], leg["volrecv"]) == 0
+                    h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_THRESHOLD"], 0.002)   # (the scene's far end meters ~0.01: the limiter works)
+                    h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_FORCE"], 20.0)
+                    links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["ec"], 0)]
+                else:
+                    links += [(leg["far"], 0, leg["ec"], 0)]
                 if mixer and endpoint_resamplers:
                     # MSAudioConference's plumbing (audioconference.c:209-257): in_resampler in front of the pin, out_resampler behind it --
                     # both at the conference's rate here: they forward (msresample.c:126-135)
@@ -202,7 +212,7 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs"):
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv"):
                 if k in leg:
                     self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
@@ -240,7 +250,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -273,6 +283,8 @@ def run(plugin_dir, fuse, scenario, h=None):
                     h.call_float(leg["vol"], VOL_SET_GAIN, val)
                 elif kind == "bypass":
                     h.call_bool(leg["ec"], EC_SET_BYPASS, val)
+                elif kind == "recv_gain":   # volrecv stops being a meter only: the leg goes back to its facades
+                    h.call_float(leg["volrecv"], VOL_SET_GAIN, val)
                 elif kind == "agc":
                     h.call_int(leg["vol"], VOL_ENABLE_AGC, val)
                 elif kind == "in_rs_rate":   # the endpoint's in_resampler is told to resample after all
@@ -284,6 +296,8 @@ def run(plugin_dir, fuse, scenario, h=None):
         if t == nt // 2:
             mid_stats = h.fused_stats()
     levels = [h.get_float(leg["vol"], VOL_GET_LINEAR) for leg in conf.legs]
+    if sc.get("echo_limiter"):
+        levels += [h.get_float(leg["volrecv"], VOL_GET_LINEAR) for leg in conf.legs]
     res = {"out": [h.drain(leg["out"]) for leg in conf.legs], "spk": [h.drain(leg["spk"]) for leg in conf.legs], "stats": mid_stats,
            "late": h.P.ms_mi355x_late_events() - late0, "levels": levels}
     conf.close()
@@ -314,6 +328,16 @@ SCENARIOS = {
     "no_agc_ptime20_16k": {"no_agc": True, "in_rate": 8000, "rate": 16000, "ptime20": True, "nticks": 100},
     # ... the sending side of a default AudioStream: sound card at the stream's rate -> MSSpeexEC -> MSVolume (meter only) -> encoder
     "no_agc_no_resampler_no_mixer": {"no_agc": True, "no_resampler": True, "in_rate": 48000, "no_mixer": True, "nconf": 1, "members": 5, "far_gaps": True},
+    # a default AudioStream with the echo limiter on (audiostream.c:2236-2240): volsend's peer is volrecv, which stands upstream of the
+    # canceller's far end -- metered beside the leg (LegBank::vol_peer), its blocks handed on in the walk
+    "echo_limiter_no_mixer": {"echo_limiter": True, "no_agc": True, "no_mixer": True, "nconf": 1, "members": 5, "far_gaps": True, "nticks": 150},
+    "echo_limiter_agc_20ms": {"echo_limiter": True, "no_mixer": True, "nconf": 1, "members": 4, "delay_ms": 10, "ptime20": True, "nticks": 150},
+    "echo_limiter_replumbed": {"echo_limiter": True, "no_agc": True, "no_mixer": True, "nconf": 1, "members": 4, "nticks": 120,
+                               "events": [(41, "reattach", 0, 0), (42, "reattach", 0, 0)], "tail_blocks": 1},
+    # volrecv is given a gain: no longer a meter only, its leg goes back to the facades (where the canceller starts over: compared up to there)
+    "echo_limiter_peer_reconfigured": {"echo_limiter": True, "no_agc": True, "no_mixer": True, "nconf": 1, "members": 4, "nticks": 120,
+                                       "events": [(80, "recv_gain", 1, 0.5)], "compare_ticks": 78},
+    "echo_limiter_conference_keeps_its_facades": {"echo_limiter": True, "nticks": 60, "expect_unfused": True},
     # the conferences re-plumbed (detached, attached again) while chunks WAIT in the mixer channels -- 20 ms packets leave one there
     # every other tick; the channel's bufferizer outlives the detach (audiomixer.c:64-76,132-135,200-208) and so must the batch's queues
     "replumbed": {"nticks": 100, "events": [(41, "reattach", 0, 0), (70, "reattach", 0, 0)], "tail_blocks": 1},
@@ -326,13 +350,15 @@ SCENARIOS = {
 }
 
 
-def compare(a, b, tail_blocks=0, block=480):
+def compare(a, b, tail_blocks=0, block=480, ticks=None):
     """fused result a against the facades one by one b: every leg's mix and speaker audio, bit for bit.  tail_blocks: the two
     forms' latencies through a re-plumbing may differ by a tick (the one-by-one mixer is pumped by the flush that brings it blocks):
     the shorter stream must be the other's beginning, short by at most that many blocks at the END of the run"""
     bad = []
     for k in ("out", "spk"):
         for s, (x, y) in enumerate(zip(a[k], b[k])):
+            if ticks is not None:   # (only the run's first `ticks` ticks are held equal: see the scenario)
+                x, y = x[:ticks * block], y[:ticks * block]
             n = min(len(x), len(y))
             if tail_blocks and abs(len(x) - len(y)) <= tail_blocks * block and n > 0 and np.array_equal(x[:n], y[:n]):
                 continue
@@ -351,7 +377,7 @@ if __name__ == "__main__":
         fused = run(d, True, SCENARIOS[name], h)
         plain = run(d, False, SCENARIOS[name], h)
         sc_ = SCENARIOS[name]
-        verdict[name] = {"bad": compare(fused, plain, sc_.get("tail_blocks", 0), sc_.get("rate", 48000) // 100), "fused_stats": fused["stats"], "plain_stats": plain["stats"], "late": [fused["late"], plain["late"]],
+        verdict[name] = {"bad": compare(fused, plain, sc_.get("tail_blocks", 0), sc_.get("rate", 48000) // 100, sc_.get("compare_ticks")), "fused_stats": fused["stats"], "plain_stats": plain["stats"], "late": [fused["late"], plain["late"]],
                          "samples": int(sum(len(x) for x in fused["out"])), "nonzero": bool(any(x.any() for x in fused["out"])),
                          "levels_equal": bool(np.allclose(fused["levels"], plain["levels"], rtol=0, atol=0)), "after": [fused["after"], plain["after"]]}
     print(json.dumps(verdict))

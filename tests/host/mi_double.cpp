@@ -59,6 +59,7 @@ struct mi_volume {
 	std::vector<mi_volume_params> params;
 	std::vector<mi_volume_state> state;
 	std::vector<float> mx;
+	mi_volume *ext = nullptr; // mi_volume_set_peer_batch
 };
 struct mi_equalizer {
 	mi_ctx *ctx;
@@ -408,6 +409,11 @@ int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_par
 	std::copy(h, h + count, v->params.begin() + first);
 	return MI_OK;
 }
+int mi_volume_set_peer_batch(mi_volume *v, mi_volume *peers) {
+	ARG(v && (!peers || peers->n >= v->n));
+	v->ext = peers;
+	return MI_OK;
+}
 int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h) {
 	ARG(v && h && first >= 0 && count >= 0 && first + count <= v->n);
 	std::copy(v->state.begin() + first, v->state.begin() + first + count, h);
@@ -431,11 +437,16 @@ int mi_volume_reset_max(mi_volume *v, int first, int count) {
 }
 int mi_volume_process(mi_volume *v, int16_t *x, int ns, int stride, const int32_t *per) {
 	ARG(v && x && ns > 0 && stride >= ns);
+	std::vector<float> before((size_t)v->n); // a peer in the same batch is read as the PREVIOUS launch left it (volume.hip: the energy double buffer)
+	for (int s = 0; s < v->n; ++s) before[(size_t)s] = v->state[(size_t)s].energy;
 	for (int s = 0; s < v->n; ++s) {
 		const int n = per ? std::min(std::max(per[s], 0), ns) : ns;
 		if (!n) continue;
 		double acc = 0;
 		mi_volume_state &st = v->state[(size_t)s];
+		const int peer = v->params[(size_t)s].peer; // an echo limiter anybody can hear: the target follows the peer's energy
+		if (peer >= 0) st.target_gain = v->params[(size_t)s].static_gain / (1.f + 1000.f * before[(size_t)peer]);
+		else if (peer == MI_VOLUME_PEER_EXTERNAL && v->ext) st.target_gain = v->params[(size_t)s].static_gain / (1.f + 1000.f * v->ext->state[(size_t)s].energy);
 		for (int i = 0; i < n; ++i) {
 			int16_t &smp = x[(size_t)s * stride + i];
 			acc += (double)smp * smp;

@@ -806,6 +806,8 @@ void ms2shim_register_test_filters(MSFactory *f) {
 }
 MSFilter *ms2shim_new_source(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SOURCE_ID); }
 MSFilter *ms2shim_new_sink(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SINK_ID); }
+/* MS_VOLUME_SET_PEER's id carries sizeof(MSFilter): spelled here, where the header is */
+int ms2shim_volume_set_peer(MSFilter *vol, MSFilter *peer) { return ms_filter_call_method(vol, MS_VOLUME_SET_PEER, peer); }
 void ms2shim_source_set_burst(MSFilter *src, int burst) { ((SrcData *)src->data)->burst = burst; }
 /* the ring stays the caller's; phase = the block the source starts with */
 void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase) {

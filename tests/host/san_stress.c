@@ -236,7 +236,7 @@ typedef struct {
 typedef struct {
 	pthread_mutex_t topo;
 	volatile int stop;
-	MSFilter *vol_conf, *vol_other, *ec_conf, *ec_bypass, *vol_solo;
+	MSFilter *vol_conf, *vol_other, *ec_conf, *ec_bypass, *vol_solo, *volrecv;
 } meddle_t;
 static void *meddler(void *arg) {
 	meddle_t *m = (meddle_t *)arg;
@@ -253,6 +253,8 @@ static void *meddler(void *arg) {
 		ms_filter_call_method(m->vol_solo, MS_VOLUME_ENABLE_AGC, k % 2 ? &on : &off); /* the leg leaves its batch ... */
 		ms_filter_call_method(m->vol_solo, MS_VOLUME_SET_GAIN, &g);                   /* ... and is addressed again at once */
 		ms_filter_call_method(m->vol_solo, MS_VOLUME_GET_LINEAR, &v);
+		ms_filter_call_method(m->volrecv, MS_VOLUME_GET, &v); /* the metered echo-limiter peer of a fused leg */
+		ms_filter_call_method(m->volrecv, MS_VOLUME_GET_MAX, &v);
 		ms_filter_call_method(m->ec_bypass, MS_ECHO_CANCELLER_SET_BYPASS_MODE, &byp);
 		pthread_mutex_unlock(&m->topo);
 		++k;
@@ -294,6 +296,10 @@ static void *conferences(void *arg) {
 		}
 		/* three call legs WITHOUT a mixer on the same ticker (an AudioStream's sending side): fused leg by leg */
 		leg_t solo[3];
+		/* leg 1 is a default AudioStream with the echo limiter on (audiostream.c:2236-2240): volrecv upstream of the canceller's far end,
+		 * named as volsend's peer -- metered beside the fused leg, its blocks handed on in the walk */
+		MSFilter *volrecv = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+		set_int(volrecv, MS_FILTER_SET_SAMPLE_RATE, 48000);
 		for (int k = 0; k < 3; ++k) {
 			leg_t *l = &solo[k];
 			l->mic = ms2shim_new_source(g_fac), l->far = ms2shim_new_source(g_fac);
@@ -309,14 +315,18 @@ static void *conferences(void *arg) {
 			if (k == 0) ms_filter_link(l->mic, 0, l->ec, 1); /* no MSResample in front: MSSpeexEC is this leg's head (48 kHz microphone) */
 			else ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1);
 			ms_filter_link(l->ec, 1, l->vol, 0);
-			ms_filter_link(l->vol, 0, l->out, 0), ms_filter_link(l->far, 0, l->ec, 0), ms_filter_link(l->ec, 0, l->spk, 0);
+			ms_filter_link(l->vol, 0, l->out, 0), ms_filter_link(l->ec, 0, l->spk, 0);
+			if (k == 1) {
+				ms_filter_link(l->far, 0, volrecv, 0), ms_filter_link(volrecv, 0, l->ec, 0);
+				CHECK(ms_filter_call_method(l->vol, MS_VOLUME_SET_PEER, volrecv) == 0);
+			} else ms_filter_link(l->far, 0, l->ec, 0);
 			CHECK(ms_ticker_attach(tk, l->mic) == 0);
 		}
 		meddle_t med;
 		pthread_t med_th;
 		pthread_mutex_init(&med.topo, NULL);
 		med.stop = 0;
-		med.vol_conf = leg[0][1].vol, med.vol_other = leg[1][0].vol, med.ec_conf = leg[0][0].ec, med.ec_bypass = leg[1][3].ec, med.vol_solo = solo[2].vol;
+		med.vol_conf = leg[0][1].vol, med.vol_other = leg[1][0].vol, med.ec_conf = leg[0][0].ec, med.ec_bypass = leg[1][3].ec, med.vol_solo = solo[2].vol, med.volrecv = volrecv;
 		for (int t = 0; t < 14; ++t) {
 			if (t == 3) CHECK(pthread_create(&med_th, NULL, meddler, &med) == 0); /* (after the census at t == 2) */
 			for (int k = 0; k < 3; ++k) {
@@ -361,6 +371,7 @@ static void *conferences(void *arg) {
 				ms_filter_link(leg[0][2].vol, 0, mx[0], 2), ms_filter_link(mx[0], 2, leg[0][2].out, 0);
 				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
 			}
+			if (t == 8) { float g = 0.5f; ms_filter_call_method(volrecv, MS_VOLUME_SET_GAIN, &g); } /* no longer a meter only: its leg goes back to the facades */
 			if (t == 12) { /* a leg without a mixer detached and attached again (its chunks and speaker frames in flight are handed on) */
 				ms_ticker_detach(tk, solo[0].mic);
 				CHECK(ms_ticker_attach(tk, solo[0].mic) == 0);
@@ -376,7 +387,11 @@ static void *conferences(void *arg) {
 			if (k == 0) ms_filter_unlink(l->mic, 0, l->ec, 1);
 			else ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1);
 			ms_filter_unlink(l->ec, 1, l->vol, 0);
-			ms_filter_unlink(l->vol, 0, l->out, 0), ms_filter_unlink(l->far, 0, l->ec, 0), ms_filter_unlink(l->ec, 0, l->spk, 0);
+			ms_filter_unlink(l->vol, 0, l->out, 0), ms_filter_unlink(l->ec, 0, l->spk, 0);
+			if (k == 1) {
+				ms_filter_unlink(l->far, 0, volrecv, 0), ms_filter_unlink(volrecv, 0, l->ec, 0);
+				ms_filter_destroy(volrecv); /* (audio_stream_free destroys volrecv before volsend, audiostream.c:357-358) */
+			} else ms_filter_unlink(l->far, 0, l->ec, 0);
 			ms_filter_destroy(l->mic), ms_filter_destroy(l->far), ms_filter_destroy(l->rs), ms_filter_destroy(l->ec);
 			ms_filter_destroy(l->vol), ms_filter_destroy(l->spk), ms_filter_destroy(l->out);
 		}

@@ -26,14 +26,59 @@ def host():
 def test_fused_conference_equals_the_facades_one_by_one(host, name):
     fused = fg.run(PKG, True, fg.SCENARIOS[name], host)
     plain = fg.run(PKG, False, fg.SCENARIOS[name], host)
-    assert fused["stats"]["legs"] > 0 and plain["stats"]["legs"] == 0
     sc = fg.SCENARIOS[name]
-    assert fg.compare(fused, plain, sc.get("tail_blocks", 0), sc.get("rate", 48000) // 100) == []
+    assert (fused["stats"]["legs"] == 0 if sc.get("expect_unfused") else fused["stats"]["legs"] > 0) and plain["stats"]["legs"] == 0
+    assert fg.compare(fused, plain, sc.get("tail_blocks", 0), sc.get("rate", 48000) // 100, sc.get("compare_ticks")) == []
     assert any(x.any() for x in fused["out"]) and sum(len(x) for x in fused["out"]) > 0
     assert fused["late"] == 0 and plain["late"] == 0, "a device queue differed from the host's framing, or a launch failed"
     assert fused["after"] == (0, 0, 0) and plain["after"] == (0, 0, 0)
-    if "ptime20" not in name and name != "replumbed":
+    if "ptime20" not in name and not sc.get("tail_blocks") and not sc.get("compare_ticks"):
         np.testing.assert_array_equal(fused["levels"], plain["levels"])
+
+
+@pytest.mark.parametrize("form", ["fused", "one_by_one"])
+def test_echo_limiter_leg_is_the_oracles_two_volume_chain(host, oracle, form):
+    """DIRECT: a default AudioStream's sending side with the echo limiter on (audiostream.c:1798-1826,2236-2240) against the chain of
+    oracle objects: volrecv (oracle.Volume, block by block, msvolume.c:505-513) meters the far end upstream of the canceller; the
+    microphone goes Resampler -> MSSpeexEC's framing -> Echo + Preproc -> volsend (oracle.Volume on 10 ms chunks, :480-503) whose echo
+    limiter (:201-238) reads volrecv's energy of the SAME tick.  What the leg sends, within north_star's 1e-4 RMS of full scale, and
+    the limiter really works in it (the far end's loud period pulls the sent level down)."""
+    sc = dict(fg.SCENARIOS["echo_limiter_no_mixer"], members=3, nticks=150, far_gaps=False)
+    res = fg.run(PKG, form == "fused", sc, host)
+    assert (res["stats"]["legs"] > 0) == (form == "fused")
+    F, rate, in_rate, ns, ni, nt = 256, 48000, 16000, 480, 160, sc["nticks"]
+    mic, far = fg.scene(3, nt, in_rate, rate, seed=sc.get("seed", 7))
+    worst = 0.0
+    for s in range(3):
+        rs, ec = oracle.Resampler(in_rate, rate), oracle.Echo(F, 128 * rate // 1000, rate)
+        pp = oracle.Preproc(F, rate, ec)
+        vr, vs = oracle.Volume(rate), oracle.Volume(rate)
+        vs.v.has_peer, vs.v.ea_thres, vs.v.force = 1, 0.002, 20.0
+        q_mic, q_ref, q_vol = (np.zeros(0, np.int16) for _ in range(3))
+        started, sent, gains = False, [], []
+        for t in range(nt):
+            fb = vr.chunk(far[s, t * ns:(t + 1) * ns])            # volrecv: a meter, the block goes on as it came
+            assert np.array_equal(fb, far[s, t * ns:(t + 1) * ns])
+            if started:                                          # speexec.c:240-247
+                q_ref = np.concatenate([q_ref, fb])
+            q_mic = np.concatenate([q_mic, rs.process(mic[s, t * ni:(t + 1) * ni])])
+            while len(q_mic) >= F:                               # :256
+                fr, q_mic, started = q_mic[:F], q_mic[F:], True
+                if len(q_ref) < F:                               # :262-275
+                    q_ref = np.concatenate([q_ref, np.zeros(F, np.int16)])
+                r, q_ref = q_ref[:F], q_ref[F:]
+                q_vol = np.concatenate([q_vol, pp.run(ec.cancel(fr, r))])
+            while len(q_vol) >= ns:                              # msvolume.c:480-503
+                ch, q_vol = q_vol[:ns], q_vol[ns:]
+                sent.append(vs.chunk(ch, peer_energy=vr.v.energy))
+                gains.append(vs.v.gain)
+        want = np.concatenate(sent)
+        got = res["out"][s]
+        assert 0 <= len(want) - len(got) <= 2 * ns and len(got) > 60000, (s, len(got), len(want))
+        d = (got.astype(np.float64) - want[:len(got)].astype(np.float64)) / 32768.0
+        worst = max(worst, float(np.sqrt(np.mean(d * d))))
+        assert min(gains) < 0.7 and np.abs(want.astype(np.int64)).max() > 100, (s, min(gains))   # (the limiter pulled the gain down; not a comparison of silences)
+    assert worst <= 1e-4, worst
 
 
 def test_the_fused_cancellers_cancel(host):

@@ -82,6 +82,50 @@ def test_volume_modes_bit_exact(ctx, oracle, rate, n):
     vb.close()
 
 
+def test_echo_limiter_peer_in_another_batch_bit_exact(ctx, oracle):
+    """mi_volume_set_peer_batch: volsend's batch reads the energy volrecv's batch was left with by ITS last launch -- the meter batch is
+    launched first in a tick (volrecv stands upstream of the canceller, audiostream.c:1812-1826), so the limiter sees the peer's
+    energy of the SAME tick, as msvolume.c:201-238 does; streams without a peer in the same batch are untouched by it."""
+    rate, n, ns, nticks = 48000, 480, 5, 80
+    send, recv = ms.VolumeBatch(ctx, ns, rate), ms.VolumeBatch(ctx, ns, rate)
+    send.set_peer_batch(recv)
+    params, osend, orecv = [], [], []
+    for i in range(ns):
+        p = send.default_params()
+        o = _mk(oracle, rate, **(dict(has_peer=1) if i != 2 else dict(agc_enabled=1)))   # stream 2: no limiter, AGC
+        if i != 2:
+            p.peer = -2   # MI_VOLUME_PEER_EXTERNAL
+            p.ea_thres = o.v.ea_thres = np.float32(0.002)
+            p.force = o.v.force = np.float32(15.0)
+        p.agc_enabled = o.v.agc_enabled
+        params.append(p)
+        osend.append(o)
+        orecv.append(_mk(oracle, rate))
+    send.set_params(params)
+    mic = [synth_pcm(i, n * nticks, sigma=2500.0, rate=rate) for i in range(ns)]
+    far = [synth_pcm(50 + i, n * nticks, sigma=4000.0, rate=rate) for i in range(ns)]
+    for i in range(ns):   # the far end comes and goes: the limiter engages, sustains, lets go
+        far[i] = (far[i].astype(np.int32) * ((np.arange(n * nticks) // (n * (9 + i))) % 2)).astype(np.int16)
+    low = 1.0
+    for t in range(nticks):
+        fx = np.stack([s[t * n:(t + 1) * n] for s in far])
+        mx = np.stack([s[t * n:(t + 1) * n] for s in mic])
+        got_r = recv.process(np.ascontiguousarray(fx.copy()))
+        got_s = send.process(np.ascontiguousarray(mx.copy()))
+        st = send.get_state()
+        for i in range(ns):
+            np.testing.assert_array_equal(got_r[i], orecv[i].chunk(fx[i]), err_msg=f"tick {t} far {i}")
+            ref = osend[i].chunk(mx[i], peer_energy=orecv[i].v.energy if i != 2 else 0.0)
+            np.testing.assert_array_equal(got_s[i], ref, err_msg=f"tick {t} stream {i}")
+            _cmp_state(st[i], osend[i].v, (t, i))
+            if i != 2:
+                low = min(low, float(osend[i].v.gain))
+    assert low < 0.5   # (the limiter really pulled the gain down)
+    send.set_peer_batch(None)
+    send.close()
+    recv.close()
+
+
 def test_volume_unity_gain_leaves_minus_32768_untouched(ctx, oracle):
     """A1: gain == 1 skips the sample loop, so -32768 survives (msvolume.c:440)."""
     vb = ms.VolumeBatch(ctx, 2, 48000)

@@ -29,15 +29,18 @@ def verdict():
                                   "no_resampler", "no_resampler_16k_ptime20", "no_resampler_no_mixer",
                                   "no_agc", "no_agc_ptime20_16k", "no_agc_no_resampler_no_mixer",
                                   "endpoint_resamplers", "endpoint_resamplers_no_agc_no_resampler",
+                                  "echo_limiter_no_mixer", "echo_limiter_agc_20ms", "echo_limiter_replumbed", "echo_limiter_peer_reconfigured",
+                                  "echo_limiter_conference_keeps_its_facades",
                                   "replumbed", "ptime20_replumbed", "ptime20_replumbed_no_early_launch", "no_agc_replumbed", "no_agc_ptime20_16k_replumbed"])
 def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
     v = verdict[name]
-    assert v["fused_stats"]["legs"] > 0 and v["plain_stats"]["legs"] == 0, v   # the first run really was fused, the second not
+    unfused = name == "echo_limiter_conference_keeps_its_facades"   # (a conference member with an echo limiter: stated in leg_chain.inl)
+    assert (v["fused_stats"]["legs"] == 0 if unfused else v["fused_stats"]["legs"] > 0) and v["plain_stats"]["legs"] == 0, v   # the first run really was fused, the second not
     assert v["bad"] == [], v["bad"][:4]
     assert v["nonzero"] and v["samples"] > 0
     assert v["late"] == [0, 0], "a device queue differed from the host's framing, or a launch failed"
     assert v["after"] == [[0, 0, 0], [0, 0, 0]], "hubs / banks / slots left behind"
-    if "ptime20" not in name and name != "replumbed":  # (a run that ends a tick apart, fused_graph.compare; with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
+    if "ptime20" not in name and "replumbed" not in name and "reconfigured" not in name:  # (a run that ends a tick apart, fused_graph.compare; with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
         assert v["levels_equal"]
 
 
