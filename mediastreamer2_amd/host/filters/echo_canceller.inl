@@ -69,6 +69,7 @@ struct EcPool : Pool {
 		}
 	}
 	bool scoped() const override { return true; }
+	void flushed() override; // (a bypass switch waiting for the last walk's frames goes live: below SpeexECState)
 	void emit(MSFilter *f, int slot) override {
 		const size_t sl = (size_t)slot;
 		for (int k = 0; k < ready[sl]; ++k) { // cleaned frames -> outputs[1] (speexec.c:303)
@@ -142,12 +143,24 @@ struct SpeexECState { // speexec.c:49-72
 	int framesize, framesize_at_8000, filterlength, samplerate, delay_ms, tail_length_ms, nominal_ref_samples;
 	char *state_str;
 	bool_t echostarted, bypass_mode, using_zeroes;
+	// bypass_mode is what MS_ECHO_CANCELLER_SET_BYPASS_MODE set (and GET returns); process() goes by bypass_live, which follows it when
+	// the blocks of the walk BEFORE the call are through (Pool::work_waiting / flushed): the reference's process() of that
+	// walk ran before the call
+	bool_t bypass_live;
 	bool_t unsupported; // the attached rate needs a frame size the kernels do not have: both pins pass (internal, not the user's flag)
 	EcPool *pool;
 	int slot;
 	FusedLeg *leg; // the filter is part of a fused call leg (filters/leg_chain.inl): its canceller and queues live in that bank
 	bool fuse_checked; // as the HEAD of a leg (no MSResample of ours in front): looked for a chain to fuse with since the last attach
 };
+
+void EcPool::flushed() {
+	for (int s = 0; s < hi; ++s) {
+		if (parked(s) || !owner[(size_t)s]) continue;
+		SpeexECState *st = (SpeexECState *)owner[(size_t)s]->data;
+		if (st->bypass_live != st->bypass_mode) __atomic_store_n(&st->bypass_live, st->bypass_mode, __ATOMIC_RELAXED);
+	}
+}
 
 void ec_init(MSFilter *f) { // speexec.c:74-109
 	SpeexECState *s = (SpeexECState *)ms_malloc0(sizeof(*s));
@@ -220,6 +233,7 @@ void ec_prepare(MSFilter *f) { // (hub locked by the caller)
 	SpeexECState *s = (SpeexECState *)f->data;
 	s->echostarted = FALSE;
 	s->fuse_checked = false;
+	__atomic_store_n(&s->bypass_live, s->bypass_mode, __ATOMIC_RELAXED);
 	s->filterlength = (s->tail_length_ms * s->samplerate) / 1000;
 	s->framesize = mi_aec_framesize(s->framesize_at_8000, s->samplerate);
 	if (s->framesize != 64 && s->framesize != 128 && s->framesize != 256) {
@@ -348,7 +362,7 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 // (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
 void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	if (!s->leg && !s->fuse_checked && s->pool && f->ticker && !__atomic_load_n(&s->bypass_mode, __ATOMIC_RELAXED) && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
+	if (!s->leg && !s->fuse_checked && s->pool && f->ticker && !__atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED) && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
 		// the first microphone block since the attach, and no MSResample of ours in front (behind one, the resampler is the leg's
 		// head and has looked already): is this the head of  MSSpeexEC -> MSVolume (AGC) -> [conference mixer | anything else] ?
 		s->fuse_checked = true;
@@ -359,7 +373,7 @@ void ec_process(MSFilter *f) {
 			else leg_try_fuse_plain_ec(f);
 		}
 	}
-	if (s->leg && !leg_has_resampler(s->leg) && leg_wants_out(s->leg)) leg_release(s->leg, true); // (behind an MSResample that filter does this)
+	if (s->leg && leg_wants_out(s->leg)) leg_release(s->leg, true); // (whichever facade of the leg is walked first -- the MSResample in front, when it has a block in this walk)
 	if (s->leg) { // fused leg: the microphone is staged (by the leg's MSResample, or here) for the device, the far end for the leg's delay line
 		HubLock lk(f, leg_pool(s->leg));
 		leg_take_far_end(f, s);
@@ -369,7 +383,7 @@ void ec_process(MSFilter *f) {
 		}
 		return;
 	}
-	if (__atomic_load_n(&s->bypass_mode, __ATOMIC_RELAXED) || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)
+	if (__atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED) || s->unsupported || !s->pool) { // both pins straight through (no canceller to be had: the same)
 		for (int pin = 0; pin < 2; ++pin)
 			for (mblk_t *m; (m = ms_queue_get(f->inputs[pin])) != NULL;) ms_queue_put(f->outputs[pin], m);
 		return;
@@ -424,6 +438,8 @@ int ec_set_bypass_mode(MSFilter *f, void *arg) {
 	HubLock lk(f);
 	__atomic_store_n(&s->bypass_mode, *(bool_t *)arg, __ATOMIC_RELAXED); // (read by process() on the ticker thread, as speexec.c:229 does; s->leg only under the hub's lock)
 	if (s->bypass_mode) leg_disqualify(s->leg); // a fused conference goes back to its facades (which then forward both pins)
+	// (a fused leg's batch has the last walk's blocks behind it when its head takes it out: ec_prepare makes the flag live there)
+	if (!(s->pool && f->ticker && s->pool->work_waiting())) __atomic_store_n(&s->bypass_live, s->bypass_mode, __ATOMIC_RELAXED);
 	return 0;
 }
 int ec_get_bypass_mode(MSFilter *f, void *arg) {

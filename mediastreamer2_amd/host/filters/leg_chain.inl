@@ -1660,7 +1660,7 @@ MSFilter *leg_find_mixer_ec(MSFilter *ec) {
 }
 
 void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess (a bank slot of its own)
-void mixer_prepare(MSFilter *f); // mixer.inl
+void mixer_prepare(MSFilter *f, bool running); // mixer.inl
 
 // MSVolume's running state goes with the filter, not with the bank slot (volume.inl: VolumeData::kept)
 void leg_keep_volume(FusedLeg *leg) {
@@ -1674,6 +1674,31 @@ void leg_keep_volume(FusedLeg *leg) {
 		if (b->vpatch[s].also_target) vd->kept.target_gain = b->vpatch[s].target;
 	}
 	vd->has_kept = true;
+}
+
+// A leg leaves its batch WHILE ATTACHED (a member stopped qualifying: a method, nothing the reference's canceller would notice): its
+// canceller goes with the filter -- the adapted state (mi_aec_export_state / import_state: a restored stream continues bit for bit) into
+// the bank slot ec_prepare has just given the facade, the microphone samples short of a frame and the far end's delay line back into
+// the facade's own bufferizers (speexec.c:60-62: `echo`, `delayed_ref`).  Before round 5's end the canceller simply started over.
+void leg_return_canceller(LegBank *b, FusedLeg *leg, bool started) {
+	SpeexECState *es = (SpeexECState *)leg->ec->data;
+	if (b->failed || !es->pool || es->slot < 0 || es->pool->failed) return;
+	static const bool off = getenv("MSMI355X_UNFUSE_RESETS_CANCELLER") != nullptr; // A/B switch
+	if (off) return;
+	std::vector<uint8_t> blob(mi_aec_blob_bytes(b->aec));
+	if (mi_aec_export_state(b->aec, leg->slot, blob.data(), blob.size()) != MI_OK || mi_aec_import_state(es->pool->a, es->slot, blob.data(), blob.size()) != MI_OK) {
+		ms_warning("mi355x: a leg's canceller could not follow it out of its batch (%s): it starts over", mi_last_error());
+		return;
+	}
+	ms_bufferizer_flush(&es->delayed_ref);
+	ms_bufferizer_flush(&es->echo);
+	const bool ok = fifo_take(b->hub->ctx, b->f_ref, b->nlegs, leg->slot, b->ns, b->d_scratch, b->d_dgate_any(), {leg->dref_level},
+	                          [&](int, const int16_t *x, int n) { bufferizer_put_samples(&es->delayed_ref, x, n); }) &&
+	                fifo_take(b->hub->ctx, b->f_mic, b->nlegs, leg->slot, b->ns, b->d_scratch, b->d_dgate_any(), {leg->echo_level},
+	                          [&](int, const int16_t *x, int n) { bufferizer_put_samples(&es->echo, x, n); });
+	if (!ok) mi_failed("taking a leg's canceller queues back");
+	leg->dref_level = leg->echo_level = 0;
+	es->echostarted = started ? TRUE : FALSE;
 }
 
 // The conference leaves its LegBank: at detach (every facade's postprocess ends up here, the first one does the work) or,
@@ -1711,8 +1736,12 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 	for (int pin = 0; pin < mm; ++pin) b->flags[(size_t)(c * mm + pin)] = 0;
 	b->ctl_dirty = true;
 	if (keep_running) { // banks of their own again, while the hub is still held by this conference's slot
-		for (FusedLeg *leg : gone) ec_prepare(leg->ec);
-		mixer_prepare(mx);
+		for (FusedLeg *leg : gone) {
+			const bool started = ((SpeexECState *)leg->ec->data)->echostarted != FALSE;
+			ec_prepare(leg->ec);
+			leg_return_canceller(b, leg, started);
+		}
+		mixer_prepare(mx, true);
 		ms_warning("mi355x: conference %p left its fused batch (a member's configuration changed); the facades carry on one by one", (void *)mx);
 	}
 	b->release(c); // (may destroy the bank)
@@ -1825,7 +1854,9 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	((SpeexECState *)leg->ec->data)->leg = nullptr;
 	((VolumeData *)leg->vol->data)->leg = nullptr;
 	if (keep_running) {
+		const bool started = ((SpeexECState *)leg->ec->data)->echostarted != FALSE;
 		ec_prepare(leg->ec); // a bank slot of its own again, while the hub is still held by this leg's slot
+		leg_return_canceller(b, leg, started);
 		ms_warning("mi355x: call leg %p left its fused batch (a member's configuration changed); the facades carry on one by one", (void *)leg->vol);
 	}
 	b->release(s); // (may destroy the bank)
@@ -1837,7 +1868,12 @@ void leg_release(FusedLeg *leg, bool keep_running) {
 	if (leg->mixer) conf_unfuse(leg->mixer, keep_running);
 	else leg_unfuse_plain(leg, keep_running);
 }
-bool leg_wants_out(FusedLeg *leg) { return leg && !leg->mixer && leg->unfuse_wanted; }
+// (a conference's flag lives with its mixer: the FIRST of its members to be walked takes the conference out, before anything of that
+// walk is staged -- the mixer itself runs behind all of them and would find a tick's rows staged in a bank it is about to leave)
+bool leg_wants_out(FusedLeg *leg) {
+	if (!leg) return false;
+	return leg->mixer ? ((MixerState *)leg->mixer->data)->unfuse_wanted.load() : leg->unfuse_wanted.load();
+}
 bool leg_has_resampler(FusedLeg *leg) { return leg && leg->rs != nullptr; }
 
 Pool *leg_pool(FusedLeg *leg) { return leg->bank; }

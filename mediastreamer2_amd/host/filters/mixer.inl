@@ -202,22 +202,24 @@ void mixer_push_controls(MSFilter *f, MixerState *s, bool from_method = false) {
 		p->ctl_dirty = true;
 	}
 }
-void mixer_prepare(MSFilter *f);
+void mixer_prepare(MSFilter *f, bool running = false);
 void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
 	HubLock lk(f);
 	((MixerState *)f->data)->fuse_state = 0;
 	mixer_prepare(f);
 }
-void mixer_prepare(MSFilter *f) { // (hub locked by the caller)
+// running: the conference left a fused batch while attached -- no preprocess in the reference's terms: the channels' clocks (census,
+// flow control) and the bypass state run on, they are the very fields the batch kept (LegBank / ServerBank::conf_tick)
+void mixer_prepare(MSFilter *f, bool running) { // (hub locked by the caller)
 	MixerState *s = (MixerState *)f->data;
 	s->bytespertick = (2 * s->nchannels * s->rate * f->ticker->interval) / 1000;
-	for (int i = 0; i < MIXER_MAX_CHANNELS; ++i) {
+	for (int i = 0; i < MIXER_MAX_CHANNELS && !running; ++i) {
 		s->channels[i].last_flow_control = (uint64_t)-1;
 		s->channels[i].last_activity = (uint64_t)-1;
 	}
 	s->skip_threshold = s->bytespertick * 2;
-	s->first_walk = true;
-	s->bypass_mode = FALSE;
+	s->first_walk = true; // (running: this walk's tick was the batch's)
+	if (!running) s->bypass_mode = FALSE;
 	s->single_output = has_single_output(f, s);
 	const int ns = s->bytespertick / 2;
 	s->pool = bank<MixerPool>("mixer:" + std::to_string(ns), 1, [&](int cap) { return new MixerPool(cap, ns); });

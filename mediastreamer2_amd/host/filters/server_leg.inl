@@ -853,7 +853,7 @@ void server_unfuse(MSFilter *mx, bool keep_running) {
 	for (int pin = 0; pin < mm; ++pin) b->flags[(size_t)(c * mm + pin)] = 0;
 	b->ctl_dirty = true;
 	if (keep_running) {
-		mixer_prepare(mx);
+		mixer_prepare(mx, true);
 		ms_warning("mi355x: conference %p left its fused batch (a member's configuration changed); the facades carry on one by one", (void *)mx);
 	}
 	b->release(c); // (may destroy the bank)

@@ -131,18 +131,29 @@ struct VolumePool : Pool {
 		}
 	}
 	bool scoped() const override { return true; }
-	void flushed() override {
-		for (int s = 0; s < hi; ++s) {
-			if (parked(s)) continue;
-			if (params_dirty[(size_t)s] == 2) params_dirty[(size_t)s] = 1;
-			if (state_dirty[(size_t)s] == 2) state_dirty[(size_t)s] = 1;
-		}
-	}
+	void flushed() override;
 	void emit(MSFilter *f, int slot) override;
 };
 
+struct VolumeData;
+void volume_framing_now(MSFilter *f);
+void VolumePool::flushed() {
+		for (int s = 0; s < hi; ++s) {
+			if (parked(s)) continue;
+			if (params_dirty[(size_t)s] == 2) {
+				params_dirty[(size_t)s] = 1;
+				if (owner[(size_t)s]) volume_framing_now(owner[(size_t)s]); // (the facade's framing follows its parameters: see VolumeData::chunks)
+			}
+			if (state_dirty[(size_t)s] == 2) state_dirty[(size_t)s] = 1;
+		}
+}
+
 struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	mi_volume_params p;
+	// how process() frames what it is handed -- 10 ms chunks with AGC or an echo-limiter peer (msvolume.c:480), else every block as it is
+	// (:505).  Follows the parameters WHEN THEY GO LIVE: a method that arrives while the last walk's blocks are still waiting for the
+	// coming flush (Pool::work_waiting) re-frames only behind that flush, as the reference's process() of that walk ran before the call
+	bool chunks;
 	float gain, target_gain; // pending values for a slot not yet acquired
 	int sample_rate, nsamples;
 	MSFilter *peer;
@@ -187,6 +198,7 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	VolumeData *d = new VolumeData();
 	mi_volume_default_params(&d->p);
 	d->gain = d->target_gain = 1;
+	d->chunks = false;
 	d->sample_rate = 8000;
 	d->nsamples = 80;
 	d->peer = NULL;
@@ -267,6 +279,7 @@ mi_volume_state volume_start_state(const VolumeData *d) {
 
 // MSVolume re-frames to 10 ms chunks with AGC or an echo-limiter peer (msvolume.c:480), else it takes every block as it is (:505)
 bool volume_chunks(const VolumeData *d) { return d->p.agc_enabled != 0 || d->peer != NULL; }
+void volume_framing_now(MSFilter *f) { ((VolumeData *)f->data)->chunks = volume_chunks((VolumeData *)f->data); }
 
 mi_volume_state *vstate(VolumeData *d) {
 	if (d->leg) return leg_vstate(d->leg);
@@ -293,6 +306,7 @@ void volume_push_params(VolumeData *d, bool f_method = true) {
 	if (!d->pool || d->slot < 0) return;
 	d->pool->params[(size_t)d->slot] = d->p;
 	d->pool->params_dirty[(size_t)d->slot] = (f_method && d->pool->work_waiting()) ? 2 : 1;
+	if (d->pool->params_dirty[(size_t)d->slot] == 1) d->chunks = volume_chunks(d);
 }
 
 void volume_attach_slot(MSFilter *f) {
@@ -355,6 +369,7 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 			conf_try_fuse(mx);
 		}
 	}
+	if (d->meter_leg && leg_wants_out(d->meter_leg)) leg_release(d->meter_leg, true); // (it stands upstream of the leg's canceller: often the first of the leg to be walked)
 	if (d->meter_leg) { // the echo-limiter peer of a fused leg: handed on as it came, a copy staged for the leg's meter
 		HubLock lk(f, leg_pool(d->meter_leg));
 		if (d->meter_leg) {
@@ -378,7 +393,7 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 	VolumePool *p = d->pool;
 	const size_t c = (size_t)p->capacity, s = (size_t)d->slot;
 	mblk_t *m;
-	if (d->p.agc_enabled || d->peer != NULL) { // :480-503 re-framed to 10 ms chunks
+	if (d->chunks) { // :480-503 re-framed to 10 ms chunks
 		const size_t nbytes = (size_t)d->nsamples * 2;
 		ms_bufferizer_put_from_queue(d->buffer, f->inputs[0]);
 		while (ms_bufferizer_get_avail(d->buffer) >= nbytes) {

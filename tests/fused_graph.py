@@ -338,6 +338,14 @@ SCENARIOS = {
     "echo_limiter_peer_reconfigured": {"echo_limiter": True, "no_agc": True, "no_mixer": True, "nconf": 1, "members": 4, "nticks": 120,
                                        "events": [(80, "recv_gain", 1, 0.5)], "compare_ticks": 78},
     "echo_limiter_conference_keeps_its_facades": {"echo_limiter": True, "nticks": 60, "expect_unfused": True},
+    # a leg / a conference leaves its batch WHILE ATTACHED (a method makes a member stop qualifying): nothing is heard of it -- the
+    # canceller's adapted state and queues, the mixer channels' queues and clocks, MSVolume's state and framing go with the filters,
+    # and the method meets the walk it preceded in both forms
+    "agc_switched_off_midcall": {"ptime20": True, "nticks": 100, "events": [(41, "agc", 1, 0), (61, "agc", 2, 0)], "tail_blocks": 1},
+    "bypass_switched_midcall": {"far_gaps": True, "delay_ms": 10, "nticks": 110, "events": [(41, "bypass", 1, True), (60, "bypass", 6, True), (80, "bypass", 1, False)],
+                                "tail_blocks": 1},
+    "agc_switched_on_midcall_no_mixer": {"no_agc": True, "no_mixer": True, "nconf": 1, "members": 5, "nticks": 100, "events": [(41, "agc", 1, 1)], "tail_blocks": 1},
+    "in_resampler_told_to_resample_midcall": {"endpoint_resamplers": True, "nticks": 100, "events": [(41, "in_rs_rate", 1, 16000)], "tail_blocks": 1},
     # the conferences re-plumbed (detached, attached again) while chunks WAIT in the mixer channels -- 20 ms packets leave one there
     # every other tick; the channel's bufferizer outlives the detach (audiomixer.c:64-76,132-135,200-208) and so must the batch's queues
     "replumbed": {"nticks": 100, "events": [(41, "reattach", 0, 0), (70, "reattach", 0, 0)], "tail_blocks": 1},
