@@ -292,6 +292,11 @@ int mi_equalizer_set_active(mi_equalizer *e, int stream, int active); /* MS_EQUA
 int mi_equalizer_dump(mi_equalizer *e, int stream, float *h_dst, int cap);
 int mi_equalizer_get_taps(mi_equalizer *e, int stream, float *h_dst, int cap); /* designs if stale */
 int mi_equalizer_set_taps(mi_equalizer *e, int stream, const float *h_taps, int n);
+/* The FIR's memory (ms_fir_mem16's `mem`, equalizer.c:256-268: the last fir_len - 1 input samples; it lives as long as the filter):
+ * fir_len int16 to and from host memory, so that a stream can move between batches and carry on sample for sample (the plugin's fused
+ * call leg takes its mic_equalizer along).  h_hist == NULL on set: cleared, as a new filter's.  Syncs. */
+int mi_equalizer_get_history(mi_equalizer *e, int stream, int16_t *h_hist, int n);
+int mi_equalizer_set_history(mi_equalizer *e, int stream, const int16_t *h_hist, int n);
 /* in place; designs + uploads stale taps first (equalizer.c:265) */
 int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride);
 int mi_equalizer_process_host(mi_equalizer *e, int16_t *h_samples, int nsamples, int stride);

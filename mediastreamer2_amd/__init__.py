@@ -367,6 +367,19 @@ class EqualizerBatch(_Batch):
         t = np.ascontiguousarray(taps, np.float32)
         check(self.ctx.L.mi_equalizer_set_taps(self.h, stream, _ptr(t), len(t)))
 
+    def history(self, stream):
+        """the FIR's memory (ms_fir_mem16's mem): fir_len int16"""
+        a = np.zeros(self.fir_len, np.int16)
+        check(self.ctx.L.mi_equalizer_get_history(self.h, stream, _ptr(a), len(a)))
+        return a
+
+    def set_history(self, stream, hist=None):
+        if hist is None:
+            check(self.ctx.L.mi_equalizer_set_history(self.h, stream, None, self.fir_len))
+        else:
+            a = np.ascontiguousarray(hist, np.int16)
+            check(self.ctx.L.mi_equalizer_set_history(self.h, stream, _ptr(a), len(a)))
+
     def process(self, x, nsamples=None):
         n, stride = x.shape
         nsamples = stride if nsamples is None else nsamples

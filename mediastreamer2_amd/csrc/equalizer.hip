@@ -372,6 +372,25 @@ int mi_equalizer_set_taps(mi_equalizer *e, int stream, const float *h_taps, int 
 	return MI_OK;
 }
 
+int mi_equalizer_get_history(mi_equalizer *e, int stream, int16_t *h_hist, int n) {
+	MI_CHECK_ARG(e && h_hist && stream >= 0 && stream < e->nstreams && n == e->nfft);
+	std::lock_guard<std::mutex> lk(e->mu);
+	if (e->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(e->ctx->stream));
+	MI_HIP(hipMemcpy(h_hist, e->d_hist + (size_t)stream * e->nfft, sizeof(int16_t) * (size_t)n, hipMemcpyDeviceToHost));
+	return MI_OK;
+}
+
+int mi_equalizer_set_history(mi_equalizer *e, int stream, const int16_t *h_hist, int n) {
+	MI_CHECK_ARG(e && stream >= 0 && stream < e->nstreams && n == e->nfft);
+	std::lock_guard<std::mutex> lk(e->mu);
+	if (e->ctx->activate() != MI_OK) return MI_ENODEV;
+	MI_HIP(hipStreamSynchronize(e->ctx->stream));
+	if (h_hist) MI_HIP(hipMemcpy(e->d_hist + (size_t)stream * e->nfft, h_hist, sizeof(int16_t) * (size_t)n, hipMemcpyHostToDevice));
+	else MI_HIP(hipMemset(e->d_hist + (size_t)stream * e->nfft, 0, sizeof(int16_t) * (size_t)n));
+	return MI_OK;
+}
+
 int mi_equalizer_process(mi_equalizer *e, int16_t *d_samples, int nsamples, int stride) {
 	return mi_equalizer_process_masked(e, d_samples, nsamples, stride, nullptr);
 }

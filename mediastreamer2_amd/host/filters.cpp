@@ -44,6 +44,7 @@
 
 extern "C" { // the descriptors (defined at the end of this file): the fused chain recognises its facades by them
 extern MSFilterDesc ms_mi355x_resample_desc, ms_mi355x_audio_mixer_desc, ms_mi355x_volume_desc, ms_mi355x_speex_ec_desc, ms_mi355x_webrtc_aec_name_desc;
+extern MSFilterDesc ms_mi355x_equalizer_desc;
 extern MSFilterDesc ms_mi355x_alaw_enc_desc, ms_mi355x_ulaw_enc_desc, ms_mi355x_alaw_dec_desc, ms_mi355x_ulaw_dec_desc;
 }
 
@@ -669,7 +670,7 @@ MSFilterDesc ms_mi355x_volume_desc = {MS_VOLUME_ID, "MSVolume", "A filter that c
                                       MS_FILTER_OTHER, NULL, 1, 1, volume_init, volume_preprocess, volume_process, volume_postprocess,
                                       volume_uninit, volume_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_equalizer_desc = {MS_EQUALIZER_ID, "MSEqualizer", "Parametric sound equalizer (MI355X batch)",
-                                         MS_FILTER_OTHER, NULL, 1, 1, equalizer_init, equalizer_preprocess, equalizer_process, generic_postprocess,
+                                         MS_FILTER_OTHER, NULL, 1, 1, equalizer_init, equalizer_preprocess, equalizer_process, equalizer_postprocess,
                                          equalizer_uninit, equalizer_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_speex_ec_desc = {MS_SPEEX_EC_ID, "MSSpeexEC", "Echo canceller, MDF + post-filter (MI355X batch)",
                                         MS_FILTER_OTHER, NULL, 2, 2, ec_init, ec_preprocess, ec_process, ec_postprocess,

@@ -9,6 +9,27 @@ struct EqualizerPool : Pool {
 	int16_t *h_buf, *d_buf;
 	int32_t *h_n, *d_n, *h_nsc; // (h_nsc: as VolumePool's)
 	std::vector<int> staged, ready;
+	// MS_EQUALIZER_SET_GAIN / SET_ACTIVE while the last walk's blocks are still waiting for the coming flush (Pool::work_waiting): they go
+	// live behind that flush (flushed()), as the reference's process() of that walk ran before the call
+	struct Op {
+		int slot, kind; // kind 0: gain, 1: active
+		MSEqualizerGain g;
+		int active;
+	};
+	std::vector<Op> later;
+	static void apply(mi_equalizer *eq, const Op &o) {
+		const int rc = o.kind == 0 ? mi_equalizer_set_gain(eq, o.slot, o.g.frequency, o.g.gain, o.g.width) : mi_equalizer_set_active(eq, o.slot, o.active);
+		if (rc != MI_OK) ms_error("mi355x equalizer: a deferred method failed: %s", mi_last_error());
+	}
+	void flushed() override {
+		if (later.empty()) return;
+		std::vector<Op> keep;
+		for (const Op &o : later) {
+			if (parked(o.slot)) keep.push_back(o);
+			else if (!failed) apply(e, o);
+		}
+		later.swap(keep);
+	}
 	EqualizerPool(int cap, int r) : rate(r) {
 		Building b(this, cap);
 		if (!failed) MI_MUST(mi_equalizer_create(hub->ctx, capacity, rate, &e));
@@ -76,7 +97,20 @@ struct EqualizerData {
 	int slot;
 	std::vector<MSEqualizerGain> *pending; // gains since the last rate change, in call order
 	MSBufferizer *spill;                   // the part of an over-long block that did not fit this tick's rounds
+	// mic_equalizer between MSResample and MSSpeexEC of a fused call leg (audiostream.c:1801; filters/leg_chain.inl): it runs in that
+	// leg's bank.  The FIR's memory goes with the FILTER from slot to slot (equalizer.c keeps it as long as the filter lives)
+	FusedLeg *leg;
+	std::vector<int16_t> *hist;
+	bool has_hist;
 };
+void leg_eq_op(FusedLeg *leg, const EqualizerPool::Op &op); // leg_chain.inl
+mi_equalizer *leg_eq(FusedLeg *leg, int *slot);
+// the batch and slot the filter's equalizer lives in right now (hub locked): its own bank's, or its fused leg's
+mi_equalizer *equalizer_where(EqualizerData *d, int *slot) {
+	if (d->leg) return leg_eq(d->leg, slot);
+	*slot = d->slot;
+	return d->pool ? d->pool->e : nullptr;
+}
 
 // Gains set before the filter is attached to a ticker are kept in `pending` and replayed, in
 // order, when the slot is acquired (the reference keeps them in its own fft_cpx array).
@@ -103,6 +137,9 @@ void equalizer_attach(MSFilter *f) {
 	MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
 	for (const MSEqualizerGain &g : *d->pending)
 		MI_MUST(mi_equalizer_set_gain(d->pool->e, d->slot, g.frequency, g.gain, g.width));
+	// a slot is a new filter's (cleared memory) unless this filter comes back from a fused leg with its own
+	MI_MUST(mi_equalizer_set_history(d->pool->e, d->slot, d->has_hist ? d->hist->data() : nullptr, mi_equalizer_fir_len(d->pool->e)));
+	d->has_hist = false;
 }
 
 void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
@@ -112,11 +149,21 @@ void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
 	d->slot = -1;
 	d->pending = new std::vector<MSEqualizerGain>();
 	d->spill = ms_bufferizer_new();
+	d->hist = new std::vector<int16_t>();
 	f->data = d;
 }
-void equalizer_preprocess(MSFilter *f) { equalizer_attach(f); }
+void equalizer_preprocess(MSFilter *f) {
+	if (!((EqualizerData *)f->data)->leg) equalizer_attach(f);
+}
+void equalizer_postprocess(MSFilter *f) {
+	EqualizerData *d = (EqualizerData *)f->data;
+	facade_detached(f);
+	if (d->leg) leg_release(d->leg, false);
+}
 void equalizer_uninit(MSFilter *f) {
 	EqualizerData *d = (EqualizerData *)f->data;
+	if (d->leg) leg_release(d->leg, false);
+	delete d->hist;
 	if (d->pool) {
 		HubLock lk(f);
 		d->pool->release(d->slot);
@@ -127,6 +174,10 @@ void equalizer_uninit(MSFilter *f) {
 }
 void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	EqualizerData *d = (EqualizerData *)f->data;
+	if (d->leg) { // part of a fused leg: the leg's MSResample emits nothing, the equalizer runs in the leg's bank
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
 	HubLock lk(f, d->pool);
 	mblk_t *m;
 	if (!d->pool) equalizer_attach(f);
@@ -169,8 +220,18 @@ void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 int equalizer_set_gain(MSFilter *f, void *arg) { // equalizer.c:290-295
 	EqualizerData *d = (EqualizerData *)f->data;
 	MSEqualizerGain *g = (MSEqualizerGain *)arg;
+	HubLock lk(f);
 	d->pending->push_back(*g);
+	const EqualizerPool::Op op{d->slot, 0, *g, 0};
+	if (d->leg) {
+		leg_eq_op(d->leg, op);
+		return 0;
+	}
 	if (!d->pool) return 0;
+	if (f->ticker && d->pool->work_waiting()) {
+		d->pool->later.push_back(op);
+		return 0;
+	}
 	return mi_equalizer_set_gain(d->pool->e, d->slot, g->frequency, g->gain, g->width) == MI_OK ? 0 : -1;
 }
 int equalizer_get_gain(MSFilter *f, void *arg) { // equalizer.c:297-303 incl. its slot-indexing quirk
@@ -178,10 +239,13 @@ int equalizer_get_gain(MSFilter *f, void *arg) { // equalizer.c:297-303 incl. it
 	MSEqualizerGain *g = (MSEqualizerGain *)arg;
 	g->width = 0;
 	g->gain = 0;
-	if (!d->pool) return -1;
-	const int nfft = mi_equalizer_fir_len(d->pool->e);
+	HubLock lk(f);
+	int slot = -1;
+	mi_equalizer *e = equalizer_where(d, &slot);
+	if (!e) return -1;
+	const int nfft = mi_equalizer_fir_len(e);
 	std::vector<float> dump((size_t)nfft / 2);
-	if (mi_equalizer_dump(d->pool->e, d->slot, dump.data(), nfft / 2) != MI_OK) return -1;
+	if (mi_equalizer_dump(e, slot, dump.data(), nfft / 2) != MI_OK) return -1;
 	int hz = (int)g->frequency;
 	if (hz >= 0) {
 		if (hz > d->rate / 2) hz = d->rate / 2;
@@ -194,22 +258,32 @@ int equalizer_get_gain(MSFilter *f, void *arg) { // equalizer.c:297-303 incl. it
 }
 int equalizer_set_rate(MSFilter *f, void *arg) { // equalizer.c:305-309
 	EqualizerData *d = (EqualizerData *)f->data;
+	HubLock lk(f);
+	if (d->leg && d->rate != *(int *)arg) leg_disqualify(d->leg);
 	d->rate = *(int *)arg;
 	d->pending->clear(); // equalizer_rate_update re-allocates a flat spectrum
+	if (d->leg) return 0; // (the leg leaves its bank at its next walk: equalizer_attach then starts from the flat spectrum)
 	if (d->pool && d->pool->rate == d->rate) MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot));
 	else equalizer_attach(f);
 	return 0;
 }
 int equalizer_set_active(MSFilter *f, void *arg) { // equalizer.c:311-315: arg read as bool_t
 	EqualizerData *d = (EqualizerData *)f->data;
+	HubLock lk(f);
 	d->active = *(bool_t *)arg != 0;
-	if (d->pool) MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
+	const EqualizerPool::Op op{d->slot, 1, MSEqualizerGain{0, 0, 0}, d->active ? 1 : 0};
+	if (d->leg) leg_eq_op(d->leg, op);
+	else if (d->pool && f->ticker && d->pool->work_waiting()) d->pool->later.push_back(op);
+	else if (d->pool) MI_MUST(mi_equalizer_set_active(d->pool->e, d->slot, d->active));
 	return 0;
 }
 int equalizer_dump(MSFilter *f, void *arg) {
 	EqualizerData *d = (EqualizerData *)f->data;
-	if (!d->pool) return -1;
-	return mi_equalizer_dump(d->pool->e, d->slot, (float *)arg, mi_equalizer_fir_len(d->pool->e) / 2) == MI_OK ? 0 : -1;
+	HubLock lk(f);
+	int slot = -1;
+	mi_equalizer *e = equalizer_where(d, &slot);
+	if (!e) return -1;
+	return mi_equalizer_dump(e, slot, (float *)arg, mi_equalizer_fir_len(e) / 2) == MI_OK ? 0 : -1;
 }
 int equalizer_get_nfreqs(MSFilter *f, void *arg) {
 	EqualizerData *d = (EqualizerData *)f->data;

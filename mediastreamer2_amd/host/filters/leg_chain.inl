@@ -138,6 +138,7 @@ struct FusedLeg {
 	bool metered = false;
 	// MSVolume's echo limiter (msvolume.c:201-238): volsend reads the energy of its peer, volrecv -- which this leg METERS beside its
 	// chain (LegBank::vol_peer): the peer facade hands its blocks on untouched in the walk and stages a copy of each for the meter
+	MSFilter *eq = nullptr; // mic_equalizer between the leg's MSResample and MSSpeexEC (audiostream.c:1801): runs in the bank (LegBank::eq)
 	MSFilter *peer = nullptr;
 	int peer_staged = 0; // blocks of the peer staged since the last launch
 	bool peer_metered = false;
@@ -205,6 +206,14 @@ struct LegBank : Pool {
 	// the legs' echo-limiter peers (FusedLeg::peer), metered block by block as volrecv without AGC meters (msvolume.c:505-513) BEFORE the
 	// chain's MSVolume runs in the same enqueue -- volsend reads what volrecv's process() of the same tick left, as in the reference,
 	// where volrecv stands upstream of the canceller (audiostream.c:1812-1826).  Created when the first such leg joins.
+	// A bank whose legs carry a mic_equalizer (audiostream.c:1801: between read_resampler and ec): the canceller's launch cannot fold the
+	// up-sampler in then -- the round's microphone rows are up-sampled (MSResample's own kernel on the leg's state), equalized where they
+	// lie (one FIR block per microphone block, equalizer.c:279-288) and handed to the canceller's launch as blocks at its rate: two
+	// launches more per round, everything still device-resident
+	mi_equalizer *eq = nullptr;
+	int16_t *d_up = nullptr;                    // [nlegs][ns] a round's up-sampled, equalized microphone blocks
+	int32_t *h_ecnt = nullptr, *d_ecnt = nullptr; // [kMaxRounds][nlegs]: ns where the leg has a microphone block in that round, else 0
+	std::vector<EqualizerPool::Op> eq_later;    // methods that wait for the coming flush (Pool::work_waiting)
 	mi_volume *vol_peer = nullptr;
 	int pcap = 0;                    // samples of a staged peer block (longer ones are cut, as the facade's light path cuts them)
 	int16_t *h_pk = nullptr, *d_pk = nullptr;   // [kMaxRounds][nlegs][pcap] pinned; [nlegs][pcap]
@@ -296,7 +305,8 @@ struct LegBank : Pool {
 	std::vector<GainPatch> vpatch; // MS_VOLUME_SET_GAIN & co. on a fused leg: the two fields, set on the state as the device holds it
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
-	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false, bool no_agc = false)
+	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false, bool no_agc = false,
+	        bool with_eq = false)
 	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer), light(no_agc) {
 		Building b(this, cap_conf);
 		ns = (int)rate / 100;
@@ -309,6 +319,12 @@ struct LegBank : Pool {
 		ref_cap = frames_up(delay + (3 + kLegRefOver) * ns + kMaxRounds * 2 * F, F);
 		if (!failed && in_rate != rate) MI_MUST(mi_resampler_create(hub->ctx, nlegs, in_rate, rate, 3, &rs)); // (no MSResample in front: the microphone arrives at the canceller's rate)
 		if (!failed) MI_MUST(mi_aec_create(hub->ctx, nlegs, (int)rate, F, flen, &aec));
+		if (!failed && with_eq) {
+			MI_MUST(mi_equalizer_create(hub->ctx, nlegs, (int)rate, &eq));
+			d_up = devmem<int16_t>((size_t)nlegs * ns);
+			h_ecnt = pinned<int32_t>(kMaxRounds * (size_t)nlegs);
+			d_ecnt = devmem<int32_t>(kMaxRounds * (size_t)nlegs);
+		}
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, mic_cap, &f_mic));
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, ref_cap, &f_ref));
 		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, out_cap, &f_out));
@@ -382,6 +398,7 @@ struct LegBank : Pool {
 		if (mix) mi_mixer_destroy(mix);
 		if (vol) mi_volume_destroy(vol);
 		if (vol_peer) mi_volume_destroy(vol_peer);
+		if (eq) mi_equalizer_destroy(eq);
 		if (vol_id) mi_volume_destroy(vol_id);
 		if (f_chan) mi_fifo_destroy(f_chan);
 		for (mi_fifo *f : {f_mic, f_ref, f_out})
@@ -550,12 +567,19 @@ struct LegBank : Pool {
 			++launches, any = true;
 		}
 		if (rounds && !zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_gate, h_gate, (size_t)rounds * L));
+		if (rounds && !zc && eq) MI_MUST(mi_copy_h2d_pinned(ctx, d_ecnt, h_ecnt, (size_t)rounds * L * 4));
 		step("gates up");
 		for (int r = 0; r < rounds; ++r) {
 			const int16_t *mic_r = h_mic + (size_t)r * L * in_len;
 			if (!zc) MI_MUST(mi_copy_h2d_pinned(ctx, d_mic, mic_r, UL * in_len * 2));
 			step("microphones up");
-			if (rs)
+			if (eq) { // (a bank with equalizers has an MSResample in every leg: leg_candidate)
+				const uint8_t *gate_r = (zc ? h_gate : d_gate) + (size_t)r * L;
+				MI_MUST(mi_resampler_process_masked(rs, zc ? mic_r : d_mic, in_len, in_len, d_up, ns, nullptr, gate_r));
+				MI_MUST(mi_equalizer_process_masked(eq, d_up, ns, ns, (zc ? h_ecnt : d_ecnt) + (size_t)r * L));
+				MI_MUST(mi_aec_process_fifos_masked(aec, f_mic, d_up, ns, f_ref, d_ref, ns, d_zero, ns, f_out, MI_AEC_MAX_TICK_FRAMES, MI_AEC_POSTFILTER, nullptr, gate_r));
+				launches += 2;
+			} else if (rs)
 				MI_MUST(mi_aec_process_fifos_resampled_masked(aec, rs, zc ? mic_r : d_mic, in_len, in_len, f_mic, f_ref, d_ref, ns, d_zero, f_out, MI_AEC_MAX_TICK_FRAMES,
 				                                              MI_AEC_POSTFILTER, nullptr, (zc ? h_gate : d_gate) + (size_t)r * L));
 			else // the microphone block as it came: queued by the same launch, no up-sampler in front
@@ -859,6 +883,8 @@ struct LegBank : Pool {
 			if (light && !plain && !leg)
 				for (int r = 0; r < kLegLightRounds; ++r) h_fcnt[(size_t)r * L + s] = 0;
 			for (int r = 0; r < kMaxRounds; ++r) h_gate[(size_t)r * L + s] = leg && r < leg->staged_mic;
+			if (eq)
+				for (int r = 0; r < kMaxRounds; ++r) h_ecnt[(size_t)r * L + s] = (leg && r < leg->staged_mic) ? ns : 0;
 			if (!leg) continue;
 			rounds = std::max(rounds, leg->staged_mic);
 			const int nfr = failed ? 0 : ec_frames(leg) + leg->pre_frames;
@@ -1087,6 +1113,11 @@ struct LegBank : Pool {
 	}
 	void flushed() override { // the coming flush is through: what the methods set while its blocks were waiting goes live
 		const size_t UL = (size_t)hi * mm;
+		if (!eq_later.empty()) {
+			if (eq && !failed)
+				for (const EqualizerPool::Op &o : eq_later) EqualizerPool::apply(eq, o);
+			eq_later.clear();
+		}
 		for (size_t s = 0; s < UL; ++s) {
 			if (vp_dirty[s] != 2 && vs_dirty[s] != 2) continue;
 			if (vp_dirty[s] == 2) vp_dirty[s] = 1;
@@ -1297,7 +1328,24 @@ struct LegCand {
 	MSFilter *rs, *ec, *vol;
 	int pin;
 	MSFilter *peer = nullptr; // MSVolume's echo-limiter peer, to be metered beside the leg
+	MSFilter *eq = nullptr;   // mic_equalizer between MSResample and MSSpeexEC
 };
+
+// a mic_equalizer of ours that can move into a leg's bank: on the leg's ticker and rate, nothing of its own in flight
+bool leg_equalizer_ok(MSFilter *eqf, MSTicker *ticker, int rate) {
+	EqualizerData *ed = (EqualizerData *)eqf->data;
+	if (eqf->ticker != ticker || ed->rate != rate || ed->leg || ms_bufferizer_get_avail(ed->spill) || !eqf->inputs[0] || !ms_queue_empty(eqf->inputs[0])) return false;
+	if (EqualizerPool *p = ed->pool) {
+		if (p->failed || p->staged[(size_t)ed->slot] || p->ready[(size_t)ed->slot]) return false;
+		for (const EqualizerPool::Op &o : p->later)
+			if (o.slot == ed->slot) return false;
+	}
+	return true;
+}
+// the equalizer moves into slot leg->slot of the bank's batch: its gains replayed as equalizer_attach replays them, its FIR memory
+// read out of the slot it gives up (or cleared: a filter that never ran) -- and back when the leg leaves (EqualizerData::hist)
+bool leg_take_equalizer(LegBank *b, FusedLeg *leg, MSFilter *eqf);
+void leg_drop_equalizer(LegBank *b, FusedLeg *leg);
 
 // MSVolume (volsend) names an echo-limiter peer (audio_stream_enable_echo_limiter, audiostream.c:2236-2240: volrecv): the leg can take
 // it along if that peer is one of ours on the same ticker and rate, a meter and nothing else, named by nobody else, with nothing of its
@@ -1399,6 +1447,14 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
 	if (!rs || rs->ticker != mx->ticker) return false;
+	c.eq = nullptr;
+	if (rs->desc == &ms_mi355x_equalizer_desc) { // mic_equalizer (audiostream.c:1801): the leg's head is the MSResample in front of it
+		if (!ms_queue_empty(qr) || !leg_equalizer_ok(rs, mx->ticker, ms->rate)) return false;
+		c.eq = rs;
+		qr = rs->inputs[0];
+		rs = qr->prev.filter;
+		if (!rs || rs->desc != &ms_mi355x_resample_desc || rs->ticker != mx->ticker) return false; // (an equalizer of ours as the head: its blocks come with the flush)
+	}
 	if (rs->desc != &ms_mi355x_resample_desc) { // anything else feeds the canceller at its own rate: MSSpeexEC is the leg's head
 		c.rs = nullptr, c.ec = ec, c.vol = vol, c.pin = pin;
 		return true;
@@ -1503,6 +1559,48 @@ void leg_stage_peer(MSFilter *f, VolumeData *d) {
 		request_flush(f);
 	}
 }
+bool leg_take_equalizer(LegBank *b, FusedLeg *leg, MSFilter *eqf) {
+	EqualizerData *ed = (EqualizerData *)eqf->data;
+	if (!b->eq) return false;
+	const int n = mi_equalizer_fir_len(b->eq), s = leg->slot;
+	if (ed->pool) { // (on this hub, which is held)
+		ed->hist->assign((size_t)n, 0);
+		ed->has_hist = mi_equalizer_get_history(ed->pool->e, ed->slot, ed->hist->data(), n) == MI_OK;
+		ed->pool->release(ed->slot);
+		ed->pool = nullptr, ed->slot = -1;
+	}
+	bool ok = mi_equalizer_flatten(b->eq, s) == MI_OK && mi_equalizer_set_active(b->eq, s, ed->active) == MI_OK;
+	for (const MSEqualizerGain &g : *ed->pending) ok = ok && mi_equalizer_set_gain(b->eq, s, g.frequency, g.gain, g.width) == MI_OK;
+	ok = ok && mi_equalizer_set_history(b->eq, s, ed->has_hist ? ed->hist->data() : nullptr, n) == MI_OK;
+	ed->has_hist = false;
+	ed->leg = leg;
+	leg->eq = eqf;
+	return ok;
+}
+void leg_drop_equalizer(LegBank *b, FusedLeg *leg) {
+	if (!leg->eq) return;
+	EqualizerData *ed = (EqualizerData *)leg->eq->data;
+	if (b->eq && !b->failed) {
+		const int n = mi_equalizer_fir_len(b->eq);
+		ed->hist->assign((size_t)n, 0);
+		ed->has_hist = mi_equalizer_get_history(b->eq, leg->slot, ed->hist->data(), n) == MI_OK;
+	}
+	b->eq_later.erase(std::remove_if(b->eq_later.begin(), b->eq_later.end(), [&](const EqualizerPool::Op &o) { return o.slot == leg->slot; }), b->eq_later.end()); // (they are in the filter's `pending` list: its next slot replays them)
+	ed->leg = nullptr;
+	leg->eq = nullptr;
+}
+void leg_eq_op(FusedLeg *leg, const EqualizerPool::Op &op0) { // MS_EQUALIZER_SET_GAIN / SET_ACTIVE on a fused leg's equalizer (hub locked)
+	LegBank *b = leg->bank;
+	if (!b->eq || b->failed) return;
+	EqualizerPool::Op op = op0;
+	op.slot = leg->slot;
+	if (b->work_waiting()) b->eq_later.push_back(op);
+	else EqualizerPool::apply(b->eq, op);
+}
+mi_equalizer *leg_eq(FusedLeg *leg, int *slot) {
+	*slot = leg->slot;
+	return leg->bank->eq;
+}
 mi_volume_state *leg_pstate(FusedLeg *leg) { return leg->bank->vol_peer ? &leg->bank->pstate[(size_t)leg->slot] : nullptr; }
 bool leg_frames_chunks(FusedLeg *leg) { return leg && !leg->bank->light; }
 
@@ -1541,7 +1639,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		const SpeexECState *e = (const SpeexECState *)c.ec->data;
 		const uint32_t ir_c = c.rs ? ((const ResampleData *)c.rs->data)->input_rate : (uint32_t)ms->rate;
 		if (e->framesize != e0->framesize || e->filterlength != e0->filterlength || e->nominal_ref_samples != e0->nominal_ref_samples ||
-		    ir_c != ir0 || (c.rs == nullptr) != (cand[0].rs == nullptr) ||
+		    ir_c != ir0 || (c.rs == nullptr) != (cand[0].rs == nullptr) || (c.eq == nullptr) != (cand[0].eq == nullptr) ||
 		    volume_chunks((VolumeData *)c.vol->data) != volume_chunks((VolumeData *)cand[0].vol->data))
 			return false;
 	}
@@ -1554,9 +1652,10 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		}
 	const uint32_t ir = ir0, rate = (uint32_t)ms->rate;
 	const int F = e0->framesize, flen = e0->filterlength, delay = e0->nominal_ref_samples;
+	const bool with_eq = cand[0].eq != nullptr;
 	LegBank *b = bank<LegBank>("leg:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
-	                               std::to_string(delay) + ":" + std::to_string(mm) + (no_agc ? ":light" : ""),
-	                           1, [&](int cap) { return new LegBank(std::max(1, cap * 4 / mm), ir, rate, F, flen, delay, mm, false, no_agc); }); // 64, 256, 1024, .. legs
+	                               std::to_string(delay) + ":" + std::to_string(mm) + (no_agc ? ":light" : "") + (with_eq ? ":eq" : ""),
+	                           1, [&](int cap) { return new LegBank(std::max(1, cap * 4 / mm), ir, rate, F, flen, delay, mm, false, no_agc, with_eq); }); // 64, 256, 1024, .. legs
 	const int c = b ? b->acquire(mx) : -1;
 	if (c < 0) return false;
 	note_slot(mx);
@@ -1624,6 +1723,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		vd->leg = leg;
 		if (!b->give_remainder(leg->slot, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
 		if (cd.peer && !leg_take_peer(b, leg, cd.peer)) mi_failed("taking the echo limiter's peer into the batch");
+		if (cd.eq && !leg_take_equalizer(b, leg, cd.eq)) mi_failed("taking the leg's equalizer into the batch");
 	}
 	ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
 	ms->pool->release(ms->slot);
@@ -1639,8 +1739,13 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 }
 
 // the head of a leg (MSResample) looks for the mixer at the end of its chain
+// (through a mic_equalizer of ours between the two, audiostream.c:1801)
+MSQueue *leg_past_equalizer(MSQueue *q) {
+	MSFilter *g = q ? q->next.filter : NULL;
+	return (g && g->desc == &ms_mi355x_equalizer_desc && q->next.pin == 0) ? g->outputs[0] : q;
+}
 MSFilter *leg_find_mixer(MSFilter *rs) {
-	MSQueue *q = rs->outputs[0];
+	MSQueue *q = leg_past_equalizer(rs->outputs[0]);
 	MSFilter *ec = q ? q->next.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || q->next.pin != 1) return NULL;
 	q = ec->outputs[1];
@@ -1722,6 +1827,7 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 		if (!leg) continue;
 		leg_keep_volume(leg);
 		leg_drop_peer(b, leg);
+		leg_drop_equalizer(b, leg);
 		if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, leg->slot, b->in_rate, b->rate);
 		b->legs[(size_t)(c * mm + pin)] = nullptr;
 		if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
@@ -1751,7 +1857,8 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 // ---- a leg WITHOUT a mixer:  MSResample -> MSSpeexEC pin 1 -> MSVolume (AGC) -> any other filter, all ours on one ticker
 bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec);
 bool leg_try_fuse_plain(MSFilter *rs) {
-	MSQueue *q = rs->outputs[0];
+	if (!ms_queue_empty(rs->outputs[0])) return false;
+	MSQueue *q = leg_past_equalizer(rs->outputs[0]);
 	MSFilter *ec = q ? q->next.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || q->next.pin != 1 || !ms_queue_empty(q)) return false;
 	return leg_fuse_plain_at(rs, ec);
@@ -1760,6 +1867,10 @@ bool leg_try_fuse_plain(MSFilter *rs) {
 bool leg_try_fuse_plain_ec(MSFilter *ec) { return leg_fuse_plain_at(nullptr, ec); }
 bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	MSFilter *head = rs ? rs : ec;
+	MSFilter *eqf = ec->inputs[1] ? ec->inputs[1]->prev.filter : NULL; // a mic_equalizer of ours between the two (audiostream.c:1801)?
+	if (eqf && eqf->desc == &ms_mi355x_equalizer_desc) {
+		if (!rs || !ms_queue_empty(ec->inputs[1]) || !leg_equalizer_ok(eqf, head->ticker, ((SpeexECState *)ec->data)->samplerate)) return false;
+	} else eqf = nullptr;
 	if (getenv("MSMI355X_NO_FUSE") != nullptr || !head->ticker || head->ticker->interval != 10 || ec->ticker != head->ticker) return false;
 	ResampleData *rd = rs ? (ResampleData *)rs->data : nullptr;
 	SpeexECState *es = (SpeexECState *)ec->data;
@@ -1777,8 +1888,8 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
 	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;
 	LegBank *b = bank<LegBank>("legp:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
-	                               std::to_string(delay) + (no_agc ? ":light" : ""),
-	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true, no_agc); }); // 64, 256, 1024, .. legs
+	                               std::to_string(delay) + (no_agc ? ":light" : "") + (eqf ? ":eq" : ""),
+	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true, no_agc, eqf != nullptr); }); // 64, 256, 1024, .. legs
 	const int s = b ? b->acquire(vol) : -1;
 	if (s < 0) return false;
 	note_slot(vol);
@@ -1832,6 +1943,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	vd->leg = leg;
 	if (!b->give_remainder(s, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
 	if (peer && !leg_take_peer(b, leg, peer)) mi_failed("taking the echo limiter's peer into the batch");
+	if (eqf && !leg_take_equalizer(b, leg, eqf)) mi_failed("taking the leg's equalizer into the batch");
 	b->staged_since = true;
 	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (%sMSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen,
 	           rs ? "MSResample -> " : "");
@@ -1847,6 +1959,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	b->take_remainders(s, 1, keep_running);
 	leg_keep_volume(leg);
 	leg_drop_peer(b, leg);
+	leg_drop_equalizer(b, leg);
 	if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, s, b->in_rate, b->rate);
 	b->legs[(size_t)s] = nullptr;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;

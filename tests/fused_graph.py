@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "tests", "host")
 
 MS_SPEEX_EC_ID, MS_RESAMPLE_ID, MS_VOLUME_ID, MS_AUDIO_MIXER_ID = 28, 41, 43, 68
+MS_EQUALIZER_ID = 61
 MS_FILTER_BASE_ID = 2
 EC_IFACE = 16384 + 4
 
@@ -69,6 +70,8 @@ class Host:
         S.ms2shim_source_push.argtypes = [vp, vp, C.c_size_t]
         S.ms2shim_source_set_burst.argtypes = [vp, C.c_int]
         S.ms2shim_volume_set_peer.argtypes = [vp, vp]
+        S.ms2shim_equalizer_set_gain.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+        S.ms2shim_equalizer_set_active.argtypes = [vp, C.c_int]
         S.ms2shim_sink_read.restype = C.c_size_t
         S.ms2shim_sink_read.argtypes = [vp, vp, C.c_size_t]
         S.ms2shim_sink_size.restype = C.c_size_t
@@ -132,7 +135,7 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False, echo_limiter=False):
+                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -166,6 +169,12 @@ class Conferences:
                 # (resampler=False: the sound card / decoder already runs at the canceller's rate -- MSSpeexEC is the head of the leg; the
                 # MSResample is created all the same and stays unlinked)
                 links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1)] if resampler else [(leg["mic"], 0, leg["ec"], 1)]
+                if mic_equalizer:   # audiostream.c:1801: between read_resampler and ec, a response of its own per leg
+                    leg["eq"] = S.ms_factory_create_filter(h.fac, MS_EQUALIZER_ID)
+                    h.call_int(leg["eq"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                    assert S.ms2shim_equalizer_set_gain(leg["eq"], 1000.0 + 300.0 * k, 2.5, 600.0) == 0
+                    assert S.ms2shim_equalizer_set_gain(leg["eq"], 4000.0, 0.4, 1500.0) == 0
+                    links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["eq"], 0), (leg["eq"], 0, leg["ec"], 1)]
                 links += [(leg["ec"], 1, leg["vol"], 0), (leg["ec"], 0, leg["spk"], 0)]
                 if echo_limiter:   # audio_stream_enable_echo_limiter (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer
                     leg["volrecv"] = S.ms_factory_create_filter(h.fac, MS_VOLUME_ID)
@@ -212,7 +221,7 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv"):
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq"):
                 if k in leg:
                     self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
@@ -250,7 +259,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -283,6 +292,10 @@ def run(plugin_dir, fuse, scenario, h=None):
                     h.call_float(leg["vol"], VOL_SET_GAIN, val)
                 elif kind == "bypass":
                     h.call_bool(leg["ec"], EC_SET_BYPASS, val)
+                elif kind == "eq_gain":     # MS_EQUALIZER_SET_GAIN in mid-call
+                    assert h.S.ms2shim_equalizer_set_gain(leg["eq"], 2000.0, val, 800.0) == 0
+                elif kind == "eq_active":
+                    assert h.S.ms2shim_equalizer_set_active(leg["eq"], int(val)) == 0
                 elif kind == "recv_gain":   # volrecv stops being a meter only: the leg goes back to its facades
                     h.call_float(leg["volrecv"], VOL_SET_GAIN, val)
                 elif kind == "agc":
@@ -338,6 +351,13 @@ SCENARIOS = {
     "echo_limiter_peer_reconfigured": {"echo_limiter": True, "no_agc": True, "no_mixer": True, "nconf": 1, "members": 4, "nticks": 120,
                                        "events": [(80, "recv_gain", 1, 0.5)], "compare_ticks": 78},
     "echo_limiter_conference_keeps_its_facades": {"echo_limiter": True, "nticks": 60, "expect_unfused": True},
+    # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's
+    # memory, the up-sampler un-folds from the canceller's launch (resample, equalize, cancel: all on the device)
+    "mic_equalizer": {"mic_equalizer": True, "delay_ms": 10, "far_gaps": True, "nticks": 110, "events": [(40, "eq_gain", 1, 3.0), (70, "eq_active", 2, 0), (90, "eq_active", 2, 1)]},
+    "mic_equalizer_no_mixer_8k_16k": {"mic_equalizer": True, "no_mixer": True, "nconf": 1, "members": 5, "in_rate": 8000, "rate": 16000, "tail_ms": 128, "ptime20": True,
+                                      "nticks": 100, "events": [(41, "eq_gain", 3, 0.3)]},
+    "mic_equalizer_replumbed_then_leaves": {"mic_equalizer": True, "no_agc": True, "nticks": 110, "events": [(41, "reattach", 0, 0), (42, "reattach", 0, 0), (75, "agc", 1, 1)],
+                                            "tail_blocks": 1},
     # a leg / a conference leaves its batch WHILE ATTACHED (a method makes a member stop qualifying): nothing is heard of it -- the
     # canceller's adapted state and queues, the mixer channels' queues and clocks, MSVolume's state and framing go with the filters,
     # and the method meets the walk it preceded in both forms

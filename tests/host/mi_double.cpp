@@ -66,6 +66,7 @@ struct mi_equalizer {
 	int n, rate, nfft;
 	std::vector<std::vector<float>> gains, taps;
 	std::vector<int> active;
+	std::vector<int16_t> last; // the "history": the stream's last input sample (enough to make a lost history audible)
 };
 struct mi_aec {
 	mi_ctx *ctx;
@@ -465,11 +466,23 @@ int mi_volume_process_host(mi_volume *v, int16_t *x, int ns, int stride, const i
 int mi_equalizer_create(mi_ctx *ctx, int n, int rate, mi_equalizer **out) {
 	ARG(ctx && out && n > 0 && rate > 0);
 	const int nfft = rate < 16000 ? 128 : (rate < 32000 ? 256 : 512); // equalizer.c:60-66
-	mi_equalizer *e = new mi_equalizer{ctx, n, rate, nfft, {}, {}, {}};
+	mi_equalizer *e = new mi_equalizer{ctx, n, rate, nfft, {}, {}, {}, {}};
 	e->gains.assign((size_t)n, std::vector<float>((size_t)nfft / 2, 1.f));
 	e->taps.assign((size_t)n, std::vector<float>((size_t)nfft, 0.f));
 	e->active.assign((size_t)n, 1);
+	e->last.assign((size_t)n, 0);
 	*out = e;
+	return MI_OK;
+}
+int mi_equalizer_get_history(mi_equalizer *e, int s, int16_t *h, int n) {
+	ARG(e && h && s >= 0 && s < e->n && n == e->nfft);
+	memset(h, 0, (size_t)n * 2);
+	h[n - 2] = e->last[(size_t)s];
+	return MI_OK;
+}
+int mi_equalizer_set_history(mi_equalizer *e, int s, const int16_t *h, int n) {
+	ARG(e && s >= 0 && s < e->n && n == e->nfft);
+	e->last[(size_t)s] = h ? h[n - 2] : 0;
 	return MI_OK;
 }
 void mi_equalizer_destroy(mi_equalizer *e) { delete e; }
@@ -509,10 +522,22 @@ int mi_equalizer_set_taps(mi_equalizer *e, int s, const float *t, int n) {
 }
 int mi_equalizer_process_masked(mi_equalizer *e, int16_t *x, int ns, int stride, const int32_t *per) {
 	ARG(e && x && ns > 0 && stride >= ns);
-	volatile int16_t touch = 0;
-	for (int s = 0; s < e->n; ++s)
-		for (int i = 0; i < (per ? std::min(std::max(per[s], 0), ns) : ns); ++i) touch = x[(size_t)s * stride + i]; // reads what the kernel would
-	(void)touch;
+	// a two-tap filter anybody can hear: y[i] = g * x[i] - x[i-1] / 4 with g from the stream's gains, its memory carried from block
+	// to block (inactive: untouched, memory and all -- equalizer.c:283)
+	for (int s = 0; s < e->n; ++s) {
+		if (!e->active[(size_t)s]) continue;
+		float g = 0;
+		for (float v : e->gains[(size_t)s]) g += v;
+		g /= (float)e->gains[(size_t)s].size();
+		int16_t prev = e->last[(size_t)s];
+		for (int i = 0; i < (per ? std::min(std::max(per[s], 0), ns) : ns); ++i) {
+			const int16_t cur = x[(size_t)s * stride + i];
+			const float y = g * (float)cur - 0.25f * (float)prev;
+			x[(size_t)s * stride + i] = (int16_t)(y > 32767.f ? 32767 : (y < -32767.f ? -32767 : (int)y));
+			prev = cur;
+		}
+		e->last[(size_t)s] = prev;
+	}
 	return MI_OK;
 }
 int mi_equalizer_process(mi_equalizer *e, int16_t *x, int ns, int stride) { return mi_equalizer_process_masked(e, x, ns, stride, nullptr); }

@@ -806,6 +806,16 @@ void ms2shim_register_test_filters(MSFactory *f) {
 }
 MSFilter *ms2shim_new_source(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SOURCE_ID); }
 MSFilter *ms2shim_new_sink(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SINK_ID); }
+/* MS_EQUALIZER_SET_GAIN takes a struct: spelled here, where the header is */
+int ms2shim_equalizer_set_gain(MSFilter *eq, float frequency, float gain, float width) {
+	MSEqualizerGain g;
+	g.frequency = frequency, g.gain = gain, g.width = width;
+	return ms_filter_call_method(eq, MS_EQUALIZER_SET_GAIN, &g);
+}
+int ms2shim_equalizer_set_active(MSFilter *eq, int active) {
+	int a = active;
+	return ms_filter_call_method(eq, MS_EQUALIZER_SET_ACTIVE, &a);
+}
 /* MS_VOLUME_SET_PEER's id carries sizeof(MSFilter): spelled here, where the header is */
 int ms2shim_volume_set_peer(MSFilter *vol, MSFilter *peer) { return ms_filter_call_method(vol, MS_VOLUME_SET_PEER, peer); }
 void ms2shim_source_set_burst(MSFilter *src, int burst) { ((SrcData *)src->data)->burst = burst; }
