@@ -38,6 +38,42 @@ def test_equalizer_taps_and_output_bit_exact(ctx, oracle, rate, n):
     eq.close()
 
 
+def test_equalizer_stream_moves_between_batches_sample_for_sample(ctx, oracle):
+    """mi_equalizer_get_history / set_history: a stream that leaves one batch for another in mid-stream (the plugin's mic_equalizer joining
+    or leaving a fused leg) carries its FIR's memory -- ms_fir_mem16's `mem` lives as long as the filter (equalizer.c:256-268) -- and
+    continues bit for bit as the oracle's single filter does; a slot whose memory was cleared starts like a new filter."""
+    rate, n = 48000, 480
+    a, b = ms.EqualizerBatch(ctx, 3, rate), ms.EqualizerBatch(ctx, 5, rate)
+    orc, fresh = oracle.Equalizer(rate), oracle.Equalizer(rate)
+    for (f, g, w) in GAINS[:3]:
+        a.set_gain(1, f, g, w)
+        b.set_gain(4, f, g, w)
+        b.set_gain(2, f, g, w)
+        orc.set_gain(f, g, w)
+        fresh.set_gain(f, g, w)
+    sig = synth_pcm(9, n * 12, sigma=3000.0, rate=rate)
+    for t in range(6):
+        x = np.zeros((3, n), np.int16)
+        x[1] = sig[t * n:(t + 1) * n]
+        np.testing.assert_array_equal(a.process(np.ascontiguousarray(x))[1], orc.run(sig[t * n:(t + 1) * n]))
+    hist = a.history(1)
+    assert hist.any()
+    b.set_history(4, hist)
+    noise = np.stack([synth_pcm(20 + i, n, sigma=3000.0, rate=rate) for i in range(5)])
+    b.process(np.ascontiguousarray(noise[:, :n].copy()), )   # (slot 2 has run on something else: its memory is not clean)
+    b.set_history(4, hist)
+    b.set_history(2, None)
+    for t in range(6, 12):
+        x = noise.copy()
+        x[4] = sig[t * n:(t + 1) * n]
+        x[2] = sig[(t - 6) * n:(t - 5) * n]
+        got = b.process(np.ascontiguousarray(x))
+        np.testing.assert_array_equal(got[4], orc.run(sig[t * n:(t + 1) * n]), err_msg=f"moved stream, tick {t}")
+        np.testing.assert_array_equal(got[2], fresh.run(sig[(t - 6) * n:(t - 5) * n]), err_msg=f"cleared slot, tick {t}")
+    a.close()
+    b.close()
+
+
 def test_equalizer_flat_is_delay_and_inactive_passthrough(ctx, oracle):
     eq = ms.EqualizerBatch(ctx, 3, 48000)
     eq.set_active(1, 0)
