@@ -236,7 +236,7 @@ typedef struct {
 typedef struct {
 	pthread_mutex_t topo;
 	volatile int stop;
-	MSFilter *vol_conf, *vol_other, *ec_conf, *ec_bypass, *vol_solo, *volrecv;
+	MSFilter *vol_conf, *vol_other, *ec_conf, *ec_bypass, *vol_solo, *volrecv, *mic_eq;
 } meddle_t;
 static void *meddler(void *arg) {
 	meddle_t *m = (meddle_t *)arg;
@@ -255,6 +255,15 @@ static void *meddler(void *arg) {
 		ms_filter_call_method(m->vol_solo, MS_VOLUME_GET_LINEAR, &v);
 		ms_filter_call_method(m->volrecv, MS_VOLUME_GET, &v); /* the metered echo-limiter peer of a fused leg */
 		ms_filter_call_method(m->volrecv, MS_VOLUME_GET_MAX, &v);
+		{ /* the mic_equalizer of a fused leg: gains and the active switch from the application's thread, its state read back */
+			MSEqualizerGain eg;
+			float dump[256];
+			int act = k % 3 != 0;
+			eg.frequency = 1500.f + 100.f * (float)(k % 5), eg.gain = 0.5f + 0.25f * (float)(k % 4), eg.width = 700.f;
+			ms_filter_call_method(m->mic_eq, MS_EQUALIZER_SET_GAIN, &eg);
+			ms_filter_call_method(m->mic_eq, MS_EQUALIZER_SET_ACTIVE, &act);
+			ms_filter_call_method(m->mic_eq, MS_EQUALIZER_DUMP_STATE, dump);
+		}
 		ms_filter_call_method(m->ec_bypass, MS_ECHO_CANCELLER_SET_BYPASS_MODE, &byp);
 		pthread_mutex_unlock(&m->topo);
 		++k;
@@ -300,6 +309,9 @@ static void *conferences(void *arg) {
 		 * named as volsend's peer -- metered beside the fused leg, its blocks handed on in the walk */
 		MSFilter *volrecv = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
 		set_int(volrecv, MS_FILTER_SET_SAMPLE_RATE, 48000);
+		/* leg 2 carries a mic_equalizer between its MSResample and its canceller (audiostream.c:1801): it moves into the leg's bank */
+		MSFilter *mic_eq = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID);
+		set_int(mic_eq, MS_FILTER_SET_SAMPLE_RATE, 48000);
 		for (int k = 0; k < 3; ++k) {
 			leg_t *l = &solo[k];
 			l->mic = ms2shim_new_source(g_fac), l->far = ms2shim_new_source(g_fac);
@@ -313,6 +325,7 @@ static void *conferences(void *arg) {
 			set_int(l->vol, MS_FILTER_SET_SAMPLE_RATE, 48000);
 			if (k != 1) set_int(l->vol, MS_VOLUME_ENABLE_AGC, 1); /* leg 1: MSVolume without AGC (the default): fused into a bank of the other kind */
 			if (k == 0) ms_filter_link(l->mic, 0, l->ec, 1); /* no MSResample in front: MSSpeexEC is this leg's head (48 kHz microphone) */
+			else if (k == 2) ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, mic_eq, 0), ms_filter_link(mic_eq, 0, l->ec, 1);
 			else ms_filter_link(l->mic, 0, l->rs, 0), ms_filter_link(l->rs, 0, l->ec, 1);
 			ms_filter_link(l->ec, 1, l->vol, 0);
 			ms_filter_link(l->vol, 0, l->out, 0), ms_filter_link(l->ec, 0, l->spk, 0);
@@ -326,7 +339,7 @@ static void *conferences(void *arg) {
 		pthread_t med_th;
 		pthread_mutex_init(&med.topo, NULL);
 		med.stop = 0;
-		med.vol_conf = leg[0][1].vol, med.vol_other = leg[1][0].vol, med.ec_conf = leg[0][0].ec, med.ec_bypass = leg[1][3].ec, med.vol_solo = solo[2].vol, med.volrecv = volrecv;
+		med.vol_conf = leg[0][1].vol, med.vol_other = leg[1][0].vol, med.ec_conf = leg[0][0].ec, med.ec_bypass = leg[1][3].ec, med.vol_solo = solo[2].vol, med.volrecv = volrecv, med.mic_eq = mic_eq;
 		for (int t = 0; t < 14; ++t) {
 			if (t == 3) CHECK(pthread_create(&med_th, NULL, meddler, &med) == 0); /* (after the census at t == 2) */
 			for (int k = 0; k < 3; ++k) {
@@ -385,7 +398,10 @@ static void *conferences(void *arg) {
 			leg_t *l = &solo[k];
 			ms_ticker_detach(tk, l->mic);
 			if (k == 0) ms_filter_unlink(l->mic, 0, l->ec, 1);
-			else ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1);
+			else if (k == 2) {
+				ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, mic_eq, 0), ms_filter_unlink(mic_eq, 0, l->ec, 1);
+				ms_filter_destroy(mic_eq);
+			} else ms_filter_unlink(l->mic, 0, l->rs, 0), ms_filter_unlink(l->rs, 0, l->ec, 1);
 			ms_filter_unlink(l->ec, 1, l->vol, 0);
 			ms_filter_unlink(l->vol, 0, l->out, 0), ms_filter_unlink(l->ec, 0, l->spk, 0);
 			if (k == 1) {
