@@ -81,6 +81,8 @@ static int g_profile, g_checksum;
 static int g_nors, g_noagc, g_nomixer; /* PLUGIN_BENCH_SHAPE: words of "nors noagc nomixer" -- the leg without MSResample / without AGC / without a conference mixer */
 static int g_server; /* ... "server": a conference server's REMOTE members (audioconference.c:121-179,209-257): 8 kHz source (decoder .. dtmfgen) -> MSVolume -> in_resampler -> pin -> out_resampler -> MSUlawEnc -> sink, no canceller */
 static int g_dec; /* ... with "server": "dec" -- the sources hand over G.711 PACKETS (rtprecv) and MSUlawDec of the plugin heads every leg */
+static int g_eq; /* ... "eq": a mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801), a response of its own per leg */
+static int g_el; /* ... "el": the echo limiter on (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer (with nomixer) */
 static int g_eprs; /* ... "eprs": every pin behind an in_resampler, in front of an out_resampler, as MSAudioConference plumbs its endpoints (audioconference.c:209-257) */
 static double now_ms(void) {
 	struct timespec ts;
@@ -151,6 +153,15 @@ static void build(TickerJob *j) {
 			if (!g_noagc) call_int(vol, MS_VOLUME_ENABLE_AGC, 1);
 			if (g_nors) {
 				ms_filter_link(mic, 0, ec, 1);
+			} else if (g_eq) {
+				MSFilter *eq = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID);
+				MSEqualizerGain eg;
+				call_int(eq, MS_FILTER_SET_SAMPLE_RATE, 48000);
+				eg.frequency = 800.f + 50.f * (float)(leg % 32), eg.gain = 2.0f, eg.width = 500.f;
+				ms_filter_call_method(eq, MS_EQUALIZER_SET_GAIN, &eg);
+				ms_filter_link(mic, 0, rs, 0);
+				ms_filter_link(rs, 0, eq, 0);
+				ms_filter_link(eq, 0, ec, 1);
 			} else {
 				ms_filter_link(mic, 0, rs, 0);
 				ms_filter_link(rs, 0, ec, 1);
@@ -169,7 +180,16 @@ static void build(TickerJob *j) {
 				ms_filter_link(vol, 0, mx, k);
 				ms_filter_link(mx, k, out, 0);
 			}
-			ms_filter_link(far, 0, ec, 0);
+			if (g_el) {
+				MSFilter *volrecv = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+				float thres = 0.002f, force = 20.f;
+				call_int(volrecv, MS_FILTER_SET_SAMPLE_RATE, 48000);
+				ms_filter_call_method(vol, MS_VOLUME_SET_PEER, volrecv);
+				ms_filter_call_method(vol, MS_VOLUME_SET_EA_THRESHOLD, &thres);
+				ms_filter_call_method(vol, MS_VOLUME_SET_EA_FORCE, &force);
+				ms_filter_link(far, 0, volrecv, 0);
+				ms_filter_link(volrecv, 0, ec, 0);
+			} else ms_filter_link(far, 0, ec, 0);
 			ms_filter_link(ec, 0, spk, 0);
 			if (c == 0 && k == 0) j->probe_out = out;
 		}
@@ -312,6 +332,7 @@ int main(int argc, char **argv) {
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
+		g_eq = strstr(sh, "eq") != NULL, g_el = strstr(sh, " el") != NULL || strncmp(sh, "el", 2) == 0;
 	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
 	const char *plugin = argv[1];
