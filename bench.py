@@ -1103,6 +1103,22 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
     return out
 
 
+def plugin_shape_point(shape, legs=32768, ticks=400, warmup=40):
+    """one paced run of tests/host/plugin_bench in another leg shape at a fixed count (detail file only: what the shape costs, not a capacity)"""
+    exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
+    plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
+    ncores, _ = _host_cores()
+    tickers = max(1, min(16, ncores))
+    env = dict(os.environ, PLUGIN_BENCH_SHAPE=shape, PLUGIN_BENCH_PACED="1")
+    env.pop("MSMI355X_NO_FUSE", None)
+    r = subprocess.run([exe, plugin, str(legs), str(tickers), str(ticks), str(warmup)], capture_output=True, text=True, timeout=300, env=env)
+    if r.returncode != 0 or not r.stdout.strip():
+        raise RuntimeError(f"plugin_bench exit {r.returncode}: {r.stderr[-300:]}")
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    return {k: d.get(k) for k in ("legs", "tickers", "ticks", "fused_legs", "p50_ms", "p99_ms", "max_ms", "late", "us_per_leg_tick", "ticker_graph_walk_ms",
+                                  "ticker_flush_ms", "launches_per_tick_and_ticker", "late_events")}
+
+
 def cpu_baseline_chain(seconds, threads=1):
     """The oracle's CHAIN (CPU restatement of the reference path: one resampler, canceller + post-filter, volume object
     per call leg, one mixer per conference of 32, driven tick by tick as an MSTicker thread would) on this host's
@@ -1998,6 +2014,13 @@ def main():
                     line["plugin_path_server"] = sv
                 except Exception as e:
                     line["plugin_path_server"] = {"error": str(e)[:300]}
+                shapes = {}   # the other leg shapes the fused chain takes, one paced point each at a fixed count
+                for name, sh in (("mic_equalizer", "eq"), ("echo_limiter_no_mixer_no_agc", "el nomixer noagc"), ("no_mixer_no_agc", "nomixer noagc"), ("server_g711_decoder_heads", "server dec")):
+                    try:
+                        shapes[name] = plugin_shape_point(sh)
+                    except Exception as e:
+                        shapes[name] = {"error": str(e)[:200]}
+                line["plugin_path_shapes"] = shapes
                 pp = line["plugin_path"]
                 if pp.get("legs"):  # the ticker threads (one core each) it would take to bring `value` legs through the boundary at this load per core
                     pp["host_cores_for_value"] = int(-(-line["value"] // max(1, pp["legs"] // pp["tickers"])))
