@@ -1419,6 +1419,7 @@ void leg_forwarder_changed(MSFilter *rs) {
 	if (ms->fbank) ms->unfuse_wanted = true;
 }
 
+bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer);
 bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	MSQueue *q = mx->inputs[pin];
 	MSFilter *vol = q->prev.filter;
@@ -1447,6 +1448,7 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
 	if (!rs || rs->ticker != mx->ticker) return false;
+	if (!leg_far_end_in_walk(ec, c.peer)) return false;
 	c.eq = nullptr;
 	if (rs->desc == &ms_mi355x_equalizer_desc) { // mic_equalizer (audiostream.c:1801): the leg's head is the MSResample in front of it
 		if (!ms_queue_empty(qr) || !leg_equalizer_ok(rs, mx->ticker, ms->rate)) return false;
@@ -1465,6 +1467,42 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	if (rd->leg || ms_bufferizer_get_avail(rd->bz) || (rd->pool && rd->pool->staged[(size_t)rd->slot])) return false;
 	c.rs = rs, c.ec = ec, c.vol = vol, c.pin = pin;
 	return true;
+}
+
+// A fused leg's canceller is launched at the END of the walk that brought its microphone block: the far end of that walk must be
+// there by then -- it must reach MSSpeexEC's pin 0 IN the walk.  What the reference's graph guarantees (synchronous filters) holds here
+// when nothing upstream of pin 0 is a facade of ours whose blocks come back with the flush: a source or CPU filters, MSVolumes that
+// are meters only (they hand their blocks on in the walk, volume_passes), the leg's own metered peer.  Anything else -- volrecv with a
+// gain, spk_equalizer, a PLC or decoder of ours without a CPU filter behind it -- keeps the leg on its facades, whose queues pair the
+// two streams by count whenever they arrive.
+bool volume_meter_config(const VolumeData *d);
+bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer) {
+	MSQueue *q = ec->inputs[0];
+	for (int hops = 0; q && hops < 12; ++hops) {
+		MSFilter *g = q->prev.filter;
+		if (!g) return true;
+		if (is_ours(g->desc)) {
+			if (g->desc != &ms_mi355x_volume_desc) return false;
+			VolumeData *vd = (VolumeData *)g->data;
+			if (g != peer && !vd->meter_leg && !volume_meter_config(vd)) return false;
+		}
+		if (g->desc->ninputs == 0) return true; // a source
+		if (g->desc->ninputs != 1) return !is_ours(g->desc); // (a mixer or the like of somebody else's: it delivers in the walk)
+		q = g->inputs[0];
+	}
+	return true;
+}
+// ... and the other way round: the fused leg whose far end passes through this MSVolume (hub locked; NULL: none)
+FusedLeg *leg_fed_far_end_by(MSFilter *vol) {
+	MSQueue *q = vol->outputs[0];
+	for (int hops = 0; q && hops < 12; ++hops) {
+		MSFilter *g = q->next.filter;
+		if (!g) return nullptr;
+		if (is_ec_desc(g->desc)) return q->next.pin == 0 ? ((SpeexECState *)g->data)->leg : nullptr;
+		if (is_ours(g->desc) || g->desc->noutputs != 1) return nullptr;
+		q = g->outputs[0];
+	}
+	return nullptr;
 }
 
 // The leg takes its MSVolume's echo-limiter peer along (hub locked): the peer gives up its bank slot, its running state starts the
@@ -1884,6 +1922,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (!leg_peer_ok(vol, vd, &peer) || vd->sample_rate != es->samplerate || vd->leg) return false;
 	if (!leg_remainder_ok(vd, 1) || ms_bufferizer_get_avail(vd->spill)) return false;
 	const bool no_agc = !volume_chunks(vd); // (10 ms chunks with AGC or an echo-limiter peer, msvolume.c:480)
+	if (!leg_far_end_in_walk(ec, peer)) return false;
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
 	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;

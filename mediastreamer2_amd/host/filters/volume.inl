@@ -43,6 +43,9 @@ struct VolumePool : Pool {
 	bool fetched = false;
 	int rounds_fetched = 0;
 	std::vector<int> staged, ready;
+	// [kMaxRounds][capacity]: the row is a COPY for the meter -- the block itself went on in the walk, untouched (volume_process: an
+	// MSVolume that is a meter and nothing else); emit() records its energy and makes no block of it
+	std::vector<uint8_t> quiet;
 	std::vector<mi_volume_params> params;
 	std::vector<mi_volume_state> state;
 	// params_dirty / state_dirty: 1 = to the device with the next enqueue, 2 = set by a method while the last walk's blocks were still
@@ -68,6 +71,7 @@ struct VolumePool : Pool {
 		h_state = pinned<mi_volume_state>(kMaxRounds * c); // row r: the meters behind round r (every chunk's energy is recorded, msvolume.c:405-406)
 		staged.assign(c, 0);
 		ready.assign(c, 0);
+		quiet.assign(kMaxRounds * c, 0);
 		mi_volume_params p;
 		mi_volume_default_params(&p);
 		params.assign(c, p);
@@ -159,6 +163,8 @@ struct VolumeData { // struct Volume msvolume.c:48-86, host-side part
 	MSFilter *peer;
 	MSBufferizer *buffer;
 	MSBufferizer *spill; // light path: the part of an over-long block that did not fit this tick's rounds
+	bool feeds_far_end;  // its blocks end up on a canceller's far-end pin (looked up at every attach: volume_passes)
+	bool spill_quiet;    // ... which is a copy for the meter (the block itself went on in the walk: volume_passes)
 	MSBufferizer *backlog; // a conference server's member (server_leg.inl): whole blocks beyond a tick's launch rounds, kept block by block
 	Extremum min, max;
 	// struct Volume lives as long as the filter: energy, the gain ramp, the noise gate's and the echo limiter's counters all survive a
@@ -199,6 +205,8 @@ void volume_init(MSFilter *f) { // msvolume.c:88-118
 	mi_volume_default_params(&d->p);
 	d->gain = d->target_gain = 1;
 	d->chunks = false;
+	d->spill_quiet = false;
+	d->feeds_far_end = false;
 	d->sample_rate = 8000;
 	d->nsamples = 80;
 	d->peer = NULL;
@@ -281,6 +289,33 @@ mi_volume_state volume_start_state(const VolumeData *d) {
 bool volume_chunks(const VolumeData *d) { return d->p.agc_enabled != 0 || d->peer != NULL; }
 void volume_framing_now(MSFilter *f) { ((VolumeData *)f->data)->chunks = volume_chunks((VolumeData *)f->data); }
 
+// MSVolume as a METER and nothing else -- volrecv of a default AudioStream: no AGC, no gate, no DC removal, no peer, every gain exactly
+// 1 -- leaves every sample as it came (volume_process :505-513 with a Q12 gain of 4096: the sample loop is skipped, msvolume.c:440).
+// Where such a filter stands upstream of a canceller's far-end pin (audiostream.c:1812-1832) it hands its blocks on IN the walk, as the
+// reference's does, and stages a copy for the meter: the far end of a call leg reaches the canceller in the walk it belongs to, where a
+// block that came back with the next flush would find the microphone block it belongs to already cancelled against silence.  (Only
+// there: in front of a mixer, a meter that is given a gain in mid-call would jump from no latency to a tick's and open a gap.)
+// (its configuration alone: what the methods have set, whatever is still on its way to the device)
+bool volume_meter_config(const VolumeData *d) {
+	return !d->p.agc_enabled && !d->p.noise_gate_enabled && !d->p.remove_dc && d->peer == NULL && d->p.static_gain == 1.f && d->gain == 1.f && d->target_gain == 1.f;
+}
+FusedLeg *leg_fed_far_end_by(MSFilter *vol); // leg_chain.inl
+// a method made this MSVolume more than a meter: a fused leg whose far end passes through it goes back to its facades (leg_far_end_in_walk)
+void volume_far_end_changed(MSFilter *f, VolumeData *d) {
+	if (volume_meter_config(d) || !f->outputs[0]) return;
+	leg_disqualify(leg_fed_far_end_by(f));
+}
+bool volume_passes(const VolumeData *d) { // (hub locked)
+	static const bool off = getenv("MSMI355X_NO_METER_PASS") != nullptr; // A/B switch: a meter's blocks come back with the flush, as up to round 5
+	if (off || !d->feeds_far_end || d->chunks || d->p.agc_enabled || d->p.noise_gate_enabled || d->p.remove_dc || d->peer || d->p.static_gain != 1.f || !d->pool || d->slot < 0) return false;
+	if ((ms_bufferizer_get_avail(d->spill) && !d->spill_quiet) || ms_bufferizer_get_avail(d->buffer)) return false;
+	const VolumePool *p = d->pool;
+	const size_t s = (size_t)d->slot;
+	if (p->failed || p->params_dirty[s] == 2 || p->state_dirty[s] == 2 || (p->state_dirty[s] && !p->gain_patch[s].whole)) return false; // (a method's change on its way: wait for it)
+	const mi_volume_state &st = p->state[s];
+	return st.gain == 1.f && st.target_gain == 1.f && st.ng_gain == 1.f;
+}
+
 mi_volume_state *vstate(VolumeData *d) {
 	if (d->leg) return leg_vstate(d->leg);
 	if (d->meter_leg) return leg_pstate(d->meter_leg);
@@ -351,6 +386,20 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 	d->nsamples = (int)(0.01 * (float)d->sample_rate);
 	d->min.reset();
 	d->max.reset();
+	d->feeds_far_end = false;
+	{ // downstream through filters that are not ours (recv_tee ..) to MSSpeexEC's pin 0?
+		MSQueue *q = f->outputs[0];
+		for (int hops = 0; q && hops < 12; ++hops) {
+			MSFilter *g = q->next.filter;
+			if (!g) break;
+			if (g->desc == &ms_mi355x_speex_ec_desc || g->desc == &ms_mi355x_webrtc_aec_name_desc) {
+				d->feeds_far_end = q->next.pin == 0;
+				break;
+			}
+			if (is_ours(g->desc) || g->desc->noutputs != 1) break;
+			q = g->outputs[0];
+		}
+	}
 	volume_attach_slot(f);
 }
 
@@ -402,11 +451,13 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 				p->emit_all();
 			}
 			ms_bufferizer_read(d->buffer, (uint8_t *)(p->h_buf + (p->staged[s] * c + s) * p->cap_samples), nbytes);
+			p->quiet[p->staged[s] * c + s] = 0;
 			p->h_n[p->staged[s] * c + s] = d->nsamples;
 			p->staged[s]++;
 		}
 	} else { // :505-512 light path: one chunk per mblk.  A block longer than a batch row (20 ms and more than 960 samples)
 		// is cut into row-sized chunks -- no sample is dropped; the meter then sees those chunks, not the whole block.
+		const bool pass = volume_passes(d); // a meter only: the blocks go on now, the rows are the meter's copies
 		for (;;) {
 			if (p->staged[s] >= kMaxRounds) {
 				if (ms_bufferizer_get_avail(d->spill) == 0 && ms_queue_empty(f->inputs[0])) break;
@@ -416,20 +467,33 @@ void volume_process(MSFilter *f) { // msvolume.c:471-514
 			int16_t *row = p->h_buf + (p->staged[s] * c + s) * p->cap_samples;
 			int n = 0;
 			const size_t spilled = ms_bufferizer_get_avail(d->spill);
+			bool row_quiet = pass;
 			if (spilled) {
 				n = (int)std::min(spilled / 2, (size_t)p->cap_samples);
 				ms_bufferizer_read(d->spill, (uint8_t *)row, (size_t)n * 2);
+				row_quiet = d->spill_quiet;
+				if (ms_bufferizer_get_avail(d->spill) == 0) d->spill_quiet = false;
 			} else if ((m = ms_queue_get(f->inputs[0])) != NULL) {
 				n = (int)(msgdsize(m) / 2);
 				if (n > p->cap_samples) {
-					ms_bufferizer_put(d->spill, m); // served chunk by chunk from the top of the loop
+					if (pass) { // (a copy is cut for the meter like any over-long block; the block itself goes on whole)
+						mblk_t *cp = allocb((size_t)n * 2, 0);
+						copy_payload(m, cp->b_wptr);
+						cp->b_wptr += (size_t)n * 2;
+						ms_bufferizer_put(d->spill, cp);
+						d->spill_quiet = true;
+						if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+						else freemsg(m);
+					} else ms_bufferizer_put(d->spill, m); // served chunk by chunk from the top of the loop
 					continue;
 				}
-				memcpy(row, m->b_rptr, (size_t)n * 2);
-				freemsg(m);
+				copy_payload(m, (uint8_t *)row);
+				if (pass && f->outputs[0]) ms_queue_put(f->outputs[0], m);
+				else freemsg(m);
 			} else {
 				break;
 			}
+			p->quiet[p->staged[s] * c + s] = row_quiet;
 			p->h_n[p->staged[s] * c + s] = n;
 			p->staged[s]++;
 		}
@@ -442,6 +506,7 @@ void VolumePool::emit(MSFilter *f, int slot) {
 	const size_t c = (size_t)capacity, s = (size_t)slot;
 	for (int r = 0; r < ready[s]; ++r) {
 		const int n = h_n[r * c + s];
+		if (quiet[r * c + s]) continue; // (the block went on in the walk)
 		mblk_t *om = allocb((size_t)n * 2, 0);
 		memcpy(om->b_wptr, h_buf + (r * c + s) * cap_samples, (size_t)n * 2);
 		om->b_wptr += n * 2;
@@ -519,6 +584,7 @@ void volume_set_gains(MSFilter *f, VolumeData *d, bool also_target) {
 		if (p->state_dirty[s] != 1) p->state_dirty[s] = p->work_waiting() ? 2 : 1;
 	}
 	volume_push_params(d);
+	volume_far_end_changed(f, d);
 }
 int volume_set_gain(MSFilter *f, void *arg) { // :270-276
 	VolumeData *d = (VolumeData *)f->data;
@@ -584,6 +650,7 @@ int volume_set_rate(MSFilter *f, void *arg) {
 		HubLock lk(f); /* (the ticker thread reads d->p under it) */ \
 		d->p.field = val;                                          \
 		volume_push_params(d);                                     \
+		volume_far_end_changed(f, d);                              \
 		return 0;                                                  \
 	}
 VOL_FLOAT_SETTER(volume_set_ea_threshold, ea_thres, val >= 0 && val <= 1) // :305-314
@@ -596,6 +663,7 @@ int volume_set_ea_sustain(MSFilter *f, void *arg) {
 	HubLock lk(f);
 	d->p.sustain_time = *(int *)arg;
 	volume_push_params(d);
+	volume_far_end_changed(f, d);
 	return 0;
 }
 int volume_set_agc(MSFilter *f, void *arg) {
@@ -603,6 +671,7 @@ int volume_set_agc(MSFilter *f, void *arg) {
 	HubLock lk(f);
 	d->p.agc_enabled = *(int *)arg;
 	volume_push_params(d);
+	volume_far_end_changed(f, d);
 	return 0;
 }
 int volume_enable_noise_gate(MSFilter *f, void *arg) { // :352-359
@@ -627,6 +696,7 @@ int volume_remove_dc(MSFilter *f, void *arg) {
 	HubLock lk(f);
 	d->p.remove_dc = *(int *)arg;
 	volume_push_params(d);
+	volume_far_end_changed(f, d);
 	return 0;
 }
 MSFilterMethod volume_methods[] = {{MS_VOLUME_GET, volume_get},

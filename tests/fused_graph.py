@@ -135,7 +135,7 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False):
+                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -176,12 +176,13 @@ class Conferences:
                     assert S.ms2shim_equalizer_set_gain(leg["eq"], 4000.0, 0.4, 1500.0) == 0
                     links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["eq"], 0), (leg["eq"], 0, leg["ec"], 1)]
                 links += [(leg["ec"], 1, leg["vol"], 0), (leg["ec"], 0, leg["spk"], 0)]
-                if echo_limiter:   # audio_stream_enable_echo_limiter (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer
+                if echo_limiter or volrecv:   # audio_stream_enable_echo_limiter (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer
                     leg["volrecv"] = S.ms_factory_create_filter(h.fac, MS_VOLUME_ID)
                     h.call_int(leg["volrecv"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
-                    assert S.ms2shim_volume_set_peer(leg["vol"], leg["volrecv"]) == 0
-                    h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_THRESHOLD"], 0.002)   # (the scene's far end meters ~0.01: the limiter works)
-                    h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_FORCE"], 20.0)
+                    if echo_limiter:
+                        assert S.ms2shim_volume_set_peer(leg["vol"], leg["volrecv"]) == 0
+                        h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_THRESHOLD"], 0.002)   # (the scene's far end meters ~0.01: the limiter works)
+                        h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_FORCE"], 20.0)
                     links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["ec"], 0)]
                 else:
                     links += [(leg["far"], 0, leg["ec"], 0)]
@@ -259,7 +260,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -309,7 +310,7 @@ def run(plugin_dir, fuse, scenario, h=None):
         if t == nt // 2:
             mid_stats = h.fused_stats()
     levels = [h.get_float(leg["vol"], VOL_GET_LINEAR) for leg in conf.legs]
-    if sc.get("echo_limiter"):
+    if sc.get("echo_limiter") or sc.get("volrecv"):
         levels += [h.get_float(leg["volrecv"], VOL_GET_LINEAR) for leg in conf.legs]
     res = {"out": [h.drain(leg["out"]) for leg in conf.legs], "spk": [h.drain(leg["spk"]) for leg in conf.legs], "stats": mid_stats,
            "late": h.P.ms_mi355x_late_events() - late0, "levels": levels}
@@ -351,6 +352,13 @@ SCENARIOS = {
     "echo_limiter_peer_reconfigured": {"echo_limiter": True, "no_agc": True, "no_mixer": True, "nconf": 1, "members": 4, "nticks": 120,
                                        "events": [(80, "recv_gain", 1, 0.5)], "compare_ticks": 78},
     "echo_limiter_conference_keeps_its_facades": {"echo_limiter": True, "nticks": 60, "expect_unfused": True},
+    # the far end as an AudioStream brings it: through volrecv (audiostream.c:1812-1832), a meter only by default -- it hands its blocks on
+    # in the walk, so that the far end meets the microphone block of the same walk in the fused canceller; given a gain (the speaker's
+    # volume) its blocks come back with the flush, and the leg goes back to its facades, whose queues pair the streams by count
+    "far_end_through_volrecv": {"volrecv": True, "far_gaps": True, "delay_ms": 20, "nticks": 110, "events": [(41, "reattach", 0, 0), (70, "recv_gain", 1, 0.5)], "tail_blocks": 1},
+    "far_end_through_volrecv_no_mixer": {"volrecv": True, "no_mixer": True, "no_agc": True, "nconf": 1, "members": 5, "ptime20": True, "nticks": 100,
+                                         "events": [(61, "recv_gain", 2, 2.0)], "tail_blocks": 1},
+    "volrecv_with_a_gain_from_the_start": {"volrecv": True, "nticks": 60, "events": [(0, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's
     # memory, the up-sampler un-folds from the canceller's launch (resample, equalize, cancel: all on the device)
     "mic_equalizer": {"mic_equalizer": True, "delay_ms": 10, "far_gaps": True, "nticks": 110, "events": [(40, "eq_gain", 1, 3.0), (70, "eq_active", 2, 0), (90, "eq_active", 2, 1)]},
