@@ -1471,24 +1471,21 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 
 // A fused leg's canceller is launched at the END of the walk that brought its microphone block: the far end of that walk must be
 // there by then -- it must reach MSSpeexEC's pin 0 IN the walk.  What the reference's graph guarantees (synchronous filters) holds here
-// when nothing upstream of pin 0 is a facade of ours whose blocks come back with the flush: a source or CPU filters, MSVolumes that
-// are meters only (they hand their blocks on in the walk, volume_passes), the leg's own metered peer.  Anything else -- volrecv with a
-// gain, spk_equalizer, a PLC or decoder of ours without a CPU filter behind it -- keeps the leg on its facades, whose queues pair the
-// two streams by count whenever they arrive.
+// when pin 0 is fed by a filter that is not ours (a source, dtmfgen, a tee: it runs in the walk), directly or through MSVolumes that
+// are meters only (they hand their blocks on in the walk, volume_passes) or the leg's own metered peer.  A facade of ours that delivers
+// with the flush directly upstream -- volrecv with a gain, spk_equalizer, a PLC or decoder without a CPU filter behind it -- keeps the
+// leg on its facades, whose queues pair the two streams by count whenever they arrive.
 bool volume_meter_config(const VolumeData *d);
 bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer) {
 	MSQueue *q = ec->inputs[0];
 	for (int hops = 0; q && hops < 12; ++hops) {
 		MSFilter *g = q->prev.filter;
 		if (!g) return true;
-		if (is_ours(g->desc)) {
-			if (g->desc != &ms_mi355x_volume_desc) return false;
-			VolumeData *vd = (VolumeData *)g->data;
-			if (g != peer && !vd->meter_leg && !volume_meter_config(vd)) return false;
-		}
-		if (g->desc->ninputs == 0) return true; // a source
-		if (g->desc->ninputs != 1) return !is_ours(g->desc); // (a mixer or the like of somebody else's: it delivers in the walk)
-		q = g->inputs[0];
+		if (!is_ours(g->desc)) return true; // a source, dtmfgen, a tee ..: it runs in the walk and delivers in it, whatever feeds it (a facade of ours above it hands its blocks over at the start of the tick)
+		if (g->desc != &ms_mi355x_volume_desc) return false;
+		VolumeData *vd = (VolumeData *)g->data;
+		if (g != peer && !vd->meter_leg && !volume_meter_config(vd)) return false;
+		q = g->inputs[0]; // (a meter only: it hands on in the walk what it is handed in it)
 	}
 	return true;
 }

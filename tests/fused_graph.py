@@ -70,6 +70,8 @@ class Host:
         S.ms2shim_source_push.argtypes = [vp, vp, C.c_size_t]
         S.ms2shim_source_set_burst.argtypes = [vp, C.c_int]
         S.ms2shim_volume_set_peer.argtypes = [vp, vp]
+        S.ms2shim_new_pass.restype = vp
+        S.ms2shim_new_pass.argtypes = [vp]
         S.ms2shim_equalizer_set_gain.argtypes = [vp, C.c_float, C.c_float, C.c_float]
         S.ms2shim_equalizer_set_active.argtypes = [vp, C.c_int]
         S.ms2shim_sink_read.restype = C.c_size_t
@@ -135,7 +137,7 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False):
+                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -183,7 +185,12 @@ class Conferences:
                         assert S.ms2shim_volume_set_peer(leg["vol"], leg["volrecv"]) == 0
                         h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_THRESHOLD"], 0.002)   # (the scene's far end meters ~0.01: the limiter works)
                         h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_FORCE"], 20.0)
-                    links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["ec"], 0)]
+                    if cpu_filters:   # dtmfgen in front of volrecv, recv_tee behind it (audiostream.c:1826-1827): the application's own filters
+                        leg["dtmfgen"], leg["recv_tee"] = S.ms2shim_new_pass(h.fac), S.ms2shim_new_pass(h.fac)
+                        links += [(leg["far"], 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0),
+                                  (leg["recv_tee"], 0, leg["ec"], 0)]
+                    else:
+                        links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["ec"], 0)]
                 else:
                     links += [(leg["far"], 0, leg["ec"], 0)]
                 if mixer and endpoint_resamplers:
@@ -195,7 +202,11 @@ class Conferences:
                         h.call_int(f, base("MS_FILTER_SET_OUTPUT_SAMPLE_RATE"), rate)
                     links += [(leg["vol"], 0, leg["in_rs"], 0), (leg["in_rs"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out_rs"], 0), (leg["out_rs"], 0, leg["out"], 0)]
                 else:
-                    links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
+                    if not mixer and cpu_filters:   # volsend -> dtmfgen_rtp -> (encoder, rtpsend: the sink)
+                        leg["dtmfgen_rtp"] = S.ms2shim_new_pass(h.fac)
+                        links += [(leg["vol"], 0, leg["dtmfgen_rtp"], 0), (leg["dtmfgen_rtp"], 0, leg["out"], 0)]
+                    else:
+                        links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
                 for a, pa, b, pb in links:
                     assert S.ms_filter_link(a, pa, b, pb) == 0
                 self.legs.append(leg)
@@ -222,7 +233,7 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq"):
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp"):
                 if k in leg:
                     self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
@@ -260,7 +271,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -358,6 +369,11 @@ SCENARIOS = {
     "far_end_through_volrecv": {"volrecv": True, "far_gaps": True, "delay_ms": 20, "nticks": 110, "events": [(41, "reattach", 0, 0), (70, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     "far_end_through_volrecv_no_mixer": {"volrecv": True, "no_mixer": True, "no_agc": True, "nconf": 1, "members": 5, "ptime20": True, "nticks": 100,
                                          "events": [(61, "recv_gain", 2, 2.0)], "tail_blocks": 1},
+    # an AudioStream as audiostream.c:1798-1832 plumbs it, the application's CPU filters included: card at the stream's rate -> ec ->
+    # volsend -> dtmfgen_rtp -> ..;  .. -> dtmfgen -> volrecv -> recv_tee -> ec
+    "audiostream_16k_with_the_applications_filters": {"volrecv": True, "cpu_filters": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 16000,
+                                                      "rate": 16000, "nconf": 1, "members": 6, "far_gaps": True, "nticks": 110,
+                                                      "events": [(41, "reattach", 0, 0), (80, "recv_gain", 2, 0.5)], "tail_blocks": 1},
     "volrecv_with_a_gain_from_the_start": {"volrecv": True, "nticks": 60, "events": [(0, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's
     # memory, the up-sampler un-folds from the canceller's launch (resample, equalize, cancel: all on the device)

@@ -710,6 +710,7 @@ int ms2shim_ticker_profile(MSTicker *t, int *ids, uint64_t *ns, int cap, int *ma
  * (the role MS_VOID_SOURCE / file player / recorder play in the reference's testers) */
 #define SHIM_SOURCE_ID ((MSFilterId)9001)
 #define SHIM_SINK_ID ((MSFilterId)9002)
+#define SHIM_PASS_ID ((MSFilterId)9003)
 
 typedef struct {
 	queue_t pending; /* blocks the test queued; one is emitted per tick ... */
@@ -798,12 +799,24 @@ static MSFilterDesc shim_source_desc = {SHIM_SOURCE_ID, "ShimSource", "test sour
 static MSFilterDesc shim_sink_desc = {SHIM_SINK_ID, "ShimSink", "test sink", MS_FILTER_OTHER, NULL, 1, 0,
                                       sink_init, NULL, sink_process, NULL, sink_uninit, NULL, 0};
 
+/* a CPU filter of the host application's that hands its blocks on in the walk: stands for dtmfgen, recv_tee, a CPU encoder's front .. */
+static void pass_process(MSFilter *f) {
+	mblk_t *m;
+	while ((m = ms_queue_get(f->inputs[0])) != NULL) {
+		if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+		else freemsg(m);
+	}
+}
+static MSFilterDesc shim_pass_desc = {SHIM_PASS_ID, "ShimPass", "test pass-through", MS_FILTER_OTHER, NULL, 1, 1, NULL, NULL, pass_process, NULL, NULL, NULL, 0};
+
 void ms2shim_sink_set_discard(MSFilter *f, int on) { ((SinkData *)f->data)->discard = on; }
 
 void ms2shim_register_test_filters(MSFactory *f) {
 	ms_factory_register_filter(f, &shim_source_desc);
 	ms_factory_register_filter(f, &shim_sink_desc);
+	ms_factory_register_filter(f, &shim_pass_desc);
 }
+MSFilter *ms2shim_new_pass(MSFactory *f) { return ms_factory_create_filter(f, SHIM_PASS_ID); }
 MSFilter *ms2shim_new_source(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SOURCE_ID); }
 MSFilter *ms2shim_new_sink(MSFactory *f) { return ms_factory_create_filter(f, SHIM_SINK_ID); }
 /* MS_EQUALIZER_SET_GAIN takes a struct: spelled here, where the header is */

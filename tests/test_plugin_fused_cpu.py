@@ -31,7 +31,7 @@ def verdict():
                                   "endpoint_resamplers", "endpoint_resamplers_no_agc_no_resampler",
                                   "echo_limiter_no_mixer", "echo_limiter_agc_20ms", "echo_limiter_replumbed", "echo_limiter_peer_reconfigured",
                                   "echo_limiter_conference_keeps_its_facades",
-                                  "far_end_through_volrecv", "far_end_through_volrecv_no_mixer", "volrecv_with_a_gain_from_the_start",
+                                  "far_end_through_volrecv", "far_end_through_volrecv_no_mixer", "volrecv_with_a_gain_from_the_start", "audiostream_16k_with_the_applications_filters",
                                   "mic_equalizer", "mic_equalizer_no_mixer_8k_16k", "mic_equalizer_replumbed_then_leaves",
                                   "agc_switched_off_midcall", "bypass_switched_midcall", "agc_switched_on_midcall_no_mixer", "in_resampler_told_to_resample_midcall",
                                   "replumbed", "ptime20_replumbed", "ptime20_replumbed_no_early_launch", "no_agc_replumbed", "no_agc_ptime20_16k_replumbed"])
@@ -43,7 +43,7 @@ def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
     assert v["nonzero"] and v["samples"] > 0
     assert v["late"] == [0, 0], "a device queue differed from the host's framing, or a launch failed"
     assert v["after"] == [[0, 0, 0], [0, 0, 0]], "hubs / banks / slots left behind"
-    if "ptime20" not in name and "replumbed" not in name and "reconfigured" not in name and "midcall" not in name and "leaves" not in name and "volrecv" not in name:  # (a run that ends a tick apart, fused_graph.compare; with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
+    if "ptime20" not in name and "replumbed" not in name and "reconfigured" not in name and "midcall" not in name and "leaves" not in name and "volrecv" not in name and "audiostream" not in name:  # (a run that ends a tick apart, fused_graph.compare; with 20 ms packets the meter of a fused leg sees its last chunk a tick later: stated in leg_chain.inl)
         assert v["levels_equal"]
 
 
