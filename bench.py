@@ -1002,7 +1002,11 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
         the first did not fit (the host's CPUs are shared; both runs are listed) -- it fits if either did;
       * the search starts at `first_legs`, steps of 8192 legs (16 conferences of 32 per ticker): up a step at a time while the
         count fits (three more at most), else the counts below are bisected; `legs` is the largest count that fit;
-        `legs_p99_criterion` reads the same runs by round 4's rule (p99 < 10 ms, never a whole interval behind)."""
+        `legs_p99_criterion` reads the same runs by round 4's rule (p99 < 10 ms, never a whole interval behind);
+      * `host_noise_floor`: one more run of the same length at 128 legs per ticker -- a walk of ~0.2 ms -- says what THIS host does to a
+        ticker thread that has next to nothing to do (the pool's boxes are shared: some drop a tick of 600 even then, with the thread's
+        CPU time equal to the tick's wall time); `legs_at_host_noise_floor` reads the same runs as "no more ticks over 10 ms than the idle
+        walk showed".  Beside `legs`, never instead of it."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
     plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
@@ -1060,6 +1064,14 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
            "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
     p99_ok = [t["legs"] for t in tried if t.get("fits_p99")]
     out["legs_p99_criterion"] = max(p99_ok) if p99_ok else 0   # round 4's reading of the same runs: the largest count tried with p99 < 10 ms
+    try:
+        f0 = run(tickers * 128, ticks)
+        out["host_noise_floor"] = {k: f0.get(k) for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "slow_ticks")}
+        at_floor = [t["legs"] for t in tried if t.get("ticks_over_10ms") is not None and t["ticks_over_10ms"] <= f0["late"] and t["max_backlog_ms"] < 10.0
+                    and t["msticker_late_events"] == 0]
+        out["legs_at_host_noise_floor"] = max(at_floor) if at_floor else 0
+    except Exception as e:
+        out["host_noise_floor"] = {"error": str(e)[:200]}
     if best is None:
         out.update({"fits": False, "legs": 0})
         return out
@@ -1105,6 +1117,7 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
 
 def plugin_shape_point(shape, legs=32768, ticks=400, warmup=40):
     """one paced run of tests/host/plugin_bench in another leg shape at a fixed count (detail file only: what the shape costs, not a capacity)"""
+    import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
     plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
     ncores, _ = _host_cores()
@@ -1540,7 +1553,9 @@ def short_line(full, detail_name):
     if pp:
         out["plugin_path"] = _pick(pp, "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
                                    "launches_per_tick", "syncs_per_tick", "max_backlog_ms", "host_cores_granted",
-                                   "legs_per_host_core", "host_cores_for_value", "legs_p99_criterion", "fits", "error")
+                                   "legs_per_host_core", "host_cores_for_value", "legs_p99_criterion", "legs_at_host_noise_floor", "fits", "error")
+        if isinstance(pp.get("host_noise_floor"), dict):
+            out["plugin_path"]["host_noise_floor"] = _pick(pp["host_noise_floor"], "legs", "ticks_over_10ms", "max_ms", "error")
         eq = pp.get("fused_equals_one_by_one_4096_legs")
         if eq:
             out["plugin_path"]["fused_equals_one_by_one"] = eq.get("equal")
