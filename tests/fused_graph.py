@@ -20,6 +20,7 @@ HOST = os.path.join(ROOT, "tests", "host")
 
 MS_SPEEX_EC_ID, MS_RESAMPLE_ID, MS_VOLUME_ID, MS_AUDIO_MIXER_ID = 28, 41, 43, 68
 MS_EQUALIZER_ID = 61
+MS_ULAW_ENC_ID, MS_ULAW_DEC_ID, MS_GENERIC_PLC_ID = 7, 8, 111
 MS_FILTER_BASE_ID = 2
 EC_IFACE = 16384 + 4
 
@@ -137,7 +138,7 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False):
+                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -187,7 +188,13 @@ class Conferences:
                         h.call_float(leg["vol"], IDS["MS_VOLUME_SET_EA_FORCE"], 20.0)
                     if cpu_filters:   # dtmfgen in front of volrecv, recv_tee behind it (audiostream.c:1826-1827): the application's own filters
                         leg["dtmfgen"], leg["recv_tee"] = S.ms2shim_new_pass(h.fac), S.ms2shim_new_pass(h.fac)
-                        links += [(leg["far"], 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0),
+                        head = leg["far"]
+                        if g711:   # rtprecv's packets -> MSUlawDec -> MSGenericPLC (audiostream.c:1813-1824), facades of the plugin
+                            leg["dec"], leg["plc"] = S.ms_factory_create_filter(h.fac, MS_ULAW_DEC_ID), S.ms_factory_create_filter(h.fac, MS_GENERIC_PLC_ID)
+                            h.call_int(leg["plc"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                            links += [(leg["far"], 0, leg["dec"], 0), (leg["dec"], 0, leg["plc"], 0)]
+                            head = leg["plc"]
+                        links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0),
                                   (leg["recv_tee"], 0, leg["ec"], 0)]
                     else:
                         links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["ec"], 0)]
@@ -204,7 +211,11 @@ class Conferences:
                 else:
                     if not mixer and cpu_filters:   # volsend -> dtmfgen_rtp -> (encoder, rtpsend: the sink)
                         leg["dtmfgen_rtp"] = S.ms2shim_new_pass(h.fac)
-                        links += [(leg["vol"], 0, leg["dtmfgen_rtp"], 0), (leg["dtmfgen_rtp"], 0, leg["out"], 0)]
+                        if g711:   # .. -> MSUlawEnc (its default 20 ms packets) -> rtpsend
+                            leg["enc"] = S.ms_factory_create_filter(h.fac, MS_ULAW_ENC_ID)
+                            links += [(leg["vol"], 0, leg["dtmfgen_rtp"], 0), (leg["dtmfgen_rtp"], 0, leg["enc"], 0), (leg["enc"], 0, leg["out"], 0)]
+                        else:
+                            links += [(leg["vol"], 0, leg["dtmfgen_rtp"], 0), (leg["dtmfgen_rtp"], 0, leg["out"], 0)]
                     else:
                         links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
                 for a, pa, b, pb in links:
@@ -233,7 +244,7 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp"):
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp", "dec", "plc", "enc"):
                 if k in leg:
                     self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
@@ -271,10 +282,17 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
+    far_codes = None
+    if sc.get("g711"):   # what the far endpoints send: their audio as PCMU (the oracle's encoder, pinned against the reference's g711.c)
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import oracle
+        oracle.build()
+        far_codes = [np.ascontiguousarray(oracle.g711_encode(1, far[s])) for s in range(n)]
     late0 = h.P.ms_mi355x_late_events()
     before = h.runtime_stats()   # (other graphs of the same process may be alive: what this run leaves behind is the difference)
     conf.attach()
@@ -290,7 +308,11 @@ def run(plugin_dir, fuse, scenario, h=None):
             else:
                 h.push(leg["mic"], mic[s, t * ni:(t + 1) * ni])
             # far end: regular, or with a late packet every 17th tick per leg (nothing, then two blocks at once)
-            if sc.get("far_gaps") and (t + 3 * s) % 17 == 5:
+            if sc.get("g711"):   # PCMU packets of 10 ms, one in 19 lost (the PLC conceals it)
+                if (t + 2 * s) % 19 != 7:
+                    pk = far_codes[s][t * ns:(t + 1) * ns]
+                    h.S.ms2shim_source_push(leg["far"], pk.ctypes.data, pk.nbytes)
+            elif sc.get("far_gaps") and (t + 3 * s) % 17 == 5:
                 h.push(leg["far"], np.zeros(0, np.int16))
             elif sc.get("far_gaps") and (t + 3 * s) % 17 == 6:
                 h.push(leg["far"], far[s, (t - 1) * ns:(t + 1) * ns])
@@ -374,6 +396,9 @@ SCENARIOS = {
     "audiostream_16k_with_the_applications_filters": {"volrecv": True, "cpu_filters": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 16000,
                                                       "rate": 16000, "nconf": 1, "members": 6, "far_gaps": True, "nticks": 110,
                                                       "events": [(41, "reattach", 0, 0), (80, "recv_gain", 2, 0.5)], "tail_blocks": 1},
+    # ... and a narrow-band G.711 call end to end: packets in through MSUlawDec -> MSGenericPLC (one in 19 lost), the card at 8 kHz, packets out of MSUlawEnc
+    "audiostream_8k_g711": {"volrecv": True, "cpu_filters": True, "g711": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000,
+                            "nconf": 1, "members": 6, "nticks": 120, "events": [(61, "reattach", 0, 0)], "tail_blocks": 2},
     "volrecv_with_a_gain_from_the_start": {"volrecv": True, "nticks": 60, "events": [(0, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's
     # memory, the up-sampler un-folds from the canceller's launch (resample, equalize, cancel: all on the device)
