@@ -2030,7 +2030,8 @@ def main():
                 except Exception as e:
                     line["plugin_path_server"] = {"error": str(e)[:300]}
                 shapes = {}   # the other leg shapes the fused chain takes, one paced point each at a fixed count
-                for name, sh in (("mic_equalizer", "eq"), ("echo_limiter_no_mixer_no_agc", "el nomixer noagc"), ("no_mixer_no_agc", "nomixer noagc"), ("server_g711_decoder_heads", "server dec")):
+                for name, sh in (("mic_equalizer", "eq"), ("echo_limiter_no_mixer_no_agc", "el nomixer noagc"), ("no_mixer_no_agc", "nomixer noagc"), ("server_g711_decoder_heads", "server dec"),
+                                 ("audiostreams_8k_g711_full_duplex", "astream")):
                     try:
                         shapes[name] = plugin_shape_point(sh)
                     except Exception as e:

@@ -40,6 +40,7 @@ void ms_ticker_step(MSTicker *t);
 void ms2shim_register_test_filters(MSFactory *f);
 MSFilter *ms2shim_new_source(MSFactory *f);
 MSFilter *ms2shim_new_sink(MSFactory *f);
+MSFilter *ms2shim_new_pass(MSFactory *f);
 void ms2shim_sink_set_discard(MSFilter *f, int on);
 void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase);
 void ms2shim_ticker_last_step(MSTicker *t, uint64_t *tasks_ns, uint64_t *step_ns);
@@ -81,6 +82,9 @@ static int g_profile, g_checksum;
 static int g_nors, g_noagc, g_nomixer; /* PLUGIN_BENCH_SHAPE: words of "nors noagc nomixer" -- the leg without MSResample / without AGC / without a conference mixer */
 static int g_server; /* ... "server": a conference server's REMOTE members (audioconference.c:121-179,209-257): 8 kHz source (decoder .. dtmfgen) -> MSVolume -> in_resampler -> pin -> out_resampler -> MSUlawEnc -> sink, no canceller */
 static int g_dec; /* ... with "server": "dec" -- the sources hand over G.711 PACKETS (rtprecv) and MSUlawDec of the plugin heads every leg */
+static int g_astream; /* ... "astream": full-duplex narrow-band AudioStreams as audiostream.c:1798-1832 plumbs them, the card at 8 kHz: PCMU packets ->
+                        MSUlawDec -> MSGenericPLC -> dtmfgen (the application's) -> volrecv -> recv_tee -> MSSpeexEC pin 0 -> speaker;  microphone -> MSSpeexEC
+                        pin 1 -> volsend -> dtmfgen_rtp -> MSUlawEnc -> packets.  The sending side fuses leg by leg, the receiving side runs as facades. */
 static int g_eq; /* ... "eq": a mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801), a response of its own per leg */
 static int g_el; /* ... "el": the echo limiter on (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer (with nomixer) */
 static int g_eprs; /* ... "eprs": every pin behind an in_resampler, in front of an out_resampler, as MSAudioConference plumbs its endpoints (audioconference.c:209-257) */
@@ -133,7 +137,31 @@ static void build(TickerJob *j) {
 			}
 			continue;
 		}
-		for (int k = 0; k < g_members; ++k) {
+		for (int k = 0; k < g_members && g_astream; ++k) {
+			MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
+			MSFilter *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID), *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID), *volrecv = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+			MSFilter *dec = ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID), *plc = ms_factory_create_filter(g_fac, MS_GENERIC_PLC_ID), *enc = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
+			MSFilter *dtmfgen = ms2shim_new_pass(g_fac), *recv_tee = ms2shim_new_pass(g_fac), *dtmfgen_rtp = ms2shim_new_pass(g_fac);
+			const int leg = (j->index * j->nconf + c) * g_members + k;
+			ms2shim_source_set_loop(mic, g_pcm8, sizeof(g_pcm8[0]), RING, leg);
+			ms2shim_source_set_loop(far, g_codes8, sizeof(g_codes8[0]), RING, leg * 7);
+			ms2shim_sink_set_discard(spk, g_checksum ? 2 : 1);
+			ms2shim_sink_set_discard(out, g_checksum ? 2 : 1);
+			j->outs[c * g_members + k] = out;
+			j->spks[c * g_members + k] = spk;
+			j->heads[c * g_members + k] = mic;
+			call_int(ec, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			call_int(ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 128);
+			call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			call_int(volrecv, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			call_int(plc, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			ms_filter_link(far, 0, dec, 0), ms_filter_link(dec, 0, plc, 0), ms_filter_link(plc, 0, dtmfgen, 0), ms_filter_link(dtmfgen, 0, volrecv, 0);
+			ms_filter_link(volrecv, 0, recv_tee, 0), ms_filter_link(recv_tee, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
+			ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vol, 0), ms_filter_link(vol, 0, dtmfgen_rtp, 0), ms_filter_link(dtmfgen_rtp, 0, enc, 0);
+			ms_filter_link(enc, 0, out, 0);
+			if (c == 0 && k == 0) j->probe_out = out;
+		}
+		for (int k = 0; k < g_members && !g_astream; ++k) {
 			MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
 			MSFilter *rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
 			MSFilter *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
@@ -332,6 +360,8 @@ int main(int argc, char **argv) {
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
+		g_astream = strstr(sh, "astream") != NULL;
+		if (g_astream) g_nomixer = 1;
 		g_eq = strstr(sh, "eq") != NULL, g_el = strstr(sh, " el") != NULL || strncmp(sh, "el", 2) == 0;
 	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */

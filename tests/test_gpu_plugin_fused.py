@@ -141,7 +141,7 @@ def test_a_volume_method_on_a_fused_leg_meets_the_next_walks_chunk_in_both_forms
     assert fused["late"] == 0 and plain["late"] == 0
 
 
-@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nors noagc nomixer", "eprs", "eq", "el nomixer noagc"])
+@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nors noagc nomixer", "eprs", "eq", "el nomixer noagc", "astream"])
 def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape):
     """4 096 full legs (128 conferences of 32, four tickers) for 190 ticks through tests/host/plugin_bench, fused and with the
     facades one by one (MSMI355X_NO_FUSE=1): every leg's mix and every leg's speaker audio, byte for byte and in order, folded
@@ -149,7 +149,8 @@ def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape
     buffers with copy launches (MSMI355X_ZERO_COPY=0).  The size-independent form of test_fused_conference_equals_...
     shape: the leg without MSResample (a 48 kHz microphone), with MSVolume's AGC off (the reference's default), without a
     conference mixer -- "nors noagc nomixer" is the sending side of a default AudioStream; "eq": a mic_equalizer in every leg;
-    "el": the echo limiter on, volrecv metered beside the leg."""
+    "el": the echo limiter on, volrecv metered beside the leg; "astream": full-duplex narrow-band G.711 AudioStreams with the
+    application's own filters in between (audiostream.c:1798-1832)."""
     import json
     import subprocess
     host_dir = os.path.join(fg.ROOT, "tests", "host")
