@@ -168,7 +168,7 @@ def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape
 
     fused, plain, staged = run(), run(MSMI355X_NO_FUSE="1"), run(MSMI355X_ZERO_COPY="0")
     assert fused["fused_legs"] == 4096 and plain["fused_legs"] == 0 and staged["fused_legs"] == 4096
-    assert fused["mix_bytes"] == plain["mix_bytes"] > 4096 * 150 * 900
+    assert fused["mix_bytes"] == plain["mix_bytes"] > 4096 * 150 * (70 if shape == "astream" else 900)   # (PCMU packets there: 80 B per leg and tick)
     assert fused["mix_checksum"] == plain["mix_checksum"] == staged["mix_checksum"], (fused["mix_checksum"], plain["mix_checksum"], staged["mix_checksum"])
     assert fused["speaker_checksum"] == plain["speaker_checksum"] == staged["speaker_checksum"]
     assert fused["late_events"] == 0 and plain["late_events"] == 0
