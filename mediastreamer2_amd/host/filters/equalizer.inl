@@ -61,10 +61,14 @@ struct EqualizerPool : Pool {
 				for (int s = 0; s < capacity; ++s)
 					if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
 			}
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, nrow, c * 4));
-			MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
-			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			if (zero_copy_rows()) { // (in place in pinned memory, as VolumePool)
+				MI_MUST(mi_equalizer_process_masked(e, h_buf + r * c * cap_samples, cap_samples, cap_samples, nrow));
+			} else {
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_n, nrow, c * 4));
+				MI_MUST(mi_equalizer_process_masked(e, d_buf, cap_samples, cap_samples, d_n));
+				MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			}
 		}
 		return maxr > 0;
 	}

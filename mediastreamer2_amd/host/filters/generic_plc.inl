@@ -100,11 +100,15 @@ struct PlcPool : Pool {
 				for (int s = 0; s < capacity; ++s)
 					if (staged[(size_t)s] <= r) h_mode[r * c + s] = MI_PLC_NONE, h_len[r * c + s] = 0;
 			}
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_rows, h_rows + r * c * kPlcBlock, c * kPlcBlock * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_len, lrow, c * 4));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_mode, mrow, c));
-			MI_MUST(mi_plc_process(plc, d_rows, kPlcBlock, d_len, d_mode));
-			MI_MUST(mi_copy_d2h_pinned(ctx, h_rows + r * c * kPlcBlock, d_rows, c * kPlcBlock * 2));
+			if (zero_copy_rows()) { // the launch works on the pieces where they lie in pinned memory: what crosses PCIe is the audio, not 1920 samples of row per stream
+				MI_MUST(mi_plc_process(plc, h_rows + r * c * kPlcBlock, kPlcBlock, lrow, mrow));
+			} else {
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_rows, h_rows + r * c * kPlcBlock, c * kPlcBlock * 2));
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_len, lrow, c * 4));
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_mode, mrow, c));
+				MI_MUST(mi_plc_process(plc, d_rows, kPlcBlock, d_len, d_mode));
+				MI_MUST(mi_copy_d2h_pinned(ctx, h_rows + r * c * kPlcBlock, d_rows, c * kPlcBlock * 2));
+			}
 		}
 		if (maxr) MI_MUST(mi_ctx_sync(ctx));
 		for (int s = 0; s < capacity; ++s) {

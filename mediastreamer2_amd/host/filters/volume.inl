@@ -113,10 +113,14 @@ struct VolumePool : Pool {
 				for (int s = 0; s < capacity; ++s)
 					if (s >= hi || staged[(size_t)s] <= r) h_n[r * c + s] = 0;
 			}
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
-			MI_MUST(mi_copy_h2d_pinned(ctx, d_n, nrow, c * 4));
-			MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
-			MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			if (zero_copy_rows()) { // the launch reads and levels the blocks where they lie in pinned memory: what crosses PCIe is the audio, not the rows' capacity
+				MI_MUST(mi_volume_process(v, h_buf + r * c * cap_samples, cap_samples, cap_samples, nrow));
+			} else {
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_buf, h_buf + r * c * cap_samples, u * cap_samples * 2));
+				MI_MUST(mi_copy_h2d_pinned(ctx, d_n, nrow, c * 4));
+				MI_MUST(mi_volume_process(v, d_buf, cap_samples, cap_samples, d_n));
+				MI_MUST(mi_copy_d2h_pinned(ctx, h_buf + r * c * cap_samples, d_buf, u * cap_samples * 2));
+			}
 			if (!failed) MI_MUST(mi_volume_get_state_async(v, 0, hi, h_state + r * c)); // meters for the app thread
 		}
 		fetched = maxr > 0 && !failed;
