@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): what the driver runs at round end -- pytest -m gpu, smoke(), bench.py -- plus the rocprofv3
 # kernel stats of the bench command itself.  Results under gpurun_out/r05_final/.
 set -u
-OUT=gpurun_out/r05_final
+OUT=gpurun_out/${R05_OUT:-r05_final}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 nproc > $OUT/env.txt; uptime >> $OUT/env.txt; lscpu | grep "Model name" >> $OUT/env.txt
