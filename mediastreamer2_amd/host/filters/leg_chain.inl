@@ -1476,6 +1476,7 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 // with the flush directly upstream -- volrecv with a gain, spk_equalizer, a PLC or decoder without a CPU filter behind it -- keeps the
 // leg on its facades, whose queues pair the two streams by count whenever they arrive.
 bool volume_meter_config(const VolumeData *d);
+bool volume_passes(const VolumeData *d);
 bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer) {
 	MSQueue *q = ec->inputs[0];
 	for (int hops = 0; q && hops < 12; ++hops) {
@@ -1484,7 +1485,7 @@ bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer) {
 		if (!is_ours(g->desc)) return true; // a source, dtmfgen, a tee ..: it runs in the walk and delivers in it, whatever feeds it (a facade of ours above it hands its blocks over at the start of the tick)
 		if (g->desc != &ms_mi355x_volume_desc) return false;
 		VolumeData *vd = (VolumeData *)g->data;
-		if (g != peer && !vd->meter_leg && !volume_meter_config(vd)) return false;
+		if (g != peer && !vd->meter_leg && !(volume_meter_config(vd) && vd->feeds_far_end && (!vd->pool || volume_passes(vd)))) return false; // (its running gain may still be on its way back to 1: then it does not pass yet)
 		q = g->inputs[0]; // (a meter only: it hands on in the walk what it is handed in it)
 	}
 	return true;
