@@ -81,6 +81,47 @@ def test_echo_limiter_leg_is_the_oracles_two_volume_chain(host, oracle, form):
     assert worst <= 1e-4, worst
 
 
+@pytest.mark.parametrize("form", ["fused", "one_by_one"])
+def test_mic_equalizer_leg_is_the_oracle_chain(host, oracle, form):
+    """DIRECT: a sending leg with a mic_equalizer (audiostream.c:1798-1810: read_resampler -> mic_equalizer -> ec -> volsend) against the
+    chain of oracle objects -- Resampler -> Equalizer (one FIR block per microphone block, its memory carried, equalizer.c:256-288) ->
+    MSSpeexEC's framing -> Echo + Preproc -> MSVolume without AGC (a meter: the frames leave as they came); a gain set in mid-call meets
+    the next walk's block.  What the leg sends, within north_star's 1e-4 RMS of full scale."""
+    sc = {"mic_equalizer": True, "no_mixer": True, "no_agc": True, "nconf": 1, "members": 3, "delay_ms": 10, "nticks": 140, "events": [(60, "eq_gain", 1, 3.0)]}
+    res = fg.run(PKG, form == "fused", sc, host)
+    assert (res["stats"]["legs"] > 0) == (form == "fused")
+    F, rate, in_rate, ns, ni, nt = 256, 48000, 16000, 480, 160, sc["nticks"]
+    mic, far = fg.scene(3, nt, in_rate, rate, seed=sc.get("seed", 7))
+    worst = 0.0
+    for s in range(3):
+        rs, eq, ec = oracle.Resampler(in_rate, rate), oracle.Equalizer(rate), oracle.Echo(F, 128 * rate // 1000, rate)
+        pp = oracle.Preproc(F, rate, ec)
+        eq.set_gain(1000.0 + 300.0 * s, 2.5, 600.0)
+        eq.set_gain(4000.0, 0.4, 1500.0)
+        D = 10 * rate // 1000
+        q_mic, q_ref = np.zeros(0, np.int16), np.zeros(D, np.int16)   # (the delay line starts with `delay` of zeros, speexec.c:205-208)
+        started, sent = False, []
+        for t in range(nt):
+            if t == 60 and s == 1:
+                eq.set_gain(2000.0, 3.0, 800.0)
+            if started:
+                q_ref = np.concatenate([q_ref, far[s, t * ns:(t + 1) * ns]])
+            q_mic = np.concatenate([q_mic, eq.run(rs.process(mic[s, t * ni:(t + 1) * ni]))])
+            while len(q_mic) >= F:
+                fr, q_mic, started = q_mic[:F], q_mic[F:], True
+                if len(q_ref) < D + F:                           # speexec.c:262-275: less than the delay + a frame queued: a frame of silence goes in
+                    q_ref = np.concatenate([q_ref, np.zeros(F, np.int16)])
+                r, q_ref = q_ref[:F], q_ref[F:]
+                sent.append(pp.run(ec.cancel(fr, r)))
+        want = np.concatenate(sent)
+        got = res["out"][s]
+        assert 0 <= len(want) - len(got) <= 3 * ns and len(got) > 60000, (s, len(got), len(want))
+        d = (got.astype(np.float64) - want[:len(got)].astype(np.float64)) / 32768.0
+        worst = max(worst, float(np.sqrt(np.mean(d * d))))
+        assert np.abs(want.astype(np.int64)).max() > 100
+    assert worst <= 1e-4, worst
+
+
 def test_the_fused_cancellers_cancel(host):
     """the microphone is the far end through a room: after two seconds a leg's mix of the OTHER legs' cleaned microphones is
     far below what the raw microphones would give (the cancellers converge inside the fused batch as anywhere else)"""
