@@ -32,6 +32,7 @@
 
 MSFilter *ms2shim_new_source(MSFactory *f);
 MSFilter *ms2shim_new_sink(MSFactory *f);
+MSFilter *ms2shim_new_pass(MSFactory *f);
 void ms2shim_register_test_filters(MSFactory *f);
 void ms2shim_source_push(MSFilter *src, const void *data, size_t nbytes);
 void ms2shim_sink_set_discard(MSFilter *f, int on);
@@ -310,6 +311,10 @@ static void *conferences(void *arg) {
 		MSFilter *volrecv = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
 		set_int(volrecv, MS_FILTER_SET_SAMPLE_RATE, 48000);
 		/* leg 2 carries a mic_equalizer between its MSResample and its canceller (audiostream.c:1801): it moves into the leg's bank */
+		/* leg 0's far end comes through a plain volrecv and the application's recv_tee (audiostream.c:1826-1828): a meter only, it hands
+		 * its blocks on in the walk -- until the meddler gives it a gain, which sends the leg back to its facades */
+		MSFilter *volrecv0 = ms_factory_create_filter(g_fac, MS_VOLUME_ID), *tee0 = ms2shim_new_pass(g_fac);
+		set_int(volrecv0, MS_FILTER_SET_SAMPLE_RATE, 48000);
 		MSFilter *mic_eq = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID);
 		set_int(mic_eq, MS_FILTER_SET_SAMPLE_RATE, 48000);
 		for (int k = 0; k < 3; ++k) {
@@ -332,6 +337,8 @@ static void *conferences(void *arg) {
 			if (k == 1) {
 				ms_filter_link(l->far, 0, volrecv, 0), ms_filter_link(volrecv, 0, l->ec, 0);
 				CHECK(ms_filter_call_method(l->vol, MS_VOLUME_SET_PEER, volrecv) == 0);
+			} else if (k == 0) {
+				ms_filter_link(l->far, 0, volrecv0, 0), ms_filter_link(volrecv0, 0, tee0, 0), ms_filter_link(tee0, 0, l->ec, 0);
 			} else ms_filter_link(l->far, 0, l->ec, 0);
 			CHECK(ms_ticker_attach(tk, l->mic) == 0);
 		}
@@ -384,6 +391,7 @@ static void *conferences(void *arg) {
 				ms_filter_link(leg[0][2].vol, 0, mx[0], 2), ms_filter_link(mx[0], 2, leg[0][2].out, 0);
 				CHECK(ms_ticker_attach(tk, mx[0]) == 0);
 			}
+			if (t == 6) { float g = 0.8f; ms_filter_call_method(volrecv0, MS_VOLUME_SET_GAIN, &g); } /* the speaker's volume: leg 0's far end now comes with the flush */
 			if (t == 8) { float g = 0.5f; ms_filter_call_method(volrecv, MS_VOLUME_SET_GAIN, &g); } /* no longer a meter only: its leg goes back to the facades */
 			if (t == 12) { /* a leg without a mixer detached and attached again (its chunks and speaker frames in flight are handed on) */
 				ms_ticker_detach(tk, solo[0].mic);
@@ -407,6 +415,9 @@ static void *conferences(void *arg) {
 			if (k == 1) {
 				ms_filter_unlink(l->far, 0, volrecv, 0), ms_filter_unlink(volrecv, 0, l->ec, 0);
 				ms_filter_destroy(volrecv); /* (audio_stream_free destroys volrecv before volsend, audiostream.c:357-358) */
+			} else if (k == 0) {
+				ms_filter_unlink(l->far, 0, volrecv0, 0), ms_filter_unlink(volrecv0, 0, tee0, 0), ms_filter_unlink(tee0, 0, l->ec, 0);
+				ms_filter_destroy(volrecv0), ms_filter_destroy(tee0);
 			} else ms_filter_unlink(l->far, 0, l->ec, 0);
 			ms_filter_destroy(l->mic), ms_filter_destroy(l->far), ms_filter_destroy(l->rs), ms_filter_destroy(l->ec);
 			ms_filter_destroy(l->vol), ms_filter_destroy(l->spk), ms_filter_destroy(l->out);
