@@ -683,6 +683,33 @@ struct LegBank : Pool {
 	// A slot's owner leaves while the bank's work for the coming tick is already out (it left at the end of the last graph walk):
 	// the reference's filters would have handed that tick's audio on in the walk itself, so it goes out now -- the speaker frames
 	// of every leg (LegBank::finish), the owner's own mix or chunks; the others' follow with the hub's flush as usual.
+	// A conference with a SINGLE contributor is in the reference's bypass mode (audiomixer.c:219-286): that pin's blocks go to the other
+	// outputs AS THEY ARE -- no input gain, no regard for MS_AUDIO_MIXER_SET_ACTIVE (mixer_dispatch_output never looks at the channel).
+	// The batch mixes such a conference all the same, with that pin's controls set to "active, gain 1" for as long as it is alone:
+	// the sum of one is the block itself (but for a sample of -32768, which the sum saturates to -32767: the stated exception).
+	std::vector<int> lone_ctl;           // per conference: the pin whose controls are overridden right now, -1 = none
+	std::vector<uint8_t> eff_flags;
+	std::vector<float> eff_gains;
+	void push_controls() {
+		if (!mix) return;
+		bool moved = false;
+		if (lone_ctl.size() != lone.size()) lone_ctl.assign(lone.size(), -1), moved = true;
+		for (size_t c = 0; c < lone.size(); ++c) {
+			if (!owner[c] && lone_ctl[c] >= 0) lone_ctl[c] = -1, moved = true; // (the slot was given up)
+			static const bool off = getenv("MSMI355X_LONE_KEEPS_ITS_CONTROLS") != nullptr; // A/B switch: as up to round 5
+			if (!off && owner[c] && conf_ready[c] && lone_ctl[c] != lone[c]) lone_ctl[c] = lone[c], moved = true; // (a conference that does not tick keeps what it had)
+		}
+		if (!ctl_dirty && !moved) return;
+		eff_flags = flags, eff_gains = gains;
+		for (size_t c = 0; c < lone_ctl.size(); ++c)
+			if (lone_ctl[c] >= 0) {
+				const size_t at = c * (size_t)mm + (size_t)lone_ctl[c];
+				eff_flags[at] |= MI_MIX_ACTIVE;
+				eff_gains[at] = 1.0f;
+			}
+		MI_MUST(mi_mixer_set_controls(mix, eff_flags.data(), eff_gains.data()));
+		ctl_dirty = false;
+	}
 	bool want_peers() { // (hub locked) the meter batch and its rows, on first use
 		if (vol_peer) return true;
 		if (failed) return false;
@@ -845,8 +872,7 @@ struct LegBank : Pool {
 		staged_since = false;
 		if (root) emitted();
 		// ---- pending control changes (methods called since the last flush)
-		if (ctl_dirty && mix) MI_MUST(mi_mixer_set_controls(mix, flags.data(), gains.data()));
-		ctl_dirty = false;
+		// (the mixer's controls go up behind the conferences' ticks below: a lone contributor's are overridden, push_controls)
 		if (v_dirty) {
 			bool held = false;
 			for (size_t s = 0; s < UL; ++s) {
@@ -931,6 +957,7 @@ struct LegBank : Pool {
 		}
 		mixed |= ticked;
 		if (failed) return false;
+		push_controls();
 		mark(2);
 		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
 		mark(3);

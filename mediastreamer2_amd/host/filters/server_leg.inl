@@ -246,8 +246,7 @@ struct ServerBank : Pool {
 		if (outstanding) sync_stream();
 		staged_since = false;
 		if (root) emitted();
-		if (ctl_dirty && mix) MI_MUST(mi_mixer_set_controls(mix, flags.data(), gains.data()));
-		ctl_dirty = false;
+		// (the mixer's controls go up behind the conferences' ticks below: a lone contributor's are overridden, push_controls)
 		if (v_dirty) {
 			for (size_t s = 0; s < UL; ++s) {
 				if (vp_dirty[s] == 1) {
@@ -287,6 +286,7 @@ struct ServerBank : Pool {
 			ticked |= conf_ready[(size_t)c] != 0;
 		}
 		if (failed) return false;
+		push_controls();
 		bool any = false, any_dev = false;
 		// ---- the device's half: every block metered and levelled as a block, then on to the channel's queue
 		if (ndec > 0 && rounds) { // the rounds' counts by kind of head
@@ -454,6 +454,33 @@ struct ServerBank : Pool {
 		next_any = false;
 	}
 	// a slot's owner leaves while the bank's work for the coming tick is already out: LegBank::deliver_in_flight
+	// A conference with a SINGLE contributor is in the reference's bypass mode (audiomixer.c:219-286): that pin's blocks go to the other
+	// outputs AS THEY ARE -- no input gain, no regard for MS_AUDIO_MIXER_SET_ACTIVE (mixer_dispatch_output never looks at the channel).
+	// The batch mixes such a conference all the same, with that pin's controls set to "active, gain 1" for as long as it is alone:
+	// the sum of one is the block itself (but for a sample of -32768, which the sum saturates to -32767: the stated exception).
+	std::vector<int> lone_ctl;           // per conference: the pin whose controls are overridden right now, -1 = none
+	std::vector<uint8_t> eff_flags;
+	std::vector<float> eff_gains;
+	void push_controls() {
+		if (!mix) return;
+		bool moved = false;
+		if (lone_ctl.size() != lone.size()) lone_ctl.assign(lone.size(), -1), moved = true;
+		for (size_t c = 0; c < lone.size(); ++c) {
+			if (!owner[c] && lone_ctl[c] >= 0) lone_ctl[c] = -1, moved = true; // (the slot was given up)
+			static const bool off = getenv("MSMI355X_LONE_KEEPS_ITS_CONTROLS") != nullptr; // A/B switch: as up to round 5
+			if (!off && owner[c] && conf_ready[c] && lone_ctl[c] != lone[c]) lone_ctl[c] = lone[c], moved = true; // (a conference that does not tick keeps what it had)
+		}
+		if (!ctl_dirty && !moved) return;
+		eff_flags = flags, eff_gains = gains;
+		for (size_t c = 0; c < lone_ctl.size(); ++c)
+			if (lone_ctl[c] >= 0) {
+				const size_t at = c * (size_t)mm + (size_t)lone_ctl[c];
+				eff_flags[at] |= MI_MIX_ACTIVE;
+				eff_gains[at] = 1.0f;
+			}
+		MI_MUST(mi_mixer_set_controls(mix, eff_flags.data(), eff_gains.data()));
+		ctl_dirty = false;
+	}
 	// a graph is being detached between two ticks (deliver_server_in_scope): rows staged in the last walk whose launches have not left --
 	// a bank without early launch, a conference that joined the bank mid-walk -- leave now, as the coming flush would send them
 	// (the walks are over and the ticker's clock reads what that flush would read): the tick in flight includes them

@@ -216,6 +216,9 @@ SCENARIOS = {
     "late_packets": {"burst": True, "nticks": 150},
     "a_member_falls_silent": {"silent": ((1, 2), 30, 70), "nticks": 200},    # one member quiet for 400 ms (census: contributes for a second), then ...
     "all_but_one_fall_silent": {"silent": ((1, 2, 3, 5, 6, 7), 20, 150), "nticks": 200},  # ... more than a second: a lone contributor, then nobody left but it
+    # a lone contributor is forwarded AS IT IS by the reference's bypass mode (audiomixer.c:219-242): muted or not, whatever its input gain
+    "a_lone_contributor_is_heard_even_muted": {"silent": ((1, 2, 3, 5, 6, 7), 20, 170), "nticks": 200,
+                                               "events": [(100, "mute", 0, True), (130, "mute", 0, False), (150, "mute", 4, True)]},
     "mute_and_gain": {"events": [(30, "mute", 1, True), (60, "mute", 1, False), (45, "gain", 2, 0.25)], "no_early_launch": True},
     "mute_and_gain_early": {"events": [(30, "mute", 1, True), (60, "mute", 1, False)]},
     "reattach": {"events": [(41, "reattach", 0, 0), (77, "reattach", 0, 0)]},  # 41: half a 20 ms packet is filled when the graph is re-plumbed
