@@ -1115,7 +1115,7 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
     return out
 
 
-def plugin_shape_point(shape, legs=32768, ticks=400, warmup=40):
+def plugin_shape_point(shape, legs=32768, ticks=300, warmup=40):
     """one paced run of tests/host/plugin_bench in another leg shape at a fixed count (detail file only: what the shape costs, not a capacity)"""
     import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
@@ -1603,6 +1603,7 @@ def emit(full, detail_path):
 
 
 def main():
+    t_main = time.time()
     a = parse()
     if not os.path.exists(os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355x.so")):
         import __graft_entry__ as entry  # build artefacts are git-ignored: a fresh checkout compiles them first
@@ -2030,7 +2031,7 @@ def main():
                 except Exception as e:
                     line["plugin_path_server"] = {"error": str(e)[:300]}
                 shapes = {}   # the other leg shapes the fused chain takes, one paced point each at a fixed count
-                for name, sh in (("mic_equalizer", "eq"), ("echo_limiter_no_mixer_no_agc", "el nomixer noagc"), ("no_mixer_no_agc", "nomixer noagc"), ("server_g711_decoder_heads", "server dec"),
+                for name, sh in (("mic_equalizer", "eq"), ("echo_limiter_no_mixer_no_agc", "el nomixer noagc"), ("server_g711_decoder_heads", "server dec"),
                                  ("audiostreams_8k_g711_full_duplex", "astream")):
                     try:
                         shapes[name] = plugin_shape_point(sh)
@@ -2059,6 +2060,7 @@ def main():
                 except Exception as e:
                     line["cpu_reference_error"] = str(e)[:200]
     if rank == 0:
+        line["bench_wall_s"] = round(time.time() - t_main, 1)   # (the whole command, every probe included: detail file)
         emit(line, a.detail)
     if dist is not None:
         dist.barrier()
