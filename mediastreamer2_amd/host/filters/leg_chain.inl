@@ -54,6 +54,17 @@ inline bool leg_prefetch_on() {
 	static const bool on = getenv("MSMI355X_NO_PREFETCH") == nullptr;
 	return on;
 }
+// how many legs ahead the facades ask for (MSMI355X_PREFETCH_AHEAD, default 3): a leg's walk takes ~1.3 us, a miss on a busy host up to
+// ~1 us -- one leg ahead is too late there (profiles/r05_prefetch_ahead.txt: 49 152 legs, three interleaved runs each on a box with load
+// 30-40: 1.55 us per leg-tick and 4-21 late ticks of 400 at 1, 1.39 us and 0-5 at 3; within the noise at 32 768)
+inline int leg_prefetch_ahead() {
+	static const int n = [] {
+		const char *e = getenv("MSMI355X_PREFETCH_AHEAD");
+		const int v = e ? atoi(e) : 3;
+		return v < 1 ? 1 : (v > 8 ? 8 : v);
+	}();
+	return n;
+}
 inline void pf(const void *p) {
 	if (p) __builtin_prefetch(p, 0, 1);
 }
@@ -1256,14 +1267,15 @@ void leg_stage_mic(MSFilter *f, ResampleData *d) {
 	FusedLeg *leg = d->leg;
 	LegBank *b = leg->bank;
 	const size_t nbytes = (size_t)b->in_len * 2;
-	if (leg_prefetch_on() && leg->slot + 1 < b->nlegs) { // the next leg's head: its filter, its state, the block waiting on its queue
-		if (const FusedLeg *nx = b->legs[(size_t)leg->slot + 1]) {
+	const int ahead = leg_prefetch_ahead();
+	if (leg_prefetch_on() && leg->slot + ahead < b->nlegs) { // the next leg's head: its filter, its state, the block waiting on its queue
+		if (const FusedLeg *nx = b->legs[(size_t)leg->slot + (size_t)ahead]) {
 			pf2(nx->rs, sizeof(MSFilter));
 			pf2(nx->rs_data, sizeof(ResampleData));
 			pf2(nx->ec, sizeof(MSFilter));
 			pf2(nx->ec_data, 192);
 		}
-		if (leg->slot + 2 < b->nlegs) pf2(b->legs[(size_t)leg->slot + 2], sizeof(FusedLeg));
+		if (leg->slot + ahead + 1 < b->nlegs) pf2(b->legs[(size_t)leg->slot + (size_t)ahead + 1], sizeof(FusedLeg));
 	}
 	// the usual case -- nothing held back, one whole 10 ms block on the queue -- goes from the block to its row in one copy
 	while (ms_bufferizer_get_avail(d->bz) == 0 && leg->staged_mic < kMaxRounds) {
@@ -1309,8 +1321,8 @@ void leg_take_far_end(MSFilter *f, SpeexECState *s) {
 	FusedLeg *leg = s->leg;
 	LegBank *b = leg->bank;
 	if (!f->inputs[0]) return;
-	if (leg_prefetch_on() && leg->slot + 1 < b->nlegs)
-		if (const FusedLeg *nx = b->legs[(size_t)leg->slot + 1]) {
+	if (leg_prefetch_on() && leg->slot + leg_prefetch_ahead() < b->nlegs)
+		if (const FusedLeg *nx = b->legs[(size_t)leg->slot + (size_t)leg_prefetch_ahead()]) {
 			pf2(static_cast<const char *>(nx->ec_data) + 192, sizeof(SpeexECState) > 192 ? sizeof(SpeexECState) - 192 : 0);
 			pf2(nx->vol, sizeof(MSFilter));
 		}
