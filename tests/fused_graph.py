@@ -138,7 +138,7 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False):
+                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False, spk_equalizer=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -196,6 +196,11 @@ class Conferences:
                             head = leg["plc"]
                         links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0),
                                   (leg["recv_tee"], 0, leg["ec"], 0)]
+                    elif spk_equalizer:   # audiostream.c:1828: an MSEqualizer of ours right in front of the canceller's far end -- it delivers with the flush
+                        leg["spk_eq"] = S.ms_factory_create_filter(h.fac, MS_EQUALIZER_ID)
+                        h.call_int(leg["spk_eq"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                        assert S.ms2shim_equalizer_set_gain(leg["spk_eq"], 1500.0, 2.0, 700.0) == 0
+                        links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["spk_eq"], 0), (leg["spk_eq"], 0, leg["ec"], 0)]
                     else:
                         links += [(leg["far"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["ec"], 0)]
                 else:
@@ -244,7 +249,7 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp", "dec", "plc", "enc"):
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp", "dec", "plc", "enc", "spk_eq"):
                 if k in leg:
                     self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
@@ -282,7 +287,7 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")), spk_equalizer=bool(sc.get("spk_equalizer")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -399,6 +404,7 @@ SCENARIOS = {
     # ... and a narrow-band G.711 call end to end: packets in through MSUlawDec -> MSGenericPLC (one in 19 lost), the card at 8 kHz, packets out of MSUlawEnc
     "audiostream_8k_g711": {"volrecv": True, "cpu_filters": True, "g711": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000,
                             "nconf": 1, "members": 6, "nticks": 120, "events": [(61, "reattach", 0, 0)], "tail_blocks": 2},
+    "spk_equalizer_keeps_the_leg_on_its_facades": {"volrecv": True, "spk_equalizer": True, "nticks": 60, "expect_unfused": True},
     "volrecv_with_a_gain_from_the_start": {"volrecv": True, "nticks": 60, "events": [(0, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's
     # memory, the up-sampler un-folds from the canceller's launch (resample, equalize, cancel: all on the device)
