@@ -998,8 +998,9 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
         into capacity), then `ticks` (600) paced ticks; a tick costs what the slowest ticker needs;
       * a count FITS when no tick of the run reaches 10 ms (ticks_over_10ms == 0) and no ticker ever started a step a whole
         interval late (max_backlog_ms < 10, msticker_late_events == 0).  Strict: p99 is reported, not the criterion;
-      * every count is measured the same way whether the search comes from below or from above: one run, and a second one if
-        the first did not fit (the host's CPUs are shared; both runs are listed) -- it fits if either did;
+      * every count is measured the same way whether the search comes from below or from above: one run; the count the search STARTS
+        at gets a second one if the first did not fit (the host's CPUs are shared; both runs are listed) -- it fits if either did
+        (up to round 5's end every count got the second run: on a busy host the probe alone then took four minutes);
       * the search starts at `first_legs`, steps of 8192 legs (16 conferences of 32 per ticker): up a step at a time while the
         count fits (three more at most), else the counts below are bisected; `legs` is the largest count that fit;
         `legs_p99_criterion` reads the same runs by round 4's rule (p99 < 10 ms, never a whole interval behind);
@@ -1037,9 +1038,9 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
     tried = []
 
     def measure(legs):
-        """one count by the rule: a run, and a second one if the first did not fit"""
+        """one count by the rule: a run, and -- for the count the search starts at -- a second one if the first did not fit"""
         best = None
-        for _ in range(2):
+        for _ in range(2 if not tried else 1):
             d = run(legs, ticks)
             # round 4's criterion beside the strict one (so that the two rounds' figures can be compared): p99 < 10 ms, never a whole interval behind
             d["fits_p99"] = bool(d["p99_ms"] < 10.0 and d["max_backlog_ms"] < 10.0 and d["msticker_late_events"] == 0)
@@ -1060,16 +1061,20 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
                    "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
                    "libmsmi355xfilters_init, one ticker thread per MSTicker in the test runtime (tests/host/plugin_bench.c); the plugin runs each "
                    "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl)",
-           "fits_definition": "no tick of 1000 paced ticks reaches 10 ms, no step starts a whole interval late; see the function's docstring",
+           "fits_definition": f"no tick of {ticks} paced ticks reaches 10 ms, no step starts a whole interval late; see the function's docstring",
            "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
     p99_ok = [t["legs"] for t in tried if t.get("fits_p99")]
     out["legs_p99_criterion"] = max(p99_ok) if p99_ok else 0   # round 4's reading of the same runs: the largest count tried with p99 < 10 ms
     try:
+        if best is not None and best["legs"] >= first_legs and extras:
+            raise StopIteration   # (the count the search started at fits: this host is quiet enough, no need to ask)
         f0 = run(tickers * 128, ticks)
         out["host_noise_floor"] = {k: f0.get(k) for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "slow_ticks")}
         at_floor = [t["legs"] for t in tried if t.get("ticks_over_10ms") is not None and t["ticks_over_10ms"] <= f0["late"] and t["max_backlog_ms"] < 10.0
                     and t["msticker_late_events"] == 0]
         out["legs_at_host_noise_floor"] = max(at_floor) if at_floor else 0
+    except StopIteration:
+        pass
     except Exception as e:
         out["host_noise_floor"] = {"error": str(e)[:200]}
     if best is None:
@@ -1115,7 +1120,7 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
     return out
 
 
-def plugin_shape_point(shape, legs=32768, ticks=300, warmup=40):
+def plugin_shape_point(shape, legs=32768, ticks=250, warmup=40):
     """one paced run of tests/host/plugin_bench in another leg shape at a fixed count (detail file only: what the shape costs, not a capacity)"""
     import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
@@ -2022,7 +2027,7 @@ def main():
             try:
                 line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)
                 try:  # a conference SERVER's remote members (volrecv -> mixer -> G.711 encoder, no canceller: filters/server_leg.inl)
-                    sv = plugin_path_probe(65536, log=log, shape="server", step_legs=32768, max_legs=131072, extras=False)
+                    sv = plugin_path_probe(65536, ticks=400, log=log, shape="server", step_legs=32768, max_legs=131072, extras=False)
                     sv["what"] = ("a conference server's REMOTE members through the plugin, PCIe included: 8 kHz source (decoder .. dtmfgen) -> MSVolume (volrecv) -> "
                                   "in_resampler -> MSAudioMixer (conferences of 32) -> out_resampler -> MSUlawEnc -> sink (audioconference.c:121-179,209-257); metered, "
                                   "queued, mixed and ENCODED in one batch per ticker")
@@ -2031,7 +2036,7 @@ def main():
                 except Exception as e:
                     line["plugin_path_server"] = {"error": str(e)[:300]}
                 shapes = {}   # the other leg shapes the fused chain takes, one paced point each at a fixed count
-                for name, sh in (("mic_equalizer", "eq"), ("echo_limiter_no_mixer_no_agc", "el nomixer noagc"), ("server_g711_decoder_heads", "server dec"),
+                for name, sh in (("mic_equalizer", "eq"), ("server_g711_decoder_heads", "server dec"),
                                  ("audiostreams_8k_g711_full_duplex", "astream")):
                     try:
                         shapes[name] = plugin_shape_point(sh)
