@@ -934,7 +934,7 @@ int mi_mixer_process_volume_fifo(mi_mixer *m, mi_volume *v, int first, mi_fifo *
 int mi_g711_decode(mi_ctx *ctx, int law, const uint8_t *codes, size_t cs, int16_t *pcm, size_t ps, const int32_t *len, int n, size_t rows) {
 	ARG(ctx && codes && pcm && n >= 0 && (law == MI_LAW_PCMA || law == MI_LAW_PCMU));
 	for (size_t r = 0; r < rows; ++r)
-		for (int i = 0; i < (len ? std::min(std::max(len[r], 0), n) : n); ++i) pcm[r * ps + i] = (int16_t)(((int)codes[r * cs + i] - 128) << 8);
+		for (int i = 0; i < (len ? std::min(std::max(len[r], 0), n) : n); ++i) pcm[r * ps + i] = (int16_t)(((int)codes[r * cs + i] - 128) * 256);
 	return MI_OK;
 }
 int mi_g711_encode(mi_ctx *ctx, int law, const int16_t *pcm, size_t ps, uint8_t *codes, size_t cs, const int32_t *len, int n, size_t rows) {

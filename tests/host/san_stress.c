@@ -450,7 +450,9 @@ static void *server_conferences(void *arg) {
 	for (int rep = 0; rep < (g_rounds + 1) / 2; ++rep) {
 		MSTicker *tk = ms_ticker_new();
 		MSFilter *mx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
-		MSFilter *src[NM], *vol[NM], *irs[NM], *ors[NM], *enc[NM], *snk[NM], *tap = ms2shim_new_sink(g_fac);
+		MSFilter *src[NM], *vol[NM], *irs[NM], *ors[NM], *enc[NM], *snk[NM], *dec[NM], *tap = ms2shim_new_sink(g_fac);
+		uint8_t codes[80];
+		for (int i = 0; i < 80; ++i) codes[i] = (uint8_t)(i * 37 + rep);
 		set_int(mx, MS_FILTER_SET_SAMPLE_RATE, 8000);
 		set_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
 		ms2shim_sink_set_discard(tap, 1);
@@ -459,12 +461,15 @@ static void *server_conferences(void *arg) {
 			vol[k] = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
 			irs[k] = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), ors[k] = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
 			enc[k] = ms_factory_create_filter(g_fac, k % 2 ? MS_ALAW_ENC_ID : MS_ULAW_ENC_ID);
+			dec[k] = (k == 0 || k == 3) ? ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID) : NULL; /* these members' packets are decoded in the batch (the decoder heads the leg) */
 			CHECK(src[k] && snk[k] && vol[k] && irs[k] && ors[k] && enc[k]);
 			ms2shim_sink_set_discard(snk[k], 1);
 			set_int(vol[k], MS_FILTER_SET_SAMPLE_RATE, 8000);
 			set_int(irs[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(irs[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
 			set_int(ors[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(ors[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
-			ms_filter_link(src[k], 0, vol[k], 0), ms_filter_link(vol[k], 0, irs[k], 0), ms_filter_link(irs[k], 0, mx, k);
+			if (dec[k]) ms_filter_link(src[k], 0, dec[k], 0), ms_filter_link(dec[k], 0, vol[k], 0);
+			else ms_filter_link(src[k], 0, vol[k], 0);
+			ms_filter_link(vol[k], 0, irs[k], 0), ms_filter_link(irs[k], 0, mx, k);
 			ms_filter_link(mx, k, ors[k], 0), ms_filter_link(ors[k], 0, enc[k], 0), ms_filter_link(enc[k], 0, snk[k], 0);
 		}
 		ms_filter_link(mx, NM + 1, tap, 0); /* a listener above the members */
@@ -472,7 +477,10 @@ static void *server_conferences(void *arg) {
 		for (int t = 0; t < 16; ++t) {
 			for (int k = 0; k < NM; ++k) {
 				const int blocks = (t == 6 && k == 2) ? 7 : 1; /* a burst: more blocks in one tick than the bank has launch rounds */
-				for (int b = 0; b < blocks; ++b) ms2shim_source_push(src[k], pcm, sizeof pcm);
+				for (int b = 0; b < blocks; ++b) {
+					if (dec[k]) ms2shim_source_push(src[k], codes, sizeof codes);
+					else ms2shim_source_push(src[k], pcm, sizeof pcm);
+				}
 			}
 			ms_ticker_step(tk);
 			if (t == 2) {
@@ -494,7 +502,11 @@ static void *server_conferences(void *arg) {
 			ms_filter_destroy(enc[k]);
 		}
 		for (int k = 0; k < NM; ++k) {
-			ms_filter_unlink(src[k], 0, vol[k], 0), ms_filter_unlink(vol[k], 0, irs[k], 0), ms_filter_unlink(irs[k], 0, mx, k), ms_filter_unlink(mx, k, ors[k], 0);
+			if (dec[k]) {
+				ms_filter_unlink(src[k], 0, dec[k], 0), ms_filter_unlink(dec[k], 0, vol[k], 0);
+				ms_filter_destroy(dec[k]);
+			} else ms_filter_unlink(src[k], 0, vol[k], 0);
+			ms_filter_unlink(vol[k], 0, irs[k], 0), ms_filter_unlink(irs[k], 0, mx, k), ms_filter_unlink(mx, k, ors[k], 0);
 			ms_filter_destroy(src[k]), ms_filter_destroy(vol[k]), ms_filter_destroy(irs[k]), ms_filter_destroy(ors[k]), ms_filter_destroy(snk[k]);
 		}
 		ms_filter_unlink(mx, NM + 1, tap, 0);
