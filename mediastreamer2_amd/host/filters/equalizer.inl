@@ -17,6 +17,7 @@ struct EqualizerPool : Pool {
 		int active;
 	};
 	std::vector<Op> later;
+	std::vector<uint8_t> used; // the slot's FIR memory may hold an earlier owner's samples (the batch is created cleared)
 	static void apply(mi_equalizer *eq, const Op &o) {
 		const int rc = o.kind == 0 ? mi_equalizer_set_gain(eq, o.slot, o.g.frequency, o.g.gain, o.g.width) : mi_equalizer_set_active(eq, o.slot, o.active);
 		if (rc != MI_OK) ms_error("mi355x equalizer: a deferred method failed: %s", mi_last_error());
@@ -142,7 +143,10 @@ void equalizer_attach(MSFilter *f) {
 	for (const MSEqualizerGain &g : *d->pending)
 		MI_MUST(mi_equalizer_set_gain(d->pool->e, d->slot, g.frequency, g.gain, g.width));
 	// a slot is a new filter's (cleared memory) unless this filter comes back from a fused leg with its own
-	MI_MUST(mi_equalizer_set_history(d->pool->e, d->slot, d->has_hist ? d->hist->data() : nullptr, mi_equalizer_fir_len(d->pool->e)));
+	if (d->pool->used.size() != (size_t)d->pool->capacity) d->pool->used.assign((size_t)d->pool->capacity, 0);
+	if (d->has_hist || d->pool->used[(size_t)d->slot])
+		MI_MUST(mi_equalizer_set_history(d->pool->e, d->slot, d->has_hist ? d->hist->data() : nullptr, mi_equalizer_fir_len(d->pool->e)));
+	d->pool->used[(size_t)d->slot] = 1;
 	d->has_hist = false;
 }
 

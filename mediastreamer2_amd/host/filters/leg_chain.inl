@@ -225,6 +225,7 @@ struct LegBank : Pool {
 	int16_t *d_up = nullptr;                    // [nlegs][ns] a round's up-sampled, equalized microphone blocks
 	int32_t *h_ecnt = nullptr, *d_ecnt = nullptr; // [kMaxRounds][nlegs]: ns where the leg has a microphone block in that round, else 0
 	std::vector<EqualizerPool::Op> eq_later;    // methods that wait for the coming flush (Pool::work_waiting)
+	std::vector<uint8_t> eq_used;               // the slot's FIR memory may hold an earlier leg's samples (a batch is created cleared: a first user needs no clearing)
 	mi_volume *vol_peer = nullptr;
 	int pcap = 0;                    // samples of a staged peer block (longer ones are cut, as the facade's light path cuts them)
 	int16_t *h_pk = nullptr, *d_pk = nullptr;   // [kMaxRounds][nlegs][pcap] pinned; [nlegs][pcap]
@@ -1644,7 +1645,9 @@ bool leg_take_equalizer(LegBank *b, FusedLeg *leg, MSFilter *eqf) {
 	}
 	bool ok = mi_equalizer_flatten(b->eq, s) == MI_OK && mi_equalizer_set_active(b->eq, s, ed->active) == MI_OK;
 	for (const MSEqualizerGain &g : *ed->pending) ok = ok && mi_equalizer_set_gain(b->eq, s, g.frequency, g.gain, g.width) == MI_OK;
-	ok = ok && mi_equalizer_set_history(b->eq, s, ed->has_hist ? ed->hist->data() : nullptr, n) == MI_OK;
+	if (b->eq_used.size() != (size_t)b->nlegs) b->eq_used.assign((size_t)b->nlegs, 0);
+	if (ed->has_hist || b->eq_used[(size_t)s]) ok = ok && mi_equalizer_set_history(b->eq, s, ed->has_hist ? ed->hist->data() : nullptr, n) == MI_OK;
+	b->eq_used[(size_t)s] = 1;
 	ed->has_hist = false;
 	ed->leg = leg;
 	leg->eq = eqf;
