@@ -2036,7 +2036,7 @@ def main():
                 except Exception as e:
                     line["plugin_path_server"] = {"error": str(e)[:300]}
                 shapes = {}   # the other leg shapes the fused chain takes, one paced point each at a fixed count
-                for name, sh in (("mic_equalizer", "eq"), ("server_g711_decoder_heads", "server dec"),
+                for name, sh in (("mic_equalizer", "eq"), ("server_g711_decoder_heads", "server dec"), ("server_g711_endpoints_in_a_16k_conference", "server dec wb"),
                                  ("audiostreams_8k_g711_full_duplex", "astream")):
                     try:
                         shapes[name] = plugin_shape_point(sh)

@@ -1436,11 +1436,12 @@ bool is_pass_resampler(MSFilter *f, MSTicker *ticker) {
 	const ResampleData *rd = (const ResampleData *)f->data;
 	return rd->input_rate == rd->output_rate && rd->in_nchannels == rd->out_nchannels && !rd->leg && !rd->pool && ms_bufferizer_get_avail(rd->bz) == 0;
 }
-// the filter MSVolume's output ends up in, behind a forwarding in_resampler if there is one
+// the filter MSVolume's output ends up in, behind an in_resampler of ours if there is one (forwarding, or -- an endpoint at another
+// rate than its conference, server_leg.inl -- working)
 MSFilter *leg_volume_sink(MSFilter *vol) {
 	MSQueue *q = vol->outputs[0];
 	MSFilter *g = q ? q->next.filter : NULL;
-	if (g && is_pass_resampler(g, vol->ticker) && ms_queue_empty(q)) {
+	if (g && g->desc == &ms_mi355x_resample_desc && g->ticker == vol->ticker && ms_queue_empty(q)) {
 		q = g->outputs[0];
 		g = q ? q->next.filter : NULL;
 	}
@@ -1449,12 +1450,13 @@ MSFilter *leg_volume_sink(MSFilter *vol) {
 
 // ... and when such a forwarder is told to resample after all, the conference behind it goes back to its facades (the mixer's next
 // process() honours it)
-void leg_forwarder_changed(MSFilter *rs) {
-	MSQueue *q = rs->outputs[0];
-	MSFilter *mx = q ? q->next.filter : NULL;
-	if (!mx || mx->desc != &ms_mi355x_audio_mixer_desc) return;
-	MixerState *ms = (MixerState *)mx->data;
-	if (ms->fbank) ms->unfuse_wanted = true;
+void leg_forwarder_changed(MSFilter *rs) { // (an endpoint's in_resampler in front of a fused conference's pin, or its out_resampler behind one)
+	for (MSQueue *q : {rs->outputs[0], rs->inputs[0]}) {
+		MSFilter *mx = q ? (q == rs->outputs[0] ? q->next.filter : q->prev.filter) : NULL;
+		if (!mx || mx->desc != &ms_mi355x_audio_mixer_desc) continue;
+		MixerState *ms = (MixerState *)mx->data;
+		if (ms->fbank || ms->sbank) ms->unfuse_wanted = true;
+	}
 }
 
 bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer);

@@ -26,9 +26,10 @@
 //     host, exactly as in LegBank::conf_tick (MSMI355X_CHECK_LEVELS compares the device queue with them every flush).
 //
 // Equal to the facades one by one bit for bit (tests/test_plugin_server_cpu.py, tests/test_gpu_plugin_server.py), with LegBank's
-// stated exception (a lone contributor is mixed, not forwarded).  With AGC on its MSVolume, a peer, another rate on either
-// resampler (a G.711 endpoint in a 16 kHz conference), a facade of this plugin feeding MSVolume (its blocks arrive with the
-// flush, not in the walk) or MSMI355X_NO_FUSE=1 the conference keeps its facades.
+// stated exception (a lone contributor is mixed, not forwarded).  Endpoints at ANOTHER rate than the conference (G.711 endpoints
+// in a 16 or 48 kHz conference: both resamplers of every member work) are served too: levelled at their own rate, up-sampled in
+// the batch, their pins' mixes down-sampled and encoded (ServerBank::re / q).  With AGC on its MSVolume, a peer, a facade of this
+// plugin feeding MSVolume (its blocks arrive with the flush, not in the walk) or MSMI355X_NO_FUSE=1 the conference keeps its facades.
 
 struct ServerBank;
 struct ServerLeg {
@@ -36,6 +37,7 @@ struct ServerLeg {
 	int slot, pin;
 	MSFilter *vol, *mixer;
 	MSFilter *enc = nullptr;   // the pin's output is encoded in the batch (MSAlawEnc / MSUlawEnc of this plugin), else PCM
+	MSFilter *irs = nullptr;   // the endpoint's in_resampler when it really resamples (the endpoint runs at another rate than the conference): its state lives in the bank
 	MSFilter *dec = nullptr;   // the leg's HEAD is MSAlawDec / MSUlawDec of this plugin right in front of MSVolume: its packets are staged as they are and decoded in the batch
 	int staged = 0;            // blocks staged since the last enqueue (launch rounds)
 	int new_samples = 0;       // samples MSVolume put on the mixer's queue since the mixer last looked
@@ -46,6 +48,17 @@ struct ServerLeg {
 
 struct ServerBank : Pool {
 	int rate, ns, mm, nlegs, cap; // cap: samples a staged block may hold (a row of the staging arrays)
+	// Endpoints at ANOTHER rate than the conference (G.711 endpoints in a 16 kHz conference: audioconference.c:209-257 puts a working
+	// in_resampler in front of every pin and a working out_resampler behind it): MSVolume meters and levels at the endpoint's rate `re`,
+	// the levelled blocks are up-sampled in the batch (MSResample's own kernel on the member's state, 10 ms at a time as the facade
+	// frames them) before they are queued on the channel, and an encoded pin's mix is down-sampled before it is encoded.  q = rate / re.
+	int re, q, nse;                  // the endpoints' rate, the ratio, samples of 10 ms at `re`
+	mi_resampler *rs_in = nullptr, *rs_out = nullptr; // [nlegs] each
+	int16_t *d_up = nullptr, *d_down = nullptr;       // [nlegs][cap * q] a round's up-sampled blocks; [nlegs][nse8] the pins' down-sampled mixes
+	uint8_t *h_umask = nullptr, *d_umask = nullptr;   // [kMaxRounds][pieces][nlegs]: the member has a p-th 10 ms piece in its block of that round
+	uint8_t *h_omask = nullptr, *d_omask = nullptr;   // [nlegs]: the pin's mix is down-sampled (and encoded) in this launch
+	int32_t *h_un = nullptr, *d_un = nullptr;         // [kMaxRounds][nlegs]: the up-sampled counts
+	int pieces = 1, nse8 = 0;
 	mi_volume *vol = nullptr, *vol_id = nullptr;
 	mi_fifo *f_chan = nullptr;
 	mi_mixer *mix = nullptr;
@@ -70,6 +83,7 @@ struct ServerBank : Pool {
 	MixSlab *cur = nullptr;
 	mblk_t *root = nullptr;
 	std::vector<ServerLeg *> legs;
+	std::vector<MSFilter *> orss; // [nlegs]: the working out_resampler in front of that encoder (endpoints at another rate), or NULL
 	std::vector<MSFilter *> encs; // [nlegs]: the encoder behind output pin (c, pin), also where no member feeds that pin (a listener)
 	std::vector<uint8_t> conf_ready, flags;
 	std::vector<int> lone;
@@ -96,15 +110,31 @@ struct ServerBank : Pool {
 	bool mixed = false, pcm_out = false, check_levels = false, lv_fresh = false, zero_copy = true;
 	uint64_t launches = 0;
 
-	ServerBank(int cap_conf, int r, int members) : rate(r), mm(members) {
+	ServerBank(int cap_conf, int r, int members, int endpoint_rate) : rate(r), mm(members), re(endpoint_rate) {
 		Building b(this, cap_conf);
 		ns = rate / 100;
+		q = rate / re;
+		nse = re / 100;
+		nse8 = (nse + 8 + 7) & ~7; // (a row for 10 ms at `re` and the resampler's spare sample)
 		nlegs = capacity * mm;
-		cap = std::min((6 * ns + 7) & ~7, 2400); // 60 ms (three 20 ms packets a jitter buffer lets go at once), and what the volume kernel's LDS staging takes (50 ms at 48 kHz); a longer block is cut (server_stage)
+		cap = std::min((6 * nse + 7) & ~7, 2400 / q); // 60 ms (three 20 ms packets a jitter buffer lets go at once), and what the volume kernel's LDS staging takes (50 ms at 48 kHz); a longer block is cut (server_stage)
+		pieces = std::max(1, cap / nse);
 		const size_t L = (size_t)nlegs;
-		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, rate, &vol));
+		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, re, &vol));
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, nlegs, rate, &vol_id));
-		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, ((4 * ns + kMaxRounds * cap) + 7) & ~7, &f_chan));
+		if (!failed) MI_MUST(mi_fifo_create(hub->ctx, nlegs, ((4 * ns + kMaxRounds * cap * q) + 7) & ~7, &f_chan));
+		if (q > 1) {
+			if (!failed) MI_MUST(mi_resampler_create(hub->ctx, nlegs, (uint32_t)re, (uint32_t)rate, 3, &rs_in));
+			if (!failed) MI_MUST(mi_resampler_create(hub->ctx, nlegs, (uint32_t)rate, (uint32_t)re, 3, &rs_out));
+			d_up = devmem<int16_t>(L * (size_t)cap * q);
+			d_down = devmem<int16_t>(L * (size_t)nse8);
+			h_umask = pinned<uint8_t>((size_t)kMaxRounds * 2 * pieces * L); // (per round two kinds of rows: MSVolume-headed from pinned memory, decoder-headed from the device)
+			d_umask = devmem<uint8_t>((size_t)kMaxRounds * 2 * pieces * L);
+			h_omask = pinned<uint8_t>(L);
+			d_omask = devmem<uint8_t>(L);
+			h_un = pinned<int32_t>(kMaxRounds * 2 * L);
+			d_un = devmem<int32_t>(kMaxRounds * 2 * L);
+		}
 		if (!failed) MI_MUST(mi_mixer_create(hub->ctx, capacity, mm, ns, &mix));
 		h_in = pinned<int16_t>(kMaxRounds * L * cap);
 		d_in = devmem<int16_t>(L * cap);
@@ -132,6 +162,7 @@ struct ServerBank : Pool {
 		h_copy = pinned<int16_t>(L * ns);
 		legs.assign(L, nullptr);
 		encs.assign(L, nullptr);
+		orss.assign(L, nullptr);
 		conf_ready.assign((size_t)capacity, 0);
 		lone.assign((size_t)capacity, -1);
 		flags.assign(L, 0);
@@ -159,6 +190,8 @@ struct ServerBank : Pool {
 		if (mix) mi_mixer_destroy(mix);
 		if (vol) mi_volume_destroy(vol);
 		if (vol_id) mi_volume_destroy(vol_id);
+		if (rs_in) mi_resampler_destroy(rs_in);
+		if (rs_out) mi_resampler_destroy(rs_out);
 		if (f_chan) mi_fifo_destroy(f_chan);
 		for (MixSlab *s : slabs)
 			if (s->state.exchange(2, std::memory_order_acq_rel) == 0) mi_host_free(hub->ctx, s);
@@ -240,6 +273,41 @@ struct ServerBank : Pool {
 		outstanding = false;
 		return any;
 	}
+	// a round's levelled blocks go onto the channels' queue: as they are, or (endpoints at another rate) up-sampled first, 10 ms at a
+	// time as MSResample's facade frames them -- the p-th launch serves every member whose block has a p-th piece
+	void queue_blocks(int r, int kind, int16_t *rows, const int32_t *cnt_host, const int32_t *cnt_launch) {
+		mi_ctx *ctx = hub->ctx;
+		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
+		if (q == 1) {
+			MI_MUST(mi_fifo_push(f_chan, rows, cap, cap, cnt_launch));
+			++launches;
+			return;
+		}
+		const size_t base = (size_t)(r * 2 + kind);
+		uint8_t *hm = h_umask + base * pieces * L, *dm = d_umask + base * pieces * L;
+		int32_t *hu = h_un + base * L, *du = d_un + base * L;
+		int maxp = 0;
+		for (size_t s = 0; s < L; ++s) {
+			const int n = s < UL ? cnt_host[s] : 0, whole = n / nse;
+			if (n % nse && legs[s]) { // MSResample's facade would carry the odd samples over to the next block: this conference goes back to its facades
+				((MixerState *)legs[s]->mixer->data)->unfuse_wanted = true;
+				g_late_events.fetch_add(1, std::memory_order_relaxed);
+			}
+			hu[s] = whole * ns;
+			maxp = std::max(maxp, whole);
+			for (int p = 0; p < pieces; ++p) hm[(size_t)p * L + s] = whole > p;
+		}
+		if (!zero_copy) {
+			MI_MUST(mi_copy_h2d_pinned(ctx, dm, hm, (size_t)pieces * L));
+			MI_MUST(mi_copy_h2d_pinned(ctx, du, hu, L * 4));
+		}
+		for (int p = 0; p < maxp; ++p) {
+			MI_MUST(mi_resampler_process_masked(rs_in, rows + (size_t)p * nse, nse, cap, d_up + (size_t)p * ns, cap * q, nullptr, (zero_copy ? hm : dm) + (size_t)p * L));
+			++launches;
+		}
+		MI_MUST(mi_fifo_push(f_chan, d_up, cap * q, cap * q, zero_copy ? hu : du));
+		++launches;
+	}
 	bool enqueue_at(uint64_t now) {
 		mi_ctx *ctx = hub->ctx;
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
@@ -270,7 +338,7 @@ struct ServerBank : Pool {
 			for (int r = st; r < kMaxRounds; ++r) h_n[(size_t)r * L + s] = 0;
 			if (!leg) continue;
 			rounds = std::max(rounds, st);
-			for (int r = 0; r < st; ++r) leg->new_samples += h_n[(size_t)r * L + s];
+			for (int r = 0; r < st; ++r) leg->new_samples += h_n[(size_t)r * L + s] * q;
 			leg->metered |= st > 0;
 			for (int r = 0; r + 1 < st && vrounds + r < kLegMeterRounds; ++r) vhas[(size_t)(vrounds + r) * L + s] = 1;
 			leg->staged = 0;
@@ -312,13 +380,13 @@ struct ServerBank : Pool {
 				}
 			if (any[3]) {
 				MI_MUST(mi_volume_process(vol, d_in, cap, cap, h_nk[3] + ro));
-				MI_MUST(mi_fifo_push(f_chan, d_in, cap, cap, h_nk[3] + ro));
-				launches += 2;
+				++launches;
+				queue_blocks(r, 1, d_in, h_nk[3] + ro, h_nk[3] + ro);
 			}
 			if (any[0]) {
 				MI_MUST(mi_volume_process(vol, h_in + ro * cap, cap, cap, h_nk[0] + ro));
-				MI_MUST(mi_fifo_push(f_chan, h_in + ro * cap, cap, cap, h_nk[0] + ro));
-				launches += 2;
+				++launches;
+				queue_blocks(r, 0, h_in + ro * cap, h_nk[0] + ro, h_nk[0] + ro);
 			}
 			if (r + 1 < rounds) meter_round(UL);
 			any_dev = mixed = true;
@@ -330,8 +398,8 @@ struct ServerBank : Pool {
 			int16_t *rows = zero_copy ? h_in + (size_t)r * L * cap : d_in;
 			if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_in, h_in + (size_t)r * L * cap, UL * cap * 2));
 			MI_MUST(mi_volume_process(vol, rows, cap, cap, cnt));
-			MI_MUST(mi_fifo_push(f_chan, rows, cap, cap, cnt));
-			launches += 2;
+			++launches;
+			queue_blocks(r, 0, rows, h_n + (size_t)r * L, cnt);
 			if (r + 1 < rounds) meter_round(UL);
 			any = mixed = true;
 		}
@@ -354,18 +422,29 @@ struct ServerBank : Pool {
 			for (size_t s = 0; s < UL; ++s) {
 				h_len[0][s] = h_len[1][s] = 0;
 				const int c = (int)s / mm, pin = (int)s % mm;
-				if (!conf_ready[(size_t)c] || !(flags[s] & MI_MIX_OUTPUT) || pin == lone[(size_t)c]) continue;
+				// (only the conferences that ticked in THIS launch: one that ticked in the walk's early launch has its codes already -- and
+				// its out_resamplers must not see the same mix twice)
+				if (!h_run[c] || !conf_ready[(size_t)c] || !(flags[s] & MI_MIX_OUTPUT) || pin == lone[(size_t)c]) continue;
 				if (MSFilter *e = encs[s]) {
 					const int law = ((MapFilter *)e->data)->law;
-					h_len[law][s] = ns;
+					h_len[law][s] = nse; // (10 ms at the endpoint's rate: ns where the endpoints run at the conference's)
 					any_law[law] = true;
 				} else pcm_out = true;
+			}
+			const int16_t *enc_src = d_mix;
+			size_t enc_stride = (size_t)ns;
+			if (q > 1 && (any_law[0] || any_law[1])) { // the encoded pins' mixes down to the endpoints' rate (their out_resamplers' states)
+				for (size_t s = 0; s < L; ++s) h_omask[s] = s < UL && (h_len[0][s] > 0 || h_len[1][s] > 0);
+				if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_omask, h_omask, L));
+				MI_MUST(mi_resampler_process_masked(rs_out, d_mix, ns, ns, d_down, nse8, nullptr, zero_copy ? h_omask : d_omask));
+				++launches;
+				enc_src = d_down, enc_stride = (size_t)nse8;
 			}
 			for (int law = 0; law < 2; ++law) {
 				if (!any_law[law]) continue;
 				if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_len[law], h_len[law], L * 4));
-				MI_MUST(mi_g711_encode(ctx, law ? MI_LAW_PCMU : MI_LAW_PCMA, d_mix, (size_t)ns, zero_copy ? h_codes : d_codes, (size_t)ns,
-				                       zero_copy ? h_len[law] : d_len[law], ns, UL));
+				MI_MUST(mi_g711_encode(ctx, law ? MI_LAW_PCMU : MI_LAW_PCMA, enc_src, enc_stride, zero_copy ? h_codes : d_codes, (size_t)ns,
+				                       zero_copy ? h_len[law] : d_len[law], nse, UL));
 				++launches;
 			}
 			if ((any_law[0] || any_law[1]) && !zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, h_codes, d_codes, UL * ns));
@@ -543,7 +622,7 @@ void ServerBank::emit(MSFilter *f, int c) { // mixer_process :336-343 (conferenc
 		if (!q || !s->channels[pin].output_enabled || pin == lone[(size_t)c]) continue;
 		const size_t at = (size_t)(c * mm + pin);
 		if (MSFilter *e = encs[at]) {
-			enc_take_codes(e, h_codes + at * ns, ns);
+			enc_take_codes(e, h_codes + at * ns, nse);
 			continue;
 		}
 		uint8_t *row = const_cast<uint8_t *>(base) + (at * ns) * 2;
@@ -653,30 +732,63 @@ void server_conf_walked(ServerBank *b, int c) {
 bool is_g711_enc(const MSFilterDesc *d) { return d == &ms_mi355x_alaw_enc_desc || d == &ms_mi355x_ulaw_enc_desc; }
 
 // the encoder behind output pin `pin` of the mixer, through a forwarding out_resampler: ours, on the mixer's ticker, idle
-MSFilter *server_find_encoder(MSFilter *mx, int pin, int rate) {
-	if (rate != 8000) return NULL; // (G.711 runs at 8 kHz: a conference at another rate resamples in between)
+bool is_working_resampler(MSFilter *f, MSTicker *ticker, uint32_t in, uint32_t out);
+// re: the endpoints' rate (== rate unless their resamplers work); *ors: the working out_resampler in front of the encoder;
+// *blocked: the pin's output is resampled by a facade of ours but does not end in an encoder the batch can serve -- the conference keeps its facades
+MSFilter *server_find_encoder(MSFilter *mx, int pin, int rate, int re, MSFilter **ors, bool *blocked) {
+	*ors = nullptr;
 	MSQueue *q = mx->outputs[pin];
 	MSFilter *g = q ? q->next.filter : NULL;
 	if (g && is_pass_resampler(g, mx->ticker) && ms_queue_empty(q)) {
 		q = g->outputs[0];
 		g = q ? q->next.filter : NULL;
+	} else if (g && g->desc == &ms_mi355x_resample_desc && re != rate) {
+		*blocked = true; // (unless everything below holds)
+		if (!is_working_resampler(g, mx->ticker, (uint32_t)rate, (uint32_t)re) || !ms_queue_empty(q)) return NULL;
+		*ors = g;
+		q = g->outputs[0];
+		g = q ? q->next.filter : NULL;
 	}
+	if (re != 8000) return NULL; // (G.711 runs at 8 kHz)
 	if (!g || !is_g711_enc(g->desc) || g->ticker != mx->ticker || !q || !ms_queue_empty(q)) return NULL;
 	MapFilter *d = (MapFilter *)g->data;
 	if (d->sleg || ms_bufferizer_get_avail(d->bz) || (d->pool && !d->pool->staged[(size_t)d->slot].empty())) return NULL;
+	*blocked = false;
 	return g;
 }
 
 bool is_g711_dec(const MSFilterDesc *d) { return d == &ms_mi355x_alaw_dec_desc || d == &ms_mi355x_ulaw_dec_desc; }
 
-bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out, MSFilter **dec_out) {
+// an MSResample of ours that really resamples in -> out (mono, nothing of its own in flight): its state can move into the bank and back
+bool is_working_resampler(MSFilter *f, MSTicker *ticker, uint32_t in, uint32_t out) {
+	if (!f || f->desc != &ms_mi355x_resample_desc || f->ticker != ticker) return false;
+	const ResampleData *rd = (const ResampleData *)f->data;
+	if (rd->input_rate != in || rd->output_rate != out || in == out || rd->in_nchannels != 1 || rd->out_nchannels != 1 || rd->leg) return false;
+	if (ms_bufferizer_get_avail(rd->bz)) return false;
+	return !(rd->pool && (rd->pool->failed || rd->pool->staged[(size_t)rd->slot] || rd->pool->ready[(size_t)rd->slot]));
+}
+// (the rates the batch resamples between: whole ratios the up-sampler's kernel takes, 10 ms a whole number of samples on both sides)
+bool server_rates_ok(int re, int rate) { return re > 0 && rate % re == 0 && (rate / re == 2 || rate / re == 3 || rate / re == 6) && re % 100 == 0; }
+
+bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out, MSFilter **dec_out, MSFilter **irs_out, int *re_out) {
 	MSQueue *q = mx->inputs[pin];
 	MSFilter *vol = q->prev.filter;
+	*irs_out = nullptr;
+	*re_out = ms->rate;
 	if (is_pass_resampler(vol, mx->ticker)) { // the endpoint's in_resampler, forwarding
 		if (!ms_queue_empty(q)) return false;
 		q = vol->inputs[0];
 		vol = q ? q->prev.filter : NULL;
+	} else if (vol && vol->desc == &ms_mi355x_resample_desc) { // ... or working: the endpoint runs at another rate (a G.711 endpoint in a 16 kHz conference)
+		static const bool off = getenv("MSMI355X_NO_FUSE_SERVER_RESAMPLED") != nullptr; // A/B switch: such a conference keeps its facades, as up to round 5
+		const int re = (int)((const ResampleData *)vol->data)->input_rate;
+		if (off || !server_rates_ok(re, ms->rate) || !is_working_resampler(vol, mx->ticker, (uint32_t)re, (uint32_t)ms->rate) || !ms_queue_empty(q)) return false;
+		*irs_out = vol;
+		*re_out = re;
+		q = vol->inputs[0];
+		vol = q ? q->prev.filter : NULL;
 	}
+	const int re = *re_out;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc || vol->ticker != mx->ticker || !ms_queue_empty(q)) return false;
 	// MSVolume must be handed its blocks IN the graph walk -- by a filter that is not one of this plugin's (dtmfgen stands in front
 	// of volrecv in an AudioStream, audiostream.c:1826; a CPU decoder; a sound card): a facade of ours delivers with the flush, a tick
@@ -690,12 +802,12 @@ bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out,
 		MSFilter *dec = qin->prev.filter;
 		MapFilter *dd = (MapFilter *)dec->data;
 		MSQueue *qd = dec->inputs[0];
-		if (!is_g711_dec(dec->desc) || dec->ticker != mx->ticker || ms->rate != 8000 || !ms_queue_empty(qin) || !qd || !qd->prev.filter || is_ours(qd->prev.filter->desc)) return false;
+		if (!is_g711_dec(dec->desc) || dec->ticker != mx->ticker || re != 8000 || !ms_queue_empty(qin) || !qd || !qd->prev.filter || is_ours(qd->prev.filter->desc)) return false;
 		if (dd->sleg || (dd->pool && (!dd->pool->staged[(size_t)dd->slot].empty() || !dd->pool->ready[(size_t)dd->slot].empty()))) return false;
 		*dec_out = dec;
 	}
 	VolumeData *vd = (VolumeData *)vol->data;
-	if (volume_is_peered(vd) || vd->sample_rate != ms->rate || vd->leg || vd->sleg || vd->p.agc_enabled) return false;
+	if (volume_is_peered(vd) || vd->sample_rate != re || vd->leg || vd->sleg || vd->p.agc_enabled) return false;
 	if (ms_bufferizer_get_avail(vd->buffer) || ms_bufferizer_get_avail(vd->spill)) return false;
 	const size_t held = ms_bufferizer_get_avail(&ms->channels[pin].bufferizer); // (from before this attach: it moves to the bank's channel queue)
 	if (held % 16 || held > (size_t)(ms->rate / 100) * 2 * 3) return false;
@@ -711,16 +823,30 @@ bool server_try_fuse(MSFilter *mx) {
 	if (!ms->pool || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 800) return false;
 	std::vector<std::pair<int, MSFilter *>> cand;
 	std::vector<MSFilter *> heads; // per candidate: the decoder that heads the leg, or NULL (MSVolume does)
-	int maxpin = -1;
+	std::vector<MSFilter *> irss;  // per candidate: its working in_resampler, or NULL
+	int maxpin = -1, re = -1;
 	for (int pin = 0; pin < mx->desc->ninputs; ++pin) {
 		if (!mx->inputs[pin]) continue;
-		MSFilter *vol = nullptr, *dec = nullptr;
-		if (!server_candidate(mx, ms, pin, &vol, &dec)) return false;
+		MSFilter *vol = nullptr, *dec = nullptr, *irs = nullptr;
+		int re_pin = 0;
+		if (!server_candidate(mx, ms, pin, &vol, &dec, &irs, &re_pin)) return false;
+		if (re >= 0 && re_pin != re) return false; // (one endpoint rate per conference: a bank is one shape)
+		re = re_pin;
 		cand.push_back({pin, vol});
 		heads.push_back(dec);
+		irss.push_back(irs);
 		maxpin = pin;
 	}
 	if (cand.empty()) return false;
+	// the outputs: an encoder of ours behind the pin (through its out_resampler) is served by the batch, anything else gets PCM at the
+	// conference's rate -- but an out_resampler of ours that WORKS must end in such an encoder (its PCM is not the batch's to make)
+	std::vector<MSFilter *> enc_of((size_t)mx->desc->noutputs, nullptr), ors_of((size_t)mx->desc->noutputs, nullptr);
+	for (int pin = 0; pin < mx->desc->noutputs; ++pin) {
+		if (!mx->outputs[pin]) continue;
+		bool blocked = false;
+		enc_of[(size_t)pin] = server_find_encoder(mx, pin, ms->rate, re, &ors_of[(size_t)pin], &blocked);
+		if (blocked) return false;
+	}
 	for (int pin = 0; pin < mx->desc->noutputs; ++pin)
 		if (mx->outputs[pin]) maxpin = std::max(maxpin, pin);
 	int mm = MIXER_MAX_CHANNELS;
@@ -730,13 +856,14 @@ bool server_try_fuse(MSFilter *mx) {
 			break;
 		}
 	const int rate = ms->rate;
-	ServerBank *b = bank<ServerBank>("srv:" + std::to_string(rate) + ":" + std::to_string(mm), 1,
-	                                 [&](int cap) { return new ServerBank(std::max(1, cap * 4 / mm), rate, mm); });
+	ServerBank *b = bank<ServerBank>("srv:" + std::to_string(rate) + ":" + std::to_string(re) + ":" + std::to_string(mm), 1,
+	                                 [&](int cap) { return new ServerBank(std::max(1, cap * 4 / mm), rate, mm, re); });
 	const int c = b ? b->acquire(mx) : -1;
 	if (c < 0) return false;
 	note_slot(mx);
 	const int s0 = c * mm;
 	bool ok = mi_fifo_reset_range(b->f_chan, s0, mm) == MI_OK && mi_volume_reset_max(b->vol, s0, mm) == MI_OK;
+	if (b->q > 1) ok = ok && mi_resampler_reset(b->rs_in, s0, mm) == MI_OK && mi_resampler_reset(b->rs_out, s0, mm) == MI_OK;
 	for (const auto &pv : cand) {
 		const size_t s = (size_t)(s0 + pv.first);
 		VolumeData *vd = (VolumeData *)pv.second->data;
@@ -754,22 +881,34 @@ bool server_try_fuse(MSFilter *mx) {
 	for (int pin = 0; pin < mm; ++pin) {
 		b->flags[(size_t)(s0 + pin)] = 0, b->gains[(size_t)(s0 + pin)] = 1.0f;
 		b->encs[(size_t)(s0 + pin)] = nullptr;
+		b->orss[(size_t)(s0 + pin)] = nullptr;
 	}
 	int nenc = 0;
 	for (int pin = 0; pin < mm && pin < mx->desc->noutputs; ++pin)
-		if (mx->outputs[pin])
-			if (MSFilter *e = server_find_encoder(mx, pin, rate)) {
-				b->encs[(size_t)(s0 + pin)] = e;
-				((MapFilter *)e->data)->sleg_bank = b;
-				((MapFilter *)e->data)->sleg = true;
-				++nenc;
+		if (MSFilter *e = enc_of[(size_t)pin]) {
+			b->encs[(size_t)(s0 + pin)] = e;
+			((MapFilter *)e->data)->sleg_bank = b;
+			((MapFilter *)e->data)->sleg = true;
+			++nenc;
+			if (MSFilter *ors = ors_of[(size_t)pin]) { // its out_resampler's state moves into the bank (msresample.c:117-120: the handle lives as long as the filter)
+				ResampleData *rd = (ResampleData *)ors->data;
+				if (rd->pool && rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
+				resample_restore_to(rd, b->rs_out, s0 + pin, (uint32_t)rate, (uint32_t)re, false);
+				b->orss[(size_t)(s0 + pin)] = ors;
 			}
+		}
 	for (size_t ci = 0; ci < cand.size(); ++ci) {
 		const auto &pv = cand[ci];
 		ServerLeg *leg = new ServerLeg();
 		leg->bank = b, leg->slot = s0 + pv.first, leg->pin = pv.first;
 		leg->vol = pv.second, leg->mixer = mx;
 		leg->enc = b->encs[(size_t)leg->slot];
+		if (MSFilter *irs = irss[ci]) { // the in_resampler's state likewise
+			ResampleData *rd = (ResampleData *)irs->data;
+			if (rd->pool && rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
+			resample_restore_to(rd, b->rs_in, leg->slot, (uint32_t)re, (uint32_t)rate, false);
+			leg->irs = irs;
+		}
 		if (MSFilter *dec = heads[ci]) {
 			MapFilter *dd = (MapFilter *)dec->data;
 			leg->dec = dec;
@@ -798,8 +937,8 @@ bool server_try_fuse(MSFilter *mx) {
 	b->staged_since = true;
 	ms->unfuse_wanted = false;
 	mixer_push_controls(mx, ms);
-	ms_message("mi355x: conference %p fused: %d remote members at %d Hz, %d of their outputs encoded in the batch (bank of %d x %d)", (void *)mx,
-	           (int)cand.size(), rate, nenc, b->capacity, mm);
+	ms_message("mi355x: conference %p fused: %d remote members at %d Hz (the conference at %d Hz), %d of their outputs encoded in the batch (bank of %d x %d)", (void *)mx,
+	           (int)cand.size(), re, rate, nenc, b->capacity, mm);
 	return true;
 }
 
@@ -823,6 +962,12 @@ void server_unfuse(MSFilter *mx, bool keep_running) {
 			mi_failed("taking the mixer channels' queues back");
 	}
 	std::vector<ServerLeg *> gone;
+	auto state_back = [&](MSFilter *rs, mi_resampler *from, int slot) { // a working resampler's state returns to its filter (and to the slot it kept)
+		ResampleData *rd = (ResampleData *)rs->data;
+		if (b->failed || !from) return;
+		resample_keep_from(rd, from, slot, rd->input_rate, rd->output_rate);
+		if (rd->pool && rd->slots->size() == 1 && !rd->pool->failed) resample_restore_to(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate, false);
+	};
 	for (int pin = 0; pin < mm; ++pin) {
 		const size_t s = (size_t)(c * mm + pin);
 		if (MSFilter *e = b->encs[s]) {
@@ -830,6 +975,11 @@ void server_unfuse(MSFilter *mx, bool keep_running) {
 			((MapFilter *)e->data)->sleg_bank = nullptr;
 			b->encs[s] = nullptr;
 		}
+		if (MSFilter *ors = b->orss[s]) {
+			state_back(ors, b->rs_out, (int)s);
+			b->orss[s] = nullptr;
+		}
+		if (b->legs[s] && b->legs[s]->irs) state_back(b->legs[s]->irs, b->rs_in, (int)s);
 		ServerLeg *leg = b->legs[s];
 		if (!leg) continue;
 		VolumeData *vd = (VolumeData *)leg->vol->data;

@@ -85,6 +85,7 @@ static int g_dec; /* ... with "server": "dec" -- the sources hand over G.711 PAC
 static int g_astream; /* ... "astream": full-duplex narrow-band AudioStreams as audiostream.c:1798-1832 plumbs them, the card at 8 kHz: PCMU packets ->
                         MSUlawDec -> MSGenericPLC -> dtmfgen (the application's) -> volrecv -> recv_tee -> MSSpeexEC pin 0 -> speaker;  microphone -> MSSpeexEC
                         pin 1 -> volsend -> dtmfgen_rtp -> MSUlawEnc -> packets.  The sending side fuses leg by leg, the receiving side runs as facades. */
+static int g_wb; /* ... "server wb": the server's conference runs at 16 kHz, its G.711 endpoints at 8 kHz -- both resamplers of every member work (audioconference.c:209-257) */
 static int g_eq; /* ... "eq": a mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801), a response of its own per leg */
 static int g_el; /* ... "el": the echo limiter on (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer (with nomixer) */
 static int g_eprs; /* ... "eprs": every pin behind an in_resampler, in front of an out_resampler, as MSAudioConference plumbs its endpoints (audioconference.c:209-257) */
@@ -114,7 +115,7 @@ static void build(TickerJob *j) {
 		call_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
 		j->mixers[c] = mx;
 		if (g_server) { /* the conference at the G.711 endpoints' rate: both resamplers forward (msresample.c:126-135) */
-			call_int(mx, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			call_int(mx, MS_FILTER_SET_SAMPLE_RATE, g_wb ? 16000 : 8000);
 			for (int k = 0; k < g_members; ++k) {
 				MSFilter *src = ms2shim_new_source(g_fac), *out = ms2shim_new_sink(g_fac), *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
 				MSFilter *in_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *out_rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID);
@@ -127,8 +128,8 @@ static void build(TickerJob *j) {
 				j->outs[c * g_members + k] = out;
 				j->spks[c * g_members + k] = NULL;
 				call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 8000);
-				call_int(in_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(in_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
-				call_int(out_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(out_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
+				call_int(in_rs, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(in_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, g_wb ? 16000 : 8000);
+				call_int(out_rs, MS_FILTER_SET_SAMPLE_RATE, g_wb ? 16000 : 8000), call_int(out_rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
 				if (dec) ms_filter_link(src, 0, dec, 0), ms_filter_link(dec, 0, vol, 0);
 				else ms_filter_link(src, 0, vol, 0);
 				ms_filter_link(vol, 0, in_rs, 0), ms_filter_link(in_rs, 0, mx, k);
@@ -361,6 +362,7 @@ int main(int argc, char **argv) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
 		g_astream = strstr(sh, "astream") != NULL;
+		g_wb = strstr(sh, " wb") != NULL;
 		if (g_astream) g_nomixer = 1;
 		g_eq = strstr(sh, "eq") != NULL, g_el = strstr(sh, " el") != NULL || strncmp(sh, "el", 2) == 0;
 	}

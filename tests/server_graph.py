@@ -37,11 +37,13 @@ class ServerConferences:
     """nconf conferences of `members` remote endpoints each on one ticker"""
 
     def __init__(self, h, nconf, members, rate=8000, law="u", ptime=0, endpoint_resamplers=True, pcm_pins=(), pins=None, gain=None, listener=False,
-                 decoders=()):
+                 decoders=(), endpoint_rate=None):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
         self.rate, self.nconf, self.members = rate, nconf, members
+        erate = endpoint_rate or rate   # the endpoints' own rate: other than the conference's, their resamplers work (audioconference.c:209-257)
+        self.erate = erate
         self.pins = list(range(members)) if pins is None else list(pins)
         self.legs, self.mixers, self.extra = [], [], []
         for c in range(nconf):
@@ -54,24 +56,23 @@ class ServerConferences:
                 leg = {"src": self.new_source(), "vol": S.ms_factory_create_filter(h.fac, fg.MS_VOLUME_ID), "out": S.ms2shim_new_sink(h.fac),
                        "mixer": mx, "pin": pin, "enc": None, "dec": None}
                 leg["law"] = law if law in ("a", "u") else ("a" if k % 2 else "u")   # "mixed": alternate
-                if rate == 8000 and (decoders is True or k in decoders):   # the source hands over G.711 packets (rtprecv): MSAlawDec / MSUlawDec of the plugin in front of volrecv
+                if erate == 8000 and (decoders is True or k in decoders):   # the source hands over G.711 packets (rtprecv): MSAlawDec / MSUlawDec of the plugin in front of volrecv
                     leg["dec"] = S.ms_factory_create_filter(h.fac, MS_ALAW_DEC_ID if leg["law"] == "a" else MS_ULAW_DEC_ID)
-                h.call_int(leg["vol"], SET_RATE, rate)
+                h.call_int(leg["vol"], SET_RATE, erate)
                 if gain is not None:
                     h.call_float(leg["vol"], fg.VOL_SET_GAIN, gain)
                 links = []
                 head, tail = (leg["vol"], 0), None
                 if endpoint_resamplers:   # audioconference.c:209-257: both at the conference's rate here -- they forward (msresample.c:126-135)
                     leg["in_rs"], leg["out_rs"] = (S.ms_factory_create_filter(h.fac, fg.MS_RESAMPLE_ID) for _ in range(2))
-                    for f in (leg["in_rs"], leg["out_rs"]):
-                        h.call_int(f, SET_RATE, rate)
-                        h.call_int(f, SET_OUT_RATE, rate)
+                    h.call_int(leg["in_rs"], SET_RATE, erate), h.call_int(leg["in_rs"], SET_OUT_RATE, rate)
+                    h.call_int(leg["out_rs"], SET_RATE, rate), h.call_int(leg["out_rs"], SET_OUT_RATE, erate)
                     links += [(leg["vol"], 0, leg["in_rs"], 0), (leg["in_rs"], 0, mx, pin), (mx, pin, leg["out_rs"], 0)]
                     tail = (leg["out_rs"], 0)
                 else:
                     links += [(leg["vol"], 0, mx, pin)]
                     tail = (mx, pin)
-                if rate == 8000 and k not in pcm_pins:
+                if erate == 8000 and k not in pcm_pins:
                     this_law = leg["law"]
                     leg["enc"] = S.ms_factory_create_filter(h.fac, MS_ALAW_ENC_ID if this_law == "a" else MS_ULAW_ENC_ID)
                     if ptime:
@@ -145,12 +146,12 @@ def run(plugin_dir, fuse, scenario, h=None):
     os.environ["MSMI355X_CHECK_LEVELS"] = "1"
     h = h or fg.Host(plugin_dir)
     sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, endpoint_resamplers=True, pcm_pins=(), pins=None, gain=None, listener=False,
-              decoders=())
+              decoders=(), endpoint_rate=None)
     sc.update(scenario)
     conf = ServerConferences(h, sc["nconf"], sc["members"], sc["rate"], sc["law"], sc["ptime"], sc["endpoint_resamplers"], sc["pcm_pins"], sc["pins"], sc["gain"],
-                             sc["listener"], sc["decoders"])
-    n, nt, ns = sc["nconf"] * sc["members"], sc["nticks"], sc["rate"] // 100
-    pcm = signals(n, nt, sc["rate"], seed=sc.get("seed", 5))
+                             sc["listener"], sc["decoders"], sc["endpoint_rate"])
+    n, nt, ns = sc["nconf"] * sc["members"], sc["nticks"], conf.erate // 100   # (the sources run at the endpoints' rate)
+    pcm = signals(n, nt, conf.erate, seed=sc.get("seed", 5))
     codes = {}
     if any(leg["dec"] for leg in conf.legs):   # what the endpoints send: their audio as G.711 (the oracle's encoder, pinned against the reference's g711.c)
         import oracle
@@ -231,6 +232,11 @@ SCENARIOS = {
     "late_packets_replumbed": {"burst": True, "nticks": 140, "events": [(50, "reattach", 0, 0), (51, "reattach", 0, 0), (90, "reattach", 0, 0)]},
     "late_packets_replumbed_no_early_launch": {"burst": True, "nticks": 120, "no_early_launch": True, "events": [(50, "reattach", 0, 0), (51, "reattach", 0, 0)]},
     "late_packets_agc_switched_on": {"burst": True, "nticks": 140, "events": [(50, "agc", 2, 1)]},
+    # G.711 endpoints in a WIDEBAND conference (audioconference.c:209-257: the endpoints' resamplers work): levelled at 8 kHz, up-sampled in
+    # the batch, mixed at 16 kHz, every pin's mix down-sampled and encoded -- the resamplers' states move into the bank and back
+    "g711_endpoints_in_a_16k_conference": {"rate": 16000, "endpoint_rate": 8000, "law": "mixed", "listener": True, "nticks": 140,
+                                           "events": [(40, "mute", 1, True), (60, "reattach", 0, 0), (61, "reattach", 0, 0), (90, "agc", 2, 1)]},
+    "g711_packets_of_20ms_into_a_48k_conference": {"rate": 48000, "endpoint_rate": 8000, "decoders": True, "ptime20_in": True, "nticks": 100},
     "g711_bridge_some_members_pcm": {"decoders": (0, 2), "burst": True, "nticks": 140, "events": [(60, "reattach", 0, 0)]},
 }
 

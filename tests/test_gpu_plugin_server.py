@@ -114,7 +114,8 @@ def oracle_server(oracle, sc_in):
     return out
 
 
-@pytest.mark.parametrize("name", [n for n in NAMES if n not in ("agc_switched_on", "late_packets_agc_switched_on", "all_but_one_fall_silent", "a_lone_contributor_is_heard_even_muted")])
+@pytest.mark.parametrize("name", [n for n in NAMES if n not in ("agc_switched_on", "late_packets_agc_switched_on", "all_but_one_fall_silent", "a_lone_contributor_is_heard_even_muted",
+                                                    "g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference")])
 @pytest.mark.parametrize("form", ["fused", "one_by_one"])
 def test_server_conference_is_the_oracle_chains(host, runs, oracle, name, form):
     """(agc_switched_on: MSVolume's AGC is the oracle's too, but the switch re-frames to 10 ms chunks -- held to the facades above;
@@ -127,3 +128,38 @@ def test_server_conference_is_the_oracle_chains(host, runs, oracle, name, form):
         # the plugin's last tick is in flight when the test drains (one block / at most one packet short of the oracle's)
         assert 0 <= len(y) - len(x) <= max(160, 2 * sg.SCENARIOS[name].get("rate", 8000) // 100), (name, s, len(x), len(y))
         assert len(x) > 1000 and np.array_equal(x, y[:len(x)]), (name, s, int(np.argmax(x != y[:len(x)])))
+
+
+@pytest.mark.parametrize("form", ["fused", "one_by_one"])
+def test_g711_endpoints_in_a_wideband_conference_against_the_oracle_chain(host, oracle, form):
+    """DIRECT: G.711 endpoints in a 16 kHz conference (audioconference.c:209-257: the endpoints' resamplers work) against the chain of
+    oracle objects -- oracle.Volume at 8 kHz -> oracle.Resampler 8k -> 16k -> OracleMixer at 16 kHz -> oracle.Resampler 16k -> 8k ->
+    oracle.g711_encode.  The resampler is held to the library's order within 1 LSB, and a sample that moves by one can cross
+    a G.711 decision level: the packets are the oracle's except for rare neighbouring code words -- fewer than 2 % of the bytes, and
+    the decoded audio within 1e-3 RMS of full scale."""
+    sc = {"rate": 16000, "endpoint_rate": 8000, "law": "mixed", "nconf": 1, "members": 3, "nticks": 120}
+    res = sg.run(PKG, form == "fused", sc, host)
+    assert (res["stats"]["legs"] > 0) == (form == "fused")
+    n, nt = 3, sc["nticks"]
+    pcm = sg.signals(n, nt, 8000, seed=5)
+    law_of = lambda k: "a" if k % 2 else "u"
+    vols = [oracle.Volume(8000) for _ in range(n)]
+    up = [oracle.Resampler(8000, 16000) for _ in range(n)]
+    down = [oracle.Resampler(16000, 8000) for _ in range(n)]
+    mixer = cg.OracleMixer(oracle, 160)
+    for k in range(n):
+        mixer.link(k)
+    heard = [[] for _ in range(n)]
+    for t in range(nt):
+        arrived = {k: up[k].process(vols[k].chunk(pcm[k, t * 80:(t + 1) * 80])) for k in range(n)}
+        for pin, row in mixer.tick(10 * t, arrived).items():
+            heard[pin].append(down[pin].process(row))
+    for k in range(n):
+        L = 0 if law_of(k) == "a" else 1
+        want = oracle.g711_encode(L, np.concatenate(heard[k]))
+        got = np.asarray(res["out"][k]).view(np.uint8)
+        assert 0 <= len(want) - len(got) <= 320 and len(got) > 8000, (k, len(got), len(want))
+        want = want[:len(got)]
+        assert np.mean(got != want) < 0.02, (k, float(np.mean(got != want)))
+        d = (oracle.g711_decode(L, got).astype(np.float64) - oracle.g711_decode(L, want).astype(np.float64)) / 32768.0
+        assert np.sqrt(np.mean(d * d)) < 1e-3, (k, float(np.sqrt(np.mean(d * d))))
