@@ -453,7 +453,8 @@ static void *server_conferences(void *arg) {
 		MSFilter *src[NM], *vol[NM], *irs[NM], *ors[NM], *enc[NM], *snk[NM], *dec[NM], *tap = ms2shim_new_sink(g_fac);
 		uint8_t codes[80];
 		for (int i = 0; i < 80; ++i) codes[i] = (uint8_t)(i * 37 + rep);
-		set_int(mx, MS_FILTER_SET_SAMPLE_RATE, 8000);
+		const int crate = (rep % 2) ? 16000 : 8000; /* every other round the conference runs at 16 kHz: the G.711 endpoints' resamplers work, in the batch */
+		set_int(mx, MS_FILTER_SET_SAMPLE_RATE, crate);
 		set_int(mx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
 		ms2shim_sink_set_discard(tap, 1);
 		for (int k = 0; k < NM; ++k) {
@@ -465,8 +466,8 @@ static void *server_conferences(void *arg) {
 			CHECK(src[k] && snk[k] && vol[k] && irs[k] && ors[k] && enc[k]);
 			ms2shim_sink_set_discard(snk[k], 1);
 			set_int(vol[k], MS_FILTER_SET_SAMPLE_RATE, 8000);
-			set_int(irs[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(irs[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
-			set_int(ors[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(ors[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
+			set_int(irs[k], MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(irs[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, crate);
+			set_int(ors[k], MS_FILTER_SET_SAMPLE_RATE, crate), set_int(ors[k], MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 8000);
 			if (dec[k]) ms_filter_link(src[k], 0, dec[k], 0), ms_filter_link(dec[k], 0, vol[k], 0);
 			else ms_filter_link(src[k], 0, vol[k], 0);
 			ms_filter_link(vol[k], 0, irs[k], 0), ms_filter_link(irs[k], 0, mx, k);
