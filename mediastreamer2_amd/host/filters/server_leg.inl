@@ -57,6 +57,8 @@ struct ServerBank : Pool {
 	int16_t *d_up = nullptr, *d_down = nullptr;       // [nlegs][cap * q] a round's up-sampled blocks; [nlegs][nse8] the pins' down-sampled mixes
 	uint8_t *h_umask = nullptr, *d_umask = nullptr;   // [kMaxRounds][pieces][nlegs]: the member has a p-th 10 ms piece in its block of that round
 	uint8_t *h_omask = nullptr, *d_omask = nullptr;   // [nlegs]: the pin's mix is down-sampled (and encoded) in this launch
+	int16_t *h_down = nullptr;                        // [nlegs][nse8] pinned: the down-sampled mixes of pins whose out_resampler is followed by somebody else's filter (PCM at `re`)
+	bool down_out = false;
 	int32_t *h_un = nullptr, *d_un = nullptr;         // [kMaxRounds][nlegs]: the up-sampled counts
 	int pieces = 1, nse8 = 0;
 	mi_volume *vol = nullptr, *vol_id = nullptr;
@@ -132,6 +134,7 @@ struct ServerBank : Pool {
 			d_umask = devmem<uint8_t>((size_t)kMaxRounds * 2 * pieces * L);
 			h_omask = pinned<uint8_t>(L);
 			d_omask = devmem<uint8_t>(L);
+			h_down = pinned<int16_t>(L * (size_t)nse8);
 			h_un = pinned<int32_t>(kMaxRounds * 2 * L);
 			d_un = devmem<int32_t>(kMaxRounds * 2 * L);
 		}
@@ -418,7 +421,9 @@ struct ServerBank : Pool {
 			}
 			// the mixes of this launch: encoded where the pin's output is an encoder of ours, PCM elsewhere
 			bool any_law[2] = {false, false};
+			bool down_now = false;
 			pcm_out = false;
+			if (q > 1) memset(h_omask, 0, L);
 			for (size_t s = 0; s < UL; ++s) {
 				h_len[0][s] = h_len[1][s] = 0;
 				const int c = (int)s / mm, pin = (int)s % mm;
@@ -429,12 +434,14 @@ struct ServerBank : Pool {
 					const int law = ((MapFilter *)e->data)->law;
 					h_len[law][s] = nse; // (10 ms at the endpoint's rate: ns where the endpoints run at the conference's)
 					any_law[law] = true;
+				} else if (orss[s]) { // a working out_resampler followed by somebody else's filter (a CPU encoder): its PCM at the endpoints' rate
+					if (q > 1) h_omask[s] = 2, down_now = true;
 				} else pcm_out = true;
 			}
 			const int16_t *enc_src = d_mix;
 			size_t enc_stride = (size_t)ns;
-			if (q > 1 && (any_law[0] || any_law[1])) { // the encoded pins' mixes down to the endpoints' rate (their out_resamplers' states)
-				for (size_t s = 0; s < L; ++s) h_omask[s] = s < UL && (h_len[0][s] > 0 || h_len[1][s] > 0);
+			if (q > 1 && (any_law[0] || any_law[1] || down_now)) { // these pins' mixes down to the endpoints' rate (their out_resamplers' states)
+				for (size_t s = 0; s < L; ++s) h_omask[s] = s < UL && (h_len[0][s] > 0 || h_len[1][s] > 0 || h_omask[s] == 2);
 				if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_omask, h_omask, L));
 				MI_MUST(mi_resampler_process_masked(rs_out, d_mix, ns, ns, d_down, nse8, nullptr, zero_copy ? h_omask : d_omask));
 				++launches;
@@ -448,6 +455,10 @@ struct ServerBank : Pool {
 				++launches;
 			}
 			if ((any_law[0] || any_law[1]) && !zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, h_codes, d_codes, UL * ns));
+			if (down_now) {
+				MI_MUST(mi_copy_d2h_pinned(ctx, h_down, d_down, UL * (size_t)nse8 * 2));
+				down_out = true;
+			}
 			if (pcm_out) {
 				if (!cur) cur = free_slab();
 				MI_MUST(mi_copy_d2h_pinned(ctx, cur ? (void *)cur->payload() : (void *)h_copy, d_mix, UL * ns * 2));
@@ -625,6 +636,18 @@ void ServerBank::emit(MSFilter *f, int c) { // mixer_process :336-343 (conferenc
 			enc_take_codes(e, h_codes + at * ns, nse);
 			continue;
 		}
+		if (MSFilter *ors = orss[at]) { // the block its out_resampler would have made of this tick's mix, on ITS output queue (ResamplePool::emit)
+			if (this->q > 1 && ors->outputs[0]) { // (`q` is the pin's queue here)
+				ResampleData *rd = (ResampleData *)ors->data;
+				mblk_t *om = allocb((size_t)nse * 2, 0);
+				memcpy(om->b_wptr, h_down + at * (size_t)nse8, (size_t)nse * 2);
+				om->b_wptr += (size_t)nse * 2;
+				mblk_set_timestamp_info(om, rd->ts); // msresample.c:168-169
+				rd->ts += (uint32_t)nse;
+				ms_queue_put(ors->outputs[0], om);
+			}
+			continue;
+		}
 		uint8_t *row = const_cast<uint8_t *>(base) + (at * ns) * 2;
 		mblk_t *om;
 		if (root) {
@@ -749,6 +772,7 @@ MSFilter *server_find_encoder(MSFilter *mx, int pin, int rate, int re, MSFilter 
 		q = g->outputs[0];
 		g = q ? q->next.filter : NULL;
 	}
+	if (*ors) *blocked = false; // (whatever follows it gets PCM at the endpoints' rate from the batch, on the out_resampler's own queue -- or, below, is an encoder the batch serves)
 	if (re != 8000) return NULL; // (G.711 runs at 8 kHz)
 	if (!g || !is_g711_enc(g->desc) || g->ticker != mx->ticker || !q || !ms_queue_empty(q)) return NULL;
 	MapFilter *d = (MapFilter *)g->data;
@@ -884,19 +908,20 @@ bool server_try_fuse(MSFilter *mx) {
 		b->orss[(size_t)(s0 + pin)] = nullptr;
 	}
 	int nenc = 0;
-	for (int pin = 0; pin < mm && pin < mx->desc->noutputs; ++pin)
+	for (int pin = 0; pin < mm && pin < mx->desc->noutputs; ++pin) {
 		if (MSFilter *e = enc_of[(size_t)pin]) {
 			b->encs[(size_t)(s0 + pin)] = e;
 			((MapFilter *)e->data)->sleg_bank = b;
 			((MapFilter *)e->data)->sleg = true;
 			++nenc;
-			if (MSFilter *ors = ors_of[(size_t)pin]) { // its out_resampler's state moves into the bank (msresample.c:117-120: the handle lives as long as the filter)
-				ResampleData *rd = (ResampleData *)ors->data;
-				if (rd->pool && rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
-				resample_restore_to(rd, b->rs_out, s0 + pin, (uint32_t)rate, (uint32_t)re, false);
-				b->orss[(size_t)(s0 + pin)] = ors;
-			}
 		}
+		if (MSFilter *ors = ors_of[(size_t)pin]) { // a working out_resampler: its state moves into the bank (msresample.c:117-120: the handle lives as long as the filter)
+			ResampleData *rd = (ResampleData *)ors->data;
+			if (rd->pool && rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
+			resample_restore_to(rd, b->rs_out, s0 + pin, (uint32_t)rate, (uint32_t)re, false);
+			b->orss[(size_t)(s0 + pin)] = ors;
+		}
+	}
 	for (size_t ci = 0; ci < cand.size(); ++ci) {
 		const auto &pv = cand[ci];
 		ServerLeg *leg = new ServerLeg();

@@ -236,6 +236,9 @@ SCENARIOS = {
     # the batch, mixed at 16 kHz, every pin's mix down-sampled and encoded -- the resamplers' states move into the bank and back
     "g711_endpoints_in_a_16k_conference": {"rate": 16000, "endpoint_rate": 8000, "law": "mixed", "listener": True, "nticks": 140,
                                            "events": [(40, "mute", 1, True), (60, "reattach", 0, 0), (61, "reattach", 0, 0), (90, "agc", 2, 1)]},
+    # wide-band endpoints (a CPU codec at 16 kHz) in a 48 kHz conference: no encoder of ours behind the out_resampler -- its PCM at 16 kHz comes from the batch
+    "wideband_endpoints_in_a_48k_conference": {"rate": 48000, "endpoint_rate": 16000, "listener": True, "nticks": 110,
+                                               "events": [(30, "mute", 1, True), (50, "reattach", 0, 0), (70, "gain", 5, 0.5)]},
     "g711_packets_of_20ms_into_a_48k_conference": {"rate": 48000, "endpoint_rate": 8000, "decoders": True, "ptime20_in": True, "nticks": 100},
     "g711_bridge_some_members_pcm": {"decoders": (0, 2), "burst": True, "nticks": 140, "events": [(60, "reattach", 0, 0)]},
 }

@@ -115,7 +115,7 @@ def oracle_server(oracle, sc_in):
 
 
 @pytest.mark.parametrize("name", [n for n in NAMES if n not in ("agc_switched_on", "late_packets_agc_switched_on", "all_but_one_fall_silent", "a_lone_contributor_is_heard_even_muted",
-                                                    "g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference")])
+                                                    "g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference", "wideband_endpoints_in_a_48k_conference")])
 @pytest.mark.parametrize("form", ["fused", "one_by_one"])
 def test_server_conference_is_the_oracle_chains(host, runs, oracle, name, form):
     """(agc_switched_on: MSVolume's AGC is the oracle's too, but the switch re-frames to 10 ms chunks -- held to the facades above;

@@ -17,7 +17,7 @@ HOST = os.path.join(ROOT, "tests", "host")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["ulaw_ptime20", "alaw_ptime10_direct", "mixed_laws_and_a_pcm_pin", "packets_of_20ms_in", "late_packets", "a_member_falls_silent",
          "all_but_one_fall_silent", "mute_and_gain", "mute_and_gain_early", "reattach", "agc_switched_on", "wideband_pcm_48k",
-         "g711_bridge_packets_of_20ms", "g711_bridge_some_members_pcm", "late_packets_replumbed", "a_lone_contributor_is_heard_even_muted", "g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference", "late_packets_replumbed_no_early_launch", "late_packets_agc_switched_on"]
+         "g711_bridge_packets_of_20ms", "g711_bridge_some_members_pcm", "late_packets_replumbed", "a_lone_contributor_is_heard_even_muted", "g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference", "wideband_endpoints_in_a_48k_conference", "late_packets_replumbed_no_early_launch", "late_packets_agc_switched_on"]
 
 
 @pytest.fixture(scope="module")
