@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--worst-ticks", type=int, default=3000, help="consecutive single ticks the worst tick is taken over")
     ap.add_argument("--zero-ticks", type=int, default=256, help="ticks of the from-reset test at the chosen count (0 = skip)")
     ap.add_argument("--paced-ticks", type=int, default=3000, help="ticks of the series run at the 10 ms cadence of an MSTicker, one per 10 ms of wall time: part of `value`'s criterion (0 = skip)")
-    ap.add_argument("--accept-seconds", type=float, default=200.0, help="wall time the step-downs of the acceptance series may take before the next count is chosen with room for the largest machine event seen on this hardware (1.8 ms)")
+    ap.add_argument("--accept-seconds", type=float, default=150.0, help="wall time the step-downs of the acceptance series may take before the next count is chosen with room for the largest machine event seen on this hardware (1.8 ms)")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the rate of full call legs through the drop-in plugin (tests/host/plugin_bench)")
     ap.add_argument("--plugin-legs", type=int, default=49152, help="full call legs the plugin path is first tried with (config[3] is 32 768: 1024 conferences x 32)")
     ap.add_argument("--no-video-host", action="store_true", help="skip the PCIe-inclusive video probe (config 5)")
