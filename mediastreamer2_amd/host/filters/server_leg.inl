@@ -58,7 +58,6 @@ struct ServerBank : Pool {
 	uint8_t *h_umask = nullptr, *d_umask = nullptr;   // [kMaxRounds][pieces][nlegs]: the member has a p-th 10 ms piece in its block of that round
 	uint8_t *h_omask = nullptr, *d_omask = nullptr;   // [nlegs]: the pin's mix is down-sampled (and encoded) in this launch
 	int16_t *h_down = nullptr;                        // [nlegs][nse8] pinned: the down-sampled mixes of pins whose out_resampler is followed by somebody else's filter (PCM at `re`)
-	bool down_out = false;
 	int32_t *h_un = nullptr, *d_un = nullptr;         // [kMaxRounds][nlegs]: the up-sampled counts
 	int pieces = 1, nse8 = 0;
 	mi_volume *vol = nullptr, *vol_id = nullptr;
@@ -455,10 +454,7 @@ struct ServerBank : Pool {
 				++launches;
 			}
 			if ((any_law[0] || any_law[1]) && !zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, h_codes, d_codes, UL * ns));
-			if (down_now) {
-				MI_MUST(mi_copy_d2h_pinned(ctx, h_down, d_down, UL * (size_t)nse8 * 2));
-				down_out = true;
-			}
+			if (down_now) MI_MUST(mi_copy_d2h_pinned(ctx, h_down, d_down, UL * (size_t)nse8 * 2));
 			if (pcm_out) {
 				if (!cur) cur = free_slab();
 				MI_MUST(mi_copy_d2h_pinned(ctx, cur ? (void *)cur->payload() : (void *)h_copy, d_mix, UL * ns * 2));
