@@ -473,6 +473,9 @@ void ms_mi355x_runtime_stats(int *hubs, int *banks, int *slots_in_use);
 /* The device of every ticker hub that has opened a context (the hubs of one process spread over MSMI355X_DEVICES,
  * default: every visible device); returns their number, fills at most `cap` entries. */
 int ms_mi355x_hub_devices(int *devices, int cap);
+/* Streams whose receiving side (MSAlawDec / MSUlawDec -> MSGenericPLC -> MSAudioFlowControl, src/voip/audiostream.c:1812-1824) lives
+ * in one device-resident batch per ticker instead of a bank per filter. */
+int ms_mi355x_recv_stats(void);
 /* Waits for every hub's stream (tests, orderly shutdown). */
 void ms_mi355x_shutdown(void);
 #ifdef __cplusplus

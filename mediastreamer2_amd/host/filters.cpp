@@ -484,12 +484,14 @@ bool already_ran_this_tick(MSFilter *f) {
 
 void deliver_fused_in_scope(TickerHub &h);  // leg_chain.inl
 void deliver_server_in_scope(TickerHub &h); // server_leg.inl
+void deliver_recv_in_scope(TickerHub &h);   // recv_leg.inl
 void flush_hub(TickerHub &h) {
 	static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr; // A/B switch: one tick per facade again
 	h.in_flush = !no_chain || h.scope; // (a detaching graph's flush always runs its chain to the end: there is no next tick for it)
 	h.touched.clear();
 	h.touched_pumps.clear();
 	if (h.scope) deliver_server_in_scope(h);
+	if (h.scope) deliver_recv_in_scope(h);
 	if (h.scope) deliver_fused_in_scope(h); // fused conferences / legs of the graph: the launches already out are waited for, their results handed on
 	auto takes_part = [&](Pool *p) { return !h.scope || p->scoped(); };
 	for (int round = 0; round < 16; ++round) { // chains deeper than this finish on the next tick
@@ -640,17 +642,34 @@ Pool *server_pool_of(ServerBank *b);
 void server_conf_walked(ServerBank *b, int c);
 void server_unfuse(MSFilter *mixer, bool keep_running);
 
+// the receiving side of an AudioStream as one batch (filters/recv_leg.inl): what the decoders, MSGenericPLC and MSAudioFlowControl need to know of it
+struct RecvLeg;
+struct MapFilter;
+struct PlcFilter;
+void recv_chain_preprocessed(MSFilter *member);
+void recv_release(RecvLeg *leg, bool keep_running);
+void recv_disqualify(RecvLeg *leg);
+bool recv_wants_out(RecvLeg *leg);
+bool recv_idle(RecvLeg *leg);
+Pool *recv_pool(RecvLeg *leg);
+void recv_stage_codes(MSFilter *f, MapFilter *d);
+void recv_plc_walk(MSFilter *f, PlcFilter *d);
+void recv_flow_drop(RecvLeg *leg, uint32_t drop, uint32_t total);
+void recv_flow_config(RecvLeg *leg, const MSAudioFlowControlConfig *cfg);
+bool recv_candidate(MSFilter *member);
+
 #include "filters/resample.inl"
 #include "filters/volume.inl"
 #include "filters/equalizer.inl"
 #include "filters/mixer.inl"
 #include "filters/echo_canceller.inl"
+#include "filters/codec.inl"
 #include "filters/leg_chain.inl"
 #include "filters/video.inl"
-#include "filters/codec.inl"
 #include "filters/server_leg.inl"
 #include "filters/flow_control.inl"
 #include "filters/generic_plc.inl"
+#include "filters/recv_leg.inl"
 
 } // namespace
 
@@ -697,9 +716,9 @@ MSScalerDesc ms_mi355x_scaler_desc = {sd_create, sd_process, sd_free};
 
 // the stages either side of the path
 MSFilterDesc ms_mi355x_alaw_dec_desc = {MS_ALAW_DEC_ID, "MSAlawDec", "ITU-G.711 alaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcma", 1, 1,
-                                        g711_dec_init_a, NULL, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_dec_init_a, g711_dec_preprocess, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_dec_desc = {MS_ULAW_DEC_ID, "MSUlawDec", "ITU-G.711 ulaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcmu", 1, 1,
-                                        g711_dec_init_u, NULL, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_dec_init_u, g711_dec_preprocess, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_alaw_enc_desc = {MS_ALAW_ENC_ID, "MSAlawEnc", "ITU-G.711 alaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcma", 1, 1,
                                         g711_enc_init_a, NULL, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_enc_desc = {MS_ULAW_ENC_ID, "MSUlawEnc", "ITU-G.711 ulaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcmu", 1, 1,
@@ -826,12 +845,27 @@ void ms_mi355x_fused_stats(int *conferences, int *legs, unsigned long long *laun
 				nc += b->in_use;
 				la += b->launches;
 				for (ServerLeg *l : b->legs) nl += l != nullptr;
+			} else if (p->key.compare(0, 4, "rcv:") == 0) { // streams' receiving sides (recv_leg.inl): their launches count, their streams are ms_mi355x_recv_stats'
+				la += static_cast<RecvBank *>(p)->launches;
 			}
 	}
 	if (conferences) *conferences = nc;
 	if (legs) *legs = nl;
 	if (launches) *launches = la;
 	if (flush_rounds) *flush_rounds = fr;
+}
+
+// streams whose receiving side (decoder -> MSGenericPLC -> MSAudioFlowControl) lives in a fused batch (filters/recv_leg.inl)
+int ms_mi355x_recv_stats(void) {
+	int n = 0;
+	for (TickerHub *h : referenced_hubs()) {
+		HubLock lk(h, HubLock::Adopt{});
+		if (lk.dead()) continue;
+		for (Pool *p : h->pools)
+			if (p->key.compare(0, 4, "rcv:") == 0)
+				for (RecvLeg *l : static_cast<RecvBank *>(p)->legs) n += l != nullptr;
+	}
+	return n;
 }
 
 // the device of every hub that has opened a context (tests: tickers spread over MSMI355X_DEVICES); returns their number

@@ -156,6 +156,10 @@ struct MapFilter { // AlawEncData alaw.c:25-30 / EncState l16.c:22-29 / AdapterS
 	void *sleg_leg; // a DECODER that heads a fused member: its ServerLeg
 	mblk_t *pending;
 	bool fuse_checked; // a decoder: looked for a conference to fuse with since the last attach
+	// a G.711 decoder that heads the receiving side of an AudioStream (decoder -> MSGenericPLC -> MSAudioFlowControl,
+	// filters/recv_leg.inl): its packets' code bytes go into that batch as they are
+	RecvLeg *rleg;
+	FusedLeg *fleg; // a G.711 encoder behind a fused sending leg's MSVolume (filters/leg_chain.inl): the leg's chunks are encoded in that batch
 };
 void server_encoder_gone(MSFilter *e); // server_leg.inl
 void server_stage_codes(MSFilter *f, MapFilter *d);
@@ -205,6 +209,8 @@ bool map_attach(MSFilter *f, MapFilter *d, MapOp op) {
 void map_uninit(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
 	if (d->sleg) server_encoder_gone(f);
+	if (d->rleg) recv_release(d->rleg, false);
+	if (d->fleg) leg_release(d->fleg, false);
 	if (d->pending) freemsg(d->pending);
 	map_release(d);
 	if (d->bz) ms_bufferizer_destroy(d->bz);
@@ -227,10 +233,23 @@ void g711_dec_postprocess(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
 	facade_detached(f);
 	if (d->sleg) server_encoder_gone(f);
+	if (d->rleg) recv_release(d->rleg, false);
 	d->fuse_checked = false;
+}
+// (alaw.c has none) the attaching thread: is this the head of a stream's receiving chain?  (the last of the chain's filters to be
+// preprocessed finds every ticker set and fuses it: msticker.c:163-166 runs the graph's preprocess calls one after the other)
+void g711_dec_preprocess(MSFilter *f) {
+	HubLock lk(f);
+	recv_chain_preprocessed(f);
 }
 void g711_dec_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
+	if (d->rleg && recv_wants_out(d->rleg)) recv_release(d->rleg, true); // a member stopped qualifying: the facades' own banks from this walk on
+	if (d->rleg) { // the head of a stream's receiving side: the packet goes into the stream's row of that batch as it is
+		HubLock lk(f, recv_pool(d->rleg));
+		recv_stage_codes(f, d);
+		return;
+	}
 	if (!d->sleg && !d->fuse_checked && f->ticker && f->inputs[0] && !ms_queue_empty(f->inputs[0])) {
 		// the first packet since the attach: decoder -> MSVolume -> [in_resampler ->] a conference mixer whose members are all remote endpoints?
 		d->fuse_checked = true;
@@ -247,7 +266,7 @@ void g711_dec_process(MSFilter *f) {
 		return;
 	}
 	map_rehome(f, d);
-	HubLock lk(f);
+	HubLock lk(f, d->pool);
 	if (!map_attach(f, d, d->law ? OP_ULAW_DEC : OP_ALAW_DEC)) {
 		ms_queue_flush(f->inputs[0]);
 		return;
@@ -290,7 +309,7 @@ void g711_enc_process(MSFilter *f) {
 	if (frame_per_packet > 14) frame_per_packet = 14; // 140 ms max (:68-69)
 	const size_t size_of_pcm = (size_t)160 * (size_t)frame_per_packet;
 	map_rehome(f, d);
-	HubLock lk(f);
+	HubLock lk(f, d->pool); // (a filter that holds a slot knows its hub through the bank: no registry look-up)
 	ms_bufferizer_put_from_queue(d->bz, f->inputs[0]);
 	if (ms_bufferizer_get_avail(d->bz) < size_of_pcm) return;
 	if (!map_attach(f, d, d->law ? OP_ULAW_ENC : OP_ALAW_ENC)) {
@@ -313,6 +332,7 @@ void g711_enc_process(MSFilter *f) {
 void g711_enc_postprocess(MSFilter *f) { // (alaw.c has none: the bufferizer -- here also the packet being filled -- outlives a detach)
 	facade_detached(f);
 	if (((MapFilter *)f->data)->sleg) server_encoder_gone(f);
+	if (((MapFilter *)f->data)->fleg) leg_release(((MapFilter *)f->data)->fleg, false);
 }
 
 // "key=value" out of an fmtp line "a=1;key=value; b=2" (what oRTP's fmtp_get_value does for the callers in alaw.c:92-105)

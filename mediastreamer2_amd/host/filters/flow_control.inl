@@ -128,6 +128,7 @@ struct FlowFilter { // MSAudioFlowControlState :154-158
 	int slot;
 	int samplerate, nchannels;
 	MSAudioFlowControlConfig config;
+	RecvLeg *rleg; // part of a stream's fused receiving side (filters/recv_leg.inl): the controller lives in that bank
 };
 
 void flowctl_init(MSFilter *f) { // :160-164
@@ -169,11 +170,17 @@ bool flowctl_attach(MSFilter *f, FlowFilter *d) {
 void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_reset
 	FlowFilter *d = (FlowFilter *)f->data;
 	HubLock lk(f);
+	recv_chain_preprocessed(f);
+	if (d->rleg || recv_candidate(f)) return; // (fused: reset with its slot there; a chain that may still fuse: process() attaches -- and resets -- when it does not)
 	if (flowctl_attach(f, d)) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1));
 }
 void flowctl_process(MSFilter *f) { // :171-183
 	FlowFilter *d = (FlowFilter *)f->data;
 	HubLock lk(f); // lock order everywhere: the hub first, the filter's own lock inside it
+	if (d->rleg) { // (nothing arrives while the chain is fused: the blocks leave this filter's output with the flush)
+		ms_queue_flush(f->inputs[0]);
+		return;
+	}
 	ms_filter_lock(f);
 	if (!flowctl_attach(f, d)) {
 		ms_queue_flush(f->inputs[0]);
@@ -206,10 +213,13 @@ void flowctl_process(MSFilter *f) { // :171-183
 	ms_filter_unlock(f);
 }
 void flowctl_postprocess(MSFilter *f) {
+	FlowFilter *d = (FlowFilter *)f->data;
 	facade_detached(f);
-	flowctl_release((FlowFilter *)f->data);
+	if (d->rleg) recv_release(d->rleg, false);
+	flowctl_release(d);
 }
 void flowctl_uninit(MSFilter *f) { // :188-191
+	if (((FlowFilter *)f->data)->rleg) recv_release(((FlowFilter *)f->data)->rleg, false);
 	flowctl_release((FlowFilter *)f->data);
 	ms_free(f->data);
 }
@@ -217,6 +227,7 @@ int flowctl_set_config(MSFilter *f, void *arg) { // :193-197
 	FlowFilter *d = (FlowFilter *)f->data;
 	HubLock lk(f);
 	d->config = *(MSAudioFlowControlConfig *)arg;
+	if (d->rleg) recv_flow_config(d->rleg, &d->config);
 	if (d->pool)
 		MI_MUST(mi_flowctl_set_config(d->pool->fc, d->slot, 1, d->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT,
 		                              d->config.silent_threshold));
@@ -227,6 +238,9 @@ int flowctl_drop(MSFilter *f, void *arg) { // :199-211; applied by the next laun
 	const MSAudioFlowControlDropEvent *ev = (const MSAudioFlowControlDropEvent *)arg;
 	HubLock lk(f);
 	ms_filter_lock(f);
+	if (d->rleg)
+		recv_flow_drop(d->rleg, (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000,
+		               (ev->flow_control_interval_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000);
 	{
 		if (d->pool && d->pool->req_drop[(size_t)d->slot] == 0 && d->pool->req_total[(size_t)d->slot] == 0) {
 			d->pool->req_drop[(size_t)d->slot] = (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;

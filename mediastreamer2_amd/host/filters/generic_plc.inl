@@ -145,6 +145,7 @@ struct PlcFilter { // generic_plc_struct msgenericplc.c:30-41
 	Concealer *concealer;
 	int rate, nchannels;
 	bool cng_set, cng_running;
+	RecvLeg *rleg; // part of a stream's fused receiving side (filters/recv_leg.inl): the concealer's decisions stay here, the context lives in that bank
 };
 
 void plc_init(MSFilter *f) { // :45-53
@@ -184,13 +185,22 @@ bool plc_attach(MSFilter *f, PlcFilter *d) { // generic_plc_preprocess :55-58: a
 	return true;
 }
 void plc_preprocess(MSFilter *f) {
+	PlcFilter *d = (PlcFilter *)f->data;
 	HubLock lk(f);
-	plc_attach(f, (PlcFilter *)f->data);
+	recv_chain_preprocessed(f);
+	if (!d->rleg && !recv_candidate(f)) plc_attach(f, d); // (a chain that may still fuse opens no bank of its own here: process() does when it does not)
 }
 void plc_process(MSFilter *f) { // generic_plc_process :59-167
 	PlcFilter *d = (PlcFilter *)f->data;
-	HubLock lk(f);
+	// a member stopped qualifying: the chain leaves its batch before anything of this walk is staged (behind a decoder of ours that did
+	// stage in this walk -- it runs first -- the chain leaves with the decoder's next packet instead)
+	if (d->rleg && recv_wants_out(d->rleg) && recv_idle(d->rleg)) recv_release(d->rleg, true);
+	HubLock lk(f, d->rleg ? recv_pool(d->rleg) : static_cast<Pool *>(d->pool)); // (a filter that holds a slot knows its hub through the bank: no registry look-up)
 	if (already_ran_this_tick(f)) return; // pumped by the flush task right behind the decoder that feeds it
+	if (d->rleg) { // the stream's receiving side is one batch: the decisions of this walk, on counts
+		recv_plc_walk(f, d);
+		return;
+	}
 	if (d->rate <= 0 || !plc_attach(f, d)) { // no usable context: the stream passes as it is
 		mblk_t *m;
 		while ((m = ms_queue_get(f->inputs[0])) != NULL) ms_queue_put(f->outputs[0], m);
@@ -252,11 +262,14 @@ void plc_process(MSFilter *f) { // generic_plc_process :59-167
 	if (any) request_flush(f);
 }
 void plc_postprocess(MSFilter *f) {
+	PlcFilter *d = (PlcFilter *)f->data;
 	facade_detached(f);
-	plc_release((PlcFilter *)f->data);
+	if (d->rleg) recv_release(d->rleg, false);
+	plc_release(d);
 }
 void plc_uninit(MSFilter *f) { // :169-178
 	PlcFilter *d = (PlcFilter *)f->data;
+	if (d->rleg) recv_release(d->rleg, false);
 	plc_release(d);
 	delete d->concealer;
 	ms_free(d);
@@ -266,7 +279,10 @@ int plc_get_sr(MSFilter *f, void *arg) {
 	return 0;
 }
 int plc_set_sr(MSFilter *f, void *arg) {
-	((PlcFilter *)f->data)->rate = *(int *)arg;
+	PlcFilter *d = (PlcFilter *)f->data;
+	HubLock lk(f);
+	if (d->rleg && d->rate != *(int *)arg) recv_disqualify(d->rleg); // (the facade's context starts over at another rate too: plc_attach)
+	d->rate = *(int *)arg;
 	return 0;
 }
 int plc_set_nch(MSFilter *f, void *arg) {

@@ -150,6 +150,10 @@ struct FusedLeg {
 	// MSVolume's echo limiter (msvolume.c:201-238): volsend reads the energy of its peer, volrecv -- which this leg METERS beside its
 	// chain (LegBank::vol_peer): the peer facade hands its blocks on untouched in the walk and stages a copy of each for the meter
 	MSFilter *eq = nullptr; // mic_equalizer between the leg's MSResample and MSSpeexEC (audiostream.c:1801): runs in the bank (LegBank::eq)
+	// the G.711 encoder behind the leg's MSVolume (audiostream.c:1803-1809: volsend -> [outbound_mixer, forwarding] -> encoder), a leg
+	// without a conference mixer: its chunks are ENCODED in the batch (LegBank::enc_law), 80 bytes of G.711 per 10 ms come back
+	// instead of 160 of PCM and the encoder facade only packs them to its ptime (enc_take_codes, alaw.c:56-90)
+	MSFilter *enc = nullptr, *omix = nullptr;
 	MSFilter *peer = nullptr;
 	int peer_staged = 0; // blocks of the peer staged since the last launch
 	bool peer_metered = false;
@@ -185,6 +189,9 @@ void spk_slab_release(void *payload) {
 }
 
 int channel_flow_control_level(Channel *chan, int level, int threshold, uint64_t now); // mixer.inl
+void enc_take_codes(MSFilter *e, const uint8_t *codes, int n); // server_leg.inl
+bool is_g711_enc(const MSFilterDesc *d);
+bool is_forwarding_mixer(MSFilter *g, MSTicker *ticker); // recv_leg.inl
 void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbytes, bool immediate);
 void conf_unfuse(MSFilter *mixer, bool keep_running);
 void leg_conf_walked(LegBank *b, int c);
@@ -302,6 +309,9 @@ struct LegBank : Pool {
 	// which the conference is mixed (volmix_kernel with an identity volume batch: pop + mix); without a mixer they are handed on
 	// frame by frame (chunk = F).
 	bool light = false;
+	int enc_law = -1;              // plain: every leg's chunks leave through MSAlawEnc (MI_LAW_PCMA) / MSUlawEnc (MI_LAW_PCMU) of ours; -1: as PCM
+	uint8_t *h_codes = nullptr, *d_codes = nullptr; // [kLegMaxChunks][nlegs][chunk]: the encoded chunks of this flush
+	int32_t *h_elen = nullptr, *d_elen = nullptr;   // [kLegMaxChunks][nlegs]: chunk where the leg has a chunk in that round, else 0
 	int chunk = 0;                 // samples of a block MSVolume hands on: 10 ms with AGC, a canceller frame without
 	mi_volume *vol_id = nullptr;   // identity batch (gain 1, nothing enabled): volmix_kernel's volume half for the levelled queue
 	mi_fifo *f_chan = nullptr;     // the mixer channels' bufferizers
@@ -318,8 +328,8 @@ struct LegBank : Pool {
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
 	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false, bool no_agc = false,
-	        bool with_eq = false)
-	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer), light(no_agc) {
+	        bool with_eq = false, int law = -1)
+	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer), light(no_agc), enc_law(law) {
 		Building b(this, cap_conf);
 		ns = (int)rate / 100;
 		chunk = light ? F : ns;
@@ -351,6 +361,12 @@ struct LegBank : Pool {
 			d_fcnt = devmem<int32_t>(kLegLightRounds * L);
 			h_dgate = pinned<uint8_t>(L);
 			d_dgate = devmem<uint8_t>(L);
+		}
+		if (enc_law >= 0) {
+			h_codes = pinned<uint8_t>((size_t)kLegMaxChunks * L * chunk);
+			d_codes = devmem<uint8_t>((size_t)kLegMaxChunks * L * chunk);
+			h_elen = pinned<int32_t>((size_t)kLegMaxChunks * L);
+			d_elen = devmem<int32_t>((size_t)kLegMaxChunks * L);
 		}
 		h_mic = pinned<int16_t>(kMaxRounds * L * in_len);
 		d_mic = devmem<int16_t>(L * in_len);
@@ -839,7 +855,22 @@ struct LegBank : Pool {
 		}
 		if (failed) return false;
 		bool any = enqueue_cancellers(any_ref, any_refx, any_inj, rounds);
-		if (maxc) {
+		if (maxc && enc_law >= 0) { // the chunks stay on the device, what comes back is their G.711 (alaw_enc_process alaw.c:56-90)
+			for (int r = 0; r < maxc; ++r)
+				for (size_t s = 0; s < L; ++s) h_elen[(size_t)r * L + s] = (s < UL && r < nout[s]) ? chunk : 0;
+			if (!zero_copy) MI_MUST(mi_copy_h2d_pinned(ctx, d_elen, h_elen, (size_t)maxc * L * 4));
+			for (int r = 0; r < maxc; ++r) {
+				MI_MUST(mi_volume_process_fifo_flags(vol, f_out, d_mix + (size_t)r * L * chunk, chunk, chunk, MI_VOLMIX_DRY_SKIPS));
+				MI_MUST(mi_g711_encode(ctx, enc_law, d_mix + (size_t)r * L * chunk, (size_t)chunk, (zero_copy ? h_codes : d_codes) + (size_t)r * L * chunk, (size_t)chunk,
+				                       (zero_copy ? h_elen : d_elen) + (size_t)r * L, chunk, UL));
+				launches += 2;
+				if (r + 1 < maxc) meter_round(UL);
+			}
+			if (!zero_copy) MI_MUST(mi_copy_d2h_pinned(ctx, h_codes, d_codes, ((size_t)(maxc - 1) * L + UL) * chunk));
+			MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
+			mixed = true;
+			any = true;
+		} else if (maxc) {
 			if (!cur) cur = free_slab();
 			uint8_t *dst = cur ? cur->payload() : reinterpret_cast<uint8_t *>(h_copy);
 			int16_t *rows = zero_copy ? reinterpret_cast<int16_t *>(dst) : d_mix;
@@ -1102,6 +1133,12 @@ struct LegBank : Pool {
 	}
 
 	void emit(MSFilter *f, int c) override { // mixer_process :336-343 (conference mode): one block per enabled output
+		if (plain && enc_law >= 0) { // ... to the leg's encoder, as codes: packed to its ptime there
+			FusedLeg *leg = legs[(size_t)c];
+			for (int r = 0; leg && leg->enc && r < nready[(size_t)c]; ++r) enc_take_codes(leg->enc, h_codes + ((size_t)r * nlegs + (size_t)c) * chunk, chunk);
+			nready[(size_t)c] = 0;
+			return;
+		}
 		if (plain) { // the leg's MSVolume hands its levelled chunks on (volume_process :500-502)
 			const uint8_t *base = root ? cur->payload() : reinterpret_cast<const uint8_t *>(h_copy);
 			for (int r = 0; r < nready[(size_t)c]; ++r) {
@@ -1830,7 +1867,8 @@ MSFilter *leg_find_mixer(MSFilter *rs) {
 	MSFilter *vol = q ? q->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc) return NULL;
 	MSFilter *mx = leg_volume_sink(vol);
-	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
+	// (a mixer that is not a conference -- an AudioStream's outbound_mixer, audiostream.c:1585-1588,1807 -- is "anything else": the leg fuses without a mixer)
+	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc && ((MixerState *)mx->data)->conf_mode != 0) ? mx : NULL;
 }
 
 // ... and MSSpeexEC, when it is the head itself
@@ -1839,7 +1877,8 @@ MSFilter *leg_find_mixer_ec(MSFilter *ec) {
 	MSFilter *vol = q ? q->next.filter : NULL;
 	if (!vol || vol->desc != &ms_mi355x_volume_desc) return NULL;
 	MSFilter *mx = leg_volume_sink(vol);
-	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc) ? mx : NULL;
+	// (a mixer that is not a conference -- an AudioStream's outbound_mixer, audiostream.c:1585-1588,1807 -- is "anything else": the leg fuses without a mixer)
+	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc && ((MixerState *)mx->data)->conf_mode != 0) ? mx : NULL;
 }
 
 void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess (a bank slot of its own)
@@ -1966,9 +2005,20 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;
 	const uint32_t rate = (uint32_t)es->samplerate, ir = rd ? rd->input_rate : rate;
 	const int F = es->framesize, flen = es->filterlength, delay = es->nominal_ref_samples;
+	// volsend -> [outbound_mixer that can only forward] -> MSAlawEnc / MSUlawEnc of ours (audiostream.c:1803-1809 without dtmfgen_rtp: a
+	// telephone-event payload is negotiated, :1396-1404): the chunks are encoded in the batch
+	MSFilter *omix = nullptr, *encf = vol->outputs[0]->next.filter;
+	static const bool no_enc = getenv("MSMI355X_NO_FUSE_ENCODER") != nullptr; // A/B switch
+	if (is_forwarding_mixer(encf, head->ticker) && ms_queue_empty(encf->outputs[0])) omix = encf, encf = encf->outputs[0]->next.filter;
+	if (!no_enc && rate == 8000 && encf && is_g711_enc(encf->desc) && encf->ticker == head->ticker && encf->inputs[0] && ms_queue_empty(encf->inputs[0])) {
+		MapFilter *ed = (MapFilter *)encf->data;
+		if (ed->sleg || ed->fleg || ms_bufferizer_get_avail(ed->bz) || (ed->pool && (!ed->pool->staged[(size_t)ed->slot].empty() || !ed->pool->ready[(size_t)ed->slot].empty()))) encf = nullptr;
+	} else encf = nullptr;
+	if (!encf) omix = nullptr;
+	const int law = encf ? (((MapFilter *)encf->data)->law ? MI_LAW_PCMU : MI_LAW_PCMA) : -1;
 	LegBank *b = bank<LegBank>("legp:" + std::to_string(ir) + ":" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen) + ":" +
-	                               std::to_string(delay) + (no_agc ? ":light" : "") + (eqf ? ":eq" : ""),
-	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true, no_agc, eqf != nullptr); }); // 64, 256, 1024, .. legs
+	                               std::to_string(delay) + (no_agc ? ":light" : "") + (eqf ? ":eq" : "") + (encf ? ":enc" + std::to_string(law) : ""),
+	                           1, [&](int cap) { return new LegBank(cap * 4, ir, rate, F, flen, delay, 1, true, no_agc, eqf != nullptr, law); }); // 64, 256, 1024, .. legs
 	const int s = b ? b->acquire(vol) : -1;
 	if (s < 0) return false;
 	note_slot(vol);
@@ -2023,9 +2073,15 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (!b->give_remainder(s, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
 	if (peer && !leg_take_peer(b, leg, peer)) mi_failed("taking the echo limiter's peer into the batch");
 	if (eqf && !leg_take_equalizer(b, leg, eqf)) mi_failed("taking the leg's equalizer into the batch");
+	if (encf) {
+		MapFilter *ed = (MapFilter *)encf->data;
+		map_release(ed); // (its own bank's slot, if it ever had one)
+		ed->fleg = leg;
+		leg->enc = encf, leg->omix = omix;
+	}
 	b->staged_since = true;
-	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (%sMSSpeexEC -> MSVolume as one device-resident batch)", (void *)vol, ir, rate, F, flen,
-	           rs ? "MSResample -> " : "");
+	ms_message("mi355x: call leg %p fused: %u -> %u Hz, frame %d, tail %d (%sMSSpeexEC -> MSVolume%s as one device-resident batch)", (void *)vol, ir, rate, F, flen,
+	           rs ? "MSResample -> " : "", encf ? (law == MI_LAW_PCMU ? " -> MSUlawEnc" : " -> MSAlawEnc") : "");
 	return true;
 }
 
@@ -2045,6 +2101,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
 	((SpeexECState *)leg->ec->data)->leg = nullptr;
 	((VolumeData *)leg->vol->data)->leg = nullptr;
+	if (leg->enc) ((MapFilter *)leg->enc->data)->fleg = nullptr; // (the packet it is filling stays with the facade: MapFilter::pending)
 	if (keep_running) {
 		const bool started = ((SpeexECState *)leg->ec->data)->echostarted != FALSE;
 		ec_prepare(leg->ec); // a bank slot of its own again, while the hub is still held by this leg's slot

@@ -119,7 +119,11 @@ struct MixerState { // audiomixer.c:132-143
 	// Blocks forwarded in bypass mode leave one tick later, like mixed ones (which come out of the next tick's flush): the
 	// filter's latency does not jump by 10 ms when a second contributor appears or the last but one falls silent -- a
 	// canceller behind two mixers would otherwise see its two inputs slip against each other (aec3_tester.c graph).
+	// A mixer with ONE linked input never leaves bypass mode (audiomixer.c:244-286: one contributor or none) -- an AudioStream's
+	// outbound_mixer without a remote player, its local_mixer without a local one (audiostream.c:1585-1588,1770-1772,1807,1815):
+	// nothing to jump between, so its blocks go on IN the walk, as the reference's do (one_input).
 	std::vector<std::pair<int, mblk_t *>> *held;
+	bool one_input;
 	// the conference and every leg that feeds it as one device-resident batch (filters/leg_chain.inl)
 	LegBank *fbank;     // non-null: fused; the conference is slot `fconf` of that bank
 	int fconf;
@@ -221,6 +225,9 @@ void mixer_prepare(MSFilter *f, bool running) { // (hub locked by the caller)
 	s->first_walk = true; // (running: this walk's tick was the batch's)
 	if (!running) s->bypass_mode = FALSE;
 	s->single_output = has_single_output(f, s);
+	int linked = 0;
+	for (int i = 0; i < f->desc->ninputs; ++i) linked += f->inputs[i] != NULL;
+	s->one_input = linked == 1;
 	const int ns = s->bytespertick / 2;
 	s->pool = bank<MixerPool>("mixer:" + std::to_string(ns), 1, [&](int cap) { return new MixerPool(cap, ns); });
 	s->slot = s->pool ? s->pool->acquire(f) : -1;
@@ -282,10 +289,16 @@ void mixer_forward(MSFilter *f, MixerState *s, int from_pin) {
 		if (!dst || !s->channels[pin].output_enabled) continue;
 		if (s->conf_mode != 0 && pin == from_pin) continue;
 		if (s->single_output) {
-			for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) s->held->push_back({pin, m});
+			for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) {
+				if (s->one_input) ms_queue_put(dst, m);
+				else s->held->push_back({pin, m});
+			}
 			break;
 		}
-		for (mblk_t *m = peekq(&src->q); m != NULL && m != &src->q._q_stopper; m = m->b_next) s->held->push_back({pin, dupmsg(m)});
+		for (mblk_t *m = peekq(&src->q); m != NULL && m != &src->q._q_stopper; m = m->b_next) {
+			if (s->one_input) ms_queue_put(dst, dupmsg(m));
+			else s->held->push_back({pin, dupmsg(m)});
+		}
 	}
 	ms_queue_flush(src);
 }

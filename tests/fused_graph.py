@@ -21,6 +21,7 @@ HOST = os.path.join(ROOT, "tests", "host")
 MS_SPEEX_EC_ID, MS_RESAMPLE_ID, MS_VOLUME_ID, MS_AUDIO_MIXER_ID = 28, 41, 43, 68
 MS_EQUALIZER_ID = 61
 MS_ULAW_ENC_ID, MS_ULAW_DEC_ID, MS_GENERIC_PLC_ID = 7, 8, 111
+MS_ALAW_ENC_ID, MS_ALAW_DEC_ID, MS_AUDIO_FLOW_CONTROL_ID = 9, 10, 141
 MS_FILTER_BASE_ID = 2
 EC_IFACE = 16384 + 4
 
@@ -75,6 +76,7 @@ class Host:
         S.ms2shim_new_pass.argtypes = [vp]
         S.ms2shim_equalizer_set_gain.argtypes = [vp, C.c_float, C.c_float, C.c_float]
         S.ms2shim_equalizer_set_active.argtypes = [vp, C.c_int]
+        S.ms2shim_flow_control_drop.argtypes = [vp, C.c_uint, C.c_uint]
         S.ms2shim_sink_read.restype = C.c_size_t
         S.ms2shim_sink_read.argtypes = [vp, vp, C.c_size_t]
         S.ms2shim_sink_size.restype = C.c_size_t
@@ -93,6 +95,9 @@ class Host:
         assert S.ms_factory_load_plugin(self.fac, plugin.encode()) == 0
         self.P = C.CDLL(plugin)
         self.P.ms_mi355x_late_events.restype = C.c_ulonglong
+
+    def recv_streams(self):
+        return int(self.P.ms_mi355x_recv_stats())
 
     def fused_stats(self):
         c, l = C.c_int(), C.c_int()
@@ -138,7 +143,8 @@ class Conferences:
     """nconf conferences of `members` legs each on one ticker"""
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
-                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False, spk_equalizer=False):
+                 endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False, spk_equalizer=False,
+                 flowcontrol=False, dtmfgen_rtp=True, encoder=True, local_mixer=0, outbound_mixer=False, alaw=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -189,11 +195,27 @@ class Conferences:
                     if cpu_filters:   # dtmfgen in front of volrecv, recv_tee behind it (audiostream.c:1826-1827): the application's own filters
                         leg["dtmfgen"], leg["recv_tee"] = S.ms2shim_new_pass(h.fac), S.ms2shim_new_pass(h.fac)
                         head = leg["far"]
-                        if g711:   # rtprecv's packets -> MSUlawDec -> MSGenericPLC (audiostream.c:1813-1824), facades of the plugin
-                            leg["dec"], leg["plc"] = S.ms_factory_create_filter(h.fac, MS_ULAW_DEC_ID), S.ms_factory_create_filter(h.fac, MS_GENERIC_PLC_ID)
+                        if g711:   # rtprecv's packets -> MSUlawDec -> [local_mixer] -> MSGenericPLC -> [MSAudioFlowControl] (audiostream.c:1813-1824), facades of the plugin
+                            leg["dec"], leg["plc"] = S.ms_factory_create_filter(h.fac, MS_ALAW_DEC_ID if alaw else MS_ULAW_DEC_ID), S.ms_factory_create_filter(h.fac, MS_GENERIC_PLC_ID)
                             h.call_int(leg["plc"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
-                            links += [(leg["far"], 0, leg["dec"], 0), (leg["dec"], 0, leg["plc"], 0)]
+                            up = leg["dec"]
+                            links += [(leg["far"], 0, leg["dec"], 0)]
+                            if local_mixer:   # AUDIO_STREAM_FEATURE_LOCAL_PLAYING (audiostream.c:1770-1772,1815): not a conference; 2 = its local player is linked too (and idle)
+                                leg["local_mixer"] = S.ms_factory_create_filter(h.fac, MS_AUDIO_MIXER_ID)
+                                h.call_int(leg["local_mixer"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                                links += [(up, 0, leg["local_mixer"], 0)]
+                                if local_mixer == 2:
+                                    leg["local_player"] = S.ms2shim_new_source(h.fac)
+                                    links += [(leg["local_player"], 0, leg["local_mixer"], 1)]
+                                up = leg["local_mixer"]
+                            links += [(up, 0, leg["plc"], 0)]
                             head = leg["plc"]
+                            if flowcontrol:   # AUDIO_STREAM_FEATURE_FLOW_CONTROL (audiostream.c:1754-1766,1824)
+                                leg["fc"] = S.ms_factory_create_filter(h.fac, MS_AUDIO_FLOW_CONTROL_ID)
+                                h.call_int(leg["fc"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                                h.call_int(leg["fc"], base("MS_FILTER_SET_NCHANNELS"), 1)
+                                links += [(leg["plc"], 0, leg["fc"], 0)]
+                                head = leg["fc"]
                         links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0),
                                   (leg["recv_tee"], 0, leg["ec"], 0)]
                     elif spk_equalizer:   # audiostream.c:1828: an MSEqualizer of ours right in front of the canceller's far end -- it delivers with the flush
@@ -214,13 +236,22 @@ class Conferences:
                         h.call_int(f, base("MS_FILTER_SET_OUTPUT_SAMPLE_RATE"), rate)
                     links += [(leg["vol"], 0, leg["in_rs"], 0), (leg["in_rs"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out_rs"], 0), (leg["out_rs"], 0, leg["out"], 0)]
                 else:
-                    if not mixer and cpu_filters:   # volsend -> dtmfgen_rtp -> (encoder, rtpsend: the sink)
-                        leg["dtmfgen_rtp"] = S.ms2shim_new_pass(h.fac)
-                        if g711:   # .. -> MSUlawEnc (its default 20 ms packets) -> rtpsend
-                            leg["enc"] = S.ms_factory_create_filter(h.fac, MS_ULAW_ENC_ID)
-                            links += [(leg["vol"], 0, leg["dtmfgen_rtp"], 0), (leg["dtmfgen_rtp"], 0, leg["enc"], 0), (leg["enc"], 0, leg["out"], 0)]
+                    if not mixer and cpu_filters:   # volsend -> [dtmfgen_rtp] -> [outbound_mixer] -> (encoder, rtpsend: the sink)
+                        up = leg["vol"]
+                        if dtmfgen_rtp:   # (only where no telephone-event payload is negotiated, audiostream.c:1396-1404)
+                            leg["dtmfgen_rtp"] = S.ms2shim_new_pass(h.fac)
+                            links += [(up, 0, leg["dtmfgen_rtp"], 0)]
+                            up = leg["dtmfgen_rtp"]
+                        if outbound_mixer:   # AUDIO_STREAM_FEATURE_REMOTE_PLAYING (audiostream.c:1585-1588,1807): one linked input unless a remote player is open
+                            leg["outbound_mixer"] = S.ms_factory_create_filter(h.fac, MS_AUDIO_MIXER_ID)
+                            h.call_int(leg["outbound_mixer"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                            links += [(up, 0, leg["outbound_mixer"], 0)]
+                            up = leg["outbound_mixer"]
+                        if g711 and encoder:   # .. -> MSUlawEnc (its default 20 ms packets) -> rtpsend
+                            leg["enc"] = S.ms_factory_create_filter(h.fac, MS_ALAW_ENC_ID if alaw else MS_ULAW_ENC_ID)
+                            links += [(up, 0, leg["enc"], 0), (leg["enc"], 0, leg["out"], 0)]
                         else:
-                            links += [(leg["vol"], 0, leg["dtmfgen_rtp"], 0), (leg["dtmfgen_rtp"], 0, leg["out"], 0)]
+                            links += [(up, 0, leg["out"], 0)]
                     else:
                         links += [(leg["vol"], 0, mx, leg["pin"]), (mx, leg["pin"], leg["out"], 0)] if mixer else [(leg["vol"], 0, leg["out"], 0)]
                 for a, pa, b, pb in links:
@@ -249,7 +280,8 @@ class Conferences:
         if self.attached:
             self.detach()
         for leg in self.legs:
-            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp", "dec", "plc", "enc", "spk_eq"):
+            for k in ("mic", "far", "spk", "out", "rs", "ec", "vol", "in_rs", "out_rs", "volrecv", "eq", "dtmfgen", "recv_tee", "dtmfgen_rtp", "dec", "plc", "enc", "spk_eq",
+                      "fc", "local_mixer", "local_player", "outbound_mixer"):
                 if k in leg:
                     self.S.ms_filter_destroy(leg[k])
         for mx in self.mixers:
@@ -287,7 +319,9 @@ def run(plugin_dir, fuse, scenario, h=None):
     sc.update(scenario)
     conf = Conferences(h, sc["nconf"], sc["members"], sc["in_rate"], sc["rate"], sc["tail_ms"], sc["delay_ms"], pins=sc["pins"],
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
-                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")), spk_equalizer=bool(sc.get("spk_equalizer")))
+                       endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")), spk_equalizer=bool(sc.get("spk_equalizer")),
+                       flowcontrol=bool(sc.get("flowcontrol")), dtmfgen_rtp=sc.get("dtmfgen_rtp", True), encoder=sc.get("encoder", True), local_mixer=int(sc.get("local_mixer", 0)),
+                       outbound_mixer=bool(sc.get("outbound_mixer")), alaw=bool(sc.get("alaw")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -297,7 +331,7 @@ def run(plugin_dir, fuse, scenario, h=None):
             sys.path.insert(0, ROOT)
         import oracle
         oracle.build()
-        far_codes = [np.ascontiguousarray(oracle.g711_encode(1, far[s])) for s in range(n)]
+        far_codes = [np.ascontiguousarray(oracle.g711_encode(0 if sc.get("alaw") else 1, far[s])) for s in range(n)]
     late0 = h.P.ms_mi355x_late_events()
     before = h.runtime_stats()   # (other graphs of the same process may be alive: what this run leaves behind is the difference)
     conf.attach()
@@ -313,10 +347,12 @@ def run(plugin_dir, fuse, scenario, h=None):
             else:
                 h.push(leg["mic"], mic[s, t * ni:(t + 1) * ni])
             # far end: regular, or with a late packet every 17th tick per leg (nothing, then two blocks at once)
-            if sc.get("g711"):   # PCMU packets of 10 ms, one in 19 lost (the PLC conceals it)
-                if (t + 2 * s) % 19 != 7:
+            if sc.get("g711"):   # G.711 packets of 10 ms, one in 19 lost (the PLC conceals it) unless the scenario says "lossless"
+                if sc.get("lossless") or (t + 2 * s) % 19 != 7:
                     pk = far_codes[s][t * ns:(t + 1) * ns]
                     h.S.ms2shim_source_push(leg["far"], pk.ctypes.data, pk.nbytes)
+                if "local_player" in leg:
+                    h.push(leg["local_player"], np.zeros(0, np.int16))   # (an idle player: nothing)
             elif sc.get("far_gaps") and (t + 3 * s) % 17 == 5:
                 h.push(leg["far"], np.zeros(0, np.int16))
             elif sc.get("far_gaps") and (t + 3 * s) % 17 == 6:
@@ -341,12 +377,15 @@ def run(plugin_dir, fuse, scenario, h=None):
                     h.call_int(leg["vol"], VOL_ENABLE_AGC, val)
                 elif kind == "in_rs_rate":   # the endpoint's in_resampler is told to resample after all
                     h.call_int(leg["in_rs"], IDS["MS_FILTER_SET_SAMPLE_RATE"], val)
+                elif kind == "flow_drop":   # MS_AUDIO_FLOW_CONTROL_DROP: val ms out of the next second (what the canceller's / the card's drop event asks for)
+                    assert h.S.ms2shim_flow_control_drop(leg["fc"], 1000, int(val)) == 0
                 elif kind == "reattach":
                     conf.detach()
                     conf.attach()
         conf.step()
         if t == nt // 2:
             mid_stats = h.fused_stats()
+            mid_stats["recv_streams"] = h.recv_streams()
     levels = [h.get_float(leg["vol"], VOL_GET_LINEAR) for leg in conf.legs]
     if sc.get("echo_limiter") or sc.get("volrecv"):
         levels += [h.get_float(leg["volrecv"], VOL_GET_LINEAR) for leg in conf.legs]
@@ -404,6 +443,24 @@ SCENARIOS = {
     # ... and a narrow-band G.711 call end to end: packets in through MSUlawDec -> MSGenericPLC (one in 19 lost), the card at 8 kHz, packets out of MSUlawEnc
     "audiostream_8k_g711": {"volrecv": True, "cpu_filters": True, "g711": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000,
                             "nconf": 1, "members": 6, "nticks": 120, "events": [(61, "reattach", 0, 0)], "tail_blocks": 2},
+    # ... the same call without losses: both forms add the same tick in either direction -- packets and speaker frames bit for bit
+    # (with a loss the fused receiving side conceals in the tick the packet is missing in, as the reference does; the facades one by one a tick later)
+    "audiostream_8k_g711_lossless": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000,
+                                     "nconf": 1, "members": 6, "nticks": 120, "events": [(61, "reattach", 0, 0)], "tail_blocks": 2},
+    # ... with MSAudioFlowControl behind the PLC (AUDIO_STREAM_FEATURE_FLOW_CONTROL) and a drop request in mid-call, A-law, and no dtmfgen_rtp
+    # (a telephone-event payload is negotiated, audiostream.c:1396-1404): volsend's frames are ENCODED in the leg's batch
+    "audiostream_8k_pcma_flowcontrol_encoder_in_the_leg": {"volrecv": True, "cpu_filters": True, "g711": True, "alaw": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False,
+                                                           "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000, "nconf": 1, "members": 5, "nticks": 130,
+                                                           "events": [(40, "flow_drop", 1, 20), (41, "flow_drop", 3, 35), (81, "reattach", 0, 0)], "tail_blocks": 2},
+    # ... and the reference's DEFAULT features (AUDIO_STREAM_FEATURE_ALL, audiostream.c:1585-1588,1770-1772,1807,1815): an outbound_mixer in front of
+    # the encoder and a local_mixer behind the decoder, each with one linked input (no player open): they can only forward, in the walk
+    "audiostream_8k_default_features": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 1, "outbound_mixer": True,
+                                        "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000, "nconf": 1, "members": 5, "nticks": 120,
+                                        "events": [(61, "reattach", 0, 0)], "tail_blocks": 2},
+    # ... with the local player linked (and idle): the local_mixer has two inputs, mixes for the first second and forwards afterwards (audiomixer.c:244-286)
+    "audiostream_8k_default_features_local_player_linked": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 2,
+                                                            "outbound_mixer": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000, "nconf": 1,
+                                                            "members": 4, "nticks": 150, "tail_blocks": 2},
     "spk_equalizer_keeps_the_leg_on_its_facades": {"volrecv": True, "spk_equalizer": True, "nticks": 60, "expect_unfused": True},
     "volrecv_with_a_gain_from_the_start": {"volrecv": True, "nticks": 60, "events": [(0, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's

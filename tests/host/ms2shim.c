@@ -831,6 +831,12 @@ int ms2shim_equalizer_set_active(MSFilter *eq, int active) {
 }
 /* MS_VOLUME_SET_PEER's id carries sizeof(MSFilter): spelled here, where the header is */
 int ms2shim_volume_set_peer(MSFilter *vol, MSFilter *peer) { return ms_filter_call_method(vol, MS_VOLUME_SET_PEER, peer); }
+/* MS_AUDIO_FLOW_CONTROL_DROP takes a struct (what MSSpeexEC's and the sound card's drop events end up as, audiostream.c:1757-1763) */
+int ms2shim_flow_control_drop(MSFilter *fc, unsigned interval_ms, unsigned drop_ms) {
+	MSAudioFlowControlDropEvent ev;
+	ev.flow_control_interval_ms = interval_ms, ev.drop_ms = drop_ms;
+	return ms_filter_call_method(fc, MS_AUDIO_FLOW_CONTROL_DROP, &ev);
+}
 void ms2shim_source_set_burst(MSFilter *src, int burst) { ((SrcData *)src->data)->burst = burst; }
 /* the ring stays the caller's; phase = the block the source starts with */
 void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase) {
