@@ -151,6 +151,10 @@ struct SpeexECState { // speexec.c:49-72
 	EcPool *pool;
 	int slot;
 	FusedLeg *leg; // the filter is part of a fused call leg (filters/leg_chain.inl): its canceller and queues live in that bank
+	// preprocess sizes the canceller (speexec.c:188-216) but opens no bank slot: a filter that joins a fused leg at the attach never
+	// needs one of its own (a bank opened for it alone would be destroyed again with its pinned and device memory, per leg) -- process()
+	// takes the slot at the first block of a filter that did not fuse (ec_acquire)
+	bool configured, acquire_failed;
 	bool fuse_checked; // as the HEAD of a leg (no MSResample of ours in front): looked for a chain to fuse with since the last attach
 };
 
@@ -252,20 +256,31 @@ void ec_prepare(MSFilter *f) { // (hub locked by the caller)
 	const int delay_samples = s->delay_ms * s->samplerate / 1000;
 	ms_message("Initializing mi355x echo canceler with framesize=%i, filterlength=%i, delay_samples=%i", s->framesize,
 	           s->filterlength, delay_samples);
-	{
-		const int rate = s->samplerate, F = s->framesize, flen = s->filterlength;
-		s->pool = bank<EcPool>("ec:" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen), 1,
-		                       [&](int cap) { return new EcPool(cap, rate, F, flen); });
-	}
-	s->slot = s->pool ? s->pool->acquire(f) : -1;
-	if (s->slot < 0) s->pool = nullptr; // no canceller to be had: process() forwards both pins, like bypass mode
-	else note_slot(f);
 	ms_bufferizer_flush(&s->delayed_ref);
 	mblk_t *m = allocb((size_t)delay_samples * 2, 0); // zeroes for the time of the delay
 	memset(m->b_wptr, 0, (size_t)delay_samples * 2);
 	m->b_wptr += delay_samples * 2;
 	ms_bufferizer_put(&s->delayed_ref, m);
 	s->nominal_ref_samples = delay_samples;
+	s->configured = true;
+	s->acquire_failed = false;
+}
+// a bank slot of its own for a canceller that did not join a fused leg (hub locked by the caller)
+void ec_acquire(MSFilter *f) {
+	SpeexECState *s = (SpeexECState *)f->data;
+	if (s->pool || !s->configured || s->unsupported) return;
+	{
+		const int rate = s->samplerate, F = s->framesize, flen = s->filterlength;
+		s->pool = bank<EcPool>("ec:" + std::to_string(rate) + ":" + std::to_string(F) + ":" + std::to_string(flen), 1,
+		                       [&](int cap) { return new EcPool(cap, rate, F, flen); });
+	}
+	s->slot = s->pool ? s->pool->acquire(f) : -1;
+	if (s->slot < 0) {
+		s->pool = nullptr; // no canceller to be had: process() forwards both pins, like bypass mode
+		s->acquire_failed = true;
+		return;
+	}
+	note_slot(f);
 	ec_apply_config(s); // :209-211
 }
 mi_aec *leg_canceller(FusedLeg *leg, int *slot); // leg_chain.inl
@@ -303,6 +318,7 @@ void ec_postprocess(MSFilter *f) { // speexec.c:307-321: state destroyed at deta
 	ms_bufferizer_flush(&s->delayed_ref);
 	ms_bufferizer_flush(&s->echo);
 	ms_bufferizer_flush(&s->ref.base);
+	s->configured = false;
 	if (s->pool) {
 		EcPool *p = s->pool;
 		p->staged[(size_t)s->slot] = p->ready[(size_t)s->slot] = 0;
@@ -362,7 +378,7 @@ void ec_emit_speaker_frame(MSFilter *f, SpeexECState *s, size_t nbytes) {
 // (3) every complete microphone frame is staged with its reference frame; the batch cancels them at the next flush
 void ec_process(MSFilter *f) {
 	SpeexECState *s = (SpeexECState *)f->data;
-	if (!s->leg && !s->fuse_checked && s->pool && f->ticker && !__atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED) && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
+	if (!s->leg && !s->fuse_checked && s->configured && f->ticker && !__atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED) && !s->unsupported && f->inputs[1] && !ms_queue_empty(f->inputs[1])) {
 		// the first microphone block since the attach, and no MSResample of ours in front (behind one, the resampler is the leg's
 		// head and has looked already): is this the head of  MSSpeexEC -> MSVolume (AGC) -> [conference mixer | anything else] ?
 		s->fuse_checked = true;
@@ -372,6 +388,10 @@ void ec_process(MSFilter *f) {
 			if (MSFilter *mx = leg_find_mixer_ec(f)) conf_try_fuse(mx);
 			else leg_try_fuse_plain_ec(f);
 		}
+	}
+	if (!s->leg && !s->pool && s->configured && !s->unsupported && !s->acquire_failed && !__atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED)) {
+		HubLock lk(f);
+		if (!s->leg) ec_acquire(f); // (not part of a fused leg: a bank slot of its own from here on)
 	}
 	if (s->leg && leg_wants_out(s->leg)) leg_release(s->leg, true); // (whichever facade of the leg is walked first -- the MSResample in front, when it has a block in this walk)
 	if (s->leg) { // fused leg: the microphone is staged (by the leg's MSResample, or here) for the device, the far end for the leg's delay line

@@ -1520,7 +1520,7 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	MSFilter *ec = qe ? qe->prev.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || qe->prev.pin != 1 || ec->ticker != mx->ticker || !ms_queue_empty(qe)) return false;
 	SpeexECState *es = (SpeexECState *)ec->data;
-	if (es->bypass_mode || es->unsupported || !es->pool || es->samplerate != ms->rate || es->echostarted || es->leg) return false;
+	if (es->bypass_mode || es->unsupported || !es->configured || es->samplerate != ms->rate || es->echostarted || es->leg) return false;
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
@@ -1733,7 +1733,7 @@ bool conf_try_fuse(MSFilter *mx) {
 bool conf_try_fuse_sending(MSFilter *mx) {
 	MixerState *ms = (MixerState *)mx->data;
 	const bool off = getenv("MSMI355X_NO_FUSE") != nullptr; // (read per attach: an A/B switch, and what the tests compare against)
-	if (off || !ms->pool || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 100) return false;
+	if (off || !ms->prepared || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 100) return false;
 	std::vector<LegCand> cand;
 	int maxpin = -1;
 	for (int pin = 0; pin < mx->desc->ninputs; ++pin) {
@@ -1827,9 +1827,11 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 			rd->leg = leg;
 		}
 		ms_bufferizer_flush(&es->delayed_ref); // the delay line lives on the device now
-		es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
-		es->pool->release(es->slot); // (the last release of a bank destroys it)
-		es->pool = nullptr, es->slot = -1;
+		if (es->pool) { // (a filter that had run on its facade before: normally preprocess opens no slot, ec_acquire)
+			es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
+			es->pool->release(es->slot); // (the last release of a bank destroys it)
+			es->pool = nullptr, es->slot = -1;
+		}
 		es->leg = leg;
 		if (vd->pool) {
 			vd->pool->release(vd->slot);
@@ -1840,9 +1842,11 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		if (cd.peer && !leg_take_peer(b, leg, cd.peer)) mi_failed("taking the echo limiter's peer into the batch");
 		if (cd.eq && !leg_take_equalizer(b, leg, cd.eq)) mi_failed("taking the leg's equalizer into the batch");
 	}
-	ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
-	ms->pool->release(ms->slot);
-	ms->pool = nullptr, ms->slot = -1;
+	if (ms->pool) { // (a conference that had mixed on its facade before: normally preprocess opens no slot, mixer_acquire)
+		ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
+		ms->pool->release(ms->slot);
+		ms->pool = nullptr, ms->slot = -1;
+	}
 	ms->fbank = b, ms->fconf = c;
 	b->conf_time[(size_t)c] = (uint64_t)-1;
 	b->staged_since = true;
@@ -1881,7 +1885,8 @@ MSFilter *leg_find_mixer_ec(MSFilter *ec) {
 	return (mx && mx->desc == &ms_mi355x_audio_mixer_desc && ((MixerState *)mx->data)->conf_mode != 0) ? mx : NULL;
 }
 
-void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess (a bank slot of its own)
+void ec_prepare(MSFilter *f);    // echo_canceller.inl: the body of ec_preprocess
+void ec_acquire(MSFilter *f);    // ... and a bank slot of its own
 void mixer_prepare(MSFilter *f, bool running); // mixer.inl
 
 // MSVolume's running state goes with the filter, not with the bank slot (volume.inl: VolumeData::kept)
@@ -1962,6 +1967,7 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 		for (FusedLeg *leg : gone) {
 			const bool started = ((SpeexECState *)leg->ec->data)->echostarted != FALSE;
 			ec_prepare(leg->ec);
+			ec_acquire(leg->ec);
 			leg_return_canceller(b, leg, started);
 		}
 		mixer_prepare(mx, true);
@@ -1991,7 +1997,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (getenv("MSMI355X_NO_FUSE") != nullptr || !head->ticker || head->ticker->interval != 10 || ec->ticker != head->ticker) return false;
 	ResampleData *rd = rs ? (ResampleData *)rs->data : nullptr;
 	SpeexECState *es = (SpeexECState *)ec->data;
-	if (es->bypass_mode || es->unsupported || !es->pool || es->echostarted || es->leg || (rd && (uint32_t)es->samplerate != rd->output_rate) || es->samplerate % 100) return false;
+	if (es->bypass_mode || es->unsupported || !es->configured || es->echostarted || es->leg || (rd && (uint32_t)es->samplerate != rd->output_rate) || es->samplerate % 100) return false;
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	MSQueue *qv = ec->outputs[1];
 	MSFilter *vol = qv ? qv->next.filter : NULL;
@@ -2061,9 +2067,11 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 		rd->leg = leg;
 	}
 	ms_bufferizer_flush(&es->delayed_ref);
-	es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
-	es->pool->release(es->slot);
-	es->pool = nullptr, es->slot = -1;
+	if (es->pool) {
+		es->pool->staged[(size_t)es->slot] = es->pool->ready[(size_t)es->slot] = 0;
+		es->pool->release(es->slot);
+		es->pool = nullptr, es->slot = -1;
+	}
 	es->leg = leg;
 	if (vd->pool) {
 		vd->pool->release(vd->slot);
@@ -2105,6 +2113,7 @@ void leg_unfuse_plain(FusedLeg *leg, bool keep_running) {
 	if (keep_running) {
 		const bool started = ((SpeexECState *)leg->ec->data)->echostarted != FALSE;
 		ec_prepare(leg->ec); // a bank slot of its own again, while the hub is still held by this leg's slot
+		ec_acquire(leg->ec);
 		leg_return_canceller(b, leg, started);
 		ms_warning("mi355x: call leg %p left its fused batch (a member's configuration changed); the facades carry on one by one", (void *)leg->vol);
 	}

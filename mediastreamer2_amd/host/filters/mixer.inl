@@ -132,6 +132,7 @@ struct MixerState { // audiomixer.c:132-143
 	int fuse_state;     // 0 not looked at since the attach, 1 fused, 2 refused
 	std::atomic<bool> unfuse_wanted; // a member stopped qualifying (set by a method on any thread, honoured by the next process())
 	bool first_walk;    // the walk right after an attach is still to come (see mixer_process)
+	bool prepared, acquire_failed; // preprocess has sized the tick; a bank slot could not be had
 };
 void leg_push_mixer_controls(MSFilter *f, MixerState *s, bool from_method); // leg_chain.inl
 void server_push_mixer_controls(MSFilter *f, MixerState *s, bool from_method); // server_leg.inl
@@ -207,6 +208,7 @@ void mixer_push_controls(MSFilter *f, MixerState *s, bool from_method = false) {
 	}
 }
 void mixer_prepare(MSFilter *f, bool running = false);
+void mixer_acquire(MSFilter *f);
 void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
 	HubLock lk(f);
 	((MixerState *)f->data)->fuse_state = 0;
@@ -228,10 +230,19 @@ void mixer_prepare(MSFilter *f, bool running) { // (hub locked by the caller)
 	int linked = 0;
 	for (int i = 0; i < f->desc->ninputs; ++i) linked += f->inputs[i] != NULL;
 	s->one_input = linked == 1;
+	s->prepared = true;
+	s->acquire_failed = false;
+	// (no bank slot yet: a conference that fuses at the attach never needs one of its own, a mixer that can only forward never mixes --
+	// mixer_acquire at the first tick that has something to mix; `running`: the conference just left its batch and mixes from this walk on)
+	if (running) mixer_acquire(f);
+}
+void mixer_acquire(MSFilter *f) { // (hub locked by the caller)
+	MixerState *s = (MixerState *)f->data;
+	if (s->pool || !s->prepared || s->acquire_failed) return;
 	const int ns = s->bytespertick / 2;
 	s->pool = bank<MixerPool>("mixer:" + std::to_string(ns), 1, [&](int cap) { return new MixerPool(cap, ns); });
 	s->slot = s->pool ? s->pool->acquire(f) : -1;
-	if (s->slot < 0) s->pool = nullptr;
+	if (s->slot < 0) s->pool = nullptr, s->acquire_failed = true;
 	else note_slot(f);
 	mixer_push_controls(f, s);
 }
@@ -241,6 +252,7 @@ void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot 
 	conf_unfuse(f, false);
 	HubLock lk(f);
 	mixer_release_held(f, s, false);
+	s->prepared = false;
 	if (s->pool) {
 		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
 		s->pool->release(s->slot); // the last release of a bank destroys it
@@ -425,11 +437,16 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	}
 	s->first_walk = false;
 	mixer_release_held(f, s, true); // what bypass mode forwarded on the previous tick
-	if (!s->pool) {
+	if (!s->prepared || s->acquire_failed) {
 		ms_filter_unlock(f);
 		return;
 	}
 	if (mixer_check_bypass(f, s)) {
+		ms_filter_unlock(f);
+		return;
+	}
+	mixer_acquire(f); // two or more contributors: a bank slot of its own from here on
+	if (!s->pool) {
 		ms_filter_unlock(f);
 		return;
 	}

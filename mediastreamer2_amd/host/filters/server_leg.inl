@@ -840,7 +840,7 @@ bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out,
 bool server_try_fuse(MSFilter *mx) {
 	MixerState *ms = (MixerState *)mx->data;
 	if (getenv("MSMI355X_NO_FUSE") != nullptr || getenv("MSMI355X_NO_FUSE_SERVER") != nullptr) return false;
-	if (!ms->pool || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 800) return false;
+	if (!ms->prepared || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 800) return false;
 	std::vector<std::pair<int, MSFilter *>> cand;
 	std::vector<MSFilter *> heads; // per candidate: the decoder that heads the leg, or NULL (MSVolume does)
 	std::vector<MSFilter *> irss;  // per candidate: its working in_resampler, or NULL
@@ -950,9 +950,11 @@ bool server_try_fuse(MSFilter *mx) {
 		}
 		vd->sleg = leg;
 	}
-	ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
-	ms->pool->release(ms->slot);
-	ms->pool = nullptr, ms->slot = -1;
+	if (ms->pool) {
+		ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
+		ms->pool->release(ms->slot);
+		ms->pool = nullptr, ms->slot = -1;
+	}
 	ms->sbank = b, ms->sconf = c;
 	b->conf_time[(size_t)c] = (uint64_t)-1;
 	b->staged_since = true;

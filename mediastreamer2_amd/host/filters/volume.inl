@@ -404,7 +404,11 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 			q = g->outputs[0];
 		}
 	}
-	volume_attach_slot(f);
+	// (no bank slot yet: a filter that joins a fused leg or conference at the attach never needs one of its own -- process() takes it
+	// at the first block of a filter that did not fuse; a slot held from before the detach is kept or re-homed there as well.  But an
+	// echo limiter's pair: the limiter addresses its peer by its slot in the SAME bank (volume_attach_slot), and two filters that take
+	// their slots one after the other at the attach land side by side)
+	if (volume_is_peered(d)) volume_attach_slot(f);
 }
 
 void volume_process(MSFilter *f) { // msvolume.c:471-514
