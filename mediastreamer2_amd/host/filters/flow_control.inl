@@ -13,6 +13,11 @@ struct FlowPool : Pool {
 	std::vector<int> req_round;                // ... and how many staged blocks of the stream precede each
 	std::vector<uint32_t> arm_drop, arm_total;
 	bool have_req = false;
+	// A method between two walks meets the NEXT walk's blocks in the reference (the filter's next process()).  Here the last walk's blocks
+	// may still be on their way to this bank (they arrive with the coming flush, Pool::work_waiting): a request made then waits in
+	// later_* and is armed when that flush is through (flushed()) -- in front of the blocks of the walk the call preceded
+	std::vector<uint32_t> later_drop, later_total;
+	bool have_later = false;
 	std::vector<int> staged, ready;
 	std::vector<std::vector<mblk_t *>> held, done; // the blocks themselves: the dropper edits them in place
 	explicit FlowPool(int cap) {
@@ -33,6 +38,8 @@ struct FlowPool : Pool {
 		req_round.assign(c, 0);
 		arm_drop.assign(c, 0);
 		arm_total.assign(c, 0);
+		later_drop.assign(c, 0);
+		later_total.assign(c, 0);
 		staged.assign(c, 0);
 		ready.assign(c, 0);
 		held.resize(c);
@@ -107,6 +114,24 @@ struct FlowPool : Pool {
 		}
 	}
 	bool scoped() const override { return true; }
+	void flushed() override {
+		if (!have_later) return;
+		bool left = false;
+		for (int s = 0; s < capacity; ++s) {
+			if (later_drop[(size_t)s] == 0 && later_total[(size_t)s] == 0) continue;
+			if (s < hi && parked(s)) {
+				left = true;
+				continue;
+			}
+			if (req_drop[(size_t)s] == 0 && req_total[(size_t)s] == 0) { // (ignored while one is pending, like :204)
+				req_drop[(size_t)s] = later_drop[(size_t)s], req_total[(size_t)s] = later_total[(size_t)s];
+				req_round[(size_t)s] = staged[(size_t)s];
+				have_req = true;
+			}
+			later_drop[(size_t)s] = later_total[(size_t)s] = 0;
+		}
+		have_later = left;
+	}
 	void emit(MSFilter *f, int slot) override {
 		const size_t c = (size_t)capacity, s = (size_t)slot;
 		for (int r = 0; r < ready[s]; ++r) {
@@ -148,6 +173,7 @@ void flowctl_release(FlowFilter *d) {
 	}
 	d->pool->staged[s] = d->pool->ready[s] = 0;
 	d->pool->req_drop[s] = d->pool->req_total[s] = 0;
+	d->pool->later_drop[s] = d->pool->later_total[s] = 0;
 	d->pool->release(d->slot);
 	d->pool = nullptr;
 	d->slot = -1;
@@ -241,7 +267,15 @@ int flowctl_drop(MSFilter *f, void *arg) { // :199-211; applied by the next laun
 	if (d->rleg)
 		recv_flow_drop(d->rleg, (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000,
 		               (ev->flow_control_interval_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000);
-	{
+	if (d->pool && f->ticker && d->pool->work_waiting()) { // the last walk's blocks are still on their way here: behind them (FlowPool::flushed)
+		FlowPool *p = d->pool;
+		const size_t s = (size_t)d->slot;
+		if (p->later_drop[s] == 0 && p->later_total[s] == 0 && p->req_drop[s] == 0 && p->req_total[s] == 0) {
+			p->later_drop[s] = (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;
+			p->later_total[s] = (ev->flow_control_interval_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;
+			p->have_later = true;
+		}
+	} else {
 		if (d->pool && d->pool->req_drop[(size_t)d->slot] == 0 && d->pool->req_total[(size_t)d->slot] == 0) {
 			d->pool->req_drop[(size_t)d->slot] = (ev->drop_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;
 			d->pool->req_total[(size_t)d->slot] = (ev->flow_control_interval_ms * (uint32_t)d->samplerate * (uint32_t)d->nchannels) / 1000;

@@ -325,6 +325,15 @@ struct LegBank : Pool {
 		bool also_target;
 	};
 	std::vector<GainPatch> vpatch; // MS_VOLUME_SET_GAIN & co. on a fused leg: the two fields, set on the state as the device holds it
+	// A leg that joins the bank costs NO device call when its slot has never been used: every batch object is created with every
+	// stream at its start state (mi_aec_create / mi_fifo_create / mi_resampler_create / mi_volume_create end in their own reset), so
+	// only a slot that HAD a leg is reset; MSVolume's parameters and start state go up with the next enqueue, neighbours in one call,
+	// and not at all where they are what the batch was created with; the delay line's zeroes (speexec.c:205-208) are pushed by the
+	// first enqueue as silence behind nothing (FusedLeg::inject).  A ticker's thousands of legs fuse at an attach: each of those calls
+	// waits for the stream, and took the attach into seconds.
+	std::vector<uint8_t> used;
+	mi_volume_params vparams0;
+	mi_volume_state vstate0;
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
 	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false, bool no_agc = false,
@@ -410,6 +419,10 @@ struct LegBank : Pool {
 		vs_dirty.assign(L, 0);
 		v_delay.assign(L, 0);
 		vpatch.assign(L, GainPatch{1.f, 1.f, false});
+		used.assign(L, 0);
+		vparams0 = p;
+		memset(&vstate0, 0, sizeof(vstate0));
+		if (!failed) MI_MUST(mi_volume_get_state(vol, 0, 1, &vstate0));
 		check_levels = getenv("MSMI355X_CHECK_LEVELS") != nullptr;
 		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
 		zero_copy = zero_copy_rows();
@@ -483,6 +496,25 @@ struct LegBank : Pool {
 		s->bytes = bytes;
 		slabs.push_back(s);
 		return s;
+	}
+
+	// legs [s0, s0 + count) are about to be taken: their per-slot objects at the start state (see `used`)
+	bool start_slots(int s0, int count) {
+		bool any = false;
+		for (int s = s0; s < s0 + count; ++s) any |= used[(size_t)s] != 0, used[(size_t)s] = 1;
+		if (!any) return true;
+		return (!rs || mi_resampler_reset(rs, s0, count) == MI_OK) && mi_aec_reset(aec, s0, count) == MI_OK && mi_fifo_reset_range(f_mic, s0, count) == MI_OK &&
+		       mi_fifo_reset_range(f_ref, s0, count) == MI_OK && mi_fifo_reset_range(f_out, s0, count) == MI_OK && mi_volume_reset_max(vol, s0, count) == MI_OK &&
+		       (!f_chan || mi_fifo_reset_range(f_chan, s0, count) == MI_OK);
+	}
+	// ... and leg s's MSVolume: parameters and running state for the slot, on the device with the next enqueue (or never: what the batch was created with)
+	void start_volume(size_t s, const mi_volume_params &p, const mi_volume_state &st, bool was_used) {
+		vparams[s] = p, vstate[s] = st;
+		vpatch[s] = GainPatch{st.gain, st.target_gain, true};
+		const bool same = !was_used && memcmp(&p, &vparams0, sizeof(p)) == 0 && memcmp(&st, &vstate0, sizeof(st)) == 0;
+		vp_dirty[s] = vs_dirty[s] = same ? 0 : 1;
+		v_delay[s] = 0;
+		v_dirty |= !same;
 	}
 
 	// ---- the canceller's framing for everything a leg staged since the last flush: the while loop of speexec.c:256-305
@@ -916,23 +948,35 @@ struct LegBank : Pool {
 		if (root) emitted();
 		// ---- pending control changes (methods called since the last flush)
 		// (the mixer's controls go up behind the conferences' ticks below: a lone contributor's are overridden, push_controls)
-		if (v_dirty) {
+		if (v_dirty) { // (runs of neighbouring legs go up in ONE call each: a ticker's legs fused at an attach are thousands of neighbours, a call waits for the stream)
 			bool held = false;
+			auto go = [&](size_t s, const std::vector<uint8_t> &dirty) { return dirty[s] == 1 && v_delay[s] <= 0; };
 			for (size_t s = 0; s < UL; ++s) {
-				if (v_delay[s] > 0 && (vp_dirty[s] == 1 || vs_dirty[s] == 1)) { // chunks from before the call are still to be taken: not yet
-					held = true;
-					continue;
-				}
-				if (vp_dirty[s] == 1) {
-					MI_MUST(mi_volume_set_params(vol, (int)s, 1, &vparams[s]));
-					vp_dirty[s] = 0;
-				}
-				if (vs_dirty[s] == 1) { // (vstate is what the device holds: read back with the last launch's results, nothing launched since)
+				if (v_delay[s] > 0 && (vp_dirty[s] == 1 || vs_dirty[s] == 1)) held = true; // chunks from before the call are still to be taken: not yet
+				if (go(s, vs_dirty)) { // (vstate is what the device holds: read back with the last launch's results, nothing launched since)
 					vstate[s].gain = vpatch[s].gain;
 					if (vpatch[s].also_target) vstate[s].target_gain = vpatch[s].target;
-					MI_MUST(mi_volume_set_state(vol, (int)s, 1, &vstate[s]));
-					vs_dirty[s] = 0;
 				}
+			}
+			for (size_t s = 0; s < UL;) {
+				if (!go(s, vp_dirty)) {
+					++s;
+					continue;
+				}
+				size_t e = s;
+				while (e < UL && go(e, vp_dirty)) vp_dirty[e++] = 0;
+				MI_MUST(mi_volume_set_params(vol, (int)s, (int)(e - s), &vparams[s]));
+				s = e;
+			}
+			for (size_t s = 0; s < UL;) {
+				if (!go(s, vs_dirty)) {
+					++s;
+					continue;
+				}
+				size_t e = s;
+				while (e < UL && go(e, vs_dirty)) vs_dirty[e++] = 0;
+				MI_MUST(mi_volume_set_state(vol, (int)s, (int)(e - s), &vstate[s]));
+				s = e;
 			}
 			v_dirty = held; // (entries at 2 wait for flushed(), which raises v_dirty again)
 		}
@@ -1777,30 +1821,26 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 	// ---- the legs: fresh per-leg state at their slots (what the filters' own banks hold at this point), then the facades let
 	// go of their own slots
 	const int s0 = c * mm;
-	bool ok = (!b->rs || mi_resampler_reset(b->rs, s0, mm) == MI_OK) && mi_aec_reset(b->aec, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_mic, s0, mm) == MI_OK &&
-	          mi_fifo_reset_range(b->f_ref, s0, mm) == MI_OK && mi_fifo_reset_range(b->f_out, s0, mm) == MI_OK && mi_volume_reset_max(b->vol, s0, mm) == MI_OK &&
-	          (!b->f_chan || mi_fifo_reset_range(b->f_chan, s0, mm) == MI_OK);
-	std::vector<int32_t> fill((size_t)b->nlegs, 0);
+	bool was_used = false;
+	for (int pin = 0; pin < mm; ++pin) was_used |= b->used[(size_t)(s0 + pin)] != 0;
+	bool ok = b->start_slots(s0, mm);
+	{ // (a pin without a leg keeps the batch's defaults)
+		mi_volume_state st0 = b->vstate0;
+		for (int pin = 0; pin < mm && was_used; ++pin) b->start_volume((size_t)(s0 + pin), b->vparams0, st0, true);
+	}
 	for (const LegCand &cd : cand) {
 		const size_t s = (size_t)(s0 + cd.pin);
 		VolumeData *vd = (VolumeData *)cd.vol->data;
 		SpeexECState *es = (SpeexECState *)cd.ec->data;
 		volume_keep_state(vd); // (its bank is on this hub, which is held)
-		b->vstate[s] = volume_start_state(vd); // as volume_attach_slot starts a slot: MSVolume's running state, if it has one already
-		b->vparams[s] = vd->p;
-		b->vparams[s].peer = cd.peer ? MI_VOLUME_PEER_EXTERNAL : -1;
-		fill[s] = delay; // zeroes for the time of the delay (speexec.c:205-208)
+		mi_volume_params vp = vd->p;
+		vp.peer = cd.peer ? MI_VOLUME_PEER_EXTERNAL : -1;
+		b->start_volume(s, vp, volume_start_state(vd), was_used); // as volume_attach_slot starts a slot: MSVolume's running state, if it has one already
 		if (es->state_str) { // a saved canceller state goes to the leg's slot (speexec.c:209-211)
 			std::vector<uint8_t> blob;
 			if (b64_decode(es->state_str, blob) && mi_aec_import_state(b->aec, (int)s, blob.data(), blob.size()) == MI_OK) ms_message("mi355x echo state restored.");
 			else ms_error("Could not apply mi355x echo blob: %s", mi_last_error());
 		}
-	}
-	ok = ok && mi_volume_set_params(b->vol, s0, mm, &b->vparams[(size_t)s0]) == MI_OK && mi_volume_set_state(b->vol, s0, mm, &b->vstate[(size_t)s0]) == MI_OK;
-	if (ok && delay > 0) {
-		int32_t *d_fill = b->d_cnt; // (idle between flushes)
-		ok = mi_copy_h2d(b->hub->ctx, d_fill, fill.data(), (size_t)b->nlegs * 4) == MI_OK && mi_fifo_push_silence(b->f_ref, d_fill) == MI_OK &&
-		     mi_ctx_sync(b->hub->ctx) == MI_OK;
 	}
 	if (!ok) {
 		mi_failed("fusing a conference's legs");
@@ -1813,7 +1853,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		leg->bank = b, leg->slot = s0 + cd.pin, leg->pin = cd.pin;
 		leg->rs = cd.rs, leg->ec = cd.ec, leg->vol = cd.vol, leg->mixer = mx;
 		leg->rs_data = cd.rs ? cd.rs->data : nullptr, leg->ec_data = cd.ec->data, leg->vol_data = cd.vol->data;
-		leg->dref_level = delay;
+		leg->dref_level = leg->inject = delay; // zeroes for the time of the delay (speexec.c:205-208): pushed by the first enqueue
 		b->legs[(size_t)leg->slot] = leg;
 		SpeexECState *es = (SpeexECState *)cd.ec->data;
 		VolumeData *vd = (VolumeData *)cd.vol->data;
@@ -1919,6 +1959,13 @@ void leg_return_canceller(LegBank *b, FusedLeg *leg, bool started) {
 	}
 	ms_bufferizer_flush(&es->delayed_ref);
 	ms_bufferizer_flush(&es->echo);
+	// (a leg that leaves before its first enqueue: the delay line's zeroes are still a count, LegBank::used)
+	const int pending = std::min(leg->inject, leg->dref_level);
+	if (pending > 0) {
+		std::vector<int16_t> z((size_t)pending, 0);
+		bufferizer_put_samples(&es->delayed_ref, z.data(), pending);
+		leg->inject -= pending, leg->dref_level -= pending;
+	}
 	const bool ok = fifo_take(b->hub->ctx, b->f_ref, b->nlegs, leg->slot, b->ns, b->d_scratch, b->d_dgate_any(), {leg->dref_level},
 	                          [&](int, const int16_t *x, int n) { bufferizer_put_samples(&es->delayed_ref, x, n); }) &&
 	                fifo_take(b->hub->ctx, b->f_mic, b->nlegs, leg->slot, b->ns, b->d_scratch, b->d_dgate_any(), {leg->echo_level},
@@ -2028,23 +2075,18 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	const int s = b ? b->acquire(vol) : -1;
 	if (s < 0) return false;
 	note_slot(vol);
-	bool ok = (!b->rs || mi_resampler_reset(b->rs, s, 1) == MI_OK) && mi_aec_reset(b->aec, s, 1) == MI_OK && mi_fifo_reset_range(b->f_mic, s, 1) == MI_OK &&
-	          mi_fifo_reset_range(b->f_ref, s, 1) == MI_OK && mi_fifo_reset_range(b->f_out, s, 1) == MI_OK && mi_volume_reset_max(b->vol, s, 1) == MI_OK;
+	const bool was_used = b->used[(size_t)s] != 0;
+	bool ok = b->start_slots(s, 1);
 	volume_keep_state(vd); // (its bank is on this hub, which is held)
-	b->vstate[(size_t)s] = volume_start_state(vd);
-	b->vparams[(size_t)s] = vd->p;
-	b->vparams[(size_t)s].peer = peer ? MI_VOLUME_PEER_EXTERNAL : -1;
+	{
+		mi_volume_params vp = vd->p;
+		vp.peer = peer ? MI_VOLUME_PEER_EXTERNAL : -1;
+		b->start_volume((size_t)s, vp, volume_start_state(vd), was_used);
+	}
 	if (es->state_str) {
 		std::vector<uint8_t> blob;
 		if (b64_decode(es->state_str, blob) && mi_aec_import_state(b->aec, s, blob.data(), blob.size()) == MI_OK) ms_message("mi355x echo state restored.");
 		else ms_error("Could not apply mi355x echo blob: %s", mi_last_error());
-	}
-	ok = ok && mi_volume_set_params(b->vol, s, 1, &b->vparams[(size_t)s]) == MI_OK && mi_volume_set_state(b->vol, s, 1, &b->vstate[(size_t)s]) == MI_OK;
-	if (ok && delay > 0) {
-		std::vector<int32_t> fill((size_t)b->nlegs, 0);
-		fill[(size_t)s] = delay;
-		ok = mi_copy_h2d(b->hub->ctx, b->d_cnt, fill.data(), (size_t)b->nlegs * 4) == MI_OK && mi_fifo_push_silence(b->f_ref, b->d_cnt) == MI_OK &&
-		     mi_ctx_sync(b->hub->ctx) == MI_OK;
 	}
 	if (!ok) {
 		mi_failed("fusing a call leg");
@@ -2055,7 +2097,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	leg->bank = b, leg->slot = s, leg->pin = 0;
 	leg->rs = rs, leg->ec = ec, leg->vol = vol, leg->mixer = nullptr;
 	leg->rs_data = rs ? rs->data : nullptr, leg->ec_data = ec->data, leg->vol_data = vol->data;
-	leg->dref_level = delay;
+	leg->dref_level = leg->inject = delay; // zeroes for the time of the delay (speexec.c:205-208): pushed by the first enqueue
 	b->legs[(size_t)s] = leg;
 	b->nout[(size_t)s] = b->nready[(size_t)s] = 0;
 	if (rd) {

@@ -62,6 +62,7 @@ struct RecvBank : Pool {
 	uint8_t *h_mode, *h_modesc, *d_mode;            // MI_PLC_* per round and stream
 	int32_t *h_olen, *d_olen = nullptr;             // [kMaxRounds][cap]: samples MSAudioFlowControl left of the block (0: dropped)
 	std::vector<RecvLeg *> legs;
+	std::vector<uint8_t> used; // the slot has had a stream since the bank was created (a fresh one needs no reset: recv_try_fuse)
 	// MS_AUDIO_FLOW_CONTROL_DROP requests since the last launch and how many staged rounds of the stream precede each (FlowPool)
 	std::vector<uint32_t> req_drop, req_total, arm_drop, arm_total;
 	std::vector<int> req_round;
@@ -94,6 +95,7 @@ struct RecvBank : Pool {
 		h_olen = pinned<int32_t>(kMaxRounds * c);
 		if (with_fc) d_olen = devmem<int32_t>(c);
 		legs.assign(c, nullptr);
+		used.assign(c, 0);
 		req_drop.assign(c, 0), req_total.assign(c, 0), arm_drop.assign(c, 0), arm_total.assign(c, 0);
 		req_round.assign(c, 0);
 		zero_copy = zero_copy_rows();
@@ -502,10 +504,17 @@ bool recv_try_fuse(MSFilter *head) {
 	const int s = b ? b->acquire(head) : -1;
 	if (s < 0) return false;
 	note_slot(head);
-	bool ok = mi_plc_reset(b->plc, s, 1) == MI_OK; // generic_plc_preprocess :55-58: a fresh context
-	if (ok && b->fc)
-		ok = mi_flowctl_reset(b->fc, s, 1) == MI_OK && // flowcontrol.c:166-169
-		     mi_flowctl_set_config(b->fc, s, 1, fd->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT, fd->config.silent_threshold) == MI_OK;
+	// generic_plc_preprocess :55-58: a fresh context; flowcontrol.c:166-169: a controller at rest.  A slot nobody has used since the bank was created
+	// IS there (mi_plc_create / mi_flowctl_create leave every stream so, with the default configuration): no device call for it
+	const bool was_used = b->used[(size_t)s] != 0;
+	b->used[(size_t)s] = 1;
+	bool ok = !was_used || mi_plc_reset(b->plc, s, 1) == MI_OK;
+	if (ok && b->fc) {
+		const bool dflt = fd->config.strategy != MSAudioFlowControlBasic && fd->config.silent_threshold == 0.02f; // ms_audio_flow_controller_init flowcontrol.c:37-41
+		if (was_used) ok = mi_flowctl_reset(b->fc, s, 1) == MI_OK;
+		if (ok && (was_used || !dflt))
+			ok = mi_flowctl_set_config(b->fc, s, 1, fd->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT, fd->config.silent_threshold) == MI_OK;
+	}
 	if (!ok) {
 		mi_failed("fusing a stream's receiving side");
 		b->release(s);
