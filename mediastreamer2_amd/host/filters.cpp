@@ -647,6 +647,8 @@ struct RecvLeg;
 struct MapFilter;
 struct PlcFilter;
 void recv_chain_preprocessed(MSFilter *member);
+void graph_preprocessed(MSFilter *f); // attach.inl: every facade's preprocess ends here
+void generic_preprocess(MSFilter *f);
 void recv_release(RecvLeg *leg, bool keep_running);
 void recv_disqualify(RecvLeg *leg);
 bool recv_wants_out(RecvLeg *leg);
@@ -670,6 +672,7 @@ bool recv_candidate(MSFilter *member);
 #include "filters/flow_control.inl"
 #include "filters/generic_plc.inl"
 #include "filters/recv_leg.inl"
+#include "filters/attach.inl"
 
 } // namespace
 
@@ -678,7 +681,7 @@ extern "C" {
 // Descriptors: same ids, names, pin counts and flags as the reference's, plus
 // MS_FILTER_IS_HW_ACCELERATED (msfilter.h:142).  Writable statics: the factory mutates flags.
 MSFilterDesc ms_mi355x_resample_desc = {MS_RESAMPLE_ID, "MSResample", "Audio resampler (MI355X batch)", MS_FILTER_OTHER,
-                                        NULL, 1, 1, resample_init, NULL, resample_process, resample_postprocess, resample_uninit,
+                                        NULL, 1, 1, resample_init, generic_preprocess, resample_process, resample_postprocess, resample_uninit,
                                         resample_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_audio_mixer_desc = {MS_AUDIO_MIXER_ID, "MSAudioMixer",
                                            "A filter that mixes down 16 bit sample audio streams (MI355X batch)",
@@ -707,10 +710,10 @@ MSFilterDesc ms_mi355x_webrtc_aec_name_desc = {MS_FILTER_PLUGIN_ID, "MSWebRTCAEC
                                                ec_uninit, ec_methods, MS_FILTER_IS_HW_ACCELERATED};
 
 MSFilterDesc ms_mi355x_size_conv_desc = {MS_SIZE_CONV_ID, "MSSizeConv", "A video size converter (MI355X batch)", MS_FILTER_OTHER,
-                                         NULL, 1, 1, size_conv_init, NULL, size_conv_process, size_conv_postprocess,
+                                         NULL, 1, 1, size_conv_init, generic_preprocess, size_conv_process, size_conv_postprocess,
                                          size_conv_uninit, sizeconv_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_pix_conv_desc = {MS_PIX_CONV_ID, "MSPixConv", "A pixel format converter (MI355X batch)", MS_FILTER_OTHER,
-                                        NULL, 1, 1, pixconv_init, NULL, pixconv_process, generic_postprocess, pixconv_uninit,
+                                        NULL, 1, 1, pixconv_init, generic_preprocess, pixconv_process, generic_postprocess, pixconv_uninit,
                                         pixconv_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSScalerDesc ms_mi355x_scaler_desc = {sd_create, sd_process, sd_free};
 
@@ -720,13 +723,13 @@ MSFilterDesc ms_mi355x_alaw_dec_desc = {MS_ALAW_DEC_ID, "MSAlawDec", "ITU-G.711 
 MSFilterDesc ms_mi355x_ulaw_dec_desc = {MS_ULAW_DEC_ID, "MSUlawDec", "ITU-G.711 ulaw decoder (MI355X batch)", MS_FILTER_DECODER, "pcmu", 1, 1,
                                         g711_dec_init_u, g711_dec_preprocess, g711_dec_process, g711_dec_postprocess, map_uninit, g711_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_alaw_enc_desc = {MS_ALAW_ENC_ID, "MSAlawEnc", "ITU-G.711 alaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcma", 1, 1,
-                                        g711_enc_init_a, NULL, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_enc_init_a, generic_preprocess, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_ulaw_enc_desc = {MS_ULAW_ENC_ID, "MSUlawEnc", "ITU-G.711 ulaw encoder (MI355X batch)", MS_FILTER_ENCODER, "pcmu", 1, 1,
-                                        g711_enc_init_u, NULL, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                        g711_enc_init_u, generic_preprocess, g711_enc_process, g711_enc_postprocess, map_uninit, g711_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_l16_enc_desc = {MS_L16_ENC_ID, "MSL16Enc", "L16 dummy encoder (MI355X batch)", MS_FILTER_ENCODER, "L16", 1, 1,
                                        l16_enc_init, l16_enc_preprocess, l16_enc_process, generic_postprocess, map_uninit, l16_enc_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_l16_dec_desc = {MS_L16_DEC_ID, "MSL16Dec", "L16 dummy decoder (MI355X batch)", MS_FILTER_DECODER, "L16", 1, 1,
-                                       l16_dec_init, NULL, l16_dec_process, generic_postprocess, map_uninit, l16_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
+                                       l16_dec_init, generic_preprocess, l16_dec_process, generic_postprocess, map_uninit, l16_dec_methods, MS_FILTER_IS_HW_ACCELERATED};
 MSFilterDesc ms_mi355x_channel_adapter_desc = {MS_CHANNEL_ADAPTER_ID, "MSChannelAdapter",
                                                "A filter that converts from mono to stereo and vice versa (MI355X batch)", MS_FILTER_OTHER, NULL, 2, 1,
                                                adapter_init, adapter_preprocess, adapter_process, adapter_postprocess, adapter_uninit,

@@ -1,0 +1,62 @@
+// filters/attach.inl -- what is decided when a graph is attached, on the ATTACHING thread.
+// Part of the single translation unit filters.cpp (included inside its anonymous namespace, last); not compiled on its own.
+//
+// ms_ticker_attach runs preprocess() of every filter of the graph on the thread that attaches, one after the other, BEFORE the graph's
+// sources join the ticker's execution list (src/base/msticker.c:153-183; f->ticker is set right in front of each call, msfilter.c:266-270).
+// The reference's filters do all their set-up there -- speex_echo_state_init, the mixer's tick buffers -- and the ticker thread's
+// first tick finds them ready.  Up to round 5 this plugin decided what to fuse, opened the fused banks and reset their slots at the
+// first block of every leg, ON THE TICKER THREAD: the first ticks of a loaded ticker took 0.2 - 2.7 s.
+//
+// Every facade's preprocess ends in graph_preprocessed().  The LAST facade of the graph to get there finds every facade's ticker
+// set, and does the graph's fusing: conferences (sending legs or a server's remote members), legs without a mixer (an AudioStream's
+// sending side, its encoder included), receiving sides (decoder -> PLC -> flow control).  The first tick then stages and launches
+// like any other.  What is looked at are THIS plugin's facades only: somebody else's filter that is preprocessed later changes nothing.
+// (The facades' first process() still looks -- fuse_checked / fuse_state -- for a graph whose facades were configured after the
+// attach; normally it finds the decision made.)
+
+void graph_preprocessed(MSFilter *f) { // (hub locked by the caller)
+	if (!f->ticker) return;
+	std::vector<MSFilter *> todo{f}, all;
+	std::unordered_set<MSFilter *> seen{f};
+	while (!todo.empty()) {
+		MSFilter *g = todo.back();
+		todo.pop_back();
+		if (is_ours(g->desc)) {
+			if (g->ticker != f->ticker) return; // a facade of the graph is still to be preprocessed: the last one does the work
+			all.push_back(g);
+		}
+		for (int i = 0; i < g->desc->ninputs; ++i)
+			if (g->inputs[i] && g->inputs[i]->prev.filter && seen.insert(g->inputs[i]->prev.filter).second) todo.push_back(g->inputs[i]->prev.filter);
+		for (int i = 0; i < g->desc->noutputs; ++i)
+			if (g->outputs[i] && g->outputs[i]->next.filter && seen.insert(g->outputs[i]->next.filter).second) todo.push_back(g->outputs[i]->next.filter);
+	}
+	// conferences first (a mixer in conference mode: its legs, or a server's remote members, conf_try_fuse looks at both shapes)
+	for (MSFilter *g : all)
+		if (g->desc == &ms_mi355x_audio_mixer_desc && ((MixerState *)g->data)->conf_mode != 0) conf_try_fuse(g);
+	// sending legs without a conference mixer: headed by MSResample (through a mic_equalizer) or by MSSpeexEC itself
+	for (MSFilter *g : all) {
+		if (!is_ec_desc(g->desc)) continue;
+		SpeexECState *s = (SpeexECState *)g->data;
+		if (s->leg || !s->configured || s->unsupported || __atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED) || !g->inputs[1]) continue;
+		MSFilter *rs = g->inputs[1]->prev.filter;
+		if (rs && rs->desc == &ms_mi355x_equalizer_desc) rs = rs->inputs[0] ? rs->inputs[0]->prev.filter : NULL;
+		if (rs && rs->desc == &ms_mi355x_resample_desc) {
+			ResampleData *rd = (ResampleData *)rs->data;
+			if (rd->input_rate == rd->output_rate || rd->leg || rd->pool) continue; // (a forwarder, or a filter that has run on its facade: its first block looks, as before)
+			rd->fuse_checked = true;
+			if (MSFilter *mx = leg_find_mixer(rs)) conf_try_fuse(mx);
+			else leg_try_fuse_plain(rs);
+			continue;
+		}
+		s->fuse_checked = true;
+		if (MSFilter *mx = leg_find_mixer_ec(g)) conf_try_fuse(mx);
+		else leg_try_fuse_plain_ec(g);
+	}
+	// receiving sides: decoder -> [local_mixer] -> MSGenericPLC -> [MSAudioFlowControl]
+	for (MSFilter *g : all)
+		if (is_g711_dec(g->desc) || g->desc == &ms_mi355x_generic_plc_desc) recv_chain_preprocessed(g);
+}
+void generic_preprocess(MSFilter *f) { // a facade with nothing of its own to prepare
+	HubLock lk(f);
+	graph_preprocessed(f);
+}

@@ -240,7 +240,7 @@ void g711_dec_postprocess(MSFilter *f) {
 // preprocessed finds every ticker set and fuses it: msticker.c:163-166 runs the graph's preprocess calls one after the other)
 void g711_dec_preprocess(MSFilter *f) {
 	HubLock lk(f);
-	recv_chain_preprocessed(f);
+	graph_preprocessed(f);
 }
 void g711_dec_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
@@ -400,7 +400,10 @@ void l16_enc_init(MSFilter *f) { // :31-39
 	d->ptime = 10;
 }
 void l16_enc_update(MapFilter *d) { d->nbytes = (size_t)((2 * d->nchannels * d->rate * d->ptime) / 1000); } // :48-50
-void l16_enc_preprocess(MSFilter *f) { l16_enc_update((MapFilter *)f->data); }
+void l16_enc_preprocess(MSFilter *f) {
+	l16_enc_update((MapFilter *)f->data);
+	generic_preprocess(f);
+}
 void l16_enc_process(MSFilter *f) {
 	MapFilter *d = (MapFilter *)f->data;
 	map_rehome(f, d);
@@ -514,6 +517,7 @@ void adapter_preprocess(MSFilter *f) { // :53-66; the two-input buffers are need
 			b->max_size_ms = (uint32_t)f->ticker->interval * 2;
 		}
 	}
+	generic_preprocess(f);
 }
 void adapter_postprocess(MSFilter *f) { // :125-135
 	MapFilter *d = (MapFilter *)f->data;

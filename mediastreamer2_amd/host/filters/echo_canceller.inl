@@ -232,6 +232,7 @@ void ec_prepare(MSFilter *f);
 void ec_preprocess(MSFilter *f) { // speexec.c:188-216
 	HubLock lk(f);
 	ec_prepare(f);
+	graph_preprocessed(f);
 }
 void ec_prepare(MSFilter *f) { // (hub locked by the caller)
 	SpeexECState *s = (SpeexECState *)f->data;

@@ -161,6 +161,10 @@ void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
 	f->data = d;
 }
 void equalizer_preprocess(MSFilter *f) {
+	{
+		HubLock lk(f);
+		graph_preprocessed(f);
+	}
 	if (!((EqualizerData *)f->data)->leg) equalizer_attach(f);
 }
 void equalizer_postprocess(MSFilter *f) {

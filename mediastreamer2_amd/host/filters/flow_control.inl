@@ -196,7 +196,7 @@ bool flowctl_attach(MSFilter *f, FlowFilter *d) {
 void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_reset
 	FlowFilter *d = (FlowFilter *)f->data;
 	HubLock lk(f);
-	recv_chain_preprocessed(f);
+	graph_preprocessed(f);
 	if (d->rleg || recv_candidate(f)) return; // (fused: reset with its slot there; a chain that may still fuse: process() attaches -- and resets -- when it does not)
 	if (flowctl_attach(f, d)) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1));
 }

@@ -187,7 +187,7 @@ bool plc_attach(MSFilter *f, PlcFilter *d) { // generic_plc_preprocess :55-58: a
 void plc_preprocess(MSFilter *f) {
 	PlcFilter *d = (PlcFilter *)f->data;
 	HubLock lk(f);
-	recv_chain_preprocessed(f);
+	graph_preprocessed(f);
 	if (!d->rleg && !recv_candidate(f)) plc_attach(f, d); // (a chain that may still fuse opens no bank of its own here: process() does when it does not)
 }
 void plc_process(MSFilter *f) { // generic_plc_process :59-167

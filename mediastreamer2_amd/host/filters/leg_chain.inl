@@ -1568,7 +1568,7 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
-	if (!rs || rs->ticker != mx->ticker) return false;
+	if (!rs || (is_ours(rs->desc) && rs->ticker != mx->ticker)) return false; // (somebody else's filter may still be waiting for its preprocess: graph_preprocessed looks at this plugin's facades only)
 	if (!leg_far_end_in_walk(ec, c.peer)) return false;
 	c.eq = nullptr;
 	if (rs->desc == &ms_mi355x_equalizer_desc) { // mic_equalizer (audiostream.c:1801): the leg's head is the MSResample in front of it

@@ -213,6 +213,7 @@ void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
 	HubLock lk(f);
 	((MixerState *)f->data)->fuse_state = 0;
 	mixer_prepare(f);
+	graph_preprocessed(f);
 }
 // running: the conference left a fused batch while attached -- no preprocess in the reference's terms: the channels' clocks (census,
 // flow control) and the bypass state run on, they are the very fields the batch kept (LegBank / ServerBank::conf_tick)

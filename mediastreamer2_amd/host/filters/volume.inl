@@ -409,6 +409,8 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 	// echo limiter's pair: the limiter addresses its peer by its slot in the SAME bank (volume_attach_slot), and two filters that take
 	// their slots one after the other at the attach land side by side)
 	if (volume_is_peered(d)) volume_attach_slot(f);
+	HubLock lk(f);
+	graph_preprocessed(f);
 }
 
 void volume_process(MSFilter *f) { // msvolume.c:471-514
@@ -578,7 +580,10 @@ void volume_set_gains(MSFilter *f, VolumeData *d, bool also_target) {
 		d->kept.gain = d->gain;
 		if (also_target) d->kept.target_gain = d->target_gain;
 	}
-	if (!d->pool || d->slot < 0) return; // not attached yet: volume_attach_slot picks d->gain / d->target_gain up
+	if (!d->pool || d->slot < 0) { // no slot yet: volume_attach_slot picks d->gain / d->target_gain up
+		volume_far_end_changed(f, d);
+		return;
+	}
 	{
 		VolumePool *p = d->pool;
 		const size_t s = (size_t)d->slot;
