@@ -80,6 +80,11 @@ int mi_device_count(void);
 int mi_ctx_create(int device, void *hip_stream, mi_ctx **out);
 void mi_ctx_destroy(mi_ctx *ctx);
 int mi_ctx_sync(mi_ctx *ctx);
+/* Loads every kernel's code object on the context's device now.  HIP loads a code object with the first launch of one of its
+ * kernels, behind a process-wide lock: a media server's first ticks -- every ticker thread's first launches -- otherwise wait for
+ * it (0.1 - 0.3 s measured with 16 tickers).  The plugin calls it from libmsmi355xfilters_init for every device it may use; the
+ * reference has no counterpart (its filters' code is mapped with the library, src/base/msfactory.c:546). */
+int mi_warmup(mi_ctx *ctx);
 void *mi_ctx_stream(mi_ctx *ctx);
 int mi_ctx_device(mi_ctx *ctx);
 /* device properties the bench reports: CU count, HBM bytes, name */
@@ -92,7 +97,7 @@ void mi_host_free(mi_ctx *ctx, void *h_ptr);    /* ctx may be NULL (a buffer tha
 int mi_copy_h2d(mi_ctx *ctx, void *d_dst, const void *h_src, size_t bytes); /* async on ctx stream */
 int mi_copy_d2h(mi_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* async on ctx stream */
 /* the same for host memory from mi_host_alloc, as a kernel of this library on the context's stream (a launch, never a call
- * into the runtime's copy path: what the plugin's tick path uses).  MSMI355X_COPY=hip: hipMemcpyAsync again. */
+ * into the runtime's copy path: what the plugin's tick path uses). */
 int mi_copy_h2d_pinned(mi_ctx *ctx, void *d_dst, const void *h_pinned_src, size_t bytes);
 int mi_copy_d2h_pinned(mi_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes);
 int mi_memset(mi_ctx *ctx, void *d_dst, int value, size_t bytes);

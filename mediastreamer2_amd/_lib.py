@@ -23,7 +23,7 @@ class MiError(RuntimeError):
 # every symbol include/msmi355x.h declares (tests check the export table against this)
 EXPORTS = [
     "mi_abi_version", "mi_last_error", "mi_device_count",
-    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
+    "mi_ctx_create", "mi_ctx_destroy", "mi_ctx_sync", "mi_warmup", "mi_ctx_stream", "mi_ctx_device", "mi_ctx_props",
     "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_pinned", "mi_copy_d2h_pinned", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
     "mi_timer_start", "mi_timer_stop",
@@ -105,6 +105,7 @@ def load():
     L.mi_ctx_destroy.argtypes = [vp]
     L.mi_ctx_destroy.restype = None
     L.mi_ctx_sync.argtypes = [vp]
+    L.mi_warmup.argtypes = [vp]
     L.mi_ctx_stream.argtypes = [vp]
     L.mi_ctx_stream.restype = vp
     L.mi_ctx_device.argtypes = [vp]

@@ -333,11 +333,6 @@ struct mi_aec {
 	int small_stride = 0;
 	int *d_order = nullptr, *d_ctl = nullptr; // leg order of the FIFO entry's launches (aec_tick.hpp: TickOrder)
 	int cap8 = 0;
-	// the small frame sizes' FIFO entries (F = 64 / 128): the tick's frames as rows between the queues and aec_group_kernel
-	// (aec_fifos_group below) -- [nstreams][MI_AEC_MAX_TICK_FRAMES * F] each, the up-sampled block [nstreams][g_up_stride], frame counts
-	int16_t *d_gmic = nullptr, *d_gref = nullptr, *d_gout = nullptr, *d_gup = nullptr;
-	uint8_t *d_gcnt = nullptr;
-	int g_up_stride = 0;
 	std::vector<float> h_prop0;
 	float spec_average, beta0, beta_max, notch_radius, ss, ss_1;
 };
@@ -537,7 +532,6 @@ int mi_aec_framesize(int framesize_at_8000, int sample_rate) { // speexec.c:171-
 }
 
 static bool aec_group_form_on();
-static int aec_group_scratch(mi_aec *a);
 int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, int filter_length, mi_aec **out) {
 	MI_CHECK_ARG(ctx && out && nstreams > 0 && sample_rate > 0 && filter_length > 0);
 	*out = nullptr;
@@ -610,13 +604,6 @@ int mi_aec_create(mi_ctx *ctx, int nstreams, int sample_rate, int frame_size, in
 			return MI_ENOMEM;
 		}
 	}
-	if (a->F != 256) { // the small frame sizes' FIFO entries work through rows of their own (aec_fifos_group): allocated here, never inside a stream capture
-		const int rc = aec_group_scratch(a);
-		if (rc != MI_OK) {
-			mi_aec_destroy(a);
-			return rc;
-		}
-	}
 	*out = a;
 	return MI_OK;
 }
@@ -631,8 +618,6 @@ void mi_aec_destroy(mi_aec *a) {
 	if (a->d_tables) (void)hipFree(a->d_tables);
 	if (a->d_order) (void)hipFree(a->d_order);
 	if (a->d_ctl) (void)hipFree(a->d_ctl);
-	for (void *p : {(void *)a->d_gmic, (void *)a->d_gref, (void *)a->d_gout, (void *)a->d_gup, (void *)a->d_gcnt})
-		if (p) (void)hipFree(p);
 	delete a;
 }
 
@@ -745,36 +730,6 @@ static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int
 		}
 		return MI_OK;
 	}
-	// EXPERIMENT (MSMI355X_AEC_W_IN_LDS=1): the headline form with frame 1's updated background resident in LDS (aec_tick.hpp: WLDS)
-	static const bool w_in_lds = [] {
-		const char *e = getenv("MSMI355X_AEC_W_IN_LDS");
-		return e && e[0] == '1';
-	}();
-	if (w_in_lds && a->F == 256 && mode == TICK_FIFO_RS && a->M * 256 * 8 <= 49152) {
-		static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&aec_tick_kernel<256, TICK_FIFO_RS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 49152) == hipSuccess;
-		if (ok) {
-			hipLaunchKernelGGL((aec_tick_kernel<256, TICK_FIFO_RS, true>), grid, dim3(64), 49152, a->ctx->stream, g);
-			MI_LAUNCH_CHECK();
-			hipLaunchKernelGGL(aec_tick_advance_kernel, dim3(1), dim3(64), 0, a->ctx->stream, a->d_ctl);
-			MI_LAUNCH_CHECK();
-			return MI_OK;
-		}
-	}
-	// (MSMI355X_AEC_LDS_PAD=<bytes>: the PRODUCT form launched with that much dynamic LDS it never touches -- what the footprint alone costs)
-	static const int lds_pad = [] {
-		const char *e = getenv("MSMI355X_AEC_LDS_PAD");
-		return e ? atoi(e) : 0;
-	}();
-	if (lds_pad > 0 && a->F == 256 && mode == TICK_FIFO_RS) {
-		static const bool okp = hipFuncSetAttribute(reinterpret_cast<const void *>(&aec_tick_kernel<256, TICK_FIFO_RS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad) == hipSuccess;
-		if (okp) {
-			hipLaunchKernelGGL((aec_tick_kernel<256, TICK_FIFO_RS, false>), grid, dim3(64), (size_t)lds_pad, a->ctx->stream, g);
-			MI_LAUNCH_CHECK();
-			hipLaunchKernelGGL(aec_tick_advance_kernel, dim3(1), dim3(64), 0, a->ctx->stream, a->d_ctl);
-			MI_LAUNCH_CHECK();
-			return MI_OK;
-		}
-	}
 #define MI_TICK_LAUNCH(FR)                                                                                          \
 	do {                                                                                                            \
 		if (mode == TICK_FIFO_RS) hipLaunchKernelGGL((aec_tick_kernel<FR, TICK_FIFO_RS>), grid, dim3(64), 0, a->ctx->stream, g); \
@@ -806,18 +761,11 @@ int mi_aec_process_frames(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref,
 	return aec_launch(a, d_mic, d_ref, d_out, stride, nullptr, d_count, max_frames, flags, nullptr);
 }
 
-// The FIFO entries at the small frame sizes (8 kHz: F = 64, 16 kHz: F = 128 -- what most real legs run, speexec.c:171-180): the
-// entry's own definition, launch by launch (msmi355x.h: "results equal mi_fifo_push x 2, mi_fifo_pop_frames x 2,
-// mi_aec_process_frames, mi_fifo_push_frames"), so that the frames are cancelled by aec_group_kernel -- four / two legs per wavefront
-// (aec_group.hpp), ~25 % / ~10 % less time per frame than one leg per wavefront -- instead of aec_tick_kernel<64 / 128>.  The queue
-// traffic between the launches is a few hundred bytes per leg; the canceller's state is what the launch moves.  mic_rows: the tick's
-// microphone blocks at the canceller's rate (rs == nullptr) or at the resampler's input rate (rs: up-sampled first, by the
-// resampler's own kernel).
-// MEASURED (round 5, 65 536 legs, whole 10 ms ticks, staggered phases; profiles/r05_small_frame_fifo_entry.txt): this path takes
-// 1 010 us at 8 kHz and 1 559 us at 16 kHz, the tick form (one leg per wavefront, the FIFOs inside the launch, exactly the frames
-// each leg has) 960 us and 1 482 us.  A tick holds 1.25 frames per leg; the group kernel runs once per frame INDEX over all legs,
-// so its second launch serves a quarter of the legs at the price of all of them.  The tick form therefore stays the FIFO entries'
-// default; MSMI355X_AEC_GROUP_FIFO=1 selects this path (bit-equal: tests/test_gpu_pipeline.py runs under both).
+// (The FIFO entries at the small frame sizes -- 8 kHz: F = 64, 16 kHz: F = 128 -- stay on the tick form, one leg per wavefront with the
+// FIFOs inside the launch.  Round 5 built the entry out of the group kernel too -- queue, pop frames into rows, one aec_group_kernel launch
+// per frame index, push -- and measured it 5 % slower per whole tick (1 010 / 1 559 us against 960 / 1 482 at 65 536 legs: a tick is 1.25
+// frames per leg and the second launch serves a quarter of the legs at the price of all): profiles/r05_small_frame_fifo_entry.txt.  That
+// path is no longer in the source; rows handed in directly -- mi_aec_process / mi_aec_process_frames -- run the group kernel.)
 static bool aec_group_form_on() {
 	if (g_group_form.load(std::memory_order_relaxed) < 0) {
 		const char *e = getenv("MSMI355X_AEC_GROUP");
@@ -825,48 +773,8 @@ static bool aec_group_form_on() {
 	}
 	return g_group_form.load(std::memory_order_relaxed) > 0;
 }
-static bool aec_group_fifo_on() {
-	static const bool on = [] {
-		const char *e = getenv("MSMI355X_AEC_GROUP_FIFO");
-		return e && e[0] == '1';
-	}();
-	return on && aec_group_form_on();
-}
-static int aec_group_scratch(mi_aec *a) { // (allocated with the batch's first small-frame FIFO call: outside any stream capture, see mi_aec_create)
-	if (a->d_gmic) return MI_OK;
-	const size_t rows = (size_t)a->nstreams * MI_AEC_MAX_TICK_FRAMES * a->F * sizeof(int16_t);
-	a->g_up_stride = ((a->rate / 100) * 2 + 15) & ~7; // a tick of up to 20 ms at the canceller's rate
-	if (hipMalloc((void **)&a->d_gmic, rows) != hipSuccess || hipMalloc((void **)&a->d_gref, rows) != hipSuccess || hipMalloc((void **)&a->d_gout, rows) != hipSuccess ||
-	    hipMalloc((void **)&a->d_gup, (size_t)a->nstreams * a->g_up_stride * sizeof(int16_t)) != hipSuccess || hipMalloc((void **)&a->d_gcnt, (size_t)a->nstreams) != hipSuccess) {
-		mi::set_error("hipMalloc failed for the small-frame FIFO entry's rows");
-		return MI_ENOMEM;
-	}
-	return MI_OK;
-}
 static int aec_launch(mi_aec *a, const int16_t *d_mic, const int16_t *d_ref, int16_t *d_out, int stride, const uint8_t *d_run,
                       const uint8_t *d_count, int max_frames, unsigned flags, const AecFifoCall *fifo);
-static int aec_fifos_group(mi_aec *a, mi_resampler *rs, const int16_t *mic_rows, int in_len, int in_stride, int tick_len, mi_fifo *f_mic, mi_fifo *f_ref,
-                           const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, mi_fifo *f_out, int max_frames, unsigned flags,
-                           uint8_t *d_count_out, const uint8_t *d_mic_gate) {
-	int rc = aec_group_scratch(a);
-	if (rc != MI_OK) return rc;
-	const int stride = MI_AEC_MAX_TICK_FRAMES * a->F;
-	uint8_t *cnt = d_count_out ? d_count_out : a->d_gcnt;
-	if (rs) {
-		if (tick_len > a->g_up_stride) {
-			mi::set_error("mi_aec_process_fifos_resampled: a block of %d samples exceeds the small-frame entry's rows (%d)", tick_len, a->g_up_stride);
-			return MI_ENOTSUP;
-		}
-		if ((rc = mi_resampler_process_masked(rs, mic_rows, in_len, in_stride, a->d_gup, a->g_up_stride, nullptr, d_mic_gate)) != MI_OK) return rc;
-		mic_rows = a->d_gup, in_stride = a->g_up_stride;
-	}
-	if ((rc = mi_fifo_push_gated(f_mic, mic_rows, tick_len, in_stride, d_mic_gate)) != MI_OK) return rc;
-	if ((rc = mi_fifo_push(f_ref, d_ref_tick, tick_len, ref_stride, d_ref_len)) != MI_OK) return rc;
-	if ((rc = mi_fifo_pop_frames(f_mic, a->F, max_frames, a->d_gmic, stride, cnt, nullptr, 0)) != MI_OK) return rc;
-	if ((rc = mi_fifo_pop_frames(f_ref, a->F, max_frames, a->d_gref, stride, nullptr, cnt, 1)) != MI_OK) return rc;
-	if ((rc = aec_launch(a, a->d_gmic, a->d_gref, a->d_gout, stride, nullptr, cnt, max_frames, flags, nullptr)) != MI_OK) return rc;
-	return mi_fifo_push_frames(f_out, a->d_gout, a->F, max_frames, stride, cnt);
-}
 
 int mi_aec_process_fifos_masked(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_tick, int mic_stride, mi_fifo *f_ref,
                                 const int16_t *d_ref_tick, int ref_stride, const int32_t *d_ref_len, int tick_len, mi_fifo *f_out,
@@ -879,9 +787,6 @@ int mi_aec_process_fifos_masked(mi_aec *a, mi_fifo *f_mic, const int16_t *d_mic_
 			mi::set_error("mi_aec_process_fifos: FIFO capacities must be multiples of the frame size %d (got %d)", a->F, f->capacity);
 			return MI_EINVAL;
 		}
-	if (a->F != 256 && aec_group_fifo_on())
-		return aec_fifos_group(a, nullptr, d_mic_tick, tick_len, mic_stride, tick_len, f_mic, f_ref, d_ref_tick, ref_stride, d_ref_len, f_out, max_frames, flags, d_count_out,
-		                       d_mic_gate);
 	AecFifoCall fc;
 	fc.f_mic = f_mic, fc.f_ref = f_ref, fc.f_out = f_out;
 	fc.d_mic_tick = d_mic_tick, fc.d_ref_tick = d_ref_tick;
@@ -923,8 +828,6 @@ int mi_aec_process_fifos_resampled_masked(mi_aec *a, mi_resampler *rs, const int
 			mi::set_error("mi_aec_process_fifos_resampled: FIFO capacities must be multiples of the frame size %d (got %d)", a->F, f->capacity);
 			return MI_EINVAL;
 		}
-	if (a->F != 256 && aec_group_fifo_on())
-		return aec_fifos_group(a, rs, d_mic_in, in_len, in_stride, tick_len, f_mic, f_ref, d_ref_tick, ref_stride, d_ref_len, f_out, max_frames, flags, d_count_out, d_mic_gate);
 	fc.rs_in = d_mic_in, fc.rs_in_len = in_len, fc.rs_in_stride = in_stride;
 	fc.f_mic = f_mic, fc.f_ref = f_ref, fc.f_out = f_out;
 	fc.d_mic_tick = nullptr, fc.d_ref_tick = d_ref_tick;
@@ -1196,3 +1099,6 @@ int mi_debug_fft(mi_aec *a, const float *d_in, float *d_out, int nframes, int in
 void mi_debug_aec_group_form(int on) { g_group_form.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_aec(reinterpret_cast<const void *>(&aec_tick_advance_kernel));

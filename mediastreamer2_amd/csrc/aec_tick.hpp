@@ -191,14 +191,12 @@ __global__ __launch_bounds__(64) void aec_tick_advance_kernel(int *ctl) {
 //   TICK_FIFO_RS  the same with the leg's MSResample folded in: the block is up-sampled by this wave (.._resampled).
 enum { TICK_ROWS = 0, TICK_FIFO = 1, TICK_FIFO_RS = 2 };
 
-// WLDS (an EXPERIMENT, MSMI355X_AEC_W_IN_LDS=1, round 5; DESIGN 7.3 / profiles/r05_w_in_lds.txt): in a two-frame tick frame 1's updated
-// background W1 (M blocks of F bins, 48 KB at M = 24) is kept in LDS instead of being redone from W0 by frame 2's pass -- frame 2
-// reads it there: one read of the background (49 KB of ~300 KB per two-frame tick) never crosses HBM, and the redo's multiply-adds
-// go.  The price is the footprint: 19 KB + 48 KB of LDS per wavefront leave TWO wavefronts per CU where the product form runs eight.
-template <int F, int MODE, bool WLDS = false>
-__global__ __launch_bounds__(64, WLDS ? 1 : (F == 256 ? 2 : (F == 128 ? 3 : 4))) void aec_tick_kernel(AecArgs a) {
+// (Round 5 built a form that keeps frame 1's updated background W1 -- 48 KB at M = 24 -- in LDS instead of redoing it from W0 in frame
+// 2's pass: bit-equal and 2.9x slower, two wavefronts per CU where this form runs eight.  profiles/r05_w_in_lds.txt holds the
+// measurement; the form is no longer in the source.)
+template <int F, int MODE>
+__global__ __launch_bounds__(64, F == 256 ? 2 : (F == 128 ? 3 : 4)) void aec_tick_kernel(AecArgs a) {
 	__shared__ TLds<F> L;
-	extern __shared__ __attribute__((aligned(16))) unsigned char w1_lds[]; // WLDS: W1, [M][F] bins (a lane writes and reads only its own)
 	using SL = TickLayout<F>;
 	constexpr int N = 2 * F, K = F / 64;
 	// ---- which leg this wavefront serves.  Rows / per-frame entries: leg = block.  FIFO entry: the leg comes out of a list
@@ -498,14 +496,8 @@ __global__ __launch_bounds__(64, WLDS ? 1 : (F == 256 ? 2 : (F == 128 ? 3 : 4)))
 			bload_bins<K>(rX, vb8, xoff(1), pre0);
 			bload_bins<K>(rX, vb8, xoff(2 < M ? 2 : M), pre1);
 			const unsigned wpre = pendingBG ? fo : wo; // frame 1 reset the background: its blocks are the foreground's
-			if (WLDS && lazy1 && !pendingBG) { // frame 1's updated blocks wait in LDS
-				const v2f *W1 = reinterpret_cast<const v2f *>(w1_lds);
-#pragma unroll
-				for (int k = 0; k < K; ++k) pre2[k] = W1[e0 + k], pre3[k] = W1[(1 < M ? 1 : 0) * F + e0 + k];
-			} else {
-				bload_bins<K>(rWF, vb8, wpre, pre2);
-				bload_bins<K>(rWF, vb8, wpre + (unsigned)(1 < M ? 1 : 0) * (unsigned)(F * 8), pre3);
-			}
+			bload_bins<K>(rWF, vb8, wpre, pre2);
+			bload_bins<K>(rWF, vb8, wpre + (unsigned)(1 < M ? 1 : 0) * (unsigned)(F * 8), pre3);
 		}
 		// ---- near end: saturation flag, DC notch (serial IIR), pre-emphasis
 		int any_sat;
@@ -626,7 +618,7 @@ __global__ __launch_bounds__(64, WLDS ? 1 : (F == 256 ? 2 : (F == 128 ? 3 : 4)))
 			const bool carryFG = pendingFG, carryBG = pendingBG;
 			pendingFG = pendingBG = false;
 			const unsigned fsrc = carryFG ? wo : fo, wsrc = carryBG ? fo : wo, wdst = carryFG ? fo : wo;
-			const bool lazy = spec && do_grad && !carryBG && !carryFG && M <= 32 && (!WLDS || M * F * 8 <= 49152); // (the block weights wait in L.prop[32..])
+			const bool lazy = spec && do_grad && !carryBG && !carryFG && M <= 32; // (the block weights wait in L.prop[32..])
 			bload_bins<K>(rX, vb8, xoff(1), xn);
 			bload_bins<K>(rWF, vb8, fsrc, fg);
 			bload_bins<K>(rWF, vb8, wsrc, wl);
@@ -641,11 +633,7 @@ __global__ __launch_bounds__(64, WLDS ? 1 : (F == 256 ? 2 : (F == 128 ? 3 : 4)))
 				const bool aumdf = (j == 0 || j == jc);
 				if (do_grad) grad(wl, xn, L.prop[j]);
 				if (aumdf) constrain(wl);
-				if (WLDS && lazy) { // every updated block waits in LDS for frame 2's pass, none goes to HBM
-					v2f *W1 = reinterpret_cast<v2f *>(w1_lds);
-#pragma unroll
-					for (int k = 0; k < K; ++k) W1[j * F + e0 + k] = wl[k];
-				} else if (lazy ? (aumdf || j == M - 1) : (do_grad || aumdf || carryBG || carryFG)) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), wl);
+				if (lazy ? (aumdf || j == M - 1) : (do_grad || aumdf || carryBG || carryFG)) bstore_bins<K>(rWF, vb8, wdst + (unsigned)j * (F * 8), wl);
 				cmac_bins<K>(yfg, xj, fg, e0);
 				cmac_bins<K>(ybgs, xj, wl, e0);
 				if (spec) cmac_bins<K>(spec2, xm1, fg, e0);
@@ -696,9 +684,7 @@ __global__ __launch_bounds__(64, WLDS ? 1 : (F == 256 ? 2 : (F == 128 ? 3 : 4)))
 			const bool redo = lazy1 && !carryBG; // frame 1 left its updated blocks unwritten (all but 0, jc1 and the last)
 			const bool keepW1 = redo && carryFG;  // ... and then made them the foreground: they must exist in that half
 			auto block = [&](int j, v2f (&w)[K], const v2f (&xa)[K], const v2f (&xb)[K], const v2f (&xc)[K]) { // X(j), X(j+1), X(j+2)
-				if (WLDS) { // (w IS W1, straight from LDS; frame 1 wrote none of it to HBM)
-					if (keepW1) bstore_bins<K>(rWF, vb8, wo + (unsigned)j * (F * 8), w);
-				} else if (redo && j != 0 && j != jc1 && j != M - 1) {
+				if (redo && j != 0 && j != jc1 && j != M - 1) {
 					grad_with(w, xc, L.prop[32 + j], E1s, p1s, p1s_F);
 					if (keepW1) bstore_bins<K>(rWF, vb8, wo + (unsigned)j * (F * 8), w);
 				}
@@ -714,15 +700,8 @@ __global__ __launch_bounds__(64, WLDS ? 1 : (F == 256 ? 2 : (F == 128 ? 3 : 4)))
 				v2f xa[K], xb[K], wa[K], wb[K]; // the next pair: X(j+3), X(j+4), W(j+2), W(j+3) (clamped at the end: dropped)
 				bload_bins<K>(rX, vb8, xclamp(j + 4), xa);
 				bload_bins<K>(rX, vb8, xclamp(j + 5), xb);
-				if (WLDS && redo) {
-					const v2f *W1 = reinterpret_cast<const v2f *>(w1_lds);
-					const int ja = j + 2 < M ? j + 2 : M - 1, jb = j + 3 < M ? j + 3 : M - 1;
-#pragma unroll
-					for (int k = 0; k < K; ++k) wa[k] = W1[ja * F + e0 + k], wb[k] = W1[jb * F + e0 + k];
-				} else {
-					bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 2), wa);
-					bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 3), wb);
-				}
+				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 2), wa);
+				bload_bins<K>(rWF, vb8, wsrc + wclamp(j + 3), wb);
 				block(j, wl, xj, xn, xn2);
 				if (j + 1 < M) block(j + 1, wl2, xn, xn2, xn3);
 #pragma unroll

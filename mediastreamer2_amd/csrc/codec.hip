@@ -530,3 +530,6 @@ int mi_flowctl_reset(mi_flowctl *f, int first, int count) { // ms_audio_flow_con
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_codec(reinterpret_cast<const void *>(&flowctl_arm_kernel));

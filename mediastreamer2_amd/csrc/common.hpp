@@ -52,6 +52,13 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline unsigned xcd_grid(unsigned n) { return (n + 7u) / 8u * 8u; }
 __device__ __forceinline__ unsigned xcd_item(unsigned block, unsigned grid) { return (block & 7u) * (grid >> 3) + (block >> 3); }
 inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+// One kernel per translation unit, registered at load time: mi_warmup (ctx.hip) asks the runtime for its attributes, which makes it load
+// the unit's code object on the context's device THEN -- not under the first launch of a ticker's first tick (HIP loads a code object
+// lazily, behind one process-wide lock: sixteen ticker threads' first ticks waited 0.1 - 0.3 s for it).
+void warm_register(const void *kernel);
+struct WarmEntry {
+	explicit WarmEntry(const void *k) { warm_register(k); }
+};
 
 } // namespace mi
 

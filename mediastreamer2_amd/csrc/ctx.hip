@@ -35,25 +35,15 @@ int mi_ctx::ensure_scratch(int slot, size_t bytes, void **out) {
 // copies around its launches, and now and then ONE hipMemcpyAsync of a few KB keeps its caller on the CPU for ~10 ms inside
 // the runtime (an ioctl under the HSA copy path in one thread, sched_yield loops in the threads beside it; tests/host/
 // plugin_bench PLUGIN_BENCH_STACKS, profiles/r04_plugin_stacks.txt) -- longer than the tick it belongs to.  A kernel launch is
-// one AQL packet: nothing to allocate, map or wait for on the way.  MSMI355X_COPY=hip puts hipMemcpyAsync back (A/B).
+// one AQL packet: nothing to allocate, map or wait for on the way.  (profiles/r04_plugin_copies_kernel_vs_hip.txt holds the A/B.)
 namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void copy_kernel(T *__restrict__ dst, const T *__restrict__ src, size_t n) {
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
-bool copy_by_kernel() {
-	static const bool v = [] {
-		const char *e = getenv("MSMI355X_COPY");
-		return !(e && strcmp(e, "hip") == 0);
-	}();
-	return v;
-}
 int copy_mapped(mi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyKind kind) {
 	if (n == 0) return MI_OK;
-	if (!copy_by_kernel()) {
-		MI_HIP(hipMemcpyAsync(dst, src, n, kind, c->stream));
-		return MI_OK;
-	}
+	(void)kind;
 	const uintptr_t al = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | (uintptr_t)n;
 	auto grid = [](size_t units) { return dim3((unsigned)std::min<size_t>((units + 255) / 256, 2048)); };
 	if ((al & 15) == 0) hipLaunchKernelGGL(copy_kernel<uint4>, grid(n / 16), dim3(256), 0, c->stream, (uint4 *)dst, (const uint4 *)src, n / 16);
@@ -293,3 +283,24 @@ int mi_timer_stop(mi_ctx *c, float *ms) {
 }
 
 } // extern "C"
+
+// ---- code objects loaded ahead of the first launch (common.hpp: WarmEntry)
+namespace mi {
+static std::vector<const void *> &warm_list() {
+	static std::vector<const void *> v; // (function-local: the units' static initialisers may run before this one's)
+	return v;
+}
+void warm_register(const void *kernel) { warm_list().push_back(kernel); }
+} // namespace mi
+static const mi::WarmEntry g_warm_ctx(reinterpret_cast<const void *>(&stamp_kernel));
+
+extern "C" int mi_warmup(mi_ctx *c) {
+	MI_CHECK_ARG(c);
+	int rc;
+	if ((rc = c->activate()) != MI_OK) return rc;
+	for (const void *k : mi::warm_list()) {
+		hipFuncAttributes at;
+		MI_HIP(hipFuncGetAttributes(&at, k)); // (makes the runtime load the kernel's code object on this device, now)
+	}
+	return MI_OK;
+}

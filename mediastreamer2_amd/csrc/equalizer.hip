@@ -455,3 +455,6 @@ int mi_equalizer_process_host(mi_equalizer *e, int16_t *h_samples, int nsamples,
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_equalizer(reinterpret_cast<const void *>(&equalizer_pk_kernel<512>));

@@ -421,3 +421,6 @@ int mi_fifo_reset(mi_fifo *f) {
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_fifo(reinterpret_cast<const void *>(&fifo_silence_kernel));

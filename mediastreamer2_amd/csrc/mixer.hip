@@ -484,3 +484,6 @@ int mi_mixer_process_host(mi_mixer *m, const int16_t *h_in, const uint8_t *h_has
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_mixer(reinterpret_cast<const void *>(&mixer_scalar_kernel<0>));

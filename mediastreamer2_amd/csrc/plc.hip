@@ -559,3 +559,6 @@ int mi_plc_info(mi_plc *p, int stream, int32_t out3[3]) {
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_plc(reinterpret_cast<const void *>(&plc_list_kernel));

@@ -1034,3 +1034,6 @@ int mi_resampler_process_host(mi_resampler *r, const int16_t *h_in, int in_len, 
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_resample(reinterpret_cast<const void *>(&fill_pos_kernel));

@@ -916,3 +916,6 @@ int mi_volume_process_host(mi_volume *v, int16_t *h_samples, int nsamples, int s
 }
 
 } // extern "C"
+
+// (mi_warmup, ctx.hip: this unit's code object is loaded when the library is, not under a tick's first launch)
+static const mi::WarmEntry g_warm_volume(reinterpret_cast<const void *>(&volume_flip_kernel));

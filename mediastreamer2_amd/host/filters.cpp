@@ -486,8 +486,7 @@ void deliver_fused_in_scope(TickerHub &h);  // leg_chain.inl
 void deliver_server_in_scope(TickerHub &h); // server_leg.inl
 void deliver_recv_in_scope(TickerHub &h);   // recv_leg.inl
 void flush_hub(TickerHub &h) {
-	static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr; // A/B switch: one tick per facade again
-	h.in_flush = !no_chain || h.scope; // (a detaching graph's flush always runs its chain to the end: there is no next tick for it)
+	h.in_flush = true;
 	h.touched.clear();
 	h.touched_pumps.clear();
 	if (h.scope) deliver_server_in_scope(h);
@@ -514,7 +513,6 @@ void flush_hub(TickerHub &h) {
 			p->emit_all();
 			p->emitted();
 		}
-		if (!h.in_flush) break;
 		std::vector<MSFilter *> run;
 		run.swap(h.touched);
 		if (run.empty()) { // nothing but pumps left: they go last, once everything that feeds them has arrived
@@ -577,8 +575,7 @@ void facade_detached(MSFilter *f) {
 	if (!h) return;
 	HubLock lk(h, HubLock::Adopt{});
 	if (lk.dead()) return;
-	static const bool drop = getenv("MSMI355X_DROP_AT_DETACH") != nullptr; // A/B switch: the tick in flight is dropped, as up to round 4
-	if (!drop && f->ticker && h->ticker == f->ticker && !h->in_flush && !(h->drained_seq == h->stage_seq && h->drained.count(f))) {
+	if (f->ticker && h->ticker == f->ticker && !h->in_flush && !(h->drained_seq == h->stage_seq && h->drained.count(f))) {
 		std::unordered_set<MSFilter *> graph;
 		graph_of(f, graph);
 		h->scope = &graph;
@@ -658,7 +655,6 @@ void recv_stage_codes(MSFilter *f, MapFilter *d);
 void recv_plc_walk(MSFilter *f, PlcFilter *d);
 void recv_flow_drop(RecvLeg *leg, uint32_t drop, uint32_t total);
 void recv_flow_config(RecvLeg *leg, const MSAudioFlowControlConfig *cfg);
-bool recv_candidate(MSFilter *member);
 
 #include "filters/resample.inl"
 #include "filters/volume.inl"
@@ -769,7 +765,16 @@ void libmsmi355xfilters_init(MSFactory *factory) {
 			return;
 		}
 	} else {
+		// every device the hubs may land on gets the kernels' code objects now: the runtime would otherwise load them under the first
+		// launches of the ticker threads' first ticks (include/msmi355x.h: mi_warmup)
+		if (mi_warmup(probe) != MI_OK) ms_warning("libmsmi355xfilters: mi_warmup on device %d: %s", g_devices[0], mi_last_error());
 		mi_ctx_destroy(probe);
+		for (size_t i = 1; i < g_devices.size(); ++i) {
+			mi_ctx *c = nullptr;
+			if (mi_ctx_create(g_devices[i], nullptr, &c) != MI_OK) continue;
+			if (mi_warmup(c) != MI_OK) ms_warning("libmsmi355xfilters: mi_warmup on device %d: %s", g_devices[i], mi_last_error());
+			mi_ctx_destroy(c);
+		}
 	}
 	ms_factory_register_filter(factory, &ms_mi355x_resample_desc);
 	ms_factory_register_filter(factory, &ms_mi355x_audio_mixer_desc);

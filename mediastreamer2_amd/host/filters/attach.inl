@@ -55,6 +55,33 @@ void graph_preprocessed(MSFilter *f) { // (hub locked by the caller)
 	// receiving sides: decoder -> [local_mixer] -> MSGenericPLC -> [MSAudioFlowControl]
 	for (MSFilter *g : all)
 		if (is_g711_dec(g->desc) || g->desc == &ms_mi355x_generic_plc_desc) recv_chain_preprocessed(g);
+	// ... and every facade that did NOT join a batch takes the slot of its own it will need, here: a bank that has to be opened (pinned and
+	// device memory, the batch objects) is opened by the attaching thread, not by the ticker's first ticks.  (A mixer that can only forward
+	// never mixes, a forwarding MSResample never resamples: no slot.  MSResample takes its slots with its first block: one per channel.)
+	for (MSFilter *g : all) {
+		if (g->desc == &ms_mi355x_volume_desc) {
+			VolumeData *d = (VolumeData *)g->data;
+			if (!d->leg && !d->sleg && !d->meter_leg && !d->pool) volume_attach_slot(g);
+		} else if (is_ec_desc(g->desc)) {
+			SpeexECState *s = (SpeexECState *)g->data;
+			if (!s->leg && !__atomic_load_n(&s->bypass_live, __ATOMIC_RELAXED)) ec_acquire(g);
+		} else if (g->desc == &ms_mi355x_audio_mixer_desc) {
+			MixerState *s = (MixerState *)g->data;
+			if (!s->fbank && !s->sbank && !s->one_input) mixer_acquire(g);
+		} else if (is_g711_dec(g->desc)) {
+			MapFilter *d = (MapFilter *)g->data;
+			if (!d->rleg && !d->sleg) map_attach(g, d, d->law ? OP_ULAW_DEC : OP_ALAW_DEC);
+		} else if (is_g711_enc(g->desc)) {
+			MapFilter *d = (MapFilter *)g->data;
+			if (!d->fleg && !d->sleg) map_attach(g, d, d->law ? OP_ULAW_ENC : OP_ALAW_ENC);
+		} else if (g->desc == &ms_mi355x_generic_plc_desc) {
+			PlcFilter *d = (PlcFilter *)g->data;
+			if (!d->rleg && d->rate > 0) plc_attach(g, d);
+		} else if (g->desc == &ms_mi355x_audio_flow_control_desc) {
+			FlowFilter *d = (FlowFilter *)g->data;
+			if (!d->rleg && flowctl_attach(g, d)) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1)); // flowcontrol.c:166-169
+		}
+	}
 }
 void generic_preprocess(MSFilter *f) { // a facade with nothing of its own to prepare
 	HubLock lk(f);

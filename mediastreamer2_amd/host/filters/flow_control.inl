@@ -196,9 +196,8 @@ bool flowctl_attach(MSFilter *f, FlowFilter *d) {
 void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_reset
 	FlowFilter *d = (FlowFilter *)f->data;
 	HubLock lk(f);
-	graph_preprocessed(f);
-	if (d->rleg || recv_candidate(f)) return; // (fused: reset with its slot there; a chain that may still fuse: process() attaches -- and resets -- when it does not)
-	if (flowctl_attach(f, d)) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1));
+	(void)d;
+	graph_preprocessed(f); // (fused: reset with its slot there; else a slot of its own bank, reset, there or at its first block)
 }
 void flowctl_process(MSFilter *f) { // :171-183
 	FlowFilter *d = (FlowFilter *)f->data;

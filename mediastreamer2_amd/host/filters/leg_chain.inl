@@ -427,6 +427,9 @@ struct LegBank : Pool {
 		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
 		zero_copy = zero_copy_rows();
 		no_early = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr; // A/B switch: everything leaves at the flush
+		// the first tick's slabs are made here (the attaching thread opens the bank), not by that tick
+		if (!failed && enc_law < 0) (void)free_slab();
+		if (!failed) (void)new_spk_slab();
 	}
 	~LegBank() override {
 		if (root) freeb(root);
@@ -451,23 +454,13 @@ struct LegBank : Pool {
 	}
 	// a frame of `nbytes` for the speaker pin: a piece of this flush's slab (NULL: no slab to be had, the caller allocates)
 	mblk_t *spk_frame(size_t nbytes) {
-		static const bool off = getenv("MSMI355X_NO_SPK_SLAB") != nullptr; // A/B switch
-		if (off) return nullptr;
 		if (!spk_cur) {
 			for (SpkSlab *s : spk_slabs)
 				if (s->state.load(std::memory_order_acquire) == 0) {
 					spk_cur = s;
 					break;
 				}
-			if (!spk_cur && spk_slabs.size() < 6) {
-				const size_t bytes = (size_t)nlegs * kMaxRounds * 2 * (size_t)F * 2; // every leg's frames of a burst of kMaxRounds blocks
-				void *p = malloc(64 + bytes);
-				if (p) {
-					spk_cur = new (p) SpkSlab();
-					spk_cur->bytes = bytes;
-					spk_slabs.push_back(spk_cur);
-				}
-			}
+			if (!spk_cur && spk_slabs.size() < 6) spk_cur = new_spk_slab();
 			if (!spk_cur) return nullptr;
 			spk_cur->used = 0;
 			spk_cur->state.store(1, std::memory_order_release);
@@ -479,6 +472,16 @@ struct LegBank : Pool {
 		m->b_wptr = m->b_rptr + nbytes;
 		spk_cur->used += nbytes;
 		return m;
+	}
+	SpkSlab *new_spk_slab() {
+		const size_t bytes = (size_t)nlegs * kMaxRounds * 2 * (size_t)F * 2; // every leg's frames of a burst of kMaxRounds blocks
+		void *p = malloc(64 + bytes);
+		if (!p) return nullptr;
+		memset(p, 0, 64 + bytes); // (touched here, by whoever creates it -- the attaching thread for a bank's first -- not page by page in a tick)
+		SpkSlab *s = new (p) SpkSlab();
+		s->bytes = bytes;
+		spk_slabs.push_back(s);
+		return s;
 	}
 	void spk_flush_done() { // the flush's own reference: the slab returns to the ring when the last frame downstream is freed
 		if (spk_root) freeb(spk_root);
@@ -756,8 +759,7 @@ struct LegBank : Pool {
 		if (lone_ctl.size() != lone.size()) lone_ctl.assign(lone.size(), -1), moved = true;
 		for (size_t c = 0; c < lone.size(); ++c) {
 			if (!owner[c] && lone_ctl[c] >= 0) lone_ctl[c] = -1, moved = true; // (the slot was given up)
-			static const bool off = getenv("MSMI355X_LONE_KEEPS_ITS_CONTROLS") != nullptr; // A/B switch: as up to round 5
-			if (!off && owner[c] && conf_ready[c] && lone_ctl[c] != lone[c]) lone_ctl[c] = lone[c], moved = true; // (a conference that does not tick keeps what it had)
+			if (owner[c] && conf_ready[c] && lone_ctl[c] != lone[c]) lone_ctl[c] = lone[c], moved = true; // (a conference that does not tick keeps what it had)
 		}
 		if (!ctl_dirty && !moved) return;
 		eff_flags = flags, eff_gains = gains;
@@ -1950,8 +1952,6 @@ void leg_keep_volume(FusedLeg *leg) {
 void leg_return_canceller(LegBank *b, FusedLeg *leg, bool started) {
 	SpeexECState *es = (SpeexECState *)leg->ec->data;
 	if (b->failed || !es->pool || es->slot < 0 || es->pool->failed) return;
-	static const bool off = getenv("MSMI355X_UNFUSE_RESETS_CANCELLER") != nullptr; // A/B switch
-	if (off) return;
 	std::vector<uint8_t> blob(mi_aec_blob_bytes(b->aec));
 	if (mi_aec_export_state(b->aec, leg->slot, blob.data(), blob.size()) != MI_OK || mi_aec_import_state(es->pool->a, es->slot, blob.data(), blob.size()) != MI_OK) {
 		ms_warning("mi355x: a leg's canceller could not follow it out of its batch (%s): it starts over", mi_last_error());

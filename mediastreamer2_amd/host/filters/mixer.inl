@@ -430,8 +430,7 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	// stream out 10 ms of silence) where the reference's first walk finds only first looks (audiomixer.c:258-260)
 	if (s->first_walk && !g_hub.in_flush) {
 		s->first_walk = false;
-		static const bool no_chain = getenv("MSMI355X_NO_CHAIN") != nullptr;
-		if (!no_chain && all_inputs_ours(f) && !inputs_waiting(f)) {
+		if (all_inputs_ours(f) && !inputs_waiting(f)) {
 			ms_filter_unlock(f);
 			return;
 		}

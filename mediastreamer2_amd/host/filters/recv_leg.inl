@@ -567,23 +567,6 @@ void recv_chain_preprocessed(MSFilter *member) {
 	}
 	recv_try_fuse(head);
 }
-// could this filter still become part of a fused chain at this attach?  (structure only: then its preprocess opens no bank of its own)
-bool recv_candidate(MSFilter *member) {
-	static const bool off = getenv("MSMI355X_NO_FUSE_RECV") != nullptr;
-	if (off || getenv("MSMI355X_NO_FUSE") != nullptr) return false;
-	MSFilter *head = recv_head_of(member);
-	if (!head) return false;
-	MSFilter *g = head;
-	bool plc = false, fc = false;
-	for (int hops = 0; g && hops < 4; ++hops) {
-		plc |= g->desc == &ms_mi355x_generic_plc_desc;
-		fc |= g->desc == &ms_mi355x_audio_flow_control_desc;
-		g = g->outputs[0] ? g->outputs[0]->next.filter : NULL;
-		if (g && !(g->desc == &ms_mi355x_generic_plc_desc || g->desc == &ms_mi355x_audio_flow_control_desc || g->desc == &ms_mi355x_audio_mixer_desc)) break;
-	}
-	return plc && (is_g711_dec(head->desc) || fc);
-}
-
 // The chain leaves its batch: at detach (keep_running false; the tick in flight was delivered by the graph's scoped flush, what is
 // left is handed on here) or because a member stopped qualifying while attached -- the facades then carry on with banks of their own,
 // the PLC and the flow controller starting over as they do at an attach.  Any of the chain's facades may call; the first does the work.

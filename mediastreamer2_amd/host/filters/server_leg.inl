@@ -553,8 +553,7 @@ struct ServerBank : Pool {
 		if (lone_ctl.size() != lone.size()) lone_ctl.assign(lone.size(), -1), moved = true;
 		for (size_t c = 0; c < lone.size(); ++c) {
 			if (!owner[c] && lone_ctl[c] >= 0) lone_ctl[c] = -1, moved = true; // (the slot was given up)
-			static const bool off = getenv("MSMI355X_LONE_KEEPS_ITS_CONTROLS") != nullptr; // A/B switch: as up to round 5
-			if (!off && owner[c] && conf_ready[c] && lone_ctl[c] != lone[c]) lone_ctl[c] = lone[c], moved = true; // (a conference that does not tick keeps what it had)
+			if (owner[c] && conf_ready[c] && lone_ctl[c] != lone[c]) lone_ctl[c] = lone[c], moved = true; // (a conference that does not tick keeps what it had)
 		}
 		if (!ctl_dirty && !moved) return;
 		eff_flags = flags, eff_gains = gains;

@@ -310,8 +310,7 @@ void volume_far_end_changed(MSFilter *f, VolumeData *d) {
 	leg_disqualify(leg_fed_far_end_by(f));
 }
 bool volume_passes(const VolumeData *d) { // (hub locked)
-	static const bool off = getenv("MSMI355X_NO_METER_PASS") != nullptr; // A/B switch: a meter's blocks come back with the flush, as up to round 5
-	if (off || !d->feeds_far_end || d->chunks || d->p.agc_enabled || d->p.noise_gate_enabled || d->p.remove_dc || d->peer || d->p.static_gain != 1.f || !d->pool || d->slot < 0) return false;
+	if (!d->feeds_far_end || d->chunks || d->p.agc_enabled || d->p.noise_gate_enabled || d->p.remove_dc || d->peer || d->p.static_gain != 1.f || !d->pool || d->slot < 0) return false;
 	if ((ms_bufferizer_get_avail(d->spill) && !d->spill_quiet) || ms_bufferizer_get_avail(d->buffer)) return false;
 	const VolumePool *p = d->pool;
 	const size_t s = (size_t)d->slot;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 6: the first ticks after an attach (from_attach) and the steady state, for several shapes, paced, 16 tickers.
+# usage: scripts/r06_attach_probe.sh <tag> [legs=32768]
+tag=${1:-x}; legs=${2:-32768}
+out=gpurun_out/r06_attach_${tag}.txt
+make -C tests/host plugin_bench >/dev/null 2>&1
+uptime > $out
+T=$(python3 -c "import os;print(min(16,len(os.sched_getaffinity(0))))")
+for shape in "astream" "" "nomixer noagc" "server dec"; do
+  echo "== shape '$shape' legs $legs" >> $out
+  PLUGIN_BENCH_SHAPE="$shape" PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so $legs $T 250 40 >> $out 2>&1
+done
+echo "== shape '' legs 16384" >> $out
+PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so 16384 $T 250 40 >> $out 2>&1
+uptime >> $out
+python3 - <<PY
+import json
+for l in open("$out"):
+    if l.startswith("=="): print(l.strip())
+    if l.startswith("{"):
+        d=json.loads(l)
+        print({k:d[k] for k in ("legs","p50_ms","p99_ms","max_ms","late","us_per_leg_tick","ticker_flush_ms","ticker_graph_walk_ms","fused_legs","late_events","build_ms")}, d["from_attach"])
+PY

@@ -143,6 +143,10 @@ int mi_ctx_create(int device, void *hip_stream, mi_ctx **out) {
 	return MI_OK;
 }
 void mi_ctx_destroy(mi_ctx *c) { delete c; }
+int mi_warmup(mi_ctx *c) {
+	ARG(c);
+	return MI_OK;
+}
 int mi_ctx_sync(mi_ctx *c) {
 	ARG(c);
 	return MI_OK;

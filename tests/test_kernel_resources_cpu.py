@@ -49,8 +49,7 @@ def usages(remarks, kernel_substr):
 def test_tick_kernel_registers_and_lds(build):
     """every form of the tick kernel (rows / FIFOs / FIFOs + folded resampler: the MODE template parameter)"""
     _, _, remarks = build
-    # (ELb1E: the W-in-LDS experiment's instantiation -- MSMI355X_AEC_W_IN_LDS=1, profiles/r05_w_in_lds.txt -- is no product form)
-    big = [(n, u) for n, u in usages(remarks, "aec_tick_kernelILi256E") if "ELb1E" not in n]
+    big = list(usages(remarks, "aec_tick_kernelILi256E"))
     assert len(big) == 3, [n for n, _ in big]
     for name, u in big:
         assert int(u["VGPRs"]) <= 256 and int(u["VGPRs Spill"]) == 0, (name, u)
@@ -70,7 +69,7 @@ def test_tick_kernel_code_fits_the_instruction_cache(build):
         dev = obj
     syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-sW", str(dev)], capture_output=True, text=True).stdout
     sizes = {ln.split()[7]: int(ln.split()[2]) for ln in syms.splitlines() if " FUNC " in ln and "aec_tick_kernel" in ln}
-    big = {k: v for k, v in sizes.items() if "ILi256E" in k and "ELb1E" not in k}
+    big = {k: v for k, v in sizes.items() if "ILi256E" in k}
     assert len(big) == 3, syms[-2000:]
     assert max(big.values()) < 65536, f"a form of aec_tick_kernel<256> is over the 64 KB instruction cache: {big}"
     headline = [v for k, v in big.items() if "ILi256ELi2E" in k]  # FIFOs + folded resampler: what the headline and the plugin's fused chain launch
