@@ -71,13 +71,13 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="call legs per GPU; 0 = capacity sweep (largest count whose worst tick < 10 ms)")
     ap.add_argument("--sweep-lo", type=int, default=98304)
     ap.add_argument("--sweep-hi", type=int, default=163840)
-    ap.add_argument("--min-timed-s", type=float, default=0.5, help="the timed region is at least this long, whatever --steps says")
+    ap.add_argument("--min-timed-s", type=float, default=0.0, help="(off by default: EXACTLY --steps steps are timed) make the timed region at least this long; the line then carries steps_requested beside steps")
     ap.add_argument("--worst-ticks", type=int, default=3000, help="consecutive single ticks the worst tick is taken over")
     ap.add_argument("--zero-ticks", type=int, default=256, help="ticks of the from-reset test at the chosen count (0 = skip)")
     ap.add_argument("--paced-ticks", type=int, default=3000, help="ticks of the series run at the 10 ms cadence of an MSTicker, one per 10 ms of wall time: part of `value`'s criterion (0 = skip)")
     ap.add_argument("--accept-seconds", type=float, default=150.0, help="wall time the step-downs of the acceptance series may take before the next count is chosen with room for the largest machine event seen on this hardware (1.8 ms)")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the rate of full call legs through the drop-in plugin (tests/host/plugin_bench)")
-    ap.add_argument("--plugin-legs", type=int, default=49152, help="full call legs the plugin path is first tried with (config[3] is 32 768: 1024 conferences x 32)")
+    ap.add_argument("--plugin-legs", type=int, default=32768, help="full call legs the plugin path is first tried with (config[3]'s count: 1024 conferences x 32)")
     ap.add_argument("--no-video-host", action="store_true", help="skip the PCIe-inclusive video probe (config 5)")
     ap.add_argument("--roofline-ticks", type=int, default=32, help="eager ticks with HIP events around the canceller's launch")
     ap.add_argument("--from-reset", action="store_true", help="measure cancellers that start from reset instead of steady state")
@@ -1002,12 +1002,13 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
         at gets a second one if the first did not fit (the host's CPUs are shared; both runs are listed) -- it fits if either did
         (up to round 5's end every count got the second run: on a busy host the probe alone then took four minutes);
       * the search starts at `first_legs`, steps of 8192 legs (16 conferences of 32 per ticker): up a step at a time while the
-        count fits (three more at most), else the counts below are bisected; `legs` is the largest count that fit;
-        `legs_p99_criterion` reads the same runs by round 4's rule (p99 < 10 ms, never a whole interval behind);
-      * `host_noise_floor`: one more run of the same length at 128 legs per ticker -- a walk of ~0.2 ms -- says what THIS host does to a
-        ticker thread that has next to nothing to do (the pool's boxes are shared: some drop a tick of 600 even then, with the thread's
-        CPU time equal to the tick's wall time); `legs_at_host_noise_floor` reads the same runs as "no more ticks over 10 ms than the idle
-        walk showed".  Beside `legs`, never instead of it."""
+        count fits (three more at most), else the counts below are bisected; `legs` is the largest count that fit -- ONE criterion
+        (rounds 4 and 5 printed two more readings of the same runs beside it);
+      * the tickers fire SPREAD over the interval (ticker k at k x 10 ms / T: a server's MSTickers start with their conferences and
+        pace themselves from their own start, msticker.c:419-443) -- `phases` in every run's record says so;
+      * `us_per_leg_tick_by_load`: what the boundary costs a host core, the figure that does not depend on the neighbours' ticks: the
+        ticker threads' mean busy time per leg and tick at 1 024 / 2 048 / 3 072 legs per ticker, median of three paced runs each;
+        `legs_per_host_core` = 10 ms over the figure at 2 048."""
     import subprocess
     exe = os.path.join(ROOT, "tests", "host", "plugin_bench")
     plugin = os.path.join(ROOT, "mediastreamer2_amd", "libmsmi355xfilters.so")
@@ -1015,7 +1016,7 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
         subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "host"), "plugin_bench"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     ncores, quota = _host_cores()
     tickers = max(1, min(16, ncores))
-    keep = ("paced", "legs", "tickers", "ticks", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "msticker_late_events", "fits",
+    keep = ("paced", "phases", "legs", "tickers", "ticks", "p50_ms", "p99_ms", "p99_9_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "msticker_late_events", "fits",
             "us_per_leg_tick", "ticker_flush_ms", "ticker_graph_walk_ms", "launches_per_tick_and_ticker", "flush_rounds_per_tick_and_ticker",
             "fused_legs", "late_events", "worst_tick", "slow_ticks", "from_attach")
 
@@ -1042,11 +1043,9 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
         best = None
         for _ in range(2 if not tried else 1):
             d = run(legs, ticks)
-            # round 4's criterion beside the strict one (so that the two rounds' figures can be compared): p99 < 10 ms, never a whole interval behind
-            d["fits_p99"] = bool(d["p99_ms"] < 10.0 and d["max_backlog_ms"] < 10.0 and d["msticker_late_events"] == 0)
-            tried.append({k: d.get(k) for k in keep + ("fits_p99",)})
+            tried.append({k: d.get(k) for k in keep})
             if log:
-                log({"plugin_path" + ("_" + shape if shape else ""): {k: d.get(k) for k in keep + ("fits_p99",) if k != "slow_ticks"}})
+                log({"plugin_path" + ("_" + shape if shape else ""): {k: d.get(k) for k in keep if k != "slow_ticks"}})
             best = d if best is None or d["fits"] else best
             if d["fits"]:
                 break
@@ -1061,22 +1060,19 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
                    "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
                    "libmsmi355xfilters_init, one ticker thread per MSTicker in the test runtime (tests/host/plugin_bench.c); the plugin runs each "
                    "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl)",
-           "fits_definition": f"no tick of {ticks} paced ticks reaches 10 ms, no step starts a whole interval late; see the function's docstring",
+           "fits_definition": f"no tick of {ticks} paced ticks reaches 10 ms, no step starts a whole interval late; tickers' phases spread over the interval; see the function's docstring",
            "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
-    p99_ok = [t["legs"] for t in tried if t.get("fits_p99")]
-    out["legs_p99_criterion"] = max(p99_ok) if p99_ok else 0   # round 4's reading of the same runs: the largest count tried with p99 < 10 ms
-    try:
-        if best is not None and best["legs"] >= first_legs and extras:
-            raise StopIteration   # (the count the search started at fits: this host is quiet enough, no need to ask)
-        f0 = run(tickers * 128, ticks)
-        out["host_noise_floor"] = {k: f0.get(k) for k in ("legs", "ticks", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "max_backlog_ms", "slow_ticks")}
-        at_floor = [t["legs"] for t in tried if t.get("ticks_over_10ms") is not None and t["ticks_over_10ms"] <= f0["late"] and t["max_backlog_ms"] < 10.0
-                    and t["msticker_late_events"] == 0]
-        out["legs_at_host_noise_floor"] = max(at_floor) if at_floor else 0
-    except StopIteration:
-        pass
-    except Exception as e:
-        out["host_noise_floor"] = {"error": str(e)[:200]}
+    if extras:
+        try:  # the cost per leg and tick at three loads per ticker thread: median of three paced runs each
+            by_load = {}
+            for lpt in (1024, 2048, 3072):
+                us = sorted(run(tickers * lpt, 250)["us_per_leg_tick"] for _ in range(3))
+                by_load[str(lpt)] = round(us[1], 4)
+            out["us_per_leg_tick_by_load"] = by_load
+            out["legs_per_host_core"] = int(10000.0 / max(by_load["2048"], 1e-3))
+        except Exception as e:
+            out["us_per_leg_tick_by_load"] = {"error": str(e)[:200]}
+    out["legs_strict"] = int(best["legs"]) if best is not None else 0
     if best is None:
         out.update({"fits": False, "legs": 0})
         return out
@@ -1084,10 +1080,9 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
                                       "slow_ticks", "us_per_leg_tick", "from_attach")})
     out.update({"launches_per_tick": best["launches_per_tick_and_ticker"], "syncs_per_tick": best["flush_rounds_per_tick_and_ticker"], "fits": True,
                 "where_the_time_goes": {"per_ticker_mean_ms": {"plugin_flush": best["ticker_flush_ms"], "graph_walk": best["ticker_graph_walk_ms"]}}})
-    # what a host core carries: the ticker threads' mean busy time per tick against the 10 ms interval
-    busy = best["ticker_flush_ms"] + best["ticker_graph_walk_ms"]
-    out["legs_per_host_core"] = int(best["legs"] / tickers * 10.0 / max(busy, 1e-3))          # a core kept busy the whole interval
-    out["legs_per_host_core_at_this_load"] = int(best["legs"] / tickers)
+    if "legs_per_host_core" not in out:  # (no by-load figure: from the run that fit -- the ticker threads' mean busy time per tick against the interval)
+        busy = best["ticker_flush_ms"] + best["ticker_graph_walk_ms"]
+        out["legs_per_host_core"] = int(best["legs"] / tickers * 10.0 / max(busy, 1e-3))
     if not extras:
         return out
     try:  # the walk by filter id (MS2SHIM_PROFILE: a timer around every process()): the plugin's facades vs the test runtime's sources and sinks
@@ -1362,16 +1357,29 @@ class Headline:
         self.gfin.launch()
 
     def run(self, steps):
-        """`steps` ticks (a multiple of the scene period); returns HIP-event ms on the launch stream"""
+        """EXACTLY `steps` ticks: whole scene periods as the period's graph, what is left tick by tick; returns HIP-event ms on the
+        launch stream.  (A count that is no multiple of the period leaves the input ring mid-period: finish_period() runs the rest.)"""
         P = self.rig.RING
         self.ctx.timer_start()
         if self.world == 1:
             for _ in range(steps // P):
                 self.gp.launch()
+            for t in range(steps % P):
+                self.g1[t].launch()
         else:
             for t in range(steps):
                 self.graph_tick(t)
         return self.ctx.timer_stop()
+
+    def finish_period(self, steps):
+        """untimed: the ticks that complete the scene period a run of `steps` left open"""
+        P = self.rig.RING
+        for t in range(steps % P, P if steps % P else 0):
+            if self.world == 1:
+                self.g1[t].launch()
+            else:
+                self.graph_tick(t)
+        self.ctx.sync()
 
     def tick_series(self, nticks):
         """`nticks` consecutive deployed ticks (with the exchange and the finalize launch at N > 1), each timed alone"""
@@ -1522,6 +1530,8 @@ def short_line(full, detail_name):
     cfg = full.get("config", {})
     out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                     "scaling", "vs_baseline", "dtype", "data")}
+    if full.get("steps_requested") not in (None, full.get("steps")):
+        out["steps_requested"] = full["steps_requested"]
     out["unit"] = "concurrent 48 kHz streams"
     c = {"workload": WORKLOAD_SHORT}
     c.update(_pick(cfg, "streams_per_gpu", "conferences_per_gpu", "worst_tick_ms", "single_tick_median_ms", "fits",
@@ -1544,7 +1554,7 @@ def short_line(full, detail_name):
     out["config"] = c
     if "roofline" in full:
         r = full["roofline"]
-        out["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+        out["roofline"] = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_src", "avg_launch_us",
                                 "algorithmic_bytes_per_launch", "kernel", "timed_launches", "measured_copy_GBps", "error")
         out["roofline"]["units_per_launch"] = r.get("units_short")
         if "tick" in r:
@@ -1558,9 +1568,9 @@ def short_line(full, detail_name):
     if pp:
         out["plugin_path"] = _pick(pp, "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
                                    "launches_per_tick", "syncs_per_tick", "max_backlog_ms", "host_cores_granted",
-                                   "legs_per_host_core", "host_cores_for_value", "legs_p99_criterion", "legs_at_host_noise_floor", "fits", "error")
-        if isinstance(pp.get("host_noise_floor"), dict):
-            out["plugin_path"]["host_noise_floor"] = _pick(pp["host_noise_floor"], "legs", "ticks_over_10ms", "max_ms", "error")
+                                   "legs_per_host_core", "legs_strict", "host_cores_for_value", "fits", "error")
+        if isinstance(pp.get("us_per_leg_tick_by_load"), dict):
+            out["plugin_path"]["us_per_leg_tick_by_load"] = pp["us_per_leg_tick_by_load"]
         eq = pp.get("fused_equals_one_by_one_4096_legs")
         if eq:
             out["plugin_path"]["fused_equals_one_by_one"] = eq.get("equal")
@@ -1572,7 +1582,7 @@ def short_line(full, detail_name):
     for key in ("plugin_path_server",):
         if full.get(key):
             out[key] = _pick(full[key], "legs", "tickers", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "us_per_leg_tick",
-                             "launches_per_tick", "pcie_bytes_per_leg_tick", "legs_p99_criterion", "fits", "error")
+                             "launches_per_tick", "pcie_bytes_per_leg_tick", "fits", "error")
     if "scaler_mpix_per_s" in full:
         sc = full["scaler_mpix_per_s"]
         out["scaler"] = {"mpix_per_s": sc.get("value"), "frac": sc.get("hbm_frac"), "frames_per_s": sc.get("frames_per_s")}
@@ -1803,13 +1813,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # K steps bracketed by (synchronize + barrier) on both sides.  A step is one 10 ms tick of every leg; the steps are
-    # whole scene periods (16 ticks: 30 canceller frames per leg) and at least --min-timed-s seconds, whatever --steps says.
+    # EXACTLY K = --steps steps bracketed by (synchronize + barrier) on both sides.  A step is one 10 ms tick of every leg (a scene
+    # period is 16 ticks: 30 canceller frames per leg; whole periods replay the period's graph, the rest go tick by tick).
     P = rig.RING
-    ctx.timer_start()
-    head.run(P)
-    est = ctx.timer_stop() / P
-    steps = -(-max(a.steps, int(np.ceil(a.min_timed_s * 1e3 / max(est, 1e-3)))) // P) * P
+    steps = max(1, a.steps)
+    if a.min_timed_s > 0:  # (asked for explicitly: the line then carries steps_requested beside steps)
+        ctx.timer_start()
+        head.run(P)
+        est = ctx.timer_stop() / P
+        steps = max(steps, int(np.ceil(a.min_timed_s * 1e3 / max(est, 1e-3))))
     if dist is not None:
         steps = int(reduce_scalar(float(steps), "MAX"))
     sync_local()
@@ -1819,6 +1831,7 @@ def main():
     sync_local()
     dt = time.perf_counter() - t0
     barrier()
+    head.finish_period(steps)
     dt = reduce_scalar(dt, "MAX")
     ev_ms = reduce_scalar(ev_ms, "MAX")
 
@@ -1908,6 +1921,8 @@ def main():
             r["units_short"] = f"{n_local} leg-ticks = {frames / launches:.0f} frames of 256 samples"
             r["timed_launches"] = launches
             r["traffic_source"] = pmc[1] if pmc else None
+            # (the short line says where `traffic` comes from: never measured by THIS run -- counters need rocprofv3 passes of their own)
+            r["traffic_src"] = None if not pmc else ("profiles@%d" % n_local if " at %d legs" % n_local in pmc[1] else "profiles, scaled to %d legs" % n_local)
         except Exception as e:
             r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "error": str(e)[:200]}
         tick_alg = n_local * (AEC_FRAMES_PER_TICK * AEC_FRAME_BYTES + 1280 + 1920 + 1920)

@@ -289,7 +289,9 @@ static void *run(void *arg) {
 			}
 		}
 		const double w0 = now_ms();
+		if (g_stack_ms > 0 && getenv("PLUGIN_BENCH_STACKS_WARMUP")) g_step_start[j->index] = mono_ns(); /* (the first ticks after the attach too) */
 		ms_ticker_step(j->ticker);
+		g_step_start[j->index] = 0;
 		j->warm_ms[t] = now_ms() - w0;
 	}
 	if (g_paced) pthread_barrier_wait(&g_bar); /* (the warm-up is through on every ticker) */

@@ -222,7 +222,7 @@ def test_the_default_audiostream_adds_one_tick_per_direction(host, oracle):
     (+ the canceller's own framing: 64-sample frames out of 80-sample blocks).  Stated in INTEGRATION.md; asserted here on a lossless call."""
     sc = dict(fg.SCENARIOS["audiostream_8k_default_features"], members=3, nticks=60, events=[])
     res = fg.run(PKG, True, sc, host)
-    assert res["stats"]["legs"] == 3 and res["stats"]["recv_streams"] == 3 and res["stats"]["flush_rounds"] <= 32   # (read at tick 30: one round per tick)
+    assert res["stats"]["legs"] == 3 and res["stats"]["recv_streams"] == 3   # (one flush round per tick: tests/test_plugin_fused_cpu.py holds the count)
     sent, spk = _audiostream_oracle(oracle, dict(sc, lossless=True), 3, "fused")
     for s in range(3):
         np.testing.assert_array_equal(res["spk"][s], spk[s][:len(res["spk"][s])])

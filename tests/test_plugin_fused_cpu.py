@@ -62,6 +62,10 @@ def test_one_flush_round_per_tick_and_few_launches(verdict):
     v = verdict["plain"]
     assert v["fused_stats"]["flush_rounds"] <= 61 and v["plain_stats"]["flush_rounds"] >= 200, v
     assert v["fused_stats"]["launches"] <= 4 * 62 + 8, v   # (the bank's work for tick t+1 leaves at the end of walk t; a conference that joins mid-walk costs a second batch once)
+    # the reference's default AudioStream (both mixers, flow control, the encoder in the leg's batch): ONE round per tick for both directions
+    # (stats read at tick 60 of 120, a re-plumbing at 61), where the facades one by one take six
+    d = verdict["audiostream_8k_default_features"]
+    assert d["fused_stats"]["flush_rounds"] <= 61 and d["plain_stats"]["flush_rounds"] >= 300, d
 
 
 @pytest.mark.parametrize("paced", [False, True])
