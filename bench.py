@@ -1072,6 +1072,15 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
             out["legs_per_host_core"] = int(10000.0 / max(by_load["2048"], 1e-3))
         except Exception as e:
             out["us_per_leg_tick_by_load"] = {"error": str(e)[:200]}
+        try:  # conferences re-plumbed under load, as MSAudioConference does around every join and leave (audioconference.c:322-374)
+            ch = run(tickers * 2048, 400, {"PLUGIN_BENCH_CHURN": "20"})
+            out["churn"] = {"legs": ch["legs"], "legs_per_ticker": 2048, "ticks": ch["ticks"], "p50_ms": ch["p50_ms"], "p99_ms": ch["p99_ms"], "max_ms": ch["max_ms"],
+                            "ticks_over_10ms": ch["late"], "replumbing": ch.get("churn"), "late_events": ch["late_events"],
+                            "what": "every ticker detaches and re-attaches one whole conference graph (32 legs: postprocess + preprocess of every filter, the fused batch "
+                                    "left and joined again) 20 times a second, ON the ticker thread in front of the step (counted in the tick: the test runtime has no "
+                                    "attach lock; the reference does it on the application's thread, msticker.c:153-183)"}
+        except Exception as e:
+            out["churn"] = {"error": str(e)[:200]}
     out["legs_strict"] = int(best["legs"]) if best is not None else 0
     if best is None:
         out.update({"fits": False, "legs": 0})
@@ -1571,6 +1580,8 @@ def short_line(full, detail_name):
                                    "legs_per_host_core", "legs_strict", "host_cores_for_value", "fits", "error")
         if isinstance(pp.get("us_per_leg_tick_by_load"), dict):
             out["plugin_path"]["us_per_leg_tick_by_load"] = pp["us_per_leg_tick_by_load"]
+        if isinstance(pp.get("churn"), dict):
+            out["plugin_path"]["churn"] = _pick(pp["churn"], "legs", "p50_ms", "p99_ms", "max_ms", "ticks_over_10ms", "error")
         eq = pp.get("fused_equals_one_by_one_4096_legs")
         if eq:
             out["plugin_path"]["fused_equals_one_by_one"] = eq.get("equal")

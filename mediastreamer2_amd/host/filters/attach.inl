@@ -79,7 +79,10 @@ void graph_preprocessed(MSFilter *f) { // (hub locked by the caller)
 			if (!d->rleg && d->rate > 0) plc_attach(g, d);
 		} else if (g->desc == &ms_mi355x_audio_flow_control_desc) {
 			FlowFilter *d = (FlowFilter *)g->data;
-			if (!d->rleg && flowctl_attach(g, d)) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1)); // flowcontrol.c:166-169
+			if (!d->rleg) {
+				const bool had = d->pool != nullptr;
+				if (flowctl_attach(g, d) && had) MI_MUST(mi_flowctl_reset(d->pool->fc, d->slot, 1)); // flowcontrol.c:166-169 (a new slot is at rest already)
+			}
 		}
 	}
 }

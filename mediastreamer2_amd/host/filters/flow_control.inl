@@ -19,6 +19,7 @@ struct FlowPool : Pool {
 	std::vector<uint32_t> later_drop, later_total;
 	bool have_later = false;
 	std::vector<int> staged, ready;
+	std::vector<uint8_t> used; // the slot has had a filter since the bank was created (a fresh one is a controller at rest with the default configuration: mi_flowctl_create)
 	std::vector<std::vector<mblk_t *>> held, done; // the blocks themselves: the dropper edits them in place
 	explicit FlowPool(int cap) {
 		Building b(this, cap);
@@ -42,6 +43,7 @@ struct FlowPool : Pool {
 		later_total.assign(c, 0);
 		staged.assign(c, 0);
 		ready.assign(c, 0);
+		used.assign(c, 0);
 		held.resize(c);
 		done.resize(c);
 	}
@@ -188,9 +190,12 @@ bool flowctl_attach(MSFilter *f, FlowFilter *d) {
 	note_slot(f);
 	d->pool = p;
 	d->slot = sl;
-	MI_MUST(mi_flowctl_reset(d->pool->fc, sl, 1));
-	MI_MUST(mi_flowctl_set_config(d->pool->fc, sl, 1, d->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT,
-	                              d->config.silent_threshold));
+	const bool was_used = p->used[(size_t)sl] != 0, dflt = d->config.strategy != MSAudioFlowControlBasic && d->config.silent_threshold == 0.02f; // flowcontrol.c:37-41
+	p->used[(size_t)sl] = 1;
+	if (was_used) MI_MUST(mi_flowctl_reset(d->pool->fc, sl, 1));
+	if (was_used || !dflt)
+		MI_MUST(mi_flowctl_set_config(d->pool->fc, sl, 1, d->config.strategy == MSAudioFlowControlBasic ? MI_FLOWCTL_BASIC : MI_FLOWCTL_SOFT,
+		                              d->config.silent_threshold));
 	return true;
 }
 void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_reset

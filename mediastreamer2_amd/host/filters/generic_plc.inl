@@ -43,6 +43,7 @@ struct PlcPool : Pool {
 	int32_t *h_len, *d_len, *h_lensc;   // (h_lensc / h_modesc: the rounds' rows while a detaching graph's slots alone are flushed)
 	uint8_t *h_mode, *d_mode, *h_modesc;
 	std::vector<int> staged;
+	std::vector<uint8_t> used; // the slot has had a filter since the bank was created (a fresh one IS a fresh context: mi_plc_create)
 	std::vector<std::vector<PlcEntry>> pending, done;
 	PlcPool(int cap, int r) : rate(r) {
 		Building b(this, cap);
@@ -57,6 +58,7 @@ struct PlcPool : Pool {
 		d_len = devmem<int32_t>(c);
 		d_mode = devmem<uint8_t>(c);
 		staged.assign(c, 0);
+		used.assign(c, 0);
 		pending.resize(c);
 		done.resize(c);
 	}
@@ -181,7 +183,8 @@ bool plc_attach(MSFilter *f, PlcFilter *d) { // generic_plc_preprocess :55-58: a
 	note_slot(f);
 	d->pool = p;
 	d->slot = sl;
-	MI_MUST(mi_plc_reset(d->pool->plc, sl, 1));
+	if (p->used[(size_t)sl]) MI_MUST(mi_plc_reset(d->pool->plc, sl, 1));
+	p->used[(size_t)sl] = 1;
 	return true;
 }
 void plc_preprocess(MSFilter *f) {

@@ -57,6 +57,9 @@ struct VolumePool : Pool {
 		bool also_gain, also_target, whole; // whole: `state[slot]` itself is to be written (a new slot's start state)
 	};
 	std::vector<GainPatch> gain_patch;
+	std::vector<uint8_t> used;         // the slot has had a filter since the bank was created
+	mi_volume_params params0;          // what mi_volume_create leaves in every slot: a new filter whose parameters and start state
+	mi_volume_state state0;            // are these needs no device call at all (volume_attach_slot)
 	VolumePool(int cap, int r) : rate(r) {
 		Building b(this, cap);
 		if (!failed) MI_MUST(mi_volume_create(hub->ctx, capacity, rate, &v));
@@ -75,8 +78,11 @@ struct VolumePool : Pool {
 		mi_volume_params p;
 		mi_volume_default_params(&p);
 		params.assign(c, p);
+		params0 = p;
 		state.resize(c);
 		if (!failed) MI_MUST(mi_volume_get_state(v, 0, capacity, state.data()));
+		state0 = state[0];
+		used.assign(c, 0);
 		params_dirty.assign(c, 0);
 		state_dirty.assign(c, 0);
 		gain_patch.assign(c, GainPatch{1.f, 1.f, false, false, false});
@@ -87,19 +93,34 @@ struct VolumePool : Pool {
 	bool enqueue() override {
 		mi_ctx *ctx = hub->ctx;
 		const size_t c = (size_t)capacity, u = (size_t)hi; // rows [0, hi) are all that was ever handed out
-		for (int s = 0; s < hi; ++s) {
-			if (params_dirty[(size_t)s] == 1) {
-				MI_MUST(mi_volume_set_params(v, s, 1, &params[(size_t)s]));
-				params_dirty[(size_t)s] = 0;
-			}
+		// (runs of neighbouring slots go up in ONE call each: every call waits for the stream, and a ticker's streams attached together are
+		// thousands of neighbours -- one call per slot took sixteen tickers' first flush to a second)
+		for (int s = 0; s < hi; ++s)
 			if (state_dirty[(size_t)s] == 1) {
 				GainPatch &g = gain_patch[(size_t)s];
 				if (g.also_gain) state[(size_t)s].gain = g.gain;
 				if (g.also_target) state[(size_t)s].target_gain = g.target;
-				MI_MUST(mi_volume_set_state(v, s, 1, &state[(size_t)s]));
 				g = GainPatch{1.f, 1.f, false, false, false};
-				state_dirty[(size_t)s] = 0;
 			}
+		for (int s = 0; s < hi;) {
+			if (params_dirty[(size_t)s] != 1) {
+				++s;
+				continue;
+			}
+			int e = s;
+			while (e < hi && params_dirty[(size_t)e] == 1) params_dirty[(size_t)e++] = 0;
+			MI_MUST(mi_volume_set_params(v, s, e - s, &params[(size_t)s]));
+			s = e;
+		}
+		for (int s = 0; s < hi;) {
+			if (state_dirty[(size_t)s] != 1) {
+				++s;
+				continue;
+			}
+			int e = s;
+			while (e < hi && state_dirty[(size_t)e] == 1) state_dirty[(size_t)e++] = 0;
+			MI_MUST(mi_volume_set_state(v, s, e - s, &state[(size_t)s]));
+			s = e;
 		}
 		int maxr = 0;
 		for (int s = 0; s < hi; ++s)
@@ -360,6 +381,7 @@ void volume_attach_slot(MSFilter *f) {
 		}
 	}
 	HubLock lk(f);
+	bool fresh = false;
 	if (!d->pool) {
 		const int rate = d->sample_rate;
 		d->pool = bank<VolumePool>("volume:" + std::to_string(rate), 1, [&](int cap) { return new VolumePool(cap, rate); });
@@ -373,6 +395,8 @@ void volume_attach_slot(MSFilter *f) {
 		d->pool->state[(size_t)d->slot] = volume_start_state(d);
 		d->pool->state_dirty[(size_t)d->slot] = 1;
 		d->pool->gain_patch[(size_t)d->slot] = VolumePool::GainPatch{1.f, 1.f, false, false, true};
+		fresh = !d->pool->used[(size_t)d->slot];
+		d->pool->used[(size_t)d->slot] = 1;
 	}
 	// the peer is addressed by its slot in the same pool
 	d->p.peer = -1;
@@ -382,6 +406,15 @@ void volume_attach_slot(MSFilter *f) {
 		else ms_warning("MSVolume[mi355x]: peer not in the same batch yet (different rate or not attached)");
 	}
 	volume_push_params(d, false); // (a slot's first parameters: at once)
+	if (fresh && d->pool && d->slot >= 0) { // a slot nobody has used: what mi_volume_create left there may be exactly what this filter starts with
+		VolumePool *p = d->pool;
+		const size_t s = (size_t)d->slot;
+		if (p->params_dirty[s] == 1 && memcmp(&p->params[s], &p->params0, sizeof(p->params0)) == 0) p->params_dirty[s] = 0;
+		if (p->state_dirty[s] == 1 && p->gain_patch[s].whole && memcmp(&p->state[s], &p->state0, sizeof(p->state0)) == 0) {
+			p->state_dirty[s] = 0;
+			p->gain_patch[s] = VolumePool::GainPatch{1.f, 1.f, false, false, false};
+		}
+	}
 }
 
 void volume_preprocess(MSFilter *f) { // msvolume.c:447-469

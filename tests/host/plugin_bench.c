@@ -69,6 +69,8 @@ typedef struct {
 	int tot_ids[16];        /* MS2SHIM_PROFILE=1: every timed step's process() time by filter id, summed */
 	uint64_t tot_ns[16];
 	int *nvcsw, *nivcsw, *minflt;        /* per tick: voluntary / involuntary context switches, minor page faults of the thread */
+	double *churn_ms;                    /* PLUGIN_BENCH_CHURN: what the re-plumbing in front of this tick's step took (0: none) */
+	int churn_next;                      /* ... the conference (or leg) re-plumbed next */
 } TickerJob;
 
 static MSFactory *g_fac;
@@ -266,6 +268,13 @@ static void *watchdog(void *arg) {
  * (audioconference.c:70-73) and each paces itself from its own start (msticker.c:419-443,496-515): their phases are spread over the
  * interval, they do not all fire in the same instant.  PLUGIN_BENCH_ALIGNED=1: all at once (the worst case; every tick before round 5) */
 static int g_aligned;
+/* PLUGIN_BENCH_CHURN=<n>: n times a second every ticker has ONE conference (or, without mixers, one leg) re-plumbed the way
+ * ms_audio_conference_add_member / remove_member do around every join and leave (src/voip/audioconference.c:322-374): the whole conference
+ * graph detached and attached again -- every filter's postprocess and preprocess, the fused batch left and joined -- while the ticker
+ * carries its full load.  The reference does this on the application's thread (msticker.c:153-183 takes the ticker's lock only to splice
+ * the sources); this runtime has no such lock, so it happens on the ticker thread in front of the step and COUNTS AGAINST THE TICK
+ * (conservative: step_ms includes it). */
+static int g_churn;
 static uint64_t phase_ns(int index) { return g_aligned ? 0 : (uint64_t)index * (10000000ull / (uint64_t)g_tickers); }
 
 static void *run(void *arg) {
@@ -314,6 +323,14 @@ static void *run(void *arg) {
 		const double c0 = thread_cpu_ms();
 		const double t0 = now_ms();
 		if (g_stack_ms > 0 && t > 50) g_step_start[j->index] = mono_ns();
+		if (g_churn > 0 && t % (100 / g_churn > 0 ? 100 / g_churn : 1) == (j->index % (100 / g_churn > 0 ? 100 / g_churn : 1))) {
+			const int units = g_nomixer ? j->nconf * g_members : j->nconf;
+			MSFilter *root = g_nomixer ? j->heads[j->churn_next % units] : j->mixers[j->churn_next % units];
+			j->churn_next++;
+			ms_ticker_detach(j->ticker, root);
+			ms_ticker_attach(j->ticker, root);
+			j->churn_ms[t] = now_ms() - t0;
+		}
 		ms_ticker_step(j->ticker);
 		g_step_start[j->index] = 0;
 		j->step_ms[t] = now_ms() - t0;
@@ -360,6 +377,8 @@ int main(int argc, char **argv) {
 	g_profile = getenv("MS2SHIM_PROFILE") != NULL;
 	g_paced = getenv("PLUGIN_BENCH_PACED") != NULL;
 	g_aligned = getenv("PLUGIN_BENCH_ALIGNED") != NULL;
+	g_churn = getenv("PLUGIN_BENCH_CHURN") ? atoi(getenv("PLUGIN_BENCH_CHURN")) : 0;
+	if (g_churn > 100) g_churn = 100;
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
@@ -423,6 +442,7 @@ int main(int argc, char **argv) {
 		jobs[i].nvcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
 		jobs[i].nivcsw = (int *)calloc((size_t)g_ticks, sizeof(int));
 		jobs[i].minflt = (int *)calloc((size_t)g_ticks, sizeof(int));
+		jobs[i].churn_ms = (double *)calloc((size_t)g_ticks, sizeof(double));
 		build(&jobs[i]);
 	}
 	const double build_ms = now_ms() - t_build0;
@@ -594,6 +614,18 @@ int main(int argc, char **argv) {
 				if (jobs[i].spks[k]) spk_sum += ms2shim_sink_sum(jobs[i].spks[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
 				out_bytes += ms2shim_sink_size(jobs[i].outs[k]);
 			}
+	char churn[256] = "null";
+	if (g_churn > 0) { /* the re-plumbings: how many, what one took (median, longest) */
+		double *ops = (double *)calloc((size_t)g_ticks * (size_t)g_tickers, sizeof(double));
+		int nops = 0;
+		for (int i = 0; i < g_tickers; ++i)
+			for (int t = 0; t < g_ticks; ++t)
+				if (jobs[i].churn_ms[t] > 0) ops[nops++] = jobs[i].churn_ms[t];
+		qsort(ops, (size_t)nops, sizeof(double), cmp_d);
+		snprintf(churn, sizeof(churn), "{\"per_second_and_ticker\": %d, \"replumbings\": %d, \"p50_ms\": %.3f, \"p99_ms\": %.3f, \"max_ms\": %.3f, \"counted_in_the_tick\": true}", g_churn, nops,
+		         nops ? pct(ops, nops, 0.5) : 0.0, nops ? pct(ops, nops, 0.99) : 0.0, nops ? ops[nops - 1] : 0.0);
+		free(ops);
+	}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);
 	printf("{\"paced\": %s, \"phases\": \"%s\", \"legs\": %d, \"members\": %d, \"conferences\": %d, \"tickers\": %d, \"ticks\": %d, \"warmup\": %d, "
 	       "\"p50_ms\": %.4f, \"p99_ms\": %.4f, \"max_ms\": %.4f, \"late\": %d, \"wall_ms_per_tick\": %.4f, "
@@ -603,14 +635,14 @@ int main(int argc, char **argv) {
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
 	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
 	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s], "
-	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}, \"from_attach\": %s}\n",
+	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}, \"from_attach\": %s, \"churn\": %s}\n",
 	       g_paced ? "true" : "false", !g_paced ? "barrier" : (g_aligned ? "aligned" : "spread"), legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
 	       worst_t, worst_i, jobs[worst_i].step_ms[worst_t], jobs[worst_i].task_ms[worst_t], pct(sorted, g_ticks, 0.999), wall_ms / g_ticks,
 	       max_backlog, ref_late_events, sum_cpu / ((double)g_ticks * g_tickers), (double)sum_flt / ((double)g_ticks * g_tickers),
-	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid, fa);
+	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid, fa, churn);
 	fflush(stdout);
 	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
 	if (getenv("PLUGIN_BENCH_CLEAN_EXIT")) exit(0); /* (under rocprofv3: its summary is written by an exit handler) */

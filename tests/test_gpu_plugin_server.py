@@ -134,12 +134,15 @@ def test_server_conference_is_the_oracle_chains(host, runs, oracle, name, form):
 def test_g711_endpoints_in_a_wideband_conference_against_the_oracle_chain(host, oracle, form):
     """DIRECT: G.711 endpoints in a 16 kHz conference (audioconference.c:209-257: the endpoints' resamplers work) against the chain of
     oracle objects -- oracle.Volume at 8 kHz -> oracle.Resampler 8k -> 16k -> OracleMixer at 16 kHz -> oracle.Resampler 16k -> 8k ->
-    oracle.g711_encode.  The resampler is held to the library's order within 1 LSB, and a sample that moves by one can cross
-    a G.711 decision level: the packets are the oracle's except for rare neighbouring code words -- fewer than 2 % of the bytes, and
-    the decoded audio within 1e-3 RMS of full scale."""
+    oracle.g711_encode.  FIRST the PCM in front of the encoders (the same conference with PCM endpoints: what the out_resamplers hand
+    on): within 1 LSB and 1e-4 RMS of full scale of the oracle chain -- north_star's bar for the float resampler (the library's order
+    is held within 1 LSB).  THEN the packets: exactly the G.711 of THAT PCM (the encoder is integer work, pinned against the
+    reference's own g711.c) -- and, because a sample that moves by one can cross a G.711 decision level, the oracle's packets except for
+    rare neighbouring code words: fewer than 2 % of the bytes."""
     sc = {"rate": 16000, "endpoint_rate": 8000, "law": "mixed", "nconf": 1, "members": 3, "nticks": 120}
     res = sg.run(PKG, form == "fused", sc, host)
-    assert (res["stats"]["legs"] > 0) == (form == "fused")
+    tap = sg.run(PKG, form == "fused", dict(sc, pcm_pins=(0, 1, 2)), host)   # the same call, every endpoint a PCM one: the mixes as the out_resamplers leave them
+    assert (res["stats"]["legs"] > 0) == (form == "fused") and (tap["stats"]["legs"] > 0) == (form == "fused")
     n, nt = 3, sc["nticks"]
     pcm = sg.signals(n, nt, 8000, seed=5)
     law_of = lambda k: "a" if k % 2 else "u"
@@ -156,10 +159,14 @@ def test_g711_endpoints_in_a_wideband_conference_against_the_oracle_chain(host, 
             heard[pin].append(down[pin].process(row))
     for k in range(n):
         L = 0 if law_of(k) == "a" else 1
-        want = oracle.g711_encode(L, np.concatenate(heard[k]))
+        want_pcm = np.concatenate(heard[k])
+        got_pcm = np.asarray(tap["out"][k])
+        assert 0 <= len(want_pcm) - len(got_pcm) <= 320 and len(got_pcm) > 8000, (k, len(got_pcm), len(want_pcm))
+        e = got_pcm.astype(np.int64) - want_pcm[:len(got_pcm)].astype(np.int64)
+        assert np.abs(e).max() <= 1, (k, int(np.abs(e).max()))
+        assert np.sqrt(np.mean((e / 32768.0) ** 2)) <= 1e-4
+        want = oracle.g711_encode(L, want_pcm)
         got = np.asarray(res["out"][k]).view(np.uint8)
         assert 0 <= len(want) - len(got) <= 320 and len(got) > 8000, (k, len(got), len(want))
-        want = want[:len(got)]
-        assert np.mean(got != want) < 0.02, (k, float(np.mean(got != want)))
-        d = (oracle.g711_decode(L, got).astype(np.float64) - oracle.g711_decode(L, want).astype(np.float64)) / 32768.0
-        assert np.sqrt(np.mean(d * d)) < 1e-3, (k, float(np.sqrt(np.mean(d * d))))
+        np.testing.assert_array_equal(got, oracle.g711_encode(L, got_pcm)[:len(got)])   # the packets ARE the G.711 of the tapped PCM
+        assert np.mean(got != want[:len(got)]) < 0.02, (k, float(np.mean(got != want[:len(got)])))
