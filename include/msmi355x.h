@@ -133,6 +133,9 @@ int mi_resampler_reset(mi_resampler *r, int first, int count);
 int mi_resampler_state_bytes(const mi_resampler *r);
 int mi_resampler_get_state(mi_resampler *r, int stream, void *h_state, size_t cap);
 int mi_resampler_set_state(mi_resampler *r, int stream, const void *h_state, size_t bytes);
+/* ... of streams [first, first + count), mi_resampler_state_bytes() each, back to back: one round trip for a conference's members */
+int mi_resampler_get_states(mi_resampler *r, int first, int count, void *h_states, size_t cap);
+int mi_resampler_set_states(mi_resampler *r, int first, int count, const void *h_states, size_t bytes);
 /* msresample.c:151-152: in_len*out_rate/in_rate + 1 */
 int mi_resampler_out_capacity(const mi_resampler *r, int in_len);
 /* filter facts for tests/DESIGN: taps per phase, phases (den_rate), num_rate,
@@ -482,6 +485,12 @@ int mi_fifo_overflows(mi_fifo *f, int32_t *h_count);
 /* debug / parity read-back (like mi_aec_get): the rings as they lie, [nstreams][capacity], and per stream the read position
  * and the level -- the samples a fused launch queued can be checked without popping them.  Any pointer may be NULL.  Syncs. */
 int mi_fifo_snapshot(mi_fifo *f, int16_t *h_rings, int32_t *h_head, int32_t *h_level);
+/* The queues of streams [first, first + count) as a host sees MSBufferizers (stream k's h_level[k] samples, oldest first, at h_samples +
+ * k * stride; stride >= the capacity) -- and back, every stream of the range replaced.  tail_at_end: the queue ends on the ring's end, as
+ * mi_fifo_reset_range_at + pushes leave it (levels then are multiples of 8).  One round trip for a whole conference that is re-plumbed
+ * (src/voip/audioconference.c:322-374: what its members' bufferizers hold outlives the detach).  Both wait for the stream. */
+int mi_fifo_export_range(mi_fifo *f, int first, int count, int16_t *h_samples, int stride, int32_t *h_level);
+int mi_fifo_import_range(mi_fifo *f, int first, int count, const int16_t *h_samples, int stride, const int32_t *h_level, int tail_at_end);
 int mi_fifo_reset(mi_fifo *f);
 int mi_fifo_reset_range(mi_fifo *f, int first, int count); /* empty the FIFOs of streams [first, first+count) */
 /* ... empty, with the read position at ring offset `head` (a multiple of 8, < capacity).  The canceller's launches append whole

@@ -166,6 +166,17 @@ class ResamplerBatch(_Batch):
         buf = (C.c_uint8 * len(state)).from_buffer_copy(state)
         check(self.ctx.L.mi_resampler_set_state(self.h, int(stream), buf, len(state)))
 
+    def get_states(self, first, count):
+        """the states of streams [first, first + count) back to back, one round trip: mi_resampler_get_states"""
+        n = self.ctx.L.mi_resampler_state_bytes(self.h) * count
+        buf = (C.c_uint8 * n)()
+        check(self.ctx.L.mi_resampler_get_states(self.h, int(first), int(count), buf, n))
+        return bytes(buf)
+
+    def set_states(self, first, count, states):
+        buf = (C.c_uint8 * len(states)).from_buffer_copy(states)
+        check(self.ctx.L.mi_resampler_set_states(self.h, int(first), int(count), buf, len(states)))
+
     def reset(self, first=0, count=None):
         check(self.ctx.L.mi_resampler_reset(self.h, first, self.nstreams - first if count is None else count))
 
@@ -633,6 +644,22 @@ class FifoBatch(_Batch):
         head, level = np.zeros(self.nstreams, np.int32), np.zeros(self.nstreams, np.int32)
         check(self.ctx.L.mi_fifo_snapshot(self.h, _ptr(rings), _ptr(head), _ptr(level)))
         return rings, head, level
+
+    def export_range(self, first, count):
+        """the queues of streams [first, first + count) as a host sees bufferizers: a list of int16 arrays, oldest sample first (syncs)"""
+        x = np.zeros((count, self.capacity), np.int16)
+        level = np.zeros(count, np.int32)
+        check(self.ctx.L.mi_fifo_export_range(self.h, first, count, _ptr(x), self.capacity, _ptr(level)))
+        return [x[k, :level[k]].copy() for k in range(count)]
+
+    def import_range(self, first, queues, tail_at_end=False):
+        """... and back: every stream of the range holds exactly its list entry (mi_fifo_import_range)"""
+        x = np.zeros((len(queues), self.capacity), np.int16)
+        level = np.zeros(len(queues), np.int32)
+        for k, q in enumerate(queues):
+            x[k, :len(q)] = q
+            level[k] = len(q)
+        check(self.ctx.L.mi_fifo_import_range(self.h, first, len(queues), _ptr(x), self.capacity, _ptr(level), int(tail_at_end)))
 
     def push_silence(self, count):
         """count [nstreams] int32 (device): samples of silence appended per stream (mi_fifo_push_silence)"""

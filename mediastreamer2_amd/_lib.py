@@ -27,7 +27,7 @@ EXPORTS = [
     "mi_dev_alloc", "mi_dev_free", "mi_host_alloc", "mi_host_free", "mi_copy_h2d", "mi_copy_d2h", "mi_copy_h2d_pinned", "mi_copy_d2h_pinned", "mi_memset",
     "mi_ctx_capture_begin", "mi_ctx_capture_end", "mi_graph_launch", "mi_graph_destroy",
     "mi_timer_start", "mi_timer_stop",
-    "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_state_bytes", "mi_resampler_get_state", "mi_resampler_set_state", "mi_resampler_out_capacity",
+    "mi_resampler_create", "mi_resampler_destroy", "mi_resampler_reset", "mi_resampler_state_bytes", "mi_resampler_get_state", "mi_resampler_set_state", "mi_resampler_get_states", "mi_resampler_set_states", "mi_resampler_out_capacity",
     "mi_resampler_info", "mi_resampler_get_table", "mi_resampler_process", "mi_resampler_process_host",
     "mi_resampler_process_masked", "mi_mixer_process_masked", "mi_equalizer_process_masked",
     "mi_mixer_create", "mi_mixer_destroy", "mi_mixer_set_controls", "mi_mixer_process",
@@ -52,7 +52,7 @@ EXPORTS = [
     "mi_flowctl_create", "mi_flowctl_destroy", "mi_flowctl_set_config", "mi_flowctl_request_drop", "mi_flowctl_process",
     "mi_flowctl_get_state", "mi_flowctl_reset",
     "mi_plc_create", "mi_plc_destroy", "mi_plc_reset", "mi_plc_process", "mi_plc_info",
-    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range", "mi_fifo_reset_range_at", "mi_fifo_push_silence", "mi_fifo_snapshot",
+    "mi_fifo_create", "mi_fifo_destroy", "mi_fifo_push", "mi_fifo_push_gated", "mi_fifo_pop", "mi_fifo_pop_frames", "mi_fifo_push_frames", "mi_fifo_levels", "mi_fifo_push_lead", "mi_fifo_phase_of", "mi_fifo_overflows", "mi_fifo_reset", "mi_fifo_reset_range", "mi_fifo_reset_range_at", "mi_fifo_push_silence", "mi_fifo_snapshot", "mi_fifo_export_range", "mi_fifo_import_range",
 ]
 
 
@@ -138,6 +138,8 @@ def load():
     L.mi_resampler_state_bytes.argtypes = [vp]
     L.mi_resampler_get_state.argtypes = [vp, i32, vp, C.c_size_t]
     L.mi_resampler_set_state.argtypes = [vp, i32, vp, C.c_size_t]
+    L.mi_resampler_get_states.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    L.mi_resampler_set_states.argtypes = [vp, i32, i32, vp, C.c_size_t]
     L.mi_resampler_out_capacity.argtypes = [vp, i32]
     L.mi_resampler_info.argtypes = [vp] + [C.POINTER(i32)] * 4
     L.mi_resampler_get_table.argtypes = [vp, vp, i32]
@@ -276,6 +278,8 @@ def load():
         L.mi_fifo_reset_range_at.argtypes = [vp, i32, i32, i32]
         L.mi_fifo_push_silence.argtypes = [vp, vp]
         L.mi_fifo_snapshot.argtypes = [vp, vp, vp, vp]
+        L.mi_fifo_export_range.argtypes = [vp, i32, i32, vp, i32, vp]
+        L.mi_fifo_import_range.argtypes = [vp, i32, i32, vp, i32, vp, i32]
     if hasattr(L, "mi_g711_decode"):
         L.mi_g711_decode.argtypes = [vp, i32, vp, sz, vp, sz, vp, i32, sz]
         L.mi_g711_encode.argtypes = [vp, i32, vp, sz, vp, sz, vp, i32, sz]

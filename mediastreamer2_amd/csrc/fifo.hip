@@ -387,6 +387,45 @@ int mi_fifo_snapshot(mi_fifo *f, int16_t *h_rings, int32_t *h_head, int32_t *h_l
 	return MI_OK;
 }
 
+// The queues of streams [first, first + count) as a host sees MSBufferizers: stream k's h_level[k] samples, oldest first, at h_samples +
+// k * stride -- and back.  A conference that is re-plumbed (audioconference.c:322-374) takes what its members' bufferizers hold out of the
+// batch and back in: one round trip for all of them (mi_fifo_pop / push, all-or-nothing per piece length, took one per member and length).
+int mi_fifo_export_range(mi_fifo *f, int first, int count, int16_t *h_samples, int stride, int32_t *h_level) {
+	MI_CHECK_ARG(f && h_samples && h_level && first >= 0 && count >= 0 && first + count <= f->nstreams && stride >= f->capacity);
+	if (count == 0) return MI_OK;
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	std::vector<int16_t> rings((size_t)count * f->capacity);
+	std::vector<int2> pos((size_t)count);
+	MI_HIP(hipStreamSynchronize(f->ctx->stream));
+	MI_HIP(hipMemcpy(rings.data(), f->d_ring + (size_t)first * f->capacity, rings.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+	MI_HIP(hipMemcpy(pos.data(), f->d_pos + first, pos.size() * sizeof(int2), hipMemcpyDeviceToHost));
+	for (int k = 0; k < count; ++k) {
+		const int head = pos[(size_t)k].x, level = pos[(size_t)k].y;
+		h_level[k] = level;
+		for (int i = 0; i < level; ++i) h_samples[(size_t)k * stride + i] = rings[(size_t)k * f->capacity + (size_t)((head + i) % f->capacity)];
+	}
+	return MI_OK;
+}
+// tail_at_end: the queue ENDS on the ring's end (head = capacity - level: the canceller's launches append whole frames at a tail they take to
+// be frame-aligned, mi_fifo_reset_range_at); levels then are multiples of 8.  Otherwise the queue starts at the ring's start.
+int mi_fifo_import_range(mi_fifo *f, int first, int count, const int16_t *h_samples, int stride, const int32_t *h_level, int tail_at_end) {
+	MI_CHECK_ARG(f && h_samples && h_level && first >= 0 && count >= 0 && first + count <= f->nstreams);
+	if (count == 0) return MI_OK;
+	for (int k = 0; k < count; ++k) MI_CHECK_ARG(h_level[k] >= 0 && h_level[k] <= f->capacity && h_level[k] <= stride && (!tail_at_end || (h_level[k] & 7) == 0));
+	if (f->ctx->activate() != MI_OK) return MI_ENODEV;
+	std::vector<int16_t> rings((size_t)count * f->capacity, 0);
+	std::vector<int2> pos((size_t)count);
+	for (int k = 0; k < count; ++k) {
+		const int level = h_level[k], head = (tail_at_end && level > 0) ? (f->capacity - level) % f->capacity : 0;
+		pos[(size_t)k] = make_int2(head, level);
+		for (int i = 0; i < level; ++i) rings[(size_t)k * f->capacity + (size_t)((head + i) % f->capacity)] = h_samples[(size_t)k * stride + i];
+	}
+	MI_HIP(hipStreamSynchronize(f->ctx->stream));
+	MI_HIP(hipMemcpy(f->d_ring + (size_t)first * f->capacity, rings.data(), rings.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+	MI_HIP(hipMemcpy(f->d_pos + first, pos.data(), pos.size() * sizeof(int2), hipMemcpyHostToDevice));
+	return MI_OK;
+}
+
 int mi_fifo_overflows(mi_fifo *f, int32_t *h_count) {
 	MI_CHECK_ARG(f && h_count);
 	if (f->ctx->activate() != MI_OK) return MI_ENODEV;

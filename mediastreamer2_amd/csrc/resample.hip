@@ -900,6 +900,43 @@ int mi_resampler_set_state(mi_resampler *r, int stream, const void *h_state, siz
 	return MI_OK;
 }
 
+// the same for streams [first, first + count), mi_resampler_state_bytes() each, back to back: one round trip for a conference's members
+int mi_resampler_get_states(mi_resampler *r, int first, int count, void *h_states, size_t cap) {
+	const size_t each = r ? (size_t)mi_resampler_state_bytes(r) : 0;
+	MI_CHECK_ARG(r && h_states && first >= 0 && count >= 0 && first + count <= r->nstreams && cap >= each * (size_t)count);
+	if (count == 0) return MI_OK;
+	if (r->ctx->activate() != MI_OK) return MI_ENODEV;
+	std::vector<int2> pos((size_t)count);
+	std::vector<int16_t> hist((size_t)count * r->hist_stride);
+	MI_HIP(hipStreamSynchronize(r->ctx->stream));
+	MI_HIP(hipMemcpy(pos.data(), r->d_pos + first, pos.size() * sizeof(int2), hipMemcpyDeviceToHost));
+	MI_HIP(hipMemcpy(hist.data(), r->d_hist + (size_t)first * r->hist_stride, hist.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+	uint8_t *dst = static_cast<uint8_t *>(h_states);
+	for (int k = 0; k < count; ++k) {
+		memcpy(dst + (size_t)k * each, &pos[(size_t)k], sizeof(int2));
+		memcpy(dst + (size_t)k * each + sizeof(int2), hist.data() + (size_t)k * r->hist_stride, (size_t)r->hist_stride * sizeof(int16_t));
+	}
+	return MI_OK;
+}
+int mi_resampler_set_states(mi_resampler *r, int first, int count, const void *h_states, size_t bytes) {
+	const size_t each = r ? (size_t)mi_resampler_state_bytes(r) : 0;
+	MI_CHECK_ARG(r && h_states && first >= 0 && count >= 0 && first + count <= r->nstreams && bytes == each * (size_t)count);
+	if (count == 0) return MI_OK;
+	if (r->ctx->activate() != MI_OK) return MI_ENODEV;
+	std::vector<int2> pos((size_t)count);
+	std::vector<int16_t> hist((size_t)count * r->hist_stride);
+	const uint8_t *src = static_cast<const uint8_t *>(h_states);
+	for (int k = 0; k < count; ++k) {
+		memcpy(&pos[(size_t)k], src + (size_t)k * each, sizeof(int2));
+		memcpy(hist.data() + (size_t)k * r->hist_stride, src + (size_t)k * each + sizeof(int2), (size_t)r->hist_stride * sizeof(int16_t));
+		if (pos[(size_t)k].x != 0 || pos[(size_t)k].y != 0) r->phase_zero = false;
+	}
+	MI_HIP(hipStreamSynchronize(r->ctx->stream));
+	MI_HIP(hipMemcpy(r->d_pos + first, pos.data(), pos.size() * sizeof(int2), hipMemcpyHostToDevice));
+	MI_HIP(hipMemcpy(r->d_hist + (size_t)first * r->hist_stride, hist.data(), hist.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+	return MI_OK;
+}
+
 int mi_resampler_out_capacity(const mi_resampler *r, int in_len) {
 	if (!r || in_len < 0) return MI_EINVAL;
 	return (int)((((uint32_t)in_len * r->out_rate) / r->in_rate) + 1);

@@ -427,9 +427,14 @@ struct LegBank : Pool {
 		if (const char *e = getenv("MSMI355X_TRACE_SLOW_MS")) trace_ms = atof(e);
 		zero_copy = zero_copy_rows();
 		no_early = getenv("MSMI355X_NO_EARLY_LAUNCH") != nullptr; // A/B switch: everything leaves at the flush
-		// the first tick's slabs are made here (the attaching thread opens the bank), not by that tick
-		if (!failed && enc_law < 0) (void)free_slab();
-		if (!failed) (void)new_spk_slab();
+		// the first ticks' slabs are made here (the attaching thread opens the bank), not by those ticks: two of each -- a flush's blocks
+		// are still held downstream when the next flush needs its slab
+		for (int i = 0; i < 2 && !failed && enc_law < 0; ++i) {
+			MixSlab *s = free_slab();
+			if (s) s->state.store(1, std::memory_order_release); // (so that the second call makes a second one)
+		}
+		for (MixSlab *s : slabs) s->state.store(0, std::memory_order_release);
+		for (int i = 0; i < 2 && !failed; ++i) (void)new_spk_slab();
 	}
 	~LegBank() override {
 		if (root) freeb(root);
@@ -669,15 +674,21 @@ struct LegBank : Pool {
 			FusedLeg *leg = legs[(size_t)s];
 			return &((MixerState *)leg->mixer->data)->channels[leg->pin].bufferizer;
 		};
-		std::vector<int> want((size_t)count, 0);
+		// the queues come back in ONE round trip for the whole range (mi_fifo_export_range: a conference that is re-plumbed with every
+		// join and leave, audioconference.c:322-374, used to pay one pop, copy and wait per member and piece length)
+		std::vector<int32_t> lvl((size_t)count, 0);
+		std::vector<int16_t> x((size_t)count * (size_t)out_cap);
 		if (light) {
+			if (mi_fifo_export_range(f_chan, s0, count, x.data(), out_cap, lvl.data()) != MI_OK || mi_fifo_reset_range(f_chan, s0, count) != MI_OK) {
+				mi_failed("taking the mixer channels' queues back");
+				return;
+			}
 			for (int s = s0; s < s0 + count; ++s)
 				if (FusedLeg *leg = legs[(size_t)s]) {
-					want[(size_t)(s - s0)] = leg->chan_samples + leg->new_samples;
+					const int n = std::min(lvl[(size_t)(s - s0)], leg->chan_samples + leg->new_samples);
+					if (n > 0) bufferizer_put_samples(channel_of(s), x.data() + (size_t)(s - s0) * out_cap, n);
 					leg->chan_samples = leg->new_samples = 0;
 				}
-			if (!fifo_take(ctx, f_chan, nlegs, s0, ns, d_scratch, d_dgate_any(), want, [&](int s, const int16_t *x, int n) { bufferizer_put_samples(channel_of(s), x, n); }))
-				mi_failed("taking the mixer channels' queues back");
 			return;
 		}
 		if (keep_running) {
@@ -704,39 +715,53 @@ struct LegBank : Pool {
 			for (int s = s0; s < s0 + count; ++s)
 				if (legs[(size_t)s]) legs[(size_t)s]->chan_chunks = legs[(size_t)s]->newchunks = 0;
 		}
+		if (mi_fifo_export_range(f_out, s0, count, x.data(), out_cap, lvl.data()) != MI_OK || mi_fifo_reset_range(f_out, s0, count) != MI_OK) {
+			mi_failed("taking MSVolume's queued samples back");
+			return;
+		}
 		for (int s = s0; s < s0 + count; ++s)
 			if (FusedLeg *leg = legs[(size_t)s]) {
-				want[(size_t)(s - s0)] = (leg->chan_chunks + leg->newchunks) * chunk + leg->vol_rem;
+				const int n = std::min(lvl[(size_t)(s - s0)], (leg->chan_chunks + leg->newchunks) * chunk + leg->vol_rem);
+				if (n > 0) bufferizer_put_samples(((VolumeData *)leg->vol->data)->buffer, x.data() + (size_t)(s - s0) * out_cap, n);
 				leg->chan_chunks = leg->newchunks = leg->vol_rem = 0;
 			}
-		if (!fifo_take(ctx, f_out, nlegs, s0, chunk, d_scratch, d_dgate_any(), want,
-		               [&](int s, const int16_t *x, int n) { bufferizer_put_samples(((VolumeData *)legs[(size_t)s]->vol->data)->buffer, x, n); }))
-			mi_failed("taking MSVolume's queued samples back");
 	}
-	// ... and the other way round when a leg joins the bank at slot s: the samples in its MSVolume's bufferizer (whole chunks in front
-	// of them: what the mixer channel held at the detach), the mixer channel's bufferizer of a bank without AGC
+	// ... and the other way round when legs join the bank at slots [s0, s0 + count): the samples in each one's MSVolume's bufferizer (whole
+	// chunks in front of them: what the mixer channel held at the detach), the mixer channel's bufferizer of a bank without AGC -- staged
+	// per leg (give_remainder) between give_begin and give_end, which sends them to the device in one round trip (mi_fifo_import_range)
+	std::vector<int16_t> imp_x;
+	std::vector<int32_t> imp_n;
+	int imp_s0 = 0, imp_count = 0;
+	bool imp_any = false;
+	void give_begin(int s0, int count) {
+		imp_s0 = s0, imp_count = count, imp_any = false;
+		imp_n.assign((size_t)count, 0);
+	}
 	bool give_remainder(int s, VolumeData *vd, FusedLeg *leg) {
-		mi_ctx *ctx = hub->ctx;
+		MSBufferizer *bz = vd->buffer;
 		if (light) {
 			if (plain) return true;
-			MSBufferizer *cb = &((MixerState *)leg->mixer->data)->channels[leg->pin].bufferizer;
-			const int n = (int)(ms_bufferizer_get_avail(cb) / 2);
-			if (n <= 0) return true;
-			std::vector<int16_t> x((size_t)n);
-			ms_bufferizer_read(cb, (uint8_t *)x.data(), (size_t)n * 2);
-			if (!fifo_give(ctx, f_chan, nlegs, s, ns, d_scratch, d_cnt, x.data(), n)) return false;
-			leg->chan_samples = n;
-			return true;
+			bz = &((MixerState *)leg->mixer->data)->channels[leg->pin].bufferizer;
 		}
-		const int rem = (int)(ms_bufferizer_get_avail(vd->buffer) / 2);
-		if (rem <= 0) return true;
-		std::vector<int16_t> x((size_t)rem);
-		ms_bufferizer_read(vd->buffer, (uint8_t *)x.data(), (size_t)rem * 2);
-		// (the canceller appends whole frames at a tail it takes to be frame-aligned: the queue starts `rem` short of the ring's end)
-		if (mi_fifo_reset_range_at(f_out, s, 1, out_cap - rem) != MI_OK || !fifo_give(ctx, f_out, nlegs, s, chunk, d_scratch, d_cnt, x.data(), rem)) return false;
-		leg->chan_chunks = plain ? 0 : rem / chunk;
-		leg->vol_rem = rem - leg->chan_chunks * chunk;
+		const int n = (int)(ms_bufferizer_get_avail(bz) / 2);
+		if (n <= 0) return true;
+		if (n > out_cap || (!light && (n & 7))) return false;
+		if (!imp_any) imp_x.assign((size_t)imp_count * (size_t)out_cap, 0);
+		imp_any = true;
+		ms_bufferizer_read(bz, (uint8_t *)(imp_x.data() + (size_t)(s - imp_s0) * out_cap), (size_t)n * 2);
+		imp_n[(size_t)(s - imp_s0)] = n;
+		if (light) {
+			leg->chan_samples = n;
+		} else {
+			leg->chan_chunks = plain ? 0 : n / chunk;
+			leg->vol_rem = n - leg->chan_chunks * chunk;
+		}
 		return true;
+	}
+	bool give_end() { // (every stream of the range is written: the others are empty, as start_slots left them.  The canceller appends whole frames at a tail it takes to be frame-aligned: f_out's queues end on the ring's end)
+		if (!imp_any) return true;
+		imp_any = false;
+		return mi_fifo_import_range(light ? f_chan : f_out, imp_s0, imp_count, imp_x.data(), out_cap, imp_n.data(), light ? 0 : 1) == MI_OK;
 	}
 	uint8_t *d_dgate_any() {
 		if (!d_takegate) d_takegate = devmem<uint8_t>((size_t)nlegs);
@@ -1850,6 +1875,12 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		return false;
 	}
 	for (int pin = 0; pin < mm; ++pin) b->flags[(size_t)(s0 + pin)] = 0, b->gains[(size_t)(s0 + pin)] = 1.0f;
+	b->give_begin(s0, mm);
+	// MSResample's position and history follow the filters from slot to slot (msresample.c:117-120: the handle outlives a detach): the
+	// conference's members in one round trip (a slot without a state to restore keeps a fresh stream's: zeros, as start_slots left it)
+	const size_t rs_each = b->rs ? (size_t)mi_resampler_state_bytes(b->rs) : 0;
+	std::vector<uint8_t> rs_buf(rs_each * (size_t)mm, 0);
+	bool rs_any = false;
 	for (const LegCand &cd : cand) {
 		FusedLeg *leg = new FusedLeg();
 		leg->bank = b, leg->slot = s0 + cd.pin, leg->pin = cd.pin;
@@ -1865,7 +1896,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 				if (rd->slots->size() == 1) resample_keep_from(rd, rd->pool->r, rd->slot, rd->input_rate, rd->output_rate);
 				resample_release(rd);
 			}
-			resample_restore_to(rd, b->rs, leg->slot, b->in_rate, b->rate, true);
+			if (rs_each) rs_any |= resample_restore_bytes(rd, rs_buf.data() + (size_t)cd.pin * rs_each, rs_each, b->in_rate, b->rate, true);
 			rd->leg = leg;
 		}
 		ms_bufferizer_flush(&es->delayed_ref); // the delay line lives on the device now
@@ -1884,6 +1915,8 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		if (cd.peer && !leg_take_peer(b, leg, cd.peer)) mi_failed("taking the echo limiter's peer into the batch");
 		if (cd.eq && !leg_take_equalizer(b, leg, cd.eq)) mi_failed("taking the leg's equalizer into the batch");
 	}
+	if (!b->give_end()) mi_failed("moving MSVolume's queued samples to the device");
+	if (rs_any && mi_resampler_set_states(b->rs, s0, mm, rs_buf.data(), rs_buf.size()) != MI_OK) mi_failed("moving the resamplers' states to the device");
 	if (ms->pool) { // (a conference that had mixed on its facade before: normally preprocess opens no slot, mixer_acquire)
 		ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
 		ms->pool->release(ms->slot);
@@ -1991,13 +2024,16 @@ void conf_unfuse(MSFilter *mx, bool keep_running) {
 	b->deliver_in_flight(mx, c);
 	b->settle_meters();
 	b->take_remainders(c * mm, mm, keep_running);
+	const size_t rs_each = (b->rs && !b->failed) ? (size_t)mi_resampler_state_bytes(b->rs) : 0;
+	std::vector<uint8_t> rs_buf(rs_each * (size_t)mm);
+	const bool rs_ok = rs_each && mi_resampler_get_states(b->rs, c * mm, mm, rs_buf.data(), rs_buf.size()) == MI_OK; // (the members' in one round trip)
 	for (int pin = 0; pin < mm; ++pin) {
 		FusedLeg *leg = b->legs[(size_t)(c * mm + pin)];
 		if (!leg) continue;
 		leg_keep_volume(leg);
 		leg_drop_peer(b, leg);
 		leg_drop_equalizer(b, leg);
-		if (leg->rs && b->rs && !b->failed) resample_keep_from((ResampleData *)leg->rs->data, b->rs, leg->slot, b->in_rate, b->rate);
+		if (leg->rs && rs_ok) resample_keep_bytes((ResampleData *)leg->rs->data, rs_buf.data() + (size_t)pin * rs_each, rs_each, b->in_rate, b->rate);
 		b->legs[(size_t)(c * mm + pin)] = nullptr;
 		if (leg->rs) ((ResampleData *)leg->rs->data)->leg = nullptr;
 		((SpeexECState *)leg->ec->data)->leg = nullptr;
@@ -2120,7 +2156,8 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 		vd->pool = nullptr, vd->slot = -1;
 	}
 	vd->leg = leg;
-	if (!b->give_remainder(s, vd, leg)) mi_failed("moving MSVolume's queued samples to the device");
+	b->give_begin(s, 1);
+	if (!b->give_remainder(s, vd, leg) || !b->give_end()) mi_failed("moving MSVolume's queued samples to the device");
 	if (peer && !leg_take_peer(b, leg, peer)) mi_failed("taking the echo limiter's peer into the batch");
 	if (eqf && !leg_take_equalizer(b, leg, eqf)) mi_failed("taking the leg's equalizer into the batch");
 	if (encf) {

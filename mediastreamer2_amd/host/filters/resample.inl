@@ -97,6 +97,26 @@ bool resample_restore_to(ResampleData *d, mi_resampler *r, int slot, uint32_t in
 	return ok;
 }
 
+// the same out of / into a buffer of mi_resampler_get_states / set_states (a whole conference's members in one round trip).
+// restore: dst keeps what it holds -- a fresh stream's state, zeros -- when there is nothing to restore
+void resample_keep_bytes(ResampleData *d, const uint8_t *src, size_t each, uint32_t in_rate, uint32_t out_rate) {
+	d->kept->clear();
+	if (each == 0 || d->in_nchannels != 1) return;
+	d->kept->assign(src, src + each);
+	d->kept_in = in_rate, d->kept_out = out_rate;
+}
+bool resample_restore_bytes(ResampleData *d, uint8_t *dst, size_t each, uint32_t in_rate, uint32_t out_rate, bool whole_periods_only) {
+	if (d->kept->empty() || d->kept_in != in_rate || d->kept_out != out_rate || d->kept->size() != each) return false;
+	if (whole_periods_only) {
+		int32_t pos[2];
+		memcpy(pos, d->kept->data(), sizeof(pos));
+		if (pos[0] != 0 || pos[1] != 0) return false;
+	}
+	memcpy(dst, d->kept->data(), each);
+	d->kept->clear();
+	return true;
+}
+
 void resample_init(MSFilter *f) { // msresample.c:44-54,:62-80
 	ResampleData *d = (ResampleData *)ms_malloc0(sizeof(*d));
 	d->bz = ms_bufferizer_new();

@@ -21,3 +21,11 @@ for l in open("$out"):
         d=json.loads(l)
         print({k:d[k] for k in ("legs","p50_ms","p99_ms","max_ms","late","us_per_leg_tick","ticker_flush_ms","ticker_graph_walk_ms","fused_legs","late_events","build_ms")}, d["from_attach"])
 PY
+echo "== churn: 20 re-plumbings a second per ticker, 2048 legs per ticker" | tee -a $out
+PLUGIN_BENCH_CHURN=20 PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so 32768 $T 400 40 2>/dev/null | tee -a $out | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ('legs','p50_ms','p99_ms','max_ms','late','us_per_leg_tick','fused_legs','late_events','churn')})"
+echo "== churn, server dec shape" | tee -a $out
+PLUGIN_BENCH_SHAPE="server dec" PLUGIN_BENCH_CHURN=20 PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so 32768 $T 400 40 2>/dev/null | tee -a $out | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ('legs','p50_ms','p99_ms','max_ms','late','us_per_leg_tick','fused_legs','late_events','churn')})"

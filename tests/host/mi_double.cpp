@@ -209,6 +209,15 @@ int mi_resampler_set_state(mi_resampler *r, int stream, const void *h_state, siz
 	ARG(r && h_state && stream >= 0 && stream < r->n && bytes == 8);
 	return MI_OK;
 }
+int mi_resampler_get_states(mi_resampler *r, int first, int count, void *h, size_t cap) {
+	ARG(r && h && first >= 0 && count >= 0 && first + count <= r->n && cap >= 8 * (size_t)count);
+	memset(h, 0, 8 * (size_t)count);
+	return MI_OK;
+}
+int mi_resampler_set_states(mi_resampler *r, int first, int count, const void *h, size_t bytes) {
+	ARG(r && h && first >= 0 && count >= 0 && first + count <= r->n && bytes == 8 * (size_t)count);
+	return MI_OK;
+}
 int mi_resampler_reset(mi_resampler *r, int first, int count) {
 	ARG(r && first >= 0 && count >= 0 && first + count <= r->n);
 	return MI_OK;
@@ -866,6 +875,23 @@ int mi_fifo_reset_range(mi_fifo *f, int first, int count) {
 int mi_fifo_reset_range_at(mi_fifo *f, int first, int count, int head) { // (the double's queues have no ring: the offset is moot)
 	ARG(f && head >= 0 && (head & 7) == 0);
 	return mi_fifo_reset_range(f, first, count);
+}
+int mi_fifo_export_range(mi_fifo *f, int first, int count, int16_t *h, int stride, int32_t *level) {
+	ARG(f && h && level && first >= 0 && count >= 0 && first + count <= f->n && stride >= f->cap);
+	for (int k = 0; k < count; ++k) {
+		const std::vector<int16_t> &q = f->q[(size_t)(first + k)];
+		level[k] = (int32_t)q.size();
+		std::copy(q.begin(), q.end(), h + (size_t)k * stride);
+	}
+	return MI_OK;
+}
+int mi_fifo_import_range(mi_fifo *f, int first, int count, const int16_t *h, int stride, const int32_t *level, int tail_at_end) {
+	ARG(f && h && level && first >= 0 && count >= 0 && first + count <= f->n);
+	for (int k = 0; k < count; ++k) {
+		ARG(level[k] >= 0 && level[k] <= f->cap && level[k] <= stride && (!tail_at_end || (level[k] & 7) == 0));
+		f->q[(size_t)(first + k)].assign(h + (size_t)k * stride, h + (size_t)k * stride + level[k]);
+	}
+	return MI_OK;
 }
 int mi_fifo_reset(mi_fifo *f) {
 	ARG(f);

@@ -850,6 +850,74 @@ def test_an_output_queue_that_starts_short_of_a_frame(ctx):
         np.testing.assert_array_equal(shifted[s][r:r + m], plain[s][:m], err_msg=f"leg {s} (r = {r})")
 
 
+def test_queues_and_resampler_states_of_a_range_in_one_round_trip(ctx):
+    """mi_fifo_export_range / import_range and mi_resampler_get_states / set_states: what a conference that is re-plumbed
+    (audioconference.c:322-374) takes out of its batch and back in for all of its members at once.  export == what pops would have
+    delivered, sample for sample, across a wrapped ring; import(tail_at_end) == mi_fifo_reset_range_at + push (head, level, content);
+    the neighbours of the range are untouched; a resampler whose states went out and into OTHER slots continues bit for bit."""
+    torch = pytest.importorskip("torch")
+    n, cap = 10, 64 * 8
+    f = ms.FifoBatch(ctx, n, cap)
+    rng = np.random.default_rng(5)
+    held = [np.zeros(0, np.int16) for _ in range(n)]
+    out, ok = torch.zeros((n, 96), dtype=torch.int16, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+    for t in range(40):   # pushes of ragged counts and pops: the heads wrap several times
+        cnt = rng.integers(0, 121, n).astype(np.int32) // 8 * 8
+        x = rng.integers(-30000, 30000, (n, 120)).astype(np.int16)
+        f.push(torch.from_numpy(x).cuda(), nsamples=120, count=torch.from_numpy(cnt).cuda())
+        for s in range(n):
+            held[s] = np.concatenate([held[s], x[s, :cnt[s]]])
+        f.pop(96, out, ok=ok, zero_fill=False)
+        ctx.sync()
+        o, k = out.cpu().numpy(), ok.cpu().numpy()
+        for s in range(n):
+            if k[s]:
+                assert np.array_equal(o[s], held[s][:96])
+                held[s] = held[s][96:]
+    assert f.overflows() == 0
+    rings0, head0, level0 = f.snapshot()
+    got = f.export_range(3, 5)
+    for k in range(5):
+        assert np.array_equal(got[k], held[3 + k]), k
+    # ... and back, the queues ending on the ring's end: the layout mi_fifo_reset_range_at + push leaves
+    qs = [q[:len(q) // 8 * 8] for q in got]
+    f.import_range(3, qs, tail_at_end=True)
+    rings1, head1, level1 = f.snapshot()
+    g = ms.FifoBatch(ctx, n, cap)
+    for k, q in enumerate(qs):
+        if len(q):
+            g.reset_range_at(3 + k, 1, cap - len(q))
+    xs = np.zeros((n, cap), np.int16)
+    cnt = np.zeros(n, np.int32)
+    for k, q in enumerate(qs):
+        xs[3 + k, :len(q)], cnt[3 + k] = q, len(q)
+    g.push(torch.from_numpy(xs).cuda(), nsamples=cap, count=torch.from_numpy(cnt).cuda())
+    ctx.sync()
+    rings2, head2, level2 = g.snapshot()
+    for s in range(3, 8):
+        assert (head1[s], level1[s]) == (head2[s], level2[s]) and np.array_equal(f.export_range(s, 1)[0], qs[s - 3])
+    for s in (0, 1, 2, 8, 9):   # the neighbours: as they were
+        assert (head1[s], level1[s]) == (head0[s], level0[s]) and np.array_equal(rings1[s], rings0[s])
+    # the resampler's states: out of slots 2..5, into slots 6..9 of a second batch -- the streams continue bit for bit
+    a, b = ms.ResamplerBatch(ctx, 8, 16000, 48000), ms.ResamplerBatch(ctx, 12, 16000, 48000)
+    x = rng.normal(0, 4000, (8, 3 * 160)).round().clip(-32767, 32767).astype(np.int16)
+    for t in range(2):
+        a.process(torch.from_numpy(np.ascontiguousarray(x[:, t * 160:(t + 1) * 160])).cuda())
+    ctx.sync()
+    st = a.get_states(2, 4)
+    assert st == b"".join(a.get_state(s) for s in range(2, 6))
+    b.set_states(6, 4, st)
+    xa = torch.from_numpy(np.ascontiguousarray(x[:, 320:480])).cuda()
+    xb = torch.zeros((12, 160), dtype=torch.int16, device="cuda")
+    xb[6:10] = xa[2:6]
+    oa, _ = a.process(xa)
+    ob, _ = b.process(xb)
+    ctx.sync()
+    assert torch.equal(oa[2:6, :480], ob[6:10, :480])
+    for o in (f, g, a, b):
+        o.close()
+
+
 def test_the_fifo_entry_serves_the_legs_sorted_by_their_frames(ctx):
     """mi_aec_process_fifos keeps eight lists of legs (one per class b % 8 = the XCD a workgroup lands on) that every launch
     rebuilds for the next one: each leg enters itself into class (own class + own position) % 8, from the front if it will
