@@ -53,7 +53,8 @@ struct MapPool : Pool {
 		used += need;
 		return p;
 	}
-	void flush() override {
+	// (in two halves, so that a hub's flush waits ONCE for all of its banks: Pool::enqueue / finish)
+	bool enqueue() override {
 		if (used && !failed) {
 			mi_ctx *ctx = hub->ctx;
 			const MapOpInfo &k = kMapOps[op];
@@ -84,8 +85,11 @@ struct MapPool : Pool {
 				break;
 			}
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_out, d_out, used * k.out_bpe));
-			MI_MUST(mi_ctx_sync(ctx));
+			return true;
 		}
+		return false;
+	}
+	void finish() override {
 		bool kept = false; // a detaching graph's slots alone leave: the others' blocks stay where they lie, converted again by their own flush (a pure map)
 		for (int s = 0; s < hi; ++s) {
 			auto &st = staged[(size_t)s], &rd = ready[(size_t)s];

@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "../../include/ms2_plugin_abi.h"
 
@@ -518,6 +519,95 @@ static void *server_conferences(void *arg) {
 	return NULL;
 }
 
+/* Full-duplex G.711 AudioStreams as audiostream.c:1796-1832 plumbs them with the default features (filters/recv_leg.inl, the encoder in the leg's
+ * batch): packets -> MSUlawDec -> local_mixer (one input) -> MSGenericPLC -> MSAudioFlowControl -> dtmfgen (the application's) -> volrecv ->
+ * MSSpeexEC pin 0 -> speaker;  microphone -> MSSpeexEC pin 1 -> volsend -> outbound_mixer (one input) -> MSUlawEnc -> packets.  Fused at the attach
+ * (on THIS thread, while other tickers run), lost packets, a drop request and a PLC rate change from ANOTHER thread during the walk, a re-plumbing,
+ * teardown with the decoder / the PLC / the encoder destroyed first in turn. */
+typedef struct {
+	MSFilter *fc, *plc, *vol;
+	volatile int stop;
+} stream_meddle_t;
+static void *stream_meddler(void *arg) {
+	stream_meddle_t *m = (stream_meddle_t *)arg;
+	int n = 0;
+	while (!__atomic_load_n(&m->stop, __ATOMIC_SEQ_CST)) {
+		MSAudioFlowControlDropEvent ev;
+		float g = (n & 1) ? 0.8f : 1.0f;
+		ev.flow_control_interval_ms = 200, ev.drop_ms = 10;
+		ms_filter_call_method(m->fc, MS_AUDIO_FLOW_CONTROL_DROP, &ev);
+		ms_filter_call_method(m->vol, MS_VOLUME_SET_GAIN, &g);
+		if (++n == 40) { /* another rate and back: the stream's receiving side leaves its batch at the next walk and carries on at 8 kHz on its facades */
+			set_int(m->plc, MS_FILTER_SET_SAMPLE_RATE, 16000);
+			set_int(m->plc, MS_FILTER_SET_SAMPLE_RATE, 8000);
+		}
+		usleep(200);
+	}
+	return NULL;
+}
+static void *audiostreams(void *arg) {
+	enum { NS_ = 5 };
+	void (*p_fused)(int *, int *, unsigned long long *, unsigned long long *) = (void (*)(int *, int *, unsigned long long *, unsigned long long *))arg;
+	int16_t pcm[80];
+	uint8_t codes[80];
+	for (int i = 0; i < 80; ++i) pcm[i] = (int16_t)(i * 211 % 6000 - 3000), codes[i] = (uint8_t)(i * 29 + 7);
+	for (int rep = 0; rep < (g_rounds + 1) / 2; ++rep) {
+		MSTicker *tk = ms_ticker_new();
+		MSFilter *mic[NS_], *far[NS_], *spk[NS_], *out[NS_], *dec[NS_], *lmx[NS_], *plc[NS_], *fc[NS_], *dtmf[NS_], *vr[NS_], *ec[NS_], *vs[NS_], *omx[NS_], *enc[NS_];
+		for (int k = 0; k < NS_; ++k) {
+			mic[k] = ms2shim_new_source(g_fac), far[k] = ms2shim_new_source(g_fac), spk[k] = ms2shim_new_sink(g_fac), out[k] = ms2shim_new_sink(g_fac);
+			dec[k] = ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID), lmx[k] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+			plc[k] = ms_factory_create_filter(g_fac, MS_GENERIC_PLC_ID), fc[k] = ms_factory_create_filter(g_fac, MS_AUDIO_FLOW_CONTROL_ID);
+			dtmf[k] = ms2shim_new_pass(g_fac), vr[k] = ms_factory_create_filter(g_fac, MS_VOLUME_ID), ec[k] = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
+			vs[k] = ms_factory_create_filter(g_fac, MS_VOLUME_ID), omx[k] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID), enc[k] = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
+			CHECK(dec[k] && lmx[k] && plc[k] && fc[k] && vr[k] && ec[k] && vs[k] && omx[k] && enc[k]);
+			ms2shim_sink_set_discard(spk[k], 1), ms2shim_sink_set_discard(out[k], 1);
+			for (MSFilter **f = (MSFilter *[]){lmx[k], plc[k], fc[k], vr[k], ec[k], vs[k], omx[k], NULL}; *f; ++f) set_int(*f, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			set_int(ec[k], MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
+			ms_filter_link(far[k], 0, dec[k], 0), ms_filter_link(dec[k], 0, lmx[k], 0), ms_filter_link(lmx[k], 0, plc[k], 0), ms_filter_link(plc[k], 0, fc[k], 0);
+			ms_filter_link(fc[k], 0, dtmf[k], 0), ms_filter_link(dtmf[k], 0, vr[k], 0), ms_filter_link(vr[k], 0, ec[k], 0), ms_filter_link(ec[k], 0, spk[k], 0);
+			ms_filter_link(mic[k], 0, ec[k], 1), ms_filter_link(ec[k], 1, vs[k], 0), ms_filter_link(vs[k], 0, omx[k], 0), ms_filter_link(omx[k], 0, enc[k], 0);
+			ms_filter_link(enc[k], 0, out[k], 0);
+			CHECK(ms_ticker_attach(tk, mic[k]) == 0);
+		}
+		stream_meddle_t md = {fc[1], plc[2], vs[3], 0};
+		pthread_t mt;
+		pthread_create(&mt, NULL, stream_meddler, &md);
+		for (int t = 0; t < 24; ++t) {
+			for (int k = 0; k < NS_; ++k) {
+				ms2shim_source_push(mic[k], pcm, sizeof pcm);
+				if ((t + k) % 7 != 3) ms2shim_source_push(far[k], codes, sizeof codes); /* (a packet lost now and then: concealed in the batch) */
+			}
+			ms_ticker_step(tk);
+			if (t == 3) {
+				int nl = 0;
+				p_fused(NULL, &nl, NULL, NULL);
+				CHECK(nl >= NS_);
+			}
+			if (t == 11) { /* one stream re-plumbed under the others' feet */
+				ms_ticker_detach(tk, mic[0]);
+				CHECK(ms_ticker_attach(tk, mic[0]) == 0);
+			}
+		}
+		__atomic_store_n(&md.stop, 1, __ATOMIC_SEQ_CST);
+		pthread_join(mt, NULL);
+		for (int k = 0; k < NS_; ++k) ms_ticker_detach(tk, mic[k]);
+		for (int k = 0; k < NS_; ++k) {
+			MSFilter *all[] = {mic[k], far[k], spk[k], out[k], dec[k], lmx[k], plc[k], fc[k], dtmf[k], vr[k], ec[k], vs[k], omx[k], enc[k]};
+			MSFilter *first = (k % 3 == 0) ? dec[k] : ((k % 3 == 1) ? plc[k] : enc[k]); /* (whoever goes first, nobody reaches into a freed filter) */
+			ms_filter_unlink(far[k], 0, dec[k], 0), ms_filter_unlink(dec[k], 0, lmx[k], 0), ms_filter_unlink(lmx[k], 0, plc[k], 0), ms_filter_unlink(plc[k], 0, fc[k], 0);
+			ms_filter_unlink(fc[k], 0, dtmf[k], 0), ms_filter_unlink(dtmf[k], 0, vr[k], 0), ms_filter_unlink(vr[k], 0, ec[k], 0), ms_filter_unlink(ec[k], 0, spk[k], 0);
+			ms_filter_unlink(mic[k], 0, ec[k], 1), ms_filter_unlink(ec[k], 1, vs[k], 0), ms_filter_unlink(vs[k], 0, omx[k], 0), ms_filter_unlink(omx[k], 0, enc[k], 0);
+			ms_filter_unlink(enc[k], 0, out[k], 0);
+			ms_filter_destroy(first);
+			for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i)
+				if (all[i] != first) ms_filter_destroy(all[i]);
+		}
+		ms_ticker_destroy(tk);
+	}
+	return NULL;
+}
+
 static void *walker(void *arg) {
 	long walks = 0;
 	(void)arg;
@@ -532,7 +622,7 @@ static void *walker(void *arg) {
 }
 
 int main(int argc, char **argv) {
-	pthread_t th[7];
+	pthread_t th[8];
 	void *p_fused = NULL;
 	void *walks = NULL;
 	int h, b, s;
@@ -565,10 +655,12 @@ int main(int argc, char **argv) {
 	pthread_create(&th[4], NULL, grower, NULL);
 	pthread_create(&th[5], NULL, conferences, p_fused);
 	pthread_create(&th[6], NULL, server_conferences, p_fused);
+	pthread_create(&th[7], NULL, audiostreams, p_fused);
 	for (int i = 0; i < 3; ++i) pthread_join(th[i], NULL);
 	pthread_join(th[4], NULL);
 	pthread_join(th[5], NULL);
 	pthread_join(th[6], NULL);
+	pthread_join(th[7], NULL);
 	__atomic_store_n(&g_stop, 1, __ATOMIC_SEQ_CST);
 	pthread_join(th[3], &walks);
 	p_flush(); /* nothing is running any more */
