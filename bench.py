@@ -1137,8 +1137,11 @@ def plugin_shape_point(shape, legs=32768, ticks=250, warmup=40):
     if r.returncode != 0 or not r.stdout.strip():
         raise RuntimeError(f"plugin_bench exit {r.returncode}: {r.stderr[-300:]}")
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    return {k: d.get(k) for k in ("legs", "tickers", "ticks", "fused_legs", "p50_ms", "p99_ms", "max_ms", "late", "us_per_leg_tick", "ticker_graph_walk_ms",
-                                  "ticker_flush_ms", "launches_per_tick_and_ticker", "late_events")}
+    out = {k: d.get(k) for k in ("legs", "tickers", "ticks", "fused_legs", "p50_ms", "p99_ms", "max_ms", "late", "us_per_leg_tick", "ticker_graph_walk_ms",
+                                 "ticker_flush_ms", "launches_per_tick_and_ticker", "flush_rounds_per_tick_and_ticker", "late_events")}
+    if isinstance(d.get("from_attach"), dict):
+        out["from_attach"] = {k: d["from_attach"].get(k) for k in ("ticks", "p50_ms", "max_ms", "ticks_over_10ms", "first_ms")}
+    return out
 
 
 def cpu_baseline_chain(seconds, threads=1):
@@ -2063,7 +2066,7 @@ def main():
                     line["plugin_path_server"] = {"error": str(e)[:300]}
                 shapes = {}   # the other leg shapes the fused chain takes, one paced point each at a fixed count
                 for name, sh in (("mic_equalizer", "eq"), ("server_g711_decoder_heads", "server dec"), ("server_g711_endpoints_in_a_16k_conference", "server dec wb"),
-                                 ("audiostreams_8k_g711_full_duplex", "astream")):
+                                 ("audiostreams_8k_g711_full_duplex", "astream"), ("audiostreams_8k_g711_default_features", "astream default")):
                     try:
                         shapes[name] = plugin_shape_point(sh)
                     except Exception as e:

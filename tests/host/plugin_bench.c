@@ -87,6 +87,9 @@ static int g_dec; /* ... with "server": "dec" -- the sources hand over G.711 PAC
 static int g_astream; /* ... "astream": full-duplex narrow-band AudioStreams as audiostream.c:1798-1832 plumbs them, the card at 8 kHz: PCMU packets ->
                         MSUlawDec -> MSGenericPLC -> dtmfgen (the application's) -> volrecv -> recv_tee -> MSSpeexEC pin 0 -> speaker;  microphone -> MSSpeexEC
                         pin 1 -> volsend -> dtmfgen_rtp -> MSUlawEnc -> packets.  The sending side fuses leg by leg, the receiving side runs as facades. */
+static int g_default; /* ... "astream default": the reference's DEFAULT features (AUDIO_STREAM_FEATURE_ALL, audiostream.c:1585-1588,1754-1772,1807,1815) with a telephone-event payload
+                        negotiated: packets -> MSUlawDec -> local_mixer -> MSGenericPLC -> MSAudioFlowControl -> dtmfgen -> volrecv -> recv_tee -> MSSpeexEC pin 0;  microphone ->
+                        MSSpeexEC pin 1 -> volsend -> outbound_mixer -> MSUlawEnc (no dtmfgen_rtp, :1396-1404): both directions device-resident, the encoder in the leg's batch */
 static int g_wb; /* ... "server wb": the server's conference runs at 16 kHz, its G.711 endpoints at 8 kHz -- both resamplers of every member work (audioconference.c:209-257) */
 static int g_eq; /* ... "eq": a mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801), a response of its own per leg */
 static int g_el; /* ... "el": the echo limiter on (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer (with nomixer) */
@@ -144,7 +147,9 @@ static void build(TickerJob *j) {
 			MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
 			MSFilter *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID), *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID), *volrecv = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
 			MSFilter *dec = ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID), *plc = ms_factory_create_filter(g_fac, MS_GENERIC_PLC_ID), *enc = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
-			MSFilter *dtmfgen = ms2shim_new_pass(g_fac), *recv_tee = ms2shim_new_pass(g_fac), *dtmfgen_rtp = ms2shim_new_pass(g_fac);
+			MSFilter *dtmfgen = ms2shim_new_pass(g_fac), *recv_tee = ms2shim_new_pass(g_fac), *dtmfgen_rtp = g_default ? NULL : ms2shim_new_pass(g_fac);
+			MSFilter *local_mixer = g_default ? ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID) : NULL, *outbound_mixer = g_default ? ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID) : NULL;
+			MSFilter *flowctl = g_default ? ms_factory_create_filter(g_fac, MS_AUDIO_FLOW_CONTROL_ID) : NULL;
 			const int leg = (j->index * j->nconf + c) * g_members + k;
 			ms2shim_source_set_loop(mic, g_pcm8, sizeof(g_pcm8[0]), RING, leg);
 			ms2shim_source_set_loop(far, g_codes8, sizeof(g_codes8[0]), RING, leg * 7);
@@ -158,9 +163,18 @@ static void build(TickerJob *j) {
 			call_int(vol, MS_FILTER_SET_SAMPLE_RATE, 8000);
 			call_int(volrecv, MS_FILTER_SET_SAMPLE_RATE, 8000);
 			call_int(plc, MS_FILTER_SET_SAMPLE_RATE, 8000);
-			ms_filter_link(far, 0, dec, 0), ms_filter_link(dec, 0, plc, 0), ms_filter_link(plc, 0, dtmfgen, 0), ms_filter_link(dtmfgen, 0, volrecv, 0);
+			if (g_default) {
+				call_int(local_mixer, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(outbound_mixer, MS_FILTER_SET_SAMPLE_RATE, 8000);
+				call_int(flowctl, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(flowctl, MS_FILTER_SET_NCHANNELS, 1);
+				ms_filter_link(far, 0, dec, 0), ms_filter_link(dec, 0, local_mixer, 0), ms_filter_link(local_mixer, 0, plc, 0), ms_filter_link(plc, 0, flowctl, 0);
+				ms_filter_link(flowctl, 0, dtmfgen, 0), ms_filter_link(dtmfgen, 0, volrecv, 0);
+			} else {
+				ms_filter_link(far, 0, dec, 0), ms_filter_link(dec, 0, plc, 0), ms_filter_link(plc, 0, dtmfgen, 0), ms_filter_link(dtmfgen, 0, volrecv, 0);
+			}
 			ms_filter_link(volrecv, 0, recv_tee, 0), ms_filter_link(recv_tee, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
-			ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vol, 0), ms_filter_link(vol, 0, dtmfgen_rtp, 0), ms_filter_link(dtmfgen_rtp, 0, enc, 0);
+			ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vol, 0);
+			if (g_default) ms_filter_link(vol, 0, outbound_mixer, 0), ms_filter_link(outbound_mixer, 0, enc, 0);
+			else ms_filter_link(vol, 0, dtmfgen_rtp, 0), ms_filter_link(dtmfgen_rtp, 0, enc, 0);
 			ms_filter_link(enc, 0, out, 0);
 			if (c == 0 && k == 0) j->probe_out = out;
 		}
@@ -383,6 +397,7 @@ int main(int argc, char **argv) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
 		g_astream = strstr(sh, "astream") != NULL;
+		g_default = g_astream && strstr(sh, "default") != NULL;
 		g_wb = strstr(sh, " wb") != NULL;
 		if (g_astream) g_nomixer = 1;
 		g_eq = strstr(sh, "eq") != NULL, g_el = strstr(sh, " el") != NULL || strncmp(sh, "el", 2) == 0;

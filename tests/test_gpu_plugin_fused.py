@@ -294,7 +294,7 @@ def test_a_volume_method_on_a_fused_leg_meets_the_next_walks_chunk_in_both_forms
     assert fused["late"] == 0 and plain["late"] == 0
 
 
-@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nors noagc nomixer", "eprs", "eq", "el nomixer noagc", "astream"])
+@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nors noagc nomixer", "eprs", "eq", "el nomixer noagc", "astream", "astream default"])
 def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape):
     """4 096 full legs (128 conferences of 32, four tickers) for 190 ticks through tests/host/plugin_bench, fused and with the
     facades one by one (MSMI355X_NO_FUSE=1): every leg's mix and every leg's speaker audio, byte for byte and in order, folded
@@ -303,7 +303,10 @@ def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape
     shape: the leg without MSResample (a 48 kHz microphone), with MSVolume's AGC off (the reference's default), without a
     conference mixer -- "nors noagc nomixer" is the sending side of a default AudioStream; "eq": a mic_equalizer in every leg;
     "el": the echo limiter on, volrecv metered beside the leg; "astream": full-duplex narrow-band G.711 AudioStreams with the
-    application's own filters in between (audiostream.c:1798-1832)."""
+    application's own filters in between (audiostream.c:1798-1832) -- the receiving side (decoder -> PLC) one batch, the sending leg
+    another, the encoder behind dtmfgen_rtp on its facade; "astream default": the reference's default features -- local_mixer, flow
+    control, outbound_mixer, no dtmfgen_rtp: the encoder inside the sending leg's batch.  (The sources deliver every packet: no
+    losses, so the two forms' timing is the same.)"""
     import json
     import subprocess
     host_dir = os.path.join(fg.ROOT, "tests", "host")
@@ -321,7 +324,7 @@ def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape
 
     fused, plain, staged = run(), run(MSMI355X_NO_FUSE="1"), run(MSMI355X_ZERO_COPY="0")
     assert fused["fused_legs"] == 4096 and plain["fused_legs"] == 0 and staged["fused_legs"] == 4096
-    assert fused["mix_bytes"] == plain["mix_bytes"] > 4096 * 150 * (70 if shape == "astream" else 900)   # (PCMU packets there: 80 B per leg and tick)
+    assert fused["mix_bytes"] == plain["mix_bytes"] > 4096 * 150 * (70 if shape.startswith("astream") else 900)   # (PCMU packets there: 80 B per leg and tick)
     assert fused["mix_checksum"] == plain["mix_checksum"] == staged["mix_checksum"], (fused["mix_checksum"], plain["mix_checksum"], staged["mix_checksum"])
     assert fused["speaker_checksum"] == plain["speaker_checksum"] == staged["speaker_checksum"]
     assert fused["late_events"] == 0 and plain["late_events"] == 0

@@ -88,7 +88,7 @@ def test_plugin_bench_runs_full_legs_through_the_double(verdict, paced):
         assert 9.0 < d["wall_ms_per_tick"] < 12.0, d["wall_ms_per_tick"]   # 40 ticks on the 10 ms grid (+ the 20 ms lead)
 
 
-@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nomixer", "nors noagc nomixer", "eprs", "server", "server dec", "eq", "eq nomixer noagc", "el nomixer", "astream", "server wb", "server dec wb"])
+@pytest.mark.parametrize("shape", ["", "nors", "noagc", "nomixer", "nors noagc nomixer", "eprs", "server", "server dec", "eq", "eq nomixer noagc", "el nomixer", "astream", "astream default", "server wb", "server dec wb"])
 def test_plugin_bench_shapes_fused_equal_one_by_one_by_checksum(verdict, shape):
     """every leg shape the fused chain takes (PLUGIN_BENCH_SHAPE: without MSResample / without AGC / without a conference mixer):
     256 legs x 70 ticks against the double, every leg's mix and speaker audio folded into one number per run -- fused ==
