@@ -51,11 +51,17 @@ def test_fused_server_conference_equals_the_facades_one_by_one(host, runs, name)
 
 def oracle_server(oracle, sc_in):
     """the scenario through the chain of oracle objects -> every member's output stream (G.711 bytes or PCM) as run() returns them"""
-    sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, pcm_pins=(), pins=None, gain=None, decoders=())
+    sc = dict(nconf=2, members=4, nticks=120, rate=8000, law="u", ptime=0, pcm_pins=(), pins=None, gain=None, decoders=(), endpoint_rate=None)
     sc.update(sc_in)
-    n, nt, ns, rate = sc["nconf"] * sc["members"], sc["nticks"], sc["rate"] // 100, sc["rate"]
+    conf_rate = sc["rate"]
+    rate = sc["endpoint_rate"] or conf_rate   # the endpoints' own rate: sources, MSVolume and the encoders run at it (audioconference.c:209-257)
+    n, nt, ns = sc["nconf"] * sc["members"], sc["nticks"], rate // 100
     pins = list(range(sc["members"])) if sc["pins"] is None else list(sc["pins"])
     pcm = sg.signals(n, nt, rate, seed=sc.get("seed", 5))
+    # endpoints at another rate than their conference: every member's in_resampler and out_resampler work (msresample.c:122-179), 10 ms at a time
+    up = [oracle.Resampler(rate, conf_rate) if rate != conf_rate else None for _ in range(n)]
+    down = [oracle.Resampler(conf_rate, rate) if rate != conf_rate else None for _ in range(n)]
+    hold = [np.zeros(0, np.int16) for _ in range(n)]   # MSVolume's bufferizer once AGC re-frames to 10 ms chunks (msvolume.c:480-486)
     law_of = lambda k: sc["law"] if sc["law"] in ("a", "u") else ("a" if k % 2 else "u")
     for s in range(n):   # a member whose packets pass MSAlawDec / MSUlawDec: what volrecv sees is the decoded audio (g711.c:113-166,200-255)
         k = s % sc["members"]
@@ -66,7 +72,7 @@ def oracle_server(oracle, sc_in):
     for v in vols:
         if sc["gain"] is not None:   # MS_VOLUME_SET_GAIN before the attach (msvolume.c:270-276)
             v.v.gain = v.v.target_gain = v.v.static_gain = sc["gain"]
-    mixers = [cg.OracleMixer(oracle, ns) for _ in range(sc["nconf"])]
+    mixers = [cg.OracleMixer(oracle, conf_rate // 100) for _ in range(sc["nconf"])]
     for c in range(sc["nconf"]):
         for k in range(sc["members"]):
             mixers[c].link(pins[k])
@@ -78,6 +84,8 @@ def oracle_server(oracle, sc_in):
             elif ev[0] == t and ev[1] == "gain":
                 v = vols[ev[2]]
                 v.v.gain = v.v.target_gain = v.v.static_gain = ev[3]
+            elif ev[0] == t and ev[1] == "agc":   # MS_VOLUME_ENABLE_AGC: from the next walk's blocks on MSVolume works on 10 ms chunks, with the AGC's target gain (msvolume.c:172-184,480-503)
+                vols[ev[2]].v.agc_enabled = int(ev[3])
             elif ev[0] == t and ev[1] == "reattach":
                 for m in mixers:   # mixer_postprocess keeps the channels' queues (audiomixer.c:132-135,200-208), preprocess restarts the clocks; MSVolume lives on
                     m.reattached()
@@ -98,9 +106,21 @@ def oracle_server(oracle, sc_in):
                     blocks += [pcm[s, (t - 1) * ns:t * ns], pcm[s, t * ns:(t + 1) * ns]]
                 else:
                     blocks.append(pcm[s, t * ns:(t + 1) * ns])
-                arrived[pins[k]] = np.concatenate([vols[s].chunk(b) for b in blocks]) if blocks else np.zeros(0, np.int16)   # msvolume.c:505-512: every block as it is
+                if vols[s].v.agc_enabled:   # :480-503: re-framed to 10 ms chunks
+                    hold[s] = np.concatenate([hold[s]] + blocks)
+                    lev = []
+                    while len(hold[s]) >= ns:
+                        lev.append(vols[s].chunk(hold[s][:ns]))
+                        hold[s] = hold[s][ns:]
+                else:
+                    lev = [vols[s].chunk(b) for b in blocks]   # :505-512: every block as it is
+                x = np.concatenate(lev) if lev else np.zeros(0, np.int16)
+                if up[s] is not None and len(x):   # the in_resampler: its input re-framed to 10 ms blocks (resample.inl / msresample.c:122-179 per block)
+                    x = np.concatenate([up[s].process(x[i:i + ns]) for i in range(0, len(x), ns)])
+                arrived[pins[k]] = x
             for pin, row in mixers[c].tick(10 * t, arrived).items():
-                heard[c * sc["members"] + pins.index(pin)].append(row)
+                s = c * sc["members"] + pins.index(pin)
+                heard[s].append(down[s].process(row) if down[s] is not None else row)
     out = []
     for s in range(n):
         k = s % sc["members"]
@@ -114,13 +134,36 @@ def oracle_server(oracle, sc_in):
     return out
 
 
-@pytest.mark.parametrize("name", [n for n in NAMES if n not in ("agc_switched_on", "late_packets_agc_switched_on", "all_but_one_fall_silent", "a_lone_contributor_is_heard_even_muted",
-                                                    "g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference", "wideband_endpoints_in_a_48k_conference")])
+RESAMPLED = ("g711_endpoints_in_a_16k_conference", "g711_packets_of_20ms_into_a_48k_conference", "wideband_endpoints_in_a_48k_conference")
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if n not in ("all_but_one_fall_silent", "a_lone_contributor_is_heard_even_muted")])
 @pytest.mark.parametrize("form", ["fused", "one_by_one"])
 def test_server_conference_is_the_oracle_chains(host, runs, oracle, name, form):
-    """(agc_switched_on: MSVolume's AGC is the oracle's too, but the switch re-frames to 10 ms chunks -- held to the facades above;
-    all_but_one_fall_silent: a lone contributor is FORWARDED by the reference, mixed here -- the stated exception -- and the oracle
-    mixer models the plugin's choice, so it would prove nothing)"""
+    """Every scenario but the two with a LONE contributor (the reference forwards that pin's blocks, this plugin mixes them -- the stated
+    exception -- and the oracle mixer models the plugin's choice, so it would prove nothing) against the chain of oracle objects, bit for
+    bit -- the AGC switches included (the oracle's MSVolume re-frames to 10 ms chunks from the walk the call preceded, msvolume.c:480-503).
+    Endpoints at another rate than their conference pass two float resamplers (held to the library's order within 1 LSB): there the
+    PCM in front of the encoders -- the same call with PCM endpoints -- is held to 1 LSB and 1e-4 RMS of full scale, and the packets to
+    exactly the G.711 of that PCM."""
+    if name in RESAMPLED:
+        sc = sg.SCENARIOS[name]
+        members = dict(nconf=2, members=4)
+        members.update(sc)
+        tap_sc = dict(sc, pcm_pins=tuple(range(members["members"])))
+        tap = sg.run(PKG, form == "fused", tap_sc, host)["out"]
+        want = oracle_server(oracle, tap_sc)
+        got = both(host, runs, name)[0 if form == "fused" else 1]
+        er = sc.get("endpoint_rate") or sc.get("rate", 8000)
+        for s, (x, y) in enumerate(zip(tap, want)):
+            assert 0 <= len(y) - len(x) <= 4 * er // 100 and len(x) > 1000, (name, s, len(x), len(y))
+            e = np.asarray(x).astype(np.int64) - y[:len(x)].astype(np.int64)
+            assert np.abs(e).max() <= 1 and np.sqrt(np.mean((e / 32768.0) ** 2)) <= 1e-4, (name, s, int(np.abs(e).max()))
+            z = got["out"][s]
+            if got["laws"][s] and np.asarray(z).dtype == np.uint8:   # an encoded pin: exactly the G.711 of the tapped PCM
+                L = 0 if got["laws"][s] == "a" else 1
+                assert len(z) > 500 and np.array_equal(z, oracle.g711_encode(L, np.asarray(x))[:len(z)]), (name, s)
+        return
     got = both(host, runs, name)[0 if form == "fused" else 1]["out"]
     want = oracle_server(oracle, sg.SCENARIOS[name])
     for s, (x, y) in enumerate(zip(got, want)):
