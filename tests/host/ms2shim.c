@@ -282,6 +282,11 @@ int ms_factory_load_plugin(MSFactory *f, const char *path) {
 	return 0;
 }
 
+typedef struct ShimHdr {
+	int idx; /* index in TickerImpl::filters while attached, else -1 */
+	int pad[3];
+} ShimHdr;
+#define SHIM_HDR(f) (((ShimHdr *)(f)) - 1)
 MSFilter *ms_factory_create_filter(MSFactory *fac, MSFilterId id) {
 	if (id == MS_FILTER_PLUGIN_ID) return NULL; /* msfactory.c:419-422 */
 	MSFilterDesc *d = ms_factory_lookup_filter_by_id(fac, id);
@@ -289,7 +294,11 @@ MSFilter *ms_factory_create_filter(MSFactory *fac, MSFilterId id) {
 		ms_error("No such filter with id %i", (int)id);
 		return NULL;
 	}
-	MSFilter *f = (MSFilter *)ms_malloc0(sizeof(MSFilter));
+	/* (this runtime's own word in FRONT of the filter -- its place in its ticker's array -- so that a detach costs the graph it
+	 * detaches, as msticker.c:197-218 does, not a pass over every filter of the ticker) */
+	ShimHdr *hdr = (ShimHdr *)ms_malloc0(sizeof(ShimHdr) + sizeof(MSFilter));
+	MSFilter *f = (MSFilter *)(hdr + 1);
+	hdr->idx = -1;
 	pthread_mutex_init(&f->lock, NULL);
 	f->desc = d;
 	f->factory = fac;
@@ -319,7 +328,7 @@ void ms_filter_destroy(MSFilter *f) {
 	free(f->inputs);
 	free(f->outputs);
 	pthread_mutex_destroy(&f->lock);
-	free(f);
+	free(SHIM_HDR(f));
 }
 
 int ms_filter_link(MSFilter *f1, int pin1, MSFilter *f2, int pin2) {
@@ -488,8 +497,8 @@ typedef struct Task {
 } Task;
 
 typedef struct TickerImpl {
-	MSFilter **filters; /* every filter of the attached graphs */
-	int nfilters, cap;
+	MSFilter **filters; /* every filter of the attached graphs, in the order they were attached; NULL: a detached filter's place (compacted when a quarter is holes) */
+	int nfilters, cap, holes;
 	Task *tasks;
 	uint64_t tasks_ns, step_ns; /* the last step, by phase */
 	/* MS2SHIM_PROFILE=1: the last step's process() calls by filter id (time summed, the longest single call) */
@@ -503,6 +512,7 @@ static void ti_add(TickerImpl *ti, MSFilter *f) {
 		ti->cap = ti->cap ? 2 * ti->cap : 1024;
 		ti->filters = (MSFilter **)realloc(ti->filters, sizeof(MSFilter *) * (size_t)ti->cap);
 	}
+	SHIM_HDR(f)->idx = ti->nfilters;
 	ti->filters[ti->nfilters++] = f;
 }
 
@@ -526,26 +536,39 @@ void ms_ticker_destroy(MSTicker *t) {
 	free(t);
 }
 
-static void find_neighbours(MSFilter *f, TickerImpl *ti) { /* msfilter.c:303-344 */
+typedef struct FList {
+	MSFilter **v;
+	int n, cap;
+} FList;
+static void find_neighbours(MSFilter *f, FList *l) { /* msfilter.c:303-344 (`seen` is its mark: clear again when the caller is done) */
 	if (f->seen) return;
 	f->seen = TRUE;
-	ti_add(ti, f);
+	if (l->n == l->cap) {
+		l->cap = l->cap ? 2 * l->cap : 64;
+		l->v = (MSFilter **)realloc(l->v, sizeof(MSFilter *) * (size_t)l->cap);
+	}
+	l->v[l->n++] = f;
 	for (int i = 0; i < f->desc->ninputs; ++i)
-		if (f->inputs[i]) find_neighbours(f->inputs[i]->prev.filter, ti);
+		if (f->inputs[i]) find_neighbours(f->inputs[i]->prev.filter, l);
 	for (int i = 0; i < f->desc->noutputs; ++i)
-		if (f->outputs[i]) find_neighbours(f->outputs[i]->next.filter, ti);
+		if (f->outputs[i]) find_neighbours(f->outputs[i]->next.filter, l);
 }
 
 int ms_ticker_attach(MSTicker *t, MSFilter *f) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
+	if (f->ticker == t) return 0; /* msticker.c:172-174: already being scheduled, nothing to do */
 	int first = ti->nfilters;
-	find_neighbours(f, ti);
+	FList l = {0};
+	find_neighbours(f, &l);
+	for (int i = 0; i < l.n; ++i) ti_add(ti, l.v[i]);
+	free(l.v);
 	for (int i = first; i < ti->nfilters; ++i) {
 		MSFilter *g = ti->filters[i];
 		g->ticker = t;
 		g->last_tick = 0;
 		if (g->desc->preprocess) g->desc->preprocess(g);
 	}
+	for (int i = first; i < ti->nfilters; ++i) ti->filters[i]->seen = FALSE; /* (`seen` is find_neighbours' mark: clear outside of it) */
 	return 0;
 }
 
@@ -566,25 +589,32 @@ static void ms2shim_purge_tasks(MSFilter *f) { remove_tasks_for_filter((TickerIm
 int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	/* detach the whole connected graph of f */
-	TickerImpl tmp;
-	memset(&tmp, 0, sizeof(tmp));
-	for (int i = 0; i < ti->nfilters; ++i) ti->filters[i]->seen = FALSE;
+	FList tmp = {0};
+	if (f->ticker != t) return 0; /* msticker.c:197-203: not scheduled (by this ticker): nothing to do */
 	find_neighbours(f, &tmp);
-	for (int i = 0; i < tmp.nfilters; ++i) {
-		MSFilter *g = tmp.filters[i];
+	for (int i = 0; i < tmp.n; ++i) {
+		MSFilter *g = tmp.v[i];
 		if (g->postponed_task) remove_tasks_for_filter(ti, g); /* call_postprocess msticker.c:187-190: BEFORE postprocess */
 		if (g->desc->postprocess) g->desc->postprocess(g);
 		g->ticker = NULL;
 		g->seen = FALSE;
 	}
-	free(tmp.filters);
-	{ /* one compaction pass: what is still scheduled by this ticker stays */
+	for (int i = 0; i < tmp.n; ++i) { /* their places in the ticker's array become holes */
+		MSFilter *g = tmp.v[i];
+		const int at = SHIM_HDR(g)->idx;
+		if (at >= 0 && at < ti->nfilters && ti->filters[at] == g) ti->filters[at] = NULL, ti->holes++;
+		SHIM_HDR(g)->idx = -1;
+	}
+	free(tmp.v);
+	if (ti->holes * 4 > ti->nfilters) { /* compaction, order kept */
 		int j = 0;
 		for (int i = 0; i < ti->nfilters; ++i)
-			if (ti->filters[i]->ticker == t) ti->filters[j++] = ti->filters[i];
-		ti->nfilters = j;
+			if (ti->filters[i]) {
+				SHIM_HDR(ti->filters[i])->idx = j;
+				ti->filters[j++] = ti->filters[i];
+			}
+		ti->nfilters = j, ti->holes = 0;
 	}
-	for (int i = 0; i < ti->nfilters; ++i) ti->filters[i]->seen = TRUE;
 	return 0;
 }
 
@@ -694,7 +724,7 @@ void ms_ticker_step(MSTicker *t) {
 	}
 	ti->tasks_ns = now_ns() - t0;
 	for (int i = 0; i < ti->nfilters; ++i)
-		if (ti->filters[i]->desc->ninputs == 0) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
+		if (ti->filters[i] && ti->filters[i]->desc->ninputs == 0) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
 	/* filters inside loops: scheduled anyway on a second pass (msticker.c:284-299) */
 	for (int i = 0, n = nunsched, dummy = 0; i < n; ++i) run_graph(unsched[i], t, unsched, &dummy, 1);
 	t->time += (uint64_t)t->interval;

@@ -70,6 +70,7 @@ typedef struct {
 	uint64_t tot_ns[16];
 	int *nvcsw, *nivcsw, *minflt;        /* per tick: voluntary / involuntary context switches, minor page faults of the thread */
 	double *churn_ms;                    /* PLUGIN_BENCH_CHURN: what the re-plumbing in front of this tick's step took (0: none) */
+	double attach_ms;                    /* what ms_ticker_attach of this ticker's graphs took (every filter's preprocess: the plugin fuses and opens its banks there) */
 	int churn_next;                      /* ... the conference (or leg) re-plumbed next */
 } TickerJob;
 
@@ -294,10 +295,12 @@ static uint64_t phase_ns(int index) { return g_aligned ? 0 : (uint64_t)index * (
 static void *run(void *arg) {
 	TickerJob *j = (TickerJob *)arg;
 	/* attach on the ticker's own thread: the hub's device context and its banks belong to the thread that ticks them */
+	const double a0 = now_ms();
 	if (g_nomixer)
 		for (int k = 0; k < j->nconf * g_members; ++k) ms_ticker_attach(j->ticker, j->heads[k]);
 	else
 		for (int c = 0; c < j->nconf; ++c) ms_ticker_attach(j->ticker, j->mixers[c]);
+	j->attach_ms = now_ms() - a0;
 	/* the steps from the attach on are timed too (a start-up stall -- fusing, banks opening, slabs, a cold device -- must be visible,
 	 * not folded into capacity): paced like the rest when PLUGIN_BENCH_PACED (a schedule of its own, origin g_w0) */
 	if (g_paced) pthread_barrier_wait(&g_bar); /* (g_w0 is set) */
@@ -629,6 +632,9 @@ int main(int argc, char **argv) {
 				if (jobs[i].spks[k]) spk_sum += ms2shim_sink_sum(jobs[i].spks[k]) * (unsigned long long)(2 * (i * jobs[i].nconf * g_members + k) + 1);
 				out_bytes += ms2shim_sink_size(jobs[i].outs[k]);
 			}
+	double attach_max = 0;
+	for (int i = 0; i < g_tickers; ++i)
+		if (jobs[i].attach_ms > attach_max) attach_max = jobs[i].attach_ms;
 	char churn[256] = "null";
 	if (g_churn > 0) { /* the re-plumbings: how many, what one took (median, longest) */
 		double *ops = (double *)calloc((size_t)g_ticks * (size_t)g_tickers, sizeof(double));
@@ -650,14 +656,14 @@ int main(int argc, char **argv) {
 	       "\"build_ms\": %.1f, \"warmup_ms\": %.1f, \"worst_tick\": {\"index\": %d, \"ticker\": %d, \"ms\": %.3f, \"flush_ms\": %.3f}, "
 	       "\"p99_9_ms\": %.4f, \"mean_ms\": %.4f, \"max_backlog_ms\": %.3f, \"msticker_late_events\": %d, "
 	       "\"ticker_cpu_ms\": %.4f, \"minflt_per_tick_and_ticker\": %.2f, \"nvcsw_per_tick_and_ticker\": %.2f, \"nivcsw_per_tick_and_ticker\": %.3f, \"slow_ticks\": [%s], "
-	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}, \"from_attach\": %s, \"churn\": %s}\n",
+	       "\"mix_checksum\": \"%016llx\", \"speaker_checksum\": \"%016llx\", \"mix_bytes\": %llu, \"walk_us_per_leg_tick_by_filter_id\": {%s}, \"from_attach\": %s, \"churn\": %s, \"attach_ms_slowest_ticker\": %.1f}\n",
 	       g_paced ? "true" : "false", !g_paced ? "barrier" : (g_aligned ? "aligned" : "spread"), legs, g_members, nconf * g_tickers, g_tickers, g_ticks, g_warmup, pct(sorted, g_ticks, 0.5), pct(sorted, g_ticks, 0.99), sorted[g_ticks - 1], late,
 	       wall_ms / g_ticks, mean_step, mean_task, mean_step - mean_task, mean_step * 1e3 * g_tickers / legs, fc1, fl1,
 	       (double)(la1 - la0) / g_ticks, (double)(la1 - la0) / g_ticks / g_tickers, (double)(fr1 - fr0) / g_ticks / g_tickers,
 	       late_events ? late_events() : 0ull, ms2shim_sink_blocks(jobs[0].probe_out), ms2shim_sink_size(jobs[0].probe_out), build_ms, t_first - t_warm0,
 	       worst_t, worst_i, jobs[worst_i].step_ms[worst_t], jobs[worst_i].task_ms[worst_t], pct(sorted, g_ticks, 0.999), wall_ms / g_ticks,
 	       max_backlog, ref_late_events, sum_cpu / ((double)g_ticks * g_tickers), (double)sum_flt / ((double)g_ticks * g_tickers),
-	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid, fa, churn);
+	       (double)sum_nv / ((double)g_ticks * g_tickers), (double)sum_niv / ((double)g_ticks * g_tickers), slow, mix_sum, spk_sum, out_bytes, byid, fa, churn, attach_max);
 	fflush(stdout);
 	/* the graphs are left as they are: the process ends here (tearing 10^5 filters down is not what is measured) */
 	if (getenv("PLUGIN_BENCH_CLEAN_EXIT")) exit(0); /* (under rocprofv3: its summary is written by an exit handler) */
