@@ -107,7 +107,25 @@ struct EqualizerData {
 	FusedLeg *leg;
 	std::vector<int16_t> *hist;
 	bool has_hist;
+	// it has been active at some point since the attach: from then on its blocks are staged (a tick of latency) whether it is active or not -- a
+	// filter that went back to forwarding in the walk when it is switched off would let two blocks meet in one tick (equalizer_passes)
+	bool was_active;
 };
+// An MSEqualizer that is NOT active hands every block on as it came, in the walk, and leaves its FIR's memory alone (equalizer.c:279-288:
+// `if (s->active) equalizer_state_run(..)` around the same ms_queue_put).  The reference's AudioStream creates BOTH equalizers whenever
+// AUDIO_STREAM_FEATURE_EQUALIZER is set -- part of AUDIO_STREAM_FEATURE_ALL -- and leaves them inactive unless the application or the
+// sound device's description asks (audiostream.c:1623-1640): mic_equalizer in front of the canceller's microphone pin, spk_equalizer in
+// front of its far end (:1801,:1828).  Such a filter is transparent: no bank slot, no tick of latency, and a fused leg is recognised
+// THROUGH it (equalizer_passes; leg_chain.inl).  Activated in mid-call it stages its blocks from the next walk on (a tick later, like
+// any facade) and the leg it stands in goes back to its facades.
+bool equalizer_passes(MSFilter *g, MSTicker *ticker) { // (hub locked)
+	if (!g || g->desc != &ms_mi355x_equalizer_desc || g->ticker != ticker) return false;
+	const EqualizerData *d = (const EqualizerData *)g->data;
+	if (d->active || d->was_active || d->leg || ms_bufferizer_get_avail(d->spill)) return false;
+	return !d->pool || (d->pool->staged[(size_t)d->slot] == 0 && d->pool->ready[(size_t)d->slot] == 0);
+}
+FusedLeg *leg_fed_far_end_by(MSFilter *f); // leg_chain.inl: the fused leg whose far end / microphone passes through this filter
+FusedLeg *leg_fed_mic_by(MSFilter *f);
 void leg_eq_op(FusedLeg *leg, const EqualizerPool::Op &op); // leg_chain.inl
 mi_equalizer *leg_eq(FusedLeg *leg, int *slot);
 // the batch and slot the filter's equalizer lives in right now (hub locked): its own bank's, or its fused leg's
@@ -161,11 +179,12 @@ void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
 	f->data = d;
 }
 void equalizer_preprocess(MSFilter *f) {
+	((EqualizerData *)f->data)->was_active = ((EqualizerData *)f->data)->active;
 	{
 		HubLock lk(f);
 		graph_preprocessed(f);
 	}
-	if (!((EqualizerData *)f->data)->leg) equalizer_attach(f);
+	if (!((EqualizerData *)f->data)->leg && ((EqualizerData *)f->data)->active) equalizer_attach(f); // (an inactive one forwards: no slot until it is switched on)
 }
 void equalizer_postprocess(MSFilter *f) {
 	EqualizerData *d = (EqualizerData *)f->data;
@@ -192,6 +211,13 @@ void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	}
 	HubLock lk(f, d->pool);
 	mblk_t *m;
+	if (equalizer_passes(f, f->ticker)) { // not active: the blocks as they came, now (equalizer.c:281-286)
+		while ((m = ms_queue_get(f->inputs[0])) != NULL) {
+			if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+			else freemsg(m);
+		}
+		return;
+	}
 	if (!d->pool) equalizer_attach(f);
 	if (!d->pool) {
 		ms_queue_flush(f->inputs[0]);
@@ -283,6 +309,11 @@ int equalizer_set_active(MSFilter *f, void *arg) { // equalizer.c:311-315: arg r
 	EqualizerData *d = (EqualizerData *)f->data;
 	HubLock lk(f);
 	d->active = *(bool_t *)arg != 0;
+	if (d->active) d->was_active = true;
+	if (d->active && !d->leg) { // no longer transparent: a fused leg recognised through it goes back to its facades
+		leg_disqualify(leg_fed_far_end_by(f));
+		leg_disqualify(leg_fed_mic_by(f));
+	}
 	const EqualizerPool::Op op{d->slot, 1, MSEqualizerGain{0, 0, 0}, d->active ? 1 : 0};
 	if (d->leg) leg_eq_op(d->leg, op);
 	else if (d->pool && f->ticker && d->pool->work_waiting()) d->pool->later.push_back(op);

@@ -1595,6 +1595,10 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
+	if (rs && equalizer_passes(rs, mx->ticker) && ms_queue_empty(qr) && rs->inputs[0]) { // a mic_equalizer that is not active (audiostream.c:1801): transparent
+		qr = rs->inputs[0];
+		rs = qr->prev.filter;
+	}
 	if (!rs || (is_ours(rs->desc) && rs->ticker != mx->ticker)) return false; // (somebody else's filter may still be waiting for its preprocess: graph_preprocessed looks at this plugin's facades only)
 	if (!leg_far_end_in_walk(ec, c.peer)) return false;
 	c.eq = nullptr;
@@ -1631,6 +1635,10 @@ bool leg_far_end_in_walk(MSFilter *ec, MSFilter *peer) {
 		MSFilter *g = q->prev.filter;
 		if (!g) return true;
 		if (!is_ours(g->desc)) return true; // a source, dtmfgen, a tee ..: it runs in the walk and delivers in it, whatever feeds it (a facade of ours above it hands its blocks over at the start of the tick)
+		if (equalizer_passes(g, ec->ticker)) { // spk_equalizer, not active (audiostream.c:1828): it hands on in the walk what it is handed in it
+			q = g->inputs[0];
+			continue;
+		}
 		if (g->desc != &ms_mi355x_volume_desc) return false;
 		VolumeData *vd = (VolumeData *)g->data;
 		if (g != peer && !vd->meter_leg && !(volume_meter_config(vd) && vd->feeds_far_end && (!vd->pool || volume_passes(vd)))) return false; // (its running gain may still be on its way back to 1: then it does not pass yet)
@@ -1645,10 +1653,20 @@ FusedLeg *leg_fed_far_end_by(MSFilter *vol) {
 		MSFilter *g = q->next.filter;
 		if (!g) return nullptr;
 		if (is_ec_desc(g->desc)) return q->next.pin == 0 ? ((SpeexECState *)g->data)->leg : nullptr;
+		if (g->desc == &ms_mi355x_equalizer_desc && !((EqualizerData *)g->data)->leg) { // (a spk_equalizer a leg may have been recognised through)
+			q = g->outputs[0];
+			continue;
+		}
 		if (is_ours(g->desc) || g->desc->noutputs != 1) return nullptr;
 		q = g->outputs[0];
 	}
 	return nullptr;
+}
+// ... and the fused leg whose MICROPHONE passes through this (inactive) mic_equalizer: the canceller right behind it
+FusedLeg *leg_fed_mic_by(MSFilter *eqf) {
+	MSQueue *q = eqf->outputs[0];
+	MSFilter *g = q ? q->next.filter : NULL;
+	return (g && is_ec_desc(g->desc) && q->next.pin == 1) ? ((SpeexECState *)g->data)->leg : nullptr;
 }
 
 // The leg takes its MSVolume's echo-limiter peer along (hub locked): the peer gives up its bank slot, its running state starts the
@@ -2074,6 +2092,7 @@ bool leg_try_fuse_plain_ec(MSFilter *ec) { return leg_fuse_plain_at(nullptr, ec)
 bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	MSFilter *head = rs ? rs : ec;
 	MSFilter *eqf = ec->inputs[1] ? ec->inputs[1]->prev.filter : NULL; // a mic_equalizer of ours between the two (audiostream.c:1801)?
+	if (eqf && equalizer_passes(eqf, head->ticker) && ms_queue_empty(ec->inputs[1])) eqf = nullptr; // (not active: transparent -- it forwards in the walk, or, behind a fused MSResample, sees nothing)
 	if (eqf && eqf->desc == &ms_mi355x_equalizer_desc) {
 		if (!rs || !ms_queue_empty(ec->inputs[1]) || !leg_equalizer_ok(eqf, head->ticker, ((SpeexECState *)ec->data)->samplerate)) return false;
 	} else eqf = nullptr;

@@ -144,7 +144,7 @@ class Conferences:
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
                  endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False, spk_equalizer=False,
-                 flowcontrol=False, dtmfgen_rtp=True, encoder=True, local_mixer=0, outbound_mixer=False, alaw=False):
+                 flowcontrol=False, dtmfgen_rtp=True, encoder=True, local_mixer=0, outbound_mixer=False, alaw=False, idle_equalizers=False):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -178,6 +178,13 @@ class Conferences:
                 # (resampler=False: the sound card / decoder already runs at the canceller's rate -- MSSpeexEC is the head of the leg; the
                 # MSResample is created all the same and stays unlinked)
                 links = [(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["ec"], 1)] if resampler else [(leg["mic"], 0, leg["ec"], 1)]
+                if idle_equalizers:   # AUDIO_STREAM_FEATURE_EQUALIZER (part of AUDIO_STREAM_FEATURE_ALL, audiostream.c:1623-1640): BOTH equalizers exist, neither is active
+                    leg["eq"], leg["spk_eq"] = (S.ms_factory_create_filter(h.fac, MS_EQUALIZER_ID) for _ in range(2))
+                    for e in (leg["eq"], leg["spk_eq"]):
+                        h.call_int(e, base("MS_FILTER_SET_SAMPLE_RATE"), rate)
+                        assert S.ms2shim_equalizer_set_gain(e, 1200.0, 2.0, 500.0) == 0   # (a response that WOULD be heard)
+                        assert S.ms2shim_equalizer_set_active(e, 0) == 0
+                    links = ([(leg["mic"], 0, leg["rs"], 0), (leg["rs"], 0, leg["eq"], 0)] if resampler else [(leg["mic"], 0, leg["eq"], 0)]) + [(leg["eq"], 0, leg["ec"], 1)]
                 if mic_equalizer:   # audiostream.c:1801: between read_resampler and ec, a response of its own per leg
                     leg["eq"] = S.ms_factory_create_filter(h.fac, MS_EQUALIZER_ID)
                     h.call_int(leg["eq"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
@@ -216,8 +223,8 @@ class Conferences:
                                 h.call_int(leg["fc"], base("MS_FILTER_SET_NCHANNELS"), 1)
                                 links += [(leg["plc"], 0, leg["fc"], 0)]
                                 head = leg["fc"]
-                        links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0),
-                                  (leg["recv_tee"], 0, leg["ec"], 0)]
+                        links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0)]
+                        links += [(leg["recv_tee"], 0, leg["spk_eq"], 0), (leg["spk_eq"], 0, leg["ec"], 0)] if idle_equalizers else [(leg["recv_tee"], 0, leg["ec"], 0)]
                     elif spk_equalizer:   # audiostream.c:1828: an MSEqualizer of ours right in front of the canceller's far end -- it delivers with the flush
                         leg["spk_eq"] = S.ms_factory_create_filter(h.fac, MS_EQUALIZER_ID)
                         h.call_int(leg["spk_eq"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
@@ -321,7 +328,7 @@ def run(plugin_dir, fuse, scenario, h=None):
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
                        endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")), spk_equalizer=bool(sc.get("spk_equalizer")),
                        flowcontrol=bool(sc.get("flowcontrol")), dtmfgen_rtp=sc.get("dtmfgen_rtp", True), encoder=sc.get("encoder", True), local_mixer=int(sc.get("local_mixer", 0)),
-                       outbound_mixer=bool(sc.get("outbound_mixer")), alaw=bool(sc.get("alaw")))
+                       outbound_mixer=bool(sc.get("outbound_mixer")), alaw=bool(sc.get("alaw")), idle_equalizers=bool(sc.get("idle_equalizers")))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -371,6 +378,8 @@ def run(plugin_dir, fuse, scenario, h=None):
                     assert h.S.ms2shim_equalizer_set_gain(leg["eq"], 2000.0, val, 800.0) == 0
                 elif kind == "eq_active":
                     assert h.S.ms2shim_equalizer_set_active(leg["eq"], int(val)) == 0
+                elif kind == "spk_eq_active":   # the speaker's equalizer switched on in mid-call: no longer transparent
+                    assert h.S.ms2shim_equalizer_set_active(leg["spk_eq"], int(val)) == 0
                 elif kind == "recv_gain":   # volrecv stops being a meter only: the leg goes back to its facades
                     h.call_float(leg["volrecv"], VOL_SET_GAIN, val)
                 elif kind == "agc":
@@ -457,6 +466,11 @@ SCENARIOS = {
     "audiostream_8k_default_features": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 1, "outbound_mixer": True,
                                         "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000, "nconf": 1, "members": 5, "nticks": 120,
                                         "events": [(61, "reattach", 0, 0)], "tail_blocks": 2},
+    # ... ALL of AUDIO_STREAM_FEATURE_ALL's filters of this plugin: the two equalizers exist too, neither active (audiostream.c:1623-1640,1801,1828) -- they hand their
+    # blocks on in the walk and the stream fuses THROUGH them; the speaker's switched on in mid-call sends one stream's leg back to its facades (compared up to there)
+    "audiostream_8k_all_features_idle_equalizers": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 1,
+                                                    "outbound_mixer": True, "idle_equalizers": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000,
+                                                    "nconf": 1, "members": 5, "nticks": 120, "events": [(41, "reattach", 0, 0), (90, "spk_eq_active", 2, 1)], "tail_blocks": 2, "compare_ticks": 88},
     # ... with the local player linked (and idle): the local_mixer has two inputs, mixes for the first second and forwards afterwards (audiomixer.c:244-286)
     "audiostream_8k_default_features_local_player_linked": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 2,
                                                             "outbound_mixer": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000, "nconf": 1,

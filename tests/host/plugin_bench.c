@@ -48,6 +48,7 @@ uint64_t ms2shim_sink_sum(MSFilter *sink);
 int ms2shim_ticker_profile(MSTicker *t, int *ids, uint64_t *ns, int cap, int *max_id, uint64_t *max_ns);
 size_t ms2shim_sink_size(MSFilter *sink);
 int ms2shim_sink_blocks(MSFilter *sink);
+int ms2shim_equalizer_set_active(MSFilter *eq, int active);
 
 #define RING 16
 static int16_t g_mic[RING][160], g_far[RING][480], g_pcm8[RING][80];
@@ -90,7 +91,8 @@ static int g_astream; /* ... "astream": full-duplex narrow-band AudioStreams as 
                         pin 1 -> volsend -> dtmfgen_rtp -> MSUlawEnc -> packets.  The sending side fuses leg by leg, the receiving side runs as facades. */
 static int g_default; /* ... "astream default": the reference's DEFAULT features (AUDIO_STREAM_FEATURE_ALL, audiostream.c:1585-1588,1754-1772,1807,1815) with a telephone-event payload
                         negotiated: packets -> MSUlawDec -> local_mixer -> MSGenericPLC -> MSAudioFlowControl -> dtmfgen -> volrecv -> recv_tee -> MSSpeexEC pin 0;  microphone ->
-                        MSSpeexEC pin 1 -> volsend -> outbound_mixer -> MSUlawEnc (no dtmfgen_rtp, :1396-1404): both directions device-resident, the encoder in the leg's batch */
+                        MSSpeexEC pin 1 -> volsend -> outbound_mixer -> MSUlawEnc (no dtmfgen_rtp, :1396-1404): both directions device-resident, the encoder in the leg's batch;
+                        and BOTH equalizers of AUDIO_STREAM_FEATURE_EQUALIZER, neither active (:1623-1640): mic_equalizer in front of pin 1, spk_equalizer behind recv_tee */
 static int g_wb; /* ... "server wb": the server's conference runs at 16 kHz, its G.711 endpoints at 8 kHz -- both resamplers of every member work (audioconference.c:209-257) */
 static int g_eq; /* ... "eq": a mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801), a response of its own per leg */
 static int g_el; /* ... "el": the echo limiter on (audiostream.c:2236-2240): volrecv upstream of the canceller's far end, volsend's peer (with nomixer) */
@@ -172,8 +174,16 @@ static void build(TickerJob *j) {
 			} else {
 				ms_filter_link(far, 0, dec, 0), ms_filter_link(dec, 0, plc, 0), ms_filter_link(plc, 0, dtmfgen, 0), ms_filter_link(dtmfgen, 0, volrecv, 0);
 			}
-			ms_filter_link(volrecv, 0, recv_tee, 0), ms_filter_link(recv_tee, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
-			ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vol, 0);
+			if (g_default) {
+				MSFilter *mic_eq = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID), *spk_eq = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID);
+				call_int(mic_eq, MS_FILTER_SET_SAMPLE_RATE, 8000), call_int(spk_eq, MS_FILTER_SET_SAMPLE_RATE, 8000);
+				ms2shim_equalizer_set_active(mic_eq, 0), ms2shim_equalizer_set_active(spk_eq, 0);
+				ms_filter_link(volrecv, 0, recv_tee, 0), ms_filter_link(recv_tee, 0, spk_eq, 0), ms_filter_link(spk_eq, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
+				ms_filter_link(mic, 0, mic_eq, 0), ms_filter_link(mic_eq, 0, ec, 1), ms_filter_link(ec, 1, vol, 0);
+			} else {
+				ms_filter_link(volrecv, 0, recv_tee, 0), ms_filter_link(recv_tee, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
+				ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vol, 0);
+			}
 			if (g_default) ms_filter_link(vol, 0, outbound_mixer, 0), ms_filter_link(outbound_mixer, 0, enc, 0);
 			else ms_filter_link(vol, 0, dtmfgen_rtp, 0), ms_filter_link(dtmfgen_rtp, 0, enc, 0);
 			ms_filter_link(enc, 0, out, 0);
