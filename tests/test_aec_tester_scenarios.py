@@ -9,7 +9,8 @@ its analysis windows and its thresholds:
 
 CPU part: the oracle's restatement of MSSpeexEC on every scene.  GPU part: the same scenes through the drop-in plugin's
 graph as the tester wires it (tests/aec_scenarios.py says what differs between MSWebRTCAEC, which the tester drives, and
-MSSpeexEC, which is what this repository replaces), the output held to the oracle's (<= 1e-4 RMS over the first 2 s)
+MSSpeexEC, which is what this repository replaces), the recorder's stream held to the oracle's filter run over exactly
+the blocks that reached the canceller's pins, tick by tick (<= 1e-5 RMS over the whole 19-22 s scene; measured <= 1.5e-6),
 and to the same bars.
 
 What the numbers say (oracle == GPU to three digits; "sim" = similarity in speech against the RAW near-end file /
@@ -329,10 +330,16 @@ def test_plugin_graph_on_the_testers_scenarios(host, oracle, name):
     seg = slice(S.FILE_RATE // 2, 2 * S.FILE_RATE)
     dd = (got[seg].astype(np.float64) - want16[seg]) / 32768.0
     rms = np.sqrt(np.mean(dd * dd))
-    print(f"{name}: GPU graph vs oracle over the first 2 s: rms {rms:.2e}; the scene starts {k_far} samples into the pins' streams")
-    tol = 1e-4 if rate == S.FILE_RATE else 2e-4  # (48 kHz: the recorder's MSResample adds its 1 LSB)
-    assert rms <= tol, f"{name}: GPU graph vs oracle rms {rms:.2e}"
     m = min(len(got), len(want16))
+    assert abs(len(got) - len(want16)) <= 2 * S.FILE_RATE // 100
+    dd = (got[:m].astype(np.float64) - want16[:m]) / 32768.0
+    rms_all = np.sqrt(np.mean(dd * dd))
+    print(f"{name}: GPU graph vs oracle rms {rms:.2e} over the first 2 s, {rms_all:.2e} over all {m / S.FILE_RATE:.1f} s; "
+          f"the scene starts {k_far} samples into the pins' streams")
+    # measured: <= 7.1e-7 over the first 2 s and <= 1.5e-6 over the whole scene in every scenario (the 48 kHz one, behind the
+    # recorder's MSResample, included); north_star asks for <= 1e-4 once the canceller adapts
+    assert rms <= 1e-5, f"{name}: GPU graph vs oracle rms {rms:.2e} over the first 2 s"
+    assert rms_all <= 1e-5, f"{name}: GPU graph vs oracle rms {rms_all:.2e} over the whole scene"
     # 3. graded as the tester grades it (the near-end file against the recorder's stream; the start-up silence is part of the
     #    stream the tester records too)
     sim_raw, sim_cond, energy = measure(name, near, cond, got[:m])
