@@ -110,6 +110,9 @@ struct EqualizerData {
 	// it has been active at some point since the attach: from then on its blocks are staged (a tick of latency) whether it is active or not -- a
 	// filter that went back to forwarding in the walk when it is switched off would let two blocks meet in one tick (equalizer_passes)
 	bool was_active;
+	// equalizer_passes() held at the attach and nothing has switched the filter on since: process() hands the blocks on without the hub's
+	// lock (nothing of the hub is touched).  Taken back for good -- until the next attach -- by MS_EQUALIZER_SET_ACTIVE(true); an acquire load
+	std::atomic<bool> passes_unlocked;
 };
 // An MSEqualizer that is NOT active hands every block on as it came, in the walk, and leaves its FIR's memory alone (equalizer.c:279-288:
 // `if (s->active) equalizer_state_run(..)` around the same ms_queue_put).  The reference's AudioStream creates BOTH equalizers whenever
@@ -183,11 +186,13 @@ void equalizer_preprocess(MSFilter *f) {
 	{
 		HubLock lk(f);
 		graph_preprocessed(f);
+		((EqualizerData *)f->data)->passes_unlocked.store(equalizer_passes(f, f->ticker), std::memory_order_release);
 	}
 	if (!((EqualizerData *)f->data)->leg && ((EqualizerData *)f->data)->active) equalizer_attach(f); // (an inactive one forwards: no slot until it is switched on)
 }
 void equalizer_postprocess(MSFilter *f) {
 	EqualizerData *d = (EqualizerData *)f->data;
+	d->passes_unlocked.store(false, std::memory_order_release);
 	facade_detached(f);
 	if (d->leg) leg_release(d->leg, false);
 }
@@ -205,12 +210,19 @@ void equalizer_uninit(MSFilter *f) {
 }
 void equalizer_process(MSFilter *f) { // equalizer.c:279-288
 	EqualizerData *d = (EqualizerData *)f->data;
+	mblk_t *m;
+	if (d->passes_unlocked.load(std::memory_order_acquire)) { // inactive since the attach (equalizer.c:281-286): the blocks as they came
+		while ((m = ms_queue_get(f->inputs[0])) != NULL) {
+			if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
+			else freemsg(m);
+		}
+		return;
+	}
 	if (d->leg) { // part of a fused leg: the leg's MSResample emits nothing, the equalizer runs in the leg's bank
 		ms_queue_flush(f->inputs[0]);
 		return;
 	}
 	HubLock lk(f, d->pool);
-	mblk_t *m;
 	if (equalizer_passes(f, f->ticker)) { // not active: the blocks as they came, now (equalizer.c:281-286)
 		while ((m = ms_queue_get(f->inputs[0])) != NULL) {
 			if (f->outputs[0]) ms_queue_put(f->outputs[0], m);
@@ -309,7 +321,7 @@ int equalizer_set_active(MSFilter *f, void *arg) { // equalizer.c:311-315: arg r
 	EqualizerData *d = (EqualizerData *)f->data;
 	HubLock lk(f);
 	d->active = *(bool_t *)arg != 0;
-	if (d->active) d->was_active = true;
+	if (d->active) d->was_active = true, d->passes_unlocked.store(false, std::memory_order_release);
 	if (d->active && !d->leg) { // no longer transparent: a fused leg recognised through it goes back to its facades
 		leg_disqualify(leg_fed_far_end_by(f));
 		leg_disqualify(leg_fed_mic_by(f));

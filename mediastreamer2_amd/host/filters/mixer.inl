@@ -124,6 +124,11 @@ struct MixerState { // audiomixer.c:132-143
 	// nothing to jump between, so its blocks go on IN the walk, as the reference's do (one_input).
 	std::vector<std::pair<int, mblk_t *>> *held;
 	bool one_input;
+	// that, outside conference mode with every linked output enabled: process() moves the pin's blocks on without the hub's (or the filter's)
+	// lock -- nothing of the hub is touched and the filter's own state is not read.  Set at the attach, taken back for good (until the next
+	// attach) by a method that changes an output or the mode; an acquire load in process()
+	std::atomic<bool> forwards_unlocked;
+	int fwd_pin;
 	// the conference and every leg that feeds it as one device-resident batch (filters/leg_chain.inl)
 	LegBank *fbank;     // non-null: fused; the conference is slot `fconf` of that bank
 	int fconf;
@@ -231,6 +236,12 @@ void mixer_prepare(MSFilter *f, bool running) { // (hub locked by the caller)
 	int linked = 0;
 	for (int i = 0; i < f->desc->ninputs; ++i) linked += f->inputs[i] != NULL;
 	s->one_input = linked == 1;
+	s->fwd_pin = -1;
+	bool every_output = true;
+	for (int i = 0; i < f->desc->ninputs; ++i)
+		if (f->inputs[i]) s->fwd_pin = i;
+	for (int i = 0; i < f->desc->noutputs; ++i) every_output = every_output && (!f->outputs[i] || s->channels[i].output_enabled);
+	s->forwards_unlocked.store(!running && s->one_input && s->conf_mode == 0 && every_output, std::memory_order_release);
 	s->prepared = true;
 	s->acquire_failed = false;
 	// (no bank slot yet: a conference that fuses at the attach never needs one of its own, a mixer that can only forward never mixes --
@@ -254,6 +265,7 @@ void mixer_postprocess(MSFilter *f) { // audiomixer.c:202-208 (slot 
 	HubLock lk(f);
 	mixer_release_held(f, s, false);
 	s->prepared = false;
+	s->forwards_unlocked.store(false, std::memory_order_release);
 	if (s->pool) {
 		s->pool->staged[(size_t)s->slot] = s->pool->ready[(size_t)s->slot] = 0;
 		s->pool->release(s->slot); // the last release of a bank destroys it
@@ -389,6 +401,23 @@ void MixerPool::emit(MSFilter *f, int slot) {
 
 void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
+	if (s->forwards_unlocked.load(std::memory_order_acquire)) { // one linked input, a plain mixer: bypass mode for life (audiomixer.c:244-286)
+		MSQueue *src = f->inputs[s->fwd_pin];
+		MSQueue *only = nullptr;
+		int nout = 0;
+		for (int pin = 0; pin < f->desc->noutputs; ++pin)
+			if (f->outputs[pin]) only = f->outputs[pin], ++nout;
+		for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) {
+			if (nout == 1) {
+				ms_queue_put(only, m);
+				continue;
+			}
+			for (int pin = 0; pin < f->desc->noutputs; ++pin)
+				if (f->outputs[pin]) ms_queue_put(f->outputs[pin], dupmsg(m));
+			freemsg(m);
+		}
+		return;
+	}
 	const double trace_ms = s->fbank ? leg_trace_ms(s->fbank) : 0.0; // MSMI355X_TRACE_SLOW_MS
 	const uint64_t tr0 = trace_ms > 0 ? leg_trace_now() : 0;
 	// lock order everywhere: the hub first, the filter's own lock inside it (the flush task pumps this filter with the hub held)
@@ -523,6 +552,7 @@ int mixer_enable_output(MSFilter *f, void *data) { // :395-408
 	HubLock lk(f);
 	ms_filter_lock(f);
 	s->channels[ctl->pin].output_enabled = (bool_t)ctl->param.enabled;
+	s->forwards_unlocked.store(false, std::memory_order_release); // (from the next walk on under the locks, whatever the new value)
 	s->single_output = has_single_output(f, s);
 	mixer_push_controls(f, s, true);
 	ms_filter_unlock(f);
@@ -532,6 +562,7 @@ int mixer_set_conference_mode(MSFilter *f, void *data) {
 	MixerState *s = (MixerState *)f->data;
 	if ((s->fbank || s->sbank) && *(int *)data == 0) s->unfuse_wanted = true; // the fused batch mixes in conference mode only
 	s->conf_mode = *(int *)data;
+	s->forwards_unlocked.store(false, std::memory_order_release);
 	return 0;
 }
 int mixer_set_master_channel(MSFilter *f, void *data) {

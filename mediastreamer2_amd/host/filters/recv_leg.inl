@@ -257,7 +257,6 @@ struct RecvBank : Pool {
 				continue;
 			}
 			const int16_t *row = h_pcm + ((size_t)e.round * c + s) * kRecvBlock;
-			if (getenv("MSMI355X_TRACE_RECV")) fprintf(stderr, "recv emit slot %d tick %u: kind %d round %d n %d left %d first %d\n", slot, hub->ticker ? (unsigned)hub->ticker->ticks : 0u, e.kind, e.round, e.n, left, row[0]);
 			mblk_t *o;
 			if (e.kind == MI_PLC_RECEIVED && law < 0) { // the block itself, edited in place
 				o = e.m;
@@ -402,7 +401,6 @@ void recv_plc_walk(MSFilter *f, PlcFilter *d) {
 	}
 	if (d->concealer->required(f->ticker->time)) { // :117-166
 		const int buff = d->rate * nch * f->ticker->interval / 1000; // samples
-		if (getenv("MSMI355X_TRACE_RECV")) fprintf(stderr, "recv %p slot %d: conceal at time %llu (tick %u), nent %d\n", (void *)f, leg->slot, (unsigned long long)f->ticker->time, (unsigned)f->ticker->ticks, leg->nent);
 		if (d->cng_set || d->cng_running) { // comfort noise: a silent block flagged as such, no concealer involved
 			if (leg->nent < kRecvEntries) {
 				mblk_t *o = allocb((size_t)buff * 2, 0);

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/resource.h>
+#include <sys/time.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -289,6 +290,57 @@ static void *watchdog(void *arg) {
 	return NULL;
 }
 
+/* PLUGIN_BENCH_SAMPLE=<Hz>: a CPU-time profiler of the walk where the box has none (no perf, no gdb): ITIMER_PROF interrupts whichever
+ * thread is running, the handler keeps the innermost frames' return addresses; at exit they go to stderr as "module+offset" chains with
+ * their counts (scripts/walk_profile.py names them with llvm-symbolizer).  Timed region only. */
+#define SAMPLE_DEPTH 6
+static void *(*g_samples)[SAMPLE_DEPTH];
+static volatile int g_nsamples, g_sampling;
+static int g_sample_cap;
+static void sample_handler(int sig) {
+	(void)sig;
+	if (!g_sampling) return;
+	void *buf[SAMPLE_DEPTH + 2];
+	const int n = backtrace(buf, SAMPLE_DEPTH + 2);
+	const int at = __sync_fetch_and_add(&g_nsamples, 1);
+	if (at >= g_sample_cap) return;
+	for (int i = 0; i < SAMPLE_DEPTH; ++i) g_samples[at][i] = i + 2 < n ? buf[i + 2] : NULL; /* (past the handler and the signal trampoline) */
+}
+static void sample_start(void) {
+	const double hz = atof(getenv("PLUGIN_BENCH_SAMPLE"));
+	g_sample_cap = 400000;
+	g_samples = calloc((size_t)g_sample_cap, sizeof(*g_samples));
+	void *warm[4];
+	backtrace(warm, 4);
+	struct sigaction sa;
+	memset(&sa, 0, sizeof(sa));
+	sa.sa_handler = sample_handler;
+	sa.sa_flags = SA_RESTART;
+	sigaction(SIGPROF, &sa, NULL);
+	struct itimerval it;
+	it.it_interval.tv_sec = 0;
+	it.it_interval.tv_usec = (long)(1e6 / (hz > 0 ? hz : 1000));
+	it.it_value = it.it_interval;
+	setitimer(ITIMER_PROF, &it, NULL);
+}
+static void sample_report(void) {
+	struct itimerval off;
+	memset(&off, 0, sizeof(off));
+	setitimer(ITIMER_PROF, &off, NULL);
+	const int n = g_nsamples < g_sample_cap ? g_nsamples : g_sample_cap;
+	fprintf(stderr, "== plugin_bench samples: %d\n", n);
+	for (int i = 0; i < n; ++i) {
+		fprintf(stderr, "S");
+		for (int k = 0; k < SAMPLE_DEPTH && g_samples[i][k]; ++k) {
+			Dl_info info;
+			if (dladdr(g_samples[i][k], &info) && info.dli_fname)
+				fprintf(stderr, " %s+0x%lx", info.dli_fname, (unsigned long)((char *)g_samples[i][k] - (char *)info.dli_fbase));
+			else fprintf(stderr, " ?+%p", g_samples[i][k]);
+		}
+		fprintf(stderr, "\n");
+	}
+}
+
 /* Paced: ticker k fires at origin + k x (10 ms / T) + n x 10 ms.  A server's MSTickers are created one by one with their conferences
  * (audioconference.c:70-73) and each paces itself from its own start (msticker.c:419-443,496-515): their phases are spread over the
  * interval, they do not all fire in the same instant.  PLUGIN_BENCH_ALIGNED=1: all at once (the worst case; every tick before round 5) */
@@ -498,6 +550,7 @@ int main(int argc, char **argv) {
 	}
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
+	if (getenv("PLUGIN_BENCH_SAMPLE")) sample_start(), g_sampling = 1;
 	if (g_paced) {
 		g_t0 = mono_ns() + 20000000ull; /* the first tick fires 20 ms from now */
 		pthread_barrier_wait(&g_bar);
@@ -514,6 +567,7 @@ int main(int argc, char **argv) {
 	}
 	pthread_barrier_wait(&g_bar);
 	const double wall_ms = now_ms() - t_first;
+	if (g_sampling) g_sampling = 0, sample_report();
 	if (fused_stats) fused_stats(&fc1, &fl1, &la1, &fr1);
 	for (int i = 0; i < g_tickers; ++i) pthread_join(th[i], NULL);
 	g_done = 1;
