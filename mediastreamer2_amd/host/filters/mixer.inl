@@ -128,7 +128,8 @@ struct MixerState { // audiomixer.c:132-143
 	// lock -- nothing of the hub is touched and the filter's own state is not read.  Set at the attach, taken back for good (until the next
 	// attach) by a method that changes an output or the mode; an acquire load in process()
 	std::atomic<bool> forwards_unlocked;
-	int fwd_pin;
+	int fwd_pin, fwd_nout;
+	MSQueue *fwd_out; // (the one linked output when fwd_nout == 1: the links stand while the filter is attached)
 	// the conference and every leg that feeds it as one device-resident batch (filters/leg_chain.inl)
 	LegBank *fbank;     // non-null: fused; the conference is slot `fconf` of that bank
 	int fconf;
@@ -240,7 +241,11 @@ void mixer_prepare(MSFilter *f, bool running) { // (hub locked by the caller)
 	bool every_output = true;
 	for (int i = 0; i < f->desc->ninputs; ++i)
 		if (f->inputs[i]) s->fwd_pin = i;
-	for (int i = 0; i < f->desc->noutputs; ++i) every_output = every_output && (!f->outputs[i] || s->channels[i].output_enabled);
+	s->fwd_nout = 0, s->fwd_out = nullptr;
+	for (int i = 0; i < f->desc->noutputs; ++i) {
+		every_output = every_output && (!f->outputs[i] || s->channels[i].output_enabled);
+		if (f->outputs[i]) s->fwd_out = f->outputs[i], s->fwd_nout++;
+	}
 	s->forwards_unlocked.store(!running && s->one_input && s->conf_mode == 0 && every_output, std::memory_order_release);
 	s->prepared = true;
 	s->acquire_failed = false;
@@ -403,13 +408,9 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 	MixerState *s = (MixerState *)f->data;
 	if (s->forwards_unlocked.load(std::memory_order_acquire)) { // one linked input, a plain mixer: bypass mode for life (audiomixer.c:244-286)
 		MSQueue *src = f->inputs[s->fwd_pin];
-		MSQueue *only = nullptr;
-		int nout = 0;
-		for (int pin = 0; pin < f->desc->noutputs; ++pin)
-			if (f->outputs[pin]) only = f->outputs[pin], ++nout;
 		for (mblk_t *m; (m = ms_queue_get(src)) != NULL;) {
-			if (nout == 1) {
-				ms_queue_put(only, m);
+			if (s->fwd_nout == 1) {
+				ms_queue_put(s->fwd_out, m);
 				continue;
 			}
 			for (int pin = 0; pin < f->desc->noutputs; ++pin)

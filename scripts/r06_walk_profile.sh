@@ -4,7 +4,7 @@
 make -C tests/host plugin_bench >/dev/null 2>&1
 T=$(python3 -c "import os;print(min(16,len(os.sched_getaffinity(0))))")
 SHAPE="${1:-astream default}"; LEGS=${2:-32768}; TAG=${3:-a}
-PLUGIN_BENCH_SHAPE="$SHAPE" PLUGIN_BENCH_PACED=1 PLUGIN_BENCH_SAMPLE=4000 timeout 300 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so $LEGS $T 600 20 > gpurun_out/r06_walk_$TAG.json 2> gpurun_out/r06_walk_$TAG.stderr
+PLUGIN_BENCH_SHAPE="$SHAPE" PLUGIN_BENCH_PACED=1 PLUGIN_BENCH_SAMPLE=2000 timeout 300 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so $LEGS $T 600 20 > gpurun_out/r06_walk_$TAG.json 2> gpurun_out/r06_walk_$TAG.stderr
 python3 -c "
 import json
 d=json.loads(open('gpurun_out/r06_walk_$TAG.json').read().strip().splitlines()[-1])

@@ -498,6 +498,7 @@ typedef struct Task {
 
 typedef struct TickerImpl {
 	MSFilter **filters; /* every filter of the attached graphs, in the order they were attached; NULL: a detached filter's place (compacted when a quarter is holes) */
+	uint8_t *is_source; /* beside `filters`: 1 = a filter without inputs -- the step starts its walks from these alone, as MSTicker walks its execution_list of sources (msticker.c:163-166,:326-343) */
 	int nfilters, cap, holes;
 	Task *tasks;
 	uint64_t tasks_ns, step_ns; /* the last step, by phase */
@@ -511,8 +512,10 @@ static void ti_add(TickerImpl *ti, MSFilter *f) {
 	if (ti->nfilters == ti->cap) {
 		ti->cap = ti->cap ? 2 * ti->cap : 1024;
 		ti->filters = (MSFilter **)realloc(ti->filters, sizeof(MSFilter *) * (size_t)ti->cap);
+		ti->is_source = (uint8_t *)realloc(ti->is_source, (size_t)ti->cap);
 	}
 	SHIM_HDR(f)->idx = ti->nfilters;
+	ti->is_source[ti->nfilters] = f->desc->ninputs == 0;
 	ti->filters[ti->nfilters++] = f;
 }
 
@@ -532,6 +535,7 @@ void ms_ticker_destroy(MSTicker *t) {
 		ti->tasks = n;
 	}
 	free(ti->filters);
+	free(ti->is_source);
 	free(ti);
 	free(t);
 }
@@ -602,7 +606,7 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 	for (int i = 0; i < tmp.n; ++i) { /* their places in the ticker's array become holes */
 		MSFilter *g = tmp.v[i];
 		const int at = SHIM_HDR(g)->idx;
-		if (at >= 0 && at < ti->nfilters && ti->filters[at] == g) ti->filters[at] = NULL, ti->holes++;
+		if (at >= 0 && at < ti->nfilters && ti->filters[at] == g) ti->filters[at] = NULL, ti->is_source[at] = 0, ti->holes++;
 		SHIM_HDR(g)->idx = -1;
 	}
 	free(tmp.v);
@@ -611,6 +615,7 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 		for (int i = 0; i < ti->nfilters; ++i)
 			if (ti->filters[i]) {
 				SHIM_HDR(ti->filters[i])->idx = j;
+				ti->is_source[j] = ti->is_source[i];
 				ti->filters[j++] = ti->filters[i];
 			}
 		ti->nfilters = j, ti->holes = 0;
@@ -724,7 +729,7 @@ void ms_ticker_step(MSTicker *t) {
 	}
 	ti->tasks_ns = now_ns() - t0;
 	for (int i = 0; i < ti->nfilters; ++i)
-		if (ti->filters[i] && ti->filters[i]->desc->ninputs == 0) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
+		if (ti->is_source[i]) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
 	/* filters inside loops: scheduled anyway on a second pass (msticker.c:284-299) */
 	for (int i = 0, n = nunsched, dummy = 0; i < n; ++i) run_graph(unsched[i], t, unsched, &dummy, 1);
 	t->time += (uint64_t)t->interval;

@@ -258,6 +258,7 @@ static void build(TickerJob *j) {
 static volatile uint64_t g_step_start[256]; /* per ticker: start of the running step (ns), 0 = not in a step */
 static pthread_t g_threads[256];
 static double g_stack_ms;
+static volatile int g_sampling;
 static volatile int g_stack_dumps, g_done;
 static uint64_t mono_ns(void) {
 	struct timespec ts;
@@ -290,12 +291,13 @@ static void *watchdog(void *arg) {
 	return NULL;
 }
 
-/* PLUGIN_BENCH_SAMPLE=<Hz>: a CPU-time profiler of the walk where the box has none (no perf, no gdb): ITIMER_PROF interrupts whichever
- * thread is running, the handler keeps the innermost frames' return addresses; at exit they go to stderr as "module+offset" chains with
+/* PLUGIN_BENCH_SAMPLE=<Hz>: a profiler of the ticker threads' steps where the box has none (no perf, no gdb): every ticker thread inside a
+ * step is signalled <Hz> times a second, the handler keeps the innermost frames' return addresses; at exit they go to stderr as "module+offset" chains with
  * their counts (scripts/walk_profile.py names them with llvm-symbolizer).  Timed region only. */
 #define SAMPLE_DEPTH 6
 static void *(*g_samples)[SAMPLE_DEPTH];
-static volatile int g_nsamples, g_sampling;
+static volatile int g_nsamples;
+static pthread_t g_sampler;
 static int g_sample_cap;
 static void sample_handler(int sig) {
 	(void)sig;
@@ -306,8 +308,20 @@ static void sample_handler(int sig) {
 	if (at >= g_sample_cap) return;
 	for (int i = 0; i < SAMPLE_DEPTH; ++i) g_samples[at][i] = i + 2 < n ? buf[i + 2] : NULL; /* (past the handler and the signal trampoline) */
 }
-static void sample_start(void) {
+/* ITIMER_PROF ticks with the kernel's jiffies (250 a second for the whole process): a thread of its own signals every ticker thread that
+ * is inside a step, `hz` times a second each */
+static void *sampler(void *arg) {
 	const double hz = atof(getenv("PLUGIN_BENCH_SAMPLE"));
+	const useconds_t gap = (useconds_t)(1e6 / (hz > 0 ? hz : 1000));
+	(void)arg;
+	while (g_sampling) {
+		for (int i = 0; i < g_tickers && i < 256; ++i)
+			if (g_step_start[i]) pthread_kill(g_threads[i], SIGPROF);
+		usleep(gap);
+	}
+	return NULL;
+}
+static void sample_start(void) {
 	g_sample_cap = 400000;
 	g_samples = calloc((size_t)g_sample_cap, sizeof(*g_samples));
 	void *warm[4];
@@ -317,16 +331,11 @@ static void sample_start(void) {
 	sa.sa_handler = sample_handler;
 	sa.sa_flags = SA_RESTART;
 	sigaction(SIGPROF, &sa, NULL);
-	struct itimerval it;
-	it.it_interval.tv_sec = 0;
-	it.it_interval.tv_usec = (long)(1e6 / (hz > 0 ? hz : 1000));
-	it.it_value = it.it_interval;
-	setitimer(ITIMER_PROF, &it, NULL);
+	g_sampling = 1;
+	pthread_create(&g_sampler, NULL, sampler, NULL);
 }
 static void sample_report(void) {
-	struct itimerval off;
-	memset(&off, 0, sizeof(off));
-	setitimer(ITIMER_PROF, &off, NULL);
+	pthread_join(g_sampler, NULL);
 	const int n = g_nsamples < g_sample_cap ? g_nsamples : g_sample_cap;
 	fprintf(stderr, "== plugin_bench samples: %d\n", n);
 	for (int i = 0; i < n; ++i) {
@@ -401,7 +410,7 @@ static void *run(void *arg) {
 		getrusage(RUSAGE_THREAD, &ru0);
 		const double c0 = thread_cpu_ms();
 		const double t0 = now_ms();
-		if (g_stack_ms > 0 && t > 50) g_step_start[j->index] = mono_ns();
+		if ((g_stack_ms > 0 && t > 50) || g_sampling) g_step_start[j->index] = mono_ns();
 		if (g_churn > 0 && t % (100 / g_churn > 0 ? 100 / g_churn : 1) == (j->index % (100 / g_churn > 0 ? 100 / g_churn : 1))) {
 			const int units = g_nomixer ? j->nconf * g_members : j->nconf;
 			MSFilter *root = g_nomixer ? j->heads[j->churn_next % units] : j->mixers[j->churn_next % units];
@@ -550,7 +559,10 @@ int main(int argc, char **argv) {
 	}
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
-	if (getenv("PLUGIN_BENCH_SAMPLE")) sample_start(), g_sampling = 1;
+	if (getenv("PLUGIN_BENCH_SAMPLE") && g_tickers <= 256) {
+		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
+		sample_start();
+	}
 	if (g_paced) {
 		g_t0 = mono_ns() + 20000000ull; /* the first tick fires 20 ms from now */
 		pthread_barrier_wait(&g_bar);
