@@ -3,7 +3,7 @@
 # usage: scripts/r06_walk_profile.sh [shape] [legs] [tag]
 make -C tests/host plugin_bench >/dev/null 2>&1
 T=$(python3 -c "import os;print(min(16,len(os.sched_getaffinity(0))))")
-SHAPE="${1:-astream default}"; LEGS=${2:-32768}; TAG=${3:-a}
+SHAPE="${1:-astream default}"; [ "$SHAPE" = std ] && SHAPE=""; LEGS=${2:-32768}; TAG=${3:-a}
 PLUGIN_BENCH_SHAPE="$SHAPE" PLUGIN_BENCH_PACED=1 PLUGIN_BENCH_SAMPLE=2000 timeout 300 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so $LEGS $T 600 20 > gpurun_out/r06_walk_$TAG.json 2> gpurun_out/r06_walk_$TAG.stderr
 python3 -c "
 import json
