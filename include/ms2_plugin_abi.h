@@ -476,6 +476,9 @@ int ms_mi355x_hub_devices(int *devices, int cap);
 /* Streams whose receiving side (MSAlawDec / MSUlawDec -> MSGenericPLC -> MSAudioFlowControl, src/voip/audiostream.c:1812-1824) lives
  * in one device-resident batch per ticker instead of a bank per filter. */
 int ms_mi355x_recv_stats(void);
+/* 1: this filter's work runs in a device-resident batch it shares with its neighbours (a fused call leg, a conference, a conference server's
+ * member, a stream's receiving side); 0: in a bank of its own type (or it has not run yet); -1: not one of this plugin's filters. */
+int ms_mi355x_filter_in_batch(MSFilter *f);
 /* Waits for every hub's stream (tests, orderly shutdown). */
 void ms_mi355x_shutdown(void);
 #ifdef __cplusplus

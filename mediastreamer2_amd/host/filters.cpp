@@ -876,6 +876,13 @@ int ms_mi355x_recv_stats(void) {
 	return n;
 }
 
+// 1: the facade's work runs in a batch it shares with its neighbours; 0: in a bank of its own (or it has not run); -1: not a filter of this plugin
+int ms_mi355x_filter_in_batch(MSFilter *f) {
+	if (!f || !f->desc || !is_ours(f->desc)) return -1;
+	HubLock lk(f);
+	return facade_in_batch(f) ? 1 : 0;
+}
+
 // the device of every hub that has opened a context (tests: tickers spread over MSMI355X_DEVICES); returns their number
 int ms_mi355x_hub_devices(int *devices, int cap) {
 	int n = 0;

@@ -90,3 +90,18 @@ void generic_preprocess(MSFilter *f) { // a facade with nothing of its own to pr
 	HubLock lk(f);
 	graph_preprocessed(f);
 }
+
+// does this facade's work run in a device-resident batch shared with its neighbours (a fused sending leg, a conference, a server's member, a
+// stream's receiving side) rather than in a bank of its own?  (hub locked)
+bool facade_in_batch(MSFilter *f) {
+	const MSFilterDesc *d = f->desc;
+	if (d == &ms_mi355x_resample_desc) return ((ResampleData *)f->data)->leg != nullptr;
+	if (is_ec_desc(d)) return ((SpeexECState *)f->data)->leg != nullptr;
+	if (d == &ms_mi355x_volume_desc) return ((VolumeData *)f->data)->leg || ((VolumeData *)f->data)->sleg || ((VolumeData *)f->data)->meter_leg;
+	if (d == &ms_mi355x_equalizer_desc) return ((EqualizerData *)f->data)->leg != nullptr;
+	if (d == &ms_mi355x_audio_mixer_desc) return ((MixerState *)f->data)->fbank || ((MixerState *)f->data)->sbank;
+	if (is_g711_dec(d) || is_g711_enc(d)) return ((MapFilter *)f->data)->sleg || ((MapFilter *)f->data)->rleg || ((MapFilter *)f->data)->fleg;
+	if (d == &ms_mi355x_generic_plc_desc) return ((PlcFilter *)f->data)->rleg != nullptr;
+	if (d == &ms_mi355x_audio_flow_control_desc) return ((FlowFilter *)f->data)->rleg != nullptr;
+	return false;
+}

@@ -127,6 +127,8 @@ bool equalizer_passes(MSFilter *g, MSTicker *ticker) { // (hub locked)
 	if (d->active || d->was_active || d->leg || ms_bufferizer_get_avail(d->spill)) return false;
 	return !d->pool || (d->pool->staged[(size_t)d->slot] == 0 && d->pool->ready[(size_t)d->slot] == 0);
 }
+// (for a neighbour's preprocess, which may run before this filter's own: `was_active` is then still the previous attach's)
+bool equalizer_idle(MSFilter *g) { return g && g->desc == &ms_mi355x_equalizer_desc && !((const EqualizerData *)g->data)->active && !((const EqualizerData *)g->data)->leg; }
 FusedLeg *leg_fed_far_end_by(MSFilter *f); // leg_chain.inl: the fused leg whose far end / microphone passes through this filter
 FusedLeg *leg_fed_mic_by(MSFilter *f);
 void leg_eq_op(FusedLeg *leg, const EqualizerPool::Op &op); // leg_chain.inl

@@ -417,13 +417,14 @@ void volume_attach_slot(MSFilter *f) {
 	}
 }
 
+bool equalizer_idle(MSFilter *g); // equalizer.inl: an MSEqualizer of ours that is switched off (it will hand its blocks on in the walk once attached)
 void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 	VolumeData *d = (VolumeData *)f->data;
 	d->nsamples = (int)(0.01 * (float)d->sample_rate);
 	d->min.reset();
 	d->max.reset();
 	d->feeds_far_end = false;
-	{ // downstream through filters that are not ours (recv_tee ..) to MSSpeexEC's pin 0?
+	{ // downstream through filters that are not ours (recv_tee ..) and a spk_equalizer that is not active (audiostream.c:1826-1829) to MSSpeexEC's pin 0?
 		MSQueue *q = f->outputs[0];
 		for (int hops = 0; q && hops < 12; ++hops) {
 			MSFilter *g = q->next.filter;
@@ -432,7 +433,7 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 				d->feeds_far_end = q->next.pin == 0;
 				break;
 			}
-			if (is_ours(g->desc) || g->desc->noutputs != 1) break;
+			if ((is_ours(g->desc) && !equalizer_idle(g)) || g->desc->noutputs != 1) break;
 			q = g->outputs[0];
 		}
 	}

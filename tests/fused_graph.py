@@ -144,7 +144,7 @@ class Conferences:
 
     def __init__(self, h, nconf, members, in_rate=16000, rate=48000, tail_ms=128, delay_ms=0, agc=True, pins=None, gain=None, mixer=True, resampler=True,
                  endpoint_resamplers=False, echo_limiter=False, mic_equalizer=False, volrecv=False, cpu_filters=False, g711=False, spk_equalizer=False,
-                 flowcontrol=False, dtmfgen_rtp=True, encoder=True, local_mixer=0, outbound_mixer=False, alaw=False, idle_equalizers=False):
+                 flowcontrol=False, dtmfgen_rtp=True, encoder=True, local_mixer=0, outbound_mixer=False, alaw=False, idle_equalizers=False, recv_tee=True):
         self.h, self.S = h, h.S
         S = h.S
         self.ticker = S.ms_ticker_new()
@@ -223,8 +223,14 @@ class Conferences:
                                 h.call_int(leg["fc"], base("MS_FILTER_SET_NCHANNELS"), 1)
                                 links += [(leg["plc"], 0, leg["fc"], 0)]
                                 head = leg["fc"]
-                        links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0), (leg["volrecv"], 0, leg["recv_tee"], 0)]
-                        links += [(leg["recv_tee"], 0, leg["spk_eq"], 0), (leg["spk_eq"], 0, leg["ec"], 0)] if idle_equalizers else [(leg["recv_tee"], 0, leg["ec"], 0)]
+                        links += [(head, 0, leg["dtmfgen"], 0), (leg["dtmfgen"], 0, leg["volrecv"], 0)]
+                        behind = leg["volrecv"]
+                        if recv_tee:   # (only with a recording feature, audiostream.c:1776-1786,1827: without one volrecv stands right in front of spk_equalizer)
+                            links += [(leg["volrecv"], 0, leg["recv_tee"], 0)]
+                            behind = leg["recv_tee"]
+                        else:
+                            S.ms_filter_destroy(leg.pop("recv_tee"))
+                        links += [(behind, 0, leg["spk_eq"], 0), (leg["spk_eq"], 0, leg["ec"], 0)] if idle_equalizers else [(behind, 0, leg["ec"], 0)]
                     elif spk_equalizer:   # audiostream.c:1828: an MSEqualizer of ours right in front of the canceller's far end -- it delivers with the flush
                         leg["spk_eq"] = S.ms_factory_create_filter(h.fac, MS_EQUALIZER_ID)
                         h.call_int(leg["spk_eq"], base("MS_FILTER_SET_SAMPLE_RATE"), rate)
@@ -328,7 +334,7 @@ def run(plugin_dir, fuse, scenario, h=None):
                        gain=sc.get("gain"), mixer=not sc.get("no_mixer"), resampler=not sc.get("no_resampler"), agc=not sc.get("no_agc"),
                        endpoint_resamplers=bool(sc.get("endpoint_resamplers")), echo_limiter=bool(sc.get("echo_limiter")), mic_equalizer=bool(sc.get("mic_equalizer")), volrecv=bool(sc.get("volrecv")), cpu_filters=bool(sc.get("cpu_filters")), g711=bool(sc.get("g711")), spk_equalizer=bool(sc.get("spk_equalizer")),
                        flowcontrol=bool(sc.get("flowcontrol")), dtmfgen_rtp=sc.get("dtmfgen_rtp", True), encoder=sc.get("encoder", True), local_mixer=int(sc.get("local_mixer", 0)),
-                       outbound_mixer=bool(sc.get("outbound_mixer")), alaw=bool(sc.get("alaw")), idle_equalizers=bool(sc.get("idle_equalizers")))
+                       outbound_mixer=bool(sc.get("outbound_mixer")), alaw=bool(sc.get("alaw")), idle_equalizers=bool(sc.get("idle_equalizers")), recv_tee=not sc.get("no_recv_tee"))
     n = sc["nconf"] * sc["members"]
     nt, ni, ns = sc["nticks"], sc["in_rate"] // 100, sc["rate"] // 100
     mic, far = scene(n, nt, sc["in_rate"], sc["rate"], seed=sc.get("seed", 7))
@@ -471,6 +477,11 @@ SCENARIOS = {
     "audiostream_8k_all_features_idle_equalizers": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 1,
                                                     "outbound_mixer": True, "idle_equalizers": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000,
                                                     "nconf": 1, "members": 5, "nticks": 120, "events": [(41, "reattach", 0, 0), (90, "spk_eq_active", 2, 1)], "tail_blocks": 2, "compare_ticks": 88},
+    # ... without a recording feature there is no recv_tee (audiostream.c:1776-1786): volrecv hands its blocks straight to the idle spk_equalizer -- it is still a meter that
+    # passes in the walk (volume_preprocess finds the canceller's far end THROUGH the equalizer) and the stream still fuses
+    "audiostream_8k_idle_equalizers_without_recv_tee": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 1,
+                                                        "outbound_mixer": True, "idle_equalizers": True, "no_recv_tee": True, "no_mixer": True, "no_agc": True, "no_resampler": True,
+                                                        "in_rate": 8000, "rate": 8000, "nconf": 1, "members": 4, "nticks": 100, "events": [(41, "reattach", 0, 0)], "tail_blocks": 2},
     # ... with the local player linked (and idle): the local_mixer has two inputs, mixes for the first second and forwards afterwards (audiomixer.c:244-286)
     "audiostream_8k_default_features_local_player_linked": {"volrecv": True, "cpu_filters": True, "g711": True, "lossless": True, "flowcontrol": True, "dtmfgen_rtp": False, "local_mixer": 2,
                                                             "outbound_mixer": True, "no_mixer": True, "no_agc": True, "no_resampler": True, "in_rate": 8000, "rate": 8000, "nconf": 1,

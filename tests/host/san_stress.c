@@ -46,6 +46,7 @@ static void (*p_stats)(int *, int *, int *);
 static void (*p_flush)(void);
 static int (*p_hub_devices)(int *, int);
 static unsigned long long (*p_late)(void);
+static int (*p_in_batch)(MSFilter *);
 
 #define CHECK(c)                                                        \
 	do {                                                                \
@@ -522,10 +523,12 @@ static void *server_conferences(void *arg) {
 /* Full-duplex G.711 AudioStreams as audiostream.c:1796-1832 plumbs them with the default features (filters/recv_leg.inl, the encoder in the leg's
  * batch): packets -> MSUlawDec -> local_mixer (one input) -> MSGenericPLC -> MSAudioFlowControl -> dtmfgen (the application's) -> volrecv ->
  * MSSpeexEC pin 0 -> speaker;  microphone -> MSSpeexEC pin 1 -> volsend -> outbound_mixer (one input) -> MSUlawEnc -> packets.  Fused at the attach
- * (on THIS thread, while other tickers run), lost packets, a drop request and a PLC rate change from ANOTHER thread during the walk, a re-plumbing,
+ * (on THIS thread, while other tickers run); both equalizers of AUDIO_STREAM_FEATURE_EQUALIZER in place and inactive (mic_equalizer in front of pin 1,
+ * spk_equalizer in front of pin 0: transparent, no lock taken); lost packets, a drop request, a PLC rate change, an equalizer switched on and a
+ * mixer's output disabled from ANOTHER thread during the walk, a re-plumbing,
  * teardown with the decoder / the PLC / the encoder destroyed first in turn. */
 typedef struct {
-	MSFilter *fc, *plc, *vol;
+	MSFilter *fc, *plc, *vol, *spk_eq, *omx;
 	volatile int stop;
 } stream_meddle_t;
 static void *stream_meddler(void *arg) {
@@ -537,6 +540,15 @@ static void *stream_meddler(void *arg) {
 		ev.flow_control_interval_ms = 200, ev.drop_ms = 10;
 		ms_filter_call_method(m->fc, MS_AUDIO_FLOW_CONTROL_DROP, &ev);
 		ms_filter_call_method(m->vol, MS_VOLUME_SET_GAIN, &g);
+		if (n == 15) { /* an equalizer that has handed its blocks on without a lock since the attach is switched on in mid-walk: its leg goes back to its facades */
+			int on = 1;
+			ms_filter_call_method(m->spk_eq, MS_EQUALIZER_SET_ACTIVE, &on);
+		}
+		if (n == 25 || n == 30) { /* the same for a one-input mixer: an output disabled and enabled again -- under the locks from then on */
+			MSAudioMixerCtl ctl;
+			ctl.pin = 0, ctl.param.enabled = n == 30;
+			ms_filter_call_method(m->omx, MS_AUDIO_MIXER_ENABLE_OUTPUT, &ctl);
+		}
 		if (++n == 40) { /* another rate and back: the stream's receiving side leaves its batch at the next walk and carries on at 8 kHz on its facades */
 			set_int(m->plc, MS_FILTER_SET_SAMPLE_RATE, 16000);
 			set_int(m->plc, MS_FILTER_SET_SAMPLE_RATE, 8000);
@@ -553,26 +565,31 @@ static void *audiostreams(void *arg) {
 	for (int i = 0; i < 80; ++i) pcm[i] = (int16_t)(i * 211 % 6000 - 3000), codes[i] = (uint8_t)(i * 29 + 7);
 	for (int rep = 0; rep < (g_rounds + 1) / 2; ++rep) {
 		MSTicker *tk = ms_ticker_new();
-		MSFilter *mic[NS_], *far[NS_], *spk[NS_], *out[NS_], *dec[NS_], *lmx[NS_], *plc[NS_], *fc[NS_], *dtmf[NS_], *vr[NS_], *ec[NS_], *vs[NS_], *omx[NS_], *enc[NS_];
+		MSFilter *mic[NS_], *far[NS_], *spk[NS_], *out[NS_], *dec[NS_], *lmx[NS_], *plc[NS_], *fc[NS_], *dtmf[NS_], *vr[NS_], *ec[NS_], *vs[NS_], *omx[NS_], *enc[NS_], *meq[NS_], *seq[NS_];
 		for (int k = 0; k < NS_; ++k) {
 			mic[k] = ms2shim_new_source(g_fac), far[k] = ms2shim_new_source(g_fac), spk[k] = ms2shim_new_sink(g_fac), out[k] = ms2shim_new_sink(g_fac);
 			dec[k] = ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID), lmx[k] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
 			plc[k] = ms_factory_create_filter(g_fac, MS_GENERIC_PLC_ID), fc[k] = ms_factory_create_filter(g_fac, MS_AUDIO_FLOW_CONTROL_ID);
 			dtmf[k] = ms2shim_new_pass(g_fac), vr[k] = ms_factory_create_filter(g_fac, MS_VOLUME_ID), ec[k] = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID);
 			vs[k] = ms_factory_create_filter(g_fac, MS_VOLUME_ID), omx[k] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID), enc[k] = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
-			CHECK(dec[k] && lmx[k] && plc[k] && fc[k] && vr[k] && ec[k] && vs[k] && omx[k] && enc[k]);
+			meq[k] = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID), seq[k] = ms_factory_create_filter(g_fac, MS_EQUALIZER_ID);
+			CHECK(dec[k] && lmx[k] && plc[k] && fc[k] && vr[k] && ec[k] && vs[k] && omx[k] && enc[k] && meq[k] && seq[k]);
+			for (MSFilter **f = (MSFilter *[]){meq[k], seq[k], NULL}; *f; ++f) {
+				int off = 0;
+				set_int(*f, MS_FILTER_SET_SAMPLE_RATE, 8000);
+				ms_filter_call_method(*f, MS_EQUALIZER_SET_ACTIVE, &off);
+			}
 			ms2shim_sink_set_discard(spk[k], 1), ms2shim_sink_set_discard(out[k], 1);
 			for (MSFilter **f = (MSFilter *[]){lmx[k], plc[k], fc[k], vr[k], ec[k], vs[k], omx[k], NULL}; *f; ++f) set_int(*f, MS_FILTER_SET_SAMPLE_RATE, 8000);
 			set_int(ec[k], MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
 			ms_filter_link(far[k], 0, dec[k], 0), ms_filter_link(dec[k], 0, lmx[k], 0), ms_filter_link(lmx[k], 0, plc[k], 0), ms_filter_link(plc[k], 0, fc[k], 0);
-			ms_filter_link(fc[k], 0, dtmf[k], 0), ms_filter_link(dtmf[k], 0, vr[k], 0), ms_filter_link(vr[k], 0, ec[k], 0), ms_filter_link(ec[k], 0, spk[k], 0);
-			ms_filter_link(mic[k], 0, ec[k], 1), ms_filter_link(ec[k], 1, vs[k], 0), ms_filter_link(vs[k], 0, omx[k], 0), ms_filter_link(omx[k], 0, enc[k], 0);
+			ms_filter_link(fc[k], 0, dtmf[k], 0), ms_filter_link(dtmf[k], 0, vr[k], 0), ms_filter_link(vr[k], 0, seq[k], 0), ms_filter_link(seq[k], 0, ec[k], 0), ms_filter_link(ec[k], 0, spk[k], 0);
+			ms_filter_link(mic[k], 0, meq[k], 0), ms_filter_link(meq[k], 0, ec[k], 1), ms_filter_link(ec[k], 1, vs[k], 0), ms_filter_link(vs[k], 0, omx[k], 0), ms_filter_link(omx[k], 0, enc[k], 0);
 			ms_filter_link(enc[k], 0, out[k], 0);
 			CHECK(ms_ticker_attach(tk, mic[k]) == 0);
 		}
-		stream_meddle_t md = {fc[1], plc[2], vs[3], 0};
+		stream_meddle_t md = {fc[1], plc[2], vs[3], seq[4], omx[0], 0};
 		pthread_t mt;
-		pthread_create(&mt, NULL, stream_meddler, &md);
 		for (int t = 0; t < 24; ++t) {
 			for (int k = 0; k < NS_; ++k) {
 				ms2shim_source_push(mic[k], pcm, sizeof pcm);
@@ -583,6 +600,9 @@ static void *audiostreams(void *arg) {
 				int nl = 0;
 				p_fused(NULL, &nl, NULL, NULL);
 				CHECK(nl >= NS_);
+				for (int k = 0; k < NS_; ++k) /* (the count above is the process's: these are THIS thread's streams, both directions) */
+					CHECK(p_in_batch(ec[k]) == 1 && p_in_batch(enc[k]) == 1 && p_in_batch(dec[k]) == 1 && p_in_batch(plc[k]) == 1 && p_in_batch(fc[k]) == 1);
+				pthread_create(&mt, NULL, stream_meddler, &md); /* (from here on legs leave their batch as the meddler's methods land) */
 			}
 			if (t == 11) { /* one stream re-plumbed under the others' feet */
 				ms_ticker_detach(tk, mic[0]);
@@ -593,11 +613,11 @@ static void *audiostreams(void *arg) {
 		pthread_join(mt, NULL);
 		for (int k = 0; k < NS_; ++k) ms_ticker_detach(tk, mic[k]);
 		for (int k = 0; k < NS_; ++k) {
-			MSFilter *all[] = {mic[k], far[k], spk[k], out[k], dec[k], lmx[k], plc[k], fc[k], dtmf[k], vr[k], ec[k], vs[k], omx[k], enc[k]};
+			MSFilter *all[] = {mic[k], far[k], spk[k], out[k], dec[k], lmx[k], plc[k], fc[k], dtmf[k], vr[k], ec[k], vs[k], omx[k], enc[k], meq[k], seq[k]};
 			MSFilter *first = (k % 3 == 0) ? dec[k] : ((k % 3 == 1) ? plc[k] : enc[k]); /* (whoever goes first, nobody reaches into a freed filter) */
 			ms_filter_unlink(far[k], 0, dec[k], 0), ms_filter_unlink(dec[k], 0, lmx[k], 0), ms_filter_unlink(lmx[k], 0, plc[k], 0), ms_filter_unlink(plc[k], 0, fc[k], 0);
-			ms_filter_unlink(fc[k], 0, dtmf[k], 0), ms_filter_unlink(dtmf[k], 0, vr[k], 0), ms_filter_unlink(vr[k], 0, ec[k], 0), ms_filter_unlink(ec[k], 0, spk[k], 0);
-			ms_filter_unlink(mic[k], 0, ec[k], 1), ms_filter_unlink(ec[k], 1, vs[k], 0), ms_filter_unlink(vs[k], 0, omx[k], 0), ms_filter_unlink(omx[k], 0, enc[k], 0);
+			ms_filter_unlink(fc[k], 0, dtmf[k], 0), ms_filter_unlink(dtmf[k], 0, vr[k], 0), ms_filter_unlink(vr[k], 0, seq[k], 0), ms_filter_unlink(seq[k], 0, ec[k], 0), ms_filter_unlink(ec[k], 0, spk[k], 0);
+			ms_filter_unlink(mic[k], 0, meq[k], 0), ms_filter_unlink(meq[k], 0, ec[k], 1), ms_filter_unlink(ec[k], 1, vs[k], 0), ms_filter_unlink(vs[k], 0, omx[k], 0), ms_filter_unlink(omx[k], 0, enc[k], 0);
 			ms_filter_unlink(enc[k], 0, out[k], 0);
 			ms_filter_destroy(first);
 			for (size_t i = 0; i < sizeof(all) / sizeof(all[0]); ++i)
@@ -645,7 +665,8 @@ int main(int argc, char **argv) {
 		p_hub_devices = (int (*)(int *, int))dlsym(so, "ms_mi355x_hub_devices");
 		p_late = (unsigned long long (*)(void))dlsym(so, "ms_mi355x_late_events");
 		p_fused = dlsym(so, "ms_mi355x_fused_stats");
-		if (!p_stats || !p_flush || !p_hub_devices || !p_late || !p_fused) {
+		p_in_batch = (int (*)(MSFilter *))dlsym(so, "ms_mi355x_filter_in_batch");
+		if (!p_stats || !p_flush || !p_hub_devices || !p_late || !p_fused || !p_in_batch) {
 			fprintf(stderr, "san_stress: plugin entry points missing\n");
 			return 2;
 		}

@@ -33,7 +33,7 @@ def verdict():
                                   "echo_limiter_conference_keeps_its_facades",
                                   "far_end_through_volrecv", "far_end_through_volrecv_no_mixer", "volrecv_with_a_gain_from_the_start", "spk_equalizer_keeps_the_leg_on_its_facades", "audiostream_16k_with_the_applications_filters", "audiostream_8k_g711",
                                   "audiostream_8k_g711_lossless", "audiostream_8k_pcma_flowcontrol_encoder_in_the_leg", "audiostream_8k_default_features",
-                                  "audiostream_8k_default_features_local_player_linked", "audiostream_8k_all_features_idle_equalizers",
+                                  "audiostream_8k_default_features_local_player_linked", "audiostream_8k_all_features_idle_equalizers", "audiostream_8k_idle_equalizers_without_recv_tee",
                                   "mic_equalizer", "mic_equalizer_no_mixer_8k_16k", "mic_equalizer_replumbed_then_leaves",
                                   "agc_switched_off_midcall", "bypass_switched_midcall", "agc_switched_on_midcall_no_mixer", "in_resampler_told_to_resample_midcall",
                                   "replumbed", "ptime20_replumbed", "ptime20_replumbed_no_early_launch", "no_agc_replumbed", "no_agc_ptime20_16k_replumbed"])
