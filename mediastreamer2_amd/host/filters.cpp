@@ -172,6 +172,7 @@ struct TickerHub {
 	int pins = 0; // objects outside the banks that use `ctx` (MSScalerDesc contexts): the hub stays while there are any
 	std::vector<Pool *> pools;         // flush order = creation order
 	MSFilter *flush_owner = nullptr;   // the filter whose postponed task will flush this ticker's pools (NULL: none pending)
+	uint32_t flush_posted_tick = 0;    // ... and the tick it was posted in (MSTicker::ticks): it runs at the head of the next one -- or it was dropped (request_flush)
 	// chain linking: while the flush task runs, a facade that emits into a queue read by ANOTHER facade of this ticker has
 	// that one run right away (then its bank is flushed in the same task): a chain of GPU filters costs one tick, not one
 	// tick per filter
@@ -202,6 +203,9 @@ struct TickerHub {
 };
 
 mi_ctx *Pool::ctx() const { return hub->ctx; }
+// MSTicker::time as a bank reads it.  The ticker's own thread advances it between ticks (msticker.c:494-495); a bank may be at work on the
+// APPLICATION's thread then -- a postprocess delivering a detaching graph's tick in flight -- and reads whichever of the two values: a relaxed load
+inline uint64_t hub_time(const TickerHub *h) { return h->ticker ? __atomic_load_n(&h->ticker->time, __ATOMIC_RELAXED) : 0; }
 bool Pool::work_waiting() const { return hub->flush_owner != nullptr && !hub->in_flush; }
 bool Pool::parked(int slot) const { return hub->scope && !(owner[(size_t)slot] && hub->scope->count(owner[(size_t)slot])); }
 void Pool::sync_stream() {
@@ -454,7 +458,9 @@ inline void emit_to(MSQueue *q, mblk_t *m) {
 	TickerHub *h = tl_hub;
 	if (!h || !h->in_flush) return;
 	MSFilter *g = q->next.filter;
-	if (!g || g->ticker != h->ticker || !h->ticker || !is_ours(g->desc)) return;
+	// (the reader may belong to a graph that is being attached right now, on the application's thread: its leg joined this hub's batch when the last
+	// facade was preprocessed, ms_ticker_attach is still setting the remaining filters' tickers -- msticker.c:163-166)
+	if (!g || !is_ours(g->desc) || __atomic_load_n(&g->ticker, __ATOMIC_RELAXED) != h->ticker || !h->ticker) return;
 	if (h->scope && !h->scope->count(g)) return; // (a detaching graph's flush runs nobody else's process())
 	std::vector<MSFilter *> &v = (g->desc->flags & MS_FILTER_IS_PUMP) ? h->touched_pumps : h->touched;
 	if (std::find(v.begin(), v.end(), g) == v.end()) v.push_back(g);
@@ -547,8 +553,13 @@ void flush_task(MSFilter *f) {
 void request_flush(MSFilter *f) {
 	++g_hub.stage_seq;
 	if (g_hub.in_flush) return; // staged from inside the flush task (chain linking): the task's loop gets to it
+	// A task posted in an earlier tick runs at the head of this one (msticker.c:484-485: run_tasks, then run_graphs).  If it is still owed, its
+	// filter left the ticker in between: ms_ticker_detach drops a detaching filter's tasks (msticker.c:187-190,:314-324) on the APPLICATION's
+	// thread, and a walk may run before that filter's postprocess tells this hub (facade_detached) -- post a new one
+	if (g_hub.flush_owner && f->ticker && g_hub.flush_posted_tick != f->ticker->ticks) g_hub.flush_owner = nullptr;
 	if (!g_hub.flush_owner) {
 		g_hub.flush_owner = f;
+		g_hub.flush_posted_tick = f->ticker ? f->ticker->ticks : 0;
 		ms_filter_postpone_task(f, flush_task);
 	}
 }

@@ -859,8 +859,8 @@ struct LegBank : Pool {
 				if (h_pn[(size_t)r * Ln + s] <= 0) continue;
 				pstate[s] = h_pround[(size_t)r * Ln + s];
 				if (hub->ticker) {
-					pd->max.record_max(hub->ticker->time, pstate[s].energy);
-					pd->min.record_min(hub->ticker->time, pstate[s].energy);
+					pd->max.record_max(hub_time(hub), pstate[s].energy);
+					pd->min.record_min(hub_time(hub), pstate[s].energy);
 				}
 			}
 		}
@@ -871,7 +871,7 @@ struct LegBank : Pool {
 	// (the walks are over and the ticker's clock reads what that flush would read): the tick in flight includes them
 	void launch_staged() {
 		if (failed || !staged_since || !hub->ticker) return;
-		const bool more = enqueue_at(hub->ticker->time);
+		const bool more = enqueue_at(hub_time(hub));
 		early_any = early ? (early_any || more) : more;
 		early = true;
 	}
@@ -880,8 +880,17 @@ struct LegBank : Pool {
 		sync_stream();
 		if (failed) return;
 		outstanding = false;
+		// (this may be the APPLICATION's thread -- a postprocess, msticker.c:221 -- while the ticker walks the bank's other graphs: only the
+		// owner's graph is handed anything here, the other legs' speaker frames follow with the ticker's own flush; TickerHub::scope)
+		const std::unordered_set<MSFilter *> *outer = hub->scope;
+		std::unordered_set<MSFilter *> own;
+		if (!outer) {
+			graph_of(owner_filter, own);
+			hub->scope = &own;
+		}
 		finish();
 		emit(owner_filter, slot);
+		hub->scope = outer;
 	}
 	// vstate as the device holds it NOW (a leg is about to leave with its MSVolume's running state): launches that are out and not
 	// waited for yet are waited for, their read-back taken
@@ -962,7 +971,7 @@ struct LegBank : Pool {
 			any = early_any;
 		}
 		// (what was staged after an early enqueue -- a conference that joined the bank later in that walk -- goes out now)
-		if (!was_early || staged_since) any |= enqueue_at(hub->ticker ? hub->ticker->time : 0);
+		if (!was_early || staged_since) any |= enqueue_at(hub_time(hub));
 		outstanding = false; // the hub waits for the stream right behind this
 		return any;
 	}
@@ -1166,11 +1175,11 @@ struct LegBank : Pool {
 					VolumeData *vd = (VolumeData *)leg->vol->data;
 					for (int r = 0; r < vrounds; ++r)
 						if (vhas[(size_t)r * L + s]) {
-							vd->max.record_max(hub->ticker->time, h_vround[(size_t)r * L + s].energy);
-							vd->min.record_min(hub->ticker->time, h_vround[(size_t)r * L + s].energy);
+							vd->max.record_max(hub_time(hub), h_vround[(size_t)r * L + s].energy);
+							vd->min.record_min(hub_time(hub), h_vround[(size_t)r * L + s].energy);
 						}
-					vd->max.record_max(hub->ticker->time, vstate[s].energy);
-					vd->min.record_min(hub->ticker->time, vstate[s].energy);
+					vd->max.record_max(hub_time(hub), vstate[s].energy);
+					vd->min.record_min(hub_time(hub), vstate[s].energy);
 				}
 				leg->metered = false;
 			}
@@ -1350,7 +1359,7 @@ void leg_conf_walked(LegBank *b, int c) {
 	if (b->walk_tick[(size_t)c] == tick) return;
 	b->walk_tick[(size_t)c] = tick;
 	if (++b->walked < b->in_use) return;
-	b->early_any = b->enqueue_at(b->hub->ticker->time + (uint64_t)b->hub->ticker->interval); // the mixers' clock reads what the flush would
+	b->early_any = b->enqueue_at(hub_time(b->hub) + (uint64_t)b->hub->ticker->interval); // the mixers' clock reads what the flush would
 	b->early = true;
 }
 
@@ -1364,7 +1373,7 @@ void leg_far_walked(LegBank *b, FusedLeg *leg) {
 	if (leg->far_tick == tick) return;
 	leg->far_tick = tick;
 	if (++b->walked < b->in_use) return;
-	b->early_any = b->enqueue_at(b->hub->ticker->time + (uint64_t)b->hub->ticker->interval);
+	b->early_any = b->enqueue_at(hub_time(b->hub) + (uint64_t)b->hub->ticker->interval);
 	b->early = true;
 }
 
@@ -1524,7 +1533,7 @@ bool leg_peer_ok(MSFilter *vol, VolumeData *vd, MSFilter **peer) {
 // ... in front of them, whole chunks that waited in the mixer channel when a fused conference was detached (LegBank::take_remainders)
 bool leg_remainder_ok(const VolumeData *vd, int max_chunks) {
 	const size_t avail = ms_bufferizer_get_avail(vd->buffer);
-	return avail == 0 || (volume_chunks(vd) && avail < (size_t)(vd->sample_rate / 100) * 2 * (size_t)max_chunks && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
+	return avail == 0 || (volume_chunks(vd) && avail <= (size_t)(vd->sample_rate / 100) * 2 * (size_t)max_chunks && avail % 16 == 0); // (whole groups of 8 samples: mi_fifo_reset_range_at)
 }
 
 bool leg_rates_ok(uint32_t in, uint32_t out) { // what the canceller's launch up-samples itself (mi_aec_process_fifos_resampled)
@@ -1582,17 +1591,22 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	// waited a tick in the channel would meet the peer's NEXT meter reading -- a leg without a mixer levels every chunk as it completes)
 	if (!leg_peer_ok(vol, vd, &c.peer) || c.peer || vd->sample_rate != ms->rate || vd->leg) return false; // (with or without AGC: the bank follows, LegBank::light)
 	// (MSVolume's bufferizer may hold samples short of a 10 ms chunk from before a detach: they move to the device, leg_give_remainder)
-	if (!leg_remainder_ok(vd, 3) || ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
+	if (ms_bufferizer_get_avail(vd->spill) || !ms_queue_empty(q)) return false;
 	// the mixer channel's own bufferizer (the facades ran one by one before this attach, or a batch without AGC was left): levelled
 	// samples -- a batch without AGC takes them into its channel queue, one with AGC queues in front of MSVolume and cannot
 	const size_t held = ms_bufferizer_get_avail(&ms->channels[pin].bufferizer);
-	if (held && (volume_chunks(vd) || held % 16 || held > (size_t)(vd->sample_rate / 100) * 2 * 3)) return false;
+	if (held && (volume_chunks(vd) || held % 2)) return false; // (how much: below, once the frame size is known)
 	MSQueue *qe = vol->inputs[0];
 	MSFilter *ec = qe ? qe->prev.filter : NULL;
 	if (!ec || !is_ec_desc(ec->desc) || qe->prev.pin != 1 || ec->ticker != mx->ticker || !ms_queue_empty(qe)) return false;
 	SpeexECState *es = (SpeexECState *)ec->data;
 	if (es->bypass_mode || es->unsupported || !es->configured || es->samplerate != ms->rate || es->echostarted || es->leg) return false;
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
+	// (what a batch handed back at the last detach -- the chunks that waited in the channel, the ticks in flight, the samples short of a chunk:
+	// take_remainders -- is whatever fits the queue it is rebuilt in, LegBank::out_cap.  The bound was "less than three chunks" until
+	// PLUGIN_BENCH_CHURN found conferences that came back with three, five, seven -- and then stayed on their facades for good)
+	const int out_cap = LegBank::frames_up(4 * (vd->sample_rate / 100) + kMaxRounds * 2 * es->framesize, es->framesize);
+	if (!leg_remainder_ok(vd, out_cap / (vd->sample_rate / 100)) || held / 2 > (size_t)out_cap) return false;
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
 	if (rs && equalizer_passes(rs, mx->ticker) && ms_queue_empty(qr) && rs->inputs[0]) { // a mic_equalizer that is not active (audiostream.c:1801): transparent
@@ -2107,7 +2121,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	VolumeData *vd = (VolumeData *)vol->data;
 	MSFilter *peer = nullptr;
 	if (!leg_peer_ok(vol, vd, &peer) || vd->sample_rate != es->samplerate || vd->leg) return false;
-	if (!leg_remainder_ok(vd, 1) || ms_bufferizer_get_avail(vd->spill)) return false;
+	if (!leg_remainder_ok(vd, 1) || ms_bufferizer_get_avail(vd->buffer) >= (size_t)(vd->sample_rate / 100) * 2 || ms_bufferizer_get_avail(vd->spill)) return false; // (MSVolume holds less than a chunk between blocks)
 	const bool no_agc = !volume_chunks(vd); // (10 ms chunks with AGC or an echo-limiter peer, msvolume.c:480)
 	if (!leg_far_end_in_walk(ec, peer)) return false;
 	if (rd && (rd->in_nchannels != 1 || rd->out_nchannels != 1 || !leg_rates_ok(rd->input_rate, rd->output_rate) || rd->leg || ms_bufferizer_get_avail(rd->bz))) return false;

@@ -271,7 +271,7 @@ struct ServerBank : Pool {
 			early = false;
 			any = early_any;
 		}
-		if (!was_early || staged_since) any |= enqueue_at(hub->ticker ? hub->ticker->time : 0);
+		if (!was_early || staged_since) any |= enqueue_at(hub_time(hub));
 		outstanding = false;
 		return any;
 	}
@@ -488,11 +488,11 @@ struct ServerBank : Pool {
 					VolumeData *vd = (VolumeData *)leg->vol->data;
 					for (int r = 0; r < vrounds; ++r)
 						if (vhas[(size_t)r * L + s]) {
-							vd->max.record_max(hub->ticker->time, h_vround[(size_t)r * L + s].energy);
-							vd->min.record_min(hub->ticker->time, h_vround[(size_t)r * L + s].energy);
+							vd->max.record_max(hub_time(hub), h_vround[(size_t)r * L + s].energy);
+							vd->min.record_min(hub_time(hub), h_vround[(size_t)r * L + s].energy);
 						}
-					vd->max.record_max(hub->ticker->time, vstate[s].energy);
-					vd->min.record_min(hub->ticker->time, vstate[s].energy);
+					vd->max.record_max(hub_time(hub), vstate[s].energy);
+					vd->min.record_min(hub_time(hub), vstate[s].energy);
 				}
 				leg->metered = false;
 			}
@@ -571,7 +571,7 @@ struct ServerBank : Pool {
 	// (the walks are over and the ticker's clock reads what that flush would read): the tick in flight includes them
 	void launch_staged() {
 		if (failed || !staged_since || !hub->ticker) return;
-		const bool more = enqueue_at(hub->ticker->time);
+		const bool more = enqueue_at(hub_time(hub));
 		early_any = early ? (early_any || more) : more;
 		early = true;
 	}
@@ -742,7 +742,7 @@ void server_conf_walked(ServerBank *b, int c) {
 	if (b->walk_tick[(size_t)c] == tick) return;
 	b->walk_tick[(size_t)c] = tick;
 	if (++b->walked < b->in_use) return;
-	b->early_any = b->enqueue_at(b->hub->ticker->time + (uint64_t)b->hub->ticker->interval);
+	b->early_any = b->enqueue_at(hub_time(b->hub) + (uint64_t)b->hub->ticker->interval);
 	b->early = true;
 }
 

@@ -497,6 +497,11 @@ typedef struct Task {
 } Task;
 
 typedef struct TickerImpl {
+	/* MSTicker::lock (msticker.c:59): held by the ticker's thread while it runs its tasks and graphs (:462-493), taken by ms_ticker_attach only to
+	 * splice the new graph's sources in AFTER every preprocess has run on the attaching thread (:163-181), and by ms_ticker_detach to take them out
+	 * BEFORE the postprocess calls (:205-221) -- an application re-plumbs a running ticker from its own thread */
+	pthread_mutex_t lock;
+	pthread_mutex_t tasks_lock; /* the task list on its own (the reference leaves it unguarded: "cannot be called outside of filter's process method", msfilter.c:289-301) */
 	MSFilter **filters; /* every filter of the attached graphs, in the order they were attached; NULL: a detached filter's place (compacted when a quarter is holes) */
 	uint8_t *is_source; /* beside `filters`: 1 = a filter without inputs -- the step starts its walks from these alone, as MSTicker walks its execution_list of sources (msticker.c:163-166,:326-343) */
 	int nfilters, cap, holes;
@@ -523,6 +528,8 @@ MSTicker *ms_ticker_new(void) {
 	MSTicker *t = (MSTicker *)ms_malloc0(sizeof(*t));
 	t->interval = 10; /* TICKER_INTERVAL msticker.c:46 */
 	t->impl = ms_malloc0(sizeof(TickerImpl));
+	pthread_mutex_init(&((TickerImpl *)t->impl)->lock, NULL);
+	pthread_mutex_init(&((TickerImpl *)t->impl)->tasks_lock, NULL);
 	return t;
 }
 
@@ -536,6 +543,8 @@ void ms_ticker_destroy(MSTicker *t) {
 	}
 	free(ti->filters);
 	free(ti->is_source);
+	pthread_mutex_destroy(&ti->lock);
+	pthread_mutex_destroy(&ti->tasks_lock);
 	free(ti);
 	free(t);
 }
@@ -561,22 +570,24 @@ static void find_neighbours(MSFilter *f, FList *l) { /* msfilter.c:303-344 (`see
 int ms_ticker_attach(MSTicker *t, MSFilter *f) {
 	TickerImpl *ti = (TickerImpl *)t->impl;
 	if (f->ticker == t) return 0; /* msticker.c:172-174: already being scheduled, nothing to do */
-	int first = ti->nfilters;
 	FList l = {0};
 	find_neighbours(f, &l);
-	for (int i = 0; i < l.n; ++i) ti_add(ti, l.v[i]);
-	free(l.v);
-	for (int i = first; i < ti->nfilters; ++i) {
-		MSFilter *g = ti->filters[i];
-		g->ticker = t;
+	for (int i = 0; i < l.n; ++i) { /* ms_filter_preprocess msfilter.c:240-250, on the attaching thread, the ticker's lock NOT held */
+		MSFilter *g = l.v[i];
+		__atomic_store_n(&g->ticker, t, __ATOMIC_RELAXED); /* (a plain store in the reference; a neighbour's flush may be reading it: relaxed atomics on both sides keep the sanitizer on the races that matter) */
 		g->last_tick = 0;
 		if (g->desc->preprocess) g->desc->preprocess(g);
 	}
-	for (int i = first; i < ti->nfilters; ++i) ti->filters[i]->seen = FALSE; /* (`seen` is find_neighbours' mark: clear outside of it) */
+	for (int i = 0; i < l.n; ++i) l.v[i]->seen = FALSE; /* (`seen` is find_neighbours' mark: clear outside of it) */
+	pthread_mutex_lock(&ti->lock);
+	for (int i = 0; i < l.n; ++i) ti_add(ti, l.v[i]);
+	pthread_mutex_unlock(&ti->lock);
+	free(l.v);
 	return 0;
 }
 
 static void remove_tasks_for_filter(TickerImpl *ti, MSFilter *f) { /* msticker.c:314-324 */
+	pthread_mutex_lock(&ti->tasks_lock);
 	Task **pp = &ti->tasks;
 	while (*pp) {
 		if ((*pp)->f == f) {
@@ -586,6 +597,7 @@ static void remove_tasks_for_filter(TickerImpl *ti, MSFilter *f) { /* msticker.c
 		} else pp = &(*pp)->next;
 	}
 	f->postponed_task = 0;
+	pthread_mutex_unlock(&ti->tasks_lock);
 }
 
 static void ms2shim_purge_tasks(MSFilter *f) { remove_tasks_for_filter((TickerImpl *)f->ticker->impl, f); }
@@ -595,13 +607,11 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 	/* detach the whole connected graph of f */
 	FList tmp = {0};
 	if (f->ticker != t) return 0; /* msticker.c:197-203: not scheduled (by this ticker): nothing to do */
+	pthread_mutex_lock(&ti->lock); /* :205: the graph leaves the execution list between two ticks */
 	find_neighbours(f, &tmp);
 	for (int i = 0; i < tmp.n; ++i) {
-		MSFilter *g = tmp.v[i];
-		if (g->postponed_task) remove_tasks_for_filter(ti, g); /* call_postprocess msticker.c:187-190: BEFORE postprocess */
-		if (g->desc->postprocess) g->desc->postprocess(g);
-		g->ticker = NULL;
-		g->seen = FALSE;
+		tmp.v[i]->seen = FALSE;
+		if (tmp.v[i]->postponed_task) remove_tasks_for_filter(ti, tmp.v[i]); /* call_postprocess msticker.c:187-190: BEFORE postprocess (here under the lock: the task list is the ticker thread's) */
 	}
 	for (int i = 0; i < tmp.n; ++i) { /* their places in the ticker's array become holes */
 		MSFilter *g = tmp.v[i];
@@ -609,7 +619,6 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 		if (at >= 0 && at < ti->nfilters && ti->filters[at] == g) ti->filters[at] = NULL, ti->is_source[at] = 0, ti->holes++;
 		SHIM_HDR(g)->idx = -1;
 	}
-	free(tmp.v);
 	if (ti->holes * 4 > ti->nfilters) { /* compaction, order kept */
 		int j = 0;
 		for (int i = 0; i < ti->nfilters; ++i)
@@ -620,6 +629,13 @@ int ms_ticker_detach(MSTicker *t, MSFilter *f) {
 			}
 		ti->nfilters = j, ti->holes = 0;
 	}
+	pthread_mutex_unlock(&ti->lock);
+	for (int i = 0; i < tmp.n; ++i) { /* :221: the postprocess calls, on the detaching thread, the lock released */
+		MSFilter *g = tmp.v[i];
+		if (g->desc->postprocess) g->desc->postprocess(g);
+		g->ticker = NULL;
+	}
+	free(tmp.v);
 	return 0;
 }
 
@@ -630,21 +646,30 @@ void ms_filter_postpone_task(MSFilter *f, MSFilterFunc task) {
 	t->f = f;
 	t->fn = task;
 	t->next = NULL;
+	pthread_mutex_lock(&ti->tasks_lock);
 	Task **pp = &ti->tasks;
 	while (*pp) pp = &(*pp)->next;
 	*pp = t;
 	f->postponed_task++;
+	pthread_mutex_unlock(&ti->tasks_lock);
 }
 
-static int inputs_have_data(MSFilter *f) {
-	for (int i = 0; i < f->desc->ninputs; ++i)
-		if (f->inputs[i] && !ms_queue_empty(f->inputs[i])) return 1;
+/* (both scans stop at the last CONNECTED pin, as the reference's do: an MSAudioMixer has 128 pins, a stream's local_mixer one linked) */
+static int inputs_have_data(MSFilter *f) { /* ms_filter_inputs_have_data msfilter.c:277-287 */
+	for (int i = 0, j = 0; i < f->desc->ninputs && j < f->n_connected_inputs; ++i)
+		if (f->inputs[i]) {
+			++j;
+			if (!ms_queue_empty(f->inputs[i])) return 1;
+		}
 	return 0;
 }
 
-static int can_process(MSFilter *f, uint32_t tick) { /* msticker.c:230-242 */
-	for (int i = 0; i < f->desc->ninputs; ++i)
-		if (f->inputs[i] && f->inputs[i]->prev.filter->last_tick != tick) return 0;
+static int can_process(MSFilter *f, uint32_t tick) { /* filter_can_process msticker.c:230-242 */
+	for (int i = 0, j = 0; i < f->desc->ninputs && j < f->n_connected_inputs; ++i)
+		if (f->inputs[i]) {
+			++j;
+			if (f->inputs[i]->prev.filter->last_tick != tick) return 0;
+		}
 	return 1;
 }
 
@@ -694,8 +719,11 @@ static void run_graph(MSFilter *f, MSTicker *t, MSFilter **unsched, int *nunsche
 	if (can_process(f, t->ticks) || force) {
 		f->last_tick = t->ticks;
 		call_process(f);
-		for (int i = 0; i < f->desc->noutputs; ++i)
-			if (f->outputs[i]) run_graph(f->outputs[i]->next.filter, t, unsched, nunsched, force);
+		for (int i = 0, j = 0; i < f->desc->noutputs && j < f->n_connected_outputs; ++i)
+			if (f->outputs[i]) {
+				++j;
+				run_graph(f->outputs[i]->next.filter, t, unsched, nunsched, force);
+			}
 	} else if (*nunsched < 256) {
 		unsched[(*nunsched)++] = f;
 	}
@@ -716,13 +744,16 @@ void ms_ticker_step(MSTicker *t) {
 		ti->max_call_ns = 0, ti->max_call_id = 0;
 	}
 	const uint64_t t0 = now_ns();
+	pthread_mutex_lock(&ti->lock); /* msticker.c:462-493: held while the tasks and the graphs run */
 	t->ticks++;
 	/* run_tasks msticker.c:301-312: postponed tasks run before the graphs */
+	pthread_mutex_lock(&ti->tasks_lock);
 	Task *tasks = ti->tasks;
 	ti->tasks = NULL;
+	for (Task *k = tasks; k; k = k->next) k->f->postponed_task--;
+	pthread_mutex_unlock(&ti->tasks_lock);
 	while (tasks) {
 		Task *n = tasks->next;
-		tasks->f->postponed_task--;
 		tasks->fn(tasks->f);
 		free(tasks);
 		tasks = n;
@@ -732,7 +763,8 @@ void ms_ticker_step(MSTicker *t) {
 		if (ti->is_source[i]) run_graph(ti->filters[i], t, unsched, &nunsched, 0);
 	/* filters inside loops: scheduled anyway on a second pass (msticker.c:284-299) */
 	for (int i = 0, n = nunsched, dummy = 0; i < n; ++i) run_graph(unsched[i], t, unsched, &dummy, 1);
-	t->time += (uint64_t)t->interval;
+	__atomic_store_n(&t->time, t->time + (uint64_t)t->interval, __ATOMIC_RELAXED);
+	pthread_mutex_unlock(&ti->lock);
 	ti->step_ns = now_ns() - t0;
 }
 /* the last step: ns in the postponed tasks (the plugin's flush) and in the whole step (tasks + graph walk) */

@@ -357,10 +357,18 @@ static int g_aligned;
 /* PLUGIN_BENCH_CHURN=<n>: n times a second every ticker has ONE conference (or, without mixers, one leg) re-plumbed the way
  * ms_audio_conference_add_member / remove_member do around every join and leave (src/voip/audioconference.c:322-374): the whole conference
  * graph detached and attached again -- every filter's postprocess and preprocess, the fused batch left and joined -- while the ticker
- * carries its full load.  The reference does this on the application's thread (msticker.c:153-183 takes the ticker's lock only to splice
- * the sources); this runtime has no such lock, so it happens on the ticker thread in front of the step and COUNTS AGAINST THE TICK
- * (conservative: step_ms includes it). */
-static int g_churn;
+ * carries its full load -- ON AN APPLICATION THREAD, as the reference's callers do: ms_ticker_detach takes the ticker's lock to take the
+ * graph's sources out (it waits for the tick in progress), runs the postprocess calls with the lock released; ms_ticker_attach runs the
+ * preprocess calls (this plugin's fusing) without the lock, while the ticker walks its other graphs, and takes it to splice the sources in
+ * (msticker.c:153-221,:462-493).  One such thread serves all the tickers in turn.  What is recorded: how long a re-plumbing took (waiting
+ * for the ticker included) -- and, in the ticks' own figures, what it cost the tickers.  PLUGIN_BENCH_CHURN_ON_TICKER=1: on the ticker's
+ * own thread in front of its step instead (counted in that tick: round 6's first measurement). */
+static int g_churn, g_churn_on_ticker;
+static volatile int g_churn_run;
+static double *g_churn_ops;
+static volatile int g_churn_nops;
+static int g_churn_cap;
+static void *churner(void *arg);
 static uint64_t phase_ns(int index) { return g_aligned ? 0 : (uint64_t)index * (10000000ull / (uint64_t)g_tickers); }
 
 static void *run(void *arg) {
@@ -411,7 +419,7 @@ static void *run(void *arg) {
 		const double c0 = thread_cpu_ms();
 		const double t0 = now_ms();
 		if ((g_stack_ms > 0 && t > 50) || g_sampling) g_step_start[j->index] = mono_ns();
-		if (g_churn > 0 && t % (100 / g_churn > 0 ? 100 / g_churn : 1) == (j->index % (100 / g_churn > 0 ? 100 / g_churn : 1))) {
+		if (g_churn > 0 && g_churn_on_ticker && t % (100 / g_churn > 0 ? 100 / g_churn : 1) == (j->index % (100 / g_churn > 0 ? 100 / g_churn : 1))) {
 			const int units = g_nomixer ? j->nconf * g_members : j->nconf;
 			MSFilter *root = g_nomixer ? j->heads[j->churn_next % units] : j->mixers[j->churn_next % units];
 			j->churn_next++;
@@ -457,6 +465,31 @@ static void *run(void *arg) {
 static int cmp_d(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
 static double pct(const double *sorted, int n, double p) { return sorted[(int)((double)(n - 1) * p)]; }
 
+static TickerJob *g_jobs;
+static void *churner(void *arg) { /* the application's thread */
+	(void)arg;
+	const double gap_ms = 1000.0 / ((double)g_churn * g_tickers);
+	double next = now_ms() + gap_ms;
+	for (int n = 0; g_churn_run; ++n) {
+		const double now = now_ms();
+		if (now < next) {
+			usleep((useconds_t)((next - now) * 1000.0));
+			continue;
+		}
+		next += gap_ms;
+		if (now - next > 50.0) next = now + gap_ms; /* (far behind: do not burst) */
+		TickerJob *j = &g_jobs[n % g_tickers];
+		const int units = g_nomixer ? j->nconf * g_members : j->nconf;
+		MSFilter *root = g_nomixer ? j->heads[j->churn_next % units] : j->mixers[j->churn_next % units];
+		j->churn_next++;
+		const double t0 = now_ms();
+		ms_ticker_detach(j->ticker, root);
+		ms_ticker_attach(j->ticker, root);
+		if (g_churn_nops < g_churn_cap) g_churn_ops[g_churn_nops++] = now_ms() - t0;
+	}
+	return NULL;
+}
+
 int main(int argc, char **argv) {
 	if (argc < 6) {
 		fprintf(stderr, "usage: plugin_bench <plugin.so> <legs> <tickers> <ticks> <warmup> [members]\n");
@@ -467,6 +500,7 @@ int main(int argc, char **argv) {
 	g_aligned = getenv("PLUGIN_BENCH_ALIGNED") != NULL;
 	g_churn = getenv("PLUGIN_BENCH_CHURN") ? atoi(getenv("PLUGIN_BENCH_CHURN")) : 0;
 	if (g_churn > 100) g_churn = 100;
+	g_churn_on_ticker = getenv("PLUGIN_BENCH_CHURN_ON_TICKER") != NULL;
 	if (getenv("PLUGIN_BENCH_SHAPE")) {
 		const char *sh = getenv("PLUGIN_BENCH_SHAPE");
 		g_nors = strstr(sh, "nors") != NULL, g_noagc = strstr(sh, "noagc") != NULL, g_nomixer = strstr(sh, "nomixer") != NULL, g_eprs = strstr(sh, "eprs") != NULL, g_server = strstr(sh, "server") != NULL, g_dec = strstr(sh, "dec") != NULL;
@@ -559,6 +593,14 @@ int main(int argc, char **argv) {
 	}
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
+	pthread_t churn_th;
+	if (g_churn > 0 && !g_churn_on_ticker) {
+		g_jobs = jobs;
+		g_churn_cap = 1 << 16;
+		g_churn_ops = (double *)calloc((size_t)g_churn_cap, sizeof(double));
+		g_churn_run = 1;
+		pthread_create(&churn_th, NULL, churner, NULL);
+	}
 	if (getenv("PLUGIN_BENCH_SAMPLE") && g_tickers <= 256) {
 		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
 		sample_start();
@@ -579,6 +621,10 @@ int main(int argc, char **argv) {
 	}
 	pthread_barrier_wait(&g_bar);
 	const double wall_ms = now_ms() - t_first;
+	if (g_churn_run) {
+		g_churn_run = 0;
+		pthread_join(churn_th, NULL);
+	}
 	if (g_sampling) g_sampling = 0, sample_report();
 	if (fused_stats) fused_stats(&fc1, &fl1, &la1, &fr1);
 	for (int i = 0; i < g_tickers; ++i) pthread_join(th[i], NULL);
@@ -711,16 +757,17 @@ int main(int argc, char **argv) {
 	double attach_max = 0;
 	for (int i = 0; i < g_tickers; ++i)
 		if (jobs[i].attach_ms > attach_max) attach_max = jobs[i].attach_ms;
-	char churn[256] = "null";
+	char churn[384] = "null";
 	if (g_churn > 0) { /* the re-plumbings: how many, what one took (median, longest) */
-		double *ops = (double *)calloc((size_t)g_ticks * (size_t)g_tickers, sizeof(double));
+		double *ops = (double *)calloc((size_t)g_ticks * (size_t)g_tickers + (size_t)g_churn_nops + 1, sizeof(double));
 		int nops = 0;
-		for (int i = 0; i < g_tickers; ++i)
+		for (int i = 0; i < g_tickers && g_churn_on_ticker; ++i)
 			for (int t = 0; t < g_ticks; ++t)
 				if (jobs[i].churn_ms[t] > 0) ops[nops++] = jobs[i].churn_ms[t];
+		for (int k = 0; k < g_churn_nops && !g_churn_on_ticker; ++k) ops[nops++] = g_churn_ops[k];
 		qsort(ops, (size_t)nops, sizeof(double), cmp_d);
-		snprintf(churn, sizeof(churn), "{\"per_second_and_ticker\": %d, \"replumbings\": %d, \"p50_ms\": %.3f, \"p99_ms\": %.3f, \"max_ms\": %.3f, \"counted_in_the_tick\": true}", g_churn, nops,
-		         nops ? pct(ops, nops, 0.5) : 0.0, nops ? pct(ops, nops, 0.99) : 0.0, nops ? ops[nops - 1] : 0.0);
+		snprintf(churn, sizeof(churn), "{\"per_second_and_ticker\": %d, \"replumbings\": %d, \"p50_ms\": %.3f, \"p99_ms\": %.3f, \"max_ms\": %.3f, \"counted_in_the_tick\": %s, \"thread\": \"%s\"}", g_churn, nops,
+		         nops ? pct(ops, nops, 0.5) : 0.0, nops ? pct(ops, nops, 0.99) : 0.0, nops ? ops[nops - 1] : 0.0, g_churn_on_ticker ? "true" : "false", g_churn_on_ticker ? "the ticker's" : "the application's");
 		free(ops);
 	}
 	const double mean_step = sum_step / ((double)g_ticks * g_tickers), mean_task = sum_task / ((double)g_ticks * g_tickers);

@@ -628,6 +628,114 @@ static void *audiostreams(void *arg) {
 	return NULL;
 }
 
+/* A ticker that is re-plumbed BY THE APPLICATION while it runs, as the reference's callers do it (ms_audio_conference_add_member / remove_member,
+ * audioconference.c:322-374; audio_stream_stop): ms_ticker_detach and ms_ticker_attach on a thread of their own -- the detach takes the ticker's
+ * lock to take the graph's sources out and runs the postprocess calls with the lock released, the attach runs the preprocess calls (this plugin's
+ * fusing: banks joined, queues moved to the device) while the ticker walks its other graphs and takes the lock to splice the sources in
+ * (msticker.c:153-221,:462-493).  Three conferences of four legs and two AudioStreams on one ticker; the application takes them out and puts them
+ * back in turn, as fast as it can, while the ticker ticks. */
+void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase);
+typedef struct {
+	MSTicker *tk;
+	MSFilter *roots[5];
+	volatile int stop;
+	int done;
+} replumber_t;
+static void *replumber(void *arg) {
+	replumber_t *r = (replumber_t *)arg;
+	for (int n = 0; !__atomic_load_n(&r->stop, __ATOMIC_SEQ_CST); ++n) {
+		/* the conferences in turn; each AudioStream twice (its PLC makes up for every tick the stream was away with a block of its own,
+		 * msgenericplc.c:117-166 -- re-plumbed every millisecond its far end would outrun the microphone and the canceller's delay line
+		 * drop, and count, the excess) */
+		MSFilter *root = (n == 6 || n == 21) ? r->roots[1] : ((n == 11 || n == 31) ? r->roots[3] : r->roots[(n % 3) * 2]);
+		ms_ticker_detach(r->tk, root);
+		CHECK(ms_ticker_attach(r->tk, root) == 0);
+		r->done++;
+		usleep(150);
+	}
+	return NULL;
+}
+static void *replumbed_by_the_application(void *arg) {
+	enum { NC2 = 3, NM2 = 4, NS2 = 2 };
+	static int16_t ring16[4][160], ring8[4][80];
+	static uint8_t codes[4][80];
+	(void)arg;
+	for (int b = 0; b < 4; ++b) {
+		for (int i = 0; i < 160; ++i) ring16[b][i] = (int16_t)((i * 97 + b * 911) % 5000 - 2500);
+		for (int i = 0; i < 80; ++i) ring8[b][i] = (int16_t)((i * 211 + b * 577) % 6000 - 3000), codes[b][i] = (uint8_t)(i * 29 + b * 7);
+	}
+	for (int rep = 0; rep < (g_rounds + 2) / 3; ++rep) {
+		MSTicker *tk = ms_ticker_new();
+		MSFilter *mx[NC2], *all[NC2 * NM2 * 7 + NC2 + NS2 * 14];
+		int nall = 0;
+		for (int c = 0; c < NC2; ++c) {
+			mx[c] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+			all[nall++] = mx[c];
+			set_int(mx[c], MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(mx[c], MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
+			for (int k = 0; k < NM2; ++k) {
+				MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
+				MSFilter *rs = ms_factory_create_filter(g_fac, MS_RESAMPLE_ID), *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID), *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+				MSFilter *seven[] = {mic, far, spk, out, rs, ec, vol};
+				for (int i = 0; i < 7; ++i) all[nall++] = seven[i];
+				ms2shim_source_set_loop(mic, ring16, sizeof ring16[0], 4, c + k), ms2shim_source_set_loop(far, ring16, sizeof ring16[0], 4, c + k + 2);
+				ms2shim_sink_set_discard(spk, 1), ms2shim_sink_set_discard(out, 1);
+				set_int(rs, MS_FILTER_SET_SAMPLE_RATE, 16000), set_int(rs, MS_FILTER_SET_OUTPUT_SAMPLE_RATE, 48000);
+				set_int(ec, MS_FILTER_SET_SAMPLE_RATE, 48000), set_int(ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
+				set_int(vol, MS_FILTER_SET_SAMPLE_RATE, 48000);
+				if (c != 1) set_int(vol, MS_VOLUME_ENABLE_AGC, 1); /* (conference 1 without AGC: the other kind of bank) */
+				ms_filter_link(mic, 0, rs, 0), ms_filter_link(rs, 0, ec, 1), ms_filter_link(ec, 1, vol, 0), ms_filter_link(vol, 0, mx[c], k), ms_filter_link(mx[c], k, out, 0);
+				ms_filter_link(far, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
+			}
+			CHECK(ms_ticker_attach(tk, mx[c]) == 0);
+		}
+		MSFilter *heads[NS2], *ecs[NS2];
+		for (int k = 0; k < NS2; ++k) { /* full-duplex G.711 AudioStreams, the default features' filters of this plugin */
+			MSFilter *mic = ms2shim_new_source(g_fac), *far = ms2shim_new_source(g_fac), *spk = ms2shim_new_sink(g_fac), *out = ms2shim_new_sink(g_fac);
+			MSFilter *dec = ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID), *lmx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID), *plc = ms_factory_create_filter(g_fac, MS_GENERIC_PLC_ID);
+			MSFilter *fc = ms_factory_create_filter(g_fac, MS_AUDIO_FLOW_CONTROL_ID), *dtmf = ms2shim_new_pass(g_fac), *vr = ms_factory_create_filter(g_fac, MS_VOLUME_ID);
+			MSFilter *ec = ms_factory_create_filter(g_fac, MS_SPEEX_EC_ID), *vs = ms_factory_create_filter(g_fac, MS_VOLUME_ID), *omx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+			MSFilter *enc = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
+			MSFilter *fourteen[] = {mic, far, spk, out, dec, lmx, plc, fc, dtmf, vr, ec, vs, omx, enc};
+			for (int i = 0; i < 14; ++i) all[nall++] = fourteen[i];
+			heads[k] = mic, ecs[k] = ec;
+			ms2shim_source_set_loop(mic, ring8, sizeof ring8[0], 4, k), ms2shim_source_set_loop(far, codes, sizeof codes[0], 4, k + 1);
+			ms2shim_sink_set_discard(spk, 1), ms2shim_sink_set_discard(out, 1);
+			for (MSFilter **f = (MSFilter *[]){lmx, plc, fc, vr, ec, vs, omx, NULL}; *f; ++f) set_int(*f, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			set_int(ec, MS_ECHO_CANCELLER_SET_TAIL_LENGTH, 64);
+			ms_filter_link(far, 0, dec, 0), ms_filter_link(dec, 0, lmx, 0), ms_filter_link(lmx, 0, plc, 0), ms_filter_link(plc, 0, fc, 0), ms_filter_link(fc, 0, dtmf, 0);
+			ms_filter_link(dtmf, 0, vr, 0), ms_filter_link(vr, 0, ec, 0), ms_filter_link(ec, 0, spk, 0);
+			ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vs, 0), ms_filter_link(vs, 0, omx, 0), ms_filter_link(omx, 0, enc, 0), ms_filter_link(enc, 0, out, 0);
+			CHECK(ms_ticker_attach(tk, mic) == 0);
+		}
+		replumber_t rp = {tk, {mx[0], heads[0], mx[1], heads[1], mx[2]}, 0, 0};
+		pthread_t rt;
+		for (int t = 0; t < 4; ++t) ms_ticker_step(tk);
+		for (int c = 0; c < NC2; ++c) CHECK(p_in_batch(mx[c]) == 1);
+		for (int k = 0; k < NS2; ++k) CHECK(p_in_batch(ecs[k]) == 1);
+		CHECK(pthread_create(&rt, NULL, replumber, &rp) == 0);
+		for (int t = 0; t < 60; ++t) { /* the ticker ticks while the application re-plumbs */
+			ms_ticker_step(tk);
+			usleep(200);
+		}
+		__atomic_store_n(&rp.stop, 1, __ATOMIC_SEQ_CST);
+		pthread_join(rt, NULL);
+		CHECK(rp.done >= 5);
+		for (int t = 0; t < 3; ++t) ms_ticker_step(tk);
+		for (int c = 0; c < NC2; ++c) CHECK(p_in_batch(mx[c]) == 1); /* every one of them found its way back into its batch */
+		for (int k = 0; k < NS2; ++k) CHECK(p_in_batch(ecs[k]) == 1);
+		for (int c = 0; c < NC2; ++c) ms_ticker_detach(tk, mx[c]);
+		for (int k = 0; k < NS2; ++k) ms_ticker_detach(tk, heads[k]);
+		for (int i = 0; i < nall; ++i) { /* (ms_filter_destroy unlinks nothing: take the links down first) */
+			MSFilter *f = all[i];
+			for (int pin = 0; pin < f->desc->noutputs; ++pin)
+				if (f->outputs[pin]) ms_filter_unlink(f, pin, f->outputs[pin]->next.filter, f->outputs[pin]->next.pin);
+		}
+		for (int i = 0; i < nall; ++i) ms_filter_destroy(all[i]);
+		ms_ticker_destroy(tk);
+	}
+	return NULL;
+}
+
 static void *walker(void *arg) {
 	long walks = 0;
 	(void)arg;
@@ -642,7 +750,7 @@ static void *walker(void *arg) {
 }
 
 int main(int argc, char **argv) {
-	pthread_t th[8];
+	pthread_t th[9];
 	void *p_fused = NULL;
 	void *walks = NULL;
 	int h, b, s;
@@ -677,11 +785,13 @@ int main(int argc, char **argv) {
 	pthread_create(&th[5], NULL, conferences, p_fused);
 	pthread_create(&th[6], NULL, server_conferences, p_fused);
 	pthread_create(&th[7], NULL, audiostreams, p_fused);
+	pthread_create(&th[8], NULL, replumbed_by_the_application, NULL);
 	for (int i = 0; i < 3; ++i) pthread_join(th[i], NULL);
 	pthread_join(th[4], NULL);
 	pthread_join(th[5], NULL);
 	pthread_join(th[6], NULL);
 	pthread_join(th[7], NULL);
+	pthread_join(th[8], NULL);
 	__atomic_store_n(&g_stop, 1, __ATOMIC_SEQ_CST);
 	pthread_join(th[3], &walks);
 	p_flush(); /* nothing is running any more */
