@@ -1075,10 +1075,11 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
         try:  # conferences re-plumbed under load, as MSAudioConference does around every join and leave (audioconference.c:322-374)
             ch = run(tickers * 2048, 400, {"PLUGIN_BENCH_CHURN": "20"})
             out["churn"] = {"legs": ch["legs"], "legs_per_ticker": 2048, "ticks": ch["ticks"], "p50_ms": ch["p50_ms"], "p99_ms": ch["p99_ms"], "max_ms": ch["max_ms"],
-                            "ticks_over_10ms": ch["late"], "replumbing": ch.get("churn"), "late_events": ch["late_events"],
-                            "what": "every ticker detaches and re-attaches one whole conference graph (32 legs: postprocess + preprocess of every filter, the fused batch "
-                                    "left and joined again) 20 times a second, ON the ticker thread in front of the step (counted in the tick: the test runtime has no "
-                                    "attach lock; the reference does it on the application's thread, msticker.c:153-183)"}
+                            "ticks_over_10ms": ch["late"], "replumbing": ch.get("churn"), "late_events": ch["late_events"], "fused_legs_at_the_end": ch.get("fused_legs"),
+                            "what": "every ticker has one whole conference graph detached and attached again (32 legs: postprocess + preprocess of every filter, the fused "
+                                    "batch left and joined again) 20 times a second, by an APPLICATION thread while the tickers run, as the reference's callers do: the detach "
+                                    "waits for the ticker's lock (the tick in progress), postprocess and preprocess run outside it (msticker.c:153-221,:462-493).  "
+                                    "replumbing.*_ms: what one took, that wait included"}
         except Exception as e:
             out["churn"] = {"error": str(e)[:200]}
     out["legs_strict"] = int(best["legs"]) if best is not None else 0
