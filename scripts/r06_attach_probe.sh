@@ -29,3 +29,11 @@ echo "== churn, server dec shape" | tee -a $out
 PLUGIN_BENCH_SHAPE="server dec" PLUGIN_BENCH_CHURN=20 PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so 32768 $T 400 40 2>/dev/null | tee -a $out | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ('legs','p50_ms','p99_ms','max_ms','late','us_per_leg_tick','fused_legs','late_events','churn')})"
+echo "== churn on the ticker's own thread (round 6's first form), for comparison" | tee -a $out
+PLUGIN_BENCH_CHURN_ON_TICKER=1 PLUGIN_BENCH_CHURN=20 PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so 32768 $T 400 40 2>/dev/null | tee -a $out | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ('legs','p50_ms','p99_ms','max_ms','late','us_per_leg_tick','fused_legs','late_events','churn')})"
+echo "== churn, astream default shape (one stream's graph at a time)" | tee -a $out
+PLUGIN_BENCH_SHAPE="astream default" PLUGIN_BENCH_CHURN=20 PLUGIN_BENCH_PACED=1 tests/host/plugin_bench mediastreamer2_amd/libmsmi355xfilters.so 16384 $T 400 40 2>/dev/null | tee -a $out | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ('legs','p50_ms','p99_ms','max_ms','late','us_per_leg_tick','fused_legs','late_events','churn')})"
