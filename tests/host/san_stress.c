@@ -632,12 +632,12 @@ static void *audiostreams(void *arg) {
  * audioconference.c:322-374; audio_stream_stop): ms_ticker_detach and ms_ticker_attach on a thread of their own -- the detach takes the ticker's
  * lock to take the graph's sources out and runs the postprocess calls with the lock released, the attach runs the preprocess calls (this plugin's
  * fusing: banks joined, queues moved to the device) while the ticker walks its other graphs and takes the lock to splice the sources in
- * (msticker.c:153-221,:462-493).  Three conferences of four legs and two AudioStreams on one ticker; the application takes them out and puts them
- * back in turn, as fast as it can, while the ticker ticks. */
+ * (msticker.c:153-221,:462-493).  Three conferences of four legs, two AudioStreams and a server's bridge of four G.711 members on one ticker; the
+ * application takes them out and puts them back in turn, as fast as it can, while the ticker ticks. */
 void ms2shim_source_set_loop(MSFilter *src, const void *ring, size_t block_bytes, int nblocks, int phase);
 typedef struct {
 	MSTicker *tk;
-	MSFilter *roots[5];
+	MSFilter *roots[6];
 	volatile int stop;
 	int done;
 } replumber_t;
@@ -647,7 +647,7 @@ static void *replumber(void *arg) {
 		/* the conferences in turn; each AudioStream twice (its PLC makes up for every tick the stream was away with a block of its own,
 		 * msgenericplc.c:117-166 -- re-plumbed every millisecond its far end would outrun the microphone and the canceller's delay line
 		 * drop, and count, the excess) */
-		MSFilter *root = (n == 6 || n == 21) ? r->roots[1] : ((n == 11 || n == 31) ? r->roots[3] : r->roots[(n % 3) * 2]);
+		MSFilter *root = (n == 6 || n == 21) ? r->roots[1] : ((n == 11 || n == 31) ? r->roots[3] : (n % 4 == 3 ? r->roots[5] : r->roots[(n % 4) * 2]));
 		ms_ticker_detach(r->tk, root);
 		CHECK(ms_ticker_attach(r->tk, root) == 0);
 		r->done++;
@@ -666,7 +666,7 @@ static void *replumbed_by_the_application(void *arg) {
 	}
 	for (int rep = 0; rep < (g_rounds + 2) / 3; ++rep) {
 		MSTicker *tk = ms_ticker_new();
-		MSFilter *mx[NC2], *all[NC2 * NM2 * 7 + NC2 + NS2 * 14];
+		MSFilter *mx[NC2], *all[NC2 * NM2 * 7 + NC2 + NS2 * 14 + 1 + NM2 * 5], *smx;
 		int nall = 0;
 		for (int c = 0; c < NC2; ++c) {
 			mx[c] = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
@@ -707,11 +707,27 @@ static void *replumbed_by_the_application(void *arg) {
 			ms_filter_link(mic, 0, ec, 1), ms_filter_link(ec, 1, vs, 0), ms_filter_link(vs, 0, omx, 0), ms_filter_link(omx, 0, enc, 0), ms_filter_link(enc, 0, out, 0);
 			CHECK(ms_ticker_attach(tk, mic) == 0);
 		}
-		replumber_t rp = {tk, {mx[0], heads[0], mx[1], heads[1], mx[2]}, 0, 0};
+		/* ... and a conference SERVER's bridge of four G.711 members (decoder -> volrecv -> pin -> encoder: server_leg.inl) */
+		smx = ms_factory_create_filter(g_fac, MS_AUDIO_MIXER_ID);
+		all[nall++] = smx;
+		set_int(smx, MS_FILTER_SET_SAMPLE_RATE, 8000), set_int(smx, MS_AUDIO_MIXER_ENABLE_CONFERENCE_MODE, 1);
+		for (int k = 0; k < NM2; ++k) {
+			MSFilter *src = ms2shim_new_source(g_fac), *snk = ms2shim_new_sink(g_fac), *dec = ms_factory_create_filter(g_fac, MS_ULAW_DEC_ID);
+			MSFilter *vol = ms_factory_create_filter(g_fac, MS_VOLUME_ID), *enc = ms_factory_create_filter(g_fac, MS_ULAW_ENC_ID);
+			MSFilter *five[] = {src, snk, dec, vol, enc};
+			for (int i = 0; i < 5; ++i) all[nall++] = five[i];
+			ms2shim_source_set_loop(src, codes, sizeof codes[0], 4, k);
+			ms2shim_sink_set_discard(snk, 1);
+			set_int(vol, MS_FILTER_SET_SAMPLE_RATE, 8000);
+			ms_filter_link(src, 0, dec, 0), ms_filter_link(dec, 0, vol, 0), ms_filter_link(vol, 0, smx, k), ms_filter_link(smx, k, enc, 0), ms_filter_link(enc, 0, snk, 0);
+		}
+		CHECK(ms_ticker_attach(tk, smx) == 0);
+		replumber_t rp = {tk, {mx[0], heads[0], mx[1], heads[1], mx[2], smx}, 0, 0};
 		pthread_t rt;
 		for (int t = 0; t < 4; ++t) ms_ticker_step(tk);
 		for (int c = 0; c < NC2; ++c) CHECK(p_in_batch(mx[c]) == 1);
 		for (int k = 0; k < NS2; ++k) CHECK(p_in_batch(ecs[k]) == 1);
+		CHECK(p_in_batch(smx) == 1);
 		CHECK(pthread_create(&rt, NULL, replumber, &rp) == 0);
 		for (int t = 0; t < 60; ++t) { /* the ticker ticks while the application re-plumbs */
 			ms_ticker_step(tk);
@@ -723,6 +739,8 @@ static void *replumbed_by_the_application(void *arg) {
 		for (int t = 0; t < 3; ++t) ms_ticker_step(tk);
 		for (int c = 0; c < NC2; ++c) CHECK(p_in_batch(mx[c]) == 1); /* every one of them found its way back into its batch */
 		for (int k = 0; k < NS2; ++k) CHECK(p_in_batch(ecs[k]) == 1);
+		CHECK(p_in_batch(smx) == 1);
+		ms_ticker_detach(tk, smx);
 		for (int c = 0; c < NC2; ++c) ms_ticker_detach(tk, mx[c]);
 		for (int k = 0; k < NS2; ++k) ms_ticker_detach(tk, heads[k]);
 		for (int i = 0; i < nall; ++i) { /* (ms_filter_destroy unlinks nothing: take the links down first) */
