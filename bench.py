@@ -2070,6 +2070,8 @@ def main():
                                  ("audiostreams_8k_g711_full_duplex", "astream"), ("audiostreams_8k_g711_default_features", "astream default")):
                     try:
                         shapes[name] = plugin_shape_point(sh)
+                        if sh.startswith("astream") and (shapes[name].get("late") or 0) > 0:   # what DOES fit on this host: the same shape at half the streams
+                            shapes[name]["at_16384_streams"] = _pick(plugin_shape_point(sh, legs=16384), "legs", "p50_ms", "p99_ms", "max_ms", "late", "us_per_leg_tick")
                     except Exception as e:
                         shapes[name] = {"error": str(e)[:200]}
                 line["plugin_path_shapes"] = shapes
