@@ -237,7 +237,8 @@ int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_par
 /* The echo limiter's peer in ANOTHER batch (msvolume.c:201-238 reads `((Volume *)v->peer->data)->energy`, whatever filter that is):
  * stream s of `v` whose params.peer is MI_VOLUME_PEER_EXTERNAL reads the smoothed energy of stream s of `peers`, as the last launch on
  * `peers` left it (launch order on the context's stream decides; both on one context).  NULL = none.  The plugin's fused call leg keeps
- * volsend in its chain's batch and meters volrecv in a batch beside it (leg_chain.inl). */
+ * volsend in its chain's batch and meters volrecv in a batch beside it (leg_chain.inl).  Destroying `peers` first is allowed: `v` loses
+ * the link, and a stream whose peer is EXTERNAL while no peer batch is set has NO peer (no limiter), as with -1. */
 int mi_volume_set_peer_batch(mi_volume *v, mi_volume *peers);
 int mi_volume_get_state(mi_volume *v, int first, int count, mi_volume_state *h_state); /* syncs */
 /* the same read-back enqueued on the context's stream behind the launches so far (h_state: pinned, mi_host_alloc); valid

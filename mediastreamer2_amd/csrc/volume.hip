@@ -23,6 +23,8 @@
 // reference (msvolume.c:440).  HBM traffic: 2 B/sample read, <= 2 B/sample
 // written, + ~100 B of per-stream state.
 #include "common.hpp"
+#include <algorithm>
+#include <vector>
 #include <atomic>
 
 #pragma clang fp contract(off)
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(VTHREADS) void volume_kernel(VolArgs a) {
 		st = a.state[s0 + tid];
 		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
 		else if (p.peer == MI_VOLUME_PEER_EXTERNAL && a.ext_state) peer_energy = a.ext_state[s0 + tid].energy;
+		else if (p.peer == MI_VOLUME_PEER_EXTERNAL) p.peer = -1; // (no peer batch set, or it has been destroyed: no peer, no limiter)
 	}
 	if (tid < SPB) {
 		int n = 0;
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(VM_THREADS) void volmix_kernel(VolMixArgs va) {
 		st = a.state[s];
 		if (p.peer >= 0) peer_energy = a.energy[*a.parity][p.peer];
 		else if (p.peer == MI_VOLUME_PEER_EXTERNAL && a.ext_state) peer_energy = a.ext_state[s].energy;
+		else if (p.peer == MI_VOLUME_PEER_EXTERNAL) p.peer = -1;
 		mflag = va.flags[c * mm + t];
 		mgain_bits = __float_as_int(va.gain[c * mm + t]);
 		win = a.win[s];
@@ -611,6 +615,7 @@ struct mi_volume {
 	int *d_parity = nullptr;
 	bool has_peers = false; // conservative: set once any stream names a peer
 	const mi_volume *ext = nullptr; // mi_volume_set_peer_batch
+	std::vector<mi_volume *> ext_users; // the batches whose `ext` is this one: told when it goes (mi_volume_destroy)
 };
 
 extern "C" {
@@ -673,6 +678,14 @@ int mi_volume_create(mi_ctx *ctx, int nstreams, int sample_rate, mi_volume **out
 
 void mi_volume_destroy(mi_volume *v) {
 	if (!v) return;
+	// (no launch may read a destroyed batch's state: whoever named this batch as its peers' loses the link -- its EXTERNAL streams then have
+	// no peer -- and this batch leaves the list of the one it named.  Calls on batches of one context come from one thread at a time, as for
+	// every object of the library)
+	for (mi_volume *u : v->ext_users) u->ext = nullptr;
+	if (v->ext) {
+		auto &l = const_cast<mi_volume *>(v->ext)->ext_users;
+		l.erase(std::remove(l.begin(), l.end(), v), l.end());
+	}
 	(void)hipSetDevice(v->ctx->device);
 	if (v->d_params) (void)hipFree(v->d_params);
 	if (v->d_state) (void)hipFree(v->d_state);
@@ -696,7 +709,12 @@ int mi_volume_set_params(mi_volume *v, int first, int count, const mi_volume_par
 
 int mi_volume_set_peer_batch(mi_volume *v, mi_volume *peers) {
 	MI_CHECK_ARG(v && (!peers || (peers->nstreams >= v->nstreams && peers->ctx == v->ctx && peers != v)));
+	if (v->ext) {
+		auto &l = const_cast<mi_volume *>(v->ext)->ext_users;
+		l.erase(std::remove(l.begin(), l.end(), v), l.end());
+	}
 	v->ext = peers;
+	if (peers) peers->ext_users.push_back(v);
 	return MI_OK;
 }
 

@@ -12,14 +12,14 @@ struct EqualizerPool : Pool {
 	// MS_EQUALIZER_SET_GAIN / SET_ACTIVE while the last walk's blocks are still waiting for the coming flush (Pool::work_waiting): they go
 	// live behind that flush (flushed()), as the reference's process() of that walk ran before the call
 	struct Op {
-		int slot, kind; // kind 0: gain, 1: active
+		int slot, kind; // kind 0: gain, 1: active, 2: flatten (MS_FILTER_SET_SAMPLE_RATE: equalizer_rate_update re-allocates a flat spectrum at ANY rate, equalizer.c:305-309)
 		MSEqualizerGain g;
 		int active;
 	};
 	std::vector<Op> later;
 	std::vector<uint8_t> used; // the slot's FIR memory may hold an earlier owner's samples (the batch is created cleared)
 	static void apply(mi_equalizer *eq, const Op &o) {
-		const int rc = o.kind == 0 ? mi_equalizer_set_gain(eq, o.slot, o.g.frequency, o.g.gain, o.g.width) : mi_equalizer_set_active(eq, o.slot, o.active);
+		const int rc = o.kind == 0 ? mi_equalizer_set_gain(eq, o.slot, o.g.frequency, o.g.gain, o.g.width) : (o.kind == 1 ? mi_equalizer_set_active(eq, o.slot, o.active) : mi_equalizer_flatten(eq, o.slot));
 		if (rc != MI_OK) ms_error("mi355x equalizer: a deferred method failed: %s", mi_last_error());
 	}
 	void flushed() override {
@@ -314,7 +314,10 @@ int equalizer_set_rate(MSFilter *f, void *arg) { // equalizer.c:305-309
 	if (d->leg && d->rate != *(int *)arg) leg_disqualify(d->leg);
 	d->rate = *(int *)arg;
 	d->pending->clear(); // equalizer_rate_update re-allocates a flat spectrum
-	if (d->leg) return 0; // (the leg leaves its bank at its next walk: equalizer_attach then starts from the flat spectrum)
+	if (d->leg) { // (another rate: the leg leaves its bank at its next walk, equalizer_attach then starts from the flat spectrum; the same rate: the slot in the leg's bank is flattened, behind the walk's blocks like every method)
+		leg_eq_op(d->leg, EqualizerPool::Op{d->slot, 2, MSEqualizerGain{0, 0, 0}, 0});
+		return 0;
+	}
 	if (d->pool && d->pool->rate == d->rate) MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot));
 	else equalizer_attach(f);
 	return 0;

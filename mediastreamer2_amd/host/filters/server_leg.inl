@@ -340,7 +340,9 @@ struct ServerBank : Pool {
 			for (int r = st; r < kMaxRounds; ++r) h_n[(size_t)r * L + s] = 0;
 			if (!leg) continue;
 			rounds = std::max(rounds, st);
-			for (int r = 0; r < st; ++r) leg->new_samples += h_n[(size_t)r * L + s] * q;
+			// (at another rate than the conference's, whole 10 ms periods of a block are up-sampled and queued -- queue_blocks; a block that is not
+			// a multiple of one sends the conference back to its facades and is counted there: the host's count follows what the device queues)
+			for (int r = 0; r < st; ++r) leg->new_samples += q == 1 ? h_n[(size_t)r * L + s] : (h_n[(size_t)r * L + s] / nse) * ns;
 			leg->metered |= st > 0;
 			for (int r = 0; r + 1 < st && vrounds + r < kLegMeterRounds; ++r) vhas[(size_t)(vrounds + r) * L + s] = 1;
 			leg->staged = 0;
