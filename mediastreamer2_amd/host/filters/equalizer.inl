@@ -18,8 +18,13 @@ struct EqualizerPool : Pool {
 	};
 	std::vector<Op> later;
 	std::vector<uint8_t> used; // the slot's FIR memory may hold an earlier owner's samples (the batch is created cleared)
+	// equalizer_rate_update (equalizer.c:57-79): a flat spectrum AND a cleared FIR memory, whatever the rate was
+	static int rate_update(mi_equalizer *eq, int slot) {
+		const int rc = mi_equalizer_flatten(eq, slot);
+		return rc != MI_OK ? rc : mi_equalizer_set_history(eq, slot, nullptr, mi_equalizer_fir_len(eq));
+	}
 	static void apply(mi_equalizer *eq, const Op &o) {
-		const int rc = o.kind == 0 ? mi_equalizer_set_gain(eq, o.slot, o.g.frequency, o.g.gain, o.g.width) : (o.kind == 1 ? mi_equalizer_set_active(eq, o.slot, o.active) : mi_equalizer_flatten(eq, o.slot));
+		const int rc = o.kind == 0 ? mi_equalizer_set_gain(eq, o.slot, o.g.frequency, o.g.gain, o.g.width) : (o.kind == 1 ? mi_equalizer_set_active(eq, o.slot, o.active) : rate_update(eq, o.slot));
 		if (rc != MI_OK) ms_error("mi355x equalizer: a deferred method failed: %s", mi_last_error());
 	}
 	void flushed() override {
@@ -318,8 +323,11 @@ int equalizer_set_rate(MSFilter *f, void *arg) { // equalizer.c:305-309
 		leg_eq_op(d->leg, EqualizerPool::Op{d->slot, 2, MSEqualizerGain{0, 0, 0}, 0});
 		return 0;
 	}
-	if (d->pool && d->pool->rate == d->rate) MI_MUST(mi_equalizer_flatten(d->pool->e, d->slot));
-	else equalizer_attach(f);
+	if (d->pool && d->pool->rate == d->rate) { // (behind the blocks of the walk that preceded the call, like the other methods: DESIGN 6.5)
+		if (f->ticker && d->pool->work_waiting()) d->pool->later.push_back(EqualizerPool::Op{d->slot, 2, MSEqualizerGain{0, 0, 0}, 0});
+		else MI_MUST(EqualizerPool::rate_update(d->pool->e, d->slot));
+		d->has_hist = false;
+	} else equalizer_attach(f);
 	return 0;
 }
 int equalizer_set_active(MSFilter *f, void *arg) { // equalizer.c:311-315: arg read as bool_t

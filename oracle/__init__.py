@@ -220,6 +220,10 @@ class Equalizer:
     def set_gain(self, freq, gain, width):
         lib().orc_equalizer_set_gain(self.h, int(freq), float(gain), int(width))
 
+    def set_rate(self, rate):
+        """MS_FILTER_SET_SAMPLE_RATE (equalizer.c:57-79,305-309): a flat spectrum and a cleared FIR memory, at the same rate too"""
+        lib().orc_equalizer_set_rate(self.h, int(rate))
+
     def taps(self):
         lib().orc_equalizer_design(self.h)
         st = self._st()

@@ -384,6 +384,8 @@ def run(plugin_dir, fuse, scenario, h=None):
                     assert h.S.ms2shim_equalizer_set_gain(leg["eq"], 2000.0, val, 800.0) == 0
                 elif kind == "eq_active":
                     assert h.S.ms2shim_equalizer_set_active(leg["eq"], int(val)) == 0
+                elif kind == "eq_rate":     # MS_FILTER_SET_SAMPLE_RATE at the rate it has: the response is flat again (equalizer.c:305-309), the leg stays fused
+                    h.call_int(leg["eq"], IDS["MS_FILTER_SET_SAMPLE_RATE"], int(val))
                 elif kind == "spk_eq_active":   # the speaker's equalizer switched on in mid-call: no longer transparent
                     assert h.S.ms2shim_equalizer_set_active(leg["spk_eq"], int(val)) == 0
                 elif kind == "recv_gain":   # volrecv stops being a meter only: the leg goes back to its facades
@@ -490,7 +492,7 @@ SCENARIOS = {
     "volrecv_with_a_gain_from_the_start": {"volrecv": True, "nticks": 60, "events": [(0, "recv_gain", 1, 0.5)], "tail_blocks": 1},
     # mic_equalizer between MSResample and MSSpeexEC (audiostream.c:1801): it moves into the leg's bank with its gains and its FIR's
     # memory, the up-sampler un-folds from the canceller's launch (resample, equalize, cancel: all on the device)
-    "mic_equalizer": {"mic_equalizer": True, "delay_ms": 10, "far_gaps": True, "nticks": 110, "events": [(40, "eq_gain", 1, 3.0), (70, "eq_active", 2, 0), (90, "eq_active", 2, 1)]},
+    "mic_equalizer": {"mic_equalizer": True, "delay_ms": 10, "far_gaps": True, "nticks": 110, "events": [(40, "eq_gain", 1, 3.0), (55, "eq_rate", 1, 48000), (70, "eq_active", 2, 0), (90, "eq_active", 2, 1)]},
     "mic_equalizer_no_mixer_8k_16k": {"mic_equalizer": True, "no_mixer": True, "nconf": 1, "members": 5, "in_rate": 8000, "rate": 16000, "tail_ms": 128, "ptime20": True,
                                       "nticks": 100, "events": [(41, "eq_gain", 3, 0.3)]},
     "mic_equalizer_replumbed_then_leaves": {"mic_equalizer": True, "no_agc": True, "nticks": 110, "events": [(41, "reattach", 0, 0), (42, "reattach", 0, 0), (75, "agc", 1, 1)],

@@ -96,8 +96,10 @@ def test_mic_equalizer_leg_is_the_oracle_chain(host, oracle, form):
     """DIRECT: a sending leg with a mic_equalizer (audiostream.c:1798-1810: read_resampler -> mic_equalizer -> ec -> volsend) against the
     chain of oracle objects -- Resampler -> Equalizer (one FIR block per microphone block, its memory carried, equalizer.c:256-288) ->
     MSSpeexEC's framing -> Echo + Preproc -> MSVolume without AGC (a meter: the frames leave as they came); a gain set in mid-call meets
-    the next walk's block.  What the leg sends, within north_star's 1e-4 RMS of full scale."""
-    sc = {"mic_equalizer": True, "no_mixer": True, "no_agc": True, "nconf": 1, "members": 3, "delay_ms": 10, "nticks": 140, "events": [(60, "eq_gain", 1, 3.0)]}
+    the next walk's block, and so does MS_FILTER_SET_SAMPLE_RATE at the filter's own rate, which makes the response flat again while the
+    leg stays in its batch.  What the leg sends, within north_star's 1e-4 RMS of full scale."""
+    sc = {"mic_equalizer": True, "no_mixer": True, "no_agc": True, "nconf": 1, "members": 3, "delay_ms": 10, "nticks": 140,
+          "events": [(60, "eq_gain", 1, 3.0), (100, "eq_rate", 2, 48000)]}   # (leg 2: MS_FILTER_SET_SAMPLE_RATE at the rate it has -- flat again, equalizer.c:305-309)
     res = fg.run(PKG, form == "fused", sc, host)
     assert (res["stats"]["legs"] > 0) == (form == "fused")
     F, rate, in_rate, ns, ni, nt = 256, 48000, 16000, 480, 160, sc["nticks"]
@@ -114,6 +116,8 @@ def test_mic_equalizer_leg_is_the_oracle_chain(host, oracle, form):
         for t in range(nt):
             if t == 60 and s == 1:
                 eq.set_gain(2000.0, 3.0, 800.0)
+            if t == 100 and s == 2:
+                eq.set_rate(rate)
             if started:
                 q_ref = np.concatenate([q_ref, far[s, t * ns:(t + 1) * ns]])
             q_mic = np.concatenate([q_mic, eq.run(rs.process(mic[s, t * ni:(t + 1) * ni]))])

@@ -126,6 +126,34 @@ def test_echo_limiter_peer_in_another_batch_bit_exact(ctx, oracle):
     recv.close()
 
 
+def test_a_peer_batch_may_be_destroyed_first(ctx, oracle):
+    """mi_volume_set_peer_batch keeps no dangling pointer: with the peers' batch destroyed (or never set) a stream whose peer is
+    MI_VOLUME_PEER_EXTERNAL has NO peer -- the oracle without a limiter, bit for bit -- and nothing reads freed device memory."""
+    rate, n, ns = 48000, 480, 3
+    send, recv = ms.VolumeBatch(ctx, ns, rate), ms.VolumeBatch(ctx, ns, rate)
+    send.set_peer_batch(recv)
+    params, orcs = [], []
+    for i in range(ns):
+        p = send.default_params()
+        p.peer = -2   # MI_VOLUME_PEER_EXTERNAL
+        p.ea_thres = np.float32(0.002)
+        p.force = np.float32(15.0)
+        params.append(p)
+        orcs.append(_mk(oracle, rate))   # (no peer: the limiter never runs)
+    send.set_params(params)
+    loud = np.stack([synth_pcm(70 + i, n, sigma=9000.0, rate=rate) for i in range(ns)])
+    recv.process(np.ascontiguousarray(loud.copy()))   # the peers' energy is high: WITH the link the limiter would pull the gain down
+    recv.close()                                      # ... and the peers go first
+    for t in range(12):
+        x = np.stack([synth_pcm(10 * t + i, n, sigma=2500.0, rate=rate) for i in range(ns)])
+        got = send.process(np.ascontiguousarray(x.copy()))
+        st = send.get_state()
+        for i in range(ns):
+            np.testing.assert_array_equal(got[i], orcs[i].chunk(x[i]), err_msg=f"tick {t} stream {i}")
+            _cmp_state(st[i], orcs[i].v, (t, i))
+    send.close()
+
+
 def test_volume_unity_gain_leaves_minus_32768_untouched(ctx, oracle):
     """A1: gain == 1 skips the sample loop, so -32768 survives (msvolume.c:440)."""
     vb = ms.VolumeBatch(ctx, 2, 48000)
