@@ -1745,7 +1745,8 @@ def main():
                 if best is not None:
                     best[2].close()
                     best = None
-                if worst < 9.75 and ups < 3 and streams + 2048 <= a.sweep_hi:
+                # (once --accept-seconds are spent on step-downs -- a box that kept producing events -- one step up is tried, not three: a try is a minute)
+                if worst < 9.75 and ups < (1 if time.perf_counter() - t_accept0 > a.accept_seconds else 3) and streams + 2048 <= a.sweep_hi:
                     best = (streams, zero, head, series, fg0, worst, paced)
                     ups += 1
                     # one step -- or, where the longest tick leaves a lot of room (the sweep's proposal was held down by one event), the
