@@ -19,6 +19,7 @@
 
 #include <dlfcn.h>
 #include <execinfo.h>
+#include <malloc.h>
 #include <signal.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -394,7 +395,7 @@ static void *run(void *arg) {
 			}
 		}
 		const double w0 = now_ms();
-		if (g_stack_ms > 0 && getenv("PLUGIN_BENCH_STACKS_WARMUP")) g_step_start[j->index] = mono_ns(); /* (the first ticks after the attach too) */
+		if ((g_stack_ms > 0 && getenv("PLUGIN_BENCH_STACKS_WARMUP")) || g_sampling) g_step_start[j->index] = mono_ns(); /* (the first ticks after the attach too) */
 		ms_ticker_step(j->ticker);
 		g_step_start[j->index] = 0;
 		j->warm_ms[t] = now_ms() - w0;
@@ -511,6 +512,11 @@ int main(int argc, char **argv) {
 		g_eq = strstr(sh, "eq") != NULL, g_el = strstr(sh, " el") != NULL || strncmp(sh, "el", 2) == 0;
 	}
 	g_checksum = getenv("PLUGIN_BENCH_CHECKSUM") != NULL; /* (costs the walk ~2 us per leg-tick: for parity runs, not for timing) */
+	/* glibc's per-thread arenas grow 128 KB at a time, each step an mprotect under the process's mmap lock: sixteen tickers allocating their first
+	 * ticks' blocks at once spent 65 % of those ticks there (scripts/r06_first_ticks_profile.sh).  The application's own choice, as a media
+	 * server would make it (or link another allocator): grow in 32 MB steps, do not give the top back */
+	mallopt(M_TOP_PAD, 32 << 20);
+	mallopt(M_TRIM_THRESHOLD, 512 << 20);
 	const char *plugin = argv[1];
 	int legs = atoi(argv[2]);
 	g_tickers = atoi(argv[3]);
@@ -584,6 +590,11 @@ int main(int argc, char **argv) {
 	int fc0 = 0, fl0 = 0, fc1 = 0, fl1 = 0;
 	unsigned long long la0 = 0, fr0 = 0, la1 = 0, fr1 = 0;
 	const double t_warm0 = now_ms();
+	const int sample_warmup = getenv("PLUGIN_BENCH_SAMPLE") && getenv("PLUGIN_BENCH_SAMPLE_WARMUP") && g_tickers <= 256; /* the ticks from the attach on instead of the timed ones */
+	if (sample_warmup) {
+		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
+		sample_start();
+	}
 	if (g_paced) {
 		g_w0 = mono_ns() + 20000000ull;
 		pthread_barrier_wait(&g_bar);
@@ -591,6 +602,7 @@ int main(int argc, char **argv) {
 	} else {
 		for (int t = 0; t < g_warmup; ++t) pthread_barrier_wait(&g_bar);
 	}
+	if (sample_warmup) g_sampling = 0, sample_report();
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
 	pthread_t churn_th;
@@ -601,7 +613,7 @@ int main(int argc, char **argv) {
 		g_churn_run = 1;
 		pthread_create(&churn_th, NULL, churner, NULL);
 	}
-	if (getenv("PLUGIN_BENCH_SAMPLE") && g_tickers <= 256) {
+	if (getenv("PLUGIN_BENCH_SAMPLE") && !sample_warmup && g_tickers <= 256) {
 		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
 		sample_start();
 	}
