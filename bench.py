@@ -1059,7 +1059,8 @@ def plugin_path_probe(first_legs, ticks=600, warmup=40, log=None, shape="", step
            "what": "full call legs through the drop-in plugin, PCIe included: source -> MSResample 16k->48k -> MSSpeexEC (128 ms tail) -> MSVolume (AGC) "
                    "-> MSAudioMixer (32-party conference mode) + the far end into MSSpeexEC pin 0, filters created by id from the factory after "
                    "libmsmi355xfilters_init, one ticker thread per MSTicker in the test runtime (tests/host/plugin_bench.c); the plugin runs each "
-                   "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl)",
+                   "ticker's conferences as one device-resident batch (host/filters/leg_chain.inl); the test program grows glibc's arenas in 32 MB steps "
+                   "(mallopt M_TOP_PAD: with the default 128 KB the first ticks after the attach are 65 % mprotect, profiles/r06_first_ticks.txt)",
            "fits_definition": f"no tick of {ticks} paced ticks reaches 10 ms, no step starts a whole interval late; tickers' phases spread over the interval; see the function's docstring",
            "host_cores_granted": ncores, "cgroup_cpu_quota_cores": quota, "ticks": ticks, "tried": tried}
     if extras:

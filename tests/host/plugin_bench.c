@@ -515,8 +515,10 @@ int main(int argc, char **argv) {
 	/* glibc's per-thread arenas grow 128 KB at a time, each step an mprotect under the process's mmap lock: sixteen tickers allocating their first
 	 * ticks' blocks at once spent 65 % of those ticks there (scripts/r06_first_ticks_profile.sh).  The application's own choice, as a media
 	 * server would make it (or link another allocator): grow in 32 MB steps, do not give the top back */
-	mallopt(M_TOP_PAD, 32 << 20);
-	mallopt(M_TRIM_THRESHOLD, 512 << 20);
+	if (!getenv("PLUGIN_BENCH_DEFAULT_MALLOC")) { /* (set: glibc's defaults, for an A/B) */
+		mallopt(M_TOP_PAD, 32 << 20);
+		mallopt(M_TRIM_THRESHOLD, 512 << 20);
+	}
 	const char *plugin = argv[1];
 	int legs = atoi(argv[2]);
 	g_tickers = atoi(argv[3]);
