@@ -2059,7 +2059,7 @@ def main():
             try:
                 line["plugin_path"] = plugin_path_probe(a.plugin_legs, log=log)
                 try:  # a conference SERVER's remote members (volrecv -> mixer -> G.711 encoder, no canceller: filters/server_leg.inl)
-                    sv = plugin_path_probe(65536, ticks=400, log=log, shape="server", step_legs=32768, max_legs=131072, extras=False)
+                    sv = plugin_path_probe(65536, ticks=400, log=log, shape="server", step_legs=16384, max_legs=131072, extras=False)
                     sv["what"] = ("a conference server's REMOTE members through the plugin, PCIe included: 8 kHz source (decoder .. dtmfgen) -> MSVolume (volrecv) -> "
                                   "in_resampler -> MSAudioMixer (conferences of 32) -> out_resampler -> MSUlawEnc -> sink (audioconference.c:121-179,209-257); metered, "
                                   "queued, mixed and ENCODED in one batch per ticker")

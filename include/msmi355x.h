@@ -297,6 +297,10 @@ int mi_equalizer_set_gain(mi_equalizer *e, int stream, float freq_hz, float gain
 /* MS_FILTER_SET_SAMPLE_RATE semantics for one stream's gains: flatten (A14) */
 int mi_equalizer_flatten(mi_equalizer *e, int stream);
 int mi_equalizer_set_active(mi_equalizer *e, int stream, int active); /* MS_EQUALIZER_SET_ACTIVE */
+/* Designs the taps of every stream whose gains changed and sends them up NOW (the launches do it themselves when they find stale streams: a
+ * host FFT per stream).  For whoever sets many streams' gains at once and wants that cost on the thread that does it -- the plugin calls it
+ * where a leg joins a bank, on the attaching thread.  Waits for the stream. */
+int mi_equalizer_prepare(mi_equalizer *e);
 /* MS_EQUALIZER_DUMP_STATE (equalizer.c:317-328): nfft/2 floats */
 int mi_equalizer_dump(mi_equalizer *e, int stream, float *h_dst, int cap);
 int mi_equalizer_get_taps(mi_equalizer *e, int stream, float *h_dst, int cap); /* designs if stale */

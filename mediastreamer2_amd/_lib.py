@@ -36,7 +36,7 @@ EXPORTS = [
     "mi_volume_create", "mi_volume_destroy", "mi_volume_default_params", "mi_volume_set_params",
     "mi_volume_get_state", "mi_volume_set_state", "mi_volume_set_peer_batch", "mi_volume_get_max", "mi_volume_reset_max", "mi_volume_process", "mi_volume_process_host", "mi_volume_process_fifo", "mi_volume_process_fifo_range", "mi_volume_process_fifo_flags", "mi_mixer_process_volume_fifo", "mi_mixer_process_volume_fifo_flags", "mi_volume_get_state_async",
     "mi_equalizer_create", "mi_equalizer_destroy", "mi_equalizer_fir_len", "mi_equalizer_set_gain",
-    "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_dump", "mi_equalizer_get_taps",
+    "mi_equalizer_flatten", "mi_equalizer_set_active", "mi_equalizer_prepare", "mi_equalizer_dump", "mi_equalizer_get_taps",
     "mi_equalizer_set_taps", "mi_equalizer_get_history", "mi_equalizer_set_history", "mi_equalizer_process", "mi_equalizer_process_host",
     "mi_aec_framesize", "mi_aec_create", "mi_aec_destroy", "mi_aec_reset", "mi_aec_process", "mi_aec_process_frames", "mi_aec_process_fifos", "mi_aec_process_fifos_resampled", "mi_aec_process_fifos_masked", "mi_aec_process_fifos_resampled_masked",
     "mi_aec_process_host", "mi_aec_state_bytes", "mi_aec_blob_bytes", "mi_aec_export_state", "mi_aec_import_state", "mi_aec_copy_state", "mi_aec_get", "mi_aec_stagger_info", "mi_aec_stagger_fifos",
@@ -206,6 +206,7 @@ def load():
         L.mi_equalizer_set_gain.argtypes = [vp, i32, f32, f32, f32]
         L.mi_equalizer_flatten.argtypes = [vp, i32]
         L.mi_equalizer_set_active.argtypes = [vp, i32, i32]
+        L.mi_equalizer_prepare.argtypes = [vp]
         L.mi_equalizer_dump.argtypes = [vp, i32, vp, i32]
         L.mi_equalizer_get_taps.argtypes = [vp, i32, vp, i32]
         L.mi_equalizer_set_taps.argtypes = [vp, i32, vp, i32]

@@ -77,6 +77,10 @@ void graph_preprocessed(MSFilter *f) { // (hub locked by the caller)
 		} else if (g->desc == &ms_mi355x_generic_plc_desc) {
 			PlcFilter *d = (PlcFilter *)g->data;
 			if (!d->rleg && d->rate > 0) plc_attach(g, d);
+		} else if (g->desc == &ms_mi355x_equalizer_desc) {
+			EqualizerData *d = (EqualizerData *)g->data;
+			if (!d->leg && d->active) equalizer_attach(g); // (an inactive one forwards: no slot until it is switched on.  Here and not in its own preprocess: a mic_equalizer that
+			                                               // joins a leg would take a slot of its own first -- bank, history read-back, release: a second per 2 048 legs)
 		} else if (g->desc == &ms_mi355x_audio_flow_control_desc) {
 			FlowFilter *d = (FlowFilter *)g->data;
 			if (!d->rleg) {

@@ -195,7 +195,8 @@ void equalizer_preprocess(MSFilter *f) {
 		graph_preprocessed(f);
 		((EqualizerData *)f->data)->passes_unlocked.store(equalizer_passes(f, f->ticker), std::memory_order_release);
 	}
-	if (!((EqualizerData *)f->data)->leg && ((EqualizerData *)f->data)->active) equalizer_attach(f); // (an inactive one forwards: no slot until it is switched on)
+	// (its own slot, where it needs one, is taken by the graph's last facade to be preprocessed -- attach.inl -- after the legs have been recognised;
+	// a graph some of whose facades were configured after the attach: process() takes it)
 }
 void equalizer_postprocess(MSFilter *f) {
 	EqualizerData *d = (EqualizerData *)f->data;

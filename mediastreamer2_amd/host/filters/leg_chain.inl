@@ -1948,6 +1948,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 		if (cd.eq && !leg_take_equalizer(b, leg, cd.eq)) mi_failed("taking the leg's equalizer into the batch");
 	}
 	if (!b->give_end()) mi_failed("moving MSVolume's queued samples to the device");
+	if (with_eq && b->eq && mi_equalizer_prepare(b->eq) != MI_OK) mi_failed("designing the legs' equalizers"); // (every leg's taps at once, on the attaching thread)
 	if (rs_any && mi_resampler_set_states(b->rs, s0, mm, rs_buf.data(), rs_buf.size()) != MI_OK) mi_failed("moving the resamplers' states to the device");
 	if (ms->pool) { // (a conference that had mixed on its facade before: normally preprocess opens no slot, mixer_acquire)
 		ms->pool->staged[(size_t)ms->slot] = ms->pool->ready[(size_t)ms->slot] = 0;
@@ -2193,6 +2194,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	if (!b->give_remainder(s, vd, leg) || !b->give_end()) mi_failed("moving MSVolume's queued samples to the device");
 	if (peer && !leg_take_peer(b, leg, peer)) mi_failed("taking the echo limiter's peer into the batch");
 	if (eqf && !leg_take_equalizer(b, leg, eqf)) mi_failed("taking the leg's equalizer into the batch");
+	if (eqf && b->eq && mi_equalizer_prepare(b->eq) != MI_OK) mi_failed("designing the leg's equalizer"); // (the taps' design -- a host FFT per stream -- here, on the attaching thread, not under the first tick's launch)
 	if (encf) {
 		MapFilter *ed = (MapFilter *)encf->data;
 		map_release(ed); // (its own bank's slot, if it ever had one)

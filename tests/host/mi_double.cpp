@@ -511,6 +511,10 @@ int mi_equalizer_flatten(mi_equalizer *e, int s) {
 	std::fill(e->gains[(size_t)s].begin(), e->gains[(size_t)s].end(), 1.f);
 	return MI_OK;
 }
+int mi_equalizer_prepare(mi_equalizer *e) {
+	ARG(e);
+	return MI_OK;
+}
 int mi_equalizer_set_active(mi_equalizer *e, int s, int on) {
 	ARG(e && s >= 0 && s < e->n);
 	e->active[(size_t)s] = on;

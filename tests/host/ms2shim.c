@@ -28,14 +28,14 @@ void ms_free(void *p) { free(p); }
  * to 0.2 - 0.8 s by itself.  What printing costs is the application's log handler's business (bctbx_set_log_handler); this runtime counts. */
 static int g_verbose = -1;
 static volatile long g_log_counts[2];
-long ms2shim_log_count(int errors) { return g_log_counts[errors ? 1 : 0]; }
+long ms2shim_log_count(int errors) { return __atomic_load_n(&g_log_counts[errors ? 1 : 0], __ATOMIC_RELAXED); }
 static void vlog(const char *lvl, const char *fmt, va_list ap) {
 	if (g_verbose < 0) g_verbose = getenv("MS2SHIM_VERBOSE") ? 1 : 0;
 	if (!g_verbose && lvl[0] == 'm') return;
 	if (lvl[0] != 'm' && !g_verbose) { /* the first 32 of a kind are printed, the rest counted -- per thread, folded into the total in lots (sixteen tickers' warnings, one per leg, on ONE counter were 7 % of the first ticks after a large attach) */
 		static __thread long mine[2];
 		const int k = lvl[0] == 'e';
-		if (g_log_counts[k] > 32) {
+		if (__atomic_load_n(&g_log_counts[k], __ATOMIC_RELAXED) > 32) {
 			if (++mine[k] >= 256) __sync_add_and_fetch(&g_log_counts[k], mine[k]), mine[k] = 0;
 			return;
 		}

@@ -588,7 +588,7 @@ static void *audiostreams(void *arg) {
 			ms_filter_link(enc[k], 0, out[k], 0);
 			CHECK(ms_ticker_attach(tk, mic[k]) == 0);
 		}
-		stream_meddle_t md = {fc[1], plc[2], vs[3], seq[4], omx[0], 0};
+		stream_meddle_t md = {fc[1], plc[2], vs[3], seq[4], omx[2], 0}; /* (not stream 0: that one is re-plumbed by THIS thread at t == 11, and an application does not call a filter while it attaches it) */
 		pthread_t mt;
 		for (int t = 0; t < 24; ++t) {
 			for (int k = 0; k < NS_; ++k) {
