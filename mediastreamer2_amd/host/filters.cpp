@@ -212,7 +212,7 @@ void Pool::sync_stream() {
 	if (hub->ctx && mi_ctx_sync(hub->ctx) != MI_OK) failed = mi_failed("mi_ctx_sync");
 }
 
-std::shared_mutex g_registry_mu;
+std::mutex g_registry_mu; // (a plain mutex: under sixteen threads attaching at once glibc's reader-preferring rwlock starved the writers -- note_slot -- for 70 % of the attach)
 std::unordered_map<MSTicker *, TickerHub *> g_hubs;          // the hub of a ticker
 struct FilterRef {
 	TickerHub *hub;
@@ -282,14 +282,14 @@ void destroy_hub(TickerHub *hub) { // the last scope of a retired hub
 
 TickerHub *hub_for(MSFilter *f, bool create) {
 	{
-		std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+		std::lock_guard<std::mutex> rl(g_registry_mu);
 		auto fi = g_filter_hubs.find(f);
 		if (fi != g_filter_hubs.end()) return fi->second.hub->ref(), fi->second.hub;
 		auto hi = g_hubs.find(f ? f->ticker : nullptr);
 		if (hi != g_hubs.end()) return hi->second->ref(), hi->second;
 	}
 	if (!create) return nullptr;
-	std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+	std::unique_lock<std::mutex> wl(g_registry_mu);
 	MSTicker *t = f ? f->ticker : nullptr;
 	auto hi = g_hubs.find(t);
 	if (hi != g_hubs.end()) return hi->second->ref(), hi->second;
@@ -313,7 +313,7 @@ struct HubLock {
 	// under it, the slot-based constructors need a bank), so refs == 1 means this scope is the only one.
 	static void retire_if_idle(TickerHub *hub) {
 		if (hub->retired() || !hub->pools.empty() || hub->pins > 0) return;
-		std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+		std::unique_lock<std::mutex> wl(g_registry_mu);
 		if (hub->refs() != 1) return;
 		auto it = g_hubs.find(hub->ticker);
 		if (it != g_hubs.end() && it->second == hub) g_hubs.erase(it);
@@ -384,7 +384,7 @@ void Pool::release(int slot) {
 	--in_use;
 	TickerHub *h = hub;
 	{
-		std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+		std::unique_lock<std::mutex> wl(g_registry_mu);
 		auto fi = g_filter_hubs.find(f);
 		if (fi != g_filter_hubs.end() && --fi->second.slots <= 0) g_filter_hubs.erase(fi);
 	}
@@ -393,7 +393,7 @@ void Pool::release(int slot) {
 		h->pools.erase(std::find(h->pools.begin(), h->pools.end(), this));
 		delete this;
 		if (h->pools.empty() && h->pins == 0) { // and with the last bank the hub (its stream): a ticker per call must not leak one
-			std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+			std::unique_lock<std::mutex> wl(g_registry_mu);
 			auto it = g_hubs.find(h->ticker);
 			if (it != g_hubs.end() && it->second == h) g_hubs.erase(it);
 			h->life.fetch_or(TickerHub::RETIRED, std::memory_order_acq_rel); // deleted by the last HubLock scope to end
@@ -444,7 +444,7 @@ struct Building {
 };
 
 void note_slot(MSFilter *f) { // the filter holds one more slot on the current hub (so a detached filter still finds it)
-	std::unique_lock<std::shared_mutex> wl(g_registry_mu);
+	std::unique_lock<std::mutex> wl(g_registry_mu);
 	FilterRef &r = g_filter_hubs[f];
 	r.hub = tl_hub;
 	r.slots++;
@@ -656,6 +656,7 @@ struct MapFilter;
 struct PlcFilter;
 void recv_chain_preprocessed(MSFilter *member);
 void graph_preprocessed(MSFilter *f); // attach.inl: every facade's preprocess ends here
+bool graph_ready(MSFilter *f);        // ... after asking, without any lock, whether it is the graph's LAST facade to be preprocessed
 void generic_preprocess(MSFilter *f);
 void recv_release(RecvLeg *leg, bool keep_running);
 void recv_disqualify(RecvLeg *leg);
@@ -810,7 +811,7 @@ void libmsmi355xfilters_init(MSFactory *factory) {
 // every hub in the registry, each with a reference taken under the registry lock (to be adopted by a HubLock)
 static std::vector<TickerHub *> referenced_hubs() {
 	std::vector<TickerHub *> hubs;
-	std::shared_lock<std::shared_mutex> rl(g_registry_mu);
+	std::lock_guard<std::mutex> rl(g_registry_mu);
 	for (auto &kv : g_hubs) {
 		kv.second->ref();
 		hubs.push_back(kv.second);

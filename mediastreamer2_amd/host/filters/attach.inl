@@ -14,6 +14,26 @@
 // (The facades' first process() still looks -- fuse_checked / fuse_state -- for a graph whose facades were configured after the
 // attach; normally it finds the decision made.)
 
+// Is every facade of this plugin in f's graph attached to f's ticker already -- is f the last of them to be preprocessed?  No lock: the graph
+// is being attached by THIS thread (ms_ticker_attach sets a filter's ticker right in front of its preprocess, msfilter.c:266-270) and nobody
+// walks it yet.  The facades that are not the last leave their preprocess without looking for their hub: with sixteen threads attaching 2 048
+// streams of seventeen filters each, the look-ups in the process-wide registry were two thirds of the attach (profiles/r06_attach_profile.txt).
+bool graph_ready(MSFilter *f) {
+	if (!f->ticker) return false;
+	std::vector<MSFilter *> todo{f};
+	std::unordered_set<MSFilter *> seen{f};
+	while (!todo.empty()) {
+		MSFilter *g = todo.back();
+		todo.pop_back();
+		if (is_ours(g->desc) && g->ticker != f->ticker) return false;
+		for (int i = 0; i < g->desc->ninputs; ++i)
+			if (g->inputs[i] && g->inputs[i]->prev.filter && seen.insert(g->inputs[i]->prev.filter).second) todo.push_back(g->inputs[i]->prev.filter);
+		for (int i = 0; i < g->desc->noutputs; ++i)
+			if (g->outputs[i] && g->outputs[i]->next.filter && seen.insert(g->outputs[i]->next.filter).second) todo.push_back(g->outputs[i]->next.filter);
+	}
+	return true;
+}
+
 void graph_preprocessed(MSFilter *f) { // (hub locked by the caller)
 	if (!f->ticker) return;
 	std::vector<MSFilter *> todo{f}, all;
@@ -91,6 +111,7 @@ void graph_preprocessed(MSFilter *f) { // (hub locked by the caller)
 	}
 }
 void generic_preprocess(MSFilter *f) { // a facade with nothing of its own to prepare
+	if (!graph_ready(f)) return;
 	HubLock lk(f);
 	graph_preprocessed(f);
 }

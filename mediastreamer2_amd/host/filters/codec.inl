@@ -243,6 +243,7 @@ void g711_dec_postprocess(MSFilter *f) {
 // (alaw.c has none) the attaching thread: is this the head of a stream's receiving chain?  (the last of the chain's filters to be
 // preprocessed finds every ticker set and fuses it: msticker.c:163-166 runs the graph's preprocess calls one after the other)
 void g711_dec_preprocess(MSFilter *f) {
+	if (!graph_ready(f)) return;
 	HubLock lk(f);
 	graph_preprocessed(f);
 }

@@ -230,11 +230,12 @@ void ec_fetch_config(SpeexECState *s);
 
 void ec_prepare(MSFilter *f);
 void ec_preprocess(MSFilter *f) { // speexec.c:188-216
+	ec_prepare(f); // (the filter's own fields: it is being attached by this thread, nobody runs it yet)
+	if (!graph_ready(f)) return;
 	HubLock lk(f);
-	ec_prepare(f);
 	graph_preprocessed(f);
 }
-void ec_prepare(MSFilter *f) { // (hub locked by the caller)
+void ec_prepare(MSFilter *f) { // (the hub locked by the caller where the filter is running: a conference that leaves its batch)
 	SpeexECState *s = (SpeexECState *)f->data;
 	s->echostarted = FALSE;
 	s->fuse_checked = false;

@@ -190,11 +190,11 @@ void equalizer_init(MSFilter *f) { // equalizer.c:271-273: default rate 8000
 }
 void equalizer_preprocess(MSFilter *f) {
 	((EqualizerData *)f->data)->was_active = ((EqualizerData *)f->data)->active;
-	{
+	if (graph_ready(f) || ((EqualizerData *)f->data)->pool) {
 		HubLock lk(f);
 		graph_preprocessed(f);
 		((EqualizerData *)f->data)->passes_unlocked.store(equalizer_passes(f, f->ticker), std::memory_order_release);
-	}
+	} else ((EqualizerData *)f->data)->passes_unlocked.store(equalizer_passes(f, f->ticker), std::memory_order_release); // (no slot: nothing of the hub's is read)
 	// (its own slot, where it needs one, is taken by the graph's last facade to be preprocessed -- attach.inl -- after the legs have been recognised;
 	// a graph some of whose facades were configured after the attach: process() takes it)
 }

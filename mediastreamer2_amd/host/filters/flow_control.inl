@@ -200,8 +200,9 @@ bool flowctl_attach(MSFilter *f, FlowFilter *d) {
 }
 void flowctl_preprocess(MSFilter *f) { // :166-169 ms_audio_flow_controller_reset
 	FlowFilter *d = (FlowFilter *)f->data;
-	HubLock lk(f);
 	(void)d;
+	if (!graph_ready(f)) return;
+	HubLock lk(f);
 	graph_preprocessed(f); // (fused: reset with its slot there; else a slot of its own bank, reset, there or at its first block)
 }
 void flowctl_process(MSFilter *f) { // :171-183

@@ -189,8 +189,9 @@ bool plc_attach(MSFilter *f, PlcFilter *d) { // generic_plc_preprocess :55-58: a
 }
 void plc_preprocess(MSFilter *f) {
 	PlcFilter *d = (PlcFilter *)f->data;
-	HubLock lk(f);
 	(void)d;
+	if (!graph_ready(f)) return;
+	HubLock lk(f);
 	graph_preprocessed(f); // (a filter that does not join a fused chain takes its own bank's slot there -- or, configured later, at its first block)
 }
 void plc_process(MSFilter *f) { // generic_plc_process :59-167

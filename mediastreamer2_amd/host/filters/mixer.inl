@@ -216,14 +216,15 @@ void mixer_push_controls(MSFilter *f, MixerState *s, bool from_method = false) {
 void mixer_prepare(MSFilter *f, bool running = false);
 void mixer_acquire(MSFilter *f);
 void mixer_preprocess(MSFilter *f) { // audiomixer.c:178-200
-	HubLock lk(f);
 	((MixerState *)f->data)->fuse_state = 0;
-	mixer_prepare(f);
+	mixer_prepare(f); // (the filter's own fields: it is being attached by this thread, nobody runs it yet)
+	if (!graph_ready(f)) return;
+	HubLock lk(f);
 	graph_preprocessed(f);
 }
 // running: the conference left a fused batch while attached -- no preprocess in the reference's terms: the channels' clocks (census,
 // flow control) and the bypass state run on, they are the very fields the batch kept (LegBank / ServerBank::conf_tick)
-void mixer_prepare(MSFilter *f, bool running) { // (hub locked by the caller)
+void mixer_prepare(MSFilter *f, bool running) { // (running: the hub locked by the caller; at an attach the filter is the attaching thread's alone)
 	MixerState *s = (MixerState *)f->data;
 	s->bytespertick = (2 * s->nchannels * s->rate * f->ticker->interval) / 1000;
 	for (int i = 0; i < MIXER_MAX_CHANNELS && !running; ++i) {

@@ -442,6 +442,7 @@ void volume_preprocess(MSFilter *f) { // msvolume.c:447-469
 	// echo limiter's pair: the limiter addresses its peer by its slot in the SAME bank (volume_attach_slot), and two filters that take
 	// their slots one after the other at the attach land side by side)
 	if (volume_is_peered(d)) volume_attach_slot(f);
+	if (!graph_ready(f)) return;
 	HubLock lk(f);
 	graph_preprocessed(f);
 }

@@ -376,11 +376,13 @@ static void *run(void *arg) {
 	TickerJob *j = (TickerJob *)arg;
 	/* attach on the ticker's own thread: the hub's device context and its banks belong to the thread that ticks them */
 	const double a0 = now_ms();
+	if (g_sampling) g_step_start[j->index] = mono_ns(); /* (PLUGIN_BENCH_SAMPLE_ATTACH: the attach is what is sampled) */
 	if (g_nomixer)
 		for (int k = 0; k < j->nconf * g_members; ++k) ms_ticker_attach(j->ticker, j->heads[k]);
 	else
 		for (int c = 0; c < j->nconf; ++c) ms_ticker_attach(j->ticker, j->mixers[c]);
 	j->attach_ms = now_ms() - a0;
+	g_step_start[j->index] = 0;
 	/* the steps from the attach on are timed too (a start-up stall -- fusing, banks opening, slabs, a cold device -- must be visible,
 	 * not folded into capacity): paced like the rest when PLUGIN_BENCH_PACED (a schedule of its own, origin g_w0) */
 	if (g_paced) pthread_barrier_wait(&g_bar); /* (g_w0 is set) */
@@ -579,7 +581,13 @@ int main(int argc, char **argv) {
 	const double build_ms = now_ms() - t_build0;
 	pthread_barrier_init(&g_bar, NULL, (unsigned)g_tickers + 1);
 	pthread_t *th = (pthread_t *)calloc((size_t)g_tickers, sizeof(pthread_t));
+	const int sample_attach = getenv("PLUGIN_BENCH_SAMPLE") && getenv("PLUGIN_BENCH_SAMPLE_ATTACH") && g_tickers <= 256;
+	if (sample_attach) g_sampling = 1; /* (the threads mark themselves from their first line on; the sampler starts once they exist) */
 	for (int i = 0; i < g_tickers; ++i) pthread_create(&th[i], NULL, run, &jobs[i]);
+	if (sample_attach) {
+		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
+		sample_start();
+	}
 	pthread_t wd;
 	if (getenv("PLUGIN_BENCH_STACKS") && g_tickers <= 256) {
 		g_stack_ms = atof(getenv("PLUGIN_BENCH_STACKS"));
@@ -592,7 +600,7 @@ int main(int argc, char **argv) {
 	int fc0 = 0, fl0 = 0, fc1 = 0, fl1 = 0;
 	unsigned long long la0 = 0, fr0 = 0, la1 = 0, fr1 = 0;
 	const double t_warm0 = now_ms();
-	const int sample_warmup = getenv("PLUGIN_BENCH_SAMPLE") && getenv("PLUGIN_BENCH_SAMPLE_WARMUP") && g_tickers <= 256; /* the ticks from the attach on instead of the timed ones */
+	const int sample_warmup = getenv("PLUGIN_BENCH_SAMPLE") && getenv("PLUGIN_BENCH_SAMPLE_WARMUP") && !sample_attach && g_tickers <= 256; /* the ticks from the attach on instead of the timed ones */
 	if (sample_warmup) {
 		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
 		sample_start();
@@ -605,6 +613,7 @@ int main(int argc, char **argv) {
 		for (int t = 0; t < g_warmup; ++t) pthread_barrier_wait(&g_bar);
 	}
 	if (sample_warmup) g_sampling = 0, sample_report();
+	if (sample_attach && g_sampling) g_sampling = 0, sample_report(); /* (the attach and the warm-up ticks behind it) */
 	/* the warm-up's last step is running; the first timed barrier releases when it is done */
 	double t_first = 0;
 	pthread_t churn_th;
@@ -615,7 +624,7 @@ int main(int argc, char **argv) {
 		g_churn_run = 1;
 		pthread_create(&churn_th, NULL, churner, NULL);
 	}
-	if (getenv("PLUGIN_BENCH_SAMPLE") && !sample_warmup && g_tickers <= 256) {
+	if (getenv("PLUGIN_BENCH_SAMPLE") && !sample_warmup && !sample_attach && g_tickers <= 256) {
 		for (int i = 0; i < g_tickers; ++i) g_threads[i] = th[i];
 		sample_start();
 	}
