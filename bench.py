@@ -1697,110 +1697,126 @@ def main():
         print("bench.py: no stream count fits the 10 ms tick on this device", file=sys.stderr)
         sys.exit(1)
 
-    # ---- the count is then held to two more tests, stepped down until it passes both (a.streams > 0: measured as given):
-    #  (1) every leg starting from RESET at the same moment (the first second of adaptation), --zero-ticks ticks;
-    #  (2) --worst-ticks (default 3000) CONSECUTIVE deployed ticks in steady state -- with the exchange at N > 1 -- none
-    #      of which may reach the 10 ms interval: a late tick is a fault (src/base/msticker.c:46,441-443).
-    zero = None
-    paced, paced_on = None, a.paced_ticks > 0 and PLATFORM.device != "cpu"
-    tried = []  # the counts that did not pass, with what they measured: the step-downs are part of the result
-    best = None  # (streams, zero, head, series, fg0, worst) of a count that passed while a larger one is being tried
-    ups = 0
-    retried = set()  # counts tried a second time because the first series' late ticks were host stalls
-    t_accept0 = time.perf_counter()
-    for attempt in range(12):
-        if a.zero_ticks > 0 and converged is not None:
-            zero = chain_capacity_point(ms, torch, ctx, streams, converged=None, worst_ticks=a.zero_ticks)
-            zero["tick_ms_worst"] = reduce_scalar(zero["tick_ms_worst"], "MAX")
-            if log:
-                log(dict(zero, test="from reset"))
-        zero_ok = zero is None or zero["tick_ms_worst"] < 10.0
-        head = None
-        if zero_ok or a.streams > 0 or streams <= 8192:
-            head = Headline(ms, torch, ctx, streams, world, rank, dist, local, exchange)
-            head.prepare(a.warmup, converged)
-            fg0 = head.rig.canceller_stats() if hasattr(head.rig, "canceller_stats") else None
-            # the read-backs above left the GPU idle for tens of ms and its clocks down: in service a tick follows the
-            # previous one within a millisecond or two.  One untimed scene period brings the device back to its running
-            # state; from there on every tick counts (scripts/outlier_probe.py: after 0.5 s of idle the first tick takes
-            # +1.7 ms, the second +0.6, then nothing)
-            head.tick_series(rig_period(head))
-            series = head.tick_series(a.worst_ticks)
-            worst = reduce_scalar(float(series.max()), "MAX")
-            if log:
-                log({"streams": head.rig.n, "test": f"{a.worst_ticks} consecutive ticks", **series_stats(series)})
-            # (3) the same number of ticks at the DEPLOYED cadence -- one per 10 ms of wall time, as an MSTicker fires them --
-            # with the product's keep-alive between them; only run when the back-to-back series passed
-            paced = None
-            if paced_on and (worst < 10.0 or a.streams > 0):
-                paced = head.paced_series(a.paced_ticks)
+    def accept(streams):
+        """The count the sweep proposed is held to the acceptance series, and moved until the verdict changes.  ALL the rules, in one place:
+          1. every leg starting from RESET at the same moment (the first second of adaptation), --zero-ticks ticks: none may reach 10 ms;
+          2. --worst-ticks (3000) CONSECUTIVE ticks in steady state -- with the exchange at N > 1 --, each timed alone: none may reach the
+             10 ms interval (a late tick is a fault, src/base/msticker.c:46,441-443; no tick is discarded);
+          3. --paced-ticks (3000) ticks at the DEPLOYED cadence, one per 10 ms of wall time (only when 2 passed): none may reach 10 ms;
+          4. a series whose ONLY late ticks were stalls of the submitting host thread (measured beside every tick) is no verdict on the
+             count: the count is tried again, once, and must then pass whole; both series stay in the record;
+          5. a count that fails is stepped DOWN to the count whose median leaves room for the failed series' longest tick (a tick costs in
+             proportion to the legs, a machine event does not), at least 2048, 2048, 4096, 4096, .. legs; once --accept-seconds are spent
+             the room is for the largest event seen on this hardware (1.8 ms, at most 2.5);
+          6. a count that passes with its longest tick below 9.75 ms is stepped UP (one step, or to the count whose longest tick would be
+             ~9.6 ms) -- at most three times, once after --accept-seconds; a step up that fails leaves the count that passed (a large step
+             is halved once);
+          7. --streams N: measured as given, no search;  at most twelve attempts in all.
+        Returns (streams, zero, head, series, fg0, worst, paced, tried); head is None when nothing passed."""
+        zero = head = series = fg0 = None
+        worst = float("inf")
+        paced, paced_on = None, a.paced_ticks > 0 and PLATFORM.device != "cpu"
+        tried = []  # the counts that did not pass, with what they measured: the step-downs are part of the result
+        best = None  # (streams, zero, head, series, fg0, worst) of a count that passed while a larger one is being tried
+        ups = 0
+        retried = set()  # counts tried a second time because the first series' late ticks were host stalls
+        t_accept0 = time.perf_counter()
+        for attempt in range(12):
+            if a.zero_ticks > 0 and converged is not None:
+                zero = chain_capacity_point(ms, torch, ctx, streams, converged=None, worst_ticks=a.zero_ticks)
+                zero["tick_ms_worst"] = reduce_scalar(zero["tick_ms_worst"], "MAX")
                 if log:
-                    log({"streams": head.rig.n, "test": f"{a.paced_ticks} paced ticks (one per 10 ms)", **series_stats(paced)})
-                worst = max(worst, reduce_scalar(float(paced.max()), "MAX"))
-            if a.streams > 0 or streams <= 8192:
-                break
-            if worst < 10.0 and zero_ok:
-                # passed.  The sweep's proposal can be low (one machine event among a point's 64 ticks fails the point): while
-                # the longest of the 3000 ticks leaves room for another step (2048 legs are ~0.15 ms), the next count up is
-                # held to the same two tests -- at most three times; a count that fails leaves the last one that passed
-                if best is not None:
-                    best[2].close()
-                    best = None
-                # (once --accept-seconds are spent on step-downs -- a box that kept producing events -- one step up is tried, not three: a try is a minute)
-                if worst < 9.75 and ups < (1 if time.perf_counter() - t_accept0 > a.accept_seconds else 3) and streams + 2048 <= a.sweep_hi:
-                    best = (streams, zero, head, series, fg0, worst, paced)
-                    ups += 1
-                    # one step -- or, where the longest tick leaves a lot of room (the sweep's proposal was held down by one event), the
-                    # count whose longest tick would be ~9.6 ms, a tick costing in proportion to the legs
-                    streams = min(a.sweep_hi // 2048 * 2048, streams + max(2048, int(streams * (9.6 / worst - 1.0)) // 2048 * 2048))
-                    continue
-                break
-            tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"],
-                          "paced": series_stats(paced) if paced is not None else None})
-            head.close()
+                    log(dict(zero, test="from reset"))
+            zero_ok = zero is None or zero["tick_ms_worst"] < 10.0
             head = None
-            # a series whose only late ticks were stalls of the submitting thread (measured beside every tick) is no verdict on
-            # the count: the count is tried again, ONCE, and must then pass whole; both series stay in the line
-            mine = [x for x in (series, paced) if x is not None and float(np.max(x)) >= 10.0]    # this rank's failed series
-            excused = zero_ok and all(host_stalls_only(x) for x in mine)                           # (none failed here: another rank's did)
-            if reduce_scalar(1.0 if excused else 0.0, "MIN") > 0 and streams not in retried:
-                retried.add(streams)
-                tried[-1]["late_ticks_were_host_stalls"] = "the count is tried again"
-                continue
-            if best is not None:  # the step up did not pass: the count below it stands ...
-                gap = streams - best[0]
-                if gap > 2048 and ups < 3:  # ... unless the step was a large one: half of it is tried (the count that passed stays in hand)
-                    ups += 1
-                    streams = best[0] + max(2048, gap // 2 // 2048 * 2048)
+            if zero_ok or a.streams > 0 or streams <= 8192:
+                head = Headline(ms, torch, ctx, streams, world, rank, dist, local, exchange)
+                head.prepare(a.warmup, converged)
+                fg0 = head.rig.canceller_stats() if hasattr(head.rig, "canceller_stats") else None
+                # the read-backs above left the GPU idle for tens of ms and its clocks down: in service a tick follows the
+                # previous one within a millisecond or two.  One untimed scene period brings the device back to its running
+                # state; from there on every tick counts (scripts/outlier_probe.py: after 0.5 s of idle the first tick takes
+                # +1.7 ms, the second +0.6, then nothing)
+                head.tick_series(rig_period(head))
+                series = head.tick_series(a.worst_ticks)
+                worst = reduce_scalar(float(series.max()), "MAX")
+                if log:
+                    log({"streams": head.rig.n, "test": f"{a.worst_ticks} consecutive ticks", **series_stats(series)})
+                # (3) the same number of ticks at the DEPLOYED cadence -- one per 10 ms of wall time, as an MSTicker fires them --
+                # with the product's keep-alive between them; only run when the back-to-back series passed
+                paced = None
+                if paced_on and (worst < 10.0 or a.streams > 0):
+                    paced = head.paced_series(a.paced_ticks)
+                    if log:
+                        log({"streams": head.rig.n, "test": f"{a.paced_ticks} paced ticks (one per 10 ms)", **series_stats(paced)})
+                    worst = max(worst, reduce_scalar(float(paced.max()), "MAX"))
+                if a.streams > 0 or streams <= 8192:
+                    break
+                if worst < 10.0 and zero_ok:
+                    # passed.  The sweep's proposal can be low (one machine event among a point's 64 ticks fails the point): while
+                    # the longest of the 3000 ticks leaves room for another step (2048 legs are ~0.15 ms), the next count up is
+                    # held to the same two tests -- at most three times; a count that fails leaves the last one that passed
+                    if best is not None:
+                        best[2].close()
+                        best = None
+                    # (once --accept-seconds are spent on step-downs -- a box that kept producing events -- one step up is tried, not three: a try is a minute)
+                    if worst < 9.75 and ups < (1 if time.perf_counter() - t_accept0 > a.accept_seconds else 3) and streams + 2048 <= a.sweep_hi:
+                        best = (streams, zero, head, series, fg0, worst, paced)
+                        ups += 1
+                        # one step -- or, where the longest tick leaves a lot of room (the sweep's proposal was held down by one event), the
+                        # count whose longest tick would be ~9.6 ms, a tick costing in proportion to the legs
+                        streams = min(a.sweep_hi // 2048 * 2048, streams + max(2048, int(streams * (9.6 / worst - 1.0)) // 2048 * 2048))
+                        continue
+                    break
+                tried.append({"streams": head.rig.n, **series_stats(series), "from_reset_worst_ms": zero and zero["tick_ms_worst"],
+                              "paced": series_stats(paced) if paced is not None else None})
+                head.close()
+                head = None
+                # a series whose only late ticks were stalls of the submitting thread (measured beside every tick) is no verdict on
+                # the count: the count is tried again, ONCE, and must then pass whole; both series stay in the line
+                mine = [x for x in (series, paced) if x is not None and float(np.max(x)) >= 10.0]    # this rank's failed series
+                excused = zero_ok and all(host_stalls_only(x) for x in mine)                           # (none failed here: another rank's did)
+                if reduce_scalar(1.0 if excused else 0.0, "MIN") > 0 and streams not in retried:
+                    retried.add(streams)
+                    tried[-1]["late_ticks_were_host_stalls"] = "the count is tried again"
                     continue
-                streams, zero, head, series, fg0, worst, paced = best
-                best = None
-                break
-            # the next count to try: the one whose median leaves room for this series' longest tick (a tick costs in
-            # proportion to the legs; what a machine event adds does not) -- rounded UP to the step, so the estimate can
-            # only be optimistic and the series at that count decides; never less than one step down
-            decisive = paced if (paced is not None and paced.max() >= series.max()) else series  # the series that failed the count
-            p50 = reduce_scalar(float(np.median(decisive)), "MAX")
-            # (a box that keeps producing events would have the default run step down for a quarter of an hour, a minute a try:
-            # once --accept-seconds are spent the next count leaves room for the LARGEST event seen on this hardware, 1.8 ms)
-            over = time.perf_counter() - t_accept0 > a.accept_seconds
-            # (... and no more than 2.5 ms: what exceeds the power controller's events -- a stall of the box -- would make a tick
-            # of ANY count late, and "room for it" would send the search to the bottom of the range)
-            event = min(max(worst - p50, 1.8) if over else worst - p50, 2.5)
-            room = int(streams * max(9.95 - event, 1.0) / p50) // 2048 * 2048 + (0 if over else 2048)
-            streams = min(streams - 2048 * (1 + attempt // 2), room)  # at least 2048, 2048, 4096, 4096, ... down
-        else:
-            tried.append({"streams": streams, "from_reset_worst_ms": zero["tick_ms_worst"]})
-            if best is not None:
-                streams, zero, head, series, fg0, worst, paced = best
-                best = None
-                break
-            streams -= 2048 * (1 + attempt // 2)
-        streams = max(streams, 8192)
-    if best is not None:  # (the attempts ran out on the way up: the last count that passed stands)
-        if head is not None and head is not best[2]:
-            head.close()
-        streams, zero, head, series, fg0, worst, paced = best
+                if best is not None:  # the step up did not pass: the count below it stands ...
+                    gap = streams - best[0]
+                    if gap > 2048 and ups < 3:  # ... unless the step was a large one: half of it is tried (the count that passed stays in hand)
+                        ups += 1
+                        streams = best[0] + max(2048, gap // 2 // 2048 * 2048)
+                        continue
+                    streams, zero, head, series, fg0, worst, paced = best
+                    best = None
+                    break
+                # the next count to try: the one whose median leaves room for this series' longest tick (a tick costs in
+                # proportion to the legs; what a machine event adds does not) -- rounded UP to the step, so the estimate can
+                # only be optimistic and the series at that count decides; never less than one step down
+                decisive = paced if (paced is not None and paced.max() >= series.max()) else series  # the series that failed the count
+                p50 = reduce_scalar(float(np.median(decisive)), "MAX")
+                # (a box that keeps producing events would have the default run step down for a quarter of an hour, a minute a try:
+                # once --accept-seconds are spent the next count leaves room for the LARGEST event seen on this hardware, 1.8 ms)
+                over = time.perf_counter() - t_accept0 > a.accept_seconds
+                # (... and no more than 2.5 ms: what exceeds the power controller's events -- a stall of the box -- would make a tick
+                # of ANY count late, and "room for it" would send the search to the bottom of the range)
+                event = min(max(worst - p50, 1.8) if over else worst - p50, 2.5)
+                room = int(streams * max(9.95 - event, 1.0) / p50) // 2048 * 2048 + (0 if over else 2048)
+                streams = min(streams - 2048 * (1 + attempt // 2), room)  # at least 2048, 2048, 4096, 4096, ... down
+            else:
+                tried.append({"streams": streams, "from_reset_worst_ms": zero["tick_ms_worst"]})
+                if best is not None:
+                    streams, zero, head, series, fg0, worst, paced = best
+                    best = None
+                    break
+                streams -= 2048 * (1 + attempt // 2)
+            streams = max(streams, 8192)
+        if best is not None:  # (the attempts ran out on the way up: the last count that passed stands)
+            if head is not None and head is not best[2]:
+                head.close()
+            streams, zero, head, series, fg0, worst, paced = best
+        return streams, zero, head, series, fg0, worst, paced, tried
+
+    streams, zero, head, series, fg0, worst, paced, tried = accept(streams)
     if head is None:
         # every attempt failed and the last one's rig is gone: the line reports what was tried, value 0 (nothing below is
         # measured on a closed rig)
