@@ -206,6 +206,7 @@ mi_ctx *Pool::ctx() const { return hub->ctx; }
 // MSTicker::time as a bank reads it.  The ticker's own thread advances it between ticks (msticker.c:494-495); a bank may be at work on the
 // APPLICATION's thread then -- a postprocess delivering a detaching graph's tick in flight -- and reads whichever of the two values: a relaxed load
 inline uint64_t hub_time(const TickerHub *h) { return h->ticker ? __atomic_load_n(&h->ticker->time, __ATOMIC_RELAXED) : 0; }
+inline uint64_t ticker_now(const MSTicker *t) { return __atomic_load_n(&t->time, __ATOMIC_RELAXED); } // (the same for code a detaching graph's flush may run on the application's thread)
 bool Pool::work_waiting() const { return hub->flush_owner != nullptr && !hub->in_flush; }
 bool Pool::parked(int slot) const { return hub->scope && !(owner[(size_t)slot] && hub->scope->count(owner[(size_t)slot])); }
 void Pool::sync_stream() {
@@ -485,7 +486,7 @@ bool already_ran_this_tick(MSFilter *f) {
 	TickerHub &h = g_hub;
 	if (h.in_flush || !f->ticker) return false;
 	auto it = h.pumped.find(f);
-	return it != h.pumped.end() && it->second == f->ticker->time;
+	return it != h.pumped.end() && it->second == ticker_now(f->ticker);
 }
 
 void deliver_fused_in_scope(TickerHub &h);  // leg_chain.inl
@@ -524,7 +525,7 @@ void flush_hub(TickerHub &h) {
 		if (run.empty()) { // nothing but pumps left: they go last, once everything that feeds them has arrived
 			for (MSFilter *g : h.touched_pumps)
 				if (all_inputs_ours(g) && g->ticker) {
-					h.pumped[g] = g->ticker->time;
+					h.pumped[g] = ticker_now(g->ticker);
 					run.push_back(g);
 				}
 			h.touched_pumps.clear();

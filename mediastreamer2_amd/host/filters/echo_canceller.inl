@@ -109,7 +109,7 @@ void flowbuf_put(FlowBuf *o, mblk_t *m, MSQueue *q = nullptr) { // msqueue.c:193
 	if (accumulated_ms < o->min_size_ms_during_interval) o->min_size_ms_during_interval = accumulated_ms;
 	if (q) ms_bufferizer_put_from_queue(&o->base, q);
 	else ms_bufferizer_put(&o->base, m);
-	const uint64_t now = o->filter->ticker->time;
+	const uint64_t now = ticker_now(o->filter->ticker);
 	const uint32_t since = (uint32_t)(now - o->flow_control_time);
 	if (o->flow_control_time == 0) o->flow_control_time = now;
 	if (since >= o->interval_ms) {

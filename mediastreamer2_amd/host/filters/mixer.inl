@@ -289,7 +289,7 @@ struct Contributors {
 
 Contributors mixer_census(MSFilter *f, MixerState *s) {
 	Contributors c;
-	const uint64_t now = f->ticker->time;
+	const uint64_t now = ticker_now(f->ticker);
 	for (int pin = 0; pin < f->desc->ninputs; ++pin) {
 		if (!f->inputs[pin]) continue;
 		uint64_t &seen = s->channels[pin].last_activity;
@@ -492,7 +492,7 @@ void mixer_process(MSFilter *f) { // audiomixer.c:288-346
 		Channel *chan = &s->channels[i];
 		ms_bufferizer_put_from_queue(&chan->bufferizer, q); // channel_process_in :78-90
 		has[i] = ms_bufferizer_read(&chan->bufferizer, (uint8_t *)(in + (size_t)i * nwords), (size_t)nwords * 2) != 0;
-		const int skip = channel_flow_control(chan, s->skip_threshold, f->ticker->time);
+		const int skip = channel_flow_control(chan, s->skip_threshold, ticker_now(f->ticker));
 		if (skip > 0)
 			ms_warning("mi355x mixer: pin %i kept more than two ticks queued for 5 s; %i ms discarded", i, (skip * 1000) / (2 * s->nchannels * s->rate));
 	}

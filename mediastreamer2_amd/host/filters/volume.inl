@@ -559,11 +559,11 @@ void VolumePool::emit(MSFilter *f, int slot) {
 	}
 	if (ready[s] && f->ticker) { // meters (update_energy msvolume.c:405-406): every chunk's energy, in order
 		for (int r = 0; r + 1 < std::min(ready[s], rounds_fetched); ++r) {
-			d->max.record_max(f->ticker->time, h_state[r * c + s].energy);
-			d->min.record_min(f->ticker->time, h_state[r * c + s].energy);
+			d->max.record_max(ticker_now(f->ticker), h_state[r * c + s].energy);
+			d->min.record_min(ticker_now(f->ticker), h_state[r * c + s].energy);
 		}
-		d->max.record_max(f->ticker->time, state[s].energy);
-		d->min.record_min(f->ticker->time, state[s].energy);
+		d->max.record_max(ticker_now(f->ticker), state[s].energy);
+		d->min.record_min(ticker_now(f->ticker), state[s].energy);
 	}
 	ready[s] = 0;
 }

@@ -731,7 +731,8 @@ static void *replumbed_by_the_application(void *arg) {
 		CHECK(pthread_create(&rt, NULL, replumber, &rp) == 0);
 		for (int t = 0; t < 60; ++t) { /* the ticker ticks while the application re-plumbs */
 			ms_ticker_step(tk);
-			usleep(200);
+			usleep(1500); /* (a re-plumbing takes about a tick's time, as in service: a stream that stays away for many ticks has its PLC make up for
+			               * all of them afterwards, msgenericplc.c:117-166, and the canceller's delay line drops -- and counts -- what the far end then runs ahead) */
 		}
 		__atomic_store_n(&rp.stop, 1, __ATOMIC_SEQ_CST);
 		pthread_join(rt, NULL);
