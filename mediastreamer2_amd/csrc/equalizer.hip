@@ -21,9 +21,6 @@
 
 namespace {
 
-constexpr int EQ_R = 4;        // outputs per lane
-constexpr int EQ_THREADS = 128;
-
 struct EqArgs {
 	int16_t *samples;
 	int16_t *hist;      // [nstreams][ord] int16 (ord-1 used)
@@ -33,66 +30,13 @@ struct EqArgs {
 	int nstreams, nsamples, stride, ord;
 };
 
-template <int ORD>
-__global__ __launch_bounds__(EQ_THREADS) void equalizer_kernel(EqArgs a) {
-	extern __shared__ __attribute__((aligned(16))) char smem[];
-	float *buf = reinterpret_cast<float *>(smem); // [ORD-1 + nsamples + EQ_R]
-	const int s = blockIdx.x;
-	if (!a.active[s]) return;
-	const int nsamples = a.nper ? min(max(a.nper[s], 0), a.nsamples) : a.nsamples;
-	if (nsamples == 0) return;
-	const int tid = threadIdx.x;
-	int16_t *xs = a.samples + (size_t)s * a.stride;
-	int16_t *hs = a.hist + (size_t)s * ORD;
-	const float *__restrict__ h = a.taps + (size_t)s * ORD;
-
-	for (int i = tid; i < ORD - 1; i += EQ_THREADS) buf[i] = (float)hs[i];
-	for (int i = tid; i < nsamples; i += EQ_THREADS) buf[ORD - 1 + i] = (float)xs[i];
-	for (int i = tid; i < EQ_R; i += EQ_THREADS) buf[ORD - 1 + nsamples + i] = 0.f;
-	__syncthreads();
-
-	for (int n0 = tid * EQ_R; n0 < nsamples; n0 += EQ_THREADS * EQ_R) {
-		float w[EQ_R], acc[EQ_R];
-#pragma unroll
-		for (int r = 0; r < EQ_R; ++r) acc[r] = 0.f;
-#pragma unroll
-		for (int r = 0; r < EQ_R - 1; ++r) w[r] = buf[n0 + r];
-		// jj = ORD-1-j: tap h[ORD-1-jj] meets buf[n + jj]  (oldest sample first)
-#pragma unroll 8
-		for (int jj = 0; jj < ORD; jj += EQ_R) {
-#pragma unroll
-			for (int u = 0; u < EQ_R; ++u) {
-				const float c = h[ORD - 1 - (jj + u)];
-				w[(u + EQ_R - 1) % EQ_R] = buf[n0 + EQ_R - 1 + jj + u];
-#pragma unroll
-				for (int r = 0; r < EQ_R; ++r) {
-					const float p = c * w[(u + r) % EQ_R];
-					acc[r] = acc[r] + p;
-				}
-			}
-		}
-#pragma unroll
-		for (int r = 0; r < EQ_R; ++r) {
-			if (n0 + r < nsamples) {
-				const float v = acc[r];
-				// (int16_t)float of the reference is UB out of range (equalizer.c:251-255); saturate
-				const int q = v >= 32767.f ? 32767 : (v <= -32768.f ? -32768 : (int)v);
-				xs[n0 + r] = (int16_t)q;
-			}
-		}
-	}
-	// new delay line: the last ORD-1 inputs
-	for (int i = tid; i < ORD - 1; i += EQ_THREADS) hs[i] = (int16_t)buf[nsamples + i];
-}
-
-// Packed form: one wavefront per stream, 8 outputs per lane held as four register pairs.  v_pk_mul_f32 +
-// v_pk_add_f32 round exactly like the scalar multiply and add (the product is NOT fused into the sum, as in the
-// reference's x86 build), but issue two outputs per slot; the tap is wave-uniform, window pairs at even offsets
-// are register pairs as they come from 16-byte LDS reads, pairs at odd offsets cost one v_pk_mov_b32 each
-// (one per two taps).  Per-output accumulation order is the reference's (oldest sample first).
+// One wavefront per stream, 8 outputs per lane held as four register pairs.  v_pk_mul_f32 + v_pk_add_f32 round exactly like the scalar
+// multiply and add (the product is NOT fused into the sum, as in the reference's x86 build), but issue two outputs per slot; the tap is
+// wave-uniform, window pairs at even offsets are register pairs as they come from 16-byte LDS reads, pairs at odd offsets cost one
+// v_pk_mov_b32 each (one per two taps).  Per-output accumulation order is the reference's (oldest sample first).  (The one-output-per-slot
+// form this replaced in round 3 left the source in round 6; scripts/micro/ keeps the idiom's own check.)
 typedef float eq_f2 __attribute__((ext_vector_type(2)));
-constexpr int EQ_PR = 8;
-
+constexpr int EQ_PR = 8; // outputs per lane
 template <int ORD>
 __global__ __launch_bounds__(64) void equalizer_pk_kernel(EqArgs a) {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -438,22 +382,11 @@ int mi_equalizer_process_masked(mi_equalizer *e, int16_t *d_samples, int nsample
 	a.stride = stride;
 	a.ord = e->nfft;
 	hipStream_t st = e->ctx->stream;
-	static const bool scalar_form = getenv("MSMI355X_EQ_SCALAR") != nullptr; // A/B switch for the older kernel
-	if (!scalar_form) {
-		const size_t lds_pk = (size_t)(e->nfft - 1 + nsamples + 16 + 3) * sizeof(float);
-		switch (e->nfft) {
-			case 128: hipLaunchKernelGGL(equalizer_pk_kernel<128>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
-			case 256: hipLaunchKernelGGL(equalizer_pk_kernel<256>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
-			default: hipLaunchKernelGGL(equalizer_pk_kernel<512>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
-		}
-		MI_LAUNCH_CHECK();
-		return MI_OK;
-	}
-	const size_t lds = (size_t)(e->nfft - 1 + nsamples + EQ_R) * sizeof(float);
+	const size_t lds_pk = (size_t)(e->nfft - 1 + nsamples + 16 + 3) * sizeof(float);
 	switch (e->nfft) {
-		case 128: hipLaunchKernelGGL(equalizer_kernel<128>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
-		case 256: hipLaunchKernelGGL(equalizer_kernel<256>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
-		default: hipLaunchKernelGGL(equalizer_kernel<512>, dim3(e->nstreams), dim3(EQ_THREADS), lds, st, a); break;
+		case 128: hipLaunchKernelGGL(equalizer_pk_kernel<128>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
+		case 256: hipLaunchKernelGGL(equalizer_pk_kernel<256>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
+		default: hipLaunchKernelGGL(equalizer_pk_kernel<512>, dim3(e->nstreams), dim3(64), lds_pk, st, a); break;
 	}
 	MI_LAUNCH_CHECK();
 	return MI_OK;
