@@ -1510,9 +1510,8 @@ bool leg_peer_ok(MSFilter *vol, VolumeData *vd, MSFilter **peer) {
 	*peer = nullptr;
 	if (!vd->peered_by.empty()) return false; // (somebody's limiter reads THIS filter's meter: it stays where they find it)
 	if (!vd->peer) return true;
-	static const bool off = getenv("MSMI355X_NO_FUSE_PEER") != nullptr; // A/B switch: a leg with an echo limiter keeps its facades, as up to round 5
 	MSFilter *pf = vd->peer;
-	if (off || pf->desc != &ms_mi355x_volume_desc || pf->ticker != vol->ticker) return false;
+	if (pf->desc != &ms_mi355x_volume_desc || pf->ticker != vol->ticker) return false;
 	VolumeData *pd = (VolumeData *)pf->data;
 	if (pd->sample_rate != vd->sample_rate || pd->leg || pd->sleg || pd->meter_leg || pd->peered_by.size() != 1 || pd->peer != NULL) return false;
 	if (ms_bufferizer_get_avail(pd->buffer) || ms_bufferizer_get_avail(pd->spill)) return false;
@@ -2131,9 +2130,8 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 	// volsend -> [outbound_mixer that can only forward] -> MSAlawEnc / MSUlawEnc of ours (audiostream.c:1803-1809 without dtmfgen_rtp: a
 	// telephone-event payload is negotiated, :1396-1404): the chunks are encoded in the batch
 	MSFilter *omix = nullptr, *encf = vol->outputs[0]->next.filter;
-	static const bool no_enc = getenv("MSMI355X_NO_FUSE_ENCODER") != nullptr; // A/B switch
 	if (is_forwarding_mixer(encf, head->ticker) && ms_queue_empty(encf->outputs[0])) omix = encf, encf = encf->outputs[0]->next.filter;
-	if (!no_enc && rate == 8000 && encf && is_g711_enc(encf->desc) && encf->ticker == head->ticker && encf->inputs[0] && ms_queue_empty(encf->inputs[0])) {
+	if (rate == 8000 && encf && is_g711_enc(encf->desc) && encf->ticker == head->ticker && encf->inputs[0] && ms_queue_empty(encf->inputs[0])) {
 		MapFilter *ed = (MapFilter *)encf->data;
 		if (ed->sleg || ed->fleg || ms_bufferizer_get_avail(ed->bz) || (ed->pool && (!ed->pool->staged[(size_t)ed->slot].empty() || !ed->pool->ready[(size_t)ed->slot].empty()))) encf = nullptr;
 	} else encf = nullptr;

@@ -25,7 +25,7 @@
 // a drop request takes effect where it fell in the stream's block sequence, as in FlowPool.  The filters leave the batch at detach
 // (the tick in flight is delivered first, filters.cpp: facade_detached) or when MSGenericPLC is given another rate in mid-call (its
 // context then starts over, as the facade's does).  A packet longer than a row (60 ms of G.711) sends the stream back to its facades.
-// MSMI355X_NO_FUSE=1 / MSMI355X_NO_FUSE_RECV=1: every facade on its own bank (what the tests compare against).
+// MSMI355X_NO_FUSE=1: every facade on its own bank (what the tests compare against).
 
 constexpr int kRecvBlock = 480;               // samples (or code bytes) per staged row: 60 ms at 8 kHz, 10 ms at 48 kHz
 constexpr int kRecvEntries = kMaxRounds + 2;  // blocks a stream can have on their way in one flush (launch rounds + a comfort-noise block)
@@ -466,8 +466,7 @@ void flowctl_release(FlowFilter *d);
 
 // `head`: a G.711 decoder of ours, or an MSGenericPLC whose input is not one.  true = the chain is fused (hub locked by the caller)
 bool recv_try_fuse(MSFilter *head) {
-	static const bool off = getenv("MSMI355X_NO_FUSE_RECV") != nullptr;
-	if (off || getenv("MSMI355X_NO_FUSE") != nullptr || !head->ticker || head->ticker->interval != 10) return false;
+	if (getenv("MSMI355X_NO_FUSE") != nullptr || !head->ticker || head->ticker->interval != 10) return false;
 	MSFilter *dec = is_g711_dec(head->desc) ? head : nullptr, *mixer = nullptr;
 	MSFilter *plcf = head;
 	if (dec) {

@@ -801,9 +801,8 @@ bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out,
 		q = vol->inputs[0];
 		vol = q ? q->prev.filter : NULL;
 	} else if (vol && vol->desc == &ms_mi355x_resample_desc) { // ... or working: the endpoint runs at another rate (a G.711 endpoint in a 16 kHz conference)
-		static const bool off = getenv("MSMI355X_NO_FUSE_SERVER_RESAMPLED") != nullptr; // A/B switch: such a conference keeps its facades, as up to round 5
 		const int re = (int)((const ResampleData *)vol->data)->input_rate;
-		if (off || !server_rates_ok(re, ms->rate) || !is_working_resampler(vol, mx->ticker, (uint32_t)re, (uint32_t)ms->rate) || !ms_queue_empty(q)) return false;
+		if (!server_rates_ok(re, ms->rate) || !is_working_resampler(vol, mx->ticker, (uint32_t)re, (uint32_t)ms->rate) || !ms_queue_empty(q)) return false;
 		*irs_out = vol;
 		*re_out = re;
 		q = vol->inputs[0];
@@ -840,7 +839,7 @@ bool server_candidate(MSFilter *mx, MixerState *ms, int pin, MSFilter **vol_out,
 // Called (hub locked, ticker thread) by conf_try_fuse when the conference is not one of sending legs.  true = fused.
 bool server_try_fuse(MSFilter *mx) {
 	MixerState *ms = (MixerState *)mx->data;
-	if (getenv("MSMI355X_NO_FUSE") != nullptr || getenv("MSMI355X_NO_FUSE_SERVER") != nullptr) return false;
+	if (getenv("MSMI355X_NO_FUSE") != nullptr) return false;
 	if (!ms->prepared || ms->conf_mode == 0 || ms->nchannels != 1 || !mx->ticker || mx->ticker->interval != 10 || ms->rate % 800) return false;
 	std::vector<std::pair<int, MSFilter *>> cand;
 	std::vector<MSFilter *> heads; // per candidate: the decoder that heads the leg, or NULL (MSVolume does)
