@@ -1322,6 +1322,18 @@ void leg_speaker_frame(MSFilter *f, SpeexECState *s, FusedLeg *leg, size_t nbyte
 	}
 	if (s->using_zeroes) ms_message("Samples are back.");
 	s->using_zeroes = FALSE;
+	// The frame as a WINDOW on the far end's own block where it lies within one (about half of them: 256-sample frames out of 480-sample
+	// blocks): a second reference to the block's data with its own read and write positions, the queue then skips those bytes -- no copy, no
+	// line of a frame buffer touched.  A frame that straddles two blocks is copied together as before.
+	mblk_t *head = peekq(&s->ref.base.q);
+	if (head && head != &s->ref.base.q._q_stopper && !head->b_cont && (size_t)(head->b_wptr - head->b_rptr) >= nbytes) {
+		mblk_t *w = dupb(head);
+		w->b_wptr = w->b_rptr + nbytes;
+		w->reserved1 = w->reserved2 = 0, w->ttl_or_hl = 0; // (a frame the reference allocates anew carries no timestamp or marker of the far end's block: speexec.c:273-284)
+		ms_bufferizer_skip_bytes(&s->ref.base, (int)nbytes);
+		hand_on(w);
+		return;
+	}
 	mblk_t *m = frame(false);
 	if (ms_bufferizer_read(&s->ref.base, m->b_rptr, nbytes) == 0) {
 		ms_error("mi355x echo canceller: the far-end bufferizer ran dry; silence sent to the speaker");
