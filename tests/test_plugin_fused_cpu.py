@@ -88,6 +88,24 @@ def test_plugin_bench_runs_full_legs_through_the_double(verdict, paced):
         assert 9.0 < d["wall_ms_per_tick"] < 12.0, d["wall_ms_per_tick"]   # 40 ticks on the 10 ms grid (+ the 20 ms lead)
 
 
+@pytest.mark.parametrize("shape", ["", "server dec", "astream default"])
+def test_graphs_replumbed_by_an_application_thread_find_their_way_back_into_their_batches(verdict, shape):
+    """PLUGIN_BENCH_CHURN: an application thread detaches and attaches one conference (or stream) graph after the other while the tickers run,
+    as the reference's callers do (msticker.c:153-221; audioconference.c:322-374) -- with MSMI355X_CHECK_LEVELS the device queues must hold
+    what the host's framing says through every re-plumbing, nothing may be dropped, and at the end EVERY leg lives in its batch again
+    (a conference that came back with three or more chunks in flight used to be refused at the attach and stayed on its facades for good)."""
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(HOST, "double"), PLUGIN_BENCH_CHURN="100", PLUGIN_BENCH_PACED="1", PLUGIN_BENCH_SHAPE=shape,
+               MSMI355X_CHECK_LEVELS="1")
+    env.pop("MSMI355X_NO_FUSE", None)
+    r = subprocess.run([os.path.join(HOST, "plugin_bench"), os.path.join(HOST, "double", "libmsmi355xfilters.so"), "512", "2", "150", "10"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["churn"]["thread"] == "the application's" and d["churn"]["replumbings"] >= 100, d["churn"]
+    assert d["fused_legs"] >= d["legs"] - (32 if shape != "astream default" else 1), d   # (at most the graph that is in the application's hands right now)
+    assert d["late_events"] == 0, d
+
+
 @pytest.mark.parametrize("shape", ["", "nors", "noagc", "nomixer", "nors noagc nomixer", "eprs", "server", "server dec", "eq", "eq nomixer noagc", "el nomixer", "astream", "astream default", "server wb", "server dec wb"])
 def test_plugin_bench_shapes_fused_equal_one_by_one_by_checksum(verdict, shape):
     """every leg shape the fused chain takes (PLUGIN_BENCH_SHAPE: without MSResample / without AGC / without a conference mixer):
