@@ -173,6 +173,16 @@ struct TickerHub {
 	std::vector<Pool *> pools;         // flush order = creation order
 	MSFilter *flush_owner = nullptr;   // the filter whose postponed task will flush this ticker's pools (NULL: none pending)
 	uint32_t flush_posted_tick = 0;    // ... and the tick it was posted in (MSTicker::ticks): it runs at the head of the next one -- or it was dropped (request_flush)
+	// More tasks for the same flush, on OTHER filters (the 2nd, 16th, 128th and 1024th to ask in the walk: other graphs, as a walk goes graph by
+	// graph): a task goes with its filter when that filter's graph is detached (msticker.c:187-190), on the application's thread, between two
+	// ticks -- and the hub's flush is every graph's.  (Found by the churn run: re-plumbed in the order they are walked, the graphs took the
+	// flush with them tick after tick; the others' results then arrived four ticks at once -- and a conference's 32 members ask one after the
+	// other, the sixteenth is no safer than the first.)  Whichever task runs first flushes, the others find the tick done (flush_done_tick).
+	static constexpr int kFlushBackups = 4;
+	MSFilter *flush_backup[kFlushBackups] = {nullptr, nullptr, nullptr, nullptr};
+	uint32_t flush_asks = 0, flush_done_tick = 0;
+	bool backup_waiting() const { return flush_backup[0] || flush_backup[1] || flush_backup[2] || flush_backup[3]; }
+	void drop_backups() { flush_backup[0] = flush_backup[1] = flush_backup[2] = flush_backup[3] = nullptr; }
 	// chain linking: while the flush task runs, a facade that emits into a queue read by ANOTHER facade of this ticker has
 	// that one run right away (then its bank is flushed in the same task): a chain of GPU filters costs one tick, not one
 	// tick per filter
@@ -207,7 +217,7 @@ mi_ctx *Pool::ctx() const { return hub->ctx; }
 // APPLICATION's thread then -- a postprocess delivering a detaching graph's tick in flight -- and reads whichever of the two values: a relaxed load
 inline uint64_t hub_time(const TickerHub *h) { return h->ticker ? __atomic_load_n(&h->ticker->time, __ATOMIC_RELAXED) : 0; }
 inline uint64_t ticker_now(const MSTicker *t) { return __atomic_load_n(&t->time, __ATOMIC_RELAXED); } // (the same for code a detaching graph's flush may run on the application's thread)
-bool Pool::work_waiting() const { return hub->flush_owner != nullptr && !hub->in_flush; }
+bool Pool::work_waiting() const { return (hub->flush_owner != nullptr || hub->backup_waiting()) && !hub->in_flush; }
 bool Pool::parked(int slot) const { return hub->scope && !(owner[(size_t)slot] && hub->scope->count(owner[(size_t)slot])); }
 void Pool::sync_stream() {
 	if (hub->ctx && mi_ctx_sync(hub->ctx) != MI_OK) failed = mi_failed("mi_ctx_sync");
@@ -318,7 +328,7 @@ struct HubLock {
 		if (hub->refs() != 1) return;
 		auto it = g_hubs.find(hub->ticker);
 		if (it != g_hubs.end() && it->second == hub) g_hubs.erase(it);
-		hub->flush_owner = nullptr;
+		hub->flush_owner = nullptr, hub->drop_backups();
 		hub->life.fetch_or(TickerHub::RETIRED, std::memory_order_acq_rel);
 	}
 	explicit HubLock(MSFilter *f) : h(nullptr), prev(tl_hub) {
@@ -398,7 +408,7 @@ void Pool::release(int slot) {
 			auto it = g_hubs.find(h->ticker);
 			if (it != g_hubs.end() && it->second == h) g_hubs.erase(it);
 			h->life.fetch_or(TickerHub::RETIRED, std::memory_order_acq_rel); // deleted by the last HubLock scope to end
-			h->flush_owner = nullptr;
+			h->flush_owner = nullptr, h->drop_backups();
 		}
 	}
 }
@@ -546,7 +556,10 @@ void flush_hub(TickerHub &h) {
 // downstream filters see them in this tick's graph run even if the owner itself gets no new input.
 void flush_task(MSFilter *f) {
 	HubLock lk(f);
-	g_hub.flush_owner = nullptr;
+	g_hub.flush_owner = nullptr, g_hub.drop_backups();
+	const uint32_t tick = g_hub.ticker ? g_hub.ticker->ticks : 0;
+	if (g_hub.ticker && g_hub.flush_done_tick == tick) return; // (the other of the two tasks ran at the head of this tick)
+	g_hub.flush_done_tick = tick;
 	flush_hub(g_hub);
 }
 
@@ -557,10 +570,18 @@ void request_flush(MSFilter *f) {
 	// A task posted in an earlier tick runs at the head of this one (msticker.c:484-485: run_tasks, then run_graphs).  If it is still owed, its
 	// filter left the ticker in between: ms_ticker_detach drops a detaching filter's tasks (msticker.c:187-190,:314-324) on the APPLICATION's
 	// thread, and a walk may run before that filter's postprocess tells this hub (facade_detached) -- post a new one
-	if (g_hub.flush_owner && f->ticker && g_hub.flush_posted_tick != f->ticker->ticks) g_hub.flush_owner = nullptr;
-	if (!g_hub.flush_owner) {
+	if ((g_hub.flush_owner || g_hub.backup_waiting()) && f->ticker && g_hub.flush_posted_tick != f->ticker->ticks) g_hub.flush_owner = nullptr, g_hub.drop_backups();
+	if (!g_hub.flush_owner && !g_hub.backup_waiting()) {
 		g_hub.flush_owner = f;
+		g_hub.flush_asks = 1;
 		g_hub.flush_posted_tick = f->ticker ? f->ticker->ticks : 0;
+		ms_filter_postpone_task(f, flush_task);
+		return;
+	}
+	const uint32_t n = ++g_hub.flush_asks; // (the 2nd, 16th, 128th, 1024th)
+	const int k = n == 2 ? 0 : n == 16 ? 1 : n == 128 ? 2 : n == 1024 ? 3 : -1;
+	if (k >= 0 && !g_hub.flush_backup[k] && f != g_hub.flush_owner) {
+		g_hub.flush_backup[k] = f;
 		ms_filter_postpone_task(f, flush_task);
 	}
 }
@@ -596,7 +617,9 @@ void facade_detached(MSFilter *f) {
 		h->drained.swap(graph);
 		h->drained_seq = h->stage_seq;
 	}
-	if (h->flush_owner == f) h->flush_owner = nullptr;
+	if (h->flush_owner == f) h->flush_owner = nullptr; // (its task went with it: the walk's next request posts another -- or the second task is still there)
+	for (MSFilter *&bk : h->flush_backup)
+		if (bk == f) bk = nullptr;
 	h->pumped.erase(f);
 }
 void generic_postprocess(MSFilter *f) { facade_detached(f); }
@@ -825,7 +848,7 @@ void ms_mi355x_flush(void) {
 	for (TickerHub *h : referenced_hubs()) {
 		HubLock lk(h, HubLock::Adopt{});
 		if (lk.dead()) continue;
-		h->flush_owner = nullptr;
+		h->flush_owner = nullptr, h->drop_backups();
 		flush_hub(*h);
 	}
 }

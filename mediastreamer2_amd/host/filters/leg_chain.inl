@@ -44,6 +44,15 @@
 constexpr int kLegRefOver = 3; // far-end ticks beyond the first that one flush carries per leg (a burst after a network hiccup)
 constexpr int kLegLightRounds = 8; // frames MSVolume (no AGC) can meter in one enqueue: kMaxRounds blocks of 10 ms in frames
 constexpr int kLegMeterRounds = 8; // rounds before the last of a flush whose meter state is read back (kLegLightRounds, kLegMaxChunks fit)
+// 10 ms chunks a conference member's result queue is sized for BESIDES a tick's bursts (LegBank::out_cap).  A running batch keeps one or two;
+// what a re-plumbed conference brings back (take_remainders) grows by up to one with every detach + attach -- the reference's mixer skips
+// the walk in which none of its pins delivers (audiomixer.c:244-286: a restarted canceller's first frame may not complete a chunk) and its
+// channels' flow control only trims after 5 s (:92-111) -- so a conference an application re-plumbs many times within seconds comes back
+// with several.  The queue takes kLegHeldChunks - 4 of them at an attach (leg_candidate) and keeps the four a running batch was sized
+// for.  (It was 4 in all, and the attach's bound the whole queue: PLUGIN_BENCH_CHURN brought conferences back with seven chunks in a
+// queue of eight and a half, the canceller's next two frames found no room -- the kernel then runs nothing for the leg and counts it --
+// and the host's framing had counted them: MSMI355X_CHECK_LEVELS, round 6.)
+constexpr int kLegHeldChunks = 16;
 constexpr int kLegMaxChunks = 5; // 10 ms chunks MSVolume can complete in one flush of a leg without a mixer (kMaxRounds blocks of 10 ms + what it held)
 
 // The walk of a ticker with thousands of legs touches a few KB of scattered host memory per leg (filters, queues, blocks, the
@@ -130,6 +139,7 @@ struct LegBank;
 struct FusedLeg {
 	LegBank *bank;
 	int slot, pin;
+	uint32_t lv_from = 0; // MSMI355X_CHECK_LEVELS: the first read-back of the queues' levels (LegBank::lv_seq) that is this leg's -- an earlier one shows the slot before it was taken
 	MSFilter *rs, *ec, *vol, *mixer;
 	void *rs_data = nullptr, *ec_data = nullptr, *vol_data = nullptr; // the facades' states (f->data), known here so that a prefetch needs no cold load
 	int staged_mic = 0;  // 10 ms blocks staged since the last flush (launch rounds)
@@ -276,6 +286,7 @@ struct LegBank : Pool {
 	// launches and the meters' read-back.  MSMI355X_ZERO_COPY=0: staged through device buffers by copy launches (A/B).
 	bool zero_copy = true;
 	bool mixed = false, check_levels = false, lv_fresh = false;
+	uint32_t lv_seq = 0; // read-backs of the levels so far (FusedLeg::lv_from)
 	double trace_ms = 0;          // MSMI355X_TRACE_SLOW_MS: an enqueue that takes longer says where (stderr)
 	uint64_t tr[8] = {0};
 	std::vector<std::pair<const char *, uint64_t>> trc; // ... and call by call inside the device's half
@@ -336,6 +347,7 @@ struct LegBank : Pool {
 	mi_volume_state vstate0;
 
 	static int frames_up(int v, int frame) { return (v + frame - 1) / frame * frame; }
+	static int out_cap_for(int ns, int F) { return frames_up(kLegHeldChunks * ns + kMaxRounds * 2 * F, F); }
 	LegBank(int cap_conf, uint32_t ir, uint32_t r, int frame, int filter_length, int delay_samples, int members, bool no_mixer = false, bool no_agc = false,
 	        bool with_eq = false, int law = -1)
 	    : in_rate(ir), rate(r), F(frame), flen(filter_length), delay(delay_samples), mm(members), plain(no_mixer), light(no_agc), enc_law(law) {
@@ -346,7 +358,7 @@ struct LegBank : Pool {
 		den = (int)(rate / in_rate);
 		nlegs = capacity * mm;
 		mic_cap = frames_up(2 * ns + 2 * F, F);
-		out_cap = frames_up(4 * ns + kMaxRounds * 2 * F, F);
+		out_cap = plain ? frames_up(4 * ns + kMaxRounds * 2 * F, F) : out_cap_for(ns, F); // (a leg without a mixer holds less than a chunk between blocks: leg_fuse_plain_at)
 		ref_cap = frames_up(delay + (3 + kLegRefOver) * ns + kMaxRounds * 2 * F, F);
 		if (!failed && in_rate != rate) MI_MUST(mi_resampler_create(hub->ctx, nlegs, in_rate, rate, 3, &rs)); // (no MSResample in front: the microphone arrives at the canceller's rate)
 		if (!failed) MI_MUST(mi_aec_create(hub->ctx, nlegs, (int)rate, F, flen, &aec));
@@ -953,7 +965,7 @@ struct LegBank : Pool {
 			any = true;
 		}
 		if (check_levels && any) {
-			lv_fresh = true;
+			lv_fresh = true, ++lv_seq;
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
@@ -1128,7 +1140,7 @@ struct LegBank : Pool {
 				for (size_t i = 1; i < trc.size(); ++i) fprintf(stderr, "    %-22s %.3f ms\n", trc[i].first, (double)(trc[i].second - trc[i - 1].second) * 1e-6);
 		}
 		if (check_levels && any) {
-			lv_fresh = true;
+			lv_fresh = true, ++lv_seq;
 			MI_MUST(mi_fifo_levels(f_mic, d_lv));
 			MI_MUST(mi_fifo_levels(f_ref, d_lv + L));
 			MI_MUST(mi_fifo_levels(f_out, d_lv + 2 * L));
@@ -1198,7 +1210,7 @@ struct LegBank : Pool {
 		if (check_levels && lv_now)
 			for (size_t s = 0; s < UL; ++s) {
 				FusedLeg *leg = legs[s];
-				if (!leg) continue;
+				if (!leg || leg->lv_from > lv_seq) continue; // (taken since the levels were read: an application's thread may re-plumb between a launch and its flush)
 				const int want_out = light ? (plain ? leg->newchunks * F : 0) : leg->vol_rem + (leg->chan_chunks + leg->newchunks) * ns;
 				if (light && !plain && h_lv[3 * L + s] != leg->chan_samples + leg->new_samples) {
 					ms_error("mi355x fused leg %d: the mixer channel's queue holds %d samples, the host's framing says %d", (int)s, h_lv[3 * L + s], leg->chan_samples + leg->new_samples);
@@ -1349,8 +1361,15 @@ void deliver_fused_in_scope(TickerHub &h) {
 	for (Pool *p : h.pools) {
 		if (p->key.compare(0, 3, "leg") != 0) continue;
 		LegBank *b = static_cast<LegBank *>(p);
+		// (a launch is the whole bank's: it leaves from here -- possibly the application's thread, in the middle of the ticker's walk of the bank's
+		// OTHER graphs, with only part of them staged -- only when the detaching graph itself staged something that has not left; between two ticks
+		// its work is out already and there is nothing to launch)
 		bool ours = false;
-		for (int s = 0; s < b->hi && !ours; ++s) ours = b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s]);
+		for (int s = 0; s < b->hi && !ours; ++s) {
+			if (!b->owner[(size_t)s] || !h.scope->count(b->owner[(size_t)s])) continue;
+			for (int pin = 0; pin < b->mm && !ours; ++pin)
+				if (const FusedLeg *leg = b->legs[(size_t)(s * b->mm + pin)]) ours = leg->staged_mic > 0 || leg->staged_ref > 0 || leg->inject > 0 || leg->pre_frames > 0;
+		}
 		if (ours) b->launch_staged();
 		for (int s = 0; s < b->hi; ++s)
 			if (b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s])) b->deliver_in_flight(b->owner[(size_t)s], s);
@@ -1614,10 +1633,11 @@ bool leg_candidate(MSFilter *mx, MixerState *ms, int pin, LegCand &c) {
 	if (es->bypass_mode || es->unsupported || !es->configured || es->samplerate != ms->rate || es->echostarted || es->leg) return false;
 	if (ms_bufferizer_get_avail(&es->echo) || (int)ms_bufferizer_get_avail(&es->delayed_ref) != es->nominal_ref_samples * 2) return false;
 	// (what a batch handed back at the last detach -- the chunks that waited in the channel, the ticks in flight, the samples short of a chunk:
-	// take_remainders -- is whatever fits the queue it is rebuilt in, LegBank::out_cap.  The bound was "less than three chunks" until
-	// PLUGIN_BENCH_CHURN found conferences that came back with three, five, seven -- and then stayed on their facades for good)
-	const int out_cap = LegBank::frames_up(4 * (vd->sample_rate / 100) + kMaxRounds * 2 * es->framesize, es->framesize);
-	if (!leg_remainder_ok(vd, out_cap / (vd->sample_rate / 100)) || held / 2 > (size_t)out_cap) return false;
+	// take_remainders -- moves into the queue it is rebuilt in as long as the queue keeps the room a running batch needs, kLegHeldChunks.
+	// The bound was "less than three chunks" until PLUGIN_BENCH_CHURN found conferences that came back with three, five, seven -- and then
+	// stayed on their facades for good)
+	const int held_max = (kLegHeldChunks - 4) * (vd->sample_rate / 100);
+	if (!leg_remainder_ok(vd, kLegHeldChunks - 4) || held / 2 > (size_t)held_max) return false;
 	MSQueue *qr = ec->inputs[1];
 	MSFilter *rs = qr ? qr->prev.filter : NULL;
 	if (rs && equalizer_passes(rs, mx->ticker) && ms_queue_empty(qr) && rs->inputs[0]) { // a mic_equalizer that is not active (audiostream.c:1801): transparent
@@ -1926,6 +1946,7 @@ bool conf_try_fuse_sending(MSFilter *mx) {
 	bool rs_any = false;
 	for (const LegCand &cd : cand) {
 		FusedLeg *leg = new FusedLeg();
+		leg->lv_from = b->lv_seq + 1;
 		leg->bank = b, leg->slot = s0 + cd.pin, leg->pin = cd.pin;
 		leg->rs = cd.rs, leg->ec = cd.ec, leg->vol = cd.vol, leg->mixer = mx;
 		leg->rs_data = cd.rs ? cd.rs->data : nullptr, leg->ec_data = cd.ec->data, leg->vol_data = cd.vol->data;
@@ -2174,6 +2195,7 @@ bool leg_fuse_plain_at(MSFilter *rs, MSFilter *ec) {
 		return false;
 	}
 	FusedLeg *leg = new FusedLeg();
+	leg->lv_from = b->lv_seq + 1;
 	leg->bank = b, leg->slot = s, leg->pin = 0;
 	leg->rs = rs, leg->ec = ec, leg->vol = vol, leg->mixer = nullptr;
 	leg->rs_data = rs ? rs->data : nullptr, leg->ec_data = ec->data, leg->vol_data = vol->data;

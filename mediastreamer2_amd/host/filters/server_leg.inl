@@ -35,6 +35,7 @@ struct ServerBank;
 struct ServerLeg {
 	ServerBank *bank;
 	int slot, pin;
+	uint32_t lv_from = 0; // MSMI355X_CHECK_LEVELS: the first read-back of the levels (ServerBank::lv_seq) that is this leg's, as FusedLeg::lv_from
 	MSFilter *vol, *mixer;
 	MSFilter *enc = nullptr;   // the pin's output is encoded in the batch (MSAlawEnc / MSUlawEnc of this plugin), else PCM
 	MSFilter *irs = nullptr;   // the endpoint's in_resampler when it really resamples (the endpoint runs at another rate than the conference): its state lives in the bank
@@ -109,6 +110,7 @@ struct ServerBank : Pool {
 	int walked = 0;
 	bool staged_since = false, outstanding = false, early = false, early_any = false, no_early = false;
 	bool mixed = false, pcm_out = false, check_levels = false, lv_fresh = false, zero_copy = true;
+	uint32_t lv_seq = 0;
 	uint64_t launches = 0;
 
 	ServerBank(int cap_conf, int r, int members, int endpoint_rate) : rate(r), mm(members), re(endpoint_rate) {
@@ -466,7 +468,7 @@ struct ServerBank : Pool {
 		}
 		if (any) MI_MUST(mi_volume_get_state_async(vol, 0, (int)UL, h_vstate));
 		if (check_levels && any) {
-			lv_fresh = true;
+			lv_fresh = true, ++lv_seq;
 			MI_MUST(mi_fifo_levels(f_chan, d_lv));
 			MI_MUST(mi_copy_d2h_pinned(ctx, h_lv, d_lv, L * 4));
 		}
@@ -510,7 +512,7 @@ struct ServerBank : Pool {
 		lv_fresh = false;
 		if (check_levels && lv_now)
 			for (size_t s = 0; s < UL; ++s)
-				if (legs[s] && h_lv[s] != legs[s]->chan_samples + legs[s]->new_samples) {
+				if (legs[s] && legs[s]->lv_from <= lv_seq && h_lv[s] != legs[s]->chan_samples + legs[s]->new_samples) {
 					ms_error("mi355x server leg %d: the mixer channel's queue holds %d samples, the host's framing says %d", (int)s, h_lv[s],
 					         legs[s]->chan_samples + legs[s]->new_samples);
 					g_late_events.fetch_add(1, std::memory_order_relaxed);
@@ -921,6 +923,7 @@ bool server_try_fuse(MSFilter *mx) {
 	for (size_t ci = 0; ci < cand.size(); ++ci) {
 		const auto &pv = cand[ci];
 		ServerLeg *leg = new ServerLeg();
+		leg->lv_from = b->lv_seq + 1;
 		leg->bank = b, leg->slot = s0 + pv.first, leg->pin = pv.first;
 		leg->vol = pv.second, leg->mixer = mx;
 		leg->enc = b->encs[(size_t)leg->slot];
@@ -1118,8 +1121,12 @@ void deliver_server_in_scope(TickerHub &h) {
 	for (Pool *p : h.pools) {
 		if (p->key.compare(0, 4, "srv:") != 0) continue;
 		ServerBank *b = static_cast<ServerBank *>(p);
-		bool ours = false;
-		for (int s = 0; s < b->hi && !ours; ++s) ours = b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s]);
+		bool ours = false; // (as in deliver_fused_in_scope: the whole bank is launched only when the detaching conference itself has staged blocks that have not left)
+		for (int s = 0; s < b->hi && !ours; ++s) {
+			if (!b->owner[(size_t)s] || !h.scope->count(b->owner[(size_t)s])) continue;
+			for (int pin = 0; pin < b->mm && !ours; ++pin)
+				if (const ServerLeg *leg = b->legs[(size_t)(s * b->mm + pin)]) ours = leg->staged > 0;
+		}
 		if (ours) b->launch_staged();
 		for (int s = 0; s < b->hi; ++s)
 			if (b->owner[(size_t)s] && h.scope->count(b->owner[(size_t)s])) b->deliver_in_flight(b->owner[(size_t)s], s);

@@ -332,3 +332,25 @@ def test_config3_sized_fused_run_equals_the_facades_one_by_one_by_checksum(shape
     assert fused["mix_checksum"] == plain["mix_checksum"] == staged["mix_checksum"], (fused["mix_checksum"], plain["mix_checksum"], staged["mix_checksum"])
     assert fused["speaker_checksum"] == plain["speaker_checksum"] == staged["speaker_checksum"]
     assert fused["late_events"] == 0 and plain["late_events"] == 0
+
+
+@pytest.mark.parametrize("shape", ["", "server dec", "astream default"])
+def test_graphs_replumbed_by_an_application_thread_on_the_device(shape):
+    """PLUGIN_BENCH_CHURN with the real kernels: an application thread detaches and attaches one conference (or stream) graph after the other
+    while four tickers carry 4 096 legs paced at 10 ms (msticker.c:153-221: the reference's threading model) -- the device queues must hold
+    what the host's framing says through every re-plumbing (MSMI355X_CHECK_LEVELS), nothing may be dropped or fail, every leg must be back in
+    its batch at the end (but for the graph that is in the application's hands when the count is read)."""
+    import json
+    import subprocess
+    host_dir = os.path.join(fg.ROOT, "tests", "host")
+    r = subprocess.run(["make", "-C", host_dir, "plugin_bench"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, PLUGIN_BENCH_CHURN="50", PLUGIN_BENCH_PACED="1", PLUGIN_BENCH_SHAPE=shape, MSMI355X_CHECK_LEVELS="1")
+    env.pop("MSMI355X_NO_FUSE", None)
+    p = subprocess.run([os.path.join(host_dir, "plugin_bench"), os.path.join(PKG, "libmsmi355xfilters.so"), "4096", "4", "200", "20"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["churn"]["thread"] == "the application's" and d["churn"]["replumbings"] >= 200, d["churn"]
+    assert d["fused_legs"] >= d["legs"] - (32 if shape != "astream default" else 1), d
+    assert d["late_events"] == 0, d
