@@ -511,6 +511,12 @@ SCENARIOS = {
     "ptime20_replumbed": {"ptime20": True, "nticks": 100, "events": [(41, "reattach", 0, 0), (60, "reattach", 0, 0)], "tail_blocks": 1},
     "ptime20_replumbed_no_early_launch": {"ptime20": True, "nticks": 100, "no_early_launch": True, "events": [(41, "reattach", 0, 0), (42, "reattach", 0, 0), (60, "reattach", 0, 0)],
                                           "tail_blocks": 1},
+    # ... eleven times within a quarter of a second (an application adding and removing members one after the other, audioconference.c:322-374):
+    # a conference can come back from EVERY re-plumbing with one more chunk waiting (the mixer skips the walk in which no pin delivers,
+    # audiomixer.c:244-286, its flow control trims after 5 s, :92-111) -- the batch's queues take what the channels' bufferizers held (LegBank:
+    # kLegHeldChunks) and the device queues hold what the host's framing says throughout
+    "replumbed_eleven_times": {"nticks": 130, "events": [(41 + 2 * k, "reattach", 0, 0) for k in range(11)], "tail_blocks": 1},
+    "ptime20_replumbed_eleven_times": {"ptime20": True, "nticks": 130, "events": [(41 + 2 * k, "reattach", 0, 0) for k in range(11)], "tail_blocks": 1},
     "no_agc_replumbed": {"no_agc": True, "gain": 0.7, "nticks": 100, "events": [(41, "reattach", 0, 0)], "tail_blocks": 1},
     "no_agc_ptime20_16k_replumbed": {"no_agc": True, "in_rate": 8000, "rate": 16000, "ptime20": True, "nticks": 100, "events": [(41, "reattach", 0, 0), (52, "reattach", 0, 0)],
                                      "tail_blocks": 1},

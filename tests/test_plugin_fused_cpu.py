@@ -36,7 +36,7 @@ def verdict():
                                   "audiostream_8k_default_features_local_player_linked", "audiostream_8k_all_features_idle_equalizers", "audiostream_8k_idle_equalizers_without_recv_tee",
                                   "mic_equalizer", "mic_equalizer_no_mixer_8k_16k", "mic_equalizer_replumbed_then_leaves",
                                   "agc_switched_off_midcall", "bypass_switched_midcall", "agc_switched_on_midcall_no_mixer", "in_resampler_told_to_resample_midcall",
-                                  "replumbed", "ptime20_replumbed", "ptime20_replumbed_no_early_launch", "no_agc_replumbed", "no_agc_ptime20_16k_replumbed"])
+                                  "replumbed", "replumbed_eleven_times", "ptime20_replumbed_eleven_times", "ptime20_replumbed", "ptime20_replumbed_no_early_launch", "no_agc_replumbed", "no_agc_ptime20_16k_replumbed"])
 def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
     v = verdict[name]
     unfused = name in ("echo_limiter_conference_keeps_its_facades", "spk_equalizer_keeps_the_leg_on_its_facades")   # (a conference member with an echo limiter: stated in leg_chain.inl)
@@ -49,6 +49,8 @@ def test_fused_conference_equals_the_facades_one_by_one(verdict, name):
         assert v["bad"] == [], v["bad"][:4]
     if name.startswith("audiostream_8k"):   # the receiving side lives in a fused batch too (recv_leg.inl) -- but for a local_mixer with two linked inputs in front of the PLC
         assert v["fused_stats"]["recv_streams"] == (0 if "local_player_linked" in name else v["fused_stats"]["legs"]) and v["plain_stats"]["recv_streams"] == 0
+    if "eleven_times" in name:   # every conference is back in its batch after the eleventh re-plumbing (with 20 ms packets they come back with five chunks and more)
+        assert v["fused_stats"]["legs"] == 8 and v["fused_stats"]["conferences"] == 2, v["fused_stats"]
     assert v["nonzero"] and v["samples"] > 0
     assert v["late"] == [0, 0], "a device queue differed from the host's framing, or a launch failed"
     assert v["after"] == [[0, 0, 0], [0, 0, 0]], "hubs / banks / slots left behind"
