@@ -580,7 +580,7 @@ void request_flush(MSFilter *f) {
 	}
 	const uint32_t n = ++g_hub.flush_asks; // (the 2nd, 16th, 128th, 1024th)
 	const int k = n == 2 ? 0 : n == 16 ? 1 : n == 128 ? 2 : n == 1024 ? 3 : -1;
-	if (k >= 0 && !g_hub.flush_backup[k] && f != g_hub.flush_owner) {
+	if (k >= 0 && !g_hub.flush_backup[k] && f != g_hub.flush_owner && f->ticker) {
 		g_hub.flush_backup[k] = f;
 		ms_filter_postpone_task(f, flush_task);
 	}
