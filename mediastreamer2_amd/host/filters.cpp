@@ -173,16 +173,22 @@ struct TickerHub {
 	std::vector<Pool *> pools;         // flush order = creation order
 	MSFilter *flush_owner = nullptr;   // the filter whose postponed task will flush this ticker's pools (NULL: none pending)
 	uint32_t flush_posted_tick = 0;    // ... and the tick it was posted in (MSTicker::ticks): it runs at the head of the next one -- or it was dropped (request_flush)
-	// More tasks for the same flush, on OTHER filters (the 2nd, 16th, 128th and 1024th to ask in the walk: other graphs, as a walk goes graph by
-	// graph): a task goes with its filter when that filter's graph is detached (msticker.c:187-190), on the application's thread, between two
+	// More tasks for the same flush, on OTHER filters (the 2nd, 4th, 8th, 16th, 64th, 256th, 1024th and 4096th to ask in the walk: other graphs,
+	// as a walk goes graph by graph, whether the graphs are two-filter chains or conferences of 32 legs): a task goes with its filter when that filter's graph is detached (msticker.c:187-190), on the application's thread, between two
 	// ticks -- and the hub's flush is every graph's.  (Found by the churn run: re-plumbed in the order they are walked, the graphs took the
 	// flush with them tick after tick; the others' results then arrived four ticks at once -- and a conference's 32 members ask one after the
 	// other, the sixteenth is no safer than the first.)  Whichever task runs first flushes, the others find the tick done (flush_done_tick).
-	static constexpr int kFlushBackups = 4;
-	MSFilter *flush_backup[kFlushBackups] = {nullptr, nullptr, nullptr, nullptr};
+	static constexpr int kFlushBackups = 8;
+	MSFilter *flush_backup[kFlushBackups] = {};
 	uint32_t flush_asks = 0, flush_done_tick = 0;
-	bool backup_waiting() const { return flush_backup[0] || flush_backup[1] || flush_backup[2] || flush_backup[3]; }
-	void drop_backups() { flush_backup[0] = flush_backup[1] = flush_backup[2] = flush_backup[3] = nullptr; }
+	bool backup_waiting() const {
+		for (const MSFilter *bk : flush_backup)
+			if (bk) return true;
+		return false;
+	}
+	void drop_backups() {
+		for (MSFilter *&bk : flush_backup) bk = nullptr;
+	}
 	// chain linking: while the flush task runs, a facade that emits into a queue read by ANOTHER facade of this ticker has
 	// that one run right away (then its bank is flushed in the same task): a chain of GPU filters costs one tick, not one
 	// tick per filter
@@ -578,8 +584,8 @@ void request_flush(MSFilter *f) {
 		ms_filter_postpone_task(f, flush_task);
 		return;
 	}
-	const uint32_t n = ++g_hub.flush_asks; // (the 2nd, 16th, 128th, 1024th)
-	const int k = n == 2 ? 0 : n == 16 ? 1 : n == 128 ? 2 : n == 1024 ? 3 : -1;
+	const uint32_t n = ++g_hub.flush_asks;
+	const int k = n == 2 ? 0 : n == 4 ? 1 : n == 8 ? 2 : n == 16 ? 3 : n == 64 ? 4 : n == 256 ? 5 : n == 1024 ? 6 : n == 4096 ? 7 : -1;
 	if (k >= 0 && !g_hub.flush_backup[k] && f != g_hub.flush_owner && f->ticker) {
 		g_hub.flush_backup[k] = f;
 		ms_filter_postpone_task(f, flush_task);
