@@ -1152,6 +1152,25 @@ struct LegBank : Pool {
 		return any;
 	}
 
+	// The kernels refuse what does not fit a queue and count it (mi_fifo_overflows: the canceller runs nothing for a leg whose result queue has
+	// no room, aec_tick.hpp); the host's framing takes the room for granted -- it is what the queues are sized by (out_cap, kLegHeldChunks).
+	// Once in 128 flushes (a second and a quarter; the stream is idle here, the read is 4 bytes) the counters are read back: one that moved
+	// means the two disagree from here on for some leg -- said, and counted as a late event (MSMI355X_CHECK_LEVELS names the leg)
+	uint32_t ovf_seq = 0;
+	int32_t ovf_seen[3] = {0, 0, 0};
+	void check_overflows() {
+		if ((++ovf_seq & 127u) || failed) return;
+		mi_fifo *const q[3] = {f_mic, f_ref, f_out};
+		static const char *const name[3] = {"microphone", "far-end", "result"};
+		for (int k = 0; k < 3; ++k) {
+			int32_t n = 0;
+			if (!q[k] || mi_fifo_overflows(q[k], &n) != MI_OK || n == ovf_seen[k]) continue;
+			ms_error("mi355x leg bank %p: the device refused %d block(s) for want of room in the legs' %s queues: the host's framing no longer describes them", (void *)this,
+			         (int)(n - ovf_seen[k]), name[k]);
+			ovf_seen[k] = n;
+			g_late_events.fetch_add(1, std::memory_order_relaxed);
+		}
+	}
 	void finish() override {
 		const size_t L = (size_t)nlegs, UL = (size_t)hi * mm;
 		// MSSpeexEC's speaker pin: one frame per microphone frame (speexec.c:261-284).  While a detaching graph is being delivered
@@ -1175,6 +1194,7 @@ struct LegBank : Pool {
 			return;
 		}
 		finish_peers();
+		check_overflows();
 		if (mixed) {
 			const bool pfon = leg_prefetch_on();
 			for (size_t s = 0; s < UL; ++s) {
